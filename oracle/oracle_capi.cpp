@@ -1,0 +1,270 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/for_codec.h header).
+// Flat C entry points over the oracle so that tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg can drive it through ctypes. Nothing here is part of the product ABI
+// (that is include/tsgpu.h).
+#include <thread>
+#include <atomic>
+#include <chrono>
+#include "oracle_index.h"
+
+using namespace oracle;
+
+extern "C" {
+
+struct orc_kw_query {
+    const uint32_t* tokens; uint32_t n_tokens;
+    const uint32_t* field_ids; const int64_t* field_weights; uint32_t n_fields;
+    int32_t match_type;
+    int32_t prioritize_exact_match, prioritize_token_position, prioritize_num_matching_fields;
+    uint32_t total_cost;
+    int32_t sort_kind[3]; int32_t sort_column[3]; int32_t sort_order[3]; uint32_t n_sort;
+    uint32_t fetch_size;
+    const uint32_t* excluded_ids; uint32_t n_excluded;
+    const uint32_t* filter_ids; uint32_t n_filter;
+};
+
+struct orc_result {
+    uint32_t cap;            // in: capacity of the per-hit arrays
+    uint32_t n;              // out: hits written (topster order)
+    uint64_t* keys;          // [cap]
+    int64_t* scores;         // [cap*3]
+    int64_t* text_match;     // [cap]
+    float* vector_distance;  // [cap]
+    int8_t* match_score_index;  // [cap]
+    uint64_t num_keyword_matches;
+    uint64_t n_result_ids;   // out: total emitted ids
+    uint32_t* result_ids;    // nullable, [result_ids_cap]
+    uint64_t result_ids_cap;
+    int32_t search_cutoff;
+};
+
+static keyword_query_t to_query(const orc_kw_query* q) {
+    keyword_query_t k;
+    k.tokens.assign(q->tokens, q->tokens + q->n_tokens);
+    for (uint32_t i = 0; i < q->n_fields; i++) k.fields.push_back({q->field_ids[i], q->field_weights[i]});
+    k.match_type = q->match_type;
+    k.prioritize_exact_match = q->prioritize_exact_match != 0;
+    k.prioritize_token_position = q->prioritize_token_position != 0;
+    k.prioritize_num_matching_fields = q->prioritize_num_matching_fields != 0;
+    k.total_cost = q->total_cost;
+    for (uint32_t i = 0; i < q->n_sort; i++) k.sort.push_back({q->sort_kind[i], q->sort_column[i], q->sort_order[i]});
+    k.fetch_size = q->fetch_size;
+    if (q->n_excluded) k.excluded_ids.assign(q->excluded_ids, q->excluded_ids + q->n_excluded);
+    if (q->n_filter) k.filter_ids.assign(q->filter_ids, q->filter_ids + q->n_filter);
+    return k;
+}
+
+static void fill(const keyword_result_t& r, orc_result* out) {
+    uint32_t n = (uint32_t)std::min<size_t>(r.kvs.size(), out->cap);
+    out->n = n;
+    for (uint32_t i = 0; i < n; i++) {
+        out->keys[i] = r.kvs[i].key;
+        for (int j = 0; j < 3; j++) out->scores[i * 3 + j] = r.kvs[i].scores[j];
+        out->text_match[i] = r.kvs[i].text_match_score;
+        out->vector_distance[i] = r.kvs[i].vector_distance;
+        if (out->match_score_index) out->match_score_index[i] = r.kvs[i].match_score_index;
+    }
+    out->num_keyword_matches = r.num_keyword_matches;
+    out->n_result_ids = r.result_ids.size();
+    if (out->result_ids) {
+        size_t m = std::min<size_t>(r.result_ids.size(), out->result_ids_cap);
+        std::copy(r.result_ids.begin(), r.result_ids.begin() + m, out->result_ids);
+    }
+    out->search_cutoff = r.search_cutoff ? 1 : 0;
+}
+
+void* orc_create(uint32_t n_fields, uint32_t n_columns) { return new Index(n_fields, n_columns); }
+void orc_free(void* h) { delete (Index*)h; }
+void orc_set_num_docs(void* h, uint32_t n) { ((Index*)h)->num_docs = n; }
+uint32_t orc_num_docs(void* h) { return ((Index*)h)->num_docs; }
+
+void orc_index_plain(void* h, uint32_t seq_id, uint32_t field, const uint32_t* toks, uint32_t n) {
+    ((Index*)h)->index_plain_field(seq_id, field, std::vector<uint32_t>(toks, toks + n));
+}
+void orc_index_array(void* h, uint32_t seq_id, uint32_t field, const uint32_t* toks, const uint32_t* elem_lens, uint32_t n_elems) {
+    std::vector<std::vector<uint32_t>> elems;
+    size_t p = 0;
+    for (uint32_t e = 0; e < n_elems; e++) { elems.emplace_back(toks + p, toks + p + elem_lens[e]); p += elem_lens[e]; }
+    ((Index*)h)->index_array_field(seq_id, field, elems);
+}
+void orc_load_posting(void* h, uint32_t field, uint32_t term, const uint32_t* ids, const uint32_t* offset_index,
+                      const uint32_t* offsets, uint32_t n, uint32_t n_offsets) {
+    ((Index*)h)->load_posting(field, term, ids, offset_index, offsets, n, n_offsets);
+}
+// decoded dump of one posting list (for building the GPU index from oracle-built postings in tests)
+// returns n ids; when buffers are null only sizes are reported
+uint32_t orc_dump_posting(void* h, uint32_t field, uint32_t term, uint32_t* ids, uint32_t* offset_index, uint32_t* offsets,
+                          uint32_t* n_offsets_out) {
+    Index* idx = (Index*)h;
+    auto it = idx->fields[field].terms.find(term);
+    if (it == idx->fields[field].terms.end()) { if (n_offsets_out) *n_offsets_out = 0; return 0; }
+    posting_list_t* pl = it->second->full;
+    std::unique_ptr<posting_list_t> tmp;
+    if (!pl) { tmp.reset(it->second->compact->to_full_posting_list((uint16_t)MAX_BLOCK_ELEMENTS)); pl = tmp.get(); }
+    uint32_t n = 0, no = 0;
+    auto iter = pl->new_iterator();
+    while (iter.valid()) {
+        auto* blk = iter.block();
+        uint32_t ci = iter.index();
+        uint32_t s = iter.offset_index[ci];
+        uint32_t e = (ci == blk->size() - 1) ? blk->offsets.getLength() : iter.offset_index[ci + 1];
+        if (ids) { ids[n] = iter.id(); offset_index[n] = no; for (uint32_t j = s; j < e; j++) offsets[no + (j - s)] = iter.offsets[j]; }
+        no += e - s;
+        n++;
+        iter.next();
+    }
+    if (n_offsets_out) *n_offsets_out = no;
+    return n;
+}
+uint32_t orc_list_terms(void* h, uint32_t field, uint32_t* terms, uint32_t cap) {
+    Index* idx = (Index*)h;
+    uint32_t n = 0;
+    for (auto& kv : idx->fields[field].terms) { if (terms && n < cap) terms[n] = kv.first; n++; }
+    return n;
+}
+int32_t orc_field_is_array(void* h, uint32_t field) { return ((Index*)h)->fields[field].is_array ? 1 : 0; }
+
+void orc_set_sort(void* h, uint32_t column, uint32_t seq_id, int64_t v) { ((Index*)h)->set_sort_value(column, seq_id, v); }
+void orc_set_sort_dense(void* h, uint32_t column, const int64_t* vals, uint32_t n) {
+    auto& m = ((Index*)h)->sort_index[column];
+    m.reserve(n);
+    for (uint32_t i = 0; i < n; i++) m[i] = vals[i];
+}
+
+void orc_vec_init(void* h, uint32_t dim, int32_t metric) { ((Index*)h)->vec_init(dim, metric); }
+void orc_vec_add(void* h, const uint32_t* labels, const float* data, uint32_t n) {
+    Index* idx = (Index*)h;
+    idx->vec_store.reserve(idx->vec_store.size() + (size_t)n * idx->num_dim);
+    for (uint32_t i = 0; i < n; i++) idx->vec_add(labels[i], data + (size_t)i * idx->num_dim);
+}
+int32_t orc_vec_get(void* h, uint32_t label, float* out) {
+    Index* idx = (Index*)h;
+    const float* p = idx->vec_get(label);
+    if (!p) return -1;
+    std::copy(p, p + idx->num_dim, out);
+    return 0;
+}
+float orc_ip_distance(const float* a, const float* b, uint32_t dim) { return Index::ip_distance(a, b, dim); }
+
+// exact k nearest, closest first; returns hits written
+uint32_t orc_flat_knn(void* h, const float* q, uint32_t k, const uint32_t* allow_ids, uint32_t n_allow,
+                      float* dist_out, uint32_t* label_out) {
+    Index* idx = (Index*)h;
+    std::vector<float> qv(q, q + idx->num_dim);
+    std::vector<uint32_t> allow;
+    if (n_allow) allow.assign(allow_ids, allow_ids + n_allow);
+    auto hits = idx->flat_knn(qv, k, n_allow ? &allow : nullptr);
+    for (size_t i = 0; i < hits.size(); i++) { dist_out[i] = hits[i].dist; label_out[i] = hits[i].seq_id; }
+    return (uint32_t)hits.size();
+}
+
+int32_t orc_search_keyword(void* h, const orc_kw_query* q, orc_result* out) {
+    fill(((Index*)h)->search_keyword(to_query(q)), out);
+    return 0;
+}
+
+int32_t orc_search_vector(void* h, const float* qvec, uint32_t k, float distance_threshold, const int32_t* sort_kind,
+                          const int32_t* sort_column, const int32_t* sort_order, uint32_t n_sort, uint32_t fetch_size,
+                          const uint32_t* filter_ids, uint32_t n_filter, orc_result* out) {
+    Index* idx = (Index*)h;
+    vector_query_t vq;
+    vq.values.assign(qvec, qvec + idx->num_dim);
+    vq.k = k;
+    vq.distance_threshold = distance_threshold;
+    std::vector<sort_by_t> sort;
+    for (uint32_t i = 0; i < n_sort; i++) sort.push_back({sort_kind[i], sort_column[i], sort_order[i]});
+    std::vector<uint32_t> filt;
+    if (n_filter) filt.assign(filter_ids, filter_ids + n_filter);
+    fill(idx->search_vector(vq, sort, fetch_size, n_filter ? &filt : nullptr), out);
+    return 0;
+}
+
+int32_t orc_search_hybrid(void* h, const orc_kw_query* q, const float* qvec, uint32_t k, float alpha,
+                          float distance_threshold, orc_result* out) {
+    Index* idx = (Index*)h;
+    vector_query_t vq;
+    vq.values.assign(qvec, qvec + idx->num_dim);
+    vq.k = k;
+    vq.alpha = alpha;
+    vq.distance_threshold = distance_threshold;
+    fill(idx->search_hybrid(to_query(q), vq), out);
+    return 0;
+}
+
+// ---- CPU baseline drivers: one query per thread, like the reference server (thread-per-request) ----
+// tokens: [nq][n_tokens]; per_query_us: [nq] (nullable). Returns wall seconds for the whole batch.
+double orc_bench_keyword(void* h, const orc_kw_query* base, const uint32_t* tokens, uint32_t nq, uint32_t n_threads,
+                         double* per_query_us, uint64_t* checksum) {
+    Index* idx = (Index*)h;
+    std::atomic<uint32_t> next(0);
+    std::atomic<uint64_t> sum(0);
+    auto t0 = std::chrono::steady_clock::now();
+    auto work = [&]() {
+        for (;;) {
+            uint32_t i = next.fetch_add(1);
+            if (i >= nq) break;
+            orc_kw_query q = *base;
+            q.tokens = tokens + (size_t)i * base->n_tokens;
+            auto q0 = std::chrono::steady_clock::now();
+            keyword_result_t r = idx->search_keyword(to_query(&q));
+            auto q1 = std::chrono::steady_clock::now();
+            if (per_query_us) per_query_us[i] = std::chrono::duration<double, std::micro>(q1 - q0).count();
+            uint64_t c = r.num_keyword_matches;
+            for (auto& kv : r.kvs) c = c * 1315423911ull + kv.key;
+            sum.fetch_add(c);
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < n_threads; t++) th.emplace_back(work);
+    for (auto& t : th) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    if (checksum) *checksum = sum.load();
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// queries: [nq][dim]; exact flat scan per query, one query per thread
+double orc_bench_vector(void* h, const float* queries, uint32_t nq, uint32_t k, uint32_t n_threads, double* per_query_us) {
+    Index* idx = (Index*)h;
+    std::atomic<uint32_t> next(0);
+    auto t0 = std::chrono::steady_clock::now();
+    auto work = [&]() {
+        for (;;) {
+            uint32_t i = next.fetch_add(1);
+            if (i >= nq) break;
+            std::vector<float> qv(queries + (size_t)i * idx->num_dim, queries + (size_t)(i + 1) * idx->num_dim);
+            auto q0 = std::chrono::steady_clock::now();
+            auto hits = idx->flat_knn(qv, k);
+            auto q1 = std::chrono::steady_clock::now();
+            if (per_query_us) per_query_us[i] = std::chrono::duration<double, std::micro>(q1 - q0).count();
+            (void)hits;
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < n_threads; t++) th.emplace_back(work);
+    for (auto& t : th) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// ---- direct hooks for unit tests of the restated Match (vs oracle/_ref) ----
+void orc_match(const uint16_t* positions, const uint32_t* lens, const uint8_t* last, uint32_t n_tokens,
+               int32_t check_exact, uint8_t* out) {
+    std::vector<token_positions_t> tp(n_tokens);
+    size_t p = 0;
+    for (uint32_t t = 0; t < n_tokens; t++) {
+        tp[t].last_token = last[t] != 0;
+        tp[t].positions.assign(positions + p, positions + p + lens[t]);
+        p += lens[t];
+    }
+    Match m(0, tp, false, check_exact != 0);
+    out[0] = m.words_present; out[1] = m.distance; out[2] = m.max_offset; out[3] = m.exact_match;
+}
+uint64_t orc_match_score(uint8_t words_present, uint8_t distance, uint8_t max_offset, uint8_t exact_match,
+                         uint32_t total_cost, uint32_t unique_words, uint8_t synonym_score) {
+    Match m(words_present, distance, max_offset, exact_match);
+    return m.get_match_score(total_cost, unique_words, synonym_score);
+}
+int64_t orc_float_to_int64(float f) { return float_to_int64_t(f); }
+float orc_int64_to_float(int64_t v) { return int64_t_to_float(v); }
+
+}  // extern "C"

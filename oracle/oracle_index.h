@@ -1,0 +1,552 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/for_codec.h header).
+// A minimal in-memory index + the query-time scoring path of the reference, restated:
+//   offset encoding at index time  : /root/reference/src/index.cpp:1323-1348 (plain string), :1351-1395 (string[])
+//   compact -> full at query time  : src/index.cpp:5637-5646, include/posting.h:45-46
+//   get_field_token_its            : src/index.cpp:5598-5660
+//   search_across_fields (lambda)  : src/index.cpp:5385-5596
+//   compute_aggregated_score       : src/index.cpp:5227-5383
+//   score_results2                 : src/index.cpp:6966-7098
+//   compute_sort_scores (subset)   : src/index.cpp:5662-5907  (text_match / seq_id / int64 column / vector_distance)
+//   float_to_int64_t / int64_t_to_float : src/index.cpp:266-284
+//   topster sizing                 : src/index.cpp:3506-3512
+//   flat vector scan               : src/index.cpp:3345-3374 ; normalize_vector include/index.h:379-388
+//   wildcard vector branch         : src/index.cpp:3645-3732
+//   hybrid rank fusion             : src/index.cpp:4036-4221 ; alpha default include/vector_query_ops.h:19
+// Terms are integer ids: the ART dictionary (token string -> posting pointer) is upstream of the
+// path and out of scope. Synonyms (syn_orig_num_tokens), typos>0, group-by, joins,
+// geo/str/eval sorts are not restated.
+//
+// Vector distance follows hnswlib's InnerProductSpace (typesense fork pinned at
+// cmake/hnsw.cmake:3 / WORKSPACE:186-191, source NOT under /root/reference): dist = 1 - sum(q_i*x_i),
+// restated with hnswlib's published 16-lane accumulate + sequential horizontal add. The HNSW graph
+// traversal (approximate) is NOT restated: "parity unpinned" for which approximate neighbours come
+// back; the oracle is the exact flat scan (what process_results_bruteforce computes).
+#pragma once
+#include <string>
+#include <cstring>
+#include <cmath>
+#include <cfloat>
+#include <unordered_map>
+#include <memory>
+#include "token_or_iter.h"
+#include "topk_heap.h"
+
+namespace oracle {
+
+static inline int64_t float_to_int64_t(float f) {  // index.cpp:266-274
+    int32_t i;
+    memcpy(&i, &f, sizeof i);
+    if (i < 0) i ^= INT32_MAX;
+    return i;
+}
+static inline float int64_t_to_float(int64_t n) {  // index.cpp:276-285
+    int32_t i = (int32_t)n;
+    if (i < 0) i ^= INT32_MAX;
+    float f;
+    memcpy(&f, &i, sizeof f);
+    return f;
+}
+
+enum text_match_type_t { max_score = 0, max_weight = 1, sum_score = 2 };  // include/index.h text_match_type_t
+enum sort_kind_t { SORT_TEXT_MATCH = 0, SORT_SEQ_ID = 1, SORT_INT64_COLUMN = 2, SORT_VECTOR_DISTANCE = 3 };
+enum vector_distance_type_t { ip = 0, cosine = 1 };                       // include/field.h:92-95
+
+struct sort_by_t { int kind = SORT_TEXT_MATCH; int column = 0; int order = 1; /* 1 = DESC, -1 = ASC */ };
+
+static const size_t COMPACT_LIST_THRESHOLD_LENGTH = 64;  // include/posting.h:45
+static const size_t MAX_BLOCK_ELEMENTS = 256;            // include/posting.h:46
+static const size_t DEFAULT_TOPSTER_SIZE = 250;          // include/index.h:679
+static const int FIELD_MAX_WEIGHT = 15;                  // include/index.h:667
+
+// tagged posting value, like art_leaf::values (include/posting.h:9-12)
+struct posting_value_t {
+    posting_list_t* full = nullptr;
+    compact_posting_list_t* compact = nullptr;
+    ~posting_value_t() { delete full; delete compact; }
+    size_t num_ids() const { return full ? full->num_ids() : (compact ? compact->num_ids() : 0); }
+};
+
+struct field_index_t {
+    bool is_array = false;
+    std::unordered_map<uint32_t, std::unique_ptr<posting_value_t>> terms;
+};
+
+struct search_field_t { uint32_t field = 0; int64_t weight = FIELD_MAX_WEIGHT; };
+
+struct keyword_query_t {
+    std::vector<uint32_t> tokens;            // term ids in query order
+    std::vector<search_field_t> fields;      // query_by fields (+ weights)
+    int match_type = max_score;
+    bool prioritize_exact_match = true;
+    bool prioritize_token_position = false;
+    bool prioritize_num_matching_fields = true;
+    uint32_t total_cost = 0;                 // sum(2*typo_cost + is_prefix), index.cpp:7233-7235
+    std::vector<sort_by_t> sort;             // <= 3
+    size_t fetch_size = 10;                  // offset + per_page
+    std::vector<uint32_t> excluded_ids;      // sorted
+    std::vector<uint32_t> filter_ids;        // sorted; empty = no filter
+    uint64_t search_stop_us = UINT64_MAX;
+};
+
+struct keyword_result_t {
+    std::vector<KV> kvs;                     // topster->sort() order
+    std::vector<uint32_t> result_ids;        // every emitted id, ascending (id_buff / all_result_ids)
+    size_t num_keyword_matches = 0;
+    bool search_cutoff = false;
+};
+
+struct vector_query_t {
+    std::vector<float> values;
+    size_t k = 0;
+    float distance_threshold = FLT_MAX;
+    float alpha = 0.3f;                      // include/vector_query_ops.h:19
+};
+
+struct vec_hit_t { float dist; uint32_t seq_id; };
+
+class Index {
+public:
+    std::vector<field_index_t> fields;
+    std::vector<std::unordered_map<uint32_t, int64_t>> sort_index;  // numeric columns: seq_id -> value (index.h:442)
+    uint32_t num_docs = 0;
+
+    // vector field
+    size_t num_dim = 0;
+    int distance_type = ip;
+    std::vector<float> vec_store;                        // row-major [n_rows][num_dim] (hnswlib level-0 data)
+    std::vector<uint32_t> vec_labels;                    // row -> label (= seq_id, index.cpp:1052-1054)
+    std::unordered_map<uint32_t, uint32_t> vec_row_of;   // label_lookup_: label -> row
+
+    explicit Index(size_t n_fields = 1, size_t n_columns = 1) : fields(n_fields), sort_index(n_columns) {}
+
+    // ---------------- index time ----------------
+    // one document's field = token id sequence (plain string field), index.cpp:1323-1348
+    void index_plain_field(uint32_t seq_id, uint32_t field, const std::vector<uint32_t>& tokens) {
+        std::unordered_map<uint32_t, std::vector<uint32_t>> token_to_offsets;
+        std::vector<uint32_t> order;
+        for (size_t i = 0; i < tokens.size(); i++) {
+            if (!token_to_offsets.count(tokens[i])) order.push_back(tokens[i]);
+            token_to_offsets[tokens[i]].push_back((uint32_t)i + 1);
+        }
+        if (!tokens.empty()) token_to_offsets[tokens.back()].push_back(0);
+        for (uint32_t t : order) upsert_posting(field, t, seq_id, token_to_offsets[t]);
+        if (seq_id + 1 > num_docs) num_docs = seq_id + 1;
+    }
+
+    // string[] field, index.cpp:1351-1395
+    void index_array_field(uint32_t seq_id, uint32_t field, const std::vector<std::vector<uint32_t>>& elems) {
+        fields[field].is_array = true;
+        std::unordered_map<uint32_t, std::vector<uint32_t>> token_positions;
+        std::vector<uint32_t> order;
+        for (size_t array_index = 0; array_index < elems.size(); array_index++) {
+            std::unordered_map<uint32_t, bool> seen_here;
+            std::vector<uint32_t> here_order;
+            uint32_t last_token = 0;
+            bool any = false;
+            for (size_t i = 0; i < elems[array_index].size(); i++) {
+                uint32_t tok = elems[array_index][i];
+                if (!token_positions.count(tok)) order.push_back(tok);
+                if (!seen_here.count(tok)) { seen_here[tok] = true; here_order.push_back(tok); }
+                token_positions[tok].push_back((uint32_t)i + 1);
+                last_token = tok;
+                any = true;
+            }
+            for (uint32_t tok : here_order) {
+                auto& v = token_positions[tok];
+                v.push_back(v.back());                 // repeat last position: end of this element
+                v.push_back((uint32_t)array_index);
+                if (any && tok == last_token) v.push_back(0);  // token is this element's last token
+            }
+        }
+        for (uint32_t t : order) upsert_posting(field, t, seq_id, token_positions[t]);
+        if (seq_id + 1 > num_docs) num_docs = seq_id + 1;
+    }
+
+    // posting_t::upsert (src/posting.cpp:247-288): compact while <= 64 cells, else full
+    void upsert_posting(uint32_t field, uint32_t term, uint32_t seq_id, const std::vector<uint32_t>& offsets) {
+        auto& slot = fields[field].terms[term];
+        if (!slot) slot.reset(new posting_value_t);
+        if (slot->full) { slot->full->upsert(seq_id, offsets); return; }
+        if (!slot->compact) slot->compact = new compact_posting_list_t;
+        slot->compact->upsert(seq_id, offsets.data(), (uint32_t)offsets.size());
+        if (slot->compact->id_offsets.size() > COMPACT_LIST_THRESHOLD_LENGTH) {
+            slot->full = slot->compact->to_full_posting_list((uint16_t)MAX_BLOCK_ELEMENTS);
+            delete slot->compact;
+            slot->compact = nullptr;
+        }
+    }
+
+    // bulk: whole posting list for one term (ids ascending), as produced by sequential upserts
+    void load_posting(uint32_t field, uint32_t term, const uint32_t* ids, const uint32_t* offset_index,
+                      const uint32_t* offsets, uint32_t n, uint32_t n_offsets) {
+        auto& slot = fields[field].terms[term];
+        slot.reset(new posting_value_t);
+        if ((size_t)n_offsets + 2 * (size_t)n <= COMPACT_LIST_THRESHOLD_LENGTH) {
+            slot->compact = compact_posting_list_t::create(n, ids, offset_index, n_offsets, offsets);
+        } else {
+            slot->full = new posting_list_t((uint16_t)MAX_BLOCK_ELEMENTS);
+            slot->full->load_sorted(ids, offset_index, offsets, n, n_offsets);
+        }
+        if (n && ids[n - 1] + 1 > num_docs) num_docs = ids[n - 1] + 1;
+    }
+
+    void set_sort_value(uint32_t column, uint32_t seq_id, int64_t v) { sort_index[column][seq_id] = v; }
+
+    // ---------------- vector index (flat) ----------------
+    static void normalize_vector(const std::vector<float>& src, std::vector<float>& norm_dest) {  // include/index.h:379-388
+        float norm = 0.0f;
+        for (float v : src) norm += v * v;
+        norm = 1.0f / (sqrtf(norm) + 1e-30f);
+        for (size_t i = 0; i < src.size(); i++) norm_dest[i] = src[i] * norm;
+    }
+
+    void vec_init(size_t dim, int dist_type) { num_dim = dim; distance_type = dist_type; }
+    void vec_add(uint32_t label, const float* v) {  // index.cpp:1040-1054
+        std::vector<float> x(v, v + num_dim);
+        if (distance_type == cosine) { std::vector<float> n(num_dim); normalize_vector(x, n); x.swap(n); }
+        auto it = vec_row_of.find(label);
+        if (it != vec_row_of.end()) {                       // addPoint on an existing label updates in place
+            std::copy(x.begin(), x.end(), vec_store.begin() + (size_t)it->second * num_dim);
+        } else {
+            vec_row_of.emplace(label, (uint32_t)vec_labels.size());
+            vec_labels.push_back(label);
+            vec_store.insert(vec_store.end(), x.begin(), x.end());
+        }
+        if (label + 1 > num_docs) num_docs = label + 1;
+    }
+    const float* vec_get(uint32_t label) const {            // getDataByLabel; nullptr = "throws"
+        auto it = vec_row_of.find(label);
+        return it == vec_row_of.end() ? nullptr : vec_store.data() + (size_t)it->second * num_dim;
+    }
+
+    // hnswlib InnerProductSpace distance: 1 - <a,b>, 16-lane accumulate (dim%16==0), 4-lane (dim%4==0),
+    // residual variants otherwise (hnswlib space_ip.h)
+    // compiled with -ffp-contract=off (oracle/Makefile): mul then add, no FMA, so the AVX-512 clone
+    // and the scalar clone of this loop give bit-identical sums
+    __attribute__((target_clones("avx512f", "avx2", "default")))
+    static float ip_partial16(const float* a, const float* b, size_t qty16) {
+        float lanes[16] = {0};
+        for (size_t i = 0; i < qty16; i += 16)
+            for (int l = 0; l < 16; l++) lanes[l] = lanes[l] + a[i + l] * b[i + l];
+        float sum = 0;
+        for (int l = 0; l < 16; l++) sum += lanes[l];
+        return sum;
+    }
+    static float ip_partial4(const float* a, const float* b, size_t qty4) {
+        float lanes[4] = {0};
+        for (size_t i = 0; i < qty4; i += 4)
+            for (int l = 0; l < 4; l++) lanes[l] = lanes[l] + a[i + l] * b[i + l];
+        return lanes[0] + lanes[1] + lanes[2] + lanes[3];
+    }
+    static float ip_scalar(const float* a, const float* b, size_t n) {
+        float r = 0;
+        for (size_t i = 0; i < n; i++) r += a[i] * b[i];
+        return r;
+    }
+    static float ip_distance(const float* a, const float* b, size_t dim) {
+        if (dim % 16 == 0) return 1.0f - ip_partial16(a, b, dim);
+        if (dim % 4 == 0) return 1.0f - ip_partial4(a, b, dim);
+        if (dim > 16) { size_t q = dim >> 4 << 4; return 1.0f - (ip_partial16(a, b, q) + ip_scalar(a + q, b + q, dim - q)); }
+        if (dim > 4) { size_t q = dim >> 2 << 2; return 1.0f - (ip_partial4(a, b, q) + ip_scalar(a + q, b + q, dim - q)); }
+        return 1.0f - ip_scalar(a, b, dim);
+    }
+
+    // exact k nearest: k smallest (dist, label) pairs, closest first (what searchKnnCloserFirst returns
+    // when the graph search is exact). allow = optional sorted id whitelist (filter / VectorFilterFunctor).
+    std::vector<vec_hit_t> flat_knn(const std::vector<float>& q_in, size_t k, const std::vector<uint32_t>* allow = nullptr,
+                                    const std::vector<uint32_t>* excluded = nullptr) const {
+        std::vector<float> q = q_in;
+        if (distance_type == cosine) { std::vector<float> n(q.size()); normalize_vector(q_in, n); q.swap(n); }
+        auto cmp = [](const vec_hit_t& a, const vec_hit_t& b) { return a.dist < b.dist || (a.dist == b.dist && a.seq_id < b.seq_id); };
+        std::vector<vec_hit_t> heap;                          // max-heap of the k best (dist, label) pairs
+        heap.reserve(k + 1);
+        for (size_t r = 0; r < vec_labels.size(); r++) {
+            uint32_t label = vec_labels[r];
+            if (allow && !std::binary_search(allow->begin(), allow->end(), label)) continue;
+            if (excluded && std::binary_search(excluded->begin(), excluded->end(), label)) continue;
+            vec_hit_t h{ip_distance(q.data(), vec_store.data() + r * num_dim, num_dim), label};
+            if (heap.size() < k) { heap.push_back(h); std::push_heap(heap.begin(), heap.end(), cmp); }
+            else if (k > 0 && cmp(h, heap.front())) { std::pop_heap(heap.begin(), heap.end(), cmp); heap.back() = h; std::push_heap(heap.begin(), heap.end(), cmp); }
+        }
+        std::sort(heap.begin(), heap.end(), cmp);
+        return heap;
+    }
+
+    // ---------------- query time: keyword ----------------
+    size_t topster_size(size_t fetch_size, size_t n_filter) const {  // index.cpp:3506-3512
+        size_t s = std::max<size_t>(fetch_size, DEFAULT_TOPSTER_SIZE);
+        if (n_filter != 0) s = std::min<size_t>(s, n_filter); else s = std::min<size_t>(s, num_docs);
+        return std::max<size_t>(1, s);
+    }
+
+    void compute_sort_scores(const std::vector<sort_by_t>& sort, uint32_t seq_id, int64_t max_field_match_score,
+                             int64_t* scores, int64_t& match_score_index, float vector_distance) const {  // index.cpp:5662-5907
+        const int64_t default_score = INT64_MIN;
+        for (size_t i = 0; i < sort.size(); i++) {
+            switch (sort[i].kind) {
+                case SORT_TEXT_MATCH: scores[i] = max_field_match_score; match_score_index = (int64_t)i; break;
+                case SORT_SEQ_ID: scores[i] = seq_id; break;
+                case SORT_VECTOR_DISTANCE: scores[i] = float_to_int64_t(vector_distance); break;
+                default: {
+                    const auto& col = sort_index[sort[i].column];
+                    auto it = col.find(seq_id);
+                    scores[i] = (it == col.end()) ? default_score : it->second;
+                }
+            }
+            if (sort[i].order == -1) scores[i] = -scores[i];
+        }
+    }
+
+    void score_results2(bool field_is_array, uint32_t total_cost, int64_t& match_score, uint32_t seq_id,
+                        bool prioritize_exact_match, bool single_exact_query_token, bool prioritize_token_position,
+                        const std::vector<posting_list_t::iterator_t>& posting_lists) const {  // index.cpp:6966-7098
+        if (posting_lists.size() <= 1) {
+            const uint8_t is_verbatim = uint8_t(prioritize_exact_match && single_exact_query_token &&
+                                                posting_list_t::is_single_token_verbatim_match(posting_lists[0], field_is_array));
+            size_t words_present = 1, distance = 0;
+            size_t max_offset = prioritize_token_position ? posting_list_t::get_last_offset(posting_lists[0], field_is_array) : 255;
+            Match m((uint8_t)words_present, (uint8_t)distance, (uint8_t)max_offset, is_verbatim);
+            match_score = (int64_t)m.get_match_score(total_cost, (uint32_t)words_present, 1);
+            return;
+        }
+        std::map<size_t, std::vector<token_positions_t>> array_token_positions;
+        posting_list_t::get_offsets(posting_lists, array_token_positions);
+        for (const auto& kv : array_token_positions) {
+            const std::vector<token_positions_t>& token_positions = kv.second;
+            if (token_positions.empty()) continue;
+            const Match match(seq_id, token_positions, false, prioritize_exact_match);
+            uint64_t s = match.get_match_score(total_cost, (uint32_t)posting_lists.size(), 1);
+            auto this_words_present = ((s >> 40) & 0xFF);
+            auto unique_words = field_is_array ? this_words_present : ((s >> 32) & 0xFF);
+            auto typo_score = ((s >> 24) & 0xFF);
+            auto proximity = ((s >> 16) & 0xFF);
+            auto verbatim = ((s >> 12) & 0xF);
+            auto offset_score = prioritize_token_position ? ((s >> 4) & 0xFF) : 0;
+            auto synonym_score = ((s >> 0) & 0xF);
+            uint64_t mod = ((int64_t(this_words_present) << 40) | (int64_t(unique_words) << 32) | (int64_t(typo_score) << 24) |
+                            (int64_t(proximity) << 16) | (int64_t(verbatim) << 12) | (int64_t(offset_score) << 4) |
+                            (int64_t(synonym_score) << 0));
+            if (mod > (uint64_t)match_score) match_score = (int64_t)mod;
+        }
+    }
+
+    int64_t compute_aggregated_score(const std::vector<or_iterator_t>& its, const keyword_query_t& q, uint32_t seq_id) const {  // index.cpp:5227-5383
+        const size_t num_search_fields = q.fields.size();
+        std::vector<std::vector<posting_list_t::iterator_t>> field_to_tokens(num_search_fields);
+        size_t query_len = 0;
+        for (size_t ti = 0; ti < its.size(); ti++) {
+            const auto& field_iters = its[ti].get_its();
+            bool found_token = false;
+            for (size_t fi = 0; fi < field_iters.size(); fi++) {
+                const auto& field_iter = field_iters[fi];
+                if (field_iter.valid() && field_iter.id() == seq_id && field_iter.get_field_id() < num_search_fields) {
+                    field_to_tokens[field_iter.get_field_id()].push_back(field_iter.clone());
+                    found_token = true;
+                }
+            }
+            if (found_token) query_len++;
+        }
+        int64_t best_field_match_score = 0, best_field_weight = 0, sum_field_weighted_score = 0;
+        uint32_t num_matching_fields = 0;
+        for (size_t fi = 0; fi < field_to_tokens.size(); fi++) {
+            const auto& token_postings = field_to_tokens[fi];
+            if (token_postings.empty()) continue;
+            const int64_t field_weight = q.fields[fi].weight;
+            const bool field_is_array = fields[q.fields[fi].field].is_array;
+            int64_t field_match_score = 0;
+            bool single_exact_query_token = (q.total_cost == 0 && q.tokens.size() == 1);
+            score_results2(field_is_array, q.total_cost, field_match_score, seq_id, q.prioritize_exact_match,
+                           single_exact_query_token, q.prioritize_token_position, token_postings);
+            if (q.match_type == max_score && field_match_score > best_field_match_score) {
+                best_field_match_score = field_match_score; best_field_weight = field_weight;
+            }
+            if (q.match_type == max_weight && field_weight > best_field_weight) {
+                best_field_weight = field_weight; best_field_match_score = field_match_score;
+            }
+            if (q.match_type == sum_score) sum_field_weighted_score += (field_weight * field_match_score);
+            num_matching_fields++;
+        }
+        query_len = (best_field_match_score == 0) ? 0 : std::min<size_t>(15, query_len);
+        auto max_field_weight = std::min<size_t>(FIELD_MAX_WEIGHT, (size_t)best_field_weight);
+        num_matching_fields = (uint32_t)std::min<size_t>(7, num_matching_fields);
+        if (!q.prioritize_num_matching_fields) num_matching_fields = 0;
+        uint64_t agg;
+        if (q.match_type == max_score)
+            agg = ((int64_t(query_len) << 59) | (int64_t(best_field_match_score) << 11) | (int64_t(max_field_weight) << 3) | int64_t(num_matching_fields));
+        else if (q.match_type == max_weight)
+            agg = ((int64_t(query_len) << 59) | (int64_t(max_field_weight) << 51) | (int64_t(best_field_match_score) << 3) | int64_t(num_matching_fields));
+        else
+            agg = ((int64_t(query_len) << 59) | (int64_t(sum_field_weighted_score) << 3) | int64_t(num_matching_fields));
+        return (int64_t)agg;
+    }
+
+    // search_across_fields, index.cpp:5385-5596 (topster owned by the caller, like the reference)
+    void search_across_fields(const keyword_query_t& q, Topster* topster, keyword_result_t& out, uint16_t query_index = 0) const {
+        std::vector<or_iterator_t> token_its;
+        std::vector<posting_list_t*> expanded_plists;
+        // get_field_token_its, index.cpp:5598-5660
+        for (size_t ti = 0; ti < q.tokens.size(); ti++) {
+            std::vector<posting_list_t::iterator_t> its;
+            for (size_t i = 0; i < q.fields.size(); i++) {
+                const auto& fidx = fields[q.fields[i].field];
+                auto leaf = fidx.terms.find(q.tokens[ti]);
+                if (leaf == fidx.terms.end()) continue;
+                if (leaf->second->compact) {
+                    posting_list_t* fl = leaf->second->compact->to_full_posting_list((uint16_t)MAX_BLOCK_ELEMENTS);
+                    expanded_plists.push_back(fl);
+                    its.push_back(fl->new_iterator(nullptr, nullptr, (uint32_t)i));
+                } else {
+                    its.push_back(leaf->second->full->new_iterator(nullptr, nullptr, (uint32_t)i));
+                }
+            }
+            if (its.empty()) continue;  // token absent from every field: silently skipped (:5651-5655)
+            or_iterator_t token_fields(its);
+            token_its.push_back(std::move(token_fields));
+        }
+
+        result_iter_state_t istate(q.excluded_ids.data(), q.excluded_ids.size(), q.filter_ids.data(), q.filter_ids.size());
+        deadline_t dl;
+        dl.search_begin_us = deadline_t::now_us();
+        dl.search_stop_us = q.search_stop_us;
+
+        or_iterator_t::intersect(token_its, istate, dl, [&](single_filter_result_t& fr, const std::vector<or_iterator_t>& its) {
+            uint32_t seq_id = fr.seq_id;
+            if (topster == nullptr) { out.result_ids.push_back(seq_id); return; }
+            int64_t aggregated_score = compute_aggregated_score(its, q, seq_id);
+            int64_t scores[3] = {0, 0, 0};
+            int64_t match_score_index = -1;
+            compute_sort_scores(q.sort, seq_id, aggregated_score, scores, match_score_index, 0);
+            KV kv(query_index, seq_id, seq_id, (int8_t)match_score_index, scores);
+            if (match_score_index != -1) {
+                kv.scores[match_score_index] = aggregated_score;
+                kv.text_match_score = aggregated_score;
+            }
+            topster->add(&kv);
+            out.result_ids.push_back(seq_id);
+        });
+
+        out.num_keyword_matches = istate.num_keyword_matches;
+        out.search_cutoff = dl.search_cutoff;
+        for (auto* p : expanded_plists) delete p;
+    }
+
+    keyword_result_t search_keyword(const keyword_query_t& q) const {
+        keyword_result_t out;
+        Topster topster(topster_size(q.fetch_size, q.filter_ids.size()));
+        search_across_fields(q, &topster, out);
+        topster.sort();
+        for (uint32_t i = 0; i < topster.size; i++) out.kvs.push_back(*topster.getKV(i));
+        return out;
+    }
+
+    // ---------------- query time: pure vector (q="*"), index.cpp:3645-3732 ----------------
+    keyword_result_t search_vector(const vector_query_t& vq, const std::vector<sort_by_t>& sort, size_t fetch_size,
+                                   const std::vector<uint32_t>* filter_ids = nullptr) const {
+        keyword_result_t out;
+        Topster topster(topster_size(fetch_size, filter_ids ? filter_ids->size() : 0));
+        size_t k = vq.k == 0 ? std::max<size_t>(vq.k, fetch_size) : vq.k;
+        std::vector<vec_hit_t> hits = flat_knn(vq.values, k, filter_ids);
+        std::sort(hits.begin(), hits.end(), [](const vec_hit_t& a, const vec_hit_t& b) { return a.seq_id < b.seq_id; });  // :3389
+        std::vector<uint32_t> nearest_ids;
+        for (const auto& h : hits) {
+            float d = (distance_type == cosine) ? std::abs(h.dist) : h.dist;
+            if (d > vq.distance_threshold) continue;
+            int64_t scores[3] = {0, 0, 0};
+            int64_t match_score_index = -1;
+            compute_sort_scores(sort, h.seq_id, 0, scores, match_score_index, d);
+            KV kv(0, h.seq_id, h.seq_id, (int8_t)match_score_index, scores);
+            kv.vector_distance = d;
+            topster.add(&kv);
+            nearest_ids.push_back(h.seq_id);
+        }
+        std::sort(nearest_ids.begin(), nearest_ids.end());
+        out.result_ids = nearest_ids;
+        topster.sort();
+        for (uint32_t i = 0; i < topster.size; i++) out.kvs.push_back(*topster.getKV(i));
+        return out;
+    }
+
+    // ---------------- query time: hybrid, index.cpp:4036-4221 ----------------
+    keyword_result_t search_hybrid(const keyword_query_t& q, const vector_query_t& vq) const {
+        keyword_result_t out;
+        Topster topster(topster_size(q.fetch_size, q.filter_ids.size()));
+        search_across_fields(q, &topster, out);
+
+        const float VECTOR_SEARCH_WEIGHT = vq.alpha;
+        const float TEXT_MATCH_WEIGHT = 1.0 - VECTOR_SEARCH_WEIGHT;
+
+        size_t default_k = 100;
+        size_t k = vq.k == 0 ? std::max<size_t>(q.fetch_size, default_k) : vq.k;
+        const std::vector<uint32_t>* allow = q.filter_ids.empty() ? nullptr : &q.filter_ids;
+        const std::vector<uint32_t>* excl = q.excluded_ids.empty() ? nullptr : &q.excluded_ids;
+        std::vector<vec_hit_t> dist_results;
+        {   // process_results_hnsw_index non-wildcard tail, index.cpp:3414-3437
+            std::vector<vec_hit_t> pairs = flat_knn(vq.values, k, allow, excl);
+            std::sort(pairs.begin(), pairs.end(), [](const vec_hit_t& a, const vec_hit_t& b) { return a.seq_id < b.seq_id; });
+            for (const auto& p : pairs) {
+                float s = (distance_type == cosine) ? std::abs(p.dist) : p.dist;
+                if (s > vq.distance_threshold) continue;
+                dist_results.push_back(p);
+            }
+            // reference: std::sort by distance (unstable); restated as a stable sort on the label-ordered
+            // sequence — differs only for bit-equal distances
+            std::stable_sort(dist_results.begin(), dist_results.end(), [](const vec_hit_t& a, const vec_hit_t& b) { return a.dist < b.dist; });
+        }
+        std::unordered_map<uint32_t, uint32_t> seq_id_to_rank;
+        for (size_t i = 0; i < dist_results.size(); i++) seq_id_to_rank.emplace(dist_results[i].seq_id, (uint32_t)i);
+        std::sort(dist_results.begin(), dist_results.end(), [](const vec_hit_t& a, const vec_hit_t& b) { return a.seq_id < b.seq_id; });
+
+        topster.sort();
+        int64_t text_rank = 0;
+        int64_t last_text_match_score = INT64_MAX;
+        for (uint32_t i = 0; i < topster.size; i++) {
+            KV* r = topster.getKV(i);
+            if (r->match_score_index < 0 || r->match_score_index > 2) continue;
+            r->text_match_score = r->scores[r->match_score_index];
+            if (r->text_match_score < last_text_match_score) ++text_rank;
+            last_text_match_score = r->text_match_score;
+            r->scores[r->match_score_index] = float_to_int64_t((1.0 / (text_rank)) * TEXT_MATCH_WEIGHT);
+        }
+
+        std::vector<uint32_t> vec_search_ids;
+        for (size_t ri = 0; ri < dist_results.size(); ri++) {
+            const auto& dr = dist_results[ri];
+            uint32_t seq_id = dr.seq_id;
+            KV* found_kv = nullptr;
+            auto it = topster.map.find(seq_id);
+            if (it != topster.map.end()) found_kv = it->second;
+            if (found_kv) {
+                if (found_kv->match_score_index < 0 || found_kv->match_score_index > 2) continue;
+                found_kv->vector_distance = dr.dist;
+                int64_t match_score = float_to_int64_t((int64_t_to_float(found_kv->scores[found_kv->match_score_index])) +
+                                                       ((1.0 / (seq_id_to_rank[seq_id] + 1)) * VECTOR_SEARCH_WEIGHT));
+                int64_t match_score_index = -1;
+                int64_t scores[3] = {0, 0, 0};
+                compute_sort_scores(q.sort, seq_id, match_score, scores, match_score_index, dr.dist);
+                for (int i = 0; i < 3; i++) found_kv->scores[i] = scores[i];
+                found_kv->match_score_index = (int8_t)match_score_index;
+            } else {
+                int64_t scores[3] = {0, 0, 0};
+                int64_t match_score = float_to_int64_t((1.0 / (seq_id_to_rank[seq_id] + 1)) * VECTOR_SEARCH_WEIGHT);
+                int64_t match_score_index = -1;
+                compute_sort_scores(q.sort, seq_id, match_score, scores, match_score_index, dr.dist);
+                KV kv(0, seq_id, seq_id, (int8_t)match_score_index, scores);
+                kv.text_match_score = 0;
+                kv.vector_distance = dr.dist;
+                topster.add(&kv);
+                vec_search_ids.push_back(seq_id);
+            }
+        }
+        if (!vec_search_ids.empty()) {  // all_result_ids = or_scalar(all_result_ids, vec_search_ids), :4206-4212
+            std::vector<uint32_t> merged;
+            std::set_union(out.result_ids.begin(), out.result_ids.end(), vec_search_ids.begin(), vec_search_ids.end(),
+                           std::back_inserter(merged));
+            out.result_ids.swap(merged);
+        }
+        topster.sort();
+        for (uint32_t i = 0; i < topster.size; i++) out.kvs.push_back(*topster.getKV(i));
+        return out;
+    }
+};
+
+}  // namespace oracle

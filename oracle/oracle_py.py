@@ -1,0 +1,290 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY. ctypes binding over oracle/_build/liboracle.so (oracle_capi.cpp)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_DIR, "_build", "liboracle.so")
+_REF = os.path.join(_DIR, "_ref", "libref_match.so")
+
+SORT_TEXT_MATCH, SORT_SEQ_ID, SORT_INT64_COLUMN, SORT_VECTOR_DISTANCE = 0, 1, 2, 3
+METRIC_IP, METRIC_COSINE = 0, 1
+MAX_SCORE, MAX_WEIGHT, SUM_SCORE = 0, 1, 2
+
+
+def build(force=False):
+    """Compile the oracle (and oracle/_ref when /root/reference exists)."""
+    if force or not os.path.exists(_LIB) or not os.path.exists(os.path.join(_DIR, "_build", "golden_tests")):
+        subprocess.check_call(["make", "-C", _DIR, "--no-print-directory"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+class KwQuery(C.Structure):
+    _fields_ = [("tokens", C.POINTER(C.c_uint32)), ("n_tokens", C.c_uint32),
+                ("field_ids", C.POINTER(C.c_uint32)), ("field_weights", C.POINTER(C.c_int64)), ("n_fields", C.c_uint32),
+                ("match_type", C.c_int32),
+                ("prioritize_exact_match", C.c_int32), ("prioritize_token_position", C.c_int32),
+                ("prioritize_num_matching_fields", C.c_int32),
+                ("total_cost", C.c_uint32),
+                ("sort_kind", C.c_int32 * 3), ("sort_column", C.c_int32 * 3), ("sort_order", C.c_int32 * 3), ("n_sort", C.c_uint32),
+                ("fetch_size", C.c_uint32),
+                ("excluded_ids", C.POINTER(C.c_uint32)), ("n_excluded", C.c_uint32),
+                ("filter_ids", C.POINTER(C.c_uint32)), ("n_filter", C.c_uint32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("cap", C.c_uint32), ("n", C.c_uint32),
+                ("keys", C.POINTER(C.c_uint64)), ("scores", C.POINTER(C.c_int64)), ("text_match", C.POINTER(C.c_int64)),
+                ("vector_distance", C.POINTER(C.c_float)), ("match_score_index", C.POINTER(C.c_int8)),
+                ("num_keyword_matches", C.c_uint64), ("n_result_ids", C.c_uint64),
+                ("result_ids", C.POINTER(C.c_uint32)), ("result_ids_cap", C.c_uint64), ("search_cutoff", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_set_num_docs.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_num_docs.restype = C.c_uint32
+        L.orc_num_docs.argtypes = [C.c_void_p]
+        L.orc_index_plain.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_index_array.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_load_posting.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.orc_dump_posting.restype = C.c_uint32
+        L.orc_dump_posting.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.orc_list_terms.restype = C.c_uint32
+        L.orc_list_terms.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_field_is_array.restype = C.c_int32
+        L.orc_field_is_array.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_set_sort.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int64]
+        L.orc_set_sort_dense.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_vec_init.argtypes = [C.c_void_p, C.c_uint32, C.c_int32]
+        L.orc_vec_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_vec_get.restype = C.c_int32
+        L.orc_vec_get.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_ip_distance.restype = C.c_float
+        L.orc_ip_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_flat_knn.restype = C.c_uint32
+        L.orc_flat_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_search_keyword.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.POINTER(Result)]
+        L.orc_search_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(Result)]
+        L.orc_search_hybrid.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.POINTER(Result)]
+        L.orc_bench_keyword.restype = C.c_double
+        L.orc_bench_keyword.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
+        L.orc_bench_vector.restype = C.c_double
+        L.orc_bench_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p]
+        L.orc_match_score.restype = C.c_uint64
+        L.orc_match_score.argtypes = [C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint32, C.c_uint32, C.c_uint8]
+        L.orc_float_to_int64.restype = C.c_int64
+        L.orc_float_to_int64.argtypes = [C.c_float]
+        L.orc_int64_to_float.restype = C.c_float
+        L.orc_int64_to_float.argtypes = [C.c_int64]
+        _lib = L
+    return _lib
+
+
+def ref_match_lib():
+    """oracle/_ref/libref_match.so: the REFERENCE's own match_score.h (None if it was never built)."""
+    if not os.path.exists(_REF):
+        return None
+    R = C.CDLL(_REF)
+    R.ref_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p]
+    R.ref_match_score.restype = C.c_uint64
+    R.ref_match_score.argtypes = [C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint32, C.c_uint32, C.c_uint8]
+    return R
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class HitList:
+    """Decoded Result: numpy arrays in topster order."""
+    def __init__(self, keys, scores, text_match, vdist, msi, num_keyword_matches, result_ids, n_result_ids, cutoff):
+        self.keys, self.scores, self.text_match, self.vector_distance = keys, scores, text_match, vdist
+        self.match_score_index = msi
+        self.num_keyword_matches, self.result_ids, self.n_result_ids = num_keyword_matches, result_ids, n_result_ids
+        self.search_cutoff = cutoff
+
+
+class OracleIndex:
+    def __init__(self, n_fields=1, n_columns=1):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.orc_create(n_fields, n_columns))
+        self.dim = 0
+
+    def close(self):
+        if self.h:
+            self.L.orc_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- index time ----
+    def index_plain(self, seq_id, field, tokens):
+        t = _u32(tokens)
+        self.L.orc_index_plain(self.h, seq_id, field, _ptr(t), t.size)
+
+    def index_array(self, seq_id, field, elems):
+        lens = _u32([len(e) for e in elems])
+        flat = _u32([t for e in elems for t in e])
+        self.L.orc_index_array(self.h, seq_id, field, _ptr(flat), _ptr(lens), lens.size)
+
+    def load_posting(self, field, term, ids, offset_index, offsets):
+        ids, offset_index, offsets = _u32(ids), _u32(offset_index), _u32(offsets)
+        self.L.orc_load_posting(self.h, field, term, _ptr(ids), _ptr(offset_index), _ptr(offsets), ids.size, offsets.size)
+
+    def dump_posting(self, field, term):
+        no = C.c_uint32(0)
+        n = self.L.orc_dump_posting(self.h, field, term, None, None, None, C.byref(no))
+        ids = np.zeros(n, np.uint32); oi = np.zeros(n, np.uint32); off = np.zeros(no.value, np.uint32)
+        if n:
+            self.L.orc_dump_posting(self.h, field, term, _ptr(ids), _ptr(oi), off.ctypes.data_as(C.c_void_p), C.byref(no))
+        return ids, oi, off
+
+    def terms(self, field):
+        n = self.L.orc_list_terms(self.h, field, None, 0)
+        t = np.zeros(n, np.uint32)
+        if n:
+            self.L.orc_list_terms(self.h, field, _ptr(t), n)
+        return np.sort(t)
+
+    def set_num_docs(self, n):
+        self.L.orc_set_num_docs(self.h, n)
+
+    def num_docs(self):
+        return self.L.orc_num_docs(self.h)
+
+    def set_sort_dense(self, column, vals):
+        v = np.ascontiguousarray(vals, dtype=np.int64)
+        self.L.orc_set_sort_dense(self.h, column, _ptr(v), v.size)
+
+    def set_sort(self, column, seq_id, v):
+        self.L.orc_set_sort(self.h, column, seq_id, int(v))
+
+    def vec_init(self, dim, metric=METRIC_IP):
+        self.dim = dim
+        self.L.orc_vec_init(self.h, dim, metric)
+
+    def vec_add(self, labels, data):
+        labels = _u32(labels)
+        data = np.ascontiguousarray(data, dtype=np.float32).reshape(labels.size, self.dim)
+        self.L.orc_vec_add(self.h, _ptr(labels), _ptr(data), labels.size)
+
+    def vec_get(self, label):
+        out = np.zeros(self.dim, np.float32)
+        rc = self.L.orc_vec_get(self.h, label, _ptr(out))
+        return out if rc == 0 else None
+
+    # ---- query time ----
+    def make_query(self, tokens, fields=((0, 15),), sort=((SORT_TEXT_MATCH, 0, 1), (SORT_SEQ_ID, 0, 1)), fetch_size=10,
+                   match_type=MAX_SCORE, prioritize_exact_match=True, prioritize_token_position=False,
+                   prioritize_num_matching_fields=True, total_cost=0, excluded_ids=None, filter_ids=None):
+        q = KwQuery()
+        keep = []
+        t = _u32(tokens); keep.append(t)
+        q.tokens = t.ctypes.data_as(C.POINTER(C.c_uint32)); q.n_tokens = t.size
+        fid = _u32([f[0] for f in fields]); fw = np.ascontiguousarray([f[1] for f in fields], dtype=np.int64)
+        keep += [fid, fw]
+        q.field_ids = fid.ctypes.data_as(C.POINTER(C.c_uint32)); q.field_weights = fw.ctypes.data_as(C.POINTER(C.c_int64))
+        q.n_fields = fid.size
+        q.match_type = match_type
+        q.prioritize_exact_match = int(prioritize_exact_match)
+        q.prioritize_token_position = int(prioritize_token_position)
+        q.prioritize_num_matching_fields = int(prioritize_num_matching_fields)
+        q.total_cost = total_cost
+        for i, s in enumerate(sort):
+            q.sort_kind[i], q.sort_column[i], q.sort_order[i] = s
+        q.n_sort = len(sort)
+        q.fetch_size = fetch_size
+        if excluded_ids is not None and len(excluded_ids):
+            e = _u32(excluded_ids); keep.append(e)
+            q.excluded_ids = e.ctypes.data_as(C.POINTER(C.c_uint32)); q.n_excluded = e.size
+        if filter_ids is not None and len(filter_ids):
+            f = _u32(filter_ids); keep.append(f)
+            q.filter_ids = f.ctypes.data_as(C.POINTER(C.c_uint32)); q.n_filter = f.size
+        q._keep = keep
+        return q
+
+    @staticmethod
+    def _alloc(cap, ids_cap):
+        r = Result()
+        bufs = dict(keys=np.zeros(cap, np.uint64), scores=np.zeros(cap * 3, np.int64), tm=np.zeros(cap, np.int64),
+                    vd=np.zeros(cap, np.float32), msi=np.zeros(cap, np.int8), ids=np.zeros(max(ids_cap, 1), np.uint32))
+        r.cap = cap
+        r.keys = bufs["keys"].ctypes.data_as(C.POINTER(C.c_uint64))
+        r.scores = bufs["scores"].ctypes.data_as(C.POINTER(C.c_int64))
+        r.text_match = bufs["tm"].ctypes.data_as(C.POINTER(C.c_int64))
+        r.vector_distance = bufs["vd"].ctypes.data_as(C.POINTER(C.c_float))
+        r.match_score_index = bufs["msi"].ctypes.data_as(C.POINTER(C.c_int8))
+        if ids_cap:
+            r.result_ids = bufs["ids"].ctypes.data_as(C.POINTER(C.c_uint32))
+            r.result_ids_cap = ids_cap
+        return r, bufs
+
+    @staticmethod
+    def _decode(r, b):
+        n = r.n
+        m = min(r.n_result_ids, r.result_ids_cap)
+        return HitList(b["keys"][:n].copy(), b["scores"][:n * 3].reshape(n, 3).copy(), b["tm"][:n].copy(), b["vd"][:n].copy(),
+                       b["msi"][:n].copy(), r.num_keyword_matches, b["ids"][:m].copy(), r.n_result_ids, bool(r.search_cutoff))
+
+    def search_keyword(self, q, cap=1024, ids_cap=0):
+        r, b = self._alloc(cap, ids_cap)
+        self.L.orc_search_keyword(self.h, C.byref(q), C.byref(r))
+        return self._decode(r, b)
+
+    def search_vector(self, qvec, k=0, fetch_size=10, sort=((SORT_VECTOR_DISTANCE, 0, -1), (SORT_SEQ_ID, 0, 1)),
+                      distance_threshold=3.4028234663852886e38, filter_ids=None, cap=1024, ids_cap=0):
+        r, b = self._alloc(cap, ids_cap)
+        qv = np.ascontiguousarray(qvec, dtype=np.float32)
+        sk = np.array([s[0] for s in sort], np.int32); sc = np.array([s[1] for s in sort], np.int32); so = np.array([s[2] for s in sort], np.int32)
+        f = _u32(filter_ids) if filter_ids is not None else None
+        self.L.orc_search_vector(self.h, _ptr(qv), k, distance_threshold, _ptr(sk), _ptr(sc), _ptr(so), len(sort), fetch_size,
+                                 _ptr(f) if f is not None else None, f.size if f is not None else 0, C.byref(r))
+        return self._decode(r, b)
+
+    def search_hybrid(self, q, qvec, k=0, alpha=0.3, distance_threshold=3.4028234663852886e38, cap=1024, ids_cap=0):
+        r, b = self._alloc(cap, ids_cap)
+        qv = np.ascontiguousarray(qvec, dtype=np.float32)
+        self.L.orc_search_hybrid(self.h, C.byref(q), _ptr(qv), k, alpha, distance_threshold, C.byref(r))
+        return self._decode(r, b)
+
+    def flat_knn(self, qvec, k, allow_ids=None):
+        qv = np.ascontiguousarray(qvec, dtype=np.float32)
+        d = np.zeros(k, np.float32); l = np.zeros(k, np.uint32)
+        a = _u32(allow_ids) if allow_ids is not None else None
+        n = self.L.orc_flat_knn(self.h, _ptr(qv), k, _ptr(a) if a is not None else None, a.size if a is not None else 0, _ptr(d), _ptr(l))
+        return d[:n], l[:n]
+
+    def bench_keyword(self, base_query, tokens, n_threads):
+        t = np.ascontiguousarray(tokens, dtype=np.uint32)
+        nq = t.shape[0]
+        per = np.zeros(nq, np.float64)
+        chk = C.c_uint64(0)
+        wall = self.L.orc_bench_keyword(self.h, C.byref(base_query), _ptr(t), nq, n_threads, _ptr(per), C.byref(chk))
+        return wall, per
+
+    def bench_vector(self, queries, k, n_threads):
+        qv = np.ascontiguousarray(queries, dtype=np.float32)
+        per = np.zeros(qv.shape[0], np.float64)
+        wall = self.L.orc_bench_vector(self.h, _ptr(qv), qv.shape[0], k, n_threads, _ptr(per))
+        return wall, per
