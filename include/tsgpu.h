@@ -1,0 +1,262 @@
+/*
+ * tsgpu.h — C-ABI of libtsgpu.so: the MI355X (gfx950) implementation of Typesense's query-time
+ * scoring hot path. Plain C, plain pointers and sizes; no torch / C++ types cross this boundary.
+ *
+ * What each entry point replaces in the reference (typesense/typesense, paths relative to the
+ * reference root; see SURVEY.md §8b and INTEGRATION.md for the call-site patches):
+ *
+ *   B1 keyword seam — the body of Index::search_across_fields from get_field_token_its to the end
+ *   of the scoring lambda (src/index.cpp:5468-5551), i.e. or_iterator_t::intersect
+ *   (include/or_iterator.h:61-182) + compute_aggregated_score (src/index.cpp:5227-5383) +
+ *   score_results2 (src/index.cpp:6966-7098) + Match (include/match_score.h:129-275) +
+ *   compute_sort_scores (src/index.cpp:5662-5907) + Topster::add/sort (include/topster.h:321-473):
+ *       tsgpu_keyword_search_batch()
+ *   fed by an index mirror built from the decoded posting blocks (posting_list_t::block_t,
+ *   include/posting_list.h:56-77) and the numeric sort index (include/index.h:442):
+ *       tsgpu_field_create() tsgpu_term_upsert() tsgpu_column_set() tsgpu_commit()
+ *
+ *   B2 vector seam — the methods Typesense calls on hnswlib::HierarchicalNSW<float> /
+ *   InnerProductSpace (include/index.h:356-370; src/index.cpp:1003-1054, 3355-3386, 7423):
+ *       tsgpu_vec_create()      ~ HierarchicalNSW ctor            (include/index.h:365-367)
+ *       tsgpu_vec_upsert()      ~ addPoint(data, label, true)     (src/index.cpp:1052-1054)
+ *       tsgpu_vec_delete()      ~ markDelete(label)               (src/index.cpp:7423)
+ *       tsgpu_vec_get()         ~ getDataByLabel<float>(label)    (src/index.cpp:3355-3359)
+ *       tsgpu_vec_count()       ~ getCurrentElementCount()        (src/index.cpp:1004-1006)
+ *       tsgpu_vec_knn_batch()   ~ searchKnnCloserFirst(q,k,ef,f)  (src/index.cpp:3384-3386), exact
+ *       tsgpu_vec_distances()   ~ process_results_bruteforce's per-id dist_func loop (src/index.cpp:3345-3374)
+ *
+ *   B3 hybrid — keyword pass, vector pass, reciprocal-rank fusion exactly as src/index.cpp:4036-4221:
+ *       tsgpu_hybrid_search_batch()
+ *
+ * Error convention mirrors Option<T> (include/option.h): every call returns a code (0 = ok, else an
+ * HTTP-like code as the reference uses: 400 bad request, 404 not found, 408 deadline, 500 device
+ * failure, 501 valid request this library does not accelerate -> caller takes its CPU path for THAT
+ * query) and tsgpu_last_error() returns the message for the calling thread. Never throws, never aborts.
+ *
+ * Threading: any number of request threads may call the search entry points concurrently on one
+ * context (the reference calls the seam under a shared_lock on Index::mutex, src/index.cpp:3488);
+ * index mutation (upsert/delete/commit) must be externally serialised against searches, exactly like
+ * the unique_lock side of Index::mutex.
+ */
+#ifndef TSGPU_H
+#define TSGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSGPU_ABI_VERSION 1
+
+/* limits of the accelerated path (anything beyond -> TSGPU_ERR_UNSUPPORTED for that query) */
+#define TSGPU_MAX_QUERY_TOKENS 10   /* = WINDOW_SIZE, include/match_score.h:11 */
+#define TSGPU_MAX_SORT_KEYS 3       /* include/topster.h:26 scores[3] */
+#define TSGPU_MAX_TOPK 1024         /* Topster capacity max(fetch_size, 250), src/index.cpp:3506 */
+#define TSGPU_DEFAULT_TOPSTER_SIZE 250 /* include/index.h:679 */
+#define TSGPU_BLOCK_IDS 256         /* posting_t::MAX_BLOCK_ELEMENTS, include/posting.h:46 */
+
+enum tsgpu_status {
+    TSGPU_OK = 0,
+    TSGPU_ERR_INVALID = 400,
+    TSGPU_ERR_NOT_FOUND = 404,
+    TSGPU_ERR_DEADLINE = 408,
+    TSGPU_ERR_DEVICE = 500,
+    TSGPU_ERR_UNSUPPORTED = 501,
+    TSGPU_ERR_NO_MEMORY = 507
+};
+
+enum tsgpu_mem_kind { TSGPU_MEM_HOST = 0, TSGPU_MEM_DEVICE = 1 };
+
+/* text_match_type_t, include/index.h (max_score default) */
+enum tsgpu_match_type { TSGPU_MAX_SCORE = 0, TSGPU_MAX_WEIGHT = 1, TSGPU_SUM_SCORE = 2 };
+
+/* what a sort_by slot reads (the sentinel maps of src/index.cpp:5722-5725, 5835-5836, 5865-5866) */
+enum tsgpu_sort_kind {
+    TSGPU_SORT_TEXT_MATCH = 0,      /* text_match_sentinel_value */
+    TSGPU_SORT_SEQ_ID = 1,          /* seq_id_sentinel_value */
+    TSGPU_SORT_INT64_COLUMN = 2,    /* sort_index[field]->find(seq_id), missing -> INT64_MIN */
+    TSGPU_SORT_VECTOR_DISTANCE = 3  /* vector_distance_sentinel_value -> float_to_int64_t(d) */
+};
+
+/* vector_distance_type_t, include/field.h:92-95 */
+enum tsgpu_metric { TSGPU_METRIC_IP = 0, TSGPU_METRIC_COSINE = 1 };
+
+typedef struct tsgpu_ctx tsgpu_ctx;
+
+/* ------------------------------------------------------------------ lifecycle */
+int tsgpu_abi_version(void);
+/* device_ordinal: HIP device index (one context per process per GPU). */
+int tsgpu_create(int device_ordinal, tsgpu_ctx** out);
+void tsgpu_destroy(tsgpu_ctx* ctx);
+/* message of the last failing call on this thread ("" if none) */
+const char* tsgpu_last_error(void);
+/* run the library's kernels on a caller-owned hipStream_t (NULL = the context's own stream) */
+int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
+/* tuning knobs (all optional): "kw_chunk_blocks" = driver posting blocks per keyword work item (default 64),
+ * "vec_rows_per_slab" = base rows per k-NN workgroup slab (default: automatic) */
+int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value);
+/* bytes of HBM held by the context's index mirrors */
+uint64_t tsgpu_device_bytes(tsgpu_ctx* ctx);
+
+/* ------------------------------------------------------------------ keyword index mirror */
+/* declare a query_by field; is_array = field is string[] (offset format of src/index.cpp:1351-1395) */
+int tsgpu_field_create(tsgpu_ctx* ctx, uint32_t field_id, int is_array);
+
+/* Replace the posting list of (field, term) with the DECODED content of its posting_list_t blocks
+ * (include/posting_list.h:56-77): ids ascending; offset_index[i] = start of doc i's run in offsets[];
+ * offsets in the reference's encoding (position+1, trailing 0 = last token, src/index.cpp:1323-1348).
+ * n_ids == 0 removes the term. Host pointers. Takes effect at the next tsgpu_commit(). */
+int tsgpu_term_upsert(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id,
+                      const uint32_t* ids, const uint32_t* offset_index, const uint32_t* offsets,
+                      uint32_t n_ids, uint32_t n_offsets);
+
+/* Bulk form of tsgpu_term_upsert for n_terms lists in CSR layout: list t owns
+ * ids[ids_ptr[t] .. ids_ptr[t+1]) ; offset_index entries are absolute indices into offsets[] and list t's
+ * offsets end at off_ptr[t+1]. Host pointers. */
+int tsgpu_terms_load_csr(tsgpu_ctx* ctx, uint32_t field_id, uint32_t n_terms, const uint32_t* term_ids,
+                         const uint64_t* ids_ptr, const uint32_t* ids, const uint64_t* offset_index,
+                         const uint64_t* off_ptr, const uint32_t* offsets);
+
+/* Dense numeric sort column (the reference's sort_index[field], include/index.h:442): values[seq_id];
+ * present == NULL means every seq_id < n has a value, else present[seq_id] != 0. mem = tsgpu_mem_kind. */
+int tsgpu_column_set(tsgpu_ctx* ctx, uint32_t column_id, const int64_t* values, const uint8_t* present,
+                     uint32_t n, int mem);
+
+/* number of documents (num_seq_ids(), bounds the Topster capacity, src/index.cpp:3510) */
+int tsgpu_set_num_docs(tsgpu_ctx* ctx, uint32_t num_docs);
+
+/* publish all pending term/column changes to HBM as one immutable snapshot */
+int tsgpu_commit(tsgpu_ctx* ctx);
+
+/* introspection (tests): number of ids of a term, 0 if absent */
+uint32_t tsgpu_term_num_ids(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id);
+/* decode a committed list back from the device format (tests: format round trip). Buffers sized by
+ * tsgpu_term_num_ids / *n_offsets (call once with NULL buffers to size). */
+int tsgpu_term_download(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, uint32_t* ids,
+                        uint32_t* offset_index, uint32_t* offsets, uint32_t* n_offsets);
+
+/* ------------------------------------------------------------------ keyword search (seam B1) */
+typedef struct tsgpu_sort_by {
+    uint8_t kind;      /* tsgpu_sort_kind */
+    int8_t order;      /* 1 = DESC, -1 = ASC (sort_order[], src/index.cpp:5901-5903) */
+    uint16_t column;   /* for TSGPU_SORT_INT64_COLUMN */
+} tsgpu_sort_by;
+
+typedef struct tsgpu_kw_query {
+    /* one candidate-token combination, i.e. ONE call of search_across_fields (src/index.cpp:5385) */
+    uint32_t n_tokens;                               /* query_tokens.size() */
+    uint32_t term_ids[TSGPU_MAX_QUERY_TOKENS];       /* tokens absent from the index are skipped (src/index.cpp:5651-5655) */
+    uint32_t n_fields;                               /* v1: 1 */
+    uint32_t field_ids[4];
+    int32_t field_weights[4];                        /* the_fields[i].weight (0..15) */
+    uint8_t match_type;                              /* tsgpu_match_type */
+    uint8_t prioritize_exact_match;
+    uint8_t prioritize_token_position;
+    uint8_t prioritize_num_matching_fields;
+    uint32_t total_cost;                             /* sum(2*typo_cost + is_prefix), src/index.cpp:7233-7235 */
+    uint32_t n_sort;
+    tsgpu_sort_by sort[TSGPU_MAX_SORT_KEYS];
+    uint32_t topster_size;                           /* Topster capacity, src/index.cpp:3506-3512 (0 = max(250, ...) by the library) */
+    const uint32_t* excluded_ids;                    /* sorted, host; may be NULL */
+    uint32_t n_excluded;
+    const uint32_t* filter_ids;                      /* sorted, host; NULL = no filter */
+    uint32_t n_filter;
+    uint64_t deadline_us;                            /* absolute epoch us after which search_cutoff is raised; 0 = none */
+} tsgpu_kw_query;
+
+/* Results, structure-of-arrays, slot q*k_stride+i = i-th best hit of query q in Topster::sort() order
+ * (descending (scores[0],scores[1],scores[2],key), include/topster.h:146-149,469-473). The host shim turns
+ * each slot into KV{key, distinct_key=key, scores, match_score_index, text_match_score} and calls topster->add. */
+typedef struct tsgpu_hits {
+    int mem;                 /* tsgpu_mem_kind of every pointer below */
+    uint32_t k_stride;       /* slots per query (>= the largest topster_size in the batch) */
+    uint64_t* keys;          /* [n_queries*k_stride] seq_id */
+    int64_t* scores;         /* [n_queries*k_stride*3] */
+    int64_t* text_match;     /* [n_queries*k_stride] aggregated text score (KV::text_match_score) */
+    float* vector_distance;  /* [n_queries*k_stride] -1.0f unless set by the vector / hybrid path */
+    int8_t* match_score_index; /* [n_queries*k_stride] */
+    uint32_t* n_hits;        /* [n_queries] */
+    uint64_t* num_matched;   /* [n_queries] num_keyword_matches (keyword) / hits returned (vector) */
+    int32_t* status;         /* [n_queries] per-query tsgpu_status (501 -> run that query on the CPU path) */
+    int32_t* search_cutoff;  /* [n_queries] 1 if the deadline passed (thread_local search_cutoff) */
+} tsgpu_hits;
+
+int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out);
+
+/* all matched ids of the LAST keyword batch for query q, ascending (id_buff / all_result_ids, src/index.cpp:5565).
+ * Only available when tsgpu_keep_result_ids(ctx, 1) was set before the batch. Returns count; copies min(count, cap). */
+int tsgpu_keep_result_ids(tsgpu_ctx* ctx, int keep);
+uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64_t cap);
+
+/* ------------------------------------------------------------------ vector index (seam B2) */
+int tsgpu_vec_create(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t dim, int metric, uint64_t capacity_hint);
+/* addPoint: cosine fields are L2-normalised on insert like src/index.cpp:1049-1052. data: [n][dim] fp32. */
+int tsgpu_vec_upsert(tsgpu_ctx* ctx, uint32_t vec_field_id, const uint64_t* labels, const float* data,
+                     uint32_t n, int mem);
+int tsgpu_vec_delete(tsgpu_ctx* ctx, uint32_t vec_field_id, uint64_t label);
+/* TSGPU_ERR_NOT_FOUND where getDataByLabel would throw */
+int tsgpu_vec_get(tsgpu_ctx* ctx, uint32_t vec_field_id, uint64_t label, float* out_host);
+uint64_t tsgpu_vec_count(tsgpu_ctx* ctx, uint32_t vec_field_id);
+
+/* exact k nearest by dist = 1 - <q,x> (cosine: q normalised first, src/index.cpp:3381-3384), closest first,
+ * ties -> smaller label first. allow_ids (sorted, NULL = all) plays VectorFilterFunctor (include/index.h:325-354).
+ * Q: [n_q][dim] fp32 (mem_q). Outputs [n_q][k] (mem_out), n_out[n_q] = hits written per query. */
+int tsgpu_vec_knn_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, int mem_q, uint32_t n_q, uint32_t k,
+                        const uint32_t* allow_ids, uint32_t n_allow, const uint32_t* excluded_ids, uint32_t n_excluded,
+                        float* dist_out, uint64_t* label_out, uint32_t* n_out, int mem_out);
+
+/* distances of one query to explicit labels (flat scan over filter ids, src/index.cpp:3345-3374);
+ * missing labels get NaN (the reference `continue`s on the throw). Host pointers. */
+int tsgpu_vec_distances(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* q, const uint64_t* labels, uint32_t n,
+                        float* dist_out);
+
+/* pure vector search (q="*", src/index.cpp:3645-3732): knn + threshold + sort scores + Topster order */
+typedef struct tsgpu_vec_query {
+    uint32_t k;                     /* vector_query.k (0 -> fetch_size) */
+    uint32_t fetch_size;
+    float distance_threshold;       /* FLT_MAX = none */
+    uint32_t n_sort;
+    tsgpu_sort_by sort[TSGPU_MAX_SORT_KEYS];
+    uint32_t topster_size;          /* 0 = library default */
+} tsgpu_vec_query;
+int tsgpu_vector_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const tsgpu_vec_query* params,
+                              const float* Q, int mem_q, uint32_t n_q, tsgpu_hits* out);
+
+/* ------------------------------------------------------------------ hybrid (B3) */
+typedef struct tsgpu_hybrid_params {
+    uint32_t k;                     /* vector_query.k (0 -> max(fetch_size, 100), src/index.cpp:4060-4063) */
+    uint32_t fetch_size;
+    float alpha;                    /* VECTOR_SEARCH_WEIGHT, default 0.3 (include/vector_query_ops.h:19) */
+    float distance_threshold;
+} tsgpu_hybrid_params;
+/* Q: [n_queries][dim] host or device; queries[i] pairs with Q[i]. Output = Topster after fusion + sort. */
+int tsgpu_hybrid_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t vec_field_id,
+                              const tsgpu_hybrid_params* params, const float* Q, int mem_q,
+                              uint32_t n_queries, tsgpu_hits* out);
+
+/* ------------------------------------------------------------------ multi-GPU (doc-range shards) */
+/* Merge G per-shard hit lists (already gathered, e.g. by an RCCL all-gather) into the global Topster
+ * order. in[g] are host-resident tsgpu_hits for the same n_queries; key_offset[g] is added to shard g's keys
+ * (0 if shards keep global seq_ids). Pure host code, exact (same comparator as include/topster.h:146-149). */
+int tsgpu_merge_shard_hits(const tsgpu_hits* in, const uint64_t* key_offset, uint32_t n_shards,
+                           uint32_t n_queries, uint32_t k, tsgpu_hits* out);
+
+/* ------------------------------------------------------------------ measurement hooks */
+/* device time (ms, HIP events on the launch stream) of the dominant kernel(s) of the last batch call */
+typedef struct tsgpu_timings {
+    float kw_search_ms;    /* keyword intersect+score+select kernel */
+    float kw_merge_ms;     /* per-query partial merge kernel */
+    float vec_knn_ms;      /* MFMA distance + running top-k kernel */
+    float vec_merge_ms;
+    float total_ms;        /* first launch -> last kernel done */
+    uint64_t kw_algorithmic_bytes;   /* SURVEY §8(d) bytes of the last keyword batch */
+    uint64_t vec_flops;              /* 2*N*D*B of the last knn batch */
+} tsgpu_timings;
+int tsgpu_last_timings(tsgpu_ctx* ctx, tsgpu_timings* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSGPU_H */

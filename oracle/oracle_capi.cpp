@@ -21,6 +21,7 @@ struct orc_kw_query {
     uint32_t fetch_size;
     const uint32_t* excluded_ids; uint32_t n_excluded;
     const uint32_t* filter_ids; uint32_t n_filter;
+    uint32_t topster_size;   // 0 = reference rule
 };
 
 struct orc_result {
@@ -51,6 +52,7 @@ static keyword_query_t to_query(const orc_kw_query* q) {
     k.fetch_size = q->fetch_size;
     if (q->n_excluded) k.excluded_ids.assign(q->excluded_ids, q->excluded_ids + q->n_excluded);
     if (q->n_filter) k.filter_ids.assign(q->filter_ids, q->filter_ids + q->n_filter);
+    k.topster_size = q->topster_size;
     return k;
 }
 

@@ -86,6 +86,7 @@ struct keyword_query_t {
     std::vector<uint32_t> excluded_ids;      // sorted
     std::vector<uint32_t> filter_ids;        // sorted; empty = no filter
     uint64_t search_stop_us = UINT64_MAX;
+    size_t topster_size = 0;                 // 0 = the reference's sizing rule; >0 = explicit Topster capacity (tests)
 };
 
 struct keyword_result_t {
@@ -432,7 +433,7 @@ public:
 
     keyword_result_t search_keyword(const keyword_query_t& q) const {
         keyword_result_t out;
-        Topster topster(topster_size(q.fetch_size, q.filter_ids.size()));
+        Topster topster(q.topster_size ? q.topster_size : topster_size(q.fetch_size, q.filter_ids.size()));
         search_across_fields(q, &topster, out);
         topster.sort();
         for (uint32_t i = 0; i < topster.size; i++) out.kvs.push_back(*topster.getKV(i));
@@ -469,7 +470,7 @@ public:
     // ---------------- query time: hybrid, index.cpp:4036-4221 ----------------
     keyword_result_t search_hybrid(const keyword_query_t& q, const vector_query_t& vq) const {
         keyword_result_t out;
-        Topster topster(topster_size(q.fetch_size, q.filter_ids.size()));
+        Topster topster(q.topster_size ? q.topster_size : topster_size(q.fetch_size, q.filter_ids.size()));
         search_across_fields(q, &topster, out);
 
         const float VECTOR_SEARCH_WEIGHT = vq.alpha;

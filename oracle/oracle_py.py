@@ -30,7 +30,7 @@ class KwQuery(C.Structure):
                 ("sort_kind", C.c_int32 * 3), ("sort_column", C.c_int32 * 3), ("sort_order", C.c_int32 * 3), ("n_sort", C.c_uint32),
                 ("fetch_size", C.c_uint32),
                 ("excluded_ids", C.POINTER(C.c_uint32)), ("n_excluded", C.c_uint32),
-                ("filter_ids", C.POINTER(C.c_uint32)), ("n_filter", C.c_uint32)]
+                ("filter_ids", C.POINTER(C.c_uint32)), ("n_filter", C.c_uint32), ("topster_size", C.c_uint32)]
 
 
 class Result(C.Structure):
@@ -197,7 +197,7 @@ class OracleIndex:
     # ---- query time ----
     def make_query(self, tokens, fields=((0, 15),), sort=((SORT_TEXT_MATCH, 0, 1), (SORT_SEQ_ID, 0, 1)), fetch_size=10,
                    match_type=MAX_SCORE, prioritize_exact_match=True, prioritize_token_position=False,
-                   prioritize_num_matching_fields=True, total_cost=0, excluded_ids=None, filter_ids=None):
+                   prioritize_num_matching_fields=True, total_cost=0, excluded_ids=None, filter_ids=None, topster_size=0):
         q = KwQuery()
         keep = []
         t = _u32(tokens); keep.append(t)
@@ -215,6 +215,7 @@ class OracleIndex:
             q.sort_kind[i], q.sort_column[i], q.sort_order[i] = s
         q.n_sort = len(sort)
         q.fetch_size = fetch_size
+        q.topster_size = topster_size
         if excluded_ids is not None and len(excluded_ids):
             e = _u32(excluded_ids); keep.append(e)
             q.excluded_ids = e.ctypes.data_as(C.POINTER(C.c_uint32)); q.n_excluded = e.size

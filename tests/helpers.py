@@ -1,0 +1,76 @@
+"""Shared test plumbing: synthetic corpora built once by the oracle and mirrored into a tsgpu context, and
+HIP-vs-oracle comparison. The oracle (oracle/) is the checker only."""
+import os
+import subprocess
+import numpy as np
+
+from oracle import oracle_py as O
+import typesense_amd as T
+from typesense_amd import _lib as B
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def emu_lib_path():
+    """tests/hipemu/_build/libtsgpu_emu.so: the unmodified product sources compiled against the SIMT emulator."""
+    out = subprocess.check_output([os.path.join(ROOT, "tests", "hipemu", "build_emu.sh")], text=True).strip().splitlines()[-1]
+    return out
+
+
+def gpu_lib_path():
+    from typesense_amd import build
+    return build.build()
+
+
+def zipf_docs(n_docs, vocab, tokens_per_doc, seed, s=1.0):
+    rng = np.random.default_rng(seed)
+    p = 1.0 / np.arange(1, vocab + 1) ** s
+    p /= p.sum()
+    cdf = np.cumsum(p)
+    u = rng.random((n_docs, tokens_per_doc))
+    return np.searchsorted(cdf, u).astype(np.uint32) + 1          # term ids 1..vocab (rank order)
+
+
+def points_of(n_docs):
+    ids = np.arange(n_docs, dtype=np.uint64)
+    return ((ids * np.uint64(2654435761)) % np.uint64(1000)).astype(np.int64)   # hash(seq_id) mod 1000
+
+
+def build_pair(docs, lib_path, points=None, n_columns=1, gpu=None):
+    """docs: [n_docs][tokens] term ids (plain string field 0). Returns (oracle index, GpuIndex)."""
+    n_docs = docs.shape[0]
+    orc = O.OracleIndex(1, n_columns)
+    for d in range(n_docs):
+        orc.index_plain(d, 0, docs[d])
+    if points is None:
+        points = points_of(n_docs)
+    orc.set_sort_dense(0, points)
+    g = gpu or T.GpuIndex(0, lib_path)
+    g.field_create(0, False)
+    for term in orc.terms(0):
+        ids, oi, off = orc.dump_posting(0, int(term))
+        g.term_upsert(0, int(term), ids, oi, off)
+    g.column_set(0, points)
+    g.set_num_docs(n_docs)
+    g.commit()
+    return orc, g
+
+
+def oracle_keyword(orc, q, cap=2048, ids_cap=0):
+    oq = orc.make_query(q.tokens, fields=((q.field, q.weight),),
+                        sort=tuple((s[0], s[2], s[1]) for s in q.sort),
+                        fetch_size=10, topster_size=q.topster_size,
+                        match_type=q.match_type, prioritize_exact_match=q.prioritize_exact_match,
+                        prioritize_token_position=q.prioritize_token_position,
+                        prioritize_num_matching_fields=q.prioritize_num_matching_fields, total_cost=q.total_cost,
+                        excluded_ids=q.excluded_ids, filter_ids=q.filter_ids)
+    return orc.search_keyword(oq, cap=cap, ids_cap=ids_cap)
+
+
+def assert_hits_equal(hits, qi, ref, what=""):
+    n = int(hits.n_hits[qi])
+    assert n == ref.keys.size, "%s q%d: n_hits %d vs oracle %d" % (what, qi, n, ref.keys.size)
+    assert np.array_equal(hits.keys[qi, :n], ref.keys), "%s q%d: keys differ\n%s\n%s" % (what, qi, hits.keys[qi, :n][:20], ref.keys[:20])
+    assert np.array_equal(hits.scores[qi, :n], ref.scores), "%s q%d: scores differ" % (what, qi)
+    assert np.array_equal(hits.text_match[qi, :n], ref.text_match), "%s q%d: text_match differ" % (what, qi)
+    assert int(hits.num_matched[qi]) == int(ref.num_keyword_matches), "%s q%d: num_matched %d vs %d" % (what, qi, hits.num_matched[qi], ref.num_keyword_matches)

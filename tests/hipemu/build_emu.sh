@@ -1,0 +1,22 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE ONLY: compiles the UNMODIFIED product sources (typesense_amd/csrc/*.hip) for the host CPU
+# against tests/hipemu/hip/hip_runtime.h (SIMT emulator) -> tests/hipemu/_build/libtsgpu_emu.so.
+# Used by the `not gpu` tests to exercise kernel + planning logic where no GPU exists. Never shipped, never
+# loaded by typesense_amd (which only ever loads the real libtsgpu.so and fails loudly without it).
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+CXX=/opt/rocm/lib/llvm/bin/clang++
+[ -x "$CXX" ] || CXX=clang++
+mkdir -p "$HERE/_build"
+OUT="$HERE/_build/libtsgpu_emu.so"
+SRCS="$ROOT/typesense_amd/csrc/tsgpu.hip $ROOT/typesense_amd/csrc/tsgpu_vec.hip"
+NEWER=0
+for f in $SRCS "$ROOT"/typesense_amd/csrc/*.h "$ROOT"/include/*.h "$HERE"/hip/hip_runtime.h; do
+  if [ ! -f "$OUT" ] || [ "$f" -nt "$OUT" ]; then NEWER=1; fi
+done
+if [ "$NEWER" = 1 ]; then
+  "$CXX" -x c++ -std=c++17 -O1 -g -fPIC -shared -DTSGPU_HIP_EMU=1 -Wno-unused-value -Wno-macro-redefined \
+      -I "$HERE" -o "$OUT" $SRCS -lpthread
+fi
+echo "$OUT"

@@ -1,0 +1,287 @@
+// TEST INFRASTRUCTURE ONLY — a tiny SIMT emulator so that the device code of typesense_amd/csrc/*.hip.h can
+// be executed on the build container's CPU (which has no GPU) by tests/test_emu_*.py.
+//
+// This directory shadows <hip/hip_runtime.h> for ONE translation unit (tests/hipemu/emu_harness.cpp), compiled
+// with the host compiler. The kernel sources are included unmodified; nothing here is linked into libtsgpu.so
+// and the product never falls back to it. It models exactly what the kernels use:
+//   * a workgroup = N cooperative fibers (ucontext), run one block at a time;
+//   * __syncthreads(): all live fibers of the block; wave collectives (__ballot, __shfl*, MFMA): all live
+//     lanes of the 64-wide wave — a collective reached by only part of a wave is reported as a divergence
+//     error instead of silently "working";
+//   * __shared__ = function-local static (one block at a time); atomics = plain ops (cooperative scheduling);
+//   * __builtin_amdgcn_mfma_f32_32x32x2f32 with the CDNA4 fragment layout and k-ordered fmaf chain
+//     (cdna_hip_programming.md §3: bit-exact model of v_mfma_f32_32x32x2_f32).
+#pragma once
+#include <ucontext.h>
+#include <time.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <functional>
+
+#define TSGPU_HIP_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __forceinline__ inline
+
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+
+namespace hipemu {
+
+enum WaitKind { RUNNING = 0, AT_BARRIER = 1, AT_WAVE = 2, DONE = 3 };
+
+struct Fiber {
+    ucontext_t ctx;
+    std::vector<char> stack;
+    dim3 tid;
+    int wait = RUNNING;
+    unsigned wave_gen = 0;
+};
+
+struct WaveState {
+    unsigned gen = 0;
+    uint64_t u64[64];
+    float f32a[64], f32b[64];
+};
+
+struct BlockState {
+    std::vector<Fiber> fibers;
+    std::vector<WaveState> waves;
+    ucontext_t sched;
+    int cur = -1;
+    dim3 block_idx, block_dim, grid_dim;
+    std::function<void()> body;
+};
+
+inline BlockState*& g() { static BlockState* b = nullptr; return b; }
+
+inline void yield_to_sched() { BlockState* b = g(); swapcontext(&b->fibers[b->cur].ctx, &b->sched); }
+
+inline void syncthreads() {
+    BlockState* b = g();
+    b->fibers[b->cur].wait = AT_BARRIER;
+    yield_to_sched();
+}
+
+// all live lanes of the calling lane's wave rendezvous here
+inline void wave_sync() {
+    BlockState* b = g();
+    b->fibers[b->cur].wait = AT_WAVE;
+    yield_to_sched();
+}
+
+inline void fiber_entry() {
+    BlockState* b = g();
+    b->body();
+    b->fibers[b->cur].wait = DONE;
+    swapcontext(&b->fibers[b->cur].ctx, &b->sched);
+}
+
+inline void run_block(BlockState& B) {
+    g() = &B;
+    const unsigned n = B.block_dim.x;
+    B.fibers.resize(n);
+    B.waves.assign((n + 63) / 64, WaveState());
+    for (unsigned i = 0; i < n; i++) {
+        Fiber& f = B.fibers[i];
+        f.stack.resize(256 * 1024);
+        f.tid = dim3(i, 0, 0);
+        f.wait = RUNNING;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack.data();
+        f.ctx.uc_stack.ss_size = f.stack.size();
+        f.ctx.uc_link = &B.sched;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+    }
+    for (;;) {
+        bool progressed = false, any_live = false;
+        for (unsigned i = 0; i < n; i++) {
+            Fiber& f = B.fibers[i];
+            if (f.wait == DONE) continue;
+            any_live = true;
+            if (f.wait == RUNNING) { B.cur = (int)i; swapcontext(&B.sched, &f.ctx); progressed = true; }
+        }
+        if (!any_live) break;
+        // release wave collectives: every live lane of a wave is AT_WAVE
+        for (unsigned w = 0; w < B.waves.size(); w++) {
+            bool all = true, any = false;
+            for (unsigned l = w * 64; l < n && l < (w + 1) * 64; l++) {
+                if (B.fibers[l].wait == DONE) continue;
+                any = true;
+                if (B.fibers[l].wait != AT_WAVE) all = false;
+            }
+            if (any && all) {
+                for (unsigned l = w * 64; l < n && l < (w + 1) * 64; l++) if (B.fibers[l].wait == AT_WAVE) B.fibers[l].wait = RUNNING;
+                progressed = true;
+            }
+        }
+        // release the block barrier: every live fiber is AT_BARRIER
+        bool all = true, any = false;
+        for (unsigned i = 0; i < n; i++) {
+            if (B.fibers[i].wait == DONE) continue;
+            any = true;
+            if (B.fibers[i].wait != AT_BARRIER) all = false;
+        }
+        if (any && all) { for (unsigned i = 0; i < n; i++) if (B.fibers[i].wait == AT_BARRIER) B.fibers[i].wait = RUNNING; progressed = true; }
+        if (!progressed) {
+            fprintf(stderr, "hipemu: DEADLOCK / divergent collective in block %u: lane states:", B.block_idx.x);
+            for (unsigned i = 0; i < n; i++) fprintf(stderr, " %d", B.fibers[i].wait);
+            fprintf(stderr, "\n");
+            abort();
+        }
+    }
+    g() = nullptr;
+}
+
+template <class F>
+inline void launch(dim3 grid, dim3 block, F body) {
+    for (unsigned bx = 0; bx < grid.x; bx++) {
+        BlockState B;
+        B.block_idx = dim3(bx, 0, 0);
+        B.block_dim = block;
+        B.grid_dim = grid;
+        B.body = body;
+        run_block(B);
+    }
+}
+
+inline dim3 cur_tid() { BlockState* b = g(); return b->fibers[b->cur].tid; }
+inline dim3 cur_bid() { return g()->block_idx; }
+inline dim3 cur_bdim() { return g()->block_dim; }
+inline dim3 cur_gdim() { return g()->grid_dim; }
+inline WaveState& cur_wave() { BlockState* b = g(); return b->waves[b->cur / 64]; }
+inline unsigned cur_lane() { return (unsigned)g()->cur & 63u; }
+inline bool lane_live(unsigned lane) { BlockState* b = g(); unsigned i = (unsigned)(b->cur / 64) * 64 + lane; return i < b->fibers.size() && b->fibers[i].wait != DONE; }
+
+inline unsigned long long ballot(int pred) {
+    WaveState& W = cur_wave();
+    W.u64[cur_lane()] = pred ? 1 : 0;
+    wave_sync();
+    unsigned long long m = 0;
+    for (unsigned l = 0; l < 64; l++) if (lane_live(l) && W.u64[l]) m |= (1ull << l);
+    wave_sync();
+    return m;
+}
+
+template <class T>
+inline T shfl(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "shfl width");
+    WaveState& W = cur_wave();
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    W.u64[cur_lane()] = bits;
+    wave_sync();
+    T out = v;
+    unsigned s = (unsigned)src_lane & 63u;
+    if (lane_live(s)) memcpy(&out, &W.u64[s], sizeof(T));
+    wave_sync();
+    return out;
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
+inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    WaveState& W = cur_wave();
+    const unsigned l = cur_lane();
+    W.f32a[l] = a;
+    W.f32b[l] = b;
+    wave_sync();
+    f32x16 d = c;
+    const unsigned col = l & 31;
+    for (int r = 0; r < 16; r++) {
+        const unsigned row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (unsigned k = 0; k < 2; k++) acc = fmaf(W.f32a[row + 32 * k], W.f32b[col + 32 * k], acc);
+        d[r] = acc;
+    }
+    wave_sync();
+    return d;
+}
+
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D: col=l&15, row=(l>>4)*4+r
+inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+    WaveState& W = cur_wave();
+    const unsigned l = cur_lane();
+    W.f32a[l] = a;
+    W.f32b[l] = b;
+    wave_sync();
+    f32x4 d = c;
+    const unsigned col = l & 15;
+    for (int r = 0; r < 4; r++) {
+        const unsigned row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (unsigned k = 0; k < 4; k++) acc = fmaf(W.f32a[row + 16 * k], W.f32b[col + 16 * k], acc);
+        d[r] = acc;
+    }
+    wave_sync();
+    return d;
+}
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::cur_tid())
+#define blockIdx (hipemu::cur_bid())
+#define blockDim (hipemu::cur_bdim())
+#define gridDim (hipemu::cur_gdim())
+
+inline void __syncthreads() { hipemu::syncthreads(); }
+inline unsigned long long __ballot(int pred) { return hipemu::ballot(pred); }
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __popc(unsigned x) { return __builtin_popcount(x); }
+template <class T> inline T __shfl(T v, int lane, int = 64) { return hipemu::shfl(v, lane); }
+template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return hipemu::shfl(v, (int)(hipemu::cur_lane() ^ (unsigned)mask)); }
+template <class T> inline T __shfl_down(T v, unsigned d, int = 64) { unsigned s = hipemu::cur_lane() + d; return hipemu::shfl(v, s < 64 ? (int)s : (int)hipemu::cur_lane()); }
+template <class T> inline T __shfl_up(T v, unsigned d, int = 64) { unsigned l = hipemu::cur_lane(); return hipemu::shfl(v, l >= d ? (int)(l - d) : (int)l); }
+
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+template <class T> inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu::mfma_32x32x2((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_16x16x4((a), (b), (c))
+inline void __builtin_amdgcn_s_setprio(int) {}
+inline void __builtin_amdgcn_sched_barrier(int) {}
+
+// ---------------------------------------------------------------- host runtime API subset (emulated)
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+typedef struct hipemu_stream* hipStream_t;
+typedef struct hipemu_event { double t; }* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
+
+inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)malloc(sizeof(hipemu_event)); (*e)->t = 0; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); e->t = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })

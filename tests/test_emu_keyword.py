@@ -1,0 +1,147 @@
+"""Keyword hot path (kw_kernels.hip.h + the planning code of tsgpu.hip) executed on the CPU under the SIMT
+emulator of tests/hipemu, checked bit-exactly against the oracle. Same sources as libtsgpu.so; logic-level
+coverage for the container that has no GPU. The `-m gpu` twin is tests/test_gpu_keyword.py."""
+import numpy as np
+import pytest
+
+import typesense_amd as T
+from typesense_amd import _lib as B
+from tests import helpers as H
+
+
+@pytest.fixture(scope="module")
+def pair():
+    docs = H.zipf_docs(3000, 300, 12, seed=1)
+    orc, g = H.build_pair(docs, H.emu_lib_path())
+    yield orc, g, docs
+    g.close()
+
+
+def _queries(rng, n, vocab_hi, n_tok, **kw):
+    out = []
+    for _ in range(n):
+        toks = rng.choice(np.arange(1, vocab_hi), size=n_tok, replace=False)
+        out.append(T.KwQuery(toks, **kw))
+    return out
+
+
+def test_posting_format_roundtrip(pair):
+    orc, g, _ = pair
+    for term in [1, 2, 17, 150, 299]:
+        ids, oi, off = orc.dump_posting(0, term)
+        gi, go, gf = g.term_download(0, term)
+        assert np.array_equal(ids, gi) and np.array_equal(oi, go) and np.array_equal(off, gf)
+
+
+@pytest.mark.parametrize("n_tok", [1, 2, 3])
+def test_keyword_topk_bit_exact_small_T(pair, n_tok):
+    orc, g, _ = pair
+    rng = np.random.default_rng(100 + n_tok)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    qs = _queries(rng, 6, 40, n_tok, sort=sort, topster_size=250)
+    hits = g.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all()
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(hits, i, H.oracle_keyword(orc, q), "T=%d" % n_tok)
+
+
+def test_keyword_generic_T_up_to_10(pair):
+    orc, g, _ = pair
+    rng = np.random.default_rng(7)
+    qs = []
+    for n_tok in (4, 5, 7, 10):
+        qs += _queries(rng, 2, 12, n_tok, sort=((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0)), topster_size=250)
+    hits = g.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all()
+    assert hits.n_hits.sum() > 0
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(hits, i, H.oracle_keyword(orc, q), "generic")
+
+
+def test_keyword_duplicate_missing_tokens_and_flags(pair):
+    orc, g, _ = pair
+    base = dict(topster_size=250)
+    qs = [
+        T.KwQuery([3, 3], **base),                               # same token twice ("mong mong")
+        T.KwQuery([2, 5, 2], **base),
+        T.KwQuery([1, 9999, 4], **base),                         # token absent from the index is skipped
+        T.KwQuery([9999], **base),                               # nothing left -> 0 hits
+        T.KwQuery([1, 2], prioritize_token_position=True, **base),
+        T.KwQuery([6], prioritize_token_position=True, **base),
+        T.KwQuery([1, 2, 3], prioritize_exact_match=False, **base),
+        T.KwQuery([1, 4], prioritize_num_matching_fields=False, **base),
+        T.KwQuery([2, 3], match_type=B.MAX_WEIGHT, weight=7, **base),
+        T.KwQuery([2, 3], match_type=B.MAX_WEIGHT, weight=0, **base),
+        T.KwQuery([2, 3], match_type=B.SUM_SCORE, weight=3, **base),
+        T.KwQuery([5, 1], total_cost=3, **base),
+        T.KwQuery([8], total_cost=0, **base),                    # single token, verbatim check
+        T.KwQuery([1, 2], sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, -1, 0)), **base),
+        T.KwQuery([1, 2], sort=((B.SORT_TEXT_MATCH, -1, 0), (B.SORT_SEQ_ID, 1, 0)), **base),   # ASC text match: :5541 override quirk
+        T.KwQuery([1, 3], sort=((B.SORT_SEQ_ID, 1, 0),), **base),                               # no text_match slot
+    ]
+    hits = g.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all()
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(hits, i, H.oracle_keyword(orc, q), "flags")
+    assert hits.n_hits[3] == 0
+
+
+def test_keyword_small_topster_and_result_ids(pair):
+    """topster_size 5 forces the threshold/compaction path; matched ids come back ascending like id_buff"""
+    orc, g, _ = pair
+    g.keep_result_ids(True)
+    qs = [T.KwQuery([1, 2], topster_size=5, sort=((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))),
+          T.KwQuery([1], topster_size=3), T.KwQuery([2, 1, 3], topster_size=1)]
+    hits = g.keyword_search_batch(qs, k_stride=8)
+    for i, q in enumerate(qs):
+        ref = H.oracle_keyword(orc, q, ids_cap=4000)
+        n = int(hits.n_hits[i])
+        assert n == min(q.topster_size, ref.keys.size) == ref.keys.size
+        H.assert_hits_equal(hits, i, ref, "small-k")
+        assert np.array_equal(g.result_ids(i), ref.result_ids)
+    g.keep_result_ids(False)
+
+
+def test_keyword_excluded_ids(pair):
+    orc, g, _ = pair
+    q0 = T.KwQuery([1, 2], topster_size=250)
+    all_ids = H.oracle_keyword(orc, q0, ids_cap=4000).result_ids
+    excl = np.sort(all_ids[::3])
+    q = T.KwQuery([1, 2], topster_size=250, excluded_ids=excl)
+    g.keep_result_ids(True)
+    hits = g.keyword_search_batch([q], k_stride=250)
+    ref = H.oracle_keyword(orc, q, ids_cap=4000)
+    H.assert_hits_equal(hits, 0, ref, "excluded")
+    assert np.array_equal(g.result_ids(0), ref.result_ids)
+    g.keep_result_ids(False)
+
+
+def test_unsupported_queries_are_reported_per_query(pair):
+    _, g, _ = pair
+    qs = [T.KwQuery([1, 2]), T.KwQuery([1, 2], filter_ids=[1, 5, 9]), T.KwQuery([1], n_fields=2),
+          T.KwQuery(list(range(1, 12))), T.KwQuery([1], topster_size=5000)]
+    hits = g.keyword_search_batch(qs, k_stride=250)
+    assert list(hits.status) == [0, B.ERR_UNSUPPORTED, B.ERR_UNSUPPORTED, B.ERR_UNSUPPORTED, B.ERR_UNSUPPORTED]
+    assert hits.n_hits[1] == 0 and hits.n_hits[0] > 0
+
+
+def test_keyword_many_work_items_and_merge(pair):
+    """kw_chunk_blocks=1: every 256-id driver block becomes its own work item, so the partial top-K merge kernel,
+    cross-chunk id concatenation and per-chunk counters are all exercised"""
+    orc, g, _ = pair
+    g.set_option("kw_chunk_blocks", 1)
+    g.keep_result_ids(True)
+    try:
+        sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+        qs = [T.KwQuery([1], sort=sort, topster_size=250), T.KwQuery([1, 2], sort=sort, topster_size=100),
+              T.KwQuery([2, 1, 3], sort=sort, topster_size=7), T.KwQuery([1, 2, 3, 4], sort=sort, topster_size=250),
+              T.KwQuery([1], sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=250)]   # ascending ids all beat the threshold
+        assert g.term_num_ids(0, 1) > 4 * 256
+        hits = g.keyword_search_batch(qs, k_stride=250)
+        for i, q in enumerate(qs):
+            ref = H.oracle_keyword(orc, q, ids_cap=4000)
+            H.assert_hits_equal(hits, i, ref, "chunks")
+            assert np.array_equal(g.result_ids(i), ref.result_ids)
+    finally:
+        g.set_option("kw_chunk_blocks", 64)
+        g.keep_result_ids(False)

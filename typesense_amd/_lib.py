@@ -1,0 +1,120 @@
+"""ctypes declarations of include/tsgpu.h. Loads typesense_amd/libtsgpu.so (built by typesense_amd/build.py)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtsgpu.so")
+
+TSGPU_OK, ERR_INVALID, ERR_NOT_FOUND, ERR_DEADLINE, ERR_DEVICE, ERR_UNSUPPORTED, ERR_NO_MEMORY = 0, 400, 404, 408, 500, 501, 507
+MEM_HOST, MEM_DEVICE = 0, 1
+SORT_TEXT_MATCH, SORT_SEQ_ID, SORT_INT64_COLUMN, SORT_VECTOR_DISTANCE = 0, 1, 2, 3
+METRIC_IP, METRIC_COSINE = 0, 1
+MAX_SCORE, MAX_WEIGHT, SUM_SCORE = 0, 1, 2
+MAX_QUERY_TOKENS = 10
+FLT_MAX = 3.4028234663852886e38
+
+
+class TsgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("tsgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+class SortBy(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("order", C.c_int8), ("column", C.c_uint16)]
+
+
+class KwQueryC(C.Structure):
+    _fields_ = [("n_tokens", C.c_uint32), ("term_ids", C.c_uint32 * MAX_QUERY_TOKENS),
+                ("n_fields", C.c_uint32), ("field_ids", C.c_uint32 * 4), ("field_weights", C.c_int32 * 4),
+                ("match_type", C.c_uint8), ("prioritize_exact_match", C.c_uint8), ("prioritize_token_position", C.c_uint8),
+                ("prioritize_num_matching_fields", C.c_uint8),
+                ("total_cost", C.c_uint32), ("n_sort", C.c_uint32), ("sort", SortBy * 3), ("topster_size", C.c_uint32),
+                ("excluded_ids", C.POINTER(C.c_uint32)), ("n_excluded", C.c_uint32),
+                ("filter_ids", C.POINTER(C.c_uint32)), ("n_filter", C.c_uint32),
+                ("deadline_us", C.c_uint64)]
+
+
+class HitsC(C.Structure):
+    _fields_ = [("mem", C.c_int), ("k_stride", C.c_uint32),
+                ("keys", C.c_void_p), ("scores", C.c_void_p), ("text_match", C.c_void_p), ("vector_distance", C.c_void_p),
+                ("match_score_index", C.c_void_p), ("n_hits", C.c_void_p), ("num_matched", C.c_void_p),
+                ("status", C.c_void_p), ("search_cutoff", C.c_void_p)]
+
+
+class VecQueryC(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("fetch_size", C.c_uint32), ("distance_threshold", C.c_float),
+                ("n_sort", C.c_uint32), ("sort", SortBy * 3), ("topster_size", C.c_uint32)]
+
+
+class HybridParamsC(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("fetch_size", C.c_uint32), ("alpha", C.c_float), ("distance_threshold", C.c_float)]
+
+
+class TimingsC(C.Structure):
+    _fields_ = [("kw_search_ms", C.c_float), ("kw_merge_ms", C.c_float), ("vec_knn_ms", C.c_float), ("vec_merge_ms", C.c_float),
+                ("total_ms", C.c_float), ("kw_algorithmic_bytes", C.c_uint64), ("vec_flops", C.c_uint64)]
+
+
+EXPORTS = [
+    "tsgpu_abi_version", "tsgpu_create", "tsgpu_destroy", "tsgpu_last_error", "tsgpu_set_stream", "tsgpu_set_option", "tsgpu_device_bytes",
+    "tsgpu_field_create", "tsgpu_term_upsert", "tsgpu_terms_load_csr", "tsgpu_column_set", "tsgpu_set_num_docs", "tsgpu_commit",
+    "tsgpu_term_num_ids", "tsgpu_term_download", "tsgpu_keyword_search_batch", "tsgpu_keep_result_ids", "tsgpu_result_ids",
+    "tsgpu_vec_create", "tsgpu_vec_upsert", "tsgpu_vec_delete", "tsgpu_vec_get", "tsgpu_vec_count", "tsgpu_vec_knn_batch",
+    "tsgpu_vec_distances", "tsgpu_vector_search_batch", "tsgpu_hybrid_search_batch", "tsgpu_merge_shard_hits", "tsgpu_last_timings",
+]
+
+_libs = {}
+
+
+def lib(path=None):
+    """Load the C-ABI library. Raises (never falls back to a CPU path) when it is missing."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise TsgpuError(ERR_DEVICE, "%s not found: build it with `python -m typesense_amd.build` (hipcc, gfx950). "
+                                     "There is no CPU fallback." % path)
+    L = C.CDLL(path)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    L.tsgpu_abi_version.restype = i32
+    L.tsgpu_create.argtypes = [i32, C.POINTER(vp)]
+    L.tsgpu_destroy.argtypes = [vp]
+    L.tsgpu_destroy.restype = None
+    L.tsgpu_last_error.restype = C.c_char_p
+    L.tsgpu_set_stream.argtypes = [vp, vp]
+    L.tsgpu_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.tsgpu_device_bytes.argtypes = [vp]
+    L.tsgpu_device_bytes.restype = u64
+    L.tsgpu_field_create.argtypes = [vp, u32, i32]
+    L.tsgpu_term_upsert.argtypes = [vp, u32, u32, vp, vp, vp, u32, u32]
+    L.tsgpu_terms_load_csr.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp, vp]
+    L.tsgpu_column_set.argtypes = [vp, u32, vp, vp, u32, i32]
+    L.tsgpu_set_num_docs.argtypes = [vp, u32]
+    L.tsgpu_commit.argtypes = [vp]
+    L.tsgpu_term_num_ids.argtypes = [vp, u32, u32]
+    L.tsgpu_term_num_ids.restype = u32
+    L.tsgpu_term_download.argtypes = [vp, u32, u32, vp, vp, vp, C.POINTER(u32)]
+    L.tsgpu_keyword_search_batch.argtypes = [vp, vp, u32, C.POINTER(HitsC)]
+    L.tsgpu_keep_result_ids.argtypes = [vp, i32]
+    L.tsgpu_result_ids.argtypes = [vp, u32, vp, u64]
+    L.tsgpu_result_ids.restype = u64
+    L.tsgpu_vec_create.argtypes = [vp, u32, u32, i32, u64]
+    L.tsgpu_vec_upsert.argtypes = [vp, u32, vp, vp, u32, i32]
+    L.tsgpu_vec_delete.argtypes = [vp, u32, u64]
+    L.tsgpu_vec_get.argtypes = [vp, u32, u64, vp]
+    L.tsgpu_vec_count.argtypes = [vp, u32]
+    L.tsgpu_vec_count.restype = u64
+    L.tsgpu_vec_knn_batch.argtypes = [vp, u32, vp, i32, u32, u32, vp, u32, vp, u32, vp, vp, vp, i32]
+    L.tsgpu_vec_distances.argtypes = [vp, u32, vp, vp, u32, vp]
+    L.tsgpu_vector_search_batch.argtypes = [vp, u32, C.POINTER(VecQueryC), vp, i32, u32, C.POINTER(HitsC)]
+    L.tsgpu_hybrid_search_batch.argtypes = [vp, vp, u32, C.POINTER(HybridParamsC), vp, i32, u32, C.POINTER(HitsC)]
+    L.tsgpu_merge_shard_hits.argtypes = [vp, vp, u32, u32, u32, C.POINTER(HitsC)]
+    L.tsgpu_last_timings.argtypes = [vp, C.POINTER(TimingsC)]
+    _libs[path] = L
+    return L
+
+
+def check(L, rc):
+    if rc != TSGPU_OK:
+        raise TsgpuError(rc, L.tsgpu_last_error().decode("utf-8", "replace"))

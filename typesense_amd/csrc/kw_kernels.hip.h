@@ -1,0 +1,682 @@
+// kw_kernels.hip.h — gfx950 kernels of the keyword hot path (seam B1, include/tsgpu.h).
+//
+// One launch of kw_search_kernel does, for a whole batch of queries, what the reference does per query on
+// one CPU thread in or_iterator_t::intersect (include/or_iterator.h:61-182) and its scoring lambda
+// (src/index.cpp:5479-5551): conjunctive doc-id intersection, per-hit Match window scoring
+// (include/match_score.h:129-275), score_results2 / compute_aggregated_score packing
+// (src/index.cpp:6966-7098, 5227-5383), compute_sort_scores (src/index.cpp:5662-5907) and the bounded
+// top-K of Topster (include/topster.h:321-473).
+//
+// Mapping to the machine (64-wide wavefronts, 256-thread workgroups, LDS queues):
+//   * a work item = (query, range of <=CHUNK 256-id blocks of the query's SHORTEST list, the "driver");
+//     one workgroup per work item, grid = all work items of the batch (>> 256 CUs);
+//   * stage 0: thread t extracts id t of the driver block straight from the bit-packed payload
+//     (coalesced dword loads, funnel shift) — no decode buffer, no allocation;
+//   * stage 1: every candidate id probes the next-shortest list: binary search of the contiguous
+//     blk_last[] skip array, then a bit-packed binary search inside the one candidate block;
+//     survivors are compacted IN ORDER with wave ballot + popcount prefix sums into an LDS queue;
+//   * stage 2 (>=3 tokens): runs only when >=256 survivors are queued, so the remaining probes execute
+//     with full wavefronts; survivors -> final queue;
+//   * score stage: dense again (>=256 queued hits or flush): per hit, token positions are read on demand
+//     from the packed offsets, the Match window runs in registers, the 64-bit text score and the
+//     (<=3) sort keys are assembled and the hit is offered to an LDS top-K buffer guarded by the
+//     current K-th-best threshold; the buffer is bitonic-sorted + truncated when it fills;
+//   * each work item writes its sorted partial top-K; kw_merge_kernel folds the partials of a query
+//     (usually 1-4) into the final Topster::sort() order.
+// Text scores depend only on the document, so chunking / sharding never changes a score.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "tsgpu_format.h"
+
+namespace tsgpu {
+
+static const int KW_THREADS = 256;
+static const int KW_QCAP = 512;            // LDS queue capacity (>= 255 leftover + 256 new)
+static const int KW_MAX_TOKENS = 10;       // TSGPU_MAX_QUERY_TOKENS
+static const uint32_t KW_WINDOW_SIZE = 10; // WINDOW_SIZE, include/match_score.h:11
+
+struct IndexView {
+    const ListDesc* lists;
+    const uint32_t* blk_last;
+    const BlockMeta* blk_meta;
+    const uint32_t* payload;
+    const int64_t* const* columns;   // columns[c][seq_id], INT64_MIN = no value (default_score, index.cpp:5696)
+    const uint32_t* column_len;
+    uint32_t n_columns;
+    uint32_t num_docs;
+};
+
+struct KwQueryDev {                  // one search_across_fields call
+    uint32_t n_lists;                // tokens that exist in the index (token_its.size())
+    uint32_t n_query_tokens;         // query_tokens.size()
+    uint32_t list[KW_MAX_TOKENS];    // list handle per found token, QUERY order (Match depends on it)
+    uint8_t probe_order[KW_MAX_TOKENS + 2];  // indices into list[], ascending n_ids; [0] = driver
+    uint8_t match_type, prio_exact, prio_pos, prio_nfields;
+    uint32_t total_cost;
+    int32_t weight;
+    uint8_t n_sort;
+    uint8_t sort_kind[3];
+    int8_t sort_order[3];
+    uint8_t pad0;
+    uint16_t sort_col[3];
+    uint16_t pad1;
+    uint32_t k;                      // Topster capacity
+    uint32_t first_work, n_work;     // this query's work items (contiguous)
+    uint32_t aux_off, n_excl, n_filt;  // excluded ids then filter ids in the aux id arena
+    uint64_t ids_out_off;            // where this query's matched ids go (if kept)
+};
+
+struct KwWorkItem {
+    uint32_t query;
+    uint32_t blk_begin, blk_end;     // driver-list block range
+    uint32_t ids_out_off;            // offset (relative to the query's ids_out_off) of this chunk's id segment
+};
+
+struct KwPartials {                  // per work item, stride = k_stride
+    int64_t* s0; int64_t* s1; int64_t* s2; int64_t* key;
+    uint32_t* cnt;                   // entries written (<= k)
+    uint32_t* n_match;               // num_keyword_matches contribution
+    uint32_t* n_emit;                // ids emitted (after exclusion / filter)
+    uint64_t* off_words;             // sum over hits of (offsets read + 1 offset_index entry) per token: algorithmic bytes / 4
+    uint32_t k_stride;
+};
+
+struct KwOut {                       // final, per query, stride = k_stride (tsgpu_hits layout)
+    uint64_t* keys; int64_t* scores; int64_t* text_match; float* vector_distance; int8_t* match_score_index;
+    uint32_t* n_hits; uint64_t* num_matched; uint64_t* off_words;
+    uint32_t k_stride;
+};
+
+// ------------------------------------------------------------------------------------------------
+// ordered compaction: exclusive prefix of `pred` over the workgroup (wave ballot + popcount, then the
+// 4 wave totals through LDS). Every thread must call it (uniform control flow).
+__device__ inline uint32_t block_compact(bool pred, uint32_t* s_wave_cnt /*[4]*/, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long mask = __ballot(pred ? 1 : 0);
+    const uint32_t lane_off = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads();                       // protect s_wave_cnt reuse from a previous call
+    if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < KW_THREADS / 64; w++) {
+        const uint32_t c = s_wave_cnt[w];
+        if ((uint32_t)w < wave) base += c;
+        tot += c;
+    }
+    total = tot;
+    return base + lane_off;
+}
+
+// is id x in the list? -> posting position (block*256 + slot). Two binary searches, all loads are
+// broadcast / same-line for neighbouring lanes because candidates ascend with the lane id.
+__device__ inline bool probe_list(const IndexView& ix, const ListDesc& d, uint32_t x, uint32_t& pos) {
+    if (x < d.first_id || x > d.last_id) return false;
+    const uint32_t* __restrict__ bl = ix.blk_last + d.blk_base;
+    uint32_t lo = 0, hi = d.n_blocks - 1;              // bl[hi] = last_id >= x: the lower bound exists
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (bl[mid] >= x) hi = mid; else lo = mid + 1;
+    }
+    const BlockMeta m = ix.blk_meta[d.blk_base + lo];
+    if (x < m.first_id) return false;
+    const uint32_t* __restrict__ w = ix.payload + d.payload_base + m.ids_woff;
+    const uint32_t target = x - m.first_id;
+    uint32_t l = 0, h = (uint32_t)m.n_ids - 1;         // packed[h] = block last >= target
+    while (l < h) {
+        const uint32_t mid = (l + h) >> 1;
+        if (unpack_at(w, mid, m.ids_bits) >= target) h = mid; else l = mid + 1;
+    }
+    if (unpack_at(w, l, m.ids_bits) != target) return false;
+    pos = lo * BLOCK_IDS + l;
+    return true;
+}
+
+// one token's occurrences inside one document (plain string field, src/index.cpp:1323-1348 encoding)
+struct TokRun {
+    const uint32_t* w;   // packed offsets of the block
+    uint32_t start;      // first element of the run
+    uint32_t n;          // number of POSITIONS (the trailing 0 flag excluded)
+    uint32_t bits, base;
+    uint32_t last_flag;  // run ends with 0: token is the last token of the field
+    uint32_t raw_len;    // elements in the run (for the algorithmic byte count)
+};
+
+__device__ inline uint32_t run_raw(const TokRun& r, uint32_t j) { return r.base + unpack_at(r.w, r.start + j, r.bits); }
+// positions.push_back((uint16_t)pos - 1), src/posting_list.cpp:906
+__device__ inline uint32_t run_pos(const TokRun& r, uint32_t j) { return (uint32_t)(uint16_t)((uint16_t)run_raw(r, j) - 1); }
+
+__device__ inline TokRun load_run(const IndexView& ix, const ListDesc& d, uint32_t pos) {
+    const uint32_t b = pos >> 8, i = pos & 255;
+    const BlockMeta m = ix.blk_meta[d.blk_base + b];
+    const uint32_t* __restrict__ base = ix.payload + d.payload_base;
+    const uint32_t s = unpack_at(base + m.oi_woff, i, m.oi_bits);
+    const uint32_t e = (i == (uint32_t)m.n_ids - 1) ? m.n_off : unpack_at(base + m.oi_woff, i + 1, m.oi_bits);
+    TokRun r;
+    r.w = base + m.off_woff;
+    r.start = s;
+    r.bits = m.off_bits;
+    r.base = m.off_base;
+    r.raw_len = e - s;
+    r.last_flag = (e > s && run_raw(r, e - s - 1) == 0) ? 1u : 0u;
+    r.n = (e - s) - r.last_flag;
+    return r;
+}
+
+// Match::Match(doc, token_positions, populate_window=false, check_exact_match) — include/match_score.h:129-275.
+// Window state lives in registers: every array index below is a compile-time constant after unrolling
+// (dynamic token ids are resolved with unrolled selects), so nothing spills to scratch.
+struct MatchOut { uint32_t words_present, distance, max_offset, exact_match; };
+
+template <int TMAX>
+__device__ inline MatchOut match_window(const TokRun (&runs)[TMAX], const uint32_t T, const bool check_exact) {
+    const uint32_t tokens_size = T < KW_WINDOW_SIZE ? T : KW_WINDOW_SIZE;
+    uint32_t wo[TMAX];   // offset (uint16 value)
+    uint32_t wt[TMAX];   // token id
+    uint32_t wi[TMAX];   // offset_index (cursor into the token's positions)
+#pragma unroll
+    for (int t = 0; t < TMAX; t++) {
+        wo[t] = ((uint32_t)t < tokens_size) ? run_pos(runs[t], 0) : 0;
+        wt[t] = (uint32_t)t;
+        wi[t] = 0;
+    }
+    uint32_t wsize = tokens_size;
+    uint32_t best_num_match = 1, best_displacement = 0xFFFFu /*MAX_DISPLACEMENT*/, max_offset = 0;
+    int prev_min_offset = -1;
+
+    while (wsize > 1) {
+        // ---- sort descending with the reference's exact tie behaviour ----
+        if (wsize == 2) {                                   // sort2, :79-84
+            if (wo[0] < wo[1]) { uint32_t a = wo[0], b = wt[0], c = wi[0]; wo[0] = wo[1]; wt[0] = wt[1]; wi[0] = wi[1]; wo[1] = a; wt[1] = b; wi[1] = c; }
+        } else if (TMAX >= 3 && wsize == 3) {               // sort3, :86-111 (NOT a stable sort: keep it literal)
+            const int i1 = TMAX >= 3 ? 1 : 0, i2 = TMAX >= 3 ? 2 : 0;
+#define TSGPU_SWAP(i, j) { uint32_t a = wo[i], b = wt[i], c = wi[i]; wo[i] = wo[j]; wt[i] = wt[j]; wi[i] = wi[j]; wo[j] = a; wt[j] = b; wi[j] = c; }
+#define TSGPU_ROT(i0, j0, k0) { /* tmp=a[i0]; a[i0]=a[j0]; a[j0]=a[k0]; a[k0]=tmp */ \
+            uint32_t a = wo[i0], b = wt[i0], c = wi[i0]; wo[i0] = wo[j0]; wt[i0] = wt[j0]; wi[i0] = wi[j0]; \
+            wo[j0] = wo[k0]; wt[j0] = wt[k0]; wi[j0] = wi[k0]; wo[k0] = a; wt[k0] = b; wi[k0] = c; }
+            if (wo[0] > wo[i1]) {
+                if (wo[i1] > wo[i2]) { /* sorted */ }
+                else if (wo[0] > wo[i2]) TSGPU_SWAP(i1, i2)
+                else TSGPU_ROT(0, i2, i1)           // tmp=a0; a0=a2; a2=a1; a1=tmp
+            } else {
+                if (wo[0] > wo[i2]) TSGPU_SWAP(0, i1)
+                else if (wo[i2] > wo[i1]) TSGPU_SWAP(0, i2)
+                else TSGPU_ROT(0, i1, i2)           // tmp=a0; a0=a1; a1=a2; a2=tmp
+            }
+        } else {
+            // std::sort(greater) on <=10 elements = libstdc++ insertion sort = a stable descending sort
+#pragma unroll
+            for (int i = 1; i < TMAX; i++) {
+#pragma unroll
+                for (int j = i; j >= 1; j--) {
+                    if ((uint32_t)i < wsize && wo[j - 1] < wo[j]) TSGPU_SWAP(j - 1, j)
+                }
+            }
+        }
+        // ---- smallest offset = window.back() ----
+        uint32_t min_offset = 0, back_t = 0, back_i = 0, front = wo[0];
+#pragma unroll
+        for (int i = 0; i < TMAX; i++) if ((uint32_t)i == wsize - 1) { min_offset = wo[i]; back_t = wt[i]; back_i = wi[i]; }
+        if ((int)min_offset < prev_min_offset) break;       // uint16 wrap-around, :164-167
+        prev_min_offset = (int)min_offset;
+
+        uint32_t this_displacement = 0, this_num_match = 0;
+#pragma unroll
+        for (int i = 0; i < TMAX; i++) {
+            if ((uint32_t)i < wsize && (wo[i] - min_offset) <= KW_WINDOW_SIZE) {
+                uint32_t next_offset = wo[i];
+                if (i + 1 < TMAX) { if ((uint32_t)(i + 1) < wsize) next_offset = wo[i + 1 < TMAX ? i + 1 : i]; }
+                this_displacement += wo[i] - next_offset;
+                this_num_match++;
+            }
+        }
+        if (this_num_match > best_num_match || (this_num_match == best_num_match && this_displacement < best_displacement)) {
+            best_displacement = this_displacement;
+            best_num_match = this_num_match;
+            max_offset = front < 255u ? front : 255u;
+        }
+        if (best_num_match == tokens_size && best_displacement == (wsize - 1)) break;
+
+        // ---- pop the smallest, push the same token's next position ----
+        wsize--;
+        uint32_t tok_n = 0, tok_last = 0, tok_next = 0;
+#pragma unroll
+        for (int t = 0; t < TMAX; t++) {
+            if ((uint32_t)t == back_t) {
+                tok_n = runs[t].n;
+                tok_last = run_pos(runs[t], runs[t].n - 1);
+                tok_next = (back_i + 1 < runs[t].n) ? run_pos(runs[t], back_i + 1) : 0;
+            }
+        }
+        (void)tok_n;
+        if (min_offset == tok_last) continue;               // "no more offsets for this token" (value compare, :212-215)
+#pragma unroll
+        for (int i = 0; i < TMAX; i++) if ((uint32_t)i == wsize) { wo[i] = tok_next; wt[i] = back_t; wi[i] = back_i + 1; }
+        wsize++;
+    }
+#undef TSGPU_SWAP
+#undef TSGPU_ROT
+    if (best_displacement == 0xFFFFu) best_displacement = 0;
+    MatchOut out;
+    out.words_present = best_num_match & 0xFF;
+    out.distance = best_displacement & 0xFF;
+    out.max_offset = max_offset;
+    out.exact_match = 0;
+    if (check_exact) {
+        const uint32_t distance = out.distance;
+        if (!(distance > T - 1)) {
+            int last_token_index = -1;
+            uint32_t total_offsets = 0;
+            bool bail = false;
+#pragma unroll
+            for (int t = 0; t < TMAX; t++) {
+                if ((uint32_t)t < T && !bail) {
+                    if (runs[t].last_flag && runs[t].n != 0) last_token_index = (int)run_pos(runs[t], runs[t].n - 1);
+                    total_offsets += runs[t].n;
+                    if (total_offsets > T && distance == T - 1) bail = true;
+                }
+            }
+            if (!bail && last_token_index == (int)T - 1) {
+                if (total_offsets == T && distance == T - 1) out.exact_match = 1;
+                else if (distance < T - 1) out.exact_match = 1;
+            }
+        }
+    }
+    return out;
+}
+
+// Match::get_match_score, include/match_score.h:56-68 (int64 shifts restated on uint64: identical bits)
+__device__ inline uint64_t pack_match_score(uint32_t words_present, uint32_t unique_words, uint32_t total_cost,
+                                            uint32_t distance, uint32_t exact, uint32_t max_offset, uint32_t synonym) {
+    return ((uint64_t)(int64_t)(int32_t)words_present << 40) | ((uint64_t)(int64_t)(int32_t)unique_words << 32) |
+           ((uint64_t)((int64_t)(255 - (int64_t)total_cost)) << 24) | ((uint64_t)((int64_t)(100 - (int64_t)distance)) << 16) |
+           ((uint64_t)exact << 12) | ((uint64_t)((int64_t)(255 - (int64_t)max_offset)) << 4) | (uint64_t)synonym;
+}
+
+struct ScoredHit { int64_t s0, s1, s2; int64_t text_match; uint32_t off_words; };
+
+// score_results2 + compute_aggregated_score + compute_sort_scores for ONE query_by field (plain string)
+template <int TMAX>
+__device__ inline ScoredHit score_hit(const IndexView& ix, const KwQueryDev& q, uint32_t seq_id, const uint32_t (&pos)[TMAX]) {
+    const uint32_t T = q.n_lists;
+    uint64_t field_match_score;
+    uint32_t off_words = 0;
+    if (T <= 1) {   // single-token fast path, src/index.cpp:6985-6996
+        const TokRun r = load_run(ix, ix.lists[q.list[0]], pos[0]);
+        off_words = r.raw_len + 1;
+        const bool single_exact_query_token = (q.total_cost == 0 && q.n_query_tokens == 1);
+        uint32_t verbatim = 0;
+        if (q.prio_exact && single_exact_query_token) {
+            // is_single_token_verbatim_match, src/posting_list.cpp:918-959 (plain field)
+            verbatim = (run_raw(r, 0) == 1 && r.raw_len == 2 && run_raw(r, 1) == 0) ? 1u : 0u;
+        }
+        uint32_t max_offset = 255;
+        if (q.prio_pos) {   // get_last_offset, src/posting_list.cpp:1899-1951 (plain field); narrowed to uint8 by Match()
+            const uint32_t lastv = run_raw(r, r.raw_len - 1);
+            max_offset = (lastv == 0 ? run_raw(r, r.raw_len - 2) : lastv) & 0xFF;
+        }
+        field_match_score = pack_match_score(1, 1, q.total_cost, 0, verbatim, max_offset, 1);
+    } else {
+        TokRun runs[TMAX];
+#pragma unroll
+        for (int t = 0; t < TMAX; t++) {
+            if ((uint32_t)t < T) { runs[t] = load_run(ix, ix.lists[q.list[t]], pos[t]); off_words += runs[t].raw_len + 1; }
+            else { runs[t].w = nullptr; runs[t].start = 0; runs[t].n = 0; runs[t].bits = 0; runs[t].base = 0; runs[t].last_flag = 0; runs[t].raw_len = 0; }
+        }
+        const MatchOut m = match_window<TMAX>(runs, T, q.prio_exact != 0);
+        const uint64_t s = pack_match_score(m.words_present, T, q.total_cost, m.distance, m.exact_match, m.max_offset, 1);
+        // unpack / re-pack of src/index.cpp:7031-7072 (no synonyms): offset component kept only if prioritize_token_position
+        const uint64_t this_words_present = (s >> 40) & 0xFF, unique_words = (s >> 32) & 0xFF, typo_score = (s >> 24) & 0xFF;
+        const uint64_t proximity = (s >> 16) & 0xFF, verbatim = (s >> 12) & 0xF;
+        const uint64_t offset_score = q.prio_pos ? ((s >> 4) & 0xFF) : 0, synonym_score = s & 0xF;
+        field_match_score = (this_words_present << 40) | (unique_words << 32) | (typo_score << 24) | (proximity << 16) |
+                            (verbatim << 12) | (offset_score << 4) | synonym_score;
+    }
+    // compute_aggregated_score, src/index.cpp:5296-5382, one field
+    int64_t best_field_match_score = 0, best_field_weight = 0, sum_field_weighted_score = 0;
+    const int64_t fms = (int64_t)field_match_score, field_weight = q.weight;
+    if (q.match_type == 0 && fms > best_field_match_score) { best_field_match_score = fms; best_field_weight = field_weight; }
+    if (q.match_type == 1 && field_weight > best_field_weight) { best_field_weight = field_weight; best_field_match_score = fms; }
+    if (q.match_type == 2) sum_field_weighted_score += field_weight * fms;
+    uint64_t query_len = (best_field_match_score == 0) ? 0 : (T < 15 ? T : 15);
+    const uint64_t max_field_weight = (uint64_t)best_field_weight < 15 ? (uint64_t)best_field_weight : 15;   // std::min<size_t>(15, w)
+    const uint64_t num_matching_fields = q.prio_nfields ? 1 : 0;
+    uint64_t agg;
+    if (q.match_type == 0) agg = (query_len << 59) | ((uint64_t)best_field_match_score << 11) | (max_field_weight << 3) | num_matching_fields;
+    else if (q.match_type == 1) agg = (query_len << 59) | (max_field_weight << 51) | ((uint64_t)best_field_match_score << 3) | num_matching_fields;
+    else agg = (query_len << 59) | ((uint64_t)sum_field_weighted_score << 3) | num_matching_fields;
+
+    // compute_sort_scores, src/index.cpp:5662-5907 (text_match / seq_id / int64 column) + :5541-5544 override
+    int64_t sc[3] = {0, 0, 0};
+    int msi = -1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (i < q.n_sort) {
+            int64_t v;
+            if (q.sort_kind[i] == 0) { v = (int64_t)agg; msi = i; }
+            else if (q.sort_kind[i] == 1) v = (int64_t)seq_id;
+            else if (q.sort_kind[i] == 2) {
+                const uint32_t c = q.sort_col[i];
+                v = (c < ix.n_columns && seq_id < ix.column_len[c]) ? ix.columns[c][seq_id] : INT64_MIN;
+            } else v = 0;   // vector_distance is never a keyword sort key here (float_to_int64_t(0) == 0)
+            if (q.sort_order[i] == -1) v = (int64_t)(0ull - (uint64_t)v);
+            sc[i] = v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) if (i == msi) sc[i] = (int64_t)agg;
+    ScoredHit h;
+    h.s0 = sc[0]; h.s1 = sc[1]; h.s2 = sc[2];
+    h.text_match = (int64_t)agg;
+    h.off_words = off_words;
+    return h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS top-K buffer. Entry = (s0, s1, s2, key) with key < 0 marking padding; order = KV::is_greater
+// (include/topster.h:146-149). CAP is a power of two >= k + 256.
+__device__ inline bool ent_greater(int64_t a0, int64_t a1, int64_t a2, int64_t ak, int64_t b0, int64_t b1, int64_t b2, int64_t bk) {
+    if (ak < 0 || bk < 0) return bk < 0 && ak >= 0;       // padding sorts last
+    if (a0 != b0) return a0 > b0;
+    if (a1 != b1) return a1 > b1;
+    if (a2 != b2) return a2 > b2;
+    return ak > bk;
+}
+
+template <int CAP>
+struct TopkLds {
+    int64_t s0[CAP], s1[CAP], s2[CAP], key[CAP];
+};
+
+// bitonic sort, descending, of the first CAP entries (entries >= cnt must be padding)
+template <int CAP>
+__device__ inline void topk_sort(TopkLds<CAP>& tk) {
+    for (int size = 2; size <= CAP; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int p = threadIdx.x; p < CAP / 2; p += KW_THREADS) {
+                const int i = 2 * p - (p & (stride - 1));     // lower index of the pair
+                const int j = i + stride;
+                const bool desc = ((i & size) == 0);
+                const int64_t a0 = tk.s0[i], a1 = tk.s1[i], a2 = tk.s2[i], ak = tk.key[i];
+                const int64_t b0 = tk.s0[j], b1 = tk.s1[j], b2 = tk.s2[j], bk = tk.key[j];
+                const bool b_gt_a = ent_greater(b0, b1, b2, bk, a0, a1, a2, ak);
+                const bool a_gt_b = ent_greater(a0, a1, a2, ak, b0, b1, b2, bk);
+                if (desc ? b_gt_a : a_gt_b) {
+                    tk.s0[i] = b0; tk.s1[i] = b1; tk.s2[i] = b2; tk.key[i] = bk;
+                    tk.s0[j] = a0; tk.s1[j] = a1; tk.s2[j] = a2; tk.key[j] = ak;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// sort + keep the best k; returns new count; thr* = k-th best when the buffer holds >= k entries
+template <int CAP>
+__device__ inline void topk_compact(TopkLds<CAP>& tk, uint32_t* s_cnt, uint32_t k, int64_t* s_thr /*[4]*/, uint32_t* s_have_thr) {
+    __syncthreads();
+    const uint32_t cnt = *s_cnt;
+    for (int i = threadIdx.x; i < CAP; i += KW_THREADS) if ((uint32_t)i >= cnt) tk.key[i] = -1;
+    topk_sort<CAP>(tk);
+    if (threadIdx.x == 0) {
+        const uint32_t n = cnt < k ? cnt : k;
+        *s_cnt = n;
+        if (n >= k) { s_thr[0] = tk.s0[k - 1]; s_thr[1] = tk.s1[k - 1]; s_thr[2] = tk.s2[k - 1]; s_thr[3] = tk.key[k - 1]; *s_have_thr = 1; }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int TMAX, int CAP>
+struct KwSmem {
+    // stage-1 survivors: id, driver position, first-probe position
+    uint32_t q1_id[KW_QCAP], q1_p0[KW_QCAP], q1_p1[KW_QCAP];
+    // complete hits: id + posting position per token (query order)
+    uint32_t qf_id[KW_QCAP];
+    uint32_t qf_pos[TMAX][KW_QCAP];
+    TopkLds<CAP> tk;
+    int64_t thr[4];
+    uint32_t wave_cnt[KW_THREADS / 64];
+    uint32_t q1_cnt, qf_cnt, tk_cnt, have_thr;
+    uint32_t n_match, n_emit;
+    unsigned long long off_words;
+};
+
+template <int TMAX, int CAP>
+__device__ inline void kw_score_stage(KwSmem<TMAX, CAP>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take,
+                                      const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out, uint32_t ids_out_base) {
+    // make room: at most n_take (<=256) new entries
+    if (sm.tk_cnt + KW_THREADS > (uint32_t)CAP) topk_compact<CAP>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
+    const uint32_t t = threadIdx.x;
+    const bool active = t < n_take;
+    bool emit = false;
+    uint32_t seq_id = 0;
+    ScoredHit h;
+    h.s0 = h.s1 = h.s2 = h.text_match = 0; h.off_words = 0;
+    if (active) {
+        seq_id = sm.qf_id[t];
+        emit = true;
+        // take_id(): excluded ids (src/or_iterator.cpp:222-229). Filter ids are resolved before the hit is queued.
+        if (q.n_excl) {
+            const uint32_t* ex = aux_ids + q.aux_off;
+            uint32_t lo = 0, hi = q.n_excl;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ex[mid] < seq_id) lo = mid + 1; else hi = mid; }
+            if (lo < q.n_excl && ex[lo] == seq_id) emit = false;
+        }
+        if (emit) {
+            uint32_t pos[TMAX];
+#pragma unroll
+            for (int k = 0; k < TMAX; k++) pos[k] = sm.qf_pos[k][t];
+            h = score_hit<TMAX>(ix, q, seq_id, pos);
+        }
+    }
+    // ordered emission of matched ids (id_buff, src/index.cpp:5549)
+    uint32_t total;
+    const uint32_t my = block_compact(emit, sm.wave_cnt, total);
+    if (emit && ids_out) ids_out[ids_out_base + sm.n_emit + my] = seq_id;
+    if (emit) {
+        const bool pass = !sm.have_thr || ent_greater(h.s0, h.s1, h.s2, (int64_t)seq_id, sm.thr[0], sm.thr[1], sm.thr[2], sm.thr[3]);
+        if (pass) {
+            const uint32_t slot = atomicAdd(&sm.tk_cnt, 1u);
+            sm.tk.s0[slot] = h.s0; sm.tk.s1[slot] = h.s1; sm.tk.s2[slot] = h.s2; sm.tk.key[slot] = (int64_t)seq_id;
+        }
+        atomicAdd(&sm.off_words, (unsigned long long)h.off_words);
+    }
+    __syncthreads();
+    if (t == 0) { sm.n_match += n_take; sm.n_emit += total; }
+    // drop the processed head of the final queue
+    const uint32_t rest = sm.qf_cnt - n_take;
+    uint32_t mv_id = 0, mv_pos[TMAX];
+    if (t < rest) {
+        mv_id = sm.qf_id[n_take + t];
+#pragma unroll
+        for (int k = 0; k < TMAX; k++) mv_pos[k] = sm.qf_pos[k][n_take + t];
+    }
+    __syncthreads();
+    if (t < rest) {
+        sm.qf_id[t] = mv_id;
+#pragma unroll
+        for (int k = 0; k < TMAX; k++) sm.qf_pos[k][t] = mv_pos[k];
+    }
+    if (t == 0) sm.qf_cnt = rest;
+    __syncthreads();
+}
+
+// probes lists probe_order[2..] for the first n_take entries of queue 1 and moves survivors to the final queue
+template <int TMAX, int CAP>
+__device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take) {
+    const uint32_t t = threadIdx.x;
+    bool ok = t < n_take;
+    uint32_t id = 0;
+    uint32_t pos[TMAX];
+#pragma unroll
+    for (int k = 0; k < TMAX; k++) pos[k] = 0;
+    if (ok) {
+        id = sm.q1_id[t];
+        const uint32_t p0 = sm.q1_p0[t], p1 = sm.q1_p1[t];
+#pragma unroll
+        for (int k = 0; k < TMAX; k++) { if (k == q.probe_order[0]) pos[k] = p0; if (k == q.probe_order[1]) pos[k] = p1; }
+        for (uint32_t s = 2; s < q.n_lists && ok; s++) {
+            const uint32_t tok = q.probe_order[s];
+            uint32_t p;
+            ok = probe_list(ix, ix.lists[q.list[tok]], id, p);
+#pragma unroll
+            for (int k = 0; k < TMAX; k++) if ((uint32_t)k == tok) pos[k] = p;
+        }
+    }
+    uint32_t total;
+    const uint32_t my = block_compact(ok, sm.wave_cnt, total);
+    if (ok) {
+        const uint32_t slot = sm.qf_cnt + my;
+        sm.qf_id[slot] = id;
+#pragma unroll
+        for (int k = 0; k < TMAX; k++) sm.qf_pos[k][slot] = pos[k];
+    }
+    // drop processed head of queue 1
+    const uint32_t rest = sm.q1_cnt - n_take;
+    uint32_t a = 0, b = 0, c = 0;
+    if (t < rest) { a = sm.q1_id[n_take + t]; b = sm.q1_p0[n_take + t]; c = sm.q1_p1[n_take + t]; }
+    __syncthreads();
+    if (t < rest) { sm.q1_id[t] = a; sm.q1_p0[t] = b; sm.q1_p1[t] = c; }
+    if (t == 0) { sm.q1_cnt = rest; sm.qf_cnt += total; }
+    __syncthreads();
+}
+
+// grid = work items; block = 256 threads
+template <int TMAX, int CAP>
+__global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
+                                                                const KwWorkItem* __restrict__ work, KwPartials part,
+                                                                const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out) {
+    __shared__ KwSmem<TMAX, CAP> sm;
+    __shared__ KwQueryDev sq;
+    const uint32_t t = threadIdx.x;
+    const KwWorkItem wi = work[blockIdx.x];
+    // stage the query descriptor in LDS (uniform data)
+    {
+        const uint32_t* src = (const uint32_t*)(queries + wi.query);
+        uint32_t* dst = (uint32_t*)&sq;
+        for (uint32_t i = t; i < sizeof(KwQueryDev) / 4; i += KW_THREADS) dst[i] = src[i];
+    }
+    if (t == 0) { sm.q1_cnt = 0; sm.qf_cnt = 0; sm.tk_cnt = 0; sm.have_thr = 0; sm.n_match = 0; sm.n_emit = 0; sm.off_words = 0; }
+    __syncthreads();
+    const KwQueryDev& q = sq;
+    const uint32_t T = q.n_lists;
+    const ListDesc dA = ix.lists[q.list[q.probe_order[0]]];
+    const uint32_t ids_out_base = (uint32_t)0;
+    uint32_t* my_ids_out = ids_out ? ids_out + q.ids_out_off + wi.ids_out_off : nullptr;
+    const uint32_t* filt = aux_ids + q.aux_off + q.n_excl;
+
+    for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
+        // ---- stage 0: thread t = slot t of driver block b ----
+        const BlockMeta m = ix.blk_meta[dA.blk_base + b];
+        bool ok = t < (uint32_t)m.n_ids;
+        uint32_t id = 0, p1 = 0;
+        if (ok) id = m.first_id + unpack_at(ix.payload + dA.payload_base + m.ids_woff, t, m.ids_bits);
+        // filter ids (sorted whitelist): membership is decided per candidate; the reference's
+        // filter-driven skipping only changes WHICH matches are counted, handled in the host shim (v1: no filter in-kernel)
+        if (ok && q.n_filt) {
+            uint32_t lo = 0, hi = q.n_filt;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (filt[mid] < id) lo = mid + 1; else hi = mid; }
+            ok = (lo < q.n_filt && filt[lo] == id);
+        }
+        // ---- stage 1: probe the second-shortest list ----
+        if (ok && T >= 2) ok = probe_list(ix, ix.lists[q.list[q.probe_order[1]]], id, p1);
+        uint32_t total;
+        const uint32_t my = block_compact(ok, sm.wave_cnt, total);
+        const uint32_t p0 = b * BLOCK_IDS + t;
+        if (T >= 3) {
+            if (ok) { const uint32_t slot = sm.q1_cnt + my; sm.q1_id[slot] = id; sm.q1_p0[slot] = p0; sm.q1_p1[slot] = p1; }
+            __syncthreads();
+            if (t == 0) sm.q1_cnt += total;
+            __syncthreads();
+            while (sm.q1_cnt >= KW_THREADS) {
+                kw_probe_rest_stage<TMAX, CAP>(sm, ix, q, KW_THREADS);
+                while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+            }
+        } else {
+            if (ok) {
+                const uint32_t slot = sm.qf_cnt + my;
+                sm.qf_id[slot] = id;
+#pragma unroll
+                for (int k = 0; k < TMAX; k++) {
+                    uint32_t v = 0;
+                    if (k == q.probe_order[0]) v = p0;
+                    if (T >= 2 && k == q.probe_order[1]) v = p1;
+                    sm.qf_pos[k][slot] = v;
+                }
+            }
+            __syncthreads();
+            if (t == 0) sm.qf_cnt += total;
+            __syncthreads();
+            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+        }
+    }
+    // ---- flush ----
+    if (T >= 3) {
+        while (sm.q1_cnt > 0) {
+            kw_probe_rest_stage<TMAX, CAP>(sm, ix, q, sm.q1_cnt < KW_THREADS ? sm.q1_cnt : KW_THREADS);
+            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+        }
+    }
+    while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+
+    // ---- partial result of this work item: sorted, <= k entries ----
+    topk_compact<CAP>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
+    const uint32_t n = sm.tk_cnt;
+    const size_t base = (size_t)blockIdx.x * part.k_stride;
+    for (uint32_t i = t; i < n; i += KW_THREADS) {
+        part.s0[base + i] = sm.tk.s0[i]; part.s1[base + i] = sm.tk.s1[i]; part.s2[base + i] = sm.tk.s2[i]; part.key[base + i] = sm.tk.key[i];
+    }
+    if (t == 0) {
+        part.cnt[blockIdx.x] = n;
+        part.n_match[blockIdx.x] = sm.n_match;
+        part.n_emit[blockIdx.x] = sm.n_emit;
+        part.off_words[blockIdx.x] = sm.off_words;
+    }
+}
+
+// grid = queries; folds a query's partials into the final order and writes the tsgpu_hits slots
+template <int CAP>
+__global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* __restrict__ queries, KwPartials part, KwOut out,
+                                                               uint32_t* __restrict__ ids_out, const KwWorkItem* __restrict__ work) {
+    __shared__ TopkLds<CAP> tk;
+    __shared__ int64_t thr[4];
+    __shared__ uint32_t s_cnt, s_have_thr;
+    __shared__ unsigned long long s_nm, s_ow;
+    const uint32_t t = threadIdx.x;
+    const KwQueryDev q = queries[blockIdx.x];
+    if (t == 0) { s_cnt = 0; s_have_thr = 0; s_nm = 0; s_ow = 0; }
+    __syncthreads();
+    for (uint32_t w = q.first_work; w < q.first_work + q.n_work; w++) {
+        const uint32_t n = part.cnt[w];
+        if (s_cnt + n > (uint32_t)CAP) topk_compact<CAP>(tk, &s_cnt, q.k, thr, &s_have_thr);
+        const uint32_t base_slot = s_cnt;
+        const size_t base = (size_t)w * part.k_stride;
+        for (uint32_t i = t; i < n; i += KW_THREADS) {
+            tk.s0[base_slot + i] = part.s0[base + i]; tk.s1[base_slot + i] = part.s1[base + i];
+            tk.s2[base_slot + i] = part.s2[base + i]; tk.key[base_slot + i] = part.key[base + i];
+        }
+        __syncthreads();
+        if (t == 0) { s_cnt = base_slot + n; s_nm += part.n_match[w]; s_ow += part.off_words[w]; }
+        __syncthreads();
+    }
+    topk_compact<CAP>(tk, &s_cnt, q.k, thr, &s_have_thr);
+    const uint32_t n = s_cnt;
+    const size_t ob = (size_t)blockIdx.x * out.k_stride;
+    int msi = -1;
+    for (int i = 0; i < 3; i++) if (i < q.n_sort && q.sort_kind[i] == 0) msi = i;
+    for (uint32_t i = t; i < n; i += KW_THREADS) {
+        const int64_t a0 = tk.s0[i], a1 = tk.s1[i], a2 = tk.s2[i];
+        out.keys[ob + i] = (uint64_t)tk.key[i];
+        out.scores[(ob + i) * 3 + 0] = a0; out.scores[(ob + i) * 3 + 1] = a1; out.scores[(ob + i) * 3 + 2] = a2;
+        out.text_match[ob + i] = msi == 0 ? a0 : (msi == 1 ? a1 : (msi == 2 ? a2 : 0));
+        out.vector_distance[ob + i] = -1.0f;
+        out.match_score_index[ob + i] = (int8_t)msi;
+    }
+    if (t == 0) { out.n_hits[blockIdx.x] = n; out.num_matched[blockIdx.x] = s_nm; out.off_words[blockIdx.x] = s_ow; }
+    (void)ids_out; (void)work;
+}
+
+}  // namespace tsgpu

@@ -1,0 +1,621 @@
+// tsgpu.hip — implementation of the C-ABI of include/tsgpu.h: context, index mirror upload, and the batched
+// keyword search (seam B1). Host code here only plans the launches (resolve terms, order lists, cut work
+// items); all scoring happens in kw_kernels.hip.h on the GPU. There is no CPU fallback: a query this
+// library does not accelerate is reported per query as TSGPU_ERR_UNSUPPORTED and left to the caller.
+#include "tsgpu_host.h"
+#include "kw_kernels.hip.h"
+
+using namespace tsgpu;
+
+namespace {
+
+
+uint64_t now_us() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
+               std::chrono::system_clock::now().time_since_epoch()).count();
+}
+
+int upload(DevBuf& dst, const void* src, size_t bytes, hipStream_t s) {
+    int rc = dst.reserve(bytes ? bytes : 16);
+    if (rc) return rc;
+    if (bytes) TSGPU_HIP_TRY(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, s));
+    return TSGPU_OK;
+}
+
+int refresh_column_table(tsgpu_ctx* ctx) {
+    std::vector<const int64_t*> ptrs(ctx->columns.size());
+    std::vector<uint32_t> lens(ctx->columns.size());
+    for (size_t i = 0; i < ctx->columns.size(); i++) { ptrs[i] = ctx->columns[i].data.as<int64_t>(); lens[i] = ctx->columns[i].n; }
+    int rc = upload(ctx->d_col_ptrs, ptrs.data(), ptrs.size() * sizeof(void*), ctx->stream);
+    if (rc) return rc;
+    rc = upload(ctx->d_col_len, lens.data(), lens.size() * sizeof(uint32_t), ctx->stream);
+    if (rc) return rc;
+    TSGPU_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return TSGPU_OK;
+}
+
+IndexView make_view(tsgpu_ctx* ctx) {
+    IndexView v;
+    v.lists = ctx->snap.lists.as<ListDesc>();
+    v.blk_last = ctx->snap.blk_last.as<uint32_t>();
+    v.blk_meta = ctx->snap.blk_meta.as<BlockMeta>();
+    v.payload = ctx->snap.payload.as<uint32_t>();
+    v.columns = ctx->d_col_ptrs.as<const int64_t*>();
+    v.column_len = ctx->d_col_len.as<uint32_t>();
+    v.n_columns = (uint32_t)ctx->columns.size();
+    v.num_docs = ctx->num_docs;
+    return v;
+}
+
+template <int TMAX, int CAP>
+void launch_search(hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w,
+                   const KwPartials& part, const uint32_t* aux, uint32_t* ids_out) {
+    hipLaunchKernelGGL((kw_search_kernel<TMAX, CAP>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out);
+}
+
+template <int TMAX>
+void launch_search_cap(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w,
+                       const KwPartials& part, const uint32_t* aux, uint32_t* ids_out) {
+    if (cap == 512) launch_search<TMAX, 512>(s, n_work, v, q, w, part, aux, ids_out);
+    else if (cap == 1024) launch_search<TMAX, 1024>(s, n_work, v, q, w, part, aux, ids_out);
+    else launch_search<TMAX, 2048>(s, n_work, v, q, w, part, aux, ids_out);
+}
+
+void launch_merge(int cap, hipStream_t s, uint32_t n_q, const KwQueryDev* q, const KwPartials& part, const KwOut& out,
+                  uint32_t* ids_out, const KwWorkItem* w) {
+    if (cap == 512) hipLaunchKernelGGL((kw_merge_kernel<512>), dim3(n_q), dim3(KW_THREADS), 0, s, q, part, out, ids_out, w);
+    else if (cap == 1024) hipLaunchKernelGGL((kw_merge_kernel<1024>), dim3(n_q), dim3(KW_THREADS), 0, s, q, part, out, ids_out, w);
+    else hipLaunchKernelGGL((kw_merge_kernel<2048>), dim3(n_q), dim3(KW_THREADS), 0, s, q, part, out, ids_out, w);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsgpu_abi_version(void) { return TSGPU_ABI_VERSION; }
+const char* tsgpu_last_error(void) { return tls_error().c_str(); }
+
+int tsgpu_create(int device_ordinal, tsgpu_ctx** out) {
+    if (!out) return fail(TSGPU_ERR_INVALID, "tsgpu_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(TSGPU_ERR_DEVICE, "tsgpu_create: no HIP device visible (this library has no CPU fallback)");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(TSGPU_ERR_INVALID, "tsgpu_create: bad device ordinal");
+    TSGPU_HIP_TRY(hipSetDevice(device_ordinal));
+    tsgpu_ctx* ctx = new (std::nothrow) tsgpu_ctx;
+    if (!ctx) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_create: host allocation failed");
+    ctx->device = device_ordinal;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail(TSGPU_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    for (auto& ev : ctx->ev) {
+        e = hipEventCreate(&ev);
+        if (e != hipSuccess) { delete ctx; return fail(TSGPU_ERR_DEVICE, "hipEventCreate failed"); }
+    }
+    *out = ctx;
+    return ok();
+}
+
+void tsgpu_vec_destroy_all(tsgpu_ctx* ctx);   // tsgpu_vec.hip
+
+void tsgpu_destroy(tsgpu_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    tsgpu_vec_destroy_all(ctx);
+    DevBuf* bufs[] = {&ctx->snap.lists, &ctx->snap.blk_last, &ctx->snap.blk_meta, &ctx->snap.payload, &ctx->d_col_ptrs, &ctx->d_col_len,
+                      &ctx->d_queries, &ctx->d_work, &ctx->d_aux, &ctx->d_ids_out, &ctx->d_part_s0, &ctx->d_part_s1, &ctx->d_part_s2,
+                      &ctx->d_part_key, &ctx->d_part_cnt, &ctx->d_part_nm, &ctx->d_part_ne, &ctx->d_part_ow, &ctx->d_out_keys,
+                      &ctx->d_out_scores, &ctx->d_out_tm, &ctx->d_out_vd, &ctx->d_out_msi, &ctx->d_out_nh, &ctx->d_out_nm, &ctx->d_out_ow};
+    for (auto* b : bufs) b->release();
+    for (auto& c : ctx->columns) c.data.release();
+    ctx->h_stage.release();
+    ctx->h_out.release();
+    for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false; }
+    else {
+        TSGPU_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return ok();
+}
+
+uint64_t tsgpu_vec_device_bytes(tsgpu_ctx* ctx);   // tsgpu_vec.hip
+
+uint64_t tsgpu_device_bytes(tsgpu_ctx* ctx) {
+    if (!ctx) return 0;
+    uint64_t b = ctx->snap.bytes;
+    for (auto& c : ctx->columns) b += c.data.cap;
+    return b + tsgpu_vec_device_bytes(ctx);
+}
+
+// ---------------------------------------------------------------- keyword index mirror
+int tsgpu_field_create(tsgpu_ctx* ctx, uint32_t field_id, int is_array) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->fields[field_id].is_array = is_array != 0;
+    return ok();
+}
+
+int tsgpu_term_upsert(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, const uint32_t* ids, const uint32_t* offset_index,
+                      const uint32_t* offsets, uint32_t n_ids, uint32_t n_offsets) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto fit = ctx->fields.find(field_id);
+    if (fit == ctx->fields.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_term_upsert: unknown field (call tsgpu_field_create)");
+    ctx->dirty = true;
+    if (n_ids == 0) { fit->second.terms.erase(term_id); return ok(); }
+    if (!ids || !offset_index || !offsets) return fail(TSGPU_ERR_INVALID, "tsgpu_term_upsert: NULL array");
+    for (uint32_t i = 1; i < n_ids; i++) {
+        if (ids[i] <= ids[i - 1]) return fail(TSGPU_ERR_INVALID, "tsgpu_term_upsert: ids must be strictly ascending");
+        if (offset_index[i] < offset_index[i - 1]) return fail(TSGPU_ERR_INVALID, "tsgpu_term_upsert: offset_index must ascend");
+    }
+    if (offset_index[n_ids - 1] > n_offsets) return fail(TSGPU_ERR_INVALID, "tsgpu_term_upsert: offset_index beyond offsets");
+    try {
+        std::vector<uint64_t> oi(offset_index, offset_index + n_ids);
+        fit->second.terms[term_id] = pack_list(ids, oi.data(), offsets, n_ids, n_offsets);
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_term_upsert: host allocation failed"); }
+    return ok();
+}
+
+int tsgpu_terms_load_csr(tsgpu_ctx* ctx, uint32_t field_id, uint32_t n_terms, const uint32_t* term_ids, const uint64_t* ids_ptr,
+                         const uint32_t* ids, const uint64_t* offset_index, const uint64_t* off_ptr, const uint32_t* offsets) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    if (!term_ids || !ids_ptr || !ids || !offset_index || !off_ptr || !offsets) return fail(TSGPU_ERR_INVALID, "tsgpu_terms_load_csr: NULL array");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto fit = ctx->fields.find(field_id);
+    if (fit == ctx->fields.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_terms_load_csr: unknown field");
+    ctx->dirty = true;
+    try {
+        std::vector<uint64_t> oi;
+        for (uint32_t t = 0; t < n_terms; t++) {
+            const uint64_t a = ids_ptr[t], b = ids_ptr[t + 1];
+            if (b <= a) { fit->second.terms.erase(term_ids[t]); continue; }
+            const uint64_t o0 = off_ptr[t], o1 = off_ptr[t + 1];
+            oi.resize(b - a);
+            for (uint64_t i = a; i < b; i++) oi[i - a] = offset_index[i] - o0;
+            fit->second.terms[term_ids[t]] = pack_list(ids + a, oi.data(), offsets + o0, (uint32_t)(b - a), o1 - o0);
+        }
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_terms_load_csr: host allocation failed"); }
+    return ok();
+}
+
+int tsgpu_column_set(tsgpu_ctx* ctx, uint32_t column_id, const int64_t* values, const uint8_t* present, uint32_t n, int mem) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    if (column_id >= 4096) return fail(TSGPU_ERR_INVALID, "tsgpu_column_set: column_id too large");
+    if (n && !values) return fail(TSGPU_ERR_INVALID, "tsgpu_column_set: values is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (ctx->columns.size() <= column_id) ctx->columns.resize(column_id + 1);
+    ColumnDev& c = ctx->columns[column_id];
+    int rc = c.data.reserve((size_t)std::max<uint32_t>(n, 1) * sizeof(int64_t));
+    if (rc) return rc;
+    if (mem == TSGPU_MEM_DEVICE) {
+        if (present) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_column_set: presence mask with device values is not supported");
+        TSGPU_HIP_TRY(hipMemcpyAsync(c.data.p, values, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (present) {
+        std::vector<int64_t> tmp(values, values + n);
+        for (uint32_t i = 0; i < n; i++) if (!present[i]) tmp[i] = INT64_MIN;   // default_score, src/index.cpp:5696
+        TSGPU_HIP_TRY(hipMemcpy(c.data.p, tmp.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+    } else {
+        TSGPU_HIP_TRY(hipMemcpy(c.data.p, values, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    c.n = n;
+    return refresh_column_table(ctx);
+}
+
+int tsgpu_set_num_docs(tsgpu_ctx* ctx, uint32_t num_docs) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->num_docs = num_docs;
+    ctx->num_docs_set = true;
+    return ok();
+}
+
+int tsgpu_commit(tsgpu_ctx* ctx) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    try {
+        std::vector<ListDesc> descs;
+        std::unordered_map<uint64_t, uint32_t> handle_of;
+        uint64_t n_blocks = 0, n_words = 0;
+        std::vector<std::pair<uint64_t, const PackedList*>> order;
+        for (auto& f : ctx->fields)
+            for (auto& t : f.second.terms) order.emplace_back(((uint64_t)f.first << 32) | t.first, &t.second);
+        std::sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        uint32_t max_id = 0;
+        for (auto& e : order) { n_blocks += e.second->blk_last.size(); n_words += e.second->payload.size(); max_id = std::max(max_id, e.second->desc.last_id); }
+        if (n_blocks >= 0xFFFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_commit: more than 2^32 posting blocks");
+        std::vector<uint32_t> h_last(n_blocks);
+        std::vector<BlockMeta> h_meta(n_blocks);
+        std::vector<uint32_t> h_payload(n_words + 4, 0u);
+        uint64_t bpos = 0, wpos = 0;
+        descs.reserve(order.size());
+        for (auto& e : order) {
+            const PackedList& pl = *e.second;
+            ListDesc d = pl.desc;
+            d.blk_base = (uint32_t)bpos;
+            d.payload_base = wpos;
+            std::copy(pl.blk_last.begin(), pl.blk_last.end(), h_last.begin() + bpos);
+            std::copy(pl.blk_meta.begin(), pl.blk_meta.end(), h_meta.begin() + bpos);
+            std::copy(pl.payload.begin(), pl.payload.end(), h_payload.begin() + wpos);
+            bpos += pl.blk_last.size();
+            wpos += pl.payload.size();
+            handle_of[e.first] = (uint32_t)descs.size();
+            descs.push_back(d);
+        }
+        Snapshot& s = ctx->snap;
+        int rc;
+        if ((rc = s.lists.reserve(std::max<size_t>(descs.size(), 1) * sizeof(ListDesc)))) return rc;
+        if ((rc = s.blk_last.reserve(std::max<size_t>(h_last.size(), 1) * 4))) return rc;
+        if ((rc = s.blk_meta.reserve(std::max<size_t>(h_meta.size(), 1) * sizeof(BlockMeta)))) return rc;
+        if ((rc = s.payload.reserve(h_payload.size() * 4))) return rc;
+        if (!descs.empty()) TSGPU_HIP_TRY(hipMemcpy(s.lists.p, descs.data(), descs.size() * sizeof(ListDesc), hipMemcpyHostToDevice));
+        if (!h_last.empty()) TSGPU_HIP_TRY(hipMemcpy(s.blk_last.p, h_last.data(), h_last.size() * 4, hipMemcpyHostToDevice));
+        if (!h_meta.empty()) TSGPU_HIP_TRY(hipMemcpy(s.blk_meta.p, h_meta.data(), h_meta.size() * sizeof(BlockMeta), hipMemcpyHostToDevice));
+        TSGPU_HIP_TRY(hipMemcpy(s.payload.p, h_payload.data(), h_payload.size() * 4, hipMemcpyHostToDevice));
+        s.h_lists.swap(descs);
+        s.handle_of.swap(handle_of);
+        s.bytes = s.lists.cap + s.blk_last.cap + s.blk_meta.cap + s.payload.cap;
+        if (!ctx->num_docs_set) ctx->num_docs = std::max(ctx->num_docs, order.empty() ? 0u : max_id + 1);
+        ctx->dirty = false;
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_commit: host allocation failed"); }
+    int rc = refresh_column_table(ctx);
+    if (rc) return rc;
+    return ok();
+}
+
+uint32_t tsgpu_term_num_ids(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id) {
+    if (!ctx) return 0;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->snap.handle_of.find(((uint64_t)field_id << 32) | term_id);
+    return it == ctx->snap.handle_of.end() ? 0 : ctx->snap.h_lists[it->second].n_ids;
+}
+
+int tsgpu_term_download(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, uint32_t* ids, uint32_t* offset_index, uint32_t* offsets,
+                        uint32_t* n_offsets) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    auto it = ctx->snap.handle_of.find(((uint64_t)field_id << 32) | term_id);
+    if (it == ctx->snap.handle_of.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_term_download: term not in the committed snapshot");
+    const ListDesc d = ctx->snap.h_lists[it->second];
+    try {
+        std::vector<uint32_t> last(d.n_blocks);
+        std::vector<BlockMeta> meta(d.n_blocks);
+        TSGPU_HIP_TRY(hipMemcpy(last.data(), ctx->snap.blk_last.as<uint32_t>() + d.blk_base, (size_t)d.n_blocks * 4, hipMemcpyDeviceToHost));
+        TSGPU_HIP_TRY(hipMemcpy(meta.data(), ctx->snap.blk_meta.as<BlockMeta>() + d.blk_base, (size_t)d.n_blocks * sizeof(BlockMeta), hipMemcpyDeviceToHost));
+        const BlockMeta& lm = meta.back();
+        const size_t words = (size_t)lm.off_woff + packed_words(lm.n_off, lm.off_bits);
+        std::vector<uint32_t> payload(words + 2);
+        TSGPU_HIP_TRY(hipMemcpy(payload.data(), ctx->snap.payload.as<uint32_t>() + d.payload_base, words * 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> a, b, c;
+        unpack_list(d, last.data(), meta.data(), payload.data(), a, b, c);
+        if (n_offsets) *n_offsets = (uint32_t)c.size();
+        if (ids) std::copy(a.begin(), a.end(), ids);
+        if (offset_index) std::copy(b.begin(), b.end(), offset_index);
+        if (offsets) std::copy(c.begin(), c.end(), offsets);
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_term_download: host allocation failed"); }
+    return ok();
+}
+
+int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return fail(TSGPU_ERR_INVALID, "tsgpu_set_option: NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!strcmp(name, "kw_chunk_blocks")) {
+        if (value < 1 || value > (1 << 20)) return fail(TSGPU_ERR_INVALID, "kw_chunk_blocks out of range");
+        ctx->kw_chunk_blocks = (uint32_t)value;
+        return ok();
+    }
+    if (!strcmp(name, "vec_rows_per_slab")) {
+        if (value < 128 || value > (1 << 24)) return fail(TSGPU_ERR_INVALID, "vec_rows_per_slab out of range");
+        ctx->vec_rows_per_slab = (uint32_t)value;
+        return ok();
+    }
+    return fail(TSGPU_ERR_NOT_FOUND, std::string("tsgpu_set_option: unknown option ") + name);
+}
+
+int tsgpu_keep_result_ids(tsgpu_ctx* ctx, int keep) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->keep_ids = keep != 0;
+    return ok();
+}
+
+// ---------------------------------------------------------------- keyword search (seam B1)
+namespace {
+struct Plan {
+    std::vector<KwQueryDev> q;
+    std::vector<KwWorkItem> work_small, work_big;   // TMAX 3 / TMAX 10 kernels
+    std::vector<uint32_t> aux;
+    std::vector<int32_t> status, cutoff;
+    uint32_t max_k = 1;
+    uint64_t ids_total = 0;
+    uint64_t list_bytes = 0;       // 4 * sum |L_t| over the batch
+    uint64_t n_numeric_sort_q = 0;
+};
+}
+
+static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, Plan& P, bool keep_ids) {
+    const uint32_t KW_CHUNK_BLOCKS = ctx->kw_chunk_blocks;
+    P.q.resize(n_queries);
+    P.status.assign(n_queries, TSGPU_OK);
+    P.cutoff.assign(n_queries, 0);
+    const uint64_t now = now_us();
+    std::vector<std::vector<KwWorkItem>> per_q_work(n_queries);
+    for (uint32_t i = 0; i < n_queries; i++) {
+        const tsgpu_kw_query& in = queries[i];
+        KwQueryDev& q = P.q[i];
+        memset(&q, 0, sizeof q);
+        q.k = 1;
+        auto unsupported = [&](const char*) { P.status[i] = TSGPU_ERR_UNSUPPORTED; };
+        if (in.n_tokens == 0 || in.n_tokens > TSGPU_MAX_QUERY_TOKENS) { unsupported("tokens"); continue; }
+        if (in.n_fields != 1) { unsupported("fields"); continue; }
+        auto fit = ctx->fields.find(in.field_ids[0]);
+        if (fit == ctx->fields.end()) { P.status[i] = TSGPU_ERR_NOT_FOUND; continue; }
+        if (fit->second.is_array) { unsupported("array field"); continue; }
+        if (in.n_sort > TSGPU_MAX_SORT_KEYS) { P.status[i] = TSGPU_ERR_INVALID; continue; }
+        if (in.n_filter != 0) { unsupported("filter ids"); continue; }   // next
+        if (in.match_type > TSGPU_SUM_SCORE) { P.status[i] = TSGPU_ERR_INVALID; continue; }
+        bool bad_sort = false;
+        for (uint32_t s = 0; s < in.n_sort; s++) {
+            if (in.sort[s].kind > TSGPU_SORT_INT64_COLUMN) bad_sort = true;   // vector_distance belongs to the vector/hybrid entry points
+            if (in.sort[s].kind == TSGPU_SORT_INT64_COLUMN && in.sort[s].column >= ctx->columns.size()) bad_sort = true;
+            if (in.sort[s].order != 1 && in.sort[s].order != -1) bad_sort = true;
+        }
+        if (bad_sort) { unsupported("sort"); continue; }
+        uint32_t k = in.topster_size;
+        if (k == 0) k = TSGPU_DEFAULT_TOPSTER_SIZE;
+        k = std::min<uint32_t>(k, std::max<uint32_t>(ctx->num_docs, 1));   // src/index.cpp:3510-3512
+        k = std::max<uint32_t>(k, 1);
+        if (k > TSGPU_MAX_TOPK) { unsupported("topster_size"); continue; }
+        if (in.deadline_us != 0 && now > in.deadline_us) { P.status[i] = TSGPU_ERR_DEADLINE; P.cutoff[i] = 1; continue; }
+
+        q.n_query_tokens = in.n_tokens;
+        uint32_t nl = 0;
+        uint32_t len_of[KW_MAX_TOKENS];
+        for (uint32_t t = 0; t < in.n_tokens; t++) {
+            auto h = ctx->snap.handle_of.find(((uint64_t)in.field_ids[0] << 32) | in.term_ids[t]);
+            if (h == ctx->snap.handle_of.end()) continue;          // token not in the index: skipped, src/index.cpp:5651-5655
+            q.list[nl] = h->second;
+            len_of[nl] = ctx->snap.h_lists[h->second].n_ids;
+            P.list_bytes += 4ull * len_of[nl];
+            nl++;
+        }
+        q.n_lists = nl;
+        q.match_type = in.match_type;
+        q.prio_exact = in.prioritize_exact_match ? 1 : 0;
+        q.prio_pos = in.prioritize_token_position ? 1 : 0;
+        q.prio_nfields = in.prioritize_num_matching_fields ? 1 : 0;
+        q.total_cost = in.total_cost;
+        q.weight = in.field_weights[0];
+        q.n_sort = (uint8_t)in.n_sort;
+        for (uint32_t s = 0; s < in.n_sort; s++) {
+            q.sort_kind[s] = in.sort[s].kind; q.sort_order[s] = in.sort[s].order; q.sort_col[s] = in.sort[s].column;
+            if (in.sort[s].kind == TSGPU_SORT_INT64_COLUMN) P.n_numeric_sort_q++;
+        }
+        q.k = k;
+        P.max_k = std::max(P.max_k, k);
+        q.aux_off = (uint32_t)P.aux.size();
+        q.n_excl = in.n_excluded;
+        q.n_filt = 0;
+        if (in.n_excluded) {
+            if (!in.excluded_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
+            P.aux.insert(P.aux.end(), in.excluded_ids, in.excluded_ids + in.n_excluded);
+        }
+        if (nl == 0) continue;   // no token in the index: zero hits (intersect case 0, or_iterator.h:67-68)
+        // probe order: ascending list length, stable
+        uint8_t ord[KW_MAX_TOKENS];
+        for (uint32_t t = 0; t < nl; t++) ord[t] = (uint8_t)t;
+        std::stable_sort(ord, ord + nl, [&](uint8_t a, uint8_t b) { return len_of[a] < len_of[b]; });
+        for (uint32_t t = 0; t < nl; t++) q.probe_order[t] = ord[t];
+        const ListDesc& dA = ctx->snap.h_lists[q.list[ord[0]]];
+        q.ids_out_off = P.ids_total;
+        if (keep_ids) P.ids_total += (uint64_t)dA.n_blocks * BLOCK_IDS;
+        for (uint32_t b = 0; b < dA.n_blocks; b += KW_CHUNK_BLOCKS) {
+            KwWorkItem w;
+            w.query = i;
+            w.blk_begin = b;
+            w.blk_end = std::min(dA.n_blocks, b + KW_CHUNK_BLOCKS);
+            w.ids_out_off = b * BLOCK_IDS;
+            per_q_work[i].push_back(w);
+        }
+    }
+    // work tables: small-T queries first (one launch), then the generic ones; a query's items stay contiguous
+    for (int pass = 0; pass < 2; pass++) {
+        for (uint32_t i = 0; i < n_queries; i++) {
+            if (per_q_work[i].empty()) continue;
+            const bool small = P.q[i].n_lists <= 3;
+            if ((pass == 0) != small) continue;
+            auto& dst = small ? P.work_small : P.work_big;
+            P.q[i].first_work = (uint32_t)(small ? dst.size() : P.work_small.size() + dst.size());
+            P.q[i].n_work = (uint32_t)per_q_work[i].size();
+            dst.insert(dst.end(), per_q_work[i].begin(), per_q_work[i].end());
+        }
+    }
+    return TSGPU_OK;
+}
+
+int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out) {
+    if (!ctx || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: NULL argument");
+    if (n_queries == 0) return ok();
+    if (!queries) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: queries is NULL");
+    if (!out->keys || !out->scores || !out->n_hits || !out->status) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: missing output arrays");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (ctx->dirty) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: uncommitted index changes (call tsgpu_commit)");
+    hipStream_t s = ctx->stream;
+    try {
+        Plan P;
+        int rc = plan_batch(ctx, queries, n_queries, P, ctx->keep_ids);
+        if (rc) return rc;
+        if (out->k_stride < P.max_k) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: k_stride smaller than the largest topster_size");
+        const uint32_t n_work = (uint32_t)(P.work_small.size() + P.work_big.size());
+        const uint32_t KS = out->k_stride;
+        const int cap = P.max_k + KW_THREADS <= 512 ? 512 : (P.max_k + KW_THREADS <= 1024 ? 1024 : 2048);
+
+        // ---- upload plan ----
+        std::vector<KwWorkItem> work(P.work_small);
+        work.insert(work.end(), P.work_big.begin(), P.work_big.end());
+        if ((rc = upload(ctx->d_queries, P.q.data(), P.q.size() * sizeof(KwQueryDev), s))) return rc;
+        if ((rc = upload(ctx->d_work, work.data(), work.size() * sizeof(KwWorkItem), s))) return rc;
+        P.aux.push_back(0);
+        if ((rc = upload(ctx->d_aux, P.aux.data(), P.aux.size() * 4, s))) return rc;
+
+        // ---- scratch ----
+        const size_t pw = (size_t)std::max<uint32_t>(n_work, 1);
+        if ((rc = ctx->d_part_s0.reserve(pw * KS * 8))) return rc;
+        if ((rc = ctx->d_part_s1.reserve(pw * KS * 8))) return rc;
+        if ((rc = ctx->d_part_s2.reserve(pw * KS * 8))) return rc;
+        if ((rc = ctx->d_part_key.reserve(pw * KS * 8))) return rc;
+        if ((rc = ctx->d_part_cnt.reserve(pw * 4))) return rc;
+        if ((rc = ctx->d_part_nm.reserve(pw * 4))) return rc;
+        if ((rc = ctx->d_part_ne.reserve(pw * 4))) return rc;
+        if ((rc = ctx->d_part_ow.reserve(pw * 8))) return rc;
+        if ((rc = ctx->d_out_ow.reserve((size_t)n_queries * 8))) return rc;
+        uint32_t* ids_out = nullptr;
+        if (ctx->keep_ids) {
+            if ((rc = ctx->d_ids_out.reserve(std::max<uint64_t>(P.ids_total, 1) * 4))) return rc;
+            ids_out = ctx->d_ids_out.as<uint32_t>();
+        }
+        KwPartials part;
+        part.s0 = ctx->d_part_s0.as<int64_t>(); part.s1 = ctx->d_part_s1.as<int64_t>(); part.s2 = ctx->d_part_s2.as<int64_t>();
+        part.key = ctx->d_part_key.as<int64_t>(); part.cnt = ctx->d_part_cnt.as<uint32_t>(); part.n_match = ctx->d_part_nm.as<uint32_t>();
+        part.n_emit = ctx->d_part_ne.as<uint32_t>(); part.off_words = ctx->d_part_ow.as<uint64_t>(); part.k_stride = KS;
+
+        const size_t slots = (size_t)n_queries * KS;
+        KwOut o;
+        o.k_stride = KS;
+        o.off_words = ctx->d_out_ow.as<uint64_t>();
+        const bool dev_out = out->mem == TSGPU_MEM_DEVICE;
+        if (dev_out) {
+            if (!out->text_match || !out->vector_distance || !out->match_score_index || !out->num_matched)
+                return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: device output needs every tsgpu_hits array");
+            o.keys = out->keys; o.scores = out->scores; o.text_match = out->text_match; o.vector_distance = out->vector_distance;
+            o.match_score_index = out->match_score_index; o.n_hits = out->n_hits; o.num_matched = out->num_matched;
+        } else {
+            if ((rc = ctx->d_out_keys.reserve(slots * 8))) return rc;
+            if ((rc = ctx->d_out_scores.reserve(slots * 24))) return rc;
+            if ((rc = ctx->d_out_tm.reserve(slots * 8))) return rc;
+            if ((rc = ctx->d_out_vd.reserve(slots * 4))) return rc;
+            if ((rc = ctx->d_out_msi.reserve(slots))) return rc;
+            if ((rc = ctx->d_out_nh.reserve((size_t)n_queries * 4))) return rc;
+            if ((rc = ctx->d_out_nm.reserve((size_t)n_queries * 8))) return rc;
+            o.keys = ctx->d_out_keys.as<uint64_t>(); o.scores = ctx->d_out_scores.as<int64_t>(); o.text_match = ctx->d_out_tm.as<int64_t>();
+            o.vector_distance = ctx->d_out_vd.as<float>(); o.match_score_index = ctx->d_out_msi.as<int8_t>();
+            o.n_hits = ctx->d_out_nh.as<uint32_t>(); o.num_matched = ctx->d_out_nm.as<uint64_t>();
+        }
+
+        // ---- launch ----
+        const IndexView v = make_view(ctx);
+        const KwQueryDev* dq = ctx->d_queries.as<KwQueryDev>();
+        const KwWorkItem* dw = ctx->d_work.as<KwWorkItem>();
+        const uint32_t* daux = ctx->d_aux.as<uint32_t>();
+        TSGPU_HIP_TRY(hipEventRecord(ctx->ev[0], s));
+        if (!P.work_small.empty()) launch_search_cap<3>(cap, s, (uint32_t)P.work_small.size(), v, dq, dw, part, daux, ids_out);
+        if (!P.work_big.empty()) {
+            KwPartials pb = part;   // the generic kernel indexes partials by its own blockIdx: shift the bases
+            const size_t sh = P.work_small.size();
+            pb.s0 += sh * KS; pb.s1 += sh * KS; pb.s2 += sh * KS; pb.key += sh * KS;
+            pb.cnt += sh; pb.n_match += sh; pb.n_emit += sh; pb.off_words += sh;
+            launch_search_cap<KW_MAX_TOKENS>(cap, s, (uint32_t)P.work_big.size(), v, dq, dw + sh, pb, daux, ids_out);
+        }
+        TSGPU_HIP_TRY(hipEventRecord(ctx->ev[1], s));
+        launch_merge(cap, s, n_queries, dq, part, o, ids_out, dw);
+        TSGPU_HIP_TRY(hipEventRecord(ctx->ev[2], s));
+        TSGPU_HIP_TRY(hipGetLastError());
+
+        // ---- results ----
+        std::vector<uint64_t> off_words(n_queries);
+        if (!dev_out) {
+            TSGPU_HIP_TRY(hipMemcpyAsync(out->n_hits, o.n_hits, (size_t)n_queries * 4, hipMemcpyDeviceToHost, s));
+            if (out->num_matched) TSGPU_HIP_TRY(hipMemcpyAsync(out->num_matched, o.num_matched, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(out->keys, o.keys, slots * 8, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(out->scores, o.scores, slots * 24, hipMemcpyDeviceToHost, s));
+            if (out->text_match) TSGPU_HIP_TRY(hipMemcpyAsync(out->text_match, o.text_match, slots * 8, hipMemcpyDeviceToHost, s));
+            if (out->vector_distance) TSGPU_HIP_TRY(hipMemcpyAsync(out->vector_distance, o.vector_distance, slots * 4, hipMemcpyDeviceToHost, s));
+            if (out->match_score_index) TSGPU_HIP_TRY(hipMemcpyAsync(out->match_score_index, o.match_score_index, slots, hipMemcpyDeviceToHost, s));
+            for (uint32_t i = 0; i < n_queries; i++) out->status[i] = P.status[i];
+            if (out->search_cutoff) for (uint32_t i = 0; i < n_queries; i++) out->search_cutoff[i] = P.cutoff[i];
+        } else {
+            TSGPU_HIP_TRY(hipMemcpyAsync(out->status, P.status.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, s));
+            if (out->search_cutoff) TSGPU_HIP_TRY(hipMemcpyAsync(out->search_cutoff, P.cutoff.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, s));
+        }
+        TSGPU_HIP_TRY(hipMemcpyAsync(off_words.data(), o.off_words, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+
+        // ---- bookkeeping: timings + algorithmic bytes ----
+        float ms_a = 0, ms_b = 0;
+        (void)hipEventElapsedTime(&ms_a, ctx->ev[0], ctx->ev[1]);
+        (void)hipEventElapsedTime(&ms_b, ctx->ev[1], ctx->ev[2]);
+        ctx->timings.kw_search_ms = ms_a;
+        ctx->timings.kw_merge_ms = ms_b;
+        ctx->timings.total_ms = ms_a + ms_b;
+        uint64_t bytes = P.list_bytes;
+        if (!dev_out && out->num_matched) {
+            for (uint32_t i = 0; i < n_queries; i++) {
+                uint32_t n_num = 0;
+                for (uint32_t k = 0; k < P.q[i].n_sort; k++) if (P.q[i].sort_kind[k] == TSGPU_SORT_INT64_COLUMN) n_num++;
+                bytes += 4ull * off_words[i] + 8ull * out->num_matched[i] * n_num;
+            }
+        } else {
+            for (uint32_t i = 0; i < n_queries; i++) bytes += 4ull * off_words[i];
+        }
+        ctx->timings.kw_algorithmic_bytes = bytes;
+        // remember where matched ids live
+        ctx->last_chunk_blocks = ctx->kw_chunk_blocks;
+        ctx->last_ids_off.assign(n_queries, 0);
+        ctx->last_ids_cap.assign(n_queries, 0);
+        ctx->last_chunk_emit.assign(n_queries, {});
+        if (ctx->keep_ids && n_work) {
+            std::vector<uint32_t> ne(n_work);
+            TSGPU_HIP_TRY(hipMemcpy(ne.data(), part.n_emit, (size_t)n_work * 4, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < n_queries; i++) {
+                if (P.status[i] != TSGPU_OK || P.q[i].n_work == 0) continue;
+                ctx->last_ids_off[i] = P.q[i].ids_out_off;
+                ctx->last_chunk_emit[i].assign(ne.begin() + P.q[i].first_work, ne.begin() + P.q[i].first_work + P.q[i].n_work);
+            }
+        }
+        // queries that were not run must not expose stale slots
+        if (!dev_out) for (uint32_t i = 0; i < n_queries; i++) if (P.status[i] != TSGPU_OK) { out->n_hits[i] = 0; if (out->num_matched) out->num_matched[i] = 0; }
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_batch: host allocation failed"); }
+    return ok();
+}
+
+uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64_t cap) {
+    if (!ctx) return 0;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (q >= ctx->last_chunk_emit.size()) return 0;
+    uint64_t total = 0;
+    const auto& ce = ctx->last_chunk_emit[q];
+    for (size_t c = 0; c < ce.size(); c++) {
+        const uint64_t seg = ctx->last_ids_off[q] + (uint64_t)c * ctx->last_chunk_blocks * BLOCK_IDS;
+        const uint64_t n = ce[c];
+        if (out_host && total < cap) {
+            const uint64_t m = std::min<uint64_t>(n, cap - total);
+            if (hipMemcpy(out_host + total, ctx->d_ids_out.as<uint32_t>() + seg, m * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+        }
+        total += n;
+    }
+    return total;
+}
+
+int tsgpu_last_timings(tsgpu_ctx* ctx, tsgpu_timings* out) {
+    if (!ctx || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_last_timings: NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    *out = ctx->timings;
+    return ok();
+}
+
+}  // extern "C"

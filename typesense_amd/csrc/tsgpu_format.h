@@ -1,0 +1,74 @@
+// tsgpu_format.h — HBM layout of the keyword index mirror, shared by the host packer and the gfx950 kernels.
+//
+// The reference keeps, per token, a chain of posting_list_t::block_t (include/posting_list.h:56-77): three
+// FOR-compressed arrays per block of <=256 docs — ids (sorted), offset_index (start of each doc's run),
+// offsets (token positions+1, 0 = "last token" flag; src/index.cpp:1323-1348) — reached through a
+// std::map<last_id, block*> (posting_list.h:130). That byte format is private to the reference (never
+// persisted), so the mirror is free to choose a layout that suits 64-wide wavefronts:
+//
+//   * every list is re-blocked into exactly TSGPU_BLOCK_IDS (256) ids per block (last block partial), so a
+//     posting position p maps to (block p>>8, slot p&255) without a per-block length lookup;
+//   * the std::map skip index becomes one contiguous u32 array blk_last[] per list (binary-searchable with
+//     coalesced / broadcast loads) plus a 32-byte BlockMeta record per block;
+//   * the three arrays stay frame-of-reference bit-packed (same arithmetic as libfor: value-base in `bits`
+//     bits, LSB-first), but in 32-bit words, each array padded to a whole word + one guard word so a lane
+//     can extract any element with two dword loads and a funnel shift — no per-block decode/alloc;
+//   * all lists of a snapshot live in three arenas (blk_last, blk_meta, payload) -> 3 allocations total.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(TSGPU_HIP_EMU)
+#define TSGPU_HD __host__ __device__
+#else
+#define TSGPU_HD
+#endif
+
+namespace tsgpu {
+
+static const uint32_t BLOCK_IDS = 256;
+
+struct BlockMeta {           // 32 bytes
+    uint32_t first_id;       // FOR base of ids (= ids[0])
+    uint32_t ids_woff;       // word offsets are relative to ListDesc::payload_base
+    uint32_t oi_woff;        // offset_index, FOR base 0 (offset_index[0] == 0 inside a block)
+    uint32_t off_woff;       // offsets, FOR base off_base
+    uint32_t n_off;          // total offsets stored in this block
+    uint32_t off_base;       // min offset value in the block
+    uint16_t n_ids;          // 1..256
+    uint8_t ids_bits;
+    uint8_t oi_bits;
+    uint8_t off_bits;
+    uint8_t pad[3];
+};
+
+struct ListDesc {            // 32 bytes
+    uint64_t payload_base;   // word index into the payload arena
+    uint32_t blk_base;       // index of the list's first block in blk_last[] / blk_meta[]
+    uint32_t n_blocks;
+    uint32_t n_ids;
+    uint32_t first_id;
+    uint32_t last_id;
+    uint32_t n_off;          // total offsets of the list (for the algorithmic-bytes accounting)
+};
+
+TSGPU_HD static inline uint32_t required_bits(uint32_t v) {   // include/array_base.h:23-25
+    return v == 0 ? 0u : 32u - (uint32_t)__builtin_clz(v);
+}
+
+// words needed for n values of `bits` bits, + 1 guard word (so unpack may always read word i+1)
+TSGPU_HD static inline uint32_t packed_words(uint32_t n, uint32_t bits) {
+    return (uint32_t)(((uint64_t)n * bits + 31) / 32) + 1;
+}
+
+// element idx of a bit-packed array (LSB-first in 32-bit words); bits in [0,32]
+TSGPU_HD static inline uint32_t unpack_at(const uint32_t* __restrict__ w, uint32_t idx, uint32_t bits) {
+    if (bits == 0) return 0;
+    const uint64_t bitpos = (uint64_t)idx * bits;
+    const uint64_t wi = bitpos >> 5;
+    const uint32_t sh = (uint32_t)(bitpos & 31);
+    const uint64_t two = (uint64_t)w[wi] | ((uint64_t)w[wi + 1] << 32);
+    const uint64_t mask = bits >= 32 ? 0xFFFFFFFFull : ((1ull << bits) - 1ull);
+    return (uint32_t)((two >> sh) & mask);
+}
+
+}  // namespace tsgpu

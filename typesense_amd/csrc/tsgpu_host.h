@@ -1,0 +1,115 @@
+// tsgpu_host.h — host-side state behind the C-ABI (include/tsgpu.h): the context, the committed HBM snapshot
+// of the keyword index, grow-only device scratch, error plumbing. HIP runtime only; no torch, no CPU scoring.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <mutex>
+#include <unordered_map>
+#include <algorithm>
+#include <chrono>
+#include <new>
+#include "../../include/tsgpu.h"
+#include "tsgpu_format.h"
+#include "tsgpu_pack.h"
+
+namespace tsgpu {
+
+// Option<T>-style error plumbing (include/option.h of the reference): code + message, never throw.
+inline std::string& tls_error() { static thread_local std::string e; return e; }
+inline int fail(int code, const std::string& msg) { tls_error() = msg; return code; }
+inline int ok() { return TSGPU_OK; }
+
+#define TSGPU_HIP_TRY(expr)                                                                          \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            return ::tsgpu::fail(_e == hipErrorOutOfMemory ? TSGPU_ERR_NO_MEMORY : TSGPU_ERR_DEVICE, \
+                                 std::string(#expr) + ": " + hipGetErrorString(_e));                \
+        }                                                                                            \
+    } while (0)
+
+// grow-only device / pinned-host buffers
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return TSGPU_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        TSGPU_HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return TSGPU_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return TSGPU_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        TSGPU_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return TSGPU_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct FieldHost {
+    bool is_array = false;
+    std::unordered_map<uint32_t, PackedList> terms;   // pending + committed host copies (source of the next snapshot)
+};
+
+struct Snapshot {            // immutable HBM image of all posting lists
+    DevBuf lists, blk_last, blk_meta, payload;
+    std::vector<ListDesc> h_lists;                                  // host copy of the descriptors
+    std::unordered_map<uint64_t, uint32_t> handle_of;               // (field<<32 | term) -> list handle
+    uint64_t bytes = 0;
+};
+
+struct ColumnDev { DevBuf data; uint32_t n = 0; };
+
+struct VecField;             // tsgpu_vec.hip
+
+}  // namespace tsgpu
+
+struct tsgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::mutex mu;                                   // serialises batch execution on the shared scratch
+
+    std::unordered_map<uint32_t, tsgpu::FieldHost> fields;
+    tsgpu::Snapshot snap;
+    bool dirty = false;
+    std::vector<tsgpu::ColumnDev> columns;
+    tsgpu::DevBuf d_col_ptrs, d_col_len;
+    uint32_t num_docs = 0;
+    bool num_docs_set = false;
+
+    // keyword batch scratch
+    tsgpu::DevBuf d_queries, d_work, d_aux, d_ids_out;
+    tsgpu::DevBuf d_part_s0, d_part_s1, d_part_s2, d_part_key, d_part_cnt, d_part_nm, d_part_ne, d_part_ow;
+    tsgpu::DevBuf d_out_keys, d_out_scores, d_out_tm, d_out_vd, d_out_msi, d_out_nh, d_out_nm, d_out_ow;
+    tsgpu::PinBuf h_stage, h_out;
+    bool keep_ids = false;
+    uint32_t kw_chunk_blocks = 64;                   // driver blocks per work item (64 -> 16K candidate ids)
+    uint32_t last_chunk_blocks = 64;
+    uint32_t vec_rows_per_slab = 0;                  // 0 = automatic
+    std::vector<uint64_t> last_ids_off;              // per query offset into d_ids_out of the last batch
+    std::vector<uint64_t> last_ids_cap;
+    std::vector<std::vector<uint32_t>> last_chunk_emit;  // filled lazily by tsgpu_result_ids
+    std::vector<tsgpu_kw_query> last_queries_shadow;
+
+    std::unordered_map<uint32_t, tsgpu::VecField*> vec_fields;
+
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    tsgpu_timings timings{};
+};

@@ -1,0 +1,276 @@
+"""Host-side mirror of the reference's operator surface for the hot path, over the C-ABI (include/tsgpu.h).
+
+GpuIndex wraps one tsgpu context = one GPU's shard of: the posting lists of the query_by fields
+(Index::search_index, include/index.h), the numeric sort index (include/index.h:442) and the vector fields
+(hnsw_index_t, include/index.h:356-389). Every method is a 1:1 call into libtsgpu.so; nothing is computed
+in Python.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib as B
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class KwQuery:
+    """One search_across_fields call (src/index.cpp:5385): tokens of one candidate combination + ranking params."""
+
+    def __init__(self, tokens, field=0, weight=15, sort=((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, 1, 0)),
+                 topster_size=0, match_type=B.MAX_SCORE, prioritize_exact_match=True, prioritize_token_position=False,
+                 prioritize_num_matching_fields=True, total_cost=0, excluded_ids=None, filter_ids=None, deadline_us=0,
+                 n_fields=1):
+        self.tokens = list(tokens)
+        self.field, self.weight, self.sort = field, weight, tuple(sort)     # sort: (kind, order, column)
+        self.topster_size = topster_size
+        self.match_type = match_type
+        self.prioritize_exact_match = prioritize_exact_match
+        self.prioritize_token_position = prioritize_token_position
+        self.prioritize_num_matching_fields = prioritize_num_matching_fields
+        self.total_cost = total_cost
+        self.excluded_ids = None if excluded_ids is None else _u32(excluded_ids)
+        self.filter_ids = None if filter_ids is None else _u32(filter_ids)
+        self.deadline_us = deadline_us
+        self.n_fields = n_fields
+
+    def fill(self, c):
+        c.n_tokens = len(self.tokens)
+        for i, t in enumerate(self.tokens[:B.MAX_QUERY_TOKENS]):
+            c.term_ids[i] = int(t)
+        c.n_fields = self.n_fields
+        c.field_ids[0] = self.field
+        c.field_weights[0] = self.weight
+        c.match_type = self.match_type
+        c.prioritize_exact_match = int(self.prioritize_exact_match)
+        c.prioritize_token_position = int(self.prioritize_token_position)
+        c.prioritize_num_matching_fields = int(self.prioritize_num_matching_fields)
+        c.total_cost = self.total_cost
+        c.n_sort = len(self.sort)
+        for i, s in enumerate(self.sort[:3]):
+            c.sort[i].kind, c.sort[i].order, c.sort[i].column = s
+        c.topster_size = self.topster_size
+        if self.excluded_ids is not None and self.excluded_ids.size:
+            c.excluded_ids = self.excluded_ids.ctypes.data_as(C.POINTER(C.c_uint32))
+            c.n_excluded = self.excluded_ids.size
+        if self.filter_ids is not None and self.filter_ids.size:
+            c.filter_ids = self.filter_ids.ctypes.data_as(C.POINTER(C.c_uint32))
+            c.n_filter = self.filter_ids.size
+        c.deadline_us = self.deadline_us
+
+
+class Hits:
+    """Host copy of tsgpu_hits for a batch (numpy, [n_queries, k_stride, ...])."""
+
+    def __init__(self, n_queries, k_stride):
+        self.n_queries, self.k_stride = n_queries, k_stride
+        self.keys = np.zeros((n_queries, k_stride), np.uint64)
+        self.scores = np.zeros((n_queries, k_stride, 3), np.int64)
+        self.text_match = np.zeros((n_queries, k_stride), np.int64)
+        self.vector_distance = np.zeros((n_queries, k_stride), np.float32)
+        self.match_score_index = np.zeros((n_queries, k_stride), np.int8)
+        self.n_hits = np.zeros(n_queries, np.uint32)
+        self.num_matched = np.zeros(n_queries, np.uint64)
+        self.status = np.zeros(n_queries, np.int32)
+        self.search_cutoff = np.zeros(n_queries, np.int32)
+
+    def c_struct(self):
+        h = B.HitsC()
+        h.mem = B.MEM_HOST
+        h.k_stride = self.k_stride
+        h.keys, h.scores, h.text_match = self.keys.ctypes.data, self.scores.ctypes.data, self.text_match.ctypes.data
+        h.vector_distance, h.match_score_index = self.vector_distance.ctypes.data, self.match_score_index.ctypes.data
+        h.n_hits, h.num_matched = self.n_hits.ctypes.data, self.num_matched.ctypes.data
+        h.status, h.search_cutoff = self.status.ctypes.data, self.search_cutoff.ctypes.data
+        return h
+
+
+def make_query_array(queries):
+    """list[KwQuery] (or a prebuilt ctypes array) -> contiguous tsgpu_kw_query[n]"""
+    if isinstance(queries, C.Array):
+        return queries
+    arr = (B.KwQueryC * len(queries))()
+    for i, q in enumerate(queries):
+        q.fill(arr[i])
+    arr._keep = queries
+    return arr
+
+
+class GpuIndex:
+    def __init__(self, device=0, lib_path=None):
+        self.L = B.lib(lib_path)
+        h = C.c_void_p()
+        B.check(self.L, self.L.tsgpu_create(device, C.byref(h)))
+        self.h = h
+        self.vec_dim = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.tsgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        B.check(self.L, rc)
+
+    # ---- keyword index mirror ----
+    def field_create(self, field_id, is_array=False):
+        self._ck(self.L.tsgpu_field_create(self.h, field_id, int(is_array)))
+
+    def term_upsert(self, field_id, term_id, ids, offset_index, offsets):
+        ids, offset_index, offsets = _u32(ids), _u32(offset_index), _u32(offsets)
+        self._ck(self.L.tsgpu_term_upsert(self.h, field_id, term_id, _vp(ids), _vp(offset_index), _vp(offsets), ids.size, offsets.size))
+
+    def terms_load_csr(self, field_id, term_ids, ids_ptr, ids, offset_index, off_ptr, offsets):
+        term_ids, ids, offsets = _u32(term_ids), _u32(ids), _u32(offsets)
+        ids_ptr = np.ascontiguousarray(ids_ptr, dtype=np.uint64)
+        off_ptr = np.ascontiguousarray(off_ptr, dtype=np.uint64)
+        offset_index = np.ascontiguousarray(offset_index, dtype=np.uint64)
+        self._ck(self.L.tsgpu_terms_load_csr(self.h, field_id, term_ids.size, _vp(term_ids), _vp(ids_ptr), _vp(ids),
+                                             _vp(offset_index), _vp(off_ptr), _vp(offsets)))
+
+    def column_set(self, column_id, values, present=None):
+        v = np.ascontiguousarray(values, dtype=np.int64)
+        p = None if present is None else np.ascontiguousarray(present, dtype=np.uint8)
+        self._ck(self.L.tsgpu_column_set(self.h, column_id, _vp(v), _vp(p) if p is not None else None, v.size, B.MEM_HOST))
+
+    def column_set_device(self, column_id, data_ptr, n):
+        self._ck(self.L.tsgpu_column_set(self.h, column_id, C.c_void_p(data_ptr), None, n, B.MEM_DEVICE))
+
+    def set_num_docs(self, n):
+        self._ck(self.L.tsgpu_set_num_docs(self.h, n))
+
+    def commit(self):
+        self._ck(self.L.tsgpu_commit(self.h))
+
+    def term_num_ids(self, field_id, term_id):
+        return self.L.tsgpu_term_num_ids(self.h, field_id, term_id)
+
+    def term_download(self, field_id, term_id):
+        n = self.term_num_ids(field_id, term_id)
+        no = C.c_uint32(0)
+        self._ck(self.L.tsgpu_term_download(self.h, field_id, term_id, None, None, None, C.byref(no)))
+        ids, oi, off = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(max(no.value, 1), np.uint32)
+        self._ck(self.L.tsgpu_term_download(self.h, field_id, term_id, _vp(ids), _vp(oi), off.ctypes.data_as(C.c_void_p), C.byref(no)))
+        return ids, oi, off[:no.value]
+
+    def device_bytes(self):
+        return self.L.tsgpu_device_bytes(self.h)
+
+    def set_option(self, name, value):
+        self._ck(self.L.tsgpu_set_option(self.h, name.encode(), int(value)))
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.L.tsgpu_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    # ---- keyword search (seam B1) ----
+    def keyword_search_batch(self, queries, k_stride=250, hits=None):
+        arr = make_query_array(queries)
+        n = len(arr)
+        hits = hits or Hits(n, k_stride)
+        hs = hits.c_struct()
+        self._ck(self.L.tsgpu_keyword_search_batch(self.h, C.cast(arr, C.c_void_p), n, C.byref(hs)))
+        return hits
+
+    def keyword_search_batch_raw(self, arr, n, hs):
+        """prebuilt ctypes query array + tsgpu_hits struct (device or host outputs); no allocation (bench loop)"""
+        self._ck(self.L.tsgpu_keyword_search_batch(self.h, C.cast(arr, C.c_void_p), n, C.byref(hs)))
+
+    def keep_result_ids(self, keep=True):
+        self._ck(self.L.tsgpu_keep_result_ids(self.h, int(keep)))
+
+    def result_ids(self, q):
+        n = self.L.tsgpu_result_ids(self.h, q, None, 0)
+        out = np.zeros(max(n, 1), np.uint32)
+        if n:
+            self.L.tsgpu_result_ids(self.h, q, _vp(out), n)
+        return out[:n]
+
+    def timings(self):
+        t = B.TimingsC()
+        self._ck(self.L.tsgpu_last_timings(self.h, C.byref(t)))
+        return t
+
+    # ---- vector index (seam B2) ----
+    def vec_create(self, field_id, dim, metric=B.METRIC_IP, capacity_hint=0):
+        self._ck(self.L.tsgpu_vec_create(self.h, field_id, dim, metric, capacity_hint))
+        self.vec_dim[field_id] = dim
+
+    def vec_upsert(self, field_id, labels, data):
+        labels = np.ascontiguousarray(labels, dtype=np.uint64)
+        data = np.ascontiguousarray(data, dtype=np.float32).reshape(labels.size, self.vec_dim[field_id])
+        self._ck(self.L.tsgpu_vec_upsert(self.h, field_id, _vp(labels), _vp(data), labels.size, B.MEM_HOST))
+
+    def vec_upsert_device(self, field_id, labels_ptr, data_ptr, n):
+        self._ck(self.L.tsgpu_vec_upsert(self.h, field_id, C.c_void_p(labels_ptr), C.c_void_p(data_ptr), n, B.MEM_DEVICE))
+
+    def vec_delete(self, field_id, label):
+        self._ck(self.L.tsgpu_vec_delete(self.h, field_id, label))
+
+    def vec_get(self, field_id, label):
+        out = np.zeros(self.vec_dim[field_id], np.float32)
+        rc = self.L.tsgpu_vec_get(self.h, field_id, label, _vp(out))
+        if rc == B.ERR_NOT_FOUND:
+            return None
+        self._ck(rc)
+        return out
+
+    def vec_count(self, field_id):
+        return self.L.tsgpu_vec_count(self.h, field_id)
+
+    def vec_knn_batch(self, field_id, Q, k, allow_ids=None, excluded_ids=None):
+        Q = np.ascontiguousarray(Q, dtype=np.float32).reshape(-1, self.vec_dim[field_id])
+        n = Q.shape[0]
+        dist = np.zeros((n, k), np.float32)
+        lab = np.zeros((n, k), np.uint64)
+        cnt = np.zeros(n, np.uint32)
+        a = None if allow_ids is None else _u32(allow_ids)
+        e = None if excluded_ids is None else _u32(excluded_ids)
+        self._ck(self.L.tsgpu_vec_knn_batch(self.h, field_id, _vp(Q), B.MEM_HOST, n, k,
+                                            _vp(a) if a is not None else None, a.size if a is not None else 0,
+                                            _vp(e) if e is not None else None, e.size if e is not None else 0,
+                                            _vp(dist), _vp(lab), _vp(cnt), B.MEM_HOST))
+        return dist, lab, cnt
+
+    def vec_knn_batch_raw(self, field_id, q_ptr, mem_q, n, k, dist_ptr, lab_ptr, cnt_ptr, mem_out):
+        self._ck(self.L.tsgpu_vec_knn_batch(self.h, field_id, C.c_void_p(q_ptr), mem_q, n, k, None, 0, None, 0,
+                                            C.c_void_p(dist_ptr), C.c_void_p(lab_ptr), C.c_void_p(cnt_ptr), mem_out))
+
+    def vec_distances(self, field_id, q, labels):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        labels = np.ascontiguousarray(labels, dtype=np.uint64)
+        out = np.zeros(labels.size, np.float32)
+        self._ck(self.L.tsgpu_vec_distances(self.h, field_id, _vp(q), _vp(labels), labels.size, _vp(out)))
+        return out
+
+    def vector_search_batch(self, field_id, Q, k=0, fetch_size=10, distance_threshold=B.FLT_MAX,
+                            sort=((B.SORT_VECTOR_DISTANCE, -1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=0, k_stride=250):
+        Q = np.ascontiguousarray(Q, dtype=np.float32).reshape(-1, self.vec_dim[field_id])
+        p = B.VecQueryC()
+        p.k, p.fetch_size, p.distance_threshold, p.n_sort, p.topster_size = k, fetch_size, distance_threshold, len(sort), topster_size
+        for i, s in enumerate(sort):
+            p.sort[i].kind, p.sort[i].order, p.sort[i].column = s
+        hits = Hits(Q.shape[0], k_stride)
+        hs = hits.c_struct()
+        self._ck(self.L.tsgpu_vector_search_batch(self.h, field_id, C.byref(p), _vp(Q), B.MEM_HOST, Q.shape[0], C.byref(hs)))
+        return hits
+
+    def hybrid_search_batch(self, queries, field_id, Q, k=0, fetch_size=10, alpha=0.3, distance_threshold=B.FLT_MAX, k_stride=250):
+        arr = make_query_array(queries)
+        Q = np.ascontiguousarray(Q, dtype=np.float32).reshape(-1, self.vec_dim[field_id])
+        p = B.HybridParamsC()
+        p.k, p.fetch_size, p.alpha, p.distance_threshold = k, fetch_size, alpha, distance_threshold
+        hits = Hits(len(arr), k_stride)
+        hs = hits.c_struct()
+        self._ck(self.L.tsgpu_hybrid_search_batch(self.h, C.cast(arr, C.c_void_p), field_id, C.byref(p), _vp(Q), B.MEM_HOST, len(arr), C.byref(hs)))
+        return hits
