@@ -21,13 +21,13 @@ protected:
     uint32_t max = std::numeric_limits<uint32_t>::min();
 
     void encode(const uint32_t* vals, uint32_t n, uint32_t base, uint32_t bits) {
-        in.assign(FOR_HEADER_BYTES + for_compressed_size_bits(n, bits) + 8, 0);
+        in.assign(FOR_HEADER_BYTES + for_compressed_size_bits(n, bits) + 16, 0);
         for_compress_bits(vals, in.data(), n, base, bits);
         length = n;
     }
 
 public:
-    array_base() { in.assign(FOR_HEADER_BYTES + 8, 0); }
+    array_base() { in.assign(FOR_HEADER_BYTES + 16, 0); }
 
     // array_base::uncompress, src/array_base.cpp:3-16 (caller owns the buffer, delete[])
     uint32_t* uncompress(uint32_t len = 0) const {

@@ -35,22 +35,23 @@ static inline uint32_t for_compressed_size_bits(uint32_t length, uint32_t bits) 
     return (full / 8) * bits + (rem * bits + 7) / 8;
 }
 
+// OR the `bits` low bits of v into a zero-initialised payload at bitpos (payload has >= 8 bytes of slack)
 static inline void for_put_bits(uint8_t* payload, uint64_t bitpos, uint32_t bits, uint32_t v) {
-    for (uint32_t b = 0; b < bits; b++) {
-        uint64_t p = bitpos + b;
-        uint8_t bit = (uint8_t)((v >> b) & 1u);
-        payload[p >> 3] = (uint8_t)((payload[p >> 3] & ~(1u << (p & 7))) | (bit << (p & 7)));
-    }
+    if (bits == 0) return;
+    uint64_t byte = bitpos >> 3;
+    uint32_t shift = (uint32_t)(bitpos & 7);
+    uint64_t cur;
+    memcpy(&cur, payload + byte, 8);
+    cur |= ((uint64_t)v) << shift;      // bits <= 32, shift <= 7 -> fits in 64 bits
+    memcpy(payload + byte, &cur, 8);
 }
 
 static inline uint32_t for_get_bits(const uint8_t* payload, uint64_t bitpos, uint32_t bits) {
     if (bits == 0) return 0;
     uint64_t byte = bitpos >> 3;
     uint32_t shift = (uint32_t)(bitpos & 7);
-    uint64_t acc = 0;
-    // read up to 5 bytes (bits <= 32, shift <= 7 -> 39 bits)
-    uint32_t need = (shift + bits + 7) / 8;
-    for (uint32_t i = 0; i < need; i++) acc |= (uint64_t)payload[byte + i] << (8 * i);
+    uint64_t acc;
+    memcpy(&acc, payload + byte, 8);    // buffers carry >= 8 bytes of slack (array_base::encode)
     acc >>= shift;
     return bits == 32 ? (uint32_t)acc : (uint32_t)(acc & ((1ull << bits) - 1));
 }
@@ -65,7 +66,7 @@ static inline uint32_t for_compress_bits(const uint32_t* in, uint8_t* out, uint3
     out[4] = (uint8_t)bits;
     uint8_t* payload = out + FOR_HEADER_BYTES;
     uint32_t nbytes = for_compressed_size_bits(length, bits);
-    memset(payload, 0, nbytes);
+    memset(payload, 0, nbytes + 8);     // callers allocate 8 bytes of slack past the payload
     for (uint32_t i = 0; i < length; i++) for_put_bits(payload, (uint64_t)i * bits, bits, in[i] - base);
     return FOR_HEADER_BYTES + nbytes;
 }
@@ -86,7 +87,17 @@ static inline uint32_t for_compress_unsorted(const uint32_t* in, uint8_t* out, u
 static inline uint32_t for_uncompress(const uint8_t* in, uint32_t* out, uint32_t length) {
     uint32_t base = for_header_base(in), bits = for_header_bits(in);
     const uint8_t* payload = in + FOR_HEADER_BYTES;
-    for (uint32_t i = 0; i < length; i++) out[i] = base + for_get_bits(payload, (uint64_t)i * bits, bits);
+    if (bits == 0) { for (uint32_t i = 0; i < length; i++) out[i] = base; }
+    else {
+        // streaming decode through a 64-bit window (libfor uses unrolled per-width kernels; same values)
+        const uint64_t mask = bits == 32 ? 0xFFFFFFFFull : ((1ull << bits) - 1);
+        uint64_t bitpos = 0;
+        for (uint32_t i = 0; i < length; i++, bitpos += bits) {
+            uint64_t acc;
+            memcpy(&acc, payload + (bitpos >> 3), 8);
+            out[i] = base + (uint32_t)((acc >> (bitpos & 7)) & mask);
+        }
+    }
     return FOR_HEADER_BYTES + for_compressed_size_bits(length, bits);
 }
 

@@ -1,0 +1,167 @@
+"""`-m gpu`: the keyword hot path on a real MI355X through the C-ABI (libtsgpu.so), bit-exact against the oracle
+(doc-id sets, num_keyword_matches, top-K order and every score). Collections follow SURVEY §8(d) config 1
+(100K docs, V=20K, 16 tokens/doc) plus a 2M-doc collection for multi-work-item queries; the full 10M-doc size
+is covered by size-independent properties (sortedness, subset/superset relations, idempotence, shard merge)."""
+import numpy as np
+import pytest
+
+import typesense_amd as T
+from typesense_amd import _lib as B, synth
+from oracle import oracle_py as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+SORT = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+OSORT = ((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1))
+
+
+class Corpus:
+    def __init__(self, n_docs, vocab, tpd, seed):
+        self.n_docs = n_docs
+        self.csr = synth.zipf_corpus_csr(n_docs, vocab, tpd, seed)
+        self.pts = synth.points_column(n_docs)
+        self.g = T.GpuIndex(0)
+        self.g.field_create(0, False)
+        c = self.csr
+        self.g.terms_load_csr(0, c["term_ids"], c["ids_ptr"], c["ids"], c["offset_index"], c["off_ptr"], c["offsets"])
+        self.g.column_set(0, self.pts)
+        self.g.set_num_docs(n_docs)
+        self.g.commit()
+        self.orc = O.OracleIndex(1, 1)
+        self.orc.set_num_docs(n_docs)
+        self.orc.set_sort_dense(0, self.pts)
+        self.loaded = set()
+
+    def need(self, terms):
+        for t in np.unique(np.asarray(terms).ravel()):
+            t = int(t)
+            if t in self.loaded or t < 1 or t > self.csr["term_ids"].size:
+                continue
+            ids, oi, off = synth.csr_term(self.csr, t)
+            if ids.size:
+                self.orc.load_posting(0, t, ids, oi, off)
+            self.loaded.add(t)
+
+    def oracle(self, q, ids_cap=0):
+        self.need(q.tokens)
+        return H.oracle_keyword(self.orc, q, ids_cap=ids_cap)
+
+
+@pytest.fixture(scope="module")
+def c100k():
+    c = Corpus(100_000, 20_000, 16, seed=1)
+    yield c
+    c.g.close()
+
+
+@pytest.fixture(scope="module")
+def c2m():
+    c = Corpus(2_000_000, 50_000, 24, seed=7)
+    yield c
+    c.g.close()
+
+
+def test_format_roundtrip_on_device(c100k):
+    for t in (1, 2, 50, 1234, 19999):
+        ids, oi, off = synth.csr_term(c100k.csr, t)
+        if not ids.size:
+            continue
+        gi, go, gf = c100k.g.term_download(0, t)
+        assert np.array_equal(ids, gi) and np.array_equal(oi, go) and np.array_equal(off, gf)
+
+
+def test_config1_three_term_and_top10_bit_exact(c100k):
+    """BASELINE config 1: 1 000 queries, 3 distinct terms, ranks log-uniform [5,500], per_page=10 -> Topster 250"""
+    qtok = synth.keyword_queries(1000, 3, 5, 500, seed=11)
+    qs = [T.KwQuery(q, sort=SORT, topster_size=250) for q in qtok]
+    hits = c100k.g.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all()
+    nonempty = 0
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(hits, i, c100k.oracle(q), "config1")
+        nonempty += int(hits.n_hits[i] > 0)
+    assert nonempty > 100
+
+
+@pytest.mark.parametrize("n_tok", [1, 2, 4, 6, 10])
+def test_token_counts_bit_exact(c100k, n_tok):
+    qtok = synth.keyword_queries(40, n_tok, 1, 60 if n_tok > 3 else 300, seed=20 + n_tok)
+    qs = [T.KwQuery(q, sort=SORT, topster_size=250) for q in qtok]
+    hits = c100k.g.keyword_search_batch(qs, k_stride=250)
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(hits, i, c100k.oracle(q), "T=%d" % n_tok)
+
+
+def test_flags_sorts_and_duplicates_bit_exact(c100k):
+    base = dict(topster_size=250)
+    qs = [
+        T.KwQuery([3, 3], **base), T.KwQuery([2, 5, 2], **base), T.KwQuery([1, 999999, 4], **base), T.KwQuery([999999], **base),
+        T.KwQuery([1, 2], prioritize_token_position=True, **base), T.KwQuery([6], prioritize_token_position=True, **base),
+        T.KwQuery([1, 2, 3], prioritize_exact_match=False, **base), T.KwQuery([1, 4], prioritize_num_matching_fields=False, **base),
+        T.KwQuery([2, 3], match_type=B.MAX_WEIGHT, weight=7, **base), T.KwQuery([2, 3], match_type=B.MAX_WEIGHT, weight=0, **base),
+        T.KwQuery([2, 3], match_type=B.SUM_SCORE, weight=3, **base), T.KwQuery([5, 1], total_cost=3, **base), T.KwQuery([8], **base),
+        T.KwQuery([1, 2], sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, -1, 0)), **base),
+        T.KwQuery([1, 2], sort=((B.SORT_TEXT_MATCH, -1, 0), (B.SORT_SEQ_ID, 1, 0)), **base),
+        T.KwQuery([1, 3], sort=((B.SORT_SEQ_ID, 1, 0),), **base),
+        T.KwQuery([1, 2], topster_size=5, sort=SORT), T.KwQuery([1], topster_size=3), T.KwQuery([2, 1, 3], topster_size=1),
+        T.KwQuery([1, 2], topster_size=1000, sort=SORT), T.KwQuery([4], topster_size=600, sort=SORT),
+    ]
+    hits = c100k.g.keyword_search_batch(qs, k_stride=1000)
+    assert (hits.status == 0).all()
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(hits, i, c100k.oracle(q), "flags")
+
+
+def test_result_ids_and_excluded_ids(c100k):
+    g = c100k.g
+    g.keep_result_ids(True)
+    try:
+        q0 = T.KwQuery([1, 2], topster_size=250, sort=SORT)
+        ref0 = c100k.oracle(q0, ids_cap=200000)
+        excl = np.sort(ref0.result_ids[::3])
+        qs = [q0, T.KwQuery([1, 2], topster_size=250, sort=SORT, excluded_ids=excl), T.KwQuery([7], topster_size=250, sort=SORT)]
+        hits = g.keyword_search_batch(qs, k_stride=250)
+        for i, q in enumerate(qs):
+            ref = c100k.oracle(q, ids_cap=200000)
+            H.assert_hits_equal(hits, i, ref, "ids")
+            assert np.array_equal(g.result_ids(i), ref.result_ids)
+    finally:
+        g.keep_result_ids(False)
+
+
+def test_two_million_docs_multi_chunk_bit_exact(c2m):
+    """lists of up to ~1M ids: drivers span many 64-block work items; partial top-K merge on device"""
+    qtok = np.concatenate([synth.keyword_queries(60, 3, 1, 200, seed=31), synth.keyword_queries(20, 2, 1, 50, seed=32)[:, [0, 1, 1]]])
+    qs = [T.KwQuery(q[:3] if i < 60 else q[:2], sort=SORT, topster_size=250) for i, q in enumerate(qtok)]
+    qs += [T.KwQuery([1], sort=SORT, topster_size=250), T.KwQuery([2], sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=250)]
+    assert c2m.g.term_num_ids(0, 1) > 64 * 256 * 4
+    hits = c2m.g.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all()
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(hits, i, c2m.oracle(q), "2M")
+
+
+def test_size_independent_properties(c2m):
+    """properties that hold at any size (used again at 10M docs by bench.py --check)"""
+    g = c2m.g
+    qtok = synth.keyword_queries(300, 3, 1, 400, seed=41)
+    q3 = [T.KwQuery(q, sort=SORT, topster_size=250) for q in qtok]
+    q2 = [T.KwQuery(q[:2], sort=SORT, topster_size=250) for q in qtok]
+    h3 = g.keyword_search_batch(q3, k_stride=250)
+    h2 = g.keyword_search_batch(q2, k_stride=250)
+    again = g.keyword_search_batch(q3, k_stride=250)
+    for i in range(len(q3)):
+        n = int(h3.n_hits[i])
+        # idempotence
+        assert n == again.n_hits[i] and np.array_equal(h3.keys[i, :n], again.keys[i, :n]) and np.array_equal(h3.scores[i, :n], again.scores[i, :n])
+        # Topster::sort() order: (s0, s1, s2, key) strictly descending
+        tup = [tuple(h3.scores[i, j]) + (int(h3.keys[i, j]),) for j in range(n)]
+        assert all(tup[j] > tup[j + 1] for j in range(n - 1))
+        # adding a token can only shrink the match set
+        assert h3.num_matched[i] <= h2.num_matched[i]
+        assert n == min(250, int(h3.num_matched[i]))
+        # text_match of a 3-token hit encodes 3 tokens matched, 1 field
+        if n:
+            tm = h3.text_match[i, :n].astype(np.uint64)
+            assert ((tm >> np.uint64(59)) == 3).all() and ((tm & np.uint64(7)) == 1).all()
