@@ -1,0 +1,193 @@
+"""Vector / hybrid path (vec_kernels.hip.h, tsgpu_vec.hip) on the CPU under the SIMT emulator (MFMA modelled as
+the k-ordered fmaf chain of v_mfma_f32_32x32x2_f32), against the oracle's exact flat scan.
+Tolerance: distances within 1e-5 relative (north_star); label sets identical; ties broken by smaller label."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import typesense_amd as T
+from typesense_amd import _lib as B
+from oracle import oracle_py as O
+from tests import helpers as H
+
+RTOL = 1e-5
+
+
+def _mk(n, dim, metric, seed, lib, labels=None):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    labels = np.arange(n, dtype=np.uint64) if labels is None else labels
+    g = T.GpuIndex(0, lib)
+    g.vec_create(1, dim, metric)
+    g.vec_upsert(1, labels, X)
+    orc = O.OracleIndex(1, 1)
+    orc.vec_init(dim, metric)
+    orc.vec_add(labels.astype(np.uint32), X)
+    return g, orc, X, rng
+
+
+def _check_knn(g, orc, Q, k, allow=None):
+    dist, lab, cnt = g.vec_knn_batch(1, Q, k, allow_ids=allow)
+    for i in range(Q.shape[0]):
+        d, l = orc.flat_knn(Q[i], k, allow_ids=allow)
+        assert cnt[i] == d.size, (cnt[i], d.size)
+        assert np.allclose(dist[i, :d.size], d, rtol=RTOL, atol=RTOL), np.abs(dist[i, :d.size] - d).max()
+        assert set(lab[i, :d.size].astype(np.int64)) == set(l.astype(np.int64))
+        assert (np.diff(dist[i, :d.size]) >= 0).all()
+
+
+@pytest.mark.parametrize("dim,n,k", [(48, 300, 10), (64, 700, 100), (70, 260, 7), (768, 300, 100), (32, 513, 200)])
+def test_knn_matches_oracle_flat_scan(dim, n, k):
+    g, orc, X, rng = _mk(n, dim, B.METRIC_IP, 5 + dim, H.emu_lib_path())
+    Q = rng.standard_normal((5, dim)).astype(np.float32)
+    _check_knn(g, orc, Q, k)
+    g.close()
+
+
+def test_cosine_normalisation_is_bit_exact_and_distances_match():
+    g, orc, X, rng = _mk(200, 40, B.METRIC_COSINE, 9, H.emu_lib_path())
+    for lab in (0, 7, 199):
+        assert np.array_equal(g.vec_get(1, lab), orc.vec_get(lab))      # hnsw_index_t::normalize_vector, include/index.h:379-388
+    Q = (rng.standard_normal((3, 40)) * 5).astype(np.float32)
+    _check_knn(g, orc, Q, 20)
+    assert g.vec_get(1, 555) is None                                    # getDataByLabel throws -> NOT_FOUND
+    g.close()
+
+
+def test_ties_prefer_smaller_label_and_many_slabs():
+    lib = H.emu_lib_path()
+    rng = np.random.default_rng(2)
+    base = rng.standard_normal((8, 16)).astype(np.float32)
+    X = np.concatenate([base] * 40)                                     # every vector 40 times: massive distance ties
+    g = T.GpuIndex(0, lib)
+    g.set_option("vec_rows_per_slab", 128)                              # 3 slabs
+    g.vec_create(1, 16, B.METRIC_IP)
+    g.vec_upsert(1, np.arange(320, dtype=np.uint64), X)
+    orc = O.OracleIndex(1, 1)
+    orc.vec_init(16, O.METRIC_IP)
+    orc.vec_add(np.arange(320, dtype=np.uint32), X)
+    Q = base[:2] * 2
+    dist, lab, cnt = g.vec_knn_batch(1, Q, 50)
+    for i in range(2):
+        d, l = orc.flat_knn(Q[i], 50)
+        assert np.array_equal(lab[i].astype(np.uint32), l)              # exact order incl. tie-break
+        assert np.allclose(dist[i], d, rtol=RTOL, atol=RTOL)
+    g.close()
+
+
+def test_upsert_delete_labels_filters_and_by_id_distances():
+    lib = H.emu_lib_path()
+    rng = np.random.default_rng(4)
+    labels = np.array([10, 3, 77, 5, 1000, 42, 8, 9, 11, 12, 13, 14], dtype=np.uint64)      # not row order
+    g, orc, X, _ = _mk(12, 24, B.METRIC_IP, 4, lib, labels=labels)
+    q = rng.standard_normal((2, 24)).astype(np.float32)
+    _check_knn(g, orc, q, 5)
+    # in-place update of an existing label + a new one
+    newv = rng.standard_normal((2, 24)).astype(np.float32)
+    g.vec_upsert(1, np.array([77, 2000], np.uint64), newv)
+    orc.vec_add(np.array([77, 2000], np.uint32), newv)
+    assert g.vec_count(1) == 13
+    assert np.array_equal(g.vec_get(1, 77), newv[0])
+    _check_knn(g, orc, q, 13)
+    # allow list (VectorFilterFunctor) and by-id distances (flat scan over filter ids)
+    allow = np.array([3, 5, 8, 77, 1000, 4242], np.uint32)
+    _check_knn(g, orc, q, 4, allow=np.sort(allow))
+    d = g.vec_distances(1, q[0], np.array([5, 77, 31337], np.uint64))
+    ref = [O.lib().orc_ip_distance(q[0].ctypes.data, orc.vec_get(l).ctypes.data, 24) for l in (5, 77)]
+    assert np.allclose(d[:2], ref, rtol=RTOL, atol=RTOL) and np.isnan(d[2])
+    # markDelete
+    g.vec_delete(1, 77)
+    assert g.vec_get(1, 77) is None
+    dist, lab, cnt = g.vec_knn_batch(1, q, 13)
+    assert cnt[0] == 12 and 77 not in set(lab[0, :12].tolist())
+    with pytest.raises(T.TsgpuError):
+        g.vec_delete(1, 77)
+    g.close()
+
+
+def _text_and_vectors(lib, n_docs=400, dim=24, seed=3):
+    docs = H.zipf_docs(n_docs, 60, 8, seed=seed)
+    orc, g = H.build_pair(docs, lib)
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n_docs, dim)).astype(np.float32)
+    g.vec_create(1, dim, B.METRIC_IP)
+    g.vec_upsert(1, np.arange(n_docs, dtype=np.uint64), X)
+    orc.vec_init(dim, O.METRIC_IP)
+    orc.vec_add(np.arange(n_docs, dtype=np.uint32), X)
+    return orc, g, rng
+
+
+def test_pure_vector_search_topster_order_matches_oracle():
+    orc, g, rng = _text_and_vectors(H.emu_lib_path())
+    Q = rng.standard_normal((4, 24)).astype(np.float32)
+    for thr in (B.FLT_MAX, 1.0):
+        hits = g.vector_search_batch(1, Q, k=0, fetch_size=30, distance_threshold=thr, k_stride=250)
+        for i in range(4):
+            ref = orc.search_vector(Q[i], k=0, fetch_size=30, distance_threshold=thr)
+            n = int(hits.n_hits[i])
+            assert n == ref.keys.size
+            assert np.array_equal(hits.keys[i, :n], ref.keys)
+            assert np.allclose(hits.vector_distance[i, :n], ref.vector_distance, rtol=RTOL, atol=RTOL)
+            assert np.array_equal(hits.scores[i, :n, 1], ref.scores[:, 1])            # seq_id slot exact
+    g.close()
+
+
+def test_hybrid_rank_fusion_matches_oracle_bit_exactly():
+    orc, g, rng = _text_and_vectors(H.emu_lib_path())
+    Q = rng.standard_normal((6, 24)).astype(np.float32)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    toks = [[1, 2], [3], [2, 5], [1, 2, 3], [59, 1], [7, 7]]
+    qs = [T.KwQuery(t, sort=sort, topster_size=0) for t in toks]
+    hits = g.hybrid_search_batch(qs, 1, Q, k=0, fetch_size=10, alpha=0.3, k_stride=250)
+    assert (hits.status == 0).all()
+    for i, q in enumerate(qs):
+        oq = orc.make_query(q.tokens, sort=((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1)), fetch_size=10)
+        ref = orc.search_hybrid(oq, Q[i], k=0, alpha=0.3)
+        n = int(hits.n_hits[i])
+        assert n == ref.keys.size
+        assert np.array_equal(hits.keys[i, :n], ref.keys), (i, hits.keys[i, :10], ref.keys[:10])
+        assert np.array_equal(hits.scores[i, :n], ref.scores)                       # fused score BITS identical
+        assert np.array_equal(hits.text_match[i, :n], ref.text_match)
+        assert np.allclose(hits.vector_distance[i, :n], ref.vector_distance, rtol=RTOL, atol=RTOL)
+    g.close()
+
+
+def test_shard_merge_equals_unsharded():
+    lib = H.emu_lib_path()
+    docs = H.zipf_docs(1200, 80, 10, seed=8)
+    pts = H.points_of(1200)
+    orc, g_all = H.build_pair(docs, lib, points=pts)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    qs = [T.KwQuery(t, sort=sort, topster_size=40) for t in ([1, 2], [3, 1, 2], [5], [4, 9])]
+    whole = g_all.keyword_search_batch(qs, k_stride=40)
+    shard_hits = []
+    for lo, hi in ((0, 500), (500, 1200)):
+        g = T.GpuIndex(0, lib)
+        g.field_create(0, False)
+        for term in orc.terms(0):
+            ids, oi, off = orc.dump_posting(0, int(term))
+            m = (ids >= lo) & (ids < hi)
+            if not m.any():
+                continue
+            sel = np.nonzero(m)[0]
+            ends = np.append(oi[1:], off.size)
+            new_off, new_oi = [], []
+            for j in sel:
+                new_oi.append(len(new_off))
+                new_off.extend(off[oi[j]:ends[j]])
+            g.term_upsert(0, int(term), ids[sel], new_oi, new_off)
+        g.column_set(0, pts)
+        g.set_num_docs(1200)
+        g.commit()
+        shard_hits.append(g.keyword_search_batch(qs, k_stride=40))
+        g.close()
+    arr = (B.HitsC * 2)(shard_hits[0].c_struct(), shard_hits[1].c_struct())
+    merged = T.Hits(len(qs), 40)
+    ms = merged.c_struct()
+    B.check(g_all.L, g_all.L.tsgpu_merge_shard_hits(C.cast(arr, C.c_void_p), None, 2, len(qs), 40, C.byref(ms)))
+    for i in range(len(qs)):
+        n = int(whole.n_hits[i])
+        assert merged.n_hits[i] == n and merged.num_matched[i] == whole.num_matched[i]
+        assert np.array_equal(merged.keys[i, :n], whole.keys[i, :n]) and np.array_equal(merged.scores[i, :n], whole.scores[i, :n])
+    g_all.close()

@@ -202,12 +202,13 @@ int tsgpu_column_set(tsgpu_ctx* ctx, uint32_t column_id, const int64_t* values, 
     if (mem == TSGPU_MEM_DEVICE) {
         if (present) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_column_set: presence mask with device values is not supported");
         TSGPU_HIP_TRY(hipMemcpyAsync(c.data.p, values, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
-    } else if (present) {
-        std::vector<int64_t> tmp(values, values + n);
-        for (uint32_t i = 0; i < n; i++) if (!present[i]) tmp[i] = INT64_MIN;   // default_score, src/index.cpp:5696
-        TSGPU_HIP_TRY(hipMemcpy(c.data.p, tmp.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+        TSGPU_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        c.host.resize(n);
+        if (n) TSGPU_HIP_TRY(hipMemcpy(c.host.data(), c.data.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
     } else {
-        TSGPU_HIP_TRY(hipMemcpy(c.data.p, values, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+        c.host.assign(values, values + n);
+        if (present) for (uint32_t i = 0; i < n; i++) if (!present[i]) c.host[i] = INT64_MIN;   // default_score, src/index.cpp:5696
+        if (n) TSGPU_HIP_TRY(hipMemcpy(c.data.p, c.host.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
     }
     c.n = n;
     return refresh_column_table(ctx);
@@ -318,7 +319,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
         return ok();
     }
     if (!strcmp(name, "vec_rows_per_slab")) {
-        if (value < 128 || value > (1 << 24)) return fail(TSGPU_ERR_INVALID, "vec_rows_per_slab out of range");
+        if (value != 0 && (value < 128 || value > (1 << 24))) return fail(TSGPU_ERR_INVALID, "vec_rows_per_slab out of range");
         ctx->vec_rows_per_slab = (uint32_t)value;
         return ok();
     }

@@ -74,7 +74,7 @@ struct Snapshot {            // immutable HBM image of all posting lists
     uint64_t bytes = 0;
 };
 
-struct ColumnDev { DevBuf data; uint32_t n = 0; };
+struct ColumnDev { DevBuf data; uint32_t n = 0; std::vector<int64_t> host; /* mirror for the <=k-hit host steps (vector / hybrid) */ };
 
 struct VecField;             // tsgpu_vec.hip
 

@@ -1,17 +1,624 @@
-// TEMPORARY stubs (vector path lands next)
+// tsgpu_vec.hip — vector index mirror + batched exact k-NN (seam B2), pure-vector search (src/index.cpp:3645-3732),
+// hybrid rank fusion (src/index.cpp:4036-4221) and the multi-GPU shard merge, behind include/tsgpu.h.
+// Distances and top-k selection run on the GPU (vec_kernels.hip.h); the host only orders <= k already-scored
+// hits per query exactly the way the reference's Topster does.
+#include <cmath>
+#include <cfloat>
 #include "tsgpu_host.h"
+#include "vec_kernels.hip.h"
+#include "host_topster.h"
+
 using namespace tsgpu;
-extern "C" {
-void tsgpu_vec_destroy_all(tsgpu_ctx*) {}
-uint64_t tsgpu_vec_device_bytes(tsgpu_ctx*) { return 0; }
-int tsgpu_vec_create(tsgpu_ctx*, uint32_t, uint32_t, int, uint64_t) { return fail(TSGPU_ERR_UNSUPPORTED, "nyi"); }
-int tsgpu_vec_upsert(tsgpu_ctx*, uint32_t, const uint64_t*, const float*, uint32_t, int) { return fail(TSGPU_ERR_UNSUPPORTED, "nyi"); }
-int tsgpu_vec_delete(tsgpu_ctx*, uint32_t, uint64_t) { return fail(TSGPU_ERR_UNSUPPORTED, "nyi"); }
-int tsgpu_vec_get(tsgpu_ctx*, uint32_t, uint64_t, float*) { return fail(TSGPU_ERR_UNSUPPORTED, "nyi"); }
-uint64_t tsgpu_vec_count(tsgpu_ctx*, uint32_t) { return 0; }
-int tsgpu_vec_knn_batch(tsgpu_ctx*, uint32_t, const float*, int, uint32_t, uint32_t, const uint32_t*, uint32_t, const uint32_t*, uint32_t, float*, uint64_t*, uint32_t*, int) { return fail(TSGPU_ERR_UNSUPPORTED, "nyi"); }
-int tsgpu_vec_distances(tsgpu_ctx*, uint32_t, const float*, const uint64_t*, uint32_t, float*) { return fail(TSGPU_ERR_UNSUPPORTED, "nyi"); }
-int tsgpu_vector_search_batch(tsgpu_ctx*, uint32_t, const tsgpu_vec_query*, const float*, int, uint32_t, tsgpu_hits*) { return fail(TSGPU_ERR_UNSUPPORTED, "nyi"); }
-int tsgpu_hybrid_search_batch(tsgpu_ctx*, const tsgpu_kw_query*, uint32_t, const tsgpu_hybrid_params*, const float*, int, uint32_t, tsgpu_hits*) { return fail(TSGPU_ERR_UNSUPPORTED, "nyi"); }
-int tsgpu_merge_shard_hits(const tsgpu_hits*, const uint64_t*, uint32_t, uint32_t, uint32_t, tsgpu_hits*) { return fail(TSGPU_ERR_UNSUPPORTED, "nyi"); }
+
+namespace tsgpu {
+
+struct VecField {
+    uint32_t dim = 0;
+    int metric = TSGPU_METRIC_IP;
+    DevBuf X, labels, row_ok;
+    uint64_t cap_rows = 0, n_rows = 0, n_live = 0;
+    std::vector<uint64_t> h_labels;
+    std::vector<uint8_t> h_ok;
+    bool identity = true;                              // label == row for every row so far
+    std::unordered_map<uint64_t, uint32_t> row_of;     // materialised when identity breaks
+    bool any_deleted = false;
+    // scratch
+    DevBuf part_keys, part_cnt, dQ, d_dist, d_lab, d_cnt, d_mask, d_rows, d_q1, d_out1;
+
+    bool find_row(uint64_t label, uint32_t& row) const {
+        if (identity) { if (label < n_rows) { row = (uint32_t)label; return true; } return false; }
+        auto it = row_of.find(label);
+        if (it == row_of.end()) return false;
+        row = it->second;
+        return true;
+    }
+    void break_identity() {
+        if (!identity) return;
+        row_of.reserve(h_labels.size() * 2);
+        for (size_t r = 0; r < h_labels.size(); r++) row_of.emplace(h_labels[r], (uint32_t)r);
+        identity = false;
+    }
+    void release() {
+        DevBuf* b[] = {&X, &labels, &row_ok, &part_keys, &part_cnt, &dQ, &d_dist, &d_lab, &d_cnt, &d_mask, &d_rows, &d_q1, &d_out1};
+        for (auto* x : b) x->release();
+    }
+};
+
+static int vec_reserve_rows(VecField* f, uint64_t rows, hipStream_t s) {
+    if (rows <= f->cap_rows) return TSGPU_OK;
+    uint64_t want = std::max<uint64_t>(rows, f->cap_rows + f->cap_rows / 2 + 1024);
+    DevBuf nx, nl, no;
+    int rc;
+    if ((rc = nx.reserve((size_t)want * f->dim * 4))) return rc;
+    if ((rc = nl.reserve((size_t)want * 8))) { nx.release(); return rc; }
+    if ((rc = no.reserve((size_t)want))) { nx.release(); nl.release(); return rc; }
+    if (f->n_rows) {
+        TSGPU_HIP_TRY(hipMemcpyAsync(nx.p, f->X.p, (size_t)f->n_rows * f->dim * 4, hipMemcpyDeviceToDevice, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(nl.p, f->labels.p, (size_t)f->n_rows * 8, hipMemcpyDeviceToDevice, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(no.p, f->row_ok.p, (size_t)f->n_rows, hipMemcpyDeviceToDevice, s));
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+    }
+    f->X.release(); f->labels.release(); f->row_ok.release();
+    f->X = nx; f->labels = nl; f->row_ok = no;
+    f->cap_rows = want;
+    return TSGPU_OK;
 }
+
+static VecField* get_field(tsgpu_ctx* ctx, uint32_t id) {
+    auto it = ctx->vec_fields.find(id);
+    return it == ctx->vec_fields.end() ? nullptr : it->second;
+}
+
+// the exact k-NN launch sequence; caller holds ctx->mu. Q_dev: [n_q][dim] on the device (already normalised for cosine).
+static int knn_device(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, uint32_t n_q, uint32_t k, const uint8_t* mask_dev,
+                      float* dist_dev, uint64_t* label_dev, uint32_t* cnt_dev) {
+    hipStream_t s = ctx->stream;
+    const bool small_k = k <= 128;
+    const uint32_t QT = small_k ? 64 : 32, KL = small_k ? 128 : 256;
+    const uint32_t n_qtiles = (n_q + QT - 1) / QT;
+    const uint32_t n_rows = (uint32_t)f->n_rows;
+    uint32_t rows_per_slab;
+    if (ctx->vec_rows_per_slab) rows_per_slab = ctx->vec_rows_per_slab;
+    else {
+        uint32_t target_slabs = std::max<uint32_t>(8, (1024 + n_qtiles - 1) / n_qtiles);
+        rows_per_slab = (n_rows + target_slabs - 1) / target_slabs;
+    }
+    rows_per_slab = std::max<uint32_t>(VEC_ROWS, (rows_per_slab + VEC_ROWS - 1) / VEC_ROWS * VEC_ROWS);
+    uint32_t n_slabs = (n_rows + rows_per_slab - 1) / rows_per_slab;
+    n_slabs = std::max<uint32_t>(8, (n_slabs + 7) / 8 * 8);
+    const size_t qstride = (size_t)n_qtiles * QT;
+    int rc;
+    if ((rc = f->part_keys.reserve((size_t)n_slabs * qstride * KL * 8))) return rc;
+    if ((rc = f->part_cnt.reserve((size_t)n_slabs * qstride * 4))) return rc;
+    VecKnnArgs a;
+    a.X = f->X.as<float>();
+    a.row_ok = mask_dev;
+    a.Q = Q_dev;
+    a.n_rows = n_rows; a.dim = f->dim; a.n_q = n_q;
+    a.rows_per_slab = rows_per_slab; a.n_slabs = n_slabs; a.n_qtiles = n_qtiles;
+    a.part_keys = f->part_keys.as<uint64_t>();
+    a.part_cnt = f->part_cnt.as<uint32_t>();
+    TSGPU_HIP_TRY(hipEventRecord(ctx->ev[3], s));
+    if (small_k) hipLaunchKernelGGL((vec_knn_kernel<64, 128>), dim3(n_slabs * n_qtiles), dim3(VEC_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((vec_knn_kernel<32, 256>), dim3(n_slabs * n_qtiles), dim3(VEC_THREADS), 0, s, a);
+    TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s));
+    if (small_k)
+        hipLaunchKernelGGL((vec_merge_kernel<128, 2048>), dim3(n_q), dim3(VEC_THREADS), 0, s, a.part_keys, a.part_cnt, n_slabs, (uint32_t)qstride, k,
+                           f->labels.as<uint64_t>(), dist_dev, label_dev, cnt_dev);
+    else
+        hipLaunchKernelGGL((vec_merge_kernel<256, 2048>), dim3(n_q), dim3(VEC_THREADS), 0, s, a.part_keys, a.part_cnt, n_slabs, (uint32_t)qstride, k,
+                           f->labels.as<uint64_t>(), dist_dev, label_dev, cnt_dev);
+    TSGPU_HIP_TRY(hipEventRecord(ctx->ev[5], s));
+    TSGPU_HIP_TRY(hipGetLastError());
+    ctx->timings.vec_flops = 2ull * n_rows * f->dim * n_q;
+    return TSGPU_OK;
+}
+
+static void knn_collect_timings(tsgpu_ctx* ctx) {
+    float a = 0, b = 0;
+    (void)hipEventElapsedTime(&a, ctx->ev[3], ctx->ev[4]);
+    (void)hipEventElapsedTime(&b, ctx->ev[4], ctx->ev[5]);
+    ctx->timings.vec_knn_ms = a;
+    ctx->timings.vec_merge_ms = b;
+    ctx->timings.total_ms = a + b;
+}
+
+// row mask for deleted rows / allow list / excluded ids; returns nullptr (all rows ok) when nothing restricts
+static int build_mask(tsgpu_ctx* ctx, VecField* f, const uint32_t* allow_ids, uint32_t n_allow, const uint32_t* excluded_ids,
+                      uint32_t n_excluded, const uint8_t** mask_dev) {
+    *mask_dev = nullptr;
+    if (!f->any_deleted && !allow_ids && n_excluded == 0) return TSGPU_OK;
+    if (!allow_ids && n_excluded == 0) { *mask_dev = f->row_ok.as<uint8_t>(); return TSGPU_OK; }
+    std::vector<uint8_t> m(f->n_rows, allow_ids ? 0 : 1);
+    uint32_t row;
+    if (allow_ids) for (uint32_t i = 0; i < n_allow; i++) if (f->find_row(allow_ids[i], row)) m[row] = 1;
+    for (uint32_t i = 0; i < n_excluded; i++) if (f->find_row(excluded_ids[i], row)) m[row] = 0;
+    if (f->any_deleted) for (size_t r = 0; r < f->n_rows; r++) if (!f->h_ok[r]) m[r] = 0;
+    int rc = f->d_mask.reserve(std::max<size_t>(m.size(), 1));
+    if (rc) return rc;
+    if (!m.empty()) TSGPU_HIP_TRY(hipMemcpyAsync(f->d_mask.p, m.data(), m.size(), hipMemcpyHostToDevice, ctx->stream));
+    TSGPU_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *mask_dev = f->d_mask.as<uint8_t>();
+    return TSGPU_OK;
+}
+
+// queries on the device, normalised for cosine fields (src/index.cpp:3381-3384)
+static int stage_queries(tsgpu_ctx* ctx, VecField* f, const float* Q, int mem_q, uint32_t n_q, const float** Q_dev) {
+    hipStream_t s = ctx->stream;
+    const size_t bytes = (size_t)n_q * f->dim * 4;
+    if (mem_q == TSGPU_MEM_DEVICE && f->metric != TSGPU_METRIC_COSINE) { *Q_dev = Q; return TSGPU_OK; }
+    int rc = f->dQ.reserve(std::max<size_t>(bytes, 16));
+    if (rc) return rc;
+    TSGPU_HIP_TRY(hipMemcpyAsync(f->dQ.p, Q, bytes, mem_q == TSGPU_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    if (f->metric == TSGPU_METRIC_COSINE)
+        hipLaunchKernelGGL(vec_normalize_rows_kernel, dim3((n_q + 63) / 64), dim3(64), 0, s, f->dQ.as<float>(), n_q, f->dim);
+    *Q_dev = f->dQ.as<float>();
+    return TSGPU_OK;
+}
+
+struct KnnHost { std::vector<float> dist; std::vector<uint64_t> lab; std::vector<uint32_t> cnt; };
+
+// knn with host results (used by the vector-search and hybrid entry points); takes the lock itself
+static int knn_to_host(tsgpu_ctx* ctx, uint32_t field_id, const float* Q, int mem_q, uint32_t n_q, uint32_t k,
+                       const uint32_t* allow, uint32_t n_allow, const uint32_t* excl, uint32_t n_excl, KnnHost& out) {
+    out.dist.assign((size_t)n_q * k, 0.f);
+    out.lab.assign((size_t)n_q * k, 0);
+    out.cnt.assign(n_q, 0);
+    return tsgpu_vec_knn_batch(ctx, field_id, Q, mem_q, n_q, k, allow, n_allow, excl, n_excl, out.dist.data(), out.lab.data(), out.cnt.data(),
+                               TSGPU_MEM_HOST);
+}
+
+// compute_sort_scores (src/index.cpp:5662-5907) for an already-found hit, on the host mirror of the columns
+static void host_sort_scores(tsgpu_ctx* ctx, const tsgpu_sort_by* sort, uint32_t n_sort, uint64_t seq_id, int64_t max_field_match_score,
+                             float vector_distance, int64_t* scores, int64_t& match_score_index) {
+    for (uint32_t i = 0; i < n_sort && i < 3; i++) {
+        int64_t v = 0;
+        switch (sort[i].kind) {
+            case TSGPU_SORT_TEXT_MATCH: v = max_field_match_score; match_score_index = i; break;
+            case TSGPU_SORT_SEQ_ID: v = (int64_t)seq_id; break;
+            case TSGPU_SORT_VECTOR_DISTANCE: v = float_to_int64(vector_distance); break;
+            default: {
+                const uint32_t c = sort[i].column;
+                v = (c < ctx->columns.size() && seq_id < ctx->columns[c].host.size()) ? ctx->columns[c].host[seq_id] : INT64_MIN;
+            }
+        }
+        if (sort[i].order == -1) v = (int64_t)(0ull - (uint64_t)v);
+        scores[i] = v;
+    }
+}
+
+static void write_hits(const HostTopster& t, uint32_t q, tsgpu_hits* out) {
+    const size_t base = (size_t)q * out->k_stride;
+    const uint32_t n = std::min<uint32_t>(t.size, out->k_stride);
+    for (uint32_t i = 0; i < n; i++) {
+        const HostKV* kv = t.kvs[i];
+        out->keys[base + i] = kv->key;
+        for (int j = 0; j < 3; j++) out->scores[(base + i) * 3 + j] = kv->scores[j];
+        if (out->text_match) out->text_match[base + i] = kv->text_match_score;
+        if (out->vector_distance) out->vector_distance[base + i] = kv->vector_distance;
+        if (out->match_score_index) out->match_score_index[base + i] = kv->match_score_index;
+    }
+    out->n_hits[q] = n;
+}
+
+}  // namespace tsgpu
+
+extern "C" {
+
+void tsgpu_vec_destroy_all(tsgpu_ctx* ctx) {
+    for (auto& kv : ctx->vec_fields) { kv.second->release(); delete kv.second; }
+    ctx->vec_fields.clear();
+}
+
+uint64_t tsgpu_vec_device_bytes(tsgpu_ctx* ctx) {
+    uint64_t b = 0;
+    for (auto& kv : ctx->vec_fields) b += kv.second->X.cap + kv.second->labels.cap + kv.second->row_ok.cap;
+    return b;
+}
+
+int tsgpu_vec_create(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t dim, int metric, uint64_t capacity_hint) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    if (dim == 0 || dim > 65536) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_create: bad dim");
+    if (metric != TSGPU_METRIC_IP && metric != TSGPU_METRIC_COSINE) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_create: metric must be ip or cosine (include/field.h:92-95)");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (ctx->vec_fields.count(vec_field_id)) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_create: field exists");
+    VecField* f = new (std::nothrow) VecField;
+    if (!f) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_create: host allocation failed");
+    f->dim = dim;
+    f->metric = metric;
+    int rc = vec_reserve_rows(f, std::max<uint64_t>(capacity_hint, 16), ctx->stream);   // include/index.h:367: init capacity 16
+    if (rc) { f->release(); delete f; return rc; }
+    ctx->vec_fields[vec_field_id] = f;
+    return ok();
+}
+
+int tsgpu_vec_upsert(tsgpu_ctx* ctx, uint32_t vec_field_id, const uint64_t* labels, const float* data, uint32_t n, int mem) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    if (n == 0) return ok();
+    if (!labels || !data) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_upsert: NULL array");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    VecField* f = get_field(ctx, vec_field_id);
+    if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_upsert: unknown vector field");
+    hipStream_t s = ctx->stream;
+    try {
+        std::vector<uint64_t> hl(n);
+        if (mem == TSGPU_MEM_DEVICE) TSGPU_HIP_TRY(hipMemcpy(hl.data(), labels, (size_t)n * 8, hipMemcpyDeviceToHost));
+        else std::copy(labels, labels + n, hl.begin());
+        // fast path: n brand-new labels continuing the identity numbering -> one bulk append
+        bool bulk = true;
+        for (uint32_t i = 0; i < n && bulk; i++) {
+            uint32_t row;
+            if (f->identity) bulk = hl[i] == f->n_rows + i;
+            else bulk = !f->find_row(hl[i], row);
+        }
+        if (!f->identity && bulk) {   // all new, but check duplicates inside the batch
+            std::vector<uint64_t> tmp(hl);
+            std::sort(tmp.begin(), tmp.end());
+            bulk = std::adjacent_find(tmp.begin(), tmp.end()) == tmp.end();
+        }
+        if (f->n_rows + n > 0xFFFFFFF0ull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_upsert: more than 2^32 rows");
+        const hipMemcpyKind kind = mem == TSGPU_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        if (bulk) {
+            int rc = vec_reserve_rows(f, f->n_rows + n, s);
+            if (rc) return rc;
+            float* dst = f->X.as<float>() + (size_t)f->n_rows * f->dim;
+            TSGPU_HIP_TRY(hipMemcpyAsync(dst, data, (size_t)n * f->dim * 4, kind, s));
+            if (f->metric == TSGPU_METRIC_COSINE)   // src/index.cpp:1049-1052
+                hipLaunchKernelGGL(vec_normalize_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, s, dst, n, f->dim);
+            TSGPU_HIP_TRY(hipMemcpyAsync(f->labels.as<uint64_t>() + f->n_rows, hl.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+            TSGPU_HIP_TRY(hipMemsetAsync(f->row_ok.as<uint8_t>() + f->n_rows, 1, n, s));
+            TSGPU_HIP_TRY(hipStreamSynchronize(s));
+            if (!f->identity) for (uint32_t i = 0; i < n; i++) f->row_of.emplace(hl[i], (uint32_t)(f->n_rows + i));
+            f->h_labels.insert(f->h_labels.end(), hl.begin(), hl.end());
+            f->h_ok.insert(f->h_ok.end(), n, 1);
+            f->n_rows += n;
+            f->n_live += n;
+        } else {
+            f->break_identity();
+            for (uint32_t i = 0; i < n; i++) {
+                uint32_t row;
+                const bool exists = f->find_row(hl[i], row);
+                if (!exists) {
+                    int rc = vec_reserve_rows(f, f->n_rows + 1, s);
+                    if (rc) return rc;
+                    row = (uint32_t)f->n_rows++;
+                    f->row_of.emplace(hl[i], row);
+                    f->h_labels.push_back(hl[i]);
+                    f->h_ok.push_back(1);
+                    f->n_live++;
+                    TSGPU_HIP_TRY(hipMemcpyAsync(f->labels.as<uint64_t>() + row, &hl[i], 8, hipMemcpyHostToDevice, s));
+                } else if (!f->h_ok[row]) { f->h_ok[row] = 1; f->n_live++; }   // addPoint on a deleted label revives it
+                float* dst = f->X.as<float>() + (size_t)row * f->dim;
+                TSGPU_HIP_TRY(hipMemcpyAsync(dst, data + (size_t)i * f->dim, (size_t)f->dim * 4, kind, s));
+                if (f->metric == TSGPU_METRIC_COSINE)
+                    hipLaunchKernelGGL(vec_normalize_rows_kernel, dim3(1), dim3(64), 0, s, dst, 1u, f->dim);
+                TSGPU_HIP_TRY(hipMemsetAsync(f->row_ok.as<uint8_t>() + row, 1, 1, s));
+                TSGPU_HIP_TRY(hipStreamSynchronize(s));
+            }
+        }
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_upsert: host allocation failed"); }
+    return ok();
+}
+
+int tsgpu_vec_delete(tsgpu_ctx* ctx, uint32_t vec_field_id, uint64_t label) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    VecField* f = get_field(ctx, vec_field_id);
+    if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_delete: unknown vector field");
+    uint32_t row;
+    if (!f->find_row(label, row) || !f->h_ok[row]) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_delete: label not found");   // markDelete throws
+    f->h_ok[row] = 0;
+    f->any_deleted = true;
+    f->n_live--;
+    TSGPU_HIP_TRY(hipMemset(f->row_ok.as<uint8_t>() + row, 0, 1));
+    return ok();
+}
+
+int tsgpu_vec_get(tsgpu_ctx* ctx, uint32_t vec_field_id, uint64_t label, float* out_host) {
+    if (!ctx || !out_host) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_get: NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    VecField* f = get_field(ctx, vec_field_id);
+    if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_get: unknown vector field");
+    uint32_t row;
+    if (!f->find_row(label, row) || !f->h_ok[row]) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_get: label not found");
+    TSGPU_HIP_TRY(hipMemcpy(out_host, f->X.as<float>() + (size_t)row * f->dim, (size_t)f->dim * 4, hipMemcpyDeviceToHost));
+    return ok();
+}
+
+uint64_t tsgpu_vec_count(tsgpu_ctx* ctx, uint32_t vec_field_id) {
+    if (!ctx) return 0;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    VecField* f = get_field(ctx, vec_field_id);
+    return f ? f->n_rows : 0;      // getCurrentElementCount counts deleted slots too
+}
+
+int tsgpu_vec_knn_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, int mem_q, uint32_t n_q, uint32_t k, const uint32_t* allow_ids,
+                        uint32_t n_allow, const uint32_t* excluded_ids, uint32_t n_excluded, float* dist_out, uint64_t* label_out,
+                        uint32_t* n_out, int mem_out) {
+    if (!ctx || !Q || !dist_out || !label_out || !n_out) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_knn_batch: NULL argument");
+    if (n_q == 0) return ok();
+    if (k == 0) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_knn_batch: k must be > 0");
+    if (k > 256) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_knn_batch: k > 256 is not accelerated");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    VecField* f = get_field(ctx, vec_field_id);
+    if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_knn_batch: unknown vector field");
+    hipStream_t s = ctx->stream;
+    try {
+        const float* Q_dev = nullptr;
+        int rc = stage_queries(ctx, f, Q, mem_q, n_q, &Q_dev);
+        if (rc) return rc;
+        const uint8_t* mask = nullptr;
+        if ((rc = build_mask(ctx, f, allow_ids, n_allow, excluded_ids, n_excluded, &mask))) return rc;
+        float* d_dist = dist_out;
+        uint64_t* d_lab = label_out;
+        uint32_t* d_cnt = n_out;
+        if (mem_out != TSGPU_MEM_DEVICE) {
+            if ((rc = f->d_dist.reserve((size_t)n_q * k * 4))) return rc;
+            if ((rc = f->d_lab.reserve((size_t)n_q * k * 8))) return rc;
+            if ((rc = f->d_cnt.reserve((size_t)n_q * 4))) return rc;
+            d_dist = f->d_dist.as<float>(); d_lab = f->d_lab.as<uint64_t>(); d_cnt = f->d_cnt.as<uint32_t>();
+        }
+        if (f->n_rows == 0) {
+            TSGPU_HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)n_q * 4, s));
+        } else if ((rc = knn_device(ctx, f, Q_dev, n_q, k, mask, d_dist, d_lab, d_cnt))) return rc;
+        if (mem_out != TSGPU_MEM_DEVICE) {
+            TSGPU_HIP_TRY(hipMemcpyAsync(dist_out, d_dist, (size_t)n_q * k * 4, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(label_out, d_lab, (size_t)n_q * k * 8, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(n_out, d_cnt, (size_t)n_q * 4, hipMemcpyDeviceToHost, s));
+        }
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        if (f->n_rows) knn_collect_timings(ctx);
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_knn_batch: host allocation failed"); }
+    return ok();
+}
+
+int tsgpu_vec_distances(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* q, const uint64_t* labels, uint32_t n, float* dist_out) {
+    if (!ctx || !q || (n && (!labels || !dist_out))) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_distances: NULL argument");
+    if (n == 0) return ok();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    VecField* f = get_field(ctx, vec_field_id);
+    if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_distances: unknown vector field");
+    hipStream_t s = ctx->stream;
+    try {
+        std::vector<uint32_t> rows(n);
+        for (uint32_t i = 0; i < n; i++) { uint32_t r; rows[i] = (f->find_row(labels[i], r) && f->h_ok[r]) ? r : 0xFFFFFFFFu; }
+        int rc;
+        if ((rc = f->d_rows.reserve((size_t)n * 4))) return rc;
+        if ((rc = f->d_q1.reserve((size_t)f->dim * 4))) return rc;
+        if ((rc = f->d_out1.reserve((size_t)n * 4))) return rc;
+        TSGPU_HIP_TRY(hipMemcpyAsync(f->d_rows.p, rows.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(f->d_q1.p, q, (size_t)f->dim * 4, hipMemcpyHostToDevice, s));
+        if (f->metric == TSGPU_METRIC_COSINE)   // the reference re-normalises q inside its loop (src/index.cpp:3362-3366)
+            hipLaunchKernelGGL(vec_normalize_rows_kernel, dim3(1), dim3(64), 0, s, f->d_q1.as<float>(), 1u, f->dim);
+        hipLaunchKernelGGL(vec_row_distances_kernel, dim3((n + 3) / 4), dim3(256), 0, s, f->X.as<float>(), f->d_q1.as<float>(), f->dim,
+                           f->d_rows.as<uint32_t>(), n, f->d_out1.as<float>());
+        TSGPU_HIP_TRY(hipMemcpyAsync(dist_out, f->d_out1.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_distances: host allocation failed"); }
+    return ok();
+}
+
+// pure vector search, src/index.cpp:3645-3732
+int tsgpu_vector_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const tsgpu_vec_query* p, const float* Q, int mem_q, uint32_t n_q,
+                              tsgpu_hits* out) {
+    if (!ctx || !p || !Q || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_vector_search_batch: NULL argument");
+    if (out->mem != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vector_search_batch: host outputs only");
+    if (n_q == 0) return ok();
+    if (p->n_sort > 3) return fail(TSGPU_ERR_INVALID, "tsgpu_vector_search_batch: more than 3 sort keys");
+    VecField* f;
+    uint32_t num_docs;
+    { std::lock_guard<std::mutex> lk(ctx->mu); f = get_field(ctx, vec_field_id); num_docs = ctx->num_docs; }
+    if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vector_search_batch: unknown vector field");
+    const uint32_t k = p->k == 0 ? std::max<uint32_t>(p->k, p->fetch_size) : p->k;   // :3646
+    if (k == 0) return fail(TSGPU_ERR_INVALID, "tsgpu_vector_search_batch: k and fetch_size are both 0");
+    try {
+        KnnHost kh;
+        int rc = knn_to_host(ctx, vec_field_id, Q, mem_q, n_q, k, nullptr, 0, nullptr, 0, kh);
+        if (rc) return rc;
+        uint32_t tsz = p->topster_size ? p->topster_size : std::max<uint32_t>(p->fetch_size, TSGPU_DEFAULT_TOPSTER_SIZE);
+        if (!p->topster_size) tsz = std::max<uint32_t>(1, std::min<uint32_t>(tsz, std::max<uint32_t>(num_docs, (uint32_t)f->n_rows)));
+        if (out->k_stride < std::min<uint32_t>(tsz, k)) return fail(TSGPU_ERR_INVALID, "tsgpu_vector_search_batch: k_stride too small");
+        std::vector<std::pair<uint64_t, float>> hits;
+        for (uint32_t q = 0; q < n_q; q++) {
+            HostTopster topster(tsz);
+            hits.clear();
+            for (uint32_t i = 0; i < kh.cnt[q]; i++) hits.emplace_back(kh.lab[(size_t)q * k + i], kh.dist[(size_t)q * k + i]);
+            std::sort(hits.begin(), hits.end(), [](const auto& a, const auto& b) { return a.first < b.first; });   // :3389
+            uint64_t added = 0;
+            for (auto& h : hits) {
+                const float d = f->metric == TSGPU_METRIC_COSINE ? std::fabs(h.second) : h.second;   // :3699
+                if (d > p->distance_threshold) continue;                                               // :3702
+                HostKV kv;
+                int64_t msi = -1;
+                host_sort_scores(ctx, p->sort, p->n_sort, h.first, 0, d, kv.scores, msi);
+                kv.match_score_index = (int8_t)msi;
+                kv.key = h.first;
+                kv.vector_distance = d;
+                if (msi >= 0) kv.text_match_score = kv.scores[msi];
+                topster.add(&kv);
+                added++;
+            }
+            topster.sort();
+            write_hits(topster, q, out);
+            if (out->num_matched) out->num_matched[q] = added;
+            out->status[q] = TSGPU_OK;
+            if (out->search_cutoff) out->search_cutoff[q] = 0;
+        }
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vector_search_batch: host allocation failed"); }
+    return ok();
+}
+
+// hybrid, src/index.cpp:4036-4221: keyword pass -> exact k-NN -> reciprocal rank fusion on the sorted Topster
+int tsgpu_hybrid_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t vec_field_id, const tsgpu_hybrid_params* p,
+                              const float* Q, int mem_q, uint32_t n_queries, tsgpu_hits* out) {
+    if (!ctx || !queries || !p || !Q || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_hybrid_search_batch: NULL argument");
+    if (out->mem != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_hybrid_search_batch: host outputs only");
+    if (n_queries == 0) return ok();
+    VecField* f;
+    { std::lock_guard<std::mutex> lk(ctx->mu); f = get_field(ctx, vec_field_id); }
+    if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_hybrid_search_batch: unknown vector field");
+    const uint32_t k = p->k == 0 ? std::max<uint32_t>(p->fetch_size, 100) : p->k;   // :4060-4063
+    try {
+        // 1) keyword pass on the GPU -> Topster contents in sort() order
+        uint32_t KS = out->k_stride;
+        std::vector<uint64_t> keys((size_t)n_queries * KS);
+        std::vector<int64_t> scores((size_t)n_queries * KS * 3), tm((size_t)n_queries * KS);
+        std::vector<float> vd((size_t)n_queries * KS);
+        std::vector<int8_t> msi((size_t)n_queries * KS);
+        std::vector<uint32_t> nh(n_queries);
+        std::vector<uint64_t> nm(n_queries);
+        std::vector<int32_t> st(n_queries), co(n_queries);
+        tsgpu_hits kw;
+        kw.mem = TSGPU_MEM_HOST; kw.k_stride = KS;
+        kw.keys = keys.data(); kw.scores = scores.data(); kw.text_match = tm.data(); kw.vector_distance = vd.data();
+        kw.match_score_index = msi.data(); kw.n_hits = nh.data(); kw.num_matched = nm.data(); kw.status = st.data(); kw.search_cutoff = co.data();
+        int rc = tsgpu_keyword_search_batch(ctx, queries, n_queries, &kw);
+        if (rc) return rc;
+        // 2) vector pass: one batched exact k-NN (filters / exclusions are per query -> not batched: unsupported in v1)
+        for (uint32_t q = 0; q < n_queries; q++)
+            if (st[q] == TSGPU_OK && (queries[q].n_excluded || queries[q].n_filter)) st[q] = TSGPU_ERR_UNSUPPORTED;
+        KnnHost kh;
+        if ((rc = knn_to_host(ctx, vec_field_id, Q, mem_q, n_queries, k, nullptr, 0, nullptr, 0, kh))) return rc;
+        // 3) fusion on the host, exactly as the reference
+        const float VECTOR_SEARCH_WEIGHT = p->alpha;
+        const float TEXT_MATCH_WEIGHT = 1.0 - VECTOR_SEARCH_WEIGHT;
+        std::vector<HostKV> sorted;
+        struct VH { float dist; uint64_t seq_id; };
+        std::vector<VH> dist_results;
+        std::unordered_map<uint64_t, uint32_t> seq_id_to_rank;
+        for (uint32_t q = 0; q < n_queries; q++) {
+            out->status[q] = st[q];
+            if (out->search_cutoff) out->search_cutoff[q] = co[q];
+            if (st[q] != TSGPU_OK) { out->n_hits[q] = 0; if (out->num_matched) out->num_matched[q] = 0; continue; }
+            const tsgpu_kw_query& kq = queries[q];
+            uint32_t tsz = kq.topster_size ? kq.topster_size : TSGPU_DEFAULT_TOPSTER_SIZE;
+            tsz = std::max<uint32_t>(1, std::min<uint32_t>(tsz, std::max<uint32_t>(ctx->num_docs, 1)));
+            HostTopster topster(tsz);
+            sorted.resize(nh[q]);
+            for (uint32_t i = 0; i < nh[q]; i++) {
+                const size_t s = (size_t)q * KS + i;
+                HostKV& kv = sorted[i];
+                kv.key = keys[s];
+                for (int j = 0; j < 3; j++) kv.scores[j] = scores[s * 3 + j];
+                kv.match_score_index = msi[s];
+                kv.text_match_score = tm[s];
+                kv.vector_distance = -1.0f;
+            }
+            topster.adopt_sorted(sorted.data(), nh[q]);
+            // vector hits: label order, threshold, then distance order (src/index.cpp:3389, 3414-3437)
+            dist_results.clear();
+            for (uint32_t i = 0; i < kh.cnt[q]; i++) dist_results.push_back({kh.dist[(size_t)q * k + i], kh.lab[(size_t)q * k + i]});
+            std::sort(dist_results.begin(), dist_results.end(), [](const VH& a, const VH& b) { return a.seq_id < b.seq_id; });
+            {
+                std::vector<VH> kept;
+                for (auto& r : dist_results) {
+                    const float sc = f->metric == TSGPU_METRIC_COSINE ? std::fabs(r.dist) : r.dist;
+                    if (sc > p->distance_threshold) continue;
+                    kept.push_back(r);
+                }
+                std::stable_sort(kept.begin(), kept.end(), [](const VH& a, const VH& b) { return a.dist < b.dist; });
+                dist_results.swap(kept);
+            }
+            seq_id_to_rank.clear();
+            for (size_t i = 0; i < dist_results.size(); i++) seq_id_to_rank.emplace(dist_results[i].seq_id, (uint32_t)i);
+            std::sort(dist_results.begin(), dist_results.end(), [](const VH& a, const VH& b) { return a.seq_id < b.seq_id; });
+            // text ranks (dense rank on score ties), :4094-4112
+            int64_t text_rank = 0, last_text_match_score = INT64_MAX;
+            for (uint32_t i = 0; i < topster.size; i++) {
+                HostKV* r = topster.kvs[i];
+                if (r->match_score_index < 0 || r->match_score_index > 2) continue;
+                r->text_match_score = r->scores[r->match_score_index];
+                if (r->text_match_score < last_text_match_score) ++text_rank;
+                last_text_match_score = r->text_match_score;
+                r->scores[r->match_score_index] = float_to_int64((1.0 / (text_rank)) * TEXT_MATCH_WEIGHT);
+            }
+            uint64_t vec_only = 0;
+            for (auto& dr : dist_results) {   // :4124-4211
+                const uint64_t seq_id = dr.seq_id;
+                auto it = topster.map.find(seq_id);
+                HostKV* found_kv = it == topster.map.end() ? nullptr : it->second;
+                if (found_kv) {
+                    if (found_kv->match_score_index < 0 || found_kv->match_score_index > 2) continue;
+                    found_kv->vector_distance = dr.dist;
+                    const int64_t match_score = float_to_int64((int64_to_float(found_kv->scores[found_kv->match_score_index])) +
+                                                               ((1.0 / (seq_id_to_rank[seq_id] + 1)) * VECTOR_SEARCH_WEIGHT));
+                    int64_t match_score_index = -1;
+                    int64_t sc[3] = {0, 0, 0};
+                    host_sort_scores(ctx, kq.sort, kq.n_sort, seq_id, match_score, dr.dist, sc, match_score_index);
+                    for (int j = 0; j < 3; j++) found_kv->scores[j] = sc[j];
+                    found_kv->match_score_index = (int8_t)match_score_index;
+                } else {
+                    HostKV kv;
+                    const int64_t match_score = float_to_int64((1.0 / (seq_id_to_rank[seq_id] + 1)) * VECTOR_SEARCH_WEIGHT);
+                    int64_t match_score_index = -1;
+                    host_sort_scores(ctx, kq.sort, kq.n_sort, seq_id, match_score, dr.dist, kv.scores, match_score_index);
+                    kv.match_score_index = (int8_t)match_score_index;
+                    kv.key = seq_id;
+                    kv.text_match_score = 0;
+                    kv.vector_distance = dr.dist;
+                    topster.add(&kv);
+                    vec_only++;
+                }
+            }
+            topster.sort();
+            write_hits(topster, q, out);
+            if (out->num_matched) out->num_matched[q] = nm[q];
+            (void)vec_only;
+        }
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_hybrid_search_batch: host allocation failed"); }
+    return ok();
+}
+
+// exact merge of per-shard Topster lists (doc-range shards): same comparator as include/topster.h:146-149
+int tsgpu_merge_shard_hits(const tsgpu_hits* in, const uint64_t* key_offset, uint32_t n_shards, uint32_t n_queries, uint32_t k, tsgpu_hits* out) {
+    if (!in || !out || n_shards == 0) return fail(TSGPU_ERR_INVALID, "tsgpu_merge_shard_hits: NULL argument");
+    if (out->k_stride < k) return fail(TSGPU_ERR_INVALID, "tsgpu_merge_shard_hits: k_stride < k");
+    for (uint32_t g = 0; g < n_shards; g++) if (in[g].mem != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_merge_shard_hits: host inputs only");
+    try {
+        std::vector<HostKV> all;
+        for (uint32_t q = 0; q < n_queries; q++) {
+            all.clear();
+            uint64_t nm = 0;
+            int32_t st = TSGPU_OK, co = 0;
+            for (uint32_t g = 0; g < n_shards; g++) {
+                const tsgpu_hits& h = in[g];
+                if (h.status && h.status[q] != TSGPU_OK) st = h.status[q];
+                if (h.search_cutoff && h.search_cutoff[q]) co = 1;
+                if (h.num_matched) nm += h.num_matched[q];
+                for (uint32_t i = 0; i < h.n_hits[q]; i++) {
+                    const size_t s = (size_t)q * h.k_stride + i;
+                    HostKV kv;
+                    kv.key = h.keys[s] + (key_offset ? key_offset[g] : 0);
+                    for (int j = 0; j < 3; j++) kv.scores[j] = h.scores[s * 3 + j];
+                    kv.text_match_score = h.text_match ? h.text_match[s] : 0;
+                    kv.vector_distance = h.vector_distance ? h.vector_distance[s] : -1.0f;
+                    kv.match_score_index = h.match_score_index ? h.match_score_index[s] : 0;
+                    all.push_back(kv);
+                }
+            }
+            std::sort(all.begin(), all.end(), [](const HostKV& a, const HostKV& b) { return kv_greater(&a, &b); });
+            const uint32_t n = (uint32_t)std::min<size_t>(all.size(), k);
+            const size_t base = (size_t)q * out->k_stride;
+            for (uint32_t i = 0; i < n; i++) {
+                out->keys[base + i] = all[i].key;
+                for (int j = 0; j < 3; j++) out->scores[(base + i) * 3 + j] = all[i].scores[j];
+                if (out->text_match) out->text_match[base + i] = all[i].text_match_score;
+                if (out->vector_distance) out->vector_distance[base + i] = all[i].vector_distance;
+                if (out->match_score_index) out->match_score_index[base + i] = all[i].match_score_index;
+            }
+            out->n_hits[q] = n;
+            if (out->num_matched) out->num_matched[q] = nm;
+            if (out->status) out->status[q] = st;
+            if (out->search_cutoff) out->search_cutoff[q] = co;
+        }
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_merge_shard_hits: host allocation failed"); }
+    return ok();
+}
+
+}  // extern "C"

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(VEC_THREADS) void vec_knn_kernel(VecKnnArgs a) {
             const uint32_t again = sm.again;
             __syncthreads();
             if (t == 0) sm.again = 0;
+            __syncthreads();                 // the reset must not overtake the next round's "left" flag
             if (!again) break;
         }
     }
