@@ -1,0 +1,129 @@
+// tsgpu_hnsw_adaptor.h — header-only C++ adaptor with the method names Typesense calls on
+// hnswlib::HierarchicalNSW<float> / hnswlib::InnerProductSpace, implemented over the C-ABI (include/tsgpu.h).
+// With it, `struct hnsw_index_t` (reference include/index.h:356-370) changes by two typedefs:
+//
+//     tsgpu::InnerProductSpace*        space;    // was hnswlib::InnerProductSpace*
+//     tsgpu::HierarchicalNSW<float>*   vecdex;   // was hnswlib::HierarchicalNSW<float>*
+//
+// Call sites that keep compiling unchanged (reference file:line):
+//     new HierarchicalNSW<float>(space, init, M, ef_c, 100, true)            include/index.h:367
+//     vecdex->getCurrentElementCount(), getMaxElements(), resizeIndex(n)     src/index.cpp:1004-1006
+//     vecdex->addPoint(vec.data(), (size_t)seq_id, true)                     src/index.cpp:1052-1054
+//     vecdex->markDelete(seq_id)                                             src/index.cpp:7423
+//     vecdex->getDataByLabel<float>(seq_id)   (throws when missing)          src/index.cpp:3355-3359, 5840, 8860
+//     vecdex->searchKnnCloserFirst(q, k, ef, &filterFunctor)                 src/index.cpp:3384-3386
+//     space->get_dist_func()(a, b, &dim)                                     src/index.cpp:3365
+// Differences, all deliberate: the search is EXACT (ef, M, ef_construction are accepted and ignored: there is no
+// graph), cosine normalisation stays where the reference does it (caller side, src/index.cpp:1049-1052, 3381-3384),
+// and the filter functor is evaluated up front into an allow-list (it is a pure predicate over seq_ids).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+#include "../../../include/tsgpu.h"
+
+namespace tsgpu {
+
+typedef size_t labeltype;
+
+class BaseFilterFunctor {
+public:
+    virtual bool operator()(labeltype) { return true; }
+    virtual ~BaseFilterFunctor() {}
+};
+
+typedef float (*DISTFUNC)(const void*, const void*, const void*);
+
+// hnswlib's InnerProductSpace::get_dist_func contract for ONE pair on the host (by-id paths); the batched
+// scans go through tsgpu_vec_knn_batch / tsgpu_vec_distances on the GPU.
+inline float InnerProductDistance(const void* a, const void* b, const void* dim_ptr) {
+    const float* x = (const float*)a;
+    const float* y = (const float*)b;
+    const size_t d = *(const size_t*)dim_ptr;
+    float lanes[16] = {0};
+    size_t q16 = d >> 4 << 4, i = 0;
+    for (; i < q16; i += 16) for (int l = 0; l < 16; l++) lanes[l] += x[i + l] * y[i + l];
+    float s = 0;
+    for (int l = 0; l < 16; l++) s += lanes[l];
+    for (; i < d; i++) s += x[i] * y[i];
+    return 1.0f - s;
+}
+
+class InnerProductSpace {
+    size_t dim_;
+public:
+    explicit InnerProductSpace(size_t dim) : dim_(dim) {}
+    DISTFUNC get_dist_func() { return InnerProductDistance; }
+    void* get_dist_func_param() { return &dim_; }
+    size_t get_data_size() { return dim_ * sizeof(float); }
+    size_t dim() const { return dim_; }
+};
+
+template <typename dist_t>
+class HierarchicalNSW {
+    tsgpu_ctx* ctx_;
+    uint32_t field_;
+    size_t dim_;
+    size_t max_elements_;
+
+    static void check(int rc, const char* what) {
+        if (rc != TSGPU_OK) throw std::runtime_error(std::string(what) + ": " + tsgpu_last_error());
+    }
+
+public:
+    // ctx / field_id select the tsgpu vector field this index mirrors; the remaining arguments are hnswlib's
+    HierarchicalNSW(tsgpu_ctx* ctx, uint32_t field_id, InnerProductSpace* s, size_t max_elements, size_t /*M*/ = 16,
+                    size_t /*ef_construction*/ = 200, size_t /*random_seed*/ = 100, bool /*allow_replace_deleted*/ = false)
+        : ctx_(ctx), field_(field_id), dim_(s->dim()), max_elements_(max_elements) {
+        check(tsgpu_vec_create(ctx_, field_, (uint32_t)dim_, TSGPU_METRIC_IP, max_elements), "tsgpu_vec_create");
+    }
+
+    size_t getCurrentElementCount() { return (size_t)tsgpu_vec_count(ctx_, field_); }
+    size_t getMaxElements() { return max_elements_; }
+    void resizeIndex(size_t n) { max_elements_ = n; }       // storage grows on demand inside the library
+    void repair_zero_indegree() {}                          // no graph to repair
+
+    void addPoint(const void* data, labeltype label, bool /*replace_deleted*/ = false) {
+        uint64_t l = (uint64_t)label;
+        check(tsgpu_vec_upsert(ctx_, field_, &l, (const float*)data, 1, TSGPU_MEM_HOST), "tsgpu_vec_upsert");
+        if (getCurrentElementCount() > max_elements_) max_elements_ = getCurrentElementCount();
+    }
+
+    void markDelete(labeltype label) { check(tsgpu_vec_delete(ctx_, field_, (uint64_t)label), "tsgpu_vec_delete"); }
+
+    template <typename data_t>
+    std::vector<data_t> getDataByLabel(labeltype label) {
+        std::vector<float> v(dim_);
+        int rc = tsgpu_vec_get(ctx_, field_, (uint64_t)label, v.data());
+        if (rc != TSGPU_OK) throw std::runtime_error("Label not found");
+        return std::vector<data_t>(v.begin(), v.end());
+    }
+
+    // closest first; filter == nullptr -> whole index
+    std::vector<std::pair<dist_t, labeltype>> searchKnnCloserFirst(const void* query, size_t k, size_t /*ef*/ = 0,
+                                                                   BaseFilterFunctor* filter = nullptr,
+                                                                   const uint32_t* candidate_ids = nullptr, uint32_t n_candidates = 0) {
+        std::vector<uint32_t> allow;
+        const uint32_t* allow_ptr = nullptr;
+        uint32_t n_allow = 0;
+        if (filter && candidate_ids) {     // evaluate the predicate once per candidate instead of once per visited node
+            for (uint32_t i = 0; i < n_candidates; i++) if ((*filter)(candidate_ids[i])) allow.push_back(candidate_ids[i]);
+            allow_ptr = allow.data();
+            n_allow = (uint32_t)allow.size();
+            if (n_allow == 0) return {};
+        }
+        std::vector<float> dist(k);
+        std::vector<uint64_t> lab(k);
+        uint32_t n = 0;
+        check(tsgpu_vec_knn_batch(ctx_, field_, (const float*)query, TSGPU_MEM_HOST, 1, (uint32_t)k, allow_ptr, n_allow, nullptr, 0,
+                                  dist.data(), lab.data(), &n, TSGPU_MEM_HOST), "tsgpu_vec_knn_batch");
+        std::vector<std::pair<dist_t, labeltype>> out;
+        for (uint32_t i = 0; i < n; i++) out.emplace_back((dist_t)dist[i], (labeltype)lab[i]);
+        return out;
+    }
+};
+
+}  // namespace tsgpu

@@ -310,15 +310,18 @@ __global__ __launch_bounds__(VEC_THREADS) void vec_merge_kernel(const uint64_t* 
 
 // ------------------------------------------------------------------------------------------------
 // L2 normalisation exactly as hnsw_index_t::normalize_vector (include/index.h:379-388): sequential fp32 sum of
-// squares (mul and add rounded separately, like the reference's non-FMA x86 build), x * 1/(sqrt(sum)+1e-30)
+// squares with the multiply and the add rounded separately (the reference's generic x86-64 build has no FMA),
+// then x * 1/(sqrt(sum)+1e-30). sqrtf and '/' are correctly rounded under hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt; contraction is switched off for this function only.
 __global__ void vec_normalize_rows_kernel(float* __restrict__ X, uint32_t n_rows, uint32_t dim) {
+#pragma clang fp contract(off)
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     float* x = X + (size_t)r * dim;
     float norm = 0.0f;
-    for (uint32_t i = 0; i < dim; i++) norm = __fadd_rn(norm, __fmul_rn(x[i], x[i]));
-    norm = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(norm), 1e-30f));
-    for (uint32_t i = 0; i < dim; i++) x[i] = __fmul_rn(x[i], norm);
+    for (uint32_t i = 0; i < dim; i++) { const float sq = x[i] * x[i]; norm = norm + sq; }
+    norm = 1.0f / (sqrtf(norm) + 1e-30f);
+    for (uint32_t i = 0; i < dim; i++) x[i] = x[i] * norm;
 }
 
 // distances of one query to explicit rows: one wave per row, lane-strided partial sums (flat scan over filter
