@@ -16,7 +16,7 @@ for f in $SRCS "$ROOT"/typesense_amd/csrc/*.h "$ROOT"/include/*.h "$HERE"/hip/hi
   if [ ! -f "$OUT" ] || [ "$f" -nt "$OUT" ]; then NEWER=1; fi
 done
 if [ "$NEWER" = 1 ]; then
-  "$CXX" -x c++ -std=c++17 -O1 -g -fPIC -shared -ffp-contract=off -DTSGPU_HIP_EMU=1 -Wno-unused-value -Wno-macro-redefined \
+  "$CXX" -x c++ -std=c++17 -O1 -g -fPIC -shared -ffp-contract=off -DTSGPU_HIP_EMU=1 -Wno-unused-value -Wno-macro-redefined -Wno-psabi \
       -I "$HERE" -o "$OUT" $SRCS -lpthread
 fi
 echo "$OUT"

@@ -244,6 +244,7 @@ template <class T> inline T __shfl_up(T v, unsigned d, int = 64) { unsigned l = 
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T> inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 

@@ -76,6 +76,47 @@ def test_ties_prefer_smaller_label_and_many_slabs():
     g.close()
 
 
+@pytest.mark.parametrize("n,dim,k,nq,sample_tiles,cap", [
+    (1500, 32, 20, 3, 2, 0),        # sample pass (2 of 12 tiles) -> tau -> filtered pass over all rows
+    (1500, 32, 20, 70, 1, 0),       # QT=128 workgroup tile (n_q > 64), 1-tile sample
+    (1000, 20, 10, 2, 1, 24),       # tiny candidate arena: lists overflow, tighten their own tau, pass 2 repeats
+    (900, 36, 50, 4, 3, 0),
+])
+def test_knn_two_pass_threshold_path_is_exact(n, dim, k, nq, sample_tiles, cap):
+    """the 10M-row code path (sample -> threshold -> filtered scan -> radix select), forced at emulator sizes"""
+    g, orc, X, rng = _mk(n, dim, B.METRIC_IP, 11 + n, H.emu_lib_path())
+    g.set_option("vec_sample_tiles", sample_tiles)
+    if cap:
+        g.set_option("vec_cand_cap", cap)
+    Q = rng.standard_normal((nq, dim)).astype(np.float32)
+    _check_knn(g, orc, Q, k)
+    # deleted rows and an allow list must not leak into the threshold sample
+    g.vec_delete(1, 0)
+    g.vec_delete(1, 129)
+    dist, lab, cnt = g.vec_knn_batch(1, Q[:2], k)
+    assert cnt[0] == k and not ({0, 129} & set(lab[0].tolist()))
+    allow = np.sort(rng.choice(n, size=40, replace=False)).astype(np.uint32)
+    dist, lab, cnt = g.vec_knn_batch(1, Q[:2], k, allow_ids=allow)
+    ok_ids = set(allow.tolist()) - {0, 129}
+    assert cnt[0] == min(k, len(ok_ids)) and set(lab[0, :cnt[0]].tolist()) <= ok_ids
+    g.close()
+
+
+def test_knn_two_pass_all_equal_distances_converges():
+    """adversarial ties: every row identical -> every key passes a distance-only filter; keys (dist,row) still converge"""
+    lib = H.emu_lib_path()
+    X = np.ones((700, 16), np.float32)
+    g = T.GpuIndex(0, lib)
+    g.set_option("vec_sample_tiles", 1)
+    g.set_option("vec_cand_cap", 40)
+    g.vec_create(1, 16, B.METRIC_IP)
+    g.vec_upsert(1, np.arange(700, dtype=np.uint64), X)
+    dist, lab, cnt = g.vec_knn_batch(1, np.ones((2, 16), np.float32), 15)
+    assert (cnt == 15).all() and np.array_equal(lab[0], np.arange(15, dtype=np.uint64))      # ties -> smaller label first
+    assert np.allclose(dist, -15.0)
+    g.close()
+
+
 def test_upsert_delete_labels_filters_and_by_id_distances():
     lib = H.emu_lib_path()
     rng = np.random.default_rng(4)

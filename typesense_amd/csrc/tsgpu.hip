@@ -323,6 +323,16 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
         ctx->vec_rows_per_slab = (uint32_t)value;
         return ok();
     }
+    if (!strcmp(name, "vec_sample_tiles")) {
+        if (value < 1 || value > (1 << 20)) return fail(TSGPU_ERR_INVALID, "vec_sample_tiles out of range");
+        ctx->vec_sample_tiles = (uint32_t)value;
+        return ok();
+    }
+    if (!strcmp(name, "vec_cand_cap")) {
+        if (value < 0 || value > (1 << 24)) return fail(TSGPU_ERR_INVALID, "vec_cand_cap out of range");
+        ctx->vec_cand_cap = (uint32_t)value;
+        return ok();
+    }
     return fail(TSGPU_ERR_NOT_FOUND, std::string("tsgpu_set_option: unknown option ") + name);
 }
 

@@ -103,6 +103,9 @@ struct tsgpu_ctx {
     uint32_t kw_chunk_blocks = 64;                   // driver blocks per work item (64 -> 16K candidate ids)
     uint32_t last_chunk_blocks = 64;
     uint32_t vec_rows_per_slab = 0;                  // 0 = automatic
+    uint32_t vec_sample_tiles = 512;                 // 128-row tiles of the threshold sample (pass 1 of the k-NN)
+    uint32_t vec_cand_cap = 0;                       // candidate slots per query in pass 2 (0 = automatic)
+    uint64_t vec_overflow_rounds = 0;                // pass-2 repeats caused by candidate overflow (introspection)
     std::vector<uint64_t> last_ids_off;              // per query offset into d_ids_out of the last batch
     std::vector<uint64_t> last_ids_cap;
     std::vector<std::vector<uint32_t>> last_chunk_emit;  // filled lazily by tsgpu_result_ids

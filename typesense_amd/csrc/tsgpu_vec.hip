@@ -23,7 +23,7 @@ struct VecField {
     std::unordered_map<uint64_t, uint32_t> row_of;     // materialised when identity breaks
     bool any_deleted = false;
     // scratch
-    DevBuf part_keys, part_cnt, dQ, d_dist, d_lab, d_cnt, d_mask, d_rows, d_q1, d_out1;
+    DevBuf d_dense, d_cand, d_cand_cnt, d_tau, dQ, d_dist, d_lab, d_cnt, d_mask, d_rows, d_q1, d_out1;
 
     bool find_row(uint64_t label, uint32_t& row) const {
         if (identity) { if (label < n_rows) { row = (uint32_t)label; return true; } return false; }
@@ -39,7 +39,7 @@ struct VecField {
         identity = false;
     }
     void release() {
-        DevBuf* b[] = {&X, &labels, &row_ok, &part_keys, &part_cnt, &dQ, &d_dist, &d_lab, &d_cnt, &d_mask, &d_rows, &d_q1, &d_out1};
+        DevBuf* b[] = {&X, &labels, &row_ok, &d_dense, &d_cand, &d_cand_cnt, &d_tau, &dQ, &d_dist, &d_lab, &d_cnt, &d_mask, &d_rows, &d_q1, &d_out1};
         for (auto* x : b) x->release();
     }
 };
@@ -69,48 +69,108 @@ static VecField* get_field(tsgpu_ctx* ctx, uint32_t id) {
     return it == ctx->vec_fields.end() ? nullptr : it->second;
 }
 
-// the exact k-NN launch sequence; caller holds ctx->mu. Q_dev: [n_q][dim] on the device (already normalised for cosine).
+// the exact k-NN launch sequence (vec_kernels.hip.h header); caller holds ctx->mu.
+// Q_dev: [n_q][dim] on the device (already normalised for cosine). Outputs [n_q][k] on the device.
+static int knn_group(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, uint32_t n_q, uint32_t k, const uint8_t* mask_dev,
+                     float* dist_dev, uint64_t* label_dev, uint32_t* cnt_dev, bool record_events) {
+    hipStream_t s = ctx->stream;
+    const uint32_t n_rows = (uint32_t)f->n_rows;
+    const uint32_t n_tiles = (n_rows + VEC_ROWS - 1) / VEC_ROWS;
+    const bool wide = n_q > 64;                                   // QT = 128 (CB = 2) or 64 (CB = 1)
+    const uint32_t QT = wide ? 128 : 64;
+    const uint32_t n_qtiles = (n_q + QT - 1) / QT;
+    const bool aligned = (f->dim % 4 == 0) && (((uintptr_t)Q_dev & 15) == 0) && (((uintptr_t)f->X.p & 15) == 0);
+    const uint32_t sample_tiles = std::max<uint32_t>(1, ctx->vec_sample_tiles);
+    int rc;
+    if ((rc = f->d_tau.reserve((size_t)n_q * 8))) return rc;
+    if ((rc = f->d_cand_cnt.reserve((size_t)n_q * 4 + 16))) return rc;
+    uint32_t* d_over = f->d_cand_cnt.as<uint32_t>() + n_q;         // overflow counter lives behind the per-query counts
+
+    auto launch_scan = [&](VecScanArgs& a, uint32_t target_wgs) {
+        // slabs: a multiple of 8 (XCD mapping), ~target_wgs workgroups in total
+        uint32_t n_slabs = std::max<uint32_t>(8, (std::max<uint32_t>(1, target_wgs / n_qtiles) + 7) / 8 * 8);
+        uint32_t per = (a.n_ord + n_slabs - 1) / n_slabs;
+        if (ctx->vec_rows_per_slab) per = std::max<uint32_t>(1, ctx->vec_rows_per_slab / VEC_ROWS);
+        per = std::max<uint32_t>(per, 1);
+        n_slabs = (a.n_ord + per - 1) / per;
+        n_slabs = std::max<uint32_t>(8, (n_slabs + 7) / 8 * 8);
+        a.ord_per_slab = per; a.n_slabs = n_slabs; a.n_qtiles = n_qtiles;
+        const dim3 grid(n_slabs * n_qtiles), block(VEC_THREADS);
+        if (wide) { if (aligned) hipLaunchKernelGGL((vec_scan_kernel<2, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((vec_scan_kernel<2, false>), grid, block, 0, s, a); }
+        else { if (aligned) hipLaunchKernelGGL((vec_scan_kernel<1, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((vec_scan_kernel<1, false>), grid, block, 0, s, a); }
+    };
+    VecScanArgs base;
+    memset(&base, 0, sizeof base);
+    base.X = f->X.as<float>(); base.row_ok = mask_dev; base.Q = Q_dev;
+    base.n_rows = n_rows; base.dim = f->dim; base.n_q = n_q;
+
+    if (record_events) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[3], s));
+    if (n_tiles <= sample_tiles) {
+        // small index: one dense pass over every row, then select
+        const uint32_t stride = n_tiles * VEC_ROWS;
+        if ((rc = f->d_dense.reserve((size_t)n_q * stride * 8))) return rc;
+        VecScanArgs a = base;
+        a.n_ord = n_tiles; a.tile_stride = 1; a.dense = f->d_dense.as<uint64_t>(); a.dense_stride = stride;
+        launch_scan(a, 512);
+        if (record_events) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s));
+        hipLaunchKernelGGL(vec_select_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint64_t*)a.dense, (size_t)stride, (const uint32_t*)nullptr, stride, k, 0,
+                           f->labels.as<uint64_t>(), dist_dev, label_dev, cnt_dev, f->d_tau.as<uint64_t>(), d_over);
+        if (record_events) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[5], s));
+        TSGPU_HIP_TRY(hipGetLastError());
+        return TSGPU_OK;
+    }
+    // pass 1: dense scan of a strided sample of the row tiles -> tau[q] = k-th best key of the sample
+    const uint32_t tile_stride = n_tiles / sample_tiles;             // >= 1; sampled tiles = 0, stride, 2*stride, ...
+    const uint32_t n_sample = (n_tiles + tile_stride - 1) / tile_stride;
+    {
+        const uint32_t stride = n_sample * VEC_ROWS;
+        if ((rc = f->d_dense.reserve((size_t)n_q * stride * 8))) return rc;
+        VecScanArgs a = base;
+        a.n_ord = n_sample; a.tile_stride = tile_stride; a.dense = f->d_dense.as<uint64_t>(); a.dense_stride = stride;
+        launch_scan(a, 512);
+        hipLaunchKernelGGL(vec_select_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint64_t*)a.dense, (size_t)stride, (const uint32_t*)nullptr, stride, k, 1,
+                           f->labels.as<uint64_t>(), dist_dev, label_dev, cnt_dev, f->d_tau.as<uint64_t>(), d_over);
+    }
+    // pass 2: every row, filtered by tau; expected survivors per query = k * n_tiles / n_sample
+    uint64_t cap = ctx->vec_cand_cap;
+    if (!cap) {
+        cap = 4ull * k * ((n_tiles + n_sample - 1) / n_sample) + 1024;
+        uint64_t p2 = 1024; while (p2 < cap) p2 <<= 1; cap = p2;
+        while (cap > 4096 && cap * n_q * 8 > (1ull << 30)) cap >>= 1;   // bound the candidate arena to 1 GiB per query group
+    }
+    cap = std::max<uint64_t>(cap, 2ull * k);     // a full list must be able to tighten its own threshold
+    if ((rc = f->d_cand.reserve((size_t)n_q * cap * 8))) return rc;
+    uint32_t h_over = 0;
+    for (int round = 0; round < 64; round++) {
+        TSGPU_HIP_TRY(hipMemsetAsync(f->d_cand_cnt.p, 0, (size_t)n_q * 4 + 4, s));
+        VecScanArgs a = base;
+        a.n_ord = n_tiles; a.tile_stride = 1; a.tau = f->d_tau.as<uint64_t>();
+        a.cand = f->d_cand.as<uint64_t>(); a.cand_cnt = f->d_cand_cnt.as<uint32_t>(); a.cand_cap = (uint32_t)cap;
+        launch_scan(a, 512);
+        if (record_events && round == 0) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s));
+        hipLaunchKernelGGL(vec_select_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint64_t*)a.cand, (size_t)cap, (const uint32_t*)a.cand_cnt, (uint32_t)cap, k, 0,
+                           f->labels.as<uint64_t>(), dist_dev, label_dev, cnt_dev, f->d_tau.as<uint64_t>(), d_over);
+        TSGPU_HIP_TRY(hipGetLastError());
+        TSGPU_HIP_TRY(hipMemcpyAsync(&h_over, d_over, 4, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        if (!h_over) break;                 // an overflowing list tightened its own tau: scan again (exactness is data-independent)
+        ctx->vec_overflow_rounds++;
+    }
+    if (h_over) return fail(TSGPU_ERR_DEVICE, "vec knn: candidate lists still overflow after 64 refinement rounds");
+    if (record_events) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[5], s));
+    return TSGPU_OK;
+}
+
 static int knn_device(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, uint32_t n_q, uint32_t k, const uint8_t* mask_dev,
                       float* dist_dev, uint64_t* label_dev, uint32_t* cnt_dev) {
-    hipStream_t s = ctx->stream;
-    const bool small_k = k <= 128;
-    const uint32_t QT = small_k ? 64 : 32, KL = small_k ? 128 : 256;
-    const uint32_t n_qtiles = (n_q + QT - 1) / QT;
-    const uint32_t n_rows = (uint32_t)f->n_rows;
-    uint32_t rows_per_slab;
-    if (ctx->vec_rows_per_slab) rows_per_slab = ctx->vec_rows_per_slab;
-    else {
-        uint32_t target_slabs = std::max<uint32_t>(8, (1024 + n_qtiles - 1) / n_qtiles);
-        rows_per_slab = (n_rows + target_slabs - 1) / target_slabs;
+    // query groups bound the scratch (dense sample + candidate arena); each group streams X once
+    const uint32_t GROUP = 512;
+    for (uint32_t q0 = 0; q0 < n_q; q0 += GROUP) {
+        const uint32_t nq = std::min<uint32_t>(GROUP, n_q - q0);
+        int rc = knn_group(ctx, f, Q_dev + (size_t)q0 * f->dim, nq, k, mask_dev, dist_dev + (size_t)q0 * k, label_dev + (size_t)q0 * k, cnt_dev + q0, q0 == 0);
+        if (rc) return rc;
     }
-    rows_per_slab = std::max<uint32_t>(VEC_ROWS, (rows_per_slab + VEC_ROWS - 1) / VEC_ROWS * VEC_ROWS);
-    uint32_t n_slabs = (n_rows + rows_per_slab - 1) / rows_per_slab;
-    n_slabs = std::max<uint32_t>(8, (n_slabs + 7) / 8 * 8);
-    const size_t qstride = (size_t)n_qtiles * QT;
-    int rc;
-    if ((rc = f->part_keys.reserve((size_t)n_slabs * qstride * KL * 8))) return rc;
-    if ((rc = f->part_cnt.reserve((size_t)n_slabs * qstride * 4))) return rc;
-    VecKnnArgs a;
-    a.X = f->X.as<float>();
-    a.row_ok = mask_dev;
-    a.Q = Q_dev;
-    a.n_rows = n_rows; a.dim = f->dim; a.n_q = n_q;
-    a.rows_per_slab = rows_per_slab; a.n_slabs = n_slabs; a.n_qtiles = n_qtiles;
-    a.part_keys = f->part_keys.as<uint64_t>();
-    a.part_cnt = f->part_cnt.as<uint32_t>();
-    TSGPU_HIP_TRY(hipEventRecord(ctx->ev[3], s));
-    if (small_k) hipLaunchKernelGGL((vec_knn_kernel<64, 128>), dim3(n_slabs * n_qtiles), dim3(VEC_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((vec_knn_kernel<32, 256>), dim3(n_slabs * n_qtiles), dim3(VEC_THREADS), 0, s, a);
-    TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s));
-    if (small_k)
-        hipLaunchKernelGGL((vec_merge_kernel<128, 2048>), dim3(n_q), dim3(VEC_THREADS), 0, s, a.part_keys, a.part_cnt, n_slabs, (uint32_t)qstride, k,
-                           f->labels.as<uint64_t>(), dist_dev, label_dev, cnt_dev);
-    else
-        hipLaunchKernelGGL((vec_merge_kernel<256, 2048>), dim3(n_q), dim3(VEC_THREADS), 0, s, a.part_keys, a.part_cnt, n_slabs, (uint32_t)qstride, k,
-                           f->labels.as<uint64_t>(), dist_dev, label_dev, cnt_dev);
-    TSGPU_HIP_TRY(hipEventRecord(ctx->ev[5], s));
-    TSGPU_HIP_TRY(hipGetLastError());
-    ctx->timings.vec_flops = 2ull * n_rows * f->dim * n_q;
+    ctx->timings.vec_flops = 2ull * f->n_rows * f->dim * std::min<uint32_t>(n_q, GROUP);   // the HIP events bracket the first query group
     return TSGPU_OK;
 }
 
@@ -342,7 +402,7 @@ int tsgpu_vec_knn_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, i
     if (!ctx || !Q || !dist_out || !label_out || !n_out) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_knn_batch: NULL argument");
     if (n_q == 0) return ok();
     if (k == 0) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_knn_batch: k must be > 0");
-    if (k > 256) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_knn_batch: k > 256 is not accelerated");
+    if (k > TSGPU_MAX_TOPK) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_knn_batch: k > TSGPU_MAX_TOPK is not accelerated");
     std::lock_guard<std::mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     VecField* f = get_field(ctx, vec_field_id);

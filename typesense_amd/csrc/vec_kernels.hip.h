@@ -3,21 +3,27 @@
 // Replaces, for a whole batch of queries, the reference's per-query distance loop (process_results_bruteforce,
 // src/index.cpp:3345-3374: dist = space->get_dist_func()(q, x, &dim) = 1 - <q,x>, hnswlib InnerProductSpace) and
 // the top-k it feeds (searchKnnCloserFirst result + Topster, src/index.cpp:3384-3389, 3682-3725) with an EXACT
-// scan: S = X · Qᵀ on the fp32-input matrix cores and a fused running top-k, so the N x B score matrix never
-// exists in memory.
+// scan: S = X · Qᵀ on the fp32-input matrix cores; the N x B score matrix never exists in memory.
 //
-// Mapping to the machine:
-//   * v_mfma_f32_32x32x2_f32 (exact fp32, bit-identical to a k-ordered fmaf chain): A = 32 base rows, B = 32
-//     queries, so one lane's 16 accumulator registers all belong to ONE query (column = lane & 31) — the
-//     per-query threshold lives in a register and the top-k filter is 16 compares per lane, no cross-lane traffic;
-//   * workgroup = 4 waves = 128 base rows x QT queries (QT = 64, or 32 when k > 128); the K dimension streams
-//     through LDS in 64-float chunks, next chunk prefetched into registers while the current one feeds the MFMAs;
-//   * each workgroup walks a contiguous slab of base rows for one query tile and keeps, per query, an LDS list
-//     of the KL best (distance, row) keys; candidates reach the list through per-query mini queues and a
-//     re-scan loop, so nothing is ever dropped (exact);
+// Three kernels, used twice each per batch:
+//   vec_scan_kernel    the GEMM. Workgroup = 4 waves = 128 base rows x QT queries (QT = 128, or 64 for small
+//                      batches); each wave owns a 64 x QT/2 sub-tile = 2 x CB accumulators of
+//                      v_mfma_f32_32x32x2_f32 (exact fp32). The K dimension streams through a double-buffered,
+//                      conflict-free LDS ring in 32-float chunks (one barrier per chunk, next chunk's global
+//                      loads in flight under the MFMAs); operands are fetched with ds_read_b128, 4 k-pairs per
+//                      read. Epilogue = a FILTER, not a heap: a score is kept iff its key (ord(dist)<<32 | row)
+//                      is <= the query's threshold key tau; survivors are appended to the query's candidate list
+//                      in HBM with one atomic. In steady state nothing survives (one max + compare per
+//                      accumulator block), so the epilogue costs ~1% of the MFMA time.
+//   vec_select_kernel  one workgroup per query: exact k-th smallest key of a candidate list by MSB-first radix
+//                      select (8-bit digits, LDS histograms), then a bitonic sort of the <= k winners.
+//   Pass 1 ("sample"): vec_scan over every (n_tiles/512)-th row tile in DENSE mode (all scores written), then
+//   vec_select gives tau[q] = k-th best of the sample — a valid upper bound of the final k-th best because the
+//   sample is a subset of the rows. Pass 2: vec_scan over ALL rows filtered by tau (expected survivors per query
+//   = k * N / sample_rows), then vec_select produces the final k. A candidate list that overflows tightens its
+//   own tau from what it holds and the pass is repeated (exactness never depends on the data distribution).
 //   * blockIdx -> (slab, query tile) is XCD-aware: the query tiles of one slab run on the same XCD back to
-//     back, so the slab is fetched from HBM once and re-served from that XCD's L2;
-//   * vec_merge_kernel folds the per-slab lists of a query into the final k (ties: smaller row first).
+//     back, so a slab is fetched from HBM once and re-served from that XCD's L2.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,11 +31,11 @@
 namespace tsgpu {
 
 static const int VEC_THREADS = 256;
-static const int VEC_ROWS = 128;        // base rows per tile (4 waves x 32)
-static const int VEC_KC = 64;           // K chunk staged in LDS
-static const int VEC_LDW = VEC_KC + 1;  // padded row stride (words): conflict-free column reads
-static const int VEC_QCAP = 8;          // per-query mini queue entries per round
+static const int VEC_ROWS = 128;        // base rows per tile (2 wave rows x 64)
+static const int VEC_KC = 32;           // K chunk staged in LDS per step
+static const int VEC_LDW = VEC_KC + 4;  // padded row stride (words): 36*r mod 64 hits 16 distinct 4-bank groups -> ds_read_b128 conflict-free
 static const uint64_t VEC_KEY_INF = 0xFFFFFFFFFFFFFFFFull;
+static const int VEC_SELECT_MAXK = 1024;   // TSGPU_MAX_TOPK
 
 typedef float vec_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -43,269 +49,298 @@ __device__ inline float ord_f32(uint32_t o) {
     return __uint_as_float(b);
 }
 
-struct VecKnnArgs {
+struct VecScanArgs {
     const float* X;            // [n_rows][dim] row-major
     const uint8_t* row_ok;     // nullable: 0 = skip row (deleted / filtered out)
     const float* Q;            // [n_q][dim]
     uint32_t n_rows, dim, n_q;
-    uint32_t rows_per_slab;    // multiple of VEC_ROWS
+    uint32_t n_ord;            // tile ordinals covered by this launch; tile id = ordinal * tile_stride
+    uint32_t tile_stride;
+    uint32_t ord_per_slab;     // ordinals per workgroup slab
     uint32_t n_slabs;          // multiple of 8 (XCD-aware mapping)
     uint32_t n_qtiles;
-    uint64_t* part_keys;       // [n_slabs][n_qtiles*QT][KL]
-    uint32_t* part_cnt;        // [n_slabs][n_qtiles*QT]
+    const uint64_t* tau;       // [n_q] threshold keys (sparse mode); null = keep everything
+    uint64_t* cand;            // sparse mode: [n_q][cand_cap]
+    uint32_t* cand_cnt;        // [n_q] (keeps counting past cand_cap: overflow is detected by the select kernel)
+    uint32_t cand_cap;
+    uint64_t* dense;           // dense mode (non-null): dense[q * dense_stride + ordinal*128 + r] = key or INF
+    uint32_t dense_stride;
 };
 
-template <int QT, int KL>
-struct VecSmem {
-    float xs[VEC_ROWS * VEC_LDW];
-    float qs[QT * VEC_LDW];
-    uint64_t list[KL * QT];             // [slot][query] : conflict-free for one-lane-per-query scans
-    uint64_t tau[QT];                   // current worst key of a full list (INF while filling)
-    uint32_t cnt[QT];
-    uint64_t mq[VEC_QCAP * QT];         // mini queues [slot][query]
-    uint32_t mq_cnt[QT];
-    uint32_t again;
+template <int QT>
+struct VecScanSmem {
+    alignas(16) float xs[2][VEC_ROWS * VEC_LDW];
+    alignas(16) float qs[2][QT * VEC_LDW];
 };
 
-// QT queries per workgroup (NB = QT/32 MFMA column blocks per wave), KL list slots per query (>= k)
-template <int QT, int KL>
-__global__ __launch_bounds__(VEC_THREADS) void vec_knn_kernel(VecKnnArgs a) {
-    constexpr int NB = QT / 32;
-    __shared__ VecSmem<QT, KL> sm;
+// CB = 32-query column blocks per wave (QT = 64 * CB); ALIGNED = dim % 4 == 0 and 16-byte aligned bases
+template <int CB, bool ALIGNED>
+__global__ __launch_bounds__(VEC_THREADS, 2) void vec_scan_kernel(VecScanArgs a) {
+    constexpr int QT = 64 * CB;
+    constexpr int XV = VEC_ROWS * VEC_KC / 4 / VEC_THREADS;     // float4 per thread per X chunk (4)
+    constexpr int QV = QT * VEC_KC / 4 / VEC_THREADS;           // 4 (QT=128) or 2 (QT=64)
+    __shared__ VecScanSmem<QT> sm;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t wrow = (wave >> 1) * 64, wcol = (wave & 1) * (32 * CB);
     // XCD-aware: blocks b, b+8, b+16.. share an XCD; give them the query tiles of the same slab
     const uint32_t b = blockIdx.x;
     const uint32_t xcd = b & 7, j = b >> 3;
     const uint32_t qtile = j % a.n_qtiles;
     const uint32_t slab = (j / a.n_qtiles) * 8 + xcd;
     const uint32_t q0 = qtile * QT;
-    const uint32_t row_begin = slab * a.rows_per_slab;
-    uint32_t row_end = row_begin + a.rows_per_slab;
-    if (row_end > a.n_rows) row_end = a.n_rows;
-
-    for (uint32_t i = t; i < (uint32_t)QT; i += VEC_THREADS) { sm.tau[i] = VEC_KEY_INF; sm.cnt[i] = 0; sm.mq_cnt[i] = 0; }
-    if (t == 0) sm.again = 0;
-    __syncthreads();
-
+    const uint32_t ord_begin = slab * a.ord_per_slab;
+    uint32_t ord_end = ord_begin + a.ord_per_slab;
+    if (ord_end > a.n_ord) ord_end = a.n_ord;
+    if (ord_begin >= ord_end) return;
     const uint32_t n_chunks = (a.dim + VEC_KC - 1) / VEC_KC;
-    // staging assignment: X tile = 128 rows x 64 floats = 2048 float4 -> 8 per thread; Q tile = QT x 64 floats
-    constexpr int XV = VEC_ROWS * VEC_KC / 4 / VEC_THREADS;     // 8
-    constexpr int QV = QT * VEC_KC / 4 / VEC_THREADS;           // 4 (QT=64) or 2 (QT=32)
+    const uint32_t total_steps = (ord_end - ord_begin) * n_chunks;
 
-    for (uint32_t r0 = row_begin; r0 < row_end; r0 += VEC_ROWS) {
-        vec_f32x16 acc[NB];
-#pragma unroll
-        for (int n = 0; n < NB; n++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[n][e] = 0.0f;
-
-        float4 xr[XV], qr[QV];
-        auto load_chunk = [&](uint32_t c) {
-            const uint32_t k0 = c * VEC_KC;
-#pragma unroll
-            for (int v = 0; v < XV; v++) {
-                const uint32_t idx = t + v * VEC_THREADS;           // float4 index in the tile
-                const uint32_t row = idx / (VEC_KC / 4), c4 = idx % (VEC_KC / 4);
-                const uint32_t gr = r0 + row, gk = k0 + c4 * 4;
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gr < row_end) {
-                    const float* p = a.X + (size_t)gr * a.dim + gk;
-                    if (gk + 3 < a.dim && ((a.dim & 3) == 0)) val = *(const float4*)p;
-                    else {
-                        if (gk < a.dim) val.x = p[0];
-                        if (gk + 1 < a.dim) val.y = p[1];
-                        if (gk + 2 < a.dim) val.z = p[2];
-                        if (gk + 3 < a.dim) val.w = p[3];
-                    }
-                }
-                xr[v] = val;
-            }
-#pragma unroll
-            for (int v = 0; v < QV; v++) {
-                const uint32_t idx = t + v * VEC_THREADS;
-                const uint32_t qi = idx / (VEC_KC / 4), c4 = idx % (VEC_KC / 4);
-                const uint32_t gq = q0 + qi, gk = k0 + c4 * 4;
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gq < a.n_q) {
-                    const float* p = a.Q + (size_t)gq * a.dim + gk;
-                    if (gk + 3 < a.dim && ((a.dim & 3) == 0)) val = *(const float4*)p;
-                    else {
-                        if (gk < a.dim) val.x = p[0];
-                        if (gk + 1 < a.dim) val.y = p[1];
-                        if (gk + 2 < a.dim) val.z = p[2];
-                        if (gk + 3 < a.dim) val.w = p[3];
-                    }
-                }
-                qr[v] = val;
-            }
-        };
-        auto store_chunk = [&]() {
-#pragma unroll
-            for (int v = 0; v < XV; v++) {
-                const uint32_t idx = t + v * VEC_THREADS;
-                const uint32_t row = idx / (VEC_KC / 4), c4 = idx % (VEC_KC / 4);
-                float* d = &sm.xs[row * VEC_LDW + c4 * 4];
-                d[0] = xr[v].x; d[1] = xr[v].y; d[2] = xr[v].z; d[3] = xr[v].w;
-            }
-#pragma unroll
-            for (int v = 0; v < QV; v++) {
-                const uint32_t idx = t + v * VEC_THREADS;
-                const uint32_t qi = idx / (VEC_KC / 4), c4 = idx % (VEC_KC / 4);
-                float* d = &sm.qs[qi * VEC_LDW + c4 * 4];
-                d[0] = qr[v].x; d[1] = qr[v].y; d[2] = qr[v].z; d[3] = qr[v].w;
-            }
-        };
-
-        load_chunk(0);
-        for (uint32_t c = 0; c < n_chunks; c++) {
-            __syncthreads();                 // previous chunk fully consumed
-            store_chunk();
-            __syncthreads();
-            if (c + 1 < n_chunks) load_chunk(c + 1);   // in flight while the MFMAs run
-            const float* xa = &sm.xs[(wave * 32 + (lane & 31)) * VEC_LDW + (lane >> 5)];
-            const float* qb = &sm.qs[(lane & 31) * VEC_LDW + (lane >> 5)];
-#pragma unroll 8
-            for (int kk = 0; kk < VEC_KC; kk += 2) {
-                const float av = xa[kk];
-#pragma unroll
-                for (int n = 0; n < NB; n++) {
-                    const float bv = qb[n * 32 * VEC_LDW + kk];
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
-                }
-            }
+    float4 xr[XV], qr[QV];
+    // branch-free guarded load: out-of-range rows / k read a clamped in-range address and are zeroed afterwards
+    auto load4 = [&](const float* base, uint32_t row, uint32_t row_lim, uint32_t gk) -> float4 {
+        const bool ok = row < row_lim && gk < a.dim;
+        const uint32_t r = row < row_lim ? row : row_lim - 1;
+        float4 val;
+        if (ALIGNED) {
+            const uint32_t kk = gk < a.dim ? gk : a.dim - 4;
+            val = *(const float4*)(base + (size_t)r * a.dim + kk);
+        } else {
+            const float* p = base + (size_t)r * a.dim;
+            const uint32_t d1 = a.dim - 1;
+            val.x = p[gk < d1 ? gk : d1];
+            val.y = (gk + 1 < a.dim) ? p[gk + 1 < d1 ? gk + 1 : d1] : 0.f;
+            val.z = (gk + 2 < a.dim) ? p[gk + 2 < d1 ? gk + 2 : d1] : 0.f;
+            val.w = (gk + 3 < a.dim) ? p[gk + 3 < d1 ? gk + 3 : d1] : 0.f;
         }
+        if (!ok) val = make_float4(0.f, 0.f, 0.f, 0.f);
+        return val;
+    };
+    // global -> registers for pipeline step s (tile ordinal = ord_begin + s / n_chunks, chunk = s % n_chunks)
+    auto load_step = [&](uint32_t s) {
+        const uint32_t o = ord_begin + s / n_chunks, c = s % n_chunks;
+        const uint32_t r0 = o * a.tile_stride * VEC_ROWS, k0 = c * VEC_KC;
+#pragma unroll
+        for (int v = 0; v < XV; v++) {
+            const uint32_t idx = t + v * VEC_THREADS;
+            const uint32_t row = r0 + idx / (VEC_KC / 4), gk = k0 + (idx % (VEC_KC / 4)) * 4;
+            xr[v] = load4(a.X, row, a.n_rows, gk);
+        }
+#pragma unroll
+        for (int v = 0; v < QV; v++) {
+            const uint32_t idx = t + v * VEC_THREADS;
+            const uint32_t gq = q0 + idx / (VEC_KC / 4), gk = k0 + (idx % (VEC_KC / 4)) * 4;
+            qr[v] = load4(a.Q, gq, a.n_q, gk);
+        }
+    };
+    auto store_step = [&](uint32_t buf) {
+#pragma unroll
+        for (int v = 0; v < XV; v++) {
+            const uint32_t idx = t + v * VEC_THREADS;
+            *(float4*)&sm.xs[buf][(idx / (VEC_KC / 4)) * VEC_LDW + (idx % (VEC_KC / 4)) * 4] = xr[v];
+        }
+#pragma unroll
+        for (int v = 0; v < QV; v++) {
+            const uint32_t idx = t + v * VEC_THREADS;
+            *(float4*)&sm.qs[buf][(idx / (VEC_KC / 4)) * VEC_LDW + (idx % (VEC_KC / 4)) * 4] = qr[v];
+        }
+    };
 
-        // ---- fused top-k: this lane owns query column (lane & 31) of each of its NB blocks ----
-        // distance = 1 - dot ; key = (ord(distance) << 32) | row   (smaller = closer; ties: smaller row)
-        uint64_t keys[NB][16];
+    // per-lane thresholds: this lane's query column in each of its CB blocks
+    uint64_t tau_key[CB];
+    float tau_dist[CB];
 #pragma unroll
-        for (int n = 0; n < NB; n++) {
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const uint32_t row = r0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const uint32_t gq = q0 + n * 32 + (lane & 31);
-                bool ok = row < row_end && gq < a.n_q;
-                if (ok && a.row_ok) ok = a.row_ok[row] != 0;
-                const float dist = 1.0f - acc[n][e];
-                keys[n][e] = ok ? (((uint64_t)f32_ord(dist) << 32) | row) : VEC_KEY_INF;
-            }
-        }
-        for (;;) {
-            // push: every still-unqueued key better than the query's threshold
-            bool left = false;
-#pragma unroll
-            for (int n = 0; n < NB; n++) {
-                const uint32_t ql = n * 32 + (lane & 31);
-                const uint64_t tau = sm.tau[ql];
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const uint64_t kv = keys[n][e];
-                    if (kv < tau) {
-                        const uint32_t slot = atomicAdd(&sm.mq_cnt[ql], 1u);
-                        if (slot < (uint32_t)VEC_QCAP) { sm.mq[slot * QT + ql] = kv; keys[n][e] = VEC_KEY_INF; }
-                        else left = true;
-                    }
-                }
-            }
-            if (left) sm.again = 1;
-            __syncthreads();
-            // drain: thread q owns query q's list
-            if (t < (uint32_t)QT) {
-                uint32_t nq = sm.mq_cnt[t];
-                if (nq > (uint32_t)VEC_QCAP) nq = VEC_QCAP;
-                uint32_t cnt = sm.cnt[t];
-                uint64_t tau = sm.tau[t];
-                for (uint32_t i = 0; i < nq; i++) {
-                    const uint64_t kv = sm.mq[i * QT + t];
-                    if (cnt < (uint32_t)KL) {
-                        sm.list[cnt * QT + t] = kv;
-                        cnt++;
-                        if (cnt == (uint32_t)KL) {          // list just filled: threshold = its worst key
-                            uint64_t mx = 0;
-                            for (int s = 0; s < KL; s++) { const uint64_t v = sm.list[s * QT + t]; if (v > mx) mx = v; }
-                            tau = mx;
-                        }
-                    } else if (kv < tau) {                  // replace the worst, recompute the threshold
-                        uint64_t mx = 0;
-                        int mpos = 0;
-                        for (int s = 0; s < KL; s++) { const uint64_t v = sm.list[s * QT + t]; if (v == tau) mpos = s; }
-                        sm.list[mpos * QT + t] = kv;
-                        for (int s = 0; s < KL; s++) { const uint64_t v = sm.list[s * QT + t]; if (v > mx) mx = v; }
-                        tau = mx;
-                    }
-                }
-                sm.cnt[t] = cnt;
-                sm.tau[t] = tau;
-                sm.mq_cnt[t] = 0;
-            }
-            __syncthreads();
-            const uint32_t again = sm.again;
-            __syncthreads();
-            if (t == 0) sm.again = 0;
-            __syncthreads();                 // the reset must not overtake the next round's "left" flag
-            if (!again) break;
-        }
+    for (int cb = 0; cb < CB; cb++) {
+        const uint32_t gq = q0 + wcol + cb * 32 + (lane & 31);
+        tau_key[cb] = (a.tau && gq < a.n_q) ? a.tau[gq] : VEC_KEY_INF;
+        tau_dist[cb] = ord_f32((uint32_t)(tau_key[cb] >> 32));
     }
+
+    vec_f32x16 acc[2][CB];
+    load_step(0);
+    store_step(0);
     __syncthreads();
-    // ---- slab result: the (unsorted) lists ----
-    const size_t qstride = (size_t)a.n_qtiles * QT;
-    for (uint32_t i = t; i < (uint32_t)(KL * QT); i += VEC_THREADS) {
-        const uint32_t s = i / QT, ql = i % QT;
-        if (s < sm.cnt[ql]) a.part_keys[((size_t)slab * qstride + q0 + ql) * KL + s] = sm.list[s * QT + ql];
+    for (uint32_t s = 0; s < total_steps; s++) {
+        const uint32_t c = s % n_chunks, buf = s & 1;
+        if (c == 0) {
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[rb][cb][e] = 0.0f;
+        }
+        if (s + 1 < total_steps) load_step(s + 1);           // in flight while the MFMAs run
+        // lane (r = lane&31, h = lane>>5) supplies k = 8*g + 4*h + i to MFMA i of group g: every k exactly once
+        const float* xa = &sm.xs[buf][(wrow + (lane & 31)) * VEC_LDW + 4 * (lane >> 5)];
+        const float* qb = &sm.qs[buf][(wcol + (lane & 31)) * VEC_LDW + 4 * (lane >> 5)];
+#pragma unroll
+        for (int g = 0; g < VEC_KC / 8; g++) {
+            float4 av[2], bv[CB];
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) av[rb] = *(const float4*)(xa + rb * 32 * VEC_LDW + 8 * g);
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) bv[cb] = *(const float4*)(qb + cb * 32 * VEC_LDW + 8 * g);
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) {
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rb].x, bv[cb].x, acc[rb][cb], 0, 0, 0);
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rb].y, bv[cb].y, acc[rb][cb], 0, 0, 0);
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rb].z, bv[cb].z, acc[rb][cb], 0, 0, 0);
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rb].w, bv[cb].w, acc[rb][cb], 0, 0, 0);
+                }
+        }
+        if (s + 1 < total_steps) store_step(buf ^ 1);
+        if (c == n_chunks - 1) {
+            // ---- tile epilogue: distance = 1 - dot; key = (ord(distance) << 32) | row ----
+            const uint32_t o = ord_begin + s / n_chunks;
+            const uint32_t r0 = o * a.tile_stride * VEC_ROWS;
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) {
+                const uint32_t gq = q0 + wcol + cb * 32 + (lane & 31);
+                if (a.dense) {
+                    if (gq < a.n_q) {
+#pragma unroll
+                        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                            for (int e = 0; e < 16; e++) {
+                                const uint32_t lr = wrow + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                                const uint32_t row = r0 + lr;
+                                bool okr = row < a.n_rows;
+                                if (okr && a.row_ok) okr = a.row_ok[row] != 0;
+                                const float dist = 1.0f - acc[rb][cb][e];
+                                a.dense[(size_t)gq * a.dense_stride + (size_t)(o * VEC_ROWS + lr)] =
+                                    okr ? (((uint64_t)f32_ord(dist) << 32) | row) : VEC_KEY_INF;
+                            }
+                    }
+                } else {
+                    // cheap reject: the best (largest) dot of this lane's 32 scores for the column
+                    float amax = acc[0][cb][0];
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) amax = fmaxf(amax, acc[rb][cb][e]);
+                    if (gq < a.n_q && !((1.0f - amax) > tau_dist[cb])) {     // NaN-safe: NaN never rejects here
+#pragma unroll
+                        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                            for (int e = 0; e < 16; e++) {
+                                const uint32_t row = r0 + wrow + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                                const float dist = 1.0f - acc[rb][cb][e];
+                                const uint64_t key = ((uint64_t)f32_ord(dist) << 32) | row;
+                                if (key <= tau_key[cb] && row < a.n_rows && (!a.row_ok || a.row_ok[row] != 0)) {
+                                    const uint32_t slot = atomicAdd(&a.cand_cnt[gq], 1u);
+                                    if (slot < a.cand_cap) a.cand[(size_t)gq * a.cand_cap + slot] = key;
+                                }
+                            }
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
-    for (uint32_t i = t; i < (uint32_t)QT; i += VEC_THREADS) a.part_cnt[(size_t)slab * qstride + q0 + i] = sm.cnt[i];
 }
 
 // ------------------------------------------------------------------------------------------------
-// one workgroup per query: k smallest keys over all slabs, ascending
-template <int KL, int BUF>
-__global__ __launch_bounds__(VEC_THREADS) void vec_merge_kernel(const uint64_t* __restrict__ part_keys, const uint32_t* __restrict__ part_cnt,
-                                                                 uint32_t n_slabs, uint32_t q_stride, uint32_t k,
-                                                                 const uint64_t* __restrict__ labels, float* __restrict__ dist_out,
-                                                                 uint64_t* __restrict__ label_out, uint32_t* __restrict__ n_out) {
-    __shared__ uint64_t buf[BUF];
-    __shared__ uint32_t s_cnt;
+// One workgroup per query: exact selection of the k smallest keys of a candidate list.
+//   keys = base + q * stride, n = cnt ? min(cnt[q], cap) : cap (dense lists are fully populated; INF = padding).
+//   mode 0 (final): writes the k smallest keys ascending as (distance, label) + n_out.
+//   mode 1 (threshold): writes tau[q] = k-th smallest key (INF when fewer than k real keys).
+//   Overflow (cnt[q] > cap): tau[q] is tightened to the k-th smallest of the cap keys held (still a valid upper
+//   bound of the true k-th best) and *overflow is raised, so the host re-runs the scan for the batch.
+__global__ __launch_bounds__(VEC_THREADS) void vec_select_kernel(const uint64_t* __restrict__ base, size_t stride, const uint32_t* __restrict__ cnt,
+                                                                  uint32_t cap, uint32_t k, int mode, const uint64_t* __restrict__ labels,
+                                                                  float* __restrict__ dist_out, uint64_t* __restrict__ label_out,
+                                                                  uint32_t* __restrict__ n_out, uint64_t* __restrict__ tau, uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint64_t win[VEC_SELECT_MAXK];
+    __shared__ uint64_t s_prefix, s_diff;
+    __shared__ uint32_t s_krem, s_win, s_valid;
     const uint32_t t = threadIdx.x, q = blockIdx.x;
-    if (t == 0) s_cnt = 0;
+    const uint64_t* __restrict__ keys = base + (size_t)q * stride;
+    const uint32_t total = cnt ? cnt[q] : cap;
+    const bool over = total > cap;
+    const uint32_t n = over ? cap : total;
+    if (t == 0) { s_prefix = 0; s_diff = 0; s_krem = k; s_win = 0; s_valid = 0; }
     __syncthreads();
-    auto sort_buf = [&]() {   // ascending bitonic sort of BUF keys (padding = INF)
-        for (uint32_t i = t; i < (uint32_t)BUF; i += VEC_THREADS) if (i >= s_cnt) buf[i] = VEC_KEY_INF;
-        for (int size = 2; size <= BUF; size <<= 1) {
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                __syncthreads();
-                for (int p = t; p < BUF / 2; p += VEC_THREADS) {
-                    const int i = 2 * p - (p & (stride - 1));
-                    const int jx = i + stride;
-                    const bool asc = ((i & size) == 0);
-                    const uint64_t x = buf[i], y = buf[jx];
-                    if (asc ? (x > y) : (x < y)) { buf[i] = y; buf[jx] = x; }
-                }
+    // number of real keys + the bits in which they differ (skips radix passes over a common prefix)
+    {
+        const uint64_t first = n ? keys[0] : 0;
+        uint64_t d = 0;
+        uint32_t valid = 0;
+        for (uint32_t i = t; i < n; i += VEC_THREADS) { const uint64_t kv = keys[i]; d |= kv ^ first; valid += kv != VEC_KEY_INF; }
+        if (d) atomicOr((unsigned long long*)&s_diff, (unsigned long long)d);
+        if (valid) atomicAdd(&s_valid, valid);
+    }
+    __syncthreads();
+    const uint32_t n_valid = s_valid;
+    uint64_t kstar = VEC_KEY_INF - 1;                       // "take every real key"
+    if (n_valid > k) {
+        const uint64_t diff = s_diff;
+        int top = 7;
+        while (top > 0 && ((diff >> (8 * top)) & 0xFF) == 0) top--;
+        uint64_t prefix = 0, pmask = 0;
+        if (top < 7) { pmask = ~0ull << (8 * (top + 1)); prefix = keys[0] & pmask; }
+        for (int p = top; p >= 0; p--) {
+            hist[t] = 0;
+            __syncthreads();
+            const int shift = 8 * p;
+            for (uint32_t i = t; i < n; i += VEC_THREADS) {
+                const uint64_t kv = keys[i];
+                if ((kv & pmask) == prefix) atomicAdd(&hist[(uint32_t)(kv >> shift) & 255u], 1u);
             }
-        }
-        __syncthreads();
-    };
-    for (uint32_t s = 0; s < n_slabs; s++) {
-        const uint32_t n = part_cnt[(size_t)s * q_stride + q];
-        if (s_cnt + n > (uint32_t)BUF) {
-            sort_buf();
-            if (t == 0) s_cnt = s_cnt < k ? s_cnt : k;
+            __syncthreads();
+            if (t == 0) {
+                uint32_t krem = s_krem, cum = 0, d = 0;
+                for (; d < 256; d++) { if (cum + hist[d] >= krem) break; cum += hist[d]; }
+                s_krem = krem - cum;
+                s_prefix = prefix | ((uint64_t)d << shift);
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            pmask |= 0xFFull << shift;
             __syncthreads();
         }
-        const uint32_t base = s_cnt;
-        for (uint32_t i = t; i < n; i += VEC_THREADS) buf[base + i] = part_keys[((size_t)s * q_stride + q) * KL + i];
-        __syncthreads();
-        if (t == 0) s_cnt = base + n;
-        __syncthreads();
+        kstar = prefix;                                     // exact k-th smallest key (keys are unique per row)
     }
-    sort_buf();
-    const uint32_t n = s_cnt < k ? s_cnt : k;
+    if (mode == 1 || over) {
+        if (t == 0) {
+            if (mode == 1) tau[q] = n_valid >= k ? kstar : VEC_KEY_INF;
+            else { tau[q] = kstar; atomicAdd(overflow, 1u); }
+        }
+        if (mode == 1) return;
+    }
+    // winners -> LDS, bitonic sort ascending, emit
+    for (uint32_t i = t; i < (uint32_t)VEC_SELECT_MAXK; i += VEC_THREADS) win[i] = VEC_KEY_INF;
+    __syncthreads();
     for (uint32_t i = t; i < n; i += VEC_THREADS) {
-        const uint64_t kv = buf[i];
+        const uint64_t kv = keys[i];
+        if (kv <= kstar && kv != VEC_KEY_INF) { const uint32_t slot = atomicAdd(&s_win, 1u); if (slot < (uint32_t)VEC_SELECT_MAXK) win[slot] = kv; }
+    }
+    __syncthreads();
+    uint32_t m = s_win < k ? s_win : k;
+    uint32_t sz = 2;
+    while (sz < s_win && sz < (uint32_t)VEC_SELECT_MAXK) sz <<= 1;
+    for (uint32_t size = 2; size <= sz; size <<= 1) {
+        for (uint32_t strd = size >> 1; strd > 0; strd >>= 1) {
+            __syncthreads();
+            for (uint32_t p = t; p < sz / 2; p += VEC_THREADS) {
+                const uint32_t i = 2 * p - (p & (strd - 1));
+                const uint32_t jx = i + strd;
+                const bool asc = ((i & size) == 0);
+                const uint64_t x = win[i], y = win[jx];
+                if (asc ? (x > y) : (x < y)) { win[i] = y; win[jx] = x; }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < m; i += VEC_THREADS) {
+        const uint64_t kv = win[i];
         const uint32_t row = (uint32_t)(kv & 0xFFFFFFFFull);
         dist_out[(size_t)q * k + i] = ord_f32((uint32_t)(kv >> 32));
         label_out[(size_t)q * k + i] = labels[row];
     }
-    if (t == 0) n_out[q] = n;
+    if (t == 0) n_out[q] = m;
 }
 
 // ------------------------------------------------------------------------------------------------
