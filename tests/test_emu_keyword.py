@@ -145,3 +145,54 @@ def test_keyword_many_work_items_and_merge(pair):
     finally:
         g.set_option("kw_chunk_blocks", 64)
         g.keep_result_ids(False)
+
+
+def _synthetic_lists(seed):
+    """posting lists with extreme length ratios so that one driver block meets runs of 1, ~10, ~40 and >64 blocks of
+    the second list, plus driver ids beyond the second list's last id (window recentring, multi-round LDS merge,
+    wide-run fallback and early exhaustion in kw_search_kernel stage 1)"""
+    rng = np.random.default_rng(seed)
+    n_docs = 4_000_000
+    b_ids = np.unique(np.concatenate([rng.choice(2_000_000, size=50_000, replace=False),
+                                      rng.integers(1_000_000, 1_030_000, size=9_000)])).astype(np.uint32)
+    a_ids = np.unique(np.concatenate([rng.choice(b_ids, size=260, replace=False),                 # guaranteed matches
+                                      rng.integers(1_000_000, 1_030_000, size=500),                # dense stretch: narrow runs
+                                      rng.choice(b_ids[b_ids > 1_000_000], size=100, replace=False),
+                                      rng.integers(0, 4_000_000, size=400)])).astype(np.uint32)    # sparse: wide runs + beyond B's end
+    c_ids = np.unique(np.concatenate([rng.choice(a_ids, size=a_ids.size // 2, replace=False),
+                                      rng.integers(0, 4_000_000, size=3_000)])).astype(np.uint32)
+    lists = {}
+    for term, ids in ((1, a_ids), (2, b_ids), (3, c_ids)):
+        pos = (ids * np.uint32(2654435761) >> np.uint32(27)).astype(np.uint32) % 7               # one position per doc
+        lists[term] = (ids, np.arange(ids.size, dtype=np.uint32), pos + 1)
+    return n_docs, lists
+
+
+@pytest.mark.parametrize("chunk", [64, 1])
+def test_stage1_block_merge_windows_fallback_and_exhaustion(chunk):
+    from oracle import oracle_py as O
+    n_docs, lists = _synthetic_lists(5)
+    pts = H.points_of(n_docs)
+    orc = O.OracleIndex(1, 1)
+    orc.set_num_docs(n_docs)
+    orc.set_sort_dense(0, pts)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.field_create(0, False)
+    for term, (ids, oi, off) in lists.items():
+        orc.load_posting(0, term, ids, oi, off)
+        g.term_upsert(0, term, ids, oi, off)
+    g.column_set(0, pts)
+    g.set_num_docs(n_docs)
+    g.commit()
+    g.set_option("kw_chunk_blocks", chunk)
+    g.keep_result_ids(True)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    qs = [T.KwQuery([1, 2], sort=sort, topster_size=250), T.KwQuery([2, 1, 3], sort=sort, topster_size=250),
+          T.KwQuery([3, 2], sort=sort, topster_size=100), T.KwQuery([3, 1], sort=sort, topster_size=250)]
+    hits = g.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all() and hits.n_hits[0] >= 250
+    for i, q in enumerate(qs):
+        ref = H.oracle_keyword(orc, q, ids_cap=100000)
+        H.assert_hits_equal(hits, i, ref, "stage1 chunk=%d" % chunk)
+        assert np.array_equal(g.result_ids(i), ref.result_ids)
+    g.close()

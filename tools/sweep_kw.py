@@ -11,7 +11,7 @@ import bench
 n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 csr = synth.zipf_corpus_csr(n_docs, 100_000, 32, seed=2)
 pts = synth.points_column(n_docs)
-g = T.GpuIndex(0)
+g = T.GpuIndex(0, os.environ.get('TSGPU_LIB') or None)
 g.field_create(0, False)
 g.terms_load_csr(0, csr["term_ids"], csr["ids_ptr"], csr["ids"], csr["offset_index"], csr["off_ptr"], csr["offsets"])
 g.column_set(0, pts); g.set_num_docs(n_docs); g.commit()

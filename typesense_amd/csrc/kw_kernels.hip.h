@@ -12,8 +12,12 @@
 //     one workgroup per work item, grid = all work items of the batch (>> 256 CUs);
 //   * stage 0: thread t extracts id t of the driver block straight from the bit-packed payload
 //     (coalesced dword loads, funnel shift) — no decode buffer, no allocation;
-//   * stage 1: every candidate id probes the next-shortest list: binary search of the contiguous
-//     blk_last[] skip array, then a bit-packed binary search inside the one candidate block;
+//   * stage 1: the 256 ascending candidates of a driver block meet the next-shortest list B as a block-level
+//     MERGE, not 256 independent probes: the run of B blocks that overlaps the driver block's id range is
+//     found with one coalesced 64-entry window load of blk_last[] + a wave ballot (the cursor only moves
+//     forward), those B blocks are decoded cooperatively (coalesced dword loads) into an LDS id tile, and each
+//     candidate finishes with two LDS binary searches (block, then slot). A window wider than 64 B blocks
+//     falls back to the per-candidate probe (binary search of blk_last[], then of the packed block);
 //     survivors are compacted IN ORDER with wave ballot + popcount prefix sums into an LDS queue;
 //   * stage 2 (>=3 tokens): runs only when >=256 survivors are queued, so the remaining probes execute
 //     with full wavefronts; survivors -> final queue;
@@ -35,11 +39,18 @@ static const int KW_THREADS = 256;
 static const int KW_QCAP = 512;            // LDS queue capacity (>= 255 leftover + 256 new)
 static const int KW_MAX_TOKENS = 10;       // TSGPU_MAX_QUERY_TOKENS
 static const uint32_t KW_WINDOW_SIZE = 10; // WINDOW_SIZE, include/match_score.h:11
+#ifndef TSGPU_KW_RMAX
+#define TSGPU_KW_RMAX 8
+#endif
+static const int KW_RMAX = TSGPU_KW_RMAX;  // blocks of the second list decoded into LDS per round (8 x 256 ids = 8 KB)
+static const int KW_WMAX = 64;             // widest run of second-list blocks merged through LDS (one wave-wide window)
 
 struct IndexView {
     const ListDesc* lists;
     const uint32_t* blk_last;
+    const BlockIds* blk_ids;
     const BlockMeta* blk_meta;
+    const uint32_t* ids_payload;
     const uint32_t* payload;
     const int64_t* const* columns;   // columns[c][seq_id], INT64_MIN = no value (default_score, index.cpp:5696)
     const uint32_t* column_len;
@@ -119,16 +130,16 @@ __device__ inline bool probe_list(const IndexView& ix, const ListDesc& d, uint32
         const uint32_t mid = (lo + hi) >> 1;
         if (bl[mid] >= x) hi = mid; else lo = mid + 1;
     }
-    const BlockMeta m = ix.blk_meta[d.blk_base + lo];
+    const BlockIds m = ix.blk_ids[d.blk_base + lo];
     if (x < m.first_id) return false;
-    const uint32_t* __restrict__ w = ix.payload + d.payload_base + m.ids_woff;
-    const uint32_t target = x - m.first_id;
-    uint32_t l = 0, h = (uint32_t)m.n_ids - 1;         // packed[h] = block last >= target
+    const uint32_t* __restrict__ w = ix.ids_payload + d.ids_base + m.ids_woff;
+    const uint32_t target = x - m.first_id, bits = m.n_ids_bits >> 16;
+    uint32_t l = 0, h = (m.n_ids_bits & 0xFFFF) - 1;     // packed[h] = block last >= target
     while (l < h) {
         const uint32_t mid = (l + h) >> 1;
-        if (unpack_at(w, mid, m.ids_bits) >= target) h = mid; else l = mid + 1;
+        if (unpack_at(w, mid, bits) >= target) h = mid; else l = mid + 1;
     }
-    if (unpack_at(w, l, m.ids_bits) != target) return false;
+    if (unpack_at(w, l, bits) != target) return false;
     pos = lo * BLOCK_IDS + l;
     return true;
 }
@@ -438,6 +449,8 @@ struct KwSmem {
     uint32_t qf_pos[TMAX][KW_QCAP];
     TopkLds<CAP> tk;
     int64_t thr[4];
+    uint32_t bids[KW_RMAX * BLOCK_IDS];      // decoded ids of the second list's blocks under the current driver block
+    uint32_t bwin[KW_WMAX];                  // blk_last[] window of the second list
     uint32_t wave_cnt[KW_THREADS / 64];
     uint32_t q1_cnt, qf_cnt, tk_cnt, have_thr;
     uint32_t n_match, n_emit;
@@ -568,12 +581,19 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
     uint32_t* my_ids_out = ids_out ? ids_out + q.ids_out_off + wi.ids_out_off : nullptr;
     const uint32_t* filt = aux_ids + q.aux_off + q.n_excl;
 
-    for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
+    const ListDesc dB = ix.lists[q.list[q.probe_order[T >= 2 ? 1 : 0]]];
+    const uint32_t* __restrict__ blB = ix.blk_last + dB.blk_base;
+    const uint32_t lane = t & 63;
+    uint32_t curB = 0;                      // forward-only cursor into B's blocks (identical in every thread)
+    bool b_exhausted = false;
+
+    for (uint32_t b = wi.blk_begin; b < wi.blk_end && !b_exhausted; b++) {
         // ---- stage 0: thread t = slot t of driver block b ----
-        const BlockMeta m = ix.blk_meta[dA.blk_base + b];
-        bool ok = t < (uint32_t)m.n_ids;
+        const BlockIds m = ix.blk_ids[dA.blk_base + b];
+        const uint32_t m_n = m.n_ids_bits & 0xFFFF;
+        bool ok = t < m_n;
         uint32_t id = 0, p1 = 0;
-        if (ok) id = m.first_id + unpack_at(ix.payload + dA.payload_base + m.ids_woff, t, m.ids_bits);
+        if (ok) id = m.first_id + unpack_at(ix.ids_payload + dA.ids_base + m.ids_woff, t, m.n_ids_bits >> 16);
         // filter ids (sorted whitelist): membership is decided per candidate; the reference's
         // filter-driven skipping only changes WHICH matches are counted, handled in the host shim (v1: no filter in-kernel)
         if (ok && q.n_filt) {
@@ -581,8 +601,81 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (filt[mid] < id) lo = mid + 1; else hi = mid; }
             ok = (lo < q.n_filt && filt[lo] == id);
         }
-        // ---- stage 1: probe the second-shortest list ----
-        if (ok && T >= 2) ok = probe_list(ix, ix.lists[q.list[q.probe_order[1]]], id, p1);
+        // ---- stage 1: merge with the second-shortest list B ----
+        if (T >= 2) {
+            // (a) B blocks [jlo, jhi] overlap this driver block's id range [first_id, last_id]. Every wave runs the
+            //     same search on the same data (uniform result, no LDS hand-off): one coalesced window of blk_last[].
+            const uint32_t lo_id = m.first_id, hi_id = m.last_id;
+            uint32_t wbase = curB;
+            uint32_t wv = (wbase + lane < dB.n_blocks) ? blB[wbase + lane] : 0xFFFFFFFFu;
+            unsigned long long mk = __ballot(wv >= lo_id ? 1 : 0);
+            if ((mk & ((wbase + 64 <= dB.n_blocks) ? ~0ull : ((1ull << (dB.n_blocks - wbase)) - 1ull))) == 0) {
+                // beyond the window: uniform binary search over the rest, then re-centre the window
+                uint32_t lo = wbase + 64 < dB.n_blocks ? wbase + 64 : dB.n_blocks, hi = dB.n_blocks;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (blB[mid] >= lo_id) hi = mid; else lo = mid + 1; }
+                wbase = lo;
+                wv = (wbase + lane < dB.n_blocks) ? blB[wbase + lane] : 0xFFFFFFFFu;
+                mk = __ballot(wv >= lo_id ? 1 : 0);
+            }
+            if (wbase >= dB.n_blocks) {
+                // every remaining candidate of this work item is beyond B's last id: nothing can match any more
+                ok = false;
+                b_exhausted = true;
+            } else {
+                const uint32_t jlo = wbase + (uint32_t)__builtin_ctzll(mk);          // first block with last >= lo_id (exists: wv of lane 0.. real)
+                const unsigned long long mh = __ballot(wv >= hi_id ? 1 : 0);         // padding lanes (FFFFFFFF) always vote yes
+                uint32_t jhi_rel = (uint32_t)__builtin_ctzll(mh | (1ull << 63));     // relative to wbase; 63 => may lie beyond the window
+                const bool wide = (mh == 0) || (wbase + jhi_rel >= dB.n_blocks && dB.n_blocks - wbase > 64);
+                uint32_t jhi = wbase + jhi_rel;
+                if (jhi >= dB.n_blocks) jhi = dB.n_blocks - 1;                       // hi_id beyond B's last id
+                if (wide || jhi - wbase >= (uint32_t)KW_WMAX) {
+                    // run of B blocks wider than the window: per-candidate probe, cursor moved by a uniform search
+                    if (ok) ok = probe_list(ix, dB, id, p1);
+                    uint32_t lo = wbase, hi = dB.n_blocks;
+                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (blB[mid] >= hi_id) hi = mid; else lo = mid + 1; }
+                    curB = lo < dB.n_blocks ? lo : dB.n_blocks - 1;
+                } else {
+                    curB = jhi;
+                    if (t < 64) sm.bwin[t] = wv;                                     // window relative to wbase (wave 0's copy)
+                    const uint32_t rlo = jlo - wbase, rhi = jhi - wbase;             // inclusive, < 64
+                    const uint32_t nblk = rhi - rlo + 1;
+                    uint32_t kblk = 0;
+                    bool found = false;
+                    for (uint32_t r0 = 0; r0 < nblk; r0 += KW_RMAX) {
+                        const uint32_t nr = nblk - r0 < (uint32_t)KW_RMAX ? nblk - r0 : (uint32_t)KW_RMAX;
+                        // (b) decode B blocks jlo+r0 .. +nr into the LDS tile: thread t = slot t of each block
+                        for (uint32_t kk = 0; kk < nr; kk++) {
+                            const BlockIds mb = ix.blk_ids[dB.blk_base + jlo + r0 + kk];
+                            const uint32_t nb = mb.n_ids_bits & 0xFFFF;
+                            sm.bids[kk * BLOCK_IDS + t] = t < nb ? mb.first_id + unpack_at(ix.ids_payload + dB.ids_base + mb.ids_woff, t, mb.n_ids_bits >> 16)
+                                                                 : 0xFFFFFFFFu;
+                        }
+                        __syncthreads();
+                        if (r0 == 0 && ok) {
+                            // (c) which block: lower bound of id in bwin[rlo..rhi] (bwin[rhi] >= hi_id >= id unless B ended)
+                            uint32_t pos = rlo;
+#pragma unroll
+                            for (uint32_t step = 32; step > 0; step >>= 1)
+                                if (pos + step <= rhi && sm.bwin[pos + step - 1] < id) pos += step;
+                            kblk = pos - rlo;
+                            if (sm.bwin[pos] < id) ok = false;                      // id beyond B's last id
+                        }
+                        if (ok && !found && kblk >= r0 && kblk < r0 + nr) {
+                            // (d) which slot: branch-free lower bound over the 256 (padded) ids of the block
+                            const uint32_t* __restrict__ a = sm.bids + (kblk - r0) * BLOCK_IDS;
+                            uint32_t pos = 0;
+#pragma unroll
+                            for (uint32_t step = 128; step > 0; step >>= 1)
+                                if (a[pos + step - 1] < id) pos += step;
+                            if (a[pos] == id) { found = true; p1 = (jlo + kblk) * BLOCK_IDS + pos; }
+                            else ok = false;
+                        }
+                        __syncthreads();                                            // tile reused by the next round / block
+                    }
+                    ok = ok && found;
+                }
+            }
+        }
         uint32_t total;
         const uint32_t my = block_compact(ok, sm.wave_cnt, total);
         const uint32_t p0 = b * BLOCK_IDS + t;
@@ -649,32 +742,50 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
     const KwQueryDev q = queries[blockIdx.x];
     if (t == 0) { s_cnt = 0; s_have_thr = 0; s_nm = 0; s_ow = 0; }
     __syncthreads();
-    for (uint32_t w = q.first_work; w < q.first_work + q.n_work; w++) {
-        const uint32_t n = part.cnt[w];
-        if (s_cnt + n > (uint32_t)CAP) topk_compact<CAP>(tk, &s_cnt, q.k, thr, &s_have_thr);
-        const uint32_t base_slot = s_cnt;
-        const size_t base = (size_t)w * part.k_stride;
-        for (uint32_t i = t; i < n; i += KW_THREADS) {
-            tk.s0[base_slot + i] = part.s0[base + i]; tk.s1[base_slot + i] = part.s1[base + i];
-            tk.s2[base_slot + i] = part.s2[base + i]; tk.key[base_slot + i] = part.key[base + i];
-        }
-        __syncthreads();
-        if (t == 0) { s_cnt = base_slot + n; s_nm += part.n_match[w]; s_ow += part.off_words[w]; }
-        __syncthreads();
-    }
-    topk_compact<CAP>(tk, &s_cnt, q.k, thr, &s_have_thr);
-    const uint32_t n = s_cnt;
     const size_t ob = (size_t)blockIdx.x * out.k_stride;
     int msi = -1;
     for (int i = 0; i < 3; i++) if (i < q.n_sort && q.sort_kind[i] == 0) msi = i;
-    for (uint32_t i = t; i < n; i += KW_THREADS) {
-        const int64_t a0 = tk.s0[i], a1 = tk.s1[i], a2 = tk.s2[i];
-        out.keys[ob + i] = (uint64_t)tk.key[i];
-        out.scores[(ob + i) * 3 + 0] = a0; out.scores[(ob + i) * 3 + 1] = a1; out.scores[(ob + i) * 3 + 2] = a2;
-        out.text_match[ob + i] = msi == 0 ? a0 : (msi == 1 ? a1 : (msi == 2 ? a2 : 0));
-        out.vector_distance[ob + i] = -1.0f;
-        out.match_score_index[ob + i] = (int8_t)msi;
+    uint32_t n;
+    if (q.n_work == 1) {
+        // a single work item already holds the query's final order: copy it through
+        const uint32_t w = q.first_work;
+        n = part.cnt[w];
+        const size_t base = (size_t)w * part.k_stride;
+        for (uint32_t i = t; i < n; i += KW_THREADS) {
+            const int64_t a0 = part.s0[base + i], a1 = part.s1[base + i], a2 = part.s2[base + i];
+            out.keys[ob + i] = (uint64_t)part.key[base + i];
+            out.scores[(ob + i) * 3 + 0] = a0; out.scores[(ob + i) * 3 + 1] = a1; out.scores[(ob + i) * 3 + 2] = a2;
+            out.text_match[ob + i] = msi == 0 ? a0 : (msi == 1 ? a1 : (msi == 2 ? a2 : 0));
+            out.vector_distance[ob + i] = -1.0f;
+            out.match_score_index[ob + i] = (int8_t)msi;
+        }
+        if (t == 0) { s_nm = part.n_match[w]; s_ow = part.off_words[w]; }
+    } else {
+        for (uint32_t w = q.first_work; w < q.first_work + q.n_work; w++) {
+            const uint32_t nw = part.cnt[w];
+            if (s_cnt + nw > (uint32_t)CAP) topk_compact<CAP>(tk, &s_cnt, q.k, thr, &s_have_thr);
+            const uint32_t base_slot = s_cnt;
+            const size_t base = (size_t)w * part.k_stride;
+            for (uint32_t i = t; i < nw; i += KW_THREADS) {
+                tk.s0[base_slot + i] = part.s0[base + i]; tk.s1[base_slot + i] = part.s1[base + i];
+                tk.s2[base_slot + i] = part.s2[base + i]; tk.key[base_slot + i] = part.key[base + i];
+            }
+            __syncthreads();
+            if (t == 0) { s_cnt = base_slot + nw; s_nm += part.n_match[w]; s_ow += part.off_words[w]; }
+            __syncthreads();
+        }
+        topk_compact<CAP>(tk, &s_cnt, q.k, thr, &s_have_thr);
+        n = s_cnt;
+        for (uint32_t i = t; i < n; i += KW_THREADS) {
+            const int64_t a0 = tk.s0[i], a1 = tk.s1[i], a2 = tk.s2[i];
+            out.keys[ob + i] = (uint64_t)tk.key[i];
+            out.scores[(ob + i) * 3 + 0] = a0; out.scores[(ob + i) * 3 + 1] = a1; out.scores[(ob + i) * 3 + 2] = a2;
+            out.text_match[ob + i] = msi == 0 ? a0 : (msi == 1 ? a1 : (msi == 2 ? a2 : 0));
+            out.vector_distance[ob + i] = -1.0f;
+            out.match_score_index[ob + i] = (int8_t)msi;
+        }
     }
+    __syncthreads();
     if (t == 0) { out.n_hits[blockIdx.x] = n; out.num_matched[blockIdx.x] = s_nm; out.off_words[blockIdx.x] = s_ow; }
     (void)ids_out; (void)work;
 }

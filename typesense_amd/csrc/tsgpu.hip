@@ -38,7 +38,9 @@ IndexView make_view(tsgpu_ctx* ctx) {
     IndexView v;
     v.lists = ctx->snap.lists.as<ListDesc>();
     v.blk_last = ctx->snap.blk_last.as<uint32_t>();
+    v.blk_ids = ctx->snap.blk_ids.as<BlockIds>();
     v.blk_meta = ctx->snap.blk_meta.as<BlockMeta>();
+    v.ids_payload = ctx->snap.ids_payload.as<uint32_t>();
     v.payload = ctx->snap.payload.as<uint32_t>();
     v.columns = ctx->d_col_ptrs.as<const int64_t*>();
     v.column_len = ctx->d_col_len.as<uint32_t>();
@@ -104,7 +106,7 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     tsgpu_vec_destroy_all(ctx);
-    DevBuf* bufs[] = {&ctx->snap.lists, &ctx->snap.blk_last, &ctx->snap.blk_meta, &ctx->snap.payload, &ctx->d_col_ptrs, &ctx->d_col_len,
+    DevBuf* bufs[] = {&ctx->snap.lists, &ctx->snap.blk_last, &ctx->snap.blk_ids, &ctx->snap.blk_meta, &ctx->snap.ids_payload, &ctx->snap.payload, &ctx->d_col_ptrs, &ctx->d_col_len,
                       &ctx->d_queries, &ctx->d_work, &ctx->d_aux, &ctx->d_ids_out, &ctx->d_part_s0, &ctx->d_part_s1, &ctx->d_part_s2,
                       &ctx->d_part_key, &ctx->d_part_cnt, &ctx->d_part_nm, &ctx->d_part_ne, &ctx->d_part_ow, &ctx->d_out_keys,
                       &ctx->d_out_scores, &ctx->d_out_tm, &ctx->d_out_vd, &ctx->d_out_msi, &ctx->d_out_nh, &ctx->d_out_nm, &ctx->d_out_ow};
@@ -229,24 +231,30 @@ int tsgpu_commit(tsgpu_ctx* ctx) {
     try {
         std::vector<ListDesc> descs;
         std::unordered_map<uint64_t, uint32_t> handle_of;
-        uint64_t n_blocks = 0, n_words = 0;
+        uint64_t n_blocks = 0, n_words = 0, n_id_words = 0;
         std::vector<std::pair<uint64_t, const PackedList*>> order;
         for (auto& f : ctx->fields)
             for (auto& t : f.second.terms) order.emplace_back(((uint64_t)f.first << 32) | t.first, &t.second);
         std::sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
         uint32_t max_id = 0;
-        for (auto& e : order) { n_blocks += e.second->blk_last.size(); n_words += e.second->payload.size(); max_id = std::max(max_id, e.second->desc.last_id); }
+        for (auto& e : order) { n_blocks += e.second->blk_last.size(); n_words += e.second->payload.size(); n_id_words += e.second->ids_payload.size(); max_id = std::max(max_id, e.second->desc.last_id); }
         if (n_blocks >= 0xFFFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_commit: more than 2^32 posting blocks");
         std::vector<uint32_t> h_last(n_blocks);
         std::vector<BlockMeta> h_meta(n_blocks);
+        std::vector<BlockIds> h_ids(n_blocks);
         std::vector<uint32_t> h_payload(n_words + 4, 0u);
-        uint64_t bpos = 0, wpos = 0;
+        std::vector<uint32_t> h_idw(n_id_words + 4, 0u);
+        uint64_t bpos = 0, wpos = 0, ipos = 0;
         descs.reserve(order.size());
         for (auto& e : order) {
             const PackedList& pl = *e.second;
             ListDesc d = pl.desc;
             d.blk_base = (uint32_t)bpos;
             d.payload_base = wpos;
+            d.ids_base = ipos;
+            std::copy(pl.blk_ids.begin(), pl.blk_ids.end(), h_ids.begin() + bpos);
+            std::copy(pl.ids_payload.begin(), pl.ids_payload.end(), h_idw.begin() + ipos);
+            ipos += pl.ids_payload.size();
             std::copy(pl.blk_last.begin(), pl.blk_last.end(), h_last.begin() + bpos);
             std::copy(pl.blk_meta.begin(), pl.blk_meta.end(), h_meta.begin() + bpos);
             std::copy(pl.payload.begin(), pl.payload.end(), h_payload.begin() + wpos);
@@ -261,13 +269,17 @@ int tsgpu_commit(tsgpu_ctx* ctx) {
         if ((rc = s.blk_last.reserve(std::max<size_t>(h_last.size(), 1) * 4))) return rc;
         if ((rc = s.blk_meta.reserve(std::max<size_t>(h_meta.size(), 1) * sizeof(BlockMeta)))) return rc;
         if ((rc = s.payload.reserve(h_payload.size() * 4))) return rc;
+        if ((rc = s.blk_ids.reserve(std::max<size_t>(h_ids.size(), 1) * sizeof(BlockIds)))) return rc;
+        if ((rc = s.ids_payload.reserve(h_idw.size() * 4))) return rc;
+        if (!h_ids.empty()) TSGPU_HIP_TRY(hipMemcpy(s.blk_ids.p, h_ids.data(), h_ids.size() * sizeof(BlockIds), hipMemcpyHostToDevice));
+        TSGPU_HIP_TRY(hipMemcpy(s.ids_payload.p, h_idw.data(), h_idw.size() * 4, hipMemcpyHostToDevice));
         if (!descs.empty()) TSGPU_HIP_TRY(hipMemcpy(s.lists.p, descs.data(), descs.size() * sizeof(ListDesc), hipMemcpyHostToDevice));
         if (!h_last.empty()) TSGPU_HIP_TRY(hipMemcpy(s.blk_last.p, h_last.data(), h_last.size() * 4, hipMemcpyHostToDevice));
         if (!h_meta.empty()) TSGPU_HIP_TRY(hipMemcpy(s.blk_meta.p, h_meta.data(), h_meta.size() * sizeof(BlockMeta), hipMemcpyHostToDevice));
         TSGPU_HIP_TRY(hipMemcpy(s.payload.p, h_payload.data(), h_payload.size() * 4, hipMemcpyHostToDevice));
         s.h_lists.swap(descs);
         s.handle_of.swap(handle_of);
-        s.bytes = s.lists.cap + s.blk_last.cap + s.blk_meta.cap + s.payload.cap;
+        s.bytes = s.lists.cap + s.blk_last.cap + s.blk_ids.cap + s.blk_meta.cap + s.ids_payload.cap + s.payload.cap;
         if (!ctx->num_docs_set) ctx->num_docs = std::max(ctx->num_docs, order.empty() ? 0u : max_id + 1);
         ctx->dirty = false;
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_commit: host allocation failed"); }
@@ -300,8 +312,11 @@ int tsgpu_term_download(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, uin
         const size_t words = (size_t)lm.off_woff + packed_words(lm.n_off, lm.off_bits);
         std::vector<uint32_t> payload(words + 2);
         TSGPU_HIP_TRY(hipMemcpy(payload.data(), ctx->snap.payload.as<uint32_t>() + d.payload_base, words * 4, hipMemcpyDeviceToHost));
+        const size_t iwords = (size_t)lm.ids_woff + packed_words(lm.n_ids, lm.ids_bits);
+        std::vector<uint32_t> idw(iwords + 2);
+        TSGPU_HIP_TRY(hipMemcpy(idw.data(), ctx->snap.ids_payload.as<uint32_t>() + d.ids_base, iwords * 4, hipMemcpyDeviceToHost));
         std::vector<uint32_t> a, b, c;
-        unpack_list(d, last.data(), meta.data(), payload.data(), a, b, c);
+        unpack_list(d, last.data(), meta.data(), idw.data(), payload.data(), a, b, c);
         if (n_offsets) *n_offsets = (uint32_t)c.size();
         if (ids) std::copy(a.begin(), a.end(), ids);
         if (offset_index) std::copy(b.begin(), b.end(), offset_index);

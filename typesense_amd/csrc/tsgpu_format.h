@@ -13,7 +13,10 @@
 //   * the three arrays stay frame-of-reference bit-packed (same arithmetic as libfor: value-base in `bits`
 //     bits, LSB-first), but in 32-bit words, each array padded to a whole word + one guard word so a lane
 //     can extract any element with two dword loads and a funnel shift — no per-block decode/alloc;
-//   * all lists of a snapshot live in three arenas (blk_last, blk_meta, payload) -> 3 allocations total.
+//   * the doc ids live in their OWN arena (ids_payload + a 16-byte BlockIds record per block), apart from the
+//     offset_index/offsets arena: the intersection streams ids only, so a cache line it fetches holds nothing
+//     but ids (with one interleaved arena ~57% of every fetched line was offsets the intersection never reads);
+//   * all lists of a snapshot live in five arenas (blk_last, blk_ids, blk_meta, ids_payload, payload).
 #pragma once
 #include <stdint.h>
 
@@ -27,9 +30,16 @@ namespace tsgpu {
 
 static const uint32_t BLOCK_IDS = 256;
 
-struct BlockMeta {           // 32 bytes
+struct BlockIds {            // 16 bytes: everything the intersection needs to decode a block's ids
     uint32_t first_id;       // FOR base of ids (= ids[0])
-    uint32_t ids_woff;       // word offsets are relative to ListDesc::payload_base
+    uint32_t last_id;        // = blk_last[]
+    uint32_t ids_woff;       // word offset relative to ListDesc::ids_base (ids_payload arena)
+    uint32_t n_ids_bits;     // n_ids (1..256) | ids_bits << 16
+};
+
+struct BlockMeta {           // 32 bytes: offsets side of a block (scoring only)
+    uint32_t first_id;       // FOR base of ids (= ids[0])
+    uint32_t ids_woff;       // relative to ListDesc::ids_base (ids_payload arena); other word offsets: ListDesc::payload_base
     uint32_t oi_woff;        // offset_index, FOR base 0 (offset_index[0] == 0 inside a block)
     uint32_t off_woff;       // offsets, FOR base off_base
     uint32_t n_off;          // total offsets stored in this block
@@ -41,8 +51,9 @@ struct BlockMeta {           // 32 bytes
     uint8_t pad[3];
 };
 
-struct ListDesc {            // 32 bytes
-    uint64_t payload_base;   // word index into the payload arena
+struct ListDesc {            // 40 bytes
+    uint64_t payload_base;   // word index into the payload arena (offset_index + offsets)
+    uint64_t ids_base;       // word index into the ids_payload arena
     uint32_t blk_base;       // index of the list's first block in blk_last[] / blk_meta[]
     uint32_t n_blocks;
     uint32_t n_ids;

@@ -68,7 +68,7 @@ struct FieldHost {
 };
 
 struct Snapshot {            // immutable HBM image of all posting lists
-    DevBuf lists, blk_last, blk_meta, payload;
+    DevBuf lists, blk_last, blk_ids, blk_meta, ids_payload, payload;
     std::vector<ListDesc> h_lists;                                  // host copy of the descriptors
     std::unordered_map<uint64_t, uint32_t> handle_of;               // (field<<32 | term) -> list handle
     uint64_t bytes = 0;

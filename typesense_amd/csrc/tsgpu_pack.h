@@ -12,8 +12,10 @@ namespace tsgpu {
 struct PackedList {
     ListDesc desc{};                    // payload_base / blk_base filled when placed into the arenas
     std::vector<uint32_t> blk_last;     // [n_blocks]
+    std::vector<BlockIds> blk_ids;      // [n_blocks]
     std::vector<BlockMeta> blk_meta;    // [n_blocks]
-    std::vector<uint32_t> payload;      // packed words
+    std::vector<uint32_t> ids_payload;  // packed doc ids
+    std::vector<uint32_t> payload;      // packed offset_index + offsets
 };
 
 static inline void pack_bits(std::vector<uint32_t>& out, const uint32_t* vals, uint32_t n, uint32_t base, uint32_t bits) {
@@ -37,6 +39,7 @@ static inline PackedList pack_list(const uint32_t* ids, const uint64_t* offset_i
     PackedList pl;
     const uint32_t nb = (n_ids + BLOCK_IDS - 1) / BLOCK_IDS;
     pl.blk_last.resize(nb);
+    pl.blk_ids.resize(nb);
     pl.blk_meta.resize(nb);
     std::vector<uint32_t> oi(BLOCK_IDS);
     for (uint32_t b = 0; b < nb; b++) {
@@ -57,14 +60,18 @@ static inline PackedList pack_list(const uint32_t* ids, const uint64_t* offset_i
         if (o1 == o0) { lo = 0; hi = 0; }
         m.off_base = lo;
         m.off_bits = (uint8_t)required_bits(hi - lo);
-        m.ids_woff = (uint32_t)pl.payload.size();
-        pack_bits(pl.payload, ids + s, cnt, m.first_id, m.ids_bits);
+        m.ids_woff = (uint32_t)pl.ids_payload.size();
+        pack_bits(pl.ids_payload, ids + s, cnt, m.first_id, m.ids_bits);
         m.oi_woff = (uint32_t)pl.payload.size();
         pack_bits(pl.payload, oi.data(), cnt, 0, m.oi_bits);
         m.off_woff = (uint32_t)pl.payload.size();
         pack_bits(pl.payload, offsets + o0, m.n_off, m.off_base, m.off_bits);
         pl.blk_meta[b] = m;
         pl.blk_last[b] = ids[s + cnt - 1];
+        BlockIds bi;
+        bi.first_id = m.first_id; bi.last_id = ids[s + cnt - 1]; bi.ids_woff = m.ids_woff;
+        bi.n_ids_bits = cnt | ((uint32_t)m.ids_bits << 16);
+        pl.blk_ids[b] = bi;
     }
     pl.desc.n_blocks = nb;
     pl.desc.n_ids = n_ids;
@@ -75,14 +82,14 @@ static inline PackedList pack_list(const uint32_t* ids, const uint64_t* offset_i
 }
 
 // inverse (tests / tsgpu_term_download): decode a packed list back into the three flat arrays
-static inline void unpack_list(const ListDesc& d, const uint32_t* blk_last, const BlockMeta* meta, const uint32_t* payload,
+static inline void unpack_list(const ListDesc& d, const uint32_t* blk_last, const BlockMeta* meta, const uint32_t* ids_payload, const uint32_t* payload,
                                std::vector<uint32_t>& ids, std::vector<uint32_t>& offset_index, std::vector<uint32_t>& offsets) {
     ids.clear(); offset_index.clear(); offsets.clear();
     for (uint32_t b = 0; b < d.n_blocks; b++) {
         const BlockMeta& m = meta[b];
         const uint32_t obase = (uint32_t)offsets.size();
         for (uint32_t i = 0; i < m.n_ids; i++) {
-            ids.push_back(m.first_id + unpack_at(payload + m.ids_woff, i, m.ids_bits));
+            ids.push_back(m.first_id + unpack_at(ids_payload + m.ids_woff, i, m.ids_bits));
             offset_index.push_back(obase + unpack_at(payload + m.oi_woff, i, m.oi_bits));
         }
         for (uint32_t i = 0; i < m.n_off; i++) offsets.push_back(m.off_base + unpack_at(payload + m.off_woff, i, m.off_bits));
