@@ -11,9 +11,10 @@ from typesense_amd import _lib as B
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def emu_lib_path():
-    """tests/hipemu/_build/libtsgpu_emu.so: the unmodified product sources compiled against the SIMT emulator."""
-    out = subprocess.check_output([os.path.join(ROOT, "tests", "hipemu", "build_emu.sh")], text=True).strip().splitlines()[-1]
+def emu_lib_path(defs="", suffix=""):
+    """tests/hipemu/_build/libtsgpu_emu.so: the unmodified product sources compiled against the SIMT emulator.
+    defs/suffix: a variant build with extra -D flags (e.g. a tiny LDS tile to force the multi-round paths)."""
+    out = subprocess.check_output([os.path.join(ROOT, "tests", "hipemu", "build_emu.sh"), defs, suffix], text=True).strip().splitlines()[-1]
     return out
 
 

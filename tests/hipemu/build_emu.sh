@@ -9,7 +9,9 @@ ROOT="$(cd "$HERE/../.." && pwd)"
 CXX=/opt/rocm/lib/llvm/bin/clang++
 [ -x "$CXX" ] || CXX=clang++
 mkdir -p "$HERE/_build"
-OUT="$HERE/_build/libtsgpu_emu.so"
+# optional: $1 = extra -D flags, $2 = output suffix (variant builds for tests that force rarely-taken paths)
+EXTRA="$1"
+OUT="$HERE/_build/libtsgpu_emu$2.so"
 SRCS="$ROOT/typesense_amd/csrc/tsgpu.hip $ROOT/typesense_amd/csrc/tsgpu_vec.hip"
 NEWER=0
 for f in $SRCS "$ROOT"/typesense_amd/csrc/*.h "$ROOT"/include/*.h "$HERE"/hip/hip_runtime.h; do
@@ -17,6 +19,6 @@ for f in $SRCS "$ROOT"/typesense_amd/csrc/*.h "$ROOT"/include/*.h "$HERE"/hip/hi
 done
 if [ "$NEWER" = 1 ]; then
   "$CXX" -x c++ -std=c++17 -O1 -g -fPIC -shared -ffp-contract=off -DTSGPU_HIP_EMU=1 -Wno-unused-value -Wno-macro-redefined -Wno-psabi \
-      -I "$HERE" -o "$OUT" $SRCS -lpthread
+      $EXTRA -I "$HERE" -o "$OUT" $SRCS -lpthread
 fi
 echo "$OUT"

@@ -168,15 +168,16 @@ def _synthetic_lists(seed):
     return n_docs, lists
 
 
-@pytest.mark.parametrize("chunk", [64, 1])
-def test_stage1_block_merge_windows_fallback_and_exhaustion(chunk):
+@pytest.mark.parametrize("chunk,tile", [(64, 0), (1, 0), (64, 512)])
+def test_stage1_block_merge_windows_fallback_and_exhaustion(chunk, tile):
     from oracle import oracle_py as O
+    lib = H.emu_lib_path("-DTSGPU_KW_TILE_WORDS=%d" % tile, "_tile%d" % tile) if tile else H.emu_lib_path()   # 512-word tile: every wide run takes several rounds
     n_docs, lists = _synthetic_lists(5)
     pts = H.points_of(n_docs)
     orc = O.OracleIndex(1, 1)
     orc.set_num_docs(n_docs)
     orc.set_sort_dense(0, pts)
-    g = T.GpuIndex(0, H.emu_lib_path())
+    g = T.GpuIndex(0, lib)
     g.field_create(0, False)
     for term, (ids, oi, off) in lists.items():
         orc.load_posting(0, term, ids, oi, off)

@@ -27,6 +27,11 @@ for n_q in (10000, 1000, 100):
             g.set_option(k, v)
         for _ in range(2):
             g.keyword_search_batch_raw(arr, n_q, hs)
+        prof = None
+        if hasattr(g.L, 'tsgpu_debug_prof') and os.environ.get('KW_PROF'):
+            import ctypes as C
+            prof = (C.c_uint64 * 16)()
+            g.L.tsgpu_debug_prof(g.h, 1, None)
         t0 = time.perf_counter(); ks = []; ms = []
         for _ in range(5):
             g.keyword_search_batch_raw(arr, n_q, hs)
@@ -34,4 +39,9 @@ for n_q in (10000, 1000, 100):
         wall = (time.perf_counter() - t0) / 5
         print(json.dumps(dict(n_q=n_q, opts=opts, wall_ms=wall * 1e3, qps=n_q / wall, search_ms=float(np.mean(ks)), merge_ms=float(np.mean(ms)),
                               alg_GBs=tm.kw_algorithmic_bytes / (np.mean(ks) * 1e-3) / 1e9)), flush=True)
+        if prof is not None:
+            g.L.tsgpu_debug_prof(g.h, 1, prof)
+            v = list(prof)
+            tot = sum(v[:12]) or 1
+            print('PROF wg=%d' % v[12], ' '.join('p%d=%.1f%%' % (i, 100.0 * v[i] / tot) for i in range(12)), 'cycles/wg=%.0f' % (tot / max(v[12], 1)), flush=True)
 g.close()

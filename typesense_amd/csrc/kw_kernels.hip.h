@@ -35,15 +35,25 @@
 
 namespace tsgpu {
 
+// TSGPU_PROF builds only (tools/): per-phase cycle accounting of kw_search_kernel (wave 0 lane 0 of every workgroup)
+#ifdef TSGPU_PROF
+#define KW_PROF_DECL unsigned long long prof_t[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long prof_last = __builtin_readcyclecounter();
+#define KW_PROF(i) { const unsigned long long _n = __builtin_readcyclecounter(); prof_t[i] += _n - prof_last; prof_last = _n; }
+#define KW_PROF_FLUSH(ptr) if (threadIdx.x == 0 && (ptr)) { for (int _i = 0; _i < 12; _i++) atomicAdd((ptr) + _i, prof_t[_i]); atomicAdd((ptr) + 12, 1ull); }
+#else
+#define KW_PROF_DECL
+#define KW_PROF(i)
+#define KW_PROF_FLUSH(ptr)
+#endif
+
 static const int KW_THREADS = 256;
 static const int KW_QCAP = 512;            // LDS queue capacity (>= 255 leftover + 256 new)
 static const int KW_MAX_TOKENS = 10;       // TSGPU_MAX_QUERY_TOKENS
 static const uint32_t KW_WINDOW_SIZE = 10; // WINDOW_SIZE, include/match_score.h:11
-#ifndef TSGPU_KW_RMAX
-#define TSGPU_KW_RMAX 8
+#ifndef TSGPU_KW_TILE_WORDS
+#define TSGPU_KW_TILE_WORDS 2048
 #endif
-static const int KW_RMAX = TSGPU_KW_RMAX;  // blocks of the second list decoded into LDS per round (8 x 256 ids = 8 KB)
-static const int KW_WMAX = 64;             // widest run of second-list blocks merged through LDS (one wave-wide window)
+static const int KW_TILE_WORDS = TSGPU_KW_TILE_WORDS;   // LDS tile of PACKED second-list ids per round (8 KB ~ 20 blocks of 12-bit ids); multiple of 256
 
 struct IndexView {
     const ListDesc* lists;
@@ -56,6 +66,7 @@ struct IndexView {
     const uint32_t* column_len;
     uint32_t n_columns;
     uint32_t num_docs;
+    unsigned long long* prof;        // TSGPU_PROF builds: 13 counters; else null
 };
 
 struct KwQueryDev {                  // one search_across_fields call
@@ -107,6 +118,25 @@ __device__ inline uint32_t block_compact(bool pred, uint32_t* s_wave_cnt /*[4]*/
     const unsigned long long mask = __ballot(pred ? 1 : 0);
     const uint32_t lane_off = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     __syncthreads();                       // protect s_wave_cnt reuse from a previous call
+    if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < KW_THREADS / 64; w++) {
+        const uint32_t c = s_wave_cnt[w];
+        if ((uint32_t)w < wave) base += c;
+        tot += c;
+    }
+    total = tot;
+    return base + lane_off;
+}
+
+// single-barrier variant for the main loop: the caller alternates between two count arrays, so the barrier of
+// call i+1 orders every read of call i before the writes of call i+2
+__device__ inline uint32_t block_compact1(bool pred, uint32_t* s_wave_cnt /*[4], alternate per call*/, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long mask = __ballot(pred ? 1 : 0);
+    const uint32_t lane_off = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
     if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
     __syncthreads();
     uint32_t base = 0, tot = 0;
@@ -449,9 +479,10 @@ struct KwSmem {
     uint32_t qf_pos[TMAX][KW_QCAP];
     TopkLds<CAP> tk;
     int64_t thr[4];
-    uint32_t bids[KW_RMAX * BLOCK_IDS];      // decoded ids of the second list's blocks under the current driver block
-    uint32_t bwin[KW_WMAX];                  // blk_last[] window of the second list
+    uint32_t btile[KW_TILE_WORDS + 2];       // packed ids of the second list's blocks under the current driver block
+    uint32_t b_last[64], b_first[64], b_woff[64], b_nb[64];   // the second list's BlockIds window, SoA
     uint32_t wave_cnt[KW_THREADS / 64];
+    uint32_t wave_cnt2[2][KW_THREADS / 64];  // block_compact1 ping-pong
     uint32_t q1_cnt, qf_cnt, tk_cnt, have_thr;
     uint32_t n_match, n_emit;
     unsigned long long off_words;
@@ -539,6 +570,9 @@ __device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP>& sm, const IndexVie
             for (int k = 0; k < TMAX; k++) if ((uint32_t)k == tok) pos[k] = p;
         }
     }
+#if defined(TSGPU_EXP) && TSGPU_EXP == 4
+    ok = ok && (id == 0xFFFFFFFEu);
+#endif
     uint32_t total;
     const uint32_t my = block_compact(ok, sm.wave_cnt, total);
     if (ok) {
@@ -583,17 +617,60 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
 
     const ListDesc dB = ix.lists[q.list[q.probe_order[T >= 2 ? 1 : 0]]];
     const uint32_t* __restrict__ blB = ix.blk_last + dB.blk_base;
+    const BlockIds* __restrict__ biA = ix.blk_ids + dA.blk_base;
+    const BlockIds* __restrict__ biB = ix.blk_ids + dB.blk_base;
+    const uint32_t* __restrict__ idwA = ix.ids_payload + dA.ids_base;
+    const uint32_t* __restrict__ idwB = ix.ids_payload + dB.ids_base;
     const uint32_t lane = t & 63;
-    uint32_t curB = 0;                      // forward-only cursor into B's blocks (identical in every thread)
+    const BlockIds PAD = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
+
+    // Software pipeline over the driver blocks. Global round trips cost ~1-2K cycles each under load, so nothing
+    // on the per-block critical path may wait for a load issued in the same iteration except the second list's
+    // payload: the driver block's BlockIds are fetched two blocks ahead, its packed ids one block ahead, and the
+    // second list's BlockIds window (lane <-> block wbase+lane) as soon as the previous block fixed the cursor.
+    auto load_words = [&](const uint32_t* __restrict__ base, const BlockIds& m, uint32_t slot, uint32_t& w0, uint32_t& w1) {
+        const uint32_t bits = m.n_ids_bits >> 16;
+        w0 = 0; w1 = 0;
+        if (slot < (m.n_ids_bits & 0xFFFF) && bits) {
+            const uint32_t wi = (slot * bits) >> 5;
+            const uint32_t* __restrict__ w = base + m.ids_woff + wi;
+            w0 = w[0]; w1 = w[1];
+        }
+    };
+    auto extract = [&](const BlockIds& m, uint32_t slot, uint32_t w0, uint32_t w1) -> uint32_t {
+        const uint32_t bits = m.n_ids_bits >> 16;
+        if (slot >= (m.n_ids_bits & 0xFFFF)) return 0xFFFFFFFFu;
+        if (bits == 0) return m.first_id;
+        const uint32_t sh = (slot * bits) & 31;
+        const uint64_t two = (uint64_t)w0 | ((uint64_t)w1 << 32);
+        const uint64_t mask = bits >= 32 ? 0xFFFFFFFFull : ((1ull << bits) - 1ull);
+        return m.first_id + (uint32_t)((two >> sh) & mask);
+    };
+    auto load_window = [&](uint32_t base) -> BlockIds { return (T >= 2 && base + lane < dB.n_blocks) ? biB[base + lane] : PAD; };
+
+    KW_PROF_DECL
+    BlockIds mA = biA[wi.blk_begin];
+    BlockIds mA1 = (wi.blk_begin + 1 < wi.blk_end) ? biA[wi.blk_begin + 1] : PAD;
+    uint32_t aw0, aw1;
+    load_words(idwA, mA, t, aw0, aw1);
+    // the second list's BlockIds, lane <-> block: win = [wbase, wbase+64), nxt = [wbase+32, wbase+96) already in
+    // flight. The cursor only moves forward; when it enters the upper half, nxt becomes win (no load on the
+    // critical path) and the following window is requested.
+    uint32_t wbase = 0;
+    BlockIds win = load_window(0), nxt = load_window(32);
+    bool win_dirty = true;                    // LDS copy of the window (b_last / b_first / b_woff / b_nb) is stale
+    uint32_t q1n = 0, qfn = 0, par = 0;       // queue fill levels mirrored in registers (identical in every thread)
     bool b_exhausted = false;
 
     for (uint32_t b = wi.blk_begin; b < wi.blk_end && !b_exhausted; b++) {
+        // ---- prefetch for the next blocks ----
+        BlockIds mA2 = (b + 2 < wi.blk_end) ? biA[b + 2] : PAD;
+        uint32_t nw0 = 0, nw1 = 0;
+        if (b + 1 < wi.blk_end) load_words(idwA, mA1, t, nw0, nw1);
         // ---- stage 0: thread t = slot t of driver block b ----
-        const BlockIds m = ix.blk_ids[dA.blk_base + b];
-        const uint32_t m_n = m.n_ids_bits & 0xFFFF;
+        const uint32_t m_n = mA.n_ids_bits & 0xFFFF;
         bool ok = t < m_n;
-        uint32_t id = 0, p1 = 0;
-        if (ok) id = m.first_id + unpack_at(ix.ids_payload + dA.ids_base + m.ids_woff, t, m.n_ids_bits >> 16);
+        uint32_t id = extract(mA, t, aw0, aw1), p1 = 0;
         // filter ids (sorted whitelist): membership is decided per candidate; the reference's
         // filter-driven skipping only changes WHICH matches are counted, handled in the host shim (v1: no filter in-kernel)
         if (ok && q.n_filt) {
@@ -601,96 +678,146 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (filt[mid] < id) lo = mid + 1; else hi = mid; }
             ok = (lo < q.n_filt && filt[lo] == id);
         }
+        KW_PROF(0)
         // ---- stage 1: merge with the second-shortest list B ----
         if (T >= 2) {
-            // (a) B blocks [jlo, jhi] overlap this driver block's id range [first_id, last_id]. Every wave runs the
-            //     same search on the same data (uniform result, no LDS hand-off): one coalesced window of blk_last[].
-            const uint32_t lo_id = m.first_id, hi_id = m.last_id;
-            uint32_t wbase = curB;
-            uint32_t wv = (wbase + lane < dB.n_blocks) ? blB[wbase + lane] : 0xFFFFFFFFu;
-            unsigned long long mk = __ballot(wv >= lo_id ? 1 : 0);
-            if ((mk & ((wbase + 64 <= dB.n_blocks) ? ~0ull : ((1ull << (dB.n_blocks - wbase)) - 1ull))) == 0) {
-                // beyond the window: uniform binary search over the rest, then re-centre the window
-                uint32_t lo = wbase + 64 < dB.n_blocks ? wbase + 64 : dB.n_blocks, hi = dB.n_blocks;
+            // (a) B blocks [jlo, jhi] overlap this driver block's id range [first_id, last_id]. Every wave holds the
+            //     same window (uniform result, no LDS hand-off). Padding lanes (beyond B's last block) hold FFFFFFFF.
+            const uint32_t lo_id = mA.first_id, hi_id = mA.last_id;
+            unsigned long long mk = __ballot(win.last_id >= lo_id ? 1 : 0);
+            if (mk != 0 && (uint32_t)__builtin_ctzll(mk) >= 32) {
+                // cursor entered the upper half: slide by 32 blocks onto the prefetched window
+                wbase += 32;
+                win = nxt;
+                nxt = load_window(wbase + 32);
+                win_dirty = true;
+                mk = __ballot(win.last_id >= lo_id ? 1 : 0);
+            }
+            if (mk == 0) {
+                // all 64 window blocks end before lo_id: uniform binary search over the rest, then re-centre
+                uint32_t lo = wbase + 64, hi = dB.n_blocks;                 // mk == 0 => all 64 lanes are real blocks
                 while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (blB[mid] >= lo_id) hi = mid; else lo = mid + 1; }
                 wbase = lo;
-                wv = (wbase + lane < dB.n_blocks) ? blB[wbase + lane] : 0xFFFFFFFFu;
-                mk = __ballot(wv >= lo_id ? 1 : 0);
+                win = load_window(wbase);
+                nxt = load_window(wbase + 32);
+                win_dirty = true;
+                mk = __ballot(win.last_id >= lo_id ? 1 : 0);                // lane 0 votes yes (real block or padding)
             }
-            if (wbase >= dB.n_blocks) {
+            const uint32_t rlo = (uint32_t)__builtin_ctzll(mk);
+            if (wbase + rlo >= dB.n_blocks) {
                 // every remaining candidate of this work item is beyond B's last id: nothing can match any more
                 ok = false;
                 b_exhausted = true;
             } else {
-                const uint32_t jlo = wbase + (uint32_t)__builtin_ctzll(mk);          // first block with last >= lo_id (exists: wv of lane 0.. real)
-                const unsigned long long mh = __ballot(wv >= hi_id ? 1 : 0);         // padding lanes (FFFFFFFF) always vote yes
-                uint32_t jhi_rel = (uint32_t)__builtin_ctzll(mh | (1ull << 63));     // relative to wbase; 63 => may lie beyond the window
-                const bool wide = (mh == 0) || (wbase + jhi_rel >= dB.n_blocks && dB.n_blocks - wbase > 64);
-                uint32_t jhi = wbase + jhi_rel;
-                if (jhi >= dB.n_blocks) jhi = dB.n_blocks - 1;                       // hi_id beyond B's last id
-                if (wide || jhi - wbase >= (uint32_t)KW_WMAX) {
-                    // run of B blocks wider than the window: per-candidate probe, cursor moved by a uniform search
+                const unsigned long long mh = __ballot(win.last_id >= hi_id ? 1 : 0);
+                if (mh == 0) {
+                    // the run of B blocks under this driver block is wider than the window: per-candidate probe;
+                    // the cursor moves by a uniform search
                     if (ok) ok = probe_list(ix, dB, id, p1);
-                    uint32_t lo = wbase, hi = dB.n_blocks;
+                    uint32_t lo = wbase + 64, hi = dB.n_blocks;
                     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (blB[mid] >= hi_id) hi = mid; else lo = mid + 1; }
-                    curB = lo < dB.n_blocks ? lo : dB.n_blocks - 1;
+                    wbase = lo < dB.n_blocks ? lo : dB.n_blocks - 1;
+                    win = load_window(wbase);
+                    nxt = load_window(wbase + 32);
+                    win_dirty = true;
                 } else {
-                    curB = jhi;
-                    if (t < 64) sm.bwin[t] = wv;                                     // window relative to wbase (wave 0's copy)
-                    const uint32_t rlo = jlo - wbase, rhi = jhi - wbase;             // inclusive, < 64
-                    const uint32_t nblk = rhi - rlo + 1;
-                    uint32_t kblk = 0;
-                    bool found = false;
-                    for (uint32_t r0 = 0; r0 < nblk; r0 += KW_RMAX) {
-                        const uint32_t nr = nblk - r0 < (uint32_t)KW_RMAX ? nblk - r0 : (uint32_t)KW_RMAX;
-                        // (b) decode B blocks jlo+r0 .. +nr into the LDS tile: thread t = slot t of each block
-                        for (uint32_t kk = 0; kk < nr; kk++) {
-                            const BlockIds mb = ix.blk_ids[dB.blk_base + jlo + r0 + kk];
-                            const uint32_t nb = mb.n_ids_bits & 0xFFFF;
-                            sm.bids[kk * BLOCK_IDS + t] = t < nb ? mb.first_id + unpack_at(ix.ids_payload + dB.ids_base + mb.ids_woff, t, mb.n_ids_bits >> 16)
-                                                                 : 0xFFFFFFFFu;
+                    uint32_t rhi = (uint32_t)__builtin_ctzll(mh);
+                    if (wbase + rhi >= dB.n_blocks) rhi = dB.n_blocks - 1 - wbase;       // hi_id beyond B's last id
+                    // (b) this wave's copy of the window -> LDS (block search + per-candidate block metadata)
+                    const uint32_t w_words = packed_words(win.n_ids_bits & 0xFFFF, win.n_ids_bits >> 16);
+                    const uint32_t w_endw = win.ids_woff + w_words;              // one past the block's packed words
+                    KW_PROF(1)
+                    if (win_dirty) {
+                        if (t < 64) { sm.b_last[t] = win.last_id; sm.b_first[t] = win.first_id; sm.b_woff[t] = win.ids_woff; sm.b_nb[t] = win.n_ids_bits; }
+                        win_dirty = false;
+                    }
+                    bool done = !ok, found = false;
+                    uint32_t kb = 0;
+#if defined(TSGPU_EXP) && TSGPU_EXP >= 3
+                    if (false)
+#endif
+                    for (uint32_t r_lo = rlo; r_lo <= rhi;) {
+                        // blocks r_lo..r_hi of the window: as many as fit the packed tile (at least one: a block is <= 257 words)
+                        const uint32_t w_begin = (uint32_t)__shfl(win.ids_woff, (int)r_lo);
+                        const unsigned long long fit = __ballot((lane >= r_lo && lane <= rhi && w_endw - w_begin <= (uint32_t)KW_TILE_WORDS) ? 1 : 0);
+                        const uint32_t r_hi = 63u - (uint32_t)__builtin_clzll(fit | 1ull);
+                        const uint32_t W = (uint32_t)__shfl(w_endw, (int)r_hi) - w_begin;
+                        // (c) coalesced copy of the PACKED ids of those blocks (contiguous in the ids arena) into LDS
+                        const uint32_t* __restrict__ src = idwB + w_begin;
+                        for (uint32_t i0 = t; i0 < W + t; i0 += 2 * KW_THREADS) {           // uniform trip count; 2 loads in flight per trip
+                            const uint32_t i1 = i0 + KW_THREADS;
+                            const uint32_t c0 = src[i0 < W ? i0 : 0], c1 = src[i1 < W ? i1 : 0];
+                            if (i0 < W) sm.btile[i0] = c0;
+                            if (i1 < W) sm.btile[i1] = c1;
                         }
+                        KW_PROF(2)
                         __syncthreads();
-                        if (r0 == 0 && ok) {
-                            // (c) which block: lower bound of id in bwin[rlo..rhi] (bwin[rhi] >= hi_id >= id unless B ended)
+                        KW_PROF(3)
+                        if (r_lo == rlo && !done) {
+                            // (d) which block: lower bound of id among the window's last ids (b_last[rhi] >= hi_id >= id unless B ended)
                             uint32_t pos = rlo;
 #pragma unroll
                             for (uint32_t step = 32; step > 0; step >>= 1)
-                                if (pos + step <= rhi && sm.bwin[pos + step - 1] < id) pos += step;
-                            kblk = pos - rlo;
-                            if (sm.bwin[pos] < id) ok = false;                      // id beyond B's last id
+                                if (pos + step <= rhi && sm.b_last[pos + step - 1] < id) pos += step;
+                            kb = pos;
+                            if (sm.b_last[pos] < id || id < sm.b_first[pos]) done = true;       // beyond B's end / in the gap between two blocks
                         }
-                        if (ok && !found && kblk >= r0 && kblk < r0 + nr) {
-                            // (d) which slot: branch-free lower bound over the 256 (padded) ids of the block
-                            const uint32_t* __restrict__ a = sm.bids + (kblk - r0) * BLOCK_IDS;
+#if defined(TSGPU_EXP) && TSGPU_EXP >= 2
+                        done = true;
+#endif
+                        if (!done && kb >= r_lo && kb <= r_hi) {
+                            // (e) which slot: branch-free lower bound over the block's packed ids, unpacked on the fly from LDS
+                            const uint32_t nb = sm.b_nb[kb], n = nb & 0xFFFF, bits = nb >> 16;
+                            const uint32_t* __restrict__ lw = sm.btile + (sm.b_woff[kb] - w_begin);
+                            const uint32_t target = id - sm.b_first[kb];
+                            const uint64_t mask = bits >= 32 ? 0xFFFFFFFFull : ((1ull << bits) - 1ull);
                             uint32_t pos = 0;
 #pragma unroll
-                            for (uint32_t step = 128; step > 0; step >>= 1)
-                                if (a[pos + step - 1] < id) pos += step;
-                            if (a[pos] == id) { found = true; p1 = (jlo + kblk) * BLOCK_IDS + pos; }
-                            else ok = false;
+                            for (uint32_t step = 128; step > 0; step >>= 1) {
+                                const uint32_t idx = pos + step - 1;
+                                const uint32_t bp = (idx < n ? idx : 0) * bits;
+                                const uint64_t two = (uint64_t)lw[bp >> 5] | ((uint64_t)lw[(bp >> 5) + 1] << 32);
+                                const uint32_t v = (uint32_t)((two >> (bp & 31)) & mask);
+                                if (pos + step <= n && v < target) pos += step;
+                            }
+                            const uint32_t bp = pos * bits;
+                            const uint64_t two = (uint64_t)lw[bp >> 5] | ((uint64_t)lw[(bp >> 5) + 1] << 32);
+                            done = true;
+                            if ((uint32_t)((two >> (bp & 31)) & mask) == target) { found = true; p1 = (wbase + kb) * BLOCK_IDS + pos; }
                         }
-                        __syncthreads();                                            // tile reused by the next round / block
+                        KW_PROF(4)
+                        r_lo = r_hi + 1;
+                        if (r_lo <= rhi) __syncthreads();                   // tile reused by the next round
                     }
                     ok = ok && found;
                 }
             }
         }
+#if defined(TSGPU_EXP) && TSGPU_EXP >= 1 && TSGPU_EXP < 4
+        ok = ok && (id == 0xFFFFFFFEu);   // ablation: drop survivors without letting the compiler drop stage 1
+#endif
         uint32_t total;
-        const uint32_t my = block_compact(ok, sm.wave_cnt, total);
+        KW_PROF(5)
+        const uint32_t my = block_compact1(ok, sm.wave_cnt2[par], total);
+        par ^= 1;
+        KW_PROF(6)
         const uint32_t p0 = b * BLOCK_IDS + t;
         if (T >= 3) {
-            if (ok) { const uint32_t slot = sm.q1_cnt + my; sm.q1_id[slot] = id; sm.q1_p0[slot] = p0; sm.q1_p1[slot] = p1; }
-            __syncthreads();
-            if (t == 0) sm.q1_cnt += total;
-            __syncthreads();
-            while (sm.q1_cnt >= KW_THREADS) {
-                kw_probe_rest_stage<TMAX, CAP>(sm, ix, q, KW_THREADS);
-                while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+            if (ok) { const uint32_t slot = q1n + my; sm.q1_id[slot] = id; sm.q1_p0[slot] = p0; sm.q1_p1[slot] = p1; }
+            q1n += total;
+            if (q1n >= KW_THREADS) {
+                __syncthreads();
+                if (t == 0) sm.q1_cnt = q1n;
+                __syncthreads();
+                while (sm.q1_cnt >= KW_THREADS) {
+                    kw_probe_rest_stage<TMAX, CAP>(sm, ix, q, KW_THREADS);
+                    while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+                }
+                q1n = sm.q1_cnt;
             }
         } else {
             if (ok) {
-                const uint32_t slot = sm.qf_cnt + my;
+                const uint32_t slot = qfn + my;
                 sm.qf_id[slot] = id;
 #pragma unroll
                 for (int k = 0; k < TMAX; k++) {
@@ -700,12 +827,21 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
                     sm.qf_pos[k][slot] = v;
                 }
             }
-            __syncthreads();
-            if (t == 0) sm.qf_cnt += total;
-            __syncthreads();
-            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+            qfn += total;
+            if (qfn >= KW_THREADS) {
+                __syncthreads();
+                if (t == 0) sm.qf_cnt = qfn;
+                __syncthreads();
+                while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+                qfn = sm.qf_cnt;
+            }
         }
+        KW_PROF(7)
+        mA = mA1; mA1 = mA2; aw0 = nw0; aw1 = nw1;
     }
+    __syncthreads();
+    if (t == 0) { if (T >= 3) sm.q1_cnt = q1n; else sm.qf_cnt = qfn; }
+    __syncthreads();
     // ---- flush ----
     if (T >= 3) {
         while (sm.q1_cnt > 0) {
@@ -714,6 +850,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
         }
     }
     while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+    KW_PROF(8)
 
     // ---- partial result of this work item: sorted, <= k entries ----
     topk_compact<CAP>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
@@ -728,6 +865,8 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
         part.n_emit[blockIdx.x] = sm.n_emit;
         part.off_words[blockIdx.x] = sm.off_words;
     }
+    KW_PROF(9)
+    KW_PROF_FLUSH(ix.prof)
 }
 
 // grid = queries; folds a query's partials into the final order and writes the tsgpu_hits slots

@@ -46,6 +46,7 @@ IndexView make_view(tsgpu_ctx* ctx) {
     v.column_len = ctx->d_col_len.as<uint32_t>();
     v.n_columns = (uint32_t)ctx->columns.size();
     v.num_docs = ctx->num_docs;
+    v.prof = ctx->d_prof.as<unsigned long long>();
     return v;
 }
 
@@ -109,7 +110,7 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->snap.lists, &ctx->snap.blk_last, &ctx->snap.blk_ids, &ctx->snap.blk_meta, &ctx->snap.ids_payload, &ctx->snap.payload, &ctx->d_col_ptrs, &ctx->d_col_len,
                       &ctx->d_queries, &ctx->d_work, &ctx->d_aux, &ctx->d_ids_out, &ctx->d_part_s0, &ctx->d_part_s1, &ctx->d_part_s2,
                       &ctx->d_part_key, &ctx->d_part_cnt, &ctx->d_part_nm, &ctx->d_part_ne, &ctx->d_part_ow, &ctx->d_out_keys,
-                      &ctx->d_out_scores, &ctx->d_out_tm, &ctx->d_out_vd, &ctx->d_out_msi, &ctx->d_out_nh, &ctx->d_out_nm, &ctx->d_out_ow};
+                      &ctx->d_out_scores, &ctx->d_out_tm, &ctx->d_out_vd, &ctx->d_out_msi, &ctx->d_out_nh, &ctx->d_out_nm, &ctx->d_out_ow, &ctx->d_prof};
     for (auto* b : bufs) b->release();
     for (auto& c : ctx->columns) c.data.release();
     ctx->h_stage.release();
@@ -635,6 +636,17 @@ uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64
         total += n;
     }
     return total;
+}
+
+// TSGPU_PROF builds (tools/ only; not declared in include/tsgpu.h): per-phase cycle counters of kw_search_kernel
+int tsgpu_debug_prof(tsgpu_ctx* ctx, int reset, uint64_t* out16) {
+    if (!ctx) return TSGPU_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_prof.reserve(16 * 8)) return TSGPU_ERR_NO_MEMORY;
+    if (out16) TSGPU_HIP_TRY(hipMemcpy(out16, ctx->d_prof.p, 16 * 8, hipMemcpyDeviceToHost));
+    if (reset) TSGPU_HIP_TRY(hipMemset(ctx->d_prof.p, 0, 16 * 8));
+    return TSGPU_OK;
 }
 
 int tsgpu_last_timings(tsgpu_ctx* ctx, tsgpu_timings* out) {
