@@ -3,21 +3,24 @@
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" = one pass of the hot path over one batch of synthetic queries:
-  * workload keyword (default, BASELINE config 2): 10M-doc Zipf collection (V=100K, 32 tokens/doc, seed 2),
-    a batch of 3-term conjunctive queries (ranks log-uniform [8,2000]), Topster 250 (per_page 100), sort
-    [_text_match desc, points desc]; N>1 = the collection split into N contiguous seq_id ranges (doc-range shards),
-    every rank scores the whole batch on its shard, RCCL all-gather of per-GPU top-K, exact merge.
-  * --workload vector (config 3): 10M x 768 fp32, batched exact inner-product top-100.
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed
-inside the library on its launch stream) and, at N=1, `cpu_baseline` (the oracle = a port of the reference's CPU
-path, timed on this box's host cores on a bounded sample of the same queries and also used as a parity check).
-The oracle is never the thing measured as `value`.
+A "step" = one pass of the hot path over one batch of synthetic queries. The headline (`metric`/`value`) is BASELINE
+config 2 — 10M-doc Zipf collection (V=100K, 32 tokens/doc, seed 2), a batch of 10 000 3-term conjunctive queries (ranks
+log-uniform [8,2000]), Topster 250 (per_page 100), sort [_text_match desc, points desc]. With the default
+`--workload all` the same JSON line also carries `vector` (config 3: 10M x 768 fp32, batched exact inner-product
+top-100) and `hybrid` (config 4: keyword + vector + reciprocal-rank fusion) sub-objects, each timed the same way.
+N>1 = the collection split into N contiguous seq_id ranges (doc-range shards, config 5): every rank scores the whole
+batch on its shard, RCCL all-gather of the per-GPU top-K, exact merge (typesense_amd/dist.py); scaling = "strong".
+
+`roofline` = the dominant kernel: algorithmic bytes (or flops) per launch / its HIP-event time measured inside the
+library on its launch stream. `cpu_baseline` (rank 0, N=1) = the oracle — a port of the reference's CPU path — timed on
+this box's host cores on a bounded sample of the same queries and used as a parity check. The oracle is never the
+thing measured as `value`; there is no CPU fallback.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import re
 import sys
 import time
 
@@ -28,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA dense peak
+K_TOPSTER = 250
 
 
 def parse():
@@ -35,9 +39,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="keyword", choices=["keyword", "vector"])
+    ap.add_argument("--workload", default="all", choices=["all", "keyword", "vector", "hybrid"])
     ap.add_argument("--n-docs", type=int, default=10_000_000)
-    ap.add_argument("--batch", type=int, default=0, help="queries per step (default 10000 keyword / 256 vector)")
+    ap.add_argument("--batch", type=int, default=0, help="keyword queries per step (default 10000)")
+    ap.add_argument("--vec-batch", type=int, default=256, help="vector / hybrid queries per step")
     ap.add_argument("--cpu-sample", type=int, default=0, help="queries of the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dim", type=int, default=768)
@@ -50,13 +55,11 @@ def dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(local)
     assert world == n_gpus, "launch with torch.distributed.run --nproc-per-node %d" % n_gpus
     return rank, world, local
 
@@ -79,8 +82,42 @@ def max_over_ranks(x, world):
     return float(t.item())
 
 
-# ------------------------------------------------------------------------------------------------ keyword
-def device_hits(torch, T, n_q, ks):
+def timed(step, steps, warmup, world, after=None):
+    """W untimed warmups, then exactly K steps bracketed by barrier + synchronize; returns (max-over-ranks seconds,
+    per-step latencies, last result). `after(result)` runs inside the timed loop after each step's synchronize."""
+    import torch
+    out = None
+    for _ in range(warmup):
+        out = step()
+    barrier(world)
+    lat = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s0 = time.perf_counter()
+        out = step()
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - s0)
+        if after:
+            after(out)
+    barrier(world)
+    return max_over_ranks(time.perf_counter() - t0, world), lat, out
+
+
+def pmc_traffic(kernel_rx, fname):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc FETCH_SIZE pass (KB, own pass);
+    None when the profile is absent. gfx950 correction (x2 for wide coalesced reads) is discussed in DESIGN.md §5."""
+    p = os.path.join(ROOT, "profiles", "r01", fname)
+    if not os.path.exists(p):
+        return None
+    for line in open(p):
+        if re.search(kernel_rx, line) and "FETCH_SIZE" in line:
+            m = re.search(r"avg=([0-9.e+]+)", line)
+            if m:
+                return float(m.group(1)) * 1024.0
+    return None
+
+
+def device_hits(torch, n_q, ks):
     from typesense_amd import _lib as B
     d = dict(keys=torch.zeros((n_q, ks), dtype=torch.int64, device="cuda"),
              scores=torch.zeros((n_q, ks, 3), dtype=torch.int64, device="cuda"),
@@ -99,222 +136,223 @@ def device_hits(torch, T, n_q, ks):
     return d, h
 
 
-def merge_shards_device(torch, gathered, k):
-    """exact G-way merge of per-shard Topster lists on the GPU: order = (s0, s1, s2, key) descending
-    (include/topster.h:146-149). gathered: dict of [G, B, K, ...] tensors."""
-    G, Bq, K = gathered["keys"].shape
-    keys = gathered["keys"].permute(1, 0, 2).reshape(Bq, G * K)
-    sc = gathered["scores"].permute(1, 0, 2, 3).reshape(Bq, G * K, 3)
-    nh = gathered["n_hits"].permute(1, 0)                                    # [B, G]
-    valid = (torch.arange(K, device=keys.device)[None, None, :] < nh[:, :, None]).reshape(Bq, G * K)
-    order = torch.arange(G * K, device=keys.device)[None, :].expand(Bq, -1)
-    # successive stable sorts, least significant key first; invalid slots last
-    for col in (keys, sc[..., 2], sc[..., 1], sc[..., 0]):
-        v = torch.gather(col, 1, order)
-        idx = torch.sort(v, dim=1, descending=True, stable=True).indices
-        order = torch.gather(order, 1, idx)
-    v = torch.gather(valid.to(torch.int8), 1, order)
-    idx = torch.sort(v, dim=1, descending=True, stable=True).indices
-    order = torch.gather(order, 1, idx)[:, :k]
-    out_keys = torch.gather(keys, 1, order)
-    out_sc = torch.gather(sc, 1, order[:, :, None].expand(-1, -1, 3))
-    n_out = torch.clamp(nh.sum(1), max=k)
-    return out_keys, out_sc, n_out
+class Bench:
+    def __init__(self, args, rank, world):
+        import torch
+        import typesense_amd as T
+        self.torch, self.T, self.args, self.rank, self.world = torch, T, args, rank, world
+        self.g = T.GpuIndex(torch.cuda.current_device())
+        self.n_docs = args.n_docs
+        from typesense_amd import dist as D
+        self.D = D
+        self.lo, self.hi = D.shard_range(self.n_docs, rank, world)
+        self.sort = None
+        self.csr = None
 
+    # ---------------------------------------------------------------- index builds (untimed)
+    def build_keyword(self):
+        from typesense_amd import _lib as B, synth
+        n_docs = self.n_docs
+        self.vocab, self.tpd = (100_000, 32) if n_docs >= 1_000_000 else (20_000, 16)
+        t0 = time.time()
+        # shard r holds docs [lo, hi): drawn slice by slice (seed per shard, shards i.i.d. like the whole collection;
+        # N=1 reproduces seed 2 exactly)
+        self.csr = synth.zipf_corpus_csr(self.hi - self.lo, self.vocab, self.tpd, seed=2 + 1000 * self.rank if self.world > 1 else 2,
+                                         doc_base=self.lo)
+        self.pts = synth.points_column(n_docs)
+        g = self.g
+        g.field_create(0, False)
+        c = self.csr
+        g.terms_load_csr(0, c["term_ids"], c["ids_ptr"], c["ids"], c["offset_index"], c["off_ptr"], c["offsets"])
+        g.column_set(0, self.pts)
+        g.set_num_docs(n_docs)
+        g.commit()
+        self.sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+        return time.time() - t0
 
-def run_keyword(args, rank, world):
-    import torch
-    import typesense_amd as T
-    from typesense_amd import _lib as B, synth
-
-    n_docs = args.n_docs
-    vocab, tpd = (100_000, 32) if n_docs >= 1_000_000 else (20_000, 16)
-    n_q = args.batch or 10_000
-    K = 250
-    lo = n_docs * rank // world
-    hi = n_docs * (rank + 1) // world
-    t0 = time.time()
-    # every rank draws the SAME collection slice-by-slice: shard r holds docs [lo, hi) (seed derived per shard so
-    # that shards are i.i.d. like the unsharded collection; N=1 reproduces seed 2 exactly)
-    csr = synth.zipf_corpus_csr(hi - lo, vocab, tpd, seed=2 + 1000 * rank if world > 1 else 2, doc_base=lo)
-    pts_all = synth.points_column(n_docs)
-    g = T.GpuIndex(torch.cuda.current_device())
-    g.field_create(0, False)
-    g.terms_load_csr(0, csr["term_ids"], csr["ids_ptr"], csr["ids"], csr["offset_index"], csr["off_ptr"], csr["offsets"])
-    g.column_set(0, pts_all)
-    g.set_num_docs(n_docs)
-    g.commit()
-    t_build = time.time() - t0
-
-    qtok = synth.keyword_queries(n_q, 3, 8, 2000, seed=4)
-    arr = (B.KwQueryC * n_q)()
-    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
-    for i in range(n_q):
-        T.KwQuery(qtok[i], sort=sort, topster_size=K).fill(arr[i])
-
-    dev, hs = device_hits(torch, T, n_q, K)
-    if world > 1:
-        import torch.distributed as dist
-        gath = {k: torch.zeros((world,) + tuple(dev[k].shape), dtype=dev[k].dtype, device="cuda") for k in ("keys", "scores", "n_hits", "num_matched")}
-
-    kern_ms, merge_ms, alg_bytes = [], [], []
-
-    def step():
-        g.keyword_search_batch_raw(arr, n_q, hs)           # synchronises its stream before returning
-        if world > 1:
-            for k in ("keys", "scores", "n_hits", "num_matched"):
-                dist.all_gather_into_tensor(gath[k], dev[k])
-            return merge_shards_device(torch, gath, K)
-        return dev["keys"], dev["scores"], dev["n_hits"]
-
-    for _ in range(args.warmup):
-        step()
-    barrier(world)
-    lat = []
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        s0 = time.perf_counter()
-        out = step()
+    def build_vectors(self):
+        from typesense_amd import _lib as B, synth
+        torch, g = self.torch, self.g
+        t0 = time.time()
+        g.vec_create(1, self.args.dim, B.METRIC_IP, self.hi - self.lo)
+        self.slab = 1 << 20
+        for a in range(self.lo, self.hi, self.slab):      # base vectors are generated on the device they live on
+            b = min(self.hi, a + self.slab)
+            x = synth.random_vectors(b - a, self.args.dim, seed=3 + a, device="cuda")
+            labels = torch.arange(a, b, dtype=torch.int64, device="cuda")
+            g.vec_upsert_device(1, labels.data_ptr(), x.data_ptr(), b - a)
+            del x
         torch.cuda.synchronize()
-        lat.append(time.perf_counter() - s0)
-        tm = g.timings()
-        kern_ms.append(tm.kw_search_ms)
-        merge_ms.append(tm.kw_merge_ms)
-        alg_bytes.append(tm.kw_algorithmic_bytes)
-    barrier(world)
-    elapsed = max_over_ranks(time.perf_counter() - t_start, world)
+        return time.time() - t0
 
-    res = dict(elapsed=elapsed, lat=lat, kern_ms=float(np.mean(kern_ms)), merge_ms=float(np.mean(merge_ms)),
-               alg_bytes=float(np.mean(alg_bytes)), n_q=n_q, t_build=t_build, n_postings=int(csr["n_postings"]))
+    def kw_query_array(self, qtok):
+        from typesense_amd import _lib as B
+        arr = (B.KwQueryC * len(qtok))()
+        for i in range(len(qtok)):
+            self.T.KwQuery(qtok[i], sort=self.sort, topster_size=K_TOPSTER).fill(arr[i])
+        return arr
 
-    # host copies for the parity check / CPU baseline (untimed)
-    keys = out[0].cpu().numpy().astype(np.uint64)
-    scores = out[1].cpu().numpy()
-    n_hits = out[2].cpu().numpy()
-    num_matched = dev["num_matched"].cpu().numpy()
-    res["nonempty"] = int((n_hits > 0).sum())
+    # ---------------------------------------------------------------- keyword (config 2 / 5)
+    def run_keyword(self):
+        from typesense_amd import synth
+        torch, g, args, world = self.torch, self.g, self.args, self.world
+        n_q = args.batch or 10_000
+        qtok = synth.keyword_queries(n_q, 3, 8, 2000, seed=4)
+        arr = self.kw_query_array(qtok)
+        dev, hs = device_hits(torch, n_q, K_TOPSTER)
+        kern_ms, merge_ms, alg_bytes = [], [], []
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle_py as O
-        ncpu = os.cpu_count() or 1
-        sample = args.cpu_sample or max(2 * ncpu, 32)
-        sample = min(sample, n_q)
-        orc = O.OracleIndex(1, 1)
-        orc.set_num_docs(n_docs)
-        orc.set_sort_dense(0, pts_all)
-        for t in np.unique(qtok[:sample]):
-            ids, oi, off = synth.csr_term(csr, t)
-            if ids.size:
-                orc.load_posting(0, int(t), ids, oi, off)
-        base = orc.make_query(qtok[0], sort=((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1)), fetch_size=100)
-        orc.bench_keyword(base, qtok[:min(sample, ncpu)], ncpu)               # warm the page cache / allocator
-        wall, per = orc.bench_keyword(base, qtok[:sample], ncpu)
-        res["cpu"] = dict(value=sample / wall, unit="queries/s", cores=ncpu, kind="port",
-                          sample="%d of the %d queries of the step, one query per thread on %d host threads (oracle = port of "
-                                 "or_iterator_t::intersect + Match + Topster); p50 %.1f ms/query" % (sample, n_q, ncpu, float(np.median(per)) / 1e3))
-        # parity at full size on the sample: identical top-K (keys + all 3 scores) and match counts
-        bad = 0
-        for i in range(min(sample, 64)):
-            oq = orc.make_query(qtok[i], sort=((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1)), fetch_size=100)
-            ref = orc.search_keyword(oq)
-            n = int(n_hits[i])
-            if n != ref.keys.size or not np.array_equal(keys[i, :n], ref.keys) or not np.array_equal(scores[i, :n], ref.scores) \
-                    or int(num_matched[i]) != int(ref.num_keyword_matches):
-                bad += 1
-        res["parity_checked"] = min(sample, 64)
-        res["parity_bad"] = bad
-    g.close()
-    return res
+        def step():
+            g.keyword_search_batch_raw(arr, n_q, hs)           # synchronises its stream before returning
+            if world > 1:
+                return self.D.sharded_keyword(dev, K_TOPSTER)
+            return dev["keys"], dev["scores"], dev["n_hits"], dev["num_matched"]
+
+        def after(_):
+            tm = g.timings()
+            kern_ms.append(tm.kw_search_ms)
+            merge_ms.append(tm.kw_merge_ms)
+            alg_bytes.append(tm.kw_algorithmic_bytes)
+
+        elapsed, lat, out = timed(step, args.steps, args.warmup, world, after)
+        res = dict(elapsed=elapsed, lat=lat, kern_ms=float(np.mean(kern_ms)), merge_ms=float(np.mean(merge_ms)),
+                   alg_bytes=float(np.mean(alg_bytes)), n_q=n_q, n_postings=int(self.csr["n_postings"]))
+        keys = out[0].cpu().numpy().astype(np.uint64)
+        scores = out[1].cpu().numpy()
+        n_hits = out[2].cpu().numpy()
+        num_matched = out[3].cpu().numpy()
+        res["nonempty"] = int((n_hits > 0).sum())
+        if self.rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle_py as O
+            ncpu = os.cpu_count() or 1
+            sample = min(args.cpu_sample or max(2 * ncpu, 32), n_q)
+            orc = O.OracleIndex(1, 1)
+            orc.set_num_docs(self.n_docs)
+            orc.set_sort_dense(0, self.pts)
+            for t in np.unique(qtok[:sample]):
+                ids, oi, off = synth.csr_term(self.csr, t)
+                if ids.size:
+                    orc.load_posting(0, int(t), ids, oi, off)
+            osort = ((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1))
+            base = orc.make_query(qtok[0], sort=osort, fetch_size=100)
+            orc.bench_keyword(base, qtok[:min(sample, ncpu)], ncpu)               # warm the page cache / allocator
+            wall, per = orc.bench_keyword(base, qtok[:sample], ncpu)
+            res["cpu"] = dict(value=sample / wall, unit="queries/s", cores=ncpu, kind="port",
+                              sample="%d of the %d queries of the step, one query per thread on %d host threads (oracle = port of "
+                                     "or_iterator_t::intersect + Match + Topster); p50 %.1f ms/query" % (sample, n_q, ncpu, float(np.median(per)) / 1e3))
+            bad = 0
+            for i in range(min(sample, 64)):       # parity at full size: identical top-K (keys + all 3 scores) and match counts
+                ref = orc.search_keyword(orc.make_query(qtok[i], sort=osort, fetch_size=100))
+                n = int(n_hits[i])
+                if n != ref.keys.size or not np.array_equal(keys[i, :n], ref.keys) or not np.array_equal(scores[i, :n], ref.scores) \
+                        or int(num_matched[i]) != int(ref.num_keyword_matches):
+                    bad += 1
+            res["parity"] = {"checked": min(sample, 64), "mismatches": bad}
+        return res
+
+    # ---------------------------------------------------------------- vector (config 3)
+    def run_vector(self):
+        from typesense_amd import _lib as B, synth
+        torch, g, args, world = self.torch, self.g, self.args, self.world
+        n, dim, k, n_q = self.n_docs, args.dim, args.k, args.vec_batch
+        self.Q = synth.random_vectors(n_q, dim, seed=4, device="cuda")
+        Q = self.Q
+        dist_o = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
+        lab_o = torch.zeros((n_q, k), dtype=torch.int64, device="cuda")
+        cnt_o = torch.zeros(n_q, dtype=torch.int32, device="cuda")
+        kern_ms, flops = [], []
+
+        def step():
+            g.vec_knn_batch_raw(1, Q.data_ptr(), B.MEM_DEVICE, n_q, k, dist_o.data_ptr(), lab_o.data_ptr(), cnt_o.data_ptr(), B.MEM_DEVICE)
+            if world > 1:
+                return self.D.sharded_knn(dist_o, lab_o, cnt_o, k)
+            return dist_o, lab_o, cnt_o
+
+        def after(_):
+            tm = g.timings()
+            kern_ms.append(tm.vec_knn_ms)
+            flops.append(tm.vec_flops)
+
+        elapsed, lat, out = timed(step, min(args.steps, 3), min(args.warmup, 1), world, after)
+        steps = min(args.steps, 3)
+        res = dict(elapsed=elapsed, steps=steps, lat=lat, kern_ms=float(np.mean(kern_ms)), flops=float(np.mean(flops)), n_q=n_q)
+        if self.rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle_py as O
+            ncpu = os.cpu_count() or 1
+            ns = min(n, 400_000)                           # bounded sample of the base: rows [0, ns)
+            orc = O.OracleIndex(1, 1)
+            orc.vec_init(dim, O.METRIC_IP)
+            xs = synth.random_vectors(min(self.slab, n), dim, seed=3, device="cuda")[:ns].cpu().numpy()
+            orc.vec_add(np.arange(ns, dtype=np.uint32), xs)
+            qs = Q[:max(ncpu, 8)].cpu().numpy()
+            orc.bench_vector(qs[:ncpu], k, ncpu)
+            wall, per = orc.bench_vector(qs, k, ncpu)
+            qps_sample = qs.shape[0] / wall
+            res["cpu"] = dict(value=qps_sample * ns / n, unit="queries/s", cores=ncpu, kind="port",
+                              sample="exact flat scan (1 - q.x, hnswlib 16-lane order) of %d queries over the first %d of %d base vectors on %d "
+                                     "host threads, %.1f q/s on the sample, scaled by %d/%d (cost is linear in N)"
+                                     % (qs.shape[0], ns, n, ncpu, qps_sample, ns, n))
+            d_gpu, l_gpu = out[0].cpu().numpy(), out[1].cpu().numpy()
+            bad = chk = 0
+            for i in range(min(8, qs.shape[0])):           # distances of the GPU's hits that fall in the sample rows
+                for j in range(k):
+                    if l_gpu[i, j] < ns:
+                        ref = float(np.float32(1.0) - np.dot(qs[i].astype(np.float64), xs[l_gpu[i, j]].astype(np.float64)))
+                        chk += 1
+                        if abs(ref - d_gpu[i, j]) > 1e-5 * max(1.0, abs(ref)):
+                            bad += 1
+            res["parity"] = {"checked": chk, "mismatches": bad, "tolerance": "1e-5 relative"}
+        return res
+
+    # ---------------------------------------------------------------- hybrid (config 4)
+    def run_hybrid(self):
+        from typesense_amd import _lib as B, synth
+        torch, g, args, world = self.torch, self.g, self.args, self.world
+        n_q, k = args.vec_batch, args.k
+        qtok = synth.keyword_queries(n_q, 3, 8, 2000, seed=5)
+        qs = [self.T.KwQuery(qtok[i], sort=self.sort, topster_size=K_TOPSTER) for i in range(n_q)]
+        arr = self.kw_query_array(qtok)
+        Qh = self.Q[:n_q].cpu().numpy()
+        if world == 1:
+            def step():
+                return g.hybrid_search_batch(qs, 1, Qh, k=k, fetch_size=100, alpha=0.3, k_stride=K_TOPSTER)
+        else:
+            dev, hs = device_hits(torch, n_q, K_TOPSTER)
+            dist_o = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
+            lab_o = torch.zeros((n_q, k), dtype=torch.int64, device="cuda")
+            cnt_o = torch.zeros(n_q, dtype=torch.int32, device="cuda")
+
+            def step():      # fuse AFTER the shard merge: reciprocal ranks are global ranks
+                g.keyword_search_batch_raw(arr, n_q, hs)
+                keys, sc, n, nm = self.D.sharded_keyword(dev, K_TOPSTER)
+                g.vec_knn_batch_raw(1, self.Q.data_ptr(), B.MEM_DEVICE, n_q, k, dist_o.data_ptr(), lab_o.data_ptr(), cnt_o.data_ptr(), B.MEM_DEVICE)
+                dm, lm, cm = self.D.sharded_knn(dist_o, lab_o, cnt_o, k)
+                if self.rank != 0:
+                    return None
+                merged = self.T.Hits(n_q, K_TOPSTER)
+                merged.keys[:] = keys.cpu().numpy().astype(np.uint64)
+                s = sc.cpu().numpy()
+                merged.scores[:] = s
+                merged.text_match[:] = s[:, :, 0]
+                merged.match_score_index[:] = 0
+                merged.n_hits[:] = n.cpu().numpy().astype(np.uint32)
+                merged.num_matched[:] = nm.cpu().numpy().astype(np.uint64)
+                return g.hybrid_fuse_batch(qs, merged, dm.cpu().numpy(), lm.cpu().numpy().astype(np.uint64), cm.cpu().numpy().astype(np.uint32),
+                                           B.METRIC_IP, k=k, fetch_size=100, alpha=0.3, k_stride=K_TOPSTER)
+        steps = min(args.steps, 3)
+        elapsed, lat, out = timed(step, steps, min(args.warmup, 1), world)
+        res = dict(elapsed=elapsed, steps=steps, lat=lat, n_q=n_q)
+        if out is not None:
+            res["fused_hits"] = int(out.n_hits.sum())
+        return res
+
+    def close(self):
+        self.g.close()
 
 
-# ------------------------------------------------------------------------------------------------ vector
-def run_vector(args, rank, world):
-    import torch
-    import typesense_amd as T
-    from typesense_amd import _lib as B, synth
-
-    n, dim, k = args.n_docs, args.dim, args.k
-    n_q = args.batch or 256
-    lo = n * rank // world
-    hi = n * (rank + 1) // world
-    t0 = time.time()
-    g = T.GpuIndex(torch.cuda.current_device())
-    g.vec_create(1, dim, B.METRIC_IP, hi - lo)
-    slab = 1 << 20
-    for a in range(lo, hi, slab):                     # base vectors are generated on the device they live on
-        b = min(hi, a + slab)
-        x = synth.random_vectors(b - a, dim, seed=3 + a, device="cuda")
-        labels = torch.arange(a, b, dtype=torch.int64, device="cuda")
-        g.vec_upsert_device(1, labels.data_ptr(), x.data_ptr(), b - a)
-        del x
-    torch.cuda.synchronize()
-    t_build = time.time() - t0
-    Q = synth.random_vectors(n_q, dim, seed=4, device="cuda")
-    dist_o = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
-    lab_o = torch.zeros((n_q, k), dtype=torch.int64, device="cuda")
-    cnt_o = torch.zeros(n_q, dtype=torch.int32, device="cuda")
-    if world > 1:
-        import torch.distributed as dist
-        gd = torch.zeros((world, n_q, k), dtype=torch.float32, device="cuda")
-        gl = torch.zeros((world, n_q, k), dtype=torch.int64, device="cuda")
-
-    def step():
-        g.vec_knn_batch_raw(1, Q.data_ptr(), B.MEM_DEVICE, n_q, k, dist_o.data_ptr(), lab_o.data_ptr(), cnt_o.data_ptr(), B.MEM_DEVICE)
-        if world > 1:
-            dist.all_gather_into_tensor(gd, dist_o)
-            dist.all_gather_into_tensor(gl, lab_o)
-            d = gd.permute(1, 0, 2).reshape(n_q, world * k)
-            l = gl.permute(1, 0, 2).reshape(n_q, world * k)
-            o = torch.sort(l, dim=1, stable=True).indices                      # ties: smaller label first
-            d, l = torch.gather(d, 1, o), torch.gather(l, 1, o)
-            o = torch.sort(d, dim=1, stable=True).indices[:, :k]
-            return torch.gather(d, 1, o), torch.gather(l, 1, o)
-        return dist_o, lab_o
-
-    for _ in range(args.warmup):
-        step()
-    barrier(world)
-    lat, kern_ms, flops = [], [], []
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        s0 = time.perf_counter()
-        out = step()
-        torch.cuda.synchronize()
-        lat.append(time.perf_counter() - s0)
-        tm = g.timings()
-        kern_ms.append(tm.vec_knn_ms)
-        flops.append(tm.vec_flops)
-    barrier(world)
-    elapsed = max_over_ranks(time.perf_counter() - t_start, world)
-    res = dict(elapsed=elapsed, lat=lat, kern_ms=float(np.mean(kern_ms)), flops=float(np.mean(flops)), n_q=n_q, t_build=t_build)
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle_py as O
-        ncpu = os.cpu_count() or 1
-        ns = min(n, 400_000)                           # bounded sample of the base: rows [0, ns)
-        orc = O.OracleIndex(1, 1)
-        orc.vec_init(dim, O.METRIC_IP)
-        xs = synth.random_vectors(min(slab, n), dim, seed=3, device="cuda")[:ns].cpu().numpy()
-        orc.vec_add(np.arange(ns, dtype=np.uint32), xs)
-        qs = Q[:max(ncpu, 8)].cpu().numpy()
-        orc.bench_vector(qs[:ncpu], k, ncpu)
-        wall, per = orc.bench_vector(qs, k, ncpu)
-        qps_sample = qs.shape[0] / wall
-        res["cpu"] = dict(value=qps_sample * ns / n, unit="queries/s", cores=ncpu, kind="port",
-                          sample="exact flat scan (1 - q.x, hnswlib 16-lane order) of %d queries over the first %d of %d base vectors on %d "
-                                 "host threads, %.1f q/s on the sample, scaled by %d/%d (cost is linear in N)" % (qs.shape[0], ns, n, ncpu, qps_sample, ns, n))
-        # parity on the sample rows: distances of the GPU's hits that fall in [0, ns) must match the oracle's
-        d_gpu, l_gpu = out[0].cpu().numpy(), out[1].cpu().numpy()
-        bad = 0
-        for i in range(min(8, qs.shape[0])):
-            for j in range(k):
-                if l_gpu[i, j] < ns:
-                    ref = float(np.float32(1.0) - np.dot(qs[i].astype(np.float64), xs[l_gpu[i, j]].astype(np.float64)))
-                    if abs(ref - d_gpu[i, j]) > 1e-5 * max(1.0, abs(ref)):
-                        bad += 1
-        res["parity_bad"] = bad
-    g.close()
-    return res
+def line_common(args, world, value, elapsed, steps, lat):
+    return {"value": value, "unit": "queries/s", "n_gpus": world, "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
+            "p50_ms_per_batch": 1e3 * float(np.median(lat))}
 
 
 def main():
@@ -329,47 +367,90 @@ def main():
         __graft_entry__.build()
     barrier(world)
 
-    if args.workload == "keyword":
-        r = run_keyword(args, rank, world)
+    wl = args.workload
+    bn = Bench(args, rank, world)
+    out = {}
+    build_s = {}
+    if wl in ("all", "keyword", "hybrid"):
+        build_s["keyword_index"] = bn.build_keyword()
+    if wl in ("all", "vector", "hybrid"):
+        build_s["vector_index"] = bn.build_vectors()
+    if wl in ("all", "keyword"):
+        out["keyword"] = bn.run_keyword()
+    if wl in ("all", "vector", "hybrid"):
+        out["vector"] = bn.run_vector()
+    if wl in ("all", "hybrid"):
+        out["hybrid"] = bn.run_hybrid()
+    bn.close()
+
+    par = "doc-range shards x%d, RCCL all-gather of per-GPU top-K + exact merge" % world if world > 1 else "1 GPU"
+    vocab, tpd = (100_000, 32) if args.n_docs >= 1_000_000 else (20_000, 16)
+    sub = {}
+    if "keyword" in out:
+        r = out["keyword"]
         qps = r["n_q"] * args.steps / r["elapsed"]
         achieved = r["alg_bytes"] / (r["kern_ms"] * 1e-3) / 1e9 if r["kern_ms"] > 0 else 0.0
-        line = {
-            "metric": "queries/sec, 10M-doc keyword 3-term AND top-100 (Topster 250)", "value": qps, "unit": "queries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * r["elapsed"] / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32/i64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: %d-doc Zipf(1.0) text, V=%d, %d tokens/doc, %d postings/shard; %d queries/step, 3 distinct "
-                                   "terms ranks log-uniform [8,2000], sort [_text_match desc, points desc], num_typos=0, prefix=false"
-                                   % (args.n_docs, 100_000 if args.n_docs >= 1_000_000 else 20_000, 32 if args.n_docs >= 1_000_000 else 16,
-                                      r["n_postings"], r["n_q"]),
-                       "parallelism": "doc-range shards x%d, RCCL all-gather of per-GPU top-250 + exact merge" % world if world > 1 else "1 GPU",
-                       "results_to": "device (tsgpu_hits mem=DEVICE); host delivery is measured in DESIGN.md"},
-            "p50_ms_per_batch": 1e3 * float(np.median(r["lat"])),
-            "queries_with_hits": r.get("nonempty"),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "kw_search_kernel<3,512>", "kernel_ms": r["kern_ms"], "merge_kernel_ms": r["merge_ms"],
-                         "algorithmic_bytes_per_launch": r["alg_bytes"]},
-            "index_build_s": r["t_build"],
-        }
-    else:
-        r = run_vector(args, rank, world)
-        qps = r["n_q"] * args.steps / r["elapsed"]
+        kw = line_common(args, world, qps, r["elapsed"], args.steps, r["lat"])
+        kw["config"] = {"workload": "BASELINE config 2: %d-doc Zipf(1.0) text, V=%d, %d tokens/doc, %d postings/shard; %d queries/step, 3 distinct "
+                                    "terms ranks log-uniform [8,2000], Topster 250, sort [_text_match desc, points desc], num_typos=0, prefix=false"
+                                    % (args.n_docs, vocab, tpd, r["n_postings"], r["n_q"]),
+                        "parallelism": par, "results_to": "device (tsgpu_hits mem=DEVICE); host delivery is quantified in DESIGN.md §5"}
+        kw["queries_with_hits"] = r.get("nonempty")
+        kw["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                          "traffic": pmc_traffic(r"kw_search_kernel", "pmc_kw_final_fetch.txt"),
+                          "kernel": "kw_search_kernel<3,512>", "kernel_ms": r["kern_ms"], "merge_kernel_ms": r["merge_ms"],
+                          "algorithmic_bytes_per_launch": r["alg_bytes"],
+                          "note": "algorithmic bytes = 4*sum|L_t| + offsets + sort keys (SURVEY 8d); the kernel skips, so fetched bytes (traffic, "
+                                  "FETCH_SIZE KB x 1024 from the committed --pmc pass, uncorrected) are far below them: latency/issue-bound, see DESIGN.md"}
+        if "cpu" in r:
+            kw["cpu_baseline"] = r["cpu"]
+            kw["speedup_vs_cpu_baseline"] = qps / r["cpu"]["value"] if r["cpu"]["value"] else None
+        if "parity" in r:
+            kw["parity"] = r["parity"]
+        sub["keyword"] = kw
+    if "vector" in out:
+        r = out["vector"]
+        qps = r["n_q"] * r["steps"] / r["elapsed"]
         tf = r["flops"] / (r["kern_ms"] * 1e-3) / 1e12 if r["kern_ms"] > 0 else 0.0
-        line = {
-            "metric": "queries/sec, 10M x 768 fp32 exact inner-product top-100", "value": qps, "unit": "queries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * r["elapsed"] / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: %d x %d fp32 N(0,1) base, %d queries/step, k=%d, dist = 1 - q.x" % (args.n_docs, args.dim, r["n_q"], args.k),
-                       "parallelism": "row-range shards x%d, RCCL all-gather of per-GPU top-k + merge" % world if world > 1 else "1 GPU"},
-            "p50_ms_per_batch": 1e3 * float(np.median(r["lat"])),
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
-                         "traffic": None, "kernel": "vec_knn_kernel", "kernel_ms": r["kern_ms"], "flops_per_launch": r["flops"]},
-            "index_build_s": r["t_build"],
-        }
-    if "cpu" in r:
-        line["cpu_baseline"] = r["cpu"]
-        line["speedup_vs_cpu_baseline"] = line["value"] / r["cpu"]["value"] if r["cpu"]["value"] else None
-    if "parity_bad" in r:
-        line["parity"] = {"checked": r.get("parity_checked"), "mismatches": r["parity_bad"]}
+        v = line_common(args, world, qps, r["elapsed"], r["steps"], r["lat"])
+        v["metric"] = "queries/sec, 10M x 768 fp32 exact inner-product top-100"
+        v["dtype"] = "f32"
+        v["config"] = {"workload": "BASELINE config 3: %d x %d fp32 N(0,1) base, %d queries/step, k=%d, dist = 1 - q.x" % (args.n_docs, args.dim, r["n_q"], args.k),
+                       "parallelism": par}
+        traffic = pmc_traffic(r"vec_scan_kernel", "pmc_vec_final_fetch.txt")
+        v["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                         "traffic": traffic, "kernel": "vec_scan_kernel<2,true> (+ sample pass and selects inside the timed events)",
+                         "kernel_ms": r["kern_ms"], "flops_per_launch": r["flops"]}
+        if "cpu" in r:
+            v["cpu_baseline"] = r["cpu"]
+            v["speedup_vs_cpu_baseline"] = qps / r["cpu"]["value"] if r["cpu"]["value"] else None
+        if "parity" in r:
+            v["parity"] = r["parity"]
+        sub["vector"] = v
+    if "hybrid" in out:
+        r = out["hybrid"]
+        qps = r["n_q"] * r["steps"] / r["elapsed"]
+        h = line_common(args, world, qps, r["elapsed"], r["steps"], r["lat"])
+        h["metric"] = "queries/sec, 10M-doc hybrid (keyword + 768-d vector, reciprocal rank fusion alpha=0.3), Topster 250"
+        h["config"] = {"workload": "BASELINE config 4: configs 2+3 on the same 10M ids, %d queries/step, k_vec=%d; keyword pass + exact k-NN on the GPU, "
+                                   "fusion (src/index.cpp:4094-4211) on the host, results delivered to host memory" % (r["n_q"], args.k),
+                       "parallelism": par + (" (fusion after the merge)" if world > 1 else "")}
+        h["fused_hits_per_batch"] = r.get("fused_hits")
+        sub["hybrid"] = h
+
+    head = "keyword" if "keyword" in sub else ("vector" if wl == "vector" else "hybrid")
+    hd = sub[head]
+    line = {"metric": "queries/sec, 10M-doc keyword 3-term AND top-100 (Topster 250)" if head == "keyword" else hd.get("metric"),
+            "value": hd["value"], "unit": "queries/s", "n_gpus": world, "steps": hd["steps"], "warmup": args.warmup, "ms_per_step": hd["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32/i64" if head == "keyword" else "f32",
+            "data": "synthetic", "config": hd["config"], "p50_ms_per_batch": hd["p50_ms_per_batch"]}
+    for k in ("queries_with_hits", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "fused_hits_per_batch"):
+        if k in hd:
+            line[k] = hd[k]
+    line["index_build_s"] = build_s
+    for k, v in sub.items():
+        if k != head:
+            line[k] = v
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

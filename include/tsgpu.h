@@ -94,8 +94,9 @@ void tsgpu_destroy(tsgpu_ctx* ctx);
 const char* tsgpu_last_error(void);
 /* run the library's kernels on a caller-owned hipStream_t (NULL = the context's own stream) */
 int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
-/* tuning knobs (all optional): "kw_chunk_blocks" = driver posting blocks per keyword work item (default 64),
- * "vec_rows_per_slab" = base rows per k-NN workgroup slab (default: automatic) */
+/* tuning knobs (all optional): "kw_chunk_blocks" = driver posting blocks per keyword work item (default 0 = sized per batch; 1..256),
+ * "vec_rows_per_slab" = base rows per k-NN workgroup slab (default: automatic), "vec_sample_tiles" = 128-row tiles of
+ * the k-NN threshold sample (default 512), "vec_cand_cap" = candidate slots per query of the filtered pass (0 = auto) */
 int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value);
 /* bytes of HBM held by the context's index mirrors */
 uint64_t tsgpu_device_bytes(tsgpu_ctx* ctx);
@@ -235,6 +236,13 @@ typedef struct tsgpu_hybrid_params {
 int tsgpu_hybrid_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t vec_field_id,
                               const tsgpu_hybrid_params* params, const float* Q, int mem_q,
                               uint32_t n_queries, tsgpu_hits* out);
+
+/* Fusion step alone (src/index.cpp:4094-4211) on already-computed results, e.g. after a shard merge where ranks must be
+ * global: kw_hits = keyword Topster content per query in sort() order, knn_* = [n_queries][knn_k] nearest neighbours
+ * (closest first) with knn_cnt[q] valid entries; metric = tsgpu_metric of the vector field. Host arrays only. */
+int tsgpu_hybrid_fuse_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsgpu_hybrid_params* params, int metric,
+                            const tsgpu_hits* kw_hits, const float* knn_dist, const uint64_t* knn_labels, const uint32_t* knn_cnt,
+                            uint32_t knn_k, uint32_t n_queries, tsgpu_hits* out);
 
 /* ------------------------------------------------------------------ multi-GPU (doc-range shards) */
 /* Merge G per-shard hit lists (already gathered, e.g. by an RCCL all-gather) into the global Topster

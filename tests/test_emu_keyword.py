@@ -143,7 +143,7 @@ def test_keyword_many_work_items_and_merge(pair):
             H.assert_hits_equal(hits, i, ref, "chunks")
             assert np.array_equal(g.result_ids(i), ref.result_ids)
     finally:
-        g.set_option("kw_chunk_blocks", 64)
+        g.set_option("kw_chunk_blocks", 0)
         g.keep_result_ids(False)
 
 

@@ -21,7 +21,7 @@ for n_q in (10000, 1000, 100):
     arr = (B.KwQueryC * n_q)()
     for i in range(n_q):
         T.KwQuery(qtok[i], sort=sort, topster_size=250).fill(arr[i])
-    dev, hs = bench.device_hits(torch, T, n_q, 250)
+    dev, hs = bench.device_hits(torch, n_q, 250)
     for opts in json.loads(os.environ.get("KW_SWEEP", '[{"kw_chunk_blocks":64}]')):
         for k, v in opts.items():
             g.set_option(k, v)

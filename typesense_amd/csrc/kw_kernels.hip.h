@@ -53,6 +53,8 @@ static const uint32_t KW_WINDOW_SIZE = 10; // WINDOW_SIZE, include/match_score.h
 #ifndef TSGPU_KW_TILE_WORDS
 #define TSGPU_KW_TILE_WORDS 2048
 #endif
+static const int KW_MAX_CHUNK = 256;        // driver blocks per work item (host clamps kw_chunk_blocks to this)
+static const int KW_PIPE_WORDS = 4;         // dwords per thread of the register-pipelined tile copy (4 x 256 words = 2048 16-bit ids)
 static const int KW_TILE_WORDS = TSGPU_KW_TILE_WORDS;   // LDS tile of PACKED second-list ids per round (8 KB ~ 20 blocks of 12-bit ids); multiple of 256
 
 struct IndexView {
@@ -163,13 +165,15 @@ __device__ inline bool probe_list(const IndexView& ix, const ListDesc& d, uint32
     const BlockIds m = ix.blk_ids[d.blk_base + lo];
     if (x < m.first_id) return false;
     const uint32_t* __restrict__ w = ix.ids_payload + d.ids_base + m.ids_woff;
-    const uint32_t target = x - m.first_id, bits = m.n_ids_bits >> 16;
-    uint32_t l = 0, h = (m.n_ids_bits & 0xFFFF) - 1;     // packed[h] = block last >= target
+    const uint32_t target = x - m.first_id;
+    const bool w16 = (m.n_ids_bits >> 16) == 16;
+    uint32_t l = 0, h = (m.n_ids_bits & 0xFFFF) - 1;     // ids[h] = block last >= target
     while (l < h) {
         const uint32_t mid = (l + h) >> 1;
-        if (unpack_at(w, mid, bits) >= target) h = mid; else l = mid + 1;
+        const uint32_t v = w16 ? (uint32_t)((const uint16_t*)w)[mid] : w[mid];
+        if (v >= target) h = mid; else l = mid + 1;
     }
-    if (unpack_at(w, l, bits) != target) return false;
+    if ((w16 ? (uint32_t)((const uint16_t*)w)[l] : w[l]) != target) return false;
     pos = lo * BLOCK_IDS + l;
     return true;
 }
@@ -480,7 +484,8 @@ struct KwSmem {
     TopkLds<CAP> tk;
     int64_t thr[4];
     uint32_t btile[KW_TILE_WORDS + 2];       // packed ids of the second list's blocks under the current driver block
-    uint32_t b_last[64], b_first[64], b_woff[64], b_nb[64];   // the second list's BlockIds window, SoA
+    uint32_t bw_last[2][64], bw_first[2][64], bw_woff[2][64], bw_nb[2][64];   // the second list's BlockIds window, SoA, two versions
+    BlockIds a_meta[KW_MAX_CHUNK];           // BlockIds of the work item's driver blocks
     uint32_t wave_cnt[KW_THREADS / 64];
     uint32_t wave_cnt2[2][KW_THREADS / 64];  // block_compact1 ping-pong
     uint32_t q1_cnt, qf_cnt, tk_cnt, have_thr;
@@ -623,181 +628,187 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
     const uint32_t* __restrict__ idwB = ix.ids_payload + dB.ids_base;
     const uint32_t lane = t & 63;
     const BlockIds PAD = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
+    const uint32_t n_filt = q.n_filt;
 
-    // Software pipeline over the driver blocks. Global round trips cost ~1-2K cycles each under load, so nothing
-    // on the per-block critical path may wait for a load issued in the same iteration except the second list's
-    // payload: the driver block's BlockIds are fetched two blocks ahead, its packed ids one block ahead, and the
-    // second list's BlockIds window (lane <-> block wbase+lane) as soon as the previous block fixed the cursor.
-    auto load_words = [&](const uint32_t* __restrict__ base, const BlockIds& m, uint32_t slot, uint32_t& w0, uint32_t& w1) {
-        const uint32_t bits = m.n_ids_bits >> 16;
-        w0 = 0; w1 = 0;
-        if (slot < (m.n_ids_bits & 0xFFFF) && bits) {
-            const uint32_t wi = (slot * bits) >> 5;
-            const uint32_t* __restrict__ w = base + m.ids_woff + wi;
-            w0 = w[0]; w1 = w[1];
-        }
-    };
-    auto extract = [&](const BlockIds& m, uint32_t slot, uint32_t w0, uint32_t w1) -> uint32_t {
-        const uint32_t bits = m.n_ids_bits >> 16;
-        if (slot >= (m.n_ids_bits & 0xFFFF)) return 0xFFFFFFFFu;
-        if (bits == 0) return m.first_id;
-        const uint32_t sh = (slot * bits) & 31;
-        const uint64_t two = (uint64_t)w0 | ((uint64_t)w1 << 32);
-        const uint64_t mask = bits >= 32 ? 0xFFFFFFFFull : ((1ull << bits) - 1ull);
-        return m.first_id + (uint32_t)((two >> sh) & mask);
+    // Doc ids of a block are stored as fixed-width deltas from the block's first id: 16 bits when the block's id
+    // range fits (the common case), else 32 (tsgpu_pack.h) — one aligned load per id, no bit arithmetic.
+    auto load_id_raw = [&](const uint32_t* __restrict__ base, const BlockIds& m, uint32_t slot) -> uint32_t {
+        const uint32_t n = m.n_ids_bits & 0xFFFF;
+        const uint32_t s2 = slot < n ? slot : 0;
+        const uint32_t* __restrict__ w = base + m.ids_woff;
+        return (m.n_ids_bits >> 16) == 16 ? (uint32_t)((const uint16_t*)w)[s2] : w[s2];
     };
     auto load_window = [&](uint32_t base) -> BlockIds { return (T >= 2 && base + lane < dB.n_blocks) ? biB[base + lane] : PAD; };
 
-    KW_PROF_DECL
-    BlockIds mA = biA[wi.blk_begin];
-    BlockIds mA1 = (wi.blk_begin + 1 < wi.blk_end) ? biA[wi.blk_begin + 1] : PAD;
-    uint32_t aw0, aw1;
-    load_words(idwA, mA, t, aw0, aw1);
-    // the second list's BlockIds, lane <-> block: win = [wbase, wbase+64), nxt = [wbase+32, wbase+96) already in
-    // flight. The cursor only moves forward; when it enters the upper half, nxt becomes win (no load on the
-    // critical path) and the following window is requested.
-    uint32_t wbase = 0;
-    BlockIds win = load_window(0), nxt = load_window(32);
-    bool win_dirty = true;                    // LDS copy of the window (b_last / b_first / b_woff / b_nb) is stale
-    uint32_t q1n = 0, qfn = 0, par = 0;       // queue fill levels mirrored in registers (identical in every thread)
-    bool b_exhausted = false;
+    // driver-side BlockIds of the whole work item -> LDS once (the host caps a work item at KW_MAX_CHUNK blocks)
+    const uint32_t nA = wi.blk_end - wi.blk_begin;
+    for (uint32_t i = t; i < nA; i += KW_THREADS) sm.a_meta[i] = biA[wi.blk_begin + i];
+    __syncthreads();
 
-    for (uint32_t b = wi.blk_begin; b < wi.blk_end && !b_exhausted; b++) {
-        // ---- prefetch for the next blocks ----
-        BlockIds mA2 = (b + 2 < wi.blk_end) ? biA[b + 2] : PAD;
-        uint32_t nw0 = 0, nw1 = 0;
-        if (b + 1 < wi.blk_end) load_words(idwA, mA1, t, nw0, nw1);
+    KW_PROF_DECL
+    // Software pipeline over the driver blocks (global round trips cost 1-2K cycles under load): block b+1's ids and
+    // block b+1's tile of second-list ids are requested while block b is being searched; the second list's BlockIds
+    // window lives in registers (lane <-> block; win = [wbase, wbase+64), nxt = [wbase+32, wbase+96) already in
+    // flight) and only slides forward.
+    uint32_t wbase = 0, wver = 0;
+    BlockIds win = load_window(0), nxt = load_window(32);
+    bool win_dirty = true;                    // LDS copy of the window (sm.bw[wver]) is stale
+    struct Plan { uint32_t mode, rlo, rhi, w_begin, W, ver, base; };   // mode: 0 tile, 1 tile in several rounds, 2 wide run (probe), 3 exhausted, 4 no second list
+    uint32_t cw[KW_PIPE_WORDS];               // block b's tile of second-list ids, in flight from the previous iteration
+    // decide how driver block `bb` meets the second list and (mode 0) request its tile
+    auto make_plan = [&](uint32_t bb) -> Plan {
+        Plan P; P.mode = 4; P.rlo = P.rhi = P.w_begin = P.W = 0; P.ver = wver; P.base = wbase;
+        if (T < 2) return P;
+        const BlockIds m = sm.a_meta[bb - wi.blk_begin];
+        const uint32_t lo_id = m.first_id, hi_id = m.last_id;
+        unsigned long long mk = __ballot(win.last_id >= lo_id ? 1 : 0);
+        if (mk != 0 && (uint32_t)__builtin_ctzll(mk) >= 32) {          // cursor entered the upper half: slide by 32 blocks
+            wbase += 32; win = nxt; nxt = load_window(wbase + 32); win_dirty = true;
+            mk = __ballot(win.last_id >= lo_id ? 1 : 0);
+        }
+        if (mk == 0) {                                                   // all 64 blocks end before lo_id: uniform search, re-centre
+            uint32_t lo = wbase + 64, hi = dB.n_blocks;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (blB[mid] >= lo_id) hi = mid; else lo = mid + 1; }
+            wbase = lo; win = load_window(wbase); nxt = load_window(wbase + 32); win_dirty = true;
+            mk = __ballot(win.last_id >= lo_id ? 1 : 0);               // lane 0 votes yes (real block or padding)
+        }
+        P.rlo = (uint32_t)__builtin_ctzll(mk);
+        P.base = wbase;
+        if (wbase + P.rlo >= dB.n_blocks) { P.mode = 3; return P; }     // every remaining driver id is beyond B's last id
+        const unsigned long long mh = __ballot(win.last_id >= hi_id ? 1 : 0);
+        if (mh == 0) { P.mode = 2; return P; }                           // run of B blocks wider than the window
+        P.rhi = (uint32_t)__builtin_ctzll(mh);
+        if (wbase + P.rhi >= dB.n_blocks) P.rhi = dB.n_blocks - 1 - wbase;   // hi_id beyond B's last id
+        if (win_dirty) {                                                 // publish the window for the block search
+            wver ^= 1;
+            if (t < 64) { sm.bw_last[wver][t] = win.last_id; sm.bw_first[wver][t] = win.first_id; sm.bw_woff[wver][t] = win.ids_woff; sm.bw_nb[wver][t] = win.n_ids_bits; }
+            win_dirty = false;
+        }
+        P.ver = wver;
+        const uint32_t w_endw = win.ids_woff + packed_words(win.n_ids_bits & 0xFFFF, win.n_ids_bits >> 16);
+        P.w_begin = (uint32_t)__shfl(win.ids_woff, (int)P.rlo);
+        P.W = (uint32_t)__shfl(w_endw, (int)P.rhi) - P.w_begin;
+        if (P.W <= (uint32_t)(KW_PIPE_WORDS * KW_THREADS)) {
+            P.mode = 0;
+            const uint32_t* __restrict__ src = idwB + P.w_begin;
+#pragma unroll
+            for (int k = 0; k < KW_PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; cw[k] = src[i < P.W ? i : 0]; }
+        } else P.mode = 1;
+        return P;
+    };
+
+    BlockIds mA = sm.a_meta[0];
+    uint32_t araw = load_id_raw(idwA, mA, t);
+    Plan P = make_plan(wi.blk_begin);
+    uint32_t q1n = 0, qfn = 0, par = 0;       // queue fill levels mirrored in registers (identical in every thread)
+
+    for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
+        if (P.mode == 3) break;
         // ---- stage 0: thread t = slot t of driver block b ----
         const uint32_t m_n = mA.n_ids_bits & 0xFFFF;
         bool ok = t < m_n;
-        uint32_t id = extract(mA, t, aw0, aw1), p1 = 0;
+        const uint32_t id = ok ? mA.first_id + araw : 0xFFFFFFFFu;
+        uint32_t p1 = 0;
         // filter ids (sorted whitelist): membership is decided per candidate; the reference's
         // filter-driven skipping only changes WHICH matches are counted, handled in the host shim (v1: no filter in-kernel)
-        if (ok && q.n_filt) {
-            uint32_t lo = 0, hi = q.n_filt;
+        if (ok && n_filt) {
+            uint32_t lo = 0, hi = n_filt;
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (filt[mid] < id) lo = mid + 1; else hi = mid; }
-            ok = (lo < q.n_filt && filt[lo] == id);
+            ok = (lo < n_filt && filt[lo] == id);
         }
         KW_PROF(0)
+        const Plan C = P;                      // this block's plan; P becomes the next block's below
         // ---- stage 1: merge with the second-shortest list B ----
-        if (T >= 2) {
-            // (a) B blocks [jlo, jhi] overlap this driver block's id range [first_id, last_id]. Every wave holds the
-            //     same window (uniform result, no LDS hand-off). Padding lanes (beyond B's last block) hold FFFFFFFF.
-            const uint32_t lo_id = mA.first_id, hi_id = mA.last_id;
-            unsigned long long mk = __ballot(win.last_id >= lo_id ? 1 : 0);
-            if (mk != 0 && (uint32_t)__builtin_ctzll(mk) >= 32) {
-                // cursor entered the upper half: slide by 32 blocks onto the prefetched window
-                wbase += 32;
-                win = nxt;
-                nxt = load_window(wbase + 32);
-                win_dirty = true;
-                mk = __ballot(win.last_id >= lo_id ? 1 : 0);
-            }
-            if (mk == 0) {
-                // all 64 window blocks end before lo_id: uniform binary search over the rest, then re-centre
-                uint32_t lo = wbase + 64, hi = dB.n_blocks;                 // mk == 0 => all 64 lanes are real blocks
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (blB[mid] >= lo_id) hi = mid; else lo = mid + 1; }
-                wbase = lo;
-                win = load_window(wbase);
-                nxt = load_window(wbase + 32);
-                win_dirty = true;
-                mk = __ballot(win.last_id >= lo_id ? 1 : 0);                // lane 0 votes yes (real block or padding)
-            }
-            const uint32_t rlo = (uint32_t)__builtin_ctzll(mk);
-            if (wbase + rlo >= dB.n_blocks) {
-                // every remaining candidate of this work item is beyond B's last id: nothing can match any more
-                ok = false;
-                b_exhausted = true;
-            } else {
-                const unsigned long long mh = __ballot(win.last_id >= hi_id ? 1 : 0);
-                if (mh == 0) {
-                    // the run of B blocks under this driver block is wider than the window: per-candidate probe;
-                    // the cursor moves by a uniform search
-                    if (ok) ok = probe_list(ix, dB, id, p1);
-                    uint32_t lo = wbase + 64, hi = dB.n_blocks;
-                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (blB[mid] >= hi_id) hi = mid; else lo = mid + 1; }
-                    wbase = lo < dB.n_blocks ? lo : dB.n_blocks - 1;
-                    win = load_window(wbase);
-                    nxt = load_window(wbase + 32);
-                    win_dirty = true;
-                } else {
-                    uint32_t rhi = (uint32_t)__builtin_ctzll(mh);
-                    if (wbase + rhi >= dB.n_blocks) rhi = dB.n_blocks - 1 - wbase;       // hi_id beyond B's last id
-                    // (b) this wave's copy of the window -> LDS (block search + per-candidate block metadata)
-                    const uint32_t w_words = packed_words(win.n_ids_bits & 0xFFFF, win.n_ids_bits >> 16);
-                    const uint32_t w_endw = win.ids_woff + w_words;              // one past the block's packed words
-                    KW_PROF(1)
-                    if (win_dirty) {
-                        if (t < 64) { sm.b_last[t] = win.last_id; sm.b_first[t] = win.first_id; sm.b_woff[t] = win.ids_woff; sm.b_nb[t] = win.n_ids_bits; }
-                        win_dirty = false;
-                    }
-                    bool done = !ok, found = false;
-                    uint32_t kb = 0;
-#if defined(TSGPU_EXP) && TSGPU_EXP >= 3
-                    if (false)
-#endif
-                    for (uint32_t r_lo = rlo; r_lo <= rhi;) {
-                        // blocks r_lo..r_hi of the window: as many as fit the packed tile (at least one: a block is <= 257 words)
-                        const uint32_t w_begin = (uint32_t)__shfl(win.ids_woff, (int)r_lo);
-                        const unsigned long long fit = __ballot((lane >= r_lo && lane <= rhi && w_endw - w_begin <= (uint32_t)KW_TILE_WORDS) ? 1 : 0);
-                        const uint32_t r_hi = 63u - (uint32_t)__builtin_clzll(fit | 1ull);
-                        const uint32_t W = (uint32_t)__shfl(w_endw, (int)r_hi) - w_begin;
-                        // (c) coalesced copy of the PACKED ids of those blocks (contiguous in the ids arena) into LDS
-                        const uint32_t* __restrict__ src = idwB + w_begin;
-                        for (uint32_t i0 = t; i0 < W + t; i0 += 2 * KW_THREADS) {           // uniform trip count; 2 loads in flight per trip
-                            const uint32_t i1 = i0 + KW_THREADS;
-                            const uint32_t c0 = src[i0 < W ? i0 : 0], c1 = src[i1 < W ? i1 : 0];
-                            if (i0 < W) sm.btile[i0] = c0;
-                            if (i1 < W) sm.btile[i1] = c1;
-                        }
-                        KW_PROF(2)
-                        __syncthreads();
-                        KW_PROF(3)
-                        if (r_lo == rlo && !done) {
-                            // (d) which block: lower bound of id among the window's last ids (b_last[rhi] >= hi_id >= id unless B ended)
-                            uint32_t pos = rlo;
+        uint32_t kb = 0, b_first = 0, b_nb = 0, b_rel = 0;
+        bool done = !ok || C.mode >= 2, found = false;
+        if (C.mode == 0) {
 #pragma unroll
-                            for (uint32_t step = 32; step > 0; step >>= 1)
-                                if (pos + step <= rhi && sm.b_last[pos + step - 1] < id) pos += step;
-                            kb = pos;
-                            if (sm.b_last[pos] < id || id < sm.b_first[pos]) done = true;       // beyond B's end / in the gap between two blocks
-                        }
-#if defined(TSGPU_EXP) && TSGPU_EXP >= 2
-                        done = true;
-#endif
-                        if (!done && kb >= r_lo && kb <= r_hi) {
-                            // (e) which slot: branch-free lower bound over the block's packed ids, unpacked on the fly from LDS
-                            const uint32_t nb = sm.b_nb[kb], n = nb & 0xFFFF, bits = nb >> 16;
-                            const uint32_t* __restrict__ lw = sm.btile + (sm.b_woff[kb] - w_begin);
-                            const uint32_t target = id - sm.b_first[kb];
-                            const uint64_t mask = bits >= 32 ? 0xFFFFFFFFull : ((1ull << bits) - 1ull);
-                            uint32_t pos = 0;
-#pragma unroll
-                            for (uint32_t step = 128; step > 0; step >>= 1) {
-                                const uint32_t idx = pos + step - 1;
-                                const uint32_t bp = (idx < n ? idx : 0) * bits;
-                                const uint64_t two = (uint64_t)lw[bp >> 5] | ((uint64_t)lw[(bp >> 5) + 1] << 32);
-                                const uint32_t v = (uint32_t)((two >> (bp & 31)) & mask);
-                                if (pos + step <= n && v < target) pos += step;
-                            }
-                            const uint32_t bp = pos * bits;
-                            const uint64_t two = (uint64_t)lw[bp >> 5] | ((uint64_t)lw[(bp >> 5) + 1] << 32);
-                            done = true;
-                            if ((uint32_t)((two >> (bp & 31)) & mask) == target) { found = true; p1 = (wbase + kb) * BLOCK_IDS + pos; }
-                        }
-                        KW_PROF(4)
-                        r_lo = r_hi + 1;
-                        if (r_lo <= rhi) __syncthreads();                   // tile reused by the next round
-                    }
-                    ok = ok && found;
-                }
-            }
+            for (int k = 0; k < KW_PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; if (i < C.W) sm.btile[i] = cw[k]; }
         }
+        KW_PROF(1)
+        __syncthreads();
+        KW_PROF(2)
+        if (C.mode <= 1 && !done) {
+            // (a) which block: lower bound of id among the window's last ids (bw_last[rhi] >= hi_id >= id unless B ended)
+            const uint32_t* __restrict__ bl = sm.bw_last[C.ver];
+            uint32_t pos = C.rlo;
+#pragma unroll
+            for (uint32_t step = 32; step > 0; step >>= 1)
+                if (pos + step <= C.rhi && bl[pos + step - 1] < id) pos += step;
+            kb = pos;
+            b_first = sm.bw_first[C.ver][pos];
+            if (bl[pos] < id || id < b_first) done = true;             // beyond B's end / in the gap between two blocks
+            b_nb = sm.bw_nb[C.ver][pos];
+            b_rel = sm.bw_woff[C.ver][pos] - C.w_begin;
+        }
+#if defined(TSGPU_EXP) && TSGPU_EXP >= 2 && TSGPU_EXP < 4
+        done = true;
+#endif
+        KW_PROF(3)
+        // ---- request the next driver block's ids and its tile (in flight during the slot search below) ----
+        BlockIds mA1 = PAD;
+        uint32_t araw1 = 0;
+        if (b + 1 < wi.blk_end) {
+            mA1 = sm.a_meta[b + 1 - wi.blk_begin];
+            araw1 = load_id_raw(idwA, mA1, t);
+            P = make_plan(b + 1);
+        }
+        KW_PROF(4)
+        // (b) which slot: branch-free lower bound over the block's ids in the LDS tile
+        auto slot_search = [&](uint32_t tile_rel) {
+            const uint32_t n = b_nb & 0xFFFF, target = id - b_first;
+            uint32_t pos = 0, hit;
+            if ((b_nb >> 16) == 16) {
+                const uint16_t* __restrict__ a16 = (const uint16_t*)(sm.btile + tile_rel);
+#pragma unroll
+                for (uint32_t step = 128; step > 0; step >>= 1)
+                    if (pos + step <= n && (uint32_t)a16[pos + step - 1] < target) pos += step;
+                hit = a16[pos];
+            } else {
+                const uint32_t* __restrict__ a32 = sm.btile + tile_rel;
+#pragma unroll
+                for (uint32_t step = 128; step > 0; step >>= 1)
+                    if (pos + step <= n && a32[pos + step - 1] < target) pos += step;
+                hit = a32[pos];
+            }
+            done = true;
+            if (hit == target) { found = true; p1 = (C.base + kb) * BLOCK_IDS + pos; }
+        };
+        if (C.mode == 0) {
+            if (!done) slot_search(b_rel);
+        } else if (C.mode == 1) {
+            // the run does not fit the pipelined tile: several rounds over [rlo, rhi], each a coalesced copy of as many
+            // whole blocks as fit the LDS tile (at least one: a block is <= 257 words)
+            const uint32_t* __restrict__ woff = sm.bw_woff[C.ver];
+            const uint32_t* __restrict__ wnb = sm.bw_nb[C.ver];
+            for (uint32_t r_lo = C.rlo; r_lo <= C.rhi;) {
+                const uint32_t w_begin = woff[r_lo];
+                uint32_t r_hi = r_lo;
+                while (r_hi < C.rhi && woff[r_hi + 1] + packed_words(wnb[r_hi + 1] & 0xFFFF, wnb[r_hi + 1] >> 16) - w_begin <= (uint32_t)KW_TILE_WORDS) r_hi++;
+                const uint32_t W = woff[r_hi] + packed_words(wnb[r_hi] & 0xFFFF, wnb[r_hi] >> 16) - w_begin;
+                const uint32_t* __restrict__ src = idwB + w_begin;
+                __syncthreads();                                        // previous round's searches are done with the tile
+                for (uint32_t i0 = t; i0 < W + t; i0 += 2 * KW_THREADS) {   // uniform trip count; 2 loads in flight per trip
+                    const uint32_t i1 = i0 + KW_THREADS;
+                    const uint32_t c0 = src[i0 < W ? i0 : 0], c1 = src[i1 < W ? i1 : 0];
+                    if (i0 < W) sm.btile[i0] = c0;
+                    if (i1 < W) sm.btile[i1] = c1;
+                }
+                __syncthreads();
+                if (!done && kb >= r_lo && kb <= r_hi) slot_search(woff[kb] - w_begin);
+                r_lo = r_hi + 1;
+            }
+        } else if (C.mode == 2) {
+            // the run of B blocks under this driver block is wider than the window: per-candidate probe; the cursor
+            // moved with the next plan (its window search re-centres)
+            if (ok) found = probe_list(ix, dB, id, p1);
+        }
+        if (T >= 2) ok = ok && found;
 #if defined(TSGPU_EXP) && TSGPU_EXP >= 1 && TSGPU_EXP < 4
         ok = ok && (id == 0xFFFFFFFEu);   // ablation: drop survivors without letting the compiler drop stage 1
 #endif
-        uint32_t total;
         KW_PROF(5)
+        uint32_t total;
         const uint32_t my = block_compact1(ok, sm.wave_cnt2[par], total);
         par ^= 1;
         KW_PROF(6)
@@ -837,7 +848,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
             }
         }
         KW_PROF(7)
-        mA = mA1; mA1 = mA2; aw0 = nw0; aw1 = nw1;
+        mA = mA1; araw = araw1;
     }
     __syncthreads();
     if (t == 0) { if (T >= 3) sm.q1_cnt = q1n; else sm.qf_cnt = qfn; }

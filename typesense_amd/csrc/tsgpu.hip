@@ -330,7 +330,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(TSGPU_ERR_INVALID, "tsgpu_set_option: NULL argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!strcmp(name, "kw_chunk_blocks")) {
-        if (value < 1 || value > (1 << 20)) return fail(TSGPU_ERR_INVALID, "kw_chunk_blocks out of range");
+        if (value < 0 || value > KW_MAX_CHUNK) return fail(TSGPU_ERR_INVALID, "kw_chunk_blocks out of range (0 = auto, 1..256)");
         ctx->kw_chunk_blocks = (uint32_t)value;
         return ok();
     }
@@ -370,11 +370,31 @@ struct Plan {
     uint64_t ids_total = 0;
     uint64_t list_bytes = 0;       // 4 * sum |L_t| over the batch
     uint64_t n_numeric_sort_q = 0;
+    uint32_t chunk_blocks = 64;
 };
 }
 
 static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, Plan& P, bool keep_ids) {
-    const uint32_t KW_CHUNK_BLOCKS = ctx->kw_chunk_blocks;
+    // driver blocks per work item: fixed by the option, or (0 = auto) sized so that the batch yields a few thousand work
+    // items (>= 3 per resident workgroup slot) without fragmenting queries into more partial top-K lists than needed
+    uint32_t KW_CHUNK_BLOCKS = ctx->kw_chunk_blocks;
+    if (KW_CHUNK_BLOCKS == 0) {
+        uint64_t total_blocks = 0;
+        for (uint32_t i = 0; i < n_queries; i++) {
+            const tsgpu_kw_query& in = queries[i];
+            if (in.n_tokens == 0 || in.n_tokens > TSGPU_MAX_QUERY_TOKENS || in.n_fields != 1) continue;
+            uint32_t best = 0xFFFFFFFFu;
+            for (uint32_t t = 0; t < in.n_tokens; t++) {
+                auto h = ctx->snap.handle_of.find(((uint64_t)in.field_ids[0] << 32) | in.term_ids[t]);
+                if (h != ctx->snap.handle_of.end()) best = std::min(best, ctx->snap.h_lists[h->second].n_blocks);
+            }
+            if (best != 0xFFFFFFFFu) total_blocks += best;
+        }
+        uint64_t c = total_blocks / 3000;
+        KW_CHUNK_BLOCKS = 16;
+        while (KW_CHUNK_BLOCKS < (uint32_t)KW_MAX_CHUNK && KW_CHUNK_BLOCKS * 2 <= c) KW_CHUNK_BLOCKS *= 2;
+    }
+    P.chunk_blocks = KW_CHUNK_BLOCKS;
     P.q.resize(n_queries);
     P.status.assign(n_queries, TSGPU_OK);
     P.cutoff.assign(n_queries, 0);
@@ -600,7 +620,7 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
         }
         ctx->timings.kw_algorithmic_bytes = bytes;
         // remember where matched ids live
-        ctx->last_chunk_blocks = ctx->kw_chunk_blocks;
+        ctx->last_chunk_blocks = P.chunk_blocks;
         ctx->last_ids_off.assign(n_queries, 0);
         ctx->last_ids_cap.assign(n_queries, 0);
         ctx->last_chunk_emit.assign(n_queries, {});

@@ -101,7 +101,7 @@ struct tsgpu_ctx {
     tsgpu::DevBuf d_prof;                            // TSGPU_PROF builds only (null otherwise)
     tsgpu::PinBuf h_stage, h_out;
     bool keep_ids = false;
-    uint32_t kw_chunk_blocks = 64;                   // driver blocks per work item (64 -> 16K candidate ids)
+    uint32_t kw_chunk_blocks = 0;                    // driver blocks per work item (0 = sized per batch, see plan_batch)
     uint32_t last_chunk_blocks = 64;
     uint32_t vec_rows_per_slab = 0;                  // 0 = automatic
     uint32_t vec_sample_tiles = 512;                 // 128-row tiles of the threshold sample (pass 1 of the k-NN)

@@ -52,7 +52,7 @@ static inline PackedList pack_list(const uint32_t* ids, const uint64_t* offset_i
         m.first_id = ids[s];
         m.n_ids = (uint16_t)cnt;
         m.n_off = (uint32_t)(o1 - o0);
-        m.ids_bits = (uint8_t)required_bits(ids[s + cnt - 1] - ids[s]);
+        m.ids_bits = required_bits(ids[s + cnt - 1] - ids[s]) <= 16 ? 16 : 32;   // fixed-width deltas: one aligned load per id in the kernels
         for (uint32_t i = 0; i < cnt; i++) oi[i] = (uint32_t)(offset_index[s + i] - o0);
         m.oi_bits = (uint8_t)required_bits(oi[cnt - 1]);
         uint32_t lo = 0xFFFFFFFFu, hi = 0;

@@ -514,6 +514,104 @@ int tsgpu_vector_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const tsgpu
     return ok();
 }
 
+// reciprocal rank fusion of ONE query, exactly src/index.cpp:4094-4211: `kw` = the keyword Topster content in sort()
+// order (slots of query q), knn = this query's exact nearest neighbours. Writes the fused + sorted Topster into out.
+static void fuse_one_query(tsgpu_ctx* ctx, int metric, const tsgpu_kw_query& kq, const tsgpu_hybrid_params* p, const tsgpu_hits& kw, uint32_t q,
+                           const float* knn_dist, const uint64_t* knn_lab, uint32_t knn_n, tsgpu_hits* out) {
+    const float VECTOR_SEARCH_WEIGHT = p->alpha;
+    const float TEXT_MATCH_WEIGHT = 1.0 - VECTOR_SEARCH_WEIGHT;
+    struct VH { float dist; uint64_t seq_id; };
+    uint32_t tsz = kq.topster_size ? kq.topster_size : TSGPU_DEFAULT_TOPSTER_SIZE;
+    tsz = std::max<uint32_t>(1, std::min<uint32_t>(tsz, std::max<uint32_t>(ctx->num_docs, 1)));
+    HostTopster topster(tsz);
+    const uint32_t nh = kw.n_hits[q];
+    std::vector<HostKV> sorted(nh);
+    for (uint32_t i = 0; i < nh; i++) {
+        const size_t s = (size_t)q * kw.k_stride + i;
+        HostKV& kv = sorted[i];
+        kv.key = kw.keys[s];
+        for (int j = 0; j < 3; j++) kv.scores[j] = kw.scores[s * 3 + j];
+        kv.match_score_index = kw.match_score_index ? kw.match_score_index[s] : 0;
+        kv.text_match_score = kw.text_match ? kw.text_match[s] : 0;
+        kv.vector_distance = -1.0f;
+    }
+    topster.adopt_sorted(sorted.data(), nh);
+    // vector hits: label order, threshold, then distance order (src/index.cpp:3389, 3414-3437)
+    std::vector<VH> dist_results;
+    for (uint32_t i = 0; i < knn_n; i++) dist_results.push_back({knn_dist[i], knn_lab[i]});
+    std::sort(dist_results.begin(), dist_results.end(), [](const VH& a, const VH& b) { return a.seq_id < b.seq_id; });
+    {
+        std::vector<VH> kept;
+        for (auto& r : dist_results) {
+            const float sc = metric == TSGPU_METRIC_COSINE ? std::fabs(r.dist) : r.dist;
+            if (sc > p->distance_threshold) continue;
+            kept.push_back(r);
+        }
+        std::stable_sort(kept.begin(), kept.end(), [](const VH& a, const VH& b) { return a.dist < b.dist; });
+        dist_results.swap(kept);
+    }
+    std::unordered_map<uint64_t, uint32_t> seq_id_to_rank;
+    for (size_t i = 0; i < dist_results.size(); i++) seq_id_to_rank.emplace(dist_results[i].seq_id, (uint32_t)i);
+    std::sort(dist_results.begin(), dist_results.end(), [](const VH& a, const VH& b) { return a.seq_id < b.seq_id; });
+    // text ranks (dense rank on score ties), :4094-4112
+    int64_t text_rank = 0, last_text_match_score = INT64_MAX;
+    for (uint32_t i = 0; i < topster.size; i++) {
+        HostKV* r = topster.kvs[i];
+        if (r->match_score_index < 0 || r->match_score_index > 2) continue;
+        r->text_match_score = r->scores[r->match_score_index];
+        if (r->text_match_score < last_text_match_score) ++text_rank;
+        last_text_match_score = r->text_match_score;
+        r->scores[r->match_score_index] = float_to_int64((1.0 / (text_rank)) * TEXT_MATCH_WEIGHT);
+    }
+    for (auto& dr : dist_results) {   // :4124-4211
+        const uint64_t seq_id = dr.seq_id;
+        auto it = topster.map.find(seq_id);
+        HostKV* found_kv = it == topster.map.end() ? nullptr : it->second;
+        if (found_kv) {
+            if (found_kv->match_score_index < 0 || found_kv->match_score_index > 2) continue;
+            found_kv->vector_distance = dr.dist;
+            const int64_t match_score = float_to_int64((int64_to_float(found_kv->scores[found_kv->match_score_index])) +
+                                                       ((1.0 / (seq_id_to_rank[seq_id] + 1)) * VECTOR_SEARCH_WEIGHT));
+            int64_t match_score_index = -1;
+            int64_t sc[3] = {0, 0, 0};
+            host_sort_scores(ctx, kq.sort, kq.n_sort, seq_id, match_score, dr.dist, sc, match_score_index);
+            for (int j = 0; j < 3; j++) found_kv->scores[j] = sc[j];
+            found_kv->match_score_index = (int8_t)match_score_index;
+        } else {
+            HostKV kv;
+            const int64_t match_score = float_to_int64((1.0 / (seq_id_to_rank[seq_id] + 1)) * VECTOR_SEARCH_WEIGHT);
+            int64_t match_score_index = -1;
+            host_sort_scores(ctx, kq.sort, kq.n_sort, seq_id, match_score, dr.dist, kv.scores, match_score_index);
+            kv.match_score_index = (int8_t)match_score_index;
+            kv.key = seq_id;
+            kv.text_match_score = 0;
+            kv.vector_distance = dr.dist;
+            topster.add(&kv);
+        }
+    }
+    topster.sort();
+    write_hits(topster, q, out);
+}
+
+// RRF fusion of already-computed (e.g. shard-merged) keyword hits and k-NN results; host arrays
+int tsgpu_hybrid_fuse_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsgpu_hybrid_params* p, int metric, const tsgpu_hits* kw_hits,
+                            const float* knn_dist, const uint64_t* knn_labels, const uint32_t* knn_cnt, uint32_t knn_k, uint32_t n_queries,
+                            tsgpu_hits* out) {
+    if (!ctx || !queries || !p || !kw_hits || !knn_dist || !knn_labels || !knn_cnt || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_hybrid_fuse_batch: NULL argument");
+    if (kw_hits->mem != TSGPU_MEM_HOST || out->mem != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_hybrid_fuse_batch: host arrays only");
+    try {
+        for (uint32_t q = 0; q < n_queries; q++) {
+            const int32_t st = kw_hits->status ? kw_hits->status[q] : TSGPU_OK;
+            out->status[q] = st;
+            if (out->search_cutoff) out->search_cutoff[q] = kw_hits->search_cutoff ? kw_hits->search_cutoff[q] : 0;
+            if (st != TSGPU_OK) { out->n_hits[q] = 0; if (out->num_matched) out->num_matched[q] = 0; continue; }
+            fuse_one_query(ctx, metric, queries[q], p, *kw_hits, q, knn_dist + (size_t)q * knn_k, knn_labels + (size_t)q * knn_k, knn_cnt[q], out);
+            if (out->num_matched) out->num_matched[q] = kw_hits->num_matched ? kw_hits->num_matched[q] : 0;
+        }
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_hybrid_fuse_batch: host allocation failed"); }
+    return ok();
+}
+
 // hybrid, src/index.cpp:4036-4221: keyword pass -> exact k-NN -> reciprocal rank fusion on the sorted Topster
 int tsgpu_hybrid_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t vec_field_id, const tsgpu_hybrid_params* p,
                               const float* Q, int mem_q, uint32_t n_queries, tsgpu_hits* out) {
@@ -546,93 +644,8 @@ int tsgpu_hybrid_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uin
         KnnHost kh;
         if ((rc = knn_to_host(ctx, vec_field_id, Q, mem_q, n_queries, k, nullptr, 0, nullptr, 0, kh))) return rc;
         // 3) fusion on the host, exactly as the reference
-        const float VECTOR_SEARCH_WEIGHT = p->alpha;
-        const float TEXT_MATCH_WEIGHT = 1.0 - VECTOR_SEARCH_WEIGHT;
-        std::vector<HostKV> sorted;
-        struct VH { float dist; uint64_t seq_id; };
-        std::vector<VH> dist_results;
-        std::unordered_map<uint64_t, uint32_t> seq_id_to_rank;
-        for (uint32_t q = 0; q < n_queries; q++) {
-            out->status[q] = st[q];
-            if (out->search_cutoff) out->search_cutoff[q] = co[q];
-            if (st[q] != TSGPU_OK) { out->n_hits[q] = 0; if (out->num_matched) out->num_matched[q] = 0; continue; }
-            const tsgpu_kw_query& kq = queries[q];
-            uint32_t tsz = kq.topster_size ? kq.topster_size : TSGPU_DEFAULT_TOPSTER_SIZE;
-            tsz = std::max<uint32_t>(1, std::min<uint32_t>(tsz, std::max<uint32_t>(ctx->num_docs, 1)));
-            HostTopster topster(tsz);
-            sorted.resize(nh[q]);
-            for (uint32_t i = 0; i < nh[q]; i++) {
-                const size_t s = (size_t)q * KS + i;
-                HostKV& kv = sorted[i];
-                kv.key = keys[s];
-                for (int j = 0; j < 3; j++) kv.scores[j] = scores[s * 3 + j];
-                kv.match_score_index = msi[s];
-                kv.text_match_score = tm[s];
-                kv.vector_distance = -1.0f;
-            }
-            topster.adopt_sorted(sorted.data(), nh[q]);
-            // vector hits: label order, threshold, then distance order (src/index.cpp:3389, 3414-3437)
-            dist_results.clear();
-            for (uint32_t i = 0; i < kh.cnt[q]; i++) dist_results.push_back({kh.dist[(size_t)q * k + i], kh.lab[(size_t)q * k + i]});
-            std::sort(dist_results.begin(), dist_results.end(), [](const VH& a, const VH& b) { return a.seq_id < b.seq_id; });
-            {
-                std::vector<VH> kept;
-                for (auto& r : dist_results) {
-                    const float sc = f->metric == TSGPU_METRIC_COSINE ? std::fabs(r.dist) : r.dist;
-                    if (sc > p->distance_threshold) continue;
-                    kept.push_back(r);
-                }
-                std::stable_sort(kept.begin(), kept.end(), [](const VH& a, const VH& b) { return a.dist < b.dist; });
-                dist_results.swap(kept);
-            }
-            seq_id_to_rank.clear();
-            for (size_t i = 0; i < dist_results.size(); i++) seq_id_to_rank.emplace(dist_results[i].seq_id, (uint32_t)i);
-            std::sort(dist_results.begin(), dist_results.end(), [](const VH& a, const VH& b) { return a.seq_id < b.seq_id; });
-            // text ranks (dense rank on score ties), :4094-4112
-            int64_t text_rank = 0, last_text_match_score = INT64_MAX;
-            for (uint32_t i = 0; i < topster.size; i++) {
-                HostKV* r = topster.kvs[i];
-                if (r->match_score_index < 0 || r->match_score_index > 2) continue;
-                r->text_match_score = r->scores[r->match_score_index];
-                if (r->text_match_score < last_text_match_score) ++text_rank;
-                last_text_match_score = r->text_match_score;
-                r->scores[r->match_score_index] = float_to_int64((1.0 / (text_rank)) * TEXT_MATCH_WEIGHT);
-            }
-            uint64_t vec_only = 0;
-            for (auto& dr : dist_results) {   // :4124-4211
-                const uint64_t seq_id = dr.seq_id;
-                auto it = topster.map.find(seq_id);
-                HostKV* found_kv = it == topster.map.end() ? nullptr : it->second;
-                if (found_kv) {
-                    if (found_kv->match_score_index < 0 || found_kv->match_score_index > 2) continue;
-                    found_kv->vector_distance = dr.dist;
-                    const int64_t match_score = float_to_int64((int64_to_float(found_kv->scores[found_kv->match_score_index])) +
-                                                               ((1.0 / (seq_id_to_rank[seq_id] + 1)) * VECTOR_SEARCH_WEIGHT));
-                    int64_t match_score_index = -1;
-                    int64_t sc[3] = {0, 0, 0};
-                    host_sort_scores(ctx, kq.sort, kq.n_sort, seq_id, match_score, dr.dist, sc, match_score_index);
-                    for (int j = 0; j < 3; j++) found_kv->scores[j] = sc[j];
-                    found_kv->match_score_index = (int8_t)match_score_index;
-                } else {
-                    HostKV kv;
-                    const int64_t match_score = float_to_int64((1.0 / (seq_id_to_rank[seq_id] + 1)) * VECTOR_SEARCH_WEIGHT);
-                    int64_t match_score_index = -1;
-                    host_sort_scores(ctx, kq.sort, kq.n_sort, seq_id, match_score, dr.dist, kv.scores, match_score_index);
-                    kv.match_score_index = (int8_t)match_score_index;
-                    kv.key = seq_id;
-                    kv.text_match_score = 0;
-                    kv.vector_distance = dr.dist;
-                    topster.add(&kv);
-                    vec_only++;
-                }
-            }
-            topster.sort();
-            write_hits(topster, q, out);
-            if (out->num_matched) out->num_matched[q] = nm[q];
-            (void)vec_only;
-        }
+        return tsgpu_hybrid_fuse_batch(ctx, queries, p, f->metric, &kw, kh.dist.data(), kh.lab.data(), kh.cnt.data(), k, n_queries, out);
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_hybrid_search_batch: host allocation failed"); }
-    return ok();
 }
 
 // exact merge of per-shard Topster lists (doc-range shards): same comparator as include/topster.h:146-149

@@ -274,3 +274,18 @@ class GpuIndex:
         hs = hits.c_struct()
         self._ck(self.L.tsgpu_hybrid_search_batch(self.h, C.cast(arr, C.c_void_p), field_id, C.byref(p), _vp(Q), B.MEM_HOST, len(arr), C.byref(hs)))
         return hits
+
+    def hybrid_fuse_batch(self, queries, kw_hits, knn_dist, knn_labels, knn_cnt, metric, k=0, fetch_size=10, alpha=0.3,
+                          distance_threshold=B.FLT_MAX, k_stride=250):
+        """fusion step alone on already-computed (e.g. shard-merged) results; kw_hits: Hits (host)"""
+        arr = make_query_array(queries)
+        p = B.HybridParamsC()
+        p.k, p.fetch_size, p.alpha, p.distance_threshold = k, fetch_size, alpha, distance_threshold
+        d = np.ascontiguousarray(knn_dist, dtype=np.float32)
+        l = np.ascontiguousarray(knn_labels, dtype=np.uint64)
+        c = np.ascontiguousarray(knn_cnt, dtype=np.uint32)
+        hits = Hits(len(arr), k_stride)
+        hs, ks = hits.c_struct(), kw_hits.c_struct()
+        self._ck(self.L.tsgpu_hybrid_fuse_batch(self.h, C.cast(arr, C.c_void_p), C.byref(p), metric, C.byref(ks), _vp(d), _vp(l), _vp(c),
+                                                d.shape[1], len(arr), C.byref(hs)))
+        return hits
