@@ -1,0 +1,36 @@
+"""Vector k-NN variant sweep: one 10M x 768 base per library variant (TSGPU_LIBS = comma-separated .so paths), B in VEC_BATCHES."""
+import os, sys, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import typesense_amd as T
+from typesense_amd import _lib as B, synth
+
+n, dim, k = int(os.environ.get("VEC_N", 10_000_000)), 768, 100
+libs = [p for p in os.environ.get("TSGPU_LIBS", "").split(",") if p] or [None]
+batches = [int(x) for x in os.environ.get("VEC_BATCHES", "256").split(",")]
+for lib in libs:
+    g = T.GpuIndex(0, lib)
+    g.vec_create(1, dim, B.METRIC_IP, n)
+    slab = 1 << 20
+    for a in range(0, n, slab):
+        b = min(n, a + slab)
+        x = synth.random_vectors(b - a, dim, seed=3 + a, device="cuda")
+        labels = torch.arange(a, b, dtype=torch.int64, device="cuda")
+        g.vec_upsert_device(1, labels.data_ptr(), x.data_ptr(), b - a)
+        del x
+    for nq in batches:
+        Q = synth.random_vectors(nq, dim, seed=4, device="cuda")
+        d = torch.zeros((nq, k), dtype=torch.float32, device="cuda"); l = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+        c = torch.zeros(nq, dtype=torch.int32, device="cuda")
+        ms = []
+        for it in range(4):
+            g.vec_knn_batch_raw(1, Q.data_ptr(), B.MEM_DEVICE, nq, k, d.data_ptr(), l.data_ptr(), c.data_ptr(), B.MEM_DEVICE)
+            tm = g.timings()
+            if it: ms.append(tm.vec_knn_ms)
+        m = float(np.mean(ms))
+        print(json.dumps(dict(lib=os.path.basename(lib or "default"), n_q=nq, knn_ms=m, tflops=tm.vec_flops / m / 1e9, qps=nq / m * 1e3,
+                              chk=int(l.sum().item()))), flush=True)
+    g.close()
+    torch.cuda.empty_cache()

@@ -33,6 +33,9 @@ namespace tsgpu {
 static const int VEC_THREADS = 256;
 static const int VEC_ROWS = 128;        // base rows per tile (2 wave rows x 64)
 static const int VEC_KC = 32;           // K chunk staged in LDS per step
+#ifndef VEC_STORE_AT_G
+#define VEC_STORE_AT_G 3   // k-group whose MFMAs cover the LDS stores of the next chunk (4 = after the MFMAs)
+#endif
 static const int VEC_LDW = VEC_KC + 4;  // padded row stride (words): 36*r mod 64 hits 16 distinct 4-bank groups -> ds_read_b128 conflict-free
 static const uint64_t VEC_KEY_INF = 0xFFFFFFFFFFFFFFFFull;
 static const int VEC_SELECT_MAXK = 1024;   // TSGPU_MAX_TOPK
@@ -96,9 +99,12 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_scan_kernel(VecScanArgs a)
     const uint32_t total_steps = (ord_end - ord_begin) * n_chunks;
 
     float4 xr[XV], qr[QV];
-    // branch-free guarded load: out-of-range rows / k read a clamped in-range address and are zeroed afterwards
+    // Guarded load without touching the loaded registers (a select on them would force the wave to wait for the
+    // global load BEFORE the chunk's MFMAs instead of after them): out-of-range rows / queries read a clamped
+    // in-range row — their scores are computed and then dropped by the epilogue (row < n_rows, gq < n_q), and every
+    // accumulator element depends on one row and one query only. Only the K tail (dim % 32 != 0, last chunk) needs
+    // zeros; they are applied in store_step, i.e. after the MFMAs of the previous chunk.
     auto load4 = [&](const float* base, uint32_t row, uint32_t row_lim, uint32_t gk) -> float4 {
-        const bool ok = row < row_lim && gk < a.dim;
         const uint32_t r = row < row_lim ? row : row_lim - 1;
         float4 val;
         if (ALIGNED) {
@@ -108,11 +114,10 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_scan_kernel(VecScanArgs a)
             const float* p = base + (size_t)r * a.dim;
             const uint32_t d1 = a.dim - 1;
             val.x = p[gk < d1 ? gk : d1];
-            val.y = (gk + 1 < a.dim) ? p[gk + 1 < d1 ? gk + 1 : d1] : 0.f;
-            val.z = (gk + 2 < a.dim) ? p[gk + 2 < d1 ? gk + 2 : d1] : 0.f;
-            val.w = (gk + 3 < a.dim) ? p[gk + 3 < d1 ? gk + 3 : d1] : 0.f;
+            val.y = p[gk + 1 < d1 ? gk + 1 : d1];
+            val.z = p[gk + 2 < d1 ? gk + 2 : d1];
+            val.w = p[gk + 3 < d1 ? gk + 3 : d1];
         }
-        if (!ok) val = make_float4(0.f, 0.f, 0.f, 0.f);
         return val;
     };
     // global -> registers for pipeline step s (tile ordinal = ord_begin + s / n_chunks, chunk = s % n_chunks)
@@ -132,7 +137,26 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_scan_kernel(VecScanArgs a)
             qr[v] = load4(a.Q, gq, a.n_q, gk);
         }
     };
-    auto store_step = [&](uint32_t buf) {
+    // registers -> LDS for pipeline step s (the K tail of the last chunk is zeroed here, on BOTH operands)
+    auto store_step = [&](uint32_t buf, uint32_t s) {
+        const uint32_t k0 = (s % n_chunks) * VEC_KC;
+        if (k0 + VEC_KC > a.dim) {                              // uniform: only the last chunk of a dim % 32 != 0 index
+            const uint32_t gk = k0 + (t % (VEC_KC / 4)) * 4;    // idx % 8 == t % 8 for every v
+#pragma unroll
+            for (int v = 0; v < XV; v++) {
+                if (gk >= a.dim) xr[v].x = 0.f;
+                if (gk + 1 >= a.dim) xr[v].y = 0.f;
+                if (gk + 2 >= a.dim) xr[v].z = 0.f;
+                if (gk + 3 >= a.dim) xr[v].w = 0.f;
+            }
+#pragma unroll
+            for (int v = 0; v < QV; v++) {
+                if (gk >= a.dim) qr[v].x = 0.f;
+                if (gk + 1 >= a.dim) qr[v].y = 0.f;
+                if (gk + 2 >= a.dim) qr[v].z = 0.f;
+                if (gk + 3 >= a.dim) qr[v].w = 0.f;
+            }
+        }
 #pragma unroll
         for (int v = 0; v < XV; v++) {
             const uint32_t idx = t + v * VEC_THREADS;
@@ -157,7 +181,7 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_scan_kernel(VecScanArgs a)
 
     vec_f32x16 acc[2][CB];
     load_step(0);
-    store_step(0);
+    store_step(0, 0);
     __syncthreads();
     for (uint32_t s = 0; s < total_steps; s++) {
         const uint32_t c = s % n_chunks, buf = s & 1;
@@ -173,24 +197,44 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_scan_kernel(VecScanArgs a)
         // lane (r = lane&31, h = lane>>5) supplies k = 8*g + 4*h + i to MFMA i of group g: every k exactly once
         const float* xa = &sm.xs[buf][(wrow + (lane & 31)) * VEC_LDW + 4 * (lane >> 5)];
         const float* qb = &sm.qs[buf][(wcol + (lane & 31)) * VEC_LDW + 4 * (lane >> 5)];
+        // operands of k-group g+1 are requested from LDS before the 16 MFMAs of group g are issued (register double
+        // buffer), and the 4 accumulators are interleaved so that consecutive MFMAs never depend on each other
+        float4 av[2][2], bv[2][CB];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) av[0][rb] = *(const float4*)(xa + rb * 32 * VEC_LDW);
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) bv[0][cb] = *(const float4*)(qb + cb * 32 * VEC_LDW);
 #pragma unroll
         for (int g = 0; g < VEC_KC / 8; g++) {
-            float4 av[2], bv[CB];
+            const int cur = g & 1, nx = cur ^ 1;
+            if (g + 1 < VEC_KC / 8) {
 #pragma unroll
-            for (int rb = 0; rb < 2; rb++) av[rb] = *(const float4*)(xa + rb * 32 * VEC_LDW + 8 * g);
+                for (int rb = 0; rb < 2; rb++) av[nx][rb] = *(const float4*)(xa + rb * 32 * VEC_LDW + 8 * (g + 1));
 #pragma unroll
-            for (int cb = 0; cb < CB; cb++) bv[cb] = *(const float4*)(qb + cb * 32 * VEC_LDW + 8 * g);
+                for (int cb = 0; cb < CB; cb++) bv[nx][cb] = *(const float4*)(qb + cb * 32 * VEC_LDW + 8 * (g + 1));
+            }
+            // the next chunk's registers -> LDS (other ring slot) go out under the last MFMA group instead of after it
+            if (g == VEC_STORE_AT_G && s + 1 < total_steps) store_step(buf ^ 1, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-                for (int cb = 0; cb < CB; cb++) {
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rb].x, bv[cb].x, acc[rb][cb], 0, 0, 0);
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rb].y, bv[cb].y, acc[rb][cb], 0, 0, 0);
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rb].z, bv[cb].z, acc[rb][cb], 0, 0, 0);
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rb].w, bv[cb].w, acc[rb][cb], 0, 0, 0);
-                }
+                for (int cb = 0; cb < CB; cb++) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][rb].x, bv[cur][cb].x, acc[rb][cb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][rb].y, bv[cur][cb].y, acc[rb][cb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][rb].z, bv[cur][cb].z, acc[rb][cb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][rb].w, bv[cur][cb].w, acc[rb][cb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (s + 1 < total_steps) store_step(buf ^ 1);
+        if (VEC_STORE_AT_G >= VEC_KC / 8 && s + 1 < total_steps) store_step(buf ^ 1, s + 1);
         if (c == n_chunks - 1) {
             // ---- tile epilogue: distance = 1 - dot; key = (ord(distance) << 32) | row ----
             const uint32_t o = ord_begin + s / n_chunks;
