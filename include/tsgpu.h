@@ -96,8 +96,13 @@ const char* tsgpu_last_error(void);
 int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
 /* tuning knobs (all optional): "kw_chunk_blocks" = driver posting blocks per keyword work item (default 0 = sized per batch; 1..256),
  * "vec_rows_per_slab" = base rows per k-NN workgroup slab (default: automatic), "vec_sample_tiles" = 128-row tiles of
- * the k-NN threshold sample (default 512), "vec_cand_cap" = candidate slots per query of the filtered pass (0 = auto) */
+ * the k-NN threshold sample (default 512), "vec_cand_cap" = candidate slots per query of the filtered pass (0 = auto),
+ * "vec_prefilter" = 1 (default): bf16 bracket scan + exact fp32 re-score of the survivors, 0: fp32 MFMA scan of every row
+ * (identical result sets either way), "vec_count_rescored" = 1: keep the vec_rescored_rows counter (costs one sync) */
 int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value);
+/* introspection counters (tests / bench): "vec_overflow_rounds", "vec_prefilter_groups", "vec_prefilter_fallbacks",
+ * "vec_rescored_rows" */
+int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out);
 /* bytes of HBM held by the context's index mirrors */
 uint64_t tsgpu_device_bytes(tsgpu_ctx* ctx);
 
@@ -259,8 +264,10 @@ typedef struct tsgpu_timings {
     float vec_knn_ms;      /* MFMA distance + running top-k kernel */
     float vec_merge_ms;
     float total_ms;        /* first launch -> last kernel done */
+    float vec_scan_ms;     /* the full-index scan kernel alone (vec_hscan_kernel / vec_scan_kernel), 0 for small indexes */
     uint64_t kw_algorithmic_bytes;   /* SURVEY §8(d) bytes of the last keyword batch */
     uint64_t vec_flops;              /* 2*N*D*B of the last knn batch */
+    uint64_t vec_scan_bytes;         /* bytes the scan kernel must stream per launch: the row matrix once + the queries */
 } tsgpu_timings;
 int tsgpu_last_timings(tsgpu_ctx* ctx, tsgpu_timings* out);
 

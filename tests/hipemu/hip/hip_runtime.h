@@ -48,6 +48,7 @@ struct WaveState {
     unsigned gen = 0;
     uint64_t u64[64];
     float f32a[64], f32b[64];
+    uint16_t bfa[64][8], bfb[64][8];
 };
 
 struct BlockState {
@@ -141,9 +142,10 @@ inline void run_block(BlockState& B) {
 
 template <class F>
 inline void launch(dim3 grid, dim3 block, F body) {
+    for (unsigned by = 0; by < grid.y; by++)
     for (unsigned bx = 0; bx < grid.x; bx++) {
         BlockState B;
-        B.block_idx = dim3(bx, 0, 0);
+        B.block_idx = dim3(bx, by, 0);
         B.block_dim = block;
         B.grid_dim = grid;
         B.body = body;
@@ -225,6 +227,36 @@ inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     return d;
 }
 
+// v_mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)..+7], B[k=8*(l>>5)..+7][j=l&31]; D as the other 32x32 forms.
+// bf16 x bf16 products are exact in fp32; the hardware's internal accumulation order is unspecified, the model
+// adds them in k order (callers must not depend on the exact rounding of this instruction).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+inline f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    WaveState& W = cur_wave();
+    const unsigned l = cur_lane();
+    uint16_t ha[8], hb[8];
+    memcpy(ha, &a, 16);
+    memcpy(hb, &b, 16);
+    for (int i = 0; i < 8; i++) { W.bfa[l][i] = ha[i]; W.bfb[l][i] = hb[i]; }
+    wave_sync();
+    f32x16 d = c;
+    const unsigned col = l & 31;
+    for (int r = 0; r < 16; r++) {
+        const unsigned row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (unsigned k = 0; k < 16; k++) {
+            uint32_t ua = (uint32_t)W.bfa[row + 32 * (k >> 3)][k & 7] << 16, ub = (uint32_t)W.bfb[col + 32 * (k >> 3)][k & 7] << 16;
+            float fa, fb;
+            memcpy(&fa, &ua, 4);
+            memcpy(&fb, &ub, 4);
+            acc = fmaf(fa, fb, acc);
+        }
+        d[r] = acc;
+    }
+    wave_sync();
+    return d;
+}
+
 }  // namespace hipemu
 
 #define threadIdx (hipemu::cur_tid())
@@ -249,6 +281,8 @@ template <class T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; 
 template <class T> inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 
 struct float4 { float x, y, z, w; };
+struct uint4 { uint32_t x, y, z, w; };
+struct uint2 { uint32_t x, y; };
 inline float4 make_float4(float x, float y, float z, float w) { float4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -260,6 +294,7 @@ inline float __fsqrt_rn(float a) { return sqrtf(a); }
 
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu::mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_16x16x4((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu::mfma_32x32x16_bf16((a), (b), (c))
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
 

@@ -114,6 +114,67 @@ def test_knn_two_pass_all_equal_distances_converges():
     dist, lab, cnt = g.vec_knn_batch(1, np.ones((2, 16), np.float32), 15)
     assert (cnt == 15).all() and np.array_equal(lab[0], np.arange(15, dtype=np.uint64))      # ties -> smaller label first
     assert np.allclose(dist, -15.0)
+    # value brackets cannot separate identical rows: the bf16 prefilter must hand the group to the fp32 scan, not loop
+    assert g.counter("vec_prefilter_fallbacks") == 1
+    g.set_option("vec_prefilter", 0)
+    dist, lab, cnt = g.vec_knn_batch(1, np.ones((2, 16), np.float32), 15)
+    assert (cnt == 15).all() and np.array_equal(lab[0], np.arange(15, dtype=np.uint64)) and g.counter("vec_prefilter_fallbacks") == 1
+    g.close()
+
+
+def _check_knn_bits(g, orc, Q, k, allow=None):
+    """bf16-prefilter path: survivors are re-scored with hnswlib's own summation order -> distances are BIT-identical
+    to the oracle and the order (incl. ties -> smaller label) is exactly the oracle's"""
+    dist, lab, cnt = g.vec_knn_batch(1, Q, k, allow_ids=allow)
+    for i in range(Q.shape[0]):
+        d, l = orc.flat_knn(Q[i], k, allow_ids=allow)
+        assert cnt[i] == d.size
+        assert np.array_equal(lab[i, :d.size].astype(np.uint32), l)
+        assert np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32))
+
+
+@pytest.mark.parametrize("dim,n,k,nq,sample_tiles,metric", [
+    (768, 300, 100, 3, 512, B.METRIC_IP),      # dim % 16 == 0: InnerProductSIMD16Ext order; dense (small index) route
+    (20, 900, 10, 2, 2, B.METRIC_IP),          # dim % 4 == 0: SIMD4Ext order; sample -> L1 -> filtered scan route
+    (70, 800, 25, 70, 1, B.METRIC_IP),         # dim > 16 residual form, QT = 128 tile
+    (7, 400, 5, 2, 1, B.METRIC_IP),            # dim > 4 residual form
+    (3, 300, 4, 2, 512, B.METRIC_IP),          # scalar form
+    (48, 600, 30, 3, 2, B.METRIC_COSINE),      # cosine: normalised rows and query
+])
+def test_prefilter_distances_are_bit_identical_to_the_reference_order(dim, n, k, nq, sample_tiles, metric):
+    g, orc, X, rng = _mk(n, dim, metric, 100 + dim, H.emu_lib_path())
+    g.set_option("vec_sample_tiles", sample_tiles)
+    g.set_option("vec_count_rescored", 1)
+    Q = (rng.standard_normal((nq, dim)) * 3).astype(np.float32)
+    _check_knn_bits(g, orc, Q, k)
+    assert g.counter("vec_prefilter_groups") >= 1 and g.counter("vec_prefilter_fallbacks") == 0
+    g.close()
+
+
+def test_prefilter_brackets_prune_but_never_drop_a_neighbour():
+    """heterogeneous norms + near-duplicates: the survivors are a small superset of the true top-k"""
+    rng = np.random.default_rng(77)
+    n, dim, k = 3000, 64, 20
+    X = rng.standard_normal((n, dim)).astype(np.float32) * rng.uniform(0.1, 8.0, size=(n, 1)).astype(np.float32)
+    X[1000:1040] = X[5] * (1 + 1e-4 * rng.standard_normal((40, 1)).astype(np.float32))     # 40 near-copies of one row
+    labels = np.arange(n, dtype=np.uint64)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.set_option("vec_sample_tiles", 4)
+    g.set_option("vec_count_rescored", 1)
+    g.vec_create(1, dim, B.METRIC_IP)
+    g.vec_upsert(1, labels, X)
+    orc = O.OracleIndex(1, 1)
+    orc.vec_init(dim, O.METRIC_IP)
+    orc.vec_add(labels.astype(np.uint32), X)
+    Q = np.stack([X[5] * 0.5, rng.standard_normal(dim).astype(np.float32), -X[77]])
+    _check_knn_bits(g, orc, Q, k)
+    assert g.counter("vec_prefilter_fallbacks") == 0
+    assert 3 * k <= g.counter("vec_rescored_rows") < 3 * n // 4        # pruned, not everything re-scored
+    # non-finite data never poisons the bounds: an inf row and a NaN row are re-scored like everyone else
+    bad = X[:2].copy(); bad[0, 3] = np.inf; bad[1, 7] = np.nan
+    g.vec_upsert(1, np.array([10, 11], np.uint64), bad)
+    dist, lab, cnt = g.vec_knn_batch(1, Q[1:2], k)
+    assert cnt[0] == k
     g.close()
 
 

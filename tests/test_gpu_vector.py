@@ -25,6 +25,10 @@ test_upsert_delete_labels_filters_and_by_id_distances = E.test_upsert_delete_lab
 test_pure_vector_search_topster_order_matches_oracle = E.test_pure_vector_search_topster_order_matches_oracle
 test_hybrid_rank_fusion_matches_oracle_bit_exactly = E.test_hybrid_rank_fusion_matches_oracle_bit_exactly
 test_shard_merge_equals_unsharded = E.test_shard_merge_equals_unsharded
+test_knn_two_pass_threshold_path_is_exact = E.test_knn_two_pass_threshold_path_is_exact
+test_knn_two_pass_all_equal_distances_converges = E.test_knn_two_pass_all_equal_distances_converges
+test_prefilter_distances_are_bit_identical_to_the_reference_order = E.test_prefilter_distances_are_bit_identical_to_the_reference_order
+test_prefilter_brackets_prune_but_never_drop_a_neighbour = E.test_prefilter_brackets_prune_but_never_drop_a_neighbour
 
 
 @pytest.fixture(scope="module")
@@ -59,6 +63,36 @@ def test_200k_x_768_batches_top100(big, n_q):
                 dx = 1.0 - float(np.dot(Q[i].astype(np.float64), X[x].astype(np.float64)))
                 assert abs(dx - float(d[-1])) <= 2 * band
         assert (np.diff(dist[i]) >= 0).all()
+
+
+@pytest.mark.parametrize("n_q,sample_tiles", [(3, 512), (70, 64), (130, 1562)])
+def test_200k_x_768_prefilter_is_bit_identical_to_the_reference_order(big, n_q, sample_tiles):
+    """bf16 bracket scan on the real matrix cores + exact fp32 re-score in hnswlib's summation order: same labels in the
+    same order and the same distance BITS as the oracle; the fp32 MFMA scan (vec_prefilter=0) returns the same label sets"""
+    g, orc, X, rng = big
+    g.set_option("vec_sample_tiles", sample_tiles)
+    g.set_option("vec_count_rescored", 1)
+    Q = rng.standard_normal((n_q, 768)).astype(np.float32)
+    f0 = g.counter("vec_prefilter_fallbacks")
+    dist, lab, cnt = g.vec_knn_batch(1, Q, 100)
+    assert (cnt == 100).all() and g.counter("vec_prefilter_fallbacks") == f0
+    assert 100 * n_q <= g.counter("vec_rescored_rows") <= 40 * 100 * n_q        # the brackets really prune (200K rows/query in)
+    for i in range(min(n_q, 12)):
+        d, l = orc.flat_knn(Q[i], 100)
+        assert np.array_equal(lab[i].astype(np.uint32), l)
+        assert np.array_equal(dist[i].view(np.uint32), d.view(np.uint32))
+    g.set_option("vec_prefilter", 0)
+    d0, l0, _ = g.vec_knn_batch(1, Q[:8], 100)
+    g.set_option("vec_prefilter", 1)
+    g.set_option("vec_sample_tiles", 512)
+    g.set_option("vec_count_rescored", 0)
+    for i in range(min(n_q, 8)):
+        assert np.allclose(d0[i], dist[i], rtol=1e-5, atol=1e-5)
+        if set(l0[i].tolist()) != set(lab[i].tolist()):      # fp32-MFMA summation order may flip members inside the 1e-5 tie band
+            band = 2e-5 * max(1.0, abs(float(dist[i][-1])))
+            for x in set(l0[i].tolist()) ^ set(lab[i].tolist()):
+                dx = 1.0 - float(np.dot(Q[i].astype(np.float64), X[int(x)].astype(np.float64)))
+                assert abs(dx - float(dist[i][-1])) <= band
 
 
 def test_knn_is_deterministic_and_slab_invariant(big):

@@ -53,11 +53,12 @@ class HybridParamsC(C.Structure):
 
 class TimingsC(C.Structure):
     _fields_ = [("kw_search_ms", C.c_float), ("kw_merge_ms", C.c_float), ("vec_knn_ms", C.c_float), ("vec_merge_ms", C.c_float),
-                ("total_ms", C.c_float), ("kw_algorithmic_bytes", C.c_uint64), ("vec_flops", C.c_uint64)]
+                ("total_ms", C.c_float), ("vec_scan_ms", C.c_float), ("kw_algorithmic_bytes", C.c_uint64), ("vec_flops", C.c_uint64),
+                ("vec_scan_bytes", C.c_uint64)]
 
 
 EXPORTS = [
-    "tsgpu_abi_version", "tsgpu_create", "tsgpu_destroy", "tsgpu_last_error", "tsgpu_set_stream", "tsgpu_set_option", "tsgpu_device_bytes",
+    "tsgpu_abi_version", "tsgpu_create", "tsgpu_destroy", "tsgpu_last_error", "tsgpu_set_stream", "tsgpu_set_option", "tsgpu_get_counter", "tsgpu_device_bytes",
     "tsgpu_field_create", "tsgpu_term_upsert", "tsgpu_terms_load_csr", "tsgpu_column_set", "tsgpu_set_num_docs", "tsgpu_commit",
     "tsgpu_term_num_ids", "tsgpu_term_download", "tsgpu_keyword_search_batch", "tsgpu_keep_result_ids", "tsgpu_result_ids",
     "tsgpu_vec_create", "tsgpu_vec_upsert", "tsgpu_vec_delete", "tsgpu_vec_get", "tsgpu_vec_count", "tsgpu_vec_knn_batch",
@@ -84,6 +85,7 @@ def lib(path=None):
     L.tsgpu_last_error.restype = C.c_char_p
     L.tsgpu_set_stream.argtypes = [vp, vp]
     L.tsgpu_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.tsgpu_get_counter.argtypes = [vp, C.c_char_p, C.POINTER(u64)]
     L.tsgpu_device_bytes.argtypes = [vp]
     L.tsgpu_device_bytes.restype = u64
     L.tsgpu_field_create.argtypes = [vp, u32, i32]

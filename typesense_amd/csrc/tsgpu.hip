@@ -349,7 +349,23 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
         ctx->vec_cand_cap = (uint32_t)value;
         return ok();
     }
+    if (!strcmp(name, "vec_count_rescored")) { ctx->vec_count_rescored = value != 0; return ok(); }
+    if (!strcmp(name, "vec_prefilter")) {
+        if (value != 0 && value != 1) return fail(TSGPU_ERR_INVALID, "vec_prefilter must be 0 or 1");
+        ctx->vec_prefilter = (uint32_t)value;
+        return ok();
+    }
     return fail(TSGPU_ERR_NOT_FOUND, std::string("tsgpu_set_option: unknown option ") + name);
+}
+
+int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
+    if (!ctx || !name || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_get_counter: NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!strcmp(name, "vec_overflow_rounds")) { *out = ctx->vec_overflow_rounds; return ok(); }
+    if (!strcmp(name, "vec_prefilter_fallbacks")) { *out = ctx->vec_prefilter_fallbacks; return ok(); }
+    if (!strcmp(name, "vec_prefilter_groups")) { *out = ctx->vec_prefilter_groups; return ok(); }
+    if (!strcmp(name, "vec_rescored_rows")) { *out = ctx->vec_rescored_rows; return ok(); }
+    return fail(TSGPU_ERR_NOT_FOUND, std::string("tsgpu_get_counter: unknown counter ") + name);
 }
 
 int tsgpu_keep_result_ids(tsgpu_ctx* ctx, int keep) {

@@ -106,6 +106,11 @@ struct tsgpu_ctx {
     uint32_t vec_rows_per_slab = 0;                  // 0 = automatic
     uint32_t vec_sample_tiles = 512;                 // 128-row tiles of the threshold sample (pass 1 of the k-NN)
     uint32_t vec_cand_cap = 0;                       // candidate slots per query in pass 2 (0 = automatic)
+    uint32_t vec_prefilter = 1;                      // 1 = bf16 bracket scan + exact fp32 re-score (default); 0 = fp32 MFMA scan
+    uint64_t vec_prefilter_groups = 0;               // query groups answered by the bf16 bracket path
+    uint64_t vec_rescored_rows = 0;                  // survivors re-scored in fp32 by the last prefilter group (sum over its queries; 0 unless vec_count_rescored)
+    uint32_t vec_count_rescored = 0;
+    uint64_t vec_prefilter_fallbacks = 0;            // query groups the bf16 bracket could not separate (ran on the fp32 scan)
     uint64_t vec_overflow_rounds = 0;                // pass-2 repeats caused by candidate overflow (introspection)
     std::vector<uint64_t> last_ids_off;              // per query offset into d_ids_out of the last batch
     std::vector<uint64_t> last_ids_cap;
@@ -116,4 +121,5 @@ struct tsgpu_ctx {
 
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     tsgpu_timings timings{};
+    bool scan_events_valid = false;                  // ev[6]/ev[7] bracket the main k-NN scan of the last batch's first query group
 };

@@ -16,6 +16,8 @@ struct VecField {
     uint32_t dim = 0;
     int metric = TSGPU_METRIC_IP;
     DevBuf X, labels, row_ok;
+    DevBuf Xh, xnorm, tile_nmax;                       // bf16 prefilter mirror: bf16 rows [cap][dimp], inflated row norms, per-tile max norm
+    uint32_t dimp = 0;                                 // dim rounded up to a multiple of 64 (zero padded)
     uint64_t cap_rows = 0, n_rows = 0, n_live = 0;
     std::vector<uint64_t> h_labels;
     std::vector<uint8_t> h_ok;
@@ -24,6 +26,7 @@ struct VecField {
     bool any_deleted = false;
     // scratch
     DevBuf d_dense, d_cand, d_cand_cnt, d_tau, dQ, d_dist, d_lab, d_cnt, d_mask, d_rows, d_q1, d_out1;
+    DevBuf d_Qh, d_cq, d_L1, d_lbkey, d_surv, d_surv_cnt;
 
     bool find_row(uint64_t label, uint32_t& row) const {
         if (identity) { if (label < n_rows) { row = (uint32_t)label; return true; } return false; }
@@ -39,7 +42,8 @@ struct VecField {
         identity = false;
     }
     void release() {
-        DevBuf* b[] = {&X, &labels, &row_ok, &d_dense, &d_cand, &d_cand_cnt, &d_tau, &dQ, &d_dist, &d_lab, &d_cnt, &d_mask, &d_rows, &d_q1, &d_out1};
+        DevBuf* b[] = {&X, &labels, &row_ok, &Xh, &xnorm, &tile_nmax, &d_dense, &d_cand, &d_cand_cnt, &d_tau, &dQ, &d_dist, &d_lab, &d_cnt, &d_mask, &d_rows,
+                       &d_q1, &d_out1, &d_Qh, &d_cq, &d_L1, &d_lbkey, &d_surv, &d_surv_cnt};
         for (auto* x : b) x->release();
     }
 };
@@ -47,19 +51,22 @@ struct VecField {
 static int vec_reserve_rows(VecField* f, uint64_t rows, hipStream_t s) {
     if (rows <= f->cap_rows) return TSGPU_OK;
     uint64_t want = std::max<uint64_t>(rows, f->cap_rows + f->cap_rows / 2 + 1024);
-    DevBuf nx, nl, no;
+    DevBuf nx, nl, no, nh, nn, nt;
     int rc;
-    if ((rc = nx.reserve((size_t)want * f->dim * 4))) return rc;
-    if ((rc = nl.reserve((size_t)want * 8))) { nx.release(); return rc; }
-    if ((rc = no.reserve((size_t)want))) { nx.release(); nl.release(); return rc; }
+    auto drop = [&]() { nx.release(); nl.release(); no.release(); nh.release(); nn.release(); nt.release(); };
+    if ((rc = nx.reserve((size_t)want * f->dim * 4)) || (rc = nl.reserve((size_t)want * 8)) || (rc = no.reserve((size_t)want)) ||
+        (rc = nh.reserve((size_t)want * f->dimp * 2)) || (rc = nn.reserve((size_t)want * 4)) || (rc = nt.reserve((size_t)(want / VEC_ROWS + 2) * 4))) { drop(); return rc; }
     if (f->n_rows) {
         TSGPU_HIP_TRY(hipMemcpyAsync(nx.p, f->X.p, (size_t)f->n_rows * f->dim * 4, hipMemcpyDeviceToDevice, s));
         TSGPU_HIP_TRY(hipMemcpyAsync(nl.p, f->labels.p, (size_t)f->n_rows * 8, hipMemcpyDeviceToDevice, s));
         TSGPU_HIP_TRY(hipMemcpyAsync(no.p, f->row_ok.p, (size_t)f->n_rows, hipMemcpyDeviceToDevice, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(nh.p, f->Xh.p, (size_t)f->n_rows * f->dimp * 2, hipMemcpyDeviceToDevice, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(nn.p, f->xnorm.p, (size_t)f->n_rows * 4, hipMemcpyDeviceToDevice, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(nt.p, f->tile_nmax.p, (size_t)((f->n_rows + VEC_ROWS - 1) / VEC_ROWS) * 4, hipMemcpyDeviceToDevice, s));
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
     }
-    f->X.release(); f->labels.release(); f->row_ok.release();
-    f->X = nx; f->labels = nl; f->row_ok = no;
+    f->X.release(); f->labels.release(); f->row_ok.release(); f->Xh.release(); f->xnorm.release(); f->tile_nmax.release();
+    f->X = nx; f->labels = nl; f->row_ok = no; f->Xh = nh; f->xnorm = nn; f->tile_nmax = nt;
     f->cap_rows = want;
     return TSGPU_OK;
 }
@@ -146,8 +153,9 @@ static int knn_group(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, uint32_t n
         VecScanArgs a = base;
         a.n_ord = n_tiles; a.tile_stride = 1; a.tau = f->d_tau.as<uint64_t>();
         a.cand = f->d_cand.as<uint64_t>(); a.cand_cnt = f->d_cand_cnt.as<uint32_t>(); a.cand_cap = (uint32_t)cap;
+        if (record_events && round == 0) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[6], s));
         launch_scan(a, 512);
-        if (record_events && round == 0) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s));
+        if (record_events && round == 0) { TSGPU_HIP_TRY(hipEventRecord(ctx->ev[7], s)); TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s)); ctx->scan_events_valid = true; }
         hipLaunchKernelGGL(vec_select_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint64_t*)a.cand, (size_t)cap, (const uint32_t*)a.cand_cnt, (uint32_t)cap, k, 0,
                            f->labels.as<uint64_t>(), dist_dev, label_dev, cnt_dev, f->d_tau.as<uint64_t>(), d_over);
         TSGPU_HIP_TRY(hipGetLastError());
@@ -161,16 +169,170 @@ static int knn_group(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, uint32_t n
     return TSGPU_OK;
 }
 
+
+// safety inflation of the stored row norms (fp32 sum-of-squares error << 2^-10)
+static const float VEC_NORM_INFLATE = 1.0f + 1.0f / 1024.0f;
+// error-radius constant of the bf16 bracket (vec_kernels.hip.h): (2u + u^2) with u = 2^-8, + dim * 2^-21 for the two fp32
+// accumulations, + 1 %
+static float vec_bracket_c(uint32_t dim) { return ((1.0f / 128.0f + 1.0f / 16384.0f) + (float)dim * (1.0f / 2097152.0f)) * 1.01f; }
+
+// (re)build the bf16 mirror + norms of rows [row0, row0 + n) and the tile maxima they touch; rows must already be
+// final in X (normalised for cosine fields). Called with ctx->mu held; enqueues on the stream.
+static int vec_refresh_mirror(VecField* f, uint32_t row0, uint32_t n, uint64_t n_rows_after, hipStream_t s) {
+    if (n == 0) return TSGPU_OK;
+    hipLaunchKernelGGL(vec_to_bf16_kernel, dim3((n + 3) / 4), dim3(256), 0, s, f->X.as<float>(), f->Xh.as<uint16_t>(), f->xnorm.as<float>(), row0, n, f->dim,
+                       f->dimp, VEC_NORM_INFLATE);
+    const uint32_t t0 = row0 / VEC_ROWS, t1 = (row0 + n - 1) / VEC_ROWS;
+    hipLaunchKernelGGL(vec_tile_nmax_kernel, dim3((t1 - t0 + 1 + 63) / 64), dim3(64), 0, s, f->xnorm.as<float>(), f->tile_nmax.as<float>(), t0, t1 - t0 + 1,
+                       (uint32_t)n_rows_after);
+    TSGPU_HIP_TRY(hipGetLastError());
+    return TSGPU_OK;
+}
+
+// the bf16-prefilter k-NN launch sequence (vec_kernels.hip.h, "bf16 PREFILTER path"); caller holds ctx->mu.
+static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, uint32_t n_q, uint32_t k, const uint8_t* mask_dev,
+                               float* dist_dev, uint64_t* label_dev, uint32_t* cnt_dev, bool record_events) {
+    hipStream_t s = ctx->stream;
+    const uint32_t n_rows = (uint32_t)f->n_rows;
+    const uint32_t n_tiles = (n_rows + VEC_ROWS - 1) / VEC_ROWS;
+    const bool wide = n_q > 64;
+    const uint32_t QT = wide ? 128 : 64;
+    const uint32_t n_qtiles = (n_q + QT - 1) / QT;
+    const uint32_t sample_tiles = std::max<uint32_t>(1, ctx->vec_sample_tiles);
+    int rc;
+    if ((rc = f->d_Qh.reserve((size_t)n_q * f->dimp * 2))) return rc;
+    if ((rc = f->d_cq.reserve((size_t)n_q * 4))) return rc;
+    if ((rc = f->d_L1.reserve((size_t)n_q * 4))) return rc;
+    if ((rc = f->d_cand_cnt.reserve((size_t)n_q * 4 + 16))) return rc;
+    if ((rc = f->d_surv_cnt.reserve((size_t)n_q * 4))) return rc;
+    if ((rc = f->d_tau.reserve((size_t)n_q * 8))) return rc;
+    uint32_t* d_over = f->d_cand_cnt.as<uint32_t>() + n_q;
+
+    auto launch_scan = [&](VecHScanArgs& a, uint32_t target_wgs) {
+        uint32_t n_slabs = std::max<uint32_t>(8, (std::max<uint32_t>(1, target_wgs / n_qtiles) + 7) / 8 * 8);
+        uint32_t per = (a.n_ord + n_slabs - 1) / n_slabs;
+        if (ctx->vec_rows_per_slab) per = std::max<uint32_t>(1, ctx->vec_rows_per_slab / VEC_ROWS);
+        per = std::max<uint32_t>(per, 1);
+        n_slabs = (a.n_ord + per - 1) / per;
+        n_slabs = std::max<uint32_t>(8, (n_slabs + 7) / 8 * 8);
+        a.ord_per_slab = per; a.n_slabs = n_slabs; a.n_qtiles = n_qtiles;
+        const dim3 grid(n_slabs * n_qtiles), block(VEC_THREADS);
+        if (wide) hipLaunchKernelGGL((vec_hscan_kernel<2>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((vec_hscan_kernel<1>), grid, block, 0, s, a);
+    };
+    if (record_events) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[3], s));
+    // queries -> bf16 + cq = c * ||q||
+    hipLaunchKernelGGL(vec_to_bf16_kernel, dim3((n_q + 3) / 4), dim3(256), 0, s, Q_dev, f->d_Qh.as<uint16_t>(), f->d_cq.as<float>(), 0u, n_q, f->dim, f->dimp,
+                       vec_bracket_c(f->dim) * VEC_NORM_INFLATE);
+    VecHScanArgs base;
+    memset(&base, 0, sizeof base);
+    base.Xh = f->Xh.as<uint16_t>(); base.row_ok = mask_dev; base.Qh = f->d_Qh.as<uint16_t>(); base.tile_nmax = f->tile_nmax.as<float>();
+    base.cq = f->d_cq.as<float>(); base.n_rows = n_rows; base.dimp = f->dimp; base.n_q = n_q; base.L1 = f->d_L1.as<float>();
+    const uint32_t splits = 4;
+
+    auto finish = [&](uint64_t* ent, size_t stride, const uint32_t* cnt, uint32_t cap) -> int {
+        // refine (L2 + survivors) -> exact re-score -> final selection
+        hipLaunchKernelGGL(vec_refine_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint64_t*)ent, stride, cnt, cap, k, (const float*)f->d_cq.as<float>(),
+                           (const float*)f->xnorm.as<float>(), f->d_L1.as<float>(), f->d_surv.as<uint32_t>(), f->d_surv_cnt.as<uint32_t>(), d_over);
+        return TSGPU_OK;
+    };
+    auto rescore_select = [&](uint64_t* ent, size_t stride, uint32_t cap) {
+        hipLaunchKernelGGL(vec_rescore_kernel, dim3(n_q, splits), dim3(VEC_THREADS), 0, s, (const float*)f->X.as<float>(), Q_dev, f->dim,
+                           (const uint32_t*)f->d_surv.as<uint32_t>(), (const uint32_t*)f->d_surv_cnt.as<uint32_t>(), stride, ent);
+        hipLaunchKernelGGL(vec_select_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint64_t*)ent, stride, (const uint32_t*)f->d_surv_cnt.as<uint32_t>(), cap, k, 0,
+                           f->labels.as<uint64_t>(), dist_dev, label_dev, cnt_dev, f->d_tau.as<uint64_t>(), d_over);
+    };
+
+    if (n_tiles <= sample_tiles) {
+        // small index: every row becomes an entry (dense), then refine / re-score / select
+        const uint32_t stride = n_tiles * VEC_ROWS;
+        if ((rc = f->d_cand.reserve((size_t)n_q * stride * 8))) return rc;
+        if ((rc = f->d_surv.reserve((size_t)n_q * stride * 4))) return rc;
+        TSGPU_HIP_TRY(hipMemsetAsync(d_over, 0, 4, s));
+        VecHScanArgs a = base;
+        a.n_ord = n_tiles; a.tile_stride = 1; a.mode = 2; a.cand = f->d_cand.as<uint64_t>(); a.dense_stride = stride;
+        launch_scan(a, 512);
+        if (record_events) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s));
+        finish(a.cand, stride, nullptr, stride);
+        rescore_select(a.cand, stride, stride);
+        ctx->vec_prefilter_groups++;
+        if (record_events) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[5], s));
+        TSGPU_HIP_TRY(hipGetLastError());
+        return TSGPU_OK;
+    }
+    // pass 1: strided sample -> L1[q] = k-th largest lower bound of the sample
+    const uint32_t tile_stride = n_tiles / sample_tiles;
+    const uint32_t n_sample = (n_tiles + tile_stride - 1) / tile_stride;
+    {
+        const uint32_t stride = n_sample * VEC_ROWS;
+        if ((rc = f->d_lbkey.reserve((size_t)n_q * stride * 4))) return rc;
+        VecHScanArgs a = base;
+        a.n_ord = n_sample; a.tile_stride = tile_stride; a.mode = 1; a.lbkey = f->d_lbkey.as<uint32_t>(); a.dense_stride = stride;
+        launch_scan(a, 512);
+        hipLaunchKernelGGL(vec_thresh_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint32_t*)a.lbkey, (size_t)stride, stride, k, f->d_L1.as<float>());
+    }
+    // pass 2: every row, kept iff its upper bound reaches L1
+    uint64_t cap = ctx->vec_cand_cap;
+    if (!cap) {
+        cap = 6ull * k * ((n_tiles + n_sample - 1) / n_sample) + 1024;
+        uint64_t p2 = 1024; while (p2 < cap) p2 <<= 1; cap = p2;
+        while (cap > 4096 && cap * n_q * 8 > (1ull << 30)) cap >>= 1;
+    }
+    cap = std::max<uint64_t>(cap, 2ull * k);
+    if ((rc = f->d_cand.reserve((size_t)n_q * cap * 8))) return rc;
+    if ((rc = f->d_surv.reserve((size_t)n_q * cap * 4))) return rc;
+    uint32_t h_over[2] = {0, 0};
+    for (int round = 0; round < 8; round++) {
+        TSGPU_HIP_TRY(hipMemsetAsync(f->d_cand_cnt.p, 0, (size_t)n_q * 4 + 8, s));
+        VecHScanArgs a = base;
+        a.n_ord = n_tiles; a.tile_stride = 1; a.mode = 0;
+        a.cand = f->d_cand.as<uint64_t>(); a.cand_cnt = f->d_cand_cnt.as<uint32_t>(); a.cand_cap = (uint32_t)cap;
+        if (record_events && round == 0) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[6], s));
+        launch_scan(a, 512);
+        if (record_events && round == 0) { TSGPU_HIP_TRY(hipEventRecord(ctx->ev[7], s)); TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s)); ctx->scan_events_valid = true; }
+        finish(a.cand, (size_t)cap, a.cand_cnt, (uint32_t)cap);
+        TSGPU_HIP_TRY(hipGetLastError());
+        TSGPU_HIP_TRY(hipMemcpyAsync(h_over, d_over, 8, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        if (!h_over[0] || h_over[1]) break;  // an overflowing list raised its own L1: scan again (unless it is stuck on ties)
+        ctx->vec_overflow_rounds++;
+    }
+    if (h_over[0]) {
+        // brackets cannot separate this data (mass ties / more near-duplicates than the candidate arena): the fp32 scan's
+        // (distance, row) keys converge on any input — run the group there
+        ctx->vec_prefilter_fallbacks++;
+        return knn_group(ctx, f, Q_dev, n_q, k, mask_dev, dist_dev, label_dev, cnt_dev, record_events);
+    }
+    rescore_select(f->d_cand.as<uint64_t>(), (size_t)cap, (uint32_t)cap);
+    TSGPU_HIP_TRY(hipGetLastError());
+    ctx->vec_prefilter_groups++;
+    if (ctx->vec_count_rescored) {        // introspection (tests / bench): how many rows reached the exact re-score
+        std::vector<uint32_t> sc(n_q);
+        TSGPU_HIP_TRY(hipMemcpyAsync(sc.data(), f->d_surv_cnt.p, (size_t)n_q * 4, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        ctx->vec_rescored_rows = 0;
+        for (uint32_t i = 0; i < n_q; i++) ctx->vec_rescored_rows += sc[i];
+    }
+    if (record_events) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[5], s));
+    return TSGPU_OK;
+}
+
 static int knn_device(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, uint32_t n_q, uint32_t k, const uint8_t* mask_dev,
                       float* dist_dev, uint64_t* label_dev, uint32_t* cnt_dev) {
     // query groups bound the scratch (dense sample + candidate arena); each group streams X once
     const uint32_t GROUP = 512;
+    ctx->scan_events_valid = false;
     for (uint32_t q0 = 0; q0 < n_q; q0 += GROUP) {
         const uint32_t nq = std::min<uint32_t>(GROUP, n_q - q0);
-        int rc = knn_group(ctx, f, Q_dev + (size_t)q0 * f->dim, nq, k, mask_dev, dist_dev + (size_t)q0 * k, label_dev + (size_t)q0 * k, cnt_dev + q0, q0 == 0);
+        int rc = ctx->vec_prefilter
+            ? knn_group_prefilter(ctx, f, Q_dev + (size_t)q0 * f->dim, nq, k, mask_dev, dist_dev + (size_t)q0 * k, label_dev + (size_t)q0 * k, cnt_dev + q0, q0 == 0)
+            : knn_group(ctx, f, Q_dev + (size_t)q0 * f->dim, nq, k, mask_dev, dist_dev + (size_t)q0 * k, label_dev + (size_t)q0 * k, cnt_dev + q0, q0 == 0);
         if (rc) return rc;
     }
     ctx->timings.vec_flops = 2ull * f->n_rows * f->dim * std::min<uint32_t>(n_q, GROUP);   // the HIP events bracket the first query group
+    // bytes one main-scan launch must stream: the row matrix once (bf16 mirror, or fp32 rows on the fp32 scan) + the queries
+    ctx->timings.vec_scan_bytes = ctx->vec_prefilter ? (uint64_t)f->n_rows * f->dimp * 2 + (uint64_t)std::min<uint32_t>(n_q, GROUP) * f->dimp * 2
+                                                     : (uint64_t)f->n_rows * f->dim * 4 + (uint64_t)std::min<uint32_t>(n_q, GROUP) * f->dim * 4;
     return TSGPU_OK;
 }
 
@@ -181,6 +343,9 @@ static void knn_collect_timings(tsgpu_ctx* ctx) {
     ctx->timings.vec_knn_ms = a;
     ctx->timings.vec_merge_ms = b;
     ctx->timings.total_ms = a + b;
+    float c = 0;
+    if (ctx->scan_events_valid) (void)hipEventElapsedTime(&c, ctx->ev[6], ctx->ev[7]);
+    ctx->timings.vec_scan_ms = c;
 }
 
 // row mask for deleted rows / allow list / excluded ids; returns nullptr (all rows ok) when nothing restricts
@@ -272,7 +437,7 @@ void tsgpu_vec_destroy_all(tsgpu_ctx* ctx) {
 
 uint64_t tsgpu_vec_device_bytes(tsgpu_ctx* ctx) {
     uint64_t b = 0;
-    for (auto& kv : ctx->vec_fields) b += kv.second->X.cap + kv.second->labels.cap + kv.second->row_ok.cap;
+    for (auto& kv : ctx->vec_fields) b += kv.second->X.cap + kv.second->labels.cap + kv.second->row_ok.cap + kv.second->Xh.cap + kv.second->xnorm.cap + kv.second->tile_nmax.cap;
     return b;
 }
 
@@ -286,6 +451,7 @@ int tsgpu_vec_create(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t dim, int me
     VecField* f = new (std::nothrow) VecField;
     if (!f) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_create: host allocation failed");
     f->dim = dim;
+    f->dimp = (dim + 63) / 64 * 64;
     f->metric = metric;
     int rc = vec_reserve_rows(f, std::max<uint64_t>(capacity_hint, 16), ctx->stream);   // include/index.h:367: init capacity 16
     if (rc) { f->release(); delete f; return rc; }
@@ -329,6 +495,7 @@ int tsgpu_vec_upsert(tsgpu_ctx* ctx, uint32_t vec_field_id, const uint64_t* labe
                 hipLaunchKernelGGL(vec_normalize_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, s, dst, n, f->dim);
             TSGPU_HIP_TRY(hipMemcpyAsync(f->labels.as<uint64_t>() + f->n_rows, hl.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
             TSGPU_HIP_TRY(hipMemsetAsync(f->row_ok.as<uint8_t>() + f->n_rows, 1, n, s));
+            if ((rc = vec_refresh_mirror(f, (uint32_t)f->n_rows, n, f->n_rows + n, s))) return rc;
             TSGPU_HIP_TRY(hipStreamSynchronize(s));
             if (!f->identity) for (uint32_t i = 0; i < n; i++) f->row_of.emplace(hl[i], (uint32_t)(f->n_rows + i));
             f->h_labels.insert(f->h_labels.end(), hl.begin(), hl.end());
@@ -355,6 +522,7 @@ int tsgpu_vec_upsert(tsgpu_ctx* ctx, uint32_t vec_field_id, const uint64_t* labe
                 if (f->metric == TSGPU_METRIC_COSINE)
                     hipLaunchKernelGGL(vec_normalize_rows_kernel, dim3(1), dim3(64), 0, s, dst, 1u, f->dim);
                 TSGPU_HIP_TRY(hipMemsetAsync(f->row_ok.as<uint8_t>() + row, 1, 1, s));
+                { int rc2 = vec_refresh_mirror(f, row, 1, f->n_rows, s); if (rc2) return rc2; }
                 TSGPU_HIP_TRY(hipStreamSynchronize(s));
             }
         }

@@ -421,4 +421,425 @@ __global__ __launch_bounds__(256) void vec_row_distances_kernel(const float* __r
     if (live && lane == 0) out[i] = row == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : 1.0f - s;
 }
 
+
+// ================================================================================================
+// bf16 PREFILTER path (default for the batched k-NN). Same exact results as the fp32 scan above, ~16x less matrix
+// time: the full N x B sweep runs on v_mfma_f32_32x32x16_bf16 over a bf16 copy of X (half the HBM bytes of the fp32
+// rows), but only to BRACKET every score — never to rank it:
+//     |s~ - s^| <= e(q,r) = c * ||q|| * ||x_r||        s~ = bf16 MFMA score, s^ = the fp32 score the reference computes
+// with c = 2^-7 + 2^-14 (round-to-nearest bf16 of both operands: (2u + u^2), u = 2^-8, times Cauchy-Schwarz) + dim*2^-21
+// (fp32 accumulation of either sum), inflated by 1 %. Let L = the k-th largest LOWER bound s~ - e over any subset of
+// the rows: at least k rows score >= L, so a row with UPPER bound s~ + e < L is not among the k nearest. Rows that
+// survive that test twice (L1 from a strided sample, then L2 from the survivors themselves; ~1.1-3 k rows per query
+// remain) are re-scored EXACTLY in fp32 with the reference's own summation order (hnswlib InnerProductSpace: 16
+// accumulator lanes, multiply and add rounded separately, sequential horizontal add — bit-identical distances), and
+// the final k are selected from those exact keys. Exactness therefore never depends on bf16 rounding, on the MFMA's
+// internal accumulation order, or on the data distribution (overflowing candidate lists tighten L1 and re-scan).
+// Non-finite scores / norms get lb = -inf, ub = +inf: always re-scored, never used as a bound.
+typedef __bf16 vec_bf16x8 __attribute__((ext_vector_type(8)));
+static const int VEC_HKC = 64;                  // bf16 K chunk per LDS step = 128 bytes per row, same LDS geometry as the fp32 scan
+static const uint64_t VEC_ENT_INVALID = 0xFFFFFFFFFFFFFFFFull;
+
+// descending-order key of a float: larger value -> smaller key; NaN never produced by callers
+__device__ inline uint32_t f32_desc_key(float f) { return ~f32_ord(f); }
+__device__ inline float desc_key_f32(uint32_t k) { return ord_f32(~k); }
+__device__ inline bool f32_finite(float f) { return (__float_as_uint(f) & 0x7F800000u) != 0x7F800000u; }
+
+// fp32 -> bf16, round to nearest even; finite values that would round to infinity saturate to the largest finite
+// bf16 (relative error still <= 2^-8), NaN stays NaN, +-inf stays +-inf
+__device__ inline uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    const uint32_t a = u & 0x7FFFFFFFu;
+    if (a > 0x7F800000u) return (u >> 16) | 0x0040u;
+    if (a == 0x7F800000u) return u >> 16;
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    uint32_t h = u >> 16;
+    if ((h & 0x7FFFu) >= 0x7F80u) h = (h & 0x8000u) | 0x7F7Fu;
+    return h;
+}
+
+// one wave per row: bf16 copy (zero padded to dimp, a multiple of 64) + norm_out[row] = scale * ||x||_2 (fp32 sum of
+// squares, `scale` carries the safety inflation / the query-side constant c)
+__global__ __launch_bounds__(256) void vec_to_bf16_kernel(const float* __restrict__ X, uint16_t* __restrict__ Xh, float* __restrict__ norm_out,
+                                                           uint32_t row0, uint32_t n_rows, uint32_t dim, uint32_t dimp, float scale) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n_rows) return;                       // whole wave exits together
+    const uint32_t r = row0 + i;
+    const float* __restrict__ x = X + (size_t)r * dim;
+    uint32_t* __restrict__ o = (uint32_t*)(Xh + (size_t)r * dimp);
+    float ss = 0.0f;
+    for (uint32_t k = 2 * lane; k < dimp; k += 128) {
+        const float a = k < dim ? x[k] : 0.0f, b = k + 1 < dim ? x[k + 1] : 0.0f;
+        ss = fmaf(a, a, ss);
+        ss = fmaf(b, b, ss);
+        o[k >> 1] = f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if (lane == 0) norm_out[r] = sqrtf(ss) * scale;
+}
+
+// per 128-row tile: max of the row norms (+inf if any is NaN / inf) — the scan epilogue's cheap bound
+__global__ void vec_tile_nmax_kernel(const float* __restrict__ xnorm, float* __restrict__ tile_nmax, uint32_t tile0, uint32_t n_tiles, uint32_t n_rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tiles) return;
+    const uint32_t tile = tile0 + i;
+    float m = 0.0f;
+    for (uint32_t r = tile * VEC_ROWS; r < (tile + 1) * VEC_ROWS && r < n_rows; r++) {
+        const float v = xnorm[r];
+        if (!f32_finite(v)) m = __uint_as_float(0x7F800000u);
+        else if (v > m) m = v;
+    }
+    tile_nmax[tile] = m;
+}
+
+struct VecHScanArgs {
+    const uint16_t* Xh;        // [n_rows][dimp] bf16
+    const uint8_t* row_ok;     // nullable
+    const uint16_t* Qh;        // [n_q][dimp] bf16
+    const float* tile_nmax;    // [n_tiles]
+    const float* cq;           // [n_q] c * ||q||
+    uint32_t n_rows, dimp, n_q;
+    uint32_t n_ord, tile_stride, ord_per_slab, n_slabs, n_qtiles;
+    int mode;                  // 0 = filtered (cand lists), 1 = sample (lower-bound keys, dense), 2 = every row (entries, dense)
+    const float* L1;           // mode 0: [n_q] thresholds
+    uint64_t* cand;            // mode 0: [n_q][cand_cap] entries (s~ bits << 32 | row); mode 2: [n_q][dense_stride]
+    uint32_t* cand_cnt;        // mode 0
+    uint32_t cand_cap;
+    uint32_t* lbkey;           // mode 1: [n_q][dense_stride] descending keys of the lower bounds (0xFFFFFFFF = no row)
+    uint32_t dense_stride;
+};
+
+template <int QT>
+struct VecHScanSmem {
+    alignas(16) uint32_t xs[2][VEC_ROWS * VEC_LDW];
+    alignas(16) uint32_t qs[2][QT * VEC_LDW];
+};
+
+template <int CB>
+__global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs a) {
+    constexpr int QT = 64 * CB;
+    constexpr int XV = VEC_ROWS * 8 / VEC_THREADS;     // 16-byte pieces per thread per X chunk (4)
+    constexpr int QV = QT * 8 / VEC_THREADS;           // 4 (QT=128) or 2 (QT=64)
+    __shared__ VecHScanSmem<QT> sm;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t wrow = (wave >> 1) * 64, wcol = (wave & 1) * (32 * CB);
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7, j = b >> 3;
+    const uint32_t qtile = j % a.n_qtiles;
+    const uint32_t slab = (j / a.n_qtiles) * 8 + xcd;
+    const uint32_t q0 = qtile * QT;
+    const uint32_t ord_begin = slab * a.ord_per_slab;
+    uint32_t ord_end = ord_begin + a.ord_per_slab;
+    if (ord_end > a.n_ord) ord_end = a.n_ord;
+    if (ord_begin >= ord_end) return;
+    const uint32_t n_chunks = a.dimp / VEC_HKC;
+    const uint32_t total_steps = (ord_end - ord_begin) * n_chunks;
+
+    uint4 xr[XV], qr[QV];
+    // out-of-range rows / queries read a clamped in-range row (scores dropped by the epilogue); no select on loaded data
+    auto load_step = [&](uint32_t s) {
+        const uint32_t o = ord_begin + s / n_chunks, c = s % n_chunks;
+        const uint32_t r0 = o * a.tile_stride * VEC_ROWS;
+#pragma unroll
+        for (int v = 0; v < XV; v++) {
+            const uint32_t idx = t + v * VEC_THREADS;
+            uint32_t row = r0 + (idx >> 3);
+            row = row < a.n_rows ? row : a.n_rows - 1;
+            xr[v] = *(const uint4*)(a.Xh + (size_t)row * a.dimp + c * VEC_HKC + (idx & 7) * 8);
+        }
+#pragma unroll
+        for (int v = 0; v < QV; v++) {
+            const uint32_t idx = t + v * VEC_THREADS;
+            uint32_t gq = q0 + (idx >> 3);
+            gq = gq < a.n_q ? gq : a.n_q - 1;
+            qr[v] = *(const uint4*)(a.Qh + (size_t)gq * a.dimp + c * VEC_HKC + (idx & 7) * 8);
+        }
+    };
+    auto store_step = [&](uint32_t buf) {
+#pragma unroll
+        for (int v = 0; v < XV; v++) {
+            const uint32_t idx = t + v * VEC_THREADS;
+            *(uint4*)&sm.xs[buf][(idx >> 3) * VEC_LDW + (idx & 7) * 4] = xr[v];
+        }
+#pragma unroll
+        for (int v = 0; v < QV; v++) {
+            const uint32_t idx = t + v * VEC_THREADS;
+            *(uint4*)&sm.qs[buf][(idx >> 3) * VEC_LDW + (idx & 7) * 4] = qr[v];
+        }
+    };
+
+    // per-lane query constants: this lane's query column in each of its CB blocks
+    float L1v[CB], cqv[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++) {
+        const uint32_t gq = q0 + wcol + cb * 32 + (lane & 31);
+        const uint32_t gc = gq < a.n_q ? gq : a.n_q - 1;
+        cqv[cb] = a.cq[gc];
+        L1v[cb] = (a.mode == 0) ? a.L1[gc] : __uint_as_float(0xFF800000u);
+    }
+
+    vec_f32x16 acc[2][CB];
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (uint32_t s = 0; s < total_steps; s++) {
+        const uint32_t c = s % n_chunks, buf = s & 1;
+        if (c == 0) {
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[rb][cb][e] = 0.0f;
+        }
+        if (s + 1 < total_steps) load_step(s + 1);           // in flight while the MFMAs run
+        // lane (r = lane&31, h = lane>>5) supplies k = 16*g + 8*h .. +7 of row r: one ds_read_b128 = one MFMA operand
+        const uint32_t* xa = &sm.xs[buf][(wrow + (lane & 31)) * VEC_LDW + 4 * (lane >> 5)];
+        const uint32_t* qb = &sm.qs[buf][(wcol + (lane & 31)) * VEC_LDW + 4 * (lane >> 5)];
+        uint4 av[2][2], bv[2][CB];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) av[0][rb] = *(const uint4*)(xa + rb * 32 * VEC_LDW);
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) bv[0][cb] = *(const uint4*)(qb + cb * 32 * VEC_LDW);
+#pragma unroll
+        for (int g = 0; g < VEC_HKC / 16; g++) {
+            const int cur = g & 1, nx = cur ^ 1;
+            if (g + 1 < VEC_HKC / 16) {
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) av[nx][rb] = *(const uint4*)(xa + rb * 32 * VEC_LDW + 8 * (g + 1));
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) bv[nx][cb] = *(const uint4*)(qb + cb * 32 * VEC_LDW + 8 * (g + 1));
+            }
+            if (g == VEC_HKC / 16 - 1 && s + 1 < total_steps) store_step(buf ^ 1);   // next chunk -> other ring slot, under the last MFMA group
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vec_bf16x8, av[cur][rb]), __builtin_bit_cast(vec_bf16x8, bv[cur][cb]),
+                                                                          acc[rb][cb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c == n_chunks - 1) {
+            const uint32_t o = ord_begin + s / n_chunks;
+            const uint32_t tile = o * a.tile_stride;
+            const uint32_t r0 = tile * VEC_ROWS;
+            const float nmax = a.tile_nmax[tile];
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) {
+                const uint32_t gq = q0 + wcol + cb * 32 + (lane & 31);
+                const float e = cqv[cb] * nmax + 1e-30f;             // >= every row's error radius in this tile
+                if (a.mode == 0) {
+                    float amax = acc[0][cb][0];
+                    bool odd = false;                                  // any non-finite score: never reject on the max
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                        for (int el = 0; el < 16; el++) { amax = fmaxf(amax, acc[rb][cb][el]); odd = odd || !f32_finite(acc[rb][cb][el]); }
+                    if (gq < a.n_q && (odd || !(amax + e < L1v[cb]))) {
+#pragma unroll
+                        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                            for (int el = 0; el < 16; el++) {
+                                const uint32_t row = r0 + wrow + rb * 32 + (el & 3) + 8 * (el >> 2) + 4 * (lane >> 5);
+                                const float sc = acc[rb][cb][el];
+                                if (!(sc + e < L1v[cb]) && row < a.n_rows && (!a.row_ok || a.row_ok[row] != 0)) {
+                                    const uint32_t slot = atomicAdd(&a.cand_cnt[gq], 1u);
+                                    if (slot < a.cand_cap) a.cand[(size_t)gq * a.cand_cap + slot] = ((uint64_t)__float_as_uint(sc) << 32) | row;
+                                }
+                            }
+                    }
+                } else if (gq < a.n_q) {
+#pragma unroll
+                    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                        for (int el = 0; el < 16; el++) {
+                            const uint32_t lr = wrow + rb * 32 + (el & 3) + 8 * (el >> 2) + 4 * (lane >> 5);
+                            const uint32_t row = r0 + lr;
+                            bool okr = row < a.n_rows;
+                            if (okr && a.row_ok) okr = a.row_ok[row] != 0;
+                            const float sc = acc[rb][cb][el];
+                            const size_t at = (size_t)gq * a.dense_stride + (size_t)(o * VEC_ROWS + lr);
+                            if (a.mode == 1) {
+                                const float lb = sc - e;
+                                a.lbkey[at] = (okr && f32_finite(lb)) ? f32_desc_key(lb) : 0xFFFFFFFFu;
+                            } else {
+                                a.cand[at] = okr ? (((uint64_t)__float_as_uint(sc) << 32) | row) : VEC_ENT_INVALID;
+                            }
+                        }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// block-wide exact k-th smallest of n 32-bit keys produced by key(i) (re-evaluated every radix pass): 4 passes of
+// 8 bits, LDS histogram. Every thread of the 256-thread block must call it. Returns the key (all threads).
+template <class KeyFn>
+__device__ inline uint32_t block_kth_smallest_u32(uint32_t n, uint32_t k, KeyFn key, uint32_t* hist /*[256]*/, uint32_t* s_state /*[2]*/) {
+    const uint32_t t = threadIdx.x;
+    uint32_t prefix = 0, pmask = 0, krem = k;
+    for (int p = 3; p >= 0; p--) {
+        hist[t] = 0;
+        __syncthreads();
+        const int shift = 8 * p;
+        for (uint32_t i = t; i < n; i += VEC_THREADS) {
+            const uint32_t kv = key(i);
+            if ((kv & pmask) == prefix) atomicAdd(&hist[(kv >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (t == 0) {
+            uint32_t cum = 0, d = 0;
+            for (; d < 255; d++) { if (cum + hist[d] >= krem) break; cum += hist[d]; }
+            s_state[0] = krem - cum;
+            s_state[1] = prefix | (d << shift);
+        }
+        __syncthreads();
+        krem = s_state[0];
+        prefix = s_state[1];
+        pmask |= 0xFFu << shift;
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// sample pass -> L1[q] = k-th largest lower bound of the sample (-inf when the sample holds fewer than k rows)
+__global__ __launch_bounds__(VEC_THREADS) void vec_thresh_kernel(const uint32_t* __restrict__ lbkey, size_t stride, uint32_t n, uint32_t k, float* __restrict__ L1) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_state[2], s_valid;
+    const uint32_t t = threadIdx.x, q = blockIdx.x;
+    const uint32_t* __restrict__ keys = lbkey + (size_t)q * stride;
+    if (t == 0) s_valid = 0;
+    __syncthreads();
+    uint32_t valid = 0;
+    for (uint32_t i = t; i < n; i += VEC_THREADS) valid += keys[i] != 0xFFFFFFFFu;
+    if (valid) atomicAdd(&s_valid, valid);
+    __syncthreads();
+    const bool enough = s_valid >= k;
+    __syncthreads();
+    const uint32_t kk = block_kth_smallest_u32(n, k, [&](uint32_t i) { return keys[i]; }, hist, s_state);
+    if (t == 0) L1[q] = enough ? desc_key_f32(kk) : __uint_as_float(0xFF800000u);
+}
+
+// one workgroup per query: L2 = k-th largest lower bound among the candidate entries, survivors (ub >= L2) -> surv rows.
+// Overflowed list (cnt > cap): L1[q] <- L2 of the entries held (a valid, tighter bound) and overflow[0] is raised
+// (overflow[1] too when the bound could not move).
+__global__ __launch_bounds__(VEC_THREADS) void vec_refine_kernel(const uint64_t* __restrict__ ent_base, size_t stride, const uint32_t* __restrict__ cnt,
+                                                                  uint32_t cap, uint32_t k, const float* __restrict__ cq, const float* __restrict__ xnorm,
+                                                                  float* __restrict__ L1, uint32_t* __restrict__ surv_base, uint32_t* __restrict__ surv_cnt,
+                                                                  uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_state[2], s_valid, s_surv;
+    const uint32_t t = threadIdx.x, q = blockIdx.x;
+    const uint64_t* __restrict__ ent = ent_base + (size_t)q * stride;
+    uint32_t* __restrict__ surv = surv_base + (size_t)q * stride;
+    const uint32_t total = cnt ? cnt[q] : cap;
+    const bool over = total > cap;
+    const uint32_t n = over ? cap : total;
+    const float cqq = cq[q];
+    if (t == 0) { s_valid = 0; s_surv = 0; }
+    __syncthreads();
+    // lower / upper bound of entry i; non-finite -> (-inf, +inf)
+    auto bounds = [&](uint64_t ev, float& lb, float& ub) -> bool {
+        const uint32_t row = (uint32_t)ev;
+        if (ev == VEC_ENT_INVALID) return false;
+        const float sc = __uint_as_float((uint32_t)(ev >> 32));
+        const float e = cqq * xnorm[row] + 1e-30f;
+        lb = sc - e; ub = sc + e;
+        if (!f32_finite(sc) || !f32_finite(e) || !f32_finite(lb) || !f32_finite(ub)) { lb = __uint_as_float(0xFF800000u); ub = __uint_as_float(0x7F800000u); }
+        return true;
+    };
+    auto lbkey = [&](uint32_t i) -> uint32_t {
+        float lb, ub;
+        if (!bounds(ent[i], lb, ub)) return 0xFFFFFFFFu;
+        return lb == __uint_as_float(0xFF800000u) ? 0xFFFFFFFEu : f32_desc_key(lb);
+    };
+    uint32_t valid = 0;
+    for (uint32_t i = t; i < n; i += VEC_THREADS) valid += lbkey(i) < 0xFFFFFFFEu;
+    if (valid) atomicAdd(&s_valid, valid);
+    __syncthreads();
+    const bool enough = s_valid >= k;
+    __syncthreads();
+    const uint32_t kk = block_kth_smallest_u32(n, k, lbkey, hist, s_state);
+    const float L2 = enough ? desc_key_f32(kk) : __uint_as_float(0xFF800000u);
+    if (over) {
+        // no progress possible (mass ties: the held entries cannot raise the bound) -> overflow[1]: the host falls back to the
+        // fp32 scan, whose (distance, row) keys converge on any data
+        if (t == 0) { if (L2 > L1[q]) L1[q] = L2; else atomicAdd(overflow + 1, 1u); atomicAdd(overflow, 1u); surv_cnt[q] = 0; }
+        return;
+    }
+    for (uint32_t i = t; i < n; i += VEC_THREADS) {
+        float lb, ub;
+        const uint64_t ev = ent[i];
+        if (bounds(ev, lb, ub) && !(ub < L2)) { const uint32_t slot = atomicAdd(&s_surv, 1u); surv[slot] = (uint32_t)ev; }
+    }
+    __syncthreads();
+    if (t == 0) surv_cnt[q] = s_surv;
+}
+
+// hnswlib InnerProductSpace::get_dist_func arithmetic for one (query, row) pair, evaluated by a 16-lane group
+// (space_ip.h: InnerProductSIMD16Ext / SIMD4Ext / *Residuals): products and sums rounded separately (no FMA),
+// 16 (or 4) running lane sums, sequential horizontal add. sub = lane index inside the group (0..15); every lane of
+// the group returns the distance. qs = the query in LDS, x = the row in global memory.
+__device__ inline float ip_distance_group16(const float* qs, const float* __restrict__ x, uint32_t dim, uint32_t sub) {
+#pragma clang fp contract(off)
+    auto part16 = [&](uint32_t off, uint32_t n16) -> float {      // n16 multiple of 16
+        float accl = 0.0f;
+        for (uint32_t i = 0; i < n16; i += 16) { const float pr = __fmul_rn(qs[off + i + sub], x[off + i + sub]); accl = __fadd_rn(accl, pr); }
+        float sum = 0.0f;
+#pragma unroll
+        for (int l = 0; l < 16; l++) sum = __fadd_rn(sum, __shfl(accl, (int)((threadIdx.x & 48u) + l)));
+        return sum;
+    };
+    auto part4 = [&](uint32_t off, uint32_t n4) -> float {
+        float accl = 0.0f;
+        if (sub < 4) for (uint32_t i = 0; i < n4; i += 4) { const float pr = __fmul_rn(qs[off + i + sub], x[off + i + sub]); accl = __fadd_rn(accl, pr); }
+        const int b0 = (int)(threadIdx.x & 48u);
+        const float l0 = __shfl(accl, b0), l1 = __shfl(accl, b0 + 1), l2 = __shfl(accl, b0 + 2), l3 = __shfl(accl, b0 + 3);
+        return __fadd_rn(__fadd_rn(__fadd_rn(l0, l1), l2), l3);
+    };
+    auto scalar = [&](uint32_t off, uint32_t n) -> float {
+        float r = 0.0f;
+        for (uint32_t i = 0; i < n; i++) r = __fadd_rn(r, __fmul_rn(qs[off + i], x[off + i]));
+        return r;
+    };
+    if (dim % 16 == 0) return __fadd_rn(1.0f, -part16(0, dim));
+    if (dim % 4 == 0) return __fadd_rn(1.0f, -part4(0, dim));
+    if (dim > 16) { const uint32_t qn = dim >> 4 << 4; const float a1 = part16(0, qn); return __fadd_rn(1.0f, -__fadd_rn(a1, scalar(qn, dim - qn))); }
+    if (dim > 4) { const uint32_t qn = dim >> 2 << 2; const float a1 = part4(0, qn); return __fadd_rn(1.0f, -__fadd_rn(a1, scalar(qn, dim - qn))); }
+    return __fadd_rn(1.0f, -scalar(0, dim));
+}
+
+// exact re-scoring of the survivors: grid (n_q, splits); 16 lanes per (query, row) pair; key = ord(dist) << 32 | row
+static const uint32_t VEC_RESCORE_LDS_DIM = 4096;     // queries up to this dim are staged in LDS; longer ones are read from L1/L2
+__global__ __launch_bounds__(VEC_THREADS) void vec_rescore_kernel(const float* __restrict__ X, const float* __restrict__ Q, uint32_t dim,
+                                                                   const uint32_t* __restrict__ surv_base, const uint32_t* __restrict__ surv_cnt, size_t stride,
+                                                                   uint64_t* __restrict__ keys_base) {
+    __shared__ float qs_lds[VEC_RESCORE_LDS_DIM];
+    const uint32_t t = threadIdx.x, q = blockIdx.x;
+    const uint32_t n = surv_cnt[q];
+    const uint32_t per = gridDim.y * 16;
+    if (blockIdx.y * 16 >= n) return;
+    const float* qs = Q + (size_t)q * dim;
+    if (dim <= VEC_RESCORE_LDS_DIM) {
+        for (uint32_t i = t; i < dim; i += VEC_THREADS) qs_lds[i] = qs[i];
+        __syncthreads();
+        qs = qs_lds;
+    }
+    const uint32_t* __restrict__ surv = surv_base + (size_t)q * stride;
+    uint64_t* __restrict__ keys = keys_base + (size_t)q * stride;
+    const uint32_t sub = t & 15, grp = t >> 4;
+    // every thread of the block runs the same number of trips (i0 is block-uniform); shuffles stay inside a 16-lane group
+    for (uint32_t i0 = blockIdx.y * 16; i0 < n; i0 += per) {
+        const uint32_t i = i0 + grp;
+        const uint32_t ic = i < n ? i : n - 1;         // idle groups recompute the last pair (keeps the wave's shuffles uniform)
+        const uint32_t row = surv[ic];
+        const float d = ip_distance_group16(qs, X + (size_t)row * dim, dim, sub);
+        if (i < n && sub == 0) keys[i] = ((uint64_t)f32_ord(d) << 32) | row;
+    }
+}
+
 }  // namespace tsgpu

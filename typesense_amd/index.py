@@ -170,6 +170,11 @@ class GpuIndex:
     def set_option(self, name, value):
         self._ck(self.L.tsgpu_set_option(self.h, name.encode(), int(value)))
 
+    def counter(self, name):
+        v = C.c_uint64(0)
+        self._ck(self.L.tsgpu_get_counter(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def set_stream(self, stream_ptr):
         self._ck(self.L.tsgpu_set_stream(self.h, C.c_void_p(stream_ptr)))
 
