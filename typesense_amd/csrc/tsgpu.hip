@@ -340,7 +340,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
         return ok();
     }
     if (!strcmp(name, "vec_sample_tiles")) {
-        if (value < 1 || value > (1 << 20)) return fail(TSGPU_ERR_INVALID, "vec_sample_tiles out of range");
+        if (value < 0 || value > (1 << 20)) return fail(TSGPU_ERR_INVALID, "vec_sample_tiles out of range");
         ctx->vec_sample_tiles = (uint32_t)value;
         return ok();
     }

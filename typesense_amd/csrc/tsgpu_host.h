@@ -104,7 +104,7 @@ struct tsgpu_ctx {
     uint32_t kw_chunk_blocks = 0;                    // driver blocks per work item (0 = sized per batch, see plan_batch)
     uint32_t last_chunk_blocks = 64;
     uint32_t vec_rows_per_slab = 0;                  // 0 = automatic
-    uint32_t vec_sample_tiles = 512;                 // 128-row tiles of the threshold sample (pass 1 of the k-NN)
+    uint32_t vec_sample_tiles = 0;   // 0 = automatic (8192 tiles on the bf16 prefilter path, 512 on the fp32 scan);                // 128-row tiles of the threshold sample (pass 1 of the k-NN)
     uint32_t vec_cand_cap = 0;                       // candidate slots per query in pass 2 (0 = automatic)
     uint32_t vec_prefilter = 1;                      // 1 = bf16 bracket scan + exact fp32 re-score (default); 0 = fp32 MFMA scan
     uint64_t vec_prefilter_groups = 0;               // query groups answered by the bf16 bracket path

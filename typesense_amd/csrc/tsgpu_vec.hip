@@ -55,12 +55,12 @@ static int vec_reserve_rows(VecField* f, uint64_t rows, hipStream_t s) {
     int rc;
     auto drop = [&]() { nx.release(); nl.release(); no.release(); nh.release(); nn.release(); nt.release(); };
     if ((rc = nx.reserve((size_t)want * f->dim * 4)) || (rc = nl.reserve((size_t)want * 8)) || (rc = no.reserve((size_t)want)) ||
-        (rc = nh.reserve((size_t)want * f->dimp * 2)) || (rc = nn.reserve((size_t)want * 4)) || (rc = nt.reserve((size_t)(want / VEC_ROWS + 2) * 4))) { drop(); return rc; }
+        (rc = nh.reserve((size_t)((want + VEC_ROWS - 1) / VEC_ROWS) * VEC_ROWS * f->dimp * 2)) || (rc = nn.reserve((size_t)want * 4)) || (rc = nt.reserve((size_t)(want / VEC_ROWS + 2) * 4))) { drop(); return rc; }
     if (f->n_rows) {
         TSGPU_HIP_TRY(hipMemcpyAsync(nx.p, f->X.p, (size_t)f->n_rows * f->dim * 4, hipMemcpyDeviceToDevice, s));
         TSGPU_HIP_TRY(hipMemcpyAsync(nl.p, f->labels.p, (size_t)f->n_rows * 8, hipMemcpyDeviceToDevice, s));
         TSGPU_HIP_TRY(hipMemcpyAsync(no.p, f->row_ok.p, (size_t)f->n_rows, hipMemcpyDeviceToDevice, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(nh.p, f->Xh.p, (size_t)f->n_rows * f->dimp * 2, hipMemcpyDeviceToDevice, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(nh.p, f->Xh.p, (size_t)((f->n_rows + VEC_ROWS - 1) / VEC_ROWS) * VEC_ROWS * f->dimp * 2, hipMemcpyDeviceToDevice, s));   // whole tiles (tiled layout)
         TSGPU_HIP_TRY(hipMemcpyAsync(nn.p, f->xnorm.p, (size_t)f->n_rows * 4, hipMemcpyDeviceToDevice, s));
         TSGPU_HIP_TRY(hipMemcpyAsync(nt.p, f->tile_nmax.p, (size_t)((f->n_rows + VEC_ROWS - 1) / VEC_ROWS) * 4, hipMemcpyDeviceToDevice, s));
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
@@ -87,7 +87,7 @@ static int knn_group(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, uint32_t n
     const uint32_t QT = wide ? 128 : 64;
     const uint32_t n_qtiles = (n_q + QT - 1) / QT;
     const bool aligned = (f->dim % 4 == 0) && (((uintptr_t)Q_dev & 15) == 0) && (((uintptr_t)f->X.p & 15) == 0);
-    const uint32_t sample_tiles = std::max<uint32_t>(1, ctx->vec_sample_tiles);
+    const uint32_t sample_tiles = ctx->vec_sample_tiles ? ctx->vec_sample_tiles : 512;
     int rc;
     if ((rc = f->d_tau.reserve((size_t)n_q * 8))) return rc;
     if ((rc = f->d_cand_cnt.reserve((size_t)n_q * 4 + 16))) return rc;
@@ -181,7 +181,7 @@ static float vec_bracket_c(uint32_t dim) { return ((1.0f / 128.0f + 1.0f / 16384
 static int vec_refresh_mirror(VecField* f, uint32_t row0, uint32_t n, uint64_t n_rows_after, hipStream_t s) {
     if (n == 0) return TSGPU_OK;
     hipLaunchKernelGGL(vec_to_bf16_kernel, dim3((n + 3) / 4), dim3(256), 0, s, f->X.as<float>(), f->Xh.as<uint16_t>(), f->xnorm.as<float>(), row0, n, f->dim,
-                       f->dimp, VEC_NORM_INFLATE);
+                       f->dimp, VEC_NORM_INFLATE, 0u);
     const uint32_t t0 = row0 / VEC_ROWS, t1 = (row0 + n - 1) / VEC_ROWS;
     hipLaunchKernelGGL(vec_tile_nmax_kernel, dim3((t1 - t0 + 1 + 63) / 64), dim3(64), 0, s, f->xnorm.as<float>(), f->tile_nmax.as<float>(), t0, t1 - t0 + 1,
                        (uint32_t)n_rows_after);
@@ -190,6 +190,7 @@ static int vec_refresh_mirror(VecField* f, uint32_t row0, uint32_t n, uint64_t n
 }
 
 // the bf16-prefilter k-NN launch sequence (vec_kernels.hip.h, "bf16 PREFILTER path"); caller holds ctx->mu.
+static const uint32_t VEC_SURV_CAP = 8192;       // rows per query that may reach the exact re-score (more -> fp32 scan fallback)
 static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, uint32_t n_q, uint32_t k, const uint8_t* mask_dev,
                                float* dist_dev, uint64_t* label_dev, uint32_t* cnt_dev, bool record_events) {
     hipStream_t s = ctx->stream;
@@ -198,112 +199,101 @@ static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, 
     const bool wide = n_q > 64;
     const uint32_t QT = wide ? 128 : 64;
     const uint32_t n_qtiles = (n_q + QT - 1) / QT;
-    const uint32_t sample_tiles = std::max<uint32_t>(1, ctx->vec_sample_tiles);
+    const uint32_t sample_tiles = ctx->vec_sample_tiles ? ctx->vec_sample_tiles : 8192;   // bf16 sample pass is cheap: ~1M rows
+    const uint32_t n_q_pad = (n_q + 127) / 128 * 128;
     int rc;
-    if ((rc = f->d_Qh.reserve((size_t)n_q * f->dimp * 2))) return rc;
+    if ((rc = f->d_Qh.reserve((size_t)n_q_pad * f->dimp * 2))) return rc;
     if ((rc = f->d_cq.reserve((size_t)n_q * 4))) return rc;
     if ((rc = f->d_L1.reserve((size_t)n_q * 4))) return rc;
-    if ((rc = f->d_cand_cnt.reserve((size_t)n_q * 4 + 16))) return rc;
-    if ((rc = f->d_surv_cnt.reserve((size_t)n_q * 4))) return rc;
+    if ((rc = f->d_surv_cnt.reserve((size_t)n_q * 4 + 16))) return rc;
     if ((rc = f->d_tau.reserve((size_t)n_q * 8))) return rc;
-    uint32_t* d_over = f->d_cand_cnt.as<uint32_t>() + n_q;
+    if ((rc = f->d_surv.reserve((size_t)n_q * VEC_SURV_CAP * 4))) return rc;
+    if ((rc = f->d_dense.reserve((size_t)n_q * VEC_SURV_CAP * 8))) return rc;          // exact keys of the survivors
+    uint32_t* d_over = f->d_surv_cnt.as<uint32_t>() + n_q;      // [0] overflow, [1] stuck (behind the per-query survivor counts)
 
-    auto launch_scan = [&](VecHScanArgs& a, uint32_t target_wgs) {
-        uint32_t n_slabs = std::max<uint32_t>(8, (std::max<uint32_t>(1, target_wgs / n_qtiles) + 7) / 8 * 8);
-        uint32_t per = (a.n_ord + n_slabs - 1) / n_slabs;
+    // slab geometry of a scan over n_ord tile ordinals: slabs are a multiple of 8 (XCD mapping), ~target workgroups in total
+    auto geometry = [&](uint32_t n_ord, uint32_t target_wgs, uint32_t& per, uint32_t& n_slabs) {
+        n_slabs = std::max<uint32_t>(8, (std::max<uint32_t>(1, target_wgs / n_qtiles) + 7) / 8 * 8);
+        per = (n_ord + n_slabs - 1) / n_slabs;
         if (ctx->vec_rows_per_slab) per = std::max<uint32_t>(1, ctx->vec_rows_per_slab / VEC_ROWS);
         per = std::max<uint32_t>(per, 1);
-        n_slabs = (a.n_ord + per - 1) / per;
+        n_slabs = (n_ord + per - 1) / per;
         n_slabs = std::max<uint32_t>(8, (n_slabs + 7) / 8 * 8);
-        a.ord_per_slab = per; a.n_slabs = n_slabs; a.n_qtiles = n_qtiles;
-        const dim3 grid(n_slabs * n_qtiles), block(VEC_THREADS);
+    };
+    auto launch_scan = [&](VecHScanArgs& a, uint32_t target_wgs) {
+        geometry(a.n_ord, target_wgs, a.ord_per_slab, a.n_slabs);
+        a.n_qtiles = n_qtiles;
+        const dim3 grid(a.n_slabs * n_qtiles), block(VEC_THREADS);
         if (wide) hipLaunchKernelGGL((vec_hscan_kernel<2>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((vec_hscan_kernel<1>), grid, block, 0, s, a);
     };
     if (record_events) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[3], s));
-    // queries -> bf16 + cq = c * ||q||
+    // queries -> bf16 (chunk-major) + cq = c * ||q||
     hipLaunchKernelGGL(vec_to_bf16_kernel, dim3((n_q + 3) / 4), dim3(256), 0, s, Q_dev, f->d_Qh.as<uint16_t>(), f->d_cq.as<float>(), 0u, n_q, f->dim, f->dimp,
-                       vec_bracket_c(f->dim) * VEC_NORM_INFLATE);
+                       vec_bracket_c(f->dim) * VEC_NORM_INFLATE, n_q_pad);
     VecHScanArgs base;
     memset(&base, 0, sizeof base);
     base.Xh = f->Xh.as<uint16_t>(); base.row_ok = mask_dev; base.Qh = f->d_Qh.as<uint16_t>(); base.tile_nmax = f->tile_nmax.as<float>();
+    base.n_q_pad = n_q_pad;
     base.cq = f->d_cq.as<float>(); base.n_rows = n_rows; base.dimp = f->dimp; base.n_q = n_q; base.L1 = f->d_L1.as<float>();
-    const uint32_t splits = 4;
 
-    auto finish = [&](uint64_t* ent, size_t stride, const uint32_t* cnt, uint32_t cap) -> int {
-        // refine (L2 + survivors) -> exact re-score -> final selection
-        hipLaunchKernelGGL(vec_refine_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint64_t*)ent, stride, cnt, cap, k, (const float*)f->d_cq.as<float>(),
-                           (const float*)f->xnorm.as<float>(), f->d_L1.as<float>(), f->d_surv.as<uint32_t>(), f->d_surv_cnt.as<uint32_t>(), d_over);
-        return TSGPU_OK;
-    };
-    auto rescore_select = [&](uint64_t* ent, size_t stride, uint32_t cap) {
-        hipLaunchKernelGGL(vec_rescore_kernel, dim3(n_q, splits), dim3(VEC_THREADS), 0, s, (const float*)f->X.as<float>(), Q_dev, f->dim,
-                           (const uint32_t*)f->d_surv.as<uint32_t>(), (const uint32_t*)f->d_surv_cnt.as<uint32_t>(), stride, ent);
-        hipLaunchKernelGGL(vec_select_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint64_t*)ent, stride, (const uint32_t*)f->d_surv_cnt.as<uint32_t>(), cap, k, 0,
-                           f->labels.as<uint64_t>(), dist_dev, label_dev, cnt_dev, f->d_tau.as<uint64_t>(), d_over);
-    };
-
-    if (n_tiles <= sample_tiles) {
-        // small index: every row becomes an entry (dense), then refine / re-score / select
-        const uint32_t stride = n_tiles * VEC_ROWS;
-        if ((rc = f->d_cand.reserve((size_t)n_q * stride * 8))) return rc;
-        if ((rc = f->d_surv.reserve((size_t)n_q * stride * 4))) return rc;
-        TSGPU_HIP_TRY(hipMemsetAsync(d_over, 0, 4, s));
-        VecHScanArgs a = base;
-        a.n_ord = n_tiles; a.tile_stride = 1; a.mode = 2; a.cand = f->d_cand.as<uint64_t>(); a.dense_stride = stride;
-        launch_scan(a, 512);
-        if (record_events) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s));
-        finish(a.cand, stride, nullptr, stride);
-        rescore_select(a.cand, stride, stride);
-        ctx->vec_prefilter_groups++;
-        if (record_events) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[5], s));
-        TSGPU_HIP_TRY(hipGetLastError());
-        return TSGPU_OK;
-    }
-    // pass 1: strided sample -> L1[q] = k-th largest lower bound of the sample
-    const uint32_t tile_stride = n_tiles / sample_tiles;
+    // pass 1: strided sample of the row tiles (all of them for a small index) -> L1[q] = k-th largest group maximum of the
+    // sample's lower bounds
+    const uint32_t tile_stride = std::max<uint32_t>(1, n_tiles / sample_tiles);
     const uint32_t n_sample = (n_tiles + tile_stride - 1) / tile_stride;
     {
-        const uint32_t stride = n_sample * VEC_ROWS;
-        if ((rc = f->d_lbkey.reserve((size_t)n_q * stride * 4))) return rc;
+        const uint32_t gstride = n_sample * 4;
+        if ((rc = f->d_lbkey.reserve((size_t)n_q * gstride * 4))) return rc;
         VecHScanArgs a = base;
-        a.n_ord = n_sample; a.tile_stride = tile_stride; a.mode = 1; a.lbkey = f->d_lbkey.as<uint32_t>(); a.dense_stride = stride;
+        a.n_ord = n_sample; a.tile_stride = tile_stride; a.mode = 1; a.gmax = f->d_lbkey.as<uint32_t>(); a.gstride = gstride;
         launch_scan(a, 512);
-        hipLaunchKernelGGL(vec_thresh_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint32_t*)a.lbkey, (size_t)stride, stride, k, f->d_L1.as<float>());
+        hipLaunchKernelGGL(vec_thresh_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint32_t*)a.gmax, (size_t)gstride, gstride, k, f->d_L1.as<float>());
     }
-    // pass 2: every row, kept iff its upper bound reaches L1
-    uint64_t cap = ctx->vec_cand_cap;
-    if (!cap) {
-        cap = 6ull * k * ((n_tiles + n_sample - 1) / n_sample) + 1024;
-        uint64_t p2 = 1024; while (p2 < cap) p2 <<= 1; cap = p2;
-        while (cap > 4096 && cap * n_q * 8 > (1ull << 30)) cap >>= 1;
+    // pass 2: every row, kept iff its upper bound reaches L1; candidates land in per-(slab, query) segments
+    uint32_t per = 0, n_slabs = 0;
+    geometry(n_tiles, 512, per, n_slabs);
+    uint64_t seg_cap = ctx->vec_cand_cap;
+    if (!seg_cap) {
+        // expected candidates per query ~ k * rows / sample rows, times the bracket's widening (x8 head-room), spread over the slabs
+        const uint64_t expect = 8ull * k * ((n_tiles + n_sample - 1) / n_sample) / n_slabs;
+        seg_cap = 128; while (seg_cap < 4 * expect + 64 && seg_cap < 8192) seg_cap <<= 1;
+        while (seg_cap > 128 && seg_cap * n_slabs * n_q * 8 > (1ull << 31)) seg_cap >>= 1;
+        // >= 128: a slab of one tile always fits, so an index too small to yield a threshold (fewer than k sample groups) still works
     }
-    cap = std::max<uint64_t>(cap, 2ull * k);
-    if ((rc = f->d_cand.reserve((size_t)n_q * cap * 8))) return rc;
-    if ((rc = f->d_surv.reserve((size_t)n_q * cap * 4))) return rc;
+    seg_cap = std::max<uint64_t>(seg_cap, 1);
+    if ((rc = f->d_cand.reserve((size_t)n_slabs * n_q * seg_cap * 8))) return rc;
+    if ((rc = f->d_cand_cnt.reserve((size_t)n_slabs * n_q * 4))) return rc;
     uint32_t h_over[2] = {0, 0};
     for (int round = 0; round < 8; round++) {
-        TSGPU_HIP_TRY(hipMemsetAsync(f->d_cand_cnt.p, 0, (size_t)n_q * 4 + 8, s));
+        TSGPU_HIP_TRY(hipMemsetAsync(f->d_cand_cnt.p, 0, (size_t)n_slabs * n_q * 4, s));
+        TSGPU_HIP_TRY(hipMemsetAsync(d_over, 0, 8, s));
         VecHScanArgs a = base;
         a.n_ord = n_tiles; a.tile_stride = 1; a.mode = 0;
-        a.cand = f->d_cand.as<uint64_t>(); a.cand_cnt = f->d_cand_cnt.as<uint32_t>(); a.cand_cap = (uint32_t)cap;
+        a.seg = f->d_cand.as<uint64_t>(); a.seg_cnt = f->d_cand_cnt.as<uint32_t>(); a.seg_cap = (uint32_t)seg_cap;
         if (record_events && round == 0) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[6], s));
         launch_scan(a, 512);
         if (record_events && round == 0) { TSGPU_HIP_TRY(hipEventRecord(ctx->ev[7], s)); TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s)); ctx->scan_events_valid = true; }
-        finish(a.cand, (size_t)cap, a.cand_cnt, (uint32_t)cap);
+        hipLaunchKernelGGL(vec_refine_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint64_t*)a.seg, (const uint32_t*)a.seg_cnt, a.n_slabs, n_q, a.seg_cap, k,
+                           (const float*)f->d_cq.as<float>(), (const float*)f->xnorm.as<float>(), f->d_L1.as<float>(), f->d_surv.as<uint32_t>(), VEC_SURV_CAP,
+                           f->d_surv_cnt.as<uint32_t>(), d_over);
         TSGPU_HIP_TRY(hipGetLastError());
         TSGPU_HIP_TRY(hipMemcpyAsync(h_over, d_over, 8, hipMemcpyDeviceToHost, s));
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
-        if (!h_over[0] || h_over[1]) break;  // an overflowing list raised its own L1: scan again (unless it is stuck on ties)
+        if (!h_over[0] || h_over[1]) break;  // an overflowing list raised its own L1: scan again (unless it is stuck)
         ctx->vec_overflow_rounds++;
     }
     if (h_over[0]) {
-        // brackets cannot separate this data (mass ties / more near-duplicates than the candidate arena): the fp32 scan's
+        // brackets cannot separate this data (mass ties / more near-duplicates than the survivor arena): the fp32 scan's
         // (distance, row) keys converge on any input — run the group there
         ctx->vec_prefilter_fallbacks++;
         return knn_group(ctx, f, Q_dev, n_q, k, mask_dev, dist_dev, label_dev, cnt_dev, record_events);
     }
-    rescore_select(f->d_cand.as<uint64_t>(), (size_t)cap, (uint32_t)cap);
+    // exact re-score of the survivors (hnswlib's summation order) and final selection
+    hipLaunchKernelGGL(vec_rescore_kernel, dim3(n_q, 4), dim3(VEC_THREADS), 0, s, (const float*)f->X.as<float>(), Q_dev, f->dim,
+                       (const uint32_t*)f->d_surv.as<uint32_t>(), (const uint32_t*)f->d_surv_cnt.as<uint32_t>(), (size_t)VEC_SURV_CAP, f->d_dense.as<uint64_t>());
+    hipLaunchKernelGGL(vec_select_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint64_t*)f->d_dense.as<uint64_t>(), (size_t)VEC_SURV_CAP,
+                       (const uint32_t*)f->d_surv_cnt.as<uint32_t>(), VEC_SURV_CAP, k, 0, f->labels.as<uint64_t>(), dist_dev, label_dev, cnt_dev,
+                       f->d_tau.as<uint64_t>(), d_over);
     TSGPU_HIP_TRY(hipGetLastError());
     ctx->vec_prefilter_groups++;
     if (ctx->vec_count_rescored) {        // introspection (tests / bench): how many rows reached the exact re-score

@@ -458,22 +458,34 @@ __device__ inline uint32_t f32_to_bf16_bits(float f) {
     return h;
 }
 
-// one wave per row: bf16 copy (zero padded to dimp, a multiple of 64) + norm_out[row] = scale * ||x||_2 (fp32 sum of
-// squares, `scale` carries the safety inflation / the query-side constant c)
+// HBM layouts of the bf16 mirrors (private to this library, chosen for the scan kernel's access pattern: every
+// pipeline step of a workgroup reads ONE contiguous 16 KB block of rows and one contiguous block of queries — a
+// row-major mirror would make each step gather 128-byte pieces at a 2*dim-byte stride, which starves HBM):
+//   rows    Xh[tile = row/128][chunk = k/64][row%128][k%64]      (tile = 128 rows, whole tiles are allocated)
+//   queries Qh[chunk = k/64][q][k%64]                             (q padded to n_pad, a multiple of 128)
+__device__ inline size_t vec_xh_index(uint32_t row, uint32_t k, uint32_t n_chunks) {
+    return ((size_t)(row >> 7) * n_chunks + (k >> 6)) * (size_t)(VEC_ROWS * VEC_HKC) + (size_t)(row & 127) * VEC_HKC + (k & 63);
+}
+__device__ inline size_t vec_qh_index(uint32_t q, uint32_t k, uint32_t n_pad) { return ((size_t)(k >> 6) * n_pad + q) * VEC_HKC + (k & 63); }
+
+// one wave per row: bf16 copy (zero padded to dimp, a multiple of 64) in the tiled layout + norm_out[row] = scale * ||x||_2
+// (fp32 sum of squares, `scale` carries the safety inflation / the query-side constant c). q_pad == 0: row layout, else
+// query layout with n_pad = q_pad.
 __global__ __launch_bounds__(256) void vec_to_bf16_kernel(const float* __restrict__ X, uint16_t* __restrict__ Xh, float* __restrict__ norm_out,
-                                                           uint32_t row0, uint32_t n_rows, uint32_t dim, uint32_t dimp, float scale) {
+                                                           uint32_t row0, uint32_t n_rows, uint32_t dim, uint32_t dimp, float scale, uint32_t q_pad) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n_rows) return;                       // whole wave exits together
     const uint32_t r = row0 + i;
     const float* __restrict__ x = X + (size_t)r * dim;
-    uint32_t* __restrict__ o = (uint32_t*)(Xh + (size_t)r * dimp);
+    const uint32_t n_chunks = dimp / VEC_HKC;
     float ss = 0.0f;
     for (uint32_t k = 2 * lane; k < dimp; k += 128) {
         const float a = k < dim ? x[k] : 0.0f, b = k + 1 < dim ? x[k + 1] : 0.0f;
         ss = fmaf(a, a, ss);
         ss = fmaf(b, b, ss);
-        o[k >> 1] = f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16);
+        const size_t at = q_pad ? vec_qh_index(r, k, q_pad) : vec_xh_index(r, k, n_chunks);
+        *(uint32_t*)(Xh + at) = f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
@@ -495,26 +507,32 @@ __global__ void vec_tile_nmax_kernel(const float* __restrict__ xnorm, float* __r
 }
 
 struct VecHScanArgs {
-    const uint16_t* Xh;        // [n_rows][dimp] bf16
+    const uint16_t* Xh;        // bf16 rows, tiled layout (vec_xh_index)
     const uint8_t* row_ok;     // nullable
-    const uint16_t* Qh;        // [n_q][dimp] bf16
+    const uint16_t* Qh;        // bf16 queries, chunk-major layout (vec_qh_index), n_q_pad rows per chunk
+    uint32_t n_q_pad;
     const float* tile_nmax;    // [n_tiles]
     const float* cq;           // [n_q] c * ||q||
     uint32_t n_rows, dimp, n_q;
     uint32_t n_ord, tile_stride, ord_per_slab, n_slabs, n_qtiles;
-    int mode;                  // 0 = filtered (cand lists), 1 = sample (lower-bound keys, dense), 2 = every row (entries, dense)
+    int mode;                  // 0 = filtered scan (candidate segments), 1 = sample (group maxima of the lower bounds)
     const float* L1;           // mode 0: [n_q] thresholds
-    uint64_t* cand;            // mode 0: [n_q][cand_cap] entries (s~ bits << 32 | row); mode 2: [n_q][dense_stride]
-    uint32_t* cand_cnt;        // mode 0
-    uint32_t cand_cap;
-    uint32_t* lbkey;           // mode 1: [n_q][dense_stride] descending keys of the lower bounds (0xFFFFFFFF = no row)
-    uint32_t dense_stride;
+    // mode 0: candidates go to a segment PRIVATE to (slab, query) — slots come from an LDS counter, no global atomics:
+    //   seg[(slab * n_q + q) * seg_cap + slot] = (s~ bits << 32 | row),  seg_cnt[slab * n_q + q] = candidates seen (may exceed seg_cap)
+    uint64_t* seg;
+    uint32_t* seg_cnt;
+    uint32_t seg_cap;
+    // mode 1: gmax[q * gstride + ordinal * 4 + g] = descending key of the largest lower bound among the 32 rows of group g
+    // (g = 64-row strip * 2 + half) of the ordinal-th sampled tile; 0xFFFFFFFF = no valid row in the group
+    uint32_t* gmax;
+    uint32_t gstride;
 };
 
 template <int QT>
 struct VecHScanSmem {
     alignas(16) uint32_t xs[2][VEC_ROWS * VEC_LDW];
     alignas(16) uint32_t qs[2][QT * VEC_LDW];
+    uint32_t cnt[QT];          // mode 0: candidates of this workgroup per query column
 };
 
 template <int CB>
@@ -537,25 +555,18 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs 
     const uint32_t n_chunks = a.dimp / VEC_HKC;
     const uint32_t total_steps = (ord_end - ord_begin) * n_chunks;
 
+    for (uint32_t i = t; i < (uint32_t)QT; i += VEC_THREADS) sm.cnt[i] = 0;     // published by the prologue's barrier
     uint4 xr[XV], qr[QV];
-    // out-of-range rows / queries read a clamped in-range row (scores dropped by the epilogue); no select on loaded data
+    // one step = one contiguous 16 KB block of the row mirror + one contiguous QT*128 B block of the query mirror; whole
+    // tiles / padded query rows exist in memory, so no clamping (scores of rows >= n_rows / queries >= n_q are dropped by the epilogue)
     auto load_step = [&](uint32_t s) {
         const uint32_t o = ord_begin + s / n_chunks, c = s % n_chunks;
-        const uint32_t r0 = o * a.tile_stride * VEC_ROWS;
+        const uint4* __restrict__ xsrc = (const uint4*)(a.Xh + ((size_t)(o * a.tile_stride) * n_chunks + c) * (size_t)(VEC_ROWS * VEC_HKC));
+        const uint4* __restrict__ qsrc = (const uint4*)(a.Qh + ((size_t)c * a.n_q_pad + q0) * VEC_HKC);
 #pragma unroll
-        for (int v = 0; v < XV; v++) {
-            const uint32_t idx = t + v * VEC_THREADS;
-            uint32_t row = r0 + (idx >> 3);
-            row = row < a.n_rows ? row : a.n_rows - 1;
-            xr[v] = *(const uint4*)(a.Xh + (size_t)row * a.dimp + c * VEC_HKC + (idx & 7) * 8);
-        }
+        for (int v = 0; v < XV; v++) xr[v] = xsrc[t + v * VEC_THREADS];
 #pragma unroll
-        for (int v = 0; v < QV; v++) {
-            const uint32_t idx = t + v * VEC_THREADS;
-            uint32_t gq = q0 + (idx >> 3);
-            gq = gq < a.n_q ? gq : a.n_q - 1;
-            qr[v] = *(const uint4*)(a.Qh + (size_t)gq * a.dimp + c * VEC_HKC + (idx & 7) * 8);
-        }
+        for (int v = 0; v < QV; v++) qr[v] = qsrc[t + v * VEC_THREADS];
     };
     auto store_step = [&](uint32_t buf) {
 #pragma unroll
@@ -627,9 +638,11 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs 
             const uint32_t tile = o * a.tile_stride;
             const uint32_t r0 = tile * VEC_ROWS;
             const float nmax = a.tile_nmax[tile];
+            const uint32_t rbase = r0 + wrow + 4 * (lane >> 5);
 #pragma unroll
             for (int cb = 0; cb < CB; cb++) {
-                const uint32_t gq = q0 + wcol + cb * 32 + (lane & 31);
+                const uint32_t col = wcol + cb * 32 + (lane & 31);
+                const uint32_t gq = q0 + col;
                 const float e = cqv[cb] * nmax + 1e-30f;             // >= every row's error radius in this tile
                 if (a.mode == 0) {
                     float amax = acc[0][cb][0];
@@ -639,41 +652,43 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs 
 #pragma unroll
                         for (int el = 0; el < 16; el++) { amax = fmaxf(amax, acc[rb][cb][el]); odd = odd || !f32_finite(acc[rb][cb][el]); }
                     if (gq < a.n_q && (odd || !(amax + e < L1v[cb]))) {
+                        uint64_t* __restrict__ seg = a.seg + ((size_t)slab * a.n_q + gq) * a.seg_cap;
 #pragma unroll
                         for (int rb = 0; rb < 2; rb++)
 #pragma unroll
                             for (int el = 0; el < 16; el++) {
-                                const uint32_t row = r0 + wrow + rb * 32 + (el & 3) + 8 * (el >> 2) + 4 * (lane >> 5);
+                                const uint32_t row = rbase + rb * 32 + (el & 3) + 8 * (el >> 2);
                                 const float sc = acc[rb][cb][el];
                                 if (!(sc + e < L1v[cb]) && row < a.n_rows && (!a.row_ok || a.row_ok[row] != 0)) {
-                                    const uint32_t slot = atomicAdd(&a.cand_cnt[gq], 1u);
-                                    if (slot < a.cand_cap) a.cand[(size_t)gq * a.cand_cap + slot] = ((uint64_t)__float_as_uint(sc) << 32) | row;
+                                    const uint32_t slot = atomicAdd(&sm.cnt[col], 1u);      // LDS
+                                    if (slot < a.seg_cap) seg[slot] = ((uint64_t)__float_as_uint(sc) << 32) | row;
                                 }
                             }
                     }
                 } else if (gq < a.n_q) {
+                    // sample pass: one key per (query, 32-row group) — the group's best lower bound. The k-th largest of
+                    // these maxima is a valid lower bound of the k-th best score (k groups -> k distinct rows).
+                    float best = __uint_as_float(0xFF800000u);
 #pragma unroll
                     for (int rb = 0; rb < 2; rb++)
 #pragma unroll
                         for (int el = 0; el < 16; el++) {
-                            const uint32_t lr = wrow + rb * 32 + (el & 3) + 8 * (el >> 2) + 4 * (lane >> 5);
-                            const uint32_t row = r0 + lr;
+                            const uint32_t row = rbase + rb * 32 + (el & 3) + 8 * (el >> 2);
                             bool okr = row < a.n_rows;
                             if (okr && a.row_ok) okr = a.row_ok[row] != 0;
-                            const float sc = acc[rb][cb][el];
-                            const size_t at = (size_t)gq * a.dense_stride + (size_t)(o * VEC_ROWS + lr);
-                            if (a.mode == 1) {
-                                const float lb = sc - e;
-                                a.lbkey[at] = (okr && f32_finite(lb)) ? f32_desc_key(lb) : 0xFFFFFFFFu;
-                            } else {
-                                a.cand[at] = okr ? (((uint64_t)__float_as_uint(sc) << 32) | row) : VEC_ENT_INVALID;
-                            }
+                            const float lb = acc[rb][cb][el] - e;
+                            if (okr && f32_finite(lb) && lb > best) best = lb;
                         }
+                    a.gmax[(size_t)gq * a.gstride + (size_t)o * 4 + (wave >> 1) * 2 + (lane >> 5)] =
+                        f32_finite(best) ? f32_desc_key(best) : 0xFFFFFFFFu;
                 }
             }
         }
         __syncthreads();
     }
+    if (a.mode == 0)
+        for (uint32_t i = t; i < (uint32_t)QT; i += VEC_THREADS)
+            if (q0 + i < a.n_q) a.seg_cnt[(size_t)slab * a.n_q + q0 + i] = sm.cnt[i];
 }
 
 // block-wide exact k-th smallest of n 32-bit keys produced by key(i) (re-evaluated every radix pass): 4 passes of
@@ -706,12 +721,12 @@ __device__ inline uint32_t block_kth_smallest_u32(uint32_t n, uint32_t k, KeyFn 
     return prefix;
 }
 
-// sample pass -> L1[q] = k-th largest lower bound of the sample (-inf when the sample holds fewer than k rows)
-__global__ __launch_bounds__(VEC_THREADS) void vec_thresh_kernel(const uint32_t* __restrict__ lbkey, size_t stride, uint32_t n, uint32_t k, float* __restrict__ L1) {
+// sample pass -> L1[q] = k-th largest group maximum of the sample's lower bounds (-inf when fewer than k groups hold a row)
+__global__ __launch_bounds__(VEC_THREADS) void vec_thresh_kernel(const uint32_t* __restrict__ gmax, size_t stride, uint32_t n, uint32_t k, float* __restrict__ L1) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_state[2], s_valid;
     const uint32_t t = threadIdx.x, q = blockIdx.x;
-    const uint32_t* __restrict__ keys = lbkey + (size_t)q * stride;
+    const uint32_t* __restrict__ keys = gmax + (size_t)q * stride;
     if (t == 0) s_valid = 0;
     __syncthreads();
     uint32_t valid = 0;
@@ -724,93 +739,124 @@ __global__ __launch_bounds__(VEC_THREADS) void vec_thresh_kernel(const uint32_t*
     if (t == 0) L1[q] = enough ? desc_key_f32(kk) : __uint_as_float(0xFF800000u);
 }
 
-// one workgroup per query: L2 = k-th largest lower bound among the candidate entries, survivors (ub >= L2) -> surv rows.
-// Overflowed list (cnt > cap): L1[q] <- L2 of the entries held (a valid, tighter bound) and overflow[0] is raised
-// (overflow[1] too when the bound could not move).
-__global__ __launch_bounds__(VEC_THREADS) void vec_refine_kernel(const uint64_t* __restrict__ ent_base, size_t stride, const uint32_t* __restrict__ cnt,
-                                                                  uint32_t cap, uint32_t k, const float* __restrict__ cq, const float* __restrict__ xnorm,
-                                                                  float* __restrict__ L1, uint32_t* __restrict__ surv_base, uint32_t* __restrict__ surv_cnt,
-                                                                  uint32_t* __restrict__ overflow) {
+// one workgroup per query. Gathers the query's candidate segments (one per slab), L2 = k-th largest lower bound
+// s~ - c|q||x_row| among them (exact per-row norms), survivors (upper bound >= L2) -> surv rows for the exact re-score.
+// The lower-bound keys of the gathered entries live in LDS for the radix passes (VEC_REFINE_LCAP entries).
+//   overflow[0] += 1 : some segment or the LDS list overflowed -> L1[q] was raised to the L2 of what is held (valid, tighter)
+//                      and the host scans again;
+//   overflow[1] += 1 : stuck — the bound cannot move (mass ties) or more than surv_cap rows sit inside the bracket of the k-th
+//                      best (near-duplicates): the host runs the group on the fp32 scan.
+static const uint32_t VEC_REFINE_LCAP = 24576;
+__global__ __launch_bounds__(VEC_THREADS) void vec_refine_kernel(const uint64_t* __restrict__ seg, const uint32_t* __restrict__ seg_cnt, uint32_t n_slabs,
+                                                                  uint32_t n_q, uint32_t seg_cap, uint32_t k, const float* __restrict__ cq,
+                                                                  const float* __restrict__ xnorm, float* __restrict__ L1, uint32_t* __restrict__ surv_base,
+                                                                  uint32_t surv_cap, uint32_t* __restrict__ surv_cnt, uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t lkeys[VEC_REFINE_LCAP];
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_state[2], s_valid, s_surv;
-    const uint32_t t = threadIdx.x, q = blockIdx.x;
-    const uint64_t* __restrict__ ent = ent_base + (size_t)q * stride;
-    uint32_t* __restrict__ surv = surv_base + (size_t)q * stride;
-    const uint32_t total = cnt ? cnt[q] : cap;
-    const bool over = total > cap;
-    const uint32_t n = over ? cap : total;
+    __shared__ uint32_t s_state[2], s_n, s_valid, s_surv, s_over;
+    const uint32_t t = threadIdx.x, q = blockIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t* __restrict__ surv = surv_base + (size_t)q * surv_cap;
     const float cqq = cq[q];
-    if (t == 0) { s_valid = 0; s_surv = 0; }
+    const float NEG_INF = __uint_as_float(0xFF800000u), POS_INF = __uint_as_float(0x7F800000u);
+    if (t == 0) { s_n = 0; s_valid = 0; s_surv = 0; s_over = 0; }
     __syncthreads();
-    // lower / upper bound of entry i; non-finite -> (-inf, +inf)
-    auto bounds = [&](uint64_t ev, float& lb, float& ub) -> bool {
+    // lower / upper bound of an entry; non-finite -> (-inf, +inf): always re-scored, never used as a bound
+    auto bounds = [&](uint64_t ev, float& lb, float& ub) {
         const uint32_t row = (uint32_t)ev;
-        if (ev == VEC_ENT_INVALID) return false;
         const float sc = __uint_as_float((uint32_t)(ev >> 32));
         const float e = cqq * xnorm[row] + 1e-30f;
         lb = sc - e; ub = sc + e;
-        if (!f32_finite(sc) || !f32_finite(e) || !f32_finite(lb) || !f32_finite(ub)) { lb = __uint_as_float(0xFF800000u); ub = __uint_as_float(0x7F800000u); }
-        return true;
+        if (!f32_finite(sc) || !f32_finite(e) || !f32_finite(lb) || !f32_finite(ub)) { lb = NEG_INF; ub = POS_INF; }
     };
-    auto lbkey = [&](uint32_t i) -> uint32_t {
-        float lb, ub;
-        if (!bounds(ent[i], lb, ub)) return 0xFFFFFFFFu;
-        return lb == __uint_as_float(0xFF800000u) ? 0xFFFFFFFEu : f32_desc_key(lb);
-    };
+    // ---- gather: wave w takes slabs w, w+4, ...; lanes stride over the segment ----
+    for (uint32_t sl = wave; sl < n_slabs; sl += VEC_THREADS / 64) {
+        const uint32_t total = seg_cnt[(size_t)sl * n_q + q];
+        const uint32_t n = total < seg_cap ? total : seg_cap;
+        if (total > seg_cap && lane == 0) s_over = 1;
+        const uint64_t* __restrict__ sp = seg + ((size_t)sl * n_q + q) * seg_cap;
+        for (uint32_t j = lane; j < n; j += 64) {
+            float lb, ub;
+            bounds(sp[j], lb, ub);
+            const uint32_t slot = atomicAdd(&s_n, 1u);
+            if (slot < VEC_REFINE_LCAP) lkeys[slot] = lb == NEG_INF ? 0xFFFFFFFEu : f32_desc_key(lb);
+        }
+    }
+    __syncthreads();
+    const uint32_t n_all = s_n;
+    const uint32_t n_held = n_all < VEC_REFINE_LCAP ? n_all : VEC_REFINE_LCAP;
+    const bool over = s_over != 0 || n_all > VEC_REFINE_LCAP;
     uint32_t valid = 0;
-    for (uint32_t i = t; i < n; i += VEC_THREADS) valid += lbkey(i) < 0xFFFFFFFEu;
+    for (uint32_t i = t; i < n_held; i += VEC_THREADS) valid += lkeys[i] < 0xFFFFFFFEu;
     if (valid) atomicAdd(&s_valid, valid);
     __syncthreads();
     const bool enough = s_valid >= k;
     __syncthreads();
-    const uint32_t kk = block_kth_smallest_u32(n, k, lbkey, hist, s_state);
-    const float L2 = enough ? desc_key_f32(kk) : __uint_as_float(0xFF800000u);
+    const uint32_t kk = block_kth_smallest_u32(n_held, k, [&](uint32_t i) { return lkeys[i]; }, hist, s_state);
+    const float L2 = enough ? desc_key_f32(kk) : NEG_INF;
     if (over) {
-        // no progress possible (mass ties: the held entries cannot raise the bound) -> overflow[1]: the host falls back to the
-        // fp32 scan, whose (distance, row) keys converge on any data
         if (t == 0) { if (L2 > L1[q]) L1[q] = L2; else atomicAdd(overflow + 1, 1u); atomicAdd(overflow, 1u); surv_cnt[q] = 0; }
         return;
     }
-    for (uint32_t i = t; i < n; i += VEC_THREADS) {
-        float lb, ub;
-        const uint64_t ev = ent[i];
-        if (bounds(ev, lb, ub) && !(ub < L2)) { const uint32_t slot = atomicAdd(&s_surv, 1u); surv[slot] = (uint32_t)ev; }
+    // ---- survivors: second walk over the segments ----
+    for (uint32_t sl = wave; sl < n_slabs; sl += VEC_THREADS / 64) {
+        const uint32_t n = seg_cnt[(size_t)sl * n_q + q];          // <= seg_cap here
+        const uint64_t* __restrict__ sp = seg + ((size_t)sl * n_q + q) * seg_cap;
+        for (uint32_t j = lane; j < n; j += 64) {
+            float lb, ub;
+            const uint64_t ev = sp[j];
+            bounds(ev, lb, ub);
+            if (!(ub < L2)) { const uint32_t slot = atomicAdd(&s_surv, 1u); if (slot < surv_cap) surv[slot] = (uint32_t)ev; }
+        }
     }
     __syncthreads();
-    if (t == 0) surv_cnt[q] = s_surv;
+    if (t == 0) {
+        if (s_surv > surv_cap) { atomicAdd(overflow, 1u); atomicAdd(overflow + 1, 1u); surv_cnt[q] = 0; }
+        else surv_cnt[q] = s_surv;
+    }
 }
 
 // hnswlib InnerProductSpace::get_dist_func arithmetic for one (query, row) pair, evaluated by a 16-lane group
 // (space_ip.h: InnerProductSIMD16Ext / SIMD4Ext / *Residuals): products and sums rounded separately (no FMA),
 // 16 (or 4) running lane sums, sequential horizontal add. sub = lane index inside the group (0..15); every lane of
-// the group returns the distance. qs = the query in LDS, x = the row in global memory.
-__device__ inline float ip_distance_group16(const float* qs, const float* __restrict__ x, uint32_t dim, uint32_t sub) {
+// the group returns the distance. qs = the query (LDS or global), x = the row in global memory.
+// Contraction is switched off lexically in every function below (the __fmul_rn/__fadd_rn header intrinsics are plain
+// operators compiled under the default -ffp-contract=fast and DO fuse after inlining).
+__device__ inline float ip_mul_add(float acc, float a, float b) {
 #pragma clang fp contract(off)
-    auto part16 = [&](uint32_t off, uint32_t n16) -> float {      // n16 multiple of 16
-        float accl = 0.0f;
-        for (uint32_t i = 0; i < n16; i += 16) { const float pr = __fmul_rn(qs[off + i + sub], x[off + i + sub]); accl = __fadd_rn(accl, pr); }
-        float sum = 0.0f;
+    const float pr = a * b;
+    return acc + pr;
+}
+__device__ inline float ip_add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ inline float ip_part16(const float* qs, const float* __restrict__ x, uint32_t off, uint32_t n16, uint32_t sub) {
+    float accl = 0.0f;
+    for (uint32_t i = 0; i < n16; i += 16) accl = ip_mul_add(accl, qs[off + i + sub], x[off + i + sub]);
+    float sum = 0.0f;
+    const int b0 = (int)(threadIdx.x & 48u);
 #pragma unroll
-        for (int l = 0; l < 16; l++) sum = __fadd_rn(sum, __shfl(accl, (int)((threadIdx.x & 48u) + l)));
-        return sum;
-    };
-    auto part4 = [&](uint32_t off, uint32_t n4) -> float {
-        float accl = 0.0f;
-        if (sub < 4) for (uint32_t i = 0; i < n4; i += 4) { const float pr = __fmul_rn(qs[off + i + sub], x[off + i + sub]); accl = __fadd_rn(accl, pr); }
-        const int b0 = (int)(threadIdx.x & 48u);
-        const float l0 = __shfl(accl, b0), l1 = __shfl(accl, b0 + 1), l2 = __shfl(accl, b0 + 2), l3 = __shfl(accl, b0 + 3);
-        return __fadd_rn(__fadd_rn(__fadd_rn(l0, l1), l2), l3);
-    };
-    auto scalar = [&](uint32_t off, uint32_t n) -> float {
-        float r = 0.0f;
-        for (uint32_t i = 0; i < n; i++) r = __fadd_rn(r, __fmul_rn(qs[off + i], x[off + i]));
-        return r;
-    };
-    if (dim % 16 == 0) return __fadd_rn(1.0f, -part16(0, dim));
-    if (dim % 4 == 0) return __fadd_rn(1.0f, -part4(0, dim));
-    if (dim > 16) { const uint32_t qn = dim >> 4 << 4; const float a1 = part16(0, qn); return __fadd_rn(1.0f, -__fadd_rn(a1, scalar(qn, dim - qn))); }
-    if (dim > 4) { const uint32_t qn = dim >> 2 << 2; const float a1 = part4(0, qn); return __fadd_rn(1.0f, -__fadd_rn(a1, scalar(qn, dim - qn))); }
-    return __fadd_rn(1.0f, -scalar(0, dim));
+    for (int l = 0; l < 16; l++) sum = ip_add(sum, __shfl(accl, b0 + l));
+    return sum;
+}
+__device__ inline float ip_part4(const float* qs, const float* __restrict__ x, uint32_t off, uint32_t n4, uint32_t sub) {
+    float accl = 0.0f;
+    if (sub < 4) for (uint32_t i = 0; i < n4; i += 4) accl = ip_mul_add(accl, qs[off + i + sub], x[off + i + sub]);
+    const int b0 = (int)(threadIdx.x & 48u);
+    const float l0 = __shfl(accl, b0), l1 = __shfl(accl, b0 + 1), l2 = __shfl(accl, b0 + 2), l3 = __shfl(accl, b0 + 3);
+    return ip_add(ip_add(ip_add(l0, l1), l2), l3);
+}
+__device__ inline float ip_scalar(const float* qs, const float* __restrict__ x, uint32_t off, uint32_t n) {
+    float r = 0.0f;
+    for (uint32_t i = 0; i < n; i++) r = ip_mul_add(r, qs[off + i], x[off + i]);
+    return r;
+}
+__device__ inline float ip_distance_group16(const float* qs, const float* __restrict__ x, uint32_t dim, uint32_t sub) {
+    if (dim % 16 == 0) return ip_add(1.0f, -ip_part16(qs, x, 0, dim, sub));
+    if (dim % 4 == 0) return ip_add(1.0f, -ip_part4(qs, x, 0, dim, sub));
+    if (dim > 16) { const uint32_t qn = dim >> 4 << 4; const float a1 = ip_part16(qs, x, 0, qn, sub); return ip_add(1.0f, -ip_add(a1, ip_scalar(qs, x, qn, dim - qn))); }
+    if (dim > 4) { const uint32_t qn = dim >> 2 << 2; const float a1 = ip_part4(qs, x, 0, qn, sub); return ip_add(1.0f, -ip_add(a1, ip_scalar(qs, x, qn, dim - qn))); }
+    return ip_add(1.0f, -ip_scalar(qs, x, 0, dim));
 }
 
 // exact re-scoring of the survivors: grid (n_q, splits); 16 lanes per (query, row) pair; key = ord(dist) << 32 | row
