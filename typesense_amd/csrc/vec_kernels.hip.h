@@ -193,7 +193,9 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_scan_kernel(VecScanArgs a)
 #pragma unroll
                     for (int e = 0; e < 16; e++) acc[rb][cb][e] = 0.0f;
         }
-        if (s + 1 < total_steps) load_step(s + 1);           // in flight while the MFMAs run
+        // UNCONDITIONAL (the last step re-requests its own block): a load under a runtime branch makes hipcc merge old/new
+        // registers with copies right behind the loads, i.e. wait for them BEFORE the MFMAs instead of after
+        load_step(s + 1 < total_steps ? s + 1 : s);          // in flight while the MFMAs run
         // lane (r = lane&31, h = lane>>5) supplies k = 8*g + 4*h + i to MFMA i of group g: every k exactly once
         const float* xa = &sm.xs[buf][(wrow + (lane & 31)) * VEC_LDW + 4 * (lane >> 5)];
         const float* qb = &sm.qs[buf][(wcol + (lane & 31)) * VEC_LDW + 4 * (lane >> 5)];
@@ -528,17 +530,42 @@ struct VecHScanArgs {
     uint32_t gstride;
 };
 
+// 16 bytes per lane straight from global memory into LDS (LDS-DMA, global_load_lds_dwordx4): the destination is
+// wave-uniform base (M0) + lane * 16, the source address is per lane — so the LDS image is linear and any swizzle is applied
+// on the SOURCE side. Issued through inline asm ON PURPOSE: hipcc cannot prove that the DMA into ring slot buf^1 does not
+// alias the ds_reads of slot buf and would drain it (s_waitcnt vmcnt(0)) before the first operand fetch of every step; an asm
+// statement is invisible to its counters, and the one wait this pipeline needs is vec_glds_wait() before the step's barrier
+// (cdna_hip_programming.md §5.7: M0 is written in the same statement that reads it; s_nop 0 covers the M0 hazard).
+__device__ inline void vec_glds16(const void* gsrc, void* lds_wave_base) {
+#ifdef TSGPU_HIP_EMU
+    hipemu_global_load_lds16(gsrc, lds_wave_base);
+#else
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+#endif
+}
+__device__ inline void vec_glds_wait() {
+#ifndef TSGPU_HIP_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+// LDS image of one pipeline step: rows of 128 bytes (64 bf16), NO padding; the eight 16-byte pieces of row R are stored
+// at piece position p ^ ((R >> 1) & 7). With that XOR the 16 lanes of every ds_read_b128 service group (rows r, r+..;
+// MI355X_MICROARCH.md §LDS) hit 16 distinct 4-bank groups: conflict-free operand fetch from an unpadded, DMA-filled tile.
 template <int QT>
 struct VecHScanSmem {
-    alignas(16) uint32_t xs[2][VEC_ROWS * VEC_LDW];
-    alignas(16) uint32_t qs[2][QT * VEC_LDW];
+    alignas(16) uint32_t xs[2][VEC_ROWS * 32];
+    alignas(16) uint32_t qs[2][QT * 32];
     uint32_t cnt[QT];          // mode 0: candidates of this workgroup per query column
 };
 
 template <int CB>
 __global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs a) {
     constexpr int QT = 64 * CB;
-    constexpr int XV = VEC_ROWS * 8 / VEC_THREADS;     // 16-byte pieces per thread per X chunk (4)
+    constexpr int XV = VEC_ROWS * 8 / VEC_THREADS;     // 16-byte pieces per thread per X block (4)
     constexpr int QV = QT * 8 / VEC_THREADS;           // 4 (QT=128) or 2 (QT=64)
     __shared__ VecHScanSmem<QT> sm;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -556,29 +583,24 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs 
     const uint32_t total_steps = (ord_end - ord_begin) * n_chunks;
 
     for (uint32_t i = t; i < (uint32_t)QT; i += VEC_THREADS) sm.cnt[i] = 0;     // published by the prologue's barrier
-    uint4 xr[XV], qr[QV];
-    // one step = one contiguous 16 KB block of the row mirror + one contiguous QT*128 B block of the query mirror; whole
-    // tiles / padded query rows exist in memory, so no clamping (scores of rows >= n_rows / queries >= n_q are dropped by the epilogue)
-    auto load_step = [&](uint32_t s) {
+    // one step = one contiguous 16 KB block of the row mirror + one contiguous QT*128 B block of the query mirror, DMA'd into
+    // the other LDS buffer while this one is multiplied. Thread t moves pieces idx = t + v*256: LDS position idx (linear),
+    // source piece (idx & 7) ^ ((row >> 1) & 7) of row idx >> 3. Whole tiles / padded query rows exist in memory: no clamping
+    // (scores of rows >= n_rows / queries >= n_q are dropped by the epilogue).
+    uint32_t src_off[XV > QV ? XV : QV];               // 16-byte units inside the block; the same for X and Q pieces
+#pragma unroll
+    for (int v = 0; v < (XV > QV ? XV : QV); v++) {
+        const uint32_t idx = t + v * VEC_THREADS, row = idx >> 3;
+        src_off[v] = row * 8 + ((idx & 7) ^ ((row >> 1) & 7));
+    }
+    auto load_step = [&](uint32_t s, uint32_t buf) {
         const uint32_t o = ord_begin + s / n_chunks, c = s % n_chunks;
         const uint4* __restrict__ xsrc = (const uint4*)(a.Xh + ((size_t)(o * a.tile_stride) * n_chunks + c) * (size_t)(VEC_ROWS * VEC_HKC));
         const uint4* __restrict__ qsrc = (const uint4*)(a.Qh + ((size_t)c * a.n_q_pad + q0) * VEC_HKC);
 #pragma unroll
-        for (int v = 0; v < XV; v++) xr[v] = xsrc[t + v * VEC_THREADS];
+        for (int v = 0; v < XV; v++) vec_glds16(xsrc + src_off[v], &sm.xs[buf][(v * VEC_THREADS + wave * 64) * 4]);
 #pragma unroll
-        for (int v = 0; v < QV; v++) qr[v] = qsrc[t + v * VEC_THREADS];
-    };
-    auto store_step = [&](uint32_t buf) {
-#pragma unroll
-        for (int v = 0; v < XV; v++) {
-            const uint32_t idx = t + v * VEC_THREADS;
-            *(uint4*)&sm.xs[buf][(idx >> 3) * VEC_LDW + (idx & 7) * 4] = xr[v];
-        }
-#pragma unroll
-        for (int v = 0; v < QV; v++) {
-            const uint32_t idx = t + v * VEC_THREADS;
-            *(uint4*)&sm.qs[buf][(idx >> 3) * VEC_LDW + (idx & 7) * 4] = qr[v];
-        }
+        for (int v = 0; v < QV; v++) vec_glds16(qsrc + src_off[v], &sm.qs[buf][(v * VEC_THREADS + wave * 64) * 4]);
     };
 
     // per-lane query constants: this lane's query column in each of its CB blocks
@@ -592,9 +614,15 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs 
     }
 
     vec_f32x16 acc[2][CB];
-    load_step(0);
-    store_step(0);
+    load_step(0, 0);
+    vec_glds_wait();
     __syncthreads();
+    // operand addresses: lane (r = lane&31, h = lane>>5) reads piece 2g+h of its rows = k 16g+8h .. +7: one ds_read_b128 = one
+    // MFMA operand; piece position = (2g+h) ^ ((r>>1)&7) (rows of a lane differ by multiples of 32 -> same swizzle)
+    const uint32_t swz = ((lane & 31) >> 1) & 7, hh = lane >> 5;
+    uint32_t poff[VEC_HKC / 16];
+#pragma unroll
+    for (int g = 0; g < VEC_HKC / 16; g++) poff[g] = (((uint32_t)(2 * g) + hh) ^ swz) * 4;
     for (uint32_t s = 0; s < total_steps; s++) {
         const uint32_t c = s % n_chunks, buf = s & 1;
         if (c == 0) {
@@ -605,33 +633,31 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs 
 #pragma unroll
                     for (int e = 0; e < 16; e++) acc[rb][cb][e] = 0.0f;
         }
-        if (s + 1 < total_steps) load_step(s + 1);           // in flight while the MFMAs run
-        // lane (r = lane&31, h = lane>>5) supplies k = 16*g + 8*h .. +7 of row r: one ds_read_b128 = one MFMA operand
-        const uint32_t* xa = &sm.xs[buf][(wrow + (lane & 31)) * VEC_LDW + 4 * (lane >> 5)];
-        const uint32_t* qb = &sm.qs[buf][(wcol + (lane & 31)) * VEC_LDW + 4 * (lane >> 5)];
+        // next step's blocks -> the other LDS buffer, in flight while this one is multiplied (the last step re-requests its
+        // own block: no branch around the loads)
+        load_step(s + 1 < total_steps ? s + 1 : s, buf ^ 1);
+        const uint32_t* xa = &sm.xs[buf][(wrow + (lane & 31)) * 32];
+        const uint32_t* qb = &sm.qs[buf][(wcol + (lane & 31)) * 32];
         uint4 av[2][2], bv[2][CB];
 #pragma unroll
-        for (int rb = 0; rb < 2; rb++) av[0][rb] = *(const uint4*)(xa + rb * 32 * VEC_LDW);
+        for (int rb = 0; rb < 2; rb++) av[0][rb] = *(const uint4*)(xa + rb * 32 * 32 + poff[0]);
 #pragma unroll
-        for (int cb = 0; cb < CB; cb++) bv[0][cb] = *(const uint4*)(qb + cb * 32 * VEC_LDW);
+        for (int cb = 0; cb < CB; cb++) bv[0][cb] = *(const uint4*)(qb + cb * 32 * 32 + poff[0]);
 #pragma unroll
         for (int g = 0; g < VEC_HKC / 16; g++) {
             const int cur = g & 1, nx = cur ^ 1;
             if (g + 1 < VEC_HKC / 16) {
 #pragma unroll
-                for (int rb = 0; rb < 2; rb++) av[nx][rb] = *(const uint4*)(xa + rb * 32 * VEC_LDW + 8 * (g + 1));
+                for (int rb = 0; rb < 2; rb++) av[nx][rb] = *(const uint4*)(xa + rb * 32 * 32 + poff[g + 1 < VEC_HKC / 16 ? g + 1 : g]);
 #pragma unroll
-                for (int cb = 0; cb < CB; cb++) bv[nx][cb] = *(const uint4*)(qb + cb * 32 * VEC_LDW + 8 * (g + 1));
+                for (int cb = 0; cb < CB; cb++) bv[nx][cb] = *(const uint4*)(qb + cb * 32 * 32 + poff[g + 1 < VEC_HKC / 16 ? g + 1 : g]);
             }
-            if (g == VEC_HKC / 16 - 1 && s + 1 < total_steps) store_step(buf ^ 1);   // next chunk -> other ring slot, under the last MFMA group
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int rb = 0; rb < 2; rb++)
 #pragma unroll
                 for (int cb = 0; cb < CB; cb++)
                     acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vec_bf16x8, av[cur][rb]), __builtin_bit_cast(vec_bf16x8, bv[cur][cb]),
                                                                           acc[rb][cb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
         }
         if (c == n_chunks - 1) {
             const uint32_t o = ord_begin + s / n_chunks;
@@ -684,6 +710,7 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs 
                 }
             }
         }
+        vec_glds_wait();                                   // the next step's blocks have landed in the other ring slot
         __syncthreads();
     }
     if (a.mode == 0)
