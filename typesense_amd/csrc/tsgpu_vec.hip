@@ -217,13 +217,14 @@ static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, 
         per = (n_ord + n_slabs - 1) / n_slabs;
         if (ctx->vec_rows_per_slab) per = std::max<uint32_t>(1, ctx->vec_rows_per_slab / VEC_ROWS);
         per = std::max<uint32_t>(per, 1);
+        per = std::min<uint32_t>(std::max<uint32_t>(per, 2), VEC_HMAX_PER) / 2 * 2;     // a workgroup steps over ordinal PAIRS; norm maxima of a slab live in LDS
         n_slabs = (n_ord + per - 1) / per;
         n_slabs = std::max<uint32_t>(8, (n_slabs + 7) / 8 * 8);
     };
     auto launch_scan = [&](VecHScanArgs& a, uint32_t target_wgs) {
         geometry(a.n_ord, target_wgs, a.ord_per_slab, a.n_slabs);
         a.n_qtiles = n_qtiles;
-        const dim3 grid(a.n_slabs * n_qtiles), block(VEC_THREADS);
+        const dim3 grid(a.n_slabs * n_qtiles), block(VEC_HTHREADS);
         if (wide) hipLaunchKernelGGL((vec_hscan_kernel<2>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((vec_hscan_kernel<1>), grid, block, 0, s, a);
     };
@@ -246,12 +247,12 @@ static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, 
         if ((rc = f->d_lbkey.reserve((size_t)n_q * gstride * 4))) return rc;
         VecHScanArgs a = base;
         a.n_ord = n_sample; a.tile_stride = tile_stride; a.mode = 1; a.gmax = f->d_lbkey.as<uint32_t>(); a.gstride = gstride;
-        launch_scan(a, 512);
+        launch_scan(a, 256);
         hipLaunchKernelGGL(vec_thresh_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint32_t*)a.gmax, (size_t)gstride, gstride, k, f->d_L1.as<float>());
     }
     // pass 2: every row, kept iff its upper bound reaches L1; candidates land in per-(slab, query) segments
     uint32_t per = 0, n_slabs = 0;
-    geometry(n_tiles, 512, per, n_slabs);
+    geometry(n_tiles, 256, per, n_slabs);
     uint64_t seg_cap = ctx->vec_cand_cap;
     if (!seg_cap) {
         // expected candidates per query ~ k * rows / sample rows, times the bracket's widening (x8 head-room), spread over the slabs
@@ -271,7 +272,7 @@ static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, 
         a.n_ord = n_tiles; a.tile_stride = 1; a.mode = 0;
         a.seg = f->d_cand.as<uint64_t>(); a.seg_cnt = f->d_cand_cnt.as<uint32_t>(); a.seg_cap = (uint32_t)seg_cap;
         if (record_events && round == 0) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[6], s));
-        launch_scan(a, 512);
+        launch_scan(a, 256);
         if (record_events && round == 0) { TSGPU_HIP_TRY(hipEventRecord(ctx->ev[7], s)); TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s)); ctx->scan_events_valid = true; }
         hipLaunchKernelGGL(vec_refine_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint64_t*)a.seg, (const uint32_t*)a.seg_cnt, a.n_slabs, n_q, a.seg_cap, k,
                            (const float*)f->d_cq.as<float>(), (const float*)f->xnorm.as<float>(), f->d_L1.as<float>(), f->d_surv.as<uint32_t>(), VEC_SURV_CAP,

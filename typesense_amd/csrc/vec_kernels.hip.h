@@ -546,30 +546,43 @@ __device__ inline void vec_glds16(const void* gsrc, void* lds_wave_base) {
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 #endif
 }
-__device__ inline void vec_glds_wait() {
+template <int N>
+__device__ inline void vec_glds_wait() {        // all but the youngest N vector-memory operations of this wave are complete
 #ifndef TSGPU_HIP_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #endif
 }
 
 // LDS image of one pipeline step: rows of 128 bytes (64 bf16), NO padding; the eight 16-byte pieces of row R are stored
-// at piece position p ^ ((R >> 1) & 7). With that XOR the 16 lanes of every ds_read_b128 service group (rows r, r+..;
-// MI355X_MICROARCH.md §LDS) hit 16 distinct 4-bank groups: conflict-free operand fetch from an unpadded, DMA-filled tile.
+// at piece position p ^ ((R >> 1) & 7). With that XOR the 16 lanes of every ds_read_b128 service group (MI355X_MICROARCH.md
+// §LDS) hit 16 distinct 4-bank groups: conflict-free operand fetch from an unpadded, DMA-filled tile.
+//
+// Workgroup = 8 waves = TWO consecutive tile ordinals (256 rows) x QT queries; wave (wr = wave>>1, wc = wave&1) owns rows
+// [64 wr, 64 wr + 64) x queries [32 CB wc, +32 CB). One workgroup per CU (128 KB of LDS), 2 waves per SIMD.
+// Pipeline (HBM latency under load is ~4K cycles, a step's MFMAs only ~0.5K): the row ring has 3 slots and runs TWO steps
+// ahead, the query ring (L2-resident data) has 2 slots and runs one step ahead. Per step: issue Q(s+1) then X(s+2); multiply
+// slot s; s_waitcnt vmcnt(XV) — loads complete in issue order, so everything but the youngest XV DMAs (= X(s+2)) has
+// landed, i.e. X(s+1) and Q(s+1); barrier.
+static const int VEC_HTHREADS = 512;
+static const int VEC_HROWS = 2 * VEC_ROWS;          // rows per workgroup step (two 128-row tiles)
+static const int VEC_HMAX_PER = 2048;               // tile ordinals per slab whose norm maxima are staged in LDS
 template <int QT>
 struct VecHScanSmem {
-    alignas(16) uint32_t xs[2][VEC_ROWS * 32];
+    alignas(16) uint32_t xs[3][VEC_HROWS * 32];
     alignas(16) uint32_t qs[2][QT * 32];
+    float nmax[VEC_HMAX_PER];  // tile_nmax of the slab's ordinals
     uint32_t cnt[QT];          // mode 0: candidates of this workgroup per query column
 };
 
 template <int CB>
-__global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs a) {
+__global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a) {
     constexpr int QT = 64 * CB;
-    constexpr int XV = VEC_ROWS * 8 / VEC_THREADS;     // 16-byte pieces per thread per X block (4)
-    constexpr int QV = QT * 8 / VEC_THREADS;           // 4 (QT=128) or 2 (QT=64)
+    constexpr int XV = VEC_HROWS * 8 / VEC_HTHREADS;    // 16-byte pieces per thread per X step (4)
+    constexpr int QV = QT * 8 / VEC_HTHREADS;           // 2 (QT=128) or 1 (QT=64)
     __shared__ VecHScanSmem<QT> sm;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint32_t wrow = (wave >> 1) * 64, wcol = (wave & 1) * (32 * CB);
+    const uint32_t wr = wave >> 1;
+    const uint32_t wrow = wr * 64, wcol = (wave & 1) * (32 * CB);
     const uint32_t b = blockIdx.x;
     const uint32_t xcd = b & 7, j = b >> 3;
     const uint32_t qtile = j % a.n_qtiles;
@@ -579,28 +592,39 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs 
     uint32_t ord_end = ord_begin + a.ord_per_slab;
     if (ord_end > a.n_ord) ord_end = a.n_ord;
     if (ord_begin >= ord_end) return;
+    const uint32_t n_ord = ord_end - ord_begin;          // <= VEC_HMAX_PER (host)
     const uint32_t n_chunks = a.dimp / VEC_HKC;
-    const uint32_t total_steps = (ord_end - ord_begin) * n_chunks;
+    const uint32_t total_steps = ((n_ord + 1) / 2) * n_chunks;
 
-    for (uint32_t i = t; i < (uint32_t)QT; i += VEC_THREADS) sm.cnt[i] = 0;     // published by the prologue's barrier
-    // one step = one contiguous 16 KB block of the row mirror + one contiguous QT*128 B block of the query mirror, DMA'd into
-    // the other LDS buffer while this one is multiplied. Thread t moves pieces idx = t + v*256: LDS position idx (linear),
-    // source piece (idx & 7) ^ ((row >> 1) & 7) of row idx >> 3. Whole tiles / padded query rows exist in memory: no clamping
-    // (scores of rows >= n_rows / queries >= n_q are dropped by the epilogue).
-    uint32_t src_off[XV > QV ? XV : QV];               // 16-byte units inside the block; the same for X and Q pieces
+    for (uint32_t i = t; i < (uint32_t)QT; i += VEC_HTHREADS) sm.cnt[i] = 0;
+    for (uint32_t i = t; i < n_ord; i += VEC_HTHREADS) sm.nmax[i] = a.tile_nmax[(ord_begin + i) * a.tile_stride];
+    __syncthreads();                                     // plain loads are done before the first DMA is issued
+
+    // Thread t moves pieces idx = t + v*512 of a step: LDS position idx (linear), source piece (idx & 7) ^ ((row >> 1) & 7) of
+    // row idx >> 3 (rows 0..127 = first ordinal, 128..255 = second). Whole tiles / padded query rows exist in memory: no
+    // clamping of rows (scores of rows >= n_rows / queries >= n_q are dropped by the epilogue).
+    uint32_t src_off[XV];                                // 16-byte units inside a 16 KB block
 #pragma unroll
-    for (int v = 0; v < (XV > QV ? XV : QV); v++) {
-        const uint32_t idx = t + v * VEC_THREADS, row = idx >> 3;
+    for (int v = 0; v < XV; v++) {
+        const uint32_t idx = t + v * VEC_HTHREADS, row = (idx >> 3) & 127;
         src_off[v] = row * 8 + ((idx & 7) ^ ((row >> 1) & 7));
     }
-    auto load_step = [&](uint32_t s, uint32_t buf) {
-        const uint32_t o = ord_begin + s / n_chunks, c = s % n_chunks;
-        const uint4* __restrict__ xsrc = (const uint4*)(a.Xh + ((size_t)(o * a.tile_stride) * n_chunks + c) * (size_t)(VEC_ROWS * VEC_HKC));
+    auto load_x = [&](uint32_t s, uint32_t slot) {
+        const uint32_t p = s / n_chunks, c = s % n_chunks;
+#pragma unroll
+        for (int v = 0; v < XV; v++) {
+            const uint32_t half = (t + v * VEC_HTHREADS) >> 10;                       // which of the two ordinals (uniform per v: 1024 pieces each)
+            uint32_t o = ord_begin + 2 * p + half;
+            o = o < ord_end ? o : ord_end - 1;                                         // odd tail: re-read the last ordinal (dropped by the epilogue)
+            const uint4* __restrict__ xsrc = (const uint4*)(a.Xh + ((size_t)(o * a.tile_stride) * n_chunks + c) * (size_t)(VEC_ROWS * VEC_HKC));
+            vec_glds16(xsrc + src_off[v], &sm.xs[slot][(v * VEC_HTHREADS + wave * 64) * 4]);
+        }
+    };
+    auto load_q = [&](uint32_t s, uint32_t slot) {
+        const uint32_t c = s % n_chunks;
         const uint4* __restrict__ qsrc = (const uint4*)(a.Qh + ((size_t)c * a.n_q_pad + q0) * VEC_HKC);
 #pragma unroll
-        for (int v = 0; v < XV; v++) vec_glds16(xsrc + src_off[v], &sm.xs[buf][(v * VEC_THREADS + wave * 64) * 4]);
-#pragma unroll
-        for (int v = 0; v < QV; v++) vec_glds16(qsrc + src_off[v], &sm.qs[buf][(v * VEC_THREADS + wave * 64) * 4]);
+        for (int v = 0; v < QV; v++) vec_glds16(qsrc + src_off[v], &sm.qs[slot][(v * VEC_HTHREADS + wave * 64) * 4]);
     };
 
     // per-lane query constants: this lane's query column in each of its CB blocks
@@ -612,10 +636,14 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs 
         cqv[cb] = a.cq[gc];
         L1v[cb] = (a.mode == 0) ? a.L1[gc] : __uint_as_float(0xFF800000u);
     }
+    __syncthreads();                                     // (their waits drain nothing of ours: no DMA issued yet)
 
     vec_f32x16 acc[2][CB];
-    load_step(0, 0);
-    vec_glds_wait();
+    const uint32_t last = total_steps - 1;
+    load_q(0, 0);
+    load_x(0, 0);
+    load_x(1 < total_steps ? 1 : last, 1);
+    vec_glds_wait<XV>();                                   // X(1) may stay in flight
     __syncthreads();
     // operand addresses: lane (r = lane&31, h = lane>>5) reads piece 2g+h of its rows = k 16g+8h .. +7: one ds_read_b128 = one
     // MFMA operand; piece position = (2g+h) ^ ((r>>1)&7) (rows of a lane differ by multiples of 32 -> same swizzle)
@@ -623,8 +651,9 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs 
     uint32_t poff[VEC_HKC / 16];
 #pragma unroll
     for (int g = 0; g < VEC_HKC / 16; g++) poff[g] = (((uint32_t)(2 * g) + hh) ^ swz) * 4;
+    uint32_t xslot = 0;                                  // s % 3
     for (uint32_t s = 0; s < total_steps; s++) {
-        const uint32_t c = s % n_chunks, buf = s & 1;
+        const uint32_t c = s % n_chunks, qslot = s & 1;
         if (c == 0) {
 #pragma unroll
             for (int rb = 0; rb < 2; rb++)
@@ -633,11 +662,11 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs 
 #pragma unroll
                     for (int e = 0; e < 16; e++) acc[rb][cb][e] = 0.0f;
         }
-        // next step's blocks -> the other LDS buffer, in flight while this one is multiplied (the last step re-requests its
-        // own block: no branch around the loads)
-        load_step(s + 1 < total_steps ? s + 1 : s, buf ^ 1);
-        const uint32_t* xa = &sm.xs[buf][(wrow + (lane & 31)) * 32];
-        const uint32_t* qb = &sm.qs[buf][(wcol + (lane & 31)) * 32];
+        // no branch around the DMAs: steps past the end re-request the last blocks into slots nobody reads any more
+        load_q(s + 1 < total_steps ? s + 1 : last, qslot ^ 1);
+        load_x(s + 2 < total_steps ? s + 2 : last, xslot >= 1 ? xslot - 1 : 2);       // (s + 2) % 3
+        const uint32_t* xa = &sm.xs[xslot][(wrow + (lane & 31)) * 32];
+        const uint32_t* qb = &sm.qs[qslot][(wcol + (lane & 31)) * 32];
         uint4 av[2][2], bv[2][CB];
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) av[0][rb] = *(const uint4*)(xa + rb * 32 * 32 + poff[0]);
@@ -660,61 +689,65 @@ __global__ __launch_bounds__(VEC_THREADS, 2) void vec_hscan_kernel(VecHScanArgs 
                                                                           acc[rb][cb], 0, 0, 0);
         }
         if (c == n_chunks - 1) {
-            const uint32_t o = ord_begin + s / n_chunks;
-            const uint32_t tile = o * a.tile_stride;
-            const uint32_t r0 = tile * VEC_ROWS;
-            const float nmax = a.tile_nmax[tile];
-            const uint32_t rbase = r0 + wrow + 4 * (lane >> 5);
+            // ---- tile epilogue: this wave's 64 rows belong to ordinal 2p + (wr >> 1) ----
+            const uint32_t oi = 2 * (s / n_chunks) + (wr >> 1);           // ordinal index inside the slab
+            if (oi < n_ord) {
+                const uint32_t o = ord_begin + oi;
+                const uint32_t r0 = o * a.tile_stride * VEC_ROWS;
+                const float nmax = sm.nmax[oi];
+                const uint32_t strip = wr & 1;                               // 64-row strip inside the tile
+                const uint32_t rbase = r0 + strip * 64 + 4 * (lane >> 5);
 #pragma unroll
-            for (int cb = 0; cb < CB; cb++) {
-                const uint32_t col = wcol + cb * 32 + (lane & 31);
-                const uint32_t gq = q0 + col;
-                const float e = cqv[cb] * nmax + 1e-30f;             // >= every row's error radius in this tile
-                if (a.mode == 0) {
-                    float amax = acc[0][cb][0];
-                    bool odd = false;                                  // any non-finite score: never reject on the max
+                for (int cb = 0; cb < CB; cb++) {
+                    const uint32_t col = wcol + cb * 32 + (lane & 31);
+                    const uint32_t gq = q0 + col;
+                    const float e = cqv[cb] * nmax + 1e-30f;             // >= every row's error radius in this tile
+                    if (a.mode == 0) {
+                        float amax = acc[0][cb][0];
+                        bool odd = false;                                  // any non-finite score: never reject on the max
 #pragma unroll
-                    for (int rb = 0; rb < 2; rb++)
+                        for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-                        for (int el = 0; el < 16; el++) { amax = fmaxf(amax, acc[rb][cb][el]); odd = odd || !f32_finite(acc[rb][cb][el]); }
-                    if (gq < a.n_q && (odd || !(amax + e < L1v[cb]))) {
-                        uint64_t* __restrict__ seg = a.seg + ((size_t)slab * a.n_q + gq) * a.seg_cap;
+                            for (int el = 0; el < 16; el++) { amax = fmaxf(amax, acc[rb][cb][el]); odd = odd || !f32_finite(acc[rb][cb][el]); }
+                        if (gq < a.n_q && (odd || !(amax + e < L1v[cb]))) {
+                            uint64_t* __restrict__ seg = a.seg + ((size_t)slab * a.n_q + gq) * a.seg_cap;
+#pragma unroll
+                            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                                for (int el = 0; el < 16; el++) {
+                                    const uint32_t row = rbase + rb * 32 + (el & 3) + 8 * (el >> 2);
+                                    const float sc = acc[rb][cb][el];
+                                    if (!(sc + e < L1v[cb]) && row < a.n_rows && (!a.row_ok || a.row_ok[row] != 0)) {
+                                        const uint32_t slot = atomicAdd(&sm.cnt[col], 1u);      // LDS
+                                        if (slot < a.seg_cap) seg[slot] = ((uint64_t)__float_as_uint(sc) << 32) | row;
+                                    }
+                                }
+                        }
+                    } else if (gq < a.n_q) {
+                        // sample pass: one key per (query, 32-row group) — the group's best lower bound. The k-th largest of
+                        // these maxima is a valid lower bound of the k-th best score (k groups -> k distinct rows).
+                        float best = __uint_as_float(0xFF800000u);
 #pragma unroll
                         for (int rb = 0; rb < 2; rb++)
 #pragma unroll
                             for (int el = 0; el < 16; el++) {
                                 const uint32_t row = rbase + rb * 32 + (el & 3) + 8 * (el >> 2);
-                                const float sc = acc[rb][cb][el];
-                                if (!(sc + e < L1v[cb]) && row < a.n_rows && (!a.row_ok || a.row_ok[row] != 0)) {
-                                    const uint32_t slot = atomicAdd(&sm.cnt[col], 1u);      // LDS
-                                    if (slot < a.seg_cap) seg[slot] = ((uint64_t)__float_as_uint(sc) << 32) | row;
-                                }
+                                bool okr = row < a.n_rows;
+                                if (okr && a.row_ok) okr = a.row_ok[row] != 0;
+                                const float lb = acc[rb][cb][el] - e;
+                                if (okr && f32_finite(lb) && lb > best) best = lb;
                             }
+                        a.gmax[(size_t)gq * a.gstride + (size_t)o * 4 + strip * 2 + (lane >> 5)] = f32_finite(best) ? f32_desc_key(best) : 0xFFFFFFFFu;
                     }
-                } else if (gq < a.n_q) {
-                    // sample pass: one key per (query, 32-row group) — the group's best lower bound. The k-th largest of
-                    // these maxima is a valid lower bound of the k-th best score (k groups -> k distinct rows).
-                    float best = __uint_as_float(0xFF800000u);
-#pragma unroll
-                    for (int rb = 0; rb < 2; rb++)
-#pragma unroll
-                        for (int el = 0; el < 16; el++) {
-                            const uint32_t row = rbase + rb * 32 + (el & 3) + 8 * (el >> 2);
-                            bool okr = row < a.n_rows;
-                            if (okr && a.row_ok) okr = a.row_ok[row] != 0;
-                            const float lb = acc[rb][cb][el] - e;
-                            if (okr && f32_finite(lb) && lb > best) best = lb;
-                        }
-                    a.gmax[(size_t)gq * a.gstride + (size_t)o * 4 + (wave >> 1) * 2 + (lane >> 5)] =
-                        f32_finite(best) ? f32_desc_key(best) : 0xFFFFFFFFu;
                 }
             }
         }
-        vec_glds_wait();                                   // the next step's blocks have landed in the other ring slot
+        vec_glds_wait<XV>();                               // all but the youngest XV DMAs (= X(s+2)) have landed: X(s+1), Q(s+1)
         __syncthreads();
+        xslot = xslot == 2 ? 0 : xslot + 1;
     }
     if (a.mode == 0)
-        for (uint32_t i = t; i < (uint32_t)QT; i += VEC_THREADS)
+        for (uint32_t i = t; i < (uint32_t)QT; i += VEC_HTHREADS)
             if (q0 + i < a.n_q) a.seg_cnt[(size_t)slab * a.n_q + q0 + i] = sm.cnt[i];
 }
 
