@@ -559,17 +559,18 @@ __device__ inline void vec_glds_wait() {        // all but the youngest N vector
 //
 // Workgroup = 8 waves = TWO consecutive tile ordinals (256 rows) x QT queries; wave (wr = wave>>1, wc = wave&1) owns rows
 // [64 wr, 64 wr + 64) x queries [32 CB wc, +32 CB). One workgroup per CU (128 KB of LDS), 2 waves per SIMD.
-// Pipeline (HBM latency under load is ~4K cycles, a step's MFMAs only ~0.5K): the row ring has 3 slots and runs TWO steps
-// ahead, the query ring (L2-resident data) has 2 slots and runs one step ahead. Per step: issue Q(s+1) then X(s+2); multiply
-// slot s; s_waitcnt vmcnt(XV) — loads complete in issue order, so everything but the youngest XV DMAs (= X(s+2)) has
-// landed, i.e. X(s+1) and Q(s+1); barrier.
+// Pipeline (memory latency under load is thousands of cycles, a step's MFMAs only ~0.5K): both rings have 3 slots and run
+// TWO steps ahead. Per step every wave issues its share of Q(s+2) and X(s+2), multiplies slot s, then s_waitcnt
+// vmcnt(XV+QV) — loads complete in issue order, so everything but this step's own DMAs has landed, i.e. X(s+1) and Q(s+1) —
+// and the workgroup barrier. (Dedicated loader waves were measured slower: two waves cannot issue a step's 48 DMAs as fast
+// as eight do, and the limiter of the combined loop is LDS bandwidth — DMA writes + operand reads — not MFMA issue.)
 static const int VEC_HTHREADS = 512;
 static const int VEC_HROWS = 2 * VEC_ROWS;          // rows per workgroup step (two 128-row tiles)
 static const int VEC_HMAX_PER = 2048;               // tile ordinals per slab whose norm maxima are staged in LDS
 template <int QT>
 struct VecHScanSmem {
     alignas(16) uint32_t xs[3][VEC_HROWS * 32];
-    alignas(16) uint32_t qs[2][QT * 32];
+    alignas(16) uint32_t qs[3][QT * 32];
     float nmax[VEC_HMAX_PER];  // tile_nmax of the slab's ordinals
     uint32_t cnt[QT];          // mode 0: candidates of this workgroup per query column
 };
@@ -577,8 +578,6 @@ struct VecHScanSmem {
 template <int CB>
 __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a) {
     constexpr int QT = 64 * CB;
-    constexpr int XV = VEC_HROWS * 8 / VEC_HTHREADS;    // 16-byte pieces per thread per X step (4)
-    constexpr int QV = QT * 8 / VEC_HTHREADS;           // 2 (QT=128) or 1 (QT=64)
     __shared__ VecHScanSmem<QT> sm;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t wr = wave >> 1;
@@ -601,8 +600,10 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
     __syncthreads();                                     // plain loads are done before the first DMA is issued
 
     // Thread t moves pieces idx = t + v*512 of a step: LDS position idx (linear), source piece (idx & 7) ^ ((row >> 1) & 7) of
-    // row idx >> 3 (rows 0..127 = first ordinal, 128..255 = second). Whole tiles / padded query rows exist in memory: no
-    // clamping of rows (scores of rows >= n_rows / queries >= n_q are dropped by the epilogue).
+    // row idx >> 3 (rows 0..127 = first ordinal of the pair, 128..255 = second). Whole tiles / padded query rows exist in
+    // memory: no clamping of rows (scores of rows >= n_rows / queries >= n_q are dropped by the epilogue).
+    constexpr int XV = VEC_HROWS * 8 / VEC_HTHREADS;    // 16-byte pieces per thread per X step (4)
+    constexpr int QV = QT * 8 / VEC_HTHREADS;           // 2 (QT=128) or 1 (QT=64)
     uint32_t src_off[XV];                                // 16-byte units inside a 16 KB block
 #pragma unroll
     for (int v = 0; v < XV; v++) {
@@ -638,12 +639,13 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
     }
     __syncthreads();                                     // (their waits drain nothing of ours: no DMA issued yet)
 
-    vec_f32x16 acc[2][CB];
     const uint32_t last = total_steps - 1;
+    vec_f32x16 acc[2][CB];
     load_q(0, 0);
     load_x(0, 0);
+    load_q(1 < total_steps ? 1 : last, 1);
     load_x(1 < total_steps ? 1 : last, 1);
-    vec_glds_wait<XV>();                                   // X(1) may stay in flight
+    vec_glds_wait<XV + QV>();                              // step 0 has landed, step 1 may stay in flight
     __syncthreads();
     // operand addresses: lane (r = lane&31, h = lane>>5) reads piece 2g+h of its rows = k 16g+8h .. +7: one ds_read_b128 = one
     // MFMA operand; piece position = (2g+h) ^ ((r>>1)&7) (rows of a lane differ by multiples of 32 -> same swizzle)
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
     for (int g = 0; g < VEC_HKC / 16; g++) poff[g] = (((uint32_t)(2 * g) + hh) ^ swz) * 4;
     uint32_t xslot = 0;                                  // s % 3
     for (uint32_t s = 0; s < total_steps; s++) {
-        const uint32_t c = s % n_chunks, qslot = s & 1;
+        const uint32_t c = s % n_chunks;
         if (c == 0) {
 #pragma unroll
             for (int rb = 0; rb < 2; rb++)
@@ -663,10 +665,12 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
                     for (int e = 0; e < 16; e++) acc[rb][cb][e] = 0.0f;
         }
         // no branch around the DMAs: steps past the end re-request the last blocks into slots nobody reads any more
-        load_q(s + 1 < total_steps ? s + 1 : last, qslot ^ 1);
-        load_x(s + 2 < total_steps ? s + 2 : last, xslot >= 1 ? xslot - 1 : 2);       // (s + 2) % 3
+#if !defined(VEC_ABL) || !(VEC_ABL & 4)   // VEC_ABL: tools/ ablation builds only (bit 0 no epilogue, bit 1 no MFMA, bit 2 no DMA)
+        load_q(s + 2 < total_steps ? s + 2 : last, xslot >= 1 ? xslot - 1 : 2);       // (s + 2) % 3
+        load_x(s + 2 < total_steps ? s + 2 : last, xslot >= 1 ? xslot - 1 : 2);
+#endif
         const uint32_t* xa = &sm.xs[xslot][(wrow + (lane & 31)) * 32];
-        const uint32_t* qb = &sm.qs[qslot][(wcol + (lane & 31)) * 32];
+        const uint32_t* qb = &sm.qs[xslot][(wcol + (lane & 31)) * 32];
         uint4 av[2][2], bv[2][CB];
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) av[0][rb] = *(const uint4*)(xa + rb * 32 * 32 + poff[0]);
@@ -681,14 +685,35 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
 #pragma unroll
                 for (int cb = 0; cb < CB; cb++) bv[nx][cb] = *(const uint4*)(qb + cb * 32 * 32 + poff[g + 1 < VEC_HKC / 16 ? g + 1 : g]);
             }
+#if defined(VEC_ABL) && (VEC_ABL & 2)
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) acc[rb][cb][0] += __uint_as_float(av[cur][rb].x ^ bv[cur][cb].y);
+#else
 #pragma unroll
             for (int rb = 0; rb < 2; rb++)
 #pragma unroll
                 for (int cb = 0; cb < CB; cb++)
                     acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vec_bf16x8, av[cur][rb]), __builtin_bit_cast(vec_bf16x8, bv[cur][cb]),
                                                                           acc[rb][cb], 0, 0, 0);
+#endif
         }
+#if defined(VEC_ABL) && (VEC_ABL & 1)
         if (c == n_chunks - 1) {
+            float keep = 0.0f;
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+                    for (int el = 0; el < 16; el++) keep = fmaxf(keep, acc[rb][cb][el]);
+            if (keep == 1.2345e30f) a.seg_cnt[0] = 1;
+        }
+        if (false) {
+#else
+        if (c == n_chunks - 1) {
+#endif
             // ---- tile epilogue: this wave's 64 rows belong to ordinal 2p + (wr >> 1) ----
             const uint32_t oi = 2 * (s / n_chunks) + (wr >> 1);           // ordinal index inside the slab
             if (oi < n_ord) {
@@ -703,13 +728,16 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
                     const uint32_t gq = q0 + col;
                     const float e = cqv[cb] * nmax + 1e-30f;             // >= every row's error radius in this tile
                     if (a.mode == 0) {
+                        // keep a row iff its upper bound reaches L1: !(sc + e < L1), tested as !(sc < L1 - e) — the 1 % slack
+                        // inside c dwarfs the rounding of that subtraction. Non-finite rows / queries have e = inf or NaN, so
+                        // thr is -inf / NaN and every compare below passes: nothing non-finite is ever rejected.
+                        const float thr = L1v[cb] - e;
                         float amax = acc[0][cb][0];
-                        bool odd = false;                                  // any non-finite score: never reject on the max
 #pragma unroll
                         for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-                            for (int el = 0; el < 16; el++) { amax = fmaxf(amax, acc[rb][cb][el]); odd = odd || !f32_finite(acc[rb][cb][el]); }
-                        if (gq < a.n_q && (odd || !(amax + e < L1v[cb]))) {
+                            for (int el = 0; el < 16; el++) amax = fmaxf(amax, acc[rb][cb][el]);       // v_max3_f32 chain
+                        if (gq < a.n_q && !(amax < thr)) {
                             uint64_t* __restrict__ seg = a.seg + ((size_t)slab * a.n_q + gq) * a.seg_cap;
 #pragma unroll
                             for (int rb = 0; rb < 2; rb++)
@@ -717,7 +745,7 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
                                 for (int el = 0; el < 16; el++) {
                                     const uint32_t row = rbase + rb * 32 + (el & 3) + 8 * (el >> 2);
                                     const float sc = acc[rb][cb][el];
-                                    if (!(sc + e < L1v[cb]) && row < a.n_rows && (!a.row_ok || a.row_ok[row] != 0)) {
+                                    if (!(sc < thr) && row < a.n_rows && (!a.row_ok || a.row_ok[row] != 0)) {
                                         const uint32_t slot = atomicAdd(&sm.cnt[col], 1u);      // LDS
                                         if (slot < a.seg_cap) seg[slot] = ((uint64_t)__float_as_uint(sc) << 32) | row;
                                     }
@@ -742,7 +770,7 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
                 }
             }
         }
-        vec_glds_wait<XV>();                               // all but the youngest XV DMAs (= X(s+2)) have landed: X(s+1), Q(s+1)
+        vec_glds_wait<XV + QV>();                          // all but this step's own DMAs have landed: X(s+1), Q(s+1)
         __syncthreads();
         xslot = xslot == 2 ? 0 : xslot + 1;
     }
