@@ -118,11 +118,78 @@ def test_keyword_excluded_ids(pair):
 
 def test_unsupported_queries_are_reported_per_query(pair):
     _, g, _ = pair
-    qs = [T.KwQuery([1, 2]), T.KwQuery([1, 2], filter_ids=[1, 5, 9]), T.KwQuery([1], n_fields=2),
+    qs = [T.KwQuery([1, 2]), T.KwQuery([1], n_fields=5),
           T.KwQuery(list(range(1, 12))), T.KwQuery([1], topster_size=5000)]
     hits = g.keyword_search_batch(qs, k_stride=250)
-    assert list(hits.status) == [0, B.ERR_UNSUPPORTED, B.ERR_UNSUPPORTED, B.ERR_UNSUPPORTED, B.ERR_UNSUPPORTED]
+    assert list(hits.status) == [0, B.ERR_UNSUPPORTED, B.ERR_UNSUPPORTED, B.ERR_UNSUPPORTED]
     assert hits.n_hits[1] == 0 and hits.n_hits[0] > 0
+
+
+@pytest.mark.parametrize("chunk", [0, 1])
+def test_keyword_filter_ids_hits_ids_and_the_reference_match_count(pair, chunk):
+    """filter ids inside the AND loop (take_id, src/or_iterator.cpp:218-272): hits = intersection & filter; num_keyword_matches
+    = the intersection ids the reference's skip-to-next-filter-id loop VISITS (include/or_iterator.h:61-182), also across
+    work-item boundaries (chunk=1: one work item per driver block)"""
+    orc, g, _ = pair
+    rng = np.random.default_rng(31)
+    g.set_option("kw_chunk_blocks", chunk)
+    g.keep_result_ids(True)
+    try:
+        sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+        all12 = H.oracle_keyword(orc, T.KwQuery([1, 2], topster_size=250), ids_cap=4000).result_ids
+        filters = [
+            np.sort(rng.choice(3000, size=40, replace=False)),                 # sparse filter: most visited ids are NOT hits
+            np.sort(rng.choice(3000, size=1500, replace=False)),               # dense filter
+            np.arange(3000),                                                   # everything
+            np.array([0]), np.array([2999]), np.array([1500, 1501, 1502]),
+            all12[::2],                                                        # only true hits
+            np.sort(np.concatenate([all12[:5], [all12[5] + 1 if all12[5] + 1 not in all12 else all12[5]]])),
+            np.arange(0, 700),                                                 # filter ends early: the loop breaks
+            np.arange(2500, 3000),                                             # filter starts late: leading ids are skipped
+        ]
+        qs = []
+        for f in filters:
+            qs.append(T.KwQuery([1, 2], sort=sort, topster_size=250, filter_ids=np.unique(f)))
+            qs.append(T.KwQuery([3], sort=sort, topster_size=0, filter_ids=np.unique(f)))          # topster capacity min(250, |filter|)
+            qs.append(T.KwQuery([2, 1, 4], sort=sort, topster_size=20, filter_ids=np.unique(f)))
+        hits = g.keyword_search_batch(qs, k_stride=250)
+        assert (hits.status == 0).all()
+        for i, q in enumerate(qs):
+            ref = H.oracle_keyword(orc, q, ids_cap=4000)
+            H.assert_hits_equal(hits, i, ref, "filter chunk=%d" % chunk)
+            assert np.array_equal(g.result_ids(i), ref.result_ids)
+        assert hits.n_hits.sum() > 100
+    finally:
+        g.set_option("kw_chunk_blocks", 0)
+        g.keep_result_ids(False)
+
+
+@pytest.mark.parametrize("chunk", [0, 1])
+def test_keyword_filter_ids_with_excluded_ids(pair, chunk):
+    """curated (excluded) ids + filter: after an excluded id the reference advances instead of skipping to the filter"""
+    orc, g, _ = pair
+    rng = np.random.default_rng(32)
+    g.set_option("kw_chunk_blocks", chunk)
+    g.keep_result_ids(True)
+    try:
+        all1 = H.oracle_keyword(orc, T.KwQuery([1], topster_size=250), ids_cap=4000).result_ids
+        qs = []
+        for trial in range(6):
+            filt = np.sort(rng.choice(3000, size=int(rng.integers(5, 900)), replace=False))
+            excl = np.sort(rng.choice(all1, size=int(rng.integers(1, all1.size // 2)), replace=False))
+            if trial == 0:
+                excl = all1[3:40]                                              # a long run of consecutive excluded hits
+            qs.append(T.KwQuery([1], topster_size=250, filter_ids=filt, excluded_ids=excl))
+            qs.append(T.KwQuery([1, 2], topster_size=50, filter_ids=filt, excluded_ids=excl))
+        hits = g.keyword_search_batch(qs, k_stride=250)
+        assert (hits.status == 0).all()
+        for i, q in enumerate(qs):
+            ref = H.oracle_keyword(orc, q, ids_cap=4000)
+            H.assert_hits_equal(hits, i, ref, "filter+excluded chunk=%d" % chunk)
+            assert np.array_equal(g.result_ids(i), ref.result_ids)
+    finally:
+        g.set_option("kw_chunk_blocks", 0)
+        g.keep_result_ids(False)
 
 
 def test_keyword_many_work_items_and_merge(pair):

@@ -103,6 +103,10 @@ struct KwPartials {                  // per work item, stride = k_stride
     uint32_t* n_match;               // num_keyword_matches contribution
     uint32_t* n_emit;                // ids emitted (after exclusion / filter)
     uint64_t* off_words;             // sum over hits of (offsets read + 1 offset_index entry) per token: algorithmic bytes / 4
+    // filtered queries only (num_keyword_matches under filter-driven skipping, see kw_filter_count): matches counted if the
+    // chunk's first hit is NOT counted (n_match) / IS counted (n_match1), filter rank of the first / last hit, and
+    // flags = nonempty | carry_out(first not counted) << 1 | carry_out(first counted) << 2
+    uint32_t* n_match1; uint32_t* first_rank; uint32_t* last_rank; uint32_t* fflags;
     uint32_t k_stride;
 };
 
@@ -491,6 +495,10 @@ struct KwSmem {
     uint32_t q1_cnt, qf_cnt, tk_cnt, have_thr;
     uint32_t n_match, n_emit;
     unsigned long long off_words;
+    // filter-id bookkeeping (take_id with filter ids, src/or_iterator.cpp:218-272)
+    uint32_t f_rank[KW_THREADS];             // filter rank (# filter ids <= hit) of the hits of the current score batch
+    uint8_t f_ex[KW_THREADS];                // hit is an excluded id
+    uint32_t f_first, f_frank, f_rp, f_ep, f_c0, f_c1, f_cnt0, f_cnt1;
 };
 
 template <int TMAX, int CAP>
@@ -500,25 +508,67 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP>& sm, const IndexView& ix
     if (sm.tk_cnt + KW_THREADS > (uint32_t)CAP) topk_compact<CAP>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
     const uint32_t t = threadIdx.x;
     const bool active = t < n_take;
-    bool emit = false;
-    uint32_t seq_id = 0;
+    bool emit = false, excl = false;
+    uint32_t seq_id = 0, rank = 0;
     ScoredHit h;
     h.s0 = h.s1 = h.s2 = h.text_match = 0; h.off_words = 0;
     if (active) {
         seq_id = sm.qf_id[t];
         emit = true;
-        // take_id(): excluded ids (src/or_iterator.cpp:222-229). Filter ids are resolved before the hit is queued.
+        // take_id(): excluded ids first (src/or_iterator.cpp:222-229) ...
         if (q.n_excl) {
             const uint32_t* ex = aux_ids + q.aux_off;
             uint32_t lo = 0, hi = q.n_excl;
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ex[mid] < seq_id) lo = mid + 1; else hi = mid; }
-            if (lo < q.n_excl && ex[lo] == seq_id) emit = false;
+            if (lo < q.n_excl && ex[lo] == seq_id) { emit = false; excl = true; }
+        }
+        // ... then the filter ids (:232-253): the hit is taken iff it is a filter id. rank = # filter ids <= hit (upper bound)
+        if (q.n_filt) {
+            const uint32_t* fl = aux_ids + q.aux_off + q.n_excl;
+            uint32_t lo = 0, hi = q.n_filt;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (fl[mid] <= seq_id) lo = mid + 1; else hi = mid; }
+            rank = lo;
+            if (!(rank > 0 && fl[rank - 1] == seq_id)) emit = false;
         }
         if (emit) {
             uint32_t pos[TMAX];
 #pragma unroll
             for (int k = 0; k < TMAX; k++) pos[k] = sm.qf_pos[k][t];
             h = score_hit<TMAX>(ix, q, seq_id, pos);
+        }
+    }
+    // num_keyword_matches under a filter (kw_filter_count below): which intersection ids does the reference's loop VISIT?
+    if (q.n_filt) {
+        if (active) { sm.f_rank[t] = rank; sm.f_ex[t] = excl ? 1 : 0; }
+        __syncthreads();
+        if (q.n_excl == 0) {
+            // a visited id = the first intersection id at or after some filter id = a hit whose filter rank exceeds its predecessor's.
+            // The chunk's very first hit depends on the previous chunk (resolved by kw_merge_kernel): it is left out of f_cnt0.
+            bool a = false;
+            if (active) {
+                if (t == 0) a = sm.f_first ? false : rank > sm.f_rp;
+                else a = rank > sm.f_rank[t - 1];
+            }
+            const unsigned long long m = __ballot(a ? 1 : 0);
+            if ((t & 63) == 0 && m) atomicAdd(&sm.f_cnt0, (uint32_t)__popcll(m));
+            __syncthreads();
+            if (t == 0) {
+                if (sm.f_first) { sm.f_frank = sm.f_rank[0]; sm.f_first = 0; }
+                sm.f_rp = sm.f_rank[n_take - 1];
+            }
+        } else if (t == 0) {
+            // exclusions AND a filter (curated hits + filter_by; rare): after an excluded id the reference advances to the very next
+            // intersection id instead of skipping to the filter (include/or_iterator.h:161-176), so "visited" becomes a first-order
+            // recurrence c_j = (rank_j > rank_{j-1}) | (c_{j-1} & excluded_{j-1}); evaluated in order by one thread, for both
+            // possible values of the chunk's first c (f_c0 / f_c1).
+            uint32_t c0 = sm.f_c0, c1 = sm.f_c1, ep = sm.f_ep, rp = sm.f_rp, first = sm.f_first, n0 = sm.f_cnt0, n1 = sm.f_cnt1;
+            for (uint32_t j = 0; j < n_take; j++) {
+                const uint32_t r = sm.f_rank[j], e = sm.f_ex[j];
+                if (first) { sm.f_frank = r; c0 = 0; c1 = 1; first = 0; }
+                else { const uint32_t a = r > rp ? 1u : 0u; c0 = a | (c0 & ep); c1 = a | (c1 & ep); }
+                n0 += c0; n1 += c1; ep = e; rp = r;
+            }
+            sm.f_c0 = c0; sm.f_c1 = c1; sm.f_ep = ep; sm.f_rp = rp; sm.f_first = first; sm.f_cnt0 = n0; sm.f_cnt1 = n1;
         }
     }
     // ordered emission of matched ids (id_buff, src/index.cpp:5549)
@@ -611,14 +661,16 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
         uint32_t* dst = (uint32_t*)&sq;
         for (uint32_t i = t; i < sizeof(KwQueryDev) / 4; i += KW_THREADS) dst[i] = src[i];
     }
-    if (t == 0) { sm.q1_cnt = 0; sm.qf_cnt = 0; sm.tk_cnt = 0; sm.have_thr = 0; sm.n_match = 0; sm.n_emit = 0; sm.off_words = 0; }
+    if (t == 0) {
+        sm.q1_cnt = 0; sm.qf_cnt = 0; sm.tk_cnt = 0; sm.have_thr = 0; sm.n_match = 0; sm.n_emit = 0; sm.off_words = 0;
+        sm.f_first = 1; sm.f_frank = 0; sm.f_rp = 0; sm.f_ep = 0; sm.f_c0 = 0; sm.f_c1 = 0; sm.f_cnt0 = 0; sm.f_cnt1 = 0;
+    }
     __syncthreads();
     const KwQueryDev& q = sq;
     const uint32_t T = q.n_lists;
     const ListDesc dA = ix.lists[q.list[q.probe_order[0]]];
     const uint32_t ids_out_base = (uint32_t)0;
     uint32_t* my_ids_out = ids_out ? ids_out + q.ids_out_off + wi.ids_out_off : nullptr;
-    const uint32_t* filt = aux_ids + q.aux_off + q.n_excl;
 
     const ListDesc dB = ix.lists[q.list[q.probe_order[T >= 2 ? 1 : 0]]];
     const uint32_t* __restrict__ blB = ix.blk_last + dB.blk_base;
@@ -628,7 +680,6 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
     const uint32_t* __restrict__ idwB = ix.ids_payload + dB.ids_base;
     const uint32_t lane = t & 63;
     const BlockIds PAD = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
-    const uint32_t n_filt = q.n_filt;
 
     // Doc ids of a block are stored as fixed-width deltas from the block's first id: 16 bits when the block's id
     // range fits (the common case), else 32 (tsgpu_pack.h) — one aligned load per id, no bit arithmetic.
@@ -709,13 +760,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
         bool ok = t < m_n;
         const uint32_t id = ok ? mA.first_id + araw : 0xFFFFFFFFu;
         uint32_t p1 = 0;
-        // filter ids (sorted whitelist): membership is decided per candidate; the reference's
-        // filter-driven skipping only changes WHICH matches are counted, handled in the host shim (v1: no filter in-kernel)
-        if (ok && n_filt) {
-            uint32_t lo = 0, hi = n_filt;
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (filt[mid] < id) lo = mid + 1; else hi = mid; }
-            ok = (lo < n_filt && filt[lo] == id);
-        }
+        // (filter ids are applied to complete hits in kw_score_stage: the reference's num_keyword_matches needs the whole intersection)
         KW_PROF(0)
         const Plan C = P;                      // this block's plan; P becomes the next block's below
         // ---- stage 1: merge with the second-shortest list B ----
@@ -872,12 +917,40 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
     }
     if (t == 0) {
         part.cnt[blockIdx.x] = n;
-        part.n_match[blockIdx.x] = sm.n_match;
         part.n_emit[blockIdx.x] = sm.n_emit;
         part.off_words[blockIdx.x] = sm.off_words;
+        if (q.n_filt == 0) part.n_match[blockIdx.x] = sm.n_match;
+        else {
+            const uint32_t nonempty = sm.f_first ? 0u : 1u;
+            const bool seq = q.n_excl != 0;                       // sequential mode tracked both variants itself
+            part.n_match[blockIdx.x] = sm.f_cnt0;
+            part.n_match1[blockIdx.x] = seq ? sm.f_cnt1 : sm.f_cnt0 + nonempty;
+            part.first_rank[blockIdx.x] = sm.f_frank;
+            part.last_rank[blockIdx.x] = sm.f_rp;
+            part.fflags[blockIdx.x] = nonempty | (seq ? ((sm.f_c0 & sm.f_ep) << 1) | ((sm.f_c1 & sm.f_ep) << 2) : 0u);
+        }
     }
     KW_PROF(9)
     KW_PROF_FLUSH(ix.prof)
+}
+
+// num_keyword_matches of a FILTERED query (include/or_iterator.h:61-182 with istate.filter_ids): the reference counts the
+// intersection ids its loop lands on, and after every non-excluded one it skips all lists to the next filter id. So an
+// intersection id x_j is counted iff a filter id lies in (x_{j-1}, x_j] — its filter rank exceeds its predecessor's — or the
+// previous visited id was excluded (then the loop just advances to the next intersection id). Every work item (a contiguous
+// slice of the intersection) reports its count for both possible states of its first hit; this chains the slices in order.
+__device__ inline unsigned long long kw_filter_count(const KwPartials& part, uint32_t first_work, uint32_t n_work) {
+    unsigned long long total = 0;
+    uint32_t r_prev = 0, carry = 0;
+    for (uint32_t w = first_work; w < first_work + n_work; w++) {
+        const uint32_t fl = part.fflags[w];
+        if (!(fl & 1u)) continue;                                  // no hit in this slice: the state carries over
+        const uint32_t u = (part.first_rank[w] > r_prev ? 1u : 0u) | carry;
+        total += u ? part.n_match1[w] : part.n_match[w];
+        carry = u ? (fl >> 2) & 1u : (fl >> 1) & 1u;
+        r_prev = part.last_rank[w];
+    }
+    return total;
 }
 
 // grid = queries; folds a query's partials into the final order and writes the tsgpu_hits slots
@@ -909,7 +982,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
             out.vector_distance[ob + i] = -1.0f;
             out.match_score_index[ob + i] = (int8_t)msi;
         }
-        if (t == 0) { s_nm = part.n_match[w]; s_ow = part.off_words[w]; }
+        if (t == 0) { s_nm = q.n_filt ? kw_filter_count(part, q.first_work, 1) : part.n_match[w]; s_ow = part.off_words[w]; }
     } else {
         for (uint32_t w = q.first_work; w < q.first_work + q.n_work; w++) {
             const uint32_t nw = part.cnt[w];
@@ -921,9 +994,10 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
                 tk.s2[base_slot + i] = part.s2[base + i]; tk.key[base_slot + i] = part.key[base + i];
             }
             __syncthreads();
-            if (t == 0) { s_cnt = base_slot + nw; s_nm += part.n_match[w]; s_ow += part.off_words[w]; }
+            if (t == 0) { s_cnt = base_slot + nw; if (!q.n_filt) s_nm += part.n_match[w]; s_ow += part.off_words[w]; }
             __syncthreads();
         }
+        if (t == 0 && q.n_filt) s_nm = kw_filter_count(part, q.first_work, q.n_work);
         topk_compact<CAP>(tk, &s_cnt, q.k, thr, &s_have_thr);
         n = s_cnt;
         for (uint32_t i = t; i < n; i += KW_THREADS) {

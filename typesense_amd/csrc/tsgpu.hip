@@ -109,7 +109,7 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
     tsgpu_vec_destroy_all(ctx);
     DevBuf* bufs[] = {&ctx->snap.lists, &ctx->snap.blk_last, &ctx->snap.blk_ids, &ctx->snap.blk_meta, &ctx->snap.ids_payload, &ctx->snap.payload, &ctx->d_col_ptrs, &ctx->d_col_len,
                       &ctx->d_queries, &ctx->d_work, &ctx->d_aux, &ctx->d_ids_out, &ctx->d_part_s0, &ctx->d_part_s1, &ctx->d_part_s2,
-                      &ctx->d_part_key, &ctx->d_part_cnt, &ctx->d_part_nm, &ctx->d_part_ne, &ctx->d_part_ow, &ctx->d_out_keys,
+                      &ctx->d_part_key, &ctx->d_part_cnt, &ctx->d_part_nm, &ctx->d_part_ne, &ctx->d_part_ow, &ctx->d_part_f, &ctx->d_out_keys,
                       &ctx->d_out_scores, &ctx->d_out_tm, &ctx->d_out_vd, &ctx->d_out_msi, &ctx->d_out_nh, &ctx->d_out_nm, &ctx->d_out_ow, &ctx->d_prof};
     for (auto* b : bufs) b->release();
     for (auto& c : ctx->columns) c.data.release();
@@ -428,7 +428,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         if (fit == ctx->fields.end()) { P.status[i] = TSGPU_ERR_NOT_FOUND; continue; }
         if (fit->second.is_array) { unsupported("array field"); continue; }
         if (in.n_sort > TSGPU_MAX_SORT_KEYS) { P.status[i] = TSGPU_ERR_INVALID; continue; }
-        if (in.n_filter != 0) { unsupported("filter ids"); continue; }   // next
+        if (in.n_filter != 0 && !in.filter_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
         if (in.match_type > TSGPU_SUM_SCORE) { P.status[i] = TSGPU_ERR_INVALID; continue; }
         bool bad_sort = false;
         for (uint32_t s = 0; s < in.n_sort; s++) {
@@ -438,8 +438,10 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         }
         if (bad_sort) { unsupported("sort"); continue; }
         uint32_t k = in.topster_size;
-        if (k == 0) k = TSGPU_DEFAULT_TOPSTER_SIZE;
-        k = std::min<uint32_t>(k, std::max<uint32_t>(ctx->num_docs, 1));   // src/index.cpp:3510-3512
+        if (k == 0) {                                                      // src/index.cpp:3506-3512
+            k = TSGPU_DEFAULT_TOPSTER_SIZE;
+            k = in.n_filter ? std::min<uint32_t>(k, in.n_filter) : std::min<uint32_t>(k, std::max<uint32_t>(ctx->num_docs, 1));
+        } else k = std::min<uint32_t>(k, std::max<uint32_t>(ctx->num_docs, 1));
         k = std::max<uint32_t>(k, 1);
         if (k > TSGPU_MAX_TOPK) { unsupported("topster_size"); continue; }
         if (in.deadline_us != 0 && now > in.deadline_us) { P.status[i] = TSGPU_ERR_DEADLINE; P.cutoff[i] = 1; continue; }
@@ -471,11 +473,12 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         P.max_k = std::max(P.max_k, k);
         q.aux_off = (uint32_t)P.aux.size();
         q.n_excl = in.n_excluded;
-        q.n_filt = 0;
+        q.n_filt = in.n_filter;
         if (in.n_excluded) {
             if (!in.excluded_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
             P.aux.insert(P.aux.end(), in.excluded_ids, in.excluded_ids + in.n_excluded);
         }
+        if (in.n_filter) P.aux.insert(P.aux.end(), in.filter_ids, in.filter_ids + in.n_filter);   // sorted ascending, unique (filter_result_t::docs)
         if (nl == 0) continue;   // no token in the index: zero hits (intersect case 0, or_iterator.h:67-68)
         // probe order: ascending list length, stable
         uint8_t ord[KW_MAX_TOKENS];
@@ -545,6 +548,7 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
         if ((rc = ctx->d_part_nm.reserve(pw * 4))) return rc;
         if ((rc = ctx->d_part_ne.reserve(pw * 4))) return rc;
         if ((rc = ctx->d_part_ow.reserve(pw * 8))) return rc;
+        if ((rc = ctx->d_part_f.reserve(pw * 16))) return rc;
         if ((rc = ctx->d_out_ow.reserve((size_t)n_queries * 8))) return rc;
         uint32_t* ids_out = nullptr;
         if (ctx->keep_ids) {
@@ -555,6 +559,7 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
         part.s0 = ctx->d_part_s0.as<int64_t>(); part.s1 = ctx->d_part_s1.as<int64_t>(); part.s2 = ctx->d_part_s2.as<int64_t>();
         part.key = ctx->d_part_key.as<int64_t>(); part.cnt = ctx->d_part_cnt.as<uint32_t>(); part.n_match = ctx->d_part_nm.as<uint32_t>();
         part.n_emit = ctx->d_part_ne.as<uint32_t>(); part.off_words = ctx->d_part_ow.as<uint64_t>(); part.k_stride = KS;
+        part.n_match1 = ctx->d_part_f.as<uint32_t>(); part.first_rank = part.n_match1 + pw; part.last_rank = part.first_rank + pw; part.fflags = part.last_rank + pw;
 
         const size_t slots = (size_t)n_queries * KS;
         KwOut o;
@@ -591,6 +596,7 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
             const size_t sh = P.work_small.size();
             pb.s0 += sh * KS; pb.s1 += sh * KS; pb.s2 += sh * KS; pb.key += sh * KS;
             pb.cnt += sh; pb.n_match += sh; pb.n_emit += sh; pb.off_words += sh;
+            pb.n_match1 += sh; pb.first_rank += sh; pb.last_rank += sh; pb.fflags += sh;
             launch_search_cap<KW_MAX_TOKENS>(cap, s, (uint32_t)P.work_big.size(), v, dq, dw + sh, pb, daux, ids_out);
         }
         TSGPU_HIP_TRY(hipEventRecord(ctx->ev[1], s));

@@ -96,7 +96,7 @@ struct tsgpu_ctx {
 
     // keyword batch scratch
     tsgpu::DevBuf d_queries, d_work, d_aux, d_ids_out;
-    tsgpu::DevBuf d_part_s0, d_part_s1, d_part_s2, d_part_key, d_part_cnt, d_part_nm, d_part_ne, d_part_ow;
+    tsgpu::DevBuf d_part_s0, d_part_s1, d_part_s2, d_part_key, d_part_cnt, d_part_nm, d_part_ne, d_part_ow, d_part_f;
     tsgpu::DevBuf d_out_keys, d_out_scores, d_out_tm, d_out_vd, d_out_msi, d_out_nh, d_out_nm, d_out_ow;
     tsgpu::DevBuf d_prof;                            // TSGPU_PROF builds only (null otherwise)
     tsgpu::PinBuf h_stage, h_out;
