@@ -57,8 +57,35 @@ def build_pair(docs, lib_path, points=None, n_columns=1, gpu=None):
     return orc, g
 
 
+def build_pair_fields(docs_per_field, lib_path, points=None):
+    """docs_per_field: list of [n_docs][tokens] term-id arrays, one plain string field each (field ids 0..F-1); a token id 0 =
+    no token at that position (fields may be shorter / empty for a document). Returns (oracle index, GpuIndex)."""
+    n_fields = len(docs_per_field)
+    n_docs = docs_per_field[0].shape[0]
+    orc = O.OracleIndex(n_fields, 1)
+    for f, docs in enumerate(docs_per_field):
+        for d in range(n_docs):
+            toks = docs[d][docs[d] != 0]
+            if toks.size:
+                orc.index_plain(d, f, toks)
+    if points is None:
+        points = points_of(n_docs)
+    orc.set_num_docs(n_docs)
+    orc.set_sort_dense(0, points)
+    g = T.GpuIndex(0, lib_path)
+    for f in range(n_fields):
+        g.field_create(f, False)
+        for term in orc.terms(f):
+            ids, oi, off = orc.dump_posting(f, int(term))
+            g.term_upsert(f, int(term), ids, oi, off)
+    g.column_set(0, points)
+    g.set_num_docs(n_docs)
+    g.commit()
+    return orc, g
+
+
 def oracle_keyword(orc, q, cap=2048, ids_cap=0):
-    oq = orc.make_query(q.tokens, fields=((q.field, q.weight),),
+    oq = orc.make_query(q.tokens, fields=tuple(q.fields),
                         sort=tuple((s[0], s[2], s[1]) for s in q.sort),
                         fetch_size=10, topster_size=q.topster_size,
                         match_type=q.match_type, prioritize_exact_match=q.prioritize_exact_match,

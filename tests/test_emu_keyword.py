@@ -264,3 +264,50 @@ def test_stage1_block_merge_windows_fallback_and_exhaustion(chunk, tile):
         H.assert_hits_equal(hits, i, ref, "stage1 chunk=%d" % chunk)
         assert np.array_equal(g.result_ids(i), ref.result_ids)
     g.close()
+
+
+@pytest.fixture(scope="module")
+def pair3():
+    """three plain string fields over the same 2500 documents; shorter fields hold zeros (= no token) in most positions"""
+    rng = np.random.default_rng(41)
+    title = H.zipf_docs(2500, 120, 6, seed=11)
+    body = H.zipf_docs(2500, 120, 14, seed=12)
+    tags = H.zipf_docs(2500, 120, 4, seed=13)
+    title[rng.random(title.shape) < 0.3] = 0
+    tags[rng.random(tags.shape) < 0.6] = 0
+    body[rng.random(2500) < 0.1] = 0                                         # some documents have no body at all
+    orc, g = H.build_pair_fields([title, body, tags], H.emu_lib_path())
+    yield orc, g
+    g.close()
+
+
+@pytest.mark.parametrize("chunk", [0, 1])
+def test_multi_field_union_per_token_and_field_aggregation(pair3, chunk):
+    """query_by over 2-3 fields: token = OR over the fields, query = AND over tokens (or_iterator_t); score_results2 per field
+    over the tokens that field holds, folded by match_type with field weights / num_matching_fields (compute_aggregated_score)"""
+    orc, g = pair3
+    g.set_option("kw_chunk_blocks", chunk)
+    g.keep_result_ids(True)
+    try:
+        sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+        f3, f2 = [(0, 15), (1, 7), (2, 3)], [(2, 2), (0, 9)]
+        qs = []
+        for toks in ([1], [2, 1], [3, 1, 2], [5, 9], [1, 2, 3, 4], [7, 1, 2, 3, 6], [119], [9999, 2], [4, 4]):
+            qs.append(T.KwQuery(toks, fields=f3, sort=sort, topster_size=250))
+            qs.append(T.KwQuery(toks, fields=f2, sort=sort, topster_size=30, match_type=B.MAX_WEIGHT))
+            qs.append(T.KwQuery(toks, fields=f3, sort=sort, topster_size=250, match_type=B.SUM_SCORE, prioritize_token_position=True))
+            qs.append(T.KwQuery(toks, fields=[(1, 1), (0, 1)], topster_size=250, prioritize_num_matching_fields=False, prioritize_exact_match=False))
+        qs.append(T.KwQuery([1, 2], fields=f3, sort=sort, topster_size=250, excluded_ids=np.arange(0, 2500, 7)))
+        hits = g.keyword_search_batch(qs, k_stride=250)
+        assert (hits.status == 0).all()
+        for i, q in enumerate(qs):
+            ref = H.oracle_keyword(orc, q, ids_cap=4000)
+            H.assert_hits_equal(hits, i, ref, "multi-field chunk=%d q=%s" % (chunk, q.tokens))
+            assert np.array_equal(g.result_ids(i), ref.result_ids)
+        assert hits.n_hits.sum() > 500
+        # not accelerated (yet): filter ids together with several fields -> the caller's CPU path for that query
+        h2 = g.keyword_search_batch([T.KwQuery([1], fields=f2, filter_ids=[1, 2, 3])], k_stride=250)
+        assert h2.status[0] == B.ERR_UNSUPPORTED
+    finally:
+        g.set_option("kw_chunk_blocks", 0)
+        g.keep_result_ids(False)

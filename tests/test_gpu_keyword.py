@@ -165,3 +165,55 @@ def test_size_independent_properties(c2m):
         if n:
             tm = h3.text_match[i, :n].astype(np.uint64)
             assert ((tm >> np.uint64(59)) == 3).all() and ((tm & np.uint64(7)) == 1).all()
+
+
+# ---- the emulator bodies against the real library (filter ids inside the AND loop, several query_by fields) ----
+from tests import test_emu_keyword as EK
+
+
+@pytest.fixture(scope="module")
+def pair():
+    docs = H.zipf_docs(3000, 300, 12, seed=1)
+    orc, g = H.build_pair(docs, H.gpu_lib_path())
+    yield orc, g, docs
+    g.close()
+
+
+@pytest.fixture(scope="module")
+def pair3():
+    rng = np.random.default_rng(41)
+    title = H.zipf_docs(2500, 120, 6, seed=11)
+    body = H.zipf_docs(2500, 120, 14, seed=12)
+    tags = H.zipf_docs(2500, 120, 4, seed=13)
+    title[rng.random(title.shape) < 0.3] = 0
+    tags[rng.random(tags.shape) < 0.6] = 0
+    body[rng.random(2500) < 0.1] = 0
+    orc, g = H.build_pair_fields([title, body, tags], H.gpu_lib_path())
+    yield orc, g
+    g.close()
+
+
+test_keyword_filter_ids_hits_ids_and_the_reference_match_count = EK.test_keyword_filter_ids_hits_ids_and_the_reference_match_count
+test_keyword_filter_ids_with_excluded_ids = EK.test_keyword_filter_ids_with_excluded_ids
+test_multi_field_union_per_token_and_field_aggregation = EK.test_multi_field_union_per_token_and_field_aggregation
+
+
+def test_filter_ids_on_2m_docs_multi_chunk(c2m):
+    """filters of very different selectivity against lists of ~1M ids: hits, match counts (chained over many work items), ids"""
+    g = c2m.g
+    rng = np.random.default_rng(5)
+    g.keep_result_ids(True)
+    try:
+        qs = []
+        for sel in (0.5, 0.01, 0.0001):
+            filt = np.unique(rng.integers(0, 2_000_000, size=int(2_000_000 * sel))).astype(np.uint32)
+            for toks in ([1, 2], [3, 1, 2], [2]):
+                qs.append(T.KwQuery(toks, sort=SORT, topster_size=250, filter_ids=filt))
+        hits = g.keyword_search_batch(qs, k_stride=250)
+        assert (hits.status == 0).all()
+        for i, q in enumerate(qs):
+            ref = c2m.oracle(q, ids_cap=2_000_000)
+            H.assert_hits_equal(hits, i, ref, "2M filter")
+            assert np.array_equal(g.result_ids(i), ref.result_ids)
+    finally:
+        g.keep_result_ids(False)

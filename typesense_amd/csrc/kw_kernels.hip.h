@@ -49,6 +49,8 @@ namespace tsgpu {
 static const int KW_THREADS = 256;
 static const int KW_QCAP = 512;            // LDS queue capacity (>= 255 leftover + 256 new)
 static const int KW_MAX_TOKENS = 10;       // TSGPU_MAX_QUERY_TOKENS
+static const int KW_MAX_FIELDS = 4;        // query_by fields per query (tsgpu_kw_query::field_ids)
+static const uint32_t KW_NONE = 0xFFFFFFFFu;
 static const uint32_t KW_WINDOW_SIZE = 10; // WINDOW_SIZE, include/match_score.h:11
 #ifndef TSGPU_KW_TILE_WORDS
 #define TSGPU_KW_TILE_WORDS 2048
@@ -69,6 +71,7 @@ struct IndexView {
     uint32_t n_columns;
     uint32_t num_docs;
     unsigned long long* prof;        // TSGPU_PROF builds: 13 counters; else null
+    const struct KwQueryMF* mf;      // multi-field queries of the batch (KwQueryDev::mf_index)
 };
 
 struct KwQueryDev {                  // one search_across_fields call
@@ -89,10 +92,21 @@ struct KwQueryDev {                  // one search_across_fields call
     uint32_t first_work, n_work;     // this query's work items (contiguous)
     uint32_t aux_off, n_excl, n_filt;  // excluded ids then filter ids in the aux id arena
     uint64_t ids_out_off;            // where this query's matched ids go (if kept)
+    uint32_t mf_index;               // KW_NONE = one query_by field; else index into IndexView::mf
+    uint32_t pad2;
+};
+
+// query_by over several fields (get_field_token_its, src/index.cpp:5598-5660): token t is the UNION over the fields of its
+// posting lists (or_iterator_t, src/or_iterator.cpp:95-171), the query the AND over tokens of those unions
+struct KwQueryMF {
+    uint32_t list[KW_MAX_TOKENS][KW_MAX_FIELDS];   // list handle of (found token t, field f) or KW_NONE
+    int32_t weight[KW_MAX_FIELDS];                 // the_fields[f].weight
+    uint32_t n_fields;
+    uint32_t driver_token;                         // the token whose lists (one work item group per field) drive the scan
 };
 
 struct KwWorkItem {
-    uint32_t query;
+    uint32_t query;                  // multi-field work items: | driver field << 28
     uint32_t blk_begin, blk_end;     // driver-list block range
     uint32_t ids_out_off;            // offset (relative to the query's ids_out_off) of this chunk's id segment
 };
@@ -345,15 +359,12 @@ __device__ inline uint64_t pack_match_score(uint32_t words_present, uint32_t uni
 
 struct ScoredHit { int64_t s0, s1, s2; int64_t text_match; uint32_t off_words; };
 
-// score_results2 + compute_aggregated_score + compute_sort_scores for ONE query_by field (plain string)
+// score_results2 (src/index.cpp:6966-7098) for ONE plain-string field: `runs[0..n_present)` = the occurrences of the query tokens
+// that this field holds for the document, in query-token order (field_to_tokens[fi], src/index.cpp:5250-5265)
 template <int TMAX>
-__device__ inline ScoredHit score_hit(const IndexView& ix, const KwQueryDev& q, uint32_t seq_id, const uint32_t (&pos)[TMAX]) {
-    const uint32_t T = q.n_lists;
-    uint64_t field_match_score;
-    uint32_t off_words = 0;
-    if (T <= 1) {   // single-token fast path, src/index.cpp:6985-6996
-        const TokRun r = load_run(ix, ix.lists[q.list[0]], pos[0]);
-        off_words = r.raw_len + 1;
+__device__ inline uint64_t field_match_score(const KwQueryDev& q, const TokRun (&runs)[TMAX], uint32_t n_present) {
+    if (n_present <= 1) {   // single-token fast path, src/index.cpp:6985-6996
+        const TokRun& r = runs[0];
         const bool single_exact_query_token = (q.total_cost == 0 && q.n_query_tokens == 1);
         uint32_t verbatim = 0;
         if (q.prio_exact && single_exact_query_token) {
@@ -365,38 +376,38 @@ __device__ inline ScoredHit score_hit(const IndexView& ix, const KwQueryDev& q, 
             const uint32_t lastv = run_raw(r, r.raw_len - 1);
             max_offset = (lastv == 0 ? run_raw(r, r.raw_len - 2) : lastv) & 0xFF;
         }
-        field_match_score = pack_match_score(1, 1, q.total_cost, 0, verbatim, max_offset, 1);
-    } else {
-        TokRun runs[TMAX];
-#pragma unroll
-        for (int t = 0; t < TMAX; t++) {
-            if ((uint32_t)t < T) { runs[t] = load_run(ix, ix.lists[q.list[t]], pos[t]); off_words += runs[t].raw_len + 1; }
-            else { runs[t].w = nullptr; runs[t].start = 0; runs[t].n = 0; runs[t].bits = 0; runs[t].base = 0; runs[t].last_flag = 0; runs[t].raw_len = 0; }
-        }
-        const MatchOut m = match_window<TMAX>(runs, T, q.prio_exact != 0);
-        const uint64_t s = pack_match_score(m.words_present, T, q.total_cost, m.distance, m.exact_match, m.max_offset, 1);
-        // unpack / re-pack of src/index.cpp:7031-7072 (no synonyms): offset component kept only if prioritize_token_position
-        const uint64_t this_words_present = (s >> 40) & 0xFF, unique_words = (s >> 32) & 0xFF, typo_score = (s >> 24) & 0xFF;
-        const uint64_t proximity = (s >> 16) & 0xFF, verbatim = (s >> 12) & 0xF;
-        const uint64_t offset_score = q.prio_pos ? ((s >> 4) & 0xFF) : 0, synonym_score = s & 0xF;
-        field_match_score = (this_words_present << 40) | (unique_words << 32) | (typo_score << 24) | (proximity << 16) |
-                            (verbatim << 12) | (offset_score << 4) | synonym_score;
+        return pack_match_score(1, 1, q.total_cost, 0, verbatim, max_offset, 1);
     }
-    // compute_aggregated_score, src/index.cpp:5296-5382, one field
-    int64_t best_field_match_score = 0, best_field_weight = 0, sum_field_weighted_score = 0;
-    const int64_t fms = (int64_t)field_match_score, field_weight = q.weight;
-    if (q.match_type == 0 && fms > best_field_match_score) { best_field_match_score = fms; best_field_weight = field_weight; }
-    if (q.match_type == 1 && field_weight > best_field_weight) { best_field_weight = field_weight; best_field_match_score = fms; }
-    if (q.match_type == 2) sum_field_weighted_score += field_weight * fms;
-    uint64_t query_len = (best_field_match_score == 0) ? 0 : (T < 15 ? T : 15);
-    const uint64_t max_field_weight = (uint64_t)best_field_weight < 15 ? (uint64_t)best_field_weight : 15;   // std::min<size_t>(15, w)
-    const uint64_t num_matching_fields = q.prio_nfields ? 1 : 0;
-    uint64_t agg;
-    if (q.match_type == 0) agg = (query_len << 59) | ((uint64_t)best_field_match_score << 11) | (max_field_weight << 3) | num_matching_fields;
-    else if (q.match_type == 1) agg = (query_len << 59) | (max_field_weight << 51) | ((uint64_t)best_field_match_score << 3) | num_matching_fields;
-    else agg = (query_len << 59) | ((uint64_t)sum_field_weighted_score << 3) | num_matching_fields;
+    const MatchOut m = match_window<TMAX>(runs, n_present, q.prio_exact != 0);
+    const uint64_t s = pack_match_score(m.words_present, n_present, q.total_cost, m.distance, m.exact_match, m.max_offset, 1);
+    // unpack / re-pack of src/index.cpp:7031-7072 (no synonyms): offset component kept only if prioritize_token_position
+    const uint64_t this_words_present = (s >> 40) & 0xFF, unique_words = (s >> 32) & 0xFF, typo_score = (s >> 24) & 0xFF;
+    const uint64_t proximity = (s >> 16) & 0xFF, verbatim = (s >> 12) & 0xF;
+    const uint64_t offset_score = q.prio_pos ? ((s >> 4) & 0xFF) : 0, synonym_score = s & 0xF;
+    return (this_words_present << 40) | (unique_words << 32) | (typo_score << 24) | (proximity << 16) |
+           (verbatim << 12) | (offset_score << 4) | synonym_score;
+}
 
-    // compute_sort_scores, src/index.cpp:5662-5907 (text_match / seq_id / int64 column) + :5541-5544 override
+// the per-field fold of compute_aggregated_score (src/index.cpp:5296-5330) and its packing (:5332-5382)
+struct AggState { int64_t best_fms = 0, best_w = 0, sum = 0; uint32_t n_fields = 0; };
+__device__ inline void agg_add(AggState& st, uint32_t match_type, uint64_t field_score, int64_t field_weight) {
+    const int64_t fms = (int64_t)field_score;
+    if (match_type == 0 && fms > st.best_fms) { st.best_fms = fms; st.best_w = field_weight; }
+    if (match_type == 1 && field_weight > st.best_w) { st.best_w = field_weight; st.best_fms = fms; }
+    if (match_type == 2) st.sum += field_weight * fms;
+    st.n_fields++;
+}
+__device__ inline uint64_t agg_finish(const AggState& st, const KwQueryDev& q, uint32_t tokens_found) {
+    const uint64_t query_len = (st.best_fms == 0) ? 0 : (tokens_found < 15 ? tokens_found : 15);
+    const uint64_t max_field_weight = (uint64_t)st.best_w < 15 ? (uint64_t)st.best_w : 15;   // std::min<size_t>(15, w)
+    const uint64_t num_matching_fields = q.prio_nfields ? (st.n_fields < 7 ? st.n_fields : 7) : 0;
+    if (q.match_type == 0) return (query_len << 59) | ((uint64_t)st.best_fms << 11) | (max_field_weight << 3) | num_matching_fields;
+    if (q.match_type == 1) return (query_len << 59) | (max_field_weight << 51) | ((uint64_t)st.best_fms << 3) | num_matching_fields;
+    return (query_len << 59) | ((uint64_t)st.sum << 3) | num_matching_fields;
+}
+
+// compute_sort_scores, src/index.cpp:5662-5907 (text_match / seq_id / int64 column) + :5541-5544 override
+__device__ inline ScoredHit sort_scores(const IndexView& ix, const KwQueryDev& q, uint32_t seq_id, uint64_t agg, uint32_t off_words) {
     int64_t sc[3] = {0, 0, 0};
     int msi = -1;
 #pragma unroll
@@ -420,6 +431,57 @@ __device__ inline ScoredHit score_hit(const IndexView& ix, const KwQueryDev& q, 
     h.text_match = (int64_t)agg;
     h.off_words = off_words;
     return h;
+}
+
+__device__ inline TokRun empty_run() { TokRun r; r.w = nullptr; r.start = 0; r.n = 0; r.bits = 0; r.base = 0; r.last_flag = 0; r.raw_len = 0; return r; }
+
+// score_results2 + compute_aggregated_score + compute_sort_scores for ONE query_by field (plain string); pos[t] = posting
+// position of found token t
+template <int TMAX>
+__device__ inline ScoredHit score_hit(const IndexView& ix, const KwQueryDev& q, uint32_t seq_id, const uint32_t (&pos)[TMAX]) {
+    const uint32_t T = q.n_lists;
+    uint32_t off_words = 0;
+    TokRun runs[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; t++) {
+        if ((uint32_t)t < T && (t == 0 || T > 1)) { runs[t] = load_run(ix, ix.lists[q.list[t]], pos[t]); off_words += runs[t].raw_len + 1; }
+        else runs[t] = empty_run();
+    }
+    AggState st;
+    agg_add(st, q.match_type, field_match_score<TMAX>(q, runs, T), q.weight);
+    return sort_scores(ix, q, seq_id, agg_finish(st, q, T), off_words);
+}
+
+// the same for several query_by fields: pos[t * KW_MAX_FIELDS + f] = position of found token t in field f's list, or KW_NONE.
+// Per field, the tokens it holds for this document (query order) are scored together; the fields are folded by match_type.
+template <int TMAX>
+__device__ inline ScoredHit score_hit_mf(const IndexView& ix, const KwQueryDev& q, const KwQueryMF& mf, uint32_t seq_id,
+                                         const uint32_t (&pos)[TMAX * KW_MAX_FIELDS]) {
+    const uint32_t T = q.n_lists;
+    uint32_t off_words = 0;
+    AggState st;
+    for (uint32_t f = 0; f < mf.n_fields; f++) {
+        TokRun runs[TMAX];
+#pragma unroll
+        for (int t = 0; t < TMAX; t++) runs[t] = empty_run();
+        uint32_t n_present = 0;
+#pragma unroll
+        for (int t = 0; t < TMAX; t++) {
+            uint32_t p = KW_NONE;
+#pragma unroll
+            for (int ff = 0; ff < KW_MAX_FIELDS; ff++) if ((uint32_t)ff == f) p = pos[t * KW_MAX_FIELDS + ff];
+            if ((uint32_t)t < T && p != KW_NONE) {
+                const TokRun r = load_run(ix, ix.lists[mf.list[t][f]], p);
+                off_words += r.raw_len + 1;
+#pragma unroll
+                for (int j = 0; j < TMAX; j++) if ((uint32_t)j == n_present) runs[j] = r;      // append without dynamic register indexing
+                n_present++;
+            }
+        }
+        if (n_present == 0) continue;                     // field holds none of the tokens for this document (:5298-5300)
+        agg_add(st, q.match_type, field_match_score<TMAX>(q, runs, n_present), mf.weight[f]);
+    }
+    return sort_scores(ix, q, seq_id, agg_finish(st, q, T), off_words);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -478,13 +540,14 @@ __device__ inline void topk_compact(TopkLds<CAP>& tk, uint32_t* s_cnt, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int TMAX, int CAP>
+template <int TMAX, int CAP, bool MF>
 struct KwSmem {
+    static const int NP = MF ? TMAX * KW_MAX_FIELDS : TMAX;    // posting positions carried per complete hit
     // stage-1 survivors: id, driver position, first-probe position
     uint32_t q1_id[KW_QCAP], q1_p0[KW_QCAP], q1_p1[KW_QCAP];
-    // complete hits: id + posting position per token (query order)
+    // complete hits: id + posting position per token (query order; multi-field: per token and field, KW_NONE = absent)
     uint32_t qf_id[KW_QCAP];
-    uint32_t qf_pos[TMAX][KW_QCAP];
+    uint32_t qf_pos[NP][KW_QCAP];
     TopkLds<CAP> tk;
     int64_t thr[4];
     uint32_t btile[KW_TILE_WORDS + 2];       // packed ids of the second list's blocks under the current driver block
@@ -501,8 +564,8 @@ struct KwSmem {
     uint32_t f_first, f_frank, f_rp, f_ep, f_c0, f_c1, f_cnt0, f_cnt1;
 };
 
-template <int TMAX, int CAP>
-__device__ inline void kw_score_stage(KwSmem<TMAX, CAP>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take,
+template <int TMAX, int CAP, bool MF>
+__device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take,
                                       const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out, uint32_t ids_out_base) {
     // make room: at most n_take (<=256) new entries
     if (sm.tk_cnt + KW_THREADS > (uint32_t)CAP) topk_compact<CAP>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
@@ -531,10 +594,12 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP>& sm, const IndexView& ix
             if (!(rank > 0 && fl[rank - 1] == seq_id)) emit = false;
         }
         if (emit) {
-            uint32_t pos[TMAX];
+            constexpr int NP = KwSmem<TMAX, CAP, MF>::NP;
+            uint32_t pos[NP];
 #pragma unroll
-            for (int k = 0; k < TMAX; k++) pos[k] = sm.qf_pos[k][t];
-            h = score_hit<TMAX>(ix, q, seq_id, pos);
+            for (int k = 0; k < NP; k++) pos[k] = sm.qf_pos[k][t];
+            if constexpr (MF) h = score_hit_mf<TMAX>(ix, q, ix.mf[q.mf_index], seq_id, pos);
+            else h = score_hit<TMAX>(ix, q, seq_id, pos);
         }
     }
     // num_keyword_matches under a filter (kw_filter_count below): which intersection ids does the reference's loop VISIT?
@@ -586,18 +651,19 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP>& sm, const IndexView& ix
     __syncthreads();
     if (t == 0) { sm.n_match += n_take; sm.n_emit += total; }
     // drop the processed head of the final queue
+    constexpr int NPQ = KwSmem<TMAX, CAP, MF>::NP;
     const uint32_t rest = sm.qf_cnt - n_take;
-    uint32_t mv_id = 0, mv_pos[TMAX];
+    uint32_t mv_id = 0, mv_pos[NPQ];
     if (t < rest) {
         mv_id = sm.qf_id[n_take + t];
 #pragma unroll
-        for (int k = 0; k < TMAX; k++) mv_pos[k] = sm.qf_pos[k][n_take + t];
+        for (int k = 0; k < NPQ; k++) mv_pos[k] = sm.qf_pos[k][n_take + t];
     }
     __syncthreads();
     if (t < rest) {
         sm.qf_id[t] = mv_id;
 #pragma unroll
-        for (int k = 0; k < TMAX; k++) sm.qf_pos[k][t] = mv_pos[k];
+        for (int k = 0; k < NPQ; k++) sm.qf_pos[k][t] = mv_pos[k];
     }
     if (t == 0) sm.qf_cnt = rest;
     __syncthreads();
@@ -605,7 +671,7 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP>& sm, const IndexView& ix
 
 // probes lists probe_order[2..] for the first n_take entries of queue 1 and moves survivors to the final queue
 template <int TMAX, int CAP>
-__device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take) {
+__device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP, false>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take) {
     const uint32_t t = threadIdx.x;
     bool ok = t < n_take;
     uint32_t id = 0;
@@ -651,7 +717,7 @@ template <int TMAX, int CAP>
 __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
                                                                 const KwWorkItem* __restrict__ work, KwPartials part,
                                                                 const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out) {
-    __shared__ KwSmem<TMAX, CAP> sm;
+    __shared__ KwSmem<TMAX, CAP, false> sm;
     __shared__ KwQueryDev sq;
     const uint32_t t = threadIdx.x;
     const KwWorkItem wi = work[blockIdx.x];
@@ -867,7 +933,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
                 __syncthreads();
                 while (sm.q1_cnt >= KW_THREADS) {
                     kw_probe_rest_stage<TMAX, CAP>(sm, ix, q, KW_THREADS);
-                    while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+                    while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
                 }
                 q1n = sm.q1_cnt;
             }
@@ -888,7 +954,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
                 __syncthreads();
                 if (t == 0) sm.qf_cnt = qfn;
                 __syncthreads();
-                while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+                while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
                 qfn = sm.qf_cnt;
             }
         }
@@ -902,10 +968,10 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
     if (T >= 3) {
         while (sm.q1_cnt > 0) {
             kw_probe_rest_stage<TMAX, CAP>(sm, ix, q, sm.q1_cnt < KW_THREADS ? sm.q1_cnt : KW_THREADS);
-            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
         }
     }
-    while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+    while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP, false>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, ids_out_base);
     KW_PROF(8)
 
     // ---- partial result of this work item: sorted, <= k entries ----
@@ -932,6 +998,116 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
     }
     KW_PROF(9)
     KW_PROF_FLUSH(ix.prof)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-field queries (query_by = f0,f1,..): work item = (query, one field's list of the DRIVER token, block range). Thread t
+// takes id t of the driver block; an id also present in an EARLIER field's list of the driver token is left to that field's
+// work items (every document of the union is produced exactly once); the other tokens are probed in every field (a token is
+// satisfied by any field, include/or_iterator.h + src/or_iterator.cpp:95-171); complete hits carry their position in every
+// (token, field) list into the shared score stage. Per-candidate probes, no block merge: the slow, general path.
+template <int TMAX, int CAP>
+__global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
+                                                                   const KwWorkItem* __restrict__ work, KwPartials part,
+                                                                   const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out) {
+    __shared__ KwSmem<TMAX, CAP, true> sm;
+    __shared__ KwQueryDev sq;
+    __shared__ KwQueryMF smf;
+    const uint32_t t = threadIdx.x;
+    const KwWorkItem wi = work[blockIdx.x];
+    const uint32_t qi = wi.query & 0x0FFFFFFFu, fdrv = wi.query >> 28;
+    {
+        const uint32_t* src = (const uint32_t*)(queries + qi);
+        uint32_t* dst = (uint32_t*)&sq;
+        for (uint32_t i = t; i < sizeof(KwQueryDev) / 4; i += KW_THREADS) dst[i] = src[i];
+    }
+    if (t == 0) {
+        sm.q1_cnt = 0; sm.qf_cnt = 0; sm.tk_cnt = 0; sm.have_thr = 0; sm.n_match = 0; sm.n_emit = 0; sm.off_words = 0;
+        sm.f_first = 1; sm.f_frank = 0; sm.f_rp = 0; sm.f_ep = 0; sm.f_c0 = 0; sm.f_c1 = 0; sm.f_cnt0 = 0; sm.f_cnt1 = 0;
+    }
+    __syncthreads();
+    {
+        const uint32_t* src = (const uint32_t*)(ix.mf + sq.mf_index);
+        uint32_t* dst = (uint32_t*)&smf;
+        for (uint32_t i = t; i < sizeof(KwQueryMF) / 4; i += KW_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    const KwQueryDev& q = sq;
+    const KwQueryMF& mf = smf;
+    const uint32_t T = q.n_lists, F = mf.n_fields, td = mf.driver_token;
+    const ListDesc dA = ix.lists[mf.list[td][fdrv]];
+    const BlockIds* __restrict__ biA = ix.blk_ids + dA.blk_base;
+    const uint32_t* __restrict__ idwA = ix.ids_payload + dA.ids_base;
+    uint32_t* my_ids_out = ids_out ? ids_out + q.ids_out_off + wi.ids_out_off : nullptr;
+    constexpr int NP = TMAX * KW_MAX_FIELDS;
+    uint32_t qfn = 0, par = 0;
+    for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
+        const BlockIds mA = biA[b];
+        const uint32_t m_n = mA.n_ids_bits & 0xFFFF;
+        bool ok = t < m_n;
+        uint32_t id = 0xFFFFFFFFu;
+        uint32_t pos[NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++) pos[k] = KW_NONE;
+        if (ok) {
+            const uint32_t* __restrict__ w = idwA + mA.ids_woff;
+            id = mA.first_id + ((mA.n_ids_bits >> 16) == 16 ? (uint32_t)((const uint16_t*)w)[t] : w[t]);
+#pragma unroll
+            for (int tt = 0; tt < TMAX; tt++) {
+                if ((uint32_t)tt < T && ok) {
+                    bool any = false;
+#pragma unroll
+                    for (int f = 0; f < KW_MAX_FIELDS; f++) {
+                        if ((uint32_t)f < F && ok) {
+                            const uint32_t h = mf.list[tt][f];
+                            uint32_t p = KW_NONE;
+                            if ((uint32_t)tt == td && (uint32_t)f == fdrv) p = b * BLOCK_IDS + t;
+                            else if (h != KW_NONE) { uint32_t pp; if (probe_list(ix, ix.lists[h], id, pp)) p = pp; }
+                            if (p != KW_NONE) {
+                                any = true;
+                                if ((uint32_t)tt == td && (uint32_t)f < fdrv) ok = false;      // produced by an earlier field's work items
+                            }
+                            pos[tt * KW_MAX_FIELDS + f] = p;
+                        }
+                    }
+                    ok = ok && any;
+                }
+            }
+        }
+        uint32_t total;
+        const uint32_t my = block_compact1(ok, sm.wave_cnt2[par], total);
+        par ^= 1;
+        if (ok) {
+            const uint32_t slot = qfn + my;
+            sm.qf_id[slot] = id;
+#pragma unroll
+            for (int k = 0; k < NP; k++) sm.qf_pos[k][slot] = pos[k];
+        }
+        qfn += total;
+        if (qfn >= KW_THREADS) {
+            __syncthreads();
+            if (t == 0) sm.qf_cnt = qfn;
+            __syncthreads();
+            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, true>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, 0u);
+            qfn = sm.qf_cnt;
+        }
+    }
+    __syncthreads();
+    if (t == 0) sm.qf_cnt = qfn;
+    __syncthreads();
+    while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP, true>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, 0u);
+    topk_compact<CAP>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
+    const uint32_t n = sm.tk_cnt;
+    const size_t base = (size_t)blockIdx.x * part.k_stride;
+    for (uint32_t i = t; i < n; i += KW_THREADS) {
+        part.s0[base + i] = sm.tk.s0[i]; part.s1[base + i] = sm.tk.s1[i]; part.s2[base + i] = sm.tk.s2[i]; part.key[base + i] = sm.tk.key[i];
+    }
+    if (t == 0) {
+        part.cnt[blockIdx.x] = n;
+        part.n_emit[blockIdx.x] = sm.n_emit;
+        part.off_words[blockIdx.x] = sm.off_words;
+        part.n_match[blockIdx.x] = sm.n_match;            // (filters are not combined with multi-field queries: the planner rejects them)
+    }
 }
 
 // num_keyword_matches of a FILTERED query (include/or_iterator.h:61-182 with istate.filter_ids): the reference counts the

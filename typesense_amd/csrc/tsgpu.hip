@@ -47,6 +47,7 @@ IndexView make_view(tsgpu_ctx* ctx) {
     v.n_columns = (uint32_t)ctx->columns.size();
     v.num_docs = ctx->num_docs;
     v.prof = ctx->d_prof.as<unsigned long long>();
+    v.mf = ctx->d_mf.as<KwQueryMF>();
     return v;
 }
 
@@ -54,6 +55,13 @@ template <int TMAX, int CAP>
 void launch_search(hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w,
                    const KwPartials& part, const uint32_t* aux, uint32_t* ids_out) {
     hipLaunchKernelGGL((kw_search_kernel<TMAX, CAP>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out);
+}
+
+template <int TMAX>
+void launch_search_mf_cap(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w,
+                          const KwPartials& part, const uint32_t* aux, uint32_t* ids_out) {
+    if (cap == 512) hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 512>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out);
+    else hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 1024>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out);
 }
 
 template <int TMAX>
@@ -108,7 +116,7 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
     (void)hipDeviceSynchronize();
     tsgpu_vec_destroy_all(ctx);
     DevBuf* bufs[] = {&ctx->snap.lists, &ctx->snap.blk_last, &ctx->snap.blk_ids, &ctx->snap.blk_meta, &ctx->snap.ids_payload, &ctx->snap.payload, &ctx->d_col_ptrs, &ctx->d_col_len,
-                      &ctx->d_queries, &ctx->d_work, &ctx->d_aux, &ctx->d_ids_out, &ctx->d_part_s0, &ctx->d_part_s1, &ctx->d_part_s2,
+                      &ctx->d_queries, &ctx->d_work, &ctx->d_aux, &ctx->d_ids_out, &ctx->d_mf, &ctx->d_part_s0, &ctx->d_part_s1, &ctx->d_part_s2,
                       &ctx->d_part_key, &ctx->d_part_cnt, &ctx->d_part_nm, &ctx->d_part_ne, &ctx->d_part_ow, &ctx->d_part_f, &ctx->d_out_keys,
                       &ctx->d_out_scores, &ctx->d_out_tm, &ctx->d_out_vd, &ctx->d_out_msi, &ctx->d_out_nh, &ctx->d_out_nm, &ctx->d_out_ow, &ctx->d_prof};
     for (auto* b : bufs) b->release();
@@ -380,6 +388,8 @@ namespace {
 struct Plan {
     std::vector<KwQueryDev> q;
     std::vector<KwWorkItem> work_small, work_big;   // TMAX 3 / TMAX 10 kernels
+    std::vector<KwWorkItem> work_mf_small, work_mf_big;   // multi-field kernels, TMAX 3 / TMAX 10
+    std::vector<KwQueryMF> mf;
     std::vector<uint32_t> aux;
     std::vector<int32_t> status, cutoff;
     uint32_t max_k = 1;
@@ -423,10 +433,18 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         q.k = 1;
         auto unsupported = [&](const char*) { P.status[i] = TSGPU_ERR_UNSUPPORTED; };
         if (in.n_tokens == 0 || in.n_tokens > TSGPU_MAX_QUERY_TOKENS) { unsupported("tokens"); continue; }
-        if (in.n_fields != 1) { unsupported("fields"); continue; }
-        auto fit = ctx->fields.find(in.field_ids[0]);
-        if (fit == ctx->fields.end()) { P.status[i] = TSGPU_ERR_NOT_FOUND; continue; }
-        if (fit->second.is_array) { unsupported("array field"); continue; }
+        if (in.n_fields == 0 || in.n_fields > (uint32_t)KW_MAX_FIELDS) { unsupported("fields"); continue; }
+        {
+            int bad = 0;
+            for (uint32_t f = 0; f < in.n_fields && !bad; f++) {
+                auto fit = ctx->fields.find(in.field_ids[f]);
+                if (fit == ctx->fields.end()) bad = TSGPU_ERR_NOT_FOUND;
+                else if (fit->second.is_array) bad = TSGPU_ERR_UNSUPPORTED;     // string[] offset format: not accelerated yet
+            }
+            if (bad) { P.status[i] = bad; continue; }
+        }
+        const bool multi = in.n_fields > 1;
+        if (multi && in.n_filter != 0) { unsupported("filter ids with several query_by fields"); continue; }
         if (in.n_sort > TSGPU_MAX_SORT_KEYS) { P.status[i] = TSGPU_ERR_INVALID; continue; }
         if (in.n_filter != 0 && !in.filter_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
         if (in.match_type > TSGPU_SUM_SCORE) { P.status[i] = TSGPU_ERR_INVALID; continue; }
@@ -447,14 +465,26 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         if (in.deadline_us != 0 && now > in.deadline_us) { P.status[i] = TSGPU_ERR_DEADLINE; P.cutoff[i] = 1; continue; }
 
         q.n_query_tokens = in.n_tokens;
+        q.mf_index = KW_NONE;
         uint32_t nl = 0;
         uint32_t len_of[KW_MAX_TOKENS];
+        KwQueryMF mfq;
+        memset(&mfq, 0xFF, sizeof mfq);
         for (uint32_t t = 0; t < in.n_tokens; t++) {
-            auto h = ctx->snap.handle_of.find(((uint64_t)in.field_ids[0] << 32) | in.term_ids[t]);
-            if (h == ctx->snap.handle_of.end()) continue;          // token not in the index: skipped, src/index.cpp:5651-5655
-            q.list[nl] = h->second;
-            len_of[nl] = ctx->snap.h_lists[h->second].n_ids;
-            P.list_bytes += 4ull * len_of[nl];
+            // one or_iterator per token = the union of its lists over the fields; a token found in no field is skipped (src/index.cpp:5651-5655)
+            uint64_t tot = 0;
+            bool found = false;
+            for (uint32_t f = 0; f < in.n_fields; f++) {
+                auto h = ctx->snap.handle_of.find(((uint64_t)in.field_ids[f] << 32) | in.term_ids[t]);
+                if (h == ctx->snap.handle_of.end()) continue;
+                if (!found) q.list[nl] = h->second;
+                found = true;
+                mfq.list[nl][f] = h->second;
+                tot += ctx->snap.h_lists[h->second].n_ids;
+                P.list_bytes += 4ull * ctx->snap.h_lists[h->second].n_ids;
+            }
+            if (!found) continue;
+            len_of[nl] = (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFull);
             nl++;
         }
         q.n_lists = nl;
@@ -480,6 +510,34 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         }
         if (in.n_filter) P.aux.insert(P.aux.end(), in.filter_ids, in.filter_ids + in.n_filter);   // sorted ascending, unique (filter_result_t::docs)
         if (nl == 0) continue;   // no token in the index: zero hits (intersect case 0, or_iterator.h:67-68)
+        if (multi) {
+            // driver = the token with the fewest postings over all fields; one group of work items per field list of it
+            uint32_t td = 0;
+            for (uint32_t t = 1; t < nl; t++) if (len_of[t] < len_of[td]) td = t;
+            mfq.n_fields = in.n_fields;
+            mfq.driver_token = td;
+            for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.weight[f] = f < in.n_fields ? in.field_weights[f] : 0;
+            if (k + KW_THREADS > 1024) { unsupported("topster_size with several query_by fields"); continue; }
+            q.mf_index = (uint32_t)P.mf.size();
+            P.mf.push_back(mfq);
+            q.ids_out_off = P.ids_total;
+            uint64_t seg = 0;
+            for (uint32_t f = 0; f < in.n_fields; f++) {
+                if (mfq.list[td][f] == KW_NONE) continue;
+                const ListDesc& dF = ctx->snap.h_lists[mfq.list[td][f]];
+                for (uint32_t b = 0; b < dF.n_blocks; b += KW_CHUNK_BLOCKS) {
+                    KwWorkItem w;
+                    w.query = i | (f << 28);
+                    w.blk_begin = b;
+                    w.blk_end = std::min(dF.n_blocks, b + KW_CHUNK_BLOCKS);
+                    w.ids_out_off = (uint32_t)seg;
+                    seg += (uint64_t)(w.blk_end - w.blk_begin) * BLOCK_IDS;
+                    per_q_work[i].push_back(w);
+                }
+            }
+            if (keep_ids) P.ids_total += seg;
+            continue;
+        }
         // probe order: ascending list length, stable
         uint8_t ord[KW_MAX_TOKENS];
         for (uint32_t t = 0; t < nl; t++) ord[t] = (uint8_t)t;
@@ -497,14 +555,18 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             per_q_work[i].push_back(w);
         }
     }
-    // work tables: small-T queries first (one launch), then the generic ones; a query's items stay contiguous
-    for (int pass = 0; pass < 2; pass++) {
+    // work tables: one launch per kernel flavour (single-field T<=3, single-field generic, multi-field T<=3, multi-field generic);
+    // a query's items stay contiguous and first_work indexes the concatenation of the four tables
+    for (int pass = 0; pass < 4; pass++) {
         for (uint32_t i = 0; i < n_queries; i++) {
             if (per_q_work[i].empty()) continue;
-            const bool small = P.q[i].n_lists <= 3;
-            if ((pass == 0) != small) continue;
-            auto& dst = small ? P.work_small : P.work_big;
-            P.q[i].first_work = (uint32_t)(small ? dst.size() : P.work_small.size() + dst.size());
+            const int flavour = (P.q[i].mf_index != KW_NONE ? 2 : 0) + (P.q[i].n_lists <= 3 ? 0 : 1);
+            if (flavour != pass) continue;
+            std::vector<KwWorkItem>* tabs[4] = {&P.work_small, &P.work_big, &P.work_mf_small, &P.work_mf_big};
+            size_t before = 0;
+            for (int j = 0; j < pass; j++) before += tabs[j]->size();
+            auto& dst = *tabs[pass];
+            P.q[i].first_work = (uint32_t)(before + dst.size());
             P.q[i].n_work = (uint32_t)per_q_work[i].size();
             dst.insert(dst.end(), per_q_work[i].begin(), per_q_work[i].end());
         }
@@ -526,13 +588,16 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
         int rc = plan_batch(ctx, queries, n_queries, P, ctx->keep_ids);
         if (rc) return rc;
         if (out->k_stride < P.max_k) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: k_stride smaller than the largest topster_size");
-        const uint32_t n_work = (uint32_t)(P.work_small.size() + P.work_big.size());
+        const uint32_t n_work = (uint32_t)(P.work_small.size() + P.work_big.size() + P.work_mf_small.size() + P.work_mf_big.size());
         const uint32_t KS = out->k_stride;
         const int cap = P.max_k + KW_THREADS <= 512 ? 512 : (P.max_k + KW_THREADS <= 1024 ? 1024 : 2048);
 
         // ---- upload plan ----
         std::vector<KwWorkItem> work(P.work_small);
         work.insert(work.end(), P.work_big.begin(), P.work_big.end());
+        work.insert(work.end(), P.work_mf_small.begin(), P.work_mf_small.end());
+        work.insert(work.end(), P.work_mf_big.begin(), P.work_mf_big.end());
+        if (!P.mf.empty() && (rc = upload(ctx->d_mf, P.mf.data(), P.mf.size() * sizeof(KwQueryMF), s))) return rc;
         if ((rc = upload(ctx->d_queries, P.q.data(), P.q.size() * sizeof(KwQueryDev), s))) return rc;
         if ((rc = upload(ctx->d_work, work.data(), work.size() * sizeof(KwWorkItem), s))) return rc;
         P.aux.push_back(0);
@@ -591,14 +656,19 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
         const uint32_t* daux = ctx->d_aux.as<uint32_t>();
         TSGPU_HIP_TRY(hipEventRecord(ctx->ev[0], s));
         if (!P.work_small.empty()) launch_search_cap<3>(cap, s, (uint32_t)P.work_small.size(), v, dq, dw, part, daux, ids_out);
-        if (!P.work_big.empty()) {
-            KwPartials pb = part;   // the generic kernel indexes partials by its own blockIdx: shift the bases
-            const size_t sh = P.work_small.size();
+        auto shifted = [&](size_t sh) {                 // every kernel indexes the partials by its own blockIdx: shift the bases
+            KwPartials pb = part;
             pb.s0 += sh * KS; pb.s1 += sh * KS; pb.s2 += sh * KS; pb.key += sh * KS;
             pb.cnt += sh; pb.n_match += sh; pb.n_emit += sh; pb.off_words += sh;
             pb.n_match1 += sh; pb.first_rank += sh; pb.last_rank += sh; pb.fflags += sh;
-            launch_search_cap<KW_MAX_TOKENS>(cap, s, (uint32_t)P.work_big.size(), v, dq, dw + sh, pb, daux, ids_out);
-        }
+            return pb;
+        };
+        size_t sh = P.work_small.size();
+        if (!P.work_big.empty()) launch_search_cap<KW_MAX_TOKENS>(cap, s, (uint32_t)P.work_big.size(), v, dq, dw + sh, shifted(sh), daux, ids_out);
+        sh += P.work_big.size();
+        if (!P.work_mf_small.empty()) launch_search_mf_cap<3>(cap, s, (uint32_t)P.work_mf_small.size(), v, dq, dw + sh, shifted(sh), daux, ids_out);
+        sh += P.work_mf_small.size();
+        if (!P.work_mf_big.empty()) launch_search_mf_cap<KW_MAX_TOKENS>(cap, s, (uint32_t)P.work_mf_big.size(), v, dq, dw + sh, shifted(sh), daux, ids_out);
         TSGPU_HIP_TRY(hipEventRecord(ctx->ev[1], s));
         launch_merge(cap, s, n_queries, dq, part, o, ids_out, dw);
         TSGPU_HIP_TRY(hipEventRecord(ctx->ev[2], s));
@@ -646,6 +716,8 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
         ctx->last_ids_off.assign(n_queries, 0);
         ctx->last_ids_cap.assign(n_queries, 0);
         ctx->last_chunk_emit.assign(n_queries, {});
+        ctx->last_chunk_off.assign(n_queries, {});
+        ctx->last_ids_unsorted.assign(n_queries, 0);
         if (ctx->keep_ids && n_work) {
             std::vector<uint32_t> ne(n_work);
             TSGPU_HIP_TRY(hipMemcpy(ne.data(), part.n_emit, (size_t)n_work * 4, hipMemcpyDeviceToHost));
@@ -653,6 +725,9 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
                 if (P.status[i] != TSGPU_OK || P.q[i].n_work == 0) continue;
                 ctx->last_ids_off[i] = P.q[i].ids_out_off;
                 ctx->last_chunk_emit[i].assign(ne.begin() + P.q[i].first_work, ne.begin() + P.q[i].first_work + P.q[i].n_work);
+                ctx->last_chunk_off[i].resize(P.q[i].n_work);
+                for (uint32_t c = 0; c < P.q[i].n_work; c++) ctx->last_chunk_off[i][c] = work[P.q[i].first_work + c].ids_out_off;
+                ctx->last_ids_unsorted[i] = P.q[i].mf_index != KW_NONE;      // several driver lists: segments are sorted, their union is not
             }
         }
         // queries that were not run must not expose stale slots
@@ -668,14 +743,27 @@ uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64
     if (q >= ctx->last_chunk_emit.size()) return 0;
     uint64_t total = 0;
     const auto& ce = ctx->last_chunk_emit[q];
-    for (size_t c = 0; c < ce.size(); c++) {
-        const uint64_t seg = ctx->last_ids_off[q] + (uint64_t)c * ctx->last_chunk_blocks * BLOCK_IDS;
-        const uint64_t n = ce[c];
-        if (out_host && total < cap) {
-            const uint64_t m = std::min<uint64_t>(n, cap - total);
-            if (hipMemcpy(out_host + total, ctx->d_ids_out.as<uint32_t>() + seg, m * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    for (size_t c = 0; c < ce.size(); c++) total += ce[c];
+    if (!out_host || cap == 0) return total;
+    if (ctx->last_ids_unsorted[q]) {
+        // multi-field query: one ascending segment per (driver field, chunk); id_buff is ascending in the reference -> merge on the host
+        std::vector<uint32_t> all(total);
+        uint64_t at = 0;
+        for (size_t c = 0; c < ce.size(); c++) {
+            if (!ce[c]) continue;
+            if (hipMemcpy(all.data() + at, ctx->d_ids_out.as<uint32_t>() + ctx->last_ids_off[q] + ctx->last_chunk_off[q][c], (size_t)ce[c] * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+            at += ce[c];
         }
-        total += n;
+        std::sort(all.begin(), all.end());
+        memcpy(out_host, all.data(), (size_t)std::min<uint64_t>(total, cap) * 4);
+        return total;
+    }
+    uint64_t done = 0;
+    for (size_t c = 0; c < ce.size() && done < cap; c++) {
+        const uint64_t seg = ctx->last_ids_off[q] + ctx->last_chunk_off[q][c];
+        const uint64_t m = std::min<uint64_t>(ce[c], cap - done);
+        if (m && hipMemcpy(out_host + done, ctx->d_ids_out.as<uint32_t>() + seg, m * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+        done += m;
     }
     return total;
 }

@@ -95,7 +95,7 @@ struct tsgpu_ctx {
     bool num_docs_set = false;
 
     // keyword batch scratch
-    tsgpu::DevBuf d_queries, d_work, d_aux, d_ids_out;
+    tsgpu::DevBuf d_queries, d_work, d_aux, d_ids_out, d_mf;
     tsgpu::DevBuf d_part_s0, d_part_s1, d_part_s2, d_part_key, d_part_cnt, d_part_nm, d_part_ne, d_part_ow, d_part_f;
     tsgpu::DevBuf d_out_keys, d_out_scores, d_out_tm, d_out_vd, d_out_msi, d_out_nh, d_out_nm, d_out_ow;
     tsgpu::DevBuf d_prof;                            // TSGPU_PROF builds only (null otherwise)
@@ -114,7 +114,9 @@ struct tsgpu_ctx {
     uint64_t vec_overflow_rounds = 0;                // pass-2 repeats caused by candidate overflow (introspection)
     std::vector<uint64_t> last_ids_off;              // per query offset into d_ids_out of the last batch
     std::vector<uint64_t> last_ids_cap;
-    std::vector<std::vector<uint32_t>> last_chunk_emit;  // filled lazily by tsgpu_result_ids
+    std::vector<std::vector<uint32_t>> last_chunk_emit;  // ids emitted per work item of the query
+    std::vector<std::vector<uint32_t>> last_chunk_off;   // where each work item's id segment starts (relative to last_ids_off)
+    std::vector<uint8_t> last_ids_unsorted;
     std::vector<tsgpu_kw_query> last_queries_shadow;
 
     std::unordered_map<uint32_t, tsgpu::VecField*> vec_fields;

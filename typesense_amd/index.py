@@ -25,9 +25,10 @@ class KwQuery:
     def __init__(self, tokens, field=0, weight=15, sort=((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, 1, 0)),
                  topster_size=0, match_type=B.MAX_SCORE, prioritize_exact_match=True, prioritize_token_position=False,
                  prioritize_num_matching_fields=True, total_cost=0, excluded_ids=None, filter_ids=None, deadline_us=0,
-                 n_fields=1):
+                 n_fields=None, fields=None):
         self.tokens = list(tokens)
         self.field, self.weight, self.sort = field, weight, tuple(sort)     # sort: (kind, order, column)
+        self.fields = [(int(f), int(w)) for f, w in fields] if fields else [(field, weight)]     # query_by fields: (field id, weight)
         self.topster_size = topster_size
         self.match_type = match_type
         self.prioritize_exact_match = prioritize_exact_match
@@ -37,15 +38,16 @@ class KwQuery:
         self.excluded_ids = None if excluded_ids is None else _u32(excluded_ids)
         self.filter_ids = None if filter_ids is None else _u32(filter_ids)
         self.deadline_us = deadline_us
-        self.n_fields = n_fields
+        self.n_fields = len(self.fields) if n_fields is None else n_fields
 
     def fill(self, c):
         c.n_tokens = len(self.tokens)
         for i, t in enumerate(self.tokens[:B.MAX_QUERY_TOKENS]):
             c.term_ids[i] = int(t)
         c.n_fields = self.n_fields
-        c.field_ids[0] = self.field
-        c.field_weights[0] = self.weight
+        for i, (f, w) in enumerate(self.fields[:4]):
+            c.field_ids[i] = f
+            c.field_weights[i] = w
         c.match_type = self.match_type
         c.prioritize_exact_match = int(self.prioritize_exact_match)
         c.prioritize_token_position = int(self.prioritize_token_position)
