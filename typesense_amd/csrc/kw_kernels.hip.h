@@ -495,14 +495,17 @@ __device__ inline bool ent_greater(int64_t a0, int64_t a1, int64_t a2, int64_t a
     return ak > bk;
 }
 
-template <int CAP>
+// S2 = false: no query of the launch has a third sort key, scores[2] is 0 everywhere and its column shrinks to one slot
+// (4 KB of LDS at CAP = 512 -> one more resident workgroup per CU)
+template <int CAP, bool S2 = true>
 struct TopkLds {
-    int64_t s0[CAP], s1[CAP], s2[CAP], key[CAP];
+    int64_t s0[CAP], s1[CAP], s2[S2 ? CAP : 1], key[CAP];
+    __device__ static inline int i2(int i) { return S2 ? i : 0; }
 };
 
 // bitonic sort, descending, of the first CAP entries (entries >= cnt must be padding)
-template <int CAP>
-__device__ inline void topk_sort(TopkLds<CAP>& tk) {
+template <int CAP, bool S2>
+__device__ inline void topk_sort(TopkLds<CAP, S2>& tk) {
     for (int size = 2; size <= CAP; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
@@ -510,13 +513,14 @@ __device__ inline void topk_sort(TopkLds<CAP>& tk) {
                 const int i = 2 * p - (p & (stride - 1));     // lower index of the pair
                 const int j = i + stride;
                 const bool desc = ((i & size) == 0);
-                const int64_t a0 = tk.s0[i], a1 = tk.s1[i], a2 = tk.s2[i], ak = tk.key[i];
-                const int64_t b0 = tk.s0[j], b1 = tk.s1[j], b2 = tk.s2[j], bk = tk.key[j];
+                const int64_t a0 = tk.s0[i], a1 = tk.s1[i], a2 = tk.s2[tk.i2(i)], ak = tk.key[i];
+                const int64_t b0 = tk.s0[j], b1 = tk.s1[j], b2 = tk.s2[tk.i2(j)], bk = tk.key[j];
                 const bool b_gt_a = ent_greater(b0, b1, b2, bk, a0, a1, a2, ak);
                 const bool a_gt_b = ent_greater(a0, a1, a2, ak, b0, b1, b2, bk);
                 if (desc ? b_gt_a : a_gt_b) {
-                    tk.s0[i] = b0; tk.s1[i] = b1; tk.s2[i] = b2; tk.key[i] = bk;
-                    tk.s0[j] = a0; tk.s1[j] = a1; tk.s2[j] = a2; tk.key[j] = ak;
+                    tk.s0[i] = b0; tk.s1[i] = b1; tk.key[i] = bk;
+                    tk.s0[j] = a0; tk.s1[j] = a1; tk.key[j] = ak;
+                    if (S2) { tk.s2[tk.i2(i)] = b2; tk.s2[tk.i2(j)] = a2; }
                 }
             }
         }
@@ -525,34 +529,34 @@ __device__ inline void topk_sort(TopkLds<CAP>& tk) {
 }
 
 // sort + keep the best k; returns new count; thr* = k-th best when the buffer holds >= k entries
-template <int CAP>
-__device__ inline void topk_compact(TopkLds<CAP>& tk, uint32_t* s_cnt, uint32_t k, int64_t* s_thr /*[4]*/, uint32_t* s_have_thr) {
+template <int CAP, bool S2>
+__device__ inline void topk_compact(TopkLds<CAP, S2>& tk, uint32_t* s_cnt, uint32_t k, int64_t* s_thr /*[4]*/, uint32_t* s_have_thr) {
     __syncthreads();
     const uint32_t cnt = *s_cnt;
     for (int i = threadIdx.x; i < CAP; i += KW_THREADS) if ((uint32_t)i >= cnt) tk.key[i] = -1;
-    topk_sort<CAP>(tk);
+    topk_sort<CAP, S2>(tk);
     if (threadIdx.x == 0) {
         const uint32_t n = cnt < k ? cnt : k;
         *s_cnt = n;
-        if (n >= k) { s_thr[0] = tk.s0[k - 1]; s_thr[1] = tk.s1[k - 1]; s_thr[2] = tk.s2[k - 1]; s_thr[3] = tk.key[k - 1]; *s_have_thr = 1; }
+        if (n >= k) { s_thr[0] = tk.s0[k - 1]; s_thr[1] = tk.s1[k - 1]; s_thr[2] = tk.s2[tk.i2(k - 1)]; s_thr[3] = tk.key[k - 1]; *s_have_thr = 1; }
     }
     __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int TMAX, int CAP, bool MF>
+template <int TMAX, int CAP, bool MF, bool S2 = true>
 struct KwSmem {
     static const int NP = MF ? TMAX * KW_MAX_FIELDS : TMAX;    // posting positions carried per complete hit
+    static const bool HAS_S2 = S2;
     // stage-1 survivors: id, driver position, first-probe position
     uint32_t q1_id[KW_QCAP], q1_p0[KW_QCAP], q1_p1[KW_QCAP];
     // complete hits: id + posting position per token (query order; multi-field: per token and field, KW_NONE = absent)
     uint32_t qf_id[KW_QCAP];
     uint32_t qf_pos[NP][KW_QCAP];
-    TopkLds<CAP> tk;
+    TopkLds<CAP, S2> tk;
     int64_t thr[4];
     uint32_t btile[KW_TILE_WORDS + 2];       // packed ids of the second list's blocks under the current driver block
     uint32_t bw_last[2][64], bw_first[2][64], bw_woff[2][64], bw_nb[2][64];   // the second list's BlockIds window, SoA, two versions
-    BlockIds a_meta[KW_MAX_CHUNK];           // BlockIds of the work item's driver blocks
     uint32_t wave_cnt[KW_THREADS / 64];
     uint32_t wave_cnt2[2][KW_THREADS / 64];  // block_compact1 ping-pong
     uint32_t q1_cnt, qf_cnt, tk_cnt, have_thr;
@@ -564,11 +568,11 @@ struct KwSmem {
     uint32_t f_first, f_frank, f_rp, f_ep, f_c0, f_c1, f_cnt0, f_cnt1;
 };
 
-template <int TMAX, int CAP, bool MF>
-__device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take,
+template <int TMAX, int CAP, bool MF, bool S2>
+__device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take,
                                       const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out, uint32_t ids_out_base) {
     // make room: at most n_take (<=256) new entries
-    if (sm.tk_cnt + KW_THREADS > (uint32_t)CAP) topk_compact<CAP>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
+    if (sm.tk_cnt + KW_THREADS > (uint32_t)CAP) topk_compact<CAP, S2>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
     const uint32_t t = threadIdx.x;
     const bool active = t < n_take;
     bool emit = false, excl = false;
@@ -594,7 +598,7 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF>& sm, const IndexView
             if (!(rank > 0 && fl[rank - 1] == seq_id)) emit = false;
         }
         if (emit) {
-            constexpr int NP = KwSmem<TMAX, CAP, MF>::NP;
+            constexpr int NP = KwSmem<TMAX, CAP, MF, S2>::NP;
             uint32_t pos[NP];
 #pragma unroll
             for (int k = 0; k < NP; k++) pos[k] = sm.qf_pos[k][t];
@@ -644,14 +648,15 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF>& sm, const IndexView
         const bool pass = !sm.have_thr || ent_greater(h.s0, h.s1, h.s2, (int64_t)seq_id, sm.thr[0], sm.thr[1], sm.thr[2], sm.thr[3]);
         if (pass) {
             const uint32_t slot = atomicAdd(&sm.tk_cnt, 1u);
-            sm.tk.s0[slot] = h.s0; sm.tk.s1[slot] = h.s1; sm.tk.s2[slot] = h.s2; sm.tk.key[slot] = (int64_t)seq_id;
+            sm.tk.s0[slot] = h.s0; sm.tk.s1[slot] = h.s1; sm.tk.key[slot] = (int64_t)seq_id;
+            if (S2) sm.tk.s2[sm.tk.i2(slot)] = h.s2;
         }
         atomicAdd(&sm.off_words, (unsigned long long)h.off_words);
     }
     __syncthreads();
     if (t == 0) { sm.n_match += n_take; sm.n_emit += total; }
     // drop the processed head of the final queue
-    constexpr int NPQ = KwSmem<TMAX, CAP, MF>::NP;
+    constexpr int NPQ = KwSmem<TMAX, CAP, MF, S2>::NP;
     const uint32_t rest = sm.qf_cnt - n_take;
     uint32_t mv_id = 0, mv_pos[NPQ];
     if (t < rest) {
@@ -670,8 +675,8 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF>& sm, const IndexView
 }
 
 // probes lists probe_order[2..] for the first n_take entries of queue 1 and moves survivors to the final queue
-template <int TMAX, int CAP>
-__device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP, false>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take) {
+template <int TMAX, int CAP, bool S2>
+__device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP, false, S2>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take) {
     const uint32_t t = threadIdx.x;
     bool ok = t < n_take;
     uint32_t id = 0;
@@ -713,11 +718,11 @@ __device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP, false>& sm, const I
 }
 
 // grid = work items; block = 256 threads
-template <int TMAX, int CAP>
+template <int TMAX, int CAP, bool S2>
 __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
                                                                 const KwWorkItem* __restrict__ work, KwPartials part,
                                                                 const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out) {
-    __shared__ KwSmem<TMAX, CAP, false> sm;
+    __shared__ KwSmem<TMAX, CAP, false, S2> sm;
     __shared__ KwQueryDev sq;
     const uint32_t t = threadIdx.x;
     const KwWorkItem wi = work[blockIdx.x];
@@ -730,6 +735,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
     if (t == 0) {
         sm.q1_cnt = 0; sm.qf_cnt = 0; sm.tk_cnt = 0; sm.have_thr = 0; sm.n_match = 0; sm.n_emit = 0; sm.off_words = 0;
         sm.f_first = 1; sm.f_frank = 0; sm.f_rp = 0; sm.f_ep = 0; sm.f_c0 = 0; sm.f_c1 = 0; sm.f_cnt0 = 0; sm.f_cnt1 = 0;
+        if (!S2) sm.tk.s2[0] = 0;                              // the one shared scores[2] slot of the two-key build
     }
     __syncthreads();
     const KwQueryDev& q = sq;
@@ -757,10 +763,9 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
     };
     auto load_window = [&](uint32_t base) -> BlockIds { return (T >= 2 && base + lane < dB.n_blocks) ? biB[base + lane] : PAD; };
 
-    // driver-side BlockIds of the whole work item -> LDS once (the host caps a work item at KW_MAX_CHUNK blocks)
-    const uint32_t nA = wi.blk_end - wi.blk_begin;
-    for (uint32_t i = t; i < nA; i += KW_THREADS) sm.a_meta[i] = biA[wi.blk_begin + i];
-    __syncthreads();
+    // driver-side BlockIds: read from memory (uniform 16-byte loads), kept TWO blocks ahead in registers — block b+1's record
+    // is needed by make_plan while block b is searched
+    auto a_meta_of = [&](uint32_t bb) -> BlockIds { return biA[bb < wi.blk_end ? bb : wi.blk_end - 1]; };
 
     KW_PROF_DECL
     // Software pipeline over the driver blocks (global round trips cost 1-2K cycles under load): block b+1's ids and
@@ -773,10 +778,9 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
     struct Plan { uint32_t mode, rlo, rhi, w_begin, W, ver, base; };   // mode: 0 tile, 1 tile in several rounds, 2 wide run (probe), 3 exhausted, 4 no second list
     uint32_t cw[KW_PIPE_WORDS];               // block b's tile of second-list ids, in flight from the previous iteration
     // decide how driver block `bb` meets the second list and (mode 0) request its tile
-    auto make_plan = [&](uint32_t bb) -> Plan {
+    auto make_plan = [&](const BlockIds& m) -> Plan {
         Plan P; P.mode = 4; P.rlo = P.rhi = P.w_begin = P.W = 0; P.ver = wver; P.base = wbase;
         if (T < 2) return P;
-        const BlockIds m = sm.a_meta[bb - wi.blk_begin];
         const uint32_t lo_id = m.first_id, hi_id = m.last_id;
         unsigned long long mk = __ballot(win.last_id >= lo_id ? 1 : 0);
         if (mk != 0 && (uint32_t)__builtin_ctzll(mk) >= 32) {          // cursor entered the upper half: slide by 32 blocks
@@ -814,9 +818,9 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
         return P;
     };
 
-    BlockIds mA = sm.a_meta[0];
+    BlockIds mA = a_meta_of(wi.blk_begin), mA1 = a_meta_of(wi.blk_begin + 1);
     uint32_t araw = load_id_raw(idwA, mA, t);
-    Plan P = make_plan(wi.blk_begin);
+    Plan P = make_plan(mA);
     uint32_t q1n = 0, qfn = 0, par = 0;       // queue fill levels mirrored in registers (identical in every thread)
 
     for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
@@ -857,12 +861,11 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
 #endif
         KW_PROF(3)
         // ---- request the next driver block's ids and its tile (in flight during the slot search below) ----
-        BlockIds mA1 = PAD;
+        const BlockIds mA2 = a_meta_of(b + 2);              // in flight during this block's search
         uint32_t araw1 = 0;
         if (b + 1 < wi.blk_end) {
-            mA1 = sm.a_meta[b + 1 - wi.blk_begin];
             araw1 = load_id_raw(idwA, mA1, t);
-            P = make_plan(b + 1);
+            P = make_plan(mA1);
         }
         KW_PROF(4)
         // (b) which slot: branch-free lower bound over the block's ids in the LDS tile
@@ -932,8 +935,8 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
                 if (t == 0) sm.q1_cnt = q1n;
                 __syncthreads();
                 while (sm.q1_cnt >= KW_THREADS) {
-                    kw_probe_rest_stage<TMAX, CAP>(sm, ix, q, KW_THREADS);
-                    while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+                    kw_probe_rest_stage<TMAX, CAP, S2>(sm, ix, q, KW_THREADS);
+                    while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
                 }
                 q1n = sm.q1_cnt;
             }
@@ -954,12 +957,12 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
                 __syncthreads();
                 if (t == 0) sm.qf_cnt = qfn;
                 __syncthreads();
-                while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+                while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
                 qfn = sm.qf_cnt;
             }
         }
         KW_PROF(7)
-        mA = mA1; araw = araw1;
+        mA = mA1; mA1 = mA2; araw = araw1;
     }
     __syncthreads();
     if (t == 0) { if (T >= 3) sm.q1_cnt = q1n; else sm.qf_cnt = qfn; }
@@ -967,19 +970,19 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, con
     // ---- flush ----
     if (T >= 3) {
         while (sm.q1_cnt > 0) {
-            kw_probe_rest_stage<TMAX, CAP>(sm, ix, q, sm.q1_cnt < KW_THREADS ? sm.q1_cnt : KW_THREADS);
-            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+            kw_probe_rest_stage<TMAX, CAP, S2>(sm, ix, q, sm.q1_cnt < KW_THREADS ? sm.q1_cnt : KW_THREADS);
+            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
         }
     }
-    while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP, false>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+    while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, ids_out_base);
     KW_PROF(8)
 
     // ---- partial result of this work item: sorted, <= k entries ----
-    topk_compact<CAP>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
+    topk_compact<CAP, decltype(sm)::HAS_S2>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
     const uint32_t n = sm.tk_cnt;
     const size_t base = (size_t)blockIdx.x * part.k_stride;
     for (uint32_t i = t; i < n; i += KW_THREADS) {
-        part.s0[base + i] = sm.tk.s0[i]; part.s1[base + i] = sm.tk.s1[i]; part.s2[base + i] = sm.tk.s2[i]; part.key[base + i] = sm.tk.key[i];
+        part.s0[base + i] = sm.tk.s0[i]; part.s1[base + i] = sm.tk.s1[i]; part.s2[base + i] = sm.tk.s2[sm.tk.i2(i)]; part.key[base + i] = sm.tk.key[i];
     }
     if (t == 0) {
         part.cnt[blockIdx.x] = n;
@@ -1088,19 +1091,19 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
             __syncthreads();
             if (t == 0) sm.qf_cnt = qfn;
             __syncthreads();
-            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, true>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, 0u);
+            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, true, true>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, 0u);
             qfn = sm.qf_cnt;
         }
     }
     __syncthreads();
     if (t == 0) sm.qf_cnt = qfn;
     __syncthreads();
-    while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP, true>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, 0u);
-    topk_compact<CAP>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
+    while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP, true, true>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, 0u);
+    topk_compact<CAP, decltype(sm)::HAS_S2>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
     const uint32_t n = sm.tk_cnt;
     const size_t base = (size_t)blockIdx.x * part.k_stride;
     for (uint32_t i = t; i < n; i += KW_THREADS) {
-        part.s0[base + i] = sm.tk.s0[i]; part.s1[base + i] = sm.tk.s1[i]; part.s2[base + i] = sm.tk.s2[i]; part.key[base + i] = sm.tk.key[i];
+        part.s0[base + i] = sm.tk.s0[i]; part.s1[base + i] = sm.tk.s1[i]; part.s2[base + i] = sm.tk.s2[sm.tk.i2(i)]; part.key[base + i] = sm.tk.key[i];
     }
     if (t == 0) {
         part.cnt[blockIdx.x] = n;
@@ -1162,7 +1165,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
     } else {
         for (uint32_t w = q.first_work; w < q.first_work + q.n_work; w++) {
             const uint32_t nw = part.cnt[w];
-            if (s_cnt + nw > (uint32_t)CAP) topk_compact<CAP>(tk, &s_cnt, q.k, thr, &s_have_thr);
+            if (s_cnt + nw > (uint32_t)CAP) topk_compact<CAP, true>(tk, &s_cnt, q.k, thr, &s_have_thr);
             const uint32_t base_slot = s_cnt;
             const size_t base = (size_t)w * part.k_stride;
             for (uint32_t i = t; i < nw; i += KW_THREADS) {
@@ -1174,7 +1177,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
             __syncthreads();
         }
         if (t == 0 && q.n_filt) s_nm = kw_filter_count(part, q.first_work, q.n_work);
-        topk_compact<CAP>(tk, &s_cnt, q.k, thr, &s_have_thr);
+        topk_compact<CAP, true>(tk, &s_cnt, q.k, thr, &s_have_thr);
         n = s_cnt;
         for (uint32_t i = t; i < n; i += KW_THREADS) {
             const int64_t a0 = tk.s0[i], a1 = tk.s1[i], a2 = tk.s2[i];

@@ -53,8 +53,10 @@ IndexView make_view(tsgpu_ctx* ctx) {
 
 template <int TMAX, int CAP>
 void launch_search(hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w,
-                   const KwPartials& part, const uint32_t* aux, uint32_t* ids_out) {
-    hipLaunchKernelGGL((kw_search_kernel<TMAX, CAP>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out);
+                   const KwPartials& part, const uint32_t* aux, uint32_t* ids_out, bool s2) {
+    // s2 = some query of the launch sorts by three keys; the two-key build (CAP 512 only) has a smaller LDS footprint
+    if (CAP == 512 && !s2) hipLaunchKernelGGL((kw_search_kernel<TMAX, CAP, CAP != 512>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out);
+    else hipLaunchKernelGGL((kw_search_kernel<TMAX, CAP, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out);
 }
 
 template <int TMAX>
@@ -66,10 +68,10 @@ void launch_search_mf_cap(int cap, hipStream_t s, uint32_t n_work, const IndexVi
 
 template <int TMAX>
 void launch_search_cap(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w,
-                       const KwPartials& part, const uint32_t* aux, uint32_t* ids_out) {
-    if (cap == 512) launch_search<TMAX, 512>(s, n_work, v, q, w, part, aux, ids_out);
-    else if (cap == 1024) launch_search<TMAX, 1024>(s, n_work, v, q, w, part, aux, ids_out);
-    else launch_search<TMAX, 2048>(s, n_work, v, q, w, part, aux, ids_out);
+                       const KwPartials& part, const uint32_t* aux, uint32_t* ids_out, bool s2) {
+    if (cap == 512) launch_search<TMAX, 512>(s, n_work, v, q, w, part, aux, ids_out, s2);
+    else if (cap == 1024) launch_search<TMAX, 1024>(s, n_work, v, q, w, part, aux, ids_out, s2);
+    else launch_search<TMAX, 2048>(s, n_work, v, q, w, part, aux, ids_out, s2);
 }
 
 void launch_merge(int cap, hipStream_t s, uint32_t n_q, const KwQueryDev* q, const KwPartials& part, const KwOut& out,
@@ -390,6 +392,7 @@ struct Plan {
     std::vector<KwWorkItem> work_small, work_big;   // TMAX 3 / TMAX 10 kernels
     std::vector<KwWorkItem> work_mf_small, work_mf_big;   // multi-field kernels, TMAX 3 / TMAX 10
     std::vector<KwQueryMF> mf;
+    bool any_s2 = false;              // some query has a third sort key
     std::vector<uint32_t> aux;
     std::vector<int32_t> status, cutoff;
     uint32_t max_k = 1;
@@ -495,6 +498,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         q.total_cost = in.total_cost;
         q.weight = in.field_weights[0];
         q.n_sort = (uint8_t)in.n_sort;
+        if (in.n_sort > 2) P.any_s2 = true;
         for (uint32_t s = 0; s < in.n_sort; s++) {
             q.sort_kind[s] = in.sort[s].kind; q.sort_order[s] = in.sort[s].order; q.sort_col[s] = in.sort[s].column;
             if (in.sort[s].kind == TSGPU_SORT_INT64_COLUMN) P.n_numeric_sort_q++;
@@ -655,7 +659,7 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
         const KwWorkItem* dw = ctx->d_work.as<KwWorkItem>();
         const uint32_t* daux = ctx->d_aux.as<uint32_t>();
         TSGPU_HIP_TRY(hipEventRecord(ctx->ev[0], s));
-        if (!P.work_small.empty()) launch_search_cap<3>(cap, s, (uint32_t)P.work_small.size(), v, dq, dw, part, daux, ids_out);
+        if (!P.work_small.empty()) launch_search_cap<3>(cap, s, (uint32_t)P.work_small.size(), v, dq, dw, part, daux, ids_out, P.any_s2);
         auto shifted = [&](size_t sh) {                 // every kernel indexes the partials by its own blockIdx: shift the bases
             KwPartials pb = part;
             pb.s0 += sh * KS; pb.s1 += sh * KS; pb.s2 += sh * KS; pb.key += sh * KS;
@@ -664,7 +668,7 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
             return pb;
         };
         size_t sh = P.work_small.size();
-        if (!P.work_big.empty()) launch_search_cap<KW_MAX_TOKENS>(cap, s, (uint32_t)P.work_big.size(), v, dq, dw + sh, shifted(sh), daux, ids_out);
+        if (!P.work_big.empty()) launch_search_cap<KW_MAX_TOKENS>(cap, s, (uint32_t)P.work_big.size(), v, dq, dw + sh, shifted(sh), daux, ids_out, P.any_s2);
         sh += P.work_big.size();
         if (!P.work_mf_small.empty()) launch_search_mf_cap<3>(cap, s, (uint32_t)P.work_mf_small.size(), v, dq, dw + sh, shifted(sh), daux, ids_out);
         sh += P.work_mf_small.size();
