@@ -105,17 +105,19 @@ def timed(step, steps, warmup, world, after=None):
     return max_over_ranks(time.perf_counter() - t0, world), lat, out
 
 
-def pmc_traffic(kernel_rx, fname):
+def pmc_traffic(kernel_rx, fname, field="avg", scale=1.0):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc FETCH_SIZE pass (KB, own pass);
-    None when the profile is absent. gfx950 correction (x2 for wide coalesced reads) is discussed in DESIGN.md §5."""
+    None when the profile is absent. `field`: avg over the kernel's dispatches, or max (the full-index dispatch when the same
+    kernel also runs a short sample pass). `scale` = 2 for kernels whose reads are all 16 B/lane: on gfx950 FETCH_SIZE reports
+    half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section)."""
     p = os.path.join(ROOT, "profiles", "r01", fname)
     if not os.path.exists(p):
         return None
     for line in open(p):
         if re.search(kernel_rx, line) and "FETCH_SIZE" in line:
-            m = re.search(r"avg=([0-9.e+]+)", line)
+            m = re.search(field + r"=([0-9.e+]+)", line)
             if m:
-                return float(m.group(1)) * 1024.0
+                return float(m.group(1)) * 1024.0 * scale
     return None
 
 
@@ -412,7 +414,7 @@ def main():
                         "parallelism": par, "results_to": "device (tsgpu_hits mem=DEVICE); host delivery is quantified in DESIGN.md §5"}
         kw["queries_with_hits"] = r.get("nonempty")
         kw["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                          "traffic": pmc_traffic(r"kw_search_kernel", "pmc_kw_final_fetch.txt"),
+                          "traffic": pmc_traffic(r"kw_search_kernel", "pmc_kw_s4_fetch.txt"),
                           "kernel": "kw_search_kernel<3,512>", "kernel_ms": r["kern_ms"], "merge_kernel_ms": r["merge_ms"],
                           "algorithmic_bytes_per_launch": r["alg_bytes"],
                           "note": "algorithmic bytes = 4*sum|L_t| + offsets + sort keys (SURVEY 8d); the kernel skips, so fetched bytes (traffic, "
@@ -442,7 +444,7 @@ def main():
             v["roofline"] = {"bound": "hbm" if hbm_bound else "mfma", "achieved": gbs if hbm_bound else tfh,
                              "peak": HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TF, "unit": "GB/s" if hbm_bound else "TFLOP/s",
                              "frac": (gbs / HBM_PEAK_GBS) if hbm_bound else (tfh / MFMA_BF16_PEAK_TF),
-                             "traffic": pmc_traffic(r"vec_hscan_kernel", "pmc_vec_prefilter_fetch.txt"),
+                             "traffic": pmc_traffic(r"vec_hscan_kernel", "pmc_vec_s4_fetch.txt", field="max", scale=2.0),
                              "kernel": "vec_hscan_kernel<%d> (bf16 bracket scan; survivors re-scored exactly in fp32)" % (2 if r["n_q"] > 64 else 1),
                              "kernel_ms": r["scan_ms"], "algorithmic_bytes_per_launch": r["scan_bytes"], "flops_per_launch": r["flops"],
                              "hbm_GBs": gbs, "bf16_mfma_TFs": tfh, "pre_ms (query cast + sample pass + threshold)": r["kern_ms"] - r["scan_ms"],

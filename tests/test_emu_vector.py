@@ -37,7 +37,7 @@ def _check_knn(g, orc, Q, k, allow=None):
         assert (np.diff(dist[i, :d.size]) >= 0).all()
 
 
-@pytest.mark.parametrize("dim,n,k", [(48, 300, 10), (64, 700, 100), (70, 260, 7), (768, 300, 100), (32, 513, 200)])
+@pytest.mark.parametrize("dim,n,k", [(48, 200, 10), (64, 400, 100), (70, 260, 7), (768, 200, 100), (32, 300, 200)])
 def test_knn_matches_oracle_flat_scan(dim, n, k):
     g, orc, X, rng = _mk(n, dim, B.METRIC_IP, 5 + dim, H.emu_lib_path())
     Q = rng.standard_normal((5, dim)).astype(np.float32)
@@ -77,10 +77,10 @@ def test_ties_prefer_smaller_label_and_many_slabs():
 
 
 @pytest.mark.parametrize("n,dim,k,nq,sample_tiles,cap", [
-    (1500, 32, 20, 3, 2, 0),        # sample pass (2 of 12 tiles) -> tau -> filtered pass over all rows
-    (1500, 32, 20, 70, 1, 0),       # QT=128 workgroup tile (n_q > 64), 1-tile sample
-    (1000, 20, 10, 2, 1, 24),       # tiny candidate arena: lists overflow, tighten their own tau, pass 2 repeats
-    (900, 36, 50, 4, 3, 0),
+    (900, 32, 20, 3, 2, 0),         # sample pass (2 of 8 tiles) -> tau -> filtered pass over all rows
+    (600, 32, 20, 65, 1, 0),        # QT=128 workgroup tile (n_q > 64), 1-tile sample
+    (700, 20, 10, 2, 1, 24),       # tiny candidate arena: lists overflow, tighten their own tau, pass 2 repeats
+    (600, 36, 50, 4, 3, 0),
 ])
 def test_knn_two_pass_threshold_path_is_exact(n, dim, k, nq, sample_tiles, cap):
     """the 10M-row code path (sample -> threshold -> filtered scan -> radix select), forced at emulator sizes"""
@@ -136,7 +136,7 @@ def _check_knn_bits(g, orc, Q, k, allow=None):
 @pytest.mark.parametrize("dim,n,k,nq,sample_tiles,metric", [
     (768, 300, 100, 3, 512, B.METRIC_IP),      # dim % 16 == 0: InnerProductSIMD16Ext order; dense (small index) route
     (20, 900, 10, 2, 2, B.METRIC_IP),          # dim % 4 == 0: SIMD4Ext order; sample -> L1 -> filtered scan route
-    (70, 800, 25, 70, 1, B.METRIC_IP),         # dim > 16 residual form, QT = 128 tile
+    (70, 400, 25, 65, 1, B.METRIC_IP),         # dim > 16 residual form, QT = 128 tile
     (7, 400, 5, 2, 1, B.METRIC_IP),            # dim > 4 residual form
     (3, 300, 4, 2, 512, B.METRIC_IP),          # scalar form
     (48, 600, 30, 3, 2, B.METRIC_COSINE),      # cosine: normalised rows and query
@@ -154,7 +154,7 @@ def test_prefilter_distances_are_bit_identical_to_the_reference_order(dim, n, k,
 def test_prefilter_brackets_prune_but_never_drop_a_neighbour():
     """heterogeneous norms + near-duplicates: the survivors are a small superset of the true top-k"""
     rng = np.random.default_rng(77)
-    n, dim, k = 3000, 64, 20
+    n, dim, k = 1500, 64, 20
     X = rng.standard_normal((n, dim)).astype(np.float32) * rng.uniform(0.1, 8.0, size=(n, 1)).astype(np.float32)
     X[1000:1040] = X[5] * (1 + 1e-4 * rng.standard_normal((40, 1)).astype(np.float32))     # 40 near-copies of one row
     labels = np.arange(n, dtype=np.uint64)

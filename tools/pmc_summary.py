@@ -5,7 +5,7 @@ from collections import defaultdict
 
 d = sys.argv[1]
 rx = re.compile(sys.argv[2]) if len(sys.argv) > 2 else None
-acc = defaultdict(lambda: [0.0, 0])
+acc = defaultdict(lambda: [0.0, 0, 0.0])
 dur = defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -13,7 +13,7 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
         if rx and not rx.search(k):
             continue
         a = acc[(k[:60], r["Counter_Name"])]
-        a[0] += float(r["Counter_Value"]); a[1] += 1
+        a[0] += float(r["Counter_Value"]); a[1] += 1; a[2] = max(a[2], float(r["Counter_Value"]))
         if "Start_Timestamp" in r and r.get("End_Timestamp"):
             t = dur[k[:60]]
             t[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6; t[1] += 1
@@ -28,11 +28,11 @@ for db in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
                 if rx and not rx.search(k):
                     continue
                 a = acc[(k[:60], cn)]
-                a[0] += float(v); a[1] += 1
+                a[0] += float(v); a[1] += 1; a[2] = max(a[2], float(v))
     except Exception as e:
         print("# db %s: %s" % (db, e))
 print("# per-dispatch averages from %s" % d)
-for (k, c), (s, n) in sorted(acc.items()):
-    print("%-60s %-32s n=%-5d avg=%.6g" % (k, c, n, s / n))
+for (k, c), (s, n, mx) in sorted(acc.items()):
+    print("%-60s %-32s n=%-5d avg=%.6g max=%.6g" % (k, c, n, s / n, mx))
 for k, (s, n) in sorted(dur.items()):
     print("%-60s %-32s n=%-5d avg_ms=%.4f" % (k, "duration(profiled)", n, s / n))
