@@ -191,6 +191,12 @@ typedef struct tsgpu_hits {
 
 int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out);
 
+/* Wildcard search, q = "*" without a vector query (Index::search_wildcard, src/index.cpp:6616-6818): every id of
+ * queries[i].filter_ids (every seq_id < num_docs when n_filter == 0) minus excluded_ids is ranked by the sort keys alone — the
+ * _text_match slot is the constant 100 the reference passes to compute_sort_scores — into a Topster of topster_size. Only
+ * sort / topster_size / excluded_ids / filter_ids / deadline_us of the query are read. num_matched = ids ranked. */
+int tsgpu_wildcard_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out);
+
 /* all matched ids of the LAST keyword batch for query q, ascending (id_buff / all_result_ids, src/index.cpp:5565).
  * Only available when tsgpu_keep_result_ids(ctx, 1) was set before the batch. Returns count; copies min(count, cap). */
 int tsgpu_keep_result_ids(tsgpu_ctx* ctx, int keep);

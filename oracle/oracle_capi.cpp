@@ -165,6 +165,11 @@ int32_t orc_search_keyword(void* h, const orc_kw_query* q, orc_result* out) {
     return 0;
 }
 
+int32_t orc_search_wildcard(void* h, const orc_kw_query* q, orc_result* out) {
+    fill(((Index*)h)->search_wildcard(to_query(q)), out);
+    return 0;
+}
+
 int32_t orc_search_vector(void* h, const float* qvec, uint32_t k, float distance_threshold, const int32_t* sort_kind,
                           const int32_t* sort_column, const int32_t* sort_order, uint32_t n_sort, uint32_t fetch_size,
                           const uint32_t* filter_ids, uint32_t n_filter, orc_result* out) {

@@ -440,6 +440,32 @@ public:
         return out;
     }
 
+    // ---------------- query time: wildcard (q="*" without a vector query), Index::search_wildcard, index.cpp:6616-6818 ----------------
+    // Every filter id (every seq_id when there is no filter) minus the excluded ids gets a KV whose text-match slot is the
+    // constant 100 (compute_sort_scores(..., max_field_match_score = 100, ...), :6728-6730 — no :5541 override here) and goes
+    // through Topster::add; the reference splits the ids over threads and merges the per-thread Topsters (aggregate_topster),
+    // which keeps exactly the global top-K. result ids = the ids processed (all_result_ids = the filter id array).
+    keyword_result_t search_wildcard(const keyword_query_t& q) const {
+        keyword_result_t out;
+        Topster topster(q.topster_size ? q.topster_size : topster_size(q.fetch_size, q.filter_ids.size()));
+        const size_t n = q.filter_ids.empty() ? num_docs : q.filter_ids.size();
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t seq_id = q.filter_ids.empty() ? (uint32_t)i : q.filter_ids[i];
+            if (!q.excluded_ids.empty() && std::binary_search(q.excluded_ids.begin(), q.excluded_ids.end(), seq_id)) continue;
+            int64_t scores[3] = {0, 0, 0};
+            int64_t match_score_index = -1;
+            compute_sort_scores(q.sort, seq_id, 100, scores, match_score_index, 0);
+            KV kv(0, seq_id, seq_id, (int8_t)match_score_index, scores);
+            if (match_score_index >= 0) kv.text_match_score = scores[match_score_index];      // KV ctor, include/topster.h:38-48
+            topster.add(&kv);
+            out.result_ids.push_back(seq_id);
+            out.num_keyword_matches++;
+        }
+        topster.sort();
+        for (uint32_t i = 0; i < topster.size; i++) out.kvs.push_back(*topster.getKV(i));
+        return out;
+    }
+
     // ---------------- query time: pure vector (q="*"), index.cpp:3645-3732 ----------------
     keyword_result_t search_vector(const vector_query_t& vq, const std::vector<sort_by_t>& sort, size_t fetch_size,
                                    const std::vector<uint32_t>* filter_ids = nullptr) const {

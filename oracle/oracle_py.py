@@ -75,6 +75,7 @@ def lib():
         L.orc_flat_knn.restype = C.c_uint32
         L.orc_flat_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_search_keyword.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.POINTER(Result)]
+        L.orc_search_wildcard.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.POINTER(Result)]
         L.orc_search_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(Result)]
         L.orc_search_hybrid.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.POINTER(Result)]
@@ -251,6 +252,11 @@ class OracleIndex:
     def search_keyword(self, q, cap=1024, ids_cap=0):
         r, b = self._alloc(cap, ids_cap)
         self.L.orc_search_keyword(self.h, C.byref(q), C.byref(r))
+        return self._decode(r, b)
+
+    def search_wildcard(self, q, cap=1024, ids_cap=0):
+        r, b = self._alloc(cap, ids_cap)
+        self.L.orc_search_wildcard(self.h, C.byref(q), C.byref(r))
         return self._decode(r, b)
 
     def search_vector(self, qvec, k=0, fetch_size=10, sort=((SORT_VECTOR_DISTANCE, 0, -1), (SORT_SEQ_ID, 0, 1)),

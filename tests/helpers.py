@@ -95,6 +95,12 @@ def oracle_keyword(orc, q, cap=2048, ids_cap=0):
     return orc.search_keyword(oq, cap=cap, ids_cap=ids_cap)
 
 
+def oracle_wildcard(orc, q, cap=2048, ids_cap=0):
+    oq = orc.make_query([], fields=((0, 0),), sort=tuple((s[0], s[2], s[1]) for s in q.sort), fetch_size=10, topster_size=q.topster_size,
+                        excluded_ids=q.excluded_ids, filter_ids=q.filter_ids)
+    return orc.search_wildcard(oq, cap=cap, ids_cap=ids_cap)
+
+
 def assert_hits_equal(hits, qi, ref, what=""):
     n = int(hits.n_hits[qi])
     assert n == ref.keys.size, "%s q%d: n_hits %d vs oracle %d" % (what, qi, n, ref.keys.size)

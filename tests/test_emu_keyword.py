@@ -311,3 +311,29 @@ def test_multi_field_union_per_token_and_field_aggregation(pair3, chunk):
     finally:
         g.set_option("kw_chunk_blocks", 0)
         g.keep_result_ids(False)
+
+
+def test_wildcard_search_ranks_filter_ids_by_sort_keys(pair):
+    """q = "*" (Index::search_wildcard, src/index.cpp:6616-6818): Topster over the filter ids (or every document) ordered by the
+    sort keys; the _text_match slot is the constant 100 (sign-flipped for ASC); excluded ids are skipped; ids = the ids ranked"""
+    orc, g, _ = pair
+    rng = np.random.default_rng(51)
+    g.keep_result_ids(True)
+    try:
+        col_desc = ((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, -1, 0))
+        sorts = [col_desc, ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, -1, 0)), ((B.SORT_SEQ_ID, 1, 0),),
+                 ((B.SORT_TEXT_MATCH, -1, 0), (B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0))]
+        filters = [None, np.sort(rng.choice(3000, size=700, replace=False)), np.array([5]), np.arange(100, 400)]
+        qs = []
+        for f in filters:
+            for so in sorts:
+                qs.append(T.KwQuery([], sort=so, topster_size=0, filter_ids=f))
+                qs.append(T.KwQuery([], sort=so, topster_size=7, filter_ids=f, excluded_ids=np.arange(0, 3000, 5)))
+        hits = g.wildcard_search_batch(qs, k_stride=250)
+        assert (hits.status == 0).all()
+        for i, q in enumerate(qs):
+            ref = H.oracle_wildcard(orc, q, ids_cap=4000)
+            H.assert_hits_equal(hits, i, ref, "wildcard")
+            assert np.array_equal(g.result_ids(i), ref.result_ids)
+    finally:
+        g.keep_result_ids(False)

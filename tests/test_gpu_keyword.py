@@ -196,6 +196,22 @@ def pair3():
 test_keyword_filter_ids_hits_ids_and_the_reference_match_count = EK.test_keyword_filter_ids_hits_ids_and_the_reference_match_count
 test_keyword_filter_ids_with_excluded_ids = EK.test_keyword_filter_ids_with_excluded_ids
 test_multi_field_union_per_token_and_field_aggregation = EK.test_multi_field_union_per_token_and_field_aggregation
+test_wildcard_search_ranks_filter_ids_by_sort_keys = EK.test_wildcard_search_ranks_filter_ids_by_sort_keys
+
+
+def test_wildcard_over_2m_docs(c2m):
+    """q = "*" over every document and over a 30 % filter: many work items, partial top-K merge, exact order"""
+    g = c2m.g
+    rng = np.random.default_rng(8)
+    filt = np.unique(rng.integers(0, 2_000_000, size=600_000)).astype(np.uint32)
+    qs = [T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, -1, 0)), topster_size=250),
+          T.KwQuery([], sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=100, filter_ids=filt),
+          T.KwQuery([], sort=((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0)), topster_size=250, filter_ids=filt,
+                    excluded_ids=filt[::2])]
+    hits = g.wildcard_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all()
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(hits, i, H.oracle_wildcard(c2m.orc, q), "wildcard 2M")
 
 
 def test_filter_ids_on_2m_docs_multi_chunk(c2m):

@@ -93,7 +93,7 @@ struct KwQueryDev {                  // one search_across_fields call
     uint32_t aux_off, n_excl, n_filt;  // excluded ids then filter ids in the aux id arena
     uint64_t ids_out_off;            // where this query's matched ids go (if kept)
     uint32_t mf_index;               // KW_NONE = one query_by field; else index into IndexView::mf
-    uint32_t pad2;
+    uint32_t wild_n_ids;             // wildcard query (q = "*"): ids to scan = filter ids, or every seq_id < num_docs; 0 = keyword query
 };
 
 // query_by over several fields (get_field_token_its, src/index.cpp:5598-5660): token t is the UNION over the fields of its
@@ -407,7 +407,8 @@ __device__ inline uint64_t agg_finish(const AggState& st, const KwQueryDev& q, u
 }
 
 // compute_sort_scores, src/index.cpp:5662-5907 (text_match / seq_id / int64 column) + :5541-5544 override
-__device__ inline ScoredHit sort_scores(const IndexView& ix, const KwQueryDev& q, uint32_t seq_id, uint64_t agg, uint32_t off_words) {
+__device__ inline ScoredHit sort_scores(const IndexView& ix, const KwQueryDev& q, uint32_t seq_id, uint64_t agg, uint32_t off_words,
+                                        bool override_text_match = true) {
     int64_t sc[3] = {0, 0, 0};
     int msi = -1;
 #pragma unroll
@@ -424,11 +425,13 @@ __device__ inline ScoredHit sort_scores(const IndexView& ix, const KwQueryDev& q
             sc[i] = v;
         }
     }
+    int64_t tm = (int64_t)agg;
 #pragma unroll
-    for (int i = 0; i < 3; i++) if (i == msi) sc[i] = (int64_t)agg;
+    for (int i = 0; i < 3; i++) if (i == msi) { if (override_text_match) sc[i] = (int64_t)agg; else tm = sc[i]; }
+    if (!override_text_match && msi < 0) tm = 0;
     ScoredHit h;
     h.s0 = sc[0]; h.s1 = sc[1]; h.s2 = sc[2];
-    h.text_match = (int64_t)agg;
+    h.text_match = tm;
     h.off_words = off_words;
     return h;
 }
@@ -1113,6 +1116,72 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wildcard search (q = "*", Index::search_wildcard, src/index.cpp:6616-6818): every filter id (every seq_id
+// without a filter) minus the excluded ids is ranked by its sort keys alone — the text-match slot is the constant 100
+// (compute_sort_scores(..., 100, ...), :6728-6730, sign-flipped for ASC, no :5541 override) — into a Topster. The reference
+// splits the id array over threads and merges per-thread Topsters; here a work item = 256-id blocks [blk_begin, blk_end) of the
+// id array, partial top-K per work item, kw_merge_kernel folds them. A pure column gather: one 8-byte load per id and key.
+template <int CAP>
+__global__ __launch_bounds__(KW_THREADS) void kw_wildcard_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
+                                                                  const KwWorkItem* __restrict__ work, KwPartials part,
+                                                                  const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out) {
+    __shared__ TopkLds<CAP> tk;
+    __shared__ int64_t thr[4];
+    __shared__ uint32_t s_cnt, s_have, s_emit, wave_cnt[KW_THREADS / 64];
+    __shared__ KwQueryDev sq;
+    const uint32_t t = threadIdx.x;
+    const KwWorkItem wi = work[blockIdx.x];
+    {
+        const uint32_t* src = (const uint32_t*)(queries + wi.query);
+        uint32_t* dst = (uint32_t*)&sq;
+        for (uint32_t i = t; i < sizeof(KwQueryDev) / 4; i += KW_THREADS) dst[i] = src[i];
+    }
+    if (t == 0) { s_cnt = 0; s_have = 0; s_emit = 0; }
+    __syncthreads();
+    const KwQueryDev& q = sq;
+    const uint32_t* ex = aux_ids + q.aux_off;
+    const uint32_t* fl = ex + q.n_excl;
+    uint32_t* my_ids_out = ids_out ? ids_out + q.ids_out_off + wi.ids_out_off : nullptr;
+    for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
+        if (s_cnt + KW_THREADS > (uint32_t)CAP) topk_compact<CAP, true>(tk, &s_cnt, q.k, thr, &s_have);
+        const uint32_t idx = b * BLOCK_IDS + t;
+        bool emit = idx < q.wild_n_ids;
+        uint32_t seq_id = 0;
+        ScoredHit h;
+        h.s0 = h.s1 = h.s2 = h.text_match = 0; h.off_words = 0;
+        if (emit) {
+            seq_id = q.n_filt ? fl[idx] : idx;
+            if (q.n_excl) {      // get_n_ids skips exclude_token_ids (:6674-6676)
+                uint32_t lo = 0, hi = q.n_excl;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ex[mid] < seq_id) lo = mid + 1; else hi = mid; }
+                if (lo < q.n_excl && ex[lo] == seq_id) emit = false;
+            }
+            if (emit) h = sort_scores(ix, q, seq_id, 100, 0, false);
+        }
+        uint32_t total;
+        const uint32_t my = block_compact(emit, wave_cnt, total);
+        if (emit && my_ids_out) my_ids_out[s_emit + my] = seq_id;
+        if (emit) {
+            const bool pass = !s_have || ent_greater(h.s0, h.s1, h.s2, (int64_t)seq_id, thr[0], thr[1], thr[2], thr[3]);
+            if (pass) {
+                const uint32_t slot = atomicAdd(&s_cnt, 1u);
+                tk.s0[slot] = h.s0; tk.s1[slot] = h.s1; tk.s2[slot] = h.s2; tk.key[slot] = (int64_t)seq_id;
+            }
+        }
+        __syncthreads();
+        if (t == 0) s_emit += total;
+        __syncthreads();
+    }
+    topk_compact<CAP, true>(tk, &s_cnt, q.k, thr, &s_have);
+    const uint32_t n = s_cnt;
+    const size_t base = (size_t)blockIdx.x * part.k_stride;
+    for (uint32_t i = t; i < n; i += KW_THREADS) {
+        part.s0[base + i] = tk.s0[i]; part.s1[base + i] = tk.s1[i]; part.s2[base + i] = tk.s2[i]; part.key[base + i] = tk.key[i];
+    }
+    if (t == 0) { part.cnt[blockIdx.x] = n; part.n_match[blockIdx.x] = s_emit; part.n_emit[blockIdx.x] = s_emit; part.off_words[blockIdx.x] = 0; }
+}
+
 // num_keyword_matches of a FILTERED query (include/or_iterator.h:61-182 with istate.filter_ids): the reference counts the
 // intersection ids its loop lands on, and after every non-excluded one it skips all lists to the next filter id. So an
 // intersection id x_j is counted iff a filter id lies in (x_{j-1}, x_j] — its filter rank exceeds its predecessor's — or the
@@ -1161,7 +1230,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
             out.vector_distance[ob + i] = -1.0f;
             out.match_score_index[ob + i] = (int8_t)msi;
         }
-        if (t == 0) { s_nm = q.n_filt ? kw_filter_count(part, q.first_work, 1) : part.n_match[w]; s_ow = part.off_words[w]; }
+        if (t == 0) { s_nm = (q.n_filt && !q.wild_n_ids) ? kw_filter_count(part, q.first_work, 1) : part.n_match[w]; s_ow = part.off_words[w]; }
     } else {
         for (uint32_t w = q.first_work; w < q.first_work + q.n_work; w++) {
             const uint32_t nw = part.cnt[w];
@@ -1173,10 +1242,10 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
                 tk.s2[base_slot + i] = part.s2[base + i]; tk.key[base_slot + i] = part.key[base + i];
             }
             __syncthreads();
-            if (t == 0) { s_cnt = base_slot + nw; if (!q.n_filt) s_nm += part.n_match[w]; s_ow += part.off_words[w]; }
+            if (t == 0) { s_cnt = base_slot + nw; if (!q.n_filt || q.wild_n_ids) s_nm += part.n_match[w]; s_ow += part.off_words[w]; }
             __syncthreads();
         }
-        if (t == 0 && q.n_filt) s_nm = kw_filter_count(part, q.first_work, q.n_work);
+        if (t == 0 && q.n_filt && !q.wild_n_ids) s_nm = kw_filter_count(part, q.first_work, q.n_work);
         topk_compact<CAP, true>(tk, &s_cnt, q.k, thr, &s_have_thr);
         n = s_cnt;
         for (uint32_t i = t; i < n; i += KW_THREADS) {

@@ -391,6 +391,7 @@ struct Plan {
     std::vector<KwQueryDev> q;
     std::vector<KwWorkItem> work_small, work_big;   // TMAX 3 / TMAX 10 kernels
     std::vector<KwWorkItem> work_mf_small, work_mf_big;   // multi-field kernels, TMAX 3 / TMAX 10
+    std::vector<KwWorkItem> work_wild;                    // wildcard scans
     std::vector<KwQueryMF> mf;
     bool any_s2 = false;              // some query has a third sort key
     std::vector<uint32_t> aux;
@@ -403,7 +404,7 @@ struct Plan {
 };
 }
 
-static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, Plan& P, bool keep_ids) {
+static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, Plan& P, bool keep_ids, bool wildcard) {
     // driver blocks per work item: fixed by the option, or (0 = auto) sized so that the batch yields a few thousand work
     // items (>= 3 per resident workgroup slot) without fragmenting queries into more partial top-K lists than needed
     uint32_t KW_CHUNK_BLOCKS = ctx->kw_chunk_blocks;
@@ -435,9 +436,9 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         memset(&q, 0, sizeof q);
         q.k = 1;
         auto unsupported = [&](const char*) { P.status[i] = TSGPU_ERR_UNSUPPORTED; };
-        if (in.n_tokens == 0 || in.n_tokens > TSGPU_MAX_QUERY_TOKENS) { unsupported("tokens"); continue; }
-        if (in.n_fields == 0 || in.n_fields > (uint32_t)KW_MAX_FIELDS) { unsupported("fields"); continue; }
-        {
+        if (!wildcard && (in.n_tokens == 0 || in.n_tokens > TSGPU_MAX_QUERY_TOKENS)) { unsupported("tokens"); continue; }
+        if (!wildcard && (in.n_fields == 0 || in.n_fields > (uint32_t)KW_MAX_FIELDS)) { unsupported("fields"); continue; }
+        if (!wildcard) {
             int bad = 0;
             for (uint32_t f = 0; f < in.n_fields && !bad; f++) {
                 auto fit = ctx->fields.find(in.field_ids[f]);
@@ -446,7 +447,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             }
             if (bad) { P.status[i] = bad; continue; }
         }
-        const bool multi = in.n_fields > 1;
+        const bool multi = !wildcard && in.n_fields > 1;
         if (multi && in.n_filter != 0) { unsupported("filter ids with several query_by fields"); continue; }
         if (in.n_sort > TSGPU_MAX_SORT_KEYS) { P.status[i] = TSGPU_ERR_INVALID; continue; }
         if (in.n_filter != 0 && !in.filter_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
@@ -466,6 +467,41 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         k = std::max<uint32_t>(k, 1);
         if (k > TSGPU_MAX_TOPK) { unsupported("topster_size"); continue; }
         if (in.deadline_us != 0 && now > in.deadline_us) { P.status[i] = TSGPU_ERR_DEADLINE; P.cutoff[i] = 1; continue; }
+
+        if (wildcard) {
+            // Index::search_wildcard (src/index.cpp:6616-6818): rank every filter id (every seq_id without a filter) by its sort keys
+            q.mf_index = KW_NONE;
+            q.n_sort = (uint8_t)in.n_sort;
+            for (uint32_t s = 0; s < in.n_sort; s++) {
+                q.sort_kind[s] = in.sort[s].kind; q.sort_order[s] = in.sort[s].order; q.sort_col[s] = in.sort[s].column;
+                if (in.sort[s].kind == TSGPU_SORT_INT64_COLUMN) P.n_numeric_sort_q++;
+            }
+            q.k = k;
+            P.max_k = std::max(P.max_k, k);
+            q.aux_off = (uint32_t)P.aux.size();
+            q.n_excl = in.n_excluded;
+            q.n_filt = in.n_filter;
+            if (in.n_excluded) {
+                if (!in.excluded_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
+                P.aux.insert(P.aux.end(), in.excluded_ids, in.excluded_ids + in.n_excluded);
+            }
+            if (in.n_filter) P.aux.insert(P.aux.end(), in.filter_ids, in.filter_ids + in.n_filter);
+            const uint32_t n_ids = in.n_filter ? in.n_filter : ctx->num_docs;
+            q.wild_n_ids = n_ids;
+            uint32_t n_num = 0;
+            for (uint32_t s = 0; s < in.n_sort; s++) n_num += in.sort[s].kind == TSGPU_SORT_INT64_COLUMN;
+            P.list_bytes += 4ull * in.n_filter + 8ull * n_ids * n_num;      // the id array + one column value per id and numeric key
+            q.ids_out_off = P.ids_total;
+            const uint32_t n_blocks = (n_ids + BLOCK_IDS - 1) / BLOCK_IDS;
+            if (keep_ids) P.ids_total += (uint64_t)n_blocks * BLOCK_IDS;
+            const uint32_t WCHUNK = 64;                                     // 16K ids per work item
+            for (uint32_t b = 0; b < n_blocks; b += WCHUNK) {
+                KwWorkItem w;
+                w.query = i; w.blk_begin = b; w.blk_end = std::min(n_blocks, b + WCHUNK); w.ids_out_off = b * BLOCK_IDS;
+                per_q_work[i].push_back(w);
+            }
+            continue;
+        }
 
         q.n_query_tokens = in.n_tokens;
         q.mf_index = KW_NONE;
@@ -561,12 +597,12 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
     }
     // work tables: one launch per kernel flavour (single-field T<=3, single-field generic, multi-field T<=3, multi-field generic);
     // a query's items stay contiguous and first_work indexes the concatenation of the four tables
-    for (int pass = 0; pass < 4; pass++) {
+    for (int pass = 0; pass < 5; pass++) {
         for (uint32_t i = 0; i < n_queries; i++) {
             if (per_q_work[i].empty()) continue;
-            const int flavour = (P.q[i].mf_index != KW_NONE ? 2 : 0) + (P.q[i].n_lists <= 3 ? 0 : 1);
+            const int flavour = P.q[i].wild_n_ids ? 4 : (P.q[i].mf_index != KW_NONE ? 2 : 0) + (P.q[i].n_lists <= 3 ? 0 : 1);
             if (flavour != pass) continue;
-            std::vector<KwWorkItem>* tabs[4] = {&P.work_small, &P.work_big, &P.work_mf_small, &P.work_mf_big};
+            std::vector<KwWorkItem>* tabs[5] = {&P.work_small, &P.work_big, &P.work_mf_small, &P.work_mf_big, &P.work_wild};
             size_t before = 0;
             for (int j = 0; j < pass; j++) before += tabs[j]->size();
             auto& dst = *tabs[pass];
@@ -578,7 +614,17 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
     return TSGPU_OK;
 }
 
+static int kw_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard);
+
 int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out) {
+    return kw_batch(ctx, queries, n_queries, out, false);
+}
+
+int tsgpu_wildcard_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out) {
+    return kw_batch(ctx, queries, n_queries, out, true);
+}
+
+static int kw_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard) {
     if (!ctx || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: NULL argument");
     if (n_queries == 0) return ok();
     if (!queries) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: queries is NULL");
@@ -589,10 +635,10 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
     hipStream_t s = ctx->stream;
     try {
         Plan P;
-        int rc = plan_batch(ctx, queries, n_queries, P, ctx->keep_ids);
+        int rc = plan_batch(ctx, queries, n_queries, P, ctx->keep_ids, wildcard);
         if (rc) return rc;
         if (out->k_stride < P.max_k) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: k_stride smaller than the largest topster_size");
-        const uint32_t n_work = (uint32_t)(P.work_small.size() + P.work_big.size() + P.work_mf_small.size() + P.work_mf_big.size());
+        const uint32_t n_work = (uint32_t)(P.work_small.size() + P.work_big.size() + P.work_mf_small.size() + P.work_mf_big.size() + P.work_wild.size());
         const uint32_t KS = out->k_stride;
         const int cap = P.max_k + KW_THREADS <= 512 ? 512 : (P.max_k + KW_THREADS <= 1024 ? 1024 : 2048);
 
@@ -601,6 +647,7 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
         work.insert(work.end(), P.work_big.begin(), P.work_big.end());
         work.insert(work.end(), P.work_mf_small.begin(), P.work_mf_small.end());
         work.insert(work.end(), P.work_mf_big.begin(), P.work_mf_big.end());
+        work.insert(work.end(), P.work_wild.begin(), P.work_wild.end());
         if (!P.mf.empty() && (rc = upload(ctx->d_mf, P.mf.data(), P.mf.size() * sizeof(KwQueryMF), s))) return rc;
         if ((rc = upload(ctx->d_queries, P.q.data(), P.q.size() * sizeof(KwQueryDev), s))) return rc;
         if ((rc = upload(ctx->d_work, work.data(), work.size() * sizeof(KwWorkItem), s))) return rc;
@@ -673,6 +720,13 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
         if (!P.work_mf_small.empty()) launch_search_mf_cap<3>(cap, s, (uint32_t)P.work_mf_small.size(), v, dq, dw + sh, shifted(sh), daux, ids_out);
         sh += P.work_mf_small.size();
         if (!P.work_mf_big.empty()) launch_search_mf_cap<KW_MAX_TOKENS>(cap, s, (uint32_t)P.work_mf_big.size(), v, dq, dw + sh, shifted(sh), daux, ids_out);
+        sh += P.work_mf_big.size();
+        if (!P.work_wild.empty()) {
+            const uint32_t nw = (uint32_t)P.work_wild.size();
+            if (cap == 512) hipLaunchKernelGGL((kw_wildcard_kernel<512>), dim3(nw), dim3(KW_THREADS), 0, s, v, dq, dw + sh, shifted(sh), daux, ids_out);
+            else if (cap == 1024) hipLaunchKernelGGL((kw_wildcard_kernel<1024>), dim3(nw), dim3(KW_THREADS), 0, s, v, dq, dw + sh, shifted(sh), daux, ids_out);
+            else hipLaunchKernelGGL((kw_wildcard_kernel<2048>), dim3(nw), dim3(KW_THREADS), 0, s, v, dq, dw + sh, shifted(sh), daux, ids_out);
+        }
         TSGPU_HIP_TRY(hipEventRecord(ctx->ev[1], s));
         launch_merge(cap, s, n_queries, dq, part, o, ids_out, dw);
         TSGPU_HIP_TRY(hipEventRecord(ctx->ev[2], s));

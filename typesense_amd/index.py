@@ -189,6 +189,15 @@ class GpuIndex:
         self._ck(self.L.tsgpu_keyword_search_batch(self.h, C.cast(arr, C.c_void_p), n, C.byref(hs)))
         return hits
 
+    def wildcard_search_batch(self, queries, k_stride=250, hits=None):
+        """q = "*": rank the filter ids (all documents without a filter) by the sort keys (Index::search_wildcard)"""
+        arr = make_query_array(queries)
+        n = len(arr)
+        hits = hits or Hits(n, k_stride)
+        hs = hits.c_struct()
+        self._ck(self.L.tsgpu_wildcard_search_batch(self.h, C.cast(arr, C.c_void_p), n, C.byref(hs)))
+        return hits
+
     def keyword_search_batch_raw(self, arr, n, hs):
         """prebuilt ctypes query array + tsgpu_hits struct (device or host outputs); no allocation (bench loop)"""
         self._ck(self.L.tsgpu_keyword_search_batch(self.h, C.cast(arr, C.c_void_p), n, C.byref(hs)))
