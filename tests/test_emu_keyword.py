@@ -337,3 +337,64 @@ def test_wildcard_search_ranks_filter_ids_by_sort_keys(pair):
             assert np.array_equal(g.result_ids(i), ref.result_ids)
     finally:
         g.keep_result_ids(False)
+
+
+def _array_docs(n_docs, vocab, seed):
+    """string[] documents: 0-4 elements of 1-5 tokens each (repeats inside and across elements, single-token elements)"""
+    rng = np.random.default_rng(seed)
+    p = 1.0 / np.arange(1, vocab + 1)
+    p /= p.sum()
+    docs = []
+    for _ in range(n_docs):
+        elems = []
+        for _e in range(int(rng.integers(0, 5))):
+            elems.append(list((rng.choice(vocab, size=int(rng.integers(1, 6)), p=p) + 1).astype(int)))
+        docs.append(elems)
+    return docs
+
+
+@pytest.fixture(scope="module")
+def pair_arr():
+    """field 0 = string[] ("tags"), field 1 = plain string ("title") over the same documents"""
+    from oracle import oracle_py as O
+    n_docs = 2000
+    arr = _array_docs(n_docs, 40, seed=61)
+    title = H.zipf_docs(n_docs, 40, 5, seed=62)
+    orc = O.OracleIndex(2, 1)
+    for d in range(n_docs):
+        if arr[d]:
+            orc.index_array(d, 0, arr[d])
+        orc.index_plain(d, 1, title[d])
+    pts = H.points_of(n_docs)
+    orc.set_num_docs(n_docs)
+    orc.set_sort_dense(0, pts)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.field_create(0, True)
+    g.field_create(1, False)
+    for f in (0, 1):
+        for term in orc.terms(f):
+            ids, oi, off = orc.dump_posting(f, int(term))
+            g.term_upsert(f, int(term), ids, oi, off)
+    g.column_set(0, pts)
+    g.set_num_docs(n_docs)
+    g.commit()
+    yield orc, g
+    g.close()
+
+
+def test_string_array_fields_match_per_element_and_mix_with_plain_fields(pair_arr):
+    """string[] offset format (src/index.cpp:1351-1395): Match runs per array element over the tokens present in it, the best
+    element wins, unique_words = words_present; single-token verbatim / last-offset readers; alone and next to a plain field"""
+    orc, g = pair_arr
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    qs = []
+    for toks in ([1], [2], [7], [1, 2], [2, 1], [1, 2, 3], [3, 1], [4, 2, 1, 3], [5, 5], [2, 9, 1, 4, 3, 6], [39], [1, 9999]):
+        qs.append(T.KwQuery(toks, fields=[(0, 15)], sort=sort, topster_size=250))
+        qs.append(T.KwQuery(toks, fields=[(0, 15)], sort=sort, topster_size=250, prioritize_token_position=True, prioritize_exact_match=False))
+        qs.append(T.KwQuery(toks, fields=[(0, 4), (1, 9)], sort=sort, topster_size=250))
+        qs.append(T.KwQuery(toks, fields=[(1, 2), (0, 6)], sort=sort, topster_size=40, match_type=B.SUM_SCORE, prioritize_token_position=True))
+    hits = g.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all()
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(hits, i, H.oracle_keyword(orc, q), "array q=%s fields=%s" % (q.tokens, q.fields))
+    assert hits.n_hits.sum() > 2000

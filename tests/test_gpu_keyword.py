@@ -197,6 +197,12 @@ test_keyword_filter_ids_hits_ids_and_the_reference_match_count = EK.test_keyword
 test_keyword_filter_ids_with_excluded_ids = EK.test_keyword_filter_ids_with_excluded_ids
 test_multi_field_union_per_token_and_field_aggregation = EK.test_multi_field_union_per_token_and_field_aggregation
 test_wildcard_search_ranks_filter_ids_by_sort_keys = EK.test_wildcard_search_ranks_filter_ids_by_sort_keys
+test_string_array_fields_match_per_element_and_mix_with_plain_fields = EK.test_string_array_fields_match_per_element_and_mix_with_plain_fields
+
+
+@pytest.fixture(scope="module")
+def pair_arr():
+    yield from EK.pair_arr.__wrapped__()
 
 
 def test_wildcard_over_2m_docs(c2m):

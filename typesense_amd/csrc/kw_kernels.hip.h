@@ -101,6 +101,7 @@ struct KwQueryDev {                  // one search_across_fields call
 struct KwQueryMF {
     uint32_t list[KW_MAX_TOKENS][KW_MAX_FIELDS];   // list handle of (found token t, field f) or KW_NONE
     int32_t weight[KW_MAX_FIELDS];                 // the_fields[f].weight
+    uint8_t is_array[KW_MAX_FIELDS];               // field f is a string[] field
     uint32_t n_fields;
     uint32_t driver_token;                         // the token whose lists (one work item group per field) drive the scan
 };
@@ -388,6 +389,129 @@ __device__ inline uint64_t field_match_score(const KwQueryDev& q, const TokRun (
            (verbatim << 12) | (offset_score << 4) | synonym_score;
 }
 
+__device__ inline TokRun empty_run() { TokRun r; r.w = nullptr; r.start = 0; r.n = 0; r.bits = 0; r.base = 0; r.last_flag = 0; r.raw_len = 0; return r; }
+
+// ---- string[] fields: one token's run holds one group per array element it occurs in —
+//      p1 .. pn, pn (last position repeated), array_index [, 0 if the token is that element's last token]
+// (src/index.cpp:1351-1395). The three readers below restate posting_list_t::get_offsets (src/posting_list.cpp:832-916),
+// is_single_token_verbatim_match (:918-959) and get_last_offset (:1899-1951) literally, quirks included.
+struct ArrCursor { uint32_t i; uint32_t is_last; };
+struct ArrElem { uint32_t start, n, aidx, last; bool valid; };
+
+// next (array_index, positions) group of the run, get_offsets' while-loop resumed at c.i
+__device__ inline ArrElem arr_next_elem(const TokRun& r, ArrCursor& c) {
+    ArrElem e; e.start = 0; e.n = 0; e.aidx = 0; e.last = 0; e.valid = false;
+    int prev_pos = -1;
+    const uint32_t len = r.raw_len;
+    while (c.i < len) {
+        const int pos = (int)run_raw(r, c.i);
+        c.i++;
+        if (pos == 0) { c.is_last = 1; c.i++; continue; }
+        if (pos == prev_pos) {                         // end of an array element
+            if (e.n != 0) {
+                e.aidx = c.i < len ? run_raw(r, c.i) : 0;
+                c.is_last = 0;
+                if (c.i + 1 < len && run_raw(r, c.i + 1) == 0) { c.is_last = 1; c.i++; }
+                c.i++;
+                e.last = c.is_last; e.valid = true;
+                return e;
+            }
+            c.i++;
+            prev_pos = -1;
+            continue;
+        }
+        prev_pos = pos;
+        if (e.n == 0) e.start = r.start + c.i - 1;
+        e.n++;
+    }
+    if (e.n != 0) { e.aidx = 0; e.last = c.is_last; e.valid = true; }     // unterminated tail: treated as a plain string run
+    return e;
+}
+
+__device__ inline uint32_t arr_single_verbatim(const TokRun& r) {
+    int prev_pos = -1;
+    uint32_t i = 0;
+    const uint32_t len = r.raw_len;
+    while (i < len) {
+        const int pos = (int)run_raw(r, i);
+        i++;
+        if (pos == prev_pos && pos == 1 && i + 1 < len && run_raw(r, i + 1) == 0) return 1;
+        prev_pos = pos;
+    }
+    return 0;
+}
+
+__device__ inline uint32_t arr_last_offset(const TokRun& r) {
+    int prev_pos = -1;
+    uint32_t i = 0, max_offset = 0;
+    const uint32_t len = r.raw_len;
+    while (i < len) {
+        const int pos = (int)run_raw(r, i);
+        i++;
+        if ((uint32_t)pos > max_offset) max_offset = (uint32_t)pos;
+        if (pos == prev_pos) {
+            if (i + 1 < len && run_raw(r, i + 1) == 0) i++;
+            i++;
+            prev_pos = -1;
+            continue;
+        }
+        prev_pos = pos;
+    }
+    return max_offset;
+}
+
+// score_results2 for a string[] field: Match per array element over the tokens that occur in it, best element wins
+template <int TMAX>
+__device__ inline uint64_t field_match_score_array(const KwQueryDev& q, const TokRun (&runs)[TMAX], uint32_t n_present) {
+    if (n_present <= 1) {
+        const TokRun& r = runs[0];
+        const bool single_exact_query_token = (q.total_cost == 0 && q.n_query_tokens == 1);
+        const uint32_t verbatim = (q.prio_exact && single_exact_query_token) ? arr_single_verbatim(r) : 0u;
+        const uint32_t max_offset = q.prio_pos ? (arr_last_offset(r) & 0xFF) : 255u;
+        return pack_match_score(1, 1, q.total_cost, 0, verbatim, max_offset, 1);
+    }
+    ArrCursor cur[TMAX];
+    ArrElem el[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; t++) {
+        cur[t].i = 0; cur[t].is_last = 0;
+        if ((uint32_t)t < n_present) el[t] = arr_next_elem(runs[t], cur[t]);
+        else { el[t].valid = false; el[t].aidx = 0; el[t].start = 0; el[t].n = 0; el[t].last = 0; }
+    }
+    uint64_t best = 0;
+    for (;;) {
+        uint32_t a = 0xFFFFFFFFu;
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < TMAX; t++) if (el[t].valid && el[t].aidx <= a) { if (!any || el[t].aidx < a) a = el[t].aidx; any = true; }
+        if (!any) break;
+        TokRun sub[TMAX];
+#pragma unroll
+        for (int t = 0; t < TMAX; t++) sub[t] = empty_run();
+        uint32_t m = 0;
+#pragma unroll
+        for (int t = 0; t < TMAX; t++) {
+            if (el[t].valid && el[t].aidx == a) {
+                TokRun r = runs[t];
+                r.start = el[t].start; r.n = el[t].n; r.last_flag = el[t].last; r.raw_len = el[t].n;
+#pragma unroll
+                for (int j = 0; j < TMAX; j++) if ((uint32_t)j == m) sub[j] = r;
+                m++;
+                el[t] = arr_next_elem(runs[t], cur[t]);       // a token may occur in the same element index only once per group
+            }
+        }
+        const MatchOut mo = match_window<TMAX>(sub, m, q.prio_exact != 0);
+        const uint64_t s = pack_match_score(mo.words_present, n_present, q.total_cost, mo.distance, mo.exact_match, mo.max_offset, 1);
+        const uint64_t this_words_present = (s >> 40) & 0xFF, unique_words = this_words_present /* array field, :7041 */, typo_score = (s >> 24) & 0xFF;
+        const uint64_t proximity = (s >> 16) & 0xFF, verbatim = (s >> 12) & 0xF;
+        const uint64_t offset_score = q.prio_pos ? ((s >> 4) & 0xFF) : 0, synonym_score = s & 0xF;
+        const uint64_t mod = (this_words_present << 40) | (unique_words << 32) | (typo_score << 24) | (proximity << 16) |
+                             (verbatim << 12) | (offset_score << 4) | synonym_score;
+        if (mod > best) best = mod;
+    }
+    return best;
+}
+
 // the per-field fold of compute_aggregated_score (src/index.cpp:5296-5330) and its packing (:5332-5382)
 struct AggState { int64_t best_fms = 0, best_w = 0, sum = 0; uint32_t n_fields = 0; };
 __device__ inline void agg_add(AggState& st, uint32_t match_type, uint64_t field_score, int64_t field_weight) {
@@ -436,7 +560,6 @@ __device__ inline ScoredHit sort_scores(const IndexView& ix, const KwQueryDev& q
     return h;
 }
 
-__device__ inline TokRun empty_run() { TokRun r; r.w = nullptr; r.start = 0; r.n = 0; r.bits = 0; r.base = 0; r.last_flag = 0; r.raw_len = 0; return r; }
 
 // score_results2 + compute_aggregated_score + compute_sort_scores for ONE query_by field (plain string); pos[t] = posting
 // position of found token t
@@ -451,7 +574,7 @@ __device__ inline ScoredHit score_hit(const IndexView& ix, const KwQueryDev& q, 
         else runs[t] = empty_run();
     }
     AggState st;
-    agg_add(st, q.match_type, field_match_score<TMAX>(q, runs, T), q.weight);
+    agg_add(st, q.match_type, field_match_score<TMAX>(q, runs, T), q.weight);      // (string[] fields take the multi-field kernel: the planner routes them)
     return sort_scores(ix, q, seq_id, agg_finish(st, q, T), off_words);
 }
 
@@ -482,7 +605,7 @@ __device__ inline ScoredHit score_hit_mf(const IndexView& ix, const KwQueryDev& 
             }
         }
         if (n_present == 0) continue;                     // field holds none of the tokens for this document (:5298-5300)
-        agg_add(st, q.match_type, field_match_score<TMAX>(q, runs, n_present), mf.weight[f]);
+        agg_add(st, q.match_type, mf.is_array[f] ? field_match_score_array<TMAX>(q, runs, n_present) : field_match_score<TMAX>(q, runs, n_present), mf.weight[f]);
     }
     return sort_scores(ix, q, seq_id, agg_finish(st, q, T), off_words);
 }

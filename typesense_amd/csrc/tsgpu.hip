@@ -443,11 +443,13 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             for (uint32_t f = 0; f < in.n_fields && !bad; f++) {
                 auto fit = ctx->fields.find(in.field_ids[f]);
                 if (fit == ctx->fields.end()) bad = TSGPU_ERR_NOT_FOUND;
-                else if (fit->second.is_array) bad = TSGPU_ERR_UNSUPPORTED;     // string[] offset format: not accelerated yet
             }
             if (bad) { P.status[i] = bad; continue; }
         }
-        const bool multi = !wildcard && in.n_fields > 1;
+        // several fields, or a string[] field: the general kernel (per-candidate probes, per-field scoring incl. the array readers);
+        // the block-merge kernel stays free of the array code (it costs 2x the registers)
+        bool multi = !wildcard && in.n_fields > 1;
+        if (!wildcard && !multi && ctx->fields[in.field_ids[0]].is_array) multi = true;
         if (multi && in.n_filter != 0) { unsupported("filter ids with several query_by fields"); continue; }
         if (in.n_sort > TSGPU_MAX_SORT_KEYS) { P.status[i] = TSGPU_ERR_INVALID; continue; }
         if (in.n_filter != 0 && !in.filter_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
@@ -556,6 +558,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             for (uint32_t t = 1; t < nl; t++) if (len_of[t] < len_of[td]) td = t;
             mfq.n_fields = in.n_fields;
             mfq.driver_token = td;
+            for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.is_array[f] = f < in.n_fields && ctx->fields[in.field_ids[f]].is_array ? 1 : 0;
             for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.weight[f] = f < in.n_fields ? in.field_weights[f] : 0;
             if (k + KW_THREADS > 1024) { unsupported("topster_size with several query_by fields"); continue; }
             q.mf_index = (uint32_t)P.mf.size();
