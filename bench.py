@@ -57,11 +57,19 @@ def dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # TSGPU_DIST_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks (all ranks share device 0,
+    # collectives through gloo); the measured configuration is always nccl (= RCCL over xGMI), one GPU per rank
+    backend = os.environ.get("TSGPU_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == n_gpus, "launch with torch.distributed.run --nproc-per-node %d" % n_gpus
     return rank, world, local
 

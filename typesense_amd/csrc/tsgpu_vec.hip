@@ -465,15 +465,18 @@ int tsgpu_vec_upsert(tsgpu_ctx* ctx, uint32_t vec_field_id, const uint64_t* labe
         else std::copy(labels, labels + n, hl.begin());
         // fast path: n brand-new labels continuing the identity numbering -> one bulk append
         bool bulk = true;
-        for (uint32_t i = 0; i < n && bulk; i++) {
-            uint32_t row;
-            if (f->identity) bulk = hl[i] == f->n_rows + i;
-            else bulk = !f->find_row(hl[i], row);
+        if (f->identity) {
+            for (uint32_t i = 0; i < n && bulk; i++) bulk = hl[i] == f->n_rows + i;
+            if (!bulk) f->break_identity();        // e.g. a doc-range shard whose labels start at its range's first seq_id
         }
-        if (!f->identity && bulk) {   // all new, but check duplicates inside the batch
-            std::vector<uint64_t> tmp(hl);
-            std::sort(tmp.begin(), tmp.end());
-            bulk = std::adjacent_find(tmp.begin(), tmp.end()) == tmp.end();
+        if (!f->identity) {                         // bulk = every label is new and unique inside the batch
+            bulk = true;
+            for (uint32_t i = 0; i < n && bulk; i++) { uint32_t row; bulk = !f->find_row(hl[i], row); }
+            if (bulk) {
+                std::vector<uint64_t> tmp(hl);
+                std::sort(tmp.begin(), tmp.end());
+                bulk = std::adjacent_find(tmp.begin(), tmp.end()) == tmp.end();
+            }
         }
         if (f->n_rows + n > 0xFFFFFFF0ull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_upsert: more than 2^32 rows");
         const hipMemcpyKind kind = mem == TSGPU_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
