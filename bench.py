@@ -222,7 +222,7 @@ class Bench:
         def step():
             g.keyword_search_batch_raw(arr, n_q, hs)           # synchronises its stream before returning
             if world > 1:
-                return self.D.sharded_keyword(dev, K_TOPSTER)
+                return self.D.sharded_keyword(dev, K_TOPSTER, index=g)
             return dev["keys"], dev["scores"], dev["n_hits"], dev["num_matched"]
 
         def after(_):
@@ -349,7 +349,7 @@ class Bench:
 
             def step():      # fuse AFTER the shard merge: reciprocal ranks are global ranks
                 g.keyword_search_batch_raw(arr, n_q, hs)
-                keys, sc, n, nm = self.D.sharded_keyword(dev, K_TOPSTER)
+                keys, sc, n, nm = self.D.sharded_keyword(dev, K_TOPSTER, index=g)
                 g.vec_knn_batch_raw(1, self.Q.data_ptr(), B.MEM_DEVICE, n_q, k, dist_o.data_ptr(), lab_o.data_ptr(), cnt_o.data_ptr(), B.MEM_DEVICE)
                 dm, lm, cm = self.D.sharded_knn(dist_o, lab_o, cnt_o, k)
                 if self.rank != 0:

@@ -262,6 +262,12 @@ int tsgpu_hybrid_fuse_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const
 int tsgpu_merge_shard_hits(const tsgpu_hits* in, const uint64_t* key_offset, uint32_t n_shards,
                            uint32_t n_queries, uint32_t k, tsgpu_hits* out);
 
+/* The same merge on the GPU, for hit lists that an RCCL all-gather left in device memory: every array of `gathered` is laid
+ * out [shard][query][gathered->k_stride] (n_hits / num_matched: [shard][query]); text_match / vector_distance /
+ * match_score_index may be NULL on either side. n_shards * gathered->k_stride <= 4096. Keys must be global seq_ids. */
+int tsgpu_merge_shard_hits_device(tsgpu_ctx* ctx, const tsgpu_hits* gathered, uint32_t n_shards, uint32_t n_queries,
+                                  uint32_t k, tsgpu_hits* out);
+
 /* ------------------------------------------------------------------ measurement hooks */
 /* device time (ms, HIP events on the launch stream) of the dominant kernel(s) of the last batch call */
 typedef struct tsgpu_timings {

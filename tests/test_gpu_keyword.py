@@ -197,6 +197,31 @@ test_keyword_filter_ids_hits_ids_and_the_reference_match_count = EK.test_keyword
 test_keyword_filter_ids_with_excluded_ids = EK.test_keyword_filter_ids_with_excluded_ids
 test_multi_field_union_per_token_and_field_aggregation = EK.test_multi_field_union_per_token_and_field_aggregation
 test_wildcard_search_ranks_filter_ids_by_sort_keys = EK.test_wildcard_search_ranks_filter_ids_by_sort_keys
+
+
+def test_device_shard_merge_on_cuda_tensors(c100k):
+    """the bench's N>1 merge path on the GPU: gathered CUDA tensors -> kw_shard_merge_kernel == torch sort-based merge"""
+    import torch
+    from typesense_amd import dist as D
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    G, Bq, K = 8, 300, 250
+    sc = torch.randint(0, 5, (G, Bq, K, 3), generator=gen, dtype=torch.int64)
+    keys = (torch.rand((G, Bq, K), generator=gen) * 1e6).to(torch.int64) * 8 + torch.arange(G)[:, None, None]      # shard-unique keys
+    n_hits = torch.randint(0, K + 1, (G, Bq), generator=gen, dtype=torch.int32)
+    # sort every per-shard list into Topster order
+    flat = torch.stack([sc[..., 0], sc[..., 1], sc[..., 2], keys], -1).reshape(G * Bq, K, 4).numpy()
+    for r in range(G * Bq):
+        flat[r] = flat[r][np.lexsort((flat[r][:, 3], flat[r][:, 2], flat[r][:, 1], flat[r][:, 0]))[::-1]]
+    flat = torch.from_numpy(flat.copy()).reshape(G, Bq, K, 4)
+    sc, keys = flat[..., :3].contiguous(), flat[..., 3].contiguous()
+    num = torch.randint(0, 10000, (G, Bq), generator=gen, dtype=torch.int64)
+    ref = D.merge_keyword_topk(keys, sc, n_hits, 250)
+    g = {"keys": keys.cuda(), "scores": sc.cuda(), "n_hits": n_hits.cuda(), "num_matched": num.cuda()}
+    k_, s_, n_, nm_ = D.merge_keyword_topk_device(c100k.g, g, 250)
+    for q in range(Bq):
+        n = int(ref[2][q])
+        assert int(n_[q]) == n and torch.equal(k_[q, :n].cpu(), ref[0][q, :n]) and torch.equal(s_[q, :n].cpu(), ref[1][q, :n])
+    assert torch.equal(nm_.cpu(), num.sum(0))
 test_string_array_fields_match_per_element_and_mix_with_plain_fields = EK.test_string_array_fields_match_per_element_and_mix_with_plain_fields
 
 

@@ -1385,4 +1385,61 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
     (void)ids_out; (void)work;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Doc-range shards: exact merge of G gathered per-shard Topster lists into the global order, one workgroup per
+// query. Inputs are what an all-gather of tsgpu_hits delivers: arrays laid out [shard][query][k_in]. Keys are unique across
+// shards, so sorting by (s0, s1, s2, key) = KV::is_greater reproduces Topster::sort() of the unsharded collection; the origin
+// slot rides in the low 16 bits of the packed key so the per-hit payload (text_match, distance, index) follows its hit.
+struct KwShardIn {
+    const uint64_t* keys; const int64_t* scores; const int64_t* text_match; const float* vector_distance; const int8_t* match_score_index;
+    const uint32_t* n_hits; const uint64_t* num_matched;
+    uint32_t n_shards, n_queries, k_in;
+};
+template <int CAP>
+__global__ __launch_bounds__(KW_THREADS) void kw_shard_merge_kernel(KwShardIn in, KwOut out, uint32_t k) {
+    __shared__ TopkLds<CAP> tk;
+    __shared__ uint32_t s_total;
+    const uint32_t t = threadIdx.x, q = blockIdx.x;
+    if (t == 0) s_total = 0;
+    for (int i = t; i < CAP; i += KW_THREADS) tk.key[i] = -1;
+    __syncthreads();
+    for (uint32_t g = 0; g < in.n_shards; g++) {
+        const uint32_t n = in.n_hits[(size_t)g * in.n_queries + q];
+        const size_t base = ((size_t)g * in.n_queries + q) * in.k_in;
+        const uint32_t at = s_total;
+        for (uint32_t i = t; i < n; i += KW_THREADS) {
+            const uint32_t slot = at + i;
+            if (slot < (uint32_t)CAP) {
+                tk.s0[slot] = in.scores[(base + i) * 3 + 0]; tk.s1[slot] = in.scores[(base + i) * 3 + 1]; tk.s2[slot] = in.scores[(base + i) * 3 + 2];
+                tk.key[slot] = (int64_t)((in.keys[base + i] << 16) | (uint64_t)(g * in.k_in + i));
+            }
+        }
+        __syncthreads();
+        if (t == 0) s_total = at + n;
+        __syncthreads();
+    }
+    topk_sort<CAP, true>(tk);
+    const uint32_t total = s_total < (uint32_t)CAP ? s_total : (uint32_t)CAP;
+    const uint32_t n_out = total < k ? total : k;
+    const size_t ob = (size_t)q * out.k_stride;
+    for (uint32_t i = t; i < n_out; i += KW_THREADS) {
+        const uint64_t packed = (uint64_t)tk.key[i];
+        const uint32_t origin = (uint32_t)(packed & 0xFFFFu);
+        const size_t src = ((size_t)(origin / in.k_in) * in.n_queries + q) * in.k_in + origin % in.k_in;
+        out.keys[ob + i] = packed >> 16;
+        out.scores[(ob + i) * 3 + 0] = tk.s0[i]; out.scores[(ob + i) * 3 + 1] = tk.s1[i]; out.scores[(ob + i) * 3 + 2] = tk.s2[i];
+        if (out.text_match) out.text_match[ob + i] = in.text_match ? in.text_match[src] : 0;
+        if (out.vector_distance) out.vector_distance[ob + i] = in.vector_distance ? in.vector_distance[src] : -1.0f;
+        if (out.match_score_index) out.match_score_index[ob + i] = in.match_score_index ? in.match_score_index[src] : (int8_t)0;
+    }
+    if (t == 0) {
+        out.n_hits[q] = n_out;
+        if (out.num_matched) {
+            unsigned long long nm = 0;
+            if (in.num_matched) for (uint32_t g = 0; g < in.n_shards; g++) nm += in.num_matched[(size_t)g * in.n_queries + q];
+            out.num_matched[q] = nm;
+        }
+    }
+}
+
 }  // namespace tsgpu

@@ -797,6 +797,35 @@ static int kw_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_qu
     return ok();
 }
 
+// device-side shard merge (the host version, tsgpu_merge_shard_hits, lives in tsgpu_vec.hip)
+int tsgpu_merge_shard_hits_device(tsgpu_ctx* ctx, const tsgpu_hits* gathered, uint32_t n_shards, uint32_t n_queries, uint32_t k, tsgpu_hits* out) {
+    if (!ctx || !gathered || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_merge_shard_hits_device: NULL argument");
+    if (gathered->mem != TSGPU_MEM_DEVICE || out->mem != TSGPU_MEM_DEVICE) return fail(TSGPU_ERR_INVALID, "tsgpu_merge_shard_hits_device: device arrays only");
+    if (!gathered->keys || !gathered->scores || !gathered->n_hits || !out->keys || !out->scores || !out->n_hits)
+        return fail(TSGPU_ERR_INVALID, "tsgpu_merge_shard_hits_device: missing arrays");
+    if (n_queries == 0) return ok();
+    if (n_shards == 0 || k == 0 || out->k_stride < k) return fail(TSGPU_ERR_INVALID, "tsgpu_merge_shard_hits_device: bad sizes");
+    const uint64_t cap_need = (uint64_t)n_shards * gathered->k_stride;
+    if (cap_need > 4096 || cap_need > 65535) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_merge_shard_hits_device: n_shards * k_stride > 4096");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    KwShardIn in;
+    in.keys = gathered->keys; in.scores = gathered->scores; in.text_match = gathered->text_match; in.vector_distance = gathered->vector_distance;
+    in.match_score_index = gathered->match_score_index; in.n_hits = gathered->n_hits; in.num_matched = gathered->num_matched;
+    in.n_shards = n_shards; in.n_queries = n_queries; in.k_in = gathered->k_stride;
+    KwOut o;
+    o.keys = out->keys; o.scores = out->scores; o.text_match = out->text_match; o.vector_distance = out->vector_distance;
+    o.match_score_index = out->match_score_index; o.n_hits = out->n_hits; o.num_matched = out->num_matched; o.off_words = nullptr; o.k_stride = out->k_stride;
+    hipStream_t s = ctx->stream;
+    if (cap_need <= 512) hipLaunchKernelGGL((kw_shard_merge_kernel<512>), dim3(n_queries), dim3(KW_THREADS), 0, s, in, o, k);
+    else if (cap_need <= 1024) hipLaunchKernelGGL((kw_shard_merge_kernel<1024>), dim3(n_queries), dim3(KW_THREADS), 0, s, in, o, k);
+    else if (cap_need <= 2048) hipLaunchKernelGGL((kw_shard_merge_kernel<2048>), dim3(n_queries), dim3(KW_THREADS), 0, s, in, o, k);
+    else hipLaunchKernelGGL((kw_shard_merge_kernel<4096>), dim3(n_queries), dim3(KW_THREADS), 0, s, in, o, k);
+    TSGPU_HIP_TRY(hipGetLastError());
+    TSGPU_HIP_TRY(hipStreamSynchronize(s));
+    return ok();
+}
+
 uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64_t cap) {
     if (!ctx) return 0;
     std::lock_guard<std::mutex> lk(ctx->mu);

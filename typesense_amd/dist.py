@@ -58,10 +58,34 @@ def merge_knn_topk(dist_t, labels, cnt, k):
     return torch.gather(d, 1, o), torch.gather(l, 1, o), torch.clamp(cnt.to(torch.int64).sum(0), max=k)
 
 
-def sharded_keyword(local, k):
+def merge_keyword_topk_device(index, g, k):
+    """the same merge by libtsgpu's kw_shard_merge_kernel (one workgroup per query, LDS bitonic sort): the gathered CUDA
+    tensors are handed over as raw pointers. index: the rank's GpuIndex."""
+    import ctypes as C
+    import torch
+    from . import _lib as B
+    G, Bq, K = g["keys"].shape
+    dev = g["keys"].device
+    out = dict(keys=torch.empty((Bq, k), dtype=torch.int64, device=dev), scores=torch.empty((Bq, k, 3), dtype=torch.int64, device=dev),
+               n_hits=torch.empty(Bq, dtype=torch.int32, device=dev), num_matched=torch.empty(Bq, dtype=torch.int64, device=dev))
+    hin, hout = B.HitsC(), B.HitsC()
+    hin.mem = hout.mem = B.MEM_DEVICE
+    hin.k_stride, hout.k_stride = K, k
+    for name in ("keys", "scores", "n_hits", "num_matched"):
+        setattr(hin, name, g[name].data_ptr())
+        setattr(hout, name, out[name].data_ptr())
+    torch.cuda.current_stream().synchronize()          # the library runs on its own stream
+    B.check(index.L, index.L.tsgpu_merge_shard_hits_device(index.h, C.byref(hin), G, Bq, k, C.byref(hout)))
+    return out["keys"], out["scores"], out["n_hits"].to(torch.int64), out["num_matched"]
+
+
+def sharded_keyword(local, k, index=None):
     """local: dict(keys [B,K] int64, scores [B,K,3] int64, n_hits [B] int32, num_matched [B] int64) of THIS shard ->
-    merged (keys, scores, n, num_matched) identical on every rank"""
+    merged (keys, scores, n, num_matched) identical on every rank. With `index` (a GpuIndex) and CUDA tensors the merge runs
+    in libtsgpu (kw_shard_merge_kernel); otherwise the torch sort-based merge (CPU tests)."""
     g = {name: all_gather_cat(local[name]) for name in ("keys", "scores", "n_hits", "num_matched")}
+    if index is not None and g["keys"].is_cuda:
+        return merge_keyword_topk_device(index, g, k)
     keys, sc, n = merge_keyword_topk(g["keys"], g["scores"], g["n_hits"], k)
     return keys, sc, n, g["num_matched"].sum(0)
 
