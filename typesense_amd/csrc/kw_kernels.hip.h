@@ -171,6 +171,9 @@ __device__ inline uint32_t block_compact1(bool pred, uint32_t* s_wave_cnt /*[4],
     return base + lane_off;
 }
 
+// (16-ary versions of these searches — 16 independent probes per round instead of 4 dependent binary steps — were measured
+// 1.5x SLOWER end to end: 3.5x the LDS reads and +14..16 VGPRs, i.e. 3 waves per SIMD instead of 4, cost more than the
+// dependent-read latency they save; profiles/r01/prof_kw_s4_kary.txt)
 // is id x in the list? -> posting position (block*256 + slot). Two binary searches, all loads are
 // broadcast / same-line for neighbouring lanes because candidates ascend with the lane id.
 __device__ inline bool probe_list(const IndexView& ix, const ListDesc& d, uint32_t x, uint32_t& pos) {
