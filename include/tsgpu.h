@@ -219,6 +219,22 @@ int tsgpu_vec_knn_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, i
                         const uint32_t* allow_ids, uint32_t n_allow, const uint32_t* excluded_ids, uint32_t n_excluded,
                         float* dist_out, uint64_t* label_out, uint32_t* n_out, int mem_out);
 
+/* HNSW graph search (hnswlib::HierarchicalNSW<float>::searchKnnCloserFirst(q, k, ef, filter) of the Typesense fork, call site
+ * src/index.cpp:3376-3445). The graph is a MIRROR of the server's hnswlib index (its construction stays in the reference's
+ * indexing path): rows of the field = hnswlib internal ids = insertion order; link0[i] = (count, up to 2M neighbour ids) of
+ * level 0 (hnswlib get_linklist0), the lists of node i for levels 1..level(i) are upper_links[(upper_ptr[i] + level - 1)] =
+ * (count, up to M ids) (hnswlib linkLists_), maxlevel / enterpoint = maxlevel_ / enterpoint_node_. Host arrays; M <= 31.
+ * Re-load after the rows change. */
+int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32_t maxlevel, uint32_t enterpoint, const uint32_t* link0,
+                        const uint64_t* upper_ptr, const uint32_t* upper_links, uint32_t n);
+/* up to k (distance, label) per query, closest first, found by greedy descent + the ef-bounded best-first search of layer 0
+ * (max(ef, k) candidates). functor_present: the caller passes a filter functor (Typesense always does) — it selects hnswlib's
+ * stricter stop rule; allow_ids (sorted, NULL = all) / excluded_ids / deleted labels are what the functor and isMarkedDeleted
+ * reject. n_out[q] == 0xFFFFFFFF: the candidate heap outgrew its LDS budget for that query — run it with tsgpu_vec_knn_batch. */
+int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, int mem_q, uint32_t n_q, uint32_t k, uint32_t ef,
+                                int functor_present, const uint32_t* allow_ids, uint32_t n_allow, const uint32_t* excluded_ids,
+                                uint32_t n_excluded, float* dist_out, uint64_t* label_out, uint32_t* n_out, int mem_out);
+
 /* distances of one query to explicit labels (flat scan over filter ids, src/index.cpp:3345-3374);
  * missing labels get NaN (the reference `continue`s on the throw). Host pointers. */
 int tsgpu_vec_distances(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* q, const uint64_t* labels, uint32_t n,

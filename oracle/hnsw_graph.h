@@ -1,0 +1,255 @@
+// TEST INFRASTRUCTURE ONLY (oracle/): CPU restatement of the HNSW index Typesense uses through
+// hnswlib::HierarchicalNSW<float> (include/index.h:356-370; call sites src/index.cpp:1003-1054 addPoint,
+// :3376-3445 searchKnnCloserFirst with a VectorFilterFunctor, :7423 markDelete).
+//
+// PARITY UNPINNED: hnswlib is a third-party dependency that is NOT under /root/reference (typesense/hnswlib fork,
+// cmake/hnsw.cmake:3 pins 21de18ffabea1a9d1e8b16b49afc6045d7707e4c, WORKSPACE:186-191 pins 687d9817...). This file restates
+// the published algorithm of hnswlib 0.7 (Malkov & Yashunin; hnswalg.h: getRandomLevel, addPoint, searchBaseLayer,
+// getNeighborsByHeuristic2, mutuallyConnectNewElement, searchKnn, searchBaseLayerST) from upstream knowledge; no reference
+// test fixes which approximate neighbours come back, so the GPU traversal is checked against THIS restatement
+// on the same graph, and its recall against the exact scan. Distances are the oracle's InnerProductSpace restatement
+// (Index::ip_distance), i.e. bit-identical to what the exact path returns.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <queue>
+#include <random>
+#include <unordered_map>
+#include <vector>
+
+namespace oracle {
+
+struct hnsw_graph_t {
+    typedef uint32_t tableint;
+    typedef std::pair<float, tableint> dist_id_t;
+    struct CompareByFirst {
+        constexpr bool operator()(const dist_id_t& a, const dist_id_t& b) const noexcept { return a.first < b.first; }
+    };
+    typedef std::priority_queue<dist_id_t, std::vector<dist_id_t>, CompareByFirst> heap_t;
+
+    size_t dim = 0, M = 16, maxM = 16, maxM0 = 32, ef_construction = 200;
+    double mult = 0;
+    int maxlevel = -1;
+    tableint enterpoint = (tableint)-1;
+    std::default_random_engine level_generator;                 // hnswlib: level_generator_.seed(random_seed), seed 100 (include/index.h:367)
+    float (*distfn)(const float*, const float*, size_t) = nullptr;
+
+    std::vector<float> data;                                    // [n][dim] (rows in insertion order = internal ids)
+    std::vector<uint64_t> labels;
+    std::vector<uint8_t> deleted;
+    std::vector<int> levels;
+    std::vector<std::vector<tableint>> link0;                   // level 0: up to maxM0 neighbours
+    std::vector<std::vector<std::vector<tableint>>> linkU;      // [node][level-1]: up to maxM neighbours
+
+    void init(size_t dim_, size_t M_, size_t efc, size_t seed, float (*fn)(const float*, const float*, size_t)) {
+        dim = dim_; M = M_; maxM = M_; maxM0 = 2 * M_; ef_construction = std::max(efc, M_);
+        mult = 1 / log(1.0 * M);
+        level_generator.seed(seed);
+        distfn = fn;
+    }
+    size_t size() const { return labels.size(); }
+    const float* vec(tableint i) const { return data.data() + (size_t)i * dim; }
+    float dist(const float* a, const float* b) const { return distfn(a, b, dim); }
+
+    int getRandomLevel(double reverse_size) {
+        std::uniform_real_distribution<double> distribution(0.0, 1.0);
+        double r = -log(distribution(level_generator)) * reverse_size;
+        return (int)r;
+    }
+    std::vector<tableint>& list_of(tableint node, int level) { return level == 0 ? link0[node] : linkU[node][level - 1]; }
+    const std::vector<tableint>& list_of(tableint node, int level) const { return level == 0 ? link0[node] : linkU[node][level - 1]; }
+
+    // searchBaseLayer (construction): ef_construction-bounded beam on one layer
+    heap_t searchBaseLayer(tableint ep_id, const float* q, int layer) {
+        std::vector<uint8_t> visited(size(), 0);
+        heap_t top_candidates, candidateSet;
+        float lowerBound;
+        if (!deleted[ep_id]) {
+            float d = dist(q, vec(ep_id));
+            top_candidates.emplace(d, ep_id);
+            lowerBound = d;
+            candidateSet.emplace(-d, ep_id);
+        } else {
+            lowerBound = std::numeric_limits<float>::max();
+            candidateSet.emplace(-lowerBound, ep_id);
+        }
+        visited[ep_id] = 1;
+        while (!candidateSet.empty()) {
+            dist_id_t curr = candidateSet.top();
+            if ((-curr.first) > lowerBound && top_candidates.size() == ef_construction) break;
+            candidateSet.pop();
+            const std::vector<tableint>& nb = list_of(curr.second, layer);
+            for (size_t j = 0; j < nb.size(); j++) {
+                tableint c = nb[j];
+                if (visited[c]) continue;
+                visited[c] = 1;
+                float d1 = dist(q, vec(c));
+                if (top_candidates.size() < ef_construction || lowerBound > d1) {
+                    candidateSet.emplace(-d1, c);
+                    if (!deleted[c]) top_candidates.emplace(d1, c);
+                    if (top_candidates.size() > ef_construction) top_candidates.pop();
+                    if (!top_candidates.empty()) lowerBound = top_candidates.top().first;
+                }
+            }
+        }
+        return top_candidates;
+    }
+
+    void getNeighborsByHeuristic2(heap_t& top_candidates, size_t Mlim) {
+        if (top_candidates.size() < Mlim) return;
+        heap_t queue_closest;
+        std::vector<dist_id_t> return_list;
+        while (top_candidates.size() > 0) {
+            queue_closest.emplace(-top_candidates.top().first, top_candidates.top().second);
+            top_candidates.pop();
+        }
+        while (queue_closest.size()) {
+            if (return_list.size() >= Mlim) break;
+            dist_id_t cur = queue_closest.top();
+            float dist_to_query = -cur.first;
+            queue_closest.pop();
+            bool good = true;
+            for (const dist_id_t& second : return_list) {
+                float curdist = dist(vec(second.second), vec(cur.second));
+                if (curdist < dist_to_query) { good = false; break; }
+            }
+            if (good) return_list.push_back(cur);
+        }
+        for (const dist_id_t& cur : return_list) top_candidates.emplace(-cur.first, cur.second);
+    }
+
+    tableint mutuallyConnectNewElement(const float* q, tableint cur_c, heap_t& top_candidates, int level) {
+        size_t Mcurmax = level ? maxM : maxM0;
+        getNeighborsByHeuristic2(top_candidates, M);
+        std::vector<tableint> selected;
+        selected.reserve(M);
+        while (top_candidates.size() > 0) { selected.push_back(top_candidates.top().second); top_candidates.pop(); }
+        tableint next_closest_entry_point = selected.back();
+        list_of(cur_c, level) = selected;
+        for (size_t idx = 0; idx < selected.size(); idx++) {
+            std::vector<tableint>& other = list_of(selected[idx], level);
+            if (other.size() < Mcurmax) {
+                other.push_back(cur_c);
+            } else {
+                float d_max = dist(vec(cur_c), vec(selected[idx]));
+                heap_t candidates;
+                candidates.emplace(d_max, cur_c);
+                for (size_t j = 0; j < other.size(); j++) candidates.emplace(dist(vec(other[j]), vec(selected[idx])), other[j]);
+                getNeighborsByHeuristic2(candidates, Mcurmax);
+                other.clear();
+                while (candidates.size() > 0) { other.push_back(candidates.top().second); candidates.pop(); }
+            }
+        }
+        (void)q;
+        return next_closest_entry_point;
+    }
+
+    // addPoint(data, label, replace_deleted = true) for a NEW label (Typesense removes + re-adds on update; src/index.cpp:1052-1054)
+    void addPoint(const float* v, uint64_t label) {
+        tableint cur_c = (tableint)size();
+        labels.push_back(label);
+        deleted.push_back(0);
+        data.insert(data.end(), v, v + dim);
+        int curlevel = getRandomLevel(mult);
+        levels.push_back(curlevel);
+        link0.emplace_back();
+        linkU.emplace_back((size_t)curlevel);
+        int maxlevelcopy = maxlevel;
+        tableint currObj = enterpoint;
+        const float* q = vec(cur_c);
+        if ((int32_t)currObj != -1) {
+            if (curlevel < maxlevelcopy) {
+                float curdist = dist(q, vec(currObj));
+                for (int level = maxlevelcopy; level > curlevel; level--) {
+                    bool changed = true;
+                    while (changed) {
+                        changed = false;
+                        const std::vector<tableint>& nb = list_of(currObj, level);
+                        for (size_t i = 0; i < nb.size(); i++) {
+                            float d = dist(q, vec(nb[i]));
+                            if (d < curdist) { curdist = d; currObj = nb[i]; changed = true; }
+                        }
+                    }
+                }
+            }
+            for (int level = std::min(curlevel, maxlevelcopy); level >= 0; level--) {
+                heap_t top_candidates = searchBaseLayer(currObj, q, level);
+                currObj = mutuallyConnectNewElement(q, cur_c, top_candidates, level);
+            }
+        } else {
+            enterpoint = 0;
+            maxlevel = curlevel;
+        }
+        if (curlevel > maxlevelcopy) { enterpoint = cur_c; maxlevel = curlevel; }
+    }
+
+    // searchBaseLayerST<has_deletions, ...>(ep, q, ef, isIdAllowed): allow == nullptr = every row allowed
+    heap_t searchBaseLayerST(tableint ep_id, const float* q, size_t ef, const uint8_t* allow, bool has_deletions, uint64_t* n_dist = nullptr) const {
+        std::vector<uint8_t> visited(size(), 0);
+        heap_t top_candidates, candidate_set;
+        float lowerBound;
+        auto ok = [&](tableint i) { return (!has_deletions || !deleted[i]) && (!allow || allow[i]); };
+        if (ok(ep_id)) {
+            float d = dist(q, vec(ep_id));
+            lowerBound = d;
+            top_candidates.emplace(d, ep_id);
+            candidate_set.emplace(-d, ep_id);
+        } else {
+            lowerBound = std::numeric_limits<float>::max();
+            candidate_set.emplace(-lowerBound, ep_id);
+        }
+        visited[ep_id] = 1;
+        while (!candidate_set.empty()) {
+            dist_id_t cur = candidate_set.top();
+            if ((-cur.first) > lowerBound && (top_candidates.size() == ef || (!allow && !has_deletions))) break;
+            candidate_set.pop();
+            const std::vector<tableint>& nb = link0[cur.second];
+            for (size_t j = 0; j < nb.size(); j++) {
+                tableint c = nb[j];
+                if (visited[c]) continue;
+                visited[c] = 1;
+                float d = dist(q, vec(c));
+                if (n_dist) (*n_dist)++;
+                if (top_candidates.size() < ef || lowerBound > d) {
+                    candidate_set.emplace(-d, c);
+                    if (ok(c)) top_candidates.emplace(d, c);
+                    if (top_candidates.size() > ef) top_candidates.pop();
+                    if (!top_candidates.empty()) lowerBound = top_candidates.top().first;
+                }
+            }
+        }
+        return top_candidates;
+    }
+
+    // searchKnnCloserFirst(q, k, ef, filter) of the Typesense fork: ef = max(ef, k) candidates at layer 0, closest first
+    std::vector<std::pair<float, uint64_t>> searchKnnCloserFirst(const float* q, size_t k, size_t ef, const uint8_t* allow, uint64_t* n_dist = nullptr) const {
+        std::vector<std::pair<float, uint64_t>> result;
+        if (size() == 0) return result;
+        tableint currObj = enterpoint;
+        float curdist = dist(q, vec(enterpoint));
+        for (int level = maxlevel; level > 0; level--) {
+            bool changed = true;
+            while (changed) {
+                changed = false;
+                const std::vector<tableint>& nb = linkU[currObj][level - 1];
+                for (size_t i = 0; i < nb.size(); i++) {
+                    float d = dist(q, vec(nb[i]));
+                    if (n_dist) (*n_dist)++;
+                    if (d < curdist) { curdist = d; currObj = nb[i]; changed = true; }
+                }
+            }
+        }
+        bool has_deletions = false;
+        for (uint8_t dlt : deleted) if (dlt) { has_deletions = true; break; }
+        heap_t top = searchBaseLayerST(currObj, q, std::max(ef, k), allow, has_deletions, n_dist);
+        while (top.size() > k) top.pop();
+        result.resize(top.size());
+        size_t sz = top.size();
+        while (!top.empty()) { result[--sz] = {top.top().first, labels[top.top().second]}; top.pop(); }
+        return result;
+    }
+};
+
+}  // namespace oracle

@@ -6,6 +6,8 @@
 #include <atomic>
 #include <chrono>
 #include "oracle_index.h"
+#include "hnsw_graph.h"
+#include <map>
 
 using namespace oracle;
 
@@ -158,6 +160,70 @@ uint32_t orc_flat_knn(void* h, const float* q, uint32_t k, const uint32_t* allow
     auto hits = idx->flat_knn(qv, k, n_allow ? &allow : nullptr);
     for (size_t i = 0; i < hits.size(); i++) { dist_out[i] = hits[i].dist; label_out[i] = hits[i].seq_id; }
     return (uint32_t)hits.size();
+}
+
+// ---- HNSW (hnsw_graph.h): graph over the index's vectors in row (= insertion) order; one graph per oracle index ----
+static std::map<void*, hnsw_graph_t*>& hnsw_of() { static std::map<void*, hnsw_graph_t*> m; return m; }
+static float hnsw_dist(const float* a, const float* b, size_t dim) { return Index::ip_distance(a, b, dim); }
+
+void orc_hnsw_build(void* h, uint32_t M, uint32_t ef_construction, uint32_t seed) {
+    Index* idx = (Index*)h;
+    auto& slot = hnsw_of()[h];
+    delete slot;
+    slot = new hnsw_graph_t;
+    slot->init(idx->num_dim, M, ef_construction, seed, hnsw_dist);
+    for (size_t r = 0; r < idx->vec_labels.size(); r++) slot->addPoint(idx->vec_store.data() + r * idx->num_dim, idx->vec_labels[r]);
+}
+void orc_hnsw_free(void* h) { auto it = hnsw_of().find(h); if (it != hnsw_of().end()) { delete it->second; hnsw_of().erase(it); } }
+int32_t orc_hnsw_mark_deleted(void* h, uint32_t label) {
+    hnsw_graph_t* g = hnsw_of()[h];
+    for (size_t i = 0; i < g->labels.size(); i++) if (g->labels[i] == label && !g->deleted[i]) { g->deleted[i] = 1; return 0; }
+    return -1;
+}
+// graph in the flat form the GPU mirror takes: levels[n]; link0[n][1 + 2M] = (count, ids..); upper lists of node i (level >= 1,
+// ascending) at upper_links[(upper_ptr[i] + level - 1) * (1 + M)] = (count, ids..). Call with NULL arrays to size: returns the
+// number of upper lists. info = {n, maxlevel, enterpoint, M}
+uint64_t orc_hnsw_export(void* h, int32_t* info, uint32_t* levels, uint32_t* link0, uint64_t* upper_ptr, uint32_t* upper_links) {
+    hnsw_graph_t* g = hnsw_of()[h];
+    const size_t n = g->size(), M = g->M, S0 = 1 + 2 * M, SU = 1 + M;
+    if (info) { info[0] = (int32_t)n; info[1] = g->maxlevel; info[2] = (int32_t)g->enterpoint; info[3] = (int32_t)M; }
+    uint64_t n_upper = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (upper_ptr) upper_ptr[i] = n_upper;
+        if (levels) levels[i] = (uint32_t)g->levels[i];
+        if (link0) {
+            link0[i * S0] = (uint32_t)g->link0[i].size();
+            for (size_t j = 0; j < g->link0[i].size(); j++) link0[i * S0 + 1 + j] = g->link0[i][j];
+        }
+        for (int l = 1; l <= g->levels[i]; l++) {
+            if (upper_links) {
+                const auto& nb = g->linkU[i][l - 1];
+                upper_links[n_upper * SU] = (uint32_t)nb.size();
+                for (size_t j = 0; j < nb.size(); j++) upper_links[n_upper * SU + 1 + j] = nb[j];
+            }
+            n_upper++;
+        }
+    }
+    if (upper_ptr) upper_ptr[n] = n_upper;
+    return n_upper;
+}
+// searchKnnCloserFirst(q, k, ef, filter): allow_ids = sorted label whitelist (VectorFilterFunctor) or NULL
+uint32_t orc_hnsw_search(void* h, const float* q, uint32_t k, uint32_t ef, int32_t functor_present, const uint32_t* allow_ids, uint32_t n_allow,
+                         float* dist_out, uint64_t* label_out, uint64_t* n_dist) {
+    Index* idx = (Index*)h;
+    hnsw_graph_t* g = hnsw_of()[h];
+    std::vector<float> qv(q, q + idx->num_dim);
+    if (idx->distance_type == cosine) { std::vector<float> nrm(qv.size()); Index::normalize_vector(qv, nrm); qv.swap(nrm); }
+    std::vector<uint8_t> allow;                      // Typesense always passes a VectorFilterFunctor (src/index.cpp:3379-3386): it may allow everything
+    if (allow_ids || functor_present) {
+        allow.assign(g->size(), allow_ids ? 0 : 1);
+        if (allow_ids) for (size_t i = 0; i < g->size(); i++) allow[i] = std::binary_search(allow_ids, allow_ids + n_allow, (uint32_t)g->labels[i]) ? 1 : 0;
+    }
+    uint64_t nd = 0;
+    auto res = g->searchKnnCloserFirst(qv.data(), k, ef, allow.empty() ? nullptr : allow.data(), &nd);
+    for (size_t i = 0; i < res.size(); i++) { dist_out[i] = res[i].first; label_out[i] = res[i].second; }
+    if (n_dist) *n_dist = nd;
+    return (uint32_t)res.size();
 }
 
 int32_t orc_search_keyword(void* h, const orc_kw_query* q, orc_result* out) {

@@ -76,6 +76,13 @@ def lib():
         L.orc_flat_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_search_keyword.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.POINTER(Result)]
         L.orc_search_wildcard.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.POINTER(Result)]
+        L.orc_hnsw_build.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_hnsw_free.argtypes = [C.c_void_p]
+        L.orc_hnsw_mark_deleted.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_hnsw_export.restype = C.c_uint64
+        L.orc_hnsw_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_hnsw_search.restype = C.c_uint32
+        L.orc_hnsw_search.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_search_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(Result)]
         L.orc_search_hybrid.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.POINTER(Result)]
@@ -274,6 +281,33 @@ class OracleIndex:
         qv = np.ascontiguousarray(qvec, dtype=np.float32)
         self.L.orc_search_hybrid(self.h, C.byref(q), _ptr(qv), k, alpha, distance_threshold, C.byref(r))
         return self._decode(r, b)
+
+    # ---- HNSW (oracle/hnsw_graph.h) ----
+    def hnsw_build(self, M=16, ef_construction=200, seed=100):
+        """HierarchicalNSW(space, 16, M, ef_construction, 100, true) + addPoint per row in insertion order (include/index.h:365-367)"""
+        self.L.orc_hnsw_build(self.h, M, ef_construction, seed)
+
+    def hnsw_mark_deleted(self, label):
+        return self.L.orc_hnsw_mark_deleted(self.h, int(label))
+
+    def hnsw_export(self):
+        """-> dict(n, maxlevel, enterpoint, M, levels[n], link0[n, 1+2M], upper_ptr[n+1], upper_links[n_upper, 1+M])"""
+        info = np.zeros(4, np.int32)
+        n_upper = self.L.orc_hnsw_export(self.h, _ptr(info), None, None, None, None)
+        n, M = int(info[0]), int(info[3])
+        levels = np.zeros(n, np.uint32); link0 = np.zeros((n, 1 + 2 * M), np.uint32)
+        upper_ptr = np.zeros(n + 1, np.uint64); upper = np.zeros((max(n_upper, 1), 1 + M), np.uint32)
+        self.L.orc_hnsw_export(self.h, _ptr(info), _ptr(levels), _ptr(link0), _ptr(upper_ptr), _ptr(upper))
+        return dict(n=n, maxlevel=int(info[1]), enterpoint=int(info[2]), M=M, levels=levels, link0=link0, upper_ptr=upper_ptr,
+                    upper_links=upper[:n_upper])
+
+    def hnsw_search(self, qvec, k, ef, allow_ids=None, functor_present=True):
+        qv = np.ascontiguousarray(qvec, dtype=np.float32)
+        d = np.zeros(max(k, 1), np.float32); l = np.zeros(max(k, 1), np.uint64); nd = np.zeros(1, np.uint64)
+        a = _u32(allow_ids) if allow_ids is not None else None
+        n = self.L.orc_hnsw_search(self.h, _ptr(qv), k, ef, int(functor_present), _ptr(a) if a is not None else None, a.size if a is not None else 0,
+                                   _ptr(d), _ptr(l), _ptr(nd))
+        return d[:n], l[:n], int(nd[0])
 
     def flat_knn(self, qvec, k, allow_ids=None):
         qv = np.ascontiguousarray(qvec, dtype=np.float32)

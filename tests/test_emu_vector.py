@@ -293,3 +293,35 @@ def test_shard_merge_equals_unsharded():
         assert merged.n_hits[i] == n and merged.num_matched[i] == whole.num_matched[i]
         assert np.array_equal(merged.keys[i, :n], whole.keys[i, :n]) and np.array_equal(merged.scores[i, :n], whole.scores[i, :n])
     g_all.close()
+
+
+@pytest.mark.parametrize("n,dim,M,metric", [(1200, 24, 16, B.METRIC_IP), (700, 48, 6, B.METRIC_COSINE)])
+def test_hnsw_graph_search_replays_the_reference_traversal(n, dim, M, metric):
+    """searchKnnCloserFirst on a mirrored hnswlib graph (oracle/hnsw_graph.h builds it: the published algorithm, parity unpinned):
+    the GPU traversal must return the SAME labels in the same order with the same distance bits as the CPU traversal of that
+    graph — for several (k, ef), with a filter functor, an allow list, deleted labels — and a sane recall vs the exact scan"""
+    g, orc, X, rng = _mk(n, dim, metric, 300 + n, H.emu_lib_path())
+    orc.hnsw_build(M=M, ef_construction=60, seed=100)
+    g.vec_hnsw_load(1, orc.hnsw_export())
+    Q = rng.standard_normal((6, dim)).astype(np.float32)
+    allow = np.sort(rng.choice(n, size=n // 3, replace=False)).astype(np.uint32)
+    hit = tot = 0
+    for k, ef, al, functor in ((10, 10, None, True), (10, 100, None, True), (5, 40, None, False), (25, 30, allow, True), (100, 10, None, True)):
+        dist, lab, cnt = g.vec_hnsw_search_batch(1, Q, k, ef, allow_ids=al, functor_present=functor)
+        for i in range(Q.shape[0]):
+            d, l, _ = orc.hnsw_search(Q[i], k, ef, allow_ids=al, functor_present=functor)
+            assert cnt[i] == d.size and np.array_equal(lab[i, :d.size], l) and np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32)), (k, ef, i)
+            if al is None and ef >= 100:
+                de, le = orc.flat_knn(Q[i], k)
+                hit += len(set(l.tolist()) & set(le.tolist())); tot += k
+    assert hit / tot > 0.9                                            # recall@10 at ef=100
+    # markDelete: deleted labels are traversed but never returned; the stricter stop rule applies
+    for lbl in (3, 77, int(l[0])):
+        g.vec_delete(1, lbl)
+        assert orc.hnsw_mark_deleted(lbl) == 0
+    dist, lab, cnt = g.vec_hnsw_search_batch(1, Q, 10, 50, functor_present=False)
+    for i in range(Q.shape[0]):
+        d, l, _ = orc.hnsw_search(Q[i], 10, 50, functor_present=False)
+        assert cnt[i] == d.size and np.array_equal(lab[i, :d.size], l) and np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32))
+        assert not ({3, 77} & set(lab[i, :cnt[i]].tolist()))
+    g.close()

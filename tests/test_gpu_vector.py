@@ -29,6 +29,39 @@ test_knn_two_pass_threshold_path_is_exact = E.test_knn_two_pass_threshold_path_i
 test_knn_two_pass_all_equal_distances_converges = E.test_knn_two_pass_all_equal_distances_converges
 test_prefilter_distances_are_bit_identical_to_the_reference_order = E.test_prefilter_distances_are_bit_identical_to_the_reference_order
 test_prefilter_brackets_prune_but_never_drop_a_neighbour = E.test_prefilter_brackets_prune_but_never_drop_a_neighbour
+test_hnsw_graph_search_replays_the_reference_traversal = E.test_hnsw_graph_search_replays_the_reference_traversal
+
+
+def test_hnsw_20k_x_96_batch_of_512_matches_the_cpu_traversal():
+    """a graph of 20 000 nodes (M=16, ef_construction=100) mirrored into HBM; 512 concurrent queries (one wavefront each):
+    identical to the CPU traversal of the same graph, recall@10 vs the exact scan reported"""
+    import time
+    rng = np.random.default_rng(12)
+    n, dim = 20_000, 96
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    g = T.GpuIndex(0)
+    g.vec_create(1, dim, B.METRIC_IP, n)
+    g.vec_upsert(1, np.arange(n, dtype=np.uint64), X)
+    orc = O.OracleIndex(1, 1)
+    orc.vec_init(dim, O.METRIC_IP)
+    orc.vec_add(np.arange(n, dtype=np.uint32), X)
+    orc.hnsw_build(M=16, ef_construction=100, seed=100)
+    g.vec_hnsw_load(1, orc.hnsw_export())
+    Q = rng.standard_normal((512, dim)).astype(np.float32)
+    dist, lab, cnt = g.vec_hnsw_search_batch(1, Q, 10, 100)
+    t0 = time.perf_counter()
+    dist, lab, cnt = g.vec_hnsw_search_batch(1, Q, 10, 100)
+    ms = (time.perf_counter() - t0) * 1e3
+    de, le, _ = g.vec_knn_batch(1, Q, 10)
+    hit = 0
+    for i in range(512):
+        if i < 48:
+            d, l, _ = orc.hnsw_search(Q[i], 10, 100)
+            assert cnt[i] == d.size and np.array_equal(lab[i, :d.size], l) and np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32))
+        hit += len(set(lab[i, :cnt[i]].tolist()) & set(le[i].tolist()))
+    print("hnsw 20Kx96 B=512 k=10 ef=100: %.2f ms/batch (host-to-host), recall@10 %.3f" % (ms, hit / 5120))
+    assert hit / 5120 > 0.8
+    g.close()
 
 
 @pytest.fixture(scope="module")

@@ -27,6 +27,12 @@ struct VecField {
     // scratch
     DevBuf d_dense, d_cand, d_cand_cnt, d_tau, dQ, d_dist, d_lab, d_cnt, d_mask, d_rows, d_q1, d_out1;
     DevBuf d_Qh, d_cq, d_L1, d_lbkey, d_surv, d_surv_cnt;
+    // HNSW graph mirror (tsgpu_vec_hnsw_load): hnswlib's link lists; rows = hnswlib internal ids
+    DevBuf g_link0, g_upper_ptr, g_upper_links, g_visited;
+    uint32_t g_M = 0, g_n = 0, g_slots = 0, g_epoch = 1;
+    int32_t g_maxlevel = -1;
+    uint32_t g_enterpoint = 0;
+    bool g_loaded = false;
 
     bool find_row(uint64_t label, uint32_t& row) const {
         if (identity) { if (label < n_rows) { row = (uint32_t)label; return true; } return false; }
@@ -43,7 +49,7 @@ struct VecField {
     }
     void release() {
         DevBuf* b[] = {&X, &labels, &row_ok, &Xh, &xnorm, &tile_nmax, &d_dense, &d_cand, &d_cand_cnt, &d_tau, &dQ, &d_dist, &d_lab, &d_cnt, &d_mask, &d_rows,
-                       &d_q1, &d_out1, &d_Qh, &d_cq, &d_L1, &d_lbkey, &d_surv, &d_surv_cnt};
+                       &d_q1, &d_out1, &d_Qh, &d_cq, &d_L1, &d_lbkey, &d_surv, &d_surv_cnt, &g_link0, &g_upper_ptr, &g_upper_links, &g_visited};
         for (auto* x : b) x->release();
     }
 };
@@ -596,6 +602,99 @@ int tsgpu_vec_knn_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, i
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
         if (f->n_rows) knn_collect_timings(ctx);
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_knn_batch: host allocation failed"); }
+    return ok();
+}
+
+// ---------------------------------------------------------------- HNSW graph mirror + search (seam B2, a18)
+int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32_t maxlevel, uint32_t enterpoint, const uint32_t* link0,
+                        const uint64_t* upper_ptr, const uint32_t* upper_links, uint32_t n) {
+    if (!ctx || !link0 || !upper_ptr) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: NULL argument");
+    if (M < 2 || M > 31) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_hnsw_load: M must be 2..31 (a level-0 list of 2M ids is fetched by one wavefront)");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    VecField* f = get_field(ctx, vec_field_id);
+    if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_hnsw_load: unknown vector field");
+    if (n != f->n_rows) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: the graph must cover exactly the rows of the field (hnswlib internal id = insertion order)");
+    if (n && enterpoint >= n) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: entry point out of range");
+    hipStream_t s = ctx->stream;
+    const uint64_t n_upper = upper_ptr[n];
+    if (n_upper && !upper_links) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: upper_links is NULL");
+    int rc;
+    if ((rc = f->g_link0.reserve((size_t)std::max<uint32_t>(n, 1) * (1 + 2 * M) * 4))) return rc;
+    if ((rc = f->g_upper_ptr.reserve((size_t)(n + 1) * 8))) return rc;
+    if ((rc = f->g_upper_links.reserve((size_t)std::max<uint64_t>(n_upper, 1) * (1 + M) * 4))) return rc;
+    TSGPU_HIP_TRY(hipMemcpyAsync(f->g_link0.p, link0, (size_t)n * (1 + 2 * M) * 4, hipMemcpyHostToDevice, s));
+    TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_ptr.p, upper_ptr, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+    if (n_upper) TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_links.p, upper_links, (size_t)n_upper * (1 + M) * 4, hipMemcpyHostToDevice, s));
+    // visited tags: one uint32 per row and concurrent query slot (hnswlib's VisitedListPool), bounded to ~4 GiB
+    uint32_t slots = 1024;
+    while (slots > 32 && (uint64_t)slots * std::max<uint32_t>(n, 1) * 4 > (4ull << 30)) slots >>= 1;
+    if ((rc = f->g_visited.reserve((size_t)slots * std::max<uint32_t>(n, 1) * 4))) return rc;
+    TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, (size_t)slots * std::max<uint32_t>(n, 1) * 4, s));
+    TSGPU_HIP_TRY(hipStreamSynchronize(s));
+    f->g_M = M; f->g_n = n; f->g_slots = slots; f->g_epoch = 1; f->g_maxlevel = maxlevel; f->g_enterpoint = enterpoint; f->g_loaded = true;
+    return ok();
+}
+
+int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, int mem_q, uint32_t n_q, uint32_t k, uint32_t ef,
+                                int functor_present, const uint32_t* allow_ids, uint32_t n_allow, const uint32_t* excluded_ids, uint32_t n_excluded,
+                                float* dist_out, uint64_t* label_out, uint32_t* n_out, int mem_out) {
+    if (!ctx || !Q || !dist_out || !label_out || !n_out) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_search_batch: NULL argument");
+    if (n_q == 0) return ok();
+    if (k == 0) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_search_batch: k must be > 0");
+    if (std::max(k, ef) > VEC_HNSW_MAX_EF) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_hnsw_search_batch: max(k, ef) > 1024 is not accelerated");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    VecField* f = get_field(ctx, vec_field_id);
+    if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_hnsw_search_batch: unknown vector field");
+    if (!f->g_loaded || f->g_n != f->n_rows) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_search_batch: no graph loaded for the current rows (tsgpu_vec_hnsw_load)");
+    hipStream_t s = ctx->stream;
+    try {
+        const float* Q_dev = nullptr;
+        int rc = stage_queries(ctx, f, Q, mem_q, n_q, &Q_dev);
+        if (rc) return rc;
+        const uint8_t* mask = nullptr;
+        if ((rc = build_mask(ctx, f, allow_ids, n_allow, excluded_ids, n_excluded, &mask))) return rc;
+        float* d_dist = dist_out; uint64_t* d_lab = label_out; uint32_t* d_cnt = n_out;
+        if (mem_out != TSGPU_MEM_DEVICE) {
+            if ((rc = f->d_dist.reserve((size_t)n_q * k * 4))) return rc;
+            if ((rc = f->d_lab.reserve((size_t)n_q * k * 8))) return rc;
+            if ((rc = f->d_cnt.reserve((size_t)n_q * 4))) return rc;
+            d_dist = f->d_dist.as<float>(); d_lab = f->d_lab.as<uint64_t>(); d_cnt = f->d_cnt.as<uint32_t>();
+        }
+        if (f->n_rows == 0) {
+            TSGPU_HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)n_q * 4, s));
+        } else {
+            const uint32_t grid = std::min<uint32_t>(n_q, f->g_slots);
+            const uint32_t iters = (n_q + grid - 1) / grid;
+            if ((uint64_t)f->g_epoch + iters >= 0xFFFFFFF0ull) {      // tag space exhausted: clear the tags
+                TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, (size_t)f->g_slots * f->g_n * 4, s));
+                f->g_epoch = 1;
+            }
+            VecHnswArgs a;
+            memset(&a, 0, sizeof a);
+            a.X = f->X.as<float>(); a.Q = Q_dev; a.dim = f->dim; a.n_rows = (uint32_t)f->n_rows; a.n_q = n_q;
+            a.link0 = f->g_link0.as<uint32_t>(); a.s0 = 1 + 2 * f->g_M;
+            a.upper_ptr = f->g_upper_ptr.as<uint64_t>(); a.upper_links = f->g_upper_links.as<uint32_t>(); a.su = 1 + f->g_M;
+            a.maxlevel = f->g_maxlevel; a.enterpoint = f->g_enterpoint;
+            a.row_ok = mask; a.strict = (functor_present || f->any_deleted) ? 1u : 0u;
+            a.k = k; a.ef = ef; a.visited = f->g_visited.as<uint32_t>(); a.epoch_base = f->g_epoch;
+            a.labels = f->labels.as<uint64_t>(); a.dist_out = d_dist; a.label_out = d_lab; a.n_out = d_cnt;
+            f->g_epoch += iters;
+            TSGPU_HIP_TRY(hipEventRecord(ctx->ev[3], s));
+            hipLaunchKernelGGL(vec_hnsw_search_kernel, dim3(grid), dim3(64), 0, s, a);
+            TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s));
+            TSGPU_HIP_TRY(hipEventRecord(ctx->ev[5], s));
+            TSGPU_HIP_TRY(hipGetLastError());
+        }
+        if (mem_out != TSGPU_MEM_DEVICE) {
+            TSGPU_HIP_TRY(hipMemcpyAsync(dist_out, d_dist, (size_t)n_q * k * 4, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(label_out, d_lab, (size_t)n_q * k * 8, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(n_out, d_cnt, (size_t)n_q * 4, hipMemcpyDeviceToHost, s));
+        }
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        if (f->n_rows) { ctx->scan_events_valid = false; knn_collect_timings(ctx); }
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_hnsw_search_batch: host allocation failed"); }
     return ok();
 }
 

@@ -976,4 +976,189 @@ __global__ __launch_bounds__(VEC_THREADS) void vec_rescore_kernel(const float* _
     }
 }
 
+// ================================================================================================
+// HNSW graph search: hnswlib::HierarchicalNSW<float>::searchKnnCloserFirst(q, k, ef, filter) of
+// the Typesense fork (call site src/index.cpp:3376-3445; VectorFilterFunctor include/index.h:325-354) on a MIRROR of the
+// server's graph — hnswlib's level-0 link lists (count + up to 2M ids per node, coalesced 4*(1+2M)-byte records) and upper-level
+// lists stream from HBM; rows = hnswlib internal ids = insertion order. hnswlib itself is not under /root/reference (PARITY
+// UNPINNED, oracle/hnsw_graph.h): the traversal below restates the published algorithm — greedy descent through the upper
+// layers, then the ef-bounded best-first search of layer 0 with two binary heaps — and is checked against the oracle's
+// restatement on the same graph. One wavefront per query: the 64 lanes fetch a node's neighbour list at once, test/mark the
+// visited tags, and compute the distances of the unvisited neighbours four at a time (16-lane groups = hnswlib's own
+// InnerProductSpace summation order, so every compare sees the bits the CPU would see); lane 0 then replays hnswlib's
+// sequential heap logic over them (std::priority_queue = libstdc++ push_heap / pop_heap, restated so that ties fall the same way).
+struct VecHnswArgs {
+    const float* X; const float* Q; uint32_t dim, n_rows, n_q;
+    const uint32_t* link0; uint32_t s0;                 // [n][s0], s0 = 1 + 2M
+    const uint64_t* upper_ptr; const uint32_t* upper_links; uint32_t su;      // su = 1 + M
+    int32_t maxlevel; uint32_t enterpoint;
+    const uint8_t* row_ok;     // nullable: 0 = deleted or filtered out (isMarkedDeleted / !isIdAllowed)
+    uint32_t strict;           // a filter functor is present or the index has deletions (hnswalg.h searchBaseLayerST break rule)
+    uint32_t k, ef;
+    uint32_t* visited; uint32_t epoch_base;             // [slots][n_rows] tags; slot = blockIdx.x
+    const uint64_t* labels;
+    float* dist_out; uint64_t* label_out; uint32_t* n_out;   // [n_q][k]; n_out = 0xFFFFFFFF: candidate heap overflow (caller re-runs exactly)
+};
+static const uint32_t VEC_HNSW_MAX_EF = 1024;
+static const uint32_t VEC_HNSW_CAND_CAP = 4096;
+static const uint32_t VEC_HNSW_QDIM = 1024;             // queries up to this dim are staged in LDS
+
+struct HnswHeap {          // max-heap on .d (CompareByFirst: a.first < b.first), libstdc++ algorithms
+    float* d; uint32_t* id; uint32_t n;
+    __device__ inline void push(float vd, uint32_t vid) {       // std::push_heap after push_back
+        uint32_t hole = n++;
+        while (hole > 0) {
+            const uint32_t parent = (hole - 1) / 2;
+            if (!(d[parent] < vd)) break;
+            d[hole] = d[parent]; id[hole] = id[parent];
+            hole = parent;
+        }
+        d[hole] = vd; id[hole] = vid;
+    }
+    __device__ inline void pop() {                               // std::pop_heap + pop_back
+        const uint32_t len = --n;                                // heap of len elements after removing the last
+        if (len == 0) return;
+        const float vd = d[len]; const uint32_t vid = id[len];   // value = *(last - 1); its slot receives the old top (dropped)
+        uint32_t hole = 0, second = 0;
+        while (second < (len - 1) / 2) {
+            second = 2 * (second + 1);
+            if (d[second] < d[second - 1]) second--;
+            d[hole] = d[second]; id[hole] = id[second];
+            hole = second;
+        }
+        if ((len & 1) == 0 && second == (len - 2) / 2) {
+            second = 2 * (second + 1);
+            d[hole] = d[second - 1]; id[hole] = id[second - 1];
+            hole = second - 1;
+        }
+        while (hole > 0) {                                       // __push_heap(first, hole, 0, value)
+            const uint32_t parent = (hole - 1) / 2;
+            if (!(d[parent] < vd)) break;
+            d[hole] = d[parent]; id[hole] = id[parent];
+            hole = parent;
+        }
+        d[hole] = vd; id[hole] = vid;
+    }
+};
+
+__global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
+    __shared__ float top_d[VEC_HNSW_MAX_EF + 1];
+    __shared__ uint32_t top_i[VEC_HNSW_MAX_EF + 1];
+    __shared__ float cand_d[VEC_HNSW_CAND_CAP];
+    __shared__ uint32_t cand_i[VEC_HNSW_CAND_CAP];
+    __shared__ float qs_lds[VEC_HNSW_QDIM];
+    __shared__ uint32_t nb_id[64];
+    __shared__ float nb_d[64];
+    __shared__ uint32_t s_cur, s_state, s_top_n;
+    __shared__ float s_curdist;
+    const uint32_t lane = threadIdx.x, sub = lane & 15, grp = lane >> 4;
+    volatile uint32_t* vis = a.visited + (size_t)blockIdx.x * a.n_rows;      // volatile: tags written by this wave are re-read later (no stale L1 lines)
+    uint32_t iter = 0;
+    for (uint32_t q = blockIdx.x; q < a.n_q; q += gridDim.x, iter++) {
+        const uint32_t epoch = a.epoch_base + iter;
+        const float* qs = a.Q + (size_t)q * a.dim;
+        __syncthreads();
+        if (a.dim <= VEC_HNSW_QDIM) {
+            for (uint32_t i = lane; i < a.dim; i += 64) qs_lds[i] = qs[i];
+            qs = qs_lds;
+        }
+        __syncthreads();
+        // distances of the nb_n ids staged in nb_id[] -> nb_d[], four per round
+        auto distances = [&](uint32_t nb_n) {
+            for (uint32_t i0 = 0; i0 < nb_n; i0 += 4) {
+                const uint32_t i = i0 + grp;
+                const uint32_t row = nb_id[i < nb_n ? i : nb_n - 1];
+                const float d = ip_distance_group16(qs, a.X + (size_t)row * a.dim, a.dim, sub);
+                if (i < nb_n && sub == 0) nb_d[i] = d;
+            }
+            __syncthreads();
+        };
+        // ---- upper layers: greedy descent (hnswalg.h searchKnn) ----
+        if (lane == 0) { nb_id[0] = a.enterpoint; }
+        __syncthreads();
+        distances(1);
+        uint32_t cur = a.enterpoint;
+        float curdist = nb_d[0];
+        __syncthreads();
+        for (int level = a.maxlevel; level > 0; level--) {
+            bool changed = true;
+            while (changed) {
+                changed = false;
+                const uint32_t* __restrict__ lst = a.upper_links + (a.upper_ptr[cur] + (uint32_t)(level - 1)) * a.su;
+                const uint32_t cnt = lst[0];
+                if (lane < cnt) nb_id[lane] = lst[1 + lane];
+                __syncthreads();
+                distances(cnt);
+                for (uint32_t i = 0; i < cnt; i++) {                 // in list order, like the reference's loop
+                    const float d = nb_d[i];
+                    if (d < curdist) { curdist = d; cur = nb_id[i]; changed = true; }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- layer 0: searchBaseLayerST(cur, q, max(ef, k), filter) ----
+        const uint32_t ef = a.ef > a.k ? a.ef : a.k;
+        HnswHeap top{top_d, top_i, 0}, cand{cand_d, cand_i, 0};
+        float lowerBound;
+        bool overflow = false;
+        if (lane == 0) {
+            const bool ok = !a.row_ok || a.row_ok[cur] != 0;
+            if (ok) { lowerBound = curdist; top.push(curdist, cur); cand.push(-curdist, cur); }
+            else { lowerBound = 3.402823466e+38f; cand.push(-lowerBound, cur); }
+            vis[cur] = epoch;
+        }
+        for (;;) {
+            if (lane == 0) {
+                uint32_t st = 0;                                  // 0 = expand s_cur, 1 = finished
+                if (cand.n == 0) st = 1;
+                else {
+                    const float cd = cand_d[0];
+                    if ((-cd) > lowerBound && (top.n == ef || !a.strict)) st = 1;
+                    else { s_cur = cand_i[0]; cand.pop(); }
+                }
+                s_state = st;
+            }
+            __syncthreads();
+            if (s_state) break;
+            const uint32_t node = s_cur;
+            const uint32_t* __restrict__ lst = a.link0 + (size_t)node * a.s0;
+            const uint32_t cnt = lst[0];
+            uint32_t c = 0;
+            bool fresh = false;
+            if (lane < cnt) { c = lst[1 + lane]; fresh = vis[c] != epoch; if (fresh) vis[c] = epoch; }
+            const unsigned long long m = __ballot(fresh ? 1 : 0);
+            const uint32_t nf = (uint32_t)__popcll(m);
+            if (fresh) nb_id[__popcll(m & ((1ull << lane) - 1ull))] = c;          // unvisited neighbours, list order kept
+            __syncthreads();
+            if (nf) distances(nf);
+            if (lane == 0) {
+                for (uint32_t i = 0; i < nf; i++) {
+                    const float d = nb_d[i];
+                    const uint32_t cid = nb_id[i];
+                    if (top.n < ef || lowerBound > d) {
+                        if (cand.n >= VEC_HNSW_CAND_CAP) { overflow = true; break; }
+                        cand.push(-d, cid);
+                        if (!a.row_ok || a.row_ok[cid] != 0) top.push(d, cid);
+                        if (top.n > ef) top.pop();
+                        if (top.n) lowerBound = top_d[0];
+                    }
+                }
+                if (overflow) { cand.n = 0; }
+            }
+            __syncthreads();
+        }
+        // ---- result: keep the k closest, closest first (searchKnn + searchKnnCloserFirst) ----
+        if (lane == 0) {
+            if (overflow) a.n_out[q] = 0xFFFFFFFFu;
+            else {
+                while (top.n > a.k) top.pop();
+                uint32_t sz = top.n;
+                a.n_out[q] = sz;
+                while (top.n) { --sz; a.dist_out[(size_t)q * a.k + sz] = top_d[0]; a.label_out[(size_t)q * a.k + sz] = a.labels[top_i[0]]; top.pop(); }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace tsgpu

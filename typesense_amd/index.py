@@ -262,6 +262,26 @@ class GpuIndex:
         self._ck(self.L.tsgpu_vec_knn_batch(self.h, field_id, C.c_void_p(q_ptr), mem_q, n, k, None, 0, None, 0,
                                             C.c_void_p(dist_ptr), C.c_void_p(lab_ptr), C.c_void_p(cnt_ptr), mem_out))
 
+    def vec_hnsw_load(self, field_id, graph):
+        """graph: dict(M, maxlevel, enterpoint, link0[n, 1+2M], upper_ptr[n+1], upper_links[n_upper, 1+M]) — hnswlib's link lists"""
+        l0 = np.ascontiguousarray(graph["link0"], dtype=np.uint32)
+        up = np.ascontiguousarray(graph["upper_ptr"], dtype=np.uint64)
+        ul = np.ascontiguousarray(graph["upper_links"], dtype=np.uint32)
+        self._ck(self.L.tsgpu_vec_hnsw_load(self.h, field_id, int(graph["M"]), int(graph["maxlevel"]), int(graph["enterpoint"]), _vp(l0), _vp(up),
+                                            _vp(ul) if ul.size else None, l0.shape[0]))
+
+    def vec_hnsw_search_batch(self, field_id, Q, k, ef, allow_ids=None, excluded_ids=None, functor_present=True):
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        n = Q.shape[0]
+        dist = np.zeros((n, k), np.float32); lab = np.zeros((n, k), np.uint64); cnt = np.zeros(n, np.uint32)
+        a = None if allow_ids is None else _u32(allow_ids)
+        e = None if excluded_ids is None else _u32(excluded_ids)
+        self._ck(self.L.tsgpu_vec_hnsw_search_batch(self.h, field_id, _vp(Q), B.MEM_HOST, n, k, ef, int(functor_present),
+                                                    _vp(a) if a is not None else None, a.size if a is not None else 0,
+                                                    _vp(e) if e is not None else None, e.size if e is not None else 0,
+                                                    _vp(dist), _vp(lab), _vp(cnt), B.MEM_HOST))
+        return dist, lab, cnt
+
     def vec_distances(self, field_id, q, labels):
         q = np.ascontiguousarray(q, dtype=np.float32)
         labels = np.ascontiguousarray(labels, dtype=np.uint64)
