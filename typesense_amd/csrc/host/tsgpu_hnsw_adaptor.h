@@ -13,8 +13,8 @@
 //     vecdex->getDataByLabel<float>(seq_id)   (throws when missing)          src/index.cpp:3355-3359, 5840, 8860
 //     vecdex->searchKnnCloserFirst(q, k, ef, &filterFunctor)                 src/index.cpp:3384-3386
 //     space->get_dist_func()(a, b, &dim)                                     src/index.cpp:3365
-// Differences, all deliberate: the search is EXACT (ef, M, ef_construction are accepted and ignored: there is no
-// graph), cosine normalisation stays where the reference does it (caller side, src/index.cpp:1049-1052, 3381-3384),
+// Differences, all deliberate: this adaptor's search is EXACT (ef, M, ef_construction are accepted and ignored) — the
+// graph-search twin is mirror_hnsw_graph() + tsgpu_vec_hnsw_search_batch() at the end of this file —, cosine normalisation stays where the reference does it (caller side, src/index.cpp:1049-1052, 3381-3384),
 // and the filter functor is evaluated up front into an allow-list (it is a pure predicate over seq_ids).
 #pragma once
 #include <cstddef>
@@ -125,5 +125,35 @@ public:
         return out;
     }
 };
+
+// Graph search instead of the exact scan: mirror the adjacency of a REAL hnswlib index (the reference keeps building it in
+// its indexing path) into HBM, then tsgpu_vec_hnsw_search_batch replays searchKnnCloserFirst on it. H = hnswlib::HierarchicalNSW<float>
+// (its members are public: data_level0_memory_, size_data_per_element_, offsetLevel0_, linkLists_, element_levels_,
+// size_links_per_element_, maxlevel_, enterpoint_node_, cur_element_count, M_); a template so that this header compiles
+// without hnswlib. The tsgpu field must hold the same vectors in the same insertion order (internal id == row).
+template <class H>
+inline int mirror_hnsw_graph(tsgpu_ctx* ctx, uint32_t field_id, const H& h) {
+    const size_t n = h.cur_element_count, M = h.M_, s0 = 1 + 2 * M, su = 1 + M;
+    std::vector<uint32_t> link0(n * s0, 0), upper;
+    std::vector<uint64_t> upper_ptr(n + 1, 0);
+    for (size_t i = 0; i < n; i++) {
+        const unsigned int* ll0 = (const unsigned int*)(h.data_level0_memory_ + i * h.size_data_per_element_ + h.offsetLevel0_);
+        const unsigned cnt0 = *((const unsigned short*)ll0);                  // getListCount: low 16 bits of the first word
+        link0[i * s0] = cnt0;
+        for (unsigned j = 0; j < cnt0; j++) link0[i * s0 + 1 + j] = ll0[1 + j];
+        upper_ptr[i] = upper.size() / su;
+        for (int level = 1; level <= h.element_levels_[i]; level++) {
+            const unsigned int* ll = (const unsigned int*)(h.linkLists_[i] + (size_t)(level - 1) * h.size_links_per_element_);
+            const unsigned cnt = *((const unsigned short*)ll);
+            const size_t at = upper.size();
+            upper.resize(at + su, 0);
+            upper[at] = cnt;
+            for (unsigned j = 0; j < cnt; j++) upper[at + 1 + j] = ll[1 + j];
+        }
+    }
+    upper_ptr[n] = upper.size() / su;
+    return tsgpu_vec_hnsw_load(ctx, field_id, (uint32_t)M, (int32_t)h.maxlevel_, (uint32_t)h.enterpoint_node_, link0.data(), upper_ptr.data(),
+                               upper.empty() ? nullptr : upper.data(), (uint32_t)n);
+}
 
 }  // namespace tsgpu
