@@ -78,7 +78,7 @@ def test_ties_prefer_smaller_label_and_many_slabs():
 
 @pytest.mark.parametrize("n,dim,k,nq,sample_tiles,cap", [
     (900, 32, 20, 3, 2, 0),         # sample pass (2 of 8 tiles) -> tau -> filtered pass over all rows
-    (600, 32, 20, 65, 1, 0),        # QT=128 workgroup tile (n_q > 64), 1-tile sample
+    (300, 32, 20, 65, 1, 0),        # QT=128 workgroup tile (n_q > 64), 1-tile sample
     (700, 20, 10, 2, 1, 24),       # tiny candidate arena: lists overflow, tighten their own tau, pass 2 repeats
     (600, 36, 50, 4, 3, 0),
 ])
@@ -136,10 +136,11 @@ def _check_knn_bits(g, orc, Q, k, allow=None):
 @pytest.mark.parametrize("dim,n,k,nq,sample_tiles,metric", [
     (768, 300, 100, 3, 512, B.METRIC_IP),      # dim % 16 == 0: InnerProductSIMD16Ext order; dense (small index) route
     (20, 900, 10, 2, 2, B.METRIC_IP),          # dim % 4 == 0: SIMD4Ext order; sample -> L1 -> filtered scan route
-    (70, 400, 25, 65, 1, B.METRIC_IP),         # dim > 16 residual form, QT = 128 tile
+    (70, 260, 25, 65, 1, B.METRIC_IP),         # dim > 16 residual form, QT = 128 tile
     (7, 400, 5, 2, 1, B.METRIC_IP),            # dim > 4 residual form
     (3, 300, 4, 2, 512, B.METRIC_IP),          # scalar form
     (48, 600, 30, 3, 2, B.METRIC_COSINE),      # cosine: normalised rows and query
+    (40, 260, 12, 130, 1, B.METRIC_IP),        # QT = 256 tile (n_q > 128): 64 x 128 wave tiles, 32-wide k steps, 4-slot rings
 ])
 def test_prefilter_distances_are_bit_identical_to_the_reference_order(dim, n, k, nq, sample_tiles, metric):
     g, orc, X, rng = _mk(n, dim, metric, 100 + dim, H.emu_lib_path())

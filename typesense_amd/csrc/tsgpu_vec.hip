@@ -202,11 +202,10 @@ static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, 
     hipStream_t s = ctx->stream;
     const uint32_t n_rows = (uint32_t)f->n_rows;
     const uint32_t n_tiles = (n_rows + VEC_ROWS - 1) / VEC_ROWS;
-    const bool wide = n_q > 64;
-    const uint32_t QT = wide ? 128 : 64;
+    const uint32_t QT = n_q > 128 ? 256 : (n_q > 64 ? 128 : 64);     // query tile of a workgroup: vec_hscan_kernel<QT / 64>
     const uint32_t n_qtiles = (n_q + QT - 1) / QT;
     const uint32_t sample_tiles = ctx->vec_sample_tiles ? ctx->vec_sample_tiles : 8192;   // bf16 sample pass is cheap: ~1M rows
-    const uint32_t n_q_pad = (n_q + 127) / 128 * 128;
+    const uint32_t n_q_pad = (n_q + 255) / 256 * 256;
     int rc;
     if ((rc = f->d_Qh.reserve((size_t)n_q_pad * f->dimp * 2))) return rc;
     if ((rc = f->d_cq.reserve((size_t)n_q * 4))) return rc;
@@ -231,7 +230,8 @@ static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, 
         geometry(a.n_ord, target_wgs, a.ord_per_slab, a.n_slabs);
         a.n_qtiles = n_qtiles;
         const dim3 grid(a.n_slabs * n_qtiles), block(VEC_HTHREADS);
-        if (wide) hipLaunchKernelGGL((vec_hscan_kernel<2>), grid, block, 0, s, a);
+        if (QT == 256) hipLaunchKernelGGL((vec_hscan_kernel<4>), grid, block, 0, s, a);
+        else if (QT == 128) hipLaunchKernelGGL((vec_hscan_kernel<2>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((vec_hscan_kernel<1>), grid, block, 0, s, a);
     };
     if (record_events) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[3], s));

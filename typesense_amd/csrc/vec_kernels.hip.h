@@ -567,10 +567,13 @@ __device__ inline void vec_glds_wait() {        // all but the youngest N vector
 static const int VEC_HTHREADS = 512;
 static const int VEC_HROWS = 2 * VEC_ROWS;          // rows per workgroup step (two 128-row tiles)
 static const int VEC_HMAX_PER = 2048;               // tile ordinals per slab whose norm maxima are staged in LDS
-template <int QT>
+// BK = k elements per pipeline step: 64 (rows of 128 B, 8 pieces, swizzle (R>>1)&7) for the 64 / 128-query tiles; 32 (rows of
+// 64 B, 4 pieces, swizzle (R>>2)&3 — the same 16-distinct-bank-groups argument) for the 256-query tile, whose wave tile is
+// 64 x 128 (CB = 4): 6 operand fetches feed 8 MFMAs instead of 4 feeding 4, and the row block is DMA'd once per 256 queries.
+template <int QT, int BK, int NS>
 struct VecHScanSmem {
-    alignas(16) uint32_t xs[3][VEC_HROWS * 32];
-    alignas(16) uint32_t qs[3][QT * 32];
+    alignas(16) uint32_t xs[NS][VEC_HROWS * BK / 2];
+    alignas(16) uint32_t qs[NS][QT * BK / 2];
     float nmax[VEC_HMAX_PER];  // tile_nmax of the slab's ordinals
     uint32_t cnt[QT];          // mode 0: candidates of this workgroup per query column
 };
@@ -578,7 +581,13 @@ struct VecHScanSmem {
 template <int CB>
 __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a) {
     constexpr int QT = 64 * CB;
-    __shared__ VecHScanSmem<QT> sm;
+    constexpr int BK = CB >= 4 ? 32 : 64;              // k per step
+    constexpr int PR = BK / 8;                          // 16-byte pieces per LDS row
+    constexpr int RW = BK / 2;                          // words per LDS row
+    constexpr int KS = BK / 16;                         // MFMA k-steps per pipeline step
+    constexpr int SWS = PR == 8 ? 1 : 2;                // swizzle = (R >> SWS) & (PR - 1)
+    constexpr int NS = CB >= 4 ? 4 : 3;                 // ring slots: the rings run NS - 1 steps ahead (32 KB slots at CB = 4 leave room for four)
+    __shared__ VecHScanSmem<QT, BK, NS> sm;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t wr = wave >> 1;
     const uint32_t wrow = wr * 64, wcol = (wave & 1) * (32 * CB);
@@ -592,40 +601,46 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
     if (ord_end > a.n_ord) ord_end = a.n_ord;
     if (ord_begin >= ord_end) return;
     const uint32_t n_ord = ord_end - ord_begin;          // <= VEC_HMAX_PER (host)
-    const uint32_t n_chunks = a.dimp / VEC_HKC;
+    const uint32_t n_chunks = a.dimp / BK;               // pipeline steps per tile pair
+    const uint32_t n_c64 = a.dimp / VEC_HKC;             // 64-wide chunks of the mirrors' layout
     const uint32_t total_steps = ((n_ord + 1) / 2) * n_chunks;
 
     for (uint32_t i = t; i < (uint32_t)QT; i += VEC_HTHREADS) sm.cnt[i] = 0;
     for (uint32_t i = t; i < n_ord; i += VEC_HTHREADS) sm.nmax[i] = a.tile_nmax[(ord_begin + i) * a.tile_stride];
     __syncthreads();                                     // plain loads are done before the first DMA is issued
 
-    // Thread t moves pieces idx = t + v*512 of a step: LDS position idx (linear), source piece (idx & 7) ^ ((row >> 1) & 7) of
-    // row idx >> 3 (rows 0..127 = first ordinal of the pair, 128..255 = second). Whole tiles / padded query rows exist in
-    // memory: no clamping of rows (scores of rows >= n_rows / queries >= n_q are dropped by the epilogue).
-    constexpr int XV = VEC_HROWS * 8 / VEC_HTHREADS;    // 16-byte pieces per thread per X step (4)
-    constexpr int QV = QT * 8 / VEC_HTHREADS;           // 2 (QT=128) or 1 (QT=64)
-    uint32_t src_off[XV];                                // 16-byte units inside a 16 KB block
+    // Thread t moves pieces idx = t + v*512 of a step: LDS position idx (linear image), LDS row R = idx / PR (rows 0..127 = first
+    // ordinal of the pair, 128..255 = second), source piece (idx % PR) ^ swizzle(R) of that row's BK-wide slice. Whole tiles /
+    // padded query rows exist in memory: no clamping of rows (scores of rows >= n_rows / queries >= n_q are dropped by the epilogue).
+    constexpr int XV = VEC_HROWS * PR / VEC_HTHREADS;    // 16-byte pieces per thread per X step (4 or 2)
+    constexpr int QV = QT * PR / VEC_HTHREADS;           // 1, 2 or 2
+    uint32_t src_off[XV > QV ? XV : QV];                 // 16-byte units inside a 128-rows x 128-byte block (row * 8 + piece)
 #pragma unroll
-    for (int v = 0; v < XV; v++) {
-        const uint32_t idx = t + v * VEC_HTHREADS, row = (idx >> 3) & 127;
-        src_off[v] = row * 8 + ((idx & 7) ^ ((row >> 1) & 7));
+    for (int v = 0; v < (XV > QV ? XV : QV); v++) {
+        const uint32_t idx = t + v * VEC_HTHREADS, R = idx / PR;
+        src_off[v] = (R & 127) * 8 + ((idx % PR) ^ ((R >> SWS) & (PR - 1)));
     }
     auto load_x = [&](uint32_t s, uint32_t slot) {
-        const uint32_t p = s / n_chunks, c = s % n_chunks;
+        const uint32_t p = s / n_chunks, ss = s % n_chunks;
+        const uint32_t c = ss * BK / VEC_HKC, sub = (ss * BK % VEC_HKC) / 8;           // 64-chunk and first piece of this step's slice
 #pragma unroll
         for (int v = 0; v < XV; v++) {
-            const uint32_t half = (t + v * VEC_HTHREADS) >> 10;                       // which of the two ordinals (uniform per v: 1024 pieces each)
+            const uint32_t half = (t + v * VEC_HTHREADS) / (128 * PR);                  // which of the two ordinals (uniform per v)
             uint32_t o = ord_begin + 2 * p + half;
             o = o < ord_end ? o : ord_end - 1;                                         // odd tail: re-read the last ordinal (dropped by the epilogue)
-            const uint4* __restrict__ xsrc = (const uint4*)(a.Xh + ((size_t)(o * a.tile_stride) * n_chunks + c) * (size_t)(VEC_ROWS * VEC_HKC));
-            vec_glds16(xsrc + src_off[v], &sm.xs[slot][(v * VEC_HTHREADS + wave * 64) * 4]);
+            const uint4* __restrict__ xsrc = (const uint4*)(a.Xh + ((size_t)(o * a.tile_stride) * n_c64 + c) * (size_t)(VEC_ROWS * VEC_HKC));
+            vec_glds16(xsrc + src_off[v] + sub, &sm.xs[slot][(v * VEC_HTHREADS + wave * 64) * 4]);
         }
     };
     auto load_q = [&](uint32_t s, uint32_t slot) {
-        const uint32_t c = s % n_chunks;
+        const uint32_t ss = s % n_chunks;
+        const uint32_t c = ss * BK / VEC_HKC, sub = (ss * BK % VEC_HKC) / 8;
         const uint4* __restrict__ qsrc = (const uint4*)(a.Qh + ((size_t)c * a.n_q_pad + q0) * VEC_HKC);
 #pragma unroll
-        for (int v = 0; v < QV; v++) vec_glds16(qsrc + src_off[v], &sm.qs[slot][(v * VEC_HTHREADS + wave * 64) * 4]);
+        for (int v = 0; v < QV; v++) {
+            const uint32_t idx = t + v * VEC_HTHREADS, R = idx / PR;                    // query rows are not folded to 128
+            vec_glds16(qsrc + R * 8 + ((idx % PR) ^ ((R >> SWS) & (PR - 1))) + sub, &sm.qs[slot][(v * VEC_HTHREADS + wave * 64) * 4]);
+        }
     };
 
     // per-lane query constants: this lane's query column in each of its CB blocks
@@ -641,19 +656,29 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
 
     const uint32_t last = total_steps - 1;
     vec_f32x16 acc[2][CB];
-    load_q(0, 0);
-    load_x(0, 0);
-    load_q(1 < total_steps ? 1 : last, 1);
-    load_x(1 < total_steps ? 1 : last, 1);
-    vec_glds_wait<XV + QV>();                              // step 0 has landed, step 1 may stay in flight
+#pragma unroll
+    for (int i = 0; i < NS - 1; i++) {
+        load_q((uint32_t)i < total_steps ? i : last, i);
+        load_x((uint32_t)i < total_steps ? i : last, i);
+    }
+    vec_glds_wait<(NS - 2) * (XV + QV)>();                 // step 0 has landed, the later ones may stay in flight
     __syncthreads();
     // operand addresses: lane (r = lane&31, h = lane>>5) reads piece 2g+h of its rows = k 16g+8h .. +7: one ds_read_b128 = one
-    // MFMA operand; piece position = (2g+h) ^ ((r>>1)&7) (rows of a lane differ by multiples of 32 -> same swizzle)
-    const uint32_t swz = ((lane & 31) >> 1) & 7, hh = lane >> 5;
-    uint32_t poff[VEC_HKC / 16];
+    // MFMA operand; piece position = (2g+h) ^ swizzle(r) (rows of a lane differ by multiples of 32 -> same swizzle)
+    const uint32_t swz = ((lane & 31) >> SWS) & (PR - 1), hh = lane >> 5;
+    uint32_t poff[KS];
 #pragma unroll
-    for (int g = 0; g < VEC_HKC / 16; g++) poff[g] = (((uint32_t)(2 * g) + hh) ^ swz) * 4;
-    uint32_t xslot = 0;                                  // s % 3
+    for (int g = 0; g < KS; g++) poff[g] = (((uint32_t)(2 * g) + hh) ^ swz) * 4;
+    uint32_t xslot = 0;                                  // s % NS
+    uint4 av[2][2], bv[2][CB];                           // operand double buffer, carried across steps
+    {
+        const uint32_t* xa0 = &sm.xs[0][(wrow + (lane & 31)) * RW];
+        const uint32_t* qb0 = &sm.qs[0][(wcol + (lane & 31)) * RW];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) av[0][rb] = *(const uint4*)(xa0 + rb * 32 * RW + poff[0]);
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) bv[0][cb] = *(const uint4*)(qb0 + cb * 32 * RW + poff[0]);
+    }
     for (uint32_t s = 0; s < total_steps; s++) {
         const uint32_t c = s % n_chunks;
         if (c == 0) {
@@ -666,24 +691,33 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
         }
         // no branch around the DMAs: steps past the end re-request the last blocks into slots nobody reads any more
 #if !defined(VEC_ABL) || !(VEC_ABL & 4)   // VEC_ABL: tools/ ablation builds only (bit 0 no epilogue, bit 1 no MFMA, bit 2 no DMA)
-        load_q(s + 2 < total_steps ? s + 2 : last, xslot >= 1 ? xslot - 1 : 2);       // (s + 2) % 3
-        load_x(s + 2 < total_steps ? s + 2 : last, xslot >= 1 ? xslot - 1 : 2);
+        load_q(s + NS - 1 < total_steps ? s + NS - 1 : last, xslot >= 1 ? xslot - 1 : NS - 1);       // (s + NS - 1) % NS
+        load_x(s + NS - 1 < total_steps ? s + NS - 1 : last, xslot >= 1 ? xslot - 1 : NS - 1);
 #endif
-        const uint32_t* xa = &sm.xs[xslot][(wrow + (lane & 31)) * 32];
-        const uint32_t* qb = &sm.qs[xslot][(wcol + (lane & 31)) * 32];
-        uint4 av[2][2], bv[2][CB];
+        const uint32_t* xa = &sm.xs[xslot][(wrow + (lane & 31)) * RW];
+        const uint32_t* qb = &sm.qs[xslot][(wcol + (lane & 31)) * RW];
 #pragma unroll
-        for (int rb = 0; rb < 2; rb++) av[0][rb] = *(const uint4*)(xa + rb * 32 * 32 + poff[0]);
+        for (int g = 0; g < KS; g++) {
+            const int cur = g & 1, nx = cur ^ 1;                 // KS is even: every step starts on buffer 0
+            if (g + 1 < KS) {
 #pragma unroll
-        for (int cb = 0; cb < CB; cb++) bv[0][cb] = *(const uint4*)(qb + cb * 32 * 32 + poff[0]);
+                for (int rb = 0; rb < 2; rb++) av[nx][rb] = *(const uint4*)(xa + rb * 32 * RW + poff[g + 1 < KS ? g + 1 : g]);
 #pragma unroll
-        for (int g = 0; g < VEC_HKC / 16; g++) {
-            const int cur = g & 1, nx = cur ^ 1;
-            if (g + 1 < VEC_HKC / 16) {
+                for (int cb = 0; cb < CB; cb++) bv[nx][cb] = *(const uint4*)(qb + cb * 32 * RW + poff[g + 1 < KS ? g + 1 : g]);
+            } else {
+                // The step's barrier sits HERE, before the last MFMA group, not after it: every operand of this step is in registers,
+                // so slot s is free; the next step's blocks have landed (counted wait), and its first operands are requested right
+                // behind the barrier — their LDS latency and the waves' barrier skew hide under the last group's MFMAs instead of
+                // stalling every wave at the top of the next step.
+                vec_glds_wait<(NS - 2) * (XV + QV)>();             // all but the youngest NS - 2 steps' DMAs have landed: X(s+1), Q(s+1)
+                __syncthreads();
+                const uint32_t nslot = xslot == NS - 1 ? 0 : xslot + 1;
+                const uint32_t* xa1 = &sm.xs[nslot][(wrow + (lane & 31)) * RW];
+                const uint32_t* qb1 = &sm.qs[nslot][(wcol + (lane & 31)) * RW];
 #pragma unroll
-                for (int rb = 0; rb < 2; rb++) av[nx][rb] = *(const uint4*)(xa + rb * 32 * 32 + poff[g + 1 < VEC_HKC / 16 ? g + 1 : g]);
+                for (int rb = 0; rb < 2; rb++) av[nx][rb] = *(const uint4*)(xa1 + rb * 32 * RW + poff[0]);
 #pragma unroll
-                for (int cb = 0; cb < CB; cb++) bv[nx][cb] = *(const uint4*)(qb + cb * 32 * 32 + poff[g + 1 < VEC_HKC / 16 ? g + 1 : g]);
+                for (int cb = 0; cb < CB; cb++) bv[nx][cb] = *(const uint4*)(qb1 + cb * 32 * RW + poff[0]);
             }
 #if defined(VEC_ABL) && (VEC_ABL & 2)
 #pragma unroll
@@ -770,10 +804,9 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
                 }
             }
         }
-        vec_glds_wait<XV + QV>();                          // all but this step's own DMAs have landed: X(s+1), Q(s+1)
-        __syncthreads();
-        xslot = xslot == 2 ? 0 : xslot + 1;
+        xslot = xslot == NS - 1 ? 0 : xslot + 1;
     }
+    __syncthreads();                                     // sm.cnt is complete
     if (a.mode == 0)
         for (uint32_t i = t; i < (uint32_t)QT; i += VEC_HTHREADS)
             if (q0 + i < a.n_q) a.seg_cnt[(size_t)slab * a.n_q + q0 + i] = sm.cnt[i];
