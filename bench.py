@@ -498,7 +498,7 @@ def main():
             "value": hd["value"], "unit": "queries/s", "n_gpus": world, "steps": hd["steps"], "warmup": args.warmup, "ms_per_step": hd["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32/i64" if head == "keyword" else "f32",
             "data": "synthetic", "config": hd["config"], "p50_ms_per_batch": hd["p50_ms_per_batch"]}
-    for k in ("queries_with_hits", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "fused_hits_per_batch"):
+    for k in ("queries_with_hits", "value_with_host_delivery", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "fused_hits_per_batch"):
         if k in hd:
             line[k] = hd[k]
     line["index_build_s"] = build_s
