@@ -4,6 +4,8 @@
 // hits per query exactly the way the reference's Topster does.
 #include <cmath>
 #include <cfloat>
+#include <atomic>
+#include <thread>
 #include "tsgpu_host.h"
 #include "vec_kernels.hip.h"
 #include "host_topster.h"
@@ -860,16 +862,34 @@ int tsgpu_hybrid_fuse_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const
                             tsgpu_hits* out) {
     if (!ctx || !queries || !p || !kw_hits || !knn_dist || !knn_labels || !knn_cnt || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_hybrid_fuse_batch: NULL argument");
     if (kw_hits->mem != TSGPU_MEM_HOST || out->mem != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_hybrid_fuse_batch: host arrays only");
-    try {
-        for (uint32_t q = 0; q < n_queries; q++) {
-            const int32_t st = kw_hits->status ? kw_hits->status[q] : TSGPU_OK;
-            out->status[q] = st;
-            if (out->search_cutoff) out->search_cutoff[q] = kw_hits->search_cutoff ? kw_hits->search_cutoff[q] : 0;
-            if (st != TSGPU_OK) { out->n_hits[q] = 0; if (out->num_matched) out->num_matched[q] = 0; continue; }
-            fuse_one_query(ctx, metric, queries[q], p, *kw_hits, q, knn_dist + (size_t)q * knn_k, knn_labels + (size_t)q * knn_k, knn_cnt[q], out);
-            if (out->num_matched) out->num_matched[q] = kw_hits->num_matched ? kw_hits->num_matched[q] : 0;
-        }
-    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_hybrid_fuse_batch: host allocation failed"); }
+    // the fusion of one query touches only that query's slots: the batch is spread over host threads (the reference fuses inside
+    // each request thread; here one call carries a whole batch)
+    std::atomic<uint32_t> next{0};
+    std::atomic<int> oom{0};
+    auto worker = [&]() {
+        try {
+            for (;;) {
+                const uint32_t q = next.fetch_add(1);
+                if (q >= n_queries) break;
+                const int32_t st = kw_hits->status ? kw_hits->status[q] : TSGPU_OK;
+                out->status[q] = st;
+                if (out->search_cutoff) out->search_cutoff[q] = kw_hits->search_cutoff ? kw_hits->search_cutoff[q] : 0;
+                if (st != TSGPU_OK) { out->n_hits[q] = 0; if (out->num_matched) out->num_matched[q] = 0; continue; }
+                fuse_one_query(ctx, metric, queries[q], p, *kw_hits, q, knn_dist + (size_t)q * knn_k, knn_labels + (size_t)q * knn_k, knn_cnt[q], out);
+                if (out->num_matched) out->num_matched[q] = kw_hits->num_matched ? kw_hits->num_matched[q] : 0;
+            }
+        } catch (const std::bad_alloc&) { oom = 1; }
+    };
+    const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(hw, 16), std::max<uint32_t>(1, n_queries / 8));
+    if (n_threads <= 1) worker();
+    else {
+        std::vector<std::thread> pool;
+        try { for (uint32_t i = 1; i < n_threads; i++) pool.emplace_back(worker); } catch (...) {}
+        worker();
+        for (auto& th : pool) th.join();
+    }
+    if (oom) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_hybrid_fuse_batch: host allocation failed");
     return ok();
 }
 
