@@ -52,6 +52,7 @@ struct WaveState {
 };
 
 struct BlockState {
+    int or_flag = 0;
     std::vector<Fiber> fibers;
     std::vector<WaveState> waves;
     ucontext_t sched;
@@ -265,6 +266,16 @@ inline f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 #define gridDim (hipemu::cur_gdim())
 
 inline void __syncthreads() { hipemu::syncthreads(); }
+inline int __syncthreads_or(int pred) {      // barrier + OR-reduction over the block (two barriers: publish, then read)
+    hipemu::BlockState* b = hipemu::g();
+    if (pred) b->or_flag = 1;
+    hipemu::syncthreads();
+    const int r = b->or_flag;
+    hipemu::syncthreads();
+    if (hipemu::cur_tid().x == 0) b->or_flag = 0;
+    hipemu::syncthreads();
+    return r;
+}
 inline unsigned long long __ballot(int pred) { return hipemu::ballot(pred); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }

@@ -1358,19 +1358,33 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
         }
         if (t == 0) { s_nm = (q.n_filt && !q.wild_n_ids) ? kw_filter_count(part, q.first_work, 1) : part.n_match[w]; s_ow = part.off_words[w]; }
     } else {
+        // Every partial list is sorted and there may be dozens per query: an entry is taken only if it beats the current k-th best
+        // (thr, refreshed by every compaction), 256 entries per round, and the buffer is re-sorted only when it could overflow —
+        // a handful of bitonic sorts per query instead of one per partial list.
         for (uint32_t w = q.first_work; w < q.first_work + q.n_work; w++) {
             const uint32_t nw = part.cnt[w];
-            if (s_cnt + nw > (uint32_t)CAP) topk_compact<CAP, true>(tk, &s_cnt, q.k, thr, &s_have_thr);
-            const uint32_t base_slot = s_cnt;
             const size_t base = (size_t)w * part.k_stride;
-            for (uint32_t i = t; i < nw; i += KW_THREADS) {
-                tk.s0[base_slot + i] = part.s0[base + i]; tk.s1[base_slot + i] = part.s1[base + i];
-                tk.s2[base_slot + i] = part.s2[base + i]; tk.key[base_slot + i] = part.key[base + i];
+            for (uint32_t i0 = 0; i0 < nw; i0 += KW_THREADS) {
+                const uint32_t held = s_cnt;                        // stable here (the previous round ended with barriers) ...
+                __syncthreads();                                    // ... and nobody appends before everyone has read it
+                if (held + KW_THREADS > (uint32_t)CAP) topk_compact<CAP, true>(tk, &s_cnt, q.k, thr, &s_have_thr);   // CAP >= k + 256
+                const uint32_t i = i0 + t;
+                bool stop = false;
+                if (i < nw) {
+                    const int64_t a0 = part.s0[base + i], a1 = part.s1[base + i], a2 = part.s2[base + i], ak = part.key[base + i];
+                    if (!s_have_thr || ent_greater(a0, a1, a2, ak, thr[0], thr[1], thr[2], thr[3])) {
+                        const uint32_t slot = atomicAdd(&s_cnt, 1u);
+                        tk.s0[slot] = a0; tk.s1[slot] = a1; tk.s2[slot] = a2; tk.key[slot] = ak;
+                    } else stop = true;
+                }
+                __syncthreads();
+                // the list is descending: once an entry fails, the rest of the list fails too
+                if (__syncthreads_or(stop ? 1 : 0)) break;
             }
             __syncthreads();
-            if (t == 0) { s_cnt = base_slot + nw; if (!q.n_filt || q.wild_n_ids) s_nm += part.n_match[w]; s_ow += part.off_words[w]; }
-            __syncthreads();
+            if (t == 0) { if (!q.n_filt || q.wild_n_ids) s_nm += part.n_match[w]; s_ow += part.off_words[w]; }
         }
+        __syncthreads();
         if (t == 0 && q.n_filt && !q.wild_n_ids) s_nm = kw_filter_count(part, q.first_work, q.n_work);
         topk_compact<CAP, true>(tk, &s_cnt, q.k, thr, &s_have_thr);
         n = s_cnt;

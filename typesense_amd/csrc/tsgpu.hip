@@ -589,11 +589,18 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         const ListDesc& dA = ctx->snap.h_lists[q.list[ord[0]]];
         q.ids_out_off = P.ids_total;
         if (keep_ids) P.ids_total += (uint64_t)dA.n_blocks * BLOCK_IDS;
-        for (uint32_t b = 0; b < dA.n_blocks; b += KW_CHUNK_BLOCKS) {
+        // at most 8..64 partial top-K lists per query: kw_merge_kernel folds a query's partials one after the other, and a small
+        // batch (auto chunk 16) would otherwise cut a long driver list into hundreds of work items
+        // (small batches: a few thousand work items fill the chip, more only lengthen the per-query merge chain; measured on the
+        // 10M-doc collection: 100 queries 1.47 -> 1.15 ms, while a cap of 8 at 1 000+ queries unbalances the search kernel)
+        uint32_t chunk_q = KW_CHUNK_BLOCKS;
+        const uint32_t max_partials = n_queries >= 512 ? 64u : std::min<uint32_t>(64, std::max<uint32_t>(16, 4096 / std::max<uint32_t>(n_queries, 1)));
+        if (ctx->kw_chunk_blocks == 0) chunk_q = std::max(chunk_q, (dA.n_blocks + max_partials - 1) / max_partials);
+        for (uint32_t b = 0; b < dA.n_blocks; b += chunk_q) {
             KwWorkItem w;
             w.query = i;
             w.blk_begin = b;
-            w.blk_end = std::min(dA.n_blocks, b + KW_CHUNK_BLOCKS);
+            w.blk_end = std::min(dA.n_blocks, b + chunk_q);
             w.ids_out_off = b * BLOCK_IDS;
             per_q_work[i].push_back(w);
         }
