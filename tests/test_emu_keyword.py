@@ -432,3 +432,29 @@ def test_device_shard_merge_equals_the_torch_merge():
         assert on[q] == n and np.array_equal(ok_[q, :n], rk[q, :n].numpy()) and np.array_equal(os_[q, :n], rs[q, :n].numpy())
         assert onm[q] == num[:, q].sum()
     g.close()
+
+
+def test_edge_cases_empty_index_missing_tokens_and_degenerate_topsters():
+    """empty / ragged inputs: index without any posting, queries whose tokens are all absent, zero queries, Topster of 1,
+    every match excluded, a 1-document collection"""
+    lib = H.emu_lib_path()
+    g = T.GpuIndex(0, lib)
+    g.field_create(0, False)
+    g.set_num_docs(0)
+    g.commit()
+    hits = g.keyword_search_batch([T.KwQuery([1, 2]), T.KwQuery([7])], k_stride=250)
+    assert (hits.status == 0).all() and (hits.n_hits == 0).all() and (hits.num_matched == 0).all()
+    assert g.keyword_search_batch([], k_stride=250).n_hits.size == 0
+    w = g.wildcard_search_batch([T.KwQuery([], sort=((B.SORT_SEQ_ID, 1, 0),))], k_stride=250)
+    assert w.status[0] == 0 and w.n_hits[0] == 0
+    g.close()
+    docs = np.array([[5, 6, 5]], np.uint32)                                   # one document, a repeated token
+    orc, g = H.build_pair(docs, lib)
+    qs = [T.KwQuery([5]), T.KwQuery([5, 6]), T.KwQuery([6, 5, 6]), T.KwQuery([5, 9]), T.KwQuery([9, 9]), T.KwQuery([5], topster_size=1),
+          T.KwQuery([5], excluded_ids=[0]), T.KwQuery([5], filter_ids=[0]), T.KwQuery([5], filter_ids=[3])]
+    hits = g.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all()
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(hits, i, H.oracle_keyword(orc, q), "edge q%d" % i)
+    assert hits.n_hits[4] == 0 and hits.n_hits[6] == 0 and hits.n_hits[8] == 0 and hits.n_hits[7] == 1
+    g.close()

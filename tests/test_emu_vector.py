@@ -326,3 +326,35 @@ def test_hnsw_graph_search_replays_the_reference_traversal(n, dim, M, metric):
         assert cnt[i] == d.size and np.array_equal(lab[i, :d.size], l) and np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32))
         assert not ({3, 77} & set(lab[i, :cnt[i]].tolist()))
     g.close()
+
+
+def test_edge_cases_empty_tiny_and_fully_deleted_indexes():
+    """ragged / degenerate inputs: empty field, one row, k larger than the index, every row deleted, a zero query, dim 1"""
+    lib = H.emu_lib_path()
+    g = T.GpuIndex(0, lib)
+    g.vec_create(1, 5, B.METRIC_IP)
+    dist, lab, cnt = g.vec_knn_batch(1, np.ones((2, 5), np.float32), 3)
+    assert (cnt == 0).all()                                                  # empty field: no hits, no error
+    X = np.arange(15, dtype=np.float32).reshape(3, 5)
+    g.vec_upsert(1, np.array([7, 8, 9], np.uint64), X)
+    orc = O.OracleIndex(1, 1)
+    orc.vec_init(5, O.METRIC_IP)
+    orc.vec_add(np.array([7, 8, 9], np.uint32), X)
+    Q = np.stack([np.zeros(5, np.float32), np.ones(5, np.float32), -np.ones(5, np.float32)])
+    dist, lab, cnt = g.vec_knn_batch(1, Q, 10)                                # k > rows: every row comes back, closest first
+    for i in range(3):
+        d, l = orc.flat_knn(Q[i], 10)
+        assert cnt[i] == 3 and np.array_equal(lab[i, :3].astype(np.uint32), l) and np.array_equal(dist[i, :3].view(np.uint32), d.view(np.uint32))
+    assert np.array_equal(lab[0, :3], [7, 8, 9])                              # zero query: all distances 1.0, ties -> smaller label
+    for lbl in (7, 8, 9):
+        g.vec_delete(1, lbl)
+    dist, lab, cnt = g.vec_knn_batch(1, Q, 2)
+    assert (cnt == 0).all()                                                  # markDelete on every label: nothing left to return
+    g.vec_upsert(1, np.array([8], np.uint64), X[1:2] * 2)                     # addPoint on a deleted label revives it
+    dist, lab, cnt = g.vec_knn_batch(1, Q[1:2], 2)
+    assert cnt[0] == 1 and lab[0, 0] == 8 and dist[0, 0] == np.float32(1.0) - np.float32((X[1] * 2).sum())
+    g.vec_create(2, 1, B.METRIC_COSINE)                                       # dim 1, cosine
+    g.vec_upsert(2, np.array([1, 2], np.uint64), np.array([[3.0], [-2.0]], np.float32))
+    dist, lab, cnt = g.vec_knn_batch(2, np.array([[5.0]], np.float32), 2)
+    assert cnt[0] == 2 and list(lab[0]) == [1, 2] and np.allclose(dist[0], [0.0, 2.0], atol=1e-6)
+    g.close()

@@ -12,6 +12,12 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _real_library(monkeypatch):
+    """bodies shared with tests/test_emu_keyword.py ask for the emulator build: give them the real library here"""
+    monkeypatch.setattr(H, "emu_lib_path", lambda *a, **k: H.gpu_lib_path())
+
 SORT = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
 OSORT = ((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1))
 
@@ -197,6 +203,7 @@ test_keyword_filter_ids_hits_ids_and_the_reference_match_count = EK.test_keyword
 test_keyword_filter_ids_with_excluded_ids = EK.test_keyword_filter_ids_with_excluded_ids
 test_multi_field_union_per_token_and_field_aggregation = EK.test_multi_field_union_per_token_and_field_aggregation
 test_wildcard_search_ranks_filter_ids_by_sort_keys = EK.test_wildcard_search_ranks_filter_ids_by_sort_keys
+test_edge_cases_empty_index_missing_tokens_and_degenerate_topsters = EK.test_edge_cases_empty_index_missing_tokens_and_degenerate_topsters
 
 
 def test_device_shard_merge_on_cuda_tensors(c100k):

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _real_library(monkeypatch):
-    monkeypatch.setattr(H, "emu_lib_path", H.gpu_lib_path)
+    monkeypatch.setattr(H, "emu_lib_path", lambda *a, **k: H.gpu_lib_path())
 
 
 test_knn_matches_oracle_flat_scan = E.test_knn_matches_oracle_flat_scan
@@ -30,6 +30,7 @@ test_knn_two_pass_all_equal_distances_converges = E.test_knn_two_pass_all_equal_
 test_prefilter_distances_are_bit_identical_to_the_reference_order = E.test_prefilter_distances_are_bit_identical_to_the_reference_order
 test_prefilter_brackets_prune_but_never_drop_a_neighbour = E.test_prefilter_brackets_prune_but_never_drop_a_neighbour
 test_hnsw_graph_search_replays_the_reference_traversal = E.test_hnsw_graph_search_replays_the_reference_traversal
+test_edge_cases_empty_tiny_and_fully_deleted_indexes = E.test_edge_cases_empty_tiny_and_fully_deleted_indexes
 
 
 def test_hnsw_20k_x_96_batch_of_512_matches_the_cpu_traversal():
