@@ -8,8 +8,12 @@ config 2 — 10M-doc Zipf collection (V=100K, 32 tokens/doc, seed 2), a batch of
 log-uniform [8,2000]), Topster 250 (per_page 100), sort [_text_match desc, points desc]. With the default
 `--workload all` the same JSON line also carries `vector` (config 3: 10M x 768 fp32, batched exact inner-product
 top-100) and `hybrid` (config 4: keyword + vector + reciprocal-rank fusion) sub-objects, each timed the same way.
-N>1 = the collection split into N contiguous seq_id ranges (doc-range shards, config 5): every rank scores the whole
-batch on its shard, RCCL all-gather of the per-GPU top-K, exact merge (typesense_amd/dist.py); scaling = "strong".
+N>1, default `--dist-mode replicas`: queries are independent units — every GPU holds the collection (10M docs + vectors fit
+one 288 GB GPU many times over), the global batch of N x 10 000 queries is sharded across the GPUs, and ONE RCCL all-gather
+hands every rank the per-GPU top-K of the whole batch; per-GPU work is fixed, scaling = "weak", value = all queries / time.
+`--dist-mode shards` = the collection split into N contiguous seq_id ranges (BASELINE config 5, for collections beyond one
+GPU): every rank scores the whole batch on its shard, all-gather of the per-GPU top-K, exact merge on the device
+(typesense_amd/dist.py, kw_shard_merge_kernel); scaling = "strong".
 
 `roofline` = the dominant kernel: algorithmic bytes (or flops) per launch / its HIP-event time measured inside the
 library on its launch stream. `cpu_baseline` (rank 0, N=1) = the oracle — a port of the reference's CPU path — timed on
@@ -32,6 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA dense peak
 MFMA_BF16_PEAK_TF = 2500.0   # bf16 MFMA dense peak (no sparsity)
+FETCH_SIZE = 100
 K_TOPSTER = 250
 
 
@@ -49,6 +54,10 @@ def parse():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--opt", action="append", default=[], help="tsgpu_set_option name=value (repeatable), e.g. vec_prefilter=0")
+    ap.add_argument("--dist-mode", default="replicas", choices=["replicas", "shards"],
+                    help="N>1: replicas = every GPU holds the collection, the global batch (N x per-GPU batch) is sharded across the GPUs, "
+                         "all-gather of the per-GPU top-K (weak scaling); shards = the collection split into N doc ranges, every GPU scores "
+                         "the whole batch on its shard, all-gather + exact merge (strong scaling, BASELINE config 5)")
     return ap.parse_args()
 
 
@@ -162,7 +171,9 @@ class Bench:
         self.n_docs = args.n_docs
         from typesense_amd import dist as D
         self.D = D
-        self.lo, self.hi = D.shard_range(self.n_docs, rank, world)
+        self.sharded = world > 1 and args.dist_mode == "shards"
+        self.lo, self.hi = D.shard_range(self.n_docs, rank, world) if self.sharded else (0, self.n_docs)
+        self.qseed = 1000 * rank if (world > 1 and not self.sharded) else 0      # replicas: every rank draws its own slice of the global batch
         self.sort = None
         self.csr = None
 
@@ -174,7 +185,7 @@ class Bench:
         t0 = time.time()
         # shard r holds docs [lo, hi): drawn slice by slice (seed per shard, shards i.i.d. like the whole collection;
         # N=1 reproduces seed 2 exactly)
-        self.csr = synth.zipf_corpus_csr(self.hi - self.lo, self.vocab, self.tpd, seed=2 + 1000 * self.rank if self.world > 1 else 2,
+        self.csr = synth.zipf_corpus_csr(self.hi - self.lo, self.vocab, self.tpd, seed=2 + 1000 * self.rank if self.sharded else 2,
                                          doc_base=self.lo)
         self.pts = synth.points_column(n_docs)
         g = self.g
@@ -214,15 +225,22 @@ class Bench:
         from typesense_amd import synth
         torch, g, args, world = self.torch, self.g, self.args, self.world
         n_q = args.batch or 10_000
-        qtok = synth.keyword_queries(n_q, 3, 8, 2000, seed=4)
+        qtok = synth.keyword_queries(n_q, 3, 8, 2000, seed=4 + self.qseed)
         arr = self.kw_query_array(qtok)
         dev, hs = device_hits(torch, n_q, K_TOPSTER)
         kern_ms, merge_ms, alg_bytes = [], [], []
 
         def step():
             g.keyword_search_batch_raw(arr, n_q, hs)           # synchronises its stream before returning
-            if world > 1:
+            if self.sharded:
                 return self.D.sharded_keyword(dev, K_TOPSTER, index=g)
+            if world > 1:
+                # replicas: ONE exchange per step — the all-gather of every GPU's top-100 (fetch size; the Topster's 250 slots are
+                # the reference's internal over-fetch) so that every rank holds the results of the whole global batch
+                top = FETCH_SIZE
+                gathered = [self.D.all_gather_cat(x) for x in (dev["keys"][:, :top].contiguous(), dev["scores"][:, :top].contiguous(),
+                                                               dev["n_hits"], dev["num_matched"])]
+                return gathered[0][self.rank], gathered[1][self.rank], gathered[2][self.rank], gathered[3][self.rank]
             return dev["keys"], dev["scores"], dev["n_hits"], dev["num_matched"]
 
         def after(_):
@@ -282,7 +300,7 @@ class Bench:
         from typesense_amd import _lib as B, synth
         torch, g, args, world = self.torch, self.g, self.args, self.world
         n, dim, k, n_q = self.n_docs, args.dim, args.k, args.vec_batch
-        self.Q = synth.random_vectors(n_q, dim, seed=4, device="cuda")
+        self.Q = synth.random_vectors(n_q, dim, seed=4 + self.qseed, device="cuda")
         Q = self.Q
         dist_o = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
         lab_o = torch.zeros((n_q, k), dtype=torch.int64, device="cuda")
@@ -291,8 +309,11 @@ class Bench:
 
         def step():
             g.vec_knn_batch_raw(1, Q.data_ptr(), B.MEM_DEVICE, n_q, k, dist_o.data_ptr(), lab_o.data_ptr(), cnt_o.data_ptr(), B.MEM_DEVICE)
-            if world > 1:
+            if self.sharded:
                 return self.D.sharded_knn(dist_o, lab_o, cnt_o, k)
+            if world > 1:
+                gathered = [self.D.all_gather_cat(x) for x in (dist_o, lab_o, cnt_o)]
+                return gathered[0][self.rank], gathered[1][self.rank], gathered[2][self.rank]
             return dist_o, lab_o, cnt_o
 
         def after(_):
@@ -344,11 +365,11 @@ class Bench:
         from typesense_amd import _lib as B, synth
         torch, g, args, world = self.torch, self.g, self.args, self.world
         n_q, k = args.vec_batch, args.k
-        qtok = synth.keyword_queries(n_q, 3, 8, 2000, seed=5)
+        qtok = synth.keyword_queries(n_q, 3, 8, 2000, seed=5 + self.qseed)
         qs = [self.T.KwQuery(qtok[i], sort=self.sort, topster_size=K_TOPSTER) for i in range(n_q)]
         arr = self.kw_query_array(qtok)
         Qh = self.Q[:n_q].cpu().numpy()
-        if world == 1:
+        if not self.sharded:                      # 1 GPU, or replicas: every rank fuses its own slice of the global batch
             def step():
                 return g.hybrid_search_batch(qs, 1, Qh, k=k, fetch_size=100, alpha=0.3, k_stride=K_TOPSTER)
         else:
@@ -418,17 +439,24 @@ def main():
         out["hybrid"] = bn.run_hybrid()
     bn.close()
 
-    par = "doc-range shards x%d, RCCL all-gather of per-GPU top-K + exact merge" % world if world > 1 else "1 GPU"
+    sharded = world > 1 and args.dist_mode == "shards"
+    mult = world if (world > 1 and not sharded) else 1            # replicas: the global batch is world x the per-GPU batch
+    if world == 1:
+        par = "1 GPU"
+    elif sharded:
+        par = "doc-range shards x%d, RCCL all-gather of per-GPU top-K + exact device merge" % world
+    else:
+        par = "%d replicas of the collection, global batch = %d x the per-GPU batch sharded across the GPUs, RCCL all-gather of the per-GPU top-K" % (world, world)
     vocab, tpd = (100_000, 32) if args.n_docs >= 1_000_000 else (20_000, 16)
     sub = {}
     if "keyword" in out:
         r = out["keyword"]
-        qps = r["n_q"] * args.steps / r["elapsed"]
+        qps = mult * r["n_q"] * args.steps / r["elapsed"]
         achieved = r["alg_bytes"] / (r["kern_ms"] * 1e-3) / 1e9 if r["kern_ms"] > 0 else 0.0
         kw = line_common(args, world, qps, r["elapsed"], args.steps, r["lat"])
         kw["config"] = {"workload": "BASELINE config 2: %d-doc Zipf(1.0) text, V=%d, %d tokens/doc, %d postings/shard; %d queries/step, 3 distinct "
                                     "terms ranks log-uniform [8,2000], Topster 250, sort [_text_match desc, points desc], num_typos=0, prefix=false"
-                                    % (args.n_docs, vocab, tpd, r["n_postings"], r["n_q"]),
+                                    % (args.n_docs, vocab, tpd, r["n_postings"], r["n_q"] * mult),
                         "parallelism": par, "results_to": "device (tsgpu_hits mem=DEVICE); host delivery is quantified in DESIGN.md §5"}
         kw["queries_with_hits"] = r.get("nonempty")
         if "host_qps" in r:
@@ -447,7 +475,7 @@ def main():
         sub["keyword"] = kw
     if "vector" in out:
         r = out["vector"]
-        qps = r["n_q"] * r["steps"] / r["elapsed"]
+        qps = mult * r["n_q"] * r["steps"] / r["elapsed"]
         tf = r["flops"] / (r["kern_ms"] * 1e-3) / 1e12 if r["kern_ms"] > 0 else 0.0
         v = line_common(args, world, qps, r["elapsed"], r["steps"], r["lat"])
         v["metric"] = "queries/sec, 10M x 768 fp32 exact inner-product top-100"
@@ -483,12 +511,12 @@ def main():
         sub["vector"] = v
     if "hybrid" in out:
         r = out["hybrid"]
-        qps = r["n_q"] * r["steps"] / r["elapsed"]
+        qps = mult * r["n_q"] * r["steps"] / r["elapsed"]
         h = line_common(args, world, qps, r["elapsed"], r["steps"], r["lat"])
         h["metric"] = "queries/sec, 10M-doc hybrid (keyword + 768-d vector, reciprocal rank fusion alpha=0.3), Topster 250"
         h["config"] = {"workload": "BASELINE config 4: configs 2+3 on the same 10M ids, %d queries/step, k_vec=%d; keyword pass + exact k-NN on the GPU, "
                                    "fusion (src/index.cpp:4094-4211) on the host, results delivered to host memory" % (r["n_q"], args.k),
-                       "parallelism": par + (" (fusion after the merge)" if world > 1 else "")}
+                       "parallelism": par + (" (fusion after the merge)" if sharded else "")}
         h["fused_hits_per_batch"] = r.get("fused_hits")
         sub["hybrid"] = h
 
@@ -496,7 +524,7 @@ def main():
     hd = sub[head]
     line = {"metric": "queries/sec, 10M-doc keyword 3-term AND top-100 (Topster 250)" if head == "keyword" else hd.get("metric"),
             "value": hd["value"], "unit": "queries/s", "n_gpus": world, "steps": hd["steps"], "warmup": args.warmup, "ms_per_step": hd["ms_per_step"],
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32/i64" if head == "keyword" else "f32",
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32/i64" if head == "keyword" else "f32",
             "data": "synthetic", "config": hd["config"], "p50_ms_per_batch": hd["p50_ms_per_batch"]}
     for k in ("queries_with_hits", "value_with_host_delivery", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "fused_hits_per_batch"):
         if k in hd:
