@@ -197,6 +197,24 @@ int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, ui
  * sort / topster_size / excluded_ids / filter_ids / deadline_us of the query are read. num_matched = ids ranked. */
 int tsgpu_wildcard_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out);
 
+/* Candidate-token combinations (Index::search_all_candidates, src/index.cpp:1794-1894). With prefix / typo
+ * candidates the reference runs one search_across_fields pass per combination of candidate tokens over ONE Topster and ONE
+ * id_buff. Here the combinations of user query g are combos[group_begin[g] .. group_begin[g+1]) in the reference's pass order
+ * (each with its own term_ids and total_cost; at most 16 per group and 16 * out->k_stride <= 4096; group_begin is a host array
+ * of n_groups + 1 entries); all of them run as one keyword batch and are folded on the device exactly like the shared Topster:
+ * a key found by several passes keeps its greatest (scores[0..2]) — the later pass when equal (include/topster.h:392-406) —
+ * and out holds the top topster_size of those in sort() order. out: [n_groups][k_stride];
+ *   query_index [n_groups][k_stride] (nullable): KV::query_index of each hit = number of earlier passes of the group that
+ *     matched anything (searched_queries.size() at the time of the pass, :5511, :5580-5585) — add the caller's base;
+ *   found [n_groups] (nullable): all_result_ids_len = distinct ids matched by any pass (id_buff -> sort + unique + or_scalar);
+ *     the ids themselves: tsgpu_candidates_result_ids(ctx, g, ...) until the next call. Needs n_groups * num_docs / 8 bytes
+ *     (<= 8 GiB) of scratch;
+ *   num_matched[g] = the LAST pass's count (the reference assigns num_keyword_matches per pass, :5553).
+ * query_index / found live where out->mem says. A group with a failing combination reports that status and no hits. */
+int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const uint32_t* group_begin, uint32_t n_groups,
+                                          tsgpu_hits* out, uint32_t* query_index, uint64_t* found);
+uint64_t tsgpu_candidates_result_ids(tsgpu_ctx* ctx, uint32_t group, uint32_t* out_host, uint64_t cap);
+
 /* all matched ids of the LAST keyword batch for query q, ascending (id_buff / all_result_ids, src/index.cpp:5565).
  * Only available when tsgpu_keep_result_ids(ctx, 1) was set before the batch. Returns count; copies min(count, cap). */
 int tsgpu_keep_result_ids(tsgpu_ctx* ctx, int keep);

@@ -231,6 +231,16 @@ int32_t orc_search_keyword(void* h, const orc_kw_query* q, orc_result* out) {
     return 0;
 }
 
+// candidate-token combinations of one user query (Index::search_all_candidates); query_index_out: [out->cap], nullable
+int32_t orc_search_candidates(void* h, const orc_kw_query* combos, uint32_t n_combos, orc_result* out, uint16_t* query_index_out) {
+    std::vector<keyword_query_t> qs;
+    for (uint32_t i = 0; i < n_combos; i++) qs.push_back(to_query(combos + i));
+    keyword_result_t r = ((Index*)h)->search_candidates(qs);
+    fill(r, out);
+    if (query_index_out) for (uint32_t i = 0; i < out->n; i++) query_index_out[i] = r.kvs[i].query_index;
+    return 0;
+}
+
 int32_t orc_search_wildcard(void* h, const orc_kw_query* q, orc_result* out) {
     fill(((Index*)h)->search_wildcard(to_query(q)), out);
     return 0;

@@ -28,6 +28,7 @@
 #include <cfloat>
 #include <unordered_map>
 #include <memory>
+#include <iterator>
 #include "token_or_iter.h"
 #include "topk_heap.h"
 
@@ -435,6 +436,43 @@ public:
         keyword_result_t out;
         Topster topster(q.topster_size ? q.topster_size : topster_size(q.fetch_size, q.filter_ids.size()));
         search_across_fields(q, &topster, out);
+        topster.sort();
+        for (uint32_t i = 0; i < topster.size; i++) out.kvs.push_back(*topster.getKV(i));
+        return out;
+    }
+
+    // ---------------- query time: candidate-token combinations, Index::search_all_candidates, index.cpp:1794-1894 ----------------
+    // One search_across_fields pass per combination (each with its own tokens and total_cost) over ONE shared Topster — a key seen
+    // again replaces its KV unless the new one is_smaller (include/topster.h:392-406: equal scores -> the LATER pass wins) — and one
+    // shared id_buff that ends as the sorted-unique all_result_ids (index.cpp:5565-5578, 5081-5090). KV::query_index =
+    // searched_queries.size() at the time of the pass; a pass is pushed to searched_queries iff it emitted ids (:5580-5585).
+    // num_keyword_matches is ASSIGNED by every pass (:5553): the last pass's count survives.
+    keyword_result_t search_candidates(const std::vector<keyword_query_t>& combos) const {
+        keyword_result_t out;
+        if (combos.empty()) return out;
+        const keyword_query_t& q0 = combos[0];
+        Topster topster(q0.topster_size ? q0.topster_size : topster_size(q0.fetch_size, q0.filter_ids.size()));
+        std::vector<uint32_t> id_buff, all_ids;
+        uint16_t searched_queries = 0;
+        auto flush = [&]() {
+            std::sort(id_buff.begin(), id_buff.end());
+            id_buff.erase(std::unique(id_buff.begin(), id_buff.end()), id_buff.end());
+            std::vector<uint32_t> merged;
+            std::set_union(all_ids.begin(), all_ids.end(), id_buff.begin(), id_buff.end(), std::back_inserter(merged));   // ArrayUtils::or_scalar
+            all_ids.swap(merged);
+            id_buff.clear();
+        };
+        for (const keyword_query_t& q : combos) {
+            keyword_result_t pass;
+            search_across_fields(q, &topster, pass, searched_queries);
+            out.num_keyword_matches = pass.num_keyword_matches;
+            out.search_cutoff = out.search_cutoff || pass.search_cutoff;
+            id_buff.insert(id_buff.end(), pass.result_ids.begin(), pass.result_ids.end());
+            if (id_buff.size() > 100000) flush();
+            if (!pass.result_ids.empty()) searched_queries++;
+        }
+        flush();
+        out.result_ids = all_ids;
         topster.sort();
         for (uint32_t i = 0; i < topster.size; i++) out.kvs.push_back(*topster.getKV(i));
         return out;

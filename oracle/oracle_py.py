@@ -76,6 +76,7 @@ def lib():
         L.orc_flat_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_search_keyword.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.POINTER(Result)]
         L.orc_search_wildcard.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.POINTER(Result)]
+        L.orc_search_candidates.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_uint32, C.POINTER(Result), C.c_void_p]
         L.orc_hnsw_build.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_hnsw_free.argtypes = [C.c_void_p]
         L.orc_hnsw_mark_deleted.argtypes = [C.c_void_p, C.c_uint32]
@@ -265,6 +266,15 @@ class OracleIndex:
         r, b = self._alloc(cap, ids_cap)
         self.L.orc_search_wildcard(self.h, C.byref(q), C.byref(r))
         return self._decode(r, b)
+
+    def search_candidates(self, combos, cap=1024, ids_cap=0):
+        """Index::search_all_candidates over the candidate-token combinations `combos` (make_query results, pass order);
+        returns (HitList, query_index[n])"""
+        r, b = self._alloc(cap, ids_cap)
+        arr = (KwQuery * len(combos))(*combos)
+        qi = np.zeros(cap, np.uint16)
+        self.L.orc_search_candidates(self.h, arr, len(combos), C.byref(r), _ptr(qi))
+        return self._decode(r, b), qi[:r.n].copy()
 
     def search_vector(self, qvec, k=0, fetch_size=10, sort=((SORT_VECTOR_DISTANCE, 0, -1), (SORT_SEQ_ID, 0, 1)),
                       distance_threshold=3.4028234663852886e38, filter_ids=None, cap=1024, ids_cap=0):

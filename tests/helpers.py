@@ -95,6 +95,19 @@ def oracle_keyword(orc, q, cap=2048, ids_cap=0):
     return orc.search_keyword(oq, cap=cap, ids_cap=ids_cap)
 
 
+def oracle_query(orc, q):
+    return orc.make_query(q.tokens, fields=tuple(q.fields), sort=tuple((s[0], s[2], s[1]) for s in q.sort), fetch_size=10,
+                          topster_size=q.topster_size, match_type=q.match_type, prioritize_exact_match=q.prioritize_exact_match,
+                          prioritize_token_position=q.prioritize_token_position,
+                          prioritize_num_matching_fields=q.prioritize_num_matching_fields, total_cost=q.total_cost,
+                          excluded_ids=q.excluded_ids, filter_ids=q.filter_ids)
+
+
+def oracle_candidates(orc, combos, cap=2048, ids_cap=0):
+    """Index::search_all_candidates over the combinations (KwQuery list, pass order) -> (HitList, query_index)"""
+    return orc.search_candidates([oracle_query(orc, q) for q in combos], cap=cap, ids_cap=ids_cap)
+
+
 def oracle_wildcard(orc, q, cap=2048, ids_cap=0):
     oq = orc.make_query([], fields=((0, 0),), sort=tuple((s[0], s[2], s[1]) for s in q.sort), fetch_size=10, topster_size=q.topster_size,
                         excluded_ids=q.excluded_ids, filter_ids=q.filter_ids)

@@ -279,6 +279,7 @@ inline int __syncthreads_or(int pred) {      // barrier + OR-reduction over the 
 inline unsigned long long __ballot(int pred) { return hipemu::ballot(pred); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline int __ffs(int x) { return __builtin_ffs(x); }
 template <class T> inline T __shfl(T v, int lane, int = 64) { return hipemu::shfl(v, lane); }
 template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return hipemu::shfl(v, (int)(hipemu::cur_lane() ^ (unsigned)mask)); }
 template <class T> inline T __shfl_down(T v, unsigned d, int = 64) { unsigned s = hipemu::cur_lane() + d; return hipemu::shfl(v, s < 64 ? (int)s : (int)hipemu::cur_lane()); }

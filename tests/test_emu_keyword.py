@@ -339,6 +339,57 @@ def test_wildcard_search_ranks_filter_ids_by_sort_keys(pair):
         g.keep_result_ids(False)
 
 
+def _candidate_groups(rng, sort, topster_size, **kw):
+    """user queries whose positions have 1-3 candidate tokens; the combinations in next_suggestion2 order, total_cost per combination"""
+    groups = []
+    for shape in [(2, 2), (3, 1), (1, 3, 2), (2, 2, 2), (3, 3), (1,), (2, 5)]:
+        cands = [rng.choice(np.arange(1, 30), size=c, replace=False) for c in shape]
+        costs = [rng.integers(0, 3, size=c) for c in shape]
+        combos = []
+        n = int(np.prod(shape))
+        for x in range(min(n, 10)):                           # combination_limit = max(10, max_candidates)
+            toks, cost, r = [], 0, x
+            for pos in range(len(shape) - 1, -1, -1):         # the last position varies fastest
+                toks.insert(0, int(cands[pos][r % shape[pos]])); cost += int(costs[pos][r % shape[pos]]); r //= shape[pos]
+            combos.append(T.KwQuery(toks, sort=sort, topster_size=topster_size, total_cost=cost, **kw))
+        groups.append(combos)
+    return groups
+
+
+@pytest.mark.parametrize("topster_size", [250, 12])
+def test_candidate_combinations_fold_like_the_shared_topster_and_id_buff(pair, topster_size):
+    """Index::search_all_candidates (src/index.cpp:1794-1894): per key the greatest KV over the passes (the later pass when the
+    scores tie), top-K of those, query_index = passes before it that matched, found / ids = sorted-unique union, num_matched =
+    the last pass's"""
+    orc, g, _ = pair
+    rng = np.random.default_rng(77)
+    tm_sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    col_sort = ((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, -1, 0))       # no _text_match key: passes tie on every shared key
+    groups = _candidate_groups(rng, tm_sort, topster_size) + _candidate_groups(rng, col_sort, topster_size)
+    groups += _candidate_groups(rng, tm_sort, topster_size, excluded_ids=np.arange(0, 3000, 3), filter_ids=np.arange(0, 3000, 2))[:3]
+    same = T.KwQuery([3, 5], sort=tm_sort, topster_size=topster_size)
+    groups.append([same, T.KwQuery([3, 5], sort=tm_sort, topster_size=topster_size)])            # identical passes: the later one owns the hits
+    groups.append([T.KwQuery([299, 298, 297], sort=tm_sort, topster_size=topster_size), same])     # a pass without matches does not count
+    groups.append([])                                                                             # no combination at all
+    hits, qidx, found = g.keyword_search_candidates_batch(groups, k_stride=250)
+    assert (hits.status == 0).all()
+    multi = 0
+    for gi, combos in enumerate(groups):
+        if not combos:
+            assert hits.n_hits[gi] == 0 and found[gi] == 0 and hits.num_matched[gi] == 0
+            continue
+        ref, ref_qi = H.oracle_candidates(orc, combos, ids_cap=4000)
+        H.assert_hits_equal(hits, gi, ref, "candidates g%d" % gi)
+        n = int(hits.n_hits[gi])
+        assert np.array_equal(qidx[gi, :n], ref_qi), "g%d query_index" % gi
+        assert int(found[gi]) == int(ref.n_result_ids)
+        assert np.array_equal(g.candidates_result_ids(gi), ref.result_ids)
+        multi += int(len(set(ref_qi.tolist())) > 1)
+    assert multi >= 5                  # hits really come from different passes
+    assert (qidx[len(groups) - 3, :int(hits.n_hits[len(groups) - 3])] == 1).all()
+    assert (qidx[len(groups) - 2, :int(hits.n_hits[len(groups) - 2])] == 0).all()
+
+
 def _array_docs(n_docs, vocab, seed):
     """string[] documents: 0-4 elements of 1-5 tokens each (repeats inside and across elements, single-token elements)"""
     rng = np.random.default_rng(seed)

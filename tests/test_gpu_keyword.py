@@ -204,6 +204,7 @@ test_keyword_filter_ids_with_excluded_ids = EK.test_keyword_filter_ids_with_excl
 test_multi_field_union_per_token_and_field_aggregation = EK.test_multi_field_union_per_token_and_field_aggregation
 test_wildcard_search_ranks_filter_ids_by_sort_keys = EK.test_wildcard_search_ranks_filter_ids_by_sort_keys
 test_edge_cases_empty_index_missing_tokens_and_degenerate_topsters = EK.test_edge_cases_empty_index_missing_tokens_and_degenerate_topsters
+test_candidate_combinations_fold_like_the_shared_topster_and_id_buff = EK.test_candidate_combinations_fold_like_the_shared_topster_and_id_buff
 
 
 def test_device_shard_merge_on_cuda_tensors(c100k):
@@ -271,3 +272,29 @@ def test_filter_ids_on_2m_docs_multi_chunk(c2m):
             assert np.array_equal(g.result_ids(i), ref.result_ids)
     finally:
         g.keep_result_ids(False)
+
+
+def test_candidate_combinations_on_2m_docs(c2m):
+    """search_all_candidates at size: 10 combinations of frequent tokens per user query (multi-work-item passes, ~1M-id unions)"""
+    g = c2m.g
+    rng = np.random.default_rng(9)
+    groups = []
+    for shape in [(2, 5), (3, 3), (2, 2, 2), (1, 4)]:
+        cands = [rng.choice(np.arange(1, 40), size=c, replace=False) for c in shape]
+        combos = []
+        for x in range(min(int(np.prod(shape)), 10)):
+            toks, r = [], x
+            for pos in range(len(shape) - 1, -1, -1):
+                toks.insert(0, int(cands[pos][r % shape[pos]])); r //= shape[pos]
+            combos.append(T.KwQuery(toks, sort=SORT, topster_size=250, total_cost=int(x % 3)))
+        groups.append(combos)
+    hits, qidx, found = g.keyword_search_candidates_batch(groups, k_stride=250)
+    assert (hits.status == 0).all()
+    for gi, combos in enumerate(groups):
+        for q in combos:
+            c2m.need(q.tokens)
+        ref, ref_qi = H.oracle_candidates(c2m.orc, combos, ids_cap=2_000_000)
+        H.assert_hits_equal(hits, gi, ref, "candidates 2M g%d" % gi)
+        assert np.array_equal(qidx[gi, :int(hits.n_hits[gi])], ref_qi)
+        assert int(found[gi]) == int(ref.n_result_ids)
+        assert np.array_equal(g.candidates_result_ids(gi), ref.result_ids)

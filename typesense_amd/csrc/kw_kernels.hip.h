@@ -50,6 +50,7 @@ static const int KW_THREADS = 256;
 static const int KW_QCAP = 512;            // LDS queue capacity (>= 255 leftover + 256 new)
 static const int KW_MAX_TOKENS = 10;       // TSGPU_MAX_QUERY_TOKENS
 static const int KW_MAX_FIELDS = 4;        // query_by fields per query (tsgpu_kw_query::field_ids)
+static const int KW_MAX_CANDIDATE_PASSES = 16;   // candidate-token combinations folded per user query (reference: max(10, max_candidates), src/index.cpp:1841-1842)
 static const uint32_t KW_NONE = 0xFFFFFFFFu;
 static const uint32_t KW_WINDOW_SIZE = 10; // WINDOW_SIZE, include/match_score.h:11
 #ifndef TSGPU_KW_TILE_WORDS
@@ -1460,6 +1461,163 @@ __global__ __launch_bounds__(KW_THREADS) void kw_shard_merge_kernel(KwShardIn in
             if (in.num_matched) for (uint32_t g = 0; g < in.n_shards; g++) nm += in.num_matched[(size_t)g * in.n_queries + q];
             out.num_matched[q] = nm;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Candidate-token combinations (Index::search_all_candidates, src/index.cpp:1794-1894): the combinations of one
+// user query ran as consecutive entries [group_begin[g], group_begin[g+1]) of one keyword batch. The reference feeds them, in
+// order, to ONE Topster: a key met again replaces its KV unless the new KV is_smaller (include/topster.h:392-406), and the heap
+// threshold only rises, so the final content is: per key the greatest (s0,s1,s2) — the LATEST pass among equals — then the top k
+// of those in KV::is_greater order. One workgroup per group:
+//   sort A: (key << 16 | pass * k_in + slot) descending with the score columns zeroed -> equal keys adjacent, later pass first;
+//           the head of each run reads the run's scores from the batch output and elects the winner;
+//   sort B: the winners by (s0, s1, s2, key) = the Topster's sort() order.
+// query_index[hit] = number of earlier passes of the group that matched anything (searched_queries.size() at the pass, :5511,
+// :5580-5585); num_matched = the last pass's (num_keyword_matches is assigned, not accumulated, :5553).
+struct KwCandIn {
+    const uint64_t* keys; const int64_t* scores; const int64_t* text_match; const float* vector_distance; const int8_t* match_score_index;
+    const uint32_t* n_hits; const uint64_t* num_matched;
+    const uint32_t* group_range;        // [n_groups][3] = first entry, one past the last entry (empty range: the group did not run), Topster capacity
+    uint32_t k_in;
+};
+template <int CAP>
+__global__ __launch_bounds__(KW_THREADS) void kw_candidates_merge_kernel(KwCandIn in, KwOut out, uint32_t* query_index) {
+    __shared__ TopkLds<CAP> tk;
+    __shared__ uint32_t s_total, s_win;
+    __shared__ uint32_t s_qidx[KW_MAX_CANDIDATE_PASSES];
+    constexpr int PER = CAP / KW_THREADS;
+    const uint32_t t = threadIdx.x, g = blockIdx.x;
+    const uint32_t e0 = in.group_range[3 * g], e1 = in.group_range[3 * g + 1], k = in.group_range[3 * g + 2];
+    if (t == 0) {
+        s_total = 0; s_win = 0;
+        uint32_t searched = 0;
+        for (uint32_t e = e0; e < e1; e++) { s_qidx[e - e0] = searched; if (in.n_hits[e] > 0) searched++; }
+    }
+    for (int i = t; i < CAP; i += KW_THREADS) { tk.key[i] = -1; tk.s0[i] = 0; tk.s1[i] = 0; tk.s2[i] = 0; }
+    __syncthreads();
+    for (uint32_t e = e0; e < e1; e++) {
+        const uint32_t n = in.n_hits[e];
+        const uint32_t at = s_total;
+        for (uint32_t i = t; i < n; i += KW_THREADS) {
+            const uint32_t slot = at + i;
+            if (slot < (uint32_t)CAP) tk.key[slot] = (int64_t)((in.keys[(size_t)e * in.k_in + i] << 16) | (uint64_t)((e - e0) * in.k_in + i));
+        }
+        __syncthreads();
+        if (t == 0) s_total = at + n;
+        __syncthreads();
+    }
+    topk_sort<CAP, true>(tk);                                   // sort A
+    const uint32_t total = s_total < (uint32_t)CAP ? s_total : (uint32_t)CAP;
+    int64_t win[PER];
+    #pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const uint32_t i = r * KW_THREADS + t;
+        win[r] = -1;
+        if (i >= total) continue;
+        const uint64_t mine = (uint64_t)tk.key[i];
+        if (i > 0 && ((uint64_t)tk.key[i - 1] >> 16) == (mine >> 16)) continue;          // not the head of its run
+        uint64_t best = mine;
+        uint32_t o = (uint32_t)(mine & 0xFFFFu);
+        size_t src = (size_t)(e0 + o / in.k_in) * in.k_in + o % in.k_in;
+        int64_t b0 = in.scores[src * 3], b1 = in.scores[src * 3 + 1], b2 = in.scores[src * 3 + 2];
+        for (uint32_t j = i + 1; j < total; j++) {             // earlier passes of the same key: win only when strictly greater
+            const uint64_t other = (uint64_t)tk.key[j];
+            if ((other >> 16) != (mine >> 16)) break;
+            o = (uint32_t)(other & 0xFFFFu);
+            src = (size_t)(e0 + o / in.k_in) * in.k_in + o % in.k_in;
+            const int64_t c0 = in.scores[src * 3], c1 = in.scores[src * 3 + 1], c2 = in.scores[src * 3 + 2];
+            if (c0 > b0 || (c0 == b0 && (c1 > b1 || (c1 == b1 && c2 > b2)))) { best = other; b0 = c0; b1 = c1; b2 = c2; }
+        }
+        win[r] = (int64_t)best;
+    }
+    __syncthreads();
+    for (int i = t; i < CAP; i += KW_THREADS) tk.key[i] = -1;
+    __syncthreads();
+    #pragma unroll
+    for (int r = 0; r < PER; r++) {
+        if (win[r] < 0) continue;
+        const uint32_t o = (uint32_t)((uint64_t)win[r] & 0xFFFFu);
+        const size_t src = (size_t)(e0 + o / in.k_in) * in.k_in + o % in.k_in;
+        const uint32_t slot = atomicAdd(&s_win, 1u);
+        tk.s0[slot] = in.scores[src * 3]; tk.s1[slot] = in.scores[src * 3 + 1]; tk.s2[slot] = in.scores[src * 3 + 2];
+        tk.key[slot] = win[r];
+    }
+    __syncthreads();
+    topk_sort<CAP, true>(tk);                                   // sort B
+    const uint32_t n_out = s_win < k ? s_win : k;
+    const size_t ob = (size_t)g * out.k_stride;
+    for (uint32_t i = t; i < n_out; i += KW_THREADS) {
+        const uint64_t packed = (uint64_t)tk.key[i];
+        const uint32_t o = (uint32_t)(packed & 0xFFFFu);
+        const size_t src = (size_t)(e0 + o / in.k_in) * in.k_in + o % in.k_in;
+        out.keys[ob + i] = packed >> 16;
+        out.scores[(ob + i) * 3 + 0] = tk.s0[i]; out.scores[(ob + i) * 3 + 1] = tk.s1[i]; out.scores[(ob + i) * 3 + 2] = tk.s2[i];
+        if (out.text_match) out.text_match[ob + i] = in.text_match ? in.text_match[src] : 0;
+        if (out.vector_distance) out.vector_distance[ob + i] = in.vector_distance ? in.vector_distance[src] : -1.0f;
+        if (out.match_score_index) out.match_score_index[ob + i] = in.match_score_index ? in.match_score_index[src] : (int8_t)0;
+        if (query_index) query_index[ob + i] = s_qidx[o / in.k_in];
+    }
+    if (t == 0) {
+        out.n_hits[g] = n_out;
+        if (out.num_matched) out.num_matched[g] = (in.num_matched && e1 > e0) ? in.num_matched[e1 - 1] : 0ull;
+    }
+}
+
+// all_result_ids of a group = sorted-unique union of the passes' emitted ids (id_buff -> timsort + unique + or_scalar,
+// src/index.cpp:5565-5578, 5081-5090): one bit per seq_id, set from the passes' id segments, then counted / expanded in order.
+struct KwIdSeg { uint64_t off; uint32_t cnt; uint32_t group; };
+__global__ __launch_bounds__(KW_THREADS) void kw_idset_mark_kernel(const uint32_t* __restrict__ ids, const KwIdSeg* __restrict__ segs,
+                                                                  uint32_t* __restrict__ bits, uint64_t words_per_group) {
+    const KwIdSeg sg = segs[blockIdx.x];
+    uint32_t* mine = bits + (uint64_t)sg.group * words_per_group;
+    for (uint32_t i = blockIdx.y * KW_THREADS + threadIdx.x; i < sg.cnt; i += gridDim.y * KW_THREADS) {
+        const uint32_t id = ids[sg.off + i];
+        atomicOr(&mine[id >> 5], 1u << (id & 31));
+    }
+}
+__global__ __launch_bounds__(KW_THREADS) void kw_idset_count_kernel(const uint32_t* __restrict__ bits, uint64_t words_per_group,
+                                                                   unsigned long long* __restrict__ found) {
+    __shared__ uint32_t s_sum[KW_THREADS / 64];
+    const uint32_t* mine = bits + (uint64_t)blockIdx.x * words_per_group;
+    uint32_t c = 0;
+    for (uint64_t w = (uint64_t)blockIdx.y * KW_THREADS + threadIdx.x; w < words_per_group; w += (uint64_t)gridDim.y * KW_THREADS) c += __popc(mine[w]);
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < KW_THREADS / 64; w++) tot += s_sum[w];
+        if (tot) atomicAdd(&found[blockIdx.x], (unsigned long long)tot);
+    }
+}
+// ascending ids of one group's bitmap -> out[0 .. found) (one workgroup walks the words, 256 at a time, with a running base)
+__global__ __launch_bounds__(KW_THREADS) void kw_idset_expand_kernel(const uint32_t* __restrict__ bits, uint64_t n_words, uint32_t* __restrict__ out, uint64_t cap) {
+    __shared__ uint32_t s_wave[KW_THREADS / 64];
+    __shared__ uint64_t s_base;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (uint64_t w0 = 0; w0 < n_words; w0 += KW_THREADS) {
+        const uint64_t w = w0 + t;
+        uint32_t word = w < n_words ? bits[w] : 0u;
+        const uint32_t c = (uint32_t)__popc(word);
+        uint32_t incl = c;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += up; }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t x = 0; x < KW_THREADS / 64; x++) { if (x < wave) before += s_wave[x]; all += s_wave[x]; }
+        uint64_t at = s_base + before + (incl - c);
+        while (word) {
+            const int b = __ffs((int)word) - 1;
+            word &= word - 1;
+            if (at < cap) out[at] = (uint32_t)(w * 32 + b);
+            at++;
+        }
+        __syncthreads();
+        if (t == 0) s_base += all;
+        __syncthreads();
     }
 }
 

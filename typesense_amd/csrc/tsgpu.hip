@@ -404,6 +404,15 @@ struct Plan {
 };
 }
 
+static uint32_t resolve_topster_size(const tsgpu_ctx* ctx, const tsgpu_kw_query& in) {
+    uint32_t k = in.topster_size;
+    if (k == 0) {                                                      // src/index.cpp:3506-3512
+        k = TSGPU_DEFAULT_TOPSTER_SIZE;
+        k = in.n_filter ? std::min<uint32_t>(k, in.n_filter) : std::min<uint32_t>(k, std::max<uint32_t>(ctx->num_docs, 1));
+    } else k = std::min<uint32_t>(k, std::max<uint32_t>(ctx->num_docs, 1));
+    return std::max<uint32_t>(k, 1);
+}
+
 static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, Plan& P, bool keep_ids, bool wildcard) {
     // driver blocks per work item: fixed by the option, or (0 = auto) sized so that the batch yields a few thousand work
     // items (>= 3 per resident workgroup slot) without fragmenting queries into more partial top-K lists than needed
@@ -461,12 +470,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             if (in.sort[s].order != 1 && in.sort[s].order != -1) bad_sort = true;
         }
         if (bad_sort) { unsupported("sort"); continue; }
-        uint32_t k = in.topster_size;
-        if (k == 0) {                                                      // src/index.cpp:3506-3512
-            k = TSGPU_DEFAULT_TOPSTER_SIZE;
-            k = in.n_filter ? std::min<uint32_t>(k, in.n_filter) : std::min<uint32_t>(k, std::max<uint32_t>(ctx->num_docs, 1));
-        } else k = std::min<uint32_t>(k, std::max<uint32_t>(ctx->num_docs, 1));
-        k = std::max<uint32_t>(k, 1);
+        const uint32_t k = resolve_topster_size(ctx, in);
         if (k > TSGPU_MAX_TOPK) { unsupported("topster_size"); continue; }
         if (in.deadline_us != 0 && now > in.deadline_us) { P.status[i] = TSGPU_ERR_DEADLINE; P.cutoff[i] = 1; continue; }
 
@@ -625,6 +629,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
 }
 
 static int kw_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard);
+static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, std::vector<int32_t>* status_host);
 
 int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out) {
     return kw_batch(ctx, queries, n_queries, out, false);
@@ -640,6 +645,11 @@ static int kw_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_qu
     if (!queries) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: queries is NULL");
     if (!out->keys || !out->scores || !out->n_hits || !out->status) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: missing output arrays");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    return kw_batch_locked(ctx, queries, n_queries, out, wildcard, nullptr);
+}
+
+// ctx->mu held by the caller; status_host (optional) receives the per-query status codes
+static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, std::vector<int32_t>* status_host) {
     (void)hipSetDevice(ctx->device);
     if (ctx->dirty) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: uncommitted index changes (call tsgpu_commit)");
     hipStream_t s = ctx->stream;
@@ -760,6 +770,7 @@ static int kw_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_qu
         }
         TSGPU_HIP_TRY(hipMemcpyAsync(off_words.data(), o.off_words, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        if (status_host) status_host->assign(P.status.begin(), P.status.end());
 
         // ---- bookkeeping: timings + algorithmic bytes ----
         float ms_a = 0, ms_b = 0;
@@ -831,6 +842,162 @@ int tsgpu_merge_shard_hits_device(tsgpu_ctx* ctx, const tsgpu_hits* gathered, ui
     TSGPU_HIP_TRY(hipGetLastError());
     TSGPU_HIP_TRY(hipStreamSynchronize(s));
     return ok();
+}
+
+// SURVEY §8f rank 2 — Index::search_all_candidates (src/index.cpp:1794-1894) for a batch of user queries: the candidate-token
+// combinations of group g are combos[group_begin[g] .. group_begin[g+1]) in the reference's pass order; all of them run as ONE
+// keyword batch, kw_candidates_merge_kernel folds each group like the shared Topster, the id-set kernels like id_buff.
+int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const uint32_t* group_begin, uint32_t n_groups,
+                                          tsgpu_hits* out, uint32_t* query_index, uint64_t* found) {
+    if (!ctx || !out || !group_begin) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_candidates_batch: NULL argument");
+    if (n_groups == 0) return ok();
+    if (!out->keys || !out->scores || !out->n_hits || !out->status) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_candidates_batch: missing output arrays");
+    const uint32_t n_combos = group_begin[n_groups];
+    if (n_combos && !combos) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_candidates_batch: combos is NULL");
+    const uint32_t KS = out->k_stride;
+    uint32_t max_passes = 0;
+    for (uint32_t g = 0; g < n_groups; g++) {
+        if (group_begin[g + 1] < group_begin[g]) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_candidates_batch: group_begin must be non-decreasing");
+        max_passes = std::max(max_passes, group_begin[g + 1] - group_begin[g]);
+    }
+    if (max_passes > (uint32_t)KW_MAX_CANDIDATE_PASSES || (uint64_t)max_passes * KS > 4096)
+        return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_candidates_batch: more than 16 combinations per query, or combinations * k_stride > 4096");
+    const bool dev_out = out->mem == TSGPU_MEM_DEVICE;
+    if (dev_out && (!out->text_match || !out->vector_distance || !out->match_score_index || !out->num_matched))
+        return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_candidates_batch: device output needs every tsgpu_hits array");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    try {
+        int rc;
+        const size_t pslots = (size_t)std::max<uint32_t>(n_combos, 1) * KS, pn = std::max<uint32_t>(n_combos, 1);
+        if ((rc = ctx->d_cand_keys.reserve(pslots * 8)) || (rc = ctx->d_cand_scores.reserve(pslots * 24)) || (rc = ctx->d_cand_tm.reserve(pslots * 8)) ||
+            (rc = ctx->d_cand_vd.reserve(pslots * 4)) || (rc = ctx->d_cand_msi.reserve(pslots)) || (rc = ctx->d_cand_nh.reserve(pn * 4)) ||
+            (rc = ctx->d_cand_nm.reserve(pn * 8)) || (rc = ctx->d_cand_st.reserve(pn * 4)))
+            return rc;
+        tsgpu_hits pass;
+        memset(&pass, 0, sizeof(pass));
+        pass.mem = TSGPU_MEM_DEVICE; pass.k_stride = KS;
+        pass.keys = ctx->d_cand_keys.as<uint64_t>(); pass.scores = ctx->d_cand_scores.as<int64_t>(); pass.text_match = ctx->d_cand_tm.as<int64_t>();
+        pass.vector_distance = ctx->d_cand_vd.as<float>(); pass.match_score_index = ctx->d_cand_msi.as<int8_t>();
+        pass.n_hits = ctx->d_cand_nh.as<uint32_t>(); pass.num_matched = ctx->d_cand_nm.as<uint64_t>(); pass.status = ctx->d_cand_st.as<int32_t>();
+        std::vector<int32_t> st;
+        if (n_combos) {
+            const bool keep_prev = ctx->keep_ids;
+            if (found) ctx->keep_ids = true;                   // the union needs every pass's emitted ids
+            rc = kw_batch_locked(ctx, combos, n_combos, &pass, false, &st);
+            ctx->keep_ids = keep_prev;
+            if (rc) return rc;
+        }
+        // a group runs only if every combination of it ran; otherwise it reports the first failing status and no hits
+        std::vector<uint32_t> range((size_t)n_groups * 3 + 3, 0);        // per group: first entry, one past the last, Topster capacity
+        std::vector<int32_t> gstatus(n_groups, TSGPU_OK);
+        for (uint32_t g = 0; g < n_groups; g++) {
+            for (uint32_t e = group_begin[g]; e < group_begin[g + 1]; e++) if (st[e] != TSGPU_OK) { gstatus[g] = st[e]; break; }
+            if (gstatus[g] == TSGPU_OK && group_begin[g + 1] > group_begin[g]) {
+                range[3 * g] = group_begin[g]; range[3 * g + 1] = group_begin[g + 1];
+                range[3 * g + 2] = std::min(resolve_topster_size(ctx, combos[group_begin[g]]), KS);      // the shared Topster is sized once, by the first pass
+            }
+        }
+        if ((rc = upload(ctx->d_cand_gb, range.data(), range.size() * 4, s))) return rc;
+
+        const size_t slots = (size_t)n_groups * KS;
+        KwOut o;
+        o.k_stride = KS; o.off_words = nullptr;
+        uint32_t* qi_dev = nullptr;
+        if (dev_out) {
+            o.keys = out->keys; o.scores = out->scores; o.text_match = out->text_match; o.vector_distance = out->vector_distance;
+            o.match_score_index = out->match_score_index; o.n_hits = out->n_hits; o.num_matched = out->num_matched;
+            qi_dev = query_index;
+        } else {
+            if ((rc = ctx->d_out_keys.reserve(slots * 8)) || (rc = ctx->d_out_scores.reserve(slots * 24)) || (rc = ctx->d_out_tm.reserve(slots * 8)) ||
+                (rc = ctx->d_out_vd.reserve(slots * 4)) || (rc = ctx->d_out_msi.reserve(slots)) || (rc = ctx->d_out_nh.reserve((size_t)n_groups * 4)) ||
+                (rc = ctx->d_out_nm.reserve((size_t)n_groups * 8)) || (rc = ctx->d_cand_qi.reserve(slots * 4)))
+                return rc;
+            o.keys = ctx->d_out_keys.as<uint64_t>(); o.scores = ctx->d_out_scores.as<int64_t>(); o.text_match = ctx->d_out_tm.as<int64_t>();
+            o.vector_distance = ctx->d_out_vd.as<float>(); o.match_score_index = ctx->d_out_msi.as<int8_t>();
+            o.n_hits = ctx->d_out_nh.as<uint32_t>(); o.num_matched = ctx->d_out_nm.as<uint64_t>();
+            qi_dev = query_index ? ctx->d_cand_qi.as<uint32_t>() : nullptr;
+        }
+        KwCandIn in;
+        in.keys = pass.keys; in.scores = pass.scores; in.text_match = pass.text_match; in.vector_distance = pass.vector_distance;
+        in.match_score_index = pass.match_score_index; in.n_hits = pass.n_hits; in.num_matched = pass.num_matched;
+        in.group_range = ctx->d_cand_gb.as<uint32_t>(); in.k_in = KS;
+        const uint64_t cap_need = (uint64_t)std::max<uint32_t>(max_passes, 1) * KS;
+        if (cap_need <= 512) hipLaunchKernelGGL((kw_candidates_merge_kernel<512>), dim3(n_groups), dim3(KW_THREADS), 0, s, in, o, qi_dev);
+        else if (cap_need <= 1024) hipLaunchKernelGGL((kw_candidates_merge_kernel<1024>), dim3(n_groups), dim3(KW_THREADS), 0, s, in, o, qi_dev);
+        else if (cap_need <= 2048) hipLaunchKernelGGL((kw_candidates_merge_kernel<2048>), dim3(n_groups), dim3(KW_THREADS), 0, s, in, o, qi_dev);
+        else hipLaunchKernelGGL((kw_candidates_merge_kernel<4096>), dim3(n_groups), dim3(KW_THREADS), 0, s, in, o, qi_dev);
+        TSGPU_HIP_TRY(hipGetLastError());
+
+        // ---- all_result_ids: one bitmap per group ----
+        ctx->last_cand_groups = 0;
+        ctx->last_cand_found.assign(n_groups, 0);
+        if (found) {
+            const uint64_t words = std::max<uint64_t>(((uint64_t)ctx->num_docs + 31) / 32, 1);
+            if ((uint64_t)n_groups * words * 4 > (8ull << 30))
+                return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_candidates_batch: id-set bitmaps (n_groups * num_docs / 8 bytes) exceed 8 GiB; split the batch");
+            std::vector<KwIdSeg> segs;
+            for (uint32_t g = 0; g < n_groups; g++) {
+                if (gstatus[g] != TSGPU_OK) continue;
+                for (uint32_t e = group_begin[g]; e < group_begin[g + 1]; e++)
+                    for (size_t c = 0; c < ctx->last_chunk_emit[e].size(); c++)
+                        if (ctx->last_chunk_emit[e][c]) segs.push_back({ctx->last_ids_off[e] + ctx->last_chunk_off[e][c], ctx->last_chunk_emit[e][c], g});
+            }
+            if ((rc = ctx->d_cand_bits.reserve((size_t)n_groups * words * 4)) || (rc = ctx->d_cand_found.reserve((size_t)n_groups * 8))) return rc;
+            TSGPU_HIP_TRY(hipMemsetAsync(ctx->d_cand_bits.p, 0, (size_t)n_groups * words * 4, s));
+            TSGPU_HIP_TRY(hipMemsetAsync(ctx->d_cand_found.p, 0, (size_t)n_groups * 8, s));
+            if (!segs.empty()) {
+                if ((rc = upload(ctx->d_cand_segs, segs.data(), segs.size() * sizeof(KwIdSeg), s))) return rc;
+                hipLaunchKernelGGL(kw_idset_mark_kernel, dim3((uint32_t)segs.size(), 8), dim3(KW_THREADS), 0, s, ctx->d_ids_out.as<uint32_t>(),
+                                   ctx->d_cand_segs.as<KwIdSeg>(), ctx->d_cand_bits.as<uint32_t>(), words);
+                const uint32_t gy = (uint32_t)std::min<uint64_t>(64, (words + KW_THREADS - 1) / KW_THREADS);
+                hipLaunchKernelGGL(kw_idset_count_kernel, dim3(n_groups, gy), dim3(KW_THREADS), 0, s, ctx->d_cand_bits.as<uint32_t>(), words,
+                                   ctx->d_cand_found.as<unsigned long long>());
+                TSGPU_HIP_TRY(hipGetLastError());
+            }
+            TSGPU_HIP_TRY(hipMemcpyAsync(ctx->last_cand_found.data(), ctx->d_cand_found.p, (size_t)n_groups * 8, hipMemcpyDeviceToHost, s));
+            if (dev_out) TSGPU_HIP_TRY(hipMemcpyAsync(found, ctx->d_cand_found.p, (size_t)n_groups * 8, hipMemcpyDeviceToDevice, s));
+            ctx->last_cand_groups = n_groups;
+            ctx->last_cand_words = words;
+        }
+
+        // ---- results ----
+        if (!dev_out) {
+            TSGPU_HIP_TRY(hipMemcpyAsync(out->n_hits, o.n_hits, (size_t)n_groups * 4, hipMemcpyDeviceToHost, s));
+            if (out->num_matched) TSGPU_HIP_TRY(hipMemcpyAsync(out->num_matched, o.num_matched, (size_t)n_groups * 8, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(out->keys, o.keys, slots * 8, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(out->scores, o.scores, slots * 24, hipMemcpyDeviceToHost, s));
+            if (out->text_match) TSGPU_HIP_TRY(hipMemcpyAsync(out->text_match, o.text_match, slots * 8, hipMemcpyDeviceToHost, s));
+            if (out->vector_distance) TSGPU_HIP_TRY(hipMemcpyAsync(out->vector_distance, o.vector_distance, slots * 4, hipMemcpyDeviceToHost, s));
+            if (out->match_score_index) TSGPU_HIP_TRY(hipMemcpyAsync(out->match_score_index, o.match_score_index, slots, hipMemcpyDeviceToHost, s));
+            if (query_index) TSGPU_HIP_TRY(hipMemcpyAsync(query_index, qi_dev, slots * 4, hipMemcpyDeviceToHost, s));
+            for (uint32_t g = 0; g < n_groups; g++) out->status[g] = gstatus[g];
+            if (out->search_cutoff) for (uint32_t g = 0; g < n_groups; g++) out->search_cutoff[g] = gstatus[g] == TSGPU_ERR_DEADLINE;
+        } else {
+            TSGPU_HIP_TRY(hipMemcpyAsync(out->status, gstatus.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice, s));
+            if (out->search_cutoff) TSGPU_HIP_TRY(hipMemsetAsync(out->search_cutoff, 0, (size_t)n_groups * 4, s));
+        }
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        if (found && !dev_out) for (uint32_t g = 0; g < n_groups; g++) found[g] = ctx->last_cand_found[g];
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_candidates_batch: host allocation failed"); }
+    return ok();
+}
+
+uint64_t tsgpu_candidates_result_ids(tsgpu_ctx* ctx, uint32_t group, uint32_t* out_host, uint64_t cap) {
+    if (!ctx) return 0;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (group >= ctx->last_cand_groups) return 0;
+    const uint64_t total = ctx->last_cand_found[group];
+    if (!out_host || cap == 0 || total == 0) return total;
+    const uint64_t m = std::min(total, cap);
+    if (ctx->d_cand_ids.reserve(m * 4)) return 0;
+    hipLaunchKernelGGL(kw_idset_expand_kernel, dim3(1), dim3(KW_THREADS), 0, ctx->stream, ctx->d_cand_bits.as<uint32_t>() + (uint64_t)group * ctx->last_cand_words,
+                       ctx->last_cand_words, ctx->d_cand_ids.as<uint32_t>(), m);
+    if (hipMemcpyAsync(out_host, ctx->d_cand_ids.p, m * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return 0;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 0;
+    return total;
 }
 
 uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64_t cap) {

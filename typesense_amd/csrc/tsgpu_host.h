@@ -98,6 +98,12 @@ struct tsgpu_ctx {
     tsgpu::DevBuf d_queries, d_work, d_aux, d_ids_out, d_mf;
     tsgpu::DevBuf d_part_s0, d_part_s1, d_part_s2, d_part_key, d_part_cnt, d_part_nm, d_part_ne, d_part_ow, d_part_f;
     tsgpu::DevBuf d_out_keys, d_out_scores, d_out_tm, d_out_vd, d_out_msi, d_out_nh, d_out_nm, d_out_ow;
+    // candidate-combination batches (tsgpu_keyword_search_candidates_batch): per-pass hits, group table, id-set bitmaps
+    tsgpu::DevBuf d_cand_keys, d_cand_scores, d_cand_tm, d_cand_vd, d_cand_msi, d_cand_nh, d_cand_nm, d_cand_st, d_cand_gb, d_cand_qi, d_cand_found,
+                  d_cand_segs, d_cand_bits, d_cand_ids;
+    uint32_t last_cand_groups = 0;                   // groups whose bitmaps d_cand_bits holds
+    uint64_t last_cand_words = 0;                    // u32 words per group bitmap
+    std::vector<uint64_t> last_cand_found;
     tsgpu::DevBuf d_prof;                            // TSGPU_PROF builds only (null otherwise)
     tsgpu::PinBuf h_stage, h_out;
     bool keep_ids = false;

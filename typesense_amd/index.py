@@ -198,6 +198,28 @@ class GpuIndex:
         self._ck(self.L.tsgpu_wildcard_search_batch(self.h, C.cast(arr, C.c_void_p), n, C.byref(hs)))
         return hits
 
+    def keyword_search_candidates_batch(self, groups, k_stride=250, want_found=True):
+        """groups: per user query the list of candidate-token combinations (KwQuery, pass order) — Index::search_all_candidates.
+        Returns (Hits [n_groups], query_index [n_groups, k_stride] u32, found [n_groups] u64 or None)."""
+        flat = [q for g in groups for q in g]
+        begin = np.zeros(len(groups) + 1, np.uint32)
+        begin[1:] = np.cumsum([len(g) for g in groups])
+        arr = make_query_array(flat) if flat else None
+        hits = Hits(len(groups), k_stride)
+        hs = hits.c_struct()
+        qi = np.zeros((len(groups), k_stride), np.uint32)
+        found = np.zeros(len(groups), np.uint64) if want_found else None
+        self._ck(self.L.tsgpu_keyword_search_candidates_batch(self.h, C.cast(arr, C.c_void_p) if flat else None, _vp(begin), len(groups), C.byref(hs),
+                                                              _vp(qi), _vp(found) if want_found else None))
+        return hits, qi, found
+
+    def candidates_result_ids(self, group):
+        n = self.L.tsgpu_candidates_result_ids(self.h, group, None, 0)
+        out = np.zeros(max(n, 1), np.uint32)
+        if n:
+            self.L.tsgpu_candidates_result_ids(self.h, group, _vp(out), n)
+        return out[:n]
+
     def keyword_search_batch_raw(self, arr, n, hs):
         """prebuilt ctypes query array + tsgpu_hits struct (device or host outputs); no allocation (bench loop)"""
         self._ck(self.L.tsgpu_keyword_search_batch(self.h, C.cast(arr, C.c_void_p), n, C.byref(hs)))
