@@ -276,6 +276,16 @@ inline int __syncthreads_or(int pred) {      // barrier + OR-reduction over the 
     hipemu::syncthreads();
     return r;
 }
+inline int __syncthreads_count(int pred) {   // barrier + number of threads of the block whose pred is non-zero
+    hipemu::BlockState* b = hipemu::g();
+    if (pred) b->or_flag += 1;                // fibers of a block run one at a time: plain increment
+    hipemu::syncthreads();
+    const int r = b->or_flag;
+    hipemu::syncthreads();
+    if (hipemu::cur_tid().x == 0) b->or_flag = 0;
+    hipemu::syncthreads();
+    return r;
+}
 inline unsigned long long __ballot(int pred) { return hipemu::ballot(pred); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }

@@ -1,0 +1,8 @@
+#!/bin/bash
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/s34
+mkdir -p $O
+cd $GRAFT_REPO_ROOT
+T=$GRAFT_REPO_ROOT/typesense_amd
+KW_BATCHES=10000,1000 KW_SWEEP='[{"kw_chunk_blocks":0}]' TSGPU_LIB=$T/libtsgpu.so timeout 420 python tools/sweep_kw.py 2>&1 | grep -E "n_q" > $O/sweep_kw.txt; cat $O/sweep_kw.txt
+timeout 900 python -m pytest tests/test_gpu_keyword.py -m gpu -x -q > $O/pytest_gpu_keyword.txt 2>&1; tail -3 $O/pytest_gpu_keyword.txt

@@ -16,7 +16,7 @@ g.field_create(0, False)
 g.terms_load_csr(0, csr["term_ids"], csr["ids_ptr"], csr["ids"], csr["offset_index"], csr["off_ptr"], csr["offsets"])
 g.column_set(0, pts); g.set_num_docs(n_docs); g.commit()
 sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
-for n_q in (10000, 1000, 100):
+for n_q in [int(x) for x in os.environ.get("KW_BATCHES", "10000,1000,100").split(",")]:
     qtok = synth.keyword_queries(n_q, 3, 8, 2000, seed=4)
     arr = (B.KwQueryC * n_q)()
     for i in range(n_q):

@@ -46,6 +46,13 @@ namespace tsgpu {
 #define KW_PROF_FLUSH(ptr)
 #endif
 
+// 4 workgroups (16 waves) per CU need <= 128 VGPRs: tell the register allocator (it lands 3 over without the hint)
+#ifdef TSGPU_HIP_EMU
+#define KW_FOUR_WAVES_PER_SIMD
+#else
+#define KW_FOUR_WAVES_PER_SIMD __attribute__((amdgpu_waves_per_eu(4)))
+#endif
+
 static const int KW_THREADS = 256;
 static const int KW_QCAP = 512;            // LDS queue capacity (>= 255 leftover + 256 new)
 static const int KW_MAX_TOKENS = 10;       // TSGPU_MAX_QUERY_TOKENS
@@ -210,12 +217,22 @@ struct TokRun {
     const uint32_t* w;   // packed offsets of the block
     uint32_t start;      // first element of the run
     uint32_t n;          // number of POSITIONS (the trailing 0 flag excluded)
-    uint32_t bits, base;
-    uint32_t last_flag;  // run ends with 0: token is the last token of the field
+    uint32_t base;
     uint32_t raw_len;    // elements in the run (for the algorithmic byte count)
+    uint32_t meta;       // bits 0..5 element width | bit 8: run ends with 0 (token is the last token of the field) | bits 16..17: nc
+    // the run's first two elements, 16 bits each, fetched together with the run header: a token rarely occurs more than once or
+    // twice in a document, so the Match window loop runs out of registers instead of issuing one dependent global load per step
+    // (nc = elements served from c01; 0 when one of them needs more than 16 bits)
+    uint32_t c01;
 };
+__device__ inline uint32_t run_bits(const TokRun& r) { return r.meta & 63u; }
+__device__ inline uint32_t run_last_flag(const TokRun& r) { return (r.meta >> 8) & 1u; }
+__device__ inline uint32_t run_raw_len(const TokRun& r) { return r.raw_len; }
 
-__device__ inline uint32_t run_raw(const TokRun& r, uint32_t j) { return r.base + unpack_at(r.w, r.start + j, r.bits); }
+__device__ inline uint32_t run_raw(const TokRun& r, uint32_t j) {
+    if (j < (r.meta >> 16)) return (r.c01 >> (j * 16)) & 0xFFFFu;
+    return r.base + unpack_at(r.w, r.start + j, run_bits(r));
+}
 // positions.push_back((uint16_t)pos - 1), src/posting_list.cpp:906
 __device__ inline uint32_t run_pos(const TokRun& r, uint32_t j) { return (uint32_t)(uint16_t)((uint16_t)run_raw(r, j) - 1); }
 
@@ -228,11 +245,22 @@ __device__ inline TokRun load_run(const IndexView& ix, const ListDesc& d, uint32
     TokRun r;
     r.w = base + m.off_woff;
     r.start = s;
-    r.bits = m.off_bits;
     r.base = m.off_base;
     r.raw_len = e - s;
-    r.last_flag = (e > s && run_raw(r, e - s - 1) == 0) ? 1u : 0u;
-    r.n = (e - s) - r.last_flag;
+    r.meta = m.off_bits;
+    r.c01 = 0;
+    if (m.off_bits <= 16) {
+        const uint64_t bitpos = (uint64_t)s * m.off_bits;
+        const uint32_t* __restrict__ cw = r.w + (bitpos >> 5);
+        const uint32_t sh = (uint32_t)(bitpos & 31);
+        const uint64_t x = ((uint64_t)cw[0] | ((uint64_t)cw[1] << 32)) >> sh;          // 2 x <=16 bits from bit sh <= 31: inside two words
+        const uint32_t mask = (1u << m.off_bits) - 1u;
+        const uint32_t v0 = m.off_base + ((uint32_t)x & mask), v1 = m.off_base + ((uint32_t)(x >> m.off_bits) & mask);
+        const uint32_t have = (e - s) < 2 ? (e - s) : 2;
+        if (((v0 | (have > 1 ? v1 : 0)) >> 16) == 0) { r.c01 = v0 | (v1 << 16); r.meta |= have << 16; }
+    }
+    if (e > s && run_raw(r, e - s - 1) == 0) r.meta |= 1u << 8;
+    r.n = (e - s) - run_last_flag(r);
     return r;
 }
 
@@ -344,7 +372,7 @@ __device__ inline MatchOut match_window(const TokRun (&runs)[TMAX], const uint32
 #pragma unroll
             for (int t = 0; t < TMAX; t++) {
                 if ((uint32_t)t < T && !bail) {
-                    if (runs[t].last_flag && runs[t].n != 0) last_token_index = (int)run_pos(runs[t], runs[t].n - 1);
+                    if (run_last_flag(runs[t]) && runs[t].n != 0) last_token_index = (int)run_pos(runs[t], runs[t].n - 1);
                     total_offsets += runs[t].n;
                     if (total_offsets > T && distance == T - 1) bail = true;
                 }
@@ -378,12 +406,12 @@ __device__ inline uint64_t field_match_score(const KwQueryDev& q, const TokRun (
         uint32_t verbatim = 0;
         if (q.prio_exact && single_exact_query_token) {
             // is_single_token_verbatim_match, src/posting_list.cpp:918-959 (plain field)
-            verbatim = (run_raw(r, 0) == 1 && r.raw_len == 2 && run_raw(r, 1) == 0) ? 1u : 0u;
+            verbatim = (run_raw(r, 0) == 1 && run_raw_len(r) == 2 && run_raw(r, 1) == 0) ? 1u : 0u;
         }
         uint32_t max_offset = 255;
         if (q.prio_pos) {   // get_last_offset, src/posting_list.cpp:1899-1951 (plain field); narrowed to uint8 by Match()
-            const uint32_t lastv = run_raw(r, r.raw_len - 1);
-            max_offset = (lastv == 0 ? run_raw(r, r.raw_len - 2) : lastv) & 0xFF;
+            const uint32_t lastv = run_raw(r, run_raw_len(r) - 1);
+            max_offset = (lastv == 0 ? run_raw(r, run_raw_len(r) - 2) : lastv) & 0xFF;
         }
         return pack_match_score(1, 1, q.total_cost, 0, verbatim, max_offset, 1);
     }
@@ -397,7 +425,7 @@ __device__ inline uint64_t field_match_score(const KwQueryDev& q, const TokRun (
            (verbatim << 12) | (offset_score << 4) | synonym_score;
 }
 
-__device__ inline TokRun empty_run() { TokRun r; r.w = nullptr; r.start = 0; r.n = 0; r.bits = 0; r.base = 0; r.last_flag = 0; r.raw_len = 0; return r; }
+__device__ inline TokRun empty_run() { TokRun r; r.w = nullptr; r.start = 0; r.n = 0; r.base = 0; r.raw_len = 0; r.meta = 0; r.c01 = 0; return r; }
 
 // ---- string[] fields: one token's run holds one group per array element it occurs in —
 //      p1 .. pn, pn (last position repeated), array_index [, 0 if the token is that element's last token]
@@ -410,7 +438,7 @@ struct ArrElem { uint32_t start, n, aidx, last; bool valid; };
 __device__ inline ArrElem arr_next_elem(const TokRun& r, ArrCursor& c) {
     ArrElem e; e.start = 0; e.n = 0; e.aidx = 0; e.last = 0; e.valid = false;
     int prev_pos = -1;
-    const uint32_t len = r.raw_len;
+    const uint32_t len = run_raw_len(r);
     while (c.i < len) {
         const int pos = (int)run_raw(r, c.i);
         c.i++;
@@ -439,7 +467,7 @@ __device__ inline ArrElem arr_next_elem(const TokRun& r, ArrCursor& c) {
 __device__ inline uint32_t arr_single_verbatim(const TokRun& r) {
     int prev_pos = -1;
     uint32_t i = 0;
-    const uint32_t len = r.raw_len;
+    const uint32_t len = run_raw_len(r);
     while (i < len) {
         const int pos = (int)run_raw(r, i);
         i++;
@@ -452,7 +480,7 @@ __device__ inline uint32_t arr_single_verbatim(const TokRun& r) {
 __device__ inline uint32_t arr_last_offset(const TokRun& r) {
     int prev_pos = -1;
     uint32_t i = 0, max_offset = 0;
-    const uint32_t len = r.raw_len;
+    const uint32_t len = run_raw_len(r);
     while (i < len) {
         const int pos = (int)run_raw(r, i);
         i++;
@@ -501,7 +529,7 @@ __device__ inline uint64_t field_match_score_array(const KwQueryDev& q, const To
         for (int t = 0; t < TMAX; t++) {
             if (el[t].valid && el[t].aidx == a) {
                 TokRun r = runs[t];
-                r.start = el[t].start; r.n = el[t].n; r.last_flag = el[t].last; r.raw_len = el[t].n;
+                r.start = el[t].start; r.n = el[t].n; r.raw_len = el[t].n; r.meta = run_bits(r) | (el[t].last << 8);      // (nc = 0: the register cache belongs to the run's own start)
 #pragma unroll
                 for (int j = 0; j < TMAX; j++) if ((uint32_t)j == m) sub[j] = r;
                 m++;
@@ -578,7 +606,7 @@ __device__ inline ScoredHit score_hit(const IndexView& ix, const KwQueryDev& q, 
     TokRun runs[TMAX];
 #pragma unroll
     for (int t = 0; t < TMAX; t++) {
-        if ((uint32_t)t < T && (t == 0 || T > 1)) { runs[t] = load_run(ix, ix.lists[q.list[t]], pos[t]); off_words += runs[t].raw_len + 1; }
+        if ((uint32_t)t < T && (t == 0 || T > 1)) { runs[t] = load_run(ix, ix.lists[q.list[t]], pos[t]); off_words += run_raw_len(runs[t]) + 1; }
         else runs[t] = empty_run();
     }
     AggState st;
@@ -606,7 +634,7 @@ __device__ inline ScoredHit score_hit_mf(const IndexView& ix, const KwQueryDev& 
             for (int ff = 0; ff < KW_MAX_FIELDS; ff++) if ((uint32_t)ff == f) p = pos[t * KW_MAX_FIELDS + ff];
             if ((uint32_t)t < T && p != KW_NONE) {
                 const TokRun r = load_run(ix, ix.lists[mf.list[t][f]], p);
-                off_words += r.raw_len + 1;
+                off_words += run_raw_len(r) + 1;
 #pragma unroll
                 for (int j = 0; j < TMAX; j++) if ((uint32_t)j == n_present) runs[j] = r;      // append without dynamic register indexing
                 n_present++;
@@ -737,7 +765,13 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2>& sm, const Index
 #pragma unroll
             for (int k = 0; k < NP; k++) pos[k] = sm.qf_pos[k][t];
             if constexpr (MF) h = score_hit_mf<TMAX>(ix, q, ix.mf[q.mf_index], seq_id, pos);
-            else h = score_hit<TMAX>(ix, q, seq_id, pos);
+            else {
+#if defined(TSGPU_EXP) && TSGPU_EXP == 6
+                h.s0 = (int64_t)(seq_id * 2654435761u); h.s1 = (int64_t)pos[0] + pos[TMAX - 1]; h.s2 = 0; h.text_match = h.s0; h.off_words = 1;
+#else
+                h = score_hit<TMAX>(ix, q, seq_id, pos);
+#endif
+            }
         }
     }
     // num_keyword_matches under a filter (kw_filter_count below): which intersection ids does the reference's loop VISIT?
@@ -779,7 +813,11 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2>& sm, const Index
     const uint32_t my = block_compact(emit, sm.wave_cnt, total);
     if (emit && ids_out) ids_out[ids_out_base + sm.n_emit + my] = seq_id;
     if (emit) {
+#if defined(TSGPU_EXP) && TSGPU_EXP == 5
+        const bool pass = seq_id == 0xFFFFFFFEu;
+#else
         const bool pass = !sm.have_thr || ent_greater(h.s0, h.s1, h.s2, (int64_t)seq_id, sm.thr[0], sm.thr[1], sm.thr[2], sm.thr[3]);
+#endif
         if (pass) {
             const uint32_t slot = atomicAdd(&sm.tk_cnt, 1u);
             sm.tk.s0[slot] = h.s0; sm.tk.s1[slot] = h.s1; sm.tk.key[slot] = (int64_t)seq_id;
@@ -853,7 +891,7 @@ __device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP, false, S2>& sm, con
 
 // grid = work items; block = 256 threads
 template <int TMAX, int CAP, bool S2>
-__global__ __launch_bounds__(KW_THREADS) void kw_search_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
+__global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
                                                                 const KwWorkItem* __restrict__ work, KwPartials part,
                                                                 const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out) {
     __shared__ KwSmem<TMAX, CAP, false, S2> sm;
