@@ -33,6 +33,8 @@
 #include <stdint.h>
 #include "tsgpu_format.h"
 
+#include <type_traits>
+
 namespace tsgpu {
 
 // TSGPU_PROF builds only (tools/): per-phase cycle accounting of kw_search_kernel (wave 0 lane 0 of every workgroup)
@@ -706,16 +708,20 @@ __device__ inline void topk_compact(TopkLds<CAP, S2>& tk, uint32_t* s_cnt, uint3
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int TMAX, int CAP, bool MF, bool S2 = true>
+struct KwNoTopk {};
+// DEFER = the "find" half of the two-kernel form (kw_search_kernel<.., DEFER = true> writes complete hits to memory, kw_score_kernel
+// scores them): no final queue, no top-K buffer, no filter bookkeeping -> 18 KB instead of 38 KB of LDS
+template <int TMAX, int CAP, bool MF, bool S2 = true, bool DEFER = false>
 struct KwSmem {
     static const int NP = MF ? TMAX * KW_MAX_FIELDS : TMAX;    // posting positions carried per complete hit
     static const bool HAS_S2 = S2;
+    static const int QF = DEFER ? 1 : KW_QCAP;
     // stage-1 survivors: id, driver position, first-probe position
     uint32_t q1_id[KW_QCAP], q1_p0[KW_QCAP], q1_p1[KW_QCAP];
     // complete hits: id + posting position per token (query order; multi-field: per token and field, KW_NONE = absent)
-    uint32_t qf_id[KW_QCAP];
-    uint32_t qf_pos[NP][KW_QCAP];
-    TopkLds<CAP, S2> tk;
+    uint32_t qf_id[QF];
+    uint32_t qf_pos[NP][QF];
+    typename std::conditional<DEFER, KwNoTopk, TopkLds<CAP, S2>>::type tk;
     int64_t thr[4];
     uint32_t btile[KW_TILE_WORDS + 2];       // packed ids of the second list's blocks under the current driver block
     uint32_t bw_last[2][64], bw_first[2][64], bw_woff[2][64], bw_nb[2][64];   // the second list's BlockIds window, SoA, two versions
@@ -725,8 +731,8 @@ struct KwSmem {
     uint32_t n_match, n_emit;
     unsigned long long off_words;
     // filter-id bookkeeping (take_id with filter ids, src/or_iterator.cpp:218-272)
-    uint32_t f_rank[KW_THREADS];             // filter rank (# filter ids <= hit) of the hits of the current score batch
-    uint8_t f_ex[KW_THREADS];                // hit is an excluded id
+    uint32_t f_rank[DEFER ? 1 : KW_THREADS]; // filter rank (# filter ids <= hit) of the hits of the current score batch
+    uint8_t f_ex[DEFER ? 4 : KW_THREADS];    // hit is an excluded id
     uint32_t f_first, f_frank, f_rp, f_ep, f_c0, f_c1, f_cnt0, f_cnt1;
 };
 
@@ -846,9 +852,14 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2>& sm, const Index
     __syncthreads();
 }
 
+// one complete hit of a query of <= 3 tokens as the find kernel hands it to kw_score_kernel: seq_id + posting position per token
+struct KwHitRec { uint32_t id, p0, p1, p2; };
+
 // probes lists probe_order[2..] for the first n_take entries of queue 1 and moves survivors to the final queue
-template <int TMAX, int CAP, bool S2>
-__device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP, false, S2>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take) {
+// (DEFER: to the work item's hit segment in memory; sm.qf_cnt counts them)
+template <int TMAX, int CAP, bool S2, bool DEFER>
+__device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP, false, S2, DEFER>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take,
+                                           KwHitRec* __restrict__ hits) {
     const uint32_t t = threadIdx.x;
     bool ok = t < n_take;
     uint32_t id = 0;
@@ -875,9 +886,15 @@ __device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP, false, S2>& sm, con
     const uint32_t my = block_compact(ok, sm.wave_cnt, total);
     if (ok) {
         const uint32_t slot = sm.qf_cnt + my;
-        sm.qf_id[slot] = id;
+        if constexpr (DEFER) {
+            static_assert(!DEFER || TMAX == 3, "deferred scoring carries three posting positions");
+            KwHitRec r; r.id = id; r.p0 = pos[0]; r.p1 = pos[TMAX > 1 ? 1 : 0]; r.p2 = pos[TMAX > 2 ? 2 : 0];
+            hits[slot] = r;
+        } else {
+            sm.qf_id[slot] = id;
 #pragma unroll
-        for (int k = 0; k < TMAX; k++) sm.qf_pos[k][slot] = pos[k];
+            for (int k = 0; k < TMAX; k++) sm.qf_pos[k][slot] = pos[k];
+        }
     }
     // drop processed head of queue 1
     const uint32_t rest = sm.q1_cnt - n_take;
@@ -889,12 +906,45 @@ __device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP, false, S2>& sm, con
     __syncthreads();
 }
 
+// the work item's partial result: its top-K in sort() order + the counters kw_merge_kernel folds
+template <int TMAX, int CAP, bool MF, bool S2>
+__device__ inline void kw_write_partial(KwSmem<TMAX, CAP, MF, S2, false>& sm, const KwQueryDev& q, const KwPartials& part) {
+    const uint32_t t = threadIdx.x;
+    topk_compact<CAP, S2>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
+    const uint32_t n = sm.tk_cnt;
+    const size_t base = (size_t)blockIdx.x * part.k_stride;
+    for (uint32_t i = t; i < n; i += KW_THREADS) {
+        part.s0[base + i] = sm.tk.s0[i]; part.s1[base + i] = sm.tk.s1[i]; part.s2[base + i] = sm.tk.s2[sm.tk.i2(i)]; part.key[base + i] = sm.tk.key[i];
+    }
+    if (t == 0) {
+        part.cnt[blockIdx.x] = n;
+        part.n_emit[blockIdx.x] = sm.n_emit;
+        part.off_words[blockIdx.x] = sm.off_words;
+        if (q.n_filt == 0) part.n_match[blockIdx.x] = sm.n_match;
+        else {
+            const uint32_t nonempty = sm.f_first ? 0u : 1u;
+            const bool seq = q.n_excl != 0;                       // sequential mode tracked both variants itself
+            part.n_match[blockIdx.x] = sm.f_cnt0;
+            part.n_match1[blockIdx.x] = seq ? sm.f_cnt1 : sm.f_cnt0 + nonempty;
+            part.first_rank[blockIdx.x] = sm.f_frank;
+            part.last_rank[blockIdx.x] = sm.f_rp;
+            part.fflags[blockIdx.x] = nonempty | (seq ? ((sm.f_c0 & sm.f_ep) << 1) | ((sm.f_c1 & sm.f_ep) << 2) : 0u);
+        }
+    }
+}
+
 // grid = work items; block = 256 threads
-template <int TMAX, int CAP, bool S2>
+// DEFER = false: intersect + score + select in one kernel. DEFER = true (queries of <= 3 tokens): the "find" half — complete hits go
+// to hits[hit_off[work item] ..] as KwHitRec, part.cnt[work item] = how many; kw_score_kernel scores them with full wavefronts.
+// Splitting takes the scoring code's registers and the top-K buffer's LDS out of the merge loop (more resident waves there) and
+// lets the score stage run on dense batches instead of on whatever a work item's queue holds when it flushes.
+template <int TMAX, int CAP, bool S2, bool DEFER = false>
 __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
                                                                 const KwWorkItem* __restrict__ work, KwPartials part,
-                                                                const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out) {
-    __shared__ KwSmem<TMAX, CAP, false, S2> sm;
+                                                                const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out,
+                                                                KwHitRec* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
+    __shared__ KwSmem<TMAX, CAP, false, S2, DEFER> sm;
+    KwHitRec* __restrict__ hits = DEFER ? hits_all + hit_off[blockIdx.x] : nullptr;
     __shared__ KwQueryDev sq;
     const uint32_t t = threadIdx.x;
     const KwWorkItem wi = work[blockIdx.x];
@@ -907,7 +957,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
     if (t == 0) {
         sm.q1_cnt = 0; sm.qf_cnt = 0; sm.tk_cnt = 0; sm.have_thr = 0; sm.n_match = 0; sm.n_emit = 0; sm.off_words = 0;
         sm.f_first = 1; sm.f_frank = 0; sm.f_rp = 0; sm.f_ep = 0; sm.f_c0 = 0; sm.f_c1 = 0; sm.f_cnt0 = 0; sm.f_cnt1 = 0;
-        if (!S2) sm.tk.s2[0] = 0;                              // the one shared scores[2] slot of the two-key build
+        if constexpr (!DEFER) { if (!S2) sm.tk.s2[0] = 0; }     // the one shared scores[2] slot of the two-key build
     }
     __syncthreads();
     const KwQueryDev& q = sq;
@@ -1107,11 +1157,21 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
                 if (t == 0) sm.q1_cnt = q1n;
                 __syncthreads();
                 while (sm.q1_cnt >= KW_THREADS) {
-                    kw_probe_rest_stage<TMAX, CAP, S2>(sm, ix, q, KW_THREADS);
-                    while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+                    kw_probe_rest_stage<TMAX, CAP, S2, DEFER>(sm, ix, q, KW_THREADS, hits);
+                    if constexpr (!DEFER)
+                        while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
                 }
                 q1n = sm.q1_cnt;
             }
+        } else if constexpr (DEFER) {
+            if (ok) {                                   // one or two lists: the stage-1 survivors ARE the complete hits
+                uint32_t v[3] = {0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 3; k++) { if (k == q.probe_order[0]) v[k] = p0; if (T >= 2 && k == q.probe_order[1]) v[k] = p1; }
+                KwHitRec r; r.id = id; r.p0 = v[0]; r.p1 = v[1]; r.p2 = v[2];
+                hits[qfn + my] = r;
+            }
+            qfn += total;
         } else {
             if (ok) {
                 const uint32_t slot = qfn + my;
@@ -1142,37 +1202,60 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
     // ---- flush ----
     if (T >= 3) {
         while (sm.q1_cnt > 0) {
-            kw_probe_rest_stage<TMAX, CAP, S2>(sm, ix, q, sm.q1_cnt < KW_THREADS ? sm.q1_cnt : KW_THREADS);
-            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+            kw_probe_rest_stage<TMAX, CAP, S2, DEFER>(sm, ix, q, sm.q1_cnt < KW_THREADS ? sm.q1_cnt : KW_THREADS, hits);
+            if constexpr (!DEFER)
+                while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
         }
     }
-    while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, ids_out_base);
-    KW_PROF(8)
-
-    // ---- partial result of this work item: sorted, <= k entries ----
-    topk_compact<CAP, decltype(sm)::HAS_S2>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
-    const uint32_t n = sm.tk_cnt;
-    const size_t base = (size_t)blockIdx.x * part.k_stride;
-    for (uint32_t i = t; i < n; i += KW_THREADS) {
-        part.s0[base + i] = sm.tk.s0[i]; part.s1[base + i] = sm.tk.s1[i]; part.s2[base + i] = sm.tk.s2[sm.tk.i2(i)]; part.key[base + i] = sm.tk.key[i];
-    }
-    if (t == 0) {
-        part.cnt[blockIdx.x] = n;
-        part.n_emit[blockIdx.x] = sm.n_emit;
-        part.off_words[blockIdx.x] = sm.off_words;
-        if (q.n_filt == 0) part.n_match[blockIdx.x] = sm.n_match;
-        else {
-            const uint32_t nonempty = sm.f_first ? 0u : 1u;
-            const bool seq = q.n_excl != 0;                       // sequential mode tracked both variants itself
-            part.n_match[blockIdx.x] = sm.f_cnt0;
-            part.n_match1[blockIdx.x] = seq ? sm.f_cnt1 : sm.f_cnt0 + nonempty;
-            part.first_rank[blockIdx.x] = sm.f_frank;
-            part.last_rank[blockIdx.x] = sm.f_rp;
-            part.fflags[blockIdx.x] = nonempty | (seq ? ((sm.f_c0 & sm.f_ep) << 1) | ((sm.f_c1 & sm.f_ep) << 2) : 0u);
-        }
+    if constexpr (DEFER) {
+        if (t == 0) part.cnt[blockIdx.x] = sm.qf_cnt;              // hits handed to kw_score_kernel
+    } else {
+        while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+        KW_PROF(8)
+        // ---- partial result of this work item: sorted, <= k entries ----
+        kw_write_partial(sm, q, part);
     }
     KW_PROF(9)
     KW_PROF_FLUSH(ix.prof)
+}
+
+// The "score" half of the two-kernel form: one workgroup per work item of the find kernel; its hits (seq_id + posting positions,
+// ascending seq_id) are scored 256 at a time — every wavefront full except the segment's last — through the same score stage,
+// top-K buffer and filter bookkeeping as the fused kernel, and leave the same partial result for kw_merge_kernel.
+template <int CAP, bool S2>
+__global__ __launch_bounds__(KW_THREADS) void kw_score_kernel(IndexView ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work,
+                                                              KwPartials part, const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out,
+                                                              const KwHitRec* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
+    __shared__ KwSmem<3, CAP, false, S2> sm;
+    __shared__ KwQueryDev sq;
+    const uint32_t t = threadIdx.x;
+    const KwWorkItem wi = work[blockIdx.x];
+    {
+        const uint32_t* src = (const uint32_t*)(queries + wi.query);
+        uint32_t* dst = (uint32_t*)&sq;
+        for (uint32_t i = t; i < sizeof(KwQueryDev) / 4; i += KW_THREADS) dst[i] = src[i];
+    }
+    if (t == 0) {
+        sm.q1_cnt = 0; sm.qf_cnt = 0; sm.tk_cnt = 0; sm.have_thr = 0; sm.n_match = 0; sm.n_emit = 0; sm.off_words = 0;
+        sm.f_first = 1; sm.f_frank = 0; sm.f_rp = 0; sm.f_ep = 0; sm.f_c0 = 0; sm.f_c1 = 0; sm.f_cnt0 = 0; sm.f_cnt1 = 0;
+        if (!S2) sm.tk.s2[0] = 0;
+    }
+    __syncthreads();
+    const KwQueryDev& q = sq;
+    uint32_t* my_ids_out = ids_out ? ids_out + q.ids_out_off + wi.ids_out_off : nullptr;
+    const uint32_t count = part.cnt[blockIdx.x];
+    const KwHitRec* __restrict__ mine = hits_all + hit_off[blockIdx.x];
+    for (uint32_t i0 = 0; i0 < count; i0 += KW_THREADS) {
+        const uint32_t n = count - i0 < (uint32_t)KW_THREADS ? count - i0 : (uint32_t)KW_THREADS;
+        if (t < n) {
+            const KwHitRec r = mine[i0 + t];
+            sm.qf_id[t] = r.id; sm.qf_pos[0][t] = r.p0; sm.qf_pos[1][t] = r.p1; sm.qf_pos[2][t] = r.p2;
+        }
+        if (t == 0) sm.qf_cnt = n;
+        __syncthreads();
+        kw_score_stage<3, CAP, false, S2>(sm, ix, q, n, aux_ids, my_ids_out, 0u);      // ends with a barrier
+    }
+    kw_write_partial(sm, q, part);
 }
 
 // ------------------------------------------------------------------------------------------------

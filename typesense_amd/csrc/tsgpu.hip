@@ -55,8 +55,18 @@ template <int TMAX, int CAP>
 void launch_search(hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w,
                    const KwPartials& part, const uint32_t* aux, uint32_t* ids_out, bool s2) {
     // s2 = some query of the launch sorts by three keys; the two-key build (CAP 512 only) has a smaller LDS footprint
-    if (CAP == 512 && !s2) hipLaunchKernelGGL((kw_search_kernel<TMAX, CAP, CAP != 512>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out);
-    else hipLaunchKernelGGL((kw_search_kernel<TMAX, CAP, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out);
+    if (CAP == 512 && !s2) hipLaunchKernelGGL((kw_search_kernel<TMAX, CAP, CAP != 512>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, (KwHitRec*)nullptr, (const uint64_t*)nullptr);
+    else hipLaunchKernelGGL((kw_search_kernel<TMAX, CAP, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, (KwHitRec*)nullptr, (const uint64_t*)nullptr);
+}
+
+// two-kernel form for queries of <= 3 tokens: find (intersection -> hit records) then score (hit records -> partial top-K)
+void launch_find_score(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w, const KwPartials& part,
+                       const uint32_t* aux, uint32_t* ids_out, bool s2, KwHitRec* hits, const uint64_t* hit_off) {
+    hipLaunchKernelGGL((kw_search_kernel<3, 512, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    if (cap == 512 && !s2) hipLaunchKernelGGL((kw_score_kernel<512, false>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    else if (cap == 512) hipLaunchKernelGGL((kw_score_kernel<512, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    else if (cap == 1024) hipLaunchKernelGGL((kw_score_kernel<1024, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    else hipLaunchKernelGGL((kw_score_kernel<2048, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
 }
 
 template <int TMAX>
@@ -339,6 +349,11 @@ int tsgpu_term_download(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, uin
 int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(TSGPU_ERR_INVALID, "tsgpu_set_option: NULL argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
+    if (!strcmp(name, "kw_hit_buffer_mb")) {
+        if (value < 1) return fail(TSGPU_ERR_INVALID, "kw_hit_buffer_mb must be >= 1");
+        ctx->kw_hit_buffer_mb = (uint32_t)value; return ok();
+    }
     if (!strcmp(name, "kw_chunk_blocks")) {
         if (value < 0 || value > KW_MAX_CHUNK) return fail(TSGPU_ERR_INVALID, "kw_chunk_blocks out of range (0 = auto, 1..256)");
         ctx->kw_chunk_blocks = (uint32_t)value;
@@ -726,7 +741,6 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
         const KwWorkItem* dw = ctx->d_work.as<KwWorkItem>();
         const uint32_t* daux = ctx->d_aux.as<uint32_t>();
         TSGPU_HIP_TRY(hipEventRecord(ctx->ev[0], s));
-        if (!P.work_small.empty()) launch_search_cap<3>(cap, s, (uint32_t)P.work_small.size(), v, dq, dw, part, daux, ids_out, P.any_s2);
         auto shifted = [&](size_t sh) {                 // every kernel indexes the partials by its own blockIdx: shift the bases
             KwPartials pb = part;
             pb.s0 += sh * KS; pb.s1 += sh * KS; pb.s2 += sh * KS; pb.key += sh * KS;
@@ -734,6 +748,29 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
             pb.n_match1 += sh; pb.first_rank += sh; pb.last_rank += sh; pb.fflags += sh;
             return pb;
         };
+        if (!P.work_small.empty()) {
+            if (ctx->kw_two_kernels) {
+                // find + score: a work item can yield at most one hit per driver id, so its segment of the hit buffer holds
+                // (blk_end - blk_begin) * 256 records; the items run in groups whose segments fit the buffer budget
+                const uint64_t budget = std::max<uint64_t>((uint64_t)ctx->kw_hit_buffer_mb << 20, (uint64_t)KW_MAX_CHUNK * BLOCK_IDS * sizeof(KwHitRec)) / sizeof(KwHitRec);
+                const size_t nws = P.work_small.size();
+                std::vector<uint64_t> hoff(nws);
+                std::vector<size_t> group_start(1, 0);
+                uint64_t used = 0, need = 0;
+                for (size_t i = 0; i < nws; i++) {
+                    const uint64_t c = (uint64_t)(P.work_small[i].blk_end - P.work_small[i].blk_begin) * BLOCK_IDS;
+                    if (used + c > budget) { group_start.push_back(i); used = 0; }
+                    hoff[i] = used; used += c; need = std::max(need, used);
+                }
+                group_start.push_back(nws);
+                if ((rc = ctx->d_hits.reserve(std::max<uint64_t>(need, 1) * sizeof(KwHitRec)))) return rc;
+                if ((rc = upload(ctx->d_hit_off, hoff.data(), nws * 8, s))) return rc;
+                for (size_t gi = 0; gi + 1 < group_start.size(); gi++) {
+                    const size_t a = group_start[gi], b = group_start[gi + 1];
+                    if (b > a) launch_find_score(cap, s, (uint32_t)(b - a), v, dq, dw + a, shifted(a), daux, ids_out, P.any_s2, ctx->d_hits.as<KwHitRec>(), ctx->d_hit_off.as<uint64_t>() + a);
+                }
+            } else launch_search_cap<3>(cap, s, (uint32_t)P.work_small.size(), v, dq, dw, part, daux, ids_out, P.any_s2);
+        }
         size_t sh = P.work_small.size();
         if (!P.work_big.empty()) launch_search_cap<KW_MAX_TOKENS>(cap, s, (uint32_t)P.work_big.size(), v, dq, dw + sh, shifted(sh), daux, ids_out, P.any_s2);
         sh += P.work_big.size();
