@@ -123,19 +123,24 @@ def timed(step, steps, warmup, world, after=None):
 
 
 def pmc_traffic(kernel_rx, fname, field="avg", scale=1.0):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc FETCH_SIZE pass (KB, own pass);
-    None when the profile is absent. `field`: avg over the kernel's dispatches, or max (the full-index dispatch when the same
+    """HBM bytes per launch of the dominant kernel(s) from the committed rocprofv3 --pmc FETCH_SIZE pass (KB, own pass);
+    None when the profile is absent. `kernel_rx`: one regex, or a list whose kernels run back to back as one step of the path
+    (their bytes add up). `field`: avg over the kernel's dispatches, or max (the full-index dispatch when the same
     kernel also runs a short sample pass). `scale` = 2 for kernels whose reads are all 16 B/lane: on gfx950 FETCH_SIZE reports
     half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section)."""
     p = os.path.join(ROOT, "profiles", "r01", fname)
     if not os.path.exists(p):
         return None
-    for line in open(p):
-        if re.search(kernel_rx, line) and "FETCH_SIZE" in line:
-            m = re.search(field + r"=([0-9.e+]+)", line)
-            if m:
-                return float(m.group(1)) * 1024.0 * scale
-    return None
+    total, seen = 0.0, 0
+    for rx in ([kernel_rx] if isinstance(kernel_rx, str) else kernel_rx):
+        for line in open(p):
+            if re.search(rx, line) and "FETCH_SIZE" in line:
+                m = re.search(field + r"=([0-9.e+]+)", line)
+                if m:
+                    total += float(m.group(1)) * 1024.0 * scale
+                    seen += 1
+                    break
+    return total if seen else None
 
 
 def device_hits(torch, n_q, ks):
@@ -462,8 +467,9 @@ def main():
         if "host_qps" in r:
             kw["value_with_host_delivery"] = r["host_qps"]       # PCIe-inclusive (80 MB of hits per 10 000-query batch into pageable host memory)
         kw["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                          "traffic": pmc_traffic(r"kw_search_kernel", "pmc_kw_s4_fetch.txt"),
-                          "kernel": "kw_search_kernel<3,512>", "kernel_ms": r["kern_ms"], "merge_kernel_ms": r["merge_ms"],
+                          "traffic": pmc_traffic([r"kw_search_kernel<3, 512, true, true>", r"kw_score_kernel"], "pmc_kw_s5_fetch.txt"),
+                          "kernel": "kw_search_kernel<3,512,find> + kw_score_kernel<512> (the two halves of the intersect+score+select step, "
+                                    "launched back to back; kernel_ms spans both)", "kernel_ms": r["kern_ms"], "merge_kernel_ms": r["merge_ms"],
                           "algorithmic_bytes_per_launch": r["alg_bytes"],
                           "note": "algorithmic bytes = 4*sum|L_t| + offsets + sort keys (SURVEY 8d); the kernel skips, so fetched bytes (traffic, "
                                   "FETCH_SIZE KB x 1024 from the committed --pmc pass, uncorrected) are far below them: latency/issue-bound, see DESIGN.md"}

@@ -339,6 +339,41 @@ def test_wildcard_search_ranks_filter_ids_by_sort_keys(pair):
         g.keep_result_ids(False)
 
 
+def test_two_kernel_form_and_fused_kernel_agree_with_the_oracle(pair):
+    """queries of <= 3 tokens run as find kernel + score kernel (hit records through memory) by default, fused when
+    kw_two_kernels=0 or when the hit buffer budget would need more than two groups: same hits, counts and ids either way"""
+    orc, g, _ = pair
+    rng = np.random.default_rng(91)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    qs = []
+    for n_tok in (1, 2, 3):
+        qs += _queries(rng, 10, 25, n_tok, sort=sort, topster_size=250)
+        qs += _queries(rng, 3, 25, n_tok, sort=sort, topster_size=9, excluded_ids=np.arange(0, 3000, 4))
+        qs += _queries(rng, 3, 25, n_tok, sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=40,
+                       filter_ids=np.sort(rng.choice(3000, size=900, replace=False)))
+    g.keep_result_ids(True)
+    try:
+        outs, groups = [], []
+        for opts in ({"kw_two_kernels": 1}, {"kw_two_kernels": 1, "kw_hit_buffer_records": -1}, {"kw_two_kernels": 0}):
+            for k, v in opts.items():
+                g.set_option(k, v if v >= 0 else g.counter("kw_last_hit_records") * 3 // 5)       # a budget that needs two groups
+            hits = g.keyword_search_batch(qs, k_stride=250)
+            assert (hits.status == 0).all()
+            groups.append(g.counter("kw_last_hit_groups"))
+            ids = [g.result_ids(i) for i in range(len(qs))]
+            outs.append((hits, ids))
+        assert groups == [1, 2, 0], groups
+        for i, q in enumerate(qs):
+            ref = H.oracle_keyword(orc, q, ids_cap=4000)
+            for hits, ids in outs:
+                H.assert_hits_equal(hits, i, ref, "two-kernel/fused")
+                assert np.array_equal(ids[i], ref.result_ids)
+    finally:
+        g.keep_result_ids(False)
+        g.set_option("kw_two_kernels", 1)
+        g.set_option("kw_hit_buffer_records", 0)
+
+
 def _candidate_groups(rng, sort, topster_size, **kw):
     """user queries whose positions have 1-3 candidate tokens; the combinations in next_suggestion2 order, total_cost per combination"""
     groups = []

@@ -205,6 +205,7 @@ test_multi_field_union_per_token_and_field_aggregation = EK.test_multi_field_uni
 test_wildcard_search_ranks_filter_ids_by_sort_keys = EK.test_wildcard_search_ranks_filter_ids_by_sort_keys
 test_edge_cases_empty_index_missing_tokens_and_degenerate_topsters = EK.test_edge_cases_empty_index_missing_tokens_and_degenerate_topsters
 test_candidate_combinations_fold_like_the_shared_topster_and_id_buff = EK.test_candidate_combinations_fold_like_the_shared_topster_and_id_buff
+test_two_kernel_form_and_fused_kernel_agree_with_the_oracle = EK.test_two_kernel_form_and_fused_kernel_agree_with_the_oracle
 
 
 def test_device_shard_merge_on_cuda_tensors(c100k):

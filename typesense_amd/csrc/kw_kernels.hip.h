@@ -67,6 +67,15 @@ static const uint32_t KW_WINDOW_SIZE = 10; // WINDOW_SIZE, include/match_score.h
 #endif
 static const int KW_MAX_CHUNK = 256;        // driver blocks per work item (host clamps kw_chunk_blocks to this)
 static const int KW_PIPE_WORDS = 4;         // dwords per thread of the register-pipelined tile copy (4 x 256 words = 2048 16-bit ids)
+// the find kernel (two-kernel form) has registers and LDS to spare: deeper register pipeline, larger tile
+#ifndef TSGPU_KW_FIND_PIPE_WORDS
+#define TSGPU_KW_FIND_PIPE_WORDS 8
+#endif
+#ifndef TSGPU_KW_FIND_TILE_WORDS
+#define TSGPU_KW_FIND_TILE_WORDS 4096
+#endif
+static const int KW_FIND_PIPE_WORDS = TSGPU_KW_FIND_PIPE_WORDS;
+static const int KW_FIND_TILE_WORDS = TSGPU_KW_FIND_TILE_WORDS;
 static const int KW_TILE_WORDS = TSGPU_KW_TILE_WORDS;   // LDS tile of PACKED second-list ids per round (8 KB ~ 20 blocks of 12-bit ids); multiple of 256
 
 struct IndexView {
@@ -711,20 +720,24 @@ __device__ inline void topk_compact(TopkLds<CAP, S2>& tk, uint32_t* s_cnt, uint3
 struct KwNoTopk {};
 // DEFER = the "find" half of the two-kernel form (kw_search_kernel<.., DEFER = true> writes complete hits to memory, kw_score_kernel
 // scores them): no final queue, no top-K buffer, no filter bookkeeping -> 18 KB instead of 38 KB of LDS
-template <int TMAX, int CAP, bool MF, bool S2 = true, bool DEFER = false>
+// SCORE = the other half (kw_score_kernel): no stage-1 queue, tile or window
+template <int TMAX, int CAP, bool MF, bool S2 = true, bool DEFER = false, bool SCORE = false>
 struct KwSmem {
+    static const int Q1 = SCORE ? 1 : KW_QCAP;
     static const int NP = MF ? TMAX * KW_MAX_FIELDS : TMAX;    // posting positions carried per complete hit
     static const bool HAS_S2 = S2;
     static const int QF = DEFER ? 1 : KW_QCAP;
     // stage-1 survivors: id, driver position, first-probe position
-    uint32_t q1_id[KW_QCAP], q1_p0[KW_QCAP], q1_p1[KW_QCAP];
+    uint32_t q1_id[Q1], q1_p0[Q1], q1_p1[Q1];
     // complete hits: id + posting position per token (query order; multi-field: per token and field, KW_NONE = absent)
     uint32_t qf_id[QF];
     uint32_t qf_pos[NP][QF];
     typename std::conditional<DEFER, KwNoTopk, TopkLds<CAP, S2>>::type tk;
     int64_t thr[4];
-    uint32_t btile[KW_TILE_WORDS + 2];       // packed ids of the second list's blocks under the current driver block
-    uint32_t bw_last[2][64], bw_first[2][64], bw_woff[2][64], bw_nb[2][64];   // the second list's BlockIds window, SoA, two versions
+    static const int TILE_WORDS = SCORE ? 2 : (DEFER ? KW_FIND_TILE_WORDS : KW_TILE_WORDS);
+    uint32_t btile[TILE_WORDS + 2];          // packed ids of the second list's blocks under the current driver block
+    static const int BW = SCORE ? 1 : 64;
+    uint32_t bw_last[2][BW], bw_first[2][BW], bw_woff[2][BW], bw_nb[2][BW];   // the second list's BlockIds window, SoA, two versions
     uint32_t wave_cnt[KW_THREADS / 64];
     uint32_t wave_cnt2[2][KW_THREADS / 64];  // block_compact1 ping-pong
     uint32_t q1_cnt, qf_cnt, tk_cnt, have_thr;
@@ -736,11 +749,12 @@ struct KwSmem {
     uint32_t f_first, f_frank, f_rp, f_ep, f_c0, f_c1, f_cnt0, f_cnt1;
 };
 
-template <int TMAX, int CAP, bool MF, bool S2>
-__device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take,
+template <int TMAX, int CAP, bool MF, bool S2, bool SCORE>
+__device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2, false, SCORE>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take,
                                       const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out, uint32_t ids_out_base) {
-    // make room: at most n_take (<=256) new entries
-    if (sm.tk_cnt + KW_THREADS > (uint32_t)CAP) topk_compact<CAP, S2>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
+    // make room: at most n_take (<=256) new entries. (The score kernel decides AFTER scoring, from the number of hits that beat the
+    // current k-th best — see below; in the fused kernel that would keep the scores live across the sort and cost it a workgroup per CU.)
+    if constexpr (!SCORE) { if (sm.tk_cnt + KW_THREADS > (uint32_t)CAP) topk_compact<CAP, S2>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr); }
     const uint32_t t = threadIdx.x;
     const bool active = t < n_take;
     bool emit = false, excl = false;
@@ -766,7 +780,7 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2>& sm, const Index
             if (!(rank > 0 && fl[rank - 1] == seq_id)) emit = false;
         }
         if (emit) {
-            constexpr int NP = KwSmem<TMAX, CAP, MF, S2>::NP;
+            constexpr int NP = KwSmem<TMAX, CAP, MF, S2, false, SCORE>::NP;
             uint32_t pos[NP];
 #pragma unroll
             for (int k = 0; k < NP; k++) pos[k] = sm.qf_pos[k][t];
@@ -818,7 +832,25 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2>& sm, const Index
     uint32_t total;
     const uint32_t my = block_compact(emit, sm.wave_cnt, total);
     if (emit && ids_out) ids_out[ids_out_base + sm.n_emit + my] = seq_id;
-    if (emit) {
+    if constexpr (SCORE) {
+        // only hits that beat the current k-th best are appended, and the buffer is re-sorted only when THEY do not fit: once the
+        // threshold is up, a batch of 256 hits adds a handful of entries
+        bool pass = emit && (!sm.have_thr || ent_greater(h.s0, h.s1, h.s2, (int64_t)seq_id, sm.thr[0], sm.thr[1], sm.thr[2], sm.thr[3]));
+        const uint32_t held = sm.tk_cnt;                             // stable: the last appends were followed by a barrier; read BEFORE anyone appends again
+        const uint32_t n_pass = (uint32_t)__syncthreads_count(pass ? 1 : 0);
+        if (held + n_pass > (uint32_t)CAP) {
+            topk_compact<CAP, S2>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);   // -> <= k entries, CAP >= k + 256
+            pass = pass && (!sm.have_thr || ent_greater(h.s0, h.s1, h.s2, (int64_t)seq_id, sm.thr[0], sm.thr[1], sm.thr[2], sm.thr[3]));
+        }
+        if (pass) {
+            const uint32_t slot = atomicAdd(&sm.tk_cnt, 1u);
+            sm.tk.s0[slot] = h.s0; sm.tk.s1[slot] = h.s1; sm.tk.key[slot] = (int64_t)seq_id;
+            if (S2) sm.tk.s2[sm.tk.i2(slot)] = h.s2;
+        }
+        uint32_t ow = emit ? h.off_words : 0u;                       // offsets read (algorithmic byte count): one LDS atomic per wave
+        for (int d = 32; d > 0; d >>= 1) ow += __shfl_down(ow, d, 64);
+        if ((t & 63) == 0 && ow) atomicAdd(&sm.off_words, (unsigned long long)ow);
+    } else if (emit) {
 #if defined(TSGPU_EXP) && TSGPU_EXP == 5
         const bool pass = seq_id == 0xFFFFFFFEu;
 #else
@@ -833,8 +865,9 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2>& sm, const Index
     }
     __syncthreads();
     if (t == 0) { sm.n_match += n_take; sm.n_emit += total; }
+    if constexpr (SCORE) return;                  // (the score kernel refills the whole queue itself)
     // drop the processed head of the final queue
-    constexpr int NPQ = KwSmem<TMAX, CAP, MF, S2>::NP;
+    constexpr int NPQ = KwSmem<TMAX, CAP, MF, S2, false, SCORE>::NP;
     const uint32_t rest = sm.qf_cnt - n_take;
     uint32_t mv_id = 0, mv_pos[NPQ];
     if (t < rest) {
@@ -907,8 +940,8 @@ __device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP, false, S2, DEFER>& 
 }
 
 // the work item's partial result: its top-K in sort() order + the counters kw_merge_kernel folds
-template <int TMAX, int CAP, bool MF, bool S2>
-__device__ inline void kw_write_partial(KwSmem<TMAX, CAP, MF, S2, false>& sm, const KwQueryDev& q, const KwPartials& part) {
+template <int TMAX, int CAP, bool MF, bool S2, bool SCORE>
+__device__ inline void kw_write_partial(KwSmem<TMAX, CAP, MF, S2, false, SCORE>& sm, const KwQueryDev& q, const KwPartials& part) {
     const uint32_t t = threadIdx.x;
     topk_compact<CAP, S2>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
     const uint32_t n = sm.tk_cnt;
@@ -998,7 +1031,9 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
     BlockIds win = load_window(0), nxt = load_window(32);
     bool win_dirty = true;                    // LDS copy of the window (sm.bw[wver]) is stale
     struct Plan { uint32_t mode, rlo, rhi, w_begin, W, ver, base; };   // mode: 0 tile, 1 tile in several rounds, 2 wide run (probe), 3 exhausted, 4 no second list
-    uint32_t cw[KW_PIPE_WORDS];               // block b's tile of second-list ids, in flight from the previous iteration
+    constexpr int PIPE_WORDS = DEFER ? KW_FIND_PIPE_WORDS : KW_PIPE_WORDS;
+    constexpr int TILE_WORDS = decltype(sm)::TILE_WORDS;
+    uint32_t cw[PIPE_WORDS];                  // block b's tile of second-list ids, in flight from the previous iteration
     // decide how driver block `bb` meets the second list and (mode 0) request its tile
     auto make_plan = [&](const BlockIds& m) -> Plan {
         Plan P; P.mode = 4; P.rlo = P.rhi = P.w_begin = P.W = 0; P.ver = wver; P.base = wbase;
@@ -1031,11 +1066,11 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
         const uint32_t w_endw = win.ids_woff + packed_words(win.n_ids_bits & 0xFFFF, win.n_ids_bits >> 16);
         P.w_begin = (uint32_t)__shfl(win.ids_woff, (int)P.rlo);
         P.W = (uint32_t)__shfl(w_endw, (int)P.rhi) - P.w_begin;
-        if (P.W <= (uint32_t)(KW_PIPE_WORDS * KW_THREADS)) {
+        if (P.W <= (uint32_t)(PIPE_WORDS * KW_THREADS)) {
             P.mode = 0;
             const uint32_t* __restrict__ src = idwB + P.w_begin;
 #pragma unroll
-            for (int k = 0; k < KW_PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; cw[k] = src[i < P.W ? i : 0]; }
+            for (int k = 0; k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; cw[k] = src[i < P.W ? i : 0]; }
         } else P.mode = 1;
         return P;
     };
@@ -1060,7 +1095,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
         bool done = !ok || C.mode >= 2, found = false;
         if (C.mode == 0) {
 #pragma unroll
-            for (int k = 0; k < KW_PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; if (i < C.W) sm.btile[i] = cw[k]; }
+            for (int k = 0; k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; if (i < C.W) sm.btile[i] = cw[k]; }
         }
         KW_PROF(1)
         __syncthreads();
@@ -1120,7 +1155,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
             for (uint32_t r_lo = C.rlo; r_lo <= C.rhi;) {
                 const uint32_t w_begin = woff[r_lo];
                 uint32_t r_hi = r_lo;
-                while (r_hi < C.rhi && woff[r_hi + 1] + packed_words(wnb[r_hi + 1] & 0xFFFF, wnb[r_hi + 1] >> 16) - w_begin <= (uint32_t)KW_TILE_WORDS) r_hi++;
+                while (r_hi < C.rhi && woff[r_hi + 1] + packed_words(wnb[r_hi + 1] & 0xFFFF, wnb[r_hi + 1] >> 16) - w_begin <= (uint32_t)TILE_WORDS) r_hi++;
                 const uint32_t W = woff[r_hi] + packed_words(wnb[r_hi] & 0xFFFF, wnb[r_hi] >> 16) - w_begin;
                 const uint32_t* __restrict__ src = idwB + w_begin;
                 __syncthreads();                                        // previous round's searches are done with the tile
@@ -1159,7 +1194,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
                 while (sm.q1_cnt >= KW_THREADS) {
                     kw_probe_rest_stage<TMAX, CAP, S2, DEFER>(sm, ix, q, KW_THREADS, hits);
                     if constexpr (!DEFER)
-                        while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+                        while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false, S2, false>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
                 }
                 q1n = sm.q1_cnt;
             }
@@ -1189,7 +1224,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
                 __syncthreads();
                 if (t == 0) sm.qf_cnt = qfn;
                 __syncthreads();
-                while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+                while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false, S2, false>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
                 qfn = sm.qf_cnt;
             }
         }
@@ -1204,13 +1239,13 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
         while (sm.q1_cnt > 0) {
             kw_probe_rest_stage<TMAX, CAP, S2, DEFER>(sm, ix, q, sm.q1_cnt < KW_THREADS ? sm.q1_cnt : KW_THREADS, hits);
             if constexpr (!DEFER)
-                while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+                while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, false, S2, false>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, ids_out_base);
         }
     }
     if constexpr (DEFER) {
         if (t == 0) part.cnt[blockIdx.x] = sm.qf_cnt;              // hits handed to kw_score_kernel
     } else {
-        while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP, false, S2>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, ids_out_base);
+        while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP, false, S2, false>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, ids_out_base);
         KW_PROF(8)
         // ---- partial result of this work item: sorted, <= k entries ----
         kw_write_partial(sm, q, part);
@@ -1226,7 +1261,7 @@ template <int CAP, bool S2>
 __global__ __launch_bounds__(KW_THREADS) void kw_score_kernel(IndexView ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work,
                                                               KwPartials part, const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out,
                                                               const KwHitRec* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
-    __shared__ KwSmem<3, CAP, false, S2> sm;
+    __shared__ KwSmem<3, CAP, false, S2, false, true> sm;
     __shared__ KwQueryDev sq;
     const uint32_t t = threadIdx.x;
     const KwWorkItem wi = work[blockIdx.x];
@@ -1253,7 +1288,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_score_kernel(IndexView ix, cons
         }
         if (t == 0) sm.qf_cnt = n;
         __syncthreads();
-        kw_score_stage<3, CAP, false, S2>(sm, ix, q, n, aux_ids, my_ids_out, 0u);      // ends with a barrier
+        kw_score_stage<3, CAP, false, S2, true>(sm, ix, q, n, aux_ids, my_ids_out, 0u);      // ends with a barrier
     }
     kw_write_partial(sm, q, part);
 }
@@ -1346,14 +1381,14 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
             __syncthreads();
             if (t == 0) sm.qf_cnt = qfn;
             __syncthreads();
-            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, true, true>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, 0u);
+            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, true, true, false>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, 0u);
             qfn = sm.qf_cnt;
         }
     }
     __syncthreads();
     if (t == 0) sm.qf_cnt = qfn;
     __syncthreads();
-    while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP, true, true>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, 0u);
+    while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP, true, true, false>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, 0u);
     topk_compact<CAP, decltype(sm)::HAS_S2>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
     const uint32_t n = sm.tk_cnt;
     const size_t base = (size_t)blockIdx.x * part.k_stride;

@@ -350,6 +350,10 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(TSGPU_ERR_INVALID, "tsgpu_set_option: NULL argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
+    if (!strcmp(name, "kw_hit_buffer_records")) {       // exact budget in hit records (tests); 0 = use kw_hit_buffer_mb
+        if (value < 0) return fail(TSGPU_ERR_INVALID, "kw_hit_buffer_records must be >= 0");
+        ctx->kw_hit_buffer_records = (uint64_t)value; return ok();
+    }
     if (!strcmp(name, "kw_hit_buffer_mb")) {
         if (value < 1) return fail(TSGPU_ERR_INVALID, "kw_hit_buffer_mb must be >= 1");
         ctx->kw_hit_buffer_mb = (uint32_t)value; return ok();
@@ -386,6 +390,8 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
 int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!ctx || !name || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_get_counter: NULL argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!strcmp(name, "kw_last_hit_groups")) { *out = ctx->kw_last_hit_groups; return ok(); }      // last keyword batch: find+score groups (0 = fused kernel)
+    if (!strcmp(name, "kw_last_hit_records")) { *out = ctx->kw_last_hit_records; return ok(); }    // hit-record capacity the last batch asked for
     if (!strcmp(name, "vec_overflow_rounds")) { *out = ctx->vec_overflow_rounds; return ok(); }
     if (!strcmp(name, "vec_prefilter_fallbacks")) { *out = ctx->vec_prefilter_fallbacks; return ok(); }
     if (!strcmp(name, "vec_prefilter_groups")) { *out = ctx->vec_prefilter_groups; return ok(); }
@@ -748,21 +754,32 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
             pb.n_match1 += sh; pb.first_rank += sh; pb.last_rank += sh; pb.fflags += sh;
             return pb;
         };
+        ctx->kw_last_hit_groups = 0;
         if (!P.work_small.empty()) {
-            if (ctx->kw_two_kernels) {
+            bool two = ctx->kw_two_kernels;
+            std::vector<uint64_t> hoff;
+            std::vector<size_t> group_start(1, 0);
+            uint64_t need = 0;
+            const size_t nws = P.work_small.size();
+            if (two) {
                 // find + score: a work item can yield at most one hit per driver id, so its segment of the hit buffer holds
                 // (blk_end - blk_begin) * 256 records; the items run in groups whose segments fit the buffer budget
-                const uint64_t budget = std::max<uint64_t>((uint64_t)ctx->kw_hit_buffer_mb << 20, (uint64_t)KW_MAX_CHUNK * BLOCK_IDS * sizeof(KwHitRec)) / sizeof(KwHitRec);
-                const size_t nws = P.work_small.size();
-                std::vector<uint64_t> hoff(nws);
-                std::vector<size_t> group_start(1, 0);
-                uint64_t used = 0, need = 0;
+                uint64_t largest = 0, all = 0;
+                for (size_t i = 0; i < nws; i++) { const uint64_t c = (uint64_t)(P.work_small[i].blk_end - P.work_small[i].blk_begin) * BLOCK_IDS; largest = std::max(largest, c); all += c; }
+                ctx->kw_last_hit_records = all;
+                const uint64_t budget = std::max<uint64_t>(ctx->kw_hit_buffer_records ? ctx->kw_hit_buffer_records : ((uint64_t)ctx->kw_hit_buffer_mb << 20) / sizeof(KwHitRec), largest);
+                hoff.resize(nws);
+                uint64_t used = 0;
                 for (size_t i = 0; i < nws; i++) {
                     const uint64_t c = (uint64_t)(P.work_small[i].blk_end - P.work_small[i].blk_begin) * BLOCK_IDS;
                     if (used + c > budget) { group_start.push_back(i); used = 0; }
                     hoff[i] = used; used += c; need = std::max(need, used);
                 }
                 group_start.push_back(nws);
+                two = group_start.size() <= 3;          // each group drains the chip between its two kernels: beyond two groups the fused kernel wins
+            }
+            ctx->kw_last_hit_groups = two ? (uint32_t)group_start.size() - 1 : 0;
+            if (two) {
                 if ((rc = ctx->d_hits.reserve(std::max<uint64_t>(need, 1) * sizeof(KwHitRec)))) return rc;
                 if ((rc = upload(ctx->d_hit_off, hoff.data(), nws * 8, s))) return rc;
                 for (size_t gi = 0; gi + 1 < group_start.size(); gi++) {
