@@ -1104,8 +1104,10 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
             // (a) which block: lower bound of id among the window's last ids (bw_last[rhi] >= hi_id >= id unless B ended)
             const uint32_t* __restrict__ bl = sm.bw_last[C.ver];
             uint32_t pos = C.rlo;
-#pragma unroll
-            for (uint32_t step = 32; step > 0; step >>= 1)
+            // (uniform trip count: a run of s+1 blocks needs the steps from the largest power of two <= s down — two or three
+            //  dependent LDS reads for the common short run instead of six)
+            const uint32_t span = C.rhi - C.rlo;
+            for (uint32_t step = span ? 1u << (31 - __builtin_clz(span)) : 0u; step > 0; step >>= 1)
                 if (pos + step <= C.rhi && bl[pos + step - 1] < id) pos += step;
             kb = pos;
             b_first = sm.bw_first[C.ver][pos];

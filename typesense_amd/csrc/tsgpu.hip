@@ -349,6 +349,7 @@ int tsgpu_term_download(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, uin
 int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(TSGPU_ERR_INVALID, "tsgpu_set_option: NULL argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!strcmp(name, "kw_sort_work")) { ctx->kw_sort_work = value != 0; return ok(); }
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
     if (!strcmp(name, "kw_hit_buffer_records")) {       // exact budget in hit records (tests); 0 = use kw_hit_buffer_mb
         if (value < 0) return fail(TSGPU_ERR_INVALID, "kw_hit_buffer_records must be >= 0");
@@ -460,6 +461,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
     P.cutoff.assign(n_queries, 0);
     const uint64_t now = now_us();
     std::vector<std::vector<KwWorkItem>> per_q_work(n_queries);
+    std::vector<double> item_cost(n_queries, 0.0);
     for (uint32_t i = 0; i < n_queries; i++) {
         const tsgpu_kw_query& in = queries[i];
         KwQueryDev& q = P.q[i];
@@ -621,6 +623,11 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         uint32_t chunk_q = KW_CHUNK_BLOCKS;
         const uint32_t max_partials = n_queries >= 512 ? 64u : std::min<uint32_t>(64, std::max<uint32_t>(16, 4096 / std::max<uint32_t>(n_queries, 1)));
         if (ctx->kw_chunk_blocks == 0) chunk_q = std::max(chunk_q, (dA.n_blocks + max_partials - 1) / max_partials);
+        {   // launch-order key: estimated cost of the query's LARGEST work item = driver blocks x (fixed cost + second-list ids per
+            // driver id); the work table is laid out heaviest first so that the long items do not start last (tail of the launch)
+            const double r = nl >= 2 ? (double)len_of[ord[1]] / (double)std::max<uint32_t>(len_of[ord[0]], 1) : 0.0;
+            item_cost[i] = (double)std::min(chunk_q, dA.n_blocks) * (4.0 + std::min(r, 64.0));
+        }
         for (uint32_t b = 0; b < dA.n_blocks; b += chunk_q) {
             KwWorkItem w;
             w.query = i;
@@ -632,8 +639,12 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
     }
     // work tables: one launch per kernel flavour (single-field T<=3, single-field generic, multi-field T<=3, multi-field generic);
     // a query's items stay contiguous and first_work indexes the concatenation of the four tables
+    std::vector<uint32_t> by_cost(n_queries);
+    for (uint32_t i = 0; i < n_queries; i++) by_cost[i] = i;
+    if (ctx->kw_sort_work) std::stable_sort(by_cost.begin(), by_cost.end(), [&](uint32_t a, uint32_t b) { return item_cost[a] > item_cost[b]; });
     for (int pass = 0; pass < 5; pass++) {
-        for (uint32_t i = 0; i < n_queries; i++) {
+        for (uint32_t oi = 0; oi < n_queries; oi++) {
+            const uint32_t i = by_cost[oi];
             if (per_q_work[i].empty()) continue;
             const int flavour = P.q[i].wild_n_ids ? 4 : (P.q[i].mf_index != KW_NONE ? 2 : 0) + (P.q[i].n_lists <= 3 ? 0 : 1);
             if (flavour != pass) continue;
