@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
     struct Plan { uint32_t mode, rlo, rhi, w_begin, W, ver, base; };   // mode: 0 tile, 1 tile in several rounds, 2 wide run (probe), 3 exhausted, 4 no second list
     constexpr int PIPE_WORDS = DEFER ? KW_FIND_PIPE_WORDS : KW_PIPE_WORDS;
     constexpr int TILE_WORDS = decltype(sm)::TILE_WORDS;
-    uint32_t cw[PIPE_WORDS];                  // block b's tile of second-list ids, in flight from the previous iteration
+    uint32_t cw[PIPE_WORDS] = {};                 // block b's tile of second-list ids, in flight from the previous iteration
     // decide how driver block `bb` meets the second list and (mode 0) request its tile
     auto make_plan = [&](const BlockIds& m) -> Plan {
         Plan P; P.mode = 4; P.rlo = P.rhi = P.w_begin = P.W = 0; P.ver = wver; P.base = wbase;
@@ -1070,7 +1070,9 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
             P.mode = 0;
             const uint32_t* __restrict__ src = idwB + P.w_begin;
 #pragma unroll
-            for (int k = 0; k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; cw[k] = src[i < P.W ? i : 0]; }
+            for (int k = 0; k < PIPE_WORDS; k++) {            // (uniform guard: a short run does not issue the loads it has no words for)
+                if ((uint32_t)(k * KW_THREADS) < P.W) { const uint32_t i = t + k * KW_THREADS; cw[k] = src[i < P.W ? i : 0]; }
+            }
         } else P.mode = 1;
         return P;
     };
@@ -1095,7 +1097,9 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
         bool done = !ok || C.mode >= 2, found = false;
         if (C.mode == 0) {
 #pragma unroll
-            for (int k = 0; k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; if (i < C.W) sm.btile[i] = cw[k]; }
+            for (int k = 0; k < PIPE_WORDS; k++) {
+                if ((uint32_t)(k * KW_THREADS) < C.W) { const uint32_t i = t + k * KW_THREADS; if (i < C.W) sm.btile[i] = cw[k]; }
+            }
         }
         KW_PROF(1)
         __syncthreads();

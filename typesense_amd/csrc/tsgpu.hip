@@ -439,7 +439,10 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
     // driver blocks per work item: fixed by the option, or (0 = auto) sized so that the batch yields a few thousand work
     // items (>= 3 per resident workgroup slot) without fragmenting queries into more partial top-K lists than needed
     uint32_t KW_CHUNK_BLOCKS = ctx->kw_chunk_blocks;
+    std::vector<uint32_t> handle_cache;      // single-field queries: list handle per token (KW_NONE - 1 = absent), looked up once
+    std::vector<uint8_t> cached(n_queries, 0);
     if (KW_CHUNK_BLOCKS == 0) {
+        handle_cache.resize((size_t)n_queries * TSGPU_MAX_QUERY_TOKENS);
         uint64_t total_blocks = 0;
         for (uint32_t i = 0; i < n_queries; i++) {
             const tsgpu_kw_query& in = queries[i];
@@ -447,8 +450,10 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             uint32_t best = 0xFFFFFFFFu;
             for (uint32_t t = 0; t < in.n_tokens; t++) {
                 auto h = ctx->snap.handle_of.find(((uint64_t)in.field_ids[0] << 32) | in.term_ids[t]);
+                handle_cache[(size_t)i * TSGPU_MAX_QUERY_TOKENS + t] = h != ctx->snap.handle_of.end() ? h->second : KW_NONE - 1;     // remembered for the main pass
                 if (h != ctx->snap.handle_of.end()) best = std::min(best, ctx->snap.h_lists[h->second].n_blocks);
             }
+            cached[i] = 1;
             if (best != 0xFFFFFFFFu) total_blocks += best;
         }
         uint64_t c = total_blocks / 3000;
@@ -460,7 +465,9 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
     P.status.assign(n_queries, TSGPU_OK);
     P.cutoff.assign(n_queries, 0);
     const uint64_t now = now_us();
-    std::vector<std::vector<KwWorkItem>> per_q_work(n_queries);
+    std::vector<KwWorkItem> flat_work;                       // every query's items, contiguous, in query order
+    flat_work.reserve((size_t)n_queries * 4);
+    std::vector<uint32_t> q_begin(n_queries, 0), q_cnt(n_queries, 0);
     std::vector<double> item_cost(n_queries, 0.0);
     for (uint32_t i = 0; i < n_queries; i++) {
         const tsgpu_kw_query& in = queries[i];
@@ -527,7 +534,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             for (uint32_t b = 0; b < n_blocks; b += WCHUNK) {
                 KwWorkItem w;
                 w.query = i; w.blk_begin = b; w.blk_end = std::min(n_blocks, b + WCHUNK); w.ids_out_off = b * BLOCK_IDS;
-                per_q_work[i].push_back(w);
+                { if (q_cnt[i] == 0) q_begin[i] = (uint32_t)flat_work.size(); flat_work.push_back(w); q_cnt[i]++; }
             }
             continue;
         }
@@ -543,13 +550,20 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             uint64_t tot = 0;
             bool found = false;
             for (uint32_t f = 0; f < in.n_fields; f++) {
-                auto h = ctx->snap.handle_of.find(((uint64_t)in.field_ids[f] << 32) | in.term_ids[t]);
-                if (h == ctx->snap.handle_of.end()) continue;
-                if (!found) q.list[nl] = h->second;
+                uint32_t handle;
+                if (cached[i]) {                     // (n_fields == 1)
+                    handle = handle_cache[(size_t)i * TSGPU_MAX_QUERY_TOKENS + t];
+                    if (handle == KW_NONE - 1) continue;
+                } else {
+                    auto h = ctx->snap.handle_of.find(((uint64_t)in.field_ids[f] << 32) | in.term_ids[t]);
+                    if (h == ctx->snap.handle_of.end()) continue;
+                    handle = h->second;
+                }
+                if (!found) q.list[nl] = handle;
                 found = true;
-                mfq.list[nl][f] = h->second;
-                tot += ctx->snap.h_lists[h->second].n_ids;
-                P.list_bytes += 4ull * ctx->snap.h_lists[h->second].n_ids;
+                mfq.list[nl][f] = handle;
+                tot += ctx->snap.h_lists[handle].n_ids;
+                P.list_bytes += 4ull * ctx->snap.h_lists[handle].n_ids;
             }
             if (!found) continue;
             len_of[nl] = (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFull);
@@ -602,7 +616,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
                     w.blk_end = std::min(dF.n_blocks, b + KW_CHUNK_BLOCKS);
                     w.ids_out_off = (uint32_t)seg;
                     seg += (uint64_t)(w.blk_end - w.blk_begin) * BLOCK_IDS;
-                    per_q_work[i].push_back(w);
+                    { if (q_cnt[i] == 0) q_begin[i] = (uint32_t)flat_work.size(); flat_work.push_back(w); q_cnt[i]++; }
                 }
             }
             if (keep_ids) P.ids_total += seg;
@@ -634,7 +648,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             w.blk_begin = b;
             w.blk_end = std::min(dA.n_blocks, b + chunk_q);
             w.ids_out_off = b * BLOCK_IDS;
-            per_q_work[i].push_back(w);
+            { if (q_cnt[i] == 0) q_begin[i] = (uint32_t)flat_work.size(); flat_work.push_back(w); q_cnt[i]++; }
         }
     }
     // work tables: one launch per kernel flavour (single-field T<=3, single-field generic, multi-field T<=3, multi-field generic);
@@ -645,7 +659,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
     for (int pass = 0; pass < 5; pass++) {
         for (uint32_t oi = 0; oi < n_queries; oi++) {
             const uint32_t i = by_cost[oi];
-            if (per_q_work[i].empty()) continue;
+            if (q_cnt[i] == 0) continue;
             const int flavour = P.q[i].wild_n_ids ? 4 : (P.q[i].mf_index != KW_NONE ? 2 : 0) + (P.q[i].n_lists <= 3 ? 0 : 1);
             if (flavour != pass) continue;
             std::vector<KwWorkItem>* tabs[5] = {&P.work_small, &P.work_big, &P.work_mf_small, &P.work_mf_big, &P.work_wild};
@@ -653,8 +667,8 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             for (int j = 0; j < pass; j++) before += tabs[j]->size();
             auto& dst = *tabs[pass];
             P.q[i].first_work = (uint32_t)(before + dst.size());
-            P.q[i].n_work = (uint32_t)per_q_work[i].size();
-            dst.insert(dst.end(), per_q_work[i].begin(), per_q_work[i].end());
+            P.q[i].n_work = q_cnt[i];
+            dst.insert(dst.end(), flat_work.begin() + q_begin[i], flat_work.begin() + q_begin[i] + q_cnt[i]);
         }
     }
     return TSGPU_OK;
@@ -686,9 +700,12 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
     if (ctx->dirty) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: uncommitted index changes (call tsgpu_commit)");
     hipStream_t s = ctx->stream;
     try {
+        static const bool host_timing = getenv("TSGPU_HOST_TIMING") != nullptr;      // diagnostics: host phases of the call on stderr
+        const uint64_t t_enter = now_us();
         Plan P;
         int rc = plan_batch(ctx, queries, n_queries, P, ctx->keep_ids, wildcard);
         if (rc) return rc;
+        const uint64_t t_planned = now_us();
         if (out->k_stride < P.max_k) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: k_stride smaller than the largest topster_size");
         const uint32_t n_work = (uint32_t)(P.work_small.size() + P.work_big.size() + P.work_mf_small.size() + P.work_mf_big.size() + P.work_wild.size());
         const uint32_t KS = out->k_stride;
@@ -753,6 +770,7 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
         }
 
         // ---- launch ----
+        const uint64_t t_uploaded = now_us();
         const IndexView v = make_view(ctx);
         const KwQueryDev* dq = ctx->d_queries.as<KwQueryDev>();
         const KwWorkItem* dw = ctx->d_work.as<KwWorkItem>();
@@ -816,6 +834,7 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
         launch_merge(cap, s, n_queries, dq, part, o, ids_out, dw);
         TSGPU_HIP_TRY(hipEventRecord(ctx->ev[2], s));
         TSGPU_HIP_TRY(hipGetLastError());
+        const uint64_t t_launched = now_us();
 
         // ---- results ----
         std::vector<uint64_t> off_words(n_queries);
@@ -836,6 +855,7 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
         TSGPU_HIP_TRY(hipMemcpyAsync(off_words.data(), o.off_words, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
         if (status_host) status_host->assign(P.status.begin(), P.status.end());
+        const uint64_t t_synced = now_us();
 
         // ---- bookkeeping: timings + algorithmic bytes ----
         float ms_a = 0, ms_b = 0;
@@ -874,6 +894,10 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
                 ctx->last_ids_unsorted[i] = P.q[i].mf_index != KW_NONE;      // several driver lists: segments are sorted, their union is not
             }
         }
+        if (host_timing)
+            fprintf(stderr, "[tsgpu] kw batch %u queries: plan %llu us, upload+reserve %llu us, launch %llu us, wait+copy %llu us, bookkeeping %llu us\n", n_queries,
+                    (unsigned long long)(t_planned - t_enter), (unsigned long long)(t_uploaded - t_planned), (unsigned long long)(t_launched - t_uploaded),
+                    (unsigned long long)(t_synced - t_launched), (unsigned long long)(now_us() - t_synced));
         // queries that were not run must not expose stale slots
         if (!dev_out) for (uint32_t i = 0; i < n_queries; i++) if (P.status[i] != TSGPU_OK) { out->n_hits[i] = 0; if (out->num_matched) out->num_matched[i] = 0; }
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_batch: host allocation failed"); }
