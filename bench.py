@@ -499,7 +499,7 @@ def main():
                              "peak": HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TF, "unit": "GB/s" if hbm_bound else "TFLOP/s",
                              "frac": (gbs / HBM_PEAK_GBS) if hbm_bound else (tfh / MFMA_BF16_PEAK_TF),
                              "traffic": pmc_traffic(r"vec_hscan_kernel", "pmc_vec_s4_fetch.txt", field="max", scale=2.0),
-                             "kernel": "vec_hscan_kernel<%d> (bf16 bracket scan; survivors re-scored exactly in fp32)" % (2 if r["n_q"] > 64 else 1),
+                             "kernel": "vec_hscan_kernel<%d> (bf16 bracket scan; survivors re-scored exactly in fp32)" % (4 if r["n_q"] >= 256 else (2 if r["n_q"] >= 128 else 1)),
                              "kernel_ms": r["scan_ms"], "algorithmic_bytes_per_launch": r["scan_bytes"], "flops_per_launch": r["flops"],
                              "hbm_GBs": gbs, "bf16_mfma_TFs": tfh, "pre_ms (query cast + sample pass + threshold)": r["kern_ms"] - r["scan_ms"],
                              "post_ms (refine + fp32 re-score + select)": r["post_ms"],
