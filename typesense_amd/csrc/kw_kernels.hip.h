@@ -194,6 +194,8 @@ __device__ inline uint32_t block_compact1(bool pred, uint32_t* s_wave_cnt /*[4],
 // LDS bitmap, the second list's prefetched ids tested against it: independent LDS reads instead of dependent search steps, the
 // same number of LDS operations) ran 26.7 ms vs 19.0 ms: one more barrier per block, 151 VGPRs = 3 waves per SIMD. The loop is
 // bound by LDS operation COUNT and occupancy, not by the dependency chain of the searches.)
+// (Again after the two-kernel split, with registers to spare in the find kernel: a 4-ary slot search — three independent probes per
+// level, four levels — ran the find kernel at 10.35 ms vs 8.92 ms for the binary search: 12 LDS reads instead of 8.)
 // (16-ary versions of these searches — 16 independent probes per round instead of 4 dependent binary steps — were measured
 // 1.5x SLOWER end to end: 3.5x the LDS reads and +14..16 VGPRs, i.e. 3 waves per SIMD instead of 4, cost more than the
 // dependent-read latency they save; profiles/r01/prof_kw_s4_kary.txt)
