@@ -1527,36 +1527,69 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
         }
         if (t == 0) { s_nm = (q.n_filt && !q.wild_n_ids) ? kw_filter_count(part, q.first_work, 1) : part.n_match[w]; s_ow = part.off_words[w]; }
     } else {
-        // Every partial list is sorted and there may be dozens per query: an entry is taken only if it beats the current k-th best
-        // (thr, refreshed by every compaction), 256 entries per round, and the buffer is re-sorted only when it could overflow —
-        // a handful of bitonic sorts per query instead of one per partial list.
+        // Every partial list is SORTED (KV::is_greater order) and keys are unique, so folding one into the running top-k is a merge
+        // by rank, not a sort: an entry's place = its index in its own list + the number of entries of the other list that are
+        // greater (one binary search). A = tk[0, na) sorted; the partial comes in pieces of <= 256 entries parked in tk[CAP-256, CAP)
+        // (k <= CAP - 256). A heavy query folds up to 64 partials in sequence in this one workgroup: ~10 dependent LDS steps per
+        // piece instead of a 45-stage bitonic sort. A partial whose best remaining entry cannot beat the current k-th is skipped.
+        constexpr int PER = CAP / KW_THREADS - 1;                    // A entries per thread (na <= k <= CAP - 256)
+        constexpr int PB = CAP - KW_THREADS;                         // where the piece is parked
+        uint32_t na = 0;
         for (uint32_t w = q.first_work; w < q.first_work + q.n_work; w++) {
             const uint32_t nw = part.cnt[w];
             const size_t base = (size_t)w * part.k_stride;
-            for (uint32_t i0 = 0; i0 < nw; i0 += KW_THREADS) {
-                const uint32_t held = s_cnt;                        // stable here (the previous round ended with barriers) ...
-                __syncthreads();                                    // ... and nobody appends before everyone has read it
-                if (held + KW_THREADS > (uint32_t)CAP) topk_compact<CAP, true>(tk, &s_cnt, q.k, thr, &s_have_thr);   // CAP >= k + 256
-                const uint32_t i = i0 + t;
-                bool stop = false;
-                if (i < nw) {
-                    const int64_t a0 = part.s0[base + i], a1 = part.s1[base + i], a2 = part.s2[base + i], ak = part.key[base + i];
-                    if (!s_have_thr || ent_greater(a0, a1, a2, ak, thr[0], thr[1], thr[2], thr[3])) {
-                        const uint32_t slot = atomicAdd(&s_cnt, 1u);
-                        tk.s0[slot] = a0; tk.s1[slot] = a1; tk.s2[slot] = a2; tk.key[slot] = ak;
-                    } else stop = true;
+            for (uint32_t p0 = 0; p0 < nw; p0 += KW_THREADS) {
+                if (na == q.k) {                                     // uniform: every thread reads the same entries
+                    const int64_t h0 = part.s0[base + p0], h1 = part.s1[base + p0], h2 = part.s2[base + p0], hk = part.key[base + p0];
+                    if (!ent_greater(h0, h1, h2, hk, tk.s0[na - 1], tk.s1[na - 1], tk.s2[na - 1], tk.key[na - 1])) break;
+                }
+                const uint32_t nb = nw - p0 < (uint32_t)KW_THREADS ? nw - p0 : (uint32_t)KW_THREADS;
+                int64_t b0 = 0, b1 = 0, b2 = 0, bk = -1;
+                if (t < nb) {
+                    b0 = part.s0[base + p0 + t]; b1 = part.s1[base + p0 + t]; b2 = part.s2[base + p0 + t]; bk = part.key[base + p0 + t];
+                    tk.s0[PB + t] = b0; tk.s1[PB + t] = b1; tk.s2[PB + t] = b2; tk.key[PB + t] = bk;
                 }
                 __syncthreads();
-                // the list is descending: once an entry fails, the rest of the list fails too
-                if (__syncthreads_or(stop ? 1 : 0)) break;
+                // piece entry t: place = t + #{A entries greater than it}
+                uint32_t rank_b = 0xFFFFFFFFu;
+                if (t < nb) {
+                    uint32_t lo = 0, hi = na;                        // first A index that is NOT greater than b
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (ent_greater(tk.s0[mid], tk.s1[mid], tk.s2[mid], tk.key[mid], b0, b1, b2, bk)) lo = mid + 1; else hi = mid;
+                    }
+                    rank_b = t + lo;
+                }
+                // A entry i: place = i + #{piece entries greater than it}
+                int64_t a0[PER], a1[PER], a2[PER], ak[PER];
+                uint32_t rank_a[PER];
+#pragma unroll
+                for (int r = 0; r < PER; r++) {
+                    const uint32_t i = r * KW_THREADS + t;
+                    rank_a[r] = 0xFFFFFFFFu;
+                    if (i < na) {
+                        a0[r] = tk.s0[i]; a1[r] = tk.s1[i]; a2[r] = tk.s2[i]; ak[r] = tk.key[i];
+                        uint32_t lo = 0, hi = nb;
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (ent_greater(tk.s0[PB + mid], tk.s1[PB + mid], tk.s2[PB + mid], tk.key[PB + mid], a0[r], a1[r], a2[r], ak[r])) lo = mid + 1; else hi = mid;
+                        }
+                        rank_a[r] = i + lo;
+                    }
+                }
+                __syncthreads();                                     // every read of the old layout is done
+                if (rank_b < q.k) { tk.s0[rank_b] = b0; tk.s1[rank_b] = b1; tk.s2[rank_b] = b2; tk.key[rank_b] = bk; }
+#pragma unroll
+                for (int r = 0; r < PER; r++)
+                    if (rank_a[r] < q.k) { tk.s0[rank_a[r]] = a0[r]; tk.s1[rank_a[r]] = a1[r]; tk.s2[rank_a[r]] = a2[r]; tk.key[rank_a[r]] = ak[r]; }
+                na = na + nb < q.k ? na + nb : q.k;
+                __syncthreads();
             }
-            __syncthreads();
             if (t == 0) { if (!q.n_filt || q.wild_n_ids) s_nm += part.n_match[w]; s_ow += part.off_words[w]; }
         }
         __syncthreads();
         if (t == 0 && q.n_filt && !q.wild_n_ids) s_nm = kw_filter_count(part, q.first_work, q.n_work);
-        topk_compact<CAP, true>(tk, &s_cnt, q.k, thr, &s_have_thr);
-        n = s_cnt;
+        n = na;
         for (uint32_t i = t; i < n; i += KW_THREADS) {
             const int64_t a0 = tk.s0[i], a1 = tk.s1[i], a2 = tk.s2[i];
             out.keys[ob + i] = (uint64_t)tk.key[i];
