@@ -300,6 +300,23 @@ int tsgpu_commit(tsgpu_ctx* ctx) {
         TSGPU_HIP_TRY(hipMemcpy(s.payload.p, h_payload.data(), h_payload.size() * 4, hipMemcpyHostToDevice));
         s.h_lists.swap(descs);
         s.handle_of.swap(handle_of);
+        {   // flat lookup tables: fields < 64, terms < 4M; a term beyond its field's table is found through handle_of
+            std::vector<std::vector<uint32_t>> dense;
+            std::vector<uint32_t> max_term;
+            for (const auto& e : s.handle_of) {
+                const uint32_t f = (uint32_t)(e.first >> 32), term = (uint32_t)e.first;
+                if (f >= 64 || term >= (4u << 20)) continue;
+                if (f >= max_term.size()) max_term.resize(f + 1, 0);
+                max_term[f] = std::max(max_term[f], term + 1);
+            }
+            dense.resize(max_term.size());
+            for (size_t f = 0; f < dense.size(); f++) dense[f].assign(max_term[f], 0xFFFFFFFFu);
+            for (const auto& e : s.handle_of) {
+                const uint32_t f = (uint32_t)(e.first >> 32), term = (uint32_t)e.first;
+                if (f < dense.size() && term < dense[f].size()) dense[f][term] = e.second;
+            }
+            s.dense_handle.swap(dense);
+        }
         s.bytes = s.lists.cap + s.blk_last.cap + s.blk_ids.cap + s.blk_meta.cap + s.ids_payload.cap + s.payload.cap;
         if (!ctx->num_docs_set) ctx->num_docs = std::max(ctx->num_docs, order.empty() ? 0u : max_id + 1);
         ctx->dirty = false;
@@ -449,9 +466,9 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             if (in.n_tokens == 0 || in.n_tokens > TSGPU_MAX_QUERY_TOKENS || in.n_fields != 1) continue;
             uint32_t best = 0xFFFFFFFFu;
             for (uint32_t t = 0; t < in.n_tokens; t++) {
-                auto h = ctx->snap.handle_of.find(((uint64_t)in.field_ids[0] << 32) | in.term_ids[t]);
-                handle_cache[(size_t)i * TSGPU_MAX_QUERY_TOKENS + t] = h != ctx->snap.handle_of.end() ? h->second : KW_NONE - 1;     // remembered for the main pass
-                if (h != ctx->snap.handle_of.end()) best = std::min(best, ctx->snap.h_lists[h->second].n_blocks);
+                const uint32_t h = ctx->snap.find_handle(in.field_ids[0], in.term_ids[t]);
+                handle_cache[(size_t)i * TSGPU_MAX_QUERY_TOKENS + t] = h != 0xFFFFFFFFu ? h : KW_NONE - 1;     // remembered for the main pass
+                if (h != 0xFFFFFFFFu) best = std::min(best, ctx->snap.h_lists[h].n_blocks);
             }
             cached[i] = 1;
             if (best != 0xFFFFFFFFu) total_blocks += best;
@@ -544,7 +561,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         uint32_t nl = 0;
         uint32_t len_of[KW_MAX_TOKENS];
         KwQueryMF mfq;
-        memset(&mfq, 0xFF, sizeof mfq);
+        if (multi) memset(&mfq, 0xFF, sizeof mfq);                // (only read by the multi-field form)
         for (uint32_t t = 0; t < in.n_tokens; t++) {
             // one or_iterator per token = the union of its lists over the fields; a token found in no field is skipped (src/index.cpp:5651-5655)
             uint64_t tot = 0;
@@ -555,9 +572,8 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
                     handle = handle_cache[(size_t)i * TSGPU_MAX_QUERY_TOKENS + t];
                     if (handle == KW_NONE - 1) continue;
                 } else {
-                    auto h = ctx->snap.handle_of.find(((uint64_t)in.field_ids[f] << 32) | in.term_ids[t]);
-                    if (h == ctx->snap.handle_of.end()) continue;
-                    handle = h->second;
+                    handle = ctx->snap.find_handle(in.field_ids[f], in.term_ids[t]);
+                    if (handle == 0xFFFFFFFFu) continue;
                 }
                 if (!found) q.list[nl] = handle;
                 found = true;
@@ -655,7 +671,17 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
     // a query's items stay contiguous and first_work indexes the concatenation of the four tables
     std::vector<uint32_t> by_cost(n_queries);
     for (uint32_t i = 0; i < n_queries; i++) by_cost[i] = i;
-    if (ctx->kw_sort_work) std::stable_sort(by_cost.begin(), by_cost.end(), [&](uint32_t a, uint32_t b) { return item_cost[a] > item_cost[b]; });
+    if (ctx->kw_sort_work) {
+        // descending cost, ties in query order: one sort of packed 64-bit keys (cost is a small non-negative number: its float bits order like the value)
+        std::vector<uint64_t> keys(n_queries);
+        for (uint32_t i = 0; i < n_queries; i++) {
+            const float c = (float)item_cost[i];
+            uint32_t bits; memcpy(&bits, &c, 4);
+            keys[i] = ((uint64_t)(0xFFFFFFFFu - bits) << 32) | i;
+        }
+        std::sort(keys.begin(), keys.end());
+        for (uint32_t i = 0; i < n_queries; i++) by_cost[i] = (uint32_t)keys[i];
+    }
     for (int pass = 0; pass < 5; pass++) {
         for (uint32_t oi = 0; oi < n_queries; oi++) {
             const uint32_t i = by_cost[oi];

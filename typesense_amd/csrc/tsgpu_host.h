@@ -71,6 +71,14 @@ struct Snapshot {            // immutable HBM image of all posting lists
     DevBuf lists, blk_last, blk_ids, blk_meta, ids_payload, payload;
     std::vector<ListDesc> h_lists;                                  // host copy of the descriptors
     std::unordered_map<uint64_t, uint32_t> handle_of;               // (field<<32 | term) -> list handle
+    // the same map as flat tables for small field / term ids (the planner resolves three tokens per query, 10 000 queries per
+    // batch: an indexed load instead of a hash probe); 0xFFFFFFFF = absent; ids beyond the tables go through handle_of
+    std::vector<std::vector<uint32_t>> dense_handle;                // [field][term]
+    uint32_t find_handle(uint32_t field, uint32_t term) const {
+        if (field < dense_handle.size() && term < dense_handle[field].size()) return dense_handle[field][term];
+        auto it = handle_of.find(((uint64_t)field << 32) | term);
+        return it == handle_of.end() ? 0xFFFFFFFFu : it->second;
+    }
     uint64_t bytes = 0;
 };
 
