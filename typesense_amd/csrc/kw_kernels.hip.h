@@ -1139,9 +1139,16 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
             uint32_t pos = 0, hit;
             if ((b_nb >> 16) == 16) {
                 const uint16_t* __restrict__ a16 = (const uint16_t*)(sm.btile + tile_rel);
+                if (n == (uint32_t)BLOCK_IDS) {
+                    // every block but a list's last is full: no bound checks, and without them the steps compile to straight-line
+                    // code (load, compare, select) instead of eight exec-mask branches
 #pragma unroll
-                for (uint32_t step = 128; step > 0; step >>= 1)
-                    if (pos + step <= n && (uint32_t)a16[pos + step - 1] < target) pos += step;
+                    for (uint32_t step = 128; step > 0; step >>= 1) { const uint32_t v = a16[pos + step - 1]; pos = v < target ? pos + step : pos; }
+                } else {
+#pragma unroll
+                    for (uint32_t step = 128; step > 0; step >>= 1)
+                        if (pos + step <= n && (uint32_t)a16[pos + step - 1] < target) pos += step;
+                }
                 hit = a16[pos];
             } else {
                 const uint32_t* __restrict__ a32 = sm.btile + tile_rel;

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <thread>
 #include "tsgpu_host.h"
+#include <chrono>
 #include "vec_kernels.hip.h"
 #include "host_topster.h"
 
@@ -917,15 +918,24 @@ int tsgpu_hybrid_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uin
         kw.mem = TSGPU_MEM_HOST; kw.k_stride = KS;
         kw.keys = keys.data(); kw.scores = scores.data(); kw.text_match = tm.data(); kw.vector_distance = vd.data();
         kw.match_score_index = msi.data(); kw.n_hits = nh.data(); kw.num_matched = nm.data(); kw.status = st.data(); kw.search_cutoff = co.data();
+        static const bool host_timing = getenv("TSGPU_HOST_TIMING") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = tsgpu_keyword_search_batch(ctx, queries, n_queries, &kw);
         if (rc) return rc;
+        const auto t1 = std::chrono::steady_clock::now();
         // 2) vector pass: one batched exact k-NN (filters / exclusions are per query -> not batched: unsupported in v1)
         for (uint32_t q = 0; q < n_queries; q++)
             if (st[q] == TSGPU_OK && (queries[q].n_excluded || queries[q].n_filter)) st[q] = TSGPU_ERR_UNSUPPORTED;
         KnnHost kh;
         if ((rc = knn_to_host(ctx, vec_field_id, Q, mem_q, n_queries, k, nullptr, 0, nullptr, 0, kh))) return rc;
+        const auto t2 = std::chrono::steady_clock::now();
         // 3) fusion on the host, exactly as the reference
-        return tsgpu_hybrid_fuse_batch(ctx, queries, p, f->metric, &kw, kh.dist.data(), kh.lab.data(), kh.cnt.data(), k, n_queries, out);
+        rc = tsgpu_hybrid_fuse_batch(ctx, queries, p, f->metric, &kw, kh.dist.data(), kh.lab.data(), kh.cnt.data(), k, n_queries, out);
+        if (host_timing) {
+            auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+            fprintf(stderr, "[tsgpu] hybrid batch %u queries: keyword pass %lld us, k-NN to host %lld us, fusion %lld us\n", n_queries, us(t0, t1), us(t1, t2), us(t2, std::chrono::steady_clock::now()));
+        }
+        return rc;
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_hybrid_search_batch: host allocation failed"); }
 }
 
