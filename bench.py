@@ -234,6 +234,9 @@ class Bench:
         arr = self.kw_query_array(qtok)
         dev, hs = device_hits(torch, n_q, K_TOPSTER)
         kern_ms, merge_ms, alg_bytes = [], [], []
+        if world > 1 and not self.sharded:
+            pack = torch.zeros((n_q, FETCH_SIZE, 4), dtype=torch.int64, device="cuda")
+            counts = torch.zeros((n_q, 2), dtype=torch.int64, device="cuda")
 
         def step():
             g.keyword_search_batch_raw(arr, n_q, hs)           # synchronises its stream before returning
@@ -243,9 +246,13 @@ class Bench:
                 # replicas: ONE exchange per step — the all-gather of every GPU's top-100 (fetch size; the Topster's 250 slots are
                 # the reference's internal over-fetch) so that every rank holds the results of the whole global batch
                 top = FETCH_SIZE
-                gathered = [self.D.all_gather_cat(x) for x in (dev["keys"][:, :top].contiguous(), dev["scores"][:, :top].contiguous(),
-                                                               dev["n_hits"], dev["num_matched"])]
-                return gathered[0][self.rank], gathered[1][self.rank], gathered[2][self.rank], gathered[3][self.rank]
+                pack[:, :, 0] = dev["keys"][:, :top]                     # {key, scores[3]} per hit: one 32 MB collective per step
+                pack[:, :, 1:] = dev["scores"][:, :top]
+                counts[:, 0] = dev["n_hits"]
+                counts[:, 1] = dev["num_matched"]
+                g_hits, g_counts = self.D.all_gather_cat(pack), self.D.all_gather_cat(counts)
+                mine, mc = g_hits[self.rank], g_counts[self.rank]
+                return mine[:, :, 0], mine[:, :, 1:], mc[:, 0], mc[:, 1]
             return dev["keys"], dev["scores"], dev["n_hits"], dev["num_matched"]
 
         def after(_):
