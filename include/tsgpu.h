@@ -95,13 +95,17 @@ const char* tsgpu_last_error(void);
 /* run the library's kernels on a caller-owned hipStream_t (NULL = the context's own stream) */
 int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
 /* tuning knobs (all optional): "kw_chunk_blocks" = driver posting blocks per keyword work item (default 0 = sized per batch; 1..256),
+ * "kw_two_kernels" = 1 (default): queries of <= 3 tokens run as a find kernel + a score kernel with 16-byte hit records between
+ * them, 0: one fused kernel (identical results); "kw_hit_buffer_mb" = budget of that hit buffer (default 20480; 16 bytes per
+ * driver posting of the batch are reserved; a batch that needs more than two buffer-sized groups runs fused);
+ * "kw_sort_work" = 1 (default): work items launched heaviest first,
  * "vec_rows_per_slab" = base rows per k-NN workgroup slab (default: automatic), "vec_sample_tiles" = 128-row tiles of
  * the k-NN threshold sample (default 512), "vec_cand_cap" = candidate slots per query of the filtered pass (0 = auto),
  * "vec_prefilter" = 1 (default): bf16 bracket scan + exact fp32 re-score of the survivors, 0: fp32 MFMA scan of every row
  * (identical result sets either way), "vec_count_rescored" = 1: keep the vec_rescored_rows counter (costs one sync) */
 int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value);
 /* introspection counters (tests / bench): "vec_overflow_rounds", "vec_prefilter_groups", "vec_prefilter_fallbacks",
- * "vec_rescored_rows" */
+ * "vec_rescored_rows", "kw_last_hit_groups" (find+score groups of the last keyword batch, 0 = fused), "kw_last_hit_records" */
 int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out);
 /* bytes of HBM held by the context's index mirrors */
 uint64_t tsgpu_device_bytes(tsgpu_ctx* ctx);
