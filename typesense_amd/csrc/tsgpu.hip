@@ -3,6 +3,7 @@
 // items); all scoring happens in kw_kernels.hip.h on the GPU. There is no CPU fallback: a query this
 // library does not accelerate is reported per query as TSGPU_ERR_UNSUPPORTED and left to the caller.
 #include "tsgpu_host.h"
+#include <cmath>
 #include "kw_kernels.hip.h"
 
 using namespace tsgpu;
@@ -130,7 +131,9 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->snap.lists, &ctx->snap.blk_last, &ctx->snap.blk_ids, &ctx->snap.blk_meta, &ctx->snap.ids_payload, &ctx->snap.payload, &ctx->d_col_ptrs, &ctx->d_col_len,
                       &ctx->d_queries, &ctx->d_work, &ctx->d_aux, &ctx->d_ids_out, &ctx->d_mf, &ctx->d_part_s0, &ctx->d_part_s1, &ctx->d_part_s2,
                       &ctx->d_part_key, &ctx->d_part_cnt, &ctx->d_part_nm, &ctx->d_part_ne, &ctx->d_part_ow, &ctx->d_part_f, &ctx->d_out_keys,
-                      &ctx->d_out_scores, &ctx->d_out_tm, &ctx->d_out_vd, &ctx->d_out_msi, &ctx->d_out_nh, &ctx->d_out_nm, &ctx->d_out_ow, &ctx->d_prof};
+                      &ctx->d_out_scores, &ctx->d_out_tm, &ctx->d_out_vd, &ctx->d_out_msi, &ctx->d_out_nh, &ctx->d_out_nm, &ctx->d_out_ow, &ctx->d_prof,
+                      &ctx->d_hits, &ctx->d_hit_off, &ctx->d_cand_keys, &ctx->d_cand_scores, &ctx->d_cand_tm, &ctx->d_cand_vd, &ctx->d_cand_msi, &ctx->d_cand_nh,
+                      &ctx->d_cand_nm, &ctx->d_cand_st, &ctx->d_cand_gb, &ctx->d_cand_qi, &ctx->d_cand_found, &ctx->d_cand_segs, &ctx->d_cand_bits, &ctx->d_cand_ids};
     for (auto* b : bufs) b->release();
     for (auto& c : ctx->columns) c.data.release();
     ctx->h_stage.release();
@@ -366,6 +369,10 @@ int tsgpu_term_download(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, uin
 int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return fail(TSGPU_ERR_INVALID, "tsgpu_set_option: NULL argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!strcmp(name, "kw_max_partials")) {
+        if (value < 1 || value > 4096) return fail(TSGPU_ERR_INVALID, "kw_max_partials out of range (1..4096)");
+        ctx->kw_max_partials = (uint32_t)value; return ok();
+    }
     if (!strcmp(name, "kw_sort_work")) { ctx->kw_sort_work = value != 0; return ok(); }
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
     if (!strcmp(name, "kw_hit_buffer_records")) {       // exact budget in hit records (tests); 0 = use kw_hit_buffer_mb
@@ -651,8 +658,13 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         // (small batches: a few thousand work items fill the chip, more only lengthen the per-query merge chain; measured on the
         // 10M-doc collection: 100 queries 1.47 -> 1.15 ms, while a cap of 8 at 1 000+ queries unbalances the search kernel)
         uint32_t chunk_q = KW_CHUNK_BLOCKS;
-        const uint32_t max_partials = n_queries >= 512 ? 64u : std::min<uint32_t>(64, std::max<uint32_t>(16, 4096 / std::max<uint32_t>(n_queries, 1)));
-        if (ctx->kw_chunk_blocks == 0) chunk_q = std::max(chunk_q, (dA.n_blocks + max_partials - 1) / max_partials);
+        // small batches are as slow as their heaviest query: its longest work item (~3 us per driver block when the chip is not full)
+        // plus the chain of partial folds in kw_merge_kernel (~4.5 us each) -> the item count that balances the two, ~sqrt(blocks / 1.5)
+        uint32_t max_partials = ctx->kw_max_partials;
+        if (n_queries < 512) max_partials = std::max(max_partials, std::min<uint32_t>(128, (uint32_t)std::sqrt((double)dA.n_blocks / 1.5)));
+        // ... but never longer than KW_MAX_CHUNK blocks: the batch is as slow as its longest work item (a 16K-block driver list cut in 16
+        // would run 1 000 blocks in sequence), and folding 64 sorted partials costs kw_merge_kernel ~0.3 ms
+        if (ctx->kw_chunk_blocks == 0) chunk_q = std::max(chunk_q, std::min<uint32_t>((dA.n_blocks + max_partials - 1) / max_partials, (uint32_t)KW_MAX_CHUNK));
         {   // launch-order key: estimated cost of the query's LARGEST work item = driver blocks x (fixed cost + second-list ids per
             // driver id); the work table is laid out heaviest first so that the long items do not start last (tail of the launch)
             const double r = nl >= 2 ? (double)len_of[ord[1]] / (double)std::max<uint32_t>(len_of[ord[0]], 1) : 0.0;
@@ -864,14 +876,29 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
 
         // ---- results ----
         std::vector<uint64_t> off_words(n_queries);
+        // small results travel through one pinned staging buffer (a pageable destination costs ~150 us per copy call, seven calls);
+        // large ones go straight to the caller's arrays (the runtime pipelines them)
+        struct Staged { void* dst; size_t off, bytes; };
+        std::vector<Staged> staged;
         if (!dev_out) {
-            TSGPU_HIP_TRY(hipMemcpyAsync(out->n_hits, o.n_hits, (size_t)n_queries * 4, hipMemcpyDeviceToHost, s));
-            if (out->num_matched) TSGPU_HIP_TRY(hipMemcpyAsync(out->num_matched, o.num_matched, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
-            TSGPU_HIP_TRY(hipMemcpyAsync(out->keys, o.keys, slots * 8, hipMemcpyDeviceToHost, s));
-            TSGPU_HIP_TRY(hipMemcpyAsync(out->scores, o.scores, slots * 24, hipMemcpyDeviceToHost, s));
-            if (out->text_match) TSGPU_HIP_TRY(hipMemcpyAsync(out->text_match, o.text_match, slots * 8, hipMemcpyDeviceToHost, s));
-            if (out->vector_distance) TSGPU_HIP_TRY(hipMemcpyAsync(out->vector_distance, o.vector_distance, slots * 4, hipMemcpyDeviceToHost, s));
-            if (out->match_score_index) TSGPU_HIP_TRY(hipMemcpyAsync(out->match_score_index, o.match_score_index, slots, hipMemcpyDeviceToHost, s));
+            const bool stage = slots * 45 + (size_t)n_queries * 12 <= (8u << 20);
+            size_t at = 0;
+            uint8_t* pin = nullptr;
+            if (stage) { if ((rc = ctx->h_out.reserve(slots * 45 + (size_t)n_queries * 12 + 64))) return rc; pin = (uint8_t*)ctx->h_out.p; }
+            auto d2h = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+                if (!stage) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+                staged.push_back({dst, at, bytes});
+                const hipError_t e = hipMemcpyAsync(pin + at, src, bytes, hipMemcpyDeviceToHost, s);
+                at += (bytes + 7) & ~(size_t)7;
+                return e;
+            };
+            TSGPU_HIP_TRY(d2h(out->n_hits, o.n_hits, (size_t)n_queries * 4));
+            if (out->num_matched) TSGPU_HIP_TRY(d2h(out->num_matched, o.num_matched, (size_t)n_queries * 8));
+            TSGPU_HIP_TRY(d2h(out->keys, o.keys, slots * 8));
+            TSGPU_HIP_TRY(d2h(out->scores, o.scores, slots * 24));
+            if (out->text_match) TSGPU_HIP_TRY(d2h(out->text_match, o.text_match, slots * 8));
+            if (out->vector_distance) TSGPU_HIP_TRY(d2h(out->vector_distance, o.vector_distance, slots * 4));
+            if (out->match_score_index) TSGPU_HIP_TRY(d2h(out->match_score_index, o.match_score_index, slots));
             for (uint32_t i = 0; i < n_queries; i++) out->status[i] = P.status[i];
             if (out->search_cutoff) for (uint32_t i = 0; i < n_queries; i++) out->search_cutoff[i] = P.cutoff[i];
         } else {
@@ -880,6 +907,7 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
         }
         TSGPU_HIP_TRY(hipMemcpyAsync(off_words.data(), o.off_words, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        for (const Staged& c : staged) memcpy(c.dst, (const uint8_t*)ctx->h_out.p + c.off, c.bytes);
         if (status_host) status_host->assign(P.status.begin(), P.status.end());
         const uint64_t t_synced = now_us();
 

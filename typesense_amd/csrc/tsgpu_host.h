@@ -115,6 +115,7 @@ struct tsgpu_ctx {
     tsgpu::DevBuf d_prof;                            // TSGPU_PROF builds only (null otherwise)
     tsgpu::PinBuf h_stage, h_out;
     bool keep_ids = false;
+    uint32_t kw_max_partials = 16;                   // work items (= partial top-K lists) per query at most; longer driver lists get longer items
     bool kw_sort_work = true;                        // lay the work table out heaviest query first
     bool kw_two_kernels = true;                      // queries of <= 3 tokens: find kernel + score kernel instead of the fused kernel
     uint32_t kw_hit_buffer_mb = 20480;               // budget of the hit-record buffer between the two (work items run in groups that fit)
