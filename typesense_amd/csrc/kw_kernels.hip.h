@@ -49,9 +49,14 @@ namespace tsgpu {
 #endif
 
 // 4 workgroups (16 waves) per CU need <= 128 VGPRs: tell the register allocator (it lands 3 over without the hint)
+#ifndef TSGPU_SCORE_WAVES
+#define TSGPU_SCORE_WAVES 5      // kw_score_kernel: 96 VGPRs = 5 waves per SIMD (2.01 -> 1.73 ms; 6 waves spills for no gain)
+#endif
 #ifdef TSGPU_HIP_EMU
 #define KW_FOUR_WAVES_PER_SIMD
+#define KW_SCORE_WAVES
 #else
+#define KW_SCORE_WAVES __attribute__((amdgpu_waves_per_eu(TSGPU_SCORE_WAVES)))
 #define KW_FOUR_WAVES_PER_SIMD __attribute__((amdgpu_waves_per_eu(4)))
 #endif
 
@@ -1273,7 +1278,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
 // ascending seq_id) are scored 256 at a time — every wavefront full except the segment's last — through the same score stage,
 // top-K buffer and filter bookkeeping as the fused kernel, and leave the same partial result for kw_merge_kernel.
 template <int CAP, bool S2>
-__global__ __launch_bounds__(KW_THREADS) void kw_score_kernel(IndexView ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work,
+__global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(IndexView ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work,
                                                               KwPartials part, const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out,
                                                               const KwHitRec* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
     __shared__ KwSmem<3, CAP, false, S2, false, true> sm;
