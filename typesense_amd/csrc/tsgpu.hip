@@ -845,9 +845,12 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
                 group_start.push_back(nws);
                 two = group_start.size() <= 3;          // each group drains the chip between its two kernels: beyond two groups the fused kernel wins
             }
+            if (two && ctx->d_hits.reserve(std::max<uint64_t>(need, 1) * sizeof(KwHitRec))) {
+                (void)hipGetLastError();                // no room for the hit buffer: the fused kernel needs none
+                two = false;
+            }
             ctx->kw_last_hit_groups = two ? (uint32_t)group_start.size() - 1 : 0;
             if (two) {
-                if ((rc = ctx->d_hits.reserve(std::max<uint64_t>(need, 1) * sizeof(KwHitRec)))) return rc;
                 if ((rc = upload(ctx->d_hit_off, hoff.data(), nws * 8, s))) return rc;
                 for (size_t gi = 0; gi + 1 < group_start.size(); gi++) {
                     const size_t a = group_start[gi], b = group_start[gi + 1];
