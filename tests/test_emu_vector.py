@@ -256,6 +256,36 @@ def test_hybrid_rank_fusion_matches_oracle_bit_exactly():
     g.close()
 
 
+def test_hybrid_with_filter_and_excluded_ids_matches_oracle():
+    """filter_by / hidden hits in a hybrid query restrict BOTH halves: take_id() in the keyword pass and the VectorFilterFunctor of the
+    k-NN (src/index.cpp:3376-3445, 4036-4221); the fused Topster must equal the oracle's bit for bit"""
+    orc, g, rng = _text_and_vectors(H.emu_lib_path())
+    n_docs = 400
+    Q = rng.standard_normal((6, 24)).astype(np.float32)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    filt = np.sort(rng.choice(n_docs, size=n_docs // 3, replace=False)).astype(np.uint32)
+    excl = np.arange(0, n_docs, 4, dtype=np.uint32)
+    cases = [dict(), dict(filter_ids=filt), dict(excluded_ids=excl), dict(filter_ids=filt, excluded_ids=excl), dict(filter_ids=filt[:7]), dict()]
+    toks = [[1, 2], [3], [2, 5], [1, 2, 3], [59, 1], [7, 7]]
+    qs = [T.KwQuery(t, sort=sort, topster_size=0, **c) for t, c in zip(toks, cases)]
+    hits = g.hybrid_search_batch(qs, 1, Q, k=0, fetch_size=10, alpha=0.3, k_stride=250)
+    assert (hits.status == 0).all()
+    for i, (q, c) in enumerate(zip(qs, cases)):
+        oq = orc.make_query(q.tokens, sort=((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1)), fetch_size=10, **c)
+        ref = orc.search_hybrid(oq, Q[i], k=0, alpha=0.3)
+        n = int(hits.n_hits[i])
+        assert n == ref.keys.size, (i, n, ref.keys.size)
+        assert np.array_equal(hits.keys[i, :n], ref.keys), (i, hits.keys[i, :10], ref.keys[:10])
+        assert np.array_equal(hits.scores[i, :n], ref.scores)
+        assert np.array_equal(hits.text_match[i, :n], ref.text_match)
+        assert np.allclose(hits.vector_distance[i, :n], ref.vector_distance, rtol=RTOL, atol=RTOL)
+        if "filter_ids" in c:
+            assert np.isin(hits.keys[i, :n], c["filter_ids"]).all()
+        if "excluded_ids" in c:
+            assert not np.isin(hits.keys[i, :n], c["excluded_ids"]).any()
+    g.close()
+
+
 def test_shard_merge_equals_unsharded():
     lib = H.emu_lib_path()
     docs = H.zipf_docs(1200, 80, 10, seed=8)

@@ -24,6 +24,7 @@ test_ties_prefer_smaller_label_and_many_slabs = E.test_ties_prefer_smaller_label
 test_upsert_delete_labels_filters_and_by_id_distances = E.test_upsert_delete_labels_filters_and_by_id_distances
 test_pure_vector_search_topster_order_matches_oracle = E.test_pure_vector_search_topster_order_matches_oracle
 test_hybrid_rank_fusion_matches_oracle_bit_exactly = E.test_hybrid_rank_fusion_matches_oracle_bit_exactly
+test_hybrid_with_filter_and_excluded_ids_matches_oracle = E.test_hybrid_with_filter_and_excluded_ids_matches_oracle
 test_shard_merge_equals_unsharded = E.test_shard_merge_equals_unsharded
 test_knn_two_pass_threshold_path_is_exact = E.test_knn_two_pass_threshold_path_is_exact
 test_knn_two_pass_all_equal_distances_converges = E.test_knn_two_pass_all_equal_distances_converges

@@ -785,8 +785,8 @@ static void fuse_one_query(tsgpu_ctx* ctx, int metric, const tsgpu_kw_query& kq,
     const float VECTOR_SEARCH_WEIGHT = p->alpha;
     const float TEXT_MATCH_WEIGHT = 1.0 - VECTOR_SEARCH_WEIGHT;
     struct VH { float dist; uint64_t seq_id; };
-    uint32_t tsz = kq.topster_size ? kq.topster_size : TSGPU_DEFAULT_TOPSTER_SIZE;
-    tsz = std::max<uint32_t>(1, std::min<uint32_t>(tsz, std::max<uint32_t>(ctx->num_docs, 1)));
+    uint32_t tsz = kq.topster_size ? kq.topster_size : TSGPU_DEFAULT_TOPSTER_SIZE;                      // src/index.cpp:3506-3512
+    tsz = std::max<uint32_t>(1, std::min<uint32_t>(tsz, (!kq.topster_size && kq.n_filter) ? kq.n_filter : std::max<uint32_t>(ctx->num_docs, 1)));
     HostTopster topster(tsz);
     const uint32_t nh = kw.n_hits[q];
     std::vector<HostKV> sorted(nh);
@@ -923,11 +923,21 @@ int tsgpu_hybrid_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uin
         int rc = tsgpu_keyword_search_batch(ctx, queries, n_queries, &kw);
         if (rc) return rc;
         const auto t1 = std::chrono::steady_clock::now();
-        // 2) vector pass: one batched exact k-NN (filters / exclusions are per query -> not batched: unsupported in v1)
-        for (uint32_t q = 0; q < n_queries; q++)
-            if (st[q] == TSGPU_OK && (queries[q].n_excluded || queries[q].n_filter)) st[q] = TSGPU_ERR_UNSUPPORTED;
+        // 2) vector pass: one batched exact k-NN for the whole batch; a query with filter_by / excluded ids (the VectorFilterFunctor of
+        //    process_results_hnsw_index, src/index.cpp:3376-3445) gets its own exact k-NN restricted to its allowed ids afterwards
         KnnHost kh;
         if ((rc = knn_to_host(ctx, vec_field_id, Q, mem_q, n_queries, k, nullptr, 0, nullptr, 0, kh))) return rc;
+        {
+            KnnHost one;
+            for (uint32_t q = 0; q < n_queries; q++) {
+                if (st[q] != TSGPU_OK || (queries[q].n_excluded == 0 && queries[q].n_filter == 0)) continue;
+                if ((rc = knn_to_host(ctx, vec_field_id, Q + (size_t)q * f->dim, mem_q, 1, k, queries[q].n_filter ? queries[q].filter_ids : nullptr, queries[q].n_filter,
+                                      queries[q].n_excluded ? queries[q].excluded_ids : nullptr, queries[q].n_excluded, one))) return rc;
+                std::copy(one.dist.begin(), one.dist.end(), kh.dist.begin() + (size_t)q * k);
+                std::copy(one.lab.begin(), one.lab.end(), kh.lab.begin() + (size_t)q * k);
+                kh.cnt[q] = one.cnt[0];
+            }
+        }
         const auto t2 = std::chrono::steady_clock::now();
         // 3) fusion on the host, exactly as the reference
         rc = tsgpu_hybrid_fuse_batch(ctx, queries, p, f->metric, &kw, kh.dist.data(), kh.lab.data(), kh.cnt.data(), k, n_queries, out);
