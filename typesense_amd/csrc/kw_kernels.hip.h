@@ -70,7 +70,10 @@ static const uint32_t KW_WINDOW_SIZE = 10; // WINDOW_SIZE, include/match_score.h
 #ifndef TSGPU_KW_TILE_WORDS
 #define TSGPU_KW_TILE_WORDS 2048
 #endif
-static const int KW_MAX_CHUNK = 256;        // driver blocks per work item (host clamps kw_chunk_blocks to this)
+#ifndef TSGPU_KW_MAX_CHUNK
+#define TSGPU_KW_MAX_CHUNK 512
+#endif
+static const int KW_MAX_CHUNK = TSGPU_KW_MAX_CHUNK;        // driver blocks per work item (host clamps kw_chunk_blocks to this)
 static const int KW_PIPE_WORDS = 4;         // dwords per thread of the register-pipelined tile copy (4 x 256 words = 2048 16-bit ids)
 // the find kernel (two-kernel form) has registers and LDS to spare: deeper register pipeline, larger tile
 #ifndef TSGPU_KW_FIND_PIPE_WORDS

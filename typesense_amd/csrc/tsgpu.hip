@@ -384,7 +384,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
         ctx->kw_hit_buffer_mb = (uint32_t)value; return ok();
     }
     if (!strcmp(name, "kw_chunk_blocks")) {
-        if (value < 0 || value > KW_MAX_CHUNK) return fail(TSGPU_ERR_INVALID, "kw_chunk_blocks out of range (0 = auto, 1..256)");
+        if (value < 0 || value > KW_MAX_CHUNK) return fail(TSGPU_ERR_INVALID, "kw_chunk_blocks out of range (0 = auto, 1..KW_MAX_CHUNK)");
         ctx->kw_chunk_blocks = (uint32_t)value;
         return ok();
     }
@@ -662,9 +662,9 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         // plus the chain of partial folds in kw_merge_kernel (~4.5 us each) -> the item count that balances the two, ~sqrt(blocks / 1.5)
         uint32_t max_partials = ctx->kw_max_partials;
         if (n_queries < 512) max_partials = std::max(max_partials, std::min<uint32_t>(128, (uint32_t)std::sqrt((double)dA.n_blocks / 1.5)));
-        // ... but never longer than KW_MAX_CHUNK blocks: the batch is as slow as its longest work item (a 16K-block driver list cut in 16
+        // ... but never longer than 256 blocks (only the batch-wide chunk of a very large batch goes beyond, up to KW_MAX_CHUNK): the batch is as slow as its longest work item (a 16K-block driver list cut in 16
         // would run 1 000 blocks in sequence), and folding 64 sorted partials costs kw_merge_kernel ~0.3 ms
-        if (ctx->kw_chunk_blocks == 0) chunk_q = std::max(chunk_q, std::min<uint32_t>((dA.n_blocks + max_partials - 1) / max_partials, (uint32_t)KW_MAX_CHUNK));
+        if (ctx->kw_chunk_blocks == 0) chunk_q = std::max(chunk_q, std::min<uint32_t>((dA.n_blocks + max_partials - 1) / max_partials, 256u));
         {   // launch-order key: estimated cost of the query's LARGEST work item = driver blocks x (fixed cost + second-list ids per
             // driver id); the work table is laid out heaviest first so that the long items do not start last (tail of the launch)
             const double r = nl >= 2 ? (double)len_of[ord[1]] / (double)std::max<uint32_t>(len_of[ord[0]], 1) : 0.0;
