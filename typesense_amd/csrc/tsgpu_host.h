@@ -116,6 +116,7 @@ struct tsgpu_ctx {
     tsgpu::PinBuf h_stage, h_out;
     bool keep_ids = false;
     uint32_t kw_max_partials = 16;                   // work items (= partial top-K lists) per query at most; longer driver lists get longer items
+    uint32_t kw_cost_fixed = 16;                     // launch-order cost model: item cost = driver blocks x (kw_cost_fixed + |B|/|A|)
     bool kw_sort_work = true;                        // lay the work table out heaviest query first
     bool kw_two_kernels = true;                      // queries of <= 3 tokens: find kernel + score kernel instead of the fused kernel
     uint32_t kw_hit_buffer_mb = 20480;               // budget of the hit-record buffer between the two (work items run in groups that fit)
