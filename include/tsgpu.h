@@ -95,9 +95,10 @@ const char* tsgpu_last_error(void);
 /* run the library's kernels on a caller-owned hipStream_t (NULL = the context's own stream) */
 int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
 /* tuning knobs (all optional): "kw_chunk_blocks" = driver posting blocks per keyword work item (default 0 = sized per batch; 1..256),
- * "kw_two_kernels" = 1 (default): queries of <= 3 tokens run as a find kernel + a score kernel with 16-byte hit records between
- * them, 0: one fused kernel (identical results); "kw_hit_buffer_mb" = budget of that hit buffer (default 20480; 16 bytes per
- * driver posting of the batch are reserved; a batch that needs more than two buffer-sized groups runs fused);
+ * "kw_two_kernels" = 1 (default): single-field queries run as a find kernel + a score kernel with hit records (seq_id + one
+ * posting position per token) between them, 0: one fused kernel (identical results); "kw_hit_buffer_mb" = budget of that hit
+ * buffer (default 20480; 16 bytes (<= 3 tokens) or 44 bytes per driver posting of the batch are reserved; a table of work items
+ * that needs more than two buffer-sized groups runs fused);
  * "kw_sort_work" = 1 (default): work items launched heaviest first,
  * "vec_rows_per_slab" = base rows per k-NN workgroup slab (default: automatic), "vec_sample_tiles" = 128-row tiles of
  * the k-NN threshold sample (default 512), "vec_cand_cap" = candidate slots per query of the filtered pass (0 = auto),

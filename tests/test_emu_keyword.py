@@ -346,8 +346,8 @@ def test_two_kernel_form_and_fused_kernel_agree_with_the_oracle(pair):
     rng = np.random.default_rng(91)
     sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
     qs = []
-    for n_tok in (1, 2, 3):
-        qs += _queries(rng, 10, 25, n_tok, sort=sort, topster_size=250)
+    for n_tok in (1, 2, 3, 5):
+        qs += _queries(rng, 10 if n_tok <= 3 else 4, 25 if n_tok <= 3 else 10, n_tok, sort=sort, topster_size=250)
         qs += _queries(rng, 3, 25, n_tok, sort=sort, topster_size=9, excluded_ids=np.arange(0, 3000, 4))
         qs += _queries(rng, 3, 25, n_tok, sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=40,
                        filter_ids=np.sort(rng.choice(3000, size=900, replace=False)))
@@ -362,7 +362,7 @@ def test_two_kernel_form_and_fused_kernel_agree_with_the_oracle(pair):
             groups.append(g.counter("kw_last_hit_groups"))
             ids = [g.result_ids(i) for i in range(len(qs))]
             outs.append((hits, ids))
-        assert groups == [1, 2, 0], groups
+        assert groups[0] == 2 and groups[1] >= 3 and groups[2] == 0, groups      # one group per table (<= 3 tokens / longer), split by the small budget, fused
         for i, q in enumerate(qs):
             ref = H.oracle_keyword(orc, q, ids_cap=4000)
             for hits, ids in outs:

@@ -1,0 +1,7 @@
+#!/bin/bash
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+for T in 4 5; do
+KW_TOKENS=$T KW_BATCHES=10000,1000 KW_SWEEP='[{"kw_two_kernels":1},{"kw_two_kernels":0}]' timeout 600 python tools/sweep_kw.py 2>&1 | grep -E "n_q|rror" | cut -c1-190
+done
+timeout 900 python -m pytest tests/test_gpu_keyword.py -m gpu -x -q 2>&1 | tail -2

@@ -17,7 +17,7 @@ g.terms_load_csr(0, csr["term_ids"], csr["ids_ptr"], csr["ids"], csr["offset_ind
 g.column_set(0, pts); g.set_num_docs(n_docs); g.commit()
 sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
 for n_q in [int(x) for x in os.environ.get("KW_BATCHES", "10000,1000,100").split(",")]:
-    qtok = synth.keyword_queries(n_q, 3, 8, 2000, seed=4)
+    qtok = synth.keyword_queries(n_q, int(os.environ.get("KW_TOKENS", "3")), 8, 2000, seed=4)
     arr = (B.KwQueryC * n_q)()
     for i in range(n_q):
         T.KwQuery(qtok[i], sort=sort, topster_size=250).fill(arr[i])

@@ -896,13 +896,26 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2, false, SCORE>& s
 }
 
 // one complete hit of a query of <= 3 tokens as the find kernel hands it to kw_score_kernel: seq_id + posting position per token
-struct KwHitRec { uint32_t id, p0, p1, p2; };
+struct KwHitRec { uint32_t id, p0, p1, p2; };              // TMAX = 3: one 16-byte store / load
+// generic record: 1 + TMAX words {seq_id, pos[0 .. TMAX)}; the buffer is addressed in words, hit_off[] counts records
+template <int TMAX>
+__device__ inline void kw_hit_store(uint32_t* __restrict__ hits, uint32_t slot, uint32_t id, const uint32_t (&pos)[TMAX]) {
+    if constexpr (TMAX == 3) {
+        KwHitRec r; r.id = id; r.p0 = pos[0]; r.p1 = pos[1]; r.p2 = pos[2];
+        ((KwHitRec*)hits)[slot] = r;
+    } else {
+        uint32_t* __restrict__ d = hits + (size_t)slot * (TMAX + 1);
+        d[0] = id;
+#pragma unroll
+        for (int k = 0; k < TMAX; k++) d[1 + k] = pos[k];
+    }
+}
 
 // probes lists probe_order[2..] for the first n_take entries of queue 1 and moves survivors to the final queue
 // (DEFER: to the work item's hit segment in memory; sm.qf_cnt counts them)
 template <int TMAX, int CAP, bool S2, bool DEFER>
 __device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP, false, S2, DEFER>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take,
-                                           KwHitRec* __restrict__ hits) {
+                                           uint32_t* __restrict__ hits) {
     const uint32_t t = threadIdx.x;
     bool ok = t < n_take;
     uint32_t id = 0;
@@ -930,9 +943,7 @@ __device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP, false, S2, DEFER>& 
     if (ok) {
         const uint32_t slot = sm.qf_cnt + my;
         if constexpr (DEFER) {
-            static_assert(!DEFER || TMAX == 3, "deferred scoring carries three posting positions");
-            KwHitRec r; r.id = id; r.p0 = pos[0]; r.p1 = pos[TMAX > 1 ? 1 : 0]; r.p2 = pos[TMAX > 2 ? 2 : 0];
-            hits[slot] = r;
+            kw_hit_store<TMAX>(hits, slot, id, pos);
         } else {
             sm.qf_id[slot] = id;
 #pragma unroll
@@ -985,9 +996,9 @@ template <int TMAX, int CAP, bool S2, bool DEFER = false>
 __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
                                                                 const KwWorkItem* __restrict__ work, KwPartials part,
                                                                 const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out,
-                                                                KwHitRec* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
+                                                                uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
     __shared__ KwSmem<TMAX, CAP, false, S2, DEFER> sm;
-    KwHitRec* __restrict__ hits = DEFER ? hits_all + hit_off[blockIdx.x] : nullptr;
+    uint32_t* __restrict__ hits = DEFER ? hits_all + hit_off[blockIdx.x] * (uint64_t)(TMAX + 1) : nullptr;
     __shared__ KwQueryDev sq;
     const uint32_t t = threadIdx.x;
     const KwWorkItem wi = work[blockIdx.x];
@@ -1223,11 +1234,10 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
             }
         } else if constexpr (DEFER) {
             if (ok) {                                   // one or two lists: the stage-1 survivors ARE the complete hits
-                uint32_t v[3] = {0, 0, 0};
+                uint32_t v[TMAX];
 #pragma unroll
-                for (int k = 0; k < 3; k++) { if (k == q.probe_order[0]) v[k] = p0; if (T >= 2 && k == q.probe_order[1]) v[k] = p1; }
-                KwHitRec r; r.id = id; r.p0 = v[0]; r.p1 = v[1]; r.p2 = v[2];
-                hits[qfn + my] = r;
+                for (int k = 0; k < TMAX; k++) { v[k] = 0; if (k == q.probe_order[0]) v[k] = p0; if (T >= 2 && k == q.probe_order[1]) v[k] = p1; }
+                kw_hit_store<TMAX>(hits, qfn + my, id, v);
             }
             qfn += total;
         } else {
@@ -1280,11 +1290,11 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
 // The "score" half of the two-kernel form: one workgroup per work item of the find kernel; its hits (seq_id + posting positions,
 // ascending seq_id) are scored 256 at a time — every wavefront full except the segment's last — through the same score stage,
 // top-K buffer and filter bookkeeping as the fused kernel, and leave the same partial result for kw_merge_kernel.
-template <int CAP, bool S2>
+template <int TMAX, int CAP, bool S2>
 __global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(IndexView ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work,
                                                               KwPartials part, const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out,
-                                                              const KwHitRec* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
-    __shared__ KwSmem<3, CAP, false, S2, false, true> sm;
+                                                              const uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
+    __shared__ KwSmem<TMAX, CAP, false, S2, false, true> sm;
     __shared__ KwQueryDev sq;
     const uint32_t t = threadIdx.x;
     const KwWorkItem wi = work[blockIdx.x];
@@ -1302,16 +1312,23 @@ __global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(Ind
     const KwQueryDev& q = sq;
     uint32_t* my_ids_out = ids_out ? ids_out + q.ids_out_off + wi.ids_out_off : nullptr;
     const uint32_t count = part.cnt[blockIdx.x];
-    const KwHitRec* __restrict__ mine = hits_all + hit_off[blockIdx.x];
+    const uint32_t* __restrict__ mine = hits_all + hit_off[blockIdx.x] * (uint64_t)(TMAX + 1);
     for (uint32_t i0 = 0; i0 < count; i0 += KW_THREADS) {
         const uint32_t n = count - i0 < (uint32_t)KW_THREADS ? count - i0 : (uint32_t)KW_THREADS;
         if (t < n) {
-            const KwHitRec r = mine[i0 + t];
-            sm.qf_id[t] = r.id; sm.qf_pos[0][t] = r.p0; sm.qf_pos[1][t] = r.p1; sm.qf_pos[2][t] = r.p2;
+            if constexpr (TMAX == 3) {
+                const KwHitRec r = ((const KwHitRec*)mine)[i0 + t];
+                sm.qf_id[t] = r.id; sm.qf_pos[0][t] = r.p0; sm.qf_pos[1][t] = r.p1; sm.qf_pos[2][t] = r.p2;
+            } else {
+                const uint32_t* __restrict__ r = mine + (size_t)(i0 + t) * (TMAX + 1);
+                sm.qf_id[t] = r[0];
+#pragma unroll
+                for (int k = 0; k < TMAX; k++) sm.qf_pos[k][t] = r[1 + k];
+            }
         }
         if (t == 0) sm.qf_cnt = n;
         __syncthreads();
-        kw_score_stage<3, CAP, false, S2, true>(sm, ix, q, n, aux_ids, my_ids_out, 0u);      // ends with a barrier
+        kw_score_stage<TMAX, CAP, false, S2, true>(sm, ix, q, n, aux_ids, my_ids_out, 0u);
     }
     kw_write_partial(sm, q, part);
 }

@@ -56,18 +56,19 @@ template <int TMAX, int CAP>
 void launch_search(hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w,
                    const KwPartials& part, const uint32_t* aux, uint32_t* ids_out, bool s2) {
     // s2 = some query of the launch sorts by three keys; the two-key build (CAP 512 only) has a smaller LDS footprint
-    if (CAP == 512 && !s2) hipLaunchKernelGGL((kw_search_kernel<TMAX, CAP, CAP != 512>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, (KwHitRec*)nullptr, (const uint64_t*)nullptr);
-    else hipLaunchKernelGGL((kw_search_kernel<TMAX, CAP, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, (KwHitRec*)nullptr, (const uint64_t*)nullptr);
+    if (CAP == 512 && !s2) hipLaunchKernelGGL((kw_search_kernel<TMAX, CAP, CAP != 512>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, (uint32_t*)nullptr, (const uint64_t*)nullptr);
+    else hipLaunchKernelGGL((kw_search_kernel<TMAX, CAP, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, (uint32_t*)nullptr, (const uint64_t*)nullptr);
 }
 
-// two-kernel form for queries of <= 3 tokens: find (intersection -> hit records) then score (hit records -> partial top-K)
+// two-kernel form: find (intersection -> hit records) then score (hit records -> partial top-K)
+template <int TMAX>
 void launch_find_score(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w, const KwPartials& part,
-                       const uint32_t* aux, uint32_t* ids_out, bool s2, KwHitRec* hits, const uint64_t* hit_off) {
-    hipLaunchKernelGGL((kw_search_kernel<3, 512, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
-    if (cap == 512 && !s2) hipLaunchKernelGGL((kw_score_kernel<512, false>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
-    else if (cap == 512) hipLaunchKernelGGL((kw_score_kernel<512, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
-    else if (cap == 1024) hipLaunchKernelGGL((kw_score_kernel<1024, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
-    else hipLaunchKernelGGL((kw_score_kernel<2048, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+                       const uint32_t* aux, uint32_t* ids_out, bool s2, uint32_t* hits, const uint64_t* hit_off) {
+    hipLaunchKernelGGL((kw_search_kernel<TMAX, 512, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    if (cap == 512 && !s2) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, false>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    else if (cap == 512) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    else if (cap == 1024) hipLaunchKernelGGL((kw_score_kernel<TMAX, 1024, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    else hipLaunchKernelGGL((kw_score_kernel<TMAX, 2048, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
 }
 
 template <int TMAX>
@@ -132,7 +133,7 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
                       &ctx->d_queries, &ctx->d_work, &ctx->d_aux, &ctx->d_ids_out, &ctx->d_mf, &ctx->d_part_s0, &ctx->d_part_s1, &ctx->d_part_s2,
                       &ctx->d_part_key, &ctx->d_part_cnt, &ctx->d_part_nm, &ctx->d_part_ne, &ctx->d_part_ow, &ctx->d_part_f, &ctx->d_out_keys,
                       &ctx->d_out_scores, &ctx->d_out_tm, &ctx->d_out_vd, &ctx->d_out_msi, &ctx->d_out_nh, &ctx->d_out_nm, &ctx->d_out_ow, &ctx->d_prof,
-                      &ctx->d_hits, &ctx->d_hit_off, &ctx->d_cand_keys, &ctx->d_cand_scores, &ctx->d_cand_tm, &ctx->d_cand_vd, &ctx->d_cand_msi, &ctx->d_cand_nh,
+                      &ctx->d_hits, &ctx->d_hit_off, &ctx->d_hit_off_big, &ctx->d_cand_keys, &ctx->d_cand_scores, &ctx->d_cand_tm, &ctx->d_cand_vd, &ctx->d_cand_msi, &ctx->d_cand_nh,
                       &ctx->d_cand_nm, &ctx->d_cand_st, &ctx->d_cand_gb, &ctx->d_cand_qi, &ctx->d_cand_found, &ctx->d_cand_segs, &ctx->d_cand_bits, &ctx->d_cand_ids};
     for (auto* b : bufs) b->release();
     for (auto& c : ctx->columns) c.data.release();
@@ -823,44 +824,53 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
             return pb;
         };
         ctx->kw_last_hit_groups = 0;
-        if (!P.work_small.empty()) {
+        ctx->kw_last_hit_records = 0;
+        // single-field tables (<= 3 tokens / up to 10 tokens): find + score kernels when the hit buffer fits, else the fused kernel.
+        // A work item can yield at most one hit per driver id, so its segment of the hit buffer holds (blk_end - blk_begin) * 256
+        // records of 1 + TMAX words; the items run in groups whose segments fit the budget.
+        auto run_table = [&](const std::vector<KwWorkItem>& tab, size_t first, auto tmax_tag) -> int {
+            constexpr int TM = decltype(tmax_tag)::value;
+            if (tab.empty()) return TSGPU_OK;
+            const size_t nws = tab.size();
+            const size_t rec_bytes = (size_t)(TM + 1) * 4;
             bool two = ctx->kw_two_kernels;
             std::vector<uint64_t> hoff;
             std::vector<size_t> group_start(1, 0);
             uint64_t need = 0;
-            const size_t nws = P.work_small.size();
             if (two) {
-                // find + score: a work item can yield at most one hit per driver id, so its segment of the hit buffer holds
-                // (blk_end - blk_begin) * 256 records; the items run in groups whose segments fit the buffer budget
                 uint64_t largest = 0, all = 0;
-                for (size_t i = 0; i < nws; i++) { const uint64_t c = (uint64_t)(P.work_small[i].blk_end - P.work_small[i].blk_begin) * BLOCK_IDS; largest = std::max(largest, c); all += c; }
-                ctx->kw_last_hit_records = all;
-                const uint64_t budget = std::max<uint64_t>(ctx->kw_hit_buffer_records ? ctx->kw_hit_buffer_records : ((uint64_t)ctx->kw_hit_buffer_mb << 20) / sizeof(KwHitRec), largest);
+                for (size_t i = 0; i < nws; i++) { const uint64_t c = (uint64_t)(tab[i].blk_end - tab[i].blk_begin) * BLOCK_IDS; largest = std::max(largest, c); all += c; }
+                ctx->kw_last_hit_records += all;
+                const uint64_t budget = std::max<uint64_t>(ctx->kw_hit_buffer_records ? ctx->kw_hit_buffer_records : ((uint64_t)ctx->kw_hit_buffer_mb << 20) / rec_bytes, largest);
                 hoff.resize(nws);
                 uint64_t used = 0;
                 for (size_t i = 0; i < nws; i++) {
-                    const uint64_t c = (uint64_t)(P.work_small[i].blk_end - P.work_small[i].blk_begin) * BLOCK_IDS;
+                    const uint64_t c = (uint64_t)(tab[i].blk_end - tab[i].blk_begin) * BLOCK_IDS;
                     if (used + c > budget) { group_start.push_back(i); used = 0; }
                     hoff[i] = used; used += c; need = std::max(need, used);
                 }
                 group_start.push_back(nws);
                 two = group_start.size() <= 3;          // each group drains the chip between its two kernels: beyond two groups the fused kernel wins
             }
-            if (two && ctx->d_hits.reserve(std::max<uint64_t>(need, 1) * sizeof(KwHitRec))) {
+            if (two && ctx->d_hits.reserve(std::max<uint64_t>(need, 1) * rec_bytes)) {
                 (void)hipGetLastError();                // no room for the hit buffer: the fused kernel needs none
                 two = false;
             }
-            ctx->kw_last_hit_groups = two ? (uint32_t)group_start.size() - 1 : 0;
             if (two) {
-                if ((rc = upload(ctx->d_hit_off, hoff.data(), nws * 8, s))) return rc;
+                ctx->kw_last_hit_groups += (uint32_t)group_start.size() - 1;
+                DevBuf& offbuf = TM == 3 ? ctx->d_hit_off : ctx->d_hit_off_big;
+                int rc2;
+                if ((rc2 = upload(offbuf, hoff.data(), nws * 8, s))) return rc2;
                 for (size_t gi = 0; gi + 1 < group_start.size(); gi++) {
                     const size_t a = group_start[gi], b = group_start[gi + 1];
-                    if (b > a) launch_find_score(cap, s, (uint32_t)(b - a), v, dq, dw + a, shifted(a), daux, ids_out, P.any_s2, ctx->d_hits.as<KwHitRec>(), ctx->d_hit_off.as<uint64_t>() + a);
+                    if (b > a) launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, ctx->d_hits.as<uint32_t>(), offbuf.as<uint64_t>() + a);
                 }
-            } else launch_search_cap<3>(cap, s, (uint32_t)P.work_small.size(), v, dq, dw, part, daux, ids_out, P.any_s2);
-        }
+            } else launch_search_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out, P.any_s2);
+            return TSGPU_OK;
+        };
+        if ((rc = run_table(P.work_small, 0, std::integral_constant<int, 3>()))) return rc;
         size_t sh = P.work_small.size();
-        if (!P.work_big.empty()) launch_search_cap<KW_MAX_TOKENS>(cap, s, (uint32_t)P.work_big.size(), v, dq, dw + sh, shifted(sh), daux, ids_out, P.any_s2);
+        if ((rc = run_table(P.work_big, sh, std::integral_constant<int, KW_MAX_TOKENS>()))) return rc;
         sh += P.work_big.size();
         if (!P.work_mf_small.empty()) launch_search_mf_cap<3>(cap, s, (uint32_t)P.work_mf_small.size(), v, dq, dw + sh, shifted(sh), daux, ids_out);
         sh += P.work_mf_small.size();
