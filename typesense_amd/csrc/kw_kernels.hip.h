@@ -1290,16 +1290,17 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
 // The "score" half of the two-kernel form: one workgroup per work item of the find kernel; its hits (seq_id + posting positions,
 // ascending seq_id) are scored 256 at a time — every wavefront full except the segment's last — through the same score stage,
 // top-K buffer and filter bookkeeping as the fused kernel, and leave the same partial result for kw_merge_kernel.
-template <int TMAX, int CAP, bool S2>
+template <int TMAX, int CAP, bool S2, bool MF = false>
 __global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(IndexView ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work,
                                                               KwPartials part, const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out,
                                                               const uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
-    __shared__ KwSmem<TMAX, CAP, false, S2, false, true> sm;
+    __shared__ KwSmem<TMAX, CAP, MF, S2, false, true> sm;
     __shared__ KwQueryDev sq;
+    constexpr int NP = decltype(sm)::NP;          // posting positions per record: TMAX, or TMAX x KW_MAX_FIELDS for several query_by fields
     const uint32_t t = threadIdx.x;
     const KwWorkItem wi = work[blockIdx.x];
     {
-        const uint32_t* src = (const uint32_t*)(queries + wi.query);
+        const uint32_t* src = (const uint32_t*)(queries + (wi.query & 0x0FFFFFFFu));      // (multi-field items carry the driver field in the top bits)
         uint32_t* dst = (uint32_t*)&sq;
         for (uint32_t i = t; i < sizeof(KwQueryDev) / 4; i += KW_THREADS) dst[i] = src[i];
     }
@@ -1312,23 +1313,23 @@ __global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(Ind
     const KwQueryDev& q = sq;
     uint32_t* my_ids_out = ids_out ? ids_out + q.ids_out_off + wi.ids_out_off : nullptr;
     const uint32_t count = part.cnt[blockIdx.x];
-    const uint32_t* __restrict__ mine = hits_all + hit_off[blockIdx.x] * (uint64_t)(TMAX + 1);
+    const uint32_t* __restrict__ mine = hits_all + hit_off[blockIdx.x] * (uint64_t)(NP + 1);
     for (uint32_t i0 = 0; i0 < count; i0 += KW_THREADS) {
         const uint32_t n = count - i0 < (uint32_t)KW_THREADS ? count - i0 : (uint32_t)KW_THREADS;
         if (t < n) {
-            if constexpr (TMAX == 3) {
+            if constexpr (TMAX == 3 && !MF) {
                 const KwHitRec r = ((const KwHitRec*)mine)[i0 + t];
                 sm.qf_id[t] = r.id; sm.qf_pos[0][t] = r.p0; sm.qf_pos[1][t] = r.p1; sm.qf_pos[2][t] = r.p2;
             } else {
-                const uint32_t* __restrict__ r = mine + (size_t)(i0 + t) * (TMAX + 1);
+                const uint32_t* __restrict__ r = mine + (size_t)(i0 + t) * (NP + 1);
                 sm.qf_id[t] = r[0];
 #pragma unroll
-                for (int k = 0; k < TMAX; k++) sm.qf_pos[k][t] = r[1 + k];
+                for (int k = 0; k < NP; k++) sm.qf_pos[k][t] = r[1 + k];
             }
         }
         if (t == 0) sm.qf_cnt = n;
         __syncthreads();
-        kw_score_stage<TMAX, CAP, false, S2, true>(sm, ix, q, n, aux_ids, my_ids_out, 0u);
+        kw_score_stage<TMAX, CAP, MF, S2, true>(sm, ix, q, n, aux_ids, my_ids_out, 0u);
     }
     kw_write_partial(sm, q, part);
 }
@@ -1339,11 +1340,13 @@ __global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(Ind
 // work items (every document of the union is produced exactly once); the other tokens are probed in every field (a token is
 // satisfied by any field, include/or_iterator.h + src/or_iterator.cpp:95-171); complete hits carry their position in every
 // (token, field) list into the shared score stage. Per-candidate probes, no block merge: the slow, general path.
-template <int TMAX, int CAP>
+// DEFER = true: the find half of the two-kernel form (records of 1 + TMAX x KW_MAX_FIELDS words -> kw_score_kernel<.., MF = true>)
+template <int TMAX, int CAP, bool DEFER = false>
 __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
                                                                    const KwWorkItem* __restrict__ work, KwPartials part,
-                                                                   const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out) {
-    __shared__ KwSmem<TMAX, CAP, true> sm;
+                                                                   const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out,
+                                                                   uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
+    __shared__ KwSmem<TMAX, CAP, true, true, DEFER> sm;
     __shared__ KwQueryDev sq;
     __shared__ KwQueryMF smf;
     const uint32_t t = threadIdx.x;
@@ -1373,6 +1376,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
     const uint32_t* __restrict__ idwA = ix.ids_payload + dA.ids_base;
     uint32_t* my_ids_out = ids_out ? ids_out + q.ids_out_off + wi.ids_out_off : nullptr;
     constexpr int NP = TMAX * KW_MAX_FIELDS;
+    uint32_t* __restrict__ hits = DEFER ? hits_all + hit_off[blockIdx.x] * (uint64_t)(NP + 1) : nullptr;
     uint32_t qfn = 0, par = 0;
     for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
         const BlockIds mA = biA[b];
@@ -1410,6 +1414,16 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
         uint32_t total;
         const uint32_t my = block_compact1(ok, sm.wave_cnt2[par], total);
         par ^= 1;
+        if constexpr (DEFER) {
+            if (ok) {
+                uint32_t* __restrict__ d = hits + (size_t)(qfn + my) * (NP + 1);
+                d[0] = id;
+#pragma unroll
+                for (int k = 0; k < NP; k++) d[1 + k] = pos[k];
+            }
+            qfn += total;
+            continue;
+        } else {
         if (ok) {
             const uint32_t slot = qfn + my;
             sm.qf_id[slot] = id;
@@ -1424,7 +1438,12 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
             while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, true, true, false>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, 0u);
             qfn = sm.qf_cnt;
         }
+        }
     }
+    if constexpr (DEFER) {
+        if (t == 0) part.cnt[blockIdx.x] = qfn;                     // hits handed to kw_score_kernel
+        return;
+    } else {
     __syncthreads();
     if (t == 0) sm.qf_cnt = qfn;
     __syncthreads();
@@ -1440,6 +1459,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
         part.n_emit[blockIdx.x] = sm.n_emit;
         part.off_words[blockIdx.x] = sm.off_words;
         part.n_match[blockIdx.x] = sm.n_match;            // (filters are not combined with multi-field queries: the planner rejects them)
+    }
     }
 }
 

@@ -74,8 +74,16 @@ void launch_find_score(int cap, hipStream_t s, uint32_t n_work, const IndexView&
 template <int TMAX>
 void launch_search_mf_cap(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w,
                           const KwPartials& part, const uint32_t* aux, uint32_t* ids_out) {
-    if (cap == 512) hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 512>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out);
-    else hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 1024>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out);
+    if (cap == 512) hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 512>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, (uint32_t*)nullptr, (const uint64_t*)nullptr);
+    else hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 1024>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, (uint32_t*)nullptr, (const uint64_t*)nullptr);
+}
+// two-kernel form of the multi-field search (k + 256 <= 1024 there)
+template <int TMAX>
+void launch_find_score_mf(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w, const KwPartials& part,
+                          const uint32_t* aux, uint32_t* ids_out, uint32_t* hits, const uint64_t* hit_off) {
+    hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 512, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    if (cap == 512) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    else hipLaunchKernelGGL((kw_score_kernel<TMAX, 1024, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
 }
 
 template <int TMAX>
@@ -133,7 +141,7 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
                       &ctx->d_queries, &ctx->d_work, &ctx->d_aux, &ctx->d_ids_out, &ctx->d_mf, &ctx->d_part_s0, &ctx->d_part_s1, &ctx->d_part_s2,
                       &ctx->d_part_key, &ctx->d_part_cnt, &ctx->d_part_nm, &ctx->d_part_ne, &ctx->d_part_ow, &ctx->d_part_f, &ctx->d_out_keys,
                       &ctx->d_out_scores, &ctx->d_out_tm, &ctx->d_out_vd, &ctx->d_out_msi, &ctx->d_out_nh, &ctx->d_out_nm, &ctx->d_out_ow, &ctx->d_prof,
-                      &ctx->d_hits, &ctx->d_hit_off, &ctx->d_hit_off_big, &ctx->d_cand_keys, &ctx->d_cand_scores, &ctx->d_cand_tm, &ctx->d_cand_vd, &ctx->d_cand_msi, &ctx->d_cand_nh,
+                      &ctx->d_hits, &ctx->d_hit_off_tab[0], &ctx->d_hit_off_tab[1], &ctx->d_hit_off_tab[2], &ctx->d_hit_off_tab[3], &ctx->d_cand_keys, &ctx->d_cand_scores, &ctx->d_cand_tm, &ctx->d_cand_vd, &ctx->d_cand_msi, &ctx->d_cand_nh,
                       &ctx->d_cand_nm, &ctx->d_cand_st, &ctx->d_cand_gb, &ctx->d_cand_qi, &ctx->d_cand_found, &ctx->d_cand_segs, &ctx->d_cand_bits, &ctx->d_cand_ids};
     for (auto* b : bufs) b->release();
     for (auto& c : ctx->columns) c.data.release();
@@ -828,11 +836,12 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
         // single-field tables (<= 3 tokens / up to 10 tokens): find + score kernels when the hit buffer fits, else the fused kernel.
         // A work item can yield at most one hit per driver id, so its segment of the hit buffer holds (blk_end - blk_begin) * 256
         // records of 1 + TMAX words; the items run in groups whose segments fit the budget.
-        auto run_table = [&](const std::vector<KwWorkItem>& tab, size_t first, auto tmax_tag) -> int {
+        auto run_table = [&](const std::vector<KwWorkItem>& tab, size_t first, auto tmax_tag, auto mf_tag) -> int {
             constexpr int TM = decltype(tmax_tag)::value;
+            constexpr bool MFT = decltype(mf_tag)::value;
             if (tab.empty()) return TSGPU_OK;
             const size_t nws = tab.size();
-            const size_t rec_bytes = (size_t)(TM + 1) * 4;
+            const size_t rec_bytes = (size_t)((MFT ? TM * KW_MAX_FIELDS : TM) + 1) * 4;
             bool two = ctx->kw_two_kernels;
             std::vector<uint64_t> hoff;
             std::vector<size_t> group_start(1, 0);
@@ -858,23 +867,26 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
             }
             if (two) {
                 ctx->kw_last_hit_groups += (uint32_t)group_start.size() - 1;
-                DevBuf& offbuf = TM == 3 ? ctx->d_hit_off : ctx->d_hit_off_big;
+                DevBuf& offbuf = ctx->d_hit_off_tab[(MFT ? 2 : 0) + (TM == 3 ? 0 : 1)];
                 int rc2;
                 if ((rc2 = upload(offbuf, hoff.data(), nws * 8, s))) return rc2;
                 for (size_t gi = 0; gi + 1 < group_start.size(); gi++) {
                     const size_t a = group_start[gi], b = group_start[gi + 1];
-                    if (b > a) launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, ctx->d_hits.as<uint32_t>(), offbuf.as<uint64_t>() + a);
+                    if (b <= a) continue;
+                    if constexpr (MFT) launch_find_score_mf<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, ctx->d_hits.as<uint32_t>(), offbuf.as<uint64_t>() + a);
+                    else launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, ctx->d_hits.as<uint32_t>(), offbuf.as<uint64_t>() + a);
                 }
-            } else launch_search_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out, P.any_s2);
+            } else if constexpr (MFT) launch_search_mf_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out);
+            else launch_search_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out, P.any_s2);
             return TSGPU_OK;
         };
-        if ((rc = run_table(P.work_small, 0, std::integral_constant<int, 3>()))) return rc;
+        if ((rc = run_table(P.work_small, 0, std::integral_constant<int, 3>(), std::false_type()))) return rc;
         size_t sh = P.work_small.size();
-        if ((rc = run_table(P.work_big, sh, std::integral_constant<int, KW_MAX_TOKENS>()))) return rc;
+        if ((rc = run_table(P.work_big, sh, std::integral_constant<int, KW_MAX_TOKENS>(), std::false_type()))) return rc;
         sh += P.work_big.size();
-        if (!P.work_mf_small.empty()) launch_search_mf_cap<3>(cap, s, (uint32_t)P.work_mf_small.size(), v, dq, dw + sh, shifted(sh), daux, ids_out);
+        if ((rc = run_table(P.work_mf_small, sh, std::integral_constant<int, 3>(), std::true_type()))) return rc;
         sh += P.work_mf_small.size();
-        if (!P.work_mf_big.empty()) launch_search_mf_cap<KW_MAX_TOKENS>(cap, s, (uint32_t)P.work_mf_big.size(), v, dq, dw + sh, shifted(sh), daux, ids_out);
+        if ((rc = run_table(P.work_mf_big, sh, std::integral_constant<int, KW_MAX_TOKENS>(), std::true_type()))) return rc;
         sh += P.work_mf_big.size();
         if (!P.work_wild.empty()) {
             const uint32_t nw = (uint32_t)P.work_wild.size();

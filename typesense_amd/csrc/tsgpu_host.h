@@ -120,7 +120,7 @@ struct tsgpu_ctx {
     bool kw_sort_work = true;                        // lay the work table out heaviest query first
     bool kw_two_kernels = true;                      // queries of <= 3 tokens: find kernel + score kernel instead of the fused kernel
     uint32_t kw_hit_buffer_mb = 20480;               // budget of the hit-record buffer between the two (work items run in groups that fit)
-    tsgpu::DevBuf d_hits, d_hit_off, d_hit_off_big;
+    tsgpu::DevBuf d_hits, d_hit_off_tab[4];          // hit records; per work table (<=3 / <=10 tokens, one / several fields) the items' record offsets
     uint32_t kw_last_hit_groups = 0;
     uint64_t kw_hit_buffer_records = 0, kw_last_hit_records = 0;
     uint32_t kw_chunk_blocks = 0;                    // driver blocks per work item (0 = sized per batch, see plan_batch)
