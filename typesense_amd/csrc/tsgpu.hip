@@ -382,6 +382,8 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
         if (value < 1 || value > 4096) return fail(TSGPU_ERR_INVALID, "kw_max_partials out of range (1..4096)");
         ctx->kw_max_partials = (uint32_t)value; return ok();
     }
+    if (!strcmp(name, "kw_cost_r_x10")) { ctx->kw_cost_r_x10 = (uint32_t)std::max<int64_t>(value, 0); return ok(); }
+    if (!strcmp(name, "kw_cost_probe_x100")) { ctx->kw_cost_probe_x100 = (uint32_t)std::max<int64_t>(value, 0); return ok(); }
     if (!strcmp(name, "kw_cost_fixed")) { ctx->kw_cost_fixed = (uint32_t)std::max<int64_t>(value, 0); return ok(); }
     if (!strcmp(name, "kw_sort_work")) { ctx->kw_sort_work = value != 0; return ok(); }
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
@@ -680,7 +682,9 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         {   // launch-order key: estimated cost of the query's LARGEST work item = driver blocks x (fixed cost + second-list ids per
             // driver id); the work table is laid out heaviest first so that the long items do not start last (tail of the launch)
             const double r = nl >= 2 ? (double)len_of[ord[1]] / (double)std::max<uint32_t>(len_of[ord[0]], 1) : 0.0;
-            item_cost[i] = (double)std::min(chunk_q, dA.n_blocks) * ((double)ctx->kw_cost_fixed + std::min(r, 64.0));
+            // + third-list probes: every stage-1 survivor (256 |B| / N per driver block) costs a two-level global binary search
+            const double surv = nl >= 3 ? 256.0 * (double)len_of[ord[1]] / (double)std::max<uint32_t>(ctx->num_docs, 1) : 0.0;
+            item_cost[i] = (double)std::min(chunk_q, dA.n_blocks) * ((double)ctx->kw_cost_fixed + 0.1 * ctx->kw_cost_r_x10 * std::min(r, 64.0) + 0.01 * ctx->kw_cost_probe_x100 * surv);
         }
         for (uint32_t b = 0; b < dA.n_blocks; b += chunk_q) {
             KwWorkItem w;

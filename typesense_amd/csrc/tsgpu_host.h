@@ -116,6 +116,7 @@ struct tsgpu_ctx {
     tsgpu::PinBuf h_stage, h_out;
     bool keep_ids = false;
     uint32_t kw_max_partials = 16;                   // work items (= partial top-K lists) per query at most; longer driver lists get longer items
+    uint32_t kw_cost_r_x10 = 10, kw_cost_probe_x100 = 20;  // ... + 0.1 x kw_cost_r_x10 x |B|/|A| + 0.01 x kw_cost_probe_x100 x (stage-1 survivors per block)
     uint32_t kw_cost_fixed = 16;                     // launch-order cost model: item cost = driver blocks x (kw_cost_fixed + |B|/|A|)
     bool kw_sort_work = true;                        // lay the work table out heaviest query first
     bool kw_two_kernels = true;                      // queries of <= 3 tokens: find kernel + score kernel instead of the fused kernel
