@@ -686,13 +686,14 @@ struct TopkLds {
     __device__ static inline int i2(int i) { return S2 ? i : 0; }
 };
 
-// bitonic sort, descending, of the first CAP entries (entries >= cnt must be padding)
+// bitonic sort, descending, of the first n entries (n a power of two <= CAP, uniform; entries >= cnt must be padding): a work item
+// with a dozen hits sorts 16 slots (10 stages), not the whole buffer (45 stages at CAP = 512)
 template <int CAP, bool S2>
-__device__ inline void topk_sort(TopkLds<CAP, S2>& tk) {
-    for (int size = 2; size <= CAP; size <<= 1) {
+__device__ inline void topk_sort(TopkLds<CAP, S2>& tk, int n = CAP) {
+    for (int size = 2; size <= n; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (int p = threadIdx.x; p < CAP / 2; p += KW_THREADS) {
+            for (int p = threadIdx.x; p < n / 2; p += KW_THREADS) {
                 const int i = 2 * p - (p & (stride - 1));     // lower index of the pair
                 const int j = i + stride;
                 const bool desc = ((i & size) == 0);
@@ -716,8 +717,10 @@ template <int CAP, bool S2>
 __device__ inline void topk_compact(TopkLds<CAP, S2>& tk, uint32_t* s_cnt, uint32_t k, int64_t* s_thr /*[4]*/, uint32_t* s_have_thr) {
     __syncthreads();
     const uint32_t cnt = *s_cnt;
-    for (int i = threadIdx.x; i < CAP; i += KW_THREADS) if ((uint32_t)i >= cnt) tk.key[i] = -1;
-    topk_sort<CAP, S2>(tk);
+    int n = 2;
+    while ((uint32_t)n < cnt) n <<= 1;                      // cnt <= CAP (a power of two)
+    for (int i = threadIdx.x; i < n; i += KW_THREADS) if ((uint32_t)i >= cnt) tk.key[i] = -1;
+    topk_sort<CAP, S2>(tk, n);
     if (threadIdx.x == 0) {
         const uint32_t n = cnt < k ? cnt : k;
         *s_cnt = n;
