@@ -1093,9 +1093,13 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
         if (P.W <= (uint32_t)(PIPE_WORDS * KW_THREADS)) {
             P.mode = 0;
             const uint32_t* __restrict__ src = idwB + P.w_begin;
+            // (a short run — the common case — does not issue the loads it has no words for: two tiers instead of a guard per load)
+            if (P.W <= 2u * KW_THREADS) {
 #pragma unroll
-            for (int k = 0; k < PIPE_WORDS; k++) {            // (uniform guard: a short run does not issue the loads it has no words for)
-                if ((uint32_t)(k * KW_THREADS) < P.W) { const uint32_t i = t + k * KW_THREADS; cw[k] = src[i < P.W ? i : 0]; }
+                for (int k = 0; k < 2 && k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; cw[k] = src[i < P.W ? i : 0]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; cw[k] = src[i < P.W ? i : 0]; }
             }
         } else P.mode = 1;
         return P;
@@ -1120,9 +1124,12 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
         uint32_t kb = 0, b_first = 0, b_nb = 0, b_rel = 0;
         bool done = !ok || C.mode >= 2, found = false;
         if (C.mode == 0) {
+            if (C.W <= 2u * KW_THREADS) {
 #pragma unroll
-            for (int k = 0; k < PIPE_WORDS; k++) {
-                if ((uint32_t)(k * KW_THREADS) < C.W) { const uint32_t i = t + k * KW_THREADS; if (i < C.W) sm.btile[i] = cw[k]; }
+                for (int k = 0; k < 2 && k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; if (i < C.W) sm.btile[i] = cw[k]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; if (i < C.W) sm.btile[i] = cw[k]; }
             }
         }
         KW_PROF(1)
