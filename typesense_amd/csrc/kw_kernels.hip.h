@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
             P.mode = 0;
             const uint32_t* __restrict__ src = idwB + P.w_begin;
             // (a short run — the common case — does not issue the loads it has no words for: two tiers instead of a guard per load)
-            if (P.W <= 2u * KW_THREADS) {
+            if (DEFER && P.W <= 2u * KW_THREADS) {            // (find kernel only: the fused kernel has no register to spare for a second code path)
 #pragma unroll
                 for (int k = 0; k < 2 && k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; cw[k] = src[i < P.W ? i : 0]; }
             } else {
@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
         uint32_t kb = 0, b_first = 0, b_nb = 0, b_rel = 0;
         bool done = !ok || C.mode >= 2, found = false;
         if (C.mode == 0) {
-            if (C.W <= 2u * KW_THREADS) {
+            if (DEFER && C.W <= 2u * KW_THREADS) {
 #pragma unroll
                 for (int k = 0; k < 2 && k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; if (i < C.W) sm.btile[i] = cw[k]; }
             } else {
