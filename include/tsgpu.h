@@ -34,9 +34,15 @@
  * query) and tsgpu_last_error() returns the message for the calling thread. Never throws, never aborts.
  *
  * Threading: any number of request threads may call the search entry points concurrently on one
- * context (the reference calls the seam under a shared_lock on Index::mutex, src/index.cpp:3488);
- * index mutation (upsert/delete/commit) must be externally serialised against searches, exactly like
- * the unique_lock side of Index::mutex.
+ * context (the reference calls the seam once per query from its request threads under a shared_lock on
+ * Index::mutex, src/index.cpp:3488, src/http_server.cpp:827-832). Small concurrent calls (host outputs,
+ * <= "batch_max_queries" queries) are COALESCED inside the library into one launch per round (micro-batcher,
+ * csrc/tsgpu_batcher.h) and every caller gets exactly its own results; larger calls run on one of two
+ * execution lanes (own stream + scratch each), so one batch is planned and uploaded while another runs.
+ * tsgpu_commit() publishes a new immutable snapshot (RCU): a search keeps the snapshot it started on, a commit
+ * never waits for searches and searches never wait for a commit. Everything else that mutates (term / vector
+ * upserts, deletes, column_set) follows the unique_lock side of Index::mutex: externally serialised against
+ * searches.
  */
 #ifndef TSGPU_H
 #define TSGPU_H
@@ -48,7 +54,7 @@
 extern "C" {
 #endif
 
-#define TSGPU_ABI_VERSION 1
+#define TSGPU_ABI_VERSION 2
 
 /* limits of the accelerated path (anything beyond -> TSGPU_ERR_UNSUPPORTED for that query) */
 #define TSGPU_MAX_QUERY_TOKENS 10   /* = WINDOW_SIZE, include/match_score.h:11 */
@@ -103,10 +109,14 @@ int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
  * "vec_rows_per_slab" = base rows per k-NN workgroup slab (default: automatic), "vec_sample_tiles" = 128-row tiles of
  * the k-NN threshold sample (default 512), "vec_cand_cap" = candidate slots per query of the filtered pass (0 = auto),
  * "vec_prefilter" = 1 (default): bf16 bracket scan + exact fp32 re-score of the survivors, 0: fp32 MFMA scan of every row
- * (identical result sets either way), "vec_count_rescored" = 1: keep the vec_rescored_rows counter (costs one sync) */
+ * (identical result sets either way), "vec_count_rescored" = 1: keep the vec_rescored_rows counter (costs one sync);
+ * micro-batcher: "batch_max_queries" = calls with at most this many queries are coalesced with concurrent callers (default 64,
+ * 0 = never), "batch_window_us" = how long a round's leader waits for the other threads that are inside the entry point to
+ * park (default 80), "batch_round_queries" = queries per coalesced round at most (default 1024) */
 int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value);
 /* introspection counters (tests / bench): "vec_overflow_rounds", "vec_prefilter_groups", "vec_prefilter_fallbacks",
- * "vec_rescored_rows", "kw_last_hit_groups" (find+score groups of the last keyword batch, 0 = fused), "kw_last_hit_records" */
+ * "vec_rescored_rows", "kw_last_hit_groups" (find+score groups of the last keyword batch, 0 = fused), "kw_last_hit_records",
+ * "batch_rounds" / "batch_coalesced_calls" (micro-batcher: rounds executed / calls they served) */
 int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out);
 /* bytes of HBM held by the context's index mirrors */
 uint64_t tsgpu_device_bytes(tsgpu_ctx* ctx);
@@ -220,8 +230,18 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
                                           tsgpu_hits* out, uint32_t* query_index, uint64_t* found);
 uint64_t tsgpu_candidates_result_ids(tsgpu_ctx* ctx, uint32_t group, uint32_t* out_host, uint64_t cap);
 
-/* all matched ids of the LAST keyword batch for query q, ascending (id_buff / all_result_ids, src/index.cpp:5565).
- * Only available when tsgpu_keep_result_ids(ctx, 1) was set before the batch. Returns count; copies min(count, cap). */
+/* Keyword search that also returns every matched id (id_buff -> all_result_ids, src/index.cpp:5549, 5565: facets, group-by and
+ * `found` read them): *ids_out receives a list object that belongs to THIS call — safe with any number of concurrent callers —
+ * holding, per query, the ascending ids that passed exclusion / filter. Free it with tsgpu_id_lists_free. */
+typedef struct tsgpu_id_lists tsgpu_id_lists;
+int tsgpu_keyword_search_batch_ids(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, tsgpu_id_lists** ids_out);
+uint64_t tsgpu_id_lists_count(const tsgpu_id_lists* lists, uint32_t q);
+const uint32_t* tsgpu_id_lists_ids(const tsgpu_id_lists* lists, uint32_t q);
+void tsgpu_id_lists_free(tsgpu_id_lists* lists);
+
+/* SINGLE-CALLER form of the same (tests, tools): all matched ids of the LAST keyword batch for query q, ascending. Only available
+ * when tsgpu_keep_result_ids(ctx, 1) was set before the batch; such batches are never coalesced and always run on lane 0. The
+ * state is context-global: with concurrent callers use tsgpu_keyword_search_batch_ids. Returns count; copies min(count, cap). */
 int tsgpu_keep_result_ids(tsgpu_ctx* ctx, int keep);
 uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64_t cap);
 

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <vector>
 #include <functional>
+#include <mutex>
 
 #define TSGPU_HIP_EMU 1
 #define __global__
@@ -141,8 +142,12 @@ inline void run_block(BlockState& B) {
     g() = nullptr;
 }
 
+// the emulator keeps ONE block's state in globals (g(), function-local statics standing in for __shared__): launches from
+// concurrent host threads (two lanes, micro-batcher tests) run one after the other
+inline std::recursive_mutex& launch_mutex() { static std::recursive_mutex m; return m; }
 template <class F>
 inline void launch(dim3 grid, dim3 block, F body) {
+    std::lock_guard<std::recursive_mutex> lk(launch_mutex());
     for (unsigned by = 0; by < grid.y; by++)
     for (unsigned bx = 0; bx < grid.x; bx++) {
         BlockState B;
@@ -354,4 +359,4 @@ inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+    hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })

@@ -1,0 +1,315 @@
+// TEST INFRASTRUCTURE — compiles the header-only host shims of the product (typesense_amd/csrc/host/*.h) the way a server
+// maintainer would: against types of the reference's SHAPE (mock posting_list_t / compact_posting_list_t / hnswlib index; the
+// oracle's KV / Topster stand in for include/topster.h), links the C-ABI library and checks every result against expectations
+// that tests/test_host_shims.py computed with the oracle. Exit code 0 + "OK <n> checks" on success.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/tsgpu.h"
+#include "../../typesense_amd/csrc/host/tsgpu_keyword_shim.h"
+#include "../../typesense_amd/csrc/host/tsgpu_hnsw_adaptor.h"
+#include "../../typesense_amd/csrc/host/tsgpu_posting_shim.h"
+#include "../../oracle/topk_heap.h"
+
+static int n_checks = 0;
+#define CHECK(c, ...) do { n_checks++; if (!(c)) { fprintf(stderr, "FAILED %s:%d: %s — ", __FILE__, __LINE__, #c); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); exit(1); } } while (0)
+
+// ---- input ----
+struct Reader {
+    std::vector<uint8_t> buf; size_t at = 0;
+    explicit Reader(const std::string& path) {
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) { fprintf(stderr, "cannot open %s\n", path.c_str()); exit(2); }
+        fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+        buf.resize((size_t)n);
+        if (n && fread(buf.data(), 1, (size_t)n, f) != (size_t)n) exit(2);
+        fclose(f);
+    }
+    template <class T> T get() { T v; memcpy(&v, buf.data() + at, sizeof(T)); at += sizeof(T); return v; }
+    template <class T> std::vector<T> vec(size_t n) { std::vector<T> v(n); if (n) memcpy(v.data(), buf.data() + at, n * sizeof(T)); at += n * sizeof(T); return v; }
+};
+
+// ---- mocks of the reference's posting structures (include/sorted_array.h, array.h, posting_list.h:56-77, posting.h:14-44) ----
+struct mock_array {
+    std::vector<uint32_t> v;
+    uint32_t* uncompress(uint32_t = 0) const { uint32_t* p = new uint32_t[v.size() + 1]; std::copy(v.begin(), v.end(), p); return p; }
+    uint32_t getLength() const { return (uint32_t)v.size(); }
+};
+struct mock_posting_list_t {
+    struct block_t { mock_array ids, offset_index, offsets; block_t* next = nullptr; };
+    block_t root_block;
+    ~mock_posting_list_t() { for (block_t* b = root_block.next; b;) { block_t* n = b->next; delete b; b = n; } }
+};
+struct mock_compact_posting_list_t { uint8_t length = 0, ids_length = 0; uint16_t capacity = 0; uint32_t id_offsets[1]; };
+
+static void build_blocks(mock_posting_list_t& pl, const std::vector<uint32_t>& ids, const std::vector<uint32_t>& oi, const std::vector<uint32_t>& off, uint32_t per_block) {
+    mock_posting_list_t::block_t* cur = &pl.root_block;
+    for (size_t s = 0; s < ids.size(); s += per_block) {
+        if (s) { cur->next = new mock_posting_list_t::block_t; cur = cur->next; }
+        const size_t e = std::min(ids.size(), s + per_block);
+        const uint32_t o0 = oi[s], o1 = e == ids.size() ? (uint32_t)off.size() : oi[e];
+        cur->ids.v.assign(ids.begin() + s, ids.begin() + e);
+        for (size_t i = s; i < e; i++) cur->offset_index.v.push_back(oi[i] - o0);         // block-relative, like the reference
+        cur->offsets.v.assign(off.begin() + o0, off.begin() + o1);
+    }
+}
+
+// ---- mock of hnswlib::HierarchicalNSW<float>'s public members that mirror_hnsw_graph reads ----
+struct mock_hnswlib {
+    size_t cur_element_count = 0, M_ = 0, size_data_per_element_ = 0, offsetLevel0_ = 0, size_links_per_element_ = 0;
+    char* data_level0_memory_ = nullptr;
+    char** linkLists_ = nullptr;
+    std::vector<int> element_levels_;
+    int maxlevel_ = -1;
+    unsigned enterpoint_node_ = 0;
+};
+
+struct EvenOnly : tsgpu::BaseFilterFunctor {          // a VectorFilterFunctor-style predicate (include/index.h:325-354)
+    std::vector<uint32_t> excluded;
+    bool operator()(tsgpu::labeltype id) override {
+        if (std::binary_search(excluded.begin(), excluded.end(), (uint32_t)id)) return false;
+        return id % 2 == 0;
+    }
+};
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    const std::string dir = argv[1];
+    tsgpu_ctx* ctx = nullptr;
+    CHECK(tsgpu_create(0, &ctx) == TSGPU_OK, "%s", tsgpu_last_error());
+
+    // ---------------- a1 / a4: posting structures -> tsgpu_term_upsert ----------------
+    {
+        Reader r(dir + "/postings.bin");
+        const uint32_t n_terms = r.get<uint32_t>();
+        CHECK(tsgpu_field_create(ctx, 0, 0) == TSGPU_OK, "field_create");
+        std::vector<std::vector<uint32_t>> keep_ids(n_terms), keep_oi(n_terms), keep_off(n_terms);
+        std::vector<uint32_t> terms(n_terms);
+        for (uint32_t t = 0; t < n_terms; t++) {
+            terms[t] = r.get<uint32_t>();
+            const uint32_t n_ids = r.get<uint32_t>(), n_off = r.get<uint32_t>();
+            keep_ids[t] = r.vec<uint32_t>(n_ids); keep_oi[t] = r.vec<uint32_t>(n_ids); keep_off[t] = r.vec<uint32_t>(n_off);
+            if (n_off <= 40 && n_ids <= 12) {
+                // short list: the compact form, behind the tagged pointer the ART leaf would hold
+                std::vector<uint32_t> words;
+                for (uint32_t i = 0; i < n_ids; i++) {
+                    const uint32_t e = i + 1 < n_ids ? keep_oi[t][i + 1] : n_off;
+                    words.push_back(e - keep_oi[t][i]);
+                    for (uint32_t j = keep_oi[t][i]; j < e; j++) words.push_back(keep_off[t][j]);
+                    words.push_back(keep_ids[t][i]);
+                }
+                auto* c = (mock_compact_posting_list_t*)calloc(1, sizeof(mock_compact_posting_list_t) + words.size() * 4);
+                c->length = (uint8_t)words.size(); c->ids_length = (uint8_t)n_ids; c->capacity = (uint16_t)words.size();
+                memcpy(c->id_offsets, words.data(), words.size() * 4);
+                const void* tagged = (const void*)((uintptr_t)c | 1);
+                CHECK((tsgpu::upsert_posting<mock_posting_list_t, mock_compact_posting_list_t>(ctx, 0, terms[t], tagged)) == TSGPU_OK, "compact upsert: %s", tsgpu_last_error());
+                free(c);
+            } else {
+                mock_posting_list_t pl;
+                build_blocks(pl, keep_ids[t], keep_oi[t], keep_off[t], 3 + t % 5);       // uneven block sizes, like a list after splits
+                CHECK((tsgpu::upsert_posting<mock_posting_list_t, mock_compact_posting_list_t>(ctx, 0, terms[t], &pl)) == TSGPU_OK, "block-chain upsert: %s", tsgpu_last_error());
+            }
+        }
+        Reader pr(dir + "/points.bin");
+        const uint32_t n_docs = pr.get<uint32_t>();
+        const std::vector<int64_t> pts = pr.vec<int64_t>(n_docs);
+        CHECK(tsgpu_column_set(ctx, 0, pts.data(), nullptr, n_docs, TSGPU_MEM_HOST) == TSGPU_OK, "column_set");
+        CHECK(tsgpu_set_num_docs(ctx, n_docs) == TSGPU_OK, "num_docs");
+        CHECK(tsgpu_commit(ctx) == TSGPU_OK, "commit: %s", tsgpu_last_error());
+        for (uint32_t t = 0; t < n_terms; t++) {      // device format round trip = the decoded content that went in
+            CHECK(tsgpu_term_num_ids(ctx, 0, terms[t]) == keep_ids[t].size(), "term %u id count", terms[t]);
+            std::vector<uint32_t> a(keep_ids[t].size()), b(keep_ids[t].size()), c(keep_off[t].size() + 1);
+            uint32_t no = 0;
+            CHECK(tsgpu_term_download(ctx, 0, terms[t], a.data(), b.data(), c.data(), &no) == TSGPU_OK, "download");
+            c.resize(no);
+            CHECK(a == keep_ids[t] && b == keep_oi[t] && c == keep_off[t], "term %u round trip", terms[t]);
+        }
+    }
+
+    // ---------------- B1: search_across_fields_gpu<KV, Topster> ----------------
+    {
+        Reader r(dir + "/queries.bin");
+        const uint32_t n_q = r.get<uint32_t>();
+        for (uint32_t qi = 0; qi < n_q; qi++) {
+            tsgpu::KeywordShimArgs a;
+            a.ctx = ctx;
+            a.query_index = (uint16_t)(qi % 7);
+            a.query.n_tokens = r.get<uint32_t>();
+            const std::vector<uint32_t> toks = r.vec<uint32_t>(a.query.n_tokens);
+            for (uint32_t i = 0; i < a.query.n_tokens; i++) a.query.term_ids[i] = toks[i];
+            const std::vector<uint32_t> filter = r.vec<uint32_t>(r.get<uint32_t>()), excl = r.vec<uint32_t>(r.get<uint32_t>());
+            a.query.n_fields = 1; a.query.field_ids[0] = 0; a.query.field_weights[0] = 15;
+            a.query.match_type = TSGPU_MAX_SCORE; a.query.prioritize_exact_match = 1; a.query.prioritize_num_matching_fields = 1;
+            a.query.n_sort = 2;
+            a.query.sort[0].kind = TSGPU_SORT_TEXT_MATCH; a.query.sort[0].order = 1;
+            a.query.sort[1].kind = TSGPU_SORT_INT64_COLUMN; a.query.sort[1].order = 1; a.query.sort[1].column = 0;
+            a.query.topster_size = r.get<uint32_t>();
+            if (!filter.empty()) { a.query.filter_ids = filter.data(); a.query.n_filter = (uint32_t)filter.size(); }
+            if (!excl.empty()) { a.query.excluded_ids = excl.data(); a.query.n_excluded = (uint32_t)excl.size(); }
+            a.want_result_ids = true;
+            const uint32_t want_n = r.get<uint32_t>();
+            const std::vector<uint64_t> want_keys = r.vec<uint64_t>(want_n);
+            const std::vector<int64_t> want_scores = r.vec<int64_t>((size_t)want_n * 3);
+            const uint64_t want_matched = r.get<uint64_t>();
+            const std::vector<uint32_t> want_ids = r.vec<uint32_t>(r.get<uint32_t>());
+
+            oracle::Topster topster(a.query.topster_size);
+            std::vector<uint32_t> id_buff = {0xDEADBEEFu};                 // the shim APPENDS (src/index.cpp:5549)
+            size_t num_keyword_matches = 0;
+            bool cutoff = false;
+            const int rc = tsgpu::search_across_fields_gpu<oracle::KV, oracle::Topster>(a, &topster, id_buff, num_keyword_matches, cutoff);
+            CHECK(rc == TSGPU_OK, "query %u: rc %d %s", qi, rc, tsgpu_last_error());
+            topster.sort();
+            CHECK(topster.size == want_n, "query %u: %u hits, oracle %u", qi, topster.size, want_n);
+            for (uint32_t i = 0; i < want_n; i++) {
+                const oracle::KV* kv = topster.getKV(i);
+                CHECK(kv->key == want_keys[i] && kv->scores[0] == want_scores[i * 3] && kv->scores[1] == want_scores[i * 3 + 1] && kv->scores[2] == want_scores[i * 3 + 2],
+                      "query %u hit %u", qi, i);
+                CHECK(kv->query_index == a.query_index && kv->text_match_score == kv->scores[0], "query %u hit %u: KV fields", qi, i);
+            }
+            CHECK(num_keyword_matches == want_matched, "query %u: num_keyword_matches %zu vs %llu", qi, num_keyword_matches, (unsigned long long)want_matched);
+            CHECK(id_buff.size() == want_ids.size() + 1 && id_buff[0] == 0xDEADBEEFu && std::equal(want_ids.begin(), want_ids.end(), id_buff.begin() + 1), "query %u: id_buff", qi);
+            CHECK(!cutoff, "query %u: cutoff", qi);
+        }
+        // an unsupported query leaves everything untouched and reports 501
+        tsgpu::KeywordShimArgs a;
+        a.ctx = ctx; a.query.n_tokens = 1; a.query.term_ids[0] = 1; a.query.n_fields = 1; a.query.n_sort = 1; a.query.sort[0].kind = TSGPU_SORT_INT64_COLUMN; a.query.sort[0].order = 1; a.query.sort[0].column = 999;
+        oracle::Topster topster(10);
+        std::vector<uint32_t> id_buff;
+        size_t nkm = 123; bool cutoff = false;
+        CHECK((tsgpu::search_across_fields_gpu<oracle::KV, oracle::Topster>(a, &topster, id_buff, nkm, cutoff)) == TSGPU_ERR_UNSUPPORTED, "501 expected");
+        CHECK(topster.size == 0 && id_buff.empty() && nkm == 123, "a 501 query must not touch the caller's state");
+    }
+
+    // ---------------- B2: the hnswlib-shaped adaptor ----------------
+    {
+        Reader r(dir + "/vec.bin");
+        const uint32_t n = r.get<uint32_t>(), dim = r.get<uint32_t>();
+        const std::vector<float> X = r.vec<float>((size_t)n * dim);
+        const uint32_t n_q = r.get<uint32_t>(), k = r.get<uint32_t>();
+        const std::vector<float> Q = r.vec<float>((size_t)n_q * dim);
+        tsgpu::InnerProductSpace space(dim);
+        tsgpu::HierarchicalNSW<float> vecdex(ctx, 7, &space, 16, 16, 200, 100, true);
+        for (uint32_t i = 0; i < n; i++) vecdex.addPoint(X.data() + (size_t)i * dim, (size_t)i, true);
+        CHECK(vecdex.getCurrentElementCount() == n, "element count");
+        vecdex.markDelete(4);
+        bool threw = false;
+        try { (void)vecdex.getDataByLabel<float>(4); } catch (const std::runtime_error&) { threw = true; }
+        CHECK(threw, "getDataByLabel of a deleted label must throw");
+        const std::vector<float> back = vecdex.getDataByLabel<float>(5);
+        CHECK(memcmp(back.data(), X.data() + (size_t)5 * dim, dim * 4) == 0, "getDataByLabel");
+        size_t d = dim;
+        CHECK(space.get_dist_func()(X.data(), X.data() + dim, &d) == tsgpu::InnerProductDistance(X.data(), X.data() + dim, &d), "dist func");
+        EvenOnly functor;
+        functor.excluded = {10, 20};
+        for (uint32_t qi = 0; qi < n_q; qi++) {
+            // expectations: (a) unfiltered, (b) the functor (even labels, minus excluded, minus the deleted label 4)
+            for (int pass = 0; pass < 2; pass++) {
+                const uint32_t want_n = r.get<uint32_t>();
+                const std::vector<uint64_t> want_l = r.vec<uint64_t>(want_n);
+                const std::vector<float> want_d = r.vec<float>(want_n);
+                // the reference's call: vecdex->searchKnnCloserFirst(q, k, ef, &filterFunctor) — NO candidate list
+                const auto got = pass == 0 ? vecdex.searchKnnCloserFirst(Q.data() + (size_t)qi * dim, k, 10, nullptr)
+                                           : vecdex.searchKnnCloserFirst(Q.data() + (size_t)qi * dim, k, 10, &functor);
+                CHECK(got.size() == want_n, "knn query %u pass %d: %zu results, oracle %u", qi, pass, got.size(), want_n);
+                for (uint32_t i = 0; i < want_n; i++) {
+                    CHECK(got[i].second == want_l[i], "knn query %u pass %d hit %u: label %zu vs %llu", qi, pass, i, got[i].second, (unsigned long long)want_l[i]);
+                    CHECK(memcmp(&got[i].first, &want_d[i], 4) == 0, "knn query %u pass %d hit %u: distance bits", qi, pass, i);
+                    if (pass == 1) CHECK(got[i].second % 2 == 0 && got[i].second != 10 && got[i].second != 20 && got[i].second != 4, "a filtered-out label came back");
+                }
+            }
+        }
+    }
+
+    // ---------------- a18: mirror_hnsw_graph from an hnswlib-shaped object ----------------
+    {
+        Reader r(dir + "/hnsw.bin");
+        const uint32_t n = r.get<uint32_t>(), dim = r.get<uint32_t>(), M = r.get<uint32_t>();
+        const int32_t maxlevel = r.get<int32_t>();
+        const uint32_t enterpoint = r.get<uint32_t>();
+        const std::vector<float> X = r.vec<float>((size_t)n * dim);
+        const std::vector<uint32_t> levels = r.vec<uint32_t>(n);
+        const std::vector<uint32_t> link0 = r.vec<uint32_t>((size_t)n * (1 + 2 * M));
+        const std::vector<uint64_t> upper_ptr = r.vec<uint64_t>(n + 1);
+        const uint32_t n_upper = r.get<uint32_t>();
+        const std::vector<uint32_t> upper = r.vec<uint32_t>((size_t)n_upper * (1 + M));
+        mock_hnswlib h;
+        h.cur_element_count = n; h.M_ = M; h.maxlevel_ = maxlevel; h.enterpoint_node_ = enterpoint;
+        h.size_data_per_element_ = 4 + 2 * M * 4 + dim * 4 + 8;           // [links][vector][label], hnswlib's level-0 layout
+        h.size_links_per_element_ = 4 + M * 4;
+        h.data_level0_memory_ = (char*)calloc(n, h.size_data_per_element_);
+        h.linkLists_ = (char**)calloc(n, sizeof(char*));
+        h.element_levels_.resize(n);
+        for (uint32_t i = 0; i < n; i++) {
+            char* e = h.data_level0_memory_ + (size_t)i * h.size_data_per_element_;
+            const uint32_t* l0 = link0.data() + (size_t)i * (1 + 2 * M);
+            const uint16_t cnt = (uint16_t)l0[0];
+            memcpy(e, &cnt, 2);
+            memcpy(e + 4, l0 + 1, (size_t)cnt * 4);
+            memcpy(e + 4 + 2 * M * 4, X.data() + (size_t)i * dim, dim * 4);
+            h.element_levels_[i] = (int)levels[i];
+            if (levels[i]) {
+                h.linkLists_[i] = (char*)calloc(levels[i], h.size_links_per_element_);
+                for (uint32_t lv = 1; lv <= levels[i]; lv++) {
+                    const uint32_t* lu = upper.data() + (upper_ptr[i] + lv - 1) * (1 + M);
+                    const uint16_t c2 = (uint16_t)lu[0];
+                    char* dst = h.linkLists_[i] + (size_t)(lv - 1) * h.size_links_per_element_;
+                    memcpy(dst, &c2, 2);
+                    memcpy(dst + 4, lu + 1, (size_t)c2 * 4);
+                }
+            }
+        }
+        CHECK(tsgpu_vec_create(ctx, 9, dim, TSGPU_METRIC_IP, n) == TSGPU_OK, "vec_create");
+        std::vector<uint64_t> labels(n);
+        for (uint32_t i = 0; i < n; i++) labels[i] = i;
+        CHECK(tsgpu_vec_upsert(ctx, 9, labels.data(), X.data(), n, TSGPU_MEM_HOST) == TSGPU_OK, "vec_upsert");
+        CHECK(tsgpu::mirror_hnsw_graph(ctx, 9, h) == TSGPU_OK, "mirror_hnsw_graph: %s", tsgpu_last_error());
+        const uint32_t n_q = r.get<uint32_t>(), k = r.get<uint32_t>(), ef = r.get<uint32_t>();
+        const std::vector<float> Q = r.vec<float>((size_t)n_q * dim);
+        std::vector<float> dist((size_t)n_q * k);
+        std::vector<uint64_t> lab((size_t)n_q * k);
+        std::vector<uint32_t> cnt(n_q);
+        CHECK(tsgpu_vec_hnsw_search_batch(ctx, 9, Q.data(), TSGPU_MEM_HOST, n_q, k, ef, 1, nullptr, 0, nullptr, 0, dist.data(), lab.data(), cnt.data(), TSGPU_MEM_HOST) == TSGPU_OK,
+              "hnsw search: %s", tsgpu_last_error());
+        for (uint32_t qi = 0; qi < n_q; qi++) {
+            const uint32_t want_n = r.get<uint32_t>();
+            const std::vector<uint64_t> want_l = r.vec<uint64_t>(want_n);
+            const std::vector<float> want_d = r.vec<float>(want_n);
+            CHECK(cnt[qi] == want_n, "hnsw query %u: %u vs %u results", qi, cnt[qi], want_n);
+            for (uint32_t i = 0; i < want_n; i++)
+                CHECK(lab[(size_t)qi * k + i] == want_l[i] && memcmp(&dist[(size_t)qi * k + i], &want_d[i], 4) == 0, "hnsw query %u hit %u", qi, i);
+        }
+        // a corrupt graph is rejected, not followed
+        std::vector<uint32_t> bad(link0);
+        bad[1] = n + 5;
+        if (bad[0] == 0) bad[0] = 1;
+        CHECK(tsgpu_vec_hnsw_load(ctx, 9, M, maxlevel, enterpoint, bad.data(), upper_ptr.data(), upper.empty() ? nullptr : upper.data(), n) == TSGPU_ERR_INVALID, "out-of-range neighbour accepted");
+        for (uint32_t i = 0; i < n; i++) free(h.linkLists_[i]);
+        free(h.linkLists_); free(h.data_level0_memory_);
+    }
+
+    // ---------------- validation shared by both term entry points ----------------
+    {
+        const uint32_t ids_bad[3] = {5, 5, 9}, oi[3] = {0, 1, 2}, off[3] = {1, 2, 3};
+        CHECK(tsgpu_term_upsert(ctx, 0, 90001, ids_bad, oi, off, 3, 3) == TSGPU_ERR_INVALID, "duplicate ids accepted");
+        const uint32_t ids_ok[3] = {5, 7, 9}, oi_empty_run[3] = {0, 1, 1};
+        CHECK(tsgpu_term_upsert(ctx, 0, 90001, ids_ok, oi_empty_run, off, 3, 3) == TSGPU_ERR_INVALID, "an empty offset run accepted");
+        const uint32_t oi_beyond[3] = {0, 1, 3};
+        CHECK(tsgpu_term_upsert(ctx, 0, 90001, ids_ok, oi_beyond, off, 3, 3) == TSGPU_ERR_INVALID, "offset_index beyond offsets accepted");
+        const uint32_t term = 90002;
+        const uint64_t ids_ptr[2] = {0, 3}, oi64[3] = {4, 5, 3}, off_ptr[2] = {3, 6};
+        const uint32_t offs[6] = {0, 0, 0, 1, 2, 3};
+        CHECK(tsgpu_terms_load_csr(ctx, 0, 1, &term, ids_ptr, ids_ok, oi64, off_ptr, offs) == TSGPU_ERR_INVALID, "csr: non-monotone offset_index accepted");
+        const uint64_t oi_under[3] = {2, 4, 5};
+        CHECK(tsgpu_terms_load_csr(ctx, 0, 1, &term, ids_ptr, ids_ok, oi_under, off_ptr, offs) == TSGPU_ERR_INVALID, "csr: offset_index below off_ptr accepted");
+    }
+
+    tsgpu_destroy(ctx);
+    printf("OK %d checks\n", n_checks);
+    return 0;
+}

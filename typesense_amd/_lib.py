@@ -61,6 +61,7 @@ EXPORTS = [
     "tsgpu_abi_version", "tsgpu_create", "tsgpu_destroy", "tsgpu_last_error", "tsgpu_set_stream", "tsgpu_set_option", "tsgpu_get_counter", "tsgpu_device_bytes",
     "tsgpu_field_create", "tsgpu_term_upsert", "tsgpu_terms_load_csr", "tsgpu_column_set", "tsgpu_set_num_docs", "tsgpu_commit",
     "tsgpu_term_num_ids", "tsgpu_term_download", "tsgpu_keyword_search_batch", "tsgpu_wildcard_search_batch", "tsgpu_keyword_search_candidates_batch", "tsgpu_candidates_result_ids", "tsgpu_keep_result_ids", "tsgpu_result_ids",
+    "tsgpu_keyword_search_batch_ids", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free",
     "tsgpu_vec_create", "tsgpu_vec_upsert", "tsgpu_vec_delete", "tsgpu_vec_get", "tsgpu_vec_count", "tsgpu_vec_knn_batch",
     "tsgpu_vec_hnsw_load", "tsgpu_vec_hnsw_search_batch", "tsgpu_vec_distances", "tsgpu_vector_search_batch", "tsgpu_hybrid_search_batch", "tsgpu_hybrid_fuse_batch", "tsgpu_merge_shard_hits", "tsgpu_merge_shard_hits_device", "tsgpu_last_timings",
 ]
@@ -105,6 +106,13 @@ def lib(path=None):
     L.tsgpu_keep_result_ids.argtypes = [vp, i32]
     L.tsgpu_result_ids.argtypes = [vp, u32, vp, u64]
     L.tsgpu_result_ids.restype = u64
+    L.tsgpu_keyword_search_batch_ids.argtypes = [vp, vp, u32, C.POINTER(HitsC), C.POINTER(vp)]
+    L.tsgpu_id_lists_count.argtypes = [vp, u32]
+    L.tsgpu_id_lists_count.restype = u64
+    L.tsgpu_id_lists_ids.argtypes = [vp, u32]
+    L.tsgpu_id_lists_ids.restype = C.POINTER(C.c_uint32)
+    L.tsgpu_id_lists_free.argtypes = [vp]
+    L.tsgpu_id_lists_free.restype = None
     L.tsgpu_vec_create.argtypes = [vp, u32, u32, i32, u64]
     L.tsgpu_vec_upsert.argtypes = [vp, u32, vp, vp, u32, i32]
     L.tsgpu_vec_delete.argtypes = [vp, u32, u64]

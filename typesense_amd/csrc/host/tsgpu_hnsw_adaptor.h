@@ -15,13 +15,17 @@
 //     space->get_dist_func()(a, b, &dim)                                     src/index.cpp:3365
 // Differences, all deliberate: this adaptor's search is EXACT (ef, M, ef_construction are accepted and ignored) — the
 // graph-search twin is mirror_hnsw_graph() + tsgpu_vec_hnsw_search_batch() at the end of this file —, cosine normalisation stays where the reference does it (caller side, src/index.cpp:1049-1052, 3381-3384),
-// and the filter functor is evaluated up front into an allow-list (it is a pure predicate over seq_ids).
+// and the filter functor is evaluated up front into an allow-list (it is a pure predicate over seq_ids): over the candidate ids
+// when the call site passes them (the filter's id array), otherwise over EVERY live label of the index — a functor is never
+// ignored (filter_by, hidden and excluded hits depend on it, include/index.h:325-354).
 #pragma once
 #include <cstddef>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <algorithm>
+#include <unordered_set>
 #include <vector>
 #include "../../../include/tsgpu.h"
 
@@ -68,6 +72,7 @@ class HierarchicalNSW {
     uint32_t field_;
     size_t dim_;
     size_t max_elements_;
+    std::unordered_set<uint32_t> live_;               // labels a filter functor can be asked about (mutated under the server's unique_lock)
 
     static void check(int rc, const char* what) {
         if (rc != TSGPU_OK) throw std::runtime_error(std::string(what) + ": " + tsgpu_last_error());
@@ -89,10 +94,14 @@ public:
     void addPoint(const void* data, labeltype label, bool /*replace_deleted*/ = false) {
         uint64_t l = (uint64_t)label;
         check(tsgpu_vec_upsert(ctx_, field_, &l, (const float*)data, 1, TSGPU_MEM_HOST), "tsgpu_vec_upsert");
+        live_.insert((uint32_t)label);
         if (getCurrentElementCount() > max_elements_) max_elements_ = getCurrentElementCount();
     }
 
-    void markDelete(labeltype label) { check(tsgpu_vec_delete(ctx_, field_, (uint64_t)label), "tsgpu_vec_delete"); }
+    void markDelete(labeltype label) {
+        check(tsgpu_vec_delete(ctx_, field_, (uint64_t)label), "tsgpu_vec_delete");
+        live_.erase((uint32_t)label);
+    }
 
     template <typename data_t>
     std::vector<data_t> getDataByLabel(labeltype label) {
@@ -109,11 +118,21 @@ public:
         std::vector<uint32_t> allow;
         const uint32_t* allow_ptr = nullptr;
         uint32_t n_allow = 0;
-        if (filter && candidate_ids) {     // evaluate the predicate once per candidate instead of once per visited node
-            for (uint32_t i = 0; i < n_candidates; i++) if ((*filter)(candidate_ids[i])) allow.push_back(candidate_ids[i]);
-            allow_ptr = allow.data();
-            n_allow = (uint32_t)allow.size();
-            if (n_allow == 0) return {};
+        if (filter) {
+            // the predicate is evaluated once per candidate instead of once per visited graph node: over the ids the call site
+            // hands over (the filter's sorted id array), or — the reference's call, searchKnnCloserFirst(q, k, ef, &functor) —
+            // over every live label. NEVER skipped: a dropped functor would return filtered-out / hidden documents.
+            if (candidate_ids) {
+                for (uint32_t i = 0; i < n_candidates; i++) if ((*filter)(candidate_ids[i])) allow.push_back(candidate_ids[i]);
+            } else {
+                allow.reserve(live_.size());
+                for (uint32_t l : live_) if ((*filter)((labeltype)l)) allow.push_back(l);
+            }
+            std::sort(allow.begin(), allow.end());
+            allow.erase(std::unique(allow.begin(), allow.end()), allow.end());
+            if (allow.empty()) return {};
+            if (allow.size() == live_.size() && !candidate_ids) allow.clear();      // the functor rejects nothing: no allow-list needed
+            else { allow_ptr = allow.data(); n_allow = (uint32_t)allow.size(); }
         }
         std::vector<float> dist(k);
         std::vector<uint64_t> lab(k);

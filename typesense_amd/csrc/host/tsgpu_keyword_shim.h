@@ -40,10 +40,12 @@ int search_across_fields_gpu(const KeywordShimArgs& a, TopsterT* topster, std::v
     h.k_stride = K;
     h.keys = keys.data(); h.scores = scores.data(); h.text_match = text_match.data(); h.vector_distance = vdist.data();
     h.match_score_index = msi.data(); h.n_hits = &n_hits; h.num_matched = &num_matched; h.status = &status; h.search_cutoff = &cutoff;
-    if (a.want_result_ids) tsgpu_keep_result_ids(a.ctx, 1);
-    int rc = tsgpu_keyword_search_batch(a.ctx, &a.query, 1, &h);
+    // the matched ids come back as a list that belongs to THIS call (tsgpu_keyword_search_batch_ids): request threads share the
+    // context, and the library may have coalesced this call with other threads' calls
+    tsgpu_id_lists* ids = nullptr;
+    int rc = a.want_result_ids ? tsgpu_keyword_search_batch_ids(a.ctx, &a.query, 1, &h, &ids) : tsgpu_keyword_search_batch(a.ctx, &a.query, 1, &h);
     if (rc != TSGPU_OK) return rc;
-    if (status != TSGPU_OK) { search_cutoff = search_cutoff || cutoff != 0; return status; }
+    if (status != TSGPU_OK) { tsgpu_id_lists_free(ids); search_cutoff = search_cutoff || cutoff != 0; return status; }
     if (topster != nullptr) {
         for (uint32_t i = 0; i < n_hits; i++) {
             KV kv(a.query_index, keys[i], keys[i], msi[i], &scores[(size_t)i * 3]);
@@ -51,11 +53,11 @@ int search_across_fields_gpu(const KeywordShimArgs& a, TopsterT* topster, std::v
             topster->add(&kv);
         }
     }
-    if (a.want_result_ids) {
-        const uint64_t n = tsgpu_result_ids(a.ctx, 0, nullptr, 0);
-        const size_t at = id_buff.size();
-        id_buff.resize(at + n);
-        if (n) tsgpu_result_ids(a.ctx, 0, id_buff.data() + at, n);
+    if (ids) {
+        const uint64_t n = tsgpu_id_lists_count(ids, 0);
+        const uint32_t* p = tsgpu_id_lists_ids(ids, 0);
+        id_buff.insert(id_buff.end(), p, p + n);
+        tsgpu_id_lists_free(ids);
     }
     num_keyword_matches = (size_t)num_matched;
     search_cutoff = search_cutoff || cutoff != 0;

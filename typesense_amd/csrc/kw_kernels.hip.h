@@ -1850,6 +1850,13 @@ __global__ __launch_bounds__(KW_THREADS) void kw_idset_count_kernel(const uint32
         if (tot) atomicAdd(&found[blockIdx.x], (unsigned long long)tot);
     }
 }
+// per-call id lists (tsgpu_keyword_search_batch_ids): the work items' id segments, scattered over the lane's id arena, copied into
+// one dense array (query after query, segment after segment) so that ONE download hands every caller its ids
+struct KwIdCopy { uint64_t src, dst; uint32_t cnt, pad; };
+__global__ __launch_bounds__(KW_THREADS) void kw_ids_gather_kernel(const uint32_t* __restrict__ ids, const KwIdCopy* __restrict__ segs, uint32_t* __restrict__ out) {
+    const KwIdCopy sg = segs[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < sg.cnt; i += KW_THREADS) out[sg.dst + i] = ids[sg.src + i];
+}
 // ascending ids of one group's bitmap -> out[0 .. found) (one workgroup walks the words, 256 at a time, with a running base)
 __global__ __launch_bounds__(KW_THREADS) void kw_idset_expand_kernel(const uint32_t* __restrict__ bits, uint64_t n_words, uint32_t* __restrict__ out, uint64_t cap) {
     __shared__ uint32_t s_wave[KW_THREADS / 64];

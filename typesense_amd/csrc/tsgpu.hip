@@ -35,21 +35,33 @@ int refresh_column_table(tsgpu_ctx* ctx) {
     return TSGPU_OK;
 }
 
-IndexView make_view(tsgpu_ctx* ctx) {
+IndexView make_view(tsgpu_ctx* ctx, const Snapshot& sn) {
     IndexView v;
-    v.lists = ctx->snap.lists.as<ListDesc>();
-    v.blk_last = ctx->snap.blk_last.as<uint32_t>();
-    v.blk_ids = ctx->snap.blk_ids.as<BlockIds>();
-    v.blk_meta = ctx->snap.blk_meta.as<BlockMeta>();
-    v.ids_payload = ctx->snap.ids_payload.as<uint32_t>();
-    v.payload = ctx->snap.payload.as<uint32_t>();
+    v.lists = sn.lists.as<ListDesc>();
+    v.blk_last = sn.blk_last.as<uint32_t>();
+    v.blk_ids = sn.blk_ids.as<BlockIds>();
+    v.blk_meta = sn.blk_meta.as<BlockMeta>();
+    v.ids_payload = sn.ids_payload.as<uint32_t>();
+    v.payload = sn.payload.as<uint32_t>();
     v.columns = ctx->d_col_ptrs.as<const int64_t*>();
     v.column_len = ctx->d_col_len.as<uint32_t>();
     v.n_columns = (uint32_t)ctx->columns.size();
     v.num_docs = ctx->num_docs;
     v.prof = ctx->d_prof.as<unsigned long long>();
-    v.mf = ctx->d_mf.as<KwQueryMF>();
+    v.mf = nullptr;                                   // per lane: set by the batch
     return v;
+}
+
+// one validator for both term entry points (tsgpu_term_upsert / tsgpu_terms_load_csr): ids strictly ascending, offset_index
+// strictly ascending (every document owns at least one offset: Match reads runs[t].n - 1) and inside [0, n_off)
+const char* validate_list(const uint32_t* ids, const uint64_t* oi, uint32_t n_ids, uint64_t n_off) {
+    if (n_ids == 0) return nullptr;
+    if (oi[n_ids - 1] >= n_off) return "offset_index beyond offsets (every document needs at least one offset)";
+    for (uint32_t i = 1; i < n_ids; i++) {
+        if (ids[i] <= ids[i - 1]) return "ids must be strictly ascending";
+        if (oi[i] <= oi[i - 1]) return "offset_index must be strictly ascending (every document needs at least one offset)";
+    }
+    return nullptr;
 }
 
 template <int TMAX, int CAP>
@@ -120,12 +132,16 @@ int tsgpu_create(int device_ordinal, tsgpu_ctx** out) {
     tsgpu_ctx* ctx = new (std::nothrow) tsgpu_ctx;
     if (!ctx) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_create: host allocation failed");
     ctx->device = device_ordinal;
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete ctx; return fail(TSGPU_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
-    for (auto& ev : ctx->ev) {
-        e = hipEventCreate(&ev);
-        if (e != hipSuccess) { delete ctx; return fail(TSGPU_ERR_DEVICE, "hipEventCreate failed"); }
+    std::atomic_store(&ctx->snap, std::shared_ptr<const Snapshot>(std::make_shared<Snapshot>()));
+    bool good = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    for (auto& ev : ctx->ev) good = good && hipEventCreate(&ev) == hipSuccess;
+    for (int l = 0; l < tsgpu_ctx::N_LANES && good; l++) {
+        KwLane& L = ctx->lanes[l];
+        if (l == 0) { L.stream = ctx->stream; L.own_stream = false; }          // lane 0 shares the vector path's stream
+        else good = good && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess;
+        for (auto& ev : L.ev) good = good && hipEventCreate(&ev) == hipSuccess;
     }
+    if (!good) { tsgpu_destroy(ctx); return fail(TSGPU_ERR_DEVICE, "tsgpu_create: stream / event creation failed"); }
     *out = ctx;
     return ok();
 }
@@ -137,16 +153,10 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     tsgpu_vec_destroy_all(ctx);
-    DevBuf* bufs[] = {&ctx->snap.lists, &ctx->snap.blk_last, &ctx->snap.blk_ids, &ctx->snap.blk_meta, &ctx->snap.ids_payload, &ctx->snap.payload, &ctx->d_col_ptrs, &ctx->d_col_len,
-                      &ctx->d_queries, &ctx->d_work, &ctx->d_aux, &ctx->d_ids_out, &ctx->d_mf, &ctx->d_part_s0, &ctx->d_part_s1, &ctx->d_part_s2,
-                      &ctx->d_part_key, &ctx->d_part_cnt, &ctx->d_part_nm, &ctx->d_part_ne, &ctx->d_part_ow, &ctx->d_part_f, &ctx->d_out_keys,
-                      &ctx->d_out_scores, &ctx->d_out_tm, &ctx->d_out_vd, &ctx->d_out_msi, &ctx->d_out_nh, &ctx->d_out_nm, &ctx->d_out_ow, &ctx->d_prof,
-                      &ctx->d_hits, &ctx->d_hit_off_tab[0], &ctx->d_hit_off_tab[1], &ctx->d_hit_off_tab[2], &ctx->d_hit_off_tab[3], &ctx->d_cand_keys, &ctx->d_cand_scores, &ctx->d_cand_tm, &ctx->d_cand_vd, &ctx->d_cand_msi, &ctx->d_cand_nh,
-                      &ctx->d_cand_nm, &ctx->d_cand_st, &ctx->d_cand_gb, &ctx->d_cand_qi, &ctx->d_cand_found, &ctx->d_cand_segs, &ctx->d_cand_bits, &ctx->d_cand_ids};
-    for (auto* b : bufs) b->release();
+    for (auto& L : ctx->lanes) L.release();
+    std::atomic_store(&ctx->snap, std::shared_ptr<const Snapshot>());
+    ctx->d_col_ptrs.release(); ctx->d_col_len.release(); ctx->d_prof.release();
     for (auto& c : ctx->columns) c.data.release();
-    ctx->h_stage.release();
-    ctx->h_out.release();
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -155,12 +165,14 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
 int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> lk0(ctx->lanes[0].mu);
     if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false; }
     else {
         TSGPU_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->own_stream = true;
     }
+    ctx->lanes[0].stream = ctx->stream;
     return ok();
 }
 
@@ -168,7 +180,7 @@ uint64_t tsgpu_vec_device_bytes(tsgpu_ctx* ctx);   // tsgpu_vec.hip
 
 uint64_t tsgpu_device_bytes(tsgpu_ctx* ctx) {
     if (!ctx) return 0;
-    uint64_t b = ctx->snap.bytes;
+    uint64_t b = ctx->snapshot()->bytes;
     for (auto& c : ctx->columns) b += c.data.cap;
     return b + tsgpu_vec_device_bytes(ctx);
 }
@@ -187,17 +199,13 @@ int tsgpu_term_upsert(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, const
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto fit = ctx->fields.find(field_id);
     if (fit == ctx->fields.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_term_upsert: unknown field (call tsgpu_field_create)");
-    ctx->dirty = true;
-    if (n_ids == 0) { fit->second.terms.erase(term_id); return ok(); }
+    if (n_ids == 0) { fit->second.terms.erase(term_id); ctx->dirty = true; return ok(); }
     if (!ids || !offset_index || !offsets) return fail(TSGPU_ERR_INVALID, "tsgpu_term_upsert: NULL array");
-    for (uint32_t i = 1; i < n_ids; i++) {
-        if (ids[i] <= ids[i - 1]) return fail(TSGPU_ERR_INVALID, "tsgpu_term_upsert: ids must be strictly ascending");
-        if (offset_index[i] < offset_index[i - 1]) return fail(TSGPU_ERR_INVALID, "tsgpu_term_upsert: offset_index must ascend");
-    }
-    if (offset_index[n_ids - 1] > n_offsets) return fail(TSGPU_ERR_INVALID, "tsgpu_term_upsert: offset_index beyond offsets");
     try {
         std::vector<uint64_t> oi(offset_index, offset_index + n_ids);
+        if (const char* why = validate_list(ids, oi.data(), n_ids, n_offsets)) return fail(TSGPU_ERR_INVALID, std::string("tsgpu_term_upsert: ") + why);
         fit->second.terms[term_id] = pack_list(ids, oi.data(), offsets, n_ids, n_offsets);
+        ctx->dirty = true;
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_term_upsert: host allocation failed"); }
     return ok();
 }
@@ -209,17 +217,33 @@ int tsgpu_terms_load_csr(tsgpu_ctx* ctx, uint32_t field_id, uint32_t n_terms, co
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto fit = ctx->fields.find(field_id);
     if (fit == ctx->fields.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_terms_load_csr: unknown field");
-    ctx->dirty = true;
     try {
-        std::vector<uint64_t> oi;
+        // validate the whole load before touching the field: a rejected call leaves the pending state as it was
         for (uint32_t t = 0; t < n_terms; t++) {
             const uint64_t a = ids_ptr[t], b = ids_ptr[t + 1];
-            if (b <= a) { fit->second.terms.erase(term_ids[t]); continue; }
+            if (b < a || off_ptr[t + 1] < off_ptr[t]) return fail(TSGPU_ERR_INVALID, "tsgpu_terms_load_csr: ids_ptr / off_ptr must be non-decreasing");
+            if (b - a > 0xFFFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_terms_load_csr: a list of more than 2^32 ids");
+        }
+        std::vector<uint64_t> oi;
+        std::vector<std::pair<uint32_t, PackedList>> packed;
+        packed.reserve(n_terms);
+        for (uint32_t t = 0; t < n_terms; t++) {
+            const uint64_t a = ids_ptr[t], b = ids_ptr[t + 1];
+            if (b == a) { packed.emplace_back(term_ids[t], PackedList()); continue; }
             const uint64_t o0 = off_ptr[t], o1 = off_ptr[t + 1];
             oi.resize(b - a);
-            for (uint64_t i = a; i < b; i++) oi[i - a] = offset_index[i] - o0;
-            fit->second.terms[term_ids[t]] = pack_list(ids + a, oi.data(), offsets + o0, (uint32_t)(b - a), o1 - o0);
+            for (uint64_t i = a; i < b; i++) {
+                if (offset_index[i] < o0) return fail(TSGPU_ERR_INVALID, "tsgpu_terms_load_csr: offset_index below the list's off_ptr");
+                oi[i - a] = offset_index[i] - o0;
+            }
+            if (const char* why = validate_list(ids + a, oi.data(), (uint32_t)(b - a), o1 - o0)) return fail(TSGPU_ERR_INVALID, std::string("tsgpu_terms_load_csr: ") + why);
+            packed.emplace_back(term_ids[t], pack_list(ids + a, oi.data(), offsets + o0, (uint32_t)(b - a), o1 - o0));
         }
+        for (auto& e : packed) {
+            if (e.second.desc.n_ids == 0) fit->second.terms.erase(e.first);
+            else fit->second.terms[e.first] = std::move(e.second);
+        }
+        ctx->dirty = true;
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_terms_load_csr: host allocation failed"); }
     return ok();
 }
@@ -257,17 +281,23 @@ int tsgpu_set_num_docs(tsgpu_ctx* ctx, uint32_t num_docs) {
     return ok();
 }
 
+// Publishes every pending term / column change as ONE new immutable snapshot. The snapshot is built in fresh device buffers and
+// swapped in (RCU) only when every upload succeeded: a search that started on the previous snapshot keeps it alive until it
+// returns, a failing commit leaves the previous snapshot in place, and searches never wait on a commit.
 int tsgpu_commit(tsgpu_ctx* ctx) {
     if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
     std::lock_guard<std::mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     try {
-        std::vector<ListDesc> descs;
-        std::unordered_map<uint64_t, uint32_t> handle_of;
+        std::shared_ptr<Snapshot> sp = std::make_shared<Snapshot>();
+        Snapshot& s = *sp;
+        std::vector<ListDesc>& descs = s.h_lists;
         uint64_t n_blocks = 0, n_words = 0, n_id_words = 0;
         std::vector<std::pair<uint64_t, const PackedList*>> order;
-        for (auto& f : ctx->fields)
+        for (auto& f : ctx->fields) {
+            s.field_is_array[f.first] = f.second.is_array;
             for (auto& t : f.second.terms) order.emplace_back(((uint64_t)f.first << 32) | t.first, &t.second);
+        }
         std::sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
         uint32_t max_id = 0;
         for (auto& e : order) { n_blocks += e.second->blk_last.size(); n_words += e.second->payload.size(); n_id_words += e.second->ids_payload.size(); max_id = std::max(max_id, e.second->desc.last_id); }
@@ -293,10 +323,9 @@ int tsgpu_commit(tsgpu_ctx* ctx) {
             std::copy(pl.payload.begin(), pl.payload.end(), h_payload.begin() + wpos);
             bpos += pl.blk_last.size();
             wpos += pl.payload.size();
-            handle_of[e.first] = (uint32_t)descs.size();
+            s.handle_of[e.first] = (uint32_t)descs.size();
             descs.push_back(d);
         }
-        Snapshot& s = ctx->snap;
         int rc;
         if ((rc = s.lists.reserve(std::max<size_t>(descs.size(), 1) * sizeof(ListDesc)))) return rc;
         if ((rc = s.blk_last.reserve(std::max<size_t>(h_last.size(), 1) * 4))) return rc;
@@ -310,8 +339,6 @@ int tsgpu_commit(tsgpu_ctx* ctx) {
         if (!h_last.empty()) TSGPU_HIP_TRY(hipMemcpy(s.blk_last.p, h_last.data(), h_last.size() * 4, hipMemcpyHostToDevice));
         if (!h_meta.empty()) TSGPU_HIP_TRY(hipMemcpy(s.blk_meta.p, h_meta.data(), h_meta.size() * sizeof(BlockMeta), hipMemcpyHostToDevice));
         TSGPU_HIP_TRY(hipMemcpy(s.payload.p, h_payload.data(), h_payload.size() * 4, hipMemcpyHostToDevice));
-        s.h_lists.swap(descs);
-        s.handle_of.swap(handle_of);
         {   // flat lookup tables: fields < 64, terms < 4M; a term beyond its field's table is found through handle_of
             std::vector<std::vector<uint32_t>> dense;
             std::vector<uint32_t> max_term;
@@ -331,40 +358,40 @@ int tsgpu_commit(tsgpu_ctx* ctx) {
         }
         s.bytes = s.lists.cap + s.blk_last.cap + s.blk_ids.cap + s.blk_meta.cap + s.ids_payload.cap + s.payload.cap;
         if (!ctx->num_docs_set) ctx->num_docs = std::max(ctx->num_docs, order.empty() ? 0u : max_id + 1);
+        s.num_docs = ctx->num_docs;
+        std::atomic_store(&ctx->snap, std::shared_ptr<const Snapshot>(sp));      // publish
         ctx->dirty = false;
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_commit: host allocation failed"); }
-    int rc = refresh_column_table(ctx);
-    if (rc) return rc;
     return ok();
 }
 
 uint32_t tsgpu_term_num_ids(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id) {
     if (!ctx) return 0;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    auto it = ctx->snap.handle_of.find(((uint64_t)field_id << 32) | term_id);
-    return it == ctx->snap.handle_of.end() ? 0 : ctx->snap.h_lists[it->second].n_ids;
+    const std::shared_ptr<const Snapshot> sn = ctx->snapshot();
+    auto it = sn->handle_of.find(((uint64_t)field_id << 32) | term_id);
+    return it == sn->handle_of.end() ? 0 : sn->h_lists[it->second].n_ids;
 }
 
 int tsgpu_term_download(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, uint32_t* ids, uint32_t* offset_index, uint32_t* offsets,
                         uint32_t* n_offsets) {
     if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
-    auto it = ctx->snap.handle_of.find(((uint64_t)field_id << 32) | term_id);
-    if (it == ctx->snap.handle_of.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_term_download: term not in the committed snapshot");
-    const ListDesc d = ctx->snap.h_lists[it->second];
+    const std::shared_ptr<const Snapshot> sn = ctx->snapshot();     // the committed snapshot: pending (uncommitted) changes are not visible here
+    auto it = sn->handle_of.find(((uint64_t)field_id << 32) | term_id);
+    if (it == sn->handle_of.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_term_download: term not in the committed snapshot");
+    const ListDesc d = sn->h_lists[it->second];
     try {
         std::vector<uint32_t> last(d.n_blocks);
         std::vector<BlockMeta> meta(d.n_blocks);
-        TSGPU_HIP_TRY(hipMemcpy(last.data(), ctx->snap.blk_last.as<uint32_t>() + d.blk_base, (size_t)d.n_blocks * 4, hipMemcpyDeviceToHost));
-        TSGPU_HIP_TRY(hipMemcpy(meta.data(), ctx->snap.blk_meta.as<BlockMeta>() + d.blk_base, (size_t)d.n_blocks * sizeof(BlockMeta), hipMemcpyDeviceToHost));
+        TSGPU_HIP_TRY(hipMemcpy(last.data(), sn->blk_last.as<uint32_t>() + d.blk_base, (size_t)d.n_blocks * 4, hipMemcpyDeviceToHost));
+        TSGPU_HIP_TRY(hipMemcpy(meta.data(), sn->blk_meta.as<BlockMeta>() + d.blk_base, (size_t)d.n_blocks * sizeof(BlockMeta), hipMemcpyDeviceToHost));
         const BlockMeta& lm = meta.back();
         const size_t words = (size_t)lm.off_woff + packed_words(lm.n_off, lm.off_bits);
         std::vector<uint32_t> payload(words + 2);
-        TSGPU_HIP_TRY(hipMemcpy(payload.data(), ctx->snap.payload.as<uint32_t>() + d.payload_base, words * 4, hipMemcpyDeviceToHost));
+        TSGPU_HIP_TRY(hipMemcpy(payload.data(), sn->payload.as<uint32_t>() + d.payload_base, words * 4, hipMemcpyDeviceToHost));
         const size_t iwords = (size_t)lm.ids_woff + packed_words(lm.n_ids, lm.ids_bits);
         std::vector<uint32_t> idw(iwords + 2);
-        TSGPU_HIP_TRY(hipMemcpy(idw.data(), ctx->snap.ids_payload.as<uint32_t>() + d.ids_base, iwords * 4, hipMemcpyDeviceToHost));
+        TSGPU_HIP_TRY(hipMemcpy(idw.data(), sn->ids_payload.as<uint32_t>() + d.ids_base, iwords * 4, hipMemcpyDeviceToHost));
         std::vector<uint32_t> a, b, c;
         unpack_list(d, last.data(), meta.data(), idw.data(), payload.data(), a, b, c);
         if (n_offsets) *n_offsets = (uint32_t)c.size();
@@ -416,6 +443,10 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
         return ok();
     }
     if (!strcmp(name, "vec_count_rescored")) { ctx->vec_count_rescored = value != 0; return ok(); }
+    // micro-batcher (tsgpu_batcher.h): concurrent small calls are coalesced into one launch
+    if (!strcmp(name, "batch_window_us")) { ctx->batch_window_us = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 100000); return ok(); }
+    if (!strcmp(name, "batch_max_queries")) { ctx->batch_max_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20); return ok(); }   // 0 = never coalesce
+    if (!strcmp(name, "batch_round_queries")) { ctx->batch_round_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 1 << 20); return ok(); }
     if (!strcmp(name, "vec_prefilter")) {
         if (value != 0 && value != 1) return fail(TSGPU_ERR_INVALID, "vec_prefilter must be 0 or 1");
         ctx->vec_prefilter = (uint32_t)value;
@@ -426,13 +457,15 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
 
 int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!ctx || !name || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_get_counter: NULL argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> lk(ctx->tm_mu);
     if (!strcmp(name, "kw_last_hit_groups")) { *out = ctx->kw_last_hit_groups; return ok(); }      // last keyword batch: find+score groups (0 = fused kernel)
     if (!strcmp(name, "kw_last_hit_records")) { *out = ctx->kw_last_hit_records; return ok(); }    // hit-record capacity the last batch asked for
     if (!strcmp(name, "vec_overflow_rounds")) { *out = ctx->vec_overflow_rounds; return ok(); }
     if (!strcmp(name, "vec_prefilter_fallbacks")) { *out = ctx->vec_prefilter_fallbacks; return ok(); }
     if (!strcmp(name, "vec_prefilter_groups")) { *out = ctx->vec_prefilter_groups; return ok(); }
     if (!strcmp(name, "vec_rescored_rows")) { *out = ctx->vec_rescored_rows; return ok(); }
+    if (!strcmp(name, "batch_rounds")) { *out = ctx->kw_comb.rounds + ctx->vec_comb.rounds; return ok(); }               // coalesced rounds executed so far
+    if (!strcmp(name, "batch_coalesced_calls")) { *out = ctx->kw_comb.coalesced_calls + ctx->vec_comb.coalesced_calls; return ok(); }   // calls served by those rounds
     return fail(TSGPU_ERR_NOT_FOUND, std::string("tsgpu_get_counter: unknown counter ") + name);
 }
 
@@ -471,7 +504,7 @@ static uint32_t resolve_topster_size(const tsgpu_ctx* ctx, const tsgpu_kw_query&
     return std::max<uint32_t>(k, 1);
 }
 
-static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, Plan& P, bool keep_ids, bool wildcard) {
+static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query* queries, uint32_t n_queries, Plan& P, bool keep_ids, bool wildcard) {
     // driver blocks per work item: fixed by the option, or (0 = auto) sized so that the batch yields a few thousand work
     // items (>= 3 per resident workgroup slot) without fragmenting queries into more partial top-K lists than needed
     uint32_t KW_CHUNK_BLOCKS = ctx->kw_chunk_blocks;
@@ -485,9 +518,9 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             if (in.n_tokens == 0 || in.n_tokens > TSGPU_MAX_QUERY_TOKENS || in.n_fields != 1) continue;
             uint32_t best = 0xFFFFFFFFu;
             for (uint32_t t = 0; t < in.n_tokens; t++) {
-                const uint32_t h = ctx->snap.find_handle(in.field_ids[0], in.term_ids[t]);
+                const uint32_t h = snap.find_handle(in.field_ids[0], in.term_ids[t]);
                 handle_cache[(size_t)i * TSGPU_MAX_QUERY_TOKENS + t] = h != 0xFFFFFFFFu ? h : KW_NONE - 1;     // remembered for the main pass
-                if (h != 0xFFFFFFFFu) best = std::min(best, ctx->snap.h_lists[h].n_blocks);
+                if (h != 0xFFFFFFFFu) best = std::min(best, snap.h_lists[h].n_blocks);
             }
             cached[i] = 1;
             if (best != 0xFFFFFFFFu) total_blocks += best;
@@ -518,15 +551,14 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         if (!wildcard) {
             int bad = 0;
             for (uint32_t f = 0; f < in.n_fields && !bad; f++) {
-                auto fit = ctx->fields.find(in.field_ids[f]);
-                if (fit == ctx->fields.end()) bad = TSGPU_ERR_NOT_FOUND;
+                if (snap.field_is_array.find(in.field_ids[f]) == snap.field_is_array.end()) bad = TSGPU_ERR_NOT_FOUND;
             }
             if (bad) { P.status[i] = bad; continue; }
         }
         // several fields, or a string[] field: the general kernel (per-candidate probes, per-field scoring incl. the array readers);
         // the block-merge kernel stays free of the array code (it costs 2x the registers)
         bool multi = !wildcard && in.n_fields > 1;
-        if (!wildcard && !multi && ctx->fields[in.field_ids[0]].is_array) multi = true;
+        if (!wildcard && !multi && snap.field_is_array.at(in.field_ids[0])) multi = true;
         if (multi && in.n_filter != 0) { unsupported("filter ids with several query_by fields"); continue; }
         if (in.n_sort > TSGPU_MAX_SORT_KEYS) { P.status[i] = TSGPU_ERR_INVALID; continue; }
         if (in.n_filter != 0 && !in.filter_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
@@ -593,14 +625,14 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
                     handle = handle_cache[(size_t)i * TSGPU_MAX_QUERY_TOKENS + t];
                     if (handle == KW_NONE - 1) continue;
                 } else {
-                    handle = ctx->snap.find_handle(in.field_ids[f], in.term_ids[t]);
+                    handle = snap.find_handle(in.field_ids[f], in.term_ids[t]);
                     if (handle == 0xFFFFFFFFu) continue;
                 }
                 if (!found) q.list[nl] = handle;
                 found = true;
                 mfq.list[nl][f] = handle;
-                tot += ctx->snap.h_lists[handle].n_ids;
-                P.list_bytes += 4ull * ctx->snap.h_lists[handle].n_ids;
+                tot += snap.h_lists[handle].n_ids;
+                P.list_bytes += 4ull * snap.h_lists[handle].n_ids;
             }
             if (!found) continue;
             len_of[nl] = (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFull);
@@ -636,7 +668,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             for (uint32_t t = 1; t < nl; t++) if (len_of[t] < len_of[td]) td = t;
             mfq.n_fields = in.n_fields;
             mfq.driver_token = td;
-            for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.is_array[f] = f < in.n_fields && ctx->fields[in.field_ids[f]].is_array ? 1 : 0;
+            for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.is_array[f] = f < in.n_fields && snap.field_is_array.at(in.field_ids[f]) ? 1 : 0;
             for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.weight[f] = f < in.n_fields ? in.field_weights[f] : 0;
             if (k + KW_THREADS > 1024) { unsupported("topster_size with several query_by fields"); continue; }
             q.mf_index = (uint32_t)P.mf.size();
@@ -645,7 +677,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
             uint64_t seg = 0;
             for (uint32_t f = 0; f < in.n_fields; f++) {
                 if (mfq.list[td][f] == KW_NONE) continue;
-                const ListDesc& dF = ctx->snap.h_lists[mfq.list[td][f]];
+                const ListDesc& dF = snap.h_lists[mfq.list[td][f]];
                 for (uint32_t b = 0; b < dF.n_blocks; b += KW_CHUNK_BLOCKS) {
                     KwWorkItem w;
                     w.query = i | (f << 28);
@@ -664,7 +696,7 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
         for (uint32_t t = 0; t < nl; t++) ord[t] = (uint8_t)t;
         std::stable_sort(ord, ord + nl, [&](uint8_t a, uint8_t b) { return len_of[a] < len_of[b]; });
         for (uint32_t t = 0; t < nl; t++) q.probe_order[t] = ord[t];
-        const ListDesc& dA = ctx->snap.h_lists[q.list[ord[0]]];
+        const ListDesc& dA = snap.h_lists[q.list[ord[0]]];
         q.ids_out_off = P.ids_total;
         if (keep_ids) P.ids_total += (uint64_t)dA.n_blocks * BLOCK_IDS;
         // at most 8..64 partial top-K lists per query: kw_merge_kernel folds a query's partials one after the other, and a small
@@ -737,36 +769,188 @@ static int plan_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_
     return TSGPU_OK;
 }
 
-static int kw_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard);
-static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, std::vector<int32_t>* status_host);
+// ---- lanes ----
+namespace {
+struct LaneLock {                                     // holds one execution lane for the duration of a batch
+    tsgpu_ctx* ctx; KwLane* L; int index;
+    explicit LaneLock(tsgpu_ctx* c, int want = -1) : ctx(c), L(nullptr), index(-1) {
+        if (want < 0) {
+            for (int i = 0; i < tsgpu_ctx::N_LANES && !L; i++) if (c->lanes[i].mu.try_lock()) { L = &c->lanes[i]; index = i; }
+            if (!L) {                                 // both busy: queue on the lane with fewer waiters
+                want = 0;
+                for (int i = 1; i < tsgpu_ctx::N_LANES; i++) if (c->lanes[i].waiters.load() < c->lanes[want].waiters.load()) want = i;
+            }
+        }
+        if (!L) {
+            KwLane& l = c->lanes[want];
+            l.waiters.fetch_add(1);
+            l.mu.lock();
+            l.waiters.fetch_sub(1);
+            L = &l; index = want;
+        }
+        c->last_lane.store(index);
+    }
+    ~LaneLock() { L->mu.unlock(); }
+};
+struct BatchOpts {
+    bool wildcard = false;
+    bool keep_ids = false;                            // emit matched ids into the lane's id arena
+    std::vector<int32_t>* status_host = nullptr;      // receives the per-query status codes
+    tsgpu_id_lists* id_lists = nullptr;               // when set: the matched ids of every query, gathered + downloaded (implies keep_ids)
+    bool record_last = true;                          // remember the id segments for the legacy tsgpu_result_ids API
+};
+}
+static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, const BatchOpts& bo);
+static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, tsgpu_id_lists** ids_out);
 
 int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out) {
-    return kw_batch(ctx, queries, n_queries, out, false);
+    return kw_dispatch(ctx, queries, n_queries, out, false, nullptr);
 }
 
 int tsgpu_wildcard_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out) {
-    return kw_batch(ctx, queries, n_queries, out, true);
+    return kw_dispatch(ctx, queries, n_queries, out, true, nullptr);
 }
 
-static int kw_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard) {
+int tsgpu_keyword_search_batch_ids(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, tsgpu_id_lists** ids_out) {
+    if (!ids_out) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch_ids: ids_out is NULL");
+    *ids_out = nullptr;
+    return kw_dispatch(ctx, queries, n_queries, out, false, ids_out);
+}
+
+uint64_t tsgpu_id_lists_count(const tsgpu_id_lists* l, uint32_t q) { return (l && (size_t)q + 1 < l->begin.size()) ? l->begin[q + 1] - l->begin[q] : 0; }
+const uint32_t* tsgpu_id_lists_ids(const tsgpu_id_lists* l, uint32_t q) { return (l && (size_t)q + 1 < l->begin.size()) ? l->ids.data() + l->begin[q] : nullptr; }
+void tsgpu_id_lists_free(tsgpu_id_lists* l) { delete l; }
+
+}  // extern "C"
+
+namespace tsgpu {
+struct KwRequest : ParkedRequest {
+    const tsgpu_kw_query* q = nullptr;
+    tsgpu_hits* out = nullptr;
+    tsgpu_id_lists* ids = nullptr;                   // non-null: the caller wants its matched ids
+};
+}
+
+// A small keyword call from one of several concurrent request threads: parked in the combiner, executed as part of one round.
+static int kw_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, tsgpu_id_lists** ids_out) {
+    std::unique_ptr<tsgpu_id_lists> lists;
+    if (ids_out) { lists.reset(new (std::nothrow) tsgpu_id_lists); if (!lists) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_batch_ids: host allocation failed"); }
+    KwRequest me;
+    me.units = n_queries; me.q = queries; me.out = out; me.ids = lists.get();
+    auto acquire = [&]() { return std::unique_ptr<LaneLock>(new LaneLock(ctx)); };
+    const uint32_t round_cap = std::max<uint32_t>(ctx->batch_round_queries, n_queries);
+    auto pick = [&](std::vector<KwRequest*>& pending, std::vector<KwRequest*>& round) {
+        uint32_t units = 0;
+        size_t take = 0;
+        while (take < pending.size() && (take == 0 || units + pending[take]->units <= round_cap)) units += pending[take++]->units;
+        round.assign(pending.begin(), pending.begin() + take);
+        pending.erase(pending.begin(), pending.begin() + take);
+    };
+    auto exec = [&](std::vector<KwRequest*>& round, std::unique_ptr<LaneLock>& guard) {
+        KwLane& L = *guard->L;
+        int rc = TSGPU_OK;
+        std::string err;
+        try {
+            uint32_t total = 0, KS = 1;
+            bool want_ids = false;
+            for (KwRequest* r : round) { total += r->units; KS = std::max(KS, r->out->k_stride); want_ids = want_ids || r->ids != nullptr; }
+            L.c_q.resize(total);
+            uint32_t at = 0;
+            for (KwRequest* r : round) { memcpy(L.c_q.data() + at, r->q, (size_t)r->units * sizeof(tsgpu_kw_query)); at += r->units; }
+            const size_t slots = (size_t)total * KS;
+            L.c_keys.resize(slots); L.c_scores.resize(slots * 3); L.c_tm.resize(slots); L.c_vd.resize(slots); L.c_msi.resize(slots);
+            L.c_nh.resize(total); L.c_nm.resize(total); L.c_st.resize(total); L.c_co.resize(total);
+            tsgpu_hits h;
+            h.mem = TSGPU_MEM_HOST; h.k_stride = KS;
+            h.keys = L.c_keys.data(); h.scores = L.c_scores.data(); h.text_match = L.c_tm.data(); h.vector_distance = L.c_vd.data();
+            h.match_score_index = L.c_msi.data(); h.n_hits = L.c_nh.data(); h.num_matched = L.c_nm.data(); h.status = L.c_st.data(); h.search_cutoff = L.c_co.data();
+            tsgpu_id_lists all_ids;
+            BatchOpts bo;
+            bo.keep_ids = want_ids;
+            bo.id_lists = want_ids ? &all_ids : nullptr;
+            bo.record_last = false;
+            rc = kw_batch_on_lane(ctx, L, L.c_q.data(), total, &h, bo);
+            if (rc != TSGPU_OK) err = tls_error();
+            else {
+                at = 0;
+                for (KwRequest* r : round) {
+                    tsgpu_hits& o = *r->out;
+                    const uint32_t ks = o.k_stride;
+                    for (uint32_t i = 0; i < r->units; i++) {
+                        const uint32_t g = at + i;
+                        int32_t st = L.c_st[g];
+                        uint32_t n = L.c_nh[g];
+                        if (st == TSGPU_OK && n > ks) { st = TSGPU_ERR_INVALID; n = 0; }       // (this caller's k_stride is smaller than its topster_size)
+                        o.status[i] = st;
+                        o.n_hits[i] = n;
+                        if (o.num_matched) o.num_matched[i] = st == TSGPU_OK ? L.c_nm[g] : 0;
+                        if (o.search_cutoff) o.search_cutoff[i] = L.c_co[g];
+                        const size_t src = (size_t)g * KS, dst = (size_t)i * ks;
+                        memcpy(o.keys + dst, L.c_keys.data() + src, (size_t)n * 8);
+                        memcpy(o.scores + dst * 3, L.c_scores.data() + src * 3, (size_t)n * 24);
+                        if (o.text_match) memcpy(o.text_match + dst, L.c_tm.data() + src, (size_t)n * 8);
+                        if (o.vector_distance) memcpy(o.vector_distance + dst, L.c_vd.data() + src, (size_t)n * 4);
+                        if (o.match_score_index) memcpy(o.match_score_index + dst, L.c_msi.data() + src, (size_t)n);
+                    }
+                    if (r->ids) {
+                        r->ids->begin.resize((size_t)r->units + 1);
+                        const uint64_t b0 = all_ids.begin[at];
+                        for (uint32_t i = 0; i <= r->units; i++) r->ids->begin[i] = all_ids.begin[at + i] - b0;
+                        r->ids->ids.assign(all_ids.ids.begin() + b0, all_ids.ids.begin() + all_ids.begin[at + r->units]);
+                    }
+                    at += r->units;
+                }
+            }
+        } catch (const std::bad_alloc&) { rc = TSGPU_ERR_NO_MEMORY; err = "tsgpu_keyword_search_batch: host allocation failed"; }
+        for (KwRequest* r : round) { r->rc = rc; r->err = err; }
+    };
+    ctx->kw_comb.run(me, ctx->kw_callers, ctx->batch_window_us, acquire, pick, exec);
+    if (me.rc != TSGPU_OK) return fail(me.rc, me.err);
+    if (ids_out) *ids_out = lists.release();
+    return ok();
+}
+
+extern "C" {
+
+// Entry of every keyword / wildcard search call. Small host-output calls from concurrent request threads (the reference calls
+// the seam once per query from its thread pool, src/index.cpp:3488, src/http_server.cpp:827-832) are coalesced by the
+// micro-batcher into one launch; everything else takes a lane directly.
+static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, tsgpu_id_lists** ids_out) {
     if (!ctx || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: NULL argument");
-    if (n_queries == 0) return ok();
+    if (n_queries == 0) { if (ids_out) { *ids_out = new (std::nothrow) tsgpu_id_lists; if (*ids_out) (*ids_out)->begin.assign(1, 0); } return ok(); }
     if (!queries) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: queries is NULL");
     if (!out->keys || !out->scores || !out->n_hits || !out->status) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: missing output arrays");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    return kw_batch_locked(ctx, queries, n_queries, out, wildcard, nullptr);
+    struct CallerCount { std::atomic<int>& c; explicit CallerCount(std::atomic<int>& x) : c(x) { c.fetch_add(1); } ~CallerCount() { c.fetch_sub(1); } } cc(ctx->kw_callers);
+    const bool legacy_keep = ctx->keep_ids;
+    if (!wildcard && !legacy_keep && out->mem == TSGPU_MEM_HOST && n_queries <= ctx->batch_max_queries && ctx->kw_callers.load() > 1)
+        return kw_coalesced(ctx, queries, n_queries, out, ids_out);
+    std::unique_ptr<tsgpu_id_lists> lists;
+    if (ids_out) { lists.reset(new (std::nothrow) tsgpu_id_lists); if (!lists) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_batch_ids: host allocation failed"); }
+    BatchOpts bo;
+    bo.wildcard = wildcard;
+    bo.keep_ids = legacy_keep || ids_out != nullptr;
+    bo.id_lists = lists.get();
+    bo.record_last = legacy_keep;
+    LaneLock ll(ctx, legacy_keep ? 0 : -1);          // the legacy "last batch" id API is single-caller: always lane 0
+    const int rc = kw_batch_on_lane(ctx, *ll.L, queries, n_queries, out, bo);
+    if (rc == TSGPU_OK && ids_out) *ids_out = lists.release();
+    return rc;
 }
 
-// ctx->mu held by the caller; status_host (optional) receives the per-query status codes
-static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, std::vector<int32_t>* status_host) {
+// the lane's mutex is held by the caller
+static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, const BatchOpts& bo) {
     (void)hipSetDevice(ctx->device);
-    if (ctx->dirty) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: uncommitted index changes (call tsgpu_commit)");
-    hipStream_t s = ctx->stream;
+    const std::shared_ptr<const Snapshot> snap_ref = ctx->snapshot();     // this batch runs on this snapshot, whatever is committed meanwhile
+    const Snapshot& snap = *snap_ref;
+    const bool wildcard = bo.wildcard;
+    const bool keep_ids = bo.keep_ids || bo.id_lists != nullptr;
+    std::vector<int32_t>* status_host = bo.status_host;
+    hipStream_t s = L.stream;
     try {
         static const bool host_timing = getenv("TSGPU_HOST_TIMING") != nullptr;      // diagnostics: host phases of the call on stderr
         const uint64_t t_enter = now_us();
         Plan P;
-        int rc = plan_batch(ctx, queries, n_queries, P, ctx->keep_ids, wildcard);
+        int rc = plan_batch(ctx, snap, queries, n_queries, P, keep_ids, wildcard);
         if (rc) return rc;
         const uint64_t t_planned = now_us();
         if (out->k_stride < P.max_k) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: k_stride smaller than the largest topster_size");
@@ -780,39 +964,39 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
         work.insert(work.end(), P.work_mf_small.begin(), P.work_mf_small.end());
         work.insert(work.end(), P.work_mf_big.begin(), P.work_mf_big.end());
         work.insert(work.end(), P.work_wild.begin(), P.work_wild.end());
-        if (!P.mf.empty() && (rc = upload(ctx->d_mf, P.mf.data(), P.mf.size() * sizeof(KwQueryMF), s))) return rc;
-        if ((rc = upload(ctx->d_queries, P.q.data(), P.q.size() * sizeof(KwQueryDev), s))) return rc;
-        if ((rc = upload(ctx->d_work, work.data(), work.size() * sizeof(KwWorkItem), s))) return rc;
+        if (!P.mf.empty() && (rc = upload(L.d_mf, P.mf.data(), P.mf.size() * sizeof(KwQueryMF), s))) return rc;
+        if ((rc = upload(L.d_queries, P.q.data(), P.q.size() * sizeof(KwQueryDev), s))) return rc;
+        if ((rc = upload(L.d_work, work.data(), work.size() * sizeof(KwWorkItem), s))) return rc;
         P.aux.push_back(0);
-        if ((rc = upload(ctx->d_aux, P.aux.data(), P.aux.size() * 4, s))) return rc;
+        if ((rc = upload(L.d_aux, P.aux.data(), P.aux.size() * 4, s))) return rc;
 
         // ---- scratch ----
         const size_t pw = (size_t)std::max<uint32_t>(n_work, 1);
-        if ((rc = ctx->d_part_s0.reserve(pw * KS * 8))) return rc;
-        if ((rc = ctx->d_part_s1.reserve(pw * KS * 8))) return rc;
-        if ((rc = ctx->d_part_s2.reserve(pw * KS * 8))) return rc;
-        if ((rc = ctx->d_part_key.reserve(pw * KS * 8))) return rc;
-        if ((rc = ctx->d_part_cnt.reserve(pw * 4))) return rc;
-        if ((rc = ctx->d_part_nm.reserve(pw * 4))) return rc;
-        if ((rc = ctx->d_part_ne.reserve(pw * 4))) return rc;
-        if ((rc = ctx->d_part_ow.reserve(pw * 8))) return rc;
-        if ((rc = ctx->d_part_f.reserve(pw * 16))) return rc;
-        if ((rc = ctx->d_out_ow.reserve((size_t)n_queries * 8))) return rc;
+        if ((rc = L.d_part_s0.reserve(pw * KS * 8))) return rc;
+        if ((rc = L.d_part_s1.reserve(pw * KS * 8))) return rc;
+        if ((rc = L.d_part_s2.reserve(pw * KS * 8))) return rc;
+        if ((rc = L.d_part_key.reserve(pw * KS * 8))) return rc;
+        if ((rc = L.d_part_cnt.reserve(pw * 4))) return rc;
+        if ((rc = L.d_part_nm.reserve(pw * 4))) return rc;
+        if ((rc = L.d_part_ne.reserve(pw * 4))) return rc;
+        if ((rc = L.d_part_ow.reserve(pw * 8))) return rc;
+        if ((rc = L.d_part_f.reserve(pw * 16))) return rc;
+        if ((rc = L.d_out_ow.reserve((size_t)n_queries * 8))) return rc;
         uint32_t* ids_out = nullptr;
-        if (ctx->keep_ids) {
-            if ((rc = ctx->d_ids_out.reserve(std::max<uint64_t>(P.ids_total, 1) * 4))) return rc;
-            ids_out = ctx->d_ids_out.as<uint32_t>();
+        if (keep_ids) {
+            if ((rc = L.d_ids_out.reserve(std::max<uint64_t>(P.ids_total, 1) * 4))) return rc;
+            ids_out = L.d_ids_out.as<uint32_t>();
         }
         KwPartials part;
-        part.s0 = ctx->d_part_s0.as<int64_t>(); part.s1 = ctx->d_part_s1.as<int64_t>(); part.s2 = ctx->d_part_s2.as<int64_t>();
-        part.key = ctx->d_part_key.as<int64_t>(); part.cnt = ctx->d_part_cnt.as<uint32_t>(); part.n_match = ctx->d_part_nm.as<uint32_t>();
-        part.n_emit = ctx->d_part_ne.as<uint32_t>(); part.off_words = ctx->d_part_ow.as<uint64_t>(); part.k_stride = KS;
-        part.n_match1 = ctx->d_part_f.as<uint32_t>(); part.first_rank = part.n_match1 + pw; part.last_rank = part.first_rank + pw; part.fflags = part.last_rank + pw;
+        part.s0 = L.d_part_s0.as<int64_t>(); part.s1 = L.d_part_s1.as<int64_t>(); part.s2 = L.d_part_s2.as<int64_t>();
+        part.key = L.d_part_key.as<int64_t>(); part.cnt = L.d_part_cnt.as<uint32_t>(); part.n_match = L.d_part_nm.as<uint32_t>();
+        part.n_emit = L.d_part_ne.as<uint32_t>(); part.off_words = L.d_part_ow.as<uint64_t>(); part.k_stride = KS;
+        part.n_match1 = L.d_part_f.as<uint32_t>(); part.first_rank = part.n_match1 + pw; part.last_rank = part.first_rank + pw; part.fflags = part.last_rank + pw;
 
         const size_t slots = (size_t)n_queries * KS;
         KwOut o;
         o.k_stride = KS;
-        o.off_words = ctx->d_out_ow.as<uint64_t>();
+        o.off_words = L.d_out_ow.as<uint64_t>();
         const bool dev_out = out->mem == TSGPU_MEM_DEVICE;
         if (dev_out) {
             if (!out->text_match || !out->vector_distance || !out->match_score_index || !out->num_matched)
@@ -820,25 +1004,26 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
             o.keys = out->keys; o.scores = out->scores; o.text_match = out->text_match; o.vector_distance = out->vector_distance;
             o.match_score_index = out->match_score_index; o.n_hits = out->n_hits; o.num_matched = out->num_matched;
         } else {
-            if ((rc = ctx->d_out_keys.reserve(slots * 8))) return rc;
-            if ((rc = ctx->d_out_scores.reserve(slots * 24))) return rc;
-            if ((rc = ctx->d_out_tm.reserve(slots * 8))) return rc;
-            if ((rc = ctx->d_out_vd.reserve(slots * 4))) return rc;
-            if ((rc = ctx->d_out_msi.reserve(slots))) return rc;
-            if ((rc = ctx->d_out_nh.reserve((size_t)n_queries * 4))) return rc;
-            if ((rc = ctx->d_out_nm.reserve((size_t)n_queries * 8))) return rc;
-            o.keys = ctx->d_out_keys.as<uint64_t>(); o.scores = ctx->d_out_scores.as<int64_t>(); o.text_match = ctx->d_out_tm.as<int64_t>();
-            o.vector_distance = ctx->d_out_vd.as<float>(); o.match_score_index = ctx->d_out_msi.as<int8_t>();
-            o.n_hits = ctx->d_out_nh.as<uint32_t>(); o.num_matched = ctx->d_out_nm.as<uint64_t>();
+            if ((rc = L.d_out_keys.reserve(slots * 8))) return rc;
+            if ((rc = L.d_out_scores.reserve(slots * 24))) return rc;
+            if ((rc = L.d_out_tm.reserve(slots * 8))) return rc;
+            if ((rc = L.d_out_vd.reserve(slots * 4))) return rc;
+            if ((rc = L.d_out_msi.reserve(slots))) return rc;
+            if ((rc = L.d_out_nh.reserve((size_t)n_queries * 4))) return rc;
+            if ((rc = L.d_out_nm.reserve((size_t)n_queries * 8))) return rc;
+            o.keys = L.d_out_keys.as<uint64_t>(); o.scores = L.d_out_scores.as<int64_t>(); o.text_match = L.d_out_tm.as<int64_t>();
+            o.vector_distance = L.d_out_vd.as<float>(); o.match_score_index = L.d_out_msi.as<int8_t>();
+            o.n_hits = L.d_out_nh.as<uint32_t>(); o.num_matched = L.d_out_nm.as<uint64_t>();
         }
 
         // ---- launch ----
         const uint64_t t_uploaded = now_us();
-        const IndexView v = make_view(ctx);
-        const KwQueryDev* dq = ctx->d_queries.as<KwQueryDev>();
-        const KwWorkItem* dw = ctx->d_work.as<KwWorkItem>();
-        const uint32_t* daux = ctx->d_aux.as<uint32_t>();
-        TSGPU_HIP_TRY(hipEventRecord(ctx->ev[0], s));
+        IndexView v = make_view(ctx, snap);
+        v.mf = L.d_mf.as<KwQueryMF>();
+        const KwQueryDev* dq = L.d_queries.as<KwQueryDev>();
+        const KwWorkItem* dw = L.d_work.as<KwWorkItem>();
+        const uint32_t* daux = L.d_aux.as<uint32_t>();
+        TSGPU_HIP_TRY(hipEventRecord(L.ev[0], s));
         auto shifted = [&](size_t sh) {                 // every kernel indexes the partials by its own blockIdx: shift the bases
             KwPartials pb = part;
             pb.s0 += sh * KS; pb.s1 += sh * KS; pb.s2 += sh * KS; pb.key += sh * KS;
@@ -846,8 +1031,8 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
             pb.n_match1 += sh; pb.first_rank += sh; pb.last_rank += sh; pb.fflags += sh;
             return pb;
         };
-        ctx->kw_last_hit_groups = 0;
-        ctx->kw_last_hit_records = 0;
+        uint32_t hit_groups = 0;
+        uint64_t hit_records = 0;
         // single-field tables (<= 3 tokens / up to 10 tokens): find + score kernels when the hit buffer fits, else the fused kernel.
         // A work item can yield at most one hit per driver id, so its segment of the hit buffer holds (blk_end - blk_begin) * 256
         // records of 1 + TMAX words; the items run in groups whose segments fit the budget.
@@ -864,7 +1049,7 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
             if (two) {
                 uint64_t largest = 0, all = 0;
                 for (size_t i = 0; i < nws; i++) { const uint64_t c = (uint64_t)(tab[i].blk_end - tab[i].blk_begin) * BLOCK_IDS; largest = std::max(largest, c); all += c; }
-                ctx->kw_last_hit_records += all;
+                hit_records += all;
                 const uint64_t budget = std::max<uint64_t>(ctx->kw_hit_buffer_records ? ctx->kw_hit_buffer_records : ((uint64_t)ctx->kw_hit_buffer_mb << 20) / rec_bytes, largest);
                 hoff.resize(nws);
                 uint64_t used = 0;
@@ -876,20 +1061,20 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
                 group_start.push_back(nws);
                 two = group_start.size() <= 3;          // each group drains the chip between its two kernels: beyond two groups the fused kernel wins
             }
-            if (two && ctx->d_hits.reserve(std::max<uint64_t>(need, 1) * rec_bytes)) {
+            if (two && L.d_hits.reserve(std::max<uint64_t>(need, 1) * rec_bytes)) {
                 (void)hipGetLastError();                // no room for the hit buffer: the fused kernel needs none
                 two = false;
             }
             if (two) {
-                ctx->kw_last_hit_groups += (uint32_t)group_start.size() - 1;
-                DevBuf& offbuf = ctx->d_hit_off_tab[(MFT ? 2 : 0) + (TM == 3 ? 0 : 1)];
+                hit_groups += (uint32_t)group_start.size() - 1;
+                DevBuf& offbuf = L.d_hit_off_tab[(MFT ? 2 : 0) + (TM == 3 ? 0 : 1)];
                 int rc2;
                 if ((rc2 = upload(offbuf, hoff.data(), nws * 8, s))) return rc2;
                 for (size_t gi = 0; gi + 1 < group_start.size(); gi++) {
                     const size_t a = group_start[gi], b = group_start[gi + 1];
                     if (b <= a) continue;
-                    if constexpr (MFT) launch_find_score_mf<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, ctx->d_hits.as<uint32_t>(), offbuf.as<uint64_t>() + a);
-                    else launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, ctx->d_hits.as<uint32_t>(), offbuf.as<uint64_t>() + a);
+                    if constexpr (MFT) launch_find_score_mf<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, L.d_hits.as<uint32_t>(), offbuf.as<uint64_t>() + a);
+                    else launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, L.d_hits.as<uint32_t>(), offbuf.as<uint64_t>() + a);
                 }
             } else if constexpr (MFT) launch_search_mf_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out);
             else launch_search_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out, P.any_s2);
@@ -909,9 +1094,9 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
             else if (cap == 1024) hipLaunchKernelGGL((kw_wildcard_kernel<1024>), dim3(nw), dim3(KW_THREADS), 0, s, v, dq, dw + sh, shifted(sh), daux, ids_out);
             else hipLaunchKernelGGL((kw_wildcard_kernel<2048>), dim3(nw), dim3(KW_THREADS), 0, s, v, dq, dw + sh, shifted(sh), daux, ids_out);
         }
-        TSGPU_HIP_TRY(hipEventRecord(ctx->ev[1], s));
+        TSGPU_HIP_TRY(hipEventRecord(L.ev[1], s));
         launch_merge(cap, s, n_queries, dq, part, o, ids_out, dw);
-        TSGPU_HIP_TRY(hipEventRecord(ctx->ev[2], s));
+        TSGPU_HIP_TRY(hipEventRecord(L.ev[2], s));
         TSGPU_HIP_TRY(hipGetLastError());
         const uint64_t t_launched = now_us();
 
@@ -925,7 +1110,7 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
             const bool stage = slots * 45 + (size_t)n_queries * 12 <= (8u << 20);
             size_t at = 0;
             uint8_t* pin = nullptr;
-            if (stage) { if ((rc = ctx->h_out.reserve(slots * 45 + (size_t)n_queries * 12 + 64))) return rc; pin = (uint8_t*)ctx->h_out.p; }
+            if (stage) { if ((rc = L.h_out.reserve(slots * 45 + (size_t)n_queries * 12 + 64))) return rc; pin = (uint8_t*)L.h_out.p; }
             auto d2h = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
                 if (!stage) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
                 staged.push_back({dst, at, bytes});
@@ -948,17 +1133,14 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
         }
         TSGPU_HIP_TRY(hipMemcpyAsync(off_words.data(), o.off_words, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
-        for (const Staged& c : staged) memcpy(c.dst, (const uint8_t*)ctx->h_out.p + c.off, c.bytes);
+        for (const Staged& c : staged) memcpy(c.dst, (const uint8_t*)L.h_out.p + c.off, c.bytes);
         if (status_host) status_host->assign(P.status.begin(), P.status.end());
         const uint64_t t_synced = now_us();
 
         // ---- bookkeeping: timings + algorithmic bytes ----
         float ms_a = 0, ms_b = 0;
-        (void)hipEventElapsedTime(&ms_a, ctx->ev[0], ctx->ev[1]);
-        (void)hipEventElapsedTime(&ms_b, ctx->ev[1], ctx->ev[2]);
-        ctx->timings.kw_search_ms = ms_a;
-        ctx->timings.kw_merge_ms = ms_b;
-        ctx->timings.total_ms = ms_a + ms_b;
+        (void)hipEventElapsedTime(&ms_a, L.ev[0], L.ev[1]);
+        (void)hipEventElapsedTime(&ms_b, L.ev[1], L.ev[2]);
         uint64_t bytes = P.list_bytes;
         if (!dev_out && out->num_matched) {
             for (uint32_t i = 0; i < n_queries; i++) {
@@ -969,24 +1151,64 @@ static int kw_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32
         } else {
             for (uint32_t i = 0; i < n_queries; i++) bytes += 4ull * off_words[i];
         }
-        ctx->timings.kw_algorithmic_bytes = bytes;
-        // remember where matched ids live
-        ctx->last_chunk_blocks = P.chunk_blocks;
-        ctx->last_ids_off.assign(n_queries, 0);
-        ctx->last_ids_cap.assign(n_queries, 0);
-        ctx->last_chunk_emit.assign(n_queries, {});
-        ctx->last_chunk_off.assign(n_queries, {});
-        ctx->last_ids_unsorted.assign(n_queries, 0);
-        if (ctx->keep_ids && n_work) {
-            std::vector<uint32_t> ne(n_work);
+        {
+            std::lock_guard<std::mutex> tl(ctx->tm_mu);
+            ctx->timings.kw_search_ms = ms_a;
+            ctx->timings.kw_merge_ms = ms_b;
+            ctx->timings.total_ms = ms_a + ms_b;
+            ctx->timings.kw_algorithmic_bytes = bytes;
+            ctx->kw_last_hit_groups = hit_groups;
+            ctx->kw_last_hit_records = hit_records;
+        }
+        // ---- matched ids (id_buff / all_result_ids, src/index.cpp:5549, 5565): every work item left an ascending segment ----
+        std::vector<uint32_t> ne;
+        if (keep_ids && n_work && (bo.record_last || bo.id_lists)) {
+            ne.resize(n_work);
             TSGPU_HIP_TRY(hipMemcpy(ne.data(), part.n_emit, (size_t)n_work * 4, hipMemcpyDeviceToHost));
+        }
+        if (bo.record_last) {                        // legacy single-caller API (tsgpu_result_ids): remember where the segments live
+            L.last_ids_off.assign(n_queries, 0);
+            L.last_chunk_emit.assign(n_queries, {});
+            L.last_chunk_off.assign(n_queries, {});
+            L.last_ids_unsorted.assign(n_queries, 0);
+            if (keep_ids && n_work) {
+                for (uint32_t i = 0; i < n_queries; i++) {
+                    if (P.status[i] != TSGPU_OK || P.q[i].n_work == 0) continue;
+                    L.last_ids_off[i] = P.q[i].ids_out_off;
+                    L.last_chunk_emit[i].assign(ne.begin() + P.q[i].first_work, ne.begin() + P.q[i].first_work + P.q[i].n_work);
+                    L.last_chunk_off[i].resize(P.q[i].n_work);
+                    for (uint32_t c = 0; c < P.q[i].n_work; c++) L.last_chunk_off[i][c] = work[P.q[i].first_work + c].ids_out_off;
+                    L.last_ids_unsorted[i] = P.q[i].mf_index != KW_NONE;      // several driver lists: segments are sorted, their union is not
+                }
+            }
+        }
+        if (bo.id_lists) {
+            // per-call id lists: the segments are gathered into one dense array on the device (one launch, one download) and belong
+            // to THIS call — concurrent callers never see each other's ids
+            tsgpu_id_lists& il = *bo.id_lists;
+            il.begin.assign((size_t)n_queries + 1, 0);
+            std::vector<KwIdCopy> segs;
+            uint64_t at = 0;
             for (uint32_t i = 0; i < n_queries; i++) {
+                il.begin[i] = at;
                 if (P.status[i] != TSGPU_OK || P.q[i].n_work == 0) continue;
-                ctx->last_ids_off[i] = P.q[i].ids_out_off;
-                ctx->last_chunk_emit[i].assign(ne.begin() + P.q[i].first_work, ne.begin() + P.q[i].first_work + P.q[i].n_work);
-                ctx->last_chunk_off[i].resize(P.q[i].n_work);
-                for (uint32_t c = 0; c < P.q[i].n_work; c++) ctx->last_chunk_off[i][c] = work[P.q[i].first_work + c].ids_out_off;
-                ctx->last_ids_unsorted[i] = P.q[i].mf_index != KW_NONE;      // several driver lists: segments are sorted, their union is not
+                for (uint32_t c = 0; c < P.q[i].n_work; c++) {
+                    const uint32_t cnt = ne[P.q[i].first_work + c];
+                    if (!cnt) continue;
+                    segs.push_back({P.q[i].ids_out_off + work[P.q[i].first_work + c].ids_out_off, at, cnt, 0u});
+                    at += cnt;
+                }
+            }
+            il.begin[n_queries] = at;
+            il.ids.resize(at);
+            if (at) {
+                if ((rc = L.d_idflat.reserve(at * 4)) || (rc = upload(L.d_idseg, segs.data(), segs.size() * sizeof(KwIdCopy), s))) return rc;
+                hipLaunchKernelGGL(kw_ids_gather_kernel, dim3((uint32_t)segs.size()), dim3(KW_THREADS), 0, s, (const uint32_t*)ids_out, L.d_idseg.as<KwIdCopy>(), L.d_idflat.as<uint32_t>());
+                TSGPU_HIP_TRY(hipGetLastError());
+                TSGPU_HIP_TRY(hipMemcpyAsync(il.ids.data(), L.d_idflat.p, at * 4, hipMemcpyDeviceToHost, s));
+                TSGPU_HIP_TRY(hipStreamSynchronize(s));
+                for (uint32_t i = 0; i < n_queries; i++)                      // several driver lists (query_by over several fields): ascending union
+                    if (P.q[i].mf_index != KW_NONE && P.status[i] == TSGPU_OK) std::sort(il.ids.begin() + il.begin[i], il.ids.begin() + il.begin[i + 1]);
             }
         }
         if (host_timing)
@@ -1049,28 +1271,30 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
     const bool dev_out = out->mem == TSGPU_MEM_DEVICE;
     if (dev_out && (!out->text_match || !out->vector_distance || !out->match_score_index || !out->num_matched))
         return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_candidates_batch: device output needs every tsgpu_hits array");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    LaneLock ll(ctx, 0);                              // (tsgpu_candidates_result_ids reads this lane's bitmaps afterwards)
+    KwLane& L = *ll.L;
     (void)hipSetDevice(ctx->device);
-    hipStream_t s = ctx->stream;
+    hipStream_t s = L.stream;
     try {
         int rc;
         const size_t pslots = (size_t)std::max<uint32_t>(n_combos, 1) * KS, pn = std::max<uint32_t>(n_combos, 1);
-        if ((rc = ctx->d_cand_keys.reserve(pslots * 8)) || (rc = ctx->d_cand_scores.reserve(pslots * 24)) || (rc = ctx->d_cand_tm.reserve(pslots * 8)) ||
-            (rc = ctx->d_cand_vd.reserve(pslots * 4)) || (rc = ctx->d_cand_msi.reserve(pslots)) || (rc = ctx->d_cand_nh.reserve(pn * 4)) ||
-            (rc = ctx->d_cand_nm.reserve(pn * 8)) || (rc = ctx->d_cand_st.reserve(pn * 4)))
+        if ((rc = L.d_cand_keys.reserve(pslots * 8)) || (rc = L.d_cand_scores.reserve(pslots * 24)) || (rc = L.d_cand_tm.reserve(pslots * 8)) ||
+            (rc = L.d_cand_vd.reserve(pslots * 4)) || (rc = L.d_cand_msi.reserve(pslots)) || (rc = L.d_cand_nh.reserve(pn * 4)) ||
+            (rc = L.d_cand_nm.reserve(pn * 8)) || (rc = L.d_cand_st.reserve(pn * 4)))
             return rc;
         tsgpu_hits pass;
         memset(&pass, 0, sizeof(pass));
         pass.mem = TSGPU_MEM_DEVICE; pass.k_stride = KS;
-        pass.keys = ctx->d_cand_keys.as<uint64_t>(); pass.scores = ctx->d_cand_scores.as<int64_t>(); pass.text_match = ctx->d_cand_tm.as<int64_t>();
-        pass.vector_distance = ctx->d_cand_vd.as<float>(); pass.match_score_index = ctx->d_cand_msi.as<int8_t>();
-        pass.n_hits = ctx->d_cand_nh.as<uint32_t>(); pass.num_matched = ctx->d_cand_nm.as<uint64_t>(); pass.status = ctx->d_cand_st.as<int32_t>();
+        pass.keys = L.d_cand_keys.as<uint64_t>(); pass.scores = L.d_cand_scores.as<int64_t>(); pass.text_match = L.d_cand_tm.as<int64_t>();
+        pass.vector_distance = L.d_cand_vd.as<float>(); pass.match_score_index = L.d_cand_msi.as<int8_t>();
+        pass.n_hits = L.d_cand_nh.as<uint32_t>(); pass.num_matched = L.d_cand_nm.as<uint64_t>(); pass.status = L.d_cand_st.as<int32_t>();
         std::vector<int32_t> st;
         if (n_combos) {
-            const bool keep_prev = ctx->keep_ids;
-            if (found) ctx->keep_ids = true;                   // the union needs every pass's emitted ids
-            rc = kw_batch_locked(ctx, combos, n_combos, &pass, false, &st);
-            ctx->keep_ids = keep_prev;
+            BatchOpts bo;
+            bo.keep_ids = found != nullptr;                    // the union needs every pass's emitted ids
+            bo.status_host = &st;
+            bo.record_last = true;
+            rc = kw_batch_on_lane(ctx, L, combos, n_combos, &pass, bo);
             if (rc) return rc;
         }
         // a group runs only if every combination of it ran; otherwise it reports the first failing status and no hits
@@ -1083,7 +1307,7 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
                 range[3 * g + 2] = std::min(resolve_topster_size(ctx, combos[group_begin[g]]), KS);      // the shared Topster is sized once, by the first pass
             }
         }
-        if ((rc = upload(ctx->d_cand_gb, range.data(), range.size() * 4, s))) return rc;
+        if ((rc = upload(L.d_cand_gb, range.data(), range.size() * 4, s))) return rc;
 
         const size_t slots = (size_t)n_groups * KS;
         KwOut o;
@@ -1094,19 +1318,19 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
             o.match_score_index = out->match_score_index; o.n_hits = out->n_hits; o.num_matched = out->num_matched;
             qi_dev = query_index;
         } else {
-            if ((rc = ctx->d_out_keys.reserve(slots * 8)) || (rc = ctx->d_out_scores.reserve(slots * 24)) || (rc = ctx->d_out_tm.reserve(slots * 8)) ||
-                (rc = ctx->d_out_vd.reserve(slots * 4)) || (rc = ctx->d_out_msi.reserve(slots)) || (rc = ctx->d_out_nh.reserve((size_t)n_groups * 4)) ||
-                (rc = ctx->d_out_nm.reserve((size_t)n_groups * 8)) || (rc = ctx->d_cand_qi.reserve(slots * 4)))
+            if ((rc = L.d_out_keys.reserve(slots * 8)) || (rc = L.d_out_scores.reserve(slots * 24)) || (rc = L.d_out_tm.reserve(slots * 8)) ||
+                (rc = L.d_out_vd.reserve(slots * 4)) || (rc = L.d_out_msi.reserve(slots)) || (rc = L.d_out_nh.reserve((size_t)n_groups * 4)) ||
+                (rc = L.d_out_nm.reserve((size_t)n_groups * 8)) || (rc = L.d_cand_qi.reserve(slots * 4)))
                 return rc;
-            o.keys = ctx->d_out_keys.as<uint64_t>(); o.scores = ctx->d_out_scores.as<int64_t>(); o.text_match = ctx->d_out_tm.as<int64_t>();
-            o.vector_distance = ctx->d_out_vd.as<float>(); o.match_score_index = ctx->d_out_msi.as<int8_t>();
-            o.n_hits = ctx->d_out_nh.as<uint32_t>(); o.num_matched = ctx->d_out_nm.as<uint64_t>();
-            qi_dev = query_index ? ctx->d_cand_qi.as<uint32_t>() : nullptr;
+            o.keys = L.d_out_keys.as<uint64_t>(); o.scores = L.d_out_scores.as<int64_t>(); o.text_match = L.d_out_tm.as<int64_t>();
+            o.vector_distance = L.d_out_vd.as<float>(); o.match_score_index = L.d_out_msi.as<int8_t>();
+            o.n_hits = L.d_out_nh.as<uint32_t>(); o.num_matched = L.d_out_nm.as<uint64_t>();
+            qi_dev = query_index ? L.d_cand_qi.as<uint32_t>() : nullptr;
         }
         KwCandIn in;
         in.keys = pass.keys; in.scores = pass.scores; in.text_match = pass.text_match; in.vector_distance = pass.vector_distance;
         in.match_score_index = pass.match_score_index; in.n_hits = pass.n_hits; in.num_matched = pass.num_matched;
-        in.group_range = ctx->d_cand_gb.as<uint32_t>(); in.k_in = KS;
+        in.group_range = L.d_cand_gb.as<uint32_t>(); in.k_in = KS;
         const uint64_t cap_need = (uint64_t)std::max<uint32_t>(max_passes, 1) * KS;
         if (cap_need <= 512) hipLaunchKernelGGL((kw_candidates_merge_kernel<512>), dim3(n_groups), dim3(KW_THREADS), 0, s, in, o, qi_dev);
         else if (cap_need <= 1024) hipLaunchKernelGGL((kw_candidates_merge_kernel<1024>), dim3(n_groups), dim3(KW_THREADS), 0, s, in, o, qi_dev);
@@ -1115,8 +1339,8 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
         TSGPU_HIP_TRY(hipGetLastError());
 
         // ---- all_result_ids: one bitmap per group ----
-        ctx->last_cand_groups = 0;
-        ctx->last_cand_found.assign(n_groups, 0);
+        L.last_cand_groups = 0;
+        L.last_cand_found.assign(n_groups, 0);
         if (found) {
             const uint64_t words = std::max<uint64_t>(((uint64_t)ctx->num_docs + 31) / 32, 1);
             if ((uint64_t)n_groups * words * 4 > (8ull << 30))
@@ -1125,25 +1349,25 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
             for (uint32_t g = 0; g < n_groups; g++) {
                 if (gstatus[g] != TSGPU_OK) continue;
                 for (uint32_t e = group_begin[g]; e < group_begin[g + 1]; e++)
-                    for (size_t c = 0; c < ctx->last_chunk_emit[e].size(); c++)
-                        if (ctx->last_chunk_emit[e][c]) segs.push_back({ctx->last_ids_off[e] + ctx->last_chunk_off[e][c], ctx->last_chunk_emit[e][c], g});
+                    for (size_t c = 0; c < L.last_chunk_emit[e].size(); c++)
+                        if (L.last_chunk_emit[e][c]) segs.push_back({L.last_ids_off[e] + L.last_chunk_off[e][c], L.last_chunk_emit[e][c], g});
             }
-            if ((rc = ctx->d_cand_bits.reserve((size_t)n_groups * words * 4)) || (rc = ctx->d_cand_found.reserve((size_t)n_groups * 8))) return rc;
-            TSGPU_HIP_TRY(hipMemsetAsync(ctx->d_cand_bits.p, 0, (size_t)n_groups * words * 4, s));
-            TSGPU_HIP_TRY(hipMemsetAsync(ctx->d_cand_found.p, 0, (size_t)n_groups * 8, s));
+            if ((rc = L.d_cand_bits.reserve((size_t)n_groups * words * 4)) || (rc = L.d_cand_found.reserve((size_t)n_groups * 8))) return rc;
+            TSGPU_HIP_TRY(hipMemsetAsync(L.d_cand_bits.p, 0, (size_t)n_groups * words * 4, s));
+            TSGPU_HIP_TRY(hipMemsetAsync(L.d_cand_found.p, 0, (size_t)n_groups * 8, s));
             if (!segs.empty()) {
-                if ((rc = upload(ctx->d_cand_segs, segs.data(), segs.size() * sizeof(KwIdSeg), s))) return rc;
-                hipLaunchKernelGGL(kw_idset_mark_kernel, dim3((uint32_t)segs.size(), 8), dim3(KW_THREADS), 0, s, ctx->d_ids_out.as<uint32_t>(),
-                                   ctx->d_cand_segs.as<KwIdSeg>(), ctx->d_cand_bits.as<uint32_t>(), words);
+                if ((rc = upload(L.d_cand_segs, segs.data(), segs.size() * sizeof(KwIdSeg), s))) return rc;
+                hipLaunchKernelGGL(kw_idset_mark_kernel, dim3((uint32_t)segs.size(), 8), dim3(KW_THREADS), 0, s, L.d_ids_out.as<uint32_t>(),
+                                   L.d_cand_segs.as<KwIdSeg>(), L.d_cand_bits.as<uint32_t>(), words);
                 const uint32_t gy = (uint32_t)std::min<uint64_t>(64, (words + KW_THREADS - 1) / KW_THREADS);
-                hipLaunchKernelGGL(kw_idset_count_kernel, dim3(n_groups, gy), dim3(KW_THREADS), 0, s, ctx->d_cand_bits.as<uint32_t>(), words,
-                                   ctx->d_cand_found.as<unsigned long long>());
+                hipLaunchKernelGGL(kw_idset_count_kernel, dim3(n_groups, gy), dim3(KW_THREADS), 0, s, L.d_cand_bits.as<uint32_t>(), words,
+                                   L.d_cand_found.as<unsigned long long>());
                 TSGPU_HIP_TRY(hipGetLastError());
             }
-            TSGPU_HIP_TRY(hipMemcpyAsync(ctx->last_cand_found.data(), ctx->d_cand_found.p, (size_t)n_groups * 8, hipMemcpyDeviceToHost, s));
-            if (dev_out) TSGPU_HIP_TRY(hipMemcpyAsync(found, ctx->d_cand_found.p, (size_t)n_groups * 8, hipMemcpyDeviceToDevice, s));
-            ctx->last_cand_groups = n_groups;
-            ctx->last_cand_words = words;
+            TSGPU_HIP_TRY(hipMemcpyAsync(L.last_cand_found.data(), L.d_cand_found.p, (size_t)n_groups * 8, hipMemcpyDeviceToHost, s));
+            if (dev_out) TSGPU_HIP_TRY(hipMemcpyAsync(found, L.d_cand_found.p, (size_t)n_groups * 8, hipMemcpyDeviceToDevice, s));
+            L.last_cand_groups = n_groups;
+            L.last_cand_words = words;
         }
 
         // ---- results ----
@@ -1163,43 +1387,47 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
             if (out->search_cutoff) TSGPU_HIP_TRY(hipMemsetAsync(out->search_cutoff, 0, (size_t)n_groups * 4, s));
         }
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
-        if (found && !dev_out) for (uint32_t g = 0; g < n_groups; g++) found[g] = ctx->last_cand_found[g];
+        if (found && !dev_out) for (uint32_t g = 0; g < n_groups; g++) found[g] = L.last_cand_found[g];
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_candidates_batch: host allocation failed"); }
     return ok();
 }
 
 uint64_t tsgpu_candidates_result_ids(tsgpu_ctx* ctx, uint32_t group, uint32_t* out_host, uint64_t cap) {
     if (!ctx) return 0;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    LaneLock ll(ctx, 0);
+    KwLane& L = *ll.L;
     (void)hipSetDevice(ctx->device);
-    if (group >= ctx->last_cand_groups) return 0;
-    const uint64_t total = ctx->last_cand_found[group];
+    if (group >= L.last_cand_groups) return 0;
+    const uint64_t total = L.last_cand_found[group];
     if (!out_host || cap == 0 || total == 0) return total;
     const uint64_t m = std::min(total, cap);
-    if (ctx->d_cand_ids.reserve(m * 4)) return 0;
-    hipLaunchKernelGGL(kw_idset_expand_kernel, dim3(1), dim3(KW_THREADS), 0, ctx->stream, ctx->d_cand_bits.as<uint32_t>() + (uint64_t)group * ctx->last_cand_words,
-                       ctx->last_cand_words, ctx->d_cand_ids.as<uint32_t>(), m);
-    if (hipMemcpyAsync(out_host, ctx->d_cand_ids.p, m * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return 0;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 0;
+    if (L.d_cand_ids.reserve(m * 4)) return 0;
+    hipLaunchKernelGGL(kw_idset_expand_kernel, dim3(1), dim3(KW_THREADS), 0, L.stream, L.d_cand_bits.as<uint32_t>() + (uint64_t)group * L.last_cand_words,
+                       L.last_cand_words, L.d_cand_ids.as<uint32_t>(), m);
+    if (hipMemcpyAsync(out_host, L.d_cand_ids.p, m * 4, hipMemcpyDeviceToHost, L.stream) != hipSuccess) return 0;
+    if (hipStreamSynchronize(L.stream) != hipSuccess) return 0;
     return total;
 }
 
+// legacy single-caller form (the ids of the LAST batch run with tsgpu_keep_result_ids(ctx, 1)); concurrent callers use
+// tsgpu_keyword_search_batch_ids, whose id lists belong to the call
 uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64_t cap) {
     if (!ctx) return 0;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    LaneLock ll(ctx, 0);
+    KwLane& L = *ll.L;
     (void)hipSetDevice(ctx->device);
-    if (q >= ctx->last_chunk_emit.size()) return 0;
+    if (q >= L.last_chunk_emit.size()) return 0;
     uint64_t total = 0;
-    const auto& ce = ctx->last_chunk_emit[q];
+    const auto& ce = L.last_chunk_emit[q];
     for (size_t c = 0; c < ce.size(); c++) total += ce[c];
     if (!out_host || cap == 0) return total;
-    if (ctx->last_ids_unsorted[q]) {
+    if (L.last_ids_unsorted[q]) {
         // multi-field query: one ascending segment per (driver field, chunk); id_buff is ascending in the reference -> merge on the host
         std::vector<uint32_t> all(total);
         uint64_t at = 0;
         for (size_t c = 0; c < ce.size(); c++) {
             if (!ce[c]) continue;
-            if (hipMemcpy(all.data() + at, ctx->d_ids_out.as<uint32_t>() + ctx->last_ids_off[q] + ctx->last_chunk_off[q][c], (size_t)ce[c] * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+            if (hipMemcpy(all.data() + at, L.d_ids_out.as<uint32_t>() + L.last_ids_off[q] + L.last_chunk_off[q][c], (size_t)ce[c] * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
             at += ce[c];
         }
         std::sort(all.begin(), all.end());
@@ -1208,9 +1436,9 @@ uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64
     }
     uint64_t done = 0;
     for (size_t c = 0; c < ce.size() && done < cap; c++) {
-        const uint64_t seg = ctx->last_ids_off[q] + ctx->last_chunk_off[q][c];
+        const uint64_t seg = L.last_ids_off[q] + L.last_chunk_off[q][c];
         const uint64_t m = std::min<uint64_t>(ce[c], cap - done);
-        if (m && hipMemcpy(out_host + done, ctx->d_ids_out.as<uint32_t>() + seg, m * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+        if (m && hipMemcpy(out_host + done, L.d_ids_out.as<uint32_t>() + seg, m * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
         done += m;
     }
     return total;
@@ -1229,7 +1457,7 @@ int tsgpu_debug_prof(tsgpu_ctx* ctx, int reset, uint64_t* out16) {
 
 int tsgpu_last_timings(tsgpu_ctx* ctx, tsgpu_timings* out) {
     if (!ctx || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_last_timings: NULL argument");
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> lk(ctx->tm_mu);
     *out = ctx->timings;
     return ok();
 }

@@ -8,6 +8,10 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <condition_variable>
+#include <memory>
+#include <atomic>
+#include <thread>
 #include <unordered_map>
 #include <algorithm>
 #include <chrono>
@@ -15,6 +19,7 @@
 #include "../../include/tsgpu.h"
 #include "tsgpu_format.h"
 #include "tsgpu_pack.h"
+#include "tsgpu_batcher.h"
 
 namespace tsgpu {
 
@@ -67,8 +72,13 @@ struct FieldHost {
     std::unordered_map<uint32_t, PackedList> terms;   // pending + committed host copies (source of the next snapshot)
 };
 
-struct Snapshot {            // immutable HBM image of all posting lists
+struct Snapshot {            // immutable HBM image of all posting lists; published by tsgpu_commit, shared (RCU) by the searches that started on it
     DevBuf lists, blk_last, blk_ids, blk_meta, ids_payload, payload;
+    std::unordered_map<uint32_t, bool> field_is_array;              // the query_by fields of this snapshot (field id -> string[])
+    Snapshot() = default;
+    Snapshot(const Snapshot&) = delete;
+    Snapshot& operator=(const Snapshot&) = delete;
+    ~Snapshot() { lists.release(); blk_last.release(); blk_ids.release(); blk_meta.release(); ids_payload.release(); payload.release(); }
     std::vector<ListDesc> h_lists;                                  // host copy of the descriptors
     std::unordered_map<uint64_t, uint32_t> handle_of;               // (field<<32 | term) -> list handle
     // the same map as flat tables for small field / term ids (the planner resolves three tokens per query, 10 000 queries per
@@ -80,40 +90,99 @@ struct Snapshot {            // immutable HBM image of all posting lists
         return it == handle_of.end() ? 0xFFFFFFFFu : it->second;
     }
     uint64_t bytes = 0;
+    uint32_t num_docs = 0;                                          // num_seq_ids() when the snapshot was published
 };
 
 struct ColumnDev { DevBuf data; uint32_t n = 0; std::vector<int64_t> host; /* mirror for the <=k-hit host steps (vector / hybrid) */ };
 
 struct VecField;             // tsgpu_vec.hip
 
-}  // namespace tsgpu
-
-struct tsgpu_ctx {
-    int device = 0;
+// One in-flight keyword batch: its own stream, events and every piece of per-batch scratch (plan upload, partial top-K lists,
+// hit records, outputs). The context owns two lanes: while one batch runs on the GPU the next is planned, uploaded and launched
+// on the other stream — searches never serialise on one global mutex, only on the lane they run on.
+struct KwLane {
+    std::mutex mu;                                   // one batch at a time per lane
+    std::atomic<int> waiters{0};
     hipStream_t stream = nullptr;
     bool own_stream = true;
-    std::mutex mu;                                   // serialises batch execution on the shared scratch
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    DevBuf d_queries, d_work, d_aux, d_ids_out, d_mf;
+    DevBuf d_part_s0, d_part_s1, d_part_s2, d_part_key, d_part_cnt, d_part_nm, d_part_ne, d_part_ow, d_part_f;
+    DevBuf d_out_keys, d_out_scores, d_out_tm, d_out_vd, d_out_msi, d_out_nh, d_out_nm, d_out_ow, d_out_cut;
+    // candidate-combination batches (tsgpu_keyword_search_candidates_batch): per-pass hits, group table, id-set bitmaps
+    DevBuf d_cand_keys, d_cand_scores, d_cand_tm, d_cand_vd, d_cand_msi, d_cand_nh, d_cand_nm, d_cand_st, d_cand_gb, d_cand_qi, d_cand_found,
+           d_cand_segs, d_cand_bits, d_cand_ids;
+    DevBuf d_hits, d_hit_off_tab[4];                 // hit records; per work table (<=3 / <=10 tokens, one / several fields) the items' record offsets
+    DevBuf d_idseg, d_idflat;                        // per-call id lists: segment table + the gathered ids
+    PinBuf h_out, h_ids;
+    // host side of a coalesced round (micro-batcher): the round's queries and its results before they are handed to the callers
+    std::vector<tsgpu_kw_query> c_q;
+    std::vector<uint64_t> c_keys, c_nm;
+    std::vector<int64_t> c_scores, c_tm;
+    std::vector<float> c_vd;
+    std::vector<int8_t> c_msi;
+    std::vector<uint32_t> c_nh;
+    std::vector<int32_t> c_st, c_co;
+    // state of the lane's last batch (legacy single-caller API: tsgpu_result_ids / tsgpu_candidates_result_ids)
+    uint32_t last_cand_groups = 0;
+    uint64_t last_cand_words = 0;
+    std::vector<uint64_t> last_cand_found;
+    std::vector<uint64_t> last_ids_off;              // per query offset into d_ids_out of the last batch
+    std::vector<std::vector<uint32_t>> last_chunk_emit;  // ids emitted per work item of the query
+    std::vector<std::vector<uint32_t>> last_chunk_off;   // where each work item's id segment starts (relative to last_ids_off)
+    std::vector<uint8_t> last_ids_unsorted;
+    void release() {
+        DevBuf* bufs[] = {&d_queries, &d_work, &d_aux, &d_ids_out, &d_mf, &d_part_s0, &d_part_s1, &d_part_s2, &d_part_key, &d_part_cnt, &d_part_nm, &d_part_ne,
+                          &d_part_ow, &d_part_f, &d_out_keys, &d_out_scores, &d_out_tm, &d_out_vd, &d_out_msi, &d_out_nh, &d_out_nm, &d_out_ow, &d_out_cut,
+                          &d_cand_keys, &d_cand_scores, &d_cand_tm, &d_cand_vd, &d_cand_msi, &d_cand_nh, &d_cand_nm, &d_cand_st, &d_cand_gb, &d_cand_qi,
+                          &d_cand_found, &d_cand_segs, &d_cand_bits, &d_cand_ids, &d_hits, &d_hit_off_tab[0], &d_hit_off_tab[1], &d_hit_off_tab[2],
+                          &d_hit_off_tab[3], &d_idseg, &d_idflat};
+        for (auto* b : bufs) b->release();
+        h_out.release(); h_ids.release();
+        for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+};
+
+struct KwRequest;                                    // tsgpu.hip
+struct VecRequest;                                   // tsgpu_vec.hip
+
+}  // namespace tsgpu
+
+// per-call matched-id lists (tsgpu_keyword_search_batch_ids): owned by the caller after the call
+struct tsgpu_id_lists {
+    std::vector<uint64_t> begin;                     // [n_queries + 1]
+    std::vector<uint32_t> ids;                       // ascending per query
+};
+
+struct tsgpu_ctx {
+    static const int N_LANES = 2;
+    int device = 0;
+    hipStream_t stream = nullptr;                    // the vector path's stream (= the stream tsgpu_set_stream installs; lane 0 shares it)
+    bool own_stream = true;
+    std::mutex mu;                                   // index mutation + the vector path's scratch (one vector batch at a time)
+    std::mutex tm_mu;                                // timings / counters of the last batch
 
     std::unordered_map<uint32_t, tsgpu::FieldHost> fields;
-    tsgpu::Snapshot snap;
+    std::shared_ptr<const tsgpu::Snapshot> snap;     // published snapshot: std::atomic_load / atomic_store
+    std::shared_ptr<const tsgpu::Snapshot> snapshot() const { return std::atomic_load(&snap); }
     bool dirty = false;
     std::vector<tsgpu::ColumnDev> columns;
     tsgpu::DevBuf d_col_ptrs, d_col_len;
     uint32_t num_docs = 0;
     bool num_docs_set = false;
 
-    // keyword batch scratch
-    tsgpu::DevBuf d_queries, d_work, d_aux, d_ids_out, d_mf;
-    tsgpu::DevBuf d_part_s0, d_part_s1, d_part_s2, d_part_key, d_part_cnt, d_part_nm, d_part_ne, d_part_ow, d_part_f;
-    tsgpu::DevBuf d_out_keys, d_out_scores, d_out_tm, d_out_vd, d_out_msi, d_out_nh, d_out_nm, d_out_ow;
-    // candidate-combination batches (tsgpu_keyword_search_candidates_batch): per-pass hits, group table, id-set bitmaps
-    tsgpu::DevBuf d_cand_keys, d_cand_scores, d_cand_tm, d_cand_vd, d_cand_msi, d_cand_nh, d_cand_nm, d_cand_st, d_cand_gb, d_cand_qi, d_cand_found,
-                  d_cand_segs, d_cand_bits, d_cand_ids;
-    uint32_t last_cand_groups = 0;                   // groups whose bitmaps d_cand_bits holds
-    uint64_t last_cand_words = 0;                    // u32 words per group bitmap
-    std::vector<uint64_t> last_cand_found;
+    tsgpu::KwLane lanes[N_LANES];
+    std::atomic<int> last_lane{0};                   // lane of the most recent batch (legacy tsgpu_result_ids)
+    tsgpu::Combiner<tsgpu::KwRequest> kw_comb;
+    tsgpu::Combiner<tsgpu::VecRequest> vec_comb;
+    std::atomic<int> kw_callers{0}, vec_callers{0};  // threads currently inside the search entry points
+    uint32_t batch_window_us = 80;                   // micro-batcher: how long a round's leader waits for more callers
+    uint32_t batch_max_queries = 64;                 // calls with more queries than this are not coalesced (they are batches already)
+    uint32_t batch_round_queries = 1024;             // queries per coalesced round at most
+
     tsgpu::DevBuf d_prof;                            // TSGPU_PROF builds only (null otherwise)
-    tsgpu::PinBuf h_stage, h_out;
     bool keep_ids = false;
     uint32_t kw_max_partials = 16;                   // work items (= partial top-K lists) per query at most; longer driver lists get longer items
     uint32_t kw_cost_r_x10 = 10, kw_cost_probe_x100 = 20;  // ... + 0.1 x kw_cost_r_x10 x |B|/|A| + 0.01 x kw_cost_probe_x100 x (stage-1 survivors per block)
@@ -121,13 +190,11 @@ struct tsgpu_ctx {
     bool kw_sort_work = true;                        // lay the work table out heaviest query first
     bool kw_two_kernels = true;                      // queries of <= 3 tokens: find kernel + score kernel instead of the fused kernel
     uint32_t kw_hit_buffer_mb = 20480;               // budget of the hit-record buffer between the two (work items run in groups that fit)
-    tsgpu::DevBuf d_hits, d_hit_off_tab[4];          // hit records; per work table (<=3 / <=10 tokens, one / several fields) the items' record offsets
     uint32_t kw_last_hit_groups = 0;
     uint64_t kw_hit_buffer_records = 0, kw_last_hit_records = 0;
     uint32_t kw_chunk_blocks = 0;                    // driver blocks per work item (0 = sized per batch, see plan_batch)
-    uint32_t last_chunk_blocks = 64;
     uint32_t vec_rows_per_slab = 0;                  // 0 = automatic
-    uint32_t vec_sample_tiles = 0;   // 0 = automatic (8192 tiles on the bf16 prefilter path, 512 on the fp32 scan);                // 128-row tiles of the threshold sample (pass 1 of the k-NN)
+    uint32_t vec_sample_tiles = 0;                   // 0 = automatic (8192 tiles on the bf16 prefilter path, 512 on the fp32 scan): 128-row tiles of the threshold sample
     uint32_t vec_cand_cap = 0;                       // candidate slots per query in pass 2 (0 = automatic)
     uint32_t vec_prefilter = 1;                      // 1 = bf16 bracket scan + exact fp32 re-score (default); 0 = fp32 MFMA scan
     uint64_t vec_prefilter_groups = 0;               // query groups answered by the bf16 bracket path
@@ -135,16 +202,10 @@ struct tsgpu_ctx {
     uint32_t vec_count_rescored = 0;
     uint64_t vec_prefilter_fallbacks = 0;            // query groups the bf16 bracket could not separate (ran on the fp32 scan)
     uint64_t vec_overflow_rounds = 0;                // pass-2 repeats caused by candidate overflow (introspection)
-    std::vector<uint64_t> last_ids_off;              // per query offset into d_ids_out of the last batch
-    std::vector<uint64_t> last_ids_cap;
-    std::vector<std::vector<uint32_t>> last_chunk_emit;  // ids emitted per work item of the query
-    std::vector<std::vector<uint32_t>> last_chunk_off;   // where each work item's id segment starts (relative to last_ids_off)
-    std::vector<uint8_t> last_ids_unsorted;
-    std::vector<tsgpu_kw_query> last_queries_shadow;
 
     std::unordered_map<uint32_t, tsgpu::VecField*> vec_fields;
 
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [3..7]: the vector path
     tsgpu_timings timings{};
     bool scan_events_valid = false;                  // ev[6]/ev[7] bracket the main k-NN scan of the last batch's first query group
 };

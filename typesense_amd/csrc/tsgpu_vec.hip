@@ -66,13 +66,15 @@ static int vec_reserve_rows(VecField* f, uint64_t rows, hipStream_t s) {
     if ((rc = nx.reserve((size_t)want * f->dim * 4)) || (rc = nl.reserve((size_t)want * 8)) || (rc = no.reserve((size_t)want)) ||
         (rc = nh.reserve((size_t)((want + VEC_ROWS - 1) / VEC_ROWS) * VEC_ROWS * f->dimp * 2)) || (rc = nn.reserve((size_t)want * 4)) || (rc = nt.reserve((size_t)(want / VEC_ROWS + 2) * 4))) { drop(); return rc; }
     if (f->n_rows) {
-        TSGPU_HIP_TRY(hipMemcpyAsync(nx.p, f->X.p, (size_t)f->n_rows * f->dim * 4, hipMemcpyDeviceToDevice, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(nl.p, f->labels.p, (size_t)f->n_rows * 8, hipMemcpyDeviceToDevice, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(no.p, f->row_ok.p, (size_t)f->n_rows, hipMemcpyDeviceToDevice, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(nh.p, f->Xh.p, (size_t)((f->n_rows + VEC_ROWS - 1) / VEC_ROWS) * VEC_ROWS * f->dimp * 2, hipMemcpyDeviceToDevice, s));   // whole tiles (tiled layout)
-        TSGPU_HIP_TRY(hipMemcpyAsync(nn.p, f->xnorm.p, (size_t)f->n_rows * 4, hipMemcpyDeviceToDevice, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(nt.p, f->tile_nmax.p, (size_t)((f->n_rows + VEC_ROWS - 1) / VEC_ROWS) * 4, hipMemcpyDeviceToDevice, s));
-        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        const size_t tiles = (size_t)((f->n_rows + VEC_ROWS - 1) / VEC_ROWS);
+        hipError_t e = hipMemcpyAsync(nx.p, f->X.p, (size_t)f->n_rows * f->dim * 4, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(nl.p, f->labels.p, (size_t)f->n_rows * 8, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(no.p, f->row_ok.p, (size_t)f->n_rows, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(nh.p, f->Xh.p, tiles * VEC_ROWS * f->dimp * 2, hipMemcpyDeviceToDevice, s);   // whole tiles (tiled layout)
+        if (e == hipSuccess) e = hipMemcpyAsync(nn.p, f->xnorm.p, (size_t)f->n_rows * 4, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(nt.p, f->tile_nmax.p, tiles * 4, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { drop(); return fail(TSGPU_ERR_DEVICE, std::string("vec_reserve_rows: ") + hipGetErrorString(e)); }   // the field keeps its old buffers
     }
     f->X.release(); f->labels.release(); f->row_ok.release(); f->Xh.release(); f->xnorm.release(); f->tile_nmax.release();
     f->X = nx; f->labels = nl; f->row_ok = no; f->Xh = nh; f->xnorm = nn; f->tile_nmax = nt;
@@ -340,11 +342,12 @@ static void knn_collect_timings(tsgpu_ctx* ctx) {
     float a = 0, b = 0;
     (void)hipEventElapsedTime(&a, ctx->ev[3], ctx->ev[4]);
     (void)hipEventElapsedTime(&b, ctx->ev[4], ctx->ev[5]);
+    float c = 0;
+    if (ctx->scan_events_valid) (void)hipEventElapsedTime(&c, ctx->ev[6], ctx->ev[7]);
+    std::lock_guard<std::mutex> tl(ctx->tm_mu);
     ctx->timings.vec_knn_ms = a;
     ctx->timings.vec_merge_ms = b;
     ctx->timings.total_ms = a + b;
-    float c = 0;
-    if (ctx->scan_events_valid) (void)hipEventElapsedTime(&c, ctx->ev[6], ctx->ev[7]);
     ctx->timings.vec_scan_ms = c;
 }
 
@@ -567,6 +570,75 @@ uint64_t tsgpu_vec_count(tsgpu_ctx* ctx, uint32_t vec_field_id) {
     return f ? f->n_rows : 0;      // getCurrentElementCount counts deleted slots too
 }
 
+}  // extern "C"
+
+namespace tsgpu {
+struct VecRequest : ParkedRequest {
+    uint32_t field = 0, k = 0;
+    const float* Q = nullptr;                        // host, [units][dim]
+    float* dist_out = nullptr; uint64_t* label_out = nullptr; uint32_t* n_out = nullptr;   // host
+};
+}
+static int vec_knn_locked(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, int mem_q, uint32_t n_q, uint32_t k, const uint32_t* allow_ids,
+                          uint32_t n_allow, const uint32_t* excluded_ids, uint32_t n_excluded, float* dist_out, uint64_t* label_out,
+                          uint32_t* n_out, int mem_out);
+
+// A small unfiltered k-NN call from one of several concurrent request threads (the reference: vecdex->searchKnnCloserFirst per
+// request thread, src/index.cpp:3384-3386): the parked calls of one (field, k) run as ONE batch — one pass over the row matrix
+// serves all of them, which is where the batched scan's throughput comes from.
+static int vec_knn_coalesced(tsgpu_ctx* ctx, uint32_t field, const float* Q, uint32_t n_q, uint32_t k, float* dist_out, uint64_t* label_out, uint32_t* n_out) {
+    VecRequest me;
+    me.units = n_q; me.field = field; me.k = k; me.Q = Q; me.dist_out = dist_out; me.label_out = label_out; me.n_out = n_out;
+    typedef std::unique_lock<std::mutex> Lock;
+    auto acquire = [&]() { return std::unique_ptr<Lock>(new Lock(ctx->mu)); };
+    const uint32_t round_cap = std::max<uint32_t>(ctx->batch_round_queries, n_q);
+    auto pick = [&](std::vector<VecRequest*>& pending, std::vector<VecRequest*>& round) {
+        const uint32_t f0 = pending[0]->field, k0 = pending[0]->k;
+        uint32_t units = 0;
+        std::vector<VecRequest*> rest;
+        for (VecRequest* r : pending) {
+            if (r->field == f0 && r->k == k0 && (round.empty() || units + r->units <= round_cap)) { round.push_back(r); units += r->units; }
+            else rest.push_back(r);
+        }
+        pending.swap(rest);
+    };
+    auto exec = [&](std::vector<VecRequest*>& round, std::unique_ptr<Lock>&) {
+        int rc = TSGPU_OK;
+        std::string err;
+        try {
+            VecField* f = get_field(ctx, round[0]->field);
+            if (!f) { rc = TSGPU_ERR_NOT_FOUND; err = "tsgpu_vec_knn_batch: unknown vector field"; }
+            else {
+                uint32_t total = 0;
+                for (VecRequest* r : round) total += r->units;
+                const uint32_t kk = round[0]->k;
+                std::vector<float> Qall((size_t)total * f->dim), d((size_t)total * kk);
+                std::vector<uint64_t> l((size_t)total * kk);
+                std::vector<uint32_t> c(total);
+                uint32_t at = 0;
+                for (VecRequest* r : round) { memcpy(Qall.data() + (size_t)at * f->dim, r->Q, (size_t)r->units * f->dim * 4); at += r->units; }
+                rc = vec_knn_locked(ctx, round[0]->field, Qall.data(), TSGPU_MEM_HOST, total, kk, nullptr, 0, nullptr, 0, d.data(), l.data(), c.data(), TSGPU_MEM_HOST);
+                if (rc != TSGPU_OK) err = tls_error();
+                else {
+                    at = 0;
+                    for (VecRequest* r : round) {
+                        memcpy(r->dist_out, d.data() + (size_t)at * kk, (size_t)r->units * kk * 4);
+                        memcpy(r->label_out, l.data() + (size_t)at * kk, (size_t)r->units * kk * 8);
+                        memcpy(r->n_out, c.data() + at, (size_t)r->units * 4);
+                        at += r->units;
+                    }
+                }
+            }
+        } catch (const std::bad_alloc&) { rc = TSGPU_ERR_NO_MEMORY; err = "tsgpu_vec_knn_batch: host allocation failed"; }
+        for (VecRequest* r : round) { r->rc = rc; r->err = err; }
+    };
+    ctx->vec_comb.run(me, ctx->vec_callers, ctx->batch_window_us, acquire, pick, exec);
+    if (me.rc != TSGPU_OK) return fail(me.rc, me.err);
+    return ok();
+}
+
+extern "C" {
+
 int tsgpu_vec_knn_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, int mem_q, uint32_t n_q, uint32_t k, const uint32_t* allow_ids,
                         uint32_t n_allow, const uint32_t* excluded_ids, uint32_t n_excluded, float* dist_out, uint64_t* label_out,
                         uint32_t* n_out, int mem_out) {
@@ -574,7 +646,19 @@ int tsgpu_vec_knn_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, i
     if (n_q == 0) return ok();
     if (k == 0) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_knn_batch: k must be > 0");
     if (k > TSGPU_MAX_TOPK) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_knn_batch: k > TSGPU_MAX_TOPK is not accelerated");
+    struct CallerCount { std::atomic<int>& c; explicit CallerCount(std::atomic<int>& x) : c(x) { c.fetch_add(1); } ~CallerCount() { c.fetch_sub(1); } } cc(ctx->vec_callers);
+    if (mem_q == TSGPU_MEM_HOST && mem_out == TSGPU_MEM_HOST && !allow_ids && n_excluded == 0 && n_q <= ctx->batch_max_queries && ctx->vec_callers.load() > 1)
+        return vec_knn_coalesced(ctx, vec_field_id, Q, n_q, k, dist_out, label_out, n_out);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    return vec_knn_locked(ctx, vec_field_id, Q, mem_q, n_q, k, allow_ids, n_allow, excluded_ids, n_excluded, dist_out, label_out, n_out, mem_out);
+}
+
+}  // extern "C"
+
+// ctx->mu held by the caller
+static int vec_knn_locked(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, int mem_q, uint32_t n_q, uint32_t k, const uint32_t* allow_ids,
+                          uint32_t n_allow, const uint32_t* excluded_ids, uint32_t n_excluded, float* dist_out, uint64_t* label_out,
+                          uint32_t* n_out, int mem_out) {
     (void)hipSetDevice(ctx->device);
     VecField* f = get_field(ctx, vec_field_id);
     if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_knn_batch: unknown vector field");
@@ -608,6 +692,8 @@ int tsgpu_vec_knn_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, i
     return ok();
 }
 
+extern "C" {
+
 // ---------------------------------------------------------------- HNSW graph mirror + search (seam B2, a18)
 int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32_t maxlevel, uint32_t enterpoint, const uint32_t* link0,
                         const uint64_t* upper_ptr, const uint32_t* upper_links, uint32_t n) {
@@ -622,6 +708,21 @@ int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32
     hipStream_t s = ctx->stream;
     const uint64_t n_upper = upper_ptr[n];
     if (n_upper && !upper_links) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: upper_links is NULL");
+    // the device follows these links unchecked: link counts within 2M / M, neighbour ids inside the graph, upper_ptr monotone
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t* l0 = link0 + (size_t)i * (1 + 2 * M);
+        if (l0[0] > 2 * M) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: a level-0 link count exceeds 2M");
+        for (uint32_t j = 0; j < l0[0]; j++) if (l0[1 + j] >= n) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: a level-0 neighbour id is out of range");
+        if (upper_ptr[i + 1] < upper_ptr[i]) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: upper_ptr must be non-decreasing");
+        if ((int64_t)(upper_ptr[i + 1] - upper_ptr[i]) > (int64_t)std::max<int32_t>(maxlevel, 0)) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: a node has more upper levels than maxlevel");
+    }
+    for (uint64_t u = 0; u < n_upper; u++) {
+        const uint32_t* lu = upper_links + u * (1 + M);
+        if (lu[0] > M) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: an upper-level link count exceeds M");
+        for (uint32_t j = 0; j < lu[0]; j++) if (lu[1 + j] >= n) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: an upper-level neighbour id is out of range");
+    }
+    if (n && maxlevel >= 0 && (int64_t)(upper_ptr[enterpoint + 1] - upper_ptr[enterpoint]) < (int64_t)maxlevel)
+        return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: the entry point does not reach maxlevel");
     int rc;
     if ((rc = f->g_link0.reserve((size_t)std::max<uint32_t>(n, 1) * (1 + 2 * M) * 4))) return rc;
     if ((rc = f->g_upper_ptr.reserve((size_t)(n + 1) * 8))) return rc;

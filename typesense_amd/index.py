@@ -224,6 +224,23 @@ class GpuIndex:
         """prebuilt ctypes query array + tsgpu_hits struct (device or host outputs); no allocation (bench loop)"""
         self._ck(self.L.tsgpu_keyword_search_batch(self.h, C.cast(arr, C.c_void_p), n, C.byref(hs)))
 
+    def keyword_search_batch_ids(self, queries, k_stride=250, hits=None):
+        """search + the matched ids of every query as a list that belongs to this call (safe with concurrent callers)"""
+        arr = make_query_array(queries)
+        n = len(arr)
+        hits = hits or Hits(n, k_stride)
+        hs = hits.c_struct()
+        lists = C.c_void_p()
+        self._ck(self.L.tsgpu_keyword_search_batch_ids(self.h, C.cast(arr, C.c_void_p), n, C.byref(hs), C.byref(lists)))
+        try:
+            ids = []
+            for q in range(n):
+                cnt = self.L.tsgpu_id_lists_count(lists, q)
+                ids.append(np.ctypeslib.as_array(self.L.tsgpu_id_lists_ids(lists, q), shape=(cnt,)).copy() if cnt else np.zeros(0, np.uint32))
+        finally:
+            self.L.tsgpu_id_lists_free(lists)
+        return hits, ids
+
     def keep_result_ids(self, keep=True):
         self._ck(self.L.tsgpu_keep_result_ids(self.h, int(keep)))
 
