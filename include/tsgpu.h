@@ -339,6 +339,7 @@ typedef struct tsgpu_timings {
     uint64_t kw_algorithmic_bytes;   /* SURVEY §8(d) bytes of the last keyword batch */
     uint64_t vec_flops;              /* 2*N*D*B of the last knn batch */
     uint64_t vec_scan_bytes;         /* bytes the scan kernel must stream per launch: the row matrix once + the queries */
+    float kw_find_ms;                /* two-kernel form, one group: the find kernel alone (kw_search_ms spans find + score); else 0 */
 } tsgpu_timings;
 int tsgpu_last_timings(tsgpu_ctx* ctx, tsgpu_timings* out);
 

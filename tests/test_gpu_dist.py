@@ -1,0 +1,29 @@
+"""`-m gpu`: the N>1 path of bench.py on ONE MI355X — two ranks share the device (collectives through gloo; the measured
+configuration is RCCL, one GPU per rank), the 2M-doc collection is cut into two doc-range shards of the SAME corpus, and the
+bench's own in-run equality checks (merged shard results == the unsharded collection: keyword top-100 + counts, k-NN labels +
+distance bits, fused hybrid scores) must report zero mismatches. BASELINE config 5 / SURVEY §8(e)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_two_rank_shards_equal_unsharded_collection():
+    env = dict(os.environ, TSGPU_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29613",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--n-docs", "2000000", "--batch", "1000", "--vec-batch", "64",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["distributed"]["world_size"] == 2 and r["distributed"]["mode"] == "shards"
+    assert r["shard_parity"]["checked"] >= 256 and r["shard_parity"]["mismatches"] == 0, r["shard_parity"]
+    assert r["vector"]["shard_parity"]["mismatches"] == 0, r["vector"]["shard_parity"]
+    assert r["hybrid"]["shard_parity"]["mismatches"] == 0, r["hybrid"]["shard_parity"]
+    assert r["replicas"]["value"] > 0 and r["value"] > 0

@@ -54,7 +54,7 @@ class HybridParamsC(C.Structure):
 class TimingsC(C.Structure):
     _fields_ = [("kw_search_ms", C.c_float), ("kw_merge_ms", C.c_float), ("vec_knn_ms", C.c_float), ("vec_merge_ms", C.c_float),
                 ("total_ms", C.c_float), ("vec_scan_ms", C.c_float), ("kw_algorithmic_bytes", C.c_uint64), ("vec_flops", C.c_uint64),
-                ("vec_scan_bytes", C.c_uint64)]
+                ("vec_scan_bytes", C.c_uint64), ("kw_find_ms", C.c_float)]
 
 
 EXPORTS = [

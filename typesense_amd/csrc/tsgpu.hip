@@ -75,8 +75,9 @@ void launch_search(hipStream_t s, uint32_t n_work, const IndexView& v, const KwQ
 // two-kernel form: find (intersection -> hit records) then score (hit records -> partial top-K)
 template <int TMAX>
 void launch_find_score(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w, const KwPartials& part,
-                       const uint32_t* aux, uint32_t* ids_out, bool s2, uint32_t* hits, const uint64_t* hit_off) {
+                       const uint32_t* aux, uint32_t* ids_out, bool s2, uint32_t* hits, const uint64_t* hit_off, hipEvent_t mid_ev = nullptr) {
     hipLaunchKernelGGL((kw_search_kernel<TMAX, 512, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    if (mid_ev) (void)hipEventRecord(mid_ev, s);           // find | score boundary of the batch's first group (tsgpu_timings::kw_find_ms)
     if (cap == 512 && !s2) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, false>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     else if (cap == 512) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     else if (cap == 1024) hipLaunchKernelGGL((kw_score_kernel<TMAX, 1024, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
@@ -1033,6 +1034,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         };
         uint32_t hit_groups = 0;
         uint64_t hit_records = 0;
+        bool find_marked = false;
         // single-field tables (<= 3 tokens / up to 10 tokens): find + score kernels when the hit buffer fits, else the fused kernel.
         // A work item can yield at most one hit per driver id, so its segment of the hit buffer holds (blk_end - blk_begin) * 256
         // records of 1 + TMAX words; the items run in groups whose segments fit the budget.
@@ -1074,7 +1076,11 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
                     const size_t a = group_start[gi], b = group_start[gi + 1];
                     if (b <= a) continue;
                     if constexpr (MFT) launch_find_score_mf<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, L.d_hits.as<uint32_t>(), offbuf.as<uint64_t>() + a);
-                    else launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, L.d_hits.as<uint32_t>(), offbuf.as<uint64_t>() + a);
+                    else {
+                        const bool mark = !find_marked;
+                        find_marked = true;
+                        launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, L.d_hits.as<uint32_t>(), offbuf.as<uint64_t>() + a, mark ? L.ev[3] : nullptr);
+                    }
                 }
             } else if constexpr (MFT) launch_search_mf_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out);
             else launch_search_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out, P.any_s2);
@@ -1141,6 +1147,8 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         float ms_a = 0, ms_b = 0;
         (void)hipEventElapsedTime(&ms_a, L.ev[0], L.ev[1]);
         (void)hipEventElapsedTime(&ms_b, L.ev[1], L.ev[2]);
+        float ms_find = 0;
+        if (find_marked && hit_groups == 1) (void)hipEventElapsedTime(&ms_find, L.ev[0], L.ev[3]);       // one find launch, then one score launch
         uint64_t bytes = P.list_bytes;
         if (!dev_out && out->num_matched) {
             for (uint32_t i = 0; i < n_queries; i++) {
@@ -1155,6 +1163,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             std::lock_guard<std::mutex> tl(ctx->tm_mu);
             ctx->timings.kw_search_ms = ms_a;
             ctx->timings.kw_merge_ms = ms_b;
+            ctx->timings.kw_find_ms = ms_find;
             ctx->timings.total_ms = ms_a + ms_b;
             ctx->timings.kw_algorithmic_bytes = bytes;
             ctx->kw_last_hit_groups = hit_groups;

@@ -105,7 +105,7 @@ struct KwLane {
     std::atomic<int> waiters{0};
     hipStream_t stream = nullptr;
     bool own_stream = true;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf d_queries, d_work, d_aux, d_ids_out, d_mf;
     DevBuf d_part_s0, d_part_s1, d_part_s2, d_part_key, d_part_cnt, d_part_nm, d_part_ne, d_part_ow, d_part_f;
     DevBuf d_out_keys, d_out_scores, d_out_tm, d_out_vd, d_out_msi, d_out_nh, d_out_nm, d_out_ow, d_out_cut;

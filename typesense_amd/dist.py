@@ -79,6 +79,18 @@ def merge_keyword_topk_device(index, g, k):
     return out["keys"], out["scores"], out["n_hits"].to(torch.int64), out["num_matched"]
 
 
+def merge_gathered_keyword(index, g_pack, g_counts, k):
+    """bench.py's shard step: ONE all-gather delivered g_pack [G,B,K,4] = {key, scores[3]} and g_counts [G,B,2] = {n_hits, num_matched};
+    exact merge on the device (kw_shard_merge_kernel): global Topster order, num_matched = sum over the shards."""
+    import torch
+    g = dict(keys=g_pack[..., 0].contiguous(), scores=g_pack[..., 1:].contiguous(),
+             n_hits=g_counts[..., 0].to(torch.int32).contiguous(), num_matched=g_counts[..., 1].contiguous())
+    if index is not None and g["keys"].is_cuda:
+        return merge_keyword_topk_device(index, g, k)
+    keys, sc, n = merge_keyword_topk(g["keys"], g["scores"], g["n_hits"], k)
+    return keys, sc, n, g["num_matched"].sum(0)
+
+
 def sharded_keyword(local, k, index=None):
     """local: dict(keys [B,K] int64, scores [B,K,3] int64, n_hits [B] int32, num_matched [B] int64) of THIS shard ->
     merged (keys, scores, n, num_matched) identical on every rank. With `index` (a GpuIndex) and CUDA tensors the merge runs

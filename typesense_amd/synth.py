@@ -17,12 +17,14 @@ def points_column(n_docs):
     return ((ids * np.uint64(2654435761)) % np.uint64(1000)).astype(np.int64)
 
 
-def zipf_corpus_csr(n_docs, vocab, tokens_per_doc, seed, s=1.0, device=None, doc_base=0):
+def zipf_corpus_csr(n_docs, vocab, tokens_per_doc, seed, s=1.0, device=None, doc_base=0, doc_range=None):
     """Returns the CSR posting arrays for tsgpu_terms_load_csr / oracle load_posting (all numpy, host):
         term_ids[u32 n_terms] (rank, 1-based, only terms that occur), ids_ptr[u64 n_terms+1], ids[u32],
         offset_index[u64 n_postings] (absolute), off_ptr[u64 n_terms+1], offsets[u32]
     Document d = tokens_per_doc i.i.d. Zipf(s) draws over `vocab` terms at positions 0..tokens_per_doc-1.
-    offsets of (term, doc) = position+1 ascending, then 0 when the term is the doc's last token."""
+    offsets of (term, doc) = position+1 ascending, then 0 when the term is the doc's last token.
+    doc_range = (lo, hi): the postings of documents lo <= d < hi of the SAME collection (the whole collection is drawn with the
+    same random stream, then cut): a doc-range shard of exactly the corpus an unsharded run indexes; ids stay global."""
     torch = _torch()
     dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
     g = torch.Generator(device=dev)
@@ -48,6 +50,10 @@ def zipf_corpus_csr(n_docs, vocab, tokens_per_doc, seed, s=1.0, device=None, doc
     doc = torch.div(rem, T, rounding_mode="floor")
     pos = rem - doc * T
     del rem
+    if doc_range is not None:
+        sel = (doc >= int(doc_range[0])) & (doc < int(doc_range[1]))
+        term, doc, pos = term[sel], doc[sel], pos[sel]
+        del sel
     n = term.numel()
     # run = one (term, doc) posting
     new_run = torch.ones(n, dtype=torch.bool, device=dev)
@@ -57,7 +63,7 @@ def zipf_corpus_csr(n_docs, vocab, tokens_per_doc, seed, s=1.0, device=None, doc
     zflag = run_end & (pos == T - 1)                       # last token of the doc -> trailing 0
     zcum = torch.cumsum(zflag.to(torch.int64), 0)
     out_pos = torch.arange(n, device=dev, dtype=torch.int64) + (zcum - zflag.to(torch.int64))   # exclusive scan
-    n_off = int(n + zcum[-1].item())
+    n_off = int(n + (zcum[-1].item() if n else 0))
     offsets = torch.zeros(n_off, dtype=torch.int32, device=dev)
     offsets[out_pos] = (pos + 1).to(torch.int32)
     ids = (doc[new_run] + doc_base).to(torch.int32)
