@@ -544,3 +544,19 @@ def test_edge_cases_empty_index_missing_tokens_and_degenerate_topsters():
         H.assert_hits_equal(hits, i, H.oracle_keyword(orc, q), "edge q%d" % i)
     assert hits.n_hits[4] == 0 and hits.n_hits[6] == 0 and hits.n_hits[8] == 0 and hits.n_hits[7] == 1
     g.close()
+
+
+def test_two_level_merge_many_work_items():
+    """a query cut into more than 16 work items: its partial lists are folded in groups of 8 (kw_merge_groups_kernel), then per query"""
+    docs = H.zipf_docs(6200, 3, 5, seed=12, s=0.2)
+    orc, g = H.build_pair(docs, H.emu_lib_path())
+    g.set_option("kw_chunk_blocks", 1)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    qs = [T.KwQuery([1], sort=sort, topster_size=40), T.KwQuery([2, 1], sort=sort, topster_size=250), T.KwQuery([3, 1, 2], sort=sort, topster_size=7),
+          T.KwQuery([1, 2], sort=sort, topster_size=250, filter_ids=np.arange(0, 6200, 3, dtype=np.uint32))]
+    assert g.term_num_ids(0, 1) > 17 * 256
+    hits = g.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all()
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(hits, i, H.oracle_keyword(orc, q), "two-level merge")
+    g.close()

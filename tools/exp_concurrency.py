@@ -1,0 +1,74 @@
+"""GPU experiment (not part of the product): 1-query callers on the 10M-doc keyword collection — threads x lanes x window sweep with the
+host-phase counters. Usage: python tools/exp_concurrency.py [n_docs]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import typesense_amd as T  # noqa: E402
+from typesense_amd import _lib as B, synth  # noqa: E402
+
+n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+import __graft_entry__
+__graft_entry__.build()
+g = T.GpuIndex(0)
+csr = synth.zipf_corpus_csr(n_docs, 100_000, 32, seed=2)
+g.field_create(0, False)
+g.terms_load_csr(0, csr["term_ids"], csr["ids_ptr"], csr["ids"], csr["offset_index"], csr["off_ptr"], csr["offsets"])
+g.column_set(0, synth.points_column(n_docs))
+g.set_num_docs(n_docs)
+g.commit()
+n_q = 10_000
+qtok = synth.keyword_queries(n_q, 3, 8, 2000, seed=4)
+sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+arr = (B.KwQueryC * n_q)()
+for i in range(n_q):
+    T.KwQuery(qtok[i], sort=sort, topster_size=250).fill(arr[i])
+LG = bench.loadgen_lib()
+fn = C.cast(g.L.tsgpu_keyword_search_batch, C.c_void_p)
+names = ["kw_batches", "kw_plan_us", "kw_upload_us", "kw_launch_us", "kw_wait_us", "kw_book_us", "batch_exec_us", "batch_scatter_us", "batch_rounds", "batch_coalesced_calls"]
+
+
+def run(threads, calls, qpc=1):
+    lat = np.zeros(threads * calls)
+    got = np.zeros(n_q, np.uint64)
+    fails = C.c_uint64(0)
+    LG.tsgpu_loadgen_keyword(fn, g.h, C.cast(arr, C.c_void_p), n_q, 250, 100, threads, max(2, calls // 8), qpc, lat.ctypes.data, got.ctypes.data, C.byref(fails))
+    c0 = {n: g.counter(n) for n in names}
+    wall = LG.tsgpu_loadgen_keyword(fn, g.h, C.cast(arr, C.c_void_p), n_q, 250, 100, threads, calls, qpc, lat.ctypes.data, got.ctypes.data, C.byref(fails))
+    c = {n: g.counter(n) - c0[n] for n in names}
+    nb = max(c["kw_batches"], 1)
+    return dict(qps=threads * calls * qpc / wall, p50=float(np.percentile(lat, 50)), p99=float(np.percentile(lat, 99)), fails=fails.value,
+                q_per_batch=threads * calls * qpc / nb, plan=c["kw_plan_us"] / nb, upload=c["kw_upload_us"] / nb, launch=c["kw_launch_us"] / nb,
+                wait=c["kw_wait_us"] / nb, book=c["kw_book_us"] / nb, exec_round=c["batch_exec_us"] / max(c["batch_rounds"], 1),
+                scatter=c["batch_scatter_us"] / max(c["batch_rounds"], 1))
+
+
+# direct batches of several sizes (single caller): the fixed cost of a batch
+hits = T.Hits(n_q, 250)
+hs = hits.c_struct()
+for nb in (1, 16, 64, 128, 256, 1024):
+    sub = (B.KwQueryC * nb).from_address(C.addressof(arr))
+    g.keyword_search_batch_raw(sub, nb, hs)
+    c0 = {n: g.counter(n) for n in names}
+    t0 = time.perf_counter()
+    for _ in range(20):
+        g.keyword_search_batch_raw(sub, nb, hs)
+    dt = (time.perf_counter() - t0) / 20
+    c = {n: (g.counter(n) - c0[n]) / 20 for n in names}
+    print("direct batch %5d: %.0f us/call  plan %.0f upload %.0f launch %.0f wait %.0f book %.0f | gpu search %.3f merge %.3f ms" %
+          (nb, dt * 1e6, c["kw_plan_us"], c["kw_upload_us"], c["kw_launch_us"], c["kw_wait_us"], c["kw_book_us"], g.timings().kw_search_ms, g.timings().kw_merge_ms), flush=True)
+
+for lanes in (2, 4):
+    g.set_option("kw_lanes", lanes)
+    for window in (80,):
+        g.set_option("batch_window_us", window)
+        for threads in (64, 256):
+            r = run(threads, max(16, 30000 // threads))
+            print("lanes %d window %3d threads %3d: %8.0f q/s p50 %6.0f p99 %6.0f us | %.1f q/batch plan %.0f upload %.0f launch %.0f wait %.0f book %.0f | round exec %.0f scatter %.0f us fails %d"
+                  % (lanes, window, threads, r["qps"], r["p50"], r["p99"], r["q_per_batch"], r["plan"], r["upload"], r["launch"], r["wait"], r["book"], r["exec_round"], r["scatter"], r["fails"]), flush=True)
+g.close()

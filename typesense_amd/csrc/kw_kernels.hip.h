@@ -121,6 +121,8 @@ struct KwQueryDev {                  // one search_across_fields call
     uint64_t ids_out_off;            // where this query's matched ids go (if kept)
     uint32_t mf_index;               // KW_NONE = one query_by field; else index into IndexView::mf
     uint32_t wild_n_ids;             // wildcard query (q = "*"): ids to scan = filter ids, or every seq_id < num_docs; 0 = keyword query
+    uint32_t m_first, m_n;           // the sorted partial lists kw_merge_kernel folds: the work items themselves, or (many work items) the
+                                     // group lists kw_merge_groups_kernel left behind them (counters always come from the work items)
 };
 
 // query_by over several fields (get_field_token_its, src/index.cpp:5598-5660): token t is the UNION over the fields of its
@@ -1558,25 +1560,105 @@ __device__ inline unsigned long long kw_filter_count(const KwPartials& part, uin
     return total;
 }
 
+// Every partial list is SORTED (KV::is_greater order) and keys are unique, so folding one into the running top-k is a merge
+// by rank, not a sort: an entry's place = its index in its own list + the number of entries of the other list that are
+// greater (one binary search). A = tk[0, na) sorted; the partial comes in pieces of <= 256 entries parked in tk[CAP-256, CAP)
+// (k <= CAP - 256): ~10 dependent LDS steps per piece instead of a 45-stage bitonic sort. A partial whose best remaining entry
+// cannot beat the current k-th is skipped. Folds partial lists [first, first + n) into tk; returns the number of entries held.
+template <int CAP>
+__device__ inline uint32_t kw_fold_partials(TopkLds<CAP>& tk, const KwPartials& part, uint32_t first, uint32_t n_lists, uint32_t k) {
+    constexpr int PER = CAP / KW_THREADS - 1;                    // A entries per thread (na <= k <= CAP - 256)
+    constexpr int PB = CAP - KW_THREADS;                         // where the piece is parked
+    const uint32_t t = threadIdx.x;
+    uint32_t na = 0;
+    for (uint32_t w = first; w < first + n_lists; w++) {
+        const uint32_t nw = part.cnt[w];
+        const size_t base = (size_t)w * part.k_stride;
+        for (uint32_t p0 = 0; p0 < nw; p0 += KW_THREADS) {
+            if (na == k) {                                       // uniform: every thread reads the same entries
+                const int64_t h0 = part.s0[base + p0], h1 = part.s1[base + p0], h2 = part.s2[base + p0], hk = part.key[base + p0];
+                if (!ent_greater(h0, h1, h2, hk, tk.s0[na - 1], tk.s1[na - 1], tk.s2[na - 1], tk.key[na - 1])) break;
+            }
+            const uint32_t nb = nw - p0 < (uint32_t)KW_THREADS ? nw - p0 : (uint32_t)KW_THREADS;
+            int64_t b0 = 0, b1 = 0, b2 = 0, bk = -1;
+            if (t < nb) {
+                b0 = part.s0[base + p0 + t]; b1 = part.s1[base + p0 + t]; b2 = part.s2[base + p0 + t]; bk = part.key[base + p0 + t];
+                tk.s0[PB + t] = b0; tk.s1[PB + t] = b1; tk.s2[PB + t] = b2; tk.key[PB + t] = bk;
+            }
+            __syncthreads();
+            // piece entry t: place = t + #{A entries greater than it}
+            uint32_t rank_b = 0xFFFFFFFFu;
+            if (t < nb) {
+                uint32_t lo = 0, hi = na;                        // first A index that is NOT greater than b
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (ent_greater(tk.s0[mid], tk.s1[mid], tk.s2[mid], tk.key[mid], b0, b1, b2, bk)) lo = mid + 1; else hi = mid;
+                }
+                rank_b = t + lo;
+            }
+            // A entry i: place = i + #{piece entries greater than it}
+            int64_t a0[PER], a1[PER], a2[PER], ak[PER];
+            uint32_t rank_a[PER];
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const uint32_t i = r * KW_THREADS + t;
+                rank_a[r] = 0xFFFFFFFFu;
+                if (i < na) {
+                    a0[r] = tk.s0[i]; a1[r] = tk.s1[i]; a2[r] = tk.s2[i]; ak[r] = tk.key[i];
+                    uint32_t lo = 0, hi = nb;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (ent_greater(tk.s0[PB + mid], tk.s1[PB + mid], tk.s2[PB + mid], tk.key[PB + mid], a0[r], a1[r], a2[r], ak[r])) lo = mid + 1; else hi = mid;
+                    }
+                    rank_a[r] = i + lo;
+                }
+            }
+            __syncthreads();                                     // every read of the old layout is done
+            if (rank_b < k) { tk.s0[rank_b] = b0; tk.s1[rank_b] = b1; tk.s2[rank_b] = b2; tk.key[rank_b] = bk; }
+#pragma unroll
+            for (int r = 0; r < PER; r++)
+                if (rank_a[r] < k) { tk.s0[rank_a[r]] = a0[r]; tk.s1[rank_a[r]] = a1[r]; tk.s2[rank_a[r]] = a2[r]; tk.key[rank_a[r]] = ak[r]; }
+            na = na + nb < k ? na + nb : k;
+            __syncthreads();
+        }
+    }
+    return na;
+}
+
+// First level of a TWO-LEVEL merge (queries cut into many work items — small batches are cut fine so that no work item runs long):
+// group g folds the partial lists [first, first + n) of one query into the sorted list `dst`, all groups in parallel; kw_merge_kernel
+// then folds a query's group lists. A chain of P sequential folds becomes G + P / G.
+struct KwMergeGroup { uint32_t query, first, n, dst; };
+template <int CAP>
+__global__ __launch_bounds__(KW_THREADS) void kw_merge_groups_kernel(const KwQueryDev* __restrict__ queries, KwPartials part, const KwMergeGroup* __restrict__ groups) {
+    __shared__ TopkLds<CAP> tk;
+    const KwMergeGroup g = groups[blockIdx.x];
+    const uint32_t k = queries[g.query].k;
+    const uint32_t n = kw_fold_partials<CAP>(tk, part, g.first, g.n, k);
+    const size_t base = (size_t)g.dst * part.k_stride;
+    for (uint32_t i = threadIdx.x; i < n; i += KW_THREADS) {
+        part.s0[base + i] = tk.s0[i]; part.s1[base + i] = tk.s1[i]; part.s2[base + i] = tk.s2[i]; part.key[base + i] = tk.key[i];
+    }
+    if (threadIdx.x == 0) part.cnt[g.dst] = n;
+}
+
 // grid = queries; folds a query's partials into the final order and writes the tsgpu_hits slots
 template <int CAP>
 __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* __restrict__ queries, KwPartials part, KwOut out,
                                                                uint32_t* __restrict__ ids_out, const KwWorkItem* __restrict__ work) {
     __shared__ TopkLds<CAP> tk;
-    __shared__ int64_t thr[4];
-    __shared__ uint32_t s_cnt, s_have_thr;
     __shared__ unsigned long long s_nm, s_ow;
     const uint32_t t = threadIdx.x;
     const KwQueryDev q = queries[blockIdx.x];
-    if (t == 0) { s_cnt = 0; s_have_thr = 0; s_nm = 0; s_ow = 0; }
+    if (t == 0) { s_nm = 0; s_ow = 0; }
     __syncthreads();
     const size_t ob = (size_t)blockIdx.x * out.k_stride;
     int msi = -1;
     for (int i = 0; i < 3; i++) if (i < q.n_sort && q.sort_kind[i] == 0) msi = i;
     uint32_t n;
-    if (q.n_work == 1) {
-        // a single work item already holds the query's final order: copy it through
-        const uint32_t w = q.first_work;
+    if (q.m_n == 1) {
+        // a single list already holds the query's final order: copy it through
+        const uint32_t w = q.m_first;
         n = part.cnt[w];
         const size_t base = (size_t)w * part.k_stride;
         for (uint32_t i = t; i < n; i += KW_THREADS) {
@@ -1587,71 +1669,8 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
             out.vector_distance[ob + i] = -1.0f;
             out.match_score_index[ob + i] = (int8_t)msi;
         }
-        if (t == 0) { s_nm = (q.n_filt && !q.wild_n_ids) ? kw_filter_count(part, q.first_work, 1) : part.n_match[w]; s_ow = part.off_words[w]; }
     } else {
-        // Every partial list is SORTED (KV::is_greater order) and keys are unique, so folding one into the running top-k is a merge
-        // by rank, not a sort: an entry's place = its index in its own list + the number of entries of the other list that are
-        // greater (one binary search). A = tk[0, na) sorted; the partial comes in pieces of <= 256 entries parked in tk[CAP-256, CAP)
-        // (k <= CAP - 256). A heavy query folds up to 64 partials in sequence in this one workgroup: ~10 dependent LDS steps per
-        // piece instead of a 45-stage bitonic sort. A partial whose best remaining entry cannot beat the current k-th is skipped.
-        constexpr int PER = CAP / KW_THREADS - 1;                    // A entries per thread (na <= k <= CAP - 256)
-        constexpr int PB = CAP - KW_THREADS;                         // where the piece is parked
-        uint32_t na = 0;
-        for (uint32_t w = q.first_work; w < q.first_work + q.n_work; w++) {
-            const uint32_t nw = part.cnt[w];
-            const size_t base = (size_t)w * part.k_stride;
-            for (uint32_t p0 = 0; p0 < nw; p0 += KW_THREADS) {
-                if (na == q.k) {                                     // uniform: every thread reads the same entries
-                    const int64_t h0 = part.s0[base + p0], h1 = part.s1[base + p0], h2 = part.s2[base + p0], hk = part.key[base + p0];
-                    if (!ent_greater(h0, h1, h2, hk, tk.s0[na - 1], tk.s1[na - 1], tk.s2[na - 1], tk.key[na - 1])) break;
-                }
-                const uint32_t nb = nw - p0 < (uint32_t)KW_THREADS ? nw - p0 : (uint32_t)KW_THREADS;
-                int64_t b0 = 0, b1 = 0, b2 = 0, bk = -1;
-                if (t < nb) {
-                    b0 = part.s0[base + p0 + t]; b1 = part.s1[base + p0 + t]; b2 = part.s2[base + p0 + t]; bk = part.key[base + p0 + t];
-                    tk.s0[PB + t] = b0; tk.s1[PB + t] = b1; tk.s2[PB + t] = b2; tk.key[PB + t] = bk;
-                }
-                __syncthreads();
-                // piece entry t: place = t + #{A entries greater than it}
-                uint32_t rank_b = 0xFFFFFFFFu;
-                if (t < nb) {
-                    uint32_t lo = 0, hi = na;                        // first A index that is NOT greater than b
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (ent_greater(tk.s0[mid], tk.s1[mid], tk.s2[mid], tk.key[mid], b0, b1, b2, bk)) lo = mid + 1; else hi = mid;
-                    }
-                    rank_b = t + lo;
-                }
-                // A entry i: place = i + #{piece entries greater than it}
-                int64_t a0[PER], a1[PER], a2[PER], ak[PER];
-                uint32_t rank_a[PER];
-#pragma unroll
-                for (int r = 0; r < PER; r++) {
-                    const uint32_t i = r * KW_THREADS + t;
-                    rank_a[r] = 0xFFFFFFFFu;
-                    if (i < na) {
-                        a0[r] = tk.s0[i]; a1[r] = tk.s1[i]; a2[r] = tk.s2[i]; ak[r] = tk.key[i];
-                        uint32_t lo = 0, hi = nb;
-                        while (lo < hi) {
-                            const uint32_t mid = (lo + hi) >> 1;
-                            if (ent_greater(tk.s0[PB + mid], tk.s1[PB + mid], tk.s2[PB + mid], tk.key[PB + mid], a0[r], a1[r], a2[r], ak[r])) lo = mid + 1; else hi = mid;
-                        }
-                        rank_a[r] = i + lo;
-                    }
-                }
-                __syncthreads();                                     // every read of the old layout is done
-                if (rank_b < q.k) { tk.s0[rank_b] = b0; tk.s1[rank_b] = b1; tk.s2[rank_b] = b2; tk.key[rank_b] = bk; }
-#pragma unroll
-                for (int r = 0; r < PER; r++)
-                    if (rank_a[r] < q.k) { tk.s0[rank_a[r]] = a0[r]; tk.s1[rank_a[r]] = a1[r]; tk.s2[rank_a[r]] = a2[r]; tk.key[rank_a[r]] = ak[r]; }
-                na = na + nb < q.k ? na + nb : q.k;
-                __syncthreads();
-            }
-            if (t == 0) { if (!q.n_filt || q.wild_n_ids) s_nm += part.n_match[w]; s_ow += part.off_words[w]; }
-        }
-        __syncthreads();
-        if (t == 0 && q.n_filt && !q.wild_n_ids) s_nm = kw_filter_count(part, q.first_work, q.n_work);
-        n = na;
+        n = kw_fold_partials<CAP>(tk, part, q.m_first, q.m_n, q.k);
         for (uint32_t i = t; i < n; i += KW_THREADS) {
             const int64_t a0 = tk.s0[i], a1 = tk.s1[i], a2 = tk.s2[i];
             out.keys[ob + i] = (uint64_t)tk.key[i];
@@ -1660,6 +1679,16 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
             out.vector_distance[ob + i] = -1.0f;
             out.match_score_index[ob + i] = (int8_t)msi;
         }
+    }
+    // counters: always from the work items themselves (num_keyword_matches, offsets read); a filtered query chains its slices in id order
+    {
+        unsigned long long nm = 0, ow = 0;
+        const bool chain = q.n_filt && !q.wild_n_ids;
+        for (uint32_t w = q.first_work + t; w < q.first_work + q.n_work; w += KW_THREADS) { if (!chain) nm += part.n_match[w]; ow += part.off_words[w]; }
+        for (int d = 32; d > 0; d >>= 1) { nm += __shfl_down(nm, d, 64); ow += __shfl_down(ow, d, 64); }
+        if ((t & 63) == 0) { if (nm) atomicAdd(&s_nm, nm); if (ow) atomicAdd(&s_ow, ow); }
+        __syncthreads();
+        if (t == 0 && chain) s_nm = kw_filter_count(part, q.first_work, q.n_work);
     }
     __syncthreads();
     if (t == 0) { out.n_hits[blockIdx.x] = n; out.num_matched[blockIdx.x] = s_nm; out.off_words[blockIdx.x] = s_ow; }

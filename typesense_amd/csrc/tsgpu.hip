@@ -445,6 +445,10 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     }
     if (!strcmp(name, "vec_count_rescored")) { ctx->vec_count_rescored = value != 0; return ok(); }
     // micro-batcher (tsgpu_batcher.h): concurrent small calls are coalesced into one launch
+    if (!strcmp(name, "kw_lanes")) {                   // execution lanes (stream + scratch each) that concurrent keyword batches spread over
+        if (value < 1 || value > tsgpu_ctx::N_LANES) return fail(TSGPU_ERR_INVALID, "kw_lanes out of range (1..8)");
+        ctx->n_lanes = (int)value; return ok();
+    }
     if (!strcmp(name, "batch_window_us")) { ctx->batch_window_us = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 100000); return ok(); }
     if (!strcmp(name, "batch_max_queries")) { ctx->batch_max_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20); return ok(); }   // 0 = never coalesce
     if (!strcmp(name, "batch_round_queries")) { ctx->batch_round_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 1 << 20); return ok(); }
@@ -465,6 +469,14 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!strcmp(name, "vec_prefilter_fallbacks")) { *out = ctx->vec_prefilter_fallbacks; return ok(); }
     if (!strcmp(name, "vec_prefilter_groups")) { *out = ctx->vec_prefilter_groups; return ok(); }
     if (!strcmp(name, "vec_rescored_rows")) { *out = ctx->vec_rescored_rows; return ok(); }
+    if (!strcmp(name, "kw_batches")) { *out = ctx->kw_batches.load(); return ok(); }                 // host-side phase totals (us) over all keyword batches
+    if (!strcmp(name, "kw_plan_us")) { *out = ctx->kw_plan_us.load(); return ok(); }
+    if (!strcmp(name, "kw_upload_us")) { *out = ctx->kw_upload_us.load(); return ok(); }
+    if (!strcmp(name, "kw_launch_us")) { *out = ctx->kw_launch_us.load(); return ok(); }
+    if (!strcmp(name, "kw_wait_us")) { *out = ctx->kw_wait_us.load(); return ok(); }
+    if (!strcmp(name, "kw_book_us")) { *out = ctx->kw_book_us.load(); return ok(); }
+    if (!strcmp(name, "batch_exec_us")) { *out = ctx->batch_exec_us.load(); return ok(); }           // coalesced rounds: batch execution / hand-out to the callers
+    if (!strcmp(name, "batch_scatter_us")) { *out = ctx->batch_scatter_us.load(); return ok(); }
     if (!strcmp(name, "batch_rounds")) { *out = ctx->kw_comb.rounds + ctx->vec_comb.rounds; return ok(); }               // coalesced rounds executed so far
     if (!strcmp(name, "batch_coalesced_calls")) { *out = ctx->kw_comb.coalesced_calls + ctx->vec_comb.coalesced_calls; return ok(); }   // calls served by those rounds
     return fail(TSGPU_ERR_NOT_FOUND, std::string("tsgpu_get_counter: unknown counter ") + name);
@@ -485,6 +497,7 @@ struct Plan {
     std::vector<KwWorkItem> work_mf_small, work_mf_big;   // multi-field kernels, TMAX 3 / TMAX 10
     std::vector<KwWorkItem> work_wild;                    // wildcard scans
     std::vector<KwQueryMF> mf;
+    std::vector<KwMergeGroup> groups;                     // first level of the two-level merge (queries with many work items)
     bool any_s2 = false;              // some query has a third sort key
     std::vector<uint32_t> aux;
     std::vector<int32_t> status, cutoff;
@@ -708,7 +721,8 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
         // small batches are as slow as their heaviest query: its longest work item (~3 us per driver block when the chip is not full)
         // plus the chain of partial folds in kw_merge_kernel (~4.5 us each) -> the item count that balances the two, ~sqrt(blocks / 1.5)
         uint32_t max_partials = ctx->kw_max_partials;
-        if (n_queries < 512) max_partials = std::max(max_partials, std::min<uint32_t>(128, (uint32_t)std::sqrt((double)dA.n_blocks / 1.5)));
+        // (with the two-level merge a chain of P folds costs G + P / G, G = 8: the balance moves to ~sqrt(2.7 x blocks) items)
+        if (n_queries < 512) max_partials = std::max(max_partials, std::min<uint32_t>(384, (uint32_t)std::sqrt((double)dA.n_blocks * 2.7)));
         // ... but never longer than 256 blocks (only the batch-wide chunk of a very large batch goes beyond, up to KW_MAX_CHUNK): the batch is as slow as its longest work item (a 16K-block driver list cut in 16
         // would run 1 000 blocks in sequence), and folding 64 sorted partials costs kw_merge_kernel ~0.3 ms
         if (ctx->kw_chunk_blocks == 0) chunk_q = std::max(chunk_q, std::min<uint32_t>((dA.n_blocks + max_partials - 1) / max_partials, 256u));
@@ -764,6 +778,18 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
             P.q[i].n_work = q_cnt[i];
             dst.insert(dst.end(), flat_work.begin() + q_begin[i], flat_work.begin() + q_begin[i] + q_cnt[i]);
         }
+        // merge sources: the work items' lists, or — more than 2 x 8 of them — group lists of 8 folded in parallel first (slots behind
+        // the work items' own)
+        const uint32_t G = 8;
+        uint32_t slot = (uint32_t)acc;
+        for (uint32_t i = 0; i < n_queries; i++) {
+            KwQueryDev& q = P.q[i];
+            q.m_first = q.first_work; q.m_n = q.n_work;
+            if (q.n_work <= 2 * G) continue;
+            q.m_first = slot;
+            q.m_n = (q.n_work + G - 1) / G;
+            for (uint32_t a = 0; a < q.n_work; a += G) P.groups.push_back({i, q.first_work + a, std::min(G, q.n_work - a), slot++});
+        }
     }
     if (plan_timing) fprintf(stderr, "[tsgpu] plan: per-query loop %llu us, cost sort %llu us, table layout %llu us\n", (unsigned long long)(tp1 - tp0),
                              (unsigned long long)(tp2 - tp1), (unsigned long long)(now_us() - tp2));
@@ -776,10 +802,11 @@ struct LaneLock {                                     // holds one execution lan
     tsgpu_ctx* ctx; KwLane* L; int index;
     explicit LaneLock(tsgpu_ctx* c, int want = -1) : ctx(c), L(nullptr), index(-1) {
         if (want < 0) {
-            for (int i = 0; i < tsgpu_ctx::N_LANES && !L; i++) if (c->lanes[i].mu.try_lock()) { L = &c->lanes[i]; index = i; }
-            if (!L) {                                 // both busy: queue on the lane with fewer waiters
+            const int n = c->n_lanes;
+            for (int i = 0; i < n && !L; i++) if (c->lanes[i].mu.try_lock()) { L = &c->lanes[i]; index = i; }
+            if (!L) {                                 // all busy: queue on the lane with the fewest waiters
                 want = 0;
-                for (int i = 1; i < tsgpu_ctx::N_LANES; i++) if (c->lanes[i].waiters.load() < c->lanes[want].waiters.load()) want = i;
+                for (int i = 1; i < n; i++) if (c->lanes[i].waiters.load() < c->lanes[want].waiters.load()) want = i;
             }
         }
         if (!L) {
@@ -870,7 +897,10 @@ static int kw_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t 
             bo.keep_ids = want_ids;
             bo.id_lists = want_ids ? &all_ids : nullptr;
             bo.record_last = false;
+            const uint64_t te0 = now_us();
             rc = kw_batch_on_lane(ctx, L, L.c_q.data(), total, &h, bo);
+            const uint64_t te1 = now_us();
+            ctx->batch_exec_us.fetch_add(te1 - te0);
             if (rc != TSGPU_OK) err = tls_error();
             else {
                 at = 0;
@@ -901,6 +931,7 @@ static int kw_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t 
                     }
                     at += r->units;
                 }
+                ctx->batch_scatter_us.fetch_add(now_us() - te1);
             }
         } catch (const std::bad_alloc&) { rc = TSGPU_ERR_NO_MEMORY; err = "tsgpu_keyword_search_batch: host allocation failed"; }
         for (KwRequest* r : round) { r->rc = rc; r->err = err; }
@@ -959,20 +990,71 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         const uint32_t KS = out->k_stride;
         const int cap = P.max_k + KW_THREADS <= 512 ? 512 : (P.max_k + KW_THREADS <= 1024 ? 1024 : 2048);
 
-        // ---- upload plan ----
+        // ---- the plan travels in ONE pinned staging buffer and ONE host-to-device copy (queries, work items, aux ids, multi-field
+        //      descriptors, hit-record offsets): a pageable source costs a staged synchronous copy per call, five calls per batch ----
         std::vector<KwWorkItem> work(P.work_small);
         work.insert(work.end(), P.work_big.begin(), P.work_big.end());
         work.insert(work.end(), P.work_mf_small.begin(), P.work_mf_small.end());
         work.insert(work.end(), P.work_mf_big.begin(), P.work_mf_big.end());
         work.insert(work.end(), P.work_wild.begin(), P.work_wild.end());
-        if (!P.mf.empty() && (rc = upload(L.d_mf, P.mf.data(), P.mf.size() * sizeof(KwQueryMF), s))) return rc;
-        if ((rc = upload(L.d_queries, P.q.data(), P.q.size() * sizeof(KwQueryDev), s))) return rc;
-        if ((rc = upload(L.d_work, work.data(), work.size() * sizeof(KwWorkItem), s))) return rc;
         P.aux.push_back(0);
-        if ((rc = upload(L.d_aux, P.aux.data(), P.aux.size() * 4, s))) return rc;
+        // single-field tables (<= 3 tokens / up to 10 tokens) and multi-field tables: find + score kernels when the hit buffer fits, else the
+        // fused kernel. A work item can yield at most one hit per driver id, so its segment of the hit buffer holds (blk_end - blk_begin) * 256
+        // records of 1 + TMAX words; the items run in groups whose segments fit the budget.
+        struct TablePlan { bool two = false; std::vector<uint64_t> hoff; std::vector<size_t> group_start; uint64_t need = 0; size_t rec_bytes = 0; size_t hoff_at = 0; };
+        uint64_t hit_records = 0;
+        auto prep_table = [&](const std::vector<KwWorkItem>& tab, int TM, bool MFT) {
+            TablePlan tp;
+            tp.group_start.assign(1, 0);
+            if (tab.empty()) return tp;
+            const size_t nws = tab.size();
+            tp.rec_bytes = (size_t)((MFT ? TM * KW_MAX_FIELDS : TM) + 1) * 4;
+            tp.two = ctx->kw_two_kernels;
+            if (tp.two) {
+                uint64_t largest = 0, all = 0;
+                for (size_t i = 0; i < nws; i++) { const uint64_t c = (uint64_t)(tab[i].blk_end - tab[i].blk_begin) * BLOCK_IDS; largest = std::max(largest, c); all += c; }
+                hit_records += all;
+                const uint64_t budget = std::max<uint64_t>(ctx->kw_hit_buffer_records ? ctx->kw_hit_buffer_records : ((uint64_t)ctx->kw_hit_buffer_mb << 20) / tp.rec_bytes, largest);
+                tp.hoff.resize(nws);
+                uint64_t used = 0;
+                for (size_t i = 0; i < nws; i++) {
+                    const uint64_t c = (uint64_t)(tab[i].blk_end - tab[i].blk_begin) * BLOCK_IDS;
+                    if (used + c > budget) { tp.group_start.push_back(i); used = 0; }
+                    tp.hoff[i] = used; used += c; tp.need = std::max(tp.need, used);
+                }
+                tp.group_start.push_back(nws);
+                tp.two = tp.group_start.size() <= 3;          // each group drains the chip between its two kernels: beyond two groups the fused kernel wins
+            }
+            if (tp.two && L.d_hits.reserve(std::max<uint64_t>(tp.need, 1) * tp.rec_bytes)) {
+                (void)hipGetLastError();                // no room for the hit buffer: the fused kernel needs none
+                tp.two = false;
+            }
+            if (!tp.two) tp.hoff.clear();
+            return tp;
+        };
+        TablePlan tps[4] = {prep_table(P.work_small, 3, false), prep_table(P.work_big, KW_MAX_TOKENS, false), prep_table(P.work_mf_small, 3, true),
+                            prep_table(P.work_mf_big, KW_MAX_TOKENS, true)};
+        size_t plan_bytes = 0;
+        auto place = [&](size_t bytes) { const size_t at = (plan_bytes + 63) & ~(size_t)63; plan_bytes = at + bytes; return at; };
+        const size_t at_q = place(P.q.size() * sizeof(KwQueryDev)), at_w = place(work.size() * sizeof(KwWorkItem)), at_aux = place(P.aux.size() * 4),
+                     at_mf = place(P.mf.size() * sizeof(KwQueryMF));
+        for (auto& tp : tps) tp.hoff_at = place(tp.hoff.size() * 8);
+        const size_t at_grp = place(P.groups.size() * sizeof(KwMergeGroup));
+        if ((rc = L.h_plan.reserve(plan_bytes + 64)) || (rc = L.d_plan.reserve(plan_bytes + 64))) return rc;
+        {
+            uint8_t* hp = (uint8_t*)L.h_plan.p;
+            memcpy(hp + at_q, P.q.data(), P.q.size() * sizeof(KwQueryDev));
+            memcpy(hp + at_w, work.data(), work.size() * sizeof(KwWorkItem));
+            memcpy(hp + at_aux, P.aux.data(), P.aux.size() * 4);
+            if (!P.mf.empty()) memcpy(hp + at_mf, P.mf.data(), P.mf.size() * sizeof(KwQueryMF));
+            for (auto& tp : tps) if (!tp.hoff.empty()) memcpy(hp + tp.hoff_at, tp.hoff.data(), tp.hoff.size() * 8);
+            if (!P.groups.empty()) memcpy(hp + at_grp, P.groups.data(), P.groups.size() * sizeof(KwMergeGroup));
+            TSGPU_HIP_TRY(hipMemcpyAsync(L.d_plan.p, hp, plan_bytes, hipMemcpyHostToDevice, s));
+        }
+        uint8_t* const dplan = (uint8_t*)L.d_plan.p;
 
         // ---- scratch ----
-        const size_t pw = (size_t)std::max<uint32_t>(n_work, 1);
+        const size_t pw = (size_t)std::max<uint32_t>(n_work, 1) + P.groups.size();      // partial lists: one per work item + one per merge group
         if ((rc = L.d_part_s0.reserve(pw * KS * 8))) return rc;
         if ((rc = L.d_part_s1.reserve(pw * KS * 8))) return rc;
         if ((rc = L.d_part_s2.reserve(pw * KS * 8))) return rc;
@@ -998,6 +1080,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         KwOut o;
         o.k_stride = KS;
         o.off_words = L.d_out_ow.as<uint64_t>();
+        size_t out_at[8] = {0, 0, 0, 0, 0, 0, 0, 0}, out_bytes = 0;
         const bool dev_out = out->mem == TSGPU_MEM_DEVICE;
         if (dev_out) {
             if (!out->text_match || !out->vector_distance || !out->match_score_index || !out->num_matched)
@@ -1005,25 +1088,26 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             o.keys = out->keys; o.scores = out->scores; o.text_match = out->text_match; o.vector_distance = out->vector_distance;
             o.match_score_index = out->match_score_index; o.n_hits = out->n_hits; o.num_matched = out->num_matched;
         } else {
-            if ((rc = L.d_out_keys.reserve(slots * 8))) return rc;
-            if ((rc = L.d_out_scores.reserve(slots * 24))) return rc;
-            if ((rc = L.d_out_tm.reserve(slots * 8))) return rc;
-            if ((rc = L.d_out_vd.reserve(slots * 4))) return rc;
-            if ((rc = L.d_out_msi.reserve(slots))) return rc;
-            if ((rc = L.d_out_nh.reserve((size_t)n_queries * 4))) return rc;
-            if ((rc = L.d_out_nm.reserve((size_t)n_queries * 8))) return rc;
-            o.keys = L.d_out_keys.as<uint64_t>(); o.scores = L.d_out_scores.as<int64_t>(); o.text_match = L.d_out_tm.as<int64_t>();
-            o.vector_distance = L.d_out_vd.as<float>(); o.match_score_index = L.d_out_msi.as<int8_t>();
-            o.n_hits = L.d_out_nh.as<uint32_t>(); o.num_matched = L.d_out_nm.as<uint64_t>();
+            // host outputs: ONE device image [n_hits | num_matched | off_words | keys | scores | text_match | vector_distance | msi]
+            // -> one device-to-host copy per batch (seven separate copies cost a small batch ~60 us of launch overhead)
+            const size_t nq8 = ((size_t)n_queries * 4 + 7) & ~(size_t)7;
+            out_at[0] = 0; out_at[1] = nq8; out_at[2] = out_at[1] + (size_t)n_queries * 8; out_at[3] = out_at[2] + (size_t)n_queries * 8;
+            out_at[4] = out_at[3] + slots * 8; out_at[5] = out_at[4] + slots * 24; out_at[6] = out_at[5] + slots * 8; out_at[7] = out_at[6] + ((slots * 4 + 7) & ~(size_t)7);
+            out_bytes = out_at[7] + ((slots + 7) & ~(size_t)7);
+            if ((rc = L.d_out_keys.reserve(out_bytes))) return rc;
+            uint8_t* ob = (uint8_t*)L.d_out_keys.p;
+            o.n_hits = (uint32_t*)(ob + out_at[0]); o.num_matched = (uint64_t*)(ob + out_at[1]); o.off_words = (uint64_t*)(ob + out_at[2]);
+            o.keys = (uint64_t*)(ob + out_at[3]); o.scores = (int64_t*)(ob + out_at[4]); o.text_match = (int64_t*)(ob + out_at[5]);
+            o.vector_distance = (float*)(ob + out_at[6]); o.match_score_index = (int8_t*)(ob + out_at[7]);
         }
 
         // ---- launch ----
         const uint64_t t_uploaded = now_us();
         IndexView v = make_view(ctx, snap);
-        v.mf = L.d_mf.as<KwQueryMF>();
-        const KwQueryDev* dq = L.d_queries.as<KwQueryDev>();
-        const KwWorkItem* dw = L.d_work.as<KwWorkItem>();
-        const uint32_t* daux = L.d_aux.as<uint32_t>();
+        v.mf = (const KwQueryMF*)(dplan + at_mf);
+        const KwQueryDev* dq = (const KwQueryDev*)(dplan + at_q);
+        const KwWorkItem* dw = (const KwWorkItem*)(dplan + at_w);
+        const uint32_t* daux = (const uint32_t*)(dplan + at_aux);
         TSGPU_HIP_TRY(hipEventRecord(L.ev[0], s));
         auto shifted = [&](size_t sh) {                 // every kernel indexes the partials by its own blockIdx: shift the bases
             KwPartials pb = part;
@@ -1033,66 +1117,35 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             return pb;
         };
         uint32_t hit_groups = 0;
-        uint64_t hit_records = 0;
         bool find_marked = false;
-        // single-field tables (<= 3 tokens / up to 10 tokens): find + score kernels when the hit buffer fits, else the fused kernel.
-        // A work item can yield at most one hit per driver id, so its segment of the hit buffer holds (blk_end - blk_begin) * 256
-        // records of 1 + TMAX words; the items run in groups whose segments fit the budget.
-        auto run_table = [&](const std::vector<KwWorkItem>& tab, size_t first, auto tmax_tag, auto mf_tag) -> int {
+        auto run_table = [&](const std::vector<KwWorkItem>& tab, const TablePlan& tp, size_t first, auto tmax_tag, auto mf_tag) {
             constexpr int TM = decltype(tmax_tag)::value;
             constexpr bool MFT = decltype(mf_tag)::value;
-            if (tab.empty()) return TSGPU_OK;
+            if (tab.empty()) return;
             const size_t nws = tab.size();
-            const size_t rec_bytes = (size_t)((MFT ? TM * KW_MAX_FIELDS : TM) + 1) * 4;
-            bool two = ctx->kw_two_kernels;
-            std::vector<uint64_t> hoff;
-            std::vector<size_t> group_start(1, 0);
-            uint64_t need = 0;
-            if (two) {
-                uint64_t largest = 0, all = 0;
-                for (size_t i = 0; i < nws; i++) { const uint64_t c = (uint64_t)(tab[i].blk_end - tab[i].blk_begin) * BLOCK_IDS; largest = std::max(largest, c); all += c; }
-                hit_records += all;
-                const uint64_t budget = std::max<uint64_t>(ctx->kw_hit_buffer_records ? ctx->kw_hit_buffer_records : ((uint64_t)ctx->kw_hit_buffer_mb << 20) / rec_bytes, largest);
-                hoff.resize(nws);
-                uint64_t used = 0;
-                for (size_t i = 0; i < nws; i++) {
-                    const uint64_t c = (uint64_t)(tab[i].blk_end - tab[i].blk_begin) * BLOCK_IDS;
-                    if (used + c > budget) { group_start.push_back(i); used = 0; }
-                    hoff[i] = used; used += c; need = std::max(need, used);
-                }
-                group_start.push_back(nws);
-                two = group_start.size() <= 3;          // each group drains the chip between its two kernels: beyond two groups the fused kernel wins
-            }
-            if (two && L.d_hits.reserve(std::max<uint64_t>(need, 1) * rec_bytes)) {
-                (void)hipGetLastError();                // no room for the hit buffer: the fused kernel needs none
-                two = false;
-            }
-            if (two) {
-                hit_groups += (uint32_t)group_start.size() - 1;
-                DevBuf& offbuf = L.d_hit_off_tab[(MFT ? 2 : 0) + (TM == 3 ? 0 : 1)];
-                int rc2;
-                if ((rc2 = upload(offbuf, hoff.data(), nws * 8, s))) return rc2;
-                for (size_t gi = 0; gi + 1 < group_start.size(); gi++) {
-                    const size_t a = group_start[gi], b = group_start[gi + 1];
+            if (tp.two) {
+                hit_groups += (uint32_t)tp.group_start.size() - 1;
+                const uint64_t* hoff_dev = (const uint64_t*)(dplan + tp.hoff_at);
+                for (size_t gi = 0; gi + 1 < tp.group_start.size(); gi++) {
+                    const size_t a = tp.group_start[gi], b = tp.group_start[gi + 1];
                     if (b <= a) continue;
-                    if constexpr (MFT) launch_find_score_mf<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, L.d_hits.as<uint32_t>(), offbuf.as<uint64_t>() + a);
+                    if constexpr (MFT) launch_find_score_mf<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, L.d_hits.as<uint32_t>(), hoff_dev + a);
                     else {
                         const bool mark = !find_marked;
                         find_marked = true;
-                        launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, L.d_hits.as<uint32_t>(), offbuf.as<uint64_t>() + a, mark ? L.ev[3] : nullptr);
+                        launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, L.d_hits.as<uint32_t>(), hoff_dev + a, mark ? L.ev[3] : nullptr);
                     }
                 }
             } else if constexpr (MFT) launch_search_mf_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out);
             else launch_search_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out, P.any_s2);
-            return TSGPU_OK;
         };
-        if ((rc = run_table(P.work_small, 0, std::integral_constant<int, 3>(), std::false_type()))) return rc;
+        run_table(P.work_small, tps[0], 0, std::integral_constant<int, 3>(), std::false_type());
         size_t sh = P.work_small.size();
-        if ((rc = run_table(P.work_big, sh, std::integral_constant<int, KW_MAX_TOKENS>(), std::false_type()))) return rc;
+        run_table(P.work_big, tps[1], sh, std::integral_constant<int, KW_MAX_TOKENS>(), std::false_type());
         sh += P.work_big.size();
-        if ((rc = run_table(P.work_mf_small, sh, std::integral_constant<int, 3>(), std::true_type()))) return rc;
+        run_table(P.work_mf_small, tps[2], sh, std::integral_constant<int, 3>(), std::true_type());
         sh += P.work_mf_small.size();
-        if ((rc = run_table(P.work_mf_big, sh, std::integral_constant<int, KW_MAX_TOKENS>(), std::true_type()))) return rc;
+        run_table(P.work_mf_big, tps[3], sh, std::integral_constant<int, KW_MAX_TOKENS>(), std::true_type());
         sh += P.work_mf_big.size();
         if (!P.work_wild.empty()) {
             const uint32_t nw = (uint32_t)P.work_wild.size();
@@ -1101,6 +1154,13 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             else hipLaunchKernelGGL((kw_wildcard_kernel<2048>), dim3(nw), dim3(KW_THREADS), 0, s, v, dq, dw + sh, shifted(sh), daux, ids_out);
         }
         TSGPU_HIP_TRY(hipEventRecord(L.ev[1], s));
+        if (!P.groups.empty()) {
+            const KwMergeGroup* dg = (const KwMergeGroup*)(dplan + at_grp);
+            const uint32_t ng = (uint32_t)P.groups.size();
+            if (cap == 512) hipLaunchKernelGGL((kw_merge_groups_kernel<512>), dim3(ng), dim3(KW_THREADS), 0, s, dq, part, dg);
+            else if (cap == 1024) hipLaunchKernelGGL((kw_merge_groups_kernel<1024>), dim3(ng), dim3(KW_THREADS), 0, s, dq, part, dg);
+            else hipLaunchKernelGGL((kw_merge_groups_kernel<2048>), dim3(ng), dim3(KW_THREADS), 0, s, dq, part, dg);
+        }
         launch_merge(cap, s, n_queries, dq, part, o, ids_out, dw);
         TSGPU_HIP_TRY(hipEventRecord(L.ev[2], s));
         TSGPU_HIP_TRY(hipGetLastError());
@@ -1108,38 +1168,42 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
 
         // ---- results ----
         std::vector<uint64_t> off_words(n_queries);
-        // small results travel through one pinned staging buffer (a pageable destination costs ~150 us per copy call, seven calls);
-        // large ones go straight to the caller's arrays (the runtime pipelines them)
-        struct Staged { void* dst; size_t off, bytes; };
-        std::vector<Staged> staged;
         if (!dev_out) {
-            const bool stage = slots * 45 + (size_t)n_queries * 12 <= (8u << 20);
-            size_t at = 0;
-            uint8_t* pin = nullptr;
-            if (stage) { if ((rc = L.h_out.reserve(slots * 45 + (size_t)n_queries * 12 + 64))) return rc; pin = (uint8_t*)L.h_out.p; }
-            auto d2h = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
-                if (!stage) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
-                staged.push_back({dst, at, bytes});
-                const hipError_t e = hipMemcpyAsync(pin + at, src, bytes, hipMemcpyDeviceToHost, s);
-                at += (bytes + 7) & ~(size_t)7;
-                return e;
-            };
-            TSGPU_HIP_TRY(d2h(out->n_hits, o.n_hits, (size_t)n_queries * 4));
-            if (out->num_matched) TSGPU_HIP_TRY(d2h(out->num_matched, o.num_matched, (size_t)n_queries * 8));
-            TSGPU_HIP_TRY(d2h(out->keys, o.keys, slots * 8));
-            TSGPU_HIP_TRY(d2h(out->scores, o.scores, slots * 24));
-            if (out->text_match) TSGPU_HIP_TRY(d2h(out->text_match, o.text_match, slots * 8));
-            if (out->vector_distance) TSGPU_HIP_TRY(d2h(out->vector_distance, o.vector_distance, slots * 4));
-            if (out->match_score_index) TSGPU_HIP_TRY(d2h(out->match_score_index, o.match_score_index, slots));
+            // small results: the whole image through the pinned staging buffer (a pageable destination costs ~150 us per copy call);
+            // large ones: straight to the caller's arrays (the runtime pipelines them)
+            const bool stage = out_bytes <= (8u << 20);
+            if (stage) {
+                if ((rc = L.h_out.reserve(out_bytes + 64))) return rc;
+                TSGPU_HIP_TRY(hipMemcpyAsync(L.h_out.p, L.d_out_keys.p, out_bytes, hipMemcpyDeviceToHost, s));
+                TSGPU_HIP_TRY(hipStreamSynchronize(s));
+                const uint8_t* hb = (const uint8_t*)L.h_out.p;
+                memcpy(out->n_hits, hb + out_at[0], (size_t)n_queries * 4);
+                if (out->num_matched) memcpy(out->num_matched, hb + out_at[1], (size_t)n_queries * 8);
+                memcpy(off_words.data(), hb + out_at[2], (size_t)n_queries * 8);
+                memcpy(out->keys, hb + out_at[3], slots * 8);
+                memcpy(out->scores, hb + out_at[4], slots * 24);
+                if (out->text_match) memcpy(out->text_match, hb + out_at[5], slots * 8);
+                if (out->vector_distance) memcpy(out->vector_distance, hb + out_at[6], slots * 4);
+                if (out->match_score_index) memcpy(out->match_score_index, hb + out_at[7], slots);
+            } else {
+                TSGPU_HIP_TRY(hipMemcpyAsync(out->n_hits, o.n_hits, (size_t)n_queries * 4, hipMemcpyDeviceToHost, s));
+                if (out->num_matched) TSGPU_HIP_TRY(hipMemcpyAsync(out->num_matched, o.num_matched, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
+                TSGPU_HIP_TRY(hipMemcpyAsync(out->keys, o.keys, slots * 8, hipMemcpyDeviceToHost, s));
+                TSGPU_HIP_TRY(hipMemcpyAsync(out->scores, o.scores, slots * 24, hipMemcpyDeviceToHost, s));
+                if (out->text_match) TSGPU_HIP_TRY(hipMemcpyAsync(out->text_match, o.text_match, slots * 8, hipMemcpyDeviceToHost, s));
+                if (out->vector_distance) TSGPU_HIP_TRY(hipMemcpyAsync(out->vector_distance, o.vector_distance, slots * 4, hipMemcpyDeviceToHost, s));
+                if (out->match_score_index) TSGPU_HIP_TRY(hipMemcpyAsync(out->match_score_index, o.match_score_index, slots, hipMemcpyDeviceToHost, s));
+                TSGPU_HIP_TRY(hipMemcpyAsync(off_words.data(), o.off_words, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
+                TSGPU_HIP_TRY(hipStreamSynchronize(s));
+            }
             for (uint32_t i = 0; i < n_queries; i++) out->status[i] = P.status[i];
             if (out->search_cutoff) for (uint32_t i = 0; i < n_queries; i++) out->search_cutoff[i] = P.cutoff[i];
         } else {
             TSGPU_HIP_TRY(hipMemcpyAsync(out->status, P.status.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, s));
             if (out->search_cutoff) TSGPU_HIP_TRY(hipMemcpyAsync(out->search_cutoff, P.cutoff.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(off_words.data(), o.off_words, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipStreamSynchronize(s));
         }
-        TSGPU_HIP_TRY(hipMemcpyAsync(off_words.data(), o.off_words, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
-        TSGPU_HIP_TRY(hipStreamSynchronize(s));
-        for (const Staged& c : staged) memcpy(c.dst, (const uint8_t*)L.h_out.p + c.off, c.bytes);
         if (status_host) status_host->assign(P.status.begin(), P.status.end());
         const uint64_t t_synced = now_us();
 
@@ -1219,6 +1283,11 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
                 for (uint32_t i = 0; i < n_queries; i++)                      // several driver lists (query_by over several fields): ascending union
                     if (P.q[i].mf_index != KW_NONE && P.status[i] == TSGPU_OK) std::sort(il.ids.begin() + il.begin[i], il.ids.begin() + il.begin[i + 1]);
             }
+        }
+        {
+            const uint64_t t_end = now_us();
+            ctx->kw_batches.fetch_add(1); ctx->kw_plan_us.fetch_add(t_planned - t_enter); ctx->kw_upload_us.fetch_add(t_uploaded - t_planned);
+            ctx->kw_launch_us.fetch_add(t_launched - t_uploaded); ctx->kw_wait_us.fetch_add(t_synced - t_launched); ctx->kw_book_us.fetch_add(t_end - t_synced);
         }
         if (host_timing)
             fprintf(stderr, "[tsgpu] kw batch %u queries: plan %llu us, upload+reserve %llu us, launch %llu us, wait+copy %llu us, bookkeeping %llu us\n", n_queries,

@@ -106,15 +106,15 @@ struct KwLane {
     hipStream_t stream = nullptr;
     bool own_stream = true;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    DevBuf d_queries, d_work, d_aux, d_ids_out, d_mf;
+    DevBuf d_plan, d_ids_out;                        // the batch plan (queries, work items, aux ids, multi-field descriptors, hit offsets): one upload
     DevBuf d_part_s0, d_part_s1, d_part_s2, d_part_key, d_part_cnt, d_part_nm, d_part_ne, d_part_ow, d_part_f;
     DevBuf d_out_keys, d_out_scores, d_out_tm, d_out_vd, d_out_msi, d_out_nh, d_out_nm, d_out_ow, d_out_cut;
     // candidate-combination batches (tsgpu_keyword_search_candidates_batch): per-pass hits, group table, id-set bitmaps
     DevBuf d_cand_keys, d_cand_scores, d_cand_tm, d_cand_vd, d_cand_msi, d_cand_nh, d_cand_nm, d_cand_st, d_cand_gb, d_cand_qi, d_cand_found,
            d_cand_segs, d_cand_bits, d_cand_ids;
-    DevBuf d_hits, d_hit_off_tab[4];                 // hit records; per work table (<=3 / <=10 tokens, one / several fields) the items' record offsets
+    DevBuf d_hits;                                   // hit records of the two-kernel form
     DevBuf d_idseg, d_idflat;                        // per-call id lists: segment table + the gathered ids
-    PinBuf h_out, h_ids;
+    PinBuf h_out, h_plan;
     // host side of a coalesced round (micro-batcher): the round's queries and its results before they are handed to the callers
     std::vector<tsgpu_kw_query> c_q;
     std::vector<uint64_t> c_keys, c_nm;
@@ -132,13 +132,12 @@ struct KwLane {
     std::vector<std::vector<uint32_t>> last_chunk_off;   // where each work item's id segment starts (relative to last_ids_off)
     std::vector<uint8_t> last_ids_unsorted;
     void release() {
-        DevBuf* bufs[] = {&d_queries, &d_work, &d_aux, &d_ids_out, &d_mf, &d_part_s0, &d_part_s1, &d_part_s2, &d_part_key, &d_part_cnt, &d_part_nm, &d_part_ne,
+        DevBuf* bufs[] = {&d_plan, &d_ids_out, &d_part_s0, &d_part_s1, &d_part_s2, &d_part_key, &d_part_cnt, &d_part_nm, &d_part_ne,
                           &d_part_ow, &d_part_f, &d_out_keys, &d_out_scores, &d_out_tm, &d_out_vd, &d_out_msi, &d_out_nh, &d_out_nm, &d_out_ow, &d_out_cut,
                           &d_cand_keys, &d_cand_scores, &d_cand_tm, &d_cand_vd, &d_cand_msi, &d_cand_nh, &d_cand_nm, &d_cand_st, &d_cand_gb, &d_cand_qi,
-                          &d_cand_found, &d_cand_segs, &d_cand_bits, &d_cand_ids, &d_hits, &d_hit_off_tab[0], &d_hit_off_tab[1], &d_hit_off_tab[2],
-                          &d_hit_off_tab[3], &d_idseg, &d_idflat};
+                          &d_cand_found, &d_cand_segs, &d_cand_bits, &d_cand_ids, &d_hits, &d_idseg, &d_idflat};
         for (auto* b : bufs) b->release();
-        h_out.release(); h_ids.release();
+        h_out.release(); h_plan.release();
         for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (own_stream && stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
@@ -157,7 +156,8 @@ struct tsgpu_id_lists {
 };
 
 struct tsgpu_ctx {
-    static const int N_LANES = 2;
+    static const int N_LANES = 8;                    // lanes that exist; `n_lanes` of them are used (option "kw_lanes")
+    int n_lanes = 4;
     int device = 0;
     hipStream_t stream = nullptr;                    // the vector path's stream (= the stream tsgpu_set_stream installs; lane 0 shares it)
     bool own_stream = true;
@@ -182,6 +182,8 @@ struct tsgpu_ctx {
     uint32_t batch_max_queries = 64;                 // calls with more queries than this are not coalesced (they are batches already)
     uint32_t batch_round_queries = 1024;             // queries per coalesced round at most
 
+    // host-side phase totals of every keyword batch (us; introspection for the latency budget of small batches)
+    std::atomic<uint64_t> kw_batches{0}, kw_plan_us{0}, kw_upload_us{0}, kw_launch_us{0}, kw_wait_us{0}, kw_book_us{0}, batch_exec_us{0}, batch_scatter_us{0};
     tsgpu::DevBuf d_prof;                            // TSGPU_PROF builds only (null otherwise)
     bool keep_ids = false;
     uint32_t kw_max_partials = 16;                   // work items (= partial top-K lists) per query at most; longer driver lists get longer items
