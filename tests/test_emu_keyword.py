@@ -305,9 +305,24 @@ def test_multi_field_union_per_token_and_field_aggregation(pair3, chunk):
             H.assert_hits_equal(hits, i, ref, "multi-field chunk=%d q=%s" % (chunk, q.tokens))
             assert np.array_equal(g.result_ids(i), ref.result_ids)
         assert hits.n_hits.sum() > 500
-        # not accelerated (yet): filter ids together with several fields -> the caller's CPU path for that query
-        h2 = g.keyword_search_batch([T.KwQuery([1], fields=f2, filter_ids=[1, 2, 3])], k_stride=250)
-        assert h2.status[0] == B.ERR_UNSUPPORTED
+        # filter ids together with several fields (take_id() on the union iterators, src/or_iterator.cpp:218-272): hits, ids AND the
+        # reference's num_keyword_matches (ids its skip-to-next-filter-id loop lands on = distinct positive filter ranks of the intersection)
+        rng = np.random.default_rng(77)
+        fq = []
+        for toks in ([1], [2, 1], [3, 1, 2], [5, 9], [7, 1, 2, 3, 6], [119]):
+            for flt in (np.sort(rng.choice(2500, size=900, replace=False)), np.arange(100, 130), np.array([2499]), np.arange(0, 2500, 2)):
+                fq.append(T.KwQuery(toks, fields=f3, sort=sort, topster_size=250, filter_ids=flt))
+                fq.append(T.KwQuery(toks, fields=f2, sort=sort, topster_size=25, match_type=B.SUM_SCORE, filter_ids=flt))
+        h2 = g.keyword_search_batch(fq, k_stride=250)
+        assert (h2.status == 0).all()
+        for i, q in enumerate(fq):
+            ref = H.oracle_keyword(orc, q, ids_cap=4000)
+            H.assert_hits_equal(h2, i, ref, "multi-field + filter chunk=%d q=%s" % (chunk, q.tokens))
+            assert np.array_equal(g.result_ids(i), ref.result_ids)
+        assert h2.n_hits.sum() > 200
+        # the one combination left to the caller's CPU path: filter ids AND excluded ids AND several fields
+        h3 = g.keyword_search_batch([T.KwQuery([1], fields=f2, filter_ids=[1, 2, 3], excluded_ids=[2])], k_stride=250)
+        assert h3.status[0] == B.ERR_UNSUPPORTED
     finally:
         g.set_option("kw_chunk_blocks", 0)
         g.keep_result_ids(False)

@@ -99,6 +99,7 @@ struct IndexView {
     uint32_t num_docs;
     unsigned long long* prof;        // TSGPU_PROF builds: 13 counters; else null
     const struct KwQueryMF* mf;      // multi-field queries of the batch (KwQueryDev::mf_index)
+    uint32_t* fbits;                 // filtered multi-field queries: one bit per filter rank (KwQueryDev::fbits_off), zeroed per batch
 };
 
 struct KwQueryDev {                  // one search_across_fields call
@@ -121,6 +122,7 @@ struct KwQueryDev {                  // one search_across_fields call
     uint64_t ids_out_off;            // where this query's matched ids go (if kept)
     uint32_t mf_index;               // KW_NONE = one query_by field; else index into IndexView::mf
     uint32_t wild_n_ids;             // wildcard query (q = "*"): ids to scan = filter ids, or every seq_id < num_docs; 0 = keyword query
+    uint64_t fbits_off;              // filtered multi-field query: word offset of its rank bitmap in IndexView::fbits
     uint32_t m_first, m_n;           // the sorted partial lists kw_merge_kernel folds: the work items themselves, or (many work items) the
                                      // group lists kw_merge_groups_kernel left behind them (counters always come from the work items)
 };
@@ -810,7 +812,23 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2, false, SCORE>& s
         }
     }
     // num_keyword_matches under a filter (kw_filter_count below): which intersection ids does the reference's loop VISIT?
-    if (q.n_filt) {
+    if (MF && q.n_filt) {
+        // Several driver lists (query_by over several fields): the work items' hit streams interleave in id order, so the slices cannot
+        // be chained. Without exclusions the count has an order-free form: filter ranks never decrease along the intersection, so the
+        // ids the reference's loop lands on — rank exceeds the predecessor's — number exactly the DISTINCT POSITIVE ranks of the
+        // intersection. Every hit's rank is recorded in the query's bitmap (equal ranks of one work item are adjacent: only the first
+        // of a run touches memory); a work item counts the bits it set first. (Filter + exclusions + several fields: rejected by the planner.)
+        if (active) sm.f_rank[t] = rank;
+        __syncthreads();
+        bool fresh = false;
+        if (active && rank > 0 && (t == 0 || sm.f_rank[t - 1] != rank)) {
+            const uint32_t bit = 1u << ((rank - 1) & 31);
+            fresh = (atomicOr(&ix.fbits[q.fbits_off + ((rank - 1) >> 5)], bit) & bit) == 0;
+        }
+        const unsigned long long m = __ballot(fresh ? 1 : 0);
+        if ((t & 63) == 0 && m) atomicAdd(&sm.f_cnt0, (uint32_t)__popcll(m));
+        __syncthreads();
+    } else if (q.n_filt) {
         if (active) { sm.f_rank[t] = rank; sm.f_ex[t] = excl ? 1 : 0; }
         __syncthreads();
         if (q.n_excl == 0) {
@@ -980,6 +998,7 @@ __device__ inline void kw_write_partial(KwSmem<TMAX, CAP, MF, S2, false, SCORE>&
         part.n_emit[blockIdx.x] = sm.n_emit;
         part.off_words[blockIdx.x] = sm.off_words;
         if (q.n_filt == 0) part.n_match[blockIdx.x] = sm.n_match;
+        else if (MF) part.n_match[blockIdx.x] = sm.f_cnt0;            // rank bits this work item set first (summed by kw_merge_kernel)
         else {
             const uint32_t nonempty = sm.f_first ? 0u : 1u;
             const bool seq = q.n_excl != 0;                       // sequential mode tracked both variants itself
@@ -1470,7 +1489,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
         part.cnt[blockIdx.x] = n;
         part.n_emit[blockIdx.x] = sm.n_emit;
         part.off_words[blockIdx.x] = sm.off_words;
-        part.n_match[blockIdx.x] = sm.n_match;            // (filters are not combined with multi-field queries: the planner rejects them)
+        part.n_match[blockIdx.x] = q.n_filt ? sm.f_cnt0 : sm.n_match;
     }
     }
 }
@@ -1683,7 +1702,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
     // counters: always from the work items themselves (num_keyword_matches, offsets read); a filtered query chains its slices in id order
     {
         unsigned long long nm = 0, ow = 0;
-        const bool chain = q.n_filt && !q.wild_n_ids;
+        const bool chain = q.n_filt && !q.wild_n_ids && q.mf_index == KW_NONE;      // (several fields: order-free count, summed)
         for (uint32_t w = q.first_work + t; w < q.first_work + q.n_work; w += KW_THREADS) { if (!chain) nm += part.n_match[w]; ow += part.off_words[w]; }
         for (int d = 32; d > 0; d >>= 1) { nm += __shfl_down(nm, d, 64); ow += __shfl_down(ow, d, 64); }
         if ((t & 63) == 0) { if (nm) atomicAdd(&s_nm, nm); if (ow) atomicAdd(&s_ow, ow); }

@@ -49,6 +49,7 @@ IndexView make_view(tsgpu_ctx* ctx, const Snapshot& sn) {
     v.num_docs = ctx->num_docs;
     v.prof = ctx->d_prof.as<unsigned long long>();
     v.mf = nullptr;                                   // per lane: set by the batch
+    v.fbits = nullptr;
     return v;
 }
 
@@ -498,6 +499,7 @@ struct Plan {
     std::vector<KwWorkItem> work_wild;                    // wildcard scans
     std::vector<KwQueryMF> mf;
     std::vector<KwMergeGroup> groups;                     // first level of the two-level merge (queries with many work items)
+    uint64_t fbits_words = 0;                             // rank bitmaps of the filtered multi-field queries
     bool any_s2 = false;              // some query has a third sort key
     std::vector<uint32_t> aux;
     std::vector<int32_t> status, cutoff;
@@ -573,7 +575,8 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
         // the block-merge kernel stays free of the array code (it costs 2x the registers)
         bool multi = !wildcard && in.n_fields > 1;
         if (!wildcard && !multi && snap.field_is_array.at(in.field_ids[0])) multi = true;
-        if (multi && in.n_filter != 0) { unsupported("filter ids with several query_by fields"); continue; }
+        // filter ids with several query_by fields: num_keyword_matches has an order-free form only without exclusions (kw_score_stage)
+        if (multi && in.n_filter != 0 && in.n_excluded != 0) { unsupported("filter ids AND excluded ids with several query_by fields"); continue; }
         if (in.n_sort > TSGPU_MAX_SORT_KEYS) { P.status[i] = TSGPU_ERR_INVALID; continue; }
         if (in.n_filter != 0 && !in.filter_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
         if (in.match_type > TSGPU_SUM_SCORE) { P.status[i] = TSGPU_ERR_INVALID; continue; }
@@ -687,6 +690,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
             if (k + KW_THREADS > 1024) { unsupported("topster_size with several query_by fields"); continue; }
             q.mf_index = (uint32_t)P.mf.size();
             P.mf.push_back(mfq);
+            if (in.n_filter) { q.fbits_off = P.fbits_words; P.fbits_words += ((uint64_t)in.n_filter + 31) / 32; }
             q.ids_out_off = P.ids_total;
             uint64_t seg = 0;
             for (uint32_t f = 0; f < in.n_fields; f++) {
@@ -1105,6 +1109,11 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         const uint64_t t_uploaded = now_us();
         IndexView v = make_view(ctx, snap);
         v.mf = (const KwQueryMF*)(dplan + at_mf);
+        if (P.fbits_words) {
+            if ((rc = L.d_fbits.reserve(P.fbits_words * 4))) return rc;
+            TSGPU_HIP_TRY(hipMemsetAsync(L.d_fbits.p, 0, P.fbits_words * 4, s));
+        }
+        v.fbits = L.d_fbits.as<uint32_t>();
         const KwQueryDev* dq = (const KwQueryDev*)(dplan + at_q);
         const KwWorkItem* dw = (const KwWorkItem*)(dplan + at_w);
         const uint32_t* daux = (const uint32_t*)(dplan + at_aux);

@@ -113,6 +113,7 @@ struct KwLane {
     DevBuf d_cand_keys, d_cand_scores, d_cand_tm, d_cand_vd, d_cand_msi, d_cand_nh, d_cand_nm, d_cand_st, d_cand_gb, d_cand_qi, d_cand_found,
            d_cand_segs, d_cand_bits, d_cand_ids;
     DevBuf d_hits;                                   // hit records of the two-kernel form
+    DevBuf d_fbits;                                  // rank bitmaps of filtered multi-field queries
     DevBuf d_idseg, d_idflat;                        // per-call id lists: segment table + the gathered ids
     PinBuf h_out, h_plan;
     // host side of a coalesced round (micro-batcher): the round's queries and its results before they are handed to the callers
@@ -135,7 +136,7 @@ struct KwLane {
         DevBuf* bufs[] = {&d_plan, &d_ids_out, &d_part_s0, &d_part_s1, &d_part_s2, &d_part_key, &d_part_cnt, &d_part_nm, &d_part_ne,
                           &d_part_ow, &d_part_f, &d_out_keys, &d_out_scores, &d_out_tm, &d_out_vd, &d_out_msi, &d_out_nh, &d_out_nm, &d_out_ow, &d_out_cut,
                           &d_cand_keys, &d_cand_scores, &d_cand_tm, &d_cand_vd, &d_cand_msi, &d_cand_nh, &d_cand_nm, &d_cand_st, &d_cand_gb, &d_cand_qi,
-                          &d_cand_found, &d_cand_segs, &d_cand_bits, &d_cand_ids, &d_hits, &d_idseg, &d_idflat};
+                          &d_cand_found, &d_cand_segs, &d_cand_bits, &d_cand_ids, &d_hits, &d_idseg, &d_idflat, &d_fbits};
         for (auto* b : bufs) b->release();
         h_out.release(); h_plan.release();
         for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
