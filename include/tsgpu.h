@@ -245,6 +245,29 @@ void tsgpu_id_lists_free(tsgpu_id_lists* lists);
 int tsgpu_keep_result_ids(tsgpu_ctx* ctx, int keep);
 uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64_t cap);
 
+/* ------------------------------------------------------------------ facet counting over matched ids */
+/* The hash-index branch of Index::do_facets (src/index.cpp:1659-1771): for every matched id (ascending, e.g. the id list of
+ * tsgpu_keyword_search_batch_ids) the field's facet hash index (facet_index_v4's hash index, a posting list seq_id -> value hashes)
+ * is looked up and result_map[hash] is bumped once per DISTINCT hash of the document; doc_id / array_pos = the last (greatest)
+ * document that carried the value and the value's position in it.
+ *   tsgpu_facet_set: the mirror of one field's facet hash index, CSR by seq_id: doc_ptr[d] .. doc_ptr[d+1] = the hashes of document d
+ *     in field order (empty = no value; documents >= n_docs have none). Host arrays; replaces the field's mirror.
+ *   tsgpu_facet_count_batch: result_ids[q] = host array of n_result_ids[q] ascending ids. sample_mod > 1 = estimate_facets (only the
+ *     ids at positions i % sample_mod == 0, :1683-1687); allowed_hashes (sorted, NULL = all) = fquery_hashes of a facet query (:1742).
+ *     out: [n_queries][cap] in ascending hash order; n_values[q] = distinct values found (may exceed cap: the first cap are returned).
+ * Not covered (the caller keeps its CPU body): group_by (hash_groups), range facets, stats, the value-index ("intersect") branch. */
+typedef struct tsgpu_facet_counts {
+    uint32_t cap;            /* slots per query */
+    uint32_t* hash;          /* [n_queries * cap] facet value hash */
+    uint32_t* count;         /* facet_count_t::count */
+    uint32_t* doc_id;        /* facet_count_t::doc_id */
+    uint32_t* array_pos;     /* facet_count_t::array_pos */
+    uint32_t* n_values;      /* [n_queries] */
+} tsgpu_facet_counts;
+int tsgpu_facet_set(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint64_t* doc_ptr, const uint32_t* hashes, uint32_t n_docs);
+int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
+                            uint32_t sample_mod, const uint32_t* allowed_hashes, uint32_t n_allowed, tsgpu_facet_counts* out);
+
 /* ------------------------------------------------------------------ vector index (seam B2) */
 int tsgpu_vec_create(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t dim, int metric, uint64_t capacity_hint);
 /* addPoint: cosine fields are L2-normalised on insert like src/index.cpp:1049-1052. data: [n][dim] fp32. */

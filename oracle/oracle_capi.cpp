@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include "oracle_index.h"
+#include "facet_count.h"
 #include "hnsw_graph.h"
 #include <map>
 
@@ -272,6 +273,27 @@ int32_t orc_search_hybrid(void* h, const orc_kw_query* q, const float* qvec, uin
     vq.distance_threshold = distance_threshold;
     fill(idx->search_hybrid(to_query(q), vq), out);
     return 0;
+}
+
+// ---- facet counting over result ids (do_facets, hash-index branch) ----
+static std::map<std::pair<void*, uint32_t>, oracle::FacetHashIndex>& facets_of() { static std::map<std::pair<void*, uint32_t>, oracle::FacetHashIndex> m; return m; }
+void orc_facet_set(void* h, uint32_t field, const uint64_t* doc_ptr, const uint32_t* hashes, uint32_t n_docs) {
+    oracle::FacetHashIndex& f = facets_of()[{h, field}];
+    f.docs.clear();
+    for (uint32_t d = 0; d < n_docs; d++)
+        if (doc_ptr[d + 1] > doc_ptr[d]) f.docs[d].assign(hashes + doc_ptr[d], hashes + doc_ptr[d + 1]);
+}
+uint32_t orc_facet_count(void* h, uint32_t field, const uint32_t* ids, uint64_t n_ids, uint32_t sample_mod, const uint32_t* allowed, uint32_t n_allowed,
+                         uint32_t* out_hash, uint32_t* out_count, uint32_t* out_doc, uint32_t* out_pos, uint32_t cap) {
+    const oracle::FacetHashIndex& f = facets_of()[{h, field}];
+    std::set<uint32_t> fq(allowed, allowed + n_allowed);
+    const auto m = f.count(ids, n_ids, sample_mod, allowed ? &fq : nullptr);
+    uint32_t i = 0;
+    for (const auto& kv : m) {
+        if (i < cap) { out_hash[i] = kv.first; out_count[i] = kv.second.count; out_doc[i] = kv.second.doc_id; out_pos[i] = kv.second.array_pos; }
+        i++;
+    }
+    return i;
 }
 
 // ---- CPU baseline drivers: one query per thread, like the reference server (thread-per-request) ----

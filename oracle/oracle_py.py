@@ -87,6 +87,9 @@ def lib():
         L.orc_search_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(Result)]
         L.orc_search_hybrid.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.POINTER(Result)]
+        L.orc_facet_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_facet_count.restype = C.c_uint32
+        L.orc_facet_count.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_bench_keyword.restype = C.c_double
         L.orc_bench_keyword.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
         L.orc_bench_vector.restype = C.c_double
@@ -291,6 +294,21 @@ class OracleIndex:
         qv = np.ascontiguousarray(qvec, dtype=np.float32)
         self.L.orc_search_hybrid(self.h, C.byref(q), _ptr(qv), k, alpha, distance_threshold, C.byref(r))
         return self._decode(r, b)
+
+    # ---- facets (oracle/facet_count.h) ----
+    def facet_set(self, field, doc_ptr, hashes):
+        dp = np.ascontiguousarray(doc_ptr, dtype=np.uint64)
+        hs = _u32(hashes)
+        self.L.orc_facet_set(self.h, field, _ptr(dp), hs.ctypes.data_as(C.c_void_p), dp.size - 1)
+
+    def facet_count(self, field, ids, sample_mod=1, allowed_hashes=None, cap=65536):
+        ids = _u32(ids)
+        a = _u32(allowed_hashes) if allowed_hashes is not None else None
+        h, c, d, p = (np.zeros(cap, np.uint32) for _ in range(4))
+        n = self.L.orc_facet_count(self.h, field, ids.ctypes.data_as(C.c_void_p), ids.size, sample_mod, a.ctypes.data_as(C.c_void_p) if a is not None else None,
+                                   a.size if a is not None else 0, _ptr(h), _ptr(c), _ptr(d), _ptr(p), cap)
+        m = min(n, cap)
+        return h[:m].copy(), c[:m].copy(), d[:m].copy(), p[:m].copy(), n
 
     # ---- HNSW (oracle/hnsw_graph.h) ----
     def hnsw_build(self, M=16, ef_construction=200, seed=100):

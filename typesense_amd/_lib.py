@@ -51,6 +51,10 @@ class HybridParamsC(C.Structure):
     _fields_ = [("k", C.c_uint32), ("fetch_size", C.c_uint32), ("alpha", C.c_float), ("distance_threshold", C.c_float)]
 
 
+class FacetCountsC(C.Structure):
+    _fields_ = [("cap", C.c_uint32), ("hash", C.c_void_p), ("count", C.c_void_p), ("doc_id", C.c_void_p), ("array_pos", C.c_void_p), ("n_values", C.c_void_p)]
+
+
 class TimingsC(C.Structure):
     _fields_ = [("kw_search_ms", C.c_float), ("kw_merge_ms", C.c_float), ("vec_knn_ms", C.c_float), ("vec_merge_ms", C.c_float),
                 ("total_ms", C.c_float), ("vec_scan_ms", C.c_float), ("kw_algorithmic_bytes", C.c_uint64), ("vec_flops", C.c_uint64),
@@ -61,7 +65,7 @@ EXPORTS = [
     "tsgpu_abi_version", "tsgpu_create", "tsgpu_destroy", "tsgpu_last_error", "tsgpu_set_stream", "tsgpu_set_option", "tsgpu_get_counter", "tsgpu_device_bytes",
     "tsgpu_field_create", "tsgpu_term_upsert", "tsgpu_terms_load_csr", "tsgpu_column_set", "tsgpu_set_num_docs", "tsgpu_commit",
     "tsgpu_term_num_ids", "tsgpu_term_download", "tsgpu_keyword_search_batch", "tsgpu_wildcard_search_batch", "tsgpu_keyword_search_candidates_batch", "tsgpu_candidates_result_ids", "tsgpu_keep_result_ids", "tsgpu_result_ids",
-    "tsgpu_keyword_search_batch_ids", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free",
+    "tsgpu_keyword_search_batch_ids", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free", "tsgpu_facet_set", "tsgpu_facet_count_batch",
     "tsgpu_vec_create", "tsgpu_vec_upsert", "tsgpu_vec_delete", "tsgpu_vec_get", "tsgpu_vec_count", "tsgpu_vec_knn_batch",
     "tsgpu_vec_hnsw_load", "tsgpu_vec_hnsw_search_batch", "tsgpu_vec_distances", "tsgpu_vector_search_batch", "tsgpu_hybrid_search_batch", "tsgpu_hybrid_fuse_batch", "tsgpu_merge_shard_hits", "tsgpu_merge_shard_hits_device", "tsgpu_last_timings",
 ]
@@ -113,6 +117,8 @@ def lib(path=None):
     L.tsgpu_id_lists_ids.restype = C.POINTER(C.c_uint32)
     L.tsgpu_id_lists_free.argtypes = [vp]
     L.tsgpu_id_lists_free.restype = None
+    L.tsgpu_facet_set.argtypes = [vp, u32, vp, vp, u32]
+    L.tsgpu_facet_count_batch.argtypes = [vp, u32, vp, vp, u32, u32, vp, u32, C.POINTER(FacetCountsC)]
     L.tsgpu_vec_create.argtypes = [vp, u32, u32, i32, u64]
     L.tsgpu_vec_upsert.argtypes = [vp, u32, vp, vp, u32, i32]
     L.tsgpu_vec_delete.argtypes = [vp, u32, u64]

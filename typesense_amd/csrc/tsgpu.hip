@@ -149,12 +149,14 @@ int tsgpu_create(int device_ordinal, tsgpu_ctx** out) {
 }
 
 void tsgpu_vec_destroy_all(tsgpu_ctx* ctx);   // tsgpu_vec.hip
+void tsgpu_facet_destroy_all(tsgpu_ctx* ctx); // tsgpu_facet.hip
 
 void tsgpu_destroy(tsgpu_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     tsgpu_vec_destroy_all(ctx);
+    tsgpu_facet_destroy_all(ctx);
     for (auto& L : ctx->lanes) L.release();
     std::atomic_store(&ctx->snap, std::shared_ptr<const Snapshot>());
     ctx->d_col_ptrs.release(); ctx->d_col_len.release(); ctx->d_prof.release();

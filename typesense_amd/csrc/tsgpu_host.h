@@ -96,6 +96,7 @@ struct Snapshot {            // immutable HBM image of all posting lists; publis
 struct ColumnDev { DevBuf data; uint32_t n = 0; std::vector<int64_t> host; /* mirror for the <=k-hit host steps (vector / hybrid) */ };
 
 struct VecField;             // tsgpu_vec.hip
+struct FacetField;           // tsgpu_facet.hip
 
 // One in-flight keyword batch: its own stream, events and every piece of per-batch scratch (plan upload, partial top-K lists,
 // hit records, outputs). The context owns two lanes: while one batch runs on the GPU the next is planned, uploaded and launched
@@ -207,6 +208,7 @@ struct tsgpu_ctx {
     uint64_t vec_overflow_rounds = 0;                // pass-2 repeats caused by candidate overflow (introspection)
 
     std::unordered_map<uint32_t, tsgpu::VecField*> vec_fields;
+    std::unordered_map<uint32_t, tsgpu::FacetField*> facet_fields;
 
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [3..7]: the vector path
     tsgpu_timings timings{};

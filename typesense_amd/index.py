@@ -241,6 +241,27 @@ class GpuIndex:
             self.L.tsgpu_id_lists_free(lists)
         return hits, ids
 
+    # ---- facet counting over matched ids (do_facets, hash-index branch) ----
+    def facet_set(self, field_id, doc_ptr, hashes):
+        doc_ptr = np.ascontiguousarray(doc_ptr, dtype=np.uint64)
+        hashes = _u32(hashes)
+        self._ck(self.L.tsgpu_facet_set(self.h, field_id, _vp(doc_ptr), hashes.ctypes.data_as(C.c_void_p), doc_ptr.size - 1))
+
+    def facet_count_batch(self, field_id, id_lists, cap=1024, sample_mod=1, allowed_hashes=None):
+        """id_lists: per query an ascending uint32 id array -> per query (hash, count, doc_id, array_pos) arrays in ascending hash order"""
+        lists = [_u32(x) for x in id_lists]
+        n = len(lists)
+        ptrs = (C.c_void_p * n)(*[x.ctypes.data if x.size else None for x in lists])
+        cnts = np.array([x.size for x in lists], np.uint64)
+        out = B.FacetCountsC()
+        h, c, d, p, nv = (np.zeros((n, cap), np.uint32) for _ in range(4)) if False else (np.zeros((n, cap), np.uint32), np.zeros((n, cap), np.uint32),
+                                                                                          np.zeros((n, cap), np.uint32), np.zeros((n, cap), np.uint32), np.zeros(n, np.uint32))
+        out.cap, out.hash, out.count, out.doc_id, out.array_pos, out.n_values = cap, h.ctypes.data, c.ctypes.data, d.ctypes.data, p.ctypes.data, nv.ctypes.data
+        a = None if allowed_hashes is None else _u32(allowed_hashes)
+        self._ck(self.L.tsgpu_facet_count_batch(self.h, field_id, C.cast(ptrs, C.c_void_p), _vp(cnts), n, sample_mod,
+                                                _vp(a) if a is not None else None, a.size if a is not None else 0, C.byref(out)))
+        return [(h[q, :min(nv[q], cap)].copy(), c[q, :min(nv[q], cap)].copy(), d[q, :min(nv[q], cap)].copy(), p[q, :min(nv[q], cap)].copy(), int(nv[q])) for q in range(n)]
+
     def keep_result_ids(self, keep=True):
         self._ck(self.L.tsgpu_keep_result_ids(self.h, int(keep)))
 
