@@ -140,6 +140,14 @@ int tsgpu_terms_load_csr(tsgpu_ctx* ctx, uint32_t field_id, uint32_t n_terms, co
                          const uint64_t* ids_ptr, const uint32_t* ids, const uint64_t* offset_index,
                          const uint64_t* off_ptr, const uint32_t* offsets);
 
+/* Single-document mutation, the calls the reference makes on an ART leaf's posting object while indexing / removing a document
+ * (posting_t::upsert(obj, id, offsets) / posting_t::erase(obj, id), src/posting.cpp:247-330, from Index::index_field_in_memory and
+ * Index::remove_field, under the unique_lock of Index::mutex): document `id` gets `offsets` (the reference's encoding) in the list of
+ * (field, term) — inserted in id order, or its run replaced — / leaves the list. ONE block of the list changes; tsgpu_commit then
+ * uploads only the changed blocks (+ the list's small descriptor arrays): a write batch costs O(changed blocks), not O(index). */
+int tsgpu_posting_upsert(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, uint32_t id, const uint32_t* offsets, uint32_t n_offsets);
+int tsgpu_posting_erase(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, uint32_t id);
+
 /* Dense numeric sort column (the reference's sort_index[field], include/index.h:442): values[seq_id];
  * present == NULL means every seq_id < n has a value, else present[seq_id] != 0. mem = tsgpu_mem_kind. */
 int tsgpu_column_set(tsgpu_ctx* ctx, uint32_t column_id, const int64_t* values, const uint8_t* present,
@@ -148,7 +156,12 @@ int tsgpu_column_set(tsgpu_ctx* ctx, uint32_t column_id, const int64_t* values, 
 /* number of documents (num_seq_ids(), bounds the Topster capacity, src/index.cpp:3510) */
 int tsgpu_set_num_docs(tsgpu_ctx* ctx, uint32_t num_docs);
 
-/* publish all pending term/column changes to HBM as one immutable snapshot */
+/* Publish all pending posting-list changes as ONE new immutable snapshot (RCU): searches that started before keep the snapshot they
+ * run on, searches never wait for a commit, a failing commit leaves the previous snapshot in place. Incremental: re-written blocks
+ * and the touched lists' descriptors are appended at the tails of the device arenas and a new descriptor table is swapped in;
+ * everything is re-packed (compaction) only at the first commit, when the tails run out of room, when garbage outweighs live data,
+ * or after tsgpu_set_option(ctx, "commit_full", 1). Counters: "commit_last_us", "commit_last_uploaded_bytes", "commit_full_count",
+ * "commit_incremental_count". */
 int tsgpu_commit(tsgpu_ctx* ctx);
 
 /* introspection (tests): number of ids of a term, 0 if absent */

@@ -12,7 +12,7 @@ mkdir -p "$HERE/_build"
 # optional: $1 = extra -D flags, $2 = output suffix (variant builds for tests that force rarely-taken paths)
 EXTRA="$1"
 OUT="$HERE/_build/libtsgpu_emu$2.so"
-SRCS="$ROOT/typesense_amd/csrc/tsgpu.hip $ROOT/typesense_amd/csrc/tsgpu_vec.hip $ROOT/typesense_amd/csrc/tsgpu_facet.hip"
+SRCS="$ROOT/typesense_amd/csrc/tsgpu.hip $ROOT/typesense_amd/csrc/tsgpu_index.hip $ROOT/typesense_amd/csrc/tsgpu_vec.hip $ROOT/typesense_amd/csrc/tsgpu_facet.hip"
 NEWER=0
 for f in $SRCS "$ROOT"/typesense_amd/csrc/*.h "$ROOT"/include/*.h "$HERE"/hip/hip_runtime.h; do
   if [ ! -f "$OUT" ] || [ "$f" -nt "$OUT" ]; then NEWER=1; fi

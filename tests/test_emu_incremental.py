@@ -1,0 +1,123 @@
+"""Incremental, block-granular commits (tsgpu_index.hip): single-document posting_t::upsert / erase calls mutate one block of one list,
+tsgpu_commit uploads only the changed blocks + the touched lists' descriptors to the arena tails and publishes a new descriptor table.
+After every commit the mirror must equal an index built from scratch: format round trip vs the oracle's postings and bit-exact
+search results (incl. lists whose relocated blocks break the coalesced runs: LIST_HAS_BREAKS -> per-candidate probes).
+Emulator tier; the `-m gpu` twin (tests/test_gpu_incremental.py) adds the 10M-doc timing bound."""
+import numpy as np
+import pytest
+
+import typesense_amd as T
+from typesense_amd import _lib as B
+from oracle import oracle_py as O
+from tests import helpers as H
+
+
+def fresh_oracle(docs, live):
+    orc = O.OracleIndex(1, 1)
+    for d in range(docs.shape[0]):
+        if live[d]:
+            orc.index_plain(d, 0, docs[d])
+    orc.set_num_docs(docs.shape[0])
+    orc.set_sort_dense(0, H.points_of(docs.shape[0]))
+    return orc
+
+
+def check_equal(g, orc, rng, what, n_queries=10):
+    for term in orc.terms(0):
+        ids, oi, off = orc.dump_posting(0, int(term))
+        gi, go, gf = g.term_download(0, int(term))
+        assert np.array_equal(ids, gi) and np.array_equal(oi, go) and np.array_equal(off, gf), "%s: posting list of term %d" % (what, term)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    qs = [T.KwQuery(rng.choice(np.arange(1, 25), size=int(rng.integers(1, 4)), replace=False), sort=sort, topster_size=250) for _ in range(n_queries)]
+    qs.append(T.KwQuery([1, 2], sort=sort, topster_size=250, filter_ids=np.arange(0, 5000, 3, dtype=np.uint32)))
+    hits = g.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all()
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(hits, i, H.oracle_keyword(orc, q), what)
+
+
+def test_appends_updates_and_removals_publish_incrementally():
+    rng = np.random.default_rng(2)
+    n0, n1 = 2600, 3000
+    docs = H.zipf_docs(n1, 60, 7, seed=9)
+    live = np.zeros(n1, bool)
+    live[:n0] = True
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.field_create(0, False)
+    for d in range(n0):
+        g.index_plain_doc(d, 0, docs[d])
+    g.column_set(0, H.points_of(n1))
+    g.set_num_docs(n1)
+    g.commit()
+    assert g.counter("commit_full_count") == 1
+    check_equal(g, fresh_oracle(docs, live), rng, "initial build through posting_upsert")
+
+    # 1) a write batch of new documents (largest ids: every touched list grows at its end)
+    for d in range(n0, n0 + 150):
+        g.index_plain_doc(d, 0, docs[d])
+        live[d] = True
+    g.commit()
+    assert g.counter("commit_incremental_count") == 1 and g.counter("commit_full_count") == 1
+    full_bytes = g.device_bytes()
+    assert g.counter("commit_last_uploaded_bytes") < full_bytes / 4, "an append batch re-uploaded most of the index"
+    check_equal(g, fresh_oracle(docs, live), rng, "after appending 150 documents")
+
+    # 2) updates of existing documents (erase the old postings, upsert the new ones: blocks in the middle of lists change, some split)
+    for d in rng.choice(n0, size=120, replace=False):
+        g.remove_plain_doc(int(d), 0, docs[d])
+        docs[d] = rng.integers(1, 30, size=docs.shape[1])
+        g.index_plain_doc(int(d), 0, docs[d])
+    # 3) removals, incl. every document of a rare term (the term disappears) ...
+    for d in rng.choice(n0, size=80, replace=False):
+        g.remove_plain_doc(int(d), 0, docs[d])
+        live[d] = False
+    rare = 59
+    for d in range(n1):
+        if live[d] and rare in docs[d]:
+            g.remove_plain_doc(d, 0, docs[d])
+            live[d] = False
+    # ... and the rest of the new documents, in one commit
+    for d in range(n0 + 150, n1):
+        if rare in docs[d]:
+            continue
+        g.index_plain_doc(d, 0, docs[d])
+        live[d] = True
+    g.commit()
+    assert g.counter("commit_incremental_count") == 2
+    orc = fresh_oracle(docs, live)
+    assert rare not in set(int(t) for t in orc.terms(0)) and g.term_num_ids(0, rare) == 0
+    check_equal(g, orc, rng, "after updates, removals and appends")
+    # a vanished term is skipped like any token absent from the index (src/index.cpp:5651-5655)
+    hits = g.keyword_search_batch([T.KwQuery([1, rare], topster_size=50)], k_stride=50)
+    H.assert_hits_equal(hits, 0, H.oracle_keyword(orc, T.KwQuery([1, rare], topster_size=50)), "vanished term")
+
+    # 4) a forced compaction restores contiguous lists and changes nothing
+    g.set_option("commit_full", 1)
+    g.commit()
+    assert g.counter("commit_full_count") == 2
+    check_equal(g, orc, rng, "after compaction")
+    g.close()
+
+
+def test_many_small_commits_until_the_tails_run_out():
+    rng = np.random.default_rng(5)
+    n = 1500
+    docs = H.zipf_docs(n, 40, 6, seed=4)
+    live = np.zeros(n, bool)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.set_option("index_min_slack_words", 3000)       # (tiny arenas: the tails fill up within a few batches)
+    g.field_create(0, False)
+    g.column_set(0, H.points_of(n))
+    g.set_num_docs(n)
+    for d in range(200):
+        g.index_plain_doc(d, 0, docs[d])
+        live[d] = True
+    g.commit()
+    for a in range(200, n, 100):                  # 13 write batches; the arenas were sized for the first 200 documents
+        for d in range(a, a + 100):
+            g.index_plain_doc(d, 0, docs[d])
+            live[d] = True
+        g.commit()
+    assert g.counter("commit_incremental_count") >= 1 and g.counter("commit_full_count") >= 2, "the tails never filled up / never compacted"
+    check_equal(g, fresh_oracle(docs, live), rng, "after 13 write batches", n_queries=6)
+    g.close()

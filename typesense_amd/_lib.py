@@ -63,7 +63,7 @@ class TimingsC(C.Structure):
 
 EXPORTS = [
     "tsgpu_abi_version", "tsgpu_create", "tsgpu_destroy", "tsgpu_last_error", "tsgpu_set_stream", "tsgpu_set_option", "tsgpu_get_counter", "tsgpu_device_bytes",
-    "tsgpu_field_create", "tsgpu_term_upsert", "tsgpu_terms_load_csr", "tsgpu_column_set", "tsgpu_set_num_docs", "tsgpu_commit",
+    "tsgpu_field_create", "tsgpu_term_upsert", "tsgpu_posting_upsert", "tsgpu_posting_erase", "tsgpu_terms_load_csr", "tsgpu_column_set", "tsgpu_set_num_docs", "tsgpu_commit",
     "tsgpu_term_num_ids", "tsgpu_term_download", "tsgpu_keyword_search_batch", "tsgpu_wildcard_search_batch", "tsgpu_keyword_search_candidates_batch", "tsgpu_candidates_result_ids", "tsgpu_keep_result_ids", "tsgpu_result_ids",
     "tsgpu_keyword_search_batch_ids", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free", "tsgpu_facet_set", "tsgpu_facet_count_batch",
     "tsgpu_vec_create", "tsgpu_vec_upsert", "tsgpu_vec_delete", "tsgpu_vec_get", "tsgpu_vec_count", "tsgpu_vec_knn_batch",
@@ -95,6 +95,8 @@ def lib(path=None):
     L.tsgpu_device_bytes.restype = u64
     L.tsgpu_field_create.argtypes = [vp, u32, i32]
     L.tsgpu_term_upsert.argtypes = [vp, u32, u32, vp, vp, vp, u32, u32]
+    L.tsgpu_posting_upsert.argtypes = [vp, u32, u32, u32, vp, u32]
+    L.tsgpu_posting_erase.argtypes = [vp, u32, u32, u32]
     L.tsgpu_terms_load_csr.argtypes = [vp, u32, u32, vp, vp, vp, vp, vp, vp]
     L.tsgpu_column_set.argtypes = [vp, u32, vp, vp, u32, i32]
     L.tsgpu_set_num_docs.argtypes = [vp, u32]

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtsgpu.so")
-SOURCES = ["tsgpu.hip", "tsgpu_vec.hip", "tsgpu_facet.hip"]
+SOURCES = ["tsgpu.hip", "tsgpu_index.hip", "tsgpu_vec.hip", "tsgpu_facet.hip"]
 
 
 def _hipcc():

@@ -1109,6 +1109,12 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
         }
         P.ver = wver;
         const uint32_t w_endw = win.ids_woff + packed_words(win.n_ids_bits & 0xFFFF, win.n_ids_bits >> 16);
+        if (dB.flags & LIST_HAS_BREAKS) {                                // (uniform, rare: blocks re-written by an incremental commit)
+            // the tile copy below takes the run's ids as ONE range of the arena: a run with a relocated block inside is probed per candidate
+            const uint32_t nxt_woff = (uint32_t)__shfl(win.ids_woff, (int)((lane + 1) & 63));
+            const bool brk = lane >= P.rlo && lane < P.rhi && w_endw != nxt_woff;
+            if (__ballot(brk ? 1 : 0) != 0) { P.mode = 2; return P; }
+        }
         P.w_begin = (uint32_t)__shfl(win.ids_woff, (int)P.rlo);
         P.W = (uint32_t)__shfl(w_endw, (int)P.rhi) - P.w_begin;
         if (P.W <= (uint32_t)(PIPE_WORDS * KW_THREADS)) {

@@ -38,11 +38,11 @@ int refresh_column_table(tsgpu_ctx* ctx) {
 IndexView make_view(tsgpu_ctx* ctx, const Snapshot& sn) {
     IndexView v;
     v.lists = sn.lists.as<ListDesc>();
-    v.blk_last = sn.blk_last.as<uint32_t>();
-    v.blk_ids = sn.blk_ids.as<BlockIds>();
-    v.blk_meta = sn.blk_meta.as<BlockMeta>();
-    v.ids_payload = sn.ids_payload.as<uint32_t>();
-    v.payload = sn.payload.as<uint32_t>();
+    v.blk_last = sn.ar ? sn.ar->blk_last.as<uint32_t>() : nullptr;
+    v.blk_ids = sn.ar ? sn.ar->blk_ids.as<BlockIds>() : nullptr;
+    v.blk_meta = sn.ar ? sn.ar->blk_meta.as<BlockMeta>() : nullptr;
+    v.ids_payload = sn.ar ? sn.ar->ids_payload.as<uint32_t>() : nullptr;
+    v.payload = sn.ar ? sn.ar->payload.as<uint32_t>() : nullptr;
     v.columns = ctx->d_col_ptrs.as<const int64_t*>();
     v.column_len = ctx->d_col_len.as<uint32_t>();
     v.n_columns = (uint32_t)ctx->columns.size();
@@ -51,18 +51,6 @@ IndexView make_view(tsgpu_ctx* ctx, const Snapshot& sn) {
     v.mf = nullptr;                                   // per lane: set by the batch
     v.fbits = nullptr;
     return v;
-}
-
-// one validator for both term entry points (tsgpu_term_upsert / tsgpu_terms_load_csr): ids strictly ascending, offset_index
-// strictly ascending (every document owns at least one offset: Match reads runs[t].n - 1) and inside [0, n_off)
-const char* validate_list(const uint32_t* ids, const uint64_t* oi, uint32_t n_ids, uint64_t n_off) {
-    if (n_ids == 0) return nullptr;
-    if (oi[n_ids - 1] >= n_off) return "offset_index beyond offsets (every document needs at least one offset)";
-    for (uint32_t i = 1; i < n_ids; i++) {
-        if (ids[i] <= ids[i - 1]) return "ids must be strictly ascending";
-        if (oi[i] <= oi[i - 1]) return "offset_index must be strictly ascending (every document needs at least one offset)";
-    }
-    return nullptr;
 }
 
 template <int TMAX, int CAP>
@@ -189,69 +177,7 @@ uint64_t tsgpu_device_bytes(tsgpu_ctx* ctx) {
     return b + tsgpu_vec_device_bytes(ctx);
 }
 
-// ---------------------------------------------------------------- keyword index mirror
-int tsgpu_field_create(tsgpu_ctx* ctx, uint32_t field_id, int is_array) {
-    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->fields[field_id].is_array = is_array != 0;
-    return ok();
-}
-
-int tsgpu_term_upsert(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, const uint32_t* ids, const uint32_t* offset_index,
-                      const uint32_t* offsets, uint32_t n_ids, uint32_t n_offsets) {
-    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    auto fit = ctx->fields.find(field_id);
-    if (fit == ctx->fields.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_term_upsert: unknown field (call tsgpu_field_create)");
-    if (n_ids == 0) { fit->second.terms.erase(term_id); ctx->dirty = true; return ok(); }
-    if (!ids || !offset_index || !offsets) return fail(TSGPU_ERR_INVALID, "tsgpu_term_upsert: NULL array");
-    try {
-        std::vector<uint64_t> oi(offset_index, offset_index + n_ids);
-        if (const char* why = validate_list(ids, oi.data(), n_ids, n_offsets)) return fail(TSGPU_ERR_INVALID, std::string("tsgpu_term_upsert: ") + why);
-        fit->second.terms[term_id] = pack_list(ids, oi.data(), offsets, n_ids, n_offsets);
-        ctx->dirty = true;
-    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_term_upsert: host allocation failed"); }
-    return ok();
-}
-
-int tsgpu_terms_load_csr(tsgpu_ctx* ctx, uint32_t field_id, uint32_t n_terms, const uint32_t* term_ids, const uint64_t* ids_ptr,
-                         const uint32_t* ids, const uint64_t* offset_index, const uint64_t* off_ptr, const uint32_t* offsets) {
-    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
-    if (!term_ids || !ids_ptr || !ids || !offset_index || !off_ptr || !offsets) return fail(TSGPU_ERR_INVALID, "tsgpu_terms_load_csr: NULL array");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    auto fit = ctx->fields.find(field_id);
-    if (fit == ctx->fields.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_terms_load_csr: unknown field");
-    try {
-        // validate the whole load before touching the field: a rejected call leaves the pending state as it was
-        for (uint32_t t = 0; t < n_terms; t++) {
-            const uint64_t a = ids_ptr[t], b = ids_ptr[t + 1];
-            if (b < a || off_ptr[t + 1] < off_ptr[t]) return fail(TSGPU_ERR_INVALID, "tsgpu_terms_load_csr: ids_ptr / off_ptr must be non-decreasing");
-            if (b - a > 0xFFFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_terms_load_csr: a list of more than 2^32 ids");
-        }
-        std::vector<uint64_t> oi;
-        std::vector<std::pair<uint32_t, PackedList>> packed;
-        packed.reserve(n_terms);
-        for (uint32_t t = 0; t < n_terms; t++) {
-            const uint64_t a = ids_ptr[t], b = ids_ptr[t + 1];
-            if (b == a) { packed.emplace_back(term_ids[t], PackedList()); continue; }
-            const uint64_t o0 = off_ptr[t], o1 = off_ptr[t + 1];
-            oi.resize(b - a);
-            for (uint64_t i = a; i < b; i++) {
-                if (offset_index[i] < o0) return fail(TSGPU_ERR_INVALID, "tsgpu_terms_load_csr: offset_index below the list's off_ptr");
-                oi[i - a] = offset_index[i] - o0;
-            }
-            if (const char* why = validate_list(ids + a, oi.data(), (uint32_t)(b - a), o1 - o0)) return fail(TSGPU_ERR_INVALID, std::string("tsgpu_terms_load_csr: ") + why);
-            packed.emplace_back(term_ids[t], pack_list(ids + a, oi.data(), offsets + o0, (uint32_t)(b - a), o1 - o0));
-        }
-        for (auto& e : packed) {
-            if (e.second.desc.n_ids == 0) fit->second.terms.erase(e.first);
-            else fit->second.terms[e.first] = std::move(e.second);
-        }
-        ctx->dirty = true;
-    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_terms_load_csr: host allocation failed"); }
-    return ok();
-}
-
+// ---------------------------------------------------------------- keyword index mirror: tsgpu_index.hip (posting lists), columns here
 int tsgpu_column_set(tsgpu_ctx* ctx, uint32_t column_id, const int64_t* values, const uint8_t* present, uint32_t n, int mem) {
     if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
     if (column_id >= 4096) return fail(TSGPU_ERR_INVALID, "tsgpu_column_set: column_id too large");
@@ -282,127 +208,6 @@ int tsgpu_set_num_docs(tsgpu_ctx* ctx, uint32_t num_docs) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->num_docs = num_docs;
     ctx->num_docs_set = true;
-    return ok();
-}
-
-// Publishes every pending term / column change as ONE new immutable snapshot. The snapshot is built in fresh device buffers and
-// swapped in (RCU) only when every upload succeeded: a search that started on the previous snapshot keeps it alive until it
-// returns, a failing commit leaves the previous snapshot in place, and searches never wait on a commit.
-int tsgpu_commit(tsgpu_ctx* ctx) {
-    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    (void)hipSetDevice(ctx->device);
-    try {
-        std::shared_ptr<Snapshot> sp = std::make_shared<Snapshot>();
-        Snapshot& s = *sp;
-        std::vector<ListDesc>& descs = s.h_lists;
-        uint64_t n_blocks = 0, n_words = 0, n_id_words = 0;
-        std::vector<std::pair<uint64_t, const PackedList*>> order;
-        for (auto& f : ctx->fields) {
-            s.field_is_array[f.first] = f.second.is_array;
-            for (auto& t : f.second.terms) order.emplace_back(((uint64_t)f.first << 32) | t.first, &t.second);
-        }
-        std::sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-        uint32_t max_id = 0;
-        for (auto& e : order) { n_blocks += e.second->blk_last.size(); n_words += e.second->payload.size(); n_id_words += e.second->ids_payload.size(); max_id = std::max(max_id, e.second->desc.last_id); }
-        if (n_blocks >= 0xFFFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_commit: more than 2^32 posting blocks");
-        std::vector<uint32_t> h_last(n_blocks);
-        std::vector<BlockMeta> h_meta(n_blocks);
-        std::vector<BlockIds> h_ids(n_blocks);
-        std::vector<uint32_t> h_payload(n_words + 4, 0u);
-        std::vector<uint32_t> h_idw(n_id_words + 4, 0u);
-        uint64_t bpos = 0, wpos = 0, ipos = 0;
-        descs.reserve(order.size());
-        for (auto& e : order) {
-            const PackedList& pl = *e.second;
-            ListDesc d = pl.desc;
-            d.blk_base = (uint32_t)bpos;
-            d.payload_base = wpos;
-            d.ids_base = ipos;
-            std::copy(pl.blk_ids.begin(), pl.blk_ids.end(), h_ids.begin() + bpos);
-            std::copy(pl.ids_payload.begin(), pl.ids_payload.end(), h_idw.begin() + ipos);
-            ipos += pl.ids_payload.size();
-            std::copy(pl.blk_last.begin(), pl.blk_last.end(), h_last.begin() + bpos);
-            std::copy(pl.blk_meta.begin(), pl.blk_meta.end(), h_meta.begin() + bpos);
-            std::copy(pl.payload.begin(), pl.payload.end(), h_payload.begin() + wpos);
-            bpos += pl.blk_last.size();
-            wpos += pl.payload.size();
-            s.handle_of[e.first] = (uint32_t)descs.size();
-            descs.push_back(d);
-        }
-        int rc;
-        if ((rc = s.lists.reserve(std::max<size_t>(descs.size(), 1) * sizeof(ListDesc)))) return rc;
-        if ((rc = s.blk_last.reserve(std::max<size_t>(h_last.size(), 1) * 4))) return rc;
-        if ((rc = s.blk_meta.reserve(std::max<size_t>(h_meta.size(), 1) * sizeof(BlockMeta)))) return rc;
-        if ((rc = s.payload.reserve(h_payload.size() * 4))) return rc;
-        if ((rc = s.blk_ids.reserve(std::max<size_t>(h_ids.size(), 1) * sizeof(BlockIds)))) return rc;
-        if ((rc = s.ids_payload.reserve(h_idw.size() * 4))) return rc;
-        if (!h_ids.empty()) TSGPU_HIP_TRY(hipMemcpy(s.blk_ids.p, h_ids.data(), h_ids.size() * sizeof(BlockIds), hipMemcpyHostToDevice));
-        TSGPU_HIP_TRY(hipMemcpy(s.ids_payload.p, h_idw.data(), h_idw.size() * 4, hipMemcpyHostToDevice));
-        if (!descs.empty()) TSGPU_HIP_TRY(hipMemcpy(s.lists.p, descs.data(), descs.size() * sizeof(ListDesc), hipMemcpyHostToDevice));
-        if (!h_last.empty()) TSGPU_HIP_TRY(hipMemcpy(s.blk_last.p, h_last.data(), h_last.size() * 4, hipMemcpyHostToDevice));
-        if (!h_meta.empty()) TSGPU_HIP_TRY(hipMemcpy(s.blk_meta.p, h_meta.data(), h_meta.size() * sizeof(BlockMeta), hipMemcpyHostToDevice));
-        TSGPU_HIP_TRY(hipMemcpy(s.payload.p, h_payload.data(), h_payload.size() * 4, hipMemcpyHostToDevice));
-        {   // flat lookup tables: fields < 64, terms < 4M; a term beyond its field's table is found through handle_of
-            std::vector<std::vector<uint32_t>> dense;
-            std::vector<uint32_t> max_term;
-            for (const auto& e : s.handle_of) {
-                const uint32_t f = (uint32_t)(e.first >> 32), term = (uint32_t)e.first;
-                if (f >= 64 || term >= (4u << 20)) continue;
-                if (f >= max_term.size()) max_term.resize(f + 1, 0);
-                max_term[f] = std::max(max_term[f], term + 1);
-            }
-            dense.resize(max_term.size());
-            for (size_t f = 0; f < dense.size(); f++) dense[f].assign(max_term[f], 0xFFFFFFFFu);
-            for (const auto& e : s.handle_of) {
-                const uint32_t f = (uint32_t)(e.first >> 32), term = (uint32_t)e.first;
-                if (f < dense.size() && term < dense[f].size()) dense[f][term] = e.second;
-            }
-            s.dense_handle.swap(dense);
-        }
-        s.bytes = s.lists.cap + s.blk_last.cap + s.blk_ids.cap + s.blk_meta.cap + s.ids_payload.cap + s.payload.cap;
-        if (!ctx->num_docs_set) ctx->num_docs = std::max(ctx->num_docs, order.empty() ? 0u : max_id + 1);
-        s.num_docs = ctx->num_docs;
-        std::atomic_store(&ctx->snap, std::shared_ptr<const Snapshot>(sp));      // publish
-        ctx->dirty = false;
-    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_commit: host allocation failed"); }
-    return ok();
-}
-
-uint32_t tsgpu_term_num_ids(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id) {
-    if (!ctx) return 0;
-    const std::shared_ptr<const Snapshot> sn = ctx->snapshot();
-    auto it = sn->handle_of.find(((uint64_t)field_id << 32) | term_id);
-    return it == sn->handle_of.end() ? 0 : sn->h_lists[it->second].n_ids;
-}
-
-int tsgpu_term_download(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, uint32_t* ids, uint32_t* offset_index, uint32_t* offsets,
-                        uint32_t* n_offsets) {
-    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
-    (void)hipSetDevice(ctx->device);
-    const std::shared_ptr<const Snapshot> sn = ctx->snapshot();     // the committed snapshot: pending (uncommitted) changes are not visible here
-    auto it = sn->handle_of.find(((uint64_t)field_id << 32) | term_id);
-    if (it == sn->handle_of.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_term_download: term not in the committed snapshot");
-    const ListDesc d = sn->h_lists[it->second];
-    try {
-        std::vector<uint32_t> last(d.n_blocks);
-        std::vector<BlockMeta> meta(d.n_blocks);
-        TSGPU_HIP_TRY(hipMemcpy(last.data(), sn->blk_last.as<uint32_t>() + d.blk_base, (size_t)d.n_blocks * 4, hipMemcpyDeviceToHost));
-        TSGPU_HIP_TRY(hipMemcpy(meta.data(), sn->blk_meta.as<BlockMeta>() + d.blk_base, (size_t)d.n_blocks * sizeof(BlockMeta), hipMemcpyDeviceToHost));
-        const BlockMeta& lm = meta.back();
-        const size_t words = (size_t)lm.off_woff + packed_words(lm.n_off, lm.off_bits);
-        std::vector<uint32_t> payload(words + 2);
-        TSGPU_HIP_TRY(hipMemcpy(payload.data(), sn->payload.as<uint32_t>() + d.payload_base, words * 4, hipMemcpyDeviceToHost));
-        const size_t iwords = (size_t)lm.ids_woff + packed_words(lm.n_ids, lm.ids_bits);
-        std::vector<uint32_t> idw(iwords + 2);
-        TSGPU_HIP_TRY(hipMemcpy(idw.data(), sn->ids_payload.as<uint32_t>() + d.ids_base, iwords * 4, hipMemcpyDeviceToHost));
-        std::vector<uint32_t> a, b, c;
-        unpack_list(d, last.data(), meta.data(), idw.data(), payload.data(), a, b, c);
-        if (n_offsets) *n_offsets = (uint32_t)c.size();
-        if (ids) std::copy(a.begin(), a.end(), ids);
-        if (offset_index) std::copy(b.begin(), b.end(), offset_index);
-        if (offsets) std::copy(c.begin(), c.end(), offsets);
-    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_term_download: host allocation failed"); }
     return ok();
 }
 
@@ -448,6 +253,8 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     }
     if (!strcmp(name, "vec_count_rescored")) { ctx->vec_count_rescored = value != 0; return ok(); }
     // micro-batcher (tsgpu_batcher.h): concurrent small calls are coalesced into one launch
+    if (!strcmp(name, "index_min_slack_words")) { ctx->index_min_slack_words = (uint64_t)std::max<int64_t>(value, 0); return ok(); }   // (tests: small arenas)
+    if (!strcmp(name, "commit_full")) { ctx->commit_force_full = value != 0; return ok(); }      // the NEXT commit re-packs every list (compaction)
     if (!strcmp(name, "kw_lanes")) {                   // execution lanes (stream + scratch each) that concurrent keyword batches spread over
         if (value < 1 || value > tsgpu_ctx::N_LANES) return fail(TSGPU_ERR_INVALID, "kw_lanes out of range (1..8)");
         ctx->n_lanes = (int)value; return ok();
@@ -472,6 +279,10 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!strcmp(name, "vec_prefilter_fallbacks")) { *out = ctx->vec_prefilter_fallbacks; return ok(); }
     if (!strcmp(name, "vec_prefilter_groups")) { *out = ctx->vec_prefilter_groups; return ok(); }
     if (!strcmp(name, "vec_rescored_rows")) { *out = ctx->vec_rescored_rows; return ok(); }
+    if (!strcmp(name, "commit_last_us")) { *out = ctx->commit_last_us; return ok(); }                        // the last tsgpu_commit: wall time, bytes uploaded
+    if (!strcmp(name, "commit_last_uploaded_bytes")) { *out = ctx->commit_last_uploaded_bytes; return ok(); }
+    if (!strcmp(name, "commit_full_count")) { *out = ctx->commit_full_count; return ok(); }                  // commits that re-packed everything / appended at the tails
+    if (!strcmp(name, "commit_incremental_count")) { *out = ctx->commit_incremental_count; return ok(); }
     if (!strcmp(name, "kw_batches")) { *out = ctx->kw_batches.load(); return ok(); }                 // host-side phase totals (us) over all keyword batches
     if (!strcmp(name, "kw_plan_us")) { *out = ctx->kw_plan_us.load(); return ok(); }
     if (!strcmp(name, "kw_upload_us")) { *out = ctx->kw_upload_us.load(); return ok(); }

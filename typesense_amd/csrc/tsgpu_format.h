@@ -16,7 +16,9 @@
 //   * the doc ids live in their OWN arena (ids_payload + a 16-byte BlockIds record per block), apart from the
 //     offset_index/offsets arena: the intersection streams ids only, so a cache line it fetches holds nothing
 //     but ids (with one interleaved arena ~57% of every fetched line was offsets the intersection never reads);
-//   * all lists of a snapshot live in five arenas (blk_last, blk_ids, blk_meta, ids_payload, payload).
+//   * all lists of a snapshot live in five arenas (blk_last, blk_ids, blk_meta, ids_payload, payload);
+//   * blocks need not be full (a posting position is block * 256 + slot whatever the fill), and a block re-written by an incremental
+//     commit lives at the arena tail: only the block's words and the list's (small) descriptor arrays are uploaded, never the list.
 #pragma once
 #include <stdint.h>
 
@@ -51,7 +53,7 @@ struct BlockMeta {           // 32 bytes: offsets side of a block (scoring only)
     uint8_t pad[3];
 };
 
-struct ListDesc {            // 40 bytes
+struct ListDesc {            // 48 bytes
     uint64_t payload_base;   // word index into the payload arena (offset_index + offsets)
     uint64_t ids_base;       // word index into the ids_payload arena
     uint32_t blk_base;       // index of the list's first block in blk_last[] / blk_meta[]
@@ -60,7 +62,12 @@ struct ListDesc {            // 40 bytes
     uint32_t first_id;
     uint32_t last_id;
     uint32_t n_off;          // total offsets of the list (for the algorithmic-bytes accounting)
+    uint32_t flags;          // LIST_HAS_BREAKS: some block's ids do not follow the previous block's in the arena (blocks re-written by an
+                             // incremental commit live at the arena tail until the next compaction); a run of blocks is ONE coalesced
+                             // range only where it has no break
+    uint32_t pad;
 };
+static const uint32_t LIST_HAS_BREAKS = 1u;
 
 TSGPU_HD static inline uint32_t required_bits(uint32_t v) {   // include/array_base.h:23-25
     return v == 0 ? 0u : 32u - (uint32_t)__builtin_clz(v);

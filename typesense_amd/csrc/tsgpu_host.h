@@ -67,30 +67,91 @@ struct PinBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
-struct FieldHost {
-    bool is_array = false;
-    std::unordered_map<uint32_t, PackedList> terms;   // pending + committed host copies (source of the next snapshot)
+// One (field, term) posting list on the host — the source of every device upload. `pl` holds the packed blocks (blk_ids / blk_meta
+// word offsets index pl.ids_payload / pl.payload; a re-written block's new words are appended, the old ones are garbage until the
+// list is re-packed). `dev[b]` = where block b's words live in the device arenas (NOPOS = not uploaded yet). Single-document
+// mutations (tsgpu_posting_upsert / _erase) work on ONE decoded "open" block per term, packed again when another block is touched
+// or at commit.
+struct TermHost {
+    static const uint64_t NOPOS = ~0ull;
+    struct BlockPos { uint64_t idw = NOPOS, pw = NOPOS; };
+    PackedList pl;
+    std::vector<BlockPos> dev;
+    uint32_t handle = 0xFFFFFFFFu;                   // its slot in the snapshot's list table (stable across commits)
+    bool dirty = true;                               // differs from the published snapshot
+    // the list's descriptor arrays on the device: blk_last / blk_ids / blk_meta [d_blk_base, + d_blk_cap), the first d_blk_n entries
+    // published. Blocks appended behind the published ones are written INTO the spare entries (no published entry changes: a search on
+    // an older snapshot never looks beyond its own n_blocks); any other change (a published block re-written, split, removed) needs
+    // the arrays re-written at the arena tail.
+    uint64_t d_blk_base = NOPOS;
+    uint32_t d_blk_cap = 0, d_blk_n = 0;
+    bool desc_rewrite = true;
+    bool has_breaks = false;                         // some block does not follow its predecessor in the ids arena (LIST_HAS_BREAKS)
+    int64_t open_b = -1;                             // decoded block being mutated (-1 = none)
+    std::vector<uint32_t> o_ids, o_oi, o_offs;       // o_oi has one extra end entry (= o_offs.size()) while open
+    uint64_t garbage_idw = 0, garbage_pw = 0;        // host words no block refers to any more
 };
 
-struct Snapshot {            // immutable HBM image of all posting lists; published by tsgpu_commit, shared (RCU) by the searches that started on it
-    DevBuf lists, blk_last, blk_ids, blk_meta, ids_payload, payload;
-    std::unordered_map<uint32_t, bool> field_is_array;              // the query_by fields of this snapshot (field id -> string[])
-    Snapshot() = default;
-    Snapshot(const Snapshot&) = delete;
-    Snapshot& operator=(const Snapshot&) = delete;
-    ~Snapshot() { lists.release(); blk_last.release(); blk_ids.release(); blk_meta.release(); ids_payload.release(); payload.release(); }
-    std::vector<ListDesc> h_lists;                                  // host copy of the descriptors
-    std::unordered_map<uint64_t, uint32_t> handle_of;               // (field<<32 | term) -> list handle
+struct FieldHost {
+    bool is_array = false;
+    std::unordered_map<uint32_t, TermHost> terms;
+};
+
+// the device arenas of the posting lists; shared by consecutive snapshots: an incremental commit appends at the tails (regions no
+// published snapshot refers to) and publishes a new descriptor table
+struct ArenaSet {
+    DevBuf blk_last, blk_ids, blk_meta, ids_payload, payload;
+    uint64_t cap_blocks = 0, cap_idw = 0, cap_pw = 0;        // capacities (elements)
+    uint64_t used_blocks = 0, used_idw = 0, used_pw = 0;     // tails
+    uint64_t live_blocks = 0, live_idw = 0, live_pw = 0;     // referenced by the newest snapshot (used - live = garbage)
+    ArenaSet() = default;
+    ArenaSet(const ArenaSet&) = delete;
+    ArenaSet& operator=(const ArenaSet&) = delete;
+    ~ArenaSet() { blk_last.release(); blk_ids.release(); blk_meta.release(); ids_payload.release(); payload.release(); }
+    uint64_t bytes() const { return blk_last.cap + blk_ids.cap + blk_meta.cap + ids_payload.cap + payload.cap; }
+};
+
+// (field << 32 | term) -> list handle; shared by the snapshots between which no term appeared or disappeared
+struct HandleMaps {
+    std::unordered_map<uint64_t, uint32_t> handle_of;
     // the same map as flat tables for small field / term ids (the planner resolves three tokens per query, 10 000 queries per
     // batch: an indexed load instead of a hash probe); 0xFFFFFFFF = absent; ids beyond the tables go through handle_of
     std::vector<std::vector<uint32_t>> dense_handle;                // [field][term]
-    uint32_t find_handle(uint32_t field, uint32_t term) const {
-        if (field < dense_handle.size() && term < dense_handle[field].size()) return dense_handle[field][term];
-        auto it = handle_of.find(((uint64_t)field << 32) | term);
-        return it == handle_of.end() ? 0xFFFFFFFFu : it->second;
+    void rebuild_dense() {
+        std::vector<uint32_t> max_term;
+        for (const auto& e : handle_of) {
+            const uint32_t f = (uint32_t)(e.first >> 32), term = (uint32_t)e.first;
+            if (f >= 64 || term >= (4u << 20)) continue;
+            if (f >= max_term.size()) max_term.resize(f + 1, 0);
+            max_term[f] = std::max(max_term[f], term + 1);
+        }
+        dense_handle.assign(max_term.size(), {});
+        for (size_t f = 0; f < dense_handle.size(); f++) dense_handle[f].assign(max_term[f], 0xFFFFFFFFu);
+        for (const auto& e : handle_of) {
+            const uint32_t f = (uint32_t)(e.first >> 32), term = (uint32_t)e.first;
+            if (f < dense_handle.size() && term < dense_handle[f].size()) dense_handle[f][term] = e.second;
+        }
     }
+};
+
+struct Snapshot {            // immutable view of all posting lists; published by tsgpu_commit, shared (RCU) by the searches that started on it
+    std::shared_ptr<ArenaSet> ar;
+    DevBuf lists;                                                   // ListDesc table (one per snapshot)
+    std::vector<ListDesc> h_lists;                                  // host copy of the descriptors
+    std::shared_ptr<const HandleMaps> maps;
+    std::unordered_map<uint32_t, bool> field_is_array;              // the query_by fields of this snapshot (field id -> string[])
     uint64_t bytes = 0;
     uint32_t num_docs = 0;                                          // num_seq_ids() when the snapshot was published
+    Snapshot() = default;
+    Snapshot(const Snapshot&) = delete;
+    Snapshot& operator=(const Snapshot&) = delete;
+    ~Snapshot() { lists.release(); }
+    uint32_t find_handle(uint32_t field, uint32_t term) const {
+        if (!maps) return 0xFFFFFFFFu;
+        if (field < maps->dense_handle.size() && term < maps->dense_handle[field].size()) return maps->dense_handle[field][term];
+        auto it = maps->handle_of.find(((uint64_t)field << 32) | term);
+        return it == maps->handle_of.end() ? 0xFFFFFFFFu : it->second;
+    }
 };
 
 struct ColumnDev { DevBuf data; uint32_t n = 0; std::vector<int64_t> host; /* mirror for the <=k-hit host steps (vector / hybrid) */ };
@@ -170,6 +231,11 @@ struct tsgpu_ctx {
     std::shared_ptr<const tsgpu::Snapshot> snap;     // published snapshot: std::atomic_load / atomic_store
     std::shared_ptr<const tsgpu::Snapshot> snapshot() const { return std::atomic_load(&snap); }
     bool dirty = false;
+    std::vector<uint64_t> dirty_terms;               // (field << 32 | term) touched since the last commit (may repeat)
+    bool dirty_fields = false;                       // a query_by field was declared since the last commit
+    uint64_t index_min_slack_words = 1u << 20;       // room (words per arena) a full commit leaves behind the data at least (option "index_min_slack_words")
+    bool commit_force_full = false;                  // option "commit_full": the next commit re-packs everything (compaction)
+    uint64_t commit_last_us = 0, commit_last_uploaded_bytes = 0, commit_full_count = 0, commit_incremental_count = 0;
     std::vector<tsgpu::ColumnDev> columns;
     tsgpu::DevBuf d_col_ptrs, d_col_len;
     uint32_t num_docs = 0;

@@ -133,6 +133,29 @@ class GpuIndex:
         ids, offset_index, offsets = _u32(ids), _u32(offset_index), _u32(offsets)
         self._ck(self.L.tsgpu_term_upsert(self.h, field_id, term_id, _vp(ids), _vp(offset_index), _vp(offsets), ids.size, offsets.size))
 
+    def posting_upsert(self, field_id, term_id, seq_id, offsets):
+        off = _u32(offsets)
+        self._ck(self.L.tsgpu_posting_upsert(self.h, field_id, term_id, seq_id, _vp(off), off.size))
+
+    def posting_erase(self, field_id, term_id, seq_id):
+        self._ck(self.L.tsgpu_posting_erase(self.h, field_id, term_id, seq_id))
+
+    def index_plain_doc(self, seq_id, field_id, tokens):
+        """what Index::tokenize_string + posting_t::upsert do for one plain string field of one document (src/index.cpp:1323-1348):
+        per distinct token its positions + 1, and a trailing 0 for the token that ends the field"""
+        toks = [int(t) for t in tokens]
+        per = {}
+        for pos, t in enumerate(toks):
+            per.setdefault(t, []).append(pos + 1)
+        if toks:
+            per[toks[-1]].append(0)
+        for t, off in per.items():
+            self.posting_upsert(field_id, t, seq_id, off)
+
+    def remove_plain_doc(self, seq_id, field_id, tokens):
+        for t in set(int(x) for x in tokens):
+            self.posting_erase(field_id, t, seq_id)
+
     def terms_load_csr(self, field_id, term_ids, ids_ptr, ids, offset_index, off_ptr, offsets):
         term_ids, ids, offsets = _u32(term_ids), _u32(ids), _u32(offsets)
         ids_ptr = np.ascontiguousarray(ids_ptr, dtype=np.uint64)
