@@ -213,25 +213,46 @@ __device__ inline uint32_t block_compact1(bool pred, uint32_t* s_wave_cnt /*[4],
 // dependent-read latency they save; profiles/r01/prof_kw_s4_kary.txt)
 // is id x in the list? -> posting position (block*256 + slot). Two binary searches, all loads are
 // broadcast / same-line for neighbouring lanes because candidates ascend with the lane id.
+// Lower bound of x in an ascending u32 / u16 array a[0 .. n) whose answer exists (a[n - 1] >= x), started from an INTERPOLATED guess:
+// doc ids are spread roughly evenly over a list, so the answer usually lies inside a 16-entry window around
+// (x - first) / (last - first) * n — one cache line. Two independent loads test the window; inside it four short steps finish the search
+// (the window's cache line is hot), otherwise the half that must hold the answer is searched by plain bisection. A dependent chain of
+// log2(n) long-latency loads becomes ~2 long + 4 short ones; the result is the same index whatever the data looks like.
+template <class LoadFn>
+__device__ inline uint32_t guided_lower_bound(uint32_t n, uint32_t x, uint32_t first, uint32_t last, LoadFn at) {
+    uint32_t lo = 0, hi = n - 1;                                  // the answer is in [lo, hi]
+    if (n > 16) {
+        const float frac = (float)(x - first) / ((float)(last - first) + 1.0f);
+        uint32_t g = (uint32_t)(frac * (float)n);
+        g = g < n ? g : n - 1;
+        const uint32_t wlo = g > 8 ? g - 8 : 0;
+        const uint32_t whi = wlo + 15 < n - 1 ? wlo + 15 : n - 1;
+        const uint32_t below = wlo ? at(wlo - 1) : 0u, top = at(whi);          // independent loads
+        const bool low_ok = wlo == 0 || below < x;
+        if (low_ok && top >= x) { lo = wlo; hi = whi; }
+        else if (!low_ok) hi = wlo - 1;                           // a[wlo - 1] >= x: the answer is at or before it
+        else lo = whi + 1;                                        // a[whi] < x
+    }
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (at(mid) >= x) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// is id x in the list? -> posting position (block*256 + slot). Two guided searches (block among the list's last ids, slot among the
+// block's ids); neighbouring lanes probe ascending candidates, so their loads share cache lines.
 __device__ inline bool probe_list(const IndexView& ix, const ListDesc& d, uint32_t x, uint32_t& pos) {
     if (x < d.first_id || x > d.last_id) return false;
     const uint32_t* __restrict__ bl = ix.blk_last + d.blk_base;
-    uint32_t lo = 0, hi = d.n_blocks - 1;              // bl[hi] = last_id >= x: the lower bound exists
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (bl[mid] >= x) hi = mid; else lo = mid + 1;
-    }
+    const uint32_t lo = guided_lower_bound(d.n_blocks, x, d.first_id, d.last_id, [&](uint32_t i) { return bl[i]; });
     const BlockIds m = ix.blk_ids[d.blk_base + lo];
     if (x < m.first_id) return false;
     const uint32_t* __restrict__ w = ix.ids_payload + d.ids_base + m.ids_woff;
     const uint32_t target = x - m.first_id;
     const bool w16 = (m.n_ids_bits >> 16) == 16;
-    uint32_t l = 0, h = (m.n_ids_bits & 0xFFFF) - 1;     // ids[h] = block last >= target
-    while (l < h) {
-        const uint32_t mid = (l + h) >> 1;
-        const uint32_t v = w16 ? (uint32_t)((const uint16_t*)w)[mid] : w[mid];
-        if (v >= target) h = mid; else l = mid + 1;
-    }
+    const uint32_t n = m.n_ids_bits & 0xFFFF;                 // ids[n - 1] = block last >= target
+    const uint32_t l = guided_lower_bound(n, target, 0u, m.last_id - m.first_id, [&](uint32_t i) { return w16 ? (uint32_t)((const uint16_t*)w)[i] : w[i]; });
     if ((w16 ? (uint32_t)((const uint16_t*)w)[l] : w[l]) != target) return false;
     pos = lo * BLOCK_IDS + l;
     return true;
@@ -1064,7 +1085,8 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
     auto load_window = [&](uint32_t base) -> BlockIds { return (T >= 2 && base + lane < dB.n_blocks) ? biB[base + lane] : PAD; };
 
     // driver-side BlockIds: read from memory (uniform 16-byte loads), kept TWO blocks ahead in registers — block b+1's record
-    // is needed by make_plan while block b is searched
+    // is needed by make_plan while block b is searched. (Measured and rejected: a lane-resident 64-block window of the driver list +
+    // four v_readlane per block instead of the scalar load: 9.45 -> 10.27 ms per 10 000-query batch.)
     auto a_meta_of = [&](uint32_t bb) -> BlockIds { return biA[bb < wi.blk_end ? bb : wi.blk_end - 1]; };
 
     KW_PROF_DECL
@@ -1151,26 +1173,46 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
         uint32_t kb = 0, b_first = 0, b_nb = 0, b_rel = 0;
         bool done = !ok || C.mode >= 2, found = false;
         if (C.mode == 0) {
+            // (words beyond the run are never read by the searches below: when the tile can hold a whole pipeline the stores carry no
+            //  guard — a guarded store is an exec-mask branch per word)
+            constexpr bool GUARD = PIPE_WORDS * KW_THREADS > TILE_WORDS;
             if (DEFER && C.W <= 2u * KW_THREADS) {
 #pragma unroll
-                for (int k = 0; k < 2 && k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; if (i < C.W) sm.btile[i] = cw[k]; }
+                for (int k = 0; k < 2 && k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; if (!GUARD || i < C.W) sm.btile[i] = cw[k]; }
             } else {
 #pragma unroll
-                for (int k = 0; k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; if (i < C.W) sm.btile[i] = cw[k]; }
+                for (int k = 0; k < PIPE_WORDS; k++) { const uint32_t i = t + k * KW_THREADS; if (!GUARD || i < C.W) sm.btile[i] = cw[k]; }
             }
         }
         KW_PROF(1)
         __syncthreads();
         KW_PROF(2)
+        // (a) which block: lower bound of id among the window's last ids (bw_last[rhi] >= hi_id >= id unless B ended).
+        // The common short run: the block = rlo + #{run blocks that END before the id}. The run's last ids are wave-uniform values sitting
+        // in the window registers (this plan's window: the next plan has not moved it yet) — one v_readlane and one compare per block
+        // instead of dependent LDS reads. (Every lane runs it: wave-uniform control flow.)
+        const uint32_t span = C.rhi - C.rlo;
+        uint32_t pos_short = C.rlo;
+#ifndef TSGPU_KW_SHORT_SPAN
+#define TSGPU_KW_SHORT_SPAN 8
+#endif
+        if (C.mode <= 1 && span <= TSGPU_KW_SHORT_SPAN) {
+            for (uint32_t j = C.rlo; j < C.rhi; j++) {
+                const uint32_t last_j = (uint32_t)__builtin_amdgcn_readlane((int)win.last_id, (int)j);
+                pos_short += last_j < id ? 1u : 0u;
+            }
+        }
         if (C.mode <= 1 && !done) {
-            // (a) which block: lower bound of id among the window's last ids (bw_last[rhi] >= hi_id >= id unless B ended)
             const uint32_t* __restrict__ bl = sm.bw_last[C.ver];
-            uint32_t pos = C.rlo;
-            // (uniform trip count: a run of s+1 blocks needs the steps from the largest power of two <= s down — two or three
-            //  dependent LDS reads for the common short run instead of six)
-            const uint32_t span = C.rhi - C.rlo;
-            for (uint32_t step = span ? 1u << (31 - __builtin_clz(span)) : 0u; step > 0; step >>= 1)
-                if (pos + step <= C.rhi && bl[pos + step - 1] < id) pos += step;
+            uint32_t pos = pos_short;
+            if (span > TSGPU_KW_SHORT_SPAN) {
+                // (uniform trip count: a run of s+1 blocks needs the steps from the largest power of two <= s down)
+                for (uint32_t step = 1u << (31 - __builtin_clz(span)); step > 0; step >>= 1) {
+                    const uint32_t j = pos + step;                       // (clamped load + select: no branch per step)
+                    const uint32_t v = bl[(j <= C.rhi ? j : C.rhi) - 1];
+                    pos = (j <= C.rhi && v < id) ? j : pos;
+                }
+            }
             kb = pos;
             b_first = sm.bw_first[C.ver][pos];
             if (bl[pos] < id || id < b_first) done = true;             // beyond B's end / in the gap between two blocks
@@ -1186,6 +1228,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
         uint32_t araw1 = 0;
         if (b + 1 < wi.blk_end) {
             araw1 = load_id_raw(idwA, mA1, t);
+            KW_PROF(10)
             P = make_plan(mA1);
         }
         KW_PROF(4)
@@ -1202,15 +1245,21 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
                     for (uint32_t step = 128; step > 0; step >>= 1) { const uint32_t v = a16[pos + step - 1]; pos = v < target ? pos + step : pos; }
                 } else {
 #pragma unroll
-                    for (uint32_t step = 128; step > 0; step >>= 1)
-                        if (pos + step <= n && (uint32_t)a16[pos + step - 1] < target) pos += step;
+                    for (uint32_t step = 128; step > 0; step >>= 1) {
+                        const uint32_t j = pos + step;
+                        const uint32_t v = a16[(j <= n ? j : n) - 1];
+                        pos = (j <= n && v < target) ? j : pos;
+                    }
                 }
                 hit = a16[pos];
             } else {
                 const uint32_t* __restrict__ a32 = sm.btile + tile_rel;
 #pragma unroll
-                for (uint32_t step = 128; step > 0; step >>= 1)
-                    if (pos + step <= n && a32[pos + step - 1] < target) pos += step;
+                for (uint32_t step = 128; step > 0; step >>= 1) {
+                    const uint32_t j = pos + step;
+                    const uint32_t v = a32[(j <= n ? j : n) - 1];
+                    pos = (j <= n && v < target) ? j : pos;
+                }
                 hit = a32[pos];
             }
             done = true;
@@ -1258,6 +1307,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
         if (T >= 3) {
             if (ok) { const uint32_t slot = q1n + my; sm.q1_id[slot] = id; sm.q1_p0[slot] = p0; sm.q1_p1[slot] = p1; }
             q1n += total;
+            KW_PROF(11)
             if (q1n >= KW_THREADS) {
                 __syncthreads();
                 if (t == 0) sm.q1_cnt = q1n;
