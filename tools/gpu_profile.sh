@@ -1,0 +1,37 @@
+#!/bin/bash
+# The profiling recipe behind profiles/rNN/ (run on the GPU box through gpurun):  tools/gpu_profile.sh r02 [tag]
+#   * rocprofv3 --kernel-trace --stats of the keyword and the vector bench legs       -> rocprof_{keyword,vector}_<tag>_stats.txt
+#   * PMC passes, each in its OWN run (no trace domains next to --pmc): FETCH_SIZE; SQ instruction mix; SQ wait / LDS conflicts
+#     -> pmc_{kw,vec}_fetch.txt, pmc_kw_sq1.txt, pmc_kw_sq2.txt (per-dispatch averages by tools/pmc_summary.py)
+#   * the GPU test tier, the smoke test and the full bench line                        -> pytest_gpu_<tag>.txt, smoke_<tag>.txt, bench_all_<tag>.json
+# bench.py reads pmc_kw_fetch.txt / pmc_kw_sq1.txt / pmc_vec_fetch.txt of the round for roofline.traffic / issue_util.
+set -u
+R=${1:-r02}; TAG=${2:-final}
+export TMPDIR=/tmp
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$ROOT/gpurun_out/prof_$TAG; P=$ROOT/gpurun_out/profiles_$R
+mkdir -p $O $P
+cd /tmp
+KW="python $ROOT/bench.py --workload keyword --no-cpu-baseline --no-extras --steps 3 --warmup 1"
+VEC="python $ROOT/bench.py --workload vector --no-cpu-baseline --no-extras --steps 3 --warmup 1"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_kw -- $KW > $O/trace_kw.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_vec -- $VEC > $O/trace_vec.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_kw_fetch -- $KW > $O/pmc_kw_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_vec_fetch -- $VEC > $O/pmc_vec_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES -d $O/pmc_kw_sq1 -- $KW > $O/pmc_kw_sq1.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_SALU -d $O/pmc_kw_sq2 -- $KW > $O/pmc_kw_sq2.log 2>&1
+cd $ROOT
+python profiles/summarize_rocprof.py $O/trace_kw > $P/rocprof_keyword_${TAG}_stats.txt 2>&1
+python profiles/summarize_rocprof.py $O/trace_vec > $P/rocprof_vector_${TAG}_stats.txt 2>&1
+python tools/pmc_summary.py $O/pmc_kw_fetch "kw_" > $P/pmc_kw_fetch.txt 2>&1
+python tools/pmc_summary.py $O/pmc_vec_fetch "vec_" > $P/pmc_vec_fetch.txt 2>&1
+python tools/pmc_summary.py $O/pmc_kw_sq1 "kw_" > $P/pmc_kw_sq1.txt 2>&1
+python tools/pmc_summary.py $O/pmc_kw_sq2 "kw_" > $P/pmc_kw_sq2.txt 2>&1
+# the bench reads the round's PMC summaries from profiles/<round>/ : put them there for THIS run, too
+mkdir -p profiles/$R && cp $P/pmc_*.txt profiles/$R/
+timeout 1500 python -m pytest tests -m gpu -x -q > $P/pytest_gpu_$TAG.txt 2>&1; tail -2 $P/pytest_gpu_$TAG.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $P/smoke_$TAG.txt 2>&1; tail -1 $P/smoke_$TAG.txt
+( time timeout 1200 python bench.py --steps 20 --warmup 5 ) > $P/bench_all_$TAG.json 2> $O/bench_all.err; tail -4 $O/bench_all.err; wc -c $P/bench_all_$TAG.json
+rocm-smi --showmeminfo vram 2>/dev/null | head -5 > $P/hw_$TAG.txt; rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6 >> $P/hw_$TAG.txt
+find $O -name "*.db" -delete; find $O -name "*.csv" -size +2M -delete; rm -rf $O/trace_* $O/pmc_*
+du -sh $ROOT/gpurun_out/profiles_$R
