@@ -78,6 +78,16 @@ def lib(path=None):
     path = path or LIB_PATH
     if path in _libs:
         return _libs[path]
+    # a process that also uses torch on the GPU: torch's bundled HIP runtime must open the device before /opt/rocm's (which
+    # libtsgpu.so links) does, or torch.cuda's lazy initialisation later reports "No HIP GPUs are available"
+    import sys
+    if "torch" in sys.modules:
+        try:
+            _t = sys.modules["torch"]
+            if _t.cuda.is_available():
+                _t.cuda.init()
+        except Exception:
+            pass
     if not os.path.exists(path):
         raise TsgpuError(ERR_DEVICE, "%s not found: build it with `python -m typesense_amd.build` (hipcc, gfx950). "
                                      "There is no CPU fallback." % path)
