@@ -197,7 +197,11 @@ typedef struct tsgpu_kw_query {
     uint32_t n_excluded;
     const uint32_t* filter_ids;                      /* sorted, host; NULL = no filter */
     uint32_t n_filter;
-    uint64_t deadline_us;                            /* absolute epoch us after which search_cutoff is raised; 0 = none */
+    uint64_t deadline_us;                            /* absolute epoch us (system clock) after which search_cutoff is raised; 0 = none. A query
+                                                        already late when its batch is planned reports 408 and no hits; one that runs out of
+                                                        time on the device stops scanning (every work item checks the device clock every 16
+                                                        driver blocks) and returns the PARTIAL hits found so far with status 0 and
+                                                        search_cutoff = 1, like the reference (include/or_iterator.h:148-153) */
 } tsgpu_kw_query;
 
 /* Results, structure-of-arrays, slot q*k_stride+i = i-th best hit of query q in Topster::sort() order

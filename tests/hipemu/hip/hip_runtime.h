@@ -325,6 +325,8 @@ inline float __fsqrt_rn(float a) { return sqrtf(a); }
 // global_load_lds_dwordx4: LDS destination = wave-uniform base + lane * 16, per-lane global source
 inline void hipemu_global_load_lds16(const void* gsrc, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * hipemu::cur_lane(), gsrc, 16); }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu::shfl(v, lane); }
+// device wall clock at 1 tick per microsecond (hipDeviceAttributeWallClockRate = 1000 kHz below)
+inline long long hipemu_wall_clock64() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (long long)ts.tv_sec * 1000000ll + ts.tv_nsec / 1000; }
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
 
@@ -337,6 +339,8 @@ enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemc
 enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
 
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 1 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 1000; return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

@@ -575,3 +575,38 @@ def test_two_level_merge_many_work_items():
     for i, q in enumerate(qs):
         H.assert_hits_equal(hits, i, H.oracle_keyword(orc, q), "two-level merge")
     g.close()
+
+
+def test_deadline_in_flight_returns_partial_hits_with_search_cutoff(pair):
+    """search_cutoff (include/or_iterator.h:148-153): a query that runs out of time ON THE DEVICE keeps what it found — status 0, partial
+    hits that are a subset of the full result with the same scores, search_cutoff = 1; a query already late at planning time gets 408"""
+    import time
+    orc, g, _ = pair
+    g.set_option("kw_chunk_blocks", 1)               # many work items, each checks the clock
+    try:
+        sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, 1, 0))
+        toks = [[1], [2, 1], [3, 1, 2], [1, 4]]
+        full = g.keyword_search_batch([T.KwQuery(t, sort=sort, topster_size=250) for t in toks], k_stride=250)
+        assert (full.search_cutoff == 0).all()
+        now = int(time.time() * 1e6)
+        # the emulator needs seconds for this batch: a budget of 2 ms is over before most work items start
+        qs = [T.KwQuery(t, sort=sort, topster_size=250, deadline_us=now + 2000) for t in toks] + [T.KwQuery([1], sort=sort, deadline_us=now - 5)]
+        hits = g.keyword_search_batch(qs, k_stride=250)
+        assert hits.status[4] == B.ERR_DEADLINE and hits.search_cutoff[4] == 1 and hits.n_hits[4] == 0
+        assert (hits.status[:4] == 0).all() and hits.search_cutoff[:4].sum() >= 1
+        for i in range(4):
+            n, nf = int(hits.n_hits[i]), int(full.n_hits[i])
+            got = {int(k): tuple(int(x) for x in s) for k, s in zip(hits.keys[i, :n], hits.scores[i, :n])}
+            ref = {int(k): tuple(int(x) for x in s) for k, s in zip(full.keys[i, :nf], full.scores[i, :nf])}
+            if not hits.search_cutoff[i]:
+                assert got == ref
+            else:
+                assert n <= nf or nf == 250
+                if nf < 250:                        # the full Topster held every match: a partial result can only be a subset of it
+                    assert all(k in ref and ref[k] == v for k, v in got.items())
+                assert int(hits.num_matched[i]) <= int(full.num_matched[i])
+        # a generous deadline changes nothing
+        late = g.keyword_search_batch([T.KwQuery(t, sort=sort, topster_size=250, deadline_us=now + 3_600_000_000) for t in toks], k_stride=250)
+        assert (late.search_cutoff == 0).all() and np.array_equal(late.keys, full.keys) and np.array_equal(late.n_hits, full.n_hits)
+    finally:
+        g.set_option("kw_chunk_blocks", 0)

@@ -299,3 +299,51 @@ def test_candidate_combinations_on_2m_docs(c2m):
         assert np.array_equal(qidx[gi, :int(hits.n_hits[gi])], ref_qi)
         assert int(found[gi]) == int(ref.n_result_ids)
         assert np.array_equal(g.candidates_result_ids(gi), ref.result_ids)
+
+
+def test_many_work_items_two_level_merge_on_2m_docs(c2m):
+    """kw_chunk_blocks = 1: the frequent terms' queries are cut into hundreds of work items -> kw_merge_groups_kernel + kw_merge_kernel"""
+    c2m.g.set_option("kw_chunk_blocks", 1)
+    try:
+        qtok = synth.keyword_queries(24, 3, 1, 60, seed=41)
+        qs = [T.KwQuery(q, sort=SORT, topster_size=250) for q in qtok] + [T.KwQuery([3], sort=SORT, topster_size=100)]
+        hits = c2m.g.keyword_search_batch(qs, k_stride=250)
+        assert (hits.status == 0).all()
+        for i, q in enumerate(qs):
+            H.assert_hits_equal(hits, i, c2m.oracle(q), "two-level merge 2M")
+    finally:
+        c2m.g.set_option("kw_chunk_blocks", 0)
+
+
+def test_deadline_in_flight_partial_hits_on_2m_docs(c2m):
+    """a batch of 6 000 queries takes milliseconds; with a few hundred us of budget queries are cut off ON THE DEVICE: status 0,
+    search_cutoff 1, the hits returned are a subset of the full result with identical scores (408 only for queries already late when
+    the batch was planned). The budget that lands between planning and the end of the launch depends on the box: several are tried."""
+    import ctypes as C
+    import time
+    qtok = synth.keyword_queries(6000, 3, 1, 3000, seed=43)         # heavy and light queries (the light ones start last: heaviest work first)
+    full = c2m.g.keyword_search_batch([T.KwQuery(q, sort=SORT, topster_size=250) for q in qtok], k_stride=250)
+    assert (full.status == 0).all() and (full.search_cutoff == 0).all()
+    arr = T.index.make_query_array([T.KwQuery(q, sort=SORT, topster_size=250, deadline_us=1) for q in qtok])
+    # the deadline is stamped into the prebuilt query array in one vectorised store right before the call (filling 6 000 structs from
+    # Python takes longer than the budget)
+    dl = np.ndarray((len(qtok),), dtype=np.uint64, buffer=arr, offset=B.KwQueryC.deadline_us.offset, strides=(C.sizeof(B.KwQueryC),))
+    checked = in_flight = 0
+    seen = []
+    for budget in (300, 500, 800, 1200, 2000, 3500, 6000):
+        dl[:] = int(time.time() * 1e6) + budget
+        hits = c2m.g.keyword_search_batch(arr, k_stride=250)
+        cut, ok = hits.search_cutoff == 1, hits.status == 0
+        assert (hits.status[~ok] == B.ERR_DEADLINE).all() and cut[~ok].all()
+        seen.append((budget, int(cut.sum()), int((cut & ok).sum())))
+        in_flight += int((cut & ok).sum())
+        for i in np.nonzero(ok)[0]:
+            n, nf = int(hits.n_hits[i]), int(full.n_hits[i])
+            if not cut[i]:
+                assert n == nf and np.array_equal(hits.keys[i, :n], full.keys[i, :n]) and np.array_equal(hits.scores[i, :n], full.scores[i, :n])
+            elif int(full.num_matched[i]) <= 250:          # the full Topster holds every match: a partial result must be a subset of it
+                ref = {int(k): tuple(int(x) for x in s) for k, s in zip(full.keys[i, :nf], full.scores[i, :nf])}
+                assert all(int(k) in ref and ref[int(k)] == tuple(int(x) for x in s) for k, s in zip(hits.keys[i, :n], hits.scores[i, :n]))
+                assert int(hits.num_matched[i]) <= int(full.num_matched[i])
+                checked += 1
+    assert in_flight > 0 and checked > 0, "no budget cut a query in flight: (budget us, cut, cut in flight) = %s" % seen

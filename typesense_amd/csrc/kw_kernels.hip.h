@@ -100,6 +100,11 @@ struct IndexView {
     unsigned long long* prof;        // TSGPU_PROF builds: 13 counters; else null
     const struct KwQueryMF* mf;      // multi-field queries of the batch (KwQueryDev::mf_index)
     uint32_t* fbits;                 // filtered multi-field queries: one bit per filter rank (KwQueryDev::fbits_off), zeroed per batch
+    // in-flight deadline (search_cutoff, include/or_iterator.h:148-153): t0 = device wall clock when the batch started (stamped by
+    // kw_stamp_kernel), ticks_per_us its rate; cutoff[query] is raised by the first work item that runs out of time
+    const long long* t0;
+    uint32_t ticks_per_us;
+    uint32_t* cutoff;
 };
 
 struct KwQueryDev {                  // one search_across_fields call
@@ -123,6 +128,8 @@ struct KwQueryDev {                  // one search_across_fields call
     uint32_t mf_index;               // KW_NONE = one query_by field; else index into IndexView::mf
     uint32_t wild_n_ids;             // wildcard query (q = "*"): ids to scan = filter ids, or every seq_id < num_docs; 0 = keyword query
     uint64_t fbits_off;              // filtered multi-field query: word offset of its rank bitmap in IndexView::fbits
+    uint32_t deadline_rem_us;        // microseconds this query may still run, counted from the batch's start stamp (0 = no deadline)
+    uint32_t pad2;
     uint32_t m_first, m_n;           // the sorted partial lists kw_merge_kernel folds: the work items themselves, or (many work items) the
                                      // group lists kw_merge_groups_kernel left behind them (counters always come from the work items)
 };
@@ -161,6 +168,29 @@ struct KwOut {                       // final, per query, stride = k_stride (tsg
     uint32_t* n_hits; uint64_t* num_matched; uint64_t* off_words;
     uint32_t k_stride;
 };
+
+// The reference checks its deadline every 65 536 loop iterations and breaks out with whatever the Topster holds
+// (include/or_iterator.h:148-153, RETURN_CIRCUIT_BREAKER). Here every work item looks at the device wall clock every 16 driver blocks
+// (wave-uniform: one s_memrealtime + a scalar load): past the query's budget it raises the query's cutoff flag and stops scanning;
+// what it found so far is scored and merged as usual, the caller gets partial hits with search_cutoff = 1.
+__device__ inline bool kw_out_of_time(const IndexView& ix, const KwQueryDev& q, uint32_t query) {
+    if (q.deadline_rem_us == 0) return false;
+#ifdef TSGPU_HIP_EMU
+    const long long now = hipemu_wall_clock64();
+#else
+    const long long now = wall_clock64();
+#endif
+    if ((unsigned long long)(now - *ix.t0) <= (unsigned long long)q.deadline_rem_us * ix.ticks_per_us) return false;
+    if (threadIdx.x == 0) atomicOr(&ix.cutoff[query], 1u);
+    return true;
+}
+__global__ void kw_stamp_kernel(long long* t0) {
+#ifdef TSGPU_HIP_EMU
+    *t0 = hipemu_wall_clock64();
+#else
+    *t0 = wall_clock64();
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 // ordered compaction: exclusive prefix of `pred` over the workgroup (wave ballot + popcount, then the
@@ -1161,6 +1191,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
 
     for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
         if (P.mode == 3) break;
+        if (((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, wi.query)) break;
         // ---- stage 0: thread t = slot t of driver block b ----
         const uint32_t m_n = mA.n_ids_bits & 0xFFFF;
         bool ok = t < m_n;
@@ -1466,6 +1497,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
     uint32_t* __restrict__ hits = DEFER ? hits_all + hit_off[blockIdx.x] * (uint64_t)(NP + 1) : nullptr;
     uint32_t qfn = 0, par = 0;
     for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
+        if (((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, qi)) break;
         const BlockIds mA = biA[b];
         const uint32_t m_n = mA.n_ids_bits & 0xFFFF;
         bool ok = t < m_n;
@@ -1578,6 +1610,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_wildcard_kernel(IndexView ix, c
     const uint32_t* fl = ex + q.n_excl;
     uint32_t* my_ids_out = ids_out ? ids_out + q.ids_out_off + wi.ids_out_off : nullptr;
     for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
+        if (((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, wi.query)) break;
         if (s_cnt + KW_THREADS > (uint32_t)CAP) topk_compact<CAP, true>(tk, &s_cnt, q.k, thr, &s_have);
         const uint32_t idx = b * BLOCK_IDS + t;
         bool emit = idx < q.wild_n_ids;

@@ -50,6 +50,7 @@ IndexView make_view(tsgpu_ctx* ctx, const Snapshot& sn) {
     v.prof = ctx->d_prof.as<unsigned long long>();
     v.mf = nullptr;                                   // per lane: set by the batch
     v.fbits = nullptr;
+    v.t0 = nullptr; v.ticks_per_us = 100; v.cutoff = nullptr;
     return v;
 }
 
@@ -122,6 +123,10 @@ int tsgpu_create(int device_ordinal, tsgpu_ctx** out) {
     tsgpu_ctx* ctx = new (std::nothrow) tsgpu_ctx;
     if (!ctx) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_create: host allocation failed");
     ctx->device = device_ordinal;
+    {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_ordinal) == hipSuccess && khz >= 1000) ctx->ticks_per_us = (uint32_t)(khz / 1000);
+    }
     std::atomic_store(&ctx->snap, std::shared_ptr<const Snapshot>(std::make_shared<Snapshot>()));
     bool good = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
     for (auto& ev : ctx->ev) good = good && hipEventCreate(&ev) == hipSuccess;
@@ -313,6 +318,7 @@ struct Plan {
     std::vector<KwQueryMF> mf;
     std::vector<KwMergeGroup> groups;                     // first level of the two-level merge (queries with many work items)
     uint64_t fbits_words = 0;                             // rank bitmaps of the filtered multi-field queries
+    bool any_deadline = false;                            // some query carries a deadline: stamp the batch start, collect cutoff flags
     bool any_s2 = false;              // some query has a third sort key
     std::vector<uint32_t> aux;
     std::vector<int32_t> status, cutoff;
@@ -403,6 +409,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
         const uint32_t k = resolve_topster_size(ctx, in);
         if (k > TSGPU_MAX_TOPK) { unsupported("topster_size"); continue; }
         if (in.deadline_us != 0 && now > in.deadline_us) { P.status[i] = TSGPU_ERR_DEADLINE; P.cutoff[i] = 1; continue; }
+        if (in.deadline_us != 0) { q.deadline_rem_us = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.deadline_us - now, 1), 0xFFFFFFFFull); P.any_deadline = true; }
 
         if (wildcard) {
             // Index::search_wildcard (src/index.cpp:6616-6818): rank every filter id (every seq_id without a filter) by its sort keys
@@ -641,6 +648,7 @@ struct BatchOpts {
     bool wildcard = false;
     bool keep_ids = false;                            // emit matched ids into the lane's id arena
     std::vector<int32_t>* status_host = nullptr;      // receives the per-query status codes
+    std::vector<int32_t>* cutoff_host = nullptr;      // ... and the per-query search_cutoff flags
     tsgpu_id_lists* id_lists = nullptr;               // when set: the matched ids of every query, gathered + downloaded (implies keep_ids)
     bool record_last = true;                          // remember the id segments for the legacy tsgpu_result_ids API
 };
@@ -927,6 +935,15 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             TSGPU_HIP_TRY(hipMemsetAsync(L.d_fbits.p, 0, P.fbits_words * 4, s));
         }
         v.fbits = L.d_fbits.as<uint32_t>();
+        if ((rc = L.d_t0.reserve(64))) return rc;
+        v.t0 = L.d_t0.as<long long>();
+        v.ticks_per_us = ctx->ticks_per_us;
+        if (P.any_deadline) {
+            if ((rc = L.d_cut.reserve((size_t)n_queries * 4))) return rc;
+            TSGPU_HIP_TRY(hipMemsetAsync(L.d_cut.p, 0, (size_t)n_queries * 4, s));
+            hipLaunchKernelGGL(kw_stamp_kernel, dim3(1), dim3(1), 0, s, L.d_t0.as<long long>());       // the queries' budgets count from here
+        }
+        v.cutoff = L.d_cut.as<uint32_t>();
         const KwQueryDev* dq = (const KwQueryDev*)(dplan + at_q);
         const KwWorkItem* dw = (const KwWorkItem*)(dplan + at_w);
         const uint32_t* daux = (const uint32_t*)(dplan + at_aux);
@@ -1026,7 +1043,18 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             TSGPU_HIP_TRY(hipMemcpyAsync(off_words.data(), o.off_words, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
             TSGPU_HIP_TRY(hipStreamSynchronize(s));
         }
+        if (P.any_deadline) {                        // work items that ran out of time raised their query's flag: partial hits + search_cutoff
+            std::vector<uint32_t> cut(n_queries);
+            TSGPU_HIP_TRY(hipMemcpy(cut.data(), L.d_cut.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost));
+            bool any = false;
+            for (uint32_t i = 0; i < n_queries; i++) if (cut[i]) { P.cutoff[i] = 1; any = true; }
+            if (any && out->search_cutoff) {
+                if (dev_out) TSGPU_HIP_TRY(hipMemcpy(out->search_cutoff, P.cutoff.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice));
+                else for (uint32_t i = 0; i < n_queries; i++) out->search_cutoff[i] = P.cutoff[i];
+            }
+        }
         if (status_host) status_host->assign(P.status.begin(), P.status.end());
+        if (bo.cutoff_host) bo.cutoff_host->assign(P.cutoff.begin(), P.cutoff.end());
         const uint64_t t_synced = now_us();
 
         // ---- bookkeeping: timings + algorithmic bytes ----
@@ -1188,19 +1216,21 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
         pass.keys = L.d_cand_keys.as<uint64_t>(); pass.scores = L.d_cand_scores.as<int64_t>(); pass.text_match = L.d_cand_tm.as<int64_t>();
         pass.vector_distance = L.d_cand_vd.as<float>(); pass.match_score_index = L.d_cand_msi.as<int8_t>();
         pass.n_hits = L.d_cand_nh.as<uint32_t>(); pass.num_matched = L.d_cand_nm.as<uint64_t>(); pass.status = L.d_cand_st.as<int32_t>();
-        std::vector<int32_t> st;
+        std::vector<int32_t> st, co;
         if (n_combos) {
             BatchOpts bo;
             bo.keep_ids = found != nullptr;                    // the union needs every pass's emitted ids
             bo.status_host = &st;
+            bo.cutoff_host = &co;
             bo.record_last = true;
             rc = kw_batch_on_lane(ctx, L, combos, n_combos, &pass, bo);
             if (rc) return rc;
         }
         // a group runs only if every combination of it ran; otherwise it reports the first failing status and no hits
         std::vector<uint32_t> range((size_t)n_groups * 3 + 3, 0);        // per group: first entry, one past the last, Topster capacity
-        std::vector<int32_t> gstatus(n_groups, TSGPU_OK);
+        std::vector<int32_t> gstatus(n_groups, TSGPU_OK), gcut(n_groups, 0);       // a group is cut off when any of its passes was
         for (uint32_t g = 0; g < n_groups; g++) {
+            for (uint32_t e = group_begin[g]; e < group_begin[g + 1]; e++) if (e < co.size() && co[e]) gcut[g] = 1;
             for (uint32_t e = group_begin[g]; e < group_begin[g + 1]; e++) if (st[e] != TSGPU_OK) { gstatus[g] = st[e]; break; }
             if (gstatus[g] == TSGPU_OK && group_begin[g + 1] > group_begin[g]) {
                 range[3 * g] = group_begin[g]; range[3 * g + 1] = group_begin[g + 1];
@@ -1281,10 +1311,10 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
             if (out->match_score_index) TSGPU_HIP_TRY(hipMemcpyAsync(out->match_score_index, o.match_score_index, slots, hipMemcpyDeviceToHost, s));
             if (query_index) TSGPU_HIP_TRY(hipMemcpyAsync(query_index, qi_dev, slots * 4, hipMemcpyDeviceToHost, s));
             for (uint32_t g = 0; g < n_groups; g++) out->status[g] = gstatus[g];
-            if (out->search_cutoff) for (uint32_t g = 0; g < n_groups; g++) out->search_cutoff[g] = gstatus[g] == TSGPU_ERR_DEADLINE;
+            if (out->search_cutoff) for (uint32_t g = 0; g < n_groups; g++) out->search_cutoff[g] = gcut[g];
         } else {
             TSGPU_HIP_TRY(hipMemcpyAsync(out->status, gstatus.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice, s));
-            if (out->search_cutoff) TSGPU_HIP_TRY(hipMemsetAsync(out->search_cutoff, 0, (size_t)n_groups * 4, s));
+            if (out->search_cutoff) TSGPU_HIP_TRY(hipMemcpyAsync(out->search_cutoff, gcut.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice, s));
         }
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
         if (found && !dev_out) for (uint32_t g = 0; g < n_groups; g++) found[g] = L.last_cand_found[g];

@@ -175,6 +175,7 @@ struct KwLane {
     DevBuf d_cand_keys, d_cand_scores, d_cand_tm, d_cand_vd, d_cand_msi, d_cand_nh, d_cand_nm, d_cand_st, d_cand_gb, d_cand_qi, d_cand_found,
            d_cand_segs, d_cand_bits, d_cand_ids;
     DevBuf d_hits;                                   // hit records of the two-kernel form
+    DevBuf d_t0, d_cut;                              // batch start stamp (device wall clock) + per-query cutoff flags (in-flight deadline)
     DevBuf d_fbits;                                  // rank bitmaps of filtered multi-field queries
     DevBuf d_idseg, d_idflat;                        // per-call id lists: segment table + the gathered ids
     PinBuf h_out, h_plan;
@@ -198,7 +199,7 @@ struct KwLane {
         DevBuf* bufs[] = {&d_plan, &d_ids_out, &d_part_s0, &d_part_s1, &d_part_s2, &d_part_key, &d_part_cnt, &d_part_nm, &d_part_ne,
                           &d_part_ow, &d_part_f, &d_out_keys, &d_out_scores, &d_out_tm, &d_out_vd, &d_out_msi, &d_out_nh, &d_out_nm, &d_out_ow, &d_out_cut,
                           &d_cand_keys, &d_cand_scores, &d_cand_tm, &d_cand_vd, &d_cand_msi, &d_cand_nh, &d_cand_nm, &d_cand_st, &d_cand_gb, &d_cand_qi,
-                          &d_cand_found, &d_cand_segs, &d_cand_bits, &d_cand_ids, &d_hits, &d_idseg, &d_idflat, &d_fbits};
+                          &d_cand_found, &d_cand_segs, &d_cand_bits, &d_cand_ids, &d_hits, &d_idseg, &d_idflat, &d_fbits, &d_t0, &d_cut};
         for (auto* b : bufs) b->release();
         h_out.release(); h_plan.release();
         for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -246,6 +247,7 @@ struct tsgpu_ctx {
     tsgpu::Combiner<tsgpu::KwRequest> kw_comb;
     tsgpu::Combiner<tsgpu::VecRequest> vec_comb;
     std::atomic<int> kw_callers{0}, vec_callers{0};  // threads currently inside the search entry points
+    uint32_t ticks_per_us = 100;                     // device wall clock (hipDeviceAttributeWallClockRate)
     uint32_t batch_window_us = 80;                   // micro-batcher: how long a round's leader waits for more callers
     uint32_t batch_max_queries = 64;                 // calls with more queries than this are not coalesced (they are batches already)
     uint32_t batch_round_queries = 1024;             // queries per coalesced round at most
