@@ -323,6 +323,7 @@ inline float __fsqrt_rn(float a) { return sqrtf(a); }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu::mfma_32x32x16_bf16((a), (b), (c))
 // global_load_lds_dwordx4: LDS destination = wave-uniform base + lane * 16, per-lane global source
+inline void hipemu_global_load_lds4(const void* gsrc, void* lds_wave_base) { memcpy((char*)lds_wave_base + 4 * hipemu::cur_lane(), gsrc, 4); }
 inline void hipemu_global_load_lds16(const void* gsrc, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * hipemu::cur_lane(), gsrc, 16); }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu::shfl(v, lane); }
 // device wall clock at 1 tick per microsecond (hipDeviceAttributeWallClockRate = 1000 kHz below)

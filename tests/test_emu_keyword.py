@@ -610,3 +610,58 @@ def test_deadline_in_flight_returns_partial_hits_with_search_cutoff(pair):
         assert (late.search_cutoff == 0).all() and np.array_equal(late.keys, full.keys) and np.array_equal(late.n_hits, full.n_hits)
     finally:
         g.set_option("kw_chunk_blocks", 0)
+
+
+@pytest.mark.parametrize("chunk", [64, 1, 3])
+def test_pair_find_kernel_matches_the_oracle(pair, chunk):
+    """kw_pair_blocks=1: the find kernel that serves two driver blocks per iteration (kw_find2.hip.h) — same hit records as the
+    one-block kernel: odd block counts (a lone last block), wide / multi-round / exhausted runs, third-list probes, filters"""
+    from oracle import oracle_py as O
+    orc, g, _ = pair
+    rng = np.random.default_rng(123)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    qs = []
+    for n_tok in (1, 2, 3):
+        qs += _queries(rng, 8, 25, n_tok, sort=sort, topster_size=250)
+        qs += _queries(rng, 3, 25, n_tok, sort=sort, topster_size=9, excluded_ids=np.arange(0, 3000, 4))
+        qs += _queries(rng, 3, 25, n_tok, sort=sort, topster_size=40, filter_ids=np.sort(rng.choice(3000, size=900, replace=False)))
+    g.set_option("kw_pair_blocks", 1)
+    g.set_option("kw_chunk_blocks", chunk)
+    g.keep_result_ids(True)
+    try:
+        hits = g.keyword_search_batch(qs, k_stride=250)
+        assert (hits.status == 0).all()
+        for i, q in enumerate(qs):
+            ref = H.oracle_keyword(orc, q, ids_cap=4000)
+            H.assert_hits_equal(hits, i, ref, "pair kernel chunk=%d" % chunk)
+            assert np.array_equal(g.result_ids(i), ref.result_ids)
+    finally:
+        g.set_option("kw_pair_blocks", 0)
+        g.set_option("kw_chunk_blocks", 0)
+        g.keep_result_ids(False)
+    # extreme length ratios
+    n_docs, lists = _synthetic_lists(6)
+    pts = H.points_of(n_docs)
+    orc2 = O.OracleIndex(1, 1)
+    orc2.set_num_docs(n_docs)
+    orc2.set_sort_dense(0, pts)
+    g2 = T.GpuIndex(0, H.emu_lib_path())
+    g2.field_create(0, False)
+    for term, (ids, oi, off) in lists.items():
+        orc2.load_posting(0, term, ids, oi, off)
+        g2.term_upsert(0, term, ids, oi, off)
+    g2.column_set(0, pts)
+    g2.set_num_docs(n_docs)
+    g2.commit()
+    g2.set_option("kw_pair_blocks", 1)
+    g2.set_option("kw_chunk_blocks", chunk)
+    g2.keep_result_ids(True)
+    qs = [T.KwQuery([1, 2], sort=sort, topster_size=250), T.KwQuery([2, 1, 3], sort=sort, topster_size=250),
+          T.KwQuery([3, 2], sort=sort, topster_size=100), T.KwQuery([3, 1], sort=sort, topster_size=250), T.KwQuery([2], sort=sort, topster_size=250)]
+    hits = g2.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all() and hits.n_hits[0] >= 250
+    for i, q in enumerate(qs):
+        ref = H.oracle_keyword(orc2, q, ids_cap=100000)
+        H.assert_hits_equal(hits, i, ref, "pair kernel stage1 chunk=%d" % chunk)
+        assert np.array_equal(g2.result_ids(i), ref.result_ids)
+    g2.close()

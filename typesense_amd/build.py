@@ -36,16 +36,39 @@ def build_loadgen(force=False):
     return LOADGEN_OUT
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=(), out=None, only_kw=False):
+    """one object per translation unit (compiled in parallel, kept under typesense_amd/_obj), then one link.
+    extra_flags/out: variant builds for tools/ experiments (-D knobs); only_kw: the flags touch tsgpu.hip only, reuse the other objects"""
     build_loadgen(force)
-    if not force and not needs_build():
-        return OUT
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-pass-failed",
-           "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    out = out or OUT
+    if not force and not extra_flags and not needs_build():
+        return out
+    tag = "default" if not extra_flags else "v_" + "_".join(f.lstrip("-D").replace("=", "-") for f in extra_flags)
+    objdir = os.path.join(HERE, "_obj", tag)
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "tsgpu.h")]
+    hdr_t = max(os.path.getmtime(h) for h in headers)
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
+    procs, objs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        flags = list(extra_flags) if (s == "tsgpu.hip" or not only_kw) else []
+        obj = os.path.join(objdir if flags or not extra_flags else os.path.join(HERE, "_obj", "default"), s + ".o")
+        os.makedirs(os.path.dirname(obj), exist_ok=True)
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(src)):
+            cmd = base + flags + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return OUT
+        print(" ".join(link))
+    subprocess.check_call(link)
+    return out
 
 
 if __name__ == "__main__":

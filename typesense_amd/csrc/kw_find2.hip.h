@@ -1,0 +1,385 @@
+// kw_find2.hip.h — the "find" half of the two-kernel keyword form with TWO driver blocks per iteration (included by kw_kernels.hip.h).
+//
+// kw_search_kernel<.., DEFER = true> spends ~43 % of a work item's cycles on per-BLOCK costs (the plan for the next block, the wait for
+// the driver block's metadata, stage 0, tile store, barrier, compaction, queue bookkeeping; TSGPU_PROF profile in DESIGN.md §5) and its
+// busiest issue port is the CU's one scalar unit. Here one iteration serves 512 driver ids: ONE plan (the run of second-list blocks under
+// both driver blocks), ONE tile, ONE barrier and ONE compaction barrier per pair; every thread carries two candidates — slot t of either
+// block — whose block / slot searches are two independent dependency chains. Everything else (window registers, tile pipeline, hit
+// records, third-list probes, deadline check) is the find kernel's; both kernels leave identical hit records (ascending ids per work item).
+#pragma once
+
+#ifndef TSGPU_F2_SPAN
+#define TSGPU_F2_SPAN 12
+#endif
+#ifndef TSGPU_F2_FAST
+#define TSGPU_F2_FAST 1
+#endif
+static const int KW_F2_SPAN = TSGPU_F2_SPAN;                 // runs of up to this many second-list blocks: block search by v_readlane over the window registers
+#ifndef TSGPU_F2_WAVES
+#define TSGPU_F2_WAVES 6
+#endif
+#ifdef TSGPU_HIP_EMU
+#define KW_F2_WAVES
+#else
+#define KW_F2_WAVES __attribute__((amdgpu_waves_per_eu(TSGPU_F2_WAVES)))
+#endif
+#ifndef TSGPU_F2_QUAD
+#define TSGPU_F2_QUAD 0
+#endif
+static const bool KW_F2_QUAD = TSGPU_F2_QUAD != 0;           // 4-ary slot search (three samples per round) instead of binary
+static const bool KW_F2_FAST = TSGPU_F2_FAST != 0;           // interleaved slot searches when a wavefront's blocks are all full 16-bit blocks
+
+// LDS-DMA tile fill: N slabs of 256 words, lane t of the workgroup copies word (slab * 256 + t) of the run straight from global memory
+// into the LDS tile (global_load_lds_dword: destination = M0 base + lane * 4 + instruction offset, the same offset advances the source) —
+// no staging registers, no ds_write. Words past the run's end are read, too: the ids arena ends with KW_TILE_OVERREAD_WORDS of padding
+// (tsgpu_index.hip) and nothing searches them. Issued through inline asm: the one wait the pipeline needs is kw_glds_wait() before the
+// barrier at the top of the next iteration (cf. vec_glds16 in vec_kernels.hip.h).
+template <int N>
+__device__ inline void kw_glds_slabs(const uint32_t* lane_src, uint32_t* lds_wave_base) {
+    static_assert(N == 2 || N == 8, "two tiers");
+#ifdef TSGPU_HIP_EMU
+    for (int k = 0; k < N; k++) hipemu_global_load_lds4(lane_src + k * 256, lds_wave_base + k * 256);
+#else
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    uint32_t keep;
+    if constexpr (N == 2) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\tglobal_load_lds_dword %1, off offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_src), "s"(dst) : "memory");
+    } else {
+        const uint32_t* lane_src2 = lane_src + 1024;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %1, off\n\tglobal_load_lds_dword %1, off offset:1024\n\t"
+                     "global_load_lds_dword %1, off offset:2048\n\tglobal_load_lds_dword %1, off offset:3072\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %2, off\n\tglobal_load_lds_dword %2, off offset:1024\n\t"
+                     "global_load_lds_dword %2, off offset:2048\n\tglobal_load_lds_dword %2, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_src), "v"(lane_src2), "s"(dst) : "memory", "scc");
+    }
+#endif
+}
+__device__ inline void kw_glds_wait() {
+#ifndef TSGPU_HIP_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+template <int TMAX>
+__global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
+                                                                                      const KwWorkItem* __restrict__ work, KwPartials part,
+                                                                                      uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
+    __shared__ KwSmem<TMAX, 512, false, true, true> sm;
+    __shared__ uint32_t wave_cnt_b[2][KW_THREADS / 64];        // second half's wave counts (the first half uses sm.wave_cnt2)
+    uint32_t* __restrict__ hits = hits_all + hit_off[blockIdx.x] * (uint64_t)(TMAX + 1);
+    __shared__ KwQueryDev sq;
+    const uint32_t t = threadIdx.x;
+    const KwWorkItem wi = work[blockIdx.x];
+    {
+        const uint32_t* src = (const uint32_t*)(queries + wi.query);
+        uint32_t* dst = (uint32_t*)&sq;
+        for (uint32_t i = t; i < sizeof(KwQueryDev) / 4; i += KW_THREADS) dst[i] = src[i];
+    }
+    if (t == 0) { sm.q1_cnt = 0; sm.qf_cnt = 0; sm.tk_cnt = 0; sm.have_thr = 0; sm.n_match = 0; sm.n_emit = 0; sm.off_words = 0; }
+    __syncthreads();
+    const KwQueryDev& q = sq;
+    const uint32_t T = q.n_lists;
+    const ListDesc dA = ix.lists[q.list[q.probe_order[0]]];
+    const ListDesc dB = ix.lists[q.list[q.probe_order[T >= 2 ? 1 : 0]]];
+    const uint32_t* __restrict__ blB = ix.blk_last + dB.blk_base;
+    const BlockIds* __restrict__ biA = ix.blk_ids + dA.blk_base;
+    const BlockIds* __restrict__ biB = ix.blk_ids + dB.blk_base;
+    const uint32_t* __restrict__ idwA = ix.ids_payload + dA.ids_base;
+    const uint32_t* __restrict__ idwB = ix.ids_payload + dB.ids_base;
+    const uint32_t lane = t & 63, wave = t >> 6;
+    const BlockIds PAD = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
+
+    auto load_id_raw = [&](const BlockIds& m, uint32_t slot) -> uint32_t {
+        const uint32_t n = m.n_ids_bits & 0xFFFF;
+        const uint32_t s2 = slot < n ? slot : 0;
+        const uint32_t* __restrict__ w = idwA + m.ids_woff;
+        return (m.n_ids_bits >> 16) == 16 ? (uint32_t)((const uint16_t*)w)[s2] : w[s2];
+    };
+    auto load_window = [&](uint32_t base) -> BlockIds { return (T >= 2 && base + lane < dB.n_blocks) ? biB[base + lane] : PAD; };
+    auto meta = [&](uint32_t bb) -> BlockIds { return biA[bb < wi.blk_end ? bb : wi.blk_end - 1]; };
+
+    uint32_t wbase = 0, wver = 0;
+    BlockIds win = load_window(0), nxt = load_window(32);
+    bool win_dirty = true;
+    struct Plan { uint32_t mode, rlo, rhi, w_begin, W, ver, base, buf; };   // mode: 0 tile, 1 tile in several rounds, 2 wide / broken run (probe), 3 exhausted, 4 no second list
+    constexpr int PIPE_WORDS = KW_FIND_PIPE_WORDS;
+    constexpr int TILE_WORDS = KW_FIND_TILE_WORDS;
+    static_assert(TILE_WORDS == 2 * PIPE_WORDS * KW_THREADS, "two tile buffers: one searched, one being filled");
+    constexpr int HALF = PIPE_WORDS * KW_THREADS;
+    uint32_t tbuf = 0;                                   // the buffer the last DMA went to
+    // how the driver ids in [lo_id, hi_id] meet the second list; mode 0 also requests the tile
+    auto make_plan = [&](uint32_t lo_id, uint32_t hi_id) -> Plan {
+        Plan P; P.mode = 4; P.rlo = P.rhi = P.w_begin = P.W = 0; P.ver = wver; P.base = wbase; P.buf = 0;
+        if (T < 2) return P;
+        unsigned long long mk = __ballot(win.last_id >= lo_id ? 1 : 0);
+        if (mk != 0 && (uint32_t)__builtin_ctzll(mk) >= 32) {          // cursor entered the upper half: slide by 32 blocks
+            wbase += 32; win = nxt; nxt = load_window(wbase + 32); win_dirty = true;
+            mk = __ballot(win.last_id >= lo_id ? 1 : 0);
+        }
+        if (mk == 0) {                                                   // all 64 blocks end before lo_id: uniform search, re-centre
+            uint32_t lo = wbase + 64, hi = dB.n_blocks;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (blB[mid] >= lo_id) hi = mid; else lo = mid + 1; }
+            wbase = lo; win = load_window(wbase); nxt = load_window(wbase + 32); win_dirty = true;
+            mk = __ballot(win.last_id >= lo_id ? 1 : 0);
+        }
+        P.rlo = (uint32_t)__builtin_ctzll(mk);
+        P.base = wbase;
+        if (wbase + P.rlo >= dB.n_blocks) { P.mode = 3; return P; }
+        const unsigned long long mh = __ballot(win.last_id >= hi_id ? 1 : 0);
+        if (mh == 0) { P.mode = 2; return P; }
+        P.rhi = (uint32_t)__builtin_ctzll(mh);
+        if (wbase + P.rhi >= dB.n_blocks) P.rhi = dB.n_blocks - 1 - wbase;
+        if (win_dirty) {
+            wver ^= 1;
+            if (t < 64) { sm.bw_last[wver][t] = win.last_id; sm.bw_first[wver][t] = win.first_id; sm.bw_woff[wver][t] = win.ids_woff; sm.bw_nb[wver][t] = win.n_ids_bits; }
+            win_dirty = false;
+        }
+        P.ver = wver;
+        const uint32_t w_endw = win.ids_woff + packed_words(win.n_ids_bits & 0xFFFF, win.n_ids_bits >> 16);
+        if (dB.flags & LIST_HAS_BREAKS) {
+            const uint32_t nxt_woff = (uint32_t)__shfl(win.ids_woff, (int)((lane + 1) & 63));
+            const bool brk = lane >= P.rlo && lane < P.rhi && w_endw != nxt_woff;
+            if (__ballot(brk ? 1 : 0) != 0) { P.mode = 2; return P; }
+        }
+        P.w_begin = (uint32_t)__shfl(win.ids_woff, (int)P.rlo);
+        P.W = (uint32_t)__shfl(w_endw, (int)P.rhi) - P.w_begin;
+        if (P.W <= (uint32_t)(PIPE_WORDS * KW_THREADS)) {
+            P.mode = 0;
+            tbuf ^= 1; P.buf = tbuf;
+            const uint32_t* lane_src = idwB + P.w_begin + t;
+            uint32_t* lds_wave_base = sm.btile + tbuf * HALF + wave * 64;
+            if (P.W <= 2u * KW_THREADS) kw_glds_slabs<2>(lane_src, lds_wave_base);
+            else kw_glds_slabs<8>(lane_src, lds_wave_base);
+        } else P.mode = 1;
+        return P;
+    };
+
+    // the pair (b, b + 1): metadata, raw ids and the plan one pair ahead
+    BlockIds mA = meta(wi.blk_begin), mB = meta(wi.blk_begin + 1), mC = meta(wi.blk_begin + 2), mD = meta(wi.blk_begin + 3);
+    uint32_t araw0 = load_id_raw(mA, t), araw1 = load_id_raw(mB, t);
+    Plan P = make_plan(mA.first_id, wi.blk_begin + 1 < wi.blk_end ? mB.last_id : mA.last_id);
+    uint32_t q1n = 0, qfn = 0, par = 0;
+    KW_PROF_DECL
+
+    auto drain_q1 = [&]() {                              // (uniform) third.. lists for full batches of stage-1 survivors
+        if (q1n >= (uint32_t)KW_THREADS) {
+            __syncthreads();
+            if (t == 0) sm.q1_cnt = q1n;
+            __syncthreads();
+            while (sm.q1_cnt >= (uint32_t)KW_THREADS) kw_probe_rest_stage<TMAX, 512, true, true>(sm, ix, q, KW_THREADS, hits);
+            q1n = sm.q1_cnt;
+        }
+    };
+
+    for (uint32_t b = wi.blk_begin, it = 0; b < wi.blk_end; b += 2, it++) {
+        if (P.mode == 3) break;
+        if ((it & 7) == 0 && kw_out_of_time(ix, q, wi.query)) break;
+        const bool two = b + 1 < wi.blk_end;
+        const uint32_t n0 = mA.n_ids_bits & 0xFFFF, n1 = two ? (mB.n_ids_bits & 0xFFFF) : 0u;
+        bool ok0 = t < n0, ok1 = t < n1;
+        const uint32_t id0 = ok0 ? mA.first_id + araw0 : 0xFFFFFFFFu, id1 = ok1 ? mB.first_id + araw1 : 0xFFFFFFFFu;
+        const Plan C = P;
+        KW_PROF(0)
+        kw_glds_wait();                                  // this pair's tile (and driver ids) have landed
+        const uint32_t* __restrict__ tile = sm.btile + C.buf * HALF;
+        KW_PROF(1)
+        __syncthreads();
+        KW_PROF(2)
+        // ---- (a) which block of the run, for both candidates ----
+        const uint32_t span = C.rhi - C.rlo;
+        uint32_t pos0 = C.rlo, pos1 = C.rlo;
+        if (C.mode <= 1 && span <= (uint32_t)KW_F2_SPAN) {
+            for (uint32_t j = C.rlo; j < C.rhi; j++) {
+                const uint32_t last_j = (uint32_t)__builtin_amdgcn_readlane((int)win.last_id, (int)j);
+                pos0 += last_j < id0 ? 1u : 0u;
+                pos1 += last_j < id1 ? 1u : 0u;
+            }
+        }
+        bool done0 = !ok0 || C.mode >= 2, done1 = !ok1 || C.mode >= 2, found0 = false, found1 = false;
+        uint32_t p10 = 0, p11 = 0;                      // posting positions in the second list
+        uint32_t first0 = 0, nb0 = 0, rel0 = 0, first1 = 0, nb1 = 0, rel1 = 0;
+        if (C.mode <= 1) {
+            const uint32_t* __restrict__ bl = sm.bw_last[C.ver];
+            if (span > (uint32_t)KW_F2_SPAN) {
+                for (uint32_t step = 1u << (31 - __builtin_clz(span)); step > 0; step >>= 1) {
+                    const uint32_t j0 = pos0 + step, j1 = pos1 + step;
+                    const uint32_t v0 = bl[(j0 <= C.rhi ? j0 : C.rhi) - 1], v1 = bl[(j1 <= C.rhi ? j1 : C.rhi) - 1];
+                    pos0 = (j0 <= C.rhi && v0 < id0) ? j0 : pos0;
+                    pos1 = (j1 <= C.rhi && v1 < id1) ? j1 : pos1;
+                }
+            }
+            // (inactive lanes carry id = 0xFFFFFFFF: pos = rhi, harmless reads)
+            first0 = sm.bw_first[C.ver][pos0]; first1 = sm.bw_first[C.ver][pos1];
+            const uint32_t l0 = bl[pos0], l1 = bl[pos1];
+            nb0 = sm.bw_nb[C.ver][pos0]; nb1 = sm.bw_nb[C.ver][pos1];
+            rel0 = sm.bw_woff[C.ver][pos0] - C.w_begin; rel1 = sm.bw_woff[C.ver][pos1] - C.w_begin;
+            if (l0 < id0 || id0 < first0) done0 = true;                  // beyond B's end / in the gap between two blocks
+            if (l1 < id1 || id1 < first1) done1 = true;
+        }
+        KW_PROF(3)
+        // ---- request the next pair (in flight during the slot searches) ----
+        uint32_t araw0n = 0, araw1n = 0;
+        if (b + 2 < wi.blk_end) {
+            araw0n = load_id_raw(mC, t);
+            araw1n = load_id_raw(mD, t);
+            KW_PROF(10)
+            P = make_plan(mC.first_id, b + 3 < wi.blk_end ? mD.last_id : mC.last_id);
+        }
+        KW_PROF(4)
+        // ---- (b) which slot: branch-free lower bound over the block's ids in the LDS tile ----
+        auto slot_search = [&](const uint32_t* __restrict__ tile_r, uint32_t id, uint32_t b_first, uint32_t b_nb, uint32_t tile_rel, uint32_t kb, bool& found, uint32_t& p1) {
+            const uint32_t n = b_nb & 0xFFFF, target = id - b_first;
+            uint32_t pos = 0, hit;
+            if ((b_nb >> 16) == 16) {
+                const uint16_t* __restrict__ a16 = (const uint16_t*)(tile_r + tile_rel);
+                if (n == (uint32_t)BLOCK_IDS) {
+#pragma unroll
+                    for (uint32_t step = 128; step > 0; step >>= 1) { const uint32_t v = a16[pos + step - 1]; pos = v < target ? pos + step : pos; }
+                } else {
+#pragma unroll
+                    for (uint32_t step = 128; step > 0; step >>= 1) {
+                        const uint32_t j = pos + step;
+                        const uint32_t v = a16[(j <= n ? j : n) - 1];
+                        pos = (j <= n && v < target) ? j : pos;
+                    }
+                }
+                hit = a16[pos];
+            } else {
+                const uint32_t* __restrict__ a32 = tile_r + tile_rel;
+#pragma unroll
+                for (uint32_t step = 128; step > 0; step >>= 1) {
+                    const uint32_t j = pos + step;
+                    const uint32_t v = a32[(j <= n ? j : n) - 1];
+                    pos = (j <= n && v < target) ? j : pos;
+                }
+                hit = a32[pos];
+            }
+            if (hit == target) { found = true; p1 = (C.base + kb) * BLOCK_IDS + pos; }
+        };
+        if (C.mode == 0) {
+            // every block but a list's last is full, and 16-bit wherever the list is dense: when that holds for all of a wavefront's
+            // candidates the two searches run as ONE straight-line sequence of two independent chains (candidates that dropped out
+            // search the tile's first block: harmless reads)
+            constexpr uint32_t FULL16 = (16u << 16) | (uint32_t)BLOCK_IDS;
+            const bool fast = (done0 || nb0 == FULL16) && (done1 || nb1 == FULL16);
+            if (KW_F2_FAST && __ballot(fast ? 0 : 1) == 0) {
+                const uint16_t* __restrict__ a0 = (const uint16_t*)(tile + (done0 ? 0u : rel0));
+                const uint16_t* __restrict__ a1 = (const uint16_t*)(tile + (done1 ? 0u : rel1));
+                const uint32_t t0 = id0 - first0, t1 = id1 - first1;
+                uint32_t s0 = 0, s1 = 0;
+                if constexpr (KW_F2_QUAD) {
+                    // 4-ary lower bound: three independent samples per round, four rounds instead of eight dependent LDS reads; the last
+                    // round's four ids are two 32-bit words (s is a multiple of 4: 8-byte offset from the word-aligned block start)
+#pragma unroll
+                    for (uint32_t step = 64; step >= 4; step >>= 2) {
+                        const uint32_t x0 = a0[s0 + step - 1], y0 = a0[s0 + 2 * step - 1], z0 = a0[s0 + 3 * step - 1];
+                        const uint32_t x1 = a1[s1 + step - 1], y1 = a1[s1 + 2 * step - 1], z1 = a1[s1 + 3 * step - 1];
+                        s0 += step * ((x0 < t0 ? 1u : 0u) + (y0 < t0 ? 1u : 0u) + (z0 < t0 ? 1u : 0u));
+                        s1 += step * ((x1 < t1 ? 1u : 0u) + (y1 < t1 ? 1u : 0u) + (z1 < t1 ? 1u : 0u));
+                    }
+                    const uint32_t* __restrict__ w0 = (const uint32_t*)(a0 + s0);
+                    const uint32_t* __restrict__ w1 = (const uint32_t*)(a1 + s1);
+                    const uint32_t wa0 = w0[0], wb0 = w0[1], wa1 = w1[0], wb1 = w1[1];
+                    const uint32_t e00 = wa0 & 0xFFFF, e01 = wa0 >> 16, e02 = wb0 & 0xFFFF, e03 = wb0 >> 16;
+                    const uint32_t e10 = wa1 & 0xFFFF, e11 = wa1 >> 16, e12 = wb1 & 0xFFFF, e13 = wb1 >> 16;
+                    found0 = !done0 && (e00 == t0 || e01 == t0 || e02 == t0 || e03 == t0);
+                    found1 = !done1 && (e10 == t1 || e11 == t1 || e12 == t1 || e13 == t1);
+                    s0 += (e00 < t0 ? 1u : 0u) + (e01 < t0 ? 1u : 0u) + (e02 < t0 ? 1u : 0u);
+                    s1 += (e10 < t1 ? 1u : 0u) + (e11 < t1 ? 1u : 0u) + (e12 < t1 ? 1u : 0u);
+                } else {
+#pragma unroll
+                    for (uint32_t step = 128; step > 0; step >>= 1) {
+                        const uint32_t v0 = a0[s0 + step - 1], v1 = a1[s1 + step - 1];
+                        s0 = v0 < t0 ? s0 + step : s0;
+                        s1 = v1 < t1 ? s1 + step : s1;
+                    }
+                    const uint32_t h0 = a0[s0], h1 = a1[s1];
+                    found0 = !done0 && h0 == t0; found1 = !done1 && h1 == t1;
+                }
+                p10 = (C.base + pos0) * BLOCK_IDS + s0; p11 = (C.base + pos1) * BLOCK_IDS + s1;
+            } else {
+                if (!done0) slot_search(tile, id0, first0, nb0, rel0, pos0, found0, p10);
+                if (!done1) slot_search(tile, id1, first1, nb1, rel1, pos1, found1, p11);
+            }
+        } else if (C.mode == 1) {
+            // the run does not fit the pipelined tile: rounds over [rlo, rhi], each a coalesced copy of as many whole blocks as fit
+            const uint32_t* __restrict__ woff = sm.bw_woff[C.ver];
+            const uint32_t* __restrict__ wnb = sm.bw_nb[C.ver];
+            uint32_t* __restrict__ rt = sm.btile + (tbuf ^ 1) * HALF;        // the buffer no DMA is writing
+            for (uint32_t r_lo = C.rlo; r_lo <= C.rhi;) {
+                const uint32_t w_begin = woff[r_lo];
+                uint32_t r_hi = r_lo;
+                while (r_hi < C.rhi && woff[r_hi + 1] + packed_words(wnb[r_hi + 1] & 0xFFFF, wnb[r_hi + 1] >> 16) - w_begin <= (uint32_t)HALF) r_hi++;
+                const uint32_t W = woff[r_hi] + packed_words(wnb[r_hi] & 0xFFFF, wnb[r_hi] >> 16) - w_begin;
+                const uint32_t* __restrict__ src = idwB + w_begin;
+                __syncthreads();
+                for (uint32_t i0 = t; i0 < W + t; i0 += 2 * KW_THREADS) {
+                    const uint32_t i1 = i0 + KW_THREADS;
+                    const uint32_t c0 = src[i0 < W ? i0 : 0], c1 = src[i1 < W ? i1 : 0];
+                    if (i0 < W) rt[i0] = c0;
+                    if (i1 < W) rt[i1] = c1;
+                }
+                __syncthreads();
+                if (!done0 && pos0 >= r_lo && pos0 <= r_hi) { slot_search(rt, id0, first0, nb0, woff[pos0] - w_begin, pos0, found0, p10); done0 = true; }
+                if (!done1 && pos1 >= r_lo && pos1 <= r_hi) { slot_search(rt, id1, first1, nb1, woff[pos1] - w_begin, pos1, found1, p11); done1 = true; }
+                r_lo = r_hi + 1;
+            }
+        } else if (C.mode == 2) {
+            if (ok0) found0 = probe_list(ix, dB, id0, p10);
+            if (ok1) found1 = probe_list(ix, dB, id1, p11);
+        }
+        if (T >= 2) { ok0 = ok0 && found0; ok1 = ok1 && found1; }
+        KW_PROF(5)
+        // ---- ordered compaction of both halves behind ONE barrier ----
+        const unsigned long long m0 = __ballot(ok0 ? 1 : 0), m1 = __ballot(ok1 ? 1 : 0);
+        const uint32_t lo0 = (uint32_t)__popcll(m0 & ((1ull << lane) - 1ull)), lo1 = (uint32_t)__popcll(m1 & ((1ull << lane) - 1ull));
+        if (lane == 0) { sm.wave_cnt2[par][wave] = (uint32_t)__popcll(m0); wave_cnt_b[par][wave] = (uint32_t)__popcll(m1); }
+        __syncthreads();
+        uint32_t base0 = 0, tot0 = 0, base1 = 0, tot1 = 0;
+#pragma unroll
+        for (int w = 0; w < KW_THREADS / 64; w++) {
+            const uint32_t c0 = sm.wave_cnt2[par][w], c1 = wave_cnt_b[par][w];
+            if ((uint32_t)w < wave) { base0 += c0; base1 += c1; }
+            tot0 += c0; tot1 += c1;
+        }
+        par ^= 1;
+        KW_PROF(6)
+        const uint32_t pa0 = b * BLOCK_IDS + t, pa1 = (b + 1) * BLOCK_IDS + t;        // posting positions in the driver list
+        if (T >= 3) {
+            if (ok0) { const uint32_t slot = q1n + base0 + lo0; sm.q1_id[slot] = id0; sm.q1_p0[slot] = pa0; sm.q1_p1[slot] = p10; }
+            q1n += tot0;
+            drain_q1();                                  // (the queue holds 512 entries: 255 left over + one block's survivors)
+            if (ok1) { const uint32_t slot = q1n + base1 + lo1; sm.q1_id[slot] = id1; sm.q1_p0[slot] = pa1; sm.q1_p1[slot] = p11; }
+            q1n += tot1;
+            drain_q1();
+        } else {
+            // one or two lists: the stage-1 survivors ARE the complete hits (ascending: block b's, then block b + 1's)
+            if (ok0) {
+                uint32_t v[TMAX];
+#pragma unroll
+                for (int k = 0; k < TMAX; k++) { v[k] = 0; if (k == q.probe_order[0]) v[k] = pa0; if (T >= 2 && k == q.probe_order[1]) v[k] = p10; }
+                kw_hit_store<TMAX>(hits, qfn + base0 + lo0, id0, v);
+            }
+            if (ok1) {
+                uint32_t v[TMAX];
+#pragma unroll
+                for (int k = 0; k < TMAX; k++) { v[k] = 0; if (k == q.probe_order[0]) v[k] = pa1; if (T >= 2 && k == q.probe_order[1]) v[k] = p11; }
+                kw_hit_store<TMAX>(hits, qfn + tot0 + base1 + lo1, id1, v);
+            }
+            qfn += tot0 + tot1;
+        }
+        KW_PROF(7)
+        mA = mC; mB = mD; mC = meta(b + 4); mD = meta(b + 5); araw0 = araw0n; araw1 = araw1n;   // (consumed in the middle of the next iteration)
+    }
+    __syncthreads();
+    if (t == 0) { if (T >= 3) sm.q1_cnt = q1n; else sm.qf_cnt = qfn; }
+    __syncthreads();
+    if (T >= 3) while (sm.q1_cnt > 0) kw_probe_rest_stage<TMAX, 512, true, true>(sm, ix, q, sm.q1_cnt < KW_THREADS ? sm.q1_cnt : KW_THREADS, hits);
+    if (t == 0) part.cnt[blockIdx.x] = sm.qf_cnt;              // hits handed to kw_score_kernel
+    KW_PROF(9)
+    KW_PROF_FLUSH(ix.prof)
+}

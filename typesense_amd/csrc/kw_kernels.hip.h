@@ -174,6 +174,9 @@ struct KwOut {                       // final, per query, stride = k_stride (tsg
 // (wave-uniform: one s_memrealtime + a scalar load): past the query's budget it raises the query's cutoff flag and stops scanning;
 // what it found so far is scored and merged as usual, the caller gets partial hits with search_cutoff = 1.
 __device__ inline bool kw_out_of_time(const IndexView& ix, const KwQueryDev& q, uint32_t query) {
+#ifdef TSGPU_NO_DEADLINE
+    return false;
+#endif
     if (q.deadline_rem_us == 0) return false;
 #ifdef TSGPU_HIP_EMU
     const long long now = hipemu_wall_clock64();
@@ -2023,5 +2026,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_idset_expand_kernel(const uint3
         __syncthreads();
     }
 }
+
+#include "kw_find2.hip.h"
 
 }  // namespace tsgpu

@@ -65,8 +65,9 @@ void launch_search(hipStream_t s, uint32_t n_work, const IndexView& v, const KwQ
 // two-kernel form: find (intersection -> hit records) then score (hit records -> partial top-K)
 template <int TMAX>
 void launch_find_score(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w, const KwPartials& part,
-                       const uint32_t* aux, uint32_t* ids_out, bool s2, uint32_t* hits, const uint64_t* hit_off, hipEvent_t mid_ev = nullptr) {
-    hipLaunchKernelGGL((kw_search_kernel<TMAX, 512, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+                       const uint32_t* aux, uint32_t* ids_out, bool s2, uint32_t* hits, const uint64_t* hit_off, hipEvent_t mid_ev = nullptr, bool pair = false) {
+    if (pair) hipLaunchKernelGGL((kw_find2_kernel<TMAX>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, hits, hit_off);
+    else hipLaunchKernelGGL((kw_search_kernel<TMAX, 512, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     if (mid_ev) (void)hipEventRecord(mid_ev, s);           // find | score boundary of the batch's first group (tsgpu_timings::kw_find_ms)
     if (cap == 512 && !s2) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, false>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     else if (cap == 512) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
@@ -228,6 +229,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_cost_fixed")) { ctx->kw_cost_fixed = (uint32_t)std::max<int64_t>(value, 0); return ok(); }
     if (!strcmp(name, "kw_sort_work")) { ctx->kw_sort_work = value != 0; return ok(); }
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
+    if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
     if (!strcmp(name, "kw_hit_buffer_records")) {       // exact budget in hit records (tests); 0 = use kw_hit_buffer_mb
         if (value < 0) return fail(TSGPU_ERR_INVALID, "kw_hit_buffer_records must be >= 0");
         ctx->kw_hit_buffer_records = (uint64_t)value; return ok();
@@ -972,7 +974,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
                     else {
                         const bool mark = !find_marked;
                         find_marked = true;
-                        launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, L.d_hits.as<uint32_t>(), hoff_dev + a, mark ? L.ev[3] : nullptr);
+                        launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, L.d_hits.as<uint32_t>(), hoff_dev + a, mark ? L.ev[3] : nullptr, ctx->kw_pair_blocks);
                     }
                 }
             } else if constexpr (MFT) launch_search_mf_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out);

@@ -53,6 +53,9 @@ struct BlockMeta {           // 32 bytes: offsets side of a block (scoring only)
     uint8_t pad[3];
 };
 
+// words the find kernel's LDS-DMA tile fill may read past the end of a run (kw_find2.hip.h): the ids arena is allocated this much larger
+static const uint32_t KW_TILE_OVERREAD_WORDS = 2048;
+
 struct ListDesc {            // 48 bytes
     uint64_t payload_base;   // word index into the payload arena (offset_index + offsets)
     uint64_t ids_base;       // word index into the ids_payload arena

@@ -371,7 +371,7 @@ int commit_full(tsgpu_ctx* ctx) {
     ar->cap_pw = n_pw + std::max<uint64_t>(n_pw / 2, min_slack) + 4;
     int rc;
     if ((rc = ar->blk_last.reserve(ar->cap_blocks * 4)) || (rc = ar->blk_ids.reserve(ar->cap_blocks * sizeof(BlockIds))) || (rc = ar->blk_meta.reserve(ar->cap_blocks * sizeof(BlockMeta))) ||
-        (rc = ar->ids_payload.reserve(ar->cap_idw * 4)) || (rc = ar->payload.reserve(ar->cap_pw * 4)))
+        (rc = ar->ids_payload.reserve((ar->cap_idw + KW_TILE_OVERREAD_WORDS) * 4)) || (rc = ar->payload.reserve(ar->cap_pw * 4)))
         return rc;
     std::vector<uint32_t> h_last; std::vector<BlockIds> h_bids; std::vector<BlockMeta> h_bmeta;
     h_last.reserve(n_slots); h_bids.reserve(n_slots); h_bmeta.reserve(n_slots);
