@@ -36,9 +36,9 @@ def build_loadgen(force=False):
     return LOADGEN_OUT
 
 
-def build(force=False, verbose=False, extra_flags=(), out=None, only_kw=False):
+def build(force=False, verbose=False, extra_flags=(), out=None, only_kw=False, only=None):
     """one object per translation unit (compiled in parallel, kept under typesense_amd/_obj), then one link.
-    extra_flags/out: variant builds for tools/ experiments (-D knobs); only_kw: the flags touch tsgpu.hip only, reuse the other objects"""
+    extra_flags/out: variant builds for tools/ experiments (-D knobs); only_kw / only=<source>: the flags touch that translation unit only (default tsgpu.hip), the other objects are reused"""
     build_loadgen(force)
     out = out or OUT
     if not force and not extra_flags and not needs_build():
@@ -52,7 +52,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None, only_kw=False):
     procs, objs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        flags = list(extra_flags) if (s == "tsgpu.hip" or not only_kw) else []
+        flags = list(extra_flags) if ((only or "tsgpu.hip") == s or not (only_kw or only)) else []
         obj = os.path.join(objdir if flags or not extra_flags else os.path.join(HERE, "_obj", "default"), s + ".o")
         os.makedirs(os.path.dirname(obj), exist_ok=True)
         objs.append(obj)

@@ -564,6 +564,15 @@ __device__ inline void vec_glds_wait() {        // all but the youngest N vector
 // vmcnt(XV+QV) — loads complete in issue order, so everything but this step's own DMAs has landed, i.e. X(s+1) and Q(s+1) —
 // and the workgroup barrier. (Dedicated loader waves were measured slower: two waves cannot issue a step's 48 DMAs as fast
 // as eight do, and the limiter of the combined loop is LDS bandwidth — DMA writes + operand reads — not MFMA issue.)
+// Round-2 measurements at B = 256 on 10M x 768 (tools/exp_vec2.py), none of which beat this form (scan 4.6 ms):
+//   * ablations: row blocks only 2.99 ms (5.1 TB/s), query blocks only (L2-resident) 2.4-2.5 ms (6.1-6.5 TB/s chip-wide = ~25 GB/s
+//     per CU: the LDS-DMA landing rate of a CU, MI355X_MICROARCH.md "ldsdma-fill"), both 3.5 ms (8.7 TB/s of LDS-DMA), MFMA + operand
+//     reads without DMA 3.1 ms; at B = 64 the same kernel streams the rows at 5.9-6.2 TB/s (of ~6.3 achievable);
+//   * separate rings — waves 0-3 issue only row blocks (5-7 slots), waves 4-7 only query blocks (2-4 slots), so more ROW bytes are
+//     in flight per CU (80-96 KB instead of 48): 5.0-5.5 ms. Depth is not the limiter;
+//   * workgroups of an XCD walking the k chunks in rotated order (no two ask L2 for the same query block at once): no change;
+//   * query blocks through registers (global_load -> ds_write_b128 by waves 4-7) to leave the DMA path to the rows: 6.3-8 ms (the
+//     loading waves stall their own MFMA stream on L2 latency).
 static const int VEC_HTHREADS = 512;
 static const int VEC_HROWS = 2 * VEC_ROWS;          // rows per workgroup step (two 128-row tiles)
 static const int VEC_HMAX_PER = 2048;               // tile ordinals per slab whose norm maxima are staged in LDS
