@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (concurrency, uncached-term batch, vector batch sweep / cosine / clustered)")
     ap.add_argument("--threads", type=int, default=256, help="host threads of the concurrency leg")
     ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--hnsw-rows", type=int, default=1_000_000, help="rows of the HNSW leg's collection (0 = skip the leg)")
+    ap.add_argument("--hnsw-batch", type=int, default=4096, help="queries per step of the HNSW leg")
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--opt", action="append", default=[], help="tsgpu_set_option name=value (repeatable), e.g. vec_prefilter=0")
     ap.add_argument("--dist-mode", default="shards", choices=["shards", "replicas"],
@@ -666,6 +668,97 @@ class Bench:
             # (the field's 45 GB stay allocated until the context closes: 288 GB of HBM)
         return out
 
+    # ---------------------------------------------------------------- HNSW (parity UNPINNED: hnswlib is not under /root/reference)
+    def run_hnsw(self):
+        """searchKnnCloserFirst on a resident graph: q/s by batch and ef, recall@k against the exact scan, the traversal checked bit for bit
+        against the oracle's restatement walking the SAME graph, and that restatement timed on the host cores as cpu_baseline (port).
+        The graph is derived on the GPU from exact k-NN lists + the neighbour-selection heuristic (typesense_amd/hnsw_synth.py) — hnswlib's
+        sequential build of 1M x 768 does not fit a bench run; the collection has a 32-dimensional latent structure (i.i.d. N(0,1) rows
+        are equidistant in 768 dimensions: no graph index has recall there, measured 0.007)."""
+        from typesense_amd import _lib as B, synth, hnsw_synth
+        torch, args, g = self.torch, self.args, self.g
+        n, dim, k, M, field = args.hnsw_rows, args.dim, args.k, 16, 7
+        t0 = time.time()
+        X = synth.latent_vectors(n, dim, seed=3, device="cuda")
+        g.vec_create(field, dim, B.METRIC_IP, n)
+        lab = torch.arange(n, dtype=torch.int64, device="cuda")
+        g.vec_upsert_device(field, lab.data_ptr(), X.data_ptr(), n)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        graph = hnsw_synth.build_graph(torch, g, field, X, M=M, K0=64, seed=100, batch=1024)
+        torch.cuda.synchronize()
+        t_build = time.time() - t1
+        g.vec_hnsw_load(field, graph)
+        nq_max = max(args.hnsw_batch, 256)
+        Q = synth.latent_vectors(nq_max, dim, seed=4, device="cuda")
+        res = {"metric": "HNSW k-NN queries/s (searchKnnCloserFirst, k=%d), PARITY UNPINNED: hnswlib is absent from the reference tree; the traversal is "
+                         "checked against the oracle's restatement of the published algorithm on the same graph" % k,
+               "unit": "queries/s", "dtype": "f32",
+               "config": {"workload": "%d x %d unit rows with a 32-dim latent structure + 0.3 noise (synth.latent_vectors), M=%d, graph = exact %d-NN lists + "
+                                      "getNeighborsByHeuristic2 + reverse links, built on the GPU (graph: knn-heuristic, NOT hnswlib's insertion-order graph)" % (n, dim, M, 64),
+                          "graph_build_s": t_build, "collection_s": t1 - t0, "maxlevel": int(graph["maxlevel"]), "mean_level0_degree": float(graph["link0"][:, 0].mean())},
+               "runs": []}
+        de = torch.zeros((256, k), dtype=torch.float32, device="cuda"); le = torch.zeros((256, k), dtype=torch.int64, device="cuda"); ce = torch.zeros(256, dtype=torch.int32, device="cuda")
+        g.vec_knn_batch_raw(field, Q.data_ptr(), B.MEM_DEVICE, 256, k, de.data_ptr(), le.data_ptr(), ce.data_ptr(), B.MEM_DEVICE)
+        torch.cuda.synchronize()
+        le_h = le.cpu().numpy()
+        keep = {}
+        for ef in (100, 400):
+            for nq in sorted({256, args.hnsw_batch}):
+                d = torch.zeros((nq, k), dtype=torch.float32, device="cuda"); l = torch.zeros((nq, k), dtype=torch.int64, device="cuda"); c = torch.zeros(nq, dtype=torch.int32, device="cuda")
+                def step():
+                    g.vec_hnsw_search_batch_raw(field, Q.data_ptr(), B.MEM_DEVICE, nq, k, ef, d.data_ptr(), l.data_ptr(), c.data_ptr(), B.MEM_DEVICE)
+                el, _, _ = timed(step, 5, 2, 1)
+                lh = l[:256].cpu().numpy()
+                rec = float(np.mean([len(set(lh[i].tolist()) & set(le_h[i].tolist())) / k for i in range(256)]))
+                dist_q = g.counter("hnsw_last_distances") / nq
+                run = {"ef": ef, "batch": nq, "value": nq * 5 / el, "unit": "queries/s", "ms_per_batch": 1e3 * el / 5, "recall_at_%d" % k: rec,
+                       "expansions_per_query": g.counter("hnsw_last_expansions") / nq, "distances_per_query": dist_q,
+                       "row_bytes_GBs": dist_q * dim * 4 * nq * 5 / el / 1e9}
+                res["runs"].append(run)
+                keep[(ef, nq)] = (d[:256].cpu().numpy(), lh, c[:256].cpu().numpy())
+        head = [x for x in res["runs"] if x["ef"] == 100 and x["batch"] == args.hnsw_batch][0]
+        res["value"] = head["value"]
+        res["recall_at_%d" % k] = head["recall_at_%d" % k]
+        res["roofline"] = {"bound": "hbm", "achieved": head["row_bytes_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["row_bytes_GBs"] / HBM_PEAK_GBS, "traffic": None,
+                           "note": "algorithmic bytes = distances computed x dim x 4 B (fp32 rows fetched at random, 3 KB each; link lists and visited tags not "
+                                   "counted) over the kernel time of the ef=100 batch"}
+        if not args.no_cpu_baseline:
+            from oracle import oracle_py as O
+            t2 = time.time()
+            orc = O.OracleIndex(1, 1)
+            orc.vec_init(dim, O.METRIC_IP)
+            S = 1 << 18
+            for a in range(0, n, S):
+                b = min(n, a + S)
+                orc.vec_add(np.arange(a, b, dtype=np.uint32), X[a:b].cpu().numpy())
+            orc.hnsw_import(graph)
+            ncpu = os.cpu_count() or 1
+            Qh = synth.latent_vectors(max(64 * ncpu, 4096), dim, seed=4, device="cuda").cpu().numpy()      # (same stream as Q: its first rows are the GPU's queries)
+            npar = 64
+            bad = 0
+            for ef in (100, 400):
+                od, ol, oc = orc.hnsw_search_batch(Qh[:npar], k, ef, threads=ncpu)
+                gd, gl, gc = keep[(ef, 256)]
+                for i in range(npar):
+                    m = int(oc[i])
+                    if not (gc[i] == m and np.array_equal(gl[i, :m].astype(np.uint64), ol[i, :m]) and np.array_equal(gd[i, :m].view(np.uint32), od[i, :m].view(np.uint32))):
+                        bad += 1
+            res["parity"] = {"queries_checked": 2 * npar, "mismatches": bad, "pinned": False,
+                             "what": "labels, order and distance bits of %d queries at ef=100 and ef=400 vs the oracle's restatement of searchKnnCloserFirst walking the "
+                                     "same %d-node graph (hnsw_import); hnswlib itself is absent: parity unpinned" % (npar, n)}
+            orc.hnsw_search_batch(Qh[:ncpu], k, 100, threads=ncpu)
+            t3 = time.time()
+            orc.hnsw_search_batch(Qh, k, 100, threads=ncpu)
+            wall = time.time() - t3
+            res["cpu_baseline"] = {"value": Qh.shape[0] / wall, "unit": "queries/s", "cores": ncpu, "kind": "port",
+                                   "sample": "%d queries at ef=100 through the oracle's HNSW restatement (scalar 16-lane-order distances, pooled visited tags) on %d host threads, "
+                                             "same graph, same rows; oracle load + import took %.0f s" % (Qh.shape[0], ncpu, t3 - t2)}
+            res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+            orc.close()
+        del X
+        return res
+
     # ---------------------------------------------------------------- hybrid (config 4)
     def run_hybrid(self):
         from typesense_amd import _lib as B, synth
@@ -788,6 +881,10 @@ def main():
         t0 = time.time()
         out["vector"]["variants"] = bn.run_vector_variants()
         build_s["vector_variants (build + run)"] = time.time() - t0
+        if args.hnsw_rows > 0:
+            t0 = time.time()
+            out["vector"]["hnsw"] = bn.run_hnsw()
+            build_s["hnsw leg (collection + graph + runs + oracle)"] = time.time() - t0
     bn.close()
 
     sharded = world > 1 and args.dist_mode == "shards"
@@ -817,7 +914,7 @@ def main():
         kw["queries_with_hits"] = r.get("nonempty")
         if "host_qps" in r:
             kw["value_with_host_delivery"] = r["host_qps"]       # PCIe-inclusive (80 MB of hits per 10 000-query batch into pageable host memory)
-        find_rx, score_rx = r"kw_search_kernel<3, 512, true, true>", r"kw_score_kernel"
+        find_rx, score_rx = r"kw_find2_kernel<3>|kw_search_kernel<3, 512, true, true>", r"kw_score_kernel"
         traffic = pmc_traffic([find_rx, score_rx], ["pmc_kw_fetch.txt", "pmc_kw_s5_fetch.txt"])
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "kw_search_kernel<3,512,find> + kw_score_kernel<512> (the two halves of the intersect+score+select step, "
@@ -887,7 +984,7 @@ def main():
             v["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                              "traffic": traffic, "kernel": "vec_scan_kernel<2,true> (+ sample pass and selects inside the timed events)",
                              "kernel_ms": r["kern_ms"], "flops_per_launch": r["flops"]}
-        for key in ("parity", "parity_fp32_scan", "batch_sweep", "concurrency", "variants", "shard_parity"):
+        for key in ("parity", "parity_fp32_scan", "batch_sweep", "concurrency", "variants", "hnsw", "shard_parity"):
             if key in r:
                 v[key] = r[key]
         if "cpu" in r:
@@ -926,7 +1023,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32/i64" if head == "keyword" else "f32",
             "data": "synthetic", "config": hd["config"], "p50_ms_per_batch": hd["p50_ms_per_batch"]}
     for k in ("queries_with_hits", "value_with_host_delivery", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "replicas", "concurrency",
-              "uncached", "fused_hits_per_batch"):
+              "uncached", "fused_hits_per_batch", "parity_fp32_scan", "batch_sweep", "variants", "hnsw"):
         if k in hd:
             line[k] = hd[k]
     if dist_info:

@@ -186,8 +186,19 @@ struct hnsw_graph_t {
     }
 
     // searchBaseLayerST<has_deletions, ...>(ep, q, ef, isIdAllowed): allow == nullptr = every row allowed
-    heap_t searchBaseLayerST(tableint ep_id, const float* q, size_t ef, const uint8_t* allow, bool has_deletions, uint64_t* n_dist = nullptr) const {
-        std::vector<uint8_t> visited(size(), 0);
+    // (tags: hnswlib's pooled VisitedList — one 16-bit tag per row and an epoch instead of a fresh zeroed array per query; optional)
+    struct visited_tags_t { std::vector<uint16_t> tag; uint16_t epoch = 0; };
+    heap_t searchBaseLayerST(tableint ep_id, const float* q, size_t ef, const uint8_t* allow, bool has_deletions, uint64_t* n_dist = nullptr,
+                             visited_tags_t* tags = nullptr) const {
+        std::vector<uint8_t> visited_own;
+        if (!tags) visited_own.assign(size(), 0);
+        else {
+            if (tags->tag.size() != size()) { tags->tag.assign(size(), 0); tags->epoch = 0; }
+            if (++tags->epoch == 0) { std::fill(tags->tag.begin(), tags->tag.end(), 0); tags->epoch = 1; }
+        }
+        struct visited_view { uint8_t* own; uint16_t* tag; uint16_t epoch;
+                              bool test_and_set(tableint i) { if (own) { bool v = own[i]; own[i] = 1; return v; } bool v = tag[i] == epoch; tag[i] = epoch; return v; } };
+        visited_view visited{tags ? nullptr : visited_own.data(), tags ? tags->tag.data() : nullptr, tags ? tags->epoch : (uint16_t)0};
         heap_t top_candidates, candidate_set;
         float lowerBound;
         auto ok = [&](tableint i) { return (!has_deletions || !deleted[i]) && (!allow || allow[i]); };
@@ -200,7 +211,7 @@ struct hnsw_graph_t {
             lowerBound = std::numeric_limits<float>::max();
             candidate_set.emplace(-lowerBound, ep_id);
         }
-        visited[ep_id] = 1;
+        visited.test_and_set(ep_id);
         while (!candidate_set.empty()) {
             dist_id_t cur = candidate_set.top();
             if ((-cur.first) > lowerBound && (top_candidates.size() == ef || (!allow && !has_deletions))) break;
@@ -208,8 +219,7 @@ struct hnsw_graph_t {
             const std::vector<tableint>& nb = link0[cur.second];
             for (size_t j = 0; j < nb.size(); j++) {
                 tableint c = nb[j];
-                if (visited[c]) continue;
-                visited[c] = 1;
+                if (visited.test_and_set(c)) continue;
                 float d = dist(q, vec(c));
                 if (n_dist) (*n_dist)++;
                 if (top_candidates.size() < ef || lowerBound > d) {
@@ -224,7 +234,8 @@ struct hnsw_graph_t {
     }
 
     // searchKnnCloserFirst(q, k, ef, filter) of the Typesense fork: ef = max(ef, k) candidates at layer 0, closest first
-    std::vector<std::pair<float, uint64_t>> searchKnnCloserFirst(const float* q, size_t k, size_t ef, const uint8_t* allow, uint64_t* n_dist = nullptr) const {
+    std::vector<std::pair<float, uint64_t>> searchKnnCloserFirst(const float* q, size_t k, size_t ef, const uint8_t* allow, uint64_t* n_dist = nullptr,
+                                                                 visited_tags_t* tags = nullptr, int has_deletions_known = -1) const {
         std::vector<std::pair<float, uint64_t>> result;
         if (size() == 0) return result;
         tableint currObj = enterpoint;
@@ -241,9 +252,9 @@ struct hnsw_graph_t {
                 }
             }
         }
-        bool has_deletions = false;
-        for (uint8_t dlt : deleted) if (dlt) { has_deletions = true; break; }
-        heap_t top = searchBaseLayerST(currObj, q, std::max(ef, k), allow, has_deletions, n_dist);
+        bool has_deletions = has_deletions_known > 0;
+        if (has_deletions_known < 0) for (uint8_t dlt : deleted) if (dlt) { has_deletions = true; break; }
+        heap_t top = searchBaseLayerST(currObj, q, std::max(ef, k), allow, has_deletions, n_dist, tags);
         while (top.size() > k) top.pop();
         result.resize(top.size());
         size_t sz = top.size();

@@ -208,6 +208,68 @@ uint64_t orc_hnsw_export(void* h, int32_t* info, uint32_t* levels, uint32_t* lin
     if (upper_ptr) upper_ptr[n] = n_upper;
     return n_upper;
 }
+// The inverse of orc_hnsw_export: adopt a graph given in the flat mirror form over the rows already added with orc_vec_add (row i =
+// internal id i). Used by the bench / tests to run the oracle's traversal on graphs that were not built by orc_hnsw_build.
+int32_t orc_hnsw_import(void* h, uint32_t M, int32_t maxlevel, uint32_t enterpoint, const uint32_t* link0, const uint64_t* upper_ptr, const uint32_t* upper_links) {
+    Index* idx = (Index*)h;
+    auto& slot = hnsw_of()[h];
+    delete slot;
+    slot = new hnsw_graph_t;
+    hnsw_graph_t* g = slot;
+    g->init(idx->num_dim, M, 200, 100, hnsw_dist);
+    const size_t n = idx->vec_labels.size(), S0 = 1 + 2 * (size_t)M, SU = 1 + (size_t)M;
+    g->data = idx->vec_store;
+    g->labels.assign(idx->vec_labels.begin(), idx->vec_labels.end());
+    g->deleted.assign(n, 0);
+    g->levels.assign(n, 0);
+    g->link0.resize(n);
+    g->linkU.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t* l0 = link0 + i * S0;
+        if (l0[0] > 2 * M) return -1;
+        g->link0[i].assign(l0 + 1, l0 + 1 + l0[0]);
+        const uint64_t nl = upper_ptr[i + 1] - upper_ptr[i];
+        g->levels[i] = (int)nl;
+        g->linkU[i].resize(nl);
+        for (uint64_t l = 0; l < nl; l++) {
+            const uint32_t* lu = upper_links + (upper_ptr[i] + l) * SU;
+            if (lu[0] > M) return -1;
+            g->linkU[i][l].assign(lu + 1, lu + 1 + lu[0]);
+        }
+    }
+    g->maxlevel = maxlevel;
+    g->enterpoint = enterpoint;
+    return 0;
+}
+// searchKnnCloserFirst for a batch of queries on `threads` host threads (pooled visited tags per thread, like hnswlib's
+// VisitedListPool): the CPU baseline of the HNSW bench leg. dist_out / label_out: [n_q][k]; n_out: [n_q]
+void orc_hnsw_search_batch(void* h, const float* Q, uint32_t n_q, uint32_t k, uint32_t ef, int32_t functor_present, uint32_t threads,
+                           float* dist_out, uint64_t* label_out, uint32_t* n_out) {
+    Index* idx = (Index*)h;
+    hnsw_graph_t* g = hnsw_of()[h];
+    std::vector<uint8_t> allow;
+    if (functor_present) allow.assign(g->size(), 1);
+    int has_del = 0;
+    for (uint8_t d : g->deleted) if (d) { has_del = 1; break; }
+    std::atomic<uint32_t> next{0};
+    auto work = [&]() {
+        hnsw_graph_t::visited_tags_t tags;
+        std::vector<float> qv(idx->num_dim), nrm(idx->num_dim);
+        for (;;) {
+            const uint32_t i = next.fetch_add(1);
+            if (i >= n_q) break;
+            qv.assign(Q + (size_t)i * idx->num_dim, Q + (size_t)(i + 1) * idx->num_dim);
+            if (idx->distance_type == cosine) { Index::normalize_vector(qv, nrm); qv.swap(nrm); }
+            auto res = g->searchKnnCloserFirst(qv.data(), k, ef, allow.empty() ? nullptr : allow.data(), nullptr, &tags, has_del);
+            n_out[i] = (uint32_t)res.size();
+            for (size_t j = 0; j < res.size(); j++) { dist_out[(size_t)i * k + j] = res[j].first; label_out[(size_t)i * k + j] = res[j].second; }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < std::max<uint32_t>(threads, 1); t++) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+}
 // searchKnnCloserFirst(q, k, ef, filter): allow_ids = sorted label whitelist (VectorFilterFunctor) or NULL
 uint32_t orc_hnsw_search(void* h, const float* q, uint32_t k, uint32_t ef, int32_t functor_present, const uint32_t* allow_ids, uint32_t n_allow,
                          float* dist_out, uint64_t* label_out, uint64_t* n_dist) {

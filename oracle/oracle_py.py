@@ -82,6 +82,10 @@ def lib():
         L.orc_hnsw_mark_deleted.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_hnsw_export.restype = C.c_uint64
         L.orc_hnsw_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_hnsw_import.restype = C.c_int32
+        L.orc_hnsw_import.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_hnsw_search_batch.restype = None
+        L.orc_hnsw_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_hnsw_search.restype = C.c_uint32
         L.orc_hnsw_search.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_search_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -328,6 +332,24 @@ class OracleIndex:
         self.L.orc_hnsw_export(self.h, _ptr(info), _ptr(levels), _ptr(link0), _ptr(upper_ptr), _ptr(upper))
         return dict(n=n, maxlevel=int(info[1]), enterpoint=int(info[2]), M=M, levels=levels, link0=link0, upper_ptr=upper_ptr,
                     upper_links=upper[:n_upper])
+
+    def hnsw_import(self, graph):
+        """adopt a graph in the flat mirror form (hnsw_export's keys) over the rows added with vec_add (row i = internal id i)"""
+        l0 = np.ascontiguousarray(graph["link0"], dtype=np.uint32)
+        up = np.ascontiguousarray(graph["upper_ptr"], dtype=np.uint64)
+        ul = np.ascontiguousarray(graph["upper_links"], dtype=np.uint32)
+        if ul.size == 0:
+            ul = np.zeros((1, 1 + int(graph["M"])), np.uint32)
+        rc = self.L.orc_hnsw_import(self.h, int(graph["M"]), int(graph["maxlevel"]), int(graph["enterpoint"]), _ptr(l0), _ptr(up), _ptr(ul))
+        assert rc == 0, "orc_hnsw_import: malformed graph"
+
+    def hnsw_search_batch(self, Q, k, ef, threads=1, functor_present=True):
+        """searchKnnCloserFirst for every row of Q on `threads` host threads -> (dist[n, k], labels[n, k], counts[n])"""
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        n = Q.shape[0]
+        dist = np.zeros((n, k), np.float32); lab = np.zeros((n, k), np.uint64); cnt = np.zeros(n, np.uint32)
+        self.L.orc_hnsw_search_batch(self.h, _ptr(Q), n, k, ef, int(functor_present), int(threads), _ptr(dist), _ptr(lab), _ptr(cnt))
+        return dist, lab, cnt
 
     def hnsw_search(self, qvec, k, ef, allow_ids=None, functor_present=True):
         qv = np.ascontiguousarray(qvec, dtype=np.float32)

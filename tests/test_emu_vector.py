@@ -388,3 +388,45 @@ def test_edge_cases_empty_tiny_and_fully_deleted_indexes():
     dist, lab, cnt = g.vec_knn_batch(2, np.array([[5.0]], np.float32), 2)
     assert cnt[0] == 2 and list(lab[0]) == [1, 2] and np.allclose(dist[0], [0.0, 2.0], atol=1e-6)
     g.close()
+
+
+def test_hnsw_on_a_knn_heuristic_graph_matches_the_oracle_traversal_of_the_same_graph():
+    """the bench's HNSW leg: a graph derived from exact k-NN lists + the neighbour-selection heuristic (typesense_amd/hnsw_synth.py,
+    tooling) is loaded into the library AND adopted by the oracle (hnsw_import); both traversals must agree bit for bit (batch API on
+    several host threads = the CPU baseline's code path), lists respect the 2M / M caps, and recall vs the exact scan is sane"""
+    import torch
+    from typesense_amd import hnsw_synth
+    n, dim, M = 2000, 32, 8
+    rng = np.random.default_rng(77)
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.vec_create(1, dim, B.METRIC_IP)
+    g.vec_upsert(1, np.arange(n, dtype=np.uint64), X)
+    orc = O.OracleIndex(1, 1)
+    orc.vec_init(dim, O.METRIC_IP)
+    orc.vec_add(np.arange(n, dtype=np.uint32), X)
+    Xt = torch.from_numpy(X)
+
+    def knn(a, b, k):                                   # (the library's exact k-NN has its own tests; a scan is slow on the emulator)
+        dv, iv = torch.topk(1.0 - Xt[a:b] @ Xt.T, k, dim=1, largest=False, sorted=True)
+        return iv, dv
+    graph = hnsw_synth.build_graph(torch, g, 1, Xt, M=M, K0=24, seed=5, batch=500, knn=knn)
+    assert graph["link0"].shape == (n, 1 + 2 * M) and graph["link0"][:, 0].max() <= 2 * M and graph["link0"][:, 0].min() >= 1
+    assert graph["maxlevel"] >= 1 and graph["upper_links"][:, 0].max() <= M
+    g.vec_hnsw_load(1, graph)
+    orc.hnsw_import(graph)
+    Q = rng.standard_normal((24, dim)).astype(np.float32)
+    hit = tot = 0
+    for k, ef in ((10, 10), (10, 64), (30, 100)):
+        dist, lab, cnt = g.vec_hnsw_search_batch(1, Q, k, ef)
+        d2, l2, c2 = orc.hnsw_search_batch(Q, k, ef, threads=3)
+        assert np.array_equal(cnt, c2) and np.array_equal(lab, l2) and np.array_equal(dist.view(np.uint32), d2.view(np.uint32)), (k, ef)
+        d1, l1, _ = orc.hnsw_search(Q[0], k, ef)
+        assert np.array_equal(l1, l2[0, :c2[0]])                          # batch API == single-query API of the oracle
+        if ef >= 64:
+            for i in range(Q.shape[0]):
+                de, le = orc.flat_knn(Q[i], k)
+                hit += len(set(lab[i, :cnt[i]].tolist()) & set(le.tolist())); tot += k
+    assert hit / tot > 0.85, hit / tot
+    g.close()

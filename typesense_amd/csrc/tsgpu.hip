@@ -286,6 +286,8 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!strcmp(name, "vec_prefilter_fallbacks")) { *out = ctx->vec_prefilter_fallbacks; return ok(); }
     if (!strcmp(name, "vec_prefilter_groups")) { *out = ctx->vec_prefilter_groups; return ok(); }
     if (!strcmp(name, "vec_rescored_rows")) { *out = ctx->vec_rescored_rows; return ok(); }
+    if (!strcmp(name, "hnsw_last_expansions")) { *out = ctx->hnsw_last_expansions; return ok(); }
+    if (!strcmp(name, "hnsw_last_distances")) { *out = ctx->hnsw_last_distances; return ok(); }
     if (!strcmp(name, "commit_last_us")) { *out = ctx->commit_last_us; return ok(); }                        // the last tsgpu_commit: wall time, bytes uploaded
     if (!strcmp(name, "commit_last_uploaded_bytes")) { *out = ctx->commit_last_uploaded_bytes; return ok(); }
     if (!strcmp(name, "commit_full_count")) { *out = ctx->commit_full_count; return ok(); }                  // commits that re-packed everything / appended at the tails

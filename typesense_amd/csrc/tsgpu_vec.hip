@@ -730,11 +730,12 @@ int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32
     TSGPU_HIP_TRY(hipMemcpyAsync(f->g_link0.p, link0, (size_t)n * (1 + 2 * M) * 4, hipMemcpyHostToDevice, s));
     TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_ptr.p, upper_ptr, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
     if (n_upper) TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_links.p, upper_links, (size_t)n_upper * (1 + M) * 4, hipMemcpyHostToDevice, s));
-    // visited tags: one uint32 per row and concurrent query slot (hnswlib's VisitedListPool), bounded to ~4 GiB
-    uint32_t slots = 1024;
-    while (slots > 32 && (uint64_t)slots * std::max<uint32_t>(n, 1) * 4 > (4ull << 30)) slots >>= 1;
-    if ((rc = f->g_visited.reserve((size_t)slots * std::max<uint32_t>(n, 1) * 4))) return rc;
-    TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, (size_t)slots * std::max<uint32_t>(n, 1) * 4, s));
+    // visited tags: one uint16 per row and concurrent query slot (hnswlib's VisitedListPool); the overflow counter sits behind them
+    // (16-bit tags, 16 GiB at most: 4096 concurrent queries up to 2M rows, 512 at 10M)
+    uint32_t slots = 4096;
+    while (slots > 32 && (uint64_t)slots * std::max<uint32_t>(n, 1) * 2 > (16ull << 30)) slots >>= 1;
+    if ((rc = f->g_visited.reserve((size_t)slots * std::max<uint32_t>(n, 1) * 2 + 64))) return rc;
+    TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, (size_t)slots * std::max<uint32_t>(n, 1) * 2 + 64, s));
     TSGPU_HIP_TRY(hipStreamSynchronize(s));
     f->g_M = M; f->g_n = n; f->g_slots = slots; f->g_epoch = 1; f->g_maxlevel = maxlevel; f->g_enterpoint = enterpoint; f->g_loaded = true;
     return ok();
@@ -771,10 +772,7 @@ int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const flo
         } else {
             const uint32_t grid = std::min<uint32_t>(n_q, f->g_slots);
             const uint32_t iters = (n_q + grid - 1) / grid;
-            if ((uint64_t)f->g_epoch + iters >= 0xFFFFFFF0ull) {      // tag space exhausted: clear the tags
-                TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, (size_t)f->g_slots * f->g_n * 4, s));
-                f->g_epoch = 1;
-            }
+            const size_t tag_bytes = ((size_t)f->g_slots * f->g_n * 2 + 7) & ~(size_t)7;
             VecHnswArgs a;
             memset(&a, 0, sizeof a);
             a.X = f->X.as<float>(); a.Q = Q_dev; a.dim = f->dim; a.n_rows = (uint32_t)f->n_rows; a.n_q = n_q;
@@ -782,11 +780,36 @@ int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const flo
             a.upper_ptr = f->g_upper_ptr.as<uint64_t>(); a.upper_links = f->g_upper_links.as<uint32_t>(); a.su = 1 + f->g_M;
             a.maxlevel = f->g_maxlevel; a.enterpoint = f->g_enterpoint;
             a.row_ok = mask; a.strict = (functor_present || f->any_deleted) ? 1u : 0u;
-            a.k = k; a.ef = ef; a.visited = f->g_visited.as<uint32_t>(); a.epoch_base = f->g_epoch;
+            a.k = k; a.ef = ef; a.visited = f->g_visited.as<uint16_t>();
+            a.overflow_cnt = (uint32_t*)((char*)f->g_visited.p + tag_bytes);
             a.labels = f->labels.as<uint64_t>(); a.dist_out = d_dist; a.label_out = d_lab; a.n_out = d_cnt;
-            f->g_epoch += iters;
+            // LDS tier by max(ef, k); a query whose candidate heap outgrows a small tier makes the batch run again on the largest
+            const uint32_t need = std::max(k, ef);
+            int tier = need <= 128 ? 0 : (need <= 512 ? 1 : 2);
             TSGPU_HIP_TRY(hipEventRecord(ctx->ev[3], s));
-            hipLaunchKernelGGL(vec_hnsw_search_kernel, dim3(grid), dim3(64), 0, s, a);
+            for (;;) {
+                if ((uint64_t)f->g_epoch + iters >= 0xFFF0ull) {      // tag space exhausted: clear the tags
+                    TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, tag_bytes, s));
+                    f->g_epoch = 1;
+                }
+                a.epoch_base = f->g_epoch;
+                f->g_epoch += iters;
+                TSGPU_HIP_TRY(hipMemsetAsync(a.overflow_cnt, 0, 56, s));
+                if (tier == 0) hipLaunchKernelGGL((vec_hnsw_search_kernel<129, 1024>), dim3(grid), dim3(64), 0, s, a);
+                else if (tier == 1) hipLaunchKernelGGL((vec_hnsw_search_kernel<513, 2048>), dim3(grid), dim3(64), 0, s, a);
+                else hipLaunchKernelGGL((vec_hnsw_search_kernel<VEC_HNSW_MAX_EF + 1, VEC_HNSW_CAND_CAP>), dim3(grid), dim3(64), 0, s, a);
+                uint32_t h_stat[14] = {0};
+                TSGPU_HIP_TRY(hipMemcpyAsync(h_stat, a.overflow_cnt, 56, hipMemcpyDeviceToHost, s));
+                TSGPU_HIP_TRY(hipStreamSynchronize(s));
+#ifdef TSGPU_HNSW_PROF
+                fprintf(stderr, "HNSW_PROF ticks(100MHz)/query: pop+barrier %.0f  links+tags %.0f  distances %.0f  heaps %.0f\n", (double)(h_stat[6] | ((uint64_t)h_stat[7] << 32)) / n_q,
+                        (double)(h_stat[8] | ((uint64_t)h_stat[9] << 32)) / n_q, (double)(h_stat[10] | ((uint64_t)h_stat[11] << 32)) / n_q, (double)(h_stat[12] | ((uint64_t)h_stat[13] << 32)) / n_q);
+#endif
+                ctx->hnsw_last_expansions = (uint64_t)h_stat[2] | ((uint64_t)h_stat[3] << 32);
+                ctx->hnsw_last_distances = (uint64_t)h_stat[4] | ((uint64_t)h_stat[5] << 32);
+                if (tier == 2 || !h_stat[0]) break;
+                tier = 2;
+            }
             TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s));
             TSGPU_HIP_TRY(hipEventRecord(ctx->ev[5], s));
             TSGPU_HIP_TRY(hipGetLastError());

@@ -969,6 +969,70 @@ __device__ inline float ip_part16(const float* qs, const float* __restrict__ x, 
     for (int l = 0; l < 16; l++) sum = ip_add(sum, __shfl(accl, b0 + l));
     return sum;
 }
+// R rows at once for one 16-lane group, same arithmetic and order as ip_part16 per row (lane `sub` accumulates elements sub, sub + 16, ..
+// in ascending order; the 16 partial sums are added lane 0 first). The point is memory-level parallelism: a lane's U x R row elements of
+// a chunk are requested back to back BEFORE the first multiply-add consumes one, so a 768-dimension row costs two memory round trips
+// instead of one per few elements (the graph traversal is a chain of such round trips: 107 expansions x ~20 neighbours per query).
+template <int R, int U>
+__device__ inline void ip_part16_rows(const float* qs, const float* (&x)[R], uint32_t n16, uint32_t sub, float (&out)[R]) {
+    float accl[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) accl[r] = 0.0f;
+    for (uint32_t i = 0; i < n16; i += 16 * U) {
+        float xv[R][U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t idx = i + 16 * u + sub;
+            const uint32_t idc = i + 16 * u < n16 ? idx : sub;            // (uniform guard per 16-element stripe; clamped load, unused)
+#pragma unroll
+            for (int r = 0; r < R; r++) xv[r][u] = x[r][idc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (i + 16 * u < n16) {
+                const float qv = qs[i + 16 * u + sub];
+#pragma unroll
+                for (int r = 0; r < R; r++) accl[r] = ip_mul_add(accl[r], qv, xv[r][u]);
+            }
+        }
+    }
+    const int b0 = (int)(threadIdx.x & 48u);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int l = 0; l < 16; l++) sum = ip_add(sum, __shfl(accl[r], b0 + l));
+        out[r] = sum;
+    }
+}
+// The same sums with 16-byte loads: FOUR lanes per row, lane v of the quad owns the virtual lanes 4v .. 4v+3 of hnswlib's 16-lane
+// accumulator (element 16 j + 4 v + c goes to virtual lane 4 v + c: four independent ascending chains per lane), a wavefront covers
+// 16 rows per round. Same products, same order inside every virtual lane, same lane-0-first final sum — a quarter of the load
+// instructions of the one-element-per-lane form (the traversal's distance phase was bound by their issue rate, not by bytes).
+template <int U>
+__device__ inline float ip_part16_quad(const float* qs, const float* __restrict__ x, uint32_t n16, uint32_t v) {
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (uint32_t i = 0; i < n16; i += 16 * U) {
+        float4 xv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) xv[u] = *(const float4*)(x + (i + 16 * u < n16 ? i + 16 * u : 0) + 4 * v);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (i + 16 * u < n16) {
+                const float4 qv = *(const float4*)(qs + i + 16 * u + 4 * v);
+                acc[0] = ip_mul_add(acc[0], qv.x, xv[u].x); acc[1] = ip_mul_add(acc[1], qv.y, xv[u].y);
+                acc[2] = ip_mul_add(acc[2], qv.z, xv[u].z); acc[3] = ip_mul_add(acc[3], qv.w, xv[u].w);
+            }
+        }
+    }
+    const int q0 = (int)(threadIdx.x & 60u);
+    float sum = 0.0f;
+#pragma unroll
+    for (int vv = 0; vv < 4; vv++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) sum = ip_add(sum, __shfl(acc[c], q0 + vv));
+    return sum;
+}
 __device__ inline float ip_part4(const float* qs, const float* __restrict__ x, uint32_t off, uint32_t n4, uint32_t sub) {
     float accl = 0.0f;
     if (sub < 4) for (uint32_t i = 0; i < n4; i += 4) accl = ip_mul_add(accl, qs[off + i + sub], x[off + i + sub]);
@@ -1037,67 +1101,84 @@ struct VecHnswArgs {
     const uint8_t* row_ok;     // nullable: 0 = deleted or filtered out (isMarkedDeleted / !isIdAllowed)
     uint32_t strict;           // a filter functor is present or the index has deletions (hnswalg.h searchBaseLayerST break rule)
     uint32_t k, ef;
-    uint32_t* visited; uint32_t epoch_base;             // [slots][n_rows] tags; slot = blockIdx.x
+    uint16_t* visited; uint32_t epoch_base;             // [slots][n_rows] 16-bit tags (hnswlib's VisitedList is 16-bit, too); slot = blockIdx.x
+    uint32_t* overflow_cnt;                             // [0] queries whose candidate heap outgrew CANDCAP; [1..2] u64 expansions, [3..4] u64 distances (batch totals)
     const uint64_t* labels;
     float* dist_out; uint64_t* label_out; uint32_t* n_out;   // [n_q][k]; n_out = 0xFFFFFFFF: candidate heap overflow (caller re-runs exactly)
 };
+#ifndef TSGPU_HNSW_ROWS
+#define TSGPU_HNSW_ROWS 4
+#endif
+#ifndef TSGPU_HNSW_CHUNK
+#define TSGPU_HNSW_CHUNK 24
+#endif
+static const int VEC_HNSW_CHUNK = TSGPU_HNSW_CHUNK;   // distance phase: 16-byte row pieces per lane requested before the first is consumed
 static const uint32_t VEC_HNSW_MAX_EF = 1024;
 static const uint32_t VEC_HNSW_CAND_CAP = 4096;
 static const uint32_t VEC_HNSW_QDIM = 1024;             // queries up to this dim are staged in LDS
 
+struct HnswEntry { float d; uint32_t id; };                      // one 8-byte LDS word per heap entry: a sift step reads both children with one ds_read2_b64
 struct HnswHeap {          // max-heap on .d (CompareByFirst: a.first < b.first), libstdc++ algorithms
-    float* d; uint32_t* id; uint32_t n;
+    HnswEntry* e; uint32_t n;
+    __device__ inline float top_d() const { return e[0].d; }
+    __device__ inline uint32_t top_id() const { return e[0].id; }
     __device__ inline void push(float vd, uint32_t vid) {       // std::push_heap after push_back
         uint32_t hole = n++;
         while (hole > 0) {
             const uint32_t parent = (hole - 1) / 2;
-            if (!(d[parent] < vd)) break;
-            d[hole] = d[parent]; id[hole] = id[parent];
+            const HnswEntry p = e[parent];
+            if (!(p.d < vd)) break;
+            e[hole] = p;
             hole = parent;
         }
-        d[hole] = vd; id[hole] = vid;
+        e[hole] = HnswEntry{vd, vid};
     }
     __device__ inline void pop() {                               // std::pop_heap + pop_back
         const uint32_t len = --n;                                // heap of len elements after removing the last
         if (len == 0) return;
-        const float vd = d[len]; const uint32_t vid = id[len];   // value = *(last - 1); its slot receives the old top (dropped)
+        const HnswEntry v = e[len];                              // value = *(last - 1); its slot receives the old top (dropped)
         uint32_t hole = 0, second = 0;
         while (second < (len - 1) / 2) {
             second = 2 * (second + 1);
-            if (d[second] < d[second - 1]) second--;
-            d[hole] = d[second]; id[hole] = id[second];
+            const HnswEntry r = e[second], l = e[second - 1];    // adjacent: one LDS round trip per level
+            HnswEntry c = r;
+            if (r.d < l.d) { second--; c = l; }
+            e[hole] = c;
             hole = second;
         }
         if ((len & 1) == 0 && second == (len - 2) / 2) {
             second = 2 * (second + 1);
-            d[hole] = d[second - 1]; id[hole] = id[second - 1];
+            e[hole] = e[second - 1];
             hole = second - 1;
         }
         while (hole > 0) {                                       // __push_heap(first, hole, 0, value)
             const uint32_t parent = (hole - 1) / 2;
-            if (!(d[parent] < vd)) break;
-            d[hole] = d[parent]; id[hole] = id[parent];
+            const HnswEntry p = e[parent];
+            if (!(p.d < v.d)) break;
+            e[hole] = p;
             hole = parent;
         }
-        d[hole] = vd; id[hole] = vid;
+        e[hole] = v;
     }
 };
 
+// TOPCAP >= max(ef, k) + 1, CANDCAP = candidate heap capacity: LDS tiers chosen by the host from ef, so that a CU holds as many
+// concurrent queries as its wave slots allow at the usual ef (13 KB per query at ef <= 128 instead of 45 KB).
+template <uint32_t TOPCAP, uint32_t CANDCAP>
 __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
-    __shared__ float top_d[VEC_HNSW_MAX_EF + 1];
-    __shared__ uint32_t top_i[VEC_HNSW_MAX_EF + 1];
-    __shared__ float cand_d[VEC_HNSW_CAND_CAP];
-    __shared__ uint32_t cand_i[VEC_HNSW_CAND_CAP];
-    __shared__ float qs_lds[VEC_HNSW_QDIM];
+    __shared__ HnswEntry top_e[TOPCAP];
+    __shared__ HnswEntry cand_e[CANDCAP];
+    __shared__ __attribute__((aligned(16))) float qs_lds[VEC_HNSW_QDIM];
     __shared__ uint32_t nb_id[64];
     __shared__ float nb_d[64];
+    __shared__ uint8_t nb_ok[64];
     __shared__ uint32_t s_cur, s_state, s_top_n;
-    __shared__ float s_curdist;
+    __shared__ float s_lb;
     const uint32_t lane = threadIdx.x, sub = lane & 15, grp = lane >> 4;
-    volatile uint32_t* vis = a.visited + (size_t)blockIdx.x * a.n_rows;      // volatile: tags written by this wave are re-read later (no stale L1 lines)
+    volatile uint16_t* vis = a.visited + (size_t)blockIdx.x * a.n_rows;      // volatile: tags written by this wave are re-read later (no stale L1 lines)
     uint32_t iter = 0;
     for (uint32_t q = blockIdx.x; q < a.n_q; q += gridDim.x, iter++) {
-        const uint32_t epoch = a.epoch_base + iter;
+        const uint16_t epoch = (uint16_t)(a.epoch_base + iter);
         const float* qs = a.Q + (size_t)q * a.dim;
         __syncthreads();
         if (a.dim <= VEC_HNSW_QDIM) {
@@ -1105,13 +1186,22 @@ __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
             qs = qs_lds;
         }
         __syncthreads();
-        // distances of the nb_n ids staged in nb_id[] -> nb_d[], four per round
+        // distances of the nb_n ids staged in nb_id[] -> nb_d[]: sixteen per round (ip_part16_quad) when the dimension is a multiple of
+        // 16, else four (16-lane groups)
         auto distances = [&](uint32_t nb_n) {
-            for (uint32_t i0 = 0; i0 < nb_n; i0 += 4) {
-                const uint32_t i = i0 + grp;
-                const uint32_t row = nb_id[i < nb_n ? i : nb_n - 1];
-                const float d = ip_distance_group16(qs, a.X + (size_t)row * a.dim, a.dim, sub);
-                if (i < nb_n && sub == 0) nb_d[i] = d;
+            if (a.dim % 16 == 0) {
+                for (uint32_t i0 = 0; i0 < nb_n; i0 += 16) {           // 16 rows per round, four lanes each
+                    const uint32_t i = i0 + (lane >> 2);
+                    const float dot = ip_part16_quad<VEC_HNSW_CHUNK>(qs, a.X + (size_t)nb_id[i < nb_n ? i : nb_n - 1] * a.dim, a.dim, lane & 3);
+                    if (i < nb_n && (lane & 3) == 0) nb_d[i] = ip_add(1.0f, -dot);
+                }
+            } else {
+                for (uint32_t i0 = 0; i0 < nb_n; i0 += 4) {
+                    const uint32_t i = i0 + grp;
+                    const uint32_t row = nb_id[i < nb_n ? i : nb_n - 1];
+                    const float d = ip_distance_group16(qs, a.X + (size_t)row * a.dim, a.dim, sub);
+                    if (i < nb_n && sub == 0) nb_d[i] = d;
+                }
             }
             __syncthreads();
         };
@@ -1128,7 +1218,8 @@ __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
                 changed = false;
                 const uint32_t* __restrict__ lst = a.upper_links + (a.upper_ptr[cur] + (uint32_t)(level - 1)) * a.su;
                 const uint32_t cnt = lst[0];
-                if (lane < cnt) nb_id[lane] = lst[1 + lane];
+                const uint32_t cw = lst[lane < a.su - 1 ? 1 + lane : 0];
+                if (lane < cnt) nb_id[lane] = cw;
                 __syncthreads();
                 distances(cnt);
                 for (uint32_t i = 0; i < cnt; i++) {                 // in list order, like the reference's loop
@@ -1140,9 +1231,16 @@ __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
         }
         // ---- layer 0: searchBaseLayerST(cur, q, max(ef, k), filter) ----
         const uint32_t ef = a.ef > a.k ? a.ef : a.k;
-        HnswHeap top{top_d, top_i, 0}, cand{cand_d, cand_i, 0};
+        HnswHeap top{top_e, 0}, cand{cand_e, 0};
         float lowerBound;
         bool overflow = false;
+        uint32_t n_exp = 0, n_dist = 0;
+#ifdef TSGPU_HNSW_PROF          // tools/ builds: wall-clock ticks (100 MHz) per phase of the layer-0 loop, batch totals behind the statistics
+        unsigned long long pt[4] = {0, 0, 0, 0}, pl = wall_clock64();
+#define HNSW_PROF(i) { const unsigned long long _n = wall_clock64(); pt[i] += _n - pl; pl = _n; }
+#else
+#define HNSW_PROF(i)
+#endif
         if (lane == 0) {
             const bool ok = !a.row_ok || a.row_ok[cur] != 0;
             if (ok) { lowerBound = curdist; top.push(curdist, cur); cand.push(-curdist, cur); }
@@ -1154,49 +1252,74 @@ __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
                 uint32_t st = 0;                                  // 0 = expand s_cur, 1 = finished
                 if (cand.n == 0) st = 1;
                 else {
-                    const float cd = cand_d[0];
+                    const float cd = cand.top_d();
                     if ((-cd) > lowerBound && (top.n == ef || !a.strict)) st = 1;
-                    else { s_cur = cand_i[0]; cand.pop(); }
+                    else { s_cur = cand.top_id(); cand.pop(); }
                 }
-                s_state = st;
+                s_state = st; s_top_n = top.n; s_lb = lowerBound;
             }
             __syncthreads();
             if (s_state) break;
+            HNSW_PROF(0)
             const uint32_t node = s_cur;
             const uint32_t* __restrict__ lst = a.link0 + (size_t)node * a.s0;
             const uint32_t cnt = lst[0];
             uint32_t c = 0;
             bool fresh = false;
-            if (lane < cnt) { c = lst[1 + lane]; fresh = vis[c] != epoch; if (fresh) vis[c] = epoch; }
+            // (count and ids requested together: a record has 1 + 2M words whatever its count; ids past the count are ignored)
+            const uint32_t cw = lst[lane < a.s0 - 1 ? 1 + lane : 0];
+            if (lane < cnt) { c = cw; fresh = vis[c] != epoch; if (fresh) vis[c] = epoch; }
             const unsigned long long m = __ballot(fresh ? 1 : 0);
             const uint32_t nf = (uint32_t)__popcll(m);
-            if (fresh) nb_id[__popcll(m & ((1ull << lane) - 1ull))] = c;          // unvisited neighbours, list order kept
+            if (fresh) {
+                const uint32_t slot = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));      // unvisited neighbours, list order kept
+                nb_id[slot] = c;
+                nb_ok[slot] = (!a.row_ok || a.row_ok[c] != 0) ? 1 : 0;
+            }
             __syncthreads();
+            HNSW_PROF(1)
             if (nf) distances(nf);
+            HNSW_PROF(2)
+            n_exp++; n_dist += nf;
+            // Which of them can enter the heaps at all? The reference tests `top.size() < ef || lowerBound > d` one neighbour after the
+            // other; once the result heap is full its bound only falls while this list is processed, so a neighbour that fails the test
+            // against the bound as it stands NOW fails it in sequence, too: all lanes test in parallel, lane 0 replays the sequential
+            // heap logic over the few that pass (a heap that is still filling takes every neighbour: no filter then).
+            const bool full = s_top_n == ef;
+            const bool pass = lane < nf && (!full || s_lb > nb_d[lane]);
+            unsigned long long pm = __ballot(pass ? 1 : 0);
             if (lane == 0) {
-                for (uint32_t i = 0; i < nf; i++) {
+                while (pm) {
+                    const uint32_t i = (uint32_t)__builtin_ctzll(pm);
+                    pm &= pm - 1;
                     const float d = nb_d[i];
                     const uint32_t cid = nb_id[i];
                     if (top.n < ef || lowerBound > d) {
-                        if (cand.n >= VEC_HNSW_CAND_CAP) { overflow = true; break; }
+                        if (cand.n >= CANDCAP) { overflow = true; break; }
                         cand.push(-d, cid);
-                        if (!a.row_ok || a.row_ok[cid] != 0) top.push(d, cid);
+                        if (nb_ok[i]) top.push(d, cid);
                         if (top.n > ef) top.pop();
-                        if (top.n) lowerBound = top_d[0];
+                        if (top.n) lowerBound = top.top_d();
                     }
                 }
                 if (overflow) { cand.n = 0; }
             }
             __syncthreads();
+            HNSW_PROF(3)
         }
+#ifdef TSGPU_HNSW_PROF
+        if (lane == 0) for (int i = 0; i < 4; i++) atomicAdd((unsigned long long*)(a.overflow_cnt + 6 + 2 * i), pt[i]);
+#endif
         // ---- result: keep the k closest, closest first (searchKnn + searchKnnCloserFirst) ----
         if (lane == 0) {
-            if (overflow) a.n_out[q] = 0xFFFFFFFFu;
+            atomicAdd((unsigned long long*)(a.overflow_cnt + 2), (unsigned long long)n_exp);
+            atomicAdd((unsigned long long*)(a.overflow_cnt + 4), (unsigned long long)n_dist);
+            if (overflow) { a.n_out[q] = 0xFFFFFFFFu; atomicAdd(a.overflow_cnt, 1u); }
             else {
                 while (top.n > a.k) top.pop();
                 uint32_t sz = top.n;
                 a.n_out[q] = sz;
-                while (top.n) { --sz; a.dist_out[(size_t)q * a.k + sz] = top_d[0]; a.label_out[(size_t)q * a.k + sz] = a.labels[top_i[0]]; top.pop(); }
+                while (top.n) { --sz; a.dist_out[(size_t)q * a.k + sz] = top.top_d(); a.label_out[(size_t)q * a.k + sz] = a.labels[top.top_id()]; top.pop(); }
             }
         }
         __syncthreads();

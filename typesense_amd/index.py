@@ -365,6 +365,10 @@ class GpuIndex:
                                                     _vp(dist), _vp(lab), _vp(cnt), B.MEM_HOST))
         return dist, lab, cnt
 
+    def vec_hnsw_search_batch_raw(self, field_id, q_ptr, mem_q, n, k, ef, dist_ptr, lab_ptr, cnt_ptr, mem_out, functor_present=True):
+        self._ck(self.L.tsgpu_vec_hnsw_search_batch(self.h, field_id, C.c_void_p(q_ptr), mem_q, n, k, ef, int(functor_present), None, 0, None, 0,
+                                                    C.c_void_p(dist_ptr), C.c_void_p(lab_ptr), C.c_void_p(cnt_ptr), mem_out))
+
     def vec_distances(self, field_id, q, labels):
         q = np.ascontiguousarray(q, dtype=np.float32)
         labels = np.ascontiguousarray(labels, dtype=np.uint64)

@@ -129,3 +129,22 @@ def random_vectors(n, dim, seed, device=None, normalize=False):
     if normalize:
         x /= (x.norm(dim=1, keepdim=True) + 1e-30)
     return x
+
+
+def latent_vectors(n, dim, seed, latent=32, noise=0.3, device=None, seed_w=9):
+    """unit rows with neighbourhood structure: x = normalise(W z + noise * e), z ~ N(0, I_latent), W a fixed dim x latent map, e ~ N(0, I_dim).
+    (i.i.d. N(0,1) rows in 768 dimensions are all but equidistant — no graph index can have recall on them; embedding collections have a
+    low intrinsic dimension, which this imitates. Used by the HNSW bench leg.)"""
+    torch = _torch()
+    dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    gw = torch.Generator(device=dev); gw.manual_seed(seed_w)
+    W = torch.randn((latent, dim), generator=gw, device=dev, dtype=torch.float32) / (latent ** 0.5)
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    x = torch.empty((n, dim), dtype=torch.float32, device=dev)
+    slab = max(1, (1 << 27) // dim)
+    for a in range(0, n, slab):
+        b = min(n, a + slab)
+        z = torch.randn((b - a, latent), generator=g, device=dev, dtype=torch.float32)
+        x[a:b] = z @ W + noise * torch.randn((b - a, dim), generator=g, device=dev, dtype=torch.float32)
+    x /= (x.norm(dim=1, keepdim=True) + 1e-30)
+    return x
