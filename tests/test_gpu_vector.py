@@ -66,6 +66,37 @@ def test_hnsw_20k_x_96_batch_of_512_matches_the_cpu_traversal():
     g.close()
 
 
+def test_hnsw_300k_x_128_graph_built_on_the_gpu_matches_the_oracle_on_the_same_graph():
+    """the bench's HNSW leg at test size: a graph derived on the GPU from exact k-NN lists + the selection heuristic (hnsw_synth), adopted by
+    the oracle; 2 048 concurrent queries (LDS tier 0 at ef=100, tier 1 at ef=300): labels, order and distance bits of the first 96
+    equal the CPU traversal of that graph; recall vs the exact scan is reported (parity unpinned: hnswlib is absent)"""
+    import torch
+    from typesense_amd import synth, hnsw_synth
+    n, dim, k = 300_000, 128, 50
+    X = synth.latent_vectors(n, dim, seed=21, latent=16, device="cuda")
+    g = T.GpuIndex(0)
+    g.vec_create(1, dim, B.METRIC_IP, n)
+    lab = torch.arange(n, dtype=torch.int64, device="cuda")
+    g.vec_upsert_device(1, lab.data_ptr(), X.data_ptr(), n)
+    graph = hnsw_synth.build_graph(torch, g, 1, X, M=16, K0=48, seed=3, batch=1024)
+    assert graph["link0"][:, 0].max() <= 32 and graph["link0"][:, 0].min() >= 1
+    g.vec_hnsw_load(1, graph)
+    orc = O.OracleIndex(1, 1)
+    orc.vec_init(dim, O.METRIC_IP)
+    orc.vec_add(np.arange(n, dtype=np.uint32), X.cpu().numpy())
+    orc.hnsw_import(graph)
+    Q = synth.latent_vectors(2048, dim, seed=22, latent=16, device="cuda").cpu().numpy()
+    de, le, _ = g.vec_knn_batch(1, Q[:128], k)
+    for ef in (100, 300):
+        dist, labs, cnt = g.vec_hnsw_search_batch(1, Q, k, ef)
+        od, ol, oc = orc.hnsw_search_batch(Q[:96], k, ef, threads=16)
+        assert np.array_equal(cnt[:96], oc) and np.array_equal(labs[:96], ol) and np.array_equal(dist[:96].view(np.uint32), od.view(np.uint32)), ef
+        rec = np.mean([len(set(labs[i].tolist()) & set(le[i].tolist())) / k for i in range(128)])
+        print("hnsw 300Kx128 knn-heuristic graph B=2048 k=%d ef=%d: recall %.3f, expansions/query %.0f" % (k, ef, rec, g.counter("hnsw_last_expansions") / 2048))
+        assert rec > (0.5 if ef == 100 else 0.8), rec
+    g.close()
+
+
 @pytest.fixture(scope="module")
 def big():
     rng = np.random.default_rng(77)

@@ -1058,11 +1058,13 @@ static const uint32_t VEC_RESCORE_LDS_DIM = 4096;     // queries up to this dim 
 __global__ __launch_bounds__(VEC_THREADS) void vec_rescore_kernel(const float* __restrict__ X, const float* __restrict__ Q, uint32_t dim,
                                                                    const uint32_t* __restrict__ surv_base, const uint32_t* __restrict__ surv_cnt, size_t stride,
                                                                    uint64_t* __restrict__ keys_base) {
-    __shared__ float qs_lds[VEC_RESCORE_LDS_DIM];
+    __shared__ __attribute__((aligned(16))) float qs_lds[VEC_RESCORE_LDS_DIM];
     const uint32_t t = threadIdx.x, q = blockIdx.x;
     const uint32_t n = surv_cnt[q];
-    const uint32_t per = gridDim.y * 16;
-    if (blockIdx.y * 16 >= n) return;
+    const bool quad = dim % 16 == 0;                     // four lanes per row, 16-byte loads (ip_part16_quad): 64 rows per trip, else 16
+    const uint32_t rows_per_trip = quad ? VEC_THREADS / 4 : 16;
+    const uint32_t per = gridDim.y * rows_per_trip;
+    if (blockIdx.y * rows_per_trip >= n) return;
     const float* qs = Q + (size_t)q * dim;
     if (dim <= VEC_RESCORE_LDS_DIM) {
         for (uint32_t i = t; i < dim; i += VEC_THREADS) qs_lds[i] = qs[i];
@@ -1071,11 +1073,20 @@ __global__ __launch_bounds__(VEC_THREADS) void vec_rescore_kernel(const float* _
     }
     const uint32_t* __restrict__ surv = surv_base + (size_t)q * stride;
     uint64_t* __restrict__ keys = keys_base + (size_t)q * stride;
+    // every thread of the block runs the same number of trips (i0 is block-uniform); shuffles stay inside a quad / a 16-lane group
+    if (quad) {
+        for (uint32_t i0 = blockIdx.y * rows_per_trip; i0 < n; i0 += per) {
+            const uint32_t i = i0 + (t >> 2);
+            const uint32_t row = surv[i < n ? i : n - 1];   // idle quads recompute the last pair (keeps the wave's shuffles uniform)
+            const float d = ip_add(1.0f, -ip_part16_quad<24>(qs, X + (size_t)row * dim, dim, t & 3));
+            if (i < n && (t & 3) == 0) keys[i] = ((uint64_t)f32_ord(d) << 32) | row;
+        }
+        return;
+    }
     const uint32_t sub = t & 15, grp = t >> 4;
-    // every thread of the block runs the same number of trips (i0 is block-uniform); shuffles stay inside a 16-lane group
     for (uint32_t i0 = blockIdx.y * 16; i0 < n; i0 += per) {
         const uint32_t i = i0 + grp;
-        const uint32_t ic = i < n ? i : n - 1;         // idle groups recompute the last pair (keeps the wave's shuffles uniform)
+        const uint32_t ic = i < n ? i : n - 1;
         const uint32_t row = surv[ic];
         const float d = ip_distance_group16(qs, X + (size_t)row * dim, dim, sub);
         if (i < n && sub == 0) keys[i] = ((uint64_t)f32_ord(d) << 32) | row;
