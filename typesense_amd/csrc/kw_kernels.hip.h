@@ -1682,21 +1682,30 @@ __device__ inline uint32_t kw_fold_partials(TopkLds<CAP>& tk, const KwPartials& 
     constexpr int PB = CAP - KW_THREADS;                         // where the piece is parked
     const uint32_t t = threadIdx.x;
     uint32_t na = 0;
-    for (uint32_t w = first; w < first + n_lists; w++) {
-        const uint32_t nw = part.cnt[w];
+    // Two-stage software pipeline over the lists: a list's first 256 entries (all of it up to k = 256) and the count of the list after
+    // it are requested one list ahead — a fold is a chain of short LDS phases behind a global-memory round trip per list otherwise.
+    uint32_t nw = n_lists ? part.cnt[first] : 0, nw_next = n_lists > 1 ? part.cnt[first + 1] : 0;
+    int64_t c0 = 0, c1 = 0, c2 = 0, ck = -1;
+    if (t < nw) { const size_t e = (size_t)first * part.k_stride + t; c0 = part.s0[e]; c1 = part.s1[e]; c2 = part.s2[e]; ck = part.key[e]; }
+    for (uint32_t li = 0; li < n_lists; li++) {
+        const uint32_t w = first + li;
         const size_t base = (size_t)w * part.k_stride;
+        int64_t n0 = 0, n1 = 0, n2 = 0, nk = -1;
+        if (li + 1 < n_lists && t < nw_next) { const size_t e = (size_t)(w + 1) * part.k_stride + t; n0 = part.s0[e]; n1 = part.s1[e]; n2 = part.s2[e]; nk = part.key[e]; }
+        const uint32_t nw_after = li + 2 < n_lists ? part.cnt[w + 2] : 0;
         for (uint32_t p0 = 0; p0 < nw; p0 += KW_THREADS) {
-            if (na == k) {                                       // uniform: every thread reads the same entries
-                const int64_t h0 = part.s0[base + p0], h1 = part.s1[base + p0], h2 = part.s2[base + p0], hk = part.key[base + p0];
-                if (!ent_greater(h0, h1, h2, hk, tk.s0[na - 1], tk.s1[na - 1], tk.s2[na - 1], tk.key[na - 1])) break;
-            }
             const uint32_t nb = nw - p0 < (uint32_t)KW_THREADS ? nw - p0 : (uint32_t)KW_THREADS;
-            int64_t b0 = 0, b1 = 0, b2 = 0, bk = -1;
-            if (t < nb) {
-                b0 = part.s0[base + p0 + t]; b1 = part.s1[base + p0 + t]; b2 = part.s2[base + p0 + t]; bk = part.key[base + p0 + t];
-                tk.s0[PB + t] = b0; tk.s1[PB + t] = b1; tk.s2[PB + t] = b2; tk.key[PB + t] = bk;
+            int64_t b0 = c0, b1 = c1, b2 = c2, bk = ck;
+            if (p0 > 0) {                                        // (k > 256 only: later pieces of a list are fetched on demand)
+                b0 = 0; b1 = 0; b2 = 0; bk = -1;
+                if (t < nb) { b0 = part.s0[base + p0 + t]; b1 = part.s1[base + p0 + t]; b2 = part.s2[base + p0 + t]; bk = part.key[base + p0 + t]; }
             }
+            if (t < nb) { tk.s0[PB + t] = b0; tk.s1[PB + t] = b1; tk.s2[PB + t] = b2; tk.key[PB + t] = bk; }
             __syncthreads();
+            if (na == k && !ent_greater(tk.s0[PB], tk.s1[PB], tk.s2[PB], tk.key[PB], tk.s0[na - 1], tk.s1[na - 1], tk.s2[na - 1], tk.key[na - 1])) {
+                __syncthreads();                                 // (uniform) the piece's best entry cannot enter: neither can the rest of the list
+                break;
+            }
             // piece entry t: place = t + #{A entries greater than it}
             uint32_t rank_b = 0xFFFFFFFFu;
             if (t < nb) {
@@ -1732,6 +1741,8 @@ __device__ inline uint32_t kw_fold_partials(TopkLds<CAP>& tk, const KwPartials& 
             na = na + nb < k ? na + nb : k;
             __syncthreads();
         }
+        c0 = n0; c1 = n1; c2 = n2; ck = nk;
+        nw = nw_next; nw_next = nw_after;
     }
     return na;
 }
