@@ -917,7 +917,7 @@ def main():
         find_rx, score_rx = r"kw_find2_kernel<3>|kw_search_kernel<3, 512, true, true>", r"kw_score_kernel"
         traffic = pmc_traffic([find_rx, score_rx], ["pmc_kw_fetch.txt", "pmc_kw_s5_fetch.txt"])
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "kw_search_kernel<3,512,find> + kw_score_kernel<512> (the two halves of the intersect+score+select step, "
+                "kernel": "kw_find2_kernel<3> (two driver blocks per iteration) + kw_score_kernel<512> (the two halves of the intersect+score+select step, "
                           "launched back to back; kernel_ms spans both)", "kernel_ms": r["kern_ms"], "merge_kernel_ms": r["merge_ms"],
                 "algorithmic_bytes_per_launch": r["alg_bytes"],
                 "note": "SURVEY 8(d) figure: algorithmic bytes = 4*sum|L_t| + offsets + sort keys over the kernel time. The kernel SKIPS (only the shortest "

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
 
     for (uint32_t b = wi.blk_begin, it = 0; b < wi.blk_end; b += 2, it++) {
         if (P.mode == 3) break;
-        if ((it & 7) == 0 && kw_out_of_time(ix, q, wi.query)) break;
+        if ((it & 7) == 0 && kw_out_of_time(ix, q, wi.query, &sm.stop)) break;
         const bool two = b + 1 < wi.blk_end;
         const uint32_t n0 = mA.n_ids_bits & 0xFFFF, n1 = two ? (mB.n_ids_bits & 0xFFFF) : 0u;
         bool ok0 = t < n0, ok1 = t < n1;

@@ -173,19 +173,26 @@ struct KwOut {                       // final, per query, stride = k_stride (tsg
 // (include/or_iterator.h:148-153, RETURN_CIRCUIT_BREAKER). Here every work item looks at the device wall clock every 16 driver blocks
 // (wave-uniform: one s_memrealtime + a scalar load): past the query's budget it raises the query's cutoff flag and stops scanning;
 // what it found so far is scored and merged as usual, the caller gets partial hits with search_cutoff = 1.
-__device__ inline bool kw_out_of_time(const IndexView& ix, const KwQueryDev& q, uint32_t query) {
+// Workgroup-uniform: every thread of the workgroup must call it at the same point. (Each wavefront reading the clock for itself is a
+// race — one wave leaves the loop, its siblings wait for it at the next barrier; the decision is taken by thread 0 and shared.)
+__device__ inline bool kw_out_of_time(const IndexView& ix, const KwQueryDev& q, uint32_t query, uint32_t* s_flag) {
 #ifdef TSGPU_NO_DEADLINE
     return false;
 #endif
-    if (q.deadline_rem_us == 0) return false;
+    if (q.deadline_rem_us == 0) return false;                       // (uniform: the query record is shared by the workgroup)
+    __syncthreads();                                                // the previous decision has been read by everyone
+    if (threadIdx.x == 0) {
 #ifdef TSGPU_HIP_EMU
-    const long long now = hipemu_wall_clock64();
+        const long long now = hipemu_wall_clock64();
 #else
-    const long long now = wall_clock64();
+        const long long now = wall_clock64();
 #endif
-    if ((unsigned long long)(now - *ix.t0) <= (unsigned long long)q.deadline_rem_us * ix.ticks_per_us) return false;
-    if (threadIdx.x == 0) atomicOr(&ix.cutoff[query], 1u);
-    return true;
+        const bool late = (unsigned long long)(now - *ix.t0) > (unsigned long long)q.deadline_rem_us * ix.ticks_per_us;
+        if (late) atomicOr(&ix.cutoff[query], 1u);
+        *s_flag = late ? 1u : 0u;
+    }
+    __syncthreads();
+    return *s_flag != 0;
 }
 __global__ void kw_stamp_kernel(long long* t0) {
 #ifdef TSGPU_HIP_EMU
@@ -811,6 +818,7 @@ struct KwSmem {
     uint32_t bw_last[2][BW], bw_first[2][BW], bw_woff[2][BW], bw_nb[2][BW];   // the second list's BlockIds window, SoA, two versions
     uint32_t wave_cnt[KW_THREADS / 64];
     uint32_t wave_cnt2[2][KW_THREADS / 64];  // block_compact1 ping-pong
+    uint32_t stop;                           // kw_out_of_time's shared decision
     uint32_t q1_cnt, qf_cnt, tk_cnt, have_thr;
     uint32_t n_match, n_emit;
     unsigned long long off_words;
@@ -1194,7 +1202,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
 
     for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
         if (P.mode == 3) break;
-        if (((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, wi.query)) break;
+        if (((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, wi.query, &sm.stop)) break;
         // ---- stage 0: thread t = slot t of driver block b ----
         const uint32_t m_n = mA.n_ids_bits & 0xFFFF;
         bool ok = t < m_n;
@@ -1500,7 +1508,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
     uint32_t* __restrict__ hits = DEFER ? hits_all + hit_off[blockIdx.x] * (uint64_t)(NP + 1) : nullptr;
     uint32_t qfn = 0, par = 0;
     for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
-        if (((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, qi)) break;
+        if (((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, qi, &sm.stop)) break;
         const BlockIds mA = biA[b];
         const uint32_t m_n = mA.n_ids_bits & 0xFFFF;
         bool ok = t < m_n;
@@ -1597,7 +1605,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_wildcard_kernel(IndexView ix, c
                                                                   const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out) {
     __shared__ TopkLds<CAP> tk;
     __shared__ int64_t thr[4];
-    __shared__ uint32_t s_cnt, s_have, s_emit, wave_cnt[KW_THREADS / 64];
+    __shared__ uint32_t s_cnt, s_have, s_emit, s_stop, wave_cnt[KW_THREADS / 64];
     __shared__ KwQueryDev sq;
     const uint32_t t = threadIdx.x;
     const KwWorkItem wi = work[blockIdx.x];
@@ -1613,7 +1621,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_wildcard_kernel(IndexView ix, c
     const uint32_t* fl = ex + q.n_excl;
     uint32_t* my_ids_out = ids_out ? ids_out + q.ids_out_off + wi.ids_out_off : nullptr;
     for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
-        if (((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, wi.query)) break;
+        if (((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, wi.query, &s_stop)) break;
         if (s_cnt + KW_THREADS > (uint32_t)CAP) topk_compact<CAP, true>(tk, &s_cnt, q.k, thr, &s_have);
         const uint32_t idx = b * BLOCK_IDS + t;
         bool emit = idx < q.wild_n_ids;
