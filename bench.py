@@ -837,6 +837,32 @@ class Bench:
                     bad += 1
             res["parity"] = {"checked": chk, "mismatches": bad,
                              "what": "fused Topster after rank fusion: keys, all 3 score words (fused score bits), vector_distance bits vs oracle.search_hybrid at 10M docs"}
+            if self.extras:
+                # rerank_hybrid_matches (Index::compute_aux_scores): the same batch with the re-ranking pass, and its parity — the oracle also needs
+                # the rows of the keyword-only hits (their distance is computed by label)
+                def step_r():
+                    return g.hybrid_search_batch(qs, 1, Qh, k=k, fetch_size=100, alpha=0.3, k_stride=K_TOPSTER, rerank=True)
+                el_r, _, out_r = timed(step_r, 3, 1, 1)
+                need = np.unique(np.concatenate([out_r.keys[i, :int(out_r.n_hits[i])] for i in range(m)])).astype(np.int64)
+                need = need[~np.isin(need, labs.astype(np.int64))]
+                S = 1 << 20
+                for s0 in range(0, self.n_docs, S):
+                    sel = need[(need >= s0) & (need < s0 + S)]
+                    if sel.size:
+                        x = self.base_slab(s0, min(self.n_docs, s0 + S))[torch.from_numpy(sel - s0).cuda()].cpu().numpy()
+                        orc.vec_add(sel.astype(np.uint32), x)
+                bad_r = 0
+                for i in range(m):
+                    ref = orc.search_hybrid(orc.make_query(qtok[i], sort=osort, fetch_size=100, topster_size=K_TOPSTER), Qe[i], k=k, alpha=0.3, cap=1024, rerank=True)
+                    nn = int(out_r.n_hits[i])
+                    if nn != ref.keys.size or not np.array_equal(out_r.keys[i, :nn], ref.keys) or not np.array_equal(out_r.scores[i, :nn], ref.scores) \
+                            or not np.array_equal(out_r.text_match[i, :nn], ref.text_match) \
+                            or not np.array_equal(out_r.vector_distance[i, :nn].view(np.uint32), ref.vector_distance.view(np.uint32)):
+                        bad_r += 1
+                res["rerank_hybrid_matches"] = {"value": n_q * 3 / el_r, "unit": "queries/s", "ms_per_step": 1e3 * el_r / 3,
+                                                "parity": {"checked": m, "mismatches": bad_r,
+                                                           "what": "Index::compute_aux_scores (src/index.cpp:8793-8923) after the fusion: keys, re-fused score bits, the filled-in "
+                                                                   "text_match scores and vector_distance bits vs the oracle's restatement at 10M docs"}}
             orc.close()
         return res
 
@@ -1000,7 +1026,7 @@ def main():
                                    "fusion (src/index.cpp:4094-4211) on the host, results delivered to host memory" % (r["n_q"], args.k),
                        "parallelism": par + (" (fusion after the merge)" if sharded else "")}
         h["fused_hits_per_batch"] = r.get("fused_hits")
-        for key in ("parity", "shard_parity"):
+        for key in ("parity", "shard_parity", "rerank_hybrid_matches"):
             if key in r:
                 h[key] = r[key]
         if "vector" in sub and "roofline" in sub["vector"]:
@@ -1023,7 +1049,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32/i64" if head == "keyword" else "f32",
             "data": "synthetic", "config": hd["config"], "p50_ms_per_batch": hd["p50_ms_per_batch"]}
     for k in ("queries_with_hits", "value_with_host_delivery", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "replicas", "concurrency",
-              "uncached", "fused_hits_per_batch", "parity_fp32_scan", "batch_sweep", "variants", "hnsw"):
+              "uncached", "fused_hits_per_batch", "parity_fp32_scan", "batch_sweep", "variants", "hnsw", "rerank_hybrid_matches"):
         if k in hd:
             line[k] = hd[k]
     if dist_info:

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define TSGPU_ABI_VERSION 2
+#define TSGPU_ABI_VERSION 3
 
 /* limits of the accelerated path (anything beyond -> TSGPU_ERR_UNSUPPORTED for that query) */
 #define TSGPU_MAX_QUERY_TOKENS 10   /* = WINDOW_SIZE, include/match_score.h:11 */
@@ -101,6 +101,7 @@ const char* tsgpu_last_error(void);
 /* run the library's kernels on a caller-owned hipStream_t (NULL = the context's own stream) */
 int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
 /* tuning knobs (all optional): "kw_chunk_blocks" = driver posting blocks per keyword work item (default 0 = sized per batch; 1..256),
+ * "kw_pair_blocks" = 1 (default): the find kernel serves two blocks of the shortest list per iteration (kw_find2_kernel; 0 = one),
  * "kw_two_kernels" = 1 (default): single-field queries run as a find kernel + a score kernel with hit records (seq_id + one
  * posting position per token) between them, 0: one fused kernel (identical results); "kw_hit_buffer_mb" = budget of that hit
  * buffer (default 20480; 16 bytes (<= 3 tokens) or 44 bytes per driver posting of the batch are reserved; a table of work items
@@ -313,7 +314,10 @@ int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32
 /* up to k (distance, label) per query, closest first, found by greedy descent + the ef-bounded best-first search of layer 0
  * (max(ef, k) candidates). functor_present: the caller passes a filter functor (Typesense always does) — it selects hnswlib's
  * stricter stop rule; allow_ids (sorted, NULL = all) / excluded_ids / deleted labels are what the functor and isMarkedDeleted
- * reject. n_out[q] == 0xFFFFFFFF: the candidate heap outgrew its LDS budget for that query — run it with tsgpu_vec_knn_batch. */
+ * reject. One wavefront per query, up to 4 096 queries in flight (16-bit visited tags per query slot, 16 GiB at most); the heaps
+ * live in LDS sized by max(ef, k) (<= 128 / 512 / 1024; max(ef, k) > 1024 -> 501), a batch in which a candidate heap outgrows a small
+ * size runs again on the largest. n_out[q] == 0xFFFFFFFF: the candidate heap outgrew even that (4 096 entries) — run the query
+ * with tsgpu_vec_knn_batch. Counters "hnsw_last_expansions" / "hnsw_last_distances": layer-0 totals of the last batch. */
 int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, int mem_q, uint32_t n_q, uint32_t k, uint32_t ef,
                                 int functor_present, const uint32_t* allow_ids, uint32_t n_allow, const uint32_t* excluded_ids,
                                 uint32_t n_excluded, float* dist_out, uint64_t* label_out, uint32_t* n_out, int mem_out);
@@ -341,11 +345,21 @@ typedef struct tsgpu_hybrid_params {
     uint32_t fetch_size;
     float alpha;                    /* VECTOR_SEARCH_WEIGHT, default 0.3 (include/vector_query_ops.h:19) */
     float distance_threshold;
+    uint32_t rerank_hybrid_matches; /* search_params->rerank_hybrid_matches: Index::compute_aux_scores (src/index.cpp:8793-8923) after the fusion — hits
+                                     * found by one side only get the other side's score (text_match of the document for the query's tokens; exact
+                                     * distance by label), then every hit is re-ranked on both and re-fused. tsgpu_hybrid_search_batch only. */
 } tsgpu_hybrid_params;
 /* Q: [n_queries][dim] host or device; queries[i] pairs with Q[i]. Output = Topster after fusion + sort. */
 int tsgpu_hybrid_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t vec_field_id,
                               const tsgpu_hybrid_params* params, const float* Q, int mem_q,
                               uint32_t n_queries, tsgpu_hits* out);
+
+/* Index::compute_aux_scores' text half (src/index.cpp:8800-8846): the aggregated text_match score (compute_aggregated_score with
+ * total_cost 0) of GIVEN documents for a query's tokens — every token's lists are positioned on the document (skip_to), the tokens it
+ * holds are scored per field, a document holding none scores 0. Item i = (queries[item_query[i]], document item_seq_id[i]);
+ * scores_out[n_items]. Host arrays. */
+int tsgpu_keyword_aux_scores(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, const uint32_t* item_query,
+                             const uint32_t* item_seq_id, uint32_t n_items, int64_t* scores_out);
 
 /* Fusion step alone (src/index.cpp:4094-4211) on already-computed results, e.g. after a shard merge where ranks must be
  * global: kw_hits = keyword Topster content per query in sort() order, knn_* = [n_queries][knn_k] nearest neighbours

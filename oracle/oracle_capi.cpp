@@ -325,6 +325,18 @@ int32_t orc_search_vector(void* h, const float* qvec, uint32_t k, float distance
     return 0;
 }
 
+int32_t orc_search_hybrid_rerank(void* h, const orc_kw_query* q, const float* qvec, uint32_t k, float alpha,
+                                 float distance_threshold, int32_t rerank_hybrid_matches, orc_result* out) {
+    Index* idx = (Index*)h;
+    vector_query_t vq;
+    vq.values.assign(qvec, qvec + idx->num_dim);
+    vq.k = k;
+    vq.alpha = alpha;
+    vq.distance_threshold = distance_threshold;
+    vq.rerank_hybrid_matches = rerank_hybrid_matches != 0;
+    fill(idx->search_hybrid(to_query(q), vq), out);
+    return 0;
+}
 int32_t orc_search_hybrid(void* h, const orc_kw_query* q, const float* qvec, uint32_t k, float alpha,
                           float distance_threshold, orc_result* out) {
     Index* idx = (Index*)h;

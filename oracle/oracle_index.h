@@ -102,6 +102,7 @@ struct vector_query_t {
     size_t k = 0;
     float distance_threshold = FLT_MAX;
     float alpha = 0.3f;                      // include/vector_query_ops.h:19
+    bool rerank_hybrid_matches = false;      // search_params->rerank_hybrid_matches -> compute_aux_scores (index.cpp:4234-4240)
 };
 
 struct vec_hit_t { float dist; uint32_t seq_id; };
@@ -382,11 +383,8 @@ public:
         return (int64_t)agg;
     }
 
-    // search_across_fields, index.cpp:5385-5596 (topster owned by the caller, like the reference)
-    void search_across_fields(const keyword_query_t& q, Topster* topster, keyword_result_t& out, uint16_t query_index = 0) const {
-        std::vector<or_iterator_t> token_its;
-        std::vector<posting_list_t*> expanded_plists;
-        // get_field_token_its, index.cpp:5598-5660
+    // get_field_token_its, index.cpp:5598-5660
+    void get_field_token_its(const keyword_query_t& q, std::vector<or_iterator_t>& token_its, std::vector<posting_list_t*>& expanded_plists) const {
         for (size_t ti = 0; ti < q.tokens.size(); ti++) {
             std::vector<posting_list_t::iterator_t> its;
             for (size_t i = 0; i < q.fields.size(); i++) {
@@ -405,6 +403,13 @@ public:
             or_iterator_t token_fields(its);
             token_its.push_back(std::move(token_fields));
         }
+    }
+
+    // search_across_fields, index.cpp:5385-5596 (topster owned by the caller, like the reference)
+    void search_across_fields(const keyword_query_t& q, Topster* topster, keyword_result_t& out, uint16_t query_index = 0) const {
+        std::vector<or_iterator_t> token_its;
+        std::vector<posting_list_t*> expanded_plists;
+        get_field_token_its(q, token_its, expanded_plists);
 
         result_iter_state_t istate(q.excluded_ids.data(), q.excluded_ids.size(), q.filter_ids.data(), q.filter_ids.size());
         deadline_t dl;
@@ -608,9 +613,62 @@ public:
                            std::back_inserter(merged));
             out.result_ids.swap(merged);
         }
+        if (vq.rerank_hybrid_matches) compute_aux_scores(&topster, q, vq);          // index.cpp:4234-4236
         topster.sort();
         for (uint32_t i = 0; i < topster.size; i++) out.kvs.push_back(*topster.getKV(i));
         return out;
+    }
+
+    // compute_aux_scores, index.cpp:8793-8923: hits found by one side only get the other side's score, then every hit is re-ranked on
+    // both and re-fused (topster->map is an unordered_map in the reference: both sorts below are total / stable on a total order, so
+    // its iteration order does not matter)
+    void compute_aux_scores(Topster* topster, const keyword_query_t& q, const vector_query_t& vq) const {
+        std::vector<KV*> text_match_ids;
+        for (auto& kv : topster->map) {
+            if (kv.second->text_match_score == 0) {
+                text_match_ids.push_back(kv.second);                                    // only found via vector distance
+            } else if (kv.second->vector_distance == -1.0f) {                         // only found via text match
+                const float* x = vec_get((uint32_t)kv.second->key);
+                if (!x) continue;                                                       // getDataByLabel throws: likely not found
+                float dist;
+                if (distance_type == cosine) {
+                    std::vector<float> normalized_q(vq.values.size());
+                    normalize_vector(vq.values, normalized_q);
+                    dist = ip_distance(normalized_q.data(), x, num_dim);
+                } else {
+                    dist = ip_distance(vq.values.data(), x, num_dim);
+                }
+                kv.second->vector_distance = dist;
+            }
+        }
+        if (!text_match_ids.empty()) {
+            std::sort(text_match_ids.begin(), text_match_ids.end(), [](const KV* a, const KV* b) { return a->key < b->key; });
+            // compute_text_match_aux_score: one iterator per token, positioned on every id in ascending order
+            std::vector<or_iterator_t> token_its;
+            std::vector<posting_list_t*> expanded_plists;
+            get_field_token_its(q, token_its, expanded_plists);
+            keyword_query_t q0 = q;
+            q0.total_cost = 0;                                                           // compute_aggregated_score(..., total_cost = 0, syn_orig_num_tokens = -1, ...)
+            for (KV* kv : text_match_ids) {
+                const uint32_t seq_id = (uint32_t)kv->key;
+                for (size_t i = 0; i < token_its.size(); i++) token_its[i].skip_to(seq_id);
+                kv->text_match_score = compute_aggregated_score(token_its, q0, seq_id);
+            }
+            for (auto* p : expanded_plists) delete p;
+        }
+        std::vector<KV*> kvs;
+        for (const auto& kv : topster->map) kvs.push_back(kv.second);
+        std::unordered_map<uint64_t, int32_t> semantic_seq_id_ranks, keyword_seq_id_ranks;
+        std::stable_sort(kvs.begin(), kvs.end(), [](const KV* a, const KV* b) { return std::tie(a->text_match_score, a->key) > std::tie(b->text_match_score, b->key); });
+        for (size_t i = 0; i < kvs.size(); ++i) keyword_seq_id_ranks.emplace(kvs[i]->key, (int32_t)i + 1);
+        std::stable_sort(kvs.begin(), kvs.end(), [](const KV* a, const KV* b) { return a->vector_distance < b->vector_distance; });
+        for (size_t i = 0; i < kvs.size(); ++i) semantic_seq_id_ranks.emplace(kvs[i]->key, (int32_t)i + 1);
+        for (auto& kv : topster->map) {
+            const uint64_t seq_id = kv.second->key;
+            if (kv.second->match_score_index < 0 || kv.second->match_score_index > 2) continue;   // (the reference indexes scores[] unguarded)
+            kv.second->scores[kv.second->match_score_index] = float_to_int64_t((1.0 / keyword_seq_id_ranks[seq_id]) * (1.0 - vq.alpha) +
+                                                                               (1.0 / semantic_seq_id_ranks[seq_id]) * vq.alpha);
+        }
     }
 };
 

@@ -91,6 +91,7 @@ def lib():
         L.orc_search_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(Result)]
         L.orc_search_hybrid.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.POINTER(Result)]
+        L.orc_search_hybrid_rerank.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int32, C.POINTER(Result)]
         L.orc_facet_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_facet_count.restype = C.c_uint32
         L.orc_facet_count.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
@@ -293,10 +294,10 @@ class OracleIndex:
                                  _ptr(f) if f is not None else None, f.size if f is not None else 0, C.byref(r))
         return self._decode(r, b)
 
-    def search_hybrid(self, q, qvec, k=0, alpha=0.3, distance_threshold=3.4028234663852886e38, cap=1024, ids_cap=0):
+    def search_hybrid(self, q, qvec, k=0, alpha=0.3, distance_threshold=3.4028234663852886e38, cap=1024, ids_cap=0, rerank=False):
         r, b = self._alloc(cap, ids_cap)
         qv = np.ascontiguousarray(qvec, dtype=np.float32)
-        self.L.orc_search_hybrid(self.h, C.byref(q), _ptr(qv), k, alpha, distance_threshold, C.byref(r))
+        self.L.orc_search_hybrid_rerank(self.h, C.byref(q), _ptr(qv), k, alpha, distance_threshold, int(bool(rerank)), C.byref(r))
         return self._decode(r, b)
 
     # ---- facets (oracle/facet_count.h) ----

@@ -256,6 +256,46 @@ def test_hybrid_rank_fusion_matches_oracle_bit_exactly():
     g.close()
 
 
+def test_hybrid_rerank_hybrid_matches_is_compute_aux_scores_bit_exactly():
+    """rerank_hybrid_matches (Index::compute_aux_scores, src/index.cpp:8793-8923): hits only the vector search found get the text_match of
+    the document for the query's tokens (documents holding SOME of the tokens score on those), hits only the keyword search found
+    their exact distance; both rankings, the re-fused score bits and the final order equal the oracle's restatement"""
+    orc, g, rng = _text_and_vectors(H.emu_lib_path())
+    Q = rng.standard_normal((6, 24)).astype(np.float32)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    toks = [[1, 2], [3], [2, 5], [1, 2, 3], [59, 1], [7, 7]]
+    qs = [T.KwQuery(t, sort=sort, topster_size=0) for t in toks]
+    plain = g.hybrid_search_batch(qs, 1, Q, k=0, fetch_size=10, alpha=0.3, k_stride=250)
+    hits = g.hybrid_search_batch(qs, 1, Q, k=0, fetch_size=10, alpha=0.3, k_stride=250, rerank=True)
+    assert (hits.status == 0).all()
+    filled_text = filled_dist = 0
+    for i, q in enumerate(qs):
+        oq = orc.make_query(q.tokens, sort=((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1)), fetch_size=10)
+        ref = orc.search_hybrid(oq, Q[i], k=0, alpha=0.3, rerank=True)
+        n = int(hits.n_hits[i])
+        assert n == ref.keys.size == int(plain.n_hits[i])
+        assert np.array_equal(hits.keys[i, :n], ref.keys), (i, hits.keys[i, :10], ref.keys[:10])
+        assert np.array_equal(hits.scores[i, :n], ref.scores)                       # re-fused score BITS identical
+        assert np.array_equal(hits.text_match[i, :n], ref.text_match)
+        assert np.allclose(hits.vector_distance[i, :n], ref.vector_distance, rtol=RTOL, atol=RTOL)
+        assert set(hits.keys[i, :n].tolist()) == set(plain.keys[i, :n].tolist())    # the same documents, re-ranked
+        p_tm = dict(zip(plain.keys[i, :n].tolist(), plain.text_match[i, :n].tolist()))
+        p_vd = dict(zip(plain.keys[i, :n].tolist(), plain.vector_distance[i, :n].tolist()))
+        for key, tm, vd in zip(hits.keys[i, :n].tolist(), hits.text_match[i, :n].tolist(), hits.vector_distance[i, :n].tolist()):
+            filled_text += p_tm[key] == 0 and tm != 0
+            filled_dist += p_vd[key] == -1.0 and vd != -1.0
+    assert filled_text > 0 and filled_dist > 0
+    # the text half alone: the C-ABI entry point vs the oracle's scores of the same documents
+    oq = orc.make_query([1, 2, 3], sort=((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1)), fetch_size=10)
+    ref = orc.search_hybrid(oq, Q[3], k=0, alpha=0.3, rerank=True)
+    sc = g.keyword_aux_scores([T.KwQuery([1, 2, 3], sort=sort, topster_size=0)], np.zeros(ref.keys.size, np.uint32), ref.keys.astype(np.uint32))
+    full = {int(k): int(t) for k, t in zip(plain.keys[3, :int(plain.n_hits[3])], plain.text_match[3, :int(plain.n_hits[3])]) if t != 0}
+    for key, t_ref, t in zip(ref.keys.tolist(), ref.text_match.tolist(), sc.tolist()):
+        if key not in full:
+            assert t == t_ref, (key, t, t_ref)            # vector-only hits: exactly the aux score
+    g.close()
+
+
 def test_hybrid_with_filter_and_excluded_ids_matches_oracle():
     """filter_by / hidden hits in a hybrid query restrict BOTH halves: take_id() in the keyword pass and the VectorFilterFunctor of the
     k-NN (src/index.cpp:3376-3445, 4036-4221); the fused Topster must equal the oracle's bit for bit"""

@@ -25,6 +25,8 @@ test_upsert_delete_labels_filters_and_by_id_distances = E.test_upsert_delete_lab
 test_pure_vector_search_topster_order_matches_oracle = E.test_pure_vector_search_topster_order_matches_oracle
 test_hybrid_rank_fusion_matches_oracle_bit_exactly = E.test_hybrid_rank_fusion_matches_oracle_bit_exactly
 test_hybrid_with_filter_and_excluded_ids_matches_oracle = E.test_hybrid_with_filter_and_excluded_ids_matches_oracle
+test_hybrid_rerank_hybrid_matches_is_compute_aux_scores_bit_exactly = E.test_hybrid_rerank_hybrid_matches_is_compute_aux_scores_bit_exactly
+test_hnsw_on_a_knn_heuristic_graph_matches_the_oracle_traversal_of_the_same_graph = E.test_hnsw_on_a_knn_heuristic_graph_matches_the_oracle_traversal_of_the_same_graph
 test_shard_merge_equals_unsharded = E.test_shard_merge_equals_unsharded
 test_knn_two_pass_threshold_path_is_exact = E.test_knn_two_pass_threshold_path_is_exact
 test_knn_two_pass_all_equal_distances_converges = E.test_knn_two_pass_all_equal_distances_converges

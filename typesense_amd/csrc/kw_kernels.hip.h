@@ -702,11 +702,13 @@ __device__ inline ScoredHit score_hit(const IndexView& ix, const KwQueryDev& q, 
 
 // the same for several query_by fields: pos[t * KW_MAX_FIELDS + f] = position of found token t in field f's list, or KW_NONE.
 // Per field, the tokens it holds for this document (query order) are scored together; the fields are folded by match_type.
+// compute_aggregated_score for several query_by fields: pos[t * KW_MAX_FIELDS + f] = position of found token t in field f's list, or
+// KW_NONE. Per field, the tokens it holds for this document (query order) are scored together; the fields are folded by match_type.
+// tokens_found = tokens present in at least one field (query_len of src/index.cpp:5265-5268).
 template <int TMAX>
-__device__ inline ScoredHit score_hit_mf(const IndexView& ix, const KwQueryDev& q, const KwQueryMF& mf, uint32_t seq_id,
-                                         const uint32_t (&pos)[TMAX * KW_MAX_FIELDS]) {
+__device__ inline uint64_t agg_score_mf(const IndexView& ix, const KwQueryDev& q, const KwQueryMF& mf, const uint32_t (&pos)[TMAX * KW_MAX_FIELDS],
+                                        uint32_t tokens_found, uint32_t& off_words) {
     const uint32_t T = q.n_lists;
-    uint32_t off_words = 0;
     AggState st;
     for (uint32_t f = 0; f < mf.n_fields; f++) {
         TokRun runs[TMAX];
@@ -729,7 +731,14 @@ __device__ inline ScoredHit score_hit_mf(const IndexView& ix, const KwQueryDev& 
         if (n_present == 0) continue;                     // field holds none of the tokens for this document (:5298-5300)
         agg_add(st, q.match_type, mf.is_array[f] ? field_match_score_array<TMAX>(q, runs, n_present) : field_match_score<TMAX>(q, runs, n_present), mf.weight[f]);
     }
-    return sort_scores(ix, q, seq_id, agg_finish(st, q, T), off_words);
+    return agg_finish(st, q, tokens_found);
+}
+template <int TMAX>
+__device__ inline ScoredHit score_hit_mf(const IndexView& ix, const KwQueryDev& q, const KwQueryMF& mf, uint32_t seq_id,
+                                         const uint32_t (&pos)[TMAX * KW_MAX_FIELDS]) {
+    uint32_t off_words = 0;
+    const uint64_t agg = agg_score_mf<TMAX>(ix, q, mf, pos, q.n_lists, off_words);       // (the AND of the tokens: every token is in some field)
+    return sort_scores(ix, q, seq_id, agg, off_words);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2044,6 +2053,36 @@ __global__ __launch_bounds__(KW_THREADS) void kw_idset_expand_kernel(const uint3
         if (t == 0) s_base += all;
         __syncthreads();
     }
+}
+
+// Index::compute_aux_scores' text half (src/index.cpp:8800-8846, rerank_hybrid_matches): the aggregated text-match score of GIVEN
+// documents — hybrid hits that only the vector search found — for a query's tokens: every token's lists are positioned on the document
+// (skip_to), the tokens it holds are scored per field, query_len = tokens found anywhere; a document with none of them scores 0.
+// One thread per (query, document); queries are described like multi-field queries (KwQueryDev with total_cost 0 + KwQueryMF).
+struct KwAuxItem { uint32_t query, seq_id; };
+__global__ __launch_bounds__(64) void kw_aux_score_kernel(IndexView ix, const KwQueryDev* __restrict__ queries, const KwQueryMF* __restrict__ mfs,
+                                                          const KwAuxItem* __restrict__ items, uint32_t n_items, int64_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const KwAuxItem it = items[i];
+    const KwQueryDev& q = queries[it.query];
+    const KwQueryMF& mf = mfs[q.mf_index];
+    uint32_t pos[KW_MAX_TOKENS * KW_MAX_FIELDS];
+    uint32_t tokens_found = 0;
+    for (int t = 0; t < KW_MAX_TOKENS; t++) {
+        bool any = false;
+        for (int f = 0; f < KW_MAX_FIELDS; f++) {
+            uint32_t p = KW_NONE;
+            if ((uint32_t)t < q.n_lists && (uint32_t)f < mf.n_fields && mf.list[t][f] != KW_NONE) {
+                uint32_t pp;
+                if (probe_list(ix, ix.lists[mf.list[t][f]], it.seq_id, pp)) { p = pp; any = true; }
+            }
+            pos[t * KW_MAX_FIELDS + f] = p;               // (runtime index: the array lives in scratch — a rare, short kernel)
+        }
+        tokens_found += any ? 1u : 0u;
+    }
+    uint32_t off_words = 0;
+    out[i] = (int64_t)agg_score_mf<KW_MAX_TOKENS>(ix, q, mf, pos, tokens_found, off_words);
 }
 
 #include "kw_find2.hip.h"

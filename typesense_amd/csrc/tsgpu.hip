@@ -1154,6 +1154,78 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
 }
 
 // device-side shard merge (the host version, tsgpu_merge_shard_hits, lives in tsgpu_vec.hip)
+// Index::compute_aux_scores' text half (src/index.cpp:8800-8846): text_match score of given documents for given queries' tokens
+int tsgpu_keyword_aux_scores(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, const uint32_t* item_query, const uint32_t* item_seq_id,
+                             uint32_t n_items, int64_t* scores_out) {
+    if (!ctx || !queries || (n_items && (!item_query || !item_seq_id || !scores_out))) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_aux_scores: NULL argument");
+    if (n_items == 0) return ok();
+    (void)hipSetDevice(ctx->device);
+    const std::shared_ptr<const Snapshot> snap_ref = ctx->snapshot();
+    const Snapshot& snap = *snap_ref;
+    try {
+        std::vector<KwQueryDev> qd(n_queries);
+        std::vector<KwQueryMF> mf(n_queries);
+        for (uint32_t i = 0; i < n_queries; i++) {
+            const tsgpu_kw_query& in = queries[i];
+            KwQueryDev& q = qd[i];
+            KwQueryMF& m = mf[i];
+            memset(&q, 0, sizeof q);
+            memset(&m, 0xFF, sizeof m);
+            if (in.n_tokens == 0 || in.n_tokens > TSGPU_MAX_QUERY_TOKENS || in.n_fields == 0 || in.n_fields > (uint32_t)KW_MAX_FIELDS || in.match_type > TSGPU_SUM_SCORE)
+                return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_aux_scores: 1..10 tokens, 1..4 query_by fields");
+            m.n_fields = in.n_fields;
+            m.driver_token = 0;
+            for (uint32_t f = 0; f < in.n_fields; f++) {
+                const auto fa = snap.field_is_array.find(in.field_ids[f]);
+                if (fa == snap.field_is_array.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_keyword_aux_scores: unknown field");
+                m.is_array[f] = fa->second ? 1 : 0;
+                m.weight[f] = in.field_weights[f];
+            }
+            // one or_iterator per token that exists in some field (get_field_token_its, src/index.cpp:5598-5660), query order
+            uint32_t nl = 0;
+            for (uint32_t t = 0; t < in.n_tokens; t++) {
+                bool found = false;
+                for (uint32_t f = 0; f < in.n_fields; f++) {
+                    const uint32_t h = snap.find_handle(in.field_ids[f], in.term_ids[t]);
+                    if (h == 0xFFFFFFFFu) continue;
+                    m.list[nl][f] = h;
+                    found = true;
+                }
+                if (found) nl++;
+            }
+            q.n_lists = nl;
+            q.n_query_tokens = in.n_tokens;
+            q.match_type = in.match_type;
+            q.prio_exact = in.prioritize_exact_match; q.prio_pos = in.prioritize_token_position; q.prio_nfields = in.prioritize_num_matching_fields;
+            q.total_cost = 0;                                    // compute_aux_scores passes total_cost = 0 (src/index.cpp:8829)
+            q.weight = in.field_weights[0];
+            q.mf_index = i;
+        }
+        for (uint32_t i = 0; i < n_items; i++) if (item_query[i] >= n_queries) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_aux_scores: item_query out of range");
+        LaneLock lane(ctx);
+        KwLane& L = *lane.L;
+        hipStream_t s = L.stream;
+        const size_t o_q = 0, o_m = (sizeof(KwQueryDev) * n_queries + 15) & ~(size_t)15, o_i = (o_m + sizeof(KwQueryMF) * n_queries + 15) & ~(size_t)15;
+        const size_t o_out = (o_i + sizeof(KwAuxItem) * n_items + 15) & ~(size_t)15, total = o_out + 8 * (size_t)n_items;
+        std::vector<unsigned char> h(total);
+        memcpy(h.data() + o_q, qd.data(), sizeof(KwQueryDev) * n_queries);
+        memcpy(h.data() + o_m, mf.data(), sizeof(KwQueryMF) * n_queries);
+        KwAuxItem* items = (KwAuxItem*)(h.data() + o_i);
+        for (uint32_t i = 0; i < n_items; i++) { items[i].query = item_query[i]; items[i].seq_id = item_seq_id[i]; }
+        int rc;
+        if ((rc = L.d_plan.reserve(total))) return rc;
+        TSGPU_HIP_TRY(hipMemcpyAsync(L.d_plan.p, h.data(), o_out, hipMemcpyHostToDevice, s));
+        IndexView v = make_view(ctx, snap);
+        char* base = (char*)L.d_plan.p;
+        hipLaunchKernelGGL(kw_aux_score_kernel, dim3((n_items + 63) / 64), dim3(64), 0, s, v, (const KwQueryDev*)(base + o_q), (const KwQueryMF*)(base + o_m),
+                           (const KwAuxItem*)(base + o_i), n_items, (int64_t*)(base + o_out));
+        TSGPU_HIP_TRY(hipGetLastError());
+        TSGPU_HIP_TRY(hipMemcpyAsync(scores_out, base + o_out, 8 * (size_t)n_items, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        return ok();
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_aux_scores: host allocation failed"); }
+}
+
 int tsgpu_merge_shard_hits_device(tsgpu_ctx* ctx, const tsgpu_hits* gathered, uint32_t n_shards, uint32_t n_queries, uint32_t k, tsgpu_hits* out) {
     if (!ctx || !gathered || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_merge_shard_hits_device: NULL argument");
     if (gathered->mem != TSGPU_MEM_DEVICE || out->mem != TSGPU_MEM_DEVICE) return fail(TSGPU_ERR_INVALID, "tsgpu_merge_shard_hits_device: device arrays only");

@@ -6,6 +6,7 @@
 #include <cfloat>
 #include <atomic>
 #include <thread>
+#include <tuple>
 #include "tsgpu_host.h"
 #include <chrono>
 #include "vec_kernels.hip.h"
@@ -844,7 +845,7 @@ int tsgpu_vec_distances(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* q, c
         TSGPU_HIP_TRY(hipMemcpyAsync(f->d_q1.p, q, (size_t)f->dim * 4, hipMemcpyHostToDevice, s));
         if (f->metric == TSGPU_METRIC_COSINE)   // the reference re-normalises q inside its loop (src/index.cpp:3362-3366)
             hipLaunchKernelGGL(vec_normalize_rows_kernel, dim3(1), dim3(64), 0, s, f->d_q1.as<float>(), 1u, f->dim);
-        hipLaunchKernelGGL(vec_row_distances_kernel, dim3((n + 3) / 4), dim3(256), 0, s, f->X.as<float>(), f->d_q1.as<float>(), f->dim,
+        hipLaunchKernelGGL(vec_row_distances_kernel, dim3((n + 15) / 16), dim3(256), 0, s, f->X.as<float>(), f->d_q1.as<float>(), f->dim,
                            f->d_rows.as<uint32_t>(), n, f->d_out1.as<float>());
         TSGPU_HIP_TRY(hipMemcpyAsync(dist_out, f->d_out1.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
@@ -1018,6 +1019,101 @@ int tsgpu_hybrid_fuse_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const
     return ok();
 }
 
+// Index::compute_aux_scores (src/index.cpp:8793-8923; rerank_hybrid_matches) on the fused hits of a batch (`out` = every query's Topster
+// content): hits only the vector search found get their text_match score (tsgpu_keyword_aux_scores), hits only the keyword search
+// found their exact distance by label; then keyword ranks by (text_match_score, key) descending, semantic ranks by distance
+// (stable, on the keyword order), fused score = 1/keyword_rank * (1 - alpha) + 1/semantic_rank * alpha into scores[match_score_index],
+// and the Topster order again.
+extern "C" int tsgpu_keyword_aux_scores(tsgpu_ctx*, const tsgpu_kw_query*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, int64_t*);
+static int hybrid_rerank(tsgpu_ctx* ctx, VecField* f, uint32_t /*vec_field_id*/, const tsgpu_kw_query* queries, const tsgpu_hybrid_params* p, const float* Q, int mem_q,
+                         uint32_t n_queries, tsgpu_hits* out) {
+    if (!out->text_match || !out->vector_distance || !out->match_score_index) return fail(TSGPU_ERR_INVALID, "rerank_hybrid_matches needs the text_match, vector_distance and match_score_index outputs");
+    const uint32_t dim = f->dim;
+    // 1) what is missing
+    std::vector<uint32_t> item_q, item_id, pair_q, pair_row;
+    std::vector<size_t> item_slot, pair_slot;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (uint32_t q = 0; q < n_queries; q++) {
+            if (out->status[q] != TSGPU_OK) continue;
+            for (uint32_t i = 0; i < out->n_hits[q]; i++) {
+                const size_t s = (size_t)q * out->k_stride + i;
+                if (out->text_match[s] == 0) { item_q.push_back(q); item_id.push_back((uint32_t)out->keys[s]); item_slot.push_back(s); }      // found via vector distance only
+                else if (out->vector_distance[s] == -1.0f) {                                                                               // found via text match only
+                    uint32_t r;
+                    if (f->find_row(out->keys[s], r) && f->h_ok[r]) { pair_q.push_back(q); pair_row.push_back(r); pair_slot.push_back(s); }   // (else getDataByLabel throws: left as it is)
+                }
+            }
+        }
+        if (!pair_q.empty()) {
+            // exact distances by label (getDataByLabel + get_dist_func, cosine: the query normalised first), ONE launch for the batch
+            hipStream_t s = ctx->stream;
+            const uint32_t n = (uint32_t)pair_q.size();
+            int rc;
+            if ((rc = f->d_rows.reserve((size_t)n * 8))) return rc;
+            if ((rc = f->d_out1.reserve((size_t)n * 4))) return rc;
+            if ((rc = f->d_q1.reserve((size_t)n_queries * dim * 4))) return rc;
+            TSGPU_HIP_TRY(hipMemcpyAsync(f->d_rows.p, pair_row.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync((char*)f->d_rows.p + (size_t)n * 4, pair_q.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(f->d_q1.p, Q, (size_t)n_queries * dim * 4, mem_q == TSGPU_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+            if (f->metric == TSGPU_METRIC_COSINE)
+                hipLaunchKernelGGL(vec_normalize_rows_kernel, dim3((n_queries + 3) / 4), dim3(256), 0, s, f->d_q1.as<float>(), n_queries, dim);
+            hipLaunchKernelGGL(vec_pair_distances_kernel, dim3((n + 15) / 16), dim3(256), 0, s, f->X.as<float>(), f->d_q1.as<float>(), dim,
+                               (const uint32_t*)((char*)f->d_rows.p + (size_t)n * 4), f->d_rows.as<uint32_t>(), n, f->d_out1.as<float>());
+            std::vector<float> d(n);
+            TSGPU_HIP_TRY(hipMemcpyAsync(d.data(), f->d_out1.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipStreamSynchronize(s));
+            for (uint32_t i = 0; i < n; i++) out->vector_distance[pair_slot[i]] = d[i];
+        }
+    }
+    // 2) text_match of the vector-only hits; the reference walks them in ascending key order per query (iterators only move forward):
+    //    the score of a document does not depend on that order
+    if (!item_q.empty()) {
+        std::vector<int64_t> sc(item_q.size());
+        const int rc = tsgpu_keyword_aux_scores(ctx, queries, n_queries, item_q.data(), item_id.data(), (uint32_t)item_q.size(), sc.data());
+        if (rc) return rc;
+        for (size_t i = 0; i < sc.size(); i++) out->text_match[item_slot[i]] = sc[i];
+    }
+    // 3) re-rank and re-fuse, query by query
+    struct E { uint64_t key; int64_t sc[3]; int64_t tm; float vd; int8_t msi; uint32_t krank, srank; };
+    std::vector<E> es;
+    std::vector<uint32_t> order;
+    for (uint32_t q = 0; q < n_queries; q++) {
+        if (out->status[q] != TSGPU_OK) continue;
+        const uint32_t n = out->n_hits[q];
+        es.resize(n);
+        for (uint32_t i = 0; i < n; i++) {
+            const size_t s = (size_t)q * out->k_stride + i;
+            E& e = es[i];
+            e.key = out->keys[s]; for (int j = 0; j < 3; j++) e.sc[j] = out->scores[s * 3 + j];
+            e.tm = out->text_match[s]; e.vd = out->vector_distance[s]; e.msi = out->match_score_index[s];
+        }
+        order.resize(n);
+        for (uint32_t i = 0; i < n; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return std::tie(es[a].tm, es[a].key) > std::tie(es[b].tm, es[b].key); });
+        for (uint32_t i = 0; i < n; i++) es[order[i]].krank = i + 1;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return es[a].vd < es[b].vd; });
+        for (uint32_t i = 0; i < n; i++) es[order[i]].srank = i + 1;
+        for (uint32_t i = 0; i < n; i++) {
+            E& e = es[i];
+            if (e.msi < 0 || e.msi > 2) continue;
+            e.sc[e.msi] = float_to_int64((1.0 / e.krank) * (1.0 - p->alpha) + (1.0 / e.srank) * p->alpha);
+        }
+        for (uint32_t i = 0; i < n; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            const E& x = es[a]; const E& y = es[b];
+            return std::tie(x.sc[0], x.sc[1], x.sc[2], x.key) > std::tie(y.sc[0], y.sc[1], y.sc[2], y.key);       // KV::is_greater, include/topster.h:146-149
+        });
+        for (uint32_t i = 0; i < n; i++) {
+            const size_t s = (size_t)q * out->k_stride + i;
+            const E& e = es[order[i]];
+            out->keys[s] = e.key; for (int j = 0; j < 3; j++) out->scores[s * 3 + j] = e.sc[j];
+            out->text_match[s] = e.tm; out->vector_distance[s] = e.vd; out->match_score_index[s] = e.msi;
+        }
+    }
+    return TSGPU_OK;
+}
+
 // hybrid, src/index.cpp:4036-4221: keyword pass -> exact k-NN -> reciprocal rank fusion on the sorted Topster
 int tsgpu_hybrid_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t vec_field_id, const tsgpu_hybrid_params* p,
                               const float* Q, int mem_q, uint32_t n_queries, tsgpu_hits* out) {
@@ -1065,6 +1161,7 @@ int tsgpu_hybrid_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uin
         const auto t2 = std::chrono::steady_clock::now();
         // 3) fusion on the host, exactly as the reference
         rc = tsgpu_hybrid_fuse_batch(ctx, queries, p, f->metric, &kw, kh.dist.data(), kh.lab.data(), kh.cnt.data(), k, n_queries, out);
+        if (!rc && p->rerank_hybrid_matches) rc = hybrid_rerank(ctx, f, vec_field_id, queries, p, Q, mem_q, n_queries, out);
         if (host_timing) {
             auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
             fprintf(stderr, "[tsgpu] hybrid batch %u queries: keyword pass %lld us, k-NN to host %lld us, fusion %lld us\n", n_queries, us(t0, t1), us(t1, t2), us(t2, std::chrono::steady_clock::now()));

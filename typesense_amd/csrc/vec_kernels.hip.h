@@ -405,25 +405,6 @@ __global__ void vec_normalize_rows_kernel(float* __restrict__ X, uint32_t n_rows
     for (uint32_t i = 0; i < dim; i++) x[i] = x[i] * norm;
 }
 
-// distances of one query to explicit rows: one wave per row, lane-strided partial sums (flat scan over filter
-// ids, src/index.cpp:3345-3374). rows[i] == 0xFFFFFFFF -> NaN (label missing).
-__global__ __launch_bounds__(256) void vec_row_distances_kernel(const float* __restrict__ X, const float* __restrict__ q, uint32_t dim,
-                                                                 const uint32_t* __restrict__ rows, uint32_t n, float* __restrict__ out) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const bool live = i < n;
-    const uint32_t row = live ? rows[i] : 0xFFFFFFFFu;
-    float s = 0.0f;
-    if (row != 0xFFFFFFFFu) {
-        const float* x = X + (size_t)row * dim;
-        for (uint32_t k = lane; k < dim; k += 64) s = fmaf(q[k], x[k], s);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (live && lane == 0) out[i] = row == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : 1.0f - s;
-}
-
-
 // ================================================================================================
 // bf16 PREFILTER path (default for the batched k-NN). Same exact results as the fp32 scan above, ~16x less matrix
 // time: the full N x B sweep runs on v_mfma_f32_32x32x16_bf16 over a bf16 copy of X (half the HBM bytes of the fp32
@@ -1051,6 +1032,30 @@ __device__ inline float ip_distance_group16(const float* qs, const float* __rest
     if (dim > 16) { const uint32_t qn = dim >> 4 << 4; const float a1 = ip_part16(qs, x, 0, qn, sub); return ip_add(1.0f, -ip_add(a1, ip_scalar(qs, x, qn, dim - qn))); }
     if (dim > 4) { const uint32_t qn = dim >> 2 << 2; const float a1 = ip_part4(qs, x, 0, qn, sub); return ip_add(1.0f, -ip_add(a1, ip_scalar(qs, x, qn, dim - qn))); }
     return ip_add(1.0f, -ip_scalar(qs, x, 0, dim));
+}
+
+// distances of one query to explicit rows (flat scan over filter ids, src/index.cpp:3345-3374; getDataByLabel + get_dist_func of
+// compute_aux_scores, :8856-8880): 16 lanes per row, hnswlib's own summation order (ip_distance_group16) — the same bits the k-NN
+// paths return. rows[i] == 0xFFFFFFFF -> NaN (label missing).
+__global__ __launch_bounds__(256) void vec_row_distances_kernel(const float* __restrict__ X, const float* __restrict__ q, uint32_t dim,
+                                                                 const uint32_t* __restrict__ rows, uint32_t n, float* __restrict__ out) {
+    const uint32_t sub = threadIdx.x & 15;
+    const uint32_t i = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    const uint32_t ic = i < n ? i : n - 1;               // idle groups recompute the last row (keeps the wave's shuffles uniform)
+    const uint32_t row = rows[ic];
+    const float d = ip_distance_group16(q, X + (size_t)(row != 0xFFFFFFFFu ? row : 0) * dim, dim, sub);
+    if (i < n && sub == 0) out[i] = row == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : d;
+}
+
+// the same for (query, row) pairs of a batch: item i = (queries[qidx[i]], rows[i])
+__global__ __launch_bounds__(256) void vec_pair_distances_kernel(const float* __restrict__ X, const float* __restrict__ Q, uint32_t dim, const uint32_t* __restrict__ qidx,
+                                                                  const uint32_t* __restrict__ rows, uint32_t n, float* __restrict__ out) {
+    const uint32_t sub = threadIdx.x & 15;
+    const uint32_t i = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    const uint32_t ic = i < n ? i : n - 1;
+    const uint32_t row = rows[ic];
+    const float d = ip_distance_group16(Q + (size_t)qidx[ic] * dim, X + (size_t)(row != 0xFFFFFFFFu ? row : 0) * dim, dim, sub);
+    if (i < n && sub == 0) out[i] = row == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : d;
 }
 
 // exact re-scoring of the survivors: grid (n_q, splits); 16 lanes per (query, row) pair; key = ord(dist) << 32 | row

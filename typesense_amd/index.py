@@ -388,11 +388,20 @@ class GpuIndex:
         self._ck(self.L.tsgpu_vector_search_batch(self.h, field_id, C.byref(p), _vp(Q), B.MEM_HOST, Q.shape[0], C.byref(hs)))
         return hits
 
-    def hybrid_search_batch(self, queries, field_id, Q, k=0, fetch_size=10, alpha=0.3, distance_threshold=B.FLT_MAX, k_stride=250):
+    def keyword_aux_scores(self, queries, item_query, item_seq_id):
+        """compute_aux_scores' text half: text_match of given documents for the queries' tokens -> int64[n_items]"""
+        arr = make_query_array(queries)
+        iq, ii = _u32(item_query), _u32(item_seq_id)
+        out = np.zeros(iq.size, np.int64)
+        self._ck(self.L.tsgpu_keyword_aux_scores(self.h, C.cast(arr, C.c_void_p), len(arr), _vp(iq), _vp(ii), iq.size, _vp(out)))
+        return out
+
+    def hybrid_search_batch(self, queries, field_id, Q, k=0, fetch_size=10, alpha=0.3, distance_threshold=B.FLT_MAX, k_stride=250, rerank=False):
         arr = make_query_array(queries)
         Q = np.ascontiguousarray(Q, dtype=np.float32).reshape(-1, self.vec_dim[field_id])
         p = B.HybridParamsC()
         p.k, p.fetch_size, p.alpha, p.distance_threshold = k, fetch_size, alpha, distance_threshold
+        p.rerank_hybrid_matches = 1 if rerank else 0
         hits = Hits(len(arr), k_stride)
         hs = hits.c_struct()
         self._ck(self.L.tsgpu_hybrid_search_batch(self.h, C.cast(arr, C.c_void_p), field_id, C.byref(p), _vp(Q), B.MEM_HOST, len(arr), C.byref(hs)))
@@ -404,6 +413,7 @@ class GpuIndex:
         arr = make_query_array(queries)
         p = B.HybridParamsC()
         p.k, p.fetch_size, p.alpha, p.distance_threshold = k, fetch_size, alpha, distance_threshold
+        p.rerank_hybrid_matches = 0
         d = np.ascontiguousarray(knn_dist, dtype=np.float32)
         l = np.ascontiguousarray(knn_labels, dtype=np.uint64)
         c = np.ascontiguousarray(knn_cnt, dtype=np.uint32)
