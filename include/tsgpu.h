@@ -55,6 +55,7 @@ extern "C" {
 #endif
 
 #define TSGPU_ABI_VERSION 3
+#define TSGPU_MAX_DROPPED_TOKENS 4
 
 /* limits of the accelerated path (anything beyond -> TSGPU_ERR_UNSUPPORTED for that query) */
 #define TSGPU_MAX_QUERY_TOKENS 10   /* = WINDOW_SIZE, include/match_score.h:11 */
@@ -203,6 +204,11 @@ typedef struct tsgpu_kw_query {
                                                         time on the device stops scanning (every work item checks the device clock every 16
                                                         driver blocks) and returns the PARTIAL hits found so far with status 0 and
                                                         search_cutoff = 1, like the reference (include/or_iterator.h:148-153) */
+    uint32_t n_dropped;                              /* dropped_tokens.size() (the drop_tokens_threshold passes, src/index.cpp:5427-5464): tokens that */
+    uint32_t dropped_term_ids[TSGPU_MAX_DROPPED_TOKENS]; /* take no part in the AND but are scored when the document holds them (compute_aggregated_score,
+                                                        :5271-5290: their postings join the field's tokens after the query's own, query_len counts them);
+                                                        n_tokens + n_dropped <= TSGPU_MAX_QUERY_TOKENS. Such queries take the general (per-candidate
+                                                        probe) kernel. */
 } tsgpu_kw_query;
 
 /* Results, structure-of-arrays, slot q*k_stride+i = i-th best hit of query q in Topster::sort() order

@@ -25,6 +25,7 @@ struct orc_kw_query {
     const uint32_t* excluded_ids; uint32_t n_excluded;
     const uint32_t* filter_ids; uint32_t n_filter;
     uint32_t topster_size;   // 0 = reference rule
+    const uint32_t* dropped_tokens; uint32_t n_dropped;
 };
 
 struct orc_result {
@@ -56,6 +57,7 @@ static keyword_query_t to_query(const orc_kw_query* q) {
     if (q->n_excluded) k.excluded_ids.assign(q->excluded_ids, q->excluded_ids + q->n_excluded);
     if (q->n_filter) k.filter_ids.assign(q->filter_ids, q->filter_ids + q->n_filter);
     k.topster_size = q->topster_size;
+    if (q->n_dropped) k.dropped_tokens.assign(q->dropped_tokens, q->dropped_tokens + q->n_dropped);
     return k;
 }
 

@@ -88,6 +88,7 @@ struct keyword_query_t {
     std::vector<uint32_t> filter_ids;        // sorted; empty = no filter
     uint64_t search_stop_us = UINT64_MAX;
     size_t topster_size = 0;                 // 0 = the reference's sizing rule; >0 = explicit Topster capacity (tests)
+    std::vector<uint32_t> dropped_tokens;    // dropped_tokens of search_across_fields (index.cpp:5427-5464): scored when present, never required
 };
 
 struct keyword_result_t {
@@ -333,7 +334,8 @@ public:
         }
     }
 
-    int64_t compute_aggregated_score(const std::vector<or_iterator_t>& its, const keyword_query_t& q, uint32_t seq_id) const {  // index.cpp:5227-5383
+    int64_t compute_aggregated_score(const std::vector<or_iterator_t>& its, const keyword_query_t& q, uint32_t seq_id,
+                                     std::vector<or_iterator_t>* dropped_token_its = nullptr) const {  // index.cpp:5227-5383
         const size_t num_search_fields = q.fields.size();
         std::vector<std::vector<posting_list_t::iterator_t>> field_to_tokens(num_search_fields);
         size_t query_len = 0;
@@ -348,6 +350,22 @@ public:
                 }
             }
             if (found_token) query_len++;
+        }
+        // check if seq_id exists in any of the dropped_token iters (:5271-5290)
+        for (size_t ti = 0; dropped_token_its && ti < dropped_token_its->size(); ti++) {
+            or_iterator_t& token_fields_iters = (*dropped_token_its)[ti];
+            if (token_fields_iters.skip_to(seq_id) && token_fields_iters.id() == seq_id) {
+                const auto& field_iters = token_fields_iters.get_its();
+                bool found_token = false;
+                for (size_t fi = 0; fi < field_iters.size(); fi++) {
+                    const auto& field_iter = field_iters[fi];
+                    if (field_iter.id() == seq_id && field_iter.get_field_id() < num_search_fields) {
+                        field_to_tokens[field_iter.get_field_id()].push_back(field_iter.clone());
+                        found_token = true;
+                    }
+                }
+                if (found_token) query_len++;
+            }
         }
         int64_t best_field_match_score = 0, best_field_weight = 0, sum_field_weighted_score = 0;
         uint32_t num_matching_fields = 0;
@@ -384,12 +402,14 @@ public:
     }
 
     // get_field_token_its, index.cpp:5598-5660
-    void get_field_token_its(const keyword_query_t& q, std::vector<or_iterator_t>& token_its, std::vector<posting_list_t*>& expanded_plists) const {
-        for (size_t ti = 0; ti < q.tokens.size(); ti++) {
+    void get_field_token_its(const keyword_query_t& q, std::vector<or_iterator_t>& token_its, std::vector<posting_list_t*>& expanded_plists,
+                             const std::vector<uint32_t>* tokens_in = nullptr, bool keep_empty = false) const {
+        const std::vector<uint32_t>& toks = tokens_in ? *tokens_in : q.tokens;
+        for (size_t ti = 0; ti < toks.size(); ti++) {
             std::vector<posting_list_t::iterator_t> its;
             for (size_t i = 0; i < q.fields.size(); i++) {
                 const auto& fidx = fields[q.fields[i].field];
-                auto leaf = fidx.terms.find(q.tokens[ti]);
+                auto leaf = fidx.terms.find(toks[ti]);
                 if (leaf == fidx.terms.end()) continue;
                 if (leaf->second->compact) {
                     posting_list_t* fl = leaf->second->compact->to_full_posting_list((uint16_t)MAX_BLOCK_ELEMENTS);
@@ -399,7 +419,7 @@ public:
                     its.push_back(leaf->second->full->new_iterator(nullptr, nullptr, (uint32_t)i));
                 }
             }
-            if (its.empty()) continue;  // token absent from every field: silently skipped (:5651-5655)
+            if (its.empty() && !keep_empty) continue;  // token absent from every field: silently skipped (:5651-5655)
             or_iterator_t token_fields(its);
             token_its.push_back(std::move(token_fields));
         }
@@ -410,6 +430,9 @@ public:
         std::vector<or_iterator_t> token_its;
         std::vector<posting_list_t*> expanded_plists;
         get_field_token_its(q, token_its, expanded_plists);
+        // one or_iterator per dropped token (:5427-5464; a token no field holds never matches a document: left out)
+        std::vector<or_iterator_t> dropped_token_its;
+        if (!q.dropped_tokens.empty()) get_field_token_its(q, dropped_token_its, expanded_plists, &q.dropped_tokens);
 
         result_iter_state_t istate(q.excluded_ids.data(), q.excluded_ids.size(), q.filter_ids.data(), q.filter_ids.size());
         deadline_t dl;
@@ -419,7 +442,7 @@ public:
         or_iterator_t::intersect(token_its, istate, dl, [&](single_filter_result_t& fr, const std::vector<or_iterator_t>& its) {
             uint32_t seq_id = fr.seq_id;
             if (topster == nullptr) { out.result_ids.push_back(seq_id); return; }
-            int64_t aggregated_score = compute_aggregated_score(its, q, seq_id);
+            int64_t aggregated_score = compute_aggregated_score(its, q, seq_id, &dropped_token_its);
             int64_t scores[3] = {0, 0, 0};
             int64_t match_score_index = -1;
             compute_sort_scores(q.sort, seq_id, aggregated_score, scores, match_score_index, 0);

@@ -30,7 +30,8 @@ class KwQuery(C.Structure):
                 ("sort_kind", C.c_int32 * 3), ("sort_column", C.c_int32 * 3), ("sort_order", C.c_int32 * 3), ("n_sort", C.c_uint32),
                 ("fetch_size", C.c_uint32),
                 ("excluded_ids", C.POINTER(C.c_uint32)), ("n_excluded", C.c_uint32),
-                ("filter_ids", C.POINTER(C.c_uint32)), ("n_filter", C.c_uint32), ("topster_size", C.c_uint32)]
+                ("filter_ids", C.POINTER(C.c_uint32)), ("n_filter", C.c_uint32), ("topster_size", C.c_uint32),
+                ("dropped_tokens", C.POINTER(C.c_uint32)), ("n_dropped", C.c_uint32)]
 
 
 class Result(C.Structure):
@@ -214,7 +215,7 @@ class OracleIndex:
     # ---- query time ----
     def make_query(self, tokens, fields=((0, 15),), sort=((SORT_TEXT_MATCH, 0, 1), (SORT_SEQ_ID, 0, 1)), fetch_size=10,
                    match_type=MAX_SCORE, prioritize_exact_match=True, prioritize_token_position=False,
-                   prioritize_num_matching_fields=True, total_cost=0, excluded_ids=None, filter_ids=None, topster_size=0):
+                   prioritize_num_matching_fields=True, total_cost=0, excluded_ids=None, filter_ids=None, topster_size=0, dropped_tokens=None):
         q = KwQuery()
         keep = []
         t = _u32(tokens); keep.append(t)
@@ -239,6 +240,9 @@ class OracleIndex:
         if filter_ids is not None and len(filter_ids):
             f = _u32(filter_ids); keep.append(f)
             q.filter_ids = f.ctypes.data_as(C.POINTER(C.c_uint32)); q.n_filter = f.size
+        if dropped_tokens is not None and len(dropped_tokens):
+            d = _u32(dropped_tokens); keep.append(d)
+            q.dropped_tokens = d.ctypes.data_as(C.POINTER(C.c_uint32)); q.n_dropped = d.size
         q._keep = keep
         return q
 

@@ -91,7 +91,7 @@ def oracle_keyword(orc, q, cap=2048, ids_cap=0):
                         match_type=q.match_type, prioritize_exact_match=q.prioritize_exact_match,
                         prioritize_token_position=q.prioritize_token_position,
                         prioritize_num_matching_fields=q.prioritize_num_matching_fields, total_cost=q.total_cost,
-                        excluded_ids=q.excluded_ids, filter_ids=q.filter_ids)
+                        excluded_ids=q.excluded_ids, filter_ids=q.filter_ids, dropped_tokens=getattr(q, "dropped_tokens", None))
     return orc.search_keyword(oq, cap=cap, ids_cap=ids_cap)
 
 
@@ -100,7 +100,7 @@ def oracle_query(orc, q):
                           topster_size=q.topster_size, match_type=q.match_type, prioritize_exact_match=q.prioritize_exact_match,
                           prioritize_token_position=q.prioritize_token_position,
                           prioritize_num_matching_fields=q.prioritize_num_matching_fields, total_cost=q.total_cost,
-                          excluded_ids=q.excluded_ids, filter_ids=q.filter_ids)
+                          excluded_ids=q.excluded_ids, filter_ids=q.filter_ids, dropped_tokens=getattr(q, "dropped_tokens", None))
 
 
 def oracle_candidates(orc, combos, cap=2048, ids_cap=0):

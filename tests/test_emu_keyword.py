@@ -665,3 +665,48 @@ def test_pair_find_kernel_matches_the_oracle(pair, chunk):
         H.assert_hits_equal(hits, i, ref, "pair kernel stage1 chunk=%d" % chunk)
         assert np.array_equal(g2.result_ids(i), ref.result_ids)
     g2.close()
+
+
+@pytest.mark.parametrize("chunk", [0, 1])
+def test_dropped_tokens_are_scored_when_present_and_never_required(pair, pair3, chunk):
+    """the drop_tokens passes of the reference call search_across_fields with the tokens it left out of the AND (`dropped_tokens`,
+    src/index.cpp:5427-5464): compute_aggregated_score positions their lists on every hit and scores the ones the document holds after
+    the query's own tokens (:5271-5290; query_len counts them). Same hit SETS as without them, different scores / order."""
+    orc, g, _ = pair
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    g.set_option("kw_chunk_blocks", chunk)
+    g.keep_result_ids(True)
+    try:
+        cases = [([1], [2]), ([2, 1], [3]), ([3], [1, 2]), ([1, 2, 3], [4, 5]), ([5], [9999]), ([4, 2], [4]), ([7], [1, 2, 3, 4]), ([6, 1, 2], [3])]
+        qs = [T.KwQuery(req, sort=sort, topster_size=250, dropped_tokens=dr) for req, dr in cases]
+        qs += [T.KwQuery(req, sort=sort, topster_size=40, dropped_tokens=dr, prioritize_token_position=True, match_type=B.SUM_SCORE) for req, dr in cases[:4]]
+        qs += [T.KwQuery([1, 2], sort=sort, topster_size=250, dropped_tokens=[3], filter_ids=np.arange(0, 3000, 3)),
+               T.KwQuery([1], sort=sort, topster_size=250, dropped_tokens=[2, 3], excluded_ids=np.arange(0, 3000, 5))]
+        plain = g.keyword_search_batch([T.KwQuery(q.tokens, sort=sort, topster_size=250) for q in qs[:8]], k_stride=250)
+        hits = g.keyword_search_batch(qs, k_stride=250)
+        assert (hits.status == 0).all()
+        changed = 0
+        for i, q in enumerate(qs):
+            ref = H.oracle_keyword(orc, q, ids_cap=4000)
+            H.assert_hits_equal(hits, i, ref, "dropped tokens chunk=%d q=%s+%s" % (chunk, q.tokens, q.dropped_tokens))
+            assert np.array_equal(g.result_ids(i), ref.result_ids)
+            if i < 8:
+                assert hits.num_matched[i] == plain.num_matched[i]                         # the AND is the query's own tokens only
+                n = int(hits.n_hits[i])
+                changed += not np.array_equal(hits.scores[i, :n], plain.scores[i, :n])
+        assert changed >= 5
+        # too many: 501
+        bad = g.keyword_search_batch([T.KwQuery(list(range(1, 9)), dropped_tokens=[9, 10, 11])], k_stride=250)
+        assert bad.status[0] == B.ERR_UNSUPPORTED
+    finally:
+        g.set_option("kw_chunk_blocks", 0)
+        g.keep_result_ids(False)
+    # several query_by fields: the dropped token may sit in another field than the query's tokens
+    orc3, g3 = pair3
+    f3 = [(0, 15), (1, 7), (2, 3)]
+    qs = [T.KwQuery(req, fields=f3, sort=sort, topster_size=250, dropped_tokens=dr) for req, dr in (([1], [2]), ([2, 1], [3, 4]), ([5], [1]), ([3, 1, 2], [9]))]
+    qs += [T.KwQuery([1, 2], fields=f3, sort=sort, topster_size=30, dropped_tokens=[3], match_type=B.MAX_WEIGHT, filter_ids=np.arange(0, 2500, 2))]
+    h3 = g3.keyword_search_batch(qs, k_stride=250)
+    assert (h3.status == 0).all()
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(h3, i, H.oracle_keyword(orc3, q, ids_cap=4000), "dropped tokens, 3 fields q=%s+%s" % (q.tokens, q.dropped_tokens))

@@ -206,6 +206,8 @@ test_wildcard_search_ranks_filter_ids_by_sort_keys = EK.test_wildcard_search_ran
 test_edge_cases_empty_index_missing_tokens_and_degenerate_topsters = EK.test_edge_cases_empty_index_missing_tokens_and_degenerate_topsters
 test_candidate_combinations_fold_like_the_shared_topster_and_id_buff = EK.test_candidate_combinations_fold_like_the_shared_topster_and_id_buff
 test_two_kernel_form_and_fused_kernel_agree_with_the_oracle = EK.test_two_kernel_form_and_fused_kernel_agree_with_the_oracle
+test_dropped_tokens_are_scored_when_present_and_never_required = EK.test_dropped_tokens_are_scored_when_present_and_never_required
+test_pair_find_kernel_matches_the_oracle = EK.test_pair_find_kernel_matches_the_oracle
 
 
 def test_device_shard_merge_on_cuda_tensors(c100k):

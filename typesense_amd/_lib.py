@@ -32,7 +32,7 @@ class KwQueryC(C.Structure):
                 ("total_cost", C.c_uint32), ("n_sort", C.c_uint32), ("sort", SortBy * 3), ("topster_size", C.c_uint32),
                 ("excluded_ids", C.POINTER(C.c_uint32)), ("n_excluded", C.c_uint32),
                 ("filter_ids", C.POINTER(C.c_uint32)), ("n_filter", C.c_uint32),
-                ("deadline_us", C.c_uint64)]
+                ("deadline_us", C.c_uint64), ("n_dropped", C.c_uint32), ("dropped_term_ids", C.c_uint32 * 4)]
 
 
 class HitsC(C.Structure):

@@ -129,7 +129,8 @@ struct KwQueryDev {                  // one search_across_fields call
     uint32_t wild_n_ids;             // wildcard query (q = "*"): ids to scan = filter ids, or every seq_id < num_docs; 0 = keyword query
     uint64_t fbits_off;              // filtered multi-field query: word offset of its rank bitmap in IndexView::fbits
     uint32_t deadline_rem_us;        // microseconds this query may still run, counted from the batch's start stamp (0 = no deadline)
-    uint32_t pad2;
+    uint32_t n_required;             // lists [0, n_required) form the AND; lists [n_required, n_lists) are dropped tokens: scored when the document
+                                     // holds them, never required (compute_aggregated_score, src/index.cpp:5271-5290); multi-field form only
     uint32_t m_first, m_n;           // the sorted partial lists kw_merge_kernel folds: the work items themselves, or (many work items) the
                                      // group lists kw_merge_groups_kernel left behind them (counters always come from the work items)
 };
@@ -737,7 +738,16 @@ template <int TMAX>
 __device__ inline ScoredHit score_hit_mf(const IndexView& ix, const KwQueryDev& q, const KwQueryMF& mf, uint32_t seq_id,
                                          const uint32_t (&pos)[TMAX * KW_MAX_FIELDS]) {
     uint32_t off_words = 0;
-    const uint64_t agg = agg_score_mf<TMAX>(ix, q, mf, pos, q.n_lists, off_words);       // (the AND of the tokens: every token is in some field)
+    // query_len = tokens found in some field: every required token (the AND) + the dropped tokens this document holds (:5265-5290)
+    uint32_t tokens_found = q.n_required;
+#pragma unroll
+    for (int t = 0; t < TMAX; t++) {
+        bool any = false;
+#pragma unroll
+        for (int f = 0; f < KW_MAX_FIELDS; f++) any = any || pos[t * KW_MAX_FIELDS + f] != KW_NONE;
+        if ((uint32_t)t >= q.n_required && (uint32_t)t < q.n_lists && any) tokens_found++;
+    }
+    const uint64_t agg = agg_score_mf<TMAX>(ix, q, mf, pos, tokens_found, off_words);
     return sort_scores(ix, q, seq_id, agg, off_words);
 }
 
@@ -1546,7 +1556,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
                             pos[tt * KW_MAX_FIELDS + f] = p;
                         }
                     }
-                    ok = ok && any;
+                    ok = ok && (any || (uint32_t)tt >= q.n_required);      // (a dropped token is probed, not required)
                 }
             }
         }

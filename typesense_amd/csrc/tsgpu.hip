@@ -398,6 +398,11 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
         // the block-merge kernel stays free of the array code (it costs 2x the registers)
         bool multi = !wildcard && in.n_fields > 1;
         if (!wildcard && !multi && snap.field_is_array.at(in.field_ids[0])) multi = true;
+        // dropped tokens (drop_tokens passes): probed and scored per candidate, never required -> the general kernel
+        if (!wildcard && in.n_dropped != 0) {
+            if (in.n_dropped > TSGPU_MAX_DROPPED_TOKENS || in.n_tokens + in.n_dropped > TSGPU_MAX_QUERY_TOKENS) { unsupported("dropped tokens"); continue; }
+            multi = true;
+        }
         // filter ids with several query_by fields: num_keyword_matches has an order-free form only without exclusions (kw_score_stage)
         if (multi && in.n_filter != 0 && in.n_excluded != 0) { unsupported("filter ids AND excluded ids with several query_by fields"); continue; }
         if (in.n_sort > TSGPU_MAX_SORT_KEYS) { P.status[i] = TSGPU_ERR_INVALID; continue; }
@@ -479,6 +484,20 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
             len_of[nl] = (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFull);
             nl++;
         }
+        q.n_required = nl;
+        for (uint32_t t = 0; t < in.n_dropped && multi; t++) {        // after the query's own tokens, in their order (:5271-5290)
+            bool found = false;
+            for (uint32_t f = 0; f < in.n_fields; f++) {
+                const uint32_t handle = snap.find_handle(in.field_ids[f], in.dropped_term_ids[t]);
+                if (handle == 0xFFFFFFFFu) continue;
+                mfq.list[nl][f] = handle;
+                found = true;
+                P.list_bytes += 4ull * snap.h_lists[handle].n_ids;
+            }
+            if (!found) continue;                                     // an or_iterator without lists: skip_to() is false for every document
+            len_of[nl] = 0xFFFFFFFFu;
+            nl++;
+        }
         q.n_lists = nl;
         q.match_type = in.match_type;
         q.prio_exact = in.prioritize_exact_match ? 1 : 0;
@@ -502,11 +521,11 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
             P.aux.insert(P.aux.end(), in.excluded_ids, in.excluded_ids + in.n_excluded);
         }
         if (in.n_filter) P.aux.insert(P.aux.end(), in.filter_ids, in.filter_ids + in.n_filter);   // sorted ascending, unique (filter_result_t::docs)
-        if (nl == 0) continue;   // no token in the index: zero hits (intersect case 0, or_iterator.h:67-68)
+        if (q.n_required == 0) continue;   // no token in the index: zero hits (intersect case 0, or_iterator.h:67-68)
         if (multi) {
             // driver = the token with the fewest postings over all fields; one group of work items per field list of it
             uint32_t td = 0;
-            for (uint32_t t = 1; t < nl; t++) if (len_of[t] < len_of[td]) td = t;
+            for (uint32_t t = 1; t < q.n_required; t++) if (len_of[t] < len_of[td]) td = t;
             mfq.n_fields = in.n_fields;
             mfq.driver_token = td;
             for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.is_array[f] = f < in.n_fields && snap.field_is_array.at(in.field_ids[f]) ? 1 : 0;

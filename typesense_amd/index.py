@@ -25,8 +25,9 @@ class KwQuery:
     def __init__(self, tokens, field=0, weight=15, sort=((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, 1, 0)),
                  topster_size=0, match_type=B.MAX_SCORE, prioritize_exact_match=True, prioritize_token_position=False,
                  prioritize_num_matching_fields=True, total_cost=0, excluded_ids=None, filter_ids=None, deadline_us=0,
-                 n_fields=None, fields=None):
+                 n_fields=None, fields=None, dropped_tokens=()):
         self.tokens = list(tokens)
+        self.dropped_tokens = list(dropped_tokens)      # scored when present, never required (drop_tokens passes)
         self.field, self.weight, self.sort = field, weight, tuple(sort)     # sort: (kind, order, column)
         self.fields = [(int(f), int(w)) for f, w in fields] if fields else [(field, weight)]     # query_by fields: (field id, weight)
         self.topster_size = topster_size
@@ -64,6 +65,9 @@ class KwQuery:
             c.filter_ids = self.filter_ids.ctypes.data_as(C.POINTER(C.c_uint32))
             c.n_filter = self.filter_ids.size
         c.deadline_us = self.deadline_us
+        c.n_dropped = len(self.dropped_tokens)
+        for i, t in enumerate(self.dropped_tokens[:4]):
+            c.dropped_term_ids[i] = int(t)
 
 
 class Hits:
