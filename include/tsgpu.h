@@ -209,6 +209,11 @@ typedef struct tsgpu_kw_query {
                                                         :5271-5290: their postings join the field's tokens after the query's own, query_len counts them);
                                                         n_tokens + n_dropped <= TSGPU_MAX_QUERY_TOKENS. Such queries take the general (per-candidate
                                                         probe) kernel. */
+    /* synonym passes (the query is a synonym's expansion; src/index.cpp:5292-5294, 6989-6994, 7024-7060). All zero = not a synonym pass. */
+    uint8_t is_synonym_query;
+    uint8_t demote_synonym_match;
+    uint8_t syn_orig_num_tokens_p1;                  /* syn_orig_num_tokens + 1 (0 = the reference's -1: none) */
+    uint8_t orig_num_tokens;
 } tsgpu_kw_query;
 
 /* Results, structure-of-arrays, slot q*k_stride+i = i-th best hit of query q in Topster::sort() order

@@ -26,6 +26,7 @@ struct orc_kw_query {
     const uint32_t* filter_ids; uint32_t n_filter;
     uint32_t topster_size;   // 0 = reference rule
     const uint32_t* dropped_tokens; uint32_t n_dropped;
+    int32_t syn_orig_num_tokens, orig_num_tokens, is_synonym_query, demote_synonym_match;   // syn_orig_num_tokens: -1 = not a synonym pass
 };
 
 struct orc_result {
@@ -58,6 +59,8 @@ static keyword_query_t to_query(const orc_kw_query* q) {
     if (q->n_filter) k.filter_ids.assign(q->filter_ids, q->filter_ids + q->n_filter);
     k.topster_size = q->topster_size;
     if (q->n_dropped) k.dropped_tokens.assign(q->dropped_tokens, q->dropped_tokens + q->n_dropped);
+    k.syn_orig_num_tokens = q->syn_orig_num_tokens; k.orig_num_tokens = q->orig_num_tokens;
+    k.is_synonym_query = q->is_synonym_query != 0; k.demote_synonym_match = q->demote_synonym_match != 0;
     return k;
 }
 

@@ -13,7 +13,7 @@
 //   wildcard vector branch         : src/index.cpp:3645-3732
 //   hybrid rank fusion             : src/index.cpp:4036-4221 ; alpha default include/vector_query_ops.h:19
 // Terms are integer ids: the ART dictionary (token string -> posting pointer) is upstream of the
-// path and out of scope. Synonyms (syn_orig_num_tokens), typos>0, group-by, joins,
+// path and out of scope. typos>0, group-by, joins,
 // geo/str/eval sorts are not restated.
 //
 // Vector distance follows hnswlib's InnerProductSpace (typesense fork pinned at
@@ -89,6 +89,11 @@ struct keyword_query_t {
     uint64_t search_stop_us = UINT64_MAX;
     size_t topster_size = 0;                 // 0 = the reference's sizing rule; >0 = explicit Topster capacity (tests)
     std::vector<uint32_t> dropped_tokens;    // dropped_tokens of search_across_fields (index.cpp:5427-5464): scored when present, never required
+    // synonym passes (index.cpp:5292-5294, 6989-6994, 7024-7060): the query is a synonym's expansion
+    int syn_orig_num_tokens = -1;            // tokens of the phrase the synonym stands for (-1 = not a synonym pass)
+    int orig_num_tokens = 0;                 // tokens of the user's query
+    bool is_synonym_query = false;
+    bool demote_synonym_match = false;
 };
 
 struct keyword_result_t {
@@ -303,14 +308,17 @@ public:
 
     void score_results2(bool field_is_array, uint32_t total_cost, int64_t& match_score, uint32_t seq_id,
                         bool prioritize_exact_match, bool single_exact_query_token, bool prioritize_token_position,
+                        size_t num_query_tokens, int syn_orig_num_tokens, int orig_num_tokens, bool is_synonym_query, bool demote_synonym_match,
                         const std::vector<posting_list_t::iterator_t>& posting_lists) const {  // index.cpp:6966-7098
         if (posting_lists.size() <= 1) {
             const uint8_t is_verbatim = uint8_t(prioritize_exact_match && single_exact_query_token &&
                                                 posting_list_t::is_single_token_verbatim_match(posting_lists[0], field_is_array));
-            size_t words_present = 1, distance = 0;
+            size_t words_present = (num_query_tokens == 1 && is_synonym_query) ? syn_orig_num_tokens : 1;
+            size_t distance = (num_query_tokens == 1 && is_synonym_query) ? syn_orig_num_tokens - 1 : 0;
             size_t max_offset = prioritize_token_position ? posting_list_t::get_last_offset(posting_lists[0], field_is_array) : 255;
+            uint8_t synonym_score = (is_synonym_query && demote_synonym_match) ? 0 : 1;
             Match m((uint8_t)words_present, (uint8_t)distance, (uint8_t)max_offset, is_verbatim);
-            match_score = (int64_t)m.get_match_score(total_cost, (uint32_t)words_present, 1);
+            match_score = (int64_t)m.get_match_score(total_cost, (uint32_t)words_present, synonym_score);
             return;
         }
         std::map<size_t, std::vector<token_positions_t>> array_token_positions;
@@ -319,7 +327,8 @@ public:
             const std::vector<token_positions_t>& token_positions = kv.second;
             if (token_positions.empty()) continue;
             const Match match(seq_id, token_positions, false, prioritize_exact_match);
-            uint64_t s = match.get_match_score(total_cost, (uint32_t)posting_lists.size(), 1);
+            uint8_t synonym_score_in = (is_synonym_query && demote_synonym_match) ? 0 : 1;
+            uint64_t s = match.get_match_score(total_cost, (uint32_t)posting_lists.size(), synonym_score_in);
             auto this_words_present = ((s >> 40) & 0xFF);
             auto unique_words = field_is_array ? this_words_present : ((s >> 32) & 0xFF);
             auto typo_score = ((s >> 24) & 0xFF);
@@ -327,6 +336,29 @@ public:
             auto verbatim = ((s >> 12) & 0xF);
             auto offset_score = prioritize_token_position ? ((s >> 4) & 0xFF) : 0;
             auto synonym_score = ((s >> 0) & 0xF);
+            if (is_synonym_query && num_query_tokens == posting_lists.size()) {
+                unique_words = syn_orig_num_tokens;
+                this_words_present = syn_orig_num_tokens;
+            }
+            if (is_synonym_query && syn_orig_num_tokens > 0 && orig_num_tokens > 0) {
+                double rel_factor = double(orig_num_tokens) / double(syn_orig_num_tokens);
+                auto scale_component = [&](uint64_t v) -> uint64_t {
+                    double scaled = double(v) * rel_factor;
+                    if (scaled > 255.0) scaled = 255.0;
+                    return (uint64_t)scaled;
+                };
+                this_words_present = scale_component(this_words_present);
+                unique_words = scale_component(unique_words);
+                auto reversed_typo_score = 255 - typo_score;
+                reversed_typo_score = scale_component(reversed_typo_score);
+                typo_score = 255 - reversed_typo_score;
+                auto reversed_proximity = 100 - proximity;
+                reversed_proximity = scale_component(reversed_proximity);
+                proximity = 100 - reversed_proximity;
+                auto reversed_offset_score = 255 - offset_score;
+                reversed_offset_score = scale_component(reversed_offset_score);
+                offset_score = prioritize_token_position ? 255 - reversed_offset_score : 0;
+            }
             uint64_t mod = ((int64_t(this_words_present) << 40) | (int64_t(unique_words) << 32) | (int64_t(typo_score) << 24) |
                             (int64_t(proximity) << 16) | (int64_t(verbatim) << 12) | (int64_t(offset_score) << 4) |
                             (int64_t(synonym_score) << 0));
@@ -367,6 +399,7 @@ public:
                 if (found_token) query_len++;
             }
         }
+        if (q.syn_orig_num_tokens != -1) query_len = q.syn_orig_num_tokens;      // :5292-5294
         int64_t best_field_match_score = 0, best_field_weight = 0, sum_field_weighted_score = 0;
         uint32_t num_matching_fields = 0;
         for (size_t fi = 0; fi < field_to_tokens.size(); fi++) {
@@ -377,7 +410,8 @@ public:
             int64_t field_match_score = 0;
             bool single_exact_query_token = (q.total_cost == 0 && q.tokens.size() == 1);
             score_results2(field_is_array, q.total_cost, field_match_score, seq_id, q.prioritize_exact_match,
-                           single_exact_query_token, q.prioritize_token_position, token_postings);
+                           single_exact_query_token, q.prioritize_token_position, q.tokens.size(), q.syn_orig_num_tokens, q.orig_num_tokens,
+                           q.is_synonym_query, q.demote_synonym_match, token_postings);
             if (q.match_type == max_score && field_match_score > best_field_match_score) {
                 best_field_match_score = field_match_score; best_field_weight = field_weight;
             }
@@ -672,6 +706,7 @@ public:
             get_field_token_its(q, token_its, expanded_plists);
             keyword_query_t q0 = q;
             q0.total_cost = 0;                                                           // compute_aggregated_score(..., total_cost = 0, syn_orig_num_tokens = -1, ...)
+            q0.syn_orig_num_tokens = -1; q0.orig_num_tokens = (int)q.tokens.size(); q0.is_synonym_query = false; q0.demote_synonym_match = false;
             for (KV* kv : text_match_ids) {
                 const uint32_t seq_id = (uint32_t)kv->key;
                 for (size_t i = 0; i < token_its.size(); i++) token_its[i].skip_to(seq_id);

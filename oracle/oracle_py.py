@@ -31,7 +31,8 @@ class KwQuery(C.Structure):
                 ("fetch_size", C.c_uint32),
                 ("excluded_ids", C.POINTER(C.c_uint32)), ("n_excluded", C.c_uint32),
                 ("filter_ids", C.POINTER(C.c_uint32)), ("n_filter", C.c_uint32), ("topster_size", C.c_uint32),
-                ("dropped_tokens", C.POINTER(C.c_uint32)), ("n_dropped", C.c_uint32)]
+                ("dropped_tokens", C.POINTER(C.c_uint32)), ("n_dropped", C.c_uint32),
+                ("syn_orig_num_tokens", C.c_int32), ("orig_num_tokens", C.c_int32), ("is_synonym_query", C.c_int32), ("demote_synonym_match", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -215,8 +216,11 @@ class OracleIndex:
     # ---- query time ----
     def make_query(self, tokens, fields=((0, 15),), sort=((SORT_TEXT_MATCH, 0, 1), (SORT_SEQ_ID, 0, 1)), fetch_size=10,
                    match_type=MAX_SCORE, prioritize_exact_match=True, prioritize_token_position=False,
-                   prioritize_num_matching_fields=True, total_cost=0, excluded_ids=None, filter_ids=None, topster_size=0, dropped_tokens=None):
+                   prioritize_num_matching_fields=True, total_cost=0, excluded_ids=None, filter_ids=None, topster_size=0, dropped_tokens=None,
+                   syn_orig_num_tokens=-1, orig_num_tokens=0, is_synonym_query=False, demote_synonym_match=False):
         q = KwQuery()
+        q.syn_orig_num_tokens, q.orig_num_tokens = syn_orig_num_tokens, orig_num_tokens
+        q.is_synonym_query, q.demote_synonym_match = int(is_synonym_query), int(demote_synonym_match)
         keep = []
         t = _u32(tokens); keep.append(t)
         q.tokens = t.ctypes.data_as(C.POINTER(C.c_uint32)); q.n_tokens = t.size

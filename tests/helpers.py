@@ -91,7 +91,9 @@ def oracle_keyword(orc, q, cap=2048, ids_cap=0):
                         match_type=q.match_type, prioritize_exact_match=q.prioritize_exact_match,
                         prioritize_token_position=q.prioritize_token_position,
                         prioritize_num_matching_fields=q.prioritize_num_matching_fields, total_cost=q.total_cost,
-                        excluded_ids=q.excluded_ids, filter_ids=q.filter_ids, dropped_tokens=getattr(q, "dropped_tokens", None))
+                        excluded_ids=q.excluded_ids, filter_ids=q.filter_ids, dropped_tokens=getattr(q, "dropped_tokens", None), syn_orig_num_tokens=getattr(q, "syn_orig_num_tokens", -1),
+                        orig_num_tokens=getattr(q, "orig_num_tokens", 0), is_synonym_query=getattr(q, "is_synonym_query", False),
+                        demote_synonym_match=getattr(q, "demote_synonym_match", False))
     return orc.search_keyword(oq, cap=cap, ids_cap=ids_cap)
 
 
@@ -100,7 +102,9 @@ def oracle_query(orc, q):
                           topster_size=q.topster_size, match_type=q.match_type, prioritize_exact_match=q.prioritize_exact_match,
                           prioritize_token_position=q.prioritize_token_position,
                           prioritize_num_matching_fields=q.prioritize_num_matching_fields, total_cost=q.total_cost,
-                          excluded_ids=q.excluded_ids, filter_ids=q.filter_ids, dropped_tokens=getattr(q, "dropped_tokens", None))
+                          excluded_ids=q.excluded_ids, filter_ids=q.filter_ids, dropped_tokens=getattr(q, "dropped_tokens", None), syn_orig_num_tokens=getattr(q, "syn_orig_num_tokens", -1),
+                        orig_num_tokens=getattr(q, "orig_num_tokens", 0), is_synonym_query=getattr(q, "is_synonym_query", False),
+                        demote_synonym_match=getattr(q, "demote_synonym_match", False))
 
 
 def oracle_candidates(orc, combos, cap=2048, ids_cap=0):

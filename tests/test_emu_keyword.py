@@ -710,3 +710,35 @@ def test_dropped_tokens_are_scored_when_present_and_never_required(pair, pair3, 
     assert (h3.status == 0).all()
     for i, q in enumerate(qs):
         H.assert_hits_equal(h3, i, H.oracle_keyword(orc3, q, ids_cap=4000), "dropped tokens, 3 fields q=%s+%s" % (q.tokens, q.dropped_tokens))
+
+
+def test_synonym_passes_score_like_score_results2(pair, pair3):
+    """a synonym's expansion searched in place of the user's phrase (is_synonym_query, syn_orig_num_tokens, orig_num_tokens,
+    demote_synonym_match): query_len = syn_orig_num_tokens (src/index.cpp:5292-5294), the single-token fast path's words_present /
+    distance (:6989-6994), the synonym bit, words replaced by the phrase's length when every token matched and every component
+    rescaled by orig / syn tokens (:7024-7060)"""
+    orc, g, _ = pair
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    flags = [dict(is_synonym_query=True, syn_orig_num_tokens=2, orig_num_tokens=1), dict(is_synonym_query=True, syn_orig_num_tokens=1, orig_num_tokens=3),
+             dict(is_synonym_query=True, syn_orig_num_tokens=3, orig_num_tokens=2, demote_synonym_match=True), dict(is_synonym_query=True, syn_orig_num_tokens=4, orig_num_tokens=4),
+             dict(is_synonym_query=False, syn_orig_num_tokens=2, orig_num_tokens=2), dict(is_synonym_query=True, syn_orig_num_tokens=-1, orig_num_tokens=2)]
+    qs = []
+    for toks in ([1], [2, 1], [3, 1, 2], [1, 2, 3, 4]):
+        for fl in flags:
+            qs.append(T.KwQuery(toks, sort=sort, topster_size=250, **fl))
+            qs.append(T.KwQuery(toks, sort=sort, topster_size=60, prioritize_token_position=True, match_type=B.SUM_SCORE, **fl))
+    plain = g.keyword_search_batch([T.KwQuery([2, 1], sort=sort, topster_size=250)], k_stride=250)
+    hits = g.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all()
+    for i, q in enumerate(qs):
+        H.assert_hits_equal(hits, i, H.oracle_keyword(orc, q), "synonym pass q=%s %s" % (q.tokens, (q.is_synonym_query, q.syn_orig_num_tokens, q.orig_num_tokens, q.demote_synonym_match)))
+    n = int(plain.n_hits[0])
+    assert not np.array_equal(hits.scores[12, :n], plain.scores[0, :n])            # [2, 1] as a synonym pass scores differently
+    orc3, g3 = pair3
+    f3 = [(0, 15), (1, 7), (2, 3)]
+    q3 = [T.KwQuery(toks, fields=f3, sort=sort, topster_size=250, **fl) for toks in ([1], [2, 1], [3, 1, 2]) for fl in flags[:4]]
+    q3 += [T.KwQuery([2, 1], fields=f3, sort=sort, topster_size=250, dropped_tokens=[3], **flags[0])]
+    h3 = g3.keyword_search_batch(q3, k_stride=250)
+    assert (h3.status == 0).all()
+    for i, q in enumerate(q3):
+        H.assert_hits_equal(h3, i, H.oracle_keyword(orc3, q), "synonym pass, 3 fields q=%s" % q.tokens)

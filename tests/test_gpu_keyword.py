@@ -208,6 +208,7 @@ test_candidate_combinations_fold_like_the_shared_topster_and_id_buff = EK.test_c
 test_two_kernel_form_and_fused_kernel_agree_with_the_oracle = EK.test_two_kernel_form_and_fused_kernel_agree_with_the_oracle
 test_dropped_tokens_are_scored_when_present_and_never_required = EK.test_dropped_tokens_are_scored_when_present_and_never_required
 test_pair_find_kernel_matches_the_oracle = EK.test_pair_find_kernel_matches_the_oracle
+test_synonym_passes_score_like_score_results2 = EK.test_synonym_passes_score_like_score_results2
 
 
 def test_device_shard_merge_on_cuda_tensors(c100k):

@@ -32,7 +32,8 @@ class KwQueryC(C.Structure):
                 ("total_cost", C.c_uint32), ("n_sort", C.c_uint32), ("sort", SortBy * 3), ("topster_size", C.c_uint32),
                 ("excluded_ids", C.POINTER(C.c_uint32)), ("n_excluded", C.c_uint32),
                 ("filter_ids", C.POINTER(C.c_uint32)), ("n_filter", C.c_uint32),
-                ("deadline_us", C.c_uint64), ("n_dropped", C.c_uint32), ("dropped_term_ids", C.c_uint32 * 4)]
+                ("deadline_us", C.c_uint64), ("n_dropped", C.c_uint32), ("dropped_term_ids", C.c_uint32 * 4),
+                ("is_synonym_query", C.c_uint8), ("demote_synonym_match", C.c_uint8), ("syn_orig_num_tokens_p1", C.c_uint8), ("orig_num_tokens", C.c_uint8)]
 
 
 class HitsC(C.Structure):

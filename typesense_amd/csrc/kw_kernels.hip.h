@@ -131,6 +131,8 @@ struct KwQueryDev {                  // one search_across_fields call
     uint32_t deadline_rem_us;        // microseconds this query may still run, counted from the batch's start stamp (0 = no deadline)
     uint32_t n_required;             // lists [0, n_required) form the AND; lists [n_required, n_lists) are dropped tokens: scored when the document
                                      // holds them, never required (compute_aggregated_score, src/index.cpp:5271-5290); multi-field form only
+    int8_t syn_orig_num_tokens;      // synonym passes (src/index.cpp:5292-5294, 6989-6994, 7024-7060): -1 = not one
+    uint8_t orig_num_tokens, is_synonym, demote_synonym;
     uint32_t m_first, m_n;           // the sorted partial lists kw_merge_kernel folds: the work items themselves, or (many work items) the
                                      // group lists kw_merge_groups_kernel left behind them (counters always come from the work items)
 };
@@ -483,6 +485,37 @@ __device__ inline uint64_t pack_match_score(uint32_t words_present, uint32_t uni
 
 struct ScoredHit { int64_t s0, s1, s2; int64_t text_match; uint32_t off_words; };
 
+// the unpack / synonym adjustment / re-pack of score_results2's window loop (src/index.cpp:7031-7072); s = get_match_score of the window
+__device__ inline uint64_t repack_match_score(const KwQueryDev& q, uint64_t s, bool field_is_array, uint32_t n_posting_lists) {
+    uint64_t this_words_present = (s >> 40) & 0xFF;
+    uint64_t unique_words = field_is_array ? this_words_present : ((s >> 32) & 0xFF);
+    uint64_t typo_score = (s >> 24) & 0xFF, proximity = (s >> 16) & 0xFF;
+    const uint64_t verbatim = (s >> 12) & 0xF, synonym_score = s & 0xF;
+    uint64_t offset_score = q.prio_pos ? ((s >> 4) & 0xFF) : 0;
+    if (q.is_synonym) {
+        if (q.n_query_tokens == n_posting_lists) { unique_words = (uint64_t)(int64_t)q.syn_orig_num_tokens; this_words_present = unique_words; }
+        if (q.syn_orig_num_tokens > 0 && q.orig_num_tokens > 0) {
+            const double rel_factor = (double)q.orig_num_tokens / (double)q.syn_orig_num_tokens;
+            auto scale = [&](uint64_t v) -> uint64_t { double sc = (double)v * rel_factor; if (sc > 255.0) sc = 255.0; return (uint64_t)sc; };
+            this_words_present = scale(this_words_present);
+            unique_words = scale(unique_words);
+            typo_score = 255 - scale(255 - typo_score);
+            proximity = 100 - scale(100 - proximity);
+            offset_score = q.prio_pos ? 255 - scale(255 - offset_score) : 0;
+        }
+    }
+    return ((uint64_t)(int64_t)this_words_present << 40) | ((uint64_t)(int64_t)unique_words << 32) | ((uint64_t)(int64_t)typo_score << 24) |
+           ((uint64_t)(int64_t)proximity << 16) | (verbatim << 12) | ((uint64_t)(int64_t)offset_score << 4) | synonym_score;
+}
+// the single-token fast path's packing (:6985-6996)
+__device__ inline uint64_t single_token_match_score(const KwQueryDev& q, uint32_t verbatim, uint32_t max_offset) {
+    const bool syn1 = q.n_query_tokens == 1 && q.is_synonym;
+    const uint32_t words_present = syn1 ? (uint32_t)(uint8_t)q.syn_orig_num_tokens : 1u;                  // Match(uint8_t words_present, ...)
+    const uint32_t distance = syn1 ? (uint32_t)(uint8_t)(q.syn_orig_num_tokens - 1) : 0u;
+    const uint32_t synonym_score = (q.is_synonym && q.demote_synonym) ? 0u : 1u;
+    return pack_match_score(words_present, words_present, q.total_cost, distance, verbatim, max_offset, synonym_score);
+}
+
 // score_results2 (src/index.cpp:6966-7098) for ONE plain-string field: `runs[0..n_present)` = the occurrences of the query tokens
 // that this field holds for the document, in query-token order (field_to_tokens[fi], src/index.cpp:5250-5265)
 template <int TMAX>
@@ -500,16 +533,11 @@ __device__ inline uint64_t field_match_score(const KwQueryDev& q, const TokRun (
             const uint32_t lastv = run_raw(r, run_raw_len(r) - 1);
             max_offset = (lastv == 0 ? run_raw(r, run_raw_len(r) - 2) : lastv) & 0xFF;
         }
-        return pack_match_score(1, 1, q.total_cost, 0, verbatim, max_offset, 1);
+        return single_token_match_score(q, verbatim, max_offset);
     }
     const MatchOut m = match_window<TMAX>(runs, n_present, q.prio_exact != 0);
-    const uint64_t s = pack_match_score(m.words_present, n_present, q.total_cost, m.distance, m.exact_match, m.max_offset, 1);
-    // unpack / re-pack of src/index.cpp:7031-7072 (no synonyms): offset component kept only if prioritize_token_position
-    const uint64_t this_words_present = (s >> 40) & 0xFF, unique_words = (s >> 32) & 0xFF, typo_score = (s >> 24) & 0xFF;
-    const uint64_t proximity = (s >> 16) & 0xFF, verbatim = (s >> 12) & 0xF;
-    const uint64_t offset_score = q.prio_pos ? ((s >> 4) & 0xFF) : 0, synonym_score = s & 0xF;
-    return (this_words_present << 40) | (unique_words << 32) | (typo_score << 24) | (proximity << 16) |
-           (verbatim << 12) | (offset_score << 4) | synonym_score;
+    const uint64_t s = pack_match_score(m.words_present, n_present, q.total_cost, m.distance, m.exact_match, m.max_offset, (q.is_synonym && q.demote_synonym) ? 0u : 1u);
+    return repack_match_score(q, s, false, n_present);
 }
 
 __device__ inline TokRun empty_run() { TokRun r; r.w = nullptr; r.start = 0; r.n = 0; r.base = 0; r.raw_len = 0; r.meta = 0; r.c01 = 0; return r; }
@@ -591,7 +619,7 @@ __device__ inline uint64_t field_match_score_array(const KwQueryDev& q, const To
         const bool single_exact_query_token = (q.total_cost == 0 && q.n_query_tokens == 1);
         const uint32_t verbatim = (q.prio_exact && single_exact_query_token) ? arr_single_verbatim(r) : 0u;
         const uint32_t max_offset = q.prio_pos ? (arr_last_offset(r) & 0xFF) : 255u;
-        return pack_match_score(1, 1, q.total_cost, 0, verbatim, max_offset, 1);
+        return single_token_match_score(q, verbatim, max_offset);
     }
     ArrCursor cur[TMAX];
     ArrElem el[TMAX];
@@ -624,12 +652,8 @@ __device__ inline uint64_t field_match_score_array(const KwQueryDev& q, const To
             }
         }
         const MatchOut mo = match_window<TMAX>(sub, m, q.prio_exact != 0);
-        const uint64_t s = pack_match_score(mo.words_present, n_present, q.total_cost, mo.distance, mo.exact_match, mo.max_offset, 1);
-        const uint64_t this_words_present = (s >> 40) & 0xFF, unique_words = this_words_present /* array field, :7041 */, typo_score = (s >> 24) & 0xFF;
-        const uint64_t proximity = (s >> 16) & 0xFF, verbatim = (s >> 12) & 0xF;
-        const uint64_t offset_score = q.prio_pos ? ((s >> 4) & 0xFF) : 0, synonym_score = s & 0xF;
-        const uint64_t mod = (this_words_present << 40) | (unique_words << 32) | (typo_score << 24) | (proximity << 16) |
-                             (verbatim << 12) | (offset_score << 4) | synonym_score;
+        const uint64_t s = pack_match_score(mo.words_present, n_present, q.total_cost, mo.distance, mo.exact_match, mo.max_offset, (q.is_synonym && q.demote_synonym) ? 0u : 1u);
+        const uint64_t mod = repack_match_score(q, s, true /* array field: unique_words = this_words_present, :7041 */, n_present);
         if (mod > best) best = mod;
     }
     return best;
@@ -645,6 +669,7 @@ __device__ inline void agg_add(AggState& st, uint32_t match_type, uint64_t field
     st.n_fields++;
 }
 __device__ inline uint64_t agg_finish(const AggState& st, const KwQueryDev& q, uint32_t tokens_found) {
+    if (q.syn_orig_num_tokens != -1) tokens_found = (uint32_t)(int32_t)q.syn_orig_num_tokens;       // :5292-5294 (size_t query_len = int)
     const uint64_t query_len = (st.best_fms == 0) ? 0 : (tokens_found < 15 ? tokens_found : 15);
     const uint64_t max_field_weight = (uint64_t)st.best_w < 15 ? (uint64_t)st.best_w : 15;   // std::min<size_t>(15, w)
     const uint64_t num_matching_fields = q.prio_nfields ? (st.n_fields < 7 ? st.n_fields : 7) : 0;

@@ -505,6 +505,8 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
         q.prio_nfields = in.prioritize_num_matching_fields ? 1 : 0;
         q.total_cost = in.total_cost;
         q.weight = in.field_weights[0];
+        q.syn_orig_num_tokens = (int8_t)((int)in.syn_orig_num_tokens_p1 - 1);
+        q.orig_num_tokens = in.orig_num_tokens; q.is_synonym = in.is_synonym_query ? 1 : 0; q.demote_synonym = in.demote_synonym_match ? 1 : 0;
         q.n_sort = (uint8_t)in.n_sort;
         if (in.n_sort > 2) P.any_s2 = true;
         for (uint32_t s = 0; s < in.n_sort; s++) {
@@ -1216,7 +1218,8 @@ int tsgpu_keyword_aux_scores(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint
             q.n_query_tokens = in.n_tokens;
             q.match_type = in.match_type;
             q.prio_exact = in.prioritize_exact_match; q.prio_pos = in.prioritize_token_position; q.prio_nfields = in.prioritize_num_matching_fields;
-            q.total_cost = 0;                                    // compute_aux_scores passes total_cost = 0 (src/index.cpp:8829)
+            q.total_cost = 0;                                    // compute_aux_scores passes total_cost = 0, syn_orig_num_tokens = -1, no synonym flags (src/index.cpp:8826-8835)
+            q.syn_orig_num_tokens = -1;
             q.weight = in.field_weights[0];
             q.mf_index = i;
         }

@@ -25,9 +25,12 @@ class KwQuery:
     def __init__(self, tokens, field=0, weight=15, sort=((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, 1, 0)),
                  topster_size=0, match_type=B.MAX_SCORE, prioritize_exact_match=True, prioritize_token_position=False,
                  prioritize_num_matching_fields=True, total_cost=0, excluded_ids=None, filter_ids=None, deadline_us=0,
-                 n_fields=None, fields=None, dropped_tokens=()):
+                 n_fields=None, fields=None, dropped_tokens=(), syn_orig_num_tokens=-1, orig_num_tokens=0, is_synonym_query=False,
+                 demote_synonym_match=False):
         self.tokens = list(tokens)
         self.dropped_tokens = list(dropped_tokens)      # scored when present, never required (drop_tokens passes)
+        self.syn_orig_num_tokens, self.orig_num_tokens = syn_orig_num_tokens, orig_num_tokens       # synonym passes
+        self.is_synonym_query, self.demote_synonym_match = is_synonym_query, demote_synonym_match
         self.field, self.weight, self.sort = field, weight, tuple(sort)     # sort: (kind, order, column)
         self.fields = [(int(f), int(w)) for f, w in fields] if fields else [(field, weight)]     # query_by fields: (field id, weight)
         self.topster_size = topster_size
@@ -65,6 +68,8 @@ class KwQuery:
             c.filter_ids = self.filter_ids.ctypes.data_as(C.POINTER(C.c_uint32))
             c.n_filter = self.filter_ids.size
         c.deadline_us = self.deadline_us
+        c.is_synonym_query, c.demote_synonym_match = int(self.is_synonym_query), int(self.demote_synonym_match)
+        c.syn_orig_num_tokens_p1, c.orig_num_tokens = self.syn_orig_num_tokens + 1, self.orig_num_tokens
         c.n_dropped = len(self.dropped_tokens)
         for i, t in enumerate(self.dropped_tokens[:4]):
             c.dropped_term_ids[i] = int(t)
