@@ -253,6 +253,11 @@ def test_hybrid_rank_fusion_matches_oracle_bit_exactly():
         assert np.array_equal(hits.scores[i, :n], ref.scores)                       # fused score BITS identical
         assert np.array_equal(hits.text_match[i, :n], ref.text_match)
         assert np.allclose(hits.vector_distance[i, :n], ref.vector_distance, rtol=RTOL, atol=RTOL)
+    # a batch large enough for the fusion to spread over the parked host threads: every query's slice is what it was alone
+    big = g.hybrid_search_batch(qs * 4, 1, np.tile(Q, (4, 1)), k=0, fetch_size=10, alpha=0.3, k_stride=250)
+    for j in range(24):
+        n = int(hits.n_hits[j % 6])
+        assert int(big.n_hits[j]) == n and np.array_equal(big.keys[j, :n], hits.keys[j % 6, :n]) and np.array_equal(big.scores[j, :n], hits.scores[j % 6, :n])
     g.close()
 
 

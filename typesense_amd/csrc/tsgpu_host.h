@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <functional>
 #include <vector>
 #include <mutex>
 #include <condition_variable>
@@ -219,7 +220,52 @@ struct tsgpu_id_lists {
     std::vector<uint32_t> ids;                       // ascending per query
 };
 
+// a few parked host threads for per-query host work of a batch (hybrid rank fusion): starting 16 std::threads per call cost more than
+// the fusion of 256 queries itself
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    const std::function<void()>* job = nullptr;
+    uint64_t gen = 0;
+    int want = 0, pending = 0;
+    bool stop = false;
+    void worker(int idx) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void()>* j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || (gen != seen && idx < want); });
+                if (stop) return;
+                seen = gen;
+                j = job;
+            }
+            (*j)();
+            { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) done_cv.notify_all(); }
+        }
+    }
+    // runs f on `helpers` pool threads and on the caller; returns when all are done. One call at a time (callers serialise on run_mu).
+    std::mutex run_mu;
+    void run(const std::function<void()>& f, int helpers) {
+        std::lock_guard<std::mutex> rl(run_mu);
+        try { while ((int)th.size() < helpers) { const int idx = (int)th.size(); th.emplace_back([this, idx] { worker(idx); }); } } catch (...) { helpers = (int)th.size(); }
+        { std::lock_guard<std::mutex> lk(mu); job = &f; want = helpers; pending = helpers; gen++; }
+        cv.notify_all();
+        f();
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return pending == 0; });
+        job = nullptr; want = 0;
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+
 struct tsgpu_ctx {
+    HostPool host_pool;
     static const int N_LANES = 8;                    // lanes that exist; `n_lanes` of them are used (option "kw_lanes")
     int n_lanes = 4;
     int device = 0;
@@ -271,6 +317,7 @@ struct tsgpu_ctx {
     uint32_t vec_cand_cap = 0;                       // candidate slots per query in pass 2 (0 = automatic)
     uint32_t vec_prefilter = 1;                      // 1 = bf16 bracket scan + exact fp32 re-score (default); 0 = fp32 MFMA scan
     uint64_t vec_prefilter_groups = 0;               // query groups answered by the bf16 bracket path
+    int fuse_threads = 16;                            // host threads of the hybrid rank fusion (option "fuse_threads")
     uint64_t hnsw_last_expansions = 0, hnsw_last_distances = 0;   // last HNSW batch: candidates expanded / distances computed at layer 0 (all queries)
     uint64_t vec_rescored_rows = 0;                  // survivors re-scored in fp32 by the last prefilter group (sum over its queries; 0 unless vec_count_rescored)
     uint32_t vec_count_rescored = 0;

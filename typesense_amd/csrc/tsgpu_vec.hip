@@ -1007,14 +1007,9 @@ int tsgpu_hybrid_fuse_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const
         } catch (const std::bad_alloc&) { oom = 1; }
     };
     const uint32_t hw = std::max(1u, std::thread::hardware_concurrency());
-    const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(hw, 16), std::max<uint32_t>(1, n_queries / 8));
+    const uint32_t n_threads = std::min<uint32_t>(std::min<uint32_t>(hw, (uint32_t)ctx->fuse_threads), std::max<uint32_t>(1, n_queries / 8));
     if (n_threads <= 1) worker();
-    else {
-        std::vector<std::thread> pool;
-        try { for (uint32_t i = 1; i < n_threads; i++) pool.emplace_back(worker); } catch (...) {}
-        worker();
-        for (auto& th : pool) th.join();
-    }
+    else ctx->host_pool.run(worker, (int)n_threads - 1);          // parked pool threads + this one
     if (oom) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_hybrid_fuse_batch: host allocation failed");
     return ok();
 }
