@@ -742,3 +742,56 @@ def test_synonym_passes_score_like_score_results2(pair, pair3):
     assert (h3.status == 0).all()
     for i, q in enumerate(q3):
         H.assert_hits_equal(h3, i, H.oracle_keyword(orc3, q), "synonym pass, 3 fields q=%s" % q.tokens)
+
+
+def test_parallel_planning_of_a_batch_gives_the_serial_plan(pair, pair3):
+    """big batches are planned in slices on the context's parked host threads (plan_threads / plan_parallel_min_queries); the slices'
+    arenas (excluded / filter ids, multi-field descriptors, id segments, rank bitmaps, work items) are concatenated and every query's
+    offsets shifted: results, counts and matched ids must equal the serial plan's for a batch that mixes every kind of query"""
+    orc, g, _ = pair
+    rng = np.random.default_rng(321)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    qs = []
+    for rep in range(40):
+        toks = rng.choice(np.arange(1, 30), size=int(rng.integers(1, 5)), replace=False)
+        kind = rep % 5
+        if kind == 0: qs.append(T.KwQuery(toks, sort=sort, topster_size=250))
+        elif kind == 1: qs.append(T.KwQuery(toks, sort=sort, topster_size=40, filter_ids=np.sort(rng.choice(3000, size=700, replace=False))))
+        elif kind == 2: qs.append(T.KwQuery(toks, sort=sort, topster_size=250, excluded_ids=np.arange(int(rng.integers(0, 5)), 3000, 5)))
+        elif kind == 3: qs.append(T.KwQuery(toks[:2], sort=sort, topster_size=250, dropped_tokens=[int(rng.integers(30, 60))]))
+        else: qs.append(T.KwQuery(list(range(1, 13)), sort=sort) if rep == 4 else T.KwQuery(toks, sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=17))
+    g.keep_result_ids(True)
+    try:
+        serial = g.keyword_search_batch(qs, k_stride=250)
+        ids_s = [g.result_ids(i) if serial.status[i] == 0 else None for i in range(len(qs))]
+        g.set_option("plan_parallel_min_queries", 1)
+        g.set_option("plan_threads", 5)
+        par = g.keyword_search_batch(qs, k_stride=250)
+        assert np.array_equal(par.status, serial.status) and (serial.status == 0).sum() >= 38
+        for i in range(len(qs)):
+            if serial.status[i] != 0:
+                continue
+            n = int(serial.n_hits[i])
+            assert par.n_hits[i] == n and par.num_matched[i] == serial.num_matched[i]
+            assert np.array_equal(par.keys[i, :n], serial.keys[i, :n]) and np.array_equal(par.scores[i, :n], serial.scores[i, :n])
+            assert np.array_equal(g.result_ids(i), ids_s[i])
+    finally:
+        g.set_option("plan_parallel_min_queries", 2048)
+        g.set_option("plan_threads", 8)
+        g.keep_result_ids(False)
+    orc3, g3 = pair3
+    f3 = [(0, 15), (1, 7), (2, 3)]
+    q3 = []
+    for rep in range(24):
+        toks = rng.choice(np.arange(1, 20), size=int(rng.integers(1, 4)), replace=False)
+        q3.append(T.KwQuery(toks, fields=f3, sort=sort, topster_size=250, filter_ids=np.sort(rng.choice(2500, size=600, replace=False)) if rep % 3 == 0 else None))
+    s3 = g3.keyword_search_batch(q3, k_stride=250)
+    g3.set_option("plan_parallel_min_queries", 1)
+    try:
+        p3 = g3.keyword_search_batch(q3, k_stride=250)
+    finally:
+        g3.set_option("plan_parallel_min_queries", 2048)
+    for i in range(len(q3)):
+        n = int(s3.n_hits[i])
+        assert p3.n_hits[i] == n and p3.num_matched[i] == s3.num_matched[i] and np.array_equal(p3.keys[i, :n], s3.keys[i, :n]) and np.array_equal(p3.scores[i, :n], s3.scores[i, :n])
+        H.assert_hits_equal(p3, i, H.oracle_keyword(orc3, q3[i]), "parallel plan, 3 fields")

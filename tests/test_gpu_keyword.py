@@ -209,6 +209,7 @@ test_two_kernel_form_and_fused_kernel_agree_with_the_oracle = EK.test_two_kernel
 test_dropped_tokens_are_scored_when_present_and_never_required = EK.test_dropped_tokens_are_scored_when_present_and_never_required
 test_pair_find_kernel_matches_the_oracle = EK.test_pair_find_kernel_matches_the_oracle
 test_synonym_passes_score_like_score_results2 = EK.test_synonym_passes_score_like_score_results2
+test_parallel_planning_of_a_batch_gives_the_serial_plan = EK.test_parallel_planning_of_a_batch_gives_the_serial_plan
 
 
 def test_device_shard_merge_on_cuda_tensors(c100k):

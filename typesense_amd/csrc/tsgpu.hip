@@ -230,6 +230,8 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_sort_work")) { ctx->kw_sort_work = value != 0; return ok(); }
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
     if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
+    if (!strcmp(name, "plan_threads")) { if (value < 1 || value > 64) return fail(TSGPU_ERR_INVALID, "plan_threads: 1..64"); ctx->plan_threads = (int)value; return ok(); }
+    if (!strcmp(name, "plan_parallel_min_queries")) { if (value < 0) return fail(TSGPU_ERR_INVALID, "plan_parallel_min_queries >= 0"); ctx->plan_parallel_min_queries = (uint32_t)value; return ok(); }
     if (!strcmp(name, "fuse_threads")) { if (value < 1 || value > 256) return fail(TSGPU_ERR_INVALID, "fuse_threads: 1..256"); ctx->fuse_threads = (int)value; return ok(); }
     if (!strcmp(name, "kw_hit_buffer_records")) {       // exact budget in hit records (tests); 0 = use kw_hit_buffer_mb
         if (value < 0) return fail(TSGPU_ERR_INVALID, "kw_hit_buffer_records must be >= 0");
@@ -376,220 +378,272 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
     P.status.assign(n_queries, TSGPU_OK);
     P.cutoff.assign(n_queries, 0);
     const uint64_t now = now_us();
-    std::vector<KwWorkItem> flat_work;                       // every query's items, contiguous, in query order
-    flat_work.reserve((size_t)n_queries * 4);
     std::vector<uint32_t> q_begin(n_queries, 0), q_cnt(n_queries, 0);
     std::vector<double> item_cost(n_queries, 0.0);
-    for (uint32_t i = 0; i < n_queries; i++) {
-        const tsgpu_kw_query& in = queries[i];
-        KwQueryDev& q = P.q[i];
-        memset(&q, 0, sizeof q);
-        q.k = 1;
-        auto unsupported = [&](const char*) { P.status[i] = TSGPU_ERR_UNSUPPORTED; };
-        if (!wildcard && (in.n_tokens == 0 || in.n_tokens > TSGPU_MAX_QUERY_TOKENS)) { unsupported("tokens"); continue; }
-        if (!wildcard && (in.n_fields == 0 || in.n_fields > (uint32_t)KW_MAX_FIELDS)) { unsupported("fields"); continue; }
-        if (!wildcard) {
-            int bad = 0;
-            for (uint32_t f = 0; f < in.n_fields && !bad; f++) {
-                if (snap.field_is_array.find(in.field_ids[f]) == snap.field_is_array.end()) bad = TSGPU_ERR_NOT_FOUND;
+    // The per-query part of the plan (handles, work items, id arenas) is independent per query: big batches are planned in slices on
+    // the context's parked host threads, every slice into its own accumulator; the slices are then concatenated in query order and the
+    // offsets a query holds into the shared arenas shifted by its slice's base (0.5 ms -> 0.1 ms of a 9 ms step at 10 000 queries).
+    struct PlanAcc {
+        std::vector<uint32_t> aux; std::vector<KwQueryMF> mf; std::vector<KwWorkItem> flat_work;
+        uint64_t fbits_words = 0, ids_total = 0, list_bytes = 0;
+        uint32_t max_k = 0, n_numeric_sort_q = 0;
+        bool any_deadline = false, any_s2 = false;
+    };
+    auto plan_range = [&](uint32_t lo, uint32_t hi, PlanAcc& A) {
+        A.flat_work.reserve((size_t)(hi - lo) * 4);
+        for (uint32_t i = lo; i < hi; i++) {
+            const tsgpu_kw_query& in = queries[i];
+            KwQueryDev& q = P.q[i];
+            memset(&q, 0, sizeof q);
+            q.k = 1;
+            auto unsupported = [&](const char*) { P.status[i] = TSGPU_ERR_UNSUPPORTED; };
+            if (!wildcard && (in.n_tokens == 0 || in.n_tokens > TSGPU_MAX_QUERY_TOKENS)) { unsupported("tokens"); continue; }
+            if (!wildcard && (in.n_fields == 0 || in.n_fields > (uint32_t)KW_MAX_FIELDS)) { unsupported("fields"); continue; }
+            if (!wildcard) {
+                int bad = 0;
+                for (uint32_t f = 0; f < in.n_fields && !bad; f++) {
+                    if (snap.field_is_array.find(in.field_ids[f]) == snap.field_is_array.end()) bad = TSGPU_ERR_NOT_FOUND;
+                }
+                if (bad) { P.status[i] = bad; continue; }
             }
-            if (bad) { P.status[i] = bad; continue; }
-        }
-        // several fields, or a string[] field: the general kernel (per-candidate probes, per-field scoring incl. the array readers);
-        // the block-merge kernel stays free of the array code (it costs 2x the registers)
-        bool multi = !wildcard && in.n_fields > 1;
-        if (!wildcard && !multi && snap.field_is_array.at(in.field_ids[0])) multi = true;
-        // dropped tokens (drop_tokens passes): probed and scored per candidate, never required -> the general kernel
-        if (!wildcard && in.n_dropped != 0) {
-            if (in.n_dropped > TSGPU_MAX_DROPPED_TOKENS || in.n_tokens + in.n_dropped > TSGPU_MAX_QUERY_TOKENS) { unsupported("dropped tokens"); continue; }
-            multi = true;
-        }
-        // filter ids with several query_by fields: num_keyword_matches has an order-free form only without exclusions (kw_score_stage)
-        if (multi && in.n_filter != 0 && in.n_excluded != 0) { unsupported("filter ids AND excluded ids with several query_by fields"); continue; }
-        if (in.n_sort > TSGPU_MAX_SORT_KEYS) { P.status[i] = TSGPU_ERR_INVALID; continue; }
-        if (in.n_filter != 0 && !in.filter_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
-        if (in.match_type > TSGPU_SUM_SCORE) { P.status[i] = TSGPU_ERR_INVALID; continue; }
-        bool bad_sort = false;
-        for (uint32_t s = 0; s < in.n_sort; s++) {
-            if (in.sort[s].kind > TSGPU_SORT_INT64_COLUMN) bad_sort = true;   // vector_distance belongs to the vector/hybrid entry points
-            if (in.sort[s].kind == TSGPU_SORT_INT64_COLUMN && in.sort[s].column >= ctx->columns.size()) bad_sort = true;
-            if (in.sort[s].order != 1 && in.sort[s].order != -1) bad_sort = true;
-        }
-        if (bad_sort) { unsupported("sort"); continue; }
-        const uint32_t k = resolve_topster_size(ctx, in);
-        if (k > TSGPU_MAX_TOPK) { unsupported("topster_size"); continue; }
-        if (in.deadline_us != 0 && now > in.deadline_us) { P.status[i] = TSGPU_ERR_DEADLINE; P.cutoff[i] = 1; continue; }
-        if (in.deadline_us != 0) { q.deadline_rem_us = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.deadline_us - now, 1), 0xFFFFFFFFull); P.any_deadline = true; }
+            // several fields, or a string[] field: the general kernel (per-candidate probes, per-field scoring incl. the array readers);
+            // the block-merge kernel stays free of the array code (it costs 2x the registers)
+            bool multi = !wildcard && in.n_fields > 1;
+            if (!wildcard && !multi && snap.field_is_array.at(in.field_ids[0])) multi = true;
+            // dropped tokens (drop_tokens passes): probed and scored per candidate, never required -> the general kernel
+            if (!wildcard && in.n_dropped != 0) {
+                if (in.n_dropped > TSGPU_MAX_DROPPED_TOKENS || in.n_tokens + in.n_dropped > TSGPU_MAX_QUERY_TOKENS) { unsupported("dropped tokens"); continue; }
+                multi = true;
+            }
+            // filter ids with several query_by fields: num_keyword_matches has an order-free form only without exclusions (kw_score_stage)
+            if (multi && in.n_filter != 0 && in.n_excluded != 0) { unsupported("filter ids AND excluded ids with several query_by fields"); continue; }
+            if (in.n_sort > TSGPU_MAX_SORT_KEYS) { P.status[i] = TSGPU_ERR_INVALID; continue; }
+            if (in.n_filter != 0 && !in.filter_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
+            if (in.match_type > TSGPU_SUM_SCORE) { P.status[i] = TSGPU_ERR_INVALID; continue; }
+            bool bad_sort = false;
+            for (uint32_t s = 0; s < in.n_sort; s++) {
+                if (in.sort[s].kind > TSGPU_SORT_INT64_COLUMN) bad_sort = true;   // vector_distance belongs to the vector/hybrid entry points
+                if (in.sort[s].kind == TSGPU_SORT_INT64_COLUMN && in.sort[s].column >= ctx->columns.size()) bad_sort = true;
+                if (in.sort[s].order != 1 && in.sort[s].order != -1) bad_sort = true;
+            }
+            if (bad_sort) { unsupported("sort"); continue; }
+            const uint32_t k = resolve_topster_size(ctx, in);
+            if (k > TSGPU_MAX_TOPK) { unsupported("topster_size"); continue; }
+            if (in.deadline_us != 0 && now > in.deadline_us) { P.status[i] = TSGPU_ERR_DEADLINE; P.cutoff[i] = 1; continue; }
+            if (in.deadline_us != 0) { q.deadline_rem_us = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.deadline_us - now, 1), 0xFFFFFFFFull); A.any_deadline = true; }
 
-        if (wildcard) {
-            // Index::search_wildcard (src/index.cpp:6616-6818): rank every filter id (every seq_id without a filter) by its sort keys
+            if (wildcard) {
+                // Index::search_wildcard (src/index.cpp:6616-6818): rank every filter id (every seq_id without a filter) by its sort keys
+                q.mf_index = KW_NONE;
+                q.n_sort = (uint8_t)in.n_sort;
+                for (uint32_t s = 0; s < in.n_sort; s++) {
+                    q.sort_kind[s] = in.sort[s].kind; q.sort_order[s] = in.sort[s].order; q.sort_col[s] = in.sort[s].column;
+                    if (in.sort[s].kind == TSGPU_SORT_INT64_COLUMN) A.n_numeric_sort_q++;
+                }
+                q.k = k;
+                A.max_k = std::max(A.max_k, k);
+                q.aux_off = (uint32_t)A.aux.size();
+                q.n_excl = in.n_excluded;
+                q.n_filt = in.n_filter;
+                if (in.n_excluded) {
+                    if (!in.excluded_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
+                    A.aux.insert(A.aux.end(), in.excluded_ids, in.excluded_ids + in.n_excluded);
+                }
+                if (in.n_filter) A.aux.insert(A.aux.end(), in.filter_ids, in.filter_ids + in.n_filter);
+                const uint32_t n_ids = in.n_filter ? in.n_filter : ctx->num_docs;
+                q.wild_n_ids = n_ids;
+                uint32_t n_num = 0;
+                for (uint32_t s = 0; s < in.n_sort; s++) n_num += in.sort[s].kind == TSGPU_SORT_INT64_COLUMN;
+                A.list_bytes += 4ull * in.n_filter + 8ull * n_ids * n_num;      // the id array + one column value per id and numeric key
+                q.ids_out_off = A.ids_total;
+                const uint32_t n_blocks = (n_ids + BLOCK_IDS - 1) / BLOCK_IDS;
+                if (keep_ids) A.ids_total += (uint64_t)n_blocks * BLOCK_IDS;
+                const uint32_t WCHUNK = 64;                                     // 16K ids per work item
+                for (uint32_t b = 0; b < n_blocks; b += WCHUNK) {
+                    KwWorkItem w;
+                    w.query = i; w.blk_begin = b; w.blk_end = std::min(n_blocks, b + WCHUNK); w.ids_out_off = b * BLOCK_IDS;
+                    { if (q_cnt[i] == 0) q_begin[i] = (uint32_t)A.flat_work.size(); A.flat_work.push_back(w); q_cnt[i]++; }
+                }
+                continue;
+            }
+
+            q.n_query_tokens = in.n_tokens;
             q.mf_index = KW_NONE;
+            uint32_t nl = 0;
+            uint32_t len_of[KW_MAX_TOKENS];
+            KwQueryMF mfq;
+            if (multi) memset(&mfq, 0xFF, sizeof mfq);                // (only read by the multi-field form)
+            for (uint32_t t = 0; t < in.n_tokens; t++) {
+                // one or_iterator per token = the union of its lists over the fields; a token found in no field is skipped (src/index.cpp:5651-5655)
+                uint64_t tot = 0;
+                bool found = false;
+                for (uint32_t f = 0; f < in.n_fields; f++) {
+                    uint32_t handle;
+                    if (cached[i]) {                     // (n_fields == 1)
+                        handle = handle_cache[(size_t)i * TSGPU_MAX_QUERY_TOKENS + t];
+                        if (handle == KW_NONE - 1) continue;
+                    } else {
+                        handle = snap.find_handle(in.field_ids[f], in.term_ids[t]);
+                        if (handle == 0xFFFFFFFFu) continue;
+                    }
+                    if (!found) q.list[nl] = handle;
+                    found = true;
+                    mfq.list[nl][f] = handle;
+                    tot += snap.h_lists[handle].n_ids;
+                    A.list_bytes += 4ull * snap.h_lists[handle].n_ids;
+                }
+                if (!found) continue;
+                len_of[nl] = (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFull);
+                nl++;
+            }
+            q.n_required = nl;
+            for (uint32_t t = 0; t < in.n_dropped && multi; t++) {        // after the query's own tokens, in their order (:5271-5290)
+                bool found = false;
+                for (uint32_t f = 0; f < in.n_fields; f++) {
+                    const uint32_t handle = snap.find_handle(in.field_ids[f], in.dropped_term_ids[t]);
+                    if (handle == 0xFFFFFFFFu) continue;
+                    mfq.list[nl][f] = handle;
+                    found = true;
+                    A.list_bytes += 4ull * snap.h_lists[handle].n_ids;
+                }
+                if (!found) continue;                                     // an or_iterator without lists: skip_to() is false for every document
+                len_of[nl] = 0xFFFFFFFFu;
+                nl++;
+            }
+            q.n_lists = nl;
+            q.match_type = in.match_type;
+            q.prio_exact = in.prioritize_exact_match ? 1 : 0;
+            q.prio_pos = in.prioritize_token_position ? 1 : 0;
+            q.prio_nfields = in.prioritize_num_matching_fields ? 1 : 0;
+            q.total_cost = in.total_cost;
+            q.weight = in.field_weights[0];
+            q.syn_orig_num_tokens = (int8_t)((int)in.syn_orig_num_tokens_p1 - 1);
+            q.orig_num_tokens = in.orig_num_tokens; q.is_synonym = in.is_synonym_query ? 1 : 0; q.demote_synonym = in.demote_synonym_match ? 1 : 0;
             q.n_sort = (uint8_t)in.n_sort;
+            if (in.n_sort > 2) A.any_s2 = true;
             for (uint32_t s = 0; s < in.n_sort; s++) {
                 q.sort_kind[s] = in.sort[s].kind; q.sort_order[s] = in.sort[s].order; q.sort_col[s] = in.sort[s].column;
-                if (in.sort[s].kind == TSGPU_SORT_INT64_COLUMN) P.n_numeric_sort_q++;
+                if (in.sort[s].kind == TSGPU_SORT_INT64_COLUMN) A.n_numeric_sort_q++;
             }
             q.k = k;
-            P.max_k = std::max(P.max_k, k);
-            q.aux_off = (uint32_t)P.aux.size();
+            A.max_k = std::max(A.max_k, k);
+            q.aux_off = (uint32_t)A.aux.size();
             q.n_excl = in.n_excluded;
             q.n_filt = in.n_filter;
             if (in.n_excluded) {
                 if (!in.excluded_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
-                P.aux.insert(P.aux.end(), in.excluded_ids, in.excluded_ids + in.n_excluded);
+                A.aux.insert(A.aux.end(), in.excluded_ids, in.excluded_ids + in.n_excluded);
             }
-            if (in.n_filter) P.aux.insert(P.aux.end(), in.filter_ids, in.filter_ids + in.n_filter);
-            const uint32_t n_ids = in.n_filter ? in.n_filter : ctx->num_docs;
-            q.wild_n_ids = n_ids;
-            uint32_t n_num = 0;
-            for (uint32_t s = 0; s < in.n_sort; s++) n_num += in.sort[s].kind == TSGPU_SORT_INT64_COLUMN;
-            P.list_bytes += 4ull * in.n_filter + 8ull * n_ids * n_num;      // the id array + one column value per id and numeric key
-            q.ids_out_off = P.ids_total;
-            const uint32_t n_blocks = (n_ids + BLOCK_IDS - 1) / BLOCK_IDS;
-            if (keep_ids) P.ids_total += (uint64_t)n_blocks * BLOCK_IDS;
-            const uint32_t WCHUNK = 64;                                     // 16K ids per work item
-            for (uint32_t b = 0; b < n_blocks; b += WCHUNK) {
+            if (in.n_filter) A.aux.insert(A.aux.end(), in.filter_ids, in.filter_ids + in.n_filter);   // sorted ascending, unique (filter_result_t::docs)
+            if (q.n_required == 0) continue;   // no token in the index: zero hits (intersect case 0, or_iterator.h:67-68)
+            if (multi) {
+                // driver = the token with the fewest postings over all fields; one group of work items per field list of it
+                uint32_t td = 0;
+                for (uint32_t t = 1; t < q.n_required; t++) if (len_of[t] < len_of[td]) td = t;
+                mfq.n_fields = in.n_fields;
+                mfq.driver_token = td;
+                for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.is_array[f] = f < in.n_fields && snap.field_is_array.at(in.field_ids[f]) ? 1 : 0;
+                for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.weight[f] = f < in.n_fields ? in.field_weights[f] : 0;
+                if (k + KW_THREADS > 1024) { unsupported("topster_size with several query_by fields"); continue; }
+                q.mf_index = (uint32_t)A.mf.size();
+                A.mf.push_back(mfq);
+                if (in.n_filter) { q.fbits_off = A.fbits_words; A.fbits_words += ((uint64_t)in.n_filter + 31) / 32; }
+                q.ids_out_off = A.ids_total;
+                uint64_t seg = 0;
+                for (uint32_t f = 0; f < in.n_fields; f++) {
+                    if (mfq.list[td][f] == KW_NONE) continue;
+                    const ListDesc& dF = snap.h_lists[mfq.list[td][f]];
+                    for (uint32_t b = 0; b < dF.n_blocks; b += KW_CHUNK_BLOCKS) {
+                        KwWorkItem w;
+                        w.query = i | (f << 28);
+                        w.blk_begin = b;
+                        w.blk_end = std::min(dF.n_blocks, b + KW_CHUNK_BLOCKS);
+                        w.ids_out_off = (uint32_t)seg;
+                        seg += (uint64_t)(w.blk_end - w.blk_begin) * BLOCK_IDS;
+                        { if (q_cnt[i] == 0) q_begin[i] = (uint32_t)A.flat_work.size(); A.flat_work.push_back(w); q_cnt[i]++; }
+                    }
+                }
+                if (keep_ids) A.ids_total += seg;
+                continue;
+            }
+            // probe order: ascending list length, stable
+            uint8_t ord[KW_MAX_TOKENS];
+            for (uint32_t t = 0; t < nl; t++) ord[t] = (uint8_t)t;
+            std::stable_sort(ord, ord + nl, [&](uint8_t a, uint8_t b) { return len_of[a] < len_of[b]; });
+            for (uint32_t t = 0; t < nl; t++) q.probe_order[t] = ord[t];
+            const ListDesc& dA = snap.h_lists[q.list[ord[0]]];
+            q.ids_out_off = A.ids_total;
+            if (keep_ids) A.ids_total += (uint64_t)dA.n_blocks * BLOCK_IDS;
+            // at most 8..64 partial top-K lists per query: kw_merge_kernel folds a query's partials one after the other, and a small
+            // batch (auto chunk 16) would otherwise cut a long driver list into hundreds of work items
+            // (small batches: a few thousand work items fill the chip, more only lengthen the per-query merge chain; measured on the
+            // 10M-doc collection: 100 queries 1.47 -> 1.15 ms, while a cap of 8 at 1 000+ queries unbalances the search kernel)
+            uint32_t chunk_q = KW_CHUNK_BLOCKS;
+            // small batches are as slow as their heaviest query: its longest work item (~3 us per driver block when the chip is not full)
+            // plus the chain of partial folds in kw_merge_kernel (~4.5 us each) -> the item count that balances the two, ~sqrt(blocks / 1.5)
+            uint32_t max_partials = ctx->kw_max_partials;
+            // (with the two-level merge a chain of P folds costs G + P / G, G = 8: the balance moves to ~sqrt(2.7 x blocks) items)
+            if (n_queries < 512) max_partials = std::max(max_partials, std::min<uint32_t>(384, (uint32_t)std::sqrt((double)dA.n_blocks * 2.7)));
+            // ... but never longer than 256 blocks (only the batch-wide chunk of a very large batch goes beyond, up to KW_MAX_CHUNK): the batch is as slow as its longest work item (a 16K-block driver list cut in 16
+            // would run 1 000 blocks in sequence), and folding 64 sorted partials costs kw_merge_kernel ~0.3 ms
+            if (ctx->kw_chunk_blocks == 0) chunk_q = std::max(chunk_q, std::min<uint32_t>((dA.n_blocks + max_partials - 1) / max_partials, 256u));
+            {   // launch-order key: estimated cost of the query's LARGEST work item = driver blocks x (fixed cost + second-list ids per
+                // driver id); the work table is laid out heaviest first so that the long items do not start last (tail of the launch)
+                const double r = nl >= 2 ? (double)len_of[ord[1]] / (double)std::max<uint32_t>(len_of[ord[0]], 1) : 0.0;
+                // + third-list probes: every stage-1 survivor (256 |B| / N per driver block) costs a two-level global binary search
+                const double surv = nl >= 3 ? 256.0 * (double)len_of[ord[1]] / (double)std::max<uint32_t>(ctx->num_docs, 1) : 0.0;
+                item_cost[i] = (double)std::min(chunk_q, dA.n_blocks) * ((double)ctx->kw_cost_fixed + 0.1 * ctx->kw_cost_r_x10 * std::min(r, 64.0) + 0.01 * ctx->kw_cost_probe_x100 * surv);
+            }
+            for (uint32_t b = 0; b < dA.n_blocks; b += chunk_q) {
                 KwWorkItem w;
-                w.query = i; w.blk_begin = b; w.blk_end = std::min(n_blocks, b + WCHUNK); w.ids_out_off = b * BLOCK_IDS;
-                { if (q_cnt[i] == 0) q_begin[i] = (uint32_t)flat_work.size(); flat_work.push_back(w); q_cnt[i]++; }
+                w.query = i;
+                w.blk_begin = b;
+                w.blk_end = std::min(dA.n_blocks, b + chunk_q);
+                w.ids_out_off = b * BLOCK_IDS;
+                { if (q_cnt[i] == 0) q_begin[i] = (uint32_t)A.flat_work.size(); A.flat_work.push_back(w); q_cnt[i]++; }
             }
-            continue;
         }
-
-        q.n_query_tokens = in.n_tokens;
-        q.mf_index = KW_NONE;
-        uint32_t nl = 0;
-        uint32_t len_of[KW_MAX_TOKENS];
-        KwQueryMF mfq;
-        if (multi) memset(&mfq, 0xFF, sizeof mfq);                // (only read by the multi-field form)
-        for (uint32_t t = 0; t < in.n_tokens; t++) {
-            // one or_iterator per token = the union of its lists over the fields; a token found in no field is skipped (src/index.cpp:5651-5655)
-            uint64_t tot = 0;
-            bool found = false;
-            for (uint32_t f = 0; f < in.n_fields; f++) {
-                uint32_t handle;
-                if (cached[i]) {                     // (n_fields == 1)
-                    handle = handle_cache[(size_t)i * TSGPU_MAX_QUERY_TOKENS + t];
-                    if (handle == KW_NONE - 1) continue;
-                } else {
-                    handle = snap.find_handle(in.field_ids[f], in.term_ids[t]);
-                    if (handle == 0xFFFFFFFFu) continue;
-                }
-                if (!found) q.list[nl] = handle;
-                found = true;
-                mfq.list[nl][f] = handle;
-                tot += snap.h_lists[handle].n_ids;
-                P.list_bytes += 4ull * snap.h_lists[handle].n_ids;
-            }
-            if (!found) continue;
-            len_of[nl] = (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFull);
-            nl++;
+    };
+    std::vector<KwWorkItem> flat_work;                       // every query's items, contiguous, in query order
+    {
+        const uint32_t min_par = ctx->plan_parallel_min_queries;
+        const uint32_t min_slice = std::max<uint32_t>(8, min_par / 8);                      // (256 queries per slice at the default threshold)
+        const uint32_t n_thr = (min_par && n_queries >= min_par) ? std::min<uint32_t>((uint32_t)std::max(1, ctx->plan_threads), std::max<uint32_t>(1, n_queries / min_slice)) : 1;
+        // (four slices per thread, handed out dynamically: a parked thread that wakes late still finds work, the caller never idles)
+        const uint32_t n_parts = n_thr == 1 ? 1 : std::min<uint32_t>(4 * n_thr, std::max<uint32_t>(1, n_queries / std::max<uint32_t>(8, min_slice / 4)));
+        std::vector<PlanAcc> parts(n_parts);
+        auto bound = [&](uint32_t k) { return (uint32_t)((uint64_t)n_queries * k / n_parts); };
+        if (n_parts == 1) plan_range(0, n_queries, parts[0]);
+        else {
+            std::atomic<uint32_t> next{0};
+            std::atomic<int> oom{0};
+            const std::function<void()> job = [&]() {
+                try { for (;;) { const uint32_t k = next.fetch_add(1); if (k >= n_parts) break; plan_range(bound(k), bound(k + 1), parts[k]); } } catch (const std::bad_alloc&) { oom = 1; }
+            };
+            ctx->host_pool.run(job, (int)n_thr - 1);
+            if (oom) throw std::bad_alloc();
         }
-        q.n_required = nl;
-        for (uint32_t t = 0; t < in.n_dropped && multi; t++) {        // after the query's own tokens, in their order (:5271-5290)
-            bool found = false;
-            for (uint32_t f = 0; f < in.n_fields; f++) {
-                const uint32_t handle = snap.find_handle(in.field_ids[f], in.dropped_term_ids[t]);
-                if (handle == 0xFFFFFFFFu) continue;
-                mfq.list[nl][f] = handle;
-                found = true;
-                P.list_bytes += 4ull * snap.h_lists[handle].n_ids;
-            }
-            if (!found) continue;                                     // an or_iterator without lists: skip_to() is false for every document
-            len_of[nl] = 0xFFFFFFFFu;
-            nl++;
-        }
-        q.n_lists = nl;
-        q.match_type = in.match_type;
-        q.prio_exact = in.prioritize_exact_match ? 1 : 0;
-        q.prio_pos = in.prioritize_token_position ? 1 : 0;
-        q.prio_nfields = in.prioritize_num_matching_fields ? 1 : 0;
-        q.total_cost = in.total_cost;
-        q.weight = in.field_weights[0];
-        q.syn_orig_num_tokens = (int8_t)((int)in.syn_orig_num_tokens_p1 - 1);
-        q.orig_num_tokens = in.orig_num_tokens; q.is_synonym = in.is_synonym_query ? 1 : 0; q.demote_synonym = in.demote_synonym_match ? 1 : 0;
-        q.n_sort = (uint8_t)in.n_sort;
-        if (in.n_sort > 2) P.any_s2 = true;
-        for (uint32_t s = 0; s < in.n_sort; s++) {
-            q.sort_kind[s] = in.sort[s].kind; q.sort_order[s] = in.sort[s].order; q.sort_col[s] = in.sort[s].column;
-            if (in.sort[s].kind == TSGPU_SORT_INT64_COLUMN) P.n_numeric_sort_q++;
-        }
-        q.k = k;
-        P.max_k = std::max(P.max_k, k);
-        q.aux_off = (uint32_t)P.aux.size();
-        q.n_excl = in.n_excluded;
-        q.n_filt = in.n_filter;
-        if (in.n_excluded) {
-            if (!in.excluded_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
-            P.aux.insert(P.aux.end(), in.excluded_ids, in.excluded_ids + in.n_excluded);
-        }
-        if (in.n_filter) P.aux.insert(P.aux.end(), in.filter_ids, in.filter_ids + in.n_filter);   // sorted ascending, unique (filter_result_t::docs)
-        if (q.n_required == 0) continue;   // no token in the index: zero hits (intersect case 0, or_iterator.h:67-68)
-        if (multi) {
-            // driver = the token with the fewest postings over all fields; one group of work items per field list of it
-            uint32_t td = 0;
-            for (uint32_t t = 1; t < q.n_required; t++) if (len_of[t] < len_of[td]) td = t;
-            mfq.n_fields = in.n_fields;
-            mfq.driver_token = td;
-            for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.is_array[f] = f < in.n_fields && snap.field_is_array.at(in.field_ids[f]) ? 1 : 0;
-            for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.weight[f] = f < in.n_fields ? in.field_weights[f] : 0;
-            if (k + KW_THREADS > 1024) { unsupported("topster_size with several query_by fields"); continue; }
-            q.mf_index = (uint32_t)P.mf.size();
-            P.mf.push_back(mfq);
-            if (in.n_filter) { q.fbits_off = P.fbits_words; P.fbits_words += ((uint64_t)in.n_filter + 31) / 32; }
-            q.ids_out_off = P.ids_total;
-            uint64_t seg = 0;
-            for (uint32_t f = 0; f < in.n_fields; f++) {
-                if (mfq.list[td][f] == KW_NONE) continue;
-                const ListDesc& dF = snap.h_lists[mfq.list[td][f]];
-                for (uint32_t b = 0; b < dF.n_blocks; b += KW_CHUNK_BLOCKS) {
-                    KwWorkItem w;
-                    w.query = i | (f << 28);
-                    w.blk_begin = b;
-                    w.blk_end = std::min(dF.n_blocks, b + KW_CHUNK_BLOCKS);
-                    w.ids_out_off = (uint32_t)seg;
-                    seg += (uint64_t)(w.blk_end - w.blk_begin) * BLOCK_IDS;
-                    { if (q_cnt[i] == 0) q_begin[i] = (uint32_t)flat_work.size(); flat_work.push_back(w); q_cnt[i]++; }
+        for (uint32_t k = 0; k < n_parts; k++) {
+            PlanAcc& A = parts[k];
+            const uint32_t aux_base = (uint32_t)P.aux.size(), mf_base = (uint32_t)P.mf.size(), work_base = (uint32_t)flat_work.size();
+            const uint64_t ids_base = P.ids_total, fbits_base = P.fbits_words;
+            if (k) {
+                for (uint32_t i = bound(k); i < bound(k + 1); i++) {
+                    KwQueryDev& q = P.q[i];
+                    q.aux_off += aux_base; q.ids_out_off += ids_base; q.fbits_off += fbits_base;
+                    if (q.mf_index != KW_NONE && P.status[i] == TSGPU_OK && !q.wild_n_ids) q.mf_index += mf_base;
+                    q_begin[i] += work_base;
                 }
             }
-            if (keep_ids) P.ids_total += seg;
-            continue;
-        }
-        // probe order: ascending list length, stable
-        uint8_t ord[KW_MAX_TOKENS];
-        for (uint32_t t = 0; t < nl; t++) ord[t] = (uint8_t)t;
-        std::stable_sort(ord, ord + nl, [&](uint8_t a, uint8_t b) { return len_of[a] < len_of[b]; });
-        for (uint32_t t = 0; t < nl; t++) q.probe_order[t] = ord[t];
-        const ListDesc& dA = snap.h_lists[q.list[ord[0]]];
-        q.ids_out_off = P.ids_total;
-        if (keep_ids) P.ids_total += (uint64_t)dA.n_blocks * BLOCK_IDS;
-        // at most 8..64 partial top-K lists per query: kw_merge_kernel folds a query's partials one after the other, and a small
-        // batch (auto chunk 16) would otherwise cut a long driver list into hundreds of work items
-        // (small batches: a few thousand work items fill the chip, more only lengthen the per-query merge chain; measured on the
-        // 10M-doc collection: 100 queries 1.47 -> 1.15 ms, while a cap of 8 at 1 000+ queries unbalances the search kernel)
-        uint32_t chunk_q = KW_CHUNK_BLOCKS;
-        // small batches are as slow as their heaviest query: its longest work item (~3 us per driver block when the chip is not full)
-        // plus the chain of partial folds in kw_merge_kernel (~4.5 us each) -> the item count that balances the two, ~sqrt(blocks / 1.5)
-        uint32_t max_partials = ctx->kw_max_partials;
-        // (with the two-level merge a chain of P folds costs G + P / G, G = 8: the balance moves to ~sqrt(2.7 x blocks) items)
-        if (n_queries < 512) max_partials = std::max(max_partials, std::min<uint32_t>(384, (uint32_t)std::sqrt((double)dA.n_blocks * 2.7)));
-        // ... but never longer than 256 blocks (only the batch-wide chunk of a very large batch goes beyond, up to KW_MAX_CHUNK): the batch is as slow as its longest work item (a 16K-block driver list cut in 16
-        // would run 1 000 blocks in sequence), and folding 64 sorted partials costs kw_merge_kernel ~0.3 ms
-        if (ctx->kw_chunk_blocks == 0) chunk_q = std::max(chunk_q, std::min<uint32_t>((dA.n_blocks + max_partials - 1) / max_partials, 256u));
-        {   // launch-order key: estimated cost of the query's LARGEST work item = driver blocks x (fixed cost + second-list ids per
-            // driver id); the work table is laid out heaviest first so that the long items do not start last (tail of the launch)
-            const double r = nl >= 2 ? (double)len_of[ord[1]] / (double)std::max<uint32_t>(len_of[ord[0]], 1) : 0.0;
-            // + third-list probes: every stage-1 survivor (256 |B| / N per driver block) costs a two-level global binary search
-            const double surv = nl >= 3 ? 256.0 * (double)len_of[ord[1]] / (double)std::max<uint32_t>(ctx->num_docs, 1) : 0.0;
-            item_cost[i] = (double)std::min(chunk_q, dA.n_blocks) * ((double)ctx->kw_cost_fixed + 0.1 * ctx->kw_cost_r_x10 * std::min(r, 64.0) + 0.01 * ctx->kw_cost_probe_x100 * surv);
-        }
-        for (uint32_t b = 0; b < dA.n_blocks; b += chunk_q) {
-            KwWorkItem w;
-            w.query = i;
-            w.blk_begin = b;
-            w.blk_end = std::min(dA.n_blocks, b + chunk_q);
-            w.ids_out_off = b * BLOCK_IDS;
-            { if (q_cnt[i] == 0) q_begin[i] = (uint32_t)flat_work.size(); flat_work.push_back(w); q_cnt[i]++; }
+            if (k == 0) { P.aux.swap(A.aux); P.mf.swap(A.mf); flat_work.swap(A.flat_work); }
+            else {
+                P.aux.insert(P.aux.end(), A.aux.begin(), A.aux.end());
+                P.mf.insert(P.mf.end(), A.mf.begin(), A.mf.end());
+                flat_work.insert(flat_work.end(), A.flat_work.begin(), A.flat_work.end());
+            }
+            P.ids_total += A.ids_total; P.fbits_words += A.fbits_words; P.list_bytes += A.list_bytes;
+            P.max_k = std::max(P.max_k, A.max_k); P.n_numeric_sort_q += A.n_numeric_sort_q;
+            P.any_deadline = P.any_deadline || A.any_deadline; P.any_s2 = P.any_s2 || A.any_s2;
         }
     }
     // work tables: one launch per kernel flavour (single-field T<=3, single-field generic, multi-field T<=3, multi-field generic);

@@ -317,6 +317,8 @@ struct tsgpu_ctx {
     uint32_t vec_cand_cap = 0;                       // candidate slots per query in pass 2 (0 = automatic)
     uint32_t vec_prefilter = 1;                      // 1 = bf16 bracket scan + exact fp32 re-score (default); 0 = fp32 MFMA scan
     uint64_t vec_prefilter_groups = 0;               // query groups answered by the bf16 bracket path
+    int plan_threads = 8;                             // host threads that plan a big keyword batch in slices ("plan_threads")
+    uint32_t plan_parallel_min_queries = 2048;        // ... from this many queries on (0 = never; "plan_parallel_min_queries")
     int fuse_threads = 32;                            // host threads of the hybrid rank fusion (option "fuse_threads")
     uint64_t hnsw_last_expansions = 0, hnsw_last_distances = 0;   // last HNSW batch: candidates expanded / distances computed at layer 0 (all queries)
     uint64_t vec_rescored_rows = 0;                  // survivors re-scored in fp32 by the last prefilter group (sum over its queries; 0 unless vec_count_rescored)
