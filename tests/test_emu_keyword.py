@@ -612,7 +612,7 @@ def test_deadline_in_flight_returns_partial_hits_with_search_cutoff(pair):
         g.set_option("kw_chunk_blocks", 0)
 
 
-@pytest.mark.parametrize("chunk", [64, 1, 3])
+@pytest.mark.parametrize("chunk", [64, 3])
 def test_pair_find_kernel_matches_the_oracle(pair, chunk):
     """kw_pair_blocks=1: the find kernel that serves two driver blocks per iteration (kw_find2.hip.h) — same hit records as the
     one-block kernel: odd block counts (a lone last block), wide / multi-round / exhausted runs, third-list probes, filters"""
