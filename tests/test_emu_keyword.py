@@ -320,9 +320,27 @@ def test_multi_field_union_per_token_and_field_aggregation(pair3, chunk):
             H.assert_hits_equal(h2, i, ref, "multi-field + filter chunk=%d q=%s" % (chunk, q.tokens))
             assert np.array_equal(g.result_ids(i), ref.result_ids)
         assert h2.n_hits.sum() > 200
-        # the one combination left to the caller's CPU path: filter ids AND excluded ids AND several fields
-        h3 = g.keyword_search_batch([T.KwQuery([1], fields=f2, filter_ids=[1, 2, 3], excluded_ids=[2])], k_stride=250)
-        assert h3.status[0] == B.ERR_UNSUPPORTED
+        # filter ids AND excluded ids AND several fields: after an excluded id the reference advances instead of skipping to the filter, so
+        # num_keyword_matches is a recurrence over the intersection IN ID ORDER — walked by kw_mf_ordered_count_kernel over the per-field
+        # streams of hit records (two-kernel form; the fused form reports 501 for this combination)
+        xq = []
+        for toks in ([1], [3, 1, 2], [7, 1, 2, 3, 6]):
+            for flt in (np.sort(rng.choice(2500, size=900, replace=False)), np.arange(0, 2500, 2)):
+                for exc in (np.sort(rng.choice(2500, size=1200, replace=False)), np.arange(100, 300)):
+                    xq.append(T.KwQuery(toks, fields=f3, sort=sort, topster_size=250, filter_ids=flt, excluded_ids=exc))
+        xq.append(T.KwQuery([1], fields=f2, filter_ids=[1, 2, 3], excluded_ids=[2]))
+        h3 = g.keyword_search_batch(xq, k_stride=250)
+        assert (h3.status == 0).all()
+        for i, q in enumerate(xq):
+            ref = H.oracle_keyword(orc, q, ids_cap=4000)
+            H.assert_hits_equal(h3, i, ref, "multi-field + filter + excluded chunk=%d q=%s" % (chunk, q.tokens))
+            assert np.array_equal(g.result_ids(i), ref.result_ids)
+        g.set_option("kw_two_kernels", 0)
+        try:
+            h4 = g.keyword_search_batch(xq[:3], k_stride=250)
+            assert (h4.status == B.ERR_UNSUPPORTED).all()
+        finally:
+            g.set_option("kw_two_kernels", 1)
     finally:
         g.set_option("kw_chunk_blocks", 0)
         g.keep_result_ids(False)

@@ -923,7 +923,7 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2, false, SCORE>& s
         // be chained. Without exclusions the count has an order-free form: filter ranks never decrease along the intersection, so the
         // ids the reference's loop lands on — rank exceeds the predecessor's — number exactly the DISTINCT POSITIVE ranks of the
         // intersection. Every hit's rank is recorded in the query's bitmap (equal ranks of one work item are adjacent: only the first
-        // of a run touches memory); a work item counts the bits it set first. (Filter + exclusions + several fields: rejected by the planner.)
+        // of a run touches memory); a work item counts the bits it set first. (Filter + exclusions + several fields: kw_mf_ordered_count_kernel.)
         if (active) sm.f_rank[t] = rank;
         __syncthreads();
         bool fresh = false;
@@ -1858,11 +1858,13 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
     {
         unsigned long long nm = 0, ow = 0;
         const bool chain = q.n_filt && !q.wild_n_ids && q.mf_index == KW_NONE;      // (several fields: order-free count, summed)
-        for (uint32_t w = q.first_work + t; w < q.first_work + q.n_work; w += KW_THREADS) { if (!chain) nm += part.n_match[w]; ow += part.off_words[w]; }
+        const bool ordered_mf = q.n_filt && q.n_excl && !q.wild_n_ids && q.mf_index != KW_NONE;    // ... with exclusions: kw_mf_ordered_count_kernel's walk
+        for (uint32_t w = q.first_work + t; w < q.first_work + q.n_work; w += KW_THREADS) { if (!chain && !ordered_mf) nm += part.n_match[w]; ow += part.off_words[w]; }
         for (int d = 32; d > 0; d >>= 1) { nm += __shfl_down(nm, d, 64); ow += __shfl_down(ow, d, 64); }
         if ((t & 63) == 0) { if (nm) atomicAdd(&s_nm, nm); if (ow) atomicAdd(&s_ow, ow); }
         __syncthreads();
         if (t == 0 && chain) s_nm = kw_filter_count(part, q.first_work, q.n_work);
+        if (t == 0 && ordered_mf && q.n_work) s_nm = part.n_match1[q.first_work];
     }
     __syncthreads();
     if (t == 0) { out.n_hits[blockIdx.x] = n; out.num_matched[blockIdx.x] = s_nm; out.off_words[blockIdx.x] = s_ow; }
@@ -2088,6 +2090,57 @@ __global__ __launch_bounds__(KW_THREADS) void kw_idset_expand_kernel(const uint3
         if (t == 0) s_base += all;
         __syncthreads();
     }
+}
+
+// num_keyword_matches of a query with filter ids AND excluded ids AND several query_by fields: the first-order recurrence of
+// kw_score_stage (c_j = rank_j > rank_{j-1} | c_{j-1} & excluded_{j-1}) needs the intersection in ascending id order, but the work
+// items of a multi-field query are one ascending stream PER FIELD of the driver token. One thread per such query (rare: curated hits
+// + filter_by + several fields) merges the <= 4 streams of hit records the find kernel left (every intersection id, before filter and
+// exclusion) and walks the filter / excluded arrays with cursors: O(ids + filter + excluded). Runs between the find and the score
+// kernel (the score kernel overwrites part.cnt); the result waits in part.n_match1[first work item] for kw_merge_kernel.
+template <int TMAX>
+__global__ __launch_bounds__(64) void kw_mf_ordered_count_kernel(const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work, KwPartials part,
+                                                                 const uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off, uint32_t table_first,
+                                                                 const uint32_t* __restrict__ aux_ids, const uint32_t* __restrict__ jobs) {
+    if (threadIdx.x != 0) return;
+    constexpr uint32_t NP1 = TMAX * KW_MAX_FIELDS + 1;
+    const KwQueryDev q = queries[jobs[blockIdx.x]];
+    const uint32_t* __restrict__ excl = aux_ids + q.aux_off;
+    const uint32_t* __restrict__ filt = excl + q.n_excl;
+    struct Stream { uint32_t item, item_end, rec, n_rec; const uint32_t* base; uint32_t id; bool valid; };
+    Stream st[KW_MAX_FIELDS];
+    int ns = 0;
+    for (uint32_t w = q.first_work, end = q.first_work + q.n_work; w < end;) {
+        const uint32_t f = work[w].query >> 28, beg = w;
+        while (w < end && (work[w].query >> 28) == f) w++;
+        if (ns < KW_MAX_FIELDS) { st[ns].item = beg; st[ns].item_end = w; st[ns].rec = 0; st[ns].n_rec = 0; st[ns].base = nullptr; st[ns].id = 0; st[ns].valid = false; ns++; }
+    }
+    auto position = [&](Stream& s) {               // on the next record of the stream, skipping work items without hits
+        s.valid = false;
+        while (s.item < s.item_end) {
+            if (s.base == nullptr) { s.n_rec = part.cnt[s.item]; s.base = hits_all + hit_off[s.item - table_first] * (uint64_t)NP1; s.rec = 0; }
+            if (s.rec < s.n_rec) { s.id = s.base[(size_t)s.rec * NP1]; s.valid = true; return; }
+            s.item++; s.base = nullptr;
+        }
+    };
+    for (int i = 0; i < ns; i++) position(st[i]);
+    uint32_t fc = 0, ec = 0, rp = 0, c = 0, ep = 0;
+    unsigned long long total = 0;
+    for (;;) {
+        int best = -1;
+        for (int i = 0; i < ns; i++) if (st[i].valid && (best < 0 || st[i].id < st[best].id)) best = i;
+        if (best < 0) break;
+        const uint32_t x = st[best].id;
+        st[best].rec++;
+        position(st[best]);
+        while (fc < q.n_filt && filt[fc] <= x) fc++;                  // rank = # filter ids <= x
+        while (ec < q.n_excl && excl[ec] < x) ec++;
+        const uint32_t e = (ec < q.n_excl && excl[ec] == x) ? 1u : 0u;
+        c = (fc > rp ? 1u : 0u) | (c & ep);
+        total += c;
+        rp = fc; ep = e;
+    }
+    part.n_match1[q.first_work] = (uint32_t)total;
 }
 
 // Index::compute_aux_scores' text half (src/index.cpp:8800-8846, rerank_hybrid_matches): the aggregated text-match score of GIVEN

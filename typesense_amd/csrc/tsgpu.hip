@@ -81,11 +81,13 @@ void launch_search_mf_cap(int cap, hipStream_t s, uint32_t n_work, const IndexVi
     if (cap == 512) hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 512>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, (uint32_t*)nullptr, (const uint64_t*)nullptr);
     else hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 1024>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, (uint32_t*)nullptr, (const uint64_t*)nullptr);
 }
-// two-kernel form of the multi-field search (k + 256 <= 1024 there)
+// two-kernel form of the multi-field search (k + 256 <= 1024 there); oc: queries with filter + excluded ids, counted in id order between the two
+struct MfOrderedCount { const uint32_t* jobs = nullptr; uint32_t n_jobs = 0, table_first = 0; const KwWorkItem* work_all = nullptr; KwPartials part_all{}; };
 template <int TMAX>
 void launch_find_score_mf(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w, const KwPartials& part,
-                          const uint32_t* aux, uint32_t* ids_out, uint32_t* hits, const uint64_t* hit_off) {
+                          const uint32_t* aux, uint32_t* ids_out, uint32_t* hits, const uint64_t* hit_off, const MfOrderedCount& oc) {
     hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 512, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    if (oc.n_jobs) hipLaunchKernelGGL((kw_mf_ordered_count_kernel<TMAX>), dim3(oc.n_jobs), dim3(64), 0, s, q, oc.work_all, oc.part_all, hits, hit_off, oc.table_first, aux, oc.jobs);
     if (cap == 512) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     else hipLaunchKernelGGL((kw_score_kernel<TMAX, 1024, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
 }
@@ -324,6 +326,7 @@ struct Plan {
     std::vector<KwWorkItem> work_wild;                    // wildcard scans
     std::vector<KwQueryMF> mf;
     std::vector<KwMergeGroup> groups;                     // first level of the two-level merge (queries with many work items)
+    std::vector<uint32_t> ordered_count_q;                // multi-field queries with filter AND excluded ids (kw_mf_ordered_count_kernel)
     uint64_t fbits_words = 0;                             // rank bitmaps of the filtered multi-field queries
     bool any_deadline = false;                            // some query carries a deadline: stamp the batch start, collect cutoff flags
     bool any_s2 = false;              // some query has a third sort key
@@ -384,7 +387,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
     // the context's parked host threads, every slice into its own accumulator; the slices are then concatenated in query order and the
     // offsets a query holds into the shared arenas shifted by its slice's base (0.5 ms -> 0.1 ms of a 9 ms step at 10 000 queries).
     struct PlanAcc {
-        std::vector<uint32_t> aux; std::vector<KwQueryMF> mf; std::vector<KwWorkItem> flat_work;
+        std::vector<uint32_t> aux, ordered_count_q; std::vector<KwQueryMF> mf; std::vector<KwWorkItem> flat_work;
         uint64_t fbits_words = 0, ids_total = 0, list_bytes = 0;
         uint32_t max_k = 0, n_numeric_sort_q = 0;
         bool any_deadline = false, any_s2 = false;
@@ -416,7 +419,10 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
                 multi = true;
             }
             // filter ids with several query_by fields: num_keyword_matches has an order-free form only without exclusions (kw_score_stage)
-            if (multi && in.n_filter != 0 && in.n_excluded != 0) { unsupported("filter ids AND excluded ids with several query_by fields"); continue; }
+            // filter ids AND excluded ids with several query_by fields: num_keyword_matches needs the intersection in id order — counted by
+            // kw_mf_ordered_count_kernel from the find kernel's hit records, i.e. in the two-kernel form only (checked after the tables are laid out)
+            const bool ordered_count = multi && in.n_filter != 0 && in.n_excluded != 0;
+            if (ordered_count && !ctx->kw_two_kernels) { unsupported("filter ids AND excluded ids with several query_by fields need the two-kernel form"); continue; }
             if (in.n_sort > TSGPU_MAX_SORT_KEYS) { P.status[i] = TSGPU_ERR_INVALID; continue; }
             if (in.n_filter != 0 && !in.filter_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
             if (in.match_type > TSGPU_SUM_SCORE) { P.status[i] = TSGPU_ERR_INVALID; continue; }
@@ -547,6 +553,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
                 if (k + KW_THREADS > 1024) { unsupported("topster_size with several query_by fields"); continue; }
                 q.mf_index = (uint32_t)A.mf.size();
                 A.mf.push_back(mfq);
+                if (ordered_count) A.ordered_count_q.push_back(i);
                 if (in.n_filter) { q.fbits_off = A.fbits_words; A.fbits_words += ((uint64_t)in.n_filter + 31) / 32; }
                 q.ids_out_off = A.ids_total;
                 uint64_t seg = 0;
@@ -641,6 +648,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
                 P.mf.insert(P.mf.end(), A.mf.begin(), A.mf.end());
                 flat_work.insert(flat_work.end(), A.flat_work.begin(), A.flat_work.end());
             }
+            P.ordered_count_q.insert(P.ordered_count_q.end(), A.ordered_count_q.begin(), A.ordered_count_q.end());
             P.ids_total += A.ids_total; P.fbits_words += A.fbits_words; P.list_bytes += A.list_bytes;
             P.max_k = std::max(P.max_k, A.max_k); P.n_numeric_sort_q += A.n_numeric_sort_q;
             P.any_deadline = P.any_deadline || A.any_deadline; P.any_s2 = P.any_s2 || A.any_s2;
@@ -939,12 +947,22 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         };
         TablePlan tps[4] = {prep_table(P.work_small, 3, false), prep_table(P.work_big, KW_MAX_TOKENS, false), prep_table(P.work_mf_small, 3, true),
                             prep_table(P.work_mf_big, KW_MAX_TOKENS, true)};
+        // multi-field queries with filter + excluded ids: counted from the hit records of ONE find launch of their table; a table that was
+        // cut into groups or runs fused cannot serve them -> 501 for those queries (their hits are not reported)
+        std::vector<uint32_t> oc_jobs[2];
+        for (uint32_t qi : P.ordered_count_q) {
+            const int tb = P.q[qi].n_lists <= 3 ? 0 : 1;
+            const TablePlan& tp = tps[2 + tb];
+            if (tp.two && tp.group_start.size() == 2) oc_jobs[tb].push_back(qi);
+            else if (P.status[qi] == TSGPU_OK) P.status[qi] = TSGPU_ERR_UNSUPPORTED;
+        }
         size_t plan_bytes = 0;
         auto place = [&](size_t bytes) { const size_t at = (plan_bytes + 63) & ~(size_t)63; plan_bytes = at + bytes; return at; };
         const size_t at_q = place(P.q.size() * sizeof(KwQueryDev)), at_w = place(work.size() * sizeof(KwWorkItem)), at_aux = place(P.aux.size() * 4),
                      at_mf = place(P.mf.size() * sizeof(KwQueryMF));
         for (auto& tp : tps) tp.hoff_at = place(tp.hoff.size() * 8);
         const size_t at_grp = place(P.groups.size() * sizeof(KwMergeGroup));
+        const size_t at_oc[2] = {place(oc_jobs[0].size() * 4), place(oc_jobs[1].size() * 4)};
         if ((rc = L.h_plan.reserve(plan_bytes + 64)) || (rc = L.d_plan.reserve(plan_bytes + 64))) return rc;
         {
             uint8_t* hp = (uint8_t*)L.h_plan.p;
@@ -954,6 +972,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             if (!P.mf.empty()) memcpy(hp + at_mf, P.mf.data(), P.mf.size() * sizeof(KwQueryMF));
             for (auto& tp : tps) if (!tp.hoff.empty()) memcpy(hp + tp.hoff_at, tp.hoff.data(), tp.hoff.size() * 8);
             if (!P.groups.empty()) memcpy(hp + at_grp, P.groups.data(), P.groups.size() * sizeof(KwMergeGroup));
+            for (int tb = 0; tb < 2; tb++) if (!oc_jobs[tb].empty()) memcpy(hp + at_oc[tb], oc_jobs[tb].data(), oc_jobs[tb].size() * 4);
             TSGPU_HIP_TRY(hipMemcpyAsync(L.d_plan.p, hp, plan_bytes, hipMemcpyHostToDevice, s));
         }
         uint8_t* const dplan = (uint8_t*)L.d_plan.p;
@@ -1048,7 +1067,15 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
                 for (size_t gi = 0; gi + 1 < tp.group_start.size(); gi++) {
                     const size_t a = tp.group_start[gi], b = tp.group_start[gi + 1];
                     if (b <= a) continue;
-                    if constexpr (MFT) launch_find_score_mf<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, L.d_hits.as<uint32_t>(), hoff_dev + a);
+                    if constexpr (MFT) {
+                        MfOrderedCount oc;
+                        const int tb = TM == 3 ? 0 : 1;
+                        if (!oc_jobs[tb].empty() && tp.group_start.size() == 2) {
+                            oc.jobs = (const uint32_t*)(dplan + at_oc[tb]); oc.n_jobs = (uint32_t)oc_jobs[tb].size(); oc.table_first = (uint32_t)first;
+                            oc.work_all = dw; oc.part_all = part;
+                        }
+                        launch_find_score_mf<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, L.d_hits.as<uint32_t>(), hoff_dev + a, oc);
+                    }
                     else {
                         const bool mark = !find_marked;
                         find_marked = true;
