@@ -194,6 +194,15 @@ def device_hits(torch, n_q, ks):
     return d, h
 
 
+def cpu_quota_cpus():
+    """CPUs the container may use (cgroup v2 cpu.max), None = unlimited: the cpu_baseline legs start one thread per visible core, the quota decides how many run"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        return None
+
+
 def loadgen_lib():
     from typesense_amd import build as Bd
     L = C.CDLL(Bd.build_loadgen())
@@ -431,7 +440,7 @@ class Bench:
             base = orc.make_query(qtok[0], sort=osort, fetch_size=100)
             orc.bench_keyword(base, qtok[:min(sample, ncpu)], ncpu)               # warm the page cache / allocator
             wall, per = orc.bench_keyword(base, qtok[:sample], ncpu)
-            res["cpu"] = dict(value=sample / wall, unit="queries/s", cores=ncpu, kind="port",
+            res["cpu"] = dict(value=sample / wall, unit="queries/s", cores=ncpu, cgroup_cpu_quota_cpus=cpu_quota_cpus(), kind="port",
                               sample="%d of the %d queries of the step, one query per thread on %d host threads (oracle = port of "
                                      "or_iterator_t::intersect + Match + Topster); p50 %.1f ms/query" % (sample, n_q, ncpu, float(np.median(per)) / 1e3))
             bad = 0
@@ -458,18 +467,31 @@ class Bench:
             want[i] = LG.tsgpu_loadgen_hits_checksum(kc[i].ctypes.data, sc[i].ctypes.data, int(n_hits[i]), int(num_matched[i]), top)
         fn = C.cast(g.L.tsgpu_keyword_search_batch, C.c_void_p)
         out = {}
-        for threads in sorted({1, 16, T_}):
+        def cgroup_cpu():
+            # the host side of this leg is CPU work of the request threads: a container CPU quota (cgroup v2 cpu.max) bounds it, and a
+            # throttled period stalls every thread for tens of milliseconds -> reported next to the numbers
+            try:
+                st = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                return int(st["usage_usec"]), int(st.get("nr_throttled", 0)), int(st.get("throttled_usec", 0)), (None if q == "max" else float(q) / float(per))
+            except Exception:
+                return 0, 0, 0, None
+        for threads in sorted({1, 16, 128, T_}):
             lat = np.zeros(threads * calls, np.float64)
             got = np.zeros(n_q, np.uint64)
             fails = C.c_uint64(0)
             r0, c0 = g.counter("batch_rounds"), g.counter("batch_coalesced_calls")
             LG.tsgpu_loadgen_keyword(fn, g.h, C.cast(arr, C.c_void_p), n_q, K_TOPSTER, top, threads, max(2, calls // 8), 1, lat.ctypes.data, got.ctypes.data, C.byref(fails))   # warm-up
+            cg0 = cgroup_cpu()
             wall = LG.tsgpu_loadgen_keyword(fn, g.h, C.cast(arr, C.c_void_p), n_q, K_TOPSTER, top, threads, calls, 1, lat.ctypes.data, got.ctypes.data, C.byref(fails))
+            cg1 = cgroup_cpu()
             rounds, ccalls = g.counter("batch_rounds") - r0, g.counter("batch_coalesced_calls") - c0
             touched = got != 0
             out[str(threads)] = {"threads": threads, "calls": threads * calls, "queries_per_call": 1, "value": threads * calls / wall, "unit": "queries/s",
                                  "p50_us": float(np.percentile(lat, 50)), "p99_us": float(np.percentile(lat, 99)), "failures": int(fails.value),
-                                 "queries_per_round": (ccalls / rounds) if rounds else 1.0,
+                                 "queries_per_round": (ccalls / rounds) if rounds else 1.0, "mean_us": float(lat.mean()), "max_us": float(lat.max()),
+                                 "host_cpu": {"cpu_us_per_call": (cg1[0] - cg0[0]) / (threads * calls), "cpus_busy": (cg1[0] - cg0[0]) / (wall * 1e6),
+                                              "cgroup_cpu_quota_cpus": cg1[3], "throttled_periods": cg1[1] - cg0[1], "throttled_thread_ms": (cg1[2] - cg0[2]) / 1e3},
                                  "parity": {"checked": int(touched.sum()), "mismatches": int((got[touched] != want[touched]).sum()),
                                             "what": "checksum of (n_hits, num_matched, top-100 keys + 3 scores) of every 1-query call vs the 10 000-query batch"}}
         return out
@@ -608,7 +630,7 @@ class Bench:
             orc.bench_vector(qs[:ncpu], k, ncpu)
             wall, per = orc.bench_vector(qs, k, ncpu)
             qps_sample = qs.shape[0] / wall
-            res["cpu"] = dict(value=qps_sample * xs.shape[0] / n, unit="queries/s", cores=ncpu, kind="port",
+            res["cpu"] = dict(value=qps_sample * xs.shape[0] / n, unit="queries/s", cores=ncpu, cgroup_cpu_quota_cpus=cpu_quota_cpus(), kind="port",
                               sample="exact flat scan (1 - q.x, hnswlib 16-lane order) of %d queries over the first %d of %d base vectors on %d "
                                      "host threads, %.1f q/s on the sample, scaled by %d/%d (cost is linear in N); the full-size parity scan above ran "
                                      "%d queries over all %d rows in %.1f s incl. regenerating + copying the rows (%.2f q/s)"
@@ -751,7 +773,7 @@ class Bench:
             t3 = time.time()
             orc.hnsw_search_batch(Qh, k, 100, threads=ncpu)
             wall = time.time() - t3
-            res["cpu_baseline"] = {"value": Qh.shape[0] / wall, "unit": "queries/s", "cores": ncpu, "kind": "port",
+            res["cpu_baseline"] = {"value": Qh.shape[0] / wall, "unit": "queries/s", "cores": ncpu, "cgroup_cpu_quota_cpus": cpu_quota_cpus(), "kind": "port",
                                    "sample": "%d queries at ef=100 through the oracle's HNSW restatement (scalar 16-lane-order distances, pooled visited tags) on %d host threads, "
                                              "same graph, same rows; oracle load + import took %.0f s" % (Qh.shape[0], ncpu, t3 - t2)}
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]

@@ -23,7 +23,8 @@ g.column_set(0, synth.points_column(n_docs))
 g.set_num_docs(n_docs)
 g.commit()
 n_q = 10_000
-qtok = synth.keyword_queries(n_q, 3, 8, 2000, seed=4)
+lo, hi = [int(x) for x in os.environ.get("RANKS", "8,2000").split(",")]
+qtok = synth.keyword_queries(n_q, 3, lo, hi, seed=4)
 sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
 arr = (B.KwQueryC * n_q)()
 for i in range(n_q):
@@ -38,10 +39,22 @@ def run(threads, calls, qpc=1):
     got = np.zeros(n_q, np.uint64)
     fails = C.c_uint64(0)
     LG.tsgpu_loadgen_keyword(fn, g.h, C.cast(arr, C.c_void_p), n_q, 250, 100, threads, max(2, calls // 8), qpc, lat.ctypes.data, got.ctypes.data, C.byref(fails))
+    def cpu_stat():
+        try:
+            d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+            return int(d["usage_usec"]), int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+        except Exception:
+            return 0, 0, 0
+    cs0 = cpu_stat()
     c0 = {n: g.counter(n) for n in names}
+    [g.counter(n) for n in ("kw_max_plan_us", "kw_max_upload_us", "kw_max_launch_us", "kw_max_wait_us", "kw_max_queue_us", "kw_max_wake_us")]
     wall = LG.tsgpu_loadgen_keyword(fn, g.h, C.cast(arr, C.c_void_p), n_q, 250, 100, threads, calls, qpc, lat.ctypes.data, got.ctypes.data, C.byref(fails))
     c = {n: g.counter(n) - c0[n] for n in names}
+    cs1 = cpu_stat()
+    print("   cgroup: %.1f CPU-us per call (%.1f CPUs busy), throttled %d times for %.1f ms (cpu.max: %s)" % ((cs1[0] - cs0[0]) / (threads * calls * qpc), (cs1[0] - cs0[0]) / (wall * 1e6), cs1[1] - cs0[1], (cs1[2] - cs0[2]) / 1e3, open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "?"), flush=True)
     nb = max(c["kw_batches"], 1)
+    print("   slowest batch phase: plan %d upload %d launch %d wait %d us; longest parked->round start %d us, results ready->caller resumes %d us" % tuple(g.counter(n) for n in ("kw_max_plan_us", "kw_max_upload_us", "kw_max_launch_us", "kw_max_wait_us", "kw_max_queue_us", "kw_max_wake_us")), flush=True)
+    print("   latency us: mean %.0f p10 %.0f p25 %.0f p50 %.0f p75 %.0f p90 %.0f p99 %.0f max %.0f | wall %.1f ms for %d calls per thread -> %.0f us per call per thread" % (lat.mean(), *[np.percentile(lat, x) for x in (10, 25, 50, 75, 90, 99)], lat.max(), wall * 1e3, calls, wall * 1e6 / calls), flush=True)
     return dict(qps=threads * calls * qpc / wall, p50=float(np.percentile(lat, 50)), p99=float(np.percentile(lat, 99)), fails=fails.value,
                 q_per_batch=threads * calls * qpc / nb, plan=c["kw_plan_us"] / nb, upload=c["kw_upload_us"] / nb, launch=c["kw_launch_us"] / nb,
                 wait=c["kw_wait_us"] / nb, book=c["kw_book_us"] / nb, exec_round=c["batch_exec_us"] / max(c["batch_rounds"], 1),
@@ -63,11 +76,11 @@ for nb in (64, 128):
     print("direct batch %5d: %.0f us/call  plan %.0f upload %.0f launch %.0f wait %.0f book %.0f | gpu search %.3f merge %.3f ms" %
           (nb, dt * 1e6, c["kw_plan_us"], c["kw_upload_us"], c["kw_launch_us"], c["kw_wait_us"], c["kw_book_us"], g.timings().kw_search_ms, g.timings().kw_merge_ms), flush=True)
 
-for lanes, bmax, window in ((4, 64, 80), (2, 128, 80), (3, 128, 80), (4, 128, 80), (2, 256, 80), (2, 128, 40), (3, 96, 40), (8, 64, 80), (6, 48, 40)):
+for lanes, bmax, window in ((4, 128, 80), (4, 128, 80)):
     g.set_option("kw_lanes", lanes)
     g.set_option("batch_max_queries", bmax)
     g.set_option("batch_window_us", window)
-    for threads in (256,):
+    for threads in [int(x) for x in os.environ.get("THREADS", "256").split(",")]:
         r = run(threads, max(16, 30000 // threads))
         print("lanes %d max %3d window %3d threads %3d: %8.0f q/s p50 %6.0f p99 %6.0f us | %.1f q/batch plan %.0f upload %.0f launch %.0f wait %.0f book %.0f | round exec %.0f scatter %.0f us fails %d"
               % (lanes, bmax, window, threads, r["qps"], r["p50"], r["p99"], r["q_per_batch"], r["plan"], r["upload"], r["launch"], r["wait"], r["book"], r["exec_round"], r["scatter"], r["fails"]), flush=True)

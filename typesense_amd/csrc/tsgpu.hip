@@ -138,6 +138,7 @@ int tsgpu_create(int device_ordinal, tsgpu_ctx** out) {
         if (l == 0) { L.stream = ctx->stream; L.own_stream = false; }          // lane 0 shares the vector path's stream
         else good = good && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess;
         for (auto& ev : L.ev) good = good && hipEventCreate(&ev) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&L.ev_block, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
     }
     if (!good) { tsgpu_destroy(ctx); return fail(TSGPU_ERR_DEVICE, "tsgpu_create: stream / event creation failed"); }
     *out = ctx;
@@ -232,6 +233,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_sort_work")) { ctx->kw_sort_work = value != 0; return ok(); }
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
     if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
+    if (!strcmp(name, "blocking_sync_min_callers")) { ctx->blocking_sync_min_callers = (int)std::max<int64_t>(0, value); return ok(); }
     if (!strcmp(name, "plan_threads")) { if (value < 1 || value > 64) return fail(TSGPU_ERR_INVALID, "plan_threads: 1..64"); ctx->plan_threads = (int)value; return ok(); }
     if (!strcmp(name, "plan_parallel_min_queries")) { if (value < 0) return fail(TSGPU_ERR_INVALID, "plan_parallel_min_queries >= 0"); ctx->plan_parallel_min_queries = (uint32_t)value; return ok(); }
     if (!strcmp(name, "fuse_threads")) { if (value < 1 || value > 256) return fail(TSGPU_ERR_INVALID, "fuse_threads: 1..256"); ctx->fuse_threads = (int)value; return ok(); }
@@ -299,6 +301,12 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!strcmp(name, "commit_incremental_count")) { *out = ctx->commit_incremental_count; return ok(); }
     if (!strcmp(name, "kw_batches")) { *out = ctx->kw_batches.load(); return ok(); }                 // host-side phase totals (us) over all keyword batches
     if (!strcmp(name, "kw_plan_us")) { *out = ctx->kw_plan_us.load(); return ok(); }
+    if (!strcmp(name, "kw_max_plan_us")) { *out = ctx->kw_max_plan_us.exchange(0); return ok(); }       // (reading resets the maxima)
+    if (!strcmp(name, "kw_max_upload_us")) { *out = ctx->kw_max_upload_us.exchange(0); return ok(); }
+    if (!strcmp(name, "kw_max_launch_us")) { *out = ctx->kw_max_launch_us.exchange(0); return ok(); }
+    if (!strcmp(name, "kw_max_wait_us")) { *out = ctx->kw_max_wait_us.exchange(0); return ok(); }
+    if (!strcmp(name, "kw_max_queue_us")) { *out = ctx->kw_max_queue_us.exchange(0); return ok(); }     // parked -> its round starts executing
+    if (!strcmp(name, "kw_max_wake_us")) { *out = ctx->kw_max_wake_us.exchange(0); return ok(); }       // results ready -> the caller runs again
     if (!strcmp(name, "kw_upload_us")) { *out = ctx->kw_upload_us.load(); return ok(); }
     if (!strcmp(name, "kw_launch_us")) { *out = ctx->kw_launch_us.load(); return ok(); }
     if (!strcmp(name, "kw_wait_us")) { *out = ctx->kw_wait_us.load(); return ok(); }
@@ -710,27 +718,15 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
 
 // ---- lanes ----
 namespace {
-struct LaneLock {                                     // holds one execution lane for the duration of a batch
+struct LaneLock {                                     // holds one execution lane for the duration of a batch (FIFO: LaneDispenser)
     tsgpu_ctx* ctx; KwLane* L; int index;
     explicit LaneLock(tsgpu_ctx* c, int want = -1) : ctx(c), L(nullptr), index(-1) {
-        if (want < 0) {
-            const int n = c->n_lanes;
-            for (int i = 0; i < n && !L; i++) if (c->lanes[i].mu.try_lock()) { L = &c->lanes[i]; index = i; }
-            if (!L) {                                 // all busy: queue on the lane with the fewest waiters
-                want = 0;
-                for (int i = 1; i < n; i++) if (c->lanes[i].waiters.load() < c->lanes[want].waiters.load()) want = i;
-            }
-        }
-        if (!L) {
-            KwLane& l = c->lanes[want];
-            l.waiters.fetch_add(1);
-            l.mu.lock();
-            l.waiters.fetch_sub(1);
-            L = &l; index = want;
-        }
+        index = c->lane_dispenser.acquire(want, c->n_lanes);
+        L = &c->lanes[index];
+        L->mu.lock();                                 // (uncontended among LaneLock holders; tsgpu_set_stream takes it, too)
         c->last_lane.store(index);
     }
-    ~LaneLock() { L->mu.unlock(); }
+    ~LaneLock() { L->mu.unlock(); ctx->lane_dispenser.release(index, ctx->n_lanes); }
 };
 struct BatchOpts {
     bool wildcard = false;
@@ -769,6 +765,7 @@ struct KwRequest : ParkedRequest {
     const tsgpu_kw_query* q = nullptr;
     tsgpu_hits* out = nullptr;
     tsgpu_id_lists* ids = nullptr;                   // non-null: the caller wants its matched ids
+    uint64_t t_arrive = 0, t_done = 0;               // diagnostics: when it parked / when its round's results were ready
 };
 }
 
@@ -778,6 +775,8 @@ static int kw_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t 
     if (ids_out) { lists.reset(new (std::nothrow) tsgpu_id_lists); if (!lists) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_batch_ids: host allocation failed"); }
     KwRequest me;
     me.units = n_queries; me.q = queries; me.out = out; me.ids = lists.get();
+    me.t_arrive = now_us();
+    auto amax = [](std::atomic<uint64_t>& a, uint64_t v) { uint64_t c = a.load(); while (v > c && !a.compare_exchange_weak(c, v)) {} };
     auto acquire = [&]() { return std::unique_ptr<LaneLock>(new LaneLock(ctx)); };
     const uint32_t round_cap = std::max<uint32_t>(ctx->batch_round_queries, n_queries);
     auto pick = [&](std::vector<KwRequest*>& pending, std::vector<KwRequest*>& round) {
@@ -811,6 +810,7 @@ static int kw_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t 
             bo.id_lists = want_ids ? &all_ids : nullptr;
             bo.record_last = false;
             const uint64_t te0 = now_us();
+            for (KwRequest* r : round) amax(ctx->kw_max_queue_us, te0 - r->t_arrive);
             rc = kw_batch_on_lane(ctx, L, L.c_q.data(), total, &h, bo);
             const uint64_t te1 = now_us();
             ctx->batch_exec_us.fetch_add(te1 - te0);
@@ -847,9 +847,11 @@ static int kw_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t 
                 ctx->batch_scatter_us.fetch_add(now_us() - te1);
             }
         } catch (const std::bad_alloc&) { rc = TSGPU_ERR_NO_MEMORY; err = "tsgpu_keyword_search_batch: host allocation failed"; }
-        for (KwRequest* r : round) { r->rc = rc; r->err = err; }
+        const uint64_t td = now_us();
+        for (KwRequest* r : round) { r->rc = rc; r->err = err; r->t_done = td; }
     };
     ctx->kw_comb.run(me, ctx->kw_callers, ctx->batch_window_us, acquire, pick, exec);
+    if (me.t_done) amax(ctx->kw_max_wake_us, now_us() - me.t_done);
     if (me.rc != TSGPU_OK) return fail(me.rc, me.err);
     if (ids_out) *ids_out = lists.release();
     return ok();
@@ -1121,7 +1123,10 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             if (stage) {
                 if ((rc = L.h_out.reserve(out_bytes + 64))) return rc;
                 TSGPU_HIP_TRY(hipMemcpyAsync(L.h_out.p, L.d_out_keys.p, out_bytes, hipMemcpyDeviceToHost, s));
-                TSGPU_HIP_TRY(hipStreamSynchronize(s));
+                // (a spinning wait costs one CPU per lane for the whole round: with many request threads — and a CPU quota — the waiting
+                //  thread sleeps on a blocking event instead: +20-40 us of latency, four CPUs back)
+                if (ctx->kw_callers.load() >= ctx->blocking_sync_min_callers) { TSGPU_HIP_TRY(hipEventRecord(L.ev_block, s)); TSGPU_HIP_TRY(hipEventSynchronize(L.ev_block)); }
+                else TSGPU_HIP_TRY(hipStreamSynchronize(s));
                 const uint8_t* hb = (const uint8_t*)L.h_out.p;
                 memcpy(out->n_hits, hb + out_at[0], (size_t)n_queries * 4);
                 if (out->num_matched) memcpy(out->num_matched, hb + out_at[1], (size_t)n_queries * 8);
@@ -1245,6 +1250,9 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             const uint64_t t_end = now_us();
             ctx->kw_batches.fetch_add(1); ctx->kw_plan_us.fetch_add(t_planned - t_enter); ctx->kw_upload_us.fetch_add(t_uploaded - t_planned);
             ctx->kw_launch_us.fetch_add(t_launched - t_uploaded); ctx->kw_wait_us.fetch_add(t_synced - t_launched); ctx->kw_book_us.fetch_add(t_end - t_synced);
+            auto amax = [](std::atomic<uint64_t>& a, uint64_t v) { uint64_t c = a.load(); while (v > c && !a.compare_exchange_weak(c, v)) {} };
+            amax(ctx->kw_max_plan_us, t_planned - t_enter); amax(ctx->kw_max_upload_us, t_uploaded - t_planned);
+            amax(ctx->kw_max_launch_us, t_launched - t_uploaded); amax(ctx->kw_max_wait_us, t_synced - t_launched);
         }
         if (host_timing)
             fprintf(stderr, "[tsgpu] kw batch %u queries: plan %llu us, upload+reserve %llu us, launch %llu us, wait+copy %llu us, bookkeeping %llu us\n", n_queries,

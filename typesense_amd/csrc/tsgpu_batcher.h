@@ -101,7 +101,9 @@ struct Combiner {
         }
         // ---- parked: spin briefly, then sleep on the bank word ----
         uint32_t st = me.state.load(std::memory_order_acquire);
-        for (int spin = 0; st == ParkedRequest::PARKED && spin < 200; spin++) {
+        // (the spin only pays when a round completes within microseconds, i.e. with few callers; with many it is CPU the quota may not have)
+        const int spins = callers.load(std::memory_order_relaxed) >= 48 ? 0 : 200;
+        for (int spin = 0; st == ParkedRequest::PARKED && spin < spins; spin++) {
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <deque>
 #include <functional>
 #include <vector>
 #include <mutex>
@@ -44,8 +45,12 @@ struct DevBuf {
     size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap) return TSGPU_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        // geometric growth (and never tiny): a re-allocation is a device-wide synchronisation of milliseconds — with exact-fit growth
+        // the lanes of the 1-query-caller regime, whose rounds differ in size, kept paying it (latency tail of 10-50 ms)
         size_t want = bytes + bytes / 4 + 256;
+        if (want < 2 * cap) want = 2 * cap;
+        if (want < (64u << 10)) want = 64u << 10;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         TSGPU_HIP_TRY(hipMalloc(&p, want));
         cap = want;
         return TSGPU_OK;
@@ -58,8 +63,10 @@ struct PinBuf {
     size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap) return TSGPU_OK;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 4 + 256;
+        if (want < 2 * cap) want = 2 * cap;
+        if (want < (64u << 10)) want = 64u << 10;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
         TSGPU_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
         cap = want;
         return TSGPU_OK;
@@ -169,6 +176,7 @@ struct KwLane {
     hipStream_t stream = nullptr;
     bool own_stream = true;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_block = nullptr;                   // hipEventBlockingSync: the waiting thread sleeps instead of spinning (many concurrent callers)
     DevBuf d_plan, d_ids_out;                        // the batch plan (queries, work items, aux ids, multi-field descriptors, hit offsets): one upload
     DevBuf d_part_s0, d_part_s1, d_part_s2, d_part_key, d_part_cnt, d_part_nm, d_part_ne, d_part_ow, d_part_f;
     DevBuf d_out_keys, d_out_scores, d_out_tm, d_out_vd, d_out_msi, d_out_nh, d_out_nm, d_out_ow, d_out_cut;
@@ -204,6 +212,7 @@ struct KwLane {
         for (auto* b : bufs) b->release();
         h_out.release(); h_plan.release();
         for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (ev_block) { (void)hipEventDestroy(ev_block); ev_block = nullptr; }
         if (own_stream && stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -264,8 +273,41 @@ struct HostPool {
     }
 };
 
+// Execution lanes are handed out in ARRIVAL ORDER. (A bare try_lock / lock on the lanes' mutexes let newly arriving round leaders barge
+// past one that was already waiting: under 192+ request threads a round could starve for 40-60 ms — 0.2 % of the calls, and the whole
+// tail of the latency distribution.) want < 0: any lane below n_lanes; else that lane.
+struct LaneDispenser {
+    struct Waiter { int want; int granted = -1; };
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Waiter*> q;
+    bool busy[8] = {false, false, false, false, false, false, false, false};
+    static bool can(int lane, int want, int n) { return want < 0 ? lane < n : want == lane; }
+    int acquire(int want, int n_lanes) {
+        std::unique_lock<std::mutex> lk(m);
+        for (int lane = 0; lane < 8; lane++) {
+            if (busy[lane] || !can(lane, want, n_lanes)) continue;
+            bool earlier = false;
+            for (const Waiter* w : q) if (can(lane, w->want, n_lanes)) { earlier = true; break; }
+            if (!earlier) { busy[lane] = true; return lane; }
+        }
+        Waiter me{want};
+        q.push_back(&me);
+        cv.wait(lk, [&] { return me.granted >= 0; });
+        return me.granted;
+    }
+    void release(int lane, int n_lanes) {
+        std::lock_guard<std::mutex> lk(m);
+        for (auto it = q.begin(); it != q.end(); ++it) {
+            if (can(lane, (*it)->want, n_lanes)) { (*it)->granted = lane; q.erase(it); cv.notify_all(); return; }      // the lane changes hands, still busy
+        }
+        busy[lane] = false;
+    }
+};
+
 struct tsgpu_ctx {
     HostPool host_pool;
+    LaneDispenser lane_dispenser;
     static const int N_LANES = 8;                    // lanes that exist; `n_lanes` of them are used (option "kw_lanes")
     int n_lanes = 4;
     int device = 0;
@@ -299,6 +341,8 @@ struct tsgpu_ctx {
     uint32_t batch_round_queries = 1024;             // queries per coalesced round at most
 
     // host-side phase totals of every keyword batch (us; introspection for the latency budget of small batches)
+    std::atomic<uint64_t> kw_max_queue_us{0}, kw_max_wake_us{0};
+    std::atomic<uint64_t> kw_max_plan_us{0}, kw_max_upload_us{0}, kw_max_launch_us{0}, kw_max_wait_us{0};     // slowest phase of any batch since the last read (diagnostics)
     std::atomic<uint64_t> kw_batches{0}, kw_plan_us{0}, kw_upload_us{0}, kw_launch_us{0}, kw_wait_us{0}, kw_book_us{0}, batch_exec_us{0}, batch_scatter_us{0};
     tsgpu::DevBuf d_prof;                            // TSGPU_PROF builds only (null otherwise)
     bool keep_ids = false;
@@ -317,6 +361,7 @@ struct tsgpu_ctx {
     uint32_t vec_cand_cap = 0;                       // candidate slots per query in pass 2 (0 = automatic)
     uint32_t vec_prefilter = 1;                      // 1 = bf16 bracket scan + exact fp32 re-score (default); 0 = fp32 MFMA scan
     uint64_t vec_prefilter_groups = 0;               // query groups answered by the bf16 bracket path
+    int blocking_sync_min_callers = 48;               // from this many threads inside the keyword entry point a lane waits for its round by sleeping (option)
     int plan_threads = 8;                             // host threads that plan a big keyword batch in slices ("plan_threads")
     uint32_t plan_parallel_min_queries = 2048;        // ... from this many queries on (0 = never; "plan_parallel_min_queries")
     int fuse_threads = 32;                            // host threads of the hybrid rank fusion (option "fuse_threads")
