@@ -7,6 +7,8 @@
 #include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "../../../include/tsgpu.h"
@@ -17,9 +19,17 @@ typedef int (*knn_fn)(tsgpu_ctx*, uint32_t, const float*, int, uint32_t, uint32_
 
 inline uint64_t mix(uint64_t h, uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); return h; }
 
+// a SLEEPING start barrier: 256 threads yielding in a loop until the last one has been created burn more CPU than the measured calls
+// (and, under a container CPU quota, get the whole process throttled before the first call)
 struct SpinBarrier {
-    std::atomic<uint32_t> n{0};
-    void wait(uint32_t total) { n.fetch_add(1); while (n.load() < total) std::this_thread::yield(); }
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t n = 0;
+    void wait(uint32_t total) {
+        std::unique_lock<std::mutex> lk(m);
+        if (++n >= total) cv.notify_all();
+        else cv.wait(lk, [&] { return n >= total; });
+    }
 };
 }  // namespace
 
