@@ -1816,11 +1816,125 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_groups_kernel(const KwQue
     if (threadIdx.x == 0) part.cnt[g.dst] = n;
 }
 
+// SELECT instead of fold, for a query cut into many work items (small batches are cut fine so that no work item runs long): the top k
+// of P sorted lists without touching most of their entries, at a cost that does not grow with P (a fold per list does).
+//   1. every list offers a PREFIX of ~2k / P entries; the union of the prefixes (<= 1 024 entries) is sorted in LDS: its k-th largest
+//      entry tau is a lower bound of the k-th best overall (k real entries are >= tau);
+//   2. per list a binary search counts its entries >= tau (one thread per list) — the prefixes' share of them is exactly k, the rest
+//      comes from lists whose whole prefix beat tau; these candidates (typically k .. 1.5 k) are gathered and sorted: the first k are
+//      the result (keys are unique: no ties).
+// Returns false (nothing written) when prefixes or candidates do not fit the LDS buffer: the caller folds the lists instead.
+// exclusive prefix sums of in[0 .. n) (n <= 2 * KW_THREADS, LDS) into out[0 .. n], out[n] = total; wsum: [KW_THREADS / 64] scratch.
+// Every thread of the block calls it. (A single thread walking 384 LDS words costs ~11 us at one wave per SIMD; this is ~1 us.)
+__device__ inline void block_excl_scan(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* wsum) {
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t a = 2 * t < n ? in[2 * t] : 0u, b = 2 * t + 1 < n ? in[2 * t + 1] : 0u;
+    uint32_t incl = a + b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < KW_THREADS / 64; w++) { const uint32_t c = wsum[w]; if ((uint32_t)w < wave) base += c; tot += c; }
+    const uint32_t ex = base + incl - (a + b);
+    if (2 * t < n) out[2 * t] = ex;
+    if (2 * t + 1 < n) out[2 * t + 1] = ex + a;
+    if (t == 0) out[n] = tot;
+    __syncthreads();
+}
+static const int KW_SEL_PMAX = 384;                      // lists per query (planner: max_partials <= 384)
+static const int KW_SEL_CCAP = 1024;                     // entries the LDS buffer holds
+struct KwSelectLds {
+    TopkLds<KW_SEL_CCAP, true> cb;
+    uint32_t cnt[KW_SEL_PMAX], take[KW_SEL_PMAX], off[KW_SEL_PMAX + 1], wsum[KW_THREADS / 64];
+    uint32_t total, n_nonempty, ok;
+};
+__device__ inline bool kw_select_partials(KwSelectLds& sl, const KwPartials& part, uint32_t first, uint32_t P, uint32_t k, const KwOut& out, size_t ob, int msi,
+                                          uint32_t& n_out) {
+    const uint32_t t = threadIdx.x;
+    if (t == 0) sl.ok = 1;
+    uint32_t my_nne = 0;
+    for (uint32_t w = t; w < P; w += KW_THREADS) {
+        const uint32_t c = part.cnt[first + w];
+        sl.cnt[w] = c;
+        sl.take[w] = c ? 1u : 0u;
+        my_nne += c ? 1u : 0u;
+    }
+    __syncthreads();
+    block_excl_scan(sl.cnt, sl.off, P, sl.wsum);
+    if (t == 0) sl.total = sl.off[P];
+    block_excl_scan(sl.take, sl.off, P, sl.wsum);
+    if (t == 0) sl.n_nonempty = sl.off[P];
+    __syncthreads();
+    (void)my_nne;
+    const uint32_t total = sl.total, nne = sl.n_nonempty;
+    if (total == 0) { n_out = 0; return true; }
+    // gathers take[w] leading entries of every list into cb (padded to a power of two), sorted descending; returns the count
+    auto gather_sorted = [&]() -> uint32_t {
+        block_excl_scan(sl.take, sl.off, P, sl.wsum);
+        if (t == 0 && sl.off[P] > (uint32_t)KW_SEL_CCAP) sl.ok = 0;
+        __syncthreads();
+        if (!sl.ok) return 0;
+        const uint32_t C = sl.off[P];
+        uint32_t n2 = 2;
+        while (n2 < C) n2 <<= 1;
+        for (uint32_t i = t; i < n2; i += KW_THREADS) {
+            if (i < C) {                                 // entry i belongs to the list w with off[w] <= i < off[w + 1]
+                uint32_t lo = 0, hi = P;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sl.off[mid] <= i) lo = mid; else hi = mid; }
+                const size_t e = (size_t)(first + lo) * part.k_stride + (i - sl.off[lo]);
+                sl.cb.s0[i] = part.s0[e]; sl.cb.s1[i] = part.s1[e]; sl.cb.s2[i] = part.s2[e]; sl.cb.key[i] = part.key[e];
+            } else sl.cb.key[i] = -1;                    // padding sorts last
+        }
+        topk_sort<KW_SEL_CCAP, true>(sl.cb, (int)n2);   // (starts and ends with a barrier)
+        return C;
+    };
+    uint32_t C;
+    if (total <= (uint32_t)KW_SEL_CCAP) {
+        for (uint32_t w = t; w < P; w += KW_THREADS) sl.take[w] = sl.cnt[w];          // few entries altogether: all of them
+        __syncthreads();
+        C = gather_sorted();
+    } else {
+        const uint32_t m = (2 * k + nne - 1) / nne;      // prefixes: >= 2k entries offered in total (total > CCAP >= k)
+        for (uint32_t w = t; w < P; w += KW_THREADS) { const uint32_t c = sl.cnt[w]; sl.take[w] = c < m ? c : m; }
+        __syncthreads();
+        const uint32_t S = gather_sorted();
+        if (!sl.ok || S < k) return false;               // (S < k: many short lists next to a few long ones — the bound needs k prefix entries)
+        const int64_t u0 = sl.cb.s0[k - 1], u1 = sl.cb.s1[k - 1], u2 = sl.cb.s2[k - 1], uk = sl.cb.key[k - 1];         // tau
+        __syncthreads();
+        for (uint32_t w = t; w < P; w += KW_THREADS) {
+            const uint32_t c = sl.cnt[w];
+            const size_t base = (size_t)(first + w) * part.k_stride;
+            uint32_t lo = 0, hi = c;                     // first index whose entry is LESS than tau (tau itself counts)
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ent_greater(u0, u1, u2, uk, part.s0[base + mid], part.s1[base + mid], part.s2[base + mid], part.key[base + mid])) hi = mid; else lo = mid + 1;
+            }
+            sl.take[w] = lo;
+        }
+        __syncthreads();
+        C = gather_sorted();
+    }
+    if (!sl.ok) return false;
+    n_out = C < k ? C : k;
+    for (uint32_t i = t; i < n_out; i += KW_THREADS) {
+        const int64_t a0 = sl.cb.s0[i], a1 = sl.cb.s1[i], a2 = sl.cb.s2[i];
+        out.keys[ob + i] = (uint64_t)sl.cb.key[i];
+        out.scores[(ob + i) * 3 + 0] = a0; out.scores[(ob + i) * 3 + 1] = a1; out.scores[(ob + i) * 3 + 2] = a2;
+        out.text_match[ob + i] = msi == 0 ? a0 : (msi == 1 ? a1 : (msi == 2 ? a2 : 0));
+        out.vector_distance[ob + i] = -1.0f;
+        out.match_score_index[ob + i] = (int8_t)msi;
+    }
+    return true;
+}
+
 // grid = queries; folds a query's partials into the final order and writes the tsgpu_hits slots
 template <int CAP>
 __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* __restrict__ queries, KwPartials part, KwOut out,
-                                                               uint32_t* __restrict__ ids_out, const KwWorkItem* __restrict__ work) {
+                                                               uint32_t* __restrict__ ids_out, const KwWorkItem* __restrict__ work, uint32_t select_min) {
     __shared__ TopkLds<CAP> tk;
+    __shared__ KwSelectLds sl;
     __shared__ unsigned long long s_nm, s_ow;
     const uint32_t t = threadIdx.x;
     const KwQueryDev q = queries[blockIdx.x];
@@ -1829,8 +1943,11 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
     const size_t ob = (size_t)blockIdx.x * out.k_stride;
     int msi = -1;
     for (int i = 0; i < 3; i++) if (i < q.n_sort && q.sort_kind[i] == 0) msi = i;
-    uint32_t n;
-    if (q.m_n == 1) {
+    uint32_t n = 0;
+    bool selected = false;
+    if (select_min && q.m_n >= select_min && q.m_n <= (uint32_t)KW_SEL_PMAX) selected = kw_select_partials(sl, part, q.m_first, q.m_n, q.k, out, ob, msi, n);   // (uniform)
+    if (selected) {
+    } else if (q.m_n == 1) {
         // a single list already holds the query's final order: copy it through
         const uint32_t w = q.m_first;
         n = part.cnt[w];
