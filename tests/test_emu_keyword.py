@@ -579,10 +579,13 @@ def test_edge_cases_empty_index_missing_tokens_and_degenerate_topsters():
     g.close()
 
 
-def test_two_level_merge_many_work_items():
-    """a query cut into more than 16 work items: its partial lists are folded in groups of 8 (kw_merge_groups_kernel), then per query"""
+@pytest.mark.parametrize("select_min", [17, 0, 3])
+def test_two_level_merge_many_work_items(select_min):
+    """a query cut into more than 16 work items: merged by selection (kw_select_partials: prefix union -> threshold -> candidates -> sort;
+    select_min = 3: also the queries with few lists) or, kw_merge_select_min = 0, folded in groups of 8 (kw_merge_groups_kernel), then per query"""
     docs = H.zipf_docs(6200, 3, 5, seed=12, s=0.2)
     orc, g = H.build_pair(docs, H.emu_lib_path())
+    g.set_option("kw_merge_select_min", select_min)
     g.set_option("kw_chunk_blocks", 1)
     sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
     qs = [T.KwQuery([1], sort=sort, topster_size=40), T.KwQuery([2, 1], sort=sort, topster_size=250), T.KwQuery([3, 1, 2], sort=sort, topster_size=7),
