@@ -1904,9 +1904,13 @@ __device__ inline bool kw_select_partials(KwSelectLds& sl, const KwPartials& par
         const int64_t u0 = sl.cb.s0[k - 1], u1 = sl.cb.s1[k - 1], u2 = sl.cb.s2[k - 1], uk = sl.cb.key[k - 1];         // tau
         __syncthreads();
         for (uint32_t w = t; w < P; w += KW_THREADS) {
-            const uint32_t c = sl.cnt[w];
+            const uint32_t c = sl.cnt[w], mw = c < m ? c : m;
             const size_t base = (size_t)(first + w) * part.k_stride;
             uint32_t lo = 0, hi = c;                     // first index whose entry is LESS than tau (tau itself counts)
+            if (mw) {                                    // one probe at the prefix's end: most lists end inside their (short) prefix
+                const size_t e = base + mw - 1;
+                if (ent_greater(u0, u1, u2, uk, part.s0[e], part.s1[e], part.s2[e], part.key[e])) hi = mw - 1; else lo = mw;
+            }
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
                 if (ent_greater(u0, u1, u2, uk, part.s0[base + mid], part.s1[base + mid], part.s2[base + mid], part.key[base + mid])) hi = mid; else lo = mid + 1;
