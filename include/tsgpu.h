@@ -114,7 +114,15 @@ int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
  * (identical result sets either way), "vec_count_rescored" = 1: keep the vec_rescored_rows counter (costs one sync);
  * micro-batcher: "batch_max_queries" = calls with at most this many queries are coalesced with concurrent callers (default 64,
  * 0 = never), "batch_window_us" = how long a round's leader waits for the other threads that are inside the entry point to
- * park (default 80), "batch_round_queries" = queries per coalesced round at most (default 1024) */
+ * park (default 80), "batch_round_queries" = queries per coalesced round at most (default 1024);
+ * "kw_merge_select_min" = from this many per-work-item Topsters per query the merge selects (threshold of the k-th largest of a
+ * prefix union, then gather + sort) instead of folding pairwise (default 17; 0 = always fold; identical results);
+ * host side: "plan_threads" (default 8) / "plan_parallel_min_queries" (default 2048) = the work table of a batch with at least
+ * that many queries is planned in slices on the context's parked host threads, "fuse_threads" (default 32) = host threads of the
+ * hybrid fusion, "blocking_sync_min_callers" (default 48) = from this many threads inside the keyword entry point a round is
+ * awaited with a blocking event instead of a spinning stream wait (the request threads need the cores);
+ * "hnsw_visited_max_gib" (default 64, 1..128) = cap of a field's HNSW visited-tag array (2 bytes x rows x concurrent queries:
+ * 4096 queries traverse at once up to 8M rows, 2048 at 10M; read by the next tsgpu_vec_hnsw_load) */
 int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value);
 /* introspection counters (tests / bench): "vec_overflow_rounds", "vec_prefilter_groups", "vec_prefilter_fallbacks",
  * "vec_rescored_rows", "kw_last_hit_groups" (find+score groups of the last keyword batch, 0 = fused), "kw_last_hit_records",

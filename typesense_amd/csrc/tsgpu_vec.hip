@@ -732,9 +732,9 @@ int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32
     TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_ptr.p, upper_ptr, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
     if (n_upper) TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_links.p, upper_links, (size_t)n_upper * (1 + M) * 4, hipMemcpyHostToDevice, s));
     // visited tags: one uint16 per row and concurrent query slot (hnswlib's VisitedListPool); the overflow counter sits behind them
-    // (16-bit tags, 16 GiB at most: 4096 concurrent queries up to 2M rows, 512 at 10M)
+    // (16-bit tags, option hnsw_visited_max_gib = 64 GiB by default: 4096 concurrent queries up to 8M rows, 2048 at 10M = 41 GB)
     uint32_t slots = 4096;
-    while (slots > 32 && (uint64_t)slots * std::max<uint32_t>(n, 1) * 2 > (16ull << 30)) slots >>= 1;
+    while (slots > 32 && (uint64_t)slots * std::max<uint32_t>(n, 1) * 2 > ((uint64_t)ctx->hnsw_visited_max_gib << 30)) slots >>= 1;
     if ((rc = f->g_visited.reserve((size_t)slots * std::max<uint32_t>(n, 1) * 2 + 64))) return rc;
     TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, (size_t)slots * std::max<uint32_t>(n, 1) * 2 + 64, s));
     TSGPU_HIP_TRY(hipStreamSynchronize(s));
