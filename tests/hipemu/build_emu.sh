@@ -13,12 +13,16 @@ mkdir -p "$HERE/_build"
 EXTRA="$1"
 OUT="$HERE/_build/libtsgpu_emu$2.so"
 SRCS="$ROOT/typesense_amd/csrc/tsgpu.hip $ROOT/typesense_amd/csrc/tsgpu_index.hip $ROOT/typesense_amd/csrc/tsgpu_vec.hip $ROOT/typesense_amd/csrc/tsgpu_facet.hip"
+# one builder at a time (pytest -n: every worker calls this), and the library appears atomically
+exec 9>"$OUT.lock"
+flock 9
 NEWER=0
 for f in $SRCS "$ROOT"/typesense_amd/csrc/*.h "$ROOT"/include/*.h "$HERE"/hip/hip_runtime.h; do
   if [ ! -f "$OUT" ] || [ "$f" -nt "$OUT" ]; then NEWER=1; fi
 done
 if [ "$NEWER" = 1 ]; then
   "$CXX" -x c++ -std=c++17 -O1 -g -fPIC -shared -ffp-contract=off -DTSGPU_HIP_EMU=1 -Wno-unused-value -Wno-macro-redefined -Wno-psabi \
-      $EXTRA -I "$HERE" -o "$OUT" $SRCS -lpthread
+      $EXTRA -I "$HERE" -o "$OUT.tmp.$$" $SRCS -lpthread
+  mv -f "$OUT.tmp.$$" "$OUT"
 fi
 echo "$OUT"

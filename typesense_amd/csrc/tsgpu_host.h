@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <chrono>
 #include <new>
+#include <exception>
 #include "../../include/tsgpu.h"
 #include "tsgpu_format.h"
 #include "tsgpu_pack.h"
@@ -250,21 +251,29 @@ struct HostPool {
                 seen = gen;
                 j = job;
             }
-            (*j)();
-            { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) done_cv.notify_all(); }
+            std::exception_ptr ex;
+            try { (*j)(); } catch (...) { ex = std::current_exception(); }
+            { std::lock_guard<std::mutex> lk(mu); if (ex && !failed) failed = ex; if (--pending == 0) done_cv.notify_all(); }
         }
     }
     // runs f on `helpers` pool threads and on the caller; returns when all are done. One call at a time (callers serialise on run_mu).
+    // An exception thrown by f on any thread (std::bad_alloc of a plan slice) is rethrown here AFTER every thread has left f.
     std::mutex run_mu;
+    std::exception_ptr failed;
     void run(const std::function<void()>& f, int helpers) {
         std::lock_guard<std::mutex> rl(run_mu);
         try { while ((int)th.size() < helpers) { const int idx = (int)th.size(); th.emplace_back([this, idx] { worker(idx); }); } } catch (...) { helpers = (int)th.size(); }
         { std::lock_guard<std::mutex> lk(mu); job = &f; want = helpers; pending = helpers; gen++; }
         cv.notify_all();
-        f();
+        std::exception_ptr mine;
+        try { f(); } catch (...) { mine = std::current_exception(); }
         std::unique_lock<std::mutex> lk(mu);
         done_cv.wait(lk, [&] { return pending == 0; });
         job = nullptr; want = 0;
+        std::exception_ptr ex = mine ? mine : failed;
+        failed = nullptr;
+        lk.unlock();
+        if (ex) std::rethrow_exception(ex);
     }
     ~HostPool() {
         { std::lock_guard<std::mutex> lk(mu); stop = true; }
