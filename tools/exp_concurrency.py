@@ -76,13 +76,19 @@ for nb in (64, 128):
     print("direct batch %5d: %.0f us/call  plan %.0f upload %.0f launch %.0f wait %.0f book %.0f | gpu search %.3f merge %.3f ms" %
           (nb, dt * 1e6, c["kw_plan_us"], c["kw_upload_us"], c["kw_launch_us"], c["kw_wait_us"], c["kw_book_us"], g.timings().kw_search_ms, g.timings().kw_merge_ms), flush=True)
 
-for lanes, bmax, window, blk in ((4, 128, 80, 48), (4, 128, 80, 100000), (8, 64, 80, 100000), (8, 64, 40, 48), (6, 96, 60, 100000), (8, 128, 80, 100000)):
+SWEEP = os.environ.get("SWEEP", "lanes")
+if SWEEP == "chunk":      # driver blocks per work item under 256 callers (auto = 8 for rounds of <= 128 queries: the single-call latency optimum)
+    combos = [(4, 128, 80, 48, ch) for ch in (0, 16, 32, 64, 0)]
+else:
+    combos = [(l, m, w, b, 0) for l, m, w, b in ((4, 128, 80, 48), (4, 128, 80, 100000), (8, 64, 80, 100000), (8, 64, 40, 48), (6, 96, 60, 100000), (8, 128, 80, 100000))]
+for lanes, bmax, window, blk, chunk in combos:
+    g.set_option("kw_chunk_blocks", chunk)
     g.set_option("blocking_sync_min_callers", blk)
     g.set_option("kw_lanes", lanes)
     g.set_option("batch_max_queries", bmax)
     g.set_option("batch_window_us", window)
     for threads in [int(x) for x in os.environ.get("THREADS", "256").split(",")]:
         r = run(threads, max(16, 30000 // threads))
-        print("blk %d lanes %d max %3d window %3d threads %3d: %8.0f q/s p50 %6.0f p99 %6.0f us | %.1f q/batch plan %.0f upload %.0f launch %.0f wait %.0f book %.0f | round exec %.0f scatter %.0f us fails %d"
-              % (blk, lanes, bmax, window, threads, r["qps"], r["p50"], r["p99"], r["q_per_batch"], r["plan"], r["upload"], r["launch"], r["wait"], r["book"], r["exec_round"], r["scatter"], r["fails"]), flush=True)
+        print("chunk %d blk %d lanes %d max %3d window %3d threads %3d: %8.0f q/s p50 %6.0f p99 %6.0f us | %.1f q/batch plan %.0f upload %.0f launch %.0f wait %.0f book %.0f | round exec %.0f scatter %.0f us fails %d"
+              % (chunk, blk, lanes, bmax, window, threads, r["qps"], r["p50"], r["p99"], r["q_per_batch"], r["plan"], r["upload"], r["launch"], r["wait"], r["book"], r["exec_round"], r["scatter"], r["fails"]), flush=True)
 g.close()
