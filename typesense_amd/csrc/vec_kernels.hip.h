@@ -553,7 +553,11 @@ __device__ inline void vec_glds_wait() {        // all but the youngest N vector
 //     in flight per CU (80-96 KB instead of 48): 5.0-5.5 ms. Depth is not the limiter;
 //   * workgroups of an XCD walking the k chunks in rotated order (no two ask L2 for the same query block at once): no change;
 //   * query blocks through registers (global_load -> ds_write_b128 by waves 4-7) to leave the DMA path to the rows: 6.3-8 ms (the
-//     loading waves stall their own MFMA stream on L2 latency).
+//     loading waves stall their own MFMA stream on L2 latency);
+//   * row operand straight from global memory into the MFMA's registers (a 16-byte load per lane = its 8 k of a row; a re-tiled mirror makes
+//     a wave-wide load 1 KB contiguous; 4-deep register ring, asm-issued loads with counted waits), only the query block in LDS: half the
+//     DMA landings, two thirds of the operand fetches, identical results, 4.74-4.81 ms. Its ablations: ds_read_b128 + barriers alone 2.07 ms,
+//     + MFMAs 3.18 ms, all data movement without MFMAs 3.57 ms (tools/experiments/, profiles/r02/exp_vec_rows_direct.txt).
 static const int VEC_HTHREADS = 512;
 static const int VEC_HROWS = 2 * VEC_ROWS;          // rows per workgroup step (two 128-row tiles)
 static const int VEC_HMAX_PER = 2048;               // tile ordinals per slab whose norm maxima are staged in LDS
