@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3     # fp32-input MFMA dense peak
 MFMA_BF16_PEAK_TF = 2500.0   # bf16 MFMA dense peak (no sparsity)
+MFMA_BF16_ISSUE_CEILING_TF = 1580.0   # measured: vec_hscan_kernel<4> with only its MFMAs left in (profiles/r02/exp_vec_abl_mfma.txt: 3.93e12 flop in 2.49 ms)
 FETCH_SIZE = 100
 K_TOPSTER = 250
 PROFILE_ROUND = "r02"
@@ -1026,7 +1027,13 @@ def main():
                              "kernel_ms": r["scan_ms"], "algorithmic_bytes_per_launch": r["scan_bytes"], "flops_per_launch": r["flops"],
                              "hbm_GBs": gbs, "bf16_mfma_TFs": tfh, "pre_ms (query cast + sample pass + threshold)": r["kern_ms"] - r["scan_ms"],
                              "post_ms (refine + fp32 re-score + select)": r["post_ms"],
-                             "prefilter_fallbacks": r["fallbacks"], "overflow_rounds": r["overflow_rounds"]}
+                             "prefilter_fallbacks": r["fallbacks"], "overflow_rounds": r["overflow_rounds"],
+                             # measured, not nominal: the same kernel with everything but its MFMAs compiled out (no DMA, no operand fetches, no
+                             # epilogue; profiles/r02/exp_vec_abl_mfma.txt) runs the 256-query scan of 10M x 768 in 2.49 ms
+                             "mfma_issue_ceiling_TFs": MFMA_BF16_ISSUE_CEILING_TF, "frac_of_mfma_issue_ceiling": tfh / MFMA_BF16_ISSUE_CEILING_TF,
+                             "note": "bound chosen from the nominal peaks (HBM 8 TB/s vs dense bf16 MFMA 2.5 PFLOP/s); back-to-back v_mfma_f32_32x32x16_bf16 "
+                                     "from this kernel's two waves per SIMD deliver %.0f TFLOP/s (MFMA-only ablation), which at 256 queries per row makes MFMA "
+                                     "issue (2.5 ms), not HBM (1.9 ms), the floor of the scan" % MFMA_BF16_ISSUE_CEILING_TF}
         else:
             traffic = pmc_traffic(r"vec_scan_kernel", "pmc_vec_final_fetch.txt")
             v["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,

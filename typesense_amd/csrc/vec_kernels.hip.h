@@ -684,7 +684,7 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
                     for (int e = 0; e < 16; e++) acc[rb][cb][e] = 0.0f;
         }
         // no branch around the DMAs: steps past the end re-request the last blocks into slots nobody reads any more
-#if !defined(VEC_ABL) || !(VEC_ABL & 4)   // VEC_ABL: tools/ ablation builds only (bit 0 no epilogue, bit 1 no MFMA, bit 2 no DMA)
+#if !defined(VEC_ABL) || !(VEC_ABL & 4)   // VEC_ABL: tools/ ablation builds only (bit 0 no epilogue, bit 1 no MFMA, bit 2 no DMA, bit 3 no operand fetches, bit 4 no step barrier)
         load_q(s + NS - 1 < total_steps ? s + NS - 1 : last, xslot >= 1 ? xslot - 1 : NS - 1);       // (s + NS - 1) % NS
         load_x(s + NS - 1 < total_steps ? s + NS - 1 : last, xslot >= 1 ? xslot - 1 : NS - 1);
 #endif
@@ -693,6 +693,18 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
 #pragma unroll
         for (int g = 0; g < KS; g++) {
             const int cur = g & 1, nx = cur ^ 1;                 // KS is even: every step starts on buffer 0
+#if defined(VEC_ABL) && (VEC_ABL & 8)
+            if (g + 1 == KS) {
+                vec_glds_wait<(NS - 2) * (XV + QV)>();
+#if !(VEC_ABL & 16)
+                __syncthreads();
+#endif
+            }
+            av[nx][0] = av[cur][0]; av[nx][1] = av[cur][1];
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) bv[nx][cb] = bv[cur][cb];
+            if (true) {} else
+#endif
             if (g + 1 < KS) {
 #pragma unroll
                 for (int rb = 0; rb < 2; rb++) av[nx][rb] = *(const uint4*)(xa + rb * 32 * RW + poff[g + 1 < KS ? g + 1 : g]);
