@@ -19,3 +19,35 @@ def pytest_configure(config):
             torch.zeros(1, device="cuda")
     except Exception:   # no torch / no GPU: the CPU tier does not need it
         pass
+
+
+def _gpu_tier(config):
+    """True when the run selects the GPU tier (-m gpu / -m "gpu and ..."), not the CPU tier (-m "not gpu")"""
+    m = (config.getoption("markexpr") or "").replace(" ", "")
+    return "gpu" in m and "notgpu" not in m
+
+
+def _emulator_mapped():
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({ln.split()[-1] for ln in f if "libtsgpu_emu" in ln})
+    except OSError:
+        return []
+
+
+@pytest.fixture(autouse=True)
+def _no_emulator_in_gpu_tier(request):
+    """GPU-tier guard (round-2 leak: a module-scoped fixture resolved the CPU emulator inside a -m gpu test): under -m gpu no
+    test may finish with tests/hipemu's libtsgpu_emu*.so mapped into the process — it fails the test that mapped it."""
+    yield
+    if _gpu_tier(request.config) and request.node.get_closest_marker("gpu"):
+        mapped = _emulator_mapped()
+        assert not mapped, "GPU-tier test ran with the CPU emulator mapped: %s" % mapped
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _gpu_tier(session.config):
+        mapped = _emulator_mapped()
+        if mapped:
+            session.exitstatus = 1
+            sys.stderr.write("\nFAILED: -m gpu session has the CPU emulator mapped: %s\n" % mapped)

@@ -472,9 +472,9 @@ def _array_docs(n_docs, vocab, seed):
     return docs
 
 
-@pytest.fixture(scope="module")
-def pair_arr():
-    """field 0 = string[] ("tags"), field 1 = plain string ("title") over the same documents"""
+def make_pair_arr(lib_path):
+    """field 0 = string[] ("tags"), field 1 = plain string ("title") over the same documents; lib_path is EXPLICIT: the GPU tier
+    passes H.gpu_lib_path() (a module-scoped fixture is set up before any function-scoped monkeypatch of H.emu_lib_path)"""
     from oracle import oracle_py as O
     n_docs = 2000
     arr = _array_docs(n_docs, 40, seed=61)
@@ -487,7 +487,7 @@ def pair_arr():
     pts = H.points_of(n_docs)
     orc.set_num_docs(n_docs)
     orc.set_sort_dense(0, pts)
-    g = T.GpuIndex(0, H.emu_lib_path())
+    g = T.GpuIndex(0, lib_path)
     g.field_create(0, True)
     g.field_create(1, False)
     for f in (0, 1):
@@ -497,6 +497,12 @@ def pair_arr():
     g.column_set(0, pts)
     g.set_num_docs(n_docs)
     g.commit()
+    return orc, g
+
+
+@pytest.fixture(scope="module")
+def pair_arr():
+    orc, g = make_pair_arr(H.emu_lib_path())
     yield orc, g
     g.close()
 

@@ -240,7 +240,10 @@ test_string_array_fields_match_per_element_and_mix_with_plain_fields = EK.test_s
 
 @pytest.fixture(scope="module")
 def pair_arr():
-    yield from EK.pair_arr.__wrapped__()
+    orc, g = EK.make_pair_arr(H.gpu_lib_path())       # the REAL library, resolved explicitly (round-2 leak: the emulator ran here)
+    assert "emu" not in g.lib_path
+    yield orc, g
+    g.close()
 
 
 def test_wildcard_over_2m_docs(c2m):

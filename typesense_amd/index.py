@@ -6,6 +6,7 @@ GpuIndex wraps one tsgpu context = one GPU's shard of: the posting lists of the 
 in Python.
 """
 import ctypes as C
+import os
 import numpy as np
 
 from . import _lib as B
@@ -115,6 +116,7 @@ def make_query_array(queries):
 class GpuIndex:
     def __init__(self, device=0, lib_path=None):
         self.L = B.lib(lib_path)
+        self.lib_path = os.path.realpath(lib_path or B.LIB_PATH)
         h = C.c_void_p()
         B.check(self.L, self.L.tsgpu_create(device, C.byref(h)))
         self.h = h
