@@ -3,6 +3,9 @@
 // Each check cites the reference test it restates. Run by tests/test_oracle_golden.py.
 // Exit code 0 = all pass; prints "FAIL <where>" lines otherwise.
 #include <cstdio>
+#include <cstring>
+#include <limits>
+#include <algorithm>
 #include <fstream>
 #include <sstream>
 #include <random>
@@ -536,6 +539,154 @@ static void test_vectors() {
     }
 }
 
+// ---------- the reference's own vector-distance known answers ----------
+// Generators are the reference's, verbatim in behaviour: std::mt19937 seed 47, std::uniform_real_distribution<> (double, two
+// engine draws per value) narrowed to float; documents travel through JSON (float -> double -> float: exact), query literals
+// through std::stof (src/vector_query_ops.cpp:70). ASSERT_FLOAT_EQ in the reference = within 4 ulp; ASSERT_EQ on .get<float>() = bit-exact.
+static int ulp_gap(float a, float b) {
+    int32_t x, y; memcpy(&x, &a, 4); memcpy(&y, &b, 4);
+    if (x < 0) x = INT32_MIN - x;
+    if (y < 0) y = INT32_MIN - y;
+    long long d = (long long)x - (long long)y;
+    return (int)(d < 0 ? -d : d);
+}
+static int g_max_pin_ulp = 0;
+#define CHECK_PIN(got, pin) do { float _g = (got), _p = (float)(pin); int _u = ulp_gap(_g, _p); if (_u > g_max_pin_ulp) g_max_pin_ulp = _u; \
+    g_checks++; if (!(std::fabs((double)_g - (double)_p) <= 1e-5 * std::fabs((double)_p))) { g_fail++; printf("FAIL %s:%d  %s = %.9g, pinned %.9g\n", __FILE__, __LINE__, #got, _g, _p); } } while (0)
+#define CHECK_PIN_BITS(got, pin) do { float _g = (got), _p = (float)(pin); g_checks++; if (memcmp(&_g, &_p, 4) != 0) { g_fail++; \
+    printf("FAIL %s:%d  %s = %.9g, pinned bits of %.9g (%d ulp)\n", __FILE__, __LINE__, #got, _g, _p, ulp_gap(_g, _p)); } } while (0)
+
+// What the result assembly prints for a `_vector_query(...)` sort key: compute_sort_scores stores float_to_int64_t(dist), negated
+// for ASC (src/index.cpp:5850, :5901-5903), and Collection::search emits -int64_t_to_float(score) (src/collection.cpp:3183).
+// The order-preserving bit trick is not symmetric under negation: the printed value is the distance moved ONE ulp towards
+// -inf in magnitude terms (|d| - 1 ulp for d > 0, |d| + 1 ulp for d < 0). The reference's pins carry exactly that shift.
+static float printed_sort_key_distance(float dist) { return -int64_t_to_float(-float_to_int64_t(dist)); }
+
+static FILE* g_pin_dump = nullptr;       // --dump-vector-pins: write tests/golden/vector_pins.json for the GPU / emulator tiers
+static void dump_matrix(const char* name, const std::vector<std::vector<float>>& rows, bool last = false) {
+    if (!g_pin_dump) return;
+    fprintf(g_pin_dump, "  \"%s\": [", name);
+    for (size_t i = 0; i < rows.size(); i++) {
+        fprintf(g_pin_dump, "%s[", i ? ", " : "");
+        for (size_t j = 0; j < rows[i].size(); j++) fprintf(g_pin_dump, "%s%.9g", j ? ", " : "", rows[i][j]);
+        fprintf(g_pin_dump, "]");
+    }
+    fprintf(g_pin_dump, "]%s\n", last ? "" : ",");
+}
+
+static void test_vector_reference_pins() {
+    const std::vector<float> q1 = {std::stof("0.96826"), std::stof("0.94"), std::stof("0.39557"), std::stof("0.306488")};
+    {   // CollectionVectorTest.BasicVectorQuerying, test/collection_vector_search_test.cpp:75-137 (cosine, 4-d)
+        Index idx(1, 1);
+        idx.vec_init(4, cosine);
+        std::vector<std::vector<float>> values = {{0.851758f, 0.909671f, 0.823431f, 0.372063f}, {0.97826f, 0.933157f, 0.39557f, 0.306488f},
+                                                  {0.230606f, 0.634397f, 0.514009f, 0.399594f}};
+        for (uint32_t i = 0; i < 3; i++) idx.vec_add(i, values[i].data());
+        vector_query_t vq; vq.values = q1;
+        auto r = idx.search_vector(vq, {{SORT_VECTOR_DISTANCE, 0, -1}, {SORT_SEQ_ID, 0, 1}}, 10);
+        CHECK_EQ(r.kvs.size(), 3u);                                                       // :113-114 found 3
+        CHECK_EQ(r.kvs[0].key, 1u); CHECK_EQ(r.kvs[1].key, 0u); CHECK_EQ(r.kvs[2].key, 2u);   // :116-118
+        CHECK_PIN_BITS(r.kvs[0].vector_distance, 3.409385681152344e-05);                  // :120-122 (bit-exact here)
+        CHECK_PIN_BITS(r.kvs[1].vector_distance, 0.04329806566238403);
+        CHECK_PIN_BITS(r.kvs[2].vector_distance, 0.15141665935516357);
+        std::vector<uint32_t> filt = {0, 1};                                              // :124-137 points:[0,1]
+        r = idx.search_vector(vq, {{SORT_VECTOR_DISTANCE, 0, -1}, {SORT_SEQ_ID, 0, 1}}, 10, &filt);
+        CHECK_EQ(r.kvs.size(), 2u); CHECK_EQ(r.kvs[0].key, 1u); CHECK_EQ(r.kvs[1].key, 0u);
+        dump_matrix("basic_docs", values);
+    }
+    {   // CollectionVectorTest.VecSearchWithFiltering, :806-901: 20 docs x 4, seed 47, uniform [0,1), cosine, flat path
+        Index idx(1, 1);
+        idx.vec_init(4, cosine);
+        std::mt19937 rng; rng.seed(47);
+        std::uniform_real_distribution<> distrib;
+        std::vector<std::vector<float>> docs;
+        for (size_t i = 0; i < 20; i++) {
+            std::vector<float> values;
+            for (size_t j = 0; j < 4; j++) values.push_back(distrib(rng));
+            idx.vec_add((uint32_t)i, values.data());
+            docs.push_back(values);
+        }
+        // the generator itself is pinned: BasicVectorQuerying's literals are documents 0..2 of this stream printed with 6 digits
+        CHECK(std::fabs(docs[1][0] - 0.97826f) < 1e-6f && std::fabs(docs[1][3] - 0.306488f) < 1e-6f && std::fabs(docs[0][0] - 0.851758f) < 1e-6f);
+        vector_query_t vq; vq.values = q1;
+        std::vector<sort_by_t> sort = {{SORT_VECTOR_DISTANCE, 0, -1}, {SORT_SEQ_ID, 0, 1}};
+        auto r = idx.search_vector(vq, sort, 20);
+        CHECK_EQ(r.kvs.size(), 20u);                                                      // :848-849
+        std::vector<uint32_t> filt; for (uint32_t i = 0; i < 10; i++) filt.push_back(i);  // points:<10
+        r = idx.search_vector(vq, sort, 3, &filt);                                        // :865-881 flat_search_cutoff 1000, per_page 3
+        // (fetch_size 3 -> k = 3; found = 10 comes from the filter, out of scope here)
+        CHECK(r.kvs.size() >= 3u);
+        CHECK_EQ(r.kvs[0].key, 1u); CHECK_PIN(r.kvs[0].vector_distance, 3.409385e-05);    // :877-878 ASSERT_FLOAT_EQ
+        CHECK_EQ(r.kvs[1].key, 5u); CHECK_PIN(r.kvs[1].vector_distance, 0.016780376);     // :880-881
+        CHECK(ulp_gap(r.kvs[0].vector_distance, 3.409385e-05f) <= 4 && ulp_gap(r.kvs[1].vector_distance, 0.016780376f) <= 4);
+        // :883-901 `vec:([], id: 3)`: the query is document 3's STORED JSON values (src/vector_query_ops.cpp:137-146), the
+        // document itself is dropped from the results and one more neighbour is fetched (src/index.cpp:3651-3654, :3686)
+        vector_query_t vid; vid.values = docs[3];
+        std::vector<vec_hit_t> hits = idx.flat_knn(vid.values, 3 + 1, &filt);
+        std::vector<vec_hit_t> kept;
+        for (auto& h : hits) if (h.seq_id != 3) kept.push_back(h);
+        CHECK_EQ(kept.size(), 3u);
+        CHECK_EQ(kept[0].seq_id, 9u); CHECK_PIN(std::abs(kept[0].dist), 0.050603985);     // :895-896
+        CHECK_EQ(kept[1].seq_id, 5u); CHECK_PIN(std::abs(kept[1].dist), 0.100155532);     // :898-899
+        CHECK(ulp_gap(std::abs(kept[0].dist), 0.050603985f) <= 4 && ulp_gap(std::abs(kept[1].dist), 0.100155532f) <= 4);
+        dump_matrix("seed47_unit_docs", docs);
+    }
+    {   // CollectionVectorTest.TestDistanceThresholdWithIP, :5093-5196: 5 docs x 5, seed 47, uniform(-1,1) interleaved with
+        // uniform_int(0,100) rank scores; IP metric; distance as a SORT KEY (`_vector_query(...)`): compute_sort_scores :5837-5851
+        Index idx(1, 1);
+        idx.vec_init(5, ip);
+        std::mt19937 rng; rng.seed(47);
+        std::uniform_real_distribution<> distrib(-1, 1);
+        std::uniform_int_distribution<> distrib2(0, 100);
+        std::vector<std::vector<float>> docs;
+        std::vector<int> rank_score;
+        for (int i = 0; i < 5; ++i) {
+            std::vector<float> vector(5);
+            std::generate(vector.begin(), vector.end(), [&]() { return distrib(rng); });
+            rank_score.push_back(distrib2(rng));
+            idx.vec_add((uint32_t)i, vector.data());
+            docs.push_back(vector);
+        }
+        const std::vector<float> q = {std::stof("0.11731103425347378"), std::stof("-0.6694758317235057"), std::stof("-0.6211945774857595"),
+                                      std::stof("-0.27966758971688255"), std::stof("-0.4683744007950299")};
+        struct row { float printed; int rank; uint32_t id; };
+        auto run = [&](const std::vector<float>& query, float threshold) {
+            std::vector<row> rows;
+            for (uint32_t i = 0; i < 5; i++) {
+                float dist = Index::ip_distance(query.data(), idx.vec_get(i), 5);                     // :5842
+                if (dist > threshold) dist = std::numeric_limits<float>::max();                         // :5844-5848
+                rows.push_back({printed_sort_key_distance(dist), rank_score[i], i});
+            }
+            // sort_by _text_match:desc (all equal: one token, same field length... every doc matches "document"), distance asc, rank_score desc
+            std::stable_sort(rows.begin(), rows.end(), [](const row& a, const row& b) { return a.printed < b.printed || (a.printed == b.printed && a.rank > b.rank); });
+            return rows;
+        };
+        auto rows = run(q, 1.0f);
+        // libstdc++'s uniform_int_distribution algorithm changed across releases; the rank scores only label the hits
+        bool ranks_ok = rows[0].rank == 93 && rows[1].rank == 51 && rows[2].rank == 94 && rows[3].rank == 80 && rows[4].rank == 18;   // :5145-5154
+        printf("vector pins: rank_score labels %s the reference's (this libstdc++'s uniform_int_distribution)\n", ranks_ok ? "reproduce" : "do NOT reproduce");
+        CHECK_PIN_BITS(rows[0].printed, 0.2189185470342636);                              // :5146 ASSERT_EQ -> bit-exact
+        CHECK_PIN_BITS(rows[1].printed, 0.7371898889541626);                              // :5148
+        for (int i = 2; i < 5; i++) CHECK_PIN_BITS(rows[i].printed, 3.4028232635611926e+38);   // :5150-5154 FLT_MAX after the same shift
+        // the RAW distances (what tsgpu returns) sit exactly one ulp from those printed values
+        {
+            float raw0 = Index::ip_distance(q.data(), idx.vec_get(rows[0].id), 5);
+            CHECK_PIN(raw0, 0.2189185470342636); CHECK_EQ(ulp_gap(raw0, 0.2189185470342636f), 1);
+        }
+        const std::vector<float> qneg(5, -100.0f);                                        // :5177-5196, no threshold
+        rows = run(qneg, std::numeric_limits<float>::max());
+        const uint32_t want_id[5] = {1, 2, 4, 3, 0};
+        const double want_d[5] = {-45.23314666748047, -38.66290283203125, -36.0988655090332, 9.637892723083496, 288.0364685058594};
+        for (int i = 0; i < 5; i++) { CHECK_EQ(rows[i].id, want_id[i]); CHECK_PIN_BITS(rows[i].printed, want_d[i]); }
+        for (int i = 0; i < 5; i++) { float raw = Index::ip_distance(qneg.data(), idx.vec_get(want_id[i]), 5); CHECK_PIN(raw, want_d[i]); CHECK_EQ(ulp_gap(raw, (float)want_d[i]), 1); }
+        dump_matrix("seed47_ip_docs", docs);
+        if (g_pin_dump) {
+            fprintf(g_pin_dump, "  \"seed47_ip_rank_scores\": [%d, %d, %d, %d, %d],\n", rank_score[0], rank_score[1], rank_score[2], rank_score[3], rank_score[4]);
+        }
+    }
+    printf("vector pins: max gap to the reference's pinned distances = %d ulp (raw distance; the printed sort-key form is bit-exact)\n", g_max_pin_ulp);
+}
+
 // ---------- hybrid rank fusion formula: test/collection_vector_search_test.cpp:1429-1431 ----------
 static void test_hybrid() {
     Index idx(1, 1);
@@ -577,6 +728,7 @@ static void test_hybrid() {
 
 int main(int argc, char** argv) {
     if (argc > 1) g_golden_dir = argv[1];
+    if (argc > 3 && std::string(argv[2]) == "--dump-vector-pins") { g_pin_dump = fopen(argv[3], "w"); if (g_pin_dump) fprintf(g_pin_dump, "{\n"); }
     test_arrays();
     test_posting_lists();
     test_or_iterator();
@@ -584,7 +736,9 @@ int main(int argc, char** argv) {
     test_topster();
     test_text_scores();
     test_vectors();
+    test_vector_reference_pins();
     test_hybrid();
+    if (g_pin_dump) { fprintf(g_pin_dump, "  \"generator\": \"oracle/golden_tests.cpp --dump-vector-pins (std::mt19937 seed 47, the reference's test generators)\"\n}\n"); fclose(g_pin_dump); }
     printf("%d checks, %d failed\n", g_checks, g_fail);
     return g_fail == 0 ? 0 : 1;
 }
