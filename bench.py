@@ -498,7 +498,7 @@ class Bench:
         return out
 
     # ---------------------------------------------------------------- exact k-NN by the oracle, streamed in chunks (parity at 10M)
-    def exact_knn_chunked(self, Qh, k, want_rows=True):
+    def exact_knn_chunked(self, Qh, k, want_rows=True, metric=None, slab_kw=None):
         """oracle flat_knn semantics (exact fp32, hnswlib summation order, ties -> smaller label) over ALL base rows: the collection is
         regenerated slab by slab on the GPU, copied to the host and scanned by the oracle, one query per host thread. Returns
         (dist [nq,k], labels [nq,k], {label: row vector} for the rows of the final top-k)."""
@@ -511,9 +511,9 @@ class Bench:
         pool = ThreadPoolExecutor(max_workers=min(nq, os.cpu_count() or 1))
         for a in range(0, self.n_docs, S):
             b = min(self.n_docs, a + S)
-            xs = self.base_slab(a, b).cpu().numpy()
+            xs = self.base_slab(a, b, **(slab_kw or {})).cpu().numpy()
             orc = O.OracleIndex(1, 1)
-            orc.vec_init(dim, O.METRIC_IP)
+            orc.vec_init(dim, O.METRIC_IP if metric is None else metric)
             orc.vec_add(np.arange(a, b, dtype=np.uint32), xs)
             res = list(pool.map(lambda i: orc.flat_knn(Qh[i], k), range(nq)))          # ctypes releases the GIL: one query per thread
             cd = np.stack([np.pad(r[0], (0, k - r[0].size), constant_values=np.inf) for r in res])
@@ -618,7 +618,7 @@ class Bench:
             bits_ok = sum(1 for i in range(npar) if np.array_equal(ed[i].view(np.uint32), d_gpu[i].view(np.uint32)))
             rel = float(np.max(np.abs(ed - d_gpu[:npar]) / np.maximum(1.0, np.abs(ed))))
             res["parity"] = {"sets_checked": npar, "identical_top%d_sets" % k: sets_ok, "identical_order (ties -> smaller label)": order_ok,
-                             "distance_bits_identical": bits_ok, "max_rel_distance_diff": rel, "tolerance": "1e-5 relative (north star); measured: bit-identical",
+                             "distance_bits_identical": bits_ok, "max_rel_distance_diff": rel, "tolerance": "1e-5 relative (north star); measured: bit-identical to the oracle (hnswlib SSE-build summation order, vec_ip_lanes=4; the oracle reproduces the reference's pinned distances, tests/test_vector_pins.py)",
                              "mismatches": npar - min(sets_ok, order_ok) + (1 if rel > 1e-5 else 0),
                              "what": "top-%d of %d queries vs the oracle's exact flat scan (hnswlib summation order) of ALL %d rows, streamed in 2^20-row chunks" % (k, npar, n)}
             # CPU baseline: the same chunked scan IS the reference's flat path on this box's cores (one query per thread)
@@ -683,11 +683,25 @@ class Bench:
             g.set_option("vec_prefilter", 0)
             fd, fl, _ = g.vec_knn_batch(field, Q[:m].cpu().numpy(), k)
             g.set_option("vec_prefilter", 1)
+            par_oracle = None
+            if name == "cosine" and self.rank == 0 and not args.no_cpu_baseline:
+                # cosine at FULL size vs the ORACLE (normalize_vector on insert and on the query, include/index.h:379-388; exact flat scan of all rows)
+                from oracle import oracle_py as O
+                mo = 4
+                Qh = Q[:mo].cpu().numpy()
+                ed, el, _ = self.exact_knn_chunked(Qh, k, want_rows=False, metric=O.METRIC_COSINE)
+                par_oracle = {"queries": mo, "identical_order": sum(1 for i in range(mo) if np.array_equal(el[i].astype(np.int64), pl[i].astype(np.int64))),
+                              "distance_bits_identical": sum(1 for i in range(mo) if np.array_equal(ed[i].view(np.uint32), pd[i].view(np.uint32))),
+                              "max_rel_distance_diff": float(np.max(np.abs(ed - pd[:mo]) / np.maximum(1e-30, np.abs(ed)))),
+                              "what": "top-%d of %d cosine queries vs the oracle's exact flat scan of all %d normalised rows" % (k, mo, self.n_docs)}
+                par_oracle["mismatches"] = mo - min(par_oracle["identical_order"], par_oracle["distance_bits_identical"])
             out[name] = {"value": n_q * r["steps"] / r["elapsed"], "unit": "queries/s", "ms_per_step": 1e3 * r["elapsed"] / r["steps"], "scan_ms": r["scan_ms"],
                          "post_ms": r["post_ms"], "rows_rescored_per_query": surv, "prefilter_fallbacks": g.counter("vec_prefilter_fallbacks") - f0,
                          "prefilter_groups": g.counter("vec_prefilter_groups") - g0, "overflow_rounds": g.counter("vec_overflow_rounds") - o0,
                          "parity_fp32_scan": {"queries": m, "identical_sets": sum(1 for i in range(m) if set(pl[i].tolist()) == set(fl[i].tolist())),
                                               "max_rel_distance_diff": float(np.max(np.abs(pd - fd) / np.maximum(1.0, np.abs(fd))))}}
+            if par_oracle is not None:
+                out[name]["parity"] = par_oracle
             # (the field's 45 GB stay allocated until the context closes: 288 GB of HBM)
         return out
 

@@ -110,6 +110,9 @@ int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
  * "kw_sort_work" = 1 (default): work items launched heaviest first,
  * "vec_rows_per_slab" = base rows per k-NN workgroup slab (default: automatic), "vec_sample_tiles" = 128-row tiles of
  * the k-NN threshold sample (default 512), "vec_cand_cap" = candidate slots per query of the filtered pass (0 = auto),
+ * "vec_ip_lanes" = 4 (default) / 8 / 16: the order every exact distance is summed in = the SIMD level hnswlib is compiled for in the
+ * server (4 = SSE, what the reference's stock build flags give; 8 = -mavx; 16 = -mavx512f): hnswlib's InnerProductSpace accumulates
+ * element i in lane i % lanes and adds the lanes left to right, so the bits of a distance depend on it;
  * "vec_prefilter" = 1 (default): bf16 bracket scan + exact fp32 re-score of the survivors, 0: fp32 MFMA scan of every row
  * (identical result sets either way), "vec_count_rescored" = 1: keep the vec_rescored_rows counter (costs one sync);
  * micro-batcher: "batch_max_queries" = calls with at most this many queries are coalesced with concurrent callers (default 64,
@@ -345,6 +348,12 @@ int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const flo
  * missing labels get NaN (the reference `continue`s on the throw). Host pointers. */
 int tsgpu_vec_distances(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* q, const uint64_t* labels, uint32_t n,
                         float* dist_out);
+
+/* ONE pair on the host: space->get_dist_func()(a, b, &dim) of hnswlib's InnerProductSpace = 1 - <a, b> (src/index.cpp:3365, :5842,
+ * :8868), summed in the order of the SIMD level hnswlib is compiled for in the server: simd_lanes = 4 (SSE: the reference's stock
+ * flags, CMakeLists.txt:8 / BUILD:81-88 pass no -march), 8 (AVX) or 16 (AVX-512); anything else = 4. The same value as option
+ * "vec_ip_lanes" makes this function, tsgpu_vec_distances and the k-NN entry points return the same bits. */
+float tsgpu_ip_distance(const float* a, const float* b, uint32_t dim, int simd_lanes);
 
 /* pure vector search (q="*", src/index.cpp:3645-3732): knn + threshold + sort scores + Topster order */
 typedef struct tsgpu_vec_query {

@@ -155,6 +155,9 @@ int32_t orc_vec_get(void* h, uint32_t label, float* out) {
     return 0;
 }
 float orc_ip_distance(const float* a, const float* b, uint32_t dim) { return Index::ip_distance(a, b, dim); }
+// summation order of the distance function = the SIMD level hnswlib was compiled for: 4 (SSE, stock reference build; default), 8 (AVX), 16 (AVX-512)
+int32_t orc_set_ip_lanes(int32_t lanes) { if (lanes != 4 && lanes != 8 && lanes != 16) return -1; Index::ip_lanes() = lanes; return 0; }
+int32_t orc_get_ip_lanes() { return Index::ip_lanes(); }
 
 // exact k nearest, closest first; returns hits written
 uint32_t orc_flat_knn(void* h, const float* q, uint32_t k, const uint32_t* allow_ids, uint32_t n_allow,

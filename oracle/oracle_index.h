@@ -228,24 +228,48 @@ public:
         return it == vec_row_of.end() ? nullptr : vec_store.data() + (size_t)it->second * num_dim;
     }
 
-    // hnswlib InnerProductSpace distance: 1 - <a,b>, 16-lane accumulate (dim%16==0), 4-lane (dim%4==0),
-    // residual variants otherwise (hnswlib space_ip.h)
-    // compiled with -ffp-contract=off (oracle/Makefile): mul then add, no FMA, so the AVX-512 clone
-    // and the scalar clone of this loop give bit-identical sums
-    __attribute__((target_clones("avx512f", "avx2", "default")))
-    static float ip_partial16(const float* a, const float* b, size_t qty16) {
+    // hnswlib InnerProductSpace distance: 1 - <a,b> (space_ip.h of the pinned fork; NOT under /root/reference — restated from the
+    // published hnswlib 0.7/0.8 source). The summation ORDER depends on the SIMD level hnswlib was COMPILED for,
+    // because the header is compiled into Typesense's own translation units with Typesense's flags:
+    //   ip_lanes = 4  (SSE)    the reference's stock build: CMakeLists.txt:8 / BUILD:81-88 pass no -march/-mavx, so only __SSE__ is
+    //                          defined on x86-64 -> InnerProductSIMD16ExtSSE / SIMD4ExtSSE: ONE __m128 accumulator, element i goes to
+    //                          lane i % 4, final sum T0+T1+T2+T3. DEFAULT.
+    //   ip_lanes = 8  (AVX)    -mavx builds: SIMD16ExtAVX = one __m256 (lane i % 8, T0+..+T7); SIMD4ExtAVX = __m256 over the 16-multiples,
+    //                          folded lo+hi into an __m128 that takes the remaining 4-groups.
+    //   ip_lanes = 16 (AVX512) -mavx512f builds: SIMD16ExtAVX512 = one __m512 (lane i % 16, T0+..+T15); SIMD4Ext = the AVX form.
+    // Residual forms (dim % 4 != 0): SIMD part + scalar tail, 1 - (res + tail). Multiply and add are rounded separately everywhere
+    // (intrinsics _mm*_mul_ps + _mm*_add_ps; compiled with -ffp-contract=off here). Pinned by the reference's own distance known
+    // answers at dims 4 and 5 (golden_tests.cpp: test_vector_reference_pins), where the three orders coincide.
+    static int& ip_lanes() { static int lanes = 4; return lanes; }
+    // lanes[l] += a[i + l] * b[i + l] for i = from, from + L, ..: written on 4-float vector registers (mulps + addps, as the
+    // intrinsics compile to) so that the CPU baseline pays what hnswlib's loop pays; lane-wise identical to the scalar statement
+    typedef float ip_v4sf __attribute__((vector_size(16), aligned(4), may_alias));
+    template <int L>
+    static void ip_accumulate(float* lanes, const float* a, const float* b, size_t from, size_t to) {
+        ip_v4sf acc[L / 4];
+        for (int v = 0; v < L / 4; v++) acc[v] = *(const ip_v4sf*)(lanes + 4 * v);
+        for (size_t i = from; i < to; i += L)
+            for (int v = 0; v < L / 4; v++) acc[v] = acc[v] + *(const ip_v4sf*)(a + i + 4 * v) * *(const ip_v4sf*)(b + i + 4 * v);
+        for (int v = 0; v < L / 4; v++) *(ip_v4sf*)(lanes + 4 * v) = acc[v];
+    }
+    static float ip_simd16ext(const float* a, const float* b, size_t qty) {              // qty % 16 == 0
         float lanes[16] = {0};
-        for (size_t i = 0; i < qty16; i += 16)
-            for (int l = 0; l < 16; l++) lanes[l] = lanes[l] + a[i + l] * b[i + l];
         float sum = 0;
-        for (int l = 0; l < 16; l++) sum += lanes[l];
+        const int L = ip_lanes();
+        if (L == 16) ip_accumulate<16>(lanes, a, b, 0, qty); else if (L == 8) ip_accumulate<8>(lanes, a, b, 0, qty); else ip_accumulate<4>(lanes, a, b, 0, qty);
+        if (L == 4) return lanes[0] + lanes[1] + lanes[2] + lanes[3];
+        for (int l = 0; l < L; l++) sum += lanes[l];
         return sum;
     }
-    static float ip_partial4(const float* a, const float* b, size_t qty4) {
-        float lanes[4] = {0};
-        for (size_t i = 0; i < qty4; i += 4)
-            for (int l = 0; l < 4; l++) lanes[l] = lanes[l] + a[i + l] * b[i + l];
-        return lanes[0] + lanes[1] + lanes[2] + lanes[3];
+    static float ip_simd4ext(const float* a, const float* b, size_t qty) {               // qty % 4 == 0
+        float lanes[8] = {0};
+        if (ip_lanes() == 4) { ip_accumulate<4>(lanes, a, b, 0, qty); return lanes[0] + lanes[1] + lanes[2] + lanes[3]; }
+        const size_t q16 = qty / 16 * 16;                                                 // InnerProductSIMD4ExtAVX
+        ip_accumulate<8>(lanes, a, b, 0, q16);
+        float s4[4];
+        for (int l = 0; l < 4; l++) s4[l] = lanes[l] + lanes[l + 4];
+        ip_accumulate<4>(s4, a, b, q16, qty);
+        return s4[0] + s4[1] + s4[2] + s4[3];
     }
     static float ip_scalar(const float* a, const float* b, size_t n) {
         float r = 0;
@@ -253,10 +277,10 @@ public:
         return r;
     }
     static float ip_distance(const float* a, const float* b, size_t dim) {
-        if (dim % 16 == 0) return 1.0f - ip_partial16(a, b, dim);
-        if (dim % 4 == 0) return 1.0f - ip_partial4(a, b, dim);
-        if (dim > 16) { size_t q = dim >> 4 << 4; return 1.0f - (ip_partial16(a, b, q) + ip_scalar(a + q, b + q, dim - q)); }
-        if (dim > 4) { size_t q = dim >> 2 << 2; return 1.0f - (ip_partial4(a, b, q) + ip_scalar(a + q, b + q, dim - q)); }
+        if (dim % 16 == 0) return 1.0f - ip_simd16ext(a, b, dim);
+        if (dim % 4 == 0) return 1.0f - ip_simd4ext(a, b, dim);
+        if (dim > 16) { size_t q = dim >> 4 << 4; return 1.0f - (ip_simd16ext(a, b, q) + ip_scalar(a + q, b + q, dim - q)); }
+        if (dim > 4) { size_t q = dim >> 2 << 2; return 1.0f - (ip_simd4ext(a, b, q) + ip_scalar(a + q, b + q, dim - q)); }
         return 1.0f - ip_scalar(a, b, dim);
     }
 

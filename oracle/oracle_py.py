@@ -74,6 +74,9 @@ def lib():
         L.orc_vec_get.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_ip_distance.restype = C.c_float
         L.orc_ip_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_set_ip_lanes.restype = C.c_int32
+        L.orc_set_ip_lanes.argtypes = [C.c_int32]
+        L.orc_get_ip_lanes.restype = C.c_int32
         L.orc_flat_knn.restype = C.c_uint32
         L.orc_flat_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_search_keyword.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.POINTER(Result)]
@@ -110,6 +113,16 @@ def lib():
         L.orc_int64_to_float.argtypes = [C.c_int64]
         _lib = L
     return _lib
+
+
+def set_ip_lanes(lanes):
+    """process-wide summation order of the oracle's distance function: 4 = SSE (stock reference build, default), 8 = AVX, 16 = AVX-512"""
+    if lib().orc_set_ip_lanes(int(lanes)) != 0:
+        raise ValueError("ip lanes must be 4, 8 or 16")
+
+
+def get_ip_lanes():
+    return int(lib().orc_get_ip_lanes())
 
 
 def ref_match_lib():

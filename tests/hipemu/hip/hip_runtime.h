@@ -326,6 +326,12 @@ inline float __fsqrt_rn(float a) { return sqrtf(a); }
 inline void hipemu_global_load_lds4(const void* gsrc, void* lds_wave_base) { memcpy((char*)lds_wave_base + 4 * hipemu::cur_lane(), gsrc, 4); }
 inline void hipemu_global_load_lds16(const void* gsrc, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * hipemu::cur_lane(), gsrc, 16); }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu::shfl(v, lane); }
+// v_mov_b32_dpp with a quad_perm control (dpp_ctrl < 0x100): lane l reads lane (l & ~3) | perm[l & 3] of its quad; full row / bank masks
+inline int __builtin_amdgcn_mov_dpp(int v, int dpp_ctrl, int row_mask, int bank_mask, bool) {
+    if (dpp_ctrl < 0 || dpp_ctrl > 0xFF || row_mask != 0xF || bank_mask != 0xF) { fprintf(stderr, "hipemu: unsupported DPP control 0x%x\n", dpp_ctrl); abort(); }
+    const unsigned l = hipemu::cur_lane();
+    return hipemu::shfl(v, (int)((l & ~3u) | (((unsigned)dpp_ctrl >> (2 * (l & 3u))) & 3u)));
+}
 // device wall clock at 1 tick per microsecond (hipDeviceAttributeWallClockRate = 1000 kHz below)
 inline long long hipemu_wall_clock64() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (long long)ts.tv_sec * 1000000ll + ts.tv_nsec / 1000; }
 inline void __builtin_amdgcn_s_setprio(int) {}

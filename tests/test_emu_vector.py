@@ -152,6 +152,43 @@ def test_prefilter_distances_are_bit_identical_to_the_reference_order(dim, n, k,
     g.close()
 
 
+@pytest.mark.parametrize("lanes", [4, 8, 16])
+def test_every_summation_order_of_hnswlibs_distance_is_bit_exact(lanes):
+    """option "vec_ip_lanes" = the SIMD level hnswlib is compiled for in the server (4 = SSE: the reference's stock flags; 8 = AVX;
+    16 = AVX-512): k-NN (quad re-score and 16-lane forms), by-id distances, the HNSW traversal and the host one-pair function
+    return the bits of the oracle's restatement of that build, for every dimension class of space_ip.h"""
+    lib = H.emu_lib_path()
+    O.set_ip_lanes(lanes)
+    try:
+        for dim, n, k in [(768, 70, 20), (64, 150, 30), (100, 140, 10), (36, 130, 7), (70, 130, 9), (21, 130, 5), (7, 100, 4), (3, 100, 3)]:
+            g, orc, X, rng = _mk(n, dim, B.METRIC_IP, 500 + dim + lanes, lib)
+            g.set_option("vec_ip_lanes", lanes)
+            Q = (rng.standard_normal((3, dim)) * 2).astype(np.float32)
+            _check_knn_bits(g, orc, Q, k)
+            labels = np.arange(0, n, 7, dtype=np.uint64)
+            d = g.vec_distances(1, Q[0], labels)
+            L = O.lib()
+            want = np.array([L.orc_ip_distance(Q[0].ctypes.data, np.ascontiguousarray(X[int(i)]).ctypes.data, dim) for i in labels], np.float32)
+            assert np.array_equal(d.view(np.uint32), want.view(np.uint32)), (dim, lanes)
+            host = np.array([g.L.tsgpu_ip_distance(Q[0].ctypes.data, np.ascontiguousarray(X[int(i)]).ctypes.data, dim, lanes) for i in labels], np.float32)
+            assert np.array_equal(host.view(np.uint32), want.view(np.uint32)), (dim, lanes)
+            g.close()
+        # the graph traversal's distance phase (quad form at dim % 16 == 0, 16-lane form otherwise)
+        for dim in (32, 20):
+            g, orc, X, rng = _mk(250, dim, B.METRIC_IP, 900 + dim + lanes, lib)
+            g.set_option("vec_ip_lanes", lanes)
+            orc.hnsw_build(M=8, ef_construction=40, seed=100)
+            g.vec_hnsw_load(1, orc.hnsw_export())
+            Q = rng.standard_normal((6, dim)).astype(np.float32)
+            dist, lab, cnt = g.vec_hnsw_search_batch(1, Q, 10, 30)
+            for i in range(6):
+                d, l, _nd = orc.hnsw_search(Q[i], 10, 30)
+                assert cnt[i] == d.size and np.array_equal(lab[i, :d.size].astype(np.uint32), l) and np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32))
+            g.close()
+    finally:
+        O.set_ip_lanes(4)
+
+
 def test_prefilter_brackets_prune_but_never_drop_a_neighbour():
     """heterogeneous norms + near-duplicates: the survivors are a small superset of the true top-k"""
     rng = np.random.default_rng(77)

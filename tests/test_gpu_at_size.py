@@ -1,0 +1,130 @@
+"""`-m gpu`: parity AT SIZE inside the test tier (not only inside bench.py): BASELINE config 2's 10M-document corpus
+(seed 2, V = 100 000, 32 tokens per document) — 512 three-term queries, Topster content + num_keyword_matches
+bit-exact vs the oracle — and hybrid search with filter ids at 2M documents (fused score bits vs oracle.search_hybrid)."""
+import numpy as np
+import pytest
+
+import typesense_amd as T
+from typesense_amd import _lib as B, synth
+from oracle import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+SORT = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+OSORT = ((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1))
+
+
+def _load(n_docs, vocab, tpd, seed):
+    csr = synth.zipf_corpus_csr(n_docs, vocab, tpd, seed=seed)
+    pts = synth.points_column(n_docs)
+    g = T.GpuIndex(0)
+    g.field_create(0, False)
+    g.terms_load_csr(0, csr["term_ids"], csr["ids_ptr"], csr["ids"], csr["offset_index"], csr["off_ptr"], csr["offsets"])
+    g.column_set(0, pts)
+    g.set_num_docs(n_docs)
+    g.commit()
+    orc = O.OracleIndex(1, 1)
+    orc.set_num_docs(n_docs)
+    orc.set_sort_dense(0, pts)
+    return csr, g, orc
+
+
+def _need(orc, csr, loaded, terms):
+    for t in np.unique(np.asarray(terms).ravel()):
+        t = int(t)
+        if t in loaded:
+            continue
+        ids, oi, off = synth.csr_term(csr, t)
+        if ids.size:
+            orc.load_posting(0, t, ids, oi, off)
+        loaded.add(t)
+
+
+def test_config2_10m_docs_512_queries_topster_and_counts_equal_the_oracle():
+    n_docs, n_q = 10_000_000, 512
+    csr, g, orc = _load(n_docs, 100_000, 32, seed=2)
+    qtok = synth.keyword_queries(n_q, 3, 8, 2000, seed=4)                     # the bench's own query stream (ranks log-uniform in [8, 2000])
+    hits = g.keyword_search_batch([T.KwQuery(q, sort=SORT, topster_size=250) for q in qtok], k_stride=250)
+    assert (hits.status == 0).all()
+    loaded = set()
+    bad, with_hits = [], 0
+    for i in range(n_q):
+        _need(orc, csr, loaded, qtok[i])
+        ref = orc.search_keyword(orc.make_query(qtok[i], sort=OSORT, fetch_size=100))
+        n = int(hits.n_hits[i])
+        with_hits += n > 0
+        if n != ref.keys.size or not np.array_equal(hits.keys[i, :n], ref.keys) or not np.array_equal(hits.scores[i, :n], ref.scores) \
+                or not np.array_equal(hits.text_match[i, :n], ref.text_match) or int(hits.num_matched[i]) != int(ref.num_keyword_matches):
+            bad.append(i)
+    assert not bad, "queries that differ from the oracle at 10M docs: %s" % bad[:20]
+    assert with_hits > n_q // 2
+    # idempotence + batch-size independence at size: the first 64 queries alone give the same lists
+    h2 = g.keyword_search_batch([T.KwQuery(q, sort=SORT, topster_size=250) for q in qtok[:64]], k_stride=250)
+    for i in range(64):
+        n = int(hits.n_hits[i])
+        assert int(h2.n_hits[i]) == n and np.array_equal(h2.keys[i, :n], hits.keys[i, :n]) and np.array_equal(h2.scores[i, :n], hits.scores[i, :n])
+    g.close()
+
+
+def test_hybrid_at_2m_docs_with_filter_ids_fused_scores_equal_the_oracle():
+    n_docs, dim, n_q = 2_000_000, 64, 24
+    csr, g, orc = _load(n_docs, 50_000, 24, seed=7)
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((n_docs, dim), dtype=np.float32)
+    g.vec_create(1, dim, B.METRIC_IP, n_docs)
+    for a in range(0, n_docs, 1 << 19):
+        b = min(n_docs, a + (1 << 19))
+        g.vec_upsert(1, np.arange(a, b, dtype=np.uint64), X[a:b])
+    orc.vec_init(dim, O.METRIC_IP)
+    orc.vec_add(np.arange(n_docs, dtype=np.uint32), X)
+    Q = rng.standard_normal((n_q, dim)).astype(np.float32)
+    qtok = synth.keyword_queries(n_q, 2, 5, 400, seed=21)
+    filt_big = np.unique(rng.integers(0, n_docs, size=700_000)).astype(np.uint32)        # ~30 % of the collection
+    filt_small = np.unique(rng.integers(0, n_docs, size=5_000)).astype(np.uint32)
+    excl = filt_big[::3].copy()
+    cases = [dict(), dict(filter_ids=filt_big), dict(filter_ids=filt_small), dict(filter_ids=filt_big, excluded_ids=excl)]
+    qs = [T.KwQuery(qtok[i], sort=SORT, topster_size=0, **cases[i % 4]) for i in range(n_q)]
+    hits = g.hybrid_search_batch(qs, 1, Q, k=0, fetch_size=100, alpha=0.3, k_stride=250)
+    assert (hits.status == 0).all()
+    loaded = set()
+    for i, q in enumerate(qs):
+        c = cases[i % 4]
+        _need(orc, csr, loaded, q.tokens)
+        oq = orc.make_query(q.tokens, sort=OSORT, fetch_size=100, **c)
+        ref = orc.search_hybrid(oq, Q[i], k=0, alpha=0.3)
+        n = int(hits.n_hits[i])
+        assert n == ref.keys.size, (i, n, ref.keys.size)
+        assert np.array_equal(hits.keys[i, :n], ref.keys), (i, hits.keys[i, :10], ref.keys[:10])
+        assert np.array_equal(hits.scores[i, :n], ref.scores), i                        # fused RRF score BITS
+        assert np.array_equal(hits.text_match[i, :n], ref.text_match), i
+        assert np.array_equal(hits.vector_distance[i, :n].view(np.uint32), ref.vector_distance.view(np.uint32)), i
+        if "filter_ids" in c:
+            assert np.isin(hits.keys[i, :n], c["filter_ids"]).all()
+        if "excluded_ids" in c:
+            assert not np.isin(hits.keys[i, :n], c["excluded_ids"]).any()
+    g.close()
+
+
+def test_cosine_2m_rows_top100_equals_the_oracle_flat_scan():
+    """cosine at size vs the ORACLE (not GPU vs GPU): rows normalised on insert exactly as hnsw_index_t::normalize_vector
+    (include/index.h:379-388), query normalised per call; labels, order and distance BITS of the top-100"""
+    n, dim, k = 2_000_000, 96, 100
+    rng = np.random.default_rng(31)
+    X = (rng.standard_normal((n, dim), dtype=np.float32) * rng.uniform(0.2, 5.0, size=(n, 1)).astype(np.float32))   # uneven norms
+    g = T.GpuIndex(0)
+    g.vec_create(1, dim, B.METRIC_COSINE, n)
+    for a in range(0, n, 1 << 19):
+        b = min(n, a + (1 << 19))
+        g.vec_upsert(1, np.arange(a, b, dtype=np.uint64), X[a:b])
+    orc = O.OracleIndex(1, 1)
+    orc.vec_init(dim, O.METRIC_COSINE)
+    orc.vec_add(np.arange(n, dtype=np.uint32), X)
+    for lab in (0, 12345, n - 1):
+        assert np.array_equal(g.vec_get(1, lab), orc.vec_get(lab))
+    Q = (rng.standard_normal((12, dim)) * 3).astype(np.float32)
+    dist, lab, cnt = g.vec_knn_batch(1, Q, k)
+    for i in range(Q.shape[0]):
+        d, l = orc.flat_knn(Q[i], k)
+        assert cnt[i] == k and np.array_equal(lab[i].astype(np.uint32), l), i
+        assert np.array_equal(dist[i].view(np.uint32), d.view(np.uint32)), i
+    g.close()

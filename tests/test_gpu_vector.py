@@ -34,6 +34,7 @@ test_prefilter_distances_are_bit_identical_to_the_reference_order = E.test_prefi
 test_prefilter_brackets_prune_but_never_drop_a_neighbour = E.test_prefilter_brackets_prune_but_never_drop_a_neighbour
 test_hnsw_graph_search_replays_the_reference_traversal = E.test_hnsw_graph_search_replays_the_reference_traversal
 test_edge_cases_empty_tiny_and_fully_deleted_indexes = E.test_edge_cases_empty_tiny_and_fully_deleted_indexes
+test_every_summation_order_of_hnswlibs_distance_is_bit_exact = E.test_every_summation_order_of_hnswlibs_distance_is_bit_exact
 
 
 def test_hnsw_20k_x_96_batch_of_512_matches_the_cpu_traversal():

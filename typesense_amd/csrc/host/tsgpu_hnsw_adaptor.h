@@ -42,18 +42,13 @@ public:
 typedef float (*DISTFUNC)(const void*, const void*, const void*);
 
 // hnswlib's InnerProductSpace::get_dist_func contract for ONE pair on the host (by-id paths); the batched
-// scans go through tsgpu_vec_knn_batch / tsgpu_vec_distances on the GPU.
+// scans go through tsgpu_vec_knn_batch / tsgpu_vec_distances on the GPU. TSGPU_IP_LANES = the SIMD level the server's own
+// hnswlib would have been compiled for (4 = SSE: the stock flags; 8 = -mavx; 16 = -mavx512f) = option "vec_ip_lanes".
+#ifndef TSGPU_IP_LANES
+#define TSGPU_IP_LANES 4
+#endif
 inline float InnerProductDistance(const void* a, const void* b, const void* dim_ptr) {
-    const float* x = (const float*)a;
-    const float* y = (const float*)b;
-    const size_t d = *(const size_t*)dim_ptr;
-    float lanes[16] = {0};
-    size_t q16 = d >> 4 << 4, i = 0;
-    for (; i < q16; i += 16) for (int l = 0; l < 16; l++) lanes[l] += x[i + l] * y[i + l];
-    float s = 0;
-    for (int l = 0; l < 16; l++) s += lanes[l];
-    for (; i < d; i++) s += x[i] * y[i];
-    return 1.0f - s;
+    return tsgpu_ip_distance((const float*)a, (const float*)b, (uint32_t)*(const size_t*)dim_ptr, TSGPU_IP_LANES);
 }
 
 class InnerProductSpace {

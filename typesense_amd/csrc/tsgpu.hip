@@ -278,6 +278,11 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "batch_window_us")) { ctx->batch_window_us = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 100000); return ok(); }
     if (!strcmp(name, "batch_max_queries")) { ctx->batch_max_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20); return ok(); }   // 0 = never coalesce
     if (!strcmp(name, "batch_round_queries")) { ctx->batch_round_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 1 << 20); return ok(); }
+    if (!strcmp(name, "vec_ip_lanes")) {               // summation order of every exact distance = the SIMD level hnswlib is compiled for in the server
+        if (value != 4 && value != 8 && value != 16) return fail(TSGPU_ERR_INVALID, "vec_ip_lanes must be 4 (SSE, stock build), 8 (AVX) or 16 (AVX-512)");
+        ctx->vec_ip_lanes = (uint32_t)value;
+        return ok();
+    }
     if (!strcmp(name, "vec_prefilter")) {
         if (value != 0 && value != 1) return fail(TSGPU_ERR_INVALID, "vec_prefilter must be 0 or 1");
         ctx->vec_prefilter = (uint32_t)value;

@@ -303,7 +303,7 @@ static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, 
     }
     // exact re-score of the survivors (hnswlib's summation order) and final selection
     hipLaunchKernelGGL(vec_rescore_kernel, dim3(n_q, 4), dim3(VEC_THREADS), 0, s, (const float*)f->X.as<float>(), Q_dev, f->dim,
-                       (const uint32_t*)f->d_surv.as<uint32_t>(), (const uint32_t*)f->d_surv_cnt.as<uint32_t>(), (size_t)VEC_SURV_CAP, f->d_dense.as<uint64_t>());
+                       (const uint32_t*)f->d_surv.as<uint32_t>(), (const uint32_t*)f->d_surv_cnt.as<uint32_t>(), (size_t)VEC_SURV_CAP, f->d_dense.as<uint64_t>(), ctx->vec_ip_lanes);
     hipLaunchKernelGGL(vec_select_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint64_t*)f->d_dense.as<uint64_t>(), (size_t)VEC_SURV_CAP,
                        (const uint32_t*)f->d_surv_cnt.as<uint32_t>(), VEC_SURV_CAP, k, 0, f->labels.as<uint64_t>(), dist_dev, label_dev, cnt_dev,
                        f->d_tau.as<uint64_t>(), d_over);
@@ -781,7 +781,7 @@ int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const flo
             a.upper_ptr = f->g_upper_ptr.as<uint64_t>(); a.upper_links = f->g_upper_links.as<uint32_t>(); a.su = 1 + f->g_M;
             a.maxlevel = f->g_maxlevel; a.enterpoint = f->g_enterpoint;
             a.row_ok = mask; a.strict = (functor_present || f->any_deleted) ? 1u : 0u;
-            a.k = k; a.ef = ef; a.visited = f->g_visited.as<uint16_t>();
+            a.k = k; a.ef = ef; a.ip_lanes = ctx->vec_ip_lanes; a.visited = f->g_visited.as<uint16_t>();
             a.overflow_cnt = (uint32_t*)((char*)f->g_visited.p + tag_bytes);
             a.labels = f->labels.as<uint64_t>(); a.dist_out = d_dist; a.label_out = d_lab; a.n_out = d_cnt;
             // LDS tier by max(ef, k); a query whose candidate heap outgrows a small tier makes the batch run again on the largest
@@ -846,12 +846,52 @@ int tsgpu_vec_distances(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* q, c
         if (f->metric == TSGPU_METRIC_COSINE)   // the reference re-normalises q inside its loop (src/index.cpp:3362-3366)
             hipLaunchKernelGGL(vec_normalize_rows_kernel, dim3(1), dim3(64), 0, s, f->d_q1.as<float>(), 1u, f->dim);
         hipLaunchKernelGGL(vec_row_distances_kernel, dim3((n + 15) / 16), dim3(256), 0, s, f->X.as<float>(), f->d_q1.as<float>(), f->dim,
-                           f->d_rows.as<uint32_t>(), n, f->d_out1.as<float>());
+                           f->d_rows.as<uint32_t>(), n, f->d_out1.as<float>(), ctx->vec_ip_lanes);
         TSGPU_HIP_TRY(hipMemcpyAsync(dist_out, f->d_out1.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_distances: host allocation failed"); }
     return ok();
 }
+
+// ONE pair on the host: hnswlib's space->get_dist_func()(a, b, &dim) (src/index.cpp:3365, :5842, :8868) in the summation order of the
+// SIMD level hnswlib is compiled for (vec_kernels.hip.h "summation orders"; oracle: ip_simd16ext / ip_simd4ext). Plain host arithmetic on
+// two vectors the caller already holds — the batched paths (k-NN, by-id distances, re-ranking) run on the device.
+#pragma clang fp contract(off)
+extern "C++" {
+namespace {
+template <int L> inline void ip_host_acc(float* lanes, const float* a, const float* b, size_t from, size_t to) {
+    for (size_t i = from; i < to; i += L) for (int l = 0; l < L; l++) { const float p = a[i + l] * b[i + l]; lanes[l] = lanes[l] + p; }
+}
+inline float ip_host_16ext(const float* a, const float* b, size_t qty, int L) {
+    float lanes[16] = {0};
+    if (L == 16) ip_host_acc<16>(lanes, a, b, 0, qty); else if (L == 8) ip_host_acc<8>(lanes, a, b, 0, qty); else ip_host_acc<4>(lanes, a, b, 0, qty);
+    if (L == 4) return lanes[0] + lanes[1] + lanes[2] + lanes[3];
+    float sum = 0;
+    for (int l = 0; l < L; l++) sum = sum + lanes[l];
+    return sum;
+}
+inline float ip_host_4ext(const float* a, const float* b, size_t qty, int L) {
+    float lanes[8] = {0};
+    if (L == 4) { ip_host_acc<4>(lanes, a, b, 0, qty); return lanes[0] + lanes[1] + lanes[2] + lanes[3]; }
+    const size_t q16 = qty / 16 * 16;
+    ip_host_acc<8>(lanes, a, b, 0, q16);
+    float s4[4];
+    for (int l = 0; l < 4; l++) s4[l] = lanes[l] + lanes[l + 4];
+    ip_host_acc<4>(s4, a, b, q16, qty);
+    return s4[0] + s4[1] + s4[2] + s4[3];
+}
+inline float ip_host_scalar(const float* a, const float* b, size_t n) { float r = 0; for (size_t i = 0; i < n; i++) { const float p = a[i] * b[i]; r = r + p; } return r; }
+}  // namespace
+}  // extern "C++"
+float tsgpu_ip_distance(const float* a, const float* b, uint32_t dim, int simd_lanes) {
+    const int L = (simd_lanes == 8 || simd_lanes == 16) ? simd_lanes : 4;
+    if (dim % 16 == 0) return 1.0f - ip_host_16ext(a, b, dim, L);
+    if (dim % 4 == 0) return 1.0f - ip_host_4ext(a, b, dim, L);
+    if (dim > 16) { const size_t q = dim >> 4 << 4; const float r = ip_host_16ext(a, b, q, L), t = ip_host_scalar(a + q, b + q, dim - q); return 1.0f - (r + t); }
+    if (dim > 4) { const size_t q = dim >> 2 << 2; const float r = ip_host_4ext(a, b, q, L), t = ip_host_scalar(a + q, b + q, dim - q); return 1.0f - (r + t); }
+    return 1.0f - ip_host_scalar(a, b, dim);
+}
+#pragma clang fp contract(fast)
 
 // pure vector search, src/index.cpp:3645-3732
 int tsgpu_vector_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const tsgpu_vec_query* p, const float* Q, int mem_q, uint32_t n_q,
@@ -1054,7 +1094,7 @@ static int hybrid_rerank(tsgpu_ctx* ctx, VecField* f, uint32_t /*vec_field_id*/,
             if (f->metric == TSGPU_METRIC_COSINE)
                 hipLaunchKernelGGL(vec_normalize_rows_kernel, dim3((n_queries + 3) / 4), dim3(256), 0, s, f->d_q1.as<float>(), n_queries, dim);
             hipLaunchKernelGGL(vec_pair_distances_kernel, dim3((n + 15) / 16), dim3(256), 0, s, f->X.as<float>(), f->d_q1.as<float>(), dim,
-                               (const uint32_t*)((char*)f->d_rows.p + (size_t)n * 4), f->d_rows.as<uint32_t>(), n, f->d_out1.as<float>());
+                               (const uint32_t*)((char*)f->d_rows.p + (size_t)n * 4), f->d_rows.as<uint32_t>(), n, f->d_out1.as<float>(), ctx->vec_ip_lanes);
             std::vector<float> d(n);
             TSGPU_HIP_TRY(hipMemcpyAsync(d.data(), f->d_out1.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
             TSGPU_HIP_TRY(hipStreamSynchronize(s));

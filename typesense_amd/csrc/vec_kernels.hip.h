@@ -953,124 +953,145 @@ __device__ inline float ip_mul_add(float acc, float a, float b) {
     const float pr = a * b;
     return acc + pr;
 }
+__device__ inline float ip_mul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
 __device__ inline float ip_add(float a, float b) {
 #pragma clang fp contract(off)
     return a + b;
 }
-__device__ inline float ip_part16(const float* qs, const float* __restrict__ x, uint32_t off, uint32_t n16, uint32_t sub) {
-    float accl = 0.0f;
-    for (uint32_t i = 0; i < n16; i += 16) accl = ip_mul_add(accl, qs[off + i + sub], x[off + i + sub]);
-    float sum = 0.0f;
+// ---- hnswlib InnerProductSpace summation orders (space_ip.h; restated in oracle/oracle_index.h: ip_simd16ext / ip_simd4ext) ----
+// `lanes` = the SIMD width hnswlib was COMPILED for, which fixes the order the products are added in: 4 = SSE (the reference's stock
+// flags pass no -march: CMakeLists.txt:8, BUILD:81-88 — element i accumulates in lane i % 4, final T0+T1+T2+T3; library default),
+// 8 = AVX (lane i % 8, T0+..+T7; dims % 4: __m256 over the 16-multiples folded lo+hi into an __m128 for the rest), 16 = AVX-512
+// (lane i % 16, T0+..+T15; dims % 4 as AVX). Option "vec_ip_lanes". Every form multiplies and adds with separate roundings.
+//
+// Generic form: 16 GPU lanes per row (sub = lane & 15), any dim; lanes sub < L own the L accumulator lanes (a strided scalar walk:
+// the by-id / odd-dimension paths, not the batched re-score).
+__device__ inline float ip_acc_strided(float acc, const float* qs, const float* __restrict__ x, uint32_t from, uint32_t to, uint32_t sub, uint32_t L) {
+    if (sub < L) for (uint32_t i = from + sub; i < to; i += L) acc = ip_mul_add(acc, qs[i], x[i]);
+    return acc;
+}
+__device__ inline float ip_hsum(float accl, uint32_t L) {                 // T0 + T1 + .. + T(L-1), left to right, over the 16-lane group's first L lanes
     const int b0 = (int)(threadIdx.x & 48u);
+    float sum = 0.0f;
+    if (L == 4) {
+        const float l0 = __shfl(accl, b0), l1 = __shfl(accl, b0 + 1), l2 = __shfl(accl, b0 + 2), l3 = __shfl(accl, b0 + 3);
+        return ip_add(ip_add(ip_add(l0, l1), l2), l3);                    // (SSE form: no leading 0 + ..)
+    }
 #pragma unroll
-    for (int l = 0; l < 16; l++) sum = ip_add(sum, __shfl(accl, b0 + l));
+    for (int l = 0; l < 16; l++) { const float v = __shfl(accl, b0 + l); if ((uint32_t)l < L) sum = ip_add(sum, v); }
     return sum;
 }
-// R rows at once for one 16-lane group, same arithmetic and order as ip_part16 per row (lane `sub` accumulates elements sub, sub + 16, ..
-// in ascending order; the 16 partial sums are added lane 0 first). The point is memory-level parallelism: a lane's U x R row elements of
-// a chunk are requested back to back BEFORE the first multiply-add consumes one, so a 768-dimension row costs two memory round trips
-// instead of one per few elements (the graph traversal is a chain of such round trips: 107 expansions x ~20 neighbours per query).
-template <int R, int U>
-__device__ inline void ip_part16_rows(const float* qs, const float* (&x)[R], uint32_t n16, uint32_t sub, float (&out)[R]) {
-    float accl[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) accl[r] = 0.0f;
-    for (uint32_t i = 0; i < n16; i += 16 * U) {
-        float xv[R][U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t idx = i + 16 * u + sub;
-            const uint32_t idc = i + 16 * u < n16 ? idx : sub;            // (uniform guard per 16-element stripe; clamped load, unused)
-#pragma unroll
-            for (int r = 0; r < R; r++) xv[r][u] = x[r][idc];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (i + 16 * u < n16) {
-                const float qv = qs[i + 16 * u + sub];
-#pragma unroll
-                for (int r = 0; r < R; r++) accl[r] = ip_mul_add(accl[r], qv, xv[r][u]);
-            }
-        }
-    }
-    const int b0 = (int)(threadIdx.x & 48u);
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        float sum = 0.0f;
-#pragma unroll
-        for (int l = 0; l < 16; l++) sum = ip_add(sum, __shfl(accl[r], b0 + l));
-        out[r] = sum;
-    }
+__device__ inline float ip_simd16ext(const float* qs, const float* __restrict__ x, uint32_t qty, uint32_t sub, uint32_t L) {    // qty % 16 == 0
+    return ip_hsum(ip_acc_strided(0.0f, qs, x, 0, qty, sub, L), L);
 }
-// The same sums with 16-byte loads: FOUR lanes per row, lane v of the quad owns the virtual lanes 4v .. 4v+3 of hnswlib's 16-lane
-// accumulator (element 16 j + 4 v + c goes to virtual lane 4 v + c: four independent ascending chains per lane), a wavefront covers
-// 16 rows per round. Same products, same order inside every virtual lane, same lane-0-first final sum — a quarter of the load
-// instructions of the one-element-per-lane form (the traversal's distance phase was bound by their issue rate, not by bytes).
-template <int U>
-__device__ inline float ip_part16_quad(const float* qs, const float* __restrict__ x, uint32_t n16, uint32_t v) {
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (uint32_t i = 0; i < n16; i += 16 * U) {
-        float4 xv[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) xv[u] = *(const float4*)(x + (i + 16 * u < n16 ? i + 16 * u : 0) + 4 * v);
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            if (i + 16 * u < n16) {
-                const float4 qv = *(const float4*)(qs + i + 16 * u + 4 * v);
-                acc[0] = ip_mul_add(acc[0], qv.x, xv[u].x); acc[1] = ip_mul_add(acc[1], qv.y, xv[u].y);
-                acc[2] = ip_mul_add(acc[2], qv.z, xv[u].z); acc[3] = ip_mul_add(acc[3], qv.w, xv[u].w);
-            }
-        }
-    }
-    const int q0 = (int)(threadIdx.x & 60u);
-    float sum = 0.0f;
-#pragma unroll
-    for (int vv = 0; vv < 4; vv++)
-#pragma unroll
-        for (int c = 0; c < 4; c++) sum = ip_add(sum, __shfl(acc[c], q0 + vv));
-    return sum;
-}
-__device__ inline float ip_part4(const float* qs, const float* __restrict__ x, uint32_t off, uint32_t n4, uint32_t sub) {
-    float accl = 0.0f;
-    if (sub < 4) for (uint32_t i = 0; i < n4; i += 4) accl = ip_mul_add(accl, qs[off + i + sub], x[off + i + sub]);
-    const int b0 = (int)(threadIdx.x & 48u);
-    const float l0 = __shfl(accl, b0), l1 = __shfl(accl, b0 + 1), l2 = __shfl(accl, b0 + 2), l3 = __shfl(accl, b0 + 3);
-    return ip_add(ip_add(ip_add(l0, l1), l2), l3);
+__device__ inline float ip_simd4ext(const float* qs, const float* __restrict__ x, uint32_t qty, uint32_t sub, uint32_t L) {     // qty % 4 == 0
+    if (L == 4) return ip_hsum(ip_acc_strided(0.0f, qs, x, 0, qty, sub, 4), 4);
+    const uint32_t q16 = qty / 16 * 16;                                   // InnerProductSIMD4ExtAVX
+    const float a8 = ip_acc_strided(0.0f, qs, x, 0, q16, sub, 8);
+    const float hi = __shfl(a8, (int)((threadIdx.x & 48u) + ((sub + 4) & 15)));
+    const float s4 = ip_add(a8, hi);                                      // lanes 0..3: lo + hi
+    return ip_hsum(ip_acc_strided(s4, qs, x, q16, qty, sub, 4), 4);
 }
 __device__ inline float ip_scalar(const float* qs, const float* __restrict__ x, uint32_t off, uint32_t n) {
     float r = 0.0f;
     for (uint32_t i = 0; i < n; i++) r = ip_mul_add(r, qs[off + i], x[off + i]);
     return r;
 }
-__device__ inline float ip_distance_group16(const float* qs, const float* __restrict__ x, uint32_t dim, uint32_t sub) {
-    if (dim % 16 == 0) return ip_add(1.0f, -ip_part16(qs, x, 0, dim, sub));
-    if (dim % 4 == 0) return ip_add(1.0f, -ip_part4(qs, x, 0, dim, sub));
-    if (dim > 16) { const uint32_t qn = dim >> 4 << 4; const float a1 = ip_part16(qs, x, 0, qn, sub); return ip_add(1.0f, -ip_add(a1, ip_scalar(qs, x, qn, dim - qn))); }
-    if (dim > 4) { const uint32_t qn = dim >> 2 << 2; const float a1 = ip_part4(qs, x, 0, qn, sub); return ip_add(1.0f, -ip_add(a1, ip_scalar(qs, x, qn, dim - qn))); }
+__device__ inline float ip_distance_group16(const float* qs, const float* __restrict__ x, uint32_t dim, uint32_t sub, uint32_t L) {
+    if (dim % 16 == 0) return ip_add(1.0f, -ip_simd16ext(qs, x, dim, sub, L));
+    if (dim % 4 == 0) return ip_add(1.0f, -ip_simd4ext(qs, x, dim, sub, L));
+    if (dim > 16) { const uint32_t qn = dim >> 4 << 4; const float a1 = ip_simd16ext(qs, x, qn, sub, L); return ip_add(1.0f, -ip_add(a1, ip_scalar(qs, x, qn, dim - qn))); }
+    if (dim > 4) { const uint32_t qn = dim >> 2 << 2; const float a1 = ip_simd4ext(qs, x, qn, sub, L); return ip_add(1.0f, -ip_add(a1, ip_scalar(qs, x, qn, dim - qn))); }
     return ip_add(1.0f, -ip_scalar(qs, x, 0, dim));
+}
+
+// Fast form for dim % 16 == 0 (the batched re-score and the graph traversal): FOUR GPU lanes per row, 16-byte loads; lane v of the
+// quad loads elements 16 j + 4 v .. + 3 of every 16-element block j and forms their four products p[v][0..3]; a wavefront covers 16
+// rows per round. Who ADDS which product follows the order:
+//   L = 16: element 16 j + 4 v + c belongs to accumulator lane 4 v + c -> lane v keeps four chains of its own products;
+//   L = 8:  accumulator lane (4 v + c) % 8 -> quad lanes 0 / 1 own lanes 0..3 / 4..7 and add their own products, then those of lane
+//           v + 2 (one quad_perm exchange per block);
+//   L = 4:  accumulator lane c takes p[0][c], p[1][c], p[2][c], p[3][c] in that order -> the 4 x 4 block of products is TRANSPOSED
+//           inside the quad (two butterfly stages over quad_perm), quad lane c owns accumulator lane c.
+// Same products, same order inside every accumulator lane, same left-to-right final sum as the CPU forms; U = blocks requested per
+// lane before the first product is consumed (memory-level parallelism: a 768-dimension row costs two round trips).
+__device__ inline float quad_xor1(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+__device__ inline float quad_xor2(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
+template <int U>
+__device__ inline float ip_dot16_quad(const float* qs, const float* __restrict__ x, uint32_t n16, uint32_t v, uint32_t L) {
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool odd = (v & 1) != 0, hi = (v & 2) != 0;
+    for (uint32_t i = 0; i < n16; i += 16 * U) {
+        float4 xv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) xv[u] = *(const float4*)(x + (i + 16 * u < n16 ? i + 16 * u : 0) + 4 * v);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (i + 16 * u < n16) {                                       // (uniform per block: n16, i, u are wave-uniform)
+                const float4 qv = *(const float4*)(qs + i + 16 * u + 4 * v);
+                if (L == 16) {
+                    acc[0] = ip_mul_add(acc[0], qv.x, xv[u].x); acc[1] = ip_mul_add(acc[1], qv.y, xv[u].y);
+                    acc[2] = ip_mul_add(acc[2], qv.z, xv[u].z); acc[3] = ip_mul_add(acc[3], qv.w, xv[u].w);
+                } else {
+                    float p[4] = {ip_mul(qv.x, xv[u].x), ip_mul(qv.y, xv[u].y), ip_mul(qv.z, xv[u].z), ip_mul(qv.w, xv[u].w)};
+                    if (L == 8) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) acc[c] = ip_add(ip_add(acc[c], p[c]), quad_xor2(p[c]));      // (meaningful on quad lanes 0 and 1)
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {                     // stage A: swap bit 0 of (lane, component)
+                            const float recv = quad_xor1(odd ? p[2 * k] : p[2 * k + 1]);
+                            if (odd) p[2 * k] = recv; else p[2 * k + 1] = recv;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {                     // stage B: swap bit 1
+                            const float recv = quad_xor2(hi ? p[k] : p[k + 2]);
+                            if (hi) p[k] = recv; else p[k + 2] = recv;
+                        }
+                        acc[0] = ip_add(ip_add(ip_add(ip_add(acc[0], p[0]), p[1]), p[2]), p[3]);                  // quad lane c = accumulator lane c
+                    }
+                }
+            }
+        }
+    }
+    const int q0 = (int)(threadIdx.x & 60u);
+    if (L == 4) {
+        const float t0 = __shfl(acc[0], q0), t1 = __shfl(acc[0], q0 + 1), t2 = __shfl(acc[0], q0 + 2), t3 = __shfl(acc[0], q0 + 3);
+        return ip_add(ip_add(ip_add(t0, t1), t2), t3);
+    }
+    float sum = 0.0f;
+    const int nl = L == 16 ? 4 : 2;                                       // quad lanes holding accumulator lanes, four each
+#pragma unroll
+    for (int vv = 0; vv < 4; vv++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) { const float t = __shfl(acc[c], q0 + vv); if (vv < nl) sum = ip_add(sum, t); }
+    return sum;
 }
 
 // distances of one query to explicit rows (flat scan over filter ids, src/index.cpp:3345-3374; getDataByLabel + get_dist_func of
 // compute_aux_scores, :8856-8880): 16 lanes per row, hnswlib's own summation order (ip_distance_group16) — the same bits the k-NN
 // paths return. rows[i] == 0xFFFFFFFF -> NaN (label missing).
 __global__ __launch_bounds__(256) void vec_row_distances_kernel(const float* __restrict__ X, const float* __restrict__ q, uint32_t dim,
-                                                                 const uint32_t* __restrict__ rows, uint32_t n, float* __restrict__ out) {
+                                                                 const uint32_t* __restrict__ rows, uint32_t n, float* __restrict__ out, uint32_t ip_lanes) {
     const uint32_t sub = threadIdx.x & 15;
     const uint32_t i = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     const uint32_t ic = i < n ? i : n - 1;               // idle groups recompute the last row (keeps the wave's shuffles uniform)
     const uint32_t row = rows[ic];
-    const float d = ip_distance_group16(q, X + (size_t)(row != 0xFFFFFFFFu ? row : 0) * dim, dim, sub);
+    const float d = ip_distance_group16(q, X + (size_t)(row != 0xFFFFFFFFu ? row : 0) * dim, dim, sub, ip_lanes);
     if (i < n && sub == 0) out[i] = row == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : d;
 }
 
 // the same for (query, row) pairs of a batch: item i = (queries[qidx[i]], rows[i])
 __global__ __launch_bounds__(256) void vec_pair_distances_kernel(const float* __restrict__ X, const float* __restrict__ Q, uint32_t dim, const uint32_t* __restrict__ qidx,
-                                                                  const uint32_t* __restrict__ rows, uint32_t n, float* __restrict__ out) {
+                                                                  const uint32_t* __restrict__ rows, uint32_t n, float* __restrict__ out, uint32_t ip_lanes) {
     const uint32_t sub = threadIdx.x & 15;
     const uint32_t i = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
     const uint32_t ic = i < n ? i : n - 1;
     const uint32_t row = rows[ic];
-    const float d = ip_distance_group16(Q + (size_t)qidx[ic] * dim, X + (size_t)(row != 0xFFFFFFFFu ? row : 0) * dim, dim, sub);
+    const float d = ip_distance_group16(Q + (size_t)qidx[ic] * dim, X + (size_t)(row != 0xFFFFFFFFu ? row : 0) * dim, dim, sub, ip_lanes);
     if (i < n && sub == 0) out[i] = row == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : d;
 }
 
@@ -1078,7 +1099,7 @@ __global__ __launch_bounds__(256) void vec_pair_distances_kernel(const float* __
 static const uint32_t VEC_RESCORE_LDS_DIM = 4096;     // queries up to this dim are staged in LDS; longer ones are read from L1/L2
 __global__ __launch_bounds__(VEC_THREADS) void vec_rescore_kernel(const float* __restrict__ X, const float* __restrict__ Q, uint32_t dim,
                                                                    const uint32_t* __restrict__ surv_base, const uint32_t* __restrict__ surv_cnt, size_t stride,
-                                                                   uint64_t* __restrict__ keys_base) {
+                                                                   uint64_t* __restrict__ keys_base, uint32_t ip_lanes) {
     __shared__ __attribute__((aligned(16))) float qs_lds[VEC_RESCORE_LDS_DIM];
     const uint32_t t = threadIdx.x, q = blockIdx.x;
     const uint32_t n = surv_cnt[q];
@@ -1099,7 +1120,7 @@ __global__ __launch_bounds__(VEC_THREADS) void vec_rescore_kernel(const float* _
         for (uint32_t i0 = blockIdx.y * rows_per_trip; i0 < n; i0 += per) {
             const uint32_t i = i0 + (t >> 2);
             const uint32_t row = surv[i < n ? i : n - 1];   // idle quads recompute the last pair (keeps the wave's shuffles uniform)
-            const float d = ip_add(1.0f, -ip_part16_quad<24>(qs, X + (size_t)row * dim, dim, t & 3));
+            const float d = ip_add(1.0f, -ip_dot16_quad<24>(qs, X + (size_t)row * dim, dim, t & 3, ip_lanes));
             if (i < n && (t & 3) == 0) keys[i] = ((uint64_t)f32_ord(d) << 32) | row;
         }
         return;
@@ -1109,7 +1130,7 @@ __global__ __launch_bounds__(VEC_THREADS) void vec_rescore_kernel(const float* _
         const uint32_t i = i0 + grp;
         const uint32_t ic = i < n ? i : n - 1;
         const uint32_t row = surv[ic];
-        const float d = ip_distance_group16(qs, X + (size_t)row * dim, dim, sub);
+        const float d = ip_distance_group16(qs, X + (size_t)row * dim, dim, sub, ip_lanes);
         if (i < n && sub == 0) keys[i] = ((uint64_t)f32_ord(d) << 32) | row;
     }
 }
@@ -1133,6 +1154,7 @@ struct VecHnswArgs {
     const uint8_t* row_ok;     // nullable: 0 = deleted or filtered out (isMarkedDeleted / !isIdAllowed)
     uint32_t strict;           // a filter functor is present or the index has deletions (hnswalg.h searchBaseLayerST break rule)
     uint32_t k, ef;
+    uint32_t ip_lanes;                                  // summation order of the distance (4 / 8 / 16: the SIMD level hnswlib was compiled for)
     uint16_t* visited; uint32_t epoch_base;             // [slots][n_rows] 16-bit tags (hnswlib's VisitedList is 16-bit, too); slot = blockIdx.x
     uint32_t* overflow_cnt;                             // [0] queries whose candidate heap outgrew CANDCAP; [1..2] u64 expansions, [3..4] u64 distances (batch totals)
     const uint64_t* labels;
@@ -1224,14 +1246,14 @@ __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
             if (a.dim % 16 == 0) {
                 for (uint32_t i0 = 0; i0 < nb_n; i0 += 16) {           // 16 rows per round, four lanes each
                     const uint32_t i = i0 + (lane >> 2);
-                    const float dot = ip_part16_quad<VEC_HNSW_CHUNK>(qs, a.X + (size_t)nb_id[i < nb_n ? i : nb_n - 1] * a.dim, a.dim, lane & 3);
+                    const float dot = ip_dot16_quad<VEC_HNSW_CHUNK>(qs, a.X + (size_t)nb_id[i < nb_n ? i : nb_n - 1] * a.dim, a.dim, lane & 3, a.ip_lanes);
                     if (i < nb_n && (lane & 3) == 0) nb_d[i] = ip_add(1.0f, -dot);
                 }
             } else {
                 for (uint32_t i0 = 0; i0 < nb_n; i0 += 4) {
                     const uint32_t i = i0 + grp;
                     const uint32_t row = nb_id[i < nb_n ? i : nb_n - 1];
-                    const float d = ip_distance_group16(qs, a.X + (size_t)row * a.dim, a.dim, sub);
+                    const float d = ip_distance_group16(qs, a.X + (size_t)row * a.dim, a.dim, sub, a.ip_lanes);
                     if (i < nb_n && sub == 0) nb_d[i] = d;
                 }
             }
