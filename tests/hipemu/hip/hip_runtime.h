@@ -339,7 +339,7 @@ inline void __builtin_amdgcn_sched_barrier(int) {}
 
 // ---------------------------------------------------------------- host runtime API subset (emulated)
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorUnknown = 999 };
 typedef struct hipemu_stream* hipStream_t;
 typedef struct hipemu_event { double t; }* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
@@ -362,12 +362,17 @@ inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); e->t = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
-inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+// fault injection (tests/test_emu_incremental.py): the N-th hipMalloc / synchronous hipMemcpy from now on fails once (0 = off).
+// One counter per library image; set through the exported hipemu_fail_nth() below.
+namespace hipemu { inline long& fail_countdown() { static long n = 0; return n; }
+inline bool inject_fault() { long& n = fail_countdown(); if (n > 0 && --n == 0) return true; return false; } }
+extern "C" inline __attribute__((visibility("default"), used)) void hipemu_fail_nth(long n) { hipemu::fail_countdown() = n; }
+inline hipError_t hipMalloc(void** p, size_t n) { if (hipemu::inject_fault()) { *p = nullptr; return hipErrorOutOfMemory; } *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
-inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (hipemu::inject_fault()) return hipErrorUnknown; if (n) memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }

@@ -9,6 +9,7 @@ import pytest
 
 import typesense_amd as T
 from typesense_amd import _lib as B
+from oracle import oracle_py as O
 from tests import helpers as H
 
 
@@ -94,6 +95,32 @@ def test_mixed_k_stride_and_failing_query_stay_per_caller(pair):
     g.set_option("batch_window_us", 80)
 
 
+def test_a_caller_whose_k_stride_is_too_small_fails_alone(pair):
+    """a coalesced round stages its results with the widest Topster of the round: the caller whose own k_stride is smaller than its
+    topster_size gets 400 for its query, the callers that shared the round get their results (as they would have, called alone)"""
+    orc, g, _ = pair
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, 1, 0))
+    g.set_option("batch_window_us", 20000)
+    good = T.KwQuery([1, 2], sort=sort, topster_size=24)
+    greedy = T.KwQuery([1], sort=sort, topster_size=200)                 # its Topster holds more hits than its caller's buffer
+    ref = H.oracle_keyword(orc, good)
+    assert H.oracle_keyword(orc, greedy).keys.size > 24
+    start = threading.Barrier(4)
+
+    def worker(i):
+        start.wait()
+        for _ in range(3):
+            if i == 0:
+                hits = g.keyword_search_batch([greedy], k_stride=24)
+                assert hits.status[0] == B.ERR_INVALID and hits.n_hits[0] == 0
+            else:
+                hits = g.keyword_search_batch([good], k_stride=24)
+                assert hits.status[0] == 0
+                H.assert_hits_equal(hits, 0, ref, "shared a round with a failing caller")
+    _run_threads(4, worker)
+    g.set_option("batch_window_us", 80)
+
+
 def test_searches_during_commits_see_old_or_new_snapshot():
     """RCU snapshots: a search that overlaps a commit returns either the pre- or the post-commit result, bit-exact vs the oracle."""
     docs = H.zipf_docs(600, 60, 8, seed=3)
@@ -106,6 +133,7 @@ def test_searches_during_commits_see_old_or_new_snapshot():
     ref_b = [H.oracle_keyword(orc_b, q) for q in qs]
     stop = threading.Event()
     seen = {"a": 0, "b": 0}
+    errors = []                     # an AssertionError inside a Thread target never reaches pytest: collect, assert on the main thread
 
     def same(hits, i, ref):
         n = int(hits.n_hits[i])
@@ -117,10 +145,18 @@ def test_searches_during_commits_see_old_or_new_snapshot():
             hits = g.keyword_search_batch(qs, k_stride=50)
             a = all(same(hits, i, ref_a[i]) for i in range(len(qs)))
             b = all(same(hits, i, ref_b[i]) for i in range(len(qs)))
-            assert a or b, "a search saw a mix of two snapshots"
+            if not (a or b):
+                errors.append("a search saw a mix of two snapshots")
+                return
             seen["a" if a else "b"] += 1
 
-    th = [threading.Thread(target=searcher, args=(i,)) for i in range(2)]
+    def guarded(i):
+        try:
+            searcher(i)
+        except Exception as e:      # noqa: BLE001 — whatever a searcher dies of must fail the test
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=guarded, args=(i,)) for i in range(2)]
     for t in th:
         t.start()
     try:
@@ -137,7 +173,86 @@ def test_searches_during_commits_see_old_or_new_snapshot():
         for t in th:
             t.join()
     g.close()
+    assert not errors, errors
     assert seen["a"] + seen["b"] > 0
+
+
+def test_searches_during_incremental_commits_see_a_published_snapshot():
+    """the same with INCREMENTAL commits (posting_upsert appends + mid-list rewrites: descriptor scatter into spare entries and tail
+    appends happen while searchers run): every search equals the oracle of one of the published states, never a mix"""
+    n0, step, n_steps = 500, 60, 3
+    docs = H.zipf_docs(n0 + step * n_steps, 50, 7, seed=17)
+    lib = H.emu_lib_path()
+    g = T.GpuIndex(0, lib)
+    g.field_create(0, False)
+    for d in range(n0):
+        g.index_plain_doc(d, 0, docs[d])
+    g.column_set(0, H.points_of(docs.shape[0]))
+    g.set_num_docs(docs.shape[0])
+    g.commit()
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, 1, 0))
+    qs = [T.KwQuery([1, 2], sort=sort, topster_size=50), T.KwQuery([3], sort=sort, topster_size=50), T.KwQuery([2, 4, 5], sort=sort, topster_size=50)]
+
+    def state_oracle(cur_docs, n_live):
+        orc = O.OracleIndex(1, 1)
+        for d in range(n_live):
+            orc.index_plain(d, 0, cur_docs[d])
+        orc.set_num_docs(docs.shape[0])
+        orc.set_sort_dense(0, H.points_of(docs.shape[0]))
+        return [H.oracle_keyword(orc, q) for q in qs]
+
+    # the published states, computed up front (the updates are deterministic)
+    rng = np.random.default_rng(3)
+    plans, cur, states = [], docs.copy(), [state_oracle(docs, n0)]
+    for s_ in range(n_steps):
+        upd = [(int(d), rng.integers(1, 20, size=docs.shape[1]).astype(np.uint32)) for d in rng.choice(n0, size=5, replace=False)]
+        plans.append(upd)
+        for d, toks in upd:
+            cur[d] = toks
+        states.append(state_oracle(cur, n0 + step * (s_ + 1)))
+    stop = threading.Event()
+    errors, seen = [], [0] * len(states)
+
+    def same(hits, i, ref):
+        n = int(hits.n_hits[i])
+        return n == ref.keys.size and np.array_equal(hits.keys[i, :n], ref.keys) and np.array_equal(hits.scores[i, :n], ref.scores) \
+            and int(hits.num_matched[i]) == int(ref.num_keyword_matches)
+
+    def searcher(_):
+        try:
+            while not stop.is_set():
+                hits = g.keyword_search_batch(qs, k_stride=50)
+                which = [k for k, st in enumerate(states) if all(same(hits, i, st[i]) for i in range(len(qs)))]
+                if not which:
+                    errors.append("a search matched none of the published snapshots")
+                    return
+                seen[which[0]] += 1
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=searcher, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    try:
+        live_docs = docs.copy()
+        for s_ in range(n_steps):
+            for d in range(n0 + step * s_, n0 + step * (s_ + 1)):
+                g.index_plain_doc(d, 0, live_docs[d])
+            for d, toks in plans[s_]:
+                g.remove_plain_doc(d, 0, live_docs[d])
+                live_docs[d] = toks
+                g.index_plain_doc(d, 0, toks)
+            g.commit()
+        assert g.counter("commit_incremental_count") >= n_steps
+        hits = g.keyword_search_batch(qs, k_stride=50)
+        assert all(same(hits, i, states[-1][i]) for i in range(len(qs)))
+    finally:
+        stop.set()
+        for t in th:
+            t.join()
+    g.close()
+    assert not errors, errors
+    assert sum(seen) > 0
 
 
 def test_concurrent_knn_calls_share_one_scan():

@@ -121,3 +121,58 @@ def test_many_small_commits_until_the_tails_run_out():
     assert g.counter("commit_incremental_count") >= 1 and g.counter("commit_full_count") >= 2, "the tails never filled up / never compacted"
     check_equal(g, fresh_oracle(docs, live), rng, "after 13 write batches", n_queries=6)
     g.close()
+
+
+def test_a_failing_commit_leaves_the_previous_snapshot_and_the_retry_is_complete():
+    """fault injection (emulator: the N-th hipMalloc / hipMemcpy fails): wherever a commit dies — incremental path, its full
+    fallback, first upload or last — searches keep answering from the snapshot published before, and the next commit (forced onto
+    the full path: a failed attempt has left arena positions in the host lists that never reached the device) publishes everything"""
+    import ctypes as C
+    lib = H.emu_lib_path()
+    emu = C.CDLL(lib)
+    emu.hipemu_fail_nth.argtypes = [C.c_long]
+    rng = np.random.default_rng(12)
+    n0, n1 = 900, 1300
+    docs = H.zipf_docs(n1, 40, 6, seed=21)
+    live = np.zeros(n1, bool)
+    live[:n0] = True
+    g = T.GpuIndex(0, lib)
+    g.field_create(0, False)
+    for d in range(n0):
+        g.index_plain_doc(d, 0, docs[d])
+    g.column_set(0, H.points_of(n1))
+    g.set_num_docs(n1)
+    g.commit()
+    old = fresh_oracle(docs, live)
+    check_equal(g, old, rng, "before the faults", n_queries=4)
+    done = n0
+    failures = 0
+    for nth in (1, 2, 3, 5, 8, 13):                      # die at a different device call of the commit each time
+        for d in range(done, done + 40):
+            g.index_plain_doc(d, 0, docs[d])
+            live[d] = True
+        # an update in the middle of published lists as well (re-written blocks, not only appended ones)
+        upd = int(rng.integers(0, n0))
+        if live[upd]:
+            g.remove_plain_doc(upd, 0, docs[upd])
+            docs[upd] = rng.integers(1, 30, size=docs.shape[1])
+            g.index_plain_doc(upd, 0, docs[upd])
+        done += 40
+        emu.hipemu_fail_nth(nth)
+        try:
+            g.commit()
+            failed = False
+        except T.TsgpuError as e:
+            failed = True
+            assert e.code in (B.ERR_DEVICE, B.ERR_NO_MEMORY), e
+        emu.hipemu_fail_nth(0)
+        if failed:
+            failures += 1
+            check_equal(g, old, rng, "after a commit that failed at device call %d: the previous snapshot must still answer" % nth, n_queries=3)
+            full_before = g.counter("commit_full_count")
+            g.commit()                                   # the retry
+            assert g.counter("commit_full_count") == full_before + 1, "the retry after a failed commit must re-pack from the host lists"
+        old = fresh_oracle(docs, live)
+        check_equal(g, old, rng, "after the retry of the commit that failed at device call %d" % nth, n_queries=4)
+    assert failures >= 4 and g.counter("commit_failed_count") == failures
+    g.close()

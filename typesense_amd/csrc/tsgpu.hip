@@ -304,6 +304,7 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!strcmp(name, "hnsw_last_distances")) { *out = ctx->hnsw_last_distances; return ok(); }
     if (!strcmp(name, "commit_last_us")) { *out = ctx->commit_last_us; return ok(); }                        // the last tsgpu_commit: wall time, bytes uploaded
     if (!strcmp(name, "commit_last_uploaded_bytes")) { *out = ctx->commit_last_uploaded_bytes; return ok(); }
+    if (!strcmp(name, "commit_failed_count")) { *out = ctx->commit_failed_count; return ok(); }
     if (!strcmp(name, "commit_full_count")) { *out = ctx->commit_full_count; return ok(); }                  // commits that re-packed everything / appended at the tails
     if (!strcmp(name, "commit_incremental_count")) { *out = ctx->commit_incremental_count; return ok(); }
     if (!strcmp(name, "kw_batches")) { *out = ctx->kw_batches.load(); return ok(); }                 // host-side phase totals (us) over all keyword batches
@@ -808,7 +809,12 @@ static int kw_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t 
         try {
             uint32_t total = 0, KS = 1;
             bool want_ids = false;
-            for (KwRequest* r : round) { total += r->units; KS = std::max(KS, r->out->k_stride); want_ids = want_ids || r->ids != nullptr; }
+            // staging stride = the widest Topster of the round (not only the widest caller buffer): a caller whose own k_stride is too
+            // small for its topster_size must fail ALONE (the per-caller `n > ks` check below), not take the round's other callers with it
+            for (KwRequest* r : round) {
+                total += r->units; KS = std::max(KS, r->out->k_stride); want_ids = want_ids || r->ids != nullptr;
+                for (uint32_t i = 0; i < r->units; i++) KS = std::max(KS, std::min<uint32_t>(resolve_topster_size(ctx, r->q[i]), TSGPU_MAX_TOPK));
+            }
             L.c_q.resize(total);
             uint32_t at = 0;
             for (KwRequest* r : round) { memcpy(L.c_q.data() + at, r->q, (size_t)r->units * sizeof(tsgpu_kw_query)); at += r->units; }

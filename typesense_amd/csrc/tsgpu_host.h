@@ -369,6 +369,7 @@ struct tsgpu_ctx {
     uint32_t vec_rows_per_slab = 0;                  // 0 = automatic
     uint32_t vec_sample_tiles = 0;                   // 0 = automatic (8192 tiles on the bf16 prefilter path, 512 on the fp32 scan): 128-row tiles of the threshold sample
     uint32_t vec_cand_cap = 0;                       // candidate slots per query in pass 2 (0 = automatic)
+    uint64_t commit_failed_count = 0;                // commits that returned an error (the next one re-packs from the host lists)
     uint32_t vec_ip_lanes = 4;                       // order of the exact distances' sums: 4 = hnswlib built for SSE (the reference's stock flags), 8 = AVX, 16 = AVX-512
     uint32_t vec_prefilter = 1;                      // 1 = bf16 bracket scan + exact fp32 re-score (default); 0 = fp32 MFMA scan
     uint64_t vec_prefilter_groups = 0;               // query groups answered by the bf16 bracket path

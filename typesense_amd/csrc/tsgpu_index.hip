@@ -32,9 +32,10 @@ inline uint32_t ids_words(const BlockMeta& m) { return packed_words(m.n_ids, m.i
 inline uint32_t pay_words(const BlockMeta& m) { return packed_words(m.n_ids, m.oi_bits) + packed_words(m.n_off, m.off_bits); }
 
 void mark_dirty(tsgpu_ctx* ctx, uint32_t field, uint32_t term, TermHost* t) {
+    ctx->dirty = true;
+    if (t && t->dirty) return;                               // already queued for the next commit (one entry per term, not per posting operation)
     if (t) t->dirty = true;
     ctx->dirty_terms.push_back(((uint64_t)field << 32) | term);
-    ctx->dirty = true;
 }
 
 void set_list(TermHost& t, PackedList&& pl) {
@@ -593,7 +594,15 @@ int tsgpu_commit(tsgpu_ctx* ctx) {
         const bool can_inc = cur && cur->ar && cur->maps && !ctx->commit_force_full && !ctx->dirty_fields;
         if (can_inc) rc = commit_incremental(ctx, cur);
         if (rc == -1) rc = commit_full(ctx);
-        if (rc != TSGPU_OK) return rc;
+        if (rc != TSGPU_OK) {
+            // A failed attempt (either path) has already written arena positions / handles / descriptor bases into the host-side
+            // lists for blocks that never reached the device. Nothing published refers to them (the previous snapshot is immutable
+            // and stays in place), but an INCREMENTAL retry would skip those blocks as "already uploaded". The next commit therefore
+            // takes the full path, which derives every position from the host lists alone.
+            ctx->commit_force_full = true;
+            ctx->commit_failed_count++;
+            return rc;
+        }
         ctx->dirty_terms.clear();
         ctx->dirty_fields = false;
         ctx->commit_force_full = false;
