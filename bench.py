@@ -239,6 +239,32 @@ class Bench:
         self.csr = None
         self.exact = None           # exact k-NN of the first queries by the oracle's chunked flat scan (vector + hybrid parity)
         self.extras = not args.no_extras and world == 1
+        # N > 1, shards: the exchange runs behind the C-ABI (tsgpu_group: RCCL ncclAllGather on the context's stream + the library's merge
+        # kernels). Rank 0's ncclUniqueId travels through torch.distributed; if RCCL cannot be brought up inside the library (every rank
+        # must agree) the step falls back to the torch.distributed all-gather + the library's merge, and the JSON line says which ran.
+        self.group, self.exchange = None, "none (1 GPU)"
+        if self.sharded:
+            self.exchange = "torch.distributed all-gather + tsgpu merge kernels"
+            if os.environ.get("TSGPU_BENCH_EXCHANGE", "group") == "group" and os.environ.get("TSGPU_DIST_BACKEND", "nccl") == "nccl":
+                import torch.distributed as dist
+                ok = 1
+                try:
+                    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                    if rank == 0:
+                        uid.copy_(torch.frombuffer(bytearray(T.GpuGroup.unique_id(self.g.L)), dtype=torch.uint8))
+                    dist.broadcast(uid, 0)
+                    self.group = T.GpuGroup.join(self.g, bytes(uid.cpu().numpy().tobytes()), rank, world)
+                except Exception as e:      # noqa: BLE001 — reported, not hidden
+                    ok = 0
+                    sys.stderr.write("[bench] rank %d: tsgpu_group unavailable (%r): torch.distributed exchange instead\n" % (rank, e))
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    self.exchange = "tsgpu_group (C-ABI): RCCL ncclAllGather on the library's stream + kw_shard_merge / vec_group_merge kernels"
+                else:
+                    if self.group is not None:
+                        self.group.close()
+                    self.group = None
 
     # ---------------------------------------------------------------- index builds (untimed)
     def build_keyword(self):
@@ -331,7 +357,23 @@ class Bench:
             pack = torch.zeros((n_q, FETCH_SIZE, 4), dtype=torch.int64, device="cuda")
             counts = torch.zeros((n_q, 2), dtype=torch.int64, device="cuda")
 
+        if self.group is not None:
+            gdev, ghs = device_hits(torch, n_q, FETCH_SIZE)
+
+        def step_torch_exchange():
+            g.keyword_search_batch_raw(arr, n_q, hs)
+            pack[:, :, 0] = dev["keys"][:, :FETCH_SIZE]
+            pack[:, :, 1:] = dev["scores"][:, :FETCH_SIZE]
+            counts[:, 0] = torch.clamp(dev["n_hits"], max=FETCH_SIZE)
+            counts[:, 1] = dev["num_matched"]
+            return self.D.merge_gathered_keyword(g, self.D.all_gather_cat(pack), self.D.all_gather_cat(counts), FETCH_SIZE)
+
         def step():
+            if self.group is not None:
+                # the whole shard step behind the C-ABI: every rank's top-250 Topster, its top-100 packed {key, scores[3]} + counts (32 MB per
+                # GPU at 10 000 queries), ONE ncclAllGather on the library's stream, exact merge (kw_shard_merge_kernel), device-resident result
+                self.group.keyword_search_batch_raw(arr, n_q, FETCH_SIZE, ghs)
+                return gdev["keys"], gdev["scores"], gdev["n_hits"], gdev["num_matched"]
             g.keyword_search_batch_raw(arr, n_q, hs)           # synchronises its stream before returning
             if world == 1:
                 return dev["keys"], dev["scores"], dev["n_hits"], dev["num_matched"]
@@ -358,6 +400,16 @@ class Bench:
         elapsed, lat, out = timed(step, args.steps, args.warmup, world, after)
         res = dict(elapsed=elapsed, lat=lat, kern_ms=float(np.mean(kern_ms)), merge_ms=float(np.mean(merge_ms)), find_ms=float(np.mean(find_ms)),
                    alg_bytes=float(np.mean(alg_bytes)), n_q=n_q, n_postings=int(self.csr["n_postings"]))
+        if self.group is not None:
+            # cross-check of the two exchange implementations (untimed): the C-ABI group's merged result == torch.distributed all-gather + merge
+            ref = step_torch_exchange()
+            nh_a, nh_b = out[2].to(torch.int64), ref[2].to(torch.int64)
+            live = torch.arange(FETCH_SIZE, device="cuda")[None, :] < nh_a[:, None]
+            same = bool(torch.equal(nh_a, nh_b)) and bool(torch.equal(out[3].to(torch.int64), ref[3].to(torch.int64))) \
+                and bool(torch.equal(out[0][:, :FETCH_SIZE][live], ref[0][:, :FETCH_SIZE][live])) and bool(torch.equal(out[1][:, :FETCH_SIZE][live], ref[1][:, :FETCH_SIZE][live]))
+            gt = self.group.timings()
+            res["exchange_check"] = {"group_equals_torch_exchange": bool(same), "local_ms": gt.local_ms, "exchange_merge_ms": gt.exchange_merge_ms,
+                                     "exchange_bytes_per_gpu": int(gt.exchange_bytes_per_member)}
         keys = out[0].cpu().numpy().astype(np.uint64)
         scores = out[1].cpu().numpy()
         n_hits = out[2].cpu().numpy()
@@ -542,6 +594,10 @@ class Bench:
         rec = dict(kern_ms=[], flops=[], scan_ms=[], scan_bytes=[], post_ms=[])
 
         def step():
+            if self.sharded and self.group is not None and g is self.g:
+                # the exchange behind the C-ABI: per-GPU k nearest as one u64 {ord(dist), label} per hit, ONE ncclAllGather, vec_group_merge_kernel
+                self.group.vec_knn_batch_raw(field, Q.data_ptr(), B.MEM_DEVICE, n_q, k, dist_o.data_ptr(), lab_o.data_ptr(), cnt_o.data_ptr(), B.MEM_DEVICE)
+                return dist_o, lab_o, cnt_o
             g.vec_knn_batch_raw(field, Q.data_ptr(), B.MEM_DEVICE, n_q, k, dist_o.data_ptr(), lab_o.data_ptr(), cnt_o.data_ptr(), B.MEM_DEVICE)
             if self.sharded:
                 return self.D.sharded_knn(dist_o, lab_o, cnt_o, k)
@@ -815,6 +871,10 @@ class Bench:
             cnt_o = torch.zeros(n_q, dtype=torch.int32, device="cuda")
 
             def step():      # fuse AFTER the shard merge: reciprocal ranks are global ranks
+                if self.group is not None:
+                    # tsgpu_group_hybrid_search_batch: merged Topsters (250, with text_match) + merged k nearest, then the reference's fusion
+                    return self.group.hybrid_search_batch(qs, 1, B.METRIC_IP, None, k=k, fetch_size=100, alpha=0.3, k_stride=K_TOPSTER,
+                                                          mem_q=B.MEM_DEVICE, q_ptr=self.Q.data_ptr(), dim=args.dim)
                 g.keyword_search_batch_raw(arr, n_q, hs)
                 keys, sc, n, nm = self.D.sharded_keyword(dev, K_TOPSTER, index=g)
                 g.vec_knn_batch_raw(1, self.Q.data_ptr(), B.MEM_DEVICE, n_q, k, dist_o.data_ptr(), lab_o.data_ptr(), cnt_o.data_ptr(), B.MEM_DEVICE)
@@ -904,6 +964,9 @@ class Bench:
         return res
 
     def close(self):
+        if self.group is not None:
+            self.group.close()
+            self.group = None
         self.g.close()
         if self.twin is not None:
             self.twin.close()
@@ -960,7 +1023,7 @@ def main():
     if world == 1:
         par = "1 GPU"
     elif sharded:
-        par = "doc-range shards x%d of the SAME 10M-doc collection, RCCL all-gather of per-GPU top-100 + counts, exact device merge" % world
+        par = "doc-range shards x%d of the SAME 10M-doc collection, RCCL all-gather of per-GPU top-100 + counts, exact device merge; exchange = %s" % (world, bn.exchange)
     else:
         par = "%d replicas of the collection, global batch = %d x the per-GPU batch sharded across the GPUs, RCCL all-gather of the per-GPU top-K" % (world, world)
     vocab, tpd = (100_000, 32) if args.n_docs >= 1_000_000 else (20_000, 16)
@@ -1008,7 +1071,7 @@ def main():
                                   "note": "wave-instructions of the find kernel / (kernel cycles x 256 CUs x issue capacity per CU: 2 VALU, 1 SALU), counters from "
                                           "the committed --pmc pass (profiles/): the shared scalar unit is the busiest issue port"}
         kw["roofline"] = roof
-        for key in ("concurrency", "uncached", "shard_parity", "replicas"):
+        for key in ("concurrency", "uncached", "shard_parity", "replicas", "exchange_check"):
             if key in r:
                 kw[key] = r[key]
         if "cpu" in r:
@@ -1091,7 +1154,7 @@ def main():
             "value": hd["value"], "unit": "queries/s", "n_gpus": world, "steps": hd["steps"], "warmup": args.warmup, "ms_per_step": hd["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32/i64" if head == "keyword" else "f32",
             "data": "synthetic", "config": hd["config"], "p50_ms_per_batch": hd["p50_ms_per_batch"]}
-    for k in ("queries_with_hits", "value_with_host_delivery", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "replicas", "concurrency",
+    for k in ("queries_with_hits", "value_with_host_delivery", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "exchange_check", "replicas", "concurrency",
               "uncached", "fused_hits_per_batch", "parity_fp32_scan", "batch_sweep", "variants", "hnsw", "rerank_hybrid_matches"):
         if k in hd:
             line[k] = hd[k]

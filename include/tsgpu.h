@@ -409,6 +409,40 @@ int tsgpu_merge_shard_hits(const tsgpu_hits* in, const uint64_t* key_offset, uin
 int tsgpu_merge_shard_hits_device(tsgpu_ctx* ctx, const tsgpu_hits* gathered, uint32_t n_shards, uint32_t n_queries,
                                   uint32_t k, tsgpu_hits* out);
 
+/* ------------------------------------------------------------------ multi-GPU group: the shard exchange behind the C-ABI */
+/* G contexts, one per GPU, each mirroring the postings / sort columns / vectors of ITS seq_id range (global seq_ids kept). A group
+ * call scores the whole batch on every member, exchanges the per-member top-k ONCE (RCCL ncclAllGather over xGMI) and merges exactly
+ * (Topster order, include/topster.h:146-149; k-NN: distance, then label); hybrid fuses AFTER the merge (src/index.cpp:4036-4221: the
+ * reciprocal ranks are ranks in the global lists). SURVEY §8(e), BASELINE config 5. The reference has no counterpart. */
+typedef struct tsgpu_group tsgpu_group;
+#define TSGPU_XCHG_RCCL 0   /* ncclAllGather on the members' streams; librccl.so.1 is resolved with dlopen at group creation */
+#define TSGPU_XCHG_COPY 1   /* device-to-device copies into member 0 (local form only; members may share a device) */
+/* ONE process owns all members (the C++ server): members run on their own host threads inside every group call */
+int tsgpu_group_create_local(tsgpu_ctx* const* members, uint32_t n_members, int transport, tsgpu_group** out);
+/* one process per GPU: rank 0 calls tsgpu_group_unique_id, the launcher broadcasts the 128 bytes, every rank joins with its context */
+int tsgpu_group_unique_id(uint8_t id[128]);
+int tsgpu_group_create_rank(tsgpu_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t n_ranks, tsgpu_group** out);
+void tsgpu_group_destroy(tsgpu_group* g);        /* (the member contexts stay the caller's) */
+uint32_t tsgpu_group_size(const tsgpu_group* g);
+/* global top-k of every query, Topster order; `out` = host memory, or device memory of member 0 / of this rank (then keys, scores,
+ * text_match, n_hits, num_matched, status are filled). k <= out->k_stride, members * k <= 4096; num_matched = sum over the shards;
+ * a query's list never exceeds its own Topster capacity (topster_size, src/index.cpp:3506-3512). */
+int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out);
+/* exact k-NN over all shards (tsgpu_vec_knn_batch per member + the exchange); labels must be seq_ids (< 2^32); members * k <= 8192 */
+int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float* Q, int mem_q, uint32_t n_queries, uint32_t k,
+                              const uint32_t* allow_ids, uint32_t n_allow, const uint32_t* excluded_ids, uint32_t n_excluded,
+                              float* dist_out, uint64_t* label_out, uint32_t* n_out, int mem_out);
+/* hybrid: merged keyword Topsters (capacity out->k_stride) + merged k nearest, then tsgpu_hybrid_fuse_batch. Host outputs; metric / dim
+ * = the vector field's (TSGPU_METRIC_*, num_dim); rerank_hybrid_matches -> 501 */
+int tsgpu_group_hybrid_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t vec_field_id, int metric, const tsgpu_hybrid_params* p,
+                                    const float* Q, int mem_q, uint32_t dim, uint32_t n_queries, tsgpu_hits* out);
+typedef struct tsgpu_group_timings {
+    float local_ms;                      /* host wall: every member's own batch + pack (members run concurrently) */
+    float exchange_merge_ms;             /* host wall: the exchange, the merge and the delivery of the merged result */
+    uint64_t exchange_bytes_per_member;  /* bytes one member contributes to the all-gather */
+} tsgpu_group_timings;
+int tsgpu_group_last_timings(tsgpu_group* g, tsgpu_group_timings* out);
+
 /* ------------------------------------------------------------------ measurement hooks */
 /* device time (ms, HIP events on the launch stream) of the dominant kernel(s) of the last batch call */
 typedef struct tsgpu_timings {

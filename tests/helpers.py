@@ -125,3 +125,22 @@ def assert_hits_equal(hits, qi, ref, what=""):
     assert np.array_equal(hits.scores[qi, :n], ref.scores), "%s q%d: scores differ" % (what, qi)
     assert np.array_equal(hits.text_match[qi, :n], ref.text_match), "%s q%d: text_match differ" % (what, qi)
     assert int(hits.num_matched[qi]) == int(ref.num_keyword_matches), "%s q%d: num_matched %d vs %d" % (what, qi, hits.num_matched[qi], ref.num_keyword_matches)
+
+
+def load_shard(g, orc, lo, hi, n_docs, points, field=0):
+    """the postings of documents [lo, hi) of the oracle's field, GLOBAL seq_ids kept, into GpuIndex g (a doc-range shard)"""
+    g.field_create(field, False)
+    for term in orc.terms(field):
+        ids, oi, off = orc.dump_posting(field, int(term))
+        sel = np.nonzero((ids >= lo) & (ids < hi))[0]
+        if sel.size == 0:
+            continue
+        ends = np.append(oi[1:], off.size)
+        new_off, new_oi = [], []
+        for j in sel:
+            new_oi.append(len(new_off))
+            new_off.extend(off[oi[j]:ends[j]])
+        g.term_upsert(field, int(term), ids[sel], new_oi, new_off)
+    g.column_set(0, points)
+    g.set_num_docs(n_docs)
+    g.commit()

@@ -376,6 +376,7 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { i
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })

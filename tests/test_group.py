@@ -1,0 +1,155 @@
+"""tsgpu_group: the doc-range shard exchange behind the C-ABI (include/tsgpu.h "multi-GPU group"; SURVEY §8e, BASELINE config 5).
+CPU tier: G members on the SIMT emulator, TSGPU_XCHG_COPY transport (a memcpy "all-gather"): keyword, k-NN and hybrid results of
+the group equal the UNSHARDED oracle bit for bit, for G = 2 and 3, uneven shards, per-query Topster capacities, filters.
+GPU tier (one MI355X): the same with members sharing the device at 2M docs, and the RCCL transport in its one-rank form
+(ncclCommInitRank / ncclAllGather / merge on a real stream; more ranks need more GPUs: the driver's scaling run)."""
+import numpy as np
+import pytest
+
+import typesense_amd as T
+from typesense_amd import _lib as B
+from oracle import oracle_py as O
+from tests import helpers as H
+
+SORT = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+OSORT = ((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1))
+
+
+def build_group(lib, cuts, n_docs, dim, transport, seed=8):
+    docs = H.zipf_docs(n_docs, 80, 10, seed=seed)
+    pts = H.points_of(n_docs)
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n_docs, dim)).astype(np.float32)
+    orc = O.OracleIndex(1, 1)
+    for d in range(n_docs):
+        orc.index_plain(d, 0, docs[d])
+    orc.set_num_docs(n_docs)
+    orc.set_sort_dense(0, pts)
+    orc.vec_init(dim, O.METRIC_IP)
+    orc.vec_add(np.arange(n_docs, dtype=np.uint32), X)
+    members = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        g = T.GpuIndex(0, lib)
+        H.load_shard(g, orc, lo, hi, n_docs, pts)
+        g.vec_create(1, dim, B.METRIC_IP)
+        if hi > lo:
+            g.vec_upsert(1, np.arange(lo, hi, dtype=np.uint64), X[lo:hi])
+        members.append(g)
+    return orc, members, T.GpuGroup(members, transport), rng
+
+
+def check_group(orc, grp, rng, n_docs, dim):
+    # ---- keyword: global Topster order, num_matched = sum, per-query Topster capacity, a query no shard can serve (501) ----
+    filt = np.sort(rng.choice(n_docs, size=n_docs // 3, replace=False)).astype(np.uint32)
+    qs = [T.KwQuery([1, 2], sort=SORT, topster_size=40), T.KwQuery([3, 1, 2], sort=SORT, topster_size=40), T.KwQuery([5], sort=SORT, topster_size=12),
+          T.KwQuery([4, 9], sort=SORT, topster_size=40, filter_ids=filt), T.KwQuery([1], sort=SORT, topster_size=0), T.KwQuery([77, 78], sort=SORT, topster_size=40),
+          T.KwQuery([2, 3], sort=SORT, topster_size=40, excluded_ids=filt[::2]),
+          T.KwQuery([1, 2], sort=((B.SORT_INT64_COLUMN, 1, 77),), topster_size=40)]           # unknown sort column -> 501 on every shard
+    hits = grp.keyword_search_batch(qs, k=250, k_stride=250)
+    for i, q in enumerate(qs[:-1]):
+        assert hits.status[i] == 0
+        H.assert_hits_equal(hits, i, H.oracle_keyword(orc, q), "group keyword")
+    assert hits.status[len(qs) - 1] == B.ERR_UNSUPPORTED and hits.n_hits[len(qs) - 1] == 0
+    # a smaller exchange (k = 10 of the Topster's 40): the global top-10
+    h10 = grp.keyword_search_batch(qs[:3], k=10, k_stride=16)
+    for i, q in enumerate(qs[:3]):
+        ref = H.oracle_keyword(orc, q)
+        n = min(10, ref.keys.size)
+        assert int(h10.n_hits[i]) == n and np.array_equal(h10.keys[i, :n], ref.keys[:n]) and np.array_equal(h10.scores[i, :n], ref.scores[:n])
+        assert int(h10.num_matched[i]) == int(ref.num_keyword_matches)
+    # ---- k-NN: closest first, ties -> smaller label; allow list ----
+    Q = rng.standard_normal((5, dim)).astype(np.float32)
+    for k in (7, 30):
+        dist, lab, cnt = grp.vec_knn_batch(1, Q, k)
+        for i in range(Q.shape[0]):
+            d, l = orc.flat_knn(Q[i], k)
+            assert cnt[i] == d.size and np.array_equal(lab[i, :d.size].astype(np.uint32), l)
+            assert np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32))
+    allow = filt[:50]
+    dist, lab, cnt = grp.vec_knn_batch(1, Q[:2], 9, allow_ids=allow)
+    for i in range(2):
+        d, l = orc.flat_knn(Q[i], 9, allow_ids=allow)
+        assert cnt[i] == d.size and np.array_equal(lab[i, :d.size].astype(np.uint32), l) and np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32))
+    # ---- hybrid: fused AFTER the merge (global ranks), incl. a filtered and a curated query ----
+    hq = [T.KwQuery([1, 2], sort=SORT, topster_size=0), T.KwQuery([3], sort=SORT, topster_size=0), T.KwQuery([2, 5], sort=SORT, topster_size=0, filter_ids=filt),
+          T.KwQuery([59, 1], sort=SORT, topster_size=0, excluded_ids=filt[::3]), T.KwQuery([7, 7], sort=SORT, topster_size=0)]
+    fused = grp.hybrid_search_batch(hq, 1, B.METRIC_IP, Q, k=0, fetch_size=10, alpha=0.3, k_stride=250)
+    assert (fused.status == 0).all()
+    for i, q in enumerate(hq):
+        kw = {}
+        if q.filter_ids is not None:
+            kw["filter_ids"] = q.filter_ids
+        if q.excluded_ids is not None:
+            kw["excluded_ids"] = q.excluded_ids
+        ref = orc.search_hybrid(orc.make_query(q.tokens, sort=OSORT, fetch_size=10, **kw), Q[i], k=0, alpha=0.3)
+        n = int(fused.n_hits[i])
+        assert n == ref.keys.size, (i, n, ref.keys.size)
+        assert np.array_equal(fused.keys[i, :n], ref.keys) and np.array_equal(fused.scores[i, :n], ref.scores), i
+        assert np.array_equal(fused.text_match[i, :n], ref.text_match), i
+        assert np.array_equal(fused.vector_distance[i, :n].view(np.uint32), ref.vector_distance.view(np.uint32)), i
+
+
+@pytest.mark.parametrize("cuts", [(0, 700, 1500), (0, 100, 1100, 1500), (0, 1500, 1500)])
+def test_group_over_copy_transport_equals_the_unsharded_oracle(cuts):
+    orc, members, grp, rng = build_group(H.emu_lib_path(), cuts, 1500, 24, B.XCHG_COPY)
+    try:
+        assert grp.size() == len(cuts) - 1
+        check_group(orc, grp, rng, 1500, 24)
+        t = grp.timings()
+        assert t.exchange_bytes_per_member > 0
+    finally:
+        grp.close()
+        for g in members:
+            g.close()
+
+
+def test_group_argument_errors_are_reported_not_crashed():
+    lib = H.emu_lib_path()
+    g = T.GpuIndex(0, lib)
+    with pytest.raises(T.TsgpuError):
+        T.GpuGroup([g, g], B.XCHG_RCCL)           # RCCL needs one GPU per member
+    grp = T.GpuGroup([g], B.XCHG_COPY)
+    with pytest.raises(T.TsgpuError):
+        grp.keyword_search_batch([T.KwQuery([1], sort=SORT)], k=2000, k_stride=2000)
+    grp.close()
+    g.close()
+
+
+@pytest.mark.gpu
+def test_group_on_one_mi355x_members_share_the_device():
+    orc, members, grp, rng = build_group(H.gpu_lib_path(), (0, 9000, 20000, 30000), 30000, 64, B.XCHG_COPY, seed=5)
+    try:
+        check_group(orc, grp, rng, 30000, 64)
+    finally:
+        grp.close()
+        for g in members:
+            g.close()
+
+
+@pytest.mark.gpu
+def test_rccl_transport_one_rank_form_runs_the_real_collective():
+    """ncclGetUniqueId -> ncclCommInitRank(1 rank) -> ncclAllGather on the context's stream -> merge: equals the plain call"""
+    lib = H.gpu_lib_path()
+    docs = H.zipf_docs(20000, 200, 10, seed=3)
+    orc, g = H.build_pair(docs, lib)
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((20000, 48)).astype(np.float32)
+    g.vec_create(1, 48, B.METRIC_IP)
+    g.vec_upsert(1, np.arange(20000, dtype=np.uint64), X)
+    uid = T.GpuGroup.unique_id(g.L)
+    grp = T.GpuGroup.join(g, uid, 0, 1)
+    try:
+        qs = [T.KwQuery(t, sort=SORT, topster_size=250) for t in ([1, 2], [3, 4, 5], [9], [150, 2])]
+        plain = g.keyword_search_batch(qs, k_stride=250)
+        got = grp.keyword_search_batch(qs, k=100, k_stride=100)
+        for i in range(len(qs)):
+            n = min(100, int(plain.n_hits[i]))
+            assert int(got.n_hits[i]) == n and np.array_equal(got.keys[i, :n], plain.keys[i, :n]) and np.array_equal(got.scores[i, :n], plain.scores[i, :n])
+            assert int(got.num_matched[i]) == int(plain.num_matched[i])
+        Q = rng.standard_normal((6, 48)).astype(np.float32)
+        d0, l0, c0 = g.vec_knn_batch(1, Q, 20)
+        d1, l1, c1 = grp.vec_knn_batch(1, Q, 20)
+        assert np.array_equal(l0, l1) and np.array_equal(d0.view(np.uint32), d1.view(np.uint32)) and np.array_equal(c0, c1)
+    finally:
+        grp.close()
+        g.close()

@@ -62,6 +62,12 @@ class TimingsC(C.Structure):
                 ("vec_scan_bytes", C.c_uint64), ("kw_find_ms", C.c_float)]
 
 
+class GroupTimingsC(C.Structure):
+    _fields_ = [("local_ms", C.c_float), ("exchange_merge_ms", C.c_float), ("exchange_bytes_per_member", C.c_uint64)]
+
+
+XCHG_RCCL, XCHG_COPY = 0, 1
+
 EXPORTS = [
     "tsgpu_abi_version", "tsgpu_create", "tsgpu_destroy", "tsgpu_last_error", "tsgpu_set_stream", "tsgpu_set_option", "tsgpu_get_counter", "tsgpu_device_bytes",
     "tsgpu_field_create", "tsgpu_term_upsert", "tsgpu_posting_upsert", "tsgpu_posting_erase", "tsgpu_terms_load_csr", "tsgpu_column_set", "tsgpu_set_num_docs", "tsgpu_commit",
@@ -69,6 +75,8 @@ EXPORTS = [
     "tsgpu_keyword_search_batch_ids", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free", "tsgpu_facet_set", "tsgpu_facet_count_batch",
     "tsgpu_vec_create", "tsgpu_vec_upsert", "tsgpu_vec_delete", "tsgpu_vec_get", "tsgpu_vec_count", "tsgpu_vec_knn_batch",
     "tsgpu_vec_hnsw_load", "tsgpu_vec_hnsw_search_batch", "tsgpu_vec_distances", "tsgpu_ip_distance", "tsgpu_vector_search_batch", "tsgpu_hybrid_search_batch", "tsgpu_hybrid_fuse_batch", "tsgpu_keyword_aux_scores", "tsgpu_merge_shard_hits", "tsgpu_merge_shard_hits_device", "tsgpu_last_timings",
+    "tsgpu_group_create_local", "tsgpu_group_unique_id", "tsgpu_group_create_rank", "tsgpu_group_destroy", "tsgpu_group_size", "tsgpu_group_keyword_search_batch",
+    "tsgpu_group_vec_knn_batch", "tsgpu_group_hybrid_search_batch", "tsgpu_group_last_timings",
 ]
 
 _libs = {}
@@ -151,6 +159,17 @@ def lib(path=None):
     L.tsgpu_merge_shard_hits.argtypes = [vp, vp, u32, u32, u32, C.POINTER(HitsC)]
     L.tsgpu_merge_shard_hits_device.argtypes = [vp, C.POINTER(HitsC), u32, u32, u32, C.POINTER(HitsC)]
     L.tsgpu_last_timings.argtypes = [vp, C.POINTER(TimingsC)]
+    L.tsgpu_group_create_local.argtypes = [vp, u32, i32, vp]
+    L.tsgpu_group_unique_id.argtypes = [vp]
+    L.tsgpu_group_create_rank.argtypes = [vp, vp, u32, u32, vp]
+    L.tsgpu_group_destroy.argtypes = [vp]
+    L.tsgpu_group_destroy.restype = None
+    L.tsgpu_group_size.argtypes = [vp]
+    L.tsgpu_group_size.restype = u32
+    L.tsgpu_group_keyword_search_batch.argtypes = [vp, vp, u32, u32, C.POINTER(HitsC)]
+    L.tsgpu_group_vec_knn_batch.argtypes = [vp, u32, vp, i32, u32, u32, vp, u32, vp, u32, vp, vp, vp, i32]
+    L.tsgpu_group_hybrid_search_batch.argtypes = [vp, vp, u32, i32, C.POINTER(HybridParamsC), vp, i32, u32, u32, C.POINTER(HitsC)]
+    L.tsgpu_group_last_timings.argtypes = [vp, C.POINTER(GroupTimingsC)]
     _libs[path] = L
     return L
 

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtsgpu.so")
-SOURCES = ["tsgpu.hip", "tsgpu_index.hip", "tsgpu_vec.hip", "tsgpu_facet.hip"]
+SOURCES = ["tsgpu.hip", "tsgpu_index.hip", "tsgpu_vec.hip", "tsgpu_facet.hip", "tsgpu_group.hip"]
 
 
 def _hipcc():
@@ -64,7 +64,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None, only_kw=False, o
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)

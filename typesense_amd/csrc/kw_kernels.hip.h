@@ -2001,7 +2001,30 @@ struct KwShardIn {
     const uint64_t* keys; const int64_t* scores; const int64_t* text_match; const float* vector_distance; const int8_t* match_score_index;
     const uint32_t* n_hits; const uint64_t* num_matched;
     uint32_t n_shards, n_queries, k_in;
+    // PACKED form (tsgpu_group's exchange buffer, one all-gather per batch): shard g's block = [query][k_in][words] u64 {key, s0, s1, s2(, text_match)}
+    // followed by [query][3] u64 {n_hits, num_matched, status}; blocks are shard_stride words apart. packed == nullptr: the arrays above.
+    const uint64_t* packed; uint64_t shard_stride; uint32_t words;
+    int32_t* status_out;           // (packed form) merged per-query status: the first non-zero status among the shards
+    const uint32_t* cap_per_query; // nullable: the merged list of query q holds min(k, cap_per_query[q]) hits (its own Topster's capacity)
 };
+// this member's top-k of a device-resident result (tsgpu_hits layout, stride k_stride) -> its exchange block (see KwShardIn::packed)
+__global__ void kw_group_pack_kernel(KwOut loc, const int32_t* status, uint32_t n_queries, uint32_t k, uint32_t words, uint64_t* dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t q = i / k, j = i - q * k;
+    if (q >= n_queries) return;
+    const bool failed = status && status[q] != 0;              // a query that was not run may expose stale slots in device outputs
+    const uint32_t n = failed ? 0u : (loc.n_hits[q] < k ? loc.n_hits[q] : k);
+    uint64_t* d = dst + ((size_t)q * k + j) * words;
+    const size_t src = (size_t)q * loc.k_stride + j;
+    const bool live = j < n;
+    d[0] = live ? loc.keys[src] : 0;
+    d[1] = live ? (uint64_t)loc.scores[src * 3 + 0] : 0; d[2] = live ? (uint64_t)loc.scores[src * 3 + 1] : 0; d[3] = live ? (uint64_t)loc.scores[src * 3 + 2] : 0;
+    if (words > 4) d[4] = live && loc.text_match ? (uint64_t)loc.text_match[src] : 0;
+    if (j == 0) {
+        uint64_t* c = dst + (size_t)n_queries * k * words + (size_t)q * 3;
+        c[0] = n; c[1] = (loc.num_matched && !failed) ? loc.num_matched[q] : 0; c[2] = status ? (uint64_t)(uint32_t)status[q] : 0;
+    }
+}
 template <int CAP>
 __global__ __launch_bounds__(KW_THREADS) void kw_shard_merge_kernel(KwShardIn in, KwOut out, uint32_t k) {
     __shared__ TopkLds<CAP> tk;
@@ -2011,14 +2034,21 @@ __global__ __launch_bounds__(KW_THREADS) void kw_shard_merge_kernel(KwShardIn in
     for (int i = t; i < CAP; i += KW_THREADS) tk.key[i] = -1;
     __syncthreads();
     for (uint32_t g = 0; g < in.n_shards; g++) {
-        const uint32_t n = in.n_hits[(size_t)g * in.n_queries + q];
+        const uint64_t* pk = in.packed ? in.packed + g * in.shard_stride : nullptr;
+        const uint32_t n = pk ? (uint32_t)pk[(size_t)in.n_queries * in.k_in * in.words + (size_t)q * 3] : in.n_hits[(size_t)g * in.n_queries + q];
         const size_t base = ((size_t)g * in.n_queries + q) * in.k_in;
         const uint32_t at = s_total;
         for (uint32_t i = t; i < n; i += KW_THREADS) {
             const uint32_t slot = at + i;
             if (slot < (uint32_t)CAP) {
-                tk.s0[slot] = in.scores[(base + i) * 3 + 0]; tk.s1[slot] = in.scores[(base + i) * 3 + 1]; tk.s2[slot] = in.scores[(base + i) * 3 + 2];
-                tk.key[slot] = (int64_t)((in.keys[base + i] << 16) | (uint64_t)(g * in.k_in + i));
+                if (pk) {
+                    const uint64_t* e = pk + ((size_t)q * in.k_in + i) * in.words;
+                    tk.s0[slot] = (int64_t)e[1]; tk.s1[slot] = (int64_t)e[2]; tk.s2[slot] = (int64_t)e[3];
+                    tk.key[slot] = (int64_t)((e[0] << 16) | (uint64_t)(g * in.k_in + i));
+                } else {
+                    tk.s0[slot] = in.scores[(base + i) * 3 + 0]; tk.s1[slot] = in.scores[(base + i) * 3 + 1]; tk.s2[slot] = in.scores[(base + i) * 3 + 2];
+                    tk.key[slot] = (int64_t)((in.keys[base + i] << 16) | (uint64_t)(g * in.k_in + i));
+                }
             }
         }
         __syncthreads();
@@ -2027,7 +2057,8 @@ __global__ __launch_bounds__(KW_THREADS) void kw_shard_merge_kernel(KwShardIn in
     }
     topk_sort<CAP, true>(tk);
     const uint32_t total = s_total < (uint32_t)CAP ? s_total : (uint32_t)CAP;
-    const uint32_t n_out = total < k ? total : k;
+    const uint32_t kq = in.cap_per_query && in.cap_per_query[q] < k ? in.cap_per_query[q] : k;
+    const uint32_t n_out = total < kq ? total : kq;
     const size_t ob = (size_t)q * out.k_stride;
     for (uint32_t i = t; i < n_out; i += KW_THREADS) {
         const uint64_t packed = (uint64_t)tk.key[i];
@@ -2035,13 +2066,29 @@ __global__ __launch_bounds__(KW_THREADS) void kw_shard_merge_kernel(KwShardIn in
         const size_t src = ((size_t)(origin / in.k_in) * in.n_queries + q) * in.k_in + origin % in.k_in;
         out.keys[ob + i] = packed >> 16;
         out.scores[(ob + i) * 3 + 0] = tk.s0[i]; out.scores[(ob + i) * 3 + 1] = tk.s1[i]; out.scores[(ob + i) * 3 + 2] = tk.s2[i];
+        if (in.packed) {
+            if (out.text_match) out.text_match[ob + i] = in.words > 4 ? (int64_t)in.packed[(origin / in.k_in) * in.shard_stride + ((size_t)q * in.k_in + origin % in.k_in) * in.words + 4] : 0;
+            if (out.vector_distance) out.vector_distance[ob + i] = -1.0f;
+            continue;
+        }
         if (out.text_match) out.text_match[ob + i] = in.text_match ? in.text_match[src] : 0;
         if (out.vector_distance) out.vector_distance[ob + i] = in.vector_distance ? in.vector_distance[src] : -1.0f;
         if (out.match_score_index) out.match_score_index[ob + i] = in.match_score_index ? in.match_score_index[src] : (int8_t)0;
     }
     if (t == 0) {
         out.n_hits[q] = n_out;
-        if (out.num_matched) {
+        if (in.packed) {
+            unsigned long long nm = 0;
+            int32_t st = 0;
+            for (uint32_t g = 0; g < in.n_shards; g++) {
+                const uint64_t* c = in.packed + g * in.shard_stride + (size_t)in.n_queries * in.k_in * in.words + (size_t)q * 3;
+                nm += c[1];
+                if (st == 0) st = (int32_t)(uint32_t)c[2];
+            }
+            if (out.num_matched) out.num_matched[q] = st == 0 ? nm : 0;
+            if (in.status_out) in.status_out[q] = st;
+            if (st != 0) out.n_hits[q] = 0;
+        } else if (out.num_matched) {
             unsigned long long nm = 0;
             if (in.num_matched) for (uint32_t g = 0; g < in.n_shards; g++) nm += in.num_matched[(size_t)g * in.n_queries + q];
             out.num_matched[q] = nm;

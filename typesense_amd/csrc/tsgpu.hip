@@ -1374,6 +1374,7 @@ int tsgpu_merge_shard_hits_device(tsgpu_ctx* ctx, const tsgpu_hits* gathered, ui
     in.keys = gathered->keys; in.scores = gathered->scores; in.text_match = gathered->text_match; in.vector_distance = gathered->vector_distance;
     in.match_score_index = gathered->match_score_index; in.n_hits = gathered->n_hits; in.num_matched = gathered->num_matched;
     in.n_shards = n_shards; in.n_queries = n_queries; in.k_in = gathered->k_stride;
+    in.packed = nullptr; in.shard_stride = 0; in.words = 0; in.status_out = nullptr; in.cap_per_query = nullptr;
     KwOut o;
     o.keys = out->keys; o.scores = out->scores; o.text_match = out->text_match; o.vector_distance = out->vector_distance;
     o.match_score_index = out->match_score_index; o.n_hits = out->n_hits; o.num_matched = out->num_matched; o.off_words = nullptr; o.k_stride = out->k_stride;
@@ -1602,3 +1603,42 @@ int tsgpu_last_timings(tsgpu_ctx* ctx, tsgpu_timings* out) {
 }
 
 }  // extern "C"
+
+// ---- tsgpu_group (tsgpu_group.hip): the device-side halves of the keyword exchange ----
+namespace tsgpu {
+int group_pack_keyword(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t k, uint32_t words, uint64_t* block, hipStream_t s) {
+    if (!loc || loc->mem != TSGPU_MEM_DEVICE || !loc->keys || !loc->scores || !loc->n_hits || k == 0 || k > loc->k_stride || (words != 4 && words != 5))
+        return fail(TSGPU_ERR_INVALID, "tsgpu_group: bad local result");
+    (void)hipSetDevice(ctx->device);
+    KwOut o;
+    o.keys = loc->keys; o.scores = loc->scores; o.text_match = loc->text_match; o.vector_distance = nullptr; o.match_score_index = nullptr;
+    o.n_hits = loc->n_hits; o.num_matched = loc->num_matched; o.off_words = nullptr; o.k_stride = loc->k_stride;
+    const uint64_t n = (uint64_t)n_q * k;
+    hipLaunchKernelGGL(kw_group_pack_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, o, (const int32_t*)loc->status, n_q, k, words, block);
+    TSGPU_HIP_TRY(hipGetLastError());
+    return TSGPU_OK;
+}
+void group_resolve_topster_sizes(const tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_q, uint32_t* caps) {
+    for (uint32_t i = 0; i < n_q; i++) caps[i] = resolve_topster_size(ctx, queries[i]);
+}
+int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard_stride_words, uint32_t n_shards, uint32_t n_q, uint32_t k, uint32_t words,
+                        const uint32_t* caps_dev, const tsgpu_hits* out, hipStream_t s) {
+    if (!out || out->mem != TSGPU_MEM_DEVICE || !out->keys || !out->scores || !out->n_hits || out->k_stride < k) return fail(TSGPU_ERR_INVALID, "tsgpu_group: bad output arrays");
+    const uint64_t cap_need = (uint64_t)n_shards * k;
+    if (cap_need > 4096) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group: members * k > 4096");
+    (void)hipSetDevice(ctx->device);
+    KwShardIn in;
+    memset(&in, 0, sizeof in);
+    in.n_shards = n_shards; in.n_queries = n_q; in.k_in = k;
+    in.packed = gathered; in.shard_stride = shard_stride_words; in.words = words; in.status_out = out->status; in.cap_per_query = caps_dev;
+    KwOut o;
+    o.keys = out->keys; o.scores = out->scores; o.text_match = out->text_match; o.vector_distance = out->vector_distance;
+    o.match_score_index = nullptr; o.n_hits = out->n_hits; o.num_matched = out->num_matched; o.off_words = nullptr; o.k_stride = out->k_stride;
+    if (cap_need <= 512) hipLaunchKernelGGL((kw_shard_merge_kernel<512>), dim3(n_q), dim3(KW_THREADS), 0, s, in, o, k);
+    else if (cap_need <= 1024) hipLaunchKernelGGL((kw_shard_merge_kernel<1024>), dim3(n_q), dim3(KW_THREADS), 0, s, in, o, k);
+    else if (cap_need <= 2048) hipLaunchKernelGGL((kw_shard_merge_kernel<2048>), dim3(n_q), dim3(KW_THREADS), 0, s, in, o, k);
+    else hipLaunchKernelGGL((kw_shard_merge_kernel<4096>), dim3(n_q), dim3(KW_THREADS), 0, s, in, o, k);
+    TSGPU_HIP_TRY(hipGetLastError());
+    return TSGPU_OK;
+}
+}  // namespace tsgpu

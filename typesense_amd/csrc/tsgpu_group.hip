@@ -1,0 +1,411 @@
+// tsgpu_group.hip — doc-range shards behind the C-ABI (BASELINE config 5): G contexts, one per GPU, each holding the
+// postings / sort columns / vectors of its seq_id range with GLOBAL seq_ids. A batch call scores the WHOLE batch on every member,
+// then ONE exchange of the per-member top-k per path (keyword: {key, scores[3](, text_match)} x k + {n_hits, num_matched, status}
+// per query; k-NN: one u64 {ord(dist), label} x k per query) and an exact merge in the reference's own order (Topster:
+// include/topster.h:146-149; k-NN: (distance, label) ascending). Hybrid fuses AFTER the merge: reciprocal ranks are global ranks
+// (src/index.cpp:4036-4221). The reference has no counterpart (it is a single-node index); what is kept is its result.
+//
+// Two forms:
+//   * tsgpu_group_create_local  — ONE process owns G contexts (how the C++ server would link it). Members run on G host threads.
+//   * tsgpu_group_create_rank   — one process per GPU (torch.distributed / MPI launchers, bench.py --gpus N): every rank passes its
+//                                 context and the 128-byte id rank 0 got from tsgpu_group_unique_id() (broadcast by the host's own channel).
+// Two transports (the exchange is the only thing that differs):
+//   * TSGPU_XCHG_RCCL — ncclAllGather on the members' streams (RCCL over xGMI). librccl.so.1 is resolved with dlopen when the first
+//                       RCCL group is created: the library itself has no link-time dependency on it (single-GPU servers, the test tiers).
+//   * TSGPU_XCHG_COPY — device-to-device copies into member 0's gather buffer (local form only; members may share one device: the
+//                       single-GPU rehearsal and the emulator tier).
+// No kernels here: the device-side halves are group_pack_* / group_merge_* (tsgpu.hip, tsgpu_vec.hip).
+#include <dlfcn.h>
+#include <thread>
+#include <chrono>
+#include "tsgpu_host.h"
+
+using namespace tsgpu;
+
+namespace {
+
+// the slice of RCCL's C ABI the exchange needs (rccl.h; values are ABI constants of NCCL 2.x)
+typedef void* xComm;
+struct xUniqueId { char internal[128]; };
+enum { X_NCCL_UINT8 = 1, X_NCCL_UINT64 = 5 };
+struct RcclApi {
+    void* h = nullptr;
+    int (*GetUniqueId)(xUniqueId*) = nullptr;
+    int (*CommInitRank)(xComm*, int, xUniqueId, int) = nullptr;
+    int (*CommInitAll)(xComm*, int, const int*) = nullptr;
+    int (*CommDestroy)(xComm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, xComm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+RcclApi* rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {getenv("TSGPU_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) { if (n && *n && (api.h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break; }
+        if (!api.h) { api.why = std::string("librccl.so.1 not found (") + (dlerror() ? dlerror() : "?") + ")"; return; }
+        auto sym = [&](const char* s) { void* p = dlsym(api.h, s); if (!p && api.why.empty()) api.why = std::string("RCCL symbol missing: ") + s; return p; };
+        api.GetUniqueId = (int (*)(xUniqueId*))sym("ncclGetUniqueId");
+        api.CommInitRank = (int (*)(xComm*, int, xUniqueId, int))sym("ncclCommInitRank");
+        api.CommInitAll = (int (*)(xComm*, int, const int*))sym("ncclCommInitAll");
+        api.CommDestroy = (int (*)(xComm))sym("ncclCommDestroy");
+        api.AllGather = (int (*)(const void*, void*, size_t, int, xComm, hipStream_t))sym("ncclAllGather");
+        api.GroupStart = (int (*)())sym("ncclGroupStart");
+        api.GroupEnd = (int (*)())sym("ncclGroupEnd");
+        api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+        if (!api.why.empty()) { dlclose(api.h); api.h = nullptr; }
+    });
+    return &api;
+}
+int rccl_fail(const char* what, int rc) {
+    RcclApi* r = rccl();
+    return fail(TSGPU_ERR_DEVICE, std::string("tsgpu_group: ") + what + ": " + (r->GetErrorString ? r->GetErrorString(rc) : "RCCL error"));
+}
+
+double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+
+struct Member {
+    tsgpu_ctx* ctx = nullptr;
+    xComm comm = nullptr;
+    DevBuf send, recv;                                   // exchange block of this member / the G gathered blocks
+    DevBuf l_keys, l_scores, l_tm, l_vd, l_msi, l_nh, l_nm, l_st, l_co;   // this member's local keyword result (device, stride KL)
+    DevBuf v_dist, v_lab, v_cnt, v_bad;                  // ... local k-NN result
+    DevBuf o_keys, o_scores, o_tm, o_nh, o_nm, o_st, o_vd, o_lab, o_cnt;   // merged result staged on the device (host outputs)
+    DevBuf caps;                                         // per-query Topster capacity (the merged list of a query never exceeds its own Topster)
+    std::vector<uint32_t> h_caps;
+    int rc = TSGPU_OK;
+    std::string err;
+};
+
+}  // namespace
+
+struct tsgpu_group {
+    int transport = TSGPU_XCHG_RCCL;
+    bool local = true;
+    uint32_t n = 1, rank = 0;            // members of the group; this process's member (rank form)
+    std::vector<Member> m;               // local form: all members; rank form: the one this process owns
+    std::mutex mu;                       // one batch at a time per group
+    tsgpu_group_timings tm{};
+};
+
+namespace {
+
+// run f(member index) for every member this process owns: member 0 on the calling thread, the others on their own threads
+// (each blocks in its context's batch call; every member sets its own device)
+template <class F> int for_members(tsgpu_group* g, F f) {
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < g->m.size(); i++) th.emplace_back([&, i] { g->m[i].rc = f(i); if (g->m[i].rc) g->m[i].err = tsgpu_last_error(); });
+    g->m[0].rc = f(0);
+    if (g->m[0].rc) g->m[0].err = tsgpu_last_error();
+    for (auto& t : th) t.join();
+    for (auto& mem : g->m) if (mem.rc) return fail(mem.rc, mem.err);
+    return TSGPU_OK;
+}
+
+// every owned member's block (bytes each) -> the gathered [n][bytes] in the recv buffer of every member (RCCL) / of member 0 (COPY)
+int exchange(tsgpu_group* g, size_t bytes) {
+    for (auto& mem : g->m) { int rc = mem.recv.reserve(bytes * g->n); if (rc) return rc; }
+    if (g->transport == TSGPU_XCHG_RCCL) {
+        RcclApi* r = rccl();
+        int rc;
+        if (g->m.size() > 1 && (rc = r->GroupStart())) return rccl_fail("ncclGroupStart", rc);
+        for (auto& mem : g->m) {
+            (void)hipSetDevice(mem.ctx->device);
+            if ((rc = r->AllGather(mem.send.p, mem.recv.p, bytes / 8, X_NCCL_UINT64, mem.comm, mem.ctx->stream))) { if (g->m.size() > 1) (void)r->GroupEnd(); return rccl_fail("ncclAllGather", rc); }
+        }
+        if (g->m.size() > 1 && (rc = r->GroupEnd())) return rccl_fail("ncclGroupEnd", rc);
+        return TSGPU_OK;
+    }
+    // COPY: the packs must have finished on their own streams, then member 0's stream pulls every block
+    for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
+    Member& root = g->m[0];
+    (void)hipSetDevice(root.ctx->device);
+    for (size_t j = 0; j < g->m.size(); j++) {
+        Member& src = g->m[j];
+        if (src.ctx->device == root.ctx->device) TSGPU_HIP_TRY(hipMemcpyAsync((char*)root.recv.p + j * bytes, src.send.p, bytes, hipMemcpyDeviceToDevice, root.ctx->stream));
+        else TSGPU_HIP_TRY(hipMemcpyPeerAsync((char*)root.recv.p + j * bytes, root.ctx->device, src.send.p, src.ctx->device, bytes, root.ctx->stream));
+    }
+    return TSGPU_OK;
+}
+
+uint32_t local_topster_stride(const tsgpu_kw_query* q, uint32_t n, uint32_t k) {
+    uint32_t ks = k;
+    for (uint32_t i = 0; i < n; i++) ks = std::max<uint32_t>(ks, q[i].topster_size ? std::min<uint32_t>(q[i].topster_size, TSGPU_MAX_TOPK) : TSGPU_DEFAULT_TOPSTER_SIZE);
+    return ks;
+}
+
+int copy_out(void* dst, const void* src, size_t bytes, int mem_out, hipStream_t s) {
+    if (!dst || !bytes) return TSGPU_OK;
+    TSGPU_HIP_TRY(hipMemcpyAsync(dst, src, bytes, mem_out == TSGPU_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+    return TSGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsgpu_group_unique_id(uint8_t id[128]) {
+    if (!id) return fail(TSGPU_ERR_INVALID, "tsgpu_group_unique_id: NULL argument");
+    RcclApi* r = rccl();
+    if (!r->h) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group: RCCL transport unavailable: " + r->why);
+    xUniqueId u;
+    int rc = r->GetUniqueId(&u);
+    if (rc) return rccl_fail("ncclGetUniqueId", rc);
+    memcpy(id, u.internal, 128);
+    return ok();
+}
+
+int tsgpu_group_create_local(tsgpu_ctx* const* members, uint32_t n_members, int transport, tsgpu_group** out) {
+    if (!members || !out || n_members == 0 || n_members > 64) return fail(TSGPU_ERR_INVALID, "tsgpu_group_create_local: bad arguments");
+    *out = nullptr;
+    for (uint32_t i = 0; i < n_members; i++) if (!members[i]) return fail(TSGPU_ERR_INVALID, "tsgpu_group_create_local: NULL member");
+    if (transport != TSGPU_XCHG_RCCL && transport != TSGPU_XCHG_COPY) return fail(TSGPU_ERR_INVALID, "tsgpu_group_create_local: unknown transport");
+    std::unique_ptr<tsgpu_group> g(new (std::nothrow) tsgpu_group);
+    if (!g) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_create_local: host allocation failed");
+    g->transport = transport; g->local = true; g->n = n_members; g->rank = 0;
+    g->m.resize(n_members);
+    for (uint32_t i = 0; i < n_members; i++) g->m[i].ctx = members[i];
+    if (transport == TSGPU_XCHG_RCCL) {
+        RcclApi* r = rccl();
+        if (!r->h) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group: RCCL transport unavailable: " + r->why);
+        std::vector<int> devs(n_members);
+        for (uint32_t i = 0; i < n_members; i++) {
+            devs[i] = members[i]->device;
+            for (uint32_t j = 0; j < i; j++) if (devs[j] == devs[i]) return fail(TSGPU_ERR_INVALID, "tsgpu_group_create_local: RCCL needs one GPU per member (use TSGPU_XCHG_COPY for members that share a device)");
+        }
+        std::vector<xComm> comms(n_members, nullptr);
+        int rc = r->CommInitAll(comms.data(), (int)n_members, devs.data());
+        if (rc) return rccl_fail("ncclCommInitAll", rc);
+        for (uint32_t i = 0; i < n_members; i++) g->m[i].comm = comms[i];
+    }
+    *out = g.release();
+    return ok();
+}
+
+int tsgpu_group_create_rank(tsgpu_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t n_ranks, tsgpu_group** out) {
+    if (!ctx || !id || !out || n_ranks == 0 || rank >= n_ranks) return fail(TSGPU_ERR_INVALID, "tsgpu_group_create_rank: bad arguments");
+    *out = nullptr;
+    RcclApi* r = rccl();
+    if (!r->h) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group: RCCL transport unavailable: " + r->why);
+    std::unique_ptr<tsgpu_group> g(new (std::nothrow) tsgpu_group);
+    if (!g) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_create_rank: host allocation failed");
+    g->transport = TSGPU_XCHG_RCCL; g->local = false; g->n = n_ranks; g->rank = rank;
+    g->m.resize(1);
+    g->m[0].ctx = ctx;
+    (void)hipSetDevice(ctx->device);
+    xUniqueId u;
+    memcpy(u.internal, id, 128);
+    int rc = r->CommInitRank(&g->m[0].comm, (int)n_ranks, u, (int)rank);
+    if (rc) return rccl_fail("ncclCommInitRank", rc);
+    *out = g.release();
+    return ok();
+}
+
+void tsgpu_group_destroy(tsgpu_group* g) {
+    if (!g) return;
+    for (auto& mem : g->m) {
+        (void)hipSetDevice(mem.ctx->device);
+        if (mem.comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(mem.comm);
+        DevBuf* b[] = {&mem.send, &mem.recv, &mem.l_keys, &mem.l_scores, &mem.l_tm, &mem.l_vd, &mem.l_msi, &mem.l_nh, &mem.l_nm, &mem.l_st, &mem.l_co, &mem.v_dist, &mem.v_lab, &mem.v_cnt, &mem.v_bad,
+                       &mem.o_keys, &mem.o_scores, &mem.o_tm, &mem.o_nh, &mem.o_nm, &mem.o_st, &mem.o_vd, &mem.o_lab, &mem.o_cnt, &mem.caps};
+        for (auto* x : b) x->release();
+    }
+    delete g;
+}
+
+uint32_t tsgpu_group_size(const tsgpu_group* g) { return g ? g->n : 0; }
+
+int tsgpu_group_last_timings(tsgpu_group* g, tsgpu_group_timings* out) {
+    if (!g || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_group_last_timings: NULL argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    *out = g->tm;
+    return ok();
+}
+
+// Keyword search of one batch over every shard: out (host, or device memory of member 0 / of this rank) receives the GLOBAL top-k per
+// query in Topster order: keys, scores, n_hits and — when the arrays are given — text_match, num_matched (= the sum over the shards),
+// status, search_cutoff (0 here: a shard's in-flight cutoff is reported through status 0 + its partial hits, as on one GPU).
+// k <= out->k_stride; every shard's Topster holds max(k, the queries' topster_size) entries, its first k travel.
+int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out) {
+    if (!g || !out || (n_queries && !queries)) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: NULL argument");
+    if (n_queries == 0) return ok();
+    if (k == 0 || k > out->k_stride || k > TSGPU_MAX_TOPK) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: k must be in 1..min(k_stride, 1024)");
+    if (!out->keys || !out->scores || !out->n_hits) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: missing output arrays");
+    if ((uint64_t)g->n * k > 4096) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_batch: members * k > 4096");
+    std::lock_guard<std::mutex> lk(g->mu);
+    try {
+        const uint32_t words = out->text_match ? 5 : 4;
+        const uint32_t KL = local_topster_stride(queries, n_queries, k);
+        const size_t block_words = group_kw_block_words(n_queries, k, words);
+        const auto t0 = std::chrono::steady_clock::now();
+        // 1) every member: its shard's Topster (device), packed into its exchange block
+        int rc = for_members(g, [&](size_t i) -> int {
+            Member& mem = g->m[i];
+            (void)hipSetDevice(mem.ctx->device);
+            int r;
+            const size_t slots = (size_t)n_queries * KL;
+            if ((r = mem.l_keys.reserve(slots * 8)) || (r = mem.l_scores.reserve(slots * 24)) || (r = mem.l_tm.reserve(slots * 8)) || (r = mem.l_vd.reserve(slots * 4)) || (r = mem.l_msi.reserve(slots)) || (r = mem.l_nh.reserve((size_t)n_queries * 4)) ||
+                (r = mem.l_nm.reserve((size_t)n_queries * 8)) || (r = mem.l_st.reserve((size_t)n_queries * 4)) || (r = mem.l_co.reserve((size_t)n_queries * 4)) ||
+                (r = mem.send.reserve(block_words * 8))) return r;
+            tsgpu_hits loc;
+            memset(&loc, 0, sizeof loc);
+            loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL;
+            loc.keys = mem.l_keys.as<uint64_t>(); loc.scores = mem.l_scores.as<int64_t>(); loc.text_match = mem.l_tm.as<int64_t>();
+            loc.vector_distance = mem.l_vd.as<float>(); loc.match_score_index = mem.l_msi.as<int8_t>();
+            loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>(); loc.search_cutoff = mem.l_co.as<int32_t>();
+            if ((r = tsgpu_keyword_search_batch(mem.ctx, queries, n_queries, &loc))) return r;
+            return group_pack_keyword(mem.ctx, &loc, n_queries, k, words, mem.send.as<uint64_t>(), mem.ctx->stream);
+        });
+        if (rc) return rc;
+        const double t_local = ms_since(t0);
+        // 2) ONE exchange, 3) exact merge on member 0 / this rank
+        const auto t1 = std::chrono::steady_clock::now();
+        if ((rc = exchange(g, block_words * 8))) return rc;
+        Member& root = g->m[0];
+        (void)hipSetDevice(root.ctx->device);
+        hipStream_t s = root.ctx->stream;
+        tsgpu_hits dev = *out;
+        if (out->mem == TSGPU_MEM_HOST) {
+            const size_t slots = (size_t)n_queries * out->k_stride;
+            if ((rc = root.o_keys.reserve(slots * 8)) || (rc = root.o_scores.reserve(slots * 24)) || (out->text_match && (rc = root.o_tm.reserve(slots * 8))) ||
+                (rc = root.o_nh.reserve((size_t)n_queries * 4)) || (rc = root.o_nm.reserve((size_t)n_queries * 8)) || (rc = root.o_st.reserve((size_t)n_queries * 4))) return rc;
+            dev.mem = TSGPU_MEM_DEVICE;
+            dev.keys = root.o_keys.as<uint64_t>(); dev.scores = root.o_scores.as<int64_t>(); dev.text_match = out->text_match ? root.o_tm.as<int64_t>() : nullptr;
+            dev.vector_distance = nullptr; dev.match_score_index = nullptr;
+            dev.n_hits = root.o_nh.as<uint32_t>(); dev.num_matched = root.o_nm.as<uint64_t>(); dev.status = root.o_st.as<int32_t>(); dev.search_cutoff = nullptr;
+        } else {
+            dev.vector_distance = nullptr; dev.match_score_index = nullptr;
+            if (!dev.status) { if ((rc = root.o_st.reserve((size_t)n_queries * 4))) return rc; dev.status = root.o_st.as<int32_t>(); }
+        }
+        root.h_caps.resize(n_queries);
+        group_resolve_topster_sizes(root.ctx, queries, n_queries, root.h_caps.data());
+        if ((rc = root.caps.reserve((size_t)n_queries * 4))) return rc;
+        TSGPU_HIP_TRY(hipMemcpyAsync(root.caps.p, root.h_caps.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, s));      // (h_caps outlives the call: it is a member field)
+        if ((rc = group_merge_keyword(root.ctx, root.recv.as<uint64_t>(), block_words, g->n, n_queries, k, words, root.caps.as<uint32_t>(), &dev, s))) return rc;
+        if (out->mem == TSGPU_MEM_HOST) {
+            const size_t slots = (size_t)n_queries * out->k_stride;
+            if ((rc = copy_out(out->keys, dev.keys, slots * 8, TSGPU_MEM_HOST, s)) || (rc = copy_out(out->scores, dev.scores, slots * 24, TSGPU_MEM_HOST, s)) ||
+                (rc = copy_out(out->text_match, dev.text_match, slots * 8, TSGPU_MEM_HOST, s)) || (rc = copy_out(out->n_hits, dev.n_hits, (size_t)n_queries * 4, TSGPU_MEM_HOST, s)) ||
+                (rc = copy_out(out->num_matched, dev.num_matched, (size_t)n_queries * 8, TSGPU_MEM_HOST, s)) || (rc = copy_out(out->status, dev.status, (size_t)n_queries * 4, TSGPU_MEM_HOST, s))) return rc;
+        }
+        if (out->search_cutoff) { if (out->mem == TSGPU_MEM_HOST) memset(out->search_cutoff, 0, (size_t)n_queries * 4); else TSGPU_HIP_TRY(hipMemsetAsync(out->search_cutoff, 0, (size_t)n_queries * 4, s)); }
+        if (out->match_score_index || out->vector_distance) {
+            // per-hit constants of a keyword pass: vector_distance = -1 (include/topster.h:29); match_score_index = position of _text_match among the sort keys
+            if (out->mem == TSGPU_MEM_HOST) {
+                for (uint32_t q = 0; q < n_queries; q++) {
+                    int8_t msi = -1;
+                    for (uint32_t j = 0; j < queries[q].n_sort && j < TSGPU_MAX_SORT_KEYS; j++) if (queries[q].sort[j].kind == TSGPU_SORT_TEXT_MATCH) { msi = (int8_t)j; break; }
+                    for (uint32_t i = 0; i < out->k_stride; i++) {
+                        if (out->match_score_index) out->match_score_index[(size_t)q * out->k_stride + i] = msi;
+                        if (out->vector_distance) out->vector_distance[(size_t)q * out->k_stride + i] = -1.0f;
+                    }
+                }
+            }
+        }
+        // the other members of an RCCL all-gather finish on their own streams; everything this call enqueued is awaited here
+        for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
+        g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1); g->tm.exchange_bytes_per_member = block_words * 8;
+        return ok();
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: host allocation failed"); }
+      catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: could not start a member thread"); }
+}
+
+// Exact k-NN of one batch over every shard (tsgpu_vec_knn_batch per member, then the exchange): closest first, ties -> smaller label.
+// Q: host memory, or device memory readable by every owned member (rank form / members sharing a device). allow_ids / excluded_ids
+// (sorted, GLOBAL seq_ids, host) restrict the whole batch like the VectorFilterFunctor. Labels must fit 32 bits (seq_ids do).
+int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float* Q, int mem_q, uint32_t n_queries, uint32_t k,
+                              const uint32_t* allow_ids, uint32_t n_allow, const uint32_t* excluded_ids, uint32_t n_excluded,
+                              float* dist_out, uint64_t* label_out, uint32_t* n_out, int mem_out) {
+    if (!g || !Q || !dist_out || !label_out || !n_out) return fail(TSGPU_ERR_INVALID, "tsgpu_group_vec_knn_batch: NULL argument");
+    if (n_queries == 0) return ok();
+    if (k == 0 || k > TSGPU_MAX_TOPK) return fail(TSGPU_ERR_INVALID, "tsgpu_group_vec_knn_batch: k must be in 1..1024");
+    if ((uint64_t)g->n * k > 8192) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_vec_knn_batch: members * k > 8192");
+    std::lock_guard<std::mutex> lk(g->mu);
+    try {
+        const size_t block_words = (size_t)n_queries * k;
+        const auto t0 = std::chrono::steady_clock::now();
+        int rc = for_members(g, [&](size_t i) -> int {
+            Member& mem = g->m[i];
+            (void)hipSetDevice(mem.ctx->device);
+            int r;
+            if ((r = mem.v_dist.reserve(block_words * 4)) || (r = mem.v_lab.reserve(block_words * 8)) || (r = mem.v_cnt.reserve((size_t)n_queries * 4)) || (r = mem.v_bad.reserve(64)) ||
+                (r = mem.send.reserve(block_words * 8))) return r;
+            if ((r = tsgpu_vec_knn_batch(mem.ctx, vec_field_id, Q, mem_q, n_queries, k, allow_ids, n_allow, excluded_ids, n_excluded,
+                                         mem.v_dist.as<float>(), mem.v_lab.as<uint64_t>(), mem.v_cnt.as<uint32_t>(), TSGPU_MEM_DEVICE))) return r;
+            TSGPU_HIP_TRY(hipMemsetAsync(mem.v_bad.p, 0, 4, mem.ctx->stream));
+            return group_pack_knn(mem.ctx, mem.v_dist.as<float>(), mem.v_lab.as<uint64_t>(), mem.v_cnt.as<uint32_t>(), n_queries, k, mem.send.as<uint64_t>(), mem.v_bad.as<uint32_t>(), mem.ctx->stream);
+        });
+        if (rc) return rc;
+        const double t_local = ms_since(t0);
+        const auto t1 = std::chrono::steady_clock::now();
+        if ((rc = exchange(g, block_words * 8))) return rc;
+        Member& root = g->m[0];
+        (void)hipSetDevice(root.ctx->device);
+        hipStream_t s = root.ctx->stream;
+        float* d_dist = dist_out; uint64_t* d_lab = label_out; uint32_t* d_cnt = n_out;
+        if (mem_out == TSGPU_MEM_HOST) {
+            if ((rc = root.o_vd.reserve(block_words * 4)) || (rc = root.o_lab.reserve(block_words * 8)) || (rc = root.o_cnt.reserve((size_t)n_queries * 4))) return rc;
+            d_dist = root.o_vd.as<float>(); d_lab = root.o_lab.as<uint64_t>(); d_cnt = root.o_cnt.as<uint32_t>();
+        }
+        if ((rc = group_merge_knn(root.ctx, root.recv.as<uint64_t>(), block_words, g->n, n_queries, k, d_dist, d_lab, d_cnt, s))) return rc;
+        if (mem_out == TSGPU_MEM_HOST) {
+            if ((rc = copy_out(dist_out, d_dist, block_words * 4, TSGPU_MEM_HOST, s)) || (rc = copy_out(label_out, d_lab, block_words * 8, TSGPU_MEM_HOST, s)) ||
+                (rc = copy_out(n_out, d_cnt, (size_t)n_queries * 4, TSGPU_MEM_HOST, s))) return rc;
+        }
+        uint32_t bad = 0;
+        for (auto& mem : g->m) {
+            (void)hipSetDevice(mem.ctx->device);
+            uint32_t b = 0;
+            TSGPU_HIP_TRY(hipMemcpyAsync(&b, mem.v_bad.p, 4, hipMemcpyDeviceToHost, mem.ctx->stream));
+            TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+            bad += b;
+        }
+        if (bad) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_vec_knn_batch: a label beyond 32 bits (the exchange carries seq_ids)");
+        g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1); g->tm.exchange_bytes_per_member = block_words * 8;
+        return ok();
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_vec_knn_batch: host allocation failed"); }
+      catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_vec_knn_batch: could not start a member thread"); }
+}
+
+// Hybrid search over the shards: the keyword Topsters (capacity = out->k_stride, with text_match) and the k nearest vectors are each
+// gathered and merged, THEN fused exactly as src/index.cpp:4036-4221 (tsgpu_hybrid_fuse_batch on member 0 / this rank): reciprocal
+// ranks are ranks in the GLOBAL lists. Host outputs, host or (see above) device queries; rerank_hybrid_matches is not sharded (501).
+int tsgpu_group_hybrid_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t vec_field_id, int metric, const tsgpu_hybrid_params* p,
+                                    const float* Q, int mem_q, uint32_t dim, uint32_t n_queries, tsgpu_hits* out) {
+    if (!g || !queries || !p || !Q || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_group_hybrid_search_batch: NULL argument");
+    if (out->mem != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_hybrid_search_batch: host outputs only");
+    if (p->rerank_hybrid_matches) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_hybrid_search_batch: rerank_hybrid_matches is not available on shards");
+    if (n_queries == 0) return ok();
+    const uint32_t k = p->k == 0 ? std::max<uint32_t>(p->fetch_size, 100) : p->k;                 // src/index.cpp:4060-4063
+    try {
+        const uint32_t KS = out->k_stride;
+        std::vector<uint64_t> keys((size_t)n_queries * KS), nm(n_queries);
+        std::vector<int64_t> scores((size_t)n_queries * KS * 3), tm((size_t)n_queries * KS);
+        std::vector<float> vd((size_t)n_queries * KS);
+        std::vector<int8_t> msi((size_t)n_queries * KS);
+        std::vector<uint32_t> nh(n_queries);
+        std::vector<int32_t> st(n_queries), co(n_queries);
+        tsgpu_hits kw;
+        kw.mem = TSGPU_MEM_HOST; kw.k_stride = KS;
+        kw.keys = keys.data(); kw.scores = scores.data(); kw.text_match = tm.data(); kw.vector_distance = vd.data();
+        kw.match_score_index = msi.data(); kw.n_hits = nh.data(); kw.num_matched = nm.data(); kw.status = st.data(); kw.search_cutoff = co.data();
+        int rc = tsgpu_group_keyword_search_batch(g, queries, n_queries, std::min<uint32_t>(KS, TSGPU_MAX_TOPK), &kw);
+        if (rc) return rc;
+        std::vector<float> kd((size_t)n_queries * k);
+        std::vector<uint64_t> kl((size_t)n_queries * k);
+        std::vector<uint32_t> kc(n_queries);
+        if ((rc = tsgpu_group_vec_knn_batch(g, vec_field_id, Q, mem_q, n_queries, k, nullptr, 0, nullptr, 0, kd.data(), kl.data(), kc.data(), TSGPU_MEM_HOST))) return rc;
+        for (uint32_t q = 0; q < n_queries; q++) {          // filter_by / hidden hits: that query's own exact k-NN over its allowed ids (VectorFilterFunctor)
+            if (st[q] != TSGPU_OK || (queries[q].n_excluded == 0 && queries[q].n_filter == 0)) continue;
+            if (mem_q != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_hybrid_search_batch: filtered queries need host-resident query vectors");
+            if ((rc = tsgpu_group_vec_knn_batch(g, vec_field_id, Q + (size_t)q * dim, mem_q, 1, k, queries[q].n_filter ? queries[q].filter_ids : nullptr, queries[q].n_filter,
+                                                queries[q].n_excluded ? queries[q].excluded_ids : nullptr, queries[q].n_excluded, kd.data() + (size_t)q * k, kl.data() + (size_t)q * k, kc.data() + q, TSGPU_MEM_HOST))) return rc;
+        }
+        return tsgpu_hybrid_fuse_batch(g->m[0].ctx, queries, p, metric, &kw, kd.data(), kl.data(), kc.data(), k, n_queries, out);
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_hybrid_search_batch: host allocation failed"); }
+}
+
+}  // extern "C"

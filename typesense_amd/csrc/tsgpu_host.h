@@ -391,3 +391,17 @@ struct tsgpu_ctx {
     tsgpu_timings timings{};
     bool scan_events_valid = false;                  // ev[6]/ev[7] bracket the main k-NN scan of the last batch's first query group
 };
+
+// ---- device-side halves of tsgpu_group's exchange (tsgpu_group.hip orchestrates; kernels: kw_kernels.hip.h / vec_kernels.hip.h).
+// All of them ENQUEUE on `s` and do not synchronise. A keyword exchange block = n_q * k * words + n_q * 3 u64 (KwShardIn::packed),
+// a k-NN block = n_q * k u64 (vec_group_pack_kernel).
+namespace tsgpu {
+inline size_t group_kw_block_words(uint32_t n_q, uint32_t k, uint32_t words) { return (size_t)n_q * k * words + (size_t)n_q * 3; }
+int group_pack_keyword(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t k, uint32_t words, uint64_t* block, hipStream_t s);
+int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard_stride_words, uint32_t n_shards, uint32_t n_q, uint32_t k, uint32_t words,
+                        const uint32_t* caps_dev, const tsgpu_hits* out_dev, hipStream_t s);
+void group_resolve_topster_sizes(const tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_q, uint32_t* caps_host);   // Topster capacity per query (src/index.cpp:3506-3512)
+int group_pack_knn(tsgpu_ctx* ctx, const float* dist_dev, const uint64_t* label_dev, const uint32_t* cnt_dev, uint32_t n_q, uint32_t k, uint64_t* block, uint32_t* bad_dev, hipStream_t s);
+int group_merge_knn(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard_stride_words, uint32_t n_shards, uint32_t n_q, uint32_t k,
+                    float* dist_dev, uint64_t* label_dev, uint32_t* cnt_dev, hipStream_t s);
+}

@@ -1252,3 +1252,26 @@ int tsgpu_merge_shard_hits(const tsgpu_hits* in, const uint64_t* key_offset, uin
 }
 
 }  // extern "C"
+
+// ---- tsgpu_group (tsgpu_group.hip): the device-side halves of the k-NN exchange ----
+namespace tsgpu {
+int group_pack_knn(tsgpu_ctx* ctx, const float* dist_dev, const uint64_t* label_dev, const uint32_t* cnt_dev, uint32_t n_q, uint32_t k, uint64_t* block, uint32_t* bad_dev, hipStream_t s) {
+    (void)hipSetDevice(ctx->device);
+    const uint64_t n = (uint64_t)n_q * k;
+    hipLaunchKernelGGL(vec_group_pack_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, dist_dev, label_dev, cnt_dev, n_q, k, block, bad_dev);
+    TSGPU_HIP_TRY(hipGetLastError());
+    return TSGPU_OK;
+}
+int group_merge_knn(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard_stride_words, uint32_t n_shards, uint32_t n_q, uint32_t k,
+                    float* dist_dev, uint64_t* label_dev, uint32_t* cnt_dev, hipStream_t s) {
+    const uint64_t need = (uint64_t)n_shards * k;
+    if (need > 8192) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group: members * k > 8192");
+    (void)hipSetDevice(ctx->device);
+    if (need <= 256) hipLaunchKernelGGL((vec_group_merge_kernel<256>), dim3(n_q), dim3(VEC_THREADS), 0, s, gathered, shard_stride_words, n_shards, n_q, k, dist_dev, label_dev, cnt_dev);
+    else if (need <= 1024) hipLaunchKernelGGL((vec_group_merge_kernel<1024>), dim3(n_q), dim3(VEC_THREADS), 0, s, gathered, shard_stride_words, n_shards, n_q, k, dist_dev, label_dev, cnt_dev);
+    else if (need <= 2048) hipLaunchKernelGGL((vec_group_merge_kernel<2048>), dim3(n_q), dim3(VEC_THREADS), 0, s, gathered, shard_stride_words, n_shards, n_q, k, dist_dev, label_dev, cnt_dev);
+    else hipLaunchKernelGGL((vec_group_merge_kernel<8192>), dim3(n_q), dim3(VEC_THREADS), 0, s, gathered, shard_stride_words, n_shards, n_q, k, dist_dev, label_dev, cnt_dev);
+    TSGPU_HIP_TRY(hipGetLastError());
+    return TSGPU_OK;
+}
+}  // namespace tsgpu

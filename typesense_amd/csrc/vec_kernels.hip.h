@@ -1135,6 +1135,63 @@ __global__ __launch_bounds__(VEC_THREADS) void vec_rescore_kernel(const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Doc-range shards (tsgpu_group): a member's k nearest of every query as ONE u64 per hit, ord(dist) << 32 | label
+// (labels are seq_ids: 32 bits; a larger label raises *bad) — ascending u64 order = (distance, label) ascending = the order
+// flat_knn / searchKnnCloserFirst results merge in. Unused slots = all ones.
+__global__ void vec_group_pack_kernel(const float* __restrict__ dist, const uint64_t* __restrict__ label, const uint32_t* __restrict__ cnt,
+                                      uint32_t n_q, uint32_t k, uint64_t* __restrict__ dst, uint32_t* bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t q = i / k, j = i - q * k;
+    if (q >= n_q) return;
+    uint64_t key = VEC_KEY_INF;
+    if (j < cnt[q]) {
+        const uint64_t l = label[(size_t)q * k + j];
+        if (l > 0xFFFFFFFFull) atomicAdd(bad, 1u);
+        key = ((uint64_t)f32_ord(dist[(size_t)q * k + j]) << 32) | (l & 0xFFFFFFFFull);
+    }
+    dst[(size_t)q * k + j] = key;
+}
+// exact merge of G gathered blocks ([shard][query][k] keys, shard_stride words apart): one workgroup per query, bitonic sort of the
+// G * k keys in LDS (CAP >= G * k, power of two), the k smallest come out closest first, ties -> smaller label
+template <int CAP>
+__global__ __launch_bounds__(VEC_THREADS) void vec_group_merge_kernel(const uint64_t* __restrict__ gathered, uint64_t shard_stride, uint32_t n_shards, uint32_t n_q, uint32_t k,
+                                                                       float* __restrict__ dist_out, uint64_t* __restrict__ label_out, uint32_t* __restrict__ cnt_out) {
+    __shared__ uint64_t keys[CAP];
+    const uint32_t t = threadIdx.x, q = blockIdx.x;
+    for (uint32_t i = t; i < (uint32_t)CAP; i += VEC_THREADS) {
+        const uint32_t g = i / k, j = i - g * k;
+        keys[i] = g < n_shards ? gathered[g * shard_stride + (size_t)q * k + j] : VEC_KEY_INF;
+    }
+    for (int size = 2; size <= CAP; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int p = t; p < CAP / 2; p += VEC_THREADS) {
+                const int i = 2 * p - (p & (stride - 1)), j = i + stride;
+                const bool up = (i & size) == 0;
+                const uint64_t a = keys[i], b = keys[j];
+                if ((a > b) == up) { keys[i] = b; keys[j] = a; }
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t n = 0;
+    for (uint32_t i = t; i < k; i += VEC_THREADS) {
+        const uint64_t key = keys[i];
+        const bool live = key != VEC_KEY_INF;
+        dist_out[(size_t)q * k + i] = live ? ord_f32((uint32_t)(key >> 32)) : 0.0f;
+        label_out[(size_t)q * k + i] = live ? (key & 0xFFFFFFFFull) : 0;
+        n += live ? 1u : 0u;
+    }
+    // count = number of live keys among the first k (they are sorted: live ones first)
+    __shared__ uint32_t s_n;
+    if (t == 0) s_n = 0;
+    __syncthreads();
+    if (n) atomicAdd(&s_n, n);
+    __syncthreads();
+    if (t == 0) cnt_out[q] = s_n;
+}
+
 // ================================================================================================
 // HNSW graph search: hnswlib::HierarchicalNSW<float>::searchKnnCloserFirst(q, k, ef, filter) of
 // the Typesense fork (call site src/index.cpp:3376-3445; VectorFilterFunctor include/index.h:325-354) on a MIRROR of the

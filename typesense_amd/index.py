@@ -433,3 +433,81 @@ class GpuIndex:
         self._ck(self.L.tsgpu_hybrid_fuse_batch(self.h, C.cast(arr, C.c_void_p), C.byref(p), metric, C.byref(ks), _vp(d), _vp(l), _vp(c),
                                                 d.shape[1], len(arr), C.byref(hs)))
         return hits
+
+
+class GpuGroup:
+    """tsgpu_group: doc-range shards behind the C-ABI (include/tsgpu.h "multi-GPU group"). Local form: GpuGroup(members=[GpuIndex, ...],
+    transport=B.XCHG_RCCL | B.XCHG_COPY); rank form (one process per GPU): GpuGroup.join(index, unique_id, rank, n_ranks)."""
+
+    def __init__(self, members=None, transport=B.XCHG_RCCL, _handle=None, _lib=None, _members=None):
+        if _handle is not None:
+            self.h, self.L, self.members = _handle, _lib, _members
+            return
+        self.members = list(members)
+        self.L = self.members[0].L
+        arr = (C.c_void_p * len(self.members))(*[m.h for m in self.members])
+        h = C.c_void_p()
+        B.check(self.L, self.L.tsgpu_group_create_local(C.cast(arr, C.c_void_p), len(self.members), transport, C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def unique_id(L):
+        buf = (C.c_uint8 * 128)()
+        B.check(L, L.tsgpu_group_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    @classmethod
+    def join(cls, index, unique_id, rank, n_ranks):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        B.check(index.L, index.L.tsgpu_group_create_rank(index.h, C.cast(buf, C.c_void_p), rank, n_ranks, C.byref(h)))
+        return cls(_handle=h, _lib=index.L, _members=[index])
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.tsgpu_group_destroy(self.h)
+            self.h = None
+
+    def size(self):
+        return int(self.L.tsgpu_group_size(self.h))
+
+    def keyword_search_batch(self, queries, k, k_stride=None):
+        arr = make_query_array(queries)
+        hits = Hits(len(arr), k_stride or k)
+        hs = hits.c_struct()
+        B.check(self.L, self.L.tsgpu_group_keyword_search_batch(self.h, C.cast(arr, C.c_void_p), len(arr), k, C.byref(hs)))
+        return hits
+
+    def keyword_search_batch_raw(self, arr, n, k, hs):
+        B.check(self.L, self.L.tsgpu_group_keyword_search_batch(self.h, C.cast(arr, C.c_void_p), n, k, C.byref(hs)))
+
+    def vec_knn_batch(self, field_id, Q, k, allow_ids=None, excluded_ids=None):
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        n = Q.shape[0]
+        dist = np.zeros((n, k), np.float32); lab = np.zeros((n, k), np.uint64); cnt = np.zeros(n, np.uint32)
+        a = None if allow_ids is None else _u32(allow_ids)
+        e = None if excluded_ids is None else _u32(excluded_ids)
+        B.check(self.L, self.L.tsgpu_group_vec_knn_batch(self.h, field_id, _vp(Q), B.MEM_HOST, n, k, _vp(a) if a is not None else None, a.size if a is not None else 0,
+                                                         _vp(e) if e is not None else None, e.size if e is not None else 0, _vp(dist), _vp(lab), _vp(cnt), B.MEM_HOST))
+        return dist, lab, cnt
+
+    def vec_knn_batch_raw(self, field_id, q_ptr, mem_q, n, k, dist_ptr, lab_ptr, cnt_ptr, mem_out):
+        B.check(self.L, self.L.tsgpu_group_vec_knn_batch(self.h, field_id, C.c_void_p(q_ptr), mem_q, n, k, None, 0, None, 0,
+                                                         C.c_void_p(dist_ptr), C.c_void_p(lab_ptr), C.c_void_p(cnt_ptr), mem_out))
+
+    def hybrid_search_batch(self, queries, field_id, metric, Q, k=0, fetch_size=10, alpha=0.3, distance_threshold=B.FLT_MAX, k_stride=250, mem_q=B.MEM_HOST, q_ptr=None, dim=None):
+        arr = make_query_array(queries)
+        p = B.HybridParamsC()
+        p.k, p.fetch_size, p.alpha, p.distance_threshold, p.rerank_hybrid_matches = k, fetch_size, alpha, distance_threshold, 0
+        hits = Hits(len(arr), k_stride)
+        hs = hits.c_struct()
+        if q_ptr is None:
+            Q = np.ascontiguousarray(Q, dtype=np.float32)
+            q_ptr, dim = Q.ctypes.data, Q.shape[1]
+        B.check(self.L, self.L.tsgpu_group_hybrid_search_batch(self.h, C.cast(arr, C.c_void_p), field_id, metric, C.byref(p), C.c_void_p(q_ptr), mem_q, dim, len(arr), C.byref(hs)))
+        return hits
+
+    def timings(self):
+        t = B.GroupTimingsC()
+        B.check(self.L, self.L.tsgpu_group_last_timings(self.h, C.byref(t)))
+        return t
