@@ -228,6 +228,9 @@ class Bench:
             name, val = o.split("=")
             self.g.set_option(name, int(val))
             self.opts[name] = int(val)
+        if world > 1 and "plan_threads" not in self.opts:
+            # N ranks share this node's host cores: a rank plans its batch on its share of them, not on the single-process default of 8 threads
+            self.g.set_option("plan_threads", max(1, min(8, int(cpu_quota_cpus() or os.cpu_count() or 8) // world)))
         self.n_docs = args.n_docs
         from typesense_amd import dist as D
         self.D = D
@@ -245,26 +248,35 @@ class Bench:
         self.group, self.exchange = None, "none (1 GPU)"
         if self.sharded:
             self.exchange = "torch.distributed all-gather + tsgpu merge kernels"
-            if os.environ.get("TSGPU_BENCH_EXCHANGE", "group") == "group" and os.environ.get("TSGPU_DIST_BACKEND", "nccl") == "nccl":
-                import torch.distributed as dist
-                ok = 1
-                try:
-                    uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-                    if rank == 0:
-                        uid.copy_(torch.frombuffer(bytearray(T.GpuGroup.unique_id(self.g.L)), dtype=torch.uint8))
-                    dist.broadcast(uid, 0)
-                    self.group = T.GpuGroup.join(self.g, bytes(uid.cpu().numpy().tobytes()), rank, world)
-                except Exception as e:      # noqa: BLE001 — reported, not hidden
-                    ok = 0
-                    sys.stderr.write("[bench] rank %d: tsgpu_group unavailable (%r): torch.distributed exchange instead\n" % (rank, e))
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) == 1:
-                    self.exchange = "tsgpu_group (C-ABI): RCCL ncclAllGather on the library's stream + kw_shard_merge / vec_group_merge kernels"
-                else:
-                    if self.group is not None:
-                        self.group.close()
-                    self.group = None
+            self.group = self.join_group(self.g)
+            if self.group is not None:
+                self.exchange = ("tsgpu_group (C-ABI): ncclAllToAll of query slices + slice merge (kw_shard_merge_kernel) + in-place ncclAllGather of the merged "
+                                 "lists, on the library's stream; k-NN: one ncclAllGather + vec_group_merge_kernel")
+
+    def join_group(self, index):
+        """tsgpu_group over this rank's context `index` (rank form): rank 0's ncclUniqueId travels through torch.distributed. Every rank must
+        succeed, else every rank falls back to the torch.distributed exchange (and the JSON line says which ran)."""
+        torch, T = self.torch, self.T
+        if os.environ.get("TSGPU_BENCH_EXCHANGE", "group") != "group" or os.environ.get("TSGPU_DIST_BACKEND", "nccl") != "nccl":
+            return None
+        import torch.distributed as dist
+        ok, grp = 1, None
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if self.rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(T.GpuGroup.unique_id(index.L)), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            grp = T.GpuGroup.join(index, bytes(uid.cpu().numpy().tobytes()), self.rank, self.world)
+        except Exception as e:      # noqa: BLE001 — reported, not hidden
+            ok = 0
+            sys.stderr.write("[bench] rank %d: tsgpu_group unavailable (%r): torch.distributed exchange instead\n" % (self.rank, e))
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            if grp is not None:
+                grp.close()
+            return None
+        return grp
 
     # ---------------------------------------------------------------- index builds (untimed)
     def build_keyword(self):
@@ -445,6 +457,28 @@ class Bench:
             res["replicas"] = {"value": world * n_q * args.steps / el_r, "unit": "queries/s", "ms_per_step": 1e3 * el_r / args.steps, "scaling": "weak",
                                "global_batch": world * n_q, "parallelism": "%d replicas of the collection, the global batch sharded across the GPUs, RCCL all-gather of "
                                                                            "the per-GPU top-100" % world}
+            if self.group is not None:
+                # third form, through the C-ABI: REPLICAS with the SAME 10 000-query batch cut into N query slices (strong scaling): rank r answers
+                # slice r on its full mirror (the twin), in-place ncclAllGathers of the slices' top-100; no merge, fixed costs shrink with the slice
+                grp_r = self.join_group(self.twin)
+                if grp_r is not None:
+                    grp_r.set_option("replicas", 1)
+                    rdev, rhs = device_hits(torch, n_q, FETCH_SIZE)
+
+                    def step_rs():
+                        grp_r.keyword_search_batch_raw(arr, n_q, FETCH_SIZE, rhs)
+                        return rdev
+                    el_s, _, o_s = timed(step_rs, args.steps, min(args.warmup, 2), world)
+                    nh = o_s["n_hits"].to(torch.int64)
+                    live = torch.arange(FETCH_SIZE, device="cuda")[None, :] < nh[:, None]
+                    same = bool(torch.equal(nh, out[2].to(torch.int64))) and bool(torch.equal(o_s["keys"][live], out[0][:, :FETCH_SIZE][live])) \
+                        and bool(torch.equal(o_s["scores"][live], out[1][:, :FETCH_SIZE][live])) and bool(torch.equal(o_s["num_matched"].to(torch.int64), out[3].to(torch.int64)))
+                    res["replicas_strong"] = {"value": n_q * args.steps / el_s, "unit": "queries/s", "ms_per_step": 1e3 * el_s / args.steps, "scaling": "strong",
+                                              "equals_the_shard_result": same,
+                                              "parallelism": "%d full mirrors of the collection, the SAME %d-query batch cut into %d query slices (tsgpu_group option replicas), "
+                                                             "in-place ncclAllGather of the slices' top-100" % (world, n_q, world)}
+                    grp_r.close()
+
 
         if world == 1:
             # the same batch with results delivered to HOST memory (pageable numpy arrays, tsgpu_hits mem=HOST): the PCIe-inclusive
@@ -1071,7 +1105,7 @@ def main():
                                   "note": "wave-instructions of the find kernel / (kernel cycles x 256 CUs x issue capacity per CU: 2 VALU, 1 SALU), counters from "
                                           "the committed --pmc pass (profiles/): the shared scalar unit is the busiest issue port"}
         kw["roofline"] = roof
-        for key in ("concurrency", "uncached", "shard_parity", "replicas", "exchange_check"):
+        for key in ("concurrency", "uncached", "shard_parity", "replicas", "replicas_strong", "exchange_check"):
             if key in r:
                 kw[key] = r[key]
         if "cpu" in r:
@@ -1154,7 +1188,7 @@ def main():
             "value": hd["value"], "unit": "queries/s", "n_gpus": world, "steps": hd["steps"], "warmup": args.warmup, "ms_per_step": hd["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32/i64" if head == "keyword" else "f32",
             "data": "synthetic", "config": hd["config"], "p50_ms_per_batch": hd["p50_ms_per_batch"]}
-    for k in ("queries_with_hits", "value_with_host_delivery", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "exchange_check", "replicas", "concurrency",
+    for k in ("queries_with_hits", "value_with_host_delivery", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "exchange_check", "replicas", "replicas_strong", "concurrency",
               "uncached", "fused_hits_per_batch", "parity_fp32_scan", "batch_sweep", "variants", "hnsw", "rerank_hybrid_matches"):
         if k in hd:
             line[k] = hd[k]

@@ -428,6 +428,14 @@ uint32_t tsgpu_group_size(const tsgpu_group* g);
  * text_match, n_hits, num_matched, status are filled). k <= out->k_stride, members * k <= 4096; num_matched = sum over the shards;
  * a query's list never exceeds its own Topster capacity (topster_size, src/index.cpp:3506-3512). */
 int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out);
+/* "kw_exchange_slices" = 1 (default): the keyword exchange is an ncclAllToAll of query slices (member j receives only the records of
+ * the 1/G of the batch it merges), a slice merge per member, and in-place ncclAllGathers of the merged lists (rank form / device outputs;
+ * the local form with host outputs delivers every slice over its own GPU's PCIe link); 0: ONE ncclAllGather of the per-GPU top-k
+ * blocks and a full merge. Identical results; at 8 GPUs and 10 000 queries 56 MB instead of 224 MB arrive per GPU. */
+/* "replicas" = 1: every member mirrors the WHOLE collection (small corpora: 10M documents = 6 GB of postings + 46 GB of vectors fit a
+ * 288 GB GPU several times); a batch is cut into G query slices, member i answers slice i, the slices are delivered / replicated as
+ * above — no merge, and the per-batch fixed costs (planning, launches) shrink with the slice. Default 0 = doc-range shards. */
+int tsgpu_group_set_option(tsgpu_group* g, const char* name, int64_t value);
 /* exact k-NN over all shards (tsgpu_vec_knn_batch per member + the exchange); labels must be seq_ids (< 2^32); members * k <= 8192 */
 int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float* Q, int mem_q, uint32_t n_queries, uint32_t k,
                               const uint32_t* allow_ids, uint32_t n_allow, const uint32_t* excluded_ids, uint32_t n_excluded,
@@ -439,7 +447,7 @@ int tsgpu_group_hybrid_search_batch(tsgpu_group* g, const tsgpu_kw_query* querie
 typedef struct tsgpu_group_timings {
     float local_ms;                      /* host wall: every member's own batch + pack (members run concurrently) */
     float exchange_merge_ms;             /* host wall: the exchange, the merge and the delivery of the merged result */
-    uint64_t exchange_bytes_per_member;  /* bytes one member contributes to the all-gather */
+    uint64_t exchange_bytes_per_member;  /* bytes one member RECEIVES from the others per call (all collectives of the call) */
 } tsgpu_group_timings;
 int tsgpu_group_last_timings(tsgpu_group* g, tsgpu_group_timings* out);
 

@@ -89,17 +89,69 @@ def check_group(orc, grp, rng, n_docs, dim):
         assert np.array_equal(fused.vector_distance[i, :n].view(np.uint32), ref.vector_distance.view(np.uint32)), i
 
 
-@pytest.mark.parametrize("cuts", [(0, 700, 1500), (0, 100, 1100, 1500), (0, 1500, 1500)])
-def test_group_over_copy_transport_equals_the_unsharded_oracle(cuts):
+def device_output_equals_host_output(grp, n_docs):
+    """`out` in device memory (of member 0): the merged slices are replicated there; same content as the host delivery"""
+    qs = [T.KwQuery(t, sort=SORT, topster_size=40) for t in ([1, 2], [3], [2, 5], [4, 9, 1], [6])]
+    host = grp.keyword_search_batch(qs, k=30, k_stride=32)
+    dev = T.Hits(len(qs), 32)
+    hs = dev.c_struct()
+    hs.mem = B.MEM_DEVICE                      # (the test tiers' "device" arrays: numpy memory on the emulator, hipMalloc'd memory below on the GPU)
+    import ctypes as C
+    L = grp.L
+    if "emu" not in grp.members[0].lib_path:
+        import torch
+        t = {name: torch.zeros(getattr(dev, name).shape, dtype=getattr(torch, str(getattr(dev, name).dtype).replace("uint64", "int64").replace("uint32", "int32")), device="cuda")
+             for name in ("keys", "scores", "text_match", "n_hits", "num_matched", "status")}
+        for name, v in t.items():
+            setattr(hs, name, v.data_ptr())
+        hs.vector_distance = hs.match_score_index = hs.search_cutoff = None
+        torch.cuda.synchronize()
+    arr = T.index.make_query_array(qs)
+    B.check(L, L.tsgpu_group_keyword_search_batch(grp.h, C.cast(arr, C.c_void_p), len(qs), 30, C.byref(hs)))
+    if "emu" not in grp.members[0].lib_path:
+        got = {name: v.cpu().numpy() for name, v in t.items()}
+    else:
+        got = {name: getattr(dev, name) for name in ("keys", "scores", "text_match", "n_hits", "num_matched", "status")}
+    for i in range(len(qs)):
+        n = int(host.n_hits[i])
+        assert int(got["n_hits"][i]) == n and int(got["num_matched"][i]) == int(host.num_matched[i]) and int(got["status"][i]) == 0
+        assert np.array_equal(got["keys"][i, :n].astype(np.uint64), host.keys[i, :n]) and np.array_equal(got["scores"][i, :n], host.scores[i, :n])
+        assert np.array_equal(got["text_match"][i, :n], host.text_match[i, :n])
+
+
+@pytest.mark.parametrize("cuts,slices", [((0, 700, 1500), 1), ((0, 100, 1100, 1500), 1), ((0, 1500, 1500), 1), ((0, 400, 900, 1500), 0)])
+def test_group_over_copy_transport_equals_the_unsharded_oracle(cuts, slices):
     orc, members, grp, rng = build_group(H.emu_lib_path(), cuts, 1500, 24, B.XCHG_COPY)
     try:
         assert grp.size() == len(cuts) - 1
+        grp.set_option("kw_exchange_slices", slices)
         check_group(orc, grp, rng, 1500, 24)
         t = grp.timings()
         assert t.exchange_bytes_per_member > 0
+        device_output_equals_host_output(grp, 1500)
     finally:
         grp.close()
         for g in members:
+            g.close()
+
+
+def test_replicas_form_cuts_the_batch_into_query_slices():
+    """option "replicas": every member mirrors the whole collection, member i answers the i-th slice of the batch; same results"""
+    lib = H.emu_lib_path()
+    n_docs, dim = 1200, 16
+    orc, members, grp, rng = build_group(lib, (0, n_docs), n_docs, dim, B.XCHG_COPY)       # one full mirror ...
+    grp.close()
+    orc2, more, grp2, _ = build_group(lib, (0, n_docs), n_docs, dim, B.XCHG_COPY)          # ... and a second one
+    grp2.close()
+    mirrors = members + more
+    grp = T.GpuGroup(mirrors + [mirrors[0]], B.XCHG_COPY)                                    # 3 replicas (two share a context: allowed)
+    try:
+        grp.set_option("replicas", 1)
+        check_group(orc, grp, rng, n_docs, dim)
+        device_output_equals_host_output(grp, n_docs)
+    finally:
+        grp.close()
+        for g in mirrors:
             g.close()
 
 
@@ -119,6 +171,9 @@ def test_group_argument_errors_are_reported_not_crashed():
 def test_group_on_one_mi355x_members_share_the_device():
     orc, members, grp, rng = build_group(H.gpu_lib_path(), (0, 9000, 20000, 30000), 30000, 64, B.XCHG_COPY, seed=5)
     try:
+        check_group(orc, grp, rng, 30000, 64)
+        device_output_equals_host_output(grp, 30000)
+        grp.set_option("kw_exchange_slices", 0)
         check_group(orc, grp, rng, 30000, 64)
     finally:
         grp.close()
@@ -141,11 +196,14 @@ def test_rccl_transport_one_rank_form_runs_the_real_collective():
     try:
         qs = [T.KwQuery(t, sort=SORT, topster_size=250) for t in ([1, 2], [3, 4, 5], [9], [150, 2])]
         plain = g.keyword_search_batch(qs, k_stride=250)
-        got = grp.keyword_search_batch(qs, k=100, k_stride=100)
-        for i in range(len(qs)):
-            n = min(100, int(plain.n_hits[i]))
-            assert int(got.n_hits[i]) == n and np.array_equal(got.keys[i, :n], plain.keys[i, :n]) and np.array_equal(got.scores[i, :n], plain.scores[i, :n])
-            assert int(got.num_matched[i]) == int(plain.num_matched[i])
+        for mode in (1, 2, 0):                # 2 = the slice form forced on one rank: ncclAllToAll + in-place ncclAllGather run for real
+            grp.set_option("kw_exchange_slices", mode)
+            got = grp.keyword_search_batch(qs, k=100, k_stride=100)
+            for i in range(len(qs)):
+                n = min(100, int(plain.n_hits[i]))
+                assert int(got.n_hits[i]) == n and np.array_equal(got.keys[i, :n], plain.keys[i, :n]) and np.array_equal(got.scores[i, :n], plain.scores[i, :n])
+                assert int(got.num_matched[i]) == int(plain.num_matched[i])
+        device_output_equals_host_output(grp, 20000)      # rank form + device outputs: the replication collectives
         Q = rng.standard_normal((6, 48)).astype(np.float32)
         d0, l0, c0 = g.vec_knn_batch(1, Q, 20)
         d1, l1, c1 = grp.vec_knn_batch(1, Q, 20)

@@ -2001,9 +2001,11 @@ struct KwShardIn {
     const uint64_t* keys; const int64_t* scores; const int64_t* text_match; const float* vector_distance; const int8_t* match_score_index;
     const uint32_t* n_hits; const uint64_t* num_matched;
     uint32_t n_shards, n_queries, k_in;
-    // PACKED form (tsgpu_group's exchange buffer, one all-gather per batch): shard g's block = [query][k_in][words] u64 {key, s0, s1, s2(, text_match)}
-    // followed by [query][3] u64 {n_hits, num_matched, status}; blocks are shard_stride words apart. packed == nullptr: the arrays above.
-    const uint64_t* packed; uint64_t shard_stride; uint32_t words;
+    // PACKED form (tsgpu_group's exchange buffer): shard g's block = per query k_in x words u64 {key, s0, s1, s2(, text_match)} followed by
+    // 3 u64 {n_hits, num_matched, status} — a query's record is contiguous (k_in * words + 3 words), so a RANGE of queries is one
+    // contiguous slice (the all-to-all form sends every rank only the queries it merges); blocks are shard_stride words apart; workgroup
+    // b reads record b of every block and writes query b + q_out_offset. packed == nullptr: the arrays above.
+    const uint64_t* packed; uint64_t shard_stride; uint32_t words; uint32_t q_out_offset;
     int32_t* status_out;           // (packed form) merged per-query status: the first non-zero status among the shards
     const uint32_t* cap_per_query; // nullable: the merged list of query q holds min(k, cap_per_query[q]) hits (its own Topster's capacity)
 };
@@ -2014,35 +2016,57 @@ __global__ void kw_group_pack_kernel(KwOut loc, const int32_t* status, uint32_t 
     if (q >= n_queries) return;
     const bool failed = status && status[q] != 0;              // a query that was not run may expose stale slots in device outputs
     const uint32_t n = failed ? 0u : (loc.n_hits[q] < k ? loc.n_hits[q] : k);
-    uint64_t* d = dst + ((size_t)q * k + j) * words;
+    const size_t qw = (size_t)k * words + 3;
+    uint64_t* d = dst + (size_t)q * qw + (size_t)j * words;
     const size_t src = (size_t)q * loc.k_stride + j;
     const bool live = j < n;
     d[0] = live ? loc.keys[src] : 0;
     d[1] = live ? (uint64_t)loc.scores[src * 3 + 0] : 0; d[2] = live ? (uint64_t)loc.scores[src * 3 + 1] : 0; d[3] = live ? (uint64_t)loc.scores[src * 3 + 2] : 0;
     if (words > 4) d[4] = live && loc.text_match ? (uint64_t)loc.text_match[src] : 0;
     if (j == 0) {
-        uint64_t* c = dst + (size_t)n_queries * k * words + (size_t)q * 3;
+        uint64_t* c = dst + (size_t)q * qw + (size_t)k * words;
         c[0] = n; c[1] = (loc.num_matched && !failed) ? loc.num_matched[q] : 0; c[2] = status ? (uint64_t)(uint32_t)status[q] : 0;
+    }
+}
+// replicas form of a group (every member mirrors the whole collection, the batch is cut into query slices): the member's own result for
+// its slice (stride loc.k_stride) -> rows [q_out_offset, ..) of the staged full-batch arrays (stride out.k_stride), truncated to k
+__global__ void kw_group_store_slice_kernel(KwOut loc, const int32_t* status, uint32_t n_queries, uint32_t q_out_offset, uint32_t k, KwOut out, int32_t* status_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t q = i / k, j = i - q * k;
+    if (q >= n_queries) return;
+    const bool failed = status && status[q] != 0;
+    const uint32_t n = failed ? 0u : (loc.n_hits[q] < k ? loc.n_hits[q] : k);
+    const size_t src = (size_t)q * loc.k_stride + j, dst = (size_t)(q + q_out_offset) * out.k_stride + j;
+    if (j < n) {
+        out.keys[dst] = loc.keys[src];
+        out.scores[dst * 3 + 0] = loc.scores[src * 3 + 0]; out.scores[dst * 3 + 1] = loc.scores[src * 3 + 1]; out.scores[dst * 3 + 2] = loc.scores[src * 3 + 2];
+        if (out.text_match) out.text_match[dst] = loc.text_match ? loc.text_match[src] : 0;
+    }
+    if (j == 0) {
+        out.n_hits[q + q_out_offset] = n;
+        if (out.num_matched) out.num_matched[q + q_out_offset] = (loc.num_matched && !failed) ? loc.num_matched[q] : 0;
+        if (status_out) status_out[q + q_out_offset] = status ? status[q] : 0;
     }
 }
 template <int CAP>
 __global__ __launch_bounds__(KW_THREADS) void kw_shard_merge_kernel(KwShardIn in, KwOut out, uint32_t k) {
     __shared__ TopkLds<CAP> tk;
     __shared__ uint32_t s_total;
-    const uint32_t t = threadIdx.x, q = blockIdx.x;
+    const uint32_t t = threadIdx.x, qi = blockIdx.x, q = in.packed ? blockIdx.x + in.q_out_offset : blockIdx.x;
+    const size_t qw = (size_t)in.k_in * in.words + 3;
     if (t == 0) s_total = 0;
     for (int i = t; i < CAP; i += KW_THREADS) tk.key[i] = -1;
     __syncthreads();
     for (uint32_t g = 0; g < in.n_shards; g++) {
-        const uint64_t* pk = in.packed ? in.packed + g * in.shard_stride : nullptr;
-        const uint32_t n = pk ? (uint32_t)pk[(size_t)in.n_queries * in.k_in * in.words + (size_t)q * 3] : in.n_hits[(size_t)g * in.n_queries + q];
+        const uint64_t* pk = in.packed ? in.packed + g * in.shard_stride + (size_t)qi * qw : nullptr;
+        const uint32_t n = pk ? (uint32_t)pk[(size_t)in.k_in * in.words] : in.n_hits[(size_t)g * in.n_queries + q];
         const size_t base = ((size_t)g * in.n_queries + q) * in.k_in;
         const uint32_t at = s_total;
         for (uint32_t i = t; i < n; i += KW_THREADS) {
             const uint32_t slot = at + i;
             if (slot < (uint32_t)CAP) {
                 if (pk) {
-                    const uint64_t* e = pk + ((size_t)q * in.k_in + i) * in.words;
+                    const uint64_t* e = pk + (size_t)i * in.words;
                     tk.s0[slot] = (int64_t)e[1]; tk.s1[slot] = (int64_t)e[2]; tk.s2[slot] = (int64_t)e[3];
                     tk.key[slot] = (int64_t)((e[0] << 16) | (uint64_t)(g * in.k_in + i));
                 } else {
@@ -2067,7 +2091,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_shard_merge_kernel(KwShardIn in
         out.keys[ob + i] = packed >> 16;
         out.scores[(ob + i) * 3 + 0] = tk.s0[i]; out.scores[(ob + i) * 3 + 1] = tk.s1[i]; out.scores[(ob + i) * 3 + 2] = tk.s2[i];
         if (in.packed) {
-            if (out.text_match) out.text_match[ob + i] = in.words > 4 ? (int64_t)in.packed[(origin / in.k_in) * in.shard_stride + ((size_t)q * in.k_in + origin % in.k_in) * in.words + 4] : 0;
+            if (out.text_match) out.text_match[ob + i] = in.words > 4 ? (int64_t)in.packed[(origin / in.k_in) * in.shard_stride + (size_t)qi * qw + (size_t)(origin % in.k_in) * in.words + 4] : 0;
             if (out.vector_distance) out.vector_distance[ob + i] = -1.0f;
             continue;
         }
@@ -2081,7 +2105,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_shard_merge_kernel(KwShardIn in
             unsigned long long nm = 0;
             int32_t st = 0;
             for (uint32_t g = 0; g < in.n_shards; g++) {
-                const uint64_t* c = in.packed + g * in.shard_stride + (size_t)in.n_queries * in.k_in * in.words + (size_t)q * 3;
+                const uint64_t* c = in.packed + g * in.shard_stride + (size_t)qi * qw + (size_t)in.k_in * in.words;
                 nm += c[1];
                 if (st == 0) st = (int32_t)(uint32_t)c[2];
             }

@@ -1374,7 +1374,7 @@ int tsgpu_merge_shard_hits_device(tsgpu_ctx* ctx, const tsgpu_hits* gathered, ui
     in.keys = gathered->keys; in.scores = gathered->scores; in.text_match = gathered->text_match; in.vector_distance = gathered->vector_distance;
     in.match_score_index = gathered->match_score_index; in.n_hits = gathered->n_hits; in.num_matched = gathered->num_matched;
     in.n_shards = n_shards; in.n_queries = n_queries; in.k_in = gathered->k_stride;
-    in.packed = nullptr; in.shard_stride = 0; in.words = 0; in.status_out = nullptr; in.cap_per_query = nullptr;
+    in.packed = nullptr; in.shard_stride = 0; in.words = 0; in.q_out_offset = 0; in.status_out = nullptr; in.cap_per_query = nullptr;
     KwOut o;
     o.keys = out->keys; o.scores = out->scores; o.text_match = out->text_match; o.vector_distance = out->vector_distance;
     o.match_score_index = out->match_score_index; o.n_hits = out->n_hits; o.num_matched = out->num_matched; o.off_words = nullptr; o.k_stride = out->k_stride;
@@ -1618,11 +1618,25 @@ int group_pack_keyword(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint
     TSGPU_HIP_TRY(hipGetLastError());
     return TSGPU_OK;
 }
+int group_store_keyword_slice(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t q_out_offset, uint32_t k, const tsgpu_hits* out, hipStream_t s) {
+    if (n_q == 0) return TSGPU_OK;
+    (void)hipSetDevice(ctx->device);
+    KwOut l, o;
+    l.keys = loc->keys; l.scores = loc->scores; l.text_match = loc->text_match; l.vector_distance = nullptr; l.match_score_index = nullptr;
+    l.n_hits = loc->n_hits; l.num_matched = loc->num_matched; l.off_words = nullptr; l.k_stride = loc->k_stride;
+    o.keys = out->keys; o.scores = out->scores; o.text_match = out->text_match; o.vector_distance = nullptr; o.match_score_index = nullptr;
+    o.n_hits = out->n_hits; o.num_matched = out->num_matched; o.off_words = nullptr; o.k_stride = out->k_stride;
+    const uint64_t n = (uint64_t)n_q * k;
+    hipLaunchKernelGGL(kw_group_store_slice_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, l, (const int32_t*)loc->status, n_q, q_out_offset, k, o, out->status);
+    TSGPU_HIP_TRY(hipGetLastError());
+    return TSGPU_OK;
+}
 void group_resolve_topster_sizes(const tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_q, uint32_t* caps) {
     for (uint32_t i = 0; i < n_q; i++) caps[i] = resolve_topster_size(ctx, queries[i]);
 }
-int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard_stride_words, uint32_t n_shards, uint32_t n_q, uint32_t k, uint32_t words,
+int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard_stride_words, uint32_t n_shards, uint32_t n_q, uint32_t q_out_offset, uint32_t k, uint32_t words,
                         const uint32_t* caps_dev, const tsgpu_hits* out, hipStream_t s) {
+    if (n_q == 0) return TSGPU_OK;
     if (!out || out->mem != TSGPU_MEM_DEVICE || !out->keys || !out->scores || !out->n_hits || out->k_stride < k) return fail(TSGPU_ERR_INVALID, "tsgpu_group: bad output arrays");
     const uint64_t cap_need = (uint64_t)n_shards * k;
     if (cap_need > 4096) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group: members * k > 4096");
@@ -1630,7 +1644,7 @@ int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard
     KwShardIn in;
     memset(&in, 0, sizeof in);
     in.n_shards = n_shards; in.n_queries = n_q; in.k_in = k;
-    in.packed = gathered; in.shard_stride = shard_stride_words; in.words = words; in.status_out = out->status; in.cap_per_query = caps_dev;
+    in.packed = gathered; in.shard_stride = shard_stride_words; in.words = words; in.q_out_offset = q_out_offset; in.status_out = out->status; in.cap_per_query = caps_dev;
     KwOut o;
     o.keys = out->keys; o.scores = out->scores; o.text_match = out->text_match; o.vector_distance = out->vector_distance;
     o.match_score_index = nullptr; o.n_hits = out->n_hits; o.num_matched = out->num_matched; o.off_words = nullptr; o.k_stride = out->k_stride;

@@ -35,6 +35,7 @@ struct RcclApi {
     int (*CommInitAll)(xComm*, int, const int*) = nullptr;
     int (*CommDestroy)(xComm) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, xComm, hipStream_t) = nullptr;
+    int (*AllToAll)(const void*, void*, size_t, int, xComm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -53,6 +54,7 @@ RcclApi* rccl() {
         api.CommInitAll = (int (*)(xComm*, int, const int*))sym("ncclCommInitAll");
         api.CommDestroy = (int (*)(xComm))sym("ncclCommDestroy");
         api.AllGather = (int (*)(const void*, void*, size_t, int, xComm, hipStream_t))sym("ncclAllGather");
+        api.AllToAll = (int (*)(const void*, void*, size_t, int, xComm, hipStream_t))sym("ncclAllToAll");
         api.GroupStart = (int (*)())sym("ncclGroupStart");
         api.GroupEnd = (int (*)())sym("ncclGroupEnd");
         api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
@@ -88,6 +90,8 @@ struct tsgpu_group {
     uint32_t n = 1, rank = 0;            // members of the group; this process's member (rank form)
     std::vector<Member> m;               // local form: all members; rank form: the one this process owns
     std::mutex mu;                       // one batch at a time per group
+    bool replicas = false;               // every member mirrors the WHOLE collection: the batch is cut into query slices (option "replicas")
+    int kw_slices = 1;                   // (2 = also with one member: exercises the collectives on a single GPU) keyword exchange: all-to-all of query slices + slice merge + all-gather of the merged lists (false: one all-gather, full merge on every rank)
     tsgpu_group_timings tm{};
 };
 
@@ -131,6 +135,55 @@ int exchange(tsgpu_group* g, size_t bytes) {
     return TSGPU_OK;
 }
 
+int copy_between(Member& dst, void* d, Member& src, const void* s_, size_t bytes) {
+    if (!bytes) return TSGPU_OK;
+    if (src.ctx->device == dst.ctx->device) TSGPU_HIP_TRY(hipMemcpyAsync(d, s_, bytes, hipMemcpyDeviceToDevice, dst.ctx->stream));
+    else TSGPU_HIP_TRY(hipMemcpyPeerAsync(d, dst.ctx->device, s_, src.ctx->device, bytes, dst.ctx->stream));
+    return TSGPU_OK;
+}
+
+// all-to-all: slice j (slice_bytes) of every member's send buffer -> member j's recv buffer, ordered by source member
+int exchange_slices(tsgpu_group* g, size_t slice_bytes) {
+    for (auto& mem : g->m) { int rc = mem.recv.reserve(slice_bytes * g->n); if (rc) return rc; }
+    if (g->transport == TSGPU_XCHG_RCCL) {
+        RcclApi* r = rccl();
+        int rc;
+        if (g->m.size() > 1 && (rc = r->GroupStart())) return rccl_fail("ncclGroupStart", rc);
+        for (auto& mem : g->m) {
+            (void)hipSetDevice(mem.ctx->device);
+            if ((rc = r->AllToAll(mem.send.p, mem.recv.p, slice_bytes / 8, X_NCCL_UINT64, mem.comm, mem.ctx->stream))) { if (g->m.size() > 1) (void)r->GroupEnd(); return rccl_fail("ncclAllToAll", rc); }
+        }
+        if (g->m.size() > 1 && (rc = r->GroupEnd())) return rccl_fail("ncclGroupEnd", rc);
+        return TSGPU_OK;
+    }
+    for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
+    for (size_t d = 0; d < g->m.size(); d++) {
+        (void)hipSetDevice(g->m[d].ctx->device);
+        for (size_t j = 0; j < g->m.size(); j++) { int rc = copy_between(g->m[d], (char*)g->m[d].recv.p + j * slice_bytes, g->m[j], (const char*)g->m[j].send.p + d * slice_bytes, slice_bytes); if (rc) return rc; }
+    }
+    return TSGPU_OK;
+}
+
+// every member holds its slice [i * per, (i + 1) * per) of `elem`-byte records in its own copy of an array: afterwards every member
+// (RCCL: in-place ncclAllGather) / member 0 (COPY) holds all slices
+int replicate_slices(tsgpu_group* g, const std::vector<void*>& arr /* per member */, size_t slice_bytes) {
+    if (g->transport == TSGPU_XCHG_RCCL) {
+        RcclApi* r = rccl();
+        for (size_t i = 0; i < g->m.size(); i++) {
+            Member& mem = g->m[i];
+            (void)hipSetDevice(mem.ctx->device);
+            const uint32_t rank = g->local ? (uint32_t)i : g->rank;
+            int rc = r->AllGather((const char*)arr[i] + (size_t)rank * slice_bytes, arr[i], slice_bytes, X_NCCL_UINT8, mem.comm, mem.ctx->stream);
+            if (rc) return rccl_fail("ncclAllGather (merged lists)", rc);
+        }
+        return TSGPU_OK;
+    }
+    Member& root = g->m[0];
+    (void)hipSetDevice(root.ctx->device);
+    for (size_t j = 1; j < g->m.size(); j++) { int rc = copy_between(root, (char*)arr[0] + j * slice_bytes, g->m[j], (const char*)arr[j] + j * slice_bytes, slice_bytes); if (rc) return rc; }
+    return TSGPU_OK;
+}
+
 uint32_t local_topster_stride(const tsgpu_kw_query* q, uint32_t n, uint32_t k) {
     uint32_t ks = k;
     for (uint32_t i = 0; i < n; i++) ks = std::max<uint32_t>(ks, q[i].topster_size ? std::min<uint32_t>(q[i].topster_size, TSGPU_MAX_TOPK) : TSGPU_DEFAULT_TOPSTER_SIZE);
@@ -141,6 +194,119 @@ int copy_out(void* dst, const void* src, size_t bytes, int mem_out, hipStream_t 
     if (!dst || !bytes) return TSGPU_OK;
     TSGPU_HIP_TRY(hipMemcpyAsync(dst, src, bytes, mem_out == TSGPU_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
     return TSGPU_OK;
+}
+
+
+struct KwArr { DevBuf Member::*buf; void* dst; size_t elem; };
+
+// merged / own slices are staged per member in full-batch arrays (n_pad queries, stride = the caller's k_stride); deliver them:
+// local form + host outputs: every member copies its own slice over its own PCIe link; otherwise the slices are replicated
+// (RCCL: in-place all-gathers, every rank ends with everything; COPY: into member 0) and copied out once
+int deliver_slices(tsgpu_group* g, const tsgpu_hits* out, uint32_t n_queries, uint32_t per, bool force = false) {
+    const size_t KS = out->k_stride;
+    const bool to_host = out->mem == TSGPU_MEM_HOST;
+    const KwArr arrs[] = {{&Member::o_keys, out->keys, KS * 8}, {&Member::o_scores, out->scores, KS * 24}, {&Member::o_tm, out->text_match, KS * 8},
+                          {&Member::o_nh, out->n_hits, 4}, {&Member::o_nm, out->num_matched, 8}, {&Member::o_st, out->status, 4}};
+    int rc;
+    if ((g->n > 1 || force) && !(g->local && to_host)) {
+        const bool grouped = g->transport == TSGPU_XCHG_RCCL && g->m.size() > 1;
+        if (grouped) { int r2 = rccl()->GroupStart(); if (r2) return rccl_fail("ncclGroupStart", r2); }
+        for (const KwArr& a : arrs) {
+            if (!a.dst) continue;
+            std::vector<void*> per_member;
+            for (auto& mem : g->m) per_member.push_back((mem.*(a.buf)).p);
+            if ((rc = replicate_slices(g, per_member, (size_t)per * a.elem))) { if (grouped) (void)rccl()->GroupEnd(); return rc; }
+        }
+        if (grouped) { int r2 = rccl()->GroupEnd(); if (r2) return rccl_fail("ncclGroupEnd", r2); }
+    }
+    if (g->n > 1 && g->local && to_host) {
+        for (size_t i = 0; i < g->m.size(); i++) {
+            Member& mem = g->m[i];
+            (void)hipSetDevice(mem.ctx->device);
+            const uint32_t q0 = (uint32_t)i * per;
+            if (q0 >= n_queries) break;
+            const uint32_t nq = std::min<uint32_t>(per, n_queries - q0);
+            for (const KwArr& a : arrs) if (a.dst)
+                if ((rc = copy_out((char*)a.dst + (size_t)q0 * a.elem, (const char*)(mem.*(a.buf)).p + (size_t)q0 * a.elem, (size_t)nq * a.elem, TSGPU_MEM_HOST, mem.ctx->stream))) return rc;
+        }
+    } else {
+        Member& root = g->m[0];
+        (void)hipSetDevice(root.ctx->device);
+        for (const KwArr& a : arrs) if (a.dst)
+            if ((rc = copy_out(a.dst, (root.*(a.buf)).p, (size_t)n_queries * a.elem, out->mem, root.ctx->stream))) return rc;
+    }
+    return TSGPU_OK;
+}
+
+void fill_keyword_constants(const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out) {
+    // per-hit constants of a keyword pass: vector_distance = -1 (include/topster.h:29); match_score_index = position of _text_match among the sort keys
+    if (out->mem != TSGPU_MEM_HOST || !(out->match_score_index || out->vector_distance)) return;
+    for (uint32_t q = 0; q < n_queries; q++) {
+        int8_t msi = -1;
+        for (uint32_t j = 0; j < queries[q].n_sort && j < TSGPU_MAX_SORT_KEYS; j++) if (queries[q].sort[j].kind == TSGPU_SORT_TEXT_MATCH) { msi = (int8_t)j; break; }
+        for (uint32_t i = 0; i < out->k_stride; i++) {
+            if (out->match_score_index) out->match_score_index[(size_t)q * out->k_stride + i] = msi;
+            if (out->vector_distance) out->vector_distance[(size_t)q * out->k_stride + i] = -1.0f;
+        }
+    }
+}
+
+tsgpu_hits staged_hits(Member& mem, const tsgpu_hits* out) {
+    tsgpu_hits d;
+    memset(&d, 0, sizeof d);
+    d.mem = TSGPU_MEM_DEVICE; d.k_stride = out->k_stride;
+    d.keys = mem.o_keys.as<uint64_t>(); d.scores = mem.o_scores.as<int64_t>(); d.text_match = out->text_match ? mem.o_tm.as<int64_t>() : nullptr;
+    d.n_hits = mem.o_nh.as<uint32_t>(); d.num_matched = mem.o_nm.as<uint64_t>(); d.status = mem.o_st.as<int32_t>();
+    return d;
+}
+
+int reserve_staging(Member& mem, const tsgpu_hits* out, uint32_t n_pad) {
+    int rc;
+    const size_t slots = (size_t)n_pad * out->k_stride;
+    (void)hipSetDevice(mem.ctx->device);
+    if ((rc = mem.o_keys.reserve(slots * 8)) || (rc = mem.o_scores.reserve(slots * 24)) || (out->text_match && (rc = mem.o_tm.reserve(slots * 8))) ||
+        (rc = mem.o_nh.reserve((size_t)n_pad * 4)) || (rc = mem.o_nm.reserve((size_t)n_pad * 8)) || (rc = mem.o_st.reserve((size_t)n_pad * 4)) || (rc = mem.caps.reserve((size_t)n_pad * 4))) return rc;
+    return TSGPU_OK;
+}
+
+// replicas form: member i answers queries [i * per, (i + 1) * per) of the batch on its own full mirror; the slices are then delivered /
+// replicated like merged slices. No merge: a member's Topster for a query IS the global one.
+int keyword_replicas(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out) {
+    const uint32_t per = (n_queries + g->n - 1) / g->n, n_pad = per * g->n;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = for_members(g, [&](size_t i) -> int {
+        Member& mem = g->m[i];
+        const uint32_t rank = g->local ? (uint32_t)i : g->rank;
+        const uint32_t q0 = rank * per, nq = q0 < n_queries ? std::min<uint32_t>(per, n_queries - q0) : 0;
+        int r;
+        if ((r = reserve_staging(mem, out, n_pad))) return r;
+        tsgpu_hits st = staged_hits(mem, out);
+        TSGPU_HIP_TRY(hipMemsetAsync(mem.o_nh.p, 0, (size_t)n_pad * 4, mem.ctx->stream));
+        TSGPU_HIP_TRY(hipMemsetAsync(mem.o_st.p, 0, (size_t)n_pad * 4, mem.ctx->stream));
+        if (nq == 0) return TSGPU_OK;
+        const uint32_t KL = local_topster_stride(queries + q0, nq, k);
+        const size_t slots = (size_t)nq * KL;
+        if ((r = mem.l_keys.reserve(slots * 8)) || (r = mem.l_scores.reserve(slots * 24)) || (r = mem.l_tm.reserve(slots * 8)) || (r = mem.l_vd.reserve(slots * 4)) || (r = mem.l_msi.reserve(slots)) ||
+            (r = mem.l_nh.reserve((size_t)nq * 4)) || (r = mem.l_nm.reserve((size_t)nq * 8)) || (r = mem.l_st.reserve((size_t)nq * 4)) || (r = mem.l_co.reserve((size_t)nq * 4))) return r;
+        tsgpu_hits loc;
+        memset(&loc, 0, sizeof loc);
+        loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL;
+        loc.keys = mem.l_keys.as<uint64_t>(); loc.scores = mem.l_scores.as<int64_t>(); loc.text_match = mem.l_tm.as<int64_t>();
+        loc.vector_distance = mem.l_vd.as<float>(); loc.match_score_index = mem.l_msi.as<int8_t>();
+        loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>(); loc.search_cutoff = mem.l_co.as<int32_t>();
+        if ((r = tsgpu_keyword_search_batch(mem.ctx, queries + q0, nq, &loc))) return r;
+        return group_store_keyword_slice(mem.ctx, &loc, nq, q0, k, &st, mem.ctx->stream);
+    });
+    if (rc) return rc;
+    const double t_local = ms_since(t0);
+    const auto t1 = std::chrono::steady_clock::now();
+    if ((rc = deliver_slices(g, out, n_queries, per))) return rc;
+    if (out->search_cutoff) { if (out->mem == TSGPU_MEM_HOST) memset(out->search_cutoff, 0, (size_t)n_queries * 4); else TSGPU_HIP_TRY(hipMemsetAsync(out->search_cutoff, 0, (size_t)n_queries * 4, g->m[0].ctx->stream)); }
+    fill_keyword_constants(queries, n_queries, out);
+    for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
+    g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1);
+    g->tm.exchange_bytes_per_member = (uint64_t)per * ((size_t)out->k_stride * (32 + (out->text_match ? 8 : 0)) + 16) * (g->n - 1);
+    return ok();
 }
 
 }  // namespace
@@ -229,6 +395,10 @@ int tsgpu_group_last_timings(tsgpu_group* g, tsgpu_group_timings* out) {
 // query in Topster order: keys, scores, n_hits and — when the arrays are given — text_match, num_matched (= the sum over the shards),
 // status, search_cutoff (0 here: a shard's in-flight cutoff is reported through status 0 + its partial hits, as on one GPU).
 // k <= out->k_stride; every shard's Topster holds max(k, the queries' topster_size) entries, its first k travel.
+// Exchange (option "kw_exchange_slices", default 1): ncclAllToAll — member j receives, from every member, only the records of the
+// queries it merges (a 1/G slice of the batch: (G-1)/G x one block per GPU on the wire instead of (G-1) blocks, and 1/G of the merge
+// per GPU) — then the merged slices are replicated with in-place ncclAllGathers (every rank ends with the whole result; the local form
+// delivers the slices straight to the caller). 0: ONE ncclAllGather of the blocks, every rank merges everything.
 int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out) {
     if (!g || !out || (n_queries && !queries)) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: NULL argument");
     if (n_queries == 0) return ok();
@@ -237,11 +407,16 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
     if ((uint64_t)g->n * k > 4096) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_batch: members * k > 4096");
     std::lock_guard<std::mutex> lk(g->mu);
     try {
+        if (g->replicas) return keyword_replicas(g, queries, n_queries, k, out);
         const uint32_t words = out->text_match ? 5 : 4;
         const uint32_t KL = local_topster_stride(queries, n_queries, k);
-        const size_t block_words = group_kw_block_words(n_queries, k, words);
+        const size_t qw = group_kw_record_words(k, words);
+        const bool slices = g->kw_slices == 2 || (g->kw_slices && g->n > 1);
+        const uint32_t per = slices ? (n_queries + g->n - 1) / g->n : n_queries;      // queries a member merges
+        const uint32_t n_pad = slices ? per * g->n : n_queries;
+        const size_t KS = out->k_stride;
         const auto t0 = std::chrono::steady_clock::now();
-        // 1) every member: its shard's Topster (device), packed into its exchange block
+        // 1) every member: its shard's Topster (device), packed into its exchange block (one contiguous record per query)
         int rc = for_members(g, [&](size_t i) -> int {
             Member& mem = g->m[i];
             (void)hipSetDevice(mem.ctx->device);
@@ -249,7 +424,7 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
             const size_t slots = (size_t)n_queries * KL;
             if ((r = mem.l_keys.reserve(slots * 8)) || (r = mem.l_scores.reserve(slots * 24)) || (r = mem.l_tm.reserve(slots * 8)) || (r = mem.l_vd.reserve(slots * 4)) || (r = mem.l_msi.reserve(slots)) || (r = mem.l_nh.reserve((size_t)n_queries * 4)) ||
                 (r = mem.l_nm.reserve((size_t)n_queries * 8)) || (r = mem.l_st.reserve((size_t)n_queries * 4)) || (r = mem.l_co.reserve((size_t)n_queries * 4)) ||
-                (r = mem.send.reserve(block_words * 8))) return r;
+                (r = mem.send.reserve((size_t)n_pad * qw * 8))) return r;
             tsgpu_hits loc;
             memset(&loc, 0, sizeof loc);
             loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL;
@@ -257,60 +432,55 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
             loc.vector_distance = mem.l_vd.as<float>(); loc.match_score_index = mem.l_msi.as<int8_t>();
             loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>(); loc.search_cutoff = mem.l_co.as<int32_t>();
             if ((r = tsgpu_keyword_search_batch(mem.ctx, queries, n_queries, &loc))) return r;
+            if (n_pad > n_queries) TSGPU_HIP_TRY(hipMemsetAsync(mem.send.as<uint64_t>() + (size_t)n_queries * qw, 0, (size_t)(n_pad - n_queries) * qw * 8, mem.ctx->stream));   // padding records: no hits
             return group_pack_keyword(mem.ctx, &loc, n_queries, k, words, mem.send.as<uint64_t>(), mem.ctx->stream);
         });
         if (rc) return rc;
         const double t_local = ms_since(t0);
-        // 2) ONE exchange, 3) exact merge on member 0 / this rank
         const auto t1 = std::chrono::steady_clock::now();
-        if ((rc = exchange(g, block_words * 8))) return rc;
-        Member& root = g->m[0];
-        (void)hipSetDevice(root.ctx->device);
-        hipStream_t s = root.ctx->stream;
-        tsgpu_hits dev = *out;
-        if (out->mem == TSGPU_MEM_HOST) {
-            const size_t slots = (size_t)n_queries * out->k_stride;
-            if ((rc = root.o_keys.reserve(slots * 8)) || (rc = root.o_scores.reserve(slots * 24)) || (out->text_match && (rc = root.o_tm.reserve(slots * 8))) ||
-                (rc = root.o_nh.reserve((size_t)n_queries * 4)) || (rc = root.o_nm.reserve((size_t)n_queries * 8)) || (rc = root.o_st.reserve((size_t)n_queries * 4))) return rc;
-            dev.mem = TSGPU_MEM_DEVICE;
-            dev.keys = root.o_keys.as<uint64_t>(); dev.scores = root.o_scores.as<int64_t>(); dev.text_match = out->text_match ? root.o_tm.as<int64_t>() : nullptr;
-            dev.vector_distance = nullptr; dev.match_score_index = nullptr;
-            dev.n_hits = root.o_nh.as<uint32_t>(); dev.num_matched = root.o_nm.as<uint64_t>(); dev.status = root.o_st.as<int32_t>(); dev.search_cutoff = nullptr;
-        } else {
-            dev.vector_distance = nullptr; dev.match_score_index = nullptr;
-            if (!dev.status) { if ((rc = root.o_st.reserve((size_t)n_queries * 4))) return rc; dev.status = root.o_st.as<int32_t>(); }
+        // 2) the exchange, 3) the exact merge, staged per member in arrays of n_pad queries (stride = the caller's k_stride)
+        const size_t mergers = slices ? g->m.size() : 1;
+        for (size_t i = 0; i < mergers; i++) if ((rc = reserve_staging(g->m[i], out, n_pad))) return rc;
+        g->m[0].h_caps.assign(n_pad, 0u);
+        group_resolve_topster_sizes(g->m[0].ctx, queries, n_queries, g->m[0].h_caps.data());
+        if ((rc = slices ? exchange_slices(g, (size_t)per * qw * 8) : exchange(g, (size_t)n_queries * qw * 8))) return rc;
+        for (size_t i = 0; i < mergers; i++) {
+            Member& mem = g->m[i];
+            (void)hipSetDevice(mem.ctx->device);
+            const uint32_t rank = g->local ? (uint32_t)i : g->rank;
+            const uint32_t q0 = slices ? rank * per : 0;
+            const uint32_t nq = slices ? (q0 < n_queries ? std::min<uint32_t>(per, n_queries - q0) : 0) : n_queries;
+            TSGPU_HIP_TRY(hipMemcpyAsync(mem.caps.p, g->m[0].h_caps.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, mem.ctx->stream));      // (h_caps is a member field: it outlives the copy)
+            tsgpu_hits d = staged_hits(mem, out);
+            if ((rc = group_merge_keyword(mem.ctx, mem.recv.as<uint64_t>(), slices ? (uint64_t)per * qw : (uint64_t)n_queries * qw, g->n, nq, q0, k, words, mem.caps.as<uint32_t>(), &d, mem.ctx->stream))) return rc;
         }
-        root.h_caps.resize(n_queries);
-        group_resolve_topster_sizes(root.ctx, queries, n_queries, root.h_caps.data());
-        if ((rc = root.caps.reserve((size_t)n_queries * 4))) return rc;
-        TSGPU_HIP_TRY(hipMemcpyAsync(root.caps.p, root.h_caps.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, s));      // (h_caps outlives the call: it is a member field)
-        if ((rc = group_merge_keyword(root.ctx, root.recv.as<uint64_t>(), block_words, g->n, n_queries, k, words, root.caps.as<uint32_t>(), &dev, s))) return rc;
-        if (out->mem == TSGPU_MEM_HOST) {
-            const size_t slots = (size_t)n_queries * out->k_stride;
-            if ((rc = copy_out(out->keys, dev.keys, slots * 8, TSGPU_MEM_HOST, s)) || (rc = copy_out(out->scores, dev.scores, slots * 24, TSGPU_MEM_HOST, s)) ||
-                (rc = copy_out(out->text_match, dev.text_match, slots * 8, TSGPU_MEM_HOST, s)) || (rc = copy_out(out->n_hits, dev.n_hits, (size_t)n_queries * 4, TSGPU_MEM_HOST, s)) ||
-                (rc = copy_out(out->num_matched, dev.num_matched, (size_t)n_queries * 8, TSGPU_MEM_HOST, s)) || (rc = copy_out(out->status, dev.status, (size_t)n_queries * 4, TSGPU_MEM_HOST, s))) return rc;
+        // 4) delivery
+        if (slices) { if ((rc = deliver_slices(g, out, n_queries, per, g->kw_slices == 2))) return rc; }
+        else {
+            Member& root = g->m[0];
+            (void)hipSetDevice(root.ctx->device);
+            const KwArr arrs[] = {{&Member::o_keys, out->keys, KS * 8}, {&Member::o_scores, out->scores, KS * 24}, {&Member::o_tm, out->text_match, KS * 8},
+                                  {&Member::o_nh, out->n_hits, 4}, {&Member::o_nm, out->num_matched, 8}, {&Member::o_st, out->status, 4}};
+            for (const KwArr& a : arrs) if (a.dst)
+                if ((rc = copy_out(a.dst, (root.*(a.buf)).p, (size_t)n_queries * a.elem, out->mem, root.ctx->stream))) return rc;
         }
-        if (out->search_cutoff) { if (out->mem == TSGPU_MEM_HOST) memset(out->search_cutoff, 0, (size_t)n_queries * 4); else TSGPU_HIP_TRY(hipMemsetAsync(out->search_cutoff, 0, (size_t)n_queries * 4, s)); }
-        if (out->match_score_index || out->vector_distance) {
-            // per-hit constants of a keyword pass: vector_distance = -1 (include/topster.h:29); match_score_index = position of _text_match among the sort keys
-            if (out->mem == TSGPU_MEM_HOST) {
-                for (uint32_t q = 0; q < n_queries; q++) {
-                    int8_t msi = -1;
-                    for (uint32_t j = 0; j < queries[q].n_sort && j < TSGPU_MAX_SORT_KEYS; j++) if (queries[q].sort[j].kind == TSGPU_SORT_TEXT_MATCH) { msi = (int8_t)j; break; }
-                    for (uint32_t i = 0; i < out->k_stride; i++) {
-                        if (out->match_score_index) out->match_score_index[(size_t)q * out->k_stride + i] = msi;
-                        if (out->vector_distance) out->vector_distance[(size_t)q * out->k_stride + i] = -1.0f;
-                    }
-                }
-            }
-        }
-        // the other members of an RCCL all-gather finish on their own streams; everything this call enqueued is awaited here
+        if (out->search_cutoff) { if (out->mem == TSGPU_MEM_HOST) memset(out->search_cutoff, 0, (size_t)n_queries * 4); else TSGPU_HIP_TRY(hipMemsetAsync(out->search_cutoff, 0, (size_t)n_queries * 4, g->m[0].ctx->stream)); }
+        fill_keyword_constants(queries, n_queries, out);
+        // everything this call enqueued on the members' streams is awaited here
         for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
-        g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1); g->tm.exchange_bytes_per_member = block_words * 8;
+        g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1);
+        g->tm.exchange_bytes_per_member = slices ? (uint64_t)per * qw * 8 * (g->n - 1) + (uint64_t)per * (KS * (32 + (out->text_match ? 8 : 0)) + 16) * (g->n - 1) : (uint64_t)n_queries * qw * 8 * (g->n - 1);
         return ok();
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: host allocation failed"); }
       catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: could not start a member thread"); }
+}
+
+int tsgpu_group_set_option(tsgpu_group* g, const char* name, int64_t value) {
+    if (!g || !name) return fail(TSGPU_ERR_INVALID, "tsgpu_group_set_option: NULL argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (!strcmp(name, "kw_exchange_slices")) { g->kw_slices = value == 2 ? 2 : (value != 0); return ok(); }
+    if (!strcmp(name, "replicas")) { g->replicas = value != 0; return ok(); }
+    return fail(TSGPU_ERR_NOT_FOUND, std::string("tsgpu_group_set_option: unknown option ") + name);
 }
 
 // Exact k-NN of one batch over every shard (tsgpu_vec_knn_batch per member, then the exchange): closest first, ties -> smaller label.
@@ -325,6 +495,59 @@ int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float
     if ((uint64_t)g->n * k > 8192) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_vec_knn_batch: members * k > 8192");
     std::lock_guard<std::mutex> lk(g->mu);
     try {
+        if (g->replicas) {
+            // every member mirrors the whole matrix: member i scans for queries [i * per, (i + 1) * per), the slices are replicated / delivered
+            uint32_t dim = 0;
+            int rc = group_vec_dim(g->m[0].ctx, vec_field_id, &dim);
+            if (rc) return rc;
+            const uint32_t per = (n_queries + g->n - 1) / g->n, n_pad = per * g->n;
+            const auto t0 = std::chrono::steady_clock::now();
+            rc = for_members(g, [&](size_t i) -> int {
+                Member& mem = g->m[i];
+                (void)hipSetDevice(mem.ctx->device);
+                const uint32_t rank = g->local ? (uint32_t)i : g->rank;
+                const uint32_t q0 = rank * per, nq = q0 < n_queries ? std::min<uint32_t>(per, n_queries - q0) : 0;
+                int r;
+                if ((r = mem.o_vd.reserve((size_t)n_pad * k * 4)) || (r = mem.o_lab.reserve((size_t)n_pad * k * 8)) || (r = mem.o_cnt.reserve((size_t)n_pad * 4))) return r;
+                TSGPU_HIP_TRY(hipMemsetAsync(mem.o_cnt.p, 0, (size_t)n_pad * 4, mem.ctx->stream));
+                TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+                if (nq == 0) return TSGPU_OK;
+                return tsgpu_vec_knn_batch(mem.ctx, vec_field_id, Q + (size_t)q0 * dim, mem_q, nq, k, allow_ids, n_allow, excluded_ids, n_excluded,
+                                           mem.o_vd.as<float>() + (size_t)q0 * k, mem.o_lab.as<uint64_t>() + (size_t)q0 * k, mem.o_cnt.as<uint32_t>() + q0, TSGPU_MEM_DEVICE);
+            });
+            if (rc) return rc;
+            const double t_local = ms_since(t0);
+            const auto t1 = std::chrono::steady_clock::now();
+            const KwArr arrs[] = {{&Member::o_vd, dist_out, (size_t)k * 4}, {&Member::o_lab, label_out, (size_t)k * 8}, {&Member::o_cnt, n_out, 4}};
+            const bool to_host = mem_out == TSGPU_MEM_HOST;
+            if (g->n > 1 && !(g->local && to_host)) {
+                const bool grouped = g->transport == TSGPU_XCHG_RCCL && g->m.size() > 1;
+                if (grouped) { int r2 = rccl()->GroupStart(); if (r2) return rccl_fail("ncclGroupStart", r2); }
+                for (const KwArr& a : arrs) {
+                    std::vector<void*> pm;
+                    for (auto& mem : g->m) pm.push_back((mem.*(a.buf)).p);
+                    if ((rc = replicate_slices(g, pm, (size_t)per * a.elem))) { if (grouped) (void)rccl()->GroupEnd(); return rc; }
+                }
+                if (grouped) { int r2 = rccl()->GroupEnd(); if (r2) return rccl_fail("ncclGroupEnd", r2); }
+            }
+            if (g->n > 1 && g->local && to_host) {
+                for (size_t i = 0; i < g->m.size(); i++) {
+                    Member& mem = g->m[i];
+                    (void)hipSetDevice(mem.ctx->device);
+                    const uint32_t q0 = (uint32_t)i * per;
+                    if (q0 >= n_queries) break;
+                    const uint32_t nq = std::min<uint32_t>(per, n_queries - q0);
+                    for (const KwArr& a : arrs) if ((rc = copy_out((char*)a.dst + (size_t)q0 * a.elem, (const char*)(mem.*(a.buf)).p + (size_t)q0 * a.elem, (size_t)nq * a.elem, TSGPU_MEM_HOST, mem.ctx->stream))) return rc;
+                }
+            } else {
+                Member& root = g->m[0];
+                (void)hipSetDevice(root.ctx->device);
+                for (const KwArr& a : arrs) if ((rc = copy_out(a.dst, (root.*(a.buf)).p, (size_t)n_queries * a.elem, mem_out, root.ctx->stream))) return rc;
+            }
+            for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
+            g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1); g->tm.exchange_bytes_per_member = (uint64_t)per * ((size_t)k * 12 + 4) * (g->n - 1);
+            return ok();
+        }
         const size_t block_words = (size_t)n_queries * k;
         const auto t0 = std::chrono::steady_clock::now();
         int rc = for_members(g, [&](size_t i) -> int {
@@ -364,7 +587,7 @@ int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float
             bad += b;
         }
         if (bad) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_vec_knn_batch: a label beyond 32 bits (the exchange carries seq_ids)");
-        g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1); g->tm.exchange_bytes_per_member = block_words * 8;
+        g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1); g->tm.exchange_bytes_per_member = block_words * 8 * (g->n - 1);
         return ok();
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_vec_knn_batch: host allocation failed"); }
       catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_vec_knn_batch: could not start a member thread"); }

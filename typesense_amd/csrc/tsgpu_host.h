@@ -393,13 +393,16 @@ struct tsgpu_ctx {
 };
 
 // ---- device-side halves of tsgpu_group's exchange (tsgpu_group.hip orchestrates; kernels: kw_kernels.hip.h / vec_kernels.hip.h).
-// All of them ENQUEUE on `s` and do not synchronise. A keyword exchange block = n_q * k * words + n_q * 3 u64 (KwShardIn::packed),
+// All of them ENQUEUE on `s` and do not synchronise. A keyword exchange block = n_q records of k * words + 3 u64 (KwShardIn::packed),
 // a k-NN block = n_q * k u64 (vec_group_pack_kernel).
 namespace tsgpu {
-inline size_t group_kw_block_words(uint32_t n_q, uint32_t k, uint32_t words) { return (size_t)n_q * k * words + (size_t)n_q * 3; }
+inline size_t group_kw_record_words(uint32_t k, uint32_t words) { return (size_t)k * words + 3; }
 int group_pack_keyword(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t k, uint32_t words, uint64_t* block, hipStream_t s);
-int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard_stride_words, uint32_t n_shards, uint32_t n_q, uint32_t k, uint32_t words,
+// merges records [0, n_q) of every gathered block into queries [q_out_offset, q_out_offset + n_q) of out_dev (caps_dev is indexed by OUTPUT query)
+int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard_stride_words, uint32_t n_shards, uint32_t n_q, uint32_t q_out_offset, uint32_t k, uint32_t words,
                         const uint32_t* caps_dev, const tsgpu_hits* out_dev, hipStream_t s);
+int group_store_keyword_slice(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t q_out_offset, uint32_t k, const tsgpu_hits* out_dev, hipStream_t s);   // replicas form
+int group_vec_dim(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t* dim);
 void group_resolve_topster_sizes(const tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_q, uint32_t* caps_host);   // Topster capacity per query (src/index.cpp:3506-3512)
 int group_pack_knn(tsgpu_ctx* ctx, const float* dist_dev, const uint64_t* label_dev, const uint32_t* cnt_dev, uint32_t n_q, uint32_t k, uint64_t* block, uint32_t* bad_dev, hipStream_t s);
 int group_merge_knn(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard_stride_words, uint32_t n_shards, uint32_t n_q, uint32_t k,

@@ -1255,6 +1255,13 @@ int tsgpu_merge_shard_hits(const tsgpu_hits* in, const uint64_t* key_offset, uin
 
 // ---- tsgpu_group (tsgpu_group.hip): the device-side halves of the k-NN exchange ----
 namespace tsgpu {
+int group_vec_dim(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t* dim) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    VecField* f = get_field(ctx, vec_field_id);
+    if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_group: unknown vector field");
+    *dim = f->dim;
+    return TSGPU_OK;
+}
 int group_pack_knn(tsgpu_ctx* ctx, const float* dist_dev, const uint64_t* label_dev, const uint32_t* cnt_dev, uint32_t n_q, uint32_t k, uint64_t* block, uint32_t* bad_dev, hipStream_t s) {
     (void)hipSetDevice(ctx->device);
     const uint64_t n = (uint64_t)n_q * k;

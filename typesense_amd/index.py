@@ -471,6 +471,9 @@ class GpuGroup:
     def size(self):
         return int(self.L.tsgpu_group_size(self.h))
 
+    def set_option(self, name, value):
+        B.check(self.L, self.L.tsgpu_group_set_option(self.h, name.encode(), int(value)))
+
     def keyword_search_batch(self, queries, k, k_stride=None):
         arr = make_query_array(queries)
         hits = Hits(len(arr), k_stride or k)
