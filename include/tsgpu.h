@@ -308,6 +308,33 @@ int tsgpu_facet_set(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint64_t* doc
 int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
                             uint32_t sample_mod, const uint32_t* allowed_hashes, uint32_t n_allowed, tsgpu_facet_counts* out);
 
+/* numeric facet stats of the same walk (should_compute_stats, src/index.cpp:1730-1741 -> compute_facet_stats :1430-1460): every
+ * (document, distinct hash) contributes its VALUE — the hash itself for int32 fields, its bits as a float for float fields, the
+ * fhash_int64_map entry (sorted int64_map_hashes -> int64_map_values; a missing hash = INT64_MAX) for int64 fields. min / max / count
+ * are exact; fvsum is exact (= the reference's double accumulation) for integer fields while count * max|value| < 2^53 (sum_exact),
+ * and for float fields equals the reference's in-order sum up to double rounding (sum_exact = 0). Untouched stats keep the
+ * reference's initial values (include/field.h:765-770). */
+#define TSGPU_FACET_INT32 0
+#define TSGPU_FACET_INT64 1
+#define TSGPU_FACET_FLOAT 2
+typedef struct tsgpu_facet_stats { double fvmin, fvmax, fvsum; uint64_t fvcount; int32_t sum_exact; int32_t pad; } tsgpu_facet_stats;
+int tsgpu_facet_stats_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, int value_type, const uint32_t* const* result_ids, const uint64_t* n_result_ids,
+                            uint32_t n_queries, uint32_t sample_mod, const uint32_t* int64_map_hashes, const int64_t* int64_map_values, uint32_t n_map,
+                            tsgpu_facet_stats* out);
+
+/* value-index branch of do_facets ("Using intersection to find facets", src/index.cpp:1596-1657 -> facet_index_t::intersect,
+ * src/facet_index.cpp:230-353). tsgpu_facet_value_set mirrors facet_index_v4's fvalue_seq_ids: value v owns the ascending seq_ids
+ * seq_ids[value_ptr[v] .. value_ptr[v+1]) and its total count; values are given in the reference's visiting order (counter_list:
+ * by count, ties as the multiset holds them). A count call visits the values in that order (or in `order`, a permutation: the
+ * alphabetical walks of sort_by _alpha), counts |ids(v) ∩ result_ids| exactly — or, with estimate_facets and more than 300 ids, with
+ * the reference's strided walk (src/id_list.cpp:725-766); is_wildcard_no_filter_query: the stored total — and returns the first
+ * max_facets values with a non-zero count: value_index / count / doc_id (= the value's first seq_id) [n_queries][cap], n_found. */
+typedef struct tsgpu_facet_value_counts { uint32_t cap; uint32_t* value_index; uint32_t* count; uint32_t* doc_id; uint32_t* n_found; } tsgpu_facet_value_counts;
+int tsgpu_facet_value_set(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint64_t* value_ptr, const uint32_t* seq_ids, const uint32_t* total_counts, uint32_t n_values);
+int tsgpu_facet_value_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
+                                  uint32_t max_facets, int is_wildcard_no_filter_query, int estimate_facets, uint32_t facet_sample_interval, const uint32_t* order,
+                                  tsgpu_facet_value_counts* out);
+
 /* ------------------------------------------------------------------ vector index (seam B2) */
 int tsgpu_vec_create(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t dim, int metric, uint64_t capacity_hint);
 /* addPoint: cosine fields are L2-normalised on insert like src/index.cpp:1049-1052. data: [n][dim] fp32. */

@@ -7,7 +7,10 @@
 // query only hashes in fquery_hashes are counted (:1742). The facet hash index itself (facet_index_v4: a posting list
 // seq_id -> value hashes, scalar fields one hash = offset(), array fields the offsets list) is held as a map here.
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <cstring>
+#include <limits>
 #include <map>
 #include <set>
 #include <vector>
@@ -18,6 +21,36 @@ struct facet_count_t { uint32_t count = 0; uint32_t doc_id = 0; uint32_t array_p
 
 struct FacetHashIndex {
     std::map<uint32_t, std::vector<uint32_t>> docs;           // seq_id -> hashes in field order (documents without a value are absent)
+
+    // should_compute_stats (src/index.cpp:1730-1741) + compute_facet_stats(a_facet, int64_t raw_value, type) (:1430-1460): the same walk,
+    // every (document, distinct hash) BEFORE the facet-query filter; value_type 0 = int32 (val = (int32) hash), 1 = int64 (fhash_int64_map,
+    // a missing hash -> INT64_MAX), 2 = float (the hash's bits). Sequential double accumulation in document order, as the reference.
+    struct stats_t { double fvmin = std::numeric_limits<double>::max(), fvmax = -std::numeric_limits<double>::max(), fvcount = 0, fvsum = 0; };   // include/field.h:765-770
+    stats_t stats(const uint32_t* result_ids, size_t results_size, size_t facet_sample_mod_value, int value_type,
+                  const std::map<uint32_t, int64_t>* fhash_int64_map) const {
+        stats_t st;
+        for (size_t i = 0; i < results_size; i++) {
+            if (facet_sample_mod_value > 1 && i % facet_sample_mod_value != 0) continue;
+            auto it = docs.lower_bound(result_ids[i]);
+            if (it == docs.end()) break;
+            if (it->first != result_ids[i]) continue;
+            const std::vector<uint32_t>& facet_hashes = it->second;
+            std::set<uint32_t> unique_facet_hashes;
+            for (size_t j = 0; j < facet_hashes.size(); j++) {
+                const uint32_t fhash = facet_hashes[j];
+                if (facet_hashes.size() > 1) {
+                    if (unique_facet_hashes.count(fhash) != 0) continue;
+                    unique_facet_hashes.insert(fhash);
+                }
+                int64_t val = fhash;                                   // (the reference widens the uint32 hash; the int32 branch truncates it again)
+                if (value_type == 1) { auto m = fhash_int64_map ? fhash_int64_map->find(fhash) : decltype(fhash_int64_map->find(fhash))(); val = (fhash_int64_map && m != fhash_int64_map->end()) ? m->second : INT64_MAX; }
+                if (value_type == 0) { int32_t v = (int32_t)val; if (v < st.fvmin) st.fvmin = v; if (v > st.fvmax) st.fvmax = v; st.fvsum += v; st.fvcount++; }
+                else if (value_type == 1) { int64_t v = val; if (v < st.fvmin) st.fvmin = v; if (v > st.fvmax) st.fvmax = v; st.fvsum += v; st.fvcount++; }
+                else { float v; uint32_t b = fhash; memcpy(&v, &b, 4); if (v < st.fvmin) st.fvmin = v; if (v > st.fvmax) st.fvmax = v; st.fvsum += v; st.fvcount++; }
+            }
+        }
+        return st;
+    }
 
     std::map<uint32_t, facet_count_t> count(const uint32_t* result_ids, size_t results_size, size_t facet_sample_mod_value,
                                              const std::set<uint32_t>* fquery_hashes) const {
@@ -45,6 +78,53 @@ struct FacetHashIndex {
             }
         }
         return result_map;
+    }
+};
+
+// Value-index branch ("Using intersection to find facets", src/index.cpp:1596-1657): facet_index_t::intersect (src/facet_index.cpp:230-353)
+// with ids_t::intersect_count (src/ids_t.cpp:148-169, 368-377; src/id_list.cpp:725-766). Values are held in the reference's visiting order
+// (counter_list); `order` = the alphabetical walks. docid_count_t = {first_id(ids), count}.
+struct FacetValueIndex {
+    std::vector<std::vector<uint32_t>> ids;                     // value -> ascending seq_ids
+    std::vector<uint32_t> total;                                // facet_count_it->count
+
+    static size_t intersect_count(const std::vector<uint32_t>& list, const uint32_t* res_ids, size_t res_ids_len, bool estimate_facets, size_t interval) {
+        size_t count = 0, res_index = 0, i = 0;
+        const bool compact = list.size() < 64;                  // ids_t::COMPACT_LIST_THRESHOLD_LENGTH: compact lists are never estimated
+        if (estimate_facets && !compact) {
+            while (i < list.size() && res_index < res_ids_len) {
+                if (list[i] == res_ids[res_index]) { count++; i += interval; res_index += interval; }
+                else if (list[i] < res_ids[res_index]) i += interval;
+                else res_index += interval;
+            }
+            count = count * interval * interval;
+        } else {
+            while (i < list.size() && res_index < res_ids_len) {
+                if (list[i] == res_ids[res_index]) { count++; i++; res_index++; }
+                else if (list[i] < res_ids[res_index]) i = std::lower_bound(list.begin() + i, list.end(), res_ids[res_index]) - list.begin();    // skip_to
+                else res_index = std::lower_bound(res_ids + res_index, res_ids + res_ids_len, list[i]) - res_ids;
+            }
+        }
+        return std::min<size_t>(list.size(), count);
+    }
+
+    struct found_t { uint32_t value, doc_id, count; };
+    std::vector<found_t> intersect(const uint32_t* result_ids, size_t results_size, size_t max_facets, bool is_wildcard_no_filter_query, bool estimate_facets,
+                                   size_t facet_sample_interval, const std::vector<uint32_t>* order) const {
+        std::vector<found_t> found;
+        if (results_size == 0) return found;                    // do_facets returns before any facet is looked at (:1531-1533)
+        for (size_t p = 0; p < ids.size(); p++) {
+            const uint32_t v = order ? (*order)[p] : (uint32_t)p;
+            uint32_t count;
+            if (is_wildcard_no_filter_query) count = total[v];
+            else {
+                const bool estimate_facet_count = estimate_facets && ids[v].size() > 300;
+                count = (uint32_t)intersect_count(ids[v], result_ids, results_size, estimate_facet_count, facet_sample_interval);
+            }
+            if (count) found.push_back({v, ids[v][0], count});
+            if (found.size() == max_facets) break;
+        }
+        return found;
     }
 };
 

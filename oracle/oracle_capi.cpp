@@ -378,6 +378,32 @@ uint32_t orc_facet_count(void* h, uint32_t field, const uint32_t* ids, uint64_t 
     return i;
 }
 
+// stats of the hash-index walk; out = {fvmin, fvmax, fvsum, fvcount}
+void orc_facet_stats(void* h, uint32_t field, const uint32_t* ids, uint64_t n_ids, uint32_t sample_mod, int32_t value_type, const uint32_t* map_hash, const int64_t* map_val,
+                     uint32_t n_map, double* out) {
+    const oracle::FacetHashIndex& f = facets_of()[{h, field}];
+    std::map<uint32_t, int64_t> m;
+    for (uint32_t i = 0; i < n_map; i++) m[map_hash[i]] = map_val[i];
+    const auto st = f.stats(ids, n_ids, sample_mod, value_type, &m);
+    out[0] = st.fvmin; out[1] = st.fvmax; out[2] = st.fvsum; out[3] = st.fvcount;
+}
+// ---- value-index branch ----
+static std::map<std::pair<void*, uint32_t>, oracle::FacetValueIndex>& facet_values_of() { static std::map<std::pair<void*, uint32_t>, oracle::FacetValueIndex> m; return m; }
+void orc_facet_value_set(void* h, uint32_t field, const uint64_t* value_ptr, const uint32_t* seq_ids, const uint32_t* total, uint32_t n_values) {
+    oracle::FacetValueIndex& f = facet_values_of()[{h, field}];
+    f.ids.assign(n_values, {}); f.total.assign(total, total + n_values);
+    for (uint32_t v = 0; v < n_values; v++) f.ids[v].assign(seq_ids + value_ptr[v], seq_ids + value_ptr[v + 1]);
+}
+uint32_t orc_facet_value_count(void* h, uint32_t field, const uint32_t* ids, uint64_t n_ids, uint32_t max_facets, int32_t wildcard_no_filter, int32_t estimate, uint32_t interval,
+                               const uint32_t* order, uint32_t* out_value, uint32_t* out_count, uint32_t* out_doc, uint32_t cap) {
+    const oracle::FacetValueIndex& f = facet_values_of()[{h, field}];
+    std::vector<uint32_t> ord;
+    if (order) ord.assign(order, order + f.ids.size());
+    const auto found = f.intersect(ids, n_ids, max_facets, wildcard_no_filter != 0, estimate != 0, interval, order ? &ord : nullptr);
+    for (size_t i = 0; i < found.size() && i < cap; i++) { out_value[i] = found[i].value; out_count[i] = found[i].count; out_doc[i] = found[i].doc_id; }
+    return (uint32_t)found.size();
+}
+
 // ---- CPU baseline drivers: one query per thread, like the reference server (thread-per-request) ----
 // tokens: [nq][n_tokens]; per_query_us: [nq] (nullable). Returns wall seconds for the whole batch.
 double orc_bench_keyword(void* h, const orc_kw_query* base, const uint32_t* tokens, uint32_t nq, uint32_t n_threads,

@@ -100,6 +100,12 @@ def lib():
         L.orc_facet_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_facet_count.restype = C.c_uint32
         L.orc_facet_count.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_facet_stats.restype = None
+        L.orc_facet_stats.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_facet_value_set.restype = None
+        L.orc_facet_value_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.orc_facet_value_count.restype = C.c_uint32
+        L.orc_facet_value_count.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.orc_bench_keyword.restype = C.c_double
         L.orc_bench_keyword.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
         L.orc_bench_vector.restype = C.c_double
@@ -335,6 +341,28 @@ class OracleIndex:
                                    a.size if a is not None else 0, _ptr(h), _ptr(c), _ptr(d), _ptr(p), cap)
         m = min(n, cap)
         return h[:m].copy(), c[:m].copy(), d[:m].copy(), p[:m].copy(), n
+
+    def facet_stats(self, field, ids, value_type, sample_mod=1, int64_map=None):
+        ids = _u32(ids)
+        mh = _u32(int64_map[0]) if int64_map is not None else None
+        mv = np.ascontiguousarray(int64_map[1], dtype=np.int64) if int64_map is not None else None
+        out = np.zeros(4, np.float64)
+        self.L.orc_facet_stats(self.h, field, ids.ctypes.data_as(C.c_void_p), ids.size, sample_mod, value_type, _ptr(mh) if mh is not None else None,
+                               _ptr(mv) if mv is not None else None, mh.size if mh is not None else 0, _ptr(out))
+        return float(out[0]), float(out[1]), float(out[2]), int(out[3])
+
+    def facet_value_set(self, field, value_ptr, seq_ids, total_counts):
+        vp = np.ascontiguousarray(value_ptr, dtype=np.uint64)
+        si, tc = _u32(seq_ids), _u32(total_counts)
+        self.L.orc_facet_value_set(self.h, field, _ptr(vp), si.ctypes.data_as(C.c_void_p), tc.ctypes.data_as(C.c_void_p), vp.size - 1)
+
+    def facet_value_count(self, field, ids, max_facets, wildcard_no_filter=False, estimate=False, sample_interval=1, order=None, cap=65536):
+        ids = _u32(ids)
+        o = _u32(order) if order is not None else None
+        v, c, d = (np.zeros(cap, np.uint32) for _ in range(3))
+        n = self.L.orc_facet_value_count(self.h, field, ids.ctypes.data_as(C.c_void_p), ids.size, int(max_facets), int(wildcard_no_filter), int(estimate), int(sample_interval),
+                                         _ptr(o) if o is not None else None, _ptr(v), _ptr(c), _ptr(d), cap)
+        return v[:n].copy(), c[:n].copy(), d[:n].copy()
 
     # ---- HNSW (oracle/hnsw_graph.h) ----
     def hnsw_build(self, M=16, ef_construction=200, seed=100):

@@ -29,6 +29,112 @@ def test_oracle_reproduces_reference_facet_counts():
         assert got[fx["values"][value]] == cnt, value
 
 
+def _csr(rows):
+    ptr = np.zeros(len(rows) + 1, np.uint64)
+    ptr[1:] = np.cumsum([len(r) for r in rows])
+    return ptr, np.array([x for r in rows for x in r], np.uint32)
+
+
+def test_oracle_reproduces_reference_facet_stats_and_value_index_counts():
+    """the reference's own numbers: numeric stats (collection_faceting_test.cpp:240-296) and the value-index counts
+    (collection_optimized_faceting_test.cpp:60-110) on test/numeric_array_documents.jsonl"""
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "facet_stats_values.json")))
+    ids = np.array(fx["result_ids"], np.uint32)
+    orc = O.OracleIndex(1, 1)
+    orc.facet_set(0, *_csr(fx["rating_bits"]))
+    mn, mx, sm, cnt = orc.facet_stats(0, ids, B.FACET_FLOAT)
+    e = fx["rating_expected"]
+    assert (mn, mx, sm, cnt) == (e["min"], e["max"], e["sum"], e["count"]) and sm / cnt == e["avg"]          # doubles, bit for bit
+    orc.facet_set(1, *_csr(fx["timestamps_hashes"]))
+    m = (np.array([h for h, _ in fx["timestamps_map"]], np.uint32), np.array([v for _, v in fx["timestamps_map"]], np.int64))
+    mn, mx, sm, cnt = orc.facet_stats(1, ids, B.FACET_INT64, int64_map=m)
+    e = fx["timestamps_expected"]
+    assert (mn, mx, sm, cnt) == (e["min"], e["max"], e["sum"], e["count"]) and sm / cnt == pytest.approx(e["avg"], rel=1e-7)   # (ASSERT_FLOAT_EQ in the reference)
+    vp, vi = _csr(fx["tags_value_ids"])
+    orc.facet_value_set(2, vp, vi, [len(r) for r in fx["tags_value_ids"]])
+    v, c, d = orc.facet_value_count(2, ids, max_facets=20)
+    assert [[fx["tags_values"][int(a)], int(b)] for a, b in zip(v, c)] == fx["tags_expected"]
+
+
+def _stats_and_values(lib, n_docs, n_values, seed=77):
+    """numeric stats of the hash-index walk and the value-index branch, product vs oracle (and vs the reference's fixture)"""
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "facet_stats_values.json")))
+    rng = np.random.default_rng(seed)
+    g = T.GpuIndex(0, lib)
+    orc = O.OracleIndex(1, 1)
+    try:
+        # -- the reference's documents --
+        ids5 = np.array(fx["result_ids"], np.uint32)
+        g.facet_set(0, *_csr(fx["rating_bits"]))
+        e = fx["rating_expected"]
+        mn, mx, sm, cnt, exact = g.facet_stats_batch(0, B.FACET_FLOAT, [ids5])[0]
+        assert (mn, mx, cnt) == (e["min"], e["max"], e["count"]) and abs(sm - e["sum"]) <= 1e-12 * abs(e["sum"]) and exact == 0
+        g.facet_set(1, *_csr(fx["timestamps_hashes"]))
+        m = (np.array([h for h, _ in fx["timestamps_map"]], np.uint32), np.array([v for _, v in fx["timestamps_map"]], np.int64))
+        e = fx["timestamps_expected"]
+        assert g.facet_stats_batch(1, B.FACET_INT64, [ids5], int64_map=m)[0] == (e["min"], e["max"], e["sum"], e["count"], 1)
+        vp, vi = _csr(fx["tags_value_ids"])
+        g.facet_value_set(2, vp, vi, [len(r) for r in fx["tags_value_ids"]])
+        v, c, d = g.facet_value_count_batch(2, [ids5], max_facets=20)[0]
+        assert [[fx["tags_values"][int(a)], int(b)] for a, b in zip(v, c)] == fx["tags_expected"] and d.tolist() == [0, 0, 2, 1]
+        # -- random collections vs the oracle --
+        lists = [np.sort(rng.choice(n_docs + 40, size=s, replace=False)).astype(np.uint32) for s in (1, 9, 400, min(n_docs, 4000))] + [np.zeros(0, np.uint32)]
+        for vt in (B.FACET_INT32, B.FACET_FLOAT, B.FACET_INT64):
+            per = rng.integers(0, 4, size=n_docs)
+            ptr = np.zeros(n_docs + 1, np.uint64); ptr[1:] = np.cumsum(per)
+            if vt == B.FACET_INT32:
+                hashes = rng.integers(-50000, 50000, size=int(ptr[-1])).astype(np.int32).view(np.uint32)
+                mp = None
+            elif vt == B.FACET_FLOAT:
+                hashes = (rng.standard_normal(int(ptr[-1])) * 100).astype(np.float32).view(np.uint32)
+                mp = None
+            else:
+                vals = rng.integers(-2**40, 2**40, size=n_values)
+                hs = np.unique(rng.integers(0, 2**32, size=n_values * 2, dtype=np.uint64).astype(np.uint32))[:n_values]
+                mp = (hs, vals[:hs.size].astype(np.int64))
+                hashes = hs[rng.integers(0, hs.size, size=int(ptr[-1]))]
+                hashes[::97] = 12345                                   # a hash absent from the map -> INT64_MAX
+            g.facet_set(3, ptr, hashes)
+            orc.facet_set(3, ptr, hashes)
+            for sample_mod in (1, 3):
+                got = g.facet_stats_batch(3, vt, lists, sample_mod=sample_mod, int64_map=mp)
+                for q, ids in enumerate(lists):
+                    mn, mx, sm, cnt = orc.facet_stats(3, ids, vt, sample_mod=sample_mod, int64_map=mp)
+                    assert got[q][0] == mn and got[q][1] == mx and got[q][3] == cnt, (vt, q)
+                    if vt == B.FACET_FLOAT:
+                        assert abs(got[q][2] - sm) <= 1e-12 * max(1.0, abs(sm)), (q, got[q][2], sm)       # order of the double additions differs
+                    elif got[q][4]:
+                        assert got[q][2] == sm, (vt, q)
+                    else:
+                        assert abs(got[q][2] - sm) <= 1e-9 * abs(sm)                                          # beyond 2^53: the reference's own sum is rounded
+        # value index: zipf-sized value lists incl. ones beyond 300 ids (the estimated walk) and shorter than 64 (compact: never estimated)
+        sizes = np.minimum((n_docs / np.arange(1, n_values + 1) ** 0.9).astype(np.int64) + 1, n_docs)
+        rows = [np.sort(rng.choice(n_docs, size=int(sz), replace=False)).astype(np.uint32) for sz in sizes]
+        vp = np.zeros(n_values + 1, np.uint64); vp[1:] = np.cumsum([r.size for r in rows])
+        vi = np.concatenate(rows)
+        tot = np.array([r.size for r in rows], np.uint32)
+        g.facet_value_set(4, vp, vi, tot)
+        orc.facet_value_set(4, vp, vi, tot)
+        alpha = rng.permutation(n_values).astype(np.uint32)
+        for kw in (dict(max_facets=10), dict(max_facets=2 * n_values), dict(max_facets=7, wildcard_no_filter=True), dict(max_facets=12, estimate=True, sample_interval=3),
+                   dict(max_facets=9, order=alpha), dict(max_facets=5, order=alpha[::-1].copy(), estimate=True, sample_interval=7)):
+            got = g.facet_value_count_batch(4, lists, cap=2 * n_values, **kw)
+            for q, ids in enumerate(lists):
+                v, c, d = orc.facet_value_count(4, ids, **kw)
+                assert np.array_equal(got[q][0], v) and np.array_equal(got[q][1], c) and np.array_equal(got[q][2], d), (kw, q)
+    finally:
+        g.close()
+
+
+def test_facet_stats_and_value_index_match_oracle_emulator():
+    _stats_and_values(H.emu_lib_path(), 2500, 60)
+
+
+@pytest.mark.gpu
+def test_facet_stats_and_value_index_match_oracle_gpu():
+    _stats_and_values(H.gpu_lib_path(), 300_000, 900)
+
+
 def _random_facet_index(rng, n_docs, n_values, array=True):
     per = rng.integers(0, 5, size=n_docs) if array else (rng.random(n_docs) < 0.9).astype(np.int64)
     ptr = np.zeros(n_docs + 1, np.uint64)

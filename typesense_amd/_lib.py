@@ -62,6 +62,17 @@ class TimingsC(C.Structure):
                 ("vec_scan_bytes", C.c_uint64), ("kw_find_ms", C.c_float)]
 
 
+class FacetStatsC(C.Structure):
+    _fields_ = [("fvmin", C.c_double), ("fvmax", C.c_double), ("fvsum", C.c_double), ("fvcount", C.c_uint64), ("sum_exact", C.c_int32), ("pad", C.c_int32)]
+
+
+class FacetValueCountsC(C.Structure):
+    _fields_ = [("cap", C.c_uint32), ("value_index", C.c_void_p), ("count", C.c_void_p), ("doc_id", C.c_void_p), ("n_found", C.c_void_p)]
+
+
+FACET_INT32, FACET_INT64, FACET_FLOAT = 0, 1, 2
+
+
 class GroupTimingsC(C.Structure):
     _fields_ = [("local_ms", C.c_float), ("exchange_merge_ms", C.c_float), ("exchange_bytes_per_member", C.c_uint64)]
 
@@ -72,7 +83,7 @@ EXPORTS = [
     "tsgpu_abi_version", "tsgpu_create", "tsgpu_destroy", "tsgpu_last_error", "tsgpu_set_stream", "tsgpu_set_option", "tsgpu_get_counter", "tsgpu_device_bytes",
     "tsgpu_field_create", "tsgpu_term_upsert", "tsgpu_posting_upsert", "tsgpu_posting_erase", "tsgpu_terms_load_csr", "tsgpu_column_set", "tsgpu_set_num_docs", "tsgpu_commit",
     "tsgpu_term_num_ids", "tsgpu_term_download", "tsgpu_keyword_search_batch", "tsgpu_wildcard_search_batch", "tsgpu_keyword_search_candidates_batch", "tsgpu_candidates_result_ids", "tsgpu_keep_result_ids", "tsgpu_result_ids",
-    "tsgpu_keyword_search_batch_ids", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free", "tsgpu_facet_set", "tsgpu_facet_count_batch",
+    "tsgpu_keyword_search_batch_ids", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free", "tsgpu_facet_set", "tsgpu_facet_count_batch", "tsgpu_facet_stats_batch", "tsgpu_facet_value_set", "tsgpu_facet_value_count_batch",
     "tsgpu_vec_create", "tsgpu_vec_upsert", "tsgpu_vec_delete", "tsgpu_vec_get", "tsgpu_vec_count", "tsgpu_vec_knn_batch",
     "tsgpu_vec_hnsw_load", "tsgpu_vec_hnsw_search_batch", "tsgpu_vec_distances", "tsgpu_ip_distance", "tsgpu_vector_search_batch", "tsgpu_hybrid_search_batch", "tsgpu_hybrid_fuse_batch", "tsgpu_keyword_aux_scores", "tsgpu_merge_shard_hits", "tsgpu_merge_shard_hits_device", "tsgpu_last_timings",
     "tsgpu_group_create_local", "tsgpu_group_unique_id", "tsgpu_group_create_rank", "tsgpu_group_destroy", "tsgpu_group_size", "tsgpu_group_keyword_search_batch",
@@ -159,6 +170,9 @@ def lib(path=None):
     L.tsgpu_merge_shard_hits.argtypes = [vp, vp, u32, u32, u32, C.POINTER(HitsC)]
     L.tsgpu_merge_shard_hits_device.argtypes = [vp, C.POINTER(HitsC), u32, u32, u32, C.POINTER(HitsC)]
     L.tsgpu_last_timings.argtypes = [vp, C.POINTER(TimingsC)]
+    L.tsgpu_facet_stats_batch.argtypes = [vp, u32, i32, vp, vp, u32, u32, vp, vp, u32, vp]
+    L.tsgpu_facet_value_set.argtypes = [vp, u32, vp, vp, vp, u32]
+    L.tsgpu_facet_value_count_batch.argtypes = [vp, u32, vp, vp, u32, u32, i32, i32, u32, vp, C.POINTER(FacetValueCountsC)]
     L.tsgpu_group_create_local.argtypes = [vp, u32, i32, vp]
     L.tsgpu_group_unique_id.argtypes = [vp]
     L.tsgpu_group_create_rank.argtypes = [vp, vp, u32, u32, vp]

@@ -98,4 +98,150 @@ __global__ __launch_bounds__(FACET_THREADS) void facet_compact_kernel(FacetArgs 
     if (threadIdx.x == 0) a.out_n[blockIdx.x] = s_n;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Numeric facet stats of the hash-index branch (should_compute_stats: src/index.cpp:1730-1741 -> compute_facet_stats :1430-1460):
+// every (document, DISTINCT hash) event of the walk above — before the facet-query filter — contributes its value to min / max / sum /
+// count. The hash IS the value for int32 (the integer) and float (its bits) fields; int64 fields go through fhash_int64_map (:1733-1738,
+// a missing hash counts as INT64_MAX). min / max / count are order-free; the sum is accumulated as an exact 64-bit integer (integer
+// types: equal to the reference's double accumulation whenever every partial sum is below 2^53 — reported as sum_exact) or with
+// double atomics (float: the reference adds in document order; a different order moves the last bits of the double only).
+struct FacetStatsDev { unsigned long long vmin, vmax, isum, count; double fsum; unsigned long long absmax; };   // vmin / vmax: order-preserving keys
+struct FacetStatsArgs {
+    const uint64_t* doc_ptr; const uint32_t* hashes; uint32_t n_docs;
+    const uint32_t* ids; const FacetQueryDev* queries; uint32_t n_queries; uint32_t sample_mod;
+    int value_type;                     // 0 int32, 1 int64, 2 float
+    const uint32_t* map_hash; const long long* map_val; uint32_t n_map;      // int64: sorted hashes -> values
+    FacetStatsDev* out;                 // [n_queries], vmin pre-set to all ones, the rest to zero
+};
+__device__ inline unsigned long long facet_i64_key(long long v) { return (unsigned long long)v ^ 0x8000000000000000ull; }
+__device__ inline unsigned long long facet_f32_key(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? (uint32_t)~b : (b | 0x80000000u); }
+__global__ __launch_bounds__(FACET_THREADS) void facet_stats_kernel(FacetStatsArgs a) {
+    __shared__ uint32_t s_q;
+    __shared__ unsigned long long s_min, s_max, s_isum, s_cnt, s_abs;
+    __shared__ double s_fsum;
+    if (threadIdx.x == 0) {
+        uint32_t lo = 0, hi = a.n_queries;
+        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (a.queries[mid].first_block <= blockIdx.x) lo = mid; else hi = mid; }
+        s_q = lo; s_min = ~0ull; s_max = 0; s_isum = 0; s_cnt = 0; s_abs = 0; s_fsum = 0.0;
+    }
+    __syncthreads();
+    const FacetQueryDev q = a.queries[s_q];
+    const uint64_t i = (uint64_t)(blockIdx.x - q.first_block) * FACET_THREADS + threadIdx.x;
+    unsigned long long mn = ~0ull, mx = 0, isum = 0, cnt = 0, amax = 0;
+    double fsum = 0.0;
+    if (i < q.n_ids && !(a.sample_mod > 1 && (i % a.sample_mod) != 0)) {
+        const uint32_t doc = a.ids[q.ids_off + i];
+        if (doc < a.n_docs) {
+            const uint64_t h0 = a.doc_ptr[doc], h1 = a.doc_ptr[doc + 1];
+            for (uint64_t j = h0; j < h1; j++) {
+                const uint32_t fh = a.hashes[j];
+                bool dup = false;
+                for (uint64_t p = h0; p < j && !dup; p++) dup = a.hashes[p] == fh;
+                if (dup) continue;
+                unsigned long long key;
+                if (a.value_type == 2) {
+                    const float v = __uint_as_float(fh);
+                    key = facet_f32_key(v);
+                    fsum += (double)v;
+                } else {
+                    long long v = (long long)(int32_t)fh;
+                    if (a.value_type == 1) {
+                        uint32_t lo = 0, hi = a.n_map;
+                        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a.map_hash[mid] < fh) lo = mid + 1; else hi = mid; }
+                        v = (lo < a.n_map && a.map_hash[lo] == fh) ? a.map_val[lo] : 0x7FFFFFFFFFFFFFFFll;
+                    }
+                    key = facet_i64_key(v);
+                    isum += (unsigned long long)v;
+                    fsum += (double)v;                                    // (used when the exact 64-bit sum cannot stand for the reference's double sum)
+                    const unsigned long long av = v < 0 ? (unsigned long long)(-(v + 1)) + 1ull : (unsigned long long)v;
+                    amax = av > amax ? av : amax;
+                }
+                mn = key < mn ? key : mn; mx = key > mx ? key : mx;
+                cnt++;
+            }
+        }
+    }
+    if (cnt) {
+        atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_isum, isum); atomicAdd(&s_cnt, cnt); atomicMax(&s_abs, amax);
+        atomicAdd(&s_fsum, fsum);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) {
+        FacetStatsDev* o = a.out + s_q;
+        atomicMin(&o->vmin, s_min); atomicMax(&o->vmax, s_max); atomicAdd(&o->isum, s_isum); atomicAdd(&o->count, s_cnt); atomicMax(&o->absmax, s_abs);
+        atomicAdd(&o->fsum, s_fsum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Value-index branch of Index::do_facets ("Using intersection to find facets", src/index.cpp:1596-1657 -> facet_index_t::intersect,
+// src/facet_index.cpp:230-353): the field's values are visited in a fixed order (counter_list = by total count, or alphabetical);
+// a value's count = |its seq_id list ∩ result_ids| (ids_t::intersect_count; with estimate_facets and more than 300 ids the strided
+// walk of id_list_t::intersect_count, src/id_list.cpp:725-766), and the walk stops once max_facets values with a non-zero count have
+// been found. Here: one wavefront per (value, query) computes every count at once, then one wavefront per query picks, in visiting
+// order, the first max_facets values whose count is non-zero.
+struct FacetValueArgs {
+    const uint64_t* val_ptr; const uint32_t* val_ids; const uint32_t* val_total; uint32_t n_values;   // value v: val_ids[val_ptr[v] .. val_ptr[v+1]) ascending
+    const uint32_t* ids; const FacetQueryDev* queries; uint32_t n_queries;                              // (ids_off, n_ids used)
+    const uint32_t* order;              // nullable: visiting order (a permutation of the values)
+    uint32_t max_facets; int wildcard_no_filter; int estimate; uint32_t interval;
+    uint32_t* counts;                   // [n_queries][n_values]
+    uint32_t cap; uint32_t* out_value; uint32_t* out_count; uint32_t* out_doc; uint32_t* out_n;        // [n_queries][cap], [n_queries]
+};
+__global__ __launch_bounds__(64) void facet_value_count_kernel(FacetValueArgs a) {
+    const uint32_t v = blockIdx.x, qi = blockIdx.y, lane = threadIdx.x;
+    const FacetQueryDev q = a.queries[qi];
+    const uint64_t v0 = a.val_ptr[v], nv = a.val_ptr[v + 1] - v0;
+    const uint32_t* __restrict__ A = a.val_ids + v0;
+    const uint32_t* __restrict__ R = a.ids + q.ids_off;
+    const uint64_t nr = q.n_ids;
+    uint32_t count = 0;
+    if (a.wildcard_no_filter) {
+        count = a.val_total[v];                                             // :305-306
+    } else if (a.estimate && nv > 300) {
+        if (lane == 0) {                                                    // the reference's strided walk, step by step
+            uint64_t i = 0, r = 0, c = 0;
+            while (i < nv && r < nr) {
+                const uint32_t x = A[i], y = R[r];
+                if (x == y) { c++; i += a.interval; r += a.interval; }
+                else if (x < y) i += a.interval;
+                else r += a.interval;
+            }
+            c = c * a.interval * a.interval;
+            count = (uint32_t)(c < nv ? c : nv);
+        }
+        count = __shfl(count, 0);
+    } else {
+        // exact: lanes stride over the shorter list and look each id up in the longer one
+        const uint32_t* S = nv <= nr ? A : R; const uint32_t* L = nv <= nr ? R : A;
+        const uint64_t ns = nv <= nr ? nv : nr, nl = nv <= nr ? nr : nv;
+        for (uint64_t i = lane; i < ns; i += 64) {
+            const uint32_t x = S[i];
+            uint64_t lo = 0, hi = nl;
+            while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (L[mid] < x) lo = mid + 1; else hi = mid; }
+            count += (lo < nl && L[lo] == x) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) count += __shfl_xor(count, off);
+    }
+    if (lane == 0) a.counts[(size_t)qi * a.n_values + v] = count;
+}
+__global__ __launch_bounds__(64) void facet_value_select_kernel(FacetValueArgs a) {
+    const uint32_t qi = blockIdx.x, lane = threadIdx.x;
+    uint32_t found = 0;
+    for (uint32_t base = 0; base < a.n_values && found < a.max_facets; base += 64) {
+        const uint32_t pos = base + lane;
+        const uint32_t v = pos < a.n_values ? (a.order ? a.order[pos] : pos) : 0;
+        const uint32_t c = pos < a.n_values ? a.counts[(size_t)qi * a.n_values + v] : 0;
+        const unsigned long long m = __ballot(c != 0);
+        const uint32_t rank = found + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (c != 0 && rank < a.max_facets && rank < a.cap) {
+            const size_t o = (size_t)qi * a.cap + rank;
+            a.out_value[o] = v; a.out_count[o] = c; a.out_doc[o] = a.val_ids[a.val_ptr[v]];     // ids_t::first_id(ids), :314
+        }
+        found += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) a.out_n[qi] = found < a.max_facets ? found : a.max_facets;
+}
+
 }  // namespace tsgpu

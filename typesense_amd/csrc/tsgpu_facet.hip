@@ -2,6 +2,7 @@
 // Index::do_facets (src/index.cpp:1659-1771). The host only sizes the per-query tables and orders the (few) distinct values the
 // device found; the per-document work runs in facet_kernels.hip.h.
 #include "tsgpu_host.h"
+#include <limits>
 #include "facet_kernels.hip.h"
 
 using namespace tsgpu;
@@ -13,8 +14,12 @@ struct FacetField {
     uint64_t n_hashes = 0;
     uint32_t n_distinct = 0, max_per_doc = 0;
     DevBuf d_ids, d_queries, d_allowed, d_key, d_cnt, d_last, d_oh, d_oc, d_od, d_op, d_on;      // per-batch scratch
+    DevBuf val_ptr, val_ids, val_total;              // value index (tsgpu_facet_value_set): value -> ascending seq_ids, in the reference's visiting order
+    uint32_t n_values = 0;
+    DevBuf d_stats, d_map_h, d_map_v, d_counts, d_order;
     void release() {
-        DevBuf* b[] = {&doc_ptr, &hashes, &d_ids, &d_queries, &d_allowed, &d_key, &d_cnt, &d_last, &d_oh, &d_oc, &d_od, &d_op, &d_on};
+        DevBuf* b[] = {&doc_ptr, &hashes, &d_ids, &d_queries, &d_allowed, &d_key, &d_cnt, &d_last, &d_oh, &d_oc, &d_od, &d_op, &d_on,
+                       &val_ptr, &val_ids, &val_total, &d_stats, &d_map_h, &d_map_v, &d_counts, &d_order};
         for (auto* x : b) x->release();
     }
 };
@@ -142,6 +147,166 @@ int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
             }
         }
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_facet_count_batch: host allocation failed"); }
+    return ok();
+}
+
+
+namespace {
+// the per-query id lists of a batch -> the id arena + FacetQueryDev table (ids_off / n_ids / first_block of a one-thread-per-id launch)
+int upload_id_lists(FacetField* f, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries, hipStream_t s, std::vector<FacetQueryDev>& qd, uint32_t& blocks) {
+    qd.assign(n_queries, FacetQueryDev());
+    uint64_t ids_total = 0;
+    blocks = 0;
+    for (uint32_t q = 0; q < n_queries; q++) {
+        if (n_result_ids[q] && !result_ids[q]) return fail(TSGPU_ERR_INVALID, "tsgpu_facet: result_ids[q] is NULL");
+        qd[q].ids_off = ids_total; qd[q].n_ids = n_result_ids[q];
+        ids_total += n_result_ids[q];
+        qd[q].first_block = blocks;
+        const uint64_t nb = (n_result_ids[q] + FACET_THREADS - 1) / FACET_THREADS;
+        if ((uint64_t)blocks + nb > 0x7FFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_facet: more than 2^31 workgroups");
+        blocks += (uint32_t)nb;
+    }
+    int rc;
+    if ((rc = f->d_ids.reserve(std::max<uint64_t>(ids_total, 1) * 4)) || (rc = f->d_queries.reserve(qd.size() * sizeof(FacetQueryDev)))) return rc;
+    for (uint32_t q = 0; q < n_queries; q++)
+        if (qd[q].n_ids) TSGPU_HIP_TRY(hipMemcpyAsync(f->d_ids.as<uint32_t>() + qd[q].ids_off, result_ids[q], qd[q].n_ids * 4, hipMemcpyHostToDevice, s));
+    TSGPU_HIP_TRY(hipMemcpyAsync(f->d_queries.p, qd.data(), qd.size() * sizeof(FacetQueryDev), hipMemcpyHostToDevice, s));
+    return TSGPU_OK;
+}
+}  // namespace
+
+// numeric facet stats of the hash-index branch (should_compute_stats): see facet_stats_kernel
+int tsgpu_facet_stats_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, int value_type, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
+                            uint32_t sample_mod, const uint32_t* int64_map_hashes, const int64_t* int64_map_values, uint32_t n_map, tsgpu_facet_stats* out) {
+    if (!ctx || !out || (n_queries && (!result_ids || !n_result_ids))) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_stats_batch: NULL argument");
+    if (value_type != TSGPU_FACET_INT32 && value_type != TSGPU_FACET_INT64 && value_type != TSGPU_FACET_FLOAT) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_stats_batch: unknown value type");
+    if (n_map && (!int64_map_hashes || !int64_map_values)) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_stats_batch: int64 map is NULL");
+    for (uint32_t i = 1; i < n_map; i++) if (int64_map_hashes[i] <= int64_map_hashes[i - 1]) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_stats_batch: int64_map_hashes must be strictly ascending");
+    if (n_queries == 0) return ok();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    auto it = ctx->facet_fields.find(facet_field_id);
+    if (it == ctx->facet_fields.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_facet_stats_batch: unknown facet field (tsgpu_facet_set)");
+    FacetField* f = it->second;
+    hipStream_t s = ctx->stream;
+    if (sample_mod == 0) sample_mod = 1;
+    try {
+        std::vector<FacetQueryDev> qd;
+        uint32_t blocks = 0;
+        int rc = upload_id_lists(f, result_ids, n_result_ids, n_queries, s, qd, blocks);
+        if (rc) return rc;
+        std::vector<FacetStatsDev> init(n_queries);
+        for (auto& d : init) { d.vmin = ~0ull; d.vmax = 0; d.isum = 0; d.count = 0; d.fsum = 0.0; d.absmax = 0; }
+        if ((rc = f->d_stats.reserve(init.size() * sizeof(FacetStatsDev))) || (rc = f->d_map_h.reserve(std::max<uint32_t>(n_map, 1) * 4)) || (rc = f->d_map_v.reserve(std::max<uint32_t>(n_map, 1) * 8))) return rc;
+        TSGPU_HIP_TRY(hipMemcpyAsync(f->d_stats.p, init.data(), init.size() * sizeof(FacetStatsDev), hipMemcpyHostToDevice, s));
+        if (n_map) {
+            TSGPU_HIP_TRY(hipMemcpyAsync(f->d_map_h.p, int64_map_hashes, (size_t)n_map * 4, hipMemcpyHostToDevice, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(f->d_map_v.p, int64_map_values, (size_t)n_map * 8, hipMemcpyHostToDevice, s));
+        }
+        FacetStatsArgs a;
+        a.doc_ptr = f->doc_ptr.as<uint64_t>(); a.hashes = f->hashes.as<uint32_t>(); a.n_docs = f->n_docs;
+        a.ids = f->d_ids.as<uint32_t>(); a.queries = f->d_queries.as<FacetQueryDev>(); a.n_queries = n_queries; a.sample_mod = sample_mod;
+        a.value_type = value_type; a.map_hash = f->d_map_h.as<uint32_t>(); a.map_val = f->d_map_v.as<long long>(); a.n_map = n_map;
+        a.out = f->d_stats.as<FacetStatsDev>();
+        if (blocks) hipLaunchKernelGGL(facet_stats_kernel, dim3(blocks), dim3(FACET_THREADS), 0, s, a);
+        TSGPU_HIP_TRY(hipGetLastError());
+        TSGPU_HIP_TRY(hipMemcpyAsync(init.data(), f->d_stats.p, init.size() * sizeof(FacetStatsDev), hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        for (uint32_t q = 0; q < n_queries; q++) {
+            const FacetStatsDev& d = init[q];
+            tsgpu_facet_stats& o = out[q];
+            o.fvcount = d.count;
+            o.fvmin = std::numeric_limits<double>::max(); o.fvmax = -std::numeric_limits<double>::max(); o.fvsum = 0.0; o.sum_exact = 1;      // include/field.h:765-770
+            if (d.count == 0) continue;
+            if (value_type == TSGPU_FACET_FLOAT) {
+                auto unkey = [](unsigned long long k) { uint32_t b = (uint32_t)k; b = (b & 0x80000000u) ? (b & 0x7FFFFFFFu) : ~b; float f; memcpy(&f, &b, 4); return f; };
+                o.fvmin = (double)unkey(d.vmin); o.fvmax = (double)unkey(d.vmax); o.fvsum = d.fsum;
+                o.sum_exact = 0;                       // the reference adds in document order; this sum differs from it by rounding only (~1e-16 relative per term)
+            } else {
+                o.fvmin = (double)(long long)(d.vmin ^ 0x8000000000000000ull); o.fvmax = (double)(long long)(d.vmax ^ 0x8000000000000000ull);
+                // every partial sum of the reference's double accumulation is an integer below count * max|v|: exact (and equal) under 2^53;
+                // beyond that the reference's own sum is a rounded one: the double-atomic sum stands in (same value up to rounding)
+                const long double bound = (long double)d.count * (long double)d.absmax;
+                o.sum_exact = bound < 9007199254740992.0L ? 1 : 0;
+                o.fvsum = o.sum_exact ? (double)(long long)d.isum : d.fsum;
+            }
+        }
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_facet_stats_batch: host allocation failed"); }
+    return ok();
+}
+
+// value index of a facet field: the seq_ids of every value, values in the reference's visiting order (counter_list: by total count)
+int tsgpu_facet_value_set(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint64_t* value_ptr, const uint32_t* seq_ids, const uint32_t* total_counts, uint32_t n_values) {
+    if (!ctx || !value_ptr || (n_values && !total_counts)) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_value_set: NULL argument");
+    if (value_ptr[0] != 0) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_value_set: value_ptr[0] must be 0");
+    for (uint32_t v = 0; v < n_values; v++) {
+        if (value_ptr[v + 1] <= value_ptr[v]) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_value_set: every value needs at least one seq_id");
+        for (uint64_t i = value_ptr[v] + 1; i < value_ptr[v + 1]; i++) if (seq_ids[i] <= seq_ids[i - 1]) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_value_set: a value's seq_ids must be strictly ascending");
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    try {
+        FacetField* f;
+        auto it = ctx->facet_fields.find(facet_field_id);
+        if (it == ctx->facet_fields.end()) { f = new FacetField; ctx->facet_fields[facet_field_id] = f; } else f = it->second;
+        DevBuf np, ni, nt;
+        int rc;
+        const uint64_t n_ids = value_ptr[n_values];
+        if ((rc = np.reserve(((size_t)n_values + 1) * 8)) || (rc = ni.reserve(std::max<uint64_t>(n_ids, 1) * 4)) || (rc = nt.reserve(std::max<uint32_t>(n_values, 1) * 4))) { np.release(); ni.release(); nt.release(); return rc; }
+        hipError_t e = hipMemcpy(np.p, value_ptr, ((size_t)n_values + 1) * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess && n_ids) e = hipMemcpy(ni.p, seq_ids, n_ids * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && n_values) e = hipMemcpy(nt.p, total_counts, (size_t)n_values * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { np.release(); ni.release(); nt.release(); return fail(TSGPU_ERR_DEVICE, std::string("tsgpu_facet_value_set: ") + hipGetErrorString(e)); }
+        f->val_ptr.release(); f->val_ids.release(); f->val_total.release();
+        f->val_ptr = np; f->val_ids = ni; f->val_total = nt; f->n_values = n_values;
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_facet_value_set: host allocation failed"); }
+    return ok();
+}
+
+// the value-index branch of do_facets for a batch of result-id lists: see facet_value_count_kernel / facet_value_select_kernel
+int tsgpu_facet_value_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
+                                  uint32_t max_facets, int is_wildcard_no_filter_query, int estimate_facets, uint32_t facet_sample_interval, const uint32_t* order,
+                                  tsgpu_facet_value_counts* out) {
+    if (!ctx || !out || (n_queries && (!result_ids || !n_result_ids))) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_value_count_batch: NULL argument");
+    if (!out->value_index || !out->count || !out->doc_id || !out->n_found || out->cap == 0) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_value_count_batch: missing output arrays");
+    if (n_queries == 0) return ok();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    auto it = ctx->facet_fields.find(facet_field_id);
+    if (it == ctx->facet_fields.end() || it->second->n_values == 0) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_facet_value_count_batch: the field has no value index (tsgpu_facet_value_set)");
+    FacetField* f = it->second;
+    hipStream_t s = ctx->stream;
+    if (facet_sample_interval == 0) facet_sample_interval = 1;
+    if (order) {
+        std::vector<uint8_t> seen(f->n_values, 0);
+        for (uint32_t i = 0; i < f->n_values; i++) { if (order[i] >= f->n_values || seen[order[i]]) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_value_count_batch: order must be a permutation of the values"); seen[order[i]] = 1; }
+    }
+    try {
+        std::vector<FacetQueryDev> qd;
+        uint32_t blocks = 0;
+        int rc = upload_id_lists(f, result_ids, n_result_ids, n_queries, s, qd, blocks);
+        if (rc) return rc;
+        const size_t n_cnt = (size_t)n_queries * f->n_values, n_out = (size_t)n_queries * out->cap;
+        if ((rc = f->d_counts.reserve(n_cnt * 4)) || (rc = f->d_oh.reserve(n_out * 4)) || (rc = f->d_oc.reserve(n_out * 4)) || (rc = f->d_od.reserve(n_out * 4)) ||
+            (rc = f->d_on.reserve((size_t)n_queries * 4)) || (rc = f->d_order.reserve((size_t)f->n_values * 4))) return rc;
+        if (order) TSGPU_HIP_TRY(hipMemcpyAsync(f->d_order.p, order, (size_t)f->n_values * 4, hipMemcpyHostToDevice, s));
+        FacetValueArgs a;
+        a.val_ptr = f->val_ptr.as<uint64_t>(); a.val_ids = f->val_ids.as<uint32_t>(); a.val_total = f->val_total.as<uint32_t>(); a.n_values = f->n_values;
+        a.ids = f->d_ids.as<uint32_t>(); a.queries = f->d_queries.as<FacetQueryDev>(); a.n_queries = n_queries;
+        a.order = order ? f->d_order.as<uint32_t>() : nullptr;
+        a.max_facets = max_facets; a.wildcard_no_filter = is_wildcard_no_filter_query; a.estimate = estimate_facets; a.interval = facet_sample_interval;
+        a.counts = f->d_counts.as<uint32_t>(); a.cap = out->cap;
+        a.out_value = f->d_oh.as<uint32_t>(); a.out_count = f->d_oc.as<uint32_t>(); a.out_doc = f->d_od.as<uint32_t>(); a.out_n = f->d_on.as<uint32_t>();
+        hipLaunchKernelGGL(facet_value_count_kernel, dim3(f->n_values, n_queries), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(facet_value_select_kernel, dim3(n_queries), dim3(64), 0, s, a);
+        TSGPU_HIP_TRY(hipGetLastError());
+        TSGPU_HIP_TRY(hipMemcpyAsync(out->value_index, f->d_oh.p, n_out * 4, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(out->count, f->d_oc.p, n_out * 4, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(out->doc_id, f->d_od.p, n_out * 4, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(out->n_found, f->d_on.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        for (uint32_t q = 0; q < n_queries; q++) if (n_result_ids[q] == 0) out->n_found[q] = 0;       // results_size == 0 -> do_facets returns at once (:1531-1533)
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_facet_value_count_batch: host allocation failed"); }
     return ok();
 }
 

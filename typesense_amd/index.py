@@ -296,6 +296,40 @@ class GpuIndex:
                                                 _vp(a) if a is not None else None, a.size if a is not None else 0, C.byref(out)))
         return [(h[q, :min(nv[q], cap)].copy(), c[q, :min(nv[q], cap)].copy(), d[q, :min(nv[q], cap)].copy(), p[q, :min(nv[q], cap)].copy(), int(nv[q])) for q in range(n)]
 
+    def facet_stats_batch(self, field_id, value_type, id_lists, sample_mod=1, int64_map=None):
+        """-> per query (fvmin, fvmax, fvsum, fvcount, sum_exact); int64_map = (sorted hashes uint32[], values int64[]) for int64 fields"""
+        lists = [_u32(x) for x in id_lists]
+        n = len(lists)
+        ptrs = (C.c_void_p * n)(*[x.ctypes.data if x.size else None for x in lists])
+        cnts = np.array([x.size for x in lists], np.uint64)
+        out = (B.FacetStatsC * n)()
+        mh = mv = None
+        if int64_map is not None:
+            mh, mv = _u32(int64_map[0]), np.ascontiguousarray(int64_map[1], dtype=np.int64)
+        self._ck(self.L.tsgpu_facet_stats_batch(self.h, field_id, value_type, C.cast(ptrs, C.c_void_p), _vp(cnts), n, sample_mod,
+                                                _vp(mh) if mh is not None else None, _vp(mv) if mv is not None else None, mh.size if mh is not None else 0, C.cast(out, C.c_void_p)))
+        return [(o.fvmin, o.fvmax, o.fvsum, int(o.fvcount), int(o.sum_exact)) for o in out]
+
+    def facet_value_set(self, field_id, value_ptr, seq_ids, total_counts):
+        value_ptr = np.ascontiguousarray(value_ptr, dtype=np.uint64)
+        seq_ids, total_counts = _u32(seq_ids), _u32(total_counts)
+        self._ck(self.L.tsgpu_facet_value_set(self.h, field_id, _vp(value_ptr), _vp(seq_ids) if seq_ids.size else None, _vp(total_counts) if total_counts.size else None, value_ptr.size - 1))
+
+    def facet_value_count_batch(self, field_id, id_lists, max_facets, wildcard_no_filter=False, estimate=False, sample_interval=1, order=None, cap=None):
+        """-> per query (value_index[], count[], doc_id[]) of the first max_facets values (visiting order) with a non-zero count"""
+        lists = [_u32(x) for x in id_lists]
+        n = len(lists)
+        cap = cap or max(int(max_facets), 1)
+        ptrs = (C.c_void_p * n)(*[x.ctypes.data if x.size else None for x in lists])
+        cnts = np.array([x.size for x in lists], np.uint64)
+        out = B.FacetValueCountsC()
+        v, c, d, nf = np.zeros((n, cap), np.uint32), np.zeros((n, cap), np.uint32), np.zeros((n, cap), np.uint32), np.zeros(n, np.uint32)
+        out.cap, out.value_index, out.count, out.doc_id, out.n_found = cap, v.ctypes.data, c.ctypes.data, d.ctypes.data, nf.ctypes.data
+        o = None if order is None else _u32(order)
+        self._ck(self.L.tsgpu_facet_value_count_batch(self.h, field_id, C.cast(ptrs, C.c_void_p), _vp(cnts), n, int(max_facets), int(wildcard_no_filter), int(estimate),
+                                                      int(sample_interval), _vp(o) if o is not None else None, C.byref(out)))
+        return [(v[q, :min(nf[q], cap)].copy(), c[q, :min(nf[q], cap)].copy(), d[q, :min(nf[q], cap)].copy()) for q in range(n)]
+
     def keep_result_ids(self, keep=True):
         self._ck(self.L.tsgpu_keep_result_ids(self.h, int(keep)))
 
