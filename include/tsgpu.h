@@ -124,8 +124,9 @@ int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
  * that many queries is planned in slices on the context's parked host threads, "fuse_threads" (default 32) = host threads of the
  * hybrid fusion, "blocking_sync_min_callers" (default 48) = from this many threads inside the keyword entry point a round is
  * awaited with a blocking event instead of a spinning stream wait (the request threads need the cores);
- * "hnsw_visited_max_gib" (default 64, 1..128) = cap of a field's HNSW visited-tag array (2 bytes x rows x concurrent queries:
- * 4096 queries traverse at once up to 8M rows, 2048 at 10M; read by the next tsgpu_vec_hnsw_load) */
+ * "hnsw_visited_hash" = 1 (default): an HNSW traversal keeps the ids it has visited in a per-query hash set (32-256 KB, whatever the
+ * row count; up to 4096 queries traverse at once), 0: 16-bit tags per row and concurrent query, capped by
+ * "hnsw_visited_max_gib" (default 64, 1..128: 2 bytes x rows x concurrent queries — 41 GB for 2048 queries at 10M rows) */
 int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value);
 /* introspection counters (tests / bench): "vec_overflow_rounds", "vec_prefilter_groups", "vec_prefilter_fallbacks",
  * "vec_rescored_rows", "kw_last_hit_groups" (find+score groups of the last keyword batch, 0 = fused), "kw_last_hit_records",

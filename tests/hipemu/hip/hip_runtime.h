@@ -335,6 +335,7 @@ inline int __builtin_amdgcn_mov_dpp(int v, int dpp_ctrl, int row_mask, int bank_
 // device wall clock at 1 tick per microsecond (hipDeviceAttributeWallClockRate = 1000 kHz below)
 inline long long hipemu_wall_clock64() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (long long)ts.tv_sec * 1000000ll + ts.tv_nsec / 1000; }
 inline void __builtin_amdgcn_s_setprio(int) {}
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 inline void __builtin_amdgcn_sched_barrier(int) {}
 
 // ---------------------------------------------------------------- host runtime API subset (emulated)

@@ -420,7 +420,12 @@ def test_hnsw_graph_search_replays_the_reference_traversal(n, dim, M, metric):
     allow = np.sort(rng.choice(n, size=n // 3, replace=False)).astype(np.uint32)
     hit = tot = 0
     for k, ef, al, functor in ((10, 10, None, True), (10, 100, None, True), (5, 40, None, False), (25, 30, allow, True), (100, 10, None, True)):
+        # visited bookkeeping: per-query hash sets (default) and hnswlib-style 16-bit tags per row give the same traversal
+        g.set_option("hnsw_visited_hash", 0)
+        tagged = g.vec_hnsw_search_batch(1, Q, k, ef, allow_ids=al, functor_present=functor)
+        g.set_option("hnsw_visited_hash", 1)
         dist, lab, cnt = g.vec_hnsw_search_batch(1, Q, k, ef, allow_ids=al, functor_present=functor)
+        assert all(np.array_equal(x, y) for x, y in zip(tagged, (dist, lab, cnt)))
         for i in range(Q.shape[0]):
             d, l, _ = orc.hnsw_search(Q[i], k, ef, allow_ids=al, functor_present=functor)
             assert cnt[i] == d.size and np.array_equal(lab[i, :d.size], l) and np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32)), (k, ef, i)

@@ -234,6 +234,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
     if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
     if (!strcmp(name, "kw_merge_select_min")) { ctx->kw_merge_select_min = (uint32_t)std::max<int64_t>(0, value); return ok(); }
+    if (!strcmp(name, "hnsw_visited_hash")) { ctx->hnsw_visited_hash = value != 0; return ok(); }
     if (!strcmp(name, "hnsw_visited_max_gib")) { ctx->hnsw_visited_max_gib = (int)std::min<int64_t>(std::max<int64_t>(1, value), 128); return ok(); }
     if (!strcmp(name, "blocking_sync_min_callers")) { ctx->blocking_sync_min_callers = (int)std::max<int64_t>(0, value); return ok(); }
     if (!strcmp(name, "plan_threads")) { if (value < 1 || value > 64) return fail(TSGPU_ERR_INVALID, "plan_threads: 1..64"); ctx->plan_threads = (int)value; return ok(); }

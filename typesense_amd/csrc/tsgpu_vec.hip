@@ -32,7 +32,8 @@ struct VecField {
     DevBuf d_dense, d_cand, d_cand_cnt, d_tau, dQ, d_dist, d_lab, d_cnt, d_mask, d_rows, d_q1, d_out1;
     DevBuf d_Qh, d_cq, d_L1, d_lbkey, d_surv, d_surv_cnt;
     // HNSW graph mirror (tsgpu_vec_hnsw_load): hnswlib's link lists; rows = hnswlib internal ids
-    DevBuf g_link0, g_upper_ptr, g_upper_links, g_visited;
+    DevBuf g_link0, g_upper_ptr, g_upper_links, g_visited, g_vhash, g_stat;
+    uint32_t g_tag_slots = 0;                          // tag mode: concurrent queries the allocated tag array serves (0 = not allocated)
     uint32_t g_M = 0, g_n = 0, g_slots = 0, g_epoch = 1;
     int32_t g_maxlevel = -1;
     uint32_t g_enterpoint = 0;
@@ -53,7 +54,7 @@ struct VecField {
     }
     void release() {
         DevBuf* b[] = {&X, &labels, &row_ok, &Xh, &xnorm, &tile_nmax, &d_dense, &d_cand, &d_cand_cnt, &d_tau, &dQ, &d_dist, &d_lab, &d_cnt, &d_mask, &d_rows,
-                       &d_q1, &d_out1, &d_Qh, &d_cq, &d_L1, &d_lbkey, &d_surv, &d_surv_cnt, &g_link0, &g_upper_ptr, &g_upper_links, &g_visited};
+                       &d_q1, &d_out1, &d_Qh, &d_cq, &d_L1, &d_lbkey, &d_surv, &d_surv_cnt, &g_link0, &g_upper_ptr, &g_upper_links, &g_visited, &g_vhash, &g_stat};
         for (auto* x : b) x->release();
     }
 };
@@ -731,12 +732,10 @@ int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32
     TSGPU_HIP_TRY(hipMemcpyAsync(f->g_link0.p, link0, (size_t)n * (1 + 2 * M) * 4, hipMemcpyHostToDevice, s));
     TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_ptr.p, upper_ptr, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
     if (n_upper) TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_links.p, upper_links, (size_t)n_upper * (1 + M) * 4, hipMemcpyHostToDevice, s));
-    // visited tags: one uint16 per row and concurrent query slot (hnswlib's VisitedListPool); the overflow counter sits behind them
-    // (16-bit tags, option hnsw_visited_max_gib = 64 GiB by default: 4096 concurrent queries up to 8M rows, 2048 at 10M = 41 GB)
-    uint32_t slots = 4096;
-    while (slots > 32 && (uint64_t)slots * std::max<uint32_t>(n, 1) * 2 > ((uint64_t)ctx->hnsw_visited_max_gib << 30)) slots >>= 1;
-    if ((rc = f->g_visited.reserve((size_t)slots * std::max<uint32_t>(n, 1) * 2 + 64))) return rc;
-    TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, (size_t)slots * std::max<uint32_t>(n, 1) * 2 + 64, s));
+    // visited bookkeeping is allocated by the search (hash sets by default; 16-bit tags with option hnsw_visited_hash = 0)
+    const uint32_t slots = 4096;
+    f->g_tag_slots = 0;
+    if ((rc = f->g_stat.reserve(64))) return rc;
     TSGPU_HIP_TRY(hipStreamSynchronize(s));
     f->g_M = M; f->g_n = n; f->g_slots = slots; f->g_epoch = 1; f->g_maxlevel = maxlevel; f->g_enterpoint = enterpoint; f->g_loaded = true;
     return ok();
@@ -771,9 +770,20 @@ int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const flo
         if (f->n_rows == 0) {
             TSGPU_HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)n_q * 4, s));
         } else {
-            const uint32_t grid = std::min<uint32_t>(n_q, f->g_slots);
+            const bool hash_mode = ctx->hnsw_visited_hash != 0;
+            uint32_t slots = f->g_slots;
+            if (!hash_mode) {
+                // tag mode: one uint16 per row and concurrent query (hnswlib's VisitedListPool); option hnsw_visited_max_gib caps the array
+                while (slots > 32 && (uint64_t)slots * std::max<uint32_t>(f->g_n, 1) * 2 > ((uint64_t)ctx->hnsw_visited_max_gib << 30)) slots >>= 1;
+                if (f->g_tag_slots != slots) {
+                    if ((rc = f->g_visited.reserve((size_t)slots * std::max<uint32_t>(f->g_n, 1) * 2 + 64))) return rc;
+                    TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, (size_t)slots * std::max<uint32_t>(f->g_n, 1) * 2 + 64, s));
+                    f->g_tag_slots = slots; f->g_epoch = 1;
+                }
+            }
+            const uint32_t grid = std::min<uint32_t>(n_q, slots);
             const uint32_t iters = (n_q + grid - 1) / grid;
-            const size_t tag_bytes = ((size_t)f->g_slots * f->g_n * 2 + 7) & ~(size_t)7;
+            const size_t tag_bytes = ((size_t)slots * f->g_n * 2 + 7) & ~(size_t)7;
             VecHnswArgs a;
             memset(&a, 0, sizeof a);
             a.X = f->X.as<float>(); a.Q = Q_dev; a.dim = f->dim; a.n_rows = (uint32_t)f->n_rows; a.n_q = n_q;
@@ -781,15 +791,20 @@ int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const flo
             a.upper_ptr = f->g_upper_ptr.as<uint64_t>(); a.upper_links = f->g_upper_links.as<uint32_t>(); a.su = 1 + f->g_M;
             a.maxlevel = f->g_maxlevel; a.enterpoint = f->g_enterpoint;
             a.row_ok = mask; a.strict = (functor_present || f->any_deleted) ? 1u : 0u;
-            a.k = k; a.ef = ef; a.ip_lanes = ctx->vec_ip_lanes; a.visited = f->g_visited.as<uint16_t>();
-            a.overflow_cnt = (uint32_t*)((char*)f->g_visited.p + tag_bytes);
+            a.k = k; a.ef = ef; a.ip_lanes = ctx->vec_ip_lanes; a.visited = hash_mode ? nullptr : f->g_visited.as<uint16_t>();
+            a.overflow_cnt = f->g_stat.as<uint32_t>();
             a.labels = f->labels.as<uint64_t>(); a.dist_out = d_dist; a.label_out = d_lab; a.n_out = d_cnt;
             // LDS tier by max(ef, k); a query whose candidate heap outgrows a small tier makes the batch run again on the largest
             const uint32_t need = std::max(k, ef);
             int tier = need <= 128 ? 0 : (need <= 512 ? 1 : 2);
             TSGPU_HIP_TRY(hipEventRecord(ctx->ev[3], s));
             for (;;) {
-                if ((uint64_t)f->g_epoch + iters >= 0xFFF0ull) {      // tag space exhausted: clear the tags
+                if (hash_mode) {
+                    // per-query visited sets: 64 x the tier's result-heap capacity (8 192 / 32 768 / 65 536 words), one per concurrent query
+                    const uint32_t vs = tier == 0 ? 8192u : (tier == 1 ? 32768u : 65536u);
+                    if ((rc = f->g_vhash.reserve((size_t)grid * vs * 4))) return rc;
+                    a.vhash = f->g_vhash.as<uint32_t>(); a.vhash_slots = vs;
+                } else if ((uint64_t)f->g_epoch + iters >= 0xFFF0ull) {      // tag space exhausted: clear the tags
                     TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, tag_bytes, s));
                     f->g_epoch = 1;
                 }

@@ -1212,7 +1212,12 @@ struct VecHnswArgs {
     uint32_t strict;           // a filter functor is present or the index has deletions (hnswalg.h searchBaseLayerST break rule)
     uint32_t k, ef;
     uint32_t ip_lanes;                                  // summation order of the distance (4 / 8 / 16: the SIMD level hnswlib was compiled for)
-    uint16_t* visited; uint32_t epoch_base;             // [slots][n_rows] 16-bit tags (hnswlib's VisitedList is 16-bit, too); slot = blockIdx.x
+    uint16_t* visited; uint32_t epoch_base;             // tag mode: [slots][n_rows] 16-bit tags (hnswlib's VisitedList is 16-bit, too); slot = blockIdx.x
+    // hash mode (default): the ids a query visits (a few thousand) live in ITS open-addressing set of vhash_slots words (a power of two,
+    // 64 x the tier's heap capacity), cleared per query — memory per concurrent query no longer depends on the row count (16-bit tags:
+    // 2 B x rows, 41 GB for 2 048 queries at 10M rows; sets: 32 KB - 256 KB each). A set that fills beyond half reports the query like a
+    // candidate-heap overflow (re-run on the largest tier, then exactly by the caller).
+    uint32_t* vhash; uint32_t vhash_slots;
     uint32_t* overflow_cnt;                             // [0] queries whose candidate heap outgrew CANDCAP; [1..2] u64 expansions, [3..4] u64 distances (batch totals)
     const uint64_t* labels;
     float* dist_out; uint64_t* label_out; uint32_t* n_out;   // [n_q][k]; n_out = 0xFFFFFFFF: candidate heap overflow (caller re-runs exactly)
@@ -1286,10 +1291,29 @@ __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
     __shared__ uint32_t s_cur, s_state, s_top_n;
     __shared__ float s_lb;
     const uint32_t lane = threadIdx.x, sub = lane & 15, grp = lane >> 4;
-    volatile uint16_t* vis = a.visited + (size_t)blockIdx.x * a.n_rows;      // volatile: tags written by this wave are re-read later (no stale L1 lines)
+    volatile uint16_t* vis = a.vhash ? nullptr : a.visited + (size_t)blockIdx.x * a.n_rows;      // volatile: tags written by this wave are re-read later (no stale L1 lines)
+    uint32_t* vset = a.vhash ? a.vhash + (size_t)blockIdx.x * a.vhash_slots : nullptr;
+    const uint32_t vmask = a.vhash_slots - 1;
+    // visited test-and-set: true = first visit. Hash mode: one CAS per probe at L2 (a wave's concurrent inserts are distinct ids; two of them
+    // racing for one empty slot are ordered by the CAS)
+    auto visit = [&](uint32_t id, uint16_t epoch, uint32_t& n_vis) -> bool {
+        if (!vset) { const bool fresh = vis[id] != epoch; if (fresh) vis[id] = epoch; return fresh; }
+        uint32_t h = (id * 2654435761u) & vmask;
+        for (;;) {
+            const uint32_t cur = atomicCAS(&vset[h], 0u, id + 1u);
+            if (cur == 0u) { n_vis++; return true; }
+            if (cur == id + 1u) return false;
+            h = (h + 1) & vmask;
+        }
+    };
     uint32_t iter = 0;
     for (uint32_t q = blockIdx.x; q < a.n_q; q += gridDim.x, iter++) {
         const uint16_t epoch = (uint16_t)(a.epoch_base + iter);
+        uint32_t n_vis = 0;                                      // (per lane; summed over the wave when checked)
+        if (vset) {
+            for (uint32_t i = lane; i < a.vhash_slots; i += 64) vset[i] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the clears are in L2 before the first CAS (atomics execute there)
+        }
         const float* qs = a.Q + (size_t)q * a.dim;
         __syncthreads();
         if (a.dim <= VEC_HNSW_QDIM) {
@@ -1356,7 +1380,7 @@ __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
             const bool ok = !a.row_ok || a.row_ok[cur] != 0;
             if (ok) { lowerBound = curdist; top.push(curdist, cur); cand.push(-curdist, cur); }
             else { lowerBound = 3.402823466e+38f; cand.push(-lowerBound, cur); }
-            vis[cur] = epoch;
+            (void)visit(cur, epoch, n_vis);
         }
         for (;;) {
             if (lane == 0) {
@@ -1379,7 +1403,11 @@ __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
             bool fresh = false;
             // (count and ids requested together: a record has 1 + 2M words whatever its count; ids past the count are ignored)
             const uint32_t cw = lst[lane < a.s0 - 1 ? 1 + lane : 0];
-            if (lane < cnt) { c = cw; fresh = vis[c] != epoch; if (fresh) vis[c] = epoch; }
+            // the set stays at most half full (n_dist counts every first visit but the entry point's; a list adds at most cnt): a query that
+            // would outgrow it stops here and is reported like a candidate-heap overflow
+            const bool room = !vset || n_dist + 1 + cnt <= a.vhash_slots / 2;
+            if (!room && lane == 0) { overflow = true; cand.n = 0; }
+            if (room && lane < cnt) { c = cw; fresh = visit(c, epoch, n_vis); }
             const unsigned long long m = __ballot(fresh ? 1 : 0);
             const uint32_t nf = (uint32_t)__popcll(m);
             if (fresh) {
