@@ -1073,7 +1073,7 @@ def main():
                         "parallelism": par, "results_to": "device (tsgpu_hits mem=DEVICE); host delivery is quantified in DESIGN.md §5"}
         kw["queries_with_hits"] = r.get("nonempty")
         if "host_qps" in r:
-            kw["value_with_host_delivery"] = r["host_qps"]       # PCIe-inclusive (80 MB of hits per 10 000-query batch into pageable host memory)
+            kw["value_with_host_delivery"] = r["host_qps"]       # PCIe-inclusive (112 MB of hit arrays per 10 000-query batch into pageable host memory)
         find_rx, score_rx = r"kw_find2_kernel<3>|kw_search_kernel<3, 512, true, true>", r"kw_score_kernel"
         traffic = pmc_traffic([find_rx, score_rx], ["pmc_kw_fetch.txt", "pmc_kw_s5_fetch.txt"])
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

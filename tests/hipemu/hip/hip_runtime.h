@@ -362,6 +362,7 @@ inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipE
 inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); e->t = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 // fault injection (tests/test_emu_incremental.py): the N-th hipMalloc / synchronous hipMemcpy from now on fails once (0 = off).
 // One counter per library image; set through the exported hipemu_fail_nth() below.
