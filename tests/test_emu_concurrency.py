@@ -111,8 +111,11 @@ def test_a_caller_whose_k_stride_is_too_small_fails_alone(pair):
         start.wait()
         for _ in range(3):
             if i == 0:
-                hits = g.keyword_search_batch([greedy], k_stride=24)
-                assert hits.status[0] == B.ERR_INVALID and hits.n_hits[0] == 0
+                try:
+                    hits = g.keyword_search_batch([greedy], k_stride=24)
+                    assert hits.status[0] == B.ERR_INVALID and hits.n_hits[0] == 0      # shared a round: its own query reports 400
+                except T.TsgpuError as e:
+                    assert e.code == B.ERR_INVALID                                       # ran alone (no other caller inside at that instant): the call reports 400
             else:
                 hits = g.keyword_search_batch([good], k_stride=24)
                 assert hits.status[0] == 0
