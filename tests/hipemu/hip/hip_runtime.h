@@ -39,7 +39,8 @@ enum WaitKind { RUNNING = 0, AT_BARRIER = 1, AT_WAVE = 2, DONE = 3 };
 
 struct Fiber {
     ucontext_t ctx;
-    std::vector<char> stack;
+    char* stack = nullptr;          // from the stack pool below: fiber stacks are reused across blocks and launches (a fresh zero-filled
+                                    // 256 KB vector per fiber per block was most of the emulator's run time: 128 MB of page faults per 512-thread block)
     dim3 tid;
     int wait = RUNNING;
     unsigned wave_gen = 0;
@@ -86,6 +87,12 @@ inline void fiber_entry() {
     swapcontext(&b->fibers[b->cur].ctx, &b->sched);
 }
 
+static const size_t FIBER_STACK = 256 * 1024;
+inline char* pooled_stack(unsigned i) {           // (launches are serialised by launch_mutex: one pool)
+    static std::vector<char*> pool;
+    while (pool.size() <= i) pool.push_back((char*)malloc(FIBER_STACK));
+    return pool[i];
+}
 inline void run_block(BlockState& B) {
     g() = &B;
     const unsigned n = B.block_dim.x;
@@ -93,12 +100,12 @@ inline void run_block(BlockState& B) {
     B.waves.assign((n + 63) / 64, WaveState());
     for (unsigned i = 0; i < n; i++) {
         Fiber& f = B.fibers[i];
-        f.stack.resize(256 * 1024);
+        f.stack = pooled_stack(i);
         f.tid = dim3(i, 0, 0);
         f.wait = RUNNING;
         getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack.data();
-        f.ctx.uc_stack.ss_size = f.stack.size();
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = FIBER_STACK;
         f.ctx.uc_link = &B.sched;
         makecontext(&f.ctx, (void (*)())fiber_entry, 0);
     }
