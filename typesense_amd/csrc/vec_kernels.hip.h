@@ -527,18 +527,6 @@ __device__ inline void vec_glds16(const void* gsrc, void* lds_wave_base) {
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 #endif
 }
-// the same with the non-temporal hint: for bytes ONE workgroup reads ONCE (the row blocks of a scan whose batch is a single query tile) —
-// MI355X_MICROARCH.md "nt-weights": issue-to-landed -18 % on streamed data; NOT for blocks other workgroups re-read from L2 (the query block)
-__device__ inline void vec_glds16_nt(const void* gsrc, void* lds_wave_base) {
-#ifdef TSGPU_HIP_EMU
-    hipemu_global_load_lds16(gsrc, lds_wave_base);
-#else
-    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-#endif
-}
 template <int N>
 __device__ inline void vec_glds_wait() {        // all but the youngest N vector-memory operations of this wave are complete
 #ifndef TSGPU_HIP_EMU
@@ -566,6 +554,8 @@ __device__ inline void vec_glds_wait() {        // all but the youngest N vector
 //   * workgroups of an XCD walking the k chunks in rotated order (no two ask L2 for the same query block at once): no change;
 //   * query blocks through registers (global_load -> ds_write_b128 by waves 4-7) to leave the DMA path to the rows: 6.3-8 ms (the
 //     loading waves stall their own MFMA stream on L2 latency);
+//   * (round 3) the non-temporal hint on the row-block DMAs (`global_load_lds_dwordx4 ... nt`; each row block is read by ONE workgroup at B = 256):
+//     4.9 -> 5.9 ms; `s_setprio 1` for the second-dispatched half of the workgroup: within run-to-run noise (+-3 %) in an A/B/A/B run;
 //   * row operand straight from global memory into the MFMA's registers (a 16-byte load per lane = its 8 k of a row; a re-tiled mirror makes
 //     a wave-wide load 1 KB contiguous; 4-deep register ring, asm-issued loads with counted waits), only the query block in LDS: half the
 //     DMA landings, two thirds of the operand fetches, identical results, 4.74-4.81 ms. Its ablations: ds_read_b128 + barriers alone 2.07 ms,
@@ -635,10 +625,6 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
             uint32_t o = ord_begin + 2 * p + half;
             o = o < ord_end ? o : ord_end - 1;                                         // odd tail: re-read the last ordinal (dropped by the epilogue)
             const uint4* __restrict__ xsrc = (const uint4*)(a.Xh + ((size_t)(o * a.tile_stride) * n_c64 + c) * (size_t)(VEC_ROWS * VEC_HKC));
-#if defined(VEC_X_NT) && VEC_X_NT
-            if (a.n_qtiles == 1) vec_glds16_nt(xsrc + src_off[v] + sub, &sm.xs[slot][(v * VEC_HTHREADS + wave * 64) * 4]);
-            else
-#endif
             vec_glds16(xsrc + src_off[v] + sub, &sm.xs[slot][(v * VEC_HTHREADS + wave * 64) * 4]);
         }
     };
@@ -665,9 +651,6 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
     __syncthreads();                                     // (their waits drain nothing of ours: no DMA issued yet)
 
     const uint32_t last = total_steps - 1;
-#if defined(VEC_PRIO_YOUNG) && VEC_PRIO_YOUNG
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);        // the second-dispatched half loses every arbitration otherwise (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-#endif
     vec_f32x16 acc[2][CB];
 #pragma unroll
     for (int i = 0; i < NS - 1; i++) {
