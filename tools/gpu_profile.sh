@@ -6,13 +6,14 @@
 #   * the GPU test tier, the smoke test and the full bench line                        -> pytest_gpu_<tag>.txt, smoke_<tag>.txt, bench_all_<tag>.json
 # bench.py reads pmc_kw_fetch.txt / pmc_kw_sq1.txt / pmc_vec_fetch.txt of the round for roofline.traffic / issue_util.
 set -u
-R=${1:-r02}; TAG=${2:-final}
+R=${1:-r03}; TAG=${2:-final}
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$ROOT/gpurun_out/prof_$TAG; P=$ROOT/gpurun_out/profiles_$R
 mkdir -p $O $P
 cd /tmp
-KW="python $ROOT/bench.py --workload keyword --no-cpu-baseline --no-extras --steps 3 --warmup 1"
+# (the profiled keyword leg runs the batch as ONE part: one find + one score launch per step, the same form bench.py measures its roofline on)
+KW="python $ROOT/bench.py --workload keyword --no-cpu-baseline --no-extras --steps 3 --warmup 1 --opt kw_stage_min_queries=0"
 VEC="python $ROOT/bench.py --workload vector --no-cpu-baseline --no-extras --steps 3 --warmup 1"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_kw -- $KW > $O/trace_kw.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_vec -- $VEC > $O/trace_vec.log 2>&1
