@@ -412,20 +412,6 @@ class Bench:
         elapsed, lat, out = timed(step, args.steps, args.warmup, world, after)
         res = dict(elapsed=elapsed, lat=lat, kern_ms=float(np.mean(kern_ms)), merge_ms=float(np.mean(merge_ms)), find_ms=float(np.mean(find_ms)),
                    alg_bytes=float(np.mean(alg_bytes)), n_q=n_q, n_postings=int(self.csr["n_postings"]))
-        if world == 1 and n_q >= 4096 and self.opts.get("kw_stage_min_queries", 4096) != 0:
-            # The timed steps ran the batch as STAGED parts on four streams (their kernels share the GPU: kern_ms above is the envelope of the
-            # parts' events). For the roofline — algorithmic bytes per launch / the kernel's duration — the same batch is run as ONE part
-            # (kw_stage_min_queries = 0: one find launch, one score launch, the durations rocprofv3 --kernel-trace reports for profiles/).
-            g.set_option("kw_stage_min_queries", 0)
-            k1, m1, f1, a1 = [], [], [], []
-            for i in range(2 + min(args.steps, 10)):
-                g.keyword_search_batch_raw(arr, n_q, hs)
-                if i >= 2:
-                    tm = g.timings()
-                    k1.append(tm.kw_search_ms); m1.append(tm.kw_merge_ms); f1.append(tm.kw_find_ms); a1.append(tm.kw_algorithmic_bytes)
-            g.set_option("kw_stage_min_queries", self.opts.get("kw_stage_min_queries", 4096))
-            res["staged_envelope_ms"] = res["kern_ms"]
-            res.update(kern_ms=float(np.mean(k1)), merge_ms=float(np.mean(m1)), find_ms=float(np.mean(f1)), alg_bytes=float(np.mean(a1)))
         if self.group is not None:
             # cross-check of the two exchange implementations (untimed): the C-ABI group's merged result == torch.distributed all-gather + merge
             ref = step_torch_exchange()
@@ -1101,8 +1087,6 @@ def main():
                 "kernel": "kw_find2_kernel<3> (two driver blocks per iteration) + kw_score_kernel<512> (the two halves of the intersect+score+select step, "
                           "launched back to back; kernel_ms spans both)", "kernel_ms": r["kern_ms"], "merge_kernel_ms": r["merge_ms"],
                 "algorithmic_bytes_per_launch": r["alg_bytes"],
-                "measured_on": ("the step's batch run as ONE part (one find + one score launch: the durations rocprofv3 reports); the timed steps run it as four "
-                                "staged parts on four streams, envelope of their find+score events %.3f ms" % r["staged_envelope_ms"]) if "staged_envelope_ms" in r else "the timed steps",
                 "note": "SURVEY 8(d) figure: algorithmic bytes = 4*sum|L_t| + offsets + sort keys over the kernel time. The kernel SKIPS (only the shortest "
                         "list is scanned, the others are touched per overlapping run) and the batch's ~2 000 distinct terms are re-read from L2 / "
                         "Infinity Cache, so this fraction is not a distance to an HBM limit: see fetched_frac (bytes the memory system actually "

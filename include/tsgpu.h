@@ -108,9 +108,6 @@ int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
  * buffer (default 20480; 16 bytes (<= 3 tokens) or 44 bytes per driver posting of the batch are reserved; a table of work items
  * that needs more than two buffer-sized groups runs fused);
  * "kw_sort_work" = 1 (default): work items launched heaviest first,
- * "kw_stage_min_queries" (default 4096, 0 = never): a batch of at least that many queries runs as up to four PARTS on separate lanes
- * (6 % / 38 % / 44 % / 12 % of the queries): the GPU starts on the small first part while the others are planned, and the parts'
- * result copies overlap the later parts' kernels (identical results: queries are independent),
  * "vec_rows_per_slab" = base rows per k-NN workgroup slab (default: automatic), "vec_sample_tiles" = 128-row tiles of
  * the k-NN threshold sample (default 512), "vec_cand_cap" = candidate slots per query of the filtered pass (0 = auto),
  * "vec_ip_lanes" = 4 (default) / 8 / 16: the order every exact distance is summed in = the SIMD level hnswlib is compiled for in the

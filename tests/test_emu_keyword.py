@@ -822,39 +822,3 @@ def test_parallel_planning_of_a_batch_gives_the_serial_plan(pair, pair3):
         n = int(s3.n_hits[i])
         assert p3.n_hits[i] == n and p3.num_matched[i] == s3.num_matched[i] and np.array_equal(p3.keys[i, :n], s3.keys[i, :n]) and np.array_equal(p3.scores[i, :n], s3.scores[i, :n])
         H.assert_hits_equal(p3, i, H.oracle_keyword(orc3, q3[i]), "parallel plan, 3 fields")
-
-
-def test_staged_big_batch_equals_the_single_lane_batch(pair):
-    """option kw_stage_min_queries: a big batch runs as up to four parts on separate lanes / host threads (6 / 38 / 44 / 12 % of the
-    queries); queries are independent, so every output array equals the unstaged call's — host and "device" outputs, with filters,
-    a 501 query and an empty query inside"""
-    orc, g, docs = pair
-    rng = np.random.default_rng(77)
-    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
-    filt = np.sort(rng.choice(3000, size=900, replace=False)).astype(np.uint32)
-    qs = []
-    for i in range(70):
-        toks = rng.choice(np.arange(1, 40), size=int(rng.integers(1, 4)), replace=False)
-        kw = {}
-        if i % 7 == 3:
-            kw["filter_ids"] = filt
-        if i % 11 == 5:
-            kw["excluded_ids"] = filt[::3]
-        qs.append(T.KwQuery(toks, sort=sort, topster_size=int(rng.choice([20, 60, 250])), **kw))
-    qs[13] = T.KwQuery([1, 2], sort=((B.SORT_INT64_COLUMN, 1, 77),), topster_size=60)      # 501
-    qs[41] = T.KwQuery([9999], sort=sort, topster_size=60)                                   # no such token
-    g.set_option("kw_stage_min_queries", 0)
-    plain = g.keyword_search_batch(qs, k_stride=250)
-    g.set_option("kw_stage_min_queries", 8)
-    for lanes in (4, 3, 2):
-        g.set_option("kw_lanes", lanes)
-        staged = g.keyword_search_batch(qs, k_stride=250)
-        assert np.array_equal(staged.status, plain.status) and np.array_equal(staged.n_hits, plain.n_hits) and np.array_equal(staged.num_matched, plain.num_matched)
-        for i in range(len(qs)):
-            n = int(plain.n_hits[i])
-            assert np.array_equal(staged.keys[i, :n], plain.keys[i, :n]) and np.array_equal(staged.scores[i, :n], plain.scores[i, :n]), (lanes, i)
-            assert np.array_equal(staged.text_match[i, :n], plain.text_match[i, :n])
-    for i in (0, 5, 33, 69):
-        H.assert_hits_equal(staged, i, H.oracle_keyword(orc, qs[i]), "staged")
-    g.set_option("kw_lanes", 4)
-    g.set_option("kw_stage_min_queries", 4096)

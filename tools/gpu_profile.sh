@@ -12,8 +12,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$ROOT/gpurun_out/prof_$TAG; P=$ROOT/gpurun_out/profiles_$R
 mkdir -p $O $P
 cd /tmp
-# (the profiled keyword leg runs the batch as ONE part: one find + one score launch per step, the same form bench.py measures its roofline on)
-KW="python $ROOT/bench.py --workload keyword --no-cpu-baseline --no-extras --steps 3 --warmup 1 --opt kw_stage_min_queries=0"
+KW="python $ROOT/bench.py --workload keyword --no-cpu-baseline --no-extras --steps 3 --warmup 1"
 VEC="python $ROOT/bench.py --workload vector --no-cpu-baseline --no-extras --steps 3 --warmup 1"
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_kw -- $KW > $O/trace_kw.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_vec -- $VEC > $O/trace_vec.log 2>&1

@@ -159,8 +159,6 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
     ctx->d_col_ptrs.release(); ctx->d_col_len.release(); ctx->d_prof.release();
     for (auto& c : ctx->columns) c.data.release();
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
-    if (ctx->ev_ref) (void)hipEventDestroy(ctx->ev_ref);
-    if (ctx->ref_stream) (void)hipStreamDestroy(ctx->ref_stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -235,7 +233,6 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_sort_work")) { ctx->kw_sort_work = value != 0; return ok(); }
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
     if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
-    if (!strcmp(name, "kw_stage_min_queries")) { ctx->kw_stage_min_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 30); return ok(); }
     if (!strcmp(name, "kw_merge_select_min")) { ctx->kw_merge_select_min = (uint32_t)std::max<int64_t>(0, value); return ok(); }
     if (!strcmp(name, "hnsw_visited_hash")) { ctx->hnsw_visited_hash = value != 0; return ok(); }
     if (!strcmp(name, "hnsw_visited_max_gib")) { ctx->hnsw_visited_max_gib = (int)std::min<int64_t>(std::max<int64_t>(1, value), 128); return ok(); }
@@ -755,10 +752,6 @@ struct BatchOpts {
     std::vector<int32_t>* cutoff_host = nullptr;      // ... and the per-query search_cutoff flags
     tsgpu_id_lists* id_lists = nullptr;               // when set: the matched ids of every query, gathered + downloaded (implies keep_ids)
     bool record_last = true;                          // remember the id segments for the legacy tsgpu_result_ids API
-    // staged big batch (kw_dispatch): this call is one PART of a caller's batch; its kernel events are reported relative to ref_event
-    // (recorded when the batch entered) instead of being written to ctx->timings
-    hipEvent_t ref_event = nullptr;
-    struct PartTimes { float t0 = 0, t_find = 0, t_score = 0, t_merge = 0; uint64_t bytes = 0; uint32_t hit_groups = 0; uint64_t hit_records = 0; bool find_marked = false; }* part_times = nullptr;
 };
 }
 static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, const BatchOpts& bo);
@@ -907,71 +900,6 @@ static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n
     bo.keep_ids = legacy_keep || ids_out != nullptr;
     bo.id_lists = lists.get();
     bo.record_last = legacy_keep;
-    // ---- staged big batch: a batch of thousands of queries runs as a few PARTS, each on its own lane (stream + scratch) from its own host
-    //      thread. The first part is small: its plan takes tens of microseconds, so the GPU starts almost at once while the big parts are
-    //      still being planned; the last part is small, too: its result copy is what remains un-overlapped at the end (host outputs: the
-    //      other parts' device-to-host copies run under the later parts' kernels). Queries are independent: the result is the batch's. ----
-    if (!legacy_keep && !ids_out && ctx->kw_stage_min_queries && n_queries >= ctx->kw_stage_min_queries && ctx->n_lanes >= 2) {
-        static const float frac4[4] = {0.06f, 0.38f, 0.44f, 0.12f}, frac3[3] = {0.08f, 0.74f, 0.18f}, frac2[2] = {0.12f, 0.88f};
-        const int P = std::min(4, ctx->n_lanes);
-        const float* fr = P == 4 ? frac4 : (P == 3 ? frac3 : frac2);
-        uint32_t cut[5] = {0, 0, 0, 0, 0};
-        { float acc = 0; for (int i = 0; i < P; i++) { acc += fr[i]; cut[i + 1] = i + 1 == P ? n_queries : std::min<uint32_t>(n_queries, (uint32_t)(acc * n_queries)); } }
-        (void)hipSetDevice(ctx->device);
-        { std::lock_guard<std::mutex> lk(ctx->tm_mu); if (!ctx->ev_ref) { (void)hipEventCreate(&ctx->ev_ref); (void)hipStreamCreateWithFlags(&ctx->ref_stream, hipStreamNonBlocking); } }
-        std::lock_guard<std::mutex> stage_lk(ctx->stage_mu);            // (one staged batch at a time: ev_ref is the context's)
-        TSGPU_HIP_TRY(hipEventRecord(ctx->ev_ref, ctx->ref_stream));
-        int rcs[4] = {0, 0, 0, 0};
-        std::string errs[4];
-        BatchOpts::PartTimes pts[4];
-        // (measured and dropped: running the parts' kernels IN ORDER — so that part i's 10-50 MB result copy would run under part i + 1's
-        // kernels — and splitting a part's copy over four streams: a device-to-host copy moves ~10 GB/s whatever it overlaps with, four of
-        // them in parallel reach the link's ~50 GB/s at the END of an unordered batch just as well; host delivery stayed at 0.85-0.9 M q/s)
-        auto run_part = [&](int i) {
-            if (cut[i + 1] == cut[i]) return;
-            const uint32_t q0 = cut[i], nq = cut[i + 1] - cut[i];
-            tsgpu_hits sub = *out;
-            const size_t ks = out->k_stride;
-            sub.keys = out->keys + (size_t)q0 * ks; sub.scores = out->scores + (size_t)q0 * ks * 3;
-            if (out->text_match) sub.text_match = out->text_match + (size_t)q0 * ks;
-            if (out->vector_distance) sub.vector_distance = out->vector_distance + (size_t)q0 * ks;
-            if (out->match_score_index) sub.match_score_index = out->match_score_index + (size_t)q0 * ks;
-            sub.n_hits = out->n_hits + q0; sub.status = out->status + q0;
-            if (out->num_matched) sub.num_matched = out->num_matched + q0;
-            if (out->search_cutoff) sub.search_cutoff = out->search_cutoff + q0;
-            BatchOpts pb = bo;
-            pb.ref_event = ctx->ev_ref; pb.part_times = &pts[i];
-            LaneLock ll(ctx, -1);
-            rcs[i] = kw_batch_on_lane(ctx, *ll.L, queries + q0, nq, &sub, pb);
-            if (rcs[i]) errs[i] = tls_error();
-        };
-        {
-            std::vector<std::thread> th;
-            try { for (int i = 1; i < P; i++) th.emplace_back(run_part, i); } catch (...) { for (auto& t : th) t.join(); return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_batch: could not start a part thread"); }
-            run_part(0);
-            for (auto& t : th) t.join();
-        }
-        for (int i = 0; i < P; i++) if (rcs[i]) return fail(rcs[i], errs[i]);
-        // kernel times of the batch = the envelope of its parts' events (their kernels share the GPU): first find start -> last score end
-        float t0 = 1e30f, t1 = 0, tf = 0, merge = 0;
-        uint64_t bytes = 0, recs = 0; uint32_t groups = 0; bool all_find = true;
-        for (int i = 0; i < P; i++) {
-            if (cut[i + 1] == cut[i]) continue;
-            t0 = std::min(t0, pts[i].t0); t1 = std::max(t1, pts[i].t_score); merge += pts[i].t_merge - pts[i].t_score;
-            all_find = all_find && pts[i].find_marked; tf = std::max(tf, pts[i].t_find);
-            bytes += pts[i].bytes; recs += pts[i].hit_records; groups = std::max(groups, pts[i].hit_groups);
-        }
-        {
-            std::lock_guard<std::mutex> tl(ctx->tm_mu);
-            ctx->timings.kw_search_ms = t1 - t0;
-            ctx->timings.kw_merge_ms = merge;
-            ctx->timings.kw_find_ms = all_find ? tf - t0 : 0.0f;
-            ctx->timings.total_ms = t1 - t0;
-            ctx->timings.kw_algorithmic_bytes = bytes;
-            ctx->kw_last_hit_groups = groups; ctx->kw_last_hit_records = recs;
-        }
-        return ok();
-    }
     LaneLock ll(ctx, legacy_keep ? 0 : -1);          // the legacy "last batch" id API is single-caller: always lane 0
     const int rc = kw_batch_on_lane(ctx, *ll.L, queries, n_queries, out, bo);
     if (rc == TSGPU_OK && ids_out) *ids_out = lists.release();
@@ -1279,15 +1207,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         } else {
             for (uint32_t i = 0; i < n_queries; i++) bytes += 4ull * off_words[i];
         }
-        if (bo.part_times) {
-            BatchOpts::PartTimes& pt = *bo.part_times;
-            (void)hipEventElapsedTime(&pt.t0, bo.ref_event, L.ev[0]);
-            (void)hipEventElapsedTime(&pt.t_score, bo.ref_event, L.ev[1]);
-            (void)hipEventElapsedTime(&pt.t_merge, bo.ref_event, L.ev[2]);
-            pt.find_marked = find_marked && hit_groups == 1;
-            if (pt.find_marked) (void)hipEventElapsedTime(&pt.t_find, bo.ref_event, L.ev[3]);
-            pt.bytes = bytes; pt.hit_groups = hit_groups; pt.hit_records = hit_records;
-        } else {
+        {
             std::lock_guard<std::mutex> tl(ctx->tm_mu);
             ctx->timings.kw_search_ms = ms_a;
             ctx->timings.kw_merge_ms = ms_b;

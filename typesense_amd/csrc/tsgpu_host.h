@@ -359,8 +359,6 @@ struct tsgpu_ctx {
     uint32_t kw_cost_r_x10 = 10, kw_cost_probe_x100 = 20;  // ... + 0.1 x kw_cost_r_x10 x |B|/|A| + 0.01 x kw_cost_probe_x100 x (stage-1 survivors per block)
     uint32_t kw_cost_fixed = 16;                     // launch-order cost model: item cost = driver blocks x (kw_cost_fixed + |B|/|A|)
     bool kw_sort_work = true;                        // lay the work table out heaviest query first
-    uint32_t kw_stage_min_queries = 4096;            // batches of at least this many queries run as staged parts on several lanes (0 = never; option)
-    hipEvent_t ev_ref = nullptr; hipStream_t ref_stream = nullptr; std::mutex stage_mu;   // reference timestamp of a staged batch
     uint32_t kw_merge_select_min = 17;               // queries with at least this many partial lists are merged by selection (kw_select_partials); 0 = always fold
     bool kw_pair_blocks = true;                      // find kernel variant: two driver blocks per iteration (kw_find2.hip.h)
     bool kw_two_kernels = true;                      // queries of <= 3 tokens: find kernel + score kernel instead of the fused kernel
