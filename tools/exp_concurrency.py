@@ -77,6 +77,17 @@ for nb in (64, 128):
           (nb, dt * 1e6, c["kw_plan_us"], c["kw_upload_us"], c["kw_launch_us"], c["kw_wait_us"], c["kw_book_us"], g.timings().kw_search_ms, g.timings().kw_merge_ms), flush=True)
 
 SWEEP = os.environ.get("SWEEP", "lanes")
+if SWEEP == "capacity":   # what the lanes + the GPU deliver for rounds of a fixed size, without the combiner: T threads, qpc-query calls, no coalescing
+    g.set_option("batch_max_queries", 0)
+    for lanes in (4, 8, 16):
+        g.set_option("kw_lanes", lanes)
+        for qpc in (16, 32, 64, 128):
+            for chunk in (0, 32):
+                g.set_option("kw_chunk_blocks", chunk)
+                r = run(lanes, max(16, 40000 // (lanes * qpc)), qpc)
+                print("capacity lanes=threads %2d qpc %3d chunk %2d: %8.0f q/s p50 %6.0f us | plan %.0f upload %.0f launch %.0f wait %.0f" % (lanes, qpc, chunk, r["qps"], r["p50"], r["plan"], r["upload"], r["launch"], r["wait"]), flush=True)
+    g.close()
+    sys.exit(0)
 if SWEEP == "chunk":      # driver blocks per work item under 256 callers (auto = 8 for rounds of <= 128 queries: the single-call latency optimum)
     combos = [(4, 128, 80, 48, ch) for ch in (0, 16, 32, 64, 0)]
 else:

@@ -1,0 +1,18 @@
+# experiment driver (GPU box): the concurrency leg of the keyword bench under option sets; prints one line per thread count
+# usage: bash tools/exp_run_conc.sh "optA=1,optB=2" "optC=3" ...
+for set in "$@"; do
+  opts=""; for o in ${set//,/ }; do [ "$o" = "-" ] || opts="$opts --opt $o"; done
+  python bench.py --workload keyword --no-cpu-baseline --steps 3 --warmup 1 $opts > /tmp/conc.json 2>/dev/null
+  SET="$set" python - <<P
+import json, os
+d=json.loads(open("/tmp/conc.json").read().strip().splitlines()[-1])
+def find(o):
+    if isinstance(o,dict):
+        if "concurrency" in o: return o["concurrency"]
+        for v in o.values():
+            r=find(v)
+            if r: return r
+print("==", os.environ["SET"], "batch", round(d["value"]), d["ms_per_step"])
+for t,v in find(d).items(): print(t, round(v["value"]), round(v["p50_us"]), round(v["p99_us"]), round(v["queries_per_round"],1), {k:round(x) for k,x in v["us_per_batch"].items()}, v["parity"]["mismatches"])
+P
+done
