@@ -576,7 +576,7 @@ class Bench:
             fails = C.c_uint64(0)
             LG.tsgpu_loadgen_keyword(fn, g.h, C.cast(arr, C.c_void_p), n_q, K_TOPSTER, top, threads, max(2, calls // 8), 1, lat.ctypes.data, got.ctypes.data, C.byref(fails))   # warm-up
             r0, c0 = g.counter("batch_rounds"), g.counter("batch_coalesced_calls")
-            PH = ("kw_batches", "kw_plan_us", "kw_upload_us", "kw_launch_us", "kw_wait_us", "kw_book_us", "batch_exec_us", "batch_scatter_us")
+            PH = ("kw_batches", "kw_plan_us", "kw_upload_us", "kw_launch_us", "kw_wait_us", "kw_book_us", "batch_exec_us", "batch_scatter_us", "kw_queue_us", "kw_wake_us")
             ph0 = [g.counter(n) for n in PH]
             cg0 = cgroup_cpu()
             wall = LG.tsgpu_loadgen_keyword(fn, g.h, C.cast(arr, C.c_void_p), n_q, K_TOPSTER, top, threads, calls, 1, lat.ctypes.data, got.ctypes.data, C.byref(fails))
@@ -584,11 +584,12 @@ class Bench:
             rounds, ccalls = g.counter("batch_rounds") - r0, g.counter("batch_coalesced_calls") - c0
             ph = dict(zip(PH, (g.counter(n) - a for n, a in zip(PH, ph0))))
             nb = max(1, ph.pop("kw_batches"))
+            per_call = {"parked_to_round_start": ph.pop("kw_queue_us") / max(1, ccalls), "results_ready_to_caller_resumes": ph.pop("kw_wake_us") / max(1, ccalls)}
             touched = got != 0
             out[str(threads)] = {"threads": threads, "calls": threads * calls, "queries_per_call": 1, "value": threads * calls / wall, "unit": "queries/s",
                                  "p50_us": float(np.percentile(lat, 50)), "p99_us": float(np.percentile(lat, 99)), "failures": int(fails.value),
                                  "queries_per_round": (ccalls / rounds) if rounds else 1.0, "mean_us": float(lat.mean()), "max_us": float(lat.max()),
-                                 "batches_per_s": nb / wall, "us_per_batch": {k_[:-3]: v_ / nb for k_, v_ in ph.items()},
+                                 "batches_per_s": nb / wall, "us_per_batch": {k_[:-3]: v_ / nb for k_, v_ in ph.items()}, "us_per_coalesced_call": per_call,
                                  "host_cpu": {"cpu_us_per_call": (cg1[0] - cg0[0]) / (threads * calls), "cpus_busy": (cg1[0] - cg0[0]) / (wall * 1e6),
                                               "cgroup_cpu_quota_cpus": cg1[3], "throttled_periods": cg1[1] - cg0[1], "throttled_thread_ms": (cg1[2] - cg0[2]) / 1e3},
                                  "parity": {"checked": int(touched.sum()), "mismatches": int((got[touched] != want[touched]).sum()),

@@ -117,9 +117,16 @@ int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
  * (identical result sets either way), "vec_count_rescored" = 1: keep the vec_rescored_rows counter (costs one sync);
  * micro-batcher: "batch_max_queries" = calls with at most this many queries are coalesced with concurrent callers (default 64,
  * 0 = never), "batch_window_us" = how long a round's leader waits for the other threads that are inside the entry point to
- * park (default 80), "batch_round_queries" = queries per coalesced round at most (default 1024);
+ * park (default 10: a lane that is free should not idle; while every lane is busy callers keep parking and the rounds size
+ * themselves), "batch_round_queries" = queries per coalesced round at most (default 1024);
  * "kw_merge_select_min" = from this many per-work-item Topsters per query the merge selects (threshold of the k-th largest of a
- * prefix union, then gather + sort) instead of folding pairwise (default 17; 0 = always fold; identical results);
+ * prefix union, then the candidates above it; both ordered by a tree of pairwise rank merges in LDS) instead of folding one list
+ * after the other (default 2; 0 = always fold; identical results);
+ * "kw_zero_copy_max_queries" = keyword batches with host output and at most this many queries have their merge kernel write the
+ * result image straight into the lane's pinned host buffer, no device-to-host copy (default 256; 0 = always copy);
+ * "kw_timing_min_queries" = keyword batches below this many queries record no phase events (tsgpu_last_timings then reports 0 ms
+ * for them; default 64: the four marker packets cost a 1-query call ~20 us of its ~80; 0 = always record; coalesced rounds never
+ * record);
  * host side: "plan_threads" (default 8) / "plan_parallel_min_queries" (default 2048) = the work table of a batch with at least
  * that many queries is planned in slices on the context's parked host threads, "fuse_threads" (default 32) = host threads of the
  * hybrid fusion, "blocking_sync_min_callers" (default 48) = from this many threads inside the keyword entry point a round is
@@ -130,7 +137,10 @@ int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
 int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value);
 /* introspection counters (tests / bench): "vec_overflow_rounds", "vec_prefilter_groups", "vec_prefilter_fallbacks",
  * "vec_rescored_rows", "kw_last_hit_groups" (find+score groups of the last keyword batch, 0 = fused), "kw_last_hit_records",
- * "batch_rounds" / "batch_coalesced_calls" (micro-batcher: rounds executed / calls they served) */
+ * "batch_rounds" / "batch_coalesced_calls" (micro-batcher: rounds executed / calls they served), host phase totals in us over all
+ * keyword batches ("kw_batches", "kw_plan_us", "kw_upload_us", "kw_launch_us", "kw_wait_us", "kw_book_us", "batch_exec_us",
+ * "batch_scatter_us") and over all coalesced calls ("kw_queue_us" = parked -> its round starts, "kw_wake_us" = results ready ->
+ * the caller runs again) */
 int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out);
 /* bytes of HBM held by the context's index mirrors */
 uint64_t tsgpu_device_bytes(tsgpu_ctx* ctx);

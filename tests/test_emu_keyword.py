@@ -585,7 +585,7 @@ def test_edge_cases_empty_index_missing_tokens_and_degenerate_topsters():
     g.close()
 
 
-@pytest.mark.parametrize("select_min", [17, 0, 3])
+@pytest.mark.parametrize("select_min", [2, 17, 0, 3])
 def test_two_level_merge_many_work_items(select_min):
     """a query cut into more than 16 work items: merged by selection (kw_select_partials: prefix union -> threshold -> candidates -> sort;
     select_min = 3: also the queries with few lists) or, kw_merge_select_min = 0, folded in groups of 8 (kw_merge_groups_kernel), then per query"""
@@ -594,10 +594,14 @@ def test_two_level_merge_many_work_items(select_min):
     g.set_option("kw_merge_select_min", select_min)
     g.set_option("kw_chunk_blocks", 1)
     sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    # Topster sizes around the selecting merge's regimes: prefix union / candidates within half the LDS buffer (tree of rank merges),
+    # beyond it (2k > 512: bitonic sort), and k close to the whole result (few entries: everything gathered)
     qs = [T.KwQuery([1], sort=sort, topster_size=40), T.KwQuery([2, 1], sort=sort, topster_size=250), T.KwQuery([3, 1, 2], sort=sort, topster_size=7),
-          T.KwQuery([1, 2], sort=sort, topster_size=250, filter_ids=np.arange(0, 6200, 3, dtype=np.uint32))]
+          T.KwQuery([1, 2], sort=sort, topster_size=250, filter_ids=np.arange(0, 6200, 3, dtype=np.uint32)),
+          T.KwQuery([1], sort=sort, topster_size=400), T.KwQuery([2, 1], sort=sort, topster_size=510), T.KwQuery([1], sort=sort, topster_size=300),
+          T.KwQuery([1, 2], sort=sort, topster_size=500, filter_ids=np.arange(0, 6200, 9, dtype=np.uint32))]
     assert g.term_num_ids(0, 1) > 17 * 256
-    hits = g.keyword_search_batch(qs, k_stride=250)
+    hits = g.keyword_search_batch(qs, k_stride=512)
     assert (hits.status == 0).all()
     for i, q in enumerate(qs):
         H.assert_hits_equal(hits, i, H.oracle_keyword(orc, q), "two-level merge")

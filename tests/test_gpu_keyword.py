@@ -308,7 +308,7 @@ def test_candidate_combinations_on_2m_docs(c2m):
         assert np.array_equal(g.candidates_result_ids(gi), ref.result_ids)
 
 
-@pytest.mark.parametrize("select_min", [17, 0])
+@pytest.mark.parametrize("select_min", [2, 17, 0])
 def test_many_work_items_two_level_merge_on_2m_docs(c2m, select_min):
     """kw_chunk_blocks = 1: the frequent terms' queries are cut into hundreds of work items -> merged by selection (kw_select_partials; past
     384 lists or 1 024 candidates: folded), or with kw_merge_select_min = 0 by kw_merge_groups_kernel + kw_merge_kernel"""
@@ -316,14 +316,15 @@ def test_many_work_items_two_level_merge_on_2m_docs(c2m, select_min):
     c2m.g.set_option("kw_merge_select_min", select_min)
     try:
         qtok = synth.keyword_queries(24, 3, 1, 60, seed=41)
-        qs = [T.KwQuery(q, sort=SORT, topster_size=250) for q in qtok] + [T.KwQuery([3], sort=SORT, topster_size=100)]
-        hits = c2m.g.keyword_search_batch(qs, k_stride=250)
+        qs = [T.KwQuery(q, sort=SORT, topster_size=250) for q in qtok] + [T.KwQuery([3], sort=SORT, topster_size=100)] + \
+             [T.KwQuery(q, sort=SORT, topster_size=ts) for q, ts in zip(qtok[:6], (400, 510, 300, 64, 500, 7))]      # (2k beyond half the LDS buffer: sorted, not tree-merged)
+        hits = c2m.g.keyword_search_batch(qs, k_stride=512)
         assert (hits.status == 0).all()
         for i, q in enumerate(qs):
             H.assert_hits_equal(hits, i, c2m.oracle(q), "two-level merge 2M")
     finally:
         c2m.g.set_option("kw_chunk_blocks", 0)
-        c2m.g.set_option("kw_merge_select_min", 17)
+        c2m.g.set_option("kw_merge_select_min", 2)
 
 
 def test_deadline_in_flight_partial_hits_on_2m_docs(c2m):

@@ -35,3 +35,24 @@ for q, v in sorted(byq.items()):
                 shown += 1
             chain = []
         chain.append((s, e, n, wg))
+# the big batch: the last run of >= 20 consecutive launches (gaps < 200 us) on one queue that contains launches of > 4096 workgroups
+import os
+if os.environ.get("BIG"):
+    for q, v in sorted(byq.items()):
+        runs, cur = [], []
+        for s, e, n, wg in v:
+            if cur and s - cur[-1][1] > 200000: runs.append(cur); cur = []
+            cur.append((s, e, n, wg))
+        runs.append(cur)
+        runs = [r for r in runs if sum(1 for c in r if c[3] > 4096 and "kw_find2" in c[2]) >= 4]
+        if not runs: continue
+        r = [c for c in runs[-1]]
+        firsts = [i for i, c in enumerate(r) if "kw_find2" in c[2]]
+        r = r[max(0, firsts[0] - 3):]
+        t0 = r[0][0]
+        print("big batch on queue %s: %d launches, span %.1f us, kernel time %.1f us" % (q, len(r), (r[-1][1] - t0) / 1e3, sum(c[1] - c[0] for c in r) / 1e3))
+        prev = t0
+        for c in r:
+            print("  %-34s wg %6d  start +%8.1f  dur %7.1f  gap %5.1f" % (c[2].replace("void tsgpu::", "").replace("__amd_rocclr_", "")[:34], c[3], (c[0] - t0) / 1e3, (c[1] - c[0]) / 1e3, (c[0] - prev) / 1e3))
+            prev = c[1]
+        break

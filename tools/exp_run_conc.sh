@@ -13,6 +13,6 @@ def find(o):
             r=find(v)
             if r: return r
 print("==", os.environ["SET"], "batch", round(d["value"]), d["ms_per_step"])
-for t,v in find(d).items(): print(t, round(v["value"]), round(v["p50_us"]), round(v["p99_us"]), round(v["queries_per_round"],1), {k:round(x) for k,x in v["us_per_batch"].items()}, v["parity"]["mismatches"])
+for t,v in find(d).items(): print(t, round(v["value"]), round(v["p50_us"]), round(v["p99_us"]), round(v["queries_per_round"],1), {k:round(x) for k,x in v["us_per_batch"].items()}, {k[:6]:round(x) for k,x in v["us_per_coalesced_call"].items()}, v["parity"]["mismatches"])
 P
 done

@@ -1849,6 +1849,7 @@ struct KwSelectLds {
     TopkLds<KW_SEL_CCAP, true> cb;
     uint32_t cnt[KW_SEL_PMAX], take[KW_SEL_PMAX], off[KW_SEL_PMAX + 1], wsum[KW_THREADS / 64];
     uint32_t total, n_nonempty, ok;
+    int64_t tau[4];
 };
 __device__ inline bool kw_select_partials(KwSelectLds& sl, const KwPartials& part, uint32_t first, uint32_t P, uint32_t k, const KwOut& out, size_t ob, int msi,
                                           uint32_t& n_out) {
@@ -1870,17 +1871,82 @@ __device__ inline bool kw_select_partials(KwSelectLds& sl, const KwPartials& par
     (void)my_nne;
     const uint32_t total = sl.total, nne = sl.n_nonempty;
     if (total == 0) { n_out = 0; return true; }
-    // gathers take[w] leading entries of every list into cb (padded to a power of two), sorted descending; returns the count
-    auto gather_sorted = [&]() -> uint32_t {
+    auto emit = [&](uint32_t i, int64_t a0, int64_t a1, int64_t a2, int64_t ak) {
+        out.keys[ob + i] = (uint64_t)ak;
+        out.scores[(ob + i) * 3 + 0] = a0; out.scores[(ob + i) * 3 + 1] = a1; out.scores[(ob + i) * 3 + 2] = a2;
+        out.text_match[ob + i] = msi == 0 ? a0 : (msi == 1 ? a1 : (msi == 2 ? a2 : 0));
+        out.vector_distance[ob + i] = -1.0f;
+        out.match_score_index[ob + i] = (int8_t)msi;
+    };
+    // gathers take[w] leading entries of every list and calls fn(rank, entry) for each with its place in the descending order of the
+    // gathered set; returns the count (0 and !ok: more than the buffer holds).
+    //   * up to HALF entries: a TREE of pairwise merges by rank. The lists are sorted and keys are unique, so merging two neighbouring
+    //     segments moves an entry to (index in its own segment) + (entries of the partner segment that are greater): one LDS binary
+    //     search per entry and level, log2(P) levels, one barrier each, ping-pong between the two halves of the buffer; an entry stays
+    //     in its thread's registers from the gather to its final rank. (36 lists: 6 levels ~ 1 us each — the bitonic sort of 512 slots
+    //     is 45 barrier stages, ~30 us for the ONE workgroup a small round's query has: profiles/r03/exp_concurrency_analysis.txt)
+    //   * more: padded to a power of two and sorted (bitonic), as before.
+    constexpr uint32_t HALF = KW_SEL_CCAP / 2;
+    constexpr int RPT = (int)(HALF / KW_THREADS);
+    auto gather_ordered = [&](auto&& fn) -> uint32_t {
         block_excl_scan(sl.take, sl.off, P, sl.wsum);
         if (t == 0 && sl.off[P] > (uint32_t)KW_SEL_CCAP) sl.ok = 0;
         __syncthreads();
         if (!sl.ok) return 0;
         const uint32_t C = sl.off[P];
+        if (C <= HALF) {
+            int64_t e0[RPT], e1[RPT], e2[RPT], ek[RPT];
+            uint32_t ew[RPT], pos[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const uint32_t i = r * KW_THREADS + t;
+                pos[r] = i;
+                if (i < C) {                             // entry i belongs to the list w with off[w] <= i < off[w + 1]
+                    uint32_t lo = 0, hi = P;
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sl.off[mid] <= i) lo = mid; else hi = mid; }
+                    const size_t e = (size_t)(first + lo) * part.k_stride + (i - sl.off[lo]);
+                    ew[r] = lo;
+                    e0[r] = part.s0[e]; e1[r] = part.s1[e]; e2[r] = part.s2[e]; ek[r] = part.key[e];
+                    sl.cb.s0[i] = e0[r]; sl.cb.s1[i] = e1[r]; sl.cb.s2[i] = e2[r]; sl.cb.key[i] = ek[r];
+                }
+            }
+            __syncthreads();
+            uint32_t cur = 0;                            // the half that holds the current level's segments
+            for (uint32_t span = 1; span < P; span <<= 1) {          // segments of `span` lists merge pairwise (uniform loop)
+#pragma unroll
+                for (int r = 0; r < RPT; r++) {
+                    if (r * KW_THREADS + t < C) {
+                        const uint32_t seg = ew[r] / span, own_list = seg * span, pair_list = (seg & ~1u) * span, other_list = (seg ^ 1u) * span;
+                        uint32_t lo = sl.off[other_list < P ? other_list : P], hi = sl.off[other_list + span < P ? other_list + span : P];
+                        const uint32_t a = lo;
+                        while (lo < hi) {                // first entry of the partner segment that is NOT greater than this one
+                            const uint32_t mid = (lo + hi) >> 1;
+                            const int64_t m0 = sl.cb.s0[cur + mid];
+                            bool gt;
+                            if (m0 != e0[r]) gt = m0 > e0[r];
+                            else {
+                                const int64_t m1 = sl.cb.s1[cur + mid], m2 = sl.cb.s2[cur + mid];
+                                gt = m1 != e1[r] ? m1 > e1[r] : (m2 != e2[r] ? m2 > e2[r] : sl.cb.key[cur + mid] > ek[r]);
+                            }
+                            if (gt) lo = mid + 1; else hi = mid;
+                        }
+                        pos[r] = sl.off[pair_list] + (pos[r] - sl.off[own_list]) + (lo - a);
+                        const uint32_t d = (cur ^ HALF) + pos[r];
+                        sl.cb.s0[d] = e0[r]; sl.cb.s1[d] = e1[r]; sl.cb.s2[d] = e2[r]; sl.cb.key[d] = ek[r];
+                    }
+                }
+                __syncthreads();
+                cur ^= HALF;
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; r++) if (r * KW_THREADS + t < C) fn(pos[r], e0[r], e1[r], e2[r], ek[r]);
+            __syncthreads();                             // (the buffer may be gathered into again)
+            return C;
+        }
         uint32_t n2 = 2;
         while (n2 < C) n2 <<= 1;
         for (uint32_t i = t; i < n2; i += KW_THREADS) {
-            if (i < C) {                                 // entry i belongs to the list w with off[w] <= i < off[w + 1]
+            if (i < C) {
                 uint32_t lo = 0, hi = P;
                 while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sl.off[mid] <= i) lo = mid; else hi = mid; }
                 const size_t e = (size_t)(first + lo) * part.k_stride + (i - sl.off[lo]);
@@ -1888,22 +1954,30 @@ __device__ inline bool kw_select_partials(KwSelectLds& sl, const KwPartials& par
             } else sl.cb.key[i] = -1;                    // padding sorts last
         }
         topk_sort<KW_SEL_CCAP, true>(sl.cb, (int)n2);   // (starts and ends with a barrier)
+        for (uint32_t i = t; i < C; i += KW_THREADS) fn(i, sl.cb.s0[i], sl.cb.s1[i], sl.cb.s2[i], sl.cb.key[i]);
+        __syncthreads();
         return C;
     };
+    auto emit_top = [&](uint32_t rank, int64_t a0, int64_t a1, int64_t a2, int64_t ak) { if (rank < k) emit(rank, a0, a1, a2, ak); };
     uint32_t C;
-    if (total <= (uint32_t)KW_SEL_CCAP) {
-        for (uint32_t w = t; w < P; w += KW_THREADS) sl.take[w] = sl.cnt[w];          // few entries altogether: all of them
+    if (total <= HALF || total <= k) {
+        for (uint32_t w = t; w < P; w += KW_THREADS) sl.take[w] = sl.cnt[w];          // few entries altogether: all of them (one tree merge)
         __syncthreads();
-        C = gather_sorted();
+        C = gather_ordered(emit_top);
     } else {
-        const uint32_t m = (2 * k + nne - 1) / nne;      // prefixes: >= 2k entries offered in total (total > CCAP >= k)
+        uint32_t m = (2 * k + nne - 1) / nne;            // prefixes: ~2k entries offered in total (total > k)
+        // (any prefix length whose union holds k entries gives a valid bound; one that keeps the union within HALF takes the tree path)
+        if (m * nne > HALF && (HALF / nne) * nne >= k + k / 4) m = HALF / nne;
         for (uint32_t w = t; w < P; w += KW_THREADS) { const uint32_t c = sl.cnt[w]; sl.take[w] = c < m ? c : m; }
         __syncthreads();
-        const uint32_t S = gather_sorted();
-        if (!sl.ok || S < k) return false;               // (S < k: many short lists next to a few long ones — the bound needs k prefix entries)
-        const int64_t u0 = sl.cb.s0[k - 1], u1 = sl.cb.s1[k - 1], u2 = sl.cb.s2[k - 1], uk = sl.cb.key[k - 1];         // tau
-        __syncthreads();
+        const uint32_t S = gather_ordered([&](uint32_t rank, int64_t a0, int64_t a1, int64_t a2, int64_t ak) {
+            if (rank == k - 1) { sl.tau[0] = a0; sl.tau[1] = a1; sl.tau[2] = a2; sl.tau[3] = ak; } });
+        if (!sl.ok) return false;
+        const bool bound = S >= k;                       // (S < k: many short lists next to a few long ones — the bound needs k prefix entries)
+        if (!bound && total > (uint32_t)KW_SEL_CCAP) return false;
+        const int64_t u0 = sl.tau[0], u1 = sl.tau[1], u2 = sl.tau[2], uk = sl.tau[3];         // tau
         for (uint32_t w = t; w < P; w += KW_THREADS) {
+            if (!bound) { sl.take[w] = sl.cnt[w]; continue; }       // no bound, but everything fits the buffer: all entries, sorted
             const uint32_t c = sl.cnt[w], mw = c < m ? c : m;
             const size_t base = (size_t)(first + w) * part.k_stride;
             uint32_t lo = 0, hi = c;                     // first index whose entry is LESS than tau (tau itself counts)
@@ -1918,18 +1992,10 @@ __device__ inline bool kw_select_partials(KwSelectLds& sl, const KwPartials& par
             sl.take[w] = lo;
         }
         __syncthreads();
-        C = gather_sorted();
+        C = gather_ordered(emit_top);
     }
     if (!sl.ok) return false;
     n_out = C < k ? C : k;
-    for (uint32_t i = t; i < n_out; i += KW_THREADS) {
-        const int64_t a0 = sl.cb.s0[i], a1 = sl.cb.s1[i], a2 = sl.cb.s2[i];
-        out.keys[ob + i] = (uint64_t)sl.cb.key[i];
-        out.scores[(ob + i) * 3 + 0] = a0; out.scores[(ob + i) * 3 + 1] = a1; out.scores[(ob + i) * 3 + 2] = a2;
-        out.text_match[ob + i] = msi == 0 ? a0 : (msi == 1 ? a1 : (msi == 2 ? a2 : 0));
-        out.vector_distance[ob + i] = -1.0f;
-        out.match_score_index[ob + i] = (int8_t)msi;
-    }
     return true;
 }
 

@@ -233,6 +233,8 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_sort_work")) { ctx->kw_sort_work = value != 0; return ok(); }
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
     if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
+    if (!strcmp(name, "kw_zero_copy_max_queries")) { ctx->kw_zero_copy_max_queries = (uint32_t)std::max<int64_t>(0, value); return ok(); }
+    if (!strcmp(name, "kw_timing_min_queries")) { ctx->kw_timing_min_queries = (uint32_t)std::max<int64_t>(0, value); return ok(); }
     if (!strcmp(name, "kw_merge_select_min")) { ctx->kw_merge_select_min = (uint32_t)std::max<int64_t>(0, value); return ok(); }
     if (!strcmp(name, "hnsw_visited_hash")) { ctx->hnsw_visited_hash = value != 0; return ok(); }
     if (!strcmp(name, "hnsw_visited_max_gib")) { ctx->hnsw_visited_max_gib = (int)std::min<int64_t>(std::max<int64_t>(1, value), 128); return ok(); }
@@ -314,6 +316,8 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!strcmp(name, "kw_max_upload_us")) { *out = ctx->kw_max_upload_us.exchange(0); return ok(); }
     if (!strcmp(name, "kw_max_launch_us")) { *out = ctx->kw_max_launch_us.exchange(0); return ok(); }
     if (!strcmp(name, "kw_max_wait_us")) { *out = ctx->kw_max_wait_us.exchange(0); return ok(); }
+    if (!strcmp(name, "kw_queue_us")) { *out = ctx->kw_queue_us.load(); return ok(); }
+    if (!strcmp(name, "kw_wake_us")) { *out = ctx->kw_wake_us.load(); return ok(); }
     if (!strcmp(name, "kw_max_queue_us")) { *out = ctx->kw_max_queue_us.exchange(0); return ok(); }     // parked -> its round starts executing
     if (!strcmp(name, "kw_max_wake_us")) { *out = ctx->kw_max_wake_us.exchange(0); return ok(); }       // results ready -> the caller runs again
     if (!strcmp(name, "kw_upload_us")) { *out = ctx->kw_upload_us.load(); return ok(); }
@@ -685,9 +689,13 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
         // descending cost, ties in query order: LSD radix sort of the float bits (costs are non-negative, so the bits order like the
         // values), two stable counting passes of 16 bits (std::sort of 10 000 keys was 0.33 ms of a 0.95 ms plan; a coarser one-pass
         // bucket order measurably lengthened the find kernel's tail)
-        std::vector<uint32_t> key(n_queries), tmp(n_queries), hist(65537);
+        // (the two 65 536-entry histograms are a FIXED ~30 us: a small round — the 1-query calling convention — sorts by comparison)
+        std::vector<uint32_t> key(n_queries);
         for (uint32_t i = 0; i < n_queries; i++) { const float c = (float)item_cost[i]; uint32_t bits; memcpy(&bits, &c, 4); key[i] = 0xFFFFFFFFu - bits; }
-        for (int pass = 0; pass < 2; pass++) {
+        const bool radix = n_queries >= 2048;
+        if (!radix && n_queries > 1) std::stable_sort(by_cost.begin(), by_cost.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+        std::vector<uint32_t> tmp(radix ? n_queries : 0), hist(radix ? 65537 : 0);
+        for (int pass = 0; radix && pass < 2; pass++) {
             const int sh = pass * 16;
             std::fill(hist.begin(), hist.end(), 0u);
             for (uint32_t i = 0; i < n_queries; i++) hist[((key[by_cost[i]] >> sh) & 0xFFFFu) + 1]++;
@@ -752,6 +760,9 @@ struct BatchOpts {
     std::vector<int32_t>* cutoff_host = nullptr;      // ... and the per-query search_cutoff flags
     tsgpu_id_lists* id_lists = nullptr;               // when set: the matched ids of every query, gathered + downloaded (implies keep_ids)
     bool record_last = true;                          // remember the id segments for the legacy tsgpu_result_ids API
+    bool alias_out = false;                           // host output through the lane's pinned image: point `out`'s arrays INTO the image instead of copying
+                                                      // them out (the coalesced round hands every caller its slice straight from there)
+    bool timing = true;                               // record the phase events (tsgpu_timings); a coalesced round has no single caller to report to
 };
 }
 static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, const BatchOpts& bo);
@@ -820,8 +831,9 @@ static int kw_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t 
             uint32_t at = 0;
             for (KwRequest* r : round) { memcpy(L.c_q.data() + at, r->q, (size_t)r->units * sizeof(tsgpu_kw_query)); at += r->units; }
             const size_t slots = (size_t)total * KS;
-            L.c_keys.resize(slots); L.c_scores.resize(slots * 3); L.c_tm.resize(slots); L.c_vd.resize(slots); L.c_msi.resize(slots);
-            L.c_nh.resize(total); L.c_nm.resize(total); L.c_st.resize(total); L.c_co.resize(total);
+            auto grow = [](auto& v, size_t n) { if (v.size() < n) v.resize(n); };     // (grow-only: a shrink + regrow zero-fills the difference every round)
+            grow(L.c_keys, slots); grow(L.c_scores, slots * 3); grow(L.c_tm, slots); grow(L.c_vd, slots); grow(L.c_msi, slots);
+            grow(L.c_nh, total); grow(L.c_nm, total); grow(L.c_st, total); grow(L.c_co, total);
             tsgpu_hits h;
             h.mem = TSGPU_MEM_HOST; h.k_stride = KS;
             h.keys = L.c_keys.data(); h.scores = L.c_scores.data(); h.text_match = L.c_tm.data(); h.vector_distance = L.c_vd.data();
@@ -831,8 +843,12 @@ static int kw_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t 
             bo.keep_ids = want_ids;
             bo.id_lists = want_ids ? &all_ids : nullptr;
             bo.record_last = false;
+            bo.timing = false;
+            bo.alias_out = true;                     // h's arrays may come back pointing into the lane's pinned result image
             const uint64_t te0 = now_us();
-            for (KwRequest* r : round) amax(ctx->kw_max_queue_us, te0 - r->t_arrive);
+            uint64_t qsum = 0;
+            for (KwRequest* r : round) { amax(ctx->kw_max_queue_us, te0 - r->t_arrive); qsum += te0 - r->t_arrive; }
+            ctx->kw_queue_us.fetch_add(qsum);
             rc = kw_batch_on_lane(ctx, L, L.c_q.data(), total, &h, bo);
             const uint64_t te1 = now_us();
             ctx->batch_exec_us.fetch_add(te1 - te0);
@@ -844,19 +860,19 @@ static int kw_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t 
                     const uint32_t ks = o.k_stride;
                     for (uint32_t i = 0; i < r->units; i++) {
                         const uint32_t g = at + i;
-                        int32_t st = L.c_st[g];
-                        uint32_t n = L.c_nh[g];
+                        int32_t st = h.status[g];
+                        uint32_t n = h.n_hits[g];
                         if (st == TSGPU_OK && n > ks) { st = TSGPU_ERR_INVALID; n = 0; }       // (this caller's k_stride is smaller than its topster_size)
                         o.status[i] = st;
                         o.n_hits[i] = n;
-                        if (o.num_matched) o.num_matched[i] = st == TSGPU_OK ? L.c_nm[g] : 0;
-                        if (o.search_cutoff) o.search_cutoff[i] = L.c_co[g];
+                        if (o.num_matched) o.num_matched[i] = st == TSGPU_OK ? h.num_matched[g] : 0;
+                        if (o.search_cutoff) o.search_cutoff[i] = h.search_cutoff[g];
                         const size_t src = (size_t)g * KS, dst = (size_t)i * ks;
-                        memcpy(o.keys + dst, L.c_keys.data() + src, (size_t)n * 8);
-                        memcpy(o.scores + dst * 3, L.c_scores.data() + src * 3, (size_t)n * 24);
-                        if (o.text_match) memcpy(o.text_match + dst, L.c_tm.data() + src, (size_t)n * 8);
-                        if (o.vector_distance) memcpy(o.vector_distance + dst, L.c_vd.data() + src, (size_t)n * 4);
-                        if (o.match_score_index) memcpy(o.match_score_index + dst, L.c_msi.data() + src, (size_t)n);
+                        memcpy(o.keys + dst, h.keys + src, (size_t)n * 8);
+                        memcpy(o.scores + dst * 3, h.scores + src * 3, (size_t)n * 24);
+                        if (o.text_match) memcpy(o.text_match + dst, h.text_match + src, (size_t)n * 8);
+                        if (o.vector_distance) memcpy(o.vector_distance + dst, h.vector_distance + src, (size_t)n * 4);
+                        if (o.match_score_index) memcpy(o.match_score_index + dst, h.match_score_index + src, (size_t)n);
                     }
                     if (r->ids) {
                         r->ids->begin.resize((size_t)r->units + 1);
@@ -873,7 +889,7 @@ static int kw_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t 
         for (KwRequest* r : round) { r->rc = rc; r->err = err; r->t_done = td; }
     };
     ctx->kw_comb.run(me, ctx->kw_callers, ctx->batch_window_us, acquire, pick, exec);
-    if (me.t_done) amax(ctx->kw_max_wake_us, now_us() - me.t_done);
+    if (me.t_done) { const uint64_t w = now_us() - me.t_done; amax(ctx->kw_max_wake_us, w); ctx->kw_wake_us.fetch_add(w); }
     if (me.rc != TSGPU_OK) return fail(me.rc, me.err);
     if (ids_out) *ids_out = lists.release();
     return ok();
@@ -1030,6 +1046,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         o.off_words = L.d_out_ow.as<uint64_t>();
         size_t out_at[8] = {0, 0, 0, 0, 0, 0, 0, 0}, out_bytes = 0;
         const bool dev_out = out->mem == TSGPU_MEM_DEVICE;
+        bool zero_copy = false;
         if (dev_out) {
             if (!out->text_match || !out->vector_distance || !out->match_score_index || !out->num_matched)
                 return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: device output needs every tsgpu_hits array");
@@ -1042,8 +1059,12 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             out_at[0] = 0; out_at[1] = nq8; out_at[2] = out_at[1] + (size_t)n_queries * 8; out_at[3] = out_at[2] + (size_t)n_queries * 8;
             out_at[4] = out_at[3] + slots * 8; out_at[5] = out_at[4] + slots * 24; out_at[6] = out_at[5] + slots * 8; out_at[7] = out_at[6] + ((slots * 4 + 7) & ~(size_t)7);
             out_bytes = out_at[7] + ((slots + 7) & ~(size_t)7);
-            if ((rc = L.d_out_keys.reserve(out_bytes))) return rc;
-            uint8_t* ob = (uint8_t*)L.d_out_keys.p;
+            // a SMALL round's merge kernel writes the image straight into the lane's pinned host buffer (device-visible, coherent): no
+            // device-to-host copy kernel (4-25 us) and no launch gap (~6 us) behind the merge; only the hits themselves cross the link
+            zero_copy = out_bytes <= (8u << 20) && n_queries <= ctx->kw_zero_copy_max_queries;
+            if (zero_copy) { if ((rc = L.h_out.reserve(out_bytes + 64))) return rc; }
+            else if ((rc = L.d_out_keys.reserve(out_bytes))) return rc;
+            uint8_t* ob = zero_copy ? (uint8_t*)L.h_out.p : (uint8_t*)L.d_out_keys.p;
             o.n_hits = (uint32_t*)(ob + out_at[0]); o.num_matched = (uint64_t*)(ob + out_at[1]); o.off_words = (uint64_t*)(ob + out_at[2]);
             o.keys = (uint64_t*)(ob + out_at[3]); o.scores = (int64_t*)(ob + out_at[4]); o.text_match = (int64_t*)(ob + out_at[5]);
             o.vector_distance = (float*)(ob + out_at[6]); o.match_score_index = (int8_t*)(ob + out_at[7]);
@@ -1070,7 +1091,8 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         const KwQueryDev* dq = (const KwQueryDev*)(dplan + at_q);
         const KwWorkItem* dw = (const KwWorkItem*)(dplan + at_w);
         const uint32_t* daux = (const uint32_t*)(dplan + at_aux);
-        TSGPU_HIP_TRY(hipEventRecord(L.ev[0], s));
+        const bool timing = bo.timing && n_queries >= ctx->kw_timing_min_queries;      // (each record is a marker packet in the stream: ~2 us of a small round)
+        if (timing) TSGPU_HIP_TRY(hipEventRecord(L.ev[0], s));
         auto shifted = [&](size_t sh) {                 // every kernel indexes the partials by its own blockIdx: shift the bases
             KwPartials pb = part;
             pb.s0 += sh * KS; pb.s1 += sh * KS; pb.s2 += sh * KS; pb.key += sh * KS;
@@ -1103,7 +1125,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
                     else {
                         const bool mark = !find_marked;
                         find_marked = true;
-                        launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, L.d_hits.as<uint32_t>(), hoff_dev + a, mark ? L.ev[3] : nullptr, ctx->kw_pair_blocks);
+                        launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, L.d_hits.as<uint32_t>(), hoff_dev + a, mark && timing ? L.ev[3] : nullptr, ctx->kw_pair_blocks);
                     }
                 }
             } else if constexpr (MFT) launch_search_mf_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out);
@@ -1123,7 +1145,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             else if (cap == 1024) hipLaunchKernelGGL((kw_wildcard_kernel<1024>), dim3(nw), dim3(KW_THREADS), 0, s, v, dq, dw + sh, shifted(sh), daux, ids_out);
             else hipLaunchKernelGGL((kw_wildcard_kernel<2048>), dim3(nw), dim3(KW_THREADS), 0, s, v, dq, dw + sh, shifted(sh), daux, ids_out);
         }
-        TSGPU_HIP_TRY(hipEventRecord(L.ev[1], s));
+        if (timing) TSGPU_HIP_TRY(hipEventRecord(L.ev[1], s));
         if (!P.groups.empty()) {
             const KwMergeGroup* dg = (const KwMergeGroup*)(dplan + at_grp);
             const uint32_t ng = (uint32_t)P.groups.size();
@@ -1132,7 +1154,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             else hipLaunchKernelGGL((kw_merge_groups_kernel<2048>), dim3(ng), dim3(KW_THREADS), 0, s, dq, part, dg);
         }
         launch_merge(cap, s, n_queries, dq, part, o, ids_out, dw, ctx->kw_merge_select_min);
-        TSGPU_HIP_TRY(hipEventRecord(L.ev[2], s));
+        if (timing) TSGPU_HIP_TRY(hipEventRecord(L.ev[2], s));
         TSGPU_HIP_TRY(hipGetLastError());
         const uint64_t t_launched = now_us();
 
@@ -1143,21 +1165,33 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             // large ones: straight to the caller's arrays (the runtime pipelines them)
             const bool stage = out_bytes <= (8u << 20);
             if (stage) {
-                if ((rc = L.h_out.reserve(out_bytes + 64))) return rc;
-                TSGPU_HIP_TRY(hipMemcpyAsync(L.h_out.p, L.d_out_keys.p, out_bytes, hipMemcpyDeviceToHost, s));
+                if (!zero_copy) {
+                    if ((rc = L.h_out.reserve(out_bytes + 64))) return rc;
+                    TSGPU_HIP_TRY(hipMemcpyAsync(L.h_out.p, L.d_out_keys.p, out_bytes, hipMemcpyDeviceToHost, s));
+                }
                 // (a spinning wait costs one CPU per lane for the whole round: with many request threads — and a CPU quota — the waiting
                 //  thread sleeps on a blocking event instead: +20-40 us of latency, four CPUs back)
                 if (ctx->kw_callers.load() >= ctx->blocking_sync_min_callers) { TSGPU_HIP_TRY(hipEventRecord(L.ev_block, s)); TSGPU_HIP_TRY(hipEventSynchronize(L.ev_block)); }
                 else TSGPU_HIP_TRY(hipStreamSynchronize(s));
-                const uint8_t* hb = (const uint8_t*)L.h_out.p;
-                memcpy(out->n_hits, hb + out_at[0], (size_t)n_queries * 4);
-                if (out->num_matched) memcpy(out->num_matched, hb + out_at[1], (size_t)n_queries * 8);
+                uint8_t* hb = (uint8_t*)L.h_out.p;
+                const uint32_t* nh = (const uint32_t*)(hb + out_at[0]);
                 memcpy(off_words.data(), hb + out_at[2], (size_t)n_queries * 8);
-                memcpy(out->keys, hb + out_at[3], slots * 8);
-                memcpy(out->scores, hb + out_at[4], slots * 24);
-                if (out->text_match) memcpy(out->text_match, hb + out_at[5], slots * 8);
-                if (out->vector_distance) memcpy(out->vector_distance, hb + out_at[6], slots * 4);
-                if (out->match_score_index) memcpy(out->match_score_index, hb + out_at[7], slots);
+                if (bo.alias_out) {
+                    out->n_hits = (uint32_t*)(hb + out_at[0]); out->num_matched = (uint64_t*)(hb + out_at[1]);
+                    out->keys = (uint64_t*)(hb + out_at[3]); out->scores = (int64_t*)(hb + out_at[4]); out->text_match = (int64_t*)(hb + out_at[5]);
+                    out->vector_distance = (float*)(hb + out_at[6]); out->match_score_index = (int8_t*)(hb + out_at[7]);
+                } else {
+                    memcpy(out->n_hits, nh, (size_t)n_queries * 4);
+                    if (out->num_matched) memcpy(out->num_matched, hb + out_at[1], (size_t)n_queries * 8);
+                    for (uint32_t i = 0; i < n_queries; i++) {           // only the hits: slots behind n_hits[i] are undefined in the image too
+                        const size_t at = (size_t)i * KS, n = std::min<uint32_t>(nh[i], KS);
+                        memcpy(out->keys + at, hb + out_at[3] + at * 8, n * 8);
+                        memcpy(out->scores + at * 3, hb + out_at[4] + at * 24, n * 24);
+                        if (out->text_match) memcpy(out->text_match + at, hb + out_at[5] + at * 8, n * 8);
+                        if (out->vector_distance) memcpy(out->vector_distance + at, hb + out_at[6] + at * 4, n * 4);
+                        if (out->match_score_index) memcpy(out->match_score_index + at, hb + out_at[7] + at, n);
+                    }
+                }
             } else {
                 TSGPU_HIP_TRY(hipMemcpyAsync(out->n_hits, o.n_hits, (size_t)n_queries * 4, hipMemcpyDeviceToHost, s));
                 if (out->num_matched) TSGPU_HIP_TRY(hipMemcpyAsync(out->num_matched, o.num_matched, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
@@ -1193,10 +1227,10 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
 
         // ---- bookkeeping: timings + algorithmic bytes ----
         float ms_a = 0, ms_b = 0;
-        (void)hipEventElapsedTime(&ms_a, L.ev[0], L.ev[1]);
-        (void)hipEventElapsedTime(&ms_b, L.ev[1], L.ev[2]);
+        if (timing) (void)hipEventElapsedTime(&ms_a, L.ev[0], L.ev[1]);
+        if (timing) (void)hipEventElapsedTime(&ms_b, L.ev[1], L.ev[2]);
         float ms_find = 0;
-        if (find_marked && hit_groups == 1) (void)hipEventElapsedTime(&ms_find, L.ev[0], L.ev[3]);       // one find launch, then one score launch
+        if (timing && find_marked && hit_groups == 1) (void)hipEventElapsedTime(&ms_find, L.ev[0], L.ev[3]);       // one find launch, then one score launch
         uint64_t bytes = P.list_bytes;
         if (!dev_out && out->num_matched) {
             for (uint32_t i = 0; i < n_queries; i++) {
@@ -1207,7 +1241,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         } else {
             for (uint32_t i = 0; i < n_queries; i++) bytes += 4ull * off_words[i];
         }
-        {
+        if (timing || bo.timing) {
             std::lock_guard<std::mutex> tl(ctx->tm_mu);
             ctx->timings.kw_search_ms = ms_a;
             ctx->timings.kw_merge_ms = ms_b;

@@ -345,12 +345,13 @@ struct tsgpu_ctx {
     tsgpu::Combiner<tsgpu::VecRequest> vec_comb;
     std::atomic<int> kw_callers{0}, vec_callers{0};  // threads currently inside the search entry points
     uint32_t ticks_per_us = 100;                     // device wall clock (hipDeviceAttributeWallClockRate)
-    uint32_t batch_window_us = 80;                   // micro-batcher: how long a round's leader waits for more callers
+    uint32_t batch_window_us = 10;                   // micro-batcher: how long a round's leader waits for more callers
     uint32_t batch_max_queries = 64;                 // calls with more queries than this are not coalesced (they are batches already)
     uint32_t batch_round_queries = 1024;             // queries per coalesced round at most
 
     // host-side phase totals of every keyword batch (us; introspection for the latency budget of small batches)
     std::atomic<uint64_t> kw_max_queue_us{0}, kw_max_wake_us{0};
+    std::atomic<uint64_t> kw_queue_us{0}, kw_wake_us{0};   // sums over the coalesced calls: parked -> round starts / results ready -> caller resumes
     std::atomic<uint64_t> kw_max_plan_us{0}, kw_max_upload_us{0}, kw_max_launch_us{0}, kw_max_wait_us{0};     // slowest phase of any batch since the last read (diagnostics)
     std::atomic<uint64_t> kw_batches{0}, kw_plan_us{0}, kw_upload_us{0}, kw_launch_us{0}, kw_wait_us{0}, kw_book_us{0}, batch_exec_us{0}, batch_scatter_us{0};
     tsgpu::DevBuf d_prof;                            // TSGPU_PROF builds only (null otherwise)
@@ -359,7 +360,9 @@ struct tsgpu_ctx {
     uint32_t kw_cost_r_x10 = 10, kw_cost_probe_x100 = 20;  // ... + 0.1 x kw_cost_r_x10 x |B|/|A| + 0.01 x kw_cost_probe_x100 x (stage-1 survivors per block)
     uint32_t kw_cost_fixed = 16;                     // launch-order cost model: item cost = driver blocks x (kw_cost_fixed + |B|/|A|)
     bool kw_sort_work = true;                        // lay the work table out heaviest query first
-    uint32_t kw_merge_select_min = 17;               // queries with at least this many partial lists are merged by selection (kw_select_partials); 0 = always fold
+    uint32_t kw_zero_copy_max_queries = 256;         // host-output keyword batches up to this many queries: the merge kernel writes into pinned host memory (0 = always copy)
+    uint32_t kw_timing_min_queries = 64;             // keyword batches below this many queries skip the phase events (tsgpu_timings reports 0 ms for them)
+    uint32_t kw_merge_select_min = 2;                // queries with at least this many partial lists are merged by selection (kw_select_partials: tree merge); 0 = always fold
     bool kw_pair_blocks = true;                      // find kernel variant: two driver blocks per iteration (kw_find2.hip.h)
     bool kw_two_kernels = true;                      // queries of <= 3 tokens: find kernel + score kernel instead of the fused kernel
     uint32_t kw_hit_buffer_mb = 20480;               // budget of the hit-record buffer between the two (work items run in groups that fit)
