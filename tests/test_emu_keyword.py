@@ -826,3 +826,37 @@ def test_parallel_planning_of_a_batch_gives_the_serial_plan(pair, pair3):
         n = int(s3.n_hits[i])
         assert p3.n_hits[i] == n and p3.num_matched[i] == s3.num_matched[i] and np.array_equal(p3.keys[i, :n], s3.keys[i, :n]) and np.array_equal(p3.scores[i, :n], s3.scores[i, :n])
         H.assert_hits_equal(p3, i, H.oracle_keyword(orc3, q3[i]), "parallel plan, 3 fields")
+
+
+def test_host_output_batch_served_in_slices_equals_the_single_batch(pair):
+    """a large batch with host output is served in slices on two lanes by two host threads (kw_split_host: slice i's copies run while
+    slice i + 1 computes); status codes, hits, counts and cut-off flags must equal the unsliced batch's, a failing query fails alone"""
+    orc, g, _ = pair
+    rng = np.random.default_rng(99)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    qs = []
+    for rep in range(53):
+        toks = rng.choice(np.arange(1, 30), size=int(rng.integers(1, 4)), replace=False)
+        if rep % 4 == 1: qs.append(T.KwQuery(toks, sort=sort, topster_size=40, filter_ids=np.sort(rng.choice(3000, size=500, replace=False))))
+        elif rep == 30: qs.append(T.KwQuery(list(range(1, 13)), sort=sort))            # too many tokens: fails alone
+        else: qs.append(T.KwQuery(toks, sort=sort, topster_size=250 if rep % 3 else 17))
+    g.set_option("kw_host_split_queries", 0)
+    whole = g.keyword_search_batch(qs, k_stride=250)
+    try:
+        g.set_option("kw_host_split_first_pct", 50)
+        g.set_option("kw_host_split_queries", 7)                                       # 26 queries, then two slices of the other 27
+        r0 = g.counter("kw_batches")
+        cut = g.keyword_search_batch(qs, k_stride=250)
+        assert g.counter("kw_batches") - r0 == 3
+        assert np.array_equal(cut.status, whole.status) and (whole.status != 0).sum() == 1
+        assert np.array_equal(cut.search_cutoff, whole.search_cutoff)
+        for i in range(len(qs)):
+            n = int(whole.n_hits[i])
+            assert cut.n_hits[i] == n and cut.num_matched[i] == whole.num_matched[i]
+            assert np.array_equal(cut.keys[i, :n], whole.keys[i, :n]) and np.array_equal(cut.scores[i, :n], whole.scores[i, :n])
+            assert np.array_equal(cut.text_match[i, :n], whole.text_match[i, :n])
+            if whole.status[i] == 0:
+                H.assert_hits_equal(cut, i, H.oracle_keyword(orc, qs[i]), "sliced host batch")
+    finally:
+        g.set_option("kw_host_split_queries", 1000)
+        g.set_option("kw_host_split_first_pct", 75)

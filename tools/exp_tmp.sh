@@ -1,9 +1,9 @@
-cd /tmp && export TMPDIR=/tmp
-for sm in 17 2; do
-rm -rf /tmp/ct
-rocprofv3 --kernel-trace --output-format csv -d /tmp/ct -- python $GRAFT_REPO_ROOT/bench.py --workload keyword --no-cpu-baseline --steps 3 --warmup 1 --opt batch_window_us=10 --opt kw_merge_select_min=$sm > /tmp/ct.json 2>/tmp/ct.err
-echo "== select_min $sm"
-python $GRAFT_REPO_ROOT/tools/exp_conc_trace.py /tmp/ct 2>&1 | grep "tsgpu::kw_merge"
+for cfg in "5000 50" "3000 70" "2500 75" "4000 60" "1250 60" "1250 70" "2000 80"; do
+set -- $cfg
+python bench.py --workload keyword --no-cpu-baseline --no-extras --steps 3 --warmup 1 --opt kw_host_split_queries=$1 --opt kw_host_split_first_pct=$2 > /tmp/h.json 2>/dev/null
+python - <<P
+import json
+d=json.loads(open("/tmp/h.json").read().strip().splitlines()[-1])
+print("min slice $1 first $2%: value", round(d["value"]), "host delivery", round(d.get("value_with_host_delivery",0)))
+P
 done
-cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_keyword.py -x -q 2>&1 | tail -2

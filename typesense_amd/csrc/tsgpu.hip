@@ -139,6 +139,7 @@ int tsgpu_create(int device_ordinal, tsgpu_ctx** out) {
         else good = good && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) == hipSuccess;
         for (auto& ev : L.ev) good = good && hipEventCreate(&ev) == hipSuccess;
         good = good && hipEventCreateWithFlags(&L.ev_block, hipEventBlockingSync | hipEventDisableTiming) == hipSuccess;
+        good = good && hipEventCreateWithFlags(&L.ev_chain, hipEventDisableTiming) == hipSuccess;
     }
     if (!good) { tsgpu_destroy(ctx); return fail(TSGPU_ERR_DEVICE, "tsgpu_create: stream / event creation failed"); }
     *out = ctx;
@@ -233,6 +234,8 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_sort_work")) { ctx->kw_sort_work = value != 0; return ok(); }
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
     if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
+    if (!strcmp(name, "kw_host_split_first_pct")) { ctx->kw_host_split_first_pct = (uint32_t)std::min<int64_t>(95, std::max<int64_t>(5, value)); return ok(); }
+    if (!strcmp(name, "kw_host_split_queries")) { ctx->kw_host_split_queries = (uint32_t)std::max<int64_t>(0, value); return ok(); }
     if (!strcmp(name, "kw_zero_copy_max_queries")) { ctx->kw_zero_copy_max_queries = (uint32_t)std::max<int64_t>(0, value); return ok(); }
     if (!strcmp(name, "kw_timing_min_queries")) { ctx->kw_timing_min_queries = (uint32_t)std::max<int64_t>(0, value); return ok(); }
     if (!strcmp(name, "kw_merge_select_min")) { ctx->kw_merge_select_min = (uint32_t)std::max<int64_t>(0, value); return ok(); }
@@ -753,6 +756,7 @@ struct LaneLock {                                     // holds one execution lan
     }
     ~LaneLock() { L->mu.unlock(); ctx->lane_dispenser.release(index, ctx->n_lanes); }
 };
+struct SliceChain { std::mutex m; hipEvent_t last = nullptr; };      // enqueue order under the mutex = execution order of the slices' kernels
 struct BatchOpts {
     bool wildcard = false;
     bool keep_ids = false;                            // emit matched ids into the lane's id arena
@@ -760,6 +764,8 @@ struct BatchOpts {
     std::vector<int32_t>* cutoff_host = nullptr;      // ... and the per-query search_cutoff flags
     tsgpu_id_lists* id_lists = nullptr;               // when set: the matched ids of every query, gathered + downloaded (implies keep_ids)
     bool record_last = true;                          // remember the id segments for the legacy tsgpu_result_ids API
+    SliceChain* chain = nullptr;                      // sliced host-output batch: this slice's kernels start when the previous slice's have finished (a
+                                                      // device-side wait; the previous slice's device-to-host copies run meanwhile: two slices never compute at once)
     bool alias_out = false;                           // host output through the lane's pinned image: point `out`'s arrays INTO the image instead of copying
                                                       // them out (the coalesced round hands every caller its slice straight from there)
     bool timing = true;                               // record the phase events (tsgpu_timings); a coalesced round has no single caller to report to
@@ -767,6 +773,7 @@ struct BatchOpts {
 }
 static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, const BatchOpts& bo);
 static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, tsgpu_id_lists** ids_out);
+static int kw_split_host(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out);
 
 int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out) {
     return kw_dispatch(ctx, queries, n_queries, out, false, nullptr);
@@ -900,6 +907,53 @@ extern "C" {
 // Entry of every keyword / wildcard search call. Small host-output calls from concurrent request threads (the reference calls
 // the seam once per query from its thread pool, src/index.cpp:3488, src/http_server.cpp:827-832) are coalesced by the
 // micro-batcher into one launch; everything else takes a lane directly.
+// A LARGE batch whose results go to host memory: 112 MB of hit arrays per 10 000 queries cross PCIe, ~2.4 ms behind a 9 ms step when
+// the copies start after the last kernel. Served in slices on two lanes by two host threads instead: a slice computes while the previous
+// one's copies run (the slices' kernels are chained by events: sharing the chip, each would take twice as long and they would reach
+// their copies together). Results are those of separate calls per slice = those of one call (a query never influences another).
+static int kw_split_host(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out) {
+    // slice sizes: the LAST slice's copies are the part nothing overlaps, and every slice costs launch tails + copy calls: a large
+    // first slice (kw_host_split_first_pct of the batch), the rest in two equal slices (one if they would be smaller than kw_host_split_queries)
+    std::vector<uint32_t> start(1, 0);
+    {
+        uint32_t first = (uint32_t)((uint64_t)n_queries * ctx->kw_host_split_first_pct / 100);
+        first = std::min(std::max(first, ctx->kw_host_split_queries), n_queries - ctx->kw_host_split_queries);
+        start.push_back(first);
+        const uint32_t rest = n_queries - first, parts = rest >= 2 * ctx->kw_host_split_queries ? 2 : 1;      // (measured: two tail slices; more cost more than they hide)
+        for (uint32_t i = 1; i <= parts; i++) start.push_back(first + (uint32_t)((uint64_t)rest * i / parts));
+    }
+    const uint32_t n_slices = (uint32_t)start.size() - 1;
+    SliceChain chain;
+    std::mutex err_mu;
+    std::atomic<uint32_t> next{0};
+    int first_rc = TSGPU_OK;
+    std::string first_err;
+    const std::function<void()> job = [&]() {
+        for (;;) {
+            const uint32_t si = next.fetch_add(1);
+            if (si >= n_slices) break;
+            const uint32_t a = start[si], n = start[si + 1] - a;
+            const size_t at = (size_t)a * out->k_stride;
+            tsgpu_hits h = *out;
+            h.keys = out->keys + at; h.scores = out->scores + at * 3; h.n_hits = out->n_hits + a; h.status = out->status + a;
+            if (out->text_match) h.text_match = out->text_match + at;
+            if (out->vector_distance) h.vector_distance = out->vector_distance + at;
+            if (out->match_score_index) h.match_score_index = out->match_score_index + at;
+            if (out->num_matched) h.num_matched = out->num_matched + a;
+            if (out->search_cutoff) h.search_cutoff = out->search_cutoff + a;
+            BatchOpts bo;
+            bo.record_last = false;
+            bo.chain = &chain;
+            int rc;
+            { LaneLock ll(ctx); rc = kw_batch_on_lane(ctx, *ll.L, queries + a, n, &h, bo); }
+            if (rc != TSGPU_OK) { std::lock_guard<std::mutex> lk(err_mu); if (first_rc == TSGPU_OK) { first_rc = rc; first_err = tls_error(); } }
+        }
+    };
+    try { ctx->split_pool.run(job, 1); } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_batch: host allocation failed"); }
+    if (first_rc != TSGPU_OK) return fail(first_rc, first_err);
+    return ok();
+}
+
 static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, tsgpu_id_lists** ids_out) {
     if (!ctx || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: NULL argument");
     if (n_queries == 0) { if (ids_out) { *ids_out = new (std::nothrow) tsgpu_id_lists; if (*ids_out) (*ids_out)->begin.assign(1, 0); } return ok(); }
@@ -909,6 +963,9 @@ static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n
     const bool legacy_keep = ctx->keep_ids;
     if (!wildcard && !legacy_keep && out->mem == TSGPU_MEM_HOST && n_queries <= ctx->batch_max_queries && ctx->kw_callers.load() > 1)
         return kw_coalesced(ctx, queries, n_queries, out, ids_out);
+    if (!wildcard && !legacy_keep && !ids_out && out->mem == TSGPU_MEM_HOST && ctx->kw_host_split_queries && ctx->n_lanes >= 2 &&
+        (uint64_t)n_queries >= 4ull * ctx->kw_host_split_queries)
+        return kw_split_host(ctx, queries, n_queries, out);
     std::unique_ptr<tsgpu_id_lists> lists;
     if (ids_out) { lists.reset(new (std::nothrow) tsgpu_id_lists); if (!lists) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_batch_ids: host allocation failed"); }
     BatchOpts bo;
@@ -1071,6 +1128,11 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         }
 
         // ---- launch ----
+        std::unique_lock<std::mutex> chain_lk;
+        if (bo.chain) {
+            chain_lk = std::unique_lock<std::mutex>(bo.chain->m);
+            if (bo.chain->last) TSGPU_HIP_TRY(hipStreamWaitEvent(s, bo.chain->last, 0));
+        }
         const uint64_t t_uploaded = now_us();
         IndexView v = make_view(ctx, snap);
         v.mf = (const KwQueryMF*)(dplan + at_mf);
@@ -1156,6 +1218,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         launch_merge(cap, s, n_queries, dq, part, o, ids_out, dw, ctx->kw_merge_select_min);
         if (timing) TSGPU_HIP_TRY(hipEventRecord(L.ev[2], s));
         TSGPU_HIP_TRY(hipGetLastError());
+        if (bo.chain) { TSGPU_HIP_TRY(hipEventRecord(L.ev_chain, s)); bo.chain->last = L.ev_chain; chain_lk.unlock(); }
         const uint64_t t_launched = now_us();
 
         // ---- results ----

@@ -177,6 +177,7 @@ struct KwLane {
     hipStream_t stream = nullptr;
     bool own_stream = true;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_chain = nullptr;                   // "this slice's kernels are done": the next slice of a sliced host-output batch waits for it ON THE DEVICE
     hipEvent_t ev_block = nullptr;                   // hipEventBlockingSync: the waiting thread sleeps instead of spinning (many concurrent callers)
     DevBuf d_plan, d_ids_out;                        // the batch plan (queries, work items, aux ids, multi-field descriptors, hit offsets): one upload
     DevBuf d_part_s0, d_part_s1, d_part_s2, d_part_key, d_part_cnt, d_part_nm, d_part_ne, d_part_ow, d_part_f;
@@ -214,6 +215,7 @@ struct KwLane {
         h_out.release(); h_plan.release();
         for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (ev_block) { (void)hipEventDestroy(ev_block); ev_block = nullptr; }
+        if (ev_chain) { (void)hipEventDestroy(ev_chain); ev_chain = nullptr; }
         if (own_stream && stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -290,11 +292,11 @@ struct LaneDispenser {
     std::mutex m;
     std::condition_variable cv;
     std::deque<Waiter*> q;
-    bool busy[8] = {false, false, false, false, false, false, false, false};
+    bool busy[16] = {};
     static bool can(int lane, int want, int n) { return want < 0 ? lane < n : want == lane; }
     int acquire(int want, int n_lanes) {
         std::unique_lock<std::mutex> lk(m);
-        for (int lane = 0; lane < 8; lane++) {
+        for (int lane = 0; lane < 16; lane++) {
             if (busy[lane] || !can(lane, want, n_lanes)) continue;
             bool earlier = false;
             for (const Waiter* w : q) if (can(lane, w->want, n_lanes)) { earlier = true; break; }
@@ -316,6 +318,7 @@ struct LaneDispenser {
 
 struct tsgpu_ctx {
     HostPool host_pool;
+    HostPool split_pool;                             // the second thread of a host-output batch served in slices (kw_split_host)
     LaneDispenser lane_dispenser;
     static const int N_LANES = 8;                    // lanes that exist; `n_lanes` of them are used (option "kw_lanes")
     int n_lanes = 4;
@@ -360,6 +363,9 @@ struct tsgpu_ctx {
     uint32_t kw_cost_r_x10 = 10, kw_cost_probe_x100 = 20;  // ... + 0.1 x kw_cost_r_x10 x |B|/|A| + 0.01 x kw_cost_probe_x100 x (stage-1 survivors per block)
     uint32_t kw_cost_fixed = 16;                     // launch-order cost model: item cost = driver blocks x (kw_cost_fixed + |B|/|A|)
     bool kw_sort_work = true;                        // lay the work table out heaviest query first
+    uint32_t kw_host_split_queries = 1000;           // a host-output keyword batch of at least FOUR times this many queries is served in slices on two lanes: a slice's
+                                                     // results cross PCIe while the next one computes (0 = never); no slice is smaller than this
+    uint32_t kw_host_split_first_pct = 75;           // ... the first slice's share of the batch (the rest: two equal slices)
     uint32_t kw_zero_copy_max_queries = 256;         // host-output keyword batches up to this many queries: the merge kernel writes into pinned host memory (0 = always copy)
     uint32_t kw_timing_min_queries = 64;             // keyword batches below this many queries skip the phase events (tsgpu_timings reports 0 ms for them)
     uint32_t kw_merge_select_min = 2;                // queries with at least this many partial lists are merged by selection (kw_select_partials: tree merge); 0 = always fold
