@@ -186,9 +186,12 @@ int tsgpu_set_num_docs(tsgpu_ctx* ctx, uint32_t num_docs);
 /* Publish all pending posting-list changes as ONE new immutable snapshot (RCU): searches that started before keep the snapshot they
  * run on, searches never wait for a commit, a failing commit leaves the previous snapshot in place. Incremental: re-written blocks
  * and the touched lists' descriptors are appended at the tails of the device arenas and a new descriptor table is swapped in;
- * everything is re-packed (compaction) only at the first commit, when the tails run out of room, when garbage outweighs live data,
- * or after tsgpu_set_option(ctx, "commit_full", 1). Counters: "commit_last_us", "commit_last_uploaded_bytes", "commit_full_count",
- * "commit_incremental_count". */
+ * everything is re-packed (compaction) only at the first commit, when the tails run out of room, when the arenas' garbage (words no
+ * list of the newest snapshot refers to) outweighs their live words (and exceeds option "index_compact_min_words", default 2^20), or
+ * after tsgpu_set_option(ctx, "commit_full", 1). Cost of an incremental commit: the changed blocks + the descriptor table (48 B per
+ * list, re-uploaded whole) + a copy of the term map when a term appeared or disappeared. Device memory of replaced snapshots is freed
+ * here, by the committing thread, never by a search. Counters: "commit_last_us", "commit_last_uploaded_bytes", "commit_full_count",
+ * "commit_incremental_count", "commit_compactions", "commit_failed_count", "index_used_words", "index_live_words". */
 int tsgpu_commit(tsgpu_ctx* ctx);
 
 /* introspection (tests): number of ids of a term, 0 if absent */

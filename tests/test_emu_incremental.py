@@ -123,6 +123,46 @@ def test_many_small_commits_until_the_tails_run_out():
     g.close()
 
 
+def test_rewrites_accumulate_garbage_until_a_commit_compacts():
+    """every re-written block leaves its old words behind in the arenas; the commit after which the garbage would outweigh the live words
+    takes the full path instead (compaction: re-pack, tail room restored, no list with breaks) — a lightly written index with large
+    tails must not keep its garbage (and its per-candidate probes across breaks) for ever"""
+    rng = np.random.default_rng(11)
+    n = 5000
+    docs = H.zipf_docs(n, 30, 6, seed=6)
+    live = np.ones(n, bool)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.set_option("index_min_slack_words", 1 << 20)     # (room for hundreds of re-writes: the tails never run out here)
+    g.set_option("index_compact_min_words", 0)
+    g.field_create(0, False)
+    g.column_set(0, H.points_of(n))
+    g.set_num_docs(n)
+    for d in range(n):
+        g.index_plain_doc(d, 0, docs[d])
+    g.commit()
+    live0 = g.counter("index_live_words")
+    assert g.counter("index_used_words") == live0 and g.counter("commit_compactions") == 0
+    rounds, peak = 0, 0
+    while g.counter("commit_compactions") == 0 and rounds < 40:      # remove + re-add the same documents: the lists' content does not grow, the arenas do
+        pick = rng.choice(n, size=4, replace=False)                   # (a few blocks of a few lists per round)
+        for d in pick:
+            g.remove_plain_doc(int(d), 0, docs[d])
+        g.commit()
+        for d in pick:
+            g.index_plain_doc(int(d), 0, docs[d])
+        g.commit()
+        rounds += 1
+        used, lv = g.counter("index_used_words"), g.counter("index_live_words")
+        if g.counter("commit_compactions") == 0:
+            peak = max(peak, used)
+        assert lv <= used and abs(int(lv) - int(live0)) <= live0 // 8, "live words drifted: %d vs %d at the start" % (lv, live0)
+    assert g.counter("commit_compactions") == 1 and rounds >= 2, "garbage never triggered a compaction (%d rounds)" % rounds
+    used, lv = g.counter("index_used_words"), g.counter("index_live_words")
+    assert used < peak and used - lv < lv // 2 and peak > 3 * live0 // 2, "the compaction did not shrink the arenas: %d words used (peak %d, live %d)" % (used, peak, lv)
+    check_equal(g, fresh_oracle(docs, live), rng, "after the compaction", n_queries=6)
+    g.close()
+
+
 def test_a_failing_commit_leaves_the_previous_snapshot_and_the_retry_is_complete():
     """fault injection (emulator: the N-th hipMalloc / hipMemcpy fails): wherever a commit dies — incremental path, its full
     fallback, first upload or last — searches keep answering from the snapshot published before, and the next commit (forced onto

@@ -157,6 +157,7 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
     tsgpu_facet_destroy_all(ctx);
     for (auto& L : ctx->lanes) L.release();
     std::atomic_store(&ctx->snap, std::shared_ptr<const Snapshot>());
+    ctx->retire_bin->drain();
     ctx->d_col_ptrs.release(); ctx->d_col_len.release(); ctx->d_prof.release();
     for (auto& c : ctx->columns) c.data.release();
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
@@ -276,6 +277,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "vec_count_rescored")) { ctx->vec_count_rescored = value != 0; return ok(); }
     // micro-batcher (tsgpu_batcher.h): concurrent small calls are coalesced into one launch
     if (!strcmp(name, "index_min_slack_words")) { ctx->index_min_slack_words = (uint64_t)std::max<int64_t>(value, 0); return ok(); }   // (tests: small arenas)
+    if (!strcmp(name, "index_compact_min_words")) { ctx->index_compact_min_words = (uint64_t)std::max<int64_t>(value, 0); return ok(); }   // (tests: small arenas)
     if (!strcmp(name, "commit_full")) { ctx->commit_force_full = value != 0; return ok(); }      // the NEXT commit re-packs every list (compaction)
     if (!strcmp(name, "kw_lanes")) {                   // execution lanes (stream + scratch each) that concurrent keyword batches spread over
         if (value < 1 || value > tsgpu_ctx::N_LANES) return fail(TSGPU_ERR_INVALID, "kw_lanes out of range (1..8)");
@@ -311,6 +313,9 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!strcmp(name, "commit_last_us")) { *out = ctx->commit_last_us; return ok(); }                        // the last tsgpu_commit: wall time, bytes uploaded
     if (!strcmp(name, "commit_last_uploaded_bytes")) { *out = ctx->commit_last_uploaded_bytes; return ok(); }
     if (!strcmp(name, "commit_failed_count")) { *out = ctx->commit_failed_count; return ok(); }
+    if (!strcmp(name, "commit_compactions")) { *out = ctx->commit_compactions; return ok(); }             // full commits taken because garbage outweighed the live words
+    if (!strcmp(name, "index_live_words")) { const auto sn = ctx->snapshot(); *out = sn && sn->ar ? sn->ar->live_idw + sn->ar->live_pw : 0; return ok(); }
+    if (!strcmp(name, "index_used_words")) { const auto sn = ctx->snapshot(); *out = sn && sn->ar ? sn->ar->used_idw + sn->ar->used_pw : 0; return ok(); }
     if (!strcmp(name, "commit_full_count")) { *out = ctx->commit_full_count; return ok(); }                  // commits that re-packed everything / appended at the tails
     if (!strcmp(name, "commit_incremental_count")) { *out = ctx->commit_incremental_count; return ok(); }
     if (!strcmp(name, "kw_batches")) { *out = ctx->kw_batches.load(); return ok(); }                 // host-side phase totals (us) over all keyword batches

@@ -99,11 +99,23 @@ struct TermHost {
     int64_t open_b = -1;                             // decoded block being mutated (-1 = none)
     std::vector<uint32_t> o_ids, o_oi, o_offs;       // o_oi has one extra end entry (= o_offs.size()) while open
     uint64_t garbage_idw = 0, garbage_pw = 0;        // host words no block refers to any more
+    uint64_t dev_idw = 0, dev_pw = 0;                // arena words the NEWEST SNAPSHOT's version of this list occupies (0 before its first commit)
 };
 
 struct FieldHost {
     bool is_array = false;
     std::unordered_map<uint32_t, TermHost> terms;
+};
+
+// Device buffers of RETIRED snapshots / arena sets. The last reference to a snapshot is usually dropped by a SEARCH thread (RCU), and
+// hipFree synchronises the whole device: the destructors hand their buffers over instead, the commit thread (tsgpu_commit, on entry and
+// after publishing) and tsgpu_destroy free them — a search never pays for a commit's garbage.
+struct RetireBin {
+    std::mutex m;
+    std::vector<void*> dev;
+    void put(DevBuf& b) { if (!b.p) return; { std::lock_guard<std::mutex> lk(m); dev.push_back(b.p); } b.p = nullptr; b.cap = 0; }
+    void drain() { std::vector<void*> v; { std::lock_guard<std::mutex> lk(m); v.swap(dev); } for (void* p : v) (void)hipFree(p); }
+    ~RetireBin() { drain(); }
 };
 
 // the device arenas of the posting lists; shared by consecutive snapshots: an incremental commit appends at the tails (regions no
@@ -116,7 +128,11 @@ struct ArenaSet {
     ArenaSet() = default;
     ArenaSet(const ArenaSet&) = delete;
     ArenaSet& operator=(const ArenaSet&) = delete;
-    ~ArenaSet() { blk_last.release(); blk_ids.release(); blk_meta.release(); ids_payload.release(); payload.release(); }
+    std::shared_ptr<RetireBin> bin;
+    ~ArenaSet() {
+        if (bin) { bin->put(blk_last); bin->put(blk_ids); bin->put(blk_meta); bin->put(ids_payload); bin->put(payload); }
+        else { blk_last.release(); blk_ids.release(); blk_meta.release(); ids_payload.release(); payload.release(); }
+    }
     uint64_t bytes() const { return blk_last.cap + blk_ids.cap + blk_meta.cap + ids_payload.cap + payload.cap; }
 };
 
@@ -154,7 +170,8 @@ struct Snapshot {            // immutable view of all posting lists; published b
     Snapshot() = default;
     Snapshot(const Snapshot&) = delete;
     Snapshot& operator=(const Snapshot&) = delete;
-    ~Snapshot() { lists.release(); }
+    std::shared_ptr<RetireBin> bin;
+    ~Snapshot() { if (bin) bin->put(lists); else lists.release(); }
     uint32_t find_handle(uint32_t field, uint32_t term) const {
         if (!maps) return 0xFFFFFFFFu;
         if (field < maps->dense_handle.size() && term < maps->dense_handle[field].size()) return maps->dense_handle[field][term];
@@ -317,6 +334,7 @@ struct LaneDispenser {
 };
 
 struct tsgpu_ctx {
+    std::shared_ptr<tsgpu::RetireBin> retire_bin = std::make_shared<tsgpu::RetireBin>();
     HostPool host_pool;
     HostPool split_pool;                             // the second thread of a host-output batch served in slices (kw_split_host)
     LaneDispenser lane_dispenser;
@@ -336,6 +354,9 @@ struct tsgpu_ctx {
     bool dirty_fields = false;                       // a query_by field was declared since the last commit
     uint64_t index_min_slack_words = 1u << 20;       // room (words per arena) a full commit leaves behind the data at least (option "index_min_slack_words")
     bool commit_force_full = false;                  // option "commit_full": the next commit re-packs everything (compaction)
+    uint64_t erased_dev_idw = 0, erased_dev_pw = 0;  // arena words of lists erased since the last commit (they become garbage when it publishes)
+    uint64_t index_compact_min_words = 1u << 20;     // garbage below this many words per arena never triggers a compaction (option "index_compact_min_words")
+    uint64_t commit_compactions = 0;                 // full commits taken because the arenas' garbage outweighed their live words
     uint64_t commit_last_us = 0, commit_last_uploaded_bytes = 0, commit_full_count = 0, commit_incremental_count = 0;
     std::vector<tsgpu::ColumnDev> columns;
     tsgpu::DevBuf d_col_ptrs, d_col_len;

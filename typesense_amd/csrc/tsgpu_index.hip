@@ -7,7 +7,8 @@
 //     and a new descriptor TABLE is published (RCU): O(touched blocks), not O(index) — searches never wait and never see a mix;
 //   * relocated blocks break the "a run of blocks is one coalesced range" property the intersection kernel exploits; such lists
 //     carry LIST_HAS_BREAKS and runs across a break are probed per candidate until the next compaction (= a full re-pack, taken
-//     when the tails run out of room, the garbage outweighs the live data, or on option "commit_full").
+//     when the tails run out of room, the arenas' garbage (used - live words, tracked per commit) outweighs their live words, or on
+//     option "commit_full").
 #include "tsgpu_host.h"
 
 using namespace tsgpu;
@@ -36,6 +37,15 @@ void mark_dirty(tsgpu_ctx* ctx, uint32_t field, uint32_t term, TermHost* t) {
     if (t && t->dirty) return;                               // already queued for the next commit (one entry per term, not per posting operation)
     if (t) t->dirty = true;
     ctx->dirty_terms.push_back(((uint64_t)field << 32) | term);
+}
+
+// a term leaves the index: what its committed version occupies in the arenas becomes garbage with the next commit
+bool erase_term(tsgpu_ctx* ctx, FieldHost& f, uint32_t term_id) {
+    auto it = f.terms.find(term_id);
+    if (it == f.terms.end()) return false;
+    ctx->erased_dev_idw += it->second.dev_idw; ctx->erased_dev_pw += it->second.dev_pw;
+    f.terms.erase(it);
+    return true;
 }
 
 void set_list(TermHost& t, PackedList&& pl) {
@@ -144,7 +154,7 @@ int tsgpu_term_upsert(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, const
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto fit = ctx->fields.find(field_id);
     if (fit == ctx->fields.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_term_upsert: unknown field (call tsgpu_field_create)");
-    if (n_ids == 0) { if (fit->second.terms.erase(term_id)) mark_dirty(ctx, field_id, term_id, nullptr); return ok(); }
+    if (n_ids == 0) { if (erase_term(ctx, fit->second, term_id)) mark_dirty(ctx, field_id, term_id, nullptr); return ok(); }
     if (!ids || !offset_index || !offsets) return fail(TSGPU_ERR_INVALID, "tsgpu_term_upsert: NULL array");
     try {
         std::vector<uint64_t> oi(offset_index, offset_index + n_ids);
@@ -188,7 +198,7 @@ int tsgpu_terms_load_csr(tsgpu_ctx* ctx, uint32_t field_id, uint32_t n_terms, co
             packed.emplace_back(term_ids[t], pack_list(ids + a, oi.data(), offsets + o0, (uint32_t)(b - a), o1 - o0));
         }
         for (auto& e : packed) {
-            if (e.second.desc.n_ids == 0) { if (fit->second.terms.erase(e.first)) mark_dirty(ctx, field_id, e.first, nullptr); continue; }
+            if (e.second.desc.n_ids == 0) { if (erase_term(ctx, fit->second, e.first)) mark_dirty(ctx, field_id, e.first, nullptr); continue; }
             TermHost& t = fit->second.terms[e.first];
             const uint32_t handle = t.handle;
             set_list(t, std::move(e.second));
@@ -290,7 +300,7 @@ int tsgpu_posting_erase(tsgpu_ctx* ctx, uint32_t field_id, uint32_t term_id, uin
         t.o_oi.erase(t.o_oi.begin() + p);
         for (size_t i = p; i < t.o_oi.size(); i++) t.o_oi[i] -= (e - s);
         flush_open(t);
-        if (t.pl.blk_last.empty()) { fit->second.terms.erase(tit); mark_dirty(ctx, field_id, term_id, nullptr); }
+        if (t.pl.blk_last.empty()) { erase_term(ctx, fit->second, term_id); mark_dirty(ctx, field_id, term_id, nullptr); }
         else mark_dirty(ctx, field_id, term_id, &t);
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_posting_erase: host allocation failed"); }
     return ok();
@@ -347,8 +357,10 @@ __global__ void index_desc_scatter_kernel(const uint64_t* __restrict__ dst, cons
 // everything re-packed into fresh arenas (first commit, compaction, or the tails ran out of room)
 int commit_full(tsgpu_ctx* ctx) {
     std::shared_ptr<Snapshot> sp = std::make_shared<Snapshot>();
+    sp->bin = ctx->retire_bin;
     Snapshot& s = *sp;
     std::shared_ptr<ArenaSet> ar = std::make_shared<ArenaSet>();
+    ar->bin = ctx->retire_bin;
     std::shared_ptr<HandleMaps> maps = std::make_shared<HandleMaps>();
     std::vector<std::pair<uint64_t, TermHost*>> order;
     for (auto& f : ctx->fields) {
@@ -398,6 +410,8 @@ int commit_full(tsgpu_ctx* ctx) {
         h_last.resize(t.d_blk_base + t.d_blk_cap, 0u); h_bids.resize(t.d_blk_base + t.d_blk_cap); h_bmeta.resize(t.d_blk_base + t.d_blk_cap);     // spare entries
         t.handle = (uint32_t)s.h_lists.size();
         t.dirty = false; t.desc_rewrite = false;
+        t.dev_idw = t.dev_pw = 0;
+        for (const BlockMeta& m : t.pl.blk_meta) { t.dev_idw += ids_words(m); t.dev_pw += pay_words(m); }
         maps->handle_of[e.first] = t.handle;
         s.h_lists.push_back(list_desc(t, ids_base, pay_base, t.d_blk_base));
     }
@@ -409,6 +423,7 @@ int commit_full(tsgpu_ctx* ctx) {
     if (!h_bmeta.empty()) TSGPU_HIP_TRY(hipMemcpy(ar->blk_meta.p, h_bmeta.data(), h_bmeta.size() * sizeof(BlockMeta), hipMemcpyHostToDevice));
     TSGPU_HIP_TRY(hipMemcpy(ar->payload.p, h_pw.data(), h_pw.size() * 4, hipMemcpyHostToDevice));
     ar->used_blocks = ar->live_blocks = n_slots; ar->used_idw = ar->live_idw = n_idw; ar->used_pw = ar->live_pw = n_pw;
+    ctx->erased_dev_idw = ctx->erased_dev_pw = 0;
     maps->rebuild_dense();
     s.ar = ar; s.maps = maps;
     s.bytes = ar->bytes() + s.lists.cap;
@@ -427,6 +442,7 @@ int commit_incremental(tsgpu_ctx* ctx, const std::shared_ptr<const Snapshot>& cu
     std::shared_ptr<ArenaSet> ar = cur->ar;
     const std::vector<uint64_t>& keys = ctx->dirty_terms;       // sorted, unique (tsgpu_commit)
     std::shared_ptr<Snapshot> sp = std::make_shared<Snapshot>();
+    sp->bin = ctx->retire_bin;
     Snapshot& s = *sp;
     s.h_lists = cur->h_lists;
     std::shared_ptr<HandleMaps> new_maps;                        // copy-on-write: only when a term appears or disappears
@@ -435,7 +451,7 @@ int commit_incremental(tsgpu_ctx* ctx, const std::shared_ptr<const Snapshot>& cu
     std::vector<BlockIds> st_bids, sc_bids;
     std::vector<BlockMeta> st_bmeta, sc_bmeta;
     std::vector<uint64_t> sc_dst;
-    uint64_t dead_slots = 0, new_live_idw = 0, new_live_pw = 0;
+    uint64_t dead_slots = 0, new_live_idw = 0, new_live_pw = 0, dead_idw = ctx->erased_dev_idw, dead_pw = ctx->erased_dev_pw;
     uint32_t max_id = 0;
     struct Touched { TermHost* t; uint64_t key; };
     std::vector<Touched> touched;
@@ -483,8 +499,19 @@ int commit_incremental(tsgpu_ctx* ctx, const std::shared_ptr<const Snapshot>& cu
             st_pw.insert(st_pw.end(), t.pl.payload.begin() + m.oi_woff, t.pl.payload.begin() + m.oi_woff + pw);
             t.dev[b].idw = ipos; t.dev[b].pw = ppos;
             ipos += iw; ppos += pw;
-            new_live_idw += iw; new_live_pw += pw;
         }
+        // live words: this list's new version replaces its committed one (re-written and removed blocks stay behind as garbage)
+        uint64_t li = 0, lp = 0;
+        for (const BlockMeta& m : t.pl.blk_meta) { li += ids_words(m); lp += pay_words(m); }
+        new_live_idw += li; new_live_pw += lp;
+        dead_idw += t.dev_idw; dead_pw += t.dev_pw;
+    }
+    // COMPACTION: when the arenas would hold more garbage than live words after this commit, re-pack everything instead (the full
+    // path; also restores the tail room and clears every LIST_HAS_BREAKS). Small indexes never bother (index_compact_min_words).
+    {
+        const uint64_t live_i = ar->live_idw + new_live_idw - std::min(ar->live_idw + new_live_idw, dead_idw), live_p = ar->live_pw + new_live_pw - std::min(ar->live_pw + new_live_pw, dead_pw);
+        const uint64_t gar_i = ipos - std::min(ipos, live_i), gar_p = ppos - std::min(ppos, live_p);
+        if ((gar_i > live_i && gar_i > ctx->index_compact_min_words) || (gar_p > live_p && gar_p > ctx->index_compact_min_words)) { ctx->commit_compactions++; return -1; }
     }
     // descriptors
     const uint64_t blk0 = ar->used_blocks;
@@ -559,7 +586,14 @@ int commit_incremental(tsgpu_ctx* ctx, const std::shared_ptr<const Snapshot>& cu
     TSGPU_HIP_TRY(hipMemcpy(s.lists.p, s.h_lists.data(), s.h_lists.size() * sizeof(ListDesc), hipMemcpyHostToDevice));
     ar->used_idw = ipos; ar->used_pw = ppos; ar->used_blocks = blk0 + st_last.size();
     ar->live_blocks = ar->live_blocks + st_last.size() - std::min<uint64_t>(dead_slots, ar->live_blocks + st_last.size());
-    ar->live_idw += new_live_idw; ar->live_pw += new_live_pw;
+    ar->live_idw = ar->live_idw + new_live_idw - std::min(ar->live_idw + new_live_idw, dead_idw);
+    ar->live_pw = ar->live_pw + new_live_pw - std::min(ar->live_pw + new_live_pw, dead_pw);
+    ctx->erased_dev_idw = ctx->erased_dev_pw = 0;
+    for (auto& tc : touched) {
+        TermHost& t = *tc.t;
+        t.dev_idw = t.dev_pw = 0;
+        for (const BlockMeta& m : t.pl.blk_meta) { t.dev_idw += ids_words(m); t.dev_pw += pay_words(m); }
+    }
     for (auto& pc : placed) { TermHost& t = *pc.t; t.d_blk_base = pc.base; t.d_blk_cap = pc.cap; t.d_blk_n = (uint32_t)t.pl.blk_last.size(); t.dirty = false; t.desc_rewrite = false; }
     if (new_maps) { new_maps->rebuild_dense(); s.maps = new_maps; } else s.maps = cur->maps;
     s.ar = ar;
@@ -580,12 +614,14 @@ extern "C" {
 
 // Publishes every pending posting-list change as ONE new immutable snapshot (RCU): a search that started on the previous snapshot
 // keeps it alive until it returns, a failing commit leaves the previous snapshot in place, and searches never wait on a commit.
-// Cost: O(changed blocks) — see the header of this file; O(index) only for the first commit and for compactions.
+// Cost: the changed blocks' words + the descriptor table (48 B per list, copied and uploaded whole) + a copy of the term map when a
+// term appeared or disappeared — see the header of this file; O(index) only for the first commit and for compactions.
 int tsgpu_commit(tsgpu_ctx* ctx) {
     if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
     std::lock_guard<std::mutex> lk(ctx->mu);
     (void)hipSetDevice(ctx->device);
     const uint64_t t0 = wall_us();
+    ctx->retire_bin->drain();                        // buffers of snapshots that searches have let go of since the last commit
     try {
         const std::shared_ptr<const Snapshot> cur = ctx->snapshot();
         int rc = -1;
@@ -608,6 +644,7 @@ int tsgpu_commit(tsgpu_ctx* ctx) {
         ctx->commit_force_full = false;
         ctx->dirty = false;
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_commit: host allocation failed"); }
+    ctx->retire_bin->drain();                        // (the snapshot this commit replaced, unless a search still holds it)
     ctx->commit_last_us = wall_us() - t0;
     return ok();
 }
