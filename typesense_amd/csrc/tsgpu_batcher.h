@@ -4,8 +4,9 @@
 //
 //   * a caller parks its request; the first parked caller without a leader becomes the LEADER of the next round;
 //   * the leader gathers until every thread that is inside the entry point (and not already being executed) has parked, or
-//     `batch_window_us` passed, then takes an execution resource (a keyword lane / the vector executor). While every
-//     resource is busy that acquisition blocks and callers keep parking: under load the rounds size themselves;
+//     `batch_window_us` passed (10 us: a free lane must not idle — with 80 us the lanes were busy 2.5 of 4 under 256 callers), then
+//     takes an execution resource (a keyword lane / the vector executor). While every resource is busy that acquisition blocks and
+//     callers keep parking: under load the rounds size themselves;
 //   * the leader takes the round (FIFO, compatible requests only), promotes the next parked caller to leader — it gathers
 //     and plans on another lane while this round runs on the GPU —, executes the round as ONE batch and hands every caller
 //     its slice.
