@@ -1,9 +1,10 @@
-for cfg in "5000 50" "3000 70" "2500 75" "4000 60" "1250 60" "1250 70" "2000 80"; do
-set -- $cfg
-python bench.py --workload keyword --no-cpu-baseline --no-extras --steps 3 --warmup 1 --opt kw_host_split_queries=$1 --opt kw_host_split_first_pct=$2 > /tmp/h.json 2>/dev/null
+for w in 300 0 600 150; do
+python bench.py --workload vector --no-cpu-baseline --steps 3 --warmup 1 --hnsw-rows 0 --opt vec_batch_post_window_us=$w > /tmp/v.json 2>/dev/null
 python - <<P
 import json
-d=json.loads(open("/tmp/h.json").read().strip().splitlines()[-1])
-print("min slice $1 first $2%: value", round(d["value"]), "host delivery", round(d.get("value_with_host_delivery",0)))
+d=json.loads(open("/tmp/v.json").read().strip().splitlines()[-1])
+c=d["concurrency"] if "concurrency" in d else d["vector"]["concurrency"]
+print("post window $w:", round(d["value"]), {k:(round(v,1) if isinstance(v,float) else v) for k,v in c.items() if k in ("value","p50_us","p99_us","queries_per_round","failures")}, c["parity"]["mismatches"])
 P
 done
+python -m pytest tests/test_gpu_at_size.py tests/test_gpu_concurrency.py -x -q 2>&1 | tail -2

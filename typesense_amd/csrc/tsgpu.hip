@@ -283,6 +283,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
         if (value < 1 || value > tsgpu_ctx::N_LANES) return fail(TSGPU_ERR_INVALID, "kw_lanes out of range (1..8)");
         ctx->n_lanes = (int)value; return ok();
     }
+    if (!strcmp(name, "vec_batch_post_window_us")) { ctx->vec_batch_post_window_us = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 100000); return ok(); }
     if (!strcmp(name, "batch_window_us")) { ctx->batch_window_us = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 100000); return ok(); }
     if (!strcmp(name, "batch_max_queries")) { ctx->batch_max_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20); return ok(); }   // 0 = never coalesce
     if (!strcmp(name, "batch_round_queries")) { ctx->batch_round_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 1 << 20); return ok(); }

@@ -72,6 +72,7 @@ struct Combiner {
     uint32_t pending_units = 0;
     bool collecting = false;                         // a leader exists (gathering / waiting for its resource)
     bool gathering = false;                          // ... and sleeps on gather_word until everyone has parked
+    int gather_target = 0;                           // ... "everyone" = this many calls (parked + executing)
     std::atomic<uint32_t> gather_word{0};
     std::atomic<int> executing_calls{0};             // calls inside rounds that are being executed
     uint64_t rounds = 0, coalesced_calls = 0, arrivals = 0;
@@ -89,14 +90,21 @@ struct Combiner {
     // std::unique_ptr to its lock; pick(pending, round) moves the requests of the round out of `pending` (FIFO, compatible ones; it
     // MUST take the front request — the leader's own); exec(round, guard) runs without the combiner's mutex and fills rc / err /
     // outputs of every request.
+    // post_window_us: a SECOND gather after the resource has been acquired, for rounds whose cost hardly depends on their size (the
+    // vector scan streams the whole collection once per round: 3.3 ms for 64 queries, 4.6 ms for 256). The callers of the round that
+    // just finished are OUTSIDE the entry point for a moment (returning their result, calling again), so "everyone inside has parked"
+    // is true too early and the rounds ping-pong between two halves of the callers; here the leader waits until as many have parked as
+    // were recently seen inside at once (peak, decaying), or the window passes.
+    int peak_callers = 0;
     template <class Acquire, class Pick, class Exec>
-    void run(Req& me, const std::atomic<int>& callers, uint32_t window_us, Acquire acquire, Pick pick, Exec exec) {
+    void run(Req& me, const std::atomic<int>& callers, uint32_t window_us, Acquire acquire, Pick pick, Exec exec, uint32_t post_window_us = 0) {
         {
             std::lock_guard<std::mutex> lk(m);
             me.bank = (uint32_t)((arrivals++ / PER_BANK) % BANKS);
             pending.push_back(&me);
             pending_units += me.units;
-            if (gathering && (int)pending.size() >= callers.load() - executing_calls.load()) { gather_word.fetch_add(1); futex_wake_all(&gather_word); }
+            peak_callers = std::max(peak_callers, callers.load());
+            if (gathering && (int)pending.size() >= gather_target - executing_calls.load()) { gather_word.fetch_add(1); futex_wake_all(&gather_word); }
             // no leader: pending was empty (a leader that leaves requests behind always promotes the front one), so this request is the front
             if (!collecting) { collecting = true; me.state.store(ParkedRequest::LEADER, std::memory_order_relaxed); }
         }
@@ -121,19 +129,28 @@ struct Combiner {
         // ---- leader of the next round (this request is the front of `pending`) ----
         std::unique_lock<std::mutex> lk(m);
         const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(window_us);
-        gathering = true;
-        while ((int)pending.size() < callers.load() - executing_calls.load()) {
-            const auto now = std::chrono::steady_clock::now();
-            if (now >= deadline) break;
-            const uint32_t w = gather_word.load();
-            lk.unlock();
-            futex_wait_u32(&gather_word, w, (long)std::max<long long>(1, std::chrono::duration_cast<std::chrono::microseconds>(deadline - now).count()));
-            lk.lock();
-        }
-        gathering = false;
+        auto gather = [&](std::chrono::steady_clock::time_point until, bool use_peak) {
+            gathering = true;
+            for (;;) {
+                gather_target = use_peak ? std::max(peak_callers, callers.load()) : callers.load();
+                if ((int)pending.size() >= gather_target - executing_calls.load()) break;
+                const auto now = std::chrono::steady_clock::now();
+                if (now >= until) break;
+                const uint32_t w = gather_word.load();
+                lk.unlock();
+                futex_wait_u32(&gather_word, w, (long)std::max<long long>(1, std::chrono::duration_cast<std::chrono::microseconds>(until - now).count()));
+                lk.lock();
+            }
+            gathering = false;
+        };
+        gather(deadline, false);
         lk.unlock();
         auto guard = acquire();                      // natural batching: callers keep parking while every resource is busy
         lk.lock();
+        if (post_window_us) {
+            gather(std::chrono::steady_clock::now() + std::chrono::microseconds(post_window_us), true);
+            peak_callers = std::max(callers.load(), peak_callers - std::max(1, peak_callers / 8));      // (decays when the load drops)
+        }
         std::vector<Req*> round;
         pick(pending, round);
         uint32_t units = 0;

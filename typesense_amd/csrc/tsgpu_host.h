@@ -369,6 +369,8 @@ struct tsgpu_ctx {
     tsgpu::Combiner<tsgpu::VecRequest> vec_comb;
     std::atomic<int> kw_callers{0}, vec_callers{0};  // threads currently inside the search entry points
     uint32_t ticks_per_us = 100;                     // device wall clock (hipDeviceAttributeWallClockRate)
+    uint32_t vec_batch_post_window_us = 300;         // vector rounds: after the executor is free the leader waits this long for the callers of the round that just
+                                                     // finished to come back (a round's cost hardly grows with its size: tsgpu_batcher.h)
     uint32_t batch_window_us = 10;                   // micro-batcher: how long a round's leader waits for more callers
     uint32_t batch_max_queries = 64;                 // calls with more queries than this are not coalesced (they are batches already)
     uint32_t batch_round_queries = 1024;             // queries per coalesced round at most

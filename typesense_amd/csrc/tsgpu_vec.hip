@@ -634,7 +634,7 @@ static int vec_knn_coalesced(tsgpu_ctx* ctx, uint32_t field, const float* Q, uin
         } catch (const std::bad_alloc&) { rc = TSGPU_ERR_NO_MEMORY; err = "tsgpu_vec_knn_batch: host allocation failed"; }
         for (VecRequest* r : round) { r->rc = rc; r->err = err; }
     };
-    ctx->vec_comb.run(me, ctx->vec_callers, ctx->batch_window_us, acquire, pick, exec);
+    ctx->vec_comb.run(me, ctx->vec_callers, ctx->batch_window_us, acquire, pick, exec, ctx->vec_batch_post_window_us);
     if (me.rc != TSGPU_OK) return fail(me.rc, me.err);
     return ok();
 }
