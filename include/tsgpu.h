@@ -119,6 +119,8 @@ int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
  * 0 = never), "batch_window_us" = how long a round's leader waits for the other threads that are inside the entry point to
  * park (default 10: a lane that is free should not idle; while every lane is busy callers keep parking and the rounds size
  * themselves), "batch_round_queries" = queries per coalesced round at most (default 1024);
+ * "hybrid_overlap" = 1 (default): tsgpu_hybrid_search_batch runs its keyword pass on a second host thread and its own lane while
+ * the vector pass runs (0: one after the other; identical results);
  * "vec_batch_post_window_us" (default 300) = a coalesced VECTOR round's leader, once the executor is free, waits this long for the
  * callers of the round that just finished to call again (a scan's cost hardly depends on the number of queries it serves);
  * "kw_merge_select_min" = from this many per-work-item Topsters per query the merge selects (threshold of the k-th largest of a

@@ -1,10 +1,10 @@
-for w in 300 0 600 150; do
-python bench.py --workload vector --no-cpu-baseline --steps 3 --warmup 1 --hnsw-rows 0 --opt vec_batch_post_window_us=$w > /tmp/v.json 2>/dev/null
+for o in 1 0 1 0; do
+python bench.py --workload hybrid --no-cpu-baseline --no-extras --steps 10 --warmup 3 --opt hybrid_overlap=$o > /tmp/h.json 2>/dev/null
 python - <<P
 import json
-d=json.loads(open("/tmp/v.json").read().strip().splitlines()[-1])
-c=d["concurrency"] if "concurrency" in d else d["vector"]["concurrency"]
-print("post window $w:", round(d["value"]), {k:(round(v,1) if isinstance(v,float) else v) for k,v in c.items() if k in ("value","p50_us","p99_us","queries_per_round","failures")}, c["parity"]["mismatches"])
+d=json.loads(open("/tmp/h.json").read().strip().splitlines()[-1])
+h=d if "hybrid" not in d else d["hybrid"]
+print("overlap $o:", round(h["value"]), round(h["ms_per_step"],3))
 P
 done
-python -m pytest tests/test_gpu_at_size.py tests/test_gpu_concurrency.py -x -q 2>&1 | tail -2
+python -m pytest tests/test_gpu_vector.py tests/test_gpu_at_size.py -x -q -k "hybrid" 2>&1 | tail -2

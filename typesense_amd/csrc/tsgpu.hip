@@ -283,6 +283,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
         if (value < 1 || value > tsgpu_ctx::N_LANES) return fail(TSGPU_ERR_INVALID, "kw_lanes out of range (1..8)");
         ctx->n_lanes = (int)value; return ok();
     }
+    if (!strcmp(name, "hybrid_overlap")) { ctx->hybrid_overlap = value != 0; return ok(); }
     if (!strcmp(name, "vec_batch_post_window_us")) { ctx->vec_batch_post_window_us = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 100000); return ok(); }
     if (!strcmp(name, "batch_window_us")) { ctx->batch_window_us = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 100000); return ok(); }
     if (!strcmp(name, "batch_max_queries")) { ctx->batch_max_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20); return ok(); }   // 0 = never coalesce
@@ -979,7 +980,7 @@ static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n
     bo.keep_ids = legacy_keep || ids_out != nullptr;
     bo.id_lists = lists.get();
     bo.record_last = legacy_keep;
-    LaneLock ll(ctx, legacy_keep ? 0 : -1);          // the legacy "last batch" id API is single-caller: always lane 0
+    LaneLock ll(ctx, legacy_keep ? 0 : (tsgpu::tls_avoid_lane0() ? -2 : -1));          // the legacy "last batch" id API is single-caller: always lane 0
     const int rc = kw_batch_on_lane(ctx, *ll.L, queries, n_queries, out, bo);
     if (rc == TSGPU_OK && ids_out) *ids_out = lists.release();
     return rc;

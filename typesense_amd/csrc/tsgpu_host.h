@@ -28,6 +28,7 @@ namespace tsgpu {
 
 // Option<T>-style error plumbing (include/option.h of the reference): code + message, never throw.
 inline std::string& tls_error() { static thread_local std::string e; return e; }
+inline bool& tls_avoid_lane0() { static thread_local bool b = false; return b; }      // this thread's keyword batches keep off lane 0 (it shares the vector path's stream)
 inline int fail(int code, const std::string& msg) { tls_error() = msg; return code; }
 inline int ok() { return TSGPU_OK; }
 
@@ -310,7 +311,7 @@ struct LaneDispenser {
     std::condition_variable cv;
     std::deque<Waiter*> q;
     bool busy[16] = {};
-    static bool can(int lane, int want, int n) { return want < 0 ? lane < n : want == lane; }
+    static bool can(int lane, int want, int n) { return want == -2 ? (lane < n && (lane >= 1 || n == 1)) : (want < 0 ? lane < n : want == lane); }    // -2: any lane but 0 (lane 0 shares the vector path's stream)
     int acquire(int want, int n_lanes) {
         std::unique_lock<std::mutex> lk(m);
         for (int lane = 0; lane < 16; lane++) {
@@ -369,6 +370,7 @@ struct tsgpu_ctx {
     tsgpu::Combiner<tsgpu::VecRequest> vec_comb;
     std::atomic<int> kw_callers{0}, vec_callers{0};  // threads currently inside the search entry points
     uint32_t ticks_per_us = 100;                     // device wall clock (hipDeviceAttributeWallClockRate)
+    bool hybrid_overlap = true;                      // tsgpu_hybrid_search_batch: keyword pass and vector pass at the same time (option "hybrid_overlap")
     uint32_t vec_batch_post_window_us = 300;         // vector rounds: after the executor is free the leader waits this long for the callers of the round that just
                                                      // finished to come back (a round's cost hardly grows with its size: tsgpu_batcher.h)
     uint32_t batch_window_us = 10;                   // micro-batcher: how long a round's leader waits for more callers

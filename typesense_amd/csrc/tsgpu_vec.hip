@@ -1190,13 +1190,31 @@ int tsgpu_hybrid_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uin
         kw.match_score_index = msi.data(); kw.n_hits = nh.data(); kw.num_matched = nm.data(); kw.status = st.data(); kw.search_cutoff = co.data();
         static const bool host_timing = getenv("TSGPU_HOST_TIMING") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
-        int rc = tsgpu_keyword_search_batch(ctx, queries, n_queries, &kw);
-        if (rc) return rc;
+        // The keyword pass runs on a second host thread and on a keyword lane of its own (not lane 0: that one shares the vector stream)
+        // WHILE the vector pass runs here: its kernels fill the chip during the vector pass's thin phases (query cast, sample pass,
+        // threshold select, refine / re-score / select: ~1.2 ms of a 6 ms pass). Neither pass reads the other's results.
+        int rc_kw = TSGPU_OK;
+        std::string err_kw;
+        std::thread kw_thread;
+        const bool overlap = ctx->hybrid_overlap && ctx->n_lanes >= 2;
+        auto kw_pass = [&]() {
+            tls_avoid_lane0() = true;
+            rc_kw = tsgpu_keyword_search_batch(ctx, queries, n_queries, &kw);
+            tls_avoid_lane0() = false;
+            if (rc_kw != TSGPU_OK) err_kw = tls_error();
+        };
+        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{kw_thread};      // (every exit path waits for the pass)
+        if (overlap) { try { kw_thread = std::thread(kw_pass); } catch (const std::system_error&) { kw_pass(); } }
+        else kw_pass();
+        if (!overlap && rc_kw) return fail(rc_kw, err_kw);
         const auto t1 = std::chrono::steady_clock::now();
         // 2) vector pass: one batched exact k-NN for the whole batch; a query with filter_by / excluded ids (the VectorFilterFunctor of
         //    process_results_hnsw_index, src/index.cpp:3376-3445) gets its own exact k-NN restricted to its allowed ids afterwards
         KnnHost kh;
-        if ((rc = knn_to_host(ctx, vec_field_id, Q, mem_q, n_queries, k, nullptr, 0, nullptr, 0, kh))) return rc;
+        int rc = knn_to_host(ctx, vec_field_id, Q, mem_q, n_queries, k, nullptr, 0, nullptr, 0, kh);
+        if (kw_thread.joinable()) kw_thread.join();
+        if (rc_kw) return fail(rc_kw, err_kw);
+        if (rc) return rc;
         {
             KnnHost one;
             for (uint32_t q = 0; q < n_queries; q++) {
