@@ -1088,7 +1088,9 @@ def main():
         if "host_qps" in r:
             kw["value_with_host_delivery"] = r["host_qps"]       # PCIe-inclusive (112 MB of hit arrays per 10 000-query batch into pageable host memory)
         find_rx, score_rx = r"kw_find2_kernel<3>|kw_search_kernel<3, 512, true, true>", r"kw_score_kernel"
-        traffic = pmc_traffic([find_rx, score_rx], ["pmc_kw_fetch.txt", "pmc_kw_s5_fetch.txt"])
+        # (max over the dispatches = the full 10 000-query launch: the profiled command also runs the host-delivery leg, whose three slices
+        #  are smaller launches of the same kernels and would dilute an average)
+        traffic = pmc_traffic([find_rx, score_rx], ["pmc_kw_fetch.txt", "pmc_kw_s5_fetch.txt"], field="max")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "kw_find2_kernel<3> (two driver blocks per iteration) + kw_score_kernel<512> (the two halves of the intersect+score+select step, "
                           "launched back to back; kernel_ms spans both)", "kernel_ms": r["kern_ms"], "merge_kernel_ms": r["merge_ms"],
@@ -1107,8 +1109,8 @@ def main():
             roof["fetched_frac"] = traffic / (r["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             roof["fetched_frac_x2"] = 2.0 * roof["fetched_frac"]      # upper bound if every read were a wide one (FETCH_SIZE halves those on gfx950)
             roof["algorithmic_over_fetched"] = r["alg_bytes"] / traffic
-        valu = pmc_counter(find_rx, ["pmc_kw_sq1.txt", "pmc_kw_s5_sq1.txt"], "SQ_INSTS_VALU")
-        salu = pmc_counter(find_rx, ["pmc_kw_sq1.txt", "pmc_kw_s5_sq1.txt"], "SQ_INSTS_SALU")
+        valu = pmc_counter(find_rx, ["pmc_kw_sq1.txt", "pmc_kw_s5_sq1.txt"], "SQ_INSTS_VALU", field="max")
+        salu = pmc_counter(find_rx, ["pmc_kw_sq1.txt", "pmc_kw_s5_sq1.txt"], "SQ_INSTS_SALU", field="max")
         busy = pmc_counter(find_rx, ["pmc_kw_sq2.txt", "pmc_kw_s5_sq2.txt"], "SQ_BUSY_CYCLES") or pmc_counter(find_rx, ["pmc_kw_sq1.txt", "pmc_kw_s5_sq1.txt"], "GRBM_GUI_ACTIVE")
         if valu and salu:
             # issue capacity per CU and cycle (MI355X_MICROARCH.md): 4 SIMD-32 units, a wave64 VALU instruction issues over 2 cycles -> 2 VALU
