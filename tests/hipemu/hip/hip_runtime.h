@@ -347,7 +347,7 @@ inline void __builtin_amdgcn_sched_barrier(int) {}
 
 // ---------------------------------------------------------------- host runtime API subset (emulated)
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNotReady = 600, hipErrorUnknown = 999 };
 typedef struct hipemu_stream* hipStream_t;
 typedef struct hipemu_event { double t; }* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
@@ -371,6 +371,7 @@ inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipE
 inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); e->t = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 // fault injection (tests/test_emu_incremental.py): the N-th hipMalloc / synchronous hipMemcpy from now on fails once (0 = off).

@@ -45,12 +45,49 @@ def run(threads, calls, qpc=1):
             return int(d["usage_usec"]), int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
         except Exception:
             return 0, 0, 0
+    def thread_cpu():        # clock ticks (utime + stime) of the threads that exist NOW (runtime helpers, host pools: the load generator's threads come and go)
+        out = {}
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                f = open("/proc/self/task/%s/stat" % tid).read()
+                comm = f[f.index("(") + 1:f.rindex(")")]
+                rest = f[f.rindex(")") + 2:].split()
+                out[tid] = (comm, int(rest[11]) + int(rest[12]))
+            except Exception:
+                pass
+        return out
+    def proc_cpu():
+        rest = open("/proc/self/stat").read()
+        rest = rest[rest.rindex(")") + 2:].split()
+        return int(rest[11]) + int(rest[12])
+    prof = None
+    if os.environ.get("PROF"):
+        import subprocess
+        so = "/tmp/libsigprof.so"
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(os.path.dirname(os.path.abspath(__file__)), "sigprof", "sigprof.cpp"), "-ldl"])
+        prof = C.CDLL(so)
+        prof.sigprof_start(2000)
+    th0, pc0 = thread_cpu(), proc_cpu()
     cs0 = cpu_stat()
     c0 = {n: g.counter(n) for n in names}
     [g.counter(n) for n in ("kw_max_plan_us", "kw_max_upload_us", "kw_max_launch_us", "kw_max_wait_us", "kw_max_queue_us", "kw_max_wake_us")]
     wall = LG.tsgpu_loadgen_keyword(fn, g.h, C.cast(arr, C.c_void_p), n_q, 250, 100, threads, calls, qpc, lat.ctypes.data, got.ctypes.data, C.byref(fails))
+    if prof:
+        out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "sigprof_%d_%d.txt" % (threads, qpc))
+        n = prof.sigprof_stop(out.encode(), 2, 8)
+        print("   sigprof: %d samples -> %s" % (n, out), flush=True)
     c = {n: g.counter(n) - c0[n] for n in names}
     cs1 = cpu_stat()
+    th1, pc1 = thread_cpu(), proc_cpu()
+    tick = os.sysconf("SC_CLK_TCK")
+    helpers = {}
+    for tid, (comm, t1) in th1.items():
+        if tid in th0:
+            helpers[comm] = helpers.get(comm, 0) + (t1 - th0[tid][1])
+    hsum = sum(helpers.values())
+    print("   process CPU %.0f ms over %.0f ms wall; threads that outlive the run (runtime helpers etc.): %.0f ms %s; request threads: %.0f ms = %.1f us per call"
+          % ((pc1 - pc0) * 1e3 / tick, wall * 1e3, hsum * 1e3 / tick, {k: round(v * 1e3 / tick) for k, v in helpers.items() if v}, (pc1 - pc0 - hsum) * 1e3 / tick,
+             (pc1 - pc0 - hsum) * 1e6 / tick / (threads * calls * qpc)), flush=True)
     print("   cgroup: %.1f CPU-us per call (%.1f CPUs busy), throttled %d times for %.1f ms (cpu.max: %s)" % ((cs1[0] - cs0[0]) / (threads * calls * qpc), (cs1[0] - cs0[0]) / (wall * 1e6), cs1[1] - cs0[1], (cs1[2] - cs0[2]) / 1e3, open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "?"), flush=True)
     nb = max(c["kw_batches"], 1)
     print("   slowest batch phase: plan %d upload %d launch %d wait %d us; longest parked->round start %d us, results ready->caller resumes %d us" % tuple(g.counter(n) for n in ("kw_max_plan_us", "kw_max_upload_us", "kw_max_launch_us", "kw_max_wait_us", "kw_max_queue_us", "kw_max_wake_us")), flush=True)
@@ -86,6 +123,14 @@ if SWEEP == "capacity":   # what the lanes + the GPU deliver for rounds of a fix
                 g.set_option("kw_chunk_blocks", chunk)
                 r = run(lanes, max(16, 40000 // (lanes * qpc)), qpc)
                 print("capacity lanes=threads %2d qpc %3d chunk %2d: %8.0f q/s p50 %6.0f us | plan %.0f upload %.0f launch %.0f wait %.0f" % (lanes, qpc, chunk, r["qps"], r["p50"], r["plan"], r["upload"], r["launch"], r["wait"]), flush=True)
+    g.close()
+    sys.exit(0)
+if SWEEP == "default":     # the shipped options, several runs: where does the latency tail come from?
+    for rep in range(1 if os.environ.get("PROF") else 2):
+        for threads in (256, 16):
+            r = run(threads, max(16, 40000 // threads) * (60 if os.environ.get("PROF") else 1))
+            print("default threads %3d: %8.0f q/s p50 %6.0f p99 %6.0f us | %.1f q/batch plan %.0f upload %.0f launch %.0f wait %.0f | round exec %.0f scatter %.0f us fails %d"
+                  % (threads, r["qps"], r["p50"], r["p99"], r["q_per_batch"], r["plan"], r["upload"], r["launch"], r["wait"], r["exec_round"], r["scatter"], r["fails"]), flush=True)
     g.close()
     sys.exit(0)
 if SWEEP == "chunk":      # driver blocks per work item under 256 callers (auto = 8 for rounds of <= 128 queries: the single-call latency optimum)

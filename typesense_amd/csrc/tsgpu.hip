@@ -3,6 +3,10 @@
 // items); all scoring happens in kw_kernels.hip.h on the GPU. There is no CPU fallback: a query this
 // library does not accelerate is reported per query as TSGPU_ERR_UNSUPPORTED and left to the caller.
 #include "tsgpu_host.h"
+#if defined(__linux__)
+#include <sys/prctl.h>
+#include <time.h>
+#endif
 #include <cmath>
 #include "kw_kernels.hip.h"
 
@@ -986,6 +990,29 @@ static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n
     return rc;
 }
 
+// Waits for everything enqueued on the lane's stream WITHOUT burning a CPU: hipEventSynchronize on a hipEventBlockingSync event still
+// spins inside the HSA runtime for most of a small round (19 % of the process's CPU time under 256 callers, profiles/r03/
+// sigprof_256threads_before.txt), and with many request threads on a CPU quota that time is the throughput. Sleep for most of the
+// lane's usual wait, then poll the event between short sleeps (timer slack lowered for the sleeps: the default 50 us would triple them).
+static hipError_t sleeping_wait(KwLane& L, hipStream_t s) {
+    hipError_t e = hipEventRecord(L.ev_block, s);
+    if (e != hipSuccess) return e;
+    const uint64_t t0 = now_us();
+#if defined(__linux__)
+    const int slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+    (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+    auto nap = [](uint64_t us) { timespec ts; ts.tv_sec = 0; ts.tv_nsec = (long)(us * 1000); (void)nanosleep(&ts, nullptr); };
+    if (L.wait_ema_us > 40) nap(std::min<uint64_t>(L.wait_ema_us * 6 / 10, 2000));
+    while ((e = hipEventQuery(L.ev_block)) == hipErrorNotReady) nap(15);
+    if (slack > 0) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)slack, 0, 0, 0);
+#else
+    e = hipEventSynchronize(L.ev_block);
+#endif
+    const uint64_t w = now_us() - t0;
+    L.wait_ema_us = (L.wait_ema_us * 7 + w) / 8;
+    return e;
+}
+
 // the lane's mutex is held by the caller
 static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, const BatchOpts& bo) {
     (void)hipSetDevice(ctx->device);
@@ -1241,7 +1268,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
                 }
                 // (a spinning wait costs one CPU per lane for the whole round: with many request threads — and a CPU quota — the waiting
                 //  thread sleeps on a blocking event instead: +20-40 us of latency, four CPUs back)
-                if (ctx->kw_callers.load() >= ctx->blocking_sync_min_callers) { TSGPU_HIP_TRY(hipEventRecord(L.ev_block, s)); TSGPU_HIP_TRY(hipEventSynchronize(L.ev_block)); }
+                if (ctx->kw_callers.load() >= ctx->blocking_sync_min_callers) TSGPU_HIP_TRY(sleeping_wait(L, s));
                 else TSGPU_HIP_TRY(hipStreamSynchronize(s));
                 uint8_t* hb = (uint8_t*)L.h_out.p;
                 const uint32_t* nh = (const uint32_t*)(hb + out_at[0]);

@@ -196,6 +196,7 @@ struct KwLane {
     bool own_stream = true;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_chain = nullptr;                   // "this slice's kernels are done": the next slice of a sliced host-output batch waits for it ON THE DEVICE
+    uint64_t wait_ema_us = 100;                      // how long this lane's recent rounds waited for the GPU (sleeping_wait)
     hipEvent_t ev_block = nullptr;                   // hipEventBlockingSync: the waiting thread sleeps instead of spinning (many concurrent callers)
     DevBuf d_plan, d_ids_out;                        // the batch plan (queries, work items, aux ids, multi-field descriptors, hit offsets): one upload
     DevBuf d_part_s0, d_part_s1, d_part_s2, d_part_key, d_part_cnt, d_part_nm, d_part_ne, d_part_ow, d_part_f;
