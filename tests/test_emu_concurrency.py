@@ -68,7 +68,48 @@ def test_concurrent_one_query_calls_are_coalesced_and_exact(pair):
     calls = g.counter("batch_coalesced_calls") - c0
     assert calls > 0 and rounds > 0
     assert rounds < calls, "no two concurrent calls ever shared a round (%d rounds, %d calls)" % (rounds, calls)
-    g.set_option("batch_window_us", 80)
+    g.set_option("batch_window_us", 10)
+
+
+@pytest.mark.parametrize("round_cap,window", [(3, 0), (1024, 0), (5, 200)])
+def test_lock_free_combiner_under_churn_every_call_gets_its_own_result(pair, round_cap, window):
+    """the micro-batcher without a lock (tsgpu_batcher.h): arrivals push on a stack and elect the leader with one exchange, the leader
+    takes the whole stack. Many short rounds with no gather window, and a round cap of 3 queries so that most of a taken stack goes
+    BACK on it and the leadership is handed to a parked request: every call must come back exactly once with its own query's result
+    (a request taken into a round between its push and its election, or left on the stack without a leader, would hang or cross wires)"""
+    orc, g, _ = pair
+    rng = np.random.default_rng(17)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    n_threads, per_thread = 24, 10
+    flat = [T.KwQuery(rng.choice(np.arange(1, 30), size=int(rng.integers(1, 4)), replace=False), sort=sort, topster_size=32) for _ in range(n_threads * per_thread)]
+    ref = g.keyword_search_batch(flat, k_stride=32)                                  # the batch path (itself checked against the oracle elsewhere)
+    assert (ref.status == 0).all()
+    g.set_option("batch_window_us", window)
+    g.set_option("batch_round_queries", round_cap)
+    r0, c0 = g.counter("batch_rounds"), g.counter("batch_coalesced_calls")
+    start = threading.Barrier(n_threads)
+    done = [0] * n_threads
+    try:
+        def worker(i):
+            start.wait()
+            for j in range(per_thread):
+                qi = i * per_thread + j
+                nq = 2 if (qi % 7 == 0 and j + 1 < per_thread) else 1                 # some calls carry two queries
+                hits = g.keyword_search_batch(flat[qi:qi + nq], k_stride=32)
+                for u in range(nq):
+                    n = int(ref.n_hits[qi + u])
+                    assert hits.status[u] == 0 and int(hits.n_hits[u]) == n and int(hits.num_matched[u]) == int(ref.num_matched[qi + u]), (i, j, u)
+                    assert np.array_equal(hits.keys[u, :n], ref.keys[qi + u, :n]) and np.array_equal(hits.scores[u, :n], ref.scores[qi + u, :n]), (i, j, u)
+                done[i] += 1
+        _run_threads(n_threads, worker)
+        assert done == [per_thread] * n_threads
+        rounds, calls = g.counter("batch_rounds") - r0, g.counter("batch_coalesced_calls") - c0
+        assert rounds > 0 and calls >= rounds
+        if round_cap <= 5:
+            assert calls <= rounds * round_cap, "a round exceeded its cap (%d calls in %d rounds)" % (calls, rounds)
+    finally:
+        g.set_option("batch_window_us", 10)
+        g.set_option("batch_round_queries", 1024)
 
 
 def test_mixed_k_stride_and_failing_query_stay_per_caller(pair):
@@ -92,7 +133,7 @@ def test_mixed_k_stride_and_failing_query_stay_per_caller(pair):
                 assert hits.status[0] == 0
                 H.assert_hits_equal(hits, 0, ref, "k_stride %d" % ks)
     _run_threads(4, worker)
-    g.set_option("batch_window_us", 80)
+    g.set_option("batch_window_us", 10)
 
 
 def test_a_caller_whose_k_stride_is_too_small_fails_alone(pair):
@@ -121,7 +162,7 @@ def test_a_caller_whose_k_stride_is_too_small_fails_alone(pair):
                 assert hits.status[0] == 0
                 H.assert_hits_equal(hits, 0, ref, "shared a round with a failing caller")
     _run_threads(4, worker)
-    g.set_option("batch_window_us", 80)
+    g.set_option("batch_window_us", 10)
 
 
 def test_searches_during_commits_see_old_or_new_snapshot():
