@@ -203,7 +203,10 @@ static int vec_refresh_mirror(VecField* f, uint32_t row0, uint32_t n, uint64_t n
 }
 
 // the bf16-prefilter k-NN launch sequence (vec_kernels.hip.h, "bf16 PREFILTER path"); caller holds ctx->mu.
-static const uint32_t VEC_SURV_CAP = 8192;       // rows per query that may reach the exact re-score (more -> fp32 scan fallback)
+// rows per query that may reach the exact re-score (more -> fp32 scan fallback) = what vec_refine_kernel's LDS list holds: a query whose
+// k-th neighbour sits in a tight cluster has the WHOLE cluster inside its bf16 bracket (unit vectors, 10 000-row clusters: ~9 800
+// survivors per query; with the former 8 192 every group fell back to the fp32 scan: 39 ms instead of ~9 per 256 queries)
+static const uint32_t VEC_SURV_CAP = VEC_REFINE_LCAP;
 static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, uint32_t n_q, uint32_t k, const uint8_t* mask_dev,
                                float* dist_dev, uint64_t* label_dev, uint32_t* cnt_dev, bool record_events) {
     hipStream_t s = ctx->stream;
