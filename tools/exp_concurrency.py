@@ -125,6 +125,24 @@ if SWEEP == "capacity":   # what the lanes + the GPU deliver for rounds of a fix
                 print("capacity lanes=threads %2d qpc %3d chunk %2d: %8.0f q/s p50 %6.0f us | plan %.0f upload %.0f launch %.0f wait %.0f" % (lanes, qpc, chunk, r["qps"], r["p50"], r["plan"], r["upload"], r["launch"], r["wait"]), flush=True)
     g.close()
     sys.exit(0)
+if SWEEP == "soak":        # many short runs over every thread count: a rare race in the lock-free combiner would show as a hang or a failure
+    import random
+    random.seed(1)
+    bad = 0
+    for rep in range(int(os.environ.get("REPS", "12"))):
+        for threads in (2, 3, 5, 8, 16, 47, 49, 64, 128, 256):
+            g.set_option("batch_window_us", random.choice([0, 10, 10, 50]))
+            g.set_option("batch_round_queries", random.choice([2, 7, 64, 1024]))
+            g.set_option("kw_lanes", random.choice([1, 2, 4, 4, 8]))
+            lat = np.zeros(threads * 40)
+            got = np.zeros(n_q, np.uint64)
+            fails = C.c_uint64(0)
+            LG.tsgpu_loadgen_keyword(fn, g.h, C.cast(arr, C.c_void_p), n_q, 250, 100, threads, 40, random.choice([1, 1, 1, 2, 5]), lat.ctypes.data, got.ctypes.data, C.byref(fails))
+            bad += int(fails.value)
+        print("soak rep %d done, failures so far %d" % (rep, bad), flush=True)
+    print("SOAK", "OK" if bad == 0 else "FAILED", flush=True)
+    g.close()
+    sys.exit(0)
 if SWEEP == "default":     # the shipped options, several runs: where does the latency tail come from?
     for rep in range(1 if os.environ.get("PROF") else 2):
         for threads in (256, 16):
