@@ -175,3 +175,35 @@ def test_knn_is_deterministic_and_slab_invariant(big):
     g.set_option("vec_rows_per_slab", 128 * 100)
     d3, l3, _ = g.vec_knn_batch(1, Q, 100)
     assert np.array_equal(d0, d2) and np.array_equal(l0, l2) and np.array_equal(d0, d3) and np.array_equal(l0, l3)
+
+
+def test_tight_clusters_keep_a_whole_cluster_inside_the_bracket_and_stay_on_the_bracket_path():
+    """unit-length rows in tight clusters of ~12 000: the bf16 bracket of a query's k-th neighbour holds its WHOLE cluster (more than the
+    8 192 survivors rounds 1-2 allowed -> every group fell back to the fp32 scan). With the survivor arena at the refine kernel's own limit
+    (24 576) the bracket path handles it: no fallback, ~a cluster re-scored per query, labels / order / distance bits = the oracle's exact scan"""
+    rng = np.random.default_rng(5)
+    n, dim, n_clusters, n_q = 384_000, 128, 32, 48
+    cen = rng.standard_normal((n_clusters, dim)).astype(np.float32)
+    idx = rng.integers(0, n_clusters, size=n)
+    X = cen[idx] + 0.15 * rng.standard_normal((n, dim)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    Q = cen[rng.integers(0, n_clusters, size=n_q)] + 0.15 * rng.standard_normal((n_q, dim)).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    g = T.GpuIndex(0)
+    g.vec_create(1, dim, B.METRIC_IP, n)
+    g.vec_upsert(1, np.arange(n, dtype=np.uint64), X)
+    g.set_option("vec_count_rescored", 1)
+    f0 = g.counter("vec_prefilter_fallbacks")
+    dist, lab, cnt = g.vec_knn_batch(1, Q, 100)
+    assert (cnt == 100).all()
+    assert g.counter("vec_prefilter_fallbacks") == f0, "the clustered batch fell back to the fp32 scan"
+    per_query = g.counter("vec_rescored_rows") / n_q
+    assert 8192 < per_query <= 24576, "expected about one cluster (~12 000 rows) inside every bracket, got %.0f rows per query" % per_query
+    orc = O.OracleIndex(1, 1)
+    orc.vec_init(dim, O.METRIC_IP)
+    orc.vec_add(np.arange(n, dtype=np.uint32), X)
+    for i in range(12):
+        d, l = orc.flat_knn(Q[i], 100)
+        assert np.array_equal(lab[i].astype(np.uint32), l), i
+        assert np.array_equal(dist[i].view(np.uint32), d.view(np.uint32)), i
+    g.close()
