@@ -122,6 +122,35 @@ def test_knn_two_pass_all_equal_distances_converges():
     g.close()
 
 
+def test_one_huge_tight_cluster_spills_the_refine_list_and_grows_the_segments():
+    """every row a near-tie of the k-th neighbour (one tight unit-length cluster of 27 000 rows): the candidates of a query outgrow the
+    (slab, query) segments (-> the host grows them and scans again) and the refine kernel's LDS list of 24 576 keys (-> the rest spills
+    to the global list); the bracket path still finishes — no fp32 fallback — and returns the oracle's neighbours bit for bit"""
+    lib = H.emu_lib_path()
+    rng = np.random.default_rng(3)
+    n, dim, k = 27_000, 16, 10
+    cen = rng.standard_normal(dim).astype(np.float32)
+    X = cen[None, :] + 0.05 * rng.standard_normal((n, dim)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    Q = cen[None, :] + 0.05 * rng.standard_normal((2, dim)).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    g = T.GpuIndex(0, lib)
+    g.vec_create(1, dim, B.METRIC_IP)
+    g.vec_upsert(1, np.arange(n, dtype=np.uint64), X)
+    g.set_option("vec_count_rescored", 1)
+    dist, lab, cnt = g.vec_knn_batch(1, Q, k)
+    assert (cnt == k).all()
+    assert g.counter("vec_prefilter_fallbacks") == 0 and g.counter("vec_overflow_rounds") >= 1
+    assert g.counter("vec_rescored_rows") > 2 * 24576, "the whole cluster should sit inside both brackets (%d rows re-scored)" % g.counter("vec_rescored_rows")
+    orc = O.OracleIndex(1, 1)
+    orc.vec_init(dim, O.METRIC_IP)
+    orc.vec_add(np.arange(n, dtype=np.uint32), X)
+    for i in range(2):
+        d, l = orc.flat_knn(Q[i], k)
+        assert np.array_equal(lab[i].astype(np.uint32), l) and np.array_equal(dist[i].view(np.uint32), d.view(np.uint32))
+    g.close()
+
+
 def _check_knn_bits(g, orc, Q, k, allow=None):
     """bf16-prefilter path: survivors are re-scored with hnswlib's own summation order -> distances are BIT-identical
     to the oracle and the order (incl. ties -> smaller label) is exactly the oracle's"""

@@ -30,7 +30,8 @@ struct VecField {
     bool any_deleted = false;
     // scratch
     DevBuf d_dense, d_cand, d_cand_cnt, d_tau, dQ, d_dist, d_lab, d_cnt, d_mask, d_rows, d_q1, d_out1;
-    DevBuf d_Qh, d_cq, d_L1, d_lbkey, d_surv, d_surv_cnt;
+    DevBuf d_Qh, d_cq, d_L1, d_lbkey, d_surv, d_surv_cnt, d_gkeys;
+    uint64_t seg_cap_hint = 0;                         // the largest (slab, query) candidate-segment capacity this field's data has needed so far
     // HNSW graph mirror (tsgpu_vec_hnsw_load): hnswlib's link lists; rows = hnswlib internal ids
     DevBuf g_link0, g_upper_ptr, g_upper_links, g_visited, g_vhash, g_stat;
     uint32_t g_tag_slots = 0;                          // tag mode: concurrent queries the allocated tag array serves (0 = not allocated)
@@ -54,7 +55,7 @@ struct VecField {
     }
     void release() {
         DevBuf* b[] = {&X, &labels, &row_ok, &Xh, &xnorm, &tile_nmax, &d_dense, &d_cand, &d_cand_cnt, &d_tau, &dQ, &d_dist, &d_lab, &d_cnt, &d_mask, &d_rows,
-                       &d_q1, &d_out1, &d_Qh, &d_cq, &d_L1, &d_lbkey, &d_surv, &d_surv_cnt, &g_link0, &g_upper_ptr, &g_upper_links, &g_visited, &g_vhash, &g_stat};
+                       &d_q1, &d_out1, &d_Qh, &d_cq, &d_L1, &d_lbkey, &d_surv, &d_surv_cnt, &d_gkeys, &g_link0, &g_upper_ptr, &g_upper_links, &g_visited, &g_vhash, &g_stat};
         for (auto* x : b) x->release();
     }
 };
@@ -203,10 +204,12 @@ static int vec_refresh_mirror(VecField* f, uint32_t row0, uint32_t n, uint64_t n
 }
 
 // the bf16-prefilter k-NN launch sequence (vec_kernels.hip.h, "bf16 PREFILTER path"); caller holds ctx->mu.
-// rows per query that may reach the exact re-score (more -> fp32 scan fallback) = what vec_refine_kernel's LDS list holds: a query whose
-// k-th neighbour sits in a tight cluster has the WHOLE cluster inside its bf16 bracket (unit vectors, 10 000-row clusters: ~9 800
-// survivors per query; with the former 8 192 every group fell back to the fp32 scan: 39 ms instead of ~9 per 256 queries)
-static const uint32_t VEC_SURV_CAP = VEC_REFINE_LCAP;
+// rows per query that may reach the exact re-score (more -> fp32 scan fallback). A query whose k-th neighbour sits in a tight cluster
+// has the WHOLE cluster inside its bf16 bracket (unit vectors, 10 000-row clusters: ~9 100 survivors per query; with the 8 192 of rounds
+// 1-2 every such group fell back to the fp32 scan: 39 ms instead of 7 per 256 queries). Re-scoring S rows per query costs S x dim x 4 B
+// of random row reads: at 64 K x 768 dims x 256 queries ~50 GB = about half the fp32 scan's time, beyond that the fallback is as good.
+static const uint32_t VEC_SURV_CAP = 65536;
+static const uint32_t VEC_REFINE_GCAP = 4 * VEC_SURV_CAP - VEC_REFINE_LCAP;      // candidates per query beyond the refine kernel's LDS list
 static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, uint32_t n_q, uint32_t k, const uint8_t* mask_dev,
                                float* dist_dev, uint64_t* label_dev, uint32_t* cnt_dev, bool record_events) {
     hipStream_t s = ctx->stream;
@@ -224,6 +227,7 @@ static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, 
     if ((rc = f->d_tau.reserve((size_t)n_q * 8))) return rc;
     if ((rc = f->d_surv.reserve((size_t)n_q * VEC_SURV_CAP * 4))) return rc;
     if ((rc = f->d_dense.reserve((size_t)n_q * VEC_SURV_CAP * 8))) return rc;          // exact keys of the survivors
+    if ((rc = f->d_gkeys.reserve((size_t)n_q * VEC_REFINE_GCAP * 4))) return rc;        // candidate keys beyond the refine kernel's LDS list
     uint32_t* d_over = f->d_surv_cnt.as<uint32_t>() + n_q;      // [0] overflow, [1] stuck (behind the per-query survivor counts)
 
     // slab geometry of a scan over n_ord tile ordinals: slabs are a multiple of 8 (XCD mapping), ~target workgroups in total
@@ -278,12 +282,15 @@ static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, 
         // >= 128: a slab of one tile always fits, so an index too small to yield a threshold (fewer than k sample groups) still works
     }
     seg_cap = std::max<uint64_t>(seg_cap, 1);
+    const uint64_t arena_limit = 4ull << 30;             // bytes of candidate segments at most (n_slabs x n_q x seg_cap x 8)
+    // (a field whose data needed larger segments before starts there: every call would otherwise pay the scan that discovers it)
+    if (!ctx->vec_cand_cap) while (seg_cap < f->seg_cap_hint && seg_cap * 2 * n_slabs * n_q * 8 <= arena_limit) seg_cap *= 2;
     if ((rc = f->d_cand.reserve((size_t)n_slabs * n_q * seg_cap * 8))) return rc;
     if ((rc = f->d_cand_cnt.reserve((size_t)n_slabs * n_q * 4))) return rc;
-    uint32_t h_over[2] = {0, 0};
-    for (int round = 0; round < 8; round++) {
+    uint32_t h_over[4] = {0, 0, 0, 0};
+    for (int round = 0; round < 10; round++) {
         TSGPU_HIP_TRY(hipMemsetAsync(f->d_cand_cnt.p, 0, (size_t)n_slabs * n_q * 4, s));
-        TSGPU_HIP_TRY(hipMemsetAsync(d_over, 0, 8, s));
+        TSGPU_HIP_TRY(hipMemsetAsync(d_over, 0, 16, s));
         VecHScanArgs a = base;
         a.n_ord = n_tiles; a.tile_stride = 1; a.mode = 0;
         a.seg = f->d_cand.as<uint64_t>(); a.seg_cnt = f->d_cand_cnt.as<uint32_t>(); a.seg_cap = (uint32_t)seg_cap;
@@ -292,12 +299,21 @@ static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, 
         if (record_events && round == 0) { TSGPU_HIP_TRY(hipEventRecord(ctx->ev[7], s)); TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s)); ctx->scan_events_valid = true; }
         hipLaunchKernelGGL(vec_refine_kernel, dim3(n_q), dim3(VEC_THREADS), 0, s, (const uint64_t*)a.seg, (const uint32_t*)a.seg_cnt, a.n_slabs, n_q, a.seg_cap, k,
                            (const float*)f->d_cq.as<float>(), (const float*)f->xnorm.as<float>(), f->d_L1.as<float>(), f->d_surv.as<uint32_t>(), VEC_SURV_CAP,
-                           f->d_surv_cnt.as<uint32_t>(), d_over);
+                           f->d_surv_cnt.as<uint32_t>(), d_over, f->d_gkeys.as<uint32_t>(), VEC_REFINE_GCAP);
         TSGPU_HIP_TRY(hipGetLastError());
-        TSGPU_HIP_TRY(hipMemcpyAsync(h_over, d_over, 8, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(h_over, d_over, 16, hipMemcpyDeviceToHost, s));
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
         if (!h_over[0] || h_over[1]) break;  // an overflowing list raised its own L1: scan again (unless it is stuck)
         ctx->vec_overflow_rounds++;
+        if (h_over[2]) {
+            // segments too small for this data (a query's candidates are the cluster around its k-th neighbour, not ~8k rows): grow them
+            const uint64_t grown = seg_cap * 4;
+            if (grown * n_slabs * n_q * 8 <= arena_limit && !ctx->vec_cand_cap) {
+                seg_cap = grown;
+                f->seg_cap_hint = std::max<uint64_t>(f->seg_cap_hint, seg_cap);
+                if ((rc = f->d_cand.reserve((size_t)n_slabs * n_q * seg_cap * 8))) return rc;
+            } else if (h_over[3]) { h_over[1] = 1; break; }                    // cannot grow and the bound cannot move: stuck
+        }
     }
     if (h_over[0]) {
         // brackets cannot separate this data (mass ties / more near-duplicates than the survivor arena): the fp32 scan's

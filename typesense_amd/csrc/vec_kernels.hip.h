@@ -870,17 +870,23 @@ __global__ __launch_bounds__(VEC_THREADS) void vec_thresh_kernel(const uint32_t*
 
 // one workgroup per query. Gathers the query's candidate segments (one per slab), L2 = k-th largest lower bound
 // s~ - c|q||x_row| among them (exact per-row norms), survivors (upper bound >= L2) -> surv rows for the exact re-score.
-// The lower-bound keys of the gathered entries live in LDS for the radix passes (VEC_REFINE_LCAP entries).
-//   overflow[0] += 1 : some segment or the LDS list overflowed -> L1[q] was raised to the L2 of what is held (valid, tighter)
+// The lower-bound keys of the gathered entries live in LDS for the radix passes (VEC_REFINE_LCAP entries); a query with more
+// candidates (its k-th neighbour sits in a cluster of tens of thousands of near-ties) spills the rest to its slice of a global list
+// (gkeys, gcap entries per query; the radix passes then read both).
+//   overflow[0] += 1 : some segment or both lists overflowed -> L1[q] was raised to the L2 of what is held (valid, tighter)
 //                      and the host scans again;
 //   overflow[1] += 1 : stuck — the bound cannot move (mass ties) or more than surv_cap rows sit inside the bracket of the k-th
 //                      best (near-duplicates): the host runs the group on the fp32 scan.
+//   overflow[2] += 1 : a (slab, query) segment overflowed; overflow[3] += 1 : ... and the bound could not move: the host grows the
+//                      segments and scans again (stuck for good only when they cannot grow).
 static const uint32_t VEC_REFINE_LCAP = 24576;
 __global__ __launch_bounds__(VEC_THREADS) void vec_refine_kernel(const uint64_t* __restrict__ seg, const uint32_t* __restrict__ seg_cnt, uint32_t n_slabs,
                                                                   uint32_t n_q, uint32_t seg_cap, uint32_t k, const float* __restrict__ cq,
                                                                   const float* __restrict__ xnorm, float* __restrict__ L1, uint32_t* __restrict__ surv_base,
-                                                                  uint32_t surv_cap, uint32_t* __restrict__ surv_cnt, uint32_t* __restrict__ overflow) {
+                                                                  uint32_t surv_cap, uint32_t* __restrict__ surv_cnt, uint32_t* __restrict__ overflow,
+                                                                  uint32_t* __restrict__ gkeys_base, uint32_t gcap) {
     __shared__ uint32_t lkeys[VEC_REFINE_LCAP];
+    uint32_t* __restrict__ gkeys = gkeys_base + (size_t)blockIdx.x * gcap;
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_state[2], s_n, s_valid, s_surv, s_over;
     const uint32_t t = threadIdx.x, q = blockIdx.x, lane = t & 63, wave = t >> 6;
@@ -907,23 +913,35 @@ __global__ __launch_bounds__(VEC_THREADS) void vec_refine_kernel(const uint64_t*
             float lb, ub;
             bounds(sp[j], lb, ub);
             const uint32_t slot = atomicAdd(&s_n, 1u);
-            if (slot < VEC_REFINE_LCAP) lkeys[slot] = lb == NEG_INF ? 0xFFFFFFFEu : f32_desc_key(lb);
+            const uint32_t kv = lb == NEG_INF ? 0xFFFFFFFEu : f32_desc_key(lb);
+            if (slot < VEC_REFINE_LCAP) lkeys[slot] = kv;
+            else if (slot - VEC_REFINE_LCAP < gcap) gkeys[slot - VEC_REFINE_LCAP] = kv;
         }
     }
     __syncthreads();
+    // (the barrier above orders the spilled keys' global stores before the reads below at workgroup scope)
     const uint32_t n_all = s_n;
-    const uint32_t n_held = n_all < VEC_REFINE_LCAP ? n_all : VEC_REFINE_LCAP;
-    const bool over = s_over != 0 || n_all > VEC_REFINE_LCAP;
+    const uint32_t hold = VEC_REFINE_LCAP + gcap;
+    const uint32_t n_held = n_all < hold ? n_all : hold;
+    const bool over = s_over != 0 || n_all > hold;
+    auto key_at = [&](uint32_t i) { return i < VEC_REFINE_LCAP ? lkeys[i] : gkeys[i - VEC_REFINE_LCAP]; };
     uint32_t valid = 0;
-    for (uint32_t i = t; i < n_held; i += VEC_THREADS) valid += lkeys[i] < 0xFFFFFFFEu;
+    for (uint32_t i = t; i < n_held; i += VEC_THREADS) valid += key_at(i) < 0xFFFFFFFEu;
     if (valid) atomicAdd(&s_valid, valid);
     __syncthreads();
     const bool enough = s_valid >= k;
     __syncthreads();
-    const uint32_t kk = block_kth_smallest_u32(n_held, k, [&](uint32_t i) { return lkeys[i]; }, hist, s_state);
+    const uint32_t kk = block_kth_smallest_u32(n_held, k, key_at, hist, s_state);
     const float L2 = enough ? desc_key_f32(kk) : NEG_INF;
     if (over) {
-        if (t == 0) { if (L2 > L1[q]) L1[q] = L2; else atomicAdd(overflow + 1, 1u); atomicAdd(overflow, 1u); surv_cnt[q] = 0; }
+        if (t == 0) {
+            const bool raised = L2 > L1[q];
+            if (raised) L1[q] = L2;
+            if (s_over) atomicAdd(overflow + 2, 1u);             // a (slab, query) segment was too small: the host may grow the segments
+            if (!raised) atomicAdd(overflow + (s_over ? 3 : 1), 1u);   // [1]: stuck for good; [3]: stuck unless the segments grow
+            atomicAdd(overflow, 1u);
+            surv_cnt[q] = 0;
+        }
         return;
     }
     // ---- survivors: second walk over the segments ----
