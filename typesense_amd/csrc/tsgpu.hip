@@ -162,6 +162,7 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
     for (auto& L : ctx->lanes) L.release();
     std::atomic_store(&ctx->snap, std::shared_ptr<const Snapshot>());
     ctx->retire_bin->drain();
+    deferred_frees().drain();
     ctx->d_col_ptrs.release(); ctx->d_col_len.release(); ctx->d_prof.release();
     for (auto& c : ctx->columns) c.data.release();
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);

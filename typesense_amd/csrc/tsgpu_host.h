@@ -14,6 +14,7 @@
 #include <memory>
 #include <atomic>
 #include <thread>
+#include <utility>
 #include <unordered_map>
 #include <algorithm>
 #include <chrono>
@@ -41,19 +42,46 @@ inline int ok() { return TSGPU_OK; }
         }                                                                                            \
     } while (0)
 
+// hipFree / hipHostFree synchronise the WHOLE device: a scratch buffer that outgrows itself in the middle of serving queries must not
+// stall every other lane for milliseconds (the latency tail of the 1-query-caller regime). The outgrown allocation is parked here
+// instead (growth is geometric: what is parked is at most what is in use) and freed where a device-wide wait hurts nobody:
+// tsgpu_commit, tsgpu_destroy, or when more than 1 GiB is parked.
+struct DeferredFrees {
+    std::mutex m;
+    std::vector<std::pair<void*, bool>> ptrs;        // (pointer, pinned host memory?)
+    size_t bytes = 0;
+    void park(void* p, size_t n, bool pinned) {
+        if (!p) return;
+        bool now = false;
+        { std::lock_guard<std::mutex> lk(m); if (n > (256u << 20) || bytes + n > (1ull << 30)) now = true; else { ptrs.emplace_back(p, pinned); bytes += n; } }
+        if (now) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); }
+    }
+    void drain() {
+        std::vector<std::pair<void*, bool>> v;
+        { std::lock_guard<std::mutex> lk(m); v.swap(ptrs); bytes = 0; }
+        for (auto& e : v) { if (e.second) (void)hipHostFree(e.first); else (void)hipFree(e.first); }
+    }
+};
+inline DeferredFrees& deferred_frees() { static DeferredFrees* d = new DeferredFrees; return *d; }      // (never destroyed: no static-destruction order issues at exit)
+
 // grow-only device / pinned-host buffers
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap) return TSGPU_OK;
-        // geometric growth (and never tiny): a re-allocation is a device-wide synchronisation of milliseconds — with exact-fit growth
-        // the lanes of the 1-query-caller regime, whose rounds differ in size, kept paying it (latency tail of 10-50 ms)
+        // geometric growth (and never tiny): with exact-fit growth the lanes of the 1-query-caller regime, whose rounds differ in
+        // size, kept re-allocating (latency tail of 10-50 ms)
         size_t want = bytes + bytes / 4 + 256;
         if (want < 2 * cap) want = 2 * cap;
         if (want < (64u << 10)) want = 64u << 10;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        TSGPU_HIP_TRY(hipMalloc(&p, want));
+        if (p) { deferred_frees().park(p, cap, false); p = nullptr; cap = 0; }
+        if (hipMalloc(&p, want) != hipSuccess) {         // out of memory with buffers parked: free them and try once more
+            (void)hipGetLastError();
+            p = nullptr;
+            deferred_frees().drain();
+            TSGPU_HIP_TRY(hipMalloc(&p, want));
+        }
         cap = want;
         return TSGPU_OK;
     }
@@ -68,7 +96,7 @@ struct PinBuf {
         size_t want = bytes + bytes / 4 + 256;
         if (want < 2 * cap) want = 2 * cap;
         if (want < (64u << 10)) want = 64u << 10;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        if (p) { deferred_frees().park(p, cap, true); p = nullptr; cap = 0; }
         TSGPU_HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
         cap = want;
         return TSGPU_OK;

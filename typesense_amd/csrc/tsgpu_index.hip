@@ -622,6 +622,7 @@ int tsgpu_commit(tsgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     const uint64_t t0 = wall_us();
     ctx->retire_bin->drain();                        // buffers of snapshots that searches have let go of since the last commit
+    deferred_frees().drain();                        // ... and scratch buffers that outgrew themselves while serving queries
     try {
         const std::shared_ptr<const Snapshot> cur = ctx->snapshot();
         int rc = -1;
