@@ -137,7 +137,8 @@ int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
  * host side: "plan_threads" (default 8) / "plan_parallel_min_queries" (default 2048) = the work table of a batch with at least
  * that many queries is planned in slices on the context's parked host threads, "fuse_threads" (default 32) = host threads of the
  * hybrid fusion, "blocking_sync_min_callers" (default 48) = from this many threads inside the keyword entry point a round is
- * awaited with a blocking event instead of a spinning stream wait (the request threads need the cores);
+ * awaited SLEEPING (most of the lane's usual wait, then event polls between 15 us naps) instead of with a spinning stream wait (the
+ * request threads need the cores; hipEventSynchronize on a blocking-sync event still spins inside the runtime);
  * "hnsw_visited_hash" = 1 (default): an HNSW traversal keeps the ids it has visited in a per-query hash set (32-256 KB, whatever the
  * row count; up to 4096 queries traverse at once), 0: 16-bit tags per row and concurrent query, capped by
  * "hnsw_visited_max_gib" (default 64, 1..128: 2 bytes x rows x concurrent queries — 41 GB for 2048 queries at 10M rows) */

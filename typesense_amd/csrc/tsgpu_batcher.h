@@ -2,20 +2,20 @@
 // under a shared lock (Index::search -> search_across_fields, src/index.cpp:3488; one request thread per HTTP request,
 // src/http_server.cpp:827-832). One query per launch leaves the GPU idle, so concurrent small calls are coalesced here:
 //
-//   * a caller parks its request; the first parked caller without a leader becomes the LEADER of the next round;
+//   * a caller pushes its request on a lock-free stack; an arrival that finds no leader makes itself the LEADER of the next round
+//     (one exchange), everybody else parks;
 //   * the leader gathers until every thread that is inside the entry point (and not already being executed) has parked, or
 //     `batch_window_us` passed (10 us: a free lane must not idle — with 80 us the lanes were busy 2.5 of 4 under 256 callers), then
 //     takes an execution resource (a keyword lane / the vector executor). While every resource is busy that acquisition blocks and
 //     callers keep parking: under load the rounds size themselves;
-//   * the leader takes the round (FIFO, compatible requests only), promotes the next parked caller to leader — it gathers
-//     and plans on another lane while this round runs on the GPU —, executes the round as ONE batch and hands every caller
-//     its slice.
+//   * the leader takes the whole stack, picks its round (FIFO, compatible requests only; the rest goes back), steps down — an
+//     arrival or, if requests are left, a promoted parked caller leads the next round, which is gathered and planned on another lane
+//     while this one runs on the GPU —, executes the round as ONE batch and hands every caller its slice.
 //
 // Waiting and waking (hundreds of request threads wake up per millisecond here): a parked caller waits on its request's state
 // word — a short spin, then a futex wait on one of 16 BANK words (consecutive arrivals share a bank, a round is a run of
 // consecutive arrivals). The leader publishes the states, bumps the touched banks and wakes each with ONE futex call: a round of
-// 64 callers costs ~5 wake syscalls instead of 64, the woken threads start in parallel and none of them needs the combiner's
-// mutex to leave.
+// 64 callers costs ~5 wake syscalls instead of 64, the woken threads start in parallel; there is no mutex anywhere on the path.
 //
 // Results are identical to separate calls: a batch entry never influences another (scores depend only on the document).
 #pragma once
