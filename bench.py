@@ -278,6 +278,30 @@ class Bench:
             return None
         return grp
 
+    def group_works(self, what, fn):
+        """one UNTIMED call of a tsgpu_group exchange on every rank: if it fails anywhere, every rank drops the group and runs the
+        torch.distributed exchange instead (an exception on one rank inside the timed loop would leave the others in a collective)"""
+        if self.group is None:
+            return False
+        import torch.distributed as dist
+        ok = 1
+        try:
+            fn()
+        except Exception as e:      # noqa: BLE001 — reported, not hidden
+            ok = 0
+            sys.stderr.write("[bench] rank %d: tsgpu_group %s failed (%r): torch.distributed exchange instead\n" % (self.rank, what, e))
+        flag = self.torch.tensor([ok], dtype=self.torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            try:
+                self.group.close()
+            except Exception:       # noqa: BLE001
+                pass
+            self.group = None
+            self.exchange = "torch.distributed all-gather + tsgpu merge kernels (tsgpu_group failed at its %s exchange)" % what
+            return False
+        return True
+
     # ---------------------------------------------------------------- index builds (untimed)
     def build_keyword(self):
         from typesense_amd import _lib as B, synth
@@ -371,6 +395,7 @@ class Bench:
 
         if self.group is not None:
             gdev, ghs = device_hits(torch, n_q, FETCH_SIZE)
+            self.group_works("keyword", lambda: self.group.keyword_search_batch_raw(arr, n_q, FETCH_SIZE, ghs))
 
         def step_torch_exchange():
             g.keyword_search_batch_raw(arr, n_q, hs)
@@ -639,6 +664,9 @@ class Bench:
         lab_o = torch.zeros((n_q, k), dtype=torch.int64, device="cuda")
         cnt_o = torch.zeros(n_q, dtype=torch.int32, device="cuda")
         rec = dict(kern_ms=[], flops=[], scan_ms=[], scan_bytes=[], post_ms=[])
+
+        if self.sharded and self.group is not None and g is self.g:
+            self.group_works("k-NN", lambda: self.group.vec_knn_batch_raw(field, Q.data_ptr(), B.MEM_DEVICE, n_q, k, dist_o.data_ptr(), lab_o.data_ptr(), cnt_o.data_ptr(), B.MEM_DEVICE))
 
         def step():
             if self.sharded and self.group is not None and g is self.g:
@@ -931,6 +959,9 @@ class Bench:
             dist_o = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
             lab_o = torch.zeros((n_q, k), dtype=torch.int64, device="cuda")
             cnt_o = torch.zeros(n_q, dtype=torch.int32, device="cuda")
+
+            self.group_works("hybrid", lambda: self.group.hybrid_search_batch(qs, 1, B.METRIC_IP, None, k=k, fetch_size=100, alpha=0.3, k_stride=K_TOPSTER,
+                                                                               mem_q=B.MEM_DEVICE, q_ptr=self.Q.data_ptr(), dim=args.dim))
 
             def step():      # fuse AFTER the shard merge: reciprocal ranks are global ranks
                 if self.group is not None:
