@@ -242,64 +242,73 @@ class Bench:
         self.csr = None
         self.exact = None           # exact k-NN of the first queries by the oracle's chunked flat scan (vector + hybrid parity)
         self.extras = not args.no_extras and world == 1
-        # N > 1, shards: the exchange runs behind the C-ABI (tsgpu_group: RCCL ncclAllGather on the context's stream + the library's merge
-        # kernels). Rank 0's ncclUniqueId travels through torch.distributed; if RCCL cannot be brought up inside the library (every rank
-        # must agree) the step falls back to the torch.distributed all-gather + the library's merge, and the JSON line says which ran.
+        # N > 1, shards: the exchange runs behind the C-ABI (tsgpu_group, rank form): RCCL collectives on the context's stream + the library's
+        # merge kernels (rank 0's ncclUniqueId travels through torch.distributed). Under TSGPU_DIST_BACKEND=gloo (rehearsal: the ranks share
+        # one GPU) the same group runs over its HOST transport (the callbacks = torch.distributed on host memory). If the group cannot be
+        # brought up, or its probe call fails on any rank, the bench FAILS on every rank: it never measures a path the product does not ship.
+        # TSGPU_BENCH_EXCHANGE=torch is the explicit opt-in to the superseded torch.distributed exchange (comparison runs only; the line says so).
         self.group, self.exchange = None, "none (1 GPU)"
         if self.sharded:
-            self.exchange = "torch.distributed all-gather + tsgpu merge kernels"
             self.group = self.join_group(self.g)
-            if self.group is not None:
-                self.exchange = ("tsgpu_group (C-ABI): ncclAllToAll of query slices + slice merge (kw_shard_merge_kernel) + in-place ncclAllGather of the merged "
+            if self.group is None:
+                self.exchange = "torch.distributed all-gather + tsgpu merge kernels (TSGPU_BENCH_EXCHANGE=torch: NOT the product's exchange)"
+            elif self.group_transport == "rccl":
+                self.exchange = ("tsgpu_group (C-ABI, rank form, RCCL): ncclAllToAll of query slices + slice merge (kw_shard_merge_kernel) + in-place ncclAllGather of the merged "
                                  "lists, on the library's stream; k-NN: one ncclAllGather + vec_group_merge_kernel")
+            else:
+                self.exchange = ("tsgpu_group (C-ABI, rank form, HOST transport over torch.distributed/%s callbacks): all-to-all of query slices + slice merge + all-gather of the "
+                                 "merged lists, staged through pinned host memory; k-NN: one all-gather + vec_group_merge_kernel" % os.environ.get("TSGPU_DIST_BACKEND", "nccl"))
 
-    def join_group(self, index):
-        """tsgpu_group over this rank's context `index` (rank form): rank 0's ncclUniqueId travels through torch.distributed. Every rank must
-        succeed, else every rank falls back to the torch.distributed exchange (and the JSON line says which ran)."""
-        torch, T = self.torch, self.T
-        if os.environ.get("TSGPU_BENCH_EXCHANGE", "group") != "group" or os.environ.get("TSGPU_DIST_BACKEND", "nccl") != "nccl":
-            return None
+    def all_ranks_or_die(self, ok, what, err):
+        """every rank learns whether `what` succeeded everywhere; if not, every rank raises (no rank is left inside a collective, and no
+        fallback path is measured in the product's name)"""
         import torch.distributed as dist
-        ok, grp = 1, None
-        try:
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if self.rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(T.GpuGroup.unique_id(index.L)), dtype=torch.uint8))
-            dist.broadcast(uid, 0)
-            grp = T.GpuGroup.join(index, bytes(uid.cpu().numpy().tobytes()), self.rank, self.world)
-        except Exception as e:      # noqa: BLE001 — reported, not hidden
-            ok = 0
-            sys.stderr.write("[bench] rank %d: tsgpu_group unavailable (%r): torch.distributed exchange instead\n" % (self.rank, e))
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) != 1:
-            if grp is not None:
-                grp.close()
+            raise RuntimeError("[bench] rank %d: tsgpu_group %s failed on at least one rank (%s here): the multi-GPU line is NOT measured on another path. "
+                               "TSGPU_BENCH_EXCHANGE=torch runs the superseded torch.distributed exchange for comparison." % (self.rank, what, err or "ok"))
+
+    def join_group(self, index):
+        """tsgpu_group over this rank's context `index` (rank form). nccl backend: RCCL inside the library; any other backend: the group's
+        HOST transport over torch.distributed callbacks. Fails on every rank if any rank fails."""
+        torch, T = self.torch, self.T
+        if os.environ.get("TSGPU_BENCH_EXCHANGE", "group") == "torch":
             return None
+        import torch.distributed as dist
+        grp, err = None, None
+        rccl = os.environ.get("TSGPU_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("TSGPU_BENCH_TRANSPORT", "rccl") == "rccl"
+        try:
+            if rccl:
+                uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if self.rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(T.GpuGroup.unique_id(index.L)), dtype=torch.uint8))
+                dist.broadcast(uid, 0)
+                grp = T.GpuGroup.join(index, bytes(uid.cpu().numpy().tobytes()), self.rank, self.world)
+            else:
+                if not hasattr(self, "host_pg"):
+                    # host collectives need a CPU-capable process group: the default one under gloo, a gloo side group under nccl
+                    self.host_pg = None if dist.get_backend() != "nccl" else dist.new_group(backend="gloo")
+                ag, a2a = self.D.torch_collectives(self.host_pg)
+                grp = T.GpuGroup.join_host(index, self.rank, self.world, ag, a2a)
+        except Exception as e:      # noqa: BLE001 — reported on every rank, then fatal
+            err = repr(e)
+            sys.stderr.write("[bench] rank %d: tsgpu_group could not be created: %s\n" % (self.rank, err))
+        self.group_transport = "rccl" if rccl else "host"
+        self.all_ranks_or_die(err is None, "creation (%s transport)" % self.group_transport, err)
         return grp
 
     def group_works(self, what, fn):
-        """one UNTIMED call of a tsgpu_group exchange on every rank: if it fails anywhere, every rank drops the group and runs the
-        torch.distributed exchange instead (an exception on one rank inside the timed loop would leave the others in a collective)"""
+        """one UNTIMED call of a tsgpu_group exchange on every rank before the timed loop: a failure anywhere is fatal everywhere"""
         if self.group is None:
             return False
-        import torch.distributed as dist
-        ok = 1
+        err = None
         try:
             fn()
-        except Exception as e:      # noqa: BLE001 — reported, not hidden
-            ok = 0
-            sys.stderr.write("[bench] rank %d: tsgpu_group %s failed (%r): torch.distributed exchange instead\n" % (self.rank, what, e))
-        flag = self.torch.tensor([ok], dtype=self.torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) != 1:
-            try:
-                self.group.close()
-            except Exception:       # noqa: BLE001
-                pass
-            self.group = None
-            self.exchange = "torch.distributed all-gather + tsgpu merge kernels (tsgpu_group failed at its %s exchange)" % what
-            return False
+        except Exception as e:      # noqa: BLE001 — reported on every rank, then fatal
+            err = repr(e)
+            sys.stderr.write("[bench] rank %d: tsgpu_group %s probe failed: %s\n" % (self.rank, what, err))
+        self.all_ranks_or_die(err is None, "%s exchange" % what, err)
         return True
 
     # ---------------------------------------------------------------- index builds (untimed)
@@ -1112,6 +1121,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl": backend == "nccl", "mode": args.dist_mode,
+                     "group_transport": getattr(bn, "group_transport", None) if sharded else None,
                      "measured": "this line is what ran; no scaling curve is claimed here — the driver computes efficiency from the per-N values"}
     if world == 1:
         par = "1 GPU"

@@ -466,11 +466,27 @@ int tsgpu_merge_shard_hits_device(tsgpu_ctx* ctx, const tsgpu_hits* gathered, ui
 typedef struct tsgpu_group tsgpu_group;
 #define TSGPU_XCHG_RCCL 0   /* ncclAllGather on the members' streams; librccl.so.1 is resolved with dlopen at group creation */
 #define TSGPU_XCHG_COPY 1   /* device-to-device copies into member 0 (local form only; members may share a device) */
+#define TSGPU_XCHG_HOST 2   /* rank form over the CALLER's collectives on host memory (tsgpu_group_create_rank_host) */
 /* ONE process owns all members (the C++ server): members run on their own host threads inside every group call */
 int tsgpu_group_create_local(tsgpu_ctx* const* members, uint32_t n_members, int transport, tsgpu_group** out);
 /* one process per GPU: rank 0 calls tsgpu_group_unique_id, the launcher broadcasts the 128 bytes, every rank joins with its context */
 int tsgpu_group_unique_id(uint8_t id[128]);
 int tsgpu_group_create_rank(tsgpu_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t n_ranks, tsgpu_group** out);
+/* Rank form over the caller's own channel (MPI, gloo, the server's RPC between nodes — where there is no xGMI): the exchange blocks are
+ * staged through pinned host memory and handed to two callbacks with the semantics of ncclAllGather / ncclAllToAll on HOST buffers:
+ *   all_gather(user, send, recv, bytes): recv[r * bytes .. (r+1) * bytes) = rank r's `send` (bytes each), on every rank;
+ *   all_to_all(user, send, recv, bytes): recv[j * bytes ..) = the slice [rank * bytes ..) of rank j's `send` (n_ranks slices of `bytes`).
+ * Both return 0 on success, are called from the thread that made the group call, and in the same order on every rank. Ranks need not own
+ * a GPU each (two ranks may share a device). The struct is copied. Same blocks, merge kernels and results as the RCCL transport.
+ * EVERY rank-form call (all transports): the ranks must pass the same n_queries, k, k_stride, options and the same SET of optional output
+ * arrays; before any data collective they exchange {return code of the local phase, signature of those arguments}: a rank whose shard
+ * failed makes the call fail on every rank (nobody is left inside a collective), differing arguments fail with 400 everywhere. */
+typedef struct tsgpu_host_collectives {
+    void* user;
+    int (*all_gather)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+    int (*all_to_all)(void* user, const void* send, void* recv, size_t bytes_per_slice);
+} tsgpu_host_collectives;
+int tsgpu_group_create_rank_host(tsgpu_ctx* ctx, const tsgpu_host_collectives* coll, uint32_t rank, uint32_t n_ranks, tsgpu_group** out);
 void tsgpu_group_destroy(tsgpu_group* g);        /* (the member contexts stay the caller's) */
 uint32_t tsgpu_group_size(const tsgpu_group* g);
 /* global top-k of every query, Topster order; `out` = host memory, or device memory of member 0 / of this rank (then keys, scores,

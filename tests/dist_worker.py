@@ -1,10 +1,13 @@
-"""world_size-2 worker of tests/test_dist_gloo.py: doc-range shards on the SIMT-emulator build of the product sources,
-gloo all-gather of the per-shard top-K, exact merge, compared on rank 0 with the unsharded oracle."""
+"""One rank of tests/test_dist_gloo.py (CPU tier: emulator build, TSGPU_WORKER_LIB = its path) and tests/test_gpu_dist.py (`-m gpu`:
+the real libtsgpu.so, the ranks share the one MI355X). Drives the PRODUCT's rank-form exchange — tsgpu_group_create_rank_host +
+tsgpu_group_keyword_search_batch / _vec_knn_batch / _hybrid_search_batch — across PROCESSES: the packed exchange blocks, the slice /
+all-gather exchanges, the merge kernels and the replicas form are the library's; only the wire is the launcher's (torch.distributed
+gloo through the two host-collective callbacks). Every rank compares the merged result with the UNSHARDED oracle bit for bit
+(Topster order include/topster.h:146-154). typesense_amd/dist.py's torch exchange is NOT used here."""
 import os
 import sys
 
 import numpy as np
-import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,25 +18,8 @@ from oracle import oracle_py as O                 # noqa: E402
 from tests import helpers as H                    # noqa: E402
 
 
-def main():
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    lib = os.environ["TSGPU_EMU_LIB"]
-    n_docs, dim, K, k_vec = 1500, 24, 40, 12
-    docs = H.zipf_docs(n_docs, 80, 10, seed=8)                      # every rank derives the same collection
-    pts = H.points_of(n_docs)
-    rng = np.random.default_rng(3)
-    X = rng.standard_normal((n_docs, dim)).astype(np.float32)
-    Q = rng.standard_normal((4, dim)).astype(np.float32)
-    lo, hi = D.shard_range(n_docs, rank, world)
-    orc = O.OracleIndex(1, 1)                                        # full-collection oracle (checker, rank 0 compares)
-    for d in range(n_docs):
-        orc.index_plain(d, 0, docs[d])
-    orc.set_sort_dense(0, pts)
-    orc.vec_init(dim, O.METRIC_IP)
-    orc.vec_add(np.arange(n_docs, dtype=np.uint32), X)
-    # ---- this rank's shard: postings restricted to [lo, hi), global seq_ids kept ----
-    g = T.GpuIndex(0, lib)
+def load_shard(g, orc, lo, hi, pts, n_docs, X, dim):
+    """postings restricted to [lo, hi), GLOBAL seq_ids kept; the sort column and the vectors of the same range"""
     g.field_create(0, False)
     for term in orc.terms(0):
         ids, oi, off = orc.dump_posting(0, int(term))
@@ -50,45 +36,119 @@ def main():
     g.set_num_docs(n_docs)
     g.commit()
     g.vec_create(1, dim, B.METRIC_IP)
-    g.vec_upsert(1, np.arange(lo, hi, dtype=np.uint64), X[lo:hi])
+    if hi > lo:
+        g.vec_upsert(1, np.arange(lo, hi, dtype=np.uint64), X[lo:hi])
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = os.environ["TSGPU_WORKER_LIB"]
+    n_docs, dim, K, k_vec = int(os.environ.get("TSGPU_WORKER_DOCS", "1500")), 24, 40, 12
+    docs = H.zipf_docs(n_docs, 80, 10, seed=8)                      # every rank derives the same collection
+    pts = H.points_of(n_docs)
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((n_docs, dim)).astype(np.float32)
+    X[7] = X[900 % n_docs]                                           # duplicate embeddings across shards: distance ties -> smaller label first
+    Q = rng.standard_normal((5, dim)).astype(np.float32)
+    orc = O.OracleIndex(1, 1)                                        # full-collection oracle (the checker)
+    for d in range(n_docs):
+        orc.index_plain(d, 0, docs[d])
+    orc.set_sort_dense(0, pts)
+    orc.vec_init(dim, O.METRIC_IP)
+    orc.vec_add(np.arange(n_docs, dtype=np.uint32), X)
     sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
-    toks = ([1, 2], [3, 1, 2], [5], [4, 9])
+    OSORT = ((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1))
+    toks = ([1, 2], [3, 1, 2], [5], [4, 9], [70, 71])                # 5 queries: not a multiple of the world size (padded slices)
     qs = [T.KwQuery(t, sort=sort, topster_size=K) for t in toks]
-    # ---- keyword: local top-K -> all-gather -> merge ----
-    h = g.keyword_search_batch(qs, k_stride=K)
-    local = dict(keys=torch.from_numpy(h.keys.astype(np.int64)), scores=torch.from_numpy(h.scores.copy()),
-                 n_hits=torch.from_numpy(h.n_hits.astype(np.int32)), num_matched=torch.from_numpy(h.num_matched.astype(np.int64)))
-    keys, sc, n, nm = D.sharded_keyword(local, K)
-    # ---- vector: local top-k -> all-gather -> merge ----
-    dl, ll, cl = g.vec_knn_batch(1, Q, k_vec)
-    dm, lm, cm = D.sharded_knn(torch.from_numpy(dl), torch.from_numpy(ll.astype(np.int64)), torch.from_numpy(cl.astype(np.int32)), k_vec)
-    # ---- hybrid: fuse AFTER the merge (ranks are global), on the merged lists ----
-    merged = T.Hits(len(qs), K)
-    merged.keys[:] = keys.numpy().astype(np.uint64)
-    merged.scores[:] = sc.numpy()
-    merged.n_hits[:] = n.numpy().astype(np.uint32)
-    merged.num_matched[:] = nm.numpy().astype(np.uint64)
-    merged.match_score_index[:] = 0
-    merged.text_match[:] = sc.numpy()[:, :, 0]
-    fused = g.hybrid_fuse_batch(qs, merged, dm.numpy(), lm.numpy().astype(np.uint64), cm.numpy().astype(np.uint32), B.METRIC_IP,
-                                k=k_vec, fetch_size=10, alpha=0.3, k_stride=K)
+    qs[3] = T.KwQuery(toks[3], sort=sort, topster_size=K, filter_ids=np.arange(0, n_docs, 2, dtype=np.uint32), excluded_ids=np.array([8, 64], np.uint32))
+    ag, a2a = D.torch_collectives()
     ok = True
-    if rank == 0:
+    log = []
+
+    def check(what, cond):
+        nonlocal ok
+        if not cond:
+            log.append("rank %d: MISMATCH %s" % (rank, what))
+            ok = False
+
+    def check_keyword(what, h):
+        check(what + " status", (h.status == 0).all())
         for i, q in enumerate(qs):
             ref = H.oracle_keyword(orc, q)
-            m = int(n[i])
-            ok &= m == ref.keys.size and np.array_equal(keys[i, :m].numpy().astype(np.uint64), ref.keys)
-            ok &= np.array_equal(sc[i, :m].numpy(), ref.scores) and int(nm[i]) == int(ref.num_keyword_matches)
+            m = int(h.n_hits[i])
+            check("%s q%d keys" % (what, i), m == ref.keys.size and np.array_equal(h.keys[i, :m], ref.keys))
+            check("%s q%d scores" % (what, i), m == ref.keys.size and np.array_equal(h.scores[i, :m], ref.scores))
+            check("%s q%d num_matched" % (what, i), int(h.num_matched[i]) == int(ref.num_keyword_matches))
+
+    def check_knn(what, dm, lm, cm, allow=None):
         for i in range(Q.shape[0]):
-            d, l = orc.flat_knn(Q[i], k_vec)
-            ok &= np.array_equal(lm[i].numpy().astype(np.uint32), l) and np.allclose(dm[i].numpy(), d, rtol=1e-5, atol=1e-5)
+            d, l = orc.flat_knn(Q[i], k_vec, allow_ids=allow) if allow is not None else orc.flat_knn(Q[i], k_vec)
+            check("%s q%d" % (what, i), int(cm[i]) == l.size and np.array_equal(lm[i, :l.size].astype(np.uint32), l) and
+                  np.array_equal(dm[i, :l.size].view(np.uint32), d.view(np.uint32)))
+
+    # (uneven cut, incl. an EMPTY shard on the last rank) x (slice exchange, literal all-gather)
+    cuts = {"uneven": [0] + [int(n_docs * (0.62 + 0.3 * r / world)) for r in range(world - 1)] + [n_docs],
+            "empty_last": [0] + [n_docs * (r + 1) // (world - 1) for r in range(world - 1)] + [n_docs]}
+    for cut_name, edges in cuts.items():
+        lo, hi = edges[rank], edges[rank + 1]
+        g = T.GpuIndex(0, lib)
+        load_shard(g, orc, lo, hi, pts, n_docs, X, dim)
+        grp = T.GpuGroup.join_host(g, rank, world, ag, a2a)
+        check("group size", grp.size() == world)
+        for slices in (1, 0):
+            grp.set_option("kw_exchange_slices", slices)
+            tag = "%s/slices=%d" % (cut_name, slices)
+            check_keyword("keyword " + tag, grp.keyword_search_batch(qs, K, k_stride=K))
+        dm, lm, cm = grp.vec_knn_batch(1, Q, k_vec)
+        check_knn("knn " + cut_name, dm, lm, cm)
+        allow = np.arange(3, n_docs, 5, dtype=np.uint32)
+        dm, lm, cm = grp.vec_knn_batch(1, Q, k_vec, allow_ids=allow)
+        check_knn("knn allow " + cut_name, dm, lm, cm, allow=allow)
+        fused = grp.hybrid_search_batch(qs, 1, B.METRIC_IP, Q, k=k_vec, fetch_size=10, alpha=0.3, k_stride=K)
+        check("hybrid status", (fused.status == 0).all())
         for i, q in enumerate(qs):
-            oq = orc.make_query(q.tokens, sort=((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1)), fetch_size=10, topster_size=K)
-            ref = orc.search_hybrid(oq, Q[i], k=k_vec, alpha=0.3)
+            kw = {}
+            if q.filter_ids is not None:
+                kw["filter_ids"] = q.filter_ids
+            if q.excluded_ids is not None:
+                kw["excluded_ids"] = q.excluded_ids
+            ref = orc.search_hybrid(orc.make_query(q.tokens, sort=OSORT, fetch_size=10, topster_size=K, **kw), Q[i], k=k_vec, alpha=0.3)
             m = int(fused.n_hits[i])
-            ok &= m == ref.keys.size and np.array_equal(fused.keys[i, :m], ref.keys) and np.array_equal(fused.scores[i, :m], ref.scores)
-        print("DIST_OK" if ok else "DIST_MISMATCH", flush=True)
+            check("hybrid %s q%d" % (cut_name, i), m == ref.keys.size and np.array_equal(fused.keys[i, :m], ref.keys) and np.array_equal(fused.scores[i, :m], ref.scores) and
+                  np.array_equal(fused.vector_distance[i, :m].view(np.uint32), ref.vector_distance.view(np.uint32)))
+        if cut_name == "uneven":
+            # agreement before the collectives: ONE rank hands a bad k -> every rank returns the error, nobody hangs in a collective
+            try:
+                grp.keyword_search_batch(qs, K + 1 if rank == world - 1 else K, k_stride=K)
+                check("bad k on one rank must fail everywhere", False)
+            except T.TsgpuError as e:
+                check("bad k: code 400 on every rank", e.code == 400)
+                check("bad k: the other ranks learn who failed", rank == world - 1 or "rank %d failed" % (world - 1) in str(e))
+            # ... and ranks called with DIFFERENT (individually valid) arguments fail together with 400
+            try:
+                grp.vec_knn_batch(1, Q, k_vec - 1 if rank == 0 else k_vec)
+                check("differing k must fail everywhere", False)
+            except T.TsgpuError as e:
+                check("differing arguments: 400", e.code == 400 and "different arguments" in str(e))
+            check_keyword("keyword after the failed calls", grp.keyword_search_batch(qs, K, k_stride=K))
+        grp.close()
+        g.close()
+
+    # replicas form: every rank mirrors the WHOLE collection, the batch is cut into query slices, no merge
+    g = T.GpuIndex(0, lib)
+    load_shard(g, orc, 0, n_docs, pts, n_docs, X, dim)
+    grp = T.GpuGroup.join_host(g, rank, world, ag, a2a)
+    grp.set_option("replicas", 1)
+    check_keyword("keyword replicas", grp.keyword_search_batch(qs, K, k_stride=K))
+    dm, lm, cm = grp.vec_knn_batch(1, Q, k_vec)
+    check_knn("knn replicas", dm, lm, cm)
+    grp.close()
     g.close()
+
+    for line in log:
+        print(line, flush=True)
+    print("rank %d: %s" % (rank, "DIST_OK" if ok else "DIST_MISMATCH"), flush=True)
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)

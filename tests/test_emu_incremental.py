@@ -216,3 +216,36 @@ def test_a_failing_commit_leaves_the_previous_snapshot_and_the_retry_is_complete
         check_equal(g, old, rng, "after the retry of the commit that failed at device call %d" % nth, n_queries=4)
     assert failures >= 4 and g.counter("commit_failed_count") == failures
     g.close()
+
+
+def test_term_created_after_the_first_commit_is_published_by_the_incremental_commit():
+    """a term CREATED after a commit (tsgpu_term_upsert / tsgpu_posting_upsert / tsgpu_terms_load_csr) must be queued
+    for the next — incremental — commit. TermHost::dirty starts true, so it cannot double as the 'already queued' marker."""
+    docs = H.zipf_docs(1500, 20, 6, seed=4)
+    orc, g = H.build_pair(docs, H.emu_lib_path())
+    assert g.counter("commit_full_count") == 1
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    # a) a whole new list through term_upsert  b) a new term through single-document posting_upsert  c) through the CSR loader
+    ids_a = np.arange(3, 1500, 7, dtype=np.uint32)
+    g.term_upsert(0, 900, ids_a, np.arange(ids_a.size, dtype=np.uint32), np.full(ids_a.size, 2, np.uint32))
+    for d in (5, 17, 400):
+        g.posting_upsert(0, 901, d, np.array([3], np.uint32))
+    ids_c = np.arange(1, 1500, 11, dtype=np.uint32)
+    g.terms_load_csr(0, np.array([902], np.uint32), np.array([0, ids_c.size], np.uint64), ids_c, np.arange(ids_c.size, dtype=np.uint32),
+                     np.array([0, ids_c.size], np.uint64), np.full(ids_c.size, 4, np.uint32))
+    g.commit()
+    assert g.counter("commit_incremental_count") == 1 and g.counter("commit_full_count") == 1, "the commit did not take the incremental path"
+    hits = g.keyword_search_batch([T.KwQuery([900], sort=sort, topster_size=250), T.KwQuery([901], sort=sort, topster_size=250),
+                                   T.KwQuery([902], sort=sort, topster_size=250), T.KwQuery([1], sort=sort, topster_size=250)], k_stride=250)
+    assert (hits.status == 0).all()
+    assert int(hits.num_matched[0]) == ids_a.size and int(hits.num_matched[1]) == 3 and int(hits.num_matched[2]) == ids_c.size
+    assert int(hits.num_matched[3]) > 0
+    gi, _, _ = g.term_download(0, 901)
+    assert np.array_equal(gi, np.array([5, 17, 400], np.uint32))
+    # a second write to the SAME new terms is queued again after the commit cleared the marker
+    g.posting_upsert(0, 901, 900, np.array([1], np.uint32))
+    g.commit()
+    assert g.counter("commit_incremental_count") == 2
+    gi, _, _ = g.term_download(0, 901)
+    assert np.array_equal(gi, np.array([5, 17, 400, 900], np.uint32))
+    g.close()

@@ -77,7 +77,14 @@ class GroupTimingsC(C.Structure):
     _fields_ = [("local_ms", C.c_float), ("exchange_merge_ms", C.c_float), ("exchange_bytes_per_member", C.c_uint64)]
 
 
-XCHG_RCCL, XCHG_COPY = 0, 1
+XCHG_RCCL, XCHG_COPY, XCHG_HOST = 0, 1, 2
+
+HOST_COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)     # (user, send, recv, bytes) -> 0 on success
+
+
+class HostCollectivesC(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather", HOST_COLLECTIVE_FN), ("all_to_all", HOST_COLLECTIVE_FN)]
+
 
 EXPORTS = [
     "tsgpu_abi_version", "tsgpu_create", "tsgpu_destroy", "tsgpu_last_error", "tsgpu_set_stream", "tsgpu_set_option", "tsgpu_get_counter", "tsgpu_device_bytes",
@@ -86,7 +93,7 @@ EXPORTS = [
     "tsgpu_keyword_search_batch_ids", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free", "tsgpu_facet_set", "tsgpu_facet_count_batch", "tsgpu_facet_stats_batch", "tsgpu_facet_value_set", "tsgpu_facet_value_count_batch",
     "tsgpu_vec_create", "tsgpu_vec_upsert", "tsgpu_vec_delete", "tsgpu_vec_get", "tsgpu_vec_count", "tsgpu_vec_knn_batch",
     "tsgpu_vec_hnsw_load", "tsgpu_vec_hnsw_search_batch", "tsgpu_vec_distances", "tsgpu_ip_distance", "tsgpu_vector_search_batch", "tsgpu_hybrid_search_batch", "tsgpu_hybrid_fuse_batch", "tsgpu_keyword_aux_scores", "tsgpu_merge_shard_hits", "tsgpu_merge_shard_hits_device", "tsgpu_last_timings",
-    "tsgpu_group_create_local", "tsgpu_group_unique_id", "tsgpu_group_create_rank", "tsgpu_group_destroy", "tsgpu_group_size", "tsgpu_group_keyword_search_batch",
+    "tsgpu_group_create_local", "tsgpu_group_unique_id", "tsgpu_group_create_rank", "tsgpu_group_create_rank_host", "tsgpu_group_destroy", "tsgpu_group_size", "tsgpu_group_keyword_search_batch",
     "tsgpu_group_vec_knn_batch", "tsgpu_group_hybrid_search_batch", "tsgpu_group_last_timings", "tsgpu_group_set_option",
 ]
 
@@ -176,6 +183,7 @@ def lib(path=None):
     L.tsgpu_group_create_local.argtypes = [vp, u32, i32, vp]
     L.tsgpu_group_unique_id.argtypes = [vp]
     L.tsgpu_group_create_rank.argtypes = [vp, vp, u32, u32, vp]
+    L.tsgpu_group_create_rank_host.argtypes = [vp, C.POINTER(HostCollectivesC), u32, u32, vp]
     L.tsgpu_group_destroy.argtypes = [vp]
     L.tsgpu_group_destroy.restype = None
     L.tsgpu_group_size.argtypes = [vp]

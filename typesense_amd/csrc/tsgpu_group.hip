@@ -9,11 +9,19 @@
 //   * tsgpu_group_create_local  — ONE process owns G contexts (how the C++ server would link it). Members run on G host threads.
 //   * tsgpu_group_create_rank   — one process per GPU (torch.distributed / MPI launchers, bench.py --gpus N): every rank passes its
 //                                 context and the 128-byte id rank 0 got from tsgpu_group_unique_id() (broadcast by the host's own channel).
-// Two transports (the exchange is the only thing that differs):
-//   * TSGPU_XCHG_RCCL — ncclAllGather on the members' streams (RCCL over xGMI). librccl.so.1 is resolved with dlopen when the first
-//                       RCCL group is created: the library itself has no link-time dependency on it (single-GPU servers, the test tiers).
+// Three transports (the exchange is the only thing that differs):
+//   * TSGPU_XCHG_RCCL — ncclAllGather / ncclAllToAll on the members' streams (RCCL over xGMI). librccl.so.1 is resolved with dlopen when
+//                       the first RCCL group is created: the library itself has no link-time dependency on it (single-GPU servers, the test tiers).
 //   * TSGPU_XCHG_COPY — device-to-device copies into member 0's gather buffer (local form only; members may share one device: the
 //                       single-GPU rehearsal and the emulator tier).
+//   * TSGPU_XCHG_HOST — rank form over the CALLER's collectives on host memory (tsgpu_group_create_rank_host: an all-gather and an
+//                       all-to-all callback — MPI, gloo, the server's own RPC): blocks are staged through pinned host buffers. Ranks need
+//                       not own a GPU each (two ranks may share one device; the emulator tier has none), and it is the transport between
+//                       NODES, where there is no xGMI. Same packed blocks, same merge kernels, same results as RCCL.
+// Rank form, every transport: the ranks AGREE on the outcome of their local phase before any data collective (one 8-byte all-gather of
+// {return code, call signature}): a rank whose shard failed (out of memory, a bad argument) makes every rank return together instead of
+// leaving the others inside a collective for ever, and ranks that were handed different arguments (n_queries, k, k_stride, the set of
+// optional output arrays) fail with 400 instead of exchanging blocks of different sizes.
 // No kernels here: the device-side halves are group_pack_* / group_merge_* (tsgpu.hip, tsgpu_vec.hip).
 #include <dlfcn.h>
 #include <thread>
@@ -78,6 +86,9 @@ struct Member {
     DevBuf o_keys, o_scores, o_tm, o_nh, o_nm, o_st, o_vd, o_lab, o_cnt;   // merged result staged on the device (host outputs)
     DevBuf caps;                                         // per-query Topster capacity (the merged list of a query never exceeds its own Topster)
     std::vector<uint32_t> h_caps;
+    PinBuf h_send, h_recv;                               // HOST transport: the staged blocks
+    DevBuf agree_d;                                      // RCCL rank form: the ranks' status words
+    PinBuf agree_h;
     int rc = TSGPU_OK;
     std::string err;
 };
@@ -92,6 +103,7 @@ struct tsgpu_group {
     std::mutex mu;                       // one batch at a time per group
     bool replicas = false;               // every member mirrors the WHOLE collection: the batch is cut into query slices (option "replicas")
     int kw_slices = 1;                   // (2 = also with one member: exercises the collectives on a single GPU) keyword exchange: all-to-all of query slices + slice merge + all-gather of the merged lists (false: one all-gather, full merge on every rank)
+    tsgpu_host_collectives coll{};       // TSGPU_XCHG_HOST
     tsgpu_group_timings tm{};
 };
 
@@ -109,7 +121,64 @@ template <class F> int for_members(tsgpu_group* g, F f) {
     return TSGPU_OK;
 }
 
-// every owned member's block (bytes each) -> the gathered [n][bytes] in the recv buffer of every member (RCCL) / of member 0 (COPY)
+// HOST transport: `send_bytes` of this rank's device memory -> pinned host -> the caller's collective -> pinned host -> device `recv`
+// (all-gather: n x per_rank_bytes arrive, ordered by rank; all-to-all: send holds n slices of per_rank_bytes, slice j goes to rank j).
+// Synchronous on the member's stream: the staging buffers are reused by the next collective of the call.
+int host_collective(tsgpu_group* g, bool all_to_all, const void* send_dev, size_t send_bytes, void* recv_dev, size_t per_rank_bytes) {
+    Member& mem = g->m[0];
+    (void)hipSetDevice(mem.ctx->device);
+    int rc;
+    if ((rc = mem.h_send.reserve(send_bytes)) || (rc = mem.h_recv.reserve(per_rank_bytes * g->n))) return rc;
+    TSGPU_HIP_TRY(hipMemcpyAsync(mem.h_send.p, send_dev, send_bytes, hipMemcpyDeviceToHost, mem.ctx->stream));
+    TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+    const int crc = all_to_all ? g->coll.all_to_all(g->coll.user, mem.h_send.p, mem.h_recv.p, per_rank_bytes) : g->coll.all_gather(g->coll.user, mem.h_send.p, mem.h_recv.p, per_rank_bytes);
+    if (crc) return fail(TSGPU_ERR_DEVICE, std::string("tsgpu_group: the caller's ") + (all_to_all ? "all_to_all" : "all_gather") + " callback failed (" + std::to_string(crc) + ")");
+    TSGPU_HIP_TRY(hipMemcpyAsync(recv_dev, mem.h_recv.p, per_rank_bytes * g->n, hipMemcpyHostToDevice, mem.ctx->stream));
+    TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+    return TSGPU_OK;
+}
+
+uint32_t call_signature(std::initializer_list<uint64_t> v) {
+    uint64_t h = 1469598103934665603ull;
+    for (uint64_t x : v) { h ^= x; h *= 1099511628211ull; }
+    return (uint32_t)(h ^ (h >> 32));
+}
+
+// Rank form: every rank reports {rc of its local phase, signature of the call's arguments}; all ranks leave with the same verdict
+// BEFORE any data collective. The failing rank keeps its own error message; the others learn which rank failed.
+int agree(tsgpu_group* g, int rc_local, uint32_t sig) {
+    if (g->local || g->n == 1) return rc_local;
+    Member& mem = g->m[0];
+    const std::string own_err = rc_local ? std::string(tsgpu_last_error()) : std::string();
+    const uint64_t w = ((uint64_t)(uint32_t)rc_local << 32) | sig;
+    std::vector<uint64_t> all(g->n, 0);
+    (void)hipSetDevice(mem.ctx->device);
+    if (g->transport == TSGPU_XCHG_HOST) {
+        const int crc = g->coll.all_gather(g->coll.user, &w, all.data(), 8);
+        if (crc) return fail(TSGPU_ERR_DEVICE, "tsgpu_group: the caller's all_gather callback failed (" + std::to_string(crc) + ")");
+    } else {
+        int rc;
+        if ((rc = mem.agree_d.reserve((size_t)(g->n + 1) * 8)) || (rc = mem.agree_h.reserve((size_t)(g->n + 1) * 8))) return rc;     // (64 KB minimum each: allocated once)
+        uint64_t* hw = mem.agree_h.as<uint64_t>();
+        hw[g->n] = w;
+        TSGPU_HIP_TRY(hipMemcpyAsync(mem.agree_d.as<uint64_t>() + g->n, hw + g->n, 8, hipMemcpyHostToDevice, mem.ctx->stream));
+        if ((rc = rccl()->AllGather(mem.agree_d.as<uint64_t>() + g->n, mem.agree_d.p, 1, X_NCCL_UINT64, mem.comm, mem.ctx->stream))) return rccl_fail("ncclAllGather (status)", rc);
+        TSGPU_HIP_TRY(hipMemcpyAsync(hw, mem.agree_d.p, (size_t)g->n * 8, hipMemcpyDeviceToHost, mem.ctx->stream));
+        TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+        for (uint32_t r = 0; r < g->n; r++) all[r] = hw[r];
+    }
+    for (uint32_t r = 0; r < g->n; r++) {
+        const int rr = (int)(uint32_t)(all[r] >> 32);
+        if (!rr) continue;
+        if (r == g->rank) return fail(rr, own_err);
+        return fail(rr, "tsgpu_group: rank " + std::to_string(r) + " failed in its local phase (code " + std::to_string(rr) + "): the call is abandoned on every rank");
+    }
+    for (uint32_t r = 0; r < g->n; r++)
+        if ((uint32_t)all[r] != sig) return fail(TSGPU_ERR_INVALID, "tsgpu_group: rank " + std::to_string(r) + " was called with different arguments (n_queries / k / k_stride / optional output arrays / options must be the same on every rank)");
+    return TSGPU_OK;
+}
+
+// every owned member's block (bytes each) -> the gathered [n][bytes] in the recv buffer of every member (RCCL / HOST) / of member 0 (COPY)
 int exchange(tsgpu_group* g, size_t bytes) {
     for (auto& mem : g->m) { int rc = mem.recv.reserve(bytes * g->n); if (rc) return rc; }
     if (g->transport == TSGPU_XCHG_RCCL) {
@@ -123,6 +192,7 @@ int exchange(tsgpu_group* g, size_t bytes) {
         if (g->m.size() > 1 && (rc = r->GroupEnd())) return rccl_fail("ncclGroupEnd", rc);
         return TSGPU_OK;
     }
+    if (g->transport == TSGPU_XCHG_HOST) return host_collective(g, false, g->m[0].send.p, bytes, g->m[0].recv.p, bytes);
     // COPY: the packs must have finished on their own streams, then member 0's stream pulls every block
     for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
     Member& root = g->m[0];
@@ -156,6 +226,7 @@ int exchange_slices(tsgpu_group* g, size_t slice_bytes) {
         if (g->m.size() > 1 && (rc = r->GroupEnd())) return rccl_fail("ncclGroupEnd", rc);
         return TSGPU_OK;
     }
+    if (g->transport == TSGPU_XCHG_HOST) return host_collective(g, true, g->m[0].send.p, slice_bytes * g->n, g->m[0].recv.p, slice_bytes);
     for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
     for (size_t d = 0; d < g->m.size(); d++) {
         (void)hipSetDevice(g->m[d].ctx->device);
@@ -178,6 +249,9 @@ int replicate_slices(tsgpu_group* g, const std::vector<void*>& arr /* per member
         }
         return TSGPU_OK;
     }
+    if (g->transport == TSGPU_XCHG_HOST) return host_collective(g, false, (const char*)arr[0] + (size_t)g->rank * slice_bytes, slice_bytes, arr[0], slice_bytes);
+    // COPY: the slices were written on their owners' streams (merge / store kernels): they must have finished before root's stream reads them
+    for (size_t j = 1; j < g->m.size(); j++) { (void)hipSetDevice(g->m[j].ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(g->m[j].ctx->stream)); }
     Member& root = g->m[0];
     (void)hipSetDevice(root.ctx->device);
     for (size_t j = 1; j < g->m.size(); j++) { int rc = copy_between(root, (char*)arr[0] + j * slice_bytes, g->m[j], (const char*)arr[j] + j * slice_bytes, slice_bytes); if (rc) return rc; }
@@ -269,6 +343,17 @@ int reserve_staging(Member& mem, const tsgpu_hits* out, uint32_t n_pad) {
     return TSGPU_OK;
 }
 
+uint64_t hits_mask(const tsgpu_hits* o) {
+    return (o->keys ? 1u : 0) | (o->scores ? 2u : 0) | (o->text_match ? 4u : 0) | (o->n_hits ? 8u : 0) | (o->num_matched ? 16u : 0) | (o->status ? 32u : 0) | ((uint64_t)o->mem << 8);
+}
+// HOST transport: the pinned staging buffers are sized in the LOCAL phase, so that nothing can fail on one rank alone after the agreement
+int reserve_host_staging(tsgpu_group* g, Member& mem, size_t bytes) {
+    if (g->transport != TSGPU_XCHG_HOST) return TSGPU_OK;
+    int rc;
+    if ((rc = mem.h_send.reserve(bytes)) || (rc = mem.h_recv.reserve(bytes))) return rc;
+    return TSGPU_OK;
+}
+
 // replicas form: member i answers queries [i * per, (i + 1) * per) of the batch on its own full mirror; the slices are then delivered /
 // replicated like merged slices. No merge: a member's Topster for a query IS the global one.
 int keyword_replicas(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out) {
@@ -279,7 +364,7 @@ int keyword_replicas(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_q
         const uint32_t rank = g->local ? (uint32_t)i : g->rank;
         const uint32_t q0 = rank * per, nq = q0 < n_queries ? std::min<uint32_t>(per, n_queries - q0) : 0;
         int r;
-        if ((r = reserve_staging(mem, out, n_pad))) return r;
+        if ((r = reserve_staging(mem, out, n_pad)) || (r = reserve_host_staging(g, mem, (size_t)n_pad * out->k_stride * 24))) return r;
         tsgpu_hits st = staged_hits(mem, out);
         TSGPU_HIP_TRY(hipMemsetAsync(mem.o_nh.p, 0, (size_t)n_pad * 4, mem.ctx->stream));
         TSGPU_HIP_TRY(hipMemsetAsync(mem.o_st.p, 0, (size_t)n_pad * 4, mem.ctx->stream));
@@ -297,7 +382,7 @@ int keyword_replicas(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_q
         if ((r = tsgpu_keyword_search_batch(mem.ctx, queries + q0, nq, &loc))) return r;
         return group_store_keyword_slice(mem.ctx, &loc, nq, q0, k, &st, mem.ctx->stream);
     });
-    if (rc) return rc;
+    if ((rc = agree(g, rc, call_signature({1, n_queries, k, out->k_stride, hits_mask(out)})))) return rc;
     const double t_local = ms_since(t0);
     const auto t1 = std::chrono::steady_clock::now();
     if ((rc = deliver_slices(g, out, n_queries, per))) return rc;
@@ -370,6 +455,21 @@ int tsgpu_group_create_rank(tsgpu_ctx* ctx, const uint8_t id[128], uint32_t rank
     return ok();
 }
 
+// Rank form over the caller's own collectives (TSGPU_XCHG_HOST): no RCCL, no GPU-per-rank requirement. `coll` is copied.
+int tsgpu_group_create_rank_host(tsgpu_ctx* ctx, const tsgpu_host_collectives* coll, uint32_t rank, uint32_t n_ranks, tsgpu_group** out) {
+    if (!ctx || !coll || !out || n_ranks == 0 || rank >= n_ranks) return fail(TSGPU_ERR_INVALID, "tsgpu_group_create_rank_host: bad arguments");
+    *out = nullptr;
+    if (!coll->all_gather || !coll->all_to_all) return fail(TSGPU_ERR_INVALID, "tsgpu_group_create_rank_host: both callbacks are required");
+    std::unique_ptr<tsgpu_group> g(new (std::nothrow) tsgpu_group);
+    if (!g) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_create_rank_host: host allocation failed");
+    g->transport = TSGPU_XCHG_HOST; g->local = false; g->n = n_ranks; g->rank = rank;
+    g->coll = *coll;
+    g->m.resize(1);
+    g->m[0].ctx = ctx;
+    *out = g.release();
+    return ok();
+}
+
 void tsgpu_group_destroy(tsgpu_group* g) {
     if (!g) return;
     for (auto& mem : g->m) {
@@ -378,6 +478,7 @@ void tsgpu_group_destroy(tsgpu_group* g) {
         DevBuf* b[] = {&mem.send, &mem.recv, &mem.l_keys, &mem.l_scores, &mem.l_tm, &mem.l_vd, &mem.l_msi, &mem.l_nh, &mem.l_nm, &mem.l_st, &mem.l_co, &mem.v_dist, &mem.v_lab, &mem.v_cnt, &mem.v_bad,
                        &mem.o_keys, &mem.o_scores, &mem.o_tm, &mem.o_nh, &mem.o_nm, &mem.o_st, &mem.o_vd, &mem.o_lab, &mem.o_cnt, &mem.caps};
         for (auto* x : b) x->release();
+        mem.agree_d.release(); mem.h_send.release(); mem.h_recv.release(); mem.agree_h.release();
     }
     delete g;
 }
@@ -402,10 +503,12 @@ int tsgpu_group_last_timings(tsgpu_group* g, tsgpu_group_timings* out) {
 int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out) {
     if (!g || !out || (n_queries && !queries)) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: NULL argument");
     if (n_queries == 0) return ok();
-    if (k == 0 || k > out->k_stride || k > TSGPU_MAX_TOPK) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: k must be in 1..min(k_stride, 1024)");
-    if (!out->keys || !out->scores || !out->n_hits) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: missing output arrays");
-    if ((uint64_t)g->n * k > 4096) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_batch: members * k > 4096");
+    int pre = TSGPU_OK;
+    if (k == 0 || k > out->k_stride || k > TSGPU_MAX_TOPK) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: k must be in 1..min(k_stride, 1024)");
+    else if (!out->keys || !out->scores || !out->n_hits) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: missing output arrays");
+    else if ((uint64_t)g->n * k > 4096) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_batch: members * k > 4096");
     std::lock_guard<std::mutex> lk(g->mu);
+    if (pre) return agree(g, pre, 0);          // (rank form: the other ranks are told instead of being left in their first collective)
     try {
         if (g->replicas) return keyword_replicas(g, queries, n_queries, k, out);
         const uint32_t words = out->text_match ? 5 : 4;
@@ -424,7 +527,9 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
             const size_t slots = (size_t)n_queries * KL;
             if ((r = mem.l_keys.reserve(slots * 8)) || (r = mem.l_scores.reserve(slots * 24)) || (r = mem.l_tm.reserve(slots * 8)) || (r = mem.l_vd.reserve(slots * 4)) || (r = mem.l_msi.reserve(slots)) || (r = mem.l_nh.reserve((size_t)n_queries * 4)) ||
                 (r = mem.l_nm.reserve((size_t)n_queries * 8)) || (r = mem.l_st.reserve((size_t)n_queries * 4)) || (r = mem.l_co.reserve((size_t)n_queries * 4)) ||
-                (r = mem.send.reserve((size_t)n_pad * qw * 8))) return r;
+                (r = mem.send.reserve((size_t)n_pad * qw * 8)) || (r = mem.recv.reserve((slices ? (size_t)n_pad : (size_t)n_queries * g->n) * qw * 8)) ||
+                ((slices || i == 0) && (r = reserve_staging(mem, out, n_pad))) ||
+                (r = reserve_host_staging(g, mem, std::max((slices ? (size_t)n_pad : (size_t)n_queries * g->n) * qw * 8, (size_t)n_pad * KS * 24)))) return r;
             tsgpu_hits loc;
             memset(&loc, 0, sizeof loc);
             loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL;
@@ -435,12 +540,11 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
             if (n_pad > n_queries) TSGPU_HIP_TRY(hipMemsetAsync(mem.send.as<uint64_t>() + (size_t)n_queries * qw, 0, (size_t)(n_pad - n_queries) * qw * 8, mem.ctx->stream));   // padding records: no hits
             return group_pack_keyword(mem.ctx, &loc, n_queries, k, words, mem.send.as<uint64_t>(), mem.ctx->stream);
         });
-        if (rc) return rc;
+        if ((rc = agree(g, rc, call_signature({2, n_queries, k, out->k_stride, hits_mask(out), (uint64_t)slices})))) return rc;
         const double t_local = ms_since(t0);
         const auto t1 = std::chrono::steady_clock::now();
         // 2) the exchange, 3) the exact merge, staged per member in arrays of n_pad queries (stride = the caller's k_stride)
-        const size_t mergers = slices ? g->m.size() : 1;
-        for (size_t i = 0; i < mergers; i++) if ((rc = reserve_staging(g->m[i], out, n_pad))) return rc;
+        const size_t mergers = slices ? g->m.size() : 1;                                 // (staging arrays: reserved in the local phase)
         g->m[0].h_caps.assign(n_pad, 0u);
         group_resolve_topster_sizes(g->m[0].ctx, queries, n_queries, g->m[0].h_caps.data());
         if ((rc = slices ? exchange_slices(g, (size_t)per * qw * 8) : exchange(g, (size_t)n_queries * qw * 8))) return rc;
@@ -491,15 +595,17 @@ int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float
                               float* dist_out, uint64_t* label_out, uint32_t* n_out, int mem_out) {
     if (!g || !Q || !dist_out || !label_out || !n_out) return fail(TSGPU_ERR_INVALID, "tsgpu_group_vec_knn_batch: NULL argument");
     if (n_queries == 0) return ok();
-    if (k == 0 || k > TSGPU_MAX_TOPK) return fail(TSGPU_ERR_INVALID, "tsgpu_group_vec_knn_batch: k must be in 1..1024");
-    if ((uint64_t)g->n * k > 8192) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_vec_knn_batch: members * k > 8192");
+    int pre = TSGPU_OK;
+    if (k == 0 || k > TSGPU_MAX_TOPK) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_vec_knn_batch: k must be in 1..1024");
+    else if ((uint64_t)g->n * k > 8192) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_vec_knn_batch: members * k > 8192");
     std::lock_guard<std::mutex> lk(g->mu);
+    if (pre) return agree(g, pre, 0);
     try {
         if (g->replicas) {
             // every member mirrors the whole matrix: member i scans for queries [i * per, (i + 1) * per), the slices are replicated / delivered
             uint32_t dim = 0;
             int rc = group_vec_dim(g->m[0].ctx, vec_field_id, &dim);
-            if (rc) return rc;
+            if (rc) return agree(g, rc, 0);
             const uint32_t per = (n_queries + g->n - 1) / g->n, n_pad = per * g->n;
             const auto t0 = std::chrono::steady_clock::now();
             rc = for_members(g, [&](size_t i) -> int {
@@ -508,14 +614,15 @@ int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float
                 const uint32_t rank = g->local ? (uint32_t)i : g->rank;
                 const uint32_t q0 = rank * per, nq = q0 < n_queries ? std::min<uint32_t>(per, n_queries - q0) : 0;
                 int r;
-                if ((r = mem.o_vd.reserve((size_t)n_pad * k * 4)) || (r = mem.o_lab.reserve((size_t)n_pad * k * 8)) || (r = mem.o_cnt.reserve((size_t)n_pad * 4))) return r;
+                if ((r = mem.o_vd.reserve((size_t)n_pad * k * 4)) || (r = mem.o_lab.reserve((size_t)n_pad * k * 8)) || (r = mem.o_cnt.reserve((size_t)n_pad * 4)) ||
+                    (r = reserve_host_staging(g, mem, (size_t)n_pad * k * 8))) return r;
                 TSGPU_HIP_TRY(hipMemsetAsync(mem.o_cnt.p, 0, (size_t)n_pad * 4, mem.ctx->stream));
                 TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
                 if (nq == 0) return TSGPU_OK;
                 return tsgpu_vec_knn_batch(mem.ctx, vec_field_id, Q + (size_t)q0 * dim, mem_q, nq, k, allow_ids, n_allow, excluded_ids, n_excluded,
                                            mem.o_vd.as<float>() + (size_t)q0 * k, mem.o_lab.as<uint64_t>() + (size_t)q0 * k, mem.o_cnt.as<uint32_t>() + q0, TSGPU_MEM_DEVICE);
             });
-            if (rc) return rc;
+            if ((rc = agree(g, rc, call_signature({3, n_queries, k, (uint64_t)mem_out, n_allow, n_excluded})))) return rc;
             const double t_local = ms_since(t0);
             const auto t1 = std::chrono::steady_clock::now();
             const KwArr arrs[] = {{&Member::o_vd, dist_out, (size_t)k * 4}, {&Member::o_lab, label_out, (size_t)k * 8}, {&Member::o_cnt, n_out, 4}};
@@ -555,13 +662,14 @@ int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float
             (void)hipSetDevice(mem.ctx->device);
             int r;
             if ((r = mem.v_dist.reserve(block_words * 4)) || (r = mem.v_lab.reserve(block_words * 8)) || (r = mem.v_cnt.reserve((size_t)n_queries * 4)) || (r = mem.v_bad.reserve(64)) ||
-                (r = mem.send.reserve(block_words * 8))) return r;
+                (r = mem.send.reserve(block_words * 8)) || (r = mem.recv.reserve(block_words * 8 * g->n)) || (r = reserve_host_staging(g, mem, block_words * 8 * g->n)) ||
+                (i == 0 && mem_out == TSGPU_MEM_HOST && ((r = mem.o_vd.reserve(block_words * 4)) || (r = mem.o_lab.reserve(block_words * 8)) || (r = mem.o_cnt.reserve((size_t)n_queries * 4))))) return r;
             if ((r = tsgpu_vec_knn_batch(mem.ctx, vec_field_id, Q, mem_q, n_queries, k, allow_ids, n_allow, excluded_ids, n_excluded,
                                          mem.v_dist.as<float>(), mem.v_lab.as<uint64_t>(), mem.v_cnt.as<uint32_t>(), TSGPU_MEM_DEVICE))) return r;
             TSGPU_HIP_TRY(hipMemsetAsync(mem.v_bad.p, 0, 4, mem.ctx->stream));
             return group_pack_knn(mem.ctx, mem.v_dist.as<float>(), mem.v_lab.as<uint64_t>(), mem.v_cnt.as<uint32_t>(), n_queries, k, mem.send.as<uint64_t>(), mem.v_bad.as<uint32_t>(), mem.ctx->stream);
         });
-        if (rc) return rc;
+        if ((rc = agree(g, rc, call_signature({4, n_queries, k, (uint64_t)mem_out, n_allow, n_excluded})))) return rc;
         const double t_local = ms_since(t0);
         const auto t1 = std::chrono::steady_clock::now();
         if ((rc = exchange(g, block_words * 8))) return rc;

@@ -117,7 +117,8 @@ struct TermHost {
     PackedList pl;
     std::vector<BlockPos> dev;
     uint32_t handle = 0xFFFFFFFFu;                   // its slot in the snapshot's list table (stable across commits)
-    bool dirty = true;                               // differs from the published snapshot
+    bool dirty = true;                               // differs from the published snapshot (a NEW term starts dirty and NOT queued)
+    bool queued = false;                             // already has an entry in ctx->dirty_terms for the next commit (mark_dirty sets, a successful commit clears)
     // the list's descriptor arrays on the device: blk_last / blk_ids / blk_meta [d_blk_base, + d_blk_cap), the first d_blk_n entries
     // published. Blocks appended behind the published ones are written INTO the spare entries (no published entry changes: a search on
     // an older snapshot never looks beyond its own n_blocks); any other change (a published block re-written, split, removed) needs

@@ -34,8 +34,8 @@ inline uint32_t pay_words(const BlockMeta& m) { return packed_words(m.n_ids, m.o
 
 void mark_dirty(tsgpu_ctx* ctx, uint32_t field, uint32_t term, TermHost* t) {
     ctx->dirty = true;
-    if (t && t->dirty) return;                               // already queued for the next commit (one entry per term, not per posting operation)
-    if (t) t->dirty = true;
+    if (t && t->queued) return;                              // already queued for the next commit (one entry per term, not per posting operation)
+    if (t) { t->dirty = true; t->queued = true; }            // (`dirty` starts true on a new term: it cannot double as the queue marker)
     ctx->dirty_terms.push_back(((uint64_t)field << 32) | term);
 }
 
@@ -409,7 +409,7 @@ int commit_full(tsgpu_ctx* ctx) {
         make_descriptors(t, 0, h_last, h_bids, h_bmeta, ids_base, pay_base);
         h_last.resize(t.d_blk_base + t.d_blk_cap, 0u); h_bids.resize(t.d_blk_base + t.d_blk_cap); h_bmeta.resize(t.d_blk_base + t.d_blk_cap);     // spare entries
         t.handle = (uint32_t)s.h_lists.size();
-        t.dirty = false; t.desc_rewrite = false;
+        t.dirty = false; t.queued = false; t.desc_rewrite = false;
         t.dev_idw = t.dev_pw = 0;
         for (const BlockMeta& m : t.pl.blk_meta) { t.dev_idw += ids_words(m); t.dev_pw += pay_words(m); }
         maps->handle_of[e.first] = t.handle;
@@ -594,7 +594,7 @@ int commit_incremental(tsgpu_ctx* ctx, const std::shared_ptr<const Snapshot>& cu
         t.dev_idw = t.dev_pw = 0;
         for (const BlockMeta& m : t.pl.blk_meta) { t.dev_idw += ids_words(m); t.dev_pw += pay_words(m); }
     }
-    for (auto& pc : placed) { TermHost& t = *pc.t; t.d_blk_base = pc.base; t.d_blk_cap = pc.cap; t.d_blk_n = (uint32_t)t.pl.blk_last.size(); t.dirty = false; t.desc_rewrite = false; }
+    for (auto& pc : placed) { TermHost& t = *pc.t; t.d_blk_base = pc.base; t.d_blk_cap = pc.cap; t.d_blk_n = (uint32_t)t.pl.blk_last.size(); t.dirty = false; t.queued = false; t.desc_rewrite = false; }
     if (new_maps) { new_maps->rebuild_dense(); s.maps = new_maps; } else s.maps = cur->maps;
     s.ar = ar;
     s.field_is_array = cur->field_is_array;

@@ -497,6 +497,32 @@ class GpuGroup:
         B.check(index.L, index.L.tsgpu_group_create_rank(index.h, C.cast(buf, C.c_void_p), rank, n_ranks, C.byref(h)))
         return cls(_handle=h, _lib=index.L, _members=[index])
 
+    @classmethod
+    def join_host(cls, index, rank, n_ranks, all_gather, all_to_all):
+        """rank form over the CALLER's collectives on host memory (tsgpu_group_create_rank_host, TSGPU_XCHG_HOST): all_gather(send, recv,
+        bytes) / all_to_all(send, recv, bytes) get numpy uint8 views of the library's pinned staging buffers (send: bytes resp. n_ranks x
+        bytes; recv: n_ranks x bytes) and follow ncclAllGather / ncclAllToAll. typesense_amd.dist.torch_collectives() backs them with
+        torch.distributed (gloo on CPU tensors)."""
+        def wrap(fn, send_slices):
+            def cb(_user, send, recv, nbytes):
+                try:
+                    ns = nbytes * (n_ranks if send_slices else 1)
+                    sv = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(ns,)) if ns else np.zeros(0, np.uint8)
+                    rv = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * n_ranks,)) if nbytes else np.zeros(0, np.uint8)
+                    fn(sv, rv, int(nbytes))
+                    return 0
+                except Exception as e:       # an exception must not unwind through the C frames: report it as a failed collective
+                    import sys, traceback
+                    traceback.print_exc(file=sys.stderr)
+                    return 1
+            return B.HOST_COLLECTIVE_FN(cb)
+        coll = B.HostCollectivesC(None, wrap(all_gather, False), wrap(all_to_all, True))
+        h = C.c_void_p()
+        B.check(index.L, index.L.tsgpu_group_create_rank_host(index.h, C.byref(coll), rank, n_ranks, C.byref(h)))
+        grp = cls(_handle=h, _lib=index.L, _members=[index])
+        grp._keepalive = coll               # the CFUNCTYPE thunks must outlive the group
+        return grp
+
     def close(self):
         if getattr(self, "h", None):
             self.L.tsgpu_group_destroy(self.h)
