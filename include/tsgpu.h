@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define TSGPU_ABI_VERSION 3
+#define TSGPU_ABI_VERSION 4
 #define TSGPU_MAX_DROPPED_TOKENS 4
 
 /* limits of the accelerated path (anything beyond -> TSGPU_ERR_UNSUPPORTED for that query) */
@@ -404,17 +404,39 @@ int tsgpu_vec_distances(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* q, c
  * "vec_ip_lanes" makes this function, tsgpu_vec_distances and the k-NN entry points return the same bits. */
 float tsgpu_ip_distance(const float* a, const float* b, uint32_t dim, int simd_lanes);
 
-/* pure vector search (q="*", src/index.cpp:3645-3732): knn + threshold + sort scores + Topster order */
+/* pure vector search (q="*", src/index.cpp:3645-3732): the vector branch of Index::search with BOTH of its sub-branches, then
+ * abs() for cosine / distance_threshold / sort scores / Topster order. One parameter block per batch (the queries share the filter).
+ *   FLAT branch (filter_by_provided && n_filter < flat_search_cutoff, :3664-3665 -> process_results_bruteforce :3345-3374): EVERY filter id
+ *     that has a vector gets its exact distance and goes to the Topster — no k cut; the excluded ids are not consulted (the reference
+ *     does not consult them there either); ties are the Topster's (default sort: larger seq_id first). num_matched = ids the threshold
+ *     kept = `found`. Device: one distance matrix [n_q][n_filter] + the wildcard ranking kernels (LDS Topster per 16K-id work item).
+ *   k-cut branch (otherwise, :3666-3670 -> process_results_hnsw_index): the exact k nearest among the ids the VectorFilterFunctor passes
+ *     (filter ids minus excluded ids; include/index.h:325-354), then the Topster. num_matched = hits kept (<= k).
+ *   query_doc_given (`vec:([], id: X)`): Q holds X's stored vector; k grows by one when X passes the functor (:3651-3654) and X itself is
+ *     left out (:3686). */
 typedef struct tsgpu_vec_query {
     uint32_t k;                     /* vector_query.k (0 -> fetch_size) */
     uint32_t fetch_size;
     float distance_threshold;       /* FLT_MAX = none */
     uint32_t n_sort;
     tsgpu_sort_by sort[TSGPU_MAX_SORT_KEYS];
-    uint32_t topster_size;          /* 0 = library default */
+    uint32_t topster_size;          /* 0 = the reference's: max(fetch_size, 250) capped by n_filter (else the collection size), :3506-3512 */
+    /* ---- ABI 4 ---- */
+    uint32_t filter_by_provided;    /* a filter_by clause exists; filter_ids = the seq_ids it matched (sorted, host) */
+    const uint32_t* filter_ids;
+    uint32_t n_filter;
+    uint32_t n_excluded;
+    const uint32_t* excluded_ids;   /* sorted, host; hidden / curated ids (k-cut branch only) */
+    uint64_t flat_search_cutoff;    /* vector_query.flat_search_cutoff (default 0: never flat), include/vector_query_ops.h:13 */
+    uint32_t query_doc_given;
+    uint32_t query_seq_id;
 } tsgpu_vec_query;
 int tsgpu_vector_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const tsgpu_vec_query* params,
                               const float* Q, int mem_q, uint32_t n_q, tsgpu_hits* out);
+/* the same + all_result_ids of every query (sorted seq_ids that went to the Topster, :3727-3732; facets and `found` read them):
+ * *ids_out is a list object the caller frees with tsgpu_id_lists_free (tsgpu_id_lists_ids / tsgpu_id_lists_count per query) */
+int tsgpu_vector_search_batch_ids(tsgpu_ctx* ctx, uint32_t vec_field_id, const tsgpu_vec_query* params,
+                                  const float* Q, int mem_q, uint32_t n_q, tsgpu_hits* out, tsgpu_id_lists** ids_out);
 
 /* ------------------------------------------------------------------ hybrid (B3) */
 typedef struct tsgpu_hybrid_params {

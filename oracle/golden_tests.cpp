@@ -613,22 +613,54 @@ static void test_vector_reference_pins() {
         auto r = idx.search_vector(vq, sort, 20);
         CHECK_EQ(r.kvs.size(), 20u);                                                      // :848-849
         std::vector<uint32_t> filt; for (uint32_t i = 0; i < 10; i++) filt.push_back(i);  // points:<10
-        r = idx.search_vector(vq, sort, 3, &filt);                                        // :865-881 flat_search_cutoff 1000, per_page 3
-        // (fetch_size 3 -> k = 3; found = 10 comes from the filter, out of scope here)
-        CHECK(r.kvs.size() >= 3u);
+        // :851-863 `flat_search_cutoff: 0` with points:<10: the k-cut (HNSW-shaped) branch, fetch_size 20 -> found 10, 10 hits
+        vq.flat_search_cutoff = 0;
+        r = idx.search_vector(vq, sort, 20, &filt);
+        CHECK_EQ(r.result_ids.size(), 10u); CHECK_EQ(r.kvs.size(), 10u);                  // :862-863
+        // :865-881 `flat_search_cutoff: 1000`, per_page 3: the FLAT branch (10 filter ids < 1000): every filter id goes to the Topster
+        // (capacity min(max(3, 250), 10) = 10, src/index.cpp:3506-3512), `found` = all 10 of them although only 3 hits are fetched
+        vq.flat_search_cutoff = 1000;
+        r = idx.search_vector(vq, sort, 3, &filt);
+        CHECK_EQ(r.result_ids.size(), 10u);                                               // :874 ASSERT_EQ(10, results["found"])
+        CHECK_EQ(r.num_keyword_matches, 10u);
+        CHECK_EQ(r.kvs.size(), 10u);                                                      // (the response pages 3 of them, :875)
         CHECK_EQ(r.kvs[0].key, 1u); CHECK_PIN(r.kvs[0].vector_distance, 3.409385e-05);    // :877-878 ASSERT_FLOAT_EQ
         CHECK_EQ(r.kvs[1].key, 5u); CHECK_PIN(r.kvs[1].vector_distance, 0.016780376);     // :880-881
         CHECK(ulp_gap(r.kvs[0].vector_distance, 3.409385e-05f) <= 4 && ulp_gap(r.kvs[1].vector_distance, 0.016780376f) <= 4);
-        // :883-901 `vec:([], id: 3)`: the query is document 3's STORED JSON values (src/vector_query_ops.cpp:137-146), the
-        // document itself is dropped from the results and one more neighbour is fetched (src/index.cpp:3651-3654, :3686)
-        vector_query_t vid; vid.values = docs[3];
-        std::vector<vec_hit_t> hits = idx.flat_knn(vid.values, 3 + 1, &filt);
-        std::vector<vec_hit_t> kept;
-        for (auto& h : hits) if (h.seq_id != 3) kept.push_back(h);
-        CHECK_EQ(kept.size(), 3u);
-        CHECK_EQ(kept[0].seq_id, 9u); CHECK_PIN(std::abs(kept[0].dist), 0.050603985);     // :895-896
-        CHECK_EQ(kept[1].seq_id, 5u); CHECK_PIN(std::abs(kept[1].dist), 0.100155532);     // :898-899
-        CHECK(ulp_gap(std::abs(kept[0].dist), 0.050603985f) <= 4 && ulp_gap(std::abs(kept[1].dist), 0.100155532f) <= 4);
+        for (size_t i = 1; i < r.kvs.size(); i++) CHECK(r.kvs[i - 1].vector_distance <= r.kvs[i].vector_distance);
+        // the same request WITHOUT the flat branch cuts at k = fetch_size = 3: found would be 3 — the pin above tells the two apart
+        vq.flat_search_cutoff = 0;
+        CHECK_EQ(idx.search_vector(vq, sort, 3, &filt).result_ids.size(), 3u);
+        // :883-901 `vec:([], id: 3, flat_search_cutoff: 1000)`: the query is document 3's STORED JSON values (src/vector_query_ops.cpp:137-146),
+        // the document itself is dropped from the results (src/index.cpp:3651-3654, :3686); flat branch again
+        vector_query_t vid; vid.values = docs[3]; vid.flat_search_cutoff = 1000; vid.query_doc_given = true; vid.seq_id = 3;
+        r = idx.search_vector(vid, sort, 3, &filt);
+        CHECK_EQ(r.result_ids.size(), 9u);                                                // the 10 filter ids minus document 3 itself
+        CHECK(r.kvs.size() >= 3u);                                                        // :890 3 hits
+        CHECK_EQ(r.kvs[0].key, 9u); CHECK_PIN(r.kvs[0].vector_distance, 0.050603985);     // :895-896
+        CHECK_EQ(r.kvs[1].key, 5u); CHECK_PIN(r.kvs[1].vector_distance, 0.100155532);     // :898-899
+        CHECK(ulp_gap(r.kvs[0].vector_distance, 0.050603985f) <= 4 && ulp_gap(r.kvs[1].vector_distance, 0.100155532f) <= 4);
+        // ... and through the k-cut branch (k = 3 + 1 because document 3 passes the functor, :3651-3654): the same three hits
+        vid.flat_search_cutoff = 0;
+        r = idx.search_vector(vid, sort, 3, &filt);
+        CHECK_EQ(r.kvs.size(), 3u); CHECK_EQ(r.kvs[0].key, 9u); CHECK_EQ(r.kvs[1].key, 5u);
+        {   // duplicate embeddings: the flat branch's ties are the TOPSTER's (default sort [vector_distance asc, seq_id desc]: the larger
+            // seq_id first, include/topster.h:146-154), the k-cut branch keeps hnswlib's smaller (distance, id) pairs at the cut
+            Index dup(1, 1);
+            dup.vec_init(4, cosine);
+            for (uint32_t i = 0; i < 8; i++) dup.vec_add(i, docs[i % 2].data());            // ids 0,2,4,6 = docs[0]; 1,3,5,7 = docs[1]
+            std::vector<uint32_t> f8 = {0, 1, 2, 3, 4, 5, 6, 7};
+            vector_query_t vd; vd.values = q1; vd.flat_search_cutoff = 1000;
+            dup.num_docs = 8;
+            auto rf = dup.search_vector(vd, sort, 3, &f8);                                  // Topster capacity min(250, 8) = 8
+            CHECK_EQ(rf.result_ids.size(), 8u); CHECK_EQ(rf.kvs.size(), 8u);
+            CHECK_EQ(rf.kvs[0].key, 7u); CHECK_EQ(rf.kvs[1].key, 5u); CHECK_EQ(rf.kvs[2].key, 3u); CHECK_EQ(rf.kvs[3].key, 1u);   // docs[1] is nearer (pin above)
+            CHECK_EQ(rf.kvs[4].key, 6u); CHECK_EQ(rf.kvs[7].key, 0u);
+            vd.flat_search_cutoff = 0;
+            auto rk = dup.search_vector(vd, sort, 3, &f8);                                  // k = 3: the cut keeps ids 1, 3, 5; the Topster orders them
+            CHECK_EQ(rk.result_ids.size(), 3u);
+            CHECK_EQ(rk.kvs[0].key, 5u); CHECK_EQ(rk.kvs[1].key, 3u); CHECK_EQ(rk.kvs[2].key, 1u);
+        }
         dump_matrix("seed47_unit_docs", docs);
     }
     {   // CollectionVectorTest.TestDistanceThresholdWithIP, :5093-5196: 5 docs x 5, seed 47, uniform(-1,1) interleaved with

@@ -317,20 +317,33 @@ int32_t orc_search_wildcard(void* h, const orc_kw_query* q, orc_result* out) {
     return 0;
 }
 
-int32_t orc_search_vector(void* h, const float* qvec, uint32_t k, float distance_threshold, const int32_t* sort_kind,
-                          const int32_t* sort_column, const int32_t* sort_order, uint32_t n_sort, uint32_t fetch_size,
-                          const uint32_t* filter_ids, uint32_t n_filter, orc_result* out) {
+// the vector branch of Index::search with both of its sub-branches (flat / k-cut), excluded ids and `vec:([], id: X)`
+int32_t orc_search_vector2(void* h, const float* qvec, uint32_t k, float distance_threshold, const int32_t* sort_kind,
+                           const int32_t* sort_column, const int32_t* sort_order, uint32_t n_sort, uint32_t fetch_size,
+                           const uint32_t* filter_ids, uint32_t n_filter, int32_t filter_by_provided, const uint32_t* excluded_ids, uint32_t n_excluded,
+                           uint64_t flat_search_cutoff, int32_t query_doc_given, uint32_t query_seq_id, orc_result* out) {
     Index* idx = (Index*)h;
     vector_query_t vq;
     vq.values.assign(qvec, qvec + idx->num_dim);
     vq.k = k;
     vq.distance_threshold = distance_threshold;
+    vq.flat_search_cutoff = flat_search_cutoff;
+    vq.query_doc_given = query_doc_given != 0;
+    vq.seq_id = query_seq_id;
     std::vector<sort_by_t> sort;
     for (uint32_t i = 0; i < n_sort; i++) sort.push_back({sort_kind[i], sort_column[i], sort_order[i]});
-    std::vector<uint32_t> filt;
+    std::vector<uint32_t> filt, excl;
     if (n_filter) filt.assign(filter_ids, filter_ids + n_filter);
-    fill(idx->search_vector(vq, sort, fetch_size, n_filter ? &filt : nullptr), out);
+    if (n_excluded) excl.assign(excluded_ids, excluded_ids + n_excluded);
+    fill(idx->search_vector(vq, sort, fetch_size, filter_by_provided ? &filt : nullptr, n_excluded ? &excl : nullptr), out);
     return 0;
+}
+
+int32_t orc_search_vector(void* h, const float* qvec, uint32_t k, float distance_threshold, const int32_t* sort_kind,
+                          const int32_t* sort_column, const int32_t* sort_order, uint32_t n_sort, uint32_t fetch_size,
+                          const uint32_t* filter_ids, uint32_t n_filter, orc_result* out) {
+    return orc_search_vector2(h, qvec, k, distance_threshold, sort_kind, sort_column, sort_order, n_sort, fetch_size, filter_ids, n_filter, n_filter ? 1 : 0,
+                              nullptr, 0, 0, 0, 0, out);
 }
 
 int32_t orc_search_hybrid_rerank(void* h, const orc_kw_query* q, const float* qvec, uint32_t k, float alpha,

@@ -109,6 +109,9 @@ struct vector_query_t {
     float distance_threshold = FLT_MAX;
     float alpha = 0.3f;                      // include/vector_query_ops.h:19
     bool rerank_hybrid_matches = false;      // search_params->rerank_hybrid_matches -> compute_aux_scores (index.cpp:4234-4240)
+    size_t flat_search_cutoff = 0;           // include/vector_query_ops.h:13: a filter matching FEWER ids takes the flat branch (index.cpp:3664)
+    uint32_t seq_id = 0;                     // vec:([], id: X): the query is document X's stored vector ...
+    bool query_doc_given = false;            // ... and X itself is left out of the results (index.cpp:3651-3654, :3686)
 };
 
 struct vec_hit_t { float dist; uint32_t seq_id; };
@@ -591,15 +594,48 @@ public:
     }
 
     // ---------------- query time: pure vector (q="*"), index.cpp:3645-3732 ----------------
+    // filter_ids = what filter_by matched (sorted; nullptr = no filter_by), excluded_ids = hidden / curated ids (sorted).
+    // Two branches, index.cpp:3664-3670:
+    //   * FLAT (`filter_by` given and its id count < vector_query.flat_search_cutoff): process_results_bruteforce, :3345-3374 — EVERY
+    //     filter id that has a vector gets its exact distance and goes to the Topster: no k, and the VectorFilterFunctor (hence the
+    //     excluded ids) is not consulted. Which ids survive is decided by the Topster alone (capacity :3506-3512, order
+    //     include/topster.h:146-154: with the default sort [vector_distance asc, seq_id desc] equal distances keep the LARGER seq_id).
+    //     result_ids (-> `found`) = every id kept by the threshold, not just the Topster's content.
+    //   * otherwise process_results_hnsw_index, :3376-3445: searchKnnCloserFirst(k, VectorFilterFunctor) — restated as the EXACT k nearest
+    //     (hnswlib's result heap orders (distance, internal id) pairs: at the k cut equal distances keep the SMALLER id), label order (:3389).
     keyword_result_t search_vector(const vector_query_t& vq, const std::vector<sort_by_t>& sort, size_t fetch_size,
-                                   const std::vector<uint32_t>* filter_ids = nullptr) const {
+                                   const std::vector<uint32_t>* filter_ids = nullptr, const std::vector<uint32_t>* excluded_ids = nullptr) const {
         keyword_result_t out;
         Topster topster(topster_size(fetch_size, filter_ids ? filter_ids->size() : 0));
-        size_t k = vq.k == 0 ? std::max<size_t>(vq.k, fetch_size) : vq.k;
-        std::vector<vec_hit_t> hits = flat_knn(vq.values, k, filter_ids);
-        std::sort(hits.begin(), hits.end(), [](const vec_hit_t& a, const vec_hit_t& b) { return a.seq_id < b.seq_id; });  // :3389
+        size_t k = vq.k == 0 ? std::max<size_t>(vq.k, fetch_size) : vq.k;                                  // :3646
+        auto functor = [&](uint32_t id) {                                                                   // include/index.h:339-353
+            const size_t nf = filter_ids ? filter_ids->size() : 0, ne = excluded_ids ? excluded_ids->size() : 0;
+            if (nf == 0 && ne == 0) return true;
+            if (ne > 0 && std::binary_search(excluded_ids->begin(), excluded_ids->end(), id)) return false;
+            if (nf == 0) return true;
+            return std::binary_search(filter_ids->begin(), filter_ids->end(), id);
+        };
+        if (vq.query_doc_given && functor(vq.seq_id)) k++;                                                  // :3651-3654
+        const bool filter_by_provided = filter_ids != nullptr;
+        const size_t filter_id_count = filter_ids ? filter_ids->size() : 0;
+        std::vector<vec_hit_t> hits;
+        if (filter_by_provided && filter_id_count < vq.flat_search_cutoff) {
+            std::vector<float> q = vq.values;
+            if (distance_type == cosine) { std::vector<float> n(q.size()); normalize_vector(vq.values, n); q.swap(n); }   // :3362-3364 (re-done per id there)
+            std::unordered_map<uint32_t, size_t> row_of;
+            for (size_t r = 0; r < vec_labels.size(); r++) row_of[vec_labels[r]] = r;
+            for (uint32_t seq_id : *filter_ids) {                                                           // the filter iterator: ascending seq_ids
+                auto it = row_of.find(seq_id);
+                if (it == row_of.end()) continue;                                                           // getDataByLabel throws: "likely not found" :3355-3360
+                hits.push_back({ip_distance(q.data(), vec_store.data() + it->second * num_dim, num_dim), seq_id});
+            }
+        } else {
+            hits = flat_knn(vq.values, k, (filter_ids && !filter_ids->empty()) ? filter_ids : nullptr, (excluded_ids && !excluded_ids->empty()) ? excluded_ids : nullptr);
+            std::sort(hits.begin(), hits.end(), [](const vec_hit_t& a, const vec_hit_t& b) { return a.seq_id < b.seq_id; });  // :3389
+        }
         std::vector<uint32_t> nearest_ids;
         for (const auto& h : hits) {
+            if (vq.query_doc_given && vq.seq_id == h.seq_id) continue;                                      // :3686
             float d = (distance_type == cosine) ? std::abs(h.dist) : h.dist;
             if (d > vq.distance_threshold) continue;
             int64_t scores[3] = {0, 0, 0};
@@ -612,6 +648,7 @@ public:
         }
         std::sort(nearest_ids.begin(), nearest_ids.end());
         out.result_ids = nearest_ids;
+        out.num_keyword_matches = nearest_ids.size();          // (all_result_ids_len -> `found`, :3727-3732)
         topster.sort();
         for (uint32_t i = 0; i < topster.size; i++) out.kvs.push_back(*topster.getKV(i));
         return out;

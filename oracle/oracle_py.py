@@ -95,6 +95,8 @@ def lib():
         L.orc_hnsw_search.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_search_vector.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(Result)]
+        L.orc_search_vector2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                         C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_uint32, C.c_void_p]
         L.orc_search_hybrid.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.POINTER(Result)]
         L.orc_search_hybrid_rerank.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int32, C.POINTER(Result)]
         L.orc_facet_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
@@ -312,13 +314,20 @@ class OracleIndex:
         return self._decode(r, b), qi[:r.n].copy()
 
     def search_vector(self, qvec, k=0, fetch_size=10, sort=((SORT_VECTOR_DISTANCE, 0, -1), (SORT_SEQ_ID, 0, 1)),
-                      distance_threshold=3.4028234663852886e38, filter_ids=None, cap=1024, ids_cap=0):
+                      distance_threshold=3.4028234663852886e38, filter_ids=None, cap=1024, ids_cap=0, excluded_ids=None,
+                      flat_search_cutoff=0, query_doc=None):
+        """the vector branch of Index::search (src/index.cpp:3645-3732): filter_ids = what filter_by matched (None = no filter_by);
+        fewer filter ids than flat_search_cutoff -> the FLAT branch (every filter id into the Topster, found = the ids kept);
+        query_doc = seq_id of `vec:([], id: X)` (the caller passes X's stored vector as qvec)"""
         r, b = self._alloc(cap, ids_cap)
         qv = np.ascontiguousarray(qvec, dtype=np.float32)
         sk = np.array([s[0] for s in sort], np.int32); sc = np.array([s[1] for s in sort], np.int32); so = np.array([s[2] for s in sort], np.int32)
         f = _u32(filter_ids) if filter_ids is not None else None
-        self.L.orc_search_vector(self.h, _ptr(qv), k, distance_threshold, _ptr(sk), _ptr(sc), _ptr(so), len(sort), fetch_size,
-                                 _ptr(f) if f is not None else None, f.size if f is not None else 0, C.byref(r))
+        e = _u32(excluded_ids) if excluded_ids is not None else None
+        self.L.orc_search_vector2(self.h, _ptr(qv), k, C.c_float(distance_threshold), _ptr(sk), _ptr(sc), _ptr(so), len(sort), fetch_size,
+                                  _ptr(f) if f is not None and f.size else None, f.size if f is not None else 0, 1 if f is not None else 0,
+                                  _ptr(e) if e is not None and e.size else None, e.size if e is not None else 0,
+                                  C.c_uint64(int(flat_search_cutoff)), 1 if query_doc is not None else 0, int(query_doc or 0), C.byref(r))
         return self._decode(r, b)
 
     def search_hybrid(self, q, qvec, k=0, alpha=0.3, distance_threshold=3.4028234663852886e38, cap=1024, ids_cap=0, rerank=False):

@@ -302,6 +302,65 @@ def test_pure_vector_search_topster_order_matches_oracle():
     g.close()
 
 
+def _flat_case(lib, n_docs, dim, metric, seed, n_filter, n_q=3):
+    """the vector branch of Index::search, both sub-branches, against the oracle (src/index.cpp:3645-3732): duplicate embeddings (the
+    flat branch's ties are the Topster's: larger seq_id first; the k-cut keeps hnswlib's smaller ids), filter ids without a vector and
+    deleted ones (skipped), thresholds, a numeric sort key, `vec:([], id: X)`, all_result_ids"""
+    docs = H.zipf_docs(n_docs, 30, 4, seed=seed)
+    orc, g = H.build_pair(docs, lib)
+    rng = np.random.default_rng(seed)
+    n_vec = n_docs - 40                                              # the last 40 documents have no vector
+    X = rng.standard_normal((n_vec, dim)).astype(np.float32)
+    X[rng.integers(0, n_vec, size=n_vec // 3)] = X[5]                # a third of the rows share one embedding: masses of exact ties
+    X[11] = X[5]
+    g.vec_create(1, dim, metric)
+    g.vec_upsert(1, np.arange(n_vec, dtype=np.uint64), X)
+    orc.vec_init(dim, metric)
+    orc.vec_add(np.arange(n_vec, dtype=np.uint32), X)
+    Q = rng.standard_normal((n_q, dim)).astype(np.float32)
+    Q[0] = X[5]
+    filt = np.sort(rng.choice(n_docs, size=n_filter, replace=False)).astype(np.uint32)
+    osort = ((O.SORT_VECTOR_DISTANCE, 0, -1), (O.SORT_SEQ_ID, 0, 1))
+    gsort = ((B.SORT_VECTOR_DISTANCE, -1, 0), (B.SORT_SEQ_ID, 1, 0))
+    cases = [dict(fetch_size=10), dict(fetch_size=30, distance_threshold=1.02 if metric == B.METRIC_COSINE else 0.5), dict(fetch_size=300, k=7),
+             dict(fetch_size=10, query_doc=int(filt[len(filt) // 2])),
+             dict(fetch_size=25, sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_VECTOR_DISTANCE, -1, 0), (B.SORT_SEQ_ID, -1, 0)),
+                  osort=((O.SORT_INT64_COLUMN, 0, 1), (O.SORT_VECTOR_DISTANCE, 0, -1), (O.SORT_SEQ_ID, 0, -1)))]
+    for cutoff in (n_filter + 1, 0):                                  # flat branch / k-cut branch
+        for c in cases:
+            c = dict(c)
+            os_ = c.pop("osort", osort)
+            gs = c.pop("sort", gsort)
+            excl = filt[::7] if cutoff == 0 else None                 # (the flat branch does not consult the excluded ids)
+            hits, ids = g.vector_search_batch(1, Q, sort=gs, k_stride=320, filter_ids=filt, excluded_ids=excl, flat_search_cutoff=cutoff, want_ids=True, **c)
+            assert (hits.status == 0).all()
+            for i in range(n_q):
+                ref = orc.search_vector(Q[i], sort=os_, filter_ids=filt, excluded_ids=excl, flat_search_cutoff=cutoff, cap=2048, ids_cap=n_docs, **c)
+                n = int(hits.n_hits[i])
+                what = (cutoff, c, i)
+                assert n == ref.keys.size, (what, n, ref.keys.size)
+                assert np.array_equal(hits.keys[i, :n], ref.keys), (what, hits.keys[i, :12], ref.keys[:12])
+                assert np.array_equal(hits.scores[i, :n], ref.scores), what
+                assert np.array_equal(hits.vector_distance[i, :n].view(np.uint32), ref.vector_distance.view(np.uint32)), what
+                assert np.array_equal(hits.match_score_index[i, :n], ref.match_score_index), what
+                assert int(hits.num_matched[i]) == int(ref.n_result_ids), (what, hits.num_matched[i], ref.n_result_ids)
+                assert np.array_equal(ids[i], ref.result_ids), what
+    # deleted rows are "not found" for the flat branch (getDataByLabel throws), too
+    victims = [int(x) for x in filt[filt < n_vec][:5]]
+    for v in victims:
+        g.vec_delete(1, v)
+    hits = g.vector_search_batch(1, Q[:1], k_stride=320, filter_ids=filt, flat_search_cutoff=n_filter + 1)
+    assert not set(victims) & set(hits.keys[0, :int(hits.n_hits[0])].tolist())
+    ref = orc.search_vector(Q[0], filter_ids=np.array([x for x in filt if x not in victims], np.uint32), flat_search_cutoff=n_filter + 1, cap=2048)
+    assert np.array_equal(hits.keys[0, :int(hits.n_hits[0])], ref.keys) and int(hits.num_matched[0]) == int(ref.n_result_ids)
+    g.close()
+
+
+@pytest.mark.parametrize("n_docs,dim,metric,n_filter", [(900, 24, B.METRIC_COSINE, 300), (700, 40, B.METRIC_IP, 90)])
+def test_vector_branch_flat_and_k_cut_match_the_oracle(n_docs, dim, metric, n_filter):
+    _flat_case(H.emu_lib_path(), n_docs, dim, metric, 5, n_filter)
+
+
 def test_hybrid_rank_fusion_matches_oracle_bit_exactly():
     orc, g, rng = _text_and_vectors(H.emu_lib_path())
     Q = rng.standard_normal((6, 24)).astype(np.float32)

@@ -35,6 +35,13 @@ test_prefilter_brackets_prune_but_never_drop_a_neighbour = E.test_prefilter_brac
 test_hnsw_graph_search_replays_the_reference_traversal = E.test_hnsw_graph_search_replays_the_reference_traversal
 test_edge_cases_empty_tiny_and_fully_deleted_indexes = E.test_edge_cases_empty_tiny_and_fully_deleted_indexes
 test_every_summation_order_of_hnswlibs_distance_is_bit_exact = E.test_every_summation_order_of_hnswlibs_distance_is_bit_exact
+test_vector_branch_flat_and_k_cut_match_the_oracle = E.test_vector_branch_flat_and_k_cut_match_the_oracle
+
+
+def test_flat_branch_at_size_many_work_items_768_dims():
+    """row a19 at size: 120 000 documents x 768 dims, 50 000 filter ids (four 16K-id work items per query, partial Topsters merged),
+    a third of the rows one duplicated embedding; hits, sort keys, distance bits, found and all_result_ids = the oracle's"""
+    E._flat_case(H.gpu_lib_path(), 120_000, 768, B.METRIC_COSINE, 7, 50_000, n_q=2)
 
 
 def test_hnsw_20k_x_96_batch_of_512_matches_the_cpu_traversal():

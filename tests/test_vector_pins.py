@@ -86,6 +86,27 @@ def run_pins(lib_path):
         assert len(keep) == 3 and keep[0][1] == 9 and keep[1][1] == 5
         assert abs(keep[0][0] - 0.050603985) <= RTOL * 0.050603985 and abs(keep[1][0] - 0.100155532) <= RTOL * 0.100155532
 
+        # the same requests through the vector branch itself (tsgpu_vector_search_batch): `flat_search_cutoff: 0` = the k-cut branch,
+        # found 10 / 10 hits (:851-863); `flat_search_cutoff: 1000`, per_page 3 = the FLAT branch: found == 10 although k = 3, the
+        # Topster (capacity min(250, 10)) holds all ten, hits 1 and 5 with the pinned distances (:865-881)
+        hits = g.vector_search_batch(2, Q1[None, :], fetch_size=20, filter_ids=filt, flat_search_cutoff=0)
+        assert int(hits.n_hits[0]) == 10 and int(hits.num_matched[0]) == 10
+        hits, ids = g.vector_search_batch(2, Q1[None, :], fetch_size=3, filter_ids=filt, flat_search_cutoff=1000, want_ids=True)
+        assert int(hits.num_matched[0]) == 10 and int(hits.n_hits[0]) == 10 and ids[0].tolist() == list(range(10))     # :874 found == 10
+        assert hits.keys[0, :2].tolist() == [1, 5]
+        d = hits.vector_distance[0, :2]
+        assert abs(d[0] - 3.409385e-05) <= RTOL * 3.409385e-05 and abs(d[1] - 0.016780376) <= RTOL * 0.016780376
+        assert np.array_equal(bits(d[0]), bits(np.float32(3.409385681152344e-05)))   # (the 17-digit pin of the same pair, :120: bit-exact)
+        assert np.array_equal(hits.scores[0, :10, 0], -f2i(hits.vector_distance[0, :10])) and np.array_equal(hits.scores[0, :10, 1], hits.keys[0, :10].astype(np.int64))
+        cut = g.vector_search_batch(2, Q1[None, :], fetch_size=3, filter_ids=filt, flat_search_cutoff=0)     # without the flat branch: k = 3 cuts, found 3
+        assert int(cut.num_matched[0]) == 3 and cut.keys[0, :2].tolist() == [1, 5]
+        # `vec:([], id: 3, flat_search_cutoff: 1000)` (:883-901): document 3 is the query and is left out; hits 9 and 5
+        for cutoff, found in ((1000, 9), (0, 3)):
+            hits = g.vector_search_batch(2, docs[3][None, :], fetch_size=3, filter_ids=filt, flat_search_cutoff=cutoff, query_doc=3)
+            assert int(hits.num_matched[0]) == found and hits.keys[0, :2].tolist() == [9, 5], (cutoff, hits.keys[0, :4], hits.num_matched[0])
+            d = hits.vector_distance[0, :2]
+            assert abs(d[0] - 0.050603985) <= RTOL * 0.050603985 and abs(d[1] - 0.100155532) <= RTOL * 0.100155532
+
         # ---- TestDistanceThresholdWithIP (:5093-5196): IP 5-d, distance as a sort key over all five documents ----
         docs = np.array(P["seed47_ip_docs"], np.float32)
         rank = np.array(P["seed47_ip_rank_scores"])

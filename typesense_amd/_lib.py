@@ -45,7 +45,9 @@ class HitsC(C.Structure):
 
 class VecQueryC(C.Structure):
     _fields_ = [("k", C.c_uint32), ("fetch_size", C.c_uint32), ("distance_threshold", C.c_float),
-                ("n_sort", C.c_uint32), ("sort", SortBy * 3), ("topster_size", C.c_uint32)]
+                ("n_sort", C.c_uint32), ("sort", SortBy * 3), ("topster_size", C.c_uint32),
+                ("filter_by_provided", C.c_uint32), ("filter_ids", C.c_void_p), ("n_filter", C.c_uint32), ("n_excluded", C.c_uint32),
+                ("excluded_ids", C.c_void_p), ("flat_search_cutoff", C.c_uint64), ("query_doc_given", C.c_uint32), ("query_seq_id", C.c_uint32)]
 
 
 class HybridParamsC(C.Structure):
@@ -92,7 +94,7 @@ EXPORTS = [
     "tsgpu_term_num_ids", "tsgpu_term_download", "tsgpu_keyword_search_batch", "tsgpu_wildcard_search_batch", "tsgpu_keyword_search_candidates_batch", "tsgpu_candidates_result_ids", "tsgpu_keep_result_ids", "tsgpu_result_ids",
     "tsgpu_keyword_search_batch_ids", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free", "tsgpu_facet_set", "tsgpu_facet_count_batch", "tsgpu_facet_stats_batch", "tsgpu_facet_value_set", "tsgpu_facet_value_count_batch",
     "tsgpu_vec_create", "tsgpu_vec_upsert", "tsgpu_vec_delete", "tsgpu_vec_get", "tsgpu_vec_count", "tsgpu_vec_knn_batch",
-    "tsgpu_vec_hnsw_load", "tsgpu_vec_hnsw_search_batch", "tsgpu_vec_distances", "tsgpu_ip_distance", "tsgpu_vector_search_batch", "tsgpu_hybrid_search_batch", "tsgpu_hybrid_fuse_batch", "tsgpu_keyword_aux_scores", "tsgpu_merge_shard_hits", "tsgpu_merge_shard_hits_device", "tsgpu_last_timings",
+    "tsgpu_vec_hnsw_load", "tsgpu_vec_hnsw_search_batch", "tsgpu_vec_distances", "tsgpu_ip_distance", "tsgpu_vector_search_batch", "tsgpu_vector_search_batch_ids", "tsgpu_hybrid_search_batch", "tsgpu_hybrid_fuse_batch", "tsgpu_keyword_aux_scores", "tsgpu_merge_shard_hits", "tsgpu_merge_shard_hits_device", "tsgpu_last_timings",
     "tsgpu_group_create_local", "tsgpu_group_unique_id", "tsgpu_group_create_rank", "tsgpu_group_create_rank_host", "tsgpu_group_destroy", "tsgpu_group_size", "tsgpu_group_keyword_search_batch",
     "tsgpu_group_vec_knn_batch", "tsgpu_group_hybrid_search_batch", "tsgpu_group_last_timings", "tsgpu_group_set_option",
 ]
@@ -172,6 +174,7 @@ def lib(path=None):
     L.tsgpu_ip_distance.restype = C.c_float
     L.tsgpu_keyword_aux_scores.argtypes = [vp, vp, u32, vp, vp, u32, vp]
     L.tsgpu_vector_search_batch.argtypes = [vp, u32, C.POINTER(VecQueryC), vp, i32, u32, C.POINTER(HitsC)]
+    L.tsgpu_vector_search_batch_ids.argtypes = [vp, u32, C.POINTER(VecQueryC), vp, i32, u32, C.POINTER(HitsC), C.POINTER(vp)]
     L.tsgpu_hybrid_search_batch.argtypes = [vp, vp, u32, C.POINTER(HybridParamsC), vp, i32, u32, C.POINTER(HitsC)]
     L.tsgpu_hybrid_fuse_batch.argtypes = [vp, vp, C.POINTER(HybridParamsC), i32, C.POINTER(HitsC), vp, vp, vp, u32, u32, C.POINTER(HitsC)]
     L.tsgpu_merge_shard_hits.argtypes = [vp, vp, u32, u32, u32, C.POINTER(HitsC)]

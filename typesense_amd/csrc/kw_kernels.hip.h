@@ -135,6 +135,12 @@ struct KwQueryDev {                  // one search_across_fields call
     uint8_t orig_num_tokens, is_synonym, demote_synonym;
     uint32_t m_first, m_n;           // the sorted partial lists kw_merge_kernel folds: the work items themselves, or (many work items) the
                                      // group lists kw_merge_groups_kernel left behind them (counters always come from the work items)
+    uint64_t vdist;                  // wildcard form used by the FLAT branch of the vector search (process_results_bruteforce, src/index.cpp:3345-3374,
+                                     // :3675-3723): device address of float dist[wild_n_ids], entry i = exact distance of filter id i (NaN: the label has
+                                     // no vector / is the query document -> skipped); 0 = a plain wildcard query
+    float vdist_thr;                 // vector_query.distance_threshold (:3702)
+    uint8_t vdist_abs;               // cosine field: std::abs(dist) (:3699)
+    uint8_t pad2[3];
 };
 
 // query_by over several fields (get_field_token_its, src/index.cpp:5598-5660): token t is the UNION over the fields of its
@@ -679,8 +685,13 @@ __device__ inline uint64_t agg_finish(const AggState& st, const KwQueryDev& q, u
 }
 
 // compute_sort_scores, src/index.cpp:5662-5907 (text_match / seq_id / int64 column) + :5541-5544 override
+__device__ inline int64_t float_to_int64_dev(float f) {       // Index::float_to_int64_t, src/index.cpp:266-274
+    int32_t i = (int32_t)__float_as_uint(f);
+    if (i < 0) i ^= INT32_MAX;
+    return (int64_t)i;
+}
 __device__ inline ScoredHit sort_scores(const IndexView& ix, const KwQueryDev& q, uint32_t seq_id, uint64_t agg, uint32_t off_words,
-                                        bool override_text_match = true) {
+                                        bool override_text_match = true, float vector_distance = 0.0f) {
     int64_t sc[3] = {0, 0, 0};
     int msi = -1;
 #pragma unroll
@@ -692,7 +703,7 @@ __device__ inline ScoredHit sort_scores(const IndexView& ix, const KwQueryDev& q
             else if (q.sort_kind[i] == 2) {
                 const uint32_t c = q.sort_col[i];
                 v = (c < ix.n_columns && seq_id < ix.column_len[c]) ? ix.columns[c][seq_id] : INT64_MIN;
-            } else v = 0;   // vector_distance is never a keyword sort key here (float_to_int64_t(0) == 0)
+            } else v = float_to_int64_dev(vector_distance);   // (:5835-5836; keyword passes hand 0: float_to_int64_t(0) == 0)
             if (q.sort_order[i] == -1) v = (int64_t)(0ull - (uint64_t)v);
             sc[i] = v;
         }
@@ -1679,7 +1690,13 @@ __global__ __launch_bounds__(KW_THREADS) void kw_wildcard_kernel(IndexView ix, c
                 while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ex[mid] < seq_id) lo = mid + 1; else hi = mid; }
                 if (lo < q.n_excl && ex[lo] == seq_id) emit = false;
             }
-            if (emit) h = sort_scores(ix, q, seq_id, 100, 0, false);
+            float vd = 0.0f;
+            if (emit && q.vdist) {           // flat vector branch: the id's exact distance, abs() for cosine, the threshold (:3699-3704)
+                vd = ((const float*)q.vdist)[idx];
+                if (q.vdist_abs) vd = fabsf(vd);
+                if (vd != vd || vd > q.vdist_thr) emit = false;
+            }
+            if (emit) h = sort_scores(ix, q, seq_id, q.vdist ? 0 : 100, 0, false, vd);      // (text-match slot: 100 for q=*, 0 in the vector branch :3711)
         }
         uint32_t total;
         const uint32_t my = block_compact(emit, wave_cnt, total);
@@ -1702,6 +1719,24 @@ __global__ __launch_bounds__(KW_THREADS) void kw_wildcard_kernel(IndexView ix, c
         part.s0[base + i] = tk.s0[i]; part.s1[base + i] = tk.s1[i]; part.s2[base + i] = tk.s2[i]; part.key[base + i] = tk.key[i];
     }
     if (t == 0) { part.cnt[blockIdx.x] = n; part.n_match[blockIdx.x] = s_emit; part.n_emit[blockIdx.x] = s_emit; part.off_words[blockIdx.x] = 0; }
+}
+
+// flat vector branch: KV::vector_distance of the merged hits (kv.vector_distance = vec_dist_score, src/index.cpp:3717) — the hit's seq_id is
+// looked up in the query's filter ids, whose index addresses the distance array. grid = queries.
+__global__ __launch_bounds__(KW_THREADS) void kw_vflat_distance_kernel(const KwQueryDev* __restrict__ queries, const uint32_t* __restrict__ aux_ids, KwOut out) {
+    const KwQueryDev& q = queries[blockIdx.x];
+    if (!q.vdist || !out.vector_distance) return;
+    const uint32_t* fl = aux_ids + q.aux_off + q.n_excl;
+    const uint32_t nh = out.n_hits[blockIdx.x], n = nh < out.k_stride ? nh : out.k_stride;
+    const size_t ob = (size_t)blockIdx.x * out.k_stride;
+    for (uint32_t i = threadIdx.x; i < n; i += KW_THREADS) {
+        const uint32_t key = (uint32_t)out.keys[ob + i];
+        uint32_t lo = 0, hi = q.n_filt;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (fl[mid] < key) lo = mid + 1; else hi = mid; }
+        float d = lo < q.n_filt ? ((const float*)q.vdist)[lo] : -1.0f;
+        if (q.vdist_abs) d = fabsf(d);
+        out.vector_distance[ob + i] = d;
+    }
 }
 
 // num_keyword_matches of a FILTERED query (include/or_iterator.h:61-182 with istate.filter_ids): the reference counts the

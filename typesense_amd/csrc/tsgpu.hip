@@ -385,7 +385,7 @@ static uint32_t resolve_topster_size(const tsgpu_ctx* ctx, const tsgpu_kw_query&
     return std::max<uint32_t>(k, 1);
 }
 
-static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query* queries, uint32_t n_queries, Plan& P, bool keep_ids, bool wildcard) {
+static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query* queries, uint32_t n_queries, Plan& P, bool keep_ids, bool wildcard, const KwVFlat* vflat = nullptr) {
     // driver blocks per work item: fixed by the option, or (0 = auto) sized so that the batch yields a few thousand work
     // items (>= 3 per resident workgroup slot) without fragmenting queries into more partial top-K lists than needed
     uint32_t KW_CHUNK_BLOCKS = ctx->kw_chunk_blocks;
@@ -468,12 +468,12 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
             if (in.match_type > TSGPU_SUM_SCORE) { P.status[i] = TSGPU_ERR_INVALID; continue; }
             bool bad_sort = false;
             for (uint32_t s = 0; s < in.n_sort; s++) {
-                if (in.sort[s].kind > TSGPU_SORT_INT64_COLUMN) bad_sort = true;   // vector_distance belongs to the vector/hybrid entry points
+                if (in.sort[s].kind > TSGPU_SORT_INT64_COLUMN && !(vflat && in.sort[s].kind == TSGPU_SORT_VECTOR_DISTANCE)) bad_sort = true;   // vector_distance belongs to the vector/hybrid entry points
                 if (in.sort[s].kind == TSGPU_SORT_INT64_COLUMN && in.sort[s].column >= ctx->columns.size()) bad_sort = true;
                 if (in.sort[s].order != 1 && in.sort[s].order != -1) bad_sort = true;
             }
             if (bad_sort) { unsupported("sort"); continue; }
-            const uint32_t k = resolve_topster_size(ctx, in);
+            const uint32_t k = vflat ? std::max<uint32_t>(in.topster_size, 1) : resolve_topster_size(ctx, in);     // (the vector branch resolved it against ITS filter / row count)
             if (k > TSGPU_MAX_TOPK) { unsupported("topster_size"); continue; }
             if (in.deadline_us != 0 && now > in.deadline_us) { P.status[i] = TSGPU_ERR_DEADLINE; P.cutoff[i] = 1; continue; }
             if (in.deadline_us != 0) { q.deadline_rem_us = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(in.deadline_us - now, 1), 0xFFFFFFFFull); A.any_deadline = true; }
@@ -488,14 +488,24 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
                 }
                 q.k = k;
                 A.max_k = std::max(A.max_k, k);
-                q.aux_off = (uint32_t)A.aux.size();
                 q.n_excl = in.n_excluded;
                 q.n_filt = in.n_filter;
-                if (in.n_excluded) {
-                    if (!in.excluded_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
-                    A.aux.insert(A.aux.end(), in.excluded_ids, in.excluded_ids + in.n_excluded);
+                if (vflat) {
+                    // flat vector branch: query i ranks ITS row of the distance matrix (aligned with the filter ids); the queries of a call share
+                    // one filter (same host array): uploaded once per planning slice
+                    if (in.n_excluded || !in.n_filter) { P.status[i] = TSGPU_ERR_INVALID; continue; }
+                    q.vdist = (uint64_t)(uintptr_t)(vflat->dist_dev + (size_t)i * vflat->stride);
+                    q.vdist_thr = vflat->threshold; q.vdist_abs = vflat->abs ? 1 : 0;
                 }
-                if (in.n_filter) A.aux.insert(A.aux.end(), in.filter_ids, in.filter_ids + in.n_filter);
+                if (vflat && i > lo && P.status[i - 1] == TSGPU_OK && queries[i - 1].filter_ids == in.filter_ids && queries[i - 1].n_filter == in.n_filter) q.aux_off = P.q[i - 1].aux_off;
+                else {
+                    q.aux_off = (uint32_t)A.aux.size();
+                    if (in.n_excluded) {
+                        if (!in.excluded_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
+                        A.aux.insert(A.aux.end(), in.excluded_ids, in.excluded_ids + in.n_excluded);
+                    }
+                    if (in.n_filter) A.aux.insert(A.aux.end(), in.filter_ids, in.filter_ids + in.n_filter);
+                }
                 const uint32_t n_ids = in.n_filter ? in.n_filter : ctx->num_docs;
                 q.wild_n_ids = n_ids;
                 uint32_t n_num = 0;
@@ -781,6 +791,7 @@ struct BatchOpts {
     bool alias_out = false;                           // host output through the lane's pinned image: point `out`'s arrays INTO the image instead of copying
                                                       // them out (the coalesced round hands every caller its slice straight from there)
     bool timing = true;                               // record the phase events (tsgpu_timings); a coalesced round has no single caller to report to
+    const KwVFlat* vflat = nullptr;                   // wildcard form ranking a distance matrix: the flat branch of the vector search (tsgpu_vector_search_batch)
 };
 }
 static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, const BatchOpts& bo);
@@ -1027,7 +1038,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         static const bool host_timing = getenv("TSGPU_HOST_TIMING") != nullptr;      // diagnostics: host phases of the call on stderr
         const uint64_t t_enter = now_us();
         Plan P;
-        int rc = plan_batch(ctx, snap, queries, n_queries, P, keep_ids, wildcard);
+        int rc = plan_batch(ctx, snap, queries, n_queries, P, keep_ids, wildcard, bo.vflat);
         if (rc) return rc;
         const uint64_t t_planned = now_us();
         if (out->k_stride < P.max_k) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: k_stride smaller than the largest topster_size");
@@ -1251,6 +1262,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             else hipLaunchKernelGGL((kw_merge_groups_kernel<2048>), dim3(ng), dim3(KW_THREADS), 0, s, dq, part, dg);
         }
         launch_merge(cap, s, n_queries, dq, part, o, ids_out, dw, ctx->kw_merge_select_min);
+        if (bo.vflat) hipLaunchKernelGGL(kw_vflat_distance_kernel, dim3(n_queries), dim3(KW_THREADS), 0, s, dq, daux, o);     // KV::vector_distance of the hits
         if (timing) TSGPU_HIP_TRY(hipEventRecord(L.ev[2], s));
         TSGPU_HIP_TRY(hipGetLastError());
         if (bo.chain) { TSGPU_HIP_TRY(hipEventRecord(L.ev_chain, s)); bo.chain->last = L.ev_chain; chain_lk.unlock(); }
@@ -1739,6 +1751,26 @@ int tsgpu_last_timings(tsgpu_ctx* ctx, tsgpu_timings* out) {
 
 // ---- tsgpu_group (tsgpu_group.hip): the device-side halves of the keyword exchange ----
 namespace tsgpu {
+// The flat branch of the vector search (tsgpu_vec.hip computes the distance matrix): every query ranks its filter ids by its sort keys with
+// the id's distance as KV::vector_distance / the vector_distance sort key — the wildcard machinery (work items of 256-id blocks, LDS
+// Topster, kw_merge_kernel) with one more column. num_matched = the ids the threshold kept = `found`; ids_out (optional) = those ids.
+int kw_vector_flat_search(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, const KwVFlat* vf, tsgpu_id_lists** ids_out) {
+    if (!ctx || !out || !queries || !vf || n_queries == 0) return fail(TSGPU_ERR_INVALID, "tsgpu_vector_search_batch: bad arguments");
+    struct CallerCount { std::atomic<int>& c; explicit CallerCount(std::atomic<int>& x) : c(x) { c.fetch_add(1); } ~CallerCount() { c.fetch_sub(1); } } cc(ctx->kw_callers);
+    std::unique_ptr<tsgpu_id_lists> lists;
+    if (ids_out) { *ids_out = nullptr; lists.reset(new (std::nothrow) tsgpu_id_lists); if (!lists) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vector_search_batch: host allocation failed"); }
+    BatchOpts bo;
+    bo.wildcard = true;
+    bo.vflat = vf;
+    bo.keep_ids = ids_out != nullptr;
+    bo.id_lists = lists.get();
+    bo.record_last = false;
+    LaneLock ll(ctx, tsgpu::tls_avoid_lane0() ? -2 : -1);
+    const int rc = kw_batch_on_lane(ctx, *ll.L, queries, n_queries, out, bo);
+    if (rc == TSGPU_OK && ids_out) *ids_out = lists.release();
+    return rc;
+}
+
 int group_pack_keyword(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t k, uint32_t words, uint64_t* block, hipStream_t s) {
     if (!loc || loc->mem != TSGPU_MEM_DEVICE || !loc->keys || !loc->scores || !loc->n_hits || k == 0 || k > loc->k_stride || (words != 4 && words != 5))
         return fail(TSGPU_ERR_INVALID, "tsgpu_group: bad local result");

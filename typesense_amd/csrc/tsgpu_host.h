@@ -462,6 +462,9 @@ struct tsgpu_ctx {
 // All of them ENQUEUE on `s` and do not synchronise. A keyword exchange block = n_q records of k * words + 3 u64 (KwShardIn::packed),
 // a k-NN block = n_q * k u64 (vec_group_pack_kernel).
 namespace tsgpu {
+// flat vector branch (tsgpu_vec.hip -> tsgpu.hip): query i ranks row i of a device distance matrix aligned with its filter ids
+struct KwVFlat { const float* dist_dev; size_t stride; float threshold; bool abs; };
+int kw_vector_flat_search(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, const KwVFlat* vf, tsgpu_id_lists** ids_out);
 inline size_t group_kw_record_words(uint32_t k, uint32_t words) { return (size_t)k * words + 3; }
 int group_pack_keyword(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t k, uint32_t words, uint64_t* block, hipStream_t s);
 // merges records [0, n_q) of every gathered block into queries [q_out_offset, q_out_offset + n_q) of out_dev (caps_dev is indexed by OUTPUT query)

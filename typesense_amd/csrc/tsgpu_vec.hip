@@ -928,25 +928,93 @@ float tsgpu_ip_distance(const float* a, const float* b, uint32_t dim, int simd_l
 #pragma clang fp contract(fast)
 
 // pure vector search, src/index.cpp:3645-3732
-int tsgpu_vector_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const tsgpu_vec_query* p, const float* Q, int mem_q, uint32_t n_q,
-                              tsgpu_hits* out) {
+// FLAT branch (src/index.cpp:3664-3665 -> :3345-3374 -> :3675-3723): the distance matrix [n_q][n_filter] on the device, then the wildcard
+// ranking machinery of the keyword module (kw_vector_flat_search) puts EVERY kept id through the Topster — no k cut.
+static int vector_search_flat(tsgpu_ctx* ctx, uint32_t vec_field_id, const tsgpu_vec_query* p, const float* Q, int mem_q, uint32_t n_q, tsgpu_hits* out,
+                              tsgpu_id_lists** ids_out) {
+    const uint32_t nf = p->n_filter;
+    const size_t stride = ((size_t)nf + 3) & ~(size_t)3;
+    DevBuf d_dist, d_rows, d_q;                        // per call (another flat search may run while this one ranks): parked, not freed, on exit
+    struct Park { DevBuf* b[3]; ~Park() { for (DevBuf* x : b) if (x->p) { deferred_frees().park(x->p, x->cap, false); x->p = nullptr; x->cap = 0; } } } park{{&d_dist, &d_rows, &d_q}};
+    bool cosine = false;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        VecField* f = get_field(ctx, vec_field_id);
+        if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vector_search_batch: unknown vector field");
+        cosine = f->metric == TSGPU_METRIC_COSINE;
+        hipStream_t s = ctx->stream;
+        std::vector<uint32_t> rows(nf);
+        for (uint32_t i = 0; i < nf; i++) {              // getDataByLabel throws for an unknown / deleted label: "likely not found", the id is skipped (:3355-3360)
+            uint32_t r;
+            rows[i] = (f->find_row(p->filter_ids[i], r) && f->h_ok[r]) ? r : 0xFFFFFFFFu;
+            if (p->query_doc_given && p->filter_ids[i] == p->query_seq_id) rows[i] = 0xFFFFFFFFu;     // the query document itself is left out (:3686)
+        }
+        int rc;
+        if ((rc = d_dist.reserve(std::max<size_t>((size_t)n_q * stride * 4, 16))) || (rc = d_rows.reserve((size_t)nf * 4)) || (rc = d_q.reserve((size_t)n_q * f->dim * 4))) return rc;
+        TSGPU_HIP_TRY(hipMemcpyAsync(d_rows.p, rows.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(d_q.p, Q, (size_t)n_q * f->dim * 4, mem_q == TSGPU_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+        if (cosine) hipLaunchKernelGGL(vec_normalize_rows_kernel, dim3((n_q + 63) / 64), dim3(64), 0, s, d_q.as<float>(), n_q, f->dim);     // (:3362-3364)
+        for (uint32_t q0 = 0; q0 < n_q; q0 += 32768) {
+            const uint32_t nq = std::min<uint32_t>(32768, n_q - q0);
+            hipLaunchKernelGGL(vec_flat_distances_kernel, dim3((nf + 15) / 16, nq), dim3(256), 0, s, f->X.as<float>(), d_q.as<float>() + (size_t)q0 * f->dim, f->dim,
+                               d_rows.as<uint32_t>(), nf, d_dist.as<float>() + (size_t)q0 * stride, stride, ctx->vec_ip_lanes);
+        }
+        TSGPU_HIP_TRY(hipGetLastError());
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));         // the ranking runs on a keyword lane's stream
+    }
+    std::vector<tsgpu_kw_query> qs(n_q);
+    memset(qs.data(), 0, qs.size() * sizeof(tsgpu_kw_query));
+    const uint32_t tsz = p->topster_size ? p->topster_size : std::max<uint32_t>(1, std::min<uint32_t>(std::max<uint32_t>(p->fetch_size, TSGPU_DEFAULT_TOPSTER_SIZE), nf));   // :3506-3512
+    for (uint32_t i = 0; i < n_q; i++) {
+        tsgpu_kw_query& q = qs[i];
+        q.n_sort = p->n_sort;
+        for (uint32_t j = 0; j < p->n_sort; j++) q.sort[j] = p->sort[j];
+        q.topster_size = tsz;
+        q.filter_ids = p->filter_ids; q.n_filter = nf;
+    }
+    KwVFlat vf{d_dist.as<float>(), stride, p->distance_threshold, cosine};
+    return kw_vector_flat_search(ctx, qs.data(), n_q, out, &vf, ids_out);
+}
+
+static int vector_search_impl(tsgpu_ctx* ctx, uint32_t vec_field_id, const tsgpu_vec_query* p, const float* Q, int mem_q, uint32_t n_q, tsgpu_hits* out,
+                              tsgpu_id_lists** ids_out) {
+    if (ids_out) *ids_out = nullptr;
     if (!ctx || !p || !Q || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_vector_search_batch: NULL argument");
-    if (out->mem != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vector_search_batch: host outputs only");
-    if (n_q == 0) return ok();
+    if (n_q == 0) { if (ids_out) { *ids_out = new (std::nothrow) tsgpu_id_lists; if (*ids_out) (*ids_out)->begin.assign(1, 0); } return ok(); }
     if (p->n_sort > 3) return fail(TSGPU_ERR_INVALID, "tsgpu_vector_search_batch: more than 3 sort keys");
+    if ((p->n_filter && !p->filter_ids) || (p->n_excluded && !p->excluded_ids)) return fail(TSGPU_ERR_INVALID, "tsgpu_vector_search_batch: id array is NULL");
+    const bool filter_by_provided = p->filter_by_provided || p->n_filter;
+    if (filter_by_provided && p->n_filter != 0 && (uint64_t)p->n_filter < p->flat_search_cutoff) {     // :3664 (an empty filter never gets here: the search returns before)
+        if (!out->keys || !out->scores || !out->n_hits || !out->status) return fail(TSGPU_ERR_INVALID, "tsgpu_vector_search_batch: missing output arrays");
+        try { return vector_search_flat(ctx, vec_field_id, p, Q, mem_q, n_q, out, ids_out); }
+        catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vector_search_batch: host allocation failed"); }
+    }
+    if (out->mem != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vector_search_batch: the k-cut branch delivers host outputs only");
     VecField* f;
     uint32_t num_docs;
     { std::lock_guard<std::mutex> lk(ctx->mu); f = get_field(ctx, vec_field_id); num_docs = ctx->num_docs; }
     if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vector_search_batch: unknown vector field");
-    const uint32_t k = p->k == 0 ? std::max<uint32_t>(p->k, p->fetch_size) : p->k;   // :3646
+    uint32_t k = p->k == 0 ? std::max<uint32_t>(p->k, p->fetch_size) : p->k;   // :3646
     if (k == 0) return fail(TSGPU_ERR_INVALID, "tsgpu_vector_search_batch: k and fetch_size are both 0");
     try {
+        // VectorFilterFunctor (include/index.h:339-353): excluded ids reject, then the filter ids (when there are any) admit
+        auto functor = [&](uint32_t id) {
+            if (p->n_filter == 0 && p->n_excluded == 0) return true;
+            if (p->n_excluded && std::binary_search(p->excluded_ids, p->excluded_ids + p->n_excluded, id)) return false;
+            if (p->n_filter == 0) return true;
+            return std::binary_search(p->filter_ids, p->filter_ids + p->n_filter, id);
+        };
+        if (p->query_doc_given && functor(p->query_seq_id)) k++;                // :3651-3654
+        if (k > TSGPU_MAX_TOPK) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vector_search_batch: k > TSGPU_MAX_TOPK is not accelerated");
         KnnHost kh;
-        int rc = knn_to_host(ctx, vec_field_id, Q, mem_q, n_q, k, nullptr, 0, nullptr, 0, kh);
+        int rc = knn_to_host(ctx, vec_field_id, Q, mem_q, n_q, k, p->n_filter ? p->filter_ids : nullptr, p->n_filter, p->n_excluded ? p->excluded_ids : nullptr, p->n_excluded, kh);
         if (rc) return rc;
         uint32_t tsz = p->topster_size ? p->topster_size : std::max<uint32_t>(p->fetch_size, TSGPU_DEFAULT_TOPSTER_SIZE);
-        if (!p->topster_size) tsz = std::max<uint32_t>(1, std::min<uint32_t>(tsz, std::max<uint32_t>(num_docs, (uint32_t)f->n_rows)));
+        if (!p->topster_size) tsz = std::max<uint32_t>(1, std::min<uint32_t>(tsz, p->n_filter ? p->n_filter : std::max<uint32_t>(num_docs, (uint32_t)f->n_rows)));   // :3506-3512
         if (out->k_stride < std::min<uint32_t>(tsz, k)) return fail(TSGPU_ERR_INVALID, "tsgpu_vector_search_batch: k_stride too small");
+        std::unique_ptr<tsgpu_id_lists> lists;
+        if (ids_out) { lists.reset(new tsgpu_id_lists); lists->begin.assign(1, 0); }
         std::vector<std::pair<uint64_t, float>> hits;
         for (uint32_t q = 0; q < n_q; q++) {
             HostTopster topster(tsz);
@@ -955,6 +1023,7 @@ int tsgpu_vector_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const tsgpu
             std::sort(hits.begin(), hits.end(), [](const auto& a, const auto& b) { return a.first < b.first; });   // :3389
             uint64_t added = 0;
             for (auto& h : hits) {
+                if (p->query_doc_given && h.first == p->query_seq_id) continue;                        // :3686
                 const float d = f->metric == TSGPU_METRIC_COSINE ? std::fabs(h.second) : h.second;   // :3699
                 if (d > p->distance_threshold) continue;                                               // :3702
                 HostKV kv;
@@ -966,15 +1035,27 @@ int tsgpu_vector_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const tsgpu
                 if (msi >= 0) kv.text_match_score = kv.scores[msi];
                 topster.add(&kv);
                 added++;
+                if (lists) lists->ids.push_back((uint32_t)h.first);                                     // nearest_ids (ascending: label order), :3727-3732
             }
             topster.sort();
             write_hits(topster, q, out);
             if (out->num_matched) out->num_matched[q] = added;
             out->status[q] = TSGPU_OK;
             if (out->search_cutoff) out->search_cutoff[q] = 0;
+            if (lists) lists->begin.push_back(lists->ids.size());
         }
+        if (ids_out) *ids_out = lists.release();
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vector_search_batch: host allocation failed"); }
     return ok();
+}
+
+int tsgpu_vector_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const tsgpu_vec_query* p, const float* Q, int mem_q, uint32_t n_q, tsgpu_hits* out) {
+    return vector_search_impl(ctx, vec_field_id, p, Q, mem_q, n_q, out, nullptr);
+}
+int tsgpu_vector_search_batch_ids(tsgpu_ctx* ctx, uint32_t vec_field_id, const tsgpu_vec_query* p, const float* Q, int mem_q, uint32_t n_q, tsgpu_hits* out,
+                                  tsgpu_id_lists** ids_out) {
+    if (!ids_out) return fail(TSGPU_ERR_INVALID, "tsgpu_vector_search_batch_ids: ids_out is NULL");
+    return vector_search_impl(ctx, vec_field_id, p, Q, mem_q, n_q, out, ids_out);
 }
 
 // reciprocal rank fusion of ONE query, exactly src/index.cpp:4094-4211: `kw` = the keyword Topster content in sort()

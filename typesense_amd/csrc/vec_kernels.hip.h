@@ -1104,6 +1104,18 @@ __global__ __launch_bounds__(256) void vec_row_distances_kernel(const float* __r
     if (i < n && sub == 0) out[i] = row == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : d;
 }
 
+// the FLAT branch's distance matrix (process_results_bruteforce, src/index.cpp:3345-3374, for a batch of queries sharing one filter):
+// out[query][i] = exact distance of row rows[i], same 16-lane summation as above; grid (rows / 16, queries). A missing label stays NaN.
+__global__ __launch_bounds__(256) void vec_flat_distances_kernel(const float* __restrict__ X, const float* __restrict__ Q, uint32_t dim, const uint32_t* __restrict__ rows,
+                                                                  uint32_t n, float* __restrict__ out, size_t out_stride, uint32_t ip_lanes) {
+    const uint32_t sub = threadIdx.x & 15;
+    const uint32_t i = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+    const uint32_t ic = i < n ? i : n - 1;
+    const uint32_t row = rows[ic];
+    const float d = ip_distance_group16(Q + (size_t)blockIdx.y * dim, X + (size_t)(row != 0xFFFFFFFFu ? row : 0) * dim, dim, sub, ip_lanes);
+    if (i < n && sub == 0) out[(size_t)blockIdx.y * out_stride + i] = row == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : d;
+}
+
 // the same for (query, row) pairs of a batch: item i = (queries[qidx[i]], rows[i])
 __global__ __launch_bounds__(256) void vec_pair_distances_kernel(const float* __restrict__ X, const float* __restrict__ Q, uint32_t dim, const uint32_t* __restrict__ qidx,
                                                                   const uint32_t* __restrict__ rows, uint32_t n, float* __restrict__ out, uint32_t ip_lanes) {

@@ -422,16 +422,38 @@ class GpuIndex:
         return out
 
     def vector_search_batch(self, field_id, Q, k=0, fetch_size=10, distance_threshold=B.FLT_MAX,
-                            sort=((B.SORT_VECTOR_DISTANCE, -1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=0, k_stride=250):
+                            sort=((B.SORT_VECTOR_DISTANCE, -1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=0, k_stride=250,
+                            filter_ids=None, excluded_ids=None, flat_search_cutoff=0, query_doc=None, want_ids=False):
+        """the vector branch of Index::search (src/index.cpp:3645-3732). filter_ids = what filter_by matched (None = no filter_by); fewer
+        of them than flat_search_cutoff -> the FLAT branch (every filter id through the Topster, num_matched = found). query_doc = X of
+        `vec:([], id: X)` (Q = X's stored vector). want_ids: also return all_result_ids per query -> (hits, [ids])."""
         Q = np.ascontiguousarray(Q, dtype=np.float32).reshape(-1, self.vec_dim[field_id])
         p = B.VecQueryC()
         p.k, p.fetch_size, p.distance_threshold, p.n_sort, p.topster_size = k, fetch_size, distance_threshold, len(sort), topster_size
         for i, s in enumerate(sort):
             p.sort[i].kind, p.sort[i].order, p.sort[i].column = s
+        f = _u32(filter_ids) if filter_ids is not None else None
+        e = _u32(excluded_ids) if excluded_ids is not None else None
+        p.filter_by_provided = 1 if f is not None else 0
+        p.filter_ids, p.n_filter = (f.ctypes.data if f is not None and f.size else None), (f.size if f is not None else 0)
+        p.excluded_ids, p.n_excluded = (e.ctypes.data if e is not None and e.size else None), (e.size if e is not None else 0)
+        p.flat_search_cutoff = int(flat_search_cutoff)
+        p.query_doc_given, p.query_seq_id = (1, int(query_doc)) if query_doc is not None else (0, 0)
         hits = Hits(Q.shape[0], k_stride)
         hs = hits.c_struct()
-        self._ck(self.L.tsgpu_vector_search_batch(self.h, field_id, C.byref(p), _vp(Q), B.MEM_HOST, Q.shape[0], C.byref(hs)))
-        return hits
+        if not want_ids:
+            self._ck(self.L.tsgpu_vector_search_batch(self.h, field_id, C.byref(p), _vp(Q), B.MEM_HOST, Q.shape[0], C.byref(hs)))
+            return hits
+        lists = C.c_void_p()
+        self._ck(self.L.tsgpu_vector_search_batch_ids(self.h, field_id, C.byref(p), _vp(Q), B.MEM_HOST, Q.shape[0], C.byref(hs), C.byref(lists)))
+        try:
+            ids = []
+            for q in range(Q.shape[0]):
+                cnt = self.L.tsgpu_id_lists_count(lists, q)
+                ids.append(np.ctypeslib.as_array(self.L.tsgpu_id_lists_ids(lists, q), shape=(cnt,)).copy() if cnt else np.zeros(0, np.uint32))
+        finally:
+            self.L.tsgpu_id_lists_free(lists)
+        return hits, ids
 
     def keyword_aux_scores(self, queries, item_query, item_seq_id):
         """compute_aux_scores' text half: text_match of given documents for the queries' tokens -> int64[n_items]"""
