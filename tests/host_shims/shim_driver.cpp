@@ -69,6 +69,11 @@ struct mock_hnswlib {
     unsigned enterpoint_node_ = 0;
 };
 
+struct CountingPassAll : tsgpu::BaseFilterFunctor {   // what the reference hands over without filter_by / hidden hits: a functor that rejects nothing
+    size_t calls = 0;
+    std::vector<uint32_t> excluded;                   // ... or only a few hidden ids
+    bool operator()(tsgpu::labeltype id) override { calls++; return !std::binary_search(excluded.begin(), excluded.end(), (uint32_t)id); }
+};
 struct EvenOnly : tsgpu::BaseFilterFunctor {          // a VectorFilterFunctor-style predicate (include/index.h:325-354)
     std::vector<uint32_t> excluded;
     bool operator()(tsgpu::labeltype id) override {
@@ -207,6 +212,24 @@ int main(int argc, char** argv) {
         CHECK(space.get_dist_func()(X.data(), X.data() + dim, &d) == tsgpu::InnerProductDistance(X.data(), X.data() + dim, &d), "dist func");
         EvenOnly functor;
         functor.excluded = {10, 20};
+        {   // the unmodified call site with a functor that rejects nothing: the predicate is asked about O(k) labels, not about every live one
+            CountingPassAll all;
+            const auto plain = vecdex.searchKnnCloserFirst(Q.data(), k, 10, nullptr);
+            const auto got = vecdex.searchKnnCloserFirst(Q.data(), k, 10, &all);
+            CHECK(all.calls <= 4 * (size_t)k, "pass-all functor: %zu predicate calls for k = %u (index of %u labels)", all.calls, k, n);
+            CHECK(got == plain, "pass-all functor changed the result");
+            // a few hidden ids among the nearest: still O(k) calls, the hidden ones are gone, the list is the oracle's order without them
+            CountingPassAll some;
+            some.excluded = {(uint32_t)plain[0].second, (uint32_t)plain[2].second};
+            std::sort(some.excluded.begin(), some.excluded.end());
+            const auto got2 = vecdex.searchKnnCloserFirst(Q.data(), k, 10, &some);
+            const auto wide = vecdex.searchKnnCloserFirst(Q.data(), k + 2, 10, nullptr);
+            std::vector<std::pair<float, tsgpu::labeltype>> want;
+            for (auto& h : wide) if (h.second != plain[0].second && h.second != plain[2].second) want.push_back(h);
+            want.resize(k);
+            CHECK(got2 == want, "two hidden ids: result differs from the unfiltered k + 2 list without them");
+            CHECK(some.calls <= 4 * (size_t)k, "two hidden ids: %zu predicate calls", some.calls);
+        }
         for (uint32_t qi = 0; qi < n_q; qi++) {
             // expectations: (a) unfiltered, (b) the functor (even labels, minus excluded, minus the deleted label 4)
             for (int pass = 0; pass < 2; pass++) {

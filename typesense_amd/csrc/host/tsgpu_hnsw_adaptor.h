@@ -15,9 +15,10 @@
 //     space->get_dist_func()(a, b, &dim)                                     src/index.cpp:3365
 // Differences, all deliberate: this adaptor's search is EXACT (ef, M, ef_construction are accepted and ignored) — the
 // graph-search twin is mirror_hnsw_graph() + tsgpu_vec_hnsw_search_batch() at the end of this file —, cosine normalisation stays where the reference does it (caller side, src/index.cpp:1049-1052, 3381-3384),
-// and the filter functor is evaluated up front into an allow-list (it is a pure predicate over seq_ids): over the candidate ids
-// when the call site passes them (the filter's id array), otherwise over EVERY live label of the index — a functor is never
-// ignored (filter_by, hidden and excluded hits depend on it, include/index.h:325-354).
+// and the filter functor (a pure predicate over seq_ids) is never ignored (filter_by, hidden and excluded hits depend on it,
+// include/index.h:325-354): at the reference's unmodified call site it is applied to the results of an over-fetching exact search
+// (2k labels asked for a functor that rejects little), with candidate ids (the filter's id array) it becomes an allow-list, and only a
+// selective functor WITHOUT candidate ids is swept over every live label (searchKnnCloserFirst below).
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -106,35 +107,67 @@ public:
         return std::vector<data_t>(v.begin(), v.end());
     }
 
-    // closest first; filter == nullptr -> whole index
+    // closest first; filter == nullptr -> whole index.
+    // With a functor and NO candidate ids — the reference's unmodified call, searchKnnCloserFirst(q, k, ef, &filterFunctor)
+    // (src/index.cpp:3384-3386) — the predicate is applied to the RESULTS of an over-fetching exact search instead of to every live label:
+    // the exact k' = 2k nearest are fetched, the functor is asked about those k' labels only, and k' doubles until k of them pass or the
+    // index is exhausted. Exact: a passing label outside the k' nearest is farther than every label inside them, and the k'-nearest lists are
+    // prefixes of each other (ties -> smaller label). Cost for a functor that rejects nothing / little (no filter_by, a few hidden hits):
+    // ONE scan and 2k predicate calls — not live_.size() virtual calls plus a sort per query. A selective functor (fewer than ~k / 1024 of
+    // the labels pass) ends in the sweep below; call sites that know the filter's id array should pass it (candidate_ids): the allow-list
+    // form is one scan whatever the selectivity.
     std::vector<std::pair<dist_t, labeltype>> searchKnnCloserFirst(const void* query, size_t k, size_t /*ef*/ = 0,
                                                                    BaseFilterFunctor* filter = nullptr,
                                                                    const uint32_t* candidate_ids = nullptr, uint32_t n_candidates = 0) {
-        std::vector<uint32_t> allow;
-        const uint32_t* allow_ptr = nullptr;
-        uint32_t n_allow = 0;
-        if (filter) {
-            // the predicate is evaluated once per candidate instead of once per visited graph node: over the ids the call site
-            // hands over (the filter's sorted id array), or — the reference's call, searchKnnCloserFirst(q, k, ef, &functor) —
-            // over every live label. NEVER skipped: a dropped functor would return filtered-out / hidden documents.
-            if (candidate_ids) {
-                for (uint32_t i = 0; i < n_candidates; i++) if ((*filter)(candidate_ids[i])) allow.push_back(candidate_ids[i]);
-            } else {
-                allow.reserve(live_.size());
-                for (uint32_t l : live_) if ((*filter)((labeltype)l)) allow.push_back(l);
-            }
-            std::sort(allow.begin(), allow.end());
-            allow.erase(std::unique(allow.begin(), allow.end()), allow.end());
-            if (allow.empty()) return {};
-            if (allow.size() == live_.size() && !candidate_ids) allow.clear();      // the functor rejects nothing: no allow-list needed
-            else { allow_ptr = allow.data(); n_allow = (uint32_t)allow.size(); }
-        }
-        std::vector<float> dist(k);
-        std::vector<uint64_t> lab(k);
-        uint32_t n = 0;
-        check(tsgpu_vec_knn_batch(ctx_, field_, (const float*)query, TSGPU_MEM_HOST, 1, (uint32_t)k, allow_ptr, n_allow, nullptr, 0,
-                                  dist.data(), lab.data(), &n, TSGPU_MEM_HOST), "tsgpu_vec_knn_batch");
         std::vector<std::pair<dist_t, labeltype>> out;
+        if (k == 0) return out;
+        std::vector<float> dist;
+        std::vector<uint64_t> lab;
+        auto knn = [&](size_t kk, const uint32_t* allow_ptr, uint32_t n_allow) -> uint32_t {
+            dist.resize(kk); lab.resize(kk);
+            uint32_t n = 0;
+            check(tsgpu_vec_knn_batch(ctx_, field_, (const float*)query, TSGPU_MEM_HOST, 1, (uint32_t)kk, allow_ptr, n_allow, nullptr, 0,
+                                      dist.data(), lab.data(), &n, TSGPU_MEM_HOST), "tsgpu_vec_knn_batch");
+            return n;
+        };
+        if (!filter) {
+            const uint32_t n = knn(k, nullptr, 0);
+            for (uint32_t i = 0; i < n; i++) out.emplace_back((dist_t)dist[i], (labeltype)lab[i]);
+            return out;
+        }
+        if (!candidate_ids && k <= TSGPU_MAX_TOPK) {
+            std::vector<uint64_t> asked_lab;                    // labels already asked about, in list order (the lists are prefixes of each other) ...
+            std::vector<uint8_t> verdict;                       // ... and what the functor said
+            for (size_t kk = std::min<size_t>(std::max<size_t>(2 * k, 16), TSGPU_MAX_TOPK);;) {
+                const uint32_t n = knn(kk, nullptr, 0);
+                size_t passed = 0;
+                out.clear();
+                for (uint32_t i = 0; i < n && passed < k; i++) {
+                    if (i < asked_lab.size() && asked_lab[i] != lab[i]) { asked_lab.resize(i); verdict.resize(i); }      // (never expected: the prefix property)
+                    if (i >= asked_lab.size()) { asked_lab.push_back(lab[i]); verdict.push_back((*filter)((labeltype)lab[i]) ? 1 : 0); }
+                    if (verdict[i]) { out.emplace_back((dist_t)dist[i], (labeltype)lab[i]); passed++; }
+                }
+                if (passed >= k || n < kk) return out;          // k neighbours pass, or the whole index has been seen
+                // what it would take at the pass rate seen so far; beyond the largest supported k the predicate has to be swept
+                const size_t need = passed ? (k * (size_t)n + passed - 1) / passed * 3 / 2 : kk * 4;
+                if (kk >= TSGPU_MAX_TOPK || need > TSGPU_MAX_TOPK) break;
+                kk = std::min<size_t>(std::max<size_t>(need, kk * 2), TSGPU_MAX_TOPK);
+            }
+            out.clear();
+        }
+        std::vector<uint32_t> allow;
+        // the predicate evaluated into an allow-list: over the ids the call site hands over (the filter's sorted id array), or over every
+        // live label (selective functors without a candidate list). NEVER skipped: a dropped functor would return filtered-out / hidden documents.
+        if (candidate_ids) {
+            for (uint32_t i = 0; i < n_candidates; i++) if ((*filter)(candidate_ids[i])) allow.push_back(candidate_ids[i]);
+        } else {
+            allow.reserve(live_.size());
+            for (uint32_t l : live_) if ((*filter)((labeltype)l)) allow.push_back(l);
+        }
+        std::sort(allow.begin(), allow.end());
+        allow.erase(std::unique(allow.begin(), allow.end()), allow.end());
+        if (allow.empty()) return {};
+        const uint32_t n = knn(k, allow.data(), (uint32_t)allow.size());
         for (uint32_t i = 0; i < n; i++) out.emplace_back((dist_t)dist[i], (labeltype)lab[i]);
         return out;
     }
