@@ -6,7 +6,7 @@
 #   * the GPU test tier, the smoke test and the full bench line                        -> pytest_gpu_<tag>.txt, smoke_<tag>.txt, bench_all_<tag>.json
 # bench.py reads pmc_kw_fetch.txt / pmc_kw_sq1.txt / pmc_vec_fetch.txt of the round for roofline.traffic / issue_util.
 set -u
-R=${1:-r03}; TAG=${2:-final}
+R=${1:-r04}; TAG=${2:-final}
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$ROOT/gpurun_out/prof_$TAG; P=$ROOT/gpurun_out/profiles_$R
@@ -14,8 +14,10 @@ mkdir -p $O $P
 cd /tmp
 KW="python $ROOT/bench.py --workload keyword --no-cpu-baseline --no-extras --steps 3 --warmup 1"
 VEC="python $ROOT/bench.py --workload vector --no-cpu-baseline --no-extras --steps 3 --warmup 1"
+KWG="python $ROOT/bench.py --workload kwgeneral --no-cpu-baseline --steps 3 --warmup 1"     # two query_by fields + 10 candidate combinations per query (general kernels)
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_kw -- $KW > $O/trace_kw.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_vec -- $VEC > $O/trace_vec.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_kwg -- $KWG > $O/trace_kwg.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_kw_fetch -- $KW > $O/pmc_kw_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_vec_fetch -- $VEC > $O/pmc_vec_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES -d $O/pmc_kw_sq1 -- $KW > $O/pmc_kw_sq1.log 2>&1
@@ -23,6 +25,7 @@ timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INS
 cd $ROOT
 python profiles/summarize_rocprof.py $O/trace_kw > $P/rocprof_keyword_${TAG}_stats.txt 2>&1
 python profiles/summarize_rocprof.py $O/trace_vec > $P/rocprof_vector_${TAG}_stats.txt 2>&1
+python profiles/summarize_rocprof.py $O/trace_kwg > $P/rocprof_kwgeneral_${TAG}_stats.txt 2>&1
 python tools/pmc_summary.py $O/pmc_kw_fetch "kw_" > $P/pmc_kw_fetch.txt 2>&1
 python tools/pmc_summary.py $O/pmc_vec_fetch "vec_" > $P/pmc_vec_fetch.txt 2>&1
 python tools/pmc_summary.py $O/pmc_kw_sq1 "kw_" > $P/pmc_kw_sq1.txt 2>&1

@@ -247,6 +247,10 @@ class GpuIndex:
                                                               _vp(qi), _vp(found) if want_found else None))
         return hits, qi, found
 
+    def keyword_search_candidates_batch_raw(self, arr, begin, n_groups, hs, qi, found):
+        """prebuilt ctypes query array (all combinations, pass order), begin[n_groups + 1], tsgpu_hits struct, query_index / found arrays (bench loop)"""
+        self._ck(self.L.tsgpu_keyword_search_candidates_batch(self.h, C.cast(arr, C.c_void_p), _vp(begin), n_groups, C.byref(hs), _vp(qi), _vp(found) if found is not None else None))
+
     def candidates_result_ids(self, group):
         n = self.L.tsgpu_candidates_result_ids(self.h, group, None, 0)
         out = np.zeros(max(n, 1), np.uint32)
