@@ -860,3 +860,60 @@ def test_host_output_batch_served_in_slices_equals_the_single_batch(pair):
     finally:
         g.set_option("kw_host_split_queries", 1000)
         g.set_option("kw_host_split_first_pct", 75)
+
+
+@pytest.mark.parametrize("chunk_opt,host_threads", [(0, 1), (4, 3)])
+def test_device_side_planner_equals_the_host_planner_and_the_oracle(pair, chunk_opt, host_threads):
+    """kw_plan.hip.h: a batch of plain single-field queries is planned by three kernels (term table -> handles, chunk rule + cost key,
+    rank layout + work items + hit offsets) instead of plan_batch(): same Topsters, counts and statuses as the host plan and the oracle —
+    1..7 tokens (both kernel tables), absent tokens, duplicates, every sort-key form, small Topsters; device AND host outputs, the sliced
+    host delivery; a batch with one query of another shape (filter ids) is handed back to the host planner whole."""
+    orc, g, _ = pair
+    rng = np.random.default_rng(77)
+    sorts = [((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0)), ((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, -1, 0)), ((B.SORT_SEQ_ID, 1, 0),)]
+    qs = []
+    for rep in range(90):
+        n_tok = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 7]))
+        toks = list(rng.choice(np.arange(1, 60), size=n_tok, replace=False))
+        if rep % 11 == 0: toks[0] = 100000 + rep            # a token the index does not hold (skipped; alone: no hits)
+        if rep % 13 == 0 and n_tok >= 2: toks[1] = toks[0]  # a duplicated token
+        if rep % 17 == 0: toks = [3000000 + rep]            # no token of the query exists (ids from 4M up live in the host map only: those batches go back to the host planner)
+        qs.append(T.KwQuery(toks, sort=sorts[rep % 3], topster_size=[250, 40, 7][rep % 3], match_type=rep % 3, prioritize_token_position=bool(rep & 1), total_cost=rep % 4))
+    try:
+        g.set_option("kw_device_plan_min_queries", 0)
+        host = g.keyword_search_batch(qs, k_stride=250)
+        g.set_option("kw_device_plan_min_queries", 8)
+        g.set_option("kw_chunk_blocks", chunk_opt)
+        g.set_option("plan_threads", host_threads)
+        g.set_option("plan_parallel_min_queries", 16 if host_threads > 1 else 2048)
+        n0, f0 = g.counter("kw_device_plans"), g.counter("kw_device_plan_fallbacks")
+        dev = g.keyword_search_batch(qs, k_stride=250)
+        assert g.counter("kw_device_plans") == n0 + 1 and g.counter("kw_device_plan_fallbacks") == f0, "the batch was not planned on the device"
+        assert np.array_equal(dev.status, host.status) and (dev.status == 0).all()
+        for i, q in enumerate(qs):
+            n = int(host.n_hits[i])
+            assert dev.n_hits[i] == n and dev.num_matched[i] == host.num_matched[i], i
+            assert np.array_equal(dev.keys[i, :n], host.keys[i, :n]) and np.array_equal(dev.scores[i, :n], host.scores[i, :n]), i
+            assert np.array_equal(dev.text_match[i, :n], host.text_match[i, :n]) and np.array_equal(dev.match_score_index[i, :n], host.match_score_index[i, :n]), i
+            H.assert_hits_equal(dev, i, H.oracle_keyword(orc, q), "device plan")
+        assert dev.n_hits.sum() > 1000
+        # the sliced host delivery (three chained slices, each planned on the device)
+        g.set_option("kw_host_split_queries", 8)
+        sl = g.keyword_search_batch(qs, k_stride=250)
+        assert g.counter("kw_device_plans") >= n0 + 3
+        for i in range(len(qs)):
+            n = int(host.n_hits[i])
+            assert sl.n_hits[i] == n and np.array_equal(sl.keys[i, :n], host.keys[i, :n]) and np.array_equal(sl.scores[i, :n], host.scores[i, :n]) and sl.num_matched[i] == host.num_matched[i]
+        # one query of another shape: the whole batch goes back to the host planner — same results
+        g.set_option("kw_host_split_queries", 0)
+        mixed = qs[:20] + [T.KwQuery([1, 2], sort=sorts[0], topster_size=250, filter_ids=np.arange(0, 3000, 3, dtype=np.uint32))]
+        f1 = g.counter("kw_device_plan_fallbacks")
+        mx = g.keyword_search_batch(mixed, k_stride=250)
+        assert g.counter("kw_device_plan_fallbacks") == f1 + 1
+        for i in range(20):
+            n = int(host.n_hits[i])
+            assert mx.n_hits[i] == n and np.array_equal(mx.keys[i, :n], host.keys[i, :n])
+        H.assert_hits_equal(mx, 20, H.oracle_keyword(orc, mixed[20]), "fallback batch")
+    finally:
+        for name, v in (("kw_device_plan_min_queries", 512), ("kw_chunk_blocks", 0), ("plan_threads", 8), ("plan_parallel_min_queries", 2048), ("kw_host_split_queries", 2500)):
+            g.set_option(name, v)

@@ -210,6 +210,7 @@ test_dropped_tokens_are_scored_when_present_and_never_required = EK.test_dropped
 test_pair_find_kernel_matches_the_oracle = EK.test_pair_find_kernel_matches_the_oracle
 test_synonym_passes_score_like_score_results2 = EK.test_synonym_passes_score_like_score_results2
 test_parallel_planning_of_a_batch_gives_the_serial_plan = EK.test_parallel_planning_of_a_batch_gives_the_serial_plan
+test_device_side_planner_equals_the_host_planner_and_the_oracle = EK.test_device_side_planner_equals_the_host_planner_and_the_oracle
 
 
 def test_device_shard_merge_on_cuda_tensors(c100k):
@@ -359,3 +360,28 @@ def test_deadline_in_flight_partial_hits_on_2m_docs(c2m):
                 assert int(hits.num_matched[i]) <= int(full.num_matched[i])
                 checked += 1
     assert in_flight > 0 and checked > 0, "no budget cut a query in flight: (budget us, cut, cut in flight) = %s" % seen
+
+
+def test_device_side_planner_on_2m_docs_many_work_items(c2m):
+    """the device planner at size: 3 000 three-term queries over 2M docs (several work items per query, both launch tables, heaviest-first
+    layout, hit offsets of a multi-GB hit buffer) = the host planner's results; a sample against the oracle"""
+    rng = np.random.default_rng(5)
+    qtok = synth.keyword_queries(3000, 3, 5, 1500, seed=12)
+    qs = [T.KwQuery(qtok[i], sort=SORT, topster_size=250) for i in range(3000)]
+    qs += [T.KwQuery(rng.choice(np.arange(5, 400), size=5, replace=False), sort=SORT, topster_size=250) for _ in range(40)]
+    g = c2m.g
+    try:
+        g.set_option("kw_device_plan_min_queries", 0)
+        host = g.keyword_search_batch(qs, k_stride=250)
+        g.set_option("kw_device_plan_min_queries", 512)
+        n0 = g.counter("kw_device_plans")
+        dev = g.keyword_search_batch(qs, k_stride=250)
+        assert g.counter("kw_device_plans") > n0
+    finally:
+        g.set_option("kw_device_plan_min_queries", 512)
+    assert np.array_equal(dev.status, host.status) and np.array_equal(dev.n_hits, host.n_hits) and np.array_equal(dev.num_matched, host.num_matched)
+    for i in range(len(qs)):
+        n = int(host.n_hits[i])
+        assert np.array_equal(dev.keys[i, :n], host.keys[i, :n]) and np.array_equal(dev.scores[i, :n], host.scores[i, :n]), i
+    for i in list(range(0, 3000, 250)) + [3001, 3020]:
+        H.assert_hits_equal(dev, i, c2m.oracle(qs[i]), "device plan at 2M docs")

@@ -9,6 +9,7 @@
 #endif
 #include <cmath>
 #include "kw_kernels.hip.h"
+#include "kw_plan.hip.h"
 
 using namespace tsgpu;
 
@@ -239,6 +240,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_cost_fixed")) { ctx->kw_cost_fixed = (uint32_t)std::max<int64_t>(value, 0); return ok(); }
     if (!strcmp(name, "kw_sort_work")) { ctx->kw_sort_work = value != 0; return ok(); }
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
+    if (!strcmp(name, "kw_device_plan_min_queries")) { ctx->kw_device_plan_min_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 30); return ok(); }
     if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
     if (!strcmp(name, "kw_host_split_first_pct")) { ctx->kw_host_split_first_pct = (uint32_t)std::min<int64_t>(95, std::max<int64_t>(5, value)); return ok(); }
     if (!strcmp(name, "kw_host_split_queries")) { ctx->kw_host_split_queries = (uint32_t)std::max<int64_t>(0, value); return ok(); }
@@ -339,6 +341,8 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!strcmp(name, "kw_launch_us")) { *out = ctx->kw_launch_us.load(); return ok(); }
     if (!strcmp(name, "kw_wait_us")) { *out = ctx->kw_wait_us.load(); return ok(); }
     if (!strcmp(name, "kw_book_us")) { *out = ctx->kw_book_us.load(); return ok(); }
+    if (!strcmp(name, "kw_device_plans")) { *out = ctx->kw_device_plans.load(); return ok(); }                     // batches planned on the device / sent back to the host planner
+    if (!strcmp(name, "kw_device_plan_fallbacks")) { *out = ctx->kw_device_plan_fallbacks.load(); return ok(); }
     if (!strcmp(name, "batch_exec_us")) { *out = ctx->batch_exec_us.load(); return ok(); }           // coalesced rounds: batch execution / hand-out to the callers
     if (!strcmp(name, "batch_scatter_us")) { *out = ctx->batch_scatter_us.load(); return ok(); }
     if (!strcmp(name, "batch_rounds")) { *out = ctx->kw_comb.rounds + ctx->vec_comb.rounds; return ok(); }               // coalesced rounds executed so far
@@ -766,6 +770,108 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
     return TSGPU_OK;
 }
 
+// ---- the same plan made ON THE DEVICE (kw_plan.hip.h) for batches of plain single-field queries ----
+namespace {
+struct DevPlan {
+    bool on = false;
+    const KwQueryDev* dq = nullptr; const KwWorkItem* dw = nullptr; const uint32_t* daux = nullptr; const uint64_t* hoff = nullptr;
+    uint32_t n_work[2] = {0, 0};
+    uint64_t hit_blocks[2] = {0, 0};
+};
+}
+// returns TSGPU_OK (DP.on tells whether the device made the plan; false = this batch needs the host planner) or an error
+static int plan_batch_device(tsgpu_ctx* ctx, KwLane& L, const Snapshot& snap, const tsgpu_kw_query* queries, uint32_t n_queries, Plan& P, DevPlan& DP, hipStream_t s) {
+    DP.on = false;
+    if (!snap.maps || !snap.maps->d_dense.p || !snap.lists.p) return TSGPU_OK;
+    // host pre-scan: eligibility + the 76-byte record per query, straight into the pinned staging buffer
+    int rc;
+    if ((rc = L.h_plan.reserve((size_t)n_queries * sizeof(KwPlanIn) + 64))) return rc;
+    KwPlanIn* hin = (KwPlanIn*)L.h_plan.p;
+    const uint32_t n_columns = (uint32_t)ctx->columns.size();
+    std::atomic<int> bad{0};
+    auto scan = [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo; i < hi; i++) {
+            const tsgpu_kw_query& in = queries[i];
+            bool ok = in.n_fields == 1 && in.n_tokens >= 1 && in.n_tokens <= TSGPU_MAX_QUERY_TOKENS && in.n_dropped == 0 && in.n_filter == 0 && in.n_excluded == 0 &&
+                      in.deadline_us == 0 && in.n_sort <= TSGPU_MAX_SORT_KEYS && in.match_type <= TSGPU_SUM_SCORE && in.field_ids[0] < 64;
+            if (ok) { auto it = snap.field_is_array.find(in.field_ids[0]); ok = it != snap.field_is_array.end() && !it->second; }
+            for (uint32_t k = 0; ok && k < in.n_sort; k++)
+                ok = in.sort[k].kind <= TSGPU_SORT_INT64_COLUMN && (in.sort[k].kind != TSGPU_SORT_INT64_COLUMN || in.sort[k].column < n_columns) && (in.sort[k].order == 1 || in.sort[k].order == -1);
+            const uint32_t k = ok ? resolve_topster_size(ctx, in) : 0;
+            if (!ok || k > TSGPU_MAX_TOPK) { bad.store(1); return; }
+            KwPlanIn& r = hin[i];
+            for (uint32_t t = 0; t < (uint32_t)TSGPU_MAX_QUERY_TOKENS; t++) r.term_ids[t] = t < in.n_tokens ? in.term_ids[t] : 0;
+            r.field = in.field_ids[0]; r.weight = in.field_weights[0]; r.k = k; r.total_cost = in.total_cost;
+            r.n_tokens = (uint8_t)in.n_tokens; r.match_type = in.match_type;
+            r.prio_bits = (uint8_t)((in.prioritize_exact_match ? 1 : 0) | (in.prioritize_token_position ? 2 : 0) | (in.prioritize_num_matching_fields ? 4 : 0));
+            r.n_sort = (uint8_t)in.n_sort;
+            for (uint32_t k2 = 0; k2 < 3; k2++) { r.sort_kind[k2] = k2 < in.n_sort ? in.sort[k2].kind : 0; r.sort_order[k2] = k2 < in.n_sort ? in.sort[k2].order : 0; r.sort_col[k2] = k2 < in.n_sort ? in.sort[k2].column : 0; }
+            r.syn_orig_num_tokens = (int8_t)((int)in.syn_orig_num_tokens_p1 - 1); r.orig_num_tokens = in.orig_num_tokens;
+            r.is_synonym = in.is_synonym_query ? 1 : 0; r.demote_synonym = in.demote_synonym_match ? 1 : 0;
+        }
+    };
+    {
+        const uint32_t min_par = ctx->plan_parallel_min_queries;
+        const uint32_t n_thr = (min_par && n_queries >= min_par) ? std::min<uint32_t>((uint32_t)std::max(1, ctx->plan_threads), std::max<uint32_t>(1, n_queries / 512)) : 1;
+        if (n_thr <= 1) scan(0, n_queries);
+        else {
+            const uint32_t n_parts = 4 * n_thr;
+            std::atomic<uint32_t> next{0};
+            const std::function<void()> job = [&]() { for (;;) { const uint32_t k = next.fetch_add(1); if (k >= n_parts || bad.load()) break; scan((uint32_t)((uint64_t)n_queries * k / n_parts), (uint32_t)((uint64_t)n_queries * (k + 1) / n_parts)); } };
+            ctx->host_pool.run(job, (int)n_thr - 1);
+        }
+    }
+    if (bad.load()) return TSGPU_OK;
+    // device buffers: [KwQueryDev x n | one aux word | totals | six scratch arrays] in d_plan, the input records in d_plan_in
+    size_t bytes = 0;
+    auto place = [&](size_t b) { const size_t at = (bytes + 63) & ~(size_t)63; bytes = at + b; return at; };
+    const size_t at_q = place((size_t)n_queries * sizeof(KwQueryDev)), at_aux = place(64), at_tot = place(sizeof(KwPlanTotals)), at_nb = place((size_t)n_queries * 4),
+                 at_la = place((size_t)n_queries * 4), at_lb = place((size_t)n_queries * 4), at_cnt = place((size_t)n_queries * 4), at_ch = place((size_t)n_queries * 4),
+                 at_key = place((size_t)n_queries * 8);
+    if ((rc = L.d_plan.reserve(bytes + 64)) || (rc = L.d_plan_in.reserve((size_t)n_queries * sizeof(KwPlanIn))) || (rc = L.h_plan_tot.reserve(2 * sizeof(KwPlanTotals)))) return rc;
+    uint8_t* const dp = (uint8_t*)L.d_plan.p;
+    KwPlanTotals* const d_tot = (KwPlanTotals*)(dp + at_tot);
+    KwPlanTotals* const h_tot = (KwPlanTotals*)L.h_plan_tot.p;
+    TSGPU_HIP_TRY(hipMemcpyAsync(L.d_plan_in.p, hin, (size_t)n_queries * sizeof(KwPlanIn), hipMemcpyHostToDevice, s));
+    TSGPU_HIP_TRY(hipMemsetAsync(dp + at_aux, 0, 64 + sizeof(KwPlanTotals) + 64, s));
+    KwPlanParams pp;
+    pp.n_queries = n_queries; pp.num_docs = ctx->num_docs; pp.n_columns = n_columns;
+    pp.chunk_blocks_opt = ctx->kw_chunk_blocks; pp.max_partials = std::max<uint32_t>(ctx->kw_max_partials, 1); pp.merge_select_min = ctx->kw_merge_select_min; pp.max_chunk = (uint32_t)KW_MAX_CHUNK;
+    pp.cost_fixed = (float)ctx->kw_cost_fixed; pp.cost_r = 0.1f * ctx->kw_cost_r_x10; pp.cost_probe = 0.01f * ctx->kw_cost_probe_x100;
+    pp.dense = snap.maps->d_dense.as<uint32_t>(); pp.lists = snap.lists.as<ListDesc>();
+    KwPlanScratch sc;
+    sc.n_blocks = (uint32_t*)(dp + at_nb); sc.len_a = (uint32_t*)(dp + at_la); sc.len_b = (uint32_t*)(dp + at_lb); sc.cnt = (uint32_t*)(dp + at_cnt); sc.chunk = (uint32_t*)(dp + at_ch);
+    sc.key = (unsigned long long*)(dp + at_key);
+    KwQueryDev* const dq = (KwQueryDev*)(dp + at_q);
+    const dim3 grid((n_queries + 255) / 256), block(256);
+    hipLaunchKernelGGL(kw_plan_resolve_kernel, grid, block, 0, s, pp, (const KwPlanIn*)L.d_plan_in.p, dq, sc, d_tot);
+    hipLaunchKernelGGL(kw_plan_chunk_kernel, grid, block, 0, s, pp, (const KwQueryDev*)dq, sc, d_tot);
+    TSGPU_HIP_TRY(hipGetLastError());
+    TSGPU_HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(KwPlanTotals), hipMemcpyDeviceToHost, s));
+    TSGPU_HIP_TRY(hipStreamSynchronize(s));
+    const KwPlanTotals t1 = *h_tot;
+    if (t1.fallback) return TSGPU_OK;
+    // the hit buffer must take each table in ONE group (else the host planner's grouping / the fused kernel decide)
+    for (int tb = 0; tb < 2; tb++) {
+        const size_t rec_bytes = (size_t)((tb == 0 ? 3 : KW_MAX_TOKENS) + 1) * 4;
+        const uint64_t budget = ctx->kw_hit_buffer_records ? ctx->kw_hit_buffer_records : ((uint64_t)ctx->kw_hit_buffer_mb << 20) / rec_bytes;
+        if (t1.hit_blocks[tb] * (uint64_t)BLOCK_IDS > budget) return TSGPU_OK;
+    }
+    const size_t n_work = (size_t)t1.n_work[0] + t1.n_work[1];
+    if ((rc = L.d_plan_work.reserve(std::max<size_t>(n_work, 1) * (sizeof(KwWorkItem) + 8) + 64))) return rc;
+    KwWorkItem* const dw = (KwWorkItem*)L.d_plan_work.p;
+    unsigned long long* const hoff = (unsigned long long*)((uint8_t*)L.d_plan_work.p + ((std::max<size_t>(n_work, 1) * sizeof(KwWorkItem) + 63) & ~(size_t)63));
+    hipLaunchKernelGGL(kw_plan_layout_kernel, grid, block, 0, s, pp, dq, sc, (const KwPlanTotals*)d_tot, dw, hoff);
+    TSGPU_HIP_TRY(hipGetLastError());
+    P.status.assign(n_queries, TSGPU_OK);
+    P.cutoff.assign(n_queries, 0);
+    P.max_k = std::max<uint32_t>(t1.max_k, 1); P.any_s2 = t1.any_s2 != 0; P.list_bytes = t1.list_bytes; P.n_numeric_sort_q = t1.n_numeric_sort_q;
+    DP.on = true;
+    DP.dq = dq; DP.dw = dw; DP.daux = (const uint32_t*)(dp + at_aux); DP.hoff = (const uint64_t*)hoff;
+    DP.n_work[0] = t1.n_work[0]; DP.n_work[1] = t1.n_work[1]; DP.hit_blocks[0] = t1.hit_blocks[0]; DP.hit_blocks[1] = t1.hit_blocks[1];
+    return TSGPU_OK;
+}
+
 // ---- lanes ----
 namespace {
 struct LaneLock {                                     // holds one execution lane for the duration of a batch (FIFO: LaneDispenser)
@@ -1038,11 +1144,19 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         static const bool host_timing = getenv("TSGPU_HOST_TIMING") != nullptr;      // diagnostics: host phases of the call on stderr
         const uint64_t t_enter = now_us();
         Plan P;
-        int rc = plan_batch(ctx, snap, queries, n_queries, P, keep_ids, wildcard, bo.vflat);
-        if (rc) return rc;
+        DevPlan DP;
+        int rc;
+        // big batches of plain single-field queries: the plan is made on the device (three small kernels, one read-back) instead of ~0.5 ms of
+        // host threads; any other shape — and anything the device planner hands back — goes through plan_batch()
+        if (!wildcard && !keep_ids && !bo.vflat && ctx->kw_two_kernels && ctx->kw_device_plan_min_queries && n_queries >= ctx->kw_device_plan_min_queries) {
+            if ((rc = plan_batch_device(ctx, L, snap, queries, n_queries, P, DP, s))) return rc;
+            if (DP.on) ctx->kw_device_plans.fetch_add(1); else ctx->kw_device_plan_fallbacks.fetch_add(1);
+        }
+        if (!DP.on && (rc = plan_batch(ctx, snap, queries, n_queries, P, keep_ids, wildcard, bo.vflat))) return rc;
         const uint64_t t_planned = now_us();
         if (out->k_stride < P.max_k) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: k_stride smaller than the largest topster_size");
-        const uint32_t n_work = (uint32_t)(P.work_small.size() + P.work_big.size() + P.work_mf_small.size() + P.work_mf_big.size() + P.work_wild.size());
+        const uint32_t n_work = DP.on ? DP.n_work[0] + DP.n_work[1]
+                                      : (uint32_t)(P.work_small.size() + P.work_big.size() + P.work_mf_small.size() + P.work_mf_big.size() + P.work_wild.size());
         const uint32_t KS = out->k_stride;
         const int cap = P.max_k + KW_THREADS <= 512 ? 512 : (P.max_k + KW_THREADS <= 1024 ? 1024 : 2048);
 
@@ -1090,6 +1204,20 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         };
         TablePlan tps[4] = {prep_table(P.work_small, 3, false), prep_table(P.work_big, KW_MAX_TOKENS, false), prep_table(P.work_mf_small, 3, true),
                             prep_table(P.work_mf_big, KW_MAX_TOKENS, true)};
+        size_t tab_n[5] = {P.work_small.size(), P.work_big.size(), P.work_mf_small.size(), P.work_mf_big.size(), P.work_wild.size()};
+        if (DP.on) {                                    // the device planner's two tables: one group each (it checked the budget), offsets already on the device
+            for (int tb = 0; tb < 2; tb++) {
+                TablePlan& tp = tps[tb];
+                tab_n[tb] = DP.n_work[tb];
+                if (!DP.n_work[tb]) continue;
+                tp.two = true;
+                tp.rec_bytes = (size_t)((tb == 0 ? 3 : KW_MAX_TOKENS) + 1) * 4;
+                tp.need = DP.hit_blocks[tb] * (uint64_t)BLOCK_IDS;
+                tp.group_start = {0, (size_t)DP.n_work[tb]};
+                hit_records += tp.need;
+                if ((rc = L.d_hits.reserve(std::max<uint64_t>(tp.need, 1) * tp.rec_bytes))) return rc;
+            }
+        }
         // multi-field queries with filter + excluded ids: counted from the hit records of ONE find launch of their table; a table that was
         // cut into groups or runs fused cannot serve them -> 501 for those queries (their hits are not reported)
         std::vector<uint32_t> oc_jobs[2];
@@ -1106,8 +1234,8 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         for (auto& tp : tps) tp.hoff_at = place(tp.hoff.size() * 8);
         const size_t at_grp = place(P.groups.size() * sizeof(KwMergeGroup));
         const size_t at_oc[2] = {place(oc_jobs[0].size() * 4), place(oc_jobs[1].size() * 4)};
-        if ((rc = L.h_plan.reserve(plan_bytes + 64)) || (rc = L.d_plan.reserve(plan_bytes + 64))) return rc;
-        {
+        if (!DP.on && ((rc = L.h_plan.reserve(plan_bytes + 64)) || (rc = L.d_plan.reserve(plan_bytes + 64)))) return rc;
+        if (!DP.on) {
             uint8_t* hp = (uint8_t*)L.h_plan.p;
             memcpy(hp + at_q, P.q.data(), P.q.size() * sizeof(KwQueryDev));
             memcpy(hp + at_w, work.data(), work.size() * sizeof(KwWorkItem));
@@ -1196,9 +1324,9 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             hipLaunchKernelGGL(kw_stamp_kernel, dim3(1), dim3(1), 0, s, L.d_t0.as<long long>());       // the queries' budgets count from here
         }
         v.cutoff = L.d_cut.as<uint32_t>();
-        const KwQueryDev* dq = (const KwQueryDev*)(dplan + at_q);
-        const KwWorkItem* dw = (const KwWorkItem*)(dplan + at_w);
-        const uint32_t* daux = (const uint32_t*)(dplan + at_aux);
+        const KwQueryDev* dq = DP.on ? DP.dq : (const KwQueryDev*)(dplan + at_q);
+        const KwWorkItem* dw = DP.on ? DP.dw : (const KwWorkItem*)(dplan + at_w);
+        const uint32_t* daux = DP.on ? DP.daux : (const uint32_t*)(dplan + at_aux);
         const bool timing = bo.timing && n_queries >= ctx->kw_timing_min_queries;      // (each record is a marker packet in the stream: ~2 us of a small round)
         if (timing) TSGPU_HIP_TRY(hipEventRecord(L.ev[0], s));
         auto shifted = [&](size_t sh) {                 // every kernel indexes the partials by its own blockIdx: shift the bases
@@ -1210,14 +1338,13 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         };
         uint32_t hit_groups = 0;
         bool find_marked = false;
-        auto run_table = [&](const std::vector<KwWorkItem>& tab, const TablePlan& tp, size_t first, auto tmax_tag, auto mf_tag) {
+        auto run_table = [&](size_t nws, const TablePlan& tp, size_t first, auto tmax_tag, auto mf_tag) {
             constexpr int TM = decltype(tmax_tag)::value;
             constexpr bool MFT = decltype(mf_tag)::value;
-            if (tab.empty()) return;
-            const size_t nws = tab.size();
+            if (nws == 0) return;
             if (tp.two) {
                 hit_groups += (uint32_t)tp.group_start.size() - 1;
-                const uint64_t* hoff_dev = (const uint64_t*)(dplan + tp.hoff_at);
+                const uint64_t* hoff_dev = DP.on ? DP.hoff + first : (const uint64_t*)(dplan + tp.hoff_at);
                 for (size_t gi = 0; gi + 1 < tp.group_start.size(); gi++) {
                     const size_t a = tp.group_start[gi], b = tp.group_start[gi + 1];
                     if (b <= a) continue;
@@ -1239,14 +1366,14 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             } else if constexpr (MFT) launch_search_mf_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out);
             else launch_search_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out, P.any_s2);
         };
-        run_table(P.work_small, tps[0], 0, std::integral_constant<int, 3>(), std::false_type());
-        size_t sh = P.work_small.size();
-        run_table(P.work_big, tps[1], sh, std::integral_constant<int, KW_MAX_TOKENS>(), std::false_type());
-        sh += P.work_big.size();
-        run_table(P.work_mf_small, tps[2], sh, std::integral_constant<int, 3>(), std::true_type());
-        sh += P.work_mf_small.size();
-        run_table(P.work_mf_big, tps[3], sh, std::integral_constant<int, KW_MAX_TOKENS>(), std::true_type());
-        sh += P.work_mf_big.size();
+        run_table(tab_n[0], tps[0], 0, std::integral_constant<int, 3>(), std::false_type());
+        size_t sh = tab_n[0];
+        run_table(tab_n[1], tps[1], sh, std::integral_constant<int, KW_MAX_TOKENS>(), std::false_type());
+        sh += tab_n[1];
+        run_table(tab_n[2], tps[2], sh, std::integral_constant<int, 3>(), std::true_type());
+        sh += tab_n[2];
+        run_table(tab_n[3], tps[3], sh, std::integral_constant<int, KW_MAX_TOKENS>(), std::true_type());
+        sh += tab_n[3];
         if (!P.work_wild.empty()) {
             const uint32_t nw = (uint32_t)P.work_wild.size();
             if (cap == 512) hipLaunchKernelGGL((kw_wildcard_kernel<512>), dim3(nw), dim3(KW_THREADS), 0, s, v, dq, dw + sh, shifted(sh), daux, ids_out);
@@ -1345,7 +1472,8 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         if (!dev_out && out->num_matched) {
             for (uint32_t i = 0; i < n_queries; i++) {
                 uint32_t n_num = 0;
-                for (uint32_t k = 0; k < P.q[i].n_sort; k++) if (P.q[i].sort_kind[k] == TSGPU_SORT_INT64_COLUMN) n_num++;
+                if (DP.on) { for (uint32_t k = 0; k < queries[i].n_sort; k++) if (queries[i].sort[k].kind == TSGPU_SORT_INT64_COLUMN) n_num++; }
+                else for (uint32_t k = 0; k < P.q[i].n_sort; k++) if (P.q[i].sort_kind[k] == TSGPU_SORT_INT64_COLUMN) n_num++;
                 bytes += 4ull * off_words[i] + 8ull * out->num_matched[i] * n_num;
             }
         } else {

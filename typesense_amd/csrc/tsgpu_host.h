@@ -170,6 +170,24 @@ struct ArenaSet {
 // (field << 32 | term) -> list handle; shared by the snapshots between which no term appeared or disappeared
 struct HandleMaps {
     std::unordered_map<uint64_t, uint32_t> handle_of;
+    // device mirror of the flat tables for the device-side planner (kw_plan.hip.h): 64 x {offset, n} words, then the fields' tables back to
+    // back; built by upload_dense() on the commit thread right after rebuild_dense(). Absent (p == nullptr) -> the host planner is used.
+    DevBuf d_dense;
+    std::shared_ptr<RetireBin> bin;
+    HandleMaps() = default;
+    HandleMaps(const HandleMaps& o) : handle_of(o.handle_of), dense_handle(o.dense_handle), bin(o.bin) {}     // (the copy gets its own mirror at its upload_dense())
+    HandleMaps& operator=(const HandleMaps&) = delete;
+    ~HandleMaps() { if (bin) bin->put(d_dense); else d_dense.release(); }
+    void upload_dense() {
+        if (dense_handle.size() > 64) return;
+        std::vector<uint32_t> img(128, 0u);
+        for (size_t f = 0; f < dense_handle.size(); f++) {
+            img[2 * f] = (uint32_t)(img.size() - 128); img[2 * f + 1] = (uint32_t)dense_handle[f].size();
+            img.insert(img.end(), dense_handle[f].begin(), dense_handle[f].end());
+        }
+        if (d_dense.reserve(img.size() * 4) != TSGPU_OK) { (void)hipGetLastError(); d_dense.p = nullptr; d_dense.cap = 0; return; }
+        if (hipMemcpy(d_dense.p, img.data(), img.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); if (bin) bin->put(d_dense); else d_dense.release(); }
+    }
     // the same map as flat tables for small field / term ids (the planner resolves three tokens per query, 10 000 queries per
     // batch: an indexed load instead of a hash probe); 0xFFFFFFFF = absent; ids beyond the tables go through handle_of
     std::vector<std::vector<uint32_t>> dense_handle;                // [field][term]
@@ -229,6 +247,8 @@ struct KwLane {
     uint64_t wait_ema_us = 100;                      // how long this lane's recent rounds waited for the GPU (sleeping_wait)
     hipEvent_t ev_block = nullptr;                   // hipEventBlockingSync: the waiting thread sleeps instead of spinning (many concurrent callers)
     DevBuf d_plan, d_ids_out;                        // the batch plan (queries, work items, aux ids, multi-field descriptors, hit offsets): one upload
+    DevBuf d_plan_in, d_plan_work;                   // device-side planner (kw_plan.hip.h): per-query input records; work items + hit offsets it writes
+    PinBuf h_plan_tot;                               // ... and its totals, read back twice per batch
     DevBuf d_part_s0, d_part_s1, d_part_s2, d_part_key, d_part_cnt, d_part_nm, d_part_ne, d_part_ow, d_part_f;
     DevBuf d_out_keys, d_out_scores, d_out_tm, d_out_vd, d_out_msi, d_out_nh, d_out_nm, d_out_ow, d_out_cut;
     // candidate-combination batches (tsgpu_keyword_search_candidates_batch): per-pass hits, group table, id-set bitmaps
@@ -256,12 +276,12 @@ struct KwLane {
     std::vector<std::vector<uint32_t>> last_chunk_off;   // where each work item's id segment starts (relative to last_ids_off)
     std::vector<uint8_t> last_ids_unsorted;
     void release() {
-        DevBuf* bufs[] = {&d_plan, &d_ids_out, &d_part_s0, &d_part_s1, &d_part_s2, &d_part_key, &d_part_cnt, &d_part_nm, &d_part_ne,
+        DevBuf* bufs[] = {&d_plan, &d_plan_in, &d_plan_work, &d_ids_out, &d_part_s0, &d_part_s1, &d_part_s2, &d_part_key, &d_part_cnt, &d_part_nm, &d_part_ne,
                           &d_part_ow, &d_part_f, &d_out_keys, &d_out_scores, &d_out_tm, &d_out_vd, &d_out_msi, &d_out_nh, &d_out_nm, &d_out_ow, &d_out_cut,
                           &d_cand_keys, &d_cand_scores, &d_cand_tm, &d_cand_vd, &d_cand_msi, &d_cand_nh, &d_cand_nm, &d_cand_st, &d_cand_gb, &d_cand_qi,
                           &d_cand_found, &d_cand_segs, &d_cand_bits, &d_cand_ids, &d_hits, &d_idseg, &d_idflat, &d_fbits, &d_t0, &d_cut};
         for (auto* b : bufs) b->release();
-        h_out.release(); h_plan.release();
+        h_out.release(); h_plan.release(); h_plan_tot.release();
         for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (ev_block) { (void)hipEventDestroy(ev_block); ev_block = nullptr; }
         if (ev_chain) { (void)hipEventDestroy(ev_chain); ev_chain = nullptr; }
@@ -427,6 +447,8 @@ struct tsgpu_ctx {
     uint32_t kw_merge_select_min = 2;                // queries with at least this many partial lists are merged by selection (kw_select_partials: tree merge); 0 = always fold
     bool kw_pair_blocks = true;                      // find kernel variant: two driver blocks per iteration (kw_find2.hip.h)
     bool kw_two_kernels = true;                      // queries of <= 3 tokens: find kernel + score kernel instead of the fused kernel
+    uint32_t kw_device_plan_min_queries = 512;       // batches of plain single-field queries from this size on are planned ON THE DEVICE (kw_plan.hip.h); 0 = always on the host
+    std::atomic<uint64_t> kw_device_plans{0}, kw_device_plan_fallbacks{0};
     uint32_t kw_hit_buffer_mb = 20480;               // budget of the hit-record buffer between the two (work items run in groups that fit)
     uint32_t kw_last_hit_groups = 0;
     uint64_t kw_hit_buffer_records = 0, kw_last_hit_records = 0;

@@ -425,6 +425,8 @@ int commit_full(tsgpu_ctx* ctx) {
     ar->used_blocks = ar->live_blocks = n_slots; ar->used_idw = ar->live_idw = n_idw; ar->used_pw = ar->live_pw = n_pw;
     ctx->erased_dev_idw = ctx->erased_dev_pw = 0;
     maps->rebuild_dense();
+    maps->bin = ctx->retire_bin;
+    maps->upload_dense();
     s.ar = ar; s.maps = maps;
     s.bytes = ar->bytes() + s.lists.cap;
     if (!ctx->num_docs_set) ctx->num_docs = std::max(ctx->num_docs, order.empty() ? 0u : max_id + 1);
@@ -595,7 +597,7 @@ int commit_incremental(tsgpu_ctx* ctx, const std::shared_ptr<const Snapshot>& cu
         for (const BlockMeta& m : t.pl.blk_meta) { t.dev_idw += ids_words(m); t.dev_pw += pay_words(m); }
     }
     for (auto& pc : placed) { TermHost& t = *pc.t; t.d_blk_base = pc.base; t.d_blk_cap = pc.cap; t.d_blk_n = (uint32_t)t.pl.blk_last.size(); t.dirty = false; t.queued = false; t.desc_rewrite = false; }
-    if (new_maps) { new_maps->rebuild_dense(); s.maps = new_maps; } else s.maps = cur->maps;
+    if (new_maps) { new_maps->rebuild_dense(); new_maps->bin = ctx->retire_bin; new_maps->upload_dense(); s.maps = new_maps; } else s.maps = cur->maps;
     s.ar = ar;
     s.field_is_array = cur->field_is_array;
     s.bytes = ar->bytes() + s.lists.cap;
