@@ -897,10 +897,10 @@ def test_device_side_planner_equals_the_host_planner_and_the_oracle(pair, chunk_
             assert np.array_equal(dev.text_match[i, :n], host.text_match[i, :n]) and np.array_equal(dev.match_score_index[i, :n], host.match_score_index[i, :n]), i
             H.assert_hits_equal(dev, i, H.oracle_keyword(orc, q), "device plan")
         assert dev.n_hits.sum() > 1000
-        # the sliced host delivery (three chained slices, each planned on the device)
+        # the sliced host delivery (three chained slices: planned on the host while the previous slice runs)
         g.set_option("kw_host_split_queries", 8)
         sl = g.keyword_search_batch(qs, k_stride=250)
-        assert g.counter("kw_device_plans") >= n0 + 3
+        assert g.counter("kw_device_plans") == n0 + 1
         for i in range(len(qs)):
             n = int(host.n_hits[i])
             assert sl.n_hits[i] == n and np.array_equal(sl.keys[i, :n], host.keys[i, :n]) and np.array_equal(sl.scores[i, :n], host.scores[i, :n]) and sl.num_matched[i] == host.num_matched[i]

@@ -12,9 +12,10 @@
 //   kw_plan_resolve_kernel : one thread per query — term ids -> list handles (device mirror of HandleMaps::dense_handle), list lengths,
 //                            probe order, the KwQueryDev record; batch totals by atomics (driver blocks for the chunk rule, bytes, max k)
 //   kw_plan_chunk_kernel   : one thread per query — chunk length, work-item count, cost key; table totals
-//   kw_plan_layout_kernel  : one thread per query — its place in the heaviest-first order of its table as a RANK computed against every other
-//                            query's key (LDS tiles; 10 000 x 10 000 compares are ~10 us on 256 CUs — no sort, no scan), prefix sums of the
-//                            work-item counts and hit-buffer blocks in that order, then the work items + hit offsets themselves
+//   kw_plan_rank_kernel    : a query's place in the heaviest-first order of its table as a RANK computed against every other query's key (LDS
+//                            tiles, the other queries cut into slices over blockIdx.y — no sort, no scan): prefix sums of the work-item counts
+//                            and hit-buffer blocks in that order, accumulated with atomics
+//   kw_plan_emit_kernel    : one thread per query — first_work / n_work, its work items and their hit offsets
 #pragma once
 
 namespace tsgpu {
@@ -63,8 +64,9 @@ struct KwPlanParams {
 
 __global__ __launch_bounds__(256) void kw_plan_resolve_kernel(KwPlanParams pp, const KwPlanIn* __restrict__ in, KwQueryDev* __restrict__ qout, KwPlanScratch sc,
                                                                KwPlanTotals* __restrict__ tot) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pp.n_queries) return;
+    const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i0 < pp.n_queries;                    // (idle lanes of the last wave re-plan the last query and contribute nothing: the wave reductions below need every lane)
+    const uint32_t i = live ? i0 : pp.n_queries - 1;
     const KwPlanIn r = in[i];
     KwQueryDev q;
     {
@@ -111,15 +113,17 @@ __global__ __launch_bounds__(256) void kw_plan_resolve_kernel(KwPlanParams pp, c
         ord[p] = (uint8_t)t;
     }
     for (uint32_t t = 0; t < nl; t++) q.probe_order[t] = ord[t];
-    qout[i] = q;
     uint32_t best = 0;
     if (nl) { best = nblk_of[0]; for (uint32_t t = 1; t < nl; t++) best = nblk_of[t] < best ? nblk_of[t] : best; }
-    sc.n_blocks[i] = nl ? nblk_of[ord[0]] : 0;
-    sc.len_a[i] = nl ? len_of[ord[0]] : 0;
-    sc.len_b[i] = nl >= 2 ? len_of[ord[1]] : 0;
+    if (live) {
+        qout[i] = q;
+        sc.n_blocks[i] = nl ? nblk_of[ord[0]] : 0;
+        sc.len_a[i] = nl ? len_of[ord[0]] : 0;
+        sc.len_b[i] = nl >= 2 ? len_of[ord[1]] : 0;
+    }
     // batch totals: one atomic per wavefront and counter
-    unsigned long long vb = best, vy = bytes, vn = n_num ? 1 : 0;
-    uint32_t vk = r.k, vs = r.n_sort > 2 ? 1u : 0u, vf = fallback ? 1u : 0u;
+    unsigned long long vb = live ? best : 0, vy = live ? bytes : 0, vn = (live && n_num) ? 1 : 0;
+    uint32_t vk = live ? r.k : 0, vs = (live && r.n_sort > 2) ? 1u : 0u, vf = (live && fallback) ? 1u : 0u;
     for (int d = 32; d > 0; d >>= 1) {
         vb += __shfl_down(vb, d, 64); vy += __shfl_down(vy, d, 64); vn += __shfl_down(vn, d, 64);
         const uint32_t ok = __shfl_down(vk, d, 64); vk = ok > vk ? ok : vk;
@@ -180,25 +184,30 @@ __global__ __launch_bounds__(256) void kw_plan_chunk_kernel(KwPlanParams pp, con
     }
 }
 
-// work: the two tables back to back (table 1 starts at n_work[0]); hoff[w] = first hit record of work item w inside ITS table's hit buffer
-__global__ __launch_bounds__(256) void kw_plan_layout_kernel(KwPlanParams pp, KwQueryDev* __restrict__ q, KwPlanScratch sc, const KwPlanTotals* __restrict__ tot,
-                                                              KwWorkItem* __restrict__ work, unsigned long long* __restrict__ hoff) {
+// Place of every query in the heaviest-first order of its table, as a RANK: query i sums the work items (and, inside its table, the driver
+// blocks) of every query whose key sorts ahead of its own. 10 000 x 10 000 compares: grid = (queries / 256) x KW_PLAN_JPARTS — each block
+// takes 256 queries against ONE slice of the other queries (LDS tiles, broadcast reads) and adds its partial sums with two atomics per query;
+// a single wave walking all 10 000 alone would be a 0.3 ms dependent loop.
+static const int KW_PLAN_JPARTS = 32;
+__global__ __launch_bounds__(256) void kw_plan_rank_kernel(KwPlanParams pp, KwPlanScratch sc, uint32_t* __restrict__ fw_acc, unsigned long long* __restrict__ hb_acc) {
     __shared__ unsigned long long s_key[256];
     __shared__ uint32_t s_cnt[256], s_nb[256];
     const uint32_t t = threadIdx.x, i = blockIdx.x * blockDim.x + t;
     const bool live = i < pp.n_queries;
     const unsigned long long my_key = live ? sc.key[i] : ~0ull;
     const uint32_t my_tab = (uint32_t)(my_key >> 32);
+    const uint32_t per = ((pp.n_queries + KW_PLAN_JPARTS - 1) / KW_PLAN_JPARTS + 255) & ~255u;
+    const uint32_t j_begin = blockIdx.y * per, j_end = j_begin + per < pp.n_queries ? j_begin + per : pp.n_queries;
     uint32_t fw = 0;                       // work items of the queries ahead of this one (both tables: first_work indexes their concatenation)
     unsigned long long hb = 0;             // driver blocks of the queries ahead of it IN ITS TABLE
-    for (uint32_t j0 = 0; j0 < pp.n_queries; j0 += 256) {
+    for (uint32_t j0 = j_begin; j0 < j_end; j0 += 256) {
         const uint32_t j = j0 + t;
         __syncthreads();
-        s_key[t] = j < pp.n_queries ? sc.key[j] : ~0ull;
-        s_cnt[t] = j < pp.n_queries ? sc.cnt[j] : 0u;
-        s_nb[t] = j < pp.n_queries ? sc.n_blocks[j] : 0u;
+        s_key[t] = j < j_end ? sc.key[j] : ~0ull;
+        s_cnt[t] = j < j_end ? sc.cnt[j] : 0u;
+        s_nb[t] = j < j_end ? sc.n_blocks[j] : 0u;
         __syncthreads();
-        const uint32_t n = pp.n_queries - j0 < 256u ? pp.n_queries - j0 : 256u;
+        const uint32_t n = j_end - j0 < 256u ? j_end - j0 : 256u;
         for (uint32_t e = 0; e < n; e++) {
             const unsigned long long kj = s_key[e];
             const bool ahead = kj < my_key || (kj == my_key && j0 + e < i);        // ties in query order (stable)
@@ -208,12 +217,19 @@ __global__ __launch_bounds__(256) void kw_plan_layout_kernel(KwPlanParams pp, Kw
         }
     }
     if (!live) return;
-    const uint32_t cnt = sc.cnt[i];
+    if (fw) atomicAdd(&fw_acc[i], fw);
+    if (hb) atomicAdd(&hb_acc[i], hb);
+}
+
+// work: the two tables back to back (table 1 starts at n_work[0]); hoff[w] = first hit record of work item w inside ITS table's hit buffer
+__global__ __launch_bounds__(256) void kw_plan_emit_kernel(KwPlanParams pp, KwQueryDev* __restrict__ q, KwPlanScratch sc, const uint32_t* __restrict__ fw_acc,
+                                                            const unsigned long long* __restrict__ hb_acc, KwWorkItem* __restrict__ work, unsigned long long* __restrict__ hoff) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pp.n_queries) return;
+    const uint32_t cnt = sc.cnt[i], fw = fw_acc[i];
+    const unsigned long long hb = hb_acc[i];
     q[i].first_work = fw; q[i].n_work = cnt; q[i].m_first = fw; q[i].m_n = cnt;
-    if (!cnt) return;
     const uint32_t nb = sc.n_blocks[i], chunk = sc.chunk[i];
-    const uint32_t tab_first = my_tab ? tot->n_work[0] : 0u;
-    (void)tab_first;
     for (uint32_t c = 0, b = 0; c < cnt; c++, b += chunk) {
         KwWorkItem w;
         w.query = i; w.blk_begin = b; w.blk_end = b + chunk < nb ? b + chunk : nb; w.ids_out_off = b * BLOCK_IDS;

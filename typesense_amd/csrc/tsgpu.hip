@@ -827,7 +827,7 @@ static int plan_batch_device(tsgpu_ctx* ctx, KwLane& L, const Snapshot& snap, co
     auto place = [&](size_t b) { const size_t at = (bytes + 63) & ~(size_t)63; bytes = at + b; return at; };
     const size_t at_q = place((size_t)n_queries * sizeof(KwQueryDev)), at_aux = place(64), at_tot = place(sizeof(KwPlanTotals)), at_nb = place((size_t)n_queries * 4),
                  at_la = place((size_t)n_queries * 4), at_lb = place((size_t)n_queries * 4), at_cnt = place((size_t)n_queries * 4), at_ch = place((size_t)n_queries * 4),
-                 at_key = place((size_t)n_queries * 8);
+                 at_key = place((size_t)n_queries * 8), at_fw = place((size_t)n_queries * 4), at_hb = place((size_t)n_queries * 8);
     if ((rc = L.d_plan.reserve(bytes + 64)) || (rc = L.d_plan_in.reserve((size_t)n_queries * sizeof(KwPlanIn))) || (rc = L.h_plan_tot.reserve(2 * sizeof(KwPlanTotals)))) return rc;
     uint8_t* const dp = (uint8_t*)L.d_plan.p;
     KwPlanTotals* const d_tot = (KwPlanTotals*)(dp + at_tot);
@@ -861,7 +861,9 @@ static int plan_batch_device(tsgpu_ctx* ctx, KwLane& L, const Snapshot& snap, co
     if ((rc = L.d_plan_work.reserve(std::max<size_t>(n_work, 1) * (sizeof(KwWorkItem) + 8) + 64))) return rc;
     KwWorkItem* const dw = (KwWorkItem*)L.d_plan_work.p;
     unsigned long long* const hoff = (unsigned long long*)((uint8_t*)L.d_plan_work.p + ((std::max<size_t>(n_work, 1) * sizeof(KwWorkItem) + 63) & ~(size_t)63));
-    hipLaunchKernelGGL(kw_plan_layout_kernel, grid, block, 0, s, pp, dq, sc, (const KwPlanTotals*)d_tot, dw, hoff);
+    TSGPU_HIP_TRY(hipMemsetAsync(dp + at_fw, 0, (at_hb - at_fw) + (size_t)n_queries * 8, s));
+    hipLaunchKernelGGL(kw_plan_rank_kernel, dim3(grid.x, KW_PLAN_JPARTS), block, 0, s, pp, sc, (uint32_t*)(dp + at_fw), (unsigned long long*)(dp + at_hb));
+    hipLaunchKernelGGL(kw_plan_emit_kernel, grid, block, 0, s, pp, dq, sc, (const uint32_t*)(dp + at_fw), (const unsigned long long*)(dp + at_hb), dw, hoff);
     TSGPU_HIP_TRY(hipGetLastError());
     P.status.assign(n_queries, TSGPU_OK);
     P.cutoff.assign(n_queries, 0);
@@ -1148,7 +1150,9 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         int rc;
         // big batches of plain single-field queries: the plan is made on the device (three small kernels, one read-back) instead of ~0.5 ms of
         // host threads; any other shape — and anything the device planner hands back — goes through plan_batch()
-        if (!wildcard && !keep_ids && !bo.vflat && ctx->kw_two_kernels && ctx->kw_device_plan_min_queries && n_queries >= ctx->kw_device_plan_min_queries) {
+        // (not for the chained slices of a sliced host delivery: there the host plans slice i + 1 WHILE slice i runs, and a planning kernel on the
+        //  second lane would wait behind the running find kernel for a place on the chip — measured: 10.05 -> 10.18 ms per 10 000 queries)
+        if (!wildcard && !keep_ids && !bo.vflat && !bo.chain && ctx->kw_two_kernels && ctx->kw_device_plan_min_queries && n_queries >= ctx->kw_device_plan_min_queries) {
             if ((rc = plan_batch_device(ctx, L, snap, queries, n_queries, P, DP, s))) return rc;
             if (DP.on) ctx->kw_device_plans.fetch_add(1); else ctx->kw_device_plan_fallbacks.fetch_add(1);
         }
