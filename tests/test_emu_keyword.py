@@ -917,3 +917,44 @@ def test_device_side_planner_equals_the_host_planner_and_the_oracle(pair, chunk_
     finally:
         for name, v in (("kw_device_plan_min_queries", 512), ("kw_chunk_blocks", 0), ("plan_threads", 8), ("plan_parallel_min_queries", 2048), ("kw_host_split_queries", 2500)):
             g.set_option(name, v)
+
+
+@pytest.mark.parametrize("chunk,two_kernels", [(64, 1), (1, 1), (64, 0)])
+def test_multi_field_block_merge_windows_wide_runs_and_exhaustion(chunk, two_kernels):
+    """kw_mf_merge_field (the multi-field find kernel's block-level merge of a driver block with the SECOND token's lists): extreme length
+    ratios in two fields — runs of 1, ~10, ~40 and > 64 blocks under one driver block (window re-centring, runs wider than the window / the
+    tile -> per-candidate probes), driver ids beyond a list's end (cursor exhaustion), a second token that only one field holds — in the
+    two-kernel form and the fused form (smaller tile): hits, scores, counts and ids = the oracle's or_iterator_t union"""
+    from oracle import oracle_py as O
+    n_docs, l0 = _synthetic_lists(5)
+    _, l1 = _synthetic_lists(9)
+    pts = H.points_of(n_docs)
+    orc = O.OracleIndex(2, 1)
+    orc.set_num_docs(n_docs)
+    orc.set_sort_dense(0, pts)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    for f, lists in ((0, l0), (1, l1)):
+        g.field_create(f, False)
+        for term, (ids, oi, off) in lists.items():
+            if f == 1 and term == 3:
+                continue                                         # token 3 lives in field 0 only
+            orc.load_posting(f, term, ids, oi, off)
+            g.term_upsert(f, term, ids, oi, off)
+    g.column_set(0, pts)
+    g.set_num_docs(n_docs)
+    g.commit()
+    g.set_option("kw_chunk_blocks", chunk)
+    g.set_option("kw_two_kernels", two_kernels)
+    g.keep_result_ids(True)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    f2 = [(0, 15), (1, 9)]
+    qs = [T.KwQuery([1, 2], fields=f2, sort=sort, topster_size=250), T.KwQuery([2, 1, 3], fields=f2, sort=sort, topster_size=250),
+          T.KwQuery([3, 2], fields=f2, sort=sort, topster_size=100), T.KwQuery([3, 1], fields=[(1, 4), (0, 4)], sort=sort, topster_size=250, match_type=B.SUM_SCORE),
+          T.KwQuery([1], fields=f2, sort=sort, topster_size=250), T.KwQuery([2, 3], fields=f2, sort=sort, topster_size=250, filter_ids=np.arange(0, n_docs, 3, dtype=np.uint32))]
+    hits = g.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all() and hits.n_hits[0] >= 250
+    for i, q in enumerate(qs):
+        ref = H.oracle_keyword(orc, q, ids_cap=200000)
+        H.assert_hits_equal(hits, i, ref, "mf merge chunk=%d two=%d q=%s" % (chunk, two_kernels, q.tokens))
+        assert np.array_equal(g.result_ids(i), ref.result_ids)
+    g.close()

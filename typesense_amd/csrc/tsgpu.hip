@@ -602,6 +602,8 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
                 for (uint32_t t = 1; t < q.n_required; t++) if (len_of[t] < len_of[td]) td = t;
                 mfq.n_fields = in.n_fields;
                 mfq.driver_token = td;
+                mfq.second_token = KW_NONE;             // the required token with the next fewest postings: merged block-wise by the find kernel
+                for (uint32_t t = 0; t < q.n_required; t++) if (t != td && (mfq.second_token == KW_NONE || len_of[t] < len_of[mfq.second_token])) mfq.second_token = t;
                 for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.is_array[f] = f < in.n_fields && snap.field_is_array.at(in.field_ids[f]) ? 1 : 0;
                 for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.weight[f] = f < in.n_fields ? in.field_weights[f] : 0;
                 if (k + KW_THREADS > 1024) { unsupported("topster_size with several query_by fields"); continue; }
