@@ -29,40 +29,7 @@ static const int KW_F2_SPAN = TSGPU_F2_SPAN;                 // runs of up to th
 static const bool KW_F2_QUAD = TSGPU_F2_QUAD != 0;           // 4-ary slot search (three samples per round) instead of binary
 static const bool KW_F2_FAST = TSGPU_F2_FAST != 0;           // interleaved slot searches when a wavefront's blocks are all full 16-bit blocks
 
-// LDS-DMA tile fill: N slabs of 256 words, lane t of the workgroup copies word (slab * 256 + t) of the run straight from global memory
-// into the LDS tile (global_load_lds_dword: destination = M0 base + lane * 4 + instruction offset, the same offset advances the source) —
-// no staging registers, no ds_write. Words past the run's end are read, too: the ids arena ends with KW_TILE_OVERREAD_WORDS of padding
-// (tsgpu_index.hip) and nothing searches them. Issued through inline asm: the one wait the pipeline needs is kw_glds_wait() before the
-// barrier at the top of the next iteration (cf. vec_glds16 in vec_kernels.hip.h).
-template <int N>
-__device__ inline void kw_glds_slabs(const uint32_t* lane_src, uint32_t* lds_wave_base) {
-    static_assert(N == 2 || N == 8, "two tiers");
-#ifdef TSGPU_HIP_EMU
-    for (int k = 0; k < N; k++) hipemu_global_load_lds4(lane_src + k * 256, lds_wave_base + k * 256);
-#else
-    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
-    uint32_t keep;
-    if constexpr (N == 2) {
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\tglobal_load_lds_dword %1, off offset:1024\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(lane_src), "s"(dst) : "memory");
-    } else {
-        const uint32_t* lane_src2 = lane_src + 1024;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                     "global_load_lds_dword %1, off\n\tglobal_load_lds_dword %1, off offset:1024\n\t"
-                     "global_load_lds_dword %1, off offset:2048\n\tglobal_load_lds_dword %1, off offset:3072\n\t"
-                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
-                     "global_load_lds_dword %2, off\n\tglobal_load_lds_dword %2, off offset:1024\n\t"
-                     "global_load_lds_dword %2, off offset:2048\n\tglobal_load_lds_dword %2, off offset:3072\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(lane_src), "v"(lane_src2), "s"(dst) : "memory", "scc");
-    }
-#endif
-}
-__device__ inline void kw_glds_wait() {
-#ifndef TSGPU_HIP_EMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
+// (kw_glds_slabs / kw_glds_wait — the LDS-DMA tile fill — live in kw_kernels.hip.h: the multi-field find kernel uses them, too)
 
 template <int TMAX>
 __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,

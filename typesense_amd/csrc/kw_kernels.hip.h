@@ -864,6 +864,8 @@ struct KwSmem {
     static const int QF = DEFER ? 1 : KW_QCAP;
     // stage-1 survivors: id, driver position, first-probe position
     uint32_t q1_id[Q1], q1_p0[Q1], q1_p1[Q1];
+    // several query_by fields: the queued survivor's positions in the SECOND token's lists of fields 1.. (field 0: q1_p1)
+    uint32_t q1_px[(MF && !SCORE) ? KW_MAX_FIELDS - 1 : 1][(MF && !SCORE) ? Q1 : 1];
     // complete hits: id + posting position per token (query order; multi-field: per token and field, KW_NONE = absent)
     uint32_t qf_id[QF];
     uint32_t qf_pos[NP][QF];
@@ -1520,6 +1522,41 @@ __global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(Ind
     kw_write_partial(sm, q, part);
 }
 
+// LDS-DMA tile fill: N slabs of 256 words, lane t of the workgroup copies word (slab * 256 + t) of the run straight from global memory
+// into the LDS tile (global_load_lds_dword: destination = M0 base + lane * 4 + instruction offset, the same offset advances the source) —
+// no staging registers, no ds_write. Words past the run's end are read, too: the ids arena ends with KW_TILE_OVERREAD_WORDS of padding
+// (tsgpu_index.hip) and nothing searches them. Issued through inline asm: the one wait the pipeline needs is kw_glds_wait() before the
+// barrier at the top of the next iteration (cf. vec_glds16 in vec_kernels.hip.h).
+template <int N>
+__device__ inline void kw_glds_slabs(const uint32_t* lane_src, uint32_t* lds_wave_base) {
+    static_assert(N == 2 || N == 8, "two tiers");
+#ifdef TSGPU_HIP_EMU
+    for (int k = 0; k < N; k++) hipemu_global_load_lds4(lane_src + k * 256, lds_wave_base + k * 256);
+#else
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    uint32_t keep;
+    if constexpr (N == 2) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\tglobal_load_lds_dword %1, off offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_src), "s"(dst) : "memory");
+    } else {
+        const uint32_t* lane_src2 = lane_src + 1024;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %1, off\n\tglobal_load_lds_dword %1, off offset:1024\n\t"
+                     "global_load_lds_dword %1, off offset:2048\n\tglobal_load_lds_dword %1, off offset:3072\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %2, off\n\tglobal_load_lds_dword %2, off offset:1024\n\t"
+                     "global_load_lds_dword %2, off offset:2048\n\tglobal_load_lds_dword %2, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_src), "v"(lane_src2), "s"(dst) : "memory", "scc");
+    }
+#endif
+}
+__device__ inline void kw_glds_wait() {
+#ifndef TSGPU_HIP_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // The multi-field find kernel's form of stage 1 (kw_find2.hip.h has the pipelined single-field one): the ids of ONE driver block against ONE
 // other list L as a block-level merge. The run of L's blocks under the driver block's id range [lo_id, hi_id] is found with a 64-block register
 // window behind a cursor that only moves forward (one coalesced load of BlockIds + two ballots; every wave computes the same), the ids of that
@@ -1541,10 +1578,8 @@ __device__ inline void kw_mf_merge_field(SM& sm, const IndexView& ix, const List
     BlockIds win = wbase + lane < d.n_blocks ? bi[wbase + lane] : PAD;
     unsigned long long mk = __ballot(win.last_id >= lo_id ? 1 : 0);
     if (mk == 0) {                                                                           // all 64 blocks end before lo_id: uniform search, re-centre
-        const uint32_t* __restrict__ bl = ix.blk_last + d.blk_base;
-        uint32_t lo = wbase + 64 < d.n_blocks ? wbase + 64 : d.n_blocks, hi = d.n_blocks;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (bl[mid] >= lo_id) hi = mid; else lo = mid + 1; }
-        wbase = lo;
+        const uint32_t* __restrict__ bl = ix.blk_last + d.blk_base;                           // (lo_id <= d.last_id: some block ends at or behind it)
+        wbase = guided_lower_bound(d.n_blocks, lo_id, d.first_id, d.last_id, [&](uint32_t i) { return bl[i]; });      // interpolation-guided: ~2 long + 4 short loads
         if (wbase >= d.n_blocks) return;
         win = wbase + lane < d.n_blocks ? bi[wbase + lane] : PAD;
         mk = __ballot(win.last_id >= lo_id ? 1 : 0);
@@ -1570,8 +1605,19 @@ __device__ inline void kw_mf_merge_field(SM& sm, const IndexView& ix, const List
     // the run's ids -> LDS (one coalesced range), its block table -> LDS
     const uint32_t* __restrict__ src = ix.ids_payload + d.ids_base + w_begin;
     __syncthreads();                                                                         // (the previous field's searches have left the tile)
-    for (uint32_t i = t; i < W; i += KW_THREADS) sm.btile[i] = src[i];
+    // LDS-DMA, every slab of the run in flight at once (a load -> ds_write loop keeps ONE load per thread in flight: 16 round trips for a 16 KB
+    // run); slabs past the run's end read the arena's padding (KW_TILE_OVERREAD_WORDS) and are never searched
+    {
+        const uint32_t* lane_src = src + t;
+        uint32_t* lds_wave_base = sm.btile + (t >> 6) * 64;
+        if (W <= 2u * KW_THREADS) kw_glds_slabs<2>(lane_src, lds_wave_base);
+        else {
+            kw_glds_slabs<8>(lane_src, lds_wave_base);
+            if constexpr (TILE > 8u * KW_THREADS) { if (W > 8u * KW_THREADS) kw_glds_slabs<8>(lane_src + 8 * KW_THREADS, lds_wave_base + 8 * KW_THREADS); }
+        }
+    }
     if (t < 64) { sm.bw_last[0][t] = win.last_id; sm.bw_first[0][t] = win.first_id; sm.bw_woff[0][t] = win.ids_woff - w_begin; sm.bw_nb[0][t] = win.n_ids_bits; }
+    kw_glds_wait();
     __syncthreads();
     if (!want) return;
     // (a) which block of the run: branch-free lower bound over the run's last ids
@@ -1646,15 +1692,18 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
     uint32_t* my_ids_out = ids_out ? ids_out + q.ids_out_off + wi.ids_out_off : nullptr;
     constexpr int NP = TMAX * KW_MAX_FIELDS;
     uint32_t* __restrict__ hits = DEFER ? hits_all + hit_off[blockIdx.x] * (uint64_t)(NP + 1) : nullptr;
-    uint32_t qfn = 0, par = 0;
+    uint32_t qfn = 0, par = 0, q1n = 0;
     uint32_t cur[KW_MAX_FIELDS];                               // the second token's lists: first block that can still hold an id >= the driver block's first
 #pragma unroll
     for (int f = 0; f < KW_MAX_FIELDS; f++) cur[f] = 0;
-    for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
-        if (((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, qi, &sm.stop)) break;
-        const BlockIds mA = biA[b];
-        const uint32_t m_n = mA.n_ids_bits & 0xFFFF;
-        bool ok = t < m_n;
+    const uint32_t ts = mf.second_token;
+
+    // Stage 2 on the first n_take queued stage-1 survivors, with FULL wavefronts (per driver block only a handful of the 256 candidates survive:
+    // probing the remaining lists right there left ~10 lanes waiting on six dependent global loads per probe): the other tokens in every field,
+    // then the driver token's other fields (an id an EARLIER field's list of the driver token holds is left to that field's work items: every
+    // document of the union is produced once). Complete hits leave in queue order (= ascending id).
+    auto stage2 = [&](uint32_t n_take) {
+        bool ok = t < n_take;
         uint32_t id = 0xFFFFFFFFu;
         uint32_t pos[NP];
 #pragma unroll
@@ -1664,30 +1713,13 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
             for (int k = 0; k < NP; k++) if ((uint32_t)k == idx) pos[k] = v;
         };
         if (ok) {
-            const uint32_t* __restrict__ w = idwA + mA.ids_woff;
-            id = mA.first_id + ((mA.n_ids_bits >> 16) == 16 ? (uint32_t)((const uint16_t*)w)[t] : w[t]);
-            set_pos(td * KW_MAX_FIELDS + fdrv, b * BLOCK_IDS + t);
-        }
-        // (1) the SECOND token (fewest postings after the driver's), every field, every candidate of the block: block-level merge through the LDS tile
-        const uint32_t ts = mf.second_token;
-        if (ts != KW_NONE) {
-            bool any = false;
+            id = sm.q1_id[t];
+            set_pos(td * KW_MAX_FIELDS + fdrv, sm.q1_p0[t]);
+            if (ts != KW_NONE) {
+                set_pos(ts * KW_MAX_FIELDS + 0, sm.q1_p1[t]);
 #pragma unroll
-            for (int f = 0; f < KW_MAX_FIELDS; f++) {
-                if ((uint32_t)f < F) {
-                    const uint32_t h = mf.list[ts][f];
-                    if (h != KW_NONE) {                                                  // (uniform)
-                        bool fnd; uint32_t pp = KW_NONE;
-                        kw_mf_merge_field(sm, ix, ix.lists[h], cur[f], mA.first_id, mA.last_id, ok, id, fnd, pp);
-                        if (ok && fnd) { any = true; set_pos(ts * KW_MAX_FIELDS + f, pp); }
-                    }
-                }
+                for (int f = 1; f < KW_MAX_FIELDS; f++) if ((uint32_t)f < F) set_pos(ts * KW_MAX_FIELDS + f, sm.q1_px[f - 1][t]);
             }
-            ok = ok && any;
-        }
-        // (2) survivors (few): the other tokens in every field, then the driver token's other fields (an id an EARLIER field's list of the driver token
-        //     holds is left to that field's work items: every document of the union is produced once)
-        if (ok) {
 #pragma unroll
             for (int tt = 0; tt < TMAX; tt++) {
                 if ((uint32_t)tt < T && (uint32_t)tt != td && (uint32_t)tt != ts && ok) {
@@ -1726,24 +1758,87 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
                 for (int k = 0; k < NP; k++) d[1 + k] = pos[k];
             }
             qfn += total;
-            continue;
         } else {
-        if (ok) {
-            const uint32_t slot = qfn + my;
-            sm.qf_id[slot] = id;
+            if (ok) {
+                const uint32_t slot = qfn + my;
+                sm.qf_id[slot] = id;
 #pragma unroll
-            for (int k = 0; k < NP; k++) sm.qf_pos[k][slot] = pos[k];
+                for (int k = 0; k < NP; k++) sm.qf_pos[k][slot] = pos[k];
+            }
+            qfn += total;
+            if (qfn >= KW_THREADS) {
+                __syncthreads();
+                if (t == 0) sm.qf_cnt = qfn;
+                __syncthreads();
+                while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, true, true, false>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, 0u);
+                qfn = sm.qf_cnt;
+            }
         }
-        qfn += total;
-        if (qfn >= KW_THREADS) {
-            __syncthreads();
-            if (t == 0) sm.qf_cnt = qfn;
-            __syncthreads();
-            while (sm.qf_cnt >= KW_THREADS) kw_score_stage<TMAX, CAP, true, true, false>(sm, ix, q, KW_THREADS, aux_ids, my_ids_out, 0u);
-            qfn = sm.qf_cnt;
+        // drop the processed head of the queue
+        const uint32_t rest = q1n - n_take;
+        uint32_t a = 0, b2 = 0, c[KW_MAX_FIELDS];
+#pragma unroll
+        for (int f = 0; f < KW_MAX_FIELDS; f++) c[f] = 0;
+        __syncthreads();                                           // (every thread has read its entry)
+        if (t < rest) {
+            a = sm.q1_id[n_take + t]; b2 = sm.q1_p0[n_take + t]; c[0] = sm.q1_p1[n_take + t];
+#pragma unroll
+            for (int f = 1; f < KW_MAX_FIELDS; f++) c[f] = sm.q1_px[f - 1][n_take + t];
         }
+        __syncthreads();
+        if (t < rest) {
+            sm.q1_id[t] = a; sm.q1_p0[t] = b2; sm.q1_p1[t] = c[0];
+#pragma unroll
+            for (int f = 1; f < KW_MAX_FIELDS; f++) sm.q1_px[f - 1][t] = c[f];
         }
+        q1n = rest;
+        __syncthreads();
+    };
+
+    for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
+        if (((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, qi, &sm.stop)) break;
+        const BlockIds mA = biA[b];
+        const uint32_t m_n = mA.n_ids_bits & 0xFFFF;
+        bool ok = t < m_n;
+        uint32_t id = 0xFFFFFFFFu;
+        if (ok) {
+            const uint32_t* __restrict__ w = idwA + mA.ids_woff;
+            id = mA.first_id + ((mA.n_ids_bits >> 16) == 16 ? (uint32_t)((const uint16_t*)w)[t] : w[t]);
+        }
+        // stage 1 — the SECOND token (fewest postings after the driver's), every field, every candidate of the block: block-level merge through the LDS tile
+        uint32_t ps[KW_MAX_FIELDS];
+#pragma unroll
+        for (int f = 0; f < KW_MAX_FIELDS; f++) ps[f] = KW_NONE;
+        if (ts != KW_NONE) {
+            bool any = false;
+#pragma unroll
+            for (int f = 0; f < KW_MAX_FIELDS; f++) {
+                if ((uint32_t)f < F) {
+                    const uint32_t h = mf.list[ts][f];
+                    if (h != KW_NONE) {                                                  // (uniform)
+                        bool fnd; uint32_t pp = KW_NONE;
+                        kw_mf_merge_field(sm, ix, ix.lists[h], cur[f], mA.first_id, mA.last_id, ok, id, fnd, pp);
+                        if (ok && fnd) { any = true; ps[f] = pp; }
+                    }
+                }
+            }
+            ok = ok && any;
+        }
+        // survivors -> the queue (block order = ascending id)
+        uint32_t total;
+        const uint32_t my = block_compact1(ok, sm.wave_cnt2[par], total);
+        par ^= 1;
+        if (ok) {
+            const uint32_t slot = q1n + my;
+            sm.q1_id[slot] = id; sm.q1_p0[slot] = b * BLOCK_IDS + t; sm.q1_p1[slot] = ps[0];
+#pragma unroll
+            for (int f = 1; f < KW_MAX_FIELDS; f++) sm.q1_px[f - 1][slot] = ps[f];
+        }
+        q1n += total;
+        if (q1n >= (uint32_t)KW_THREADS) { __syncthreads(); stage2(KW_THREADS); }      // (the queue holds 512: < 256 left over + one block's survivors)
     }
+    __syncthreads();
+    while (q1n > 0) stage2(q1n < (uint32_t)KW_THREADS ? q1n : (uint32_t)KW_THREADS);
     if constexpr (DEFER) {
         if (t == 0) part.cnt[blockIdx.x] = qfn;                     // hits handed to kw_score_kernel
         return;

@@ -400,7 +400,25 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
         uint64_t total_blocks = 0;
         for (uint32_t i = 0; i < n_queries; i++) {
             const tsgpu_kw_query& in = queries[i];
-            if (in.n_tokens == 0 || in.n_tokens > TSGPU_MAX_QUERY_TOKENS || in.n_fields != 1) continue;
+            if (in.n_tokens == 0 || in.n_tokens > TSGPU_MAX_QUERY_TOKENS || in.n_fields == 0 || in.n_fields > (uint32_t)KW_MAX_FIELDS) continue;
+            if (in.n_fields != 1) {
+                // several query_by fields: the driver is the token with the fewest postings over all fields, one group of work items per field list
+                // of it — its blocks enter the chunk rule, too (before, such batches were always cut with the minimum chunk: 2 000 two-field queries on
+                // 10M documents = 101 000 work items of 16 blocks)
+                uint64_t best_ids = ~0ull; uint32_t best_blocks = 0;
+                for (uint32_t t = 0; t < in.n_tokens; t++) {
+                    uint64_t ids = 0; uint32_t blocks = 0; bool found = false;
+                    for (uint32_t f = 0; f < in.n_fields; f++) {
+                        const uint32_t h = snap.find_handle(in.field_ids[f], in.term_ids[t]);
+                        if (h == 0xFFFFFFFFu) continue;
+                        found = true; ids += snap.h_lists[h].n_ids; blocks += snap.h_lists[h].n_blocks;
+                    }
+                    if (found && ids < best_ids) { best_ids = ids; best_blocks = blocks; }
+                }
+                total_blocks += best_blocks / 4;        // (a multi-field driver block costs ~4x a single-field one — two tile merges, wider records — so these batches are
+                                                        //  cut finer; measured, 2 000 two-field queries on 10M documents: 64-block items 20.4 ms, 16 -> 23.2, 256 -> 24.4)
+                continue;
+            }
             uint32_t best = 0xFFFFFFFFu;
             for (uint32_t t = 0; t < in.n_tokens; t++) {
                 const uint32_t h = snap.find_handle(in.field_ids[0], in.term_ids[t]);
