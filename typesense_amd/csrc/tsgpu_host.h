@@ -64,6 +64,9 @@ struct DeferredFrees {
 };
 inline DeferredFrees& deferred_frees() { static DeferredFrees* d = new DeferredFrees; return *d; }      // (never destroyed: no static-destruction order issues at exit)
 
+typedef void (*OomHook)();
+inline OomHook& oom_hook() { static OomHook h = nullptr; return h; }      // set once RetireBin exists (below): what else can be freed when hipMalloc fails
+
 // grow-only device / pinned-host buffers
 struct DevBuf {
     void* p = nullptr;
@@ -81,6 +84,7 @@ struct DevBuf {
             (void)hipGetLastError();
             p = nullptr;
             deferred_frees().drain();
+            if (oom_hook()) oom_hook()();                // ... and the retired snapshots' buffers (RetireBin::drain_all)
             TSGPU_HIP_TRY(hipMalloc(&p, want));
         }
         cap = want;
@@ -144,9 +148,25 @@ struct FieldHost {
 struct RetireBin {
     std::mutex m;
     std::vector<void*> dev;
-    void put(DevBuf& b) { if (!b.p) return; { std::lock_guard<std::mutex> lk(m); dev.push_back(b.p); } b.p = nullptr; b.cap = 0; }
-    void drain() { std::vector<void*> v; { std::lock_guard<std::mutex> lk(m); v.swap(dev); } for (void* p : v) (void)hipFree(p); }
-    ~RetireBin() { drain(); }
+    size_t bytes = 0;
+    RetireBin() { oom_hook() = &RetireBin::drain_all; std::lock_guard<std::mutex> lk(registry_mu()); registry().push_back(this); }
+    // (more than 1 GiB parked — a whole retired index copy after a compaction while writes go idle — is freed on the spot, like DeferredFrees)
+    void put(DevBuf& b) {
+        if (!b.p) return;
+        bool now = false;
+        { std::lock_guard<std::mutex> lk(m); if (bytes + b.cap > (1ull << 30)) now = true; else { dev.push_back(b.p); bytes += b.cap; } }
+        if (now) (void)hipFree(b.p);
+        b.p = nullptr; b.cap = 0;
+    }
+    void drain() { std::vector<void*> v; { std::lock_guard<std::mutex> lk(m); v.swap(dev); bytes = 0; } for (void* p : v) (void)hipFree(p); }
+    ~RetireBin() {
+        { std::lock_guard<std::mutex> lk(registry_mu()); auto& r = registry(); for (size_t i = 0; i < r.size(); i++) if (r[i] == this) { r[i] = r.back(); r.pop_back(); break; } }
+        drain();
+    }
+    // every live bin: an allocation that fails drains them all before it gives up (DevBuf::reserve)
+    static std::mutex& registry_mu() { static std::mutex* mu = new std::mutex; return *mu; }
+    static std::vector<RetireBin*>& registry() { static std::vector<RetireBin*>* r = new std::vector<RetireBin*>; return *r; }
+    static void drain_all() { std::lock_guard<std::mutex> lk(registry_mu()); for (RetireBin* b : registry()) b->drain(); }
 };
 
 // the device arenas of the posting lists; shared by consecutive snapshots: an incremental commit appends at the tails (regions no

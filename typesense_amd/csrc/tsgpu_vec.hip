@@ -817,11 +817,15 @@ int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const flo
             const uint32_t need = std::max(k, ef);
             int tier = need <= 128 ? 0 : (need <= 512 ? 1 : 2);
             TSGPU_HIP_TRY(hipEventRecord(ctx->ev[3], s));
+            uint32_t vs_boost = 1, grid_now = grid;
             for (;;) {
                 if (hash_mode) {
-                    // per-query visited sets: 64 x the tier's result-heap capacity (8 192 / 32 768 / 65 536 words), one per concurrent query
-                    const uint32_t vs = tier == 0 ? 8192u : (tier == 1 ? 32768u : 65536u);
-                    if ((rc = f->g_vhash.reserve((size_t)grid * vs * 4))) return rc;
+                    // per-query visited sets: 64 x the tier's result-heap capacity (8 192 / 32 768 / 65 536 words), one per concurrent query; a traversal
+                    // that outgrows the largest tier's set (large ef / k, strict filters: many visited, few admitted) runs again with sets 8x / 64x as
+                    // large and fewer queries in flight (<= 8 GiB of sets) instead of being reported as overflowed
+                    const uint32_t vs = (tier == 0 ? 8192u : (tier == 1 ? 32768u : 65536u)) * vs_boost;
+                    grid_now = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, (8ull << 30) / ((uint64_t)vs * 4)));
+                    if ((rc = f->g_vhash.reserve((size_t)grid_now * vs * 4))) return rc;
                     a.vhash = f->g_vhash.as<uint32_t>(); a.vhash_slots = vs;
                 } else if ((uint64_t)f->g_epoch + iters >= 0xFFF0ull) {      // tag space exhausted: clear the tags
                     TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, tag_bytes, s));
@@ -830,9 +834,9 @@ int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const flo
                 a.epoch_base = f->g_epoch;
                 f->g_epoch += iters;
                 TSGPU_HIP_TRY(hipMemsetAsync(a.overflow_cnt, 0, 56, s));
-                if (tier == 0) hipLaunchKernelGGL((vec_hnsw_search_kernel<129, 1024>), dim3(grid), dim3(64), 0, s, a);
-                else if (tier == 1) hipLaunchKernelGGL((vec_hnsw_search_kernel<513, 2048>), dim3(grid), dim3(64), 0, s, a);
-                else hipLaunchKernelGGL((vec_hnsw_search_kernel<VEC_HNSW_MAX_EF + 1, VEC_HNSW_CAND_CAP>), dim3(grid), dim3(64), 0, s, a);
+                if (tier == 0) hipLaunchKernelGGL((vec_hnsw_search_kernel<129, 1024>), dim3(grid_now), dim3(64), 0, s, a);
+                else if (tier == 1) hipLaunchKernelGGL((vec_hnsw_search_kernel<513, 2048>), dim3(grid_now), dim3(64), 0, s, a);
+                else hipLaunchKernelGGL((vec_hnsw_search_kernel<VEC_HNSW_MAX_EF + 1, VEC_HNSW_CAND_CAP>), dim3(grid_now), dim3(64), 0, s, a);
                 uint32_t h_stat[14] = {0};
                 TSGPU_HIP_TRY(hipMemcpyAsync(h_stat, a.overflow_cnt, 56, hipMemcpyDeviceToHost, s));
                 TSGPU_HIP_TRY(hipStreamSynchronize(s));
@@ -842,8 +846,10 @@ int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const flo
 #endif
                 ctx->hnsw_last_expansions = (uint64_t)h_stat[2] | ((uint64_t)h_stat[3] << 32);
                 ctx->hnsw_last_distances = (uint64_t)h_stat[4] | ((uint64_t)h_stat[5] << 32);
-                if (tier == 2 || !h_stat[0]) break;
-                tier = 2;
+                if (!h_stat[0]) break;
+                if (tier < 2) { tier = 2; continue; }
+                if (hash_mode && vs_boost < 64) { vs_boost *= 8; continue; }
+                break;                                   // (a candidate heap beyond the largest tier: those queries report n_out = 0xFFFFFFFF)
             }
             TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s));
             TSGPU_HIP_TRY(hipEventRecord(ctx->ev[5], s));
