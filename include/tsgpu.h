@@ -382,6 +382,21 @@ int tsgpu_vec_knn_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, i
  * Re-load after the rows change. */
 int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32_t maxlevel, uint32_t enterpoint, const uint32_t* link0,
                         const uint64_t* upper_ptr, const uint32_t* upper_links, uint32_t n);
+/* The graph BUILT inside the library — hnswlib's incremental addPoint (level draw from default_random_engine(seed), mult = 1 / ln M,
+ * greedy descent, ef_construction-bounded beam per layer, getNeighborsByHeuristic2, reverse links, markDelete), the way the reference
+ * inserts (src/index.cpp:1002-1075; ctor arguments include/index.h:365-367: M 16, ef_construction 200, seed 100) — so that the B2
+ * typedef swap leaves a graph to search. From this call on every NEW label given to tsgpu_vec_upsert is inserted into
+ * the graph as well (rows already in the field are inserted first, in row order); tsgpu_vec_delete = markDelete; the graph search uploads
+ * the lists when they changed. n_threads: host threads inserting the rows of ONE upsert call concurrently with hnswlib's locking
+ * (1 = the sequential algorithm, deterministic: equal, link for link, to the oracle's restatement; the reference itself indexes on four
+ * threads). Overwriting a live label / re-using a deleted label's slot (hnswlib updatePoint, allow_replace_deleted) is not followed: the
+ * graph is marked stale, tsgpu_vec_hnsw_search_batch reports 501 and the exact k-NN answers. PARITY UNPINNED (hnswlib is not in the
+ * reference tree). M <= 31. */
+int tsgpu_vec_hnsw_enable(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, uint32_t ef_construction, uint32_t seed, uint32_t n_threads);
+/* the built graph in tsgpu_vec_hnsw_load's flat form (tests, persistence). info = {n, maxlevel, enterpoint, M}; *n_upper = upper lists.
+ * Arrays may be NULL (sizes only): levels[n], link0[n][1 + 2M], upper_ptr[n + 1], upper_links[n_upper][1 + M]. */
+int tsgpu_vec_hnsw_export(tsgpu_ctx* ctx, uint32_t vec_field_id, int32_t info[4], uint32_t* levels, uint32_t* link0, uint64_t* upper_ptr,
+                          uint32_t* upper_links, uint64_t* n_upper);
 /* up to k (distance, label) per query, closest first, found by greedy descent + the ef-bounded best-first search of layer 0
  * (max(ef, k) candidates). functor_present: the caller passes a filter functor (Typesense always does) — it selects hnswlib's
  * stricter stop rule; allow_ids (sorted, NULL = all) / excluded_ids / deleted labels are what the functor and isMarkedDeleted

@@ -183,6 +183,12 @@ void orc_hnsw_build(void* h, uint32_t M, uint32_t ef_construction, uint32_t seed
     slot->init(idx->num_dim, M, ef_construction, seed, hnsw_dist);
     for (size_t r = 0; r < idx->vec_labels.size(); r++) slot->addPoint(idx->vec_store.data() + r * idx->num_dim, idx->vec_labels[r]);
 }
+// incremental addPoint after orc_hnsw_build: the rows that orc_vec_add appended since (row order = insertion order)
+void orc_hnsw_add_new_rows(void* h) {
+    Index* idx = (Index*)h;
+    hnsw_graph_t* g = hnsw_of()[h];
+    for (size_t r = g->size(); r < idx->vec_labels.size(); r++) g->addPoint(idx->vec_store.data() + r * idx->num_dim, idx->vec_labels[r]);
+}
 void orc_hnsw_free(void* h) { auto it = hnsw_of().find(h); if (it != hnsw_of().end()) { delete it->second; hnsw_of().erase(it); } }
 int32_t orc_hnsw_mark_deleted(void* h, uint32_t label) {
     hnsw_graph_t* g = hnsw_of()[h];

@@ -85,6 +85,8 @@ def lib():
         L.orc_hnsw_build.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_hnsw_free.argtypes = [C.c_void_p]
         L.orc_hnsw_mark_deleted.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_hnsw_add_new_rows.argtypes = [C.c_void_p]
+        L.orc_hnsw_add_new_rows.restype = None
         L.orc_hnsw_export.restype = C.c_uint64
         L.orc_hnsw_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_hnsw_import.restype = C.c_int32
@@ -377,6 +379,11 @@ class OracleIndex:
     def hnsw_build(self, M=16, ef_construction=200, seed=100):
         """HierarchicalNSW(space, 16, M, ef_construction, 100, true) + addPoint per row in insertion order (include/index.h:365-367)"""
         self.L.orc_hnsw_build(self.h, M, ef_construction, seed)
+
+    def hnsw_add(self, labels, X):
+        """vec_add + hnswlib addPoint for rows that arrive after hnsw_build (insertion order = row order)"""
+        self.vec_add(labels, X)
+        self.L.orc_hnsw_add_new_rows(self.h)
 
     def hnsw_mark_deleted(self, label):
         return self.L.orc_hnsw_mark_deleted(self.h, int(label))

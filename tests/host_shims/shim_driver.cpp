@@ -249,6 +249,54 @@ int main(int argc, char** argv) {
         }
     }
 
+    // ---------------- B2 with the graph built INSIDE the library (the index that survives the typedef swap) ----------------
+    {
+        Reader r(dir + "/hnsw.bin");
+        const uint32_t n = r.get<uint32_t>(), dim = r.get<uint32_t>(), M = r.get<uint32_t>();
+        (void)r.get<int32_t>(); (void)r.get<uint32_t>();
+        const std::vector<float> X = r.vec<float>((size_t)n * dim);
+        tsgpu::InnerProductSpace space(dim);
+        // `new HierarchicalNSW<float>(space, 16, M, ef_construction, 100, true)` (include/index.h:367) + graph_threads = 1 (sequential: deterministic)
+        tsgpu::HierarchicalNSW<float> vecdex(ctx, 11, &space, 16, M, 60, 100, true, 1);
+        for (uint32_t i = 0; i < n; i++) vecdex.addPoint(X.data() + (size_t)i * dim, (size_t)i, true);         // src/index.cpp:1052-1054, one call per document
+        // the library's graph == the oracle's build of the same rows (the fixture's lists were exported from it)
+        int32_t info[4]; uint64_t n_upper = 0;
+        CHECK(tsgpu_vec_hnsw_export(ctx, 11, info, nullptr, nullptr, nullptr, nullptr, &n_upper) == TSGPU_OK, "hnsw export: %s", tsgpu_last_error());
+        std::vector<uint32_t> levels(n), link0((size_t)n * (1 + 2 * M)), upper((size_t)std::max<uint64_t>(n_upper, 1) * (1 + M));
+        std::vector<uint64_t> uptr(n + 1);
+        CHECK(tsgpu_vec_hnsw_export(ctx, 11, info, levels.data(), link0.data(), uptr.data(), upper.data(), &n_upper) == TSGPU_OK, "hnsw export (2)");
+        const std::vector<uint32_t> want_levels = r.vec<uint32_t>(n), want_l0 = r.vec<uint32_t>((size_t)n * (1 + 2 * M));
+        const std::vector<uint64_t> want_uptr = r.vec<uint64_t>(n + 1);
+        const uint32_t want_nu = r.get<uint32_t>();
+        const std::vector<uint32_t> want_upper = r.vec<uint32_t>((size_t)want_nu * (1 + M));
+        CHECK((uint32_t)info[0] == n && (uint32_t)info[3] == M && n_upper == want_nu, "built graph: size / M / upper lists");
+        CHECK(levels == want_levels && uptr == want_uptr, "built graph: levels");
+        bool same = true;
+        for (uint32_t i = 0; i < n && same; i++) {
+            const uint32_t c = link0[(size_t)i * (1 + 2 * M)];
+            same = c == want_l0[(size_t)i * (1 + 2 * M)] && memcmp(&link0[(size_t)i * (1 + 2 * M) + 1], &want_l0[(size_t)i * (1 + 2 * M) + 1], c * 4) == 0;
+        }
+        CHECK(same, "built graph: a level-0 list differs from the oracle's");
+        // searchKnnCloserFirst through the adaptor = the oracle's traversal of that graph (no functor; then a functor that rejects nothing)
+        const uint32_t n_q = r.get<uint32_t>(), k = r.get<uint32_t>(), ef = r.get<uint32_t>();
+        const std::vector<float> Q = r.vec<float>((size_t)n_q * dim);
+        CountingPassAll all;
+        for (uint32_t qi = 0; qi < n_q; qi++) {
+            const uint32_t want_n = r.get<uint32_t>();
+            const std::vector<uint64_t> want_l = r.vec<uint64_t>(want_n);
+            const std::vector<float> want_d = r.vec<float>(want_n);
+            // the reference's call: a functor is always passed (hnswlib's stricter stop rule: the fixture's expectation); it rejects nothing here, and
+            // the adaptor asks it about the over-fetched 2k results only — whose first k are the k-result search's (same ef)
+            const auto got = vecdex.searchKnnCloserFirst(Q.data() + (size_t)qi * dim, k, ef, &all);
+            CHECK(got.size() == want_n, "graph adaptor query %u: %zu vs %u results", qi, got.size(), want_n);
+            for (uint32_t i = 0; i < want_n && i < got.size(); i++)
+                CHECK(got[i].second == want_l[i] && memcmp(&got[i].first, &want_d[i], 4) == 0, "graph adaptor query %u hit %u: %zu vs %llu", qi, i, got[i].second, (unsigned long long)want_l[i]);
+            const auto got2 = vecdex.searchKnnCloserFirst(Q.data() + (size_t)qi * dim, k, ef, nullptr);
+            CHECK(got2.size() == k, "graph adaptor without a functor: %zu results", got2.size());
+        }
+        CHECK(all.calls <= 4 * (size_t)k * n_q, "graph adaptor: %zu predicate calls", all.calls);
+    }
+
     // ---------------- a18: mirror_hnsw_graph from an hnswlib-shaped object ----------------
     {
         Reader r(dir + "/hnsw.bin");

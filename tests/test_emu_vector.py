@@ -605,3 +605,67 @@ def test_hnsw_on_a_knn_heuristic_graph_matches_the_oracle_traversal_of_the_same_
                 hit += len(set(lab[i, :cnt[i]].tolist()) & set(le.tolist())); tot += k
     assert hit / tot > 0.85, hit / tot
     g.close()
+
+
+def _graphs_equal(a, b):
+    return (a["n"] == b["n"] and a["M"] == b["M"] and a["maxlevel"] == b["maxlevel"] and a["enterpoint"] == b["enterpoint"] and np.array_equal(a["levels"], b["levels"]) and
+            np.array_equal(a["upper_ptr"], b["upper_ptr"]) and np.array_equal(a["upper_links"], b["upper_links"]) and
+            all(np.array_equal(a["link0"][i, :1 + a["link0"][i, 0]], b["link0"][i, :1 + b["link0"][i, 0]]) for i in range(a["n"])))
+
+
+@pytest.mark.parametrize("n,dim,M,efc,metric", [(900, 24, 16, 60, B.METRIC_IP), (500, 40, 5, 30, B.METRIC_COSINE)])
+def test_hnsw_graph_built_inside_the_library_equals_the_oracles_link_for_link(n, dim, M, efc, metric):
+    """tsgpu_vec_hnsw_enable (an HNSW graph that survives the B2 typedef swap): hnswlib's incremental addPoint inside the
+    library — batches, one-row upserts, markDelete in between — builds, on ONE thread, exactly the graph the oracle's restatement builds
+    from the same rows in the same order (levels, entry point, every link list in order); the search then uploads it by itself and replays
+    the oracle's traversal. Concurrent insertion (hnswlib's locking, like the reference's four indexing threads) is not deterministic:
+    checked for structural validity and recall. PARITY UNPINNED (hnswlib is not in the reference tree)."""
+    rng = np.random.default_rng(50 + n)
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    lib = H.emu_lib_path()
+    g = T.GpuIndex(0, lib)
+    g.vec_create(1, dim, metric)
+    a, b = n // 9, 2 * n // 3
+    c = b + 40
+    g.vec_upsert(1, np.arange(a, dtype=np.uint64), X[:a])              # rows that exist before the graph is switched on: inserted in row order
+    g.vec_hnsw_enable(1, M=M, ef_construction=efc, seed=100, threads=1)
+    g.vec_upsert(1, np.arange(a, b, dtype=np.uint64), X[a:b])            # one batch
+    for i in range(b, c):                                                # the server's calling convention: addPoint per document
+        g.vec_upsert(1, np.array([i], np.uint64), X[i:i + 1])
+    g.vec_delete(1, 17); g.vec_delete(1, 333)                            # markDelete: later insertions no longer keep them in their beams
+    g.vec_upsert(1, np.arange(c, n, dtype=np.uint64), X[c:])
+    orc = O.OracleIndex(1, 1)
+    orc.vec_init(dim, metric)
+    orc.vec_add(np.arange(c, dtype=np.uint32), X[:c])
+    orc.hnsw_build(M=M, ef_construction=efc, seed=100)
+    orc.hnsw_mark_deleted(17); orc.hnsw_mark_deleted(333)
+    orc.hnsw_add(np.arange(c, n, dtype=np.uint32), X[c:])
+    mine, ref = g.vec_hnsw_export(1), orc.hnsw_export()
+    assert mine["n"] == n and _graphs_equal(mine, ref), "the library's graph differs from the oracle's"
+    Q = rng.standard_normal((5, dim)).astype(np.float32)
+    for k, ef in ((10, 10), (10, 80)):
+        dist, lab, cnt = g.vec_hnsw_search_batch(1, Q, k, ef)             # (uploads the lists: nothing was loaded by hand)
+        for i in range(Q.shape[0]):
+            d, l, _ = orc.hnsw_search(Q[i], k, ef, functor_present=True)
+            assert cnt[i] == d.size and np.array_equal(lab[i, :d.size], l) and np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32)), (k, ef, i)
+            assert 17 not in l and 333 not in l
+    # overwriting a live label is hnswlib's updatePoint: not followed -> the graph is stale, the graph search says 501, the exact path answers
+    g.vec_upsert(1, np.array([5], np.uint64), X[6:7])
+    with pytest.raises(T.TsgpuError) as e:
+        g.vec_hnsw_search_batch(1, Q, 10, 10)
+    assert e.value.code == B.ERR_UNSUPPORTED
+    assert g.vec_knn_batch(1, Q, 10)[2][0] == 10
+    g.close()
+    # concurrent insertion of a batch
+    g = T.GpuIndex(0, lib)
+    g.vec_create(1, dim, metric)
+    g.vec_hnsw_enable(1, M=M, ef_construction=efc, seed=100, threads=4)
+    g.vec_upsert(1, np.arange(n, dtype=np.uint64), X)
+    par = g.vec_hnsw_export(1)
+    assert par["n"] == n and np.array_equal(par["levels"], ref["levels"])                      # (levels are drawn in label order before the threads start)
+    cnts = par["link0"][:, 0]
+    assert cnts.max() <= 2 * M and (cnts[1:] > 0).all() and all((par["link0"][i, 1:1 + cnts[i]] < n).all() and i not in par["link0"][i, 1:1 + cnts[i]] for i in range(n))
+    dist, lab, cnt = g.vec_hnsw_search_batch(1, Q, 10, 100)
+    exact = g.vec_knn_batch(1, Q, 10)[1]
+    assert np.mean([len(set(lab[i].tolist()) & set(exact[i].tolist())) for i in range(Q.shape[0])]) >= 8.5
+    g.close()

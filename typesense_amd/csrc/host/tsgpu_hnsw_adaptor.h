@@ -13,8 +13,9 @@
 //     vecdex->getDataByLabel<float>(seq_id)   (throws when missing)          src/index.cpp:3355-3359, 5840, 8860
 //     vecdex->searchKnnCloserFirst(q, k, ef, &filterFunctor)                 src/index.cpp:3384-3386
 //     space->get_dist_func()(a, b, &dim)                                     src/index.cpp:3365
-// Differences, all deliberate: this adaptor's search is EXACT (ef, M, ef_construction are accepted and ignored) — the
-// graph-search twin is mirror_hnsw_graph() + tsgpu_vec_hnsw_search_batch() at the end of this file —, cosine normalisation stays where the reference does it (caller side, src/index.cpp:1049-1052, 3381-3384),
+// Differences, all deliberate: by default this adaptor's search is EXACT (ef, M, ef_construction are accepted and ignored); with
+// graph_threads > 0 the library builds hnswlib's graph itself from the addPoint calls and searches it (tsgpu_hnsw_build.h); a graph built
+// by a real hnswlib can be mirrored with mirror_hnsw_graph() at the end of this file. cosine normalisation stays where the reference does it (caller side, src/index.cpp:1049-1052, 3381-3384),
 // and the filter functor (a pure predicate over seq_ids) is never ignored (filter_by, hidden and excluded hits depend on it,
 // include/index.h:325-354): at the reference's unmodified call site it is applied to the results of an over-fetching exact search
 // (2k labels asked for a functor that rejects little), with candidate ids (the filter's id array) it becomes an allow-list, and only a
@@ -69,6 +70,7 @@ class HierarchicalNSW {
     size_t dim_;
     size_t max_elements_;
     std::unordered_set<uint32_t> live_;               // labels a filter functor can be asked about (mutated under the server's unique_lock)
+    bool graph_ = false;                              // the library builds and searches hnswlib's graph (constructor: graph_threads > 0)
 
     static void check(int rc, const char* what) {
         if (rc != TSGPU_OK) throw std::runtime_error(std::string(what) + ": " + tsgpu_last_error());
@@ -76,10 +78,14 @@ class HierarchicalNSW {
 
 public:
     // ctx / field_id select the tsgpu vector field this index mirrors; the remaining arguments are hnswlib's
-    HierarchicalNSW(tsgpu_ctx* ctx, uint32_t field_id, InnerProductSpace* s, size_t max_elements, size_t /*M*/ = 16,
-                    size_t /*ef_construction*/ = 200, size_t /*random_seed*/ = 100, bool /*allow_replace_deleted*/ = false)
-        : ctx_(ctx), field_(field_id), dim_(s->dim()), max_elements_(max_elements) {
+    // graph_threads > 0: the library also BUILDS hnswlib's graph from the addPoint calls (tsgpu_vec_hnsw_enable: M, ef_construction, seed as
+    // given; graph_threads host threads per addPoint batch) and searchKnnCloserFirst answers from it (approximate, like hnswlib; parity
+    // unpinned) instead of from the exact scan. 0 (default) = exact search, no graph.
+    HierarchicalNSW(tsgpu_ctx* ctx, uint32_t field_id, InnerProductSpace* s, size_t max_elements, size_t M = 16,
+                    size_t ef_construction = 200, size_t random_seed = 100, bool /*allow_replace_deleted*/ = false, unsigned graph_threads = 0)
+        : ctx_(ctx), field_(field_id), dim_(s->dim()), max_elements_(max_elements), graph_(graph_threads > 0) {
         check(tsgpu_vec_create(ctx_, field_, (uint32_t)dim_, TSGPU_METRIC_IP, max_elements), "tsgpu_vec_create");
+        if (graph_) check(tsgpu_vec_hnsw_enable(ctx_, field_, (uint32_t)M, (uint32_t)ef_construction, (uint32_t)random_seed, graph_threads), "tsgpu_vec_hnsw_enable");
     }
 
     size_t getCurrentElementCount() { return (size_t)tsgpu_vec_count(ctx_, field_); }
@@ -116,16 +122,25 @@ public:
     // ONE scan and 2k predicate calls — not live_.size() virtual calls plus a sort per query. A selective functor (fewer than ~k / 1024 of
     // the labels pass) ends in the sweep below; call sites that know the filter's id array should pass it (candidate_ids): the allow-list
     // form is one scan whatever the selectivity.
-    std::vector<std::pair<dist_t, labeltype>> searchKnnCloserFirst(const void* query, size_t k, size_t /*ef*/ = 0,
+    std::vector<std::pair<dist_t, labeltype>> searchKnnCloserFirst(const void* query, size_t k, size_t ef = 0,
                                                                    BaseFilterFunctor* filter = nullptr,
                                                                    const uint32_t* candidate_ids = nullptr, uint32_t n_candidates = 0) {
         std::vector<std::pair<dist_t, labeltype>> out;
         if (k == 0) return out;
         std::vector<float> dist;
         std::vector<uint64_t> lab;
+        bool use_graph = graph_ && !candidate_ids;
         auto knn = [&](size_t kk, const uint32_t* allow_ptr, uint32_t n_allow) -> uint32_t {
             dist.resize(kk); lab.resize(kk);
             uint32_t n = 0;
+            if (use_graph && !allow_ptr) {
+                // hnswlib's own search on the graph the library built: max(ef, kk) candidates at layer 0 (the functor, when there is one, is applied
+                // to an over-fetched result below instead of inside the traversal). A stale graph (501) / an outgrown heap: the exact scan answers.
+                const int rc = tsgpu_vec_hnsw_search_batch(ctx_, field_, (const float*)query, TSGPU_MEM_HOST, 1, (uint32_t)kk, (uint32_t)std::max(ef, kk), filter ? 1 : 0,
+                                                           nullptr, 0, nullptr, 0, dist.data(), lab.data(), &n, TSGPU_MEM_HOST);
+                if (rc == TSGPU_OK && n != 0xFFFFFFFFu) return n;
+                use_graph = false;
+            }
             check(tsgpu_vec_knn_batch(ctx_, field_, (const float*)query, TSGPU_MEM_HOST, 1, (uint32_t)kk, allow_ptr, n_allow, nullptr, 0,
                                       dist.data(), lab.data(), &n, TSGPU_MEM_HOST), "tsgpu_vec_knn_batch");
             return n;
@@ -147,7 +162,12 @@ public:
                     if (i >= asked_lab.size()) { asked_lab.push_back(lab[i]); verdict.push_back((*filter)((labeltype)lab[i]) ? 1 : 0); }
                     if (verdict[i]) { out.emplace_back((dist_t)dist[i], (labeltype)lab[i]); passed++; }
                 }
-                if (passed >= k || n < kk) return out;          // k neighbours pass, or the whole index has been seen
+                if (passed >= k) return out;
+                if (n < kk) {                                   // fewer than asked for: the whole index has been seen — or the graph search found no more
+                    if (!use_graph) return out;
+                    use_graph = false; asked_lab.clear(); verdict.clear();      // (approximate lists are not prefixes of the exact ones)
+                    continue;
+                }
                 // what it would take at the pass rate seen so far; beyond the largest supported k the predicate has to be swept
                 const size_t need = passed ? (k * (size_t)n + passed - 1) / passed * 3 / 2 : kk * 4;
                 if (kk >= TSGPU_MAX_TOPK || need > TSGPU_MAX_TOPK) break;

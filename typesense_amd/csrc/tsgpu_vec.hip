@@ -12,6 +12,8 @@
 #include "vec_kernels.hip.h"
 #include "host_topster.h"
 
+#include "tsgpu_hnsw_build.h"
+
 using namespace tsgpu;
 
 namespace tsgpu {
@@ -39,6 +41,7 @@ struct VecField {
     int32_t g_maxlevel = -1;
     uint32_t g_enterpoint = 0;
     bool g_loaded = false;
+    std::unique_ptr<HnswBuilder> hb;                   // graph construction inside the library (tsgpu_vec_hnsw_enable); null = the graph is mirrored from outside
 
     bool find_row(uint64_t label, uint32_t& row) const {
         if (identity) { if (label < n_rows) { row = (uint32_t)label; return true; } return false; }
@@ -529,6 +532,11 @@ int tsgpu_vec_upsert(tsgpu_ctx* ctx, uint32_t vec_field_id, const uint64_t* labe
             f->h_ok.insert(f->h_ok.end(), n, 1);
             f->n_rows += n;
             f->n_live += n;
+            if (f->hb && !f->hb->stale) {            // hnswlib addPoint for the new rows, in row order, on the rows AS STORED (cosine: normalised)
+                std::vector<float> rows((size_t)n * f->dim);
+                TSGPU_HIP_TRY(hipMemcpy(rows.data(), dst, rows.size() * 4, hipMemcpyDeviceToHost));
+                f->hb->add_batch(rows.data(), n);
+            }
         } else {
             f->break_identity();
             for (uint32_t i = 0; i < n; i++) {
@@ -543,7 +551,10 @@ int tsgpu_vec_upsert(tsgpu_ctx* ctx, uint32_t vec_field_id, const uint64_t* labe
                     f->h_ok.push_back(1);
                     f->n_live++;
                     TSGPU_HIP_TRY(hipMemcpyAsync(f->labels.as<uint64_t>() + row, &hl[i], 8, hipMemcpyHostToDevice, s));
-                } else if (!f->h_ok[row]) { f->h_ok[row] = 1; f->n_live++; }   // addPoint on a deleted label revives it
+                } else {
+                    if (!f->h_ok[row]) { f->h_ok[row] = 1; f->n_live++; }   // addPoint on a deleted label revives it
+                    if (f->hb) f->hb->stale = true;                         // (hnswlib's updatePoint / slot re-use is not followed: the exact path answers)
+                }
                 float* dst = f->X.as<float>() + (size_t)row * f->dim;
                 TSGPU_HIP_TRY(hipMemcpyAsync(dst, data + (size_t)i * f->dim, (size_t)f->dim * 4, kind, s));
                 if (f->metric == TSGPU_METRIC_COSINE)
@@ -551,6 +562,11 @@ int tsgpu_vec_upsert(tsgpu_ctx* ctx, uint32_t vec_field_id, const uint64_t* labe
                 TSGPU_HIP_TRY(hipMemsetAsync(f->row_ok.as<uint8_t>() + row, 1, 1, s));
                 { int rc2 = vec_refresh_mirror(f, row, 1, f->n_rows, s); if (rc2) return rc2; }
                 TSGPU_HIP_TRY(hipStreamSynchronize(s));
+                if (!exists && f->hb && !f->hb->stale) {
+                    std::vector<float> one(f->dim);
+                    TSGPU_HIP_TRY(hipMemcpy(one.data(), dst, (size_t)f->dim * 4, hipMemcpyDeviceToHost));
+                    f->hb->add_batch(one.data(), 1);
+                }
             }
         }
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_upsert: host allocation failed"); }
@@ -568,6 +584,7 @@ int tsgpu_vec_delete(tsgpu_ctx* ctx, uint32_t vec_field_id, uint64_t label) {
     f->h_ok[row] = 0;
     f->any_deleted = true;
     f->n_live--;
+    if (f->hb && row < f->hb->deleted.size()) f->hb->deleted[row] = 1;     // markDelete: construction beams no longer keep it as a result
     TSGPU_HIP_TRY(hipMemset(f->row_ok.as<uint8_t>() + row, 0, 1));
     return ok();
 }
@@ -716,6 +733,27 @@ static int vec_knn_locked(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q,
 extern "C" {
 
 // ---------------------------------------------------------------- HNSW graph mirror + search (seam B2, a18)
+// ctx->mu held; the lists have been validated (tsgpu_vec_hnsw_load) or come from the library's own builder
+static int hnsw_upload_locked(tsgpu_ctx* ctx, VecField* f, uint32_t M, int32_t maxlevel, uint32_t enterpoint, const uint32_t* link0, const uint64_t* upper_ptr,
+                              const uint32_t* upper_links, uint32_t n) {
+    hipStream_t s = ctx->stream;
+    const uint64_t n_upper = upper_ptr[n];
+    int rc;
+    if ((rc = f->g_link0.reserve((size_t)std::max<uint32_t>(n, 1) * (1 + 2 * M) * 4))) return rc;
+    if ((rc = f->g_upper_ptr.reserve((size_t)(n + 1) * 8))) return rc;
+    if ((rc = f->g_upper_links.reserve((size_t)std::max<uint64_t>(n_upper, 1) * (1 + M) * 4))) return rc;
+    TSGPU_HIP_TRY(hipMemcpyAsync(f->g_link0.p, link0, (size_t)n * (1 + 2 * M) * 4, hipMemcpyHostToDevice, s));
+    TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_ptr.p, upper_ptr, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+    if (n_upper) TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_links.p, upper_links, (size_t)n_upper * (1 + M) * 4, hipMemcpyHostToDevice, s));
+    // visited bookkeeping is allocated by the search (hash sets by default; 16-bit tags with option hnsw_visited_hash = 0)
+    const uint32_t slots = 4096;
+    f->g_tag_slots = 0;
+    if ((rc = f->g_stat.reserve(64))) return rc;
+    TSGPU_HIP_TRY(hipStreamSynchronize(s));
+    f->g_M = M; f->g_n = n; f->g_slots = slots; f->g_epoch = 1; f->g_maxlevel = maxlevel; f->g_enterpoint = enterpoint; f->g_loaded = true;
+    return TSGPU_OK;
+}
+
 int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32_t maxlevel, uint32_t enterpoint, const uint32_t* link0,
                         const uint64_t* upper_ptr, const uint32_t* upper_links, uint32_t n) {
     if (!ctx || !link0 || !upper_ptr) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: NULL argument");
@@ -724,6 +762,7 @@ int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32
     (void)hipSetDevice(ctx->device);
     VecField* f = get_field(ctx, vec_field_id);
     if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_hnsw_load: unknown vector field");
+    if (f->hb) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: this field builds its own graph (tsgpu_vec_hnsw_enable)");
     if (n != f->n_rows) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: the graph must cover exactly the rows of the field (hnswlib internal id = insertion order)");
     if (n && enterpoint >= n) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: entry point out of range");
     hipStream_t s = ctx->stream;
@@ -744,19 +783,45 @@ int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32
     }
     if (n && maxlevel >= 0 && (int64_t)(upper_ptr[enterpoint + 1] - upper_ptr[enterpoint]) < (int64_t)maxlevel)
         return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_load: the entry point does not reach maxlevel");
-    int rc;
-    if ((rc = f->g_link0.reserve((size_t)std::max<uint32_t>(n, 1) * (1 + 2 * M) * 4))) return rc;
-    if ((rc = f->g_upper_ptr.reserve((size_t)(n + 1) * 8))) return rc;
-    if ((rc = f->g_upper_links.reserve((size_t)std::max<uint64_t>(n_upper, 1) * (1 + M) * 4))) return rc;
-    TSGPU_HIP_TRY(hipMemcpyAsync(f->g_link0.p, link0, (size_t)n * (1 + 2 * M) * 4, hipMemcpyHostToDevice, s));
-    TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_ptr.p, upper_ptr, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
-    if (n_upper) TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_links.p, upper_links, (size_t)n_upper * (1 + M) * 4, hipMemcpyHostToDevice, s));
-    // visited bookkeeping is allocated by the search (hash sets by default; 16-bit tags with option hnsw_visited_hash = 0)
-    const uint32_t slots = 4096;
-    f->g_tag_slots = 0;
-    if ((rc = f->g_stat.reserve(64))) return rc;
-    TSGPU_HIP_TRY(hipStreamSynchronize(s));
-    f->g_M = M; f->g_n = n; f->g_slots = slots; f->g_epoch = 1; f->g_maxlevel = maxlevel; f->g_enterpoint = enterpoint; f->g_loaded = true;
+    const int urc = hnsw_upload_locked(ctx, f, M, maxlevel, enterpoint, link0, upper_ptr, upper_links, n);
+    return urc ? urc : ok();
+}
+
+int tsgpu_vec_hnsw_enable(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, uint32_t ef_construction, uint32_t seed, uint32_t n_threads) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    if (M < 2 || M > 31) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_hnsw_enable: M must be 2..31 (a level-0 list of 2M ids is fetched by one wavefront)");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    VecField* f = get_field(ctx, vec_field_id);
+    if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_hnsw_enable: unknown vector field");
+    try {
+        f->hb.reset(new HnswBuilder);
+        f->hb->init(f->dim, M, ef_construction, seed, n_threads, (int)ctx->vec_ip_lanes);
+        f->g_loaded = false;
+        if (f->n_rows) {                                 // rows that are already there: inserted in row order (= the order they were added in)
+            std::vector<float> rows((size_t)f->n_rows * f->dim);
+            TSGPU_HIP_TRY(hipMemcpy(rows.data(), f->X.p, rows.size() * 4, hipMemcpyDeviceToHost));
+            f->hb->add_batch(rows.data(), f->n_rows);
+            for (size_t r = 0; r < f->n_rows; r++) if (!f->h_ok[r]) f->hb->deleted[r] = 1;
+        }
+    } catch (const std::bad_alloc&) { f->hb.reset(); return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_hnsw_enable: host allocation failed"); }
+      catch (const std::system_error&) { f->hb.reset(); return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_hnsw_enable: could not start an insertion thread"); }
+    return ok();
+}
+
+int tsgpu_vec_hnsw_export(tsgpu_ctx* ctx, uint32_t vec_field_id, int32_t info[4], uint32_t* levels, uint32_t* link0, uint64_t* upper_ptr, uint32_t* upper_links,
+                          uint64_t* n_upper) {
+    if (!ctx || !info) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_export: NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    VecField* f = get_field(ctx, vec_field_id);
+    if (!f || !f->hb) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_hnsw_export: no graph is being built for this field (tsgpu_vec_hnsw_enable)");
+    const HnswBuilder& hb = *f->hb;
+    info[0] = (int32_t)hb.size(); info[1] = hb.maxlevel; info[2] = (int32_t)hb.enterpoint; info[3] = (int32_t)hb.M;
+    if (n_upper) *n_upper = hb.n_upper_lists();
+    if (levels) for (size_t i = 0; i < hb.size(); i++) levels[i] = (uint32_t)hb.levels[i];
+    if (link0) std::copy(hb.link0.begin(), hb.link0.end(), link0);
+    if (upper_ptr) { for (size_t i = 0; i < hb.size(); i++) upper_ptr[i] = hb.upper_at[i]; upper_ptr[hb.size()] = hb.n_upper_lists(); }
+    if (upper_links) std::copy(hb.upper.begin(), hb.upper.end(), upper_links);
     return ok();
 }
 
@@ -771,7 +836,20 @@ int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const flo
     (void)hipSetDevice(ctx->device);
     VecField* f = get_field(ctx, vec_field_id);
     if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_hnsw_search_batch: unknown vector field");
-    if (!f->g_loaded || f->g_n != f->n_rows) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_search_batch: no graph loaded for the current rows (tsgpu_vec_hnsw_load)");
+    if (f->hb) {                                       // the graph is built inside the library: bring the device copy up to date
+        if (f->hb->stale) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_hnsw_search_batch: the built graph no longer matches the rows (a live label was overwritten / a deleted one re-used): use tsgpu_vec_knn_batch");
+        if (f->hb->dirty || !f->g_loaded || f->g_n != f->n_rows) {
+            HnswBuilder& hb = *f->hb;
+            if (hb.size() != f->n_rows) return fail(TSGPU_ERR_DEVICE, "tsgpu_vec_hnsw_search_batch: the builder and the field disagree on the row count");
+            std::vector<uint64_t> up(hb.size() + 1);
+            for (size_t i = 0; i < hb.size(); i++) up[i] = hb.upper_at[i];
+            up[hb.size()] = hb.n_upper_lists();
+            const int urc = hnsw_upload_locked(ctx, f, hb.M, hb.maxlevel, hb.enterpoint == 0xFFFFFFFFu ? 0u : hb.enterpoint, hb.link0.data(), up.data(), hb.upper.data(), (uint32_t)hb.size());
+            if (urc) return urc;
+            hb.dirty = false;
+        }
+    }
+    if (!f->g_loaded || f->g_n != f->n_rows) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_search_batch: no graph loaded for the current rows (tsgpu_vec_hnsw_load / tsgpu_vec_hnsw_enable)");
     hipStream_t s = ctx->stream;
     try {
         const float* Q_dev = nullptr;

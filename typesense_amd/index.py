@@ -402,6 +402,21 @@ class GpuIndex:
         self._ck(self.L.tsgpu_vec_hnsw_load(self.h, field_id, int(graph["M"]), int(graph["maxlevel"]), int(graph["enterpoint"]), _vp(l0), _vp(up),
                                             _vp(ul) if ul.size else None, l0.shape[0]))
 
+    def vec_hnsw_enable(self, field_id, M=16, ef_construction=200, seed=100, threads=1):
+        """build the field's HNSW graph inside the library (hnswlib's addPoint on every new label; include/index.h:365-367 defaults)"""
+        self._ck(self.L.tsgpu_vec_hnsw_enable(self.h, field_id, M, ef_construction, seed, threads))
+
+    def vec_hnsw_export(self, field_id):
+        """-> dict(n, maxlevel, enterpoint, M, levels[n], link0[n, 1+2M], upper_ptr[n+1], upper_links[n_upper, 1+M]) (the oracle's hnsw_export keys)"""
+        info = np.zeros(4, np.int32)
+        nu = C.c_uint64(0)
+        self._ck(self.L.tsgpu_vec_hnsw_export(self.h, field_id, _vp(info), None, None, None, None, C.byref(nu)))
+        n, M, n_upper = int(info[0]), int(info[3]), int(nu.value)
+        levels = np.zeros(n, np.uint32); link0 = np.zeros((n, 1 + 2 * M), np.uint32)
+        upper_ptr = np.zeros(n + 1, np.uint64); upper = np.zeros((max(n_upper, 1), 1 + M), np.uint32)
+        self._ck(self.L.tsgpu_vec_hnsw_export(self.h, field_id, _vp(info), _vp(levels), _vp(link0), _vp(upper_ptr), _vp(upper), C.byref(nu)))
+        return dict(n=n, maxlevel=int(info[1]), enterpoint=int(np.uint32(info[2])), M=M, levels=levels, link0=link0, upper_ptr=upper_ptr, upper_links=upper[:n_upper])
+
     def vec_hnsw_search_batch(self, field_id, Q, k, ef, allow_ids=None, excluded_ids=None, functor_present=True):
         Q = np.ascontiguousarray(Q, dtype=np.float32)
         n = Q.shape[0]
