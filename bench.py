@@ -60,7 +60,10 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (concurrency, uncached-term batch, vector batch sweep / cosine / clustered)")
     ap.add_argument("--threads", type=int, default=256, help="host threads of the concurrency leg")
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--hnsw-rows", type=int, default=1_000_000, help="rows of the HNSW leg's collection (0 = skip the leg)")
+    ap.add_argument("--hnsw-rows", type=int, default=300_000, help="rows of the HNSW leg's collection (0 = skip the leg); the insertion-order build costs ~0.1 ms per row and host core")
+    ap.add_argument("--hnsw-graph", default="inserted", choices=["inserted", "knn"],
+                    help="inserted (default) = hnswlib's incremental addPoint inside the library (tsgpu_vec_hnsw_enable, label order, one host thread per CPU of the quota); "
+                         "knn = the round-2 stand-in derived on the GPU from exact k-NN lists (typesense_amd/hnsw_synth.py)")
     ap.add_argument("--hnsw-batch", type=int, default=4096, help="queries per step of the HNSW leg")
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--opt", action="append", default=[], help="tsgpu_set_option name=value (repeatable), e.g. vec_prefilter=0")
@@ -1019,28 +1022,45 @@ class Bench:
         X = synth.latent_vectors(n, dim, seed=3, device="cuda")
         g.vec_create(field, dim, B.METRIC_IP, n)
         lab = torch.arange(n, dtype=torch.int64, device="cuda")
-        g.vec_upsert_device(field, lab.data_ptr(), X.data_ptr(), n)
-        torch.cuda.synchronize()
-        t1 = time.time()
-        graph = hnsw_synth.build_graph(torch, g, field, X, M=M, K0=64, seed=100, batch=1024)
-        torch.cuda.synchronize()
-        t_build = time.time() - t1
-        g.vec_hnsw_load(field, graph)
+        inserted = args.hnsw_graph == "inserted"
+        build_threads = max(1, int(cpu_quota_cpus() or os.cpu_count() or 1))
+        if inserted:
+            # the graph the reference would have: hnswlib's addPoint in label order (M 16, ef_construction 200, seed 100: include/index.h:365-367),
+            # built INSIDE the library while the rows are upserted (tsgpu_hnsw_build.h), concurrently like the reference's indexing threads
+            g.vec_hnsw_enable(field, M=M, ef_construction=200, seed=100, threads=build_threads)
+            t1 = time.time()
+            step_rows = 1 << 16
+            for a in range(0, n, step_rows):
+                b = min(n, a + step_rows)
+                g.vec_upsert_device(field, lab[a:b].data_ptr(), X[a:b].data_ptr(), b - a)
+            torch.cuda.synchronize()
+            t_build = time.time() - t1
+            graph = g.vec_hnsw_export(field)
+        else:
+            g.vec_upsert_device(field, lab.data_ptr(), X.data_ptr(), n)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            graph = hnsw_synth.build_graph(torch, g, field, X, M=M, K0=64, seed=100, batch=1024)
+            torch.cuda.synchronize()
+            t_build = time.time() - t1
+            g.vec_hnsw_load(field, graph)
         nq_max = max(args.hnsw_batch, 256)
         Q = synth.latent_vectors(nq_max, dim, seed=4, device="cuda")
         res = {"metric": "HNSW k-NN queries/s (searchKnnCloserFirst, k=%d), PARITY UNPINNED: hnswlib is absent from the reference tree; the traversal is "
                          "checked against the oracle's restatement of the published algorithm on the same graph" % k,
                "unit": "queries/s", "dtype": "f32",
-               "config": {"workload": "%d x %d unit rows with a 32-dim latent structure + 0.3 noise (synth.latent_vectors), M=%d, graph = exact %d-NN lists + "
-                                      "getNeighborsByHeuristic2 + reverse links, built on the GPU (graph: knn-heuristic, NOT hnswlib's insertion-order graph)" % (n, dim, M, 64),
-                          "graph_build_s": t_build, "collection_s": t1 - t0, "maxlevel": int(graph["maxlevel"]), "mean_level0_degree": float(graph["link0"][:, 0].mean())},
+               "config": {"workload": ("%d x %d unit rows with a 32-dim latent structure + 0.3 noise (synth.latent_vectors), M=%d, ef_construction 200, seed 100: hnswlib's incremental "
+                                       "addPoint in label order INSIDE the library (tsgpu_vec_hnsw_enable), %d host threads per 65 536-row upsert" % (n, dim, M, build_threads)) if inserted else
+                                      ("%d x %d unit rows with a 32-dim latent structure + 0.3 noise (synth.latent_vectors), M=%d, graph = exact %d-NN lists + "
+                                       "getNeighborsByHeuristic2 + reverse links, built on the GPU (graph: knn-heuristic, NOT hnswlib's insertion-order graph)" % (n, dim, M, 64)),
+                          "graph": args.hnsw_graph, "graph_build_s": t_build, "graph_build_rows_per_s": n / t_build if t_build > 0 else None, "collection_s": t1 - t0, "maxlevel": int(graph["maxlevel"]), "mean_level0_degree": float(graph["link0"][:, 0].mean())},
                "runs": []}
         de = torch.zeros((256, k), dtype=torch.float32, device="cuda"); le = torch.zeros((256, k), dtype=torch.int64, device="cuda"); ce = torch.zeros(256, dtype=torch.int32, device="cuda")
         g.vec_knn_batch_raw(field, Q.data_ptr(), B.MEM_DEVICE, 256, k, de.data_ptr(), le.data_ptr(), ce.data_ptr(), B.MEM_DEVICE)
         torch.cuda.synchronize()
         le_h = le.cpu().numpy()
         keep = {}
-        for ef in (100, 400):
+        for ef in (100, 200, 400):
             for nq in sorted({256, args.hnsw_batch}):
                 d = torch.zeros((nq, k), dtype=torch.float32, device="cuda"); l = torch.zeros((nq, k), dtype=torch.int64, device="cuda"); c = torch.zeros(nq, dtype=torch.int32, device="cuda")
                 def step():
@@ -1069,8 +1089,12 @@ class Bench:
                 res["visited_tags_variant"] = {"error": repr(e)}
             finally:
                 g.set_option("hnsw_visited_hash", 1)
-        head = [x for x in res["runs"] if x["ef"] == 100 and x["batch"] == args.hnsw_batch][0]
+        # the quoted run: the smallest ef whose recall@k reaches 0.9 (the reference's default ef = 10 means max(ef, k) = k = 100 candidates)
+        cands = [x for x in res["runs"] if x["batch"] == args.hnsw_batch]
+        good = [x for x in cands if x["recall_at_%d" % k] >= 0.9]
+        head = good[0] if good else cands[-1]
         res["value"] = head["value"]
+        res["ef"] = head["ef"]
         res["recall_at_%d" % k] = head["recall_at_%d" % k]
         res["roofline"] = {"bound": "hbm", "achieved": head["row_bytes_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["row_bytes_GBs"] / HBM_PEAK_GBS, "traffic": None,
                            "note": "algorithmic bytes = distances computed x dim x 4 B (fp32 rows fetched at random, 3 KB each; link lists and visited tags not "
@@ -1099,13 +1123,13 @@ class Bench:
             res["parity"] = {"queries_checked": 2 * npar, "mismatches": bad, "pinned": False,
                              "what": "labels, order and distance bits of %d queries at ef=100 and ef=400 vs the oracle's restatement of searchKnnCloserFirst walking the "
                                      "same %d-node graph (hnsw_import); hnswlib itself is absent: parity unpinned" % (npar, n)}
-            orc.hnsw_search_batch(Qh[:ncpu], k, 100, threads=ncpu)
+            orc.hnsw_search_batch(Qh[:ncpu], k, res["ef"], threads=ncpu)
             t3 = time.time()
-            orc.hnsw_search_batch(Qh, k, 100, threads=ncpu)
+            orc.hnsw_search_batch(Qh, k, res["ef"], threads=ncpu)
             wall = time.time() - t3
             res["cpu_baseline"] = {"value": Qh.shape[0] / wall, "unit": "queries/s", "cores": ncpu, "cgroup_cpu_quota_cpus": cpu_quota_cpus(), "kind": "port",
-                                   "sample": "%d queries at ef=100 through the oracle's HNSW restatement (scalar 16-lane-order distances, pooled visited tags) on %d host threads, "
-                                             "same graph, same rows; oracle load + import took %.0f s" % (Qh.shape[0], ncpu, t3 - t2)}
+                                   "sample": "%d queries at ef=%d (the quoted run's) through the oracle's HNSW restatement (scalar distances in the SSE-build order, pooled visited tags) on %d host threads, "
+                                             "same graph, same rows; oracle load + import took %.0f s" % (Qh.shape[0], res["ef"], ncpu, t3 - t2)}
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
             orc.close()
         del X
