@@ -51,6 +51,7 @@ struct WaveState {
     uint64_t u64[64];
     float f32a[64], f32b[64];
     uint16_t bfa[64][8], bfb[64][8];
+    int8_t i8a[64][16], i8b[64][16];
 };
 
 struct BlockState {
@@ -270,6 +271,28 @@ inline f32x16 mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return d;
 }
 
+// v_mfma_i32_32x32x32_i8: A[i=l&31][k=16*(l>>5)..+15], B[k=16*(l>>5)..+15][j=l&31] (16 int8 per lane = four dwords); exact int32 accumulation;
+// D as the other 32x32 forms.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+inline i32x16 mfma_32x32x32_i8(i32x4 a, i32x4 b, i32x16 c) {
+    WaveState& W = cur_wave();
+    const unsigned l = cur_lane();
+    memcpy(W.i8a[l], &a, 16);
+    memcpy(W.i8b[l], &b, 16);
+    wave_sync();
+    i32x16 d = c;
+    const unsigned col = l & 31;
+    for (int r = 0; r < 16; r++) {
+        const unsigned row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        int acc = c[r];
+        for (unsigned k = 0; k < 32; k++) acc += (int)W.i8a[row + 32 * (k >> 4)][k & 15] * (int)W.i8b[col + 32 * (k >> 4)][k & 15];
+        d[r] = acc;
+    }
+    wave_sync();
+    return d;
+}
+
 }  // namespace hipemu
 
 #define threadIdx (hipemu::cur_tid())
@@ -329,6 +352,7 @@ inline float __fsqrt_rn(float a) { return sqrtf(a); }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu::mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu::mfma_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu::mfma_32x32x16_bf16((a), (b), (c))
+#define __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, x, y, z) hipemu::mfma_32x32x32_i8((a), (b), (c))
 // global_load_lds_dwordx4: LDS destination = wave-uniform base + lane * 16, per-lane global source
 inline void hipemu_global_load_lds4(const void* gsrc, void* lds_wave_base) { memcpy((char*)lds_wave_base + 4 * hipemu::cur_lane(), gsrc, 4); }
 inline void hipemu_global_load_lds16(const void* gsrc, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * hipemu::cur_lane(), gsrc, 16); }

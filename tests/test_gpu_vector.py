@@ -36,6 +36,9 @@ test_hnsw_graph_search_replays_the_reference_traversal = E.test_hnsw_graph_searc
 test_edge_cases_empty_tiny_and_fully_deleted_indexes = E.test_edge_cases_empty_tiny_and_fully_deleted_indexes
 test_every_summation_order_of_hnswlibs_distance_is_bit_exact = E.test_every_summation_order_of_hnswlibs_distance_is_bit_exact
 test_vector_branch_flat_and_k_cut_match_the_oracle = E.test_vector_branch_flat_and_k_cut_match_the_oracle
+test_int8_bracket_mirror_returns_the_oracles_neighbours_bit_for_bit = E.test_int8_bracket_mirror_returns_the_oracles_neighbours_bit_for_bit
+test_int8_bracket_mirror_hard_cases_zero_rows_huge_values_non_finite_and_ties = E.test_int8_bracket_mirror_hard_cases_zero_rows_huge_values_non_finite_and_ties
+test_hnsw_graph_built_inside_the_library_equals_the_oracles_link_for_link = E.test_hnsw_graph_built_inside_the_library_equals_the_oracles_link_for_link
 
 
 def test_flat_branch_at_size_many_work_items_768_dims():

@@ -301,7 +301,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
         return ok();
     }
     if (!strcmp(name, "vec_prefilter")) {
-        if (value != 0 && value != 1) return fail(TSGPU_ERR_INVALID, "vec_prefilter must be 0 or 1");
+        if (value < 0 || value > 2) return fail(TSGPU_ERR_INVALID, "vec_prefilter must be 0 (fp32 MFMA scan), 1 (bf16 bracket scan) or 2 (int8 bracket scan; read when a vector field is created)");
         ctx->vec_prefilter = (uint32_t)value;
         return ok();
     }
