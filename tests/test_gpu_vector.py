@@ -79,6 +79,32 @@ def test_hnsw_20k_x_96_batch_of_512_matches_the_cpu_traversal():
     g.close()
 
 
+def test_hnsw_20k_x_96_built_inside_the_library_link_for_link_and_searched_on_the_gpu():
+    """tsgpu_vec_hnsw_enable at the reference's construction parameters (M 16, ef_construction 200, seed 100; include/index.h:365-367), one thread:
+    20 000 x 96 rows inserted in label order = the oracle's restatement of hnswlib's addPoint link for link (every level, the entry point, every
+    list in order); then 64 queries on the GPU = the oracle's traversal of that graph (labels, order, distance bits). PARITY UNPINNED."""
+    n, dim = 20000, 96
+    rng = np.random.default_rng(2024)
+    X = rng.standard_normal((n, dim)).astype(np.float32)
+    g = T.GpuIndex(0, H.gpu_lib_path())
+    g.vec_create(1, dim, B.METRIC_IP)
+    g.vec_hnsw_enable(1, M=16, ef_construction=200, seed=100, threads=1)
+    for a in range(0, n, 4096):
+        g.vec_upsert(1, np.arange(a, min(n, a + 4096), dtype=np.uint64), X[a:a + 4096])
+    orc = O.OracleIndex(1, 1)
+    orc.vec_init(dim, B.METRIC_IP)
+    orc.vec_add(np.arange(n, dtype=np.uint32), X)
+    orc.hnsw_build(M=16, ef_construction=200, seed=100)
+    mine, ref = g.vec_hnsw_export(1), orc.hnsw_export()
+    assert mine["n"] == n and E._graphs_equal(mine, ref), "the library's graph differs from the oracle's"
+    Q = rng.standard_normal((64, dim)).astype(np.float32)
+    dist, lab, cnt = g.vec_hnsw_search_batch(1, Q, 100, 100)
+    for i in range(Q.shape[0]):
+        d, l, _ = orc.hnsw_search(Q[i], 100, 100, functor_present=True)
+        assert cnt[i] == d.size and np.array_equal(lab[i, :d.size], l) and np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32)), i
+    g.close()
+
+
 def test_hnsw_300k_x_128_graph_built_on_the_gpu_matches_the_oracle_on_the_same_graph():
     """the bench's HNSW leg at test size: a graph derived on the GPU from exact k-NN lists + the selection heuristic (hnsw_synth), adopted by
     the oracle; 2 048 concurrent queries (LDS tier 0 at ef=100, tier 1 at ef=300): labels, order and distance bits of the first 96
