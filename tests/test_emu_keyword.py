@@ -235,6 +235,44 @@ def _synthetic_lists(seed):
     return n_docs, lists
 
 
+@pytest.mark.parametrize("chunk", [256, 70])
+def test_long_work_items_reload_the_driver_metadata_window(chunk):
+    """kw_find2_kernel keeps the driver list's BlockIds in a lane-resident 64-block window (four v_readlane per block); a work item longer than
+    64 driver blocks reloads it — 176 driver blocks as ONE work item (two reloads, the last window partial) and as items of 70 blocks
+    (a reload one pair before the item ends; odd tail pairs): hits, counts and ids = the oracle, two and three tokens."""
+    from oracle import oracle_py as O
+    rng = np.random.default_rng(99)
+    n_docs = 1_000_000
+    a_ids = np.sort(rng.choice(n_docs, size=176 * 256 - 131, replace=False)).astype(np.uint32)
+    b_ids = np.sort(rng.choice(n_docs, size=130_000, replace=False)).astype(np.uint32)
+    c_ids = np.sort(rng.choice(n_docs, size=300_000, replace=False)).astype(np.uint32)
+    pts = H.points_of(n_docs)
+    orc = O.OracleIndex(1, 1)
+    orc.set_num_docs(n_docs)
+    orc.set_sort_dense(0, pts)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.field_create(0, False)
+    for term, ids in ((1, a_ids), (2, b_ids), (3, c_ids)):
+        pos = (ids * np.uint32(2654435761) >> np.uint32(27)).astype(np.uint32) % 7 + 1
+        oi = np.arange(ids.size, dtype=np.uint32)
+        orc.load_posting(0, term, ids, oi, pos)
+        g.term_upsert(0, term, ids, oi, pos)
+    g.column_set(0, pts)
+    g.set_num_docs(n_docs)
+    g.commit()
+    g.set_option("kw_chunk_blocks", chunk)
+    g.keep_result_ids(True)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    qs = [T.KwQuery([1, 2], sort=sort, topster_size=250), T.KwQuery([3, 1, 2], sort=sort, topster_size=250), T.KwQuery([1], sort=sort, topster_size=100)]
+    hits = g.keyword_search_batch(qs, k_stride=250)
+    assert (hits.status == 0).all() and hits.num_matched[0] > 4000 and hits.num_matched[1] > 1000
+    for i, q in enumerate(qs):
+        ref = H.oracle_keyword(orc, q, ids_cap=100000)
+        H.assert_hits_equal(hits, i, ref, "query %d" % i)
+        assert np.array_equal(g.result_ids(i), ref.result_ids)
+    g.close()
+
+
 @pytest.mark.parametrize("chunk,tile", [(64, 0), (1, 0), (64, 512)])
 def test_stage1_block_merge_windows_fallback_and_exhaustion(chunk, tile):
     from oracle import oracle_py as O
@@ -646,13 +684,14 @@ def test_deadline_in_flight_returns_partial_hits_with_search_cutoff(pair):
 @pytest.mark.parametrize("chunk", [64, 3])
 def test_pair_find_kernel_matches_the_oracle(pair, chunk):
     """kw_pair_blocks=1: the find kernel that serves two driver blocks per iteration (kw_find2.hip.h) — same hit records as the
-    one-block kernel: odd block counts (a lone last block), wide / multi-round / exhausted runs, third-list probes, filters"""
+    one-block kernel: odd block counts (a lone last block), wide / multi-round / exhausted runs, third-list probes (1..7 tokens: both
+    tables), filters"""
     from oracle import oracle_py as O
     orc, g, _ = pair
     rng = np.random.default_rng(123)
     sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
     qs = []
-    for n_tok in (1, 2, 3):
+    for n_tok in (1, 2, 3, 4, 5, 7):
         qs += _queries(rng, 8, 25, n_tok, sort=sort, topster_size=250)
         qs += _queries(rng, 3, 25, n_tok, sort=sort, topster_size=9, excluded_ids=np.arange(0, 3000, 4))
         qs += _queries(rng, 3, 25, n_tok, sort=sort, topster_size=40, filter_ids=np.sort(rng.choice(3000, size=900, replace=False)))

@@ -212,6 +212,7 @@ test_synonym_passes_score_like_score_results2 = EK.test_synonym_passes_score_lik
 test_parallel_planning_of_a_batch_gives_the_serial_plan = EK.test_parallel_planning_of_a_batch_gives_the_serial_plan
 test_device_side_planner_equals_the_host_planner_and_the_oracle = EK.test_device_side_planner_equals_the_host_planner_and_the_oracle
 test_multi_field_block_merge_windows_wide_runs_and_exhaustion = EK.test_multi_field_block_merge_windows_wide_runs_and_exhaustion
+test_long_work_items_reload_the_driver_metadata_window = EK.test_long_work_items_reload_the_driver_metadata_window
 
 
 def test_device_shard_merge_on_cuda_tensors(c100k):

@@ -32,12 +32,12 @@ for n_q in [int(x) for x in os.environ.get("KW_BATCHES", "10000,1000,100").split
             import ctypes as C
             prof = (C.c_uint64 * 16)()
             g.L.tsgpu_debug_prof(g.h, 1, None)
-        t0 = time.perf_counter(); ks = []; ms = []
+        t0 = time.perf_counter(); ks = []; ms = []; fs = []
         for _ in range(5):
             g.keyword_search_batch_raw(arr, n_q, hs)
-            tm = g.timings(); ks.append(tm.kw_search_ms); ms.append(tm.kw_merge_ms)
+            tm = g.timings(); ks.append(tm.kw_search_ms); ms.append(tm.kw_merge_ms); fs.append(tm.kw_find_ms)
         wall = (time.perf_counter() - t0) / 5
-        print(json.dumps(dict(n_q=n_q, opts=opts, wall_ms=wall * 1e3, qps=n_q / wall, search_ms=float(np.mean(ks)), merge_ms=float(np.mean(ms)),
+        print(json.dumps(dict(n_q=n_q, opts=opts, wall_ms=wall * 1e3, qps=n_q / wall, search_ms=float(np.mean(ks)), find_ms=float(np.mean(fs)), merge_ms=float(np.mean(ms)),
                               alg_GBs=tm.kw_algorithmic_bytes / (np.mean(ks) * 1e-3) / 1e9)), flush=True)
         if prof is not None:
             g.L.tsgpu_debug_prof(g.h, 1, prof)

@@ -27,7 +27,12 @@ static const int KW_F2_SPAN = TSGPU_F2_SPAN;                 // runs of up to th
 #define TSGPU_F2_QUAD 0
 #endif
 static const bool KW_F2_QUAD = TSGPU_F2_QUAD != 0;           // 4-ary slot search (three samples per round) instead of binary
-static const bool KW_F2_FAST = TSGPU_F2_FAST != 0;           // interleaved slot searches when a wavefront's blocks are all full 16-bit blocks
+static const bool KW_F2_FAST = TSGPU_F2_FAST != 0;
+#ifdef TSGPU_F2_NOBAR                                       // tools/ ablation only (results are WRONG): what the barrier at the top of the pair loop costs (the compaction barrier stays: it keeps the queue counts uniform)
+#define KW_F2_LOOP_BARRIER()
+#else
+#define KW_F2_LOOP_BARRIER() __syncthreads()
+#endif           // interleaved slot searches when a wavefront's blocks are all full 16-bit blocks
 
 // (kw_glds_slabs / kw_glds_wait — the LDS-DMA tile fill — live in kw_kernels.hip.h: the multi-field find kernel uses them, too)
 
@@ -67,7 +72,22 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
         return (m.n_ids_bits >> 16) == 16 ? (uint32_t)((const uint16_t*)w)[s2] : w[s2];
     };
     auto load_window = [&](uint32_t base) -> BlockIds { return (T >= 2 && base + lane < dB.n_blocks) ? biB[base + lane] : PAD; };
-    auto meta = [&](uint32_t bb) -> BlockIds { return biA[bb < wi.blk_end ? bb : wi.blk_end - 1]; };
+    // Driver-list metadata: lane j of every wave holds BlockIds[abase + j] — ONE vector load serves 32 pairs (most work items need only the
+    // prologue's), a block's record is four v_readlane. (As per-pair loads they were uniform, so hipcc wanted them in SGPRs at once: a
+    // global_load + s_waitcnt vmcnt(0) at the END of every iteration — a full memory round trip exposed per pair, which also drained the next
+    // pair's tile DMA and driver ids before the iteration could end. TSGPU_PROF: 14 % of a work item's time.)
+    uint32_t abase = wi.blk_begin;
+    auto load_awin = [&](uint32_t base) -> BlockIds { const uint32_t bb = base + lane; return biA[bb < wi.blk_end ? bb : wi.blk_end - 1]; };
+    BlockIds awin = load_awin(abase);
+    auto meta = [&](uint32_t bb) -> BlockIds {          // bb: uniform, abase <= min(bb, blk_end - 1) < abase + 64
+        const int j = (int)((bb < wi.blk_end ? bb : wi.blk_end - 1) - abase);
+        BlockIds m;
+        m.first_id = (uint32_t)__builtin_amdgcn_readlane((int)awin.first_id, j);
+        m.last_id = (uint32_t)__builtin_amdgcn_readlane((int)awin.last_id, j);
+        m.ids_woff = (uint32_t)__builtin_amdgcn_readlane((int)awin.ids_woff, j);
+        m.n_ids_bits = (uint32_t)__builtin_amdgcn_readlane((int)awin.n_ids_bits, j);
+        return m;
+    };
 
     uint32_t wbase = 0, wver = 0;
     BlockIds win = load_window(0), nxt = load_window(32);
@@ -144,6 +164,9 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
 
     for (uint32_t b = wi.blk_begin, it = 0; b < wi.blk_end; b += 2, it++) {
         if (P.mode == 3) break;
+        KW_PROF(8)
+        kw_glds_wait();                                  // this pair's tile (and driver ids) have landed
+        KW_PROF(1)
         if ((it & 7) == 0 && kw_out_of_time(ix, q, wi.query, &sm.stop)) break;
         const bool two = b + 1 < wi.blk_end;
         const uint32_t n0 = mA.n_ids_bits & 0xFFFF, n1 = two ? (mB.n_ids_bits & 0xFFFF) : 0u;
@@ -151,10 +174,8 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
         const uint32_t id0 = ok0 ? mA.first_id + araw0 : 0xFFFFFFFFu, id1 = ok1 ? mB.first_id + araw1 : 0xFFFFFFFFu;
         const Plan C = P;
         KW_PROF(0)
-        kw_glds_wait();                                  // this pair's tile (and driver ids) have landed
         const uint32_t* __restrict__ tile = sm.btile + C.buf * HALF;
-        KW_PROF(1)
-        __syncthreads();
+        KW_F2_LOOP_BARRIER();
         KW_PROF(2)
         // ---- (a) which block of the run, for both candidates ----
         const uint32_t span = C.rhi - C.rlo;
@@ -316,13 +337,20 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
         par ^= 1;
         KW_PROF(6)
         const uint32_t pa0 = b * BLOCK_IDS + t, pa1 = (b + 1) * BLOCK_IDS + t;        // posting positions in the driver list
+#ifdef TSGPU_F2_NOSTAGE2                                     // tools/ ablation only (results are WRONG): the pair loop without the third.. lists
+        if (T >= 3) { q1n = 0; } else
+#endif
         if (T >= 3) {
             if (ok0) { const uint32_t slot = q1n + base0 + lo0; sm.q1_id[slot] = id0; sm.q1_p0[slot] = pa0; sm.q1_p1[slot] = p10; }
             q1n += tot0;
+            KW_PROF(7)
             drain_q1();                                  // (the queue holds 512 entries: 255 left over + one block's survivors)
+            KW_PROF(11)
             if (ok1) { const uint32_t slot = q1n + base1 + lo1; sm.q1_id[slot] = id1; sm.q1_p0[slot] = pa1; sm.q1_p1[slot] = p11; }
             q1n += tot1;
+            KW_PROF(7)
             drain_q1();
+            KW_PROF(11)
         } else {
             // one or two lists: the stage-1 survivors ARE the complete hits (ascending: block b's, then block b + 1's)
             if (ok0) {
@@ -340,6 +368,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
             qfn += tot0 + tot1;
         }
         KW_PROF(7)
+        if (b + 5 >= abase + 64 && b + 4 < wi.blk_end) { abase = b + 4; awin = load_awin(abase); }   // (every 30 pairs: the one exposed load left)
         mA = mC; mB = mD; mC = meta(b + 4); mD = meta(b + 5); araw0 = araw0n; araw1 = araw1n;   // (consumed in the middle of the next iteration)
     }
     __syncthreads();

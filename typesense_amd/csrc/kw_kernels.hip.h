@@ -295,6 +295,13 @@ __device__ inline uint32_t guided_lower_bound(uint32_t n, uint32_t x, uint32_t f
 // block's ids); neighbouring lanes probe ascending candidates, so their loads share cache lines.
 __device__ inline bool probe_list(const IndexView& ix, const ListDesc& d, uint32_t x, uint32_t& pos) {
     if (x < d.first_id || x > d.last_id) return false;
+#ifdef TSGPU_EXP_FAKEBM                                       // tools/ experiment only (results are WRONG): what a one-load bitmap probe of dense lists would cost
+    if (d.n_ids >= (1u << 18)) {
+        const uint2 wv = ((const uint2*)(ix.ids_payload + d.ids_base))[(x >> 5) % (d.n_ids >> 2)];
+        pos = (wv.x % (d.n_blocks - 1)) * BLOCK_IDS + ((wv.x >> 20) & 255u);
+        return ((wv.y >> (x & 31)) & 1u) && ((wv.y >> ((x + 7) & 31)) & 1u);
+    }
+#endif
     const uint32_t* __restrict__ bl = ix.blk_last + d.blk_base;
     const uint32_t lo = guided_lower_bound(d.n_blocks, x, d.first_id, d.last_id, [&](uint32_t i) { return bl[i]; });
     const BlockIds m = ix.blk_ids[d.blk_base + lo];
