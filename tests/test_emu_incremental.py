@@ -249,3 +249,91 @@ def test_term_created_after_the_first_commit_is_published_by_the_incremental_com
     gi, _, _ = g.term_download(0, 901)
     assert np.array_equal(gi, np.array([5, 17, 400, 900], np.uint32))
     g.close()
+
+
+def test_id_directories_follow_commits_and_never_change_a_result():
+    """ID DIRECTORIES of the long lists (tsgpu_format.h: {position, bits} per 32 doc ids; probe_list answers from ONE load): which lists carry
+    one, that an incremental commit rebuilds exactly the directories of the long lists it touched and shares the others with the previous
+    snapshot, that the pool is replaced when the collection outgrows its id range, entries that straddle two blocks (dense lists: most block
+    boundaries), ids beyond the pool's range — and that switching the directories off changes nothing (3..5-token queries = the oracle)."""
+    rng = np.random.default_rng(31)
+    n0, n1 = 3000, 8000
+    docs = H.zipf_docs(n1, 40, 9, seed=17)
+    docs[:, 0] = 1                                                 # term 1 is in every document: consecutive ids, every entry full, every block boundary inside an entry
+    live = np.zeros(n1, bool)
+    live[:n0] = True
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.field_create(0, False)
+    for d in range(n0):
+        g.index_plain_doc(d, 0, docs[d])
+    g.column_set(0, H.points_of(n1))
+    g.set_num_docs(n0)                                             # (the server's num_seq_ids(): the directories' id range is sized from it)
+    g.commit()
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+
+    def check(what):
+        orc = fresh_oracle(docs, live)
+        orc.set_num_docs(int(np.nonzero(live)[0].max()) + 1)
+        qs = [T.KwQuery(rng.choice(np.arange(1, 30), size=n_tok, replace=False), sort=sort, topster_size=250) for n_tok in (3, 3, 3, 4, 5, 3, 2, 3) for _ in range(3)]
+        qs.append(T.KwQuery([35, 1, 2], sort=sort, topster_size=250))        # a short driver against the two longest lists
+        qs.append(T.KwQuery([1, 2, 3], sort=sort, topster_size=100, filter_ids=np.arange(0, n1, 3, dtype=np.uint32)))
+        hits = g.keyword_search_batch(qs, k_stride=250)
+        assert (hits.status == 0).all() and hits.n_hits.sum() > 500
+        for i, q in enumerate(qs):
+            H.assert_hits_equal(hits, i, H.oracle_keyword(orc, q), what)
+        return qs, hits
+
+    n_long = sum(1 for t in range(1, 41) if g.term_num_ids(0, t) >= 256)
+    assert n_long >= 10 and g.counter("kw_iddir_lists") == n_long and g.counter("kw_iddir_built") == n_long
+    qs, with_dir = check("initial build")
+    # a write batch that touches three long lists and one short one: three directories rebuilt, the rest shared
+    built = g.counter("kw_iddir_built")
+    for d in range(n0, n0 + 40):
+        docs[d] = 0
+        docs[d, :4] = (1, 2, 3, 39)
+        g.index_plain_doc(d, 0, docs[d])
+        live[d] = True
+    g.commit()
+    assert g.counter("commit_incremental_count") == 1
+    assert g.counter("kw_iddir_built") == built + 3 and g.counter("kw_iddir_lists") == n_long
+    check("after an append batch")
+    # updates / removals in the middle of long lists (blocks re-packed at the tail, partial blocks in mid-list)
+    built = g.counter("kw_iddir_built")
+    for d in rng.choice(n0, size=150, replace=False):
+        g.remove_plain_doc(int(d), 0, docs[d])
+        if d % 3:
+            docs[d] = rng.integers(1, 30, size=docs.shape[1])
+            g.index_plain_doc(int(d), 0, docs[d])
+        else:
+            live[d] = False
+    g.commit()
+    assert g.counter("kw_iddir_built") > built
+    check("after updates and removals")
+    # the collection outgrows the pool's id range (3000 + 1/8 + 1024 rounded up to 6144) while num_docs still says 3000: the pool stays, ids
+    # beyond its range are found by the regular probe ...
+    for d in range(n0 + 40, 6500):
+        g.index_plain_doc(d, 0, docs[d])
+        live[d] = True
+    full = g.counter("commit_full_count")
+    g.commit()
+    assert g.counter("commit_full_count") == full
+    check("ids beyond the directories' range")
+    # ... and once num_docs is raised, the next (incremental) commit replaces the pool: every long list gets a directory over the new range
+    built = g.counter("kw_iddir_built")
+    g.set_num_docs(6500)
+    g.index_plain_doc(6500, 0, docs[6500]); live[6500] = True
+    g.commit()
+    assert g.counter("commit_full_count") == full
+    n_long2 = sum(1 for t in range(1, 41) if g.term_num_ids(0, t) >= 256)
+    assert g.counter("kw_iddir_lists") == n_long2 and g.counter("kw_iddir_built") == built + n_long2
+    check("after the pool was replaced")
+    # ... and with the directories switched off every result is the same
+    qs2, on = check("directories on")
+    g.set_option("kw_iddir_min_ids", 0)
+    g.commit()
+    assert g.counter("kw_iddir_lists") == 0
+    off = g.keyword_search_batch(qs2, k_stride=250)
+    for i in range(len(qs2)):
+        n = int(on.n_hits[i])
+        assert off.n_hits[i] == n and np.array_equal(off.keys[i, :n], on.keys[i, :n]) and np.array_equal(off.scores[i, :n], on.scores[i, :n]) and off.num_matched[i] == on.num_matched[i]
+    g.close()

@@ -126,14 +126,16 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
             win_dirty = false;
         }
         P.ver = wver;
-        const uint32_t w_endw = win.ids_woff + packed_words(win.n_ids_bits & 0xFFFF, win.n_ids_bits >> 16);
         if (dB.flags & LIST_HAS_BREAKS) {
+            const uint32_t w_endw = win.ids_woff + packed_words(win.n_ids_bits & 0xFFFF, win.n_ids_bits >> 16);
             const uint32_t nxt_woff = (uint32_t)__shfl(win.ids_woff, (int)((lane + 1) & 63));
             const bool brk = lane >= P.rlo && lane < P.rhi && w_endw != nxt_woff;
             if (__ballot(brk ? 1 : 0) != 0) { P.mode = 2; return P; }
         }
-        P.w_begin = (uint32_t)__shfl(win.ids_woff, (int)P.rlo);
-        P.W = (uint32_t)__shfl(w_endw, (int)P.rhi) - P.w_begin;
+        // (rlo / rhi are uniform: v_readlane + scalar arithmetic, not two ds_bpermute round trips and a per-lane multiply)
+        P.w_begin = (uint32_t)__builtin_amdgcn_readlane((int)win.ids_woff, (int)P.rlo);
+        const uint32_t nb_hi = (uint32_t)__builtin_amdgcn_readlane((int)win.n_ids_bits, (int)P.rhi);
+        P.W = (uint32_t)__builtin_amdgcn_readlane((int)win.ids_woff, (int)P.rhi) + packed_words(nb_hi & 0xFFFF, nb_hi >> 16) - P.w_begin;
         if (P.W <= (uint32_t)(PIPE_WORDS * KW_THREADS)) {
             P.mode = 0;
             tbuf ^= 1; P.buf = tbuf;
@@ -177,12 +179,23 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
         const uint32_t* __restrict__ tile = sm.btile + C.buf * HALF;
         KW_F2_LOOP_BARRIER();
         KW_PROF(2)
+        // ---- request the next pair first (driver ids, plan, tile DMA: in flight during both searches of this pair). The plan may slide the
+        //      window registers: this pair's block search reads the last ids it was planned on from a copy ----
+        const uint32_t cur_last = win.last_id;
+        uint32_t araw0n = 0, araw1n = 0;
+        if (b + 2 < wi.blk_end) {
+            araw0n = load_id_raw(mC, t);
+            araw1n = load_id_raw(mD, t);
+            KW_PROF(10)
+            P = make_plan(mC.first_id, b + 3 < wi.blk_end ? mD.last_id : mC.last_id);
+        }
+        KW_PROF(4)
         // ---- (a) which block of the run, for both candidates ----
         const uint32_t span = C.rhi - C.rlo;
         uint32_t pos0 = C.rlo, pos1 = C.rlo;
         if (C.mode <= 1 && span <= (uint32_t)KW_F2_SPAN) {
             for (uint32_t j = C.rlo; j < C.rhi; j++) {
-                const uint32_t last_j = (uint32_t)__builtin_amdgcn_readlane((int)win.last_id, (int)j);
+                const uint32_t last_j = (uint32_t)__builtin_amdgcn_readlane((int)cur_last, (int)j);
                 pos0 += last_j < id0 ? 1u : 0u;
                 pos1 += last_j < id1 ? 1u : 0u;
             }
@@ -209,15 +222,6 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
             if (l1 < id1 || id1 < first1) done1 = true;
         }
         KW_PROF(3)
-        // ---- request the next pair (in flight during the slot searches) ----
-        uint32_t araw0n = 0, araw1n = 0;
-        if (b + 2 < wi.blk_end) {
-            araw0n = load_id_raw(mC, t);
-            araw1n = load_id_raw(mD, t);
-            KW_PROF(10)
-            P = make_plan(mC.first_id, b + 3 < wi.blk_end ? mD.last_id : mC.last_id);
-        }
-        KW_PROF(4)
         // ---- (b) which slot: branch-free lower bound over the block's ids in the LDS tile ----
         auto slot_search = [&](const uint32_t* __restrict__ tile_r, uint32_t id, uint32_t b_first, uint32_t b_nb, uint32_t tile_rel, uint32_t kb, bool& found, uint32_t& p1) {
             const uint32_t n = b_nb & 0xFFFF, target = id - b_first;

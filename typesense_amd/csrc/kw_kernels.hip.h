@@ -97,6 +97,9 @@ struct IndexView {
     const uint32_t* column_len;
     uint32_t n_columns;
     uint32_t num_docs;
+    const uint2* iddir;              // id directories of the long lists (tsgpu_format.h): slot s at iddir + s * iddir_slot_entries
+    uint32_t iddir_slot_entries;     // entries per slot (= ceil(iddir_cap_ids / 32))
+    uint32_t iddir_cap_ids;          // doc ids the directories cover: [0, cap)
     unsigned long long* prof;        // TSGPU_PROF builds: 13 counters; else null
     const struct KwQueryMF* mf;      // multi-field queries of the batch (KwQueryDev::mf_index)
     uint32_t* fbits;                 // filtered multi-field queries: one bit per filter rank (KwQueryDev::fbits_off), zeroed per batch
@@ -295,6 +298,12 @@ __device__ inline uint32_t guided_lower_bound(uint32_t n, uint32_t x, uint32_t f
 // block's ids); neighbouring lanes probe ascending candidates, so their loads share cache lines.
 __device__ inline bool probe_list(const IndexView& ix, const ListDesc& d, uint32_t x, uint32_t& pos) {
     if (x < d.first_id || x > d.last_id) return false;
+    if (d.dir_slot && x < ix.iddir_cap_ids) {                  // a long list: one load answers most probes (tsgpu_format.h, ID DIRECTORY)
+        const uint2 e = ix.iddir[(size_t)(d.dir_slot - 1) * ix.iddir_slot_entries + (x >> 5)];
+        const uint32_t b = x & 31u;
+        if (!((e.y >> b) & 1u)) return false;
+        if (!(e.x & IDDIR_SPLIT)) { pos = e.x + (uint32_t)__popc(e.y & ((1u << b) - 1u)); return true; }
+    }
 #ifdef TSGPU_EXP_FAKEBM                                       // tools/ experiment only (results are WRONG): what a one-load bitmap probe of dense lists would cost
     if (d.n_ids >= (1u << 18)) {
         const uint2 wv = ((const uint2*)(ix.ids_payload + d.ids_base))[(x >> 5) % (d.n_ids >> 2)];

@@ -52,6 +52,9 @@ IndexView make_view(tsgpu_ctx* ctx, const Snapshot& sn) {
     v.column_len = ctx->d_col_len.as<uint32_t>();
     v.n_columns = (uint32_t)ctx->columns.size();
     v.num_docs = ctx->num_docs;
+    v.iddir = sn.dir_pool ? sn.dir_pool->buf.as<uint2>() : nullptr;
+    v.iddir_slot_entries = sn.dir_pool ? sn.dir_pool->slot_entries : 0u;
+    v.iddir_cap_ids = sn.dir_pool ? sn.dir_pool->cap_ids : 0u;
     v.prof = ctx->d_prof.as<unsigned long long>();
     v.mf = nullptr;                                   // per lane: set by the batch
     v.fbits = nullptr;
@@ -242,6 +245,9 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
     if (!strcmp(name, "kw_device_plan_min_queries")) { ctx->kw_device_plan_min_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 30); return ok(); }
     if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
+    if (!strcmp(name, "kw_iddir_min_ids")) { ctx->kw_iddir_min_ids = value < 0 ? 0 : value; ctx->commit_force_full = true; return ok(); }
+    if (!strcmp(name, "kw_iddir_density_div")) { ctx->kw_iddir_density_div = value < 1 ? 1 : value; ctx->commit_force_full = true; return ok(); }
+    if (!strcmp(name, "kw_iddir_budget_mb")) { ctx->kw_iddir_budget_mb = value < 0 ? 0 : value; ctx->commit_force_full = true; return ok(); }
     if (!strcmp(name, "kw_host_split_first_pct")) { ctx->kw_host_split_first_pct = (uint32_t)std::min<int64_t>(95, std::max<int64_t>(5, value)); return ok(); }
     if (!strcmp(name, "kw_host_split_queries")) { ctx->kw_host_split_queries = (uint32_t)std::max<int64_t>(0, value); return ok(); }
     if (!strcmp(name, "kw_zero_copy_max_queries")) { ctx->kw_zero_copy_max_queries = (uint32_t)std::max<int64_t>(0, value); return ok(); }
@@ -343,6 +349,8 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!strcmp(name, "kw_book_us")) { *out = ctx->kw_book_us.load(); return ok(); }
     if (!strcmp(name, "kw_device_plans")) { *out = ctx->kw_device_plans.load(); return ok(); }                     // batches planned on the device / sent back to the host planner
     if (!strcmp(name, "kw_device_plan_fallbacks")) { *out = ctx->kw_device_plan_fallbacks.load(); return ok(); }
+    if (!strcmp(name, "kw_iddir_built")) { *out = ctx->kw_iddir_built; return ok(); }                               // id directories (re)built by commits so far
+    if (!strcmp(name, "kw_iddir_lists")) { const auto sn = ctx->snapshot(); uint64_t n = 0; if (sn) for (const auto& r : sn->dir_of) n += r ? 1 : 0; *out = n; return ok(); }   // lists of the current snapshot that carry one
     if (!strcmp(name, "batch_exec_us")) { *out = ctx->batch_exec_us.load(); return ok(); }           // coalesced rounds: batch execution / hand-out to the callers
     if (!strcmp(name, "batch_scatter_us")) { *out = ctx->batch_scatter_us.load(); return ok(); }
     if (!strcmp(name, "batch_rounds")) { *out = ctx->kw_comb.rounds + ctx->vec_comb.rounds; return ok(); }               // coalesced rounds executed so far

@@ -68,9 +68,18 @@ struct ListDesc {            // 48 bytes
     uint32_t flags;          // LIST_HAS_BREAKS: some block's ids do not follow the previous block's in the arena (blocks re-written by an
                              // incremental commit live at the arena tail until the next compaction); a run of blocks is ONE coalesced
                              // range only where it has no break
-    uint32_t pad;
+    uint32_t dir_slot;       // 0: none; else 1 + the slot of the list's ID DIRECTORY (below) in the snapshot's directory pool
 };
 static const uint32_t LIST_HAS_BREAKS = 1u;
+
+// ID DIRECTORY of a long list (n_ids >= num_docs / 64 by default): one 8-byte entry per 32 consecutive doc ids,
+//   {pos, bits}: bits = which of the ids [32w, 32w + 32) the list holds; pos = posting position (block * 256 + slot) of the lowest one.
+// "Is id x in the list, and where?" — what every probe of the third.. lists asks (posting_list_t::iterator_t::skip_to + the equality test of
+// or_iterator_t::intersect, /root/reference/src/or_iterator.cpp:20-79) — is ONE load: bit x & 31 of entry x >> 5, position = pos + popcount of
+// the lower bits (the ids of one entry are consecutive slots of one block). Entries whose ids straddle two blocks carry IDDIR_SPLIT in pos:
+// those (one per block, ~0.4 % of a list's ids) and ids beyond the pool's range take the regular two-level search. 8 bytes x num_docs / 32
+// per list (2.8 MB at 10M documents), built on the device by index_iddir_build_kernel at commit time.
+static const uint32_t IDDIR_SPLIT = 0x80000000u;
 
 TSGPU_HD static inline uint32_t required_bits(uint32_t v) {   // include/array_base.h:23-25
     return v == 0 ? 0u : 32u - (uint32_t)__builtin_clz(v);

@@ -228,8 +228,35 @@ struct HandleMaps {
     }
 };
 
+// ID DIRECTORIES of the long lists (tsgpu_format.h): fixed-size slots of one device buffer. A snapshot holds a reference per list; lists that
+// did not change between two commits share theirs, a changed list gets a fresh slot (its directory is rebuilt on the device), and a slot
+// returns to the pool's free list when the last snapshot that shows it is dropped — by whichever thread drops it: no device call.
+struct IdDirPool {
+    DevBuf buf;
+    std::shared_ptr<RetireBin> bin;
+    uint32_t slot_entries = 0, cap_ids = 0, n_slots = 0;
+    std::mutex mu;
+    std::vector<uint32_t> free_slots;
+    IdDirPool() = default;
+    IdDirPool(const IdDirPool&) = delete;
+    IdDirPool& operator=(const IdDirPool&) = delete;
+    ~IdDirPool() { if (bin) bin->put(buf); else buf.release(); }
+    bool take(uint32_t& slot) { std::lock_guard<std::mutex> lk(mu); if (free_slots.empty()) return false; slot = free_slots.back(); free_slots.pop_back(); return true; }
+    void give(uint32_t slot) { std::lock_guard<std::mutex> lk(mu); free_slots.push_back(slot); }
+};
+struct IdDirRef {
+    std::shared_ptr<IdDirPool> pool;
+    uint32_t slot = 0;
+    IdDirRef(std::shared_ptr<IdDirPool> p, uint32_t s) : pool(std::move(p)), slot(s) {}
+    IdDirRef(const IdDirRef&) = delete;
+    IdDirRef& operator=(const IdDirRef&) = delete;
+    ~IdDirRef() { if (pool) pool->give(slot); }
+};
+
 struct Snapshot {            // immutable view of all posting lists; published by tsgpu_commit, shared (RCU) by the searches that started on it
     std::shared_ptr<ArenaSet> ar;
+    std::shared_ptr<IdDirPool> dir_pool;                             // id directories of the long lists (null: none)
+    std::vector<std::shared_ptr<IdDirRef>> dir_of;                   // by list handle (shorter than h_lists / null entries: no directory)
     DevBuf lists;                                                   // ListDesc table (one per snapshot)
     std::vector<ListDesc> h_lists;                                  // host copy of the descriptors
     std::shared_ptr<const HandleMaps> maps;
@@ -466,6 +493,10 @@ struct tsgpu_ctx {
     uint32_t kw_timing_min_queries = 64;             // keyword batches below this many queries skip the phase events (tsgpu_timings reports 0 ms for them)
     uint32_t kw_merge_select_min = 2;                // queries with at least this many partial lists are merged by selection (kw_select_partials: tree merge); 0 = always fold
     bool kw_pair_blocks = true;                      // find kernel variant: two driver blocks per iteration (kw_find2.hip.h)
+    long long kw_iddir_min_ids = 256;                // id directories (tsgpu_format.h): lists of at least max(this, num_docs / kw_iddir_density_div) ids get one; 0 = none
+    long long kw_iddir_density_div = 64;
+    long long kw_iddir_budget_mb = 4096;             // device memory for the directory pool (longest lists first)
+    uint64_t kw_iddir_built = 0;                     // counter: directories (re)built by commits
     bool kw_two_kernels = true;                      // queries of <= 3 tokens: find kernel + score kernel instead of the fused kernel
     uint32_t kw_device_plan_min_queries = 512;       // batches of plain single-field queries from this size on are planned ON THE DEVICE (kw_plan.hip.h); 0 = always on the host
     std::atomic<uint64_t> kw_device_plans{0}, kw_device_plan_fallbacks{0};

@@ -333,7 +333,7 @@ ListDesc list_desc(const TermHost& t, uint64_t ids_base, uint64_t pay_base, uint
     ListDesc d = t.pl.desc;
     d.ids_base = ids_base; d.payload_base = pay_base; d.blk_base = (uint32_t)blk_base;
     d.flags = t.has_breaks ? LIST_HAS_BREAKS : 0u;
-    d.pad = 0;
+    d.dir_slot = 0;
     return d;
 }
 
@@ -352,6 +352,102 @@ __global__ void index_desc_scatter_kernel(const uint64_t* __restrict__ dst, cons
     if (i >= n) return;
     const uint64_t d = dst[i];
     a_last[d] = last[i]; a_bids[d] = bids[i]; a_bmeta[d] = bmeta[i];
+}
+
+// ---- id directories of the long lists (tsgpu_format.h) -----------------------------------------------------------------------------------
+struct IdDirJob { uint64_t ids_base; uint64_t first_block; uint32_t blk_base, n_blocks, slot, pad; };      // first_block: prefix of n_blocks over the jobs
+
+// one workgroup per posting block of a list that gets a (new) directory; thread t = slot t: sets its id's bit, and the entry's position if
+// it is the lowest id of its entry; an entry that also holds ids of the previous block is marked IDDIR_SPLIT. (atomicOr on zeroed memory:
+// every writer of an entry agrees with every other.)
+__global__ __launch_bounds__(256) void index_iddir_build_kernel(const IdDirJob* __restrict__ jobs, uint32_t n_jobs, const BlockIds* __restrict__ blk_ids,
+                                                                const uint32_t* __restrict__ ids_payload, uint2* __restrict__ dir, uint32_t slot_entries, uint32_t cap_ids) {
+    const uint64_t gb = blockIdx.x;
+    uint32_t lo = 0, hi = n_jobs - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (jobs[mid].first_block <= gb) lo = mid; else hi = mid - 1; }
+    const IdDirJob j = jobs[lo];
+    const uint32_t b = (uint32_t)(gb - j.first_block);
+    const BlockIds m = blk_ids[j.blk_base + b];
+    const uint32_t n = m.n_ids_bits & 0xFFFF, t = threadIdx.x;
+    if (t >= n) return;
+    const uint32_t* __restrict__ w = ids_payload + j.ids_base + m.ids_woff;
+    const bool w16 = (m.n_ids_bits >> 16) == 16;
+    const uint32_t id = m.first_id + (w16 ? (uint32_t)((const uint16_t*)w)[t] : w[t]);
+    if (id >= cap_ids) return;
+    unsigned int* e = (unsigned int*)(dir + (size_t)j.slot * slot_entries + (id >> 5));
+    bool lowest;
+    if (t == 0) {
+        const bool shared = b > 0 && (blk_ids[j.blk_base + b - 1].last_id >> 5) == (id >> 5);
+        if (shared) atomicOr(e, IDDIR_SPLIT);
+        lowest = !shared;
+    } else lowest = ((m.first_id + (w16 ? (uint32_t)((const uint16_t*)w)[t - 1] : w[t - 1])) >> 5) != (id >> 5);
+    if (lowest) atomicOr(e, b * (uint32_t)BLOCK_IDS + t);
+    atomicOr(e + 1, 1u << (id & 31u));
+}
+
+// Decides which lists of the snapshot being built carry a directory, shares the unchanged ones with the previous snapshot, builds the others
+// on the device and writes ListDesc::dir_slot of every list (so: call it BEFORE s.h_lists goes to the device, AFTER the arenas hold the
+// snapshot's blocks). touched = handles whose list changed since `cur` (null: every list is new). Running out of slots or of memory is not
+// an error: such lists simply keep the two-level probe.
+int build_id_directories(tsgpu_ctx* ctx, Snapshot& s, const Snapshot* cur, const std::vector<uint32_t>* touched, uint32_t num_docs) {
+    for (ListDesc& d : s.h_lists) d.dir_slot = 0;
+    s.dir_pool.reset(); s.dir_of.clear();
+    if (ctx->kw_iddir_min_ids <= 0 || ctx->kw_iddir_budget_mb <= 0 || !s.ar || s.h_lists.empty()) return TSGPU_OK;
+    const uint64_t thr = std::max<uint64_t>((uint64_t)ctx->kw_iddir_min_ids, num_docs / (uint64_t)ctx->kw_iddir_density_div);
+    std::vector<uint32_t> want;
+    for (size_t h = 0; h < s.h_lists.size(); h++) if (s.h_lists[h].n_ids >= thr && s.h_lists[h].n_blocks) want.push_back((uint32_t)h);
+    if (want.empty()) return TSGPU_OK;
+    std::sort(want.begin(), want.end(), [&](uint32_t a, uint32_t b) { return s.h_lists[a].n_ids != s.h_lists[b].n_ids ? s.h_lists[a].n_ids > s.h_lists[b].n_ids : a < b; });
+    std::shared_ptr<IdDirPool> pool = (cur && touched && cur->dir_pool && num_docs <= cur->dir_pool->cap_ids) ? cur->dir_pool : nullptr;
+    const bool reuse = (bool)pool;
+    if (!pool) {
+        const uint64_t cap = ((uint64_t)num_docs + num_docs / 8 + 1024 + 2047) / 2048 * 2048;
+        if (cap > 0xFFFFF000ull) return TSGPU_OK;
+        const uint64_t slot_bytes = cap / 32 * sizeof(uint2);
+        const uint64_t n_slots = std::min<uint64_t>((uint64_t)ctx->kw_iddir_budget_mb * (1ull << 20) / slot_bytes, 2 * want.size() + 8);
+        if (n_slots == 0) return TSGPU_OK;
+        pool = std::make_shared<IdDirPool>();
+        pool->bin = ctx->retire_bin;
+        if (pool->buf.reserve(n_slots * slot_bytes) != TSGPU_OK) { tls_error().clear(); return TSGPU_OK; }
+        pool->cap_ids = (uint32_t)cap; pool->slot_entries = (uint32_t)(cap / 32); pool->n_slots = (uint32_t)n_slots;
+        for (uint32_t i = (uint32_t)n_slots; i-- > 0;) pool->free_slots.push_back(i);
+    }
+    if (want.size() > (size_t)pool->n_slots / 2 + 4) want.resize((size_t)pool->n_slots / 2 + 4);     // (a tight budget: the longest lists, with room to double-buffer them)
+    std::vector<uint8_t> is_touched;
+    if (touched) { is_touched.assign(s.h_lists.size(), 0); for (uint32_t h : *touched) if (h < is_touched.size()) is_touched[h] = 1; }
+    s.dir_of.assign(s.h_lists.size(), nullptr);
+    std::vector<IdDirJob> jobs;
+    uint64_t total_blocks = 0;
+    for (uint32_t h : want) {
+        if (reuse && h < cur->dir_of.size() && cur->dir_of[h] && !is_touched[h]) { s.dir_of[h] = cur->dir_of[h]; continue; }
+        uint32_t slot;
+        if (!pool->take(slot)) continue;                 // every slot is held by snapshots that searches still use: this list goes without
+        s.dir_of[h] = std::make_shared<IdDirRef>(pool, slot);
+        const ListDesc& d = s.h_lists[h];
+        jobs.push_back({d.ids_base, total_blocks, d.blk_base, d.n_blocks, slot, 0u});
+        total_blocks += d.n_blocks;
+    }
+    if (!jobs.empty()) {
+        if (total_blocks > 0x7FFFFFFFull) { s.dir_of.clear(); return TSGPU_OK; }
+        DevBuf d_jobs;
+        int rc = d_jobs.reserve(jobs.size() * sizeof(IdDirJob));
+        if (rc != TSGPU_OK) { s.dir_of.clear(); tls_error().clear(); return TSGPU_OK; }
+        hipError_t e = hipMemcpy(d_jobs.p, jobs.data(), jobs.size() * sizeof(IdDirJob), hipMemcpyHostToDevice);
+        for (size_t i = 0; i < jobs.size() && e == hipSuccess; i++)
+            e = hipMemsetAsync(pool->buf.as<uint2>() + (size_t)jobs[i].slot * pool->slot_entries, 0, (size_t)pool->slot_entries * sizeof(uint2), ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(index_iddir_build_kernel, dim3((uint32_t)total_blocks), dim3(256), 0, ctx->stream, d_jobs.as<IdDirJob>(), (uint32_t)jobs.size(), s.ar->blk_ids.as<BlockIds>(),
+                               s.ar->ids_payload.as<uint32_t>(), pool->buf.as<uint2>(), pool->slot_entries, pool->cap_ids);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        }
+        d_jobs.release();
+        if (e != hipSuccess) { s.dir_of.clear(); return fail(TSGPU_ERR_DEVICE, std::string("tsgpu_commit: id directories: ") + hipGetErrorString(e)); }
+        ctx->kw_iddir_built += jobs.size();
+    }
+    s.dir_pool = pool;
+    for (size_t h = 0; h < s.dir_of.size(); h++) if (s.dir_of[h]) s.h_lists[h].dir_slot = s.dir_of[h]->slot + 1;
+    return TSGPU_OK;
 }
 
 // everything re-packed into fresh arenas (first commit, compaction, or the tails ran out of room)
@@ -418,10 +514,12 @@ int commit_full(tsgpu_ctx* ctx) {
     if ((rc = s.lists.reserve(std::max<size_t>(s.h_lists.size() + s.h_lists.size() / 4 + 64, 64) * sizeof(ListDesc)))) return rc;
     if (!h_bids.empty()) TSGPU_HIP_TRY(hipMemcpy(ar->blk_ids.p, h_bids.data(), h_bids.size() * sizeof(BlockIds), hipMemcpyHostToDevice));
     TSGPU_HIP_TRY(hipMemcpy(ar->ids_payload.p, h_idw.data(), h_idw.size() * 4, hipMemcpyHostToDevice));
-    if (!s.h_lists.empty()) TSGPU_HIP_TRY(hipMemcpy(s.lists.p, s.h_lists.data(), s.h_lists.size() * sizeof(ListDesc), hipMemcpyHostToDevice));
     if (!h_last.empty()) TSGPU_HIP_TRY(hipMemcpy(ar->blk_last.p, h_last.data(), h_last.size() * 4, hipMemcpyHostToDevice));
     if (!h_bmeta.empty()) TSGPU_HIP_TRY(hipMemcpy(ar->blk_meta.p, h_bmeta.data(), h_bmeta.size() * sizeof(BlockMeta), hipMemcpyHostToDevice));
     TSGPU_HIP_TRY(hipMemcpy(ar->payload.p, h_pw.data(), h_pw.size() * 4, hipMemcpyHostToDevice));
+    s.ar = ar;
+    if ((rc = build_id_directories(ctx, s, nullptr, nullptr, ctx->num_docs_set ? ctx->num_docs : std::max(ctx->num_docs, order.empty() ? 0u : max_id + 1)))) return rc;
+    if (!s.h_lists.empty()) TSGPU_HIP_TRY(hipMemcpy(s.lists.p, s.h_lists.data(), s.h_lists.size() * sizeof(ListDesc), hipMemcpyHostToDevice));
     ar->used_blocks = ar->live_blocks = n_slots; ar->used_idw = ar->live_idw = n_idw; ar->used_pw = ar->live_pw = n_pw;
     ctx->erased_dev_idw = ctx->erased_dev_pw = 0;
     maps->rebuild_dense();
@@ -584,6 +682,12 @@ int commit_incremental(tsgpu_ctx* ctx, const std::shared_ptr<const Snapshot>& cu
         }
         drop();
         if (e != hipSuccess) return fail(TSGPU_ERR_DEVICE, std::string("tsgpu_commit: descriptor scatter: ") + hipGetErrorString(e));
+    }
+    {
+        std::vector<uint32_t> touched_handles;
+        for (auto& pc : placed) touched_handles.push_back(pc.t->handle);
+        s.ar = ar;
+        if ((rc = build_id_directories(ctx, s, cur.get(), &touched_handles, ctx->num_docs_set ? ctx->num_docs : std::max(ctx->num_docs, max_id + 1)))) return rc;
     }
     TSGPU_HIP_TRY(hipMemcpy(s.lists.p, s.h_lists.data(), s.h_lists.size() * sizeof(ListDesc), hipMemcpyHostToDevice));
     ar->used_idw = ipos; ar->used_pw = ppos; ar->used_blocks = blk0 + st_last.size();
