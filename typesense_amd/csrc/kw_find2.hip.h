@@ -16,7 +16,7 @@
 #endif
 static const int KW_F2_SPAN = TSGPU_F2_SPAN;                 // runs of up to this many second-list blocks: block search by v_readlane over the window registers
 #ifndef TSGPU_F2_WAVES
-#define TSGPU_F2_WAVES 6
+#define TSGPU_F2_WAVES 7
 #endif
 #ifdef TSGPU_HIP_EMU
 #define KW_F2_WAVES
@@ -28,6 +28,13 @@ static const int KW_F2_SPAN = TSGPU_F2_SPAN;                 // runs of up to th
 #endif
 static const bool KW_F2_QUAD = TSGPU_F2_QUAD != 0;           // 4-ary slot search (three samples per round) instead of binary
 static const bool KW_F2_FAST = TSGPU_F2_FAST != 0;
+#ifndef TSGPU_F2_ROUNDS
+#define TSGPU_F2_ROUNDS 0
+#endif
+// Runs wider than the tile (the second list holds > 8 ids per driver id there): 1 = searched in several tile rounds, 0 (default since round 4) = probed
+// per candidate like broken runs. With id directories a probe of a long list is one load, and the pair loop without the multi-round code is
+// a smaller kernel: find 5.78 -> 5.03 ms on the 10 000-query batch (profiles/r04/exp_kw_find_split_probe.txt).
+static const bool KW_F2_ROUNDS = TSGPU_F2_ROUNDS != 0;
 #ifdef TSGPU_F2_NOBAR                                       // tools/ ablation only (results are WRONG): what the barrier at the top of the pair loop costs (the compaction barrier stays: it keeps the queue counts uniform)
 #define KW_F2_LOOP_BARRIER()
 #else
@@ -142,8 +149,8 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
             const uint32_t* lane_src = idwB + P.w_begin + t;
             uint32_t* lds_wave_base = sm.btile + tbuf * HALF + wave * 64;
             if (P.W <= 2u * KW_THREADS) kw_glds_slabs<2>(lane_src, lds_wave_base);
-            else kw_glds_slabs<8>(lane_src, lds_wave_base);
-        } else P.mode = 1;
+            else kw_glds_slabs<PIPE_WORDS>(lane_src, lds_wave_base);
+        } else P.mode = KW_F2_ROUNDS ? 1 : 2;
         return P;
     };
 
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
                 if (!done0) slot_search(tile, id0, first0, nb0, rel0, pos0, found0, p10);
                 if (!done1) slot_search(tile, id1, first1, nb1, rel1, pos1, found1, p11);
             }
-        } else if (C.mode == 1) {
+        } else if (KW_F2_ROUNDS && C.mode == 1) {
             // the run does not fit the pipelined tile: rounds over [rlo, rhi], each a coalesced copy of as many whole blocks as fit
             const uint32_t* __restrict__ woff = sm.bw_woff[C.ver];
             const uint32_t* __restrict__ wnb = sm.bw_nb[C.ver];

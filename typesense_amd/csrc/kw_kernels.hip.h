@@ -75,13 +75,16 @@ static const uint32_t KW_WINDOW_SIZE = 10; // WINDOW_SIZE, include/match_score.h
 #endif
 static const int KW_MAX_CHUNK = TSGPU_KW_MAX_CHUNK;        // driver blocks per work item (host clamps kw_chunk_blocks to this)
 static const int KW_PIPE_WORDS = 4;         // dwords per thread of the register-pipelined tile copy (4 x 256 words = 2048 16-bit ids)
-// the find kernel (two-kernel form) has registers and LDS to spare: deeper register pipeline, larger tile
+// the find kernels (two-kernel form): two tile buffers of 7 slabs (256 words each) — with 8, the pair kernel's LDS (tile + 6 KB survivor queue +
+// 2 KB window copies) is 24.4 KB = six workgroups per CU; 7 slabs = 22.4 KB = SEVEN (and <= 72 VGPRs since the multi-round path left the loop):
+// find 5.04 -> 4.80 ms. Runs beyond a buffer are probed per candidate (one load where the list has an id directory).
 #ifndef TSGPU_KW_FIND_PIPE_WORDS
-#define TSGPU_KW_FIND_PIPE_WORDS 8
+#define TSGPU_KW_FIND_PIPE_WORDS 7
 #endif
 #ifndef TSGPU_KW_FIND_TILE_WORDS
-#define TSGPU_KW_FIND_TILE_WORDS 4096
+#define TSGPU_KW_FIND_TILE_WORDS 3584
 #endif
+static const int KW_MF_TILE_WORDS = 4096;   // the multi-field find kernel's tile (one run of up to 16 slabs)
 static const int KW_FIND_PIPE_WORDS = TSGPU_KW_FIND_PIPE_WORDS;
 static const int KW_FIND_TILE_WORDS = TSGPU_KW_FIND_TILE_WORDS;
 static const int KW_TILE_WORDS = TSGPU_KW_TILE_WORDS;   // LDS tile of PACKED second-list ids per round (8 KB ~ 20 blocks of 12-bit ids); multiple of 256
@@ -887,7 +890,7 @@ struct KwSmem {
     uint32_t qf_pos[NP][QF];
     typename std::conditional<DEFER, KwNoTopk, TopkLds<CAP, S2>>::type tk;
     int64_t thr[4];
-    static const int TILE_WORDS = SCORE ? 2 : (DEFER ? KW_FIND_TILE_WORDS : KW_TILE_WORDS);
+    static const int TILE_WORDS = SCORE ? 2 : (DEFER ? (MF ? KW_MF_TILE_WORDS : KW_FIND_TILE_WORDS) : KW_TILE_WORDS);
     uint32_t btile[TILE_WORDS + 2];          // packed ids of the second list's blocks under the current driver block
     static const int BW = SCORE ? 1 : 64;
     uint32_t bw_last[2][BW], bw_first[2][BW], bw_woff[2][BW], bw_nb[2][BW];   // the second list's BlockIds window, SoA, two versions
@@ -1545,7 +1548,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(Ind
 // barrier at the top of the next iteration (cf. vec_glds16 in vec_kernels.hip.h).
 template <int N>
 __device__ inline void kw_glds_slabs(const uint32_t* lane_src, uint32_t* lds_wave_base) {
-    static_assert(N == 2 || N == 8, "two tiers");
+    static_assert(N == 2 || N == 4 || N == 6 || N == 7 || N == 8, "slabs of 256 words, four per M0 setting");
 #ifdef TSGPU_HIP_EMU
     for (int k = 0; k < N; k++) hipemu_global_load_lds4(lane_src + k * 256, lds_wave_base + k * 256);
 #else
@@ -1554,6 +1557,30 @@ __device__ inline void kw_glds_slabs(const uint32_t* lane_src, uint32_t* lds_wav
     if constexpr (N == 2) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\tglobal_load_lds_dword %1, off offset:1024\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(lane_src), "s"(dst) : "memory");
+    } else if constexpr (N == 4) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %1, off\n\tglobal_load_lds_dword %1, off offset:1024\n\t"
+                     "global_load_lds_dword %1, off offset:2048\n\tglobal_load_lds_dword %1, off offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_src), "s"(dst) : "memory");
+    } else if constexpr (N == 7) {
+        const uint32_t* lane_src2 = lane_src + 1024;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %1, off\n\tglobal_load_lds_dword %1, off offset:1024\n\t"
+                     "global_load_lds_dword %1, off offset:2048\n\tglobal_load_lds_dword %1, off offset:3072\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %2, off\n\tglobal_load_lds_dword %2, off offset:1024\n\tglobal_load_lds_dword %2, off offset:2048\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_src), "v"(lane_src2), "s"(dst) : "memory", "scc");
+    } else if constexpr (N == 6) {
+        const uint32_t* lane_src2 = lane_src + 1024;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %1, off\n\tglobal_load_lds_dword %1, off offset:1024\n\t"
+                     "global_load_lds_dword %1, off offset:2048\n\tglobal_load_lds_dword %1, off offset:3072\n\t"
+                     "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %2, off\n\tglobal_load_lds_dword %2, off offset:1024\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_src), "v"(lane_src2), "s"(dst) : "memory", "scc");
     } else {
         const uint32_t* lane_src2 = lane_src + 1024;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
