@@ -898,7 +898,7 @@ def test_host_output_batch_served_in_slices_equals_the_single_batch(pair):
                 H.assert_hits_equal(cut, i, H.oracle_keyword(orc, qs[i]), "sliced host batch")
     finally:
         g.set_option("kw_host_split_queries", 1000)
-        g.set_option("kw_host_split_first_pct", 75)
+        g.set_option("kw_host_split_first_pct", 70)
 
 
 @pytest.mark.parametrize("chunk_opt,host_threads", [(0, 1), (4, 3)])

@@ -50,7 +50,7 @@ namespace tsgpu {
 
 // 4 workgroups (16 waves) per CU need <= 128 VGPRs: tell the register allocator (it lands 3 over without the hint)
 #ifndef TSGPU_SCORE_WAVES
-#define TSGPU_SCORE_WAVES 5      // kw_score_kernel: 96 VGPRs = 5 waves per SIMD (2.01 -> 1.73 ms; 6 waves spills for no gain)
+#define TSGPU_SCORE_WAVES 6      // kw_score_kernel: <= 80 VGPRs = 6 waves per SIMD (round 1: 4 -> 5 waves 2.01 -> 1.73 ms; round 4, after the PLAIN instantiation: 5 -> 6 waves 1.45 -> 1.38 ms, 7: 1.42, 8: 1.70)
 #endif
 #ifdef TSGPU_HIP_EMU
 #define KW_FOUR_WAVES_PER_SIMD
@@ -906,7 +906,9 @@ struct KwSmem {
     uint32_t f_first, f_frank, f_rp, f_ep, f_c0, f_c1, f_cnt0, f_cnt1;
 };
 
-template <int TMAX, int CAP, bool MF, bool S2, bool SCORE>
+// PLAIN (score kernel only): no query of the launch has filter ids or excluded ids and no caller keeps the matched ids — the host knows, and the
+// instantiation without those paths is a smaller kernel (registers, not LDS, set the score kernel's occupancy).
+template <int TMAX, int CAP, bool MF, bool S2, bool SCORE, bool PLAIN = false>
 __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2, false, SCORE>& sm, const IndexView& ix, const KwQueryDev& q, uint32_t n_take,
                                       const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out, uint32_t ids_out_base) {
     // make room: at most n_take (<=256) new entries. (The score kernel decides AFTER scoring, from the number of hits that beat the
@@ -922,14 +924,14 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2, false, SCORE>& s
         seq_id = sm.qf_id[t];
         emit = true;
         // take_id(): excluded ids first (src/or_iterator.cpp:222-229) ...
-        if (q.n_excl) {
+        if (!PLAIN && q.n_excl) {
             const uint32_t* ex = aux_ids + q.aux_off;
             uint32_t lo = 0, hi = q.n_excl;
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ex[mid] < seq_id) lo = mid + 1; else hi = mid; }
             if (lo < q.n_excl && ex[lo] == seq_id) { emit = false; excl = true; }
         }
         // ... then the filter ids (:232-253): the hit is taken iff it is a filter id. rank = # filter ids <= hit (upper bound)
-        if (q.n_filt) {
+        if (!PLAIN && q.n_filt) {
             const uint32_t* fl = aux_ids + q.aux_off + q.n_excl;
             uint32_t lo = 0, hi = q.n_filt;
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (fl[mid] <= seq_id) lo = mid + 1; else hi = mid; }
@@ -952,7 +954,8 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2, false, SCORE>& s
         }
     }
     // num_keyword_matches under a filter (kw_filter_count below): which intersection ids does the reference's loop VISIT?
-    if (MF && q.n_filt) {
+    if constexpr (PLAIN) {
+    } else if (MF && q.n_filt) {
         // Several driver lists (query_by over several fields): the work items' hit streams interleave in id order, so the slices cannot
         // be chained. Without exclusions the count has an order-free form: filter ranks never decrease along the intersection, so the
         // ids the reference's loop lands on — rank exceeds the predecessor's — number exactly the DISTINCT POSITIVE ranks of the
@@ -1004,7 +1007,7 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2, false, SCORE>& s
     // ordered emission of matched ids (id_buff, src/index.cpp:5549)
     uint32_t total;
     const uint32_t my = block_compact(emit, sm.wave_cnt, total);
-    if (emit && ids_out) ids_out[ids_out_base + sm.n_emit + my] = seq_id;
+    if (!PLAIN && emit && ids_out) ids_out[ids_out_base + sm.n_emit + my] = seq_id;
     if constexpr (SCORE) {
         // only hits that beat the current k-th best are appended, and the buffer is re-sorted only when THEY do not fit: once the
         // threshold is up, a batch of 256 hits adds a handful of entries
@@ -1497,7 +1500,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
 // The "score" half of the two-kernel form: one workgroup per work item of the find kernel; its hits (seq_id + posting positions,
 // ascending seq_id) are scored 256 at a time — every wavefront full except the segment's last — through the same score stage,
 // top-K buffer and filter bookkeeping as the fused kernel, and leave the same partial result for kw_merge_kernel.
-template <int TMAX, int CAP, bool S2, bool MF = false>
+template <int TMAX, int CAP, bool S2, bool MF = false, bool PLAIN = false>
 __global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(IndexView ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work,
                                                               KwPartials part, const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out,
                                                               const uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
@@ -1536,7 +1539,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(Ind
         }
         if (t == 0) sm.qf_cnt = n;
         __syncthreads();
-        kw_score_stage<TMAX, CAP, MF, S2, true>(sm, ix, q, n, aux_ids, my_ids_out, 0u);
+        kw_score_stage<TMAX, CAP, MF, S2, true, PLAIN>(sm, ix, q, n, aux_ids, my_ids_out, 0u);
     }
     kw_write_partial(sm, q, part);
 }

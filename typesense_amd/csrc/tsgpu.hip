@@ -73,11 +73,12 @@ void launch_search(hipStream_t s, uint32_t n_work, const IndexView& v, const KwQ
 // two-kernel form: find (intersection -> hit records) then score (hit records -> partial top-K)
 template <int TMAX>
 void launch_find_score(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w, const KwPartials& part,
-                       const uint32_t* aux, uint32_t* ids_out, bool s2, uint32_t* hits, const uint64_t* hit_off, hipEvent_t mid_ev = nullptr, bool pair = false) {
+                       const uint32_t* aux, uint32_t* ids_out, bool s2, uint32_t* hits, const uint64_t* hit_off, hipEvent_t mid_ev = nullptr, bool pair = false, bool plain = false) {
     if (pair) hipLaunchKernelGGL((kw_find2_kernel<TMAX>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, hits, hit_off);
     else hipLaunchKernelGGL((kw_search_kernel<TMAX, 512, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     if (mid_ev) (void)hipEventRecord(mid_ev, s);           // find | score boundary of the batch's first group (tsgpu_timings::kw_find_ms)
-    if (cap == 512 && !s2) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, false>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    if (cap == 512 && !s2 && plain && !ids_out) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, false, false, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    else if (cap == 512 && !s2) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, false>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     else if (cap == 512) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     else if (cap == 1024) hipLaunchKernelGGL((kw_score_kernel<TMAX, 1024, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     else hipLaunchKernelGGL((kw_score_kernel<TMAX, 2048, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
@@ -378,6 +379,7 @@ struct Plan {
     uint64_t fbits_words = 0;                             // rank bitmaps of the filtered multi-field queries
     bool any_deadline = false;                            // some query carries a deadline: stamp the batch start, collect cutoff flags
     bool any_s2 = false;              // some query has a third sort key
+    bool any_aux = false;             // some query has filter ids or excluded ids (else the score kernel's PLAIN instantiation serves the batch)
     std::vector<uint32_t> aux;
     std::vector<int32_t> status, cutoff;
     uint32_t max_k = 1;
@@ -460,7 +462,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
         std::vector<uint32_t> aux, ordered_count_q; std::vector<KwQueryMF> mf; std::vector<KwWorkItem> flat_work;
         uint64_t fbits_words = 0, ids_total = 0, list_bytes = 0;
         uint32_t max_k = 0, n_numeric_sort_q = 0;
-        bool any_deadline = false, any_s2 = false;
+        bool any_deadline = false, any_s2 = false, any_aux = false;
     };
     auto plan_range = [&](uint32_t lo, uint32_t hi, PlanAcc& A) {
         A.flat_work.reserve((size_t)(hi - lo) * 4);
@@ -616,6 +618,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
             q.aux_off = (uint32_t)A.aux.size();
             q.n_excl = in.n_excluded;
             q.n_filt = in.n_filter;
+            if (in.n_excluded || in.n_filter) A.any_aux = true;
             if (in.n_excluded) {
                 if (!in.excluded_ids) { P.status[i] = TSGPU_ERR_INVALID; continue; }
                 A.aux.insert(A.aux.end(), in.excluded_ids, in.excluded_ids + in.n_excluded);
@@ -734,7 +737,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
             P.ordered_count_q.insert(P.ordered_count_q.end(), A.ordered_count_q.begin(), A.ordered_count_q.end());
             P.ids_total += A.ids_total; P.fbits_words += A.fbits_words; P.list_bytes += A.list_bytes;
             P.max_k = std::max(P.max_k, A.max_k); P.n_numeric_sort_q += A.n_numeric_sort_q;
-            P.any_deadline = P.any_deadline || A.any_deadline; P.any_s2 = P.any_s2 || A.any_s2;
+            P.any_deadline = P.any_deadline || A.any_deadline; P.any_s2 = P.any_s2 || A.any_s2; P.any_aux = P.any_aux || A.any_aux;
         }
     }
     // work tables: one launch per kernel flavour (single-field T<=3, single-field generic, multi-field T<=3, multi-field generic);
@@ -1392,7 +1395,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
                     else {
                         const bool mark = !find_marked;
                         find_marked = true;
-                        launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, L.d_hits.as<uint32_t>(), hoff_dev + a, mark && timing ? L.ev[3] : nullptr, ctx->kw_pair_blocks);
+                        launch_find_score<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, P.any_s2, L.d_hits.as<uint32_t>(), hoff_dev + a, mark && timing ? L.ev[3] : nullptr, ctx->kw_pair_blocks, !P.any_aux);
                     }
                 }
             } else if constexpr (MFT) launch_search_mf_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out);
