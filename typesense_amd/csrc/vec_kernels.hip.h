@@ -778,6 +778,15 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
     for (int cb = 0; cb < CB; cb++) {
         if constexpr (I8) { const uint32_t gq = q0 + wcol + cb * 32 + (lane & 31); sqv[cb] = a.sq[gq < a.n_q ? gq : a.n_q - 1]; } else sqv[cb] = 1.0f;
     }
+    // The per-lane constants above come from plain global loads, and hipcc waits for a load where its value is FIRST USED — here the tile
+    // epilogue, INSIDE the pipelined loop: `s_waitcnt vmcnt(3) .. vmcnt(0)` before the four `cq * nmax` products, in every epilogue. Its counter
+    // model knows nothing of the asm-issued LDS-DMAs, the hardware counter does: each of those waits drained the DMA ring, once per tile and
+    // wave (the "epilogue" that cost 0.5 of the scan's 4.6 ms in round 2's ablation was mostly this). Using the values here makes the
+    // compiler wait NOW, before the first DMA is in flight, and leaves nothing of its own pending inside the loop.
+#ifndef TSGPU_HIP_EMU
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++) asm volatile("" ::"v"(cqv[cb]), "v"(L1v[cb]), "v"(sqv[cb]));
+#endif
 #pragma unroll
     for (int i = 0; i < NS - 1; i++) {
         load_q((uint32_t)i < total_steps ? i : last, i);
@@ -921,17 +930,28 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
                                 for (int el = 0; el < 16; el++) amax = fmaxf(amax, acc[rb][cb][el]);       // v_max3_f32 chain
                         }
                         if (gq < a.n_q && !(amax < thr)) {
+                            // (nearly every wave has SOME lane in here for every column block — ~1.2 candidates per (wave, block) at 10M rows — so what
+                            // counts is the instructions the wave issues inside: the 32 scores are tested in groups of 4 behind their maximum, and only
+                            // a group that holds a candidate for some lane is walked)
                             uint64_t* __restrict__ seg = a.seg + ((size_t)slab * a.n_q + gq) * a.seg_cap;
 #pragma unroll
                             for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-                                for (int el = 0; el < 16; el++) {
-                                    const uint32_t row = rbase + rb * 32 + (el & 3) + 8 * (el >> 2);
-                                    float sc = (float)acc[rb][cb][el];
-                                    if constexpr (I8) sc *= scale;
-                                    if (!(sc < thr) && row < a.n_rows && (!a.row_ok || a.row_ok[row] != 0)) {
-                                        const uint32_t slot = atomicAdd(&sm.cnt[col], 1u);      // LDS
-                                        if (slot < a.seg_cap) seg[slot] = ((uint64_t)__float_as_uint(sc) << 32) | row;
+                                for (int g4 = 0; g4 < 4; g4++) {
+                                    float gm;
+                                    if constexpr (I8) { int m4 = acc[rb][cb][4 * g4]; for (int e4 = 1; e4 < 4; e4++) m4 = acc[rb][cb][4 * g4 + e4] > m4 ? acc[rb][cb][4 * g4 + e4] : m4; gm = (float)m4 * scale; }
+                                    else gm = fmaxf(fmaxf((float)acc[rb][cb][4 * g4], (float)acc[rb][cb][4 * g4 + 1]), fmaxf((float)acc[rb][cb][4 * g4 + 2], (float)acc[rb][cb][4 * g4 + 3]));
+                                    if (gm < thr) continue;
+#pragma unroll
+                                    for (int e4 = 0; e4 < 4; e4++) {
+                                        const int el = 4 * g4 + e4;
+                                        const uint32_t row = rbase + rb * 32 + (el & 3) + 8 * (el >> 2);
+                                        float sc = (float)acc[rb][cb][el];
+                                        if constexpr (I8) sc *= scale;
+                                        if (!(sc < thr) && row < a.n_rows && (!a.row_ok || a.row_ok[row] != 0)) {
+                                            const uint32_t slot = atomicAdd(&sm.cnt[col], 1u);      // LDS
+                                            if (slot < a.seg_cap) seg[slot] = ((uint64_t)__float_as_uint(sc) << 32) | row;
+                                        }
                                     }
                                 }
                         }
