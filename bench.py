@@ -452,12 +452,22 @@ class Bench:
         # link, as the local form of tsgpu_group does). The device-resident step is timed as well (`value_device_only`): it is the
         # single-launch form the roofline / rocprof durations refer to.
         if world == 1:
+            # the arrays the seam's shim requests for a query that sorts on _text_match (csrc/host/tsgpu_keyword_shim.h): keys, scores[3],
+            # match_score_index + the per-query counts; text_match (= scores[match_score_index]) and vector_distance (a keyword KV's default)
+            # are not requested. The same step with EVERY tsgpu_hits array delivered is timed as `value_host_all_arrays`.
             hh = self.T.Hits(n_q, K_TOPSTER)
-            hhs = hh.c_struct()
+            hhs = hh.c_struct(seam_arrays_only=True)
+            hhs_all = hh.c_struct()
 
             def step_host():
                 g.keyword_search_batch_raw(arr, n_q, hhs)
                 return hh
+
+            def step_host_all():
+                g.keyword_search_batch_raw(arr, n_q, hhs_all)
+                return hh
+            el_all, _lat_all, _ = timed(step_host_all, max(args.steps // 2, 3), min(args.warmup, 2), world)
+            self.host_all_arrays_ms = 1e3 * el_all / max(args.steps // 2, 3)
             el_host, lat_host, _ = timed(step_host, args.steps, args.warmup, world)
             elapsed_dev, lat_dev, out = timed(step, args.steps, min(args.warmup, 2), world, after)
             elapsed, lat = el_host, lat_host
@@ -479,7 +489,8 @@ class Bench:
             elapsed, lat, out = timed(step_deliver, args.steps, args.warmup, world, after)
             elapsed_dev, lat_dev = None, None
         res = dict(elapsed=elapsed, lat=lat, kern_ms=float(np.mean(kern_ms)), merge_ms=float(np.mean(merge_ms)), find_ms=float(np.mean(find_ms)),
-                   alg_bytes=float(np.mean(alg_bytes)), n_q=n_q, n_postings=int(self.csr["n_postings"]), elapsed_dev=elapsed_dev, lat_dev=lat_dev)
+                   alg_bytes=float(np.mean(alg_bytes)), n_q=n_q, n_postings=int(self.csr["n_postings"]), elapsed_dev=elapsed_dev, lat_dev=lat_dev,
+                   host_all_arrays_ms=getattr(self, "host_all_arrays_ms", None))
         if self.group is not None:
             # cross-check of the two exchange implementations (untimed): the C-ABI group's merged result == torch.distributed all-gather + merge
             ref = step_torch_exchange()
@@ -1332,10 +1343,15 @@ def main():
                                     "terms ranks log-uniform [8,2000], Topster 250, sort [_text_match desc, points desc], num_typos=0, prefix=false"
                                     % (args.n_docs, vocab, tpd, r["n_postings"], r["n_q"] * mult),
                         "parallelism": par,
-                        "results_to": ("HOST memory inside the timed steps (tsgpu_hits mem=HOST, pageable arrays: what the B1 seam hands to the server's Topster); "
+                        "results_to": ("HOST memory inside the timed steps (tsgpu_hits mem=HOST, pageable arrays: what the B1 seam hands to the server's Topster — the arrays "
+                                       "its shim requests for a query that sorts on _text_match: keys, scores[3], match_score_index, n_hits, num_matched, status; "
+                                       "value_host_all_arrays = text_match and vector_distance delivered as well); "
                                        "value_device_only = the same batch with device-resident outputs") if world == 1 else
                                       "device (every rank holds the merged result), then every rank copies the 1/N query slice it merged to pinned host memory over its own PCIe link, inside the timed steps"}
         kw["queries_with_hits"] = r.get("nonempty")
+        if r.get("host_all_arrays_ms"):
+            kw["value_host_all_arrays"] = r["n_q"] / (r["host_all_arrays_ms"] * 1e-3)
+            kw["ms_per_step_host_all_arrays"] = r["host_all_arrays_ms"]
         if r.get("elapsed_dev"):
             kw["value_device_only"] = mult * r["n_q"] * args.steps / r["elapsed_dev"]       # outputs left in HBM: the single-launch form the roofline / rocprof durations refer to
             kw["ms_per_step_device_only"] = 1e3 * r["elapsed_dev"] / args.steps
@@ -1457,7 +1473,7 @@ def main():
             "value": hd["value"], "unit": "queries/s", "n_gpus": world, "steps": hd["steps"], "warmup": args.warmup, "ms_per_step": hd["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32/i64" if head == "keyword" else "f32",
             "data": "synthetic", "config": hd["config"], "p50_ms_per_batch": hd["p50_ms_per_batch"]}
-    for k in ("queries_with_hits", "value_device_only", "ms_per_step_device_only", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "exchange_check", "replicas", "replicas_strong", "concurrency",
+    for k in ("queries_with_hits", "value_device_only", "ms_per_step_device_only", "value_host_all_arrays", "ms_per_step_host_all_arrays", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "exchange_check", "replicas", "replicas_strong", "concurrency",
               "uncached", "general_kernels", "fused_hits_per_batch", "parity_fp32_scan", "batch_sweep", "variants", "hnsw", "rerank_hybrid_matches"):
         if k in hd:
             line[k] = hd[k]

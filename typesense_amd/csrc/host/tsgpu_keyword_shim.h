@@ -38,7 +38,11 @@ int search_across_fields_gpu(const KeywordShimArgs& a, TopsterT* topster, std::v
     tsgpu_hits h;
     h.mem = TSGPU_MEM_HOST;
     h.k_stride = K;
-    h.keys = keys.data(); h.scores = scores.data(); h.text_match = text_match.data(); h.vector_distance = vdist.data();
+    // KV::text_match_score = scores[match_score_index] whenever _text_match is one of the sort keys (src/index.cpp:5541-5544), and a keyword
+    // KV keeps its default vector_distance: neither array is requested then — a quarter of the bytes a large batch sends across PCIe
+    bool sorts_on_text_match = false;
+    for (uint32_t s = 0; s < a.query.n_sort; s++) sorts_on_text_match = sorts_on_text_match || a.query.sort[s].kind == TSGPU_SORT_TEXT_MATCH;
+    h.keys = keys.data(); h.scores = scores.data(); h.text_match = sorts_on_text_match ? nullptr : text_match.data(); h.vector_distance = nullptr;
     h.match_score_index = msi.data(); h.n_hits = &n_hits; h.num_matched = &num_matched; h.status = &status; h.search_cutoff = &cutoff;
     // the matched ids come back as a list that belongs to THIS call (tsgpu_keyword_search_batch_ids): request threads share the
     // context, and the library may have coalesced this call with other threads' calls
@@ -49,7 +53,7 @@ int search_across_fields_gpu(const KeywordShimArgs& a, TopsterT* topster, std::v
     if (topster != nullptr) {
         for (uint32_t i = 0; i < n_hits; i++) {
             KV kv(a.query_index, keys[i], keys[i], msi[i], &scores[(size_t)i * 3]);
-            kv.text_match_score = text_match[i];
+            kv.text_match_score = sorts_on_text_match ? (msi[i] >= 0 ? scores[(size_t)i * 3 + (size_t)msi[i]] : 0) : text_match[i];
             topster->add(&kv);
         }
     }

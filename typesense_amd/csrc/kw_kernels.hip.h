@@ -763,7 +763,8 @@ __device__ inline ScoredHit score_hit(const IndexView& ix, const KwQueryDev& q, 
 // compute_aggregated_score for several query_by fields: pos[t * KW_MAX_FIELDS + f] = position of found token t in field f's list, or
 // KW_NONE. Per field, the tokens it holds for this document (query order) are scored together; the fields are folded by match_type.
 // tokens_found = tokens present in at least one field (query_len of src/index.cpp:5265-5268).
-template <int TMAX>
+// ARR = false: no query of the launch has a string[] field (the host knows) — the instantiation without the per-element scorer.
+template <int TMAX, bool ARR = true>
 __device__ inline uint64_t agg_score_mf(const IndexView& ix, const KwQueryDev& q, const KwQueryMF& mf, const uint32_t (&pos)[TMAX * KW_MAX_FIELDS],
                                         uint32_t tokens_found, uint32_t& off_words) {
     const uint32_t T = q.n_lists;
@@ -787,11 +788,11 @@ __device__ inline uint64_t agg_score_mf(const IndexView& ix, const KwQueryDev& q
             }
         }
         if (n_present == 0) continue;                     // field holds none of the tokens for this document (:5298-5300)
-        agg_add(st, q.match_type, mf.is_array[f] ? field_match_score_array<TMAX>(q, runs, n_present) : field_match_score<TMAX>(q, runs, n_present), mf.weight[f]);
+        agg_add(st, q.match_type, (ARR && mf.is_array[f]) ? field_match_score_array<TMAX>(q, runs, n_present) : field_match_score<TMAX>(q, runs, n_present), mf.weight[f]);
     }
     return agg_finish(st, q, tokens_found);
 }
-template <int TMAX>
+template <int TMAX, bool ARR = true>
 __device__ inline ScoredHit score_hit_mf(const IndexView& ix, const KwQueryDev& q, const KwQueryMF& mf, uint32_t seq_id,
                                          const uint32_t (&pos)[TMAX * KW_MAX_FIELDS]) {
     uint32_t off_words = 0;
@@ -804,7 +805,7 @@ __device__ inline ScoredHit score_hit_mf(const IndexView& ix, const KwQueryDev& 
         for (int f = 0; f < KW_MAX_FIELDS; f++) any = any || pos[t * KW_MAX_FIELDS + f] != KW_NONE;
         if ((uint32_t)t >= q.n_required && (uint32_t)t < q.n_lists && any) tokens_found++;
     }
-    const uint64_t agg = agg_score_mf<TMAX>(ix, q, mf, pos, tokens_found, off_words);
+    const uint64_t agg = agg_score_mf<TMAX, ARR>(ix, q, mf, pos, tokens_found, off_words);
     return sort_scores(ix, q, seq_id, agg, off_words);
 }
 
@@ -943,7 +944,7 @@ __device__ inline void kw_score_stage(KwSmem<TMAX, CAP, MF, S2, false, SCORE>& s
             uint32_t pos[NP];
 #pragma unroll
             for (int k = 0; k < NP; k++) pos[k] = sm.qf_pos[k][t];
-            if constexpr (MF) h = score_hit_mf<TMAX>(ix, q, ix.mf[q.mf_index], seq_id, pos);
+            if constexpr (MF) h = score_hit_mf<TMAX, !PLAIN>(ix, q, ix.mf[q.mf_index], seq_id, pos);     // (PLAIN multi-field launches: no string[] field either)
             else {
 #if defined(TSGPU_EXP) && TSGPU_EXP == 6
                 h.s0 = (int64_t)(seq_id * 2654435761u); h.s1 = (int64_t)pos[0] + pos[TMAX - 1]; h.s2 = 0; h.text_match = h.s0; h.off_words = 1;

@@ -94,10 +94,11 @@ void launch_search_mf_cap(int cap, hipStream_t s, uint32_t n_work, const IndexVi
 struct MfOrderedCount { const uint32_t* jobs = nullptr; uint32_t n_jobs = 0, table_first = 0; const KwWorkItem* work_all = nullptr; KwPartials part_all{}; };
 template <int TMAX>
 void launch_find_score_mf(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w, const KwPartials& part,
-                          const uint32_t* aux, uint32_t* ids_out, uint32_t* hits, const uint64_t* hit_off, const MfOrderedCount& oc) {
+                          const uint32_t* aux, uint32_t* ids_out, uint32_t* hits, const uint64_t* hit_off, const MfOrderedCount& oc, bool plain = false) {
     hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 512, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     if (oc.n_jobs) hipLaunchKernelGGL((kw_mf_ordered_count_kernel<TMAX>), dim3(oc.n_jobs), dim3(64), 0, s, q, oc.work_all, oc.part_all, hits, hit_off, oc.table_first, aux, oc.jobs);
-    if (cap == 512) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    if (cap == 512 && plain && !ids_out && !oc.n_jobs) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, true, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+    else if (cap == 512) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     else hipLaunchKernelGGL((kw_score_kernel<TMAX, 1024, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
 }
 
@@ -380,6 +381,7 @@ struct Plan {
     bool any_deadline = false;                            // some query carries a deadline: stamp the batch start, collect cutoff flags
     bool any_s2 = false;              // some query has a third sort key
     bool any_aux = false;             // some query has filter ids or excluded ids (else the score kernel's PLAIN instantiation serves the batch)
+    bool any_array = false;           // some multi-field query has a string[] field
     std::vector<uint32_t> aux;
     std::vector<int32_t> status, cutoff;
     uint32_t max_k = 1;
@@ -462,7 +464,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
         std::vector<uint32_t> aux, ordered_count_q; std::vector<KwQueryMF> mf; std::vector<KwWorkItem> flat_work;
         uint64_t fbits_words = 0, ids_total = 0, list_bytes = 0;
         uint32_t max_k = 0, n_numeric_sort_q = 0;
-        bool any_deadline = false, any_s2 = false, any_aux = false;
+        bool any_deadline = false, any_s2 = false, any_aux = false, any_array = false;
     };
     auto plan_range = [&](uint32_t lo, uint32_t hi, PlanAcc& A) {
         A.flat_work.reserve((size_t)(hi - lo) * 4);
@@ -633,7 +635,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
                 mfq.driver_token = td;
                 mfq.second_token = KW_NONE;             // the required token with the next fewest postings: merged block-wise by the find kernel
                 for (uint32_t t = 0; t < q.n_required; t++) if (t != td && (mfq.second_token == KW_NONE || len_of[t] < len_of[mfq.second_token])) mfq.second_token = t;
-                for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.is_array[f] = f < in.n_fields && snap.field_is_array.at(in.field_ids[f]) ? 1 : 0;
+                for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) { mfq.is_array[f] = f < in.n_fields && snap.field_is_array.at(in.field_ids[f]) ? 1 : 0; if (mfq.is_array[f]) A.any_array = true; }
                 for (uint32_t f = 0; f < (uint32_t)KW_MAX_FIELDS; f++) mfq.weight[f] = f < in.n_fields ? in.field_weights[f] : 0;
                 if (k + KW_THREADS > 1024) { unsupported("topster_size with several query_by fields"); continue; }
                 q.mf_index = (uint32_t)A.mf.size();
@@ -737,7 +739,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
             P.ordered_count_q.insert(P.ordered_count_q.end(), A.ordered_count_q.begin(), A.ordered_count_q.end());
             P.ids_total += A.ids_total; P.fbits_words += A.fbits_words; P.list_bytes += A.list_bytes;
             P.max_k = std::max(P.max_k, A.max_k); P.n_numeric_sort_q += A.n_numeric_sort_q;
-            P.any_deadline = P.any_deadline || A.any_deadline; P.any_s2 = P.any_s2 || A.any_s2; P.any_aux = P.any_aux || A.any_aux;
+            P.any_deadline = P.any_deadline || A.any_deadline; P.any_s2 = P.any_s2 || A.any_s2; P.any_aux = P.any_aux || A.any_aux; P.any_array = P.any_array || A.any_array;
         }
     }
     // work tables: one launch per kernel flavour (single-field T<=3, single-field generic, multi-field T<=3, multi-field generic);
@@ -1390,7 +1392,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
                             oc.jobs = (const uint32_t*)(dplan + at_oc[tb]); oc.n_jobs = (uint32_t)oc_jobs[tb].size(); oc.table_first = (uint32_t)first;
                             oc.work_all = dw; oc.part_all = part;
                         }
-                        launch_find_score_mf<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, L.d_hits.as<uint32_t>(), hoff_dev + a, oc);
+                        launch_find_score_mf<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, L.d_hits.as<uint32_t>(), hoff_dev + a, oc, !P.any_aux && !P.any_array);
                     }
                     else {
                         const bool mark = !find_marked;

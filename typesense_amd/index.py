@@ -91,12 +91,15 @@ class Hits:
         self.status = np.zeros(n_queries, np.int32)
         self.search_cutoff = np.zeros(n_queries, np.int32)
 
-    def c_struct(self):
+    def c_struct(self, seam_arrays_only=False):
+        """seam_arrays_only: what the B1 shim asks for when the query sorts on _text_match (typesense_amd/csrc/host/tsgpu_keyword_shim.h) — keys, scores
+        and match_score_index; KV::text_match_score is scores[match_score_index] and KV::vector_distance its default there, so those two
+        arrays are not requested (NULL: the library does not deliver them)."""
         h = B.HitsC()
         h.mem = B.MEM_HOST
         h.k_stride = self.k_stride
-        h.keys, h.scores, h.text_match = self.keys.ctypes.data, self.scores.ctypes.data, self.text_match.ctypes.data
-        h.vector_distance, h.match_score_index = self.vector_distance.ctypes.data, self.match_score_index.ctypes.data
+        h.keys, h.scores, h.text_match = self.keys.ctypes.data, self.scores.ctypes.data, (None if seam_arrays_only else self.text_match.ctypes.data)
+        h.vector_distance, h.match_score_index = (None if seam_arrays_only else self.vector_distance.ctypes.data), self.match_score_index.ctypes.data
         h.n_hits, h.num_matched = self.n_hits.ctypes.data, self.num_matched.ctypes.data
         h.status, h.search_cutoff = self.status.ctypes.data, self.search_cutoff.ctypes.data
         return h
