@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtsgpu.so")
+LIB_PATH = os.environ.get("TSGPU_LIB") or os.path.join(HERE, "libtsgpu.so")     # (TSGPU_LIB: a variant build under typesense_amd/variants/, tools/ experiments only)
 
 TSGPU_OK, ERR_INVALID, ERR_NOT_FOUND, ERR_DEADLINE, ERR_DEVICE, ERR_UNSUPPORTED, ERR_NO_MEMORY = 0, 400, 404, 408, 500, 501, 507
 MEM_HOST, MEM_DEVICE = 0, 1

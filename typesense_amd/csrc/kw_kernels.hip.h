@@ -84,7 +84,10 @@ static const int KW_PIPE_WORDS = 4;         // dwords per thread of the register
 #ifndef TSGPU_KW_FIND_TILE_WORDS
 #define TSGPU_KW_FIND_TILE_WORDS 3584
 #endif
-static const int KW_MF_TILE_WORDS = 4096;   // the multi-field find kernel's tile (one run of up to 16 slabs)
+#ifndef TSGPU_KW_MF_TILE_WORDS
+#define TSGPU_KW_MF_TILE_WORDS 2048
+#endif
+static const int KW_MF_TILE_WORDS = TSGPU_KW_MF_TILE_WORDS;   // the multi-field find kernel's tile: 2048 (default: 23 KB of LDS = 7 workgroups per CU, 17.5 -> 16.2 ms on the two-field bench leg; wider runs are probed), 3072 or 4096
 static const int KW_FIND_PIPE_WORDS = TSGPU_KW_FIND_PIPE_WORDS;
 static const int KW_FIND_TILE_WORDS = TSGPU_KW_FIND_TILE_WORDS;
 static const int KW_TILE_WORDS = TSGPU_KW_TILE_WORDS;   // LDS tile of PACKED second-list ids per round (8 KB ~ 20 blocks of 12-bit ids); multiple of 256
@@ -1660,7 +1663,7 @@ __device__ inline void kw_mf_merge_field(SM& sm, const IndexView& ix, const List
         if (W <= 2u * KW_THREADS) kw_glds_slabs<2>(lane_src, lds_wave_base);
         else {
             kw_glds_slabs<8>(lane_src, lds_wave_base);
-            if constexpr (TILE > 8u * KW_THREADS) { if (W > 8u * KW_THREADS) kw_glds_slabs<8>(lane_src + 8 * KW_THREADS, lds_wave_base + 8 * KW_THREADS); }
+            if constexpr (TILE > 8u * KW_THREADS) { if (W > 8u * KW_THREADS) kw_glds_slabs<(int)(TILE / KW_THREADS) - 8>(lane_src + 8 * KW_THREADS, lds_wave_base + 8 * KW_THREADS); }
         }
     }
     if (t < 64) { sm.bw_last[0][t] = win.last_id; sm.bw_first[0][t] = win.first_id; sm.bw_woff[0][t] = win.ids_woff - w_begin; sm.bw_nb[0][t] = win.n_ids_bits; }
