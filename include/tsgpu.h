@@ -257,7 +257,9 @@ typedef struct tsgpu_kw_query {
 
 /* Results, structure-of-arrays, slot q*k_stride+i = i-th best hit of query q in Topster::sort() order
  * (descending (scores[0],scores[1],scores[2],key), include/topster.h:146-149,469-473). The host shim turns
- * each slot into KV{key, distinct_key=key, scores, match_score_index, text_match_score} and calls topster->add. */
+ * each slot into KV{key, distinct_key=key, scores, match_score_index, text_match_score} and calls topster->add.
+ * With mem = HOST the arrays text_match, vector_distance, match_score_index, num_matched and search_cutoff are OPTIONAL (NULL: not delivered;
+ * text_match equals scores[match_score_index] whenever _text_match is a sort key); device outputs need every array. */
 typedef struct tsgpu_hits {
     int mem;                 /* tsgpu_mem_kind of every pointer below */
     uint32_t k_stride;       /* slots per query (>= the largest topster_size in the batch) */
