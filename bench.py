@@ -486,7 +486,32 @@ class Bench:
                     pin["num_matched"][:q1 - q0].copy_(o[3][q0:q1].to(torch.int64), non_blocking=True)
                     torch.cuda.synchronize()
                 return o
-            elapsed, lat, out = timed(step_deliver, args.steps, args.warmup, world, after)
+            if self.group is not None and self.sharded:
+                # the same delivery INSIDE the library (group option kw_own_slice_only): after the all-to-all and the slice merge a rank copies the
+                # slice it merged straight to its host arrays — no all-gather of the merged lists, no second pass over the result in python.
+                # (The full, replicated result is produced once more after the timed loop for the in-run checks below.)
+                ph = dict(keys=torch.zeros((n_q, FETCH_SIZE), dtype=torch.int64).pin_memory(), scores=torch.zeros((n_q, FETCH_SIZE, 3), dtype=torch.int64).pin_memory(),
+                          n_hits=torch.zeros(n_q, dtype=torch.int32).pin_memory(), num_matched=torch.zeros(n_q, dtype=torch.int64).pin_memory(),
+                          status=torch.zeros(n_q, dtype=torch.int32).pin_memory())
+                phs = B.HitsC()
+                phs.mem, phs.k_stride = B.MEM_HOST, FETCH_SIZE
+                phs.keys, phs.scores, phs.n_hits, phs.num_matched, phs.status = (ph[k].data_ptr() for k in ("keys", "scores", "n_hits", "num_matched", "status"))
+                self.group.set_option("kw_own_slice_only", 1)
+                try:
+                    def step_own_slice():
+                        self.group.keyword_search_batch_raw(arr, n_q, FETCH_SIZE, phs)
+                        return None
+                    elapsed, lat, _ = timed(step_own_slice, args.steps, args.warmup, world, after)
+                finally:
+                    self.group.set_option("kw_own_slice_only", 0)
+                out = step()
+                mine = slice(q0, q1)
+                self.own_slice_ok = bool(q1 <= q0 or (torch.equal(ph["n_hits"][mine].to(torch.int64), out[2][mine].to(torch.int64).cpu()) and
+                                                    torch.equal(ph["num_matched"][mine], out[3][mine].to(torch.int64).cpu()) and
+                                                    torch.equal(ph["keys"][mine][torch.arange(FETCH_SIZE)[None, :] < ph["n_hits"][mine][:, None]],
+                                                                out[0][mine, :FETCH_SIZE].cpu()[torch.arange(FETCH_SIZE)[None, :] < ph["n_hits"][mine][:, None]])))
+            else:
+                elapsed, lat, out = timed(step_deliver, args.steps, args.warmup, world, after)
             elapsed_dev, lat_dev = None, None
         res = dict(elapsed=elapsed, lat=lat, kern_ms=float(np.mean(kern_ms)), merge_ms=float(np.mean(merge_ms)), find_ms=float(np.mean(find_ms)),
                    alg_bytes=float(np.mean(alg_bytes)), n_q=n_q, n_postings=int(self.csr["n_postings"]), elapsed_dev=elapsed_dev, lat_dev=lat_dev,
@@ -500,7 +525,10 @@ class Bench:
                 and bool(torch.equal(out[0][:, :FETCH_SIZE][live], ref[0][:, :FETCH_SIZE][live])) and bool(torch.equal(out[1][:, :FETCH_SIZE][live], ref[1][:, :FETCH_SIZE][live]))
             gt = self.group.timings()
             res["exchange_check"] = {"group_equals_torch_exchange": bool(same), "local_ms": gt.local_ms, "exchange_merge_ms": gt.exchange_merge_ms,
-                                     "exchange_bytes_per_gpu": int(gt.exchange_bytes_per_member)}
+                                     "exchange_bytes_per_gpu": int(gt.exchange_bytes_per_member),
+                                     "timed_form": "kw_own_slice_only: all-to-all + slice merge, every rank delivers the slice it merged to its own host (no all-gather of the merged lists)"
+                                                   if getattr(self, "own_slice_ok", None) is not None else "full result on every rank + per-rank slice copy",
+                                     "own_slice_delivery_equals_full_result": getattr(self, "own_slice_ok", None)}
         keys = out[0].cpu().numpy().astype(np.uint64)
         scores = out[1].cpu().numpy()
         n_hits = out[2].cpu().numpy()

@@ -542,6 +542,10 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
  * the 1/G of the batch it merges), a slice merge per member, and in-place ncclAllGathers of the merged lists (rank form / device outputs;
  * the local form with host outputs delivers every slice over its own GPU's PCIe link); 0: ONE ncclAllGather of the per-GPU top-k
  * blocks and a full merge. Identical results; at 8 GPUs and 10 000 queries 56 MB instead of 224 MB arrive per GPU. */
+/* "kw_own_slice_only" = 1 (rank form, slice exchange): a rank delivers only the query slice it merged — queries [rank * per, (rank + 1) * per),
+ * per = ceil(n_queries / n_ranks) — into its output arrays at those queries' slots; the all-gather of the merged lists is skipped (at 8
+ * GPUs and 10 000 queries 35 MB instead of 70 MB arrive per GPU). For deployments where every rank serves its own callers, and what the local
+ * form does with host outputs anyway. Every rank must set it (it is part of the call's agreed signature). */
 /* "replicas" = 1: every member mirrors the WHOLE collection (small corpora: 10M documents = 6 GB of postings + 46 GB of vectors fit a
  * 288 GB GPU several times); a batch is cut into G query slices, member i answers slice i, the slices are delivered / replicated as
  * above — no merge, and the per-batch fixed costs (planning, launches) shrink with the slice. Default 0 = doc-range shards. */

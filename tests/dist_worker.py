@@ -100,6 +100,17 @@ def main():
             grp.set_option("kw_exchange_slices", slices)
             tag = "%s/slices=%d" % (cut_name, slices)
             check_keyword("keyword " + tag, grp.keyword_search_batch(qs, K, k_stride=K))
+        # kw_own_slice_only: a rank delivers the slice of the batch it merged (queries [rank * per, (rank + 1) * per)) and nothing else
+        grp.set_option("kw_exchange_slices", 1)
+        grp.set_option("kw_own_slice_only", 1)
+        h = grp.keyword_search_batch(qs, K, k_stride=K)
+        grp.set_option("kw_own_slice_only", 0)
+        per = (len(qs) + world - 1) // world
+        for i in range(rank * per, min(len(qs), (rank + 1) * per)):
+            ref = H.oracle_keyword(orc, qs[i])
+            m = int(h.n_hits[i])
+            check("own slice %s q%d" % (cut_name, i), h.status[i] == 0 and m == ref.keys.size and np.array_equal(h.keys[i, :m], ref.keys) and
+                  np.array_equal(h.scores[i, :m], ref.scores) and int(h.num_matched[i]) == int(ref.num_keyword_matches))
         dm, lm, cm = grp.vec_knn_batch(1, Q, k_vec)
         check_knn("knn " + cut_name, dm, lm, cm)
         allow = np.arange(3, n_docs, 5, dtype=np.uint32)

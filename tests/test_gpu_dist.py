@@ -31,6 +31,7 @@ def test_two_rank_shards_equal_unsharded_collection():
     assert r["replicas"]["value"] > 0 and r["value"] > 0
     assert r["distributed"]["group_transport"] == "host" and "tsgpu_group" in r["config"]["parallelism"], r["distributed"]
     assert r["exchange_check"]["group_equals_torch_exchange"] is True, r.get("exchange_check")
+    assert r["exchange_check"]["own_slice_delivery_equals_full_result"] is True, r.get("exchange_check")      # the timed form: every rank delivers the slice it merged
 
 
 @pytest.mark.gpu

@@ -102,6 +102,9 @@ struct tsgpu_group {
     std::vector<Member> m;               // local form: all members; rank form: the one this process owns
     std::mutex mu;                       // one batch at a time per group
     bool replicas = false;               // every member mirrors the WHOLE collection: the batch is cut into query slices (option "replicas")
+    bool own_slice_only = false;         // rank form, slice exchange (option "kw_own_slice_only"): a rank delivers only the slice of the batch it merged — queries
+                                         // [rank * per, (rank + 1) * per), per = ceil(n_queries / n_ranks) — into its output arrays (at those queries' slots); no all-gather of
+                                         // the merged lists. What a deployment with one request router per rank needs, and what the local form does with host outputs.
     int kw_slices = 1;                   // (2 = also with one member: exercises the collectives on a single GPU) keyword exchange: all-to-all of query slices + slice merge + all-gather of the merged lists (false: one all-gather, full merge on every rank)
     tsgpu_host_collectives coll{};       // TSGPU_XCHG_HOST
     tsgpu_group_timings tm{};
@@ -282,6 +285,17 @@ int deliver_slices(tsgpu_group* g, const tsgpu_hits* out, uint32_t n_queries, ui
     const KwArr arrs[] = {{&Member::o_keys, out->keys, KS * 8}, {&Member::o_scores, out->scores, KS * 24}, {&Member::o_tm, out->text_match, KS * 8},
                           {&Member::o_nh, out->n_hits, 4}, {&Member::o_nm, out->num_matched, 8}, {&Member::o_st, out->status, 4}};
     int rc;
+    if (!g->local && g->own_slice_only) {                 // rank form: this rank's merged slice, nothing else (the other slots of `out` stay untouched)
+        Member& mem = g->m[0];
+        (void)hipSetDevice(mem.ctx->device);
+        const uint32_t q0 = g->rank * per;
+        if (q0 < n_queries) {
+            const uint32_t nq = std::min<uint32_t>(per, n_queries - q0);
+            for (const KwArr& a : arrs) if (a.dst)
+                if ((rc = copy_out((char*)a.dst + (size_t)q0 * a.elem, (const char*)(mem.*(a.buf)).p + (size_t)q0 * a.elem, (size_t)nq * a.elem, out->mem, mem.ctx->stream))) return rc;
+        }
+        return TSGPU_OK;
+    }
     if ((g->n > 1 || force) && !(g->local && to_host)) {
         const bool grouped = g->transport == TSGPU_XCHG_RCCL && g->m.size() > 1;
         if (grouped) { int r2 = rccl()->GroupStart(); if (r2) return rccl_fail("ncclGroupStart", r2); }
@@ -540,7 +554,7 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
             if (n_pad > n_queries) TSGPU_HIP_TRY(hipMemsetAsync(mem.send.as<uint64_t>() + (size_t)n_queries * qw, 0, (size_t)(n_pad - n_queries) * qw * 8, mem.ctx->stream));   // padding records: no hits
             return group_pack_keyword(mem.ctx, &loc, n_queries, k, words, mem.send.as<uint64_t>(), mem.ctx->stream);
         });
-        if ((rc = agree(g, rc, call_signature({2, n_queries, k, out->k_stride, hits_mask(out), (uint64_t)slices})))) return rc;
+        if ((rc = agree(g, rc, call_signature({2, n_queries, k, out->k_stride, hits_mask(out), (uint64_t)slices, (uint64_t)g->own_slice_only})))) return rc;
         const double t_local = ms_since(t0);
         const auto t1 = std::chrono::steady_clock::now();
         // 2) the exchange, 3) the exact merge, staged per member in arrays of n_pad queries (stride = the caller's k_stride)
@@ -573,7 +587,7 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
         // everything this call enqueued on the members' streams is awaited here
         for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
         g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1);
-        g->tm.exchange_bytes_per_member = slices ? (uint64_t)per * qw * 8 * (g->n - 1) + (uint64_t)per * (KS * (32 + (out->text_match ? 8 : 0)) + 16) * (g->n - 1) : (uint64_t)n_queries * qw * 8 * (g->n - 1);
+        g->tm.exchange_bytes_per_member = slices ? (uint64_t)per * qw * 8 * (g->n - 1) + ((!g->local && g->own_slice_only) ? 0ull : (uint64_t)per * (KS * (32 + (out->text_match ? 8 : 0)) + 16) * (g->n - 1)) : (uint64_t)n_queries * qw * 8 * (g->n - 1);
         return ok();
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: host allocation failed"); }
       catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: could not start a member thread"); }
@@ -584,6 +598,7 @@ int tsgpu_group_set_option(tsgpu_group* g, const char* name, int64_t value) {
     std::lock_guard<std::mutex> lk(g->mu);
     if (!strcmp(name, "kw_exchange_slices")) { g->kw_slices = value == 2 ? 2 : (value != 0); return ok(); }
     if (!strcmp(name, "replicas")) { g->replicas = value != 0; return ok(); }
+    if (!strcmp(name, "kw_own_slice_only")) { g->own_slice_only = value != 0; return ok(); }
     return fail(TSGPU_ERR_NOT_FOUND, std::string("tsgpu_group_set_option: unknown option ") + name);
 }
 
