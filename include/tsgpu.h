@@ -134,9 +134,11 @@ int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
  * after the other (default 2; 0 = always fold; identical results);
  * "kw_zero_copy_max_queries" = keyword batches with host output and at most this many queries have their merge kernel write the
  * result image straight into the lane's pinned host buffer, no device-to-host copy (default 256; 0 = always copy);
- * "kw_host_split_queries" (default 1000) / "kw_host_split_first_pct" (default 70) = a keyword batch with HOST output of at least four
- * times kw_host_split_queries queries is served in three slices (75 % / 12.5 % / 12.5 %) on two lanes by two host threads: a slice's
- * hit arrays cross PCIe while the next slice computes (10 000 queries: 11.2 -> 10.0 ms; identical results; 0 = never);
+ * "kw_host_split_queries" (default 1000) / "kw_host_split_first_pct" (default 85) / "kw_host_split_tail_slices" (default 1; 2) /
+ * "kw_host_split_device_plan" (default 1) = a keyword batch with HOST output of at least four times kw_host_split_queries queries is
+ * served in two slices (85 % / 15 %), each on a lane and host thread of its own, enqueued in slice order: the large slice — planned on the
+ * device — runs first, and its hit arrays cross PCIe while the small slice computes (10 000 queries: 8.1 -> 7.5 ms; identical results;
+ * kw_host_split_queries = 0: never);
  * "kw_timing_min_queries" = keyword batches below this many queries record no phase events (tsgpu_last_timings then reports 0 ms
  * for them; default 64: the four marker packets cost a 1-query call ~20 us of its ~80; 0 = always record; coalesced rounds never
  * record);

@@ -868,8 +868,8 @@ def test_parallel_planning_of_a_batch_gives_the_serial_plan(pair, pair3):
 
 
 def test_host_output_batch_served_in_slices_equals_the_single_batch(pair):
-    """a large batch with host output is served in slices on two lanes by two host threads (kw_split_host: slice i's copies run while
-    slice i + 1 computes); status codes, hits, counts and cut-off flags must equal the unsliced batch's, a failing query fails alone"""
+    """a large batch with host output is served in slices, each on a lane and host thread of its own, enqueued in slice order (kw_split_host:
+    slice i's copies run while slice i + 1 computes); status codes, hits, counts and cut-off flags must equal the unsliced batch's, a failing query fails alone"""
     orc, g, _ = pair
     rng = np.random.default_rng(99)
     sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
@@ -883,10 +883,18 @@ def test_host_output_batch_served_in_slices_equals_the_single_batch(pair):
     whole = g.keyword_search_batch(qs, k_stride=250)
     try:
         g.set_option("kw_host_split_first_pct", 50)
-        g.set_option("kw_host_split_queries", 7)                                       # 26 queries, then two slices of the other 27
+        g.set_option("kw_host_split_queries", 7)                                       # 26 queries + the other 27 (default: one tail slice)
+        r0 = g.counter("kw_batches")
+        two = g.keyword_search_batch(qs, k_stride=250)
+        assert g.counter("kw_batches") - r0 == 2
+        g.set_option("kw_host_split_tail_slices", 2)                                   # 26 queries, then two slices of the other 27
         r0 = g.counter("kw_batches")
         cut = g.keyword_search_batch(qs, k_stride=250)
         assert g.counter("kw_batches") - r0 == 3
+        assert np.array_equal(two.status, cut.status) and np.array_equal(two.n_hits, cut.n_hits) and np.array_equal(two.num_matched, cut.num_matched)
+        for i in range(len(qs)):
+            n = int(cut.n_hits[i])
+            assert np.array_equal(two.keys[i, :n], cut.keys[i, :n]) and np.array_equal(two.scores[i, :n], cut.scores[i, :n])
         assert np.array_equal(cut.status, whole.status) and (whole.status != 0).sum() == 1
         assert np.array_equal(cut.search_cutoff, whole.search_cutoff)
         for i in range(len(qs)):
@@ -898,7 +906,8 @@ def test_host_output_batch_served_in_slices_equals_the_single_batch(pair):
                 H.assert_hits_equal(cut, i, H.oracle_keyword(orc, qs[i]), "sliced host batch")
     finally:
         g.set_option("kw_host_split_queries", 1000)
-        g.set_option("kw_host_split_first_pct", 70)
+        g.set_option("kw_host_split_first_pct", 85)
+        g.set_option("kw_host_split_tail_slices", 1)
 
 
 @pytest.mark.parametrize("chunk_opt,host_threads", [(0, 1), (4, 3)])
@@ -936,10 +945,14 @@ def test_device_side_planner_equals_the_host_planner_and_the_oracle(pair, chunk_
             assert np.array_equal(dev.text_match[i, :n], host.text_match[i, :n]) and np.array_equal(dev.match_score_index[i, :n], host.match_score_index[i, :n]), i
             H.assert_hits_equal(dev, i, H.oracle_keyword(orc, q), "device plan")
         assert dev.n_hits.sum() > 1000
-        # the sliced host delivery (three chained slices: planned on the host while the previous slice runs)
+        # the sliced host delivery (chained slices, enqueued in slice order): the first, large slice is planned on the device, the others on the host
         g.set_option("kw_host_split_queries", 8)
         sl = g.keyword_search_batch(qs, k_stride=250)
-        assert g.counter("kw_device_plans") == n0 + 1
+        assert g.counter("kw_device_plans") == n0 + 2
+        g.set_option("kw_host_split_device_plan", 0)
+        sl0 = g.keyword_search_batch(qs, k_stride=250)
+        g.set_option("kw_host_split_device_plan", 1)
+        assert g.counter("kw_device_plans") == n0 + 2 and np.array_equal(sl0.keys, sl.keys) and np.array_equal(sl0.n_hits, sl.n_hits)
         for i in range(len(qs)):
             n = int(host.n_hits[i])
             assert sl.n_hits[i] == n and np.array_equal(sl.keys[i, :n], host.keys[i, :n]) and np.array_equal(sl.scores[i, :n], host.scores[i, :n]) and sl.num_matched[i] == host.num_matched[i]

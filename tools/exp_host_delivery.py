@@ -28,11 +28,12 @@ arr = (B.KwQueryC * n_q)()
 for i in range(n_q):
     T.KwQuery(qtok[i], sort=sort, topster_size=250).fill(arr[i])
 hh = T.Hits(n_q, 250)
-hs = hh.c_struct()
+hs = hh.c_struct(seam_arrays_only=True)
 ref = None
 for cfg in [(0, 50)] + [tuple(int(x) for x in c.split(":")) for c in os.environ.get("CFGS", "1000:75,1000:72,1000:70,1000:78,1000:75").split(",")] + [(0, 50)]:
     g.set_option("kw_host_split_queries", cfg[0])
     g.set_option("kw_host_split_first_pct", cfg[1])
+    g.set_option("kw_host_split_device_plan", cfg[2] if len(cfg) > 2 else 1)
     g.keyword_search_batch_raw(arr, n_q, hs)
     ts = []
     for _ in range(12):
@@ -42,5 +43,5 @@ for cfg in [(0, 50)] + [tuple(int(x) for x in c.split(":")) for c in os.environ.
     chk = (int(hh.n_hits.sum()), int(hh.num_matched.sum()), int(hh.keys[:, 0][hh.n_hits > 0].sum()), int(hh.scores[:, 0, 1][hh.n_hits > 0].sum()))
     ref = ref or chk
     ts = np.array(ts) * 1e3
-    print("min slice %5d first %2d%%: median %.2f ms (min %.2f max %.2f) -> %.0f q/s  same results: %s" % (cfg[0], cfg[1], np.median(ts), ts.min(), ts.max(), n_q / np.median(ts) * 1e3, chk == ref), flush=True)
+    print("min slice %5d first %2d%% dp %s: median %.2f ms (min %.2f max %.2f) -> %.0f q/s  same results: %s" % (cfg[0], cfg[1], cfg[2] if len(cfg) > 2 else 1, np.median(ts), ts.min(), ts.max(), n_q / np.median(ts) * 1e3, chk == ref), flush=True)
 g.close()

@@ -22,6 +22,9 @@ for n_q in [int(x) for x in os.environ.get("KW_BATCHES", "10000,1000,100").split
     for i in range(n_q):
         T.KwQuery(qtok[i], sort=sort, topster_size=250).fill(arr[i])
     dev, hs = bench.device_hits(torch, n_q, 250)
+    if os.environ.get("KW_HOST"):                       # host outputs (the sliced delivery): the arrays the B1 shim requests
+        hh = T.Hits(n_q, 250)
+        hs = hh.c_struct(seam_arrays_only=True)
     for opts in json.loads(os.environ.get("KW_SWEEP", '[{"kw_chunk_blocks":64}]')):
         for k, v in opts.items():
             g.set_option(k, v)

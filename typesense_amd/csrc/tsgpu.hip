@@ -250,6 +250,8 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_iddir_min_ids")) { ctx->kw_iddir_min_ids = value < 0 ? 0 : value; ctx->commit_force_full = true; return ok(); }
     if (!strcmp(name, "kw_iddir_density_div")) { ctx->kw_iddir_density_div = value < 1 ? 1 : value; ctx->commit_force_full = true; return ok(); }
     if (!strcmp(name, "kw_iddir_budget_mb")) { ctx->kw_iddir_budget_mb = value < 0 ? 0 : value; ctx->commit_force_full = true; return ok(); }
+    if (!strcmp(name, "kw_host_split_tail_slices")) { ctx->kw_host_split_tail_slices = value >= 2 ? 2 : 1; return ok(); }
+    if (!strcmp(name, "kw_host_split_device_plan")) { ctx->kw_host_split_device_plan = value != 0; return ok(); }
     if (!strcmp(name, "kw_host_split_first_pct")) { ctx->kw_host_split_first_pct = (uint32_t)std::min<int64_t>(95, std::max<int64_t>(5, value)); return ok(); }
     if (!strcmp(name, "kw_host_split_queries")) { ctx->kw_host_split_queries = (uint32_t)std::max<int64_t>(0, value); return ok(); }
     if (!strcmp(name, "kw_zero_copy_max_queries")) { ctx->kw_zero_copy_max_queries = (uint32_t)std::max<int64_t>(0, value); return ok(); }
@@ -919,7 +921,20 @@ struct LaneLock {                                     // holds one execution lan
     }
     ~LaneLock() { L->mu.unlock(); ctx->lane_dispenser.release(index, ctx->n_lanes); }
 };
-struct SliceChain { std::mutex m; hipEvent_t last = nullptr; };      // enqueue order under the mutex = execution order of the slices' kernels
+// Slices of a sliced host-output batch: they are ENQUEUED in slice order (turn), whichever host thread finishes planning first — the large first
+// slice has to run first, so that its device-to-host copy runs under the small ones' kernels (left to the planning race, the small second slice was
+// usually enqueued ahead of it: kernel timeline in profiles/r04) — and a slice's kernels start when the previous slice's have finished (last).
+struct SliceChain {
+    std::mutex m; std::condition_variable cv; uint32_t turn = 0; hipEvent_t last = nullptr;
+    // RAII for one slice: wait_turn() before enqueueing; the destructor passes the turn on (also on every error path, after waiting for it)
+    struct Turn {
+        SliceChain* c; uint32_t idx; bool waited = false; std::unique_lock<std::mutex> lk;
+        Turn(SliceChain* c_, uint32_t i) : c(c_), idx(i) {}
+        void wait_turn() { if (!c) return; lk = std::unique_lock<std::mutex>(c->m); c->cv.wait(lk, [&] { return c->turn == idx; }); waited = true; }
+        void pass() { if (!c) return; if (!waited) wait_turn(); c->turn = idx + 1; c = nullptr; lk.unlock(); }
+        ~Turn() { if (c) { SliceChain* cc = c; pass(); cc->cv.notify_all(); } }
+    };
+};
 struct BatchOpts {
     bool wildcard = false;
     bool keep_ids = false;                            // emit matched ids into the lane's id arena
@@ -927,6 +942,7 @@ struct BatchOpts {
     std::vector<int32_t>* cutoff_host = nullptr;      // ... and the per-query search_cutoff flags
     tsgpu_id_lists* id_lists = nullptr;               // when set: the matched ids of every query, gathered + downloaded (implies keep_ids)
     bool record_last = true;                          // remember the id segments for the legacy tsgpu_result_ids API
+    uint32_t chain_index = 0;                         // ... this slice's position in it
     SliceChain* chain = nullptr;                      // sliced host-output batch: this slice's kernels start when the previous slice's have finished (a
                                                       // device-side wait; the previous slice's device-to-host copies run meanwhile: two slices never compute at once)
     bool alias_out = false;                           // host output through the lane's pinned image: point `out`'s arrays INTO the image instead of copying
@@ -1083,7 +1099,10 @@ static int kw_split_host(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t
         uint32_t first = (uint32_t)((uint64_t)n_queries * ctx->kw_host_split_first_pct / 100);
         first = std::min(std::max(first, ctx->kw_host_split_queries), n_queries - ctx->kw_host_split_queries);
         start.push_back(first);
-        const uint32_t rest = n_queries - first, parts = rest >= 2 * ctx->kw_host_split_queries ? 2 : 1;      // (measured: two tail slices; more cost more than they hide)
+        // ONE tail slice (round 4, kernel timeline in profiles/r04/exp_host_delivery_r04.txt): every extra launch has its own tail of long work items —
+        // three slices kept the GPU busy for 8.4 ms against 6.3 ms for one launch — and with the slices enqueued in order the large one's copy
+        // hides under ONE small slice's kernels: 85 % + 15 % = 7.5 ms per 10 000 queries (70 / 15 / 15: 8.0 ms; unsliced: 8.1 ms)
+        const uint32_t rest = n_queries - first, parts = ctx->kw_host_split_tail_slices >= 2 && rest >= 2 * ctx->kw_host_split_queries ? 2 : 1;
         for (uint32_t i = 1; i <= parts; i++) start.push_back(first + (uint32_t)((uint64_t)rest * i / parts));
     }
     const uint32_t n_slices = (uint32_t)start.size() - 1;
@@ -1108,12 +1127,14 @@ static int kw_split_host(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t
             BatchOpts bo;
             bo.record_last = false;
             bo.chain = &chain;
+            bo.chain_index = si;
             int rc;
             { LaneLock ll(ctx); rc = kw_batch_on_lane(ctx, *ll.L, queries + a, n, &h, bo); }
             if (rc != TSGPU_OK) { std::lock_guard<std::mutex> lk(err_mu); if (first_rc == TSGPU_OK) { first_rc = rc; first_err = tls_error(); } }
         }
     };
-    try { ctx->split_pool.run(job, 1); } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_batch: host allocation failed"); }
+    // one host thread (and lane) per slice: every slice is planned at once, enqueued in order, and waits for / copies out its own results
+    try { ctx->split_pool.run(job, std::min<uint32_t>(n_slices, (uint32_t)ctx->n_lanes) - 1); } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_batch: host allocation failed"); }
     if (first_rc != TSGPU_OK) return fail(first_rc, first_err);
     return ok();
 }
@@ -1175,6 +1196,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
     const bool keep_ids = bo.keep_ids || bo.id_lists != nullptr;
     std::vector<int32_t>* status_host = bo.status_host;
     hipStream_t s = L.stream;
+    SliceChain::Turn chain_turn(bo.chain, bo.chain_index);     // (passes the turn on when this slice leaves, whatever happens to it)
     try {
         static const bool host_timing = getenv("TSGPU_HOST_TIMING") != nullptr;      // diagnostics: host phases of the call on stderr
         const uint64_t t_enter = now_us();
@@ -1185,7 +1207,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         // host threads; any other shape — and anything the device planner hands back — goes through plan_batch()
         // (not for the chained slices of a sliced host delivery: there the host plans slice i + 1 WHILE slice i runs, and a planning kernel on the
         //  second lane would wait behind the running find kernel for a place on the chip — measured: 10.05 -> 10.18 ms per 10 000 queries)
-        if (!wildcard && !keep_ids && !bo.vflat && !bo.chain && ctx->kw_two_kernels && ctx->kw_device_plan_min_queries && n_queries >= ctx->kw_device_plan_min_queries) {
+        if (!wildcard && !keep_ids && !bo.vflat && (!bo.chain || (bo.chain_index == 0 && ctx->kw_host_split_device_plan)) && ctx->kw_two_kernels && ctx->kw_device_plan_min_queries && n_queries >= ctx->kw_device_plan_min_queries) {
             if ((rc = plan_batch_device(ctx, L, snap, queries, n_queries, P, DP, s))) return rc;
             if (DP.on) ctx->kw_device_plans.fetch_add(1); else ctx->kw_device_plan_fallbacks.fetch_add(1);
         }
@@ -1339,9 +1361,8 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         }
 
         // ---- launch ----
-        std::unique_lock<std::mutex> chain_lk;
         if (bo.chain) {
-            chain_lk = std::unique_lock<std::mutex>(bo.chain->m);
+            chain_turn.wait_turn();
             if (bo.chain->last) TSGPU_HIP_TRY(hipStreamWaitEvent(s, bo.chain->last, 0));
         }
         const uint64_t t_uploaded = now_us();
@@ -1429,7 +1450,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         if (bo.vflat) hipLaunchKernelGGL(kw_vflat_distance_kernel, dim3(n_queries), dim3(KW_THREADS), 0, s, dq, daux, o);     // KV::vector_distance of the hits
         if (timing) TSGPU_HIP_TRY(hipEventRecord(L.ev[2], s));
         TSGPU_HIP_TRY(hipGetLastError());
-        if (bo.chain) { TSGPU_HIP_TRY(hipEventRecord(L.ev_chain, s)); bo.chain->last = L.ev_chain; chain_lk.unlock(); }
+        if (bo.chain) { TSGPU_HIP_TRY(hipEventRecord(L.ev_chain, s)); bo.chain->last = L.ev_chain; SliceChain* cc = bo.chain; chain_turn.pass(); cc->cv.notify_all(); }
         const uint64_t t_launched = now_us();
 
         // ---- results ----

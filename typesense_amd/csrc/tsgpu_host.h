@@ -488,7 +488,9 @@ struct tsgpu_ctx {
     bool kw_sort_work = true;                        // lay the work table out heaviest query first
     uint32_t kw_host_split_queries = 1000;           // a host-output keyword batch of at least FOUR times this many queries is served in slices on two lanes: a slice's
                                                      // results cross PCIe while the next one computes (0 = never); no slice is smaller than this
-    uint32_t kw_host_split_first_pct = 70;           // ... the first slice's share of the batch (the rest: two equal slices)
+    bool kw_host_split_device_plan = true;           // ... whose first (large) slice is planned on the device (kw_plan.hip.h) when it qualifies
+    uint32_t kw_host_split_tail_slices = 1;          // slices behind the first one (1 or 2)
+    uint32_t kw_host_split_first_pct = 85;           // ... the first slice's share of the batch (the rest: two equal slices)
     uint32_t kw_zero_copy_max_queries = 256;         // host-output keyword batches up to this many queries: the merge kernel writes into pinned host memory (0 = always copy)
     uint32_t kw_timing_min_queries = 64;             // keyword batches below this many queries skip the phase events (tsgpu_timings reports 0 ms for them)
     uint32_t kw_merge_select_min = 2;                // queries with at least this many partial lists are merged by selection (kw_select_partials: tree merge); 0 = always fold
