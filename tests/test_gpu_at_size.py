@@ -63,11 +63,18 @@ def test_config2_10m_docs_512_queries_topster_and_counts_equal_the_oracle():
     for i in range(64):
         n = int(hits.n_hits[i])
         assert int(h2.n_hits[i]) == n and np.array_equal(h2.keys[i, :n], hits.keys[i, :n]) and np.array_equal(h2.scores[i, :n], hits.scores[i, :n])
-    # the host-output batch served in three chained slices on two lanes (kw_split_host: 384 + 64 + 64 queries here) gives the same lists
-    g.set_option("kw_host_split_queries", 64)
+    # the host-output batch served in chained slices, enqueued in order, the first planned on the device (kw_split_host: 435 + 77 queries by default,
+    # 435 + 38 + 39 with two tail slices) gives the same lists
+    g.set_option("kw_host_split_queries", 32)
+    g.set_option("kw_device_plan_min_queries", 256)
     b0 = g.counter("kw_batches")
     h3 = g.keyword_search_batch([T.KwQuery(q, sort=SORT, topster_size=250) for q in qtok], k_stride=250)
-    assert g.counter("kw_batches") - b0 == 3 and (h3.status == 0).all()
+    assert g.counter("kw_batches") - b0 == 2 and (h3.status == 0).all()
+    g.set_option("kw_host_split_tail_slices", 2)
+    b0 = g.counter("kw_batches")
+    h4 = g.keyword_search_batch([T.KwQuery(q, sort=SORT, topster_size=250) for q in qtok], k_stride=250)
+    assert g.counter("kw_batches") - b0 == 3 and (h4.status == 0).all()
+    assert np.array_equal(h4.n_hits, h3.n_hits) and np.array_equal(h4.num_matched, h3.num_matched) and np.array_equal(h4.keys, h3.keys)
     assert np.array_equal(h3.n_hits, hits.n_hits) and np.array_equal(h3.num_matched, hits.num_matched)
     for i in range(n_q):
         n = int(hits.n_hits[i])
