@@ -158,18 +158,42 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
     BlockIds mA = meta(wi.blk_begin), mB = meta(wi.blk_begin + 1), mC = meta(wi.blk_begin + 2), mD = meta(wi.blk_begin + 3);
     uint32_t araw0 = load_id_raw(mA, t), araw1 = load_id_raw(mB, t);
     Plan P = make_plan(mA.first_id, wi.blk_begin + 1 < wi.blk_end ? mB.last_id : mA.last_id);
-    uint32_t q1n = 0, qfn = 0, par = 0;
+    uint32_t q1n = 0, qfn = 0, par = 0, qh = 0;         // survivor queue: a RING of KW_QCAP entries, head qh, q1n queued; qfn = complete hits written (all uniform, in registers)
     KW_PROF_DECL
+    static_assert((KW_QCAP & (KW_QCAP - 1)) == 0 && KW_QCAP >= 2 * KW_THREADS, "ring of at least 255 left-over + 256 new entries");
 
-    auto drain_q1 = [&]() {                              // (uniform) third.. lists for full batches of stage-1 survivors
-        if (q1n >= (uint32_t)KW_THREADS) {
-            __syncthreads();
-            if (t == 0) sm.q1_cnt = q1n;
-            __syncthreads();
-            while (sm.q1_cnt >= (uint32_t)KW_THREADS) kw_probe_rest_stage<TMAX, 512, true, true>(sm, ix, q, KW_THREADS, hits);
-            q1n = sm.q1_cnt;
+    // third.. lists for the first n_take queued survivors (one per thread, queue order = ascending id), complete hits to the work item's segment.
+    // Two barriers per batch — the appends become visible / the ordered compaction — and no queue shuffle: the head just advances. (The shared
+    // kw_probe_rest_stage keeps its counters in LDS and moves the left-over entries down: six barriers per batch.)
+    auto probe_batch = [&](uint32_t n_take) {
+        __syncthreads();                                 // (appends of every wave are visible; nobody is still reading the entries a previous batch freed)
+        bool ok = t < n_take;
+        uint32_t id = 0, v[TMAX];
+#pragma unroll
+        for (int k = 0; k < TMAX; k++) v[k] = 0;
+        if (ok) {
+            const uint32_t e = (qh + t) & (uint32_t)(KW_QCAP - 1);
+            id = sm.q1_id[e];
+            const uint32_t p0 = sm.q1_p0[e], p1 = sm.q1_p1[e];
+#pragma unroll
+            for (int k = 0; k < TMAX; k++) { if (k == q.probe_order[0]) v[k] = p0; if (k == q.probe_order[1]) v[k] = p1; }
+            for (uint32_t s = 2; s < T && ok; s++) {
+                const uint32_t tok = q.probe_order[s];
+                uint32_t p;
+                ok = probe_list(ix, ix.lists[q.list[tok]], id, p);
+#pragma unroll
+                for (int k = 0; k < TMAX; k++) if ((uint32_t)k == tok) v[k] = p;
+            }
         }
+        uint32_t total;
+        const uint32_t my = block_compact1(ok, sm.wave_cnt2[par], total);
+        par ^= 1;
+        if (ok) kw_hit_store<TMAX>(hits, qfn + my, id, v);
+        qfn += total;
+        qh = (qh + n_take) & (uint32_t)(KW_QCAP - 1);
+        q1n -= n_take;
     };
+    auto drain_q1 = [&]() { while (q1n >= (uint32_t)KW_THREADS) probe_batch(KW_THREADS); };   // (uniform) full batches only
 
     for (uint32_t b = wi.blk_begin, it = 0; b < wi.blk_end; b += 2, it++) {
         if (P.mode == 3) break;
@@ -352,12 +376,12 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
         if (T >= 3) { q1n = 0; } else
 #endif
         if (T >= 3) {
-            if (ok0) { const uint32_t slot = q1n + base0 + lo0; sm.q1_id[slot] = id0; sm.q1_p0[slot] = pa0; sm.q1_p1[slot] = p10; }
+            if (ok0) { const uint32_t slot = (qh + q1n + base0 + lo0) & (uint32_t)(KW_QCAP - 1); sm.q1_id[slot] = id0; sm.q1_p0[slot] = pa0; sm.q1_p1[slot] = p10; }
             q1n += tot0;
             KW_PROF(7)
             drain_q1();                                  // (the queue holds 512 entries: 255 left over + one block's survivors)
             KW_PROF(11)
-            if (ok1) { const uint32_t slot = q1n + base1 + lo1; sm.q1_id[slot] = id1; sm.q1_p0[slot] = pa1; sm.q1_p1[slot] = p11; }
+            if (ok1) { const uint32_t slot = (qh + q1n + base1 + lo1) & (uint32_t)(KW_QCAP - 1); sm.q1_id[slot] = id1; sm.q1_p0[slot] = pa1; sm.q1_p1[slot] = p11; }
             q1n += tot1;
             KW_PROF(7)
             drain_q1();
@@ -382,11 +406,8 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
         if (b + 5 >= abase + 64 && b + 4 < wi.blk_end) { abase = b + 4; awin = load_awin(abase); }   // (every 30 pairs: the one exposed load left)
         mA = mC; mB = mD; mC = meta(b + 4); mD = meta(b + 5); araw0 = araw0n; araw1 = araw1n;   // (consumed in the middle of the next iteration)
     }
-    __syncthreads();
-    if (t == 0) { if (T >= 3) sm.q1_cnt = q1n; else sm.qf_cnt = qfn; }
-    __syncthreads();
-    if (T >= 3) while (sm.q1_cnt > 0) kw_probe_rest_stage<TMAX, 512, true, true>(sm, ix, q, sm.q1_cnt < KW_THREADS ? sm.q1_cnt : KW_THREADS, hits);
-    if (t == 0) part.cnt[blockIdx.x] = sm.qf_cnt;              // hits handed to kw_score_kernel
+    if (T >= 3) while (q1n > 0) probe_batch(q1n < (uint32_t)KW_THREADS ? q1n : (uint32_t)KW_THREADS);
+    if (t == 0) part.cnt[blockIdx.x] = qfn;                    // hits handed to kw_score_kernel
     KW_PROF(9)
     KW_PROF_FLUSH(ix.prof)
 }
