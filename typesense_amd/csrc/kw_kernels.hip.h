@@ -1925,16 +1925,32 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
         __syncthreads();
     };
 
+    // driver-list metadata in a lane-resident window (as kw_find2_kernel: a per-block uniform load is a memory round trip exposed per block), and the
+    // NEXT block's ids requested at the top of this block's stage 1 (their latency runs beside the tile DMA's instead of in front of it)
+    const uint32_t lane_a = t & 63;
+    uint32_t abase = wi.blk_begin;
+    auto load_awin = [&](uint32_t base) -> BlockIds { const uint32_t bb = base + lane_a; return biA[bb < wi.blk_end ? bb : wi.blk_end - 1]; };
+    BlockIds awin = load_awin(abase);
+    auto meta_a = [&](uint32_t bb) -> BlockIds {        // bb uniform; abase <= min(bb, blk_end - 1) < abase + 64
+        const int j = (int)((bb < wi.blk_end ? bb : wi.blk_end - 1) - abase);
+        BlockIds m;
+        m.first_id = (uint32_t)__builtin_amdgcn_readlane((int)awin.first_id, j); m.last_id = (uint32_t)__builtin_amdgcn_readlane((int)awin.last_id, j);
+        m.ids_woff = (uint32_t)__builtin_amdgcn_readlane((int)awin.ids_woff, j); m.n_ids_bits = (uint32_t)__builtin_amdgcn_readlane((int)awin.n_ids_bits, j);
+        return m;
+    };
+    auto load_raw = [&](const BlockIds& m) -> uint32_t {
+        const uint32_t n = m.n_ids_bits & 0xFFFF, s2 = t < n ? t : 0;
+        const uint32_t* __restrict__ w = idwA + m.ids_woff;
+        return (m.n_ids_bits >> 16) == 16 ? (uint32_t)((const uint16_t*)w)[s2] : w[s2];
+    };
+    BlockIds mA = meta_a(wi.blk_begin), mN = meta_a(wi.blk_begin + 1);
+    uint32_t araw = load_raw(mA);
     for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
         if (((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, qi, &sm.stop)) break;
-        const BlockIds mA = biA[b];
         const uint32_t m_n = mA.n_ids_bits & 0xFFFF;
         bool ok = t < m_n;
-        uint32_t id = 0xFFFFFFFFu;
-        if (ok) {
-            const uint32_t* __restrict__ w = idwA + mA.ids_woff;
-            id = mA.first_id + ((mA.n_ids_bits >> 16) == 16 ? (uint32_t)((const uint16_t*)w)[t] : w[t]);
-        }
+        const uint32_t id = ok ? mA.first_id + araw : 0xFFFFFFFFu;
+        const uint32_t araw_n = b + 1 < wi.blk_end ? load_raw(mN) : 0u;
         // stage 1 — the SECOND token (fewest postings after the driver's), every field, every candidate of the block: block-level merge through the LDS tile
         uint32_t ps[KW_MAX_FIELDS];
 #pragma unroll
@@ -1966,6 +1982,8 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
         }
         q1n += total;
         if (q1n >= (uint32_t)KW_THREADS) { __syncthreads(); stage2(KW_THREADS); }      // (the queue holds 512: < 256 left over + one block's survivors)
+        if (b + 3 >= abase + 64 && b + 2 < wi.blk_end) { abase = b + 2; awin = load_awin(abase); }
+        mA = mN; mN = meta_a(b + 2); araw = araw_n;
     }
     __syncthreads();
     while (q1n > 0) stage2(q1n < (uint32_t)KW_THREADS ? q1n : (uint32_t)KW_THREADS);
