@@ -971,7 +971,7 @@ def test_device_side_planner_equals_the_host_planner_and_the_oracle(pair, chunk_
             g.set_option(name, v)
 
 
-@pytest.mark.parametrize("chunk,two_kernels", [(64, 1), (1, 1), (64, 0)])
+@pytest.mark.parametrize("chunk,two_kernels", [(64, 1), (1, 1), (64, 0), (256, 1)])
 def test_multi_field_block_merge_windows_wide_runs_and_exhaustion(chunk, two_kernels):
     """kw_mf_merge_field (the multi-field find kernel's block-level merge of a driver block with the SECOND token's lists): extreme length
     ratios in two fields — runs of 1, ~10, ~40 and > 64 blocks under one driver block (window re-centring, runs wider than the window / the
@@ -1002,7 +1002,8 @@ def test_multi_field_block_merge_windows_wide_runs_and_exhaustion(chunk, two_ker
     f2 = [(0, 15), (1, 9)]
     qs = [T.KwQuery([1, 2], fields=f2, sort=sort, topster_size=250), T.KwQuery([2, 1, 3], fields=f2, sort=sort, topster_size=250),
           T.KwQuery([3, 2], fields=f2, sort=sort, topster_size=100), T.KwQuery([3, 1], fields=[(1, 4), (0, 4)], sort=sort, topster_size=250, match_type=B.SUM_SCORE),
-          T.KwQuery([1], fields=f2, sort=sort, topster_size=250), T.KwQuery([2, 3], fields=f2, sort=sort, topster_size=250, filter_ids=np.arange(0, n_docs, 3, dtype=np.uint32))]
+          T.KwQuery([1], fields=f2, sort=sort, topster_size=250), T.KwQuery([2, 3], fields=f2, sort=sort, topster_size=250, filter_ids=np.arange(0, n_docs, 3, dtype=np.uint32)),
+          T.KwQuery([2], fields=f2, sort=sort, topster_size=250)]       # a driver list of ~230 blocks: with chunk = 64 / 256 a work item reloads its lane-resident metadata window
     hits = g.keyword_search_batch(qs, k_stride=250)
     assert (hits.status == 0).all() and hits.n_hits[0] >= 250
     for i, q in enumerate(qs):
