@@ -21,19 +21,22 @@ for lib in libs:
         g.vec_upsert_device(1, labels.data_ptr(), x.data_ptr(), b - a)
         del x
     for nq in batches:
-        Q = synth.random_vectors(nq, dim, seed=4, device="cuda")
-        d = torch.zeros((nq, k), dtype=torch.float32, device="cuda"); l = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
-        c = torch.zeros(nq, dtype=torch.int32, device="cuda")
-        ms, sc = [], []
-        for it in range(4):
-            try:
-                g.vec_knn_batch_raw(1, Q.data_ptr(), B.MEM_DEVICE, nq, k, d.data_ptr(), l.data_ptr(), c.data_ptr(), B.MEM_DEVICE)
-            except Exception as e:          # ablation builds return nonsense candidates: only the scan time matters
-                pass
-            tm = g.timings()
-            if it: ms.append(tm.vec_knn_ms); sc.append(tm.vec_scan_ms)
-        m = float(np.mean(ms)); sm = float(np.mean(sc))
-        print(json.dumps(dict(lib=os.path.basename(lib or "default"), n_q=nq, knn_ms=m, scan_ms=sm, scan_tflops=tm.vec_flops / max(sm, 1e-9) / 1e9,
-                              scan_GBs=tm.vec_scan_bytes / max(sm, 1e-9) / 1e6, chk=int(l.sum().item()))), flush=True)
+        for opts in json.loads(os.environ.get("VEC_SWEEP", "[{}]")):                   # e.g. [{"vec_sample_tiles":8192},{"vec_sample_tiles":4096}]
+            for name, val in opts.items():
+                g.set_option(name, val)
+            Q = synth.random_vectors(nq, dim, seed=4, device="cuda")
+            d = torch.zeros((nq, k), dtype=torch.float32, device="cuda"); l = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+            c = torch.zeros(nq, dtype=torch.int32, device="cuda")
+            ms, sc = [], []
+            for it in range(4):
+                try:
+                    g.vec_knn_batch_raw(1, Q.data_ptr(), B.MEM_DEVICE, nq, k, d.data_ptr(), l.data_ptr(), c.data_ptr(), B.MEM_DEVICE)
+                except Exception as e:          # ablation builds return nonsense candidates: only the scan time matters
+                    pass
+                tm = g.timings()
+                if it: ms.append(tm.vec_knn_ms); sc.append(tm.vec_scan_ms)
+            m = float(np.mean(ms)); sm = float(np.mean(sc))
+            print(json.dumps(dict(lib=os.path.basename(lib or "default"), opts=opts, n_q=nq, knn_ms=m, scan_ms=sm, scan_tflops=tm.vec_flops / max(sm, 1e-9) / 1e9,
+                                  scan_GBs=tm.vec_scan_bytes / max(sm, 1e-9) / 1e6, chk=int(l.sum().item()))), flush=True)
     g.close()
     torch.cuda.empty_cache()
