@@ -393,7 +393,13 @@ int build_id_directories(tsgpu_ctx* ctx, Snapshot& s, const Snapshot* cur, const
     for (ListDesc& d : s.h_lists) d.dir_slot = 0;
     s.dir_pool.reset(); s.dir_of.clear();
     if (ctx->kw_iddir_min_ids <= 0 || ctx->kw_iddir_budget_mb <= 0 || !s.ar || s.h_lists.empty()) return TSGPU_OK;
-    const uint64_t thr = std::max<uint64_t>((uint64_t)ctx->kw_iddir_min_ids, num_docs / (uint64_t)ctx->kw_iddir_density_div);
+    // density is judged over the id range this context's lists cover: a doc-range shard keeps GLOBAL seq_ids, so its lists are as dense
+    // inside [lo, hi) as the unsharded ones are inside [0, num_docs) — with num_docs as the yardstick an eighth-shard would give directories to
+    // an eighth of the lists that deserve one
+    uint64_t id_lo = ~0ull, id_hi = 0;
+    for (const ListDesc& d : s.h_lists) if (d.n_ids) { id_lo = std::min<uint64_t>(id_lo, d.first_id); id_hi = std::max<uint64_t>(id_hi, d.last_id); }
+    const uint64_t id_span = id_hi >= id_lo ? std::min<uint64_t>(id_hi - id_lo + 1, num_docs ? num_docs : ~0ull) : num_docs;
+    const uint64_t thr = std::max<uint64_t>((uint64_t)ctx->kw_iddir_min_ids, id_span / (uint64_t)ctx->kw_iddir_density_div);
     std::vector<uint32_t> want;
     for (size_t h = 0; h < s.h_lists.size(); h++) if (s.h_lists[h].n_ids >= thr && s.h_lists[h].n_blocks) want.push_back((uint32_t)h);
     if (want.empty()) return TSGPU_OK;
