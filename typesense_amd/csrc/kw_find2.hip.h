@@ -158,6 +158,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
     BlockIds mA = meta(wi.blk_begin), mB = meta(wi.blk_begin + 1), mC = meta(wi.blk_begin + 2), mD = meta(wi.blk_begin + 3);
     uint32_t araw0 = load_id_raw(mA, t), araw1 = load_id_raw(mB, t);
     Plan P = make_plan(mA.first_id, wi.blk_begin + 1 < wi.blk_end ? mB.last_id : mA.last_id);
+    const bool has_deadline = q.deadline_rem_us != 0;   // (read once: inside the loop the compiler re-reads the LDS copy of the query — and waits for it — every iteration)
     uint32_t q1n = 0, qfn = 0, par = 0, qh = 0;         // survivor queue: a RING of KW_QCAP entries, head qh, q1n queued; qfn = complete hits written (all uniform, in registers)
     KW_PROF_DECL
     static_assert((KW_QCAP & (KW_QCAP - 1)) == 0 && KW_QCAP >= 2 * KW_THREADS, "ring of at least 255 left-over + 256 new entries");
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
         KW_PROF(8)
         kw_glds_wait();                                  // this pair's tile (and driver ids) have landed
         KW_PROF(1)
-        if ((it & 7) == 0 && kw_out_of_time(ix, q, wi.query, &sm.stop)) break;
+        if (has_deadline && (it & 7) == 0 && kw_out_of_time(ix, q, wi.query, &sm.stop)) break;
         const bool two = b + 1 < wi.blk_end;
         const uint32_t n0 = mA.n_ids_bits & 0xFFFF, n1 = two ? (mB.n_ids_bits & 0xFFFF) : 0u;
         bool ok0 = t < n0, ok1 = t < n1;

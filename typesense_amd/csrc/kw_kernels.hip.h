@@ -1943,10 +1943,11 @@ __global__ __launch_bounds__(KW_THREADS) void kw_search_mf_kernel(IndexView ix, 
         const uint32_t* __restrict__ w = idwA + m.ids_woff;
         return (m.n_ids_bits >> 16) == 16 ? (uint32_t)((const uint16_t*)w)[s2] : w[s2];
     };
+    const bool has_deadline = q.deadline_rem_us != 0;
     BlockIds mA = meta_a(wi.blk_begin), mN = meta_a(wi.blk_begin + 1);
     uint32_t araw = load_raw(mA);
     for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
-        if (((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, qi, &sm.stop)) break;
+        if (has_deadline && ((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, qi, &sm.stop)) break;
         const uint32_t m_n = mA.n_ids_bits & 0xFFFF;
         bool ok = t < m_n;
         const uint32_t id = ok ? mA.first_id + araw : 0xFFFFFFFFu;
