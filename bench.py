@@ -448,7 +448,7 @@ class Bench:
             alg_bytes.append(tm.kw_algorithmic_bytes)
 
         # HEADLINE = what the B1 seam returns: the hit arrays delivered to HOST memory inside the timed steps (1 GPU: tsgpu_hits mem=HOST,
-        # pageable arrays, the library's three chained slices; N GPUs: every rank copies the 1/N query slice it merged over its own PCIe
+        # pageable arrays, the library's two chained slices; N GPUs: every rank copies the 1/N query slice it merged over its own PCIe
         # link, as the local form of tsgpu_group does). The device-resident step is timed as well (`value_device_only`): it is the
         # single-launch form the roofline / rocprof durations refer to.
         if world == 1:
@@ -1384,7 +1384,7 @@ def main():
             kw["value_device_only"] = mult * r["n_q"] * args.steps / r["elapsed_dev"]       # outputs left in HBM: the single-launch form the roofline / rocprof durations refer to
             kw["ms_per_step_device_only"] = 1e3 * r["elapsed_dev"] / args.steps
         find_rx, score_rx = r"kw_find2_kernel<3>|kw_search_kernel<3, 512, true, true>", r"kw_score_kernel"
-        # (max over the dispatches = the full 10 000-query launch: the profiled command also runs the host-delivery leg, whose three slices
+        # (max over the dispatches = the full 10 000-query launch: the profiled command also runs the host-delivery leg, whose slices
         #  are smaller launches of the same kernels and would dilute an average)
         traffic = pmc_traffic([find_rx, score_rx], ["pmc_kw_fetch.txt", "pmc_kw_s5_fetch.txt"], field="max")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

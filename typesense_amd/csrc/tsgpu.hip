@@ -1087,13 +1087,14 @@ extern "C" {
 // Entry of every keyword / wildcard search call. Small host-output calls from concurrent request threads (the reference calls
 // the seam once per query from its thread pool, src/index.cpp:3488, src/http_server.cpp:827-832) are coalesced by the
 // micro-batcher into one launch; everything else takes a lane directly.
-// A LARGE batch whose results go to host memory: 112 MB of hit arrays per 10 000 queries cross PCIe, ~2.4 ms behind a 9 ms step when
-// the copies start after the last kernel. Served in slices on two lanes by two host threads instead: a slice computes while the previous
-// one's copies run (the slices' kernels are chained by events: sharing the chip, each would take twice as long and they would reach
-// their copies together). Results are those of separate calls per slice = those of one call (a query never influences another).
+// A LARGE batch whose results go to host memory: 82-112 MB of hit arrays per 10 000 queries cross PCIe, 1.5-2 ms behind a 6.3 ms step when
+// the copies start after the last kernel. Served in slices instead, each on a lane and host thread of its own: a slice computes while the
+// previous one's copies run (the slices are ENQUEUED in slice order and their kernels chained by events: sharing the chip, each would take
+// twice as long and they would reach their copies together). Results are those of separate calls per slice = those of one call (a query
+// never influences another).
 static int kw_split_host(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out) {
     // slice sizes: the LAST slice's copies are the part nothing overlaps, and every slice costs launch tails + copy calls: a large
-    // first slice (kw_host_split_first_pct of the batch), the rest in two equal slices (one if they would be smaller than kw_host_split_queries)
+    // first slice (kw_host_split_first_pct of the batch), the rest in one slice (two with kw_host_split_tail_slices = 2)
     std::vector<uint32_t> start(1, 0);
     {
         uint32_t first = (uint32_t)((uint64_t)n_queries * ctx->kw_host_split_first_pct / 100);
