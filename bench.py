@@ -66,6 +66,10 @@ def parse():
                          "knn = the round-2 stand-in derived on the GPU from exact k-NN lists (typesense_amd/hnsw_synth.py)")
     ap.add_argument("--hnsw-batch", type=int, default=4096, help="queries per step of the HNSW leg")
     ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--dry", default=None, metavar="FULL_LINE.json",
+                    help="no GPU work: read a FULL bench record (e.g. profiles/r04/bench_default_final.json) and print what the driver would get "
+                         "for it — the compact last line (CPU-tier test of the output contract)")
+    ap.add_argument("--detail-out", default=None, help="where the full record goes (default: gpurun_out/bench_detail.json under the repo root)")
     ap.add_argument("--opt", action="append", default=[], help="tsgpu_set_option name=value (repeatable), e.g. vec_prefilter=0")
     ap.add_argument("--dist-mode", default="shards", choices=["shards", "replicas"],
                     help="N>1: shards (default, BASELINE config 5) = the collection cut into N doc ranges, every GPU scores the whole batch on its "
@@ -1302,8 +1306,149 @@ def line_common(args, world, value, elapsed, steps, lat):
             "p50_ms_per_batch": 1e3 * float(np.median(lat))}
 
 
+COMPACT_LIMIT = 6144            # bytes: the driver parsed 17 KB lines and lost a 20 KB one (round 4); the last stdout line stays far below either
+
+
+def _r(x, nd=4):
+    """floats to `nd` significant digits (the full-precision values are in the detail record)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (nd + 2, x))
+    return x
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and k in d and not isinstance(d[k], (dict, list))}
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def _parity_small(p):
+    """{checked, mismatches} of a parity object whatever its leg calls the counters."""
+    if not isinstance(p, dict):
+        return None
+    checked = next((p[k] for k in ("checked", "sets_checked", "queries_checked", "n_checked", "queries", "user_queries_checked") if k in p), None)
+    mism = next((p[k] for k in ("mismatches", "mismatched", "n_mismatch", "mismatched_queries") if k in p), None)
+    out = {"checked": checked, "mismatches": mism}
+    if "vs" in p:
+        out["vs"] = _short(p["vs"], 60)
+    return out
+
+
+def _roof_small(rf):
+    if not isinstance(rf, dict):
+        return None
+    out = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes_per_launch", "flops_per_launch",
+                     "algorithmic_frac", "touched_bytes_per_launch", "touched_frac", "unique_list_bytes", "l2_refetch", "hbm_frac", "mfma_frac", "counter"))
+    if "kernel" in rf:
+        out["kernel"] = _short(rf["kernel"], 72)
+    return out
+
+
+def _cpu_small(c):
+    if not isinstance(c, dict):
+        return None
+    out = _pick(c, ("value", "unit", "cores", "kind"))
+    if "sample" in c:
+        out["sample"] = _short(c["sample"], 110)
+    return out
+
+
+def _sub_small(o):
+    """a secondary config (vector / hybrid) reduced to what the contract asks of it."""
+    out = _pick(o, ("value", "unit", "ms_per_step", "p50_ms_per_batch", "steps"))
+    rf = o.get("roofline") or {}
+    out["roofline"] = _pick(rf, ("bound", "frac", "kernel_ms", "achieved", "peak", "unit"))
+    if rf.get("kernel") or rf.get("dominant_kernel"):
+        out["roofline"]["kernel"] = _short(rf.get("kernel") or rf.get("dominant_kernel"), 40)
+    if isinstance(o.get("cpu_baseline"), dict):
+        out["cpu_baseline"] = _pick(o["cpu_baseline"], ("value", "unit", "cores", "kind"))
+    if "parity" in o:
+        out["parity"] = _parity_small(o["parity"])
+    if isinstance(o.get("shard_parity"), dict):
+        out["shard_parity"] = _parity_small(o["shard_parity"])
+    return out
+
+
+def compact_line(full, detail_path=None):
+    """The LAST stdout line: the contract's keys + `roofline` + `cpu_baseline` + `parity`, `vector` / `hybrid` reduced to
+    {value, ms_per_step, roofline.frac, cpu_baseline.value, parity.mismatches}; everything else lives in the detail record."""
+    line = {k: _r(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                          "vs_baseline", "dtype", "data")}
+    cfg = full.get("config") or {}
+    line["config"] = {"workload": _short(cfg.get("workload", ""), 260), "parallelism": _short(cfg.get("parallelism", ""), 200),
+                      "results_to": _short(cfg.get("results_to", ""), 120)}
+    for k in ("p50_ms_per_batch", "queries_with_hits", "value_device_only", "ms_per_step_device_only", "speedup_vs_cpu_baseline"):
+        if k in full:
+            line[k] = _r(full[k])
+    line["roofline"] = _roof_small(full.get("roofline"))
+    iu = (full.get("roofline") or {}).get("issue_util")
+    if isinstance(iu, dict) and line["roofline"] is not None:
+        line["roofline"]["issue_util"] = _pick(iu, ("valu", "salu"))
+    line["cpu_baseline"] = _cpu_small(full.get("cpu_baseline"))
+    line["parity"] = _parity_small(full.get("parity"))
+    if isinstance(full.get("shard_parity"), dict):
+        line["shard_parity"] = _parity_small(full["shard_parity"])
+    for k in ("replicas", "replicas_strong"):
+        if isinstance(full.get(k), dict):
+            line[k] = _pick(full[k], ("value", "unit", "ms_per_step", "global_batch", "scaling"))
+    conc = full.get("concurrency")
+    if isinstance(conc, dict):
+        line["concurrency"] = {t: _pick(c, ("value", "p50_us", "p99_us")) for t, c in conc.items() if isinstance(c, dict)}
+    gk = full.get("general_kernels")
+    if isinstance(gk, dict):
+        line["general_kernels"] = {}
+        for name, o in gk.items():
+            if isinstance(o, dict):
+                e = _pick(o, ("value", "unit", "ms_per_step", "kernel_ms", "find_ms", "score_ms"))
+                if "parity" in o:
+                    e["parity"] = _parity_small(o["parity"])
+                line["general_kernels"][name] = e
+    for name in ("vector", "hybrid", "keyword"):
+        if isinstance(full.get(name), dict):
+            line[name] = _sub_small(full[name])
+    hn = (full.get("vector") or {}).get("hnsw") if isinstance(full.get("vector"), dict) else full.get("hnsw")
+    if isinstance(hn, dict):
+        line["hnsw"] = _pick(hn, ("value", "unit", "rows", "ef", "batch", "recall_at_100"))
+        line["hnsw"]["parity"] = "UNPINNED (hnswlib is not under /root/reference); traversal = the oracle's restatement"
+    if isinstance(full.get("distributed"), dict):
+        line["distributed"] = _pick(full["distributed"], ("backend", "world_size", "rccl", "mode", "group_transport"))
+    line["detail"] = detail_path
+    # the contract is a byte budget, not a hope: shed the optional objects, last added first, until the line fits
+    for k in ("hnsw", "general_kernels", "concurrency", "replicas", "replicas_strong", "keyword", "hybrid", "vector"):
+        if len(json.dumps(line)) <= COMPACT_LIMIT:
+            break
+        line.pop(k, None)
+    return line
+
+
+def emit(full, detail_out=None):
+    """Full record -> the detail file (+ one stderr line); compact record -> the last (and only) stdout line."""
+    path = detail_out or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    shown = None
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f)
+        shown = os.path.relpath(path, ROOT)
+    except OSError as e:
+        sys.stderr.write("bench.py: could not write the detail record to %s: %s\n" % (path, e))
+    sys.stderr.write("BENCH_DETAIL " + json.dumps(full) + "\n")
+    sys.stderr.flush()
+    sys.stdout.flush()
+    print(json.dumps(compact_line(full, shown)), flush=True)
+
+
 def main():
     args = parse()
+    if args.dry:
+        with open(args.dry) as f:
+            emit(json.load(f), args.detail_out or os.path.join("/tmp", "bench_detail_dry.json"))
+        return
     import torch
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU visible: bench.py measures the HIP path only (there is no CPU fallback)"}))
@@ -1512,7 +1657,7 @@ def main():
         if k != head:
             line[k] = v
     if rank == 0:
-        print(json.dumps(line))
+        emit(line, args.detail_out)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
