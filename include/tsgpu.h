@@ -583,6 +583,34 @@ typedef struct tsgpu_timings {
 } tsgpu_timings;
 int tsgpu_last_timings(tsgpu_ctx* ctx, tsgpu_timings* out);
 
+/* Bytes the keyword kernels REQUEST, counted by the find kernel itself (measurement; bench.py `roofline.touched_bytes_per_launch`).
+ * tsgpu_set_option("kw_count_touched", 1) makes keyword batches launch a second instantiation of the pair-find kernel
+ * (kw_find2_kernel<TMAX, COUNT = true>) in which every lane adds the width of each of its own loads / LDS-DMA words / stores to
+ * per-thread counters (one reduction + atomics per wavefront at the end) — the default instantiation carries none of it, so the
+ * timed kernel is unchanged; results are identical. Host-planned batches only (set "kw_device_plan_min_queries" above the batch).
+ * score_requested_bytes = hit records x the score kernel's fixed request sizes (host outputs; 0 otherwise). */
+typedef struct tsgpu_kw_touched {
+    uint64_t find_requested_bytes;   /* sum of the five classes below */
+    uint64_t find_driver_ids;        /* the shortest list's ids, one aligned 2/4-byte load per slot */
+    uint64_t find_metadata;          /* BlockIds windows of both lists, descriptors, query records, block-search loads */
+    uint64_t find_tile_dma;          /* second-list runs copied into the LDS tile (2 or 7 slabs of 1 KB per pair of driver blocks) */
+    uint64_t find_probes;            /* third.. lists (and wide / broken runs of the second): directory entries, guided searches */
+    uint64_t find_records;           /* hit records written for the score kernel */
+    uint64_t find_work_items, find_hit_records;
+    uint64_t score_requested_bytes;
+} tsgpu_kw_touched;
+int tsgpu_kw_last_touched(tsgpu_ctx* ctx, tsgpu_kw_touched* out);
+/* What the DISTINCT posting lists of n (field, term) pairs occupy in the mirror (terms not in the index are skipped): the working set a
+ * batch's requested / fetched bytes are compared with (`roofline.l2_refetch`). Exact — block records are read back from the device. */
+typedef struct tsgpu_kw_footprint {
+    uint64_t n_lists, n_ids;
+    uint64_t ids_bytes;              /* ids arena words of the lists' blocks (fixed-width deltas + guard words) */
+    uint64_t block_metadata_bytes;   /* BlockIds (16) + blk_last (4) + BlockMeta (32) per block */
+    uint64_t directory_bytes;        /* id directories of the long lists */
+    uint64_t payload_bytes;          /* offset_index + offsets (the score kernel's side) */
+} tsgpu_kw_footprint;
+int tsgpu_kw_lists_footprint(tsgpu_ctx* ctx, const uint32_t* field_ids, const uint32_t* term_ids, uint32_t n, tsgpu_kw_footprint* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -737,6 +737,52 @@ def test_pair_find_kernel_matches_the_oracle(pair, chunk):
     g2.close()
 
 
+def test_find_kernel_counts_the_bytes_it_requests_without_changing_the_results(pair):
+    """option kw_count_touched: the COUNT instantiation of kw_find2_kernel (bench.py `roofline.touched_bytes_per_launch`) — same hits,
+    counters that add up and respond to the work: a batch repeated twice requests twice the bytes; every driver id is requested once
+    (2 or 4 bytes each); the lists' footprint hook agrees with the ids the oracle holds"""
+    orc, g, docs = pair
+    rng = np.random.default_rng(77)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    qs = _queries(rng, 12, 25, 3, sort=sort, topster_size=250) + _queries(rng, 6, 25, 2, sort=sort, topster_size=250) + _queries(rng, 4, 40, 4, sort=sort, topster_size=250)
+    g.set_option("kw_pair_blocks", 1)
+    base = g.keyword_search_batch(qs, k_stride=250)
+    g.set_option("kw_count_touched", 1)
+    try:
+        hits = g.keyword_search_batch(qs, k_stride=250)
+        t1 = g.kw_touched()
+        hits2 = g.keyword_search_batch(qs + qs, k_stride=250)
+        t2 = g.kw_touched()
+    finally:
+        g.set_option("kw_count_touched", 0)
+        g.set_option("kw_pair_blocks", 0)
+    for name in ("keys", "scores", "n_hits", "num_matched", "status"):
+        assert np.array_equal(getattr(hits, name), getattr(base, name)), name
+        assert np.array_equal(getattr(hits2, name)[:len(qs)], getattr(base, name)), name
+    parts = ("find_driver_ids", "find_metadata", "find_tile_dma", "find_probes", "find_records")
+    assert t1["find_requested_bytes"] == sum(t1[p] for p in parts) > 0
+    assert all(t1[p] > 0 for p in parts)
+    for p in parts + ("find_work_items", "find_hit_records", "score_requested_bytes"):
+        assert t2[p] == 2 * t1[p], p
+    # every id of every query's shortest list is requested exactly once, 2 or 4 bytes each
+    df = {}
+
+    def n_docs_of(t):
+        if t not in df:
+            df[t] = int((docs == t).any(axis=1).sum())
+        return df[t]
+    drv = sum(min(n_docs_of(int(t)) for t in q.tokens) for q in qs)
+    assert 2 * drv <= t1["find_driver_ids"] <= 4 * drv
+    assert t1["find_records"] == t1["find_hit_records"] * 4 * (3 + 1) or t1["find_records"] >= t1["find_hit_records"] * 16       # (TMAX 3 and TMAX 10 tables)
+    assert t1["find_hit_records"] == int(base.num_matched.sum())
+    assert t1["score_requested_bytes"] > 0
+    terms = np.unique(np.concatenate([np.asarray(q.tokens) for q in qs])).astype(np.uint32)
+    fp = g.kw_lists_footprint(np.zeros(terms.size, np.uint32), terms)
+    assert fp["n_lists"] == terms.size
+    assert fp["n_ids"] == sum(n_docs_of(int(t)) for t in terms)
+    assert 2 * fp["n_ids"] <= fp["ids_bytes"] <= 4 * fp["n_ids"] + 8 * (fp["n_ids"] // 256 + terms.size) and fp["payload_bytes"] > 0 and fp["block_metadata_bytes"] > 0
+
+
 @pytest.mark.parametrize("chunk", [0, 1])
 def test_dropped_tokens_are_scored_when_present_and_never_required(pair, pair3, chunk):
     """the drop_tokens passes of the reference call search_across_fields with the tokens it left out of the AND (`dropped_tokens`,

@@ -43,7 +43,11 @@ static const bool KW_F2_ROUNDS = TSGPU_F2_ROUNDS != 0;
 
 // (kw_glds_slabs / kw_glds_wait — the LDS-DMA tile fill — live in kw_kernels.hip.h: the multi-field find kernel uses them, too)
 
-template <int TMAX>
+// COUNT = true: the kernel also COUNTS THE BYTES IT REQUESTS (every lane adds the width of each of its own loads / DMA words / stores to one of five
+// per-thread counters: driver ids, block metadata, tile DMA, third.. list probes, hit records; one wave reduction + five atomics per wave at the
+// end into IndexView::touched). A second instantiation launched only under option kw_count_touched — the timed kernel carries none of it.
+// Same results either way (tests/test_emu_keyword.py runs both and compares).
+template <int TMAX, bool COUNT = false>
 __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
                                                                                       const KwWorkItem* __restrict__ work, KwPartials part,
                                                                                       uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
@@ -53,10 +57,11 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
     __shared__ KwQueryDev sq;
     const uint32_t t = threadIdx.x;
     const KwWorkItem wi = work[blockIdx.x];
+    uint32_t cb_ids = 0, cb_meta = 0, cb_tile = 0, cb_probe = 0, cb_rec = 0;      // COUNT only: bytes THIS lane requested
     {
         const uint32_t* src = (const uint32_t*)(queries + wi.query);
         uint32_t* dst = (uint32_t*)&sq;
-        for (uint32_t i = t; i < sizeof(KwQueryDev) / 4; i += KW_THREADS) dst[i] = src[i];
+        for (uint32_t i = t; i < sizeof(KwQueryDev) / 4; i += KW_THREADS) { dst[i] = src[i]; if constexpr (COUNT) cb_meta += 4; }
     }
     if (t == 0) { sm.q1_cnt = 0; sm.qf_cnt = 0; sm.tk_cnt = 0; sm.have_thr = 0; sm.n_match = 0; sm.n_emit = 0; sm.off_words = 0; }
     __syncthreads();
@@ -71,20 +76,25 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
     const uint32_t* __restrict__ idwB = ix.ids_payload + dB.ids_base;
     const uint32_t lane = t & 63, wave = t >> 6;
     const BlockIds PAD = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
+    if constexpr (COUNT) { if (lane == 0) cb_meta += 2 * (uint32_t)sizeof(ListDesc) + 16; }      // (uniform loads: once per wave) two descriptors + the work item
 
     auto load_id_raw = [&](const BlockIds& m, uint32_t slot) -> uint32_t {
         const uint32_t n = m.n_ids_bits & 0xFFFF;
         const uint32_t s2 = slot < n ? slot : 0;
         const uint32_t* __restrict__ w = idwA + m.ids_woff;
+        if constexpr (COUNT) { if (slot < n) cb_ids += (m.n_ids_bits >> 16) == 16 ? 2u : 4u; }
         return (m.n_ids_bits >> 16) == 16 ? (uint32_t)((const uint16_t*)w)[s2] : w[s2];
     };
-    auto load_window = [&](uint32_t base) -> BlockIds { return (T >= 2 && base + lane < dB.n_blocks) ? biB[base + lane] : PAD; };
+    auto load_window = [&](uint32_t base) -> BlockIds {
+        if constexpr (COUNT) { if (T >= 2 && base + lane < dB.n_blocks) cb_meta += 16; }
+        return (T >= 2 && base + lane < dB.n_blocks) ? biB[base + lane] : PAD;
+    };
     // Driver-list metadata: lane j of every wave holds BlockIds[abase + j] — ONE vector load serves 32 pairs (most work items need only the
     // prologue's), a block's record is four v_readlane. (As per-pair loads they were uniform, so hipcc wanted them in SGPRs at once: a
     // global_load + s_waitcnt vmcnt(0) at the END of every iteration — a full memory round trip exposed per pair, which also drained the next
     // pair's tile DMA and driver ids before the iteration could end. TSGPU_PROF: 14 % of a work item's time.)
     uint32_t abase = wi.blk_begin;
-    auto load_awin = [&](uint32_t base) -> BlockIds { const uint32_t bb = base + lane; return biA[bb < wi.blk_end ? bb : wi.blk_end - 1]; };
+    auto load_awin = [&](uint32_t base) -> BlockIds { const uint32_t bb = base + lane; if constexpr (COUNT) { if (bb < wi.blk_end) cb_meta += 16; } return biA[bb < wi.blk_end ? bb : wi.blk_end - 1]; };
     BlockIds awin = load_awin(abase);
     auto meta = [&](uint32_t bb) -> BlockIds {          // bb: uniform, abase <= min(bb, blk_end - 1) < abase + 64
         const int j = (int)((bb < wi.blk_end ? bb : wi.blk_end - 1) - abase);
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
         }
         if (mk == 0) {                                                   // all 64 blocks end before lo_id: uniform search, re-centre
             uint32_t lo = wbase + 64, hi = dB.n_blocks;
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (blB[mid] >= lo_id) hi = mid; else lo = mid + 1; }
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if constexpr (COUNT) { if (lane == 0) cb_meta += 4; } if (blB[mid] >= lo_id) hi = mid; else lo = mid + 1; }
             wbase = lo; win = load_window(wbase); nxt = load_window(wbase + 32); win_dirty = true;
             mk = __ballot(win.last_id >= lo_id ? 1 : 0);
         }
@@ -150,6 +160,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
             uint32_t* lds_wave_base = sm.btile + tbuf * HALF + wave * 64;
             if (P.W <= 2u * KW_THREADS) kw_glds_slabs<2>(lane_src, lds_wave_base);
             else kw_glds_slabs<PIPE_WORDS>(lane_src, lds_wave_base);
+            if constexpr (COUNT) cb_tile += 4u * (P.W <= 2u * KW_THREADS ? 2u : (uint32_t)PIPE_WORDS);
         } else P.mode = KW_F2_ROUNDS ? 1 : 2;
         return P;
     };
@@ -181,7 +192,8 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
             for (uint32_t s = 2; s < T && ok; s++) {
                 const uint32_t tok = q.probe_order[s];
                 uint32_t p;
-                ok = probe_list(ix, ix.lists[q.list[tok]], id, p);
+                if constexpr (COUNT) ok = probe_list<true>(ix, ix.lists[q.list[tok]], id, p, &cb_probe);
+                else ok = probe_list(ix, ix.lists[q.list[tok]], id, p);
 #pragma unroll
                 for (int k = 0; k < TMAX; k++) if ((uint32_t)k == tok) v[k] = p;
             }
@@ -190,6 +202,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
         const uint32_t my = block_compact1(ok, sm.wave_cnt2[par], total);
         par ^= 1;
         if (ok) kw_hit_store<TMAX>(hits, qfn + my, id, v);
+        if constexpr (COUNT) { if (ok) cb_rec += 4u * (TMAX + 1); if (lane == 0 && T > 2) cb_meta += (T - 2) * (uint32_t)sizeof(ListDesc); }
         qfn += total;
         qh = (qh + n_take) & (uint32_t)(KW_QCAP - 1);
         q1n -= n_take;
@@ -353,8 +366,13 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
                 r_lo = r_hi + 1;
             }
         } else if (C.mode == 2) {
-            if (ok0) found0 = probe_list(ix, dB, id0, p10);
-            if (ok1) found1 = probe_list(ix, dB, id1, p11);
+            if constexpr (COUNT) {
+                if (ok0) found0 = probe_list<true>(ix, dB, id0, p10, &cb_probe);
+                if (ok1) found1 = probe_list<true>(ix, dB, id1, p11, &cb_probe);
+            } else {
+                if (ok0) found0 = probe_list(ix, dB, id0, p10);
+                if (ok1) found1 = probe_list(ix, dB, id1, p11);
+            }
         }
         if (T >= 2) { ok0 = ok0 && found0; ok1 = ok1 && found1; }
         KW_PROF(5)
@@ -394,12 +412,14 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
 #pragma unroll
                 for (int k = 0; k < TMAX; k++) { v[k] = 0; if (k == q.probe_order[0]) v[k] = pa0; if (T >= 2 && k == q.probe_order[1]) v[k] = p10; }
                 kw_hit_store<TMAX>(hits, qfn + base0 + lo0, id0, v);
+                if constexpr (COUNT) cb_rec += 4u * (TMAX + 1);
             }
             if (ok1) {
                 uint32_t v[TMAX];
 #pragma unroll
                 for (int k = 0; k < TMAX; k++) { v[k] = 0; if (k == q.probe_order[0]) v[k] = pa1; if (T >= 2 && k == q.probe_order[1]) v[k] = p11; }
                 kw_hit_store<TMAX>(hits, qfn + tot0 + base1 + lo1, id1, v);
+                if constexpr (COUNT) cb_rec += 4u * (TMAX + 1);
             }
             qfn += tot0 + tot1;
         }
@@ -409,6 +429,15 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
     }
     if (T >= 3) while (q1n > 0) probe_batch(q1n < (uint32_t)KW_THREADS ? q1n : (uint32_t)KW_THREADS);
     if (t == 0) part.cnt[blockIdx.x] = qfn;                    // hits handed to kw_score_kernel
+    if constexpr (COUNT) {
+        uint32_t c[5] = {cb_ids, cb_meta, cb_tile, cb_probe, cb_rec};
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            for (int m = 32; m > 0; m >>= 1) c[k] += __shfl_xor(c[k], m);
+            if (lane == 0 && ix.touched) atomicAdd(ix.touched + k, (unsigned long long)c[k]);
+        }
+        if (t == 0 && ix.touched) { atomicAdd(ix.touched + 5, 1ull); atomicAdd(ix.touched + 6, (unsigned long long)qfn); }      // work items, hit records
+    }
     KW_PROF(9)
     KW_PROF_FLUSH(ix.prof)
 }

@@ -107,6 +107,7 @@ struct IndexView {
     uint32_t iddir_slot_entries;     // entries per slot (= ceil(iddir_cap_ids / 32))
     uint32_t iddir_cap_ids;          // doc ids the directories cover: [0, cap)
     unsigned long long* prof;        // TSGPU_PROF builds: 13 counters; else null
+    unsigned long long* touched;     // option kw_count_touched: 8 counters the COUNT instantiation of the find kernel adds its requested bytes to; else null
     const struct KwQueryMF* mf;      // multi-field queries of the batch (KwQueryDev::mf_index)
     uint32_t* fbits;                 // filtered multi-field queries: one bit per filter rank (KwQueryDev::fbits_off), zeroed per batch
     // in-flight deadline (search_cutoff, include/or_iterator.h:148-153): t0 = device wall clock when the batch started (stamped by
@@ -302,9 +303,12 @@ __device__ inline uint32_t guided_lower_bound(uint32_t n, uint32_t x, uint32_t f
 
 // is id x in the list? -> posting position (block*256 + slot). Two guided searches (block among the list's last ids, slot among the
 // block's ids); neighbouring lanes probe ascending candidates, so their loads share cache lines.
-__device__ inline bool probe_list(const IndexView& ix, const ListDesc& d, uint32_t x, uint32_t& pos) {
+// (COUNT: *cnt += the bytes of every load this probe issues — the counting instantiation of the find kernel, kw_find2.hip.h)
+template <bool COUNT = false>
+__device__ inline bool probe_list(const IndexView& ix, const ListDesc& d, uint32_t x, uint32_t& pos, uint32_t* cnt = nullptr) {
     if (x < d.first_id || x > d.last_id) return false;
     if (d.dir_slot && x < ix.iddir_cap_ids) {                  // a long list: one load answers most probes (tsgpu_format.h, ID DIRECTORY)
+        if constexpr (COUNT) *cnt += 8;
         const uint2 e = ix.iddir[(size_t)(d.dir_slot - 1) * ix.iddir_slot_entries + (x >> 5)];
         const uint32_t b = x & 31u;
         if (!((e.y >> b) & 1u)) return false;
@@ -318,14 +322,16 @@ __device__ inline bool probe_list(const IndexView& ix, const ListDesc& d, uint32
     }
 #endif
     const uint32_t* __restrict__ bl = ix.blk_last + d.blk_base;
-    const uint32_t lo = guided_lower_bound(d.n_blocks, x, d.first_id, d.last_id, [&](uint32_t i) { return bl[i]; });
+    const uint32_t lo = guided_lower_bound(d.n_blocks, x, d.first_id, d.last_id, [&](uint32_t i) { if constexpr (COUNT) *cnt += 4; return bl[i]; });
     const BlockIds m = ix.blk_ids[d.blk_base + lo];
+    if constexpr (COUNT) *cnt += 16;
     if (x < m.first_id) return false;
     const uint32_t* __restrict__ w = ix.ids_payload + d.ids_base + m.ids_woff;
     const uint32_t target = x - m.first_id;
     const bool w16 = (m.n_ids_bits >> 16) == 16;
     const uint32_t n = m.n_ids_bits & 0xFFFF;                 // ids[n - 1] = block last >= target
-    const uint32_t l = guided_lower_bound(n, target, 0u, m.last_id - m.first_id, [&](uint32_t i) { return w16 ? (uint32_t)((const uint16_t*)w)[i] : w[i]; });
+    const uint32_t l = guided_lower_bound(n, target, 0u, m.last_id - m.first_id, [&](uint32_t i) { if constexpr (COUNT) *cnt += w16 ? 2 : 4; return w16 ? (uint32_t)((const uint16_t*)w)[i] : w[i]; });
+    if constexpr (COUNT) *cnt += w16 ? 2 : 4;
     if ((w16 ? (uint32_t)((const uint16_t*)w)[l] : w[l]) != target) return false;
     pos = lo * BLOCK_IDS + l;
     return true;

@@ -56,6 +56,7 @@ IndexView make_view(tsgpu_ctx* ctx, const Snapshot& sn) {
     v.iddir_slot_entries = sn.dir_pool ? sn.dir_pool->slot_entries : 0u;
     v.iddir_cap_ids = sn.dir_pool ? sn.dir_pool->cap_ids : 0u;
     v.prof = ctx->d_prof.as<unsigned long long>();
+    v.touched = nullptr;                              // per batch, option kw_count_touched
     v.mf = nullptr;                                   // per lane: set by the batch
     v.fbits = nullptr;
     v.t0 = nullptr; v.ticks_per_us = 100; v.cutoff = nullptr;
@@ -74,7 +75,8 @@ void launch_search(hipStream_t s, uint32_t n_work, const IndexView& v, const KwQ
 template <int TMAX>
 void launch_find_score(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w, const KwPartials& part,
                        const uint32_t* aux, uint32_t* ids_out, bool s2, uint32_t* hits, const uint64_t* hit_off, hipEvent_t mid_ev = nullptr, bool pair = false, bool plain = false) {
-    if (pair) hipLaunchKernelGGL((kw_find2_kernel<TMAX>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, hits, hit_off);
+    if (pair && v.touched) hipLaunchKernelGGL((kw_find2_kernel<TMAX, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, hits, hit_off);   // the byte-counting instantiation (measurement option)
+    else if (pair) hipLaunchKernelGGL((kw_find2_kernel<TMAX>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, hits, hit_off);
     else hipLaunchKernelGGL((kw_search_kernel<TMAX, 512, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     if (mid_ev) (void)hipEventRecord(mid_ev, s);           // find | score boundary of the batch's first group (tsgpu_timings::kw_find_ms)
     if (cap == 512 && !s2 && plain && !ids_out) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, false, false, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
@@ -247,6 +249,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
     if (!strcmp(name, "kw_device_plan_min_queries")) { ctx->kw_device_plan_min_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 30); return ok(); }
     if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
+    if (!strcmp(name, "kw_count_touched")) { ctx->kw_count_touched = value != 0; return ok(); }
     if (!strcmp(name, "kw_iddir_min_ids")) { ctx->kw_iddir_min_ids = value < 0 ? 0 : value; ctx->commit_force_full = true; return ok(); }
     if (!strcmp(name, "kw_iddir_density_div")) { ctx->kw_iddir_density_div = value < 1 ? 1 : value; ctx->commit_force_full = true; return ok(); }
     if (!strcmp(name, "kw_iddir_budget_mb")) { ctx->kw_iddir_budget_mb = value < 0 ? 0 : value; ctx->commit_force_full = true; return ok(); }
@@ -1383,6 +1386,12 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             hipLaunchKernelGGL(kw_stamp_kernel, dim3(1), dim3(1), 0, s, L.d_t0.as<long long>());       // the queries' budgets count from here
         }
         v.cutoff = L.d_cut.as<uint32_t>();
+        const bool count_touched = ctx->kw_count_touched;
+        if (count_touched) {                         // measurement option: the find kernel's COUNT instantiation adds the bytes it requests here
+            if ((rc = L.d_touched.reserve(8 * 8))) return rc;
+            TSGPU_HIP_TRY(hipMemsetAsync(L.d_touched.p, 0, 8 * 8, s));
+            v.touched = L.d_touched.as<unsigned long long>();
+        }
         const KwQueryDev* dq = DP.on ? DP.dq : (const KwQueryDev*)(dplan + at_q);
         const KwWorkItem* dw = DP.on ? DP.dw : (const KwWorkItem*)(dplan + at_w);
         const uint32_t* daux = DP.on ? DP.daux : (const uint32_t*)(dplan + at_aux);
@@ -1547,6 +1556,31 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             ctx->timings.kw_algorithmic_bytes = bytes;
             ctx->kw_last_hit_groups = hit_groups;
             ctx->kw_last_hit_records = hit_records;
+        }
+        if (count_touched) {
+            uint64_t c[8];
+            TSGPU_HIP_TRY(hipMemcpy(c, L.d_touched.p, sizeof(c), hipMemcpyDeviceToHost));
+            std::lock_guard<std::mutex> tl(ctx->tm_mu);
+            tsgpu_kw_touched& tt = ctx->kw_touched;
+            tt.find_driver_ids = c[0]; tt.find_metadata = c[1]; tt.find_tile_dma = c[2]; tt.find_probes = c[3]; tt.find_records = c[4];
+            tt.find_work_items = c[5]; tt.find_hit_records = c[6];
+            tt.find_requested_bytes = c[0] + c[1] + c[2] + c[3] + c[4];
+            // the score kernel's requests per hit record are fixed sizes (kw_score_kernel / load_runs_staged): the record itself, per token one
+            // BlockMeta (32 B), the offset_index pair (two 8-byte fetches) and the first offsets (8 B); per numeric sort key one column value; the
+            // rare third.. occurrence of a token in a document (one more 8-byte fetch each) is not counted
+            uint64_t sb = 0;
+            std::vector<uint64_t> nm_host;
+            const uint64_t* nm = !dev_out ? out->num_matched : nullptr;
+            if (dev_out && o.num_matched) {                          // (measurement only: one small read-back)
+                nm_host.resize(n_queries);
+                if (hipMemcpy(nm_host.data(), o.num_matched, (size_t)n_queries * 8, hipMemcpyDeviceToHost) == hipSuccess) nm = nm_host.data();
+            }
+            for (uint32_t i = 0; nm && !DP.on && i < n_queries; i++) {
+                uint32_t n_num = 0;
+                for (uint32_t k = 0; k < P.q[i].n_sort; k++) if (P.q[i].sort_kind[k] == TSGPU_SORT_INT64_COLUMN) n_num++;
+                sb += nm[i] * (4ull * ((P.q[i].n_lists <= 3 ? 3 : KW_MAX_TOKENS) + 1) + 56ull * P.q[i].n_lists + 8ull * n_num);
+            }
+            tt.score_requested_bytes = sb;
         }
         // ---- matched ids (id_buff / all_result_ids, src/index.cpp:5549, 5565): every work item left an ascending segment ----
         std::vector<uint32_t> ne;
@@ -1925,6 +1959,42 @@ int tsgpu_debug_prof(tsgpu_ctx* ctx, int reset, uint64_t* out16) {
     if (out16) TSGPU_HIP_TRY(hipMemcpy(out16, ctx->d_prof.p, 16 * 8, hipMemcpyDeviceToHost));
     if (reset) TSGPU_HIP_TRY(hipMemset(ctx->d_prof.p, 0, 16 * 8));
     return TSGPU_OK;
+}
+
+int tsgpu_kw_last_touched(tsgpu_ctx* ctx, tsgpu_kw_touched* out) {
+    if (!ctx || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_kw_last_touched: NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->tm_mu);
+    *out = ctx->kw_touched;
+    return ok();
+}
+
+// measurement hook: what the DISTINCT posting lists of a set of (field, term) pairs occupy in the mirror — the working set a batch's requested
+// bytes are compared with (bench.py `roofline.l2_refetch`). Exact: the lists' block records are read back from the device.
+int tsgpu_kw_lists_footprint(tsgpu_ctx* ctx, const uint32_t* field_ids, const uint32_t* term_ids, uint32_t n, tsgpu_kw_footprint* out) {
+    if (!ctx || !out || (n && (!field_ids || !term_ids))) return fail(TSGPU_ERR_INVALID, "tsgpu_kw_lists_footprint: NULL argument");
+    (void)hipSetDevice(ctx->device);
+    std::shared_ptr<const Snapshot> snap = std::atomic_load(&ctx->snap);
+    memset(out, 0, sizeof(*out));
+    if (!snap || !snap->ar) return ok();
+    std::vector<uint32_t> handles;
+    for (uint32_t i = 0; i < n; i++) { const uint32_t h = snap->find_handle(field_ids[i], term_ids[i]); if (h != 0xFFFFFFFFu) handles.push_back(h); }
+    std::sort(handles.begin(), handles.end());
+    handles.erase(std::unique(handles.begin(), handles.end()), handles.end());
+    std::vector<BlockMeta> bm;
+    for (uint32_t h : handles) {
+        const ListDesc& d = snap->h_lists[h];
+        bm.resize(d.n_blocks);
+        if (d.n_blocks) TSGPU_HIP_TRY(hipMemcpy(bm.data(), snap->ar->blk_meta.as<BlockMeta>() + d.blk_base, (size_t)d.n_blocks * sizeof(BlockMeta), hipMemcpyDeviceToHost));
+        for (const BlockMeta& m : bm) {
+            out->ids_bytes += 4ull * packed_words(m.n_ids, m.ids_bits);
+            out->payload_bytes += 4ull * (packed_words(m.n_ids, m.oi_bits) + packed_words(m.n_off, m.off_bits));
+        }
+        out->block_metadata_bytes += (uint64_t)d.n_blocks * (sizeof(BlockIds) + 4 + sizeof(BlockMeta));
+        if (d.dir_slot && snap->dir_pool) out->directory_bytes += 8ull * snap->dir_pool->slot_entries;
+        out->n_ids += d.n_ids;
+    }
+    out->n_lists = handles.size();
+    return ok();
 }
 
 int tsgpu_last_timings(tsgpu_ctx* ctx, tsgpu_timings* out) {

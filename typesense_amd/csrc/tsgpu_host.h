@@ -293,6 +293,7 @@ struct KwLane {
     hipEvent_t ev_chain = nullptr;                   // "this slice's kernels are done": the next slice of a sliced host-output batch waits for it ON THE DEVICE
     uint64_t wait_ema_us = 100;                      // how long this lane's recent rounds waited for the GPU (sleeping_wait)
     hipEvent_t ev_block = nullptr;                   // hipEventBlockingSync: the waiting thread sleeps instead of spinning (many concurrent callers)
+    DevBuf d_touched;                                // option kw_count_touched: the find kernel's 8 byte counters
     DevBuf d_plan, d_ids_out;                        // the batch plan (queries, work items, aux ids, multi-field descriptors, hit offsets): one upload
     DevBuf d_plan_in, d_plan_work;                   // device-side planner (kw_plan.hip.h): per-query input records; work items + hit offsets it writes
     PinBuf h_plan_tot;                               // ... and its totals, read back twice per batch
@@ -494,6 +495,8 @@ struct tsgpu_ctx {
     uint32_t kw_zero_copy_max_queries = 256;         // host-output keyword batches up to this many queries: the merge kernel writes into pinned host memory (0 = always copy)
     uint32_t kw_timing_min_queries = 64;             // keyword batches below this many queries skip the phase events (tsgpu_timings reports 0 ms for them)
     uint32_t kw_merge_select_min = 2;                // queries with at least this many partial lists are merged by selection (kw_select_partials: tree merge); 0 = always fold
+    bool kw_count_touched = false;                   // measurement option: keyword batches launch the byte-counting instantiation of the find kernel
+    tsgpu_kw_touched kw_touched{};                   // ... and leave its counters here (tsgpu_kw_last_touched; under tm_mu)
     bool kw_pair_blocks = true;                      // find kernel variant: two driver blocks per iteration (kw_find2.hip.h)
     long long kw_iddir_min_ids = 256;                // id directories (tsgpu_format.h): lists of at least max(this, num_docs / kw_iddir_density_div) ids get one; 0 = none
     long long kw_iddir_density_div = 64;

@@ -352,6 +352,20 @@ class GpuIndex:
         self._ck(self.L.tsgpu_last_timings(self.h, C.byref(t)))
         return t
 
+    def kw_touched(self):
+        """bytes the find kernel counted itself during the last keyword batch run under option kw_count_touched (measurement)"""
+        t = B.KwTouchedC()
+        self._ck(self.L.tsgpu_kw_last_touched(self.h, C.byref(t)))
+        return {n: int(getattr(t, n)) for n, _ in t._fields_}
+
+    def kw_lists_footprint(self, field_ids, term_ids):
+        """what the DISTINCT posting lists of the (field, term) pairs occupy in the mirror (measurement)"""
+        f = np.ascontiguousarray(field_ids, np.uint32)
+        t = np.ascontiguousarray(term_ids, np.uint32)
+        out = B.KwFootprintC()
+        self._ck(self.L.tsgpu_kw_lists_footprint(self.h, f.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), int(t.size), C.byref(out)))
+        return {n: int(getattr(out, n)) for n, _ in out._fields_}
+
     # ---- vector index (seam B2) ----
     def vec_create(self, field_id, dim, metric=B.METRIC_IP, capacity_hint=0):
         self._ck(self.L.tsgpu_vec_create(self.h, field_id, dim, metric, capacity_hint))
