@@ -103,6 +103,9 @@ const char* tsgpu_last_error(void);
 int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
 /* tuning knobs (all optional): "kw_chunk_blocks" = driver posting blocks per keyword work item (default 0 = sized per batch; 1..256),
  * "kw_pair_blocks" = 1 (default): the find kernel serves two blocks of the shortest list per iteration (kw_find2_kernel; 0 = one),
+ * "kw_mf_pipelined" = 1 (default): launches whose multi-field queries have at most two query_by fields run the PIPELINED find kernel
+ * (kw_find_mf2_kernel: the second token's lists of both fields merged block-wise through double-buffered LDS tiles, requested one driver
+ * block ahead; 0 = kw_search_mf_kernel, which also serves three and four fields); counter "kw_mf_pipelined_launches",
  * "kw_iddir_min_ids" (default 256) / "kw_iddir_density_div" (default 64) / "kw_iddir_budget_mb" (default 4096): posting lists of at least
  * max(min_ids, S / density_div) ids (S = the doc-id range the context's lists cover: num_docs, or a shard's range) carry an ID DIRECTORY in HBM — 8 bytes per 32 doc ids, {posting position, bits} — that answers
  * "is id x in the list, and where" (the probes of a query's third.. lists, of runs wider than the find kernel's tile, of the multi-field and

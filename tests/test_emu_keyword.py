@@ -1017,8 +1017,8 @@ def test_device_side_planner_equals_the_host_planner_and_the_oracle(pair, chunk_
             g.set_option(name, v)
 
 
-@pytest.mark.parametrize("chunk,two_kernels", [(64, 1), (1, 1), (64, 0), (256, 1)])
-def test_multi_field_block_merge_windows_wide_runs_and_exhaustion(chunk, two_kernels):
+@pytest.mark.parametrize("chunk,two_kernels,pipelined", [(64, 1, 1), (1, 1, 1), (256, 1, 1), (64, 1, 0), (1, 1, 0), (64, 0, 0), (256, 1, 0)])
+def test_multi_field_block_merge_windows_wide_runs_and_exhaustion(chunk, two_kernels, pipelined):
     """kw_mf_merge_field (the multi-field find kernel's block-level merge of a driver block with the SECOND token's lists): extreme length
     ratios in two fields — runs of 1, ~10, ~40 and > 64 blocks under one driver block (window re-centring, runs wider than the window / the
     tile -> per-candidate probes), driver ids beyond a list's end (cursor exhaustion), a second token that only one field holds — in the
@@ -1043,6 +1043,7 @@ def test_multi_field_block_merge_windows_wide_runs_and_exhaustion(chunk, two_ker
     g.commit()
     g.set_option("kw_chunk_blocks", chunk)
     g.set_option("kw_two_kernels", two_kernels)
+    g.set_option("kw_mf_pipelined", pipelined)         # 1: kw_find_mf2_kernel (two query_by fields: both second lists pipelined through LDS tiles), 0: kw_search_mf_kernel
     g.keep_result_ids(True)
     sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
     f2 = [(0, 15), (1, 9)]
@@ -1054,6 +1055,58 @@ def test_multi_field_block_merge_windows_wide_runs_and_exhaustion(chunk, two_ker
     assert (hits.status == 0).all() and hits.n_hits[0] >= 250
     for i, q in enumerate(qs):
         ref = H.oracle_keyword(orc, q, ids_cap=200000)
-        H.assert_hits_equal(hits, i, ref, "mf merge chunk=%d two=%d q=%s" % (chunk, two_kernels, q.tokens))
+        H.assert_hits_equal(hits, i, ref, "mf merge chunk=%d two=%d pipelined=%d q=%s" % (chunk, two_kernels, pipelined, q.tokens))
         assert np.array_equal(g.result_ids(i), ref.result_ids)
     g.close()
+
+
+@pytest.mark.parametrize("chunk", [0, 1, 3])
+def test_pipelined_two_field_find_kernel_equals_the_block_at_a_time_kernel_and_the_oracle(pair3, chunk):
+    """kw_find_mf2_kernel (kw_mf_pipelined = 1, launches whose queries have <= 2 query_by fields) against kw_search_mf_kernel (0) and the oracle's
+    or_iterator_t union (/root/reference/src/or_iterator.cpp:95-171): every pair of the three fields in either order, 1..7 tokens, a token only
+    one field holds, tokens no field holds, duplicate tokens, dropped tokens, filters, excluded ids, small Topsters; a batch that ALSO holds a
+    three-field query must fall back to the old kernel as a whole"""
+    orc, g = pair3
+    rng = np.random.default_rng(505)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    pairs = [[(0, 15), (1, 7)], [(1, 7), (0, 15)], [(2, 2), (0, 9)], [(1, 3), (2, 3)], [(2, 1), (1, 1)]]
+    qs = []
+    for fp in pairs:
+        for toks in ([1], [2, 1], [3, 1, 2], [5, 9], [1, 2, 3, 4], [7, 1, 2, 3, 6], [119], [9999, 2], [4, 4], [30, 2, 11], [1, 2, 3, 4, 5, 6, 8]):
+            qs.append(T.KwQuery(toks, fields=fp, sort=sort, topster_size=250))
+        qs.append(T.KwQuery([2, 1], fields=fp, sort=sort, topster_size=12, match_type=B.SUM_SCORE, excluded_ids=np.arange(0, 2500, 7)))
+        qs.append(T.KwQuery([3, 1, 2], fields=fp, sort=sort, topster_size=250, filter_ids=np.sort(rng.choice(2500, size=900, replace=False))))
+        qs.append(T.KwQuery([1, 2], fields=fp, sort=sort, topster_size=250, dropped_tokens=[3, 40]))
+        qs.append(T.KwQuery([5], fields=fp, sort=sort, topster_size=250, dropped_tokens=[1], match_type=B.MAX_WEIGHT))
+        qs.append(T.KwQuery([3, 1], fields=fp, sort=sort, topster_size=250, filter_ids=np.arange(0, 2500, 2), excluded_ids=np.arange(100, 300)))
+    g.set_option("kw_chunk_blocks", chunk)
+    g.keep_result_ids(True)
+    try:
+        outs = []
+        for pipelined in (1, 0):
+            g.set_option("kw_mf_pipelined", pipelined)
+            n0 = g.counter("kw_mf_pipelined_launches")
+            h = g.keyword_search_batch(qs, k_stride=250)
+            assert (h.status == 0).all()
+            assert (g.counter("kw_mf_pipelined_launches") > n0) == bool(pipelined)
+            outs.append((h, [g.result_ids(i).copy() for i in range(len(qs))]))
+        (h1, ids1), (h0, ids0) = outs
+        for name in ("keys", "scores", "n_hits", "num_matched"):
+            assert np.array_equal(getattr(h1, name), getattr(h0, name)), name
+        for i, q in enumerate(qs):
+            ref = H.oracle_keyword(orc, q, ids_cap=4000)
+            H.assert_hits_equal(h1, i, ref, "pipelined two-field kernel chunk=%d fields=%s q=%s" % (chunk, q.fields, q.tokens))
+            assert np.array_equal(ids1[i], ref.result_ids) and np.array_equal(ids0[i], ref.result_ids)
+        assert h1.n_hits.sum() > 1000
+        # one three-field query in the batch: the whole launch takes kw_search_mf_kernel (the host decides per launch)
+        g.set_option("kw_mf_pipelined", 1)
+        mixed = qs[:8] + [T.KwQuery([3, 1, 2], fields=[(0, 15), (1, 7), (2, 3)], sort=sort, topster_size=250)]
+        n0 = g.counter("kw_mf_pipelined_launches")
+        hm = g.keyword_search_batch(mixed, k_stride=250)
+        assert g.counter("kw_mf_pipelined_launches") == n0
+        for i, q in enumerate(mixed):
+            H.assert_hits_equal(hm, i, H.oracle_keyword(orc, q, ids_cap=4000), "mixed 2/3-field batch q=%s" % (q.tokens,))
+    finally:
+        g.set_option("kw_mf_pipelined", 1)
+        g.set_option("kw_chunk_blocks", 0)
+        g.keep_result_ids(False)

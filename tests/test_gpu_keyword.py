@@ -213,6 +213,8 @@ test_parallel_planning_of_a_batch_gives_the_serial_plan = EK.test_parallel_plann
 test_device_side_planner_equals_the_host_planner_and_the_oracle = EK.test_device_side_planner_equals_the_host_planner_and_the_oracle
 test_multi_field_block_merge_windows_wide_runs_and_exhaustion = EK.test_multi_field_block_merge_windows_wide_runs_and_exhaustion
 test_long_work_items_reload_the_driver_metadata_window = EK.test_long_work_items_reload_the_driver_metadata_window
+test_pipelined_two_field_find_kernel_equals_the_block_at_a_time_kernel_and_the_oracle = EK.test_pipelined_two_field_find_kernel_equals_the_block_at_a_time_kernel_and_the_oracle
+test_find_kernel_counts_the_bytes_it_requests_without_changing_the_results = EK.test_find_kernel_counts_the_bytes_it_requests_without_changing_the_results
 
 
 def test_device_shard_merge_on_cuda_tensors(c100k):
@@ -387,3 +389,47 @@ def test_device_side_planner_on_2m_docs_many_work_items(c2m):
         assert np.array_equal(dev.keys[i, :n], host.keys[i, :n]) and np.array_equal(dev.scores[i, :n], host.scores[i, :n]), i
     for i in list(range(0, 3000, 250)) + [3001, 3020]:
         H.assert_hits_equal(dev, i, c2m.oracle(qs[i]), "device plan at 2M docs")
+
+
+def test_pipelined_two_field_find_kernel_on_1m_docs_two_fields():
+    """kw_find_mf2_kernel at size: 1M documents, two string fields, 400 three-term queries over both (driver lists of hundreds of blocks: window
+    slides and re-centring, runs in both tile sizes and wider than the tile, many work items per query) — identical to kw_search_mf_kernel on
+    every output array, and 24 of them identical to the oracle's or_iterator_t union (/root/reference/src/or_iterator.cpp:95-171)"""
+    n_docs = 1_000_000
+    csr = [synth.zipf_corpus_csr(n_docs, 20_000, 20, seed=71), synth.zipf_corpus_csr(n_docs, 20_000, 10, seed=72)]
+    pts = synth.points_column(n_docs)
+    g = T.GpuIndex(0)
+    for f, c in enumerate(csr):
+        g.field_create(f, False)
+        g.terms_load_csr(f, c["term_ids"], c["ids_ptr"], c["ids"], c["offset_index"], c["off_ptr"], c["offsets"])
+    g.column_set(0, pts)
+    g.set_num_docs(n_docs)
+    g.commit()
+    try:
+        qtok = np.concatenate([synth.keyword_queries(300, 3, 1, 300, seed=81), synth.keyword_queries(100, 3, 2, 4000, seed=82)])
+        fields = ((0, 15), (1, 14))
+        qs = [T.KwQuery(q, sort=SORT, topster_size=250, fields=fields if i % 3 else ((1, 14), (0, 15))) for i, q in enumerate(qtok)]
+        outs = []
+        for pipelined in (1, 0):
+            g.set_option("kw_mf_pipelined", pipelined)
+            n0 = g.counter("kw_mf_pipelined_launches")
+            h = g.keyword_search_batch(qs, k_stride=250)
+            assert (h.status == 0).all()
+            assert (g.counter("kw_mf_pipelined_launches") > n0) == bool(pipelined)
+            outs.append(h)
+        for name in ("keys", "scores", "n_hits", "num_matched"):
+            assert np.array_equal(getattr(outs[0], name), getattr(outs[1], name)), name
+        assert int(outs[0].n_hits.sum()) > 20_000
+        orc = O.OracleIndex(2, 1)
+        orc.set_num_docs(n_docs)
+        orc.set_sort_dense(0, pts)
+        for t in np.unique(qtok[:24]):
+            for f, c in enumerate(csr):
+                ids, oi, off = synth.csr_term(c, int(t))
+                if ids.size:
+                    orc.load_posting(f, int(t), ids, oi, off)
+        for i in range(24):
+            H.assert_hits_equal(outs[0], i, H.oracle_keyword(orc, qs[i]), "1M docs, two fields, pipelined find kernel")
+        orc.close()
+    finally:
+        g.close()

@@ -1,0 +1,367 @@
+// kw_find_mf2.hip.h — the "find" half of the two-kernel MULTI-FIELD keyword form, PIPELINED (round 5; included by kw_kernels.hip.h).
+//
+// query_by = f0,f1: token t is the union over the fields of its posting lists (or_iterator_t, /root/reference/src/or_iterator.cpp:95-171), the
+// query the AND over the tokens of those unions (get_field_token_its, src/index.cpp:5598-5660). Work item = (query, ONE field's list of the
+// driver token, block range), as in kw_search_mf_kernel<.., DEFER>, and the same hit records leave it (ascending ids, 1 + TMAX x KW_MAX_FIELDS
+// words). What is new is HOW a driver block meets the second token's lists:
+//   * kw_search_mf_kernel runs kw_mf_merge_field once per field and driver block, start to finish: window load from memory, ballots, barrier,
+//     LDS-DMA of the run, wait, barrier, searches — two exposed memory round trips and two barriers per (driver block, field), nothing in flight
+//     meanwhile: 13 us per driver block and workgroup on the two-field bench leg (11.5 ms per 2 000 queries, 13x the single-field pair kernel
+//     per query for 2x the lists: VERDICT r4 weak #3);
+//   * here the second token's lists of BOTH fields are handled the way kw_find2_kernel handles its second list — BlockIds windows that stay in
+//     registers behind forward-only cursors (lane <-> block; the next 32 blocks already requested), the plan of the NEXT driver block (run of
+//     blocks under its id range, per list) made and its tiles requested by LDS-DMA BEFORE this block is searched (two tile buffers per list),
+//     one wait + one barrier per driver block for both lists — and every candidate's two slot searches (one per list) run as ONE straight-line
+//     sequence of two independent chains, the way kw_find2_kernel interleaves its two driver blocks. The roles are swapped: one driver block,
+//     two second lists per iteration instead of two driver blocks, one second list;
+//   * the window's per-block fields reach a candidate through ds_bpermute on the window REGISTERS (the block search runs before the next plan
+//     may slide them) instead of through versioned LDS copies: no LDS for block tables, no writes.
+// Stage 2 (the other tokens in every field, the driver token's other fields with the "an id an EARLIER field's list of the driver token holds
+// is left to that field's work items" rule) runs on full 256-entry batches of queued survivors out of a RING (head in a register, two barriers
+// per batch) as in kw_find2_kernel.
+// Serves launches whose multi-field queries have at most KW_MF2_LISTS (2) query_by fields — the host knows (Plan::mf_max_fields); three and four
+// fields keep kw_search_mf_kernel. Option kw_mf_pipelined = 0 restores the old kernel for every launch. Same records bit for bit: the tests run both.
+#pragma once
+
+#ifndef TSGPU_MF2_SLABS
+#define TSGPU_MF2_SLABS 4
+#endif
+#ifndef TSGPU_MF2_WAVES
+#define TSGPU_MF2_WAVES 6
+#endif
+#ifndef TSGPU_MF2_SPAN
+#define TSGPU_MF2_SPAN 8
+#endif
+#ifdef TSGPU_HIP_EMU
+#define KW_MF2_WAVES_ATTR
+#else
+#define KW_MF2_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(TSGPU_MF2_WAVES)))
+#endif
+static const int KW_MF2_LISTS = 2;                              // second-token lists merged block-wise per iteration (= query_by fields served)
+static const int KW_MF2_SLABS = TSGPU_MF2_SLABS;                // 1 KB slabs per (list, tile buffer): runs of up to SLABS x 512 16-bit ids under one driver block
+static const int KW_MF2_TILE = KW_MF2_SLABS * KW_THREADS;       // words
+static const int KW_MF2_SPAN = TSGPU_MF2_SPAN;                  // runs of up to this many blocks: block search by v_readlane compares
+
+template <int TMAX>
+__global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
+                                                                                       const KwWorkItem* __restrict__ work, KwPartials part,
+                                                                                       uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
+    constexpr int NB = KW_MF2_LISTS;
+    constexpr int NP = TMAX * KW_MAX_FIELDS;
+    constexpr int TILE = KW_MF2_TILE;
+    static_assert(KW_MF2_SLABS == 2 || KW_MF2_SLABS == 4 || KW_MF2_SLABS == 6 || KW_MF2_SLABS == 8, "kw_glds_slabs forms");
+    static_assert(KW_MF2_SLABS * KW_THREADS <= (int)KW_TILE_OVERREAD_WORDS, "the tile fill reads whole slabs past a run's end: the ids arena's padding");
+    __shared__ uint32_t btile[2 * NB * TILE + 2];               // [buffer][list][TILE]: one set searched, one landing
+    __shared__ uint32_t q_id[KW_QCAP], q_p0[KW_QCAP], q_p1[NB][KW_QCAP];     // survivor ring: id, driver position, position in either second list (KW_NONE: absent)
+    __shared__ uint32_t wave_cnt[2][KW_THREADS / 64];
+    __shared__ uint32_t s_stop;
+    __shared__ KwQueryDev sq;
+    __shared__ KwQueryMF smf;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const KwWorkItem wi = work[blockIdx.x];
+    const uint32_t qi = wi.query & 0x0FFFFFFFu, fdrv = wi.query >> 28;
+    {
+        const uint32_t* src = (const uint32_t*)(queries + qi);
+        uint32_t* dst = (uint32_t*)&sq;
+        for (uint32_t i = t; i < sizeof(KwQueryDev) / 4; i += KW_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    {
+        const uint32_t* src = (const uint32_t*)(ix.mf + sq.mf_index);
+        uint32_t* dst = (uint32_t*)&smf;
+        for (uint32_t i = t; i < sizeof(KwQueryMF) / 4; i += KW_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    const KwQueryDev& q = sq;
+    const KwQueryMF& mf = smf;
+    const uint32_t T = q.n_lists, F = mf.n_fields, td = mf.driver_token, ts = mf.second_token;
+    const ListDesc dA = ix.lists[mf.list[td][fdrv]];
+    const BlockIds* __restrict__ biA = ix.blk_ids + dA.blk_base;
+    const uint32_t* __restrict__ idwA = ix.ids_payload + dA.ids_base;
+    uint32_t* __restrict__ hits = hits_all + hit_off[blockIdx.x] * (uint64_t)(NP + 1);
+    const BlockIds PAD = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
+
+    // ---- the second token's lists: descriptor, BlockIds window (lane <-> block), the next 32 blocks, forward-only cursor ----
+    bool have[NB];
+    ListDesc dB[NB];
+    uint32_t wbase[NB];
+    BlockIds win[NB], nxt[NB];
+#pragma unroll
+    for (int f = 0; f < NB; f++) {
+        const uint32_t h = (ts != KW_NONE && (uint32_t)f < F) ? mf.list[ts][f] : KW_NONE;
+        have[f] = h != KW_NONE;
+        dB[f] = ix.lists[have[f] ? h : mf.list[td][fdrv]];
+        wbase[f] = 0;
+    }
+    auto load_window = [&](int f, uint32_t base) -> BlockIds {
+        return (have[f] && base + lane < dB[f].n_blocks) ? (ix.blk_ids + dB[f].blk_base)[base + lane] : PAD;
+    };
+#pragma unroll
+    for (int f = 0; f < NB; f++) { win[f] = load_window(f, 0); nxt[f] = load_window(f, 32); }
+
+    // driver-list metadata: lane j of every wave holds BlockIds[abase + j] (kw_find2_kernel: one vector load per 60 blocks, four v_readlane per block)
+    uint32_t abase = wi.blk_begin;
+    auto load_awin = [&](uint32_t base) -> BlockIds { const uint32_t bb = base + lane; return biA[bb < wi.blk_end ? bb : wi.blk_end - 1]; };
+    BlockIds awin = load_awin(abase);
+    auto meta = [&](uint32_t bb) -> BlockIds {           // bb uniform; abase <= min(bb, blk_end - 1) < abase + 64
+        const int j = (int)((bb < wi.blk_end ? bb : wi.blk_end - 1) - abase);
+        BlockIds m;
+        m.first_id = (uint32_t)__builtin_amdgcn_readlane((int)awin.first_id, j); m.last_id = (uint32_t)__builtin_amdgcn_readlane((int)awin.last_id, j);
+        m.ids_woff = (uint32_t)__builtin_amdgcn_readlane((int)awin.ids_woff, j); m.n_ids_bits = (uint32_t)__builtin_amdgcn_readlane((int)awin.n_ids_bits, j);
+        return m;
+    };
+    auto load_raw = [&](const BlockIds& m) -> uint32_t {
+        const uint32_t n = m.n_ids_bits & 0xFFFF, s2 = t < n ? t : 0;
+        const uint32_t* __restrict__ w = idwA + m.ids_woff;
+        return (m.n_ids_bits >> 16) == 16 ? (uint32_t)((const uint16_t*)w)[s2] : w[s2];
+    };
+
+    // how the driver ids in [lo_id, hi_id] meet list f; mode 0 also requests the tile into buffer `buf`
+    struct Plan { uint32_t mode, rlo, rhi, w_begin, base; };     // mode: 0 tile, 2 wide / broken run (probe per candidate), 3 exhausted, 4 no such list
+    auto make_plan = [&](int f, uint32_t lo_id, uint32_t hi_id, uint32_t buf) -> Plan {
+        Plan P; P.mode = 4; P.rlo = P.rhi = P.w_begin = 0; P.base = wbase[f];
+        if (!have[f]) return P;
+        if (wbase[f] >= dB[f].n_blocks || lo_id > dB[f].last_id) { P.mode = 3; return P; }
+        unsigned long long mk = __ballot(win[f].last_id >= lo_id ? 1 : 0);
+        if (mk != 0 && (uint32_t)__builtin_ctzll(mk) >= 32) {          // the cursor entered the upper half: slide by 32 blocks
+            wbase[f] += 32; win[f] = nxt[f]; nxt[f] = load_window(f, wbase[f] + 32);
+            mk = __ballot(win[f].last_id >= lo_id ? 1 : 0);
+        }
+        if (mk == 0) {                                                   // all 64 blocks end before lo_id: uniform search, re-centre
+            const uint32_t* __restrict__ bl = ix.blk_last + dB[f].blk_base;
+            uint32_t lo = wbase[f] + 64, hi = dB[f].n_blocks;
+            if (lo > hi) lo = hi;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (bl[mid] >= lo_id) hi = mid; else lo = mid + 1; }
+            wbase[f] = lo; win[f] = load_window(f, lo); nxt[f] = load_window(f, lo + 32);
+            mk = __ballot(win[f].last_id >= lo_id ? 1 : 0);
+            if (mk == 0) { P.mode = 3; P.base = wbase[f]; return P; }
+        }
+        P.rlo = (uint32_t)__builtin_ctzll(mk);
+        P.base = wbase[f];
+        if (wbase[f] + P.rlo >= dB[f].n_blocks) { P.mode = 3; return P; }
+        if ((uint32_t)__builtin_amdgcn_readlane((int)win[f].first_id, (int)P.rlo) > hi_id) { P.mode = 4; return P; }      // the run starts behind this driver block: nobody is in the list
+        const unsigned long long mh = __ballot(win[f].last_id >= hi_id ? 1 : 0);
+        if (mh == 0) { P.mode = 2; return P; }                           // the run leaves the window
+        P.rhi = (uint32_t)__builtin_ctzll(mh);
+        if (wbase[f] + P.rhi >= dB[f].n_blocks) P.rhi = dB[f].n_blocks - 1 - wbase[f];
+        if (dB[f].flags & LIST_HAS_BREAKS) {
+            const uint32_t w_endw = win[f].ids_woff + packed_words(win[f].n_ids_bits & 0xFFFF, win[f].n_ids_bits >> 16);
+            const uint32_t nxt_woff = (uint32_t)__shfl(win[f].ids_woff, (int)((lane + 1) & 63));
+            if (__ballot((lane >= P.rlo && lane < P.rhi && w_endw != nxt_woff) ? 1 : 0) != 0) { P.mode = 2; return P; }
+        }
+        P.w_begin = (uint32_t)__builtin_amdgcn_readlane((int)win[f].ids_woff, (int)P.rlo);
+        const uint32_t nb_hi = (uint32_t)__builtin_amdgcn_readlane((int)win[f].n_ids_bits, (int)P.rhi);
+        const uint32_t W = (uint32_t)__builtin_amdgcn_readlane((int)win[f].ids_woff, (int)P.rhi) + packed_words(nb_hi & 0xFFFF, nb_hi >> 16) - P.w_begin;
+        if (W > (uint32_t)TILE) { P.mode = 2; return P; }
+        P.mode = 0;
+        const uint32_t* lane_src = ix.ids_payload + dB[f].ids_base + P.w_begin + t;
+        uint32_t* lds_wave_base = btile + (buf * NB + f) * TILE + wave * 64;
+        if (W <= 2u * KW_THREADS) kw_glds_slabs<2>(lane_src, lds_wave_base);
+        else kw_glds_slabs<KW_MF2_SLABS == 2 ? 4 : KW_MF2_SLABS>(lane_src, lds_wave_base);
+        return P;
+    };
+
+    // ---- stage 2 on the first n_take queued survivors (one per thread, ring order = ascending id): the other tokens in every field, then the driver
+    //      token's other fields; complete hits go to the work item's segment in queue order ----
+    uint32_t q1n = 0, qfn = 0, qh = 0, par = 0;
+    auto probe_batch = [&](uint32_t n_take) {
+        __syncthreads();                                  // the appends of every wave are visible; nobody still reads the entries a previous batch freed
+        bool ok = t < n_take;
+        uint32_t id = 0xFFFFFFFFu;
+        uint32_t pos[NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++) pos[k] = KW_NONE;
+        auto set_pos = [&](uint32_t idx, uint32_t v) {              // (unrolled selects: a dynamically indexed register array would live in scratch)
+#pragma unroll
+            for (int k = 0; k < NP; k++) if ((uint32_t)k == idx) pos[k] = v;
+        };
+        if (ok) {
+            const uint32_t e = (qh + t) & (uint32_t)(KW_QCAP - 1);
+            id = q_id[e];
+            set_pos(td * KW_MAX_FIELDS + fdrv, q_p0[e]);
+            if (ts != KW_NONE) {
+#pragma unroll
+                for (int f = 0; f < NB; f++) set_pos(ts * KW_MAX_FIELDS + f, q_p1[f][e]);
+            }
+#pragma unroll
+            for (int tt = 0; tt < TMAX; tt++) {
+                if ((uint32_t)tt < T && (uint32_t)tt != td && (uint32_t)tt != ts && ok) {
+                    bool any = false;
+#pragma unroll
+                    for (int f = 0; f < NB; f++) {
+                        if ((uint32_t)f < F) {
+                            const uint32_t h = mf.list[tt][f];
+                            uint32_t pp;
+                            if (h != KW_NONE && probe_list(ix, ix.lists[h], id, pp)) { any = true; pos[tt * KW_MAX_FIELDS + f] = pp; }
+                        }
+                    }
+                    ok = ok && (any || (uint32_t)tt >= q.n_required);      // (a dropped token is probed, not required)
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < NB; f++) {
+                if ((uint32_t)f < F && (uint32_t)f != fdrv && ok) {
+                    const uint32_t h = mf.list[td][f];
+                    uint32_t pp;
+                    if (h != KW_NONE && probe_list(ix, ix.lists[h], id, pp)) {
+                        if ((uint32_t)f < fdrv) ok = false;       // an earlier field's list of the driver token holds it: that field's work items produce it
+                        else set_pos(td * KW_MAX_FIELDS + f, pp);
+                    }
+                }
+            }
+        }
+        uint32_t total;
+        const uint32_t my = block_compact1(ok, wave_cnt[par], total);
+        par ^= 1;
+        if (ok) {
+            uint32_t* __restrict__ d = hits + (size_t)(qfn + my) * (NP + 1);
+            d[0] = id;
+#pragma unroll
+            for (int k = 0; k < NP; k++) d[1 + k] = pos[k];
+        }
+        qfn += total;
+        qh = (qh + n_take) & (uint32_t)(KW_QCAP - 1);
+        q1n -= n_take;
+    };
+
+    // ---- the pipeline: block b's ids and tiles were requested one iteration ago ----
+    const bool has_deadline = q.deadline_rem_us != 0;
+    BlockIds mA = meta(wi.blk_begin), mN = meta(wi.blk_begin + 1);
+    uint32_t araw = load_raw(mA);
+    uint32_t tbuf = 0;
+    Plan P[NB];
+#pragma unroll
+    for (int f = 0; f < NB; f++) P[f] = make_plan(f, mA.first_id, mA.last_id, tbuf);
+    for (uint32_t b = wi.blk_begin; b < wi.blk_end; b++) {
+        if (has_deadline && ((b - wi.blk_begin) & 15) == 0 && kw_out_of_time(ix, q, qi, &s_stop)) break;
+        // every second list has ended before this driver block and the token is required: nothing more can match
+        if (ts != KW_NONE) {
+            bool live = false;
+#pragma unroll
+            for (int f = 0; f < NB; f++) live = live || (have[f] && P[f].mode != 3);
+            if (!live) break;
+        }
+        kw_glds_wait();                                   // this block's tiles and ids have landed
+        const uint32_t m_n = mA.n_ids_bits & 0xFFFF;
+        bool ok = t < m_n;
+        const uint32_t id = ok ? mA.first_id + araw : 0xFFFFFFFFu;
+        Plan C[NB];
+#pragma unroll
+        for (int f = 0; f < NB; f++) C[f] = P[f];
+        const uint32_t* __restrict__ tile = btile + tbuf * (NB * TILE);
+        __syncthreads();                                  // tiles visible to every wave; everyone has left the other buffer's searches
+        // ---- the next block's ids are requested first ... ----
+        uint32_t araw_n = 0;
+        if (b + 1 < wi.blk_end) araw_n = load_raw(mN);
+        // ---- (a) which block of either run — on the window registers as they were planned on (before the next plan may slide them): a
+        //      candidate reaches another lane's block record through ds_bpermute, no LDS copy of the window ----
+        uint32_t pos_b[NB], first[NB], nb[NB], rel[NB];
+        bool done[NB], found[NB];
+        uint32_t pp[NB];
+#pragma unroll
+        for (int f = 0; f < NB; f++) {
+            found[f] = false; pp[f] = KW_NONE; pos_b[f] = C[f].rlo; first[f] = 0; nb[f] = 0; rel[f] = 0;
+            done[f] = !ok || C[f].mode != 0;
+            if (C[f].mode == 0) {
+                const uint32_t span = C[f].rhi - C[f].rlo;
+                if (span <= (uint32_t)KW_MF2_SPAN) {
+                    for (uint32_t j = C[f].rlo; j < C[f].rhi; j++) {
+                        const uint32_t last_j = (uint32_t)__builtin_amdgcn_readlane((int)win[f].last_id, (int)j);
+                        pos_b[f] += last_j < id ? 1u : 0u;
+                    }
+                } else {
+                    for (uint32_t step = 1u << (31 - __builtin_clz(span)); step > 0; step >>= 1) {
+                        const uint32_t j = pos_b[f] + step;
+                        const uint32_t v = (uint32_t)__shfl(win[f].last_id, (int)((j <= C[f].rhi ? j : C[f].rhi) - 1));
+                        pos_b[f] = (j <= C[f].rhi && v < id) ? j : pos_b[f];
+                    }
+                }
+                // (inactive lanes carry id = 0xFFFFFFFF: pos = rhi, harmless reads)
+                first[f] = (uint32_t)__shfl(win[f].first_id, (int)pos_b[f]);
+                const uint32_t l = (uint32_t)__shfl(win[f].last_id, (int)pos_b[f]);
+                nb[f] = (uint32_t)__shfl(win[f].n_ids_bits, (int)pos_b[f]);
+                rel[f] = (uint32_t)__shfl(win[f].ids_woff, (int)pos_b[f]) - C[f].w_begin;
+                if (l < id || id < first[f]) done[f] = true;              // beyond the list's end / in the gap between two blocks
+            }
+        }
+        // ---- ... then its plans and tiles (in flight during this block's slot searches and stage 2) ----
+        if (b + 1 < wi.blk_end) {
+            tbuf ^= 1;
+#pragma unroll
+            for (int f = 0; f < NB; f++) P[f] = make_plan(f, mN.first_id, mN.last_id, tbuf);
+        }
+        // ---- (b) which slot: branch-free lower bounds over the blocks' ids in the LDS tiles ----
+        auto slot_search = [&](const uint32_t* __restrict__ tile_r, uint32_t b_first, uint32_t b_nb, uint32_t tile_rel, uint32_t blk, bool& fnd, uint32_t& p1) {
+            const uint32_t n = b_nb & 0xFFFF, target = id - b_first;
+            uint32_t pos = 0, hit;
+            if ((b_nb >> 16) == 16) {
+                const uint16_t* __restrict__ a16 = (const uint16_t*)(tile_r + tile_rel);
+#pragma unroll
+                for (uint32_t step = 128; step > 0; step >>= 1) {
+                    const uint32_t j = pos + step;
+                    const uint32_t v = a16[(j <= n ? j : n) - 1];
+                    pos = (j <= n && v < target) ? j : pos;
+                }
+                hit = a16[pos < n ? pos : n - 1];
+            } else {
+                const uint32_t* __restrict__ a32 = tile_r + tile_rel;
+#pragma unroll
+                for (uint32_t step = 128; step > 0; step >>= 1) {
+                    const uint32_t j = pos + step;
+                    const uint32_t v = a32[(j <= n ? j : n) - 1];
+                    pos = (j <= n && v < target) ? j : pos;
+                }
+                hit = a32[pos < n ? pos : n - 1];
+            }
+            if (pos < n && hit == target) { fnd = true; p1 = blk * BLOCK_IDS + pos; }
+        };
+        {
+            // every block but a list's last is full, and 16-bit wherever the list is dense: when that holds for all of a wavefront's candidates in
+            // both lists the two searches run as ONE straight-line sequence of two independent chains (candidates that dropped out search the
+            // tile's first block: harmless reads)
+            constexpr uint32_t FULL16 = (16u << 16) | (uint32_t)BLOCK_IDS;
+            const bool fast = (done[0] || nb[0] == FULL16) && (done[1] || nb[1] == FULL16);
+            if (__ballot(fast ? 0 : 1) == 0) {
+                const uint16_t* __restrict__ a0 = (const uint16_t*)(tile + (done[0] ? 0u : rel[0]));
+                const uint16_t* __restrict__ a1 = (const uint16_t*)(tile + TILE + (done[1] ? 0u : rel[1]));
+                const uint32_t t0 = id - first[0], t1 = id - first[1];
+                uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+                for (uint32_t step = 128; step > 0; step >>= 1) {
+                    const uint32_t v0 = a0[s0 + step - 1], v1 = a1[s1 + step - 1];
+                    s0 = v0 < t0 ? s0 + step : s0;
+                    s1 = v1 < t1 ? s1 + step : s1;
+                }
+                const uint32_t h0 = a0[s0], h1 = a1[s1];
+                found[0] = !done[0] && h0 == t0; found[1] = !done[1] && h1 == t1;
+                pp[0] = (C[0].base + pos_b[0]) * BLOCK_IDS + s0; pp[1] = (C[1].base + pos_b[1]) * BLOCK_IDS + s1;
+            } else {
+#pragma unroll
+                for (int f = 0; f < NB; f++) if (!done[f]) slot_search(tile + f * TILE, first[f], nb[f], rel[f], C[f].base + pos_b[f], found[f], pp[f]);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < NB; f++) {
+            if (C[f].mode == 2 && ok) { uint32_t p2; if (probe_list(ix, dB[f], id, p2)) { found[f] = true; pp[f] = p2; } }
+            if (!found[f]) pp[f] = KW_NONE;
+        }
+        if (ts != KW_NONE) ok = ok && (found[0] || found[1]);
+        // ---- survivors -> the ring (block order = ascending id), behind ONE barrier ----
+        uint32_t total;
+        const uint32_t my = block_compact1(ok, wave_cnt[par], total);
+        par ^= 1;
+        if (ok) {
+            const uint32_t slot = (qh + q1n + my) & (uint32_t)(KW_QCAP - 1);
+            q_id[slot] = id; q_p0[slot] = b * BLOCK_IDS + t;
+#pragma unroll
+            for (int f = 0; f < NB; f++) q_p1[f][slot] = pp[f];
+        }
+        q1n += total;
+        if (q1n >= (uint32_t)KW_THREADS) probe_batch(KW_THREADS);          // (uniform) the ring holds 512: < 256 left over + one block's survivors
+        if (b + 3 >= abase + 64 && b + 2 < wi.blk_end) { abase = b + 2; awin = load_awin(abase); }
+        mA = mN; mN = meta(b + 2); araw = araw_n;
+    }
+    kw_glds_wait();                                       // (a tile requested for a block the loop never reached must land before the workgroup ends)
+    while (q1n > 0) probe_batch(q1n < (uint32_t)KW_THREADS ? q1n : (uint32_t)KW_THREADS);
+    if (t == 0) part.cnt[blockIdx.x] = qfn;                // hits handed to kw_score_kernel<.., MF = true>
+}

@@ -2836,5 +2836,6 @@ __global__ __launch_bounds__(64) void kw_aux_score_kernel(IndexView ix, const Kw
 }
 
 #include "kw_find2.hip.h"
+#include "kw_find_mf2.hip.h"
 
 }  // namespace tsgpu

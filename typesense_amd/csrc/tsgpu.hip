@@ -96,8 +96,10 @@ void launch_search_mf_cap(int cap, hipStream_t s, uint32_t n_work, const IndexVi
 struct MfOrderedCount { const uint32_t* jobs = nullptr; uint32_t n_jobs = 0, table_first = 0; const KwWorkItem* work_all = nullptr; KwPartials part_all{}; };
 template <int TMAX>
 void launch_find_score_mf(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w, const KwPartials& part,
-                          const uint32_t* aux, uint32_t* ids_out, uint32_t* hits, const uint64_t* hit_off, const MfOrderedCount& oc, bool plain = false) {
-    hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 512, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
+                          const uint32_t* aux, uint32_t* ids_out, uint32_t* hits, const uint64_t* hit_off, const MfOrderedCount& oc, bool plain = false, bool pipelined = false) {
+    // pipelined: every multi-field query of the launch has at most KW_MF2_LISTS query_by fields (kw_find_mf2.hip.h); same hit records either way
+    if (pipelined) hipLaunchKernelGGL((kw_find_mf2_kernel<TMAX>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, hits, hit_off);
+    else hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 512, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     if (oc.n_jobs) hipLaunchKernelGGL((kw_mf_ordered_count_kernel<TMAX>), dim3(oc.n_jobs), dim3(64), 0, s, q, oc.work_all, oc.part_all, hits, hit_off, oc.table_first, aux, oc.jobs);
     if (cap == 512 && plain && !ids_out && !oc.n_jobs) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, true, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     else if (cap == 512) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
@@ -249,6 +251,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
     if (!strcmp(name, "kw_device_plan_min_queries")) { ctx->kw_device_plan_min_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 30); return ok(); }
     if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
+    if (!strcmp(name, "kw_mf_pipelined")) { ctx->kw_mf_pipelined = value != 0; return ok(); }
     if (!strcmp(name, "kw_count_touched")) { ctx->kw_count_touched = value != 0; return ok(); }
     if (!strcmp(name, "kw_iddir_min_ids")) { ctx->kw_iddir_min_ids = value < 0 ? 0 : value; ctx->commit_force_full = true; return ok(); }
     if (!strcmp(name, "kw_iddir_density_div")) { ctx->kw_iddir_density_div = value < 1 ? 1 : value; ctx->commit_force_full = true; return ok(); }
@@ -325,6 +328,7 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!ctx || !name || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_get_counter: NULL argument");
     std::lock_guard<std::mutex> lk(ctx->tm_mu);
     if (!strcmp(name, "kw_last_hit_groups")) { *out = ctx->kw_last_hit_groups; return ok(); }      // last keyword batch: find+score groups (0 = fused kernel)
+    if (!strcmp(name, "kw_mf_pipelined_launches")) { *out = ctx->kw_mf_pipelined_launches; return ok(); }     // find launches served by kw_find_mf2_kernel
     if (!strcmp(name, "kw_last_hit_records")) { *out = ctx->kw_last_hit_records; return ok(); }    // hit-record capacity the last batch asked for
     if (!strcmp(name, "vec_overflow_rounds")) { *out = ctx->vec_overflow_rounds; return ok(); }
     if (!strcmp(name, "vec_prefilter_fallbacks")) { *out = ctx->vec_prefilter_fallbacks; return ok(); }
@@ -387,6 +391,7 @@ struct Plan {
     bool any_s2 = false;              // some query has a third sort key
     bool any_aux = false;             // some query has filter ids or excluded ids (else the score kernel's PLAIN instantiation serves the batch)
     bool any_array = false;           // some multi-field query has a string[] field
+    uint32_t mf_max_fields = 0;       // most query_by fields of any multi-field query (<= 2: the pipelined find kernel, kw_find_mf2.hip.h)
     std::vector<uint32_t> aux;
     std::vector<int32_t> status, cutoff;
     uint32_t max_k = 1;
@@ -470,6 +475,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
         uint64_t fbits_words = 0, ids_total = 0, list_bytes = 0;
         uint32_t max_k = 0, n_numeric_sort_q = 0;
         bool any_deadline = false, any_s2 = false, any_aux = false, any_array = false;
+        uint32_t mf_max_fields = 0;
     };
     auto plan_range = [&](uint32_t lo, uint32_t hi, PlanAcc& A) {
         A.flat_work.reserve((size_t)(hi - lo) * 4);
@@ -637,6 +643,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
                 uint32_t td = 0;
                 for (uint32_t t = 1; t < q.n_required; t++) if (len_of[t] < len_of[td]) td = t;
                 mfq.n_fields = in.n_fields;
+                A.mf_max_fields = std::max(A.mf_max_fields, (uint32_t)in.n_fields);
                 mfq.driver_token = td;
                 mfq.second_token = KW_NONE;             // the required token with the next fewest postings: merged block-wise by the find kernel
                 for (uint32_t t = 0; t < q.n_required; t++) if (t != td && (mfq.second_token == KW_NONE || len_of[t] < len_of[mfq.second_token])) mfq.second_token = t;
@@ -744,7 +751,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
             P.ordered_count_q.insert(P.ordered_count_q.end(), A.ordered_count_q.begin(), A.ordered_count_q.end());
             P.ids_total += A.ids_total; P.fbits_words += A.fbits_words; P.list_bytes += A.list_bytes;
             P.max_k = std::max(P.max_k, A.max_k); P.n_numeric_sort_q += A.n_numeric_sort_q;
-            P.any_deadline = P.any_deadline || A.any_deadline; P.any_s2 = P.any_s2 || A.any_s2; P.any_aux = P.any_aux || A.any_aux; P.any_array = P.any_array || A.any_array;
+            P.any_deadline = P.any_deadline || A.any_deadline; P.any_s2 = P.any_s2 || A.any_s2; P.any_aux = P.any_aux || A.any_aux; P.any_array = P.any_array || A.any_array; P.mf_max_fields = std::max(P.mf_max_fields, A.mf_max_fields);
         }
     }
     // work tables: one launch per kernel flavour (single-field T<=3, single-field generic, multi-field T<=3, multi-field generic);
@@ -1423,7 +1430,9 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
                             oc.jobs = (const uint32_t*)(dplan + at_oc[tb]); oc.n_jobs = (uint32_t)oc_jobs[tb].size(); oc.table_first = (uint32_t)first;
                             oc.work_all = dw; oc.part_all = part;
                         }
-                        launch_find_score_mf<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, L.d_hits.as<uint32_t>(), hoff_dev + a, oc, !P.any_aux && !P.any_array);
+                        const bool mf_pipe = ctx->kw_mf_pipelined && P.mf_max_fields <= (uint32_t)KW_MF2_LISTS;
+                        if (mf_pipe) ctx->kw_mf_pipelined_launches++;
+                        launch_find_score_mf<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, L.d_hits.as<uint32_t>(), hoff_dev + a, oc, !P.any_aux && !P.any_array, mf_pipe);
                     }
                     else {
                         const bool mark = !find_marked;
