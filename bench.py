@@ -702,7 +702,17 @@ class Bench:
         def after(_):
             tm = g.timings()
             kern.append(tm.kw_search_ms); merge.append(tm.kw_merge_ms); algb.append(tm.kw_algorithmic_bytes)
+        prof = None
+        if os.environ.get("KW_PROF") and hasattr(g.L, "tsgpu_debug_prof"):       # tools/ only: a TSGPU_PROF build's per-phase cycle counters of the find kernel
+            step()
+            prof = (C.c_uint64 * 16)()
+            g.L.tsgpu_debug_prof(g.h, 1, None)
         el, lat, out = timed(step, steps, 2, 1, after)
+        if prof is not None:
+            g.L.tsgpu_debug_prof(g.h, 1, prof)
+            v = list(prof)
+            tot = sum(v[:12]) or 1
+            sys.stderr.write("PROF mf find kernel: wg=%d %s cycles/wg=%.0f\n" % (v[12], " ".join("p%d=%.1f%%" % (i, 100.0 * v[i] / tot) for i in range(12)), tot / max(v[12], 1)))
         keys, scores = out["keys"].cpu().numpy().astype(np.uint64), out["scores"].cpu().numpy()
         n_hits, nm, st = out["n_hits"].cpu().numpy(), out["num_matched"].cpu().numpy(), out["status"].cpu().numpy()
         mf = {"workload": "%d queries/step, 3 distinct terms (ranks log-uniform [8,2000]), query_by = two string fields (weights 15, 14) over the same %d documents, "

@@ -340,6 +340,7 @@ template <class T> inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp
 struct float4 { float x, y, z, w; };
 struct uint4 { uint32_t x, y, z, w; };
 struct uint2 { uint32_t x, y; };
+inline uint2 make_uint2(uint32_t x, uint32_t y) { uint2 r; r.x = x; r.y = y; return r; }
 inline float4 make_float4(float x, float y, float z, float w) { float4 v; v.x = x; v.y = y; v.z = z; v.w = w; return v; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }

@@ -40,6 +40,19 @@
 static const int KW_MF2_LISTS = 2;                              // second-token lists merged block-wise per iteration (= query_by fields served)
 static const int KW_MF2_SLABS = TSGPU_MF2_SLABS;                // 1 KB slabs per (list, tile buffer): runs of up to SLABS x 512 16-bit ids under one driver block
 static const int KW_MF2_TILE = KW_MF2_SLABS * KW_THREADS;       // words
+#ifndef TSGPU_MF2_WIDE
+#define TSGPU_MF2_WIDE 0
+#endif
+// (measured and left off, profiles/r05/exp_mf2_find_kernel.txt: requesting a survivor's directory entries when it is QUEUED — LDS-DMA into a sink —
+//  11.16 -> 11.52 ms; the 16-entry search windows of directory-less probes requested at once (wide_lower_bound) 11.06 -> 11.28 ms: twelve
+//  spilled VGPRs. The stage-2 batch is not waiting for those loads: the TSGPU_PROF shares did not move.)
+#ifndef TSGPU_MF2_PREFETCH
+#define TSGPU_MF2_PREFETCH 0
+#endif
+#ifndef TSGPU_MF2_TOUCH
+#define TSGPU_MF2_TOUCH 1
+#endif
+static const bool KW_MF2_WIDE = TSGPU_MF2_WIDE != 0;            // probes without a directory: the 16-entry search windows requested at once (wide_lower_bound)
 static const int KW_MF2_SPAN = TSGPU_MF2_SPAN;                  // runs of up to this many blocks: block search by v_readlane compares
 
 template <int TMAX>
@@ -55,6 +68,8 @@ __global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kern
     __shared__ uint32_t q_id[KW_QCAP], q_p0[KW_QCAP], q_p1[NB][KW_QCAP];     // survivor ring: id, driver position, position in either second list (KW_NONE: absent)
     __shared__ uint32_t wave_cnt[2][KW_THREADS / 64];
     __shared__ uint32_t s_stop;
+    __shared__ unsigned long long pf_dir[NB];                  // directory of the first stage-2 token's list in either field (0: none): what a queued survivor will be probed in
+    __shared__ uint32_t pf_sink[128];                          // where the prefetching LDS-DMAs land (never read)
     __shared__ KwQueryDev sq;
     __shared__ KwQueryMF smf;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -81,6 +96,19 @@ __global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kern
     uint32_t* __restrict__ hits = hits_all + hit_off[blockIdx.x] * (uint64_t)(NP + 1);
     const BlockIds PAD = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u};
 
+    if (t < (uint32_t)NB) {
+        // the first token stage 2 will probe (the longest lists of the query: their directory entries come from the Infinity Cache / HBM, ~1 us):
+        // a survivor's entries are REQUESTED when it is queued, so that they are in L2 when its batch is probed
+        unsigned long long ptr = 0;
+        uint32_t tt3 = KW_NONE;
+        for (uint32_t tt = 0; tt < T; tt++) if (tt != td && tt != ts && tt3 == KW_NONE) tt3 = tt;
+        if (tt3 != KW_NONE && t < F) {
+            const uint32_t h = mf.list[tt3][t];
+            if (h != KW_NONE) { const uint32_t slot = ix.lists[h].dir_slot; if (slot) ptr = (unsigned long long)(uintptr_t)(ix.iddir + (size_t)(slot - 1) * ix.iddir_slot_entries); }
+        }
+        pf_dir[t] = ptr;
+    }
+    __syncthreads();
     // ---- the second token's lists: descriptor, BlockIds window (lane <-> block), the next 32 blocks, forward-only cursor ----
     bool have[NB];
     ListDesc dB[NB];
@@ -164,6 +192,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kern
     // ---- stage 2 on the first n_take queued survivors (one per thread, ring order = ascending id): the other tokens in every field, then the driver
     //      token's other fields; complete hits go to the work item's segment in queue order ----
     uint32_t q1n = 0, qfn = 0, qh = 0, par = 0;
+    KW_PROF_DECL
     auto probe_batch = [&](uint32_t n_take) {
         __syncthreads();                                  // the appends of every wave are visible; nobody still reads the entries a previous batch freed
         bool ok = t < n_take;
@@ -183,33 +212,45 @@ __global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kern
 #pragma unroll
                 for (int f = 0; f < NB; f++) set_pos(ts * KW_MAX_FIELDS + f, q_p1[f][e]);
             }
+            // (a token's lists in both fields are probed TOGETHER: both directory entries are requested before either is looked at — one memory
+            //  round trip per token instead of one per (token, field))
 #pragma unroll
             for (int tt = 0; tt < TMAX; tt++) {
                 if ((uint32_t)tt < T && (uint32_t)tt != td && (uint32_t)tt != ts && ok) {
                     bool any = false;
+                    ProbeReq rq[NB];
+                    uint32_t hh[NB];
 #pragma unroll
                     for (int f = 0; f < NB; f++) {
-                        if ((uint32_t)f < F) {
-                            const uint32_t h = mf.list[tt][f];
-                            uint32_t pp;
-                            if (h != KW_NONE && probe_list(ix, ix.lists[h], id, pp)) { any = true; pos[tt * KW_MAX_FIELDS + f] = pp; }
-                        }
+                        hh[f] = (uint32_t)f < F ? mf.list[tt][f] : KW_NONE;
+                        rq[f].state = 0; rq[f].e = make_uint2(0u, 0u);
+                        if (hh[f] != KW_NONE) probe_issue(ix, ix.lists[hh[f]], id, rq[f]);
+                    }
+#pragma unroll
+                    for (int f = 0; f < NB; f++) {
+                        uint32_t pp;
+                        if (hh[f] != KW_NONE && probe_finish<KW_MF2_WIDE>(ix, ix.lists[hh[f]], id, rq[f], pp)) { any = true; pos[tt * KW_MAX_FIELDS + f] = pp; }
                     }
                     ok = ok && (any || (uint32_t)tt >= q.n_required);      // (a dropped token is probed, not required)
                 }
             }
+            KW_PROF(10)
 #pragma unroll
             for (int f = 0; f < NB; f++) {
                 if ((uint32_t)f < F && (uint32_t)f != fdrv && ok) {
                     const uint32_t h = mf.list[td][f];
                     uint32_t pp;
-                    if (h != KW_NONE && probe_list(ix, ix.lists[h], id, pp)) {
+                    ProbeReq rq;
+                    rq.state = 0; rq.e = make_uint2(0u, 0u);
+                    if (h != KW_NONE) probe_issue(ix, ix.lists[h], id, rq);
+                    if (h != KW_NONE && probe_finish<KW_MF2_WIDE>(ix, ix.lists[h], id, rq, pp)) {
                         if ((uint32_t)f < fdrv) ok = false;       // an earlier field's list of the driver token holds it: that field's work items produce it
                         else set_pos(td * KW_MAX_FIELDS + f, pp);
                     }
                 }
             }
         }
+        KW_PROF(11)
         uint32_t total;
         const uint32_t my = block_compact1(ok, wave_cnt[par], total);
         par ^= 1;
@@ -241,7 +282,17 @@ __global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kern
             for (int f = 0; f < NB; f++) live = live || (have[f] && P[f].mode != 3);
             if (!live) break;
         }
+        KW_PROF(8)
         kw_glds_wait();                                   // this block's tiles and ids have landed
+#if !defined(TSGPU_HIP_EMU) && TSGPU_MF2_TOUCH
+        // every load this wave has issued has landed here — tell the compiler so for the prefetched windows: it waits for a load where its value is
+        // first USED (`win = nxt` inside the next plan, after that plan's tile DMAs were issued), and its counter model knows nothing of the asm-issued
+        // DMAs: the hardware counter would drain them there (the same trap as the scan kernel's per-lane constants)
+#pragma unroll
+        for (int f = 0; f < NB; f++) asm volatile("" : "+v"(nxt[f].first_id), "+v"(nxt[f].last_id), "+v"(nxt[f].ids_woff), "+v"(nxt[f].n_ids_bits), "+v"(win[f].first_id), "+v"(win[f].last_id), "+v"(win[f].ids_woff), "+v"(win[f].n_ids_bits));
+        asm volatile("" : "+v"(awin.first_id), "+v"(awin.last_id), "+v"(awin.ids_woff), "+v"(awin.n_ids_bits), "+v"(araw));
+#endif
+        KW_PROF(0)
         const uint32_t m_n = mA.n_ids_bits & 0xFFFF;
         bool ok = t < m_n;
         const uint32_t id = ok ? mA.first_id + araw : 0xFFFFFFFFu;
@@ -250,6 +301,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kern
         for (int f = 0; f < NB; f++) C[f] = P[f];
         const uint32_t* __restrict__ tile = btile + tbuf * (NB * TILE);
         __syncthreads();                                  // tiles visible to every wave; everyone has left the other buffer's searches
+        KW_PROF(1)
         // ---- the next block's ids are requested first ... ----
         uint32_t araw_n = 0;
         if (b + 1 < wi.blk_end) araw_n = load_raw(mN);
@@ -284,12 +336,14 @@ __global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kern
                 if (l < id || id < first[f]) done[f] = true;              // beyond the list's end / in the gap between two blocks
             }
         }
+        KW_PROF(2)
         // ---- ... then its plans and tiles (in flight during this block's slot searches and stage 2) ----
         if (b + 1 < wi.blk_end) {
             tbuf ^= 1;
 #pragma unroll
             for (int f = 0; f < NB; f++) P[f] = make_plan(f, mN.first_id, mN.last_id, tbuf);
         }
+        KW_PROF(3)
         // ---- (b) which slot: branch-free lower bounds over the blocks' ids in the LDS tiles ----
         auto slot_search = [&](const uint32_t* __restrict__ tile_r, uint32_t b_first, uint32_t b_nb, uint32_t tile_rel, uint32_t blk, bool& fnd, uint32_t& p1) {
             const uint32_t n = b_nb & 0xFFFF, target = id - b_first;
@@ -340,11 +394,18 @@ __global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kern
                 for (int f = 0; f < NB; f++) if (!done[f]) slot_search(tile + f * TILE, first[f], nb[f], rel[f], C[f].base + pos_b[f], found[f], pp[f]);
             }
         }
+        KW_PROF(4)
+        {
+            ProbeReq rq[NB];
 #pragma unroll
-        for (int f = 0; f < NB; f++) {
-            if (C[f].mode == 2 && ok) { uint32_t p2; if (probe_list(ix, dB[f], id, p2)) { found[f] = true; pp[f] = p2; } }
-            if (!found[f]) pp[f] = KW_NONE;
+            for (int f = 0; f < NB; f++) { rq[f].state = 0; rq[f].e = make_uint2(0u, 0u); if (C[f].mode == 2 && ok) probe_issue(ix, dB[f], id, rq[f]); }
+#pragma unroll
+            for (int f = 0; f < NB; f++) {
+                if (C[f].mode == 2 && ok) { uint32_t p2; if (probe_finish<KW_MF2_WIDE>(ix, dB[f], id, rq[f], p2)) { found[f] = true; pp[f] = p2; } }
+                if (!found[f]) pp[f] = KW_NONE;
+            }
         }
+        KW_PROF(5)
         if (ts != KW_NONE) ok = ok && (found[0] || found[1]);
         // ---- survivors -> the ring (block order = ascending id), behind ONE barrier ----
         uint32_t total;
@@ -355,13 +416,34 @@ __global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kern
             q_id[slot] = id; q_p0[slot] = b * BLOCK_IDS + t;
 #pragma unroll
             for (int f = 0; f < NB; f++) q_p1[f][slot] = pp[f];
+#if !defined(TSGPU_HIP_EMU) && TSGPU_MF2_PREFETCH
+            if (id < ix.iddir_cap_ids) {
+                // LDS-DMA into a sink: a load without a destination register (nothing to keep live, nothing the compiler must wait for); the wait
+                // at the top of the next iteration covers it
+                const uint32_t sink = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)pf_sink);
+#pragma unroll
+                for (int f = 0; f < NB; f++) {
+                    const unsigned long long base = pf_dir[f];
+                    if (base) {                                       // (uniform)
+                        const uint32_t* a = (const uint32_t*)(uintptr_t)(base + (unsigned long long)(id >> 5) * 8ull);
+                        uint32_t keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(a), "s"(sink + (uint32_t)f * 256u) : "memory");
+                    }
+                }
+            }
+#endif
         }
         q1n += total;
+        KW_PROF(6)
         if (q1n >= (uint32_t)KW_THREADS) probe_batch(KW_THREADS);          // (uniform) the ring holds 512: < 256 left over + one block's survivors
+        KW_PROF(7)
         if (b + 3 >= abase + 64 && b + 2 < wi.blk_end) { abase = b + 2; awin = load_awin(abase); }
         mA = mN; mN = meta(b + 2); araw = araw_n;
     }
     kw_glds_wait();                                       // (a tile requested for a block the loop never reached must land before the workgroup ends)
     while (q1n > 0) probe_batch(q1n < (uint32_t)KW_THREADS ? q1n : (uint32_t)KW_THREADS);
     if (t == 0) part.cnt[blockIdx.x] = qfn;                // hits handed to kw_score_kernel<.., MF = true>
+    KW_PROF(9)
+    KW_PROF_FLUSH(ix.prof)
 }

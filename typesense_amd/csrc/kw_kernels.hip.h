@@ -337,6 +337,87 @@ __device__ inline bool probe_list(const IndexView& ix, const ListDesc& d, uint32
     return true;
 }
 
+// probe_list in two halves, so that SEVERAL probes of one candidate (the lists of a token in every query_by field) have their first — usually
+// only — load in flight together: probe_issue() requests the directory entry, probe_finish() evaluates it (and falls back to the two-level search
+// for lists without a directory, split entries and ids beyond the directories' range). Same answers as probe_list.
+struct ProbeReq { uint2 e; uint32_t state; };                 // state: 0 = x outside the list's id range, 1 = directory entry requested, 2 = no directory: search
+__device__ inline void probe_issue(const IndexView& ix, const ListDesc& d, uint32_t x, ProbeReq& r) {
+    r.e = make_uint2(0u, 0u); r.state = 0;
+    if (x < d.first_id || x > d.last_id) return;
+    if (d.dir_slot && x < ix.iddir_cap_ids) { r.e = ix.iddir[(size_t)(d.dir_slot - 1) * ix.iddir_slot_entries + (x >> 5)]; r.state = 1; }
+    else r.state = 2;
+}
+__device__ inline bool probe_search(const IndexView& ix, const ListDesc& d, uint32_t x, uint32_t& pos) {     // (the two-level search of probe_list)
+    const uint32_t* __restrict__ bl = ix.blk_last + d.blk_base;
+    const uint32_t lo = guided_lower_bound(d.n_blocks, x, d.first_id, d.last_id, [&](uint32_t i) { return bl[i]; });
+    const BlockIds m = ix.blk_ids[d.blk_base + lo];
+    if (x < m.first_id) return false;
+    const uint32_t* __restrict__ w = ix.ids_payload + d.ids_base + m.ids_woff;
+    const uint32_t target = x - m.first_id;
+    const bool w16 = (m.n_ids_bits >> 16) == 16;
+    const uint32_t n = m.n_ids_bits & 0xFFFF;
+    const uint32_t l = guided_lower_bound(n, target, 0u, m.last_id - m.first_id, [&](uint32_t i) { return w16 ? (uint32_t)((const uint16_t*)w)[i] : w[i]; });
+    if ((w16 ? (uint32_t)((const uint16_t*)w)[l] : w[l]) != target) return false;
+    pos = lo * BLOCK_IDS + l;
+    return true;
+}
+// guided_lower_bound with the whole 16-entry window around the interpolated guess requested AT ONCE (17 independent loads, counted in registers)
+// instead of two window tests followed by four dependent steps inside the window: one memory round trip per search level where the guided form
+// takes 2 long + 4 short ones. TSGPU_PROF, kw_find_mf2_kernel on the two-field bench leg: a 256-survivor stage-2 batch took ~25 000 cycles, almost
+// all of it the dependent chain of the ONE probe per survivor that has no directory behind it (the driver token's list in the other field: a short
+// list) — two search levels x (2 + 4) loads + the block record + the final compare. Same index on any data (the fallback bisection is the guided form's).
+template <class LoadFn>
+__device__ inline uint32_t wide_lower_bound(uint32_t n, uint32_t x, uint32_t first, uint32_t last, LoadFn at) {
+    uint32_t lo = 0, hi = n - 1;                                  // the answer is in [lo, hi] (a[n - 1] >= x)
+    const float frac = (float)(x - first) / ((float)(last - first) + 1.0f);
+    uint32_t g = (uint32_t)(frac * (float)n);
+    g = g < n ? g : n - 1;
+    const uint32_t w0 = g > 8 ? g - 8 : 0;
+    const uint32_t whi = w0 + 15 < n - 1 ? w0 + 15 : n - 1;
+    uint32_t v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = at(w0 + (uint32_t)i < n - 1 ? w0 + (uint32_t)i : n - 1);
+    const uint32_t below = w0 ? at(w0 - 1) : 0u;
+    const bool low_ok = w0 == 0 || below < x;
+    if (low_ok && v[15] >= x) {                                   // (v[15] = a[whi]; slots past the array's end repeat a[n - 1] >= x: they count 0)
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) c += v[i] < x ? 1u : 0u;
+        return w0 + c;
+    }
+    if (!low_ok) hi = w0 - 1; else lo = whi + 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (at(mid) >= x) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+__device__ inline bool probe_search_wide(const IndexView& ix, const ListDesc& d, uint32_t x, uint32_t& pos) {
+    const uint32_t* __restrict__ bl = ix.blk_last + d.blk_base;
+    const uint32_t lo = wide_lower_bound(d.n_blocks, x, d.first_id, d.last_id, [&](uint32_t i) { return bl[i]; });
+    const BlockIds m = ix.blk_ids[d.blk_base + lo];
+    if (x < m.first_id) return false;
+    const uint32_t* __restrict__ w = ix.ids_payload + d.ids_base + m.ids_woff;
+    const uint32_t target = x - m.first_id;
+    const bool w16 = (m.n_ids_bits >> 16) == 16;
+    const uint32_t n = m.n_ids_bits & 0xFFFF;
+    const uint32_t l = wide_lower_bound(n, target, 0u, m.last_id - m.first_id, [&](uint32_t i) { return w16 ? (uint32_t)((const uint16_t*)w)[i] : w[i]; });
+    if ((w16 ? (uint32_t)((const uint16_t*)w)[l] : w[l]) != target) return false;
+    pos = lo * BLOCK_IDS + l;
+    return true;
+}
+template <bool WIDE = false>
+__device__ inline bool probe_finish(const IndexView& ix, const ListDesc& d, uint32_t x, const ProbeReq& r, uint32_t& pos) {
+    if (r.state == 0) return false;
+    if (r.state == 1) {
+        const uint32_t b = x & 31u;
+        if (!((r.e.y >> b) & 1u)) return false;
+        if (!(r.e.x & IDDIR_SPLIT)) { pos = r.e.x + (uint32_t)__popc(r.e.y & ((1u << b) - 1u)); return true; }
+    }
+    if constexpr (WIDE) return probe_search_wide(ix, d, x, pos);
+    else return probe_search(ix, d, x, pos);
+}
+
 // one token's occurrences inside one document (plain string field, src/index.cpp:1323-1348 encoding)
 struct TokRun {
     const uint32_t* w;   // packed offsets of the block
@@ -2476,6 +2557,10 @@ struct KwShardIn {
     // contiguous slice (the all-to-all form sends every rank only the queries it merges); blocks are shard_stride words apart; workgroup
     // b reads record b of every block and writes query b + q_out_offset. packed == nullptr: the arrays above.
     const uint64_t* packed; uint64_t shard_stride; uint32_t words; uint32_t q_out_offset;
+    // BOUND-PRUNED packed form (pruned_per > 0; kw_group_pack_pruned_kernel): shard g's slice = pruned_per header pairs
+    // {n | status << 16 | first entry << 32, num_matched} — one per query of the slice — followed by the slice's entries, `words` u64 each,
+    // compact: query b's are entries [first, first + n). Slices are shard_stride words apart.
+    uint32_t pruned_per;
     int32_t* status_out;           // (packed form) merged per-query status: the first non-zero status among the shards
     const uint32_t* cap_per_query; // nullable: the merged list of query q holds min(k, cap_per_query[q]) hits (its own Topster's capacity)
 };
@@ -2497,6 +2582,92 @@ __global__ void kw_group_pack_kernel(KwOut loc, const int32_t* status, uint32_t 
         uint64_t* c = dst + (size_t)q * qw + (size_t)k * words;
         c[0] = n; c[1] = (loc.num_matched && !failed) ? loc.num_matched[q] : 0; c[2] = status ? (uint64_t)(uint32_t)status[q] : 0;
     }
+}
+// ---- bound-pruned exchange (round 5) ----------------------------------------------------------------------------------------
+// A merged list holds kq = min(k, the query's Topster capacity) hits. A shard that holds at least kq hits of a query PROVES, with its kq-th
+// best entry e*, that the kq-th best entry of the whole collection is at least e*: it owns kq entries >= e*. So with B[q] = the greatest of the
+// shards' kq-th entries under the Topster comparator (KV::is_greater, /root/reference/include/topster.h:146-154; keys are unique: a strict
+// total order), no entry below B[q] can be among the global top kq — at least kq entries lie above it — and every shard sends only its entries
+// >= B[q]: in total about kq plus a few per query over ALL shards instead of G x k. A shard with fewer than kq hits reports "none" (key < 0:
+// sorts below everything) and prunes nothing unless another shard supplies a bound.
+// (1) this shard's kq-th best entry per query: {s0, s1, s2, key} (key = -1: none)
+__global__ void kw_group_kth_kernel(KwOut loc, const int32_t* status, const uint32_t* cap_per_query, uint32_t n_queries, uint32_t k, int64_t* kth) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_queries) return;
+    const bool failed = status && status[q] != 0;
+    const uint32_t n = failed ? 0u : (loc.n_hits[q] < k ? loc.n_hits[q] : k);
+    const uint32_t kq = cap_per_query && cap_per_query[q] < k ? cap_per_query[q] : k;
+    int64_t* d = kth + (size_t)q * 4;
+    if (kq == 0 || n < kq) { d[0] = 0; d[1] = 0; d[2] = 0; d[3] = -1; return; }
+    const size_t src = (size_t)q * loc.k_stride + (kq - 1);
+    d[0] = loc.scores[src * 3 + 0]; d[1] = loc.scores[src * 3 + 1]; d[2] = loc.scores[src * 3 + 2]; d[3] = (int64_t)loc.keys[src];
+}
+// (2) B[q] from the gathered kq-th entries ([shard][query][4]); cnt[q] = this shard's entries >= B[q] — a PREFIX of its sorted list (binary
+// search); tot[q / per] += cnt[q] (the entries bound for the member that merges the query's slice)
+__global__ void kw_group_count_kernel(KwOut loc, const int32_t* status, uint32_t n_queries, uint32_t k, const int64_t* kth_all, uint32_t n_shards,
+                                      uint32_t per, uint32_t* cnt, uint32_t* tot) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_queries) return;
+    const bool failed = status && status[q] != 0;
+    const uint32_t n = failed ? 0u : (loc.n_hits[q] < k ? loc.n_hits[q] : k);
+    int64_t b0 = 0, b1 = 0, b2 = 0, bk = -1;
+    for (uint32_t g = 0; g < n_shards; g++) {
+        const int64_t* e = kth_all + ((size_t)g * n_queries + q) * 4;
+        if (ent_greater(e[0], e[1], e[2], e[3], b0, b1, b2, bk)) { b0 = e[0]; b1 = e[1]; b2 = e[2]; bk = e[3]; }
+    }
+    uint32_t lo = 0, hi = n;                                   // first index whose entry is BELOW the bound (none: everything stays)
+    if (bk >= 0) {
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const size_t src = (size_t)q * loc.k_stride + mid;
+            const bool below = ent_greater(b0, b1, b2, bk, loc.scores[src * 3 + 0], loc.scores[src * 3 + 1], loc.scores[src * 3 + 2], (int64_t)loc.keys[src]);
+            if (below) hi = mid; else lo = mid + 1;
+        }
+    } else lo = n;
+    cnt[q] = lo;
+    if (lo) atomicAdd(tot + q / per, lo);
+}
+// (3a) one workgroup per destination slice: exclusive scan of cnt over the slice's queries -> the header pairs of the slice
+__global__ __launch_bounds__(KW_THREADS) void kw_group_pruned_header_kernel(KwOut loc, const int32_t* status, uint32_t n_queries, uint32_t per, const uint32_t* cnt,
+                                                                            uint64_t slice_words, uint64_t* dst, uint32_t* first_of) {
+    __shared__ uint32_t s_wave[KW_THREADS / 64], s_run;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, j = blockIdx.x;
+    uint64_t* hdr = dst + (size_t)j * slice_words;
+    if (t == 0) s_run = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < per; base += KW_THREADS) {
+        const uint32_t i = base + t, q = j * per + i;
+        const bool live = i < per && q < n_queries;
+        const uint32_t c = live ? cnt[q] : 0u;
+        uint32_t incl = c;                                          // inclusive scan inside the wavefront
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, (unsigned)d); if (lane >= (uint32_t)d) incl += v; }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = s_run;
+        for (uint32_t w = 0; w < wave; w++) before += s_wave[w];
+        const uint32_t first = before + incl - c;
+        if (i < per) {
+            const bool failed = live && status && status[q] != 0;
+            hdr[(size_t)i * 2] = (uint64_t)c | ((uint64_t)(live && status ? (uint32_t)status[q] & 0xFFFFu : 0u) << 16) | ((uint64_t)first << 32);
+            hdr[(size_t)i * 2 + 1] = (live && loc.num_matched && !failed) ? loc.num_matched[q] : 0;
+            if (live) first_of[q] = first;
+        }
+        __syncthreads();
+        if (t == KW_THREADS - 1) s_run = before + incl;             // (the last thread's inclusive value = the chunk's total)
+        __syncthreads();
+    }
+}
+// (3b) the entries: thread (q, i < cnt[q]) copies entry i of query q behind its slice's header
+__global__ void kw_group_pruned_entries_kernel(KwOut loc, uint32_t n_queries, uint32_t k, uint32_t words, uint32_t per, const uint32_t* cnt, const uint32_t* first_of,
+                                               uint64_t slice_words, uint64_t* dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t q = i / k, e = i - q * k;
+    if (q >= n_queries || e >= cnt[q]) return;
+    const size_t src = (size_t)q * loc.k_stride + e;
+    uint64_t* d = dst + (size_t)(q / per) * slice_words + (size_t)per * 2 + ((size_t)first_of[q] + e) * words;
+    d[0] = loc.keys[src];
+    d[1] = (uint64_t)loc.scores[src * 3 + 0]; d[2] = (uint64_t)loc.scores[src * 3 + 1]; d[3] = (uint64_t)loc.scores[src * 3 + 2];
+    if (words > 4) d[4] = loc.text_match ? (uint64_t)loc.text_match[src] : 0;
 }
 // replicas form of a group (every member mirrors the whole collection, the batch is cut into query slices): the member's own result for
 // its slice (stride loc.k_stride) -> rows [q_out_offset, ..) of the staged full-batch arrays (stride out.k_stride), truncated to k
@@ -2527,9 +2698,21 @@ __global__ __launch_bounds__(KW_THREADS) void kw_shard_merge_kernel(KwShardIn in
     if (t == 0) s_total = 0;
     for (int i = t; i < CAP; i += KW_THREADS) tk.key[i] = -1;
     __syncthreads();
+    // the entries of shard g for this query, and their number (packed forms)
+    auto shard_entries = [&](uint32_t g, uint32_t& n) -> const uint64_t* {
+        const uint64_t* blk = in.packed + g * in.shard_stride;
+        if (in.pruned_per) {
+            const uint64_t h = blk[(size_t)qi * 2];
+            n = (uint32_t)(h & 0xFFFFu);
+            return blk + (size_t)in.pruned_per * 2 + (size_t)(h >> 32) * in.words;
+        }
+        n = (uint32_t)blk[(size_t)qi * qw + (size_t)in.k_in * in.words];
+        return blk + (size_t)qi * qw;
+    };
     for (uint32_t g = 0; g < in.n_shards; g++) {
-        const uint64_t* pk = in.packed ? in.packed + g * in.shard_stride + (size_t)qi * qw : nullptr;
-        const uint32_t n = pk ? (uint32_t)pk[(size_t)in.k_in * in.words] : in.n_hits[(size_t)g * in.n_queries + q];
+        uint32_t n = 0;
+        const uint64_t* pk = in.packed ? shard_entries(g, n) : nullptr;
+        if (!pk) n = in.n_hits[(size_t)g * in.n_queries + q];
         const size_t base = ((size_t)g * in.n_queries + q) * in.k_in;
         const uint32_t at = s_total;
         for (uint32_t i = t; i < n; i += KW_THREADS) {
@@ -2561,7 +2744,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_shard_merge_kernel(KwShardIn in
         out.keys[ob + i] = packed >> 16;
         out.scores[(ob + i) * 3 + 0] = tk.s0[i]; out.scores[(ob + i) * 3 + 1] = tk.s1[i]; out.scores[(ob + i) * 3 + 2] = tk.s2[i];
         if (in.packed) {
-            if (out.text_match) out.text_match[ob + i] = in.words > 4 ? (int64_t)in.packed[(origin / in.k_in) * in.shard_stride + (size_t)qi * qw + (size_t)(origin % in.k_in) * in.words + 4] : 0;
+            if (out.text_match) { uint32_t n_g; out.text_match[ob + i] = in.words > 4 ? (int64_t)shard_entries(origin / in.k_in, n_g)[(size_t)(origin % in.k_in) * in.words + 4] : 0; }
             if (out.vector_distance) out.vector_distance[ob + i] = -1.0f;
             continue;
         }
@@ -2575,6 +2758,12 @@ __global__ __launch_bounds__(KW_THREADS) void kw_shard_merge_kernel(KwShardIn in
             unsigned long long nm = 0;
             int32_t st = 0;
             for (uint32_t g = 0; g < in.n_shards; g++) {
+                if (in.pruned_per) {
+                    const uint64_t* h = in.packed + g * in.shard_stride + (size_t)qi * 2;
+                    nm += h[1];
+                    if (st == 0) st = (int32_t)(uint32_t)((h[0] >> 16) & 0xFFFFu);
+                    continue;
+                }
                 const uint64_t* c = in.packed + g * in.shard_stride + (size_t)qi * qw + (size_t)in.k_in * in.words;
                 nm += c[1];
                 if (st == 0) st = (int32_t)(uint32_t)c[2];

@@ -2049,6 +2049,39 @@ int group_pack_keyword(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint
     TSGPU_HIP_TRY(hipGetLastError());
     return TSGPU_OK;
 }
+// bound-pruned exchange (kw_kernels.hip.h, "bound-pruned exchange"): this shard's kq-th best entry per query -> kth[n_q][4]
+static KwOut kw_out_of(const tsgpu_hits* loc) {
+    KwOut o;
+    o.keys = loc->keys; o.scores = loc->scores; o.text_match = loc->text_match; o.vector_distance = nullptr; o.match_score_index = nullptr;
+    o.n_hits = loc->n_hits; o.num_matched = loc->num_matched; o.off_words = nullptr; o.k_stride = loc->k_stride;
+    return o;
+}
+int group_kw_kth(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t k, const uint32_t* caps_dev, int64_t* kth, hipStream_t s) {
+    (void)hipSetDevice(ctx->device);
+    hipLaunchKernelGGL(kw_group_kth_kernel, dim3((n_q + 255) / 256), dim3(256), 0, s, kw_out_of(loc), (const int32_t*)loc->status, caps_dev, n_q, k, kth);
+    TSGPU_HIP_TRY(hipGetLastError());
+    return TSGPU_OK;
+}
+// ... the bound per query from the gathered kq-th entries, this shard's entries at or above it (cnt[n_q]) and their totals per destination slice (tot[n_dst], zeroed here)
+int group_kw_count(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t k, const int64_t* kth_all, uint32_t n_shards, uint32_t per, uint32_t n_dst,
+                   uint32_t* cnt, uint32_t* tot, hipStream_t s) {
+    (void)hipSetDevice(ctx->device);
+    TSGPU_HIP_TRY(hipMemsetAsync(tot, 0, (size_t)n_dst * 4, s));
+    hipLaunchKernelGGL(kw_group_count_kernel, dim3((n_q + 255) / 256), dim3(256), 0, s, kw_out_of(loc), (const int32_t*)loc->status, n_q, k, kth_all, n_shards, per, cnt, tot);
+    TSGPU_HIP_TRY(hipGetLastError());
+    return TSGPU_OK;
+}
+// ... and the exchange block: n_dst slices of slice_words u64 (per header pairs + room for the slice's entries)
+int group_kw_pack_pruned(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t k, uint32_t words, uint32_t per, uint32_t n_dst, const uint32_t* cnt, uint32_t* first_of,
+                         uint64_t slice_words, uint64_t* block, hipStream_t s) {
+    (void)hipSetDevice(ctx->device);
+    const KwOut o = kw_out_of(loc);
+    hipLaunchKernelGGL(kw_group_pruned_header_kernel, dim3(n_dst), dim3(KW_THREADS), 0, s, o, (const int32_t*)loc->status, n_q, per, cnt, slice_words, block, first_of);
+    const uint64_t n = (uint64_t)n_q * k;
+    hipLaunchKernelGGL(kw_group_pruned_entries_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, o, n_q, k, words, per, cnt, first_of, slice_words, block);
+    TSGPU_HIP_TRY(hipGetLastError());
+    return TSGPU_OK;
+}
 int group_store_keyword_slice(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t q_out_offset, uint32_t k, const tsgpu_hits* out, hipStream_t s) {
     if (n_q == 0) return TSGPU_OK;
     (void)hipSetDevice(ctx->device);
@@ -2066,7 +2099,7 @@ void group_resolve_topster_sizes(const tsgpu_ctx* ctx, const tsgpu_kw_query* que
     for (uint32_t i = 0; i < n_q; i++) caps[i] = resolve_topster_size(ctx, queries[i]);
 }
 int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard_stride_words, uint32_t n_shards, uint32_t n_q, uint32_t q_out_offset, uint32_t k, uint32_t words,
-                        const uint32_t* caps_dev, const tsgpu_hits* out, hipStream_t s) {
+                        const uint32_t* caps_dev, const tsgpu_hits* out, hipStream_t s, uint32_t pruned_per) {
     if (n_q == 0) return TSGPU_OK;
     if (!out || out->mem != TSGPU_MEM_DEVICE || !out->keys || !out->scores || !out->n_hits || out->k_stride < k) return fail(TSGPU_ERR_INVALID, "tsgpu_group: bad output arrays");
     const uint64_t cap_need = (uint64_t)n_shards * k;
@@ -2076,6 +2109,7 @@ int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard
     memset(&in, 0, sizeof in);
     in.n_shards = n_shards; in.n_queries = n_q; in.k_in = k;
     in.packed = gathered; in.shard_stride = shard_stride_words; in.words = words; in.q_out_offset = q_out_offset; in.status_out = out->status; in.cap_per_query = caps_dev;
+    in.pruned_per = pruned_per;
     KwOut o;
     o.keys = out->keys; o.scores = out->scores; o.text_match = out->text_match; o.vector_distance = out->vector_distance;
     o.match_score_index = nullptr; o.n_hits = out->n_hits; o.num_matched = out->num_matched; o.off_words = nullptr; o.k_stride = out->k_stride;

@@ -85,6 +85,8 @@ struct Member {
     DevBuf v_dist, v_lab, v_cnt, v_bad;                  // ... local k-NN result
     DevBuf o_keys, o_scores, o_tm, o_nh, o_nm, o_st, o_vd, o_lab, o_cnt;   // merged result staged on the device (host outputs)
     DevBuf caps;                                         // per-query Topster capacity (the merged list of a query never exceeds its own Topster)
+    DevBuf kth_send, kth_recv, p_cnt, p_first, p_tot;    // bound-pruned exchange: this shard's kq-th entries / every shard's; entries at or above the bound, their offsets, totals per slice
+    std::vector<uint32_t> h_tot;
     std::vector<uint32_t> h_caps;
     PinBuf h_send, h_recv;                               // HOST transport: the staged blocks
     DevBuf agree_d;                                      // RCCL rank form: the ranks' status words
@@ -105,6 +107,7 @@ struct tsgpu_group {
     bool own_slice_only = false;         // rank form, slice exchange (option "kw_own_slice_only"): a rank delivers only the slice of the batch it merged — queries
                                          // [rank * per, (rank + 1) * per), per = ceil(n_queries / n_ranks) — into its output arrays (at those queries' slots); no all-gather of
                                          // the merged lists. What a deployment with one request router per rank needs, and what the local form does with host outputs.
+    bool kw_pruned = true;               // keyword exchange: every shard sends only its entries at or above the query's bound (option "kw_exchange_pruned")
     int kw_slices = 1;                   // (2 = also with one member: exercises the collectives on a single GPU) keyword exchange: all-to-all of query slices + slice merge + all-gather of the merged lists (false: one all-gather, full merge on every rank)
     tsgpu_host_collectives coll{};       // TSGPU_XCHG_HOST
     tsgpu_group_timings tm{};
@@ -205,6 +208,52 @@ int exchange(tsgpu_group* g, size_t bytes) {
         if (src.ctx->device == root.ctx->device) TSGPU_HIP_TRY(hipMemcpyAsync((char*)root.recv.p + j * bytes, src.send.p, bytes, hipMemcpyDeviceToDevice, root.ctx->stream));
         else TSGPU_HIP_TRY(hipMemcpyPeerAsync((char*)root.recv.p + j * bytes, root.ctx->device, src.send.p, src.ctx->device, bytes, root.ctx->stream));
     }
+    return TSGPU_OK;
+}
+
+int copy_between(Member& dst, void* d, Member& src, const void* s_, size_t bytes);
+// `bytes` of every member's `send` buffer -> [n][bytes] in EVERY owned member's `recv` buffer (both reserved by the caller in the local phase)
+int all_gather_everywhere(tsgpu_group* g, DevBuf Member::*send, DevBuf Member::*recv, size_t bytes) {
+    if (g->transport == TSGPU_XCHG_RCCL) {
+        RcclApi* r = rccl();
+        int rc;
+        if (g->m.size() > 1 && (rc = r->GroupStart())) return rccl_fail("ncclGroupStart", rc);
+        for (auto& mem : g->m) {
+            (void)hipSetDevice(mem.ctx->device);
+            if ((rc = r->AllGather((mem.*send).p, (mem.*recv).p, bytes / 8, X_NCCL_UINT64, mem.comm, mem.ctx->stream))) { if (g->m.size() > 1) (void)r->GroupEnd(); return rccl_fail("ncclAllGather (bounds)", rc); }
+        }
+        if (g->m.size() > 1 && (rc = r->GroupEnd())) return rccl_fail("ncclGroupEnd", rc);
+        return TSGPU_OK;
+    }
+    if (g->transport == TSGPU_XCHG_HOST) return host_collective(g, false, (g->m[0].*send).p, bytes, (g->m[0].*recv).p, bytes);
+    for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
+    for (size_t d = 0; d < g->m.size(); d++) {
+        (void)hipSetDevice(g->m[d].ctx->device);
+        for (size_t j = 0; j < g->m.size(); j++) { int rc = copy_between(g->m[d], (char*)(g->m[d].*recv).p + j * bytes, g->m[j], (g->m[j].*send).p, bytes); if (rc) return rc; }
+    }
+    return TSGPU_OK;
+}
+// the greatest of one u64 per member over the whole group (local form: the caller already holds every member's value)
+int group_max_u64(tsgpu_group* g, uint64_t mine, uint64_t* out) {
+    *out = mine;
+    if (g->local || g->n == 1) return TSGPU_OK;
+    Member& mem = g->m[0];
+    std::vector<uint64_t> all(g->n, 0);
+    (void)hipSetDevice(mem.ctx->device);
+    if (g->transport == TSGPU_XCHG_HOST) {
+        const int crc = g->coll.all_gather(g->coll.user, &mine, all.data(), 8);
+        if (crc) return fail(TSGPU_ERR_DEVICE, "tsgpu_group: the caller's all_gather callback failed (" + std::to_string(crc) + ")");
+    } else {
+        uint64_t* hw = mem.agree_h.as<uint64_t>();          // (reserved by agree(): every rank-form call begins with it)
+        hw[g->n] = mine;
+        TSGPU_HIP_TRY(hipMemcpyAsync(mem.agree_d.as<uint64_t>() + g->n, hw + g->n, 8, hipMemcpyHostToDevice, mem.ctx->stream));
+        int rc;
+        if ((rc = rccl()->AllGather(mem.agree_d.as<uint64_t>() + g->n, mem.agree_d.p, 1, X_NCCL_UINT64, mem.comm, mem.ctx->stream))) return rccl_fail("ncclAllGather (slice capacity)", rc);
+        TSGPU_HIP_TRY(hipMemcpyAsync(hw, mem.agree_d.p, (size_t)g->n * 8, hipMemcpyDeviceToHost, mem.ctx->stream));
+        TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+        for (uint32_t r = 0; r < g->n; r++) all[r] = hw[r];
+    }
+    for (uint64_t v : all) *out = std::max(*out, v);
     return TSGPU_OK;
 }
 
@@ -532,8 +581,13 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
         const uint32_t per = slices ? (n_queries + g->n - 1) / g->n : n_queries;      // queries a member merges
         const uint32_t n_pad = slices ? per * g->n : n_queries;
         const size_t KS = out->k_stride;
+        const bool pruned = g->kw_pruned && g->n > 1;
+        const uint32_t n_dst = slices ? g->n : 1;                                      // destination slices of a member's exchange block
         const auto t0 = std::chrono::steady_clock::now();
-        // 1) every member: its shard's Topster (device), packed into its exchange block (one contiguous record per query)
+        g->m[0].h_caps.assign(n_pad, 0u);
+        group_resolve_topster_sizes(g->m[0].ctx, queries, n_queries, g->m[0].h_caps.data());
+        // 1) every member: its shard's Topster (device), packed into its exchange block (one contiguous record per query) — or, bound-pruned
+        //    exchange, its kq-th best entry per query (the block is packed after the bounds are known)
         int rc = for_members(g, [&](size_t i) -> int {
             Member& mem = g->m[i];
             (void)hipSetDevice(mem.ctx->device);
@@ -544,6 +598,9 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
                 (r = mem.send.reserve((size_t)n_pad * qw * 8)) || (r = mem.recv.reserve((slices ? (size_t)n_pad : (size_t)n_queries * g->n) * qw * 8)) ||
                 ((slices || i == 0) && (r = reserve_staging(mem, out, n_pad))) ||
                 (r = reserve_host_staging(g, mem, std::max((slices ? (size_t)n_pad : (size_t)n_queries * g->n) * qw * 8, (size_t)n_pad * KS * 24)))) return r;
+            if (pruned && ((r = mem.kth_send.reserve((size_t)n_queries * 32)) || (r = mem.kth_recv.reserve((size_t)n_queries * 32 * g->n)) || (r = mem.p_cnt.reserve((size_t)n_queries * 4)) ||
+                           (r = mem.p_first.reserve((size_t)n_queries * 4)) || (r = mem.p_tot.reserve((size_t)n_dst * 4)) || (r = mem.caps.reserve((size_t)n_pad * 4)) ||
+                           (r = reserve_host_staging(g, mem, (size_t)n_queries * 32 * g->n)))) return r;
             tsgpu_hits loc;
             memset(&loc, 0, sizeof loc);
             loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL;
@@ -551,26 +608,59 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
             loc.vector_distance = mem.l_vd.as<float>(); loc.match_score_index = mem.l_msi.as<int8_t>();
             loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>(); loc.search_cutoff = mem.l_co.as<int32_t>();
             if ((r = tsgpu_keyword_search_batch(mem.ctx, queries, n_queries, &loc))) return r;
+            if (pruned) {
+                TSGPU_HIP_TRY(hipMemcpyAsync(mem.caps.p, g->m[0].h_caps.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, mem.ctx->stream));      // (h_caps is a member field: it outlives the copy)
+                return group_kw_kth(mem.ctx, &loc, n_queries, k, mem.caps.as<uint32_t>(), mem.kth_send.as<int64_t>(), mem.ctx->stream);
+            }
             if (n_pad > n_queries) TSGPU_HIP_TRY(hipMemsetAsync(mem.send.as<uint64_t>() + (size_t)n_queries * qw, 0, (size_t)(n_pad - n_queries) * qw * 8, mem.ctx->stream));   // padding records: no hits
             return group_pack_keyword(mem.ctx, &loc, n_queries, k, words, mem.send.as<uint64_t>(), mem.ctx->stream);
         });
-        if ((rc = agree(g, rc, call_signature({2, n_queries, k, out->k_stride, hits_mask(out), (uint64_t)slices, (uint64_t)g->own_slice_only})))) return rc;
+        if ((rc = agree(g, rc, call_signature({2, n_queries, k, out->k_stride, hits_mask(out), (uint64_t)slices, (uint64_t)g->own_slice_only, (uint64_t)pruned})))) return rc;
         const double t_local = ms_since(t0);
         const auto t1 = std::chrono::steady_clock::now();
         // 2) the exchange, 3) the exact merge, staged per member in arrays of n_pad queries (stride = the caller's k_stride)
         const size_t mergers = slices ? g->m.size() : 1;                                 // (staging arrays: reserved in the local phase)
-        g->m[0].h_caps.assign(n_pad, 0u);
-        group_resolve_topster_sizes(g->m[0].ctx, queries, n_queries, g->m[0].h_caps.data());
-        if ((rc = slices ? exchange_slices(g, (size_t)per * qw * 8) : exchange(g, (size_t)n_queries * qw * 8))) return rc;
+        size_t slice_words = (size_t)per * qw;                                           // one destination slice of a member's block, in u64 words
+        if (pruned) {
+            // 2a) the bounds: every shard's kq-th entries everywhere (32 B per query and shard); 2b) each member counts its entries at or above the
+            //     bound, per destination slice; 2c) the slice capacity M = the largest (source, destination) total of the whole group (one u64 per
+            //     rank: collectives move equal-sized slices); 2d) the pruned blocks are packed: per slice `per` header pairs + M entries
+            if ((rc = all_gather_everywhere(g, &Member::kth_send, &Member::kth_recv, (size_t)n_queries * 32))) return rc;
+            uint64_t most = 0;
+            for (auto& mem : g->m) {
+                tsgpu_hits loc;
+                memset(&loc, 0, sizeof loc);
+                loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL; loc.keys = mem.l_keys.as<uint64_t>(); loc.scores = mem.l_scores.as<int64_t>(); loc.text_match = mem.l_tm.as<int64_t>();
+                loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>();
+                if ((rc = group_kw_count(mem.ctx, &loc, n_queries, k, mem.kth_recv.as<int64_t>(), g->n, per, n_dst, mem.p_cnt.as<uint32_t>(), mem.p_tot.as<uint32_t>(), mem.ctx->stream))) return rc;
+                mem.h_tot.assign(n_dst, 0u);
+                TSGPU_HIP_TRY(hipMemcpyAsync(mem.h_tot.data(), mem.p_tot.p, (size_t)n_dst * 4, hipMemcpyDeviceToHost, mem.ctx->stream));
+            }
+            for (auto& mem : g->m) {
+                (void)hipSetDevice(mem.ctx->device);
+                TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+                for (uint32_t v : mem.h_tot) most = std::max<uint64_t>(most, v);
+            }
+            if ((rc = group_max_u64(g, most, &most))) return rc;
+            slice_words = (size_t)per * 2 + (size_t)most * words;                        // (<= per * qw: a count never exceeds k, two header words replace three)
+            for (auto& mem : g->m) {
+                tsgpu_hits loc;
+                memset(&loc, 0, sizeof loc);
+                loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL; loc.keys = mem.l_keys.as<uint64_t>(); loc.scores = mem.l_scores.as<int64_t>(); loc.text_match = mem.l_tm.as<int64_t>();
+                loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>();
+                if ((rc = group_kw_pack_pruned(mem.ctx, &loc, n_queries, k, words, per, n_dst, mem.p_cnt.as<uint32_t>(), mem.p_first.as<uint32_t>(), slice_words, mem.send.as<uint64_t>(), mem.ctx->stream))) return rc;
+            }
+        }
+        if ((rc = slices ? exchange_slices(g, slice_words * 8) : exchange(g, slice_words * 8))) return rc;
         for (size_t i = 0; i < mergers; i++) {
             Member& mem = g->m[i];
             (void)hipSetDevice(mem.ctx->device);
             const uint32_t rank = g->local ? (uint32_t)i : g->rank;
             const uint32_t q0 = slices ? rank * per : 0;
             const uint32_t nq = slices ? (q0 < n_queries ? std::min<uint32_t>(per, n_queries - q0) : 0) : n_queries;
-            TSGPU_HIP_TRY(hipMemcpyAsync(mem.caps.p, g->m[0].h_caps.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, mem.ctx->stream));      // (h_caps is a member field: it outlives the copy)
+            if (!pruned) TSGPU_HIP_TRY(hipMemcpyAsync(mem.caps.p, g->m[0].h_caps.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, mem.ctx->stream));      // (h_caps is a member field: it outlives the copy)
             tsgpu_hits d = staged_hits(mem, out);
-            if ((rc = group_merge_keyword(mem.ctx, mem.recv.as<uint64_t>(), slices ? (uint64_t)per * qw : (uint64_t)n_queries * qw, g->n, nq, q0, k, words, mem.caps.as<uint32_t>(), &d, mem.ctx->stream))) return rc;
+            if ((rc = group_merge_keyword(mem.ctx, mem.recv.as<uint64_t>(), slice_words, g->n, nq, q0, k, words, mem.caps.as<uint32_t>(), &d, mem.ctx->stream, pruned ? per : 0u))) return rc;
         }
         // 4) delivery
         if (slices) { if ((rc = deliver_slices(g, out, n_queries, per, g->kw_slices == 2))) return rc; }
@@ -587,7 +677,7 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
         // everything this call enqueued on the members' streams is awaited here
         for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
         g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1);
-        g->tm.exchange_bytes_per_member = slices ? (uint64_t)per * qw * 8 * (g->n - 1) + ((!g->local && g->own_slice_only) ? 0ull : (uint64_t)per * (KS * (32 + (out->text_match ? 8 : 0)) + 16) * (g->n - 1)) : (uint64_t)n_queries * qw * 8 * (g->n - 1);
+        g->tm.exchange_bytes_per_member = (pruned ? (uint64_t)n_queries * 32 * (g->n - 1) : 0ull) + (slices ? (uint64_t)slice_words * 8 * (g->n - 1) + ((!g->local && g->own_slice_only) ? 0ull : (uint64_t)per * (KS * (32 + (out->text_match ? 8 : 0)) + 16) * (g->n - 1)) : (uint64_t)slice_words * 8 * (g->n - 1));
         return ok();
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: host allocation failed"); }
       catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: could not start a member thread"); }
@@ -596,6 +686,7 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
 int tsgpu_group_set_option(tsgpu_group* g, const char* name, int64_t value) {
     if (!g || !name) return fail(TSGPU_ERR_INVALID, "tsgpu_group_set_option: NULL argument");
     std::lock_guard<std::mutex> lk(g->mu);
+    if (!strcmp(name, "kw_exchange_pruned")) { g->kw_pruned = value != 0; return ok(); }
     if (!strcmp(name, "kw_exchange_slices")) { g->kw_slices = value == 2 ? 2 : (value != 0); return ok(); }
     if (!strcmp(name, "replicas")) { g->replicas = value != 0; return ok(); }
     if (!strcmp(name, "kw_own_slice_only")) { g->own_slice_only = value != 0; return ok(); }
