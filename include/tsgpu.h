@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define TSGPU_ABI_VERSION 4
+#define TSGPU_ABI_VERSION 5
 #define TSGPU_MAX_DROPPED_TOKENS 4
 
 /* limits of the accelerated path (anything beyond -> TSGPU_ERR_UNSUPPORTED for that query) */
@@ -567,6 +567,8 @@ typedef struct tsgpu_group_timings {
     float local_ms;                      /* host wall: every member's own batch + pack (members run concurrently) */
     float exchange_merge_ms;             /* host wall: the exchange, the merge and the delivery of the merged result */
     uint64_t exchange_bytes_per_member;  /* bytes one member RECEIVES from the others per call (all collectives of the call) */
+    uint64_t hit_exchange_bytes_per_member;  /* (ABI 5) the part of it that carries the shards' hits to their mergers: the bounds + the (pruned) slices /
+                                              * blocks — without the replication of the merged lists, which does not depend on how the hits travelled */
 } tsgpu_group_timings;
 int tsgpu_group_last_timings(tsgpu_group* g, tsgpu_group_timings* out);
 

@@ -98,8 +98,14 @@ def main():
         check("group size", grp.size() == world)
         for slices in (1, 0):
             grp.set_option("kw_exchange_slices", slices)
-            tag = "%s/slices=%d" % (cut_name, slices)
-            check_keyword("keyword " + tag, grp.keyword_search_batch(qs, K, k_stride=K))
+            vol = {}
+            for pruned in (1, 0):                  # bound-pruned exchange (default) and the full top-k exchange: same merged result
+                grp.set_option("kw_exchange_pruned", pruned)
+                tag = "%s/slices=%d/pruned=%d" % (cut_name, slices, pruned)
+                check_keyword("keyword " + tag, grp.keyword_search_batch(qs, K, k_stride=K))
+                vol[pruned] = int(grp.timings().hit_exchange_bytes_per_member)
+            check("exchange volumes are reported (%s, slices=%d): %s" % (cut_name, slices, vol), vol[1] > 0 and vol[0] > 0)   # (HOST callbacks move equal-sized slices padded to the largest: five queries save nothing here; tests/test_group.py measures the exact-size form)
+            grp.set_option("kw_exchange_pruned", 1)
         # kw_own_slice_only: a rank delivers the slice of the batch it merged (queries [rank * per, (rank + 1) * per)) and nothing else
         grp.set_option("kw_exchange_slices", 1)
         grp.set_option("kw_own_slice_only", 1)

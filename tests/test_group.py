@@ -211,3 +211,60 @@ def test_rccl_transport_one_rank_form_runs_the_real_collective():
     finally:
         grp.close()
         g.close()
+
+
+@pytest.mark.parametrize("slices", [1, 0])
+def test_bound_pruned_exchange_equals_the_unpruned_one_and_the_oracle_under_skew(slices):
+    """option kw_exchange_pruned (default 1): every shard sends only its entries at or above B[q] = the greatest of the shards' kq-th
+    best entries (KV::is_greater order, /root/reference/include/topster.h:146-154). Adversarial data: the documents that win every query live in
+    ONE shard (that shard supplies the bound, the others send nothing or almost nothing), thousands of documents TIE on (text_match, points) around
+    the bound (the key decides), queries with fewer hits than the Topster holds (no bound: nothing may be pruned), per-query Topster capacities,
+    a failing query, an empty shard. Both forms = the unsharded oracle bit for bit, and the pruned form moves fewer bytes."""
+    n_docs, dim = 1500, 8
+    docs = H.zipf_docs(n_docs, 60, 8, seed=21)
+    pts = np.where(np.arange(n_docs) < 500, 1000 + (np.arange(n_docs) % 2), np.arange(n_docs) % 3).astype(np.int64)   # shard 0 wins; two- and three-way ties everywhere
+    orc = O.OracleIndex(1, 1)
+    for d in range(n_docs):
+        orc.index_plain(d, 0, docs[d])
+    orc.set_num_docs(n_docs)
+    orc.set_sort_dense(0, pts)
+    cuts = (0, 500, 1000, 1000, 1500)                        # four members, the third one empty
+    members = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        g = T.GpuIndex(0, H.emu_lib_path())
+        H.load_shard(g, orc, lo, hi, n_docs, pts)
+        members.append(g)
+    grp = T.GpuGroup(members, B.XCHG_COPY)
+    try:
+        grp.set_option("kw_exchange_slices", slices)
+        filt = np.arange(0, n_docs, 3, dtype=np.uint32)
+        qs = [T.KwQuery([1], sort=SORT, topster_size=0), T.KwQuery([1, 2], sort=SORT, topster_size=40), T.KwQuery([2], sort=SORT, topster_size=12),
+              T.KwQuery([3, 1, 2], sort=SORT, topster_size=40), T.KwQuery([55, 56], sort=SORT, topster_size=40), T.KwQuery([4], sort=SORT, topster_size=40, filter_ids=filt),
+              T.KwQuery([2, 3], sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_TEXT_MATCH, 1, 0)), topster_size=40),     # ascending points: the winners are NOT in shard 0
+              T.KwQuery([1, 2], sort=((B.SORT_INT64_COLUMN, 1, 77),), topster_size=40), T.KwQuery([9999], sort=SORT, topster_size=40), T.KwQuery([5], sort=SORT, topster_size=1)]
+        out = {}
+        for pruned in (1, 0):
+            grp.set_option("kw_exchange_pruned", pruned)
+            for k in (250, 40, 7):
+                out[(pruned, k)] = (grp.keyword_search_batch(qs, k=k, k_stride=250), grp.timings().hit_exchange_bytes_per_member)
+        for k in (250, 40, 7):
+            (hp, bytes_p), (hu, bytes_u) = out[(1, k)], out[(0, k)]
+            for name in ("keys", "scores", "text_match", "n_hits", "num_matched", "status"):
+                assert np.array_equal(getattr(hp, name), getattr(hu, name)), (name, k)
+            assert k < 40 or bytes_p < bytes_u, (k, bytes_p, bytes_u)     # (at k = 7 the 32-byte bounds outweigh what they save)
+            for i, q in enumerate(qs):
+                if i == 7:
+                    assert hp.status[i] == B.ERR_UNSUPPORTED and hp.n_hits[i] == 0
+                    continue
+                ref = H.oracle_keyword(orc, q)
+                n = min(k, ref.keys.size)
+                assert hp.status[i] == 0 and int(hp.n_hits[i]) == n, (i, k, int(hp.n_hits[i]), n)
+                assert np.array_equal(hp.keys[i, :n], ref.keys[:n]) and np.array_equal(hp.scores[i, :n], ref.scores[:n]), (i, k)
+                assert int(hp.num_matched[i]) == int(ref.num_keyword_matches)
+        # the winners of the default sort live in shard 0: at k = 40 the other shards' entries all fall below its 40th entry. What crosses the wire
+        # is the bounds (32 B per query and shard) + per slice the header pairs + the LARGEST (source, destination) total of entries
+        assert int(out[(1, 250)][0].n_hits[0]) == 250 and out[(1, 40)][1] * 2 < out[(0, 40)][1], (out[(1, 40)][1], out[(0, 40)][1])
+    finally:
+        grp.close()
+        for g in members:
+            g.close()

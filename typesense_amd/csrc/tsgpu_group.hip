@@ -44,6 +44,8 @@ struct RcclApi {
     int (*CommDestroy)(xComm) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, xComm, hipStream_t) = nullptr;
     int (*AllToAll)(const void*, void*, size_t, int, xComm, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, xComm, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, xComm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -63,6 +65,8 @@ RcclApi* rccl() {
         api.CommDestroy = (int (*)(xComm))sym("ncclCommDestroy");
         api.AllGather = (int (*)(const void*, void*, size_t, int, xComm, hipStream_t))sym("ncclAllGather");
         api.AllToAll = (int (*)(const void*, void*, size_t, int, xComm, hipStream_t))sym("ncclAllToAll");
+        api.Send = (int (*)(const void*, size_t, int, int, xComm, hipStream_t))sym("ncclSend");
+        api.Recv = (int (*)(void*, size_t, int, int, xComm, hipStream_t))sym("ncclRecv");
         api.GroupStart = (int (*)())sym("ncclGroupStart");
         api.GroupEnd = (int (*)())sym("ncclGroupEnd");
         api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
@@ -85,7 +89,7 @@ struct Member {
     DevBuf v_dist, v_lab, v_cnt, v_bad;                  // ... local k-NN result
     DevBuf o_keys, o_scores, o_tm, o_nh, o_nm, o_st, o_vd, o_lab, o_cnt;   // merged result staged on the device (host outputs)
     DevBuf caps;                                         // per-query Topster capacity (the merged list of a query never exceeds its own Topster)
-    DevBuf kth_send, kth_recv, p_cnt, p_first, p_tot;    // bound-pruned exchange: this shard's kq-th entries / every shard's; entries at or above the bound, their offsets, totals per slice
+    DevBuf kth_send, kth_recv, p_cnt, p_first, p_tot, p_totall;    // bound-pruned exchange: this shard's kq-th entries / every shard's; entries at or above the bound, their offsets, totals per slice
     std::vector<uint32_t> h_tot;
     std::vector<uint32_t> h_caps;
     PinBuf h_send, h_recv;                               // HOST transport: the staged blocks
@@ -233,27 +237,32 @@ int all_gather_everywhere(tsgpu_group* g, DevBuf Member::*send, DevBuf Member::*
     }
     return TSGPU_OK;
 }
-// the greatest of one u64 per member over the whole group (local form: the caller already holds every member's value)
-int group_max_u64(tsgpu_group* g, uint64_t mine, uint64_t* out) {
-    *out = mine;
-    if (g->local || g->n == 1) return TSGPU_OK;
+// bound-pruned exchange: every member's per-destination entry totals (p_tot: n_dst u32 on its device) -> tot_all[src * n_dst + dst] on the host
+int gather_totals(tsgpu_group* g, uint32_t n_dst, std::vector<uint32_t>& tot_all) {
+    tot_all.assign((size_t)g->n * n_dst, 0u);
+    if (g->local) {
+        for (size_t i = 0; i < g->m.size(); i++) {
+            Member& mem = g->m[i];
+            (void)hipSetDevice(mem.ctx->device);
+            TSGPU_HIP_TRY(hipMemcpyAsync(tot_all.data() + i * n_dst, mem.p_tot.p, (size_t)n_dst * 4, hipMemcpyDeviceToHost, mem.ctx->stream));
+        }
+        for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
+        return TSGPU_OK;
+    }
     Member& mem = g->m[0];
-    std::vector<uint64_t> all(g->n, 0);
     (void)hipSetDevice(mem.ctx->device);
     if (g->transport == TSGPU_XCHG_HOST) {
-        const int crc = g->coll.all_gather(g->coll.user, &mine, all.data(), 8);
-        if (crc) return fail(TSGPU_ERR_DEVICE, "tsgpu_group: the caller's all_gather callback failed (" + std::to_string(crc) + ")");
-    } else {
-        uint64_t* hw = mem.agree_h.as<uint64_t>();          // (reserved by agree(): every rank-form call begins with it)
-        hw[g->n] = mine;
-        TSGPU_HIP_TRY(hipMemcpyAsync(mem.agree_d.as<uint64_t>() + g->n, hw + g->n, 8, hipMemcpyHostToDevice, mem.ctx->stream));
-        int rc;
-        if ((rc = rccl()->AllGather(mem.agree_d.as<uint64_t>() + g->n, mem.agree_d.p, 1, X_NCCL_UINT64, mem.comm, mem.ctx->stream))) return rccl_fail("ncclAllGather (slice capacity)", rc);
-        TSGPU_HIP_TRY(hipMemcpyAsync(hw, mem.agree_d.p, (size_t)g->n * 8, hipMemcpyDeviceToHost, mem.ctx->stream));
+        std::vector<uint32_t> mine(n_dst, 0u);
+        TSGPU_HIP_TRY(hipMemcpyAsync(mine.data(), mem.p_tot.p, (size_t)n_dst * 4, hipMemcpyDeviceToHost, mem.ctx->stream));
         TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
-        for (uint32_t r = 0; r < g->n; r++) all[r] = hw[r];
+        const int crc = g->coll.all_gather(g->coll.user, mine.data(), tot_all.data(), (size_t)n_dst * 4);
+        if (crc) return fail(TSGPU_ERR_DEVICE, "tsgpu_group: the caller's all_gather callback failed (" + std::to_string(crc) + ")");
+        return TSGPU_OK;
     }
-    for (uint64_t v : all) *out = std::max(*out, v);
+    int rc;
+    if ((rc = rccl()->AllGather(mem.p_tot.p, mem.p_totall.p, (size_t)n_dst * 4, X_NCCL_UINT8, mem.comm, mem.ctx->stream))) return rccl_fail("ncclAllGather (slice totals)", rc);
+    TSGPU_HIP_TRY(hipMemcpyAsync(tot_all.data(), mem.p_totall.p, tot_all.size() * 4, hipMemcpyDeviceToHost, mem.ctx->stream));
+    TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
     return TSGPU_OK;
 }
 
@@ -283,6 +292,35 @@ int exchange_slices(tsgpu_group* g, size_t slice_bytes) {
     for (size_t d = 0; d < g->m.size(); d++) {
         (void)hipSetDevice(g->m[d].ctx->device);
         for (size_t j = 0; j < g->m.size(); j++) { int rc = copy_between(g->m[d], (char*)g->m[d].recv.p + j * slice_bytes, g->m[j], (const char*)g->m[j].send.p + d * slice_bytes, slice_bytes); if (rc) return rc; }
+    }
+    return TSGPU_OK;
+}
+
+// bound-pruned all-to-all at exact sizes: slice j of a member's send buffer (slice_words apart) = `per` header pairs + tot[src][j] entries -> slot src
+// of member j's recv buffer (slots slice_words apart: the merge kernel's stride). RCCL: grouped ncclSend / ncclRecv pairs; COPY: device copies.
+int exchange_slices_exact(tsgpu_group* g, size_t slice_words, const std::vector<uint32_t>& tot, uint32_t per, uint32_t words) {
+    for (auto& mem : g->m) { int rc = mem.recv.reserve(slice_words * 8 * g->n); if (rc) return rc; }      // (reserved in the local phase at the unpruned size: never grows here)
+    auto used = [&](uint32_t src, uint32_t dst) { return ((size_t)per * 2 + (size_t)tot[(size_t)src * g->n + dst] * words) * 8; };
+    if (g->transport == TSGPU_XCHG_RCCL) {
+        RcclApi* r = rccl();
+        int rc;
+        if ((rc = r->GroupStart())) return rccl_fail("ncclGroupStart", rc);
+        for (size_t i = 0; i < g->m.size(); i++) {
+            Member& mem = g->m[i];
+            (void)hipSetDevice(mem.ctx->device);
+            const uint32_t me = g->local ? (uint32_t)i : g->rank;
+            for (uint32_t j = 0; j < g->n; j++) {
+                if ((rc = r->Send((const char*)mem.send.p + (size_t)j * slice_words * 8, used(me, j), X_NCCL_UINT8, (int)j, mem.comm, mem.ctx->stream)) ||
+                    (rc = r->Recv((char*)mem.recv.p + (size_t)j * slice_words * 8, used(j, me), X_NCCL_UINT8, (int)j, mem.comm, mem.ctx->stream))) { (void)r->GroupEnd(); return rccl_fail("ncclSend / ncclRecv (pruned slices)", rc); }
+            }
+        }
+        if ((rc = r->GroupEnd())) return rccl_fail("ncclGroupEnd", rc);
+        return TSGPU_OK;
+    }
+    for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
+    for (size_t d = 0; d < g->m.size(); d++) {
+        (void)hipSetDevice(g->m[d].ctx->device);
+        for (size_t j = 0; j < g->m.size(); j++) { int rc = copy_between(g->m[d], (char*)g->m[d].recv.p + j * slice_words * 8, g->m[j], (const char*)g->m[j].send.p + d * slice_words * 8, used((uint32_t)j, (uint32_t)d)); if (rc) return rc; }
     }
     return TSGPU_OK;
 }
@@ -599,7 +637,7 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
                 ((slices || i == 0) && (r = reserve_staging(mem, out, n_pad))) ||
                 (r = reserve_host_staging(g, mem, std::max((slices ? (size_t)n_pad : (size_t)n_queries * g->n) * qw * 8, (size_t)n_pad * KS * 24)))) return r;
             if (pruned && ((r = mem.kth_send.reserve((size_t)n_queries * 32)) || (r = mem.kth_recv.reserve((size_t)n_queries * 32 * g->n)) || (r = mem.p_cnt.reserve((size_t)n_queries * 4)) ||
-                           (r = mem.p_first.reserve((size_t)n_queries * 4)) || (r = mem.p_tot.reserve((size_t)n_dst * 4)) || (r = mem.caps.reserve((size_t)n_pad * 4)) ||
+                           (r = mem.p_first.reserve((size_t)n_queries * 4)) || (r = mem.p_tot.reserve((size_t)n_dst * 4)) || (r = mem.p_totall.reserve((size_t)n_dst * 4 * g->n)) || (r = mem.caps.reserve((size_t)n_pad * 4)) ||
                            (r = reserve_host_staging(g, mem, (size_t)n_queries * 32 * g->n)))) return r;
             tsgpu_hits loc;
             memset(&loc, 0, sizeof loc);
@@ -621,6 +659,7 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
         // 2) the exchange, 3) the exact merge, staged per member in arrays of n_pad queries (stride = the caller's k_stride)
         const size_t mergers = slices ? g->m.size() : 1;                                 // (staging arrays: reserved in the local phase)
         size_t slice_words = (size_t)per * qw;                                           // one destination slice of a member's block, in u64 words
+        std::vector<uint32_t> tot_all;                                                   // bound-pruned: entries member src sends to destination slice dst
         if (pruned) {
             // 2a) the bounds: every shard's kq-th entries everywhere (32 B per query and shard); 2b) each member counts its entries at or above the
             //     bound, per destination slice; 2c) the slice capacity M = the largest (source, destination) total of the whole group (one u64 per
@@ -633,15 +672,9 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
                 loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL; loc.keys = mem.l_keys.as<uint64_t>(); loc.scores = mem.l_scores.as<int64_t>(); loc.text_match = mem.l_tm.as<int64_t>();
                 loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>();
                 if ((rc = group_kw_count(mem.ctx, &loc, n_queries, k, mem.kth_recv.as<int64_t>(), g->n, per, n_dst, mem.p_cnt.as<uint32_t>(), mem.p_tot.as<uint32_t>(), mem.ctx->stream))) return rc;
-                mem.h_tot.assign(n_dst, 0u);
-                TSGPU_HIP_TRY(hipMemcpyAsync(mem.h_tot.data(), mem.p_tot.p, (size_t)n_dst * 4, hipMemcpyDeviceToHost, mem.ctx->stream));
             }
-            for (auto& mem : g->m) {
-                (void)hipSetDevice(mem.ctx->device);
-                TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
-                for (uint32_t v : mem.h_tot) most = std::max<uint64_t>(most, v);
-            }
-            if ((rc = group_max_u64(g, most, &most))) return rc;
+            if ((rc = gather_totals(g, n_dst, tot_all))) return rc;
+            for (uint32_t v : tot_all) most = std::max<uint64_t>(most, v);
             slice_words = (size_t)per * 2 + (size_t)most * words;                        // (<= per * qw: a count never exceeds k, two header words replace three)
             for (auto& mem : g->m) {
                 tsgpu_hits loc;
@@ -651,7 +684,10 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
                 if ((rc = group_kw_pack_pruned(mem.ctx, &loc, n_queries, k, words, per, n_dst, mem.p_cnt.as<uint32_t>(), mem.p_first.as<uint32_t>(), slice_words, mem.send.as<uint64_t>(), mem.ctx->stream))) return rc;
             }
         }
-        if ((rc = slices ? exchange_slices(g, slice_words * 8) : exchange(g, slice_words * 8))) return rc;
+        // (pruned slices travel at their EXACT sizes where the transport can — RCCL send / recv pairs, device copies: when one shard owns a query's winners
+        //  it alone sends entries for it; the HOST callbacks move equal-sized slices, padded to the largest)
+        const bool exact = pruned && slices && g->transport != TSGPU_XCHG_HOST;
+        if ((rc = exact ? exchange_slices_exact(g, slice_words, tot_all, per, words) : slices ? exchange_slices(g, slice_words * 8) : exchange(g, slice_words * 8))) return rc;
         for (size_t i = 0; i < mergers; i++) {
             Member& mem = g->m[i];
             (void)hipSetDevice(mem.ctx->device);
@@ -677,6 +713,17 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
         // everything this call enqueued on the members' streams is awaited here
         for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
         g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1);
+        g->tm.hit_exchange_bytes_per_member = (pruned ? (uint64_t)n_queries * 32 * (g->n - 1) : 0ull) + (uint64_t)slice_words * 8 * (g->n - 1);
+        if (exact) {                                     // what the busiest receiver of this process's members took in
+            uint64_t worst = 0;
+            for (size_t i = 0; i < g->m.size(); i++) {
+                const uint32_t d = g->local ? (uint32_t)i : g->rank;
+                uint64_t in = 0;
+                for (uint32_t j = 0; j < g->n; j++) if (j != d) in += ((uint64_t)per * 2 + (uint64_t)tot_all[(size_t)j * n_dst + d] * words) * 8;
+                worst = std::max(worst, in);
+            }
+            g->tm.hit_exchange_bytes_per_member = (uint64_t)n_queries * 32 * (g->n - 1) + worst;
+        }
         g->tm.exchange_bytes_per_member = (pruned ? (uint64_t)n_queries * 32 * (g->n - 1) : 0ull) + (slices ? (uint64_t)slice_words * 8 * (g->n - 1) + ((!g->local && g->own_slice_only) ? 0ull : (uint64_t)per * (KS * (32 + (out->text_match ? 8 : 0)) + 16) * (g->n - 1)) : (uint64_t)slice_words * 8 * (g->n - 1));
         return ok();
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: host allocation failed"); }
@@ -758,7 +805,7 @@ int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float
                 for (const KwArr& a : arrs) if ((rc = copy_out(a.dst, (root.*(a.buf)).p, (size_t)n_queries * a.elem, mem_out, root.ctx->stream))) return rc;
             }
             for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
-            g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1); g->tm.exchange_bytes_per_member = (uint64_t)per * ((size_t)k * 12 + 4) * (g->n - 1);
+            g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1); g->tm.exchange_bytes_per_member = (uint64_t)per * ((size_t)k * 12 + 4) * (g->n - 1); g->tm.hit_exchange_bytes_per_member = 0;
             return ok();
         }
         const size_t block_words = (size_t)n_queries * k;
@@ -801,7 +848,7 @@ int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float
             bad += b;
         }
         if (bad) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_vec_knn_batch: a label beyond 32 bits (the exchange carries seq_ids)");
-        g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1); g->tm.exchange_bytes_per_member = block_words * 8 * (g->n - 1);
+        g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1); g->tm.exchange_bytes_per_member = block_words * 8 * (g->n - 1); g->tm.hit_exchange_bytes_per_member = g->tm.exchange_bytes_per_member;
         return ok();
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_vec_knn_batch: host allocation failed"); }
       catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_vec_knn_batch: could not start a member thread"); }
