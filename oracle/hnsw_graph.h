@@ -120,12 +120,13 @@ struct hnsw_graph_t {
         for (const dist_id_t& cur : return_list) top_candidates.emplace(-cur.first, cur.second);
     }
 
-    tableint mutuallyConnectNewElement(const float* q, tableint cur_c, heap_t& top_candidates, int level) {
+    tableint mutuallyConnectNewElement(const float* q, tableint cur_c, heap_t& top_candidates, int level, tableint prev_entry_point) {
         size_t Mcurmax = level ? maxM : maxM0;
         getNeighborsByHeuristic2(top_candidates, M);
         std::vector<tableint> selected;
         selected.reserve(M);
         while (top_candidates.size() > 0) { selected.push_back(top_candidates.top().second); top_candidates.pop(); }
+        if (selected.empty()) return prev_entry_point;          // (unreachable once addPoint re-adds a deleted entry point; never index an empty selection)
         tableint next_closest_entry_point = selected.back();
         list_of(cur_c, level) = selected;
         for (size_t idx = 0; idx < selected.size(); idx++) {
@@ -158,8 +159,12 @@ struct hnsw_graph_t {
         linkU.emplace_back((size_t)curlevel);
         int maxlevelcopy = maxlevel;
         tableint currObj = enterpoint;
+        const tableint enterpoint_copy = enterpoint;
         const float* q = vec(cur_c);
         if ((int32_t)currObj != -1) {
+            // hnswlib addPoint: `bool epDeleted = isMarkedDeleted(enterpoint_copy);` — a deleted entry point is put back into every level's
+            // candidates (searchBaseLayer leaves deleted nodes out of its result heap), so that an emptied and refilled index still links its new nodes
+            const bool epDeleted = deleted[enterpoint_copy] != 0;
             if (curlevel < maxlevelcopy) {
                 float curdist = dist(q, vec(currObj));
                 for (int level = maxlevelcopy; level > curlevel; level--) {
@@ -176,7 +181,11 @@ struct hnsw_graph_t {
             }
             for (int level = std::min(curlevel, maxlevelcopy); level >= 0; level--) {
                 heap_t top_candidates = searchBaseLayer(currObj, q, level);
-                currObj = mutuallyConnectNewElement(q, cur_c, top_candidates, level);
+                if (epDeleted) {
+                    top_candidates.emplace(dist(q, vec(enterpoint_copy)), enterpoint_copy);
+                    if (top_candidates.size() > ef_construction) top_candidates.pop();
+                }
+                currObj = mutuallyConnectNewElement(q, cur_c, top_candidates, level, currObj);
             }
         } else {
             enterpoint = 0;

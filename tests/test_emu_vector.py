@@ -754,3 +754,41 @@ def test_int8_bracket_mirror_hard_cases_zero_rows_huge_values_non_finite_and_tie
         assert np.array_equal(lab[i, :d.size][keep_g][:m].astype(np.uint32), l[keep_o][:m]), i
         assert np.array_equal(dist[i, :d.size][keep_g][:m].view(np.uint32), d[keep_o][:m].view(np.uint32)), i
     g.close()
+
+
+def test_hnsw_build_after_every_row_was_deleted_relinks_through_the_deleted_entry_point():
+    """hnswlib's addPoint puts a DELETED entry point back into every level's candidates (`epDeleted`); without it a collection
+    that was emptied and refilled handed empty heaps to mutuallyConnectNewElement — new nodes without links, unreachable by the graph search.
+    Upsert one row, delete it, upsert 60 more (one addPoint per document, the server's calling convention), delete them ALL, upsert 80 more:
+    the library's graph = the oracle's link for link, every live node has level-0 links, and the graph search finds the exact neighbours."""
+    dim, M, efc = 16, 6, 40
+    rng = np.random.default_rng(321)
+    X = rng.standard_normal((141, dim)).astype(np.float32)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.vec_create(1, dim, B.METRIC_IP)
+    g.vec_hnsw_enable(1, M=M, ef_construction=efc, seed=100, threads=1)
+    orc = O.OracleIndex(1, 1)
+    orc.vec_init(dim, B.METRIC_IP)
+    orc.vec_add(np.array([0], np.uint32), X[:1])
+    orc.hnsw_build(M=M, ef_construction=efc, seed=100)
+    g.vec_upsert(1, np.array([0], np.uint64), X[:1])
+    g.vec_delete(1, 0); orc.hnsw_mark_deleted(0)
+    for i in range(1, 61):
+        g.vec_upsert(1, np.array([i], np.uint64), X[i:i + 1])
+        orc.hnsw_add(np.array([i], np.uint32), X[i:i + 1])
+    for i in range(1, 61):
+        g.vec_delete(1, i); orc.hnsw_mark_deleted(i)
+    g.vec_upsert(1, np.arange(61, 141, dtype=np.uint64), X[61:])
+    orc.hnsw_add(np.arange(61, 141, dtype=np.uint32), X[61:])
+    mine, ref = g.vec_hnsw_export(1), orc.hnsw_export()
+    assert mine["n"] == 141 and _graphs_equal(mine, ref)
+    cnts = mine["link0"][:, 0]
+    assert (cnts[2:61] > 0).all() and (cnts[62:] > 0).all(), "a node inserted behind a deleted entry point has no links"
+    Q = rng.standard_normal((6, dim)).astype(np.float32)
+    dist, lab, cnt = g.vec_hnsw_search_batch(1, Q, 10, 80)
+    exact = g.vec_knn_batch(1, Q, 10)[1]
+    for i in range(Q.shape[0]):
+        d, l, _ = orc.hnsw_search(Q[i], 10, 80, functor_present=True)
+        assert cnt[i] == d.size == 10 and np.array_equal(lab[i, :10], l) and (l >= 61).all()
+        assert len(set(lab[i].tolist()) & set(exact[i].tolist())) >= 9
+    g.close()

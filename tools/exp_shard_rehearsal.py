@@ -35,10 +35,13 @@ def main():
         T.KwQuery(qtok[i], sort=sort, topster_size=250).fill(arr[i])
     out = {"n_docs": n_docs, "batch": n_q, "shards": {}}
     for G in (1, 2, 4, 8):
-        lo, hi = 0, n_docs // G
-        csr = synth.zipf_corpus_csr(n_docs, vocab, tpd, seed=2, doc_range=(lo, hi) if G > 1 else None)
-        members = []
-        for _ in range(1 if G == 1 else 2):          # two members sharing the device are enough to exercise pack + exchange copy + merge of G blocks below
+        # G DISTINCT doc-range shards, all resident on this one device (round 5: the bound-pruned exchange depends on how the winners spread over
+        # the shards — G copies of one shard would prune nothing). Member 0's local step is timed alone; the group call then runs every member's
+        # pack / bound / count / pruned-pack kernels, the slice copies and the G slice merges on the ONE device: that time / G = one GPU's share.
+        members, postings = [], 0
+        for i in range(G):
+            lo, hi = i * (n_docs // G), (i + 1) * (n_docs // G) if i + 1 < G else n_docs
+            csr = synth.zipf_corpus_csr(n_docs, vocab, tpd, seed=2, doc_range=(lo, hi) if G > 1 else None)
             g = T.GpuIndex(0)
             g.field_create(0, False)
             g.terms_load_csr(0, csr["term_ids"], csr["ids_ptr"], csr["ids"], csr["offset_index"], csr["off_ptr"], csr["offsets"])
@@ -46,6 +49,9 @@ def main():
             g.set_num_docs(n_docs)
             g.commit()
             members.append(g)
+            if i == 0:
+                postings = int(csr["n_postings"])
+            del csr
         g = members[0]
         dev, hs = device_hits(torch, n_q, 250)
         for _ in range(3):
@@ -58,29 +64,25 @@ def main():
             kern.append(tm.kw_search_ms); merge.append(tm.kw_merge_ms); find.append(tm.kw_find_ms)
         local_ms = 1e3 * (time.perf_counter() - t0) / args.steps
         rec = {"local_step_ms": local_ms, "find_plus_score_kernel_ms": float(np.mean(kern)), "find_kernel_ms": float(np.mean(find)), "partial_merge_kernel_ms": float(np.mean(merge)),
-               "host_ms (plan + launch + sync)": local_ms - float(np.mean(kern)) - float(np.mean(merge)), "postings": int(csr["n_postings"])}
+               "host_ms (plan + launch + sync)": local_ms - float(np.mean(kern)) - float(np.mean(merge)), "postings": postings}
         if G > 1:
-            # pack + the merge of G gathered blocks: a COPY group of G members is emulated by gathering member 0's block G times — the merge
-            # kernel's cost depends on G * k entries per query, not on whose they are
-            grp = T.GpuGroup(members + [members[1]] * (G - 2), B.XCHG_COPY) if G > 2 else T.GpuGroup(members, B.XCHG_COPY)
+            grp = T.GpuGroup(members, B.XCHG_COPY)
             gdev, ghs = device_hits(torch, n_q, 100)
-            for _ in range(2):
-                grp.keyword_search_batch_raw(arr, n_q, 100, ghs)
-            ex = []
-            for _ in range(4):
-                grp.keyword_search_batch_raw(arr, n_q, 100, ghs)
-                ex.append(grp.timings().exchange_merge_ms)
-            rec["slices: copies + G slice merges + replication, ALL on this one device (ms)"] = float(np.mean(ex))
-            rec["slices: bytes received per GPU"] = int(grp.timings().exchange_bytes_per_member)
-            grp.set_option("kw_exchange_slices", 0)
-            for _ in range(2):
-                grp.keyword_search_batch_raw(arr, n_q, 100, ghs)
-            ex = []
-            for _ in range(4):
-                grp.keyword_search_batch_raw(arr, n_q, 100, ghs)
-                ex.append(grp.timings().exchange_merge_ms)
-            rec["all-gather form: G block copies + full merge on one device (ms)"] = float(np.mean(ex))
-            rec["all-gather form: bytes received per GPU"] = int(grp.timings().exchange_bytes_per_member)
+            for form, slices in (("slices", 1), ("all-gather form", 0)):
+                grp.set_option("kw_exchange_slices", slices)
+                for pruned in (1, 0):
+                    grp.set_option("kw_exchange_pruned", pruned)
+                    for _ in range(2):
+                        grp.keyword_search_batch_raw(arr, n_q, 100, ghs)
+                    ex, loc = [], []
+                    for _ in range(4):
+                        grp.keyword_search_batch_raw(arr, n_q, 100, ghs)
+                        tmg = grp.timings()
+                        ex.append(tmg.exchange_merge_ms); loc.append(tmg.local_ms)
+                    tag = "%s, %s" % (form, "bound-pruned" if pruned else "full top-k")
+                    rec[tag + ": exchange kernels + copies + merges of ALL %d members on this one device (ms)" % G] = float(np.mean(ex))
+                    rec[tag + ": hit bytes received per GPU (bounds + slices / blocks)"] = int(tmg.hit_exchange_bytes_per_member)
+                    rec[tag + ": all bytes received per GPU (+ replication of the merged lists)"] = int(tmg.exchange_bytes_per_member)
             grp.close()
         out["shards"][str(G)] = rec
         for m in members:
@@ -90,15 +92,24 @@ def main():
     pred = {}
     for G in (2, 4, 8):
         r = out["shards"][str(G)]
-        # wire time over xGMI modelled at 150 GB/s (conservative) and 300 GB/s (RCCL bus bandwidth on a full mesh) received per GPU
-        for form, key_ms, key_b, div in (("slices (all-to-all + slice merge + all-gather of merged lists)", "slices: copies + G slice merges + replication, ALL on this one device (ms)",
-                                          "slices: bytes received per GPU", G),
-                                         ("one all-gather + full merge", "all-gather form: G block copies + full merge on one device (ms)", "all-gather form: bytes received per GPU", 1)):
-            wire = [1e3 * r[key_b] / bw for bw in (150e9, 300e9)]
-            dev_ms = r[key_ms] / div            # the slice form's device work is spread over the G GPUs
-            step = [r["local_step_ms"] + dev_ms + w for w in wire]
-            pred.setdefault(str(G), {})[form] = {"wire_ms@150GB/s,300GB/s": wire, "pack+merge_ms_per_gpu": dev_ms, "predicted_step_ms": step,
-                                                 "predicted_speedup_vs_1gpu": [base / x for x in step], "predicted_qps": [n_q / (x * 1e-3) for x in step]}
+        # MODEL, every term listed: step(G) = local step of a 1/G shard (measured alone: kernels + per-batch host work)
+        #                                   + this GPU's share of the exchange's device work (measured for all G members on one device, / G for the slice form: every member
+        #                                     packs its own block and merges its own slice; / 1 for the all-gather form: every rank merges everything)
+        #                                   + wire time = bytes received per GPU / bandwidth, at 150 GB/s (one xGMI link, conservative) and 300 GB/s (several links busy)
+        # own-slice delivery (rank form, option kw_own_slice_only: what bench.py --gpus N times): the replication of the merged lists is not sent -> hit bytes only.
+        for pruned in ("bound-pruned", "full top-k"):
+            for form, div in (("slices", G), ("all-gather form", 1)):
+                tag = "%s, %s" % (form, pruned)
+                dev_ms = r[tag + ": exchange kernels + copies + merges of ALL %d members on this one device (ms)" % G] / div
+                for deliver, key_b in (("replicated result", ": all bytes received per GPU (+ replication of the merged lists)"), ("own slice only", ": hit bytes received per GPU (bounds + slices / blocks)")):
+                    if form != "slices" and deliver == "own slice only":
+                        continue
+                    wire = [1e3 * r[tag + key_b] / bw for bw in (150e9, 300e9)]
+                    step = [r["local_step_ms"] + dev_ms + w for w in wire]
+                    pred.setdefault(str(G), {})["%s, %s" % (tag, deliver)] = {
+                        "terms_ms": {"local_step": r["local_step_ms"], "exchange_device_work_per_gpu": dev_ms, "wire@150GB/s,300GB/s": wire},
+                        "bytes_received_per_gpu": r[tag + key_b], "predicted_step_ms": step,
+                        "predicted_speedup_vs_1gpu": [base / x for x in step], "predicted_qps": [n_q / (x * 1e-3) for x in step]}
     out["predicted"] = pred
     print(json.dumps(out))
 

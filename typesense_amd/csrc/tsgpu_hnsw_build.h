@@ -25,6 +25,15 @@
 
 namespace tsgpu {
 
+struct VisitedList {                                  // hnswlib's VisitedList: a tag per node and an epoch instead of a cleared array per search
+    std::vector<uint16_t> tag; uint16_t epoch = 0;
+    void begin(size_t n) {
+        if (tag.size() < n) tag.resize(std::max(n, tag.size() + tag.size() / 2), 0);      // (geometric: one-row insertions do not reallocate every time)
+        if (++epoch == 0) { std::fill(tag.begin(), tag.end(), 0); epoch = 1; }
+    }
+    bool test_and_set(uint32_t i) { const bool v = tag[i] == epoch; tag[i] = epoch; return v; }
+};
+
 struct HnswBuilder {
     typedef std::pair<float, uint32_t> DistId;
     struct ByDist { bool operator()(const DistId& a, const DistId& b) const noexcept { return a.first < b.first; } };
@@ -48,6 +57,8 @@ struct HnswBuilder {
     std::vector<uint32_t> upper;                      // [(node, level >= 1)][1 + M]
     std::deque<std::mutex> node_mu;                   // one per node (stable addresses while the deque grows)
     std::mutex global_mu;
+    std::deque<VisitedList> vis_pool;          // one visited list per inserting thread, kept across add_batch calls: the server's calling convention is
+                                                      // one addPoint per document, and a fresh list per call allocates and zeroes a tag per NODE (O(n) per insertion)
 
     void init(uint32_t dim_, uint32_t M_, uint32_t efc, uint32_t seed, uint32_t threads, int lanes) {
         dim = dim_; M = M_; ef_construction = std::max(efc, M_); mult = 1.0 / std::log(1.0 * M_);
@@ -62,11 +73,7 @@ struct HnswBuilder {
     uint32_t* list_of(uint32_t node, int level) { return level == 0 ? link0.data() + (size_t)node * s0() : upper.data() + (upper_at[node] + (uint64_t)(level - 1)) * su(); }
     uint64_t n_upper_lists() const { return upper.size() / su(); }
 
-    struct Visited {                                  // hnswlib's VisitedList: a tag per node and an epoch instead of a cleared array per search
-        std::vector<uint16_t> tag; uint16_t epoch = 0;
-        void begin(size_t n) { if (tag.size() < n) tag.resize(n, 0); if (++epoch == 0) { std::fill(tag.begin(), tag.end(), 0); epoch = 1; } }
-        bool test_and_set(uint32_t i) { const bool v = tag[i] == epoch; tag[i] = epoch; return v; }
-    };
+    typedef VisitedList Visited;
 
     // the ef_construction-bounded beam of one layer (searchBaseLayer)
     Heap search_layer(uint32_t ep, const float* q, int layer, Visited& vis, bool locked) {
@@ -119,12 +126,13 @@ struct HnswBuilder {
     }
 
     // mutuallyConnectNewElement: the new node's list on this level, then the reverse links
-    uint32_t connect(uint32_t cur, Heap& top, int level, bool locked) {
+    uint32_t connect(uint32_t cur, Heap& top, int level, bool locked, uint32_t prev_ep) {
         const size_t cap = level ? M : 2 * (size_t)M;
         select_neighbours(top, M);
         std::vector<uint32_t> sel;
         sel.reserve(M);
         while (!top.empty()) { sel.push_back(top.top().second); top.pop(); }
+        if (sel.empty()) return prev_ep;                  // (cannot happen once addPoint re-adds a deleted entry point, below; never index an empty selection)
         const uint32_t next_ep = sel.back();
         {
             std::unique_lock<std::mutex> lk(node_mu[cur], std::defer_lock);
@@ -160,8 +168,13 @@ struct HnswBuilder {
         const int maxlevel_copy = maxlevel;
         if (locked && curlevel <= maxlevel_copy) glk.unlock();          // (held to the end only when this node becomes the entry point)
         uint32_t ep = enterpoint;
+        const uint32_t ep_copy = ep;
         const float* q = vec(cur);
         if (ep != 0xFFFFFFFFu) {
+            // hnswlib's addPoint: `bool epDeleted = isMarkedDeleted(enterpoint_copy)` — a deleted entry point never enters a beam's result heap, so
+            // a collection whose rows were ALL deleted (emptied and refilled) would hand empty heaps to mutuallyConnectNewElement; the entry point is
+            // put back into every level's candidates instead (without it new nodes got no links and became unreachable)
+            const bool ep_deleted = deleted[ep_copy] != 0;
             if (curlevel < maxlevel_copy) {
                 float curdist = dist(q, vec(ep));
                 std::vector<uint32_t> nb;
@@ -181,7 +194,11 @@ struct HnswBuilder {
             }
             for (int level = std::min(curlevel, maxlevel_copy); level >= 0; level--) {
                 Heap top = search_layer(ep, q, level, vis, locked);
-                ep = connect(cur, top, level, locked);
+                if (ep_deleted) {
+                    top.emplace(dist(q, vec(ep_copy)), ep_copy);
+                    if (top.size() > ef_construction) top.pop();
+                }
+                ep = connect(cur, top, level, locked, ep);
             }
         } else { enterpoint = cur; maxlevel = curlevel; }
         if (curlevel > maxlevel_copy) { enterpoint = cur; maxlevel = curlevel; }
@@ -206,11 +223,13 @@ struct HnswBuilder {
         dirty = true;
         const uint32_t T = (uint32_t)std::min<size_t>(n_threads, n);
         // the very first node has nothing to connect to; it (and any node that raises the top level) is inserted before the concurrent part
-        if (T <= 1) { Visited vis; for (size_t i = 0; i < n; i++) insert((uint32_t)(n0 + i), vis, false); return; }
+        while (vis_pool.size() < std::max<uint32_t>(T, 1)) vis_pool.emplace_back();
+        if (T <= 1) { for (size_t i = 0; i < n; i++) insert((uint32_t)(n0 + i), vis_pool[0], false); return; }
         std::atomic<size_t> next{0};
-        if (n0 == 0) { Visited vis; insert(0, vis, false); next = 1; }
+        if (n0 == 0) { insert(0, vis_pool[0], false); next = 1; }
+        for (uint32_t t = 0; t < T; t++) vis_pool[t].begin(size());      // (grown here: a tag array must not reallocate under a sibling's feet — each thread owns its own anyway)
         std::vector<std::thread> th;
-        for (uint32_t t = 0; t < T; t++) th.emplace_back([&]() { Visited vis; for (;;) { const size_t i = next.fetch_add(1); if (i >= n) break; insert((uint32_t)(n0 + i), vis, true); } });
+        for (uint32_t t = 0; t < T; t++) th.emplace_back([&, t]() { Visited& vis = vis_pool[t]; for (;;) { const size_t i = next.fetch_add(1); if (i >= n) break; insert((uint32_t)(n0 + i), vis, true); } });
         for (auto& x : th) x.join();
     }
 };

@@ -821,7 +821,10 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
                     for (int e = 0; e < 16; e++) acc[rb][cb][e] = 0.0f;
         }
         // no branch around the DMAs: steps past the end re-request the last blocks into slots nobody reads any more
-#if !defined(VEC_ABL) || !(VEC_ABL & 4)   // VEC_ABL: tools/ ablation builds only (bit 0 no epilogue, bit 1 no MFMA, bit 2 no DMA, bit 3 no operand fetches, bit 4 no step barrier)
+#if !defined(VEC_ABL) || !(VEC_ABL & 4)   // VEC_ABL: tools/ ablation builds only (bit 0 no epilogue, bit 1 no MFMA, bit 2 no DMA, bit 3 no operand fetches, bit 4 no step barrier, bit 5 one query DMA in seven skipped)
+#if defined(VEC_ABL) && (VEC_ABL & 32)     // (results WRONG) the query DMA of one k chunk in seven is skipped: what an LDS-RESIDENT seventh of the query block (all that fits beside the rings) would save
+        if ((s + NS - 1) % n_chunks % 7 != 0)
+#endif
         load_q(s + NS - 1 < total_steps ? s + NS - 1 : last, xslot >= 1 ? xslot - 1 : NS - 1);       // (s + NS - 1) % NS
         load_x(s + NS - 1 < total_steps ? s + NS - 1 : last, xslot >= 1 ? xslot - 1 : NS - 1);
 #endif
