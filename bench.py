@@ -11,10 +11,10 @@ top-100) and `hybrid` (config 4: keyword + vector + reciprocal-rank fusion) sub-
 its own parity object checked at FULL size against the oracle.
 
 N>1 (BASELINE config 5), default `--dist-mode shards`: the SAME 10M-doc collection cut into N contiguous seq_id ranges, every
-GPU scores the whole query batch on its shard, ONE RCCL all-gather of the per-GPU top-100 + counts, exact merge on the device
-(typesense_amd/dist.py, kw_shard_merge_kernel); total work is fixed -> "scaling": "strong". Rank 0 also holds an unsharded twin
-of the collection and checks a sample of the merged results against it inside the bench. `--dist-mode replicas` (second form:
-every GPU holds the collection, the global batch of N x 10 000 queries is sharded across the GPUs) is reported as a sub-object.
+GPU scores the whole query batch on its shard, then the exchange behind the C-ABI (tsgpu_group, rank form, RCCL: the shards' bounds,
+the bound-pruned query slices, an exact slice merge on the device); total work is fixed -> "scaling": "strong". Rank 0
+also holds an unsharded twin of the collection and checks a sample of the merged results against it inside the bench.
+`--dist-mode replicas`: every GPU holds the collection and answers its own batch — N independent replicas, no collective.
 
 `roofline` = the dominant kernel: algorithmic bytes (or flops) per launch / its HIP-event time measured inside the
 library on its launch stream. `cpu_baseline` (rank 0, N=1) = the oracle — a port of the reference's CPU path — timed on
@@ -240,11 +240,11 @@ class Bench:
             # N ranks share this node's host cores: a rank plans its batch on its share of them, not on the single-process default of 8 threads
             self.g.set_option("plan_threads", max(1, min(8, int(cpu_quota_cpus() or os.cpu_count() or 8) // world)))
         self.n_docs = args.n_docs
-        from typesense_amd import dist as D
+        from typesense_amd import hostcoll as D           # doc-range arithmetic + the torch.distributed callbacks of the group's HOST transport (plumbing only)
         self.D = D
         self.sharded = world > 1 and args.dist_mode == "shards"
         self.lo, self.hi = D.shard_range(self.n_docs, rank, world) if self.sharded else (0, self.n_docs)
-        self.qseed = 1000 * rank if (world > 1 and not self.sharded) else 0      # replicas: every rank draws its own slice of the global batch
+        self.qseed = 1000 * rank if (world > 1 and not self.sharded) else 0      # replicas: every rank draws its own batch
         self.twin = None            # shards mode, rank 0: the unsharded collection (in-bench equality check of the merged results)
         self.sort = None
         self.csr = None
@@ -254,18 +254,15 @@ class Bench:
         # merge kernels (rank 0's ncclUniqueId travels through torch.distributed). Under TSGPU_DIST_BACKEND=gloo (rehearsal: the ranks share
         # one GPU) the same group runs over its HOST transport (the callbacks = torch.distributed on host memory). If the group cannot be
         # brought up, or its probe call fails on any rank, the bench FAILS on every rank: it never measures a path the product does not ship.
-        # TSGPU_BENCH_EXCHANGE=torch is the explicit opt-in to the superseded torch.distributed exchange (comparison runs only; the line says so).
-        self.group, self.exchange = None, "none (1 GPU)"
+        self.group, self.exchange = None, "none (1 GPU)" if world == 1 else "none (independent replicas)"
         if self.sharded:
             self.group = self.join_group(self.g)
-            if self.group is None:
-                self.exchange = "torch.distributed all-gather + tsgpu merge kernels (TSGPU_BENCH_EXCHANGE=torch: NOT the product's exchange)"
-            elif self.group_transport == "rccl":
-                self.exchange = ("tsgpu_group (C-ABI, rank form, RCCL): ncclAllToAll of query slices + slice merge (kw_shard_merge_kernel) + in-place ncclAllGather of the merged "
-                                 "lists, on the library's stream; k-NN: one ncclAllGather + vec_group_merge_kernel")
+            if self.group_transport == "rccl":
+                self.exchange = ("tsgpu_group (C-ABI, rank form, RCCL): ncclAllGather of the shards' bounds, bound-pruned query slices by ncclSend/ncclRecv, slice merge "
+                                 "(kw_shard_merge_kernel), on the library's stream; k-NN: one ncclAllGather + vec_group_merge_kernel")
             else:
-                self.exchange = ("tsgpu_group (C-ABI, rank form, HOST transport over torch.distributed/%s callbacks): all-to-all of query slices + slice merge + all-gather of the "
-                                 "merged lists, staged through pinned host memory; k-NN: one all-gather + vec_group_merge_kernel" % os.environ.get("TSGPU_DIST_BACKEND", "nccl"))
+                self.exchange = ("tsgpu_group (C-ABI, rank form, HOST transport over torch.distributed/%s callbacks): all-gather of the shards' bounds, all-to-all of the bound-pruned "
+                                 "query slices + slice merge, staged through pinned host memory; k-NN: one all-gather + vec_group_merge_kernel" % os.environ.get("TSGPU_DIST_BACKEND", "nccl"))
 
     def all_ranks_or_die(self, ok, what, err):
         """every rank learns whether `what` succeeded everywhere; if not, every rank raises (no rank is left inside a collective, and no
@@ -274,15 +271,12 @@ class Bench:
         flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) != 1:
-            raise RuntimeError("[bench] rank %d: tsgpu_group %s failed on at least one rank (%s here): the multi-GPU line is NOT measured on another path. "
-                               "TSGPU_BENCH_EXCHANGE=torch runs the superseded torch.distributed exchange for comparison." % (self.rank, what, err or "ok"))
+            raise RuntimeError("[bench] rank %d: tsgpu_group %s failed on at least one rank (%s here): the multi-GPU line is NOT measured on another path." % (self.rank, what, err or "ok"))
 
     def join_group(self, index):
         """tsgpu_group over this rank's context `index` (rank form). nccl backend: RCCL inside the library; any other backend: the group's
         HOST transport over torch.distributed callbacks. Fails on every rank if any rank fails."""
         torch, T = self.torch, self.T
-        if os.environ.get("TSGPU_BENCH_EXCHANGE", "group") == "torch":
-            return None
         import torch.distributed as dist
         grp, err = None, None
         rccl = os.environ.get("TSGPU_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("TSGPU_BENCH_TRANSPORT", "rccl") == "rccl"
@@ -406,43 +400,19 @@ class Bench:
         arr = self.kw_query_array(qtok)
         dev, hs = device_hits(torch, n_q, K_TOPSTER)
         kern_ms, merge_ms, find_ms, alg_bytes = [], [], [], []
-        if world > 1:
-            pack = torch.zeros((n_q, FETCH_SIZE, 4), dtype=torch.int64, device="cuda")
-            counts = torch.zeros((n_q, 2), dtype=torch.int64, device="cuda")
 
         if self.group is not None:
             gdev, ghs = device_hits(torch, n_q, FETCH_SIZE)
             self.group_works("keyword", lambda: self.group.keyword_search_batch_raw(arr, n_q, FETCH_SIZE, ghs))
 
-        def step_torch_exchange():
-            g.keyword_search_batch_raw(arr, n_q, hs)
-            pack[:, :, 0] = dev["keys"][:, :FETCH_SIZE]
-            pack[:, :, 1:] = dev["scores"][:, :FETCH_SIZE]
-            counts[:, 0] = torch.clamp(dev["n_hits"], max=FETCH_SIZE)
-            counts[:, 1] = dev["num_matched"]
-            return self.D.merge_gathered_keyword(g, self.D.all_gather_cat(pack), self.D.all_gather_cat(counts), FETCH_SIZE)
-
         def step():
             if self.group is not None:
-                # the whole shard step behind the C-ABI: every rank's top-250 Topster, its top-100 packed {key, scores[3]} + counts (32 MB per
-                # GPU at 10 000 queries), ONE ncclAllGather on the library's stream, exact merge (kw_shard_merge_kernel), device-resident result
+                # the whole shard step behind the C-ABI: every rank's top-250 Topster, the shards' bounds (32-byte entries), the bound-pruned
+                # slices of its top-100 to the ranks that merge them, exact slice merge (kw_shard_merge_kernel), device-resident result
                 self.group.keyword_search_batch_raw(arr, n_q, FETCH_SIZE, ghs)
                 return gdev["keys"], gdev["scores"], gdev["n_hits"], gdev["num_matched"]
-            g.keyword_search_batch_raw(arr, n_q, hs)           # synchronises its stream before returning
-            if world == 1:
-                return dev["keys"], dev["scores"], dev["n_hits"], dev["num_matched"]
-            # ONE exchange per step: the all-gather of every GPU's top-100 (fetch size; the Topster's 250 slots are the reference's
-            # internal over-fetch) {key, scores[3]} + {n_hits, num_matched}: 10 000 x 100 x 32 B = 32 MB per GPU
-            top = FETCH_SIZE
-            pack[:, :, 0] = dev["keys"][:, :top]
-            pack[:, :, 1:] = dev["scores"][:, :top]
-            counts[:, 0] = torch.clamp(dev["n_hits"], max=top)
-            counts[:, 1] = dev["num_matched"]
-            g_hits, g_counts = self.D.all_gather_cat(pack), self.D.all_gather_cat(counts)
-            if self.sharded:       # exact merge of the shards' lists on the device (kw_shard_merge_kernel); num_matched = sum over shards
-                return self.D.merge_gathered_keyword(g, g_hits, g_counts, top)
-            mine, mc = g_hits[self.rank], g_counts[self.rank]
-            return mine[:, :, 0], mine[:, :, 1:], mc[:, 0], mc[:, 1]
+            g.keyword_search_batch_raw(arr, n_q, hs)           # synchronises its stream before returning (1 GPU, or one of N independent replicas)
+            return dev["keys"], dev["scores"], dev["n_hits"], dev["num_matched"]
 
         def after(_):
             tm = g.timings()
@@ -455,7 +425,7 @@ class Bench:
         # pageable arrays, the library's two chained slices; N GPUs: every rank copies the 1/N query slice it merged over its own PCIe
         # link, as the local form of tsgpu_group does). The device-resident step is timed as well (`value_device_only`): it is the
         # single-launch form the roofline / rocprof durations refer to.
-        if world == 1:
+        if self.group is None:
             # the arrays the seam's shim requests for a query that sorts on _text_match (csrc/host/tsgpu_keyword_shim.h): keys, scores[3],
             # match_score_index + the per-query counts; text_match (= scores[match_score_index]) and vector_distance (a keyword KV's default)
             # are not requested. The same step with EVERY tsgpu_hits array delivered is timed as `value_host_all_arrays`.
@@ -478,20 +448,8 @@ class Bench:
         else:
             per = (n_q + world - 1) // world
             q0, q1 = min(self.rank * per, n_q), min((self.rank + 1) * per, n_q)
-            pin = dict(keys=torch.zeros((per, FETCH_SIZE), dtype=torch.int64).pin_memory(), scores=torch.zeros((per, FETCH_SIZE, 3), dtype=torch.int64).pin_memory(),
-                       n_hits=torch.zeros(per, dtype=torch.int32).pin_memory(), num_matched=torch.zeros(per, dtype=torch.int64).pin_memory())
-
-            def step_deliver():
-                o = step()
-                if q1 > q0:
-                    pin["keys"][:q1 - q0].copy_(o[0][q0:q1, :FETCH_SIZE], non_blocking=True)
-                    pin["scores"][:q1 - q0].copy_(o[1][q0:q1, :FETCH_SIZE], non_blocking=True)
-                    pin["n_hits"][:q1 - q0].copy_(o[2][q0:q1].to(torch.int32), non_blocking=True)
-                    pin["num_matched"][:q1 - q0].copy_(o[3][q0:q1].to(torch.int64), non_blocking=True)
-                    torch.cuda.synchronize()
-                return o
-            if self.group is not None and self.sharded:
-                # the same delivery INSIDE the library (group option kw_own_slice_only): after the all-to-all and the slice merge a rank copies the
+            if True:
+                # the delivery INSIDE the library (group option kw_own_slice_only): after the slice exchange and the slice merge a rank copies the
                 # slice it merged straight to its host arrays — no all-gather of the merged lists, no second pass over the result in python.
                 # (The full, replicated result is produced once more after the timed loop for the in-run checks below.)
                 ph = dict(keys=torch.zeros((n_q, FETCH_SIZE), dtype=torch.int64).pin_memory(), scores=torch.zeros((n_q, FETCH_SIZE, 3), dtype=torch.int64).pin_memory(),
@@ -514,8 +472,6 @@ class Bench:
                                                     torch.equal(ph["num_matched"][mine], out[3][mine].to(torch.int64).cpu()) and
                                                     torch.equal(ph["keys"][mine][torch.arange(FETCH_SIZE)[None, :] < ph["n_hits"][mine][:, None]],
                                                                 out[0][mine, :FETCH_SIZE].cpu()[torch.arange(FETCH_SIZE)[None, :] < ph["n_hits"][mine][:, None]])))
-            else:
-                elapsed, lat, out = timed(step_deliver, args.steps, args.warmup, world, after)
             elapsed_dev, lat_dev = None, None
         touched = None
         if world == 1:
@@ -535,17 +491,22 @@ class Bench:
                    alg_bytes=float(np.mean(alg_bytes)), n_q=n_q, n_postings=int(self.csr["n_postings"]), elapsed_dev=elapsed_dev, lat_dev=lat_dev,
                    host_all_arrays_ms=getattr(self, "host_all_arrays_ms", None))
         if self.group is not None:
-            # cross-check of the two exchange implementations (untimed): the C-ABI group's merged result == torch.distributed all-gather + merge
-            ref = step_torch_exchange()
+            # the bound-pruned exchange against the full top-k exchange (untimed): same merged result, fewer bytes
+            gt = self.group.timings()
+            self.group.set_option("kw_exchange_pruned", 0)
+            try:
+                ref = tuple(x.clone() for x in step())
+                gu = self.group.timings()
+            finally:
+                self.group.set_option("kw_exchange_pruned", 1)
             nh_a, nh_b = out[2].to(torch.int64), ref[2].to(torch.int64)
             live = torch.arange(FETCH_SIZE, device="cuda")[None, :] < nh_a[:, None]
             same = bool(torch.equal(nh_a, nh_b)) and bool(torch.equal(out[3].to(torch.int64), ref[3].to(torch.int64))) \
                 and bool(torch.equal(out[0][:, :FETCH_SIZE][live], ref[0][:, :FETCH_SIZE][live])) and bool(torch.equal(out[1][:, :FETCH_SIZE][live], ref[1][:, :FETCH_SIZE][live]))
-            gt = self.group.timings()
-            res["exchange_check"] = {"group_equals_torch_exchange": bool(same), "local_ms": gt.local_ms, "exchange_merge_ms": gt.exchange_merge_ms,
-                                     "exchange_bytes_per_gpu": int(gt.exchange_bytes_per_member),
-                                     "timed_form": "kw_own_slice_only: all-to-all + slice merge, every rank delivers the slice it merged to its own host (no all-gather of the merged lists)"
-                                                   if getattr(self, "own_slice_ok", None) is not None else "full result on every rank + per-rank slice copy",
+            res["exchange_check"] = {"pruned_equals_full_exchange": bool(same), "local_ms": gt.local_ms, "exchange_merge_ms": gt.exchange_merge_ms,
+                                     "exchange_bytes_per_gpu": int(gt.exchange_bytes_per_member), "hit_exchange_bytes_per_gpu": int(gt.hit_exchange_bytes_per_member),
+                                     "full_topk_hit_exchange_bytes_per_gpu": int(gu.hit_exchange_bytes_per_member),
+                                     "timed_form": "kw_own_slice_only: bounds all-gather + bound-pruned slice exchange + slice merge, every rank delivers the slice it merged to its own host",
                                      "own_slice_delivery_equals_full_result": getattr(self, "own_slice_ok", None)}
         keys = out[0].cpu().numpy().astype(np.uint64)
         scores = out[1].cpu().numpy()
@@ -571,17 +532,16 @@ class Bench:
             qt_r = synth.keyword_queries(n_q, 3, 8, 2000, seed=4 + 1000 * self.rank)
             arr_r = self.kw_query_array(qt_r)
 
-            def step_r():
-                self.twin.keyword_search_batch_raw(arr_r, n_q, hs)
-                pack[:, :, 0] = dev["keys"][:, :FETCH_SIZE]
-                pack[:, :, 1:] = dev["scores"][:, :FETCH_SIZE]
-                counts[:, 0] = torch.clamp(dev["n_hits"], max=FETCH_SIZE)
-                counts[:, 1] = dev["num_matched"]
-                return self.D.all_gather_cat(pack), self.D.all_gather_cat(counts)
+            hh_r = self.T.Hits(n_q, K_TOPSTER)
+            hhs_r = hh_r.c_struct(seam_arrays_only=True)
+
+            def step_r():      # N independent replicas: every rank answers ITS batch on its full mirror and delivers it to its own host; no collective
+                self.twin.keyword_search_batch_raw(arr_r, n_q, hhs_r)
+                return hh_r
             el_r, lat_r, _ = timed(step_r, args.steps, min(args.warmup, 2), world)
             res["replicas"] = {"value": world * n_q * args.steps / el_r, "unit": "queries/s", "ms_per_step": 1e3 * el_r / args.steps, "scaling": "weak",
-                               "global_batch": world * n_q, "parallelism": "%d replicas of the collection, the global batch sharded across the GPUs, RCCL all-gather of "
-                                                                           "the per-GPU top-100" % world}
+                               "global_batch": world * n_q, "parallelism": "%d independent replicas of the collection, every rank its own %d-query batch delivered to its own host "
+                                                                           "(no collective: replicas do not exchange anything)" % (world, n_q)}
             if self.group is not None:
                 # third form, through the C-ABI: REPLICAS with the SAME 10 000-query batch cut into N query slices (strong scaling): rank r answers
                 # slice r on its full mirror (the twin), in-place ncclAllGathers of the slices' top-100; no merge, fixed costs shrink with the slice
@@ -903,12 +863,7 @@ class Bench:
                 self.group.vec_knn_batch_raw(field, Q.data_ptr(), B.MEM_DEVICE, n_q, k, dist_o.data_ptr(), lab_o.data_ptr(), cnt_o.data_ptr(), B.MEM_DEVICE)
                 return dist_o, lab_o, cnt_o
             g.vec_knn_batch_raw(field, Q.data_ptr(), B.MEM_DEVICE, n_q, k, dist_o.data_ptr(), lab_o.data_ptr(), cnt_o.data_ptr(), B.MEM_DEVICE)
-            if self.sharded:
-                return self.D.sharded_knn(dist_o, lab_o, cnt_o, k)
-            if world > 1:
-                gathered = [self.D.all_gather_cat(x) for x in (dist_o, lab_o, cnt_o)]
-                return gathered[0][self.rank], gathered[1][self.rank], gathered[2][self.rank]
-            return dist_o, lab_o, cnt_o
+            return dist_o, lab_o, cnt_o                   # (1 GPU, the unsharded twin, or one of N independent replicas)
 
         def after(_):
             tm = g.timings()
@@ -1224,26 +1179,9 @@ class Bench:
                                                                                mem_q=B.MEM_DEVICE, q_ptr=self.Q.data_ptr(), dim=args.dim))
 
             def step():      # fuse AFTER the shard merge: reciprocal ranks are global ranks
-                if self.group is not None:
-                    # tsgpu_group_hybrid_search_batch: merged Topsters (250, with text_match) + merged k nearest, then the reference's fusion
-                    return self.group.hybrid_search_batch(qs, 1, B.METRIC_IP, None, k=k, fetch_size=100, alpha=0.3, k_stride=K_TOPSTER,
-                                                          mem_q=B.MEM_DEVICE, q_ptr=self.Q.data_ptr(), dim=args.dim)
-                g.keyword_search_batch_raw(arr, n_q, hs)
-                keys, sc, n, nm = self.D.sharded_keyword(dev, K_TOPSTER, index=g)
-                g.vec_knn_batch_raw(1, self.Q.data_ptr(), B.MEM_DEVICE, n_q, k, dist_o.data_ptr(), lab_o.data_ptr(), cnt_o.data_ptr(), B.MEM_DEVICE)
-                dm, lm, cm = self.D.sharded_knn(dist_o, lab_o, cnt_o, k)
-                if self.rank != 0:
-                    return None
-                merged = self.T.Hits(n_q, K_TOPSTER)
-                merged.keys[:] = keys.cpu().numpy().astype(np.uint64)
-                s = sc.cpu().numpy()
-                merged.scores[:] = s
-                merged.text_match[:] = s[:, :, 0]
-                merged.match_score_index[:] = 0
-                merged.n_hits[:] = n.cpu().numpy().astype(np.uint32)
-                merged.num_matched[:] = nm.cpu().numpy().astype(np.uint64)
-                return g.hybrid_fuse_batch(qs, merged, dm.cpu().numpy(), lm.cpu().numpy().astype(np.uint64), cm.cpu().numpy().astype(np.uint32),
-                                           B.METRIC_IP, k=k, fetch_size=100, alpha=0.3, k_stride=K_TOPSTER)
+                # tsgpu_group_hybrid_search_batch: merged Topsters (250, with text_match) + merged k nearest, then the reference's fusion
+                return self.group.hybrid_search_batch(qs, 1, B.METRIC_IP, None, k=k, fetch_size=100, alpha=0.3, k_stride=K_TOPSTER,
+                                                      mem_q=B.MEM_DEVICE, q_ptr=self.Q.data_ptr(), dim=args.dim)
         steps = args.steps
         elapsed, lat, out = timed(step, steps, min(args.warmup, 2), world)
         res = dict(elapsed=elapsed, steps=steps, lat=lat, n_q=n_q)
@@ -1419,6 +1357,9 @@ def compact_line(full, detail_path=None):
     line["parity"] = _parity_small(full.get("parity"))
     if isinstance(full.get("shard_parity"), dict):
         line["shard_parity"] = _parity_small(full["shard_parity"])
+    if isinstance(full.get("exchange_check"), dict):
+        line["exchange_check"] = _pick(full["exchange_check"], ("pruned_equals_full_exchange", "local_ms", "exchange_merge_ms", "exchange_bytes_per_gpu", "hit_exchange_bytes_per_gpu",
+                                                                "full_topk_hit_exchange_bytes_per_gpu", "own_slice_delivery_equals_full_result"))
     for k in ("replicas", "replicas_strong"):
         if isinstance(full.get(k), dict):
             line[k] = _pick(full[k], ("value", "unit", "ms_per_step", "global_batch", "scaling"))
@@ -1445,7 +1386,7 @@ def compact_line(full, detail_path=None):
         line["distributed"] = _pick(full["distributed"], ("backend", "world_size", "rccl", "mode", "group_transport"))
     line["detail"] = detail_path
     # the contract is a byte budget, not a hope: shed the optional objects, last added first, until the line fits
-    for k in ("hnsw", "general_kernels", "concurrency", "replicas", "replicas_strong", "keyword", "hybrid", "vector"):
+    for k in ("hnsw", "general_kernels", "concurrency", "replicas", "replicas_strong", "exchange_check", "keyword", "hybrid", "vector"):
         if len(json.dumps(line)) <= COMPACT_LIMIT:
             break
         line.pop(k, None)
@@ -1528,9 +1469,9 @@ def main():
     if world == 1:
         par = "1 GPU"
     elif sharded:
-        par = "doc-range shards x%d of the SAME 10M-doc collection, RCCL all-gather of per-GPU top-100 + counts, exact device merge; exchange = %s" % (world, bn.exchange)
+        par = "doc-range shards x%d of the SAME 10M-doc collection, bound-pruned exchange of the per-GPU top-100 + counts, exact device merge; exchange = %s" % (world, bn.exchange)
     else:
-        par = "%d replicas of the collection, global batch = %d x the per-GPU batch sharded across the GPUs, RCCL all-gather of the per-GPU top-K" % (world, world)
+        par = "%d independent replicas of the collection, every rank answers its own batch (global batch = %d x the per-GPU batch), no collective" % (world, world)
     vocab, tpd = (100_000, 32) if args.n_docs >= 1_000_000 else (20_000, 16)
     sub = {}
     if "keyword" in out:

@@ -569,6 +569,7 @@ typedef struct tsgpu_group_timings {
     uint64_t exchange_bytes_per_member;  /* bytes one member RECEIVES from the others per call (all collectives of the call) */
     uint64_t hit_exchange_bytes_per_member;  /* (ABI 5) the part of it that carries the shards' hits to their mergers: the bounds + the (pruned) slices /
                                               * blocks — without the replication of the merged lists, which does not depend on how the hits travelled */
+    float exchange_kernels_ms;               /* (ABI 5) device time (HIP events, member 0's stream) of the exchange's own kernels: pack or bounds, count + pruned pack, slice merge */
 } tsgpu_group_timings;
 int tsgpu_group_last_timings(tsgpu_group* g, tsgpu_group_timings* out);
 

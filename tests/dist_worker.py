@@ -3,7 +3,7 @@ the real libtsgpu.so, the ranks share the one MI355X). Drives the PRODUCT's rank
 tsgpu_group_keyword_search_batch / _vec_knn_batch / _hybrid_search_batch — across PROCESSES: the packed exchange blocks, the slice /
 all-gather exchanges, the merge kernels and the replicas form are the library's; only the wire is the launcher's (torch.distributed
 gloo through the two host-collective callbacks). Every rank compares the merged result with the UNSHARDED oracle bit for bit
-(Topster order include/topster.h:146-154). typesense_amd/dist.py's torch exchange is NOT used here."""
+(Topster order include/topster.h:146-154). typesense_amd/hostcoll.py only supplies the HOST transport's two callbacks."""
 import os
 import sys
 
@@ -13,7 +13,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import typesense_amd as T                         # noqa: E402
-from typesense_amd import _lib as B, dist as D    # noqa: E402
+from typesense_amd import _lib as B, hostcoll as D    # noqa: E402
 from oracle import oracle_py as O                 # noqa: E402
 from tests import helpers as H                    # noqa: E402
 

@@ -144,3 +144,17 @@ def load_shard(g, orc, lo, hi, n_docs, points, field=0):
     g.column_set(0, points)
     g.set_num_docs(n_docs)
     g.commit()
+
+
+def reference_shard_merge(keys, scores, n_hits, k):
+    """exact G-way merge of per-shard Topster lists in numpy (test reference for tsgpu_merge_shard_hits_device / kw_shard_merge_kernel):
+    keys [G,B,K] int64, scores [G,B,K,3] int64, n_hits [G,B] -> per query (keys[:n], scores[:n]) in KV::is_greater order
+    (include/topster.h:146-149: s0, s1, s2, key descending), n = min(k, total hits)"""
+    G, Bq, K = keys.shape
+    out = []
+    for q in range(Bq):
+        kk = np.concatenate([keys[g, q, :n_hits[g, q]] for g in range(G)]) if G else np.zeros(0, np.int64)
+        sc = np.concatenate([scores[g, q, :n_hits[g, q]] for g in range(G)]) if G else np.zeros((0, 3), np.int64)
+        order = np.lexsort((kk, sc[:, 2], sc[:, 1], sc[:, 0]))[::-1][:k] if kk.size else np.zeros(0, np.int64)
+        out.append((kk[order], sc[order]))
+    return out

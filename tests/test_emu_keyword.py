@@ -564,10 +564,8 @@ def test_string_array_fields_match_per_element_and_mix_with_plain_fields(pair_ar
 
 
 def test_device_shard_merge_equals_the_torch_merge():
-    """kw_shard_merge_kernel (what bench.py --gpus N runs after the RCCL all-gather) vs typesense_amd.dist.merge_keyword_topk"""
+    """kw_shard_merge_kernel through tsgpu_merge_shard_hits_device (array form of the shard merge) vs a numpy lexsort reference"""
     import ctypes as C
-    import torch
-    from typesense_amd import dist as D
     rng = np.random.default_rng(9)
     G, Bq, K, k = 4, 7, 60, 50
     keys = np.zeros((G, Bq, K), np.int64); scores = np.zeros((G, Bq, K, 3), np.int64); n_hits = np.zeros((G, Bq), np.int32)
@@ -581,7 +579,7 @@ def test_device_shard_merge_equals_the_torch_merge():
             sc = np.stack([rng.integers(0, 4, n), rng.integers(-3, 3, n), rng.integers(0, 2, n)], 1).astype(np.int64)   # heavy ties
             order = sorted(range(n), key=lambda i: (sc[i, 0], sc[i, 1], sc[i, 2], ks[i]), reverse=True)
             keys[g_, q, :n] = ks[order]; scores[g_, q, :n] = sc[order]; n_hits[g_, q] = n
-    rk, rs, rn = D.merge_keyword_topk(torch.from_numpy(keys), torch.from_numpy(scores), torch.from_numpy(n_hits), k)
+    ref = H.reference_shard_merge(keys, scores, n_hits, k)
     g = T.GpuIndex(0, H.emu_lib_path())
     ok_ = np.zeros((Bq, k), np.int64); os_ = np.zeros((Bq, k, 3), np.int64); on = np.zeros(Bq, np.int32); onm = np.zeros(Bq, np.int64)
     hin, hout = B.HitsC(), B.HitsC()
@@ -591,8 +589,8 @@ def test_device_shard_merge_equals_the_torch_merge():
         setattr(hin, name, a.ctypes.data); setattr(hout, name, o.ctypes.data)
     B.check(g.L, g.L.tsgpu_merge_shard_hits_device(g.h, C.byref(hin), G, Bq, k, C.byref(hout)))
     for q in range(Bq):
-        n = int(rn[q])
-        assert on[q] == n and np.array_equal(ok_[q, :n], rk[q, :n].numpy()) and np.array_equal(os_[q, :n], rs[q, :n].numpy())
+        n = ref[q][0].size
+        assert on[q] == n and np.array_equal(ok_[q, :n], ref[q][0]) and np.array_equal(os_[q, :n], ref[q][1])
         assert onm[q] == num[:, q].sum()
     g.close()
 

@@ -218,9 +218,9 @@ test_find_kernel_counts_the_bytes_it_requests_without_changing_the_results = EK.
 
 
 def test_device_shard_merge_on_cuda_tensors(c100k):
-    """the bench's N>1 merge path on the GPU: gathered CUDA tensors -> kw_shard_merge_kernel == torch sort-based merge"""
+    """the array form of the shard merge on the GPU: gathered CUDA tensors -> kw_shard_merge_kernel (tsgpu_merge_shard_hits_device) == a numpy lexsort merge"""
+    import ctypes as C
     import torch
-    from typesense_amd import dist as D
     gen = torch.Generator(device="cpu").manual_seed(3)
     G, Bq, K = 8, 300, 250
     sc = torch.randint(0, 5, (G, Bq, K, 3), generator=gen, dtype=torch.int64)
@@ -233,13 +233,23 @@ def test_device_shard_merge_on_cuda_tensors(c100k):
     flat = torch.from_numpy(flat.copy()).reshape(G, Bq, K, 4)
     sc, keys = flat[..., :3].contiguous(), flat[..., 3].contiguous()
     num = torch.randint(0, 10000, (G, Bq), generator=gen, dtype=torch.int64)
-    ref = D.merge_keyword_topk(keys, sc, n_hits, 250)
+    ref = H.reference_shard_merge(keys.numpy(), sc.numpy(), n_hits.numpy(), 250)
     g = {"keys": keys.cuda(), "scores": sc.cuda(), "n_hits": n_hits.cuda(), "num_matched": num.cuda()}
-    k_, s_, n_, nm_ = D.merge_keyword_topk_device(c100k.g, g, 250)
+    out = dict(keys=torch.empty((Bq, 250), dtype=torch.int64, device="cuda"), scores=torch.empty((Bq, 250, 3), dtype=torch.int64, device="cuda"),
+               n_hits=torch.empty(Bq, dtype=torch.int32, device="cuda"), num_matched=torch.empty(Bq, dtype=torch.int64, device="cuda"))
+    hin, hout = B.HitsC(), B.HitsC()
+    hin.mem = hout.mem = B.MEM_DEVICE
+    hin.k_stride, hout.k_stride = K, 250
+    for name in ("keys", "scores", "n_hits", "num_matched"):
+        setattr(hin, name, g[name].data_ptr())
+        setattr(hout, name, out[name].data_ptr())
+    torch.cuda.synchronize()
+    B.check(c100k.g.L, c100k.g.L.tsgpu_merge_shard_hits_device(c100k.g.h, C.byref(hin), G, Bq, 250, C.byref(hout)))
+    k_, s_, n_ = out["keys"].cpu().numpy(), out["scores"].cpu().numpy(), out["n_hits"].cpu().numpy()
     for q in range(Bq):
-        n = int(ref[2][q])
-        assert int(n_[q]) == n and torch.equal(k_[q, :n].cpu(), ref[0][q, :n]) and torch.equal(s_[q, :n].cpu(), ref[1][q, :n])
-    assert torch.equal(nm_.cpu(), num.sum(0))
+        n = ref[q][0].size
+        assert int(n_[q]) == n and np.array_equal(k_[q, :n], ref[q][0]) and np.array_equal(s_[q, :n], ref[q][1])
+    assert torch.equal(out["num_matched"].cpu(), num.sum(0))
 test_string_array_fields_match_per_element_and_mix_with_plain_fields = EK.test_string_array_fields_match_per_element_and_mix_with_plain_fields
 
 

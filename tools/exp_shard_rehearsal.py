@@ -74,13 +74,14 @@ def main():
                     grp.set_option("kw_exchange_pruned", pruned)
                     for _ in range(2):
                         grp.keyword_search_batch_raw(arr, n_q, 100, ghs)
-                    ex, loc = [], []
+                    ex, loc, kn = [], [], []
                     for _ in range(4):
                         grp.keyword_search_batch_raw(arr, n_q, 100, ghs)
                         tmg = grp.timings()
-                        ex.append(tmg.exchange_merge_ms); loc.append(tmg.local_ms)
+                        ex.append(tmg.exchange_merge_ms); loc.append(tmg.local_ms); kn.append(tmg.exchange_kernels_ms)
                     tag = "%s, %s" % (form, "bound-pruned" if pruned else "full top-k")
                     rec[tag + ": exchange kernels + copies + merges of ALL %d members on this one device (ms)" % G] = float(np.mean(ex))
+                    rec[tag + ": ONE member's exchange kernels, HIP events (pack or bounds, count, pruned pack, its merge) (ms)"] = float(np.mean(kn))
                     rec[tag + ": hit bytes received per GPU (bounds + slices / blocks)"] = int(tmg.hit_exchange_bytes_per_member)
                     rec[tag + ": all bytes received per GPU (+ replication of the merged lists)"] = int(tmg.exchange_bytes_per_member)
             grp.close()
@@ -93,14 +94,18 @@ def main():
     for G in (2, 4, 8):
         r = out["shards"][str(G)]
         # MODEL, every term listed: step(G) = local step of a 1/G shard (measured alone: kernels + per-batch host work)
-        #                                   + this GPU's share of the exchange's device work (measured for all G members on one device, / G for the slice form: every member
-        #                                     packs its own block and merges its own slice; / 1 for the all-gather form: every rank merges everything)
+        #                                   + ONE member's exchange kernels (HIP events on its stream: pack or bounds, count, pruned pack, the merge of its slice / of everything)
+        #                                   + 30 us per collective call (bounds all-gather, totals all-gather, slice exchange: 3 pruned, 1 full)
         #                                   + wire time = bytes received per GPU / bandwidth, at 150 GB/s (one xGMI link, conservative) and 300 GB/s (several links busy)
         # own-slice delivery (rank form, option kw_own_slice_only: what bench.py --gpus N times): the replication of the merged lists is not sent -> hit bytes only.
         for pruned in ("bound-pruned", "full top-k"):
             for form, div in (("slices", G), ("all-gather form", 1)):
                 tag = "%s, %s" % (form, pruned)
-                dev_ms = r[tag + ": exchange kernels + copies + merges of ALL %d members on this one device (ms)" % G] / div
+                # one member's own kernels (HIP events on its stream; in the slice form it merges only its slice). The wall time of all members'
+                # work on the one device (also recorded) is dominated by the COPY transport's G x G host-issued copies, which a rank of an RCCL group
+                # replaces by one collective call each: COLLECTIVE_LAUNCHES x 30 us are added for those instead
+                n_coll = (3 if pruned == "bound-pruned" else 1) + (0 if form != "slices" else 0)
+                dev_ms = r[tag + ": ONE member's exchange kernels, HIP events (pack or bounds, count, pruned pack, its merge) (ms)"] + 0.03 * n_coll
                 for deliver, key_b in (("replicated result", ": all bytes received per GPU (+ replication of the merged lists)"), ("own slice only", ": hit bytes received per GPU (bounds + slices / blocks)")):
                     if form != "slices" and deliver == "own slice only":
                         continue

@@ -85,7 +85,7 @@ FACET_INT32, FACET_INT64, FACET_FLOAT = 0, 1, 2
 
 
 class GroupTimingsC(C.Structure):
-    _fields_ = [("local_ms", C.c_float), ("exchange_merge_ms", C.c_float), ("exchange_bytes_per_member", C.c_uint64), ("hit_exchange_bytes_per_member", C.c_uint64)]
+    _fields_ = [("local_ms", C.c_float), ("exchange_merge_ms", C.c_float), ("exchange_bytes_per_member", C.c_uint64), ("hit_exchange_bytes_per_member", C.c_uint64), ("exchange_kernels_ms", C.c_float)]
 
 
 XCHG_RCCL, XCHG_COPY, XCHG_HOST = 0, 1, 2

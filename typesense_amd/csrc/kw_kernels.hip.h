@@ -2584,36 +2584,59 @@ __global__ void kw_group_pack_kernel(KwOut loc, const int32_t* status, uint32_t 
     }
 }
 // ---- bound-pruned exchange (round 5) ----------------------------------------------------------------------------------------
-// A merged list holds kq = min(k, the query's Topster capacity) hits. A shard that holds at least kq hits of a query PROVES, with its kq-th
-// best entry e*, that the kq-th best entry of the whole collection is at least e*: it owns kq entries >= e*. So with B[q] = the greatest of the
-// shards' kq-th entries under the Topster comparator (KV::is_greater, /root/reference/include/topster.h:146-154; keys are unique: a strict
-// total order), no entry below B[q] can be among the global top kq — at least kq entries lie above it — and every shard sends only its entries
-// >= B[q]: in total about kq plus a few per query over ALL shards instead of G x k. A shard with fewer than kq hits reports "none" (key < 0:
-// sorts below everything) and prunes nothing unless another shard supplies a bound.
-// (1) this shard's kq-th best entry per query: {s0, s1, s2, key} (key = -1: none)
-__global__ void kw_group_kth_kernel(KwOut loc, const int32_t* status, const uint32_t* cap_per_query, uint32_t n_queries, uint32_t k, int64_t* kth) {
+// A merged list holds kq = min(k, the query's Topster capacity) hits, ordered by KV::is_greater (/root/reference/include/topster.h:146-154; keys
+// are unique: a strict total order). Any entry e such that at least kq entries >= e exist in the whole collection is a LOWER BOUND of the global
+// kq-th best entry, and nothing below a lower bound can be in the merged list. Every shard reports two of its own entries per query —
+//   e_k = its kq-th best (it alone owns kq entries >= e_k), and
+//   e_r = its r-th best, r = ceil(1.5 kq / G)   (when the winners are spread over the G shards the global kq-th sits near every shard's (kq / G)-th)
+// — and with m = ceil(kq / r):   B[q] = the greater of  max over shards of e_k  and  the m-th largest of the shards' e_r
+// (the m shards behind the m largest e_r own at least m x r >= kq entries >= the m-th largest). A shard with too few hits reports "none" (key < 0:
+// sorts below everything); when neither bound exists nothing is pruned. Every shard then sends only its entries >= B[q]: about kq .. 1.6 kq per query
+// over ALL shards when the winners are spread evenly (instead of G x k), and only the winning shard's when one shard owns them all.
+__device__ inline uint32_t kw_group_bound_rank(uint32_t kq, uint32_t n_shards) {           // r: 1 <= r <= kq
+    const uint32_t r = (3u * kq + 2u * n_shards - 1u) / (2u * n_shards);
+    return r < 1u ? 1u : (r > kq ? kq : r);
+}
+// (1) this shard's two reported entries per query: kth[q][0] = e_r, kth[q][1] = e_k, each {s0, s1, s2, key} (key = -1: none)
+__global__ void kw_group_kth_kernel(KwOut loc, const int32_t* status, const uint32_t* cap_per_query, uint32_t n_queries, uint32_t k, uint32_t n_shards, int64_t* kth) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_queries) return;
     const bool failed = status && status[q] != 0;
     const uint32_t n = failed ? 0u : (loc.n_hits[q] < k ? loc.n_hits[q] : k);
     const uint32_t kq = cap_per_query && cap_per_query[q] < k ? cap_per_query[q] : k;
-    int64_t* d = kth + (size_t)q * 4;
-    if (kq == 0 || n < kq) { d[0] = 0; d[1] = 0; d[2] = 0; d[3] = -1; return; }
-    const size_t src = (size_t)q * loc.k_stride + (kq - 1);
-    d[0] = loc.scores[src * 3 + 0]; d[1] = loc.scores[src * 3 + 1]; d[2] = loc.scores[src * 3 + 2]; d[3] = (int64_t)loc.keys[src];
+    int64_t* d = kth + (size_t)q * 8;
+    const uint32_t want[2] = {kq ? kw_group_bound_rank(kq, n_shards) : 0u, kq};
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        if (want[w] == 0 || n < want[w]) { d[4 * w] = 0; d[4 * w + 1] = 0; d[4 * w + 2] = 0; d[4 * w + 3] = -1; continue; }
+        const size_t src = (size_t)q * loc.k_stride + (want[w] - 1);
+        d[4 * w] = loc.scores[src * 3 + 0]; d[4 * w + 1] = loc.scores[src * 3 + 1]; d[4 * w + 2] = loc.scores[src * 3 + 2]; d[4 * w + 3] = (int64_t)loc.keys[src];
+    }
 }
-// (2) B[q] from the gathered kq-th entries ([shard][query][4]); cnt[q] = this shard's entries >= B[q] — a PREFIX of its sorted list (binary
+// (2) B[q] from the gathered reports ([shard][query][2][4]); cnt[q] = this shard's entries >= B[q] — a PREFIX of its sorted list (binary
 // search); tot[q / per] += cnt[q] (the entries bound for the member that merges the query's slice)
-__global__ void kw_group_count_kernel(KwOut loc, const int32_t* status, uint32_t n_queries, uint32_t k, const int64_t* kth_all, uint32_t n_shards,
+__global__ void kw_group_count_kernel(KwOut loc, const int32_t* status, const uint32_t* cap_per_query, uint32_t n_queries, uint32_t k, const int64_t* kth_all, uint32_t n_shards,
                                       uint32_t per, uint32_t* cnt, uint32_t* tot) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_queries) return;
     const bool failed = status && status[q] != 0;
     const uint32_t n = failed ? 0u : (loc.n_hits[q] < k ? loc.n_hits[q] : k);
+    const uint32_t kq = cap_per_query && cap_per_query[q] < k ? cap_per_query[q] : k;
     int64_t b0 = 0, b1 = 0, b2 = 0, bk = -1;
-    for (uint32_t g = 0; g < n_shards; g++) {
-        const int64_t* e = kth_all + ((size_t)g * n_queries + q) * 4;
+    auto rec = [&](uint32_t g, int w) { return kth_all + (((size_t)g * n_queries + q) * 2 + (size_t)w) * 4; };
+    for (uint32_t g = 0; g < n_shards; g++) {                  // the single-shard bound: the greatest e_k
+        const int64_t* e = rec(g, 1);
         if (ent_greater(e[0], e[1], e[2], e[3], b0, b1, b2, bk)) { b0 = e[0]; b1 = e[1]; b2 = e[2]; bk = e[3]; }
+    }
+    if (kq) {                                                  // the spread bound: the m-th largest e_r (its rank among the reports = m - 1)
+        const uint32_t r = kw_group_bound_rank(kq, n_shards), m = (kq + r - 1) / r;
+        for (uint32_t g = 0; g < n_shards && m <= n_shards; g++) {
+            const int64_t* e = rec(g, 0);
+            if (e[3] < 0) continue;
+            uint32_t above = 0;
+            for (uint32_t h = 0; h < n_shards; h++) { const int64_t* f = rec(h, 0); if (h != g && ent_greater(f[0], f[1], f[2], f[3], e[0], e[1], e[2], e[3])) above++; }
+            if (above == m - 1) { if (ent_greater(e[0], e[1], e[2], e[3], b0, b1, b2, bk)) { b0 = e[0]; b1 = e[1]; b2 = e[2]; bk = e[3]; } break; }
+        }
     }
     uint32_t lo = 0, hi = n;                                   // first index whose entry is BELOW the bound (none: everything stays)
     if (bk >= 0) {

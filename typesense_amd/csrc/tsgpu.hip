@@ -2056,18 +2056,18 @@ static KwOut kw_out_of(const tsgpu_hits* loc) {
     o.n_hits = loc->n_hits; o.num_matched = loc->num_matched; o.off_words = nullptr; o.k_stride = loc->k_stride;
     return o;
 }
-int group_kw_kth(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t k, const uint32_t* caps_dev, int64_t* kth, hipStream_t s) {
+int group_kw_kth(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t k, uint32_t n_shards, const uint32_t* caps_dev, int64_t* kth, hipStream_t s) {
     (void)hipSetDevice(ctx->device);
-    hipLaunchKernelGGL(kw_group_kth_kernel, dim3((n_q + 255) / 256), dim3(256), 0, s, kw_out_of(loc), (const int32_t*)loc->status, caps_dev, n_q, k, kth);
+    hipLaunchKernelGGL(kw_group_kth_kernel, dim3((n_q + 255) / 256), dim3(256), 0, s, kw_out_of(loc), (const int32_t*)loc->status, caps_dev, n_q, k, n_shards, kth);
     TSGPU_HIP_TRY(hipGetLastError());
     return TSGPU_OK;
 }
 // ... the bound per query from the gathered kq-th entries, this shard's entries at or above it (cnt[n_q]) and their totals per destination slice (tot[n_dst], zeroed here)
-int group_kw_count(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t k, const int64_t* kth_all, uint32_t n_shards, uint32_t per, uint32_t n_dst,
+int group_kw_count(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t k, const uint32_t* caps_dev, const int64_t* kth_all, uint32_t n_shards, uint32_t per, uint32_t n_dst,
                    uint32_t* cnt, uint32_t* tot, hipStream_t s) {
     (void)hipSetDevice(ctx->device);
     TSGPU_HIP_TRY(hipMemsetAsync(tot, 0, (size_t)n_dst * 4, s));
-    hipLaunchKernelGGL(kw_group_count_kernel, dim3((n_q + 255) / 256), dim3(256), 0, s, kw_out_of(loc), (const int32_t*)loc->status, n_q, k, kth_all, n_shards, per, cnt, tot);
+    hipLaunchKernelGGL(kw_group_count_kernel, dim3((n_q + 255) / 256), dim3(256), 0, s, kw_out_of(loc), (const int32_t*)loc->status, caps_dev, n_q, k, kth_all, n_shards, per, cnt, tot);
     TSGPU_HIP_TRY(hipGetLastError());
     return TSGPU_OK;
 }

@@ -95,6 +95,7 @@ struct Member {
     PinBuf h_send, h_recv;                               // HOST transport: the staged blocks
     DevBuf agree_d;                                      // RCCL rank form: the ranks' status words
     PinBuf agree_h;
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // member 0 only: its exchange kernels bracketed (tsgpu_group_timings::exchange_kernels_ms)
     int rc = TSGPU_OK;
     std::string err;
 };
@@ -146,6 +147,23 @@ int host_collective(tsgpu_group* g, bool all_to_all, const void* send_dev, size_
     TSGPU_HIP_TRY(hipMemcpyAsync(recv_dev, mem.h_recv.p, per_rank_bytes * g->n, hipMemcpyHostToDevice, mem.ctx->stream));
     TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
     return TSGPU_OK;
+}
+
+// member 0's exchange kernels are timed with HIP events on its stream (four brackets: pack or bounds | count | merge | pruned pack)
+void mark(tsgpu_group* g, size_t member, int i) {
+    if (member != 0) return;
+    Member& mem = g->m[0];
+    if (!mem.ev[i]) { (void)hipSetDevice(mem.ctx->device); if (hipEventCreate(&mem.ev[i]) != hipSuccess) { mem.ev[i] = nullptr; return; } }
+    (void)hipEventRecord(mem.ev[i], mem.ctx->stream);
+}
+float marked_ms(tsgpu_group* g, bool mid) {
+    Member& mem = g->m[0];
+    float tot = 0, ms = 0;
+    for (int b = 0; b < 4; b++) {
+        if ((b == 1 || b == 3) && !mid) continue;
+        if (mem.ev[2 * b] && mem.ev[2 * b + 1] && hipEventElapsedTime(&ms, mem.ev[2 * b], mem.ev[2 * b + 1]) == hipSuccess) tot += ms;
+    }
+    return tot;
 }
 
 uint32_t call_signature(std::initializer_list<uint64_t> v) {
@@ -572,6 +590,7 @@ int tsgpu_group_create_rank_host(tsgpu_ctx* ctx, const tsgpu_host_collectives* c
 }
 
 void tsgpu_group_destroy(tsgpu_group* g) {
+    if (g) for (auto& mem : g->m) for (hipEvent_t& e : mem.ev) if (e) { (void)hipSetDevice(mem.ctx->device); (void)hipEventDestroy(e); e = nullptr; }
     if (!g) return;
     for (auto& mem : g->m) {
         (void)hipSetDevice(mem.ctx->device);
@@ -636,9 +655,9 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
                 (r = mem.send.reserve((size_t)n_pad * qw * 8)) || (r = mem.recv.reserve((slices ? (size_t)n_pad : (size_t)n_queries * g->n) * qw * 8)) ||
                 ((slices || i == 0) && (r = reserve_staging(mem, out, n_pad))) ||
                 (r = reserve_host_staging(g, mem, std::max((slices ? (size_t)n_pad : (size_t)n_queries * g->n) * qw * 8, (size_t)n_pad * KS * 24)))) return r;
-            if (pruned && ((r = mem.kth_send.reserve((size_t)n_queries * 32)) || (r = mem.kth_recv.reserve((size_t)n_queries * 32 * g->n)) || (r = mem.p_cnt.reserve((size_t)n_queries * 4)) ||
+            if (pruned && ((r = mem.kth_send.reserve((size_t)n_queries * 64)) || (r = mem.kth_recv.reserve((size_t)n_queries * 64 * g->n)) || (r = mem.p_cnt.reserve((size_t)n_queries * 4)) ||
                            (r = mem.p_first.reserve((size_t)n_queries * 4)) || (r = mem.p_tot.reserve((size_t)n_dst * 4)) || (r = mem.p_totall.reserve((size_t)n_dst * 4 * g->n)) || (r = mem.caps.reserve((size_t)n_pad * 4)) ||
-                           (r = reserve_host_staging(g, mem, (size_t)n_queries * 32 * g->n)))) return r;
+                           (r = reserve_host_staging(g, mem, (size_t)n_queries * 64 * g->n)))) return r;
             tsgpu_hits loc;
             memset(&loc, 0, sizeof loc);
             loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL;
@@ -646,12 +665,17 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
             loc.vector_distance = mem.l_vd.as<float>(); loc.match_score_index = mem.l_msi.as<int8_t>();
             loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>(); loc.search_cutoff = mem.l_co.as<int32_t>();
             if ((r = tsgpu_keyword_search_batch(mem.ctx, queries, n_queries, &loc))) return r;
+            mark(g, i, 0);
             if (pruned) {
                 TSGPU_HIP_TRY(hipMemcpyAsync(mem.caps.p, g->m[0].h_caps.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, mem.ctx->stream));      // (h_caps is a member field: it outlives the copy)
-                return group_kw_kth(mem.ctx, &loc, n_queries, k, mem.caps.as<uint32_t>(), mem.kth_send.as<int64_t>(), mem.ctx->stream);
+                r = group_kw_kth(mem.ctx, &loc, n_queries, k, g->n, mem.caps.as<uint32_t>(), mem.kth_send.as<int64_t>(), mem.ctx->stream);
+                mark(g, i, 1);
+                return r;
             }
             if (n_pad > n_queries) TSGPU_HIP_TRY(hipMemsetAsync(mem.send.as<uint64_t>() + (size_t)n_queries * qw, 0, (size_t)(n_pad - n_queries) * qw * 8, mem.ctx->stream));   // padding records: no hits
-            return group_pack_keyword(mem.ctx, &loc, n_queries, k, words, mem.send.as<uint64_t>(), mem.ctx->stream);
+            r = group_pack_keyword(mem.ctx, &loc, n_queries, k, words, mem.send.as<uint64_t>(), mem.ctx->stream);
+            mark(g, i, 1);
+            return r;
         });
         if ((rc = agree(g, rc, call_signature({2, n_queries, k, out->k_stride, hits_mask(out), (uint64_t)slices, (uint64_t)g->own_slice_only, (uint64_t)pruned})))) return rc;
         const double t_local = ms_since(t0);
@@ -664,14 +688,16 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
             // 2a) the bounds: every shard's kq-th entries everywhere (32 B per query and shard); 2b) each member counts its entries at or above the
             //     bound, per destination slice; 2c) the slice capacity M = the largest (source, destination) total of the whole group (one u64 per
             //     rank: collectives move equal-sized slices); 2d) the pruned blocks are packed: per slice `per` header pairs + M entries
-            if ((rc = all_gather_everywhere(g, &Member::kth_send, &Member::kth_recv, (size_t)n_queries * 32))) return rc;
+            if ((rc = all_gather_everywhere(g, &Member::kth_send, &Member::kth_recv, (size_t)n_queries * 64))) return rc;
             uint64_t most = 0;
+            mark(g, 0, 2);
             for (auto& mem : g->m) {
                 tsgpu_hits loc;
                 memset(&loc, 0, sizeof loc);
                 loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL; loc.keys = mem.l_keys.as<uint64_t>(); loc.scores = mem.l_scores.as<int64_t>(); loc.text_match = mem.l_tm.as<int64_t>();
                 loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>();
-                if ((rc = group_kw_count(mem.ctx, &loc, n_queries, k, mem.kth_recv.as<int64_t>(), g->n, per, n_dst, mem.p_cnt.as<uint32_t>(), mem.p_tot.as<uint32_t>(), mem.ctx->stream))) return rc;
+                if ((rc = group_kw_count(mem.ctx, &loc, n_queries, k, mem.caps.as<uint32_t>(), mem.kth_recv.as<int64_t>(), g->n, per, n_dst, mem.p_cnt.as<uint32_t>(), mem.p_tot.as<uint32_t>(), mem.ctx->stream))) return rc;
+                if (&mem == &g->m[0]) mark(g, 0, 3);
             }
             if ((rc = gather_totals(g, n_dst, tot_all))) return rc;
             for (uint32_t v : tot_all) most = std::max<uint64_t>(most, v);
@@ -681,7 +707,9 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
                 memset(&loc, 0, sizeof loc);
                 loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL; loc.keys = mem.l_keys.as<uint64_t>(); loc.scores = mem.l_scores.as<int64_t>(); loc.text_match = mem.l_tm.as<int64_t>();
                 loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>();
+                if (&mem == &g->m[0]) mark(g, 0, 6);
                 if ((rc = group_kw_pack_pruned(mem.ctx, &loc, n_queries, k, words, per, n_dst, mem.p_cnt.as<uint32_t>(), mem.p_first.as<uint32_t>(), slice_words, mem.send.as<uint64_t>(), mem.ctx->stream))) return rc;
+                if (&mem == &g->m[0]) mark(g, 0, 7);
             }
         }
         // (pruned slices travel at their EXACT sizes where the transport can — RCCL send / recv pairs, device copies: when one shard owns a query's winners
@@ -696,7 +724,9 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
             const uint32_t nq = slices ? (q0 < n_queries ? std::min<uint32_t>(per, n_queries - q0) : 0) : n_queries;
             if (!pruned) TSGPU_HIP_TRY(hipMemcpyAsync(mem.caps.p, g->m[0].h_caps.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, mem.ctx->stream));      // (h_caps is a member field: it outlives the copy)
             tsgpu_hits d = staged_hits(mem, out);
+            mark(g, i, 4);
             if ((rc = group_merge_keyword(mem.ctx, mem.recv.as<uint64_t>(), slice_words, g->n, nq, q0, k, words, mem.caps.as<uint32_t>(), &d, mem.ctx->stream, pruned ? per : 0u))) return rc;
+            mark(g, i, 5);
         }
         // 4) delivery
         if (slices) { if ((rc = deliver_slices(g, out, n_queries, per, g->kw_slices == 2))) return rc; }
@@ -713,7 +743,8 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
         // everything this call enqueued on the members' streams is awaited here
         for (auto& mem : g->m) { (void)hipSetDevice(mem.ctx->device); TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream)); }
         g->tm.local_ms = (float)t_local; g->tm.exchange_merge_ms = (float)ms_since(t1);
-        g->tm.hit_exchange_bytes_per_member = (pruned ? (uint64_t)n_queries * 32 * (g->n - 1) : 0ull) + (uint64_t)slice_words * 8 * (g->n - 1);
+        g->tm.exchange_kernels_ms = marked_ms(g, pruned);
+        g->tm.hit_exchange_bytes_per_member = (pruned ? (uint64_t)n_queries * 64 * (g->n - 1) : 0ull) + (uint64_t)slice_words * 8 * (g->n - 1);
         if (exact) {                                     // what the busiest receiver of this process's members took in
             uint64_t worst = 0;
             for (size_t i = 0; i < g->m.size(); i++) {
@@ -722,9 +753,9 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
                 for (uint32_t j = 0; j < g->n; j++) if (j != d) in += ((uint64_t)per * 2 + (uint64_t)tot_all[(size_t)j * n_dst + d] * words) * 8;
                 worst = std::max(worst, in);
             }
-            g->tm.hit_exchange_bytes_per_member = (uint64_t)n_queries * 32 * (g->n - 1) + worst;
+            g->tm.hit_exchange_bytes_per_member = (uint64_t)n_queries * 64 * (g->n - 1) + worst;
         }
-        g->tm.exchange_bytes_per_member = (pruned ? (uint64_t)n_queries * 32 * (g->n - 1) : 0ull) + (slices ? (uint64_t)slice_words * 8 * (g->n - 1) + ((!g->local && g->own_slice_only) ? 0ull : (uint64_t)per * (KS * (32 + (out->text_match ? 8 : 0)) + 16) * (g->n - 1)) : (uint64_t)slice_words * 8 * (g->n - 1));
+        g->tm.exchange_bytes_per_member = (pruned ? (uint64_t)n_queries * 64 * (g->n - 1) : 0ull) + (slices ? (uint64_t)slice_words * 8 * (g->n - 1) + ((!g->local && g->own_slice_only) ? 0ull : (uint64_t)per * (KS * (32 + (out->text_match ? 8 : 0)) + 16) * (g->n - 1)) : (uint64_t)slice_words * 8 * (g->n - 1));
         return ok();
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: host allocation failed"); }
       catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: could not start a member thread"); }

@@ -551,8 +551,8 @@ int group_pack_keyword(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q
 int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard_stride_words, uint32_t n_shards, uint32_t n_q, uint32_t q_out_offset, uint32_t k, uint32_t words,
                         const uint32_t* caps_dev, const tsgpu_hits* out_dev, hipStream_t s, uint32_t pruned_per = 0);
 // bound-pruned exchange (kw_kernels.hip.h): the shard's kq-th entries; counts against the gathered bounds; the pruned exchange block
-int group_kw_kth(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t k, const uint32_t* caps_dev, int64_t* kth, hipStream_t s);
-int group_kw_count(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t k, const int64_t* kth_all, uint32_t n_shards, uint32_t per, uint32_t n_dst,
+int group_kw_kth(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t k, uint32_t n_shards, const uint32_t* caps_dev, int64_t* kth, hipStream_t s);
+int group_kw_count(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t k, const uint32_t* caps_dev, const int64_t* kth_all, uint32_t n_shards, uint32_t per, uint32_t n_dst,
                    uint32_t* cnt, uint32_t* tot, hipStream_t s);
 int group_kw_pack_pruned(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t k, uint32_t words, uint32_t per, uint32_t n_dst, const uint32_t* cnt, uint32_t* first_of,
                          uint64_t slice_words, uint64_t* block, hipStream_t s);

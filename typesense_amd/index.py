@@ -559,7 +559,7 @@ class GpuGroup:
     def join_host(cls, index, rank, n_ranks, all_gather, all_to_all):
         """rank form over the CALLER's collectives on host memory (tsgpu_group_create_rank_host, TSGPU_XCHG_HOST): all_gather(send, recv,
         bytes) / all_to_all(send, recv, bytes) get numpy uint8 views of the library's pinned staging buffers (send: bytes resp. n_ranks x
-        bytes; recv: n_ranks x bytes) and follow ncclAllGather / ncclAllToAll. typesense_amd.dist.torch_collectives() backs them with
+        bytes; recv: n_ranks x bytes) and follow ncclAllGather / ncclAllToAll. typesense_amd.hostcoll.torch_collectives() backs them with
         torch.distributed (gloo on CPU tensors)."""
         def wrap(fn, send_slices):
             def cb(_user, send, recv, nbytes):
