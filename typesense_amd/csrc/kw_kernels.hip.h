@@ -2613,84 +2613,80 @@ __global__ void kw_group_kth_kernel(KwOut loc, const int32_t* status, const uint
         d[4 * w] = loc.scores[src * 3 + 0]; d[4 * w + 1] = loc.scores[src * 3 + 1]; d[4 * w + 2] = loc.scores[src * 3 + 2]; d[4 * w + 3] = (int64_t)loc.keys[src];
     }
 }
-// (2) B[q] from the gathered reports ([shard][query][2][4]); cnt[q] = this shard's entries >= B[q] — a PREFIX of its sorted list (binary
-// search); tot[q / per] += cnt[q] (the entries bound for the member that merges the query's slice)
-__global__ void kw_group_count_kernel(KwOut loc, const int32_t* status, const uint32_t* cap_per_query, uint32_t n_queries, uint32_t k, const int64_t* kth_all, uint32_t n_shards,
-                                      uint32_t per, uint32_t* cnt, uint32_t* tot) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n_queries) return;
+// (2) + (3) ONE WAVEFRONT PER QUERY: B[q] from the gathered reports ([shard][query][2][4]); this shard's entries >= B[q] are a PREFIX of its sorted
+// list (every lane tests its own entries, one ballot counts them); lane 0 takes their place in the destination slice with one atomicAdd on the slice's
+// cursor (queries land in the slice's entry area in arrival order — the header pair says where), the lanes copy them, lane 0 writes the header pair.
+// cursor[slice] ends as the slice's entry total (what the exact-size exchange sends). Queries >= n_queries (padding of the last slice): empty headers.
+// Slice layout: [per header pairs][entries], slices slice_words apart (capacity: per * k entries).
+__global__ __launch_bounds__(256) void kw_group_prune_pack_kernel(KwOut loc, const int32_t* status, const uint32_t* cap_per_query, uint32_t n_queries, uint32_t n_pad, uint32_t k,
+                                                                  uint32_t words, const int64_t* kth_all, uint32_t n_shards, uint32_t per, uint64_t slice_words, uint64_t* dst,
+                                                                  uint32_t* cursor) {
+    const uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (q >= n_pad) return;
+    const uint32_t j = q / per, i = q - j * per;
+    uint64_t* slice = dst + (size_t)j * slice_words;
+    if (q >= n_queries) { if (lane == 0) { slice[(size_t)i * 2] = 0; slice[(size_t)i * 2 + 1] = 0; } return; }
     const bool failed = status && status[q] != 0;
     const uint32_t n = failed ? 0u : (loc.n_hits[q] < k ? loc.n_hits[q] : k);
     const uint32_t kq = cap_per_query && cap_per_query[q] < k ? cap_per_query[q] : k;
     int64_t b0 = 0, b1 = 0, b2 = 0, bk = -1;
     auto rec = [&](uint32_t g, int w) { return kth_all + (((size_t)g * n_queries + q) * 2 + (size_t)w) * 4; };
-    for (uint32_t g = 0; g < n_shards; g++) {                  // the single-shard bound: the greatest e_k
+    for (uint32_t g = 0; g < n_shards; g++) {                  // the single-shard bound: the greatest e_k (uniform loads)
         const int64_t* e = rec(g, 1);
         if (ent_greater(e[0], e[1], e[2], e[3], b0, b1, b2, bk)) { b0 = e[0]; b1 = e[1]; b2 = e[2]; bk = e[3]; }
     }
-    if (kq) {                                                  // the spread bound: the m-th largest e_r (its rank among the reports = m - 1)
+    if (kq) {                                                  // the spread bound: the m-th largest e_r — lane g ranks shard g's report among the others
         const uint32_t r = kw_group_bound_rank(kq, n_shards), m = (kq + r - 1) / r;
-        for (uint32_t g = 0; g < n_shards && m <= n_shards; g++) {
-            const int64_t* e = rec(g, 0);
-            if (e[3] < 0) continue;
-            uint32_t above = 0;
-            for (uint32_t h = 0; h < n_shards; h++) { const int64_t* f = rec(h, 0); if (h != g && ent_greater(f[0], f[1], f[2], f[3], e[0], e[1], e[2], e[3])) above++; }
-            if (above == m - 1) { if (ent_greater(e[0], e[1], e[2], e[3], b0, b1, b2, bk)) { b0 = e[0]; b1 = e[1]; b2 = e[2]; bk = e[3]; } break; }
+        if (m <= n_shards) {
+            for (uint32_t g0 = 0; g0 < n_shards; g0 += 64) {
+                const uint32_t g = g0 + lane;
+                bool mine = false;
+                int64_t e0 = 0, e1 = 0, e2 = 0, e3 = -1;
+                if (g < n_shards) {
+                    const int64_t* e = rec(g, 0);
+                    e0 = e[0]; e1 = e[1]; e2 = e[2]; e3 = e[3];
+                    if (e3 >= 0) {
+                        uint32_t above = 0;
+                        for (uint32_t h = 0; h < n_shards; h++) { const int64_t* f = rec(h, 0); if (h != g && ent_greater(f[0], f[1], f[2], f[3], e0, e1, e2, e3)) above++; }
+                        mine = above == m - 1;
+                    }
+                }
+                const unsigned long long who = __ballot(mine ? 1 : 0);
+                if (who) {                                     // (keys are unique: at most one report has exactly m - 1 above it)
+                    const int src = (int)__builtin_ctzll(who);
+                    e0 = __shfl(e0, src); e1 = __shfl(e1, src); e2 = __shfl(e2, src); e3 = __shfl(e3, src);
+                    if (ent_greater(e0, e1, e2, e3, b0, b1, b2, bk)) { b0 = e0; b1 = e1; b2 = e2; bk = e3; }
+                    break;
+                }
+            }
         }
     }
-    uint32_t lo = 0, hi = n;                                   // first index whose entry is BELOW the bound (none: everything stays)
-    if (bk >= 0) {
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const size_t src = (size_t)q * loc.k_stride + mid;
-            const bool below = ent_greater(b0, b1, b2, bk, loc.scores[src * 3 + 0], loc.scores[src * 3 + 1], loc.scores[src * 3 + 2], (int64_t)loc.keys[src]);
-            if (below) hi = mid; else lo = mid + 1;
+    // entries at or above the bound: a prefix of the sorted list
+    uint32_t c = 0;
+    for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        bool keep = false;
+        if (e < n) {
+            const size_t src = (size_t)q * loc.k_stride + e;
+            keep = bk < 0 || !ent_greater(b0, b1, b2, bk, loc.scores[src * 3 + 0], loc.scores[src * 3 + 1], loc.scores[src * 3 + 2], (int64_t)loc.keys[src]);
         }
-    } else lo = n;
-    cnt[q] = lo;
-    if (lo) atomicAdd(tot + q / per, lo);
-}
-// (3a) one workgroup per destination slice: exclusive scan of cnt over the slice's queries -> the header pairs of the slice
-__global__ __launch_bounds__(KW_THREADS) void kw_group_pruned_header_kernel(KwOut loc, const int32_t* status, uint32_t n_queries, uint32_t per, const uint32_t* cnt,
-                                                                            uint64_t slice_words, uint64_t* dst, uint32_t* first_of) {
-    __shared__ uint32_t s_wave[KW_THREADS / 64], s_run;
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6, j = blockIdx.x;
-    uint64_t* hdr = dst + (size_t)j * slice_words;
-    if (t == 0) s_run = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < per; base += KW_THREADS) {
-        const uint32_t i = base + t, q = j * per + i;
-        const bool live = i < per && q < n_queries;
-        const uint32_t c = live ? cnt[q] : 0u;
-        uint32_t incl = c;                                          // inclusive scan inside the wavefront
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, (unsigned)d); if (lane >= (uint32_t)d) incl += v; }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t before = s_run;
-        for (uint32_t w = 0; w < wave; w++) before += s_wave[w];
-        const uint32_t first = before + incl - c;
-        if (i < per) {
-            const bool failed = live && status && status[q] != 0;
-            hdr[(size_t)i * 2] = (uint64_t)c | ((uint64_t)(live && status ? (uint32_t)status[q] & 0xFFFFu : 0u) << 16) | ((uint64_t)first << 32);
-            hdr[(size_t)i * 2 + 1] = (live && loc.num_matched && !failed) ? loc.num_matched[q] : 0;
-            if (live) first_of[q] = first;
-        }
-        __syncthreads();
-        if (t == KW_THREADS - 1) s_run = before + incl;             // (the last thread's inclusive value = the chunk's total)
-        __syncthreads();
+        c += (uint32_t)__popcll(__ballot(keep ? 1 : 0));
     }
-}
-// (3b) the entries: thread (q, i < cnt[q]) copies entry i of query q behind its slice's header
-__global__ void kw_group_pruned_entries_kernel(KwOut loc, uint32_t n_queries, uint32_t k, uint32_t words, uint32_t per, const uint32_t* cnt, const uint32_t* first_of,
-                                               uint64_t slice_words, uint64_t* dst) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t q = i / k, e = i - q * k;
-    if (q >= n_queries || e >= cnt[q]) return;
-    const size_t src = (size_t)q * loc.k_stride + e;
-    uint64_t* d = dst + (size_t)(q / per) * slice_words + (size_t)per * 2 + ((size_t)first_of[q] + e) * words;
-    d[0] = loc.keys[src];
-    d[1] = (uint64_t)loc.scores[src * 3 + 0]; d[2] = (uint64_t)loc.scores[src * 3 + 1]; d[3] = (uint64_t)loc.scores[src * 3 + 2];
-    if (words > 4) d[4] = loc.text_match ? (uint64_t)loc.text_match[src] : 0;
+    uint32_t first = 0;
+    if (lane == 0 && c) first = atomicAdd(cursor + j, c);
+    first = __shfl(first, 0);
+    uint64_t* ent = slice + (size_t)per * 2 + (size_t)first * words;
+    for (uint32_t e = lane; e < c; e += 64) {
+        const size_t src = (size_t)q * loc.k_stride + e;
+        uint64_t* d = ent + (size_t)e * words;
+        d[0] = loc.keys[src];
+        d[1] = (uint64_t)loc.scores[src * 3 + 0]; d[2] = (uint64_t)loc.scores[src * 3 + 1]; d[3] = (uint64_t)loc.scores[src * 3 + 2];
+        if (words > 4) d[4] = loc.text_match ? (uint64_t)loc.text_match[src] : 0;
+    }
+    if (lane == 0) {
+        slice[(size_t)i * 2] = (uint64_t)c | ((uint64_t)(status ? (uint32_t)status[q] & 0xFFFFu : 0u) << 16) | ((uint64_t)first << 32);
+        slice[(size_t)i * 2 + 1] = (loc.num_matched && !failed) ? loc.num_matched[q] : 0;
+    }
 }
 // replicas form of a group (every member mirrors the whole collection, the batch is cut into query slices): the member's own result for
 // its slice (stride loc.k_stride) -> rows [q_out_offset, ..) of the staged full-batch arrays (stride out.k_stride), truncated to k
@@ -2755,8 +2751,12 @@ __global__ __launch_bounds__(KW_THREADS) void kw_shard_merge_kernel(KwShardIn in
         if (t == 0) s_total = at + n;
         __syncthreads();
     }
-    topk_sort<CAP, true>(tk);
     const uint32_t total = s_total < (uint32_t)CAP ? s_total : (uint32_t)CAP;
+    {   // sort only as many slots as hold entries (the rest is padding, key < 0): a bound-pruned query brings ~1.5 k entries, not G x k
+        int n_sort = 64;
+        while (n_sort < (int)total) n_sort <<= 1;
+        topk_sort<CAP, true>(tk, n_sort < CAP ? n_sort : CAP);
+    }
     const uint32_t kq = in.cap_per_query && in.cap_per_query[q] < k ? in.cap_per_query[q] : k;
     const uint32_t n_out = total < kq ? total : kq;
     const size_t ob = (size_t)q * out.k_stride;

@@ -2062,23 +2062,14 @@ int group_kw_kth(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t k
     TSGPU_HIP_TRY(hipGetLastError());
     return TSGPU_OK;
 }
-// ... the bound per query from the gathered kq-th entries, this shard's entries at or above it (cnt[n_q]) and their totals per destination slice (tot[n_dst], zeroed here)
-int group_kw_count(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t k, const uint32_t* caps_dev, const int64_t* kth_all, uint32_t n_shards, uint32_t per, uint32_t n_dst,
-                   uint32_t* cnt, uint32_t* tot, hipStream_t s) {
+// ... the bounds from the gathered reports, this shard's entries at or above them packed into n_dst slices of slice_words u64 (per header pairs + room for
+// per * k entries); cursor[n_dst] (zeroed here) ends as the slices' entry totals
+int group_kw_prune_pack(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t n_pad, uint32_t k, uint32_t words, const uint32_t* caps_dev, const int64_t* kth_all,
+                        uint32_t n_shards, uint32_t per, uint32_t n_dst, uint64_t slice_words, uint64_t* block, uint32_t* cursor, hipStream_t s) {
     (void)hipSetDevice(ctx->device);
-    TSGPU_HIP_TRY(hipMemsetAsync(tot, 0, (size_t)n_dst * 4, s));
-    hipLaunchKernelGGL(kw_group_count_kernel, dim3((n_q + 255) / 256), dim3(256), 0, s, kw_out_of(loc), (const int32_t*)loc->status, caps_dev, n_q, k, kth_all, n_shards, per, cnt, tot);
-    TSGPU_HIP_TRY(hipGetLastError());
-    return TSGPU_OK;
-}
-// ... and the exchange block: n_dst slices of slice_words u64 (per header pairs + room for the slice's entries)
-int group_kw_pack_pruned(tsgpu_ctx* ctx, const tsgpu_hits* loc, uint32_t n_q, uint32_t k, uint32_t words, uint32_t per, uint32_t n_dst, const uint32_t* cnt, uint32_t* first_of,
-                         uint64_t slice_words, uint64_t* block, hipStream_t s) {
-    (void)hipSetDevice(ctx->device);
-    const KwOut o = kw_out_of(loc);
-    hipLaunchKernelGGL(kw_group_pruned_header_kernel, dim3(n_dst), dim3(KW_THREADS), 0, s, o, (const int32_t*)loc->status, n_q, per, cnt, slice_words, block, first_of);
-    const uint64_t n = (uint64_t)n_q * k;
-    hipLaunchKernelGGL(kw_group_pruned_entries_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, o, n_q, k, words, per, cnt, first_of, slice_words, block);
+    TSGPU_HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)n_dst * 4, s));
+    hipLaunchKernelGGL(kw_group_prune_pack_kernel, dim3((n_pad + 3) / 4), dim3(256), 0, s, kw_out_of(loc), (const int32_t*)loc->status, caps_dev, n_q, n_pad, k, words, kth_all, n_shards,
+                       per, slice_words, block, cursor);
     TSGPU_HIP_TRY(hipGetLastError());
     return TSGPU_OK;
 }

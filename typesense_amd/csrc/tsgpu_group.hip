@@ -89,7 +89,7 @@ struct Member {
     DevBuf v_dist, v_lab, v_cnt, v_bad;                  // ... local k-NN result
     DevBuf o_keys, o_scores, o_tm, o_nh, o_nm, o_st, o_vd, o_lab, o_cnt;   // merged result staged on the device (host outputs)
     DevBuf caps;                                         // per-query Topster capacity (the merged list of a query never exceeds its own Topster)
-    DevBuf kth_send, kth_recv, p_cnt, p_first, p_tot, p_totall;    // bound-pruned exchange: this shard's kq-th entries / every shard's; entries at or above the bound, their offsets, totals per slice
+    DevBuf kth_send, kth_recv, p_tot, p_totall;          // bound-pruned exchange: this shard's reported entries / every shard's; the slices' cursors = entry totals; every rank's totals
     std::vector<uint32_t> h_tot;
     std::vector<uint32_t> h_caps;
     PinBuf h_send, h_recv;                               // HOST transport: the staged blocks
@@ -149,7 +149,7 @@ int host_collective(tsgpu_group* g, bool all_to_all, const void* send_dev, size_
     return TSGPU_OK;
 }
 
-// member 0's exchange kernels are timed with HIP events on its stream (four brackets: pack or bounds | count | merge | pruned pack)
+// member 0's exchange kernels are timed with HIP events on its stream (three brackets: pack or bounds | prune + pack | merge)
 void mark(tsgpu_group* g, size_t member, int i) {
     if (member != 0) return;
     Member& mem = g->m[0];
@@ -160,10 +160,26 @@ float marked_ms(tsgpu_group* g, bool mid) {
     Member& mem = g->m[0];
     float tot = 0, ms = 0;
     for (int b = 0; b < 4; b++) {
-        if ((b == 1 || b == 3) && !mid) continue;
+        if (b == 3 || (b == 1 && !mid)) continue;          // brackets: 0 pack or bounds | 1 prune + pack | 2 merge
         if (mem.ev[2 * b] && mem.ev[2 * b + 1] && hipEventElapsedTime(&ms, mem.ev[2 * b], mem.ev[2 * b + 1]) == hipSuccess) tot += ms;
     }
     return tot;
+}
+
+// HOST transport, bound-pruned slices: the used prefix (used_bytes) of each of this rank's n slices (stride_bytes apart in its send buffer) -> pinned host,
+// the caller's all_to_all on equal pieces of used_bytes, one copy back: the received pieces are used_bytes apart in the recv buffer
+int host_all_to_all_prefix(tsgpu_group* g, size_t stride_bytes, size_t used_bytes) {
+    Member& mem = g->m[0];
+    (void)hipSetDevice(mem.ctx->device);
+    int rc;
+    if ((rc = mem.h_send.reserve(used_bytes * g->n)) || (rc = mem.h_recv.reserve(used_bytes * g->n)) || (rc = mem.recv.reserve(used_bytes * g->n))) return rc;   // (all within the local phase's reservations)
+    for (uint32_t j = 0; j < g->n; j++) TSGPU_HIP_TRY(hipMemcpyAsync((char*)mem.h_send.p + (size_t)j * used_bytes, (const char*)mem.send.p + (size_t)j * stride_bytes, used_bytes, hipMemcpyDeviceToHost, mem.ctx->stream));
+    TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+    const int crc = g->coll.all_to_all(g->coll.user, mem.h_send.p, mem.h_recv.p, used_bytes);
+    if (crc) return fail(TSGPU_ERR_DEVICE, "tsgpu_group: the caller's all_to_all callback failed (" + std::to_string(crc) + ")");
+    TSGPU_HIP_TRY(hipMemcpyAsync(mem.recv.p, mem.h_recv.p, used_bytes * g->n, hipMemcpyHostToDevice, mem.ctx->stream));
+    TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+    return TSGPU_OK;
 }
 
 uint32_t call_signature(std::initializer_list<uint64_t> v) {
@@ -655,8 +671,7 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
                 (r = mem.send.reserve((size_t)n_pad * qw * 8)) || (r = mem.recv.reserve((slices ? (size_t)n_pad : (size_t)n_queries * g->n) * qw * 8)) ||
                 ((slices || i == 0) && (r = reserve_staging(mem, out, n_pad))) ||
                 (r = reserve_host_staging(g, mem, std::max((slices ? (size_t)n_pad : (size_t)n_queries * g->n) * qw * 8, (size_t)n_pad * KS * 24)))) return r;
-            if (pruned && ((r = mem.kth_send.reserve((size_t)n_queries * 64)) || (r = mem.kth_recv.reserve((size_t)n_queries * 64 * g->n)) || (r = mem.p_cnt.reserve((size_t)n_queries * 4)) ||
-                           (r = mem.p_first.reserve((size_t)n_queries * 4)) || (r = mem.p_tot.reserve((size_t)n_dst * 4)) || (r = mem.p_totall.reserve((size_t)n_dst * 4 * g->n)) || (r = mem.caps.reserve((size_t)n_pad * 4)) ||
+            if (pruned && ((r = mem.kth_send.reserve((size_t)n_queries * 64)) || (r = mem.kth_recv.reserve((size_t)n_queries * 64 * g->n)) || (r = mem.p_tot.reserve((size_t)n_dst * 4)) || (r = mem.p_totall.reserve((size_t)n_dst * 4 * g->n)) || (r = mem.caps.reserve((size_t)n_pad * 4)) ||
                            (r = reserve_host_staging(g, mem, (size_t)n_queries * 64 * g->n)))) return r;
             tsgpu_hits loc;
             memset(&loc, 0, sizeof loc);
@@ -685,37 +700,34 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
         size_t slice_words = (size_t)per * qw;                                           // one destination slice of a member's block, in u64 words
         std::vector<uint32_t> tot_all;                                                   // bound-pruned: entries member src sends to destination slice dst
         if (pruned) {
-            // 2a) the bounds: every shard's kq-th entries everywhere (32 B per query and shard); 2b) each member counts its entries at or above the
-            //     bound, per destination slice; 2c) the slice capacity M = the largest (source, destination) total of the whole group (one u64 per
-            //     rank: collectives move equal-sized slices); 2d) the pruned blocks are packed: per slice `per` header pairs + M entries
+            // 2a) the bounds: every shard's two reported entries per query, everywhere (64 B per query and shard); 2b) each member packs its entries at or
+            //     above the bound into n_dst slices (capacity stride: per header pairs + per * k entries), the slices' cursors end as their entry totals;
+            //     2c) the totals of every (source, destination) pair reach every rank: the exact transfer sizes
             if ((rc = all_gather_everywhere(g, &Member::kth_send, &Member::kth_recv, (size_t)n_queries * 64))) return rc;
-            uint64_t most = 0;
+            slice_words = (size_t)per * 2 + (size_t)per * k * words;                     // (<= per * qw: two header words replace three)
             mark(g, 0, 2);
             for (auto& mem : g->m) {
                 tsgpu_hits loc;
                 memset(&loc, 0, sizeof loc);
                 loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL; loc.keys = mem.l_keys.as<uint64_t>(); loc.scores = mem.l_scores.as<int64_t>(); loc.text_match = mem.l_tm.as<int64_t>();
                 loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>();
-                if ((rc = group_kw_count(mem.ctx, &loc, n_queries, k, mem.caps.as<uint32_t>(), mem.kth_recv.as<int64_t>(), g->n, per, n_dst, mem.p_cnt.as<uint32_t>(), mem.p_tot.as<uint32_t>(), mem.ctx->stream))) return rc;
+                if ((rc = group_kw_prune_pack(mem.ctx, &loc, n_queries, n_pad, k, words, mem.caps.as<uint32_t>(), mem.kth_recv.as<int64_t>(), g->n, per, n_dst, slice_words,
+                                              mem.send.as<uint64_t>(), mem.p_tot.as<uint32_t>(), mem.ctx->stream))) return rc;
                 if (&mem == &g->m[0]) mark(g, 0, 3);
             }
             if ((rc = gather_totals(g, n_dst, tot_all))) return rc;
-            for (uint32_t v : tot_all) most = std::max<uint64_t>(most, v);
-            slice_words = (size_t)per * 2 + (size_t)most * words;                        // (<= per * qw: a count never exceeds k, two header words replace three)
-            for (auto& mem : g->m) {
-                tsgpu_hits loc;
-                memset(&loc, 0, sizeof loc);
-                loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL; loc.keys = mem.l_keys.as<uint64_t>(); loc.scores = mem.l_scores.as<int64_t>(); loc.text_match = mem.l_tm.as<int64_t>();
-                loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>();
-                if (&mem == &g->m[0]) mark(g, 0, 6);
-                if ((rc = group_kw_pack_pruned(mem.ctx, &loc, n_queries, k, words, per, n_dst, mem.p_cnt.as<uint32_t>(), mem.p_first.as<uint32_t>(), slice_words, mem.send.as<uint64_t>(), mem.ctx->stream))) return rc;
-                if (&mem == &g->m[0]) mark(g, 0, 7);
-            }
         }
-        // (pruned slices travel at their EXACT sizes where the transport can — RCCL send / recv pairs, device copies: when one shard owns a query's winners
-        //  it alone sends entries for it; the HOST callbacks move equal-sized slices, padded to the largest)
+        // Pruned slices travel at their EXACT sizes where the transport can (RCCL send / recv pairs, device copies: when one shard owns a query's winners it
+        // alone sends entries for it); the HOST callbacks and the literal all-gather form move equal-sized pieces: the used prefix of the largest slice.
         const bool exact = pruned && slices && g->transport != TSGPU_XCHG_HOST;
-        if ((rc = exact ? exchange_slices_exact(g, slice_words, tot_all, per, words) : slices ? exchange_slices(g, slice_words * 8) : exchange(g, slice_words * 8))) return rc;
+        if (pruned && !exact) {
+            uint64_t most = 0;
+            for (uint32_t v : tot_all) most = std::max<uint64_t>(most, v);
+            const size_t used = (size_t)per * 2 + (size_t)most * words;
+            if (slices) { if ((rc = host_all_to_all_prefix(g, slice_words * 8, used * 8))) return rc; }       // HOST: strided prefixes out, contiguous in
+            else if ((rc = exchange(g, used * 8))) return rc;                                                // one slice per member: its prefix is contiguous
+            slice_words = used;                                                                              // the gathered pieces are `used` words apart
+        } else if ((rc = exact ? exchange_slices_exact(g, slice_words, tot_all, per, words) : slices ? exchange_slices(g, slice_words * 8) : exchange(g, slice_words * 8))) return rc;
         for (size_t i = 0; i < mergers; i++) {
             Member& mem = g->m[i];
             (void)hipSetDevice(mem.ctx->device);

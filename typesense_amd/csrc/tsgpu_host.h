@@ -552,10 +552,8 @@ int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard
                         const uint32_t* caps_dev, const tsgpu_hits* out_dev, hipStream_t s, uint32_t pruned_per = 0);
 // bound-pruned exchange (kw_kernels.hip.h): the shard's kq-th entries; counts against the gathered bounds; the pruned exchange block
 int group_kw_kth(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t k, uint32_t n_shards, const uint32_t* caps_dev, int64_t* kth, hipStream_t s);
-int group_kw_count(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t k, const uint32_t* caps_dev, const int64_t* kth_all, uint32_t n_shards, uint32_t per, uint32_t n_dst,
-                   uint32_t* cnt, uint32_t* tot, hipStream_t s);
-int group_kw_pack_pruned(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t k, uint32_t words, uint32_t per, uint32_t n_dst, const uint32_t* cnt, uint32_t* first_of,
-                         uint64_t slice_words, uint64_t* block, hipStream_t s);
+int group_kw_prune_pack(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t n_pad, uint32_t k, uint32_t words, const uint32_t* caps_dev, const int64_t* kth_all,
+                        uint32_t n_shards, uint32_t per, uint32_t n_dst, uint64_t slice_words, uint64_t* block, uint32_t* cursor, hipStream_t s);
 int group_store_keyword_slice(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t q_out_offset, uint32_t k, const tsgpu_hits* out_dev, hipStream_t s);   // replicas form
 int group_vec_dim(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t* dim);
 void group_resolve_topster_sizes(const tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_q, uint32_t* caps_host);   // Topster capacity per query (src/index.cpp:3506-3512)
