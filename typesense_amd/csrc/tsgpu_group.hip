@@ -112,6 +112,7 @@ struct tsgpu_group {
     bool own_slice_only = false;         // rank form, slice exchange (option "kw_own_slice_only"): a rank delivers only the slice of the batch it merged — queries
                                          // [rank * per, (rank + 1) * per), per = ceil(n_queries / n_ranks) — into its output arrays (at those queries' slots); no all-gather of
                                          // the merged lists. What a deployment with one request router per rank needs, and what the local form does with host outputs.
+    bool kw_pruned_force = false;        // (option value 2: also with one member — exercises the bounds all-gather and the send / recv pairs on a single GPU)
     bool kw_pruned = true;               // keyword exchange: every shard sends only its entries at or above the query's bound (option "kw_exchange_pruned")
     int kw_slices = 1;                   // (2 = also with one member: exercises the collectives on a single GPU) keyword exchange: all-to-all of query slices + slice merge + all-gather of the merged lists (false: one all-gather, full merge on every rank)
     tsgpu_host_collectives coll{};       // TSGPU_XCHG_HOST
@@ -161,7 +162,10 @@ float marked_ms(tsgpu_group* g, bool mid) {
     float tot = 0, ms = 0;
     for (int b = 0; b < 4; b++) {
         if (b == 3 || (b == 1 && !mid)) continue;          // brackets: 0 pack or bounds | 1 prune + pack | 2 merge
-        if (mem.ev[2 * b] && mem.ev[2 * b + 1] && hipEventElapsedTime(&ms, mem.ev[2 * b], mem.ev[2 * b + 1]) == hipSuccess) tot += ms;
+        if (mem.ev[2 * b] && mem.ev[2 * b + 1] && hipEventElapsedTime(&ms, mem.ev[2 * b], mem.ev[2 * b + 1]) == hipSuccess) {
+            tot += ms;
+            if (getenv("TSGPU_GROUP_DEBUG")) fprintf(stderr, "[tsgpu_group] exchange kernels, bracket %d: %.3f ms\n", b, ms);
+        }
     }
     return tot;
 }
@@ -654,7 +658,7 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
         const uint32_t per = slices ? (n_queries + g->n - 1) / g->n : n_queries;      // queries a member merges
         const uint32_t n_pad = slices ? per * g->n : n_queries;
         const size_t KS = out->k_stride;
-        const bool pruned = g->kw_pruned && g->n > 1;
+        const bool pruned = g->kw_pruned && (g->n > 1 || g->kw_pruned_force);
         const uint32_t n_dst = slices ? g->n : 1;                                      // destination slices of a member's exchange block
         const auto t0 = std::chrono::steady_clock::now();
         g->m[0].h_caps.assign(n_pad, 0u);
@@ -776,7 +780,7 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
 int tsgpu_group_set_option(tsgpu_group* g, const char* name, int64_t value) {
     if (!g || !name) return fail(TSGPU_ERR_INVALID, "tsgpu_group_set_option: NULL argument");
     std::lock_guard<std::mutex> lk(g->mu);
-    if (!strcmp(name, "kw_exchange_pruned")) { g->kw_pruned = value != 0; return ok(); }
+    if (!strcmp(name, "kw_exchange_pruned")) { g->kw_pruned = value != 0; g->kw_pruned_force = value == 2; return ok(); }
     if (!strcmp(name, "kw_exchange_slices")) { g->kw_slices = value == 2 ? 2 : (value != 0); return ok(); }
     if (!strcmp(name, "replicas")) { g->replicas = value != 0; return ok(); }
     if (!strcmp(name, "kw_own_slice_only")) { g->own_slice_only = value != 0; return ok(); }
