@@ -148,6 +148,14 @@ def main():
                 check("differing k must fail everywhere", False)
             except T.TsgpuError as e:
                 check("differing arguments: 400", e.code == 400 and "different arguments" in str(e))
+            # ... and so does a rank that is called with an EMPTY batch while the others bring queries (it used to return before the agreement
+            # step and leave the others waiting in it); everybody empty is fine
+            try:
+                grp.keyword_search_batch([] if rank == 0 else qs, K, k_stride=K)
+                check("an empty batch on one rank must fail everywhere", False)
+            except T.TsgpuError as e:
+                check("empty batch on one rank: 400", e.code == 400 and "different arguments" in str(e))
+            grp.keyword_search_batch([], K, k_stride=K)
             check_keyword("keyword after the failed calls", grp.keyword_search_batch(qs, K, k_stride=K))
         grp.close()
         g.close()

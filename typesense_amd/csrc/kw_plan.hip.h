@@ -20,7 +20,7 @@
 
 namespace tsgpu {
 
-struct KwPlanIn {                    // what the host pre-scan keeps of one tsgpu_kw_query (64 bytes, pinned staging -> one upload)
+struct KwPlanIn {                    // what the host pre-scan keeps of one tsgpu_kw_query (76 bytes, pinned staging -> one upload)
     uint32_t term_ids[TSGPU_MAX_QUERY_TOKENS];
     uint32_t field;
     int32_t weight;
@@ -33,6 +33,8 @@ struct KwPlanIn {                    // what the host pre-scan keeps of one tsgp
     int8_t syn_orig_num_tokens;
     uint8_t orig_num_tokens, is_synonym, demote_synonym;
 };
+
+static_assert(sizeof(KwPlanIn) == 76, "the comments (and DESIGN.md) quote the record's size");
 
 struct KwPlanTotals {                // device-resident, read back by the host (twice: after resolve, after layout)
     unsigned long long total_best_blocks;   // sum over the queries of their shortest list's blocks (the auto chunk rule's input)

@@ -590,6 +590,8 @@ int tsgpu_group_create_rank(tsgpu_ctx* ctx, const uint8_t id[128], uint32_t rank
     memcpy(u.internal, id, 128);
     int rc = r->CommInitRank(&g->m[0].comm, (int)n_ranks, u, (int)rank);
     if (rc) return rccl_fail("ncclCommInitRank", rc);
+    // the agreement step's buffers exist from here on: a reservation that fails inside agree() would leave the other ranks in its collective
+    if ((rc = g->m[0].agree_d.reserve((size_t)(n_ranks + 1) * 8)) || (rc = g->m[0].agree_h.reserve((size_t)(n_ranks + 1) * 8))) { (void)r->CommDestroy(g->m[0].comm); return rc; }
     *out = g.release();
     return ok();
 }
@@ -642,7 +644,8 @@ int tsgpu_group_last_timings(tsgpu_group* g, tsgpu_group_timings* out) {
 // delivers the slices straight to the caller). 0: ONE ncclAllGather of the blocks, every rank merges everything.
 int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out) {
     if (!g || !out || (n_queries && !queries)) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: NULL argument");
-    if (n_queries == 0) return ok();
+    if (n_queries == 0) { std::lock_guard<std::mutex> lk0(g->mu); return agree(g, TSGPU_OK, call_signature({2, 0})); }      // (rank form: a rank called with an empty batch still meets
+                                                                                                                             //  the others in the agreement step — they learn of the mismatch instead of waiting for it forever)
     int pre = TSGPU_OK;
     if (k == 0 || k > out->k_stride || k > TSGPU_MAX_TOPK) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: k must be in 1..min(k_stride, 1024)");
     else if (!out->keys || !out->scores || !out->n_hits) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: missing output arrays");
@@ -794,7 +797,7 @@ int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float
                               const uint32_t* allow_ids, uint32_t n_allow, const uint32_t* excluded_ids, uint32_t n_excluded,
                               float* dist_out, uint64_t* label_out, uint32_t* n_out, int mem_out) {
     if (!g || !Q || !dist_out || !label_out || !n_out) return fail(TSGPU_ERR_INVALID, "tsgpu_group_vec_knn_batch: NULL argument");
-    if (n_queries == 0) return ok();
+    if (n_queries == 0) { std::lock_guard<std::mutex> lk0(g->mu); return agree(g, TSGPU_OK, call_signature({4, 0})); }
     int pre = TSGPU_OK;
     if (k == 0 || k > TSGPU_MAX_TOPK) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_vec_knn_batch: k must be in 1..1024");
     else if ((uint64_t)g->n * k > 8192) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_vec_knn_batch: members * k > 8192");
@@ -909,7 +912,7 @@ int tsgpu_group_hybrid_search_batch(tsgpu_group* g, const tsgpu_kw_query* querie
     if (!g || !queries || !p || !Q || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_group_hybrid_search_batch: NULL argument");
     if (out->mem != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_hybrid_search_batch: host outputs only");
     if (p->rerank_hybrid_matches) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_hybrid_search_batch: rerank_hybrid_matches is not available on shards");
-    if (n_queries == 0) return ok();
+    if (n_queries == 0) return tsgpu_group_keyword_search_batch(g, queries, 0, 1, out);      // (the agreement step of the keyword half: a rank with an empty batch still meets the others)
     const uint32_t k = p->k == 0 ? std::max<uint32_t>(p->fetch_size, 100) : p->k;                 // src/index.cpp:4060-4063
     try {
         const uint32_t KS = out->k_stride;

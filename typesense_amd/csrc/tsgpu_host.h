@@ -150,12 +150,32 @@ struct RetireBin {
     std::vector<void*> dev;
     size_t bytes = 0;
     RetireBin() { oom_hook() = &RetireBin::drain_all; std::lock_guard<std::mutex> lk(registry_mu()); registry().push_back(this); }
-    // (more than 1 GiB parked — a whole retired index copy after a compaction while writes go idle — is freed on the spot, like DeferredFrees)
+    // More than 1 GiB parked — a whole retired index copy after a compaction while writes go idle — is not kept until the next commit, but it is not
+    // freed HERE either: put() runs on whichever thread drops the last reference, usually a search thread finishing a batch on an old snapshot, and
+    // hipFree synchronises the device (a compaction under load stalled that search and serialised every lane). The buffer goes to a
+    // reaper thread, started on first use, whose hipFree calls block nobody's request.
+    struct Reaper {
+        std::mutex m; std::condition_variable cv; std::vector<void*> q; bool started = false;
+        void give(void* p) {
+            std::lock_guard<std::mutex> lk(m);
+            q.push_back(p);
+            if (!started) { started = true; std::thread([this] { run(); }).detach(); }
+            cv.notify_one();
+        }
+        void run() {
+            for (;;) {
+                std::vector<void*> v;
+                { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !q.empty(); }); v.swap(q); }
+                for (void* p : v) (void)hipFree(p);
+            }
+        }
+    };
+    static Reaper& reaper() { static Reaper* r = new Reaper; return *r; }      // (never destroyed: outlives every bin)
     void put(DevBuf& b) {
         if (!b.p) return;
-        bool now = false;
-        { std::lock_guard<std::mutex> lk(m); if (bytes + b.cap > (1ull << 30)) now = true; else { dev.push_back(b.p); bytes += b.cap; } }
-        if (now) (void)hipFree(b.p);
+        bool over = false;
+        { std::lock_guard<std::mutex> lk(m); if (bytes + b.cap > (1ull << 30)) over = true; else { dev.push_back(b.p); bytes += b.cap; } }
+        if (over) reaper().give(b.p);
         b.p = nullptr; b.cap = 0;
     }
     void drain() { std::vector<void*> v; { std::lock_guard<std::mutex> lk(m); v.swap(dev); bytes = 0; } for (void* p : v) (void)hipFree(p); }
@@ -491,7 +511,7 @@ struct tsgpu_ctx {
                                                      // results cross PCIe while the next one computes (0 = never); no slice is smaller than this
     bool kw_host_split_device_plan = true;           // ... whose first (large) slice is planned on the device (kw_plan.hip.h) when it qualifies
     uint32_t kw_host_split_tail_slices = 1;          // slices behind the first one (1 or 2)
-    uint32_t kw_host_split_first_pct = 85;           // ... the first slice's share of the batch (the rest: two equal slices)
+    uint32_t kw_host_split_first_pct = 85;           // ... the first slice's share of the batch (the rest: ONE tail slice; two with kw_host_split_tail_slices = 2)
     uint32_t kw_zero_copy_max_queries = 256;         // host-output keyword batches up to this many queries: the merge kernel writes into pinned host memory (0 = always copy)
     uint32_t kw_timing_min_queries = 64;             // keyword batches below this many queries skip the phase events (tsgpu_timings reports 0 ms for them)
     uint32_t kw_merge_select_min = 2;                // queries with at least this many partial lists are merged by selection (kw_select_partials: tree merge); 0 = always fold
