@@ -28,6 +28,9 @@ static const int KW_F2_SPAN = TSGPU_F2_SPAN;                 // runs of up to th
 #endif
 static const bool KW_F2_QUAD = TSGPU_F2_QUAD != 0;           // 4-ary slot search (three samples per round) instead of binary
 static const bool KW_F2_FAST = TSGPU_F2_FAST != 0;
+#ifndef TSGPU_F2_MIDSLABS
+#define TSGPU_F2_MIDSLABS 0
+#endif
 #ifndef TSGPU_F2_ROUNDS
 #define TSGPU_F2_ROUNDS 0
 #endif
@@ -158,9 +161,18 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
             tbuf ^= 1; P.buf = tbuf;
             const uint32_t* lane_src = idwB + P.w_begin + t;
             uint32_t* lds_wave_base = sm.btile + tbuf * HALF + wave * 64;
+#if TSGPU_F2_MIDSLABS
+            // (three fill sizes: the COUNT instantiation showed 10.5 of the find kernel's 17 GB of requests per 10 000-query batch to be tile DMA, two thirds of
+            //  the pairs taking the 7-slab form for runs of 513..1024 words)
+            if (P.W <= 2u * KW_THREADS) kw_glds_slabs<2>(lane_src, lds_wave_base);
+            else if (PIPE_WORDS > 4 && P.W <= 4u * KW_THREADS) kw_glds_slabs<4>(lane_src, lds_wave_base);
+            else kw_glds_slabs<PIPE_WORDS>(lane_src, lds_wave_base);
+            if constexpr (COUNT) cb_tile += 4u * (P.W <= 2u * KW_THREADS ? 2u : ((PIPE_WORDS > 4 && P.W <= 4u * KW_THREADS) ? 4u : (uint32_t)PIPE_WORDS));
+#else
             if (P.W <= 2u * KW_THREADS) kw_glds_slabs<2>(lane_src, lds_wave_base);
             else kw_glds_slabs<PIPE_WORDS>(lane_src, lds_wave_base);
             if constexpr (COUNT) cb_tile += 4u * (P.W <= 2u * KW_THREADS ? 2u : (uint32_t)PIPE_WORDS);
+#endif
         } else P.mode = KW_F2_ROUNDS ? 1 : 2;
         return P;
     };

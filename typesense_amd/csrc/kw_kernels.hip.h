@@ -1051,7 +1051,8 @@ struct KwSmem {
     static const int Q1 = SCORE ? 1 : KW_QCAP;
     static const int NP = MF ? TMAX * KW_MAX_FIELDS : TMAX;    // posting positions carried per complete hit
     static const bool HAS_S2 = S2;
-    static const int QF = DEFER ? 1 : KW_QCAP;
+    static const int QF = DEFER ? 1 : (SCORE ? KW_THREADS : KW_QCAP);     // (the score kernel stages 256 records per round: half the queue — 13 KB less LDS in the
+                                                                         //  multi-field instantiation, whose records carry TMAX x 4 positions: 3 -> 4 workgroups per CU)
     // stage-1 survivors: id, driver position, first-probe position
     uint32_t q1_id[Q1], q1_p0[Q1], q1_p1[Q1];
     // several query_by fields: the queued survivor's positions in the SECOND token's lists of fields 1.. (field 0: q1_p1)
