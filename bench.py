@@ -1120,7 +1120,9 @@ class Bench:
         res["recall_at_%d" % k] = head["recall_at_%d" % k]
         res["roofline"] = {"bound": "hbm", "achieved": head["row_bytes_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["row_bytes_GBs"] / HBM_PEAK_GBS, "traffic": None,
                            "note": "algorithmic bytes = distances computed x dim x 4 B (fp32 rows fetched at random, 3 KB each; link lists and visited tags not "
-                                   "counted) over the kernel time of the ef=100 batch"}
+                                   "counted) over the kernel time of the QUOTED run (ef = %d, batch %d: the smallest ef with recall@%d >= 0.9; "
+                                   "at the reference's effective ef = max(ef, k) = %d recall@%d is %.2f on this data: runs[])" % (
+                                       head["ef"], head["batch"], k, k, k, next((x["recall_at_%d" % k] for x in cands if x["ef"] == k), float("nan")))}
         if not args.no_cpu_baseline:
             from oracle import oracle_py as O
             t2 = time.time()

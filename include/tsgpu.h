@@ -330,7 +330,8 @@ uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64
  *   tsgpu_facet_count_batch: result_ids[q] = host array of n_result_ids[q] ascending ids. sample_mod > 1 = estimate_facets (only the
  *     ids at positions i % sample_mod == 0, :1683-1687); allowed_hashes (sorted, NULL = all) = fquery_hashes of a facet query (:1742).
  *     out: [n_queries][cap] in ascending hash order; n_values[q] = distinct values found (may exceed cap: the first cap are returned).
- * Not covered (the caller keeps its CPU body): group_by (hash_groups), range facets, stats, the value-index ("intersect") branch. */
+ * Facet stats (tsgpu_facet_stats_batch) and the value-index ("intersect") branch (tsgpu_facet_value_set / tsgpu_facet_value_count_batch) follow below.
+ * Not covered (the caller keeps its CPU body): group_by (hash_groups) and range facets. */
 typedef struct tsgpu_facet_counts {
     uint32_t cap;            /* slots per query */
     uint32_t* hash;          /* [n_queries * cap] facet value hash */
