@@ -1497,7 +1497,7 @@ def main():
         if r.get("elapsed_dev"):
             kw["value_device_only"] = mult * r["n_q"] * args.steps / r["elapsed_dev"]       # outputs left in HBM: the single-launch form the roofline / rocprof durations refer to
             kw["ms_per_step_device_only"] = 1e3 * r["elapsed_dev"] / args.steps
-        find_rx, score_rx = r"kw_find2_kernel<3>|kw_search_kernel<3, 512, true, true>", r"kw_score_kernel"
+        find_rx, score_rx = r"kw_find2_kernel<3(, false)?>|kw_search_kernel<3, 512, true, true>", r"kw_score_kernel<3, 512, false, false, true>"      # (not the COUNT instantiation's one launch)
         # (max over the dispatches = the full 10 000-query launch: the profiled command also runs the host-delivery leg, whose slices
         #  are smaller launches of the same kernels and would dilute an average)
         traffic = pmc_traffic([find_rx, score_rx], ["pmc_kw_fetch.txt", "pmc_kw_s5_fetch.txt"], field="max")

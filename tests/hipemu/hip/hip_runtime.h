@@ -324,6 +324,8 @@ inline int __syncthreads_count(int pred) {   // barrier + number of threads of t
 inline unsigned long long __ballot(int pred) { return hipemu::ballot(pred); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
 inline int __ffs(int x) { return __builtin_ffs(x); }
 template <class T> inline T __shfl(T v, int lane, int = 64) { return hipemu::shfl(v, lane); }
 template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return hipemu::shfl(v, (int)(hipemu::cur_lane() ^ (unsigned)mask)); }

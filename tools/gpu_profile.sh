@@ -6,7 +6,7 @@
 #   * the GPU test tier, the smoke test and the full bench line                        -> pytest_gpu_<tag>.txt, smoke_<tag>.txt, bench_all_<tag>.json
 # bench.py reads pmc_kw_fetch.txt / pmc_kw_sq1.txt / pmc_vec_fetch.txt of the round for roofline.traffic / issue_util.
 set -u
-R=${1:-r04}; TAG=${2:-final}
+R=${1:-r05}; TAG=${2:-final}
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$ROOT/gpurun_out/prof_$TAG; P=$ROOT/gpurun_out/profiles_$R
@@ -34,7 +34,8 @@ python tools/pmc_summary.py $O/pmc_kw_sq2 "kw_" > $P/pmc_kw_sq2.txt 2>&1
 mkdir -p profiles/$R && cp $P/pmc_*.txt profiles/$R/
 timeout 1500 python -m pytest tests -m gpu -x -q > $P/pytest_gpu_$TAG.txt 2>&1; tail -2 $P/pytest_gpu_$TAG.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $P/smoke_$TAG.txt 2>&1; tail -1 $P/smoke_$TAG.txt
-( time timeout 1200 python bench.py --steps 20 --warmup 5 ) > $P/bench_all_$TAG.json 2> $O/bench_all.err; tail -4 $O/bench_all.err; wc -c $P/bench_all_$TAG.json
+# (round 5: stdout = the compact line the driver parses; the full record = --detail-out; stderr carries a copy of it)
+( time timeout 1200 python bench.py --steps 20 --warmup 5 --detail-out $P/bench_all_${TAG}_detail.json ) > $P/bench_all_$TAG.json 2> $O/bench_all.err; grep -v BENCH_DETAIL $O/bench_all.err | tail -4; wc -c $P/bench_all_$TAG.json $P/bench_all_${TAG}_detail.json
 rocm-smi --showmeminfo vram 2>/dev/null | head -5 > $P/hw_$TAG.txt; rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6 >> $P/hw_$TAG.txt
 find $O -name "*.db" -delete; find $O -name "*.csv" -size +2M -delete; rm -rf $O/trace_* $O/pmc_*
 du -sh $ROOT/gpurun_out/profiles_$R

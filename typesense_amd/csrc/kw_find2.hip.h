@@ -50,16 +50,17 @@ static const bool KW_F2_ROUNDS = TSGPU_F2_ROUNDS != 0;
 // per-thread counters: driver ids, block metadata, tile DMA, third.. list probes, hit records; one wave reduction + five atomics per wave at the
 // end into IndexView::touched). A second instantiation launched only under option kw_count_touched — the timed kernel carries none of it.
 // Same results either way (tests/test_emu_keyword.py runs both and compares).
+// (the body is a device function — work item index `bid` instead of blockIdx.x — so that kw_round_kernel, kw_kernels.hip.h, can run find, score and
+//  merge of a SMALL round in one launch; kw_find2_kernel below is the same code behind its own launch)
 template <int TMAX, bool COUNT = false>
-__global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
-                                                                                      const KwWorkItem* __restrict__ work, KwPartials part,
-                                                                                      uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
+__device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work, const KwPartials& part,
+                                              uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off, const uint32_t bid) {
     __shared__ KwSmem<TMAX, 512, false, true, true> sm;
     __shared__ uint32_t wave_cnt_b[2][KW_THREADS / 64];        // second half's wave counts (the first half uses sm.wave_cnt2)
-    uint32_t* __restrict__ hits = hits_all + hit_off[blockIdx.x] * (uint64_t)(TMAX + 1);
+    uint32_t* __restrict__ hits = hits_all + hit_off[bid] * (uint64_t)(TMAX + 1);
     __shared__ KwQueryDev sq;
     const uint32_t t = threadIdx.x;
-    const KwWorkItem wi = work[blockIdx.x];
+    const KwWorkItem wi = work[bid];
     uint32_t cb_ids = 0, cb_meta = 0, cb_tile = 0, cb_probe = 0, cb_rec = 0;      // COUNT only: bytes THIS lane requested
     {
         const uint32_t* src = (const uint32_t*)(queries + wi.query);
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
         mA = mC; mB = mD; mC = meta(b + 4); mD = meta(b + 5); araw0 = araw0n; araw1 = araw1n;   // (consumed in the middle of the next iteration)
     }
     if (T >= 3) while (q1n > 0) probe_batch(q1n < (uint32_t)KW_THREADS ? q1n : (uint32_t)KW_THREADS);
-    if (t == 0) part.cnt[blockIdx.x] = qfn;                    // hits handed to kw_score_kernel
+    if (t == 0) part.cnt[bid] = qfn;                           // hits handed to kw_score_kernel
     if constexpr (COUNT) {
         uint32_t c[5] = {cb_ids, cb_meta, cb_tile, cb_probe, cb_rec};
 #pragma unroll
@@ -452,4 +453,11 @@ __global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexV
     }
     KW_PROF(9)
     KW_PROF_FLUSH(ix.prof)
+}
+
+template <int TMAX, bool COUNT = false>
+__global__ __launch_bounds__(KW_THREADS) KW_F2_WAVES void kw_find2_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
+                                                                                      const KwWorkItem* __restrict__ work, KwPartials part,
+                                                                                      uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
+    kw_find2_body<TMAX, COUNT>(ix, queries, work, part, hits_all, hit_off, blockIdx.x);
 }

@@ -1300,28 +1300,28 @@ __device__ inline void kw_probe_rest_stage(KwSmem<TMAX, CAP, false, S2, DEFER>& 
 
 // the work item's partial result: its top-K in sort() order + the counters kw_merge_kernel folds
 template <int TMAX, int CAP, bool MF, bool S2, bool SCORE>
-__device__ inline void kw_write_partial(KwSmem<TMAX, CAP, MF, S2, false, SCORE>& sm, const KwQueryDev& q, const KwPartials& part) {
+__device__ inline void kw_write_partial(KwSmem<TMAX, CAP, MF, S2, false, SCORE>& sm, const KwQueryDev& q, const KwPartials& part, const uint32_t bid) {
     const uint32_t t = threadIdx.x;
     topk_compact<CAP, S2>(sm.tk, &sm.tk_cnt, q.k, sm.thr, &sm.have_thr);
     const uint32_t n = sm.tk_cnt;
-    const size_t base = (size_t)blockIdx.x * part.k_stride;
+    const size_t base = (size_t)bid * part.k_stride;
     for (uint32_t i = t; i < n; i += KW_THREADS) {
         part.s0[base + i] = sm.tk.s0[i]; part.s1[base + i] = sm.tk.s1[i]; part.s2[base + i] = sm.tk.s2[sm.tk.i2(i)]; part.key[base + i] = sm.tk.key[i];
     }
     if (t == 0) {
-        part.cnt[blockIdx.x] = n;
-        part.n_emit[blockIdx.x] = sm.n_emit;
-        part.off_words[blockIdx.x] = sm.off_words;
-        if (q.n_filt == 0) part.n_match[blockIdx.x] = sm.n_match;
-        else if (MF) part.n_match[blockIdx.x] = sm.f_cnt0;            // rank bits this work item set first (summed by kw_merge_kernel)
+        part.cnt[bid] = n;
+        part.n_emit[bid] = sm.n_emit;
+        part.off_words[bid] = sm.off_words;
+        if (q.n_filt == 0) part.n_match[bid] = sm.n_match;
+        else if (MF) part.n_match[bid] = sm.f_cnt0;            // rank bits this work item set first (summed by kw_merge_kernel)
         else {
             const uint32_t nonempty = sm.f_first ? 0u : 1u;
             const bool seq = q.n_excl != 0;                       // sequential mode tracked both variants itself
-            part.n_match[blockIdx.x] = sm.f_cnt0;
-            part.n_match1[blockIdx.x] = seq ? sm.f_cnt1 : sm.f_cnt0 + nonempty;
-            part.first_rank[blockIdx.x] = sm.f_frank;
-            part.last_rank[blockIdx.x] = sm.f_rp;
-            part.fflags[blockIdx.x] = nonempty | (seq ? ((sm.f_c0 & sm.f_ep) << 1) | ((sm.f_c1 & sm.f_ep) << 2) : 0u);
+            part.n_match[bid] = sm.f_cnt0;
+            part.n_match1[bid] = seq ? sm.f_cnt1 : sm.f_cnt0 + nonempty;
+            part.first_rank[bid] = sm.f_frank;
+            part.last_rank[bid] = sm.f_rp;
+            part.fflags[bid] = nonempty | (seq ? ((sm.f_c0 & sm.f_ep) << 1) | ((sm.f_c1 & sm.f_ep) << 2) : 0u);
         }
     }
 }
@@ -1663,7 +1663,7 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
         while (sm.qf_cnt > 0) kw_score_stage<TMAX, CAP, false, S2, false>(sm, ix, q, sm.qf_cnt < KW_THREADS ? sm.qf_cnt : KW_THREADS, aux_ids, my_ids_out, ids_out_base);
         KW_PROF(8)
         // ---- partial result of this work item: sorted, <= k entries ----
-        kw_write_partial(sm, q, part);
+        kw_write_partial(sm, q, part, blockIdx.x);
     }
     KW_PROF(9)
     KW_PROF_FLUSH(ix.prof)
@@ -1672,15 +1672,16 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
 // The "score" half of the two-kernel form: one workgroup per work item of the find kernel; its hits (seq_id + posting positions,
 // ascending seq_id) are scored 256 at a time — every wavefront full except the segment's last — through the same score stage,
 // top-K buffer and filter bookkeeping as the fused kernel, and leave the same partial result for kw_merge_kernel.
+// (body = device function with the work item's index as a parameter: kw_round_kernel runs it behind the find body in the same launch)
 template <int TMAX, int CAP, bool S2, bool MF = false, bool PLAIN = false>
-__global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(IndexView ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work,
-                                                              KwPartials part, const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out,
-                                                              const uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
+__device__ __forceinline__ void kw_score_body(const IndexView& ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work,
+                                              const KwPartials& part, const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out,
+                                              const uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off, const uint32_t bid) {
     __shared__ KwSmem<TMAX, CAP, MF, S2, false, true> sm;
     __shared__ KwQueryDev sq;
     constexpr int NP = decltype(sm)::NP;          // posting positions per record: TMAX, or TMAX x KW_MAX_FIELDS for several query_by fields
     const uint32_t t = threadIdx.x;
-    const KwWorkItem wi = work[blockIdx.x];
+    const KwWorkItem wi = work[bid];
     {
         const uint32_t* src = (const uint32_t*)(queries + (wi.query & 0x0FFFFFFFu));      // (multi-field items carry the driver field in the top bits)
         uint32_t* dst = (uint32_t*)&sq;
@@ -1694,8 +1695,8 @@ __global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(Ind
     __syncthreads();
     const KwQueryDev& q = sq;
     uint32_t* my_ids_out = ids_out ? ids_out + q.ids_out_off + wi.ids_out_off : nullptr;
-    const uint32_t count = part.cnt[blockIdx.x];
-    const uint32_t* __restrict__ mine = hits_all + hit_off[blockIdx.x] * (uint64_t)(NP + 1);
+    const uint32_t count = part.cnt[bid];
+    const uint32_t* __restrict__ mine = hits_all + hit_off[bid] * (uint64_t)(NP + 1);
     for (uint32_t i0 = 0; i0 < count; i0 += KW_THREADS) {
         const uint32_t n = count - i0 < (uint32_t)KW_THREADS ? count - i0 : (uint32_t)KW_THREADS;
         if (t < n) {
@@ -1713,7 +1714,13 @@ __global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(Ind
         __syncthreads();
         kw_score_stage<TMAX, CAP, MF, S2, true, PLAIN>(sm, ix, q, n, aux_ids, my_ids_out, 0u);
     }
-    kw_write_partial(sm, q, part);
+    kw_write_partial(sm, q, part, bid);
+}
+template <int TMAX, int CAP, bool S2, bool MF = false, bool PLAIN = false>
+__global__ __launch_bounds__(KW_THREADS) KW_SCORE_WAVES void kw_score_kernel(IndexView ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work,
+                                                              KwPartials part, const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out,
+                                                              const uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
+    kw_score_body<TMAX, CAP, S2, MF, PLAIN>(ix, queries, work, part, aux_ids, ids_out, hits_all, hit_off, blockIdx.x);
 }
 
 // LDS-DMA tile fill: N slabs of 256 words, lane t of the workgroup copies word (slab * 256 + t) of the run straight from global memory
@@ -2487,16 +2494,15 @@ __device__ inline bool kw_select_partials(KwSelectLds& sl, const KwPartials& par
 
 // grid = queries; folds a query's partials into the final order and writes the tsgpu_hits slots
 template <int CAP>
-__global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* __restrict__ queries, KwPartials part, KwOut out,
-                                                               uint32_t* __restrict__ ids_out, const KwWorkItem* __restrict__ work, uint32_t select_min) {
+__device__ __forceinline__ void kw_merge_body(const KwQueryDev* __restrict__ queries, const KwPartials& part, const KwOut& out, uint32_t select_min, const uint32_t qid) {
     __shared__ TopkLds<CAP> tk;
     __shared__ KwSelectLds sl;
     __shared__ unsigned long long s_nm, s_ow;
     const uint32_t t = threadIdx.x;
-    const KwQueryDev q = queries[blockIdx.x];
+    const KwQueryDev q = queries[qid];
     if (t == 0) { s_nm = 0; s_ow = 0; }
     __syncthreads();
-    const size_t ob = (size_t)blockIdx.x * out.k_stride;
+    const size_t ob = (size_t)qid * out.k_stride;
     int msi = -1;
     for (int i = 0; i < 3; i++) if (i < q.n_sort && q.sort_kind[i] == 0) msi = i;
     uint32_t n = 0;
@@ -2540,7 +2546,12 @@ __global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* 
         if (t == 0 && ordered_mf && q.n_work) s_nm = part.n_match1[q.first_work];
     }
     __syncthreads();
-    if (t == 0) { out.n_hits[blockIdx.x] = n; out.num_matched[blockIdx.x] = s_nm; out.off_words[blockIdx.x] = s_ow; }
+    if (t == 0) { out.n_hits[qid] = n; out.num_matched[qid] = s_nm; out.off_words[qid] = s_ow; }
+}
+template <int CAP>
+__global__ __launch_bounds__(KW_THREADS) void kw_merge_kernel(const KwQueryDev* __restrict__ queries, KwPartials part, KwOut out,
+                                                               uint32_t* __restrict__ ids_out, const KwWorkItem* __restrict__ work, uint32_t select_min) {
+    kw_merge_body<CAP>(queries, part, out, select_min, blockIdx.x);
     (void)ids_out; (void)work;
 }
 
@@ -3050,5 +3061,43 @@ __global__ __launch_bounds__(64) void kw_aux_score_kernel(IndexView ix, const Kw
 
 #include "kw_find2.hip.h"
 #include "kw_find_mf2.hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// ONE LAUNCH PER SMALL ROUND (round 5). The server's calling convention (one query per call from many request threads, gathered
+// into rounds of a few dozen queries by the micro-batcher) ran every round as three launches — find | score | merge — with 6-7 us between
+// them: a tenth of a 16-query round. Here one workgroup per work item runs the pair-find body, then — its own hit records are in memory: a
+// workgroup-level fence and a barrier — the score body, writes its partial top-K, and takes a TICKET of its query (device-scope atomic behind a
+// device-scope release: the partial lists of a query are written by workgroups on several XCDs, each with its own L2). The work item that draws
+// the last ticket of its query acquires and merges the query's partial lists into the caller's arrays (kw_merge_body) and puts the ticket back to
+// zero. Same bodies, same results as the three kernels; for plain single-field queries of <= 3 tokens with two sort keys (the PLAIN score
+// instantiation) in rounds below option kw_round_fused_max_queries — larger batches fill the chip per kernel and keep the leaner kernels.
+template <int TMAX>
+__global__ __launch_bounds__(KW_THREADS) void kw_round_kernel(IndexView ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work, KwPartials part,
+                                                               uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off, KwOut out, uint32_t select_min,
+                                                               uint32_t* __restrict__ ticket, uint32_t n_work, uint32_t n_queries) {
+    __shared__ uint32_t s_last;
+    const uint32_t bid = blockIdx.x;
+    // a query without work items (a token no list holds) is nobody's to merge: workgroup b < n_queries writes query b's empty result if it is one
+    // (grid = max(work items, queries); the workgroups beyond the work table do only this)
+    if (bid < n_queries && threadIdx.x == 0 && queries[bid].n_work == 0) { out.n_hits[bid] = 0; out.num_matched[bid] = 0; out.off_words[bid] = 0; }
+    if (bid >= n_work) return;
+    kw_find2_body<TMAX, false>(ix, queries, work, part, hits_all, hit_off, bid);
+    __threadfence_block();                                // this workgroup's hit records and part.cnt[bid] are in memory before any of its threads reads them back
+    __syncthreads();
+    kw_score_body<TMAX, 512, false, false, true>(ix, queries, work, part, nullptr, nullptr, hits_all, hit_off, bid);
+    __threadfence();                                      // release: the partial list must be visible to whichever workgroup merges the query
+    __syncthreads();
+    const uint32_t qid = work[bid].query;
+    if (threadIdx.x == 0) {
+        const uint32_t n_work = queries[qid].n_work;
+        const uint32_t drawn = atomicAdd(ticket + qid, 1u);
+        s_last = drawn + 1 == n_work ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;                                  // (uniform)
+    __threadfence();                                      // acquire: the other work items' partial lists
+    kw_merge_body<512>(queries, part, out, select_min, qid);
+    if (threadIdx.x == 0) ticket[qid] = 0;                // the next round finds its tickets at zero (rounds of one lane follow each other on one stream)
+}
 
 }  // namespace tsgpu
