@@ -3070,7 +3070,10 @@ __global__ __launch_bounds__(64) void kw_aux_score_kernel(IndexView ix, const Kw
 // device-scope release: the partial lists of a query are written by workgroups on several XCDs, each with its own L2). The work item that draws
 // the last ticket of its query acquires and merges the query's partial lists into the caller's arrays (kw_merge_body) and puts the ticket back to
 // zero. Same bodies, same results as the three kernels; for plain single-field queries of <= 3 tokens with two sort keys (the PLAIN score
-// instantiation) in rounds below option kw_round_fused_max_queries — larger batches fill the chip per kernel and keep the leaner kernels.
+// instantiation) in rounds below option kw_round_fused_max_queries.
+// MEASURED AND LEFT OFF (default 0; profiles/r05/exp_one_launch_rounds.txt): one request thread 55 us per call with either form — the gaps between
+// the three launches are not what a lone round waits for — and 256 request threads 455 K -> 96 K q/s: the three bodies' static LDS adds up to 95 KB
+// (one workgroup per CU) and 143 VGPRs, so the rounds of the four lanes, which overlap on the device as separate lean kernels, queue behind each other.
 template <int TMAX>
 __global__ __launch_bounds__(KW_THREADS) void kw_round_kernel(IndexView ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work, KwPartials part,
                                                                uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off, KwOut out, uint32_t select_min,

@@ -1419,7 +1419,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         // single-field <= 3-token queries, one hit-record group, no merge groups, nothing the PLAIN score instantiation lacks
         bool round_fused = false;
         if (ctx->kw_round_fused_max_queries && n_queries <= ctx->kw_round_fused_max_queries && !DP.on && tab_n[0] && !tab_n[1] && !tab_n[2] && !tab_n[3] && P.work_wild.empty() &&
-            tps[0].two && tps[0].group_start.size() == 2 && ctx->kw_pair_blocks && !v.touched && cap == 512 && !P.any_s2 && !P.any_aux && !ids_out && P.groups.empty() && !bo.vflat && !timing) {
+            tps[0].two && tps[0].group_start.size() == 2 && ctx->kw_pair_blocks && !v.touched && cap == 512 && !P.any_s2 && !P.any_aux && !ids_out && P.groups.empty() && !bo.vflat) {
             if ((rc = L.d_ticket.reserve_zeroed((size_t)n_queries * 4, s))) return rc;
             round_fused = true;
         }

@@ -527,7 +527,8 @@ struct tsgpu_ctx {
     bool kw_count_touched = false;                   // measurement option: keyword batches launch the byte-counting instantiation of the find kernel
     tsgpu_kw_touched kw_touched{};                   // ... and leave its counters here (tsgpu_kw_last_touched; under tm_mu)
     std::atomic<uint64_t> kw_mf_pipelined_launches{0}, kw_round_fused_launches{0};
-    uint32_t kw_round_fused_max_queries = 256;       // keyword rounds of at most this many plain single-field queries run as ONE launch (kw_round_kernel); 0 = never
+    uint32_t kw_round_fused_max_queries = 0;         // keyword rounds of at most this many plain single-field queries run as ONE launch (kw_round_kernel); 0 = never (default:
+                                                     // measured slower — 256 request threads 455 K -> 96 K q/s, one thread 55 us either way; profiles/r05/exp_one_launch_rounds.txt)
     bool kw_mf_pipelined = true;                     // multi-field find kernel: the pipelined form for launches of <= 2 query_by fields (kw_find_mf2.hip.h)
     bool kw_pair_blocks = true;                      // find kernel variant: two driver blocks per iteration (kw_find2.hip.h)
     long long kw_iddir_min_ids = 256;                // id directories (tsgpu_format.h): lists of at least max(this, num_docs / kw_iddir_density_div) ids get one; 0 = none
