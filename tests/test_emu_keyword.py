@@ -477,8 +477,30 @@ def test_candidate_combinations_fold_like_the_shared_topster_and_id_buff(pair, t
     groups.append([same, T.KwQuery([3, 5], sort=tm_sort, topster_size=topster_size)])            # identical passes: the later one owns the hits
     groups.append([T.KwQuery([299, 298, 297], sort=tm_sort, topster_size=topster_size), same])     # a pass without matches does not count
     groups.append([])                                                                             # no combination at all
+    # a third sort key (the S2 instantiation of the sort-free fold; <= 8 passes: its LDS) in a call of its own
+    s3 = ((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, 1, 0))
+    g3 = [grp[:8] for grp in _candidate_groups(rng, s3, topster_size)[:3]] + [[T.KwQuery([1 + j, 2], sort=s3, topster_size=topster_size) for j in range(2, 10)]]
+    n0 = g.counter("kw_candidates_rank_launches")
+    h3, q3, f3 = g.keyword_search_candidates_batch(g3, k_stride=250)
+    assert g.counter("kw_candidates_rank_launches") > n0
+    for gi, combos in enumerate(g3):
+        ref, ref_qi = H.oracle_candidates(orc, combos, ids_cap=4000)
+        H.assert_hits_equal(h3, gi, ref, "candidates, three sort keys g%d" % gi)
+        assert np.array_equal(q3[gi, :int(h3.n_hits[gi])], ref_qi) and int(f3[gi]) == int(ref.n_result_ids)
+    # the sort-free fold (kw_candidates_rank_kernel, default) and the two-sort kernel give the same arrays
+    g.set_option("kw_candidates_rank_fold", 0)
+    h0, q0, f0 = g.keyword_search_candidates_batch(groups, k_stride=250)
+    g.set_option("kw_candidates_rank_fold", 1)
+    n0 = g.counter("kw_candidates_rank_launches")
     hits, qidx, found = g.keyword_search_candidates_batch(groups, k_stride=250)
+    assert g.counter("kw_candidates_rank_launches") > n0
     assert (hits.status == 0).all()
+    assert np.array_equal(hits.n_hits, h0.n_hits) and np.array_equal(found, f0) and np.array_equal(hits.num_matched, h0.num_matched)
+    for gi in range(len(groups)):
+        n = int(hits.n_hits[gi])
+        for name in ("keys", "scores", "text_match", "match_score_index"):
+            assert np.array_equal(getattr(hits, name)[gi, :n], getattr(h0, name)[gi, :n]), (name, gi)
+        assert np.array_equal(qidx[gi, :n], q0[gi, :n]), gi
     multi = 0
     for gi, combos in enumerate(groups):
         if not combos:

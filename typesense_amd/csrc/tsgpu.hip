@@ -252,6 +252,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_device_plan_min_queries")) { ctx->kw_device_plan_min_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 30); return ok(); }
     if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
     if (!strcmp(name, "kw_round_fused_max_queries")) { ctx->kw_round_fused_max_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20); return ok(); }
+    if (!strcmp(name, "kw_candidates_rank_fold")) { ctx->kw_candidates_rank_fold = value != 0; return ok(); }
     if (!strcmp(name, "kw_mf_pipelined")) { ctx->kw_mf_pipelined = value != 0; return ok(); }
     if (!strcmp(name, "kw_count_touched")) { ctx->kw_count_touched = value != 0; return ok(); }
     if (!strcmp(name, "kw_iddir_min_ids")) { ctx->kw_iddir_min_ids = value < 0 ? 0 : value; ctx->commit_force_full = true; return ok(); }
@@ -330,6 +331,7 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     std::lock_guard<std::mutex> lk(ctx->tm_mu);
     if (!strcmp(name, "kw_last_hit_groups")) { *out = ctx->kw_last_hit_groups; return ok(); }      // last keyword batch: find+score groups (0 = fused kernel)
     if (!strcmp(name, "kw_round_fused_launches")) { *out = ctx->kw_round_fused_launches; return ok(); }     // rounds served by kw_round_kernel (one launch)
+    if (!strcmp(name, "kw_candidates_rank_launches")) { *out = ctx->kw_candidates_rank_launches; return ok(); }
     if (!strcmp(name, "kw_mf_pipelined_launches")) { *out = ctx->kw_mf_pipelined_launches; return ok(); }     // find launches served by kw_find_mf2_kernel
     if (!strcmp(name, "kw_last_hit_records")) { *out = ctx->kw_last_hit_records; return ok(); }    // hit-record capacity the last batch asked for
     if (!strcmp(name, "vec_overflow_rounds")) { *out = ctx->vec_overflow_rounds; return ok(); }
@@ -1864,6 +1866,19 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
         in.match_score_index = pass.match_score_index; in.n_hits = pass.n_hits; in.num_matched = pass.num_matched;
         in.group_range = L.d_cand_gb.as<uint32_t>(); in.k_in = KS;
         const uint64_t cap_need = (uint64_t)std::max<uint32_t>(max_passes, 1) * KS;
+        bool any_s2 = false;
+        for (uint32_t e = 0; e < n_combos; e++) any_s2 = any_s2 || combos[e].n_sort > 2;
+        // the sort-free fold (kw_candidates_rank_kernel); three sort keys AND more than 2 048 slots do not fit its LDS next to the hash table: the sorting kernel
+        if (ctx->kw_candidates_rank_fold && !(cap_need > 2048 && any_s2)) {
+            ctx->kw_candidates_rank_launches++;
+#define TSGPU_CAND_RANK(C) do { if (any_s2) hipLaunchKernelGGL((kw_candidates_rank_kernel<C, true>), dim3(n_groups), dim3(KW_THREADS), 0, s, in, o, qi_dev); \
+                                else hipLaunchKernelGGL((kw_candidates_rank_kernel<C, false>), dim3(n_groups), dim3(KW_THREADS), 0, s, in, o, qi_dev); } while (0)
+            if (cap_need <= 512) TSGPU_CAND_RANK(512);
+            else if (cap_need <= 1024) TSGPU_CAND_RANK(1024);
+            else if (cap_need <= 2048) TSGPU_CAND_RANK(2048);
+            else hipLaunchKernelGGL((kw_candidates_rank_kernel<4096, false>), dim3(n_groups), dim3(KW_THREADS), 0, s, in, o, qi_dev);
+#undef TSGPU_CAND_RANK
+        } else
         if (cap_need <= 512) hipLaunchKernelGGL((kw_candidates_merge_kernel<512>), dim3(n_groups), dim3(KW_THREADS), 0, s, in, o, qi_dev);
         else if (cap_need <= 1024) hipLaunchKernelGGL((kw_candidates_merge_kernel<1024>), dim3(n_groups), dim3(KW_THREADS), 0, s, in, o, qi_dev);
         else if (cap_need <= 2048) hipLaunchKernelGGL((kw_candidates_merge_kernel<2048>), dim3(n_groups), dim3(KW_THREADS), 0, s, in, o, qi_dev);

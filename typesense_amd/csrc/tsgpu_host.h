@@ -526,7 +526,8 @@ struct tsgpu_ctx {
     uint32_t kw_merge_select_min = 2;                // queries with at least this many partial lists are merged by selection (kw_select_partials: tree merge); 0 = always fold
     bool kw_count_touched = false;                   // measurement option: keyword batches launch the byte-counting instantiation of the find kernel
     tsgpu_kw_touched kw_touched{};                   // ... and leave its counters here (tsgpu_kw_last_touched; under tm_mu)
-    std::atomic<uint64_t> kw_mf_pipelined_launches{0}, kw_round_fused_launches{0};
+    std::atomic<uint64_t> kw_mf_pipelined_launches{0}, kw_round_fused_launches{0}, kw_candidates_rank_launches{0};
+    bool kw_candidates_rank_fold = true;             // candidate combinations: the sort-free fold (kw_candidates_rank_kernel) instead of two bitonic sorts
     uint32_t kw_round_fused_max_queries = 0;         // keyword rounds of at most this many plain single-field queries run as ONE launch (kw_round_kernel); 0 = never (default:
                                                      // measured slower — 256 request threads 455 K -> 96 K q/s, one thread 55 us either way; profiles/r05/exp_one_launch_rounds.txt)
     bool kw_mf_pipelined = true;                     // multi-field find kernel: the pipelined form for launches of <= 2 query_by fields (kw_find_mf2.hip.h)
