@@ -722,7 +722,7 @@ class Bench:
         carr = self.T.index.make_query_array(flat)
         begin = np.arange(0, 10 * n_g + 1, 10, dtype=np.uint32)
         hits = self.T.Hits(n_g, K_TOPSTER)
-        chs = hits.c_struct()
+        chs = hits.c_struct(seam_arrays_only=True)         # what the B1 shim requests (as in the headline): keys, scores[3], match_score_index, counts (+ query_index)
         qi = np.zeros((n_g, K_TOPSTER), np.uint32)
         found = np.zeros(n_g, np.uint64)
 
@@ -735,7 +735,7 @@ class Bench:
             kern.append(tm.kw_search_ms); merge.append(tm.kw_merge_ms)
         el, lat, (hits, qi, found) = timed(step_c, steps, 2, 1, after_c)
         cand = {"workload": "%d user queries/step x 10 candidate-token combinations each (= %d search_across_fields passes per step), 3 positions, shared Topster 250, "
-                            "found = |union of the passes' result ids|; host outputs (the call's only form)" % (n_g, 10 * n_g),
+                            "found = |union of the passes' result ids|; host outputs: the arrays the seam's shim requests (keys, scores[3], match_score_index, query_index, counts)" % (n_g, 10 * n_g),
                 "value": n_g * steps / el, "unit": "user queries/s", "passes_per_s": 10 * n_g * steps / el, "ms_per_step": 1e3 * el / steps,
                 "kernel_ms (find + score of all passes)": float(np.mean(kern)), "merge_ms (per-pass merge; the candidate fold runs after it)": float(np.mean(merge)),
                 "queries_with_hits": int((hits.n_hits > 0).sum())}
