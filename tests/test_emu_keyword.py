@@ -726,7 +726,7 @@ def test_pair_find_kernel_matches_the_oracle(pair, chunk):
             H.assert_hits_equal(hits, i, ref, "pair kernel chunk=%d" % chunk)
             assert np.array_equal(g.result_ids(i), ref.result_ids)
     finally:
-        g.set_option("kw_pair_blocks", 0)
+        g.set_option("kw_pair_blocks", 1)
         g.set_option("kw_chunk_blocks", 0)
         g.keep_result_ids(False)
     # extreme length ratios
@@ -775,7 +775,7 @@ def test_find_kernel_counts_the_bytes_it_requests_without_changing_the_results(p
         t2 = g.kw_touched()
     finally:
         g.set_option("kw_count_touched", 0)
-        g.set_option("kw_pair_blocks", 0)
+        g.set_option("kw_pair_blocks", 1)
     for name in ("keys", "scores", "n_hits", "num_matched", "status"):
         assert np.array_equal(getattr(hits, name), getattr(base, name)), name
         assert np.array_equal(getattr(hits2, name)[:len(qs)], getattr(base, name)), name
@@ -1133,7 +1133,7 @@ def test_pipelined_two_field_find_kernel_equals_the_block_at_a_time_kernel_and_t
 
 
 def test_one_launch_rounds_equal_the_three_kernel_form(pair):
-    """kw_round_kernel (option kw_round_fused_max_queries, default 256): find + score per work item and the merge by the query's last work item in ONE
+    """kw_round_kernel (option kw_round_fused_max_queries; off by default, 256 here): find + score per work item and the merge by the query's last work item in ONE
     launch, for rounds of plain single-field <= 3-token queries — same hits, counts and order as find | score | merge, incl. queries without work
     items (a token no list holds), queries cut into many work items (the ticket), one-token and two-token queries; rounds the PLAIN score
     instantiation cannot serve (filter ids, three sort keys, > 3 tokens, kept ids) keep the three kernels"""
@@ -1143,6 +1143,8 @@ def test_one_launch_rounds_equal_the_three_kernel_form(pair):
     qs = _queries(rng, 20, 25, 3, sort=sort, topster_size=250) + _queries(rng, 8, 25, 2, sort=sort, topster_size=250) + _queries(rng, 6, 25, 1, sort=sort, topster_size=40)
     qs += [T.KwQuery([9999, 1], sort=sort, topster_size=250), T.KwQuery([1, 2, 9998], sort=sort, topster_size=250), T.KwQuery([3, 3], sort=sort, topster_size=250)]
     outs = []
+    g.set_option("kw_pair_blocks", 1)                    # (the default; the one-launch form is built on the pair-find body)
+    g.set_option("kw_two_kernels", 1)
     for chunk in (0, 1):
         g.set_option("kw_chunk_blocks", chunk)           # 1: every driver block its own work item — the ticket counts to many
         for fused in (256, 0):
@@ -1156,13 +1158,13 @@ def test_one_launch_rounds_equal_the_three_kernel_form(pair):
             for name in ("keys", "scores", "n_hits", "num_matched"):
                 assert np.array_equal(getattr(h2, name), getattr(h, name)[:5]), name
     g.set_option("kw_chunk_blocks", 0)
-    g.set_option("kw_round_fused_max_queries", 256)
     for h in outs[1:]:
         for name in ("keys", "scores", "text_match", "n_hits", "num_matched"):
             assert np.array_equal(getattr(h, name), getattr(outs[0], name)), name
     for i, q in enumerate(qs):
         H.assert_hits_equal(outs[0], i, H.oracle_keyword(orc, q), "one-launch round q=%s" % (q.tokens,))
     # not served by the one-launch form: the counter stays
+    g.set_option("kw_round_fused_max_queries", 256)
     n0 = g.counter("kw_round_fused_launches")
     others = [T.KwQuery([1, 2], sort=sort, topster_size=250, filter_ids=np.arange(0, 3000, 2)), T.KwQuery([1, 2, 3, 4], sort=sort, topster_size=250)]
     for q in others:
@@ -1170,3 +1172,4 @@ def test_one_launch_rounds_equal_the_three_kernel_form(pair):
         H.assert_hits_equal(h, 0, H.oracle_keyword(orc, q), "three-kernel round")
     h = g.keyword_search_batch([T.KwQuery([1, 2], sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=250)], k_stride=250)
     assert g.counter("kw_round_fused_launches") == n0
+    g.set_option("kw_round_fused_max_queries", 0)        # (the default)

@@ -75,13 +75,13 @@ def main():
                     for _ in range(2):
                         grp.keyword_search_batch_raw(arr, n_q, 100, ghs)
                     ex, loc, kn = [], [], []
-                    for _ in range(4):
+                    for _ in range(7):
                         grp.keyword_search_batch_raw(arr, n_q, 100, ghs)
                         tmg = grp.timings()
                         ex.append(tmg.exchange_merge_ms); loc.append(tmg.local_ms); kn.append(tmg.exchange_kernels_ms)
                     tag = "%s, %s" % (form, "bound-pruned" if pruned else "full top-k")
-                    rec[tag + ": exchange kernels + copies + merges of ALL %d members on this one device (ms)" % G] = float(np.mean(ex))
-                    rec[tag + ": ONE member's exchange kernels, HIP events (pack or bounds, count, pruned pack, its merge) (ms)"] = float(np.mean(kn))
+                    rec[tag + ": exchange kernels + copies + merges of ALL %d members on this one device (ms)" % G] = float(np.median(ex))
+                    rec[tag + ": ONE member's exchange kernels, HIP events (pack or bounds, count, pruned pack, its merge) (ms)"] = float(np.median(kn))     # (median: a call that re-allocates a staging buffer is an outlier)
                     rec[tag + ": hit bytes received per GPU (bounds + slices / blocks)"] = int(tmg.hit_exchange_bytes_per_member)
                     rec[tag + ": all bytes received per GPU (+ replication of the merged lists)"] = int(tmg.exchange_bytes_per_member)
             grp.close()
