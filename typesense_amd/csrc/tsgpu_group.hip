@@ -774,7 +774,9 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
             }
             g->tm.hit_exchange_bytes_per_member = (uint64_t)n_queries * 64 * (g->n - 1) + worst;
         }
-        g->tm.exchange_bytes_per_member = (pruned ? (uint64_t)n_queries * 64 * (g->n - 1) : 0ull) + (slices ? (uint64_t)slice_words * 8 * (g->n - 1) + ((!g->local && g->own_slice_only) ? 0ull : (uint64_t)per * (KS * (32 + (out->text_match ? 8 : 0)) + 16) * (g->n - 1)) : (uint64_t)slice_words * 8 * (g->n - 1));
+        // everything one member receives: the hit exchange + (slice form, unless every rank keeps only its own slice) the replication of the merged lists
+        g->tm.exchange_bytes_per_member = g->tm.hit_exchange_bytes_per_member +
+            ((slices && !(!g->local && g->own_slice_only)) ? (uint64_t)per * (KS * (32 + (out->text_match ? 8 : 0)) + 16) * (g->n - 1) : 0ull);
         return ok();
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: host allocation failed"); }
       catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: could not start a member thread"); }
