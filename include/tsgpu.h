@@ -406,9 +406,12 @@ int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32
  * the graph as well (rows already in the field are inserted first, in row order); tsgpu_vec_delete = markDelete; the graph search uploads
  * the lists when they changed. n_threads: host threads inserting the rows of ONE upsert call concurrently with hnswlib's locking
  * (1 = the sequential algorithm, deterministic: equal, link for link, to the oracle's restatement; the reference itself indexes on four
- * threads). Overwriting a live label / re-using a deleted label's slot (hnswlib updatePoint, allow_replace_deleted) is not followed: the
- * graph is marked stale, tsgpu_vec_hnsw_search_batch reports 501 and the exact k-NN answers. PARITY UNPINNED (hnswlib is not in the
- * reference tree). M <= 31. */
+ * threads). Round 5: the reference's addPoint(vec, seq_id, replace_deleted = true) on an index built with allow_replace_deleted = true
+ * (include/index.h:367) is followed — tsgpu_vec_upsert of a LIVE label runs hnswlib's updatePoint on its row; of any other label while deleted
+ * rows exist RE-USES the most recently deleted row (the label moves there, unmarkDeleted, updatePoint); only without one the row is appended —
+ * so the graph stays searchable through updates (Typesense's update = markDelete + addPoint lands in the document's own row). Two choices
+ * hnswlib leaves to std::unordered_set are fixed (which deleted slot; candidate order on equal distances): csrc/tsgpu_hnsw_build.h.
+ * PARITY UNPINNED (hnswlib is not in the reference tree). M <= 31. */
 int tsgpu_vec_hnsw_enable(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, uint32_t ef_construction, uint32_t seed, uint32_t n_threads);
 /* the built graph in tsgpu_vec_hnsw_load's flat form (tests, persistence). info = {n, maxlevel, enterpoint, M}; *n_upper = upper lists.
  * Arrays may be NULL (sizes only): levels[n], link0[n][1 + 2M], upper_ptr[n + 1], upper_links[n_upper][1 + M]. */

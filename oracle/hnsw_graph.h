@@ -10,6 +10,7 @@
 // on the same graph, and its recall against the exact scan. Distances are the oracle's InnerProductSpace restatement
 // (Index::ip_distance), i.e. bit-identical to what the exact path returns.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -42,6 +43,9 @@ struct hnsw_graph_t {
     std::vector<int> levels;
     std::vector<std::vector<tableint>> link0;                   // level 0: up to maxM0 neighbours
     std::vector<std::vector<std::vector<tableint>>> linkU;      // [node][level-1]: up to maxM neighbours
+    std::unordered_map<uint64_t, tableint> label_lookup;        // hnswlib label_lookup_
+    std::vector<tableint> deleted_order;                        // hnswlib deleted_elements (an unordered_set there: WHICH deleted slot addPoint re-uses is the standard
+                                                                // library's choice; here, and in the library's builder, the most recently deleted one)
 
     void init(size_t dim_, size_t M_, size_t efc, size_t seed, float (*fn)(const float*, const float*, size_t)) {
         dim = dim_; M = M_; maxM = M_; maxM0 = 2 * M_; ef_construction = std::max(efc, M_);
@@ -120,7 +124,7 @@ struct hnsw_graph_t {
         for (const dist_id_t& cur : return_list) top_candidates.emplace(-cur.first, cur.second);
     }
 
-    tableint mutuallyConnectNewElement(const float* q, tableint cur_c, heap_t& top_candidates, int level, tableint prev_entry_point) {
+    tableint mutuallyConnectNewElement(const float* q, tableint cur_c, heap_t& top_candidates, int level, tableint prev_entry_point, bool isUpdate = false) {
         size_t Mcurmax = level ? maxM : maxM0;
         getNeighborsByHeuristic2(top_candidates, M);
         std::vector<tableint> selected;
@@ -131,6 +135,11 @@ struct hnsw_graph_t {
         list_of(cur_c, level) = selected;
         for (size_t idx = 0; idx < selected.size(); idx++) {
             std::vector<tableint>& other = list_of(selected[idx], level);
+            if (isUpdate) {                                     // "If cur_c is already present in the neighboring connections ... no need to modify any connections"
+                bool is_cur_c_present = false;
+                for (tableint x : other) if (x == cur_c) { is_cur_c_present = true; break; }
+                if (is_cur_c_present) continue;
+            }
             if (other.size() < Mcurmax) {
                 other.push_back(cur_c);
             } else {
@@ -151,6 +160,7 @@ struct hnsw_graph_t {
     void addPoint(const float* v, uint64_t label) {
         tableint cur_c = (tableint)size();
         labels.push_back(label);
+        label_lookup[label] = cur_c;
         deleted.push_back(0);
         data.insert(data.end(), v, v + dim);
         int curlevel = getRandomLevel(mult);
@@ -192,6 +202,109 @@ struct hnsw_graph_t {
             maxlevel = curlevel;
         }
         if (curlevel > maxlevelcopy) { enterpoint = cur_c; maxlevel = curlevel; }
+    }
+
+    // markDelete(label) -> markDeletedInternal: with allow_replace_deleted the slot becomes available to a later addPoint
+    bool markDelete(uint64_t label) {
+        auto it = label_lookup.find(label);
+        if (it == label_lookup.end() || deleted[it->second]) return false;
+        deleted[it->second] = 1;
+        deleted_order.push_back(it->second);
+        return true;
+    }
+    // addPoint(data, label, replace_deleted = true) as Typesense calls it (src/index.cpp:1052-1054; index built with allow_replace_deleted = true,
+    // include/index.h:367): a live label is updated in place (hnswlib's inner addPoint -> updatePoint); otherwise a vacant (deleted) slot is re-used —
+    // setExternalLabel, label_lookup_ moved, unmarkDeletedInternal, updatePoint(data, slot, 1.0) — and only without one a new element is appended.
+    // (Deviation, stated: hnswlib looks for the vacant slot BEFORE it looks the label up, so a LIVE label next to a vacant slot gets a second slot there;
+    //  Typesense never does that — an update is remove + add — and this restatement updates the live slot. Returns the internal id.)
+    tableint addPointReplace(const float* v, uint64_t label) {
+        auto it = label_lookup.find(label);
+        if (it != label_lookup.end() && !deleted[it->second]) { updatePoint(v, it->second); return it->second; }
+        while (!deleted_order.empty()) {
+            const tableint slot = deleted_order.back();
+            deleted_order.pop_back();
+            if (!deleted[slot]) continue;
+            const uint64_t label_replaced = labels[slot];
+            auto old = label_lookup.find(label_replaced);
+            if (old != label_lookup.end() && old->second == slot) label_lookup.erase(old);
+            labels[slot] = label;
+            label_lookup[label] = slot;
+            deleted[slot] = 0;
+            updatePoint(v, slot);
+            return slot;
+        }
+        addPoint(v, label);
+        return (tableint)size() - 1;
+    }
+    // updatePoint(dataPoint, internalId, updateNeighborProbability = 1.0). hnswlib walks two unordered_sets (sCand, sNeigh); the order matters for
+    // candidates at EQUAL distance only and is fixed here as ascending ids (as in the library's builder).
+    void updatePoint(const float* v, tableint internalId) {
+        std::copy(v, v + dim, data.begin() + (size_t)internalId * dim);
+        const int maxLevelCopy = maxlevel;
+        const tableint entryPointCopy = enterpoint;
+        if (entryPointCopy == internalId && size() == 1) return;
+        const int elemLevel = levels[internalId];
+        for (int layer = 0; layer <= elemLevel; layer++) {
+            const std::vector<tableint> listOneHop = list_of(internalId, layer);
+            if (listOneHop.empty()) continue;
+            std::vector<tableint> sCand{internalId}, sNeigh;
+            for (tableint elOneHop : listOneHop) {
+                sCand.push_back(elOneHop);
+                sNeigh.push_back(elOneHop);
+                for (tableint elTwoHop : list_of(elOneHop, layer)) sCand.push_back(elTwoHop);
+            }
+            std::sort(sCand.begin(), sCand.end()); sCand.erase(std::unique(sCand.begin(), sCand.end()), sCand.end());
+            std::sort(sNeigh.begin(), sNeigh.end()); sNeigh.erase(std::unique(sNeigh.begin(), sNeigh.end()), sNeigh.end());
+            for (tableint neigh : sNeigh) {
+                heap_t candidates;
+                const size_t size_ = std::binary_search(sCand.begin(), sCand.end(), neigh) ? sCand.size() - 1 : sCand.size();
+                const size_t elementsToKeep = std::min(ef_construction, size_);
+                for (tableint cand : sCand) {
+                    if (cand == neigh) continue;
+                    const float distance = dist(vec(neigh), vec(cand));
+                    if (candidates.size() < elementsToKeep) candidates.emplace(distance, cand);
+                    else if (distance < candidates.top().first) { candidates.pop(); candidates.emplace(distance, cand); }
+                }
+                getNeighborsByHeuristic2(candidates, layer == 0 ? maxM0 : maxM);
+                std::vector<tableint>& ll = list_of(neigh, layer);
+                ll.clear();
+                while (candidates.size() > 0) { ll.push_back(candidates.top().second); candidates.pop(); }
+            }
+        }
+        repairConnectionsForUpdate(vec(internalId), entryPointCopy, internalId, elemLevel, maxLevelCopy);
+    }
+    void repairConnectionsForUpdate(const float* dataPoint, tableint entryPointInternalId, tableint dataPointInternalId, int dataPointLevel, int maxLevel) {
+        tableint currObj = entryPointInternalId;
+        if (dataPointLevel < maxLevel) {
+            float curdist = dist(dataPoint, vec(currObj));
+            for (int level = maxLevel; level > dataPointLevel; level--) {
+                bool changed = true;
+                while (changed) {
+                    changed = false;
+                    const std::vector<tableint> nb = list_of(currObj, level);
+                    for (tableint cand : nb) {
+                        const float d = dist(dataPoint, vec(cand));
+                        if (d < curdist) { curdist = d; currObj = cand; changed = true; }
+                    }
+                }
+            }
+        }
+        for (int level = std::min(dataPointLevel, maxLevel); level >= 0; level--) {
+            heap_t topCandidates = searchBaseLayer(currObj, dataPoint, level);
+            heap_t filteredTopCandidates;
+            while (topCandidates.size() > 0) {
+                if (topCandidates.top().second != dataPointInternalId) filteredTopCandidates.push(topCandidates.top());
+                topCandidates.pop();
+            }
+            // "there could be cases where topCandidates could just contain the entry point itself. To prevent self loops ... can be empty"
+            if (filteredTopCandidates.size() > 0) {
+                if (deleted[entryPointInternalId]) {
+                    filteredTopCandidates.emplace(dist(dataPoint, vec(entryPointInternalId)), entryPointInternalId);
+                    if (filteredTopCandidates.size() > ef_construction) filteredTopCandidates.pop();
+                }
+                currObj = mutuallyConnectNewElement(dataPoint, dataPointInternalId, filteredTopCandidates, level, currObj, true);
+            }
+        }
     }
 
     // searchBaseLayerST<has_deletions, ...>(ep, q, ef, isIdAllowed): allow == nullptr = every row allowed

@@ -192,8 +192,21 @@ void orc_hnsw_add_new_rows(void* h) {
 void orc_hnsw_free(void* h) { auto it = hnsw_of().find(h); if (it != hnsw_of().end()) { delete it->second; hnsw_of().erase(it); } }
 int32_t orc_hnsw_mark_deleted(void* h, uint32_t label) {
     hnsw_graph_t* g = hnsw_of()[h];
-    for (size_t i = 0; i < g->labels.size(); i++) if (g->labels[i] == label && !g->deleted[i]) { g->deleted[i] = 1; return 0; }
-    return -1;
+    return g->markDelete(label) ? 0 : -1;
+}
+// addPoint(vec, label, replace_deleted = true) for a label whose vector orc_vec_add has just stored / overwritten: a live label is updated in place, a
+// vacant slot re-used, else a new element appended (hnsw_graph_t::addPointReplace). Returns the internal id, -1 when the label has no vector.
+int32_t orc_hnsw_add_point_replace(void* h, uint32_t label) {
+    Index* idx = (Index*)h;
+    hnsw_graph_t* g = hnsw_of()[h];
+    const float* v = idx->vec_get(label);
+    if (!g || !v) return -1;
+    return (int32_t)g->addPointReplace(v, label);
+}
+// labels[n] of the graph's internal ids (slot re-use moves labels between rows)
+void orc_hnsw_labels(void* h, uint64_t* out) {
+    hnsw_graph_t* g = hnsw_of()[h];
+    for (size_t i = 0; i < g->labels.size(); i++) out[i] = g->labels[i];
 }
 // graph in the flat form the GPU mirror takes: levels[n]; link0[n][1 + 2M] = (count, ids..); upper lists of node i (level >= 1,
 // ascending) at upper_links[(upper_ptr[i] + level - 1) * (1 + M)] = (count, ids..). Call with NULL arrays to size: returns the
@@ -234,6 +247,7 @@ int32_t orc_hnsw_import(void* h, uint32_t M, int32_t maxlevel, uint32_t enterpoi
     const size_t n = idx->vec_labels.size(), S0 = 1 + 2 * (size_t)M, SU = 1 + (size_t)M;
     g->data = idx->vec_store;
     g->labels.assign(idx->vec_labels.begin(), idx->vec_labels.end());
+    for (size_t i = 0; i < g->labels.size(); i++) g->label_lookup[g->labels[i]] = (hnsw_graph_t::tableint)i;
     g->deleted.assign(n, 0);
     g->levels.assign(n, 0);
     g->link0.resize(n);

@@ -87,6 +87,10 @@ def lib():
         L.orc_hnsw_mark_deleted.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_hnsw_add_new_rows.argtypes = [C.c_void_p]
         L.orc_hnsw_add_new_rows.restype = None
+        L.orc_hnsw_add_point_replace.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_hnsw_add_point_replace.restype = C.c_int32
+        L.orc_hnsw_labels.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_hnsw_labels.restype = None
         L.orc_hnsw_export.restype = C.c_uint64
         L.orc_hnsw_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_hnsw_import.restype = C.c_int32
@@ -387,6 +391,17 @@ class OracleIndex:
 
     def hnsw_mark_deleted(self, label):
         return self.L.orc_hnsw_mark_deleted(self.h, int(label))
+
+    def hnsw_upsert(self, label, x):
+        """addPoint(vec, label, replace_deleted=True) the way the reference calls it (src/index.cpp:1052-1054): the flat store takes the vector
+        (vec_add), the graph updates a live label in place, re-uses a deleted slot, or appends. Returns the graph's internal id."""
+        self.vec_add(np.array([label], np.uint32), np.ascontiguousarray(x, np.float32).reshape(1, -1))
+        return int(self.L.orc_hnsw_add_point_replace(self.h, int(label)))
+
+    def hnsw_labels(self, n):
+        out = np.zeros(n, np.uint64)
+        self.L.orc_hnsw_labels(self.h, _ptr(out))
+        return out
 
     def hnsw_export(self):
         """-> dict(n, maxlevel, enterpoint, M, levels[n], link0[n, 1+2M], upper_ptr[n+1], upper_links[n_upper, 1+M])"""

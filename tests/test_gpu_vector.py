@@ -39,6 +39,8 @@ test_vector_branch_flat_and_k_cut_match_the_oracle = E.test_vector_branch_flat_a
 test_int8_bracket_mirror_returns_the_oracles_neighbours_bit_for_bit = E.test_int8_bracket_mirror_returns_the_oracles_neighbours_bit_for_bit
 test_int8_bracket_mirror_hard_cases_zero_rows_huge_values_non_finite_and_ties = E.test_int8_bracket_mirror_hard_cases_zero_rows_huge_values_non_finite_and_ties
 test_hnsw_graph_built_inside_the_library_equals_the_oracles_link_for_link = E.test_hnsw_graph_built_inside_the_library_equals_the_oracles_link_for_link
+test_hnsw_updates_and_slot_reuse_follow_addpoint_with_replace_deleted = E.test_hnsw_updates_and_slot_reuse_follow_addpoint_with_replace_deleted
+test_hnsw_build_after_every_row_was_deleted_relinks_through_the_deleted_entry_point = E.test_hnsw_build_after_every_row_was_deleted_relinks_through_the_deleted_entry_point
 
 
 def test_flat_branch_at_size_many_work_items_768_dims():

@@ -91,7 +91,7 @@ public:
     size_t getCurrentElementCount() { return (size_t)tsgpu_vec_count(ctx_, field_); }
     size_t getMaxElements() { return max_elements_; }
     void resizeIndex(size_t n) { max_elements_ = n; }       // storage grows on demand inside the library
-    void repair_zero_indegree() {}                          // no graph to repair
+    void repair_zero_indegree() {}                          // (fork-only call, src/index.cpp:8367; its source is not under /root/reference: nothing to restate)
 
     void addPoint(const void* data, labeltype label, bool /*replace_deleted*/ = false) {
         uint64_t l = (uint64_t)label;

@@ -14,8 +14,12 @@
 // [(node, level)][1 + M], so an upload is a plain copy. Distances are tsgpu_ip_distance in the summation order of option vec_ip_lanes — the
 // bits every other path returns. Concurrent insertion of a batch follows hnswlib's locking (a global lock while the entry point may move,
 // one lock per node around its link lists, a visited list per thread); like the reference's four indexing threads it is not deterministic.
-// Not covered (the graph is marked stale and the exact path answers): overwriting a live label (hnswlib's updatePoint) and re-using the
-// slot of a deleted label (allow_replace_deleted).
+// Round 5: the reference constructs the index with allow_replace_deleted = true and always calls addPoint(vec, seq_id, true)
+// (/root/reference/include/index.h:367, src/index.cpp:1052-1054), so an insertion after a markDelete RE-USES a deleted slot and runs hnswlib's
+// updatePoint on it, and addPoint on a live label is an updatePoint, too: update_point() / repair_connections_for_update() below restate both
+// (updateNeighborProbability = 1.0). Two choices hnswlib leaves to the standard library are fixed here AND in the oracle: which deleted slot is
+// taken (`*deleted_elements.begin()` of an unordered_set: here the most recently deleted one — for Typesense's update = remove + add that is the
+// document's own slot) and the order in which updatePoint walks its candidate sets (ascending ids; it matters for equal distances only).
 #pragma once
 #include <cmath>
 #include <deque>
@@ -57,6 +61,7 @@ struct HnswBuilder {
     std::vector<uint32_t> upper;                      // [(node, level >= 1)][1 + M]
     std::deque<std::mutex> node_mu;                   // one per node (stable addresses while the deque grows)
     std::mutex global_mu;
+    std::vector<uint32_t> deleted_stack;              // markDelete order (hnswlib's deleted_elements): the most recently deleted slot is re-used first
     std::deque<VisitedList> vis_pool;          // one visited list per inserting thread, kept across add_batch calls: the server's calling convention is
                                                       // one addPoint per document, and a fresh list per call allocates and zeroes a tag per NODE (O(n) per insertion)
 
@@ -126,7 +131,7 @@ struct HnswBuilder {
     }
 
     // mutuallyConnectNewElement: the new node's list on this level, then the reverse links
-    uint32_t connect(uint32_t cur, Heap& top, int level, bool locked, uint32_t prev_ep) {
+    uint32_t connect(uint32_t cur, Heap& top, int level, bool locked, uint32_t prev_ep, bool is_update = false) {
         const size_t cap = level ? M : 2 * (size_t)M;
         select_neighbours(top, M);
         std::vector<uint32_t> sel;
@@ -138,6 +143,7 @@ struct HnswBuilder {
             std::unique_lock<std::mutex> lk(node_mu[cur], std::defer_lock);
             if (locked) lk.lock();
             uint32_t* l = list_of(cur, level);
+            for (size_t j = sel.size(); j < l[0]; j++) l[1 + j] = 0;      // (an update overwrites a longer list: slots behind the count stay zero)
             l[0] = (uint32_t)sel.size();
             for (size_t j = 0; j < sel.size(); j++) l[1 + j] = sel[j];
         }
@@ -145,6 +151,11 @@ struct HnswBuilder {
             std::unique_lock<std::mutex> lk(node_mu[s], std::defer_lock);
             if (locked) lk.lock();
             uint32_t* l = list_of(s, level);
+            if (is_update) {                              // (mutuallyConnectNewElement, isUpdate: a neighbour that already points back keeps its list)
+                bool present = false;
+                for (uint32_t j = 0; j < l[0]; j++) if (l[1 + j] == cur) { present = true; break; }
+                if (present) continue;
+            }
             if (l[0] < cap) { l[1 + l[0]] = cur; l[0]++; }
             else {
                 Heap c;
@@ -203,6 +214,91 @@ struct HnswBuilder {
         } else { enterpoint = cur; maxlevel = curlevel; }
         if (curlevel > maxlevel_copy) { enterpoint = cur; maxlevel = curlevel; }
     }
+
+    // hnswlib updatePoint(dataPoint, internalId, 1.0): the row's vector is replaced, the lists of its one-hop neighbours are re-selected among the
+    // one- and two-hop neighbourhood, then its own connections are repaired from the entry point down (repairConnectionsForUpdate)
+    void update_point(uint32_t id, const float* v) {
+        std::copy(v, v + dim, data.begin() + (size_t)id * dim);
+        dirty = true;
+        const int maxlevel_copy = maxlevel;
+        const uint32_t ep_copy = enterpoint;
+        if (ep_copy == id && size() == 1) return;
+        const int elem_level = levels[id];
+        for (int layer = 0; layer <= elem_level; layer++) {
+            const uint32_t* l = list_of(id, layer);
+            std::vector<uint32_t> one_hop(l + 1, l + 1 + l[0]);
+            if (one_hop.empty()) continue;
+            std::vector<uint32_t> cand{id}, neigh;
+            for (uint32_t e : one_hop) {
+                cand.push_back(e); neigh.push_back(e);
+                const uint32_t* l2 = list_of(e, layer);
+                cand.insert(cand.end(), l2 + 1, l2 + 1 + l2[0]);
+            }
+            std::sort(cand.begin(), cand.end()); cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+            std::sort(neigh.begin(), neigh.end()); neigh.erase(std::unique(neigh.begin(), neigh.end()), neigh.end());
+            for (uint32_t nb : neigh) {
+                Heap c;
+                const size_t n_other = std::binary_search(cand.begin(), cand.end(), nb) ? cand.size() - 1 : cand.size();
+                const size_t keep = std::min<size_t>(ef_construction, n_other);
+                for (uint32_t x : cand) {
+                    if (x == nb) continue;
+                    const float d = dist(vec(nb), vec(x));
+                    if (c.size() < keep) c.emplace(d, x);
+                    else if (d < c.top().first) { c.pop(); c.emplace(d, x); }
+                }
+                select_neighbours(c, layer == 0 ? 2 * (size_t)M : (size_t)M);
+                uint32_t* ln = list_of(nb, layer);
+                const uint32_t old = ln[0];
+                uint32_t n = 0;
+                while (!c.empty()) { ln[1 + n++] = c.top().second; c.pop(); }
+                for (uint32_t j = n; j < old; j++) ln[1 + j] = 0;
+                ln[0] = n;
+            }
+        }
+        repair_connections_for_update(id, ep_copy, elem_level, maxlevel_copy);
+    }
+    void repair_connections_for_update(uint32_t id, uint32_t ep, int level_of_id, int maxlevel_copy) {
+        const float* q = vec(id);
+        uint32_t cur = ep;
+        if (level_of_id < maxlevel_copy) {
+            float curdist = dist(q, vec(cur));
+            for (int level = maxlevel_copy; level > level_of_id; level--) {
+                bool changed = true;
+                while (changed) {
+                    changed = false;
+                    const uint32_t* l = list_of(cur, level);
+                    const std::vector<uint32_t> nb(l + 1, l + 1 + l[0]);
+                    for (uint32_t c : nb) { const float d = dist(q, vec(c)); if (d < curdist) { curdist = d; cur = c; changed = true; } }
+                }
+            }
+        }
+        while (vis_pool.empty()) vis_pool.emplace_back();
+        for (int level = std::min(level_of_id, maxlevel_copy); level >= 0; level--) {
+            Heap top = search_layer(cur, q, level, vis_pool[0], false);
+            Heap filtered;
+            while (!top.empty()) { if (top.top().second != id) filtered.push(top.top()); top.pop(); }
+            // (the beam may hold nothing but the row itself: no self loops, and then nothing to connect on this level)
+            if (!filtered.empty()) {
+                if (deleted[ep]) {
+                    filtered.emplace(dist(q, vec(ep)), ep);
+                    if (filtered.size() > ef_construction) filtered.pop();
+                }
+                cur = connect(id, filtered, level, false, cur, true);
+            }
+        }
+    }
+    void mark_deleted(uint32_t id) { if (id < deleted.size() && !deleted[id]) { deleted[id] = 1; deleted_stack.push_back(id); } }
+    // the slot addPoint(.., replace_deleted = true) takes for a label that is not live: none (-1: append), or the most recently deleted one
+    int64_t take_deleted_slot() {
+        while (!deleted_stack.empty()) {
+            const uint32_t id = deleted_stack.back();
+            deleted_stack.pop_back();
+            if (id < deleted.size() && deleted[id]) return id;
+        }
+        return -1;
+    }
+    // ... that slot gets the new vector: unmarkDeletedInternal + updatePoint
+    void replace_deleted(uint32_t id, const float* v) { deleted[id] = 0; update_point(id, v); }
 
     // n new rows (appended in this order = their internal ids). Levels are drawn in label order before any insertion, so the one-thread
     // build is the sequential algorithm exactly; with more threads the rows of the batch are inserted concurrently (hnswlib's locking).

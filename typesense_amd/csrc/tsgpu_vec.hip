@@ -544,6 +544,8 @@ int tsgpu_vec_upsert(tsgpu_ctx* ctx, uint32_t vec_field_id, const uint64_t* labe
                 bulk = std::adjacent_find(tmp.begin(), tmp.end()) == tmp.end();
             }
         }
+        // the in-library graph follows addPoint(.., replace_deleted = true): while deleted slots exist, new labels RE-USE them (one by one, below)
+        if (bulk && f->hb && !f->hb->stale && !f->hb->deleted_stack.empty()) bulk = false;
         if (f->n_rows + n > 0xFFFFFFF0ull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_upsert: more than 2^32 rows");
         const hipMemcpyKind kind = mem == TSGPU_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         if (bulk) {
@@ -569,22 +571,42 @@ int tsgpu_vec_upsert(tsgpu_ctx* ctx, uint32_t vec_field_id, const uint64_t* labe
             }
         } else {
             f->break_identity();
+            const bool graph = f->hb && !f->hb->stale;
             for (uint32_t i = 0; i < n; i++) {
                 uint32_t row;
                 const bool exists = f->find_row(hl[i], row);
-                if (!exists) {
+                const bool live = exists && f->h_ok[row];
+                // hnswlib addPoint(vec, label, replace_deleted = true), as the reference calls it (src/index.cpp:1052-1054; csrc/tsgpu_hnsw_build.h):
+                //   a LIVE label            -> its row is overwritten, the graph runs updatePoint on it;
+                //   otherwise, graph on     -> the most recently deleted row is RE-USED (its label moves: the old label loses its mapping), unmarked, updatePoint;
+                //                              without a deleted row the new label is appended (addPoint);
+                //   otherwise, no graph     -> a deleted label is revived in its own row, a new one appended.
+                int mode = live ? 0 : (exists ? 1 : 2);            // 0 overwrite live, 1 revive own row, 2 append, 3 re-use another / own deleted row (graph)
+                if (!live && graph) {
+                    const int64_t slot = f->hb->take_deleted_slot();
+                    if (slot >= 0) {
+                        mode = 3;
+                        const uint32_t r2 = (uint32_t)slot;
+                        const uint64_t old_label = f->h_labels[r2];
+                        auto it = f->row_of.find(old_label);
+                        if (it != f->row_of.end() && it->second == r2) f->row_of.erase(it);
+                        // (the label's own deleted row, when it is not the one re-used, stays deleted: its stale label no longer maps to it)
+                        row = r2;
+                        f->row_of[hl[i]] = row;
+                        f->h_labels[row] = hl[i];
+                        TSGPU_HIP_TRY(hipMemcpyAsync(f->labels.as<uint64_t>() + row, &hl[i], 8, hipMemcpyHostToDevice, s));
+                    } else mode = 2;                               // (a deleted label always finds at least its own row: only new labels land here)
+                }
+                if (mode == 2) {
                     int rc = vec_reserve_rows(f, f->n_rows + 1, s);
                     if (rc) return rc;
                     row = (uint32_t)f->n_rows++;
-                    f->row_of.emplace(hl[i], row);
+                    f->row_of[hl[i]] = row;
                     f->h_labels.push_back(hl[i]);
                     f->h_ok.push_back(1);
                     f->n_live++;
                     TSGPU_HIP_TRY(hipMemcpyAsync(f->labels.as<uint64_t>() + row, &hl[i], 8, hipMemcpyHostToDevice, s));
-                } else {
-                    if (!f->h_ok[row]) { f->h_ok[row] = 1; f->n_live++; }   // addPoint on a deleted label revives it
-                    if (f->hb) f->hb->stale = true;                         // (hnswlib's updatePoint / slot re-use is not followed: the exact path answers)
-                }
+                } else if (!f->h_ok[row]) { f->h_ok[row] = 1; f->n_live++; }
                 float* dst = f->X.as<float>() + (size_t)row * f->dim;
                 TSGPU_HIP_TRY(hipMemcpyAsync(dst, data + (size_t)i * f->dim, (size_t)f->dim * 4, kind, s));
                 if (f->metric == TSGPU_METRIC_COSINE)
@@ -592,10 +614,13 @@ int tsgpu_vec_upsert(tsgpu_ctx* ctx, uint32_t vec_field_id, const uint64_t* labe
                 TSGPU_HIP_TRY(hipMemsetAsync(f->row_ok.as<uint8_t>() + row, 1, 1, s));
                 { int rc2 = vec_refresh_mirror(f, row, 1, f->n_rows, s); if (rc2) return rc2; }
                 TSGPU_HIP_TRY(hipStreamSynchronize(s));
-                if (!exists && f->hb && !f->hb->stale) {
-                    std::vector<float> one(f->dim);
+                if (graph) {
+                    std::vector<float> one(f->dim);                // the row AS STORED (cosine: normalised)
                     TSGPU_HIP_TRY(hipMemcpy(one.data(), dst, (size_t)f->dim * 4, hipMemcpyDeviceToHost));
-                    f->hb->add_batch(one.data(), 1);
+                    if (mode == 2) f->hb->add_batch(one.data(), 1);
+                    else if (mode == 3) f->hb->replace_deleted(row, one.data());
+                    else if (mode == 0) f->hb->update_point(row, one.data());
+                    // (mode 1 cannot happen with the graph on: a deleted label takes the slot path)
                 }
             }
         }
@@ -614,7 +639,7 @@ int tsgpu_vec_delete(tsgpu_ctx* ctx, uint32_t vec_field_id, uint64_t label) {
     f->h_ok[row] = 0;
     f->any_deleted = true;
     f->n_live--;
-    if (f->hb && row < f->hb->deleted.size()) f->hb->deleted[row] = 1;     // markDelete: construction beams no longer keep it as a result
+    if (f->hb) f->hb->mark_deleted(row);                                   // markDelete: construction beams no longer keep it as a result; the slot becomes re-usable
     TSGPU_HIP_TRY(hipMemset(f->row_ok.as<uint8_t>() + row, 0, 1));
     return ok();
 }
@@ -832,7 +857,7 @@ int tsgpu_vec_hnsw_enable(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, uin
             std::vector<float> rows((size_t)f->n_rows * f->dim);
             TSGPU_HIP_TRY(hipMemcpy(rows.data(), f->X.p, rows.size() * 4, hipMemcpyDeviceToHost));
             f->hb->add_batch(rows.data(), f->n_rows);
-            for (size_t r = 0; r < f->n_rows; r++) if (!f->h_ok[r]) f->hb->deleted[r] = 1;
+            for (size_t r = 0; r < f->n_rows; r++) if (!f->h_ok[r]) f->hb->mark_deleted((uint32_t)r);     // (rows deleted before the graph was switched on: in row order)
         }
     } catch (const std::bad_alloc&) { f->hb.reset(); return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_hnsw_enable: host allocation failed"); }
       catch (const std::system_error&) { f->hb.reset(); return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_hnsw_enable: could not start an insertion thread"); }
@@ -867,7 +892,7 @@ int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const flo
     VecField* f = get_field(ctx, vec_field_id);
     if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_hnsw_search_batch: unknown vector field");
     if (f->hb) {                                       // the graph is built inside the library: bring the device copy up to date
-        if (f->hb->stale) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_hnsw_search_batch: the built graph no longer matches the rows (a live label was overwritten / a deleted one re-used): use tsgpu_vec_knn_batch");
+        if (f->hb->stale) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_hnsw_search_batch: the built graph no longer matches the rows: use tsgpu_vec_knn_batch");
         if (f->hb->dirty || !f->g_loaded || f->g_n != f->n_rows) {
             HnswBuilder& hb = *f->hb;
             if (hb.size() != f->n_rows) return fail(TSGPU_ERR_DEVICE, "tsgpu_vec_hnsw_search_batch: the builder and the field disagree on the row count");
