@@ -106,9 +106,9 @@ int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
  * "kw_round_fused_max_queries" (default 0 = off): keyword rounds of at most this many plain single-field <= 3-token queries run as ONE launch
  * (kw_round_kernel: find + score per work item, the query's last work item merges) instead of find | score | merge — identical results; measured
  * slower under concurrent callers (the fused kernel's LDS and registers keep one workgroup per CU), so it is an option only,
- * "kw_mf_pipelined" = 1 (default): launches whose multi-field queries have at most two query_by fields run the PIPELINED find kernel
- * (kw_find_mf2_kernel: the second token's lists of both fields merged block-wise through double-buffered LDS tiles, requested one driver
- * block ahead; 0 = kw_search_mf_kernel, which also serves three and four fields); counter "kw_mf_pipelined_launches",
+ * "kw_mf_pipelined" = 1 (default): launches with multi-field queries run the PIPELINED find kernel (kw_find_mf2_kernel<., 2> when no query
+ * of the launch has more than two query_by fields, <., 4> otherwise: the second token's lists of all fields merged block-wise through
+ * double-buffered LDS tiles, requested one driver block ahead; 0 = kw_search_mf_kernel, block at a time); counter "kw_mf_pipelined_launches",
  * "kw_iddir_min_ids" (default 256) / "kw_iddir_density_div" (default 64) / "kw_iddir_budget_mb" (default 4096): posting lists of at least
  * max(min_ids, S / density_div) ids (S = the doc-id range the context's lists cover: num_docs, or a shard's range) carry an ID DIRECTORY in HBM — 8 bytes per 32 doc ids, {posting position, bits} — that answers
  * "is id x in the list, and where" (the probes of a query's third.. lists, of runs wider than the find kernel's tile, of the multi-field and

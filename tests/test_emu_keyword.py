@@ -319,11 +319,13 @@ def pair3():
     g.close()
 
 
-@pytest.mark.parametrize("chunk", [0, 1])
-def test_multi_field_union_per_token_and_field_aggregation(pair3, chunk):
+@pytest.mark.parametrize("chunk,pipelined", [(0, 1), (1, 1), (0, 0), (1, 0)])
+def test_multi_field_union_per_token_and_field_aggregation(pair3, chunk, pipelined):
     """query_by over 2-3 fields: token = OR over the fields, query = AND over tokens (or_iterator_t); score_results2 per field
-    over the tokens that field holds, folded by match_type with field weights / num_matching_fields (compute_aggregated_score)"""
+    over the tokens that field holds, folded by match_type with field weights / num_matching_fields (compute_aggregated_score).
+    pipelined = 1: kw_find_mf2_kernel (three fields in the batch: its four-list instantiation); 0: kw_search_mf_kernel"""
     orc, g = pair3
+    g.set_option("kw_mf_pipelined", pipelined)
     g.set_option("kw_chunk_blocks", chunk)
     g.keep_result_ids(True)
     try:
@@ -380,6 +382,7 @@ def test_multi_field_union_per_token_and_field_aggregation(pair3, chunk):
         finally:
             g.set_option("kw_two_kernels", 1)
     finally:
+        g.set_option("kw_mf_pipelined", 1)
         g.set_option("kw_chunk_blocks", 0)
         g.keep_result_ids(False)
 
@@ -1085,7 +1088,7 @@ def test_pipelined_two_field_find_kernel_equals_the_block_at_a_time_kernel_and_t
     """kw_find_mf2_kernel (kw_mf_pipelined = 1, launches whose queries have <= 2 query_by fields) against kw_search_mf_kernel (0) and the oracle's
     or_iterator_t union (/root/reference/src/or_iterator.cpp:95-171): every pair of the three fields in either order, 1..7 tokens, a token only
     one field holds, tokens no field holds, duplicate tokens, dropped tokens, filters, excluded ids, small Topsters; a batch that ALSO holds a
-    three-field query must fall back to the old kernel as a whole"""
+    three-field query takes the kernel's four-list instantiation as a whole"""
     orc, g = pair3
     rng = np.random.default_rng(505)
     sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
@@ -1118,12 +1121,15 @@ def test_pipelined_two_field_find_kernel_equals_the_block_at_a_time_kernel_and_t
             H.assert_hits_equal(h1, i, ref, "pipelined two-field kernel chunk=%d fields=%s q=%s" % (chunk, q.fields, q.tokens))
             assert np.array_equal(ids1[i], ref.result_ids) and np.array_equal(ids0[i], ref.result_ids)
         assert h1.n_hits.sum() > 1000
-        # one three-field query in the batch: the whole launch takes kw_search_mf_kernel (the host decides per launch)
+        # three-field queries in the batch: the whole launch takes the four-list instantiation (the host decides per launch)
         g.set_option("kw_mf_pipelined", 1)
-        mixed = qs[:8] + [T.KwQuery([3, 1, 2], fields=[(0, 15), (1, 7), (2, 3)], sort=sort, topster_size=250)]
+        f3 = [(0, 15), (1, 7), (2, 3)]
+        mixed = qs[:8] + [T.KwQuery(t, fields=f3, sort=sort, topster_size=250) for t in ([3, 1, 2], [1], [2, 1], [7, 1, 2, 3, 6], [5, 9], [9999, 2])]
+        mixed += [T.KwQuery([3, 1], fields=[(2, 3), (1, 7), (0, 15)], sort=sort, topster_size=250, filter_ids=np.arange(0, 2500, 2)),
+                  T.KwQuery([1, 2], fields=f3, sort=sort, topster_size=250, dropped_tokens=[3])]
         n0 = g.counter("kw_mf_pipelined_launches")
         hm = g.keyword_search_batch(mixed, k_stride=250)
-        assert g.counter("kw_mf_pipelined_launches") == n0
+        assert g.counter("kw_mf_pipelined_launches") > n0
         for i, q in enumerate(mixed):
             H.assert_hits_equal(hm, i, H.oracle_keyword(orc, q, ids_cap=4000), "mixed 2/3-field batch q=%s" % (q.tokens,))
     finally:

@@ -402,12 +402,13 @@ def test_device_side_planner_on_2m_docs_many_work_items(c2m):
         H.assert_hits_equal(dev, i, c2m.oracle(qs[i]), "device plan at 2M docs")
 
 
-def test_pipelined_two_field_find_kernel_on_1m_docs_two_fields():
-    """kw_find_mf2_kernel at size: 1M documents, two string fields, 400 three-term queries over both (driver lists of hundreds of blocks: window
+@pytest.mark.parametrize("n_fields", [2, 3, 4])
+def test_pipelined_find_kernel_on_1m_docs_several_fields(n_fields):
+    """kw_find_mf2_kernel<., 2> / <., 4> at size: 1M documents, two to four string fields, 400 three-term queries over all of them (driver lists of hundreds of blocks: window
     slides and re-centring, runs in both tile sizes and wider than the tile, many work items per query) — identical to kw_search_mf_kernel on
     every output array, and 24 of them identical to the oracle's or_iterator_t union (/root/reference/src/or_iterator.cpp:95-171)"""
     n_docs = 1_000_000
-    csr = [synth.zipf_corpus_csr(n_docs, 20_000, 20, seed=71), synth.zipf_corpus_csr(n_docs, 20_000, 10, seed=72)]
+    csr = [synth.zipf_corpus_csr(n_docs, 20_000, (20, 10, 6, 12)[f], seed=71 + f) for f in range(n_fields)]
     pts = synth.points_column(n_docs)
     g = T.GpuIndex(0)
     for f, c in enumerate(csr):
@@ -418,8 +419,8 @@ def test_pipelined_two_field_find_kernel_on_1m_docs_two_fields():
     g.commit()
     try:
         qtok = np.concatenate([synth.keyword_queries(300, 3, 1, 300, seed=81), synth.keyword_queries(100, 3, 2, 4000, seed=82)])
-        fields = ((0, 15), (1, 14))
-        qs = [T.KwQuery(q, sort=SORT, topster_size=250, fields=fields if i % 3 else ((1, 14), (0, 15))) for i, q in enumerate(qtok)]
+        fields = tuple((f, 15 - f) for f in range(n_fields))
+        qs = [T.KwQuery(q, sort=SORT, topster_size=250, fields=fields if i % 3 else fields[::-1]) for i, q in enumerate(qtok)]
         outs = []
         for pipelined in (1, 0):
             g.set_option("kw_mf_pipelined", pipelined)
@@ -431,7 +432,7 @@ def test_pipelined_two_field_find_kernel_on_1m_docs_two_fields():
         for name in ("keys", "scores", "n_hits", "num_matched"):
             assert np.array_equal(getattr(outs[0], name), getattr(outs[1], name)), name
         assert int(outs[0].n_hits.sum()) > 20_000
-        orc = O.OracleIndex(2, 1)
+        orc = O.OracleIndex(n_fields, 1)
         orc.set_num_docs(n_docs)
         orc.set_sort_dense(0, pts)
         for t in np.unique(qtok[:24]):
@@ -440,7 +441,7 @@ def test_pipelined_two_field_find_kernel_on_1m_docs_two_fields():
                 if ids.size:
                     orc.load_posting(f, int(t), ids, oi, off)
         for i in range(24):
-            H.assert_hits_equal(outs[0], i, H.oracle_keyword(orc, qs[i]), "1M docs, two fields, pipelined find kernel")
+            H.assert_hits_equal(outs[0], i, H.oracle_keyword(orc, qs[i]), "1M docs, %d fields, pipelined find kernel" % n_fields)
         orc.close()
     finally:
         g.close()

@@ -19,8 +19,8 @@
 // Stage 2 (the other tokens in every field, the driver token's other fields with the "an id an EARLIER field's list of the driver token holds
 // is left to that field's work items" rule) runs on full 256-entry batches of queued survivors out of a RING (head in a register, two barriers
 // per batch) as in kw_find2_kernel.
-// Serves launches whose multi-field queries have at most KW_MF2_LISTS (2) query_by fields — the host knows (Plan::mf_max_fields); three and four
-// fields keep kw_search_mf_kernel. Option kw_mf_pipelined = 0 restores the old kernel for every launch. Same records bit for bit: the tests run both.
+// Two instantiations: NB = 2 serves launches whose multi-field queries have at most two query_by fields, NB = 4 those with three or four (the host knows:
+// Plan::mf_max_fields). Option kw_mf_pipelined = 0 restores kw_search_mf_kernel for every launch. Same records bit for bit: the tests run both.
 #pragma once
 
 #ifndef TSGPU_MF2_SLABS
@@ -32,14 +32,16 @@
 #ifndef TSGPU_MF2_SPAN
 #define TSGPU_MF2_SPAN 8
 #endif
+#ifndef TSGPU_MF2_WAVES4
+#define TSGPU_MF2_WAVES4 4
+#endif
 #ifdef TSGPU_HIP_EMU
 #define KW_MF2_WAVES_ATTR
 #else
-#define KW_MF2_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(TSGPU_MF2_WAVES)))
+#define KW_MF2_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NB == 2 ? TSGPU_MF2_WAVES : TSGPU_MF2_WAVES4)))
 #endif
-static const int KW_MF2_LISTS = 2;                              // second-token lists merged block-wise per iteration (= query_by fields served)
-static const int KW_MF2_SLABS = TSGPU_MF2_SLABS;                // 1 KB slabs per (list, tile buffer): runs of up to SLABS x 512 16-bit ids under one driver block
-static const int KW_MF2_TILE = KW_MF2_SLABS * KW_THREADS;       // words
+static const int KW_MF2_LISTS = 2;                              // second-token lists merged block-wise per iteration by the two-field instantiation (NB = 4: three and four fields)
+static const int KW_MF2_SLABS = TSGPU_MF2_SLABS;                // 1 KB slabs per (list, tile buffer), NB = 2: runs of up to SLABS x 512 16-bit ids under one driver block (NB = 4: two slabs)
 #ifndef TSGPU_MF2_WIDE
 #define TSGPU_MF2_WIDE 0
 #endif
@@ -55,15 +57,19 @@ static const int KW_MF2_TILE = KW_MF2_SLABS * KW_THREADS;       // words
 static const bool KW_MF2_WIDE = TSGPU_MF2_WIDE != 0;            // probes without a directory: the 16-entry search windows requested at once (wide_lower_bound)
 static const int KW_MF2_SPAN = TSGPU_MF2_SPAN;                  // runs of up to this many blocks: block search by v_readlane compares
 
-template <int TMAX>
+// NB = query_by fields served = second-token lists merged block-wise per iteration: 2 (the common request; 25 KB of LDS, six workgroups per CU) or 4 (three and
+// four fields: 2-slab tiles, 29 KB of LDS, the windows of four lists in registers)
+template <int TMAX, int NB = KW_MF2_LISTS>
 __global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kernel(IndexView ix, const KwQueryDev* __restrict__ queries,
                                                                                        const KwWorkItem* __restrict__ work, KwPartials part,
                                                                                        uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off) {
-    constexpr int NB = KW_MF2_LISTS;
+    static_assert(NB == 2 || NB == 4, "two or four second-token lists");
     constexpr int NP = TMAX * KW_MAX_FIELDS;
-    constexpr int TILE = KW_MF2_TILE;
-    static_assert(KW_MF2_SLABS == 2 || KW_MF2_SLABS == 4 || KW_MF2_SLABS == 6 || KW_MF2_SLABS == 8, "kw_glds_slabs forms");
-    static_assert(KW_MF2_SLABS * KW_THREADS <= (int)KW_TILE_OVERREAD_WORDS, "the tile fill reads whole slabs past a run's end: the ids arena's padding");
+    constexpr int SLABS = NB == 2 ? KW_MF2_SLABS : 2;
+    constexpr int TILE = SLABS * KW_THREADS;
+    static_assert(SLABS == 2 || SLABS == 4 || SLABS == 6 || SLABS == 8, "kw_glds_slabs forms");
+    static_assert(SLABS * KW_THREADS <= (int)KW_TILE_OVERREAD_WORDS, "the tile fill reads whole slabs past a run's end: the ids arena's padding");
+    static_assert(NB <= KW_MAX_FIELDS, "one list per query_by field");
     __shared__ uint32_t btile[2 * NB * TILE + 2];               // [buffer][list][TILE]: one set searched, one landing
     __shared__ uint32_t q_id[KW_QCAP], q_p0[KW_QCAP], q_p1[NB][KW_QCAP];     // survivor ring: id, driver position, position in either second list (KW_NONE: absent)
     __shared__ uint32_t wave_cnt[2][KW_THREADS / 64];
@@ -184,8 +190,8 @@ __global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kern
         P.mode = 0;
         const uint32_t* lane_src = ix.ids_payload + dB[f].ids_base + P.w_begin + t;
         uint32_t* lds_wave_base = btile + (buf * NB + f) * TILE + wave * 64;
-        if (W <= 2u * KW_THREADS) kw_glds_slabs<2>(lane_src, lds_wave_base);
-        else kw_glds_slabs<KW_MF2_SLABS == 2 ? 4 : KW_MF2_SLABS>(lane_src, lds_wave_base);
+        if (SLABS == 2 || W <= 2u * KW_THREADS) kw_glds_slabs<2>(lane_src, lds_wave_base);
+        else kw_glds_slabs<SLABS == 2 ? 4 : SLABS>(lane_src, lds_wave_base);
         return P;
     };
 
@@ -374,21 +380,28 @@ __global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kern
             // both lists the two searches run as ONE straight-line sequence of two independent chains (candidates that dropped out search the
             // tile's first block: harmless reads)
             constexpr uint32_t FULL16 = (16u << 16) | (uint32_t)BLOCK_IDS;
-            const bool fast = (done[0] || nb[0] == FULL16) && (done[1] || nb[1] == FULL16);
+            bool fast = true;
+#pragma unroll
+            for (int f = 0; f < NB; f++) fast = fast && (done[f] || nb[f] == FULL16);
             if (__ballot(fast ? 0 : 1) == 0) {
-                const uint16_t* __restrict__ a0 = (const uint16_t*)(tile + (done[0] ? 0u : rel[0]));
-                const uint16_t* __restrict__ a1 = (const uint16_t*)(tile + TILE + (done[1] ? 0u : rel[1]));
-                const uint32_t t0 = id - first[0], t1 = id - first[1];
-                uint32_t s0 = 0, s1 = 0;
+                const uint16_t* __restrict__ a[NB];
+                uint32_t tg[NB], sl[NB];
+#pragma unroll
+                for (int f = 0; f < NB; f++) { a[f] = (const uint16_t*)(tile + f * TILE + (done[f] ? 0u : rel[f])); tg[f] = id - first[f]; sl[f] = 0; }
 #pragma unroll
                 for (uint32_t step = 128; step > 0; step >>= 1) {
-                    const uint32_t v0 = a0[s0 + step - 1], v1 = a1[s1 + step - 1];
-                    s0 = v0 < t0 ? s0 + step : s0;
-                    s1 = v1 < t1 ? s1 + step : s1;
+                    uint32_t v[NB];
+#pragma unroll
+                    for (int f = 0; f < NB; f++) v[f] = a[f][sl[f] + step - 1];
+#pragma unroll
+                    for (int f = 0; f < NB; f++) sl[f] = v[f] < tg[f] ? sl[f] + step : sl[f];
                 }
-                const uint32_t h0 = a0[s0], h1 = a1[s1];
-                found[0] = !done[0] && h0 == t0; found[1] = !done[1] && h1 == t1;
-                pp[0] = (C[0].base + pos_b[0]) * BLOCK_IDS + s0; pp[1] = (C[1].base + pos_b[1]) * BLOCK_IDS + s1;
+#pragma unroll
+                for (int f = 0; f < NB; f++) {
+                    const uint32_t h = a[f][sl[f]];
+                    found[f] = !done[f] && h == tg[f];
+                    pp[f] = (C[f].base + pos_b[f]) * BLOCK_IDS + sl[f];
+                }
             } else {
 #pragma unroll
                 for (int f = 0; f < NB; f++) if (!done[f]) slot_search(tile + f * TILE, first[f], nb[f], rel[f], C[f].base + pos_b[f], found[f], pp[f]);
@@ -406,7 +419,10 @@ __global__ __launch_bounds__(KW_THREADS) KW_MF2_WAVES_ATTR void kw_find_mf2_kern
             }
         }
         KW_PROF(5)
-        if (ts != KW_NONE) ok = ok && (found[0] || found[1]);
+        if (ts != KW_NONE) { bool any = false;
+#pragma unroll
+            for (int f = 0; f < NB; f++) any = any || found[f];
+            ok = ok && any; }
         // ---- survivors -> the ring (block order = ascending id), behind ONE barrier ----
         uint32_t total;
         const uint32_t my = block_compact1(ok, wave_cnt[par], total);

@@ -96,9 +96,11 @@ void launch_search_mf_cap(int cap, hipStream_t s, uint32_t n_work, const IndexVi
 struct MfOrderedCount { const uint32_t* jobs = nullptr; uint32_t n_jobs = 0, table_first = 0; const KwWorkItem* work_all = nullptr; KwPartials part_all{}; };
 template <int TMAX>
 void launch_find_score_mf(int cap, hipStream_t s, uint32_t n_work, const IndexView& v, const KwQueryDev* q, const KwWorkItem* w, const KwPartials& part,
-                          const uint32_t* aux, uint32_t* ids_out, uint32_t* hits, const uint64_t* hit_off, const MfOrderedCount& oc, bool plain = false, bool pipelined = false) {
-    // pipelined: every multi-field query of the launch has at most KW_MF2_LISTS query_by fields (kw_find_mf2.hip.h); same hit records either way
-    if (pipelined) hipLaunchKernelGGL((kw_find_mf2_kernel<TMAX>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, hits, hit_off);
+                          const uint32_t* aux, uint32_t* ids_out, uint32_t* hits, const uint64_t* hit_off, const MfOrderedCount& oc, bool plain = false, int pipelined_lists = 0) {
+    // pipelined_lists: 2 / 4 = the pipelined find kernel's instantiation that covers every multi-field query of the launch (kw_find_mf2.hip.h); 0 = kw_search_mf_kernel.
+    // Same hit records either way.
+    if (pipelined_lists == 2) hipLaunchKernelGGL((kw_find_mf2_kernel<TMAX, 2>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, hits, hit_off);
+    else if (pipelined_lists == 4) hipLaunchKernelGGL((kw_find_mf2_kernel<TMAX, 4>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, hits, hit_off);
     else hipLaunchKernelGGL((kw_search_mf_kernel<TMAX, 512, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
     if (oc.n_jobs) hipLaunchKernelGGL((kw_mf_ordered_count_kernel<TMAX>), dim3(oc.n_jobs), dim3(64), 0, s, q, oc.work_all, oc.part_all, hits, hit_off, oc.table_first, aux, oc.jobs);
     if (cap == 512 && plain && !ids_out && !oc.n_jobs) hipLaunchKernelGGL((kw_score_kernel<TMAX, 512, true, true, true>), dim3(n_work), dim3(KW_THREADS), 0, s, v, q, w, part, aux, ids_out, hits, hit_off);
@@ -1442,7 +1444,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
                             oc.jobs = (const uint32_t*)(dplan + at_oc[tb]); oc.n_jobs = (uint32_t)oc_jobs[tb].size(); oc.table_first = (uint32_t)first;
                             oc.work_all = dw; oc.part_all = part;
                         }
-                        const bool mf_pipe = ctx->kw_mf_pipelined && P.mf_max_fields <= (uint32_t)KW_MF2_LISTS;
+                        const int mf_pipe = !ctx->kw_mf_pipelined ? 0 : (P.mf_max_fields <= 2 ? 2 : (P.mf_max_fields <= 4 ? 4 : 0));
                         if (mf_pipe) ctx->kw_mf_pipelined_launches++;
                         launch_find_score_mf<TM>(cap, s, (uint32_t)(b - a), v, dq, dw + first + a, shifted(first + a), daux, ids_out, L.d_hits.as<uint32_t>(), hoff_dev + a, oc, !P.any_aux && !P.any_array, mf_pipe);
                     }
