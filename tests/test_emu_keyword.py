@@ -517,6 +517,20 @@ def test_candidate_combinations_fold_like_the_shared_topster_and_id_buff(pair, t
         assert np.array_equal(g.candidates_result_ids(gi), ref.result_ids)
         multi += int(len(set(ref_qi.tolist())) > 1)
     assert multi >= 5                  # hits really come from different passes
+    # plain passes planned ON THE DEVICE (big candidate batches: kw_plan.hip.h lays the id arena out itself, the id-set marks read the device tables)
+    plain = [grp for grp in groups[:14] if grp and all(c.filter_ids is None and c.excluded_ids is None for c in grp)]
+    g.set_option("kw_device_plan_min_queries", 1)
+    n0 = g.counter("kw_device_plans")
+    hd, qd, fd = g.keyword_search_candidates_batch(plain, k_stride=250)
+    planned = g.counter("kw_device_plans") - n0
+    ids_d = [g.candidates_result_ids(gi) for gi in range(len(plain))]
+    g.set_option("kw_device_plan_min_queries", 512)
+    assert planned == 1
+    for gi, combos in enumerate(plain):
+        ref, ref_qi = H.oracle_candidates(orc, combos, ids_cap=4000)
+        H.assert_hits_equal(hd, gi, ref, "candidates, device plan g%d" % gi)
+        assert np.array_equal(qd[gi, :int(hd.n_hits[gi])], ref_qi) and int(fd[gi]) == int(ref.n_result_ids)
+        assert np.array_equal(ids_d[gi], ref.result_ids)
     assert (qidx[len(groups) - 3, :int(hits.n_hits[len(groups) - 3])] == 1).all()
     assert (qidx[len(groups) - 2, :int(hits.n_hits[len(groups) - 2])] == 0).all()
 

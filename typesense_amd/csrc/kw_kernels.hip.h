@@ -3052,30 +3052,28 @@ __global__ __launch_bounds__(KW_THREADS) void kw_candidates_rank_kernel(KwCandIn
 
 // all_result_ids of a group = sorted-unique union of the passes' emitted ids (id_buff -> timsort + unique + or_scalar,
 // src/index.cpp:5565-5578, 5081-5090): one bit per seq_id, set from the passes' id segments, then counted / expanded in order.
-struct KwIdSeg { uint64_t off; uint32_t cnt; uint32_t group; };
-__global__ __launch_bounds__(KW_THREADS) void kw_idset_mark_kernel(const uint32_t* __restrict__ ids, const KwIdSeg* __restrict__ segs,
-                                                                  uint32_t* __restrict__ bits, uint64_t words_per_group) {
-    const KwIdSeg sg = segs[blockIdx.x];
-    uint32_t* mine = bits + (uint64_t)sg.group * words_per_group;
-    for (uint32_t i = blockIdx.y * KW_THREADS + threadIdx.x; i < sg.cnt; i += gridDim.y * KW_THREADS) {
-        const uint32_t id = ids[sg.off + i];
-        atomicOr(&mine[id >> 5], 1u << (id & 31));
-    }
-}
-__global__ __launch_bounds__(KW_THREADS) void kw_idset_count_kernel(const uint32_t* __restrict__ bits, uint64_t words_per_group,
-                                                                   unsigned long long* __restrict__ found) {
-    __shared__ uint32_t s_sum[KW_THREADS / 64];
-    const uint32_t* mine = bits + (uint64_t)blockIdx.x * words_per_group;
+// Marked from the batch's own tables: one workgroup row per WORK ITEM — its segment of the id arena is queries[item.query].ids_out_off +
+// item.ids_out_off, n_emit[item] ids long —, the group of the item's pass from group_of[] (KW_NONE: the group reports a failing pass -> no
+// ids). A bit that this thread's atomicOr turned on is a NEW member of the union, so the marks count the union themselves (found[group]):
+// no pass over the bitmaps (round 4: 0.39 ms per 1 000 groups at 10M documents), no host-built segment list, no n_emit read-back.
+__global__ __launch_bounds__(KW_THREADS) void kw_idset_mark_items_kernel(const uint32_t* __restrict__ ids, const KwQueryDev* __restrict__ queries,
+                                                                        const KwWorkItem* __restrict__ work, const uint32_t* __restrict__ n_emit,
+                                                                        const uint32_t* __restrict__ group_of, uint32_t* __restrict__ bits,
+                                                                        uint64_t words_per_group, unsigned long long* __restrict__ found) {
+    const uint32_t cnt = n_emit[blockIdx.x];
+    if (blockIdx.y * KW_THREADS >= cnt) return;                       // (uniform)
+    const KwWorkItem wi = work[blockIdx.x];
+    const uint32_t qi = wi.query & 0x0FFFFFFFu, g = group_of[qi];
+    if (g == KW_NONE) return;
+    const uint32_t* src = ids + queries[qi].ids_out_off + wi.ids_out_off;
+    uint32_t* mine = bits + (uint64_t)g * words_per_group;
     uint32_t c = 0;
-    for (uint64_t w = (uint64_t)blockIdx.y * KW_THREADS + threadIdx.x; w < words_per_group; w += (uint64_t)gridDim.y * KW_THREADS) c += __popc(mine[w]);
-    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
-    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int w = 0; w < KW_THREADS / 64; w++) tot += s_sum[w];
-        if (tot) atomicAdd(&found[blockIdx.x], (unsigned long long)tot);
+    for (uint32_t i = blockIdx.y * KW_THREADS + threadIdx.x; i < cnt; i += gridDim.y * KW_THREADS) {
+        const uint32_t id = src[i], bit = 1u << (id & 31);
+        c += (atomicOr(&mine[id >> 5], bit) & bit) ? 0u : 1u;
     }
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&found[g], (unsigned long long)c);
 }
 // per-call id lists (tsgpu_keyword_search_batch_ids): the work items' id segments, scattered over the lane's id arena, copied into
 // one dense array (query after query, segment after segment) so that ONE download hands every caller its ids

@@ -225,12 +225,16 @@ __global__ __launch_bounds__(256) void kw_plan_rank_kernel(KwPlanParams pp, KwPl
 
 // work: the two tables back to back (table 1 starts at n_work[0]); hoff[w] = first hit record of work item w inside ITS table's hit buffer
 __global__ __launch_bounds__(256) void kw_plan_emit_kernel(KwPlanParams pp, KwQueryDev* __restrict__ q, KwPlanScratch sc, const uint32_t* __restrict__ fw_acc,
-                                                            const unsigned long long* __restrict__ hb_acc, KwWorkItem* __restrict__ work, unsigned long long* __restrict__ hoff) {
+                                                            const unsigned long long* __restrict__ hb_acc, KwWorkItem* __restrict__ work, unsigned long long* __restrict__ hoff,
+                                                            const KwPlanTotals* __restrict__ tot) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pp.n_queries) return;
     const uint32_t cnt = sc.cnt[i], fw = fw_acc[i];
     const unsigned long long hb = hb_acc[i];
     q[i].first_work = fw; q[i].n_work = cnt; q[i].m_first = fw; q[i].m_n = cnt;
+    // the id arena (batches that keep the matched ids): a query's segment sits where its hit records sit — driver blocks of the queries ahead of it in
+    // its table, table 1 behind table 0 —, its work items' segments at their first block (ids_out_off below), 256 ids per driver block
+    q[i].ids_out_off = (((sc.key[i] >> 32) ? tot->hit_blocks[0] : 0ull) + hb) * (unsigned long long)BLOCK_IDS;
     const uint32_t nb = sc.n_blocks[i], chunk = sc.chunk[i];
     for (uint32_t c = 0, b = 0; c < cnt; c++, b += chunk) {
         KwWorkItem w;

@@ -914,7 +914,7 @@ static int plan_batch_device(tsgpu_ctx* ctx, KwLane& L, const Snapshot& snap, co
     unsigned long long* const hoff = (unsigned long long*)((uint8_t*)L.d_plan_work.p + ((std::max<size_t>(n_work, 1) * sizeof(KwWorkItem) + 63) & ~(size_t)63));
     TSGPU_HIP_TRY(hipMemsetAsync(dp + at_fw, 0, (at_hb - at_fw) + (size_t)n_queries * 8, s));
     hipLaunchKernelGGL(kw_plan_rank_kernel, dim3(grid.x, KW_PLAN_JPARTS), block, 0, s, pp, sc, (uint32_t*)(dp + at_fw), (unsigned long long*)(dp + at_hb));
-    hipLaunchKernelGGL(kw_plan_emit_kernel, grid, block, 0, s, pp, dq, sc, (const uint32_t*)(dp + at_fw), (const unsigned long long*)(dp + at_hb), dw, hoff);
+    hipLaunchKernelGGL(kw_plan_emit_kernel, grid, block, 0, s, pp, dq, sc, (const uint32_t*)(dp + at_fw), (const unsigned long long*)(dp + at_hb), dw, hoff, (const KwPlanTotals*)d_tot);
     TSGPU_HIP_TRY(hipGetLastError());
     P.status.assign(n_queries, TSGPU_OK);
     P.cutoff.assign(n_queries, 0);
@@ -1224,9 +1224,11 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         // host threads; any other shape — and anything the device planner hands back — goes through plan_batch()
         // (not for the chained slices of a sliced host delivery: there the host plans slice i + 1 WHILE slice i runs, and a planning kernel on the
         //  second lane would wait behind the running find kernel for a place on the chip — measured: 10.05 -> 10.18 ms per 10 000 queries)
-        if (!wildcard && !keep_ids && !bo.vflat && (!bo.chain || (bo.chain_index == 0 && ctx->kw_host_split_device_plan)) && ctx->kw_two_kernels && ctx->kw_device_plan_min_queries && n_queries >= ctx->kw_device_plan_min_queries) {
+        // (batches that keep the matched ids: only when nobody reads the segments back per query — the candidate call marks its id sets from the device tables)
+        if (!wildcard && (!keep_ids || (!bo.record_last && !bo.id_lists)) && !bo.vflat && (!bo.chain || (bo.chain_index == 0 && ctx->kw_host_split_device_plan)) && ctx->kw_two_kernels && ctx->kw_device_plan_min_queries && n_queries >= ctx->kw_device_plan_min_queries) {
             if ((rc = plan_batch_device(ctx, L, snap, queries, n_queries, P, DP, s))) return rc;
             if (DP.on) ctx->kw_device_plans.fetch_add(1); else ctx->kw_device_plan_fallbacks.fetch_add(1);
+            if (DP.on && keep_ids) P.ids_total = (DP.hit_blocks[0] + DP.hit_blocks[1]) * (uint64_t)BLOCK_IDS;
         }
         if (!DP.on && (rc = plan_batch(ctx, snap, queries, n_queries, P, keep_ids, wildcard, bo.vflat))) return rc;
         const uint64_t t_planned = now_us();
@@ -1407,6 +1409,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         }
         const KwQueryDev* dq = DP.on ? DP.dq : (const KwQueryDev*)(dplan + at_q);
         const KwWorkItem* dw = DP.on ? DP.dw : (const KwWorkItem*)(dplan + at_w);
+        L.last_tab_q = dq; L.last_tab_w = dw; L.last_tab_n_work = n_work;
         const uint32_t* daux = DP.on ? DP.daux : (const uint32_t*)(dplan + at_aux);
         const bool timing = bo.timing && n_queries >= ctx->kw_timing_min_queries;      // (each record is a marker packet in the stream: ~2 us of a small round)
         if (timing) TSGPU_HIP_TRY(hipEventRecord(L.ev[0], s));
@@ -1823,14 +1826,31 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
         pass.vector_distance = L.d_cand_vd.as<float>(); pass.match_score_index = L.d_cand_msi.as<int8_t>();
         pass.n_hits = L.d_cand_nh.as<uint32_t>(); pass.num_matched = L.d_cand_nm.as<uint64_t>(); pass.status = L.d_cand_st.as<int32_t>();
         std::vector<int32_t> st, co;
+        // all_result_ids: one bitmap per group (below). They are cleared on a second stream while the passes run — 1.25 MB per group at 10M documents is
+        // HBM-rate work the scalar-bound find kernel does not notice (as a memset in front of the marks it was 0.18 ms of the 7.3 ms step of 1 000 groups)
+        const uint64_t id_words = std::max<uint64_t>(((uint64_t)ctx->num_docs + 31) / 32, 1);
+        L.last_cand_groups = 0;
+        if (found) {
+            if ((uint64_t)n_groups * id_words * 4 > (8ull << 30))
+                return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_candidates_batch: id-set bitmaps (n_groups * num_docs / 8 bytes) exceed 8 GiB; split the batch");
+            if ((rc = L.d_cand_bits.reserve((size_t)n_groups * id_words * 4)) || (rc = L.d_cand_found.reserve((size_t)n_groups * 8))) return rc;
+            if (!L.aux_stream) TSGPU_HIP_TRY(hipStreamCreateWithFlags(&L.aux_stream, hipStreamNonBlocking));
+            if (!L.ev_aux) TSGPU_HIP_TRY(hipEventCreateWithFlags(&L.ev_aux, hipEventDisableTiming));
+            TSGPU_HIP_TRY(hipEventRecord(L.ev_aux, s));                       // (whatever the caller's stream still does with the last call's bitmaps comes first)
+            TSGPU_HIP_TRY(hipStreamWaitEvent(L.aux_stream, L.ev_aux, 0));
+            TSGPU_HIP_TRY(hipMemsetAsync(L.d_cand_bits.p, 0, (size_t)n_groups * id_words * 4, L.aux_stream));
+            TSGPU_HIP_TRY(hipMemsetAsync(L.d_cand_found.p, 0, (size_t)n_groups * 8, L.aux_stream));
+            TSGPU_HIP_TRY(hipEventRecord(L.ev_aux, L.aux_stream));
+        }
+        L.last_tab_n_work = 0;
         if (n_combos) {
             BatchOpts bo;
             bo.keep_ids = found != nullptr;                    // the union needs every pass's emitted ids
             bo.status_host = &st;
             bo.cutoff_host = &co;
-            bo.record_last = true;
+            bo.record_last = false;                            // (the marks below read the batch's tables on the device; tsgpu_candidates_result_ids reads the bitmaps)
             rc = kw_batch_on_lane(ctx, L, combos, n_combos, &pass, bo);
-            if (rc) return rc;
+            if (rc) { if (found) (void)hipStreamSynchronize(L.aux_stream); return rc; }
         }
         // a group runs only if every combination of it ran; otherwise it reports the first failing status and no hits
         std::vector<uint32_t> range((size_t)n_groups * 3 + 3, 0);        // per group: first entry, one past the last, Topster capacity
@@ -1887,36 +1907,24 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
         else hipLaunchKernelGGL((kw_candidates_merge_kernel<4096>), dim3(n_groups), dim3(KW_THREADS), 0, s, in, o, qi_dev);
         TSGPU_HIP_TRY(hipGetLastError());
 
-        // ---- all_result_ids: one bitmap per group ----
-        L.last_cand_groups = 0;
+        // ---- all_result_ids: one bitmap per group, marked from the passes' id segments; the marks count the union (kw_idset_mark_items_kernel) ----
         L.last_cand_found.assign(n_groups, 0);
         if (found) {
-            const uint64_t words = std::max<uint64_t>(((uint64_t)ctx->num_docs + 31) / 32, 1);
-            if ((uint64_t)n_groups * words * 4 > (8ull << 30))
-                return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_candidates_batch: id-set bitmaps (n_groups * num_docs / 8 bytes) exceed 8 GiB; split the batch");
-            std::vector<KwIdSeg> segs;
-            for (uint32_t g = 0; g < n_groups; g++) {
-                if (gstatus[g] != TSGPU_OK) continue;
-                for (uint32_t e = group_begin[g]; e < group_begin[g + 1]; e++)
-                    for (size_t c = 0; c < L.last_chunk_emit[e].size(); c++)
-                        if (L.last_chunk_emit[e][c]) segs.push_back({L.last_ids_off[e] + L.last_chunk_off[e][c], L.last_chunk_emit[e][c], g});
-            }
-            if ((rc = L.d_cand_bits.reserve((size_t)n_groups * words * 4)) || (rc = L.d_cand_found.reserve((size_t)n_groups * 8))) return rc;
-            TSGPU_HIP_TRY(hipMemsetAsync(L.d_cand_bits.p, 0, (size_t)n_groups * words * 4, s));
-            TSGPU_HIP_TRY(hipMemsetAsync(L.d_cand_found.p, 0, (size_t)n_groups * 8, s));
-            if (!segs.empty()) {
-                if ((rc = upload(L.d_cand_segs, segs.data(), segs.size() * sizeof(KwIdSeg), s))) return rc;
-                hipLaunchKernelGGL(kw_idset_mark_kernel, dim3((uint32_t)segs.size(), 8), dim3(KW_THREADS), 0, s, L.d_ids_out.as<uint32_t>(),
-                                   L.d_cand_segs.as<KwIdSeg>(), L.d_cand_bits.as<uint32_t>(), words);
-                const uint32_t gy = (uint32_t)std::min<uint64_t>(64, (words + KW_THREADS - 1) / KW_THREADS);
-                hipLaunchKernelGGL(kw_idset_count_kernel, dim3(n_groups, gy), dim3(KW_THREADS), 0, s, L.d_cand_bits.as<uint32_t>(), words,
-                                   L.d_cand_found.as<unsigned long long>());
+            TSGPU_HIP_TRY(hipStreamWaitEvent(s, L.ev_aux, 0));               // the cleared bitmaps
+            if (n_combos && L.last_tab_n_work) {
+                std::vector<uint32_t> group_of(n_combos, KW_NONE);
+                for (uint32_t g = 0; g < n_groups; g++)
+                    if (gstatus[g] == TSGPU_OK) for (uint32_t e = group_begin[g]; e < group_begin[g + 1]; e++) group_of[e] = g;
+                if ((rc = upload(L.d_cand_segs, group_of.data(), group_of.size() * 4, s))) return rc;
+                hipLaunchKernelGGL(kw_idset_mark_items_kernel, dim3(L.last_tab_n_work, 8), dim3(KW_THREADS), 0, s, L.d_ids_out.as<uint32_t>(),
+                                   (const KwQueryDev*)L.last_tab_q, (const KwWorkItem*)L.last_tab_w, L.d_part_ne.as<uint32_t>(), L.d_cand_segs.as<uint32_t>(),
+                                   L.d_cand_bits.as<uint32_t>(), id_words, L.d_cand_found.as<unsigned long long>());
                 TSGPU_HIP_TRY(hipGetLastError());
             }
             TSGPU_HIP_TRY(hipMemcpyAsync(L.last_cand_found.data(), L.d_cand_found.p, (size_t)n_groups * 8, hipMemcpyDeviceToHost, s));
             if (dev_out) TSGPU_HIP_TRY(hipMemcpyAsync(found, L.d_cand_found.p, (size_t)n_groups * 8, hipMemcpyDeviceToDevice, s));
             L.last_cand_groups = n_groups;
-            L.last_cand_words = words;
+            L.last_cand_words = id_words;
         }
 
         // ---- results ----

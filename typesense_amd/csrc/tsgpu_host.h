@@ -348,6 +348,11 @@ struct KwLane {
     uint32_t last_cand_groups = 0;
     uint64_t last_cand_words = 0;
     std::vector<uint64_t> last_cand_found;
+    const void* last_tab_q = nullptr;                // the last batch's tables ON THE DEVICE (queries, work items in partial-list order; valid until the lane's next batch):
+    const void* last_tab_w = nullptr;                //   the candidate call's id-set marks read them instead of a host-built segment list
+    uint32_t last_tab_n_work = 0;
+    hipStream_t aux_stream = nullptr;                // candidate calls: the id-set bitmaps are cleared here WHILE the passes' find / score kernels run (created on first use)
+    hipEvent_t ev_aux = nullptr;
     std::vector<uint64_t> last_ids_off;              // per query offset into d_ids_out of the last batch
     std::vector<std::vector<uint32_t>> last_chunk_emit;  // ids emitted per work item of the query
     std::vector<std::vector<uint32_t>> last_chunk_off;   // where each work item's id segment starts (relative to last_ids_off)
@@ -362,6 +367,8 @@ struct KwLane {
         for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (ev_block) { (void)hipEventDestroy(ev_block); ev_block = nullptr; }
         if (ev_chain) { (void)hipEventDestroy(ev_chain); ev_chain = nullptr; }
+        if (ev_aux) { (void)hipEventDestroy(ev_aux); ev_aux = nullptr; }
+        if (aux_stream) { (void)hipStreamDestroy(aux_stream); aux_stream = nullptr; }
         if (own_stream && stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
