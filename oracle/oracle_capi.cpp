@@ -101,6 +101,95 @@ void orc_load_posting(void* h, uint32_t field, uint32_t term, const uint32_t* id
                       const uint32_t* offsets, uint32_t n, uint32_t n_offsets) {
     ((Index*)h)->load_posting(field, term, ids, offset_index, offsets, n, n_offsets);
 }
+// ---- group_by (oracle/group_topster.h) ----
+struct orc_grouped {
+    uint32_t group_cap, kv_cap;     // in: capacities
+    uint32_t n_groups;              // out
+    uint32_t* group_size;           // [group_cap] KVs of each returned group
+    uint32_t* group_found;          // [group_cap] groups_processed[distinct_key]
+    uint64_t* distinct_key;         // [group_cap]
+    uint64_t* keys;                 // [kv_cap] group-major
+    int64_t* scores;                // [kv_cap*3]
+    uint64_t groups_count, groups_exact;
+    uint8_t* loglog;                // nullable, [16384]
+    uint32_t* missing_ids; uint64_t missing_cap, n_missing;   // group_by_missing_value_ids of a first pass (ascending)
+    uint64_t num_keyword_matches, n_result_ids;
+    uint32_t* result_ids; uint64_t result_ids_cap;
+};
+static void fill_grouped(const grouped_result_t& g, orc_grouped* out) {
+    out->n_groups = (uint32_t)std::min<size_t>(g.groups.size(), out->group_cap);
+    size_t at = 0;
+    for (uint32_t i = 0; i < out->n_groups; i++) {
+        const auto& v = g.groups[i];
+        out->group_size[i] = (uint32_t)v.size();
+        out->group_found[i] = g.group_found[i];
+        out->distinct_key[i] = v.empty() ? 0 : v[0].distinct_key;
+        for (const KV& kv : v) {
+            if (at >= out->kv_cap) break;
+            out->keys[at] = kv.key;
+            for (int j = 0; j < 3; j++) out->scores[at * 3 + j] = kv.scores[j];
+            at++;
+        }
+    }
+    out->groups_count = g.groups_count; out->groups_exact = g.groups_exact;
+    if (out->loglog) memcpy(out->loglog, g.loglog.data(), g.loglog.size());
+}
+int32_t orc_search_keyword_grouped(void* h, const orc_kw_query* q, const uint64_t* distinct_ids, const uint8_t* has_value, uint32_t n_distinct,
+                                   int32_t group_missing_values, uint32_t group_limit, int32_t first_pass, orc_grouped* out) {
+    std::vector<uint64_t> d(distinct_ids, distinct_ids + n_distinct);
+    std::vector<uint8_t> hv;
+    if (has_value) hv.assign(has_value, has_value + n_distinct);
+    grouped_result_t g;
+    std::vector<uint32_t> missing;
+    const keyword_result_t r = ((Index*)h)->search_keyword_grouped(to_query(q), d, hv, group_missing_values != 0, group_limit, first_pass != 0, g, &missing);
+    fill_grouped(g, out);
+    out->n_missing = missing.size();
+    if (out->missing_ids) std::copy(missing.begin(), missing.begin() + std::min<size_t>(missing.size(), out->missing_cap), out->missing_ids);
+    out->num_keyword_matches = r.num_keyword_matches;
+    out->n_result_ids = r.result_ids.size();
+    if (out->result_ids) std::copy(r.result_ids.begin(), r.result_ids.begin() + std::min<size_t>(r.result_ids.size(), out->result_ids_cap), out->result_ids);
+    return 0;
+}
+// the distinct Topster alone, fed a sequence of KVs (key, distinct_key, scores[3]) in order: what add() returned per KV + the collector's content
+int32_t orc_group_topster_run(uint32_t capacity, uint32_t distinct, int32_t first_pass, uint32_t n, const uint64_t* keys, const uint64_t* dkeys,
+                              const int64_t* scores, int32_t* ret_out, orc_grouped* out) {
+    GroupTopster t(capacity, distinct, first_pass != 0);
+    std::unordered_map<uint64_t, uint32_t> processed;
+    std::unordered_set<uint64_t> seen;
+    for (uint32_t i = 0; i < n; i++) {
+        KV kv(0, keys[i], dkeys[i], 0, scores + (size_t)i * 3);
+        const int r = t.add(&kv);
+        if (ret_out) ret_out[i] = r;
+        if (r < 2) processed[dkeys[i]]++;
+        seen.insert(dkeys[i]);
+    }
+    grouped_result_t g;
+    populate_grouped(t, processed, g);
+    g.groups_exact = seen.size();
+    fill_grouped(g, out);
+    return 0;
+}
+uint64_t orc_hash_wy(const void* key, uint64_t len) { return hash_wy(key, len); }
+uint64_t orc_hash_combine(uint64_t a, uint64_t b) { return hash_combine(a, b); }
+uint64_t orc_loglog_of_keys(const uint64_t* dkeys, uint64_t n, uint8_t* registers_out) {
+    LogLogBeta c;
+    for (uint64_t i = 0; i < n; i++) c.add(std::to_string(dkeys[i]));
+    if (registers_out) memcpy(registers_out, c.registers_.data(), c.registers_.size());
+    return c.cardinality();
+}
+uint64_t orc_loglog_cardinality(const uint8_t* registers) { return LogLogBeta::cardinality_of(registers); }
+// Index::get_distinct_id over n_fields facet hash indexes in CSR form (field f: doc d owns hashes[f][ptr[f][d] .. ptr[f][d+1]))
+void orc_distinct_ids(uint32_t n_docs, uint32_t n_fields, const uint64_t* const* ptr, const uint32_t* const* hashes, int32_t group_missing_values,
+                      uint64_t* distinct_out, uint8_t* has_value_out) {
+    std::vector<std::vector<uint32_t>> hs(n_fields);
+    for (uint32_t d = 0; d < n_docs; d++) {
+        for (uint32_t f = 0; f < n_fields; f++) hs[f].assign(hashes[f] + ptr[f][d], hashes[f] + ptr[f][d + 1]);
+        bool missing = false;
+        distinct_out[d] = distinct_id_of(d, hs, group_missing_values != 0, &missing);
+        if (has_value_out) has_value_out[d] = missing ? 0 : 1;
+    }
+}
+
 // decoded dump of one posting list (for building the GPU index from oracle-built postings in tests)
 // returns n ids; when buffers are null only sizes are reported
 uint32_t orc_dump_posting(void* h, uint32_t field, uint32_t term, uint32_t* ids, uint32_t* offset_index, uint32_t* offsets,

@@ -31,6 +31,7 @@
 #include <iterator>
 #include "token_or_iter.h"
 #include "topk_heap.h"
+#include "group_topster.h"
 
 namespace oracle {
 
@@ -527,6 +528,53 @@ public:
         search_across_fields(q, &topster, out);
         topster.sort();
         for (uint32_t i = 0; i < topster.size; i++) out.kvs.push_back(*topster.getKV(i));
+        return out;
+    }
+
+    // ---------------- group_by: search_across_fields with group_limit != 0 (index.cpp:5511-5520, 5546-5549) ----------------
+    // distinct_ids / has_value: per seq_id, what Index::get_distinct_id yields for the query's group_by fields and whether every field
+    // held a value (oracle::distinct_id_of computes both from the facet hashes; has_value only feeds missing_ids). One pass of the reference's two-pass protocol
+    // (Index::run_search, index.cpp:2488-2760): first_pass = the Topster keyed by distinct key + the LogLogBeta counter; else the
+    // second pass' group_kv_map followed by populate_result_kvs. missing_ids = group_by_missing_value_ids of a first pass.
+    keyword_result_t search_keyword_grouped(const keyword_query_t& q, const std::vector<uint64_t>& distinct_ids, const std::vector<uint8_t>& has_value,
+                                            bool group_missing_values, size_t group_limit, bool first_pass, grouped_result_t& gout,
+                                            std::vector<uint32_t>* missing_ids = nullptr) const {
+        keyword_result_t out;
+        GroupTopster topster(q.topster_size ? q.topster_size : topster_size(q.fetch_size, q.filter_ids.size()), group_limit, first_pass);
+        std::unordered_map<uint64_t, uint32_t> groups_processed;
+        std::unordered_set<uint64_t> seen;
+
+        std::vector<or_iterator_t> token_its;
+        std::vector<posting_list_t*> expanded_plists;
+        get_field_token_its(q, token_its, expanded_plists);
+        std::vector<or_iterator_t> dropped_token_its;
+        if (!q.dropped_tokens.empty()) get_field_token_its(q, dropped_token_its, expanded_plists, &q.dropped_tokens);
+        result_iter_state_t istate(q.excluded_ids.data(), q.excluded_ids.size(), q.filter_ids.data(), q.filter_ids.size());
+        deadline_t dl;
+        dl.search_begin_us = deadline_t::now_us();
+        dl.search_stop_us = q.search_stop_us;
+        or_iterator_t::intersect(token_its, istate, dl, [&](single_filter_result_t& fr, const std::vector<or_iterator_t>& its) {
+            const uint32_t seq_id = fr.seq_id;
+            const int64_t aggregated_score = compute_aggregated_score(its, q, seq_id, &dropped_token_its);
+            // distinct_ids[seq_id] = get_distinct_id's result (a document without any value: seq_id, or 1 with group_missing_values, :7105-7106, :7137-7139)
+            const uint64_t distinct_id = seq_id < distinct_ids.size() ? distinct_ids[seq_id] : (group_missing_values ? 1 : (uint64_t)seq_id);
+            const bool valued = seq_id < distinct_ids.size() && (has_value.empty() || has_value[seq_id]);
+            if (!valued && first_pass && missing_ids) missing_ids->push_back(seq_id);
+            int64_t scores[3] = {0, 0, 0};
+            int64_t match_score_index = -1;
+            compute_sort_scores(q.sort, seq_id, aggregated_score, scores, match_score_index, 0);
+            KV kv(0, seq_id, distinct_id, (int8_t)match_score_index, scores);
+            if (match_score_index != -1) { kv.scores[match_score_index] = aggregated_score; kv.text_match_score = aggregated_score; }
+            const int ret = topster.add(&kv);
+            if (ret < 2) groups_processed[distinct_id]++;                       // :5546-5549
+            seen.insert(distinct_id);
+            out.result_ids.push_back(seq_id);
+        });
+        out.num_keyword_matches = istate.num_keyword_matches;
+        out.search_cutoff = dl.search_cutoff;
+        for (auto* p : expanded_plists) delete p;
+        populate_grouped(topster, groups_processed, gout);
+        gout.groups_exact = seen.size();
         return out;
     }
 

@@ -43,6 +43,51 @@ class Result(C.Structure):
                 ("result_ids", C.POINTER(C.c_uint32)), ("result_ids_cap", C.c_uint64), ("search_cutoff", C.c_int32)]
 
 
+class Grouped(C.Structure):
+    _fields_ = [("group_cap", C.c_uint32), ("kv_cap", C.c_uint32), ("n_groups", C.c_uint32),
+                ("group_size", C.POINTER(C.c_uint32)), ("group_found", C.POINTER(C.c_uint32)), ("distinct_key", C.POINTER(C.c_uint64)),
+                ("keys", C.POINTER(C.c_uint64)), ("scores", C.POINTER(C.c_int64)),
+                ("groups_count", C.c_uint64), ("groups_exact", C.c_uint64), ("loglog", C.POINTER(C.c_uint8)),
+                ("missing_ids", C.POINTER(C.c_uint32)), ("missing_cap", C.c_uint64), ("n_missing", C.c_uint64),
+                ("num_keyword_matches", C.c_uint64), ("n_result_ids", C.c_uint64),
+                ("result_ids", C.POINTER(C.c_uint32)), ("result_ids_cap", C.c_uint64)]
+
+
+class GroupedHits:
+    """Decoded Grouped: groups in the collector's order; group g = keys[begin[g]:begin[g+1]] (+ scores rows), its distinct key and found count."""
+    def __init__(self, g, b):
+        n = g.n_groups
+        self.n_groups = n
+        self.group_size = b["gsize"][:n].copy()
+        self.group_found = b["gfound"][:n].copy()
+        self.distinct_key = b["dkey"][:n].copy()
+        self.begin = np.concatenate([[0], np.cumsum(self.group_size)]).astype(np.int64)
+        tot = int(self.begin[-1])
+        self.keys = b["keys"][:tot].copy()
+        self.scores = b["scores"][:tot * 3].reshape(tot, 3).copy()
+        self.groups_count, self.groups_exact = int(g.groups_count), int(g.groups_exact)
+        self.loglog = b["loglog"].copy()
+        self.missing_ids = b["missing"][:min(g.n_missing, g.missing_cap)].copy()
+        self.num_keyword_matches = int(g.num_keyword_matches)
+        self.result_ids = b["ids"][:min(g.n_result_ids, g.result_ids_cap)].copy()
+
+
+def _alloc_grouped(group_cap, kv_cap, ids_cap=0):
+    g = Grouped()
+    b = dict(gsize=np.zeros(group_cap, np.uint32), gfound=np.zeros(group_cap, np.uint32), dkey=np.zeros(group_cap, np.uint64),
+             keys=np.zeros(kv_cap, np.uint64), scores=np.zeros(kv_cap * 3, np.int64), loglog=np.zeros(16384, np.uint8),
+             missing=np.zeros(max(ids_cap, 1), np.uint32), ids=np.zeros(max(ids_cap, 1), np.uint32))
+    g.group_cap, g.kv_cap = group_cap, kv_cap
+    g.group_size = b["gsize"].ctypes.data_as(C.POINTER(C.c_uint32)); g.group_found = b["gfound"].ctypes.data_as(C.POINTER(C.c_uint32))
+    g.distinct_key = b["dkey"].ctypes.data_as(C.POINTER(C.c_uint64))
+    g.keys = b["keys"].ctypes.data_as(C.POINTER(C.c_uint64)); g.scores = b["scores"].ctypes.data_as(C.POINTER(C.c_int64))
+    g.loglog = b["loglog"].ctypes.data_as(C.POINTER(C.c_uint8))
+    if ids_cap:
+        g.missing_ids = b["missing"].ctypes.data_as(C.POINTER(C.c_uint32)); g.missing_cap = ids_cap
+        g.result_ids = b["ids"].ctypes.data_as(C.POINTER(C.c_uint32)); g.result_ids_cap = ids_cap
+    return g, b
+
+
 _lib = None
 
 
@@ -81,6 +126,18 @@ def lib():
         L.orc_flat_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_search_keyword.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.POINTER(Result)]
         L.orc_search_wildcard.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.POINTER(Result)]
+        L.orc_search_keyword_grouped.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, C.c_int32, C.POINTER(Grouped)]
+        L.orc_group_topster_run.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Grouped)]
+        L.orc_hash_wy.restype = C.c_uint64
+        L.orc_hash_wy.argtypes = [C.c_char_p, C.c_uint64]
+        L.orc_hash_combine.restype = C.c_uint64
+        L.orc_hash_combine.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_loglog_of_keys.restype = C.c_uint64
+        L.orc_loglog_of_keys.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_loglog_cardinality.restype = C.c_uint64
+        L.orc_loglog_cardinality.argtypes = [C.c_void_p]
+        L.orc_distinct_ids.restype = None
+        L.orc_distinct_ids.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.orc_search_candidates.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_uint32, C.POINTER(Result), C.c_void_p]
         L.orc_hnsw_build.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_hnsw_free.argtypes = [C.c_void_p]
@@ -148,6 +205,60 @@ def ref_match_lib():
     R.ref_match_score.restype = C.c_uint64
     R.ref_match_score.argtypes = [C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint32, C.c_uint32, C.c_uint8]
     return R
+
+
+_REF_TOPSTER = os.path.join(_DIR, "_ref", "libref_topster.so")
+
+
+def ref_topster_lib():
+    """oracle/_ref/libref_topster.so: the REFERENCE's own topster.h / loglogbeta.h / wyhash_v5.h (None if it was never built)."""
+    if not os.path.exists(_REF_TOPSTER):
+        return None
+    R = C.CDLL(_REF_TOPSTER)
+    R.ref_hash_wy.restype = C.c_uint64
+    R.ref_hash_wy.argtypes = [C.c_char_p, C.c_uint64]
+    R.ref_hash_combine.restype = C.c_uint64
+    R.ref_hash_combine.argtypes = [C.c_uint64, C.c_uint64]
+    R.ref_loglog_of_keys.restype = C.c_uint64
+    R.ref_loglog_of_keys.argtypes = [C.c_void_p, C.c_uint64]
+    R.ref_topster_run.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return R
+
+
+def group_topster_run(capacity, distinct, first_pass, keys, dkeys, scores):
+    """the restated distinct Topster fed (key, distinct_key, scores[3]) in order -> (add() return values, GroupedHits)"""
+    keys = np.ascontiguousarray(keys, np.uint64); dkeys = np.ascontiguousarray(dkeys, np.uint64); scores = np.ascontiguousarray(scores, np.int64)
+    n = keys.size
+    ret = np.zeros(max(n, 1), np.int32)
+    g, b = _alloc_grouped(max(n, 1), max(n, 1))
+    lib().orc_group_topster_run(capacity, distinct, int(first_pass), n, _ptr(keys), _ptr(dkeys), _ptr(scores), _ptr(ret), C.byref(g))
+    return ret[:n], GroupedHits(g, b)
+
+
+def ref_group_topster_run(R, capacity, distinct, first_pass, keys, dkeys, scores):
+    """the same through the reference's own Topster<KV> (ref_topster_lib()) -> (ret, group_size, distinct_key, keys, scores[n,3], groups_count)"""
+    keys = np.ascontiguousarray(keys, np.uint64); dkeys = np.ascontiguousarray(dkeys, np.uint64); scores = np.ascontiguousarray(scores, np.int64)
+    n = keys.size
+    cap = max(n, 1)
+    ret = np.zeros(cap, np.int32); gsize = np.zeros(cap, np.uint32); dk = np.zeros(cap, np.uint64); ok = np.zeros(cap, np.uint64); osc = np.zeros(cap * 3, np.int64)
+    ng = C.c_uint32(0); gc = C.c_uint64(0)
+    R.ref_topster_run(capacity, distinct, int(first_pass), n, _ptr(keys), _ptr(dkeys), _ptr(scores), _ptr(ret), cap, cap, C.byref(ng), _ptr(gsize), _ptr(dk),
+                      _ptr(ok), _ptr(osc), C.byref(gc))
+    tot = int(gsize[:ng.value].sum())
+    return ret[:n], gsize[:ng.value].copy(), dk[:ng.value].copy(), ok[:tot].copy(), osc[:tot * 3].reshape(tot, 3).copy(), int(gc.value)
+
+
+def distinct_ids(n_docs, fields, group_missing_values=False):
+    """Index::get_distinct_id per document over the group_by fields: fields = [(doc_ptr uint64[n_docs+1], hashes uint32[]), ...] (facet hash indexes, CSR)
+    -> (distinct uint64[n_docs], has_value uint8[n_docs])"""
+    ptrs = [np.ascontiguousarray(f[0], np.uint64) for f in fields]
+    hs = [np.ascontiguousarray(f[1] if len(f[1]) else [0], np.uint32) for f in fields]
+    pa = (C.c_void_p * len(fields))(*[p.ctypes.data for p in ptrs])
+    ha = (C.c_void_p * len(fields))(*[h.ctypes.data for h in hs])
+    out = np.zeros(n_docs, np.uint64); hv = np.zeros(n_docs, np.uint8)
+    lib().orc_distinct_ids(n_docs, len(fields), pa, ha, int(group_missing_values), _ptr(out), _ptr(hv))
+    return out, hv
 
 
 def _u32(a):
@@ -304,6 +415,15 @@ class OracleIndex:
         r, b = self._alloc(cap, ids_cap)
         self.L.orc_search_keyword(self.h, C.byref(q), C.byref(r))
         return self._decode(r, b)
+
+    def search_keyword_grouped(self, q, distinct, group_limit, first_pass, has_value=None, group_missing_values=False, group_cap=4096, kv_cap=65536, ids_cap=0):
+        """one pass of a group_by search (oracle_index.h search_keyword_grouped): distinct[seq_id] = get_distinct_id's result"""
+        d = np.ascontiguousarray(distinct, np.uint64)
+        hv = np.ascontiguousarray(has_value, np.uint8) if has_value is not None else None
+        g, b = _alloc_grouped(group_cap, kv_cap, ids_cap)
+        self.L.orc_search_keyword_grouped(self.h, C.byref(q), _ptr(d), _ptr(hv) if hv is not None else None, d.size, int(group_missing_values), group_limit,
+                                          int(first_pass), C.byref(g))
+        return GroupedHits(g, b)
 
     def search_wildcard(self, q, cap=1024, ids_cap=0):
         r, b = self._alloc(cap, ids_cap)

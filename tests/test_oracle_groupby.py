@@ -1,0 +1,119 @@
+"""oracle/group_topster.h (the restated distinct Topster, LogLogBeta, wyhash, hash_combine) against the reference.
+
+Pins: TopsterTest.DistinctIntValues (/root/reference/test/topster_test.cpp:181-262) as literal vectors, and — where oracle/_ref/libref_topster.so
+exists (compiled by oracle/Makefile from the reference's OWN include/topster.h, loglogbeta.h, wyhash_v5.h where they lie; it travels with the
+snapshot) — random KV streams through both collectors: add()'s return values, the first pass' heap array, the second pass' populate_result_kvs
+order, getGroupsCount(). Where _ref is missing the golden file tests/golden/group_topster_vectors.json (made from _ref by
+tests/golden/make_group_topster_vectors.py) stands in.
+"""
+import json
+import os
+import numpy as np
+import pytest
+from oracle import oracle_py as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "group_topster_vectors.json")
+
+# TopsterTest.DistinctIntValues: {query_index, distinct_key, match_score, primary_attr, secondary_attr}, key = i + 100
+DATA = [(0, 1, 11, 20, 30), (0, 1, 12, 20, 32), (0, 2, 4, 20, 30), (2, 3, 7, 20, 30), (0, 4, 14, 20, 30), (1, 5, 9, 20, 30), (1, 5, 10, 20, 32),
+        (1, 5, 9, 20, 30), (0, 6, 6, 20, 30), (2, 7, 6, 22, 30), (2, 7, 6, 22, 30), (1, 8, 9, 20, 30), (0, 9, 8, 20, 30), (3, 10, 5, 20, 30)]
+
+
+def _distinct_int_values():
+    return [i + 100 for i in range(14)], [d[1] for d in DATA], [[d[2], d[3], d[4]] for d in DATA]
+
+
+def test_distinct_int_values_first_pass_golden():
+    keys, dk, sc = _distinct_int_values()
+    ret, g = O.group_topster_run(7, 2, True, keys, dk, sc)
+    # topster_test.cpp:249-258: the heap array as it lies (sort() is a no-op), group_kv_map empty, loglog cardinality 10
+    assert list(g.distinct_key) == [7, 5, 3, 4, 1, 9, 8]
+    assert list(g.keys) == [110, 106, 103, 104, 101, 112, 111]
+    assert g.groups_count == 10 and g.groups_exact == 10
+
+
+def test_distinct_int_values_second_pass_golden():
+    keys, dk, sc = _distinct_int_values()
+    ret, g = O.group_topster_run(5, 2, False, keys, dk, sc)
+    # topster_test.cpp:217-235: group 1 holds {12, 11}, group 5 holds {10, 9}; every KV goes to its group's Topster (the outer heap stays empty)
+    groups = {int(g.distinct_key[i]): (list(g.keys[g.begin[i]:g.begin[i + 1]]), list(g.scores[g.begin[i]:g.begin[i + 1], 0])) for i in range(g.n_groups)}
+    assert groups[1] == ([101, 100], [12, 11])
+    assert groups[5][1] == [10, 9] and groups[5][0][0] == 106
+    # populate_result_kvs: the five best groups by their head, best first
+    assert list(g.distinct_key) == [4, 1, 5, 8, 9]
+    assert list(ret) == [1] * 14
+
+
+def _random_stream(rng, n, n_groups, score_range, dup_keys):
+    dk = rng.integers(0, n_groups, n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1)
+    if dup_keys:
+        keys = rng.integers(0, max(2, n // 2), n).astype(np.uint64)
+        # a document belongs to ONE group: derive the group from the key
+        dk = (keys % np.uint64(n_groups)) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1)
+    else:
+        keys = rng.permutation(n * 3)[:n].astype(np.uint64)
+    sc = rng.integers(-score_range, score_range + 1, (n, 3)).astype(np.int64)
+    return keys, dk, sc
+
+
+def _compare(R, cap, distinct, first_pass, keys, dk, sc):
+    ret, g = O.group_topster_run(cap, distinct, first_pass, keys, dk, sc)
+    rret, gsize, rdk, rkeys, rsc, rcount = O.ref_group_topster_run(R, cap, distinct, first_pass, keys, dk, sc)
+    assert np.array_equal(ret, rret)
+    assert np.array_equal(g.group_size, gsize) and np.array_equal(g.distinct_key, rdk)
+    assert np.array_equal(g.keys, rkeys) and np.array_equal(g.scores, rsc)
+    if first_pass:
+        assert g.groups_count == rcount
+
+
+def test_group_topster_equals_reference_topster_on_random_streams():
+    R = O.ref_topster_lib()
+    if R is None:
+        pytest.skip("oracle/_ref/libref_topster.so not built (no /root/reference here); the golden file covers it")
+    rng = np.random.default_rng(5)
+    n_cases = 0
+    for cap in (1, 2, 5, 16, 250):
+        for distinct in (1, 2, 3, 7):
+            for first_pass in (True, False):
+                for n, n_groups, rng_s, dup in ((0, 1, 1, False), (1, 1, 1, False), (30, 4, 2, False), (200, 40, 3, False), (200, 500, 1000, False),
+                                                (1500, 300, 5, False), (300, 30, 2, True)):
+                    keys, dk, sc = _random_stream(rng, n, n_groups, rng_s, dup)
+                    _compare(R, cap, distinct, first_pass, keys, dk, sc)
+                    n_cases += 1
+    assert n_cases == 5 * 4 * 2 * 7
+
+
+def test_wyhash_loglog_hash_combine_equal_reference():
+    R = O.ref_topster_lib()
+    L = O.lib()
+    rng = np.random.default_rng(2)
+    if R is not None:
+        for n in list(range(0, 70)) + [127, 128, 129, 200]:
+            for _ in range(10):
+                s = bytes(int(x) for x in rng.integers(1, 256, n))
+                assert L.orc_hash_wy(s, len(s)) == R.ref_hash_wy(s, len(s))
+        for _ in range(1000):
+            a, b = int(rng.integers(0, 2**63)) * 2 + 1, int(rng.integers(0, 2**63))
+            assert L.orc_hash_combine(a, b) == R.ref_hash_combine(a, b)
+        for n in (0, 1, 10, 1000, 20000, 200000):
+            dk = rng.integers(0, 2**63, n).astype(np.uint64)
+            assert L.orc_loglog_of_keys(dk.ctypes.data, n, None) == R.ref_loglog_of_keys(dk.ctypes.data, n)
+    # known answers (made from _ref by tests/golden/make_group_topster_vectors.py): the decimal strings the first pass hashes
+    gold = json.load(open(GOLD))
+    for s, h in gold["hash_wy"]:
+        assert L.orc_hash_wy(s.encode(), len(s)) == int(h)
+    for a, b, h in gold["hash_combine"]:
+        assert L.orc_hash_combine(int(a), int(b)) == int(h)
+
+
+def test_group_topster_golden_file():
+    gold = json.load(open(GOLD))
+    for case in gold["streams"]:
+        keys = np.array(case["keys"], np.uint64); dk = np.array([int(x) for x in case["dkeys"]], np.uint64); sc = np.array(case["scores"], np.int64).reshape(-1, 3)
+        ret, g = O.group_topster_run(case["capacity"], case["distinct"], case["first_pass"], keys, dk, sc)
+        assert list(ret) == case["ret"]
+        assert [int(x) for x in g.group_size] == case["group_size"] and [str(int(x)) for x in g.distinct_key] == case["distinct_key"]
+        assert [int(x) for x in g.keys] == case["out_keys"]
+        if case["first_pass"]:
+            assert g.groups_count == case["groups_count"]
