@@ -759,6 +759,71 @@ class Bench:
             cand["parity"] = {"checked": npar, "mismatches": bad, "what": "shared Topster (keys, 3 scores, order), query_index of every hit and found vs the oracle's search_all_candidates at %d docs" % self.n_docs}
             orc.close()
         res["candidate_combinations"] = cand
+
+        # ---- (iii) group_by: the distinct Topster (tsgpu_keyword_search_grouped_batch) — both passes of Index::run_search's two-pass protocol ----
+        n_u = max(8, (args.batch or 10_000) // 10)
+        gtok = synth.keyword_queries(n_u, 3, 8, 2000, seed=51)
+        ids64 = np.arange(self.n_docs, dtype=np.uint64)
+        n_grp = max(16, self.n_docs // 200)
+        distinct = (((ids64 * np.uint64(2654435761)) % np.uint64(n_grp)) * np.uint64(0x100000001B3) + np.uint64(0x517cc1b727220a95)).astype(np.uint64)   # ~n_docs/200 groups
+        g.column_set(7, distinct.view(np.int64))
+        gqs = [self.T.KwQuery(gtok[i], sort=self.sort, topster_size=K_TOPSTER) for i in range(n_u)]
+        garr = self.T.index.make_query_array(gqs)
+        gl = 3                                                        # group_limit default of the reference
+        first = (B.GroupByC * n_u)()
+        second = (B.GroupByC * n_u)()
+        for i in range(n_u):
+            first[i].group_limit = second[i].group_limit = gl
+            first[i].column = second[i].column = 7
+            first[i].first_pass = 1
+        h1, g1 = self.T.Hits(n_u, K_TOPSTER), self.T.GroupedHits(n_u, K_TOPSTER)
+        h2, g2 = self.T.Hits(n_u, K_TOPSTER * gl), self.T.GroupedHits(n_u, K_TOPSTER)
+        c1, cg1, c2, cg2 = h1.c_struct(), g1.c_struct(), h2.c_struct(), g2.c_struct()
+
+        def step_g():
+            g._ck(g.L.tsgpu_keyword_search_grouped_batch(g.h, garr, first, n_u, C.byref(c1), C.byref(cg1), None))
+            g._ck(g.L.tsgpu_keyword_search_grouped_batch(g.h, garr, second, n_u, C.byref(c2), C.byref(cg2), None))
+            return None
+        el, lat, _ = timed(step_g, steps, 2, 1)
+        grp = {"workload": "%d user queries/step, each as the reference runs a group_by request: a FIRST pass (distinct Topster keyed by group, LogLogBeta group count) and a SECOND "
+                           "pass (group_limit %d KVs per group, populate_result_kvs order); 3 distinct terms (ranks log-uniform [8,2000]), %d groups over %d documents, Topster 250; host "
+                           "outputs" % (n_u, gl, n_grp, self.n_docs),
+               "value": n_u * steps / el, "unit": "grouped user queries/s (two passes each)", "ms_per_step": 1e3 * el / steps, "matched_ids_per_step": int(h2.num_matched.sum()),
+               "groups_returned_per_query": float(g2.n_groups.mean()), "queries_with_hits": int((h2.n_hits > 0).sum()), "status_nonzero": int((h2.status != 0).sum() + (h1.status != 0).sum())}
+        if not args.no_cpu_baseline:
+            npar = min(n_u, 8)
+            orc = O.OracleIndex(1, 1)
+            orc.set_num_docs(self.n_docs)
+            orc.set_sort_dense(0, self.pts)
+            for t in np.unique(gtok[:npar]):
+                ids, oi, off = synth.csr_term(self.csr, t)
+                if ids.size:
+                    orc.load_posting(0, int(t), ids, oi, off)
+            bad = 0
+            t_cpu = 0.0
+            for i in range(npar):
+                oq = orc.make_query(gtok[i], sort=osort, fetch_size=100)
+                tc = time.time()
+                r1 = orc.search_keyword_grouped(oq, distinct, gl, True)
+                r2 = orc.search_keyword_grouped(oq, distinct, gl, False)
+                t_cpu += time.time() - tc
+                n1, n2 = int(g1.n_groups[i]), int(g2.n_groups[i])
+                want1 = sorted(zip(r1.scores[:, 0].tolist(), r1.scores[:, 1].tolist(), r1.scores[:, 2].tolist(), r1.keys.tolist(), r1.distinct_key.tolist(), r1.group_found.tolist()), reverse=True)
+                got1 = list(zip(h1.scores[i, :n1, 0].tolist(), h1.scores[i, :n1, 1].tolist(), h1.scores[i, :n1, 2].tolist(), h1.keys[i, :n1].tolist(), g1.distinct_key[i, :n1].tolist(),
+                                g1.group_found[i, :n1].tolist()))
+                ok = n1 == r1.n_groups and got1 == want1 and int(g1.groups_count[i]) == r1.groups_count and int(g1.groups_total[i]) == r1.groups_exact
+                ok = ok and n2 == r2.n_groups and np.array_equal(g2.distinct_key[i, :n2], r2.distinct_key) and np.array_equal(g2.group_found[i, :n2], r2.group_found) \
+                    and np.array_equal(g2.group_size[i, :n2], r2.group_size) and int(h2.num_matched[i]) == r2.num_keyword_matches
+                for r in range(n2 if ok else 0):
+                    a, b = int(r2.begin[r]), int(r2.begin[r + 1])
+                    ok = ok and np.array_equal(h2.keys[i, r * gl:r * gl + b - a], r2.keys[a:b]) and np.array_equal(h2.scores[i, r * gl:r * gl + b - a], r2.scores[a:b])
+                bad += 0 if ok else 1
+            grp["parity"] = {"checked": npar, "mismatches": bad, "what": "first pass: the groups' greatest KVs (as a set), groups_processed, getGroupsCount (LogLogBeta), distinct-key count; second pass: "
+                                                                        "group order, every KV of every group, group sizes, groups_processed vs the oracle's distinct Topster at %d docs" % self.n_docs}
+            grp["cpu_baseline"] = {"value": npar / t_cpu if t_cpu > 0 else None, "unit": "grouped user queries/s (two passes each)", "cores": 1, "kind": "port",
+                                   "sample": "%d of the step's queries, both passes, oracle/oracle_index.h search_keyword_grouped on one core" % npar}
+            orc.close()
+        res["group_by"] = grp
         return res
 
     def concurrency_keyword(self, arr, n_q, keys, scores, n_hits, num_matched):

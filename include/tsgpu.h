@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define TSGPU_ABI_VERSION 5
+#define TSGPU_ABI_VERSION 6
 #define TSGPU_MAX_DROPPED_TOKENS 4
 
 /* limits of the accelerated path (anything beyond -> TSGPU_ERR_UNSUPPORTED for that query) */
@@ -323,6 +323,53 @@ void tsgpu_id_lists_free(tsgpu_id_lists* lists);
 int tsgpu_keep_result_ids(tsgpu_ctx* ctx, int keep);
 uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64_t cap);
 
+/* ------------------------------------------------------------------ group_by: the DISTINCT Topster */
+/* One pass of the reference's two-pass grouped search (Index::run_search, src/index.cpp:2488-2760) through search_across_fields with
+ * group_limit != 0 (src/index.cpp:5511-5520, 5546-5549) — or Index::search_wildcard's grouped loop (:6736-6760) — into
+ * Topster(capacity, distinct = group_limit, is_group_by_first_pass) (include/topster.h:266-296, add :321-466) and, for the second
+ * pass, populate_result_kvs' grouped branch (src/index.cpp:8962-9011).
+ *   column: a column set with tsgpu_column_set(ctx, column, values, NULL, n, mem) whose values[seq_id] are the bits of the uint64
+ *     Index::get_distinct_id yields for the request's group_by fields (src/index.cpp:7100-7142: hash_combine over the fields' facet
+ *     hashes; a document without any value: its seq_id, or 1 with group_missing_values) — the server computes it once per
+ *     (collection, group_by fields, group_missing_values) from facet_index_v4's hash indexes (host helper: tsgpu_groupby_shim.h). A
+ *     seq_id >= n has no value. (With SEVERAL group_by fields the reference's result for a document that lies beyond the last id of
+ *     a later field's hash index depends on which documents the query visited before — its iterator is then already exhausted,
+ *     :7104-7111 —; the column holds the value of a fresh iterator.)
+ *   first_pass = 1: out holds ONE hit per group — the group's greatest KV — for the topster_size groups with the greatest such
+ *     KVs, best first (the reference's heap holds the same KVs in heap-array order; its consumers read them as a set:
+ *     Index::get_group_by_values, src/index.cpp:7144-7170). groups_count = Topster::getGroupsCount() = the LogLogBeta estimate over
+ *     every distinct key of the pass (include/loglogbeta.h; the registers themselves on request: mergeGroupsCount).
+ *   first_pass = 0: the groups populate_result_kvs returns, best head first; group r's KVs — the group Topster's content in sort()
+ *     order, group_size[r] <= group_limit of them — occupy hit slots [r * group_limit, r * group_limit + group_size[r]) of the query;
+ *     out->k_stride >= topster_size * group_limit. n_hits = the sum of the group sizes.
+ *   group_found = groups_processed[distinct_key] (:5546-5549: the group's matched documents); groups_total = the exact number of
+ *     distinct keys among the matched documents (not a reference quantity).
+ *   wildcard = 1: q = "*" (only sort / topster_size / excluded_ids / filter_ids of the query are read, as in tsgpu_wildcard_search_batch).
+ * `sort_by: _group_found` (the count-min sketch, include/topster.h:327-340), curated hits and Union_KV are not covered: 501.
+ * out and gout are HOST arrays. ids_out (nullable): the matched ids of every query (all_result_ids; group_by_missing_value_ids = those
+ * of them without a value: the caller knows which). The call holds the context's index lock like a search holds Index::mutex. */
+#define TSGPU_MAX_GROUP_LIMIT 256
+typedef struct tsgpu_group_by {
+    uint32_t group_limit;            /* Topster's `distinct`, 1..TSGPU_MAX_GROUP_LIMIT */
+    uint16_t column;                 /* distinct-key column */
+    uint8_t first_pass;              /* is_group_by_first_pass */
+    uint8_t group_missing_values;    /* distinct key of a seq_id beyond the column: 1 (true) or the seq_id (false) */
+    uint8_t wildcard;                /* the query is q = "*" */
+    uint8_t pad[3];
+} tsgpu_group_by;
+typedef struct tsgpu_grouped_hits {
+    uint32_t g_stride;               /* group slots per query (>= the largest topster_size of the batch) */
+    uint32_t* n_groups;              /* [n_queries] groups returned */
+    uint64_t* distinct_key;          /* [n_queries * g_stride] */
+    uint32_t* group_size;            /* [n_queries * g_stride] KVs of the group in out (first pass: 1) */
+    uint32_t* group_found;           /* [n_queries * g_stride] */
+    uint64_t* groups_total;          /* [n_queries], nullable */
+    uint64_t* groups_count;          /* [n_queries], nullable: first pass = LogLogBeta::cardinality(); second pass 0 */
+    uint8_t* loglog_registers;       /* [n_queries * 16384], nullable: the first pass' sketch registers */
+} tsgpu_grouped_hits;
+int tsgpu_keyword_search_grouped_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries,
+                                       tsgpu_hits* out, tsgpu_grouped_hits* gout, tsgpu_id_lists** ids_out);
+
 /* ------------------------------------------------------------------ facet counting over matched ids */
 /* The hash-index branch of Index::do_facets (src/index.cpp:1659-1771): for every matched id (ascending, e.g. the id list of
  * tsgpu_keyword_search_batch_ids) the field's facet hash index (facet_index_v4's hash index, a posting list seq_id -> value hashes)
@@ -334,7 +381,7 @@ uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64
  *     ids at positions i % sample_mod == 0, :1683-1687); allowed_hashes (sorted, NULL = all) = fquery_hashes of a facet query (:1742).
  *     out: [n_queries][cap] in ascending hash order; n_values[q] = distinct values found (may exceed cap: the first cap are returned).
  * Facet stats (tsgpu_facet_stats_batch) and the value-index ("intersect") branch (tsgpu_facet_value_set / tsgpu_facet_value_count_batch) follow below.
- * Not covered (the caller keeps its CPU body): group_by (hash_groups) and range facets. */
+ * Not covered (the caller keeps its CPU body): the facets' own group_by (hash_groups) and range facets. */
 typedef struct tsgpu_facet_counts {
     uint32_t cap;            /* slots per query */
     uint32_t* hash;          /* [n_queries * cap] facet value hash */

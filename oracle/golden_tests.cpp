@@ -431,6 +431,42 @@ static void test_topster() {
 }
 
 // ---------- end-to-end text_match values ----------
+// ---------- test/topster_test.cpp:181-262 (TopsterTest.DistinctIntValues): the group_by forms of the collector ----------
+static void test_distinct_topster() {
+    struct { uint16_t qi; uint64_t dk; uint64_t ms; int64_t p, s; } data[14] = {
+        {0, 1, 11, 20, 30}, {0, 1, 12, 20, 32}, {0, 2, 4, 20, 30}, {2, 3, 7, 20, 30}, {0, 4, 14, 20, 30}, {1, 5, 9, 20, 30}, {1, 5, 10, 20, 32},
+        {1, 5, 9, 20, 30}, {0, 6, 6, 20, 30}, {2, 7, 6, 22, 30}, {2, 7, 6, 22, 30}, {1, 8, 9, 20, 30}, {0, 9, 8, 20, 30}, {3, 10, 5, 20, 30}};
+    {   // second pass: Topster<KV> dist_topster(5, 2, false) — every KV lands in its group's Topster, the outer heap stays empty (:182-236)
+        GroupTopster t(5, 2, false);
+        for (int i = 0; i < 14; i++) { int64_t sc[3] = {(int64_t)data[i].ms, data[i].p, data[i].s}; KV kv(data[i].qi, (uint64_t)i + 100, data[i].dk, 0, sc); CHECK_EQ(t.add(&kv), 1); }
+        t.sort();
+        CHECK_EQ(t.size, 0u);
+        CHECK_EQ(t.group_kv_map.size(), (size_t)10);
+        for (auto& g : t.group_kv_map) g.second->sort();
+        CHECK_EQ(t.group_kv_map[1]->size, 2u); CHECK_EQ(t.group_kv_map[1]->getKV(0)->scores[0], 12); CHECK_EQ(t.group_kv_map[1]->getKV(1)->scores[0], 11);
+        CHECK_EQ(t.group_kv_map[5]->size, 2u); CHECK_EQ(t.group_kv_map[5]->getKV(0)->scores[0], 10); CHECK_EQ(t.group_kv_map[5]->getKV(1)->scores[0], 9);
+        // populate_result_kvs (src/index.cpp:8962-9011) over it: the five best groups by their head
+        std::unordered_map<uint64_t, uint32_t> processed;
+        for (int i = 0; i < 14; i++) processed[data[i].dk]++;
+        grouped_result_t out;
+        populate_grouped(t, processed, out);
+        const uint64_t order[5] = {4, 1, 5, 8, 9};
+        CHECK_EQ(out.groups.size(), (size_t)5);
+        for (size_t i = 0; i < out.groups.size() && i < 5; i++) CHECK_EQ(out.groups[i][0].distinct_key, order[i]);
+        CHECK_EQ(out.group_found[2], 3u);
+    }
+    {   // first pass: Topster<KV> dist_topster_first_pass(7, 2, true) — the heap array as it lies + the loglog cardinality (:238-261)
+        GroupTopster t(7, 2, true);
+        for (int i = 0; i < 14; i++) { int64_t sc[3] = {(int64_t)data[i].ms, data[i].p, data[i].s}; KV kv(data[i].qi, (uint64_t)i + 100, data[i].dk, 0, sc); t.add(&kv); }
+        t.sort();
+        const uint64_t distinct_ids[7] = {7, 5, 3, 4, 1, 9, 8}, ids[7] = {110, 106, 103, 104, 101, 112, 111};
+        CHECK_EQ(t.size, 7u);
+        for (uint32_t i = 0; i < t.size && i < 7; i++) { CHECK_EQ(t.kvs[i]->distinct_key, distinct_ids[i]); CHECK_EQ(t.kvs[i]->key, ids[i]); }
+        CHECK(t.group_kv_map.empty());
+        CHECK_EQ(t.loglog_counter->cardinality(), (uint64_t)10);
+    }
+}
+
 static void test_text_scores() {
     // vocabulary ids: nike=1 running=2 shoes=3 x=4 mong=5 spencer=6
     {   // test/collection_vector_search_test.cpp:5462-5497 text_match constants (1 field, weight 15, max_score)
@@ -766,6 +802,7 @@ int main(int argc, char** argv) {
     test_or_iterator();
     test_match();
     test_topster();
+    test_distinct_topster();
     test_text_scores();
     test_vectors();
     test_vector_reference_pins();

@@ -327,6 +327,9 @@ inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 inline int __ffs(int x) { return __builtin_ffs(x); }
+inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
+inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
 template <class T> inline T __shfl(T v, int lane, int = 64) { return hipemu::shfl(v, lane); }
 template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return hipemu::shfl(v, (int)(hipemu::cur_lane() ^ (unsigned)mask)); }
 template <class T> inline T __shfl_down(T v, unsigned d, int = 64) { unsigned s = hipemu::cur_lane() + d; return hipemu::shfl(v, s < 64 ? (int)s : (int)hipemu::cur_lane()); }

@@ -12,9 +12,14 @@
 
 #include "../../include/tsgpu.h"
 #include "../../typesense_amd/csrc/host/tsgpu_keyword_shim.h"
+#include "../../typesense_amd/csrc/host/tsgpu_groupby_shim.h"
 #include "../../typesense_amd/csrc/host/tsgpu_hnsw_adaptor.h"
 #include "../../typesense_amd/csrc/host/tsgpu_posting_shim.h"
 #include "../../oracle/topk_heap.h"
+#include "../../oracle/group_topster.h"
+#include <set>
+#include <tuple>
+#include <unordered_map>
 
 static int n_checks = 0;
 #define CHECK(c, ...) do { n_checks++; if (!(c)) { fprintf(stderr, "FAILED %s:%d: %s — ", __FILE__, __LINE__, #c); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); exit(1); } } while (0)
@@ -189,6 +194,71 @@ int main(int argc, char** argv) {
         size_t nkm = 123; bool cutoff = false;
         CHECK((tsgpu::search_across_fields_gpu<oracle::KV, oracle::Topster>(a, &topster, id_buff, nkm, cutoff)) == TSGPU_ERR_UNSUPPORTED, "501 expected");
         CHECK(topster.size == 0 && id_buff.empty() && nkm == 123, "a 501 query must not touch the caller's state");
+    }
+
+    // ---------------- B1, grouped: build_distinct_column + search_across_fields_grouped_gpu<KV, Topster, groups_processed> ----------------
+    {
+        Reader r(dir + "/grouped.bin");
+        const uint32_t n_docs = r.get<uint32_t>();
+        const std::vector<uint64_t> doc_ptr = r.vec<uint64_t>((size_t)n_docs + 1);
+        const std::vector<uint32_t> hashes = r.vec<uint32_t>(r.get<uint32_t>());
+        const std::vector<uint64_t> want_distinct = r.vec<uint64_t>(n_docs);
+        std::vector<int64_t> column; std::vector<uint8_t> has_value;
+        tsgpu::build_distinct_column(n_docs, {doc_ptr.data()}, {hashes.data()}, false, column, has_value);
+        CHECK(memcmp(column.data(), want_distinct.data(), (size_t)n_docs * 8) == 0, "build_distinct_column vs Index::get_distinct_id (oracle)");
+        CHECK(tsgpu_column_set(ctx, 5, column.data(), nullptr, n_docs, TSGPU_MEM_HOST) == TSGPU_OK, "%s", tsgpu_last_error());
+        const uint32_t n_cases = r.get<uint32_t>();
+        for (uint32_t c = 0; c < n_cases; c++) {
+            tsgpu::GroupByShimArgs a;
+            a.ctx = ctx; a.query_index = 3; a.has_value = has_value.data(); a.n_has_value = n_docs;
+            a.query.n_tokens = r.get<uint32_t>();
+            const std::vector<uint32_t> toks = r.vec<uint32_t>(a.query.n_tokens);
+            for (uint32_t i = 0; i < a.query.n_tokens; i++) a.query.term_ids[i] = toks[i];
+            a.query.n_fields = 1; a.query.field_ids[0] = 0; a.query.field_weights[0] = 15;
+            a.query.match_type = TSGPU_MAX_SCORE; a.query.prioritize_exact_match = 1; a.query.prioritize_num_matching_fields = 1;
+            a.query.n_sort = 2;
+            a.query.sort[0].kind = TSGPU_SORT_TEXT_MATCH; a.query.sort[0].order = 1;
+            a.query.sort[1].kind = TSGPU_SORT_INT64_COLUMN; a.query.sort[1].order = 1; a.query.sort[1].column = 0;
+            a.query.topster_size = r.get<uint32_t>();
+            a.group.group_limit = r.get<uint32_t>(); a.group.first_pass = (uint8_t)r.get<uint32_t>(); a.group.column = 5;
+            const uint32_t want_groups = r.get<uint32_t>();
+            std::vector<std::tuple<int64_t, int64_t, int64_t, uint64_t, uint64_t, uint32_t>> want;      // per KV: scores, key, distinct key, group found
+            std::vector<uint32_t> want_size(want_groups);
+            for (uint32_t g = 0; g < want_groups; g++) {
+                const uint64_t dk = r.get<uint64_t>(); const uint32_t found = r.get<uint32_t>(); want_size[g] = r.get<uint32_t>();
+                const std::vector<uint64_t> keys = r.vec<uint64_t>(want_size[g]); const std::vector<int64_t> sc = r.vec<int64_t>((size_t)want_size[g] * 3);
+                for (uint32_t j = 0; j < want_size[g]; j++) want.emplace_back(sc[j * 3], sc[j * 3 + 1], sc[j * 3 + 2], keys[j], dk, found);
+            }
+            const uint64_t want_count = r.get<uint64_t>();
+            const std::vector<uint32_t> want_missing = r.vec<uint32_t>(r.get<uint32_t>());
+            const uint64_t want_matched = r.get<uint64_t>();
+
+            oracle::GroupTopster topster(a.query.topster_size, a.group.group_limit, a.group.first_pass != 0);      // stands in for Topster<KV>(capacity, distinct, first_pass)
+            std::unordered_map<uint64_t, uint32_t> groups_processed;
+            std::vector<uint32_t> id_buff;
+            std::set<uint32_t> missing;
+            size_t nkm = 0; bool cutoff = false;
+            const int rc = tsgpu::search_across_fields_grouped_gpu<oracle::KV>(a, &topster, groups_processed, id_buff, nkm, cutoff, &missing);
+            CHECK(rc == TSGPU_OK, "grouped case %u: rc %d %s", c, rc, tsgpu_last_error());
+            oracle::grouped_result_t got;
+            oracle::populate_grouped(topster, groups_processed, got);                                             // populate_result_kvs over the caller's Topster
+            CHECK(got.groups.size() == want_groups, "grouped case %u: %zu groups, oracle %u", c, got.groups.size(), want_groups);
+            std::vector<std::tuple<int64_t, int64_t, int64_t, uint64_t, uint64_t, uint32_t>> have;
+            for (size_t g = 0; g < got.groups.size(); g++) {
+                for (const auto& kv : got.groups[g]) {
+                    have.emplace_back(kv.scores[0], kv.scores[1], kv.scores[2], kv.key, kv.distinct_key, got.group_found[g]);
+                    CHECK(kv.query_index == 3 && kv.text_match_score == kv.scores[0], "grouped case %u: KV fields", c);
+                }
+                if (!a.group.first_pass) CHECK(got.groups[g].size() == want_size[g], "grouped case %u group %zu: size", c, g);
+            }
+            if (a.group.first_pass) { std::sort(have.begin(), have.end()); std::sort(want.begin(), want.end()); }    // the first pass' heap is read as a set
+            CHECK(have == want, "grouped case %u (first_pass %u): groups / KVs differ from the oracle", c, (unsigned)a.group.first_pass);
+            if (a.group.first_pass) {
+                CHECK(topster.getGroupsCount() == want_count, "grouped case %u: getGroupsCount %zu vs %llu", c, topster.getGroupsCount(), (unsigned long long)want_count);
+                CHECK(std::vector<uint32_t>(missing.begin(), missing.end()) == want_missing, "grouped case %u: group_by_missing_value_ids", c);
+            }
+            CHECK(nkm == want_matched, "grouped case %u: num_keyword_matches", c);
+        }
     }
 
     // ---------------- B2: the hnswlib-shaped adaptor ----------------

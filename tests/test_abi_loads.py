@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported(lib):
     raw = C.CDLL(so)
     missing = [s for s in sorted(declared) if not hasattr(raw, s)]
     assert not missing, missing
-    assert L.tsgpu_abi_version() == 5
+    assert L.tsgpu_abi_version() == 6
 
 
 def test_binding_covers_the_header(lib):

@@ -1,0 +1,232 @@
+"""group_by (tsgpu_keyword_search_grouped_batch: kw_groupby.hip.h + tsgpu_groupby.inc.h) executed on the CPU under the SIMT emulator of
+tests/hipemu and checked against the oracle's restated distinct Topster (oracle/group_topster.h, itself pinned to the reference's own
+topster.h: tests/test_oracle_groupby.py). Same sources as libtsgpu.so. The `-m gpu` twin is tests/test_gpu_groupby.py."""
+import numpy as np
+import pytest
+
+import typesense_amd as T
+from typesense_amd import _lib as B
+from oracle import oracle_py as O
+from tests import helpers as H
+
+GROUP_COL = 1
+
+
+def group_column(n_docs, seed, n_values=37, missing_every=11, two_fields=False, group_missing_values=False):
+    """facet hashes of one (or two) group_by fields -> (distinct uint64[n_docs], has_value): Index::get_distinct_id per document"""
+    rng = np.random.default_rng(seed)
+    fields = []
+    for f in range(2 if two_fields else 1):
+        ptr = np.zeros(n_docs + 1, np.uint64)
+        hs = []
+        for d in range(n_docs):
+            if missing_every and d % missing_every == f:
+                pass                                                  # no value in this field
+            elif f == 1 and d % 5 == 0:
+                hs += [int(x) for x in rng.integers(1, 9, 2)]         # an array field: two hashes
+            else:
+                hs.append(int(rng.integers(1, n_values + 1)) * 2654435761 % (2**32))
+            ptr[d + 1] = len(hs)
+        fields.append((ptr, np.array(hs, np.uint32)))
+    return O.distinct_ids(n_docs, fields, group_missing_values)
+
+
+def sort_key_rows(keys, scores):
+    return sorted([(int(s[0]), int(s[1]), int(s[2]), int(k)) for k, s in zip(keys, scores)], reverse=True)
+
+
+def check_query(h, gh, i, ref, first_pass, group_limit, what=""):
+    assert int(h.status[i]) == 0, (what, h.status[i])
+    ng = int(gh.n_groups[i])
+    assert ng == ref.n_groups, "%s q%d: %d groups vs oracle %d" % (what, i, ng, ref.n_groups)
+    assert int(gh.groups_total[i]) == ref.groups_exact, what
+    assert int(h.num_matched[i]) == ref.num_keyword_matches, what
+    if first_pass:
+        # the reference keeps these KVs in heap-array order and reads them as a set; the library returns them best first
+        want = sorted([(int(ref.scores[j, 0]), int(ref.scores[j, 1]), int(ref.scores[j, 2]), int(ref.keys[j]), int(ref.distinct_key[j]), int(ref.group_found[j]))
+                       for j in range(ref.n_groups)], reverse=True)
+        got = [(int(h.scores[i, r, 0]), int(h.scores[i, r, 1]), int(h.scores[i, r, 2]), int(h.keys[i, r]), int(gh.distinct_key[i, r]), int(gh.group_found[i, r]))
+               for r in range(ng)]
+        assert got == want, "%s q%d first pass\n%s\n%s" % (what, i, got[:5], want[:5])
+        assert int(h.n_hits[i]) == ng and (gh.group_size[i, :ng] == 1).all()
+        assert int(gh.groups_count[i]) == ref.groups_count, (what, gh.groups_count[i], ref.groups_count)
+        if gh.loglog_registers is not None:
+            assert np.array_equal(gh.loglog_registers[i], ref.loglog), what
+    else:
+        assert np.array_equal(gh.distinct_key[i, :ng], ref.distinct_key), "%s q%d: group order\n%s\n%s" % (what, i, gh.distinct_key[i, :ng][:8], ref.distinct_key[:8])
+        assert np.array_equal(gh.group_found[i, :ng], ref.group_found), what
+        assert np.array_equal(gh.group_size[i, :ng], ref.group_size), what
+        for r in range(ng):
+            n = int(ref.group_size[r])
+            lo = r * group_limit
+            assert np.array_equal(h.keys[i, lo:lo + n], ref.keys[ref.begin[r]:ref.begin[r + 1]]), "%s q%d group %d keys" % (what, i, r)
+            assert np.array_equal(h.scores[i, lo:lo + n], ref.scores[ref.begin[r]:ref.begin[r + 1]]), "%s q%d group %d scores" % (what, i, r)
+        assert int(h.n_hits[i]) == int(ref.group_size.sum())
+        assert int(gh.groups_count[i]) == 0
+
+
+def oracle_grouped(orc, q, distinct, has_value, group_limit, first_pass, gmv=False, wildcard=False, n_docs=None):
+    if wildcard:
+        raise AssertionError("use oracle_grouped_wildcard")
+    oq = H.oracle_query(orc, q)
+    return orc.search_keyword_grouped(oq, distinct, group_limit, first_pass, has_value=has_value, group_missing_values=gmv, ids_cap=1 << 20)
+
+
+def oracle_grouped_wildcard(q, n_docs, points, distinct, group_limit, first_pass, gmv=False):
+    """Index::search_wildcard's grouped loop restated with the oracle's collector: every filter id (every seq_id) minus the excluded ids is
+    scored by its sort keys (text-match slot = 100, sign-flipped for ASC) and added with its distinct key"""
+    ids = np.arange(n_docs, dtype=np.uint32) if q.filter_ids is None else q.filter_ids
+    if q.excluded_ids is not None:
+        ids = np.setdiff1d(ids, q.excluded_ids)
+    sc = np.zeros((ids.size, 3), np.int64)
+    for c, (kind, order, col) in enumerate(q.sort):
+        v = np.full(ids.size, 100, np.int64) if kind == B.SORT_TEXT_MATCH else (ids.astype(np.int64) if kind == B.SORT_SEQ_ID else points[ids])
+        sc[:, c] = v if order == 1 else -v
+    dk = np.array([int(distinct[i]) if i < distinct.size else (1 if gmv else int(i)) for i in ids], np.uint64)
+    cap = q.topster_size if q.topster_size else min(250, ids.size if q.filter_ids is not None else n_docs)
+    cap = max(1, min(cap, n_docs))
+    ret, g = O.group_topster_run(cap, group_limit, first_pass, ids.astype(np.uint64), dk, sc)
+    g.num_keyword_matches = int(ids.size)
+    return g
+
+
+@pytest.fixture(scope="module")
+def world():
+    docs = H.zipf_docs(3000, 300, 12, seed=1)
+    orc, g = H.build_pair(docs, H.emu_lib_path())
+    distinct, has_value = group_column(3000, seed=3)
+    g.column_set(GROUP_COL, distinct.view(np.int64))
+    yield orc, g, docs, distinct, has_value
+    g.close()
+
+
+def _queries(rng, n, vocab_hi, n_tok, **kw):
+    return [T.KwQuery(rng.choice(np.arange(1, vocab_hi), size=n_tok, replace=False), **kw) for _ in range(n)]
+
+
+@pytest.mark.parametrize("first_pass", [True, False])
+def test_grouped_keyword_equals_oracle(world, first_pass):
+    orc, g, _, distinct, has_value = world
+    rng = np.random.default_rng(10 + int(first_pass))
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    qs = _queries(rng, 3, 12, 1, sort=sort, topster_size=250) + _queries(rng, 4, 30, 2, sort=sort, topster_size=250) + _queries(rng, 3, 25, 3, sort=sort, topster_size=250)
+    limits = [1, 2, 3, 7, 3, 3, 2, 3, 5, 3]
+    groups = [(limits[i], GROUP_COL, int(first_pass), 0, 0) for i in range(len(qs))]
+    h, gh = g.keyword_search_grouped_batch(qs, groups, k_stride=250 * 7, g_stride=250, want_registers=True)
+    assert gh.n_groups.sum() > 30
+    for i, q in enumerate(qs):
+        check_query(h, gh, i, oracle_grouped(orc, q, distinct, has_value, limits[i], first_pass), first_pass, limits[i], "kw")
+
+
+@pytest.mark.parametrize("first_pass", [True, False])
+def test_grouped_small_topster_selects_the_best_groups(world, first_pass):
+    orc, g, _, distinct, has_value = world
+    sort3 = ((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, -1, 0))
+    qs = [T.KwQuery([1], topster_size=1), T.KwQuery([2], topster_size=2), T.KwQuery([1, 2], topster_size=5), T.KwQuery([3], topster_size=5, sort=sort3),
+          T.KwQuery([4, 2], topster_size=3, sort=((B.SORT_SEQ_ID, 1, 0),)), T.KwQuery([9999], topster_size=4), T.KwQuery([5], topster_size=30, sort=((B.SORT_TEXT_MATCH, -1, 0), (B.SORT_SEQ_ID, 1, 0)))]
+    groups = [(3, GROUP_COL, int(first_pass), 0, 0)] * len(qs)
+    h, gh = g.keyword_search_grouped_batch(qs, groups, k_stride=30 * 3, g_stride=30, want_registers=True)
+    for i, q in enumerate(qs):
+        check_query(h, gh, i, oracle_grouped(orc, q, distinct, has_value, 3, first_pass), first_pass, 3, "small k")
+    assert int(gh.n_groups[5]) == 0 and int(h.n_hits[5]) == 0
+
+
+@pytest.mark.parametrize("first_pass", [True, False])
+def test_grouped_with_filter_excluded_dropped_and_flags(world, first_pass):
+    orc, g, _, distinct, has_value = world
+    rng = np.random.default_rng(4)
+    filt = np.sort(rng.choice(3000, 900, replace=False)).astype(np.uint32)
+    excl = np.sort(rng.choice(3000, 200, replace=False)).astype(np.uint32)
+    base = dict(topster_size=40)
+    qs = [T.KwQuery([1, 2], filter_ids=filt, **base), T.KwQuery([2], excluded_ids=excl, **base), T.KwQuery([3, 1], filter_ids=filt, excluded_ids=excl, **base),
+          T.KwQuery([2, 3], dropped_tokens=[1], **base), T.KwQuery([1, 2], match_type=B.SUM_SCORE, weight=3, total_cost=2, **base),
+          T.KwQuery([1, 2], prioritize_token_position=True, prioritize_exact_match=False, **base)]
+    groups = [(2, GROUP_COL, int(first_pass), 0, 0)] * len(qs)
+    h, gh = g.keyword_search_grouped_batch(qs, groups, k_stride=80, g_stride=40)
+    for i, q in enumerate(qs):
+        check_query(h, gh, i, oracle_grouped(orc, q, distinct, has_value, 2, first_pass), first_pass, 2, "filter")
+
+
+@pytest.mark.parametrize("first_pass", [True, False])
+def test_grouped_wildcard_and_many_groups(world, first_pass):
+    """q = *: 3 000 documents; with a column shorter than the collection every document beyond it is its own group (or all of them ONE group with
+    group_missing_values): thousands of groups go through the select kernel's compaction"""
+    orc, g, docs, distinct, has_value = world
+    points = H.points_of(3000)
+    short = distinct[:1200].copy()
+    short[7] = np.uint64(2**64 - 1)                                   # the key that equals the table's empty marker
+    short[9] = np.uint64(2**64 - 1)
+    g.column_set(2, short.view(np.int64))
+    rng = np.random.default_rng(8)
+    filt = np.sort(rng.choice(3000, 1500, replace=False)).astype(np.uint32)
+    excl = np.sort(rng.choice(3000, 100, replace=False)).astype(np.uint32)
+    sort = ((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, -1, 0))
+    qs = [T.KwQuery([], sort=sort, topster_size=250), T.KwQuery([], sort=sort, topster_size=250, filter_ids=filt, excluded_ids=excl),
+          T.KwQuery([], sort=((B.SORT_TEXT_MATCH, -1, 0), (B.SORT_INT64_COLUMN, -1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=100, excluded_ids=excl)]
+    for gmv in (0, 1):
+        groups = [(3, 2, int(first_pass), gmv, 1)] * len(qs)
+        h, gh = g.keyword_search_grouped_batch(qs, groups, k_stride=750, g_stride=250, want_registers=True)
+        for i, q in enumerate(qs):
+            check_query(h, gh, i, oracle_grouped_wildcard(q, 3000, points, short, 3, first_pass, bool(gmv)), first_pass, 3, "wild gmv=%d" % gmv)
+        assert int(gh.groups_total[0]) == (1800 + len(set(short.tolist())) if not gmv else len(set(short.tolist()) | {1}))
+
+
+def test_grouped_queries_of_more_than_three_tokens(world):
+    """a batch that holds a query of more than three lists takes the 10-token form of the scoring kernel (one wave per workgroup)"""
+    orc, g, _, distinct, has_value = world
+    qs = [T.KwQuery([1, 2, 3, 4], topster_size=40), T.KwQuery([2, 1], topster_size=40), T.KwQuery([5, 3, 1, 2, 4, 6], topster_size=40),
+          T.KwQuery([1, 2, 3], dropped_tokens=[4, 5], topster_size=40)]
+    for first_pass in (True, False):
+        h, gh = g.keyword_search_grouped_batch(qs, [(2, GROUP_COL, int(first_pass), 0, 0)] * len(qs), k_stride=80, g_stride=40)
+        for i, q in enumerate(qs):
+            check_query(h, gh, i, oracle_grouped(orc, q, distinct, has_value, 2, first_pass), first_pass, 2, "T>3")
+    assert gh.n_groups.sum() > 10
+
+
+def test_grouped_two_fields_arrays_and_missing_ids(world):
+    """two group_by fields (one an array): hash_combine over all hashes; ids_out carries all_result_ids, from which the caller takes
+    group_by_missing_value_ids"""
+    orc, g, _, _, _ = world
+    distinct, has_value = group_column(3000, seed=5, two_fields=True)
+    g.column_set(3, distinct.view(np.int64))
+    q = T.KwQuery([1, 2], topster_size=50)
+    h, gh, ids = g.keyword_search_grouped_batch([q, q], [(3, 3, 1, 0, 0), (3, 3, 0, 0, 0)], k_stride=150, g_stride=50, want_ids=True)
+    ref1 = oracle_grouped(orc, q, distinct, has_value, 3, True)
+    check_query(h, gh, 0, ref1, True, 3, "two fields")
+    check_query(h, gh, 1, oracle_grouped(orc, q, distinct, has_value, 3, False), False, 3, "two fields")
+    assert np.array_equal(ids[0], ref1.result_ids) and np.array_equal(ids[1], ref1.result_ids)
+    missing = ids[0][has_value[ids[0]] == 0]
+    assert np.array_equal(missing, ref1.missing_ids) and missing.size > 0
+
+
+def test_grouped_multi_field_query():
+    rng = np.random.default_rng(21)
+    d0 = H.zipf_docs(1500, 120, 8, seed=2)
+    d1 = H.zipf_docs(1500, 120, 5, seed=3)
+    orc, g = H.build_pair_fields([d0, d1], H.emu_lib_path())
+    try:
+        distinct, has_value = group_column(1500, seed=9, n_values=20)
+        g.column_set(1, distinct.view(np.int64))
+        qs = [T.KwQuery([1, 2], fields=[(0, 15), (1, 7)], topster_size=60), T.KwQuery([3], fields=[(0, 3), (1, 15)], topster_size=60, match_type=B.MAX_WEIGHT),
+              T.KwQuery([2, 5, 1], fields=[(0, 15), (1, 15)], topster_size=60)]
+        for first_pass in (1, 0):
+            h, gh = g.keyword_search_grouped_batch(qs, [(2, 1, first_pass, 0, 0)] * len(qs), k_stride=120, g_stride=60)
+            for i, q in enumerate(qs):
+                check_query(h, gh, i, oracle_grouped(orc, q, distinct, has_value, 2, bool(first_pass)), bool(first_pass), 2, "multi-field")
+    finally:
+        g.close()
+
+
+def test_grouped_bad_queries_do_not_disturb_their_neighbours(world):
+    orc, g, _, distinct, has_value = world
+    good = T.KwQuery([1, 2], topster_size=20)
+    qs = [good, T.KwQuery(list(range(1, 12)), topster_size=20), good, T.KwQuery([1], topster_size=20), good]
+    groups = [(2, GROUP_COL, 0, 0, 0), (2, GROUP_COL, 0, 0, 0), (0, GROUP_COL, 0, 0, 0), (2, 77, 0, 0, 0), (2, GROUP_COL, 1, 0, 0)]
+    h, gh = g.keyword_search_grouped_batch(qs, groups, k_stride=40, g_stride=20)
+    assert list(h.status) == [0, B.ERR_UNSUPPORTED, B.ERR_INVALID, B.ERR_NOT_FOUND, 0]
+    assert list(h.n_hits[1:4]) == [0, 0, 0] and list(gh.n_groups[1:4]) == [0, 0, 0]
+    check_query(h, gh, 0, oracle_grouped(orc, good, distinct, has_value, 2, False), False, 2, "neighbour")
+    check_query(h, gh, 4, oracle_grouped(orc, good, distinct, has_value, 2, True), True, 2, "neighbour")
+    # strides too small for the request: 400 for that query
+    h, gh = g.keyword_search_grouped_batch([good], [(3, GROUP_COL, 0, 0, 0)], k_stride=40, g_stride=20)
+    assert int(h.status[0]) == B.ERR_INVALID

@@ -1,7 +1,8 @@
 """The drop-in boundary as a server maintainer meets it: the header-only C++ shims (typesense_amd/csrc/host/) are compiled with
 g++ against mock types of the reference's shape (tests/host_shims/shim_driver.cpp), linked to the C-ABI library and checked
 against the oracle — the posting decode shim (block chains + compact lists -> tsgpu_term_upsert), the keyword seam
-(search_across_fields_gpu<KV, Topster>, per-call id lists), the hnswlib-shaped adaptor INCLUDING a VectorFilterFunctor-style
+(search_across_fields_gpu<KV, Topster>, per-call id lists), its grouped form (build_distinct_column + search_across_fields_grouped_gpu over the
+distinct Topster), the hnswlib-shaped adaptor INCLUDING a VectorFilterFunctor-style
 predicate passed without a candidate list (src/index.cpp:3384-3386), mirror_hnsw_graph, and the input validators.
 CPU tier: links the emulator build of the unmodified product sources. The `-m gpu` twin links libtsgpu.so."""
 import os
@@ -53,6 +54,28 @@ def _write_fixture(d):
             f.write(_u32(toks.size) + toks.tobytes() + _u32(filt.size) + filt.tobytes() + _u32(excl.size) + excl.tobytes() + _u32(tsz))
             f.write(_u32(ref.keys.size) + ref.keys.astype(np.uint64).tobytes() + ref.scores.astype(np.int64).tobytes())
             f.write(struct.pack("<Q", int(ref.num_keyword_matches)) + _u32(ref.result_ids.size) + ref.result_ids.astype(np.uint32).tobytes())
+    # group_by: the facet hash index of one group_by field (CSR), Index::get_distinct_id per document, grouped passes over all matched documents
+    gptr = np.zeros(n_docs + 1, np.uint64)
+    ghs = []
+    for dd in range(n_docs):
+        if dd % 13 != 5:
+            ghs.append(int(rng.integers(1, 30)) * 40503 % (2**32))
+        gptr[dd + 1] = len(ghs)
+    ghs = np.array(ghs, np.uint32)
+    distinct, has_value = O.distinct_ids(n_docs, [(gptr, ghs)], False)
+    with open(os.path.join(d, "grouped.bin"), "wb") as f:
+        f.write(_u32(n_docs) + gptr.tobytes() + _u32(ghs.size) + ghs.tobytes() + distinct.astype(np.uint64).tobytes())
+        cases = [([1], 250, 3, 1), ([1], 250, 3, 0), ([2, 3], 5, 2, 1), ([2, 3], 5, 2, 0), ([4], 10, 1, 0), ([1, 2, 3], 250, 4, 1), ([7], 3, 5, 0), ([9999], 10, 2, 1)]
+        f.write(_u32(len(cases)))
+        for toks, tsz, limit, first in cases:
+            toks = np.array(toks, np.uint32)
+            q = orc.make_query(toks, sort=sort, fetch_size=10, topster_size=tsz)
+            ref = orc.search_keyword_grouped(q, distinct, limit, bool(first), has_value=has_value, ids_cap=4096)
+            f.write(_u32(toks.size) + toks.tobytes() + _u32(tsz) + _u32(limit) + _u32(first) + _u32(ref.n_groups))
+            for gi in range(ref.n_groups):
+                a, b = int(ref.begin[gi]), int(ref.begin[gi + 1])
+                f.write(struct.pack("<Q", int(ref.distinct_key[gi])) + _u32(ref.group_found[gi]) + _u32(b - a) + ref.keys[a:b].astype(np.uint64).tobytes() + ref.scores[a:b].astype(np.int64).tobytes())
+            f.write(struct.pack("<Q", ref.groups_count) + _u32(ref.missing_ids.size) + ref.missing_ids.astype(np.uint32).tobytes() + struct.pack("<Q", ref.num_keyword_matches))
     # vectors
     n, dim, k = 400, 40, 12
     X = rng.standard_normal((n, dim)).astype(np.float32)

@@ -5,4 +5,4 @@ only a thin ctypes binding over that ABI for tests, bench.py and multi-GPU plumb
 no compute of its own and NO CPU fallback: importing `typesense_amd.lib()` raises if libtsgpu.so is missing.
 """
 from ._lib import lib, TsgpuError, LIB_PATH  # noqa: F401
-from .index import GpuIndex, GpuGroup, KwQuery, Hits  # noqa: F401
+from .index import GpuIndex, GpuGroup, KwQuery, Hits, GroupedHits  # noqa: F401

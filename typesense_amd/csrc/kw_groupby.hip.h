@@ -1,0 +1,372 @@
+// kw_groupby.hip.h — group_by on the device: the DISTINCT form of the Topster and what the reference wraps around it
+// on the scoring path. Included at the end of kw_kernels.hip.h (it scores with the same device functions as the keyword kernels).
+//
+// Reference (one pass of Index::run_search's two-pass protocol, src/index.cpp:2488-2760):
+//   search_across_fields, group_limit != 0   : src/index.cpp:5511-5520 (distinct_id = get_distinct_id over the group_by fields), :5546-5549
+//                                              (ret = topster->add(&kv); if (ret < 2) groups_processed[distinct_id]++)
+//   Topster(capacity, distinct, first_pass)  : include/topster.h:266-296
+//     first pass  (:342-349, :378-428)       : the heap is keyed by distinct key — ONE KV per group, its greatest — and keeps the `capacity`
+//                                              groups with the greatest such KVs; every distinct key reaches loglog_counter (LogLogBeta over
+//                                              hash_wy(std::to_string(key)), include/loglogbeta.h) -> getGroupsCount() = found
+//     second pass (:355-376)                 : group_kv_map[distinct_key] = a Topster of `distinct` (group_limit) KVs per group
+//   populate_result_kvs, grouped branch      : src/index.cpp:8962-9011: the groups' heads go through a Topster(capacity); the surviving groups,
+//                                              best head first, each with its KVs in sort() order
+// Both passes are ORDER-FREE functions of the set of (key, distinct_key, scores) the pass produced, because is_greater / is_smaller
+// (include/topster.h:146-154) order KVs totally (the key is unique within a pass) and a document belongs to one group:
+//   first pass  = for every group its greatest KV; the `capacity` greatest of those            (a KV evicted from the heap is smaller than every
+//                 later heap minimum, so a group that re-enters does so with a KV greater than anything it lost — the heap never ends on a
+//                 group's non-greatest KV; oracle/group_topster.h replays the heap itself and agrees on 280 random streams)
+//   second pass = the same selection of groups (heads = greatest KVs), each with its min(group_limit, members) greatest KVs, descending;
+//                 groups_processed[g] = members of g (every add returns 1: a seq_id is met once per pass)
+// That is what the kernels below compute, with one open-addressing table per query in HBM (like facet_kernels.hip.h):
+//   gb_score_kernel    one thread per matched id: probes every (token, field) list of the query for the id, scores it exactly like the keyword
+//                      kernels (agg_score_mf + sort_scores; the wildcard form: sort_scores with the constant 100), reads its distinct key from
+//                      the group column -> (s0, s1, s2, dkey) per matched id
+//   gb_insert_kernel   one thread per matched id: claims / finds the slot of its distinct key (64-bit CAS), counts the group's members
+//                      (atomicAdd), and raises the group's best record (a CAS loop on a record index: records are immutable, the comparison is
+//                      the Topster's) — no ordering between threads is needed
+//   gb_select_kernel   one workgroup per query: walks the table; every group's best record goes through the LDS top-K buffer the keyword
+//                      kernels use (TopkLds, bitonic compaction) -> the `capacity` best groups in sort order, their rank written back into the
+//                      table; first pass: the LogLogBeta registers of ALL distinct keys are built in LDS (wyhash of the decimal string, restated
+//                      for the 1..20 bytes a uint64 prints to) and the groups' best KVs are the hits; second pass: member-list offsets
+//   gb_scatter_kernel  second pass, one thread per matched id: members of a selected group append themselves to the group's member list
+//   gb_members_kernel  second pass, one wave per (query, selected group): the group's min(group_limit, members) greatest records by repeated
+//                      wave-wide extraction of the greatest record below the previous one (group_limit is 3 by default, <= 99)
+// Bound: HBM latency / atomics of a random-access table, like the facet kernels; algorithmic bytes per matched id = 4 (id) + 32 (record) + the
+// posting probes of gb_score_kernel. Grouped queries are the minority of a server's traffic; the ungrouped keyword path is untouched.
+#pragma once
+// (inside namespace tsgpu)
+
+static const int GB_THREADS = 256;
+static const unsigned long long GB_EMPTY = ~0ull;     // empty table slot; a distinct key that IS ~0 owns the extra slot tab_mask + 1
+static const uint32_t GB_NONE = 0xFFFFFFFFu;
+static const uint32_t GB_LOGLOG_M = 16384;            // LogLogBeta::M (PRECISION 14)
+static const uint32_t GB_LOGLOG_HIST = 52;            // register values 0..51 (rho <= 50 + 1: the low 14 bits of the shifted hash are ones)
+
+struct GbQuery {
+    uint64_t item_begin;      // first matched id of the query in the flat arrays
+    uint64_t tab_off;         // first slot of its table
+    uint32_t n_items;
+    uint32_t tab_mask;        // slots - 1 (a power of two >= 2 x n_items)
+    uint32_t k;               // Topster capacity
+    uint32_t group_limit;
+    uint32_t column;          // the distinct-key column
+    uint32_t first_block;     // the query's first workgroup in the per-item launches (ceil(n_items / GB_THREADS) workgroups each: no workgroup spans two queries)
+    uint8_t first_pass, group_missing_values, wildcard, run;   // run = 0: the query failed upstream, nothing is produced
+};
+
+struct GbArgs {
+    const GbQuery* gq; uint32_t n_queries;
+    const KwQueryDev* queries; const KwQueryMF* mfs;
+    uint64_t n_items;
+    const uint32_t* ids;                                                       // matched ids, ascending per query
+    int64_t* s0; int64_t* s1; int64_t* s2; unsigned long long* dkey; uint32_t* rslot;    // per matched id
+    unsigned long long* hkey; uint32_t* hcount; uint32_t* hbest; uint32_t* hrank;          // per table slot
+    uint32_t* glist; uint32_t* gcount;                                         // the slots in use, per query (at item_begin; <= n_items of them) and how many
+    uint32_t* members;                                                         // second pass: per query, the selected groups' members (local item indices)
+    uint32_t g_stride;                                                         // group slots per query (>= every k)
+    uint32_t* n_groups; unsigned long long* groups_total;                      // per query
+    unsigned long long* g_dkey; uint32_t* g_found; uint32_t* g_size; uint32_t* g_mofs; uint32_t* g_mcur;   // per (query, returned group)
+    uint8_t* loglog;                                                           // [n_queries][GB_LOGLOG_M] (rows of first-pass queries are written), or null
+    uint32_t* loglog_hist;                                                     // [n_queries][GB_LOGLOG_HIST]: registers per value (first-pass queries): all cardinality() needs
+    KwOut out;
+};
+
+// per-item launches: workgroup b serves the query q with first_block[q] <= b < first_block[q + 1] (one search per workgroup, shared through LDS);
+// returns false for the threads behind the query's last item
+template <int BLOCK = GB_THREADS>                               // BLOCK-thread workgroups: GB_THREADS / BLOCK of them share one GB_THREADS-item chunk
+__device__ inline bool gb_item_of(const GbArgs& a, uint32_t& qi, uint64_t& item) {
+    __shared__ uint32_t s_q;
+    const uint32_t chunk = blockIdx.x / (GB_THREADS / BLOCK), sub = blockIdx.x % (GB_THREADS / BLOCK);
+    if (threadIdx.x == 0) {
+        uint32_t lo = 0, hi = a.n_queries;                      // the last query whose first_block <= chunk (queries without items share their successor's)
+        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (a.gq[mid].first_block <= chunk) lo = mid; else hi = mid; }
+        s_q = lo;
+    }
+    __syncthreads();
+    qi = s_q;
+    const uint32_t local = (chunk - a.gq[qi].first_block) * GB_THREADS + sub * BLOCK + threadIdx.x;
+    item = a.gq[qi].item_begin + local;
+    return local < a.gq[qi].n_items;
+}
+
+__device__ inline bool gb_rec_greater(const GbArgs& a, uint64_t x, uint64_t y) {       // KV::is_greater on records (global item indices)
+    return ent_greater(a.s0[x], a.s1[x], a.s2[x], (int64_t)a.ids[x], a.s0[y], a.s1[y], a.s2[y], (int64_t)a.ids[y]);
+}
+
+// ---- scoring of every matched id ----
+template <int TMAX>                                                          // 3: every query of the batch has <= 3 lists (a fifth of the registers of the 10-token form)
+__global__ __launch_bounds__(TMAX <= 3 ? GB_THREADS : 64) void gb_score_kernel(IndexView ix, GbArgs a) {      // (the 10-token form holds 40 positions per thread: one wave per workgroup)
+    uint32_t qi; uint64_t i;
+    if (!gb_item_of<(TMAX <= 3 ? GB_THREADS : 64)>(a, qi, i)) return;
+    const GbQuery g = a.gq[qi];
+    const KwQueryDev& q = a.queries[qi];
+    const uint32_t seq_id = a.ids[i];
+    ScoredHit h;
+    if (g.wildcard) {
+        h = sort_scores(ix, q, seq_id, 100, 0, false, 0.0f);                 // Index::search_wildcard: the text-match slot is the constant 100 (src/index.cpp:6728-6730)
+    } else {
+        const KwQueryMF& mf = a.mfs[qi];
+        uint32_t pos[TMAX * KW_MAX_FIELDS];
+        uint32_t tokens_found = 0;
+#pragma unroll
+        for (int t = 0; t < TMAX; t++) {
+            bool any = false;
+#pragma unroll
+            for (int f = 0; f < KW_MAX_FIELDS; f++) {
+                uint32_t p = KW_NONE;
+                if ((uint32_t)t < q.n_lists && (uint32_t)f < mf.n_fields && mf.list[t][f] != KW_NONE) {
+                    uint32_t pp;
+                    if (probe_list(ix, ix.lists[mf.list[t][f]], seq_id, pp)) { p = pp; any = true; }
+                }
+                pos[t * KW_MAX_FIELDS + f] = p;
+            }
+            tokens_found += any ? 1u : 0u;                                  // every required token (the id matched) + the dropped tokens it holds
+        }
+        uint32_t off_words = 0;
+        const uint64_t agg = agg_score_mf<TMAX>(ix, q, mf, pos, tokens_found, off_words);
+        h = sort_scores(ix, q, seq_id, agg, off_words);
+    }
+    a.s0[i] = h.s0; a.s1[i] = h.s1; a.s2[i] = h.s2;
+    const uint32_t c = g.column;
+    // the group column holds get_distinct_id's result per seq_id; a document beyond it has no value in any group_by field (src/index.cpp:7104-7111)
+    a.dkey[i] = (c < ix.n_columns && seq_id < ix.column_len[c]) ? (unsigned long long)ix.columns[c][seq_id]
+                                                                 : (g.group_missing_values ? 1ull : (unsigned long long)seq_id);
+}
+
+__device__ inline uint64_t gb_mix(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+
+// ---- group table: slot per distinct key, member count, best record ----
+__global__ __launch_bounds__(GB_THREADS) void gb_insert_kernel(GbArgs a) {
+    uint32_t qi; uint64_t i;
+    if (!gb_item_of(a, qi, i)) return;
+    const GbQuery g = a.gq[qi];
+    const unsigned long long key = a.dkey[i];
+    uint32_t slot;
+    if (key == GB_EMPTY) slot = g.tab_mask + 1;
+    else {
+        slot = (uint32_t)gb_mix(key) & g.tab_mask;
+        for (;;) {
+            unsigned long long* kp = a.hkey + g.tab_off + slot;
+            unsigned long long cur = *kp;                                   // (a slot's key never changes once set; a stale EMPTY is resolved by the CAS)
+            if (cur == GB_EMPTY) { cur = atomicCAS(kp, GB_EMPTY, key); if (cur == GB_EMPTY) cur = key; }
+            if (cur == key) break;
+            slot = (slot + 1) & g.tab_mask;
+        }
+    }
+    a.rslot[i] = slot;
+    // the group's first member lists its slot; one counter update per wave (every lane of a workgroup serves the same query)
+    const bool first = atomicAdd(&a.hcount[g.tab_off + slot], 1u) == 0;
+    const unsigned long long fm = __ballot(first ? 1 : 0);
+    if (fm) {
+        const uint32_t lane = threadIdx.x & 63;
+        uint32_t base_at = 0;
+        if (lane == (uint32_t)__ffsll((long long)fm) - 1) base_at = atomicAdd(&a.gcount[qi], (uint32_t)__popcll(fm));
+        base_at = __shfl(base_at, __ffsll((long long)fm) - 1, 64);
+        if (first) a.glist[g.item_begin + base_at + (uint32_t)__popcll(fm & ((1ull << lane) - 1))] = slot;
+    }
+    // the group's greatest record: hbest holds a LOCAL item index; whoever holds a greater record replaces it
+    const uint32_t me = (uint32_t)(i - g.item_begin);
+    uint32_t* bp = a.hbest + g.tab_off + slot;
+    uint32_t cur = atomicCAS(bp, GB_NONE, me);
+    while (cur != GB_NONE && gb_rec_greater(a, i, g.item_begin + cur)) {
+        const uint32_t prev = atomicCAS(bp, cur, me);
+        if (prev == cur) break;
+        cur = prev;
+    }
+}
+
+// ---- wyhash v5 (default secret, seed 0) of the decimal string of a uint64 = StringUtils::hash_wy(std::to_string(key)) (include/string_utils.h:316-320,
+// include/wyhash_v5.h:69-94; the branches for 1..20 bytes) ----
+__device__ inline uint64_t gb_wymum(uint64_t A, uint64_t B) { return __umul64hi(A, B) ^ (A * B); }
+__device__ inline uint64_t gb_wymix(uint64_t A, uint64_t B) { return A ^ B ^ gb_wymum(A, B); }
+__device__ inline uint64_t gb_hash_wy_decimal(uint64_t v) {
+    const uint64_t P0 = 0xa0761d6478bd642full, P1 = 0xe7037ed1a0b428dbull, P4 = 0x1d8e4e27c47d124full, P5 = 0x72b22b96e169b471ull;
+    uint8_t rev[20];
+    uint32_t len = 0;
+    do { rev[len++] = (uint8_t)('0' + (uint32_t)(v % 10)); v /= 10; } while (v);
+    // byte j of the string = rev[len - 1 - j]; little-endian reads of n bytes at string offset p
+    auto rd = [&](uint32_t p, uint32_t n) { uint64_t x = 0; for (uint32_t j = 0; j < n; j++) x |= (uint64_t)rev[len - 1 - (p + j)] << (8 * j); return x; };
+    const uint64_t seed = P4;                                               // seed 0 ^ secret[4]
+    uint64_t h;
+    if (len >= 8) {
+        if (len <= 16) h = gb_wymix(rd(0, 8) ^ P0, rd(len - 8, 8) ^ seed);
+        else h = gb_wymix(rd(0, 8) ^ P0, rd(8, 8) ^ seed) ^ gb_wymix(rd(len - 16, 8) ^ P1, rd(len - 8, 8) ^ seed);
+    } else if (len >= 4) h = gb_wymix(rd(0, 4) ^ P0, rd(len - 4, 4) ^ seed);
+    else h = gb_wymix((((uint64_t)rev[len - 1] << 16) | ((uint64_t)rev[len - 1 - (len >> 1)] << 8) | rev[0]) ^ P0, seed);     // _wyr3: p[0], p[len >> 1], p[len - 1]
+    h = gb_wymum(h ^ len, P5);
+    return h != ~0ull ? h : ~0ull - 1;
+}
+
+// ---- selection of the `capacity` best groups; first pass: the hits + the LogLogBeta registers ----
+template <int CAP>
+__global__ __launch_bounds__(GB_THREADS) void gb_select_kernel(GbArgs a) {
+    __shared__ TopkLds<CAP, true> tk;
+    __shared__ int64_t thr[4];
+    __shared__ uint32_t s_cnt, s_have;
+    __shared__ uint32_t regs[GB_LOGLOG_M / 4];                               // LogLogBeta registers, four per word
+    __shared__ uint32_t hist[GB_LOGLOG_HIST];                                // ... and how many registers hold each value
+    const uint32_t t = threadIdx.x;
+    const uint32_t qi = blockIdx.x;
+    const GbQuery g = a.gq[qi];
+    const size_t gbase = (size_t)qi * a.g_stride;
+    if (!g.run) { if (t == 0) { a.n_groups[qi] = 0; a.groups_total[qi] = 0; a.out.n_hits[qi] = 0; } return; }
+    if (t == 0) { s_cnt = 0; s_have = 0; }
+    for (uint32_t w = t; w < GB_LOGLOG_M / 4; w += GB_THREADS) regs[w] = 0;
+    __syncthreads();
+    const uint32_t n_used = a.gcount[qi];                                    // distinct keys of the pass (gb_insert_kernel listed their slots)
+    for (uint32_t base = 0; base < n_used; base += GB_THREADS) {
+        const bool have = base + t < n_used;
+        uint32_t slot = 0;
+        int64_t e0 = 0, e1 = 0, e2 = 0, ek = -1;
+        if (have) {
+            slot = a.glist[g.item_begin + base + t];
+            const uint64_t b = g.item_begin + a.hbest[g.tab_off + slot];
+            e0 = a.s0[b]; e1 = a.s1[b]; e2 = a.s2[b]; ek = (int64_t)a.ids[b];
+        }
+        // only entries that beat the current k-th best are appended; the buffer is compacted when THEY do not fit. Everybody reads the held count
+        // BEFORE the counting barrier and appends after it (a count read next to other threads' appends splits the workgroup at the compaction's barriers)
+        bool pass = have && (!s_have || ent_greater(e0, e1, e2, ek, thr[0], thr[1], thr[2], thr[3]));
+        const uint32_t held = s_cnt;
+        const uint32_t n_pass = (uint32_t)__syncthreads_count(pass ? 1 : 0);
+        if (held + n_pass > (uint32_t)CAP) {
+            topk_compact<CAP, true>(tk, &s_cnt, g.k, thr, &s_have);          // -> <= k entries, CAP >= k + GB_THREADS
+            pass = pass && (!s_have || ent_greater(e0, e1, e2, ek, thr[0], thr[1], thr[2], thr[3]));
+        }
+        if (pass) {
+            const uint32_t at = atomicAdd(&s_cnt, 1u);
+            tk.s0[at] = e0; tk.s1[at] = e1; tk.s2[at] = e2; tk.key[at] = ek;
+        }
+        if (have) {
+            if (g.first_pass) {
+                // loglog_counter->add(std::to_string(distinct_key)) (include/topster.h:346, :408; loglogbeta.h:86-105): every distinct key, once
+                const unsigned long long key = slot == g.tab_mask + 1 ? GB_EMPTY : a.hkey[g.tab_off + slot];
+                const uint64_t x = gb_hash_wy_decimal(key);
+                const uint32_t kreg = (uint32_t)(x >> 50);
+                const uint64_t shifted = (x << 14) ^ 0x3FFFull;
+                const uint32_t val = (uint32_t)__clzll((long long)shifted) + 1;          // (shifted >= 0x3FFF: never 0)
+                uint32_t* w = &regs[kreg >> 2];
+                const uint32_t sh = (kreg & 3) * 8;
+                uint32_t old = *w;
+                for (;;) {
+                    if (((old >> sh) & 0xFFu) >= val) break;
+                    const uint32_t nw = (old & ~(0xFFu << sh)) | (val << sh);
+                    const uint32_t prev = atomicCAS(w, old, nw);
+                    if (prev == old) break;
+                    old = prev;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    topk_compact<CAP, true>(tk, &s_cnt, g.k, thr, &s_have);
+    const uint32_t n = s_cnt;                                                // min(k, groups), sorted descending
+    int msi = -1;
+    for (int i = 0; i < 3; i++) if (i < (int)a.queries[qi].n_sort && a.queries[qi].sort_kind[i] == 0) msi = i;
+    const uint32_t* qids = a.ids + g.item_begin;
+    for (uint32_t r = t; r < n; r += GB_THREADS) {
+        const uint32_t key = (uint32_t)tk.key[r];
+        uint32_t lo = 0, hi = g.n_items;                                     // the record of the entry: its id's position in the query's ascending ids
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (qids[mid] < key) lo = mid + 1; else hi = mid; }
+        const uint32_t slot = a.rslot[g.item_begin + lo];
+        a.hrank[g.tab_off + slot] = r;
+        const uint32_t members = a.hcount[g.tab_off + slot];
+        a.g_dkey[gbase + r] = a.dkey[g.item_begin + lo];
+        a.g_found[gbase + r] = members;
+        a.g_size[gbase + r] = g.first_pass ? 1u : (members < g.group_limit ? members : g.group_limit);
+        if (g.first_pass) {
+            const size_t o = (size_t)qi * a.out.k_stride + r;
+            a.out.keys[o] = key;
+            a.out.scores[o * 3 + 0] = tk.s0[r]; a.out.scores[o * 3 + 1] = tk.s1[r]; a.out.scores[o * 3 + 2] = tk.s2[r];
+            a.out.text_match[o] = msi == 0 ? tk.s0[r] : (msi == 1 ? tk.s1[r] : (msi == 2 ? tk.s2[r] : 0));
+            a.out.vector_distance[o] = -1.0f;
+            a.out.match_score_index[o] = (int8_t)msi;
+        }
+    }
+    if (!g.first_pass) for (uint32_t r = t; r < n; r += GB_THREADS) regs[r] = a.g_found[gbase + r];       // (the register words are free in a second pass; n <= 1024 < 4096)
+    __syncthreads();
+    if (t == 0) {
+        a.n_groups[qi] = n;
+        a.groups_total[qi] = n_used;
+        uint32_t hits = n;
+        if (!g.first_pass) {
+            uint32_t ofs = 0;
+            hits = 0;
+            for (uint32_t r = 0; r < n; r++) {
+                const uint32_t members = regs[r];
+                a.g_mofs[gbase + r] = ofs; a.g_mcur[gbase + r] = 0;
+                ofs += members; hits += members < g.group_limit ? members : g.group_limit;
+            }
+        }
+        a.out.n_hits[qi] = hits;
+    }
+    if (g.first_pass) {
+        // what LogLogBeta::cardinality() reads: how many registers hold each value (the host sums 2^-value over them), and the registers themselves on request
+        if (t < GB_LOGLOG_HIST) hist[t] = 0;
+        __syncthreads();
+        for (uint32_t w = t; w < GB_LOGLOG_M / 4; w += GB_THREADS) {
+            const uint32_t v = regs[w];
+            if (v == 0) { atomicAdd(&hist[0], 4u); continue; }
+            for (int b = 0; b < 4; b++) { const uint32_t x = (v >> (8 * b)) & 0xFFu; atomicAdd(&hist[x < GB_LOGLOG_HIST ? x : GB_LOGLOG_HIST - 1], 1u); }
+            if (a.loglog) ((uint32_t*)(a.loglog + (size_t)qi * GB_LOGLOG_M))[w] = v;          // (the rows are zeroed per batch: only non-zero words travel)
+        }
+        __syncthreads();
+        if (t < GB_LOGLOG_HIST) a.loglog_hist[(size_t)qi * GB_LOGLOG_HIST + t] = hist[t];
+    }
+}
+
+// ---- second pass: members of the selected groups ----
+__global__ __launch_bounds__(GB_THREADS) void gb_scatter_kernel(GbArgs a) {
+    uint32_t qi; uint64_t i;
+    if (!gb_item_of(a, qi, i)) return;
+    const GbQuery g = a.gq[qi];
+    if (g.first_pass) return;
+    const uint32_t r = a.hrank[g.tab_off + a.rslot[i]];
+    if (r == GB_NONE) return;
+    const size_t gi = (size_t)qi * a.g_stride + r;
+    const uint32_t at = atomicAdd(&a.g_mcur[gi], 1u);
+    a.members[g.item_begin + a.g_mofs[gi] + at] = (uint32_t)(i - g.item_begin);
+}
+
+// one wave per (query, selected group): the group Topster's content in sort() order = its min(group_limit, members) greatest records, descending.
+// Hit slot of the j-th KV of the r-th group: r * group_limit + j.
+__global__ __launch_bounds__(GB_THREADS) void gb_members_kernel(GbArgs a) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t pair = (uint64_t)blockIdx.x * (GB_THREADS / 64) + (threadIdx.x >> 6);
+    const uint32_t qi = (uint32_t)(pair / a.g_stride), r = (uint32_t)(pair % a.g_stride);
+    if (qi >= a.n_queries) return;
+    const GbQuery g = a.gq[qi];
+    if (!g.run || g.first_pass || r >= a.n_groups[qi]) return;              // (wave-uniform)
+    const size_t gi = (size_t)qi * a.g_stride + r;
+    const uint32_t cnt = a.g_found[gi], take = a.g_size[gi];
+    const uint32_t* mem = a.members + g.item_begin + a.g_mofs[gi];
+    const KwQueryDev& q = a.queries[qi];
+    int msi = -1;
+    for (int i = 0; i < 3; i++) if (i < (int)q.n_sort && q.sort_kind[i] == 0) msi = i;
+    int64_t p0 = 0, p1 = 0, p2 = 0, pk = -1;                                 // the previous extraction (pk < 0: none yet)
+    for (uint32_t j = 0; j < take; j++) {
+        int64_t b0 = 0, b1 = 0, b2 = 0, bk = -1;                             // this lane's greatest record below the previous extraction (bk < 0: none)
+        for (uint32_t m = lane; m < cnt; m += 64) {
+            const uint64_t x = g.item_begin + mem[m];
+            const int64_t c0 = a.s0[x], c1 = a.s1[x], c2 = a.s2[x], ck = (int64_t)a.ids[x];
+            if (pk >= 0 && !ent_greater(p0, p1, p2, pk, c0, c1, c2, ck)) continue;
+            if (ent_greater(c0, c1, c2, ck, b0, b1, b2, bk)) { b0 = c0; b1 = c1; b2 = c2; bk = ck; }
+        }
+        for (int d = 32; d > 0; d >>= 1) {
+            const int64_t o0 = __shfl_xor(b0, d, 64), o1 = __shfl_xor(b1, d, 64), o2 = __shfl_xor(b2, d, 64), ok = __shfl_xor(bk, d, 64);
+            if (ent_greater(o0, o1, o2, ok, b0, b1, b2, bk)) { b0 = o0; b1 = o1; b2 = o2; bk = ok; }
+        }
+        if (lane == 0) {
+            const size_t o = (size_t)qi * a.out.k_stride + (size_t)r * g.group_limit + j;
+            a.out.keys[o] = (uint64_t)bk;
+            a.out.scores[o * 3 + 0] = b0; a.out.scores[o * 3 + 1] = b1; a.out.scores[o * 3 + 2] = b2;
+            a.out.text_match[o] = msi == 0 ? b0 : (msi == 1 ? b1 : (msi == 2 ? b2 : 0));
+            a.out.vector_distance[o] = -1.0f;
+            a.out.match_score_index[o] = (int8_t)msi;
+        }
+        p0 = b0; p1 = b1; p2 = b2; pk = bk;
+    }
+}

@@ -3237,4 +3237,6 @@ __global__ __launch_bounds__(KW_THREADS) void kw_round_kernel(IndexView ix, cons
     if (threadIdx.x == 0) ticket[qid] = 0;                // the next round finds its tickets at zero (rounds of one lane follow each other on one stream)
 }
 
+#include "kw_groupby.hip.h"
+
 }  // namespace tsgpu

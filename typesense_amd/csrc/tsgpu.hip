@@ -164,6 +164,7 @@ int tsgpu_create(int device_ordinal, tsgpu_ctx** out) {
 
 void tsgpu_vec_destroy_all(tsgpu_ctx* ctx);   // tsgpu_vec.hip
 void tsgpu_facet_destroy_all(tsgpu_ctx* ctx); // tsgpu_facet.hip
+void tsgpu_groupby_destroy(tsgpu_ctx* ctx);   // tsgpu_groupby.inc.h
 
 void tsgpu_destroy(tsgpu_ctx* ctx) {
     if (!ctx) return;
@@ -171,6 +172,7 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
     (void)hipDeviceSynchronize();
     tsgpu_vec_destroy_all(ctx);
     tsgpu_facet_destroy_all(ctx);
+    tsgpu_groupby_destroy(ctx);
     for (auto& L : ctx->lanes) L.release();
     std::atomic_store(&ctx->snap, std::shared_ptr<const Snapshot>());
     ctx->retire_bin->drain();
@@ -2154,3 +2156,5 @@ int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard
     return TSGPU_OK;
 }
 }  // namespace tsgpu
+
+#include "tsgpu_groupby.inc.h"

@@ -375,6 +375,7 @@ struct KwLane {
 };
 
 struct KwRequest;                                    // tsgpu.hip
+struct GroupByScratch;                               // tsgpu_groupby.inc.h
 struct VecRequest;                                   // tsgpu_vec.hip
 
 }  // namespace tsgpu
@@ -571,6 +572,7 @@ struct tsgpu_ctx {
 
     std::unordered_map<uint32_t, tsgpu::VecField*> vec_fields;
     std::unordered_map<uint32_t, tsgpu::FacetField*> facet_fields;
+    tsgpu::GroupByScratch* groupby = nullptr;        // device scratch of tsgpu_keyword_search_grouped_batch (under mu)
 
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [3..7]: the vector path
     tsgpu_timings timings{};

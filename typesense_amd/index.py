@@ -105,6 +105,28 @@ class Hits:
         return h
 
 
+class GroupedHits:
+    """Host copy of tsgpu_grouped_hits (numpy, [n_queries, g_stride])."""
+
+    def __init__(self, n_queries, g_stride, registers=False):
+        self.n_queries, self.g_stride = n_queries, g_stride
+        self.n_groups = np.zeros(n_queries, np.uint32)
+        self.distinct_key = np.zeros((n_queries, g_stride), np.uint64)
+        self.group_size = np.zeros((n_queries, g_stride), np.uint32)
+        self.group_found = np.zeros((n_queries, g_stride), np.uint32)
+        self.groups_total = np.zeros(n_queries, np.uint64)
+        self.groups_count = np.zeros(n_queries, np.uint64)
+        self.loglog_registers = np.zeros((n_queries, 16384), np.uint8) if registers else None
+
+    def c_struct(self):
+        g = B.GroupedHitsC()
+        g.g_stride = self.g_stride
+        g.n_groups, g.distinct_key, g.group_size, g.group_found = self.n_groups.ctypes.data, self.distinct_key.ctypes.data, self.group_size.ctypes.data, self.group_found.ctypes.data
+        g.groups_total, g.groups_count = self.groups_total.ctypes.data, self.groups_count.ctypes.data
+        g.loglog_registers = self.loglog_registers.ctypes.data if self.loglog_registers is not None else None
+        return g
+
+
 def make_query_array(queries):
     """list[KwQuery] (or a prebuilt ctypes array) -> contiguous tsgpu_kw_query[n]"""
     if isinstance(queries, C.Array):
@@ -283,6 +305,30 @@ class GpuIndex:
         return hits, ids
 
     # ---- facet counting over matched ids (do_facets, hash-index branch) ----
+    def keyword_search_grouped_batch(self, queries, groups, k_stride, g_stride=250, want_ids=False, want_registers=False):
+        """tsgpu_keyword_search_grouped_batch: groups = [(group_limit, column, first_pass, group_missing_values, wildcard), ...] per query.
+        Returns (Hits, GroupedHits[, id lists])."""
+        arr = make_query_array(queries)
+        n = len(arr)
+        ga = (B.GroupByC * n)()
+        for i, g in enumerate(groups):
+            ga[i].group_limit, ga[i].column, ga[i].first_pass, ga[i].group_missing_values, ga[i].wildcard = int(g[0]), int(g[1]), int(g[2]), int(g[3]), int(g[4])
+        h = Hits(n, k_stride)
+        gh = GroupedHits(n, g_stride, want_registers)
+        hs, gs = h.c_struct(), gh.c_struct()
+        handle = C.c_void_p()
+        self._ck(self.L.tsgpu_keyword_search_grouped_batch(self.h, arr, ga, n, C.byref(hs), C.byref(gs), C.byref(handle) if want_ids else None))
+        if not want_ids:
+            return h, gh
+        lists = []
+        try:
+            for q in range(n):
+                cnt = int(self.L.tsgpu_id_lists_count(handle, q))
+                lists.append(np.ctypeslib.as_array(self.L.tsgpu_id_lists_ids(handle, q), shape=(cnt,)).copy() if cnt else np.zeros(0, np.uint32))
+        finally:
+            self.L.tsgpu_id_lists_free(handle)
+        return h, gh, lists
+
     def facet_set(self, field_id, doc_ptr, hashes):
         doc_ptr = np.ascontiguousarray(doc_ptr, dtype=np.uint64)
         hashes = _u32(hashes)
