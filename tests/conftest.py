@@ -9,6 +9,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the SIMT emulator aborts when the threads of a workgroup meet at different textual barriers (tests/test_hipemu_selftest.py)
+    os.environ.setdefault("HIPEMU_STRICT_BARRIERS", "1")
     # Two HIP runtimes live in a GPU test process: the one bundled with torch and /opt/rocm's, which libtsgpu.so links. torch's must
     # initialise FIRST (observed on the GPU box: after libtsgpu.so has opened the device, torch.cuda's lazy init reports "No HIP GPUs
     # are available"); tests that hand CUDA tensors to the library (shard merge, synthetic corpora built on the device) depend on it.

@@ -8,6 +8,8 @@
 //   * __syncthreads(): all live fibers of the block; wave collectives (__ballot, __shfl*, MFMA): all live
 //     lanes of the 64-wide wave — a collective reached by only part of a wave is reported as a divergence
 //     error instead of silently "working";
+//   * every textual __syncthreads() carries an id: fibers of a block that meet at DIFFERENT barriers (a race on the way into barrier-carrying
+//     code, which the cooperative schedule would otherwise hide) are reported, fatally under HIPEMU_STRICT_BARRIERS=1 (the test tier sets it);
 //   * __shared__ = function-local static (one block at a time); atomics = plain ops (cooperative scheduling);
 //   * __builtin_amdgcn_mfma_f32_32x32x2f32 with the CDNA4 fragment layout and k-ordered fmaf chain
 //     (cdna_hip_programming.md §3: bit-exact model of v_mfma_f32_32x32x2_f32).
@@ -44,6 +46,7 @@ struct Fiber {
     dim3 tid;
     int wait = RUNNING;
     unsigned wave_gen = 0;
+    int barrier_site = 0;           // which textual __syncthreads() the fiber waits at (0 = an internal barrier of a wrapper)
 };
 
 struct WaveState {
@@ -68,9 +71,10 @@ inline BlockState*& g() { static BlockState* b = nullptr; return b; }
 
 inline void yield_to_sched() { BlockState* b = g(); swapcontext(&b->fibers[b->cur].ctx, &b->sched); }
 
-inline void syncthreads() {
+inline void syncthreads(int site = 0) {
     BlockState* b = g();
     b->fibers[b->cur].wait = AT_BARRIER;
+    b->fibers[b->cur].barrier_site = site;
     yield_to_sched();
 }
 
@@ -139,7 +143,26 @@ inline void run_block(BlockState& B) {
             any = true;
             if (B.fibers[i].wait != AT_BARRIER) all = false;
         }
-        if (any && all) { for (unsigned i = 0; i < n; i++) if (B.fibers[i].wait == AT_BARRIER) B.fibers[i].wait = RUNNING; progressed = true; }
+        if (any && all) {
+            // every live fiber is at A barrier — on the hardware that is enough (s_barrier counts arrivals), but fibers that meet at DIFFERENT textual
+            // barriers took different paths through barrier-carrying code (e.g. part of a workgroup entered a compaction the rest skipped): a race in
+            // the kernel that a cooperative schedule would otherwise hide. Reported; fatal with HIPEMU_STRICT_BARRIERS=1.
+            int site = -1; bool mixed = false;
+            for (unsigned i = 0; i < n; i++) if (B.fibers[i].wait == AT_BARRIER) { if (site < 0) site = B.fibers[i].barrier_site; else if (B.fibers[i].barrier_site != site) mixed = true; }
+            if (mixed) {
+                static int reported = 0;
+                static const bool strict = getenv("HIPEMU_STRICT_BARRIERS") != nullptr;
+                if (reported++ < 8 || strict) {
+                    fprintf(stderr, "hipemu: block %u: fibers met at DIFFERENT __syncthreads() call sites:", B.block_idx.x);
+                    int last = -2;
+                    for (unsigned i = 0; i < n; i++) if (B.fibers[i].wait == AT_BARRIER && B.fibers[i].barrier_site != last) { last = B.fibers[i].barrier_site; fprintf(stderr, " [t%u: site %d]", i, last); }
+                    fprintf(stderr, "\n");
+                }
+                if (strict) abort();
+            }
+            for (unsigned i = 0; i < n; i++) if (B.fibers[i].wait == AT_BARRIER) B.fibers[i].wait = RUNNING;
+            progressed = true;
+        }
         if (!progressed) {
             fprintf(stderr, "hipemu: DEADLOCK / divergent collective in block %u: lane states:", B.block_idx.x);
             for (unsigned i = 0; i < n; i++) fprintf(stderr, " %d", B.fibers[i].wait);
@@ -300,27 +323,32 @@ inline i32x16 mfma_32x32x32_i8(i32x4 a, i32x4 b, i32x16 c) {
 #define blockDim (hipemu::cur_bdim())
 #define gridDim (hipemu::cur_gdim())
 
-inline void __syncthreads() { hipemu::syncthreads(); }
-inline int __syncthreads_or(int pred) {      // barrier + OR-reduction over the block (two barriers: publish, then read)
-    hipemu::BlockState* b = hipemu::g();
+// every textual barrier gets an id (__COUNTER__): the scheduler checks that the fibers of a block meet at the SAME one
+#define __syncthreads() hipemu::syncthreads(__COUNTER__ + 1)
+#define __syncthreads_or(pred) hipemu::syncthreads_or_at((pred), __COUNTER__ + 1)
+#define __syncthreads_count(pred) hipemu::syncthreads_count_at((pred), __COUNTER__ + 1)
+namespace hipemu {
+inline int syncthreads_or_at(int pred, int site) {      // barrier + OR-reduction over the block (two more barriers: read, then reset)
+    BlockState* b = g();
     if (pred) b->or_flag = 1;
-    hipemu::syncthreads();
+    syncthreads(site);
     const int r = b->or_flag;
-    hipemu::syncthreads();
-    if (hipemu::cur_tid().x == 0) b->or_flag = 0;
-    hipemu::syncthreads();
+    syncthreads(site);
+    if (cur_tid().x == 0) b->or_flag = 0;
+    syncthreads(site);
     return r;
 }
-inline int __syncthreads_count(int pred) {   // barrier + number of threads of the block whose pred is non-zero
-    hipemu::BlockState* b = hipemu::g();
+inline int syncthreads_count_at(int pred, int site) {   // barrier + number of threads of the block whose pred is non-zero
+    BlockState* b = g();
     if (pred) b->or_flag += 1;                // fibers of a block run one at a time: plain increment
-    hipemu::syncthreads();
+    syncthreads(site);
     const int r = b->or_flag;
-    hipemu::syncthreads();
-    if (hipemu::cur_tid().x == 0) b->or_flag = 0;
-    hipemu::syncthreads();
+    syncthreads(site);
+    if (cur_tid().x == 0) b->or_flag = 0;
+    syncthreads(site);
     return r;
 }
+}  // namespace hipemu
 inline unsigned long long __ballot(int pred) { return hipemu::ballot(pred); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
