@@ -10,6 +10,7 @@
 //     error instead of silently "working";
 //   * every textual __syncthreads() carries an id: fibers of a block that meet at DIFFERENT barriers (a race on the way into barrier-carrying
 //     code, which the cooperative schedule would otherwise hide) are reported, fatally under HIPEMU_STRICT_BARRIERS=1 (the test tier sets it);
+//   * runnable fibers take turns in ascending order, or — HIPEMU_SCHEDULE=reverse | shuffle — in another one: results must not depend on it;
 //   * __shared__ = function-local static (one block at a time); atomics = plain ops (cooperative scheduling);
 //   * __builtin_amdgcn_mfma_f32_32x32x2f32 with the CDNA4 fragment layout and k-ordered fmaf chain
 //     (cdna_hip_programming.md §3: bit-exact model of v_mfma_f32_32x32x2_f32).
@@ -114,9 +115,17 @@ inline void run_block(BlockState& B) {
         f.ctx.uc_link = &B.sched;
         makecontext(&f.ctx, (void (*)())fiber_entry, 0);
     }
+    // the order in which runnable fibers get their turn. The hardware promises none: a kernel whose RESULT depends on it has a race. Default:
+    // ascending; HIPEMU_SCHEDULE=reverse | shuffle (per-block pseudo-random, reseeded every pass) to run the same tests under other orders.
+    static const int sched_mode = [] { const char* e = getenv("HIPEMU_SCHEDULE"); return !e ? 0 : (!strcmp(e, "reverse") ? 1 : (!strcmp(e, "shuffle") ? 2 : 0)); }();
+    std::vector<unsigned> order(n);
+    for (unsigned i = 0; i < n; i++) order[i] = sched_mode == 1 ? n - 1 - i : i;
+    uint64_t rng = 0x9E3779B97F4A7C15ull * (B.block_idx.x + 1) + n;
     for (;;) {
         bool progressed = false, any_live = false;
-        for (unsigned i = 0; i < n; i++) {
+        if (sched_mode == 2) for (unsigned i = n; i > 1; i--) { rng = rng * 6364136223846793005ull + 1442695040888963407ull; std::swap(order[i - 1], order[(rng >> 33) % i]); }
+        for (unsigned oi = 0; oi < n; oi++) {
+            const unsigned i = order[oi];
             Fiber& f = B.fibers[i];
             if (f.wait == DONE) continue;
             any_live = true;

@@ -171,6 +171,23 @@ def test_grouped_wildcard_and_many_groups(world, first_pass):
         assert int(gh.groups_total[0]) == (1800 + len(set(short.tolist())) if not gmv else len(set(short.tolist()) | {1}))
 
 
+def test_group_count_sketch_for_keys_of_every_printed_length(world):
+    """LogLogBeta hashes std::to_string(distinct_key): 1 to 20 characters, four wyhash branches (<= 3, 4..7, 8..16, 17..20 bytes)"""
+    orc, g, _, _, _ = world
+    vals = []
+    for k in range(20):
+        vals += [max(10**k - 1, 0), 10**k, 10**k + 1, 7 * 10**k + 12345 % (10**k + 1)]
+    vals = sorted(set(v for v in vals if v < 2**64)) + [2**64 - 1, 2**63, 99999999, 100000000, 9999999999999999, 10**16, 2**32 - 1, 2**32]
+    col = np.array([vals[i % len(vals)] for i in range(3000)], np.uint64)
+    g.column_set(4, col.view(np.int64))
+    q = T.KwQuery([], sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=250)
+    h, gh = g.keyword_search_grouped_batch([q], [(1, 4, 1, 0, 1)], k_stride=250, g_stride=250, want_registers=True)
+    regs = np.zeros(16384, np.uint8)
+    want = O.lib().orc_loglog_of_keys(np.ascontiguousarray(np.unique(col)).ctypes.data, int(np.unique(col).size), regs.ctypes.data)
+    assert int(gh.groups_total[0]) == np.unique(col).size
+    assert np.array_equal(gh.loglog_registers[0], regs) and int(gh.groups_count[0]) == want
+
+
 def test_grouped_queries_of_more_than_three_tokens(world):
     """a batch that holds a query of more than three lists takes the 10-token form of the scoring kernel (one wave per workgroup)"""
     orc, g, _, distinct, has_value = world

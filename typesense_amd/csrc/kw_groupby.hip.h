@@ -185,18 +185,28 @@ __device__ inline uint64_t gb_wymum(uint64_t A, uint64_t B) { return __umul64hi(
 __device__ inline uint64_t gb_wymix(uint64_t A, uint64_t B) { return A ^ B ^ gb_wymum(A, B); }
 __device__ inline uint64_t gb_hash_wy_decimal(uint64_t v) {
     const uint64_t P0 = 0xa0761d6478bd642full, P1 = 0xe7037ed1a0b428dbull, P4 = 0x1d8e4e27c47d124full, P5 = 0x72b22b96e169b471ull;
-    uint8_t rev[20];
+    // the string's bytes in three registers, little-endian (byte j of the string = byte j of w2:w1:w0): the digits come out last first, each one shifts
+    // the image up by a byte — no byte array (a runtime-indexed one lives in scratch memory)
+    uint64_t w0 = 0, w1 = 0, w2 = 0;
     uint32_t len = 0;
-    do { rev[len++] = (uint8_t)('0' + (uint32_t)(v % 10)); v /= 10; } while (v);
-    // byte j of the string = rev[len - 1 - j]; little-endian reads of n bytes at string offset p
-    auto rd = [&](uint32_t p, uint32_t n) { uint64_t x = 0; for (uint32_t j = 0; j < n; j++) x |= (uint64_t)rev[len - 1 - (p + j)] << (8 * j); return x; };
+    do {
+        const uint64_t q = v / 10;
+        w2 = (w2 << 8) | (w1 >> 56); w1 = (w1 << 8) | (w0 >> 56); w0 = (w0 << 8) | (uint64_t)('0' + (uint32_t)(v - q * 10));
+        v = q; len++;
+    } while (v);
+    auto rd8 = [&](uint32_t p) -> uint64_t {                               // _wyr8 at string offset p (p + 8 <= len <= 20)
+        if (p == 0) return w0;
+        if (p < 8) return (w0 >> (8 * p)) | (w1 << (64 - 8 * p));
+        if (p == 8) return w1;
+        return (w1 >> (8 * (p - 8))) | (w2 << (64 - 8 * (p - 8)));
+    };
     const uint64_t seed = P4;                                               // seed 0 ^ secret[4]
     uint64_t h;
     if (len >= 8) {
-        if (len <= 16) h = gb_wymix(rd(0, 8) ^ P0, rd(len - 8, 8) ^ seed);
-        else h = gb_wymix(rd(0, 8) ^ P0, rd(8, 8) ^ seed) ^ gb_wymix(rd(len - 16, 8) ^ P1, rd(len - 8, 8) ^ seed);
-    } else if (len >= 4) h = gb_wymix(rd(0, 4) ^ P0, rd(len - 4, 4) ^ seed);
-    else h = gb_wymix((((uint64_t)rev[len - 1] << 16) | ((uint64_t)rev[len - 1 - (len >> 1)] << 8) | rev[0]) ^ P0, seed);     // _wyr3: p[0], p[len >> 1], p[len - 1]
+        if (len <= 16) h = gb_wymix(rd8(0) ^ P0, rd8(len - 8) ^ seed);
+        else h = gb_wymix(rd8(0) ^ P0, rd8(8) ^ seed) ^ gb_wymix(rd8(len - 16) ^ P1, rd8(len - 8) ^ seed);
+    } else if (len >= 4) h = gb_wymix((w0 & 0xFFFFFFFFull) ^ P0, ((w0 >> (8 * (len - 4))) & 0xFFFFFFFFull) ^ seed);       // _wyr4(p), _wyr4(p + len - 4)
+    else h = gb_wymix((((w0 & 0xFF) << 16) | (((w0 >> (8 * (len >> 1))) & 0xFF) << 8) | ((w0 >> (8 * (len - 1))) & 0xFF)) ^ P0, seed);     // _wyr3: p[0], p[len >> 1], p[len - 1]
     h = gb_wymum(h ^ len, P5);
     return h != ~0ull ? h : ~0ull - 1;
 }
