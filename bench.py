@@ -220,6 +220,10 @@ def loadgen_lib():
     L.tsgpu_loadgen_hits_checksum.argtypes = [vp, vp, u32, u64, u32]
     L.tsgpu_loadgen_keyword.restype = C.c_double
     L.tsgpu_loadgen_keyword.argtypes = [vp, vp, vp, u32, u32, u32, u32, u32, u32, vp, vp, C.POINTER(u64)]
+    L.tsgpu_loadgen_grouped_checksum.restype = u64
+    L.tsgpu_loadgen_grouped_checksum.argtypes = [u32, u64, u32, vp, vp, vp, vp, vp, u32]
+    L.tsgpu_loadgen_grouped.restype = C.c_double
+    L.tsgpu_loadgen_grouped.argtypes = [vp, vp, vp, u32, u32, u32, u32, u32, u32, vp, vp, C.POINTER(u64)]
     L.tsgpu_loadgen_knn.restype = C.c_double
     L.tsgpu_loadgen_knn.argtypes = [vp, vp, u32, vp, u32, u32, u32, u32, u32, vp, vp, vp, C.POINTER(u64)]
     return L
@@ -823,6 +827,33 @@ class Bench:
             grp["cpu_baseline"] = {"value": npar / t_cpu if t_cpu > 0 else None, "unit": "grouped user queries/s (two passes each)", "cores": 1, "kind": "port",
                                    "sample": "%d of the step's queries, both passes, oracle/oracle_index.h search_keyword_grouped on one core" % npar}
             orc.close()
+        # the reference's calling convention for a grouped request: T request threads, each user query = a first-pass call + a second-pass call of ONE query;
+        # concurrent calls are coalesced inside the library (the grouped combiner); every call's results against the batch path's (checksums)
+        try:
+            LG = loadgen_lib()
+            want = np.zeros(n_u, np.uint64)
+            for i in range(n_u):
+                n2 = int(g2.n_groups[i])
+                want[i] = LG.tsgpu_loadgen_grouped_checksum(int(g1.n_groups[i]), int(g1.groups_count[i]), n2, g2.distinct_key[i].ctypes.data, g2.group_found[i].ctypes.data,
+                                                            g2.group_size[i].ctypes.data, h2.keys[i].ctypes.data, h2.scores[i].ctypes.data, gl)
+            fn = C.cast(g.L.tsgpu_keyword_search_grouped_batch, C.c_void_p)
+            conc = {}
+            for threads in (1, 64, 256):
+                calls = max(2, (2000 if threads > 1 else 300) // threads)
+                lat = np.zeros(threads * calls, np.float64)
+                got = np.zeros(n_u, np.uint64)
+                fails = C.c_uint64(0)
+                LG.tsgpu_loadgen_grouped(fn, g.h, C.cast(garr, C.c_void_p), n_u, K_TOPSTER, gl, 7, threads, max(1, calls // 4), lat.ctypes.data, got.ctypes.data, C.byref(fails))   # warm-up
+                r0, c0 = g.counter("gb_batch_rounds"), g.counter("gb_batch_coalesced_calls")
+                wall = LG.tsgpu_loadgen_grouped(fn, g.h, C.cast(garr, C.c_void_p), n_u, K_TOPSTER, gl, 7, threads, calls, lat.ctypes.data, got.ctypes.data, C.byref(fails))
+                r1, c1 = g.counter("gb_batch_rounds"), g.counter("gb_batch_coalesced_calls")
+                seen = got != 0
+                conc[str(threads)] = {"value": threads * calls / wall, "unit": "grouped user queries/s (two 1-query calls each)", "p50_us": float(np.percentile(lat, 50)),
+                                      "p99_us": float(np.percentile(lat, 99)), "failures": int(fails.value), "calls_per_round": (c1 - c0) / max(1, r1 - r0),
+                                      "checksum_mismatches_vs_batch_path": int((got[seen] != want[seen]).sum()), "queries_checked": int(seen.sum())}
+            grp["concurrency"] = conc
+        except Exception as e:      # noqa: BLE001  (measurement tooling must not take the leg down)
+            grp["concurrency"] = {"error": repr(e)}
         res["group_by"] = grp
         return res
 

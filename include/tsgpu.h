@@ -159,7 +159,7 @@ int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
 int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value);
 /* introspection counters (tests / bench): "vec_overflow_rounds", "vec_prefilter_groups", "vec_prefilter_fallbacks",
  * "vec_rescored_rows", "kw_last_hit_groups" (find+score groups of the last keyword batch, 0 = fused), "kw_last_hit_records",
- * "batch_rounds" / "batch_coalesced_calls" (micro-batcher: rounds executed / calls they served), host phase totals in us over all
+ * "batch_rounds" / "batch_coalesced_calls" (micro-batcher: rounds executed / calls they served; "gb_batch_rounds" / "gb_batch_coalesced_calls": of grouped calls), host phase totals in us over all
  * keyword batches ("kw_batches", "kw_plan_us", "kw_upload_us", "kw_launch_us", "kw_wait_us", "kw_book_us", "batch_exec_us",
  * "batch_scatter_us") and over all coalesced calls ("kw_queue_us" = parked -> its round starts, "kw_wake_us" = results ready ->
  * the caller runs again) */
@@ -347,7 +347,8 @@ uint64_t tsgpu_result_ids(tsgpu_ctx* ctx, uint32_t q, uint32_t* out_host, uint64
  *   wildcard = 1: q = "*" (only sort / topster_size / excluded_ids / filter_ids of the query are read, as in tsgpu_wildcard_search_batch).
  * `sort_by: _group_found` (the count-min sketch, include/topster.h:327-340), curated hits and Union_KV are not covered: 501.
  * out and gout are HOST arrays. ids_out (nullable): the matched ids of every query (all_result_ids; group_by_missing_value_ids = those
- * of them without a value: the caller knows which). The call holds the context's index lock like a search holds Index::mutex. */
+ * of them without a value: the caller knows which). The call holds the context's index lock like a search holds Index::mutex; small calls from
+ * concurrent request threads (<= "batch_max_queries" queries each) are coalesced into one grouped batch like the plain keyword calls. */
 #define TSGPU_MAX_GROUP_LIMIT 256
 typedef struct tsgpu_group_by {
     uint32_t group_limit;            /* Topster's `distinct`, 1..TSGPU_MAX_GROUP_LIMIT */

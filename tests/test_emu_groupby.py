@@ -171,6 +171,16 @@ def test_grouped_wildcard_and_many_groups(world, first_pass):
         assert int(gh.groups_total[0]) == (1800 + len(set(short.tolist())) if not gmv else len(set(short.tolist()) | {1}))
 
 
+def test_grouped_big_output_arrays_take_the_direct_delivery(world):
+    """output arrays beyond 4 MB are copied to the caller array by array (small calls come back as one packed block)"""
+    orc, g, _, distinct, has_value = world
+    qs = [T.KwQuery([1, 2], topster_size=40), T.KwQuery([3], topster_size=40), T.KwQuery([9999], topster_size=40)]
+    for first_pass in (True, False):
+        h, gh = g.keyword_search_grouped_batch(qs, [(2, GROUP_COL, int(first_pass), 0, 0)] * len(qs), k_stride=40000, g_stride=40, want_registers=True)
+        for i, q in enumerate(qs):
+            check_query(h, gh, i, oracle_grouped(orc, q, distinct, has_value, 2, first_pass), first_pass, 2, "big strides")
+
+
 def test_group_count_sketch_for_keys_of_every_printed_length(world):
     """LogLogBeta hashes std::to_string(distinct_key): 1 to 20 characters, four wyhash branches (<= 3, 4..7, 8..16, 17..20 bytes)"""
     orc, g, _, _, _ = world
@@ -247,3 +257,62 @@ def test_grouped_bad_queries_do_not_disturb_their_neighbours(world):
     # strides too small for the request: 400 for that query
     h, gh = g.keyword_search_grouped_batch([good], [(3, GROUP_COL, 0, 0, 0)], k_stride=40, g_stride=20)
     assert int(h.status[0]) == B.ERR_INVALID
+
+
+def test_grouped_calls_from_concurrent_threads_are_coalesced_and_keep_their_own_results(world):
+    """the server's calling convention: one grouped query per call from many request threads — parked in the library's combiner, run as one batch, every
+    caller gets its own slice / id list / status (a caller whose strides are too small for its own request fails alone)"""
+    import threading
+    orc, g, _, distinct, has_value = world
+    rng = np.random.default_rng(77)
+    qs = _queries(rng, 10, 25, 2, topster_size=30) + _queries(rng, 6, 12, 1, topster_size=30)
+    passes = [int(i % 2 == 0) for i in range(len(qs))]
+    want = []
+    for q, fp in zip(qs, passes):
+        h, gh, ids = g.keyword_search_grouped_batch([q], [(2, GROUP_COL, fp, 0, 0)], k_stride=60, g_stride=30, want_ids=True, want_registers=True)
+        want.append((h, gh, ids))
+    rounds0 = g.counter("gb_batch_rounds")
+    got = [None] * len(qs)
+    errs = []
+    start = threading.Barrier(len(qs) + 1)
+
+    def body(i):
+        try:
+            start.wait()
+            for _ in range(3):
+                if i == 5:        # strides too small for this request: 400 for this caller only
+                    h, gh = g.keyword_search_grouped_batch([qs[i]], [(2, GROUP_COL, passes[i], 0, 0)], k_stride=4, g_stride=2)
+                    got[i] = (h, gh, None)
+                else:
+                    got[i] = g.keyword_search_grouped_batch([qs[i]], [(2, GROUP_COL, passes[i], 0, 0)], k_stride=60, g_stride=30, want_ids=True, want_registers=True)
+        except Exception as e:      # noqa: BLE001
+            errs.append((i, repr(e)))
+    th = [threading.Thread(target=body, args=(i,)) for i in range(len(qs))]
+    for t in th:
+        t.start()
+    start.wait()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(len(qs)):
+        h, gh, ids = got[i]
+        wh, wgh, wids = want[i]
+        if i == 5:
+            assert int(h.status[0]) in (B.ERR_INVALID, 0)
+            if int(wgh.n_groups[0]) > 2:
+                assert int(h.status[0]) == B.ERR_INVALID and int(h.n_hits[0]) == 0
+            continue
+        assert int(h.status[0]) == 0
+        assert np.array_equal(h.n_hits, wh.n_hits) and np.array_equal(h.num_matched, wh.num_matched) and np.array_equal(gh.n_groups, wgh.n_groups)
+        ng = int(gh.n_groups[0])
+        ext = int(h.n_hits[0]) if passes[i] else ng * 2
+        assert np.array_equal(gh.distinct_key[0, :ng], wgh.distinct_key[0, :ng]) and np.array_equal(gh.group_found[0, :ng], wgh.group_found[0, :ng])
+        assert np.array_equal(gh.group_size[0, :ng], wgh.group_size[0, :ng])
+        for r in range(ng):
+            n = int(gh.group_size[0, r]); lo = r * (1 if passes[i] else 2)
+            assert np.array_equal(h.keys[0, lo:lo + n], wh.keys[0, lo:lo + n]) and np.array_equal(h.scores[0, lo:lo + n], wh.scores[0, lo:lo + n])
+        assert int(gh.groups_count[0]) == int(wgh.groups_count[0]) and int(gh.groups_total[0]) == int(wgh.groups_total[0])
+        assert np.array_equal(gh.loglog_registers[0], wgh.loglog_registers[0])
+        assert np.array_equal(ids[0], wids[0]) and ext >= 0
+    # (whether calls were coalesced depends on timing; under 16 threads x 3 calls some rounds serve several callers)
+    assert g.counter("gb_batch_rounds") > rounds0

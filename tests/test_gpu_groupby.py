@@ -54,6 +54,8 @@ def test_grouped_two_fields_multi_field_and_bad_queries(world):
     E.test_grouped_two_fields_arrays_and_missing_ids(world)
     E.test_grouped_queries_of_more_than_three_tokens(world)
     E.test_group_count_sketch_for_keys_of_every_printed_length(world)
+    E.test_grouped_big_output_arrays_take_the_direct_delivery(world)
+    E.test_grouped_calls_from_concurrent_threads_are_coalesced_and_keep_their_own_results(world)
     E.test_grouped_multi_field_query()
     E.test_grouped_bad_queries_do_not_disturb_their_neighbours(world)
 

@@ -15,6 +15,7 @@
 
 namespace {
 typedef int (*kw_search_fn)(tsgpu_ctx*, const tsgpu_kw_query*, uint32_t, tsgpu_hits*);
+typedef int (*grouped_fn)(tsgpu_ctx*, const tsgpu_kw_query*, const tsgpu_group_by*, uint32_t, tsgpu_hits*, tsgpu_grouped_hits*, tsgpu_id_lists**);
 typedef int (*knn_fn)(tsgpu_ctx*, uint32_t, const float*, int, uint32_t, uint32_t, const uint32_t*, uint32_t, const uint32_t*, uint32_t, float*, uint64_t*, uint32_t*, int);
 
 inline uint64_t mix(uint64_t h, uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); return h; }
@@ -88,6 +89,72 @@ double tsgpu_loadgen_keyword(void* fn_search, tsgpu_ctx* ctx, const tsgpu_kw_que
     for (uint32_t t = 0; t < n_threads; t++) pool.emplace_back(body, t);
     start.wait(n_threads + 1);
     t0 = std::chrono::steady_clock::now();
+    for (auto& th : pool) th.join();
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (failures) *failures = fails.load();
+    return wall;
+}
+
+// checksum of one grouped user query: the first pass' group count and getGroupsCount(), then the second pass' groups in order (distinct key, found, size, every KV)
+uint64_t tsgpu_loadgen_grouped_checksum(uint32_t first_groups, uint64_t groups_count, uint32_t n_groups, const uint64_t* dkeys, const uint32_t* found, const uint32_t* gsize,
+                                        const uint64_t* keys, const int64_t* scores, uint32_t group_limit) {
+    uint64_t h = mix(0x4321, first_groups);
+    h = mix(h, groups_count);
+    h = mix(h, n_groups);
+    for (uint32_t r = 0; r < n_groups; r++) {
+        h = mix(h, dkeys[r]); h = mix(h, found[r]); h = mix(h, gsize[r]);
+        for (uint32_t j = 0; j < gsize[r]; j++) {
+            const size_t o = (size_t)r * group_limit + j;
+            h = mix(h, keys[o]); h = mix(h, (uint64_t)scores[o * 3]); h = mix(h, (uint64_t)scores[o * 3 + 1]); h = mix(h, (uint64_t)scores[o * 3 + 2]);
+        }
+    }
+    return h;
+}
+
+// group_by under the reference's calling convention: thread t issues calls_per_thread USER queries, each as the reference runs a grouped request — a FIRST-pass call,
+// then a SECOND-pass call of the same query (tsgpu_keyword_search_grouped_batch with one query each). latency_us = both calls of a user query.
+double tsgpu_loadgen_grouped(void* fn_grouped, tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t topster, uint32_t group_limit, uint32_t column,
+                             uint32_t n_threads, uint32_t calls_per_thread, double* latency_us, uint64_t* checksum, uint64_t* failures) {
+    grouped_fn search = (grouped_fn)fn_grouped;
+    std::atomic<uint64_t> fails{0};
+    SpinBarrier start;
+    auto body = [&](uint32_t t) {
+        const size_t slots = (size_t)topster * group_limit;
+        std::vector<uint64_t> keys(slots), dk(topster);
+        std::vector<int64_t> scores(slots * 3);
+        std::vector<int8_t> msi(slots);
+        std::vector<uint32_t> gs(topster), gf(topster);
+        uint32_t nh = 0, ng = 0; uint64_t nm = 0, gc = 0; int32_t st = 0, co = 0;
+        tsgpu_hits h;
+        memset(&h, 0, sizeof h);
+        h.mem = TSGPU_MEM_HOST; h.k_stride = (uint32_t)slots;
+        h.keys = keys.data(); h.scores = scores.data(); h.match_score_index = msi.data(); h.n_hits = &nh; h.num_matched = &nm; h.status = &st; h.search_cutoff = &co;
+        tsgpu_grouped_hits g;
+        memset(&g, 0, sizeof g);
+        g.g_stride = topster; g.n_groups = &ng; g.distinct_key = dk.data(); g.group_size = gs.data(); g.group_found = gf.data(); g.groups_count = &gc;
+        tsgpu_group_by gb;
+        memset(&gb, 0, sizeof gb);
+        gb.group_limit = group_limit; gb.column = (uint16_t)column;
+        start.wait(n_threads + 1);
+        for (uint32_t c = 0; c < calls_per_thread; c++) {
+            const uint64_t qi = ((uint64_t)t * calls_per_thread + c) % n_queries;
+            const tsgpu_kw_query q = queries[qi];
+            const auto a = std::chrono::steady_clock::now();
+            gb.first_pass = 1;
+            int rc = search(ctx, &q, &gb, 1, &h, &g, nullptr);
+            const uint32_t first_groups = ng; const uint64_t first_count = gc; const int32_t st1 = st;
+            gb.first_pass = 0;
+            if (rc == TSGPU_OK) rc = search(ctx, &q, &gb, 1, &h, &g, nullptr);
+            const auto b = std::chrono::steady_clock::now();
+            latency_us[(size_t)t * calls_per_thread + c] = std::chrono::duration<double, std::micro>(b - a).count();
+            if (rc != TSGPU_OK || st != TSGPU_OK || st1 != TSGPU_OK) { fails.fetch_add(1); continue; }
+            checksum[qi] = tsgpu_loadgen_grouped_checksum(first_groups, first_count, ng, dk.data(), gf.data(), gs.data(), keys.data(), scores.data(), group_limit);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < n_threads; t++) pool.emplace_back(body, t);
+    start.wait(n_threads + 1);
+    const auto t0 = std::chrono::steady_clock::now();
     for (auto& th : pool) th.join();
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (failures) *failures = fails.load();

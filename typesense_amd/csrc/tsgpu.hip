@@ -373,6 +373,8 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!strcmp(name, "batch_exec_us")) { *out = ctx->batch_exec_us.load(); return ok(); }           // coalesced rounds: batch execution / hand-out to the callers
     if (!strcmp(name, "batch_scatter_us")) { *out = ctx->batch_scatter_us.load(); return ok(); }
     if (!strcmp(name, "batch_rounds")) { *out = ctx->kw_comb.rounds + ctx->vec_comb.rounds; return ok(); }               // coalesced rounds executed so far
+    if (!strcmp(name, "gb_batch_rounds")) { *out = ctx->gb_comb.rounds; return ok(); }                                          // ... of grouped keyword calls
+    if (!strcmp(name, "gb_batch_coalesced_calls")) { *out = ctx->gb_comb.coalesced_calls; return ok(); }
     if (!strcmp(name, "batch_coalesced_calls")) { *out = ctx->kw_comb.coalesced_calls + ctx->vec_comb.coalesced_calls; return ok(); }   // calls served by those rounds
     return fail(TSGPU_ERR_NOT_FOUND, std::string("tsgpu_get_counter: unknown counter ") + name);
 }

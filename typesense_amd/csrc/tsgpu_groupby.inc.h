@@ -12,14 +12,29 @@
 
 namespace tsgpu {
 struct GroupByScratch {
-    DevBuf ids, gq, qd, mf, s0, s1, s2, dkey, rslot, hkey, hcount, hbest, hrank, members, glist, gcount;
-    DevBuf n_groups, g_total, g_dkey, g_found, g_size, g_mofs, g_mcur, loglog, loglog_hist;
-    DevBuf o_keys, o_scores, o_tm, o_vd, o_msi, o_nhits;
+    // One block per direction and kind, sub-arrays at 16-byte aligned offsets: a call costs ONE upload, TWO memsets and ONE download whatever its size (a 1-query call
+    // from a request thread spent 150 us in a dozen small pageable copies before). in = [GbQuery | KwQueryDev | KwQueryMF | ids]; ff = what starts as 0xFF
+    // [hkey | hbest | hrank]; zero = [hcount | gcount]; out = [n_hits | n_groups | groups_total | loglog_hist | g_dkey | g_size | g_found | keys | scores |
+    // match_score_index | text_match | vector_distance] (the optional arrays last: only the requested prefix crosses PCIe).
+    DevBuf in, ff, zero, out, work, loglog;          // work = per-item records + member lists + per-group offsets (never initialised, never delivered)
+    PinBuf h_in, h_out;
+    // staging of a coalesced round (gb_coalesced, under ctx->mu): grow-only — value-initialising 4 MB of vectors per round cost a millisecond
+    std::vector<uint64_t> c_keys, c_nm, c_dk, c_gtot, c_gcnt;
+    std::vector<int64_t> c_scores, c_tm;
+    std::vector<float> c_vd;
+    std::vector<int8_t> c_msi;
+    std::vector<uint32_t> c_nh, c_ng, c_gsz, c_gfound;
+    std::vector<int32_t> c_st, c_co;
+    std::vector<uint8_t> c_regs;
     void release() {
-        DevBuf* b[] = {&ids, &gq, &qd, &mf, &s0, &s1, &s2, &dkey, &rslot, &hkey, &hcount, &hbest, &hrank, &members, &glist, &gcount, &loglog_hist, &n_groups, &g_total, &g_dkey, &g_found,
-                       &g_size, &g_mofs, &g_mcur, &loglog, &o_keys, &o_scores, &o_tm, &o_vd, &o_msi, &o_nhits};
+        DevBuf* b[] = {&in, &ff, &zero, &out, &work, &loglog};
         for (auto* x : b) x->release();
+        h_in.release(); h_out.release();
     }
+};
+struct GbLayout {                                    // byte offsets inside a block
+    size_t at = 0;
+    size_t take(size_t bytes) { const size_t o = at; at = (at + bytes + 15) & ~(size_t)15; return o; }
 };
 
 // LogLogBeta::cardinality() (include/loglogbeta.h:30-44 betaApprox, :62-75 regSumAndZeros, :107-121) from the sketch's registers, or from how many
@@ -114,16 +129,11 @@ void tsgpu_groupby_destroy(tsgpu_ctx* ctx) {
     if (ctx->groupby) { ctx->groupby->release(); delete ctx->groupby; ctx->groupby = nullptr; }
 }
 
-int tsgpu_keyword_search_grouped_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries,
-                                       tsgpu_hits* out, tsgpu_grouped_hits* gout, tsgpu_id_lists** ids_out) {
-    if (ids_out) *ids_out = nullptr;
-    if (!ctx || !out || !gout || (n_queries && (!queries || !groups))) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_grouped_batch: NULL argument");
-    if (n_queries == 0) return ok();
-    if (out->mem != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_grouped_batch: host output arrays only");
-    if (!out->keys || !out->scores || !out->n_hits || !out->status) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_grouped_batch: keys / scores / n_hits / status are required");
-    if (!gout->n_groups || !gout->distinct_key || !gout->group_size || !gout->group_found || gout->g_stride == 0 || out->k_stride == 0)
-        return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_grouped_batch: n_groups / distinct_key / group_size / group_found and the strides are required");
-    std::lock_guard<std::mutex> lk(ctx->mu);                 // like a search holds Index::mutex: no commit between the id pass and the scoring
+}  // extern "C"
+
+// one grouped batch; the caller holds ctx->mu (like a search holds Index::mutex: no commit lands between the id pass and the scoring; the scratch is the context's)
+static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries,
+                           tsgpu_hits* out, tsgpu_grouped_hits* gout, tsgpu_id_lists** ids_out) {
     (void)hipSetDevice(ctx->device);
     const std::shared_ptr<const Snapshot> snap_ref = ctx->snapshot();
     const Snapshot& snap = *snap_ref;
@@ -242,48 +252,56 @@ int tsgpu_keyword_search_grouped_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* que
         const uint32_t gs = gout->g_stride, ks = out->k_stride;
         const size_t n_out = (size_t)n_queries * ks, n_g = (size_t)n_queries * gs;
         const uint64_t ni = std::max<uint64_t>(n_items, 1);
+        GbLayout Lin, Lff, Lzero, Lout, Lwork;
+        const size_t i_gq = Lin.take(sizeof(GbQuery) * n_queries), i_qd = Lin.take(sizeof(KwQueryDev) * n_queries), i_mf = Lin.take(sizeof(KwQueryMF) * n_queries), i_ids = Lin.take(ni * 4);
+        const size_t f_hkey = Lff.take(n_slots * 8), f_hbest = Lff.take(n_slots * 4), f_hrank = Lff.take(n_slots * 4);
+        const size_t z_hcount = Lzero.take(n_slots * 4), z_gcount = Lzero.take((size_t)n_queries * 4);
+        const size_t o_nhits = Lout.take((size_t)n_queries * 4), o_ng = Lout.take((size_t)n_queries * 4), o_gtot = Lout.take((size_t)n_queries * 8),
+                     o_hist = Lout.take((size_t)n_queries * GB_LOGLOG_HIST * 4), o_gdkey = Lout.take(n_g * 8), o_gsize = Lout.take(n_g * 4), o_gfound = Lout.take(n_g * 4),
+                     o_keys = Lout.take(n_out * 8), o_scores = Lout.take(n_out * 24), o_msi = Lout.take(n_out);
+        const size_t end_required = Lout.at;
+        const size_t o_tm = Lout.take(n_out * 8);
+        const size_t end_tm = Lout.at;
+        const size_t o_vd = Lout.take(n_out * 4);
+        const size_t w_s0 = Lwork.take(ni * 8), w_s1 = Lwork.take(ni * 8), w_s2 = Lwork.take(ni * 8), w_dkey = Lwork.take(ni * 8), w_rslot = Lwork.take(ni * 4),
+                     w_members = Lwork.take(ni * 4), w_glist = Lwork.take(ni * 4), w_mofs = Lwork.take(n_g * 4), w_mcur = Lwork.take(n_g * 4);
+        const size_t out_bytes = out->vector_distance ? Lout.at : (out->text_match ? end_tm : end_required);      // what the caller asked for, as a prefix
         int rc;
-        if ((rc = S.ids.reserve(ni * 4)) || (rc = S.gq.reserve(sizeof(GbQuery) * n_queries)) || (rc = S.qd.reserve(sizeof(KwQueryDev) * n_queries)) ||
-            (rc = S.mf.reserve(sizeof(KwQueryMF) * n_queries)) || (rc = S.s0.reserve(ni * 8)) || (rc = S.s1.reserve(ni * 8)) || (rc = S.s2.reserve(ni * 8)) ||
-            (rc = S.dkey.reserve(ni * 8)) || (rc = S.rslot.reserve(ni * 4)) || (rc = S.members.reserve(ni * 4)) || (rc = S.glist.reserve(ni * 4)) ||
-            (rc = S.gcount.reserve((size_t)n_queries * 4)) || (rc = S.loglog_hist.reserve((size_t)n_queries * GB_LOGLOG_HIST * 4)) || (rc = S.hkey.reserve(n_slots * 8)) ||
-            (rc = S.hcount.reserve(n_slots * 4)) || (rc = S.hbest.reserve(n_slots * 4)) || (rc = S.hrank.reserve(n_slots * 4)) ||
-            (rc = S.n_groups.reserve((size_t)n_queries * 4)) || (rc = S.g_total.reserve((size_t)n_queries * 8)) || (rc = S.g_dkey.reserve(n_g * 8)) ||
-            (rc = S.g_found.reserve(n_g * 4)) || (rc = S.g_size.reserve(n_g * 4)) || (rc = S.g_mofs.reserve(n_g * 4)) || (rc = S.g_mcur.reserve(n_g * 4)) ||
-            (rc = S.o_keys.reserve(n_out * 8)) || (rc = S.o_scores.reserve(n_out * 24)) || (rc = S.o_tm.reserve(n_out * 8)) || (rc = S.o_vd.reserve(n_out * 4)) ||
-            (rc = S.o_msi.reserve(n_out)) || (rc = S.o_nhits.reserve((size_t)n_queries * 4)))
+        if ((rc = S.in.reserve(Lin.at)) || (rc = S.ff.reserve(Lff.at)) || (rc = S.zero.reserve(Lzero.at)) || (rc = S.out.reserve(Lout.at)) || (rc = S.work.reserve(Lwork.at)) ||
+            (rc = S.h_in.reserve(Lin.at)) || (rc = S.h_out.reserve(out_bytes <= (4u << 20) ? out_bytes : o_gdkey)))
             return rc;
         const bool want_loglog = any_first;
         if (want_loglog && (rc = S.loglog.reserve((size_t)n_queries * GB_LOGLOG_M))) return rc;
-        std::vector<uint32_t> flat_ids(n_items);                 // ONE upload (a copy per query cost 7 us each: 7 ms of a 1 000-query batch)
-        for (uint32_t i = 0; i < n_queries; i++) {
-            if (!gq[i].run || gq[i].n_items == 0) continue;
-            const uint32_t* src = groups[i].wildcard ? wild_ids[i].data() : tsgpu_id_lists_ids(idl.get(), kw_index[i]);
-            memcpy(flat_ids.data() + gq[i].item_begin, src, (size_t)gq[i].n_items * 4);
+        {
+            char* hin = (char*)S.h_in.p;
+            memcpy(hin + i_gq, gq.data(), sizeof(GbQuery) * n_queries);
+            memcpy(hin + i_qd, qd.data(), sizeof(KwQueryDev) * n_queries);
+            memcpy(hin + i_mf, mf.data(), sizeof(KwQueryMF) * n_queries);
+            for (uint32_t i = 0; i < n_queries; i++) {
+                if (!gq[i].run || gq[i].n_items == 0) continue;
+                const uint32_t* src = groups[i].wildcard ? wild_ids[i].data() : tsgpu_id_lists_ids(idl.get(), kw_index[i]);
+                memcpy(hin + i_ids + (size_t)gq[i].item_begin * 4, src, (size_t)gq[i].n_items * 4);
+            }
         }
-        if (n_items) TSGPU_HIP_TRY(hipMemcpyAsync(S.ids.p, flat_ids.data(), (size_t)n_items * 4, hipMemcpyHostToDevice, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(S.gq.p, gq.data(), sizeof(GbQuery) * n_queries, hipMemcpyHostToDevice, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(S.qd.p, qd.data(), sizeof(KwQueryDev) * n_queries, hipMemcpyHostToDevice, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(S.mf.p, mf.data(), sizeof(KwQueryMF) * n_queries, hipMemcpyHostToDevice, s));
-        TSGPU_HIP_TRY(hipMemsetAsync(S.hkey.p, 0xFF, n_slots * 8, s));
-        TSGPU_HIP_TRY(hipMemsetAsync(S.hcount.p, 0, n_slots * 4, s));
-        TSGPU_HIP_TRY(hipMemsetAsync(S.hbest.p, 0xFF, n_slots * 4, s));
-        TSGPU_HIP_TRY(hipMemsetAsync(S.hrank.p, 0xFF, n_slots * 4, s));
-        TSGPU_HIP_TRY(hipMemsetAsync(S.gcount.p, 0, (size_t)n_queries * 4, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(S.in.p, S.h_in.p, i_ids + (size_t)n_items * 4, hipMemcpyHostToDevice, s));      // (pinned: the ids' one extra host copy buys a DMA at link speed)
+        TSGPU_HIP_TRY(hipMemsetAsync(S.ff.p, 0xFF, Lff.at, s));
+        TSGPU_HIP_TRY(hipMemsetAsync(S.zero.p, 0, Lzero.at, s));
         if (want_loglog) TSGPU_HIP_TRY(hipMemsetAsync(S.loglog.p, 0, (size_t)n_queries * GB_LOGLOG_M, s));     // (the kernel writes the non-zero register words)
-        // (the output staging arrays are not cleared: a caller reads the slots n_groups / group_size / n_hits describe, and those are written)
+        // (the output block is not cleared: a caller reads the slots n_groups / group_size / n_hits describe, and those are written)
         GbArgs a;
-        a.gq = S.gq.as<GbQuery>(); a.n_queries = n_queries; a.queries = S.qd.as<KwQueryDev>(); a.mfs = S.mf.as<KwQueryMF>();
-        a.n_items = n_items; a.ids = S.ids.as<uint32_t>();
-        a.s0 = S.s0.as<int64_t>(); a.s1 = S.s1.as<int64_t>(); a.s2 = S.s2.as<int64_t>(); a.dkey = S.dkey.as<unsigned long long>(); a.rslot = S.rslot.as<uint32_t>();
-        a.hkey = S.hkey.as<unsigned long long>(); a.hcount = S.hcount.as<uint32_t>(); a.hbest = S.hbest.as<uint32_t>(); a.hrank = S.hrank.as<uint32_t>();
-        a.members = S.members.as<uint32_t>(); a.glist = S.glist.as<uint32_t>(); a.gcount = S.gcount.as<uint32_t>(); a.g_stride = gs;
-        a.n_groups = S.n_groups.as<uint32_t>(); a.groups_total = S.g_total.as<unsigned long long>();
-        a.g_dkey = S.g_dkey.as<unsigned long long>(); a.g_found = S.g_found.as<uint32_t>(); a.g_size = S.g_size.as<uint32_t>();
-        a.g_mofs = S.g_mofs.as<uint32_t>(); a.g_mcur = S.g_mcur.as<uint32_t>();
-        a.loglog = want_loglog ? S.loglog.as<uint8_t>() : nullptr; a.loglog_hist = S.loglog_hist.as<uint32_t>();
-        a.out.keys = S.o_keys.as<uint64_t>(); a.out.scores = S.o_scores.as<int64_t>(); a.out.text_match = S.o_tm.as<int64_t>();
-        a.out.vector_distance = S.o_vd.as<float>(); a.out.match_score_index = S.o_msi.as<int8_t>(); a.out.n_hits = S.o_nhits.as<uint32_t>();
+        char* din = (char*)S.in.p; char* dff = (char*)S.ff.p; char* dz = (char*)S.zero.p; char* dout = (char*)S.out.p; char* dw = (char*)S.work.p;
+        a.gq = (const GbQuery*)(din + i_gq); a.n_queries = n_queries; a.queries = (const KwQueryDev*)(din + i_qd); a.mfs = (const KwQueryMF*)(din + i_mf);
+        a.n_items = n_items; a.ids = (const uint32_t*)(din + i_ids);
+        a.s0 = (int64_t*)(dw + w_s0); a.s1 = (int64_t*)(dw + w_s1); a.s2 = (int64_t*)(dw + w_s2); a.dkey = (unsigned long long*)(dw + w_dkey); a.rslot = (uint32_t*)(dw + w_rslot);
+        a.hkey = (unsigned long long*)(dff + f_hkey); a.hbest = (uint32_t*)(dff + f_hbest); a.hrank = (uint32_t*)(dff + f_hrank);
+        a.hcount = (uint32_t*)(dz + z_hcount); a.gcount = (uint32_t*)(dz + z_gcount);
+        a.members = (uint32_t*)(dw + w_members); a.glist = (uint32_t*)(dw + w_glist); a.g_stride = gs;
+        a.n_groups = (uint32_t*)(dout + o_ng); a.groups_total = (unsigned long long*)(dout + o_gtot);
+        a.g_dkey = (unsigned long long*)(dout + o_gdkey); a.g_found = (uint32_t*)(dout + o_gfound); a.g_size = (uint32_t*)(dout + o_gsize);
+        a.g_mofs = (uint32_t*)(dw + w_mofs); a.g_mcur = (uint32_t*)(dw + w_mcur);
+        a.loglog = want_loglog ? S.loglog.as<uint8_t>() : nullptr; a.loglog_hist = (uint32_t*)(dout + o_hist);
+        a.out.keys = (uint64_t*)(dout + o_keys); a.out.scores = (int64_t*)(dout + o_scores); a.out.text_match = (int64_t*)(dout + o_tm);
+        a.out.vector_distance = (float*)(dout + o_vd); a.out.match_score_index = (int8_t*)(dout + o_msi); a.out.n_hits = (uint32_t*)(dout + o_nhits);
         a.out.num_matched = nullptr; a.out.off_words = nullptr; a.out.k_stride = ks;
         IndexView v = make_view(ctx, snap);
         if (n_items) {
@@ -304,22 +322,20 @@ int tsgpu_keyword_search_grouped_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* que
         TSGPU_HIP_TRY(hipGetLastError());
         uint64_t t_launched = now_us(), t_kernels = t_launched;
         if (host_timing) { TSGPU_HIP_TRY(hipStreamSynchronize(s)); t_kernels = now_us(); }
-        // ---- delivery ----
-        TSGPU_HIP_TRY(hipMemcpyAsync(out->keys, S.o_keys.p, n_out * 8, hipMemcpyDeviceToHost, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(out->scores, S.o_scores.p, n_out * 24, hipMemcpyDeviceToHost, s));
-        if (out->text_match) TSGPU_HIP_TRY(hipMemcpyAsync(out->text_match, S.o_tm.p, n_out * 8, hipMemcpyDeviceToHost, s));
-        if (out->vector_distance) TSGPU_HIP_TRY(hipMemcpyAsync(out->vector_distance, S.o_vd.p, n_out * 4, hipMemcpyDeviceToHost, s));
-        if (out->match_score_index) TSGPU_HIP_TRY(hipMemcpyAsync(out->match_score_index, S.o_msi.p, n_out, hipMemcpyDeviceToHost, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(out->n_hits, S.o_nhits.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(gout->n_groups, S.n_groups.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(gout->distinct_key, S.g_dkey.p, n_g * 8, hipMemcpyDeviceToHost, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(gout->group_size, S.g_size.p, n_g * 4, hipMemcpyDeviceToHost, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(gout->group_found, S.g_found.p, n_g * 4, hipMemcpyDeviceToHost, s));
-        if (gout->groups_total) TSGPU_HIP_TRY(hipMemcpyAsync(gout->groups_total, S.g_total.p, (size_t)n_queries * 8, hipMemcpyDeviceToHost, s));
-        std::vector<uint32_t> hist_host;
-        if (want_loglog && gout->groups_count) {
-            hist_host.resize((size_t)n_queries * GB_LOGLOG_HIST);
-            TSGPU_HIP_TRY(hipMemcpyAsync(hist_host.data(), S.loglog_hist.p, hist_host.size() * 4, hipMemcpyDeviceToHost, s));
+        // ---- delivery: one download + plain copies of the used extents into the caller's arrays (calls of a few queries: a dozen small copies cost 150 us);
+        // a big batch's arrays go straight to the caller (two passes over 30+ MB on the host cost more than the copy calls) ----
+        const bool packed_delivery = out_bytes <= (4u << 20);
+        const size_t small_bytes = o_gdkey;                      // [n_hits | n_groups | groups_total | loglog_hist]
+        TSGPU_HIP_TRY(hipMemcpyAsync(S.h_out.p, S.out.p, packed_delivery ? out_bytes : small_bytes, hipMemcpyDeviceToHost, s));
+        if (!packed_delivery) {
+            TSGPU_HIP_TRY(hipMemcpyAsync(gout->distinct_key, dout + o_gdkey, n_g * 8, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(gout->group_size, dout + o_gsize, n_g * 4, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(gout->group_found, dout + o_gfound, n_g * 4, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(out->keys, dout + o_keys, n_out * 8, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(out->scores, dout + o_scores, n_out * 24, hipMemcpyDeviceToHost, s));
+            if (out->match_score_index) TSGPU_HIP_TRY(hipMemcpyAsync(out->match_score_index, dout + o_msi, n_out, hipMemcpyDeviceToHost, s));
+            if (out->text_match) TSGPU_HIP_TRY(hipMemcpyAsync(out->text_match, dout + o_tm, n_out * 8, hipMemcpyDeviceToHost, s));
+            if (out->vector_distance) TSGPU_HIP_TRY(hipMemcpyAsync(out->vector_distance, dout + o_vd, n_out * 4, hipMemcpyDeviceToHost, s));
         }
         if (gout->loglog_registers) {
             if (want_loglog) TSGPU_HIP_TRY(hipMemcpyAsync(gout->loglog_registers, S.loglog.p, (size_t)n_queries * GB_LOGLOG_M, hipMemcpyDeviceToHost, s));
@@ -331,6 +347,27 @@ int tsgpu_keyword_search_grouped_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* que
             fprintf(stderr, "[tsgpu] grouped batch %u queries, %llu matched ids, %llu slots: id pass %llu us, layout+upload+launch %llu us, kernels %llu us, delivery %llu us\n", n_queries,
                     (unsigned long long)n_items, (unsigned long long)n_slots, (unsigned long long)(t_ids - t_enter), (unsigned long long)(t_launched - t_ids),
                     (unsigned long long)(t_kernels - t_launched), (unsigned long long)(t_delivered - t_kernels));
+        {
+            const char* ho = (const char*)S.h_out.p;
+            memcpy(out->n_hits, ho + o_nhits, (size_t)n_queries * 4);
+            memcpy(gout->n_groups, ho + o_ng, (size_t)n_queries * 4);
+            if (gout->groups_total) memcpy(gout->groups_total, ho + o_gtot, (size_t)n_queries * 8);
+            // a caller reads the slots its counts describe: copy the rows' used extents, not the strides
+            for (uint32_t i = 0; packed_delivery && i < n_queries; i++) {
+                if (status[i] != TSGPU_OK) continue;
+                const size_t ng = gout->n_groups[i], ext = groups[i].first_pass ? out->n_hits[i] : ng * groups[i].group_limit;
+                const size_t go = (size_t)i * gs, ro = (size_t)i * ks;
+                memcpy(gout->distinct_key + go, ho + o_gdkey + go * 8, ng * 8);
+                memcpy(gout->group_size + go, ho + o_gsize + go * 4, ng * 4);
+                memcpy(gout->group_found + go, ho + o_gfound + go * 4, ng * 4);
+                memcpy(out->keys + ro, ho + o_keys + ro * 8, ext * 8);
+                memcpy(out->scores + ro * 3, ho + o_scores + ro * 24, ext * 24);
+                if (out->match_score_index) memcpy(out->match_score_index + ro, ho + o_msi + ro, ext);
+                if (out->text_match) memcpy(out->text_match + ro, ho + o_tm + ro * 8, ext * 8);
+                if (out->vector_distance) memcpy(out->vector_distance + ro, ho + o_vd + ro * 4, ext * 4);
+            }
+        }
+        const uint32_t* hist_host = (const uint32_t*)((const char*)S.h_out.p + o_hist);
         for (uint32_t i = 0; i < n_queries; i++) {
             out->status[i] = status[i];
             if (out->num_matched) out->num_matched[i] = status[i] == TSGPU_OK ? num_matched[i] : 0;
@@ -338,7 +375,7 @@ int tsgpu_keyword_search_grouped_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* que
             if (status[i] != TSGPU_OK) { out->n_hits[i] = 0; gout->n_groups[i] = 0; if (gout->groups_total) gout->groups_total[i] = 0; }
             if (gout->groups_count) {
                 uint64_t card = 0;
-                if (status[i] == TSGPU_OK && groups[i].first_pass && !gb_loglog_cardinality_hist(hist_host.data() + (size_t)i * GB_LOGLOG_HIST, &card)) {
+                if (status[i] == TSGPU_OK && groups[i].first_pass && !gb_loglog_cardinality_hist(hist_host + (size_t)i * GB_LOGLOG_HIST, &card)) {
                     std::vector<uint8_t> regs(GB_LOGLOG_M);      // (a register above 38: the ordered sum over the registers themselves)
                     TSGPU_HIP_TRY(hipMemcpy(regs.data(), S.loglog.as<uint8_t>() + (size_t)i * GB_LOGLOG_M, GB_LOGLOG_M, hipMemcpyDeviceToHost));
                     card = gb_loglog_cardinality(regs.data());
@@ -360,6 +397,140 @@ int tsgpu_keyword_search_grouped_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* que
         }
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_grouped_batch: host allocation failed"); }
     return ok();
+}
+
+namespace tsgpu {
+struct GbRequest : ParkedRequest {
+    const tsgpu_kw_query* q = nullptr;
+    const tsgpu_group_by* g = nullptr;
+    tsgpu_hits* out = nullptr;
+    tsgpu_grouped_hits* gout = nullptr;
+    tsgpu_id_lists* ids = nullptr;                   // non-null: the caller wants its matched ids
+};
+}
+
+// The reference reaches the grouped seam like the plain one: once per query, from many request threads (src/index.cpp:3488). Small concurrent calls are
+// parked in a combiner (tsgpu_batcher.h) and run as ONE grouped batch; every caller gets its own slice, id list and status (a caller whose strides are too
+// small for its own request fails alone).
+static int gb_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries, tsgpu_hits* out, tsgpu_grouped_hits* gout,
+                        tsgpu_id_lists** ids_out) {
+    std::unique_ptr<tsgpu_id_lists> lists;
+    if (ids_out) { lists.reset(new (std::nothrow) tsgpu_id_lists); if (!lists) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_grouped_batch: host allocation failed"); }
+    GbRequest me;
+    me.units = n_queries; me.q = queries; me.g = groups; me.out = out; me.gout = gout; me.ids = lists.get();
+    typedef std::unique_lock<std::mutex> Lock;
+    auto acquire = [&]() { return std::unique_ptr<Lock>(new Lock(ctx->mu)); };
+    const uint32_t round_cap = std::max<uint32_t>(ctx->batch_round_queries, n_queries);
+    auto pick = [&](std::vector<GbRequest*>& pending, std::vector<GbRequest*>& round) {
+        uint32_t units = 0;
+        size_t take = 0;
+        while (take < pending.size() && (take == 0 || units + pending[take]->units <= round_cap)) units += pending[take++]->units;
+        round.assign(pending.begin(), pending.begin() + take);
+        pending.erase(pending.begin(), pending.begin() + take);
+    };
+    auto exec = [&](std::vector<GbRequest*>& round, std::unique_ptr<Lock>&) {
+        int rc = TSGPU_OK;
+        std::string err;
+        try {
+            uint32_t total = 0, KS = 1, GS = 1;
+            bool want_ids = false, want_regs = false;
+            for (GbRequest* r : round) {
+                total += r->units; KS = std::max(KS, r->out->k_stride); GS = std::max(GS, r->gout->g_stride);
+                want_ids = want_ids || r->ids != nullptr; want_regs = want_regs || r->gout->loglog_registers != nullptr;
+            }
+            std::vector<tsgpu_kw_query> q(total);
+            std::vector<tsgpu_group_by> g(total);
+            uint32_t at = 0;
+            for (GbRequest* r : round) {
+                memcpy(q.data() + at, r->q, (size_t)r->units * sizeof(tsgpu_kw_query)); memcpy(g.data() + at, r->g, (size_t)r->units * sizeof(tsgpu_group_by));
+                at += r->units;
+            }
+            const size_t slots = (size_t)total * KS, gslots = (size_t)total * GS;
+            if (!ctx->groupby) ctx->groupby = new GroupByScratch;
+            GroupByScratch& S = *ctx->groupby;
+            auto grow = [](auto& v, size_t n) { if (v.size() < n) v.resize(n); };
+            grow(S.c_keys, slots); grow(S.c_nm, total); grow(S.c_dk, gslots); grow(S.c_gtot, total); grow(S.c_gcnt, total); grow(S.c_scores, slots * 3); grow(S.c_tm, slots);
+            grow(S.c_vd, slots); grow(S.c_msi, slots); grow(S.c_nh, total); grow(S.c_ng, total); grow(S.c_gsz, gslots); grow(S.c_gfound, gslots); grow(S.c_st, total); grow(S.c_co, total);
+            if (want_regs) grow(S.c_regs, (size_t)total * GB_LOGLOG_M);
+            auto &keys = S.c_keys, &nm = S.c_nm, &dk = S.c_dk, &gtot = S.c_gtot, &gcnt = S.c_gcnt;
+            auto &scores = S.c_scores, &tm = S.c_tm; auto& vd = S.c_vd; auto& msi = S.c_msi;
+            auto &nh = S.c_nh, &ng = S.c_ng, &gsz = S.c_gsz, &gfound = S.c_gfound; auto &st = S.c_st, &co = S.c_co; auto& regs = S.c_regs;
+            tsgpu_hits h;
+            memset(&h, 0, sizeof h);
+            h.mem = TSGPU_MEM_HOST; h.k_stride = KS;
+            h.keys = keys.data(); h.scores = scores.data(); h.text_match = tm.data(); h.vector_distance = vd.data(); h.match_score_index = msi.data();
+            h.n_hits = nh.data(); h.num_matched = nm.data(); h.status = st.data(); h.search_cutoff = co.data();
+            tsgpu_grouped_hits gh;
+            memset(&gh, 0, sizeof gh);
+            gh.g_stride = GS; gh.n_groups = ng.data(); gh.distinct_key = dk.data(); gh.group_size = gsz.data(); gh.group_found = gfound.data();
+            gh.groups_total = gtot.data(); gh.groups_count = gcnt.data(); gh.loglog_registers = want_regs ? regs.data() : nullptr;
+            tsgpu_id_lists* all_raw = nullptr;
+            rc = gb_batch_locked(ctx, q.data(), g.data(), total, &h, &gh, want_ids ? &all_raw : nullptr);
+            std::unique_ptr<tsgpu_id_lists> all_ids(all_raw);
+            if (rc != TSGPU_OK) err = tls_error();
+            else {
+                at = 0;
+                for (GbRequest* r : round) {
+                    tsgpu_hits& o = *r->out;
+                    tsgpu_grouped_hits& og = *r->gout;
+                    for (uint32_t i = 0; i < r->units; i++) {
+                        const uint32_t gi = at + i;
+                        int32_t s_ = st[gi];
+                        uint32_t groups_n = ng[gi], hits_n = nh[gi];
+                        size_t extent = r->g[i].first_pass ? hits_n : (size_t)groups_n * r->g[i].group_limit;       // second pass: group r at slot r * group_limit
+                        if (s_ == TSGPU_OK && (extent > o.k_stride || groups_n > og.g_stride)) { s_ = TSGPU_ERR_INVALID; groups_n = 0; hits_n = 0; extent = 0; }   // this caller's strides are too small
+                        if (s_ != TSGPU_OK) { groups_n = 0; hits_n = 0; extent = 0; }
+                        o.status[i] = s_; o.n_hits[i] = hits_n;
+                        if (o.num_matched) o.num_matched[i] = s_ == TSGPU_OK ? nm[gi] : 0;
+                        if (o.search_cutoff) o.search_cutoff[i] = co[gi];
+                        const size_t src = (size_t)gi * KS, dst = (size_t)i * o.k_stride;
+                        memcpy(o.keys + dst, keys.data() + src, extent * 8);
+                        memcpy(o.scores + dst * 3, scores.data() + src * 3, extent * 24);
+                        if (o.text_match) memcpy(o.text_match + dst, tm.data() + src, extent * 8);
+                        if (o.vector_distance) memcpy(o.vector_distance + dst, vd.data() + src, extent * 4);
+                        if (o.match_score_index) memcpy(o.match_score_index + dst, msi.data() + src, extent);
+                        const size_t gsrc = (size_t)gi * GS, gdst = (size_t)i * og.g_stride;
+                        og.n_groups[i] = groups_n;
+                        memcpy(og.distinct_key + gdst, dk.data() + gsrc, (size_t)groups_n * 8);
+                        memcpy(og.group_size + gdst, gsz.data() + gsrc, (size_t)groups_n * 4);
+                        memcpy(og.group_found + gdst, gfound.data() + gsrc, (size_t)groups_n * 4);
+                        if (og.groups_total) og.groups_total[i] = s_ == TSGPU_OK ? gtot[gi] : 0;
+                        if (og.groups_count) og.groups_count[i] = s_ == TSGPU_OK ? gcnt[gi] : 0;
+                        if (og.loglog_registers) memcpy(og.loglog_registers + (size_t)i * GB_LOGLOG_M, regs.data() + (size_t)gi * GB_LOGLOG_M, GB_LOGLOG_M);
+                    }
+                    if (r->ids) {
+                        r->ids->begin.resize((size_t)r->units + 1);
+                        const uint64_t b0 = all_ids->begin[at];
+                        for (uint32_t i = 0; i <= r->units; i++) r->ids->begin[i] = all_ids->begin[at + i] - b0;
+                        r->ids->ids.assign(all_ids->ids.begin() + b0, all_ids->ids.begin() + all_ids->begin[at + r->units]);
+                    }
+                    at += r->units;
+                }
+            }
+        } catch (const std::bad_alloc&) { rc = TSGPU_ERR_NO_MEMORY; err = "tsgpu_keyword_search_grouped_batch: host allocation failed"; }
+        for (GbRequest* r : round) { r->rc = rc; r->err = err; }
+    };
+    ctx->gb_comb.run(me, ctx->gb_callers, ctx->batch_window_us, acquire, pick, exec);
+    if (me.rc != TSGPU_OK) return fail(me.rc, me.err);
+    if (ids_out) *ids_out = lists.release();
+    return ok();
+}
+
+extern "C" {
+
+int tsgpu_keyword_search_grouped_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries,
+                                       tsgpu_hits* out, tsgpu_grouped_hits* gout, tsgpu_id_lists** ids_out) {
+    if (ids_out) *ids_out = nullptr;
+    if (!ctx || !out || !gout || (n_queries && (!queries || !groups))) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_grouped_batch: NULL argument");
+    if (n_queries == 0) return ok();
+    if (out->mem != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_grouped_batch: host output arrays only");
+    if (!out->keys || !out->scores || !out->n_hits || !out->status) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_grouped_batch: keys / scores / n_hits / status are required");
+    if (!gout->n_groups || !gout->distinct_key || !gout->group_size || !gout->group_found || gout->g_stride == 0 || out->k_stride == 0)
+        return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_grouped_batch: n_groups / distinct_key / group_size / group_found and the strides are required");
+    struct CallerCount { std::atomic<int>& c; explicit CallerCount(std::atomic<int>& x) : c(x) { c.fetch_add(1); } ~CallerCount() { c.fetch_sub(1); } } cc(ctx->gb_callers);
+    if (n_queries <= ctx->batch_max_queries && ctx->gb_callers.load() > 1) return gb_coalesced(ctx, queries, groups, n_queries, out, gout, ids_out);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return gb_batch_locked(ctx, queries, groups, n_queries, out, gout, ids_out);
 }
 
 }  // extern "C"

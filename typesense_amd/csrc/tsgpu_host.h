@@ -376,6 +376,7 @@ struct KwLane {
 
 struct KwRequest;                                    // tsgpu.hip
 struct GroupByScratch;                               // tsgpu_groupby.inc.h
+struct GbRequest;                                    // tsgpu_groupby.inc.h
 struct VecRequest;                                   // tsgpu_vec.hip
 
 }  // namespace tsgpu
@@ -504,7 +505,8 @@ struct tsgpu_ctx {
     std::atomic<int> last_lane{0};                   // lane of the most recent batch (legacy tsgpu_result_ids)
     tsgpu::Combiner<tsgpu::KwRequest> kw_comb;
     tsgpu::Combiner<tsgpu::VecRequest> vec_comb;
-    std::atomic<int> kw_callers{0}, vec_callers{0};  // threads currently inside the search entry points
+    tsgpu::Combiner<tsgpu::GbRequest> gb_comb;       // grouped keyword calls (tsgpu_keyword_search_grouped_batch)
+    std::atomic<int> kw_callers{0}, vec_callers{0}, gb_callers{0};  // threads currently inside the search entry points
     uint32_t ticks_per_us = 100;                     // device wall clock (hipDeviceAttributeWallClockRate)
     bool hybrid_overlap = true;                      // tsgpu_hybrid_search_batch: keyword pass and vector pass at the same time (option "hybrid_overlap")
     uint32_t vec_batch_post_window_us = 300;         // vector rounds: after the executor is free the leader waits this long for the callers of the round that just
