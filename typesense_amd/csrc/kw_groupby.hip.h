@@ -53,6 +53,7 @@ struct GbQuery {
     uint32_t column;          // the distinct-key column
     uint32_t first_block;     // the query's first workgroup in the per-item launches (ceil(n_items / GB_THREADS) workgroups each: no workgroup spans two queries)
     uint8_t first_pass, group_missing_values, wildcard, run;   // run = 0: the query failed upstream, nothing is produced
+    uint8_t iota, pad[3];     // q = * over the whole collection: the matched ids are 0 .. n_items - 1 (gb_iota_kernel writes them)
 };
 
 struct GbArgs {
@@ -92,6 +93,13 @@ __device__ inline bool gb_item_of(const GbArgs& a, uint32_t& qi, uint64_t& item)
 
 __device__ inline bool gb_rec_greater(const GbArgs& a, uint64_t x, uint64_t y) {       // KV::is_greater on records (global item indices)
     return ent_greater(a.s0[x], a.s1[x], a.s2[x], (int64_t)a.ids[x], a.s0[y], a.s1[y], a.s2[y], (int64_t)a.ids[y]);
+}
+
+// ---- q = * without filter / excluded ids: the id array of the query is 0 .. num_docs - 1 ----
+__global__ __launch_bounds__(GB_THREADS) void gb_iota_kernel(GbArgs a) {
+    uint32_t qi; uint64_t i;
+    if (!gb_item_of(a, qi, i)) return;
+    if (a.gq[qi].iota) ((uint32_t*)a.ids)[i] = (uint32_t)(i - a.gq[qi].item_begin);
 }
 
 // ---- scoring of every matched id ----

@@ -176,6 +176,8 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
         }
         // ---- step 1: the matched ids ----
         std::vector<std::vector<uint32_t>> wild_ids(n_queries);
+        std::vector<uint8_t> iota(n_queries, 0);             // q = * without filter / excluded ids: the matched ids are 0 .. num_docs - 1, written on the device
+        bool any_iota = false;
         std::unique_ptr<tsgpu_id_lists> idl;
         std::vector<uint32_t> kw_index(n_queries, 0xFFFFFFFFu);
         {
@@ -186,6 +188,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
                 const tsgpu_kw_query& in = queries[i];
                 if (groups[i].wildcard) {
                     // Index::search_wildcard ranks the filter ids (every seq_id without a filter) minus the excluded ids (src/index.cpp:6674-6676)
+                    if (in.n_filter == 0 && in.n_excluded == 0) { iota[i] = 1; any_iota = true; num_matched[i] = ctx->num_docs; continue; }
                     std::vector<uint32_t>& w = wild_ids[i];
                     const uint32_t n = in.n_filter ? in.n_filter : ctx->num_docs;
                     w.reserve(n);
@@ -233,8 +236,9 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
             GbQuery& g = gq[i];
             g.item_begin = n_items; g.tab_off = n_slots;
             g.run = status[i] == TSGPU_OK ? 1 : 0;
+            g.iota = iota[i];
             uint64_t n = 0;
-            if (g.run) n = groups[i].wildcard ? wild_ids[i].size() : tsgpu_id_lists_count(idl.get(), kw_index[i]);
+            if (g.run) n = iota[i] ? ctx->num_docs : (groups[i].wildcard ? wild_ids[i].size() : tsgpu_id_lists_count(idl.get(), kw_index[i]));
             if (n > 0x7FFFFFFFull) { status[i] = TSGPU_ERR_UNSUPPORTED; g.run = 0; n = 0; }
             g.n_items = (uint32_t)n;
             uint64_t size = 64;
@@ -278,12 +282,19 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
             memcpy(hin + i_qd, qd.data(), sizeof(KwQueryDev) * n_queries);
             memcpy(hin + i_mf, mf.data(), sizeof(KwQueryMF) * n_queries);
             for (uint32_t i = 0; i < n_queries; i++) {
-                if (!gq[i].run || gq[i].n_items == 0) continue;
+                if (!gq[i].run || gq[i].n_items == 0 || iota[i]) continue;
                 const uint32_t* src = groups[i].wildcard ? wild_ids[i].data() : tsgpu_id_lists_ids(idl.get(), kw_index[i]);
                 memcpy(hin + i_ids + (size_t)gq[i].item_begin * 4, src, (size_t)gq[i].n_items * 4);
             }
         }
-        TSGPU_HIP_TRY(hipMemcpyAsync(S.in.p, S.h_in.p, i_ids + (size_t)n_items * 4, hipMemcpyHostToDevice, s));      // (pinned: the ids' one extra host copy buys a DMA at link speed)
+        if (!any_iota) TSGPU_HIP_TRY(hipMemcpyAsync(S.in.p, S.h_in.p, i_ids + (size_t)n_items * 4, hipMemcpyHostToDevice, s));      // (pinned: the ids' one extra host copy buys a DMA at link speed)
+        else {
+            // the descriptions, then the id arrays of the queries that have one; the others' ids (0 .. num_docs - 1) are written by gb_iota_kernel
+            TSGPU_HIP_TRY(hipMemcpyAsync(S.in.p, S.h_in.p, i_ids, hipMemcpyHostToDevice, s));
+            for (uint32_t i = 0; i < n_queries; i++)
+                if (gq[i].run && gq[i].n_items && !iota[i])
+                    TSGPU_HIP_TRY(hipMemcpyAsync((char*)S.in.p + i_ids + (size_t)gq[i].item_begin * 4, (char*)S.h_in.p + i_ids + (size_t)gq[i].item_begin * 4, (size_t)gq[i].n_items * 4, hipMemcpyHostToDevice, s));
+        }
         TSGPU_HIP_TRY(hipMemsetAsync(S.ff.p, 0xFF, Lff.at, s));
         TSGPU_HIP_TRY(hipMemsetAsync(S.zero.p, 0, Lzero.at, s));
         if (want_loglog) TSGPU_HIP_TRY(hipMemsetAsync(S.loglog.p, 0, (size_t)n_queries * GB_LOGLOG_M, s));     // (the kernel writes the non-zero register words)
@@ -305,6 +316,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
         a.out.num_matched = nullptr; a.out.off_words = nullptr; a.out.k_stride = ks;
         IndexView v = make_view(ctx, snap);
         if (n_items) {
+            if (any_iota) hipLaunchKernelGGL(gb_iota_kernel, dim3((uint32_t)n_blocks), dim3(GB_THREADS), 0, s, a);
             uint32_t max_lists = 0;
             for (uint32_t i = 0; i < n_queries; i++) if (gq[i].run) max_lists = std::max(max_lists, qd[i].n_lists);
             if (max_lists <= 3) hipLaunchKernelGGL((gb_score_kernel<3>), dim3((uint32_t)n_blocks), dim3(GB_THREADS), 0, s, v, a);
@@ -390,6 +402,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
             il->ids.resize(il->begin[n_queries]);
             for (uint32_t i = 0; i < n_queries; i++) {
                 if (!gq[i].n_items) continue;
+                if (iota[i]) { for (uint32_t j = 0; j < gq[i].n_items; j++) il->ids[il->begin[i] + j] = j; continue; }
                 const uint32_t* src = groups[i].wildcard ? wild_ids[i].data() : tsgpu_id_lists_ids(idl.get(), kw_index[i]);
                 memcpy(il->ids.data() + il->begin[i], src, (size_t)gq[i].n_items * 4);
             }
