@@ -26,6 +26,7 @@ cd $ROOT
 python profiles/summarize_rocprof.py $O/trace_kw > $P/rocprof_keyword_${TAG}_stats.txt 2>&1
 python profiles/summarize_rocprof.py $O/trace_vec > $P/rocprof_vector_${TAG}_stats.txt 2>&1
 python profiles/summarize_rocprof.py $O/trace_kwg > $P/rocprof_kwgeneral_${TAG}_stats.txt 2>&1
+python profiles/summarize_rocprof.py $O/trace_kwg gb_ > $P/rocprof_groupby_${TAG}_stats.txt 2>&1          # the group_by leg's kernels (kw_groupby.hip.h)
 python tools/pmc_summary.py $O/pmc_kw_fetch "kw_" > $P/pmc_kw_fetch.txt 2>&1
 python tools/pmc_summary.py $O/pmc_vec_fetch "vec_" > $P/pmc_vec_fetch.txt 2>&1
 python tools/pmc_summary.py $O/pmc_kw_sq1 "kw_" > $P/pmc_kw_sq1.txt 2>&1
