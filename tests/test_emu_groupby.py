@@ -162,13 +162,17 @@ def test_grouped_wildcard_and_many_groups(world, first_pass):
     excl = np.sort(rng.choice(3000, 100, replace=False)).astype(np.uint32)
     sort = ((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, -1, 0))
     qs = [T.KwQuery([], sort=sort, topster_size=250), T.KwQuery([], sort=sort, topster_size=250, filter_ids=filt, excluded_ids=excl),
-          T.KwQuery([], sort=((B.SORT_TEXT_MATCH, -1, 0), (B.SORT_INT64_COLUMN, -1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=100, excluded_ids=excl)]
+          T.KwQuery([], sort=((B.SORT_TEXT_MATCH, -1, 0), (B.SORT_INT64_COLUMN, -1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=100, excluded_ids=excl),
+          T.KwQuery([], sort=sort, topster_size=600), T.KwQuery([], sort=sort, topster_size=1000, excluded_ids=excl)]      # Topsters beyond 256 / 768: the larger top-K buffers
     for gmv in (0, 1):
         groups = [(3, 2, int(first_pass), gmv, 1)] * len(qs)
-        h, gh = g.keyword_search_grouped_batch(qs, groups, k_stride=750, g_stride=250, want_registers=True)
+        h, gh = g.keyword_search_grouped_batch(qs, groups, k_stride=3000, g_stride=1000, want_registers=True)
         for i, q in enumerate(qs):
             check_query(h, gh, i, oracle_grouped_wildcard(q, 3000, points, short, 3, first_pass, bool(gmv)), first_pass, 3, "wild gmv=%d" % gmv)
         assert int(gh.groups_total[0]) == (1800 + len(set(short.tolist())) if not gmv else len(set(short.tolist()) | {1}))
+    # a batch whose largest Topster is 600: the middle top-K buffer
+    h, gh = g.keyword_search_grouped_batch(qs[3:4], [(2, 2, int(first_pass), 0, 1)], k_stride=1200, g_stride=600)
+    check_query(h, gh, 0, oracle_grouped_wildcard(qs[3], 3000, points, short, 2, first_pass, False), first_pass, 2, "wild k=600")
 
 
 def test_grouped_big_output_arrays_take_the_direct_delivery(world):
