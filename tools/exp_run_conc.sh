@@ -2,10 +2,10 @@
 # usage: bash tools/exp_run_conc.sh "optA=1,optB=2" "optC=3" ...
 for set in "$@"; do
   opts=""; for o in ${set//,/ }; do [ "$o" = "-" ] || opts="$opts --opt $o"; done
-  python bench.py --workload keyword --no-cpu-baseline --steps 3 --warmup 1 $opts > /tmp/conc.json 2>/dev/null
+  python bench.py --workload keyword --no-cpu-baseline --steps 3 --warmup 1 --detail-out /tmp/conc_detail.json $opts > /tmp/conc.json 2>/dev/null   # (the compact stdout line carries only value / p50 / p99 per thread count: the full record is the detail file)
   SET="$set" python - <<P
 import json, os
-d=json.loads(open("/tmp/conc.json").read().strip().splitlines()[-1])
+d=json.load(open("/tmp/conc_detail.json"))
 def find(o):
     if isinstance(o,dict):
         if "concurrency" in o: return o["concurrency"]
