@@ -969,10 +969,12 @@ struct BatchOpts {
                                                       // them out (the coalesced round hands every caller its slice straight from there)
     bool timing = true;                               // record the phase events (tsgpu_timings); a coalesced round has no single caller to report to
     const KwVFlat* vflat = nullptr;                   // wildcard form ranking a distance matrix: the flat branch of the vector search (tsgpu_vector_search_batch)
+    DevBuf* ids_dev = nullptr;                        // with id_lists: gather the matched ids into THIS device buffer (the caller's) and leave id_lists->ids empty — for a
+    bool* ids_dev_done = nullptr;                     // consumer on the device (group_by, tsgpu_groupby.inc.h); not done (false) when a query's ids need the host's sort
 };
 }
 static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, const BatchOpts& bo);
-static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, tsgpu_id_lists** ids_out);
+static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, tsgpu_id_lists** ids_out, DevBuf* ids_dev = nullptr, bool* ids_dev_done = nullptr);
 static int kw_split_host(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out);
 
 int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out) {
@@ -1160,14 +1162,15 @@ static int kw_split_host(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t
     return ok();
 }
 
-static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, tsgpu_id_lists** ids_out) {
+static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, tsgpu_id_lists** ids_out, DevBuf* ids_dev, bool* ids_dev_done) {
+    if (ids_dev_done) *ids_dev_done = false;
     if (!ctx || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: NULL argument");
     if (n_queries == 0) { if (ids_out) { *ids_out = new (std::nothrow) tsgpu_id_lists; if (*ids_out) (*ids_out)->begin.assign(1, 0); } return ok(); }
     if (!queries) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: queries is NULL");
     if (!out->keys || !out->scores || !out->n_hits || !out->status) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: missing output arrays");
     struct CallerCount { std::atomic<int>& c; explicit CallerCount(std::atomic<int>& x) : c(x) { c.fetch_add(1); } ~CallerCount() { c.fetch_sub(1); } } cc(ctx->kw_callers);
     const bool legacy_keep = ctx->keep_ids;
-    if (!wildcard && !legacy_keep && out->mem == TSGPU_MEM_HOST && n_queries <= ctx->batch_max_queries && ctx->kw_callers.load() > 1)
+    if (!wildcard && !legacy_keep && !ids_dev && out->mem == TSGPU_MEM_HOST && n_queries <= ctx->batch_max_queries && ctx->kw_callers.load() > 1)
         return kw_coalesced(ctx, queries, n_queries, out, ids_out);
     if (!wildcard && !legacy_keep && !ids_out && out->mem == TSGPU_MEM_HOST && ctx->kw_host_split_queries && ctx->n_lanes >= 2 &&
         (uint64_t)n_queries >= 4ull * ctx->kw_host_split_queries)
@@ -1178,6 +1181,7 @@ static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n
     bo.wildcard = wildcard;
     bo.keep_ids = legacy_keep || ids_out != nullptr;
     bo.id_lists = lists.get();
+    bo.ids_dev = lists ? ids_dev : nullptr; bo.ids_dev_done = ids_dev_done;
     bo.record_last = legacy_keep;
     LaneLock ll(ctx, legacy_keep ? 0 : (tsgpu::tls_avoid_lane0() ? -2 : -1));          // the legacy "last batch" id API is single-caller: always lane 0
     const int rc = kw_batch_on_lane(ctx, *ll.L, queries, n_queries, out, bo);
@@ -1659,6 +1663,18 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
                 }
             }
             il.begin[n_queries] = at;
+            bool to_dev = bo.ids_dev != nullptr;              // the ids stay on the device, in the caller's buffer (several driver lists: the union is sorted on the host below)
+            for (uint32_t i = 0; to_dev && i < n_queries; i++) if (P.status[i] == TSGPU_OK && P.q[i].mf_index != KW_NONE) to_dev = false;
+            if (bo.ids_dev_done) *bo.ids_dev_done = to_dev;
+            if (to_dev) {
+                if (at) {
+                    if ((rc = bo.ids_dev->reserve(at * 4)) || (rc = upload(L.d_idseg, segs.data(), segs.size() * sizeof(KwIdCopy), s))) return rc;
+                    hipLaunchKernelGGL(kw_ids_gather_kernel, dim3((uint32_t)segs.size()), dim3(KW_THREADS), 0, s, (const uint32_t*)ids_out, L.d_idseg.as<KwIdCopy>(), bo.ids_dev->as<uint32_t>());
+                    TSGPU_HIP_TRY(hipGetLastError());
+                    TSGPU_HIP_TRY(hipStreamSynchronize(s));    // (the consumer runs on another stream)
+                }
+                at = 0;                                       // nothing to download
+            }
             il.ids.resize(at);
             if (at) {
                 if ((rc = L.d_idflat.reserve(at * 4)) || (rc = upload(L.d_idseg, segs.data(), segs.size() * sizeof(KwIdCopy), s))) return rc;

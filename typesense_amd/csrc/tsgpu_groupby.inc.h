@@ -17,6 +17,7 @@ struct GroupByScratch {
     // [hkey | hbest | hrank]; zero = [hcount | gcount]; out = [n_hits | n_groups | groups_total | loglog_hist | g_dkey | g_size | g_found | keys | scores |
     // match_score_index | text_match | vector_distance] (the optional arrays last: only the requested prefix crosses PCIe).
     DevBuf in, ff, zero, out, work, loglog;          // work = per-item records + member lists + per-group offsets (never initialised, never delivered)
+    DevBuf ids_dev;                                  // the id pass' matched ids when they never leave the device (a batch of single-field keyword queries)
     PinBuf h_in, h_out;
     // staging of a coalesced round (gb_coalesced, under ctx->mu): grow-only — value-initialising 4 MB of vectors per round cost a millisecond
     std::vector<uint64_t> c_keys, c_nm, c_dk, c_gtot, c_gcnt;
@@ -27,7 +28,7 @@ struct GroupByScratch {
     std::vector<int32_t> c_st, c_co;
     std::vector<uint8_t> c_regs;
     void release() {
-        DevBuf* b[] = {&in, &ff, &zero, &out, &work, &loglog};
+        DevBuf* b[] = {&in, &ff, &zero, &out, &work, &loglog, &ids_dev};
         for (auto* x : b) x->release();
         h_in.release(); h_out.release();
     }
@@ -180,6 +181,8 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
         bool any_iota = false;
         std::unique_ptr<tsgpu_id_lists> idl;
         std::vector<uint32_t> kw_index(n_queries, 0xFFFFFFFFu);
+        bool ids_on_dev = false, any_wild = false;
+        for (uint32_t i = 0; i < n_queries; i++) any_wild = any_wild || (status[i] == TSGPU_OK && groups[i].wildcard);
         {
             std::vector<tsgpu_kw_query> kq;
             std::vector<uint32_t> kq_of;
@@ -220,7 +223,9 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
                 th.keys = t_keys.data(); th.scores = t_scores.data(); th.match_score_index = t_msi.data(); th.n_hits = t_nh.data(); th.num_matched = t_nm.data();
                 th.status = t_st.data(); th.search_cutoff = t_co.data();
                 tsgpu_id_lists* raw = nullptr;
-                const int rc = kw_dispatch(ctx, kq.data(), nk, &th, false, &raw);
+                // a batch without wildcard queries: the ids go straight into this call's device buffer (no download + upload) unless a query's ids need the host's sort
+                if (!ctx->groupby) ctx->groupby = new GroupByScratch;
+                const int rc = kw_dispatch(ctx, kq.data(), nk, &th, false, &raw, any_wild ? nullptr : &ctx->groupby->ids_dev, &ids_on_dev);
                 idl.reset(raw);
                 if (rc != TSGPU_OK) return rc;
                 for (uint32_t j = 0; j < nk; j++) {
@@ -257,7 +262,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
         const size_t n_out = (size_t)n_queries * ks, n_g = (size_t)n_queries * gs;
         const uint64_t ni = std::max<uint64_t>(n_items, 1);
         GbLayout Lin, Lff, Lzero, Lout, Lwork;
-        const size_t i_gq = Lin.take(sizeof(GbQuery) * n_queries), i_qd = Lin.take(sizeof(KwQueryDev) * n_queries), i_mf = Lin.take(sizeof(KwQueryMF) * n_queries), i_ids = Lin.take(ni * 4);
+        const size_t i_gq = Lin.take(sizeof(GbQuery) * n_queries), i_qd = Lin.take(sizeof(KwQueryDev) * n_queries), i_mf = Lin.take(sizeof(KwQueryMF) * n_queries), i_ids = Lin.take(ids_on_dev ? 16 : ni * 4);
         const size_t f_hkey = Lff.take(n_slots * 8), f_hbest = Lff.take(n_slots * 4), f_hrank = Lff.take(n_slots * 4);
         const size_t z_hcount = Lzero.take(n_slots * 4), z_gcount = Lzero.take((size_t)n_queries * 4);
         const size_t o_nhits = Lout.take((size_t)n_queries * 4), o_ng = Lout.take((size_t)n_queries * 4), o_gtot = Lout.take((size_t)n_queries * 8),
@@ -281,13 +286,14 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
             memcpy(hin + i_gq, gq.data(), sizeof(GbQuery) * n_queries);
             memcpy(hin + i_qd, qd.data(), sizeof(KwQueryDev) * n_queries);
             memcpy(hin + i_mf, mf.data(), sizeof(KwQueryMF) * n_queries);
-            for (uint32_t i = 0; i < n_queries; i++) {
+            for (uint32_t i = 0; !ids_on_dev && i < n_queries; i++) {
                 if (!gq[i].run || gq[i].n_items == 0 || iota[i]) continue;
                 const uint32_t* src = groups[i].wildcard ? wild_ids[i].data() : tsgpu_id_lists_ids(idl.get(), kw_index[i]);
                 memcpy(hin + i_ids + (size_t)gq[i].item_begin * 4, src, (size_t)gq[i].n_items * 4);
             }
         }
-        if (!any_iota) TSGPU_HIP_TRY(hipMemcpyAsync(S.in.p, S.h_in.p, i_ids + (size_t)n_items * 4, hipMemcpyHostToDevice, s));      // (pinned: the ids' one extra host copy buys a DMA at link speed)
+        if (ids_on_dev) TSGPU_HIP_TRY(hipMemcpyAsync(S.in.p, S.h_in.p, i_ids, hipMemcpyHostToDevice, s));      // the descriptions only: the ids are where the id pass gathered them
+        else if (!any_iota) TSGPU_HIP_TRY(hipMemcpyAsync(S.in.p, S.h_in.p, i_ids + (size_t)n_items * 4, hipMemcpyHostToDevice, s));      // (pinned: the ids' one extra host copy buys a DMA at link speed)
         else {
             // the descriptions, then the id arrays of the queries that have one; the others' ids (0 .. num_docs - 1) are written by gb_iota_kernel
             TSGPU_HIP_TRY(hipMemcpyAsync(S.in.p, S.h_in.p, i_ids, hipMemcpyHostToDevice, s));
@@ -302,7 +308,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
         GbArgs a;
         char* din = (char*)S.in.p; char* dff = (char*)S.ff.p; char* dz = (char*)S.zero.p; char* dout = (char*)S.out.p; char* dw = (char*)S.work.p;
         a.gq = (const GbQuery*)(din + i_gq); a.n_queries = n_queries; a.queries = (const KwQueryDev*)(din + i_qd); a.mfs = (const KwQueryMF*)(din + i_mf);
-        a.n_items = n_items; a.ids = (const uint32_t*)(din + i_ids);
+        a.n_items = n_items; a.ids = ids_on_dev ? S.ids_dev.as<uint32_t>() : (const uint32_t*)(din + i_ids);
         a.s0 = (int64_t*)(dw + w_s0); a.s1 = (int64_t*)(dw + w_s1); a.s2 = (int64_t*)(dw + w_s2); a.dkey = (unsigned long long*)(dw + w_dkey); a.rslot = (uint32_t*)(dw + w_rslot);
         a.hkey = (unsigned long long*)(dff + f_hkey); a.hbest = (uint32_t*)(dff + f_hbest); a.hrank = (uint32_t*)(dff + f_hrank);
         a.hcount = (uint32_t*)(dz + z_hcount); a.gcount = (uint32_t*)(dz + z_gcount);
@@ -400,7 +406,8 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
             il->begin.assign((size_t)n_queries + 1, 0);
             for (uint32_t i = 0; i < n_queries; i++) il->begin[i + 1] = il->begin[i] + gq[i].n_items;
             il->ids.resize(il->begin[n_queries]);
-            for (uint32_t i = 0; i < n_queries; i++) {
+            if (ids_on_dev && n_items) TSGPU_HIP_TRY(hipMemcpy(il->ids.data(), S.ids_dev.p, (size_t)n_items * 4, hipMemcpyDeviceToHost));      // (same order: query by query)
+            for (uint32_t i = 0; !ids_on_dev && i < n_queries; i++) {
                 if (!gq[i].n_items) continue;
                 if (iota[i]) { for (uint32_t j = 0; j < gq[i].n_items; j++) il->ids[il->begin[i] + j] = j; continue; }
                 const uint32_t* src = groups[i].wildcard ? wild_ids[i].data() : tsgpu_id_lists_ids(idl.get(), kw_index[i]);
