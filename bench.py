@@ -854,6 +854,56 @@ class Bench:
             grp["concurrency"] = conc
         except Exception as e:      # noqa: BLE001  (measurement tooling must not take the leg down)
             grp["concurrency"] = {"error": repr(e)}
+        # search_all_candidates with group_by: 10 candidate combinations per user query folded into ONE distinct Topster (tsgpu_keyword_search_grouped_candidates_batch)
+        try:
+            n_cu = max(4, n_g // 5)
+            ccombos = [[self.T.KwQuery(c, sort=self.sort, topster_size=K_TOPSTER, total_cost=(j > 0)) for j, c in enumerate(gtoks[u])] for u in range(n_cu)]
+            cres = {}
+            for fp in (1, 0):
+                tbest = None
+                for _ in range(3):
+                    t0 = time.time()
+                    ch, cg, cq = g.keyword_search_grouped_candidates_batch(ccombos, [(gl, 7, fp, 0, 0)] * n_cu, k_stride=K_TOPSTER * gl, g_stride=K_TOPSTER)
+                    dt = time.time() - t0
+                    tbest = dt if tbest is None else min(tbest, dt)
+                cres[fp] = (ch, cg, cq, tbest)
+            cand_g = {"workload": "%d user queries x 10 candidate-token combinations each, group_by (%d groups), both passes; one distinct Topster and one groups_processed per user query" % (n_cu, n_grp),
+                      "first_pass_ms": 1e3 * cres[1][3], "second_pass_ms": 1e3 * cres[0][3], "value": n_cu / (cres[1][3] + cres[0][3]), "unit": "grouped user queries/s (10 combinations, two passes each)",
+                      "status_nonzero": int((cres[0][0].status != 0).sum() + (cres[1][0].status != 0).sum())}
+            if not args.no_cpu_baseline:
+                npar = min(n_cu, 4)
+                orc = O.OracleIndex(1, 1)
+                orc.set_num_docs(self.n_docs)
+                orc.set_sort_dense(0, self.pts)
+                for t in np.unique(np.concatenate([np.concatenate(gtoks[u]) for u in range(npar)])):
+                    ids, oi, off = synth.csr_term(self.csr, t)
+                    if ids.size:
+                        orc.load_posting(0, int(t), ids, oi, off)
+                bad = 0
+                for u in range(npar):
+                    oqs = [orc.make_query(c, sort=osort, fetch_size=100, total_cost=int(j > 0)) for j, c in enumerate(gtoks[u])]
+                    for fp in (1, 0):
+                        ref, rqi = orc.search_candidates_grouped(oqs, distinct, gl, bool(fp))
+                        ch, cg, cq, _ = cres[fp]
+                        n = int(cg.n_groups[u])
+                        ok = n == ref.n_groups and int(ch.num_matched[u]) == ref.num_keyword_matches and int(cg.groups_total[u]) == ref.groups_exact
+                        if ok and fp:
+                            want = sorted(zip(ref.scores[:, 0].tolist(), ref.scores[:, 1].tolist(), ref.keys.tolist(), ref.distinct_key.tolist(), ref.group_found.tolist(), rqi.tolist()), reverse=True)
+                            got = list(zip(ch.scores[u, :n, 0].tolist(), ch.scores[u, :n, 1].tolist(), ch.keys[u, :n].tolist(), cg.distinct_key[u, :n].tolist(), cg.group_found[u, :n].tolist(), cq[u, :n].tolist()))
+                            ok = got == want and int(cg.groups_count[u]) == ref.groups_count
+                        elif ok:
+                            ok = np.array_equal(cg.distinct_key[u, :n], ref.distinct_key) and np.array_equal(cg.group_found[u, :n], ref.group_found)
+                            for r in range(n if ok else 0):
+                                a, b = int(ref.begin[r]), int(ref.begin[r + 1])
+                                ok = ok and np.array_equal(ch.keys[u, r * gl:r * gl + b - a], ref.keys[a:b]) and np.array_equal(ch.scores[u, r * gl:r * gl + b - a], ref.scores[a:b]) \
+                                    and np.array_equal(cq[u, r * gl:r * gl + b - a], rqi[a:b].astype(np.uint32))
+                        bad += 0 if ok else 1
+                cand_g["parity"] = {"checked": 2 * npar, "mismatches": bad, "what": "both passes of %d user queries vs the oracle's search_all_candidates over one distinct Topster at %d docs "
+                                                                                    "(groups, KVs, query_index, groups_processed, group count)" % (npar, self.n_docs)}
+                orc.close()
+            grp["candidate_combinations"] = cand_g
+        except Exception as e:      # noqa: BLE001
+            grp["candidate_combinations"] = {"error": repr(e)}
         # q = * with group_by over the whole collection (every document is a matched id: the tables hold 2 x n_docs slots)
         try:
             wq = self.T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=K_TOPSTER)

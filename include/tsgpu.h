@@ -370,6 +370,18 @@ typedef struct tsgpu_grouped_hits {
 } tsgpu_grouped_hits;
 int tsgpu_keyword_search_grouped_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries,
                                        tsgpu_hits* out, tsgpu_grouped_hits* gout, tsgpu_id_lists** ids_out);
+/* The same over candidate-token combinations (Index::search_all_candidates with group_limit != 0, src/index.cpp:1794-1894 over :5511-5549): the combinations of user
+ * query u — combos[group_begin[u] .. group_begin[u + 1]), at most 16, in the reference's pass order, groups[u] its group_by — are one search_across_fields pass each
+ * over ONE distinct Topster and ONE groups_processed, folded on the device:
+ *   first pass : a group's KV = the greatest over all combinations' KVs of its documents (an equal KV of a later combination replaces the earlier one,
+ *     include/topster.h:392-406: its query_index is the later pass'); group_found counts every add, as the reference's first pass does; the sketch sees every key;
+ *   second pass: a document met by several combinations counts ONCE (group_doc_seq_ids -> ret == 2, src/index.cpp:5546-5549) and contributes its greatest KV (the
+ *     later combination's on ties) to its group's Topster.
+ * query_index [n_user * out->k_stride] (nullable): KV::query_index per hit slot = the earlier combinations of the user query that matched anything (add the caller's
+ * searched_queries.size()); num_matched = the LAST combination's count; ids_out = per user query the ascending union of its combinations' ids (all_result_ids).
+ * A user query with a failing combination reports that status and nothing else. Not coalesced across callers (a call is a batch already). */
+int tsgpu_keyword_search_grouped_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const uint32_t* group_begin, const tsgpu_group_by* groups, uint32_t n_user,
+                                                  tsgpu_hits* out, tsgpu_grouped_hits* gout, uint32_t* query_index, tsgpu_id_lists** ids_out);
 
 /* ------------------------------------------------------------------ facet counting over matched ids */
 /* The hash-index branch of Index::do_facets (src/index.cpp:1659-1771): for every matched id (ascending, e.g. the id list of

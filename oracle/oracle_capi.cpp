@@ -150,6 +150,26 @@ int32_t orc_search_keyword_grouped(void* h, const orc_kw_query* q, const uint64_
     if (out->result_ids) std::copy(r.result_ids.begin(), r.result_ids.begin() + std::min<size_t>(r.result_ids.size(), out->result_ids_cap), out->result_ids);
     return 0;
 }
+int32_t orc_search_candidates_grouped(void* h, const orc_kw_query* combos, uint32_t n_combos, const uint64_t* distinct_ids, const uint8_t* has_value, uint32_t n_distinct,
+                                      int32_t group_missing_values, uint32_t group_limit, int32_t first_pass, orc_grouped* out, uint16_t* query_index_out) {
+    std::vector<keyword_query_t> qs;
+    for (uint32_t i = 0; i < n_combos; i++) qs.push_back(to_query(combos + i));
+    std::vector<uint64_t> d(distinct_ids, distinct_ids + n_distinct);
+    std::vector<uint8_t> hv;
+    if (has_value) hv.assign(has_value, has_value + n_distinct);
+    grouped_result_t g;
+    const keyword_result_t r = ((Index*)h)->search_candidates_grouped(qs, d, hv, group_missing_values != 0, group_limit, first_pass != 0, g);
+    fill_grouped(g, out);
+    if (query_index_out) {                       // per KV, in the order of out->keys
+        size_t at = 0;
+        for (uint32_t i = 0; i < out->n_groups; i++) for (const KV& kv : g.groups[i]) { if (at < out->kv_cap) query_index_out[at] = kv.query_index; at++; }
+    }
+    out->n_missing = 0;
+    out->num_keyword_matches = r.num_keyword_matches;
+    out->n_result_ids = r.result_ids.size();
+    if (out->result_ids) std::copy(r.result_ids.begin(), r.result_ids.begin() + std::min<size_t>(r.result_ids.size(), out->result_ids_cap), out->result_ids);
+    return 0;
+}
 // the distinct Topster alone, fed a sequence of KVs (key, distinct_key, scores[3]) in order: what add() returned per KV + the collector's content
 int32_t orc_group_topster_run(uint32_t capacity, uint32_t distinct, int32_t first_pass, uint32_t n, const uint64_t* keys, const uint64_t* dkeys,
                               const int64_t* scores, int32_t* ret_out, orc_grouped* out) {

@@ -536,14 +536,10 @@ public:
     // held a value (oracle::distinct_id_of computes both from the facet hashes; has_value only feeds missing_ids). One pass of the reference's two-pass protocol
     // (Index::run_search, index.cpp:2488-2760): first_pass = the Topster keyed by distinct key + the LogLogBeta counter; else the
     // second pass' group_kv_map followed by populate_result_kvs. missing_ids = group_by_missing_value_ids of a first pass.
-    keyword_result_t search_keyword_grouped(const keyword_query_t& q, const std::vector<uint64_t>& distinct_ids, const std::vector<uint8_t>& has_value,
-                                            bool group_missing_values, size_t group_limit, bool first_pass, grouped_result_t& gout,
-                                            std::vector<uint32_t>* missing_ids = nullptr) const {
-        keyword_result_t out;
-        GroupTopster topster(q.topster_size ? q.topster_size : topster_size(q.fetch_size, q.filter_ids.size()), group_limit, first_pass);
-        std::unordered_map<uint64_t, uint32_t> groups_processed;
-        std::unordered_set<uint64_t> seen;
-
+    // one grouped pass of search_across_fields into the caller's collector (the reference's pass over the caller's Topster)
+    void grouped_pass(const keyword_query_t& q, const std::vector<uint64_t>& distinct_ids, const std::vector<uint8_t>& has_value, bool group_missing_values,
+                      GroupTopster& topster, std::unordered_map<uint64_t, uint32_t>& groups_processed, std::unordered_set<uint64_t>& seen, keyword_result_t& out,
+                      uint16_t query_index, std::vector<uint32_t>* missing_ids) const {
         std::vector<or_iterator_t> token_its;
         std::vector<posting_list_t*> expanded_plists;
         get_field_token_its(q, token_its, expanded_plists);
@@ -553,6 +549,7 @@ public:
         deadline_t dl;
         dl.search_begin_us = deadline_t::now_us();
         dl.search_stop_us = q.search_stop_us;
+        const bool first_pass = topster.is_group_by_first_pass;
         or_iterator_t::intersect(token_its, istate, dl, [&](single_filter_result_t& fr, const std::vector<or_iterator_t>& its) {
             const uint32_t seq_id = fr.seq_id;
             const int64_t aggregated_score = compute_aggregated_score(its, q, seq_id, &dropped_token_its);
@@ -563,7 +560,7 @@ public:
             int64_t scores[3] = {0, 0, 0};
             int64_t match_score_index = -1;
             compute_sort_scores(q.sort, seq_id, aggregated_score, scores, match_score_index, 0);
-            KV kv(0, seq_id, distinct_id, (int8_t)match_score_index, scores);
+            KV kv(query_index, seq_id, distinct_id, (int8_t)match_score_index, scores);
             if (match_score_index != -1) { kv.scores[match_score_index] = aggregated_score; kv.text_match_score = aggregated_score; }
             const int ret = topster.add(&kv);
             if (ret < 2) groups_processed[distinct_id]++;                       // :5546-5549
@@ -573,6 +570,45 @@ public:
         out.num_keyword_matches = istate.num_keyword_matches;
         out.search_cutoff = dl.search_cutoff;
         for (auto* p : expanded_plists) delete p;
+    }
+
+    keyword_result_t search_keyword_grouped(const keyword_query_t& q, const std::vector<uint64_t>& distinct_ids, const std::vector<uint8_t>& has_value,
+                                            bool group_missing_values, size_t group_limit, bool first_pass, grouped_result_t& gout,
+                                            std::vector<uint32_t>* missing_ids = nullptr) const {
+        keyword_result_t out;
+        GroupTopster topster(q.topster_size ? q.topster_size : topster_size(q.fetch_size, q.filter_ids.size()), group_limit, first_pass);
+        std::unordered_map<uint64_t, uint32_t> groups_processed;
+        std::unordered_set<uint64_t> seen;
+        grouped_pass(q, distinct_ids, has_value, group_missing_values, topster, groups_processed, seen, out, 0, missing_ids);
+        populate_grouped(topster, groups_processed, gout);
+        gout.groups_exact = seen.size();
+        return out;
+    }
+
+    // Index::search_all_candidates with group_limit != 0 (index.cpp:1794-1894 over :5511-5549): one grouped pass per candidate combination over ONE collector
+    // and ONE groups_processed; KV::query_index = searched_queries.size() at the time of the pass; a second pass counts a document once (ret == 2 afterwards),
+    // a first pass counts every add; all_result_ids = the union of the passes' ids.
+    keyword_result_t search_candidates_grouped(const std::vector<keyword_query_t>& combos, const std::vector<uint64_t>& distinct_ids, const std::vector<uint8_t>& has_value,
+                                               bool group_missing_values, size_t group_limit, bool first_pass, grouped_result_t& gout) const {
+        keyword_result_t out;
+        if (combos.empty()) return out;
+        const keyword_query_t& q0 = combos[0];
+        GroupTopster topster(q0.topster_size ? q0.topster_size : topster_size(q0.fetch_size, q0.filter_ids.size()), group_limit, first_pass);
+        std::unordered_map<uint64_t, uint32_t> groups_processed;
+        std::unordered_set<uint64_t> seen;
+        std::vector<uint32_t> all_ids;
+        uint16_t searched_queries = 0;
+        for (const keyword_query_t& q : combos) {
+            keyword_result_t pass;
+            grouped_pass(q, distinct_ids, has_value, group_missing_values, topster, groups_processed, seen, pass, searched_queries, nullptr);
+            out.num_keyword_matches = pass.num_keyword_matches;
+            out.search_cutoff = out.search_cutoff || pass.search_cutoff;
+            all_ids.insert(all_ids.end(), pass.result_ids.begin(), pass.result_ids.end());
+            if (!pass.result_ids.empty()) searched_queries++;
+        }
+        std::sort(all_ids.begin(), all_ids.end());
+        all_ids.erase(std::unique(all_ids.begin(), all_ids.end()), all_ids.end());
+        out.result_ids = all_ids;
         populate_grouped(topster, groups_processed, gout);
         gout.groups_exact = seen.size();
         return out;

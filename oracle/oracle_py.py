@@ -127,6 +127,7 @@ def lib():
         L.orc_search_keyword.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.POINTER(Result)]
         L.orc_search_wildcard.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.POINTER(Result)]
         L.orc_search_keyword_grouped.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, C.c_int32, C.POINTER(Grouped)]
+        L.orc_search_candidates_grouped.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_uint32, C.c_int32, C.POINTER(Grouped), C.c_void_p]
         L.orc_group_topster_run.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Grouped)]
         L.orc_hash_wy.restype = C.c_uint64
         L.orc_hash_wy.argtypes = [C.c_char_p, C.c_uint64]
@@ -424,6 +425,18 @@ class OracleIndex:
         self.L.orc_search_keyword_grouped(self.h, C.byref(q), _ptr(d), _ptr(hv) if hv is not None else None, d.size, int(group_missing_values), group_limit,
                                           int(first_pass), C.byref(g))
         return GroupedHits(g, b)
+
+    def search_candidates_grouped(self, combos, distinct, group_limit, first_pass, has_value=None, group_missing_values=False, group_cap=4096, kv_cap=65536, ids_cap=0):
+        """Index::search_all_candidates with group_by: one grouped pass per combination over ONE collector -> (GroupedHits, query_index per KV)"""
+        d = np.ascontiguousarray(distinct, np.uint64)
+        hv = np.ascontiguousarray(has_value, np.uint8) if has_value is not None else None
+        g, b = _alloc_grouped(group_cap, kv_cap, ids_cap)
+        arr = (KwQuery * len(combos))(*combos)
+        qi = np.zeros(kv_cap, np.uint16)
+        self.L.orc_search_candidates_grouped(self.h, arr, len(combos), _ptr(d), _ptr(hv) if hv is not None else None, d.size, int(group_missing_values), group_limit,
+                                             int(first_pass), C.byref(g), _ptr(qi))
+        gh = GroupedHits(g, b)
+        return gh, qi[:gh.keys.size].copy()
 
     def search_wildcard(self, q, cap=1024, ids_cap=0):
         r, b = self._alloc(cap, ids_cap)

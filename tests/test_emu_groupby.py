@@ -320,3 +320,37 @@ def test_grouped_calls_from_concurrent_threads_are_coalesced_and_keep_their_own_
         assert np.array_equal(ids[0], wids[0]) and ext >= 0
     # (whether calls were coalesced depends on timing; under 16 threads x 3 calls some rounds serve several callers)
     assert g.counter("gb_batch_rounds") > rounds0
+
+
+@pytest.mark.parametrize("first_pass", [True, False])
+def test_grouped_candidate_combinations_fold_like_the_shared_collector(world, first_pass):
+    """Index::search_all_candidates with group_by: the combinations of a user query are passes over ONE distinct Topster and ONE groups_processed. Neighbouring
+    token ranks make the passes overlap heavily: documents met by several combinations (a second pass counts them once, with their greatest KV — the later
+    combination on ties), passes without matches, a single-combination user query, small Topsters"""
+    orc, g, _, distinct, has_value = world
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    users = [[[1, 2], [1, 3], [2, 3], [1, 2], [9999, 1]],                      # a repeated combination: every KV ties with its earlier self -> the later pass wins
+             [[3], [4], [3, 4], [5]],
+             [[2, 1, 3]],
+             [[9999], [9998]],
+             [[1], [2], [3], [4], [5], [6], [7], [8]]]
+    tsz = [40, 5, 40, 40, 250]
+    limit = 3
+    combos = [[T.KwQuery(c, sort=sort, topster_size=tsz[u], total_cost=int(j > 0)) for j, c in enumerate(cs)] for u, cs in enumerate(users)]
+    groups = [(limit, GROUP_COL, int(first_pass), 0, 0)] * len(users)
+    h, gh, qidx, ids = g.keyword_search_grouped_candidates_batch(combos, groups, k_stride=750, g_stride=250, want_ids=True, want_registers=True)
+    assert (h.status == 0).all()
+    for u, cs in enumerate(combos):
+        ref, rqi = orc.search_candidates_grouped([H.oracle_query(orc, q) for q in cs], distinct, limit, first_pass, has_value=has_value, ids_cap=1 << 20)
+        check_query(h, gh, u, ref, first_pass, limit, "candidates u%d" % u)
+        assert np.array_equal(ids[u], ref.result_ids), u
+        ng = int(gh.n_groups[u])
+        if first_pass:        # the reference's heap order is not the library's: compare query_index per key
+            want = {int(k): int(q) for k, q in zip(ref.keys, rqi)}
+            got = {int(h.keys[u, r]): int(qidx[u, r]) for r in range(ng)}
+            assert got == want, u
+        else:
+            for r in range(ng):
+                n = int(ref.group_size[r])
+                assert np.array_equal(qidx[u, r * limit:r * limit + n], rqi[ref.begin[r]:ref.begin[r + 1]].astype(np.uint32)), (u, r)
+    assert int(gh.n_groups[3]) == 0 and int(gh.n_groups[0]) > 5

@@ -50,6 +50,11 @@ def test_grouped_wildcard_and_many_groups(world, first_pass):
     E.test_grouped_wildcard_and_many_groups(world, first_pass)
 
 
+@pytest.mark.parametrize("first_pass", [True, False])
+def test_grouped_candidate_combinations_fold_like_the_shared_collector(world, first_pass):
+    E.test_grouped_candidate_combinations_fold_like_the_shared_collector(world, first_pass)
+
+
 def test_grouped_two_fields_multi_field_and_bad_queries(world):
     E.test_grouped_two_fields_arrays_and_missing_ids(world)
     E.test_grouped_queries_of_more_than_three_tokens(world)
@@ -109,3 +114,37 @@ def test_grouped_at_2m_documents_keyword_and_wildcard(c2m):
             ret, ref = O.group_topster_run(250, 3, bool(first_pass), ids, arr, sc)
             ref.num_keyword_matches = c.n_docs
             E.check_query(h, gh, 0, ref, bool(first_pass), 3, "2M wildcard col %d" % col)
+
+
+def test_grouped_candidate_combinations_at_2m_documents(c2m):
+    """ten candidate combinations per user query (neighbouring term ranks, as the ART walk returns them) over the 2M-document collection, both passes"""
+    c = c2m
+    few, many, own = _distinct_columns(c.n_docs)
+    c.g.column_set(2, many.view(np.int64))
+    rng = np.random.default_rng(5)
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    users = []
+    for u in range(6):
+        base = rng.choice(np.arange(20, 400), size=2, replace=False)
+        cs = [base.copy()]
+        while len(cs) < 10:
+            x = cs[int(rng.integers(0, len(cs)))].copy()
+            x[int(rng.integers(0, 2))] += int(rng.integers(1, 15))
+            if x[0] != x[1] and not any(np.array_equal(x, y) for y in cs):
+                cs.append(x)
+        users.append(cs)
+    combos = [[T.KwQuery(cc, sort=sort, topster_size=250, total_cost=int(j > 0)) for j, cc in enumerate(cs)] for cs in users]
+    for first_pass in (True, False):
+        h, gh, qidx, ids = c.g.keyword_search_grouped_candidates_batch(combos, [(3, 2, int(first_pass), 0, 0)] * len(users), k_stride=750, g_stride=250, want_ids=True, want_registers=True)
+        assert (h.status == 0).all()
+        for u, cs in enumerate(combos):
+            for q in cs:
+                c.need(q.tokens)
+            ref, rqi = c.orc.search_candidates_grouped([H.oracle_query(c.orc, q) for q in cs], many, 3, first_pass, group_cap=4096, kv_cap=16384, ids_cap=1 << 22)
+            E.check_query(h, gh, u, ref, first_pass, 3, "2M candidates u%d" % u)
+            assert np.array_equal(ids[u], ref.result_ids)
+            if not first_pass:
+                for r in range(int(gh.n_groups[u])):
+                    n = int(ref.group_size[r])
+                    assert np.array_equal(qidx[u, r * 3:r * 3 + n], rqi[ref.begin[r]:ref.begin[r + 1]].astype(np.uint32))
+    assert int(gh.n_groups.sum()) > 100

@@ -111,7 +111,7 @@ EXPORTS = [
     "tsgpu_abi_version", "tsgpu_create", "tsgpu_destroy", "tsgpu_last_error", "tsgpu_set_stream", "tsgpu_set_option", "tsgpu_get_counter", "tsgpu_device_bytes",
     "tsgpu_field_create", "tsgpu_term_upsert", "tsgpu_posting_upsert", "tsgpu_posting_erase", "tsgpu_terms_load_csr", "tsgpu_column_set", "tsgpu_set_num_docs", "tsgpu_commit",
     "tsgpu_term_num_ids", "tsgpu_term_download", "tsgpu_keyword_search_batch", "tsgpu_wildcard_search_batch", "tsgpu_keyword_search_candidates_batch", "tsgpu_candidates_result_ids", "tsgpu_keep_result_ids", "tsgpu_result_ids",
-    "tsgpu_keyword_search_batch_ids", "tsgpu_keyword_search_grouped_batch", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free", "tsgpu_facet_set", "tsgpu_facet_count_batch", "tsgpu_facet_stats_batch", "tsgpu_facet_value_set", "tsgpu_facet_value_count_batch",
+    "tsgpu_keyword_search_batch_ids", "tsgpu_keyword_search_grouped_batch", "tsgpu_keyword_search_grouped_candidates_batch", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free", "tsgpu_facet_set", "tsgpu_facet_count_batch", "tsgpu_facet_stats_batch", "tsgpu_facet_value_set", "tsgpu_facet_value_count_batch",
     "tsgpu_vec_create", "tsgpu_vec_upsert", "tsgpu_vec_delete", "tsgpu_vec_get", "tsgpu_vec_count", "tsgpu_vec_knn_batch",
     "tsgpu_vec_hnsw_load", "tsgpu_vec_hnsw_enable", "tsgpu_vec_hnsw_export", "tsgpu_vec_hnsw_search_batch", "tsgpu_vec_distances", "tsgpu_ip_distance", "tsgpu_vector_search_batch", "tsgpu_vector_search_batch_ids", "tsgpu_hybrid_search_batch", "tsgpu_hybrid_fuse_batch", "tsgpu_keyword_aux_scores", "tsgpu_merge_shard_hits", "tsgpu_merge_shard_hits_device", "tsgpu_last_timings", "tsgpu_kw_last_touched", "tsgpu_kw_lists_footprint",
     "tsgpu_group_create_local", "tsgpu_group_unique_id", "tsgpu_group_create_rank", "tsgpu_group_create_rank_host", "tsgpu_group_destroy", "tsgpu_group_size", "tsgpu_group_keyword_search_batch",
@@ -172,6 +172,7 @@ def lib(path=None):
     L.tsgpu_result_ids.restype = u64
     L.tsgpu_keyword_search_batch_ids.argtypes = [vp, vp, u32, C.POINTER(HitsC), C.POINTER(vp)]
     L.tsgpu_keyword_search_grouped_batch.argtypes = [vp, vp, vp, u32, C.POINTER(HitsC), C.POINTER(GroupedHitsC), C.POINTER(vp)]
+    L.tsgpu_keyword_search_grouped_candidates_batch.argtypes = [vp, vp, vp, vp, u32, C.POINTER(HitsC), C.POINTER(GroupedHitsC), vp, C.POINTER(vp)]
     L.tsgpu_id_lists_count.argtypes = [vp, u32]
     L.tsgpu_id_lists_count.restype = u64
     L.tsgpu_id_lists_ids.argtypes = [vp, u32]

@@ -53,12 +53,19 @@ struct GbQuery {
     uint32_t column;          // the distinct-key column
     uint32_t first_block;     // the query's first workgroup in the per-item launches (ceil(n_items / GB_THREADS) workgroups each: no workgroup spans two queries)
     uint8_t first_pass, group_missing_values, wildcard, run;   // run = 0: the query failed upstream, nothing is produced
-    uint8_t iota, pad[3];     // q = * over the whole collection: the matched ids are 0 .. n_items - 1 (gb_iota_kernel writes them)
+    uint8_t iota, dedupe, pad[2];   // iota: q = * over the whole collection, the matched ids are 0 .. n_items - 1 (gb_iota_kernel writes them); dedupe: a SECOND pass over several
+                              // candidate combinations — a document met by several of them counts once, with its greatest KV (the later combination on ties)
+    uint32_t first_combo, n_combos; // the user query's candidate combinations (search_all_candidates: one search_across_fields pass each; 1 = a plain pass): its items are the
+                              // combinations' matched ids one after the other, combination c at items [combo_begin[c], combo_begin[c + 1])
 };
 
 struct GbArgs {
     const GbQuery* gq; uint32_t n_queries;
-    const KwQueryDev* queries; const KwQueryMF* mfs;
+    const KwQueryDev* queries; const KwQueryMF* mfs;                       // per COMBINATION
+    const unsigned long long* combo_begin; const uint32_t* qidx_of_combo;   // per combination: first item; KV::query_index of its hits (earlier combinations of the user query that matched)
+    uint8_t* pass;                                                             // per matched id: which combination of its user query met it
+    uint32_t* dkey32; uint32_t* dbest;                                         // per table slot, dedupe only: the document table (seq_id -> its greatest record)
+    uint32_t* out_qidx;                                                        // per hit slot (like out): KV::query_index
     uint64_t n_items;
     const uint32_t* ids;                                                       // matched ids, ascending per query
     int64_t* s0; int64_t* s1; int64_t* s2; unsigned long long* dkey; uint32_t* rslot;    // per matched id
@@ -91,8 +98,12 @@ __device__ inline bool gb_item_of(const GbArgs& a, uint32_t& qi, uint64_t& item)
     return local < a.gq[qi].n_items;
 }
 
-__device__ inline bool gb_rec_greater(const GbArgs& a, uint64_t x, uint64_t y) {       // KV::is_greater on records (global item indices)
-    return ent_greater(a.s0[x], a.s1[x], a.s2[x], (int64_t)a.ids[x], a.s0[y], a.s1[y], a.s2[y], (int64_t)a.ids[y]);
+__device__ inline bool gb_rec_greater(const GbArgs& a, uint64_t x, uint64_t y) {       // KV::is_greater on records (global item indices); equal KVs of one document
+    if (a.s0[x] != a.s0[y]) return a.s0[x] > a.s0[y];                                   // (met by two candidate combinations): the LATER combination wins — Topster::add
+    if (a.s1[x] != a.s1[y]) return a.s1[x] > a.s1[y];                                   // replaces a KV unless the new one is smaller (include/topster.h:392-406)
+    if (a.s2[x] != a.s2[y]) return a.s2[x] > a.s2[y];
+    if (a.ids[x] != a.ids[y]) return a.ids[x] > a.ids[y];
+    return a.pass[x] > a.pass[y];
 }
 
 // ---- q = * without filter / excluded ids: the id array of the query is 0 .. num_docs - 1 ----
@@ -108,13 +119,16 @@ __global__ __launch_bounds__(TMAX <= 3 ? GB_THREADS : 64) void gb_score_kernel(I
     uint32_t qi; uint64_t i;
     if (!gb_item_of<(TMAX <= 3 ? GB_THREADS : 64)>(a, qi, i)) return;
     const GbQuery g = a.gq[qi];
-    const KwQueryDev& q = a.queries[qi];
+    uint32_t c = g.first_combo;                                              // the combination that met this id (<= 16 per user query)
+    while (c + 1 < g.first_combo + g.n_combos && a.combo_begin[c + 1] <= i) c++;
+    a.pass[i] = (uint8_t)(c - g.first_combo);
+    const KwQueryDev& q = a.queries[c];
     const uint32_t seq_id = a.ids[i];
     ScoredHit h;
     if (g.wildcard) {
         h = sort_scores(ix, q, seq_id, 100, 0, false, 0.0f);                 // Index::search_wildcard: the text-match slot is the constant 100 (src/index.cpp:6728-6730)
     } else {
-        const KwQueryMF& mf = a.mfs[qi];
+        const KwQueryMF& mf = a.mfs[c];
         uint32_t pos[TMAX * KW_MAX_FIELDS];
         uint32_t tokens_found = 0;
 #pragma unroll
@@ -136,9 +150,9 @@ __global__ __launch_bounds__(TMAX <= 3 ? GB_THREADS : 64) void gb_score_kernel(I
         h = sort_scores(ix, q, seq_id, agg, off_words);
     }
     a.s0[i] = h.s0; a.s1[i] = h.s1; a.s2[i] = h.s2;
-    const uint32_t c = g.column;
+    const uint32_t col = g.column;
     // the group column holds get_distinct_id's result per seq_id; a document beyond it has no value in any group_by field (src/index.cpp:7104-7111)
-    a.dkey[i] = (c < ix.n_columns && seq_id < ix.column_len[c]) ? (unsigned long long)ix.columns[c][seq_id]
+    a.dkey[i] = (col < ix.n_columns && seq_id < ix.column_len[col]) ? (unsigned long long)ix.columns[col][seq_id]
                                                                  : (g.group_missing_values ? 1ull : (unsigned long long)seq_id);
 }
 
@@ -147,11 +161,39 @@ __device__ inline uint64_t gb_mix(uint64_t x) {
     return x;
 }
 
+// ---- second pass over several candidate combinations: one record per document (its greatest KV, the later combination on ties) ----
+__device__ inline uint32_t gb_doc_slot(const GbArgs& a, const GbQuery& g, uint32_t seq_id, bool claim) {
+    uint32_t slot = (seq_id * 2654435761u) & g.tab_mask;
+    for (;;) {
+        uint32_t* kp = a.dkey32 + g.tab_off + slot;
+        uint32_t cur = *kp;
+        if (cur == GB_NONE && claim) { cur = atomicCAS(kp, GB_NONE, seq_id); if (cur == GB_NONE) cur = seq_id; }
+        if (cur == seq_id) return slot;
+        slot = (slot + 1) & g.tab_mask;
+    }
+}
+__global__ __launch_bounds__(GB_THREADS) void gb_dedupe_kernel(GbArgs a) {
+    uint32_t qi; uint64_t i;
+    if (!gb_item_of(a, qi, i)) return;
+    const GbQuery g = a.gq[qi];
+    if (!g.dedupe) return;
+    const uint32_t slot = gb_doc_slot(a, g, a.ids[i], true);
+    const uint32_t me = (uint32_t)(i - g.item_begin);
+    uint32_t* bp = a.dbest + g.tab_off + slot;
+    uint32_t cur = atomicCAS(bp, GB_NONE, me);
+    while (cur != GB_NONE && gb_rec_greater(a, i, g.item_begin + cur)) {
+        const uint32_t prev = atomicCAS(bp, cur, me);
+        if (prev == cur) break;
+        cur = prev;
+    }
+}
+
 // ---- group table: slot per distinct key, member count, best record ----
 __global__ __launch_bounds__(GB_THREADS) void gb_insert_kernel(GbArgs a) {
     uint32_t qi; uint64_t i;
     if (!gb_item_of(a, qi, i)) return;
     const GbQuery g = a.gq[qi];
+    if (g.dedupe && a.dbest[g.tab_off + gb_doc_slot(a, g, a.ids[i], false)] != (uint32_t)(i - g.item_begin)) { a.rslot[i] = GB_NONE; return; }   // not its document's record
     const unsigned long long key = a.dkey[i];
     uint32_t slot;
     if (key == GB_EMPTY) slot = g.tab_mask + 1;
@@ -283,12 +325,23 @@ __global__ __launch_bounds__(GB_THREADS) void gb_select_kernel(GbArgs a) {
     topk_compact<CAP, true>(tk, &s_cnt, g.k, thr, &s_have);
     const uint32_t n = s_cnt;                                                // min(k, groups), sorted descending
     int msi = -1;
-    for (int i = 0; i < 3; i++) if (i < (int)a.queries[qi].n_sort && a.queries[qi].sort_kind[i] == 0) msi = i;
+    for (int i = 0; i < 3; i++) if (i < (int)a.queries[g.first_combo].n_sort && a.queries[g.first_combo].sort_kind[i] == 0) msi = i;
     const uint32_t* qids = a.ids + g.item_begin;
     for (uint32_t r = t; r < n; r += GB_THREADS) {
         const uint32_t key = (uint32_t)tk.key[r];
-        uint32_t lo = 0, hi = g.n_items;                                     // the record of the entry: its id's position in the query's ascending ids
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (qids[mid] < key) lo = mid + 1; else hi = mid; }
+        // the record of the entry: its id's position in a combination's ascending ids — the one its group's table names as the best record
+        uint32_t lo = 0;
+        for (uint32_t c = g.first_combo; c < g.first_combo + g.n_combos; c++) {
+            const uint32_t b = (uint32_t)(a.combo_begin[c] - g.item_begin);
+            uint32_t hi = (uint32_t)(a.combo_begin[c + 1] - g.item_begin);
+            const uint32_t end = hi;
+            lo = b;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (qids[mid] < key) lo = mid + 1; else hi = mid; }
+            if (lo < end && qids[lo] == key) {
+                const uint32_t sl = a.rslot[g.item_begin + lo];
+                if (sl != GB_NONE && a.hbest[g.tab_off + sl] == lo) break;
+            }
+        }
         const uint32_t slot = a.rslot[g.item_begin + lo];
         a.hrank[g.tab_off + slot] = r;
         const uint32_t members = a.hcount[g.tab_off + slot];
@@ -302,6 +355,7 @@ __global__ __launch_bounds__(GB_THREADS) void gb_select_kernel(GbArgs a) {
             a.out.text_match[o] = msi == 0 ? tk.s0[r] : (msi == 1 ? tk.s1[r] : (msi == 2 ? tk.s2[r] : 0));
             a.out.vector_distance[o] = -1.0f;
             a.out.match_score_index[o] = (int8_t)msi;
+            a.out_qidx[o] = a.qidx_of_combo[g.first_combo + a.pass[g.item_begin + lo]];
         }
     }
     if (!g.first_pass) for (uint32_t r = t; r < n; r += GB_THREADS) regs[r] = a.g_found[gbase + r];       // (the register words are free in a second pass; n <= 1024 < 4096)
@@ -342,7 +396,9 @@ __global__ __launch_bounds__(GB_THREADS) void gb_scatter_kernel(GbArgs a) {
     if (!gb_item_of(a, qi, i)) return;
     const GbQuery g = a.gq[qi];
     if (g.first_pass) return;
-    const uint32_t r = a.hrank[g.tab_off + a.rslot[i]];
+    const uint32_t rs = a.rslot[i];
+    if (rs == GB_NONE) return;                                               // (dedupe: not its document's record)
+    const uint32_t r = a.hrank[g.tab_off + rs];
     if (r == GB_NONE) return;
     const size_t gi = (size_t)qi * a.g_stride + r;
     const uint32_t at = atomicAdd(&a.g_mcur[gi], 1u);
@@ -361,21 +417,23 @@ __global__ __launch_bounds__(GB_THREADS) void gb_members_kernel(GbArgs a) {
     const size_t gi = (size_t)qi * a.g_stride + r;
     const uint32_t cnt = a.g_found[gi], take = a.g_size[gi];
     const uint32_t* mem = a.members + g.item_begin + a.g_mofs[gi];
-    const KwQueryDev& q = a.queries[qi];
+    const KwQueryDev& q = a.queries[g.first_combo];
     int msi = -1;
     for (int i = 0; i < 3; i++) if (i < (int)q.n_sort && q.sort_kind[i] == 0) msi = i;
     int64_t p0 = 0, p1 = 0, p2 = 0, pk = -1;                                 // the previous extraction (pk < 0: none yet)
     for (uint32_t j = 0; j < take; j++) {
         int64_t b0 = 0, b1 = 0, b2 = 0, bk = -1;                             // this lane's greatest record below the previous extraction (bk < 0: none)
+        uint32_t bx = 0;                                                     // ... and which record it is (local item index)
         for (uint32_t m = lane; m < cnt; m += 64) {
             const uint64_t x = g.item_begin + mem[m];
             const int64_t c0 = a.s0[x], c1 = a.s1[x], c2 = a.s2[x], ck = (int64_t)a.ids[x];
             if (pk >= 0 && !ent_greater(p0, p1, p2, pk, c0, c1, c2, ck)) continue;
-            if (ent_greater(c0, c1, c2, ck, b0, b1, b2, bk)) { b0 = c0; b1 = c1; b2 = c2; bk = ck; }
+            if (ent_greater(c0, c1, c2, ck, b0, b1, b2, bk)) { b0 = c0; b1 = c1; b2 = c2; bk = ck; bx = mem[m]; }
         }
         for (int d = 32; d > 0; d >>= 1) {
             const int64_t o0 = __shfl_xor(b0, d, 64), o1 = __shfl_xor(b1, d, 64), o2 = __shfl_xor(b2, d, 64), ok = __shfl_xor(bk, d, 64);
-            if (ent_greater(o0, o1, o2, ok, b0, b1, b2, bk)) { b0 = o0; b1 = o1; b2 = o2; bk = ok; }
+            const uint32_t ox = __shfl_xor(bx, d, 64);
+            if (ent_greater(o0, o1, o2, ok, b0, b1, b2, bk)) { b0 = o0; b1 = o1; b2 = o2; bk = ok; bx = ox; }
         }
         if (lane == 0) {
             const size_t o = (size_t)qi * a.out.k_stride + (size_t)r * g.group_limit + j;
@@ -384,6 +442,7 @@ __global__ __launch_bounds__(GB_THREADS) void gb_members_kernel(GbArgs a) {
             a.out.text_match[o] = msi == 0 ? b0 : (msi == 1 ? b1 : (msi == 2 ? b2 : 0));
             a.out.vector_distance[o] = -1.0f;
             a.out.match_score_index[o] = (int8_t)msi;
+            a.out_qidx[o] = a.qidx_of_combo[g.first_combo + a.pass[g.item_begin + bx]];
         }
         p0 = b0; p1 = b1; p2 = b2; pk = bk;
     }

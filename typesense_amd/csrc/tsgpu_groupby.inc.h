@@ -132,47 +132,55 @@ void tsgpu_groupby_destroy(tsgpu_ctx* ctx) {
 
 }  // extern "C"
 
-// one grouped batch; the caller holds ctx->mu (like a search holds Index::mutex: no commit lands between the id pass and the scoring; the scratch is the context's)
-static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries,
-                           tsgpu_hits* out, tsgpu_grouped_hits* gout, tsgpu_id_lists** ids_out) {
+// one grouped batch; the caller holds ctx->mu (like a search holds Index::mutex: no commit lands between the id pass and the scoring; the scratch is the context's).
+// User query u owns the candidate combinations combos[cfirst[u] .. cfirst[u + 1]) — one search_across_fields pass each over ONE collector (Index::search_all_candidates,
+// src/index.cpp:1794-1894); the plain entry point passes one combination per query. query_index (nullable): KV::query_index per hit slot.
+static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const uint32_t* cfirst, const tsgpu_group_by* groups, uint32_t n_queries,
+                           tsgpu_hits* out, tsgpu_grouped_hits* gout, uint32_t* query_index, tsgpu_id_lists** ids_out) {
     (void)hipSetDevice(ctx->device);
     const std::shared_ptr<const Snapshot> snap_ref = ctx->snapshot();
     const Snapshot& snap = *snap_ref;
     hipStream_t s = ctx->stream;
     static const bool host_timing = getenv("TSGPU_HOST_TIMING") != nullptr;
     const uint64_t t_enter = now_us();
+    const uint32_t n_combos = cfirst[n_queries];
     try {
         std::vector<int32_t> status(n_queries, TSGPU_OK), cutoff(n_queries, 0);
         std::vector<uint64_t> num_matched(n_queries, 0);
-        std::vector<KwQueryDev> qd(n_queries);
-        std::vector<KwQueryMF> mf(n_queries);
+        std::vector<KwQueryDev> qd(std::max<uint32_t>(n_combos, 1));
+        std::vector<KwQueryMF> mf(std::max<uint32_t>(n_combos, 1));
         std::vector<GbQuery> gq(n_queries);
-        std::vector<uint32_t> kcap(n_queries, 1);
-        bool any_first = false, any_second = false;
+        bool any_first = false, any_second = false, any_dedupe = false;
         uint32_t max_k = 1;
         for (uint32_t i = 0; i < n_queries; i++) {
-            const tsgpu_kw_query& in = queries[i];
             const tsgpu_group_by& gb = groups[i];
             memset(&gq[i], 0, sizeof(GbQuery));
-            int st = gb_translate(ctx, snap, in, gb.wildcard != 0, qd[i], mf[i]);
+            const uint32_t c0 = cfirst[i], nc = cfirst[i + 1] - c0;
+            gq[i].first_combo = c0; gq[i].n_combos = nc;
+            int st = TSGPU_OK;
+            if (nc == 0 || nc > (uint32_t)KW_MAX_CANDIDATE_PASSES || (gb.wildcard && nc != 1)) st = TSGPU_ERR_INVALID;
+            for (uint32_t c = c0; st == TSGPU_OK && c < c0 + nc; c++) {
+                const tsgpu_kw_query& in = combos[c];
+                st = gb_translate(ctx, snap, in, gb.wildcard != 0, qd[c], mf[c]);
+                if (st == TSGPU_OK && (in.n_filter != 0 && !in.filter_ids)) st = TSGPU_ERR_INVALID;
+                if (st == TSGPU_OK && (in.n_excluded != 0 && !in.excluded_ids)) st = TSGPU_ERR_INVALID;
+            }
             if (st == TSGPU_OK && (gb.group_limit == 0 || gb.group_limit > TSGPU_MAX_GROUP_LIMIT)) st = TSGPU_ERR_INVALID;
             if (st == TSGPU_OK && gb.column >= ctx->columns.size()) st = TSGPU_ERR_NOT_FOUND;
-            if (st == TSGPU_OK && (in.n_filter != 0 && !in.filter_ids)) st = TSGPU_ERR_INVALID;
-            if (st == TSGPU_OK && (in.n_excluded != 0 && !in.excluded_ids)) st = TSGPU_ERR_INVALID;
             uint32_t k = 1;
             if (st == TSGPU_OK) {
-                k = resolve_topster_size(ctx, in);
+                k = resolve_topster_size(ctx, combos[c0]);                 // ONE collector for all combinations (src/index.cpp:3506-3514)
                 if (k > TSGPU_MAX_TOPK) st = TSGPU_ERR_UNSUPPORTED;
                 else if (k > gout->g_stride) st = TSGPU_ERR_INVALID;
                 else if ((uint64_t)k * (gb.first_pass ? 1u : gb.group_limit) > out->k_stride) st = TSGPU_ERR_INVALID;   // second pass: slot r * group_limit + j
             }
             status[i] = st;
             if (st != TSGPU_OK) continue;
-            kcap[i] = k;
             max_k = std::max(max_k, k);
-            qd[i].k = k;
             gq[i].k = k; gq[i].group_limit = gb.group_limit; gq[i].column = gb.column;
             gq[i].first_pass = gb.first_pass ? 1 : 0; gq[i].group_missing_values = gb.group_missing_values ? 1 : 0; gq[i].wildcard = gb.wildcard ? 1 : 0;
+            gq[i].dedupe = (!gb.first_pass && nc > 1) ? 1 : 0;             // a second pass counts a document once, with its greatest KV (group_doc_seq_ids + replace-unless-smaller)
+            any_dedupe = any_dedupe || gq[i].dedupe;
             (gb.first_pass ? any_first : any_second) = true;
         }
         // ---- step 1: the matched ids ----
@@ -180,7 +188,9 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
         std::vector<uint8_t> iota(n_queries, 0);             // q = * without filter / excluded ids: the matched ids are 0 .. num_docs - 1, written on the device
         bool any_iota = false;
         std::unique_ptr<tsgpu_id_lists> idl;
-        std::vector<uint32_t> kw_index(n_queries, 0xFFFFFFFFu);
+        std::vector<uint32_t> kw_index(std::max<uint32_t>(n_combos, 1), 0xFFFFFFFFu);      // per combination: its query in the id pass
+        std::vector<int32_t> c_status(std::max<uint32_t>(n_combos, 1), TSGPU_OK);
+        std::vector<uint64_t> c_matched(std::max<uint32_t>(n_combos, 1), 0);
         bool ids_on_dev = false, any_wild = false;
         for (uint32_t i = 0; i < n_queries; i++) any_wild = any_wild || (status[i] == TSGPU_OK && groups[i].wildcard);
         {
@@ -188,7 +198,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
             std::vector<uint32_t> kq_of;
             for (uint32_t i = 0; i < n_queries; i++) {
                 if (status[i] != TSGPU_OK) continue;
-                const tsgpu_kw_query& in = queries[i];
+                const tsgpu_kw_query& in = combos[cfirst[i]];
                 if (groups[i].wildcard) {
                     // Index::search_wildcard ranks the filter ids (every seq_id without a filter) minus the excluded ids (src/index.cpp:6674-6676)
                     if (in.n_filter == 0 && in.n_excluded == 0) { iota[i] = 1; any_iota = true; num_matched[i] = ctx->num_docs; continue; }
@@ -205,10 +215,12 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
                     num_matched[i] = w.size();
                     continue;
                 }
-                kw_index[i] = (uint32_t)kq.size();
-                kq.push_back(in);
-                kq.back().topster_size = 1;              // the pass is run for its ids and counters; the Topster it fills is not read
-                kq_of.push_back(i);
+                for (uint32_t c = cfirst[i]; c < cfirst[i + 1]; c++) {
+                    kw_index[c] = (uint32_t)kq.size();
+                    kq.push_back(combos[c]);
+                    kq.back().topster_size = 1;          // the pass is run for its ids and counters; the Topster it fills is not read
+                    kq_of.push_back(c);
+                }
             }
             if (!kq.empty()) {
                 const uint32_t nk = (uint32_t)kq.size();
@@ -228,23 +240,38 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
                 const int rc = kw_dispatch(ctx, kq.data(), nk, &th, false, &raw, any_wild ? nullptr : &ctx->groupby->ids_dev, &ids_on_dev);
                 idl.reset(raw);
                 if (rc != TSGPU_OK) return rc;
-                for (uint32_t j = 0; j < nk; j++) {
-                    const uint32_t i = kq_of[j];
-                    status[i] = t_st[j]; cutoff[i] = t_co[j]; num_matched[i] = t_nm[j];
+                for (uint32_t j = 0; j < nk; j++) { c_status[kq_of[j]] = t_st[j]; c_matched[kq_of[j]] = t_nm[j]; }
+                for (uint32_t i = 0; i < n_queries; i++) {
+                    if (status[i] != TSGPU_OK || groups[i].wildcard) continue;
+                    for (uint32_t c = cfirst[i]; c < cfirst[i + 1]; c++) {
+                        if (status[i] == TSGPU_OK && c_status[c] != TSGPU_OK) status[i] = c_status[c];       // a failing combination fails its user query
+                        cutoff[i] = cutoff[i] || t_co[kw_index[c]];
+                    }
+                    num_matched[i] = c_matched[cfirst[i + 1] - 1];                                         // the reference assigns num_keyword_matches per pass: the last one stays
                 }
             }
         }
         const uint64_t t_ids = now_us();
         // ---- layout ----
         uint64_t n_items = 0, n_slots = 0, n_blocks = 0;
+        std::vector<unsigned long long> combo_begin((size_t)n_combos + 1, 0);
+        std::vector<uint32_t> qidx_of_combo(std::max<uint32_t>(n_combos, 1), 0);
         for (uint32_t i = 0; i < n_queries; i++) {
             GbQuery& g = gq[i];
             g.item_begin = n_items; g.tab_off = n_slots;
             g.run = status[i] == TSGPU_OK ? 1 : 0;
             g.iota = iota[i];
             uint64_t n = 0;
-            if (g.run) n = iota[i] ? ctx->num_docs : (groups[i].wildcard ? wild_ids[i].size() : tsgpu_id_lists_count(idl.get(), kw_index[i]));
-            if (n > 0x7FFFFFFFull) { status[i] = TSGPU_ERR_UNSUPPORTED; g.run = 0; n = 0; }
+            uint32_t matched_before = 0;                  // searched_queries.size() at the time of a pass: the earlier combinations that matched anything (:5580-5585)
+            for (uint32_t c = cfirst[i]; c < cfirst[i + 1]; c++) {
+                combo_begin[c] = n_items + n;
+                qidx_of_combo[c] = matched_before;
+                uint64_t nc = 0;
+                if (g.run) nc = iota[i] ? ctx->num_docs : (groups[i].wildcard ? wild_ids[i].size() : tsgpu_id_lists_count(idl.get(), kw_index[c]));
+                n += nc;
+                if (nc) matched_before++;
+            }
+            if (n > 0x7FFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_grouped_batch: more than 2^31 matched ids in one query");
             g.n_items = (uint32_t)n;
             uint64_t size = 64;
             while (size < 2 * n) size <<= 1;
@@ -254,6 +281,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
             n_items += n;
             n_slots += size + 1;                          // + the slot of the key ~0
         }
+        combo_begin[n_combos] = n_items;
         if (n_blocks > 0x1FFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_grouped_batch: too many matched ids in one batch");
         if (n_slots * 20 + n_items * 48 > (64ull << 30)) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_grouped_batch: the group tables of this batch exceed 64 GiB; split it");
         if (!ctx->groupby) ctx->groupby = new GroupByScratch;
@@ -262,8 +290,11 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
         const size_t n_out = (size_t)n_queries * ks, n_g = (size_t)n_queries * gs;
         const uint64_t ni = std::max<uint64_t>(n_items, 1);
         GbLayout Lin, Lff, Lzero, Lout, Lwork;
-        const size_t i_gq = Lin.take(sizeof(GbQuery) * n_queries), i_qd = Lin.take(sizeof(KwQueryDev) * n_queries), i_mf = Lin.take(sizeof(KwQueryMF) * n_queries), i_ids = Lin.take(ids_on_dev ? 16 : ni * 4);
-        const size_t f_hkey = Lff.take(n_slots * 8), f_hbest = Lff.take(n_slots * 4), f_hrank = Lff.take(n_slots * 4);
+        const uint32_t ncz = std::max<uint32_t>(n_combos, 1);
+        const size_t i_gq = Lin.take(sizeof(GbQuery) * n_queries), i_qd = Lin.take(sizeof(KwQueryDev) * ncz), i_mf = Lin.take(sizeof(KwQueryMF) * ncz),
+                     i_cb = Lin.take(((size_t)n_combos + 1) * 8), i_qx = Lin.take((size_t)ncz * 4), i_ids = Lin.take(ids_on_dev ? 16 : ni * 4);
+        const size_t f_hkey = Lff.take(n_slots * 8), f_hbest = Lff.take(n_slots * 4), f_hrank = Lff.take(n_slots * 4),
+                     f_dkey = Lff.take(any_dedupe ? n_slots * 4 : 16), f_dbest = Lff.take(any_dedupe ? n_slots * 4 : 16);      // the document tables of the second passes over several combinations
         const size_t z_hcount = Lzero.take(n_slots * 4), z_gcount = Lzero.take((size_t)n_queries * 4);
         const size_t o_nhits = Lout.take((size_t)n_queries * 4), o_ng = Lout.take((size_t)n_queries * 4), o_gtot = Lout.take((size_t)n_queries * 8),
                      o_hist = Lout.take((size_t)n_queries * GB_LOGLOG_HIST * 4), o_gdkey = Lout.take(n_g * 8), o_gsize = Lout.take(n_g * 4), o_gfound = Lout.take(n_g * 4),
@@ -272,9 +303,11 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
         const size_t o_tm = Lout.take(n_out * 8);
         const size_t end_tm = Lout.at;
         const size_t o_vd = Lout.take(n_out * 4);
+        const size_t end_vd = Lout.at;
+        const size_t o_qx = Lout.take(n_out * 4);                 // KV::query_index per hit slot (only with several combinations per query)
         const size_t w_s0 = Lwork.take(ni * 8), w_s1 = Lwork.take(ni * 8), w_s2 = Lwork.take(ni * 8), w_dkey = Lwork.take(ni * 8), w_rslot = Lwork.take(ni * 4),
-                     w_members = Lwork.take(ni * 4), w_glist = Lwork.take(ni * 4), w_mofs = Lwork.take(n_g * 4), w_mcur = Lwork.take(n_g * 4);
-        const size_t out_bytes = out->vector_distance ? Lout.at : (out->text_match ? end_tm : end_required);      // what the caller asked for, as a prefix
+                     w_members = Lwork.take(ni * 4), w_glist = Lwork.take(ni * 4), w_mofs = Lwork.take(n_g * 4), w_mcur = Lwork.take(n_g * 4), w_pass = Lwork.take(ni);
+        const size_t out_bytes = query_index ? Lout.at : (out->vector_distance ? end_vd : (out->text_match ? end_tm : end_required));      // what the caller asked for, as a prefix
         int rc;
         if ((rc = S.in.reserve(Lin.at)) || (rc = S.ff.reserve(Lff.at)) || (rc = S.zero.reserve(Lzero.at)) || (rc = S.out.reserve(Lout.at)) || (rc = S.work.reserve(Lwork.at)) ||
             (rc = S.h_in.reserve(Lin.at)) || (rc = S.h_out.reserve(out_bytes <= (4u << 20) ? out_bytes : o_gdkey)))
@@ -284,12 +317,17 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
         {
             char* hin = (char*)S.h_in.p;
             memcpy(hin + i_gq, gq.data(), sizeof(GbQuery) * n_queries);
-            memcpy(hin + i_qd, qd.data(), sizeof(KwQueryDev) * n_queries);
-            memcpy(hin + i_mf, mf.data(), sizeof(KwQueryMF) * n_queries);
+            memcpy(hin + i_qd, qd.data(), sizeof(KwQueryDev) * n_combos);
+            memcpy(hin + i_mf, mf.data(), sizeof(KwQueryMF) * n_combos);
+            memcpy(hin + i_cb, combo_begin.data(), ((size_t)n_combos + 1) * 8);
+            memcpy(hin + i_qx, qidx_of_combo.data(), (size_t)n_combos * 4);
             for (uint32_t i = 0; !ids_on_dev && i < n_queries; i++) {
                 if (!gq[i].run || gq[i].n_items == 0 || iota[i]) continue;
-                const uint32_t* src = groups[i].wildcard ? wild_ids[i].data() : tsgpu_id_lists_ids(idl.get(), kw_index[i]);
-                memcpy(hin + i_ids + (size_t)gq[i].item_begin * 4, src, (size_t)gq[i].n_items * 4);
+                if (groups[i].wildcard) { memcpy(hin + i_ids + (size_t)gq[i].item_begin * 4, wild_ids[i].data(), (size_t)gq[i].n_items * 4); continue; }
+                for (uint32_t c = cfirst[i]; c < cfirst[i + 1]; c++) {       // the combinations' ascending id lists, one after the other
+                    const uint64_t nc = combo_begin[c + 1] - combo_begin[c];
+                    if (nc) memcpy(hin + i_ids + (size_t)combo_begin[c] * 4, tsgpu_id_lists_ids(idl.get(), kw_index[c]), (size_t)nc * 4);
+                }
             }
         }
         if (ids_on_dev) TSGPU_HIP_TRY(hipMemcpyAsync(S.in.p, S.h_in.p, i_ids, hipMemcpyHostToDevice, s));      // the descriptions only: the ids are where the id pass gathered them
@@ -308,6 +346,8 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
         GbArgs a;
         char* din = (char*)S.in.p; char* dff = (char*)S.ff.p; char* dz = (char*)S.zero.p; char* dout = (char*)S.out.p; char* dw = (char*)S.work.p;
         a.gq = (const GbQuery*)(din + i_gq); a.n_queries = n_queries; a.queries = (const KwQueryDev*)(din + i_qd); a.mfs = (const KwQueryMF*)(din + i_mf);
+        a.combo_begin = (const unsigned long long*)(din + i_cb); a.qidx_of_combo = (const uint32_t*)(din + i_qx); a.pass = (uint8_t*)(dw + w_pass);
+        a.dkey32 = (uint32_t*)(dff + f_dkey); a.dbest = (uint32_t*)(dff + f_dbest); a.out_qidx = (uint32_t*)(dout + o_qx);
         a.n_items = n_items; a.ids = ids_on_dev ? S.ids_dev.as<uint32_t>() : (const uint32_t*)(din + i_ids);
         a.s0 = (int64_t*)(dw + w_s0); a.s1 = (int64_t*)(dw + w_s1); a.s2 = (int64_t*)(dw + w_s2); a.dkey = (unsigned long long*)(dw + w_dkey); a.rslot = (uint32_t*)(dw + w_rslot);
         a.hkey = (unsigned long long*)(dff + f_hkey); a.hbest = (uint32_t*)(dff + f_hbest); a.hrank = (uint32_t*)(dff + f_hrank);
@@ -324,9 +364,10 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
         if (n_items) {
             if (any_iota) hipLaunchKernelGGL(gb_iota_kernel, dim3((uint32_t)n_blocks), dim3(GB_THREADS), 0, s, a);
             uint32_t max_lists = 0;
-            for (uint32_t i = 0; i < n_queries; i++) if (gq[i].run) max_lists = std::max(max_lists, qd[i].n_lists);
+            for (uint32_t i = 0; i < n_queries; i++) if (gq[i].run) for (uint32_t c = cfirst[i]; c < cfirst[i + 1]; c++) max_lists = std::max(max_lists, qd[c].n_lists);
             if (max_lists <= 3) hipLaunchKernelGGL((gb_score_kernel<3>), dim3((uint32_t)n_blocks), dim3(GB_THREADS), 0, s, v, a);
             else hipLaunchKernelGGL((gb_score_kernel<KW_MAX_TOKENS>), dim3((uint32_t)(n_blocks * (GB_THREADS / 64))), dim3(64), 0, s, v, a);
+            if (any_dedupe) hipLaunchKernelGGL(gb_dedupe_kernel, dim3((uint32_t)n_blocks), dim3(GB_THREADS), 0, s, a);
             hipLaunchKernelGGL(gb_insert_kernel, dim3((uint32_t)n_blocks), dim3(GB_THREADS), 0, s, a);
         }
         if (max_k + GB_THREADS <= 512) hipLaunchKernelGGL((gb_select_kernel<512>), dim3(n_queries), dim3(GB_THREADS), 0, s, a);
@@ -354,6 +395,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
             if (out->match_score_index) TSGPU_HIP_TRY(hipMemcpyAsync(out->match_score_index, dout + o_msi, n_out, hipMemcpyDeviceToHost, s));
             if (out->text_match) TSGPU_HIP_TRY(hipMemcpyAsync(out->text_match, dout + o_tm, n_out * 8, hipMemcpyDeviceToHost, s));
             if (out->vector_distance) TSGPU_HIP_TRY(hipMemcpyAsync(out->vector_distance, dout + o_vd, n_out * 4, hipMemcpyDeviceToHost, s));
+            if (query_index) TSGPU_HIP_TRY(hipMemcpyAsync(query_index, dout + o_qx, n_out * 4, hipMemcpyDeviceToHost, s));
         }
         if (gout->loglog_registers) {
             if (want_loglog) TSGPU_HIP_TRY(hipMemcpyAsync(gout->loglog_registers, S.loglog.p, (size_t)n_queries * GB_LOGLOG_M, hipMemcpyDeviceToHost, s));
@@ -383,6 +425,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
                 if (out->match_score_index) memcpy(out->match_score_index + ro, ho + o_msi + ro, ext);
                 if (out->text_match) memcpy(out->text_match + ro, ho + o_tm + ro * 8, ext * 8);
                 if (out->vector_distance) memcpy(out->vector_distance + ro, ho + o_vd + ro * 4, ext * 4);
+                if (query_index) memcpy(query_index + ro, ho + o_qx + ro * 4, ext * 4);
             }
         }
         const uint32_t* hist_host = (const uint32_t*)((const char*)S.h_out.p + o_hist);
@@ -402,16 +445,24 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const 
             }
         }
         if (ids_out) {
+            // all_result_ids per user query: the union of its combinations' matched ids, ascending (id_buff -> sort + unique + or_scalar, src/index.cpp:5565-5578)
             std::unique_ptr<tsgpu_id_lists> il(new tsgpu_id_lists);
+            std::vector<uint32_t> flat(n_items);
+            if (ids_on_dev && n_items) TSGPU_HIP_TRY(hipMemcpy(flat.data(), S.ids_dev.p, (size_t)n_items * 4, hipMemcpyDeviceToHost));
+            else if (n_items) {
+                for (uint32_t i = 0; i < n_queries; i++) {
+                    if (!gq[i].n_items) continue;
+                    if (iota[i]) { for (uint32_t j = 0; j < gq[i].n_items; j++) flat[gq[i].item_begin + j] = j; continue; }
+                    memcpy(flat.data() + gq[i].item_begin, (const char*)S.h_in.p + i_ids + (size_t)gq[i].item_begin * 4, (size_t)gq[i].n_items * 4);
+                }
+            }
             il->begin.assign((size_t)n_queries + 1, 0);
-            for (uint32_t i = 0; i < n_queries; i++) il->begin[i + 1] = il->begin[i] + gq[i].n_items;
-            il->ids.resize(il->begin[n_queries]);
-            if (ids_on_dev && n_items) TSGPU_HIP_TRY(hipMemcpy(il->ids.data(), S.ids_dev.p, (size_t)n_items * 4, hipMemcpyDeviceToHost));      // (same order: query by query)
-            for (uint32_t i = 0; !ids_on_dev && i < n_queries; i++) {
-                if (!gq[i].n_items) continue;
-                if (iota[i]) { for (uint32_t j = 0; j < gq[i].n_items; j++) il->ids[il->begin[i] + j] = j; continue; }
-                const uint32_t* src = groups[i].wildcard ? wild_ids[i].data() : tsgpu_id_lists_ids(idl.get(), kw_index[i]);
-                memcpy(il->ids.data() + il->begin[i], src, (size_t)gq[i].n_items * 4);
+            for (uint32_t i = 0; i < n_queries; i++) {
+                uint32_t* b = flat.data() + gq[i].item_begin;
+                uint32_t n = gq[i].n_items;
+                if (gq[i].n_combos > 1 && n) { std::sort(b, b + n); n = (uint32_t)(std::unique(b, b + n) - b); }
+                il->ids.insert(il->ids.end(), b, b + n);
+                il->begin[i + 1] = il->ids.size();
             }
             *ids_out = il.release();
         }
@@ -485,7 +536,9 @@ static int gb_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsg
             gh.g_stride = GS; gh.n_groups = ng.data(); gh.distinct_key = dk.data(); gh.group_size = gsz.data(); gh.group_found = gfound.data();
             gh.groups_total = gtot.data(); gh.groups_count = gcnt.data(); gh.loglog_registers = want_regs ? regs.data() : nullptr;
             tsgpu_id_lists* all_raw = nullptr;
-            rc = gb_batch_locked(ctx, q.data(), g.data(), total, &h, &gh, want_ids ? &all_raw : nullptr);
+            std::vector<uint32_t> cf((size_t)total + 1);
+            for (uint32_t i = 0; i <= total; i++) cf[i] = i;     // one combination per query
+            rc = gb_batch_locked(ctx, q.data(), cf.data(), g.data(), total, &h, &gh, nullptr, want_ids ? &all_raw : nullptr);
             std::unique_ptr<tsgpu_id_lists> all_ids(all_raw);
             if (rc != TSGPU_OK) err = tls_error();
             else {
@@ -549,8 +602,25 @@ int tsgpu_keyword_search_grouped_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* que
         return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_grouped_batch: n_groups / distinct_key / group_size / group_found and the strides are required");
     struct CallerCount { std::atomic<int>& c; explicit CallerCount(std::atomic<int>& x) : c(x) { c.fetch_add(1); } ~CallerCount() { c.fetch_sub(1); } } cc(ctx->gb_callers);
     if (n_queries <= ctx->batch_max_queries && ctx->gb_callers.load() > 1) return gb_coalesced(ctx, queries, groups, n_queries, out, gout, ids_out);
+    std::vector<uint32_t> cf((size_t)n_queries + 1);
+    for (uint32_t i = 0; i <= n_queries; i++) cf[i] = i;         // one combination per query
     std::lock_guard<std::mutex> lk(ctx->mu);
-    return gb_batch_locked(ctx, queries, groups, n_queries, out, gout, ids_out);
+    return gb_batch_locked(ctx, queries, cf.data(), groups, n_queries, out, gout, nullptr, ids_out);
+}
+
+int tsgpu_keyword_search_grouped_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const uint32_t* group_begin, const tsgpu_group_by* groups, uint32_t n_user,
+                                                  tsgpu_hits* out, tsgpu_grouped_hits* gout, uint32_t* query_index, tsgpu_id_lists** ids_out) {
+    if (ids_out) *ids_out = nullptr;
+    if (!ctx || !out || !gout || (n_user && (!combos || !groups || !group_begin))) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_grouped_candidates_batch: NULL argument");
+    if (n_user == 0) return ok();
+    if (out->mem != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_grouped_candidates_batch: host output arrays only");
+    if (!out->keys || !out->scores || !out->n_hits || !out->status) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_grouped_candidates_batch: keys / scores / n_hits / status are required");
+    if (!gout->n_groups || !gout->distinct_key || !gout->group_size || !gout->group_found || gout->g_stride == 0 || out->k_stride == 0)
+        return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_grouped_candidates_batch: n_groups / distinct_key / group_size / group_found and the strides are required");
+    if (group_begin[0] != 0) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_grouped_candidates_batch: group_begin[0] must be 0");
+    for (uint32_t u = 0; u < n_user; u++) if (group_begin[u + 1] < group_begin[u]) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_grouped_candidates_batch: group_begin must be non-decreasing");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return gb_batch_locked(ctx, combos, group_begin, groups, n_user, out, gout, query_index, ids_out);
 }
 
 }  // extern "C"

@@ -329,6 +329,35 @@ class GpuIndex:
             self.L.tsgpu_id_lists_free(handle)
         return h, gh, lists
 
+    def keyword_search_grouped_candidates_batch(self, user_combos, groups, k_stride, g_stride=250, want_ids=False, want_registers=False):
+        """tsgpu_keyword_search_grouped_candidates_batch: user_combos = [[KwQuery, ...], ...] (the candidate combinations of every user query, pass order),
+        groups as in keyword_search_grouped_batch (one per user query). Returns (Hits, GroupedHits, query_index[n_user, k_stride][, id lists])."""
+        flat = [q for combos in user_combos for q in combos]
+        arr = make_query_array(flat)
+        n = len(user_combos)
+        begin = np.zeros(n + 1, np.uint32)
+        begin[1:] = np.cumsum([len(c) for c in user_combos])
+        ga = (B.GroupByC * n)()
+        for i, g in enumerate(groups):
+            ga[i].group_limit, ga[i].column, ga[i].first_pass, ga[i].group_missing_values, ga[i].wildcard = int(g[0]), int(g[1]), int(g[2]), int(g[3]), int(g[4])
+        h = Hits(n, k_stride)
+        gh = GroupedHits(n, g_stride, want_registers)
+        qidx = np.zeros((n, k_stride), np.uint32)
+        hs, gs = h.c_struct(), gh.c_struct()
+        handle = C.c_void_p()
+        self._ck(self.L.tsgpu_keyword_search_grouped_candidates_batch(self.h, arr, begin.ctypes.data, ga, n, C.byref(hs), C.byref(gs), qidx.ctypes.data,
+                                                                      C.byref(handle) if want_ids else None))
+        if not want_ids:
+            return h, gh, qidx
+        lists = []
+        try:
+            for q in range(n):
+                cnt = int(self.L.tsgpu_id_lists_count(handle, q))
+                lists.append(np.ctypeslib.as_array(self.L.tsgpu_id_lists_ids(handle, q), shape=(cnt,)).copy() if cnt else np.zeros(0, np.uint32))
+        finally:
+            self.L.tsgpu_id_lists_free(handle)
+        return h, gh, qidx, lists
+
     def facet_set(self, field_id, doc_ptr, hashes):
         doc_ptr = np.ascontiguousarray(doc_ptr, dtype=np.uint64)
         hashes = _u32(hashes)
