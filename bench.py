@@ -871,7 +871,7 @@ class Bench:
                       "first_pass_ms": 1e3 * cres[1][3], "second_pass_ms": 1e3 * cres[0][3], "value": n_cu / (cres[1][3] + cres[0][3]), "unit": "grouped user queries/s (10 combinations, two passes each)",
                       "status_nonzero": int((cres[0][0].status != 0).sum() + (cres[1][0].status != 0).sum())}
             if not args.no_cpu_baseline:
-                npar = min(n_cu, 4)
+                npar = min(n_cu, 2)                      # (20 oracle passes at full size: the leg's share of the default run stays under half a minute)
                 orc = O.OracleIndex(1, 1)
                 orc.set_num_docs(self.n_docs)
                 orc.set_sort_dense(0, self.pts)

@@ -32,6 +32,10 @@
 //   gb_scatter_kernel  second pass, one thread per matched id: members of a selected group append themselves to the group's member list
 //   gb_members_kernel  second pass, one wave per (query, selected group): the group's min(group_limit, members) greatest records by repeated
 //                      wave-wide extraction of the greatest record below the previous one (group_limit is 3 by default, <= 99)
+//   gb_dedupe_kernel   candidate combinations (Index::search_all_candidates with group_limit != 0: several passes over ONE collector), second pass only: a
+//                      document met by several combinations keeps ONE record — its greatest KV, the later combination on ties (Topster::add replaces unless
+//                      smaller, topster.h:392-406; group_doc_seq_ids -> ret == 2: counted once) — in a per-query document table; the others leave the fold.
+//                      A user query's items are its combinations' ascending id lists one after the other (GbQuery::first_combo / n_combos, GbArgs::combo_begin).
 // Bound: HBM latency / atomics of a random-access table, like the facet kernels; algorithmic bytes per matched id = 4 (id) + 32 (record) + the
 // posting probes of gb_score_kernel. Grouped queries are the minority of a server's traffic; the ungrouped keyword path is untouched.
 #pragma once
