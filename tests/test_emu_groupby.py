@@ -248,6 +248,27 @@ def test_grouped_multi_field_query():
         g.close()
 
 
+def test_grouped_string_array_fields():
+    """a string[] query_by field (per-element Match, src/index.cpp:1351-1395) alone and next to a plain field, grouped"""
+    from tests.test_emu_keyword import make_pair_arr
+    orc, g = make_pair_arr(H.emu_lib_path())
+    try:
+        distinct, has_value = group_column(2000, seed=12, n_values=15)
+        g.column_set(1, distinct.view(np.int64))
+        sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+        qs = []
+        for toks in ([1], [1, 2], [2, 1, 3], [4, 2, 1, 3]):
+            qs.append(T.KwQuery(toks, fields=[(0, 15)], sort=sort, topster_size=60))
+            qs.append(T.KwQuery(toks, fields=[(0, 4), (1, 9)], sort=sort, topster_size=60, prioritize_token_position=True))
+        for first_pass in (True, False):
+            h, gh = g.keyword_search_grouped_batch(qs, [(2, 1, int(first_pass), 0, 0)] * len(qs), k_stride=120, g_stride=60)
+            for i, q in enumerate(qs):
+                check_query(h, gh, i, oracle_grouped(orc, q, distinct, has_value, 2, first_pass), first_pass, 2, "array fields")
+        assert gh.n_groups.sum() > 20
+    finally:
+        g.close()
+
+
 def test_grouped_bad_queries_do_not_disturb_their_neighbours(world):
     orc, g, _, distinct, has_value = world
     good = T.KwQuery([1, 2], topster_size=20)

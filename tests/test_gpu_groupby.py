@@ -62,6 +62,7 @@ def test_grouped_two_fields_multi_field_and_bad_queries(world):
     E.test_grouped_big_output_arrays_take_the_direct_delivery(world)
     E.test_grouped_calls_from_concurrent_threads_are_coalesced_and_keep_their_own_results(world)
     E.test_grouped_multi_field_query()
+    E.test_grouped_string_array_fields()
     E.test_grouped_bad_queries_do_not_disturb_their_neighbours(world)
 
 
