@@ -261,6 +261,62 @@ int main(int argc, char** argv) {
         }
     }
 
+    // ---------------- B1, grouped, one level up: search_all_candidates_grouped_gpu (the candidate loop over ONE distinct Topster) ----------------
+    {
+        Reader r(dir + "/grouped_candidates.bin");
+        const uint32_t n_docs = r.get<uint32_t>();
+        std::vector<uint8_t> has_value = r.vec<uint8_t>(n_docs);
+        const uint32_t n_cases = r.get<uint32_t>();
+        for (uint32_t c = 0; c < n_cases; c++) {
+            tsgpu::GroupByCandidatesShimArgs a;
+            a.ctx = ctx; a.base_query_index = 2; a.has_value = has_value.data(); a.n_has_value = n_docs;
+            const uint32_t n_combos = r.get<uint32_t>(), topster_size = r.get<uint32_t>();
+            a.group.group_limit = r.get<uint32_t>(); a.group.first_pass = (uint8_t)r.get<uint32_t>(); a.group.column = 5;
+            for (uint32_t j = 0; j < n_combos; j++) {
+                tsgpu_kw_query q{};
+                q.n_tokens = r.get<uint32_t>();
+                const std::vector<uint32_t> toks = r.vec<uint32_t>(q.n_tokens);
+                for (uint32_t i = 0; i < q.n_tokens; i++) q.term_ids[i] = toks[i];
+                q.n_fields = 1; q.field_ids[0] = 0; q.field_weights[0] = 15;
+                q.match_type = TSGPU_MAX_SCORE; q.prioritize_exact_match = 1; q.prioritize_num_matching_fields = 1;
+                q.total_cost = j > 0 ? 1 : 0;
+                q.n_sort = 2;
+                q.sort[0].kind = TSGPU_SORT_TEXT_MATCH; q.sort[0].order = 1;
+                q.sort[1].kind = TSGPU_SORT_INT64_COLUMN; q.sort[1].order = 1; q.sort[1].column = 0;
+                q.topster_size = topster_size;
+                a.combos.push_back(q);
+            }
+            const uint32_t want_groups = r.get<uint32_t>();
+            std::vector<std::tuple<int64_t, int64_t, int64_t, uint64_t, uint64_t, uint32_t, uint32_t>> want;      // per KV: scores, key, distinct key, group found, query_index
+            for (uint32_t g = 0; g < want_groups; g++) {
+                const uint64_t dk = r.get<uint64_t>(); const uint32_t found = r.get<uint32_t>(), size = r.get<uint32_t>();
+                const std::vector<uint64_t> keys = r.vec<uint64_t>(size); const std::vector<int64_t> sc = r.vec<int64_t>((size_t)size * 3); const std::vector<uint16_t> qi = r.vec<uint16_t>(size);
+                for (uint32_t j = 0; j < size; j++) want.emplace_back(sc[j * 3], sc[j * 3 + 1], sc[j * 3 + 2], keys[j], dk, found, (uint32_t)qi[j] + 2u);
+            }
+            const uint64_t want_count = r.get<uint64_t>();
+            const std::vector<uint32_t> want_ids = r.vec<uint32_t>(r.get<uint32_t>());
+            const uint64_t want_matched = r.get<uint64_t>();
+
+            oracle::GroupTopster topster(topster_size, a.group.group_limit, a.group.first_pass != 0);
+            std::unordered_map<uint64_t, uint32_t> groups_processed;
+            std::vector<uint32_t> id_buff;
+            std::set<uint32_t> missing;
+            size_t nkm = 0; bool cutoff = false;
+            const int rc = tsgpu::search_all_candidates_grouped_gpu<oracle::KV>(a, &topster, groups_processed, id_buff, nkm, cutoff, &missing);
+            CHECK(rc == TSGPU_OK, "grouped candidates case %u: rc %d %s", c, rc, tsgpu_last_error());
+            oracle::grouped_result_t got;
+            oracle::populate_grouped(topster, groups_processed, got);
+            std::vector<std::tuple<int64_t, int64_t, int64_t, uint64_t, uint64_t, uint32_t, uint32_t>> have;
+            for (size_t g = 0; g < got.groups.size(); g++)
+                for (const auto& kv : got.groups[g]) have.emplace_back(kv.scores[0], kv.scores[1], kv.scores[2], kv.key, kv.distinct_key, got.group_found[g], (uint32_t)kv.query_index);
+            if (a.group.first_pass) { std::sort(have.begin(), have.end()); std::sort(want.begin(), want.end()); }
+            CHECK(got.groups.size() == want_groups && have == want, "grouped candidates case %u (first_pass %u): groups / KVs / query_index differ from the oracle", c, (unsigned)a.group.first_pass);
+            if (a.group.first_pass) CHECK(topster.getGroupsCount() == want_count, "grouped candidates case %u: getGroupsCount", c);
+            CHECK(id_buff == want_ids, "grouped candidates case %u: all_result_ids (%zu vs %zu)", c, id_buff.size(), want_ids.size());
+            CHECK(nkm == want_matched, "grouped candidates case %u: num_keyword_matches", c);
+        }
+    }
+
     // ---------------- B2: the hnswlib-shaped adaptor ----------------
     {
         Reader r(dir + "/vec.bin");

@@ -76,6 +76,22 @@ def _write_fixture(d):
                 a, b = int(ref.begin[gi]), int(ref.begin[gi + 1])
                 f.write(struct.pack("<Q", int(ref.distinct_key[gi])) + _u32(ref.group_found[gi]) + _u32(b - a) + ref.keys[a:b].astype(np.uint64).tobytes() + ref.scores[a:b].astype(np.int64).tobytes())
             f.write(struct.pack("<Q", ref.groups_count) + _u32(ref.missing_ids.size) + ref.missing_ids.astype(np.uint32).tobytes() + struct.pack("<Q", ref.num_keyword_matches))
+    with open(os.path.join(d, "grouped_candidates.bin"), "wb") as f:
+        f.write(_u32(n_docs) + has_value.astype(np.uint8).tobytes())
+        ccases = [([[1, 2], [1, 3], [2, 3], [1, 2], [9999]], 30, 2, 1), ([[1, 2], [1, 3], [2, 3], [1, 2], [9999]], 30, 2, 0), ([[3], [4], [5]], 4, 3, 0), ([[3], [4], [5]], 4, 3, 1)]
+        f.write(_u32(len(ccases)))
+        for cs, tsz, limit, first in ccases:
+            oqs = [orc.make_query(np.array(c, np.uint32), sort=sort, fetch_size=10, topster_size=tsz, total_cost=int(j > 0)) for j, c in enumerate(cs)]
+            ref, rqi = orc.search_candidates_grouped(oqs, distinct, limit, bool(first), has_value=has_value, ids_cap=1 << 16)
+            f.write(_u32(len(cs)) + _u32(tsz) + _u32(limit) + _u32(first))
+            for c in cs:
+                f.write(_u32(len(c)) + np.array(c, np.uint32).tobytes())
+            f.write(_u32(ref.n_groups))
+            for gi in range(ref.n_groups):
+                a, b = int(ref.begin[gi]), int(ref.begin[gi + 1])
+                f.write(struct.pack("<Q", int(ref.distinct_key[gi])) + _u32(ref.group_found[gi]) + _u32(b - a) + ref.keys[a:b].astype(np.uint64).tobytes()
+                        + ref.scores[a:b].astype(np.int64).tobytes() + rqi[a:b].astype(np.uint16).tobytes())
+            f.write(struct.pack("<Q", ref.groups_count) + _u32(ref.result_ids.size) + ref.result_ids.astype(np.uint32).tobytes() + struct.pack("<Q", ref.num_keyword_matches))
     # vectors
     n, dim, k = 400, 40, 12
     X = rng.standard_normal((n, dim)).astype(np.float32)

@@ -113,4 +113,72 @@ int search_across_fields_grouped_gpu(const GroupByShimArgs& a, TopsterT* topster
     return TSGPU_OK;
 }
 
+// The candidate loop of Index::search_all_candidates with group_limit != 0 (src/index.cpp:1794-1894): `combos` = the candidate-token combinations in the reference's
+// pass order (each filled like KeywordShimArgs::query, its own term_ids / total_cost); ONE call folds them like the one Topster and the one groups_processed the reference
+// passes through the loop. base_query_index = searched_queries.size() before the loop; matched_combos (out) = which combinations matched anything (the reference appends
+// exactly those to searched_queries, :5580-5585). Everything else as in search_across_fields_grouped_gpu; id_buff receives the ascending UNION of the passes' ids.
+struct GroupByCandidatesShimArgs {
+    tsgpu_ctx* ctx = nullptr;
+    std::vector<tsgpu_kw_query> combos;
+    tsgpu_group_by group{};
+    uint16_t base_query_index = 0;
+    const uint8_t* has_value = nullptr;
+    uint32_t n_has_value = 0;
+};
+
+template <class KV, class TopsterT, class GroupsProcessed>
+int search_all_candidates_grouped_gpu(const GroupByCandidatesShimArgs& a, TopsterT* topster, GroupsProcessed& groups_processed, std::vector<uint32_t>& id_buff,
+                                      size_t& num_keyword_matches, bool& search_cutoff, std::set<uint32_t>* group_by_missing_value_ids) {
+    if (a.combos.empty()) return TSGPU_OK;
+    const uint32_t K = a.combos[0].topster_size ? a.combos[0].topster_size : TSGPU_DEFAULT_TOPSTER_SIZE;
+    const uint32_t L = a.group.first_pass ? 1u : a.group.group_limit;
+    const size_t slots = (size_t)K * (L ? L : 1);
+    std::vector<uint64_t> keys(slots), dkeys(K);
+    std::vector<int64_t> scores(slots * 3), text_match(slots);
+    std::vector<int8_t> msi(slots);
+    std::vector<uint32_t> gsize(K), gfound(K), qidx(slots);
+    std::vector<uint8_t> regs(a.group.first_pass ? 16384 : 0);
+    uint32_t n_hits = 0, n_groups = 0;
+    uint64_t num_matched = 0;
+    int32_t status = 0, cutoff = 0;
+    tsgpu_hits h{};
+    h.mem = TSGPU_MEM_HOST; h.k_stride = (uint32_t)slots;
+    h.keys = keys.data(); h.scores = scores.data(); h.text_match = text_match.data(); h.match_score_index = msi.data();
+    h.n_hits = &n_hits; h.num_matched = &num_matched; h.status = &status; h.search_cutoff = &cutoff;
+    tsgpu_grouped_hits g{};
+    g.g_stride = K; g.n_groups = &n_groups; g.distinct_key = dkeys.data(); g.group_size = gsize.data(); g.group_found = gfound.data();
+    g.loglog_registers = a.group.first_pass ? regs.data() : nullptr;
+    const uint32_t begin[2] = {0, (uint32_t)a.combos.size()};
+    tsgpu_id_lists* ids = nullptr;
+    const int rc = tsgpu_keyword_search_grouped_candidates_batch(a.ctx, a.combos.data(), begin, &a.group, 1, &h, &g, qidx.data(), &ids);
+    if (rc != TSGPU_OK) return rc;
+    if (status != TSGPU_OK) { tsgpu_id_lists_free(ids); search_cutoff = search_cutoff || cutoff != 0; return status; }
+    for (uint32_t r = 0; r < n_groups; r++) {
+        for (uint32_t j = 0; j < gsize[r]; j++) {
+            const size_t o = (size_t)r * L + j;
+            KV kv((uint16_t)(a.base_query_index + qidx[o]), keys[o], dkeys[r], msi[o], &scores[o * 3]);
+            kv.text_match_score = text_match[o];
+            topster->add(&kv);
+        }
+        groups_processed[dkeys[r]] += gfound[r];
+    }
+    if (a.group.first_pass && topster->loglog_counter) {
+        for (uint32_t k = 0; k < 16384; k++) {
+            const uint32_t v = regs[k];
+            if (v) topster->loglog_counter->addHash(((uint64_t)k << 50) | (v <= 50 ? 1ull << (50 - v) : 0ull));
+        }
+    }
+    if (ids) {
+        const uint64_t n = tsgpu_id_lists_count(ids, 0);
+        const uint32_t* p = tsgpu_id_lists_ids(ids, 0);
+        id_buff.insert(id_buff.end(), p, p + n);
+        if (a.group.first_pass && group_by_missing_value_ids)
+            for (uint64_t i = 0; i < n; i++) if (p[i] >= a.n_has_value || (a.has_value && !a.has_value[p[i]])) group_by_missing_value_ids->insert(p[i]);
+        tsgpu_id_lists_free(ids);
+    }
+    num_keyword_matches = (size_t)num_matched;
+    search_cutoff = search_cutoff || cutoff != 0;
+    return TSGPU_OK;
+}
+
 }  // namespace tsgpu
