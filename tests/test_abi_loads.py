@@ -54,13 +54,15 @@ def test_struct_layouts_match_the_header():
     #include <stdio.h>
     #include <stddef.h>
     #include "tsgpu.h"
-    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tsgpu_kw_query), offsetof(tsgpu_kw_query, sort),
+    int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tsgpu_kw_query), offsetof(tsgpu_kw_query, sort),
       offsetof(tsgpu_kw_query, excluded_ids), offsetof(tsgpu_kw_query, deadline_us), sizeof(tsgpu_hits), sizeof(tsgpu_vec_query),
-      sizeof(tsgpu_hybrid_params), sizeof(tsgpu_timings), offsetof(tsgpu_timings, kw_algorithmic_bytes)); return 0; }'''
+      sizeof(tsgpu_hybrid_params), sizeof(tsgpu_timings), offsetof(tsgpu_timings, kw_algorithmic_bytes),
+      sizeof(tsgpu_group_by), offsetof(tsgpu_group_by, wildcard), sizeof(tsgpu_grouped_hits), offsetof(tsgpu_grouped_hits, loglog_registers)); return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
         out = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
     K = B.KwQueryC
     assert out == [C.sizeof(K), K.sort.offset, K.excluded_ids.offset, K.deadline_us.offset, C.sizeof(B.HitsC), C.sizeof(B.VecQueryC),
-                   C.sizeof(B.HybridParamsC), C.sizeof(B.TimingsC), B.TimingsC.kw_algorithmic_bytes.offset]
+                   C.sizeof(B.HybridParamsC), C.sizeof(B.TimingsC), B.TimingsC.kw_algorithmic_bytes.offset,
+                   C.sizeof(B.GroupByC), B.GroupByC.wildcard.offset, C.sizeof(B.GroupedHitsC), B.GroupedHitsC.loglog_registers.offset]
