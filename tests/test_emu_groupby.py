@@ -269,6 +269,38 @@ def test_grouped_string_array_fields():
         g.close()
 
 
+def test_grouped_big_groups_are_cut_into_chunks():
+    """a group_by field with a handful of values over many matches: groups of more than 4096 members take the chunked path of the second pass (one workgroup per
+    8192 members, the last chunk folds the partial lists) and the wave-aggregated table update; q = * needs no postings — 30 000 documents, groups of 70 % / 29 % /
+    1 % + singletons, group_limit 3 and 50, with and without filter / excluded ids"""
+    n = 30000
+    g = T.GpuIndex(0, H.emu_lib_path())
+    try:
+        g.field_create(0, False)
+        g.set_num_docs(n)
+        points = H.points_of(n)
+        g.column_set(0, points)
+        g.commit()
+        rng = np.random.default_rng(3)
+        u = rng.random(n)
+        col = np.where(u < 0.7, 111, np.where(u < 0.99, 222, 333)).astype(np.uint64)
+        col[rng.choice(n, 40, replace=False)] = np.arange(40, dtype=np.uint64) + np.uint64(10**12)       # singletons
+        g.column_set(1, col.view(np.int64))
+        excl = np.sort(rng.choice(n, 500, replace=False)).astype(np.uint32)
+        filt = np.sort(rng.choice(n, 20000, replace=False)).astype(np.uint32)
+        sort = ((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, -1, 0))
+        qs = [T.KwQuery([], sort=sort, topster_size=250), T.KwQuery([], sort=sort, topster_size=30, filter_ids=filt, excluded_ids=excl),
+              T.KwQuery([], sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=2)]
+        for limit in (3, 50):
+            for first_pass in (False, True):
+                h, gh = g.keyword_search_grouped_batch(qs, [(limit, 1, int(first_pass), 0, 1)] * len(qs), k_stride=250 * limit, g_stride=250, want_registers=True)
+                for i, q in enumerate(qs):
+                    check_query(h, gh, i, oracle_grouped_wildcard(q, n, points, col, limit, first_pass), first_pass, limit, "big groups limit %d" % limit)
+        assert int(gh.group_found[0, :int(gh.n_groups[0])].max()) > 8192 * 2
+    finally:
+        g.close()
+
+
 def test_grouped_bad_queries_do_not_disturb_their_neighbours(world):
     orc, g, _, distinct, has_value = world
     good = T.KwQuery([1, 2], topster_size=20)

@@ -62,6 +62,7 @@ def test_grouped_two_fields_multi_field_and_bad_queries(world):
     E.test_grouped_big_output_arrays_take_the_direct_delivery(world)
     E.test_grouped_calls_from_concurrent_threads_are_coalesced_and_keep_their_own_results(world)
     E.test_grouped_multi_field_query()
+    E.test_grouped_big_groups_are_cut_into_chunks()
     E.test_grouped_string_array_fields()
     E.test_grouped_bad_queries_do_not_disturb_their_neighbours(world)
 
@@ -149,3 +150,15 @@ def test_grouped_candidate_combinations_at_2m_documents(c2m):
                     n = int(ref.group_size[r])
                     assert np.array_equal(qidx[u, r * 3:r * 3 + n], rqi[ref.begin[r]:ref.begin[r + 1]].astype(np.uint32))
     assert int(gh.n_groups.sum()) > 100
+    # a three-value group_by field: every group far beyond 4096 members — the chunked second pass over deduplicated records (query_index through the document table)
+    tiny = (np.arange(c.n_docs, dtype=np.uint64) % np.uint64(3)) + np.uint64(77)
+    c.g.column_set(3, tiny.view(np.int64))
+    for first_pass in (True, False):
+        h, gh, qidx, ids = c.g.keyword_search_grouped_candidates_batch(combos[:3], [(5, 3, int(first_pass), 0, 0)] * 3, k_stride=1250, g_stride=250, want_ids=True, want_registers=True)
+        for u, cs in enumerate(combos[:3]):
+            ref, rqi = c.orc.search_candidates_grouped([H.oracle_query(c.orc, q) for q in cs], tiny, 5, first_pass, group_cap=4096, kv_cap=16384, ids_cap=1 << 22)
+            E.check_query(h, gh, u, ref, first_pass, 5, "2M candidates, three groups u%d" % u)
+            if not first_pass:
+                for r in range(int(gh.n_groups[u])):
+                    n = int(ref.group_size[r])
+                    assert np.array_equal(qidx[u, r * 5:r * 5 + n], rqi[ref.begin[r]:ref.begin[r + 1]].astype(np.uint32))

@@ -30,8 +30,10 @@
 //                      table; first pass: the LogLogBeta registers of ALL distinct keys are built in LDS (wyhash of the decimal string, restated
 //                      for the 1..20 bytes a uint64 prints to) and the groups' best KVs are the hits; second pass: member-list offsets
 //   gb_scatter_kernel  second pass, one thread per matched id: members of a selected group append themselves to the group's member list
-//   gb_members_kernel  second pass, one wave per (query, selected group): the group's min(group_limit, members) greatest records by repeated
-//                      wave-wide extraction of the greatest record below the previous one (group_limit is 3 by default, <= 99)
+//   gb_members_kernel  second pass, one wave per (query, selected group of <= GB_BIG members): the group's min(group_limit, members) greatest records by
+//                      repeated wave-wide extraction of the greatest record below the previous one (group_limit is 3 by default)
+//   gb_chunk_kernel    second pass, bigger groups: one workgroup per chunk of GB_CHUNK members (LDS top-K buffer, k = group_limit), the group's last chunk folds
+//                      the partial lists and writes the hits
 //   gb_dedupe_kernel   candidate combinations (Index::search_all_candidates with group_limit != 0: several passes over ONE collector), second pass only: a
 //                      document met by several combinations keeps ONE record — its greatest KV, the later combination on ties (Topster::add replaces unless
 //                      smaller, topster.h:392-406; group_doc_seq_ids -> ret == 2: counted once) — in a per-query document table; the others leave the fold.
@@ -46,6 +48,8 @@ static const unsigned long long GB_EMPTY = ~0ull;     // empty table slot; a dis
 static const uint32_t GB_NONE = 0xFFFFFFFFu;
 static const uint32_t GB_LOGLOG_M = 16384;            // LogLogBeta::M (PRECISION 14)
 static const uint32_t GB_LOGLOG_HIST = 52;            // register values 0..51 (rho <= 50 + 1: the low 14 bits of the shifted hash are ones)
+static const uint32_t GB_BIG = 4096;                  // second pass: a selected group with more members than this is cut into chunks (gb_chunk_kernel) instead of being
+static const uint32_t GB_CHUNK = 8192;                // walked by one wave (gb_members_kernel): members per chunk
 
 struct GbQuery {
     uint64_t item_begin;      // first matched id of the query in the flat arrays
@@ -59,6 +63,8 @@ struct GbQuery {
     uint8_t first_pass, group_missing_values, wildcard, run;   // run = 0: the query failed upstream, nothing is produced
     uint8_t iota, dedupe, pad[2];   // iota: q = * over the whole collection, the matched ids are 0 .. n_items - 1 (gb_iota_kernel writes them); dedupe: a SECOND pass over several
                               // candidate combinations — a document met by several of them counts once, with its greatest KV (the later combination on ties)
+    uint32_t pw_begin, pw_cap;      // second pass: the query's chunk work list (entries [pw_begin, pw_begin + pw_cap): n_items / GB_CHUNK + n_items / GB_BIG + 1 at most)
+    uint64_t pbuf_off;              // ... and its partial top-L buffer (pw_cap x group_limit entries)
     uint32_t first_combo, n_combos; // the user query's candidate combinations (search_all_candidates: one search_across_fields pass each; 1 = a plain pass): its items are the
                               // combinations' matched ids one after the other, combination c at items [combo_begin[c], combo_begin[c + 1])
 };
@@ -70,6 +76,10 @@ struct GbArgs {
     uint8_t* pass;                                                             // per matched id: which combination of its user query met it
     uint32_t* dkey32; uint32_t* dbest;                                         // per table slot, dedupe only: the document table (seq_id -> its greatest record)
     uint32_t* out_qidx;                                                        // per hit slot (like out): KV::query_index
+    uint32_t n_pw;                                                             // chunk work list: total capacity (= the chunk kernel's grid), entries (group rank | chunk << 10),
+    uint32_t* pw_list; uint32_t* pw_count; uint32_t* pw_n;                     // per-query count, entries of each partial; per (query, group): first partial, chunks, ticket
+    uint32_t* g_pfirst; uint32_t* g_nchunk; uint32_t* g_ticket;
+    int64_t* pb_s0; int64_t* pb_s1; int64_t* pb_s2; int64_t* pb_key;           // partial top-L lists (sorted), group_limit entries per work-list entry
     uint64_t n_items;
     const uint32_t* ids;                                                       // matched ids, ascending per query
     int64_t* s0; int64_t* s1; int64_t* s2; unsigned long long* dkey; uint32_t* rslot;    // per matched id
@@ -195,41 +205,79 @@ __global__ __launch_bounds__(GB_THREADS) void gb_dedupe_kernel(GbArgs a) {
 // ---- group table: slot per distinct key, member count, best record ----
 __global__ __launch_bounds__(GB_THREADS) void gb_insert_kernel(GbArgs a) {
     uint32_t qi; uint64_t i;
-    if (!gb_item_of(a, qi, i)) return;
+    bool active = gb_item_of(a, qi, i);                                      // (nobody leaves: the wave-wide steps below need every lane)
     const GbQuery g = a.gq[qi];
-    if (g.dedupe && a.dbest[g.tab_off + gb_doc_slot(a, g, a.ids[i], false)] != (uint32_t)(i - g.item_begin)) { a.rslot[i] = GB_NONE; return; }   // not its document's record
-    const unsigned long long key = a.dkey[i];
-    uint32_t slot;
-    if (key == GB_EMPTY) slot = g.tab_mask + 1;
-    else {
-        slot = (uint32_t)gb_mix(key) & g.tab_mask;
-        for (;;) {
-            unsigned long long* kp = a.hkey + g.tab_off + slot;
-            unsigned long long cur = *kp;                                   // (a slot's key never changes once set; a stale EMPTY is resolved by the CAS)
-            if (cur == GB_EMPTY) { cur = atomicCAS(kp, GB_EMPTY, key); if (cur == GB_EMPTY) cur = key; }
-            if (cur == key) break;
-            slot = (slot + 1) & g.tab_mask;
+    if (active && g.dedupe && a.dbest[g.tab_off + gb_doc_slot(a, g, a.ids[i], false)] != (uint32_t)(i - g.item_begin)) { a.rslot[i] = GB_NONE; active = false; }   // not its document's record
+    uint32_t slot = GB_NONE;
+    if (active) {
+        const unsigned long long key = a.dkey[i];
+        if (key == GB_EMPTY) slot = g.tab_mask + 1;
+        else {
+            slot = (uint32_t)gb_mix(key) & g.tab_mask;
+            for (;;) {
+                unsigned long long* kp = a.hkey + g.tab_off + slot;
+                unsigned long long cur = *kp;                               // (a slot's key never changes once set; a stale EMPTY is resolved by the CAS)
+                if (cur == GB_EMPTY) { cur = atomicCAS(kp, GB_EMPTY, key); if (cur == GB_EMPTY) cur = key; }
+                if (cur == key) break;
+                slot = (slot + 1) & g.tab_mask;
+            }
+        }
+        a.rslot[i] = slot;
+    }
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t me = (uint32_t)(i - g.item_begin);
+    // Skewed groups (a field with a handful of values over millions of matches): thousands of threads would hammer ONE slot's counter and best-record word
+    // (measured: one group of 10M documents 117 ms in this kernel). Lanes of a wave that share a slot update it ONCE: the count
+    // by their number, the best record by their greatest (a wave-wide reduction of the Topster's comparison).
+    // Up to three rounds: each takes the slot of the first lane not yet assigned; when at least 4 lanes share it they update it together.
+    bool first = false, pending = active, solo = false;
+    for (int round = 0; round < 3; round++) {
+        const unsigned long long rem = __ballot(pending ? 1 : 0);
+        if (!rem) break;                                                     // (wave-uniform)
+        const uint32_t leader = (uint32_t)__ffsll((long long)rem) - 1;
+        const uint32_t lslot = __shfl(slot, (int)leader, 64);
+        const bool mine = pending && slot == lslot;
+        const unsigned long long same = __ballot(mine ? 1 : 0);
+        if (__popcll(same) < 4) { if (mine) { solo = true; pending = false; } continue; }      // (wave-uniform) too few: on their own below
+        int64_t v0 = 0, v1 = 0, v2 = 0, vk = -1; uint32_t vp = 0, vi = 0;      // this lane's candidate (vk < 0: none)
+        if (mine) { v0 = a.s0[i]; v1 = a.s1[i]; v2 = a.s2[i]; vk = (int64_t)a.ids[i]; vp = a.pass[i]; vi = me; }
+        for (int d = 32; d > 0; d >>= 1) {
+            const int64_t o0 = __shfl_xor(v0, d, 64), o1 = __shfl_xor(v1, d, 64), o2 = __shfl_xor(v2, d, 64), ok = __shfl_xor(vk, d, 64);
+            const uint32_t op = __shfl_xor(vp, d, 64), oi = __shfl_xor(vi, d, 64);
+            const bool og = ent_greater(o0, o1, o2, ok, v0, v1, v2, vk) || (ok >= 0 && ok == vk && o0 == v0 && o1 == v1 && o2 == v2 && op > vp);
+            if (og) { v0 = o0; v1 = o1; v2 = o2; vk = ok; vp = op; vi = oi; }
+        }
+        if (lane == leader) {
+            first = atomicAdd(&a.hcount[g.tab_off + slot], (uint32_t)__popcll(same)) == 0;
+            uint32_t* bp = a.hbest + g.tab_off + slot;
+            uint32_t cur = atomicCAS(bp, GB_NONE, vi);
+            while (cur != GB_NONE && gb_rec_greater(a, g.item_begin + vi, g.item_begin + cur)) {
+                const uint32_t prev = atomicCAS(bp, cur, vi);
+                if (prev == cur) break;
+                cur = prev;
+            }
+        }
+        if (mine) pending = false;
+    }
+    if (pending) solo = true;                                                // (not reached in three rounds)
+    if (solo) {
+        first = atomicAdd(&a.hcount[g.tab_off + slot], 1u) == 0;
+        // the group's greatest record: hbest holds a LOCAL item index; whoever holds a greater record replaces it
+        uint32_t* bp = a.hbest + g.tab_off + slot;
+        uint32_t cur = atomicCAS(bp, GB_NONE, me);
+        while (cur != GB_NONE && gb_rec_greater(a, i, g.item_begin + cur)) {
+            const uint32_t prev = atomicCAS(bp, cur, me);
+            if (prev == cur) break;
+            cur = prev;
         }
     }
-    a.rslot[i] = slot;
     // the group's first member lists its slot; one counter update per wave (every lane of a workgroup serves the same query)
-    const bool first = atomicAdd(&a.hcount[g.tab_off + slot], 1u) == 0;
     const unsigned long long fm = __ballot(first ? 1 : 0);
     if (fm) {
-        const uint32_t lane = threadIdx.x & 63;
         uint32_t base_at = 0;
         if (lane == (uint32_t)__ffsll((long long)fm) - 1) base_at = atomicAdd(&a.gcount[qi], (uint32_t)__popcll(fm));
         base_at = __shfl(base_at, __ffsll((long long)fm) - 1, 64);
         if (first) a.glist[g.item_begin + base_at + (uint32_t)__popcll(fm & ((1ull << lane) - 1))] = slot;
-    }
-    // the group's greatest record: hbest holds a LOCAL item index; whoever holds a greater record replaces it
-    const uint32_t me = (uint32_t)(i - g.item_begin);
-    uint32_t* bp = a.hbest + g.tab_off + slot;
-    uint32_t cur = atomicCAS(bp, GB_NONE, me);
-    while (cur != GB_NONE && gb_rec_greater(a, i, g.item_begin + cur)) {
-        const uint32_t prev = atomicCAS(bp, cur, me);
-        if (prev == cur) break;
-        cur = prev;
     }
 }
 
@@ -277,7 +325,7 @@ __global__ __launch_bounds__(GB_THREADS) void gb_select_kernel(GbArgs a) {
     const uint32_t qi = blockIdx.x;
     const GbQuery g = a.gq[qi];
     const size_t gbase = (size_t)qi * a.g_stride;
-    if (!g.run) { if (t == 0) { a.n_groups[qi] = 0; a.groups_total[qi] = 0; a.out.n_hits[qi] = 0; } return; }
+    if (!g.run) { if (t == 0) { a.n_groups[qi] = 0; a.groups_total[qi] = 0; a.out.n_hits[qi] = 0; a.pw_count[qi] = 0; } return; }
     if (t == 0) { s_cnt = 0; s_have = 0; }
     for (uint32_t w = t; w < GB_LOGLOG_M / 4; w += GB_THREADS) regs[w] = 0;
     __syncthreads();
@@ -369,14 +417,25 @@ __global__ __launch_bounds__(GB_THREADS) void gb_select_kernel(GbArgs a) {
         a.groups_total[qi] = n_used;
         uint32_t hits = n;
         if (!g.first_pass) {
-            uint32_t ofs = 0;
+            uint32_t ofs = 0, pw = 0;
             hits = 0;
             for (uint32_t r = 0; r < n; r++) {
                 const uint32_t members = regs[r];
                 a.g_mofs[gbase + r] = ofs; a.g_mcur[gbase + r] = 0;
                 ofs += members; hits += members < g.group_limit ? members : g.group_limit;
+                // a big group's members are cut into chunks, one workgroup each (gb_chunk_kernel); the work list cannot overflow: a big group has more than
+                // GB_BIG members, so there are at most n_items / GB_BIG of them and n_items / GB_CHUNK + that many chunks
+                uint32_t nch = 0;
+                if (members > GB_BIG) {
+                    nch = (members + GB_CHUNK - 1) / GB_CHUNK;
+                    if (pw + nch > g.pw_cap) nch = 0;                    // (cannot happen; a group left to the one-wave walk is still answered correctly)
+                }
+                a.g_pfirst[gbase + r] = pw; a.g_nchunk[gbase + r] = nch;
+                for (uint32_t c = 0; c < nch; c++) a.pw_list[g.pw_begin + pw + c] = r | (c << 10);
+                pw += nch;
             }
-        }
+            a.pw_count[qi] = pw;
+        } else a.pw_count[qi] = 0;
         a.out.n_hits[qi] = hits;
     }
     if (g.first_pass) {
@@ -397,16 +456,35 @@ __global__ __launch_bounds__(GB_THREADS) void gb_select_kernel(GbArgs a) {
 // ---- second pass: members of the selected groups ----
 __global__ __launch_bounds__(GB_THREADS) void gb_scatter_kernel(GbArgs a) {
     uint32_t qi; uint64_t i;
-    if (!gb_item_of(a, qi, i)) return;
+    const bool in_range = gb_item_of(a, qi, i);                               // (nobody leaves: the wave-wide step below needs every lane)
     const GbQuery g = a.gq[qi];
-    if (g.first_pass) return;
-    const uint32_t rs = a.rslot[i];
-    if (rs == GB_NONE) return;                                               // (dedupe: not its document's record)
-    const uint32_t r = a.hrank[g.tab_off + rs];
-    if (r == GB_NONE) return;
-    const size_t gi = (size_t)qi * a.g_stride + r;
-    const uint32_t at = atomicAdd(&a.g_mcur[gi], 1u);
-    a.members[g.item_begin + a.g_mofs[gi] + at] = (uint32_t)(i - g.item_begin);
+    uint32_t r = GB_NONE;
+    if (in_range && !g.first_pass) {
+        const uint32_t rs = a.rslot[i];                                      // (GB_NONE with dedupe: not its document's record)
+        if (rs != GB_NONE) r = a.hrank[g.tab_off + rs];
+    }
+    // members of one selected group in one wave take their places in its list with ONE cursor update (a group of 10M members: 100 ms of same-address atomics otherwise)
+    const uint32_t lane = threadIdx.x & 63;
+    bool pending = r != GB_NONE;
+    for (int round = 0; round < 3; round++) {
+        const unsigned long long rem = __ballot(pending ? 1 : 0);
+        if (!rem) break;                                                     // (wave-uniform)
+        const uint32_t leader = (uint32_t)__ffsll((long long)rem) - 1;
+        const uint32_t lr = __shfl(r, (int)leader, 64);
+        const bool mine = pending && r == lr;
+        const unsigned long long same = __ballot(mine ? 1 : 0);
+        uint32_t base_at = 0;
+        if (lane == leader) base_at = atomicAdd(&a.g_mcur[(size_t)qi * a.g_stride + lr], (uint32_t)__popcll(same));
+        base_at = __shfl(base_at, (int)leader, 64);
+        if (mine) {
+            a.members[g.item_begin + a.g_mofs[(size_t)qi * a.g_stride + r] + base_at + (uint32_t)__popcll(same & ((1ull << lane) - 1))] = (uint32_t)(i - g.item_begin);
+            pending = false;
+        }
+    }
+    if (pending) {                                                           // (more than three groups in one wave: the rest one by one)
+        const size_t gi = (size_t)qi * a.g_stride + r;
+        a.members[g.item_begin + a.g_mofs[gi] + atomicAdd(&a.g_mcur[gi], 1u)] = (uint32_t)(i - g.item_begin);
+    }
 }
 
 // one wave per (query, selected group): the group Topster's content in sort() order = its min(group_limit, members) greatest records, descending.
@@ -419,6 +497,7 @@ __global__ __launch_bounds__(GB_THREADS) void gb_members_kernel(GbArgs a) {
     const GbQuery g = a.gq[qi];
     if (!g.run || g.first_pass || r >= a.n_groups[qi]) return;              // (wave-uniform)
     const size_t gi = (size_t)qi * a.g_stride + r;
+    if (a.g_nchunk[gi]) return;                                              // a big group: gb_chunk_kernel
     const uint32_t cnt = a.g_found[gi], take = a.g_size[gi];
     const uint32_t* mem = a.members + g.item_begin + a.g_mofs[gi];
     const KwQueryDev& q = a.queries[g.first_combo];
@@ -449,5 +528,96 @@ __global__ __launch_bounds__(GB_THREADS) void gb_members_kernel(GbArgs a) {
             a.out_qidx[o] = a.qidx_of_combo[g.first_combo + a.pass[g.item_begin + bx]];
         }
         p0 = b0; p1 = b1; p2 = b2; pk = bk;
+    }
+}
+
+// ---- second pass, big groups: one workgroup per chunk of GB_CHUNK members keeps the chunk's group_limit greatest records (the LDS top-K buffer of the keyword
+// kernels, k = group_limit) as a sorted partial list; the workgroup that finishes a group's LAST chunk (a ticket per group, device-scope release / acquire around
+// it: the partial lists were written by workgroups on other XCDs) folds the group's partial lists the same way and writes the group's hits. One wave walking a
+// group of 10M members cost 0.6 s at group_limit 3 and 7 s at 50 (tools/experiments/giant_group_probe.py); the chunks of such a group run on the whole chip. ----
+__device__ inline uint32_t gb_record_of_key(const GbArgs& a, const GbQuery& g, uint32_t key) {       // local item index of the group member with this id
+    if (g.n_combos > 1) return a.dbest[g.tab_off + gb_doc_slot(a, g, key, false)];              // (a second pass over several combinations keeps one record per document)
+    const uint32_t* qids = a.ids + g.item_begin;
+    uint32_t lo = 0, hi = g.n_items;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (qids[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(GB_THREADS) void gb_chunk_kernel(GbArgs a) {
+    __shared__ TopkLds<512, true> tk;
+    __shared__ int64_t thr[4];
+    __shared__ uint32_t s_cnt, s_have, s_q, s_last;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) {
+        uint32_t lo = 0, hi = a.n_queries;                                   // the last query whose pw_begin <= blockIdx.x
+        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (a.gq[mid].pw_begin <= blockIdx.x) lo = mid; else hi = mid; }
+        s_q = lo; s_cnt = 0; s_have = 0;
+    }
+    __syncthreads();
+    const uint32_t qi = s_q;
+    const GbQuery g = a.gq[qi];
+    const uint32_t w = blockIdx.x - g.pw_begin;
+    if (w >= g.pw_cap || w >= a.pw_count[qi]) return;                        // (workgroup-uniform)
+    const uint32_t e = a.pw_list[g.pw_begin + w], r = e & 1023u, c = e >> 10;
+    const size_t gi = (size_t)qi * a.g_stride + r;
+    const uint32_t L = g.group_limit, members = a.g_found[gi];
+    const uint32_t* mem = a.members + g.item_begin + a.g_mofs[gi];
+    const uint32_t m0 = c * GB_CHUNK, m1 = m0 + GB_CHUNK < members ? m0 + GB_CHUNK : members;
+    // stream [first, first + count) entries produced by `get` through the top-L buffer (the select kernel's loop)
+    auto fold = [&](uint32_t count, auto get) {
+        for (uint32_t base = 0; base < count; base += GB_THREADS) {
+            const bool have = base + t < count;
+            int64_t e0 = 0, e1 = 0, e2 = 0, ek = -1;
+            const bool valid = have && get(base + t, e0, e1, e2, ek);
+            bool pass = valid && (!s_have || ent_greater(e0, e1, e2, ek, thr[0], thr[1], thr[2], thr[3]));
+            const uint32_t held = s_cnt;
+            const uint32_t n_pass = (uint32_t)__syncthreads_count(pass ? 1 : 0);
+            if (held + n_pass > 512u) {
+                topk_compact<512, true>(tk, &s_cnt, L, thr, &s_have);
+                pass = pass && (!s_have || ent_greater(e0, e1, e2, ek, thr[0], thr[1], thr[2], thr[3]));
+            }
+            if (pass) { const uint32_t at = atomicAdd(&s_cnt, 1u); tk.s0[at] = e0; tk.s1[at] = e1; tk.s2[at] = e2; tk.key[at] = ek; }
+            __syncthreads();
+        }
+        topk_compact<512, true>(tk, &s_cnt, L, thr, &s_have);
+    };
+    fold(m1 - m0, [&](uint32_t j, int64_t& e0, int64_t& e1, int64_t& e2, int64_t& ek) {
+        const uint64_t x = g.item_begin + mem[m0 + j];
+        e0 = a.s0[x]; e1 = a.s1[x]; e2 = a.s2[x]; ek = (int64_t)a.ids[x];
+        return true;
+    });
+    const uint32_t np = s_cnt;                                               // min(L, members of the chunk), sorted descending
+    const size_t pb = g.pbuf_off + (size_t)w * L;
+    for (uint32_t j = t; j < np; j += GB_THREADS) { a.pb_s0[pb + j] = tk.s0[j]; a.pb_s1[pb + j] = tk.s1[j]; a.pb_s2[pb + j] = tk.s2[j]; a.pb_key[pb + j] = tk.key[j]; }
+    if (t == 0) a.pw_n[g.pw_begin + w] = np;
+    __threadfence();                                                         // release: this chunk's partial list before its ticket
+    __syncthreads();
+    if (t == 0) s_last = atomicAdd(&a.g_ticket[gi], 1u) + 1 == a.g_nchunk[gi] ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                                         // acquire: the other chunks' partial lists
+    // ---- the group's last chunk: fold the partial lists, write the hits ----
+    const uint32_t pf = a.g_pfirst[gi], nch = a.g_nchunk[gi];
+    if (t == 0) { s_cnt = 0; s_have = 0; }
+    __syncthreads();
+    fold(nch * L, [&](uint32_t j, int64_t& e0, int64_t& e1, int64_t& e2, int64_t& ek) {
+        const uint32_t ch = j / L, k = j % L;
+        if (k >= a.pw_n[g.pw_begin + pf + ch]) return false;               // (a chunk with fewer than L members)
+        const size_t o = g.pbuf_off + (size_t)(pf + ch) * L + k;
+        e0 = a.pb_s0[o]; e1 = a.pb_s1[o]; e2 = a.pb_s2[o]; ek = a.pb_key[o];
+        return true;
+    });
+    const uint32_t take = s_cnt;                                             // = g_size: min(L, members)
+    const KwQueryDev& q = a.queries[g.first_combo];
+    int msi = -1;
+    for (int i = 0; i < 3; i++) if (i < (int)q.n_sort && q.sort_kind[i] == 0) msi = i;
+    for (uint32_t j = t; j < take && j < L; j += GB_THREADS) {
+        const size_t o = (size_t)qi * a.out.k_stride + (size_t)r * L + j;
+        a.out.keys[o] = (uint64_t)tk.key[j];
+        a.out.scores[o * 3 + 0] = tk.s0[j]; a.out.scores[o * 3 + 1] = tk.s1[j]; a.out.scores[o * 3 + 2] = tk.s2[j];
+        a.out.text_match[o] = msi == 0 ? tk.s0[j] : (msi == 1 ? tk.s1[j] : (msi == 2 ? tk.s2[j] : 0));
+        a.out.vector_distance[o] = -1.0f;
+        a.out.match_score_index[o] = (int8_t)msi;
+        a.out_qidx[o] = a.qidx_of_combo[g.first_combo + a.pass[g.item_begin + gb_record_of_key(a, g, (uint32_t)tk.key[j])]];
     }
 }

@@ -282,6 +282,16 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
             n_slots += size + 1;                          // + the slot of the key ~0
         }
         combo_begin[n_combos] = n_items;
+        // second passes: the chunk work lists of the big groups and their partial top-L buffers
+        uint64_t n_pw = 0, n_pb = 0;
+        for (uint32_t i = 0; i < n_queries; i++) {
+            GbQuery& g = gq[i];
+            g.pw_begin = (uint32_t)n_pw; g.pbuf_off = n_pb;
+            g.pw_cap = (g.run && !g.first_pass) ? g.n_items / GB_CHUNK + g.n_items / GB_BIG + 1 : 0;
+            n_pw += g.pw_cap;
+            n_pb += (uint64_t)g.pw_cap * g.group_limit;
+        }
+        if (n_pw > 0x7FFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_grouped_batch: too many matched ids in one batch");
         if (n_blocks > 0x1FFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_grouped_batch: too many matched ids in one batch");
         if (n_slots * 20 + n_items * 48 > (64ull << 30)) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_grouped_batch: the group tables of this batch exceed 64 GiB; split it");
         if (!ctx->groupby) ctx->groupby = new GroupByScratch;
@@ -295,7 +305,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
                      i_cb = Lin.take(((size_t)n_combos + 1) * 8), i_qx = Lin.take((size_t)ncz * 4), i_ids = Lin.take(ids_on_dev ? 16 : ni * 4);
         const size_t f_hkey = Lff.take(n_slots * 8), f_hbest = Lff.take(n_slots * 4), f_hrank = Lff.take(n_slots * 4),
                      f_dkey = Lff.take(any_dedupe ? n_slots * 4 : 16), f_dbest = Lff.take(any_dedupe ? n_slots * 4 : 16);      // the document tables of the second passes over several combinations
-        const size_t z_hcount = Lzero.take(n_slots * 4), z_gcount = Lzero.take((size_t)n_queries * 4);
+        const size_t z_hcount = Lzero.take(n_slots * 4), z_gcount = Lzero.take((size_t)n_queries * 4), z_ticket = Lzero.take(n_g * 4);
         const size_t o_nhits = Lout.take((size_t)n_queries * 4), o_ng = Lout.take((size_t)n_queries * 4), o_gtot = Lout.take((size_t)n_queries * 8),
                      o_hist = Lout.take((size_t)n_queries * GB_LOGLOG_HIST * 4), o_gdkey = Lout.take(n_g * 8), o_gsize = Lout.take(n_g * 4), o_gfound = Lout.take(n_g * 4),
                      o_keys = Lout.take(n_out * 8), o_scores = Lout.take(n_out * 24), o_msi = Lout.take(n_out);
@@ -306,7 +316,10 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
         const size_t end_vd = Lout.at;
         const size_t o_qx = Lout.take(n_out * 4);                 // KV::query_index per hit slot (only with several combinations per query)
         const size_t w_s0 = Lwork.take(ni * 8), w_s1 = Lwork.take(ni * 8), w_s2 = Lwork.take(ni * 8), w_dkey = Lwork.take(ni * 8), w_rslot = Lwork.take(ni * 4),
-                     w_members = Lwork.take(ni * 4), w_glist = Lwork.take(ni * 4), w_mofs = Lwork.take(n_g * 4), w_mcur = Lwork.take(n_g * 4), w_pass = Lwork.take(ni);
+                     w_members = Lwork.take(ni * 4), w_glist = Lwork.take(ni * 4), w_mofs = Lwork.take(n_g * 4), w_mcur = Lwork.take(n_g * 4), w_pass = Lwork.take(ni),
+                     w_pfirst = Lwork.take(n_g * 4), w_nchunk = Lwork.take(n_g * 4), w_pwlist = Lwork.take(std::max<uint64_t>(n_pw, 1) * 4), w_pwn = Lwork.take(std::max<uint64_t>(n_pw, 1) * 4),
+                     w_pwcount = Lwork.take((size_t)n_queries * 4), w_pb0 = Lwork.take(std::max<uint64_t>(n_pb, 1) * 8), w_pb1 = Lwork.take(std::max<uint64_t>(n_pb, 1) * 8),
+                     w_pb2 = Lwork.take(std::max<uint64_t>(n_pb, 1) * 8), w_pbk = Lwork.take(std::max<uint64_t>(n_pb, 1) * 8);
         const size_t out_bytes = query_index ? Lout.at : (out->vector_distance ? end_vd : (out->text_match ? end_tm : end_required));      // what the caller asked for, as a prefix
         int rc;
         if ((rc = S.in.reserve(Lin.at)) || (rc = S.ff.reserve(Lff.at)) || (rc = S.zero.reserve(Lzero.at)) || (rc = S.out.reserve(Lout.at)) || (rc = S.work.reserve(Lwork.at)) ||
@@ -348,6 +361,9 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
         a.gq = (const GbQuery*)(din + i_gq); a.n_queries = n_queries; a.queries = (const KwQueryDev*)(din + i_qd); a.mfs = (const KwQueryMF*)(din + i_mf);
         a.combo_begin = (const unsigned long long*)(din + i_cb); a.qidx_of_combo = (const uint32_t*)(din + i_qx); a.pass = (uint8_t*)(dw + w_pass);
         a.dkey32 = (uint32_t*)(dff + f_dkey); a.dbest = (uint32_t*)(dff + f_dbest); a.out_qidx = (uint32_t*)(dout + o_qx);
+        a.n_pw = (uint32_t)n_pw; a.pw_list = (uint32_t*)(dw + w_pwlist); a.pw_count = (uint32_t*)(dw + w_pwcount); a.pw_n = (uint32_t*)(dw + w_pwn);
+        a.g_pfirst = (uint32_t*)(dw + w_pfirst); a.g_nchunk = (uint32_t*)(dw + w_nchunk); a.g_ticket = (uint32_t*)(dz + z_ticket);
+        a.pb_s0 = (int64_t*)(dw + w_pb0); a.pb_s1 = (int64_t*)(dw + w_pb1); a.pb_s2 = (int64_t*)(dw + w_pb2); a.pb_key = (int64_t*)(dw + w_pbk);
         a.n_items = n_items; a.ids = ids_on_dev ? S.ids_dev.as<uint32_t>() : (const uint32_t*)(din + i_ids);
         a.s0 = (int64_t*)(dw + w_s0); a.s1 = (int64_t*)(dw + w_s1); a.s2 = (int64_t*)(dw + w_s2); a.dkey = (unsigned long long*)(dw + w_dkey); a.rslot = (uint32_t*)(dw + w_rslot);
         a.hkey = (unsigned long long*)(dff + f_hkey); a.hbest = (uint32_t*)(dff + f_hbest); a.hrank = (uint32_t*)(dff + f_hrank);
@@ -377,6 +393,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
             hipLaunchKernelGGL(gb_scatter_kernel, dim3((uint32_t)n_blocks), dim3(GB_THREADS), 0, s, a);
             const uint64_t pairs = (uint64_t)n_queries * gs;
             hipLaunchKernelGGL(gb_members_kernel, dim3((uint32_t)((pairs + GB_THREADS / 64 - 1) / (GB_THREADS / 64))), dim3(GB_THREADS), 0, s, a);
+            if (n_pw) hipLaunchKernelGGL(gb_chunk_kernel, dim3((uint32_t)n_pw), dim3(GB_THREADS), 0, s, a);      // (workgroups beyond a query's chunk count leave at once)
         }
         TSGPU_HIP_TRY(hipGetLastError());
         uint64_t t_launched = now_us(), t_kernels = t_launched;
