@@ -143,12 +143,13 @@ def _random_facet_index(rng, n_docs, n_values, array=True):
     return ptr, hashes
 
 
-def _check(g, orc, lists, **kw):
-    got = g.facet_count_batch(0, lists, cap=4096, **kw)
+def _check(g, orc, lists, cap=4096, **kw):
+    got = g.facet_count_batch(0, lists, cap=cap, **kw)
     for q, ids in enumerate(lists):
         h, c, d, p, n = orc.facet_count(0, ids, sample_mod=kw.get("sample_mod", 1), allowed_hashes=kw.get("allowed_hashes"))
         gh, gc, gd, gp, gn = got[q]
         assert gn == n, "query %d: %d distinct values, oracle %d" % (q, gn, n)
+        h, c, d, p = h[:cap], c[:cap], d[:cap], p[:cap]           # (the first `cap` values in hash order are returned)
         assert np.array_equal(gh, h) and np.array_equal(gc, c) and np.array_equal(gd, d) and np.array_equal(gp, p), "query %d" % q
 
 
@@ -169,6 +170,28 @@ def _run(lib, n_docs, n_values):
     g.facet_set(0, ptr2, hashes2)
     orc.facet_set(0, ptr2, hashes2)
     _check(g, orc, lists)
+    _check(g, orc, lists, cap=4)                                  # more values than the caller takes: only the first `cap` hashes are put in order
+    # two values over every document (whole waves on one counter: counted once per wave), in an array field whose documents repeat them
+    per = rng.integers(1, 4, size=n_docs)
+    ptr3 = np.zeros(n_docs + 1, np.uint64)
+    ptr3[1:] = np.cumsum(per)
+    hashes3 = np.where(rng.random(int(ptr3[-1])) < 0.7, np.uint32(0xDEADBEEF), np.uint32(12345)).astype(np.uint32)
+    g.facet_set(0, ptr3, hashes3)
+    orc.facet_set(0, ptr3, hashes3)
+    everything = [np.arange(n_docs, dtype=np.uint32)] + lists
+    _check(g, orc, everything)
+    _check(g, orc, everything, sample_mod=7)
+    _check(g, orc, everything, allowed_hashes=np.array([12345], np.uint32))
+    # workgroups that walk several rounds of ids before they add their LDS counts to the table; and a field of more values than the LDS table holds
+    g.set_option("facet_ids_per_block", 1024)
+    _check(g, orc, everything)
+    ptr4, _ = _random_facet_index(rng, n_docs, 1 << 20)
+    hashes4 = rng.integers(0, 1 << 32, size=int(ptr4[-1]), dtype=np.uint64).astype(np.uint32)      # (every hash its own value: the LDS tables overflow)
+    g.facet_set(0, ptr4, hashes4)
+    orc.facet_set(0, ptr4, hashes4)
+    _check(g, orc, everything, cap=1 << 16)
+    g.set_option("facet_ids_per_block", 0)
+    _check(g, orc, everything, cap=1 << 16, sample_mod=2)
     g.close()
 
 

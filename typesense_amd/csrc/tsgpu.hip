@@ -312,6 +312,10 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
         if (value < 1 || value > tsgpu_ctx::N_LANES) return fail(TSGPU_ERR_INVALID, "kw_lanes out of range (1..8)");
         ctx->n_lanes = (int)value; return ok();
     }
+    if (!strcmp(name, "facet_ids_per_block")) {        // result ids per workgroup of the facet counting launch; 0 = chosen per batch (tests: the multi-round walk on small inputs)
+        if (value < 0 || value > 4096 || (value % 256) != 0) return fail(TSGPU_ERR_INVALID, "facet_ids_per_block must be 0 or a multiple of 256 up to 4096");
+        ctx->facet_ids_per_block = (uint32_t)value; return ok();
+    }
     if (!strcmp(name, "hybrid_overlap")) { ctx->hybrid_overlap = value != 0; return ok(); }
     if (!strcmp(name, "vec_batch_post_window_us")) { ctx->vec_batch_post_window_us = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 100000); return ok(); }
     if (!strcmp(name, "batch_window_us")) { ctx->batch_window_us = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 100000); return ok(); }

@@ -78,8 +78,15 @@ int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
     if (sample_mod == 0) sample_mod = 1;
     try {
         std::vector<FacetQueryDev> qd(n_queries);
-        uint64_t ids_total = 0, tab_total = 0, out_total = 0;
+        uint64_t ids_total = 0, tab_total = 0, out_total = 0, max_size = 64;
         uint32_t blocks = 0;
+        // ids per workgroup: the more ids a workgroup folds in LDS before it touches the query's table the fewer atomics meet there, as long as a
+        // couple of thousand workgroups remain to fill the 256 CUs
+        uint64_t all_ids = 0;
+        for (uint32_t q = 0; q < n_queries; q++) all_ids += n_result_ids[q];
+        uint32_t ids_per_block = FACET_THREADS;
+        while (ids_per_block < 4096 && all_ids / (ids_per_block * 2) >= 2048) ids_per_block *= 2;
+        if (ctx->facet_ids_per_block) ids_per_block = ctx->facet_ids_per_block;
         for (uint32_t q = 0; q < n_queries; q++) {
             if (n_result_ids[q] && !result_ids[q]) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_count_batch: result_ids[q] is NULL");
             FacetQueryDev& d = qd[q];
@@ -96,7 +103,8 @@ int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
             d.out_off = out_total;
             out_total += size / 2 + 1;
             d.first_block = blocks;
-            const uint64_t nb = (d.n_ids + FACET_THREADS - 1) / FACET_THREADS;
+            max_size = std::max(max_size, size);
+            const uint64_t nb = (d.n_ids + ids_per_block - 1) / ids_per_block;
             if ((uint64_t)blocks + nb > 0x7FFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_facet_count_batch: more than 2^31 workgroups");
             blocks += (uint32_t)nb;
         }
@@ -114,15 +122,16 @@ int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
         TSGPU_HIP_TRY(hipMemsetAsync(f->d_key.p, 0, tab_total * 8, s));
         TSGPU_HIP_TRY(hipMemsetAsync(f->d_cnt.p, 0, tab_total * 4, s));
         TSGPU_HIP_TRY(hipMemsetAsync(f->d_last.p, 0, tab_total * 8, s));
+        TSGPU_HIP_TRY(hipMemsetAsync(f->d_on.p, 0, (size_t)n_queries * 4, s));
         FacetArgs a;
         a.doc_ptr = f->doc_ptr.as<uint64_t>(); a.hashes = f->hashes.as<uint32_t>(); a.n_docs = f->n_docs;
-        a.ids = f->d_ids.as<uint32_t>(); a.queries = f->d_queries.as<FacetQueryDev>(); a.n_queries = n_queries; a.sample_mod = sample_mod;
+        a.ids = f->d_ids.as<uint32_t>(); a.queries = f->d_queries.as<FacetQueryDev>(); a.n_queries = n_queries; a.sample_mod = sample_mod; a.ids_per_block = ids_per_block;
         a.allowed = n_allowed ? f->d_allowed.as<uint32_t>() : nullptr; a.n_allowed = n_allowed;
         a.tab_key = f->d_key.as<unsigned long long>(); a.tab_cnt = f->d_cnt.as<uint32_t>(); a.tab_last = f->d_last.as<unsigned long long>();
         a.out_hash = f->d_oh.as<uint32_t>(); a.out_cnt = f->d_oc.as<uint32_t>(); a.out_doc = f->d_od.as<uint32_t>(); a.out_pos = f->d_op.as<uint32_t>();
         a.out_n = f->d_on.as<uint32_t>();
         if (blocks) hipLaunchKernelGGL(facet_count_kernel, dim3(blocks), dim3(FACET_THREADS), 0, s, a);
-        hipLaunchKernelGGL(facet_compact_kernel, dim3(n_queries), dim3(FACET_THREADS), 0, s, a);
+        hipLaunchKernelGGL(facet_compact_kernel, dim3(n_queries, (uint32_t)std::min<uint64_t>((max_size + FACET_COMPACT_SLOTS - 1) / FACET_COMPACT_SLOTS, 4096)), dim3(FACET_THREADS), 0, s, a);
         TSGPU_HIP_TRY(hipGetLastError());
         std::vector<uint32_t> hn(n_queries), hh(out_total), hc(out_total), hd(out_total), hp(out_total);
         TSGPU_HIP_TRY(hipMemcpyAsync(hn.data(), f->d_on.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost, s));
@@ -132,18 +141,21 @@ int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
         TSGPU_HIP_TRY(hipMemcpyAsync(hp.data(), f->d_op.p, out_total * 4, hipMemcpyDeviceToHost, s));
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
         // the distinct values of a query in ascending hash order (result_map is keyed by the hash); the first `cap` of them are returned
-        std::vector<uint32_t> order;
+        // (hash << 32 | position in the device list: only the first `cap` hashes are put in order when the query met more values than that)
+        std::vector<uint64_t> order;
         for (uint32_t q = 0; q < n_queries; q++) {
             const uint32_t n = hn[q];
             const uint64_t base = qd[q].out_off;
             order.resize(n);
-            for (uint32_t i = 0; i < n; i++) order[i] = i;
-            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return hh[base + x] < hh[base + y]; });
+            for (uint32_t i = 0; i < n; i++) order[i] = ((uint64_t)hh[base + i] << 32) | i;
             out->n_values[q] = n;
             const uint32_t m = std::min(n, out->cap);
+            if (m < n) std::nth_element(order.begin(), order.begin() + m, order.end());
+            std::sort(order.begin(), order.begin() + m);
             for (uint32_t i = 0; i < m; i++) {
                 const size_t o = (size_t)q * out->cap + i;
-                out->hash[o] = hh[base + order[i]]; out->count[o] = hc[base + order[i]]; out->doc_id[o] = hd[base + order[i]]; out->array_pos[o] = hp[base + order[i]];
+                const uint32_t at = (uint32_t)order[i];
+                out->hash[o] = hh[base + at]; out->count[o] = hc[base + at]; out->doc_id[o] = hd[base + at]; out->array_pos[o] = hp[base + at];
             }
         }
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_facet_count_batch: host allocation failed"); }

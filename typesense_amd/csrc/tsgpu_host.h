@@ -509,6 +509,7 @@ struct tsgpu_ctx {
     std::atomic<int> kw_callers{0}, vec_callers{0}, gb_callers{0};  // threads currently inside the search entry points
     uint32_t ticks_per_us = 100;                     // device wall clock (hipDeviceAttributeWallClockRate)
     bool hybrid_overlap = true;                      // tsgpu_hybrid_search_batch: keyword pass and vector pass at the same time (option "hybrid_overlap")
+    uint32_t facet_ids_per_block = 0;      // 0 = chosen per batch (tsgpu_facet_count_batch)
     uint32_t vec_batch_post_window_us = 300;         // vector rounds: after the executor is free the leader waits this long for the callers of the round that just
                                                      // finished to come back (a round's cost hardly grows with its size: tsgpu_batcher.h)
     uint32_t batch_window_us = 10;                   // micro-batcher: how long a round's leader waits for more callers
