@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import typesense_amd as T
 from typesense_amd import _lib as B
 n = 10_000_000
@@ -8,7 +8,11 @@ g.set_num_docs(n)
 pts = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) % np.uint64(1000)).astype(np.int64)
 g.column_set(0, pts)
 g.field_create(0, False); g.commit()
-for name, col in (("one group", np.full(n, 12345, np.uint64)), ("two groups 99/1", np.where(np.arange(n) % 100 == 0, 7, 12345).astype(np.uint64)), ("1000 groups", (np.arange(n, dtype=np.uint64) % np.uint64(1000)) + np.uint64(5))):
+for name, col in (("one group", np.full(n, 12345, np.uint64)), ("two groups 99/1", np.where(np.arange(n) % 100 == 0, 7, 12345).astype(np.uint64)), ("1000 groups", (np.arange(n, dtype=np.uint64) % np.uint64(1000)) + np.uint64(5)),
+                  ("10 groups", (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) % np.uint64(10)) + np.uint64(5)), ("30 groups", (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) % np.uint64(30)) + np.uint64(5)),
+                  ("100 groups", (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) % np.uint64(100)) + np.uint64(5))):
+    if len(sys.argv) > 1 and sys.argv[1] not in name:
+        continue
     g.column_set(1, col.view(np.int64))
     q = T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=250)
     for fp in (1, 0):

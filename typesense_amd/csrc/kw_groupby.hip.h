@@ -44,6 +44,7 @@
 // (inside namespace tsgpu)
 
 static const int GB_THREADS = 256;
+constexpr uint32_t GB_WG_SLOTS_LOG2 = 9, GB_WG_SLOTS = 1u << GB_WG_SLOTS_LOG2;      // a workgroup's LDS table over its GB_THREADS items (insert / scatter): twice as many slots, never full
 static const unsigned long long GB_EMPTY = ~0ull;     // empty table slot; a distinct key that IS ~0 owns the extra slot tab_mask + 1
 static const uint32_t GB_NONE = 0xFFFFFFFFu;
 static const uint32_t GB_LOGLOG_M = 16384;            // LogLogBeta::M (PRECISION 14)
@@ -60,8 +61,9 @@ struct GbQuery {
     uint32_t group_limit;
     uint32_t column;          // the distinct-key column
     uint32_t first_block;     // the query's first workgroup in the per-item launches (ceil(n_items / GB_THREADS) workgroups each: no workgroup spans two queries)
+    uint32_t first_sblock;    // ... and in the member scatter (ceil(n_items / GB_SCATTER_ITEMS) workgroups each)
     uint8_t first_pass, group_missing_values, wildcard, run;   // run = 0: the query failed upstream, nothing is produced
-    uint8_t iota, dedupe, pad[2];   // iota: q = * over the whole collection, the matched ids are 0 .. n_items - 1 (gb_iota_kernel writes them); dedupe: a SECOND pass over several
+    uint8_t iota, dedupe, pad[6];   // iota: q = * over the whole collection, the matched ids are 0 .. n_items - 1 (gb_iota_kernel writes them); dedupe: a SECOND pass over several
                               // candidate combinations — a document met by several of them counts once, with its greatest KV (the later combination on ties)
     uint32_t pw_begin, pw_cap;      // second pass: the query's chunk work list (entries [pw_begin, pw_begin + pw_cap): n_items / GB_CHUNK + n_items / GB_BIG + 1 at most)
     uint64_t pbuf_off;              // ... and its partial top-L buffer (pw_cap x group_limit entries)
@@ -227,18 +229,39 @@ __global__ __launch_bounds__(GB_THREADS) void gb_insert_kernel(GbArgs a) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t me = (uint32_t)(i - g.item_begin);
     // Skewed groups (a field with a handful of values over millions of matches): thousands of threads would hammer ONE slot's counter and best-record word
-    // (measured: one group of 10M documents 117 ms in this kernel). Lanes of a wave that share a slot update it ONCE: the count
-    // by their number, the best record by their greatest (a wave-wide reduction of the Topster's comparison).
-    // Up to three rounds: each takes the slot of the first lane not yet assigned; when at least 4 lanes share it they update it together.
-    bool first = false, pending = active, solo = false;
-    for (int round = 0; round < 3; round++) {
+    // (measured: one group of 10M documents 117 ms in this kernel; same-address atomics retire at ~40 M/s). Two levels of combining in front of the table:
+    //   * lanes of a wave that share a slot update it ONCE — the count by their number, the best record by their greatest (a wave-wide reduction of the
+    //     Topster's comparison); slot after slot while the groups hold three lanes or more (at most 16), the rest one by one;
+    //   * those updates go to a workgroup table in LDS (GB_WG_SLOTS = 2 x the workgroup's items: it cannot fill up), and every slot the workgroup met
+    //     is updated in HBM once at the end (10 groups over 10M ids: 10.3 -> see profiles/r05/exp_groupby.txt).
+    __shared__ uint32_t s_slot[GB_WG_SLOTS], s_cnt[GB_WG_SLOTS], s_best[GB_WG_SLOTS];
+    for (uint32_t t = threadIdx.x; t < GB_WG_SLOTS; t += GB_THREADS) { s_slot[t] = GB_NONE; s_cnt[t] = 0; s_best[t] = GB_NONE; }
+    __syncthreads();
+    auto wg_put = [&](uint32_t sl, uint32_t times, uint32_t rec) {           // rec: LOCAL item index of the greatest of the `times` records
+        uint32_t h = (sl * 2654435761u) >> (32 - GB_WG_SLOTS_LOG2);
+        for (;;) {
+            uint32_t cur = s_slot[h];
+            if (cur == GB_NONE) { cur = atomicCAS(&s_slot[h], GB_NONE, sl); if (cur == GB_NONE) cur = sl; }
+            if (cur == sl) break;
+            h = (h + 1) & (GB_WG_SLOTS - 1);
+        }
+        atomicAdd(&s_cnt[h], times);
+        uint32_t cur = atomicCAS(&s_best[h], GB_NONE, rec);
+        while (cur != GB_NONE && gb_rec_greater(a, g.item_begin + rec, g.item_begin + cur)) {
+            const uint32_t prev = atomicCAS(&s_best[h], cur, rec);
+            if (prev == cur) break;
+            cur = prev;
+        }
+    };
+    bool pending = active;
+    for (int round = 0; round < 16; round++) {
         const unsigned long long rem = __ballot(pending ? 1 : 0);
         if (!rem) break;                                                     // (wave-uniform)
         const uint32_t leader = (uint32_t)__ffsll((long long)rem) - 1;
         const uint32_t lslot = __shfl(slot, (int)leader, 64);
         const bool mine = pending && slot == lslot;
         const unsigned long long same = __ballot(mine ? 1 : 0);
-        if (__popcll(same) < 4) { if (mine) { solo = true; pending = false; } continue; }      // (wave-uniform) too few: on their own below
+        if (__popcll(same) < 3) break;                                       // (wave-uniform) the first waiting lane is nearly alone in its group: many groups, one by one below
         int64_t v0 = 0, v1 = 0, v2 = 0, vk = -1; uint32_t vp = 0, vi = 0;      // this lane's candidate (vk < 0: none)
         if (mine) { v0 = a.s0[i]; v1 = a.s1[i]; v2 = a.s2[i]; vk = (int64_t)a.ids[i]; vp = a.pass[i]; vi = me; }
         for (int d = 32; d > 0; d >>= 1) {
@@ -247,37 +270,34 @@ __global__ __launch_bounds__(GB_THREADS) void gb_insert_kernel(GbArgs a) {
             const bool og = ent_greater(o0, o1, o2, ok, v0, v1, v2, vk) || (ok >= 0 && ok == vk && o0 == v0 && o1 == v1 && o2 == v2 && op > vp);
             if (og) { v0 = o0; v1 = o1; v2 = o2; vk = ok; vp = op; vi = oi; }
         }
-        if (lane == leader) {
-            first = atomicAdd(&a.hcount[g.tab_off + slot], (uint32_t)__popcll(same)) == 0;
-            uint32_t* bp = a.hbest + g.tab_off + slot;
-            uint32_t cur = atomicCAS(bp, GB_NONE, vi);
-            while (cur != GB_NONE && gb_rec_greater(a, g.item_begin + vi, g.item_begin + cur)) {
-                const uint32_t prev = atomicCAS(bp, cur, vi);
+        if (lane == leader) wg_put(slot, (uint32_t)__popcll(same), vi);
+        if (mine) pending = false;
+    }
+    if (pending) wg_put(slot, 1u, me);
+    __syncthreads();
+    // every slot this workgroup met: its count and its greatest record into the query's table (hbest holds a LOCAL item index; whoever holds a greater
+    // record replaces it); the group's first members list its slot — one counter update per wave (every lane of a workgroup serves the same query)
+    for (uint32_t t = threadIdx.x; t < GB_WG_SLOTS; t += GB_THREADS) {       // (workgroup-uniform trip count)
+        const uint32_t sl = s_slot[t];
+        bool first = false;
+        if (sl != GB_NONE) {
+            const uint32_t rec = s_best[t];
+            first = atomicAdd(&a.hcount[g.tab_off + sl], s_cnt[t]) == 0;
+            uint32_t* bp = a.hbest + g.tab_off + sl;
+            uint32_t cur = atomicCAS(bp, GB_NONE, rec);
+            while (cur != GB_NONE && gb_rec_greater(a, g.item_begin + rec, g.item_begin + cur)) {
+                const uint32_t prev = atomicCAS(bp, cur, rec);
                 if (prev == cur) break;
                 cur = prev;
             }
         }
-        if (mine) pending = false;
-    }
-    if (pending) solo = true;                                                // (not reached in three rounds)
-    if (solo) {
-        first = atomicAdd(&a.hcount[g.tab_off + slot], 1u) == 0;
-        // the group's greatest record: hbest holds a LOCAL item index; whoever holds a greater record replaces it
-        uint32_t* bp = a.hbest + g.tab_off + slot;
-        uint32_t cur = atomicCAS(bp, GB_NONE, me);
-        while (cur != GB_NONE && gb_rec_greater(a, i, g.item_begin + cur)) {
-            const uint32_t prev = atomicCAS(bp, cur, me);
-            if (prev == cur) break;
-            cur = prev;
+        const unsigned long long fm = __ballot(first ? 1 : 0);
+        if (fm) {
+            uint32_t base_at = 0;
+            if (lane == (uint32_t)__ffsll((long long)fm) - 1) base_at = atomicAdd(&a.gcount[qi], (uint32_t)__popcll(fm));
+            base_at = __shfl(base_at, __ffsll((long long)fm) - 1, 64);
+            if (first) a.glist[g.item_begin + base_at + (uint32_t)__popcll(fm & ((1ull << lane) - 1))] = sl;
         }
-    }
-    // the group's first member lists its slot; one counter update per wave (every lane of a workgroup serves the same query)
-    const unsigned long long fm = __ballot(first ? 1 : 0);
-    if (fm) {
-        uint32_t base_at = 0;
-        if (lane == (uint32_t)__ffsll((long long)fm) - 1) base_at = atomicAdd(&a.gcount[qi], (uint32_t)__popcll(fm));
-        base_at = __shfl(base_at, __ffsll((long long)fm) - 1, 64);
-        if (first) a.glist[g.item_begin + base_at + (uint32_t)__popcll(fm & ((1ull << lane) - 1))] = slot;
     }
 }
 
@@ -454,37 +474,65 @@ __global__ __launch_bounds__(GB_THREADS) void gb_select_kernel(GbArgs a) {
 }
 
 // ---- second pass: members of the selected groups ----
+// Second pass: every record of a selected group takes its place in the group's member list (local item indices; any order — the member kernels rank them).
+// One workgroup per GB_SCATTER_ITEMS consecutive items of ONE query (first_sblock). A group of millions of members would mean millions of adds on its
+// cursor, and the cursors of a query share a few cache lines whose atomics retire one after the other (measured: 100 groups over 10M ids 5.8 ms in this
+// kernel with one add per 256-item workgroup and group): lanes of a wave that share a group reserve together (group after group while they hold three
+// lanes or more) in an LDS counter per group rank, the workgroup reserves each of its groups' ranges in HBM ONCE, and every item writes itself at
+// range + its place inside the workgroup.
+constexpr uint32_t GB_SCATTER_ROUNDS = 8, GB_SCATTER_ITEMS = GB_SCATTER_ROUNDS * GB_THREADS;
+constexpr uint32_t GB_RANKS = 1024;                             // group ranks of a query (TSGPU_MAX_TOPK)
 __global__ __launch_bounds__(GB_THREADS) void gb_scatter_kernel(GbArgs a) {
-    uint32_t qi; uint64_t i;
-    const bool in_range = gb_item_of(a, qi, i);                               // (nobody leaves: the wave-wide step below needs every lane)
+    __shared__ uint32_t s_q;
+    __shared__ uint32_t s_cnt[GB_RANKS], s_base[GB_RANKS];
+    if (threadIdx.x == 0) {
+        uint32_t lo = 0, hi = a.n_queries;                      // the last query whose first_sblock <= blockIdx.x (queries without items share their successor's)
+        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (a.gq[mid].first_sblock <= blockIdx.x) lo = mid; else hi = mid; }
+        s_q = lo;
+    }
+    __syncthreads();
+    const uint32_t qi = s_q;
     const GbQuery g = a.gq[qi];
-    uint32_t r = GB_NONE;
-    if (in_range && !g.first_pass) {
-        const uint32_t rs = a.rslot[i];                                      // (GB_NONE with dedupe: not its document's record)
-        if (rs != GB_NONE) r = a.hrank[g.tab_off + rs];
-    }
-    // members of one selected group in one wave take their places in its list with ONE cursor update (a group of 10M members: 100 ms of same-address atomics otherwise)
+    if (g.first_pass || !g.run) return;                                       // (workgroup-uniform)
+    const uint32_t ng = a.n_groups[qi] < GB_RANKS ? a.n_groups[qi] : GB_RANKS;
+    for (uint32_t t = threadIdx.x; t < ng; t += GB_THREADS) s_cnt[t] = 0;
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
-    bool pending = r != GB_NONE;
-    for (int round = 0; round < 3; round++) {
-        const unsigned long long rem = __ballot(pending ? 1 : 0);
-        if (!rem) break;                                                     // (wave-uniform)
-        const uint32_t leader = (uint32_t)__ffsll((long long)rem) - 1;
-        const uint32_t lr = __shfl(r, (int)leader, 64);
-        const bool mine = pending && r == lr;
-        const unsigned long long same = __ballot(mine ? 1 : 0);
-        uint32_t base_at = 0;
-        if (lane == leader) base_at = atomicAdd(&a.g_mcur[(size_t)qi * a.g_stride + lr], (uint32_t)__popcll(same));
-        base_at = __shfl(base_at, (int)leader, 64);
-        if (mine) {
-            a.members[g.item_begin + a.g_mofs[(size_t)qi * a.g_stride + r] + base_at + (uint32_t)__popcll(same & ((1ull << lane) - 1))] = (uint32_t)(i - g.item_begin);
-            pending = false;
+    const uint32_t local0 = (blockIdx.x - g.first_sblock) * GB_SCATTER_ITEMS + threadIdx.x;
+    uint32_t rk[GB_SCATTER_ROUNDS], off[GB_SCATTER_ROUNDS];
+#pragma unroll
+    for (uint32_t k = 0; k < GB_SCATTER_ROUNDS; k++) {
+        const uint32_t local = local0 + k * GB_THREADS;
+        uint32_t r = GB_NONE;
+        if (local < g.n_items) {
+            const uint32_t rs = a.rslot[g.item_begin + local];               // (GB_NONE with dedupe: not its document's record)
+            if (rs != GB_NONE) r = a.hrank[g.tab_off + rs];                  // (GB_NONE: not a selected group)
         }
+        uint32_t at = 0;
+        bool pending = r != GB_NONE;
+        for (int round = 0; round < 16; round++) {
+            const unsigned long long rem = __ballot(pending ? 1 : 0);
+            if (!rem) break;                                                 // (wave-uniform)
+            const uint32_t leader = (uint32_t)__ffsll((long long)rem) - 1;
+            const uint32_t lr = __shfl(r, (int)leader, 64);
+            const bool mine = pending && r == lr;
+            const unsigned long long same = __ballot(mine ? 1 : 0);
+            if (__popcll(same) < 3) break;                                   // (wave-uniform) many groups: one by one below
+            uint32_t first = 0;
+            if (lane == leader) first = atomicAdd(&s_cnt[lr], (uint32_t)__popcll(same));
+            first = __shfl(first, (int)leader, 64);
+            if (mine) { at = first + (uint32_t)__popcll(same & ((1ull << lane) - 1)); pending = false; }
+        }
+        if (pending) at = atomicAdd(&s_cnt[r], 1u);
+        rk[k] = r; off[k] = at;
     }
-    if (pending) {                                                           // (more than three groups in one wave: the rest one by one)
-        const size_t gi = (size_t)qi * a.g_stride + r;
-        a.members[g.item_begin + a.g_mofs[gi] + atomicAdd(&a.g_mcur[gi], 1u)] = (uint32_t)(i - g.item_begin);
-    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < ng; t += GB_THREADS)
+        if (s_cnt[t]) s_base[t] = atomicAdd(&a.g_mcur[(size_t)qi * a.g_stride + t], s_cnt[t]);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < GB_SCATTER_ROUNDS; k++)
+        if (rk[k] != GB_NONE) a.members[g.item_begin + a.g_mofs[(size_t)qi * a.g_stride + rk[k]] + s_base[rk[k]] + off[k]] = local0 + k * GB_THREADS;
 }
 
 // one wave per (query, selected group): the group Topster's content in sort() order = its min(group_limit, members) greatest records, descending.

@@ -253,7 +253,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
         }
         const uint64_t t_ids = now_us();
         // ---- layout ----
-        uint64_t n_items = 0, n_slots = 0, n_blocks = 0;
+        uint64_t n_items = 0, n_slots = 0, n_blocks = 0, n_sblocks = 0;
         std::vector<unsigned long long> combo_begin((size_t)n_combos + 1, 0);
         std::vector<uint32_t> qidx_of_combo(std::max<uint32_t>(n_combos, 1), 0);
         for (uint32_t i = 0; i < n_queries; i++) {
@@ -278,6 +278,8 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
             g.tab_mask = (uint32_t)(size - 1);
             g.first_block = n_blocks;
             n_blocks += (n + GB_THREADS - 1) / GB_THREADS;
+            g.first_sblock = (uint32_t)n_sblocks;
+            n_sblocks += (n + GB_SCATTER_ITEMS - 1) / GB_SCATTER_ITEMS;
             n_items += n;
             n_slots += size + 1;                          // + the slot of the key ~0
         }
@@ -390,7 +392,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
         else if (max_k + GB_THREADS <= 1024) hipLaunchKernelGGL((gb_select_kernel<1024>), dim3(n_queries), dim3(GB_THREADS), 0, s, a);
         else hipLaunchKernelGGL((gb_select_kernel<2048>), dim3(n_queries), dim3(GB_THREADS), 0, s, a);
         if (any_second && n_items) {
-            hipLaunchKernelGGL(gb_scatter_kernel, dim3((uint32_t)n_blocks), dim3(GB_THREADS), 0, s, a);
+            hipLaunchKernelGGL(gb_scatter_kernel, dim3((uint32_t)n_sblocks), dim3(GB_THREADS), 0, s, a);
             const uint64_t pairs = (uint64_t)n_queries * gs;
             hipLaunchKernelGGL(gb_members_kernel, dim3((uint32_t)((pairs + GB_THREADS / 64 - 1) / (GB_THREADS / 64))), dim3(GB_THREADS), 0, s, a);
             if (n_pw) hipLaunchKernelGGL(gb_chunk_kernel, dim3((uint32_t)n_pw), dim3(GB_THREADS), 0, s, a);      // (workgroups beyond a query's chunk count leave at once)
