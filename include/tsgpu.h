@@ -407,6 +407,26 @@ int tsgpu_facet_set(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint64_t* doc
 int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
                             uint32_t sample_mod, const uint32_t* allowed_hashes, uint32_t n_allowed, tsgpu_facet_counts* out);
 
+/* facets of a GROUPED search (group_limit != 0, src/index.cpp:1747-1749, 1756-1758): instead of counting documents the walk records
+ * hash_groups[value].emplace(distinct_id) and a value's count becomes the number of groups it was seen in (:4455-4458; hash_groups holds
+ * uint32_t: the distinct id is truncated, include/field.h:791). group_column = the distinct-id column of tsgpu_keyword_search_grouped_batch
+ * (get_distinct_id per document; beyond its length: 1 with group_missing_values, else the seq_id). Everything else as tsgpu_facet_count_batch. */
+int tsgpu_facet_count_grouped_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
+                                    uint32_t sample_mod, const uint32_t* allowed_hashes, uint32_t n_allowed, uint32_t group_column, int group_missing_values,
+                                    tsgpu_facet_counts* out);
+
+/* range facets (a_facet.is_range_query in the same walk, src/index.cpp:1738-1750): per result document the facet hash index holds, once per
+ * DISTINCT hash of the document, the field's sort-index value (value_column: dense int64, INT64_MAX where the sort index has no entry —
+ * get_doc_val_from_sort_index, :1470-1482; float fields hold Index::float_to_int64_t keys like the sort index) is looked up in facet_range_map
+ * (facet::get_range, include/field.h:820-838): range r = [range_lower[r], range_upper[r]) with range_upper strictly ascending (the map's key);
+ * the first range whose upper bound is greater than the value is taken if the value reaches its lower bound. counts[q * n_ranges + r] =
+ * result_map[range_upper[r]].count; 0 = the range is not in result_map. group_column != TSGPU_NO_COLUMN: the grouped form (count = number of
+ * groups, sets keyed by the range id's low 32 bits like hash_groups). */
+#define TSGPU_NO_COLUMN 0xFFFFFFFFu
+int tsgpu_facet_range_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, uint32_t value_column, const int64_t* range_upper, const int64_t* range_lower, uint32_t n_ranges,
+                                  const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries, uint32_t sample_mod,
+                                  uint32_t group_column, int group_missing_values, uint32_t* counts);
+
 /* numeric facet stats of the same walk (should_compute_stats, src/index.cpp:1730-1741 -> compute_facet_stats :1430-1460): every
  * (document, distinct hash) contributes its VALUE — the hash itself for int32 fields, its bits as a float for float fields, the
  * fhash_int64_map entry (sorted int64_map_hashes -> int64_map_values; a missing hash = INT64_MAX) for int64 fields. min / max / count

@@ -1,6 +1,6 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/for_codec.h header).
 // Restates the hash-index branch of Index::do_facets, /root/reference/src/index.cpp:1659-1771 ("Using hashing to find facets"),
-// for the plain case the GPU path covers (no group_by, no range facet, no stats): result ids are walked in ascending order; a
+// (plain counts: count(); the group_by and range-facet forms of the same walk: count_ex()): result ids are walked in ascending order; a
 // document absent from the facet hash index is skipped (:1696-1698) and the walk stops once the index is exhausted (:1692-1694);
 // per document every DISTINCT hash (unique_facet_hashes, :1719-1728) bumps result_map[hash].count and records doc_id / array_pos
 // (:1744-1752); estimate_facets skips ids whose position is not a multiple of facet_sample_mod_value (:1683-1687); with a facet
@@ -77,6 +77,57 @@ struct FacetHashIndex {
                 fc.count += 1;
             }
         }
+        return result_map;
+    }
+
+    // The same walk with the two forms count() leaves out (src/index.cpp:1738-1760):
+    //  * range facets (a_facet.is_range_query): per DISTINCT hash of the document (the branch sits inside the hash loop) doc_val =
+    //    get_doc_val_from_sort_index (:1470-1482, INT64_MAX when the sort index has no entry) goes through facet::get_range
+    //    (include/field.h:820-838 over facet_range_map: upper bound -> {label, lower_range}; range_specs_t::is_in_range :776-778) and
+    //    result_map[range_id].count += 1 (doc_id / array_pos untouched);
+    //  * group_limit != 0: hash_groups[key].emplace(distinct_id) — spp::sparse_hash_map<uint32_t, sparse_hash_set<uint32_t>> (:791), both truncated —
+    //    plain values do NOT count documents then (:1756-1760), ranges do; afterwards every result_map entry's count = hash_groups[key].size()
+    //    (:4455-4458).
+    // doc_val / distinct_id: the per-document values the caller read from the sort index / get_distinct_id.
+    template <class DocVal, class DistinctId>
+    std::map<uint64_t, facet_count_t> count_ex(const uint32_t* result_ids, size_t results_size, size_t facet_sample_mod_value, const std::set<uint32_t>* fquery_hashes,
+                                                const std::map<int64_t, int64_t>* facet_range_map, DocVal doc_val, bool group_limit, DistinctId distinct_id_of) const {
+        std::map<uint64_t, facet_count_t> result_map;
+        std::map<uint32_t, std::set<uint32_t>> hash_groups;
+        for (size_t i = 0; i < results_size; i++) {
+            if (facet_sample_mod_value > 1 && i % facet_sample_mod_value != 0) continue;
+            const uint32_t doc_seq_id = result_ids[i];
+            auto it = docs.lower_bound(doc_seq_id);
+            if (it == docs.end()) break;
+            if (it->first != doc_seq_id) continue;
+            const std::vector<uint32_t>& facet_hashes = it->second;
+            const uint64_t distinct_id = group_limit ? distinct_id_of(doc_seq_id) : 0;
+            std::set<uint32_t> unique_facet_hashes;
+            for (size_t j = 0; j < facet_hashes.size(); j++) {
+                const uint32_t fhash = facet_hashes[j];
+                if (facet_hashes.size() > 1) {
+                    if (unique_facet_hashes.count(fhash) != 0) continue;
+                    unique_facet_hashes.insert(fhash);
+                }
+                if (facet_range_map) {
+                    const int64_t key = doc_val(doc_seq_id);
+                    auto rit = facet_range_map->lower_bound(key);                              // facet::get_range
+                    if (rit != facet_range_map->end() && rit->first == key) rit++;
+                    if (rit != facet_range_map->end() && key >= rit->second) {
+                        const int64_t range_id = rit->first;
+                        result_map[(uint64_t)range_id].count += 1;
+                        if (group_limit) hash_groups[(uint32_t)range_id].emplace((uint32_t)distinct_id);
+                    }
+                } else if (!fquery_hashes || fquery_hashes->find(fhash) != fquery_hashes->end()) {
+                    facet_count_t& fc = result_map[fhash];
+                    fc.doc_id = doc_seq_id;
+                    fc.array_pos = (uint32_t)j;
+                    if (group_limit) hash_groups[fhash].emplace((uint32_t)distinct_id);
+                    else fc.count += 1;
+                }
+            }
+        }
+        if (group_limit) for (auto& kv : result_map) kv.second.count = (uint32_t)hash_groups[(uint32_t)kv.first].size();
         return result_map;
     }
 };

@@ -520,6 +520,27 @@ uint32_t orc_facet_count(void* h, uint32_t field, const uint32_t* ids, uint64_t 
     return i;
 }
 
+// the grouped / range forms of the walk (FacetHashIndex::count_ex). n_ranges != 0: keys are the ranges' upper bounds; doc_vals = the sort index as a dense column
+// (beyond n_doc_vals: INT64_MAX). distinct_ids != null: group_limit != 0, the per-document distinct id (beyond n_distinct: 1 with group_missing_values, else seq_id).
+uint32_t orc_facet_count_ex(void* h, uint32_t field, const uint32_t* ids, uint64_t n_ids, uint32_t sample_mod, const uint32_t* allowed, uint32_t n_allowed,
+                            const int64_t* range_upper, const int64_t* range_lower, uint32_t n_ranges, const int64_t* doc_vals, uint64_t n_doc_vals,
+                            const uint64_t* distinct_ids, uint64_t n_distinct, int32_t group_missing_values,
+                            uint64_t* out_key, uint32_t* out_count, uint32_t* out_doc, uint32_t* out_pos, uint32_t cap) {
+    const oracle::FacetHashIndex& f = facets_of()[{h, field}];
+    std::set<uint32_t> fq(allowed, allowed + n_allowed);
+    std::map<int64_t, int64_t> ranges;
+    for (uint32_t r = 0; r < n_ranges; r++) ranges[range_upper[r]] = range_lower[r];
+    const auto m = f.count_ex(ids, n_ids, sample_mod, allowed ? &fq : nullptr, n_ranges ? &ranges : nullptr,
+                              [&](uint32_t d) -> int64_t { return d < n_doc_vals ? doc_vals[d] : INT64_MAX; }, distinct_ids != nullptr,
+                              [&](uint32_t d) -> uint64_t { return d < n_distinct ? distinct_ids[d] : (group_missing_values ? 1ull : (uint64_t)d); });
+    uint32_t i = 0;
+    for (const auto& kv : m) {
+        if (i < cap) { out_key[i] = kv.first; out_count[i] = kv.second.count; out_doc[i] = kv.second.doc_id; out_pos[i] = kv.second.array_pos; }
+        i++;
+    }
+    return i;
+}
+
 // stats of the hash-index walk; out = {fvmin, fvmax, fvsum, fvcount}
 void orc_facet_stats(void* h, uint32_t field, const uint32_t* ids, uint64_t n_ids, uint32_t sample_mod, int32_t value_type, const uint32_t* map_hash, const int64_t* map_val,
                      uint32_t n_map, double* out) {

@@ -490,6 +490,27 @@ class OracleIndex:
         m = min(n, cap)
         return h[:m].copy(), c[:m].copy(), d[:m].copy(), p[:m].copy(), n
 
+    def facet_count_ex(self, field, ids, sample_mod=1, allowed_hashes=None, ranges=None, doc_vals=None, distinct_ids=None, group_missing_values=False, cap=65536):
+        """the grouped (distinct_ids = the per-document distinct id column) and range (ranges = [(upper, lower), ...], doc_vals = the sort index as a dense
+        column) forms of the walk -> (keys uint64 ascending, count, doc_id, array_pos, n)"""
+        ids = _u32(ids)
+        a = _u32(allowed_hashes) if allowed_hashes is not None else None
+        up = np.ascontiguousarray([r[0] for r in ranges], dtype=np.int64) if ranges else None
+        lo = np.ascontiguousarray([r[1] for r in ranges], dtype=np.int64) if ranges else None
+        dv = np.ascontiguousarray(doc_vals, dtype=np.int64) if doc_vals is not None else None
+        di = np.ascontiguousarray(distinct_ids, dtype=np.uint64) if distinct_ids is not None else None
+        k = np.zeros(cap, np.uint64)
+        c, d, p = (np.zeros(cap, np.uint32) for _ in range(3))
+        fn = self.L.orc_facet_count_ex
+        fn.restype = C.c_uint32
+        fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
+                       C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        vp = lambda x: x.ctypes.data_as(C.c_void_p) if x is not None else None
+        n = fn(self.h, field, vp(ids), ids.size, sample_mod, vp(a), a.size if a is not None else 0, vp(up), vp(lo), len(ranges) if ranges else 0, vp(dv),
+               dv.size if dv is not None else 0, vp(di), di.size if di is not None else 0, int(group_missing_values), vp(k), vp(c), vp(d), vp(p), cap)
+        m = min(n, cap)
+        return k[:m].copy(), c[:m].copy(), d[:m].copy(), p[:m].copy(), n
+
     def facet_stats(self, field, ids, value_type, sample_mod=1, int64_map=None):
         ids = _u32(ids)
         mh = _u32(int64_map[0]) if int64_map is not None else None

@@ -1,0 +1,34 @@
+"""Generates tests/golden/facet_group_range.json from the REFERENCE's own fixtures + assertions (run in the build container):
+ * grouped facet counts: documents = /root/reference/test/group_documents.jsonl, expected = CollectionGroupingTest.GroupingBasics
+   (/root/reference/test/collection_grouping_test.cpp:71-110): q = *, facet `brand`, group_by `size` -> Beta 3, Omega 3, Xorp 2, Zeta 1
+   (= the number of distinct sizes per brand; the plain document counts would be 3, 4, 2, 1);
+ * range facets: CollectionFacetingTest.RangeFacetTest (/root/reference/test/collection_faceting_test.cpp:1500-1590: `visitors` with
+   Busy:[0, 200000], VeryBusy:[200000, 500000]; "Karnataka" = documents 0, 1 -> Busy 1, VeryBusy 1; "Gujarat" = document 4 -> VeryBusy 1)
+   and CollectionFacetingTest.RangeFacetTestWithGroupBy (:3419-3524: "Karnataka" -> VeryBusy 2; q = * grouped by `rating` -> VeryBusy 2, Busy 1).
+Value hashes = crc32 of the value's string (any injective map works); the documents of the two range tests are inline in the tests."""
+import json
+import os
+import zlib
+
+h = lambda v: zlib.crc32(str(v).encode()) & 0xFFFFFFFF
+docs = [json.loads(l) for l in open("/root/reference/test/group_documents.jsonl") if l.strip()]
+out = {"source": "test/group_documents.jsonl + test/collection_grouping_test.cpp:71-110; test/collection_faceting_test.cpp:1500-1590, 3419-3524",
+       "grouping_basics": {
+           "brand_hashes": [[h(d["brand"])] if "brand" in d else [] for d in docs],
+           "brand_values": {b: h(b) for b in sorted({d["brand"] for d in docs if "brand" in d})},
+           "size_hashes": [[h(d["size"])] for d in docs],                # the group_by field's facet hashes: distinct id = hash_combine(1, hash)
+           "result_ids": list(range(len(docs))),
+           "expected_grouped": {"Beta": 3, "Omega": 3, "Xorp": 2, "Zeta": 1}},
+       "range_facet_test": {
+           "visitors": [235486, 187654, 174684, 246676, 345878],
+           "ranges": [[200000, 0], [500000, 200000]],                     # (upper, lower): Busy, VeryBusy
+           "karnataka_ids": [0, 1], "karnataka_expected": [1, 1],
+           "gujarat_ids": [4], "gujarat_expected": [0, 1]},
+       "range_facet_with_group_by": {
+           "visitors": [235486, 201022, 174684, 246676, 345878],
+           "rating_hashes": [[h(4.5)], [h(4.5)], [h(3.8)], [h(4.5)], [h(3.8)]],
+           "ranges": [[200000, 0], [500000, 200000]],
+           "karnataka_ids": [0, 1], "karnataka_expected": [0, 2],
+           "all_ids": [0, 1, 2, 3, 4], "all_grouped_expected": [1, 2]}}
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "facet_group_range.json"), "w"), indent=1)
+print(len(docs), "documents")

@@ -56,6 +56,89 @@ def test_oracle_reproduces_reference_facet_stats_and_value_index_counts():
     assert [[fx["tags_values"][int(a)], int(b)] for a, b in zip(v, c)] == fx["tags_expected"]
 
 
+def test_oracle_reproduces_reference_grouped_and_range_facet_counts():
+    """the reference's own numbers: facet counts of a grouped search (collection_grouping_test.cpp:71-110) and range facets, plain and
+    grouped (collection_faceting_test.cpp:1500-1590, 3419-3524)"""
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "facet_group_range.json")))
+    g = fx["grouping_basics"]
+    orc = O.OracleIndex(1, 1)
+    orc.facet_set(0, *_csr(g["brand_hashes"]))
+    distinct = O.distinct_ids(len(g["size_hashes"]), [_csr(g["size_hashes"])], False)[0]
+    k, c, d, p, n = orc.facet_count_ex(0, np.array(g["result_ids"], np.uint32), distinct_ids=distinct)
+    got = {int(a): int(b) for a, b in zip(k, c)}
+    assert {v: got[hh] for v, hh in g["brand_values"].items()} == g["expected_grouped"]
+    for name in ("range_facet_test", "range_facet_with_group_by"):
+        r = fx[name]
+        hashes = [[7 + v % 5] for v in r["visitors"]]                                   # (the facet hash index of `visitors`: one hash per document)
+        orc.facet_set(1, *_csr(hashes))
+        ranges = [tuple(x) for x in r["ranges"]]
+        def counts(ids, **kw):
+            k, c, d, p, n = orc.facet_count_ex(1, np.array(ids, np.uint32), ranges=ranges, doc_vals=np.array(r["visitors"], np.int64), **kw)
+            m = {int(a): int(b) for a, b in zip(k.view(np.int64), c)}
+            return [m.get(up, 0) for up, lo in ranges]
+        assert counts(r["karnataka_ids"]) == r["karnataka_expected"]
+        if "gujarat_ids" in r:
+            assert counts(r["gujarat_ids"]) == r["gujarat_expected"]
+        if "all_ids" in r:
+            distinct = O.distinct_ids(5, [_csr(r["rating_hashes"])], False)[0]
+            assert counts(r["all_ids"], distinct_ids=distinct) == r["all_grouped_expected"]
+
+
+def _grouped_and_ranges(lib, n_docs, n_values, seed=5):
+    """the grouped and the range forms of the walk, product vs oracle: array and scalar fields, sampling, facet query, missing sort-index entries,
+    few and many groups, distinct ids that differ only above bit 32, range ids that agree in their low 32 bits"""
+    rng = np.random.default_rng(seed)
+    g = T.GpuIndex(0, lib)
+    orc = O.OracleIndex(1, 1)
+    g.set_num_docs(n_docs)
+    lists = [np.sort(rng.choice(n_docs + 50, size=s, replace=False)).astype(np.uint32) for s in (1, 9, 400, min(n_docs, 6000))] + [np.zeros(0, np.uint32), np.arange(n_docs, dtype=np.uint32)]
+    for array in (True, False):
+        ptr, hashes = _random_facet_index(rng, n_docs, n_values, array=array)
+        g.facet_set(0, ptr, hashes)
+        orc.facet_set(0, ptr, hashes)
+        for n_groups, short in ((7, 0), (n_docs // 3, 40)):
+            distinct = rng.integers(0, n_groups, size=n_docs - short).astype(np.uint64) * np.uint64(0x100000001) + np.uint64(3)   # (the high half repeats the low one: truncation merges nothing it should not)
+            if n_groups == 7:
+                distinct[::2] += np.uint64(1 << 40)                        # equal low halves, different ids: ONE group for hash_groups
+            g.column_set(2, distinct.view(np.int64))
+            for gmv in (False, True):
+                for kw in ({}, {"sample_mod": 3}, {"allowed_hashes": np.unique(hashes)[::2]}):
+                    got = g.facet_count_batch(0, lists, cap=8192, group_column=2, group_missing_values=gmv, **kw)
+                    for q, ids in enumerate(lists):
+                        k, c, d, p, n = orc.facet_count_ex(0, ids, distinct_ids=distinct, group_missing_values=gmv, **kw)
+                        gh, gc, gd, gp, gn = got[q]
+                        assert gn == n and np.array_equal(gh, k.astype(np.uint32)) and np.array_equal(gc, c) and np.array_equal(gd, d) and np.array_equal(gp, p), (array, n_groups, gmv, q)
+            # ranges over a sort-index column that is shorter than the collection (INT64_MAX beyond it), negative values, an open top, a gap, a value on a bound
+            vals = rng.integers(-1000, 5000, size=n_docs - 25).astype(np.int64)
+            vals[::17] = 1000
+            g.column_set(3, vals)
+            big = 1 << 32
+            for ranges in ([(0, -500), (1000, 0), (1001, 1000), (3000, 2000), (np.iinfo(np.int64).max, 4000)],
+                           [(100, -1000), (100 + big, 100), (100 + 2 * big, 4000)],       # range ids equal in their low 32 bits: one set of groups (hash_groups' uint32 key)
+                           [(2500, 2499)]):
+                for kw in ({}, {"sample_mod": 4}):
+                    for grouped in (False, True):
+                        got = g.facet_range_count_batch(0, 3, ranges, lists, group_column=2 if grouped else None, **kw)
+                        for q, ids in enumerate(lists):
+                            k, c, d, p, n = orc.facet_count_ex(0, ids, ranges=ranges, doc_vals=vals, distinct_ids=distinct if grouped else None, **kw)
+                            m = {int(a): int(b) for a, b in zip(k.view(np.int64), c)}
+                            assert [m.get(int(up), 0) for up, lo in ranges] == got[q].tolist(), (array, ranges, kw, grouped, q)
+    with pytest.raises(T.TsgpuError):
+        g.facet_range_count_batch(0, 3, [(5, 0), (5, 1)], lists)                         # upper bounds must ascend strictly
+    with pytest.raises(T.TsgpuError):
+        g.facet_count_batch(0, lists, group_column=77)
+    g.close()
+
+
+def test_grouped_and_range_facets_match_oracle_emulator():
+    _grouped_and_ranges(H.emu_lib_path(), 3000, 60)
+
+
+@pytest.mark.gpu
+def test_grouped_and_range_facets_match_oracle_gpu():
+    _grouped_and_ranges(H.gpu_lib_path(), 300_000, 3000)
+
+
 def _stats_and_values(lib, n_docs, n_values, seed=77):
     """numeric stats of the hash-index walk and the value-index branch, product vs oracle (and vs the reference's fixture)"""
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "facet_stats_values.json")))

@@ -64,6 +64,9 @@ class HybridParamsC(C.Structure):
     _fields_ = [("k", C.c_uint32), ("fetch_size", C.c_uint32), ("alpha", C.c_float), ("distance_threshold", C.c_float), ("rerank_hybrid_matches", C.c_uint32)]
 
 
+NO_COLUMN = 0xFFFFFFFF
+
+
 class FacetCountsC(C.Structure):
     _fields_ = [("cap", C.c_uint32), ("hash", C.c_void_p), ("count", C.c_void_p), ("doc_id", C.c_void_p), ("array_pos", C.c_void_p), ("n_values", C.c_void_p)]
 
@@ -111,7 +114,7 @@ EXPORTS = [
     "tsgpu_abi_version", "tsgpu_create", "tsgpu_destroy", "tsgpu_last_error", "tsgpu_set_stream", "tsgpu_set_option", "tsgpu_get_counter", "tsgpu_device_bytes",
     "tsgpu_field_create", "tsgpu_term_upsert", "tsgpu_posting_upsert", "tsgpu_posting_erase", "tsgpu_terms_load_csr", "tsgpu_column_set", "tsgpu_set_num_docs", "tsgpu_commit",
     "tsgpu_term_num_ids", "tsgpu_term_download", "tsgpu_keyword_search_batch", "tsgpu_wildcard_search_batch", "tsgpu_keyword_search_candidates_batch", "tsgpu_candidates_result_ids", "tsgpu_keep_result_ids", "tsgpu_result_ids",
-    "tsgpu_keyword_search_batch_ids", "tsgpu_keyword_search_grouped_batch", "tsgpu_keyword_search_grouped_candidates_batch", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free", "tsgpu_facet_set", "tsgpu_facet_count_batch", "tsgpu_facet_stats_batch", "tsgpu_facet_value_set", "tsgpu_facet_value_count_batch",
+    "tsgpu_keyword_search_batch_ids", "tsgpu_keyword_search_grouped_batch", "tsgpu_keyword_search_grouped_candidates_batch", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free", "tsgpu_facet_set", "tsgpu_facet_count_batch", "tsgpu_facet_count_grouped_batch", "tsgpu_facet_range_count_batch", "tsgpu_facet_stats_batch", "tsgpu_facet_value_set", "tsgpu_facet_value_count_batch",
     "tsgpu_vec_create", "tsgpu_vec_upsert", "tsgpu_vec_delete", "tsgpu_vec_get", "tsgpu_vec_count", "tsgpu_vec_knn_batch",
     "tsgpu_vec_hnsw_load", "tsgpu_vec_hnsw_enable", "tsgpu_vec_hnsw_export", "tsgpu_vec_hnsw_search_batch", "tsgpu_vec_distances", "tsgpu_ip_distance", "tsgpu_vector_search_batch", "tsgpu_vector_search_batch_ids", "tsgpu_hybrid_search_batch", "tsgpu_hybrid_fuse_batch", "tsgpu_keyword_aux_scores", "tsgpu_merge_shard_hits", "tsgpu_merge_shard_hits_device", "tsgpu_last_timings", "tsgpu_kw_last_touched", "tsgpu_kw_lists_footprint",
     "tsgpu_group_create_local", "tsgpu_group_unique_id", "tsgpu_group_create_rank", "tsgpu_group_create_rank_host", "tsgpu_group_destroy", "tsgpu_group_size", "tsgpu_group_keyword_search_batch",
@@ -181,6 +184,8 @@ def lib(path=None):
     L.tsgpu_id_lists_free.restype = None
     L.tsgpu_facet_set.argtypes = [vp, u32, vp, vp, u32]
     L.tsgpu_facet_count_batch.argtypes = [vp, u32, vp, vp, u32, u32, vp, u32, C.POINTER(FacetCountsC)]
+    L.tsgpu_facet_count_grouped_batch.argtypes = [vp, u32, vp, vp, u32, u32, vp, u32, u32, i32, C.POINTER(FacetCountsC)]
+    L.tsgpu_facet_range_count_batch.argtypes = [vp, u32, u32, vp, vp, u32, vp, vp, u32, u32, u32, i32, vp]
     L.tsgpu_vec_create.argtypes = [vp, u32, u32, i32, u64]
     L.tsgpu_vec_upsert.argtypes = [vp, u32, vp, vp, u32, i32]
     L.tsgpu_vec_delete.argtypes = [vp, u32, u64]

@@ -19,6 +19,9 @@ struct FacetQueryDev {
     uint32_t tab_mask;       // table size - 1 (a power of two >= 2 x the distinct values it can meet)
     uint32_t first_block;    // first workgroup of this query in the launch
     uint64_t out_off;        // where its compacted (hash, count, doc, pos) entries go
+    uint64_t pair_off;       // grouped counting: its (value, group) pair table in the pair arena
+    uint32_t pair_mask;      // pair table size - 1 (a power of two >= 2 x the pairs it can meet)
+    uint32_t pad;
 };
 
 struct FacetArgs {
@@ -35,9 +38,32 @@ struct FacetArgs {
     unsigned long long* tab_key; // 0 = empty, else (1 << 32 | hash)
     uint32_t* tab_cnt;
     unsigned long long* tab_last;  // doc_id << 32 | array_pos of the greatest document seen
+    // facets of a grouped search (group_limit != 0: hash_groups[value].emplace(distinct_id), src/index.cpp:1747-1749, 1756-1758; the count of a value
+    // becomes the number of groups it was seen in, :4455-4458): grouped != 0 -> every NEW (value, (uint32) distinct id) pair bumps tab_gcnt[value]
+    uint32_t grouped; uint32_t group_missing_values;
+    const long long* group_col; uint32_t group_len;     // distinct id per seq_id (beyond group_len: 1 with group_missing_values, else the seq_id — get_distinct_id, :7100-7142)
+    unsigned long long* pair_key;                        // ~0 = empty, else value << 32 | (uint32) distinct id; the pair of all ones lives in pair_ones[query]
+    uint32_t* pair_ones; uint32_t* tab_gcnt;
     // compaction
     uint32_t* out_hash; uint32_t* out_cnt; uint32_t* out_doc; uint32_t* out_pos; uint32_t* out_n;
 };
+
+__device__ inline uint32_t facet_distinct_id32(const long long* group_col, uint32_t group_len, uint32_t group_missing_values, uint32_t doc) {
+    return doc < group_len ? (uint32_t)(unsigned long long)group_col[doc] : (group_missing_values ? 1u : doc);      // (hash_groups holds uint32_t: the id is truncated, include/field.h:791)
+}
+// hash_groups[value].emplace(distinct_id): true when the pair is new
+__device__ inline bool facet_pair_insert(unsigned long long* pair_key, uint32_t* pair_ones, uint32_t qi, uint64_t pair_off, uint32_t pair_mask, uint32_t value, uint32_t did) {
+    const unsigned long long key = ((unsigned long long)value << 32) | did;
+    if (key == ~0ull) return atomicExch(&pair_ones[qi], 1u) == 0u;
+    uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & pair_mask;
+    for (;;) {
+        unsigned long long* kp = pair_key + pair_off + slot;
+        unsigned long long cur = *kp;
+        if (cur == ~0ull) { cur = atomicCAS(kp, ~0ull, key); if (cur == ~0ull) return true; }
+        if (cur == key) return false;
+        slot = (slot + 1) & pair_mask;
+    }
+}
 
 // grid = sum over queries of ceil(n_ids / ids_per_block) workgroups; block b belongs to the query q with first_block[q] <= b < first_block[q+1].
 // A facet field is typically a few dozen to a few thousand values counted over up to millions of result ids: straight into the query's table
@@ -50,8 +76,8 @@ constexpr uint32_t FACET_LDS_SLOTS = 1024;
 __global__ __launch_bounds__(FACET_THREADS) void facet_count_kernel(FacetArgs a) {
     __shared__ uint32_t s_q;
     __shared__ unsigned long long s_key[FACET_LDS_SLOTS], s_last[FACET_LDS_SLOTS];
-    __shared__ uint32_t s_cnt[FACET_LDS_SLOTS];
-    for (uint32_t t = threadIdx.x; t < FACET_LDS_SLOTS; t += FACET_THREADS) { s_key[t] = 0; s_last[t] = 0; s_cnt[t] = 0; }
+    __shared__ uint32_t s_cnt[FACET_LDS_SLOTS], s_gcnt[FACET_LDS_SLOTS];
+    for (uint32_t t = threadIdx.x; t < FACET_LDS_SLOTS; t += FACET_THREADS) { s_key[t] = 0; s_last[t] = 0; s_cnt[t] = 0; s_gcnt[t] = 0; }
     if (threadIdx.x == 0) {
         uint32_t lo = 0, hi = a.n_queries;                      // last query whose first_block <= blockIdx.x
         while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (a.queries[mid].first_block <= blockIdx.x) lo = mid; else hi = mid; }
@@ -60,7 +86,7 @@ __global__ __launch_bounds__(FACET_THREADS) void facet_count_kernel(FacetArgs a)
     __syncthreads();
     const FacetQueryDev q = a.queries[s_q];
     const uint32_t lane = threadIdx.x & 63;
-    auto bump_table = [&](uint32_t fh, uint32_t times, unsigned long long last) {    // result_map[fh].count += times; the greatest (doc, position) wins
+    auto bump_table = [&](uint32_t fh, uint32_t times, uint32_t gtimes, unsigned long long last) {    // result_map[fh].count += times; the greatest (doc, position) wins
         const unsigned long long key = (1ull << 32) | fh;
         uint32_t slot = (fh * 2654435761u) & q.tab_mask;
         for (;;) {
@@ -71,18 +97,19 @@ __global__ __launch_bounds__(FACET_THREADS) void facet_count_kernel(FacetArgs a)
             slot = (slot + 1) & q.tab_mask;
         }
         atomicAdd(&a.tab_cnt[q.tab_off + slot], times);
+        if (gtimes) atomicAdd(&a.tab_gcnt[q.tab_off + slot], gtimes);
         atomicMax(&a.tab_last[q.tab_off + slot], last);
     };
-    auto bump = [&](uint32_t fh, uint32_t times, unsigned long long last) {
+    auto bump = [&](uint32_t fh, uint32_t times, uint32_t gtimes, unsigned long long last) {
         const unsigned long long key = (1ull << 32) | fh;
         uint32_t slot = ((fh * 2654435761u) >> 16) & (FACET_LDS_SLOTS - 1);
         for (int probe = 0; probe < 8; probe++) {
             unsigned long long cur = s_key[slot];
             if (cur == 0) cur = atomicCAS(&s_key[slot], 0ull, key), cur = cur == 0 ? key : cur;
-            if (cur == key) { atomicAdd(&s_cnt[slot], times); atomicMax(&s_last[slot], last); return; }
+            if (cur == key) { atomicAdd(&s_cnt[slot], times); if (gtimes) atomicAdd(&s_gcnt[slot], gtimes); atomicMax(&s_last[slot], last); return; }
             slot = (slot + 1) & (FACET_LDS_SLOTS - 1);
         }
-        bump_table(fh, times, last);
+        bump_table(fh, times, gtimes, last);
     };
     for (uint32_t rep = 0; rep < a.ids_per_block; rep += FACET_THREADS) {           // (workgroup-uniform)
         const uint64_t i = (uint64_t)(blockIdx.x - q.first_block) * a.ids_per_block + rep + threadIdx.x;
@@ -105,6 +132,8 @@ __global__ __launch_bounds__(FACET_THREADS) void facet_count_kernel(FacetArgs a)
                 }
             }
             const unsigned long long mine_last = ((unsigned long long)doc << 32) | (unsigned long long)it;
+            const bool is_new = count_it && a.grouped &&
+                                facet_pair_insert(a.pair_key, a.pair_ones, s_q, q.pair_off, q.pair_mask, fh, facet_distinct_id32(a.group_col, a.group_len, a.group_missing_values, doc));
             bool pending = count_it;
             for (int round = 0; round < 16; round++) {
                 const unsigned long long rem = __ballot(pending ? 1 : 0);
@@ -116,15 +145,16 @@ __global__ __launch_bounds__(FACET_THREADS) void facet_count_kernel(FacetArgs a)
                 if (__popcll(same) < 3) break;                       // (wave-uniform) the first waiting lane is nearly alone with its value: many values, one by one below
                 unsigned long long mx = mine ? mine_last : 0ull;
                 for (int d = 32; d > 0; d >>= 1) { const unsigned long long o = __shfl_xor(mx, d, 64); if (o > mx) mx = o; }
-                if (lane == leader) bump(fh, (uint32_t)__popcll(same), mx);
+                const unsigned long long fresh = __ballot(mine && is_new ? 1 : 0);
+                if (lane == leader) bump(fh, (uint32_t)__popcll(same), (uint32_t)__popcll(fresh), mx);
                 if (mine) pending = false;
             }
-            if (pending) bump(fh, 1u, mine_last);
+            if (pending) bump(fh, 1u, is_new ? 1u : 0u, mine_last);
         }
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < FACET_LDS_SLOTS; t += FACET_THREADS)
-        if (s_key[t] != 0) bump_table((uint32_t)s_key[t], s_cnt[t], s_last[t]);
+        if (s_key[t] != 0) bump_table((uint32_t)s_key[t], s_cnt[t], s_gcnt[t], s_last[t]);
 }
 
 // the occupied slots of every query's table -> a dense list (any order; the host orders by hash). grid = (n_queries, min(ceil(largest table /
@@ -150,9 +180,68 @@ __global__ __launch_bounds__(FACET_THREADS) void facet_compact_kernel(FacetArgs 
         at += (uint32_t)__popcll(occ & ((1ull << lane) - 1ull));
         const unsigned long long last = a.tab_last[q.tab_off + s];
         a.out_hash[q.out_off + at] = (uint32_t)k;
-        a.out_cnt[q.out_off + at] = a.tab_cnt[q.tab_off + s];
+        a.out_cnt[q.out_off + at] = a.grouped ? a.tab_gcnt[q.tab_off + s] : a.tab_cnt[q.tab_off + s];       // (grouped: hash_groups[value].size(), src/index.cpp:4455-4458)
         a.out_doc[q.out_off + at] = (uint32_t)(last >> 32);
         a.out_pos[q.out_off + at] = (uint32_t)last;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Range facets of the hash-index branch (a_facet.is_range_query, src/index.cpp:1738-1750): per result document that the facet hash index holds, ONCE PER DISTINCT
+// HASH of the document (the branch sits inside the loop over its hashes), doc_val = the field's sort-index value (get_doc_val_from_sort_index, :1470-1482: INT64_MAX
+// when absent) is looked up in facet_range_map (facet::get_range, include/field.h:820-838: the first range whose upper bound is GREATER than the value, taken when
+// value >= its lower bound) and result_map[range_id].count += 1; with group_limit also hash_groups[range_id].emplace(distinct_id), the final count being the set's
+// size (:4455-4458) — sets keyed by (uint32) range_id, so ranges whose upper bounds agree in their low 32 bits share one (range_set[r] = the first such range).
+// Ranges are given in ascending upper-bound order (std::map order). One LDS counter per range and workgroup, one add per range and workgroup at the end.
+constexpr uint32_t FACET_MAX_RANGES = 1024;
+struct FacetRangeArgs {
+    const uint64_t* doc_ptr; const uint32_t* hashes; uint32_t n_docs;
+    const uint32_t* ids; const FacetQueryDev* queries; uint32_t n_queries; uint32_t sample_mod; uint32_t ids_per_block;
+    const long long* val_col; uint32_t val_len;                                 // the field's sort index as a dense column (beyond val_len: INT64_MAX)
+    const long long* range_upper; const long long* range_lower; const uint32_t* range_set; uint32_t n_ranges;
+    uint32_t grouped; uint32_t group_missing_values; const long long* group_col; uint32_t group_len;
+    unsigned long long* pair_key; uint32_t* pair_ones;
+    uint32_t* out_count; uint32_t* out_gcount;                                  // [n_queries][n_ranges], zeroed by the host
+};
+__global__ __launch_bounds__(FACET_THREADS) void facet_range_kernel(FacetRangeArgs a) {
+    __shared__ uint32_t s_q;
+    __shared__ uint32_t s_cnt[FACET_MAX_RANGES], s_gcnt[FACET_MAX_RANGES];
+    for (uint32_t t = threadIdx.x; t < a.n_ranges; t += FACET_THREADS) { s_cnt[t] = 0; s_gcnt[t] = 0; }
+    if (threadIdx.x == 0) {
+        uint32_t lo = 0, hi = a.n_queries;
+        while (lo + 1 < hi) { const uint32_t mid = (lo + hi) >> 1; if (a.queries[mid].first_block <= blockIdx.x) lo = mid; else hi = mid; }
+        s_q = lo;
+    }
+    __syncthreads();
+    const FacetQueryDev q = a.queries[s_q];
+    for (uint32_t rep = 0; rep < a.ids_per_block; rep += FACET_THREADS) {
+        const uint64_t i = (uint64_t)(blockIdx.x - q.first_block) * a.ids_per_block + rep + threadIdx.x;
+        if (i >= q.n_ids || (a.sample_mod > 1 && (i % a.sample_mod) != 0)) continue;
+        const uint32_t doc = a.ids[q.ids_off + i];
+        if (doc >= a.n_docs) continue;                                          // beyond the index: facet_index_it is exhausted
+        const uint64_t h0 = a.doc_ptr[doc], h1 = a.doc_ptr[doc + 1];
+        uint32_t times = 0;                                                     // distinct hashes of the document (unique_facet_hashes)
+        for (uint64_t j = h0; j < h1; j++) {
+            bool dup = false;
+            for (uint64_t p = h0; p < j && !dup; p++) dup = a.hashes[p] == a.hashes[j];
+            times += dup ? 0u : 1u;
+        }
+        if (times == 0) continue;                                               // not in the facet hash index
+        const long long v = doc < a.val_len ? a.val_col[doc] : 0x7FFFFFFFFFFFFFFFll;
+        uint32_t lo = 0, hi = a.n_ranges;                                       // lower_bound(v), stepping over an upper bound equal to v = the first upper bound > v
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a.range_upper[mid] <= v) lo = mid + 1; else hi = mid; }
+        if (lo >= a.n_ranges || v < a.range_lower[lo]) continue;
+        atomicAdd(&s_cnt[lo], times);
+        if (a.grouped) {
+            const uint32_t set = a.range_set[lo];
+            if (facet_pair_insert(a.pair_key, a.pair_ones, s_q, q.pair_off, q.pair_mask, set, facet_distinct_id32(a.group_col, a.group_len, a.group_missing_values, doc)))
+                atomicAdd(&s_gcnt[set], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < a.n_ranges; t += FACET_THREADS) {
+        if (s_cnt[t]) atomicAdd(&a.out_count[(size_t)s_q * a.n_ranges + t], s_cnt[t]);
+        if (s_gcnt[t]) atomicAdd(&a.out_gcount[(size_t)s_q * a.n_ranges + t], s_gcnt[t]);
     }
 }
 

@@ -17,9 +17,11 @@ struct FacetField {
     DevBuf val_ptr, val_ids, val_total;              // value index (tsgpu_facet_value_set): value -> ascending seq_ids, in the reference's visiting order
     uint32_t n_values = 0;
     DevBuf d_stats, d_map_h, d_map_v, d_counts, d_order;
+    DevBuf d_gcnt, d_pair, d_pair_ones, d_rng_up, d_rng_lo, d_rng_set, d_rng_cnt, d_rng_gcnt;      // grouped counting / range facets
     void release() {
         DevBuf* b[] = {&doc_ptr, &hashes, &d_ids, &d_queries, &d_allowed, &d_key, &d_cnt, &d_last, &d_oh, &d_oc, &d_od, &d_op, &d_on,
-                       &val_ptr, &val_ids, &val_total, &d_stats, &d_map_h, &d_map_v, &d_counts, &d_order};
+                       &val_ptr, &val_ids, &val_total, &d_stats, &d_map_h, &d_map_v, &d_counts, &d_order,
+                       &d_gcnt, &d_pair, &d_pair_ones, &d_rng_up, &d_rng_lo, &d_rng_set, &d_rng_cnt, &d_rng_gcnt};
         for (auto* x : b) x->release();
     }
 };
@@ -63,8 +65,9 @@ int tsgpu_facet_set(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint64_t* doc
     return ok();
 }
 
-int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
-                            uint32_t sample_mod, const uint32_t* allowed_hashes, uint32_t n_allowed, tsgpu_facet_counts* out) {
+static int facet_count_impl(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
+                            uint32_t sample_mod, const uint32_t* allowed_hashes, uint32_t n_allowed, bool grouped, uint32_t group_column, bool group_missing_values,
+                            tsgpu_facet_counts* out) {
     if (!ctx || !out || (n_queries && (!result_ids || !n_result_ids))) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_count_batch: NULL argument");
     if (n_queries == 0) return ok();
     if (!out->hash || !out->count || !out->doc_id || !out->array_pos || !out->n_values) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_count_batch: missing output arrays");
@@ -76,9 +79,10 @@ int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
     FacetField* f = it->second;
     hipStream_t s = ctx->stream;
     if (sample_mod == 0) sample_mod = 1;
+    if (grouped && group_column >= ctx->columns.size()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_facet_count_grouped_batch: unknown group column (tsgpu_column_set)");
     try {
         std::vector<FacetQueryDev> qd(n_queries);
-        uint64_t ids_total = 0, tab_total = 0, out_total = 0, max_size = 64;
+        uint64_t ids_total = 0, tab_total = 0, out_total = 0, max_size = 64, pair_total = 0;
         uint32_t blocks = 0;
         // ids per workgroup: the more ids a workgroup folds in LDS before it touches the query's table the fewer atomics meet there, as long as a
         // couple of thousand workgroups remain to fill the 256 CUs
@@ -104,12 +108,21 @@ int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
             out_total += size / 2 + 1;
             d.first_block = blocks;
             max_size = std::max(max_size, size);
+            d.pair_off = pair_total; d.pair_mask = 0;
+            if (grouped) {                                       // every (document, hash) of the query may be a pair of its own
+                uint64_t psize = 64;
+                while (psize < 2 * sampled * std::max<uint32_t>(f->max_per_doc, 1)) psize <<= 1;
+                if (psize > (1ull << 31)) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_facet_count_grouped_batch: more than 2^30 (value, group) pairs in one query");
+                d.pair_mask = (uint32_t)(psize - 1);
+                pair_total += psize;
+            }
             const uint64_t nb = (d.n_ids + ids_per_block - 1) / ids_per_block;
             if ((uint64_t)blocks + nb > 0x7FFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_facet_count_batch: more than 2^31 workgroups");
             blocks += (uint32_t)nb;
         }
-        if (tab_total * 20 > (32ull << 30)) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_facet_count_batch: the counting tables of this batch exceed 32 GiB; split it");
+        if (tab_total * 24 + pair_total * 8 > (32ull << 30)) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_facet_count_batch: the counting tables of this batch exceed 32 GiB; split it");
         int rc;
+        if (grouped && ((rc = f->d_gcnt.reserve(tab_total * 4)) || (rc = f->d_pair.reserve(std::max<uint64_t>(pair_total, 1) * 8)) || (rc = f->d_pair_ones.reserve((size_t)n_queries * 4)))) return rc;
         if ((rc = f->d_ids.reserve(std::max<uint64_t>(ids_total, 1) * 4)) || (rc = f->d_queries.reserve(qd.size() * sizeof(FacetQueryDev))) ||
             (rc = f->d_key.reserve(tab_total * 8)) || (rc = f->d_cnt.reserve(tab_total * 4)) || (rc = f->d_last.reserve(tab_total * 8)) ||
             (rc = f->d_oh.reserve(out_total * 4)) || (rc = f->d_oc.reserve(out_total * 4)) || (rc = f->d_od.reserve(out_total * 4)) ||
@@ -123,6 +136,11 @@ int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
         TSGPU_HIP_TRY(hipMemsetAsync(f->d_cnt.p, 0, tab_total * 4, s));
         TSGPU_HIP_TRY(hipMemsetAsync(f->d_last.p, 0, tab_total * 8, s));
         TSGPU_HIP_TRY(hipMemsetAsync(f->d_on.p, 0, (size_t)n_queries * 4, s));
+        if (grouped) {
+            TSGPU_HIP_TRY(hipMemsetAsync(f->d_gcnt.p, 0, tab_total * 4, s));
+            TSGPU_HIP_TRY(hipMemsetAsync(f->d_pair.p, 0xFF, std::max<uint64_t>(pair_total, 1) * 8, s));
+            TSGPU_HIP_TRY(hipMemsetAsync(f->d_pair_ones.p, 0, (size_t)n_queries * 4, s));
+        }
         FacetArgs a;
         a.doc_ptr = f->doc_ptr.as<uint64_t>(); a.hashes = f->hashes.as<uint32_t>(); a.n_docs = f->n_docs;
         a.ids = f->d_ids.as<uint32_t>(); a.queries = f->d_queries.as<FacetQueryDev>(); a.n_queries = n_queries; a.sample_mod = sample_mod; a.ids_per_block = ids_per_block;
@@ -130,6 +148,10 @@ int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
         a.tab_key = f->d_key.as<unsigned long long>(); a.tab_cnt = f->d_cnt.as<uint32_t>(); a.tab_last = f->d_last.as<unsigned long long>();
         a.out_hash = f->d_oh.as<uint32_t>(); a.out_cnt = f->d_oc.as<uint32_t>(); a.out_doc = f->d_od.as<uint32_t>(); a.out_pos = f->d_op.as<uint32_t>();
         a.out_n = f->d_on.as<uint32_t>();
+        a.grouped = grouped ? 1u : 0u; a.group_missing_values = group_missing_values ? 1u : 0u;
+        a.group_col = grouped ? ctx->columns[group_column].data.as<long long>() : nullptr; a.group_len = grouped ? ctx->columns[group_column].n : 0;
+        a.pair_key = grouped ? f->d_pair.as<unsigned long long>() : nullptr; a.pair_ones = grouped ? f->d_pair_ones.as<uint32_t>() : nullptr;
+        a.tab_gcnt = grouped ? f->d_gcnt.as<uint32_t>() : nullptr;
         if (blocks) hipLaunchKernelGGL(facet_count_kernel, dim3(blocks), dim3(FACET_THREADS), 0, s, a);
         hipLaunchKernelGGL(facet_compact_kernel, dim3(n_queries, (uint32_t)std::min<uint64_t>((max_size + FACET_COMPACT_SLOTS - 1) / FACET_COMPACT_SLOTS, 4096)), dim3(FACET_THREADS), 0, s, a);
         TSGPU_HIP_TRY(hipGetLastError());
@@ -159,6 +181,111 @@ int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
             }
         }
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_facet_count_batch: host allocation failed"); }
+    return ok();
+}
+
+int tsgpu_facet_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
+                            uint32_t sample_mod, const uint32_t* allowed_hashes, uint32_t n_allowed, tsgpu_facet_counts* out) {
+    return facet_count_impl(ctx, facet_field_id, result_ids, n_result_ids, n_queries, sample_mod, allowed_hashes, n_allowed, false, 0, false, out);
+}
+
+int tsgpu_facet_count_grouped_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
+                                    uint32_t sample_mod, const uint32_t* allowed_hashes, uint32_t n_allowed, uint32_t group_column, int group_missing_values,
+                                    tsgpu_facet_counts* out) {
+    return facet_count_impl(ctx, facet_field_id, result_ids, n_result_ids, n_queries, sample_mod, allowed_hashes, n_allowed, true, group_column, group_missing_values != 0, out);
+}
+
+int tsgpu_facet_range_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, uint32_t value_column, const int64_t* range_upper, const int64_t* range_lower, uint32_t n_ranges,
+                                  const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries, uint32_t sample_mod,
+                                  uint32_t group_column, int group_missing_values, uint32_t* counts) {
+    if (!ctx || !counts || !range_upper || !range_lower || (n_queries && (!result_ids || !n_result_ids))) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_range_count_batch: NULL argument");
+    if (n_ranges == 0 || n_ranges > FACET_MAX_RANGES) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_facet_range_count_batch: 1 .. 1024 ranges");
+    for (uint32_t r = 1; r < n_ranges; r++)
+        if (range_upper[r] <= range_upper[r - 1]) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_range_count_batch: range_upper must be strictly ascending (facet_range_map is a std::map)");
+    if (n_queries == 0) return ok();
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    auto it = ctx->facet_fields.find(facet_field_id);
+    if (it == ctx->facet_fields.end()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_facet_range_count_batch: unknown facet field (tsgpu_facet_set)");
+    FacetField* f = it->second;
+    if (value_column >= ctx->columns.size()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_facet_range_count_batch: unknown value column (tsgpu_column_set)");
+    const bool grouped = group_column != TSGPU_NO_COLUMN;
+    if (grouped && group_column >= ctx->columns.size()) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_facet_range_count_batch: unknown group column (tsgpu_column_set)");
+    hipStream_t s = ctx->stream;
+    if (sample_mod == 0) sample_mod = 1;
+    try {
+        std::vector<FacetQueryDev> qd(n_queries);
+        uint64_t ids_total = 0, pair_total = 0, all_ids = 0;
+        uint32_t blocks = 0;
+        for (uint32_t q = 0; q < n_queries; q++) all_ids += n_result_ids[q];
+        uint32_t ids_per_block = FACET_THREADS;
+        while (ids_per_block < 4096 && all_ids / (ids_per_block * 2) >= 2048) ids_per_block *= 2;
+        if (ctx->facet_ids_per_block) ids_per_block = ctx->facet_ids_per_block;
+        for (uint32_t q = 0; q < n_queries; q++) {
+            if (n_result_ids[q] && !result_ids[q]) return fail(TSGPU_ERR_INVALID, "tsgpu_facet_range_count_batch: result_ids[q] is NULL");
+            FacetQueryDev& d = qd[q];
+            memset(&d, 0, sizeof(d));
+            d.ids_off = ids_total; d.n_ids = n_result_ids[q];
+            ids_total += d.n_ids;
+            d.first_block = blocks;
+            const uint64_t nb = (d.n_ids + ids_per_block - 1) / ids_per_block;
+            if ((uint64_t)blocks + nb > 0x7FFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_facet_range_count_batch: more than 2^31 workgroups");
+            blocks += (uint32_t)nb;
+            d.pair_off = pair_total;
+            if (grouped) {                                       // one pair per document at most
+                const uint64_t sampled = (d.n_ids + sample_mod - 1) / sample_mod;
+                uint64_t psize = 64;
+                while (psize < 2 * sampled) psize <<= 1;
+                d.pair_mask = (uint32_t)(psize - 1);
+                pair_total += psize;
+            }
+        }
+        // hash_groups is keyed by (uint32) range_id: ranges whose upper bounds agree in the low 32 bits share one set of groups
+        std::vector<uint32_t> rset(n_ranges);
+        for (uint32_t r = 0; r < n_ranges; r++) {
+            rset[r] = r;
+            for (uint32_t p = 0; p < r; p++) if ((uint32_t)(uint64_t)range_upper[p] == (uint32_t)(uint64_t)range_upper[r]) { rset[r] = p; break; }
+        }
+        const size_t cells = (size_t)n_queries * n_ranges;
+        int rc;
+        if ((rc = f->d_ids.reserve(std::max<uint64_t>(ids_total, 1) * 4)) || (rc = f->d_queries.reserve(qd.size() * sizeof(FacetQueryDev))) ||
+            (rc = f->d_rng_up.reserve((size_t)n_ranges * 8)) || (rc = f->d_rng_lo.reserve((size_t)n_ranges * 8)) || (rc = f->d_rng_set.reserve((size_t)n_ranges * 4)) ||
+            (rc = f->d_rng_cnt.reserve(cells * 4)) || (rc = f->d_rng_gcnt.reserve(cells * 4)) ||
+            (rc = f->d_pair.reserve(std::max<uint64_t>(pair_total, 1) * 8)) || (rc = f->d_pair_ones.reserve((size_t)n_queries * 4))) return rc;
+        for (uint32_t q = 0; q < n_queries; q++)
+            if (qd[q].n_ids) TSGPU_HIP_TRY(hipMemcpyAsync(f->d_ids.as<uint32_t>() + qd[q].ids_off, result_ids[q], qd[q].n_ids * 4, hipMemcpyHostToDevice, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(f->d_queries.p, qd.data(), qd.size() * sizeof(FacetQueryDev), hipMemcpyHostToDevice, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(f->d_rng_up.p, range_upper, (size_t)n_ranges * 8, hipMemcpyHostToDevice, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(f->d_rng_lo.p, range_lower, (size_t)n_ranges * 8, hipMemcpyHostToDevice, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(f->d_rng_set.p, rset.data(), (size_t)n_ranges * 4, hipMemcpyHostToDevice, s));
+        TSGPU_HIP_TRY(hipMemsetAsync(f->d_rng_cnt.p, 0, cells * 4, s));
+        TSGPU_HIP_TRY(hipMemsetAsync(f->d_rng_gcnt.p, 0, cells * 4, s));
+        if (grouped) {
+            TSGPU_HIP_TRY(hipMemsetAsync(f->d_pair.p, 0xFF, std::max<uint64_t>(pair_total, 1) * 8, s));
+            TSGPU_HIP_TRY(hipMemsetAsync(f->d_pair_ones.p, 0, (size_t)n_queries * 4, s));
+        }
+        FacetRangeArgs a;
+        a.doc_ptr = f->doc_ptr.as<uint64_t>(); a.hashes = f->hashes.as<uint32_t>(); a.n_docs = f->n_docs;
+        a.ids = f->d_ids.as<uint32_t>(); a.queries = f->d_queries.as<FacetQueryDev>(); a.n_queries = n_queries; a.sample_mod = sample_mod; a.ids_per_block = ids_per_block;
+        a.val_col = ctx->columns[value_column].data.as<long long>(); a.val_len = ctx->columns[value_column].n;
+        a.range_upper = f->d_rng_up.as<long long>(); a.range_lower = f->d_rng_lo.as<long long>(); a.range_set = f->d_rng_set.as<uint32_t>(); a.n_ranges = n_ranges;
+        a.grouped = grouped ? 1u : 0u; a.group_missing_values = group_missing_values ? 1u : 0u;
+        a.group_col = grouped ? ctx->columns[group_column].data.as<long long>() : nullptr; a.group_len = grouped ? ctx->columns[group_column].n : 0;
+        a.pair_key = f->d_pair.as<unsigned long long>(); a.pair_ones = f->d_pair_ones.as<uint32_t>();
+        a.out_count = f->d_rng_cnt.as<uint32_t>(); a.out_gcount = f->d_rng_gcnt.as<uint32_t>();
+        if (blocks) hipLaunchKernelGGL(facet_range_kernel, dim3(blocks), dim3(FACET_THREADS), 0, s, a);
+        TSGPU_HIP_TRY(hipGetLastError());
+        std::vector<uint32_t> hc(cells), hg(cells);
+        TSGPU_HIP_TRY(hipMemcpyAsync(hc.data(), f->d_rng_cnt.p, cells * 4, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(hg.data(), f->d_rng_gcnt.p, cells * 4, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        // a range is in result_map when a document fell into it; grouped: its count = the size of the set its (uint32) id names (:4455-4458)
+        for (uint32_t q = 0; q < n_queries; q++)
+            for (uint32_t r = 0; r < n_ranges; r++) {
+                const size_t c = (size_t)q * n_ranges + r;
+                counts[c] = hc[c] == 0 ? 0u : (grouped ? hg[(size_t)q * n_ranges + rset[r]] : hc[c]);
+            }
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_facet_range_count_batch: host allocation failed"); }
     return ok();
 }
 

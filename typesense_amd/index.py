@@ -363,8 +363,9 @@ class GpuIndex:
         hashes = _u32(hashes)
         self._ck(self.L.tsgpu_facet_set(self.h, field_id, _vp(doc_ptr), hashes.ctypes.data_as(C.c_void_p), doc_ptr.size - 1))
 
-    def facet_count_batch(self, field_id, id_lists, cap=1024, sample_mod=1, allowed_hashes=None):
-        """id_lists: per query an ascending uint32 id array -> per query (hash, count, doc_id, array_pos) arrays in ascending hash order"""
+    def facet_count_batch(self, field_id, id_lists, cap=1024, sample_mod=1, allowed_hashes=None, group_column=None, group_missing_values=False):
+        """id_lists: per query an ascending uint32 id array -> per query (hash, count, doc_id, array_pos) arrays in ascending hash order;
+        group_column: the facets of a grouped search (count = number of groups the value was seen in)"""
         lists = [_u32(x) for x in id_lists]
         n = len(lists)
         ptrs = (C.c_void_p * n)(*[x.ctypes.data if x.size else None for x in lists])
@@ -374,9 +375,26 @@ class GpuIndex:
                                                                                           np.zeros((n, cap), np.uint32), np.zeros((n, cap), np.uint32), np.zeros(n, np.uint32))
         out.cap, out.hash, out.count, out.doc_id, out.array_pos, out.n_values = cap, h.ctypes.data, c.ctypes.data, d.ctypes.data, p.ctypes.data, nv.ctypes.data
         a = None if allowed_hashes is None else _u32(allowed_hashes)
-        self._ck(self.L.tsgpu_facet_count_batch(self.h, field_id, C.cast(ptrs, C.c_void_p), _vp(cnts), n, sample_mod,
-                                                _vp(a) if a is not None else None, a.size if a is not None else 0, C.byref(out)))
+        if group_column is None:
+            self._ck(self.L.tsgpu_facet_count_batch(self.h, field_id, C.cast(ptrs, C.c_void_p), _vp(cnts), n, sample_mod,
+                                                    _vp(a) if a is not None else None, a.size if a is not None else 0, C.byref(out)))
+        else:
+            self._ck(self.L.tsgpu_facet_count_grouped_batch(self.h, field_id, C.cast(ptrs, C.c_void_p), _vp(cnts), n, sample_mod,
+                                                            _vp(a) if a is not None else None, a.size if a is not None else 0, int(group_column), int(group_missing_values), C.byref(out)))
         return [(h[q, :min(nv[q], cap)].copy(), c[q, :min(nv[q], cap)].copy(), d[q, :min(nv[q], cap)].copy(), p[q, :min(nv[q], cap)].copy(), int(nv[q])) for q in range(n)]
+
+    def facet_range_count_batch(self, field_id, value_column, ranges, id_lists, sample_mod=1, group_column=None, group_missing_values=False):
+        """ranges: [(upper, lower), ...] in ascending upper order (facet_range_map) -> counts uint32 [n_queries][n_ranges] (0 = not in result_map)"""
+        lists = [_u32(x) for x in id_lists]
+        n = len(lists)
+        ptrs = (C.c_void_p * max(n, 1))(*[x.ctypes.data if x.size else None for x in lists])
+        cnts = np.array([x.size for x in lists], np.uint64)
+        up = np.ascontiguousarray([r[0] for r in ranges], dtype=np.int64)
+        lo = np.ascontiguousarray([r[1] for r in ranges], dtype=np.int64)
+        counts = np.zeros((n, len(ranges)), np.uint32)
+        self._ck(self.L.tsgpu_facet_range_count_batch(self.h, field_id, int(value_column), _vp(up), _vp(lo), len(ranges), C.cast(ptrs, C.c_void_p), _vp(cnts), n, sample_mod,
+                                                      B.NO_COLUMN if group_column is None else int(group_column), int(group_missing_values), _vp(counts)))
+        return counts
 
     def facet_stats_batch(self, field_id, value_type, id_lists, sample_mod=1, int64_map=None):
         """-> per query (fvmin, fvmax, fvsum, fvcount, sum_exact); int64_map = (sorted hashes uint32[], values int64[]) for int64 fields"""
