@@ -942,7 +942,85 @@ class Bench:
         except Exception as e:      # noqa: BLE001
             grp["wildcard"] = {"error": repr(e)}
         res["group_by"] = grp
+        # ---- (iv) facets (do_facets, hash-index branch) over the matched ids of a keyword batch and over q = * ----
+        try:
+            res["facets"] = self.run_facets(gtok)
+        except Exception as e:      # noqa: BLE001
+            res["facets"] = {"error": repr(e)}
         return res
+
+    def run_facets(self, gtok):
+        """tsgpu_facet_count_batch / _grouped_batch / tsgpu_facet_range_count_batch at the keyword config's size: an ARRAY facet field (1-3 of 2 000 values per
+        document, repeats inside a document happen), counted (a) over the per-query id lists of a keyword batch, (b) over all documents (q = *) — plain,
+        as the facets of a grouped search (50 000 groups) and as 10 ranges of the points column. Parity: the oracle on the batch's queries; q = * against
+        a numpy recount (the oracle's std::map index over 10M documents is not built here)."""
+        from oracle import oracle_py as O
+        g, args, n = self.g, self.args, self.n_docs
+        steps = max(3, min(args.steps, 10))
+        ids64 = np.arange(n, dtype=np.uint64)
+        per = (1 + (ids64 * np.uint64(0x9E3779B97F4A7C15) >> np.uint64(61)) % np.uint64(3)).astype(np.uint64)
+        ptr = np.zeros(n + 1, np.uint64)
+        ptr[1:] = np.cumsum(per)
+        owner = np.repeat(ids64, per.astype(np.int64))
+        pos = np.arange(int(ptr[-1]), dtype=np.uint64) - ptr[owner.astype(np.int64)]
+        n_val = 2000
+        hashes = ((((owner * np.uint64(2654435761) + pos * np.uint64(40503)) >> np.uint64(7)) % np.uint64(n_val)).astype(np.uint32) * np.uint32(2654435761)).astype(np.uint32)
+        g.facet_set(5, ptr, hashes)
+        n_f = min(len(gtok), 1000)
+        qs = [self.T.KwQuery(gtok[i], sort=self.sort, topster_size=K_TOPSTER) for i in range(n_f)]
+        _, lists = g.keyword_search_batch_ids(qs, k_stride=K_TOPSTER)
+        cap = 2048
+        el, lat, got = timed(lambda: g.facet_count_batch(5, lists, cap=cap), steps, 1, 1)
+        out = {"workload": "array facet field (1-3 of %d values per document) over %d documents; (a) the id lists of %d keyword queries (3-term AND) per step, (b) q = *: all "
+                           "documents, plain / grouped (the group_by leg's %d groups) / 10 ranges of the points column; host inputs and outputs" % (n_val, n, n_f, max(16, n // 200)),
+               "value": n_f * steps / el, "unit": "facet-counted queries/s", "ms_per_step": 1e3 * el / steps, "ids_per_step": int(sum(x.size for x in lists)),
+               "values_per_query": float(np.mean([r[4] for r in got]))}
+        everything = [np.arange(n, dtype=np.uint32)]
+        pts = np.ascontiguousarray(self.pts, dtype=np.int64)                          # (column 0 of the collection)
+        lo_v, hi_v = int(pts.min()), int(pts.max()) + 1
+        edges = np.linspace(lo_v, hi_v, 11).astype(np.int64)
+        ranges = [(int(edges[r + 1]), int(edges[r])) for r in range(10) if edges[r + 1] > edges[r]]
+        wild = {}
+        for name, fn in (("plain", lambda: g.facet_count_batch(5, everything, cap=cap)),
+                         ("grouped", lambda: g.facet_count_batch(5, everything, cap=cap, group_column=7)),
+                         ("ranges", lambda: g.facet_range_count_batch(5, 0, ranges, everything)),
+                         ("ranges_grouped", lambda: g.facet_range_count_batch(5, 0, ranges, everything, group_column=7))):
+            e2, _, r2 = timed(fn, steps, 1, 1)
+            wild[name] = {"ms_per_call": 1e3 * e2 / steps}
+            wild["_" + name] = r2
+        # q = * recount: every (document, distinct hash) once
+        pair = np.unique(owner.astype(np.uint64) << np.uint64(32) | hashes.astype(np.uint64))
+        uh, uc = np.unique((pair & np.uint64(0xFFFFFFFF)).astype(np.uint32), return_counts=True)
+        h0, c0, d0, p0, n0 = wild.pop("_plain")[0]
+        bad = 0 if (n0 == uh.size and np.array_equal(h0, uh[:cap]) and np.array_equal(c0, uc[:cap].astype(np.uint32))) else 1
+        rc = wild.pop("_ranges")[0]
+        per_doc = np.diff(np.unique(pair >> np.uint64(32), return_index=True)[1], append=pair.size)          # distinct hashes per document
+        which = np.searchsorted(np.array([u for u, _ in ranges], np.int64), pts, side="right")
+        okr = which < len(ranges)
+        okr[okr] &= pts[okr] >= np.array([l for _, l in ranges], np.int64)[which[okr]]
+        want_r = np.bincount(which[okr], weights=per_doc[okr], minlength=len(ranges)).astype(np.uint32)
+        bad += 0 if np.array_equal(rc, want_r) else 1
+        wild.pop("_grouped"); wild.pop("_ranges_grouped")
+        wild["parity"] = {"checked": 2, "mismatches": bad, "what": "q = *: plain counts (the first %d values in hash order) and the range counts vs a numpy recount of every (document, distinct hash)" % cap}
+        out["wildcard"] = wild
+        if not args.no_cpu_baseline:
+            npar = min(n_f, 8)
+            need = np.unique(np.concatenate([lists[i] for i in range(npar)] + [np.zeros(0, np.uint32)]))
+            keep = np.zeros(n, bool)
+            keep[need] = True
+            sp = np.zeros(n + 1, np.uint64)
+            sp[1:] = np.cumsum(np.where(keep, per, 0))
+            orc = O.OracleIndex(1, 1)
+            orc.facet_set(0, sp, hashes[keep[owner.astype(np.int64)]])               # (only the documents these queries matched: the walk meets no other)
+            bad, t0 = 0, time.perf_counter()
+            for i in range(npar):
+                h, c, d, p, nn = orc.facet_count(0, lists[i])
+                gh, gc, gd, gp, gn = got[i]
+                bad += 0 if (gn == nn and np.array_equal(gh, h[:cap]) and np.array_equal(gc, c[:cap]) and np.array_equal(gd, d[:cap]) and np.array_equal(gp, p[:cap])) else 1
+            cpu_s = time.perf_counter() - t0
+            out["parity"] = {"checked": npar, "mismatches": bad, "what": "value hashes, counts, last document and array position of every value vs oracle/facet_count.h on the queries' own id lists"}
+            out["cpu_baseline"] = {"value": npar / cpu_s, "unit": "facet-counted queries/s", "cores": 1, "kind": "port", "sample": "%d of the step's queries, oracle/facet_count.h on one core" % npar}
+        return out
 
     def concurrency_keyword(self, arr, n_q, keys, scores, n_hits, num_matched):
         """the reference's calling convention (src/index.cpp:3488, src/http_server.cpp:827-832): T host threads, blocking 1-query calls on one
