@@ -17,14 +17,33 @@ struct FacetField {
     DevBuf val_ptr, val_ids, val_total;              // value index (tsgpu_facet_value_set): value -> ascending seq_ids, in the reference's visiting order
     uint32_t n_values = 0;
     DevBuf d_stats, d_map_h, d_map_v, d_counts, d_order;
+    PinBuf h_in, h_out;                               // staged id lists of a multi-query call (ONE upload), the compacted lists (pinned: no page-by-page DMA)
+    DevBuf d_sh, d_sc, d_sd, d_sp;                    // the compacted lists in hash order (facet_sort_kernel)
     DevBuf d_gcnt, d_pair, d_pair_ones, d_rng_up, d_rng_lo, d_rng_set, d_rng_cnt, d_rng_gcnt;      // grouped counting / range facets
     void release() {
         DevBuf* b[] = {&doc_ptr, &hashes, &d_ids, &d_queries, &d_allowed, &d_key, &d_cnt, &d_last, &d_oh, &d_oc, &d_od, &d_op, &d_on,
                        &val_ptr, &val_ids, &val_total, &d_stats, &d_map_h, &d_map_v, &d_counts, &d_order,
-                       &d_gcnt, &d_pair, &d_pair_ones, &d_rng_up, &d_rng_lo, &d_rng_set, &d_rng_cnt, &d_rng_gcnt};
+                       &d_sh, &d_sc, &d_sd, &d_sp, &d_gcnt, &d_pair, &d_pair_ones, &d_rng_up, &d_rng_lo, &d_rng_set, &d_rng_cnt, &d_rng_gcnt};
         for (auto* x : b) x->release();
+        h_in.release(); h_out.release();
     }
 };
+// the id lists of a call -> the id arena (d_ids reserved by the caller). Many small lists (a keyword batch's per-query ids) are packed into one pinned block
+// and cross in ONE copy (1 000 lists: 1 000 copies of ~7 KB cost ~10 ms before); a single list, or lists of megabytes, go straight from the caller's memory.
+static int facet_upload_ids(FacetField* f, const std::vector<FacetQueryDev>& qd, const uint32_t* const* result_ids, uint32_t n_queries, uint64_t ids_total, hipStream_t s) {
+    if (n_queries > 1 && ids_total && ids_total / n_queries < (256u << 10)) {
+        int rc = f->h_in.reserve(ids_total * 4);
+        if (rc) return rc;
+        // (every facet call ends with a stream synchronisation under ctx->mu: the block is not feeding an earlier copy any more)
+        for (uint32_t q = 0; q < n_queries; q++)
+            if (qd[q].n_ids) memcpy(f->h_in.as<uint32_t>() + qd[q].ids_off, result_ids[q], qd[q].n_ids * 4);
+        TSGPU_HIP_TRY(hipMemcpyAsync(f->d_ids.p, f->h_in.p, ids_total * 4, hipMemcpyHostToDevice, s));
+        return TSGPU_OK;
+    }
+    for (uint32_t q = 0; q < n_queries; q++)
+        if (qd[q].n_ids) TSGPU_HIP_TRY(hipMemcpyAsync(f->d_ids.as<uint32_t>() + qd[q].ids_off, result_ids[q], qd[q].n_ids * 4, hipMemcpyHostToDevice, s));
+    return TSGPU_OK;
+}
 }  // namespace tsgpu
 
 extern "C" {
@@ -126,10 +145,10 @@ static int facet_count_impl(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
         if ((rc = f->d_ids.reserve(std::max<uint64_t>(ids_total, 1) * 4)) || (rc = f->d_queries.reserve(qd.size() * sizeof(FacetQueryDev))) ||
             (rc = f->d_key.reserve(tab_total * 8)) || (rc = f->d_cnt.reserve(tab_total * 4)) || (rc = f->d_last.reserve(tab_total * 8)) ||
             (rc = f->d_oh.reserve(out_total * 4)) || (rc = f->d_oc.reserve(out_total * 4)) || (rc = f->d_od.reserve(out_total * 4)) ||
-            (rc = f->d_op.reserve(out_total * 4)) || (rc = f->d_on.reserve((size_t)n_queries * 4)) || (rc = f->d_allowed.reserve(std::max<uint32_t>(n_allowed, 1) * 4)))
+            (rc = f->d_op.reserve(out_total * 4)) || (rc = f->d_on.reserve((size_t)n_queries * 4)) || (rc = f->d_allowed.reserve(std::max<uint32_t>(n_allowed, 1) * 4)) ||
+            (rc = f->d_sh.reserve(out_total * 4)) || (rc = f->d_sc.reserve(out_total * 4)) || (rc = f->d_sd.reserve(out_total * 4)) || (rc = f->d_sp.reserve(out_total * 4)))
             return rc;
-        for (uint32_t q = 0; q < n_queries; q++)
-            if (qd[q].n_ids) TSGPU_HIP_TRY(hipMemcpyAsync(f->d_ids.as<uint32_t>() + qd[q].ids_off, result_ids[q], qd[q].n_ids * 4, hipMemcpyHostToDevice, s));
+        if ((rc = facet_upload_ids(f, qd, result_ids, n_queries, ids_total, s))) return rc;
         TSGPU_HIP_TRY(hipMemcpyAsync(f->d_queries.p, qd.data(), qd.size() * sizeof(FacetQueryDev), hipMemcpyHostToDevice, s));
         if (n_allowed) TSGPU_HIP_TRY(hipMemcpyAsync(f->d_allowed.p, allowed_hashes, (size_t)n_allowed * 4, hipMemcpyHostToDevice, s));
         TSGPU_HIP_TRY(hipMemsetAsync(f->d_key.p, 0, tab_total * 8, s));
@@ -154,30 +173,41 @@ static int facet_count_impl(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
         a.tab_gcnt = grouped ? f->d_gcnt.as<uint32_t>() : nullptr;
         if (blocks) hipLaunchKernelGGL(facet_count_kernel, dim3(blocks), dim3(FACET_THREADS), 0, s, a);
         hipLaunchKernelGGL(facet_compact_kernel, dim3(n_queries, (uint32_t)std::min<uint64_t>((max_size + FACET_COMPACT_SLOTS - 1) / FACET_COMPACT_SLOTS, 4096)), dim3(FACET_THREADS), 0, s, a);
+        FacetSortOut so;
+        so.hash = f->d_sh.as<uint32_t>(); so.cnt = f->d_sc.as<uint32_t>(); so.doc = f->d_sd.as<uint32_t>(); so.pos = f->d_sp.as<uint32_t>();
+        hipLaunchKernelGGL(facet_sort_kernel, dim3(n_queries), dim3(FACET_THREADS), 0, s, a, so);
         TSGPU_HIP_TRY(hipGetLastError());
-        std::vector<uint32_t> hn(n_queries), hh(out_total), hc(out_total), hd(out_total), hp(out_total);
-        TSGPU_HIP_TRY(hipMemcpyAsync(hn.data(), f->d_on.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(hh.data(), f->d_oh.p, out_total * 4, hipMemcpyDeviceToHost, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(hc.data(), f->d_oc.p, out_total * 4, hipMemcpyDeviceToHost, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(hd.data(), f->d_od.p, out_total * 4, hipMemcpyDeviceToHost, s));
-        TSGPU_HIP_TRY(hipMemcpyAsync(hp.data(), f->d_op.p, out_total * 4, hipMemcpyDeviceToHost, s));
+        if ((rc = f->h_out.reserve(((size_t)n_queries + 4 * out_total) * 4))) return rc;
+        uint32_t* hn = f->h_out.as<uint32_t>();
+        uint32_t *hh = hn + n_queries, *hc = hh + out_total, *hd = hc + out_total, *hp = hd + out_total;
+        TSGPU_HIP_TRY(hipMemcpyAsync(hn, f->d_on.p, (size_t)n_queries * 4, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(hh, f->d_sh.p, out_total * 4, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(hc, f->d_sc.p, out_total * 4, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(hd, f->d_sd.p, out_total * 4, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(hp, f->d_sp.p, out_total * 4, hipMemcpyDeviceToHost, s));
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
-        // the distinct values of a query in ascending hash order (result_map is keyed by the hash); the first `cap` of them are returned
-        // (hash << 32 | position in the device list: only the first `cap` hashes are put in order when the query met more values than that)
+        // the distinct values of a query in ascending hash order (result_map is keyed by the hash); the first `cap` of them are returned. The device ordered every
+        // list of up to FACET_SORT_MAX values; a longer one arrives as the table held it and only its first `cap` hashes are put in order here
+        // (hash << 32 | position in the device list)
         std::vector<uint64_t> order;
         for (uint32_t q = 0; q < n_queries; q++) {
             const uint32_t n = hn[q];
             const uint64_t base = qd[q].out_off;
-            order.resize(n);
-            for (uint32_t i = 0; i < n; i++) order[i] = ((uint64_t)hh[base + i] << 32) | i;
             out->n_values[q] = n;
             const uint32_t m = std::min(n, out->cap);
+            const size_t o = (size_t)q * out->cap;
+            if (n <= FACET_SORT_MAX) {
+                memcpy(out->hash + o, hh + base, (size_t)m * 4); memcpy(out->count + o, hc + base, (size_t)m * 4);
+                memcpy(out->doc_id + o, hd + base, (size_t)m * 4); memcpy(out->array_pos + o, hp + base, (size_t)m * 4);
+                continue;
+            }
+            order.resize(n);
+            for (uint32_t i = 0; i < n; i++) order[i] = ((uint64_t)hh[base + i] << 32) | i;
             if (m < n) std::nth_element(order.begin(), order.begin() + m, order.end());
             std::sort(order.begin(), order.begin() + m);
             for (uint32_t i = 0; i < m; i++) {
-                const size_t o = (size_t)q * out->cap + i;
                 const uint32_t at = (uint32_t)order[i];
-                out->hash[o] = hh[base + at]; out->count[o] = hc[base + at]; out->doc_id[o] = hd[base + at]; out->array_pos[o] = hp[base + at];
+                out->hash[o + i] = hh[base + at]; out->count[o + i] = hc[base + at]; out->doc_id[o + i] = hd[base + at]; out->array_pos[o + i] = hp[base + at];
             }
         }
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_facet_count_batch: host allocation failed"); }
@@ -252,8 +282,7 @@ int tsgpu_facet_range_count_batch(tsgpu_ctx* ctx, uint32_t facet_field_id, uint3
             (rc = f->d_rng_up.reserve((size_t)n_ranges * 8)) || (rc = f->d_rng_lo.reserve((size_t)n_ranges * 8)) || (rc = f->d_rng_set.reserve((size_t)n_ranges * 4)) ||
             (rc = f->d_rng_cnt.reserve(cells * 4)) || (rc = f->d_rng_gcnt.reserve(cells * 4)) ||
             (rc = f->d_pair.reserve(std::max<uint64_t>(pair_total, 1) * 8)) || (rc = f->d_pair_ones.reserve((size_t)n_queries * 4))) return rc;
-        for (uint32_t q = 0; q < n_queries; q++)
-            if (qd[q].n_ids) TSGPU_HIP_TRY(hipMemcpyAsync(f->d_ids.as<uint32_t>() + qd[q].ids_off, result_ids[q], qd[q].n_ids * 4, hipMemcpyHostToDevice, s));
+        if ((rc = facet_upload_ids(f, qd, result_ids, n_queries, ids_total, s))) return rc;
         TSGPU_HIP_TRY(hipMemcpyAsync(f->d_queries.p, qd.data(), qd.size() * sizeof(FacetQueryDev), hipMemcpyHostToDevice, s));
         TSGPU_HIP_TRY(hipMemcpyAsync(f->d_rng_up.p, range_upper, (size_t)n_ranges * 8, hipMemcpyHostToDevice, s));
         TSGPU_HIP_TRY(hipMemcpyAsync(f->d_rng_lo.p, range_lower, (size_t)n_ranges * 8, hipMemcpyHostToDevice, s));
@@ -307,8 +336,7 @@ int upload_id_lists(FacetField* f, const uint32_t* const* result_ids, const uint
     }
     int rc;
     if ((rc = f->d_ids.reserve(std::max<uint64_t>(ids_total, 1) * 4)) || (rc = f->d_queries.reserve(qd.size() * sizeof(FacetQueryDev)))) return rc;
-    for (uint32_t q = 0; q < n_queries; q++)
-        if (qd[q].n_ids) TSGPU_HIP_TRY(hipMemcpyAsync(f->d_ids.as<uint32_t>() + qd[q].ids_off, result_ids[q], qd[q].n_ids * 4, hipMemcpyHostToDevice, s));
+    if ((rc = facet_upload_ids(f, qd, result_ids, n_queries, ids_total, s))) return rc;
     TSGPU_HIP_TRY(hipMemcpyAsync(f->d_queries.p, qd.data(), qd.size() * sizeof(FacetQueryDev), hipMemcpyHostToDevice, s));
     return TSGPU_OK;
 }
