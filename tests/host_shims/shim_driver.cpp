@@ -13,6 +13,8 @@
 #include "../../include/tsgpu.h"
 #include "../../typesense_amd/csrc/host/tsgpu_keyword_shim.h"
 #include "../../typesense_amd/csrc/host/tsgpu_groupby_shim.h"
+#include "../../typesense_amd/csrc/host/tsgpu_facet_shim.h"
+#include <map>
 #include "../../typesense_amd/csrc/host/tsgpu_hnsw_adaptor.h"
 #include "../../typesense_amd/csrc/host/tsgpu_posting_shim.h"
 #include "../../oracle/topk_heap.h"
@@ -488,6 +490,55 @@ int main(int argc, char** argv) {
         CHECK(tsgpu_vec_hnsw_load(ctx, 9, M, maxlevel, enterpoint, bad.data(), upper_ptr.data(), upper.empty() ? nullptr : upper.data(), n) == TSGPU_ERR_INVALID, "out-of-range neighbour accepted");
         for (uint32_t i = 0; i < n; i++) free(h.linkLists_[i]);
         free(h.linkLists_); free(h.data_level0_memory_);
+    }
+
+    // ---------------- do_facets, hash-index branch: the facet shim against mocks of include/field.h's facet / facet_count_t / range_specs_t ----------------
+    {
+        struct mock_facet_count_t { uint32_t count = 0; uint32_t doc_id = 0; uint32_t array_pos = 0; };
+        struct mock_range_specs_t { std::string range_label; int64_t lower_range; };
+        struct mock_facet { std::map<uint64_t, mock_facet_count_t> result_map; std::map<int64_t, mock_range_specs_t> facet_range_map; bool is_range_query = false; };
+        Reader r(dir + "/facets.bin");
+        const uint32_t n_docs = r.get<uint32_t>();
+        const std::vector<uint64_t> ptr = r.vec<uint64_t>(n_docs + 1);
+        const std::vector<uint32_t> hashes = r.vec<uint32_t>((size_t)ptr[n_docs]);
+        const std::vector<int64_t> vals = r.vec<int64_t>(n_docs), distinct = r.vec<int64_t>(n_docs);
+        CHECK(tsgpu_facet_set(ctx, 40, ptr.data(), hashes.data(), n_docs) == TSGPU_OK, "%s", tsgpu_last_error());
+        CHECK(tsgpu_column_set(ctx, 12, vals.data(), nullptr, n_docs, TSGPU_MEM_HOST) == TSGPU_OK, "%s", tsgpu_last_error());
+        CHECK(tsgpu_column_set(ctx, 13, distinct.data(), nullptr, n_docs, TSGPU_MEM_HOST) == TSGPU_OK, "%s", tsgpu_last_error());
+        const uint32_t n_cases = r.get<uint32_t>();
+        for (uint32_t c = 0; c < n_cases; c++) {
+            const uint32_t n_ids = r.get<uint32_t>();
+            const std::vector<uint32_t> ids = r.vec<uint32_t>(n_ids);
+            const uint32_t sample_mod = r.get<uint32_t>(), use_fq = r.get<uint32_t>(), n_fq = r.get<uint32_t>();
+            const std::vector<uint32_t> fq = r.vec<uint32_t>(n_fq);
+            const uint32_t grouped = r.get<uint32_t>(), n_ranges = r.get<uint32_t>();
+            mock_facet f;
+            for (uint32_t k = 0; k < n_ranges; k++) { const int64_t up = r.get<int64_t>(), lo = r.get<int64_t>(); f.facet_range_map[up] = {"r" + std::to_string(k), lo}; }
+            f.is_range_query = n_ranges != 0;
+            tsgpu::FacetShimArgs a;
+            a.ctx = ctx; a.facet_field_id = 40; a.result_ids = ids.data(); a.results_size = n_ids;
+            a.estimate_facets = sample_mod > 1; a.facet_sample_mod_value = sample_mod;
+            a.use_facet_query = use_fq != 0; a.fquery_hashes = fq.data(); a.n_fquery_hashes = n_fq;
+            a.group_limit = grouped ? 3 : 0; a.group_column = 13; a.group_missing_values = false; a.value_column = 12;
+            a.values_hint = 8;                                                   // (smaller than the value count: the shim asks again)
+            CHECK(tsgpu::do_facets_hash_gpu(a, f) == TSGPU_OK, "facet case %u: %s", c, tsgpu_last_error());
+            const uint32_t n_exp = r.get<uint32_t>();
+            CHECK(f.result_map.size() == n_exp, "facet case %u: %zu values, expected %u", c, f.result_map.size(), n_exp);
+            for (uint32_t k = 0; k < n_exp; k++) {
+                const uint64_t key = r.get<uint64_t>();
+                const uint32_t cnt = r.get<uint32_t>(), doc = r.get<uint32_t>(), pos = r.get<uint32_t>();
+                auto it = f.result_map.find(key);
+                CHECK(it != f.result_map.end(), "facet case %u: value %llu missing", c, (unsigned long long)key);
+                CHECK(it->second.count == cnt && it->second.doc_id == doc && it->second.array_pos == pos, "facet case %u value %llu: %u/%u/%u, expected %u/%u/%u", c,
+                      (unsigned long long)key, it->second.count, it->second.doc_id, it->second.array_pos, cnt, doc, pos);
+            }
+        }
+        // an unknown facet field: the error comes back and the caller's facet is untouched
+        mock_facet f;
+        tsgpu::FacetShimArgs a;
+        const uint32_t one = 1;
+        a.ctx = ctx; a.facet_field_id = 4040; a.result_ids = &one; a.results_size = 1;
+        CHECK(tsgpu::do_facets_hash_gpu(a, f) == TSGPU_ERR_NOT_FOUND && f.result_map.empty(), "unknown facet field");
     }
 
     // ---------------- validation shared by both term entry points ----------------

@@ -76,6 +76,30 @@ def _write_fixture(d):
                 a, b = int(ref.begin[gi]), int(ref.begin[gi + 1])
                 f.write(struct.pack("<Q", int(ref.distinct_key[gi])) + _u32(ref.group_found[gi]) + _u32(b - a) + ref.keys[a:b].astype(np.uint64).tobytes() + ref.scores[a:b].astype(np.int64).tobytes())
             f.write(struct.pack("<Q", ref.groups_count) + _u32(ref.missing_ids.size) + ref.missing_ids.astype(np.uint32).tobytes() + struct.pack("<Q", ref.num_keyword_matches))
+    # do_facets (hash-index branch): an array facet field, the sort-index column of a range facet, the distinct ids of a grouped search; expectations = the oracle's walk
+    fptr = np.zeros(n_docs + 1, np.uint64)
+    fptr[1:] = np.cumsum(rng.integers(0, 4, size=n_docs))
+    fh = (rng.zipf(1.4, size=int(fptr[-1])) % 40).astype(np.uint32) * np.uint32(2654435761)
+    fvals = rng.integers(-500, 3000, size=n_docs).astype(np.int64)
+    forc = O.OracleIndex(1, 1)
+    forc.facet_set(0, fptr, fh)
+    with open(os.path.join(d, "facets.bin"), "wb") as f:
+        f.write(_u32(n_docs) + fptr.tobytes() + fh.tobytes() + fvals.tobytes() + distinct.astype(np.uint64).tobytes())
+        all_ids = np.arange(n_docs, dtype=np.uint32)
+        some = np.sort(rng.choice(n_docs, size=200, replace=False)).astype(np.uint32)
+        fq = np.unique(fh)[::3]
+        ranges = [(0, -400), (1000, 0), (1001, 1000), (2500, 1500)]
+        cases = [(all_ids, 1, None, 0, None), (some, 1, None, 0, None), (all_ids, 3, None, 0, None), (all_ids, 1, fq, 0, None), (all_ids, 1, np.zeros(0, np.uint32), 0, None),
+                 (all_ids, 1, None, 1, None), (some, 2, fq, 1, None), (all_ids, 1, None, 0, ranges), (some, 3, None, 0, ranges), (all_ids, 1, None, 1, ranges), (np.zeros(0, np.uint32), 1, None, 0, None)]
+        f.write(_u32(len(cases)))
+        for ids, mod, allowed, grouped, rngs in cases:
+            k, c, dd, p, nn = forc.facet_count_ex(0, ids, sample_mod=mod, allowed_hashes=allowed if (allowed is not None and allowed.size) else None, ranges=rngs, doc_vals=fvals if rngs else None,
+                                                  distinct_ids=distinct if grouped else None)
+            if allowed is not None and allowed.size == 0:
+                k, c, dd, p = k[:0], c[:0], dd[:0], p[:0]                         # a facet query that matched no value: nothing is counted (:1751)
+            f.write(_u32(ids.size) + ids.tobytes() + _u32(mod) + _u32(allowed is not None) + _u32(allowed.size if allowed is not None else 0) + (allowed.tobytes() if allowed is not None else b""))
+            f.write(_u32(grouped) + _u32(len(rngs) if rngs else 0) + b"".join(struct.pack("<qq", u, l) for u, l in (rngs or [])))
+            f.write(_u32(k.size) + b"".join(struct.pack("<QIII", int(a), int(b), int(x), int(y)) for a, b, x, y in zip(k, c, dd, p)))
     with open(os.path.join(d, "grouped_candidates.bin"), "wb") as f:
         f.write(_u32(n_docs) + has_value.astype(np.uint8).tobytes())
         ccases = [([[1, 2], [1, 3], [2, 3], [1, 2], [9999]], 30, 2, 1), ([[1, 2], [1, 3], [2, 3], [1, 2], [9999]], 30, 2, 0), ([[3], [4], [5]], 4, 3, 0), ([[3], [4], [5]], 4, 3, 1)]
