@@ -15,6 +15,7 @@ cd /tmp
 KW="python $ROOT/bench.py --workload keyword --no-cpu-baseline --no-extras --steps 3 --warmup 1"
 VEC="python $ROOT/bench.py --workload vector --no-cpu-baseline --no-extras --steps 3 --warmup 1"
 KWG="python $ROOT/bench.py --workload kwgeneral --no-cpu-baseline --steps 3 --warmup 1"     # two query_by fields + 10 candidate combinations per query (general kernels)
+if [ "${SKIP_PROF:-0}" != "1" ]; then          # SKIP_PROF=1: only the GPU tier, the smoke test and the bench line (the committed rocprof / PMC summaries stay)
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_kw -- $KW > $O/trace_kw.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_vec -- $VEC > $O/trace_vec.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_kwg -- $KWG > $O/trace_kwg.log 2>&1
@@ -31,8 +32,9 @@ python tools/pmc_summary.py $O/pmc_kw_fetch "kw_" > $P/pmc_kw_fetch.txt 2>&1
 python tools/pmc_summary.py $O/pmc_vec_fetch "vec_" > $P/pmc_vec_fetch.txt 2>&1
 python tools/pmc_summary.py $O/pmc_kw_sq1 "kw_" > $P/pmc_kw_sq1.txt 2>&1
 python tools/pmc_summary.py $O/pmc_kw_sq2 "kw_" > $P/pmc_kw_sq2.txt 2>&1
+fi
 # the bench reads the round's PMC summaries from profiles/<round>/ : put them there for THIS run, too
-mkdir -p profiles/$R && cp $P/pmc_*.txt profiles/$R/
+mkdir -p profiles/$R && { ls $P/pmc_*.txt > /dev/null 2>&1 && cp $P/pmc_*.txt profiles/$R/; }
 timeout 1500 python -m pytest tests -m gpu -x -q > $P/pytest_gpu_$TAG.txt 2>&1; tail -2 $P/pytest_gpu_$TAG.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $P/smoke_$TAG.txt 2>&1; tail -1 $P/smoke_$TAG.txt
 # (round 5: stdout = the compact line the driver parses; the full record = --detail-out; stderr carries a copy of it)
