@@ -33,6 +33,7 @@ python tools/pmc_summary.py $O/pmc_vec_fetch "vec_" > $P/pmc_vec_fetch.txt 2>&1
 python tools/pmc_summary.py $O/pmc_kw_sq1 "kw_" > $P/pmc_kw_sq1.txt 2>&1
 python tools/pmc_summary.py $O/pmc_kw_sq2 "kw_" > $P/pmc_kw_sq2.txt 2>&1
 fi
+cd $ROOT
 # the bench reads the round's PMC summaries from profiles/<round>/ : put them there for THIS run, too
 mkdir -p profiles/$R && { ls $P/pmc_*.txt > /dev/null 2>&1 && cp $P/pmc_*.txt profiles/$R/; }
 timeout 1500 python -m pytest tests -m gpu -x -q > $P/pytest_gpu_$TAG.txt 2>&1; tail -2 $P/pytest_gpu_$TAG.txt
