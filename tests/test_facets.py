@@ -279,6 +279,31 @@ def _run(lib, n_docs, n_values):
     g.close()
 
 
+def _sort_boundaries(lib):
+    """lists of exactly 0 / 1 / 2 / 4 095 / 4 096 (the device orders them) and 4 097 (the host does) distinct values, hashes with the top bit set, caps below and above"""
+    rng = np.random.default_rng(8)
+    n_docs = 4200
+    g = T.GpuIndex(0, lib)
+    orc = O.OracleIndex(1, 1)
+    hashes = rng.permutation(np.arange(n_docs, dtype=np.uint32) * np.uint32(1022117) + np.uint32(0x80000000))       # one value per document, all distinct
+    ptr = np.arange(n_docs + 1, dtype=np.uint64)
+    g.facet_set(0, ptr, hashes)
+    orc.facet_set(0, ptr, hashes)
+    lists = [np.arange(m, dtype=np.uint32) for m in (0, 1, 2, 4095, 4096, 4097, 4200)]
+    for cap in (1, 4096, 8192):
+        _check(g, orc, lists, cap=cap)
+    g.close()
+
+
+def test_facet_value_order_at_the_device_sort_boundaries_emulator():
+    _sort_boundaries(H.emu_lib_path())
+
+
+@pytest.mark.gpu
+def test_facet_value_order_at_the_device_sort_boundaries_gpu():
+    _sort_boundaries(H.gpu_lib_path())
+
+
 def test_facet_counts_match_oracle_emulator():
     _run(H.emu_lib_path(), 3000, 90)
 
