@@ -394,7 +394,9 @@ int tsgpu_keyword_search_grouped_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw
  *     ids at positions i % sample_mod == 0, :1683-1687); allowed_hashes (sorted, NULL = all) = fquery_hashes of a facet query (:1742).
  *     out: [n_queries][cap] in ascending hash order; n_values[q] = distinct values found (may exceed cap: the first cap are returned).
  * Facet stats (tsgpu_facet_stats_batch) and the value-index ("intersect") branch (tsgpu_facet_value_set / tsgpu_facet_value_count_batch) follow below.
- * Not covered (the caller keeps its CPU body): the facets' own group_by (hash_groups) and range facets. */
+ * The facets of a grouped search (hash_groups: tsgpu_facet_count_grouped_batch) and range facets (tsgpu_facet_range_count_batch) follow them.
+ * Left to the caller, being lookups by what these calls return: sort_field_val (the sort-index value of the returned doc_id, :1765-1767) and
+ * hash_tokens (fquery_hashes.at(hash), :1761-1764). */
 typedef struct tsgpu_facet_counts {
     uint32_t cap;            /* slots per query */
     uint32_t* hash;          /* [n_queries * cap] facet value hash */
