@@ -5,6 +5,8 @@
  * range facets: CollectionFacetingTest.RangeFacetTest (/root/reference/test/collection_faceting_test.cpp:1500-1590: `visitors` with
    Busy:[0, 200000], VeryBusy:[200000, 500000]; "Karnataka" = documents 0, 1 -> Busy 1, VeryBusy 1; "Gujarat" = document 4 -> VeryBusy 1)
    and CollectionFacetingTest.RangeFacetTestWithGroupBy (:3419-3524: "Karnataka" -> VeryBusy 2; q = * grouped by `rating` -> VeryBusy 2, Busy 1).
+ * float range facets: RangeFacetsFloatRange (:1839-1891), RangeFacetsMinMaxRange (:1893-1945: an open bound = INT64_MIN / INT64_MAX, src/collection.cpp:7547-7569)
+   and RangeFacetRangeNegativeRanges (:1986-2043); values and bounds as Index::float_to_int64_t keys (src/index.cpp:266-274), like the sort index holds them.
 Value hashes = crc32 of the value's string (any injective map works); the documents of the two range tests are inline in the tests."""
 import json
 import os
@@ -30,5 +32,23 @@ out = {"source": "test/group_documents.jsonl + test/collection_grouping_test.cpp
            "ranges": [[200000, 0], [500000, 200000]],
            "karnataka_ids": [0, 1], "karnataka_expected": [0, 2],
            "all_ids": [0, 1, 2, 3, 4], "all_grouped_expected": [1, 2]}}
+import struct
+I64_MIN, I64_MAX = -(1 << 63), (1 << 63) - 1
+
+
+def f2i(x):                                   # Index::float_to_int64_t (src/index.cpp:266-274)
+    i = struct.unpack("<i", struct.pack("<f", x))[0]
+    return i ^ 0x7FFFFFFF if i < 0 else i
+
+
+inches = [f2i(v) for v in (32.4, 55, 55.6)]
+nrr = [f2i(v) for v in (1.353, -0.193, -0.400, -0.969, -1.048, -1.248, -1.253, 1.481)]
+out["float_ranges"] = [
+    {"test": "RangeFacetsFloatRange small:[0, 55.5]", "vals": inches, "ranges": [[f2i(55.5), f2i(0.0)]], "expected": [2]},
+    {"test": "RangeFacetsFloatRange big:[55, 55.6]", "vals": inches, "ranges": [[f2i(55.6), f2i(55.0)]], "expected": [1]},
+    {"test": "RangeFacetsMinMaxRange small:[0, 55], large:[55, ]", "vals": inches, "ranges": [[f2i(55.0), f2i(0.0)], [I64_MAX, f2i(55.0)]], "expected": [1, 2]},
+    {"test": "RangeFacetsMinMaxRange small:[,55]", "vals": inches, "ranges": [[f2i(55.0), I64_MIN]], "expected": [1]},
+    {"test": "RangeFacetRangeNegativeRanges poor:[-1.5,-1], decent:[-1,0], good:[0,2]", "vals": nrr,
+     "ranges": [[f2i(-1.0), f2i(-1.5)], [f2i(0.0), f2i(-1.0)], [f2i(2.0), f2i(0.0)]], "expected": [3, 3, 2]}]
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "facet_group_range.json"), "w"), indent=1)
 print(len(docs), "documents")

@@ -84,6 +84,43 @@ def test_oracle_reproduces_reference_grouped_and_range_facet_counts():
             assert counts(r["all_ids"], distinct_ids=distinct) == r["all_grouped_expected"]
 
 
+def _float_range_cases():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "facet_group_range.json")))["float_ranges"]
+
+
+def test_oracle_reproduces_reference_float_and_open_ended_range_facets():
+    """RangeFacetsFloatRange / RangeFacetsMinMaxRange / RangeFacetRangeNegativeRanges (collection_faceting_test.cpp:1839-2043): float_to_int64_t keys, open bounds"""
+    orc = O.OracleIndex(1, 1)
+    for case in _float_range_cases():
+        n = len(case["vals"])
+        orc.facet_set(0, *_csr([[i + 1] for i in range(n)]))
+        ranges = [tuple(x) for x in case["ranges"]]
+        k, c, d, p, nn = orc.facet_count_ex(0, np.arange(n, dtype=np.uint32), ranges=ranges, doc_vals=np.array(case["vals"], np.int64))
+        m = {int(a): int(b) for a, b in zip(k.view(np.int64), c)}
+        assert [m.get(up, 0) for up, lo in ranges] == case["expected"], case["test"]
+
+
+def _float_ranges_product(lib):
+    g = T.GpuIndex(0, lib)
+    for case in _float_range_cases():
+        n = len(case["vals"])
+        g.set_num_docs(n)
+        g.facet_set(0, *_csr([[i + 1] for i in range(n)]))
+        g.column_set(3, np.array(case["vals"], np.int64))
+        got = g.facet_range_count_batch(0, 3, [tuple(x) for x in case["ranges"]], [np.arange(n, dtype=np.uint32)])
+        assert got[0].tolist() == case["expected"], case["test"]
+    g.close()
+
+
+def test_product_reproduces_reference_float_and_open_ended_range_facets_emulator():
+    _float_ranges_product(H.emu_lib_path())
+
+
+@pytest.mark.gpu
+def test_product_reproduces_reference_float_and_open_ended_range_facets_gpu():
+    _float_ranges_product(H.gpu_lib_path())
+
+
 def _grouped_and_ranges(lib, n_docs, n_values, seed=5):
     """the grouped and the range forms of the walk, product vs oracle: array and scalar fields, sampling, facet query, missing sort-index entries,
     few and many groups, distinct ids that differ only above bit 32, range ids that agree in their low 32 bits"""
