@@ -31,7 +31,7 @@ struct FacetField {
 // the id lists of a call -> the id arena (d_ids reserved by the caller). Many small lists (a keyword batch's per-query ids) are packed into one pinned block
 // and cross in ONE copy (1 000 lists: 1 000 copies of ~7 KB cost ~10 ms before); a single list, or lists of megabytes, go straight from the caller's memory.
 static int facet_upload_ids(FacetField* f, const std::vector<FacetQueryDev>& qd, const uint32_t* const* result_ids, uint32_t n_queries, uint64_t ids_total, hipStream_t s) {
-    if (n_queries > 1 && ids_total && ids_total / n_queries < (256u << 10)) {
+    if (n_queries > 1 && ids_total && ids_total / n_queries < (256u << 10) && ids_total <= (64u << 20)) {        // (at most 256 MB of pinned staging)
         int rc = f->h_in.reserve(ids_total * 4);
         if (rc) return rc;
         // (every facet call ends with a stream synchronisation under ctx->mu: the block is not feeding an earlier copy any more)

@@ -371,8 +371,8 @@ class GpuIndex:
         ptrs = (C.c_void_p * n)(*[x.ctypes.data if x.size else None for x in lists])
         cnts = np.array([x.size for x in lists], np.uint64)
         out = B.FacetCountsC()
-        h, c, d, p, nv = (np.zeros((n, cap), np.uint32) for _ in range(4)) if False else (np.zeros((n, cap), np.uint32), np.zeros((n, cap), np.uint32),
-                                                                                          np.zeros((n, cap), np.uint32), np.zeros((n, cap), np.uint32), np.zeros(n, np.uint32))
+        h, c, d, p = (np.empty((n, cap), np.uint32) for _ in range(4))              # (only the first n_values[q] entries of a row are written and returned)
+        nv = np.zeros(n, np.uint32)
         out.cap, out.hash, out.count, out.doc_id, out.array_pos, out.n_values = cap, h.ctypes.data, c.ctypes.data, d.ctypes.data, p.ctypes.data, nv.ctypes.data
         a = None if allowed_hashes is None else _u32(allowed_hashes)
         if group_column is None:
