@@ -364,3 +364,46 @@ def test_facets_over_the_id_lists_of_a_keyword_batch():
         assert np.array_equal(ids[i], H.oracle_keyword(orc, q, ids_cap=30000).result_ids)
     _check(g, orc, ids)
     g.close()
+
+
+def test_random_facet_walks_match_oracle_emulator():
+    """randomized cases (seeded): tiny to mid-size indexes with empty documents, repeated hashes, ids beyond the index, every option combination of the walk —
+    plain, grouped and range forms against the oracle"""
+    rng = np.random.default_rng(2024)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    orc = O.OracleIndex(1, 1)
+    for case in range(40):
+        n_docs = int(rng.integers(1, 700))
+        g.set_num_docs(n_docs)
+        per = rng.integers(0, 6, size=n_docs) * (rng.random(n_docs) < 0.8)
+        ptr = np.zeros(n_docs + 1, np.uint64)
+        ptr[1:] = np.cumsum(per)
+        n_val = int(rng.choice([1, 2, 5, 50, 5000]))
+        hashes = rng.integers(0, n_val, size=int(ptr[-1])).astype(np.uint32) * np.uint32(0x9E3779B1) + np.uint32(rng.integers(0, 2)) * np.uint32(0xFFFFFFFF)
+        g.facet_set(0, ptr, hashes)
+        orc.facet_set(0, ptr, hashes)
+        lists = [np.sort(rng.choice(n_docs + 30, size=int(rng.integers(0, n_docs + 30)), replace=False)).astype(np.uint32) for _ in range(int(rng.integers(1, 5)))]
+        mod = int(rng.choice([1, 1, 2, 5]))
+        allowed = np.unique(rng.choice(hashes, size=max(1, hashes.size // 3))) if (hashes.size and rng.random() < 0.4) else None
+        short = int(rng.integers(0, min(n_docs, 20)))
+        distinct = rng.integers(0, int(rng.choice([1, 3, 1000])), size=n_docs - short).astype(np.uint64) + (np.uint64(1) << np.uint64(int(rng.integers(0, 40))))
+        vals = rng.integers(-50, 50, size=n_docs - int(rng.integers(0, min(n_docs, 10)))).astype(np.int64)
+        g.column_set(2, distinct.view(np.int64))
+        g.column_set(3, vals)
+        gmv = bool(rng.integers(0, 2))
+        cap = int(rng.choice([1, 7, 8192]))
+        _check(g, orc, lists, cap=cap, sample_mod=mod, allowed_hashes=allowed)
+        got = g.facet_count_batch(0, lists, cap=8192, sample_mod=mod, allowed_hashes=allowed, group_column=2, group_missing_values=gmv)
+        edges = np.unique(rng.integers(-60, 60, size=int(rng.integers(1, 6))))
+        ranges = [(int(edges[i]), int(edges[i - 1]) if i and rng.random() < 0.8 else int(edges[i]) - int(rng.integers(1, 30))) for i in range(edges.size)]
+        rc = g.facet_range_count_batch(0, 3, ranges, lists, sample_mod=mod)
+        rg = g.facet_range_count_batch(0, 3, ranges, lists, sample_mod=mod, group_column=2, group_missing_values=gmv)
+        for q, ids in enumerate(lists):
+            k, c, d, p, n = orc.facet_count_ex(0, ids, sample_mod=mod, allowed_hashes=allowed, distinct_ids=distinct, group_missing_values=gmv)
+            gh, gc, gd, gp, gn = got[q]
+            assert gn == n and np.array_equal(gh, k.astype(np.uint32)) and np.array_equal(gc, c) and np.array_equal(gd, d) and np.array_equal(gp, p), (case, q)
+            for grouped, res in ((False, rc), (True, rg)):
+                k, c, d, p, n = orc.facet_count_ex(0, ids, sample_mod=mod, ranges=ranges, doc_vals=vals, distinct_ids=distinct if grouped else None, group_missing_values=gmv)
+                m = {int(a): int(b) for a, b in zip(k.view(np.int64), c)}
+                assert [m.get(up, 0) for up, lo in ranges] == res[q].tolist(), (case, q, grouped, ranges)
+    g.close()
