@@ -18,9 +18,12 @@ out = {"source": "test/group_documents.jsonl + test/collection_grouping_test.cpp
        "grouping_basics": {
            "brand_hashes": [[h(d["brand"])] if "brand" in d else [] for d in docs],
            "brand_values": {b: h(b) for b in sorted({d["brand"] for d in docs if "brand" in d})},
-           "size_hashes": [[h(d["size"])] for d in docs],                # the group_by field's facet hashes: distinct id = hash_combine(1, hash)
+           "size_hashes": [[d["size"]] for d in docs],                   # the group_by field's facet hashes — an int32 field's hash IS its value (src/index.cpp:1733) —: distinct id = hash_combine(1, hash), the reference's own ids
            "result_ids": list(range(len(docs))),
-           "expected_grouped": {"Beta": 3, "Omega": 3, "Xorp": 2, "Zeta": 1}},
+           "expected_grouped": {"Beta": 3, "Omega": 3, "Xorp": 2, "Zeta": 1},
+           # the grouped hits of the same request (:76-96; group_limit 2, default_sorting_field rating): found_docs 12, found 3, groups in this order
+           "rating_keys": None,
+           "expected_groups": [{"size": 11, "found": 2, "hits": [5, 1]}, {"size": 10, "found": 7, "hits": [4, 3]}, {"size": 12, "found": 3, "hits": [2, 8]}]},
        "range_facet_test": {
            "visitors": [235486, 187654, 174684, 246676, 345878],
            "ranges": [[200000, 0], [500000, 200000]],                     # (upper, lower): Busy, VeryBusy
@@ -50,5 +53,7 @@ out["float_ranges"] = [
     {"test": "RangeFacetsMinMaxRange small:[,55]", "vals": inches, "ranges": [[f2i(55.0), I64_MIN]], "expected": [1]},
     {"test": "RangeFacetRangeNegativeRanges poor:[-1.5,-1], decent:[-1,0], good:[0,2]", "vals": nrr,
      "ranges": [[f2i(-1.0), f2i(-1.5)], [f2i(0.0), f2i(-1.0)], [f2i(2.0), f2i(0.0)]], "expected": [3, 3, 2]}]
+out["grouping_basics"]["rating_keys"] = [f2i(d["rating"]) for d in docs]
+out["grouping_basics"]["sizes"] = [d["size"] for d in docs]
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "facet_group_range.json"), "w"), indent=1)
 print(len(docs), "documents")

@@ -407,3 +407,32 @@ def test_grouped_candidate_combinations_fold_like_the_shared_collector(world, fi
                 n = int(ref.group_size[r])
                 assert np.array_equal(qidx[u, r * limit:r * limit + n], rqi[ref.begin[r]:ref.begin[r + 1]].astype(np.uint32)), (u, r)
     assert int(gh.n_groups[3]) == 0 and int(gh.n_groups[0]) > 5
+
+
+def _grouping_basics_product(lib):
+    """CollectionGroupingTest.GroupingBasics (/root/reference/test/collection_grouping_test.cpp:71-96) through the library: q = *, group_by size, group_limit 2,
+    sort rating desc: found_docs 12, found 3; groups 11 / 10 / 12 with 2 / 7 / 3 documents and the hits 5,1 / 4,3 / 2,8"""
+    import json, os
+    from tests.test_oracle_groupby import _grouping_basics
+    fx, n, distinct = _grouping_basics()
+    g = T.GpuIndex(0, lib)
+    g.set_num_docs(n)
+    g.field_create(0, False)
+    g.commit()
+    g.column_set(0, np.array(fx["rating_keys"], np.int64))
+    g.column_set(1, distinct.view(np.int64))
+    wq = T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0),), topster_size=250)
+    h, gh = g.keyword_search_grouped_batch([wq], [(2, 1, 0, 0, 1)], k_stride=500, g_stride=250)
+    assert int(h.status[0]) == 0 and int(h.num_matched[0]) == 12 and int(gh.n_groups[0]) == 3
+    for r, e in enumerate(fx["expected_groups"]):
+        assert int(gh.group_found[0, r]) == e["found"] and int(gh.group_size[0, r]) == len(e["hits"])
+        assert h.keys[0, r * 2:r * 2 + 2].tolist() == e["hits"]
+    h1, g1 = g.keyword_search_grouped_batch([wq], [(2, 1, 1, 0, 1)], k_stride=250, g_stride=250)
+    assert int(g1.n_groups[0]) == 3 and sorted(h1.keys[0, :3].tolist()) == [2, 4, 5]
+    # getGroupsCount() = LogLogBeta's truncated estimate (2 for these keys, from the reference's own Topster too); `found` = max(it, groups returned) = 3 (src/index.cpp:2766-2770)
+    assert int(g1.groups_count[0]) == 2 and max(int(g1.groups_count[0]), int(gh.n_groups[0])) == 3
+    g.close()
+
+
+def test_grouping_basics_known_answer_through_the_library():
+    _grouping_basics_product(H.emu_lib_path())

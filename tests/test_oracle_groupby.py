@@ -117,3 +117,33 @@ def test_group_topster_golden_file():
         assert [int(x) for x in g.keys] == case["out_keys"]
         if case["first_pass"]:
             assert g.groups_count == case["groups_count"]
+
+
+def _grouping_basics():
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "facet_group_range.json")))["grouping_basics"]
+    n = len(fx["sizes"])
+    ptr = np.arange(n + 1, dtype=np.uint64)
+    distinct = O.distinct_ids(n, [(ptr, np.array([h[0] for h in fx["size_hashes"]], np.uint32))], False)[0]
+    return fx, n, distinct
+
+
+def test_grouping_basics_known_answer_of_the_reference():
+    """CollectionGroupingTest.GroupingBasics (/root/reference/test/collection_grouping_test.cpp:71-96): q = *, group_by size, group_limit 2, default sort (rating desc):
+    three groups in the order 11, 10, 12 with the hits 5,1 / 4,3 / 2,8 — the restated distinct Topster's second pass + populate_result_kvs order"""
+    fx, n, distinct = _grouping_basics()
+    sc = np.zeros((n, 3), np.int64)
+    sc[:, 0] = fx["rating_keys"]
+    ret, gh = O.group_topster_run(250, 2, False, np.arange(n, dtype=np.uint64), distinct, sc)
+    assert gh.n_groups == len(fx["expected_groups"])
+    for r, e in enumerate(fx["expected_groups"]):
+        a, b = int(gh.begin[r]), int(gh.begin[r + 1])
+        assert gh.keys[a:b].tolist() == e["hits"], (r, gh.keys[a:b])
+        assert {fx["sizes"][int(k)] for k in gh.keys[a:b]} == {e["size"]}
+    # first pass: one KV per group (its greatest). getGroupsCount() is LogLogBeta's TRUNCATED estimate — 2 for these three keys, from the reference's own Topster
+    # too —; the response's `found` = max(that, groups returned) (Index::run_search, src/index.cpp:2766-2770) = 3, as the test asserts (:74)
+    ret, g1 = O.group_topster_run(250, 2, True, np.arange(n, dtype=np.uint64), distinct, sc)
+    assert sorted(g1.keys.tolist()) == sorted(e["hits"][0] for e in fx["expected_groups"])
+    assert g1.groups_count == 2 and max(g1.groups_count, gh.n_groups) == 3
+    R = O.ref_topster_lib()
+    if R is not None:
+        assert O.ref_group_topster_run(R, 250, 2, True, np.arange(n, dtype=np.uint64), distinct, sc)[-1] == 2
