@@ -55,5 +55,10 @@ out["float_ranges"] = [
      "ranges": [[f2i(-1.0), f2i(-1.5)], [f2i(0.0), f2i(-1.0)], [f2i(2.0), f2i(0.0)]], "expected": [3, 3, 2]}]
 out["grouping_basics"]["rating_keys"] = [f2i(d["rating"]) for d in docs]
 out["grouping_basics"]["sizes"] = [d["size"] for d in docs]
+# the second request of GroupingBasics (:112-148): group_by rating (a float field's facet hash = the float's bits, src/index.cpp:791), sort_by size DESC, group_limit 2:
+# found_docs 12, found 7, seven groups; the test asserts groups 0, 1, 5 and 6
+out["grouping_basics"]["rating_hashes"] = [[struct.unpack("<I", struct.pack("<f", d["rating"]))[0]] for d in docs]
+out["grouping_basics"]["by_rating_expected"] = {"n_groups": 7, "groups": {"0": {"found": 1, "hits": [8]}, "1": {"found": 4, "hits": [6, 1]},
+                                                                       "5": {"found": 1, "hits": [9]}, "6": {"found": 1, "hits": [0]}}}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "facet_group_range.json"), "w"), indent=1)
 print(len(docs), "documents")

@@ -431,6 +431,18 @@ def _grouping_basics_product(lib):
     assert int(g1.n_groups[0]) == 3 and sorted(h1.keys[0, :3].tolist()) == [2, 4, 5]
     # getGroupsCount() = LogLogBeta's truncated estimate (2 for these keys, from the reference's own Topster too); `found` = max(it, groups returned) = 3 (src/index.cpp:2766-2770)
     assert int(g1.groups_count[0]) == 2 and max(int(g1.groups_count[0]), int(gh.n_groups[0])) == 3
+    # the second request (:112-148): group_by rating, sort_by size DESC -> 7 groups, groups 0 / 1 / 5 / 6 as the test asserts them
+    from tests.test_oracle_groupby import _by_rating
+    fx, n, by_rating = _by_rating()
+    g.column_set(2, np.array(fx["sizes"], np.int64))
+    g.column_set(3, by_rating.view(np.int64))
+    wq = T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 2),), topster_size=250)
+    h, gh = g.keyword_search_grouped_batch([wq], [(2, 3, 0, 0, 1)], k_stride=500, g_stride=250)
+    e = fx["by_rating_expected"]
+    assert int(h.num_matched[0]) == 12 and int(gh.n_groups[0]) == e["n_groups"]
+    for r, want in e["groups"].items():
+        r = int(r)
+        assert int(gh.group_found[0, r]) == want["found"] and h.keys[0, r * 2:r * 2 + int(gh.group_size[0, r])].tolist() == want["hits"]
     g.close()
 
 

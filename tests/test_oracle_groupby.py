@@ -147,3 +147,24 @@ def test_grouping_basics_known_answer_of_the_reference():
     R = O.ref_topster_lib()
     if R is not None:
         assert O.ref_group_topster_run(R, 250, 2, True, np.arange(n, dtype=np.uint64), distinct, sc)[-1] == 2
+
+
+def _by_rating():
+    fx, n, _ = _grouping_basics()
+    ptr = np.arange(n + 1, dtype=np.uint64)
+    distinct = O.distinct_ids(n, [(ptr, np.array([h[0] for h in fx["rating_hashes"]], np.uint32))], False)[0]
+    return fx, n, distinct
+
+
+def test_grouping_basics_by_rating_known_answer_of_the_reference():
+    """the second request of GroupingBasics (collection_grouping_test.cpp:112-148): group_by rating, sort_by size DESC, group_limit 2 -> 7 groups; groups 0, 1, 5, 6 as asserted there"""
+    fx, n, distinct = _by_rating()
+    sc = np.zeros((n, 3), np.int64)
+    sc[:, 0] = fx["sizes"]
+    ret, gh = O.group_topster_run(250, 2, False, np.arange(n, dtype=np.uint64), distinct, sc)
+    e = fx["by_rating_expected"]
+    assert gh.n_groups == e["n_groups"]
+    for r, want in e["groups"].items():
+        a, b = int(gh.begin[int(r)]), int(gh.begin[int(r) + 1])
+        assert gh.keys[a:b].tolist() == want["hits"], (r, gh.keys[a:b])
+
