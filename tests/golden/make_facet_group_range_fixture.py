@@ -60,5 +60,15 @@ out["grouping_basics"]["sizes"] = [d["size"] for d in docs]
 out["grouping_basics"]["rating_hashes"] = [[struct.unpack("<I", struct.pack("<f", d["rating"]))[0]] for d in docs]
 out["grouping_basics"]["by_rating_expected"] = {"n_groups": 7, "groups": {"0": {"found": 1, "hits": [8]}, "1": {"found": 4, "hits": [6, 1]},
                                                                        "5": {"found": 1, "hits": [9]}, "6": {"found": 1, "hits": [0]}}}
+# CollectionGroupingTest.GroupingCompoundKey (:150-215): group_by size + brand (brand is optional: documents 10 and 11 have none; group_missing_values = true keeps them in the
+# group of their size alone), group_limit 2, default sort (rating desc): found_docs 12, found 10; groups 0, 1, 2 and 5 as asserted; facet counts of `brand` = groups per brand.
+# A string field's facet ids are handed out in order of first appearance (++next_facet_id, src/facet_index.cpp:38-41): Omega 1, Beta 2, Xorp 3, Zeta 4.
+brand_ids = {}
+for d in docs:
+    if "brand" in d and d["brand"] not in brand_ids:
+        brand_ids[d["brand"]] = len(brand_ids) + 1
+out["compound_key"] = {"brand_ids": brand_ids, "brand_hashes": [[brand_ids[d["brand"]]] if "brand" in d else [] for d in docs],
+                       "n_groups": 10, "groups": {"0": {"found": 1, "hits": [5]}, "1": {"found": 1, "hits": [4]}, "2": {"found": 2, "hits": [3, 0]}, "5": {"found": 2, "hits": [10, 11]}},
+                       "expected_grouped_facets": {"Beta": 3, "Omega": 3, "Xorp": 2, "Zeta": 1}}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "facet_group_range.json"), "w"), indent=1)
 print(len(docs), "documents")

@@ -443,6 +443,20 @@ def _grouping_basics_product(lib):
     for r, want in e["groups"].items():
         r = int(r)
         assert int(gh.group_found[0, r]) == want["found"] and h.keys[0, r * 2:r * 2 + int(gh.group_size[0, r])].tolist() == want["hits"]
+    # CollectionGroupingTest.GroupingCompoundKey (:150-215): group_by size + brand (optional), 10 groups, and the brand facet counted by groups
+    from tests.test_oracle_groupby import _compound_key
+    fx, ck, n, compound, brand = _compound_key()
+    g.column_set(4, compound.view(np.int64))
+    wq = T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0),), topster_size=250)
+    h, gh = g.keyword_search_grouped_batch([wq], [(2, 4, 0, 1, 1)], k_stride=500, g_stride=250)
+    assert int(h.num_matched[0]) == 12 and int(gh.n_groups[0]) == ck["n_groups"]
+    for r, want in ck["groups"].items():
+        r = int(r)
+        assert int(gh.group_found[0, r]) == want["found"] and h.keys[0, r * 2:r * 2 + int(gh.group_size[0, r])].tolist() == want["hits"]
+    g.facet_set(0, *brand)
+    fh, fc, fd, fp, fn = g.facet_count_batch(0, [np.arange(n, dtype=np.uint32)], group_column=4, group_missing_values=True)[0]
+    got = {int(a): int(b) for a, b in zip(fh, fc)}
+    assert {name: got[i] for name, i in ck["brand_ids"].items()} == ck["expected_grouped_facets"]
     g.close()
 
 

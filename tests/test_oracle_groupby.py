@@ -168,3 +168,32 @@ def test_grouping_basics_by_rating_known_answer_of_the_reference():
         a, b = int(gh.begin[int(r)]), int(gh.begin[int(r) + 1])
         assert gh.keys[a:b].tolist() == want["hits"], (r, gh.keys[a:b])
 
+
+def _compound_key():
+    fx, n, _ = _grouping_basics()
+    ck = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "facet_group_range.json")))["compound_key"]
+    ptr = np.arange(n + 1, dtype=np.uint64)
+    bptr = np.zeros(n + 1, np.uint64)
+    bptr[1:] = np.cumsum([len(h) for h in ck["brand_hashes"]])
+    brand = (bptr, np.array([h[0] for h in ck["brand_hashes"] if h], np.uint32))
+    distinct, has_value = O.distinct_ids(n, [(ptr, np.array([h[0] for h in fx["size_hashes"]], np.uint32)), brand], True)      # group_missing_values = true (the request's default)
+    return fx, ck, n, distinct, brand
+
+
+def test_grouping_compound_key_known_answer_of_the_reference():
+    """CollectionGroupingTest.GroupingCompoundKey (collection_grouping_test.cpp:150-215): group_by size + brand with an optional brand -> 10 groups; groups 0, 1, 2, 5 as asserted;
+    the facet counts of `brand` under that grouping"""
+    fx, ck, n, distinct, brand = _compound_key()
+    sc = np.zeros((n, 3), np.int64)
+    sc[:, 0] = fx["rating_keys"]
+    ret, gh = O.group_topster_run(250, 2, False, np.arange(n, dtype=np.uint64), distinct, sc)
+    assert gh.n_groups == ck["n_groups"]
+    for r, want in ck["groups"].items():
+        a, b = int(gh.begin[int(r)]), int(gh.begin[int(r) + 1])
+        assert gh.keys[a:b].tolist() == want["hits"], (r, gh.keys[a:b])
+    orc = O.OracleIndex(1, 1)
+    orc.facet_set(0, *brand)
+    k, c, d, p, nn = orc.facet_count_ex(0, np.arange(n, dtype=np.uint32), distinct_ids=distinct, group_missing_values=True)
+    got = {int(a): int(b) for a, b in zip(k, c)}
+    assert {name: got[i] for name, i in ck["brand_ids"].items()} == ck["expected_grouped_facets"]
+
