@@ -70,5 +70,14 @@ for d in docs:
 out["compound_key"] = {"brand_ids": brand_ids, "brand_hashes": [[brand_ids[d["brand"]]] if "brand" in d else [] for d in docs],
                        "n_groups": 10, "groups": {"0": {"found": 1, "hits": [5]}, "1": {"found": 1, "hits": [4]}, "2": {"found": 2, "hits": [3, 0]}, "5": {"found": 2, "hits": [10, 11]}},
                        "expected_grouped_facets": {"Beta": 3, "Omega": 3, "Xorp": 2, "Zeta": 1}}
+# CollectionGroupingTest.GroupingWithGropLimitOfOne (:372-411): group_by brand (optional; the two unbranded documents form ONE group under the default group_missing_values = true),
+# group_limit 1: found_docs 12, found 5; every brand's facet count is 1 (one group each).
+out["group_limit_of_one"] = {"n_groups": 5, "groups": [{"found": 3, "hits": [5]}, {"found": 4, "hits": [3]}, {"found": 2, "hits": [8]}, {"found": 2, "hits": [10]}, {"found": 1, "hits": [9]}],
+                             "expected_grouped_facets": {"Beta": 1, "Omega": 1, "Xorp": 1, "Zeta": 1}}
+# CollectionGroupingTest.ControlMissingValues (:646-715): four documents, brand = Omega, null, null, Omega; no sort field (order = seq_id desc); group_limit 2.
+# group_missing_values = false: three groups — Omega (3, 0), then documents 2 and 1 on their own; true (the default): two groups — Omega (3, 0) and the missing ones (2, 1)
+out["control_missing_values"] = {"brand_hashes": [[1], [], [], [1]],
+                                 "gmv_false": [{"hits": [3, 0]}, {"hits": [2]}, {"hits": [1]}],
+                                 "gmv_true": [{"hits": [3, 0]}, {"hits": [2, 1]}]}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "facet_group_range.json"), "w"), indent=1)
 print(len(docs), "documents")

@@ -457,6 +457,35 @@ def _grouping_basics_product(lib):
     fh, fc, fd, fp, fn = g.facet_count_batch(0, [np.arange(n, dtype=np.uint32)], group_column=4, group_missing_values=True)[0]
     got = {int(a): int(b) for a, b in zip(fh, fc)}
     assert {name: got[i] for name, i in ck["brand_ids"].items()} == ck["expected_grouped_facets"]
+    # GroupingWithGropLimitOfOne (:372-411): group_by brand (optional), group_limit 1 -> 5 groups, every brand counted once
+    from tests.test_oracle_groupby import _by_brand, _fixture
+    one = _fixture()["group_limit_of_one"]
+    fx, ck, n, by_brand, brand = _by_brand(True)
+    g.column_set(5, by_brand.view(np.int64))
+    h, gh = g.keyword_search_grouped_batch([wq], [(1, 5, 0, 1, 1)], k_stride=250, g_stride=250)
+    assert int(gh.n_groups[0]) == one["n_groups"]
+    for r, want in enumerate(one["groups"]):
+        assert int(gh.group_found[0, r]) == want["found"] and int(gh.group_size[0, r]) == 1 and [int(h.keys[0, r])] == want["hits"]
+    fh, fc, fd, fp, fn = g.facet_count_batch(0, [np.arange(n, dtype=np.uint32)], group_column=5, group_missing_values=True)[0]
+    got = {int(a): int(b) for a, b in zip(fh, fc)}
+    assert {name: got[i] for name, i in ck["brand_ids"].items()} == one["expected_grouped_facets"]
+    g.close()
+    # ControlMissingValues (:646-715): four documents, two without a brand; no sort field (the greater seq_id first)
+    cm = _fixture()["control_missing_values"]
+    bptr = np.zeros(5, np.uint64)
+    bptr[1:] = np.cumsum([len(x) for x in cm["brand_hashes"]])
+    bh = np.array([x[0] for x in cm["brand_hashes"] if x], np.uint32)
+    g = T.GpuIndex(0, lib)
+    g.set_num_docs(4)
+    g.field_create(0, False)
+    g.commit()
+    wq = T.KwQuery([], sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=250)
+    for gmv, key in ((False, "gmv_false"), (True, "gmv_true")):
+        g.column_set(1, O.distinct_ids(4, [(bptr, bh)], gmv)[0].view(np.int64))
+        h, gh = g.keyword_search_grouped_batch([wq], [(2, 1, 0, int(gmv), 1)], k_stride=500, g_stride=250)
+        assert int(gh.n_groups[0]) == len(cm[key])
+        for r, want in enumerate(cm[key]):
+            assert h.keys[0, r * 2:r * 2 + int(gh.group_size[0, r])].tolist() == want["hits"], (gmv, r)
     g.close()
 
 

@@ -197,3 +197,40 @@ def test_grouping_compound_key_known_answer_of_the_reference():
     got = {int(a): int(b) for a, b in zip(k, c)}
     assert {name: got[i] for name, i in ck["brand_ids"].items()} == ck["expected_grouped_facets"]
 
+
+def _fixture():
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "facet_group_range.json")))
+
+
+def _by_brand(gmv=True):
+    fx, ck, n, _, brand = _compound_key()
+    distinct, has_value = O.distinct_ids(n, [brand], gmv)
+    return fx, ck, n, distinct, brand
+
+
+def test_group_limit_of_one_and_control_missing_values_known_answers_of_the_reference():
+    """CollectionGroupingTest.GroupingWithGropLimitOfOne (collection_grouping_test.cpp:372-411) and ControlMissingValues (:646-715)"""
+    one = _fixture()["group_limit_of_one"]
+    fx, ck, n, distinct, brand = _by_brand(True)
+    sc = np.zeros((n, 3), np.int64)
+    sc[:, 0] = fx["rating_keys"]
+    ret, gh = O.group_topster_run(250, 1, False, np.arange(n, dtype=np.uint64), distinct, sc)
+    assert gh.n_groups == one["n_groups"]
+    for r, want in enumerate(one["groups"]):
+        assert gh.keys[int(gh.begin[r]):int(gh.begin[r + 1])].tolist() == want["hits"]
+    orc = O.OracleIndex(1, 1)
+    orc.facet_set(0, *brand)
+    k, c, d, p, nn = orc.facet_count_ex(0, np.arange(n, dtype=np.uint32), distinct_ids=distinct, group_missing_values=True)
+    got = {int(a): int(b) for a, b in zip(k, c)}
+    assert {name: got[i] for name, i in ck["brand_ids"].items()} == one["expected_grouped_facets"]
+    cm = _fixture()["control_missing_values"]
+    bptr = np.zeros(5, np.uint64)
+    bptr[1:] = np.cumsum([len(h) for h in cm["brand_hashes"]])
+    bh = np.array([h[0] for h in cm["brand_hashes"] if h], np.uint32)
+    for gmv, key in ((False, "gmv_false"), (True, "gmv_true")):
+        distinct = O.distinct_ids(4, [(bptr, bh)], gmv)[0]
+        ret, gh = O.group_topster_run(250, 2, False, np.arange(4, dtype=np.uint64), distinct, np.zeros((4, 3), np.int64))       # equal scores: the greater seq_id first
+        assert gh.n_groups == len(cm[key])
+        for r, want in enumerate(cm[key]):
+            assert gh.keys[int(gh.begin[r]):int(gh.begin[r + 1])].tolist() == want["hits"], (gmv, r)
+
