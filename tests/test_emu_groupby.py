@@ -489,5 +489,28 @@ def _grouping_basics_product(lib):
     g.close()
 
 
+def _group_order_product(lib):
+    """GroupOrderIndependence / UseHighestValueInGroupForOrdering (collection_grouping_test.cpp:510-613) through the library: both passes"""
+    from tests.test_oracle_groupby import order_cases
+    for name, pts, grp, first_hits in order_cases():
+        n = len(pts)
+        g = T.GpuIndex(0, lib)
+        g.set_num_docs(n)
+        g.field_create(0, False)
+        g.commit()
+        g.column_set(0, np.array(pts, np.int64))
+        g.column_set(1, O.distinct_ids(n, [(np.arange(n + 1, dtype=np.uint64), np.array(grp, np.uint32))], True)[0].view(np.int64))
+        wq = T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0),), topster_size=250)
+        h, gh = g.keyword_search_grouped_batch([wq], [(10, 1, 0, 1, 1)], k_stride=2500, g_stride=250)
+        assert int(gh.n_groups[0]) == 250 and h.keys[0, :int(gh.group_size[0, 0])].tolist() == first_hits, name
+        h1, g1 = g.keyword_search_grouped_batch([wq], [(10, 1, 1, 1, 1)], k_stride=250, g_stride=250)
+        assert int(g1.n_groups[0]) == 250 and first_hits[0] in h1.keys[0, :250].tolist(), name
+        g.close()
+
+
+def test_group_order_known_answers_through_the_library():
+    _group_order_product(H.emu_lib_path())
+
+
 def test_grouping_basics_known_answer_through_the_library():
     _grouping_basics_product(H.emu_lib_path())

@@ -234,3 +234,26 @@ def test_group_limit_of_one_and_control_missing_values_known_answers_of_the_refe
         for r, want in enumerate(cm[key]):
             assert gh.keys[int(gh.begin[r]):int(gh.begin[r + 1])].tolist() == want["hits"], (gmv, r)
 
+
+def order_cases():
+    """GroupOrderIndependence (collection_grouping_test.cpp:510-561) and UseHighestValueInGroupForOrdering (:563-613): more groups than the Topster holds (250),
+    sort_by points DESC, group_limit 10 — (points, facet id of `group` per document (handed out in order of first appearance), expected first group's hits)"""
+    a_pts = [100 + i for i in range(256)] + [50, 500]
+    a_grp = [i + 1 for i in range(256)] + [257, 257]
+    b_pts = [100 + i for i in range(250)] + [50, 60]
+    b_grp = [i + 1 for i in range(250)] + [250, 251]
+    return [("GroupOrderIndependence", a_pts, a_grp, [257, 256]), ("UseHighestValueInGroupForOrdering", b_pts, b_grp, [249, 250])]
+
+
+def test_group_order_known_answers_of_the_reference():
+    for name, pts, grp, first_hits in order_cases():
+        n = len(pts)
+        distinct = O.distinct_ids(n, [(np.arange(n + 1, dtype=np.uint64), np.array(grp, np.uint32))], True)[0]
+        sc = np.zeros((n, 3), np.int64)
+        sc[:, 0] = pts
+        ret, gh = O.group_topster_run(250, 10, False, np.arange(n, dtype=np.uint64), distinct, sc)
+        assert gh.n_groups == 250 and gh.keys[int(gh.begin[0]):int(gh.begin[1])].tolist() == first_hits, name
+        # the first pass keeps that group too (its greatest KV), whatever the order the documents arrive in
+        ret, g1 = O.group_topster_run(250, 10, True, np.arange(n, dtype=np.uint64), distinct, sc)
+        assert first_hits[0] in g1.keys.tolist(), name
+
