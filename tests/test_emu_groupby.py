@@ -508,6 +508,21 @@ def _group_order_product(lib):
         g.close()
 
 
+def test_group_count_of_300_groups_through_the_library():
+    """SortingMoreThanMaxTopsterSize's collection (collection_grouping_test.cpp:876-925): found_docs 1 000, found 300 = the sketch the device built"""
+    from tests.test_oracle_groupby import three_hundred_groups
+    n, distinct = three_hundred_groups()
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.set_num_docs(n)
+    g.field_create(0, False)
+    g.commit()
+    g.column_set(1, distinct.view(np.int64))
+    wq = T.KwQuery([], sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=250)
+    h, gh = g.keyword_search_grouped_batch([wq], [(2, 1, 1, 1, 1)], k_stride=250, g_stride=250)
+    assert int(h.num_matched[0]) == 1000 and int(gh.groups_count[0]) == 300 and int(gh.n_groups[0]) == 250
+    g.close()
+
+
 def test_group_order_known_answers_through_the_library():
     _group_order_product(H.emu_lib_path())
 

@@ -257,3 +257,21 @@ def test_group_order_known_answers_of_the_reference():
         ret, g1 = O.group_topster_run(250, 10, True, np.arange(n, dtype=np.uint64), distinct, sc)
         assert first_hits[0] in g1.keys.tolist(), name
 
+
+def three_hundred_groups():
+    """the collection of SortingMoreThanMaxTopsterSize (collection_grouping_test.cpp:876-925): 150 sizes x 4 documents, 100 x 3, 50 x 2 = 1 000 documents in 300 groups"""
+    sizes = [i for i in range(150) for _ in range(4)] + [i for i in range(150, 250) for _ in range(3)] + [i for i in range(250, 300) for _ in range(2)]
+    n = len(sizes)
+    return n, O.distinct_ids(n, [(np.arange(n + 1, dtype=np.uint64), np.array(sizes, np.uint32))], True)[0]
+
+
+def test_group_count_of_300_groups_is_the_reference_found():
+    """`found` = 300 there (:929, :941, :957, :969) with a Topster of 250: it can only come from getGroupsCount() — get_distinct_id -> std::to_string -> wyhash -> LogLogBeta::cardinality()
+    must give exactly 300 for these keys"""
+    n, distinct = three_hundred_groups()
+    ret, g1 = O.group_topster_run(250, 2, True, np.arange(n, dtype=np.uint64), distinct, np.zeros((n, 3), np.int64))
+    assert g1.groups_count == 300 and g1.n_groups == 250
+    R = O.ref_topster_lib()
+    if R is not None:
+        assert O.ref_group_topster_run(R, 250, 2, True, np.arange(n, dtype=np.uint64), distinct, np.zeros((n, 3), np.int64))[-1] == 300
+
