@@ -407,3 +407,21 @@ def test_random_facet_walks_match_oracle_emulator():
                 m = {int(a): int(b) for a, b in zip(k.view(np.int64), c)}
                 assert [m.get(up, 0) for up, lo in ranges] == res[q].tolist(), (case, q, grouped, ranges)
     g.close()
+
+
+def test_int32_stats_with_a_negative_value_known_answer_of_the_reference():
+    """CollectionFacetingTest.FacetingWithNegativeInt (collection_faceting_test.cpp:3892-3929): points 20, 10, -5 (an int32 field's facet hash is the value's bits) ->
+    min -5, max 20, sum 25, avg 8.333333333333334 — oracle and library"""
+    hashes = np.array([20, 10, -5], np.int32).view(np.uint32)
+    ptr = np.arange(4, dtype=np.uint64)
+    ids = np.arange(3, dtype=np.uint32)
+    orc = O.OracleIndex(1, 1)
+    orc.facet_set(0, ptr, hashes)
+    mn, mx, sm, cnt = orc.facet_stats(0, ids, B.FACET_INT32)
+    assert (mn, mx, sm, cnt) == (-5.0, 20.0, 25.0, 3) and sm / cnt == pytest.approx(8.333333333333334, rel=1e-7)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.set_num_docs(3)
+    g.facet_set(0, ptr, hashes)
+    fmin, fmax, fsum, fcnt, exact = g.facet_stats_batch(0, B.FACET_INT32, [ids])[0]
+    assert (fmin, fmax, fsum, fcnt) == (-5.0, 20.0, 25.0, 3) and exact
+    g.close()
