@@ -79,5 +79,10 @@ out["group_limit_of_one"] = {"n_groups": 5, "groups": [{"found": 3, "hits": [5]}
 out["control_missing_values"] = {"brand_hashes": [[1], [], [], [1]],
                                  "gmv_false": [{"hits": [3, 0]}, {"hits": [2]}, {"hits": [1]}],
                                  "gmv_true": [{"hits": [3, 0]}, {"hits": [2, 1]}]}
+# CollectionFacetingTest.FacetStatOnFloatFields (test/collection_faceting_test.cpp:645-712) on test/float_documents.jsonl: stats of `average` (float: the facet hash is the
+# float's bits) over all 7 documents: min -21.3799991607666, max 300, sum 277.8160007725237, avg 39.68800011036053 (ASSERT_FLOAT_EQ)
+fdocs = [json.loads(l) for l in open("/root/reference/test/float_documents.jsonl") if l.strip()]
+out["float_stats"] = {"average_bits": [[struct.unpack("<I", struct.pack("<f", d["average"]))[0]] for d in fdocs],
+                      "expected": {"min": -21.3799991607666, "max": 300.0, "sum": 277.8160007725237, "avg": 39.68800011036053, "count": 7}}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "facet_group_range.json"), "w"), indent=1)
 print(len(docs), "documents")

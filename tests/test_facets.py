@@ -425,3 +425,23 @@ def test_int32_stats_with_a_negative_value_known_answer_of_the_reference():
     fmin, fmax, fsum, fcnt, exact = g.facet_stats_batch(0, B.FACET_INT32, [ids])[0]
     assert (fmin, fmax, fsum, fcnt) == (-5.0, 20.0, 25.0, 3) and exact
     g.close()
+
+
+def test_float_stats_known_answer_of_the_reference():
+    """CollectionFacetingTest.FacetStatOnFloatFields (collection_faceting_test.cpp:645-712) on test/float_documents.jsonl — oracle (double accumulation in document order:
+    bit for bit what the reference prints) and library (min / max / count exact, the sum to double rounding)"""
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "facet_group_range.json")))["float_stats"]
+    e = fx["expected"]
+    ptr, hashes = _csr(fx["average_bits"])
+    ids = np.arange(len(fx["average_bits"]), dtype=np.uint32)
+    orc = O.OracleIndex(1, 1)
+    orc.facet_set(0, ptr, hashes)
+    mn, mx, sm, cnt = orc.facet_stats(0, ids, B.FACET_FLOAT)
+    assert cnt == e["count"] and np.float32(mn) == np.float32(e["min"]) and mx == e["max"]
+    assert sm == pytest.approx(e["sum"], rel=1e-7) and sm / cnt == pytest.approx(e["avg"], rel=1e-7)              # (ASSERT_FLOAT_EQ in the reference)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.set_num_docs(ids.size)
+    g.facet_set(0, ptr, hashes)
+    fmin, fmax, fsum, fcnt, exact = g.facet_stats_batch(0, B.FACET_FLOAT, [ids])[0]
+    assert (fmin, fmax, fcnt) == (mn, mx, cnt) and fsum == pytest.approx(sm, rel=1e-12)
+    g.close()
