@@ -9,7 +9,7 @@
 // What the library returns is ALREADY the pass' outcome (first pass: the greatest KV of each of the best groups; second pass: populate_result_kvs'
 // groups with their KVs). The shim re-adds exactly those KVs to the caller's Topster, which thereby holds the state the reference's consumers read:
 //   first pass : the same set of (distinct key -> greatest KV) — consumers take it as a set (Index::get_group_by_values, src/index.cpp:7144-7170);
-//                loglog_counter receives EVERY distinct key of the pass through the sketch registers the device built (getGroupsCount() = found);
+//                loglog_counter receives EVERY distinct key of the pass through the sketch registers the device built (getGroupsCount() as Index::run_search reads it, :2691);
 //   second pass: group_kv_map holds the returned groups with their group_limit greatest KVs each, so populate_result_kvs (src/index.cpp:8962-9011)
 //                yields what it would have yielded over all matched documents;
 //   groups_processed[distinct_key] = the group's matched documents (:5546-5549), id_buff / num_keyword_matches / search_cutoff as in the plain shim,
