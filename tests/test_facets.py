@@ -445,3 +445,34 @@ def test_float_stats_known_answer_of_the_reference():
     fmin, fmax, fsum, fcnt, exact = g.facet_stats_batch(0, B.FACET_FLOAT, [ids])[0]
     assert (fmin, fmax, fcnt) == (mn, mx, cnt) and fsum == pytest.approx(sm, rel=1e-12)
     g.close()
+
+
+def test_facet_edge_cases_emulator():
+    """empty field, empty batch, a field without any document, 1 024 ranges (the maximum) and one more, ranges that no value reaches"""
+    g = T.GpuIndex(0, H.emu_lib_path())
+    orc = O.OracleIndex(1, 1)
+    g.set_num_docs(50)
+    ptr = np.zeros(51, np.uint64)                                     # fifty documents, none with a value
+    g.facet_set(0, ptr, np.zeros(0, np.uint32))
+    orc.facet_set(0, ptr, np.zeros(0, np.uint32))
+    lists = [np.arange(50, dtype=np.uint32), np.zeros(0, np.uint32)]
+    _check(g, orc, lists)
+    assert g.facet_count_batch(0, [], cap=8) == []
+    g.column_set(1, np.arange(50, dtype=np.int64))
+    assert g.facet_range_count_batch(0, 1, [(10, 0)], lists).tolist() == [[0], [0]]
+    got = g.facet_count_batch(0, lists, cap=8, group_column=1)
+    assert [r[4] for r in got] == [0, 0]
+    # every document one value; 1 024 one-wide ranges over the values 0 .. 49 (most of them empty), then 1 025
+    ptr = np.arange(51, dtype=np.uint64)
+    hashes = np.arange(50, dtype=np.uint32) + np.uint32(5)
+    g.facet_set(0, ptr, hashes)
+    orc.facet_set(0, ptr, hashes)
+    ranges = [(i - 499, i - 500) for i in range(1024)]
+    rc = g.facet_range_count_batch(0, 1, ranges, lists)
+    k, c, d, p, n = orc.facet_count_ex(0, lists[0], ranges=ranges, doc_vals=np.arange(50, dtype=np.int64))
+    m = {int(a): int(b) for a, b in zip(k.view(np.int64), c)}
+    assert rc[0].tolist() == [m.get(up, 0) for up, lo in ranges] and int(rc[0].sum()) == 50 and int(rc[1].sum()) == 0
+    with pytest.raises(T.TsgpuError):
+        g.facet_range_count_batch(0, 1, [(i, i - 1) for i in range(1025)], lists)
+    assert g.facet_range_count_batch(0, 1, [(-10, -20), (1000, 900)], lists).tolist() == [[0, 0], [0, 0]]
+    g.close()
