@@ -529,3 +529,32 @@ def test_group_order_known_answers_through_the_library():
 
 def test_grouping_basics_known_answer_through_the_library():
     _grouping_basics_product(H.emu_lib_path())
+
+
+def test_random_skewed_wildcard_groupings_match_oracle():
+    """q = * over 300 .. 6 000 documents grouped by fields of 1 .. 60 values (whole waves in one group, workgroups that meet a handful of groups, member lists that
+    span several scatter workgroups and the chunked path), Topsters that hold fewer groups than exist, both passes, ties in the sort key — seeded"""
+    rng = np.random.default_rng(77)
+    for case in range(14):
+        n = int(rng.choice([300, 1100, 2500, 6000]))
+        n_groups = int(rng.choice([1, 2, 3, 9, 60]))
+        g = T.GpuIndex(0, H.emu_lib_path())
+        g.set_num_docs(n)
+        g.field_create(0, False)
+        g.commit()
+        points = rng.integers(0, int(rng.choice([3, 1000])), size=n).astype(np.int64)            # (few distinct sort keys: ties resolved by the seq_id)
+        g.column_set(0, points)
+        short = int(rng.integers(0, 40))
+        probs = rng.dirichlet(np.ones(n_groups) * 0.5)
+        distinct = (rng.choice(n_groups, size=n - short, p=probs).astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        g.column_set(1, distinct.view(np.int64))
+        limit = int(rng.choice([1, 3, 7]))
+        k = int(rng.choice([2, 50, 250]))
+        sort = ((B.SORT_INT64_COLUMN, int(rng.choice([1, -1])), 0), (B.SORT_SEQ_ID, int(rng.choice([1, -1])), 0))
+        excl = np.sort(rng.choice(n, size=int(rng.integers(0, n // 4)), replace=False)).astype(np.uint32)
+        q = T.KwQuery([], sort=sort, topster_size=k, excluded_ids=excl if excl.size else None)
+        gmv = int(rng.integers(0, 2))
+        for first_pass in (1, 0):
+            h, gh = g.keyword_search_grouped_batch([q], [(limit, 1, first_pass, gmv, 1)], k_stride=k * limit, g_stride=max(k, 1), want_registers=True)
+            check_query(h, gh, 0, oracle_grouped_wildcard(q, n, points, distinct, limit, bool(first_pass), bool(gmv)), bool(first_pass), limit, "case %d" % case)
+        g.close()
