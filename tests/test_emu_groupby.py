@@ -558,3 +558,28 @@ def test_random_skewed_wildcard_groupings_match_oracle():
             h, gh = g.keyword_search_grouped_batch([q], [(limit, 1, first_pass, gmv, 1)], k_stride=k * limit, g_stride=max(k, 1), want_registers=True)
             check_query(h, gh, 0, oracle_grouped_wildcard(q, n, points, distinct, limit, bool(first_pass), bool(gmv)), bool(first_pass), limit, "case %d" % case)
         g.close()
+
+
+@pytest.mark.parametrize("n_values", [1, 2, 7])
+def test_grouped_candidate_combinations_over_few_groups(world, n_values):
+    """the candidate fold when the group_by field has one, two or seven values: the deduplicated records of a second pass all land in a handful of table slots
+    (wave groups + workgroup LDS tables), frequent tokens so that a user query holds thousands of records"""
+    orc, g, _, _, _ = world
+    few = (np.arange(3000, dtype=np.uint64) * np.uint64(2654435761) % np.uint64(n_values)) * np.uint64(0x100000001B3) + np.uint64(11)
+    g.column_set(4, few.view(np.int64))
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    users = [[[1], [2], [1, 2], [3], [1]], [[2, 3], [1, 3], [4]], [[5], [6], [7], [8], [9], [10]]]
+    limit = 4
+    combos = [[T.KwQuery(c, sort=sort, topster_size=250, total_cost=int(j > 0)) for j, c in enumerate(cs)] for cs in users]
+    for first_pass in (True, False):
+        h, gh, qidx, ids = g.keyword_search_grouped_candidates_batch(combos, [(limit, 4, int(first_pass), 0, 0)] * len(users), k_stride=1000, g_stride=250, want_ids=True, want_registers=True)
+        assert (h.status == 0).all()
+        for u, cs in enumerate(combos):
+            ref, rqi = orc.search_candidates_grouped([H.oracle_query(orc, q) for q in cs], few, limit, first_pass, ids_cap=1 << 20)
+            check_query(h, gh, u, ref, first_pass, limit, "few groups %d u%d" % (n_values, u))
+            assert np.array_equal(ids[u], ref.result_ids), u
+            if not first_pass:
+                for r in range(int(gh.n_groups[u])):
+                    n = int(ref.group_size[r])
+                    assert np.array_equal(qidx[u, r * limit:r * limit + n], rqi[ref.begin[r]:ref.begin[r + 1]].astype(np.uint32)), (u, r)
+        assert int(h.num_matched.sum()) > 1000
