@@ -476,3 +476,21 @@ def test_facet_edge_cases_emulator():
         g.facet_range_count_batch(0, 1, [(i, i - 1) for i in range(1025)], lists)
     assert g.facet_range_count_batch(0, 1, [(-10, -20), (1000, 900)], lists).tolist() == [[0, 0], [0, 0]]
     g.close()
+
+
+def test_repeated_array_values_count_once_known_answer_of_the_reference():
+    """CollectionFacetingTest.FacetByArrayField (collection_faceting_test.cpp:1176-1224): data = ["Foo", "Foo"] and ["Foo", "Foo", "Bazinga"] -> Foo 2, Bazinga 1;
+    with the facet query that only matches Bazinga -> Bazinga 1 (string facet ids in order of first appearance: Foo 1, Bazinga 2)"""
+    ptr, hashes = _csr([[1, 1], [1, 1, 2]])
+    ids = np.arange(2, dtype=np.uint32)
+    orc = O.OracleIndex(1, 1)
+    orc.facet_set(0, ptr, hashes)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.set_num_docs(2)
+    g.facet_set(0, ptr, hashes)
+    for allowed, want in ((None, {1: 2, 2: 1}), (np.array([2], np.uint32), {2: 1})):
+        h, c, d, p, n = orc.facet_count(0, ids, allowed_hashes=allowed)
+        assert {int(a): int(b) for a, b in zip(h, c)} == want
+        gh, gc, gd, gp, gn = g.facet_count_batch(0, [ids], cap=8, allowed_hashes=allowed)[0]
+        assert {int(a): int(b) for a, b in zip(gh, gc)} == want and np.array_equal(gd, d) and np.array_equal(gp, p)
+    g.close()
