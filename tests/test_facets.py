@@ -494,3 +494,23 @@ def test_repeated_array_values_count_once_known_answer_of_the_reference():
         gh, gc, gd, gp, gn = g.facet_count_batch(0, [ids], cap=8, allowed_hashes=allowed)[0]
         assert {int(a): int(b) for a, b in zip(gh, gc)} == want and np.array_equal(gd, d) and np.array_equal(gp, p)
     g.close()
+
+
+def test_bool_facet_with_the_hash_zero():
+    """CollectionFacetingTest.FacetCountsBool (collection_faceting_test.cpp:422-476): in_stock = true, false, true; filter in_stock:true leaves documents 0 and 2 -> true 2.
+    A bool field's facet hash is (uint32) the value: `false` is the hash 0, which the tables must tell from an empty slot (all three documents: true 2, false 1)"""
+    ptr, hashes = _csr([[1], [0], [1]])
+    orc = O.OracleIndex(1, 1)
+    orc.facet_set(0, ptr, hashes)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.set_num_docs(3)
+    g.facet_set(0, ptr, hashes)
+    g.column_set(1, np.array([7, 7, 9], np.int64))
+    for ids, want in ((np.array([0, 2], np.uint32), {1: 2}), (np.arange(3, dtype=np.uint32), {0: 1, 1: 2})):
+        h, c, d, p, n = orc.facet_count(0, ids)
+        assert {int(a): int(b) for a, b in zip(h, c)} == want
+        gh, gc, gd, gp, gn = g.facet_count_batch(0, [ids], cap=8)[0]
+        assert {int(a): int(b) for a, b in zip(gh, gc)} == want and np.array_equal(gd, d)
+    gh, gc, gd, gp, gn = g.facet_count_batch(0, [np.arange(3, dtype=np.uint32)], cap=8, group_column=1)[0]
+    assert {int(a): int(b) for a, b in zip(gh, gc)} == {0: 1, 1: 2}                     # (groups 7 and 9 hold `true`, group 7 holds `false`)
+    g.close()
