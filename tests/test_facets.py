@@ -514,3 +514,21 @@ def test_bool_facet_with_the_hash_zero():
     gh, gc, gd, gp, gn = g.facet_count_batch(0, [np.arange(3, dtype=np.uint32)], cap=8, group_column=1)[0]
     assert {int(a): int(b) for a, b in zip(gh, gc)} == {0: 1, 1: 2}                     # (groups 7 and 9 hold `true`, group 7 holds `false`)
     g.close()
+
+
+def test_grouped_pair_of_all_ones_emulator():
+    """the (value, group) pair 0xFFFFFFFF / 0xFFFFFFFF equals the pair table's empty marker: it is counted through a flag of its own, once"""
+    ptr, hashes = _csr([[0xFFFFFFFF], [0xFFFFFFFF], [0xFFFFFFFF, 5], [5]])
+    distinct = np.array([0xFFFFFFFF, 0x1FFFFFFFF, 0xFFFFFFFF, 3], np.uint64)            # (documents 0, 1, 2: one group for hash_groups' uint32 set)
+    orc = O.OracleIndex(1, 1)
+    orc.facet_set(0, ptr, hashes)
+    g = T.GpuIndex(0, H.emu_lib_path())
+    g.set_num_docs(4)
+    g.facet_set(0, ptr, hashes)
+    g.column_set(1, distinct.view(np.int64))
+    ids = np.arange(4, dtype=np.uint32)
+    k, c, d, p, n = orc.facet_count_ex(0, ids, distinct_ids=distinct)
+    assert {int(a): int(b) for a, b in zip(k, c)} == {5: 2, 0xFFFFFFFF: 1}
+    gh, gc, gd, gp, gn = g.facet_count_batch(0, [ids, ids], cap=8, group_column=1)[1]
+    assert np.array_equal(gh, k.astype(np.uint32)) and np.array_equal(gc, c) and np.array_equal(gd, d) and np.array_equal(gp, p)
+    g.close()
