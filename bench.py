@@ -1086,38 +1086,15 @@ class Bench:
 
     # ---------------------------------------------------------------- exact k-NN by the oracle, streamed in chunks (parity at 10M)
     def exact_knn_chunked(self, Qh, k, want_rows=True, metric=None, slab_kw=None):
-        """oracle flat_knn semantics (exact fp32, hnswlib summation order, ties -> smaller label) over ALL base rows: the collection is
-        regenerated slab by slab on the GPU, copied to the host and scanned by the oracle, one query per host thread. Returns
-        (dist [nq,k], labels [nq,k], {label: row vector} for the rows of the final top-k)."""
+        """oracle flat_knn semantics (exact fp32, hnswlib summation order, ties -> smaller label) over ALL base rows, streamed slab by slab:
+        tests/helpers.py::exact_knn_chunked — the same checker the `-m gpu` at-size tests use (tests/test_gpu_at_size.py). Parity legs only."""
         from oracle import oracle_py as O
-        nq, dim = Qh.shape
-        best_d = np.full((nq, 0), 0, np.float32)
-        best_l = np.zeros((nq, 0), np.uint32)
-        keep = {}
-        S = 1 << 20
-        pool = ThreadPoolExecutor(max_workers=min(nq, os.cpu_count() or 1))
-        for a in range(0, self.n_docs, S):
-            b = min(self.n_docs, a + S)
-            xs = self.base_slab(a, b, **(slab_kw or {})).cpu().numpy()
-            orc = O.OracleIndex(1, 1)
-            orc.vec_init(dim, O.METRIC_IP if metric is None else metric)
-            orc.vec_add(np.arange(a, b, dtype=np.uint32), xs)
-            res = list(pool.map(lambda i: orc.flat_knn(Qh[i], k), range(nq)))          # ctypes releases the GIL: one query per thread
-            cd = np.stack([np.pad(r[0], (0, k - r[0].size), constant_values=np.inf) for r in res])
-            cl = np.stack([np.pad(r[1], (0, k - r[1].size), constant_values=0xFFFFFFFF) for r in res]).astype(np.uint32)
-            if want_rows:
-                for i in range(nq):
-                    for lab in res[i][1]:
-                        keep.setdefault(int(lab), xs[int(lab) - a].copy())
-            d = np.concatenate([best_d, cd], axis=1)
-            l = np.concatenate([best_l, cl], axis=1)
-            order = np.lexsort((l, d), axis=1)[:, :k]                                   # (distance, label) ascending
-            best_d, best_l = np.take_along_axis(d, order, 1), np.take_along_axis(l, order, 1)
-            orc.close()
-            del xs
-        pool.shutdown()
-        final = set(int(x) for x in best_l.ravel())
-        return best_d, best_l, {lab: v for lab, v in keep.items() if lab in final}
+        tdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests")
+        if tdir not in sys.path:
+            sys.path.insert(0, tdir)
+        import helpers as H
+        m = O.METRIC_IP if metric is None else metric
+        return H.exact_knn_chunked(self.n_docs, self.args.dim, {m: np.ascontiguousarray(Qh)}, k, want_rows=want_rows, slab_kw=slab_kw)[m]
 
     # ---------------------------------------------------------------- vector (config 3)
     def knn_run(self, g, field, Q, n_q, k, steps, warmup):
@@ -1196,7 +1173,7 @@ class Bench:
             from oracle import oracle_py as O
             ncpu = os.cpu_count() or 1
             # parity leg 2 (GPU vs the oracle at FULL size): exact flat scan of all rows, streamed in chunks
-            npar = min(n_q, 16)
+            npar = min(n_q, 64)
             t0 = time.time()
             Qh = Q[:npar].cpu().numpy()
             ed, el, rows = self.exact_knn_chunked(Qh, k)
@@ -1478,7 +1455,7 @@ class Bench:
             # (exact_knn_chunked): flat_knn over a superset of the true top-100 returns exactly the true top-100.
             from oracle import oracle_py as O
             Qe, ed, el, rows = self.exact
-            m = min(n_q, Qe.shape[0], 16)
+            m = min(n_q, Qe.shape[0], 32)
             orc = O.OracleIndex(1, 1)
             orc.set_num_docs(self.n_docs)
             orc.set_sort_dense(0, self.pts)

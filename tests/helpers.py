@@ -158,3 +158,117 @@ def reference_shard_merge(keys, scores, n_hits, k):
         order = np.lexsort((kk, sc[:, 2], sc[:, 1], sc[:, 0]))[::-1][:k] if kk.size else np.zeros(0, np.int64)
         out.append((kk[order], sc[order]))
     return out
+
+
+# ---------------------------------------------------------------- BASELINE configs 3 / 4 at size (tests/test_gpu_at_size.py, bench.py parity legs)
+VEC_SLAB = 1 << 20
+
+
+def vector_slab(n_docs, dim, a, b, normalize=False, clustered=False):
+    """base vectors of global rows [a, b) of the config-3 collection (i.i.d. N(0,1), seed 3) as a CUDA tensor: the collection is
+    defined on a fixed grid of 2^20-row slabs (seed 3 + slab start), so every shard / chunk / test regenerates exactly the same rows"""
+    import torch
+    from typesense_amd import synth
+    parts = []
+    for s0 in range(a // VEC_SLAB * VEC_SLAB, b, VEC_SLAB):
+        n = min(VEC_SLAB, n_docs - s0)
+        x = synth.random_vectors(n, dim, seed=3 + s0, device="cuda")
+        if clustered:
+            # 1024 tight clusters: centre + 0.15 x noise, unit length — many near-ties around every query's k-th neighbour
+            gcen = torch.Generator(device="cuda")
+            gcen.manual_seed(77)
+            cen = torch.randn((1024, dim), generator=gcen, device="cuda", dtype=torch.float32)
+            gi = torch.Generator(device="cuda")
+            gi.manual_seed(78 + s0)
+            idx = torch.randint(0, 1024, (n,), generator=gi, device="cuda")
+            x = cen[idx] + 0.15 * x
+        if normalize or clustered:
+            x /= (x.norm(dim=1, keepdim=True) + 1e-30)
+        parts.append(x[max(a, s0) - s0:min(b, s0 + n) - s0])
+    return parts[0] if len(parts) == 1 else torch.cat(parts)
+
+
+def load_vector_field(g, field, metric, n_docs, dim, lo=0, hi=None, **slab_kw):
+    """rows [lo, hi) of the config-3 collection into vector field `field` of GpuIndex g, generated on the device slab by slab (label = row)"""
+    import torch
+    hi = n_docs if hi is None else hi
+    g.vec_create(field, dim, metric, hi - lo)
+    for a in range(lo, hi, VEC_SLAB):
+        b = min(hi, a + VEC_SLAB)
+        x = vector_slab(n_docs, dim, a, b, **slab_kw).contiguous()
+        labels = torch.arange(a, b, dtype=torch.int64, device="cuda")
+        g.vec_upsert_device(field, labels.data_ptr(), x.data_ptr(), b - a)
+        del x
+    torch.cuda.synchronize()
+
+
+def exact_knn_chunked(n_docs, dim, queries, k, want_rows=True, slab_kw=None, threads=None):
+    """The oracle's flat_knn (exact fp32, hnswlib summation order, ties -> smaller label; process_results_bruteforce,
+    /root/reference/src/index.cpp:3345-3374) over ALL rows of the config-3 collection, which is regenerated slab by slab on the GPU, copied
+    to the host ONCE per slab and scanned by the oracle, one query per host thread.
+    queries: {oracle metric: Qh [nq, dim]} (several metrics share the slab copy; a cosine oracle normalises the rows on add like
+    hnsw_index_t::normalize_vector, include/index.h:379-388). Returns {metric: (dist [nq,k], labels [nq,k], {label: raw row} of the final top-k)}."""
+    from concurrent.futures import ThreadPoolExecutor
+    state = {m: dict(d=np.zeros((Q.shape[0], 0), np.float32), l=np.zeros((Q.shape[0], 0), np.uint32), keep={}) for m, Q in queries.items()}
+    nthreads = threads or min(max(Q.shape[0] for Q in queries.values()), os.cpu_count() or 1)
+    pool = ThreadPoolExecutor(max_workers=nthreads)
+    for a in range(0, n_docs, VEC_SLAB):
+        b = min(n_docs, a + VEC_SLAB)
+        xs = vector_slab(n_docs, dim, a, b, **(slab_kw or {})).cpu().numpy()
+        for metric, Qh in queries.items():
+            st = state[metric]
+            nq = Qh.shape[0]
+            orc = O.OracleIndex(1, 1)
+            orc.vec_init(dim, metric)
+            orc.vec_add(np.arange(a, b, dtype=np.uint32), xs)
+            res = list(pool.map(lambda i: orc.flat_knn(Qh[i], k), range(nq)))          # ctypes releases the GIL: one query per thread
+            cd = np.stack([np.pad(r[0], (0, k - r[0].size), constant_values=np.inf) for r in res])
+            cl = np.stack([np.pad(r[1], (0, k - r[1].size), constant_values=0xFFFFFFFF) for r in res]).astype(np.uint32)
+            if want_rows:
+                for i in range(nq):
+                    for lab in res[i][1]:
+                        st["keep"].setdefault(int(lab), xs[int(lab) - a].copy())
+            d = np.concatenate([st["d"], cd], axis=1)
+            l = np.concatenate([st["l"], cl], axis=1)
+            order = np.lexsort((l, d), axis=1)[:, :k]                                   # (distance, label) ascending
+            st["d"], st["l"] = np.take_along_axis(d, order, 1), np.take_along_axis(l, order, 1)
+            orc.close()
+        del xs
+    pool.shutdown()
+    out = {}
+    for metric, st in state.items():
+        final = set(int(x) for x in st["l"].ravel())
+        out[metric] = (st["d"], st["l"], {lab: v for lab, v in st["keep"].items() if lab in final})
+    return out
+
+
+def oracle_for_hybrid_at_size(n_docs, dim, csr, points, qtok, rows, metric=None):
+    """an oracle index able to answer search_hybrid for the queries `qtok` at full size without holding the 30 GB matrix: the keyword half gets
+    the decoded postings of the queries' terms; the vector store gets `rows` = the rows of the oracle's OWN exact top-k over all rows
+    (exact_knn_chunked): flat_knn over a superset of the true top-k returns exactly the true top-k. Returns (orc, labels held)."""
+    from typesense_amd import synth
+    orc = O.OracleIndex(1, 1)
+    orc.set_num_docs(n_docs)
+    orc.set_sort_dense(0, points)
+    for t in np.unique(np.asarray(qtok).ravel()):
+        ids, oi, off = synth.csr_term(csr, int(t))
+        if ids.size:
+            orc.load_posting(0, int(t), ids, oi, off)
+    orc.vec_init(dim, O.METRIC_IP if metric is None else metric)
+    labs = np.array(sorted(rows.keys()), np.uint32)
+    orc.vec_add(labs, np.stack([rows[int(x)] for x in labs]))
+    return orc, labs
+
+
+def oracle_add_rows(orc, n_docs, dim, have, need, **slab_kw):
+    """adds the rows `need` (labels) the oracle's vector store does not hold yet (rerank_hybrid_matches computes the distance of keyword-only
+    hits BY LABEL, /root/reference/src/index.cpp:8860-8876), regenerated slab by slab on the GPU"""
+    import torch
+    need = np.unique(np.asarray(need).astype(np.int64))
+    need = need[~np.isin(need, np.asarray(have).astype(np.int64))]
+    for s0 in range(0, n_docs, VEC_SLAB):
+        sel = need[(need >= s0) & (need < s0 + VEC_SLAB)]
+        if sel.size:
+            x = vector_slab(n_docs, dim, s0, min(n_docs, s0 + VEC_SLAB), **slab_kw)[torch.from_numpy(sel - s0).cuda()].cpu().numpy()
+            orc.vec_add(sel.astype(np.uint32), x)
+    return need

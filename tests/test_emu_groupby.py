@@ -409,6 +409,33 @@ def test_grouped_candidate_combinations_fold_like_the_shared_collector(world, fi
     assert int(gh.n_groups[3]) == 0 and int(gh.n_groups[0]) > 5
 
 
+def test_grouped_candidates_a_user_query_failing_after_the_id_pass_leaves_its_neighbours_alone(world):
+    """user 0 = one healthy combination + one whose deadline has passed (408 in the id pass, after the translation accepted it); with the ids on the
+    device the healthy combination's ids are packed into the id buffer all the same. User 0 reports 408 and nothing else; user 1 and 2 must get exactly what
+    they get in a batch without user 0 (ids, hits, groups) — before the fix every later query's item range was short by user 0's ids"""
+    orc, g, _, distinct, has_value = world
+    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
+    for first_pass in (True, False):
+        grp = (3, GROUP_COL, int(first_pass), 0, 0)
+        healthy = [[T.KwQuery([3], sort=sort, topster_size=40)], [T.KwQuery([2, 1], sort=sort, topster_size=40), T.KwQuery([4], sort=sort, topster_size=40, total_cost=1)]]
+        failing = [T.KwQuery([1, 2], sort=sort, topster_size=40), T.KwQuery([1, 3], sort=sort, topster_size=40, total_cost=1, deadline_us=1)]
+        wh, wgh, wq, wids = g.keyword_search_grouped_candidates_batch(healthy, [grp] * 2, k_stride=750, g_stride=250, want_ids=True, want_registers=True)
+        assert (wh.status == 0).all() and wids[0].size > 0 and wids[1].size > 0
+        h, gh, qx, ids = g.keyword_search_grouped_candidates_batch([failing] + healthy, [grp] * 3, k_stride=750, g_stride=250, want_ids=True, want_registers=True)
+        assert list(h.status) == [B.ERR_DEADLINE, 0, 0], list(h.status)
+        assert int(h.n_hits[0]) == 0 and int(gh.n_groups[0]) == 0 and ids[0].size == 0
+        for u in (0, 1):
+            ref, _ = orc.search_candidates_grouped([H.oracle_query(orc, q) for q in healthy[u]], distinct, 3, first_pass, has_value=has_value, ids_cap=1 << 20)
+            check_query(h, gh, u + 1, ref, first_pass, 3, "neighbour of a failed user query")
+            assert np.array_equal(ids[u + 1], wids[u]) and np.array_equal(ids[u + 1], ref.result_ids)
+            assert int(h.n_hits[u + 1]) == int(wh.n_hits[u]) and int(gh.n_groups[u + 1]) == int(wgh.n_groups[u])
+            ng = int(wgh.n_groups[u])
+            assert np.array_equal(gh.distinct_key[u + 1, :ng], wgh.distinct_key[u, :ng]) and np.array_equal(gh.group_size[u + 1, :ng], wgh.group_size[u, :ng])
+            for r in range(ng):                           # (a group's unused slots are not written)
+                lo, n = r * (1 if first_pass else 3), int(wgh.group_size[u, r])
+                assert np.array_equal(h.keys[u + 1, lo:lo + n], wh.keys[u, lo:lo + n]) and np.array_equal(qx[u + 1, lo:lo + n], wq[u, lo:lo + n])
+
+
 def _grouping_basics_product(lib):
     """CollectionGroupingTest.GroupingBasics (/root/reference/test/collection_grouping_test.cpp:71-96) through the library: q = *, group_by size, group_limit 2,
     sort rating desc: found_docs 12, found 3; groups 11 / 10 / 12 with 2 / 7 / 3 documents and the hits 5,1 / 4,3 / 2,8"""

@@ -261,13 +261,17 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
             g.item_begin = n_items; g.tab_off = n_slots;
             g.run = status[i] == TSGPU_OK ? 1 : 0;
             g.iota = iota[i];
-            uint64_t n = 0;
+            uint64_t n = 0, gap = 0;
             uint32_t matched_before = 0;                  // searched_queries.size() at the time of a pass: the earlier combinations that matched anything (:5580-5585)
             for (uint32_t c = cfirst[i]; c < cfirst[i + 1]; c++) {
-                combo_begin[c] = n_items + n;
+                combo_begin[c] = n_items + n + gap;
                 qidx_of_combo[c] = matched_before;
                 uint64_t nc = 0;
                 if (g.run) nc = iota[i] ? ctx->num_docs : (groups[i].wildcard ? wild_ids[i].size() : tsgpu_id_lists_count(idl.get(), kw_index[c]));
+                // a user query that FAILED after the id pass (one of its combinations ran out of time, ...) while another of its combinations succeeded: with the
+                // ids on the device, kw_dispatch packed the successful combination's ids into ids_dev like everybody else's. They are a GAP of the item space
+                // (nobody reads them: the query has no items), or every later query's combo_begin / item_begin would be short by that many ids
+                else if (ids_on_dev && kw_index[c] != 0xFFFFFFFFu) gap += tsgpu_id_lists_count(idl.get(), kw_index[c]);
                 n += nc;
                 if (nc) matched_before++;
             }
@@ -280,7 +284,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
             n_blocks += (n + GB_THREADS - 1) / GB_THREADS;
             g.first_sblock = (uint32_t)n_sblocks;
             n_sblocks += (n + GB_SCATTER_ITEMS - 1) / GB_SCATTER_ITEMS;
-            n_items += n;
+            n_items += n + gap;
             n_slots += size + 1;                          // + the slot of the key ~0
         }
         combo_begin[n_combos] = n_items;
