@@ -103,9 +103,6 @@ const char* tsgpu_last_error(void);
 int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
 /* tuning knobs (all optional): "kw_chunk_blocks" = driver posting blocks per keyword work item (default 0 = sized per batch; 1..256),
  * "kw_pair_blocks" = 1 (default): the find kernel serves two blocks of the shortest list per iteration (kw_find2_kernel; 0 = one),
- * "kw_round_fused_max_queries" (default 0 = off): keyword rounds of at most this many plain single-field <= 3-token queries run as ONE launch
- * (kw_round_kernel: find + score per work item, the query's last work item merges) instead of find | score | merge — identical results; measured
- * slower under concurrent callers (the fused kernel's LDS and registers keep one workgroup per CU), so it is an option only,
  * "kw_mf_pipelined" = 1 (default): launches with multi-field queries run the PIPELINED find kernel (kw_find_mf2_kernel<., 2> when no query
  * of the launch has more than two query_by fields, <., 4> otherwise: the second token's lists of all fields merged block-wise through
  * double-buffered LDS tiles, requested one driver block ahead; 0 = kw_search_mf_kernel, block at a time); counter "kw_mf_pipelined_launches",

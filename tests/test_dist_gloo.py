@@ -44,6 +44,8 @@ def run_ranks(world, lib, extra_env=None, timeout=900):
         assert "rank %d: DIST_OK" % r in o, o
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 8])          # (three ranks: the `-m gpu` tier, tests/test_gpu_dist.py)
 def test_rank_form_group_over_gloo_equals_unsharded_oracle(world):
-    run_ranks(world, H.emu_lib_path())
+    """world 8 = the node BASELINE config 5 names: eight doc-range shards (uneven cut; a cut with an EMPTY shard), five queries over eight ranks (three ranks
+    merge an empty, padded query slice), pruned and full exchange, slice exchange and literal all-gather, the replicas form, the agreement step"""
+    run_ranks(world, H.emu_lib_path(), timeout=1500)

@@ -1150,46 +1150,3 @@ def test_pipelined_two_field_find_kernel_equals_the_block_at_a_time_kernel_and_t
         g.set_option("kw_mf_pipelined", 1)
         g.set_option("kw_chunk_blocks", 0)
         g.keep_result_ids(False)
-
-
-def test_one_launch_rounds_equal_the_three_kernel_form(pair):
-    """kw_round_kernel (option kw_round_fused_max_queries; off by default, 256 here): find + score per work item and the merge by the query's last work item in ONE
-    launch, for rounds of plain single-field <= 3-token queries — same hits, counts and order as find | score | merge, incl. queries without work
-    items (a token no list holds), queries cut into many work items (the ticket), one-token and two-token queries; rounds the PLAIN score
-    instantiation cannot serve (filter ids, three sort keys, > 3 tokens, kept ids) keep the three kernels"""
-    orc, g, _ = pair
-    rng = np.random.default_rng(2025)
-    sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
-    qs = _queries(rng, 20, 25, 3, sort=sort, topster_size=250) + _queries(rng, 8, 25, 2, sort=sort, topster_size=250) + _queries(rng, 6, 25, 1, sort=sort, topster_size=40)
-    qs += [T.KwQuery([9999, 1], sort=sort, topster_size=250), T.KwQuery([1, 2, 9998], sort=sort, topster_size=250), T.KwQuery([3, 3], sort=sort, topster_size=250)]
-    outs = []
-    g.set_option("kw_pair_blocks", 1)                    # (the default; the one-launch form is built on the pair-find body)
-    g.set_option("kw_two_kernels", 1)
-    for chunk in (0, 1):
-        g.set_option("kw_chunk_blocks", chunk)           # 1: every driver block its own work item — the ticket counts to many
-        for fused in (256, 0):
-            g.set_option("kw_round_fused_max_queries", fused)
-            n0 = g.counter("kw_round_fused_launches")
-            h = g.keyword_search_batch(qs, k_stride=250)
-            assert (h.status == 0).all()
-            assert (g.counter("kw_round_fused_launches") > n0) == bool(fused)
-            outs.append(h)
-            h2 = g.keyword_search_batch(qs[:5], k_stride=250)          # the next round finds its tickets at zero
-            for name in ("keys", "scores", "n_hits", "num_matched"):
-                assert np.array_equal(getattr(h2, name), getattr(h, name)[:5]), name
-    g.set_option("kw_chunk_blocks", 0)
-    for h in outs[1:]:
-        for name in ("keys", "scores", "text_match", "n_hits", "num_matched"):
-            assert np.array_equal(getattr(h, name), getattr(outs[0], name)), name
-    for i, q in enumerate(qs):
-        H.assert_hits_equal(outs[0], i, H.oracle_keyword(orc, q), "one-launch round q=%s" % (q.tokens,))
-    # not served by the one-launch form: the counter stays
-    g.set_option("kw_round_fused_max_queries", 256)
-    n0 = g.counter("kw_round_fused_launches")
-    others = [T.KwQuery([1, 2], sort=sort, topster_size=250, filter_ids=np.arange(0, 3000, 2)), T.KwQuery([1, 2, 3, 4], sort=sort, topster_size=250)]
-    for q in others:
-        h = g.keyword_search_batch([q], k_stride=250)
-        H.assert_hits_equal(h, 0, H.oracle_keyword(orc, q), "three-kernel round")
-    h = g.keyword_search_batch([T.KwQuery([1, 2], sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_TEXT_MATCH, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=250)], k_stride=250)
-    assert g.counter("kw_round_fused_launches") == n0
-    g.set_option("kw_round_fused_max_queries", 0)        # (the default)

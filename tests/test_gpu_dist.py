@@ -36,7 +36,7 @@ def test_two_rank_shards_equal_unsharded_collection():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_rank_form_group_on_the_real_library(world):
     from tests import helpers as H
     from tests.test_dist_gloo import run_ranks

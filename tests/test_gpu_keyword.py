@@ -215,7 +215,6 @@ test_multi_field_block_merge_windows_wide_runs_and_exhaustion = EK.test_multi_fi
 test_long_work_items_reload_the_driver_metadata_window = EK.test_long_work_items_reload_the_driver_metadata_window
 test_pipelined_two_field_find_kernel_equals_the_block_at_a_time_kernel_and_the_oracle = EK.test_pipelined_two_field_find_kernel_equals_the_block_at_a_time_kernel_and_the_oracle
 test_find_kernel_counts_the_bytes_it_requests_without_changing_the_results = EK.test_find_kernel_counts_the_bytes_it_requests_without_changing_the_results
-test_one_launch_rounds_equal_the_three_kernel_form = EK.test_one_launch_rounds_equal_the_three_kernel_form
 
 
 def test_device_shard_merge_on_cuda_tensors(c100k):

@@ -50,8 +50,6 @@ static const bool KW_F2_ROUNDS = TSGPU_F2_ROUNDS != 0;
 // per-thread counters: driver ids, block metadata, tile DMA, third.. list probes, hit records; one wave reduction + five atomics per wave at the
 // end into IndexView::touched). A second instantiation launched only under option kw_count_touched — the timed kernel carries none of it.
 // Same results either way (tests/test_emu_keyword.py runs both and compares).
-// (the body is a device function — work item index `bid` instead of blockIdx.x — so that kw_round_kernel, kw_kernels.hip.h, can run find, score and
-//  merge of a SMALL round in one launch; kw_find2_kernel below is the same code behind its own launch)
 template <int TMAX, bool COUNT = false>
 __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work, const KwPartials& part,
                                               uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off, const uint32_t bid) {

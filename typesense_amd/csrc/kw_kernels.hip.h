@@ -52,14 +52,21 @@ namespace tsgpu {
 #ifndef TSGPU_SCORE_WAVES
 #define TSGPU_SCORE_WAVES 6      // kw_score_kernel: <= 80 VGPRs = 6 waves per SIMD (round 1: 4 -> 5 waves 2.01 -> 1.73 ms; round 4, after the PLAIN instantiation: 5 -> 6 waves 1.45 -> 1.38 ms, 7: 1.42, 8: 1.70)
 #endif
+#ifndef TSGPU_SCORE_MF_WAVES
+#define TSGPU_SCORE_MF_WAVES 4   // kw_score_kernel<.., MF = true>: its 31.6 KB of LDS allow four workgroups per CU = four waves per SIMD whatever the registers: <= 128 VGPRs,
+#endif                           // room for the six staged runs of a two-field hit (round 6; as MF ? .. : .. in the attribute: the template argument decides)
 #ifdef TSGPU_HIP_EMU
 #define KW_FOUR_WAVES_PER_SIMD
 #define KW_SCORE_WAVES
 #else
-#define KW_SCORE_WAVES __attribute__((amdgpu_waves_per_eu(TSGPU_SCORE_WAVES)))
+#define KW_SCORE_WAVES __attribute__((amdgpu_waves_per_eu(MF ? TSGPU_SCORE_MF_WAVES : TSGPU_SCORE_WAVES)))
 #define KW_FOUR_WAVES_PER_SIMD __attribute__((amdgpu_waves_per_eu(4)))
 #endif
 
+#ifndef TSGPU_MF_STAGED
+#define TSGPU_MF_STAGED 1        // multi-field score kernel (<= 3 tokens): a hit's runs loaded level by level for all tokens of a field (load_runs_staged_slots); 0 = one load_run per (token, field)
+#endif
+static const bool KW_MF_STAGED = TSGPU_MF_STAGED != 0;
 static const int KW_THREADS = 256;
 static const int KW_QCAP = 512;            // LDS queue capacity (>= 255 leftover + 256 new)
 static const int KW_MAX_TOKENS = 10;       // TSGPU_MAX_QUERY_TOKENS
@@ -547,6 +554,74 @@ __device__ inline void load_runs_staged(const IndexView& ix, const KwQueryDev& q
     }
 }
 
+// The same for N (list, posting position) SLOTS of one hit — the multi-field score kernel's form (round 6): a hit of a query over two query_by fields holds up
+// to T x 2 runs, and agg_score_mf fetched them ONE load_run AFTER THE OTHER — up to six dependent chains of five round trips per scored hit. Here every
+// level's loads of all slots (the tokens of one field) are issued before any is waited for. A slot that is off (token absent from that field) reads
+// the addresses of the caller's fallback slot (always a present one: the driver token's own field) — loads a neighbour issues anyway — and yields empty_run().
+// Same values as load_run (the arithmetic is load_runs_staged's, which is checked against the oracle on every single-field hit).
+template <int N>
+__device__ inline void load_runs_staged_slots(const IndexView& ix, const uint32_t (&lst)[N], const uint32_t (&pos)[N], const bool (&on)[N], TokRun (&runs)[N], uint32_t& off_words) {
+    const uint32_t* base[N];
+    uint32_t blk[N];
+#pragma unroll
+    for (int t = 0; t < N; t++) {
+        const ListDesc& d = ix.lists[lst[t]];
+        base[t] = ix.payload + d.payload_base;
+        blk[t] = d.blk_base + (pos[t] >> 8);
+    }
+    BlockMeta m[N];
+#pragma unroll
+    for (int t = 0; t < N; t++) m[t] = ix.blk_meta[blk[t]];
+    uint32_t s[N], e[N];
+#pragma unroll
+    for (int t = 0; t < N; t++) {
+        const uint32_t i = pos[t] & 255;
+        const uint32_t* __restrict__ oi = base[t] + m[t].oi_woff;
+        s[t] = unpack_at_nb(oi, i, m[t].oi_bits);
+        const uint32_t nx = unpack_at_nb(oi, i + 1 < (uint32_t)m[t].n_ids ? i + 1 : i, m[t].oi_bits);
+        e[t] = (i == (uint32_t)m[t].n_ids - 1) ? m[t].n_off : nx;
+    }
+    uint64_t x[N];
+#pragma unroll
+    for (int t = 0; t < N; t++) {
+        const uint32_t ob = m[t].off_bits <= 16 ? m[t].off_bits : 0;
+        const uint64_t bitpos = (uint64_t)s[t] * ob;
+        const uint32_t* __restrict__ cw = base[t] + m[t].off_woff + (bitpos >> 5);
+        x[t] = ((uint64_t)cw[0] | ((uint64_t)cw[1] << 32)) >> (uint32_t)(bitpos & 31);
+    }
+#pragma unroll
+    for (int t = 0; t < N; t++) {
+        TokRun r;
+        r.w = base[t] + m[t].off_woff;
+        r.start = s[t];
+        r.base = m[t].off_base;
+        r.raw_len = e[t] - s[t];
+        r.meta = m[t].off_bits;
+        r.c01 = 0;
+        if (m[t].off_bits <= 16) {
+            const uint32_t mask = (1u << m[t].off_bits) - 1u;
+            const uint32_t v0 = m[t].off_base + ((uint32_t)x[t] & mask), v1 = m[t].off_base + ((uint32_t)(x[t] >> m[t].off_bits) & mask);
+            const uint32_t have = (e[t] - s[t]) < 2 ? (e[t] - s[t]) : 2;
+            if (((v0 | (have > 1 ? v1 : 0)) >> 16) == 0) { r.c01 = v0 | (v1 << 16); r.meta |= have << 16; }
+        }
+        runs[t] = r;
+    }
+    uint32_t lastv[N];
+#pragma unroll
+    for (int t = 0; t < N; t++) {                         // the run's last element (0 = the token ends the field): from c01 when it is there, else one more fetch
+        const uint32_t n = runs[t].raw_len, j = n ? n - 1 : 0;
+        lastv[t] = j < (runs[t].meta >> 16) ? ((runs[t].c01 >> (j * 16)) & 0xFFFFu) : runs[t].base + unpack_at_nb(runs[t].w, runs[t].start + j, run_bits(runs[t]));
+    }
+#pragma unroll
+    for (int t = 0; t < N; t++) {
+        if (on[t]) {
+            if (runs[t].raw_len > 0 && lastv[t] == 0) runs[t].meta |= 1u << 8;
+            runs[t].n = runs[t].raw_len - run_last_flag(runs[t]);
+            off_words += run_raw_len(runs[t]) + 1;
+        } else { TokRun r; r.w = nullptr; r.start = 0; r.n = 0; r.base = 0; r.raw_len = 0; r.meta = 0; r.c01 = 0; runs[t] = r; }      // (= empty_run())
+    }
+}
+
 // Match::Match(doc, token_positions, populate_window=false, check_exact_match) — include/match_score.h:129-275.
 // Window state lives in registers: every array index below is a compile-time constant after unrolling
 // (dynamic token ids are resolved with unrolled selects), so nothing spills to scratch.
@@ -939,6 +1014,54 @@ __device__ inline uint64_t agg_score_mf(const IndexView& ix, const KwQueryDev& q
                                         uint32_t tokens_found, uint32_t& off_words) {
     const uint32_t T = q.n_lists;
     AggState st;
+    if constexpr (TMAX <= 3 && KW_MF_STAGED) {
+        // (round 6) the runs of ONE field's tokens level by level (load_runs_staged_slots): five dependent round trips per field instead of five per (token, field).
+        // (Two fields at a time — six staged runs — needs more than the 128 registers the kernel's occupancy allows: 108 B of scratch, 3.41 -> 3.76 ms.)
+        uint32_t fb_list = 0, fb_pos = 0;
+        bool have_fb = false;
+#pragma unroll
+        for (int t = 0; t < TMAX; t++) {
+#pragma unroll
+            for (int ff = 0; ff < KW_MAX_FIELDS; ff++) {
+                const uint32_t p = pos[t * KW_MAX_FIELDS + ff];
+                if (!have_fb && (uint32_t)t < T && (uint32_t)ff < mf.n_fields && p != KW_NONE) { have_fb = true; fb_list = mf.list[t][ff]; fb_pos = p; }
+            }
+        }
+        if (!have_fb) return agg_finish(st, q, tokens_found);      // (cannot happen: a hit holds the driver token in the item's own field)
+        for (uint32_t f = 0; f < mf.n_fields; f++) {
+            uint32_t lst[TMAX], ps[TMAX];
+            bool on[TMAX];
+            uint32_t n_on = 0;
+#pragma unroll
+            for (int t = 0; t < TMAX; t++) {
+                uint32_t p = KW_NONE;
+#pragma unroll
+                for (int g = 0; g < KW_MAX_FIELDS; g++) if ((uint32_t)g == f) p = pos[t * KW_MAX_FIELDS + g];
+                const bool o = (uint32_t)t < T && p != KW_NONE;
+                on[t] = o;
+                lst[t] = o ? mf.list[t][f] : fb_list;
+                ps[t] = o ? p : fb_pos;
+                n_on += o ? 1u : 0u;
+            }
+            if (n_on == 0) continue;                          // field holds none of the tokens for this document (:5298-5300)
+            TokRun all[TMAX];
+            load_runs_staged_slots<TMAX>(ix, lst, ps, on, all, off_words);
+            TokRun runs[TMAX];
+#pragma unroll
+            for (int t = 0; t < TMAX; t++) runs[t] = empty_run();
+            uint32_t n_present = 0;
+#pragma unroll
+            for (int t = 0; t < TMAX; t++) {
+                if (on[t]) {
+#pragma unroll
+                    for (int j = 0; j < TMAX; j++) if ((uint32_t)j == n_present) runs[j] = all[t];      // append without dynamic register indexing
+                    n_present++;
+                }
+            }
+            agg_add(st, q.match_type, (ARR && mf.is_array[f]) ? field_match_score_array<TMAX>(q, runs, n_present) : field_match_score<TMAX>(q, runs, n_present), mf.weight[f]);
+        }
+        return agg_finish(st, q, tokens_found);
+    }
     for (uint32_t f = 0; f < mf.n_fields; f++) {
         TokRun runs[TMAX];
 #pragma unroll
@@ -1672,7 +1795,8 @@ __global__ __launch_bounds__(KW_THREADS) KW_FOUR_WAVES_PER_SIMD void kw_search_k
 // The "score" half of the two-kernel form: one workgroup per work item of the find kernel; its hits (seq_id + posting positions,
 // ascending seq_id) are scored 256 at a time — every wavefront full except the segment's last — through the same score stage,
 // top-K buffer and filter bookkeeping as the fused kernel, and leave the same partial result for kw_merge_kernel.
-// (body = device function with the work item's index as a parameter: kw_round_kernel runs it behind the find body in the same launch)
+// (body = a device function with the work item's index as a parameter; round 5's one-launch round kernel, measured slower and removed in round 6 —
+//  profiles/r05/exp_one_launch_rounds.txt — ran it behind the find body)
 template <int TMAX, int CAP, bool S2, bool MF = false, bool PLAIN = false>
 __device__ __forceinline__ void kw_score_body(const IndexView& ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work,
                                               const KwPartials& part, const uint32_t* __restrict__ aux_ids, uint32_t* __restrict__ ids_out,
@@ -3195,47 +3319,6 @@ __global__ __launch_bounds__(64) void kw_aux_score_kernel(IndexView ix, const Kw
 
 #include "kw_find2.hip.h"
 #include "kw_find_mf2.hip.h"
-
-// ------------------------------------------------------------------------------------------------
-// ONE LAUNCH PER SMALL ROUND (round 5). The server's calling convention (one query per call from many request threads, gathered
-// into rounds of a few dozen queries by the micro-batcher) ran every round as three launches — find | score | merge — with 6-7 us between
-// them: a tenth of a 16-query round. Here one workgroup per work item runs the pair-find body, then — its own hit records are in memory: a
-// workgroup-level fence and a barrier — the score body, writes its partial top-K, and takes a TICKET of its query (device-scope atomic behind a
-// device-scope release: the partial lists of a query are written by workgroups on several XCDs, each with its own L2). The work item that draws
-// the last ticket of its query acquires and merges the query's partial lists into the caller's arrays (kw_merge_body) and puts the ticket back to
-// zero. Same bodies, same results as the three kernels; for plain single-field queries of <= 3 tokens with two sort keys (the PLAIN score
-// instantiation) in rounds below option kw_round_fused_max_queries.
-// MEASURED AND LEFT OFF (default 0; profiles/r05/exp_one_launch_rounds.txt): one request thread 55 us per call with either form — the gaps between
-// the three launches are not what a lone round waits for — and 256 request threads 455 K -> 96 K q/s: the three bodies' static LDS adds up to 95 KB
-// (one workgroup per CU) and 143 VGPRs, so the rounds of the four lanes, which overlap on the device as separate lean kernels, queue behind each other.
-template <int TMAX>
-__global__ __launch_bounds__(KW_THREADS) void kw_round_kernel(IndexView ix, const KwQueryDev* __restrict__ queries, const KwWorkItem* __restrict__ work, KwPartials part,
-                                                               uint32_t* __restrict__ hits_all, const uint64_t* __restrict__ hit_off, KwOut out, uint32_t select_min,
-                                                               uint32_t* __restrict__ ticket, uint32_t n_work, uint32_t n_queries) {
-    __shared__ uint32_t s_last;
-    const uint32_t bid = blockIdx.x;
-    // a query without work items (a token no list holds) is nobody's to merge: workgroup b < n_queries writes query b's empty result if it is one
-    // (grid = max(work items, queries); the workgroups beyond the work table do only this)
-    if (bid < n_queries && threadIdx.x == 0 && queries[bid].n_work == 0) { out.n_hits[bid] = 0; out.num_matched[bid] = 0; out.off_words[bid] = 0; }
-    if (bid >= n_work) return;
-    kw_find2_body<TMAX, false>(ix, queries, work, part, hits_all, hit_off, bid);
-    __threadfence_block();                                // this workgroup's hit records and part.cnt[bid] are in memory before any of its threads reads them back
-    __syncthreads();
-    kw_score_body<TMAX, 512, false, false, true>(ix, queries, work, part, nullptr, nullptr, hits_all, hit_off, bid);
-    __threadfence();                                      // release: the partial list must be visible to whichever workgroup merges the query
-    __syncthreads();
-    const uint32_t qid = work[bid].query;
-    if (threadIdx.x == 0) {
-        const uint32_t n_work = queries[qid].n_work;
-        const uint32_t drawn = atomicAdd(ticket + qid, 1u);
-        s_last = drawn + 1 == n_work ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;                                  // (uniform)
-    __threadfence();                                      // acquire: the other work items' partial lists
-    kw_merge_body<512>(queries, part, out, select_min, qid);
-    if (threadIdx.x == 0) ticket[qid] = 0;                // the next round finds its tickets at zero (rounds of one lane follow each other on one stream)
-}
 
 #include "kw_groupby.hip.h"
 

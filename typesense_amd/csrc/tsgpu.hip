@@ -255,7 +255,6 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
     if (!strcmp(name, "kw_device_plan_min_queries")) { ctx->kw_device_plan_min_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 30); return ok(); }
     if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
-    if (!strcmp(name, "kw_round_fused_max_queries")) { ctx->kw_round_fused_max_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 20); return ok(); }
     if (!strcmp(name, "kw_candidates_rank_fold")) { ctx->kw_candidates_rank_fold = value != 0; return ok(); }
     if (!strcmp(name, "kw_mf_pipelined")) { ctx->kw_mf_pipelined = value != 0; return ok(); }
     if (!strcmp(name, "kw_count_touched")) { ctx->kw_count_touched = value != 0; return ok(); }
@@ -338,7 +337,6 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!ctx || !name || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_get_counter: NULL argument");
     std::lock_guard<std::mutex> lk(ctx->tm_mu);
     if (!strcmp(name, "kw_last_hit_groups")) { *out = ctx->kw_last_hit_groups; return ok(); }      // last keyword batch: find+score groups (0 = fused kernel)
-    if (!strcmp(name, "kw_round_fused_launches")) { *out = ctx->kw_round_fused_launches; return ok(); }     // rounds served by kw_round_kernel (one launch)
     if (!strcmp(name, "kw_candidates_rank_launches")) { *out = ctx->kw_candidates_rank_launches; return ok(); }
     if (!strcmp(name, "kw_mf_pipelined_launches")) { *out = ctx->kw_mf_pipelined_launches; return ok(); }     // find launches served by kw_find_mf2_kernel
     if (!strcmp(name, "kw_last_hit_records")) { *out = ctx->kw_last_hit_records; return ok(); }    // hit-record capacity the last batch asked for
@@ -1434,14 +1432,6 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         };
         uint32_t hit_groups = 0;
         bool find_marked = false;
-        // ONE launch for the whole round (kw_round_kernel: find + score per work item, the query's last work item merges): a small round of plain
-        // single-field <= 3-token queries, one hit-record group, no merge groups, nothing the PLAIN score instantiation lacks
-        bool round_fused = false;
-        if (ctx->kw_round_fused_max_queries && n_queries <= ctx->kw_round_fused_max_queries && !DP.on && tab_n[0] && !tab_n[1] && !tab_n[2] && !tab_n[3] && P.work_wild.empty() &&
-            tps[0].two && tps[0].group_start.size() == 2 && ctx->kw_pair_blocks && !v.touched && cap == 512 && !P.any_s2 && !P.any_aux && !ids_out && P.groups.empty() && !bo.vflat) {
-            if ((rc = L.d_ticket.reserve_zeroed((size_t)n_queries * 4, s))) return rc;
-            round_fused = true;
-        }
         auto run_table = [&](size_t nws, const TablePlan& tp, size_t first, auto tmax_tag, auto mf_tag) {
             constexpr int TM = decltype(tmax_tag)::value;
             constexpr bool MFT = decltype(mf_tag)::value;
@@ -1472,13 +1462,6 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             } else if constexpr (MFT) launch_search_mf_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out);
             else launch_search_cap<TM>(cap, s, (uint32_t)nws, v, dq, dw + first, shifted(first), daux, ids_out, P.any_s2);
         };
-        if (round_fused) {
-            const uint64_t* hoff_dev = (const uint64_t*)(dplan + tps[0].hoff_at);
-            hit_groups = 1;
-            ctx->kw_round_fused_launches++;
-            hipLaunchKernelGGL((kw_round_kernel<3>), dim3(std::max<uint32_t>((uint32_t)tab_n[0], n_queries)), dim3(KW_THREADS), 0, s, v, dq, dw, part, L.d_hits.as<uint32_t>(), hoff_dev, o,
-                               ctx->kw_merge_select_min, L.d_ticket.as<uint32_t>(), (uint32_t)tab_n[0], n_queries);
-        } else
         run_table(tab_n[0], tps[0], 0, std::integral_constant<int, 3>(), std::false_type());
         size_t sh = tab_n[0];
         run_table(tab_n[1], tps[1], sh, std::integral_constant<int, KW_MAX_TOKENS>(), std::false_type());
@@ -1501,7 +1484,7 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
             else if (cap == 1024) hipLaunchKernelGGL((kw_merge_groups_kernel<1024>), dim3(ng), dim3(KW_THREADS), 0, s, dq, part, dg);
             else hipLaunchKernelGGL((kw_merge_groups_kernel<2048>), dim3(ng), dim3(KW_THREADS), 0, s, dq, part, dg);
         }
-        if (!round_fused) launch_merge(cap, s, n_queries, dq, part, o, ids_out, dw, ctx->kw_merge_select_min);
+        launch_merge(cap, s, n_queries, dq, part, o, ids_out, dw, ctx->kw_merge_select_min);
         if (bo.vflat) hipLaunchKernelGGL(kw_vflat_distance_kernel, dim3(n_queries), dim3(KW_THREADS), 0, s, dq, daux, o);     // KV::vector_distance of the hits
         if (timing) TSGPU_HIP_TRY(hipEventRecord(L.ev[2], s));
         TSGPU_HIP_TRY(hipGetLastError());

@@ -314,15 +314,6 @@ struct KwLane {
     uint64_t wait_ema_us = 100;                      // how long this lane's recent rounds waited for the GPU (sleeping_wait)
     hipEvent_t ev_block = nullptr;                   // hipEventBlockingSync: the waiting thread sleeps instead of spinning (many concurrent callers)
     DevBuf d_touched;                                // option kw_count_touched: the find kernel's 8 byte counters
-    struct TicketBuf : DevBuf {                      // kw_round_kernel's per-query tickets: zero when a round starts (the kernel puts them back), so only NEW capacity is cleared
-        int reserve_zeroed(size_t bytes, hipStream_t s) {
-            if (bytes <= cap) return TSGPU_OK;
-            int rc = reserve(bytes);
-            if (rc) return rc;
-            TSGPU_HIP_TRY(hipMemsetAsync(p, 0, cap, s));
-            return TSGPU_OK;
-        }
-    } d_ticket;
     DevBuf d_plan, d_ids_out;                        // the batch plan (queries, work items, aux ids, multi-field descriptors, hit offsets): one upload
     DevBuf d_plan_in, d_plan_work;                   // device-side planner (kw_plan.hip.h): per-query input records; work items + hit offsets it writes
     PinBuf h_plan_tot;                               // ... and its totals, read back twice per batch
@@ -537,10 +528,8 @@ struct tsgpu_ctx {
     uint32_t kw_merge_select_min = 2;                // queries with at least this many partial lists are merged by selection (kw_select_partials: tree merge); 0 = always fold
     bool kw_count_touched = false;                   // measurement option: keyword batches launch the byte-counting instantiation of the find kernel
     tsgpu_kw_touched kw_touched{};                   // ... and leave its counters here (tsgpu_kw_last_touched; under tm_mu)
-    std::atomic<uint64_t> kw_mf_pipelined_launches{0}, kw_round_fused_launches{0}, kw_candidates_rank_launches{0};
+    std::atomic<uint64_t> kw_mf_pipelined_launches{0}, kw_candidates_rank_launches{0};
     bool kw_candidates_rank_fold = true;             // candidate combinations: the sort-free fold (kw_candidates_rank_kernel) instead of two bitonic sorts
-    uint32_t kw_round_fused_max_queries = 0;         // keyword rounds of at most this many plain single-field queries run as ONE launch (kw_round_kernel); 0 = never (default:
-                                                     // measured slower — 256 request threads 455 K -> 96 K q/s, one thread 55 us either way; profiles/r05/exp_one_launch_rounds.txt)
     bool kw_mf_pipelined = true;                     // multi-field find kernel: the pipelined form for launches of <= 2 query_by fields (kw_find_mf2.hip.h)
     bool kw_pair_blocks = true;                      // find kernel variant: two driver blocks per iteration (kw_find2.hip.h)
     long long kw_iddir_min_ids = 256;                // id directories (tsgpu_format.h): lists of at least max(this, num_docs / kw_iddir_density_div) ids get one; 0 = none
