@@ -87,9 +87,10 @@ __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQuery
         if constexpr (COUNT) { if (slot < n) cb_ids += (m.n_ids_bits >> 16) == 16 ? 2u : 4u; }
         return (m.n_ids_bits >> 16) == 16 ? (uint32_t)((const uint16_t*)w)[s2] : w[s2];
     };
+    const uint32_t nB = T >= 2 ? dB.n_blocks : 0u;       // (no second list: every window slot is padding)
     auto load_window = [&](uint32_t base) -> BlockIds {
-        if constexpr (COUNT) { if (T >= 2 && base + lane < dB.n_blocks) cb_meta += 16; }
-        return (T >= 2 && base + lane < dB.n_blocks) ? biB[base + lane] : PAD;
+        if constexpr (COUNT) { if (base + lane < nB) cb_meta += 16; }
+        return base + lane < nB ? biB[base + lane] : PAD;
     };
     // Driver-list metadata: lane j of every wave holds BlockIds[abase + j] — ONE vector load serves 32 pairs (most work items need only the
     // prologue's), a block's record is four v_readlane. (As per-pair loads they were uniform, so hipcc wanted them in SGPRs at once: a
@@ -110,7 +111,7 @@ __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQuery
 
     uint32_t wbase = 0, wver = 0;
     BlockIds win = load_window(0), nxt = load_window(32);
-    bool win_dirty = true;
+    uint32_t win_dirty = 1;                               // (an integer, not a bool: a uniform bool lives in an SGPR PAIR as a lane mask)
     struct Plan { uint32_t mode, rlo, rhi, w_begin, W, ver, base, buf; };   // mode: 0 tile, 1 tile in several rounds, 2 wide / broken run (probe), 3 exhausted, 4 no second list
     constexpr int PIPE_WORDS = KW_FIND_PIPE_WORDS;
     constexpr int TILE_WORDS = KW_FIND_TILE_WORDS;
@@ -123,13 +124,13 @@ __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQuery
         if (T < 2) return P;
         unsigned long long mk = __ballot(win.last_id >= lo_id ? 1 : 0);
         if (mk != 0 && (uint32_t)__builtin_ctzll(mk) >= 32) {          // cursor entered the upper half: slide by 32 blocks
-            wbase += 32; win = nxt; nxt = load_window(wbase + 32); win_dirty = true;
+            wbase += 32; win = nxt; nxt = load_window(wbase + 32); win_dirty = 1;
             mk = __ballot(win.last_id >= lo_id ? 1 : 0);
         }
         if (mk == 0) {                                                   // all 64 blocks end before lo_id: uniform search, re-centre
             uint32_t lo = wbase + 64, hi = dB.n_blocks;
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if constexpr (COUNT) { if (lane == 0) cb_meta += 4; } if (blB[mid] >= lo_id) hi = mid; else lo = mid + 1; }
-            wbase = lo; win = load_window(wbase); nxt = load_window(wbase + 32); win_dirty = true;
+            wbase = lo; win = load_window(wbase); nxt = load_window(wbase + 32); win_dirty = 1;
             mk = __ballot(win.last_id >= lo_id ? 1 : 0);
         }
         P.rlo = (uint32_t)__builtin_ctzll(mk);
@@ -142,10 +143,12 @@ __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQuery
         if (win_dirty) {
             wver ^= 1;
             if (t < 64) { sm.bw_last[wver][t] = win.last_id; sm.bw_first[wver][t] = win.first_id; sm.bw_woff[wver][t] = win.ids_woff; sm.bw_nb[wver][t] = win.n_ids_bits; }
-            win_dirty = false;
+            win_dirty = 0;
         }
         P.ver = wver;
-        if (dB.flags & LIST_HAS_BREAKS) {
+        uint32_t has_breaks = dB.flags & LIST_HAS_BREAKS;
+        KW_UNIFORM_OPAQUE(has_breaks);
+        if (has_breaks) {
             const uint32_t w_endw = win.ids_woff + packed_words(win.n_ids_bits & 0xFFFF, win.n_ids_bits >> 16);
             const uint32_t nxt_woff = (uint32_t)__shfl(win.ids_woff, (int)((lane + 1) & 63));
             const bool brk = lane >= P.rlo && lane < P.rhi && w_endw != nxt_woff;
@@ -176,11 +179,19 @@ __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQuery
         return P;
     };
 
-    // the pair (b, b + 1): metadata, raw ids and the plan one pair ahead
-    BlockIds mA = meta(wi.blk_begin), mB = meta(wi.blk_begin + 1), mC = meta(wi.blk_begin + 2), mD = meta(wi.blk_begin + 3);
-    uint32_t araw0 = load_id_raw(mA, t), araw1 = load_id_raw(mB, t);
-    Plan P = make_plan(mA.first_id, wi.blk_begin + 1 < wi.blk_end ? mB.last_id : mA.last_id);
-    const bool has_deadline = q.deadline_rem_us != 0;   // (read once: inside the loop the compiler re-reads the LDS copy of the query — and waits for it — every iteration)
+    // the pair (b, b + 1): metadata, raw ids and the plan one pair ahead. Of a pair's metadata only (first id, id count) of either block live on into the
+    // iteration that searches it; the next pair's records are read out of the window registers where they are used (as four whole records carried across
+    // the loop's back edge they were 16 of the kernel's 67 spilled SGPRs, each reload a v_readlane on the vector ALU: profiles/r06/exp_find2_valu.txt)
+    uint32_t a_first, a_nb, b_first, b_nb;
+    uint32_t araw0, araw1;
+    Plan P;
+    {
+        const BlockIds mA = meta(wi.blk_begin), mB = meta(wi.blk_begin + 1);
+        araw0 = load_id_raw(mA, t); araw1 = load_id_raw(mB, t);
+        P = make_plan(mA.first_id, wi.blk_begin + 1 < wi.blk_end ? mB.last_id : mA.last_id);
+        a_first = mA.first_id; a_nb = mA.n_ids_bits; b_first = mB.first_id; b_nb = mB.n_ids_bits;
+    }
+    const uint32_t has_deadline = q.deadline_rem_us;   // (read once: inside the loop the compiler re-reads the LDS copy of the query — and waits for it — every iteration)
     uint32_t q1n = 0, qfn = 0, par = 0, qh = 0;         // survivor queue: a RING of KW_QCAP entries, head qh, q1n queued; qfn = complete hits written (all uniform, in registers)
     KW_PROF_DECL
     static_assert((KW_QCAP & (KW_QCAP - 1)) == 0 && KW_QCAP >= 2 * KW_THREADS, "ring of at least 255 left-over + 256 new entries");
@@ -194,6 +205,7 @@ __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQuery
         uint32_t id = 0, v[TMAX];
 #pragma unroll
         for (int k = 0; k < TMAX; k++) v[k] = 0;
+        const IndexView ixp = KW_RELOAD_VIEW(ix);       // (the view's fields are read from the kernarg segment here, not kept in SGPRs across the pair loop)
         if (ok) {
             const uint32_t e = (qh + t) & (uint32_t)(KW_QCAP - 1);
             id = sm.q1_id[e];
@@ -203,8 +215,8 @@ __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQuery
             for (uint32_t s = 2; s < T && ok; s++) {
                 const uint32_t tok = q.probe_order[s];
                 uint32_t p;
-                if constexpr (COUNT) ok = probe_list<true>(ix, ix.lists[q.list[tok]], id, p, &cb_probe);
-                else ok = probe_list(ix, ix.lists[q.list[tok]], id, p);
+                if constexpr (COUNT) ok = probe_list<true>(ixp, ixp.lists[q.list[tok]], id, p, &cb_probe);
+                else ok = probe_list(ixp, ixp.lists[q.list[tok]], id, p);
 #pragma unroll
                 for (int k = 0; k < TMAX; k++) if ((uint32_t)k == tok) v[k] = p;
             }
@@ -222,14 +234,16 @@ __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQuery
 
     for (uint32_t b = wi.blk_begin, it = 0; b < wi.blk_end; b += 2, it++) {
         if (P.mode == 3) break;
+        uint32_t Tl = T;                                 // (the loop's own copy of T: its T >= 2 / T >= 3 tests are compares, not hoisted lane masks)
+        KW_UNIFORM_OPAQUE(Tl);
         KW_PROF(8)
         kw_glds_wait();                                  // this pair's tile (and driver ids) have landed
         KW_PROF(1)
-        if (has_deadline && (it & 7) == 0 && kw_out_of_time(ix, q, wi.query, &sm.stop)) break;
+        if (has_deadline) { if ((it & 7) == 0 && kw_out_of_time<true>(KW_RELOAD_VIEW(ix), q, wi.query, &sm.stop)) break; }
         const bool two = b + 1 < wi.blk_end;
-        const uint32_t n0 = mA.n_ids_bits & 0xFFFF, n1 = two ? (mB.n_ids_bits & 0xFFFF) : 0u;
+        const uint32_t n0 = a_nb & 0xFFFF, n1 = two ? (b_nb & 0xFFFF) : 0u;
         bool ok0 = t < n0, ok1 = t < n1;
-        const uint32_t id0 = ok0 ? mA.first_id + araw0 : 0xFFFFFFFFu, id1 = ok1 ? mB.first_id + araw1 : 0xFFFFFFFFu;
+        const uint32_t id0 = ok0 ? a_first + araw0 : 0xFFFFFFFFu, id1 = ok1 ? b_first + araw1 : 0xFFFFFFFFu;
         const Plan C = P;
         KW_PROF(0)
         const uint32_t* __restrict__ tile = sm.btile + C.buf * HALF;
@@ -240,10 +254,12 @@ __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQuery
         const uint32_t cur_last = win.last_id;
         uint32_t araw0n = 0, araw1n = 0;
         if (b + 2 < wi.blk_end) {
+            const BlockIds mC = meta(b + 2), mD = meta(b + 3);
             araw0n = load_id_raw(mC, t);
             araw1n = load_id_raw(mD, t);
             KW_PROF(10)
             P = make_plan(mC.first_id, b + 3 < wi.blk_end ? mD.last_id : mC.last_id);
+            a_first = mC.first_id; a_nb = mC.n_ids_bits; b_first = mD.first_id; b_nb = mD.n_ids_bits;      // (this pair's ids were formed above)
         }
         KW_PROF(4)
         // ---- (a) which block of the run, for both candidates ----
@@ -339,13 +355,18 @@ __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQuery
                     s0 += (e00 < t0 ? 1u : 0u) + (e01 < t0 ? 1u : 0u) + (e02 < t0 ? 1u : 0u);
                     s1 += (e10 < t1 ? 1u : 0u) + (e11 < t1 ? 1u : 0u) + (e12 < t1 ? 1u : 0u);
                 } else {
+                    // (the cursor IS the LDS address: per step one add, one compare, one select — the index form costs a fourth VALU instruction per step and
+                    //  chain for the address, and the vector ALU is the kernel's busiest port: profiles/r06/exp_find2_valu.txt)
+                    const uint16_t* __restrict__ c0 = a0;
+                    const uint16_t* __restrict__ c1 = a1;
 #pragma unroll
                     for (uint32_t step = 128; step > 0; step >>= 1) {
-                        const uint32_t v0 = a0[s0 + step - 1], v1 = a1[s1 + step - 1];
-                        s0 = v0 < t0 ? s0 + step : s0;
-                        s1 = v1 < t1 ? s1 + step : s1;
+                        const uint32_t v0 = c0[step - 1], v1 = c1[step - 1];
+                        c0 = v0 < t0 ? c0 + step : c0;
+                        c1 = v1 < t1 ? c1 + step : c1;
                     }
-                    const uint32_t h0 = a0[s0], h1 = a1[s1];
+                    const uint32_t h0 = c0[0], h1 = c1[0];
+                    s0 = (uint32_t)(c0 - a0); s1 = (uint32_t)(c1 - a1);
                     found0 = !done0 && h0 == t0; found1 = !done1 && h1 == t1;
                 }
                 p10 = (C.base + pos0) * BLOCK_IDS + s0; p11 = (C.base + pos1) * BLOCK_IDS + s1;
@@ -377,15 +398,21 @@ __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQuery
                 r_lo = r_hi + 1;
             }
         } else if (C.mode == 2) {
+            const IndexView ixp = KW_RELOAD_VIEW(ix);   // (wide / broken runs: the view and the second list's descriptor re-read here)
+            const ListDesc dBp = ixp.lists[q.list[q.probe_order[1]]];
             if constexpr (COUNT) {
-                if (ok0) found0 = probe_list<true>(ix, dB, id0, p10, &cb_probe);
-                if (ok1) found1 = probe_list<true>(ix, dB, id1, p11, &cb_probe);
+                if (ok0) found0 = probe_list<true>(ixp, dBp, id0, p10, &cb_probe);
+                if (ok1) found1 = probe_list<true>(ixp, dBp, id1, p11, &cb_probe);
             } else {
-                if (ok0) found0 = probe_list(ix, dB, id0, p10);
-                if (ok1) found1 = probe_list(ix, dB, id1, p11);
+                ProbeReq r0, r1;                             // (both candidates' directory entries requested before either is looked at)
+                r0.e = make_uint2(0u, 0u); r0.state = 0; r1.e = make_uint2(0u, 0u); r1.state = 0;
+                if (ok0) probe_issue(ixp, dBp, id0, r0);
+                if (ok1) probe_issue(ixp, dBp, id1, r1);
+                if (ok0) found0 = probe_finish(ixp, dBp, id0, r0, p10);
+                if (ok1) found1 = probe_finish(ixp, dBp, id1, r1, p11);
             }
         }
-        if (T >= 2) { ok0 = ok0 && found0; ok1 = ok1 && found1; }
+        if (Tl >= 2) { ok0 = ok0 && found0; ok1 = ok1 && found1; }
         KW_PROF(5)
         // ---- ordered compaction of both halves behind ONE barrier ----
         const unsigned long long m0 = __ballot(ok0 ? 1 : 0), m1 = __ballot(ok1 ? 1 : 0);
@@ -403,9 +430,9 @@ __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQuery
         KW_PROF(6)
         const uint32_t pa0 = b * BLOCK_IDS + t, pa1 = (b + 1) * BLOCK_IDS + t;        // posting positions in the driver list
 #ifdef TSGPU_F2_NOSTAGE2                                     // tools/ ablation only (results are WRONG): the pair loop without the third.. lists
-        if (T >= 3) { q1n = 0; } else
+        if (Tl >= 3) { q1n = 0; } else
 #endif
-        if (T >= 3) {
+        if (Tl >= 3) {
             if (ok0) { const uint32_t slot = (qh + q1n + base0 + lo0) & (uint32_t)(KW_QCAP - 1); sm.q1_id[slot] = id0; sm.q1_p0[slot] = pa0; sm.q1_p1[slot] = p10; }
             q1n += tot0;
             KW_PROF(7)
@@ -421,22 +448,22 @@ __device__ __forceinline__ void kw_find2_body(const IndexView& ix, const KwQuery
             if (ok0) {
                 uint32_t v[TMAX];
 #pragma unroll
-                for (int k = 0; k < TMAX; k++) { v[k] = 0; if (k == q.probe_order[0]) v[k] = pa0; if (T >= 2 && k == q.probe_order[1]) v[k] = p10; }
+                for (int k = 0; k < TMAX; k++) { v[k] = 0; if (k == q.probe_order[0]) v[k] = pa0; if (Tl >= 2 && k == q.probe_order[1]) v[k] = p10; }
                 kw_hit_store<TMAX>(hits, qfn + base0 + lo0, id0, v);
                 if constexpr (COUNT) cb_rec += 4u * (TMAX + 1);
             }
             if (ok1) {
                 uint32_t v[TMAX];
 #pragma unroll
-                for (int k = 0; k < TMAX; k++) { v[k] = 0; if (k == q.probe_order[0]) v[k] = pa1; if (T >= 2 && k == q.probe_order[1]) v[k] = p11; }
+                for (int k = 0; k < TMAX; k++) { v[k] = 0; if (k == q.probe_order[0]) v[k] = pa1; if (Tl >= 2 && k == q.probe_order[1]) v[k] = p11; }
                 kw_hit_store<TMAX>(hits, qfn + tot0 + base1 + lo1, id1, v);
                 if constexpr (COUNT) cb_rec += 4u * (TMAX + 1);
             }
             qfn += tot0 + tot1;
         }
         KW_PROF(7)
-        if (b + 5 >= abase + 64 && b + 4 < wi.blk_end) { abase = b + 4; awin = load_awin(abase); }   // (every 30 pairs: the one exposed load left)
-        mA = mC; mB = mD; mC = meta(b + 4); mD = meta(b + 5); araw0 = araw0n; araw1 = araw1n;   // (consumed in the middle of the next iteration)
+        if (b + 5 >= abase + 64 && b + 4 < wi.blk_end) { abase = b + 4; awin = load_awin(abase); }   // (every 30 pairs; waited for by the next iteration's kw_glds_wait, read by its meta(b + 2), meta(b + 3))
+        araw0 = araw0n; araw1 = araw1n;
     }
     if (T >= 3) while (q1n > 0) probe_batch(q1n < (uint32_t)KW_THREADS ? q1n : (uint32_t)KW_THREADS);
     if (t == 0) part.cnt[bid] = qfn;                           // hits handed to kw_score_kernel

@@ -67,6 +67,15 @@ namespace tsgpu {
 #define TSGPU_MF_STAGED 1        // multi-field score kernel (<= 3 tokens): a hit's runs loaded level by level for all tokens of a field (load_runs_staged_slots); 0 = one load_run per (token, field)
 #endif
 static const bool KW_MF_STAGED = TSGPU_MF_STAGED != 0;
+// A UNIFORM integer the compiler may not reason about across this point ("+s": it stays in an SGPR). Loop-invariant uniform PREDICATES (T >= 3, a list's
+// flag bit, ...) are hoisted out of a loop as i1 values, and a uniform i1 lives in an SGPR PAIR as a lane mask for the whole loop — in the find kernels that
+// is what pushes the allocator past 102 SGPRs, and every reload of a spilled SGPR is a v_readlane on the vector ALU, the kernels' busiest port. Laundering the
+// integer inside the loop makes the test a fresh s_cmp where it is used.
+#ifdef TSGPU_HIP_EMU
+#define KW_UNIFORM_OPAQUE(x) ((void)0)
+#else
+#define KW_UNIFORM_OPAQUE(x) asm volatile("" : "+s"(x))
+#endif
 static const int KW_THREADS = 256;
 static const int KW_QCAP = 512;            // LDS queue capacity (>= 255 leftover + 256 new)
 static const int KW_MAX_TOKENS = 10;       // TSGPU_MAX_QUERY_TOKENS
@@ -123,6 +132,30 @@ struct IndexView {
     uint32_t ticks_per_us;
     uint32_t* cutoff;
 };
+
+// The kernel's IndexView argument RE-READ from the kernarg segment (s_load where it is used) instead of kept live: the find kernels use most of its
+// fields only in their occasional paths (third-list probes of a drained batch, probes of wide runs, the deadline check), but hipcc loads every kernel
+// argument once at entry and keeps it in SGPRs for the whole pair loop — with the loop's own state that is ~150 uniform values for 102 registers, and
+// every reload of a spilled one is a v_readlane on the vector ALU. Valid only inside a __global__ function whose FIRST parameter is the IndexView.
+#if defined(TSGPU_HIP_EMU) || defined(TSGPU_NO_KERNARG_RELOAD)
+#define KW_RELOAD_VIEW(ix) (ix)
+#else
+__device__ __forceinline__ IndexView kw_reload_view_from_kernarg(const IndexView& ix) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) uint32_t* KernargWords;
+    KernargWords p = (KernargWords)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    union { IndexView v; uint32_t w[sizeof(IndexView) / 4]; } u;
+    static_assert(sizeof(IndexView) % 4 == 0, "copied as dwords");
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(IndexView) / 4); i++) u.w[i] = p[i];      // (scalar loads; only the fields the caller uses survive)
+    return u.v;
+#else
+    return ix;
+#endif
+}
+#define KW_RELOAD_VIEW(ix) kw_reload_view_from_kernarg(ix)
+#endif
 
 struct KwQueryDev {                  // one search_across_fields call
     uint32_t n_lists;                // tokens that exist in the index (token_its.size())
@@ -203,11 +236,14 @@ struct KwOut {                       // final, per query, stride = k_stride (tsg
 // what it found so far is scored and merged as usual, the caller gets partial hits with search_cutoff = 1.
 // Workgroup-uniform: every thread of the workgroup must call it at the same point. (Each wavefront reading the clock for itself is a
 // race — one wave leaves the loop, its siblings wait for it at the next barrier; the decision is taken by thread 0 and shared.)
+// KNOWN = the caller has already established (outside its loop) that the query has a deadline: the per-call test of the LDS copy of the query — a
+// dependent LDS round trip the compiler hoists to the top of EVERY iteration of the caller's loop — is left out
+template <bool KNOWN = false>
 __device__ inline bool kw_out_of_time(const IndexView& ix, const KwQueryDev& q, uint32_t query, uint32_t* s_flag) {
 #ifdef TSGPU_NO_DEADLINE
     return false;
 #endif
-    if (q.deadline_rem_us == 0) return false;                       // (uniform: the query record is shared by the workgroup)
+    if constexpr (!KNOWN) { if (q.deadline_rem_us == 0) return false; }      // (uniform: the query record is shared by the workgroup)
     __syncthreads();                                                // the previous decision has been read by everyone
     if (threadIdx.x == 0) {
 #ifdef TSGPU_HIP_EMU
