@@ -708,6 +708,15 @@ class Bench:
               "merge_ms": float(np.mean(merge)), "algorithmic_bytes_per_launch": float(np.mean(algb)),
               "achieved_GBs_on_algorithmic_bytes": float(np.mean(algb)) / (float(np.mean(kern)) * 1e-3) / 1e9 if np.mean(kern) > 0 else None,
               "queries_with_hits": int((n_hits > 0).sum()), "status_nonzero": int((st != 0).sum()), "second_field_build_s": build_s}
+        mf["kernel_ms"] = float(np.mean(kern))
+        if np.mean(kern) > 0:
+            ach = float(np.mean(algb)) / (float(np.mean(kern)) * 1e-3) / 1e9
+            mf["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                              "traffic": pmc_traffic([r"kw_find_mf2_kernel<3, 2>", r"kw_score_kernel<3, 512, true, true, true>"], ["pmc_kwg_fetch.txt"], field="max"),
+                              "kernel": "kw_find_mf2_kernel<3, 2> + kw_score_kernel<3, 512, MF> (back to back; kernel_ms spans both)", "kernel_ms": float(np.mean(kern)),
+                              "algorithmic_bytes_per_launch": float(np.mean(algb)),
+                              "note": "SURVEY 8(d) bytes over BOTH fields' lists / the two kernels' live time / 8 TB/s; like the single-field pair (frac 1.4) the kernels skip, but a two-field "
+                                      "driver block costs two tile merges + the other field's probes: 0.33 of peak on the same yardstick"}
         if not args.no_cpu_baseline:
             npar = min(n_q, 32)
             orc = O.OracleIndex(2, 1)
@@ -811,12 +820,27 @@ class Bench:
             g._ck(g.L.tsgpu_keyword_search_grouped_batch(g.h, garr, first, n_u, C.byref(c1), C.byref(cg1), None))
             g._ck(g.L.tsgpu_keyword_search_grouped_batch(g.h, garr, second, n_u, C.byref(c2), C.byref(cg2), None))
             return None
-        el, lat, _ = timed(step_g, steps, 2, 1)
+        gb_rec = {"kern": [], "fold": [], "sel": [], "idp": [], "bytes": [], "ids": [], "slots": []}
+
+        def after_g(_):
+            t = g.aux_timings()          # (the SECOND pass of the step: the last grouped batch)
+            gb_rec["kern"].append(t.gb_kernels_ms); gb_rec["fold"].append(t.gb_fold_ms); gb_rec["sel"].append(t.gb_select_ms); gb_rec["idp"].append(t.gb_id_pass_ms)
+            gb_rec["bytes"].append(t.gb_algorithmic_bytes); gb_rec["ids"].append(t.gb_matched_ids); gb_rec["slots"].append(t.gb_table_slots)
+        el, lat, _ = timed(step_g, steps, 2, 1, after_g)
         grp = {"workload": "%d user queries/step, each as the reference runs a group_by request: a FIRST pass (distinct Topster keyed by group, LogLogBeta group count) and a SECOND "
                            "pass (group_limit %d KVs per group, populate_result_kvs order); 3 distinct terms (ranks log-uniform [8,2000]), %d groups over %d documents, Topster 250; host "
                            "outputs" % (n_u, gl, n_grp, self.n_docs),
                "value": n_u * steps / el, "unit": "grouped user queries/s (two passes each)", "ms_per_step": 1e3 * el / steps, "matched_ids_per_step": int(h2.num_matched.sum()),
                "groups_returned_per_query": float(g2.n_groups.mean()), "queries_with_hits": int((h2.n_hits > 0).sum()), "status_nonzero": int((h2.status != 0).sum() + (h1.status != 0).sum())}
+        if gb_rec["kern"] and np.mean(gb_rec["kern"]) > 0:
+            km, by = float(np.mean(gb_rec["kern"])), float(np.mean(gb_rec["bytes"]))
+            ach = by / (km * 1e-3) / 1e9
+            grp["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic([r"gb_score_kernel", r"gb_insert_kernel", r"gb_select_kernel"], ["pmc_kwg_fetch.txt"], field="max"),
+                               "kernel": "the gb_* kernels of ONE pass (second pass of the step): gb_score + gb_insert (one thread per matched id) | gb_select (one workgroup per query) | gb_scatter + gb_members",
+                               "kernel_ms": km, "fold_ms (score + insert)": float(np.mean(gb_rec["fold"])), "select_ms": float(np.mean(gb_rec["sel"])), "id_pass_ms (host clock: the keyword kernels that produce the matched ids)": float(np.mean(gb_rec["idp"])),
+                               "algorithmic_bytes_per_launch": by, "matched_ids": float(np.mean(gb_rec["ids"])), "table_slots": float(np.mean(gb_rec["slots"])),
+                               "note": "algorithmic bytes = 36 per matched id (id + its 32-byte record) + 20 per table slot (key, best, rank, count: what the select kernel walks); the kernels are bound by "
+                                       "the LATENCY of random table atomics and by one workgroup per query in gb_select, not by bytes: the fraction of HBM peak is small by construction (kw_groupby.hip.h header)"}
         if not args.no_cpu_baseline:
             npar = min(n_u, 8)
             orc = O.OracleIndex(1, 1)
@@ -1005,12 +1029,26 @@ class Bench:
         def step_f():
             g._ck(g.L.tsgpu_facet_count_batch(g.h, 5, C.cast(ptrs, C.c_void_p), cnts.ctypes.data_as(C.c_void_p), n_f, 1, None, 0, C.byref(fo)))
             return None
-        el, lat, _ = timed(step_f, steps, 1, 1)
+        f_rec = {"kern": [], "cnt": [], "bytes": []}
+
+        def after_f(_):
+            t = g.aux_timings()
+            f_rec["kern"].append(t.facet_kernels_ms); f_rec["cnt"].append(t.facet_count_ms); f_rec["bytes"].append(t.facet_algorithmic_bytes)
+        el, lat, _ = timed(step_f, steps, 1, 1, after_f)
         got = [(oh[q, :min(onv[q], cap)], oc[q, :min(onv[q], cap)], od[q, :min(onv[q], cap)], op_[q, :min(onv[q], cap)], int(onv[q])) for q in range(n_f)]
         out = {"workload": "array facet field (1-3 of %d values per document) over %d documents; (a) the id lists of %d keyword queries (3-term AND) per step, (b) q = *: all "
                            "documents, plain / grouped (the group_by leg's %d groups) / 10 ranges of the points column; host inputs and outputs" % (n_val, n, n_f, max(16, n // 200)),
                "value": n_f * steps / el, "unit": "facet-counted queries/s", "ms_per_step": 1e3 * el / steps, "ids_per_step": int(sum(x.size for x in lists)),
                "values_per_query": float(np.mean([r[4] for r in got]))}
+        if f_rec["kern"] and np.mean(f_rec["kern"]) > 0:
+            km, by = float(np.mean(f_rec["kern"])), float(np.mean(f_rec["bytes"]))
+            ach = by / (km * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic([r"facet_count_kernel", r"facet_compact_kernel", r"facet_sort_kernel"], ["pmc_kwg_fetch.txt"], field="max"),
+                               "kernel": "facet_count_kernel (+ facet_compact + facet_sort)", "kernel_ms": km, "count_kernel_ms": float(np.mean(f_rec["cnt"])), "algorithmic_bytes_per_launch": by,
+                               "host_share_of_step": 1.0 - km / (1e3 * el / steps),
+                               "note": "algorithmic bytes = 20 per id (id + doc_ptr pair) + 4 per value it holds + 20 per table slot; the step is mostly HOST work — %d pageable id arrays gathered into the "
+                                       "pinned staging block, one upload, five downloads, per-query slicing of the outputs — which is why its rate moves with the box's host (580 K - 713 K q/s "
+                                       "between two boxes in round 5) while the kernels do not" % n_f}
         everything = [np.arange(n, dtype=np.uint32)]
         pts = np.ascontiguousarray(self.pts, dtype=np.int64)                          # (column 0 of the collection)
         lo_v, hi_v = int(pts.min()), int(pts.max()) + 1
@@ -1648,6 +1686,8 @@ def compact_line(full, detail_path=None):
         for name, o in gk.items():
             if isinstance(o, dict):
                 e = _pick(o, ("value", "unit", "ms_per_step", "kernel_ms", "find_ms", "score_ms"))
+                if isinstance(o.get("roofline"), dict):
+                    e["roofline"] = _pick(o["roofline"], ("bound", "frac", "kernel_ms", "achieved", "peak", "unit"))
                 if "parity" in o:
                     e["parity"] = _parity_small(o["parity"])
                 line["general_kernels"][name] = e

@@ -675,6 +675,23 @@ typedef struct tsgpu_timings {
 } tsgpu_timings;
 int tsgpu_last_timings(tsgpu_ctx* ctx, tsgpu_timings* out);
 
+/* Kernel time and algorithmic bytes of the last group_by batch (tsgpu_keyword_search_grouped[_candidates]_batch) and of the last facet-count batch
+ * (tsgpu_facet_count[_grouped]_batch) of this context (measurement; bench.py `general_kernels.{group_by, facets}.roofline`). HIP events on the
+ * library's own stream around the launches named below; the id pass of a grouped batch (the keyword kernels that produce the matched ids) is timed on
+ * the host clock. Bytes: per matched id 4 (id) + 32 (its record: three sort keys + distinct key) and per table slot 20 (key, best record, rank, count:
+ * what gb_select_kernel walks); facets: per id 4 + 16 (its doc_ptr pair) + 4 per value it holds, per table slot 20 (cleared + compacted). */
+typedef struct tsgpu_aux_timings {
+    float gb_id_pass_ms;             /* host clock: tsgpu_keyword_search_batch_ids of the combinations (0 for q = * over the whole collection) */
+    float gb_kernels_ms;             /* gb_iota .. gb_chunk: everything between the id pass and the delivery */
+    float gb_fold_ms;                /* ... of which gb_score + gb_dedupe + gb_insert (one thread per matched id) */
+    float gb_select_ms;              /* ... gb_select_kernel (one workgroup per query) */
+    uint64_t gb_matched_ids, gb_table_slots, gb_algorithmic_bytes;
+    float facet_kernels_ms;          /* facet_count + facet_compact + facet_sort */
+    float facet_count_ms;            /* ... facet_count_kernel alone */
+    uint64_t facet_ids, facet_table_slots, facet_algorithmic_bytes;
+} tsgpu_aux_timings;
+int tsgpu_last_aux_timings(tsgpu_ctx* ctx, tsgpu_aux_timings* out);
+
 /* Bytes the keyword kernels REQUEST, counted by the find kernel itself (measurement; bench.py `roofline.touched_bytes_per_launch`).
  * tsgpu_set_option("kw_count_touched", 1) makes keyword batches launch a second instantiation of the pair-find kernel
  * (kw_find2_kernel<TMAX, COUNT = true>) in which every lane adds the width of each of its own loads / LDS-DMA words / stores to

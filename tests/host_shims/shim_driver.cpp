@@ -240,8 +240,12 @@ int main(int argc, char** argv) {
             std::vector<uint32_t> id_buff;
             std::set<uint32_t> missing;
             size_t nkm = 0; bool cutoff = false;
-            const int rc = tsgpu::search_across_fields_grouped_gpu<oracle::KV>(a, &topster, groups_processed, id_buff, nkm, cutoff, &missing);
+            uint64_t groups_total = ~0ull;
+            const int rc = tsgpu::search_across_fields_grouped_gpu<oracle::KV>(a, &topster, groups_processed, id_buff, nkm, cutoff, &missing, &groups_total);
             CHECK(rc == TSGPU_OK, "grouped case %u: rc %d %s", c, rc, tsgpu_last_error());
+            // the exact distinct-key count of the pass (what the reference's groups_processed.size() is): never below the groups returned, equal to them while the Topster is not full
+            CHECK(groups_total >= groups_processed.size() && (groups_processed.size() >= a.query.topster_size || groups_total == groups_processed.size()),
+                  "grouped case %u: groups_total %llu vs %zu returned groups", c, (unsigned long long)groups_total, groups_processed.size());
             oracle::grouped_result_t got;
             oracle::populate_grouped(topster, groups_processed, got);                                             // populate_result_kvs over the caller's Topster
             CHECK(got.groups.size() == want_groups, "grouped case %u: %zu groups, oracle %u", c, got.groups.size(), want_groups);

@@ -436,6 +436,18 @@ def test_grouped_candidates_a_user_query_failing_after_the_id_pass_leaves_its_ne
                 assert np.array_equal(h.keys[u + 1, lo:lo + n], wh.keys[u, lo:lo + n]) and np.array_equal(qx[u + 1, lo:lo + n], wq[u, lo:lo + n])
 
 
+def test_aux_timings_describe_the_last_grouped_batch(world):
+    """tsgpu_last_aux_timings (bench.py `general_kernels.group_by.roofline`): matched ids, table slots and algorithmic bytes of the last grouped batch"""
+    orc, g, _, distinct, has_value = world
+    qs = [T.KwQuery([1, 2], topster_size=20), T.KwQuery([3], topster_size=20)]
+    h, gh = g.keyword_search_grouped_batch(qs, [(2, GROUP_COL, 0, 0, 0)] * 2, k_stride=40, g_stride=20)
+    t = g.aux_timings()
+    ids = int(h.num_matched.sum())
+    assert t.gb_matched_ids == ids > 0 and t.gb_table_slots >= 2 * ids
+    assert t.gb_algorithmic_bytes == 36 * t.gb_matched_ids + 20 * t.gb_table_slots
+    assert t.gb_kernels_ms >= t.gb_fold_ms >= 0 and t.gb_kernels_ms >= t.gb_select_ms >= 0 and t.gb_id_pass_ms > 0
+
+
 def _grouping_basics_product(lib):
     """CollectionGroupingTest.GroupingBasics (/root/reference/test/collection_grouping_test.cpp:71-96) through the library: q = *, group_by size, group_limit 2,
     sort rating desc: found_docs 12, found 3; groups 11 / 10 / 12 with 2 / 7 / 3 documents and the hits 5,1 / 4,3 / 2,8"""

@@ -672,91 +672,6 @@ def test_hnsw_graph_built_inside_the_library_equals_the_oracles_link_for_link(n,
     g.close()
 
 
-def _mk_i8(n, dim, metric, seed, lib, X=None):
-    """like _mk, with the field's bracket mirror in int8 (option vec_prefilter = 2 while the field is created)"""
-    rng = np.random.default_rng(seed)
-    X = rng.standard_normal((n, dim)).astype(np.float32) if X is None else X
-    g = T.GpuIndex(0, lib)
-    g.set_option("vec_prefilter", 2)
-    g.vec_create(1, dim, metric)
-    g.vec_upsert(1, np.arange(n, dtype=np.uint64), X)
-    orc = O.OracleIndex(1, 1)
-    orc.vec_init(dim, metric)
-    orc.vec_add(np.arange(n, dtype=np.uint32), X)
-    return g, orc, X, rng
-
-
-def _check_bits(g, orc, Q, k, allow=None):
-    dist, lab, cnt = g.vec_knn_batch(1, Q, k, allow_ids=allow)
-    for i in range(Q.shape[0]):
-        d, l = orc.flat_knn(Q[i], k, allow_ids=allow)
-        assert cnt[i] == d.size, (i, cnt[i], d.size)
-        assert np.array_equal(lab[i, :d.size].astype(np.uint32), l), (i, lab[i, :8], l[:8])
-        assert np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32)), i
-
-
-@pytest.mark.parametrize("n,dim,k,nq,sample_tiles,metric", [
-    (900, 32, 20, 3, 2, B.METRIC_IP),        # dim not a multiple of 128: zero-padded int8 columns
-    (700, 768, 100, 5, 1, B.METRIC_IP),      # the benchmark's dimension
-    (300, 130, 20, 70, 1, B.METRIC_COSINE),  # QT = 128 workgroup tile, unit rows, two int8 chunks with a ragged tail
-    (1100, 256, 10, 130, 3, B.METRIC_IP),    # QT = 256 (the <4, true> kernel)
-])
-def test_int8_bracket_mirror_returns_the_oracles_neighbours_bit_for_bit(n, dim, k, nq, sample_tiles, metric):
-    """vec_prefilter = 2: the bracket scan on v_mfma_i32_32x32x32_i8 over the int8 mirror (per-tile row scales, per-query scales, exact
-    residual norms in the bracket) prunes, the exact fp32 re-score decides — labels, order and distance bits = the oracle's flat scan; the
-    bracket path itself answers (no fp32-scan fallback), with deletions, an allow list and rows added later (their tile is re-quantised)"""
-    g, orc, X, rng = _mk_i8(n, dim, metric, 40 + n, H.emu_lib_path())
-    g.set_option("vec_sample_tiles", sample_tiles)
-    Q = rng.standard_normal((nq, dim)).astype(np.float32)
-    Q[0] = X[5] * 1.5
-    f0 = g.counter("vec_prefilter_fallbacks")
-    _check_bits(g, orc, Q, k)
-    assert g.counter("vec_prefilter_fallbacks") == f0 and g.counter("vec_prefilter_groups") > 0
-    allow = np.sort(rng.choice(n, size=max(40, n // 5), replace=False)).astype(np.uint32)
-    _check_bits(g, orc, Q[:3], min(k, 30), allow=allow)
-    # rows that arrive later, among them one with entries far beyond the tile's old maximum: the tile's scale changes, all of it is re-quantised
-    Xn = rng.standard_normal((70, dim)).astype(np.float32)
-    Xn[3] *= 9.0
-    g.vec_upsert(1, np.arange(n, n + 70, dtype=np.uint64), Xn)
-    orc.vec_add(np.arange(n, n + 70, dtype=np.uint32), Xn)
-    for i in range(n + 5, n + 25):
-        one = rng.standard_normal((1, dim)).astype(np.float32)
-        g.vec_upsert(1, np.array([i + 100], np.uint64), one)
-        orc.vec_add(np.array([i + 100], np.uint32), one)
-    _check_bits(g, orc, Q[:4], k)
-    g.vec_delete(1, 0); g.vec_delete(1, int(n + 3))
-    dist, lab, cnt = g.vec_knn_batch(1, Q[:2], k)
-    assert not ({0, n + 3} & set(lab[0, :cnt[0]].tolist()))
-    g.close()
-
-
-def test_int8_bracket_mirror_hard_cases_zero_rows_huge_values_non_finite_and_ties():
-    lib = H.emu_lib_path()
-    rng = np.random.default_rng(8)
-    n, dim = 600, 64
-    X = rng.standard_normal((n, dim)).astype(np.float32)
-    X[10] = 0.0                                     # an all-zero row
-    X[128:256] = 0.0                                # an all-zero TILE (scale 1)
-    X[300] *= 1e18; X[301] *= 1e-18                 # a tile whose scale is set by one huge row: its other rows quantise to 0 (wide brackets, still exact)
-    X[400, 3] = np.inf; X[401, 7] = np.nan          # non-finite rows are never rejected by a bracket
-    X[500:520] = X[499]                             # exact duplicates: ties -> smaller label
-    g, orc, X, _ = _mk_i8(n, dim, B.METRIC_IP, 1, lib, X=X)
-    g.set_option("vec_sample_tiles", 1)
-    Q = rng.standard_normal((4, dim)).astype(np.float32)
-    Q[1] = X[499]; Q[2] = 0.0; Q[3] = X[300] * 1e-18
-    dist, lab, cnt = g.vec_knn_batch(1, Q, 25)
-    for i in range(4):
-        d, l = orc.flat_knn(Q[i], 25)
-        assert cnt[i] == d.size
-        # (where a NaN distance sorts is not part of the contract: the two non-finite rows are left out of the comparison)
-        keep_g = ~np.isin(lab[i, :d.size], [400, 401]); keep_o = ~np.isin(l, [400, 401])
-        m = min(int(keep_g.sum()), int(keep_o.sum()))
-        assert m >= 23
-        assert np.array_equal(lab[i, :d.size][keep_g][:m].astype(np.uint32), l[keep_o][:m]), i
-        assert np.array_equal(dist[i, :d.size][keep_g][:m].view(np.uint32), d[keep_o][:m].view(np.uint32)), i
-    g.close()
-
-
 def test_hnsw_build_after_every_row_was_deleted_relinks_through_the_deleted_entry_point():
     """hnswlib's addPoint puts a DELETED entry point back into every level's candidates (`epDeleted`); without it a collection
     that was emptied and refilled handed empty heaps to mutuallyConnectNewElement — new nodes without links, unreachable by the graph search.

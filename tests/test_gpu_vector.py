@@ -36,8 +36,6 @@ test_hnsw_graph_search_replays_the_reference_traversal = E.test_hnsw_graph_searc
 test_edge_cases_empty_tiny_and_fully_deleted_indexes = E.test_edge_cases_empty_tiny_and_fully_deleted_indexes
 test_every_summation_order_of_hnswlibs_distance_is_bit_exact = E.test_every_summation_order_of_hnswlibs_distance_is_bit_exact
 test_vector_branch_flat_and_k_cut_match_the_oracle = E.test_vector_branch_flat_and_k_cut_match_the_oracle
-test_int8_bracket_mirror_returns_the_oracles_neighbours_bit_for_bit = E.test_int8_bracket_mirror_returns_the_oracles_neighbours_bit_for_bit
-test_int8_bracket_mirror_hard_cases_zero_rows_huge_values_non_finite_and_ties = E.test_int8_bracket_mirror_hard_cases_zero_rows_huge_values_non_finite_and_ties
 test_hnsw_graph_built_inside_the_library_equals_the_oracles_link_for_link = E.test_hnsw_graph_built_inside_the_library_equals_the_oracles_link_for_link
 test_hnsw_updates_and_slot_reuse_follow_addpoint_with_replace_deleted = E.test_hnsw_updates_and_slot_reuse_follow_addpoint_with_replace_deleted
 test_hnsw_build_after_every_row_was_deleted_relinks_through_the_deleted_entry_point = E.test_hnsw_build_after_every_row_was_deleted_relinks_through_the_deleted_entry_point

@@ -77,6 +77,13 @@ class TimingsC(C.Structure):
                 ("vec_scan_bytes", C.c_uint64), ("kw_find_ms", C.c_float)]
 
 
+class AuxTimingsC(C.Structure):
+    _fields_ = [("gb_id_pass_ms", C.c_float), ("gb_kernels_ms", C.c_float), ("gb_fold_ms", C.c_float), ("gb_select_ms", C.c_float),
+                ("gb_matched_ids", C.c_uint64), ("gb_table_slots", C.c_uint64), ("gb_algorithmic_bytes", C.c_uint64),
+                ("facet_kernels_ms", C.c_float), ("facet_count_ms", C.c_float), ("facet_ids", C.c_uint64), ("facet_table_slots", C.c_uint64),
+                ("facet_algorithmic_bytes", C.c_uint64)]
+
+
 class KwTouchedC(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("find_requested_bytes", "find_driver_ids", "find_metadata", "find_tile_dma", "find_probes", "find_records",
                                           "find_work_items", "find_hit_records", "score_requested_bytes")]
@@ -116,7 +123,7 @@ EXPORTS = [
     "tsgpu_term_num_ids", "tsgpu_term_download", "tsgpu_keyword_search_batch", "tsgpu_wildcard_search_batch", "tsgpu_keyword_search_candidates_batch", "tsgpu_candidates_result_ids", "tsgpu_keep_result_ids", "tsgpu_result_ids",
     "tsgpu_keyword_search_batch_ids", "tsgpu_keyword_search_grouped_batch", "tsgpu_keyword_search_grouped_candidates_batch", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free", "tsgpu_facet_set", "tsgpu_facet_count_batch", "tsgpu_facet_count_grouped_batch", "tsgpu_facet_range_count_batch", "tsgpu_facet_stats_batch", "tsgpu_facet_value_set", "tsgpu_facet_value_count_batch",
     "tsgpu_vec_create", "tsgpu_vec_upsert", "tsgpu_vec_delete", "tsgpu_vec_get", "tsgpu_vec_count", "tsgpu_vec_knn_batch",
-    "tsgpu_vec_hnsw_load", "tsgpu_vec_hnsw_enable", "tsgpu_vec_hnsw_export", "tsgpu_vec_hnsw_search_batch", "tsgpu_vec_distances", "tsgpu_ip_distance", "tsgpu_vector_search_batch", "tsgpu_vector_search_batch_ids", "tsgpu_hybrid_search_batch", "tsgpu_hybrid_fuse_batch", "tsgpu_keyword_aux_scores", "tsgpu_merge_shard_hits", "tsgpu_merge_shard_hits_device", "tsgpu_last_timings", "tsgpu_kw_last_touched", "tsgpu_kw_lists_footprint",
+    "tsgpu_vec_hnsw_load", "tsgpu_vec_hnsw_enable", "tsgpu_vec_hnsw_export", "tsgpu_vec_hnsw_search_batch", "tsgpu_vec_distances", "tsgpu_ip_distance", "tsgpu_vector_search_batch", "tsgpu_vector_search_batch_ids", "tsgpu_hybrid_search_batch", "tsgpu_hybrid_fuse_batch", "tsgpu_keyword_aux_scores", "tsgpu_merge_shard_hits", "tsgpu_merge_shard_hits_device", "tsgpu_last_timings", "tsgpu_last_aux_timings", "tsgpu_kw_last_touched", "tsgpu_kw_lists_footprint",
     "tsgpu_group_create_local", "tsgpu_group_unique_id", "tsgpu_group_create_rank", "tsgpu_group_create_rank_host", "tsgpu_group_destroy", "tsgpu_group_size", "tsgpu_group_keyword_search_batch",
     "tsgpu_group_vec_knn_batch", "tsgpu_group_hybrid_search_batch", "tsgpu_group_last_timings", "tsgpu_group_set_option",
 ]
@@ -209,6 +216,7 @@ def lib(path=None):
     L.tsgpu_merge_shard_hits_device.argtypes = [vp, C.POINTER(HitsC), u32, u32, u32, C.POINTER(HitsC)]
     L.tsgpu_last_timings.argtypes = [vp, C.POINTER(TimingsC)]
     L.tsgpu_kw_last_touched.argtypes = [vp, C.POINTER(KwTouchedC)]
+    L.tsgpu_last_aux_timings.argtypes = [vp, C.POINTER(AuxTimingsC)]
     L.tsgpu_kw_lists_footprint.argtypes = [vp, vp, vp, u32, C.POINTER(KwFootprintC)]
     L.tsgpu_facet_stats_batch.argtypes = [vp, u32, i32, vp, vp, u32, u32, vp, vp, u32, vp]
     L.tsgpu_facet_value_set.argtypes = [vp, u32, vp, vp, vp, u32]

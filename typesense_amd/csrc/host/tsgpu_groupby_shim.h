@@ -58,9 +58,12 @@ struct GroupByShimArgs {
     uint32_t n_has_value = 0;
 };
 
+// groups_processed receives the groups the call RETURNS (at most topster_size of them), the reference fills it for every distinct key of the pass. Index::search
+// reads groups_processed.size() as results_count for the typo_tokens_threshold / drop_tokens_threshold decisions (src/index.cpp:5095, 3617): with a threshold
+// above topster_size use *groups_total — the exact number of distinct keys of the pass — in its place.
 template <class KV, class TopsterT, class GroupsProcessed>
 int search_across_fields_grouped_gpu(const GroupByShimArgs& a, TopsterT* topster, GroupsProcessed& groups_processed, std::vector<uint32_t>& id_buff,
-                                     size_t& num_keyword_matches, bool& search_cutoff, std::set<uint32_t>* group_by_missing_value_ids) {
+                                     size_t& num_keyword_matches, bool& search_cutoff, std::set<uint32_t>* group_by_missing_value_ids, uint64_t* groups_total = nullptr) {
     const uint32_t K = a.query.topster_size ? a.query.topster_size : TSGPU_DEFAULT_TOPSTER_SIZE;
     const uint32_t L = a.group.first_pass ? 1u : a.group.group_limit;
     const size_t slots = (size_t)K * (L ? L : 1);
@@ -79,6 +82,8 @@ int search_across_fields_grouped_gpu(const GroupByShimArgs& a, TopsterT* topster
     tsgpu_grouped_hits g{};
     g.g_stride = K; g.n_groups = &n_groups; g.distinct_key = dkeys.data(); g.group_size = gsize.data(); g.group_found = gfound.data();
     g.loglog_registers = a.group.first_pass ? regs.data() : nullptr;
+    uint64_t gtotal = 0;
+    g.groups_total = &gtotal;
     tsgpu_id_lists* ids = nullptr;
     const int rc = tsgpu_keyword_search_grouped_batch(a.ctx, &a.query, &a.group, 1, &h, &g, &ids);
     if (rc != TSGPU_OK) return rc;
@@ -110,6 +115,7 @@ int search_across_fields_grouped_gpu(const GroupByShimArgs& a, TopsterT* topster
     }
     num_keyword_matches = (size_t)num_matched;
     search_cutoff = search_cutoff || cutoff != 0;
+    if (groups_total) *groups_total = gtotal;
     return TSGPU_OK;
 }
 
@@ -128,7 +134,7 @@ struct GroupByCandidatesShimArgs {
 
 template <class KV, class TopsterT, class GroupsProcessed>
 int search_all_candidates_grouped_gpu(const GroupByCandidatesShimArgs& a, TopsterT* topster, GroupsProcessed& groups_processed, std::vector<uint32_t>& id_buff,
-                                      size_t& num_keyword_matches, bool& search_cutoff, std::set<uint32_t>* group_by_missing_value_ids) {
+                                      size_t& num_keyword_matches, bool& search_cutoff, std::set<uint32_t>* group_by_missing_value_ids, uint64_t* groups_total = nullptr) {
     if (a.combos.empty()) return TSGPU_OK;
     const uint32_t K = a.combos[0].topster_size ? a.combos[0].topster_size : TSGPU_DEFAULT_TOPSTER_SIZE;
     const uint32_t L = a.group.first_pass ? 1u : a.group.group_limit;
@@ -148,6 +154,8 @@ int search_all_candidates_grouped_gpu(const GroupByCandidatesShimArgs& a, Topste
     tsgpu_grouped_hits g{};
     g.g_stride = K; g.n_groups = &n_groups; g.distinct_key = dkeys.data(); g.group_size = gsize.data(); g.group_found = gfound.data();
     g.loglog_registers = a.group.first_pass ? regs.data() : nullptr;
+    uint64_t gtotal = 0;
+    g.groups_total = &gtotal;
     const uint32_t begin[2] = {0, (uint32_t)a.combos.size()};
     tsgpu_id_lists* ids = nullptr;
     const int rc = tsgpu_keyword_search_grouped_candidates_batch(a.ctx, a.combos.data(), begin, &a.group, 1, &h, &g, qidx.data(), &ids);
@@ -178,6 +186,7 @@ int search_all_candidates_grouped_gpu(const GroupByCandidatesShimArgs& a, Topste
     }
     num_keyword_matches = (size_t)num_matched;
     search_cutoff = search_cutoff || cutoff != 0;
+    if (groups_total) *groups_total = gtotal;
     return TSGPU_OK;
 }
 

@@ -180,6 +180,7 @@ void tsgpu_destroy(tsgpu_ctx* ctx) {
     ctx->d_col_ptrs.release(); ctx->d_col_len.release(); ctx->d_prof.release();
     for (auto& c : ctx->columns) c.data.release();
     for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ctx->aux_ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -326,7 +327,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
         return ok();
     }
     if (!strcmp(name, "vec_prefilter")) {
-        if (value < 0 || value > 2) return fail(TSGPU_ERR_INVALID, "vec_prefilter must be 0 (fp32 MFMA scan), 1 (bf16 bracket scan) or 2 (int8 bracket scan; read when a vector field is created)");
+        if (value < 0 || value > 1) return fail(TSGPU_ERR_INVALID, "vec_prefilter must be 0 (fp32 MFMA scan) or 1 (bf16 bracket scan)");
         ctx->vec_prefilter = (uint32_t)value;
         return ok();
     }
@@ -2052,6 +2053,13 @@ int tsgpu_kw_lists_footprint(tsgpu_ctx* ctx, const uint32_t* field_ids, const ui
         out->n_ids += d.n_ids;
     }
     out->n_lists = handles.size();
+    return ok();
+}
+
+int tsgpu_last_aux_timings(tsgpu_ctx* ctx, tsgpu_aux_timings* out) {
+    if (!ctx || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_last_aux_timings: NULL argument");
+    std::lock_guard<std::mutex> lk(ctx->tm_mu);
+    *out = ctx->aux_timings;
     return ok();
 }
 

@@ -171,11 +171,15 @@ static int facet_count_impl(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
         a.group_col = grouped ? ctx->columns[group_column].data.as<long long>() : nullptr; a.group_len = grouped ? ctx->columns[group_column].n : 0;
         a.pair_key = grouped ? f->d_pair.as<unsigned long long>() : nullptr; a.pair_ones = grouped ? f->d_pair_ones.as<uint32_t>() : nullptr;
         a.tab_gcnt = grouped ? f->d_gcnt.as<uint32_t>() : nullptr;
+        for (int e = 0; e < 3; e++) if (!ctx->aux_ev[e]) TSGPU_HIP_TRY(hipEventCreate(&ctx->aux_ev[e]));      // (tsgpu_last_aux_timings)
+        TSGPU_HIP_TRY(hipEventRecord(ctx->aux_ev[0], s));
         if (blocks) hipLaunchKernelGGL(facet_count_kernel, dim3(blocks), dim3(FACET_THREADS), 0, s, a);
+        TSGPU_HIP_TRY(hipEventRecord(ctx->aux_ev[1], s));
         hipLaunchKernelGGL(facet_compact_kernel, dim3(n_queries, (uint32_t)std::min<uint64_t>((max_size + FACET_COMPACT_SLOTS - 1) / FACET_COMPACT_SLOTS, 4096)), dim3(FACET_THREADS), 0, s, a);
         FacetSortOut so;
         so.hash = f->d_sh.as<uint32_t>(); so.cnt = f->d_sc.as<uint32_t>(); so.doc = f->d_sd.as<uint32_t>(); so.pos = f->d_sp.as<uint32_t>();
         hipLaunchKernelGGL(facet_sort_kernel, dim3(n_queries), dim3(FACET_THREADS), 0, s, a, so);
+        TSGPU_HIP_TRY(hipEventRecord(ctx->aux_ev[2], s));
         TSGPU_HIP_TRY(hipGetLastError());
         if ((rc = f->h_out.reserve(((size_t)n_queries + 4 * out_total) * 4))) return rc;
         uint32_t* hn = f->h_out.as<uint32_t>();
@@ -186,6 +190,15 @@ static int facet_count_impl(tsgpu_ctx* ctx, uint32_t facet_field_id, const uint3
         TSGPU_HIP_TRY(hipMemcpyAsync(hd, f->d_sd.p, out_total * 4, hipMemcpyDeviceToHost, s));
         TSGPU_HIP_TRY(hipMemcpyAsync(hp, f->d_sp.p, out_total * 4, hipMemcpyDeviceToHost, s));
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        {
+            float cnt = 0, all = 0;
+            (void)hipEventElapsedTime(&cnt, ctx->aux_ev[0], ctx->aux_ev[1]); (void)hipEventElapsedTime(&all, ctx->aux_ev[0], ctx->aux_ev[2]);
+            std::lock_guard<std::mutex> tl(ctx->tm_mu);
+            tsgpu_aux_timings& A = ctx->aux_timings;
+            A.facet_kernels_ms = all; A.facet_count_ms = cnt; A.facet_ids = ids_total; A.facet_table_slots = tab_total;
+            // per id: the id + its doc_ptr pair + (on average n_hashes / n_docs) value hashes; per table slot: key 8 + count 4 + last 8 cleared, then compacted
+            A.facet_algorithmic_bytes = ids_total * 20ull + (uint64_t)((double)ids_total * (f->n_docs ? (double)f->n_hashes / f->n_docs : 0.0)) * 4ull + tab_total * 20ull;
+        }
         // the distinct values of a query in ascending hash order (result_map is keyed by the hash); the first `cap` of them are returned. The device ordered every
         // list of up to FACET_SORT_MAX values; a longer one arrives as the table held it and only its first `cap` hashes are put in order here
         // (hash << 32 | position in the device list)

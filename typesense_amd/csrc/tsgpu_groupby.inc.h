@@ -383,6 +383,8 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
         a.out.vector_distance = (float*)(dout + o_vd); a.out.match_score_index = (int8_t*)(dout + o_msi); a.out.n_hits = (uint32_t*)(dout + o_nhits);
         a.out.num_matched = nullptr; a.out.off_words = nullptr; a.out.k_stride = ks;
         IndexView v = make_view(ctx, snap);
+        for (int e = 0; e < 4; e++) if (!ctx->aux_ev[e]) TSGPU_HIP_TRY(hipEventCreate(&ctx->aux_ev[e]));      // (tsgpu_last_aux_timings: four marks per batch, ~2 us each)
+        TSGPU_HIP_TRY(hipEventRecord(ctx->aux_ev[0], s));
         if (n_items) {
             if (any_iota) hipLaunchKernelGGL(gb_iota_kernel, dim3((uint32_t)n_blocks), dim3(GB_THREADS), 0, s, a);
             uint32_t max_lists = 0;
@@ -392,15 +394,18 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
             if (any_dedupe) hipLaunchKernelGGL(gb_dedupe_kernel, dim3((uint32_t)n_blocks), dim3(GB_THREADS), 0, s, a);
             hipLaunchKernelGGL(gb_insert_kernel, dim3((uint32_t)n_blocks), dim3(GB_THREADS), 0, s, a);
         }
+        TSGPU_HIP_TRY(hipEventRecord(ctx->aux_ev[1], s));
         if (max_k + GB_THREADS <= 512) hipLaunchKernelGGL((gb_select_kernel<512>), dim3(n_queries), dim3(GB_THREADS), 0, s, a);
         else if (max_k + GB_THREADS <= 1024) hipLaunchKernelGGL((gb_select_kernel<1024>), dim3(n_queries), dim3(GB_THREADS), 0, s, a);
         else hipLaunchKernelGGL((gb_select_kernel<2048>), dim3(n_queries), dim3(GB_THREADS), 0, s, a);
+        TSGPU_HIP_TRY(hipEventRecord(ctx->aux_ev[2], s));
         if (any_second && n_items) {
             hipLaunchKernelGGL(gb_scatter_kernel, dim3((uint32_t)n_sblocks), dim3(GB_THREADS), 0, s, a);
             const uint64_t pairs = (uint64_t)n_queries * gs;
             hipLaunchKernelGGL(gb_members_kernel, dim3((uint32_t)((pairs + GB_THREADS / 64 - 1) / (GB_THREADS / 64))), dim3(GB_THREADS), 0, s, a);
             if (n_pw) hipLaunchKernelGGL(gb_chunk_kernel, dim3((uint32_t)n_pw), dim3(GB_THREADS), 0, s, a);      // (workgroups beyond a query's chunk count leave at once)
         }
+        TSGPU_HIP_TRY(hipEventRecord(ctx->aux_ev[3], s));
         TSGPU_HIP_TRY(hipGetLastError());
         uint64_t t_launched = now_us(), t_kernels = t_launched;
         if (host_timing) { TSGPU_HIP_TRY(hipStreamSynchronize(s)); t_kernels = now_us(); }
@@ -426,6 +431,14 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
         }
         TSGPU_HIP_TRY(hipStreamSynchronize(s));
         const uint64_t t_delivered = now_us();
+        {
+            float fold = 0, sel = 0, all = 0;
+            (void)hipEventElapsedTime(&fold, ctx->aux_ev[0], ctx->aux_ev[1]); (void)hipEventElapsedTime(&sel, ctx->aux_ev[1], ctx->aux_ev[2]); (void)hipEventElapsedTime(&all, ctx->aux_ev[0], ctx->aux_ev[3]);
+            std::lock_guard<std::mutex> tl(ctx->tm_mu);
+            tsgpu_aux_timings& A = ctx->aux_timings;
+            A.gb_id_pass_ms = (float)((t_ids - t_enter) * 1e-3); A.gb_kernels_ms = all; A.gb_fold_ms = fold; A.gb_select_ms = sel;
+            A.gb_matched_ids = n_items; A.gb_table_slots = n_slots; A.gb_algorithmic_bytes = n_items * 36ull + n_slots * 20ull;
+        }
         if (host_timing)
             fprintf(stderr, "[tsgpu] grouped batch %u queries, %llu matched ids, %llu slots: id pass %llu us, layout+upload+launch %llu us, kernels %llu us, delivery %llu us\n", n_queries,
                     (unsigned long long)n_items, (unsigned long long)n_slots, (unsigned long long)(t_ids - t_enter), (unsigned long long)(t_launched - t_ids),

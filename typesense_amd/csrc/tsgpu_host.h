@@ -548,7 +548,7 @@ struct tsgpu_ctx {
     uint32_t vec_cand_cap = 0;                       // candidate slots per query in pass 2 (0 = automatic)
     uint64_t commit_failed_count = 0;                // commits that returned an error (the next one re-packs from the host lists)
     uint32_t vec_ip_lanes = 4;                       // order of the exact distances' sums: 4 = hnswlib built for SSE (the reference's stock flags), 8 = AVX, 16 = AVX-512
-    uint32_t vec_prefilter = 1;                      // 1 = bf16 bracket scan + exact fp32 re-score (default); 2 = the same on an int8 mirror (fields created while it is set); 0 = fp32 MFMA scan
+    uint32_t vec_prefilter = 1;                      // 1 = bf16 bracket scan + exact fp32 re-score (default); 0 = fp32 MFMA scan
     uint64_t vec_prefilter_groups = 0;               // query groups answered by the bf16 bracket path
     int hnsw_visited_hash = 1;                        // 1 = per-query hash sets of visited ids (default), 0 = 16-bit tags per row and concurrent query
     int hnsw_visited_max_gib = 64;                    // cap of one field's HNSW visited-tag array (option): bounds the queries traversing concurrently
@@ -568,6 +568,8 @@ struct tsgpu_ctx {
 
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [3..7]: the vector path
     tsgpu_timings timings{};
+    tsgpu_aux_timings aux_timings{};                 // group_by / facet batches (tsgpu_last_aux_timings; under tm_mu)
+    hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // created on first use, on the context's device
     bool scan_events_valid = false;                  // ev[6]/ev[7] bracket the main k-NN scan of the last batch's first query group
 };
 

@@ -24,11 +24,6 @@ struct VecField {
     DevBuf X, labels, row_ok;
     DevBuf Xh, xnorm, tile_nmax;                       // bf16 prefilter mirror: bf16 rows [cap][dimp], inflated row norms, per-tile max norm
     uint32_t dimp = 0;                                 // dim rounded up to a multiple of 64 (zero padded)
-    // int8 bracket mirror (option vec_prefilter = 2 when the mirror is built): Xh holds int8 rows (dimp8 = dim rounded up to 128 columns, half the
-    // bytes), xnorm the bracket weights w[row], sx_tile the tile scales (vec_kernels.hip.h "int8 BRACKET mirror")
-    bool mirror_i8 = false;
-    uint32_t dimp8 = 0;
-    DevBuf sx_tile, d_sq;
     uint64_t cap_rows = 0, n_rows = 0, n_live = 0;
     std::vector<uint64_t> h_labels;
     std::vector<uint8_t> h_ok;
@@ -62,7 +57,7 @@ struct VecField {
         identity = false;
     }
     void release() {
-        DevBuf* b[] = {&X, &labels, &row_ok, &Xh, &xnorm, &tile_nmax, &sx_tile, &d_sq, &d_dense, &d_cand, &d_cand_cnt, &d_tau, &dQ, &d_dist, &d_lab, &d_cnt, &d_mask, &d_rows,
+        DevBuf* b[] = {&X, &labels, &row_ok, &Xh, &xnorm, &tile_nmax, &d_dense, &d_cand, &d_cand_cnt, &d_tau, &dQ, &d_dist, &d_lab, &d_cnt, &d_mask, &d_rows,
                        &d_q1, &d_out1, &d_Qh, &d_cq, &d_L1, &d_lbkey, &d_surv, &d_surv_cnt, &d_gkeys, &g_link0, &g_upper_ptr, &g_upper_links, &g_visited, &g_vhash, &g_stat};
         for (auto* x : b) x->release();
     }
@@ -71,12 +66,11 @@ struct VecField {
 static int vec_reserve_rows(VecField* f, uint64_t rows, hipStream_t s) {
     if (rows <= f->cap_rows) return TSGPU_OK;
     uint64_t want = std::max<uint64_t>(rows, f->cap_rows + f->cap_rows / 2 + 1024);
-    DevBuf nx, nl, no, nh, nn, nt, ns;
+    DevBuf nx, nl, no, nh, nn, nt;
     int rc;
-    auto drop = [&]() { nx.release(); nl.release(); no.release(); nh.release(); nn.release(); nt.release(); ns.release(); };
+    auto drop = [&]() { nx.release(); nl.release(); no.release(); nh.release(); nn.release(); nt.release(); };
     if ((rc = nx.reserve((size_t)want * f->dim * 4)) || (rc = nl.reserve((size_t)want * 8)) || (rc = no.reserve((size_t)want)) ||
-        (rc = nh.reserve((size_t)((want + VEC_ROWS - 1) / VEC_ROWS) * VEC_ROWS * f->dimp * 2)) || (rc = nn.reserve((size_t)want * 4)) || (rc = nt.reserve((size_t)(want / VEC_ROWS + 2) * 4)) ||
-        (rc = ns.reserve((size_t)(want / VEC_ROWS + 2) * 4))) { drop(); return rc; }
+        (rc = nh.reserve((size_t)((want + VEC_ROWS - 1) / VEC_ROWS) * VEC_ROWS * f->dimp * 2)) || (rc = nn.reserve((size_t)want * 4)) || (rc = nt.reserve((size_t)(want / VEC_ROWS + 2) * 4))) { drop(); return rc; }
     if (f->n_rows) {
         const size_t tiles = (size_t)((f->n_rows + VEC_ROWS - 1) / VEC_ROWS);
         hipError_t e = hipMemcpyAsync(nx.p, f->X.p, (size_t)f->n_rows * f->dim * 4, hipMemcpyDeviceToDevice, s);
@@ -85,12 +79,11 @@ static int vec_reserve_rows(VecField* f, uint64_t rows, hipStream_t s) {
         if (e == hipSuccess) e = hipMemcpyAsync(nh.p, f->Xh.p, tiles * VEC_ROWS * f->dimp * 2, hipMemcpyDeviceToDevice, s);   // whole tiles (tiled layout)
         if (e == hipSuccess) e = hipMemcpyAsync(nn.p, f->xnorm.p, (size_t)f->n_rows * 4, hipMemcpyDeviceToDevice, s);
         if (e == hipSuccess) e = hipMemcpyAsync(nt.p, f->tile_nmax.p, tiles * 4, hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess && f->sx_tile.p) e = hipMemcpyAsync(ns.p, f->sx_tile.p, tiles * 4, hipMemcpyDeviceToDevice, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { drop(); return fail(TSGPU_ERR_DEVICE, std::string("vec_reserve_rows: ") + hipGetErrorString(e)); }   // the field keeps its old buffers
     }
-    f->X.release(); f->labels.release(); f->row_ok.release(); f->Xh.release(); f->xnorm.release(); f->tile_nmax.release(); f->sx_tile.release();
-    f->X = nx; f->labels = nl; f->row_ok = no; f->Xh = nh; f->xnorm = nn; f->tile_nmax = nt; f->sx_tile = ns;
+    f->X.release(); f->labels.release(); f->row_ok.release(); f->Xh.release(); f->xnorm.release(); f->tile_nmax.release();
+    f->X = nx; f->labels = nl; f->row_ok = no; f->Xh = nh; f->xnorm = nn; f->tile_nmax = nt;
     f->cap_rows = want;
     return TSGPU_OK;
 }
@@ -204,16 +197,6 @@ static float vec_bracket_c(uint32_t dim) { return ((1.0f / 128.0f + 1.0f / 16384
 // final in X (normalised for cosine fields). Called with ctx->mu held; enqueues on the stream.
 static int vec_refresh_mirror(VecField* f, uint32_t row0, uint32_t n, uint64_t n_rows_after, hipStream_t s) {
     if (n == 0) return TSGPU_OK;
-    if (f->mirror_i8) {
-        // int8 mirror: a tile's scale is the maximum over ALL of its rows, so every tile the rows touch is quantised again as a whole
-        const uint32_t t0 = row0 / VEC_ROWS, t1 = (row0 + n - 1) / VEC_ROWS;
-        hipLaunchKernelGGL(vec_tile_to_i8_kernel, dim3(t1 - t0 + 1), dim3(256), 0, s, f->X.as<float>(), f->Xh.as<uint8_t>(), f->xnorm.as<float>(), f->sx_tile.as<float>(), t0,
-                           (uint32_t)n_rows_after, f->dim, f->dimp8, (float)f->dim * (1.0f / 2097152.0f), VEC_NORM_INFLATE);
-        hipLaunchKernelGGL(vec_tile_nmax_kernel, dim3((t1 - t0 + 1 + 63) / 64), dim3(64), 0, s, f->xnorm.as<float>(), f->tile_nmax.as<float>(), t0, t1 - t0 + 1,
-                           (uint32_t)n_rows_after);
-        TSGPU_HIP_TRY(hipGetLastError());
-        return TSGPU_OK;
-    }
     hipLaunchKernelGGL(vec_to_bf16_kernel, dim3((n + 3) / 4), dim3(256), 0, s, f->X.as<float>(), f->Xh.as<uint16_t>(), f->xnorm.as<float>(), row0, n, f->dim,
                        f->dimp, VEC_NORM_INFLATE, 0u);
     const uint32_t t0 = row0 / VEC_ROWS, t1 = (row0 + n - 1) / VEC_ROWS;
@@ -264,29 +247,19 @@ static int knn_group_prefilter(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, 
         geometry(a.n_ord, target_wgs, a.ord_per_slab, a.n_slabs);
         a.n_qtiles = n_qtiles;
         const dim3 grid(a.n_slabs * n_qtiles), block(VEC_HTHREADS);
-        if (f->mirror_i8) {
-            if (QT == 256) hipLaunchKernelGGL((vec_hscan_kernel<4, true>), grid, block, 0, s, a);
-            else if (QT == 128) hipLaunchKernelGGL((vec_hscan_kernel<2, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((vec_hscan_kernel<1, true>), grid, block, 0, s, a);
-        } else if (QT == 256) hipLaunchKernelGGL((vec_hscan_kernel<4>), grid, block, 0, s, a);
+        if (QT == 256) hipLaunchKernelGGL((vec_hscan_kernel<4>), grid, block, 0, s, a);
         else if (QT == 128) hipLaunchKernelGGL((vec_hscan_kernel<2>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((vec_hscan_kernel<1>), grid, block, 0, s, a);
     };
     if (record_events) TSGPU_HIP_TRY(hipEventRecord(ctx->ev[3], s));
     // queries -> bf16 (chunk-major) + cq = c * ||q||
-    if (f->mirror_i8) {
-        if ((rc = f->d_sq.reserve((size_t)n_q * 4))) return rc;
-        hipLaunchKernelGGL(vec_query_to_i8_kernel, dim3((n_q + 3) / 4), dim3(256), 0, s, Q_dev, f->d_Qh.as<uint8_t>(), f->d_cq.as<float>(), f->d_sq.as<float>(), n_q, f->dim, f->dimp8,
-                           n_q_pad, (float)f->dim * (1.0f / 2097152.0f), VEC_NORM_INFLATE * 1.01f);
-    } else
     hipLaunchKernelGGL(vec_to_bf16_kernel, dim3((n_q + 3) / 4), dim3(256), 0, s, Q_dev, f->d_Qh.as<uint16_t>(), f->d_cq.as<float>(), 0u, n_q, f->dim, f->dimp,
                        vec_bracket_c(f->dim) * VEC_NORM_INFLATE, n_q_pad);
     VecHScanArgs base;
     memset(&base, 0, sizeof base);
     base.Xh = f->Xh.as<uint16_t>(); base.row_ok = mask_dev; base.Qh = f->d_Qh.as<uint16_t>(); base.tile_nmax = f->tile_nmax.as<float>();
     base.n_q_pad = n_q_pad;
-    base.cq = f->d_cq.as<float>(); base.n_rows = n_rows; base.dimp = f->mirror_i8 ? f->dimp8 / 2 : f->dimp; base.n_q = n_q; base.L1 = f->d_L1.as<float>();
-    base.sx_tile = f->sx_tile.as<float>(); base.sq = f->d_sq.as<float>();
+    base.cq = f->d_cq.as<float>(); base.n_rows = n_rows; base.dimp = f->dimp; base.n_q = n_q; base.L1 = f->d_L1.as<float>();
 
     // pass 1: strided sample of the row tiles (all of them for a small index) -> L1[q] = k-th largest group maximum of the
     // sample's lower bounds
@@ -384,8 +357,7 @@ static int knn_device(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, uint32_t 
     }
     ctx->timings.vec_flops = 2ull * f->n_rows * f->dim * std::min<uint32_t>(n_q, GROUP);   // the HIP events bracket the first query group
     // bytes one main-scan launch must stream: the row matrix once (bf16 mirror, or fp32 rows on the fp32 scan) + the queries
-    ctx->timings.vec_scan_bytes = ctx->vec_prefilter ? (f->mirror_i8 ? (uint64_t)f->n_rows * f->dimp8 + (uint64_t)std::min<uint32_t>(n_q, GROUP) * f->dimp8
-                                                                       : (uint64_t)f->n_rows * f->dimp * 2 + (uint64_t)std::min<uint32_t>(n_q, GROUP) * f->dimp * 2)
+    ctx->timings.vec_scan_bytes = ctx->vec_prefilter ? (uint64_t)f->n_rows * f->dimp * 2 + (uint64_t)std::min<uint32_t>(n_q, GROUP) * f->dimp * 2
                                                      : (uint64_t)f->n_rows * f->dim * 4 + (uint64_t)std::min<uint32_t>(n_q, GROUP) * f->dim * 4;
     return TSGPU_OK;
 }
@@ -507,8 +479,6 @@ int tsgpu_vec_create(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t dim, int me
     if (!f) return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_create: host allocation failed");
     f->dim = dim;
     f->dimp = (dim + 63) / 64 * 64;
-    f->dimp8 = (dim + 127) / 128 * 128;
-    f->mirror_i8 = ctx->vec_prefilter == 2;
     f->metric = metric;
     int rc = vec_reserve_rows(f, std::max<uint64_t>(capacity_hint, 16), ctx->stream);   // include/index.h:367: init capacity 16
     if (rc) { f->release(); delete f; return rc; }

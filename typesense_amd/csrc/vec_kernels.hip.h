@@ -490,117 +490,6 @@ __global__ void vec_tile_nmax_kernel(const float* __restrict__ xnorm, float* __r
     tile_nmax[tile] = m;
 }
 
-// ---- int8 BRACKET mirror (option vec_prefilter = 2) -----------------------------------------------------------------------------------
-// The same bracket scan on v_mfma_i32_32x32x32_i8: half the mirror bytes (HBM and the LDS-DMA ingest that bounds the 256-query scan) and
-// twice the MFMA rate of bf16. Rows are quantised per 128-row TILE: sx = max|x| over the tile / 127, xq = rint(x / sx); queries per query:
-// sq = max|q| / 127. With dx = x - sx xq and dq = q - sq qq (exact residuals, their norms computed in fp32 and inflated):
-//     q.x = sq sx (qq.xq) + (sq qq).dx + dq.x          =>   |q.x - sq sx I| <= (||q|| + ||dq||) ||dx|| + ||dq|| ||x||,   I = qq.xq exact in int32
-// The bracket keeps its ONE-product form e = cq[query] * w[row] (so the scan epilogue, the threshold select and the refine kernel are shared
-// with the bf16 mirror): w[row] = ||dx|| + rho ||x||, cq = max(||q|| + ||dq||, (||dq|| + g ||q||) / rho), rho = 2^-7, g = dim 2^-21 (the fp32
-// summation of the exact distance, as in vec_bracket_c) — then cq w >= the bound above. Both factors carry a safety inflation (the host passes it).
-// Layout: the int8 mirror is addressed by the scan kernel as if it were a bf16 matrix of dim / 2 (two int8 per "element"): same tiles,
-// same 16 KB blocks, same swizzle, half as many pipeline steps.
-static const float VEC_I8_RHO = 1.0f / 128.0f;
-
-// one workgroup (256 threads) per 128-row tile: tile scale, int8 rows in the tiled layout (dimp8 = dim rounded up to 128, zero padded),
-// w[row] into xnorm. Rows >= n_rows of the last tile are zero.
-__global__ __launch_bounds__(256) void vec_tile_to_i8_kernel(const float* __restrict__ X, uint8_t* __restrict__ Xq, float* __restrict__ wnorm, float* __restrict__ sx_tile,
-                                                              uint32_t tile0, uint32_t n_rows, uint32_t dim, uint32_t dimp8, float g_sum, float inflate) {
-    __shared__ float s_red[4];
-    __shared__ float s_scale;
-    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint32_t tile = tile0 + blockIdx.x, r0 = tile * VEC_ROWS;
-    // (1) max |x| over the tile (non-finite values are left out of the scale: such rows get w = inf below and are never rejected)
-    float m = 0.0f;
-    for (uint32_t r = wave; r < (uint32_t)VEC_ROWS; r += 4) {
-        if (r0 + r >= n_rows) break;
-        const float* __restrict__ x = X + (size_t)(r0 + r) * dim;
-        for (uint32_t k = lane; k < dim; k += 64) { const float a = fabsf(x[k]); if (f32_finite(a) && a > m) m = a; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if (lane == 0) s_red[wave] = m;
-    __syncthreads();
-    if (t == 0) {
-        const float mm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-        s_scale = mm > 0.0f ? mm / 127.0f : 1.0f;
-        sx_tile[tile] = s_scale;
-    }
-    __syncthreads();
-    const float sx = s_scale, inv = 1.0f / sx;
-    // (2) quantise: one wave per row, four int8 per lane and step (one dword store into the tiled layout: [tile][k / 128][row][k % 128])
-    const uint32_t n_c128 = dimp8 / 128;
-    for (uint32_t r = wave; r < (uint32_t)VEC_ROWS; r += 4) {
-        const bool live = r0 + r < n_rows;
-        const float* __restrict__ x = X + (size_t)(live ? r0 + r : 0) * dim;
-        float sd = 0.0f, sxx = 0.0f;
-        bool bad = false;
-        for (uint32_t k = 4 * lane; k < dimp8; k += 256) {
-            uint32_t packed = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float a = (live && k + j < dim) ? x[k + j] : 0.0f;
-                if (!f32_finite(a)) bad = true;
-                float qf = rintf(a * inv);
-                qf = qf > 127.0f ? 127.0f : (qf < -127.0f ? -127.0f : qf);
-                const int qi = f32_finite(a) ? (int)qf : 0;
-                const float d = a - sx * (float)qi;
-                sd = fmaf(d, d, sd);
-                sxx = fmaf(a, a, sxx);
-                packed |= ((uint32_t)qi & 0xFFu) << (8 * j);
-            }
-            uint8_t* __restrict__ dst = Xq + ((size_t)tile * n_c128 + (k >> 7)) * (size_t)(VEC_ROWS * 128) + (size_t)r * 128 + (k & 127);
-            *(uint32_t*)dst = packed;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { sd += __shfl_xor(sd, off); sxx += __shfl_xor(sxx, off); bad = bad || (__shfl_xor(bad ? 1 : 0, off) != 0); }
-        if (lane == 0 && live) {
-            const float w = (sqrtf(sd) + (VEC_I8_RHO + g_sum) * sqrtf(sxx)) * inflate;
-            wnorm[r0 + r] = bad ? __uint_as_float(0x7F800000u) : w;
-        }
-    }
-}
-
-// one wave per query: int8 copy in the query layout (as "bf16 pairs": [k / 128][q][k % 128]), sq[q], cq[q]
-__global__ __launch_bounds__(256) void vec_query_to_i8_kernel(const float* __restrict__ Q, uint8_t* __restrict__ Qq, float* __restrict__ cq, float* __restrict__ sq_out,
-                                                               uint32_t n_q, uint32_t dim, uint32_t dimp8, uint32_t q_pad, float g_sum, float inflate) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (q >= n_q) return;                          // whole wave exits together
-    const float* __restrict__ x = Q + (size_t)q * dim;
-    float m = 0.0f;
-    bool bad = false;
-    for (uint32_t k = lane; k < dim; k += 64) { const float a = fabsf(x[k]); if (!f32_finite(a)) bad = true; else if (a > m) m = a; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { m = fmaxf(m, __shfl_xor(m, off)); bad = bad || (__shfl_xor(bad ? 1 : 0, off) != 0); }
-    const float sq = m > 0.0f ? m / 127.0f : 1.0f, inv = 1.0f / sq;
-    float sd = 0.0f, sqq = 0.0f;
-    for (uint32_t k = 4 * lane; k < dimp8; k += 256) {
-        uint32_t packed = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float a = k + j < dim ? x[k + j] : 0.0f;
-            float qf = rintf(a * inv);
-            qf = qf > 127.0f ? 127.0f : (qf < -127.0f ? -127.0f : qf);
-            const int qi = f32_finite(a) ? (int)qf : 0;
-            const float d = a - sq * (float)qi;
-            sd = fmaf(d, d, sd);
-            sqq = fmaf(a, a, sqq);
-            packed |= ((uint32_t)qi & 0xFFu) << (8 * j);
-        }
-        uint8_t* __restrict__ dst = Qq + ((size_t)(k >> 7) * q_pad + q) * 128 + (k & 127);
-        *(uint32_t*)dst = packed;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { sd += __shfl_xor(sd, off); sqq += __shfl_xor(sqq, off); }
-    if (lane == 0) {
-        const float qn = sqrtf(sqq), dqn = sqrtf(sd);
-        const float a1 = qn + dqn, a2 = (dqn + g_sum * qn) / VEC_I8_RHO;
-        cq[q] = bad ? __uint_as_float(0x7FC00000u) : (a1 > a2 ? a1 : a2) * inflate;
-        sq_out[q] = sq;
-    }
-}
-
 struct VecHScanArgs {
     const uint16_t* Xh;        // bf16 rows, tiled layout (vec_xh_index)
     const uint8_t* row_ok;     // nullable
@@ -608,8 +497,6 @@ struct VecHScanArgs {
     uint32_t n_q_pad;
     const float* tile_nmax;    // [n_tiles]
     const float* cq;           // [n_q] c * ||q||
-    const float* sx_tile;      // int8 mirror: [n_tiles] tile scales; sq: [n_q] query scales (score = sq * sx * the int32 dot)
-    const float* sq;
     uint32_t n_rows, dimp, n_q;
     uint32_t n_ord, tile_stride, ord_per_slab, n_slabs, n_qtiles;
     int mode;                  // 0 = filtered scan (candidate segments), 1 = sample (group maxima of the lower bounds)
@@ -688,11 +575,9 @@ struct VecHScanSmem {
     uint32_t cnt[QT];          // mode 0: candidates of this workgroup per query column
 };
 
-typedef int vec_i32x4 __attribute__((ext_vector_type(4)));
-typedef int vec_i32x16 __attribute__((ext_vector_type(16)));
-// I8 = the int8 mirror (v_mfma_i32_32x32x32_i8, exact int32 accumulators; a.dimp = int8 columns / 2: the kernel moves the same bytes per
-// step, each step covers twice the k): only the MFMA and the epilogue's view of the accumulators differ.
-template <int CB, bool I8 = false>
+// (round 4's int8 mirror — v_mfma_i32_32x32x32_i8 over per-tile quantised rows: the scan itself 3.1 ms instead of 4.4, but its wider bracket sent 3-4x the rows
+//  to the exact re-score, a net loss end to end; profiles/r04/exp_vec_int8.txt — was removed in round 6)
+template <int CB>
 __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a) {
     constexpr int QT = 64 * CB;
     constexpr int BK = CB >= 4 ? 32 : 64;              // k per step
@@ -769,15 +654,7 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
     __syncthreads();                                     // (their waits drain nothing of ours: no DMA issued yet)
 
     const uint32_t last = total_steps - 1;
-    typedef typename std::conditional<I8, vec_i32x16, vec_f32x16>::type AccT;
-    AccT acc[2][CB];
-    // int8: score = scale * (int32 dot), scale = sq[query] * sx[tile] (the epilogue compares the lane's MAXIMUM dot once per column; the float
-    // rounding of that product is far inside the bracket's slack)
-    float sqv[CB];
-#pragma unroll
-    for (int cb = 0; cb < CB; cb++) {
-        if constexpr (I8) { const uint32_t gq = q0 + wcol + cb * 32 + (lane & 31); sqv[cb] = a.sq[gq < a.n_q ? gq : a.n_q - 1]; } else sqv[cb] = 1.0f;
-    }
+    vec_f32x16 acc[2][CB];
     // The per-lane constants above come from plain global loads, and hipcc waits for a load where its value is FIRST USED — here the tile
     // epilogue, INSIDE the pipelined loop: `s_waitcnt vmcnt(3) .. vmcnt(0)` before the four `cq * nmax` products, in every epilogue. Its counter
     // model knows nothing of the asm-issued LDS-DMAs, the hardware counter does: each of those waits drained the DMA ring, once per tile and
@@ -785,7 +662,7 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
     // compiler wait NOW, before the first DMA is in flight, and leaves nothing of its own pending inside the loop.
 #ifndef TSGPU_HIP_EMU
 #pragma unroll
-    for (int cb = 0; cb < CB; cb++) asm volatile("" ::"v"(cqv[cb]), "v"(L1v[cb]), "v"(sqv[cb]));
+    for (int cb = 0; cb < CB; cb++) asm volatile("" ::"v"(cqv[cb]), "v"(L1v[cb]));
 #endif
 #pragma unroll
     for (int i = 0; i < NS - 1; i++) {
@@ -875,8 +752,7 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
             for (int rb = 0; rb < 2; rb++)
 #pragma unroll
                 for (int cb = 0; cb < CB; cb++) {
-                    if constexpr (I8) acc[rb][cb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(vec_i32x4, av[cur][rb]), __builtin_bit_cast(vec_i32x4, bv[cur][cb]), acc[rb][cb], 0, 0, 0);
-                    else acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vec_bf16x8, av[cur][rb]), __builtin_bit_cast(vec_bf16x8, bv[cur][cb]),
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vec_bf16x8, av[cur][rb]), __builtin_bit_cast(vec_bf16x8, bv[cur][cb]),
                                                                                acc[rb][cb], 0, 0, 0);
                 }
 #endif
@@ -902,8 +778,6 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
                 const uint32_t o = ord_begin + oi;
                 const uint32_t r0 = o * a.tile_stride * VEC_ROWS;
                 const float nmax = sm.nmax[oi];
-                float sxt = 1.0f;
-                if constexpr (I8) sxt = a.sx_tile[o * a.tile_stride];
                 const uint32_t strip = wr & 1;                               // 64-row strip inside the tile
                 const uint32_t rbase = r0 + strip * 64 + 4 * (lane >> 5);
 #pragma unroll
@@ -916,22 +790,11 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
                         // inside c dwarfs the rounding of that subtraction. Non-finite rows / queries have e = inf or NaN, so
                         // thr is -inf / NaN and every compare below passes: nothing non-finite is ever rejected.
                         const float thr = L1v[cb] - e;
-                        const float scale = sqv[cb] * sxt;                                             // (1 on the bf16 mirror)
-                        float amax;
-                        if constexpr (I8) {
-                            int mi = acc[0][cb][0];
+                        float amax = acc[0][cb][0];
 #pragma unroll
-                            for (int rb = 0; rb < 2; rb++)
+                        for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-                                for (int el = 0; el < 16; el++) mi = acc[rb][cb][el] > mi ? acc[rb][cb][el] : mi;       // v_max3_i32 chain (scale > 0: the largest dot is the largest score)
-                            amax = (float)mi * scale;
-                        } else {
-                            amax = acc[0][cb][0];
-#pragma unroll
-                            for (int rb = 0; rb < 2; rb++)
-#pragma unroll
-                                for (int el = 0; el < 16; el++) amax = fmaxf(amax, acc[rb][cb][el]);       // v_max3_f32 chain
-                        }
+                            for (int el = 0; el < 16; el++) amax = fmaxf(amax, acc[rb][cb][el]);       // v_max3_f32 chain
                         if (gq < a.n_q && !(amax < thr)) {
                             // (nearly every wave has SOME lane in here for every column block — ~1.2 candidates per (wave, block) at 10M rows — so what
                             // counts is the instructions the wave issues inside: the 32 scores are tested in groups of 4 behind their maximum, and only
@@ -941,16 +804,13 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
                             for (int rb = 0; rb < 2; rb++)
 #pragma unroll
                                 for (int g4 = 0; g4 < 4; g4++) {
-                                    float gm;
-                                    if constexpr (I8) { int m4 = acc[rb][cb][4 * g4]; for (int e4 = 1; e4 < 4; e4++) m4 = acc[rb][cb][4 * g4 + e4] > m4 ? acc[rb][cb][4 * g4 + e4] : m4; gm = (float)m4 * scale; }
-                                    else gm = fmaxf(fmaxf((float)acc[rb][cb][4 * g4], (float)acc[rb][cb][4 * g4 + 1]), fmaxf((float)acc[rb][cb][4 * g4 + 2], (float)acc[rb][cb][4 * g4 + 3]));
+                                    const float gm = fmaxf(fmaxf(acc[rb][cb][4 * g4], acc[rb][cb][4 * g4 + 1]), fmaxf(acc[rb][cb][4 * g4 + 2], acc[rb][cb][4 * g4 + 3]));
                                     if (gm < thr) continue;
 #pragma unroll
                                     for (int e4 = 0; e4 < 4; e4++) {
                                         const int el = 4 * g4 + e4;
                                         const uint32_t row = rbase + rb * 32 + (el & 3) + 8 * (el >> 2);
-                                        float sc = (float)acc[rb][cb][el];
-                                        if constexpr (I8) sc *= scale;
+                                        const float sc = acc[rb][cb][el];
                                         if (!(sc < thr) && row < a.n_rows && (!a.row_ok || a.row_ok[row] != 0)) {
                                             const uint32_t slot = atomicAdd(&sm.cnt[col], 1u);      // LDS
                                             if (slot < a.seg_cap) seg[slot] = ((uint64_t)__float_as_uint(sc) << 32) | row;
@@ -969,9 +829,7 @@ __global__ __launch_bounds__(VEC_HTHREADS) void vec_hscan_kernel(VecHScanArgs a)
                                 const uint32_t row = rbase + rb * 32 + (el & 3) + 8 * (el >> 2);
                                 bool okr = row < a.n_rows;
                                 if (okr && a.row_ok) okr = a.row_ok[row] != 0;
-                                float sc1 = (float)acc[rb][cb][el];
-                                if constexpr (I8) sc1 *= sqv[cb] * sxt;
-                                const float lb = sc1 - e;
+                                const float lb = acc[rb][cb][el] - e;
                                 if (okr && f32_finite(lb) && lb > best) best = lb;
                             }
                         a.gmax[(size_t)gq * a.gstride + (size_t)o * 4 + strip * 2 + (lane >> 5)] = f32_finite(best) ? f32_desc_key(best) : 0xFFFFFFFFu;

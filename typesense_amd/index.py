@@ -445,6 +445,12 @@ class GpuIndex:
         self._ck(self.L.tsgpu_last_timings(self.h, C.byref(t)))
         return t
 
+    def aux_timings(self):
+        """tsgpu_last_aux_timings: kernel time / algorithmic bytes of the last group_by batch and the last facet-count batch"""
+        t = B.AuxTimingsC()
+        self._ck(self.L.tsgpu_last_aux_timings(self.h, C.byref(t)))
+        return t
+
     def kw_touched(self):
         """bytes the find kernel counted itself during the last keyword batch run under option kw_count_touched (measurement)"""
         t = B.KwTouchedC()
