@@ -553,6 +553,38 @@ class Bench:
                     bad += 1
             res["shard_parity"] = {"checked": m, "mismatches": bad, "against": "the unsharded collection on rank 0 (top-100 keys, 3 scores, num_matched)"}
 
+        if self.sharded and self.group is not None:
+            # candidate combinations over the shards (tsgpu_group_keyword_search_candidates_batch; Index::search_all_candidates, src/index.cpp:1794-1894): 10 combinations per
+            # user query, per-shard fold + exchange + global query_index; rank 0 checks the merged result against the unsharded twin's own fold
+            n_u = max(8, min(n_q // 10, 200))
+            base_c = synth.keyword_queries(n_u, 3, 8, 2000, seed=41)
+            rng_c = np.random.default_rng(43)
+            users = []
+            for i in range(n_u):
+                combos = [base_c[i].copy()]
+                while len(combos) < 10:
+                    c = combos[int(rng_c.integers(0, len(combos)))].copy()
+                    c[int(rng_c.integers(0, 3))] = max(8, min(2000, int(c[int(rng_c.integers(0, 3))]) + int(rng_c.integers(1, 40))))
+                    if len(set(c.tolist())) == 3 and not any(np.array_equal(c, x) for x in combos):
+                        combos.append(c)
+                users.append([self.T.KwQuery(c, sort=self.sort, topster_size=K_TOPSTER, total_cost=(j > 0)) for j, c in enumerate(combos)])
+            self.group.keyword_search_candidates_batch(users, k=FETCH_SIZE, k_stride=FETCH_SIZE)          # warm-up
+            barrier(world)
+            t0 = time.perf_counter()
+            ch, cqi, cfound = self.group.keyword_search_candidates_batch(users, k=FETCH_SIZE, k_stride=FETCH_SIZE)
+            el_c = max_over_ranks(time.perf_counter() - t0, world)
+            res["candidate_combinations_sharded"] = {"value": n_u / el_c, "unit": "user queries/s (10 combinations each)", "ms_per_call": 1e3 * el_c, "user_queries": n_u}
+            if self.rank == 0:
+                th, tqi, tfound = self.twin.keyword_search_candidates_batch(users, k_stride=K_TOPSTER)
+                bad = 0
+                for u in range(n_u):
+                    n = min(int(th.n_hits[u]), FETCH_SIZE)
+                    if int(ch.n_hits[u]) != n or not np.array_equal(ch.keys[u, :n], th.keys[u, :n]) or not np.array_equal(ch.scores[u, :n], th.scores[u, :n]) \
+                            or not np.array_equal(cqi[u, :n], tqi[u, :n]) or int(ch.num_matched[u]) != int(th.num_matched[u]) or int(cfound[u]) != int(tfound[u]):
+                        bad += 1
+                res["candidate_combinations_sharded"]["shard_parity"] = {"checked": n_u, "mismatches": bad,
+                                                                         "against": "the unsharded collection's own fold on rank 0 (keys, scores, query_index, num_matched, found)"}
+
         if self.sharded:
             # second multi-GPU form, reported as a sub-object: replicas — every GPU holds the collection, the global batch of N x 10 000 queries
             # is sharded across the GPUs, one all-gather of the per-GPU top-100 (weak scaling)
@@ -1677,6 +1709,11 @@ def compact_line(full, detail_path=None):
     for k in ("replicas", "replicas_strong"):
         if isinstance(full.get(k), dict):
             line[k] = _pick(full[k], ("value", "unit", "ms_per_step", "global_batch", "scaling"))
+    if isinstance(full.get("candidate_combinations_sharded"), dict):
+        cs = full["candidate_combinations_sharded"]
+        line["candidate_combinations_sharded"] = _pick(cs, ("value", "unit", "ms_per_call"))
+        if isinstance(cs.get("shard_parity"), dict):
+            line["candidate_combinations_sharded"]["shard_parity"] = _parity_small(cs["shard_parity"])
     conc = full.get("concurrency")
     if isinstance(conc, dict):
         line["concurrency"] = {t: _pick(c, ("value", "p50_us", "p99_us")) for t, c in conc.items() if isinstance(c, dict)}
@@ -1878,7 +1915,7 @@ def main():
                                   "kernel_src_sha16": cur, "pmc_of_these_sources": bool(meta) and meta.get("kernel_src_sha16") == cur,
                                   "note": "wave-instructions of the find kernel (rocprofv3 --pmc, own pass) / (live kernel cycles x 256 CUs x 1 per cycle); no port is saturated"}
         kw["roofline"] = roof
-        for key in ("concurrency", "uncached", "shard_parity", "replicas", "replicas_strong", "exchange_check"):
+        for key in ("concurrency", "uncached", "shard_parity", "replicas", "replicas_strong", "exchange_check", "candidate_combinations_sharded"):
             if key in r:
                 kw[key] = r[key]
         if "cpu" in r:
@@ -1963,7 +2000,7 @@ def main():
             "value": hd["value"], "unit": "queries/s", "n_gpus": world, "steps": hd["steps"], "warmup": args.warmup, "ms_per_step": hd["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32/i64" if head == "keyword" else "f32",
             "data": "synthetic", "config": hd["config"], "p50_ms_per_batch": hd["p50_ms_per_batch"]}
-    for k in ("queries_with_hits", "value_device_only", "ms_per_step_device_only", "value_host_all_arrays", "ms_per_step_host_all_arrays", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "exchange_check", "replicas", "replicas_strong", "concurrency",
+    for k in ("queries_with_hits", "value_device_only", "ms_per_step_device_only", "value_host_all_arrays", "ms_per_step_host_all_arrays", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "exchange_check", "replicas", "replicas_strong", "candidate_combinations_sharded", "concurrency",
               "uncached", "general_kernels", "fused_hits_per_batch", "parity_fp32_scan", "batch_sweep", "variants", "hnsw", "rerank_hybrid_matches"):
         if k in hd:
             line[k] = hd[k]

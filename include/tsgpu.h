@@ -629,6 +629,14 @@ uint32_t tsgpu_group_size(const tsgpu_group* g);
  * text_match, n_hits, num_matched, status are filled). k <= out->k_stride, members * k <= 4096; num_matched = sum over the shards;
  * a query's list never exceeds its own Topster capacity (topster_size, src/index.cpp:3506-3512). */
 int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out);
+/* Candidate-token combinations over the shards (Index::search_all_candidates, src/index.cpp:1794-1894 — the reference's default `prefix = true` request):
+ * tsgpu_keyword_search_candidates_batch's arguments and results with `out`, query_index ([n_groups][k_stride]) and found ([n_groups]) in host memory or in device
+ * memory of member 0 / of this rank. Every shard folds its own passes (the fold is per key and a document lives in one shard), the folded Topsters take the
+ * keyword exchange (top k per user query, num_matched = the last pass's counts added up, found = the union counts added up); KV::query_index — the earlier passes
+ * that matched ANYTHING, :5511, :5580-5585 — is taken from the OR of the shards' pass masks (one more all-gather of 16 bytes per user query). At most 16
+ * combinations per user query; the replicas form answers on one member; 501 with "kw_own_slice_only"; tsgpu_candidates_result_ids is per member (the ids of ITS shard). */
+int tsgpu_group_keyword_search_candidates_batch(tsgpu_group* g, const tsgpu_kw_query* combos, const uint32_t* group_begin, uint32_t n_groups, uint32_t k, tsgpu_hits* out,
+                                                uint32_t* query_index, uint64_t* found);
 /* "kw_exchange_slices" = 1 (default): the keyword exchange is an ncclAllToAll of query slices (member j receives only the records of
  * the 1/G of the batch it merges), a slice merge per member, and in-place ncclAllGathers of the merged lists (rank form / device outputs;
  * the local form with host outputs delivers every slice over its own GPU's PCIe link); 0: ONE ncclAllGather of the per-GPU top-k

@@ -59,7 +59,8 @@ def main():
     orc.vec_add(np.arange(n_docs, dtype=np.uint32), X)
     sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
     OSORT = ((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1))
-    toks = ([1, 2], [3, 1, 2], [5], [4, 9], [70, 71])                # 5 queries: not a multiple of the world size (padded slices)
+    toks = ([1, 2], [3, 1, 2], [5], [4, 9], [79, 80])                # 5 queries: not a multiple of the world size (padded slices); the last one: the two rarest
+                                                                     # terms — some shards hold no posting of one of them (an EMPTY list there, not a dropped token)
     qs = [T.KwQuery(t, sort=sort, topster_size=K) for t in toks]
     qs[3] = T.KwQuery(toks[3], sort=sort, topster_size=K, filter_ids=np.arange(0, n_docs, 2, dtype=np.uint32), excluded_ids=np.array([8, 64], np.uint32))
     ag, a2a = D.torch_collectives()
@@ -117,6 +118,16 @@ def main():
             m = int(h.n_hits[i])
             check("own slice %s q%d" % (cut_name, i), h.status[i] == 0 and m == ref.keys.size and np.array_equal(h.keys[i, :m], ref.keys) and
                   np.array_equal(h.scores[i, :m], ref.scores) and int(h.num_matched[i]) == int(ref.num_keyword_matches))
+        # candidate combinations over the shards (tsgpu_group_keyword_search_candidates_batch): per-shard fold, merged Topster, GLOBAL query_index, union counts
+        users = [[[1, 2], [1, 3], [79, 80], [1, 2]], [[78, 79], [3], [3, 4]], [[80], [77, 78]]]
+        combos = [[T.KwQuery(c, sort=sort, topster_size=K, total_cost=int(j > 0)) for j, c in enumerate(cs)] for cs in users]
+        ch, cqi, cfound = grp.keyword_search_candidates_batch(combos, k=K, k_stride=K)
+        check("candidates status " + cut_name, (ch.status == 0).all())
+        for u, cs in enumerate(combos):
+            ref, rqi = H.oracle_candidates(orc, cs, ids_cap=1 << 20)
+            m = int(ch.n_hits[u])
+            check("candidates %s u%d" % (cut_name, u), m == min(K, ref.keys.size) and np.array_equal(ch.keys[u, :m], ref.keys[:m]) and np.array_equal(ch.scores[u, :m], ref.scores[:m]) and
+                  np.array_equal(cqi[u, :m], rqi[:m].astype(np.uint32)) and int(ch.num_matched[u]) == int(ref.num_keyword_matches) and int(cfound[u]) == int(ref.n_result_ids))
         dm, lm, cm = grp.vec_knn_batch(1, Q, k_vec)
         check_knn("knn " + cut_name, dm, lm, cm)
         allow = np.arange(3, n_docs, 5, dtype=np.uint32)

@@ -44,6 +44,11 @@ def check_group(orc, grp, rng, n_docs, dim):
     qs = [T.KwQuery([1, 2], sort=SORT, topster_size=40), T.KwQuery([3, 1, 2], sort=SORT, topster_size=40), T.KwQuery([5], sort=SORT, topster_size=12),
           T.KwQuery([4, 9], sort=SORT, topster_size=40, filter_ids=filt), T.KwQuery([1], sort=SORT, topster_size=0), T.KwQuery([77, 78], sort=SORT, topster_size=40),
           T.KwQuery([2, 3], sort=SORT, topster_size=40, excluded_ids=filt[::2]),
+          # the rarest terms: a small shard holds no posting of some of them. The reference DROPS a token that matches no field (get_field_token_its,
+          # src/index.cpp:5651-5655) — of the whole collection: a token missing on one shard and present on another is an EMPTY list there, not a dropped token
+          # (round 6: before, such a shard answered the query without the token and contributed documents the collection's answer does not hold)
+          T.KwQuery([79, 78], sort=SORT, topster_size=40), T.KwQuery([80, 1], sort=SORT, topster_size=40), T.KwQuery([76, 77, 2], sort=SORT, topster_size=40),
+          T.KwQuery([9999, 80], sort=SORT, topster_size=40),                                    # 9999 exists NOWHERE: dropped on every shard, the query is [80]
           T.KwQuery([1, 2], sort=((B.SORT_INT64_COLUMN, 1, 77),), topster_size=40)]           # unknown sort column -> 501 on every shard
     hits = grp.keyword_search_batch(qs, k=250, k_stride=250)
     for i, q in enumerate(qs[:-1]):
@@ -57,6 +62,24 @@ def check_group(orc, grp, rng, n_docs, dim):
         n = min(10, ref.keys.size)
         assert int(h10.n_hits[i]) == n and np.array_equal(h10.keys[i, :n], ref.keys[:n]) and np.array_equal(h10.scores[i, :n], ref.scores[:n])
         assert int(h10.num_matched[i]) == int(ref.num_keyword_matches)
+    # ---- candidate combinations (Index::search_all_candidates over the shards): per-shard fold, merged Topster, GLOBAL query_index, union counts ----
+    users = [[[1, 2], [1, 3], [2, 3], [1, 2], [77, 78]],          # a repeated combination (the later pass wins ties), a pass without matches anywhere
+             [[79, 80], [3], [4], [3, 4]],                        # the FIRST pass matches nothing: every later pass's query_index starts at 0
+             [[2, 1, 3]],
+             [[77], [78, 79]],                                     # no pass matches anything
+             [[60], [61], [62], [63], [64], [65], [5], [6]]]       # rare terms: passes that match on SOME shards only (the masks differ between shards)
+    tsz = [40, 7, 40, 40, 250]
+    combos = [[T.KwQuery(c, sort=SORT, topster_size=tsz[u], total_cost=int(j > 0)) for j, c in enumerate(cs)] for u, cs in enumerate(users)]
+    for kk in (250, 10):
+        ch, cqi, cfound = grp.keyword_search_candidates_batch(combos, k=kk, k_stride=250)
+        assert (ch.status == 0).all()
+        for u, cs in enumerate(combos):
+            ref, rqi = H.oracle_candidates(orc, cs, ids_cap=1 << 20)
+            n = min(kk, ref.keys.size)
+            assert int(ch.n_hits[u]) == n, (kk, u, int(ch.n_hits[u]), n)
+            assert np.array_equal(ch.keys[u, :n], ref.keys[:n]) and np.array_equal(ch.scores[u, :n], ref.scores[:n]) and np.array_equal(ch.text_match[u, :n], ref.text_match[:n]), (kk, u)
+            assert np.array_equal(cqi[u, :n], rqi[:n].astype(np.uint32)), (kk, u, cqi[u, :n][:12], rqi[:12])
+            assert int(ch.num_matched[u]) == int(ref.num_keyword_matches) and int(cfound[u]) == int(ref.n_result_ids), (kk, u)
     # ---- k-NN: closest first, ties -> smaller label; allow list ----
     Q = rng.standard_normal((5, dim)).astype(np.float32)
     for k in (7, 30):

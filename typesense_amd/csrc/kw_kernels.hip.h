@@ -2862,6 +2862,35 @@ __global__ __launch_bounds__(256) void kw_group_prune_pack_kernel(KwOut loc, con
 }
 // replicas form of a group (every member mirrors the whole collection, the batch is cut into query slices): the member's own result for
 // its slice (stride loc.k_stride) -> rows [q_out_offset, ..) of the staged full-batch arrays (stride out.k_stride), truncated to k
+// shard form of the candidate fold: (a) before the exchange every hit's key carries its pass in the low 4 bits (key' = key << 4 | pass: seq_ids are below 2^32 and a
+// document lives in ONE shard, so the merge's last tie-break — the key — orders the tagged keys exactly as it orders the keys) and the shard's (pass mask, union
+// count) pair is laid out for the all-gather; (b) after the merge the tags come off: key = key' >> 4, query_index = the passes before the hit's that matched on
+// ANY shard (searched_queries.size() at the time of the pass, src/index.cpp:5511, 5580-5585), found = the shards' union counts added up (disjoint documents).
+__global__ void kw_group_cand_tag_kernel(uint64_t* keys, const uint32_t* pass_of_hit, const uint32_t* n_hits, const int32_t* status, uint32_t k_stride, uint32_t n_groups,
+                                         const uint32_t* pass_mask, const unsigned long long* found, unsigned long long* meta /*[n_groups][2]*/) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = (uint32_t)(i / k_stride), j = (uint32_t)(i % k_stride);
+    if (g >= n_groups) return;
+    const bool ok = status[g] == 0;
+    if (ok && j < n_hits[g]) keys[i] = (keys[i] << 4) | (uint64_t)(pass_of_hit[i] & 15u);
+    if (j == 0) { meta[2 * (size_t)g] = ok ? pass_mask[g] : 0u; meta[2 * (size_t)g + 1] = (ok && found) ? found[g] : 0ull; }
+}
+__global__ void kw_group_cand_fix_kernel(uint64_t* keys, uint32_t* query_index, const uint32_t* n_hits, uint32_t k_stride, uint32_t q0, uint32_t q1,
+                                         const unsigned long long* meta_all /*[n_shards][n_groups][2]*/, uint32_t n_shards, uint32_t n_groups, unsigned long long* found) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = q0 + (uint32_t)(i / k_stride), j = (uint32_t)(i % k_stride);
+    if (g >= q1) return;
+    uint32_t mask = 0;
+    unsigned long long f = 0;
+    for (uint32_t s = 0; s < n_shards; s++) { mask |= (uint32_t)meta_all[((size_t)s * n_groups + g) * 2]; f += meta_all[((size_t)s * n_groups + g) * 2 + 1]; }
+    if (j == 0 && found) found[g] = f;
+    if (j >= n_hits[g]) return;
+    const size_t at = (size_t)g * k_stride + j;
+    const uint64_t kt = keys[at];
+    const uint32_t pass = (uint32_t)(kt & 15u);
+    keys[at] = kt >> 4;
+    if (query_index) query_index[at] = (uint32_t)__popc(mask & ((1u << pass) - 1u));
+}
 __global__ void kw_group_store_slice_kernel(KwOut loc, const int32_t* status, uint32_t n_queries, uint32_t q_out_offset, uint32_t k, KwOut out, int32_t* status_out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t q = i / k, j = i - q * k;
@@ -2990,6 +3019,11 @@ struct KwCandIn {
     const uint32_t* n_hits; const uint64_t* num_matched;
     const uint32_t* group_range;        // [n_groups][3] = first entry, one past the last entry (empty range: the group did not run), Topster capacity
     uint32_t k_in;
+    // the shard form (tsgpu_group_keyword_search_candidates_batch): query_index[hit] = the PASS that produced the hit instead of the number of earlier passes that
+    // matched — "matched anything" is a property of the whole collection, so the shards exchange pass_mask (bit p = pass p matched on THIS shard) and the count is
+    // taken from the OR of the masks after the merge
+    uint32_t raw_pass;
+    uint32_t* pass_mask;                // nullable: [n_groups]
 };
 template <int CAP>
 __global__ __launch_bounds__(KW_THREADS) void kw_candidates_merge_kernel(KwCandIn in, KwOut out, uint32_t* query_index) {
@@ -3001,8 +3035,9 @@ __global__ __launch_bounds__(KW_THREADS) void kw_candidates_merge_kernel(KwCandI
     const uint32_t e0 = in.group_range[3 * g], e1 = in.group_range[3 * g + 1], k = in.group_range[3 * g + 2];
     if (t == 0) {
         s_total = 0; s_win = 0;
-        uint32_t searched = 0;
-        for (uint32_t e = e0; e < e1; e++) { s_qidx[e - e0] = searched; if (in.n_hits[e] > 0) searched++; }
+        uint32_t searched = 0, mask = 0;
+        for (uint32_t e = e0; e < e1; e++) { s_qidx[e - e0] = in.raw_pass ? e - e0 : searched; if (in.n_hits[e] > 0) { searched++; mask |= 1u << (e - e0); } }
+        if (in.pass_mask) in.pass_mask[g] = mask;
     }
     for (int i = t; i < CAP; i += KW_THREADS) { tk.key[i] = -1; tk.s0[i] = 0; tk.s1[i] = 0; tk.s2[i] = 0; }
     __syncthreads();
@@ -3096,13 +3131,14 @@ __global__ __launch_bounds__(KW_THREADS) void kw_candidates_rank_kernel(KwCandIn
     const uint32_t e0 = in.group_range[3 * g], e1 = in.group_range[3 * g + 1], k = in.group_range[3 * g + 2];
     const uint32_t P = e1 - e0;
     if (t == 0) {
-        uint32_t searched = 0, at = 0;
+        uint32_t searched = 0, at = 0, mask = 0;
         for (uint32_t p = 0; p < P; p++) {
             const uint32_t n = in.n_hits[e0 + p] < in.k_in ? in.n_hits[e0 + p] : in.k_in;
             s_base[p] = at; at += n; if (at > (uint32_t)CAP) at = CAP;           // (the host sizes CAP >= passes x k_stride)
-            s_qidx[p] = searched; if (n > 0) searched++;
+            s_qidx[p] = in.raw_pass ? p : searched; if (n > 0) { searched++; mask |= 1u << p; }
         }
         s_base[P] = at;
+        if (in.pass_mask) in.pass_mask[g] = mask;
     }
     for (int i = t; i < 2 * CAP; i += KW_THREADS) hs[i] = 0;
     __syncthreads();

@@ -424,7 +424,8 @@ static uint32_t resolve_topster_size(const tsgpu_ctx* ctx, const tsgpu_kw_query&
     return std::max<uint32_t>(k, 1);
 }
 
-static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query* queries, uint32_t n_queries, Plan& P, bool keep_ids, bool wildcard, const KwVFlat* vflat = nullptr) {
+static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query* queries, uint32_t n_queries, Plan& P, bool keep_ids, bool wildcard, const KwVFlat* vflat = nullptr,
+                      const uint16_t* present_elsewhere = nullptr) {
     // driver blocks per work item: fixed by the option, or (0 = auto) sized so that the batch yields a few thousand work
     // items (>= 3 per resident workgroup slot) without fragmenting queries into more partial top-K lists than needed
     uint32_t KW_CHUNK_BLOCKS = ctx->kw_chunk_blocks;
@@ -587,6 +588,7 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
             uint32_t len_of[KW_MAX_TOKENS];
             KwQueryMF mfq;
             if (multi) memset(&mfq, 0xFF, sizeof mfq);                // (only read by the multi-field form)
+            bool empty_here = false;
             for (uint32_t t = 0; t < in.n_tokens; t++) {
                 // one or_iterator per token = the union of its lists over the fields; a token found in no field is skipped (src/index.cpp:5651-5655)
                 uint64_t tot = 0;
@@ -606,10 +608,11 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
                     tot += snap.h_lists[handle].n_ids;
                     A.list_bytes += 4ull * snap.h_lists[handle].n_ids;
                 }
-                if (!found) continue;
+                if (!found) { if (present_elsewhere && ((present_elsewhere[i] >> t) & 1u)) empty_here = true; continue; }      // (exists on another shard: an EMPTY list here)
                 len_of[nl] = (uint32_t)std::min<uint64_t>(tot, 0xFFFFFFFFull);
                 nl++;
             }
+            if (empty_here) nl = 0;               // a required token without postings on this shard: the AND finds nothing here (zero hits below), whatever the others hold
             q.n_required = nl;
             for (uint32_t t = 0; t < in.n_dropped && multi; t++) {        // after the query's own tokens, in their order (:5271-5290)
                 bool found = false;
@@ -974,10 +977,13 @@ struct BatchOpts {
     const KwVFlat* vflat = nullptr;                   // wildcard form ranking a distance matrix: the flat branch of the vector search (tsgpu_vector_search_batch)
     DevBuf* ids_dev = nullptr;                        // with id_lists: gather the matched ids into THIS device buffer (the caller's) and leave id_lists->ids empty — for a
     bool* ids_dev_done = nullptr;                     // consumer on the device (group_by, tsgpu_groupby.inc.h); not done (false) when a query's ids need the host's sort
+    const uint16_t* present_elsewhere = nullptr;      // doc-range shard of a group whose members' dictionaries differ: per query, the tokens that exist on ANOTHER shard
+                                                      // (missing here they are empty lists, not dropped tokens: kw_search_batch_masked, tsgpu_host.h); host planner
 };
 }
 static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, const BatchOpts& bo);
-static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, tsgpu_id_lists** ids_out, DevBuf* ids_dev = nullptr, bool* ids_dev_done = nullptr);
+static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, tsgpu_id_lists** ids_out, DevBuf* ids_dev = nullptr, bool* ids_dev_done = nullptr,
+                       const uint16_t* present_elsewhere = nullptr);
 static int kw_split_host(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out);
 
 int tsgpu_keyword_search_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out) {
@@ -1165,7 +1171,8 @@ static int kw_split_host(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t
     return ok();
 }
 
-static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, tsgpu_id_lists** ids_out, DevBuf* ids_dev, bool* ids_dev_done) {
+static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, bool wildcard, tsgpu_id_lists** ids_out, DevBuf* ids_dev, bool* ids_dev_done,
+                       const uint16_t* present_elsewhere) {
     if (ids_dev_done) *ids_dev_done = false;
     if (!ctx || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: NULL argument");
     if (n_queries == 0) { if (ids_out) { *ids_out = new (std::nothrow) tsgpu_id_lists; if (*ids_out) (*ids_out)->begin.assign(1, 0); } return ok(); }
@@ -1173,9 +1180,9 @@ static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n
     if (!out->keys || !out->scores || !out->n_hits || !out->status) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: missing output arrays");
     struct CallerCount { std::atomic<int>& c; explicit CallerCount(std::atomic<int>& x) : c(x) { c.fetch_add(1); } ~CallerCount() { c.fetch_sub(1); } } cc(ctx->kw_callers);
     const bool legacy_keep = ctx->keep_ids;
-    if (!wildcard && !legacy_keep && !ids_dev && out->mem == TSGPU_MEM_HOST && n_queries <= ctx->batch_max_queries && ctx->kw_callers.load() > 1)
+    if (!wildcard && !legacy_keep && !ids_dev && !present_elsewhere && out->mem == TSGPU_MEM_HOST && n_queries <= ctx->batch_max_queries && ctx->kw_callers.load() > 1)
         return kw_coalesced(ctx, queries, n_queries, out, ids_out);
-    if (!wildcard && !legacy_keep && !ids_out && out->mem == TSGPU_MEM_HOST && ctx->kw_host_split_queries && ctx->n_lanes >= 2 &&
+    if (!wildcard && !legacy_keep && !ids_out && !present_elsewhere && out->mem == TSGPU_MEM_HOST && ctx->kw_host_split_queries && ctx->n_lanes >= 2 &&
         (uint64_t)n_queries >= 4ull * ctx->kw_host_split_queries)
         return kw_split_host(ctx, queries, n_queries, out);
     std::unique_ptr<tsgpu_id_lists> lists;
@@ -1186,6 +1193,7 @@ static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n
     bo.id_lists = lists.get();
     bo.ids_dev = lists ? ids_dev : nullptr; bo.ids_dev_done = ids_dev_done;
     bo.record_last = legacy_keep;
+    bo.present_elsewhere = present_elsewhere;
     LaneLock ll(ctx, legacy_keep ? 0 : (tsgpu::tls_avoid_lane0() ? -2 : -1));          // the legacy "last batch" id API is single-caller: always lane 0
     const int rc = kw_batch_on_lane(ctx, *ll.L, queries, n_queries, out, bo);
     if (rc == TSGPU_OK && ids_out) *ids_out = lists.release();
@@ -1236,12 +1244,12 @@ static int kw_batch_on_lane(tsgpu_ctx* ctx, KwLane& L, const tsgpu_kw_query* que
         // (not for the chained slices of a sliced host delivery: there the host plans slice i + 1 WHILE slice i runs, and a planning kernel on the
         //  second lane would wait behind the running find kernel for a place on the chip — measured: 10.05 -> 10.18 ms per 10 000 queries)
         // (batches that keep the matched ids: only when nobody reads the segments back per query — the candidate call marks its id sets from the device tables)
-        if (!wildcard && (!keep_ids || (!bo.record_last && !bo.id_lists)) && !bo.vflat && (!bo.chain || (bo.chain_index == 0 && ctx->kw_host_split_device_plan)) && ctx->kw_two_kernels && ctx->kw_device_plan_min_queries && n_queries >= ctx->kw_device_plan_min_queries) {
+        if (!wildcard && !bo.present_elsewhere && (!keep_ids || (!bo.record_last && !bo.id_lists)) && !bo.vflat && (!bo.chain || (bo.chain_index == 0 && ctx->kw_host_split_device_plan)) && ctx->kw_two_kernels && ctx->kw_device_plan_min_queries && n_queries >= ctx->kw_device_plan_min_queries) {
             if ((rc = plan_batch_device(ctx, L, snap, queries, n_queries, P, DP, s))) return rc;
             if (DP.on) ctx->kw_device_plans.fetch_add(1); else ctx->kw_device_plan_fallbacks.fetch_add(1);
             if (DP.on && keep_ids) P.ids_total = (DP.hit_blocks[0] + DP.hit_blocks[1]) * (uint64_t)BLOCK_IDS;
         }
-        if (!DP.on && (rc = plan_batch(ctx, snap, queries, n_queries, P, keep_ids, wildcard, bo.vflat))) return rc;
+        if (!DP.on && (rc = plan_batch(ctx, snap, queries, n_queries, P, keep_ids, wildcard, bo.vflat, bo.present_elsewhere))) return rc;
         const uint64_t t_planned = now_us();
         if (out->k_stride < P.max_k) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: k_stride smaller than the largest topster_size");
         const uint32_t n_work = DP.on ? DP.n_work[0] + DP.n_work[1]
@@ -1800,6 +1808,14 @@ int tsgpu_merge_shard_hits_device(tsgpu_ctx* ctx, const tsgpu_hits* gathered, ui
 // keyword batch, kw_candidates_merge_kernel folds each group like the shared Topster, the id-set kernels like id_buff.
 int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const uint32_t* group_begin, uint32_t n_groups,
                                           tsgpu_hits* out, uint32_t* query_index, uint64_t* found) {
+    return kw_candidates_batch_ex(ctx, combos, group_begin, n_groups, out, query_index, found, false, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+namespace tsgpu {
+int kw_candidates_batch_ex(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const uint32_t* group_begin, uint32_t n_groups,
+                           tsgpu_hits* out, uint32_t* query_index, uint64_t* found, bool raw_pass, uint32_t* pass_mask_dev, const uint16_t* present_elsewhere) {
     if (!ctx || !out || !group_begin) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_candidates_batch: NULL argument");
     if (n_groups == 0) return ok();
     if (!out->keys || !out->scores || !out->n_hits || !out->status) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_candidates_batch: missing output arrays");
@@ -1857,6 +1873,7 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
             bo.status_host = &st;
             bo.cutoff_host = &co;
             bo.record_last = false;                            // (the marks below read the batch's tables on the device; tsgpu_candidates_result_ids reads the bitmaps)
+            bo.present_elsewhere = present_elsewhere;
             rc = kw_batch_on_lane(ctx, L, combos, n_combos, &pass, bo);
             if (rc) { if (found) (void)hipStreamSynchronize(L.aux_stream); return rc; }
         }
@@ -1895,6 +1912,7 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
         in.keys = pass.keys; in.scores = pass.scores; in.text_match = pass.text_match; in.vector_distance = pass.vector_distance;
         in.match_score_index = pass.match_score_index; in.n_hits = pass.n_hits; in.num_matched = pass.num_matched;
         in.group_range = L.d_cand_gb.as<uint32_t>(); in.k_in = KS;
+        in.raw_pass = raw_pass ? 1u : 0u; in.pass_mask = pass_mask_dev;
         const uint64_t cap_need = (uint64_t)std::max<uint32_t>(max_passes, 1) * KS;
         bool any_s2 = false;
         for (uint32_t e = 0; e < n_combos; e++) any_s2 = any_s2 || combos[e].n_sort > 2;
@@ -1956,6 +1974,48 @@ int tsgpu_keyword_search_candidates_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* 
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_keyword_search_candidates_batch: host allocation failed"); }
     return ok();
 }
+
+uint64_t kw_dictionary_fingerprint(tsgpu_ctx* ctx) {
+    const std::shared_ptr<const Snapshot> sn = ctx->snapshot();
+    return (sn && sn->maps) ? sn->maps->dict_fp : 0ull;
+}
+int kw_terms_present(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, uint16_t* masks) {
+    const std::shared_ptr<const Snapshot> sn = ctx->snapshot();
+    for (uint32_t i = 0; i < n_queries; i++) {
+        const tsgpu_kw_query& in = queries[i];
+        uint16_t m = 0;
+        for (uint32_t t = 0; t < in.n_tokens && t < TSGPU_MAX_QUERY_TOKENS; t++)
+            for (uint32_t f = 0; f < in.n_fields; f++)
+                if (sn && sn->find_handle(in.field_ids[f], in.term_ids[t]) != 0xFFFFFFFFu) { m |= (uint16_t)(1u << t); break; }
+        masks[i] = m;
+    }
+    return TSGPU_OK;
+}
+int kw_search_batch_masked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, const uint16_t* present_elsewhere) {
+    return kw_dispatch(ctx, queries, n_queries, out, false, nullptr, nullptr, nullptr, present_elsewhere);
+}
+int group_cand_tag(tsgpu_ctx* ctx, const tsgpu_hits* loc, const uint32_t* pass_of_hit, uint32_t n_groups, const uint32_t* pass_mask, const uint64_t* found, uint64_t* meta, hipStream_t s) {
+    if (n_groups == 0) return TSGPU_OK;
+    (void)hipSetDevice(ctx->device);
+    const uint64_t n = (uint64_t)n_groups * loc->k_stride;
+    hipLaunchKernelGGL(kw_group_cand_tag_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, loc->keys, pass_of_hit, (const uint32_t*)loc->n_hits, (const int32_t*)loc->status, loc->k_stride, n_groups,
+                       pass_mask, (const unsigned long long*)found, (unsigned long long*)meta);
+    TSGPU_HIP_TRY(hipGetLastError());
+    return TSGPU_OK;
+}
+int group_cand_fix(tsgpu_ctx* ctx, uint64_t* keys, uint32_t* query_index, const uint32_t* n_hits, uint32_t k_stride, uint32_t q0, uint32_t q1, const uint64_t* meta_all, uint32_t n_shards,
+                   uint32_t n_groups, uint64_t* found, hipStream_t s) {
+    if (q1 <= q0) return TSGPU_OK;
+    (void)hipSetDevice(ctx->device);
+    const uint64_t n = (uint64_t)(q1 - q0) * k_stride;
+    hipLaunchKernelGGL(kw_group_cand_fix_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, keys, query_index, n_hits, k_stride, q0, q1, (const unsigned long long*)meta_all, n_shards, n_groups,
+                       (unsigned long long*)found);
+    TSGPU_HIP_TRY(hipGetLastError());
+    return TSGPU_OK;
+}
+}  // namespace tsgpu
+
+extern "C" {
 
 uint64_t tsgpu_candidates_result_ids(tsgpu_ctx* ctx, uint32_t group, uint32_t* out_host, uint64_t cap) {
     if (!ctx) return 0;

@@ -89,6 +89,9 @@ struct Member {
     DevBuf v_dist, v_lab, v_cnt, v_bad;                  // ... local k-NN result
     DevBuf o_keys, o_scores, o_tm, o_nh, o_nm, o_st, o_vd, o_lab, o_cnt;   // merged result staged on the device (host outputs)
     DevBuf caps;                                         // per-query Topster capacity (the merged list of a query never exceeds its own Topster)
+    DevBuf c_fp, c_fp_all, c_tok, c_tok_all;             // dictionary fingerprints / per-query token presence masks of the members (group_keyword_core step 0)
+    std::vector<uint16_t> h_tok, h_elsewhere;
+    DevBuf c_pass, c_mask, c_found, c_meta, c_meta_all, c_qi;   // candidate combinations: every local hit's pass, the shard's pass masks / union counts, their all-gathered pairs
     DevBuf kth_send, kth_recv, p_tot, p_totall;          // bound-pruned exchange: this shard's reported entries / every shard's; the slices' cursors = entry totals; every rank's totals
     std::vector<uint32_t> h_tot;
     std::vector<uint32_t> h_caps;
@@ -194,27 +197,30 @@ uint32_t call_signature(std::initializer_list<uint64_t> v) {
 
 // Rank form: every rank reports {rc of its local phase, signature of the call's arguments}; all ranks leave with the same verdict
 // BEFORE any data collective. The failing rank keeps its own error message; the others learn which rank failed.
-int agree(tsgpu_group* g, int rc_local, uint32_t sig) {
+// (round 6: a second word rides along — `extra`, e.g. the rank's dictionary fingerprint; *extra_equal = every rank sent the same one)
+int agree(tsgpu_group* g, int rc_local, uint32_t sig, uint64_t extra = 0, bool* extra_equal = nullptr) {
+    if (extra_equal) *extra_equal = true;
     if (g->local || g->n == 1) return rc_local;
     Member& mem = g->m[0];
     const std::string own_err = rc_local ? std::string(tsgpu_last_error()) : std::string();
-    const uint64_t w = ((uint64_t)(uint32_t)rc_local << 32) | sig;
-    std::vector<uint64_t> all(g->n, 0);
+    const uint64_t w[2] = {((uint64_t)(uint32_t)rc_local << 32) | sig, extra};
+    std::vector<uint64_t> both((size_t)g->n * 2, 0), all(g->n, 0);
     (void)hipSetDevice(mem.ctx->device);
     if (g->transport == TSGPU_XCHG_HOST) {
-        const int crc = g->coll.all_gather(g->coll.user, &w, all.data(), 8);
+        const int crc = g->coll.all_gather(g->coll.user, w, both.data(), 16);
         if (crc) return fail(TSGPU_ERR_DEVICE, "tsgpu_group: the caller's all_gather callback failed (" + std::to_string(crc) + ")");
     } else {
         int rc;
-        if ((rc = mem.agree_d.reserve((size_t)(g->n + 1) * 8)) || (rc = mem.agree_h.reserve((size_t)(g->n + 1) * 8))) return rc;     // (64 KB minimum each: allocated once)
+        if ((rc = mem.agree_d.reserve((size_t)(g->n + 1) * 16)) || (rc = mem.agree_h.reserve((size_t)(g->n + 1) * 16))) return rc;     // (64 KB minimum each: allocated once)
         uint64_t* hw = mem.agree_h.as<uint64_t>();
-        hw[g->n] = w;
-        TSGPU_HIP_TRY(hipMemcpyAsync(mem.agree_d.as<uint64_t>() + g->n, hw + g->n, 8, hipMemcpyHostToDevice, mem.ctx->stream));
-        if ((rc = rccl()->AllGather(mem.agree_d.as<uint64_t>() + g->n, mem.agree_d.p, 1, X_NCCL_UINT64, mem.comm, mem.ctx->stream))) return rccl_fail("ncclAllGather (status)", rc);
-        TSGPU_HIP_TRY(hipMemcpyAsync(hw, mem.agree_d.p, (size_t)g->n * 8, hipMemcpyDeviceToHost, mem.ctx->stream));
+        hw[2 * g->n] = w[0]; hw[2 * g->n + 1] = w[1];
+        TSGPU_HIP_TRY(hipMemcpyAsync(mem.agree_d.as<uint64_t>() + 2 * g->n, hw + 2 * g->n, 16, hipMemcpyHostToDevice, mem.ctx->stream));
+        if ((rc = rccl()->AllGather(mem.agree_d.as<uint64_t>() + 2 * g->n, mem.agree_d.p, 2, X_NCCL_UINT64, mem.comm, mem.ctx->stream))) return rccl_fail("ncclAllGather (status)", rc);
+        TSGPU_HIP_TRY(hipMemcpyAsync(hw, mem.agree_d.p, (size_t)g->n * 16, hipMemcpyDeviceToHost, mem.ctx->stream));
         TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
-        for (uint32_t r = 0; r < g->n; r++) all[r] = hw[r];
+        for (uint32_t r = 0; r < 2 * g->n; r++) both[r] = hw[r];
     }
+    for (uint32_t r = 0; r < g->n; r++) { all[r] = both[2 * r]; if (extra_equal && both[2 * r + 1] != both[1]) *extra_equal = false; }
     for (uint32_t r = 0; r < g->n; r++) {
         const int rr = (int)(uint32_t)(all[r] >> 32);
         if (!rr) continue;
@@ -617,6 +623,8 @@ void tsgpu_group_destroy(tsgpu_group* g) {
     for (auto& mem : g->m) {
         (void)hipSetDevice(mem.ctx->device);
         if (mem.comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(mem.comm);
+        DevBuf* cb[] = {&mem.c_pass, &mem.c_mask, &mem.c_found, &mem.c_meta, &mem.c_meta_all, &mem.c_qi, &mem.c_fp, &mem.c_fp_all, &mem.c_tok, &mem.c_tok_all};
+        for (auto* x : cb) x->release();
         DevBuf* b[] = {&mem.send, &mem.recv, &mem.l_keys, &mem.l_scores, &mem.l_tm, &mem.l_vd, &mem.l_msi, &mem.l_nh, &mem.l_nm, &mem.l_st, &mem.l_co, &mem.v_dist, &mem.v_lab, &mem.v_cnt, &mem.v_bad,
                        &mem.o_keys, &mem.o_scores, &mem.o_tm, &mem.o_nh, &mem.o_nm, &mem.o_st, &mem.o_vd, &mem.o_lab, &mem.o_cnt, &mem.caps};
         for (auto* x : b) x->release();
@@ -642,18 +650,61 @@ int tsgpu_group_last_timings(tsgpu_group* g, tsgpu_group_timings* out) {
 // queries it merges (a 1/G slice of the batch: (G-1)/G x one block per GPU on the wire instead of (G-1) blocks, and 1/G of the merge
 // per GPU) — then the merged slices are replicated with in-place ncclAllGathers (every rank ends with the whole result; the local form
 // delivers the slices straight to the caller). 0: ONE ncclAllGather of the blocks, every rank merges everything.
-int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out) {
-    if (!g || !out || (n_queries && !queries)) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: NULL argument");
-    if (n_queries == 0) { std::lock_guard<std::mutex> lk0(g->mu); return agree(g, TSGPU_OK, call_signature({2, 0})); }      // (rank form: a rank called with an empty batch still meets
-                                                                                                                             //  the others in the agreement step — they learn of the mismatch instead of waiting for it forever)
-    int pre = TSGPU_OK;
-    if (k == 0 || k > out->k_stride || k > TSGPU_MAX_TOPK) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: k must be in 1..min(k_stride, 1024)");
-    else if (!out->keys || !out->scores || !out->n_hits) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: missing output arrays");
-    else if ((uint64_t)g->n * k > 4096) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_batch: members * k > 4096");
-    std::lock_guard<std::mutex> lk(g->mu);
-    if (pre) return agree(g, pre, 0);          // (rank form: the other ranks are told instead of being left in their first collective)
+}  // extern "C"
+
+namespace {
+// The keyword exchange behind tsgpu_group_keyword_search_batch AND its candidate-combination form: `queries` describes the n_queries result lists (Topster
+// capacities, per-hit constants); `local_search(member, loc)` fills the member's local result (device arrays, stride KL). Called with g->mu held.
+// `lq` / `n_lq` = the queries the local search runs (the batch itself, or every combination of a candidates call): when the members' dictionaries differ
+// (kw_dictionary_fingerprint) the shards first exchange which of those queries' tokens each of them holds, and local_search receives per query the tokens that
+// exist on ANOTHER shard (present_elsewhere; nullptr when every shard holds the same terms — the usual case, and then nothing is exchanged).
+typedef std::function<int(Member&, tsgpu_hits*, const uint16_t*)> LocalSearch;
+
+// do all members hold the same (field, term) dictionary? Local form: a comparison. (Rank form: the fingerprints ride in the call's FIRST agreement step.)
+bool local_dictionaries_equal(tsgpu_group* g) {
+    const uint64_t f0 = kw_dictionary_fingerprint(g->m[0].ctx);
+    for (auto& mem : g->m) if (kw_dictionary_fingerprint(mem.ctx) != f0) return false;
+    return true;
+}
+// per member and local query: the tokens that some OTHER member holds (Member::h_elsewhere)
+int exchange_token_masks(tsgpu_group* g, const tsgpu_kw_query* lq, uint32_t n_lq) {
+    const size_t bytes = ((size_t)n_lq * 2 + 15) & ~(size_t)15;
+    for (auto& mem : g->m) {
+        int rc;
+        (void)hipSetDevice(mem.ctx->device);
+        if ((rc = mem.c_tok.reserve(bytes)) || (rc = mem.c_tok_all.reserve(bytes * g->n)) || (rc = reserve_host_staging(g, mem, bytes * g->n))) return rc;
+        mem.h_tok.assign(bytes / 2, 0);
+        if ((rc = kw_terms_present(mem.ctx, lq, n_lq, mem.h_tok.data()))) return rc;
+        TSGPU_HIP_TRY(hipMemcpyAsync(mem.c_tok.p, mem.h_tok.data(), bytes, hipMemcpyHostToDevice, mem.ctx->stream));
+        TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+    }
+    int rc;
+    if ((rc = all_gather_everywhere(g, &Member::c_tok, &Member::c_tok_all, bytes))) return rc;
+    for (size_t i = 0; i < g->m.size(); i++) {
+        Member& mem = g->m[i];
+        Member& src = mem;
+        (void)hipSetDevice(src.ctx->device);
+        std::vector<uint16_t> all(bytes / 2 * g->n);
+        TSGPU_HIP_TRY(hipMemcpyAsync(all.data(), src.c_tok_all.p, bytes * g->n, hipMemcpyDeviceToHost, src.ctx->stream));
+        TSGPU_HIP_TRY(hipStreamSynchronize(src.ctx->stream));
+        const uint32_t me = g->local ? (uint32_t)i : g->rank;
+        mem.h_elsewhere.assign(n_lq, 0);
+        for (uint32_t r = 0; r < g->n; r++) if (r != me) for (uint32_t q = 0; q < n_lq; q++) mem.h_elsewhere[q] |= all[(size_t)r * (bytes / 2) + q];
+    }
+    return TSGPU_OK;
+}
+
+int group_keyword_core(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out, const LocalSearch& local_search, uint64_t sig_tag,
+                       const tsgpu_kw_query* lq, uint32_t n_lq) {
     try {
-        if (g->replicas) return keyword_replicas(g, queries, n_queries, k, out);
+        // 0) the reference drops a token that matches no field (get_field_token_its, src/index.cpp:5651-5655): "no field" means no field of the WHOLE collection.
+        //    Shards whose dictionaries differ exchange per query which tokens each of them holds; a token missing here and present elsewhere is an empty list here.
+        //    Rank form: a first agreement step carries the arguments' signature AND the rank's dictionary fingerprint (every rank's first collective of a call is an
+        //    agreement step, whatever happened to it locally); the second one, after the local phase, carries the local phase's return code.
+        bool same_dict = true;
+        if (g->local) same_dict = g->n == 1 || local_dictionaries_equal(g);
+        else { int rc0 = agree(g, TSGPU_OK, call_signature({sig_tag, n_queries, k, out->k_stride, hits_mask(out), 0xD1C7u}), kw_dictionary_fingerprint(g->m[0].ctx), &same_dict); if (rc0) return rc0; }
+        if (!same_dict) { int rc0 = exchange_token_masks(g, lq, n_lq); if (rc0) return rc0; }
         const uint32_t words = out->text_match ? 5 : 4;
         const uint32_t KL = local_topster_stride(queries, n_queries, k);
         const size_t qw = group_kw_record_words(k, words);
@@ -686,7 +737,7 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
             loc.keys = mem.l_keys.as<uint64_t>(); loc.scores = mem.l_scores.as<int64_t>(); loc.text_match = mem.l_tm.as<int64_t>();
             loc.vector_distance = mem.l_vd.as<float>(); loc.match_score_index = mem.l_msi.as<int8_t>();
             loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>(); loc.search_cutoff = mem.l_co.as<int32_t>();
-            if ((r = tsgpu_keyword_search_batch(mem.ctx, queries, n_queries, &loc))) return r;
+            if ((r = local_search(mem, &loc, same_dict ? nullptr : mem.h_elsewhere.data()))) return r;
             mark(g, i, 0);
             if (pruned) {
                 TSGPU_HIP_TRY(hipMemcpyAsync(mem.caps.p, g->m[0].h_caps.data(), (size_t)n_pad * 4, hipMemcpyHostToDevice, mem.ctx->stream));      // (h_caps is a member field: it outlives the copy)
@@ -699,7 +750,7 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
             mark(g, i, 1);
             return r;
         });
-        if ((rc = agree(g, rc, call_signature({2, n_queries, k, out->k_stride, hits_mask(out), (uint64_t)slices, (uint64_t)g->own_slice_only, (uint64_t)pruned})))) return rc;
+        if ((rc = agree(g, rc, call_signature({sig_tag, n_queries, k, out->k_stride, hits_mask(out), (uint64_t)slices, (uint64_t)g->own_slice_only, (uint64_t)pruned})))) return rc;
         const double t_local = ms_since(t0);
         const auto t1 = std::chrono::steady_clock::now();
         // 2) the exchange, 3) the exact merge, staged per member in arrays of n_pad queries (stride = the caller's k_stride)
@@ -780,6 +831,109 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
         return ok();
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: host allocation failed"); }
       catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: could not start a member thread"); }
+}
+}  // namespace
+
+extern "C" {
+
+int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out) {
+    if (!g || !out || (n_queries && !queries)) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: NULL argument");
+    if (n_queries == 0) { std::lock_guard<std::mutex> lk0(g->mu); return agree(g, TSGPU_OK, call_signature({2, 0})); }      // (rank form: a rank called with an empty batch still meets
+                                                                                                                             //  the others in the agreement step — they learn of the mismatch instead of waiting for it forever)
+    int pre = TSGPU_OK;
+    if (k == 0 || k > out->k_stride || k > TSGPU_MAX_TOPK) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: k must be in 1..min(k_stride, 1024)");
+    else if (!out->keys || !out->scores || !out->n_hits) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_batch: missing output arrays");
+    else if ((uint64_t)g->n * k > 4096) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_batch: members * k > 4096");
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (pre) return agree(g, pre, 0);          // (rank form: the other ranks are told instead of being left in their first collective)
+    if (g->replicas) {
+        try { return keyword_replicas(g, queries, n_queries, k, out); }
+        catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: host allocation failed"); }
+        catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_batch: could not start a member thread"); }
+    }
+    return group_keyword_core(g, queries, n_queries, k, out, [&](Member& mem, tsgpu_hits* loc, const uint16_t* elsewhere) { return kw_search_batch_masked(mem.ctx, queries, n_queries, loc, elsewhere); }, 2,
+                              queries, n_queries);
+}
+
+// Candidate-token combinations over doc-range shards (Index::search_all_candidates, /root/reference/src/index.cpp:1794-1894; the single-GPU form:
+// tsgpu_keyword_search_candidates_batch). The fold of a user query's passes is per KEY (a key met by several passes keeps its greatest KV, the later pass on ties,
+// include/topster.h:392-406) and a document lives in ONE shard, so every shard folds its own passes and the shards' folded Topsters are merged like any keyword
+// result: same exchange (bound-pruned slices, exact merge), num_matched = the shards' last-pass counts added up, found = their union counts added up. What is NOT
+// shard-local is KV::query_index = "the earlier passes that matched ANYTHING" (:5511, :5580-5585): the shards exchange per user query the mask of passes that
+// matched on them (one more all-gather of 16 bytes per user query), every hit travels with its pass in the low 4 bits of its key (order-preserving: keys are
+// unique), and after the merge query_index = popcount(OR of the masks below the hit's pass).
+int tsgpu_group_keyword_search_candidates_batch(tsgpu_group* g, const tsgpu_kw_query* combos, const uint32_t* group_begin, uint32_t n_groups, uint32_t k, tsgpu_hits* out,
+                                                uint32_t* query_index, uint64_t* found) {
+    if (!g || !out || !group_begin || (n_groups && group_begin[n_groups] && !combos)) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_candidates_batch: NULL argument");
+    if (n_groups == 0) { std::lock_guard<std::mutex> lk0(g->mu); return agree(g, TSGPU_OK, call_signature({5, 0})); }
+    int pre = TSGPU_OK;
+    uint32_t max_passes = 0;
+    for (uint32_t u = 0; u < n_groups; u++) {
+        if (group_begin[u + 1] <= group_begin[u]) { pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_candidates_batch: every user query needs at least one combination"); break; }
+        max_passes = std::max(max_passes, group_begin[u + 1] - group_begin[u]);
+    }
+    if (pre) {}
+    else if (k == 0 || k > out->k_stride || k > TSGPU_MAX_TOPK) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_candidates_batch: k must be in 1..min(k_stride, 1024)");
+    else if (!out->keys || !out->scores || !out->n_hits) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_candidates_batch: missing output arrays");
+    else if ((uint64_t)g->n * k > 4096) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_candidates_batch: members * k > 4096");
+    else if (max_passes > 16) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_candidates_batch: more than 16 combinations per user query");
+    else if (!g->local && g->own_slice_only) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_candidates_batch: not with kw_own_slice_only");
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (pre) return agree(g, pre, 0);
+    if (g->replicas) {
+        // every member mirrors the WHOLE collection: any of them answers the call alone (member 0 / this rank; no exchange, the agreement step only)
+        int rc = agree(g, TSGPU_OK, call_signature({6, n_groups, k, out->k_stride, hits_mask(out)}));
+        if (rc) return rc;
+        if ((rc = tsgpu_keyword_search_candidates_batch(g->m[0].ctx, combos, group_begin, n_groups, out, query_index, found))) return rc;
+        // (the member returns its whole Topster: the call's k cuts the lists)
+        if (out->mem == TSGPU_MEM_HOST) { for (uint32_t u = 0; u < n_groups; u++) out->n_hits[u] = std::min(out->n_hits[u], k); }
+        else {
+            std::vector<uint32_t> nh(n_groups);
+            (void)hipSetDevice(g->m[0].ctx->device);
+            TSGPU_HIP_TRY(hipMemcpy(nh.data(), out->n_hits, (size_t)n_groups * 4, hipMemcpyDeviceToHost));
+            for (auto& v : nh) v = std::min(v, k);
+            TSGPU_HIP_TRY(hipMemcpy(out->n_hits, nh.data(), (size_t)n_groups * 4, hipMemcpyHostToDevice));
+        }
+        return ok();
+    }
+    try {
+        // the result lists are described by every user query's FIRST combination (the shared Topster is sized once, by the first pass: tsgpu.hip)
+        std::vector<tsgpu_kw_query> firsts(n_groups);
+        for (uint32_t u = 0; u < n_groups; u++) firsts[u] = combos[group_begin[u]];
+        const uint32_t KL = local_topster_stride(firsts.data(), n_groups, k);
+        const size_t meta_bytes = (size_t)n_groups * 16;
+        int rc = group_keyword_core(g, firsts.data(), n_groups, k, out, [&](Member& mem, tsgpu_hits* loc, const uint16_t* elsewhere) -> int {
+            int r;
+            if ((r = mem.c_pass.reserve((size_t)n_groups * KL * 4)) || (r = mem.c_mask.reserve((size_t)n_groups * 4)) || (r = mem.c_found.reserve((size_t)n_groups * 8)) ||
+                (r = mem.c_meta.reserve(meta_bytes)) || (r = mem.c_meta_all.reserve(meta_bytes * g->n)) || (r = mem.c_qi.reserve((size_t)n_groups * out->k_stride * 4)) ||
+                (r = reserve_host_staging(g, mem, meta_bytes * g->n))) return r;
+            if ((r = kw_candidates_batch_ex(mem.ctx, combos, group_begin, n_groups, loc, mem.c_pass.as<uint32_t>(), found ? mem.c_found.as<uint64_t>() : nullptr, true, mem.c_mask.as<uint32_t>(), elsewhere))) return r;
+            return group_cand_tag(mem.ctx, loc, mem.c_pass.as<uint32_t>(), n_groups, mem.c_mask.as<uint32_t>(), found ? mem.c_found.as<uint64_t>() : nullptr, mem.c_meta.as<uint64_t>(), mem.ctx->stream);
+        }, 5, combos, group_begin[n_groups]);
+        if (rc) return rc;
+        // every shard's (pass mask, union count) per user query, everywhere; then the tags come off the merged keys
+        if ((rc = all_gather_everywhere(g, &Member::c_meta, &Member::c_meta_all, meta_bytes))) return rc;
+        Member& root = g->m[0];
+        (void)hipSetDevice(root.ctx->device);
+        hipStream_t s = root.ctx->stream;
+        const size_t KS = out->k_stride, slots = (size_t)n_groups * KS;
+        if (out->mem == TSGPU_MEM_DEVICE) {
+            if ((rc = group_cand_fix(root.ctx, out->keys, query_index, out->n_hits, (uint32_t)KS, 0, n_groups, root.c_meta_all.as<uint64_t>(), g->n, n_groups, found, s))) return rc;
+            TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        } else {
+            // host outputs: the merged keys go up once more, come back untagged with their query_index (n_groups x k_stride words: small next to the exchange)
+            if ((rc = root.o_keys.reserve(slots * 8)) || (rc = root.o_nh.reserve((size_t)n_groups * 4)) || (rc = root.c_found.reserve((size_t)n_groups * 8))) return rc;
+            TSGPU_HIP_TRY(hipMemcpyAsync(root.o_keys.p, out->keys, slots * 8, hipMemcpyHostToDevice, s));
+            TSGPU_HIP_TRY(hipMemcpyAsync(root.o_nh.p, out->n_hits, (size_t)n_groups * 4, hipMemcpyHostToDevice, s));
+            if ((rc = group_cand_fix(root.ctx, root.o_keys.as<uint64_t>(), root.c_qi.as<uint32_t>(), root.o_nh.as<uint32_t>(), (uint32_t)KS, 0, n_groups, root.c_meta_all.as<uint64_t>(), g->n, n_groups,
+                                     root.c_found.as<uint64_t>(), s))) return rc;
+            TSGPU_HIP_TRY(hipMemcpyAsync(out->keys, root.o_keys.p, slots * 8, hipMemcpyDeviceToHost, s));
+            if (query_index) TSGPU_HIP_TRY(hipMemcpyAsync(query_index, root.c_qi.p, slots * 4, hipMemcpyDeviceToHost, s));
+            if (found) TSGPU_HIP_TRY(hipMemcpyAsync(found, root.c_found.p, (size_t)n_groups * 8, hipMemcpyDeviceToHost, s));
+            TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        }
+        return ok();
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_candidates_batch: host allocation failed"); }
 }
 
 int tsgpu_group_set_option(tsgpu_group* g, const char* name, int64_t value) {

@@ -215,7 +215,7 @@ struct HandleMaps {
     DevBuf d_dense;
     std::shared_ptr<RetireBin> bin;
     HandleMaps() = default;
-    HandleMaps(const HandleMaps& o) : handle_of(o.handle_of), dense_handle(o.dense_handle), bin(o.bin) {}     // (the copy gets its own mirror at its upload_dense())
+    HandleMaps(const HandleMaps& o) : handle_of(o.handle_of), bin(o.bin), dense_handle(o.dense_handle), dict_fp(o.dict_fp) {}     // (the copy gets its own mirror at its upload_dense())
     HandleMaps& operator=(const HandleMaps&) = delete;
     ~HandleMaps() { if (bin) bin->put(d_dense); else d_dense.release(); }
     void upload_dense() {
@@ -231,8 +231,13 @@ struct HandleMaps {
     // the same map as flat tables for small field / term ids (the planner resolves three tokens per query, 10 000 queries per
     // batch: an indexed load instead of a hash probe); 0xFFFFFFFF = absent; ids beyond the tables go through handle_of
     std::vector<std::vector<uint32_t>> dense_handle;                // [field][term]
+    // order-free fingerprint of the (field, term) pairs that have a posting list: doc-range shards compare theirs (tsgpu_group) — only when they differ can a
+    // token be missing from one shard and present on another, and only then do the shards exchange per-query token masks
+    uint64_t dict_fp = 0;
     void rebuild_dense() {
         std::vector<uint32_t> max_term;
+        dict_fp = 0;
+        for (const auto& e : handle_of) { uint64_t z = e.first + 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; dict_fp += z ^ (z >> 31); }
         for (const auto& e : handle_of) {
             const uint32_t f = (uint32_t)(e.first >> 32), term = (uint32_t)e.first;
             if (f >= 64 || term >= (4u << 20)) continue;
@@ -586,6 +591,20 @@ int group_pack_keyword(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q
 int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard_stride_words, uint32_t n_shards, uint32_t n_q, uint32_t q_out_offset, uint32_t k, uint32_t words,
                         const uint32_t* caps_dev, const tsgpu_hits* out_dev, hipStream_t s, uint32_t pruned_per = 0);
 // bound-pruned exchange (kw_kernels.hip.h): the shard's kq-th entries; counts against the gathered bounds; the pruned exchange block
+// shard form of the candidate fold (tsgpu_group_keyword_search_candidates_batch): the candidates call with query_index = the hit's PASS and the shard's pass masks
+// (device arrays), the tagging of the keys before the exchange and the fix-up after the merge (kw_group_cand_*_kernel)
+int kw_candidates_batch_ex(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const uint32_t* group_begin, uint32_t n_groups, tsgpu_hits* out, uint32_t* query_index, uint64_t* found,
+                           bool raw_pass, uint32_t* pass_mask_dev, const uint16_t* present_elsewhere = nullptr);
+// Doc-range shards and the reference's "a token that matches no field is dropped" (get_field_token_its, src/index.cpp:5651-5655): whether a token EXISTS is a property of
+// the whole collection. kw_dictionary_fingerprint: order-free hash of the context's (field, term) pairs with postings; kw_terms_present: bit t of masks[i] = token t of
+// query i has a list in one of the query's fields HERE; kw_search_batch_masked: tsgpu_keyword_search_batch where bit t of present_elsewhere[i] says the token exists on
+// ANOTHER shard — missing here, it is then an EMPTY list (the AND finds nothing on this shard) instead of a dropped token.
+uint64_t kw_dictionary_fingerprint(tsgpu_ctx* ctx);
+int kw_terms_present(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, uint16_t* masks);
+int kw_search_batch_masked(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n_queries, tsgpu_hits* out, const uint16_t* present_elsewhere);
+int group_cand_tag(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, const uint32_t* pass_of_hit, uint32_t n_groups, const uint32_t* pass_mask, const uint64_t* found, uint64_t* meta, hipStream_t s);
+int group_cand_fix(tsgpu_ctx* ctx, uint64_t* keys, uint32_t* query_index, const uint32_t* n_hits, uint32_t k_stride, uint32_t q0, uint32_t q1, const uint64_t* meta_all, uint32_t n_shards,
+                   uint32_t n_groups, uint64_t* found, hipStream_t s);
 int group_kw_kth(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t k, uint32_t n_shards, const uint32_t* caps_dev, int64_t* kth, hipStream_t s);
 int group_kw_prune_pack(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t n_pad, uint32_t k, uint32_t words, const uint32_t* caps_dev, const int64_t* kth_all,
                         uint32_t n_shards, uint32_t per, uint32_t n_dst, uint64_t slice_words, uint64_t* block, uint32_t* cursor, hipStream_t s);

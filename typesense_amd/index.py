@@ -701,6 +701,21 @@ class GpuGroup:
     def keyword_search_batch_raw(self, arr, n, k, hs):
         B.check(self.L, self.L.tsgpu_group_keyword_search_batch(self.h, C.cast(arr, C.c_void_p), n, k, C.byref(hs)))
 
+    def keyword_search_candidates_batch(self, groups, k, k_stride=None, want_found=True):
+        """tsgpu_group_keyword_search_candidates_batch: groups = per user query the list of candidate-token combinations (KwQuery, pass order).
+        Returns (Hits [n_groups], query_index [n_groups, k_stride] u32, found [n_groups] u64 or None) — Index::search_all_candidates over the shards."""
+        flat = [q for g in groups for q in g]
+        begin = np.zeros(len(groups) + 1, np.uint32)
+        begin[1:] = np.cumsum([len(g) for g in groups])
+        arr = make_query_array(flat) if flat else None
+        hits = Hits(len(groups), k_stride or k)
+        hs = hits.c_struct()
+        qi = np.zeros((len(groups), k_stride or k), np.uint32)
+        found = np.zeros(len(groups), np.uint64) if want_found else None
+        B.check(self.L, self.L.tsgpu_group_keyword_search_candidates_batch(self.h, C.cast(arr, C.c_void_p) if flat else None, _vp(begin), len(groups), k, C.byref(hs),
+                                                                            _vp(qi), _vp(found) if want_found else None))
+        return hits, qi, found
+
     def vec_knn_batch(self, field_id, Q, k, allow_ids=None, excluded_ids=None):
         Q = np.ascontiguousarray(Q, dtype=np.float32)
         n = Q.shape[0]
