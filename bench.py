@@ -360,6 +360,7 @@ class Bench:
             return csr
         self.csr = load(self.g, (self.lo, self.hi) if self.sharded else None)
         if self.sharded:
+            self.g.set_option("doc_range_lo", int(self.lo)); self.g.set_option("doc_range_hi", int(self.hi))      # the seq_ids this shard owns (q = * ranks only those)
             # every rank also holds the WHOLE collection (6 GB): rank 0 checks the merged shard results against it, and all ranks run the
             # second multi-GPU form (replicas) on it
             self.twin = self.T.GpuIndex(self.torch.cuda.current_device())
@@ -584,6 +585,31 @@ class Bench:
                         bad += 1
                 res["candidate_combinations_sharded"]["shard_parity"] = {"checked": n_u, "mismatches": bad,
                                                                          "against": "the unsharded collection's own fold on rank 0 (keys, scores, query_index, num_matched, found)"}
+
+        if self.sharded and self.group is not None:
+            # q = * over the shards (tsgpu_group_wildcard_search_batch; Index::search_wildcard, src/index.cpp:6616-6818): every rank ranks the ids of its doc range by the
+            # sort keys, the per-shard Topsters take the keyword exchange; rank 0 checks the merged result against the unsharded twin
+            fl_w = np.arange(1, self.n_docs, 3, dtype=np.uint32)
+            wqs = [self.T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=K_TOPSTER),
+                   self.T.KwQuery([], sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_SEQ_ID, -1, 0)), topster_size=K_TOPSTER, filter_ids=fl_w),
+                   self.T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, -1, 0)), topster_size=K_TOPSTER, excluded_ids=fl_w[::1000]),
+                   self.T.KwQuery([], sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=K_TOPSTER, filter_ids=fl_w[:5])]
+            self.group.wildcard_search_batch(wqs, k=FETCH_SIZE, k_stride=FETCH_SIZE)          # warm-up
+            barrier(world)
+            t0 = time.perf_counter()
+            wh = self.group.wildcard_search_batch(wqs, k=FETCH_SIZE, k_stride=FETCH_SIZE)
+            el_w = max_over_ranks(time.perf_counter() - t0, world)
+            res["wildcard_sharded"] = {"ms_per_call": 1e3 * el_w, "queries": len(wqs), "docs_ranked_per_s": (2 * self.n_docs + 2 * fl_w.size) / el_w,
+                                       "workload": "q = * over %d documents cut into %d doc ranges: all ids / every third id (filter) / excluded ids / a 5-id filter" % (self.n_docs, world)}
+            if self.rank == 0:
+                th = self.twin.wildcard_search_batch(wqs, k_stride=K_TOPSTER)
+                bad = 0
+                for i in range(len(wqs)):
+                    n = min(int(th.n_hits[i]), FETCH_SIZE)
+                    if int(wh.n_hits[i]) != n or not np.array_equal(wh.keys[i, :n], th.keys[i, :n]) or not np.array_equal(wh.scores[i, :n], th.scores[i, :n]) \
+                            or int(wh.num_matched[i]) != int(th.num_matched[i]):
+                        bad += 1
+                res["wildcard_sharded"]["shard_parity"] = {"checked": len(wqs), "mismatches": bad, "against": "the unsharded collection on rank 0 (keys, scores, num_matched)"}
 
         if self.sharded:
             # second multi-GPU form, reported as a sub-object: replicas — every GPU holds the collection, the global batch of N x 10 000 queries
@@ -1709,6 +1735,10 @@ def compact_line(full, detail_path=None):
     for k in ("replicas", "replicas_strong"):
         if isinstance(full.get(k), dict):
             line[k] = _pick(full[k], ("value", "unit", "ms_per_step", "global_batch", "scaling"))
+    if isinstance(full.get("wildcard_sharded"), dict):
+        line["wildcard_sharded"] = _pick(full["wildcard_sharded"], ("ms_per_call", "docs_ranked_per_s"))
+        if "shard_parity" in full["wildcard_sharded"]:
+            line["wildcard_sharded"]["shard_parity"] = _parity_small(full["wildcard_sharded"]["shard_parity"])
     if isinstance(full.get("candidate_combinations_sharded"), dict):
         cs = full["candidate_combinations_sharded"]
         line["candidate_combinations_sharded"] = _pick(cs, ("value", "unit", "ms_per_call"))
@@ -1915,7 +1945,7 @@ def main():
                                   "kernel_src_sha16": cur, "pmc_of_these_sources": bool(meta) and meta.get("kernel_src_sha16") == cur,
                                   "note": "wave-instructions of the find kernel (rocprofv3 --pmc, own pass) / (live kernel cycles x 256 CUs x 1 per cycle); no port is saturated"}
         kw["roofline"] = roof
-        for key in ("concurrency", "uncached", "shard_parity", "replicas", "replicas_strong", "exchange_check", "candidate_combinations_sharded"):
+        for key in ("concurrency", "uncached", "shard_parity", "replicas", "replicas_strong", "exchange_check", "candidate_combinations_sharded", "wildcard_sharded"):
             if key in r:
                 kw[key] = r[key]
         if "cpu" in r:
@@ -2000,7 +2030,7 @@ def main():
             "value": hd["value"], "unit": "queries/s", "n_gpus": world, "steps": hd["steps"], "warmup": args.warmup, "ms_per_step": hd["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32/i64" if head == "keyword" else "f32",
             "data": "synthetic", "config": hd["config"], "p50_ms_per_batch": hd["p50_ms_per_batch"]}
-    for k in ("queries_with_hits", "value_device_only", "ms_per_step_device_only", "value_host_all_arrays", "ms_per_step_host_all_arrays", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "exchange_check", "replicas", "replicas_strong", "candidate_combinations_sharded", "concurrency",
+    for k in ("queries_with_hits", "value_device_only", "ms_per_step_device_only", "value_host_all_arrays", "ms_per_step_host_all_arrays", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "exchange_check", "replicas", "replicas_strong", "candidate_combinations_sharded", "wildcard_sharded", "concurrency",
               "uncached", "general_kernels", "fused_hits_per_batch", "parity_fp32_scan", "batch_sweep", "variants", "hnsw", "rerank_hybrid_matches"):
         if k in hd:
             line[k] = hd[k]

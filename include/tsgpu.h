@@ -101,7 +101,9 @@ void tsgpu_destroy(tsgpu_ctx* ctx);
 const char* tsgpu_last_error(void);
 /* run the library's kernels on a caller-owned hipStream_t (NULL = the context's own stream) */
 int tsgpu_set_stream(tsgpu_ctx* ctx, void* hip_stream);
-/* tuning knobs (all optional): "kw_chunk_blocks" = driver posting blocks per keyword work item (default 0 = sized per batch; 1..256),
+/* "doc_range_lo" / "doc_range_hi" (default 0 / 0 = the whole collection): the seq_ids [lo, hi) this context OWNS when it is a doc-range shard of a
+ * group (tsgpu_group_wildcard_search_batch ranks only those; posting lists need no range: they hold what was fed).
+ * tuning knobs (all optional): "kw_chunk_blocks" = driver posting blocks per keyword work item (default 0 = sized per batch; 1..256),
  * "kw_pair_blocks" = 1 (default): the find kernel serves two blocks of the shortest list per iteration (kw_find2_kernel; 0 = one),
  * "kw_mf_pipelined" = 1 (default): launches with multi-field queries run the PIPELINED find kernel (kw_find_mf2_kernel<., 2> when no query
  * of the launch has more than two query_by fields, <., 4> otherwise: the second token's lists of all fields merged block-wise through
@@ -637,6 +639,11 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
  * combinations per user query; the replicas form answers on one member; 501 with "kw_own_slice_only"; tsgpu_candidates_result_ids is per member (the ids of ITS shard). */
 int tsgpu_group_keyword_search_candidates_batch(tsgpu_group* g, const tsgpu_kw_query* combos, const uint32_t* group_begin, uint32_t n_groups, uint32_t k, tsgpu_hits* out,
                                                 uint32_t* query_index, uint64_t* found);
+/* Wildcard search (q = "*", Index::search_wildcard, src/index.cpp:6616-6818) over the shards: tsgpu_wildcard_search_batch's queries; every member ranks the ids it
+ * OWNS — tsgpu_set_option(member, "doc_range_lo" / "doc_range_hi", ...) when the shard is loaded (hi exclusive; without them a context ranks every seq_id below
+ * num_docs, which is what a single GPU wants) — and the per-shard Topsters take the keyword exchange; num_matched = the ids ranked, added up. 400 when a member of
+ * a group of several has no range. */
+int tsgpu_group_wildcard_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out);
 /* "kw_exchange_slices" = 1 (default): the keyword exchange is an ncclAllToAll of query slices (member j receives only the records of
  * the 1/G of the batch it merges), a slice merge per member, and in-place ncclAllGathers of the merged lists (rank form / device outputs;
  * the local form with host outputs delivers every slice over its own GPU's PCIe link); 0: ONE ncclAllGather of the per-GPU top-k

@@ -35,6 +35,7 @@ def load_shard(g, orc, lo, hi, pts, n_docs, X, dim):
     g.column_set(0, pts)
     g.set_num_docs(n_docs)
     g.commit()
+    g.set_option("doc_range_lo", lo); g.set_option("doc_range_hi", hi)          # the seq_ids this shard owns (q = * ranks only those)
     g.vec_create(1, dim, B.METRIC_IP)
     if hi > lo:
         g.vec_upsert(1, np.arange(lo, hi, dtype=np.uint64), X[lo:hi])
@@ -128,6 +129,18 @@ def main():
             m = int(ch.n_hits[u])
             check("candidates %s u%d" % (cut_name, u), m == min(K, ref.keys.size) and np.array_equal(ch.keys[u, :m], ref.keys[:m]) and np.array_equal(ch.scores[u, :m], ref.scores[:m]) and
                   np.array_equal(cqi[u, :m], rqi[:m].astype(np.uint32)) and int(ch.num_matched[u]) == int(ref.num_keyword_matches) and int(cfound[u]) == int(ref.n_result_ids))
+        # wildcard over the shards (tsgpu_group_wildcard_search_batch): every rank ranks the ids of its range
+        fl = np.arange(2, n_docs, 7, dtype=np.uint32)
+        wq = [T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=K),
+              T.KwQuery([], sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_SEQ_ID, -1, 0)), topster_size=K, filter_ids=fl),
+              T.KwQuery([], sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=K, excluded_ids=fl[::3]),
+              T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=K, filter_ids=fl[:2])]
+        wh = grp.wildcard_search_batch(wq, k=K, k_stride=K)
+        for i, q in enumerate(wq):
+            ref = H.oracle_wildcard(orc, q)
+            m = int(wh.n_hits[i])
+            check("wildcard %s q%d" % (cut_name, i), wh.status[i] == 0 and m == min(K, ref.keys.size) and np.array_equal(wh.keys[i, :m], ref.keys[:m]) and
+                  np.array_equal(wh.scores[i, :m], ref.scores[:m]) and int(wh.num_matched[i]) == int(ref.num_keyword_matches))
         dm, lm, cm = grp.vec_knn_batch(1, Q, k_vec)
         check_knn("knn " + cut_name, dm, lm, cm)
         allow = np.arange(3, n_docs, 5, dtype=np.uint32)
@@ -177,6 +190,11 @@ def main():
     grp = T.GpuGroup.join_host(g, rank, world, ag, a2a)
     grp.set_option("replicas", 1)
     check_keyword("keyword replicas", grp.keyword_search_batch(qs, K, k_stride=K))
+    wq = [T.KwQuery([], sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_SEQ_ID, -1, 0)), topster_size=K, filter_ids=np.arange(1, n_docs, 5, dtype=np.uint32))]
+    wh = grp.wildcard_search_batch(wq, k=K, k_stride=K)
+    ref = H.oracle_wildcard(orc, wq[0])
+    m = int(wh.n_hits[0])
+    check("wildcard replicas", wh.status[0] == 0 and m == min(K, ref.keys.size) and np.array_equal(wh.keys[0, :m], ref.keys[:m]) and np.array_equal(wh.scores[0, :m], ref.scores[:m]))
     dm, lm, cm = grp.vec_knn_batch(1, Q, k_vec)
     check_knn("knn replicas", dm, lm, cm)
     grp.close()

@@ -31,6 +31,7 @@ def build_group(lib, cuts, n_docs, dim, transport, seed=8):
     for lo, hi in zip(cuts[:-1], cuts[1:]):
         g = T.GpuIndex(0, lib)
         H.load_shard(g, orc, lo, hi, n_docs, pts)
+        g.set_option("doc_range_lo", lo); g.set_option("doc_range_hi", hi)          # the seq_ids this shard OWNS (q = * ranks only those)
         g.vec_create(1, dim, B.METRIC_IP)
         if hi > lo:
             g.vec_upsert(1, np.arange(lo, hi, dtype=np.uint64), X[lo:hi])
@@ -80,6 +81,15 @@ def check_group(orc, grp, rng, n_docs, dim):
             assert np.array_equal(ch.keys[u, :n], ref.keys[:n]) and np.array_equal(ch.scores[u, :n], ref.scores[:n]) and np.array_equal(ch.text_match[u, :n], ref.text_match[:n]), (kk, u)
             assert np.array_equal(cqi[u, :n], rqi[:n].astype(np.uint32)), (kk, u, cqi[u, :n][:12], rqi[:12])
             assert int(ch.num_matched[u]) == int(ref.num_keyword_matches) and int(cfound[u]) == int(ref.n_result_ids), (kk, u)
+    # ---- wildcard (Index::search_wildcard over the shards): every member ranks the ids it owns; filter / excluded ids, ascending and descending keys ----
+    wq = [T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=40),
+          T.KwQuery([], sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_SEQ_ID, -1, 0)), topster_size=25, filter_ids=filt),
+          T.KwQuery([], sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=40, excluded_ids=filt[::2]),
+          T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=40, filter_ids=filt[:3])]       # three documents: most shards own none of them
+    wh = grp.wildcard_search_batch(wq, k=250, k_stride=250)
+    assert (wh.status == 0).all()
+    for i, q in enumerate(wq):
+        H.assert_hits_equal(wh, i, H.oracle_wildcard(orc, q), "group wildcard")
     # ---- k-NN: closest first, ties -> smaller label; allow list ----
     Q = rng.standard_normal((5, dim)).astype(np.float32)
     for k in (7, 30):

@@ -191,6 +191,8 @@ struct KwQueryDev {                  // one search_across_fields call
     float vdist_thr;                 // vector_query.distance_threshold (:3702)
     uint8_t vdist_abs;               // cosine field: std::abs(dist) (:3699)
     uint8_t pad2[3];
+    uint32_t wild_base;              // wildcard query without filter ids on a doc-range shard (context options doc_range_lo / _hi): the ids scanned are wild_base + [0, wild_n_ids)
+    uint32_t pad3;
 };
 
 // query_by over several fields (get_field_token_its, src/index.cpp:5598-5660): token t is the UNION over the fields of its
@@ -2302,7 +2304,7 @@ __global__ __launch_bounds__(KW_THREADS) void kw_wildcard_kernel(IndexView ix, c
         ScoredHit h;
         h.s0 = h.s1 = h.s2 = h.text_match = 0; h.off_words = 0;
         if (emit) {
-            seq_id = q.n_filt ? fl[idx] : idx;
+            seq_id = q.n_filt ? fl[idx] : idx + q.wild_base;
             if (q.n_excl) {      // get_n_ids skips exclude_token_ids (:6674-6676)
                 uint32_t lo = 0, hi = q.n_excl;
                 while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (ex[mid] < seq_id) lo = mid + 1; else hi = mid; }

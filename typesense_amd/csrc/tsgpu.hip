@@ -256,6 +256,8 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_two_kernels")) { ctx->kw_two_kernels = value != 0; return ok(); }
     if (!strcmp(name, "kw_device_plan_min_queries")) { ctx->kw_device_plan_min_queries = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 1 << 30); return ok(); }
     if (!strcmp(name, "kw_pair_blocks")) { ctx->kw_pair_blocks = value != 0; return ok(); }
+    if (!strcmp(name, "doc_range_lo")) { ctx->doc_range_set = true; ctx->doc_range_lo = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 0xFFFFFFFFll); return ok(); }
+    if (!strcmp(name, "doc_range_hi")) { ctx->doc_range_set = true; ctx->doc_range_hi = (uint32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 0xFFFFFFFFll); return ok(); }
     if (!strcmp(name, "kw_candidates_rank_fold")) { ctx->kw_candidates_rank_fold = value != 0; return ok(); }
     if (!strcmp(name, "kw_mf_pipelined")) { ctx->kw_mf_pipelined = value != 0; return ok(); }
     if (!strcmp(name, "kw_count_touched")) { ctx->kw_count_touched = value != 0; return ok(); }
@@ -565,8 +567,21 @@ static int plan_batch(tsgpu_ctx* ctx, const Snapshot& snap, const tsgpu_kw_query
                     }
                     if (in.n_filter) A.aux.insert(A.aux.end(), in.filter_ids, in.filter_ids + in.n_filter);
                 }
-                const uint32_t n_ids = in.n_filter ? in.n_filter : ctx->num_docs;
+                uint32_t n_ids = in.n_filter ? in.n_filter : ctx->num_docs;
+                if (!vflat && ctx->doc_range_set) {
+                    // a doc-range shard ranks the ids it OWNS: the filter ids inside [lo, hi) (a sub-array: they ascend), or lo .. hi - 1
+                    const uint32_t lo_id = ctx->doc_range_lo, hi_id = std::min(ctx->doc_range_hi, ctx->num_docs);
+                    if (in.n_filter) {
+                        const uint32_t* fb = in.filter_ids;
+                        const uint32_t a = (uint32_t)(std::lower_bound(fb, fb + in.n_filter, lo_id) - fb), b = (uint32_t)(std::lower_bound(fb, fb + in.n_filter, hi_id) - fb);
+                        A.aux.resize(A.aux.size() - in.n_filter);                       // (the filter ids were appended last: keep the sub-array)
+                        A.aux.insert(A.aux.end(), fb + a, fb + b);
+                        q.n_filt = b - a;
+                        n_ids = b - a;
+                    } else { n_ids = hi_id > lo_id ? hi_id - lo_id : 0; q.wild_base = lo_id; }
+                }
                 q.wild_n_ids = n_ids;
+                if (n_ids == 0) continue;                                               // (nothing of this query on this shard: zero hits, status 0)
                 uint32_t n_num = 0;
                 for (uint32_t s = 0; s < in.n_sort; s++) n_num += in.sort[s].kind == TSGPU_SORT_INT64_COLUMN;
                 A.list_bytes += 4ull * in.n_filter + 8ull * n_ids * n_num;      // the id array + one column value per id and numeric key

@@ -702,8 +702,8 @@ int group_keyword_core(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n
         //    Rank form: a first agreement step carries the arguments' signature AND the rank's dictionary fingerprint (every rank's first collective of a call is an
         //    agreement step, whatever happened to it locally); the second one, after the local phase, carries the local phase's return code.
         bool same_dict = true;
-        if (g->local) same_dict = g->n == 1 || local_dictionaries_equal(g);
-        else { int rc0 = agree(g, TSGPU_OK, call_signature({sig_tag, n_queries, k, out->k_stride, hits_mask(out), 0xD1C7u}), kw_dictionary_fingerprint(g->m[0].ctx), &same_dict); if (rc0) return rc0; }
+        if (g->local) same_dict = g->n == 1 || n_lq == 0 || local_dictionaries_equal(g);
+        else { int rc0 = agree(g, TSGPU_OK, call_signature({sig_tag, n_queries, k, out->k_stride, hits_mask(out), 0xD1C7u}), n_lq ? kw_dictionary_fingerprint(g->m[0].ctx) : 0ull, &same_dict); if (rc0) return rc0; }
         if (!same_dict) { int rc0 = exchange_token_masks(g, lq, n_lq); if (rc0) return rc0; }
         const uint32_t words = out->text_match ? 5 : 4;
         const uint32_t KL = local_topster_stride(queries, n_queries, k);
@@ -853,6 +853,28 @@ int tsgpu_group_keyword_search_batch(tsgpu_group* g, const tsgpu_kw_query* queri
     }
     return group_keyword_core(g, queries, n_queries, k, out, [&](Member& mem, tsgpu_hits* loc, const uint16_t* elsewhere) { return kw_search_batch_masked(mem.ctx, queries, n_queries, loc, elsewhere); }, 2,
                               queries, n_queries);
+}
+
+// Wildcard search (q = *) over doc-range shards (Index::search_wildcard, /root/reference/src/index.cpp:6616-6818; the single-GPU form: tsgpu_wildcard_search_batch):
+// every member ranks the ids it OWNS — context options doc_range_lo / doc_range_hi, set when the shard is loaded — by the sort keys, the per-shard Topsters take
+// the keyword exchange (exact merge; num_matched = ids ranked, added up).
+int tsgpu_group_wildcard_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out) {
+    if (!g || !out || (n_queries && !queries)) return fail(TSGPU_ERR_INVALID, "tsgpu_group_wildcard_search_batch: NULL argument");
+    if (n_queries == 0) { std::lock_guard<std::mutex> lk0(g->mu); return agree(g, TSGPU_OK, call_signature({7, 0})); }
+    int pre = TSGPU_OK;
+    if (k == 0 || k > out->k_stride || k > TSGPU_MAX_TOPK) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_wildcard_search_batch: k must be in 1..min(k_stride, 1024)");
+    else if (!out->keys || !out->scores || !out->n_hits) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_wildcard_search_batch: missing output arrays");
+    else if ((uint64_t)g->n * k > 4096) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_wildcard_search_batch: members * k > 4096");
+    else if (!g->local && g->own_slice_only) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_wildcard_search_batch: not with kw_own_slice_only");
+    else if (g->n > 1 && !g->replicas) for (auto& mem : g->m) if (!mem.ctx->doc_range_set) { pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_wildcard_search_batch: every member needs its doc range (tsgpu_set_option doc_range_lo / doc_range_hi): a shard ranks the ids it owns"); break; }
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (pre) return agree(g, pre, 0);
+    if (g->replicas) {                       // every member mirrors the whole collection: one of them answers
+        int rc = agree(g, TSGPU_OK, call_signature({8, n_queries, k, out->k_stride, hits_mask(out)}));
+        if (rc) return rc;
+        return tsgpu_wildcard_search_batch(g->m[0].ctx, queries, n_queries, out);
+    }
+    return group_keyword_core(g, queries, n_queries, k, out, [&](Member& mem, tsgpu_hits* loc, const uint16_t*) { return tsgpu_wildcard_search_batch(mem.ctx, queries, n_queries, loc); }, 7, nullptr, 0);
 }
 
 // Candidate-token combinations over doc-range shards (Index::search_all_candidates, /root/reference/src/index.cpp:1794-1894; the single-GPU form:

@@ -537,6 +537,8 @@ struct tsgpu_ctx {
     bool kw_candidates_rank_fold = true;             // candidate combinations: the sort-free fold (kw_candidates_rank_kernel) instead of two bitonic sorts
     bool kw_mf_pipelined = true;                     // multi-field find kernel: the pipelined form for launches of <= 2 query_by fields (kw_find_mf2.hip.h)
     bool kw_pair_blocks = true;                      // find kernel variant: two driver blocks per iteration (kw_find2.hip.h)
+    bool doc_range_set = false; uint32_t doc_range_lo = 0, doc_range_hi = 0;     // a doc-range shard of a group (options doc_range_lo / doc_range_hi; hi = 0: the whole collection): which seq_ids this context
+                                                     // OWNS — a wildcard search (q = *) ranks only those (tsgpu_group_wildcard_search_batch); postings need no range: they are what was fed
     long long kw_iddir_min_ids = 256;                // id directories (tsgpu_format.h): lists of at least max(this, num_docs / kw_iddir_density_div) ids get one; 0 = none
     long long kw_iddir_density_div = 64;
     long long kw_iddir_budget_mb = 4096;             // device memory for the directory pool (longest lists first)

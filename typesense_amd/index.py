@@ -701,6 +701,14 @@ class GpuGroup:
     def keyword_search_batch_raw(self, arr, n, k, hs):
         B.check(self.L, self.L.tsgpu_group_keyword_search_batch(self.h, C.cast(arr, C.c_void_p), n, k, C.byref(hs)))
 
+    def wildcard_search_batch(self, queries, k, k_stride=None):
+        """tsgpu_group_wildcard_search_batch: q = * over the shards (every member ranks the ids of its doc range)"""
+        arr = make_query_array(queries)
+        hits = Hits(len(arr), k_stride or k)
+        hs = hits.c_struct()
+        B.check(self.L, self.L.tsgpu_group_wildcard_search_batch(self.h, C.cast(arr, C.c_void_p), len(arr), k, C.byref(hs)))
+        return hits
+
     def keyword_search_candidates_batch(self, groups, k, k_stride=None, want_found=True):
         """tsgpu_group_keyword_search_candidates_batch: groups = per user query the list of candidate-token combinations (KwQuery, pass order).
         Returns (Hits [n_groups], query_index [n_groups, k_stride] u32, found [n_groups] u64 or None) — Index::search_all_candidates over the shards."""
