@@ -60,9 +60,11 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (concurrency, uncached-term batch, vector batch sweep / cosine / clustered)")
     ap.add_argument("--threads", type=int, default=256, help="host threads of the concurrency leg")
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--hnsw-rows", type=int, default=300_000, help="rows of the HNSW leg's collection (0 = skip the leg); the insertion-order build costs ~0.1 ms per row and host core")
-    ap.add_argument("--hnsw-graph", default="inserted", choices=["inserted", "knn"],
-                    help="inserted (default) = hnswlib's incremental addPoint inside the library (tsgpu_vec_hnsw_enable, label order, one host thread per CPU of the quota); "
+    ap.add_argument("--hnsw-rows", type=int, default=2_000_000, help="rows of the HNSW leg's collection (0 = skip the leg); the bulk build on the device runs at ~150 K rows/s "
+                                                                    "(10M x 768: 70 s, profiles/r06/bench_hnsw_10m.json), the insertion-order build (--hnsw-graph inserted) at ~8 K rows/s on 16 host threads")
+    ap.add_argument("--hnsw-graph", default="bulk", choices=["bulk", "inserted", "knn"],
+                    help="bulk (default) = tsgpu_vec_hnsw_build: the graph built in batches on the device (hnswlib's level draw, beam, neighbour heuristic and reverse-link "
+                         "rule per batch; csrc/vec_hnsw_build.hip.h); inserted = hnswlib's incremental addPoint inside the library (tsgpu_vec_hnsw_enable, label order, one host thread per CPU of the quota); "
                          "knn = the round-2 stand-in derived on the GPU from exact k-NN lists (typesense_amd/hnsw_synth.py)")
     ap.add_argument("--hnsw-batch", type=int, default=4096, help="queries per step of the HNSW leg")
     ap.add_argument("--k", type=int, default=100)
@@ -1415,8 +1417,20 @@ class Bench:
         g.vec_create(field, dim, B.METRIC_IP, n)
         lab = torch.arange(n, dtype=torch.int64, device="cuda")
         inserted = args.hnsw_graph == "inserted"
+        bulk = args.hnsw_graph == "bulk"
         build_threads = max(1, int(cpu_quota_cpus() or os.cpu_count() or 1))
-        if inserted:
+        build_info = None
+        if bulk:
+            # the graph of a LOADED collection: built in batches on the device over the rows the field holds (tsgpu_vec_hnsw_build; M 16, ef_construction 200,
+            # seed 100: include/index.h:365-367's defaults). Levels as hnswlib draws them; the rows with level >= 2 and the first 1 024 inserted on the host.
+            g.vec_upsert_device(field, lab.data_ptr(), X.data_ptr(), n)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            build_info = g.vec_hnsw_build(field, M=M, ef_construction=200, seed=100, threads=build_threads)
+            torch.cuda.synchronize()
+            t_build = time.time() - t1
+            graph = g.vec_hnsw_export(field)
+        elif inserted:
             # the graph the reference would have: hnswlib's addPoint in label order (M 16, ef_construction 200, seed 100: include/index.h:365-367),
             # built INSIDE the library while the rows are upserted (tsgpu_hnsw_build.h), concurrently like the reference's indexing threads
             g.vec_hnsw_enable(field, M=M, ef_construction=200, seed=100, threads=build_threads)
@@ -1441,18 +1455,21 @@ class Bench:
         res = {"metric": "HNSW k-NN queries/s (searchKnnCloserFirst, k=%d), PARITY UNPINNED: hnswlib is absent from the reference tree; the traversal is "
                          "checked against the oracle's restatement of the published algorithm on the same graph" % k,
                "unit": "queries/s", "dtype": "f32",
-               "config": {"workload": ("%d x %d unit rows with a 32-dim latent structure + 0.3 noise (synth.latent_vectors), M=%d, ef_construction 200, seed 100: hnswlib's incremental "
+               "config": {"workload": ("%d x %d unit rows with a 32-dim latent structure + 0.3 noise (synth.latent_vectors), M=%d, ef_construction 200, seed 100: the graph built in "
+                                       "batches ON THE DEVICE (tsgpu_vec_hnsw_build: hnswlib's level draw, ef_construction beam, neighbour heuristic and reverse-link rule applied per "
+                                       "batch; %d seed rows inserted by %d host threads)" % (n, dim, M, build_info["n_seed"], build_threads)) if bulk else
+                                      ("%d x %d unit rows with a 32-dim latent structure + 0.3 noise (synth.latent_vectors), M=%d, ef_construction 200, seed 100: hnswlib's incremental "
                                        "addPoint in label order INSIDE the library (tsgpu_vec_hnsw_enable), %d host threads per 65 536-row upsert" % (n, dim, M, build_threads)) if inserted else
                                       ("%d x %d unit rows with a 32-dim latent structure + 0.3 noise (synth.latent_vectors), M=%d, graph = exact %d-NN lists + "
                                        "getNeighborsByHeuristic2 + reverse links, built on the GPU (graph: knn-heuristic, NOT hnswlib's insertion-order graph)" % (n, dim, M, 64)),
-                          "graph": args.hnsw_graph, "graph_build_s": t_build, "graph_build_rows_per_s": n / t_build if t_build > 0 else None, "collection_s": t1 - t0, "maxlevel": int(graph["maxlevel"]), "mean_level0_degree": float(graph["link0"][:, 0].mean())},
+                          "rows": n, "graph": args.hnsw_graph, "graph_build": build_info, "graph_build_s": t_build, "graph_build_rows_per_s": n / t_build if t_build > 0 else None, "collection_s": t1 - t0, "maxlevel": int(graph["maxlevel"]), "mean_level0_degree": float(graph["link0"][:, 0].mean())},
                "runs": []}
         de = torch.zeros((256, k), dtype=torch.float32, device="cuda"); le = torch.zeros((256, k), dtype=torch.int64, device="cuda"); ce = torch.zeros(256, dtype=torch.int32, device="cuda")
         g.vec_knn_batch_raw(field, Q.data_ptr(), B.MEM_DEVICE, 256, k, de.data_ptr(), le.data_ptr(), ce.data_ptr(), B.MEM_DEVICE)
         torch.cuda.synchronize()
         le_h = le.cpu().numpy()
         keep = {}
-        for ef in (100, 200, 400):
+        for ef in (100, 200, 400) + ((800,) if n > 3_000_000 else ()):      # (a 10M-row graph needs a wider beam for recall 0.9 on this data)
             for nq in sorted({256, args.hnsw_batch}):
                 d = torch.zeros((nq, k), dtype=torch.float32, device="cuda"); l = torch.zeros((nq, k), dtype=torch.int64, device="cuda"); c = torch.zeros(nq, dtype=torch.int32, device="cuda")
                 def step():
@@ -1493,7 +1510,9 @@ class Bench:
                                    "counted) over the kernel time of the QUOTED run (ef = %d, batch %d: the smallest ef with recall@%d >= 0.9; "
                                    "at the reference's effective ef = max(ef, k) = %d recall@%d is %.2f on this data: runs[])" % (
                                        head["ef"], head["batch"], k, k, k, next((x["recall_at_%d" % k] for x in cands if x["ef"] == k), float("nan")))}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and n > 3_000_000:
+            res["parity"] = {"queries_checked": 0, "pinned": False, "what": "skipped: the oracle's copy of %d x %d rows (+ the graph) is not held on the host beyond 3M rows" % (n, dim)}
+        elif not args.no_cpu_baseline:
             from oracle import oracle_py as O
             t2 = time.time()
             orc = O.OracleIndex(1, 1)
@@ -1764,6 +1783,10 @@ def compact_line(full, detail_path=None):
     hn = (full.get("vector") or {}).get("hnsw") if isinstance(full.get("vector"), dict) else full.get("hnsw")
     if isinstance(hn, dict):
         line["hnsw"] = _pick(hn, ("value", "unit", "rows", "ef", "batch", "recall_at_100"))
+        cfg = hn.get("config") or {}
+        line["hnsw"]["rows"] = cfg.get("rows")
+        line["hnsw"]["graph"] = cfg.get("graph")
+        line["hnsw"]["graph_build_s"] = cfg.get("graph_build_s")
         line["hnsw"]["parity"] = "UNPINNED (hnswlib is not under /root/reference); traversal = the oracle's restatement"
     if isinstance(full.get("distributed"), dict):
         line["distributed"] = _pick(full["distributed"], ("backend", "world_size", "rccl", "mode", "group_transport"))

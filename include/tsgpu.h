@@ -494,6 +494,21 @@ int tsgpu_vec_hnsw_load(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, int32
  * hnswlib leaves to std::unordered_set are fixed (which deleted slot; candidate order on equal distances): csrc/tsgpu_hnsw_build.h.
  * PARITY UNPINNED (hnswlib is not in the reference tree). M <= 31. */
 int tsgpu_vec_hnsw_enable(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, uint32_t ef_construction, uint32_t seed, uint32_t n_threads);
+/* BULK construction of the graph over the rows the field holds NOW, on the device — what a restart or an import of a collection needs (the reference re-runs
+ * addPoint per document from its indexing threads, src/index.cpp:1002-1075: minutes to hours at BASELINE config 3's size). Levels as hnswlib draws them
+ * (default_random_engine(seed), label order); the rows with level >= 2 (one in M^2) and the first seed_min rows (0 = 1024) are inserted by the sequential
+ * algorithm on n_threads host threads; the rest (levels 0 and 1) in batches of at most max_batch (0 = 65 536) and a sixteenth of what is linked: per row and
+ * layer the ef_construction beam on the device, hnswlib's neighbour heuristic, reverse links applied per node for the whole batch (csrc/vec_hnsw_build.hip.h).
+ * 10M x 768 rows, M 16, ef_construction 200: about a minute on one MI355X (the row-by-row insertion: 8 K rows/s on 16 host threads). Deterministic for
+ * n_threads = 1 (oracle: hnsw_graph_t::bulk_build). The graph lives on the device like a loaded mirror (tsgpu_vec_hnsw_search_batch serves it,
+ * tsgpu_vec_hnsw_export reads it back); rows added afterwards need a new build. PARITY UNPINNED like the search. M <= 31, ef_construction <= 1024. */
+typedef struct tsgpu_hnsw_build_info {
+    uint32_t n, n_seed, n_batches, unlinked;         /* rows, rows inserted on the host, device batches, rows whose beam overflowed (left without links; 0 in practice) */
+    int32_t maxlevel; uint32_t enterpoint;
+    double seed_seconds, device_seconds, search_seconds, link_seconds;      /* host insertion of the seed set; the batches: their beams, their links */
+} tsgpu_hnsw_build_info;
+int tsgpu_vec_hnsw_build(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, uint32_t ef_construction, uint32_t seed, uint32_t n_threads, uint32_t seed_min, uint32_t max_batch,
+                         tsgpu_hnsw_build_info* info);
 /* the built graph in tsgpu_vec_hnsw_load's flat form (tests, persistence). info = {n, maxlevel, enterpoint, M}; *n_upper = upper lists.
  * Arrays may be NULL (sizes only): levels[n], link0[n][1 + 2M], upper_ptr[n + 1], upper_links[n_upper][1 + M]. */
 int tsgpu_vec_hnsw_export(tsgpu_ctx* ctx, uint32_t vec_field_id, int32_t info[4], uint32_t* levels, uint32_t* link0, uint64_t* upper_ptr,

@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <queue>
 #include <random>
 #include <unordered_map>
@@ -202,6 +203,127 @@ struct hnsw_graph_t {
             maxlevel = curlevel;
         }
         if (curlevel > maxlevelcopy) { enterpoint = cur_c; maxlevel = curlevel; }
+    }
+
+    // ---- BULK build in batches (the library's tsgpu_vec_hnsw_build; csrc/vec_hnsw_build.hip.h states the algorithm) — NOT hnswlib's insertion order: a
+    // deterministic batched variant of it whose pieces are hnswlib's (level draw, searchBaseLayer, getNeighborsByHeuristic2, the reverse-link rule).
+    //   1. levels of all rows drawn in label order; 2. the seed set (level >= 2, or id < seed_min; level >= 1 when no such row has an upper level) inserted
+    //      by the sequential algorithm in id order; 3. the other rows (levels 0 and 1) in id order, in batches of min(max_batch, max(64, linked / 16)): each
+    //      searches the graph as it stood BEFORE the batch — the beam of layer 1 if it has that level, and the beam of layer 0 —, keeps <= M neighbours per
+    //      layer by the heuristic over the beam (closest first), and asks each of them for a reverse link; after the batch's beams, layer 1 then layer 0: a
+    //      node that was asked takes the requests ordered (distance, id): appended while its list has room for all, else the heuristic over list + the
+    //      closest requests (256 candidates at most) ordered (distance, id).
+    // the heuristic over candidates given closest first (ids + distances to the centre): kept ids in order
+    std::vector<dist_id_t> selectClosestFirst(const std::vector<dist_id_t>& cand, size_t Mlim) {
+        if (cand.size() < Mlim) return cand;
+        std::vector<dist_id_t> keep;
+        for (const dist_id_t& cur : cand) {
+            if (keep.size() >= Mlim) break;
+            bool good = true;
+            for (const dist_id_t& k : keep) if (dist(vec(k.second), vec(cur.second)) < cur.first) { good = false; break; }
+            if (good) keep.push_back(cur);
+        }
+        return keep;
+    }
+    // addPoint's linking part for a row that is already placed (data, level, empty lists)
+    void linkExisting(tableint cur_c) {
+        const int curlevel = levels[cur_c];
+        int maxlevelcopy = maxlevel;
+        tableint currObj = enterpoint;
+        const float* q = vec(cur_c);
+        if ((int32_t)currObj != -1) {
+            if (curlevel < maxlevelcopy) {
+                float curdist = dist(q, vec(currObj));
+                for (int level = maxlevelcopy; level > curlevel; level--) {
+                    bool changed = true;
+                    while (changed) {
+                        changed = false;
+                        const std::vector<tableint>& nb = list_of(currObj, level);
+                        for (size_t i = 0; i < nb.size(); i++) { float d = dist(q, vec(nb[i])); if (d < curdist) { curdist = d; currObj = nb[i]; changed = true; } }
+                    }
+                }
+            }
+            for (int level = std::min(curlevel, maxlevelcopy); level >= 0; level--) {
+                heap_t top_candidates = searchBaseLayer(currObj, q, level);
+                currObj = mutuallyConnectNewElement(q, cur_c, top_candidates, level, currObj);
+            }
+        } else { enterpoint = cur_c; maxlevel = curlevel; }
+        if (curlevel > maxlevelcopy) { enterpoint = cur_c; maxlevel = curlevel; }
+    }
+    // greedy descent from the entry point down to (not into) `stop_above`, then the beam of that layer: closest first
+    std::vector<dist_id_t> beamClosestFirst(tableint c, int layer) {
+        const float* q = vec(c);
+        tableint currObj = enterpoint;
+        float curdist = dist(q, vec(currObj));
+        for (int level = maxlevel; level > layer; level--) {
+            bool changed = true;
+            while (changed) {
+                changed = false;
+                const std::vector<tableint>& nb = list_of(currObj, level);
+                for (size_t i = 0; i < nb.size(); i++) { float d = dist(q, vec(nb[i])); if (d < curdist) { curdist = d; currObj = nb[i]; changed = true; } }
+            }
+        }
+        heap_t top = searchBaseLayer(currObj, q, layer);
+        std::vector<dist_id_t> beam;
+        while (!top.empty()) { beam.push_back(top.top()); top.pop(); }
+        std::reverse(beam.begin(), beam.end());                                  // closest first (the order searchKnnCloserFirst hands out)
+        return beam;
+    }
+    // one round of links on `layer`: the new rows' lists = their choices, then every asked node answers all its requests at once
+    void linkRound(int layer, const std::vector<tableint>& rows, const std::vector<std::vector<dist_id_t>>& chosen) {
+        const size_t TCAP = 256, cap = layer ? maxM : maxM0;
+        std::map<tableint, std::vector<dist_id_t>> asked;                       // node -> requests (distance, new row)
+        for (size_t r = 0; r < rows.size(); r++) {
+            std::vector<tableint>& own = list_of(rows[r], layer);
+            own.clear();
+            for (const dist_id_t& k : chosen[r]) { own.push_back(k.second); asked[k.second].emplace_back(k.first, rows[r]); }
+        }
+        for (auto& kv : asked) {
+            const tableint s = kv.first;
+            std::vector<dist_id_t>& req = kv.second;
+            std::sort(req.begin(), req.end());                                   // (distance, id)
+            std::vector<tableint>& lst = list_of(s, layer);
+            if (lst.size() + req.size() <= cap) { for (const dist_id_t& r : req) lst.push_back(r.second); continue; }
+            if (req.size() > TCAP - lst.size()) req.resize(TCAP - lst.size());
+            std::vector<dist_id_t> cand;
+            for (tableint x : lst) cand.emplace_back(dist(vec(x), vec(s)), x);
+            cand.insert(cand.end(), req.begin(), req.end());
+            std::sort(cand.begin(), cand.end());
+            const std::vector<dist_id_t> keep = selectClosestFirst(cand, cap);
+            lst.clear();
+            for (const dist_id_t& k : keep) lst.push_back(k.second);
+        }
+    }
+    void bulk_build(const float* rows, const uint64_t* row_labels, size_t n, size_t seed_min, size_t max_batch) {
+        data.assign(rows, rows + n * dim);
+        labels.assign(row_labels, row_labels + n);
+        for (size_t i = 0; i < n; i++) label_lookup[labels[i]] = (tableint)i;
+        deleted.assign(n, 0);
+        levels.resize(n);
+        link0.assign(n, {});
+        linkU.resize(n);
+        for (size_t i = 0; i < n; i++) { levels[i] = getRandomLevel(mult); linkU[i].assign((size_t)levels[i], {}); }
+        int seed_top = 0;
+        for (size_t i = 0; i < n; i++) if (levels[i] >= 2 || i < seed_min) seed_top = std::max(seed_top, levels[i]);
+        const int host_from = seed_top >= 1 ? 2 : 1;
+        std::vector<tableint> rest;
+        size_t linked = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (levels[i] >= host_from || i < seed_min) { linkExisting((tableint)i); linked++; }
+            else rest.push_back((tableint)i);
+        }
+        size_t pos = 0;
+        while (pos < rest.size()) {
+            const size_t b = std::min(std::min(max_batch, std::max<size_t>(64, linked / 16)), rest.size() - pos);
+            std::vector<tableint> rows0(rest.begin() + pos, rest.begin() + pos + b), rows1;
+            for (tableint c : rows0) if (levels[c] == 1) rows1.push_back(c);
+            std::vector<std::vector<dist_id_t>> chosen0(rows0.size()), chosen1(rows1.size());      // the beams first, on the graph as it stands; the links after both
+            for (size_t r = 0; r < rows1.size(); r++) chosen1[r] = selectClosestFirst(beamClosestFirst(rows1[r], 1), M);
+            for (size_t r = 0; r < rows0.size(); r++) chosen0[r] = selectClosestFirst(beamClosestFirst(rows0[r], 0), M);
+            linkRound(1, rows1, chosen1);
+            linkRound(0, rows0, chosen0);
+            pos += b; linked += b;
+        }
     }
 
     // markDelete(label) -> markDeletedInternal: with allow_replace_deleted the slot becomes available to a later addPoint

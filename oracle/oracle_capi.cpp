@@ -292,6 +292,16 @@ void orc_hnsw_build(void* h, uint32_t M, uint32_t ef_construction, uint32_t seed
     slot->init(idx->num_dim, M, ef_construction, seed, hnsw_dist);
     for (size_t r = 0; r < idx->vec_labels.size(); r++) slot->addPoint(idx->vec_store.data() + r * idx->num_dim, idx->vec_labels[r]);
 }
+// the batched bulk build the library runs on the device (tsgpu_vec_hnsw_build), restated: hnsw_graph_t::bulk_build
+void orc_hnsw_bulk_build(void* h, uint32_t M, uint32_t ef_construction, uint32_t seed, uint32_t seed_min, uint32_t max_batch) {
+    Index* idx = (Index*)h;
+    auto& slot = hnsw_of()[h];
+    delete slot;
+    slot = new hnsw_graph_t;
+    slot->init(idx->num_dim, M, ef_construction, seed, hnsw_dist);
+    std::vector<uint64_t> lab(idx->vec_labels.begin(), idx->vec_labels.end());
+    slot->bulk_build(idx->vec_store.data(), lab.data(), lab.size(), seed_min ? seed_min : 1024, max_batch ? max_batch : 65536);
+}
 // incremental addPoint after orc_hnsw_build: the rows that orc_vec_add appended since (row order = insertion order)
 void orc_hnsw_add_new_rows(void* h) {
     Index* idx = (Index*)h;

@@ -141,6 +141,8 @@ def lib():
         L.orc_distinct_ids.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.orc_search_candidates.argtypes = [C.c_void_p, C.POINTER(KwQuery), C.c_uint32, C.POINTER(Result), C.c_void_p]
         L.orc_hnsw_build.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_hnsw_bulk_build.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_hnsw_bulk_build.restype = None
         L.orc_hnsw_free.argtypes = [C.c_void_p]
         L.orc_hnsw_mark_deleted.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_hnsw_add_new_rows.argtypes = [C.c_void_p]
@@ -537,6 +539,10 @@ class OracleIndex:
     def hnsw_build(self, M=16, ef_construction=200, seed=100):
         """HierarchicalNSW(space, 16, M, ef_construction, 100, true) + addPoint per row in insertion order (include/index.h:365-367)"""
         self.L.orc_hnsw_build(self.h, M, ef_construction, seed)
+
+    def hnsw_bulk_build(self, M=16, ef_construction=200, seed=100, seed_min=0, max_batch=0):
+        """the batched bulk build of tsgpu_vec_hnsw_build over the rows added with vec_add (hnsw_graph_t::bulk_build)"""
+        self.L.orc_hnsw_bulk_build(self.h, M, ef_construction, seed, seed_min, max_batch)
 
     def hnsw_add(self, labels, X):
         """vec_add + hnswlib addPoint for rows that arrive after hnsw_build (insertion order = row order)"""

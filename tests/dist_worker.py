@@ -129,6 +129,18 @@ def main():
             m = int(ch.n_hits[u])
             check("candidates %s u%d" % (cut_name, u), m == min(K, ref.keys.size) and np.array_equal(ch.keys[u, :m], ref.keys[:m]) and np.array_equal(ch.scores[u, :m], ref.scores[:m]) and
                   np.array_equal(cqi[u, :m], rqi[:m].astype(np.uint32)) and int(ch.num_matched[u]) == int(ref.num_keyword_matches) and int(cfound[u]) == int(ref.n_result_ids))
+        if cut_name == "uneven":
+            # a rank that fails BETWEEN the agreement and the sized exchange takes every rank out with it, in the same collective: nobody waits for it
+            grp.set_option("kw_exchange_pruned", 2)
+            grp.set_option("test_fail_prune_pack_rank", world)                 # the last rank fails
+            try:
+                grp.keyword_search_batch(qs, K, k_stride=K)
+                check("injected failure " + cut_name, False)
+            except B.TsgpuError as e:
+                check("injected failure " + cut_name, ("injected" in str(e)) == (rank == world - 1) and (rank == world - 1 or "another rank failed" in str(e)))
+            grp.set_option("test_fail_prune_pack_rank", 0)
+            grp.set_option("kw_exchange_pruned", 1)
+            check_keyword("after the injected failure " + cut_name, grp.keyword_search_batch(qs, K, k_stride=K))
         # wildcard over the shards (tsgpu_group_wildcard_search_batch): every rank ranks the ids of its range
         fl = np.arange(2, n_docs, 7, dtype=np.uint32)
         wq = [T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=K),

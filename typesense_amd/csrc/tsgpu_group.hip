@@ -112,6 +112,7 @@ struct tsgpu_group {
     std::vector<Member> m;               // local form: all members; rank form: the one this process owns
     std::mutex mu;                       // one batch at a time per group
     bool replicas = false;               // every member mirrors the WHOLE collection: the batch is cut into query slices (option "replicas")
+    uint32_t test_fail_pack_rank = 0;    // TESTS ONLY (option "test_fail_prune_pack_rank" = rank + 1): that rank fails between the agreement and the sized exchange
     bool own_slice_only = false;         // rank form, slice exchange (option "kw_own_slice_only"): a rank delivers only the slice of the batch it merged — queries
                                          // [rank * per, (rank + 1) * per), per = ceil(n_queries / n_ranks) — into its output arrays (at those queries' slots); no all-gather of
                                          // the merged lists. What a deployment with one request router per rank needs, and what the local form does with host outputs.
@@ -282,9 +283,12 @@ int all_gather_everywhere(tsgpu_group* g, DevBuf Member::*send, DevBuf Member::*
     return TSGPU_OK;
 }
 // bound-pruned exchange: every member's per-destination entry totals (p_tot: n_dst u32 on its device) -> tot_all[src * n_dst + dst] on the host
-int gather_totals(tsgpu_group* g, uint32_t n_dst, std::vector<uint32_t>& tot_all) {
+// rc_local (rank form): this rank failed between the agreement and here. It still takes part — with totals of 0xFFFFFFFF, which no slice can have — so that
+// every rank sees the failure in the same collective and all of them leave together (nobody waits in the sized exchange for a rank that returned)
+int gather_totals(tsgpu_group* g, uint32_t n_dst, std::vector<uint32_t>& tot_all, int rc_local = TSGPU_OK) {
     tot_all.assign((size_t)g->n * n_dst, 0u);
     if (g->local) {
+        if (rc_local) return rc_local;
         for (size_t i = 0; i < g->m.size(); i++) {
             Member& mem = g->m[i];
             (void)hipSetDevice(mem.ctx->device);
@@ -296,17 +300,22 @@ int gather_totals(tsgpu_group* g, uint32_t n_dst, std::vector<uint32_t>& tot_all
     Member& mem = g->m[0];
     (void)hipSetDevice(mem.ctx->device);
     if (g->transport == TSGPU_XCHG_HOST) {
-        std::vector<uint32_t> mine(n_dst, 0u);
-        TSGPU_HIP_TRY(hipMemcpyAsync(mine.data(), mem.p_tot.p, (size_t)n_dst * 4, hipMemcpyDeviceToHost, mem.ctx->stream));
-        TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+        std::vector<uint32_t> mine(n_dst, rc_local ? 0xFFFFFFFFu : 0u);
+        if (!rc_local) {
+            TSGPU_HIP_TRY(hipMemcpyAsync(mine.data(), mem.p_tot.p, (size_t)n_dst * 4, hipMemcpyDeviceToHost, mem.ctx->stream));
+            TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+        }
         const int crc = g->coll.all_gather(g->coll.user, mine.data(), tot_all.data(), (size_t)n_dst * 4);
         if (crc) return fail(TSGPU_ERR_DEVICE, "tsgpu_group: the caller's all_gather callback failed (" + std::to_string(crc) + ")");
-        return TSGPU_OK;
+    } else {
+        int rc;
+        if (rc_local) (void)hipMemsetAsync(mem.p_tot.p, 0xFF, (size_t)n_dst * 4, mem.ctx->stream);
+        if ((rc = rccl()->AllGather(mem.p_tot.p, mem.p_totall.p, (size_t)n_dst * 4, X_NCCL_UINT8, mem.comm, mem.ctx->stream))) return rccl_fail("ncclAllGather (slice totals)", rc);
+        TSGPU_HIP_TRY(hipMemcpyAsync(tot_all.data(), mem.p_totall.p, tot_all.size() * 4, hipMemcpyDeviceToHost, mem.ctx->stream));
+        TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
     }
-    int rc;
-    if ((rc = rccl()->AllGather(mem.p_tot.p, mem.p_totall.p, (size_t)n_dst * 4, X_NCCL_UINT8, mem.comm, mem.ctx->stream))) return rccl_fail("ncclAllGather (slice totals)", rc);
-    TSGPU_HIP_TRY(hipMemcpyAsync(tot_all.data(), mem.p_totall.p, tot_all.size() * 4, hipMemcpyDeviceToHost, mem.ctx->stream));
-    TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+    if (rc_local) return rc_local;
+    for (uint32_t v : tot_all) if (v == 0xFFFFFFFFu) return fail(TSGPU_ERR_DEVICE, "tsgpu_group: another rank failed while it packed its slices of the bound-pruned exchange");
     return TSGPU_OK;
 }
 
@@ -769,11 +778,12 @@ int group_keyword_core(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n
                 memset(&loc, 0, sizeof loc);
                 loc.mem = TSGPU_MEM_DEVICE; loc.k_stride = KL; loc.keys = mem.l_keys.as<uint64_t>(); loc.scores = mem.l_scores.as<int64_t>(); loc.text_match = mem.l_tm.as<int64_t>();
                 loc.n_hits = mem.l_nh.as<uint32_t>(); loc.num_matched = mem.l_nm.as<uint64_t>(); loc.status = mem.l_st.as<int32_t>();
+                if (!g->local && g->test_fail_pack_rank == g->rank + 1) { rc = fail(TSGPU_ERR_DEVICE, "tsgpu_group: injected failure before the sized exchange (test_fail_prune_pack_rank)"); break; }
                 if ((rc = group_kw_prune_pack(mem.ctx, &loc, n_queries, n_pad, k, words, mem.caps.as<uint32_t>(), mem.kth_recv.as<int64_t>(), g->n, per, n_dst, slice_words,
-                                              mem.send.as<uint64_t>(), mem.p_tot.as<uint32_t>(), mem.ctx->stream))) return rc;
+                                              mem.send.as<uint64_t>(), mem.p_tot.as<uint32_t>(), mem.ctx->stream))) break;      // (a rank that fails here still joins the totals' collective)
                 if (&mem == &g->m[0]) mark(g, 0, 3);
             }
-            if ((rc = gather_totals(g, n_dst, tot_all))) return rc;
+            if ((rc = gather_totals(g, n_dst, tot_all, rc))) return rc;
         }
         // Pruned slices travel at their EXACT sizes where the transport can (RCCL send / recv pairs, device copies: when one shard owns a query's winners it
         // alone sends entries for it); the HOST callbacks and the literal all-gather form move equal-sized pieces: the used prefix of the largest slice.
@@ -965,6 +975,7 @@ int tsgpu_group_set_option(tsgpu_group* g, const char* name, int64_t value) {
     if (!strcmp(name, "kw_exchange_slices")) { g->kw_slices = value == 2 ? 2 : (value != 0); return ok(); }
     if (!strcmp(name, "replicas")) { g->replicas = value != 0; return ok(); }
     if (!strcmp(name, "kw_own_slice_only")) { g->own_slice_only = value != 0; return ok(); }
+    if (!strcmp(name, "test_fail_prune_pack_rank")) { g->test_fail_pack_rank = (uint32_t)std::max<int64_t>(value, 0); return ok(); }
     return fail(TSGPU_ERR_NOT_FOUND, std::string("tsgpu_group_set_option: unknown option ") + name);
 }
 

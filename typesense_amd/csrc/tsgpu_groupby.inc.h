@@ -329,8 +329,14 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
         const size_t out_bytes = query_index ? Lout.at : (out->vector_distance ? end_vd : (out->text_match ? end_tm : end_required));      // what the caller asked for, as a prefix
         int rc;
         if ((rc = S.in.reserve(Lin.at)) || (rc = S.ff.reserve(Lff.at)) || (rc = S.zero.reserve(Lzero.at)) || (rc = S.out.reserve(Lout.at)) || (rc = S.work.reserve(Lwork.at)) ||
-            (rc = S.h_in.reserve(Lin.at)) || (rc = S.h_out.reserve(out_bytes <= (4u << 20) ? out_bytes : o_gdkey)))
+            (rc = S.h_out.reserve(out_bytes <= (4u << 20) ? out_bytes : o_gdkey)))
             return rc;
+        // the pinned staging holds the descriptions and the id arrays that come FROM the host: not the ids the id pass left on the device, not the ids
+        // gb_iota_kernel writes for q = * (40 MB of pinned memory per 10M documents otherwise)
+        uint64_t host_items_end = 0;
+        for (uint32_t i = 0; !ids_on_dev && i < n_queries; i++)
+            if (gq[i].run && gq[i].n_items && !iota[i]) host_items_end = std::max<uint64_t>(host_items_end, (uint64_t)gq[i].item_begin + gq[i].n_items);
+        if ((rc = S.h_in.reserve(i_ids + 16 + host_items_end * 4))) return rc;
         const bool want_loglog = any_first;
         if (want_loglog && (rc = S.loglog.reserve((size_t)n_queries * GB_LOGLOG_M))) return rc;
         {

@@ -302,7 +302,8 @@ struct HnswBuilder {
 
     // n new rows (appended in this order = their internal ids). Levels are drawn in label order before any insertion, so the one-thread
     // build is the sequential algorithm exactly; with more threads the rows of the batch are inserted concurrently (hnswlib's locking).
-    void add_batch(const float* rows, size_t n) {
+    // preset_levels (tsgpu_vec_hnsw_build's seed set): the levels were drawn by the caller — for ALL rows of the collection, of which these are some
+    void add_batch(const float* rows, size_t n, const int32_t* preset_levels = nullptr) {
         if (n == 0) return;
         const size_t n0 = size();
         data.insert(data.end(), rows, rows + n * dim);
@@ -310,7 +311,7 @@ struct HnswBuilder {
         link0.resize((n0 + n) * s0(), 0u);
         for (size_t i = 0; i < n; i++) {
             std::uniform_real_distribution<double> u(0.0, 1.0);
-            const int lv = (int)(-std::log(u(level_generator)) * mult);
+            const int lv = preset_levels ? preset_levels[i] : (int)(-std::log(u(level_generator)) * mult);
             levels.push_back(lv);
             upper_at.push_back(upper.size() / su());
             upper.resize(upper.size() + (size_t)lv * su(), 0u);

@@ -13,6 +13,7 @@
 #include "host_topster.h"
 
 #include "tsgpu_hnsw_build.h"
+#include "vec_hnsw_build.hip.h"
 
 using namespace tsgpu;
 
@@ -839,7 +840,20 @@ int tsgpu_vec_hnsw_export(tsgpu_ctx* ctx, uint32_t vec_field_id, int32_t info[4]
     if (!ctx || !info) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_export: NULL argument");
     std::lock_guard<std::mutex> lk(ctx->mu);
     VecField* f = get_field(ctx, vec_field_id);
-    if (!f || !f->hb) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_hnsw_export: no graph is being built for this field (tsgpu_vec_hnsw_enable)");
+    if (f && !f->hb && f->g_loaded) {                  // a graph that lives on the device only (tsgpu_vec_hnsw_build, tsgpu_vec_hnsw_load): read back
+        (void)hipSetDevice(ctx->device);
+        const uint32_t n = f->g_n, M = f->g_M;
+        std::vector<uint64_t> up((size_t)n + 1);
+        TSGPU_HIP_TRY(hipMemcpy(up.data(), f->g_upper_ptr.p, up.size() * 8, hipMemcpyDeviceToHost));
+        info[0] = (int32_t)n; info[1] = f->g_maxlevel; info[2] = (int32_t)f->g_enterpoint; info[3] = (int32_t)M;
+        if (n_upper) *n_upper = up[n];
+        if (levels) for (uint32_t i = 0; i < n; i++) levels[i] = (uint32_t)(up[i + 1] - up[i]);
+        if (link0 && n) TSGPU_HIP_TRY(hipMemcpy(link0, f->g_link0.p, (size_t)n * (1 + 2 * M) * 4, hipMemcpyDeviceToHost));
+        if (upper_ptr) std::copy(up.begin(), up.end(), upper_ptr);
+        if (upper_links && up[n]) TSGPU_HIP_TRY(hipMemcpy(upper_links, f->g_upper_links.p, (size_t)up[n] * (1 + M) * 4, hipMemcpyDeviceToHost));
+        return ok();
+    }
+    if (!f || !f->hb) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_hnsw_export: no graph for this field (tsgpu_vec_hnsw_enable / tsgpu_vec_hnsw_build / tsgpu_vec_hnsw_load)");
     const HnswBuilder& hb = *f->hb;
     info[0] = (int32_t)hb.size(); info[1] = hb.maxlevel; info[2] = (int32_t)hb.enterpoint; info[3] = (int32_t)hb.M;
     if (n_upper) *n_upper = hb.n_upper_lists();
@@ -847,6 +861,239 @@ int tsgpu_vec_hnsw_export(tsgpu_ctx* ctx, uint32_t vec_field_id, int32_t info[4]
     if (link0) std::copy(hb.link0.begin(), hb.link0.end(), link0);
     if (upper_ptr) { for (size_t i = 0; i < hb.size(); i++) upper_ptr[i] = hb.upper_at[i]; upper_ptr[hb.size()] = hb.n_upper_lists(); }
     if (upper_links) std::copy(hb.upper.begin(), hb.upper.end(), upper_links);
+    return ok();
+}
+
+// the traversal kernel over n_q queries (Q_dev, or the rows q_rows[] of the field itself): LDS tier by max(ef, k), visited bookkeeping, the re-runs when a
+// candidate heap or a visited set outgrows its tier. ctx->mu held; results stay on the device. labels = nullptr: internal ids come back.
+static int hnsw_search_launch(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, const uint32_t* q_rows, uint32_t n_q, uint32_t k, uint32_t ef, const uint8_t* mask, bool strict,
+                              const uint64_t* labels, float* d_dist, uint64_t* d_lab, uint32_t* d_cnt, int build_layer = -1) {
+    hipStream_t s = ctx->stream;
+    int rc;
+    const bool hash_mode = ctx->hnsw_visited_hash != 0;
+    uint32_t slots = f->g_slots;
+    if (!hash_mode) {
+        // tag mode: one uint16 per row and concurrent query (hnswlib's VisitedListPool); option hnsw_visited_max_gib caps the array
+        while (slots > 32 && (uint64_t)slots * std::max<uint32_t>(f->g_n, 1) * 2 > ((uint64_t)ctx->hnsw_visited_max_gib << 30)) slots >>= 1;
+        if (f->g_tag_slots != slots) {
+            if ((rc = f->g_visited.reserve((size_t)slots * std::max<uint32_t>(f->g_n, 1) * 2 + 64))) return rc;
+            TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, (size_t)slots * std::max<uint32_t>(f->g_n, 1) * 2 + 64, s));
+            f->g_tag_slots = slots; f->g_epoch = 1;
+        }
+    }
+    const uint32_t grid = std::min<uint32_t>(n_q, slots);
+    const uint32_t iters = (n_q + grid - 1) / grid;
+    const size_t tag_bytes = ((size_t)slots * f->g_n * 2 + 7) & ~(size_t)7;
+    VecHnswArgs a;
+    memset(&a, 0, sizeof a);
+    a.X = f->X.as<float>(); a.Q = Q_dev; a.q_rows = q_rows; a.base_level = build_layer > 0 ? (uint32_t)build_layer : 0u; a.dim = f->dim; a.n_rows = (uint32_t)f->n_rows; a.n_q = n_q;
+    a.link0 = f->g_link0.as<uint32_t>(); a.s0 = 1 + 2 * f->g_M;
+    a.upper_ptr = f->g_upper_ptr.as<uint64_t>(); a.upper_links = f->g_upper_links.as<uint32_t>(); a.su = 1 + f->g_M;
+    a.maxlevel = f->g_maxlevel; a.enterpoint = f->g_enterpoint;
+    a.row_ok = mask; a.strict = strict ? 1u : 0u;
+    a.k = k; a.ef = ef; a.ip_lanes = ctx->vec_ip_lanes; a.visited = hash_mode ? nullptr : f->g_visited.as<uint16_t>();
+    a.overflow_cnt = f->g_stat.as<uint32_t>();
+    a.labels = labels; a.dist_out = d_dist; a.label_out = d_lab; a.n_out = d_cnt;
+    // LDS tier by max(ef, k); a query whose candidate heap outgrows a small tier makes the batch run again on the largest
+    const uint32_t need = std::max(k, ef);
+    int tier = need <= 128 ? 0 : (need <= 512 ? 1 : 2);
+    uint32_t vs_boost = 1, grid_now = grid;
+    for (;;) {
+        if (hash_mode) {
+            // per-query visited sets: 64 x the tier's result-heap capacity (8 192 / 32 768 / 65 536 words), one per concurrent query; a traversal
+            // that outgrows the largest tier's set (large ef / k, strict filters: many visited, few admitted) runs again with sets 8x / 64x as
+            // large and fewer queries in flight (<= 8 GiB of sets) instead of being reported as overflowed
+            const uint32_t vs = (tier == 0 ? 8192u : (tier == 1 ? 32768u : 65536u)) * vs_boost;
+            grid_now = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, (8ull << 30) / ((uint64_t)vs * 4)));
+            if ((rc = f->g_vhash.reserve((size_t)grid_now * vs * 4))) return rc;
+            a.vhash = f->g_vhash.as<uint32_t>(); a.vhash_slots = vs;
+        } else if ((uint64_t)f->g_epoch + iters >= 0xFFF0ull) {      // tag space exhausted: clear the tags
+            TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, tag_bytes, s));
+            f->g_epoch = 1;
+        }
+        a.epoch_base = f->g_epoch;
+        f->g_epoch += iters;
+        TSGPU_HIP_TRY(hipMemsetAsync(a.overflow_cnt, 0, 56, s));
+        if (build_layer > 0) {                           // the bulk build's beam on an upper layer
+            if (tier == 0) hipLaunchKernelGGL((vec_hnsw_search_kernel<129, 1024, true>), dim3(grid_now), dim3(64), 0, s, a);
+            else if (tier == 1) hipLaunchKernelGGL((vec_hnsw_search_kernel<513, 2048, true>), dim3(grid_now), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((vec_hnsw_search_kernel<VEC_HNSW_MAX_EF + 1, VEC_HNSW_CAND_CAP, true>), dim3(grid_now), dim3(64), 0, s, a);
+        } else if (tier == 0) hipLaunchKernelGGL((vec_hnsw_search_kernel<129, 1024>), dim3(grid_now), dim3(64), 0, s, a);
+        else if (tier == 1) hipLaunchKernelGGL((vec_hnsw_search_kernel<513, 2048>), dim3(grid_now), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((vec_hnsw_search_kernel<VEC_HNSW_MAX_EF + 1, VEC_HNSW_CAND_CAP>), dim3(grid_now), dim3(64), 0, s, a);
+        uint32_t h_stat[14] = {0};
+        TSGPU_HIP_TRY(hipMemcpyAsync(h_stat, a.overflow_cnt, 56, hipMemcpyDeviceToHost, s));
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+#ifdef TSGPU_HNSW_PROF
+        fprintf(stderr, "HNSW_PROF ticks(100MHz)/query: pop+barrier %.0f  links+tags %.0f  distances %.0f  heaps %.0f\n", (double)(h_stat[6] | ((uint64_t)h_stat[7] << 32)) / n_q,
+                (double)(h_stat[8] | ((uint64_t)h_stat[9] << 32)) / n_q, (double)(h_stat[10] | ((uint64_t)h_stat[11] << 32)) / n_q, (double)(h_stat[12] | ((uint64_t)h_stat[13] << 32)) / n_q);
+#endif
+        ctx->hnsw_last_expansions = (uint64_t)h_stat[2] | ((uint64_t)h_stat[3] << 32);
+        ctx->hnsw_last_distances = (uint64_t)h_stat[4] | ((uint64_t)h_stat[5] << 32);
+        if (!h_stat[0]) break;
+        if (tier < 2) { tier = 2; continue; }
+        if (hash_mode && vs_boost < 64) { vs_boost *= 8; continue; }
+        break;                                   // (a candidate heap beyond the largest tier: those queries report n_out = 0xFFFFFFFF)
+    }
+    return TSGPU_OK;
+}
+
+// BULK construction on the device (csrc/vec_hnsw_build.hip.h holds the algorithm and the kernels). ctx->mu is held for the whole build.
+int tsgpu_vec_hnsw_build(tsgpu_ctx* ctx, uint32_t vec_field_id, uint32_t M, uint32_t ef_construction, uint32_t seed, uint32_t n_threads, uint32_t seed_min, uint32_t max_batch,
+                         tsgpu_hnsw_build_info* info) {
+    if (!ctx) return fail(TSGPU_ERR_INVALID, "ctx is NULL");
+    if (M < 2 || M > 31) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_hnsw_build: M must be 2..31 (a level-0 list of 2M ids is fetched by one wavefront)");
+    ef_construction = std::max(ef_construction, M);
+    if (ef_construction > VEC_HNSW_MAX_EF) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_vec_hnsw_build: ef_construction > 1024");
+    if (seed_min == 0) seed_min = 1024;
+    if (max_batch == 0) max_batch = 65536;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    VecField* f = get_field(ctx, vec_field_id);
+    if (!f) return fail(TSGPU_ERR_NOT_FOUND, "tsgpu_vec_hnsw_build: unknown vector field");
+    if (f->hb) return fail(TSGPU_ERR_INVALID, "tsgpu_vec_hnsw_build: this field inserts incrementally (tsgpu_vec_hnsw_enable)");
+    hipStream_t s = ctx->stream;
+    tsgpu_hnsw_build_info bi;
+    memset(&bi, 0, sizeof bi);
+    typedef std::chrono::steady_clock Clock;
+    auto secs = [](Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    try {
+        const uint32_t n = (uint32_t)f->n_rows, s0 = 1 + 2 * M, su = 1 + M, dim = f->dim;
+        f->g_loaded = false;
+        // 1. levels of ALL rows, drawn as hnswlib draws them (label order)
+        std::vector<int32_t> levels(n);
+        {
+            std::default_random_engine gen;
+            gen.seed(seed);
+            const double mult = 1.0 / std::log(1.0 * M);
+            for (uint32_t i = 0; i < n; i++) { std::uniform_real_distribution<double> u(0.0, 1.0); levels[i] = (int32_t)(-std::log(u(gen)) * mult); }
+        }
+        // 2. the seed set on the host: every row with an upper level, and the first seed_min rows
+        const auto t0 = Clock::now();
+        std::vector<uint32_t> seed_ids, rest_ids;
+        int32_t seed_top = 0;
+        for (uint32_t i = 0; i < n; i++) if (levels[i] >= 2 || i < seed_min) seed_top = std::max(seed_top, levels[i]);
+        const int32_t host_from = seed_top >= 1 ? 2 : 1;          // (no seed row with an upper level: the level-1 rows are inserted on the host, too)
+        std::vector<uint32_t> rest1_ids;                        // the level-1 rows among rest_ids (ascending like them)
+        for (uint32_t i = 0; i < n; i++) {
+            if (levels[i] >= host_from || i < seed_min) seed_ids.push_back(i);
+            else { rest_ids.push_back(i); if (levels[i] == 1) rest1_ids.push_back(i); }
+        }
+        const uint32_t n_seed = (uint32_t)seed_ids.size(), n_rest = (uint32_t)rest_ids.size();
+        std::vector<uint64_t> up((size_t)n + 1, 0);
+        for (uint32_t i = 0; i < n; i++) up[i + 1] = up[i] + (uint64_t)levels[i];
+        int rc;
+        DevBuf d_rest1, d_cd1, d_ci1, d_cn1;
+        DevBuf d_ids, d_tmp, d_rest, d_cd, d_ci, d_cn, d_req_s, d_req_d, d_cnt, d_fill, d_start, d_touched, d_counters, d_seg_c, d_seg_d;
+        struct Scratch { std::vector<DevBuf*> b; ~Scratch() { for (auto* x : b) x->release(); } } scratch;           // (declared after the buffers: released first)
+        scratch.b = {&d_rest1, &d_cd1, &d_ci1, &d_cn1, &d_ids, &d_tmp, &d_rest, &d_cd, &d_ci, &d_cn, &d_req_s, &d_req_d, &d_cnt, &d_fill, &d_start, &d_touched, &d_counters, &d_seg_c, &d_seg_d};
+        HnswBuilder hs;
+        hs.init(dim, M, ef_construction, seed, n_threads, (int)ctx->vec_ip_lanes);
+        if ((rc = f->g_link0.reserve((size_t)std::max<uint32_t>(n, 1) * s0 * 4))) return rc;
+        if ((rc = f->g_upper_ptr.reserve((size_t)(n + 1) * 8))) return rc;
+        if ((rc = f->g_upper_links.reserve((size_t)std::max<uint64_t>(up[n], 1) * su * 4))) return rc;
+        if ((rc = f->g_stat.reserve(64))) return rc;
+        TSGPU_HIP_TRY(hipMemsetAsync(f->g_link0.p, 0, (size_t)std::max<uint32_t>(n, 1) * s0 * 4, s));
+        if (n_seed) {
+            if ((rc = d_ids.reserve((size_t)n_seed * 4))) return rc;
+            if ((rc = d_tmp.reserve(std::max((size_t)n_seed * dim * 4, (size_t)n_seed * s0 * 4)))) return rc;
+            TSGPU_HIP_TRY(hipMemcpyAsync(d_ids.p, seed_ids.data(), (size_t)n_seed * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(vec_hnsw_build_gather_rows_kernel, dim3(4096), dim3(256), 0, s, f->X.as<float>(), d_ids.as<uint32_t>(), n_seed, dim, d_tmp.as<float>());
+            {
+                std::vector<float> rows((size_t)n_seed * dim);
+                std::vector<int32_t> lv(n_seed);
+                for (uint32_t i = 0; i < n_seed; i++) lv[i] = levels[seed_ids[i]];
+                TSGPU_HIP_TRY(hipMemcpyAsync(rows.data(), d_tmp.p, rows.size() * 4, hipMemcpyDeviceToHost, s));
+                TSGPU_HIP_TRY(hipStreamSynchronize(s));
+                hs.add_batch(rows.data(), n_seed, lv.data());
+            }
+            TSGPU_HIP_TRY(hipMemcpyAsync(d_tmp.p, hs.link0.data(), (size_t)n_seed * s0 * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(vec_hnsw_build_place_seed_kernel, dim3(4096), dim3(256), 0, s, d_tmp.as<uint32_t>(), d_ids.as<uint32_t>(), n_seed, s0, f->g_link0.as<uint32_t>());
+            // the upper lists of the seed rows move to their places in the pool of ALL rows' upper lists (the device rows' level-1 lists start empty);
+            // members map through seed_ids
+            std::vector<uint32_t> pool((size_t)up[n] * su, 0u);
+            for (uint32_t i = 0; i < n_seed; i++)
+                for (int32_t l = 0; l < levels[seed_ids[i]]; l++) {
+                    const uint32_t* src = hs.upper.data() + (hs.upper_at[i] + (uint64_t)l) * su;
+                    uint32_t* dst = pool.data() + (up[seed_ids[i]] + (uint64_t)l) * su;
+                    dst[0] = src[0];
+                    for (uint32_t j = 0; j < src[0]; j++) dst[1 + j] = seed_ids[src[1 + j]];
+                }
+            if (up[n]) TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_links.p, pool.data(), pool.size() * 4, hipMemcpyHostToDevice, s));
+            TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        } else if (up[n]) TSGPU_HIP_TRY(hipMemsetAsync(f->g_upper_links.p, 0, (size_t)up[n] * su * 4, s));
+        TSGPU_HIP_TRY(hipMemcpyAsync(f->g_upper_ptr.p, up.data(), up.size() * 8, hipMemcpyHostToDevice, s));
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));
+        f->g_M = M; f->g_n = n; f->g_slots = 4096; f->g_tag_slots = 0; f->g_epoch = 1;
+        f->g_maxlevel = n_seed ? hs.maxlevel : -1;
+        f->g_enterpoint = n_seed ? seed_ids[hs.enterpoint] : 0u;
+        const auto t1 = Clock::now();
+        bi.n = n; bi.n_seed = n_seed; bi.maxlevel = f->g_maxlevel; bi.enterpoint = f->g_enterpoint; bi.seed_seconds = secs(t0, t1);
+        // 3. the level-0 rows, in batches against the graph as it stood before the batch
+        if (n_rest) {
+            const uint32_t B = std::min(max_batch, n_rest), k = ef_construction, n_rest1 = (uint32_t)rest1_ids.size();
+            const size_t bm = (size_t)B * M;
+            if ((rc = d_rest1.reserve((size_t)std::max<uint32_t>(n_rest1, 1) * 4)) || (rc = d_cd1.reserve((size_t)B * k * 4)) || (rc = d_ci1.reserve((size_t)B * k * 8)) || (rc = d_cn1.reserve((size_t)B * 4))) return rc;
+            if (n_rest1) TSGPU_HIP_TRY(hipMemcpyAsync(d_rest1.p, rest1_ids.data(), (size_t)n_rest1 * 4, hipMemcpyHostToDevice, s));
+            if ((rc = d_rest.reserve((size_t)n_rest * 4)) || (rc = d_cd.reserve((size_t)B * k * 4)) || (rc = d_ci.reserve((size_t)B * k * 8)) || (rc = d_cn.reserve((size_t)B * 4)) ||
+                (rc = d_req_s.reserve(bm * 4)) || (rc = d_req_d.reserve(bm * 4)) || (rc = d_cnt.reserve((size_t)n * 4)) || (rc = d_fill.reserve((size_t)n * 4)) ||
+                (rc = d_start.reserve((size_t)n * 4)) || (rc = d_touched.reserve(bm * 4)) || (rc = d_counters.reserve(64)) || (rc = d_seg_c.reserve(bm * 4)) || (rc = d_seg_d.reserve(bm * 4)))
+                return rc;
+            TSGPU_HIP_TRY(hipMemcpyAsync(d_rest.p, rest_ids.data(), (size_t)n_rest * 4, hipMemcpyHostToDevice, s));
+            TSGPU_HIP_TRY(hipMemsetAsync(d_cnt.p, 0, (size_t)n * 4, s));
+            TSGPU_HIP_TRY(hipMemsetAsync(d_fill.p, 0, (size_t)n * 4, s));
+            TSGPU_HIP_TRY(hipMemsetAsync(d_counters.p, 0, 64, s));
+            HnswBuildArgs a;
+            memset(&a, 0, sizeof a);
+            a.X = f->X.as<float>(); a.dim = dim; a.ip_lanes = ctx->vec_ip_lanes; a.link0 = f->g_link0.as<uint32_t>(); a.s0 = s0; a.M = M; a.k = k;
+            a.upper_ptr = f->g_upper_ptr.as<uint64_t>(); a.upper_links = f->g_upper_links.as<uint32_t>(); a.su = su;
+            a.req_s = d_req_s.as<uint32_t>(); a.req_d = d_req_d.as<float>(); a.cnt = d_cnt.as<uint32_t>(); a.fill = d_fill.as<uint32_t>(); a.start = d_start.as<uint32_t>();
+            a.touched = d_touched.as<uint32_t>(); a.counters = d_counters.as<uint32_t>(); a.seg_c = d_seg_c.as<uint32_t>(); a.seg_d = d_seg_d.as<float>();
+            f->g_loaded = true;                          // (the traversal below reads the device graph)
+            uint32_t pos = 0, pos1 = 0, inserted = n_seed;
+            // one round = the rows' lists on `layer` from their beams, the reverse-link requests, and every asked node's answer
+            auto link_round = [&](uint32_t layer, const uint32_t* rows, uint32_t nb, DevBuf& ci, DevBuf& cd, DevBuf& cn) -> int {
+                a.layer = layer; a.rows = rows; a.n_batch = nb;
+                a.cand_id = ci.as<uint64_t>(); a.cand_d = cd.as<float>(); a.n_cand = cn.as<uint32_t>();
+                TSGPU_HIP_TRY(hipMemsetAsync(d_counters.p, 0, 8, s));
+                hipLaunchKernelGGL(vec_hnsw_build_select_kernel, dim3(std::min<uint32_t>(nb, 16384)), dim3(64), 0, s, a);
+                hipLaunchKernelGGL(vec_hnsw_build_offsets_kernel, dim3(std::min<uint32_t>((nb * M + 255) / 256, 1024)), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(vec_hnsw_build_scatter_kernel, dim3(std::min<uint32_t>((nb * M + 255) / 256, 2048)), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(vec_hnsw_build_backlink_kernel, dim3(std::min<uint32_t>(nb * M, 16384)), dim3(64), 0, s, a);
+                return TSGPU_OK;
+            };
+            while (pos < n_rest) {
+                const uint32_t b = std::min(std::min(max_batch, std::max(64u, inserted / 16)), n_rest - pos);
+                uint32_t b1 = 0;                         // the batch's rows with level 1: a run of rest1_ids
+                while (pos1 + b1 < n_rest1 && rest1_ids[pos1 + b1] <= rest_ids[pos + b - 1]) b1++;
+                const auto ta = Clock::now();
+                // the beams first — layer 1 for the rows that have it, layer 0 for all —, on the graph as it stands; the links after both
+                if (b1 && (rc = hnsw_search_launch(ctx, f, nullptr, d_rest1.as<uint32_t>() + pos1, b1, k, k, nullptr, true, nullptr, d_cd1.as<float>(), d_ci1.as<uint64_t>(), d_cn1.as<uint32_t>(), 1))) {
+                    f->g_loaded = false;
+                    return rc;
+                }
+                if ((rc = hnsw_search_launch(ctx, f, nullptr, d_rest.as<uint32_t>() + pos, b, k, k, nullptr, true, nullptr, d_cd.as<float>(), d_ci.as<uint64_t>(), d_cn.as<uint32_t>()))) {
+                    f->g_loaded = false;
+                    return rc;
+                }
+                const auto tb = Clock::now();
+                if (b1 && (rc = link_round(1, d_rest1.as<uint32_t>() + pos1, b1, d_ci1, d_cd1, d_cn1))) return rc;
+                if ((rc = link_round(0, d_rest.as<uint32_t>() + pos, b, d_ci, d_cd, d_cn))) return rc;
+                TSGPU_HIP_TRY(hipStreamSynchronize(s));
+                const auto tc = Clock::now();
+                bi.search_seconds += secs(ta, tb); bi.link_seconds += secs(tb, tc);
+                pos += b; pos1 += b1; inserted += b; bi.n_batches++;
+            }
+            uint32_t h_counters[4] = {0, 0, 0, 0};
+            TSGPU_HIP_TRY(hipMemcpy(h_counters, d_counters.p, 16, hipMemcpyDeviceToHost));
+            bi.unlinked = h_counters[2];
+            TSGPU_HIP_TRY(hipGetLastError());
+        }
+        f->g_loaded = true;
+        bi.device_seconds = secs(t1, Clock::now());
+    } catch (const std::bad_alloc&) { f->g_loaded = false; return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_hnsw_build: host allocation failed"); }
+      catch (const std::system_error&) { f->g_loaded = false; return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_vec_hnsw_build: could not start an insertion thread"); }
+    if (info) *info = bi;
     return ok();
 }
 
@@ -892,68 +1139,8 @@ int tsgpu_vec_hnsw_search_batch(tsgpu_ctx* ctx, uint32_t vec_field_id, const flo
         if (f->n_rows == 0) {
             TSGPU_HIP_TRY(hipMemsetAsync(d_cnt, 0, (size_t)n_q * 4, s));
         } else {
-            const bool hash_mode = ctx->hnsw_visited_hash != 0;
-            uint32_t slots = f->g_slots;
-            if (!hash_mode) {
-                // tag mode: one uint16 per row and concurrent query (hnswlib's VisitedListPool); option hnsw_visited_max_gib caps the array
-                while (slots > 32 && (uint64_t)slots * std::max<uint32_t>(f->g_n, 1) * 2 > ((uint64_t)ctx->hnsw_visited_max_gib << 30)) slots >>= 1;
-                if (f->g_tag_slots != slots) {
-                    if ((rc = f->g_visited.reserve((size_t)slots * std::max<uint32_t>(f->g_n, 1) * 2 + 64))) return rc;
-                    TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, (size_t)slots * std::max<uint32_t>(f->g_n, 1) * 2 + 64, s));
-                    f->g_tag_slots = slots; f->g_epoch = 1;
-                }
-            }
-            const uint32_t grid = std::min<uint32_t>(n_q, slots);
-            const uint32_t iters = (n_q + grid - 1) / grid;
-            const size_t tag_bytes = ((size_t)slots * f->g_n * 2 + 7) & ~(size_t)7;
-            VecHnswArgs a;
-            memset(&a, 0, sizeof a);
-            a.X = f->X.as<float>(); a.Q = Q_dev; a.dim = f->dim; a.n_rows = (uint32_t)f->n_rows; a.n_q = n_q;
-            a.link0 = f->g_link0.as<uint32_t>(); a.s0 = 1 + 2 * f->g_M;
-            a.upper_ptr = f->g_upper_ptr.as<uint64_t>(); a.upper_links = f->g_upper_links.as<uint32_t>(); a.su = 1 + f->g_M;
-            a.maxlevel = f->g_maxlevel; a.enterpoint = f->g_enterpoint;
-            a.row_ok = mask; a.strict = (functor_present || f->any_deleted) ? 1u : 0u;
-            a.k = k; a.ef = ef; a.ip_lanes = ctx->vec_ip_lanes; a.visited = hash_mode ? nullptr : f->g_visited.as<uint16_t>();
-            a.overflow_cnt = f->g_stat.as<uint32_t>();
-            a.labels = f->labels.as<uint64_t>(); a.dist_out = d_dist; a.label_out = d_lab; a.n_out = d_cnt;
-            // LDS tier by max(ef, k); a query whose candidate heap outgrows a small tier makes the batch run again on the largest
-            const uint32_t need = std::max(k, ef);
-            int tier = need <= 128 ? 0 : (need <= 512 ? 1 : 2);
             TSGPU_HIP_TRY(hipEventRecord(ctx->ev[3], s));
-            uint32_t vs_boost = 1, grid_now = grid;
-            for (;;) {
-                if (hash_mode) {
-                    // per-query visited sets: 64 x the tier's result-heap capacity (8 192 / 32 768 / 65 536 words), one per concurrent query; a traversal
-                    // that outgrows the largest tier's set (large ef / k, strict filters: many visited, few admitted) runs again with sets 8x / 64x as
-                    // large and fewer queries in flight (<= 8 GiB of sets) instead of being reported as overflowed
-                    const uint32_t vs = (tier == 0 ? 8192u : (tier == 1 ? 32768u : 65536u)) * vs_boost;
-                    grid_now = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, (8ull << 30) / ((uint64_t)vs * 4)));
-                    if ((rc = f->g_vhash.reserve((size_t)grid_now * vs * 4))) return rc;
-                    a.vhash = f->g_vhash.as<uint32_t>(); a.vhash_slots = vs;
-                } else if ((uint64_t)f->g_epoch + iters >= 0xFFF0ull) {      // tag space exhausted: clear the tags
-                    TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, tag_bytes, s));
-                    f->g_epoch = 1;
-                }
-                a.epoch_base = f->g_epoch;
-                f->g_epoch += iters;
-                TSGPU_HIP_TRY(hipMemsetAsync(a.overflow_cnt, 0, 56, s));
-                if (tier == 0) hipLaunchKernelGGL((vec_hnsw_search_kernel<129, 1024>), dim3(grid_now), dim3(64), 0, s, a);
-                else if (tier == 1) hipLaunchKernelGGL((vec_hnsw_search_kernel<513, 2048>), dim3(grid_now), dim3(64), 0, s, a);
-                else hipLaunchKernelGGL((vec_hnsw_search_kernel<VEC_HNSW_MAX_EF + 1, VEC_HNSW_CAND_CAP>), dim3(grid_now), dim3(64), 0, s, a);
-                uint32_t h_stat[14] = {0};
-                TSGPU_HIP_TRY(hipMemcpyAsync(h_stat, a.overflow_cnt, 56, hipMemcpyDeviceToHost, s));
-                TSGPU_HIP_TRY(hipStreamSynchronize(s));
-#ifdef TSGPU_HNSW_PROF
-                fprintf(stderr, "HNSW_PROF ticks(100MHz)/query: pop+barrier %.0f  links+tags %.0f  distances %.0f  heaps %.0f\n", (double)(h_stat[6] | ((uint64_t)h_stat[7] << 32)) / n_q,
-                        (double)(h_stat[8] | ((uint64_t)h_stat[9] << 32)) / n_q, (double)(h_stat[10] | ((uint64_t)h_stat[11] << 32)) / n_q, (double)(h_stat[12] | ((uint64_t)h_stat[13] << 32)) / n_q);
-#endif
-                ctx->hnsw_last_expansions = (uint64_t)h_stat[2] | ((uint64_t)h_stat[3] << 32);
-                ctx->hnsw_last_distances = (uint64_t)h_stat[4] | ((uint64_t)h_stat[5] << 32);
-                if (!h_stat[0]) break;
-                if (tier < 2) { tier = 2; continue; }
-                if (hash_mode && vs_boost < 64) { vs_boost *= 8; continue; }
-                break;                                   // (a candidate heap beyond the largest tier: those queries report n_out = 0xFFFFFFFF)
-            }
+            if ((rc = hnsw_search_launch(ctx, f, Q_dev, nullptr, n_q, k, ef, mask, functor_present || f->any_deleted, f->labels.as<uint64_t>(), d_dist, d_lab, d_cnt))) return rc;
             TSGPU_HIP_TRY(hipEventRecord(ctx->ev[4], s));
             TSGPU_HIP_TRY(hipEventRecord(ctx->ev[5], s));
             TSGPU_HIP_TRY(hipGetLastError());

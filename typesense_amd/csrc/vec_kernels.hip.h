@@ -1262,6 +1262,8 @@ __global__ __launch_bounds__(VEC_THREADS) void vec_group_merge_kernel(const uint
 // sequential heap logic over them (std::priority_queue = libstdc++ push_heap / pop_heap, restated so that ties fall the same way).
 struct VecHnswArgs {
     const float* X; const float* Q; uint32_t dim, n_rows, n_q;
+    const uint32_t* q_rows;                             // nullable: query q is ROW q_rows[q] of X (the bulk build searches for the rows it inserts) instead of Q[q]
+    uint32_t base_level;                                // BUILD instantiations only: the beam runs on this layer's lists (the descent stops above it); the search proper is layer 0
     const uint32_t* link0; uint32_t s0;                 // [n][s0], s0 = 1 + 2M
     const uint64_t* upper_ptr; const uint32_t* upper_links; uint32_t su;      // su = 1 + M
     int32_t maxlevel; uint32_t enterpoint;
@@ -1276,7 +1278,7 @@ struct VecHnswArgs {
     // candidate-heap overflow (re-run on the largest tier, then exactly by the caller).
     uint32_t* vhash; uint32_t vhash_slots;
     uint32_t* overflow_cnt;                             // [0] queries whose candidate heap outgrew CANDCAP; [1..2] u64 expansions, [3..4] u64 distances (batch totals)
-    const uint64_t* labels;
+    const uint64_t* labels;                             // nullable: internal ids come back
     float* dist_out; uint64_t* label_out; uint32_t* n_out;   // [n_q][k]; n_out = 0xFFFFFFFF: candidate heap overflow (caller re-runs exactly)
 };
 #ifndef TSGPU_HNSW_ROWS
@@ -1337,8 +1339,9 @@ struct HnswHeap {          // max-heap on .d (CompareByFirst: a.first < b.first)
 
 // TOPCAP >= max(ef, k) + 1, CANDCAP = candidate heap capacity: LDS tiers chosen by the host from ef, so that a CU holds as many
 // concurrent queries as its wave slots allow at the usual ef (13 KB per query at ef <= 128 instead of 45 KB).
-template <uint32_t TOPCAP, uint32_t CANDCAP>
+template <uint32_t TOPCAP, uint32_t CANDCAP, bool BUILD = false>
 __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
+    const uint32_t base = BUILD ? a.base_level : 0u;
     __shared__ HnswEntry top_e[TOPCAP];
     __shared__ HnswEntry cand_e[CANDCAP];
     __shared__ __attribute__((aligned(16))) float qs_lds[VEC_HNSW_QDIM];
@@ -1371,7 +1374,7 @@ __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
             for (uint32_t i = lane; i < a.vhash_slots; i += 64) vset[i] = 0u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // the clears are in L2 before the first CAS (atomics execute there)
         }
-        const float* qs = a.Q + (size_t)q * a.dim;
+        const float* qs = a.q_rows ? a.X + (size_t)a.q_rows[q] * a.dim : a.Q + (size_t)q * a.dim;
         __syncthreads();
         if (a.dim <= VEC_HNSW_QDIM) {
             for (uint32_t i = lane; i < a.dim; i += 64) qs_lds[i] = qs[i];
@@ -1404,7 +1407,7 @@ __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
         uint32_t cur = a.enterpoint;
         float curdist = nb_d[0];
         __syncthreads();
-        for (int level = a.maxlevel; level > 0; level--) {
+        for (int level = a.maxlevel; level > (int)base; level--) {
             bool changed = true;
             while (changed) {
                 changed = false;
@@ -1454,12 +1457,13 @@ __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
             if (s_state) break;
             HNSW_PROF(0)
             const uint32_t node = s_cur;
-            const uint32_t* __restrict__ lst = a.link0 + (size_t)node * a.s0;
+            const uint32_t* __restrict__ lst = (BUILD && base) ? a.upper_links + (a.upper_ptr[node] + (base - 1)) * a.su : a.link0 + (size_t)node * a.s0;
+            const uint32_t lw = (BUILD && base) ? a.su : a.s0;
             const uint32_t cnt = lst[0];
             uint32_t c = 0;
             bool fresh = false;
             // (count and ids requested together: a record has 1 + 2M words whatever its count; ids past the count are ignored)
-            const uint32_t cw = lst[lane < a.s0 - 1 ? 1 + lane : 0];
+            const uint32_t cw = lst[lane < lw - 1 ? 1 + lane : 0];
             // the set stays at most half full (n_dist counts every first visit but the entry point's; a list adds at most cnt): a query that
             // would outgrow it stops here and is reported like a candidate-heap overflow
             const bool room = !vset || n_dist + 1 + cnt <= a.vhash_slots / 2;
@@ -1515,7 +1519,7 @@ __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
                 while (top.n > a.k) top.pop();
                 uint32_t sz = top.n;
                 a.n_out[q] = sz;
-                while (top.n) { --sz; a.dist_out[(size_t)q * a.k + sz] = top.top_d(); a.label_out[(size_t)q * a.k + sz] = a.labels[top.top_id()]; top.pop(); }
+                while (top.n) { --sz; a.dist_out[(size_t)q * a.k + sz] = top.top_d(); a.label_out[(size_t)q * a.k + sz] = a.labels ? a.labels[top.top_id()] : (uint64_t)top.top_id(); top.pop(); }
             }
         }
         __syncthreads();

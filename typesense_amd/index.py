@@ -522,6 +522,12 @@ class GpuIndex:
         """build the field's HNSW graph inside the library (hnswlib's addPoint on every new label; include/index.h:365-367 defaults)"""
         self._ck(self.L.tsgpu_vec_hnsw_enable(self.h, field_id, M, ef_construction, seed, threads))
 
+    def vec_hnsw_build(self, field_id, M=16, ef_construction=200, seed=100, threads=1, seed_min=0, max_batch=0):
+        """tsgpu_vec_hnsw_build: the graph over the rows the field holds now, built in batches on the device -> dict of tsgpu_hnsw_build_info"""
+        bi = B.HnswBuildInfoC()
+        self._ck(self.L.tsgpu_vec_hnsw_build(self.h, field_id, M, ef_construction, seed, threads, seed_min, max_batch, C.byref(bi)))
+        return {n: getattr(bi, n) for n, _ in bi._fields_}
+
     def vec_hnsw_export(self, field_id):
         """-> dict(n, maxlevel, enterpoint, M, levels[n], link0[n, 1+2M], upper_ptr[n+1], upper_links[n_upper, 1+M]) (the oracle's hnsw_export keys)"""
         info = np.zeros(4, np.int32)
