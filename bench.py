@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="all", choices=["all", "keyword", "vector", "hybrid", "kwgeneral"],
+    ap.add_argument("--workload", default="all", choices=["all", "keyword", "vector", "hybrid", "kwgeneral", "hnsw"],
                     help="kwgeneral = only the two general-kernel keyword legs (two query_by fields; 10 candidate combinations per query) at the keyword config's size")
     ap.add_argument("--n-docs", type=int, default=10_000_000)
     ap.add_argument("--batch", type=int, default=0, help="keyword queries per step (default 10000)")
@@ -60,8 +60,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (concurrency, uncached-term batch, vector batch sweep / cosine / clustered)")
     ap.add_argument("--threads", type=int, default=256, help="host threads of the concurrency leg")
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--hnsw-rows", type=int, default=2_000_000, help="rows of the HNSW leg's collection (0 = skip the leg); the bulk build on the device runs at ~150 K rows/s "
-                                                                    "(10M x 768: 70 s, profiles/r06/bench_hnsw_10m.json), the insertion-order build (--hnsw-graph inserted) at ~8 K rows/s on 16 host threads")
+    ap.add_argument("--hnsw-rows", type=int, default=2_000_000, help="rows of the HNSW leg's collection (0 = skip the leg); the bulk build on the device runs at ~170 K rows/s "
+                                                                    "(10M x 768: 58 s, profiles/r06/bench_hnsw_10m.json), the insertion-order build (--hnsw-graph inserted) at ~8 K rows/s on 16 host threads")
     ap.add_argument("--hnsw-graph", default="bulk", choices=["bulk", "inserted", "knn"],
                     help="bulk (default) = tsgpu_vec_hnsw_build: the graph built in batches on the device (hnswlib's level draw, beam, neighbour heuristic and reverse-link "
                          "rule per batch; csrc/vec_hnsw_build.hip.h); inserted = hnswlib's incremental addPoint inside the library (tsgpu_vec_hnsw_enable, label order, one host thread per CPU of the quota); "
@@ -473,6 +473,32 @@ class Bench:
             el_all, _lat_all, _ = timed(step_host_all, max(args.steps // 2, 3), min(args.warmup, 2), world)
             self.host_all_arrays_ms = 1e3 * el_all / max(args.steps // 2, 3)
             el_host, lat_host, _ = timed(step_host, args.steps, args.warmup, world)
+            # the same host-delivered batches from TWO request threads (two lanes: one caller's copy-out runs under the other's kernels) — what a server
+            # with concurrent requests sees; reported NEXT TO the headline (`value_two_callers`), which stays the single blocking caller
+            try:
+                import threading
+                hh2 = self.T.Hits(n_q, K_TOPSTER)
+                hhs2 = hh2.c_struct(seam_arrays_only=True)
+                go = threading.Barrier(3)
+                def caller(h):
+                    go.wait()
+                    for _ in range(args.steps):
+                        g.keyword_search_batch_raw(arr, n_q, h)
+                th = [threading.Thread(target=caller, args=(h,)) for h in (hhs, hhs2)]
+                for x in th:
+                    x.start()
+                torch.cuda.synchronize()
+                go.wait()
+                t0 = time.perf_counter()
+                for x in th:
+                    x.join()
+                torch.cuda.synchronize()
+                self.two_callers = {"elapsed": time.perf_counter() - t0, "batches": 2 * args.steps,
+                                    "same_as_one_caller": bool(np.array_equal(hh.n_hits, hh2.n_hits) and all(
+                                        np.array_equal(hh.keys[i, :hh.n_hits[i]], hh2.keys[i, :hh.n_hits[i]]) and np.array_equal(hh.scores[i, :hh.n_hits[i]], hh2.scores[i, :hh.n_hits[i]])
+                                        for i in range(0, n_q, 7)))}
+            except Exception as e:      # noqa: BLE001
+                self.two_callers = {"error": repr(e)}
             elapsed_dev, lat_dev, out = timed(step, args.steps, min(args.warmup, 2), world, after)
             elapsed, lat = el_host, lat_host
         else:
@@ -519,7 +545,7 @@ class Bench:
                 g.set_option("kw_device_plan_min_queries", 512)      # (the default, csrc/tsgpu_host.h)
         res = dict(elapsed=elapsed, lat=lat, touched=touched, kern_ms=float(np.mean(kern_ms)), merge_ms=float(np.mean(merge_ms)), find_ms=float(np.mean(find_ms)),
                    alg_bytes=float(np.mean(alg_bytes)), n_q=n_q, n_postings=int(self.csr["n_postings"]), elapsed_dev=elapsed_dev, lat_dev=lat_dev,
-                   host_all_arrays_ms=getattr(self, "host_all_arrays_ms", None))
+                   host_all_arrays_ms=getattr(self, "host_all_arrays_ms", None), two_callers=getattr(self, "two_callers", None))
         if self.group is not None:
             # the bound-pruned exchange against the full top-k exchange (untimed): same merged result, fewer bytes
             gt = self.group.timings()
@@ -1406,11 +1432,25 @@ class Bench:
     def run_hnsw(self):
         """searchKnnCloserFirst on a resident graph: q/s by batch and ef, recall@k against the exact scan, the traversal checked bit for bit
         against the oracle's restatement walking the SAME graph, and that restatement timed on the host cores as cpu_baseline (port).
-        The graph is derived on the GPU from exact k-NN lists + the neighbour-selection heuristic (typesense_amd/hnsw_synth.py) — hnswlib's
-        sequential build of 1M x 768 does not fit a bench run; the collection has a 32-dimensional latent structure (i.i.d. N(0,1) rows
-        are equidistant in 768 dimensions: no graph index has recall there, measured 0.007)."""
+        The graph is built in batches on the device (tsgpu_vec_hnsw_build; --hnsw-graph inserted: hnswlib's row-by-row insertion inside the
+        library, knn: the round-2 stand-in); the collection has a 32-dimensional latent structure (i.i.d. N(0,1) rows are equidistant in 768
+        dimensions: no graph index has recall there, measured 0.007)."""
         from typesense_amd import _lib as B, synth, hnsw_synth
-        torch, args, g = self.torch, self.args, self.g
+        torch, args = self.torch, self.args
+        # a context of its own, closed when the leg ends: its rows, bf16 mirror, graph and visited sets go back to the device (the three 10M x 768 fields of
+        # the vector legs stay resident in self.g; with a 2M-row HNSW collection next to them the general-kernel leg ran out of HBM)
+        g = self.T.GpuIndex(torch.cuda.current_device())
+        for name, val in self.opts.items():
+            g.set_option(name, val)
+        try:
+            return self._run_hnsw(g)
+        finally:
+            g.close()
+            torch.cuda.empty_cache()
+
+    def _run_hnsw(self, g):
+        from typesense_amd import _lib as B, synth, hnsw_synth
+        torch, args = self.torch, self.args
         n, dim, k, M, field = args.hnsw_rows, args.dim, args.k, 16, 7
         t0 = time.time()
         X = synth.latent_vectors(n, dim, seed=3, device="cuda")
@@ -1737,7 +1777,7 @@ def compact_line(full, detail_path=None):
     cfg = full.get("config") or {}
     line["config"] = {"workload": _short(cfg.get("workload", ""), 260), "parallelism": _short(cfg.get("parallelism", ""), 200),
                       "results_to": _short(cfg.get("results_to", ""), 120)}
-    for k in ("p50_ms_per_batch", "queries_with_hits", "value_device_only", "ms_per_step_device_only", "speedup_vs_cpu_baseline"):
+    for k in ("p50_ms_per_batch", "queries_with_hits", "value_device_only", "ms_per_step_device_only", "value_two_callers", "speedup_vs_cpu_baseline"):
         if k in full:
             line[k] = _r(full[k])
     line["roofline"] = _roof_small(full.get("roofline"))
@@ -1858,6 +1898,12 @@ def main():
         t0 = time.time()
         out["keyword_general"] = bn.run_keyword_general()       # (last: it adds a second string field to the keyword index)
         build_s["general-kernel keyword legs (second field + runs + oracle)"] = time.time() - t0
+    if wl == "hnsw":                                # only the HNSW leg (tools/gpu_profile.sh runs it at BASELINE config 3's 10M rows)
+        t0 = time.time()
+        hn = bn.run_hnsw()
+        bn.close()
+        print(json.dumps({"metric": "HNSW leg at %d x %d rows" % (args.hnsw_rows, args.dim), "n_gpus": world, "data": "synthetic", "hnsw": hn, "leg_s": time.time() - t0}))
+        return
     bn.close()
     if wl == "kwgeneral":
         print(json.dumps({"metric": "queries/sec, general keyword kernels at %d docs" % args.n_docs, "n_gpus": world, "data": "synthetic", "general_kernels": out.get("keyword_general"),
@@ -1898,6 +1944,13 @@ def main():
         if r.get("host_all_arrays_ms"):
             kw["value_host_all_arrays"] = r["n_q"] / (r["host_all_arrays_ms"] * 1e-3)
             kw["ms_per_step_host_all_arrays"] = r["host_all_arrays_ms"]
+        tc = r.get("two_callers")
+        if tc and tc.get("elapsed"):
+            kw["value_two_callers"] = r["n_q"] * tc["batches"] / tc["elapsed"]
+            kw["two_callers"] = {"batches": tc["batches"], "ms_per_batch": 1e3 * tc["elapsed"] / tc["batches"], "same_as_one_caller": tc["same_as_one_caller"],
+                                 "what": "two request threads, each issuing the headline's blocking host-delivered batch call (both calls are cut into chained slices over the lanes): no gain over one caller, whose own slices already hide most of the copy-out"}
+        elif tc:
+            kw["two_callers"] = tc
         if r.get("elapsed_dev"):
             kw["value_device_only"] = mult * r["n_q"] * args.steps / r["elapsed_dev"]       # outputs left in HBM: the single-launch form the roofline / rocprof durations refer to
             kw["ms_per_step_device_only"] = 1e3 * r["elapsed_dev"] / args.steps
@@ -2053,7 +2106,7 @@ def main():
             "value": hd["value"], "unit": "queries/s", "n_gpus": world, "steps": hd["steps"], "warmup": args.warmup, "ms_per_step": hd["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32/i64" if head == "keyword" else "f32",
             "data": "synthetic", "config": hd["config"], "p50_ms_per_batch": hd["p50_ms_per_batch"]}
-    for k in ("queries_with_hits", "value_device_only", "ms_per_step_device_only", "value_host_all_arrays", "ms_per_step_host_all_arrays", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "exchange_check", "replicas", "replicas_strong", "candidate_combinations_sharded", "wildcard_sharded", "concurrency",
+    for k in ("queries_with_hits", "value_device_only", "ms_per_step_device_only", "value_two_callers", "two_callers", "value_host_all_arrays", "ms_per_step_host_all_arrays", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "exchange_check", "replicas", "replicas_strong", "candidate_combinations_sharded", "wildcard_sharded", "concurrency",
               "uncached", "general_kernels", "fused_hits_per_batch", "parity_fp32_scan", "batch_sweep", "variants", "hnsw", "rerank_hybrid_matches"):
         if k in hd:
             line[k] = hd[k]

@@ -49,7 +49,7 @@ def test_bulk_build_on_the_device_equals_the_oracles_batched_build_link_for_link
     assert _graphs_equal(mine, ref)
     # the search serves the device-resident graph and replays the oracle's traversal of the same graph
     Q = rng.standard_normal((6, dim)).astype(np.float32)
-    for k, ef in ((10, 10), (10, 60)):
+    for k, ef in ((10, 10), (10, 60), (10, 200)):                               # (ef 200: the 256-entry LDS tier)
         dist, lab, cnt = g.vec_hnsw_search_batch(1, Q, k, ef)
         for i in range(Q.shape[0]):
             d, l, _ = orc.hnsw_search(Q[i], k, ef, functor_present=True)

@@ -55,7 +55,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $P/smoke_$TAG.t
 ( time timeout 1200 python bench.py --steps 20 --warmup 5 --detail-out $P/bench_all_${TAG}_detail.json ) > $P/bench_all_$TAG.json 2> $O/bench_all.err; grep -v BENCH_DETAIL $O/bench_all.err | tail -4; wc -c $P/bench_all_$TAG.json $P/bench_all_${TAG}_detail.json
 # round 6: the HNSW leg at BASELINE config 3's size (10M x 768; the graph built on the device by tsgpu_vec_hnsw_build) + the kernel trace of a 2M-row bulk build
 if [ "${SKIP_HNSW10M:-0}" != "1" ]; then
-( time timeout 1500 python bench.py --workload vector --no-extras --no-cpu-baseline --hnsw-rows 10000000 --steps 3 --warmup 1 --detail-out $P/bench_hnsw_10m_detail.json ) > $P/bench_hnsw_10m.json 2> $O/bench_hnsw_10m.err; tail -3 $O/bench_hnsw_10m.err
+( time timeout 1500 python bench.py --workload hnsw --no-cpu-baseline --hnsw-rows 10000000 ) > $P/bench_hnsw_10m.json 2> $O/bench_hnsw_10m.err; tail -3 $O/bench_hnsw_10m.err
 ( cd /tmp; HNSW_SKIP_INSERTED=1 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_hnsw -- python $ROOT/tools/experiments/exp_r06_hnsw_bulk.py 2000000 > $O/trace_hnsw.log 2>&1 )
 python profiles/summarize_rocprof.py $O/trace_hnsw vec_hnsw > $P/rocprof_hnsw_build_${TAG}_stats.txt 2>&1
 fi

@@ -1195,7 +1195,7 @@ static int kw_dispatch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, uint32_t n
     if (!out->keys || !out->scores || !out->n_hits || !out->status) return fail(TSGPU_ERR_INVALID, "tsgpu_keyword_search_batch: missing output arrays");
     struct CallerCount { std::atomic<int>& c; explicit CallerCount(std::atomic<int>& x) : c(x) { c.fetch_add(1); } ~CallerCount() { c.fetch_sub(1); } } cc(ctx->kw_callers);
     const bool legacy_keep = ctx->keep_ids;
-    if (!wildcard && !legacy_keep && !ids_dev && !present_elsewhere && out->mem == TSGPU_MEM_HOST && n_queries <= ctx->batch_max_queries && ctx->kw_callers.load() > 1)
+    if (!wildcard && !legacy_keep && !ids_dev && !present_elsewhere && !tsgpu::tls_no_coalesce() && out->mem == TSGPU_MEM_HOST && n_queries <= ctx->batch_max_queries && ctx->kw_callers.load() > 1)
         return kw_coalesced(ctx, queries, n_queries, out, ids_out);
     if (!wildcard && !legacy_keep && !ids_out && !present_elsewhere && out->mem == TSGPU_MEM_HOST && ctx->kw_host_split_queries && ctx->n_lanes >= 2 &&
         (uint64_t)n_queries >= 4ull * ctx->kw_host_split_queries)

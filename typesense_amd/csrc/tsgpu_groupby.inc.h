@@ -237,6 +237,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
                 tsgpu_id_lists* raw = nullptr;
                 // a batch without wildcard queries: the ids go straight into this call's device buffer (no download + upload) unless a query's ids need the host's sort
                 if (!ctx->groupby) ctx->groupby = new GroupByScratch;
+                struct NoCoalesce { bool old; NoCoalesce() : old(tsgpu::tls_no_coalesce()) { tsgpu::tls_no_coalesce() = true; } ~NoCoalesce() { tsgpu::tls_no_coalesce() = old; } } nc;
                 const int rc = kw_dispatch(ctx, kq.data(), nk, &th, false, &raw, any_wild ? nullptr : &ctx->groupby->ids_dev, &ids_on_dev);
                 idl.reset(raw);
                 if (rc != TSGPU_OK) return rc;

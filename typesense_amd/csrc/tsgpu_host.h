@@ -29,6 +29,8 @@ namespace tsgpu {
 
 // Option<T>-style error plumbing (include/option.h of the reference): code + message, never throw.
 inline std::string& tls_error() { static thread_local std::string e; return e; }
+inline bool& tls_no_coalesce() { static thread_local bool b = false; return b; }     // this thread's keyword batches go to a lane directly, never into the combiner of the 1-query
+                                                                                      // callers (a grouped call's nested id pass holds ctx->mu: it must not park there)
 inline bool& tls_avoid_lane0() { static thread_local bool b = false; return b; }      // this thread's keyword batches keep off lane 0 (it shares the vector path's stream)
 inline int fail(int code, const std::string& msg) { tls_error() = msg; return code; }
 inline int ok() { return TSGPU_OK; }

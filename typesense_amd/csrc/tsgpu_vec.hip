@@ -896,14 +896,16 @@ static int hnsw_search_launch(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, c
     a.labels = labels; a.dist_out = d_dist; a.label_out = d_lab; a.n_out = d_cnt;
     // LDS tier by max(ef, k); a query whose candidate heap outgrows a small tier makes the batch run again on the largest
     const uint32_t need = std::max(k, ef);
-    int tier = need <= 128 ? 0 : (need <= 512 ? 1 : 2);
+    // (tiers: result heap 128 / 256 / 512 / 1024 entries, candidate heap 1024 / 1024 / 2048 / 4096: 13.6 / 14.6 / 25 / 45 KB of LDS per query = 11 / 10 / 6 / 3
+    //  queries in flight per CU. The 256 tier — round 6 — is the bulk build's: ef_construction 200 ran on the 512 tier's six queries per CU before)
+    int tier = need <= 128 ? 0 : (need <= 256 ? 1 : (need <= 512 ? 2 : 3));
     uint32_t vs_boost = 1, grid_now = grid;
     for (;;) {
         if (hash_mode) {
             // per-query visited sets: 64 x the tier's result-heap capacity (8 192 / 32 768 / 65 536 words), one per concurrent query; a traversal
             // that outgrows the largest tier's set (large ef / k, strict filters: many visited, few admitted) runs again with sets 8x / 64x as
             // large and fewer queries in flight (<= 8 GiB of sets) instead of being reported as overflowed
-            const uint32_t vs = (tier == 0 ? 8192u : (tier == 1 ? 32768u : 65536u)) * vs_boost;
+            const uint32_t vs = (tier == 0 ? 8192u : (tier == 1 ? 16384u : (tier == 2 ? 32768u : 65536u))) * vs_boost;
             grid_now = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, (8ull << 30) / ((uint64_t)vs * 4)));
             if ((rc = f->g_vhash.reserve((size_t)grid_now * vs * 4))) return rc;
             a.vhash = f->g_vhash.as<uint32_t>(); a.vhash_slots = vs;
@@ -916,10 +918,12 @@ static int hnsw_search_launch(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, c
         TSGPU_HIP_TRY(hipMemsetAsync(a.overflow_cnt, 0, 56, s));
         if (build_layer > 0) {                           // the bulk build's beam on an upper layer
             if (tier == 0) hipLaunchKernelGGL((vec_hnsw_search_kernel<129, 1024, true>), dim3(grid_now), dim3(64), 0, s, a);
-            else if (tier == 1) hipLaunchKernelGGL((vec_hnsw_search_kernel<513, 2048, true>), dim3(grid_now), dim3(64), 0, s, a);
+            else if (tier == 1) hipLaunchKernelGGL((vec_hnsw_search_kernel<257, 1024, true>), dim3(grid_now), dim3(64), 0, s, a);
+            else if (tier == 2) hipLaunchKernelGGL((vec_hnsw_search_kernel<513, 2048, true>), dim3(grid_now), dim3(64), 0, s, a);
             else hipLaunchKernelGGL((vec_hnsw_search_kernel<VEC_HNSW_MAX_EF + 1, VEC_HNSW_CAND_CAP, true>), dim3(grid_now), dim3(64), 0, s, a);
         } else if (tier == 0) hipLaunchKernelGGL((vec_hnsw_search_kernel<129, 1024>), dim3(grid_now), dim3(64), 0, s, a);
-        else if (tier == 1) hipLaunchKernelGGL((vec_hnsw_search_kernel<513, 2048>), dim3(grid_now), dim3(64), 0, s, a);
+        else if (tier == 1) hipLaunchKernelGGL((vec_hnsw_search_kernel<257, 1024>), dim3(grid_now), dim3(64), 0, s, a);
+        else if (tier == 2) hipLaunchKernelGGL((vec_hnsw_search_kernel<513, 2048>), dim3(grid_now), dim3(64), 0, s, a);
         else hipLaunchKernelGGL((vec_hnsw_search_kernel<VEC_HNSW_MAX_EF + 1, VEC_HNSW_CAND_CAP>), dim3(grid_now), dim3(64), 0, s, a);
         uint32_t h_stat[14] = {0};
         TSGPU_HIP_TRY(hipMemcpyAsync(h_stat, a.overflow_cnt, 56, hipMemcpyDeviceToHost, s));
@@ -931,7 +935,7 @@ static int hnsw_search_launch(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, c
         ctx->hnsw_last_expansions = (uint64_t)h_stat[2] | ((uint64_t)h_stat[3] << 32);
         ctx->hnsw_last_distances = (uint64_t)h_stat[4] | ((uint64_t)h_stat[5] << 32);
         if (!h_stat[0]) break;
-        if (tier < 2) { tier = 2; continue; }
+        if (tier < 3) { tier = 3; continue; }
         if (hash_mode && vs_boost < 64) { vs_boost *= 8; continue; }
         break;                                   // (a candidate heap beyond the largest tier: those queries report n_out = 0xFFFFFFFF)
     }
