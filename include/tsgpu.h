@@ -676,7 +676,8 @@ int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float
                               const uint32_t* allow_ids, uint32_t n_allow, const uint32_t* excluded_ids, uint32_t n_excluded,
                               float* dist_out, uint64_t* label_out, uint32_t* n_out, int mem_out);
 /* hybrid: merged keyword Topsters (capacity out->k_stride) + merged k nearest, then tsgpu_hybrid_fuse_batch. Host outputs; metric / dim
- * = the vector field's (TSGPU_METRIC_*, num_dim); rerank_hybrid_matches -> 501 */
+ * = the vector field's (TSGPU_METRIC_*, num_dim); rerank_hybrid_matches (compute_aux_scores): every shard scores the one-sided hits it owns, the answers are gathered,
+ * every rank re-fuses */
 int tsgpu_group_hybrid_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t vec_field_id, int metric, const tsgpu_hybrid_params* p,
                                     const float* Q, int mem_q, uint32_t dim, uint32_t n_queries, tsgpu_hits* out);
 typedef struct tsgpu_group_timings {

@@ -170,6 +170,19 @@ def main():
             m = int(fused.n_hits[i])
             check("hybrid %s q%d" % (cut_name, i), m == ref.keys.size and np.array_equal(fused.keys[i, :m], ref.keys) and np.array_equal(fused.scores[i, :m], ref.scores) and
                   np.array_equal(fused.vector_distance[i, :m].view(np.uint32), ref.vector_distance.view(np.uint32)))
+        # rerank_hybrid_matches over the ranks: the rank whose shard owns a one-sided hit supplies its missing score (gathered), every rank re-fuses
+        fused = grp.hybrid_search_batch(qs, 1, B.METRIC_IP, Q, k=k_vec, fetch_size=10, alpha=0.3, k_stride=K, rerank=True)
+        check("hybrid rerank status", (fused.status == 0).all())
+        for i, q in enumerate(qs):
+            kw = {}
+            if q.filter_ids is not None:
+                kw["filter_ids"] = q.filter_ids
+            if q.excluded_ids is not None:
+                kw["excluded_ids"] = q.excluded_ids
+            ref = orc.search_hybrid(orc.make_query(q.tokens, sort=OSORT, fetch_size=10, topster_size=K, **kw), Q[i], k=k_vec, alpha=0.3, rerank=True)
+            m = int(fused.n_hits[i])
+            check("hybrid rerank %s q%d" % (cut_name, i), m == ref.keys.size and np.array_equal(fused.keys[i, :m], ref.keys) and np.array_equal(fused.scores[i, :m], ref.scores) and
+                  np.array_equal(fused.text_match[i, :m], ref.text_match) and np.array_equal(fused.vector_distance[i, :m].view(np.uint32), ref.vector_distance.view(np.uint32)))
         if cut_name == "uneven":
             # agreement before the collectives: ONE rank hands a bad k -> every rank returns the error, nobody hangs in a collective
             try:

@@ -120,6 +120,23 @@ def check_group(orc, grp, rng, n_docs, dim):
         assert np.array_equal(fused.keys[i, :n], ref.keys) and np.array_equal(fused.scores[i, :n], ref.scores), i
         assert np.array_equal(fused.text_match[i, :n], ref.text_match), i
         assert np.array_equal(fused.vector_distance[i, :n].view(np.uint32), ref.vector_distance.view(np.uint32)), i
+    # rerank_hybrid_matches over the shards (Index::compute_aux_scores): the shard that owns a one-sided hit supplies its missing score, every rank re-fuses
+    fused = grp.hybrid_search_batch(hq, 1, B.METRIC_IP, Q, k=0, fetch_size=10, alpha=0.3, k_stride=250, rerank=True)
+    assert (fused.status == 0).all()
+    one_sided = 0
+    for i, q in enumerate(hq):
+        kw = {}
+        if q.filter_ids is not None:
+            kw["filter_ids"] = q.filter_ids
+        if q.excluded_ids is not None:
+            kw["excluded_ids"] = q.excluded_ids
+        ref = orc.search_hybrid(orc.make_query(q.tokens, sort=OSORT, fetch_size=10, **kw), Q[i], k=0, alpha=0.3, rerank=True)
+        n = int(fused.n_hits[i])
+        assert n == ref.keys.size, (i, n, ref.keys.size)
+        assert np.array_equal(fused.keys[i, :n], ref.keys) and np.array_equal(fused.scores[i, :n], ref.scores), ("rerank", i)
+        assert np.array_equal(fused.text_match[i, :n], ref.text_match), ("rerank", i)
+        assert np.array_equal(fused.vector_distance[i, :n].view(np.uint32), ref.vector_distance.view(np.uint32)), ("rerank", i)
+        one_sided += int((ref.text_match == 0).sum())
 
 
 def device_output_equals_host_output(grp, n_docs):

@@ -1095,12 +1095,13 @@ int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float
 
 // Hybrid search over the shards: the keyword Topsters (capacity = out->k_stride, with text_match) and the k nearest vectors are each
 // gathered and merged, THEN fused exactly as src/index.cpp:4036-4221 (tsgpu_hybrid_fuse_batch on member 0 / this rank): reciprocal
-// ranks are ranks in the GLOBAL lists. Host outputs, host or (see above) device queries; rerank_hybrid_matches is not sharded (501).
+// ranks are ranks in the GLOBAL lists. Host outputs, host or (see above) device queries; rerank_hybrid_matches: the shard that owns a hit supplies its missing score.
 int tsgpu_group_hybrid_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t vec_field_id, int metric, const tsgpu_hybrid_params* p,
                                     const float* Q, int mem_q, uint32_t dim, uint32_t n_queries, tsgpu_hits* out) {
     if (!g || !queries || !p || !Q || !out) return fail(TSGPU_ERR_INVALID, "tsgpu_group_hybrid_search_batch: NULL argument");
     if (out->mem != TSGPU_MEM_HOST) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_hybrid_search_batch: host outputs only");
-    if (p->rerank_hybrid_matches) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_hybrid_search_batch: rerank_hybrid_matches is not available on shards");
+    if (p->rerank_hybrid_matches && (!out->text_match || !out->vector_distance || !out->match_score_index))
+        return fail(TSGPU_ERR_INVALID, "tsgpu_group_hybrid_search_batch: rerank_hybrid_matches needs the text_match, vector_distance and match_score_index outputs");
     if (n_queries == 0) return tsgpu_group_keyword_search_batch(g, queries, 0, 1, out);      // (the agreement step of the keyword half: a rank with an empty batch still meets the others)
     const uint32_t k = p->k == 0 ? std::max<uint32_t>(p->fetch_size, 100) : p->k;                 // src/index.cpp:4060-4063
     try {
@@ -1127,7 +1128,57 @@ int tsgpu_group_hybrid_search_batch(tsgpu_group* g, const tsgpu_kw_query* querie
             if ((rc = tsgpu_group_vec_knn_batch(g, vec_field_id, Q + (size_t)q * dim, mem_q, 1, k, queries[q].n_filter ? queries[q].filter_ids : nullptr, queries[q].n_filter,
                                                 queries[q].n_excluded ? queries[q].excluded_ids : nullptr, queries[q].n_excluded, kd.data() + (size_t)q * k, kl.data() + (size_t)q * k, kc.data() + q, TSGPU_MEM_HOST))) return rc;
         }
-        return tsgpu_hybrid_fuse_batch(g->m[0].ctx, queries, p, metric, &kw, kd.data(), kl.data(), kc.data(), k, n_queries, out);
+        tsgpu_hybrid_params p0 = *p;
+        p0.rerank_hybrid_matches = 0;
+        if ((rc = tsgpu_hybrid_fuse_batch(g->m[0].ctx, queries, &p0, metric, &kw, kd.data(), kl.data(), kc.data(), k, n_queries, out)) || !p->rerank_hybrid_matches) return rc;
+        // rerank_hybrid_matches (Index::compute_aux_scores, src/index.cpp:8793-8923) over the shards: the fused lists are the same on every rank, so every rank
+        // derives the same items — hits found by one side only. The shard that OWNS a document knows the missing score: every member scores every item on its
+        // shard (text_match of a document it does not hold: 0; distance of a label it does not hold: NaN), the answers are gathered, the owner's is taken
+        // (max of the scores — they are not negative —, the one distance that is a number), and every rank re-fuses.
+        std::vector<uint32_t> item_q, item_id, pair_q;
+        std::vector<uint64_t> pair_label;
+        std::vector<size_t> item_slot, pair_slot;
+        hybrid_missing_items(n_queries, out, item_q, item_id, item_slot, pair_q, pair_label, pair_slot);
+        const size_t ni = item_q.size(), np_ = pair_q.size(), words = ni + (np_ + 1) / 2;      // one u64 per score, two distances per u64
+        std::lock_guard<std::mutex> lk(g->mu);
+        std::vector<std::vector<uint64_t>> mine(g->m.size(), std::vector<uint64_t>(std::max<size_t>(words, 1), 0));
+        rc = TSGPU_OK;
+        for (size_t i = 0; i < g->m.size() && !rc; i++) {
+            Member& mem = g->m[i];
+            (void)hipSetDevice(mem.ctx->device);
+            std::vector<int64_t> sc(ni);
+            std::vector<float> d(np_);
+            if (ni) rc = tsgpu_keyword_aux_scores(mem.ctx, queries, n_queries, item_q.data(), item_id.data(), (uint32_t)ni, sc.data());
+            if (!rc && np_) rc = hybrid_missing_distances(mem.ctx, vec_field_id, Q, mem_q, n_queries, pair_q.data(), pair_label.data(), (uint32_t)np_, d.data());
+            if (rc) break;
+            memcpy(mine[i].data(), sc.data(), ni * 8);
+            memcpy(mine[i].data() + ni, d.data(), np_ * 4);
+            if ((rc = mem.c_meta.reserve(std::max<size_t>(words, 1) * 8)) || (rc = mem.c_meta_all.reserve(std::max<size_t>(words, 1) * 8 * g->n))) break;
+        }
+        if ((rc = agree(g, rc, call_signature({9, n_queries, (uint64_t)ni, (uint64_t)np_})))) return rc;      // (a rank whose shard failed takes the others with it BEFORE the gather)
+        std::vector<uint64_t> all((size_t)g->n * std::max<size_t>(words, 1), 0);
+        if (g->local) { for (size_t i = 0; i < g->m.size(); i++) memcpy(all.data() + i * std::max<size_t>(words, 1), mine[i].data(), std::max<size_t>(words, 1) * 8); }
+        else if (words) {
+            Member& mem = g->m[0];
+            (void)hipSetDevice(mem.ctx->device);
+            TSGPU_HIP_TRY(hipMemcpyAsync(mem.c_meta.p, mine[0].data(), words * 8, hipMemcpyHostToDevice, mem.ctx->stream));
+            if ((rc = all_gather_everywhere(g, &Member::c_meta, &Member::c_meta_all, words * 8))) return rc;
+            TSGPU_HIP_TRY(hipMemcpyAsync(all.data(), mem.c_meta_all.p, (size_t)g->n * words * 8, hipMemcpyDeviceToHost, mem.ctx->stream));
+            TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+        }
+        const size_t stride = std::max<size_t>(words, 1);
+        for (size_t i = 0; i < ni; i++) {
+            int64_t best = 0;
+            for (uint32_t r = 0; r < g->n; r++) best = std::max(best, (int64_t)all[r * stride + i]);
+            out->text_match[item_slot[i]] = best;
+        }
+        for (size_t i = 0; i < np_; i++)
+            for (uint32_t r = 0; r < g->n; r++) {
+                const float d = ((const float*)(all.data() + r * stride + ni))[i];
+                if (d == d) { out->vector_distance[pair_slot[i]] = d; break; }       // (no shard holds a vector for the label: left as it is, like the single-GPU call)
+            }
+        hybrid_refuse(p, n_queries, out);
+        return ok();
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_hybrid_search_batch: host allocation failed"); }
 }
 

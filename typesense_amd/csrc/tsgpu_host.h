@@ -599,6 +599,11 @@ int group_merge_keyword(tsgpu_ctx* ctx, const uint64_t* gathered, uint64_t shard
 // (device arrays), the tagging of the keys before the exchange and the fix-up after the merge (kw_group_cand_*_kernel)
 int kw_candidates_batch_ex(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const uint32_t* group_begin, uint32_t n_groups, tsgpu_hits* out, uint32_t* query_index, uint64_t* found,
                            bool raw_pass, uint32_t* pass_mask_dev, const uint16_t* present_elsewhere = nullptr);
+// rerank_hybrid_matches in pieces (tsgpu_vec.hip), shared with the group call: the missing distances BY LABEL (NaN: not in this context), which hits miss what, the re-fusion
+int hybrid_missing_distances(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, int mem_q, uint32_t n_queries, const uint32_t* pair_q, const uint64_t* pair_label, uint32_t n, float* d_out);   // tsgpu_vec.hip
+void hybrid_missing_items(uint32_t n_queries, const tsgpu_hits* out, std::vector<uint32_t>& item_q, std::vector<uint32_t>& item_id, std::vector<size_t>& item_slot,
+                          std::vector<uint32_t>& pair_q, std::vector<uint64_t>& pair_label, std::vector<size_t>& pair_slot);
+void hybrid_refuse(const tsgpu_hybrid_params* p, uint32_t n_queries, tsgpu_hits* out);
 // Doc-range shards and the reference's "a token that matches no field is dropped" (get_field_token_its, src/index.cpp:5651-5655): whether a token EXISTS is a property of
 // the whole collection. kw_dictionary_fingerprint: order-free hash of the context's (field, term) pairs with postings; kw_terms_present: bit t of masks[i] = token t of
 // query i has a list in one of the query's fields HERE; kw_search_batch_masked: tsgpu_keyword_search_batch where bit t of present_elsewhere[i] says the token exists on

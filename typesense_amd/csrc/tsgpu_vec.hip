@@ -1475,56 +1475,60 @@ int tsgpu_hybrid_fuse_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const
 // (stable, on the keyword order), fused score = 1/keyword_rank * (1 - alpha) + 1/semantic_rank * alpha into scores[match_score_index],
 // and the Topster order again.
 extern "C" int tsgpu_keyword_aux_scores(tsgpu_ctx*, const tsgpu_kw_query*, uint32_t, const uint32_t*, const uint32_t*, uint32_t, int64_t*);
-static int hybrid_rerank(tsgpu_ctx* ctx, VecField* f, uint32_t /*vec_field_id*/, const tsgpu_kw_query* queries, const tsgpu_hybrid_params* p, const float* Q, int mem_q,
-                         uint32_t n_queries, tsgpu_hits* out) {
-    if (!out->text_match || !out->vector_distance || !out->match_score_index) return fail(TSGPU_ERR_INVALID, "rerank_hybrid_matches needs the text_match, vector_distance and match_score_index outputs");
+}  // extern "C"
+namespace tsgpu {
+// exact distances of (query, label) pairs BY LABEL (getDataByLabel + get_dist_func, cosine: the query normalised first), ONE launch for the batch;
+// d_out[i] = NaN when the label has no live row in THIS context (a shard that does not own the document; the reference's getDataByLabel throws)
+int hybrid_missing_distances(tsgpu_ctx* ctx, uint32_t vec_field_id, const float* Q, int mem_q, uint32_t n_queries, const uint32_t* pair_q, const uint64_t* pair_label, uint32_t n, float* d_out) {
+    if (n == 0) return TSGPU_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    VecField* f = get_field(ctx, vec_field_id);
+    if (!f) return fail(TSGPU_ERR_NOT_FOUND, "rerank_hybrid_matches: unknown vector field");
     const uint32_t dim = f->dim;
-    // 1) what is missing
-    std::vector<uint32_t> item_q, item_id, pair_q, pair_row;
-    std::vector<size_t> item_slot, pair_slot;
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        for (uint32_t q = 0; q < n_queries; q++) {
-            if (out->status[q] != TSGPU_OK) continue;
-            for (uint32_t i = 0; i < out->n_hits[q]; i++) {
-                const size_t s = (size_t)q * out->k_stride + i;
-                if (out->text_match[s] == 0) { item_q.push_back(q); item_id.push_back((uint32_t)out->keys[s]); item_slot.push_back(s); }      // found via vector distance only
-                else if (out->vector_distance[s] == -1.0f) {                                                                               // found via text match only
-                    uint32_t r;
-                    if (f->find_row(out->keys[s], r) && f->h_ok[r]) { pair_q.push_back(q); pair_row.push_back(r); pair_slot.push_back(s); }   // (else getDataByLabel throws: left as it is)
-                }
-            }
-        }
-        if (!pair_q.empty()) {
-            // exact distances by label (getDataByLabel + get_dist_func, cosine: the query normalised first), ONE launch for the batch
-            hipStream_t s = ctx->stream;
-            const uint32_t n = (uint32_t)pair_q.size();
-            int rc;
-            if ((rc = f->d_rows.reserve((size_t)n * 8))) return rc;
-            if ((rc = f->d_out1.reserve((size_t)n * 4))) return rc;
-            if ((rc = f->d_q1.reserve((size_t)n_queries * dim * 4))) return rc;
-            TSGPU_HIP_TRY(hipMemcpyAsync(f->d_rows.p, pair_row.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-            TSGPU_HIP_TRY(hipMemcpyAsync((char*)f->d_rows.p + (size_t)n * 4, pair_q.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-            TSGPU_HIP_TRY(hipMemcpyAsync(f->d_q1.p, Q, (size_t)n_queries * dim * 4, mem_q == TSGPU_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-            if (f->metric == TSGPU_METRIC_COSINE)
-                hipLaunchKernelGGL(vec_normalize_rows_kernel, dim3((n_queries + 3) / 4), dim3(256), 0, s, f->d_q1.as<float>(), n_queries, dim);
-            hipLaunchKernelGGL(vec_pair_distances_kernel, dim3((n + 15) / 16), dim3(256), 0, s, f->X.as<float>(), f->d_q1.as<float>(), dim,
-                               (const uint32_t*)((char*)f->d_rows.p + (size_t)n * 4), f->d_rows.as<uint32_t>(), n, f->d_out1.as<float>(), ctx->vec_ip_lanes);
-            std::vector<float> d(n);
-            TSGPU_HIP_TRY(hipMemcpyAsync(d.data(), f->d_out1.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-            TSGPU_HIP_TRY(hipStreamSynchronize(s));
-            for (uint32_t i = 0; i < n; i++) out->vector_distance[pair_slot[i]] = d[i];
+    std::vector<uint32_t> rows, qs, at;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t r;
+        d_out[i] = std::numeric_limits<float>::quiet_NaN();
+        if (f->find_row(pair_label[i], r) && f->h_ok[r]) { rows.push_back(r); qs.push_back(pair_q[i]); at.push_back(i); }
+    }
+    const uint32_t m = (uint32_t)rows.size();
+    if (m == 0) return TSGPU_OK;
+    hipStream_t s = ctx->stream;
+    int rc;
+    if ((rc = f->d_rows.reserve((size_t)m * 8))) return rc;
+    if ((rc = f->d_out1.reserve((size_t)m * 4))) return rc;
+    if ((rc = f->d_q1.reserve((size_t)n_queries * dim * 4))) return rc;
+    TSGPU_HIP_TRY(hipMemcpyAsync(f->d_rows.p, rows.data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
+    TSGPU_HIP_TRY(hipMemcpyAsync((char*)f->d_rows.p + (size_t)m * 4, qs.data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
+    TSGPU_HIP_TRY(hipMemcpyAsync(f->d_q1.p, Q, (size_t)n_queries * dim * 4, mem_q == TSGPU_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    if (f->metric == TSGPU_METRIC_COSINE)
+        hipLaunchKernelGGL(vec_normalize_rows_kernel, dim3((n_queries + 3) / 4), dim3(256), 0, s, f->d_q1.as<float>(), n_queries, dim);
+    hipLaunchKernelGGL(vec_pair_distances_kernel, dim3((m + 15) / 16), dim3(256), 0, s, f->X.as<float>(), f->d_q1.as<float>(), dim,
+                       (const uint32_t*)((char*)f->d_rows.p + (size_t)m * 4), f->d_rows.as<uint32_t>(), m, f->d_out1.as<float>(), ctx->vec_ip_lanes);
+    std::vector<float> d(m);
+    TSGPU_HIP_TRY(hipMemcpyAsync(d.data(), f->d_out1.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    TSGPU_HIP_TRY(hipStreamSynchronize(s));
+    for (uint32_t i = 0; i < m; i++) d_out[at[i]] = d[i];
+    return TSGPU_OK;
+}
+
+// which fused hits miss one side's score: item_* = found via vector distance only (text_match == 0), pair_* = via text match only (vector_distance == -1)
+void hybrid_missing_items(uint32_t n_queries, const tsgpu_hits* out, std::vector<uint32_t>& item_q, std::vector<uint32_t>& item_id, std::vector<size_t>& item_slot,
+                          std::vector<uint32_t>& pair_q, std::vector<uint64_t>& pair_label, std::vector<size_t>& pair_slot) {
+    for (uint32_t q = 0; q < n_queries; q++) {
+        if (out->status[q] != TSGPU_OK) continue;
+        for (uint32_t i = 0; i < out->n_hits[q]; i++) {
+            const size_t s = (size_t)q * out->k_stride + i;
+            if (out->text_match[s] == 0) { item_q.push_back(q); item_id.push_back((uint32_t)out->keys[s]); item_slot.push_back(s); }
+            else if (out->vector_distance[s] == -1.0f) { pair_q.push_back(q); pair_label.push_back(out->keys[s]); pair_slot.push_back(s); }
         }
     }
-    // 2) text_match of the vector-only hits; the reference walks them in ascending key order per query (iterators only move forward):
-    //    the score of a document does not depend on that order
-    if (!item_q.empty()) {
-        std::vector<int64_t> sc(item_q.size());
-        const int rc = tsgpu_keyword_aux_scores(ctx, queries, n_queries, item_q.data(), item_id.data(), (uint32_t)item_q.size(), sc.data());
-        if (rc) return rc;
-        for (size_t i = 0; i < sc.size(); i++) out->text_match[item_slot[i]] = sc[i];
-    }
-    // 3) re-rank and re-fuse, query by query
+}
+
+// compute_aux_scores' last step: keyword ranks by (text_match_score, key) descending, semantic ranks by distance (stable, on the keyword order), fused score =
+// 1/keyword_rank * (1 - alpha) + 1/semantic_rank * alpha into scores[match_score_index], and the Topster order again
+void hybrid_refuse(const tsgpu_hybrid_params* p, uint32_t n_queries, tsgpu_hits* out) {
     struct E { uint64_t key; int64_t sc[3]; int64_t tm; float vd; int8_t msi; uint32_t krank, srank; };
     std::vector<E> es;
     std::vector<uint32_t> order;
@@ -1561,6 +1565,34 @@ static int hybrid_rerank(tsgpu_ctx* ctx, VecField* f, uint32_t /*vec_field_id*/,
             out->text_match[s] = e.tm; out->vector_distance[s] = e.vd; out->match_score_index[s] = e.msi;
         }
     }
+}
+}  // namespace tsgpu
+extern "C" {
+
+static int hybrid_rerank(tsgpu_ctx* ctx, VecField* /*f*/, uint32_t vec_field_id, const tsgpu_kw_query* queries, const tsgpu_hybrid_params* p, const float* Q, int mem_q,
+                         uint32_t n_queries, tsgpu_hits* out) {
+    if (!out->text_match || !out->vector_distance || !out->match_score_index) return fail(TSGPU_ERR_INVALID, "rerank_hybrid_matches needs the text_match, vector_distance and match_score_index outputs");
+    // 1) what is missing
+    std::vector<uint32_t> item_q, item_id, pair_q;
+    std::vector<uint64_t> pair_label;
+    std::vector<size_t> item_slot, pair_slot;
+    tsgpu::hybrid_missing_items(n_queries, out, item_q, item_id, item_slot, pair_q, pair_label, pair_slot);
+    if (!pair_q.empty()) {
+        std::vector<float> d(pair_q.size());
+        const int rc = tsgpu::hybrid_missing_distances(ctx, vec_field_id, Q, mem_q, n_queries, pair_q.data(), pair_label.data(), (uint32_t)pair_q.size(), d.data());
+        if (rc) return rc;
+        for (size_t i = 0; i < d.size(); i++) if (d[i] == d[i]) out->vector_distance[pair_slot[i]] = d[i];      // (a label without a vector: getDataByLabel throws, the hit is left as it is)
+    }
+    // 2) text_match of the vector-only hits; the reference walks them in ascending key order per query (iterators only move forward):
+    //    the score of a document does not depend on that order
+    if (!item_q.empty()) {
+        std::vector<int64_t> sc(item_q.size());
+        const int rc = tsgpu_keyword_aux_scores(ctx, queries, n_queries, item_q.data(), item_id.data(), (uint32_t)item_q.size(), sc.data());
+        if (rc) return rc;
+        for (size_t i = 0; i < sc.size(); i++) out->text_match[item_slot[i]] = sc[i];
+    }
+    // 3) re-rank and re-fuse, query by query
+    tsgpu::hybrid_refuse(p, n_queries, out);
     return TSGPU_OK;
 }
 

@@ -744,10 +744,11 @@ class GpuGroup:
         B.check(self.L, self.L.tsgpu_group_vec_knn_batch(self.h, field_id, C.c_void_p(q_ptr), mem_q, n, k, None, 0, None, 0,
                                                          C.c_void_p(dist_ptr), C.c_void_p(lab_ptr), C.c_void_p(cnt_ptr), mem_out))
 
-    def hybrid_search_batch(self, queries, field_id, metric, Q, k=0, fetch_size=10, alpha=0.3, distance_threshold=B.FLT_MAX, k_stride=250, mem_q=B.MEM_HOST, q_ptr=None, dim=None):
+    def hybrid_search_batch(self, queries, field_id, metric, Q, k=0, fetch_size=10, alpha=0.3, distance_threshold=B.FLT_MAX, k_stride=250, mem_q=B.MEM_HOST, q_ptr=None, dim=None,
+                            rerank=False):
         arr = make_query_array(queries)
         p = B.HybridParamsC()
-        p.k, p.fetch_size, p.alpha, p.distance_threshold, p.rerank_hybrid_matches = k, fetch_size, alpha, distance_threshold, 0
+        p.k, p.fetch_size, p.alpha, p.distance_threshold, p.rerank_hybrid_matches = k, fetch_size, alpha, distance_threshold, int(bool(rerank))
         hits = Hits(len(arr), k_stride)
         hs = hits.c_struct()
         if q_ptr is None:
