@@ -680,6 +680,12 @@ int tsgpu_group_vec_knn_batch(tsgpu_group* g, uint32_t vec_field_id, const float
  * every rank re-fuses */
 int tsgpu_group_hybrid_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t vec_field_id, int metric, const tsgpu_hybrid_params* p,
                                     const float* Q, int mem_q, uint32_t dim, uint32_t n_queries, tsgpu_hits* out);
+/* facet counts (tsgpu_facet_count_batch's arguments and output; the hash-index branch of Index::do_facets, src/index.cpp:1659-1771) over doc-range shards: every
+ * member holds the facet mirror of ITS documents (tsgpu_facet_set with global seq_ids: the documents of other shards have no hashes), walks the matched ids of its
+ * doc range (the whole lists with sample_mod > 1, or when a member has no doc_range_lo / _hi), and the per-shard lists are gathered and merged: counts add up,
+ * doc_id / array_pos = the greatest document's. Exact for the first `cap` values; n_values is exact while no shard had more than cap, else a lower bound > cap. */
+int tsgpu_group_facet_count_batch(tsgpu_group* g, uint32_t facet_field_id, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
+                                  uint32_t sample_mod, const uint32_t* allowed_hashes, uint32_t n_allowed, tsgpu_facet_counts* out);
 typedef struct tsgpu_group_timings {
     float local_ms;                      /* host wall: every member's own batch + pack (members run concurrently) */
     float exchange_merge_ms;             /* host wall: the exchange, the merge and the delivery of the merged result */

@@ -36,6 +36,8 @@ def load_shard(g, orc, lo, hi, pts, n_docs, X, dim):
     g.set_num_docs(n_docs)
     g.commit()
     g.set_option("doc_range_lo", lo); g.set_option("doc_range_hi", hi)          # the seq_ids this shard owns (q = * ranks only those)
+    fptr, fhash = H.facet_csr_of(n_docs)
+    g.facet_set(5, *H.facet_csr_shard(fptr, fhash, lo, hi))
     g.vec_create(1, dim, B.METRIC_IP)
     if hi > lo:
         g.vec_upsert(1, np.arange(lo, hi, dtype=np.uint64), X[lo:hi])
@@ -58,6 +60,7 @@ def main():
     orc.set_sort_dense(0, pts)
     orc.vec_init(dim, O.METRIC_IP)
     orc.vec_add(np.arange(n_docs, dtype=np.uint32), X)
+    orc.facet_set(5, *H.facet_csr_of(n_docs))
     sort = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
     OSORT = ((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1))
     toks = ([1, 2], [3, 1, 2], [5], [4, 9], [79, 80])                # 5 queries: not a multiple of the world size (padded slices); the last one: the two rarest
@@ -141,6 +144,15 @@ def main():
             grp.set_option("test_fail_prune_pack_rank", 0)
             grp.set_option("kw_exchange_pruned", 1)
             check_keyword("after the injected failure " + cut_name, grp.keyword_search_batch(qs, K, k_stride=K))
+        # facet counts over the ranks (tsgpu_group_facet_count_batch): two gathers (counts, entries), merged on every rank
+        id_lists = [np.arange(n_docs, dtype=np.uint32), np.arange(1, n_docs, 3, dtype=np.uint32), np.array([], np.uint32)]
+        for cap, sample_mod in ((512, 1), (5, 1), (512, 4)):
+            got = grp.facet_count_batch(5, id_lists, cap=cap, sample_mod=sample_mod)
+            for i, ids in enumerate(id_lists):
+                rh, rc_, rd, rp, rn = orc.facet_count(5, ids, sample_mod=sample_mod, cap=cap)
+                h, c, d, p, n = got[i]
+                check("facets %s cap %d mod %d q%d" % (cut_name, cap, sample_mod, i), np.array_equal(h, rh) and np.array_equal(c, rc_) and np.array_equal(d, rd) and np.array_equal(p, rp) and
+                      ((n == rn) if rn <= cap else (n > cap)))
         # wildcard over the shards (tsgpu_group_wildcard_search_batch): every rank ranks the ids of its range
         fl = np.arange(2, n_docs, 7, dtype=np.uint32)
         wq = [T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=K),

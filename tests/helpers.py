@@ -272,3 +272,26 @@ def oracle_add_rows(orc, n_docs, dim, have, need, **slab_kw):
             x = vector_slab(n_docs, dim, s0, min(n_docs, s0 + VEC_SLAB), **slab_kw)[torch.from_numpy(sel - s0).cuda()].cpu().numpy()
             orc.vec_add(sel.astype(np.uint32), x)
     return need
+
+
+def facet_csr_of(n_docs, seed=77, n_values=40, max_per_doc=3):
+    """a facet field's hash index as CSR by seq_id (doc_ptr [n_docs + 1], hashes): 0..max_per_doc values per document out of n_values (duplicates inside a
+    document occur: counted once per document by the walk), deterministic in (n_docs, seed)"""
+    rng = np.random.default_rng(seed)
+    per = rng.integers(0, max_per_doc + 1, size=n_docs)
+    ptr = np.zeros(n_docs + 1, np.uint64)
+    ptr[1:] = np.cumsum(per)
+    hashes = (rng.integers(0, n_values, size=int(ptr[-1])).astype(np.uint32) * np.uint32(2654435761) >> np.uint32(7)).astype(np.uint32)
+    return ptr, hashes
+
+
+def facet_csr_shard(ptr, hashes, lo, hi):
+    """the same index as a shard holds it: the documents outside [lo, hi) have no hashes (global seq_ids kept)"""
+    n_docs = ptr.size - 1
+    per = np.diff(ptr).astype(np.int64)
+    keep = np.zeros(n_docs, bool)
+    keep[lo:hi] = True
+    per2 = np.where(keep, per, 0)
+    ptr2 = np.zeros(n_docs + 1, np.uint64)
+    ptr2[1:] = np.cumsum(per2)
+    return ptr2, hashes[int(ptr[lo]):int(ptr[hi])].copy()

@@ -27,10 +27,13 @@ def build_group(lib, cuts, n_docs, dim, transport, seed=8):
     orc.set_sort_dense(0, pts)
     orc.vec_init(dim, O.METRIC_IP)
     orc.vec_add(np.arange(n_docs, dtype=np.uint32), X)
+    fptr, fhash = H.facet_csr_of(n_docs)
+    orc.facet_set(5, fptr, fhash)
     members = []
     for lo, hi in zip(cuts[:-1], cuts[1:]):
         g = T.GpuIndex(0, lib)
         H.load_shard(g, orc, lo, hi, n_docs, pts)
+        g.facet_set(5, *H.facet_csr_shard(fptr, fhash, lo, hi))                      # the facet hash index of the shard's own documents
         g.set_option("doc_range_lo", lo); g.set_option("doc_range_hi", hi)          # the seq_ids this shard OWNS (q = * ranks only those)
         g.vec_create(1, dim, B.METRIC_IP)
         if hi > lo:
@@ -90,6 +93,17 @@ def check_group(orc, grp, rng, n_docs, dim):
     assert (wh.status == 0).all()
     for i, q in enumerate(wq):
         H.assert_hits_equal(wh, i, H.oracle_wildcard(orc, q), "group wildcard")
+    # ---- facet counts over the shards (do_facets' hash-index branch): counts add up, doc_id / array_pos of the greatest document; a small cap (truncated lists
+    #      merge exactly for the first cap values), a facet query's allowed hashes, estimate_facets' sampling of the WHOLE list ----
+    id_lists = [np.arange(n_docs, dtype=np.uint32), filt, filt[::5], np.array([], np.uint32), np.array([3, n_docs - 1], np.uint32)]
+    allowed = np.unique(orc.facet_count(5, np.arange(n_docs, dtype=np.uint32))[0])[::2]
+    for cap, sample_mod, allow in ((1024, 1, None), (7, 1, None), (1024, 3, None), (1024, 1, allowed)):
+        got = grp.facet_count_batch(5, id_lists, cap=cap, sample_mod=sample_mod, allowed_hashes=allow)
+        for i, ids in enumerate(id_lists):
+            rh, rc_, rd, rp, rn = orc.facet_count(5, ids, sample_mod=sample_mod, allowed_hashes=allow, cap=cap)
+            h, c, d, p, n = got[i]
+            assert np.array_equal(h, rh) and np.array_equal(c, rc_) and np.array_equal(d, rd) and np.array_equal(p, rp), ("facets", cap, sample_mod, i)
+            assert (n == rn) if rn <= cap else (n > cap), ("facet n_values", cap, sample_mod, i, n, rn)
     # ---- k-NN: closest first, ties -> smaller label; allow list ----
     Q = rng.standard_normal((5, dim)).astype(np.float32)
     for k in (7, 30):

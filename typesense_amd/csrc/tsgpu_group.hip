@@ -887,6 +887,128 @@ int tsgpu_group_wildcard_search_batch(tsgpu_group* g, const tsgpu_kw_query* quer
     return group_keyword_core(g, queries, n_queries, k, out, [&](Member& mem, tsgpu_hits* loc, const uint16_t*) { return tsgpu_wildcard_search_batch(mem.ctx, queries, n_queries, loc); }, 7, nullptr, 0);
 }
 
+// Facet counts (the hash-index branch of Index::do_facets, /root/reference/src/index.cpp:1659-1771; single GPU: tsgpu_facet_count_batch) over doc-range shards:
+// every member walks the matched ids through ITS facet mirror (a document it does not hold has no hashes there: it contributes nothing), the per-shard
+// (hash, count, doc_id, array_pos) lists — ascending hashes — are gathered and merged per query: counts add up, doc_id / array_pos are those of the greatest
+// document that carried the value (the walk's "last one wins", the ids ascend). A hash among the first `cap` of the union is among the first `cap` of every shard
+// that has it, so the truncated lists merge exactly; n_values is exact while no shard's list was truncated, else a lower bound (still > cap: "truncated").
+// sample_mod > 1 (estimate_facets: the ids at positions i % sample_mod == 0 of the WHOLE list) is a property of the global list: every member gets the whole list.
+int tsgpu_group_facet_count_batch(tsgpu_group* g, uint32_t facet_field_id, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
+                                  uint32_t sample_mod, const uint32_t* allowed_hashes, uint32_t n_allowed, tsgpu_facet_counts* out) {
+    if (!g || !out || (n_queries && (!result_ids || !n_result_ids))) return fail(TSGPU_ERR_INVALID, "tsgpu_group_facet_count_batch: NULL argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (n_queries == 0) return agree(g, TSGPU_OK, call_signature({10, 0}));
+    int pre = TSGPU_OK;
+    if (!out->cap || !out->hash || !out->count || !out->doc_id || !out->array_pos || !out->n_values) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_facet_count_batch: missing output arrays");
+    if (pre) return agree(g, pre, 0);
+    try {
+        const uint32_t cap = out->cap;
+        const size_t nm = g->m.size();
+        struct Loc { std::vector<uint32_t> h, c, d, p, nv; };
+        std::vector<Loc> loc(nm);
+        int rc = for_members(g, [&](size_t i) -> int {
+            Member& mem = g->m[i];
+            (void)hipSetDevice(mem.ctx->device);
+            Loc& L = loc[i];
+            L.h.resize((size_t)n_queries * cap); L.c.resize(L.h.size()); L.d.resize(L.h.size()); L.p.resize(L.h.size()); L.nv.assign(n_queries, 0);
+            tsgpu_facet_counts fc;
+            fc.cap = cap; fc.hash = L.h.data(); fc.count = L.c.data(); fc.doc_id = L.d.data(); fc.array_pos = L.p.data(); fc.n_values = L.nv.data();
+            // the slice of every id list inside the member's doc range (they ascend) — unless positions in the whole list matter (sample_mod) or the range is unknown
+            std::vector<const uint32_t*> ptr(n_queries);
+            std::vector<uint64_t> cnt(n_queries);
+            const bool slice = sample_mod <= 1 && mem.ctx->doc_range_set && !g->replicas;
+            for (uint32_t q = 0; q < n_queries; q++) {
+                const uint32_t* b = result_ids[q];
+                const uint32_t* e = b + n_result_ids[q];
+                if (slice && b) { b = std::lower_bound(b, e, mem.ctx->doc_range_lo); e = std::lower_bound(b, e, mem.ctx->doc_range_hi); }
+                ptr[q] = b; cnt[q] = (uint64_t)(e - b);
+            }
+            if (!g->local) {                                     // (the first gather's buffers: a failure here is still covered by the agreement step)
+                const size_t b1 = ((size_t)n_queries * 4 + 7) & ~(size_t)7;
+                int r;
+                if ((r = mem.c_meta.reserve(b1)) || (r = mem.c_meta_all.reserve(b1 * g->n))) return r;
+            }
+            if (g->replicas && i > 0) return TSGPU_OK;           // every member mirrors everything: member 0 answers, the others contribute nothing
+            return tsgpu_facet_count_batch(mem.ctx, facet_field_id, ptr.data(), cnt.data(), n_queries, sample_mod, allowed_hashes, n_allowed, &fc);
+        });
+        if ((rc = agree(g, rc, call_signature({10, n_queries, cap, sample_mod, n_allowed})))) return rc;
+        // the lists of every shard, per query: [n][n_queries] counts, then [n][n_queries][stride] entries of 4 words
+        std::vector<uint32_t> nv_all((size_t)g->n * n_queries, 0), ent_all;
+        size_t stride = 0;
+        auto used = [&](uint32_t v) { return std::min<uint32_t>(v, cap); };
+        if (g->local) {
+            for (size_t i = 0; i < nm; i++) for (uint32_t q = 0; q < n_queries; q++) { nv_all[i * n_queries + q] = loc[i].nv[q]; stride = std::max<size_t>(stride, used(loc[i].nv[q])); }
+        } else {
+            Member& mem = g->m[0];
+            (void)hipSetDevice(mem.ctx->device);
+            const size_t b1 = ((size_t)n_queries * 4 + 7) & ~(size_t)7;
+            TSGPU_HIP_TRY(hipMemcpyAsync(mem.c_meta.p, loc[0].nv.data(), (size_t)n_queries * 4, hipMemcpyHostToDevice, mem.ctx->stream));
+            if ((rc = all_gather_everywhere(g, &Member::c_meta, &Member::c_meta_all, b1))) return rc;
+            std::vector<uint32_t> tmp(b1 / 4 * g->n);
+            TSGPU_HIP_TRY(hipMemcpyAsync(tmp.data(), mem.c_meta_all.p, b1 * g->n, hipMemcpyDeviceToHost, mem.ctx->stream));
+            TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+            for (uint32_t r = 0; r < g->n; r++) for (uint32_t q = 0; q < n_queries; q++) { nv_all[(size_t)r * n_queries + q] = tmp[r * (b1 / 4) + q]; stride = std::max<size_t>(stride, used(tmp[r * (b1 / 4) + q])); }
+        }
+        stride = std::max<size_t>(stride, 1);
+        const size_t per = (size_t)n_queries * stride * 4;      // words of one shard's block
+        ent_all.assign(per * g->n, 0);
+        auto pack = [&](const Loc& L, uint32_t* dst) {
+            for (uint32_t q = 0; q < n_queries; q++)
+                for (uint32_t j = 0; j < used(L.nv[q]); j++) {
+                    uint32_t* e = dst + ((size_t)q * stride + j) * 4;
+                    const size_t at = (size_t)q * cap + j;
+                    e[0] = L.h[at]; e[1] = L.c[at]; e[2] = L.d[at]; e[3] = L.p[at];
+                }
+        };
+        if (g->local) { for (size_t i = 0; i < nm; i++) pack(loc[i], ent_all.data() + i * per); }
+        else {
+            Member& mem = g->m[0];
+            std::vector<uint32_t> mine(per, 0);
+            pack(loc[0], mine.data());
+            if ((rc = mem.c_meta.reserve(per * 4)) || (rc = mem.c_meta_all.reserve(per * 4 * g->n))) return rc;   // (sized by the gathered counts, the same on every rank; a rank that cannot allocate here leaves the others in the gather: out of memory is not survivable anyway)
+            TSGPU_HIP_TRY(hipMemcpyAsync(mem.c_meta.p, mine.data(), per * 4, hipMemcpyHostToDevice, mem.ctx->stream));
+            if ((rc = all_gather_everywhere(g, &Member::c_meta, &Member::c_meta_all, per * 4))) return rc;
+            TSGPU_HIP_TRY(hipMemcpyAsync(ent_all.data(), mem.c_meta_all.p, per * 4 * g->n, hipMemcpyDeviceToHost, mem.ctx->stream));
+            TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+        }
+        // the merge, query by query: ascending hashes over the shards' cursors
+        std::vector<uint32_t> cur(g->n);
+        for (uint32_t q = 0; q < n_queries; q++) {
+            std::fill(cur.begin(), cur.end(), 0u);
+            uint32_t n_out = 0, distinct = 0, most = 0;
+            bool truncated = false;
+            for (uint32_t r = 0; r < g->n; r++) { const uint32_t v = nv_all[(size_t)r * n_queries + q]; most = std::max(most, v); truncated = truncated || v > cap; }
+            for (;;) {
+                uint32_t h = 0; bool any = false;
+                for (uint32_t r = 0; r < g->n; r++) {
+                    if (cur[r] >= used(nv_all[(size_t)r * n_queries + q])) continue;
+                    const uint32_t hr = ent_all[r * per + ((size_t)q * stride + cur[r]) * 4];
+                    if (!any || hr < h) { h = hr; any = true; }
+                }
+                if (!any) break;
+                uint64_t count = 0; uint32_t doc = 0, pos = 0; bool first = true;
+                for (uint32_t r = 0; r < g->n; r++) {
+                    if (cur[r] >= used(nv_all[(size_t)r * n_queries + q])) continue;
+                    const uint32_t* e = &ent_all[r * per + ((size_t)q * stride + cur[r]) * 4];
+                    if (e[0] != h) continue;
+                    count += e[1];
+                    if (first || e[2] > doc) { doc = e[2]; pos = e[3]; first = false; }
+                    cur[r]++;
+                }
+                distinct++;
+                if (n_out < cap) {
+                    const size_t at = (size_t)q * cap + n_out;
+                    out->hash[at] = h; out->count[at] = (uint32_t)std::min<uint64_t>(count, 0xFFFFFFFFull); out->doc_id[at] = doc; out->array_pos[at] = pos;
+                    n_out++;
+                }
+            }
+            out->n_values[q] = truncated ? std::max(std::max(distinct, most), cap + 1) : distinct;
+        }
+        return ok();
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_facet_count_batch: host allocation failed"); }
+      catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_facet_count_batch: could not start a member thread"); }
+}
+
 // Candidate-token combinations over doc-range shards (Index::search_all_candidates, /root/reference/src/index.cpp:1794-1894; the single-GPU form:
 // tsgpu_keyword_search_candidates_batch). The fold of a user query's passes is per KEY (a key met by several passes keeps its greatest KV, the later pass on ties,
 // include/topster.h:392-406) and a document lives in ONE shard, so every shard folds its own passes and the shards' folded Topsters are merged like any keyword

@@ -715,6 +715,21 @@ class GpuGroup:
         B.check(self.L, self.L.tsgpu_group_wildcard_search_batch(self.h, C.cast(arr, C.c_void_p), len(arr), k, C.byref(hs)))
         return hits
 
+    def facet_count_batch(self, field_id, id_lists, cap=1024, sample_mod=1, allowed_hashes=None):
+        """tsgpu_group_facet_count_batch: GpuIndex.facet_count_batch over the shards (GLOBAL ascending id lists)"""
+        lists = [_u32(x) for x in id_lists]
+        n = len(lists)
+        ptrs = (C.c_void_p * max(n, 1))(*[x.ctypes.data if x.size else None for x in lists])
+        cnts = np.array([x.size for x in lists], np.uint64)
+        out = B.FacetCountsC()
+        h, c, d, p = (np.empty((n, cap), np.uint32) for _ in range(4))
+        nv = np.zeros(n, np.uint32)
+        out.cap, out.hash, out.count, out.doc_id, out.array_pos, out.n_values = cap, h.ctypes.data, c.ctypes.data, d.ctypes.data, p.ctypes.data, nv.ctypes.data
+        a = None if allowed_hashes is None else _u32(allowed_hashes)
+        B.check(self.L, self.L.tsgpu_group_facet_count_batch(self.h, field_id, C.cast(ptrs, C.c_void_p), _vp(cnts), n, sample_mod,
+                                                             _vp(a) if a is not None else None, a.size if a is not None else 0, C.byref(out)))
+        return [(h[q, :min(nv[q], cap)].copy(), c[q, :min(nv[q], cap)].copy(), d[q, :min(nv[q], cap)].copy(), p[q, :min(nv[q], cap)].copy(), int(nv[q])) for q in range(n)]
+
     def keyword_search_candidates_batch(self, groups, k, k_stride=None, want_found=True):
         """tsgpu_group_keyword_search_candidates_batch: groups = per user query the list of candidate-token combinations (KwQuery, pass order).
         Returns (Hits [n_groups], query_index [n_groups, k_stride] u32, found [n_groups] u64 or None) — Index::search_all_candidates over the shards."""
