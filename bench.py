@@ -601,61 +601,67 @@ class Bench:
             res["shard_parity"] = {"checked": m, "mismatches": bad, "against": "the unsharded collection on rank 0 (top-100 keys, 3 scores, num_matched)"}
 
         if self.sharded and self.group is not None:
-            # candidate combinations over the shards (tsgpu_group_keyword_search_candidates_batch; Index::search_all_candidates, src/index.cpp:1794-1894): 10 combinations per
-            # user query, per-shard fold + exchange + global query_index; rank 0 checks the merged result against the unsharded twin's own fold
-            n_u = max(8, min(n_q // 10, 200))
-            base_c = synth.keyword_queries(n_u, 3, 8, 2000, seed=41)
-            rng_c = np.random.default_rng(43)
-            users = []
-            for i in range(n_u):
-                combos = [base_c[i].copy()]
-                while len(combos) < 10:
-                    c = combos[int(rng_c.integers(0, len(combos)))].copy()
-                    c[int(rng_c.integers(0, 3))] = max(8, min(2000, int(c[int(rng_c.integers(0, 3))]) + int(rng_c.integers(1, 40))))
-                    if len(set(c.tolist())) == 3 and not any(np.array_equal(c, x) for x in combos):
-                        combos.append(c)
-                users.append([self.T.KwQuery(c, sort=self.sort, topster_size=K_TOPSTER, total_cost=(j > 0)) for j, c in enumerate(combos)])
-            self.group.keyword_search_candidates_batch(users, k=FETCH_SIZE, k_stride=FETCH_SIZE)          # warm-up
-            barrier(world)
-            t0 = time.perf_counter()
-            ch, cqi, cfound = self.group.keyword_search_candidates_batch(users, k=FETCH_SIZE, k_stride=FETCH_SIZE)
-            el_c = max_over_ranks(time.perf_counter() - t0, world)
-            res["candidate_combinations_sharded"] = {"value": n_u / el_c, "unit": "user queries/s (10 combinations each)", "ms_per_call": 1e3 * el_c, "user_queries": n_u}
-            if self.rank == 0:
-                th, tqi, tfound = self.twin.keyword_search_candidates_batch(users, k_stride=K_TOPSTER)
-                bad = 0
-                for u in range(n_u):
-                    n = min(int(th.n_hits[u]), FETCH_SIZE)
-                    if int(ch.n_hits[u]) != n or not np.array_equal(ch.keys[u, :n], th.keys[u, :n]) or not np.array_equal(ch.scores[u, :n], th.scores[u, :n]) \
-                            or not np.array_equal(cqi[u, :n], tqi[u, :n]) or int(ch.num_matched[u]) != int(th.num_matched[u]) or int(cfound[u]) != int(tfound[u]):
-                        bad += 1
-                res["candidate_combinations_sharded"]["shard_parity"] = {"checked": n_u, "mismatches": bad,
-                                                                         "against": "the unsharded collection's own fold on rank 0 (keys, scores, query_index, num_matched, found)"}
+            try:
+                # candidate combinations over the shards (tsgpu_group_keyword_search_candidates_batch; Index::search_all_candidates, src/index.cpp:1794-1894): 10 combinations per
+                # user query, per-shard fold + exchange + global query_index; rank 0 checks the merged result against the unsharded twin's own fold
+                n_u = max(8, min(n_q // 10, 200))
+                base_c = synth.keyword_queries(n_u, 3, 8, 2000, seed=41)
+                rng_c = np.random.default_rng(43)
+                users = []
+                for i in range(n_u):
+                    combos = [base_c[i].copy()]
+                    while len(combos) < 10:
+                        c = combos[int(rng_c.integers(0, len(combos)))].copy()
+                        c[int(rng_c.integers(0, 3))] = max(8, min(2000, int(c[int(rng_c.integers(0, 3))]) + int(rng_c.integers(1, 40))))
+                        if len(set(c.tolist())) == 3 and not any(np.array_equal(c, x) for x in combos):
+                            combos.append(c)
+                    users.append([self.T.KwQuery(c, sort=self.sort, topster_size=K_TOPSTER, total_cost=(j > 0)) for j, c in enumerate(combos)])
+                self.group.keyword_search_candidates_batch(users, k=FETCH_SIZE, k_stride=FETCH_SIZE)          # warm-up
+                barrier(world)
+                t0 = time.perf_counter()
+                ch, cqi, cfound = self.group.keyword_search_candidates_batch(users, k=FETCH_SIZE, k_stride=FETCH_SIZE)
+                el_c = max_over_ranks(time.perf_counter() - t0, world)
+                res["candidate_combinations_sharded"] = {"value": n_u / el_c, "unit": "user queries/s (10 combinations each)", "ms_per_call": 1e3 * el_c, "user_queries": n_u}
+                if self.rank == 0:
+                    th, tqi, tfound = self.twin.keyword_search_candidates_batch(users, k_stride=K_TOPSTER)
+                    bad = 0
+                    for u in range(n_u):
+                        n = min(int(th.n_hits[u]), FETCH_SIZE)
+                        if int(ch.n_hits[u]) != n or not np.array_equal(ch.keys[u, :n], th.keys[u, :n]) or not np.array_equal(ch.scores[u, :n], th.scores[u, :n]) \
+                                or not np.array_equal(cqi[u, :n], tqi[u, :n]) or int(ch.num_matched[u]) != int(th.num_matched[u]) or int(cfound[u]) != int(tfound[u]):
+                            bad += 1
+                    res["candidate_combinations_sharded"]["shard_parity"] = {"checked": n_u, "mismatches": bad,
+                                                                             "against": "the unsharded collection's own fold on rank 0 (keys, scores, query_index, num_matched, found)"}
+            except Exception as e:      # noqa: BLE001 (a secondary leg must not take the headline line with it)
+                res["candidate_combinations_sharded"] = {"error": repr(e)}
 
         if self.sharded and self.group is not None:
-            # q = * over the shards (tsgpu_group_wildcard_search_batch; Index::search_wildcard, src/index.cpp:6616-6818): every rank ranks the ids of its doc range by the
-            # sort keys, the per-shard Topsters take the keyword exchange; rank 0 checks the merged result against the unsharded twin
-            fl_w = np.arange(1, self.n_docs, 3, dtype=np.uint32)
-            wqs = [self.T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=K_TOPSTER),
-                   self.T.KwQuery([], sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_SEQ_ID, -1, 0)), topster_size=K_TOPSTER, filter_ids=fl_w),
-                   self.T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, -1, 0)), topster_size=K_TOPSTER, excluded_ids=fl_w[::1000]),
-                   self.T.KwQuery([], sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=K_TOPSTER, filter_ids=fl_w[:5])]
-            self.group.wildcard_search_batch(wqs, k=FETCH_SIZE, k_stride=FETCH_SIZE)          # warm-up
-            barrier(world)
-            t0 = time.perf_counter()
-            wh = self.group.wildcard_search_batch(wqs, k=FETCH_SIZE, k_stride=FETCH_SIZE)
-            el_w = max_over_ranks(time.perf_counter() - t0, world)
-            res["wildcard_sharded"] = {"ms_per_call": 1e3 * el_w, "queries": len(wqs), "docs_ranked_per_s": (2 * self.n_docs + 2 * fl_w.size) / el_w,
-                                       "workload": "q = * over %d documents cut into %d doc ranges: all ids / every third id (filter) / excluded ids / a 5-id filter" % (self.n_docs, world)}
-            if self.rank == 0:
-                th = self.twin.wildcard_search_batch(wqs, k_stride=K_TOPSTER)
-                bad = 0
-                for i in range(len(wqs)):
-                    n = min(int(th.n_hits[i]), FETCH_SIZE)
-                    if int(wh.n_hits[i]) != n or not np.array_equal(wh.keys[i, :n], th.keys[i, :n]) or not np.array_equal(wh.scores[i, :n], th.scores[i, :n]) \
-                            or int(wh.num_matched[i]) != int(th.num_matched[i]):
-                        bad += 1
-                res["wildcard_sharded"]["shard_parity"] = {"checked": len(wqs), "mismatches": bad, "against": "the unsharded collection on rank 0 (keys, scores, num_matched)"}
+            try:
+                # q = * over the shards (tsgpu_group_wildcard_search_batch; Index::search_wildcard, src/index.cpp:6616-6818): every rank ranks the ids of its doc range by the
+                # sort keys, the per-shard Topsters take the keyword exchange; rank 0 checks the merged result against the unsharded twin
+                fl_w = np.arange(1, self.n_docs, 3, dtype=np.uint32)
+                wqs = [self.T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=K_TOPSTER),
+                       self.T.KwQuery([], sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_SEQ_ID, -1, 0)), topster_size=K_TOPSTER, filter_ids=fl_w),
+                       self.T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, -1, 0)), topster_size=K_TOPSTER, excluded_ids=fl_w[::1000]),
+                       self.T.KwQuery([], sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=K_TOPSTER, filter_ids=fl_w[:5])]
+                self.group.wildcard_search_batch(wqs, k=FETCH_SIZE, k_stride=FETCH_SIZE)          # warm-up
+                barrier(world)
+                t0 = time.perf_counter()
+                wh = self.group.wildcard_search_batch(wqs, k=FETCH_SIZE, k_stride=FETCH_SIZE)
+                el_w = max_over_ranks(time.perf_counter() - t0, world)
+                res["wildcard_sharded"] = {"ms_per_call": 1e3 * el_w, "queries": len(wqs), "docs_ranked_per_s": (2 * self.n_docs + 2 * fl_w.size) / el_w,
+                                           "workload": "q = * over %d documents cut into %d doc ranges: all ids / every third id (filter) / excluded ids / a 5-id filter" % (self.n_docs, world)}
+                if self.rank == 0:
+                    th = self.twin.wildcard_search_batch(wqs, k_stride=K_TOPSTER)
+                    bad = 0
+                    for i in range(len(wqs)):
+                        n = min(int(th.n_hits[i]), FETCH_SIZE)
+                        if int(wh.n_hits[i]) != n or not np.array_equal(wh.keys[i, :n], th.keys[i, :n]) or not np.array_equal(wh.scores[i, :n], th.scores[i, :n]) \
+                                or int(wh.num_matched[i]) != int(th.num_matched[i]):
+                            bad += 1
+                    res["wildcard_sharded"]["shard_parity"] = {"checked": len(wqs), "mismatches": bad, "against": "the unsharded collection on rank 0 (keys, scores, num_matched)"}
+            except Exception as e:      # noqa: BLE001 (a secondary leg must not take the headline line with it)
+                res["wildcard_sharded"] = {"error": repr(e)}
 
         if self.sharded:
             # second multi-GPU form, reported as a sub-object: replicas — every GPU holds the collection, the global batch of N x 10 000 queries
