@@ -54,6 +54,15 @@ def test_bulk_build_on_the_device_equals_the_oracles_batched_build_link_for_link
         for i in range(Q.shape[0]):
             d, l, _ = orc.hnsw_search(Q[i], k, ef, functor_present=True)
             assert cnt[i] == d.size and np.array_equal(lab[i, :d.size], l) and np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32)), (k, ef, i)
+    # a candidate heap that outgrows its LDS tier: those queries — and only those — run again on the largest tier (forced here with a 24-entry heap), same answer
+    g.set_option("hnsw_test_tiny_cand", 1)
+    r0 = g.counter("hnsw_tier_reruns")
+    dist, lab, cnt = g.vec_hnsw_search_batch(1, Q, 10, 60)
+    assert g.counter("hnsw_tier_reruns") > r0
+    g.set_option("hnsw_test_tiny_cand", 0)
+    for i in range(Q.shape[0]):
+        d, l, _ = orc.hnsw_search(Q[i], 10, 60, functor_present=True)
+        assert cnt[i] == d.size and np.array_equal(lab[i, :d.size], l) and np.array_equal(dist[i, :d.size].view(np.uint32), d.view(np.uint32)), ("re-run", i)
     g.close()
 
 

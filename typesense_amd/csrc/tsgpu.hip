@@ -272,6 +272,7 @@ int tsgpu_set_option(tsgpu_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "kw_timing_min_queries")) { ctx->kw_timing_min_queries = (uint32_t)std::max<int64_t>(0, value); return ok(); }
     if (!strcmp(name, "kw_merge_select_min")) { ctx->kw_merge_select_min = (uint32_t)std::max<int64_t>(0, value); return ok(); }
     if (!strcmp(name, "hnsw_visited_hash")) { ctx->hnsw_visited_hash = value != 0; return ok(); }
+    if (!strcmp(name, "hnsw_test_tiny_cand")) { ctx->hnsw_test_tiny_cand = value != 0; return ok(); }
     if (!strcmp(name, "hnsw_visited_max_gib")) { ctx->hnsw_visited_max_gib = (int)std::min<int64_t>(std::max<int64_t>(1, value), 128); return ok(); }
     if (!strcmp(name, "blocking_sync_min_callers")) { ctx->blocking_sync_min_callers = (int)std::max<int64_t>(0, value); return ok(); }
     if (!strcmp(name, "plan_threads")) { if (value < 1 || value > 64) return fail(TSGPU_ERR_INVALID, "plan_threads: 1..64"); ctx->plan_threads = (int)value; return ok(); }
@@ -348,6 +349,7 @@ int tsgpu_get_counter(tsgpu_ctx* ctx, const char* name, uint64_t* out) {
     if (!strcmp(name, "vec_prefilter_groups")) { *out = ctx->vec_prefilter_groups; return ok(); }
     if (!strcmp(name, "vec_rescored_rows")) { *out = ctx->vec_rescored_rows; return ok(); }
     if (!strcmp(name, "hnsw_last_expansions")) { *out = ctx->hnsw_last_expansions; return ok(); }
+    if (!strcmp(name, "hnsw_tier_reruns")) { *out = ctx->hnsw_tier_reruns; return ok(); }
     if (!strcmp(name, "hnsw_last_distances")) { *out = ctx->hnsw_last_distances; return ok(); }
     if (!strcmp(name, "commit_last_us")) { *out = ctx->commit_last_us; return ok(); }                        // the last tsgpu_commit: wall time, bytes uploaded
     if (!strcmp(name, "commit_last_uploaded_bytes")) { *out = ctx->commit_last_uploaded_bytes; return ok(); }

@@ -559,6 +559,9 @@ struct tsgpu_ctx {
     uint32_t vec_ip_lanes = 4;                       // order of the exact distances' sums: 4 = hnswlib built for SSE (the reference's stock flags), 8 = AVX, 16 = AVX-512
     uint32_t vec_prefilter = 1;                      // 1 = bf16 bracket scan + exact fp32 re-score (default); 0 = fp32 MFMA scan
     uint64_t vec_prefilter_groups = 0;               // query groups answered by the bf16 bracket path
+    int hnsw_test_tiny_cand = 0;                      // TESTS ONLY (option "hnsw_test_tiny_cand"): searches with max(ef, k) <= 128 start on a 24-entry candidate heap, so that
+                                                     // the re-run of the overflowed queries on the largest tier is exercised on small graphs
+    uint64_t hnsw_tier_reruns = 0;                   // queries that were run again on the largest tier since the context was created (counter "hnsw_tier_reruns")
     int hnsw_visited_hash = 1;                        // 1 = per-query hash sets of visited ids (default), 0 = 16-bit tags per row and concurrent query
     int hnsw_visited_max_gib = 64;                    // cap of one field's HNSW visited-tag array (option): bounds the queries traversing concurrently
     int blocking_sync_min_callers = 48;               // from this many threads inside the keyword entry point a lane waits for its round by sleeping (option)

@@ -36,7 +36,7 @@ struct VecField {
     DevBuf d_Qh, d_cq, d_L1, d_lbkey, d_surv, d_surv_cnt, d_gkeys;
     uint64_t seg_cap_hint = 0;                         // the largest (slab, query) candidate-segment capacity this field's data has needed so far
     // HNSW graph mirror (tsgpu_vec_hnsw_load): hnswlib's link lists; rows = hnswlib internal ids
-    DevBuf g_link0, g_upper_ptr, g_upper_links, g_visited, g_vhash, g_stat;
+    DevBuf g_link0, g_upper_ptr, g_upper_links, g_visited, g_vhash, g_stat, g_sel;
     uint32_t g_tag_slots = 0;                          // tag mode: concurrent queries the allocated tag array serves (0 = not allocated)
     uint32_t g_M = 0, g_n = 0, g_slots = 0, g_epoch = 1;
     int32_t g_maxlevel = -1;
@@ -59,7 +59,7 @@ struct VecField {
     }
     void release() {
         DevBuf* b[] = {&X, &labels, &row_ok, &Xh, &xnorm, &tile_nmax, &d_dense, &d_cand, &d_cand_cnt, &d_tau, &dQ, &d_dist, &d_lab, &d_cnt, &d_mask, &d_rows,
-                       &d_q1, &d_out1, &d_Qh, &d_cq, &d_L1, &d_lbkey, &d_surv, &d_surv_cnt, &d_gkeys, &g_link0, &g_upper_ptr, &g_upper_links, &g_visited, &g_vhash, &g_stat};
+                       &d_q1, &d_out1, &d_Qh, &d_cq, &d_L1, &d_lbkey, &d_surv, &d_surv_cnt, &d_gkeys, &g_link0, &g_upper_ptr, &g_upper_links, &g_visited, &g_vhash, &g_stat, &g_sel};
         for (auto* x : b) x->release();
     }
 };
@@ -882,7 +882,6 @@ static int hnsw_search_launch(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, c
         }
     }
     const uint32_t grid = std::min<uint32_t>(n_q, slots);
-    const uint32_t iters = (n_q + grid - 1) / grid;
     const size_t tag_bytes = ((size_t)slots * f->g_n * 2 + 7) & ~(size_t)7;
     VecHnswArgs a;
     memset(&a, 0, sizeof a);
@@ -894,34 +893,47 @@ static int hnsw_search_launch(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, c
     a.k = k; a.ef = ef; a.ip_lanes = ctx->vec_ip_lanes; a.visited = hash_mode ? nullptr : f->g_visited.as<uint16_t>();
     a.overflow_cnt = f->g_stat.as<uint32_t>();
     a.labels = labels; a.dist_out = d_dist; a.label_out = d_lab; a.n_out = d_cnt;
-    // LDS tier by max(ef, k); a query whose candidate heap outgrows a small tier makes the batch run again on the largest
+    // LDS tier by max(ef, k): result heap 128 / 256 / 512 / 1024 entries, candidate heap 1024 / 1024 / 2048 / 4096 = 13.6 / 14.6 / 25 / 45 KB of LDS per query
+    // = 11 / 10 / 6 / 3 queries in flight per CU (the 256 tier — round 6 — is the bulk build's: ef_construction 200 ran on the 512 tier's six before). The
+    // queries whose candidate heap (or visited set) outgrows their tier — and only those — run again on the largest (round 6: before, one of them sent the
+    // whole batch there). Smaller candidate heaps for the upper tiers were measured and lose: at ef 400 / 800 most queries outgrow 1024 / 2048 entries
+    // (10M x 768: 105 K -> 48 K q/s, 31 K -> 26 K q/s with the re-runs).
     const uint32_t need = std::max(k, ef);
-    // (tiers: result heap 128 / 256 / 512 / 1024 entries, candidate heap 1024 / 1024 / 2048 / 4096: 13.6 / 14.6 / 25 / 45 KB of LDS per query = 11 / 10 / 6 / 3
-    //  queries in flight per CU. The 256 tier — round 6 — is the bulk build's: ef_construction 200 ran on the 512 tier's six queries per CU before)
     int tier = need <= 128 ? 0 : (need <= 256 ? 1 : (need <= 512 ? 2 : 3));
-    uint32_t vs_boost = 1, grid_now = grid;
+    const int TOP = 3;
+    const bool tiny = ctx->hnsw_test_tiny_cand && need <= 128;
+    uint32_t vs_boost = 1, grid_now = grid, n_now = n_q;
+    uint64_t tot_exp = 0, tot_dist = 0;
+    std::vector<uint32_t> h_cnt, h_sel;
     for (;;) {
+        const uint32_t grid_t = std::min<uint32_t>(n_now, grid);
+        const uint32_t iters_t = (n_now + grid_t - 1) / grid_t;
         if (hash_mode) {
-            // per-query visited sets: 64 x the tier's result-heap capacity (8 192 / 32 768 / 65 536 words), one per concurrent query; a traversal
+            // per-query visited sets: 64 x the tier's result-heap capacity (8 192 .. 65 536 words), one per concurrent query; a traversal
             // that outgrows the largest tier's set (large ef / k, strict filters: many visited, few admitted) runs again with sets 8x / 64x as
             // large and fewer queries in flight (<= 8 GiB of sets) instead of being reported as overflowed
             const uint32_t vs = (tier == 0 ? 8192u : (tier == 1 ? 16384u : (tier == 2 ? 32768u : 65536u))) * vs_boost;
-            grid_now = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid, (8ull << 30) / ((uint64_t)vs * 4)));
+            grid_now = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(grid_t, (8ull << 30) / ((uint64_t)vs * 4)));
             if ((rc = f->g_vhash.reserve((size_t)grid_now * vs * 4))) return rc;
             a.vhash = f->g_vhash.as<uint32_t>(); a.vhash_slots = vs;
-        } else if ((uint64_t)f->g_epoch + iters >= 0xFFF0ull) {      // tag space exhausted: clear the tags
-            TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, tag_bytes, s));
-            f->g_epoch = 1;
+        } else {
+            grid_now = grid_t;
+            if ((uint64_t)f->g_epoch + iters_t >= 0xFFF0ull) {      // tag space exhausted: clear the tags
+                TSGPU_HIP_TRY(hipMemsetAsync(f->g_visited.p, 0, tag_bytes, s));
+                f->g_epoch = 1;
+            }
         }
         a.epoch_base = f->g_epoch;
-        f->g_epoch += iters;
+        f->g_epoch += (n_now + grid_now - 1) / grid_now;
+        a.n_q = n_now;
         TSGPU_HIP_TRY(hipMemsetAsync(a.overflow_cnt, 0, 56, s));
         if (build_layer > 0) {                           // the bulk build's beam on an upper layer
             if (tier == 0) hipLaunchKernelGGL((vec_hnsw_search_kernel<129, 1024, true>), dim3(grid_now), dim3(64), 0, s, a);
             else if (tier == 1) hipLaunchKernelGGL((vec_hnsw_search_kernel<257, 1024, true>), dim3(grid_now), dim3(64), 0, s, a);
             else if (tier == 2) hipLaunchKernelGGL((vec_hnsw_search_kernel<513, 2048, true>), dim3(grid_now), dim3(64), 0, s, a);
             else hipLaunchKernelGGL((vec_hnsw_search_kernel<VEC_HNSW_MAX_EF + 1, VEC_HNSW_CAND_CAP, true>), dim3(grid_now), dim3(64), 0, s, a);
-        } else if (tier == 0) hipLaunchKernelGGL((vec_hnsw_search_kernel<129, 1024>), dim3(grid_now), dim3(64), 0, s, a);
+        } else if (tier == 0 && tiny) hipLaunchKernelGGL((vec_hnsw_search_kernel<129, 24>), dim3(grid_now), dim3(64), 0, s, a);
+        else if (tier == 0) hipLaunchKernelGGL((vec_hnsw_search_kernel<129, 1024>), dim3(grid_now), dim3(64), 0, s, a);
         else if (tier == 1) hipLaunchKernelGGL((vec_hnsw_search_kernel<257, 1024>), dim3(grid_now), dim3(64), 0, s, a);
         else if (tier == 2) hipLaunchKernelGGL((vec_hnsw_search_kernel<513, 2048>), dim3(grid_now), dim3(64), 0, s, a);
         else hipLaunchKernelGGL((vec_hnsw_search_kernel<VEC_HNSW_MAX_EF + 1, VEC_HNSW_CAND_CAP>), dim3(grid_now), dim3(64), 0, s, a);
@@ -932,13 +944,28 @@ static int hnsw_search_launch(tsgpu_ctx* ctx, VecField* f, const float* Q_dev, c
         fprintf(stderr, "HNSW_PROF ticks(100MHz)/query: pop+barrier %.0f  links+tags %.0f  distances %.0f  heaps %.0f\n", (double)(h_stat[6] | ((uint64_t)h_stat[7] << 32)) / n_q,
                 (double)(h_stat[8] | ((uint64_t)h_stat[9] << 32)) / n_q, (double)(h_stat[10] | ((uint64_t)h_stat[11] << 32)) / n_q, (double)(h_stat[12] | ((uint64_t)h_stat[13] << 32)) / n_q);
 #endif
-        ctx->hnsw_last_expansions = (uint64_t)h_stat[2] | ((uint64_t)h_stat[3] << 32);
-        ctx->hnsw_last_distances = (uint64_t)h_stat[4] | ((uint64_t)h_stat[5] << 32);
+        tot_exp += (uint64_t)h_stat[2] | ((uint64_t)h_stat[3] << 32);
+        tot_dist += (uint64_t)h_stat[4] | ((uint64_t)h_stat[5] << 32);
         if (!h_stat[0]) break;
-        if (tier < 3) { tier = 3; continue; }
-        if (hash_mode && vs_boost < 64) { vs_boost *= 8; continue; }
-        break;                                   // (a candidate heap beyond the largest tier: those queries report n_out = 0xFFFFFFFF)
+        if (tier == TOP && !(hash_mode && vs_boost < 64)) break;      // (a candidate heap beyond the largest tier: those queries report n_out = 0xFFFFFFFF)
+        // which queries: the ones marked 0xFFFFFFFF (of this launch's selection, or of the whole batch the first time)
+        h_cnt.resize(n_q);
+        TSGPU_HIP_TRY(hipMemcpy(h_cnt.data(), d_cnt, (size_t)n_q * 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> again;
+        if (h_sel.empty()) { for (uint32_t q = 0; q < n_q; q++) if (h_cnt[q] == 0xFFFFFFFFu) again.push_back(q); }
+        else for (uint32_t q : h_sel) if (h_cnt[q] == 0xFFFFFFFFu) again.push_back(q);
+        if (again.empty()) break;
+        h_sel.swap(again);
+        if ((rc = f->g_sel.reserve(h_sel.size() * 4))) return rc;
+        TSGPU_HIP_TRY(hipMemcpyAsync(f->g_sel.p, h_sel.data(), h_sel.size() * 4, hipMemcpyHostToDevice, s));
+        TSGPU_HIP_TRY(hipStreamSynchronize(s));          // (h_sel is reused)
+        a.q_sel = f->g_sel.as<uint32_t>();
+        n_now = (uint32_t)h_sel.size();
+        ctx->hnsw_tier_reruns += n_now;
+        if (tier < TOP) tier = TOP; else vs_boost *= 8;
     }
+    ctx->hnsw_last_expansions = tot_exp;
+    ctx->hnsw_last_distances = tot_dist;
     return TSGPU_OK;
 }
 

@@ -1263,6 +1263,7 @@ __global__ __launch_bounds__(VEC_THREADS) void vec_group_merge_kernel(const uint
 struct VecHnswArgs {
     const float* X; const float* Q; uint32_t dim, n_rows, n_q;
     const uint32_t* q_rows;                             // nullable: query q is ROW q_rows[q] of X (the bulk build searches for the rows it inserts) instead of Q[q]
+    const uint32_t* q_sel;                              // nullable: this launch serves the queries q_sel[0 .. n_q) of the batch (the ones whose heaps outgrew a smaller tier)
     uint32_t base_level;                                // BUILD instantiations only: the beam runs on this layer's lists (the descent stops above it); the search proper is layer 0
     const uint32_t* link0; uint32_t s0;                 // [n][s0], s0 = 1 + 2M
     const uint64_t* upper_ptr; const uint32_t* upper_links; uint32_t su;      // su = 1 + M
@@ -1367,7 +1368,8 @@ __global__ __launch_bounds__(64) void vec_hnsw_search_kernel(VecHnswArgs a) {
         }
     };
     uint32_t iter = 0;
-    for (uint32_t q = blockIdx.x; q < a.n_q; q += gridDim.x, iter++) {
+    for (uint32_t qn = blockIdx.x; qn < a.n_q; qn += gridDim.x, iter++) {
+        const uint32_t q = a.q_sel ? a.q_sel[qn] : qn;
         const uint16_t epoch = (uint16_t)(a.epoch_base + iter);
         uint32_t n_vis = 0;                                      // (per lane; summed over the wave when checked)
         if (vset) {
