@@ -277,6 +277,31 @@ def test_rccl_transport_one_rank_form_runs_the_real_collective():
         d0, l0, c0 = g.vec_knn_batch(1, Q, 20)
         d1, l1, c1 = grp.vec_knn_batch(1, Q, 20)
         assert np.array_equal(l0, l1) and np.array_equal(d0.view(np.uint32), d1.view(np.uint32)) and np.array_equal(c0, c1)
+        # round 6's group calls through the same transport (their gathers are ncclAllGather on the member's stream): candidate combinations, q = *,
+        # rerank_hybrid_matches, facet counts — each equals the plain call on the one context
+        users = [[T.KwQuery(c, sort=SORT, topster_size=250, total_cost=int(j > 0)) for j, c in enumerate(cs)] for cs in ([[1, 2], [1, 3], [150, 2]], [[9], [3, 4]])]
+        ph, pqi, pf = g.keyword_search_candidates_batch(users, k_stride=250)
+        ch, cqi, cf = grp.keyword_search_candidates_batch(users, k=100, k_stride=100)
+        for u in range(len(users)):
+            n = min(100, int(ph.n_hits[u]))
+            assert int(ch.n_hits[u]) == n and np.array_equal(ch.keys[u, :n], ph.keys[u, :n]) and np.array_equal(ch.scores[u, :n], ph.scores[u, :n]) and np.array_equal(cqi[u, :n], pqi[u, :n])
+            assert int(cf[u]) == int(pf[u]) and int(ch.num_matched[u]) == int(ph.num_matched[u])
+        wq = [T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=250, filter_ids=np.arange(3, 20000, 7, dtype=np.uint32))]
+        pw = g.wildcard_search_batch(wq, k_stride=250)
+        gw = grp.wildcard_search_batch(wq, k=100, k_stride=100)
+        assert int(gw.n_hits[0]) == 100 and np.array_equal(gw.keys[0, :100], pw.keys[0, :100]) and np.array_equal(gw.scores[0, :100], pw.scores[0, :100]) and int(gw.num_matched[0]) == int(pw.num_matched[0])
+        hq = [T.KwQuery([1, 2], sort=SORT, topster_size=0), T.KwQuery([9], sort=SORT, topster_size=0)]
+        pf_ = g.hybrid_search_batch(hq, 1, Q[:2], k=0, fetch_size=10, alpha=0.3, k_stride=250, rerank=True)
+        gf = grp.hybrid_search_batch(hq, 1, B.METRIC_IP, Q[:2], k=0, fetch_size=10, alpha=0.3, k_stride=250, rerank=True)
+        for i in range(2):
+            n = int(pf_.n_hits[i])
+            assert int(gf.n_hits[i]) == n and np.array_equal(gf.keys[i, :n], pf_.keys[i, :n]) and np.array_equal(gf.scores[i, :n], pf_.scores[i, :n]) and np.array_equal(gf.text_match[i, :n], pf_.text_match[i, :n])
+        g.facet_set(5, *H.facet_csr_of(20000))
+        id_lists = [np.arange(20000, dtype=np.uint32), np.arange(1, 20000, 3, dtype=np.uint32)]
+        for cap in (512, 6):
+            a, b = g.facet_count_batch(5, id_lists, cap=cap), grp.facet_count_batch(5, id_lists, cap=cap)
+            for x, y in zip(a, b):
+                assert all(np.array_equal(x[j], y[j]) for j in range(4)) and ((x[4] == y[4]) if x[4] <= cap else (y[4] > cap))
     finally:
         grp.close()
         g.close()
