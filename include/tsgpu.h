@@ -686,6 +686,12 @@ int tsgpu_group_hybrid_search_batch(tsgpu_group* g, const tsgpu_kw_query* querie
  * doc_id / array_pos = the greatest document's. Exact for the first `cap` values; n_values is exact while no shard had more than cap, else a lower bound > cap. */
 int tsgpu_group_facet_count_batch(tsgpu_group* g, uint32_t facet_field_id, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
                                   uint32_t sample_mod, const uint32_t* allowed_hashes, uint32_t n_allowed, tsgpu_facet_counts* out);
+/* ... the range facets (tsgpu_facet_range_count_batch without a group column: the counts add up; the grouped form is not sharded) and the facet stats
+ * (tsgpu_facet_stats_batch: min / max / count / sum merged, sum_exact recomputed from the merged values) over the shards */
+int tsgpu_group_facet_range_count_batch(tsgpu_group* g, uint32_t facet_field_id, uint32_t value_column, const int64_t* range_upper, const int64_t* range_lower, uint32_t n_ranges,
+                                        const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries, uint32_t sample_mod, uint32_t* counts);
+int tsgpu_group_facet_stats_batch(tsgpu_group* g, uint32_t facet_field_id, int value_type, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
+                                  uint32_t sample_mod, const uint32_t* int64_map_hashes, const int64_t* int64_map_values, uint32_t n_map, tsgpu_facet_stats* out);
 typedef struct tsgpu_group_timings {
     float local_ms;                      /* host wall: every member's own batch + pack (members run concurrently) */
     float exchange_merge_ms;             /* host wall: the exchange, the merge and the delivery of the merged result */

@@ -153,6 +153,16 @@ def main():
                 h, c, d, p, n = got[i]
                 check("facets %s cap %d mod %d q%d" % (cut_name, cap, sample_mod, i), np.array_equal(h, rh) and np.array_equal(c, rc_) and np.array_equal(d, rd) and np.array_equal(p, rp) and
                       ((n == rn) if rn <= cap else (n > cap)))
+        edges = np.linspace(int(pts.min()), int(pts.max()) + 1, 5).astype(np.int64)
+        ranges = [(int(edges[r + 1]), int(edges[r])) for r in range(4) if edges[r + 1] > edges[r]]
+        got = grp.facet_range_count_batch(5, 0, ranges, id_lists)
+        st = grp.facet_stats_batch(5, B.FACET_INT32, id_lists)
+        for i, ids in enumerate(id_lists):
+            k, c, d, p, n = orc.facet_count_ex(5, ids, ranges=ranges, doc_vals=pts)
+            m = {int(a): int(b) for a, b in zip(k.view(np.int64), c)}
+            check("range facets %s q%d" % (cut_name, i), [m.get(int(up), 0) for up, _ in ranges] == got[i].tolist())
+            mn, mx, sm, cnt = orc.facet_stats(5, ids, B.FACET_INT32)
+            check("facet stats %s q%d" % (cut_name, i), st[i][:4] == (mn, mx, sm, cnt))
         # wildcard over the shards (tsgpu_group_wildcard_search_batch): every rank ranks the ids of its range
         fl = np.arange(2, n_docs, 7, dtype=np.uint32)
         wq = [T.KwQuery([], sort=((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0)), topster_size=K),

@@ -104,6 +104,21 @@ def check_group(orc, grp, rng, n_docs, dim):
             h, c, d, p, n = got[i]
             assert np.array_equal(h, rh) and np.array_equal(c, rc_) and np.array_equal(d, rd) and np.array_equal(p, rp), ("facets", cap, sample_mod, i)
             assert (n == rn) if rn <= cap else (n > cap), ("facet n_values", cap, sample_mod, i, n, rn)
+    # ---- range facets and facet stats over the shards: the counts add up; min / max / count / sum merge ----
+    pts = H.points_of(n_docs)
+    lo_v, hi_v = int(pts.min()), int(pts.max()) + 1
+    edges = np.linspace(lo_v, hi_v, 6).astype(np.int64)
+    ranges = [(int(edges[r + 1]), int(edges[r])) for r in range(5) if edges[r + 1] > edges[r]]
+    for sample_mod in (1, 3):
+        got = grp.facet_range_count_batch(5, 0, ranges, id_lists, sample_mod=sample_mod)
+        for i, ids in enumerate(id_lists):
+            k, c, d, p, n = orc.facet_count_ex(5, ids, ranges=ranges, doc_vals=pts, sample_mod=sample_mod)
+            m = {int(a): int(b) for a, b in zip(k.view(np.int64), c)}
+            assert [m.get(int(up), 0) for up, _ in ranges] == got[i].tolist(), ("range facets", sample_mod, i)
+        st = grp.facet_stats_batch(5, B.FACET_INT32, id_lists, sample_mod=sample_mod)
+        for i, ids in enumerate(id_lists):
+            mn, mx, sm, cnt = orc.facet_stats(5, ids, B.FACET_INT32, sample_mod=sample_mod)
+            assert st[i][:4] == (mn, mx, sm, cnt) and st[i][4] == 1, ("facet stats", sample_mod, i, st[i], (mn, mx, sm, cnt))
     # ---- k-NN: closest first, ties -> smaller label; allow list ----
     Q = rng.standard_normal((5, dim)).astype(np.float32)
     for k in (7, 30):
@@ -302,6 +317,9 @@ def test_rccl_transport_one_rank_form_runs_the_real_collective():
             a, b = g.facet_count_batch(5, id_lists, cap=cap), grp.facet_count_batch(5, id_lists, cap=cap)
             for x, y in zip(a, b):
                 assert all(np.array_equal(x[j], y[j]) for j in range(4)) and ((x[4] == y[4]) if x[4] <= cap else (y[4] > cap))
+        ranges = [(250, 0), (500, 250), (1000, 600)]
+        assert np.array_equal(g.facet_range_count_batch(5, 0, ranges, id_lists), grp.facet_range_count_batch(5, 0, ranges, id_lists))
+        assert g.facet_stats_batch(5, B.FACET_INT32, id_lists) == grp.facet_stats_batch(5, B.FACET_INT32, id_lists)
     finally:
         grp.close()
         g.close()

@@ -1009,6 +1009,112 @@ int tsgpu_group_facet_count_batch(tsgpu_group* g, uint32_t facet_field_id, const
       catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_facet_count_batch: could not start a member thread"); }
 }
 
+namespace {
+// the part of every matched-id list a member walks: the ids inside its doc range (they ascend), or the whole lists when positions in the whole list matter
+// (sample_mod > 1), the member has no doc range, or the members are replicas (then member 0 answers alone: *skip = true for the others)
+void member_id_slices(tsgpu_group* g, size_t i, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries, uint32_t sample_mod,
+                      std::vector<const uint32_t*>& ptr, std::vector<uint64_t>& cnt, bool* skip) {
+    Member& mem = g->m[i];
+    const bool slice = sample_mod <= 1 && mem.ctx->doc_range_set && !g->replicas;
+    ptr.resize(n_queries); cnt.resize(n_queries);
+    for (uint32_t q = 0; q < n_queries; q++) {
+        const uint32_t* b = result_ids[q];
+        const uint32_t* e = b + n_result_ids[q];
+        if (slice && b) { b = std::lower_bound(b, e, mem.ctx->doc_range_lo); e = std::lower_bound(b, e, mem.ctx->doc_range_hi); }
+        ptr[q] = b; cnt[q] = (uint64_t)(e - b);
+    }
+    *skip = g->replicas && i > 0;
+}
+// rank form: `bytes` (a multiple of 8, the same on every rank) of host data from every rank -> all[n][bytes]; local form: the members' blocks side by side
+int gather_host_blocks(tsgpu_group* g, const std::vector<std::vector<uint8_t>>& mine, size_t bytes, std::vector<uint8_t>& all) {
+    all.assign(bytes * g->n, 0);
+    if (g->local) { for (size_t i = 0; i < g->m.size(); i++) memcpy(all.data() + i * bytes, mine[i].data(), bytes); return TSGPU_OK; }
+    Member& mem = g->m[0];
+    (void)hipSetDevice(mem.ctx->device);
+    int rc;
+    if ((rc = mem.c_meta.reserve(bytes)) || (rc = mem.c_meta_all.reserve(bytes * g->n))) return rc;
+    TSGPU_HIP_TRY(hipMemcpyAsync(mem.c_meta.p, mine[0].data(), bytes, hipMemcpyHostToDevice, mem.ctx->stream));
+    if ((rc = all_gather_everywhere(g, &Member::c_meta, &Member::c_meta_all, bytes))) return rc;
+    TSGPU_HIP_TRY(hipMemcpyAsync(all.data(), mem.c_meta_all.p, bytes * g->n, hipMemcpyDeviceToHost, mem.ctx->stream));
+    TSGPU_HIP_TRY(hipStreamSynchronize(mem.ctx->stream));
+    return TSGPU_OK;
+}
+}  // namespace
+
+// Range facets (tsgpu_facet_range_count_batch; src/index.cpp:1738-1750) over doc-range shards: every member counts the documents of its range, the counts add up
+// (0 = the range is in no shard's result_map). The grouped form (group_column) is not sharded: a group's documents live on several shards (501).
+int tsgpu_group_facet_range_count_batch(tsgpu_group* g, uint32_t facet_field_id, uint32_t value_column, const int64_t* range_upper, const int64_t* range_lower, uint32_t n_ranges,
+                                        const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries, uint32_t sample_mod, uint32_t* counts) {
+    if (!g || (n_queries && (!result_ids || !n_result_ids || !counts)) || (n_ranges && (!range_upper || !range_lower))) return fail(TSGPU_ERR_INVALID, "tsgpu_group_facet_range_count_batch: NULL argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (n_queries == 0 || n_ranges == 0) return agree(g, TSGPU_OK, call_signature({11, 0}));
+    try {
+        const size_t words = (size_t)n_queries * n_ranges, bytes = (words * 4 + 7) & ~(size_t)7;
+        std::vector<std::vector<uint8_t>> mine(g->m.size(), std::vector<uint8_t>(bytes, 0));
+        int rc = for_members(g, [&](size_t i) -> int {
+            Member& mem = g->m[i];
+            (void)hipSetDevice(mem.ctx->device);
+            std::vector<const uint32_t*> ptr; std::vector<uint64_t> cnt; bool skip;
+            member_id_slices(g, i, result_ids, n_result_ids, n_queries, sample_mod, ptr, cnt, &skip);
+            if (skip) return TSGPU_OK;
+            return tsgpu_facet_range_count_batch(mem.ctx, facet_field_id, value_column, range_upper, range_lower, n_ranges, ptr.data(), cnt.data(), n_queries, sample_mod,
+                                                 TSGPU_NO_COLUMN, 0, (uint32_t*)mine[i].data());
+        });
+        if ((rc = agree(g, rc, call_signature({11, n_queries, n_ranges, sample_mod})))) return rc;
+        std::vector<uint8_t> all;
+        if ((rc = gather_host_blocks(g, mine, bytes, all))) return rc;
+        for (size_t w = 0; w < words; w++) {
+            uint64_t c = 0;
+            for (uint32_t r = 0; r < g->n; r++) c += ((const uint32_t*)(all.data() + r * bytes))[w];
+            counts[w] = (uint32_t)std::min<uint64_t>(c, 0xFFFFFFFFull);
+        }
+        return ok();
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_facet_range_count_batch: host allocation failed"); }
+      catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_facet_range_count_batch: could not start a member thread"); }
+}
+
+// Facet stats (tsgpu_facet_stats_batch; compute_facet_stats, src/index.cpp:1430-1460) over doc-range shards: min of the minima, max of the maxima, the counts and the
+// sums add up (integer fields: every partial sum is an exact integer in a double while the TOTAL count * max|value| < 2^53 — sum_exact is recomputed from the merged
+// values; float fields: the reference's in-order sum up to double rounding, as on one GPU). Shards that saw nothing carry the reference's initial values, which merge away.
+int tsgpu_group_facet_stats_batch(tsgpu_group* g, uint32_t facet_field_id, int value_type, const uint32_t* const* result_ids, const uint64_t* n_result_ids, uint32_t n_queries,
+                                  uint32_t sample_mod, const uint32_t* int64_map_hashes, const int64_t* int64_map_values, uint32_t n_map, tsgpu_facet_stats* out) {
+    if (!g || (n_queries && (!result_ids || !n_result_ids || !out))) return fail(TSGPU_ERR_INVALID, "tsgpu_group_facet_stats_batch: NULL argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (n_queries == 0) return agree(g, TSGPU_OK, call_signature({12, 0}));
+    try {
+        const size_t bytes = (size_t)n_queries * sizeof(tsgpu_facet_stats);
+        static_assert(sizeof(tsgpu_facet_stats) % 8 == 0, "gathered in 8-byte words");
+        std::vector<std::vector<uint8_t>> mine(g->m.size(), std::vector<uint8_t>(bytes, 0));
+        // (a member that is skipped — replicas — must still carry the initial values: it runs the call on EMPTY lists)
+        int rc = for_members(g, [&](size_t i) -> int {
+            Member& mem = g->m[i];
+            (void)hipSetDevice(mem.ctx->device);
+            std::vector<const uint32_t*> ptr; std::vector<uint64_t> cnt; bool skip;
+            member_id_slices(g, i, result_ids, n_result_ids, n_queries, sample_mod, ptr, cnt, &skip);
+            if (skip) std::fill(cnt.begin(), cnt.end(), 0ull);
+            return tsgpu_facet_stats_batch(mem.ctx, facet_field_id, value_type, ptr.data(), cnt.data(), n_queries, sample_mod, int64_map_hashes, int64_map_values, n_map,
+                                           (tsgpu_facet_stats*)mine[i].data());
+        });
+        if ((rc = agree(g, rc, call_signature({12, n_queries, (uint64_t)value_type, sample_mod, n_map})))) return rc;
+        std::vector<uint8_t> all;
+        if ((rc = gather_host_blocks(g, mine, bytes, all))) return rc;
+        for (uint32_t q = 0; q < n_queries; q++) {
+            tsgpu_facet_stats m = ((const tsgpu_facet_stats*)all.data())[q];
+            for (uint32_t r = 1; r < g->n; r++) {
+                const tsgpu_facet_stats& x = ((const tsgpu_facet_stats*)(all.data() + r * bytes))[q];
+                m.fvmin = std::min(m.fvmin, x.fvmin); m.fvmax = std::max(m.fvmax, x.fvmax); m.fvsum += x.fvsum; m.fvcount += x.fvcount;
+            }
+            if (m.fvcount == 0) m.sum_exact = 1;
+            else if (value_type == TSGPU_FACET_FLOAT) m.sum_exact = 0;
+            else m.sum_exact = ( (long double)m.fvcount * (long double)std::max(std::fabs(m.fvmin), std::fabs(m.fvmax)) < 9007199254740992.0L) ? 1 : 0;
+            m.pad = 0;
+            out[q] = m;
+        }
+        return ok();
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_facet_stats_batch: host allocation failed"); }
+      catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_facet_stats_batch: could not start a member thread"); }
+}
+
 // Candidate-token combinations over doc-range shards (Index::search_all_candidates, /root/reference/src/index.cpp:1794-1894; the single-GPU form:
 // tsgpu_keyword_search_candidates_batch). The fold of a user query's passes is per KEY (a key met by several passes keeps its greatest KV, the later pass on ties,
 // include/topster.h:392-406) and a document lives in ONE shard, so every shard folds its own passes and the shards' folded Topsters are merged like any keyword

@@ -730,6 +730,32 @@ class GpuGroup:
                                                              _vp(a) if a is not None else None, a.size if a is not None else 0, C.byref(out)))
         return [(h[q, :min(nv[q], cap)].copy(), c[q, :min(nv[q], cap)].copy(), d[q, :min(nv[q], cap)].copy(), p[q, :min(nv[q], cap)].copy(), int(nv[q])) for q in range(n)]
 
+    def facet_range_count_batch(self, field_id, value_column, ranges, id_lists, sample_mod=1):
+        """tsgpu_group_facet_range_count_batch: ranges = [(upper, lower), ...] in ascending upper order -> counts uint32 [n_queries][n_ranges]"""
+        lists = [_u32(x) for x in id_lists]
+        n = len(lists)
+        ptrs = (C.c_void_p * max(n, 1))(*[x.ctypes.data if x.size else None for x in lists])
+        cnts = np.array([x.size for x in lists], np.uint64)
+        up = np.ascontiguousarray([r[0] for r in ranges], dtype=np.int64)
+        lo = np.ascontiguousarray([r[1] for r in ranges], dtype=np.int64)
+        counts = np.zeros((n, len(ranges)), np.uint32)
+        B.check(self.L, self.L.tsgpu_group_facet_range_count_batch(self.h, field_id, value_column, _vp(up), _vp(lo), len(ranges), C.cast(ptrs, C.c_void_p), _vp(cnts), n, sample_mod, _vp(counts)))
+        return counts
+
+    def facet_stats_batch(self, field_id, value_type, id_lists, sample_mod=1, int64_map=None):
+        """tsgpu_group_facet_stats_batch -> per query (fvmin, fvmax, fvsum, fvcount, sum_exact)"""
+        lists = [_u32(x) for x in id_lists]
+        n = len(lists)
+        ptrs = (C.c_void_p * max(n, 1))(*[x.ctypes.data if x.size else None for x in lists])
+        cnts = np.array([x.size for x in lists], np.uint64)
+        out = (B.FacetStatsC * n)()
+        mh = mv = None
+        if int64_map is not None:
+            mh, mv = _u32(int64_map[0]), np.ascontiguousarray(int64_map[1], dtype=np.int64)
+        B.check(self.L, self.L.tsgpu_group_facet_stats_batch(self.h, field_id, value_type, C.cast(ptrs, C.c_void_p), _vp(cnts), n, sample_mod,
+                                                             _vp(mh) if mh is not None else None, _vp(mv) if mv is not None else None, mh.size if mh is not None else 0, C.cast(out, C.c_void_p)))
+        return [(o.fvmin, o.fvmax, o.fvsum, int(o.fvcount), int(o.sum_exact)) for o in out]
+
     def keyword_search_candidates_batch(self, groups, k, k_stride=None, want_found=True):
         """tsgpu_group_keyword_search_candidates_batch: groups = per user query the list of candidate-token combinations (KwQuery, pass order).
         Returns (Hits [n_groups], query_index [n_groups, k_stride] u32, found [n_groups] u64 or None) — Index::search_all_candidates over the shards."""
