@@ -659,6 +659,14 @@ int tsgpu_group_keyword_search_candidates_batch(tsgpu_group* g, const tsgpu_kw_q
  * num_docs, which is what a single GPU wants) — and the per-shard Topsters take the keyword exchange; num_matched = the ids ranked, added up. 400 when a member of
  * a group of several has no range. */
 int tsgpu_group_wildcard_search_batch(tsgpu_group* g, const tsgpu_kw_query* queries, uint32_t n_queries, uint32_t k, tsgpu_hits* out);
+/* group_by over doc-range shards: tsgpu_keyword_search_grouped_batch (one combination per query; first or second pass, keyword or q = *) when a group's documents live on
+ * several shards. Round 1: every shard's `capacity` best groups with their greatest KVs -> per distinct key the greatest head, the collection's `capacity` best groups,
+ * best first (a group the collection selects is among the best of the shard that holds its head); round 2: every shard answers for exactly those groups (slot r = group r:
+ * its member count and its group_limit greatest KVs on that shard) -> group_found adds up, a group's KVs merge to its group_limit greatest, groups_count = cardinality of the
+ * shards' LogLogBeta registers merged by their maxima (first pass), num_matched adds up. Results are those of the one-GPU call on the whole collection
+ * (Topster(capacity, distinct, first_pass), include/topster.h:266-466; populate_result_kvs, src/index.cpp:8962-9011). gout->groups_total must be NULL (the exact distinct-key
+ * count is not computed across shards: 501); matched-id lists are not offered. Every member needs its doc range for q = * queries. out / gout: HOST arrays. */
+int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries, tsgpu_hits* out, tsgpu_grouped_hits* gout);
 /* "kw_exchange_slices" = 1 (default): the keyword exchange is an ncclAllToAll of query slices (member j receives only the records of
  * the 1/G of the batch it merges), a slice merge per member, and in-place ncclAllGathers of the merged lists (rank form / device outputs;
  * the local form with host outputs delivers every slice over its own GPU's PCIe link); 0: ONE ncclAllGather of the per-GPU top-k

@@ -33,6 +33,8 @@ def load_shard(g, orc, lo, hi, pts, n_docs, X, dim):
             new_off.extend(off[oi[j]:ends[j]])
         g.term_upsert(0, int(term), ids[sel], new_oi, new_off)
     g.column_set(0, pts)
+    from tests.test_emu_groupby import group_column
+    g.column_set(1, group_column(n_docs, seed=3)[0].view(np.int64))              # the group_by column (Index::get_distinct_id per document)
     g.set_num_docs(n_docs)
     g.commit()
     g.set_option("doc_range_lo", lo); g.set_option("doc_range_hi", hi)          # the seq_ids this shard owns (q = * ranks only those)
@@ -175,6 +177,21 @@ def main():
             m = int(wh.n_hits[i])
             check("wildcard %s q%d" % (cut_name, i), wh.status[i] == 0 and m == min(K, ref.keys.size) and np.array_equal(wh.keys[i, :m], ref.keys[:m]) and
                   np.array_equal(wh.scores[i, :m], ref.scores[:m]) and int(wh.num_matched[i]) == int(ref.num_keyword_matches))
+        # group_by over the ranks (tsgpu_group_keyword_search_grouped_batch): two rounds of gathers (heads, then the given groups' counts and KVs), merged on every rank
+        from tests.test_emu_groupby import group_column, check_query, oracle_grouped, oracle_grouped_wildcard
+        distinct, has_value = group_column(n_docs, seed=3)
+        gqs = [T.KwQuery([1, 2], sort=sort, topster_size=250), T.KwQuery([3], sort=sort, topster_size=4), T.KwQuery([79, 80], sort=sort, topster_size=K),
+               T.KwQuery([4, 9], sort=sort, topster_size=6, filter_ids=np.arange(0, n_docs, 2, dtype=np.uint32))]
+        glim = [3, 2, 3, 1]
+        for first_pass in (1, 0):
+            grs = [(glim[i], 1, first_pass, 0, 0) for i in range(len(gqs))] + [(2, 1, first_pass, 0, 1)]
+            try:
+                h, gh = grp.keyword_search_grouped_batch(gqs + [wq[1]], grs, k_stride=750, g_stride=250, want_registers=bool(first_pass))
+                for i, q in enumerate(gqs):
+                    check_query(h, gh, i, oracle_grouped(orc, q, distinct, has_value, glim[i], first_pass), first_pass, glim[i], "group_by", check_total=False)
+                check_query(h, gh, len(gqs), oracle_grouped_wildcard(wq[1], n_docs, pts, distinct, 2, first_pass), first_pass, 2, "group_by wildcard", check_total=False)
+            except AssertionError as e:
+                check("group_by %s pass %d: %s" % (cut_name, first_pass, str(e)[:300]), False)
         dm, lm, cm = grp.vec_knn_batch(1, Q, k_vec)
         check_knn("knn " + cut_name, dm, lm, cm)
         allow = np.arange(3, n_docs, 5, dtype=np.uint32)

@@ -35,11 +35,11 @@ def sort_key_rows(keys, scores):
     return sorted([(int(s[0]), int(s[1]), int(s[2]), int(k)) for k, s in zip(keys, scores)], reverse=True)
 
 
-def check_query(h, gh, i, ref, first_pass, group_limit, what=""):
+def check_query(h, gh, i, ref, first_pass, group_limit, what="", check_total=True):
     assert int(h.status[i]) == 0, (what, h.status[i])
     ng = int(gh.n_groups[i])
     assert ng == ref.n_groups, "%s q%d: %d groups vs oracle %d" % (what, i, ng, ref.n_groups)
-    assert int(gh.groups_total[i]) == ref.groups_exact, what
+    assert not check_total or int(gh.groups_total[i]) == ref.groups_exact, what
     assert int(h.num_matched[i]) == ref.num_keyword_matches, what
     if first_pass:
         # the reference keeps these KVs in heap-array order and reads them as a set; the library returns them best first

@@ -10,7 +10,9 @@ import typesense_amd as T
 from typesense_amd import _lib as B
 from oracle import oracle_py as O
 from tests import helpers as H
+from tests.test_emu_groupby import group_column, check_query, oracle_grouped, oracle_grouped_wildcard
 
+GROUP_COL = 1
 SORT = ((B.SORT_TEXT_MATCH, 1, 0), (B.SORT_INT64_COLUMN, 1, 0))
 OSORT = ((O.SORT_TEXT_MATCH, 0, 1), (O.SORT_INT64_COLUMN, 0, 1))
 
@@ -30,9 +32,11 @@ def build_group(lib, cuts, n_docs, dim, transport, seed=8):
     fptr, fhash = H.facet_csr_of(n_docs)
     orc.facet_set(5, fptr, fhash)
     members = []
+    distinct, _ = group_column(n_docs, seed=3)
     for lo, hi in zip(cuts[:-1], cuts[1:]):
         g = T.GpuIndex(0, lib)
         H.load_shard(g, orc, lo, hi, n_docs, pts)
+        g.column_set(GROUP_COL, distinct.view(np.int64))                             # Index::get_distinct_id per document (the group_by column; global seq_ids)
         g.facet_set(5, *H.facet_csr_shard(fptr, fhash, lo, hi))                      # the facet hash index of the shard's own documents
         g.set_option("doc_range_lo", lo); g.set_option("doc_range_hi", hi)          # the seq_ids this shard OWNS (q = * ranks only those)
         g.vec_create(1, dim, B.METRIC_IP)
@@ -93,6 +97,7 @@ def check_group(orc, grp, rng, n_docs, dim):
     assert (wh.status == 0).all()
     for i, q in enumerate(wq):
         H.assert_hits_equal(wh, i, H.oracle_wildcard(orc, q), "group wildcard")
+    check_group_by(orc, grp, rng, n_docs, filt)
     # ---- facet counts over the shards (do_facets' hash-index branch): counts add up, doc_id / array_pos of the greatest document; a small cap (truncated lists
     #      merge exactly for the first cap values), a facet query's allowed hashes, estimate_facets' sampling of the WHOLE list ----
     id_lists = [np.arange(n_docs, dtype=np.uint32), filt, filt[::5], np.array([], np.uint32), np.array([3, n_docs - 1], np.uint32)]
@@ -168,6 +173,42 @@ def check_group(orc, grp, rng, n_docs, dim):
         one_sided += int((ref.text_match == 0).sum())
 
 
+def check_group_by(orc, grp, rng, n_docs, filt):
+    """group_by over the shards (tsgpu_group_keyword_search_grouped_batch): both passes, keyword and q = *, against the UNSHARDED oracle's distinct Topster.
+    Small Topsters: a group the collection selects is missing from the best groups of most shards (its documents there still count and compete for its KVs)."""
+    distinct, has_value = group_column(n_docs, seed=3)
+    pts = H.points_of(n_docs)
+    wsort = ((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, 1, 0))
+    qs = [T.KwQuery([1, 2], sort=SORT, topster_size=250), T.KwQuery([3], sort=SORT, topster_size=5), T.KwQuery([2], sort=SORT, topster_size=3),
+          T.KwQuery([4, 9], sort=SORT, topster_size=250, filter_ids=filt), T.KwQuery([2, 3], sort=SORT, topster_size=7, excluded_ids=filt[::2]),
+          T.KwQuery([79, 78], sort=SORT, topster_size=40), T.KwQuery([80, 1], sort=SORT, topster_size=40),        # rare terms: an empty list on some shards
+          T.KwQuery([77, 78, 79], sort=SORT, topster_size=40),                                                    # matches nothing anywhere
+          T.KwQuery([1], sort=SORT, topster_size=0)]
+    limits = [3, 1, 2, 3, 3, 2, 3, 3, 5]
+    wq = [T.KwQuery([], sort=wsort, topster_size=40), T.KwQuery([], sort=((B.SORT_INT64_COLUMN, -1, 0), (B.SORT_SEQ_ID, -1, 0)), topster_size=6, filter_ids=filt),
+          T.KwQuery([], sort=wsort, topster_size=4, excluded_ids=filt[::2]), T.KwQuery([], sort=wsort, topster_size=40, filter_ids=filt[:3])]
+    wlimits = [3, 2, 4, 3]
+    for first_pass in (1, 0):
+        for gmv in (0, 1):
+            groups = [(limits[i], GROUP_COL, first_pass, gmv, 0) for i in range(len(qs))] + [(wlimits[i], GROUP_COL, first_pass, gmv, 1) for i in range(len(wq))]
+            h, gh = grp.keyword_search_grouped_batch(qs + wq, groups, k_stride=250 * 5, g_stride=250, want_registers=bool(first_pass))
+            for i, q in enumerate(qs):
+                ref = oracle_grouped(orc, q, distinct, has_value, limits[i], first_pass, gmv=bool(gmv))
+                check_query(h, gh, i, ref, first_pass, limits[i], "group group_by kw pass%d gmv%d" % (first_pass, gmv), check_total=False)
+            for j, q in enumerate(wq):
+                ref = oracle_grouped_wildcard(q, n_docs, pts, distinct, wlimits[j], first_pass, gmv=bool(gmv))
+                check_query(h, gh, len(qs) + j, ref, first_pass, wlimits[j], "group group_by wildcard pass%d gmv%d" % (first_pass, gmv), check_total=False)
+    # a bad query next to good ones (unknown group column -> 404 on every shard), strides too small for the capacity (400), groups_total asked for across shards (501)
+    h, gh = grp.keyword_search_grouped_batch([qs[0], qs[1], qs[0]], [(3, GROUP_COL, 0, 0, 0), (1, 77, 0, 0, 0), (3, GROUP_COL, 0, 0, 0)], k_stride=300, g_stride=250)
+    assert h.status.tolist() == [B.ERR_INVALID, B.ERR_NOT_FOUND, B.ERR_INVALID] and h.n_hits.sum() == 0
+    h, gh = grp.keyword_search_grouped_batch([qs[1], qs[1]], [(1, GROUP_COL, 0, 0, 0), (1, 77, 1, 0, 0)], k_stride=300, g_stride=250)
+    assert h.status.tolist() == [0, B.ERR_NOT_FOUND]
+    check_query(h, gh, 0, oracle_grouped(orc, qs[1], distinct, has_value, 1, 0), 0, 1, "next to a bad query", check_total=False)
+    if grp.size() > 1 and not getattr(grp, "replicas_form", False):
+        with pytest.raises(T.TsgpuError):
+            grp.keyword_search_grouped_batch(qs[:1], [(3, GROUP_COL, 1, 0, 0)], k_stride=750, g_stride=250, want_totals=True)
+
+
 def device_output_equals_host_output(grp, n_docs):
     """`out` in device memory (of member 0): the merged slices are replicated there; same content as the host delivery"""
     qs = [T.KwQuery(t, sort=SORT, topster_size=40) for t in ([1, 2], [3], [2, 5], [4, 9, 1], [6])]
@@ -226,6 +267,7 @@ def test_replicas_form_cuts_the_batch_into_query_slices():
     grp = T.GpuGroup(mirrors + [mirrors[0]], B.XCHG_COPY)                                    # 3 replicas (two share a context: allowed)
     try:
         grp.set_option("replicas", 1)
+        grp.replicas_form = True
         check_group(orc, grp, rng, n_docs, dim)
         device_output_equals_host_output(grp, n_docs)
     finally:
@@ -311,6 +353,23 @@ def test_rccl_transport_one_rank_form_runs_the_real_collective():
         for i in range(2):
             n = int(pf_.n_hits[i])
             assert int(gf.n_hits[i]) == n and np.array_equal(gf.keys[i, :n], pf_.keys[i, :n]) and np.array_equal(gf.scores[i, :n], pf_.scores[i, :n]) and np.array_equal(gf.text_match[i, :n], pf_.text_match[i, :n])
+        # group_by through the same transport (two rounds of ncclAllGather'd host blocks): equals the plain grouped call on the one context
+        distinct, _ = group_column(20000, seed=3)
+        g.column_set(GROUP_COL, distinct.view(np.int64))
+        gq = [T.KwQuery([1, 2], sort=SORT, topster_size=250), T.KwQuery([9], sort=SORT, topster_size=5), wq[0]]
+        for first_pass in (1, 0):
+            grs = [(3, GROUP_COL, first_pass, 0, 0), (2, GROUP_COL, first_pass, 0, 0), (2, GROUP_COL, first_pass, 0, 1)]
+            ph_, pg = g.keyword_search_grouped_batch(gq, grs, k_stride=750, g_stride=250, want_registers=bool(first_pass))
+            sh_, sg = grp.keyword_search_grouped_batch(gq, grs, k_stride=750, g_stride=250, want_registers=bool(first_pass))
+            for i in range(len(gq)):
+                ng = int(pg.n_groups[i])
+                assert int(sh_.status[i]) == 0 and int(sg.n_groups[i]) == ng and int(sh_.n_hits[i]) == int(ph_.n_hits[i]) and int(sh_.num_matched[i]) == int(ph_.num_matched[i]), (first_pass, i)
+                assert np.array_equal(sg.distinct_key[i, :ng], pg.distinct_key[i, :ng]) and np.array_equal(sg.group_found[i, :ng], pg.group_found[i, :ng]) and np.array_equal(sg.group_size[i, :ng], pg.group_size[i, :ng])
+                L = 1 if first_pass else grs[i][0]
+                for r in range(ng):
+                    n = int(pg.group_size[i, r])
+                    assert np.array_equal(sh_.keys[i, r * L:r * L + n], ph_.keys[i, r * L:r * L + n]) and np.array_equal(sh_.scores[i, r * L:r * L + n], ph_.scores[i, r * L:r * L + n]), (first_pass, i, r)
+                assert int(sg.groups_count[i]) == int(pg.groups_count[i]) and (not first_pass or np.array_equal(sg.loglog_registers[i], pg.loglog_registers[i]))
         g.facet_set(5, *H.facet_csr_of(20000))
         id_lists = [np.arange(20000, dtype=np.uint32), np.arange(1, 20000, 3, dtype=np.uint32)]
         for cap in (512, 6):

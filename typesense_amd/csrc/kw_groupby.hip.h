@@ -63,10 +63,12 @@ struct GbQuery {
     uint32_t first_block;     // the query's first workgroup in the per-item launches (ceil(n_items / GB_THREADS) workgroups each: no workgroup spans two queries)
     uint32_t first_sblock;    // ... and in the member scatter (ceil(n_items / GB_SCATTER_ITEMS) workgroups each)
     uint8_t first_pass, group_missing_values, wildcard, run;   // run = 0: the query failed upstream, nothing is produced
-    uint8_t iota, dedupe, pad[6];   // iota: q = * over the whole collection, the matched ids are 0 .. n_items - 1 (gb_iota_kernel writes them); dedupe: a SECOND pass over several
+    uint8_t iota, dedupe, forced, pad[5];   // forced: the groups to return are GIVEN (forced_begin / n_forced below). iota: q = * over the whole collection, the matched ids are 0 .. n_items - 1 (gb_iota_kernel writes them); dedupe: a SECOND pass over several
                               // candidate combinations — a document met by several of them counts once, with its greatest KV (the later combination on ties)
     uint32_t pw_begin, pw_cap;      // second pass: the query's chunk work list (entries [pw_begin, pw_begin + pw_cap): n_items / GB_CHUNK + n_items / GB_BIG + 1 at most)
     uint64_t pbuf_off;              // ... and its partial top-L buffer (pw_cap x group_limit entries)
+    uint32_t forced_begin, n_forced; // forced = 1 (a doc-range shard answering for the groups the whole collection selected, tsgpu_group_keyword_search_grouped_batch): returned group r
+                              // IS the key GbArgs::forced_keys[forced_begin + r], r < n_forced <= k — present on this shard or not (then group_found = group_size = 0)
     uint32_t first_combo, n_combos; // the user query's candidate combinations (search_all_candidates: one search_across_fields pass each; 1 = a plain pass): its items are the
                               // combinations' matched ids one after the other, combination c at items [combo_begin[c], combo_begin[c + 1])
 };
@@ -74,6 +76,7 @@ struct GbQuery {
 struct GbArgs {
     const GbQuery* gq; uint32_t n_queries;
     const KwQueryDev* queries; const KwQueryMF* mfs;                       // per COMBINATION
+    const unsigned long long* forced_keys;                                     // the given groups of the forced queries (GbQuery::forced_begin)
     const unsigned long long* combo_begin; const uint32_t* qidx_of_combo;   // per combination: first item; KV::query_index of its hits (earlier combinations of the user query that matched)
     uint8_t* pass;                                                             // per matched id: which combination of its user query met it
     uint32_t* dkey32; uint32_t* dbest;                                         // per table slot, dedupe only: the document table (seq_id -> its greatest record)
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(GB_THREADS) void gb_select_kernel(GbArgs a) {
     for (uint32_t w = t; w < GB_LOGLOG_M / 4; w += GB_THREADS) regs[w] = 0;
     __syncthreads();
     const uint32_t n_used = a.gcount[qi];                                    // distinct keys of the pass (gb_insert_kernel listed their slots)
-    for (uint32_t base = 0; base < n_used; base += GB_THREADS) {
+    for (uint32_t base = 0; base < n_used && !g.forced; base += GB_THREADS) {
         const bool have = base + t < n_used;
         uint32_t slot = 0;
         int64_t e0 = 0, e1 = 0, e2 = 0, ek = -1;
@@ -394,12 +397,46 @@ __global__ __launch_bounds__(GB_THREADS) void gb_select_kernel(GbArgs a) {
         }
         __syncthreads();
     }
-    topk_compact<CAP, true>(tk, &s_cnt, g.k, thr, &s_have);
-    const uint32_t n = s_cnt;                                                // min(k, groups), sorted descending
+    if (!g.forced) topk_compact<CAP, true>(tk, &s_cnt, g.k, thr, &s_have);
+    const uint32_t n = g.forced ? g.n_forced : s_cnt;                        // min(k, groups), sorted descending — or the given groups, in the given order
     int msi = -1;
     for (int i = 0; i < 3; i++) if (i < (int)a.queries[g.first_combo].n_sort && a.queries[g.first_combo].sort_kind[i] == 0) msi = i;
     const uint32_t* qids = a.ids + g.item_begin;
-    for (uint32_t r = t; r < n; r += GB_THREADS) {
+    // the given groups (forced): returned group r is the r-th given key — looked up in the table this shard's matched documents built; a key without documents
+    // here is returned empty (group_found = group_size = 0, no hit), so that slot r means the same group on every shard
+    for (uint32_t r = t; g.forced && r < n; r += GB_THREADS) {
+        const unsigned long long dk = a.forced_keys[g.forced_begin + r];
+        uint32_t slot = GB_NONE;
+        if (g.n_items) {
+            if (dk == GB_EMPTY) { if (a.hcount[g.tab_off + g.tab_mask + 1]) slot = g.tab_mask + 1; }
+            else {
+                for (uint32_t s = (uint32_t)gb_mix(dk) & g.tab_mask;; s = (s + 1) & g.tab_mask) {      // (the table is at most half full: an empty slot ends the probe)
+                    const unsigned long long cur = a.hkey[g.tab_off + s];
+                    if (cur == dk) { slot = s; break; }
+                    if (cur == GB_EMPTY) break;
+                }
+            }
+        }
+        a.g_dkey[gbase + r] = dk;
+        if (slot == GB_NONE) { a.g_found[gbase + r] = 0; a.g_size[gbase + r] = 0; continue; }
+        a.hrank[g.tab_off + slot] = r;
+        const uint32_t members = a.hcount[g.tab_off + slot];
+        a.g_found[gbase + r] = members;
+        a.g_size[gbase + r] = g.first_pass ? 1u : (members < g.group_limit ? members : g.group_limit);
+        if (g.first_pass) {
+            const uint32_t lo = a.hbest[g.tab_off + slot];
+            const uint64_t b = g.item_begin + lo;
+            const size_t o = (size_t)qi * a.out.k_stride + r;
+            const int64_t e0 = a.s0[b], e1 = a.s1[b], e2 = a.s2[b];
+            a.out.keys[o] = a.ids[b];
+            a.out.scores[o * 3 + 0] = e0; a.out.scores[o * 3 + 1] = e1; a.out.scores[o * 3 + 2] = e2;
+            a.out.text_match[o] = msi == 0 ? e0 : (msi == 1 ? e1 : (msi == 2 ? e2 : 0));
+            a.out.vector_distance[o] = -1.0f;
+            a.out.match_score_index[o] = (int8_t)msi;
+            a.out_qidx[o] = a.qidx_of_combo[g.first_combo + a.pass[b]];
+        }
+    }
+    for (uint32_t r = t; !g.forced && r < n; r += GB_THREADS) {
         const uint32_t key = (uint32_t)tk.key[r];
         // the record of the entry: its id's position in a combination's ascending ids — the one its group's table names as the best record
         uint32_t lo = 0;
@@ -458,7 +495,7 @@ __global__ __launch_bounds__(GB_THREADS) void gb_select_kernel(GbArgs a) {
         } else a.pw_count[qi] = 0;
         a.out.n_hits[qi] = hits;
     }
-    if (g.first_pass) {
+    if (g.first_pass && !g.forced) {                                         // (a forced pass repeats a pass whose sketch the caller already holds)
         // what LogLogBeta::cardinality() reads: how many registers hold each value (the host sums 2^-value over them), and the registers themselves on request
         if (t < GB_LOGLOG_HIST) hist[t] = 0;
         __syncthreads();

@@ -1196,6 +1196,216 @@ int tsgpu_group_keyword_search_candidates_batch(tsgpu_group* g, const tsgpu_kw_q
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_candidates_batch: host allocation failed"); }
 }
 
+// group_by over doc-range shards (tsgpu_keyword_search_grouped_batch on one GPU; Topster(capacity, distinct, first_pass), /root/reference/include/topster.h:266-466,
+// populate_result_kvs' grouped branch, src/index.cpp:8962-9011). A group's documents live on SEVERAL shards, so a top-k exchange is not enough — the exchange is keyed:
+//   round 1  every shard runs the pass as a FIRST pass: its `capacity` best groups, each with its greatest KV (+ the sketch registers of a first pass). A group the whole
+//            collection selects is among the best `capacity` of the shard that holds its greatest KV (fewer than `capacity` groups beat it anywhere), so the union of the
+//            shards' lists — per distinct key the greatest head — holds the collection's selection: its `capacity` greatest heads, best first, on every rank alike.
+//   round 2  every shard runs the pass again with those groups GIVEN (GbShard::forced_keys): slot r = group r on every shard — its member count here and, second pass,
+//            its group_limit greatest KVs here. The counts add up (groups_processed), a group's KV lists merge to its group_limit greatest (a document lives in one shard).
+// groups_count: the shards' LogLogBeta registers merge by their maxima (the sketch of the union); num_matched adds up. Each shard searches twice (the second pass of the
+// reference's own two-pass protocol costs as much); gout->groups_total — the exact number of distinct keys, not a reference quantity — is not computed across shards (501
+// unless NULL), ids_out is not offered. out / gout: HOST arrays, as on one GPU.
+int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries, tsgpu_hits* out, tsgpu_grouped_hits* gout) {
+    if (!g || !out || !gout || (n_queries && (!queries || !groups))) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_grouped_batch: NULL argument");
+    if (n_queries == 0) { std::lock_guard<std::mutex> lk0(g->mu); return agree(g, TSGPU_OK, call_signature({13, 0})); }
+    int pre = TSGPU_OK;
+    if (out->mem != TSGPU_MEM_HOST) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_grouped_batch: host output arrays only");
+    else if (!out->keys || !out->scores || !out->n_hits || !out->status) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_grouped_batch: keys / scores / n_hits / status are required");
+    else if (!gout->n_groups || !gout->distinct_key || !gout->group_size || !gout->group_found || gout->g_stride == 0 || out->k_stride == 0)
+        pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_grouped_batch: n_groups / distinct_key / group_size / group_found and the strides are required");
+    else if (gout->groups_total && !g->replicas) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_grouped_batch: groups_total (the exact distinct-key count) is not computed across shards: pass NULL");
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (pre) return agree(g, pre, 0);
+    const uint64_t omask = hits_mask(out) | (gout->groups_count ? 1ull << 20 : 0) | (gout->loglog_registers ? 1ull << 21 : 0) | (gout->groups_total ? 1ull << 22 : 0);
+    if (g->replicas) {
+        // every member mirrors the WHOLE collection: member 0 / this rank answers alone
+        int rc = agree(g, TSGPU_OK, call_signature({14, n_queries, out->k_stride, gout->g_stride, omask}));
+        if (rc) return rc;
+        return tsgpu_keyword_search_grouped_batch(g->m[0].ctx, queries, groups, n_queries, out, gout, nullptr);
+    }
+    try {
+        // 0) token existence is a property of the whole collection (group_keyword_core's step 0)
+        bool same_dict = true, any_kw = false;
+        for (uint32_t i = 0; i < n_queries; i++) any_kw = any_kw || !groups[i].wildcard;
+        if (g->local) same_dict = g->n == 1 || !any_kw || local_dictionaries_equal(g);
+        else { int rc0 = agree(g, TSGPU_OK, call_signature({13, n_queries, out->k_stride, gout->g_stride, omask}), any_kw ? kw_dictionary_fingerprint(g->m[0].ctx) : 0ull, &same_dict); if (rc0) return rc0; }
+        if (!same_dict) { int rc0 = exchange_token_masks(g, queries, n_queries); if (rc0) return rc0; }
+        const size_t nm = g->m.size();
+        std::vector<uint32_t> caps(n_queries, 0u);
+        group_resolve_topster_sizes(g->m[0].ctx, queries, n_queries, caps.data());
+        uint32_t K1 = 1;
+        bool want_regs = false;
+        for (uint32_t i = 0; i < n_queries; i++) { K1 = std::max(K1, std::min<uint32_t>(caps[i], TSGPU_MAX_TOPK)); want_regs = want_regs || (groups[i].first_pass && (gout->groups_count || gout->loglog_registers)); }
+        std::vector<tsgpu_group_by> g1(groups, groups + n_queries);
+        for (auto& x : g1) x.first_pass = 1;
+        // ---- round 1: every shard's best groups and their heads ----
+        struct Hdr1 { int32_t status, cutoff; uint32_t n_groups, pad; uint64_t num_matched; };
+        struct Ent1 { uint64_t dkey, key; int64_t s0, s1, s2; };
+        const size_t o_hdr = 0, o_ent = o_hdr + sizeof(Hdr1) * n_queries, o_regs = o_ent + sizeof(Ent1) * n_queries * K1, bytes1 = (o_regs + (want_regs ? (size_t)n_queries * 16384 : 0) + 7) & ~(size_t)7;
+        std::vector<std::vector<uint8_t>> mine(nm, std::vector<uint8_t>(bytes1, 0));
+        int rc = for_members(g, [&](size_t m) -> int {
+            Member& mem = g->m[m];
+            (void)hipSetDevice(mem.ctx->device);
+            const size_t slots = (size_t)n_queries * K1;
+            std::vector<uint64_t> keys(slots), nmv(n_queries), dk(slots);
+            std::vector<int64_t> sc(slots * 3);
+            std::vector<uint32_t> nh(n_queries), ng(n_queries), gsz(slots), gf(slots);
+            std::vector<int32_t> st(n_queries), co(n_queries);
+            tsgpu_hits h; memset(&h, 0, sizeof h);
+            h.mem = TSGPU_MEM_HOST; h.k_stride = K1; h.keys = keys.data(); h.scores = sc.data(); h.n_hits = nh.data(); h.num_matched = nmv.data(); h.status = st.data(); h.search_cutoff = co.data();
+            tsgpu_grouped_hits gh; memset(&gh, 0, sizeof gh);
+            gh.g_stride = K1; gh.n_groups = ng.data(); gh.distinct_key = dk.data(); gh.group_size = gsz.data(); gh.group_found = gf.data();
+            gh.loglog_registers = want_regs ? mine[m].data() + o_regs : nullptr;
+            const GbShard sh = {nullptr, nullptr, same_dict ? nullptr : mem.h_elsewhere.data()};
+            const int r = gb_shard_batch(mem.ctx, queries, g1.data(), n_queries, &h, &gh, &sh);
+            if (r) return r;
+            Hdr1* hd = (Hdr1*)(mine[m].data() + o_hdr);
+            Ent1* en = (Ent1*)(mine[m].data() + o_ent);
+            for (uint32_t i = 0; i < n_queries; i++) {
+                hd[i].status = st[i]; hd[i].cutoff = co[i]; hd[i].n_groups = st[i] == TSGPU_OK ? ng[i] : 0; hd[i].pad = 0; hd[i].num_matched = nmv[i];
+                for (uint32_t r2 = 0; r2 < hd[i].n_groups; r2++) {
+                    const size_t o = (size_t)i * K1 + r2;
+                    en[o].dkey = dk[o]; en[o].key = keys[o]; en[o].s0 = sc[o * 3]; en[o].s1 = sc[o * 3 + 1]; en[o].s2 = sc[o * 3 + 2];
+                }
+            }
+            return TSGPU_OK;
+        });
+        if ((rc = agree(g, rc, call_signature({13, 1, n_queries, K1, (uint64_t)want_regs})))) return rc;
+        std::vector<uint8_t> all1;
+        if ((rc = gather_host_blocks(g, mine, bytes1, all1))) return rc;
+        const size_t stride1 = bytes1;
+        // ---- the collection's selection per query: per distinct key its greatest head, the `capacity` greatest of those, best first (the same on every rank) ----
+        auto kv_greater = [](const Ent1& a, const Ent1& b) { if (a.s0 != b.s0) return a.s0 > b.s0; if (a.s1 != b.s1) return a.s1 > b.s1; if (a.s2 != b.s2) return a.s2 > b.s2; return (int64_t)a.key > (int64_t)b.key; };
+        std::vector<int32_t> status(n_queries, TSGPU_OK), cutoff(n_queries, 0);
+        std::vector<uint64_t> num_matched(n_queries, 0);
+        std::vector<uint32_t> fbegin((size_t)n_queries + 1, 0);
+        std::vector<uint64_t> fkeys;
+        std::vector<Ent1> pool;
+        uint32_t K2 = 1, G2 = 1;
+        for (uint32_t i = 0; i < n_queries; i++) {
+            pool.clear();
+            for (uint32_t r = 0; r < g->n; r++) {
+                const Hdr1& hd = ((const Hdr1*)(all1.data() + r * stride1 + o_hdr))[i];
+                if (hd.status != TSGPU_OK && status[i] == TSGPU_OK) status[i] = hd.status;
+                cutoff[i] = cutoff[i] || hd.cutoff; num_matched[i] += hd.num_matched;
+                const Ent1* en = (const Ent1*)(all1.data() + r * stride1 + o_ent) + (size_t)i * K1;
+                pool.insert(pool.end(), en, en + std::min<uint32_t>(hd.n_groups, K1));
+            }
+            if (status[i] == TSGPU_OK) {
+                std::sort(pool.begin(), pool.end(), [&](const Ent1& a, const Ent1& b) { return a.dkey != b.dkey ? a.dkey < b.dkey : kv_greater(a, b); });
+                pool.erase(std::unique(pool.begin(), pool.end(), [](const Ent1& a, const Ent1& b) { return a.dkey == b.dkey; }), pool.end());
+                std::sort(pool.begin(), pool.end(), kv_greater);
+                // the caller's strides against the CAPACITY, as on one GPU (tsgpu_groupby.inc.h): slot r * group_limit + j of a second pass
+                const uint32_t cap = std::min<uint32_t>(caps[i], TSGPU_MAX_TOPK), L = groups[i].first_pass ? 1u : groups[i].group_limit;
+                if (cap > gout->g_stride || (uint64_t)cap * L > out->k_stride) status[i] = TSGPU_ERR_INVALID;
+                else {
+                    const uint32_t n = (uint32_t)std::min<size_t>(pool.size(), cap);
+                    for (uint32_t r = 0; r < n; r++) fkeys.push_back(pool[r].dkey);
+                    K2 = std::max<uint32_t>(K2, n * L); G2 = std::max(G2, n);
+                }
+            }
+            fbegin[i + 1] = (uint32_t)fkeys.size();
+        }
+        // ---- round 2: the given groups on every shard ----
+        const size_t slots2 = (size_t)n_queries * K2, gsl2 = (size_t)n_queries * G2;
+        const size_t p_st = 0, p_found = p_st + (((size_t)n_queries * 8 + 7) & ~(size_t)7), p_size = p_found + ((gsl2 * 4 + 7) & ~(size_t)7), p_keys = p_size + ((gsl2 * 4 + 7) & ~(size_t)7),
+                     p_sc = p_keys + slots2 * 8, p_tm = p_sc + slots2 * 24, p_vd = p_tm + slots2 * 8, p_msi = p_vd + ((slots2 * 4 + 7) & ~(size_t)7), bytes2 = p_msi + ((slots2 + 7) & ~(size_t)7);
+        for (auto& b : mine) { b.assign(bytes2, 0); }
+        rc = for_members(g, [&](size_t m) -> int {
+            Member& mem = g->m[m];
+            (void)hipSetDevice(mem.ctx->device);
+            uint8_t* blk = mine[m].data();
+            std::vector<uint64_t> nmv(n_queries), dk(gsl2);
+            std::vector<uint32_t> nh(n_queries), ng(n_queries);
+            std::vector<int32_t> st(n_queries), co(n_queries);
+            tsgpu_hits h; memset(&h, 0, sizeof h);
+            h.mem = TSGPU_MEM_HOST; h.k_stride = K2; h.keys = (uint64_t*)(blk + p_keys); h.scores = (int64_t*)(blk + p_sc); h.text_match = (int64_t*)(blk + p_tm); h.vector_distance = (float*)(blk + p_vd);
+            h.match_score_index = (int8_t*)(blk + p_msi); h.n_hits = nh.data(); h.num_matched = nmv.data(); h.status = st.data(); h.search_cutoff = co.data();
+            tsgpu_grouped_hits gh; memset(&gh, 0, sizeof gh);
+            gh.g_stride = G2; gh.n_groups = ng.data(); gh.distinct_key = dk.data(); gh.group_size = (uint32_t*)(blk + p_size); gh.group_found = (uint32_t*)(blk + p_found);
+            const GbShard sh = {fkeys.data(), fbegin.data(), same_dict ? nullptr : mem.h_elsewhere.data()};
+            const int r = gb_shard_batch(mem.ctx, queries, groups, n_queries, &h, &gh, &sh);
+            if (r) return r;
+            int32_t* pst = (int32_t*)(blk + p_st);
+            for (uint32_t i = 0; i < n_queries; i++) {
+                pst[2 * i] = st[i]; pst[2 * i + 1] = co[i];
+                if (st[i] != TSGPU_OK) for (uint32_t r2 = 0; r2 < G2; r2++) ((uint32_t*)(blk + p_size))[(size_t)i * G2 + r2] = ((uint32_t*)(blk + p_found))[(size_t)i * G2 + r2] = 0;
+            }
+            return TSGPU_OK;
+        });
+        if ((rc = agree(g, rc, call_signature({13, 2, n_queries, K2, G2, fkeys.size()})))) return rc;
+        std::vector<uint8_t> all2;
+        if ((rc = gather_host_blocks(g, mine, bytes2, all2))) return rc;
+        // ---- merge: counts add up, a group's KV lists merge to its group_limit greatest ----
+        struct KV { int64_t s0, s1, s2; uint64_t key; int64_t tm; float vd; int8_t msi; };
+        auto kv2_greater = [](const KV& a, const KV& b) { if (a.s0 != b.s0) return a.s0 > b.s0; if (a.s1 != b.s1) return a.s1 > b.s1; if (a.s2 != b.s2) return a.s2 > b.s2; return (int64_t)a.key > (int64_t)b.key; };
+        std::vector<KV> kvs;
+        std::vector<uint8_t> regs(16384);
+        for (uint32_t i = 0; i < n_queries; i++) {
+            for (uint32_t r = 0; r < g->n && status[i] == TSGPU_OK; r++) {
+                const int32_t* pst = (const int32_t*)(all2.data() + r * bytes2 + p_st);
+                if (pst[2 * i] != TSGPU_OK) status[i] = pst[2 * i];
+                cutoff[i] = cutoff[i] || pst[2 * i + 1];
+            }
+            out->status[i] = status[i];
+            if (out->search_cutoff) out->search_cutoff[i] = cutoff[i];
+            if (out->num_matched) out->num_matched[i] = status[i] == TSGPU_OK ? num_matched[i] : 0;
+            if (gout->groups_count) gout->groups_count[i] = 0;
+            if (gout->loglog_registers) memset(gout->loglog_registers + (size_t)i * 16384, 0, 16384);
+            if (status[i] != TSGPU_OK) { out->n_hits[i] = 0; gout->n_groups[i] = 0; continue; }
+            const uint32_t n = fbegin[i + 1] - fbegin[i], L = groups[i].first_pass ? 1u : groups[i].group_limit;
+            uint32_t hits = 0;
+            for (uint32_t gr = 0; gr < n; gr++) {
+                uint64_t found = 0;
+                kvs.clear();
+                for (uint32_t r = 0; r < g->n; r++) {
+                    const uint8_t* blk = all2.data() + r * bytes2;
+                    found += ((const uint32_t*)(blk + p_found))[(size_t)i * G2 + gr];
+                    const uint32_t sz = std::min(((const uint32_t*)(blk + p_size))[(size_t)i * G2 + gr], L);
+                    for (uint32_t j = 0; j < sz; j++) {
+                        const size_t o = (size_t)i * K2 + (size_t)gr * L + j;
+                        KV kv;
+                        kv.key = ((const uint64_t*)(blk + p_keys))[o];
+                        const int64_t* sc = (const int64_t*)(blk + p_sc) + o * 3;
+                        kv.s0 = sc[0]; kv.s1 = sc[1]; kv.s2 = sc[2];
+                        kv.tm = ((const int64_t*)(blk + p_tm))[o]; kv.vd = ((const float*)(blk + p_vd))[o]; kv.msi = ((const int8_t*)(blk + p_msi))[o];
+                        kvs.push_back(kv);
+                    }
+                }
+                std::sort(kvs.begin(), kvs.end(), kv2_greater);
+                const uint32_t take = (uint32_t)std::min<size_t>(kvs.size(), L);
+                const size_t go = (size_t)i * gout->g_stride + gr;
+                gout->distinct_key[go] = fkeys[fbegin[i] + gr];
+                gout->group_found[go] = (uint32_t)std::min<uint64_t>(found, 0xFFFFFFFFull);
+                gout->group_size[go] = take;
+                for (uint32_t j = 0; j < take; j++) {
+                    const size_t o = (size_t)i * out->k_stride + (size_t)gr * L + j;
+                    out->keys[o] = kvs[j].key; out->scores[o * 3] = kvs[j].s0; out->scores[o * 3 + 1] = kvs[j].s1; out->scores[o * 3 + 2] = kvs[j].s2;
+                    if (out->text_match) out->text_match[o] = kvs[j].tm;
+                    if (out->vector_distance) out->vector_distance[o] = kvs[j].vd;
+                    if (out->match_score_index) out->match_score_index[o] = kvs[j].msi;
+                }
+                hits += take;
+            }
+            gout->n_groups[i] = n;
+            out->n_hits[i] = groups[i].first_pass ? n : hits;
+            if (groups[i].first_pass && want_regs) {
+                // the sketch of the union: the registers' maxima (LogLogBeta::merge), then cardinality() over them
+                std::fill(regs.begin(), regs.end(), 0);
+                for (uint32_t r = 0; r < g->n; r++) {
+                    const uint8_t* rr = all1.data() + r * stride1 + o_regs + (size_t)i * 16384;
+                    for (uint32_t x = 0; x < 16384; x++) regs[x] = std::max(regs[x], rr[x]);
+                }
+                if (gout->groups_count) gout->groups_count[i] = gb_registers_cardinality(regs.data());
+                if (gout->loglog_registers) memcpy(gout->loglog_registers + (size_t)i * 16384, regs.data(), 16384);
+            }
+        }
+        return ok();
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_grouped_batch: host allocation failed"); }
+      catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_grouped_batch: could not start a member thread"); }
+}
+
 int tsgpu_group_set_option(tsgpu_group* g, const char* name, int64_t value) {
     if (!g || !name) return fail(TSGPU_ERR_INVALID, "tsgpu_group_set_option: NULL argument");
     std::lock_guard<std::mutex> lk(g->mu);

@@ -135,8 +135,13 @@ void tsgpu_groupby_destroy(tsgpu_ctx* ctx) {
 // one grouped batch; the caller holds ctx->mu (like a search holds Index::mutex: no commit lands between the id pass and the scoring; the scratch is the context's).
 // User query u owns the candidate combinations combos[cfirst[u] .. cfirst[u + 1]) — one search_across_fields pass each over ONE collector (Index::search_all_candidates,
 // src/index.cpp:1794-1894); the plain entry point passes one combination per query. query_index (nullable): KV::query_index per hit slot.
+// `shard` (nullable; tsgpu_group_keyword_search_grouped_batch, one combination per query): this context answers as a doc-range shard of a group —
+//   forced_keys / forced_begin: the groups of query i are GIVEN (keys forced_keys[forced_begin[i] .. forced_begin[i + 1]), best first, as the whole collection selected
+//     them): returned group r is the r-th key whether or not the shard holds documents of it (then group_found = group_size = 0), groups_count is not computed;
+//   present_elsewhere: per query, the tokens that exist on ANOTHER shard (a token missing here is then an empty list, not a dropped token: kw_dispatch).
+// A q = * query of a context with a doc range matches the seq_ids the context OWNS.
 static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const uint32_t* cfirst, const tsgpu_group_by* groups, uint32_t n_queries,
-                           tsgpu_hits* out, tsgpu_grouped_hits* gout, uint32_t* query_index, tsgpu_id_lists** ids_out) {
+                           tsgpu_hits* out, tsgpu_grouped_hits* gout, uint32_t* query_index, tsgpu_id_lists** ids_out, const tsgpu::GbShard* shard = nullptr) {
     (void)hipSetDevice(ctx->device);
     const std::shared_ptr<const Snapshot> snap_ref = ctx->snapshot();
     const Snapshot& snap = *snap_ref;
@@ -168,17 +173,21 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
             if (st == TSGPU_OK && (gb.group_limit == 0 || gb.group_limit > TSGPU_MAX_GROUP_LIMIT)) st = TSGPU_ERR_INVALID;
             if (st == TSGPU_OK && gb.column >= ctx->columns.size()) st = TSGPU_ERR_NOT_FOUND;
             uint32_t k = 1;
+            const bool forced = shard && shard->forced_begin;
             if (st == TSGPU_OK) {
                 k = resolve_topster_size(ctx, combos[c0]);                 // ONE collector for all combinations (src/index.cpp:3506-3514)
+                if (forced) k = std::max<uint32_t>(1, shard->forced_begin[i + 1] - shard->forced_begin[i]);     // (the given groups: all of them are returned)
                 if (k > TSGPU_MAX_TOPK) st = TSGPU_ERR_UNSUPPORTED;
                 else if (k > gout->g_stride) st = TSGPU_ERR_INVALID;
                 else if ((uint64_t)k * (gb.first_pass ? 1u : gb.group_limit) > out->k_stride) st = TSGPU_ERR_INVALID;   // second pass: slot r * group_limit + j
+                if (st == TSGPU_OK && forced && nc != 1) st = TSGPU_ERR_UNSUPPORTED;
             }
             status[i] = st;
             if (st != TSGPU_OK) continue;
             max_k = std::max(max_k, k);
             gq[i].k = k; gq[i].group_limit = gb.group_limit; gq[i].column = gb.column;
             gq[i].first_pass = gb.first_pass ? 1 : 0; gq[i].group_missing_values = gb.group_missing_values ? 1 : 0; gq[i].wildcard = gb.wildcard ? 1 : 0;
+            if (forced) { gq[i].forced = 1; gq[i].forced_begin = shard->forced_begin[i]; gq[i].n_forced = shard->forced_begin[i + 1] - shard->forced_begin[i]; }
             gq[i].dedupe = (!gb.first_pass && nc > 1) ? 1 : 0;             // a second pass counts a document once, with its greatest KV (group_doc_seq_ids + replace-unless-smaller)
             any_dedupe = any_dedupe || gq[i].dedupe;
             (gb.first_pass ? any_first : any_second) = true;
@@ -201,12 +210,19 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
                 const tsgpu_kw_query& in = combos[cfirst[i]];
                 if (groups[i].wildcard) {
                     // Index::search_wildcard ranks the filter ids (every seq_id without a filter) minus the excluded ids (src/index.cpp:6674-6676)
-                    if (in.n_filter == 0 && in.n_excluded == 0) { iota[i] = 1; any_iota = true; num_matched[i] = ctx->num_docs; continue; }
+                    // (a doc-range shard of a group ranks the ids it OWNS, like tsgpu_wildcard_search_batch: context options doc_range_lo / _hi)
+                    const bool ranged = ctx->doc_range_set;
+                    const uint32_t own_lo = ranged ? ctx->doc_range_lo : 0u, own_hi = ranged ? std::min(ctx->doc_range_hi, ctx->num_docs) : ctx->num_docs;
+                    if (in.n_filter == 0 && in.n_excluded == 0 && !ranged) { iota[i] = 1; any_iota = true; num_matched[i] = ctx->num_docs; continue; }
                     std::vector<uint32_t>& w = wild_ids[i];
-                    const uint32_t n = in.n_filter ? in.n_filter : ctx->num_docs;
-                    w.reserve(n);
+                    uint32_t j0 = 0, n = in.n_filter ? in.n_filter : own_hi;
+                    if (in.n_filter && ranged) {
+                        j0 = (uint32_t)(std::lower_bound(in.filter_ids, in.filter_ids + in.n_filter, own_lo) - in.filter_ids);
+                        n = (uint32_t)(std::lower_bound(in.filter_ids, in.filter_ids + in.n_filter, own_hi) - in.filter_ids);
+                    } else if (!in.n_filter) j0 = std::min(own_lo, own_hi);
+                    w.reserve(n - j0);
                     uint32_t e = 0;
-                    for (uint32_t j = 0; j < n; j++) {
+                    for (uint32_t j = j0; j < n; j++) {
                         const uint32_t id = in.n_filter ? in.filter_ids[j] : j;
                         while (e < in.n_excluded && in.excluded_ids[e] < id) e++;
                         if (e < in.n_excluded && in.excluded_ids[e] == id) continue;
@@ -238,7 +254,9 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
                 // a batch without wildcard queries: the ids go straight into this call's device buffer (no download + upload) unless a query's ids need the host's sort
                 if (!ctx->groupby) ctx->groupby = new GroupByScratch;
                 struct NoCoalesce { bool old; NoCoalesce() : old(tsgpu::tls_no_coalesce()) { tsgpu::tls_no_coalesce() = true; } ~NoCoalesce() { tsgpu::tls_no_coalesce() = old; } } nc;
-                const int rc = kw_dispatch(ctx, kq.data(), nk, &th, false, &raw, any_wild ? nullptr : &ctx->groupby->ids_dev, &ids_on_dev);
+                std::vector<uint16_t> pe;
+                if (shard && shard->present_elsewhere) { pe.resize(nk); for (uint32_t j = 0; j < nk; j++) pe[j] = shard->present_elsewhere[kq_of[j]]; }
+                const int rc = kw_dispatch(ctx, kq.data(), nk, &th, false, &raw, any_wild ? nullptr : &ctx->groupby->ids_dev, &ids_on_dev, pe.empty() ? nullptr : pe.data());
                 idl.reset(raw);
                 if (rc != TSGPU_OK) return rc;
                 for (uint32_t j = 0; j < nk; j++) { c_status[kq_of[j]] = t_st[j]; c_matched[kq_of[j]] = t_nm[j]; }
@@ -309,7 +327,8 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
         GbLayout Lin, Lff, Lzero, Lout, Lwork;
         const uint32_t ncz = std::max<uint32_t>(n_combos, 1);
         const size_t i_gq = Lin.take(sizeof(GbQuery) * n_queries), i_qd = Lin.take(sizeof(KwQueryDev) * ncz), i_mf = Lin.take(sizeof(KwQueryMF) * ncz),
-                     i_cb = Lin.take(((size_t)n_combos + 1) * 8), i_qx = Lin.take((size_t)ncz * 4), i_ids = Lin.take(ids_on_dev ? 16 : ni * 4);
+                     i_cb = Lin.take(((size_t)n_combos + 1) * 8), i_qx = Lin.take((size_t)ncz * 4),
+                     i_fk = Lin.take(((shard && shard->forced_begin) ? (size_t)shard->forced_begin[n_queries] : 0) * 8 + 8), i_ids = Lin.take(ids_on_dev ? 16 : ni * 4);
         const size_t f_hkey = Lff.take(n_slots * 8), f_hbest = Lff.take(n_slots * 4), f_hrank = Lff.take(n_slots * 4),
                      f_dkey = Lff.take(any_dedupe ? n_slots * 4 : 16), f_dbest = Lff.take(any_dedupe ? n_slots * 4 : 16);      // the document tables of the second passes over several combinations
         const size_t z_hcount = Lzero.take(n_slots * 4), z_gcount = Lzero.take((size_t)n_queries * 4), z_ticket = Lzero.take(n_g * 4);
@@ -347,6 +366,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
             memcpy(hin + i_mf, mf.data(), sizeof(KwQueryMF) * n_combos);
             memcpy(hin + i_cb, combo_begin.data(), ((size_t)n_combos + 1) * 8);
             memcpy(hin + i_qx, qidx_of_combo.data(), (size_t)n_combos * 4);
+            if (shard && shard->forced_begin && shard->forced_begin[n_queries]) memcpy(hin + i_fk, shard->forced_keys, (size_t)shard->forced_begin[n_queries] * 8);
             for (uint32_t i = 0; !ids_on_dev && i < n_queries; i++) {
                 if (!gq[i].run || gq[i].n_items == 0 || iota[i]) continue;
                 if (groups[i].wildcard) { memcpy(hin + i_ids + (size_t)gq[i].item_begin * 4, wild_ids[i].data(), (size_t)gq[i].n_items * 4); continue; }
@@ -372,6 +392,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
         GbArgs a;
         char* din = (char*)S.in.p; char* dff = (char*)S.ff.p; char* dz = (char*)S.zero.p; char* dout = (char*)S.out.p; char* dw = (char*)S.work.p;
         a.gq = (const GbQuery*)(din + i_gq); a.n_queries = n_queries; a.queries = (const KwQueryDev*)(din + i_qd); a.mfs = (const KwQueryMF*)(din + i_mf);
+        a.forced_keys = (const unsigned long long*)(din + i_fk);
         a.combo_begin = (const unsigned long long*)(din + i_cb); a.qidx_of_combo = (const uint32_t*)(din + i_qx); a.pass = (uint8_t*)(dw + w_pass);
         a.dkey32 = (uint32_t*)(dff + f_dkey); a.dbest = (uint32_t*)(dff + f_dbest); a.out_qidx = (uint32_t*)(dout + o_qx);
         a.n_pw = (uint32_t)n_pw; a.pw_list = (uint32_t*)(dw + w_pwlist); a.pw_count = (uint32_t*)(dw + w_pwcount); a.pw_n = (uint32_t*)(dw + w_pwn);
@@ -479,7 +500,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
             if (status[i] != TSGPU_OK) { out->n_hits[i] = 0; gout->n_groups[i] = 0; if (gout->groups_total) gout->groups_total[i] = 0; }
             if (gout->groups_count) {
                 uint64_t card = 0;
-                if (status[i] == TSGPU_OK && groups[i].first_pass && !gb_loglog_cardinality_hist(hist_host + (size_t)i * GB_LOGLOG_HIST, &card)) {
+                if (status[i] == TSGPU_OK && groups[i].first_pass && !gq[i].forced && !gb_loglog_cardinality_hist(hist_host + (size_t)i * GB_LOGLOG_HIST, &card)) {
                     std::vector<uint8_t> regs(GB_LOGLOG_M);      // (a register above 38: the ordered sum over the registers themselves)
                     TSGPU_HIP_TRY(hipMemcpy(regs.data(), S.loglog.as<uint8_t>() + (size_t)i * GB_LOGLOG_M, GB_LOGLOG_M, hipMemcpyDeviceToHost));
                     card = gb_loglog_cardinality(regs.data());
@@ -631,6 +652,18 @@ static int gb_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsg
     if (ids_out) *ids_out = lists.release();
     return ok();
 }
+
+namespace tsgpu {
+uint64_t gb_registers_cardinality(const uint8_t* regs) { return gb_loglog_cardinality(regs); }
+int gb_shard_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries, tsgpu_hits* out, tsgpu_grouped_hits* gout, const GbShard* shard) {
+    if (!ctx || !out || !gout || (n_queries && (!queries || !groups))) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_grouped_batch: NULL argument");
+    if (n_queries == 0) return ok();
+    std::vector<uint32_t> cf((size_t)n_queries + 1);
+    for (uint32_t i = 0; i <= n_queries; i++) cf[i] = i;         // one combination per query
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return gb_batch_locked(ctx, queries, cf.data(), groups, n_queries, out, gout, nullptr, nullptr, shard);
+}
+}  // namespace tsgpu
 
 extern "C" {
 

@@ -108,8 +108,8 @@ class Hits:
 class GroupedHits:
     """Host copy of tsgpu_grouped_hits (numpy, [n_queries, g_stride])."""
 
-    def __init__(self, n_queries, g_stride, registers=False):
-        self.n_queries, self.g_stride = n_queries, g_stride
+    def __init__(self, n_queries, g_stride, registers=False, totals=True):
+        self.n_queries, self.g_stride, self.totals = n_queries, g_stride, totals
         self.n_groups = np.zeros(n_queries, np.uint32)
         self.distinct_key = np.zeros((n_queries, g_stride), np.uint64)
         self.group_size = np.zeros((n_queries, g_stride), np.uint32)
@@ -122,7 +122,7 @@ class GroupedHits:
         g = B.GroupedHitsC()
         g.g_stride = self.g_stride
         g.n_groups, g.distinct_key, g.group_size, g.group_found = self.n_groups.ctypes.data, self.distinct_key.ctypes.data, self.group_size.ctypes.data, self.group_found.ctypes.data
-        g.groups_total, g.groups_count = self.groups_total.ctypes.data, self.groups_count.ctypes.data
+        g.groups_total, g.groups_count = (self.groups_total.ctypes.data if self.totals else None), self.groups_count.ctypes.data
         g.loglog_registers = self.loglog_registers.ctypes.data if self.loglog_registers is not None else None
         return g
 
@@ -714,6 +714,20 @@ class GpuGroup:
         hs = hits.c_struct()
         B.check(self.L, self.L.tsgpu_group_wildcard_search_batch(self.h, C.cast(arr, C.c_void_p), len(arr), k, C.byref(hs)))
         return hits
+
+    def keyword_search_grouped_batch(self, queries, groups, k_stride, g_stride=250, want_registers=False, want_totals=False):
+        """tsgpu_group_keyword_search_grouped_batch: group_by over the shards (keyed exchange in two rounds); groups as in GpuIndex.keyword_search_grouped_batch.
+        groups_total is not computed across shards (want_totals=True asks for it anyway: 501 unless the group is in replicas form)"""
+        arr = make_query_array(queries)
+        n = len(arr)
+        ga = (B.GroupByC * max(n, 1))()
+        for i, g in enumerate(groups):
+            ga[i].group_limit, ga[i].column, ga[i].first_pass, ga[i].group_missing_values, ga[i].wildcard = int(g[0]), int(g[1]), int(g[2]), int(g[3]), int(g[4])
+        h = Hits(n, k_stride)
+        gh = GroupedHits(n, g_stride, want_registers, totals=want_totals)
+        hs, gs = h.c_struct(), gh.c_struct()
+        B.check(self.L, self.L.tsgpu_group_keyword_search_grouped_batch(self.h, C.cast(arr, C.c_void_p), ga, n, C.byref(hs), C.byref(gs)))
+        return h, gh
 
     def facet_count_batch(self, field_id, id_lists, cap=1024, sample_mod=1, allowed_hashes=None):
         """tsgpu_group_facet_count_batch: GpuIndex.facet_count_batch over the shards (GLOBAL ascending id lists)"""
