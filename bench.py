@@ -663,6 +663,48 @@ class Bench:
             except Exception as e:      # noqa: BLE001 (a secondary leg must not take the headline line with it)
                 res["wildcard_sharded"] = {"error": repr(e)}
 
+        if self.sharded and self.group is not None:
+            try:
+                # group_by over the shards (tsgpu_group_keyword_search_grouped_batch): a group's documents live on several shards -> keyed exchange in two rounds (the shards'
+                # best groups and heads; the selected groups' counts and KVs); rank 0 checks both passes against the unsharded twin's own grouped call
+                n_g = max(8, min(n_q // 50, 100))
+                gtok = synth.keyword_queries(n_g, 3, 8, 2000, seed=61)
+                ids64 = np.arange(self.n_docs, dtype=np.uint64)
+                n_grp = max(16, self.n_docs // 200)
+                distinct = (((ids64 * np.uint64(2654435761)) % np.uint64(n_grp)) * np.uint64(0x100000001B3) + np.uint64(0x517cc1b727220a95)).astype(np.uint64)
+                self.g.column_set(7, distinct.view(np.int64))
+                gqs = [self.T.KwQuery(gtok[i], sort=self.sort, topster_size=FETCH_SIZE) for i in range(n_g)]
+                gl = 3
+                el_g, got = {}, {}
+                for fp in (1, 0):
+                    grs = [(gl, 7, fp, 0, 0)] * n_g
+                    self.group.keyword_search_grouped_batch(gqs, grs, k_stride=FETCH_SIZE * gl, g_stride=FETCH_SIZE)          # warm-up
+                    barrier(world)
+                    t0 = time.perf_counter()
+                    got[fp] = self.group.keyword_search_grouped_batch(gqs, grs, k_stride=FETCH_SIZE * gl, g_stride=FETCH_SIZE)
+                    el_g[fp] = max_over_ranks(time.perf_counter() - t0, world)
+                res["group_by_sharded"] = {"value": n_g / (el_g[1] + el_g[0]), "unit": "grouped user queries/s (first + second pass each)", "ms_first_pass": 1e3 * el_g[1], "ms_second_pass": 1e3 * el_g[0],
+                                           "queries": n_g, "workload": "3-term queries, group_limit 3, %d groups over %d documents in %d doc ranges, Topster %d" % (n_grp, self.n_docs, world, FETCH_SIZE)}
+                if self.rank == 0:
+                    self.twin.column_set(7, distinct.view(np.int64))
+                    bad = 0
+                    for fp in (1, 0):
+                        th, tg = self.twin.keyword_search_grouped_batch(gqs, [(gl, 7, fp, 0, 0)] * n_g, k_stride=FETCH_SIZE * gl, g_stride=FETCH_SIZE)
+                        sh, sg = got[fp]
+                        L = 1 if fp else gl
+                        for i in range(n_g):
+                            ng = int(tg.n_groups[i])
+                            same = int(sg.n_groups[i]) == ng and int(sh.n_hits[i]) == int(th.n_hits[i]) and int(sh.num_matched[i]) == int(th.num_matched[i]) and int(sg.groups_count[i]) == int(tg.groups_count[i]) \
+                                and np.array_equal(sg.distinct_key[i, :ng], tg.distinct_key[i, :ng]) and np.array_equal(sg.group_found[i, :ng], tg.group_found[i, :ng]) and np.array_equal(sg.group_size[i, :ng], tg.group_size[i, :ng])
+                            for r in range(ng if same else 0):
+                                n = int(tg.group_size[i, r])
+                                same = same and np.array_equal(sh.keys[i, r * L:r * L + n], th.keys[i, r * L:r * L + n]) and np.array_equal(sh.scores[i, r * L:r * L + n], th.scores[i, r * L:r * L + n])
+                            bad += 0 if same else 1
+                    res["group_by_sharded"]["shard_parity"] = {"checked": 2 * n_g, "mismatches": bad,
+                                                               "against": "the unsharded collection's grouped call on rank 0, both passes (groups, group_found, group_size, KVs, groups_count, num_matched)"}
+            except Exception as e:      # noqa: BLE001 (a secondary leg must not take the headline line with it)
+                res["group_by_sharded"] = {"error": repr(e)}
+
         if self.sharded:
             # second multi-GPU form, reported as a sub-object: replicas — every GPU holds the collection, the global batch of N x 10 000 queries
             # is sharded across the GPUs, one all-gather of the per-GPU top-100 (weak scaling)
@@ -1822,6 +1864,11 @@ def compact_line(full, detail_path=None):
         line["wildcard_sharded"] = _pick(full["wildcard_sharded"], ("ms_per_call", "docs_ranked_per_s"))
         if "shard_parity" in full["wildcard_sharded"]:
             line["wildcard_sharded"]["shard_parity"] = _parity_small(full["wildcard_sharded"]["shard_parity"])
+    if isinstance(full.get("group_by_sharded"), dict):
+        gs_ = full["group_by_sharded"]
+        line["group_by_sharded"] = _pick(gs_, ("value", "unit", "ms_first_pass", "ms_second_pass", "error"))
+        if "shard_parity" in gs_:
+            line["group_by_sharded"]["shard_parity"] = _parity_small(gs_["shard_parity"])
     if isinstance(full.get("candidate_combinations_sharded"), dict):
         cs = full["candidate_combinations_sharded"]
         line["candidate_combinations_sharded"] = _pick(cs, ("value", "unit", "ms_per_call"))
@@ -2051,7 +2098,7 @@ def main():
                                   "kernel_src_sha16": cur, "pmc_of_these_sources": bool(meta) and meta.get("kernel_src_sha16") == cur,
                                   "note": "wave-instructions of the find kernel (rocprofv3 --pmc, own pass) / (live kernel cycles x 256 CUs x 1 per cycle); no port is saturated"}
         kw["roofline"] = roof
-        for key in ("concurrency", "uncached", "shard_parity", "replicas", "replicas_strong", "exchange_check", "candidate_combinations_sharded", "wildcard_sharded"):
+        for key in ("concurrency", "uncached", "shard_parity", "replicas", "replicas_strong", "exchange_check", "candidate_combinations_sharded", "wildcard_sharded", "group_by_sharded"):
             if key in r:
                 kw[key] = r[key]
         if "cpu" in r:
@@ -2136,7 +2183,7 @@ def main():
             "value": hd["value"], "unit": "queries/s", "n_gpus": world, "steps": hd["steps"], "warmup": args.warmup, "ms_per_step": hd["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32/i64" if head == "keyword" else "f32",
             "data": "synthetic", "config": hd["config"], "p50_ms_per_batch": hd["p50_ms_per_batch"]}
-    for k in ("queries_with_hits", "value_device_only", "ms_per_step_device_only", "value_two_callers", "two_callers", "value_host_pinned", "host_pinned", "value_host_all_arrays", "ms_per_step_host_all_arrays", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "exchange_check", "replicas", "replicas_strong", "candidate_combinations_sharded", "wildcard_sharded", "concurrency",
+    for k in ("queries_with_hits", "value_device_only", "ms_per_step_device_only", "value_two_callers", "two_callers", "value_host_pinned", "host_pinned", "value_host_all_arrays", "ms_per_step_host_all_arrays", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "parity", "shard_parity", "exchange_check", "replicas", "replicas_strong", "candidate_combinations_sharded", "wildcard_sharded", "group_by_sharded", "concurrency",
               "uncached", "general_kernels", "fused_hits_per_batch", "parity_fp32_scan", "batch_sweep", "variants", "hnsw", "rerank_hybrid_matches"):
         if k in hd:
             line[k] = hd[k]

@@ -38,6 +38,7 @@ def test_n_rank_shards_equal_unsharded_collection(world):
     assert r["exchange_check"]["own_slice_delivery_equals_full_result"] is True, r.get("exchange_check")      # the timed form: every rank delivers the slice it merged
     assert r["candidate_combinations_sharded"]["shard_parity"]["mismatches"] == 0 and r["candidate_combinations_sharded"]["shard_parity"]["checked"] >= 8, r.get("candidate_combinations_sharded")
     assert r["wildcard_sharded"]["shard_parity"]["mismatches"] == 0 and r["wildcard_sharded"]["shard_parity"]["checked"] == 4, r.get("wildcard_sharded")      # q = * over the doc-range shards
+    assert r["group_by_sharded"]["shard_parity"]["mismatches"] == 0 and r["group_by_sharded"]["shard_parity"]["checked"] >= 16, r.get("group_by_sharded")      # group_by, both passes, keyed exchange
 
 
 @pytest.mark.gpu

@@ -204,6 +204,10 @@ def check_group_by(orc, grp, rng, n_docs, filt):
     h, gh = grp.keyword_search_grouped_batch([qs[1], qs[1]], [(1, GROUP_COL, 0, 0, 0), (1, 77, 1, 0, 0)], k_stride=300, g_stride=250)
     assert h.status.tolist() == [0, B.ERR_NOT_FOUND]
     check_query(h, gh, 0, oracle_grouped(orc, qs[1], distinct, has_value, 1, 0), 0, 1, "next to a bad query", check_total=False)
+    # a batch whose only query matches nothing anywhere (no groups: the second round still runs, with nothing given)
+    for first_pass in (1, 0):
+        h, gh = grp.keyword_search_grouped_batch([qs[7]], [(3, GROUP_COL, first_pass, 0, 0)], k_stride=750, g_stride=250)
+        assert int(h.status[0]) == 0 and int(gh.n_groups[0]) == 0 and int(h.n_hits[0]) == 0 and int(h.num_matched[0]) == 0
     if grp.size() > 1 and not getattr(grp, "replicas_form", False):
         with pytest.raises(T.TsgpuError):
             grp.keyword_search_grouped_batch(qs[:1], [(3, GROUP_COL, 1, 0, 0)], k_stride=750, g_stride=250, want_totals=True)

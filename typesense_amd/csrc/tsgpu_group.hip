@@ -1302,7 +1302,7 @@ int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_quer
                 else {
                     const uint32_t n = (uint32_t)std::min<size_t>(pool.size(), cap);
                     for (uint32_t r = 0; r < n; r++) fkeys.push_back(pool[r].dkey);
-                    K2 = std::max<uint32_t>(K2, n * L); G2 = std::max(G2, n);
+                    K2 = std::max<uint32_t>(K2, std::max(n, 1u) * L); G2 = std::max(G2, n);        // (a query without groups still passes the shard's capacity x group_limit check: capacity 1)
                 }
             }
             fbegin[i + 1] = (uint32_t)fkeys.size();
