@@ -667,6 +667,11 @@ int tsgpu_group_wildcard_search_batch(tsgpu_group* g, const tsgpu_kw_query* quer
  * (Topster(capacity, distinct, first_pass), include/topster.h:266-466; populate_result_kvs, src/index.cpp:8962-9011). gout->groups_total must be NULL (the exact distinct-key
  * count is not computed across shards: 501); matched-id lists are not offered. Every member needs its doc range for q = * queries. out / gout: HOST arrays. */
 int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries, tsgpu_hits* out, tsgpu_grouped_hits* gout);
+/* ... and over candidate-token combinations (tsgpu_keyword_search_grouped_candidates_batch over the shards: combos / group_begin / groups / query_index as there, 1..16
+ * combinations per user query): both rounds run the shards' own folds (a document lives in one shard); KV::query_index — the earlier passes that matched ANYTHING — comes from
+ * the OR of the shards' pass masks; num_matched = the last pass' counts added up. Same restrictions as the call above. */
+int tsgpu_group_keyword_search_grouped_candidates_batch(tsgpu_group* g, const tsgpu_kw_query* combos, const uint32_t* group_begin, const tsgpu_group_by* groups, uint32_t n_user,
+                                                        tsgpu_hits* out, tsgpu_grouped_hits* gout, uint32_t* query_index);
 /* "kw_exchange_slices" = 1 (default): the keyword exchange is an ncclAllToAll of query slices (member j receives only the records of
  * the 1/G of the batch it merges), a slice merge per member, and in-place ncclAllGathers of the merged lists (rank form / device outputs;
  * the local form with host outputs delivers every slice over its own GPU's PCIe link); 0: ONE ncclAllGather of the per-GPU top-k

@@ -192,6 +192,23 @@ def main():
                 check_query(h, gh, len(gqs), oracle_grouped_wildcard(wq[1], n_docs, pts, distinct, 2, first_pass), first_pass, 2, "group_by wildcard", check_total=False)
             except AssertionError as e:
                 check("group_by %s pass %d: %s" % (cut_name, first_pass, str(e)[:300]), False)
+            # ... and over candidate combinations: the ranks' own folds, query_index from the OR of the ranks' pass masks
+            gusers = [[[1, 2], [1, 3], [79, 80], [1, 2]], [[78, 79], [3], [3, 4]], [[80], [77, 78]]]
+            gcombos = [[T.KwQuery(c, sort=sort, topster_size=K, total_cost=int(j > 0)) for j, c in enumerate(cs)] for cs in gusers]
+            try:
+                h, gh, gqi = grp.keyword_search_grouped_candidates_batch(gcombos, [(3, 1, first_pass, 0, 0)] * len(gusers), k_stride=750, g_stride=250, want_registers=bool(first_pass))
+                for u, cs in enumerate(gcombos):
+                    ref, rqi = orc.search_candidates_grouped([H.oracle_query(orc, q) for q in cs], distinct, 3, first_pass, has_value=has_value, ids_cap=1 << 20)
+                    check_query(h, gh, u, ref, first_pass, 3, "grouped candidates", check_total=False)
+                    ng = int(gh.n_groups[u])
+                    if first_pass:
+                        assert {int(h.keys[u, r]): int(gqi[u, r]) for r in range(ng)} == {int(k): int(q) for k, q in zip(ref.keys, rqi)}, "query_index"
+                    else:
+                        for r in range(ng):
+                            n = int(ref.group_size[r])
+                            assert np.array_equal(gqi[u, r * 3:r * 3 + n], rqi[ref.begin[r]:ref.begin[r + 1]].astype(np.uint32)), "query_index"
+            except AssertionError as e:
+                check("grouped candidates %s pass %d: %s" % (cut_name, first_pass, str(e)[:300]), False)
         dm, lm, cm = grp.vec_knn_batch(1, Q, k_vec)
         check_knn("knn " + cut_name, dm, lm, cm)
         allow = np.arange(3, n_docs, 5, dtype=np.uint32)

@@ -198,6 +198,27 @@ def check_group_by(orc, grp, rng, n_docs, filt):
             for j, q in enumerate(wq):
                 ref = oracle_grouped_wildcard(q, n_docs, pts, distinct, wlimits[j], first_pass, gmv=bool(gmv))
                 check_query(h, gh, len(qs) + j, ref, first_pass, wlimits[j], "group group_by wildcard pass%d gmv%d" % (first_pass, gmv), check_total=False)
+    # ---- the same over candidate combinations (tsgpu_group_keyword_search_grouped_candidates_batch): the shards' own folds, GLOBAL query_index from the shards' pass masks ----
+    users = [[[1, 2], [1, 3], [2, 3], [1, 2], [77, 78]],          # a repeated combination (the later pass wins ties), a pass that matches nothing anywhere
+             [[79, 80], [3], [4], [3, 4]],                        # the FIRST pass matches nothing anywhere: the later passes' query_index starts at 0
+             [[2, 1, 3]],
+             [[77], [78, 79]],
+             [[60], [61], [62], [63], [64], [65], [5], [6]]]       # rare terms: passes that match on SOME shards only (the masks differ between shards)
+    tsz = [40, 5, 40, 40, 250]
+    combos = [[T.KwQuery(c, sort=SORT, topster_size=tsz[u], total_cost=int(j > 0)) for j, c in enumerate(cs)] for u, cs in enumerate(users)]
+    for first_pass in (1, 0):
+        h, gh, qidx = grp.keyword_search_grouped_candidates_batch(combos, [(3, GROUP_COL, first_pass, 0, 0)] * len(users), k_stride=750, g_stride=250, want_registers=bool(first_pass))
+        assert (h.status == 0).all()
+        for u, cs in enumerate(combos):
+            ref, rqi = orc.search_candidates_grouped([H.oracle_query(orc, q) for q in cs], distinct, 3, first_pass, has_value=has_value, ids_cap=1 << 20)
+            check_query(h, gh, u, ref, first_pass, 3, "group grouped candidates u%d pass%d" % (u, first_pass), check_total=False)
+            ng = int(gh.n_groups[u])
+            if first_pass:        # (the reference's heap order is not the library's: compare query_index per key)
+                assert {int(h.keys[u, r]): int(qidx[u, r]) for r in range(ng)} == {int(k): int(q) for k, q in zip(ref.keys, rqi)}, u
+            else:
+                for r in range(ng):
+                    n = int(ref.group_size[r])
+                    assert np.array_equal(qidx[u, r * 3:r * 3 + n], rqi[ref.begin[r]:ref.begin[r + 1]].astype(np.uint32)), (u, r)
     # a bad query next to good ones (unknown group column -> 404 on every shard), strides too small for the capacity (400), groups_total asked for across shards (501)
     h, gh = grp.keyword_search_grouped_batch([qs[0], qs[1], qs[0]], [(3, GROUP_COL, 0, 0, 0), (1, 77, 0, 0, 0), (3, GROUP_COL, 0, 0, 0)], k_stride=300, g_stride=250)
     assert h.status.tolist() == [B.ERR_INVALID, B.ERR_NOT_FOUND, B.ERR_INVALID] and h.n_hits.sum() == 0

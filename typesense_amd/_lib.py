@@ -129,7 +129,7 @@ EXPORTS = [
     "tsgpu_keyword_search_batch_ids", "tsgpu_keyword_search_grouped_batch", "tsgpu_keyword_search_grouped_candidates_batch", "tsgpu_id_lists_count", "tsgpu_id_lists_ids", "tsgpu_id_lists_free", "tsgpu_facet_set", "tsgpu_facet_count_batch", "tsgpu_facet_count_grouped_batch", "tsgpu_facet_range_count_batch", "tsgpu_facet_stats_batch", "tsgpu_facet_value_set", "tsgpu_facet_value_count_batch",
     "tsgpu_vec_create", "tsgpu_vec_upsert", "tsgpu_vec_delete", "tsgpu_vec_get", "tsgpu_vec_count", "tsgpu_vec_knn_batch",
     "tsgpu_vec_hnsw_load", "tsgpu_vec_hnsw_enable", "tsgpu_vec_hnsw_build", "tsgpu_vec_hnsw_export", "tsgpu_vec_hnsw_search_batch", "tsgpu_vec_distances", "tsgpu_ip_distance", "tsgpu_vector_search_batch", "tsgpu_vector_search_batch_ids", "tsgpu_hybrid_search_batch", "tsgpu_hybrid_fuse_batch", "tsgpu_keyword_aux_scores", "tsgpu_merge_shard_hits", "tsgpu_merge_shard_hits_device", "tsgpu_last_timings", "tsgpu_last_aux_timings", "tsgpu_kw_last_touched", "tsgpu_kw_lists_footprint",
-    "tsgpu_group_create_local", "tsgpu_group_unique_id", "tsgpu_group_create_rank", "tsgpu_group_create_rank_host", "tsgpu_group_destroy", "tsgpu_group_size", "tsgpu_group_keyword_search_batch", "tsgpu_group_keyword_search_candidates_batch", "tsgpu_group_wildcard_search_batch", "tsgpu_group_keyword_search_grouped_batch", "tsgpu_group_facet_count_batch", "tsgpu_group_facet_range_count_batch", "tsgpu_group_facet_stats_batch",
+    "tsgpu_group_create_local", "tsgpu_group_unique_id", "tsgpu_group_create_rank", "tsgpu_group_create_rank_host", "tsgpu_group_destroy", "tsgpu_group_size", "tsgpu_group_keyword_search_batch", "tsgpu_group_keyword_search_candidates_batch", "tsgpu_group_wildcard_search_batch", "tsgpu_group_keyword_search_grouped_batch", "tsgpu_group_keyword_search_grouped_candidates_batch", "tsgpu_group_facet_count_batch", "tsgpu_group_facet_range_count_batch", "tsgpu_group_facet_stats_batch",
     "tsgpu_group_vec_knn_batch", "tsgpu_group_hybrid_search_batch", "tsgpu_group_last_timings", "tsgpu_group_set_option",
 ]
 
@@ -239,6 +239,7 @@ def lib(path=None):
     L.tsgpu_group_keyword_search_candidates_batch.argtypes = [vp, vp, vp, u32, u32, C.POINTER(HitsC), vp, vp]
     L.tsgpu_group_wildcard_search_batch.argtypes = [vp, vp, u32, u32, C.POINTER(HitsC)]
     L.tsgpu_group_keyword_search_grouped_batch.argtypes = [vp, vp, vp, u32, C.POINTER(HitsC), C.POINTER(GroupedHitsC)]
+    L.tsgpu_group_keyword_search_grouped_candidates_batch.argtypes = [vp, vp, vp, vp, u32, C.POINTER(HitsC), C.POINTER(GroupedHitsC), vp]
     L.tsgpu_group_facet_count_batch.argtypes = [vp, u32, vp, vp, u32, u32, vp, u32, C.POINTER(FacetCountsC)]
     L.tsgpu_group_facet_range_count_batch.argtypes = [vp, u32, u32, vp, vp, u32, vp, vp, u32, u32, vp]
     L.tsgpu_group_facet_stats_batch.argtypes = [vp, u32, i32, vp, vp, u32, u32, vp, vp, u32, vp]

@@ -1206,10 +1206,17 @@ int tsgpu_group_keyword_search_candidates_batch(tsgpu_group* g, const tsgpu_kw_q
 // groups_count: the shards' LogLogBeta registers merge by their maxima (the sketch of the union); num_matched adds up. Each shard searches twice (the second pass of the
 // reference's own two-pass protocol costs as much); gout->groups_total — the exact number of distinct keys, not a reference quantity — is not computed across shards (501
 // unless NULL), ids_out is not offered. out / gout: HOST arrays, as on one GPU.
-int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries, tsgpu_hits* out, tsgpu_grouped_hits* gout) {
-    if (!g || !out || !gout || (n_queries && (!queries || !groups))) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_grouped_batch: NULL argument");
+// `queries` = the candidate combinations; user query i owns queries[cfirst[i] .. cfirst[i + 1]) (the plain call: one each, query_index == nullptr)
+static int group_grouped_core(tsgpu_group* g, const tsgpu_kw_query* queries, const uint32_t* cfirst, const tsgpu_group_by* groups, uint32_t n_queries, tsgpu_hits* out, tsgpu_grouped_hits* gout,
+                              uint32_t* query_index, bool candidates) {
+    if (!g || !out || !gout || !cfirst || (n_queries && (!queries || !groups))) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_grouped_batch: NULL argument");
     if (n_queries == 0) { std::lock_guard<std::mutex> lk0(g->mu); return agree(g, TSGPU_OK, call_signature({13, 0})); }
+    const uint32_t n_combos = cfirst[n_queries];
     int pre = TSGPU_OK;
+    if (cfirst[0] != 0) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_grouped_candidates_batch: group_begin[0] must be 0");
+    for (uint32_t i = 0; i < n_queries && !pre; i++)
+        if (cfirst[i + 1] <= cfirst[i] || cfirst[i + 1] - cfirst[i] > 16) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_grouped_candidates_batch: every user query needs 1..16 combinations");
+    if (pre) {} else
     if (out->mem != TSGPU_MEM_HOST) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_grouped_batch: host output arrays only");
     else if (!out->keys || !out->scores || !out->n_hits || !out->status) pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_grouped_batch: keys / scores / n_hits / status are required");
     else if (!gout->n_groups || !gout->distinct_key || !gout->group_size || !gout->group_found || gout->g_stride == 0 || out->k_stride == 0)
@@ -1217,12 +1224,14 @@ int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_quer
     else if (gout->groups_total && !g->replicas) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_grouped_batch: groups_total (the exact distinct-key count) is not computed across shards: pass NULL");
     std::lock_guard<std::mutex> lk(g->mu);
     if (pre) return agree(g, pre, 0);
-    const uint64_t omask = hits_mask(out) | (gout->groups_count ? 1ull << 20 : 0) | (gout->loglog_registers ? 1ull << 21 : 0) | (gout->groups_total ? 1ull << 22 : 0);
+    const uint64_t omask = hits_mask(out) | (gout->groups_count ? 1ull << 20 : 0) | (gout->loglog_registers ? 1ull << 21 : 0) | (gout->groups_total ? 1ull << 22 : 0) | (query_index ? 1ull << 23 : 0) |
+                           (candidates ? 1ull << 24 : 0) | ((uint64_t)n_combos << 32);
     if (g->replicas) {
         // every member mirrors the WHOLE collection: member 0 / this rank answers alone
         int rc = agree(g, TSGPU_OK, call_signature({14, n_queries, out->k_stride, gout->g_stride, omask}));
         if (rc) return rc;
-        return tsgpu_keyword_search_grouped_batch(g->m[0].ctx, queries, groups, n_queries, out, gout, nullptr);
+        return candidates ? tsgpu_keyword_search_grouped_candidates_batch(g->m[0].ctx, queries, cfirst, groups, n_queries, out, gout, query_index, nullptr)
+                          : tsgpu_keyword_search_grouped_batch(g->m[0].ctx, queries, groups, n_queries, out, gout, nullptr);
     }
     try {
         // 0) token existence is a property of the whole collection (group_keyword_core's step 0)
@@ -1230,10 +1239,15 @@ int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_quer
         for (uint32_t i = 0; i < n_queries; i++) any_kw = any_kw || !groups[i].wildcard;
         if (g->local) same_dict = g->n == 1 || !any_kw || local_dictionaries_equal(g);
         else { int rc0 = agree(g, TSGPU_OK, call_signature({13, n_queries, out->k_stride, gout->g_stride, omask}), any_kw ? kw_dictionary_fingerprint(g->m[0].ctx) : 0ull, &same_dict); if (rc0) return rc0; }
-        if (!same_dict) { int rc0 = exchange_token_masks(g, queries, n_queries); if (rc0) return rc0; }
+        if (!same_dict) { int rc0 = exchange_token_masks(g, queries, n_combos); if (rc0) return rc0; }
         const size_t nm = g->m.size();
         std::vector<uint32_t> caps(n_queries, 0u);
-        group_resolve_topster_sizes(g->m[0].ctx, queries, n_queries, caps.data());
+        {
+            // ONE collector per user query, sized by its first combination (src/index.cpp:3506-3514)
+            std::vector<tsgpu_kw_query> firsts(n_queries);
+            for (uint32_t i = 0; i < n_queries; i++) firsts[i] = queries[cfirst[i]];
+            group_resolve_topster_sizes(g->m[0].ctx, firsts.data(), n_queries, caps.data());
+        }
         uint32_t K1 = 1;
         bool want_regs = false;
         for (uint32_t i = 0; i < n_queries; i++) { K1 = std::max(K1, std::min<uint32_t>(caps[i], TSGPU_MAX_TOPK)); want_regs = want_regs || (groups[i].first_pass && (gout->groups_count || gout->loglog_registers)); }
@@ -1257,8 +1271,8 @@ int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_quer
             tsgpu_grouped_hits gh; memset(&gh, 0, sizeof gh);
             gh.g_stride = K1; gh.n_groups = ng.data(); gh.distinct_key = dk.data(); gh.group_size = gsz.data(); gh.group_found = gf.data();
             gh.loglog_registers = want_regs ? mine[m].data() + o_regs : nullptr;
-            const GbShard sh = {nullptr, nullptr, same_dict ? nullptr : mem.h_elsewhere.data()};
-            const int r = gb_shard_batch(mem.ctx, queries, g1.data(), n_queries, &h, &gh, &sh);
+            const GbShard sh = {nullptr, nullptr, same_dict ? nullptr : mem.h_elsewhere.data(), nullptr};
+            const int r = gb_shard_batch(mem.ctx, queries, cfirst, g1.data(), n_queries, &h, &gh, nullptr, &sh);
             if (r) return r;
             Hdr1* hd = (Hdr1*)(mine[m].data() + o_hdr);
             Ent1* en = (Ent1*)(mine[m].data() + o_ent);
@@ -1309,8 +1323,8 @@ int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_quer
         }
         // ---- round 2: the given groups on every shard ----
         const size_t slots2 = (size_t)n_queries * K2, gsl2 = (size_t)n_queries * G2;
-        const size_t p_st = 0, p_found = p_st + (((size_t)n_queries * 8 + 7) & ~(size_t)7), p_size = p_found + ((gsl2 * 4 + 7) & ~(size_t)7), p_keys = p_size + ((gsl2 * 4 + 7) & ~(size_t)7),
-                     p_sc = p_keys + slots2 * 8, p_tm = p_sc + slots2 * 24, p_vd = p_tm + slots2 * 8, p_msi = p_vd + ((slots2 * 4 + 7) & ~(size_t)7), bytes2 = p_msi + ((slots2 + 7) & ~(size_t)7);
+        const size_t p_st = 0, p_found = p_st + (size_t)n_queries * 16, p_size = p_found + ((gsl2 * 4 + 7) & ~(size_t)7), p_keys = p_size + ((gsl2 * 4 + 7) & ~(size_t)7),
+                     p_sc = p_keys + slots2 * 8, p_tm = p_sc + slots2 * 24, p_vd = p_tm + slots2 * 8, p_msi = p_vd + ((slots2 * 4 + 7) & ~(size_t)7), p_qx = p_msi + ((slots2 + 7) & ~(size_t)7), bytes2 = p_qx + ((slots2 * 4 + 7) & ~(size_t)7);
         for (auto& b : mine) { b.assign(bytes2, 0); }
         rc = for_members(g, [&](size_t m) -> int {
             Member& mem = g->m[m];
@@ -1324,12 +1338,13 @@ int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_quer
             h.match_score_index = (int8_t*)(blk + p_msi); h.n_hits = nh.data(); h.num_matched = nmv.data(); h.status = st.data(); h.search_cutoff = co.data();
             tsgpu_grouped_hits gh; memset(&gh, 0, sizeof gh);
             gh.g_stride = G2; gh.n_groups = ng.data(); gh.distinct_key = dk.data(); gh.group_size = (uint32_t*)(blk + p_size); gh.group_found = (uint32_t*)(blk + p_found);
-            const GbShard sh = {fkeys.data(), fbegin.data(), same_dict ? nullptr : mem.h_elsewhere.data()};
-            const int r = gb_shard_batch(mem.ctx, queries, groups, n_queries, &h, &gh, &sh);
+            std::vector<uint32_t> pmask(n_queries, 0u);
+            const GbShard sh = {fkeys.data(), fbegin.data(), same_dict ? nullptr : mem.h_elsewhere.data(), pmask.data()};
+            const int r = gb_shard_batch(mem.ctx, queries, cfirst, groups, n_queries, &h, &gh, (uint32_t*)(blk + p_qx), &sh);      // (query_index = the hits' PASSES)
             if (r) return r;
             int32_t* pst = (int32_t*)(blk + p_st);
             for (uint32_t i = 0; i < n_queries; i++) {
-                pst[2 * i] = st[i]; pst[2 * i + 1] = co[i];
+                pst[4 * i] = st[i]; pst[4 * i + 1] = co[i]; pst[4 * i + 2] = (int32_t)pmask[i]; pst[4 * i + 3] = 0;
                 if (st[i] != TSGPU_OK) for (uint32_t r2 = 0; r2 < G2; r2++) ((uint32_t*)(blk + p_size))[(size_t)i * G2 + r2] = ((uint32_t*)(blk + p_found))[(size_t)i * G2 + r2] = 0;
             }
             return TSGPU_OK;
@@ -1338,16 +1353,19 @@ int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_quer
         std::vector<uint8_t> all2;
         if ((rc = gather_host_blocks(g, mine, bytes2, all2))) return rc;
         // ---- merge: counts add up, a group's KV lists merge to its group_limit greatest ----
-        struct KV { int64_t s0, s1, s2; uint64_t key; int64_t tm; float vd; int8_t msi; };
+        struct KV { int64_t s0, s1, s2; uint64_t key; int64_t tm; float vd; int8_t msi; uint32_t pass; };
         auto kv2_greater = [](const KV& a, const KV& b) { if (a.s0 != b.s0) return a.s0 > b.s0; if (a.s1 != b.s1) return a.s1 > b.s1; if (a.s2 != b.s2) return a.s2 > b.s2; return (int64_t)a.key > (int64_t)b.key; };
         std::vector<KV> kvs;
         std::vector<uint8_t> regs(16384);
         for (uint32_t i = 0; i < n_queries; i++) {
             for (uint32_t r = 0; r < g->n && status[i] == TSGPU_OK; r++) {
                 const int32_t* pst = (const int32_t*)(all2.data() + r * bytes2 + p_st);
-                if (pst[2 * i] != TSGPU_OK) status[i] = pst[2 * i];
-                cutoff[i] = cutoff[i] || pst[2 * i + 1];
+                if (pst[4 * i] != TSGPU_OK) status[i] = pst[4 * i];
+                cutoff[i] = cutoff[i] || pst[4 * i + 1];
             }
+            // KV::query_index = the earlier passes of the user query that matched ANYTHING (src/index.cpp:5511, :5580-5585) — anywhere: the OR of the shards' pass masks
+            uint32_t gmask = 0;
+            for (uint32_t r = 0; r < g->n; r++) gmask |= (uint32_t)((const int32_t*)(all2.data() + r * bytes2 + p_st))[4 * i + 2];
             out->status[i] = status[i];
             if (out->search_cutoff) out->search_cutoff[i] = cutoff[i];
             if (out->num_matched) out->num_matched[i] = status[i] == TSGPU_OK ? num_matched[i] : 0;
@@ -1369,7 +1387,7 @@ int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_quer
                         kv.key = ((const uint64_t*)(blk + p_keys))[o];
                         const int64_t* sc = (const int64_t*)(blk + p_sc) + o * 3;
                         kv.s0 = sc[0]; kv.s1 = sc[1]; kv.s2 = sc[2];
-                        kv.tm = ((const int64_t*)(blk + p_tm))[o]; kv.vd = ((const float*)(blk + p_vd))[o]; kv.msi = ((const int8_t*)(blk + p_msi))[o];
+                        kv.tm = ((const int64_t*)(blk + p_tm))[o]; kv.vd = ((const float*)(blk + p_vd))[o]; kv.msi = ((const int8_t*)(blk + p_msi))[o]; kv.pass = ((const uint32_t*)(blk + p_qx))[o];
                         kvs.push_back(kv);
                     }
                 }
@@ -1385,6 +1403,7 @@ int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_quer
                     if (out->text_match) out->text_match[o] = kvs[j].tm;
                     if (out->vector_distance) out->vector_distance[o] = kvs[j].vd;
                     if (out->match_score_index) out->match_score_index[o] = kvs[j].msi;
+                    if (query_index) query_index[o] = (uint32_t)__builtin_popcount(gmask & ((1u << (kvs[j].pass & 31u)) - 1u));
                 }
                 hits += take;
             }
@@ -1404,6 +1423,23 @@ int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_quer
         return ok();
     } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_grouped_batch: host allocation failed"); }
       catch (const std::system_error&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_grouped_batch: could not start a member thread"); }
+}
+
+int tsgpu_group_keyword_search_grouped_batch(tsgpu_group* g, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries, tsgpu_hits* out, tsgpu_grouped_hits* gout) {
+    try {
+        std::vector<uint32_t> cf((size_t)n_queries + 1);
+        for (uint32_t i = 0; i <= n_queries; i++) cf[i] = i;         // one combination per query
+        return group_grouped_core(g, queries, cf.data(), groups, n_queries, out, gout, nullptr, false);
+    } catch (const std::bad_alloc&) { return fail(TSGPU_ERR_NO_MEMORY, "tsgpu_group_keyword_search_grouped_batch: host allocation failed"); }
+}
+
+// The same over candidate-token combinations (tsgpu_keyword_search_grouped_candidates_batch; Index::search_all_candidates with group_limit != 0, src/index.cpp:1794-1894): the
+// fold of a user query's passes is per document (a second pass counts a document once, with its greatest KV) and per group (a first pass keeps a group's greatest KV over all
+// passes), and a document lives in ONE shard — so both rounds run the shards' own folds. What is not shard-local is KV::query_index (the earlier passes that matched
+// ANYTHING): every hit travels with its pass, the shards' pass masks are OR'ed, query_index = the matching passes below the hit's. num_matched = the LAST pass' counts added up.
+int tsgpu_group_keyword_search_grouped_candidates_batch(tsgpu_group* g, const tsgpu_kw_query* combos, const uint32_t* group_begin, const tsgpu_group_by* groups, uint32_t n_user,
+                                                        tsgpu_hits* out, tsgpu_grouped_hits* gout, uint32_t* query_index) {
+    return group_grouped_core(g, combos, group_begin, groups, n_user, out, gout, query_index, true);
 }
 
 int tsgpu_group_set_option(tsgpu_group* g, const char* name, int64_t value) {

@@ -138,7 +138,9 @@ void tsgpu_groupby_destroy(tsgpu_ctx* ctx) {
 // `shard` (nullable; tsgpu_group_keyword_search_grouped_batch, one combination per query): this context answers as a doc-range shard of a group —
 //   forced_keys / forced_begin: the groups of query i are GIVEN (keys forced_keys[forced_begin[i] .. forced_begin[i + 1]), best first, as the whole collection selected
 //     them): returned group r is the r-th key whether or not the shard holds documents of it (then group_found = group_size = 0), groups_count is not computed;
-//   present_elsewhere: per query, the tokens that exist on ANOTHER shard (a token missing here is then an empty list, not a dropped token: kw_dispatch).
+//   pass_mask (out, per user query, zeroed by the caller): bit p = combination p matched something here, and query_index holds every hit's PASS instead of
+//     the count of earlier matching passes (which is a property of all shards together);
+//   present_elsewhere: per COMBINATION, the tokens that exist on ANOTHER shard (a token missing here is then an empty list, not a dropped token: kw_dispatch).
 // A q = * query of a context with a doc range matches the seq_ids the context OWNS.
 static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const uint32_t* cfirst, const tsgpu_group_by* groups, uint32_t n_queries,
                            tsgpu_hits* out, tsgpu_grouped_hits* gout, uint32_t* query_index, tsgpu_id_lists** ids_out, const tsgpu::GbShard* shard = nullptr) {
@@ -180,7 +182,6 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
                 if (k > TSGPU_MAX_TOPK) st = TSGPU_ERR_UNSUPPORTED;
                 else if (k > gout->g_stride) st = TSGPU_ERR_INVALID;
                 else if ((uint64_t)k * (gb.first_pass ? 1u : gb.group_limit) > out->k_stride) st = TSGPU_ERR_INVALID;   // second pass: slot r * group_limit + j
-                if (st == TSGPU_OK && forced && nc != 1) st = TSGPU_ERR_UNSUPPORTED;
             }
             status[i] = st;
             if (st != TSGPU_OK) continue;
@@ -284,7 +285,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
             uint32_t matched_before = 0;                  // searched_queries.size() at the time of a pass: the earlier combinations that matched anything (:5580-5585)
             for (uint32_t c = cfirst[i]; c < cfirst[i + 1]; c++) {
                 combo_begin[c] = n_items + n + gap;
-                qidx_of_combo[c] = matched_before;
+                qidx_of_combo[c] = (shard && shard->pass_mask) ? c - cfirst[i] : matched_before;      // (shard form: the hit's PASS travels; "matched anything" is decided over all shards)
                 uint64_t nc = 0;
                 if (g.run) nc = iota[i] ? ctx->num_docs : (groups[i].wildcard ? wild_ids[i].size() : tsgpu_id_lists_count(idl.get(), kw_index[c]));
                 // a user query that FAILED after the id pass (one of its combinations ran out of time, ...) while another of its combinations succeeded: with the
@@ -292,7 +293,7 @@ static int gb_batch_locked(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const u
                 // (nobody reads them: the query has no items), or every later query's combo_begin / item_begin would be short by that many ids
                 else if (ids_on_dev && kw_index[c] != 0xFFFFFFFFu) gap += tsgpu_id_lists_count(idl.get(), kw_index[c]);
                 n += nc;
-                if (nc) matched_before++;
+                if (nc) { matched_before++; if (shard && shard->pass_mask) shard->pass_mask[i] |= 1u << (c - cfirst[i]); }
             }
             if (n > 0x7FFFFFFFull) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_keyword_search_grouped_batch: more than 2^31 matched ids in one query");
             g.n_items = (uint32_t)n;
@@ -655,13 +656,12 @@ static int gb_coalesced(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsg
 
 namespace tsgpu {
 uint64_t gb_registers_cardinality(const uint8_t* regs) { return gb_loglog_cardinality(regs); }
-int gb_shard_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries, tsgpu_hits* out, tsgpu_grouped_hits* gout, const GbShard* shard) {
-    if (!ctx || !out || !gout || (n_queries && (!queries || !groups))) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_grouped_batch: NULL argument");
+int gb_shard_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const uint32_t* cfirst, const tsgpu_group_by* groups, uint32_t n_queries, tsgpu_hits* out, tsgpu_grouped_hits* gout,
+                   uint32_t* query_index, const GbShard* shard) {
+    if (!ctx || !out || !gout || !cfirst || (n_queries && (!combos || !groups))) return fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_grouped_batch: NULL argument");
     if (n_queries == 0) return ok();
-    std::vector<uint32_t> cf((size_t)n_queries + 1);
-    for (uint32_t i = 0; i <= n_queries; i++) cf[i] = i;         // one combination per query
     std::lock_guard<std::mutex> lk(ctx->mu);
-    return gb_batch_locked(ctx, queries, cf.data(), groups, n_queries, out, gout, nullptr, nullptr, shard);
+    return gb_batch_locked(ctx, combos, cfirst, groups, n_queries, out, gout, query_index, nullptr, shard);
 }
 }  // namespace tsgpu
 

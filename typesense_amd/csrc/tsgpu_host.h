@@ -620,9 +620,13 @@ int group_cand_fix(tsgpu_ctx* ctx, uint64_t* keys, uint32_t* query_index, const 
 // shard form of group_by (tsgpu_group_keyword_search_grouped_batch): one grouped pass of a doc-range shard (tsgpu_groupby.inc.h) — tsgpu_keyword_search_grouped_batch with
 // the shard options below, never coalesced with other callers. forced_begin == nullptr: the shard's own selection (round 1); else the groups of query i are the given keys
 // forced_keys[forced_begin[i] .. forced_begin[i + 1]) (round 2: slot r = key r on every shard). present_elsewhere: as kw_search_batch_masked.
-struct GbShard { const uint64_t* forced_keys; const uint32_t* forced_begin; const uint16_t* present_elsewhere; };
+// cfirst: user query i owns the candidate combinations combos[cfirst[i] .. cfirst[i + 1]) (one each: the plain call). pass_mask (out, zeroed by the caller; nullable): bit p of
+// pass_mask[i] = combination p of user query i matched something on this shard — and then query_index holds every hit's PASS (KV::query_index counts the earlier passes that
+// matched ANYWHERE: the group call derives it from the shards' masks).
+struct GbShard { const uint64_t* forced_keys; const uint32_t* forced_begin; const uint16_t* present_elsewhere; uint32_t* pass_mask; };
 uint64_t gb_registers_cardinality(const uint8_t* regs);      // LogLogBeta::cardinality() of 16384 registers (the shards' sketches merge by the registers' maxima)
-int gb_shard_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* queries, const tsgpu_group_by* groups, uint32_t n_queries, tsgpu_hits* out, tsgpu_grouped_hits* gout, const GbShard* shard);
+int gb_shard_batch(tsgpu_ctx* ctx, const tsgpu_kw_query* combos, const uint32_t* cfirst, const tsgpu_group_by* groups, uint32_t n_queries, tsgpu_hits* out, tsgpu_grouped_hits* gout,
+                   uint32_t* query_index, const GbShard* shard);
 int group_kw_kth(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t k, uint32_t n_shards, const uint32_t* caps_dev, int64_t* kth, hipStream_t s);
 int group_kw_prune_pack(tsgpu_ctx* ctx, const tsgpu_hits* local_dev, uint32_t n_q, uint32_t n_pad, uint32_t k, uint32_t words, const uint32_t* caps_dev, const int64_t* kth_all,
                         uint32_t n_shards, uint32_t per, uint32_t n_dst, uint64_t slice_words, uint64_t* block, uint32_t* cursor, hipStream_t s);

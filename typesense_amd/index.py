@@ -729,6 +729,23 @@ class GpuGroup:
         B.check(self.L, self.L.tsgpu_group_keyword_search_grouped_batch(self.h, C.cast(arr, C.c_void_p), ga, n, C.byref(hs), C.byref(gs)))
         return h, gh
 
+    def keyword_search_grouped_candidates_batch(self, user_combos, groups, k_stride, g_stride=250, want_registers=False):
+        """tsgpu_group_keyword_search_grouped_candidates_batch: GpuIndex.keyword_search_grouped_candidates_batch over the shards. Returns (Hits, GroupedHits, query_index)"""
+        flat = [q for combos in user_combos for q in combos]
+        arr = make_query_array(flat)
+        n = len(user_combos)
+        begin = np.zeros(n + 1, np.uint32)
+        begin[1:] = np.cumsum([len(c) for c in user_combos])
+        ga = (B.GroupByC * max(n, 1))()
+        for i, g in enumerate(groups):
+            ga[i].group_limit, ga[i].column, ga[i].first_pass, ga[i].group_missing_values, ga[i].wildcard = int(g[0]), int(g[1]), int(g[2]), int(g[3]), int(g[4])
+        h = Hits(n, k_stride)
+        gh = GroupedHits(n, g_stride, want_registers, totals=False)
+        qidx = np.zeros((n, k_stride), np.uint32)
+        hs, gs = h.c_struct(), gh.c_struct()
+        B.check(self.L, self.L.tsgpu_group_keyword_search_grouped_candidates_batch(self.h, C.cast(arr, C.c_void_p) if flat else None, begin.ctypes.data, ga, n, C.byref(hs), C.byref(gs), qidx.ctypes.data))
+        return h, gh, qidx
+
     def facet_count_batch(self, field_id, id_lists, cap=1024, sample_mod=1, allowed_hashes=None):
         """tsgpu_group_facet_count_batch: GpuIndex.facet_count_batch over the shards (GLOBAL ascending id lists)"""
         lists = [_u32(x) for x in id_lists]
