@@ -10,8 +10,8 @@ db = glob.glob("/tmp/hd_trace/**/*.db", recursive=True)[0]
 cur = sqlite3.connect(db).cursor()
 rows = cur.execute("select start, end, name, grid_x from kernels where name like '%tsgpu%' order by start").fetchall()
 finds = [i for i, r in enumerate(rows) if "kw_find2" in r[2]]
-# the sliced calls launch three find kernels each: take the last 6 finds (two calls) before the final unsliced call
-sel = rows[finds[-6]:] if len(finds) >= 6 else rows
+# the sliced calls launch three find kernels each: take the last 4 finds (two calls of two slices) before the final unsliced call
+sel = rows[finds[-4]:] if len(finds) >= 4 else rows
 t0 = sel[0][0]
 for s, e, n, gx in sel:
     print("%9.3f -> %9.3f  %7.3f ms  grid %8d  %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, gx, n.split("(")[0][-44:]))
