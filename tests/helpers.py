@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def emu_lib_path(defs="", suffix=""):
     """tests/hipemu/_build/libtsgpu_emu.so: the unmodified product sources compiled against the SIMT emulator.
     defs/suffix: a variant build with extra -D flags (e.g. a tiny LDS tile to force the multi-round paths)."""
+    if not defs and os.environ.get("TSGPU_EMU_DEFS"):      # run the whole emulator tier on a variant build (experiments: a kernel behind a -D knob)
+        defs, suffix = os.environ["TSGPU_EMU_DEFS"], os.environ.get("TSGPU_EMU_SUFFIX", "_env")
     out = subprocess.check_output([os.path.join(ROOT, "tests", "hipemu", "build_emu.sh"), defs, suffix], text=True).strip().splitlines()[-1]
     return out
 
