@@ -304,7 +304,7 @@ def test_replicas_form_cuts_the_batch_into_query_slices():
 def test_group_by_over_shards_with_big_groups_takes_the_chunked_path_in_the_given_groups_round():
     """a group_by field with a handful of values over many matches, cut into two doc ranges: in round 2 (the groups GIVEN) a shard's groups of more than 4096 members
     take gb_chunk_kernel, a singleton group lives on ONE shard (the other answers it empty), group_limit 50 merges two shards' lists of 50; q = * needs no postings"""
-    n = 30000
+    n = 20000
     lib = H.emu_lib_path()
     rng = np.random.default_rng(3)
     points = H.points_of(n)
@@ -312,7 +312,7 @@ def test_group_by_over_shards_with_big_groups_takes_the_chunked_path_in_the_give
     col = np.where(u < 0.7, 111, np.where(u < 0.99, 222, 333)).astype(np.uint64)
     col[rng.choice(n, 40, replace=False)] = np.arange(40, dtype=np.uint64) + np.uint64(10**12)       # singletons
     members = []
-    for lo, hi in ((0, 13000), (13000, n)):
+    for lo, hi in ((0, 9000), (9000, n)):
         g = T.GpuIndex(0, lib)
         g.field_create(0, False)
         g.set_num_docs(n)
@@ -324,16 +324,16 @@ def test_group_by_over_shards_with_big_groups_takes_the_chunked_path_in_the_give
     grp = T.GpuGroup(members, B.XCHG_COPY)
     try:
         excl = np.sort(rng.choice(n, 500, replace=False)).astype(np.uint32)
-        filt = np.sort(rng.choice(n, 20000, replace=False)).astype(np.uint32)
+        filt = np.sort(rng.choice(n, 14000, replace=False)).astype(np.uint32)
         sort = ((B.SORT_INT64_COLUMN, 1, 0), (B.SORT_SEQ_ID, -1, 0))
         qs = [T.KwQuery([], sort=sort, topster_size=250), T.KwQuery([], sort=sort, topster_size=30, filter_ids=filt, excluded_ids=excl),
               T.KwQuery([], sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=2)]
-        for limit in (3, 50):
-            for first_pass in (False, True):
+        for limit, passes in ((3, (False, True)), (50, (False,))):
+            for first_pass in passes:
                 h, gh = grp.keyword_search_grouped_batch(qs, [(limit, GROUP_COL, int(first_pass), 0, 1)] * len(qs), k_stride=250 * limit, g_stride=250, want_registers=True)
                 for i, q in enumerate(qs):
                     check_query(h, gh, i, oracle_grouped_wildcard(q, n, points, col, limit, first_pass), first_pass, limit, "sharded big groups limit %d" % limit, check_total=False)
-        assert int(gh.group_found[0, :int(gh.n_groups[0])].max()) > 8192 * 2
+        assert int(gh.group_found[0, :int(gh.n_groups[0])].max()) > 8192          # (a group of two chunks on the larger shard)
     finally:
         grp.close()
         for g in members:
