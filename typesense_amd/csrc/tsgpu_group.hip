@@ -1325,6 +1325,9 @@ static int group_grouped_core(tsgpu_group* g, const tsgpu_kw_query* queries, con
         const size_t slots2 = (size_t)n_queries * K2, gsl2 = (size_t)n_queries * G2;
         const size_t p_st = 0, p_found = p_st + (size_t)n_queries * 16, p_size = p_found + ((gsl2 * 4 + 7) & ~(size_t)7), p_keys = p_size + ((gsl2 * 4 + 7) & ~(size_t)7),
                      p_sc = p_keys + slots2 * 8, p_tm = p_sc + slots2 * 24, p_vd = p_tm + slots2 * 8, p_msi = p_vd + ((slots2 * 4 + 7) & ~(size_t)7), p_qx = p_msi + ((slots2 + 7) & ~(size_t)7), bytes2 = p_qx + ((slots2 * 4 + 7) & ~(size_t)7);
+        // (every rank holds every shard's round-2 block: capacity x group_limit x 45 bytes per query and shard — a bound instead of an allocation failure half-way;
+        //  every rank derives the same sizes from the same gathered round-1 data: they all leave here together)
+        if ((uint64_t)bytes2 * g->n > (4ull << 30)) return fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_grouped_batch: the gathered group lists of this batch exceed 4 GiB; split it");
         for (auto& b : mine) { b.assign(bytes2, 0); }
         rc = for_members(g, [&](size_t m) -> int {
             Member& mem = g->m[m];
