@@ -343,6 +343,12 @@ def test_group_by_over_shards_with_big_groups_takes_the_chunked_path_in_the_give
 def test_group_argument_errors_are_reported_not_crashed():
     lib = H.emu_lib_path()
     g = T.GpuIndex(0, lib)
+    g2 = T.GpuIndex(0, lib)
+    two = T.GpuGroup([g, g2], B.XCHG_COPY)
+    with pytest.raises(T.TsgpuError):             # q = * grouped over shards without doc ranges: every shard would group every document
+        two.keyword_search_grouped_batch([T.KwQuery([], sort=((B.SORT_SEQ_ID, 1, 0),), topster_size=5)], [(3, 0, 1, 0, 1)], k_stride=16, g_stride=8)
+    two.close()
+    g2.close()
     with pytest.raises(T.TsgpuError):
         T.GpuGroup([g, g], B.XCHG_RCCL)           # RCCL needs one GPU per member
     grp = T.GpuGroup([g], B.XCHG_COPY)

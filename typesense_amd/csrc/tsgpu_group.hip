@@ -1222,6 +1222,11 @@ static int group_grouped_core(tsgpu_group* g, const tsgpu_kw_query* queries, con
     else if (!gout->n_groups || !gout->distinct_key || !gout->group_size || !gout->group_found || gout->g_stride == 0 || out->k_stride == 0)
         pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_grouped_batch: n_groups / distinct_key / group_size / group_found and the strides are required");
     else if (gout->groups_total && !g->replicas) pre = fail(TSGPU_ERR_UNSUPPORTED, "tsgpu_group_keyword_search_grouped_batch: groups_total (the exact distinct-key count) is not computed across shards: pass NULL");
+    else if (g->n > 1 && !g->replicas) {
+        bool any_wild = false;
+        for (uint32_t i = 0; i < n_queries; i++) any_wild = any_wild || groups[i].wildcard;
+        for (auto& mem : g->m) if (any_wild && !mem.ctx->doc_range_set) { pre = fail(TSGPU_ERR_INVALID, "tsgpu_group_keyword_search_grouped_batch: a q = * query needs every member's doc range (tsgpu_set_option doc_range_lo / doc_range_hi): a shard groups the ids it owns"); break; }
+    }
     std::lock_guard<std::mutex> lk(g->mu);
     if (pre) return agree(g, pre, 0);
     const uint64_t omask = hits_mask(out) | (gout->groups_count ? 1ull << 20 : 0) | (gout->loglog_registers ? 1ull << 21 : 0) | (gout->groups_total ? 1ull << 22 : 0) | (query_index ? 1ull << 23 : 0) |
